@@ -1,0 +1,16 @@
+"""pytest configuration: markers and import paths.
+
+``oracle/`` is test infrastructure; it is put on ``sys.path`` here (and only used by tests).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for path in (ROOT, os.path.join(ROOT, "oracle")):
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running oracle cases")
