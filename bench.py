@@ -1,0 +1,140 @@
+"""bench.py -- simplex pivots/sec on Netlib 25FV47 (BASELINE.json configs[1]) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 25fv47]
+
+One "step" = one complete ``solve_relaxation`` of the workload, LP resident in HBM when the timed region starts
+(MPS parsing, standardisation and the H2D upload happen before it).  ``value`` = pivots of all ranks / wall time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank solves its own copy -- independent LPs shard
+one per GPU with no data-path collective (weak scaling); the barrier + max-over-ranks timing is the only exchange.
+
+The JSON line also carries ``roofline`` (pricing kernel: algorithmic bytes / HIP-event time per launch vs 8 TB/s HBM)
+and ``cpu_baseline`` (the exact-rational restatement of relp's own algorithm on one host core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "25fv47": os.path.join(ROOT, "data", "netlib", "25FV47.SIF"),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(path, budget_seconds):
+    """relp-equivalent exact CPU path (the oracle: kind "port"), first pivots of the same workload, one core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from relp_oracle import solve_relaxation
+    from relp_oracle.mps import load_problem
+    from relp_oracle.solve import PivotLimit, Trace
+
+    _, data = load_problem(path)
+
+    class Timed(Trace):
+        def __init__(self):
+            super().__init__()
+            self.start = None
+
+        def record(self, q, p, leaving, cost):
+            super().record(q, p, leaving, cost)
+            if time.perf_counter() - self.start > budget_seconds:
+                raise PivotLimit()
+
+    trace = Timed()
+    trace.start = time.perf_counter()
+    try:
+        solve_relaxation(data, trace=trace)
+    except PivotLimit:
+        pass
+    elapsed = time.perf_counter() - trace.start
+    pivots = len(trace.pivots)
+    return {"value": pivots / elapsed if elapsed > 0 else 0.0, "unit": "pivots/s", "cores": 1, "kind": "port",
+            "sample": "first %d pivots (%.1f s) of the same LP with exact rationals (Python Fraction restatement of "
+                      "relp's LU/Forrest-Tomlin steepest-edge path)" % (pivots, elapsed)}
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=5)
+    parser.add_argument("--warmup", type=int, default=1)
+    parser.add_argument("--workload", default="25fv47")
+    parser.add_argument("--cpu-seconds", type=float, default=15.0)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import relp_amd
+    path = WORKLOADS[args.workload]
+    solver = relp_amd.Solver(device=local_rank).load_mps(path)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.solve_relaxation()
+    barrier()
+    start = time.perf_counter()
+    pivots = 0
+    last = None
+    for _ in range(args.steps):
+        last = solver.solve_relaxation()
+        pivots += last.pivots_phase_one + last.pivots_phase_two
+    barrier()
+    elapsed = time.perf_counter() - start
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        p = torch.tensor([pivots], dtype=torch.float64, device="cuda")
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        pivots = int(p.item())
+
+    if rank == 0:
+        # roofline of the dominant kernel (pricing pass), measured live with HIP events on the solver's stream
+        solver.begin_phase_one()
+        solver.iterate(200)
+        reps = 200
+        seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(["price", "ftran_ratio", "update"])}
+        stats = solver.stats()
+        dominant = max(("price", "update"), key=lambda k: seconds[k])
+        bytes_per_launch = stats.price_bytes if dominant == "price" else stats.update_bytes
+        achieved = bytes_per_launch / seconds[dominant] / 1e9
+        line = {
+            "metric": "simplex pivots/sec + wall-clock to optimal, Netlib 25fv47 @1 GPU",
+            "value": pivots / elapsed, "unit": "pivots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "Netlib 25FV47.SIF (shipped problem file), one copy per GPU",
+            "config": {"workload": "Netlib 25FV47 821x1876 (+520 virtual artificials), steepest-edge pricing, "
+                                   "explicit-inverse carry, no presolve",
+                       "pivots_per_solve": int(last.pivots_phase_one + last.pivots_phase_two),
+                       "objective": last.objective, "wall_clock_to_optimal_s": last.solve_seconds,
+                       "parallelism": "1 LP per GPU x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(path, args.cpu_seconds)
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

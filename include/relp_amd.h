@@ -1,0 +1,199 @@
+/*
+ * relp_amd -- C ABI of the MI355X-native revised-simplex hot path (drop-in boundary).
+ *
+ * The reference (vandenheuvel/relp, Rust) has no FFI today; its plug-in surface for this path is four generic
+ * traits.  Each entry point below names the reference interface it replaces; paths are
+ * relative to /root/reference/src/algorithm/two_phase/.  A Rust shim that binds these is shown in INTEGRATION.md.
+ *
+ * Conventions: every call returns a relp_status (0 = ok); arrays are caller-owned; indices are 0-based;
+ * a handle is confined to one host thread and owns one HIP stream on one device; distinct handles are independent.
+ * Provider column indices are the reference's `MatrixData` indices (matrix_data.rs:115-145): structural columns
+ * first, then the five virtual slack groups.  Exact values cross the boundary as (numerator, denominator) pairs of
+ * int64 -- the reference's `Rational64` input type (io/mps/number/parse.rs:46-65).
+ */
+#ifndef RELP_AMD_H
+#define RELP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct relp_handle relp_handle;
+
+typedef enum relp_status {
+    RELP_OK = 0,
+    RELP_ERR_ARGUMENT = 1,      /* bad pointer / size / index */
+    RELP_ERR_PARSE = 2,         /* io::error::{Parse, Inconsistency} (src/io/error.rs:15-237) */
+    RELP_ERR_DEVICE = 3,        /* no HIP device or a HIP call failed: the product has NO CPU fallback */
+    RELP_ERR_OVERFLOW = 4,      /* fixed-width exact arithmetic overflowed */
+    RELP_ERR_STATE = 5,         /* call out of order (e.g. solve before load) */
+    RELP_ERR_NUMERICAL = 6      /* f64 breakdown that polishing could not repair */
+} relp_status;
+
+/* algorithm/mod.rs:43-47 `OptimizationResult` plus the states a library must report instead of panicking. */
+typedef enum relp_result_kind {
+    RELP_RESULT_NONE = 0,
+    RELP_RESULT_FINITE_OPTIMUM = 1,
+    RELP_RESULT_INFEASIBLE = 2,
+    RELP_RESULT_UNBOUNDED = 3,
+    RELP_RESULT_ITERATION_LIMIT = 4
+} relp_result_kind;
+
+/* strategy/pivot_rule.rs:86-305: the four `PivotRule` implementations. */
+typedef enum relp_pivot_rule {
+    RELP_PIVOT_STEEPEST_EDGE = 0,          /* SteepestDescentAlongObjective (the reference's hard-wired default) */
+    RELP_PIVOT_DANTZIG = 1,                /* SteepestDescentAlongVariable */
+    RELP_PIVOT_FIRST_PROFITABLE = 2,       /* FirstProfitable */
+    RELP_PIVOT_FIRST_PROFITABLE_MEMORY = 3 /* FirstProfitableWithMemory */
+} relp_pivot_rule;
+
+typedef struct relp_options {
+    int32_t device;            /* HIP device ordinal */
+    int32_t pivot_rule;        /* relp_pivot_rule */
+    int32_t polish_period;     /* pivots between Newton-Schulz polishes of the explicit inverse (role of
+                                  BasisInverse::should_refactor, lower_upper/mod.rs:249-252) */
+    int32_t pivots_per_launch; /* pivots enqueued per host round trip (hipGraph replay length) */
+    int64_t max_pivots;        /* iteration cap (the reference has none; cycling is acknowledged, tests/netlib/test.rs:221) */
+    double tol_dual;           /* cbar_j < -tol_dual makes j a pricing candidate */
+    double tol_pivot;          /* alpha_i > tol_pivot takes part in the ratio test */
+    double harris_delta;       /* feasibility slack of the two-pass ratio test */
+    double tol_feasible;       /* phase-one objective above tol_feasible*(1+|b|_1) => infeasible */
+    int32_t certify;           /* 1: after the f64 solve, prove the basis optimal in exact arithmetic and return the
+                                  exact rational objective (bit-exact with the reference's RationalBig optimum) */
+    int32_t use_graph;         /* 1: replay the pivot loop from a hipGraph */
+    int32_t verbose;
+    int32_t reserved;
+} relp_options;
+
+typedef struct relp_result {
+    int32_t kind;              /* relp_result_kind */
+    int32_t certified;         /* 1 when the exact certificate holds */
+    int64_t pivots_phase_one;  /* bring_into_basis calls: phase_one.rs:145,265 */
+    int64_t pivots_phase_two;  /* phase_two.rs:47 */
+    int64_t polishes;
+    int64_t exact_repair_pivots;
+    double objective;          /* f64 objective incl. fixed cost (general_form/mod.rs:840-851) */
+    double solve_seconds;      /* wall clock of solve_relaxation only (device-resident in, result out) */
+    double certify_seconds;
+    double max_residual;       /* largest |I - B Binv| entry seen by a polish */
+} relp_result;
+
+typedef struct relp_stats {
+    int64_t launches;          /* kernel launches issued */
+    int64_t price_launches;
+    double price_seconds;      /* HIP-event time spent in the pricing kernel (the dominant kernel), see bench.py */
+    double update_seconds;
+    double ftran_seconds;
+    int64_t price_bytes;       /* algorithmic bytes of one pricing launch */
+    int64_t update_bytes;
+} relp_stats;
+
+int32_t relp_options_default(relp_options* options);
+
+/* ---- host-only model: the provider without a device (usable on a machine with no GPU) ------------------------
+ * `relp_model` is the `MatrixData` a provider call sequence would see; it needs no HIP device, so the host logic
+ * (parser, standardisation, virtual slack columns) is testable on CPU.  relp_load_model uploads it to a handle. */
+typedef struct relp_model relp_model;
+int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model** out, char* error, int32_t error_capacity);
+int32_t relp_model_free(relp_model* model);
+int32_t relp_model_dimensions(const relp_model* model, int32_t* nr_rows, int32_t* nr_columns, int32_t* nr_constraints,
+                              int32_t* nr_structural, int64_t* nnz, int32_t group_counts[4]);
+int32_t relp_model_column(const relp_model* model, int32_t j, int32_t capacity, int32_t* count,
+                          int32_t* row_index, double* value);
+/* exact form of one column: values as decimal strings "num/den" joined by ';' are avoided -- int64 pairs instead;
+ * returns RELP_ERR_OVERFLOW when a value does not fit int64. */
+int32_t relp_model_column_exact(const relp_model* model, int32_t j, int32_t capacity, int32_t* count,
+                                int32_t* row_index, int64_t* num, int64_t* den);
+int32_t relp_model_cost(const relp_model* model, int32_t j, double* cost);
+int32_t relp_model_right_hand_side(const relp_model* model, double* rhs);
+int32_t relp_model_initial_pivots(const relp_model* model, int32_t capacity, int32_t* count, int32_t* rows, int32_t* columns);
+int32_t relp_model_fixed_cost(const relp_model* model, double* fixed_cost);
+
+/* Lifetime.  relp_create fails with RELP_ERR_DEVICE when no MI355X/HIP device is usable. */
+int32_t relp_create(const relp_options* options, relp_handle** out);
+int32_t relp_destroy(relp_handle* handle);
+const char* relp_last_error(const relp_handle* handle);
+
+/* ---- provider: replaces `MatrixData::new` (matrix_provider/matrix_data.rs:172-248) -------------------------
+ * constraints: CSC over the constraint rows (sorted rows per column, no zeros), values num/den;
+ * b: one per constraint row (>= 0); ranges: one per range row; upper_*: per variable, has_upper[j] != 0 adds a
+ * virtual bound row + slack.  Row order must be Equality | Range | <= | >= (general_form/mod.rs:651-717). */
+int32_t relp_load_matrix_data(relp_handle* handle,
+                              int32_t nr_constraints, int32_t nr_variables,
+                              const int64_t* column_start, const int32_t* row_index,
+                              const int64_t* value_num, const int64_t* value_den,
+                              const int64_t* b_num, const int64_t* b_den,
+                              const int64_t* cost_num, const int64_t* cost_den,
+                              const uint8_t* has_upper, const int64_t* upper_num, const int64_t* upper_den,
+                              const int64_t* range_num, const int64_t* range_den,
+                              int32_t nr_equality, int32_t nr_range, int32_t nr_upper, int32_t nr_lower,
+                              int64_t fixed_cost_num, int64_t fixed_cost_den);
+
+/* Convenience for the step before the path: `parse_fixed`/`parse_free` + `TryInto<GeneralForm>` +
+ * `standardize()` + `derive_matrix_data()` (tests/netlib/mod.rs:55-61, without presolve). */
+int32_t relp_load_mps(relp_handle* handle, const char* path, int32_t fixed_format);
+int32_t relp_load_model(relp_handle* handle, const relp_model* model);
+
+/* `MatrixProvider::{nr_rows, nr_columns, nr_constraints, nr_variable_bounds}` (matrix_provider/mod.rs:37-134). */
+int32_t relp_get_dimensions(const relp_handle* handle, int32_t* nr_rows, int32_t* nr_columns,
+                            int32_t* nr_constraints, int32_t* nr_structural, int32_t* nr_artificial, int64_t* nnz);
+/* `MatrixProvider::column(j)`; returns nnz through *count (capacity entries are written at most). */
+int32_t relp_get_column(const relp_handle* handle, int32_t j, int32_t capacity, int32_t* count,
+                        int32_t* row_index, double* value);
+int32_t relp_get_cost(const relp_handle* handle, int32_t j, double* cost);            /* cost_value(j) */
+int32_t relp_get_right_hand_side(const relp_handle* handle, double* rhs);             /* right_hand_side() */
+int32_t relp_get_initial_pivots(const relp_handle* handle, int32_t capacity, int32_t* count,
+                                int32_t* rows, int32_t* columns);                      /* pivot_element_indices() */
+
+/* ---- `SolveRelaxation::solve_relaxation::<Carry<_, _>>()` (algorithm/mod.rs:17-36, two_phase/mod.rs:25-109) -- */
+int32_t relp_solve_relaxation(relp_handle* handle, relp_result* result);
+/* OptimizationResult::FiniteOptimum(x) after `reconstruct_solution` (matrix_data.rs:402-411): structural columns. */
+int32_t relp_get_solution(const relp_handle* handle, double* x_structural);
+/* Exact optimal objective "num/den" incl. fixed cost (needs options.certify); returns needed length in *length. */
+int32_t relp_get_objective_exact(const relp_handle* handle, char* buffer, int32_t capacity, int32_t* length);
+/* `InverseMaintainer::basis_column_index_for_row` for all rows (provider indices; -1-k for artificial k). */
+int32_t relp_get_basis(const relp_handle* handle, int32_t* basis);
+
+/* ---- fine-grained trait parity (tests and the Rust shim) ---------------------------------------------------- */
+/* `InverseMaintainer::from_basis` (inverse_maintenance/mod.rs:92-101): start phase two from the given basis
+ * (provider column per row).  Also the checkpoint/resume entry. */
+int32_t relp_set_basis(relp_handle* handle, const int32_t* basis_columns);
+/* Phase-one start: `Tableau::<_, Partially<_>>::new` (kind/artificial/partially.rs:125-205). */
+int32_t relp_begin_phase_one(relp_handle* handle);
+/* `Tableau::from_artificial` hand-over (kind/non_artificial.rs:99-120, carry/mod.rs:499-525). */
+int32_t relp_begin_phase_two(relp_handle* handle);
+/* `BasisInverse::left_multiply_by_basis_inverse` (carry/mod.rs:98-107; lower_upper/mod.rs:180-210): FTRAN. */
+int32_t relp_bi_ftran(relp_handle* handle, int32_t nnz, const int32_t* row_index, const double* value, double* out_m);
+/* `BasisInverse::right_multiply_by_basis_inverse` (lower_upper/mod.rs:212-237): BTRAN. */
+int32_t relp_bi_btran(relp_handle* handle, int32_t nnz, const int32_t* row_index, const double* value, double* out_m);
+/* `BasisInverse::basis_inverse_row` (lower_upper/mod.rs:254-272). */
+int32_t relp_bi_row(relp_handle* handle, int32_t row, double* out_m);
+/* `PivotRule::select_primal_pivot_column` (strategy/pivot_rule.rs:221-241): *column = -1 when none. */
+int32_t relp_price(relp_handle* handle, int32_t* column, double* relative_cost);
+/* `Tableau::relative_cost(j)` for every column of the current index space (tableau/mod.rs:106-112). */
+int32_t relp_relative_costs(relp_handle* handle, double* out_n);
+/* Steepest-edge weights gamma_j (strategy/pivot_rule.rs:190-219); NaN for basic / artificial columns. */
+int32_t relp_get_gamma(relp_handle* handle, double* out_n);
+/* `Tableau::generate_column` + `select_primal_pivot_row` (tableau/mod.rs:126-130, 287-313): *row = -1 when unbounded. */
+int32_t relp_ratio(relp_handle* handle, int32_t column, int32_t* row, double* out_alpha_m);
+/* One full iteration of phase_one.rs:134-178 / phase_two.rs:36-58, repeated `count` times on the device. */
+int32_t relp_iterate(relp_handle* handle, int64_t count, int64_t* done, int32_t* stop_reason);
+/* `InverseMaintainer::{b, get_objective_function_value}` (inverse_maintenance/mod.rs:240-264). */
+int32_t relp_get_b(relp_handle* handle, double* out_m);
+int32_t relp_get_objective(relp_handle* handle, double* objective);
+int32_t relp_get_stats(const relp_handle* handle, relp_stats* stats);
+int32_t relp_reset_stats(relp_handle* handle);
+/* Measurement hook for bench.py: average seconds of ONE launch of a hot-loop kernel, timed with HIP events on the
+ * handle's stream around `repetitions` back-to-back launches on the current device state (state is restored).
+ * which: 0 pricing pass (with the steepest-edge update) | 1 ftran+ratio | 2 inverse update (+ w partials). */
+int32_t relp_profile_kernel(relp_handle* handle, int32_t which, int32_t repetitions, double* seconds_per_launch);
+
+/* Version / build info ("relp_amd <ver> gfx950"). */
+const char* relp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELP_AMD_H */

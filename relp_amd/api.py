@@ -1,0 +1,336 @@
+"""ctypes binding of ``librelp_amd.so`` (the C ABI in ``include/relp_amd.h``).
+
+This module is plumbing for tests, ``bench.py`` and ``__graft_entry__``: every compute call goes through the C ABI
+into the HIP kernels.  There is no Python or CPU implementation behind it -- if the shared library is missing, or no
+HIP device is usable, calls raise.  Names mirror the reference's traits (``solve_relaxation``,
+``left_multiply_by_basis_inverse`` ...) so that the parity tests read like the reference's own tests.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librelp_amd.so")
+
+OK, ERR_ARGUMENT, ERR_PARSE, ERR_DEVICE, ERR_OVERFLOW, ERR_STATE, ERR_NUMERICAL = range(7)
+FINITE_OPTIMUM, INFEASIBLE, UNBOUNDED, ITERATION_LIMIT = 1, 2, 3, 4
+STEEPEST_EDGE, DANTZIG, FIRST_PROFITABLE, FIRST_PROFITABLE_MEMORY = 0, 1, 2, 3
+STOP_NO_ENTERING, STOP_UNBOUNDED, STOP_BUDGET = 1, 2, 3
+
+
+class RelpError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("relp_amd status %d: %s" % (status, message))
+        self.status = status
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("pivot_rule", C.c_int32), ("polish_period", C.c_int32),
+                ("pivots_per_launch", C.c_int32), ("max_pivots", C.c_int64), ("tol_dual", C.c_double),
+                ("tol_pivot", C.c_double), ("harris_delta", C.c_double), ("tol_feasible", C.c_double),
+                ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("certified", C.c_int32), ("pivots_phase_one", C.c_int64),
+                ("pivots_phase_two", C.c_int64), ("polishes", C.c_int64), ("exact_repair_pivots", C.c_int64),
+                ("objective", C.c_double), ("solve_seconds", C.c_double), ("certify_seconds", C.c_double),
+                ("max_residual", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("price_launches", C.c_int64), ("price_seconds", C.c_double),
+                ("update_seconds", C.c_double), ("ftran_seconds", C.c_double), ("price_bytes", C.c_int64),
+                ("update_bytes", C.c_int64)]
+
+
+_lib = None
+
+# every symbol include/relp_amd.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_free", "relp_model_dimensions",
+    "relp_model_column", "relp_model_column_exact", "relp_model_cost", "relp_model_right_hand_side",
+    "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
+    "relp_load_matrix_data", "relp_load_mps", "relp_load_model", "relp_get_dimensions", "relp_get_column",
+    "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
+    "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
+    "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
+    "relp_get_gamma", "relp_ratio", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
+    "relp_reset_stats", "relp_profile_kernel",
+]
+
+
+def lib():
+    """Load the shared library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RelpError(ERR_DEVICE, "%s is missing: run __graft_entry__.build() (make -C relp_amd/csrc)" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.relp_version.restype = C.c_char_p
+        _lib.relp_last_error.restype = C.c_char_p
+        _lib.relp_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _ptr(array, ctype):
+    return array.ctypes.data_as(C.POINTER(ctype))
+
+
+def default_options(**overrides):
+    options = Options()
+    lib().relp_options_default(C.byref(options))
+    for key, value in overrides.items():
+        if not hasattr(options, key):
+            raise AttributeError(key)
+        setattr(options, key, value)
+    return options
+
+
+class Model:
+    """Host-only provider (``MatrixData``; matrix_provider/matrix_data.rs:63-102).  Needs no GPU."""
+
+    def __init__(self, path, fixed=None):
+        if fixed is None:
+            fixed = str(path).upper().endswith(".SIF")  # tests/netlib/mod.rs:55 uses parse_fixed for the .SIF files
+        self._h = C.c_void_p()
+        error = C.create_string_buffer(512)
+        status = lib().relp_model_from_mps(str(path).encode(), int(fixed), C.byref(self._h), error, 512)
+        if status != OK:
+            raise RelpError(status, error.value.decode())
+        rows, cols, cons, struct = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        nnz = C.c_int64()
+        groups = (C.c_int32 * 4)()
+        lib().relp_model_dimensions(self._h, C.byref(rows), C.byref(cols), C.byref(cons), C.byref(struct), C.byref(nnz), groups)
+        self.nr_rows, self.nr_columns, self.nr_constraints = rows.value, cols.value, cons.value
+        self.nr_structural, self.nnz, self.group_counts = struct.value, nnz.value, list(groups)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().relp_model_free(self._h)
+            self._h = None
+
+    def column(self, j):
+        count = C.c_int32()
+        rows = np.zeros(self.nr_rows, dtype=np.int32)
+        vals = np.zeros(self.nr_rows, dtype=np.float64)
+        status = lib().relp_model_column(self._h, j, self.nr_rows, C.byref(count), _ptr(rows, C.c_int32), _ptr(vals, C.c_double))
+        if status != OK:
+            raise RelpError(status, "column")
+        return rows[:count.value].copy(), vals[:count.value].copy()
+
+    def column_exact(self, j):
+        count = C.c_int32()
+        rows = np.zeros(self.nr_rows, dtype=np.int32)
+        num = np.zeros(self.nr_rows, dtype=np.int64)
+        den = np.zeros(self.nr_rows, dtype=np.int64)
+        status = lib().relp_model_column_exact(self._h, j, self.nr_rows, C.byref(count), _ptr(rows, C.c_int32),
+                                               _ptr(num, C.c_int64), _ptr(den, C.c_int64))
+        if status != OK:
+            raise RelpError(status, "column_exact")
+        k = count.value
+        return [(int(rows[e]), int(num[e]), int(den[e])) for e in range(k)]
+
+    def cost_value(self, j):
+        out = C.c_double()
+        lib().relp_model_cost(self._h, j, C.byref(out))
+        return out.value
+
+    def right_hand_side(self):
+        out = np.zeros(self.nr_rows)
+        lib().relp_model_right_hand_side(self._h, _ptr(out, C.c_double))
+        return out
+
+    def pivot_element_indices(self):
+        count = C.c_int32()
+        rows = np.zeros(self.nr_rows, dtype=np.int32)
+        cols = np.zeros(self.nr_rows, dtype=np.int32)
+        lib().relp_model_initial_pivots(self._h, self.nr_rows, C.byref(count), _ptr(rows, C.c_int32), _ptr(cols, C.c_int32))
+        return [(int(rows[k]), int(cols[k])) for k in range(count.value)]
+
+    def fixed_cost(self):
+        out = C.c_double()
+        lib().relp_model_fixed_cost(self._h, C.byref(out))
+        return out.value
+
+
+class Solver:
+    """One handle = one LP resident on one GPU (``Tableau<Carry<f64, _>, _>`` + ``PivotRule`` state)."""
+
+    def __init__(self, options=None, **overrides):
+        self.options = options or default_options(**overrides)
+        self._h = C.c_void_p()
+        status = lib().relp_create(C.byref(self.options), C.byref(self._h))
+        if status != OK:
+            raise RelpError(status, "relp_create failed (no usable HIP device? the product has no CPU fallback)")
+        self.m = self.n_provider = self.n_art = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().relp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, status):
+        if status != OK:
+            raise RelpError(status, lib().relp_last_error(self._h).decode())
+
+    def _dims(self):
+        rows, cols, cons, struct, art = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        nnz = C.c_int64()
+        self._check(lib().relp_get_dimensions(self._h, C.byref(rows), C.byref(cols), C.byref(cons), C.byref(struct),
+                                              C.byref(art), C.byref(nnz)))
+        self.m, self.n_provider, self.n_art, self.nnz = rows.value, cols.value, art.value, nnz.value
+        self.n_structural = struct.value
+        self.n = self.n_art + self.n_provider
+
+    # ---- provider ------------------------------------------------------------------------------
+    def load_mps(self, path, fixed=None):
+        if fixed is None:
+            fixed = str(path).upper().endswith(".SIF")
+        self._check(lib().relp_load_mps(self._h, str(path).encode(), int(fixed)))
+        self._dims()
+        return self
+
+    def load_model(self, model):
+        self._check(lib().relp_load_model(self._h, model._h))
+        self._dims()
+        return self
+
+    def load_matrix_data(self, column_start, row_index, value_num, value_den, b, cost, upper=None, ranges=(),
+                         counts=(0, 0, 0, 0), fixed_cost=(0, 1)):
+        """``MatrixData::new`` (matrix_data.rs:172-248).  ``b``/``cost``/``upper``/``ranges``: lists of (num, den) or ints."""
+        def pairs(values):
+            num = np.array([v[0] if isinstance(v, tuple) else v for v in values], dtype=np.int64)
+            den = np.array([v[1] if isinstance(v, tuple) else 1 for v in values], dtype=np.int64)
+            return num, den
+        column_start = np.ascontiguousarray(column_start, dtype=np.int64)
+        row_index = np.ascontiguousarray(row_index, dtype=np.int32)
+        value_num = np.ascontiguousarray(value_num, dtype=np.int64)
+        value_den = np.ascontiguousarray(value_den, dtype=np.int64)
+        n = len(column_start) - 1
+        b_num, b_den = pairs(b)
+        c_num, c_den = pairs(cost)
+        has_upper = np.zeros(n, dtype=np.uint8)
+        u_num = np.zeros(n, dtype=np.int64)
+        u_den = np.ones(n, dtype=np.int64)
+        if upper is not None:
+            for j, u in enumerate(upper):
+                if u is not None:
+                    has_upper[j] = 1
+                    u_num[j], u_den[j] = (u if isinstance(u, tuple) else (u, 1))
+        r_num, r_den = pairs(list(ranges)) if len(ranges) else (np.zeros(1, dtype=np.int64), np.ones(1, dtype=np.int64))
+        self._keep = (column_start, row_index, value_num, value_den, b_num, b_den, c_num, c_den, has_upper, u_num, u_den, r_num, r_den)
+        self._check(lib().relp_load_matrix_data(
+            self._h, C.c_int32(len(b)), C.c_int32(n), _ptr(column_start, C.c_int64), _ptr(row_index, C.c_int32),
+            _ptr(value_num, C.c_int64), _ptr(value_den, C.c_int64), _ptr(b_num, C.c_int64), _ptr(b_den, C.c_int64),
+            _ptr(c_num, C.c_int64), _ptr(c_den, C.c_int64), _ptr(has_upper, C.c_uint8), _ptr(u_num, C.c_int64),
+            _ptr(u_den, C.c_int64), _ptr(r_num, C.c_int64), _ptr(r_den, C.c_int64),
+            C.c_int32(counts[0]), C.c_int32(counts[1]), C.c_int32(counts[2]), C.c_int32(counts[3]),
+            C.c_int64(fixed_cost[0]), C.c_int64(fixed_cost[1])))
+        self._dims()
+        return self
+
+    # ---- solve_relaxation ------------------------------------------------------------------------
+    def solve_relaxation(self):
+        result = Result()
+        self._check(lib().relp_solve_relaxation(self._h, C.byref(result)))
+        return result
+
+    def solution(self):
+        """``FiniteOptimum`` vector after ``reconstruct_solution`` (structural columns only)."""
+        out = np.zeros(self.n_structural)
+        self._check(lib().relp_get_solution(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def objective_exact(self):
+        length = C.c_int32()
+        lib().relp_get_objective_exact(self._h, None, 0, C.byref(length))
+        buf = C.create_string_buffer(length.value + 1)
+        self._check(lib().relp_get_objective_exact(self._h, buf, length.value + 1, C.byref(length)))
+        return buf.value.decode()
+
+    def basis(self):
+        out = np.zeros(self.m, dtype=np.int32)
+        self._check(lib().relp_get_basis(self._h, _ptr(out, C.c_int32)))
+        return out
+
+    def set_basis(self, basis):
+        arr = np.ascontiguousarray(basis, dtype=np.int32)
+        self._check(lib().relp_set_basis(self._h, _ptr(arr, C.c_int32)))
+
+    # ---- fine-grained trait ops -------------------------------------------------------------------
+    def begin_phase_one(self):
+        self._check(lib().relp_begin_phase_one(self._h))
+
+    def begin_phase_two(self):
+        self._check(lib().relp_begin_phase_two(self._h))
+
+    def left_multiply_by_basis_inverse(self, rows, values):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        out = np.zeros(self.m)
+        self._check(lib().relp_bi_ftran(self._h, len(rows), _ptr(rows, C.c_int32), _ptr(values, C.c_double), _ptr(out, C.c_double)))
+        return out
+
+    def right_multiply_by_basis_inverse(self, rows, values):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        out = np.zeros(self.m)
+        self._check(lib().relp_bi_btran(self._h, len(rows), _ptr(rows, C.c_int32), _ptr(values, C.c_double), _ptr(out, C.c_double)))
+        return out
+
+    def basis_inverse_row(self, row):
+        out = np.zeros(self.m)
+        self._check(lib().relp_bi_row(self._h, int(row), _ptr(out, C.c_double)))
+        return out
+
+    def select_primal_pivot_column(self):
+        column, cost = C.c_int32(), C.c_double()
+        self._check(lib().relp_price(self._h, C.byref(column), C.byref(cost)))
+        return (None if column.value < 0 else (column.value, cost.value))
+
+    def relative_costs(self):
+        out = np.zeros(self.n)
+        self._check(lib().relp_relative_costs(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def gamma(self):
+        out = np.zeros(self.n)
+        self._check(lib().relp_get_gamma(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def select_primal_pivot_row(self, column):
+        row = C.c_int32()
+        alpha = np.zeros(self.m)
+        self._check(lib().relp_ratio(self._h, int(column), C.byref(row), _ptr(alpha, C.c_double)))
+        return (None if row.value < 0 else row.value), alpha
+
+    def iterate(self, count):
+        done, reason = C.c_int64(), C.c_int32()
+        self._check(lib().relp_iterate(self._h, int(count), C.byref(done), C.byref(reason)))
+        return done.value, reason.value
+
+    def b(self):
+        out = np.zeros(self.m)
+        self._check(lib().relp_get_b(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def objective_function_value(self):
+        out = C.c_double()
+        self._check(lib().relp_get_objective(self._h, C.byref(out)))
+        return out.value
+
+    def stats(self):
+        stats = Stats()
+        self._check(lib().relp_get_stats(self._h, C.byref(stats)))
+        return stats
+
+    def profile_kernel(self, which, repetitions):
+        """Average duration (seconds) of one launch of kernel ``which`` (0 price, 1 ftran+ratio (dry), 2 update)
+        measured with HIP events on the handle's stream around ``repetitions`` back-to-back launches."""
+        out = C.c_double()
+        self._check(lib().relp_profile_kernel(self._h, int(which), int(repetitions), C.byref(out)))
+        return out.value

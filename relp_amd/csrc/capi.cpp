@@ -1,0 +1,465 @@
+// extern "C" boundary (include/relp_amd.h).  Plain pointers and sizes only; exceptions are mapped to status codes.
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <sstream>
+
+#include "solver.hpp"
+
+using namespace relp;
+
+struct relp_model {
+    StandardForm form;
+};
+
+struct relp_handle {
+    relp_options options;
+    Solver* solver = nullptr;
+    std::string error;
+};
+
+namespace {
+
+template <class F>
+int32_t guarded(relp_handle* h, F&& f) {
+    try {
+        f();
+        return RELP_OK;
+    } catch (const DeviceError& e) {
+        if (h) h->error = e.what();
+        return RELP_ERR_DEVICE;
+    } catch (const RatOverflow& e) {
+        if (h) h->error = e.what();
+        return RELP_ERR_OVERFLOW;
+    } catch (const std::invalid_argument& e) {
+        if (h) h->error = e.what();
+        return RELP_ERR_ARGUMENT;
+    } catch (const std::exception& e) {
+        if (h) h->error = e.what();
+        return RELP_ERR_STATE;
+    }
+}
+
+Rat make_rat(int64_t n, int64_t d) { return Rat((i128)n, (i128)d); }
+
+}  // namespace
+
+extern "C" {
+
+const char* relp_version(void) { return "relp_amd 0.1 gfx950"; }
+
+int32_t relp_options_default(relp_options* o) {
+    if (!o) return RELP_ERR_ARGUMENT;
+    std::memset(o, 0, sizeof(*o));
+    o->device = 0;
+    o->pivot_rule = RELP_PIVOT_STEEPEST_EDGE;  // two_phase/mod.rs:57,68,107
+    o->polish_period = 64;
+    o->pivots_per_launch = 32;
+    o->max_pivots = 0;
+    o->tol_dual = 1e-9;
+    o->tol_pivot = 1e-9;
+    o->harris_delta = 1e-9;
+    o->tol_feasible = 1e-7;
+    o->certify = 0;
+    o->use_graph = 1;
+    o->verbose = 0;
+    return RELP_OK;
+}
+
+// ---- host-only model ------------------------------------------------------------------------------------
+int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model** out, char* error, int32_t error_capacity) {
+    if (!path || !out) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    auto fail = [&](const std::string& what, int32_t code) {
+        if (error && error_capacity > 0) {
+            std::strncpy(error, what.c_str(), error_capacity - 1);
+            error[error_capacity - 1] = 0;
+        }
+        return code;
+    };
+    std::ifstream in(path);
+    if (!in) return fail(std::string("cannot open ") + path, RELP_ERR_PARSE);
+    std::stringstream buffer;
+    buffer << in.rdbuf();
+    try {
+        relp_model* model = new relp_model();
+        model->form = load_mps(buffer.str(), fixed_format != 0);
+        *out = model;
+        return RELP_OK;
+    } catch (const RatOverflow& e) {
+        return fail(e.what(), RELP_ERR_OVERFLOW);
+    } catch (const std::exception& e) {
+        return fail(e.what(), RELP_ERR_PARSE);
+    }
+}
+int32_t relp_model_free(relp_model* model) {
+    delete model;
+    return RELP_OK;
+}
+static int32_t model_dimensions(const MatrixData& md, int32_t* nr_rows, int32_t* nr_columns, int32_t* nr_constraints,
+                                int32_t* nr_structural, int64_t* nnz, int32_t group_counts[4]) {
+    if (nr_rows) *nr_rows = md.nr_rows();
+    if (nr_columns) *nr_columns = md.nr_columns();
+    if (nr_constraints) *nr_constraints = md.nr_constraints();
+    if (nr_structural) *nr_structural = md.nr_normal_variables();
+    if (nnz) {
+        int64_t total = 0;
+        for (const auto& c : md.constraints) total += (int64_t)c.nnz();
+        *nnz = total;
+    }
+    if (group_counts) {
+        group_counts[0] = md.nr_equality;
+        group_counts[1] = md.nr_range;
+        group_counts[2] = md.nr_upper;
+        group_counts[3] = md.nr_lower;
+    }
+    return RELP_OK;
+}
+int32_t relp_model_dimensions(const relp_model* model, int32_t* nr_rows, int32_t* nr_columns, int32_t* nr_constraints,
+                              int32_t* nr_structural, int64_t* nnz, int32_t group_counts[4]) {
+    if (!model) return RELP_ERR_ARGUMENT;
+    return model_dimensions(model->form.data, nr_rows, nr_columns, nr_constraints, nr_structural, nnz, group_counts);
+}
+int32_t relp_model_column(const relp_model* model, int32_t j, int32_t capacity, int32_t* count, int32_t* row_index, double* value) {
+    if (!model || !count || j < 0 || j >= model->form.data.nr_columns()) return RELP_ERR_ARGUMENT;
+    SparseColumn c = model->form.data.column(j);
+    *count = (int32_t)c.nnz();
+    for (int32_t e = 0; e < *count && e < capacity; ++e) {
+        if (row_index) row_index[e] = c.index[e];
+        if (value) value[e] = c.value[e].to_double();
+    }
+    return RELP_OK;
+}
+int32_t relp_model_column_exact(const relp_model* model, int32_t j, int32_t capacity, int32_t* count, int32_t* row_index,
+                                int64_t* num, int64_t* den) {
+    if (!model || !count || j < 0 || j >= model->form.data.nr_columns()) return RELP_ERR_ARGUMENT;
+    SparseColumn c = model->form.data.column(j);
+    *count = (int32_t)c.nnz();
+    for (int32_t e = 0; e < *count && e < capacity; ++e) {
+        const Rat& v = c.value[e];
+        if (v.n > INT64_MAX || v.n < INT64_MIN || v.d > INT64_MAX) return RELP_ERR_OVERFLOW;
+        if (row_index) row_index[e] = c.index[e];
+        if (num) num[e] = (int64_t)v.n;
+        if (den) den[e] = (int64_t)v.d;
+    }
+    return RELP_OK;
+}
+int32_t relp_model_cost(const relp_model* model, int32_t j, double* cost) {
+    if (!model || !cost || j < 0 || j >= model->form.data.nr_columns()) return RELP_ERR_ARGUMENT;
+    *cost = model->form.data.cost_value(j).to_double();
+    return RELP_OK;
+}
+int32_t relp_model_right_hand_side(const relp_model* model, double* rhs) {
+    if (!model || !rhs) return RELP_ERR_ARGUMENT;
+    auto values = model->form.data.right_hand_side();
+    for (size_t i = 0; i < values.size(); ++i) rhs[i] = values[i].to_double();
+    return RELP_OK;
+}
+int32_t relp_model_initial_pivots(const relp_model* model, int32_t capacity, int32_t* count, int32_t* rows, int32_t* columns) {
+    if (!model || !count) return RELP_ERR_ARGUMENT;
+    auto pivots = model->form.data.pivot_element_indices();
+    *count = (int32_t)pivots.size();
+    for (int32_t k = 0; k < *count && k < capacity; ++k) {
+        if (rows) rows[k] = pivots[k].first;
+        if (columns) columns[k] = pivots[k].second;
+    }
+    return RELP_OK;
+}
+int32_t relp_model_fixed_cost(const relp_model* model, double* fixed_cost) {
+    if (!model || !fixed_cost) return RELP_ERR_ARGUMENT;
+    *fixed_cost = model->form.fixed_cost.to_double();
+    return RELP_OK;
+}
+
+int32_t relp_load_model(relp_handle* h, const relp_model* model) {
+    if (!h || !h->solver || !model) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] {
+        StandardForm copy = model->form;
+        h->solver->load(std::move(copy));
+    });
+}
+
+int32_t relp_create(const relp_options* options, relp_handle** out) {
+    if (!out) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    relp_handle* h = new (std::nothrow) relp_handle();
+    if (!h) return RELP_ERR_STATE;
+    if (options) h->options = *options;
+    else relp_options_default(&h->options);
+    int32_t status = guarded(h, [&] { h->solver = new Solver(h->options); });
+    if (status != RELP_OK) {
+        // keep the message reachable: the handle is returned only on success
+        delete h;
+        return status;
+    }
+    *out = h;
+    return RELP_OK;
+}
+
+int32_t relp_destroy(relp_handle* h) {
+    if (!h) return RELP_ERR_ARGUMENT;
+    delete h->solver;
+    delete h;
+    return RELP_OK;
+}
+
+const char* relp_last_error(const relp_handle* h) { return h ? h->error.c_str() : "null handle"; }
+
+int32_t relp_load_matrix_data(relp_handle* h, int32_t nr_constraints, int32_t nr_variables,
+                              const int64_t* column_start, const int32_t* row_index,
+                              const int64_t* value_num, const int64_t* value_den,
+                              const int64_t* b_num, const int64_t* b_den,
+                              const int64_t* cost_num, const int64_t* cost_den,
+                              const uint8_t* has_upper, const int64_t* upper_num, const int64_t* upper_den,
+                              const int64_t* range_num, const int64_t* range_den,
+                              int32_t nr_equality, int32_t nr_range, int32_t nr_upper, int32_t nr_lower,
+                              int64_t fixed_cost_num, int64_t fixed_cost_den) {
+    if (!h || !column_start || nr_constraints < 0 || nr_variables < 0) return RELP_ERR_ARGUMENT;
+    if (nr_equality + nr_range + nr_upper + nr_lower != nr_constraints) {
+        h->error = "row group counts do not add up to nr_constraints";
+        return RELP_ERR_ARGUMENT;
+    }
+    return guarded(h, [&] {
+        StandardForm form;
+        MatrixData& md = form.data;
+        md.nr_equality = nr_equality;
+        md.nr_range = nr_range;
+        md.nr_upper = nr_upper;
+        md.nr_lower = nr_lower;
+        md.constraints.resize(nr_variables);
+        md.variables.resize(nr_variables);
+        for (int j = 0; j < nr_variables; ++j) {
+            int previous = -1;
+            for (int64_t e = column_start[j]; e < column_start[j + 1]; ++e) {
+                if (row_index[e] <= previous || row_index[e] >= nr_constraints) throw std::invalid_argument("rows of a column must be sorted, unique and in range");
+                previous = row_index[e];
+                Rat v = make_rat(value_num[e], value_den ? value_den[e] : 1);
+                if (v.is_zero()) throw std::invalid_argument("explicit zero in sparse column");
+                md.constraints[j].push(row_index[e], v);
+            }
+            md.variables[j].cost = make_rat(cost_num[j], cost_den ? cost_den[j] : 1);
+            if (has_upper && has_upper[j]) {
+                md.variables[j].has_upper = true;
+                md.variables[j].upper = make_rat(upper_num[j], upper_den ? upper_den[j] : 1);
+            }
+        }
+        md.b.resize(nr_constraints);
+        for (int i = 0; i < nr_constraints; ++i) {
+            md.b[i] = make_rat(b_num[i], b_den ? b_den[i] : 1);
+            if (md.b[i].sign() < 0) throw std::invalid_argument("b must be non-negative (general_form/mod.rs:592-618)");
+        }
+        for (int i = 0; i < nr_range; ++i) md.ranges.push_back(make_rat(range_num[i], range_den ? range_den[i] : 1));
+        md.finalize();
+        form.fixed_cost = make_rat(fixed_cost_num, fixed_cost_den ? fixed_cost_den : 1);
+        form.nr_original = nr_variables;
+        form.free_negative_part.assign(nr_variables, -1);
+        h->solver->load(std::move(form));
+    });
+}
+
+int32_t relp_load_mps(relp_handle* h, const char* path, int32_t fixed_format) {
+    if (!h || !path) return RELP_ERR_ARGUMENT;
+    std::ifstream in(path);
+    if (!in) {
+        h->error = std::string("cannot open ") + path;
+        return RELP_ERR_PARSE;
+    }
+    std::stringstream buffer;
+    buffer << in.rdbuf();
+    StandardForm form;
+    try {
+        form = load_mps(buffer.str(), fixed_format != 0);
+    } catch (const RatOverflow& e) {
+        h->error = e.what();
+        return RELP_ERR_OVERFLOW;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        return RELP_ERR_PARSE;
+    }
+    return guarded(h, [&] { h->solver->load(std::move(form)); });
+}
+
+#define REQUIRE_LOADED(h)                                   \
+    if (!(h) || !(h)->solver) return RELP_ERR_ARGUMENT;     \
+    if (!(h)->solver->loaded()) {                           \
+        const_cast<relp_handle*>(h)->error = "no LP loaded"; \
+        return RELP_ERR_STATE;                              \
+    }
+
+int32_t relp_get_dimensions(const relp_handle* h, int32_t* nr_rows, int32_t* nr_columns, int32_t* nr_constraints,
+                            int32_t* nr_structural, int32_t* nr_artificial, int64_t* nnz) {
+    REQUIRE_LOADED(h);
+    if (nr_artificial) *nr_artificial = h->solver->n_art();
+    return model_dimensions(h->solver->form().data, nr_rows, nr_columns, nr_constraints, nr_structural, nnz, nullptr);
+}
+
+int32_t relp_get_column(const relp_handle* h, int32_t j, int32_t capacity, int32_t* count, int32_t* row_index, double* value) {
+    REQUIRE_LOADED(h);
+    const MatrixData& md = h->solver->form().data;
+    if (j < 0 || j >= md.nr_columns() || !count) return RELP_ERR_ARGUMENT;
+    SparseColumn c = md.column(j);
+    *count = (int32_t)c.nnz();
+    for (int32_t e = 0; e < *count && e < capacity; ++e) {
+        if (row_index) row_index[e] = c.index[e];
+        if (value) value[e] = c.value[e].to_double();
+    }
+    return RELP_OK;
+}
+
+int32_t relp_get_cost(const relp_handle* h, int32_t j, double* cost) {
+    REQUIRE_LOADED(h);
+    const MatrixData& md = h->solver->form().data;
+    if (j < 0 || j >= md.nr_columns() || !cost) return RELP_ERR_ARGUMENT;
+    *cost = md.cost_value(j).to_double();
+    return RELP_OK;
+}
+
+int32_t relp_get_right_hand_side(const relp_handle* h, double* rhs) {
+    REQUIRE_LOADED(h);
+    if (!rhs) return RELP_ERR_ARGUMENT;
+    auto values = h->solver->form().data.right_hand_side();
+    for (size_t i = 0; i < values.size(); ++i) rhs[i] = values[i].to_double();
+    return RELP_OK;
+}
+
+int32_t relp_get_initial_pivots(const relp_handle* h, int32_t capacity, int32_t* count, int32_t* rows, int32_t* columns) {
+    REQUIRE_LOADED(h);
+    if (!count) return RELP_ERR_ARGUMENT;
+    auto pivots = h->solver->form().data.pivot_element_indices();
+    *count = (int32_t)pivots.size();
+    for (int32_t k = 0; k < *count && k < capacity; ++k) {
+        if (rows) rows[k] = pivots[k].first;
+        if (columns) columns[k] = pivots[k].second;
+    }
+    return RELP_OK;
+}
+
+int32_t relp_solve_relaxation(relp_handle* h, relp_result* result) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] { h->solver->solve(result); });
+}
+
+int32_t relp_get_solution(const relp_handle* h, double* x) {
+    REQUIRE_LOADED(h);
+    if (!x) return RELP_ERR_ARGUMENT;
+    h->solver->get_solution(x);
+    return RELP_OK;
+}
+
+int32_t relp_get_objective_exact(const relp_handle* h, char* buffer, int32_t capacity, int32_t* length) {
+    REQUIRE_LOADED(h);
+    const std::string& s = h->solver->exact_objective;
+    if (length) *length = (int32_t)s.size();
+    if (s.empty()) {
+        const_cast<relp_handle*>(h)->error = "no exact objective (set options.certify and solve)";
+        return RELP_ERR_STATE;
+    }
+    if (buffer && capacity > 0) {
+        int32_t nbytes = std::min<int32_t>((int32_t)s.size(), capacity - 1);
+        std::memcpy(buffer, s.data(), nbytes);
+        buffer[nbytes] = 0;
+    }
+    return RELP_OK;
+}
+
+int32_t relp_get_basis(const relp_handle* h, int32_t* basis) {
+    REQUIRE_LOADED(h);
+    if (!basis) return RELP_ERR_ARGUMENT;
+    return guarded(const_cast<relp_handle*>(h), [&] { h->solver->get_basis(basis); });
+}
+
+int32_t relp_set_basis(relp_handle* h, const int32_t* basis_columns) {
+    REQUIRE_LOADED(h);
+    if (!basis_columns) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->set_basis(basis_columns); });
+}
+
+int32_t relp_begin_phase_one(relp_handle* h) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] { h->solver->begin_phase_one(); });
+}
+int32_t relp_begin_phase_two(relp_handle* h) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] { h->solver->begin_phase_two(); });
+}
+int32_t relp_bi_ftran(relp_handle* h, int32_t nnz, const int32_t* rows, const double* values, double* out) {
+    REQUIRE_LOADED(h);
+    if (nnz < 0 || !out) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->ftran(nnz, rows, values, out); });
+}
+int32_t relp_bi_btran(relp_handle* h, int32_t nnz, const int32_t* rows, const double* values, double* out) {
+    REQUIRE_LOADED(h);
+    if (nnz < 0 || !out) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->btran(nnz, rows, values, out); });
+}
+int32_t relp_bi_row(relp_handle* h, int32_t row, double* out) {
+    REQUIRE_LOADED(h);
+    if (!out) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->inverse_row(row, out); });
+}
+int32_t relp_price(relp_handle* h, int32_t* column, double* relative_cost) {
+    REQUIRE_LOADED(h);
+    if (!column || !relative_cost) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] {
+        int c;
+        double v;
+        h->solver->price(&c, &v);
+        *column = c;
+        *relative_cost = v;
+    });
+}
+int32_t relp_relative_costs(relp_handle* h, double* out) {
+    REQUIRE_LOADED(h);
+    if (!out) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->relative_costs(out); });
+}
+int32_t relp_get_gamma(relp_handle* h, double* out) {
+    REQUIRE_LOADED(h);
+    if (!out) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->get_gamma(out); });
+}
+int32_t relp_ratio(relp_handle* h, int32_t column, int32_t* row, double* out_alpha) {
+    REQUIRE_LOADED(h);
+    if (!row) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] {
+        int r;
+        h->solver->ratio(column, &r, out_alpha);
+        *row = r;
+    });
+}
+int32_t relp_iterate(relp_handle* h, int64_t count, int64_t* done, int32_t* stop_reason) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] {
+        int reason = 0;
+        long long d = h->solver->iterate(count, &reason);
+        if (done) *done = d;
+        if (stop_reason) *stop_reason = reason;
+    });
+}
+int32_t relp_get_b(relp_handle* h, double* out) {
+    REQUIRE_LOADED(h);
+    if (!out) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->get_b(out); });
+}
+int32_t relp_get_objective(relp_handle* h, double* objective) {
+    REQUIRE_LOADED(h);
+    if (!objective) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { *objective = h->solver->objective(); });
+}
+int32_t relp_get_stats(const relp_handle* h, relp_stats* stats) {
+    if (!h || !h->solver || !stats) return RELP_ERR_ARGUMENT;
+    *stats = h->solver->stats();
+    return RELP_OK;
+}
+int32_t relp_profile_kernel(relp_handle* h, int32_t which, int32_t repetitions, double* seconds) {
+    REQUIRE_LOADED(h);
+    if (!seconds || repetitions < 1 || which < 0 || which > 2) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { *seconds = h->solver->profile_kernel(which, repetitions); });
+}
+int32_t relp_reset_stats(relp_handle* h) {
+    if (!h || !h->solver) return RELP_ERR_ARGUMENT;
+    h->solver->reset_stats();
+    return RELP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,398 @@
+// MPS (fixed / free) reader and standardisation: the step immediately before the hot path.
+//
+// Replaces, for the un-presolved pipeline of tests/netlib/mod.rs:47-71 of the reference:
+//   io/mps/parse/{mod,fixed,free}.rs   section reader (rows sorted by NAME: parse/mod.rs:243-262)
+//   io/mps/number/parse.rs:77-119      exact decimal -> rational (no exponent syntax)
+//   io/mps/convert.rs:29-394           bounds (GLPK-like UP rule :211-216), ranges, rhs -> GeneralForm
+//   general_form/mod.rs:325-332        standardize(): split free, flip/shift to x>=0, b>=0, minimise, E|R|L|G order
+//   general_form/mod.rs:262-304        derive_matrix_data()
+// The reference's presolve (general_form/presolve/**) is out of scope this round; both this code and the oracle
+// solve the un-presolved standard form, whose optimum is the same.
+#include <algorithm>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "model.hpp"
+
+namespace relp {
+namespace {
+
+Rat parse_number(const std::string& text) {
+    if (text.empty()) throw std::runtime_error("empty number");
+    size_t pos = 0;
+    bool negative = false;
+    if (text[0] == '-') { negative = true; pos = 1; }
+    i128 integer = 0;
+    int steps = 0;
+    bool seen_dot = false;
+    for (; pos < text.size(); ++pos) {
+        char c = text[pos];
+        if (c == '.') {
+            if (seen_dot) throw std::runtime_error("bad number: " + text);
+            seen_dot = true;
+        } else if (c >= '0' && c <= '9') {
+            integer = add_checked(mul_checked(integer, 10), c - '0');
+            if (seen_dot) ++steps;
+        } else {
+            throw std::runtime_error("bad number (exponents are not accepted, number/parse.rs:77): " + text);
+        }
+    }
+    i128 den = 1;
+    for (int k = 0; k < steps; ++k) den = mul_checked(den, 10);
+    return Rat(negative ? -integer : integer, den);
+}
+
+std::string trim(const std::string& s) {
+    size_t a = s.find_first_not_of(" \t\r");
+    if (a == std::string::npos) return "";
+    size_t b = s.find_last_not_of(" \t\r");
+    return s.substr(a, b - a + 1);
+}
+
+// io/mps/parse/fixed.rs:137-145
+const int FIELD_START[7] = {0, 1, 4, 14, 24, 39, 49};
+const int FIELD_END[7] = {1, 3, 12, 22, 36, 47, 61};
+
+std::string field(const std::string& line, int k) {
+    if ((int)line.size() <= FIELD_START[k]) return "";
+    int end = std::min<int>(FIELD_END[k], (int)line.size());
+    return trim(line.substr(FIELD_START[k], end - FIELD_START[k]));
+}
+
+std::vector<std::string> split_ws(const std::string& line) {
+    std::istringstream in(line);
+    std::vector<std::string> out;
+    std::string tok;
+    while (in >> tok) out.push_back(tok);
+    return out;
+}
+
+enum RowKind { EQUAL = 0, RANGE = 1, LESS = 2, GREATER = 3 };
+
+struct GeneralVariable {
+    Rat cost;
+    bool has_lower = false, has_upper = false;
+    Rat lower, upper, shift;
+    bool flipped = false;
+};
+
+struct Raw {
+    std::string name;
+    bool maximize = false;
+    std::string cost_row;
+    std::vector<std::pair<std::string, RowKind>> rows;  // sorted by name
+    std::vector<std::string> column_names;
+    std::vector<SparseColumn> columns;
+    std::vector<Rat> cost;
+    std::vector<std::vector<std::pair<int, Rat>>> rhs_groups, range_groups;
+    struct Bound { int column; std::string type; Rat value; };
+    std::vector<Bound> bounds;
+};
+
+Raw parse(const std::string& text, bool fixed) {
+    Raw raw;
+    std::vector<std::string> lines;
+    {
+        std::istringstream in(text);
+        std::string line;
+        while (std::getline(in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty()) continue;
+            std::string t = trim(line);
+            if (!t.empty() && t[0] == '*') continue;  // parse/mod.rs:97-103
+            lines.push_back(line);
+        }
+    }
+    if (lines.empty() || lines[0].compare(0, 4, "NAME") != 0) throw std::runtime_error("expected NAME");
+    {
+        auto toks = split_ws(lines[0].substr(4));
+        raw.name = toks.empty() ? "" : toks[0];
+    }
+    std::string section;
+    std::vector<std::pair<std::string, RowKind>> rows_unsorted;
+    std::unordered_map<std::string, int> row_index, column_index;
+    std::vector<std::vector<std::pair<std::string, Rat>>> column_entries;
+    std::string last_rhs_name, last_range_name;
+    bool have_rhs_group = false, have_range_group = false;
+
+    auto data_fields = [&](const std::string& line) {
+        if (fixed) return std::vector<std::string>{field(line, 2), field(line, 3), field(line, 4), field(line, 5), field(line, 6)};
+        return split_ws(line);
+    };
+
+    for (size_t li = 1; li < lines.size(); ++li) {
+        const std::string& line = lines[li];
+        if (line[0] != ' ' && line[0] != '\t') {
+            section = split_ws(line)[0];
+            if (section == "ENDATA") break;
+            if (section == "COLUMNS") {
+                raw.rows = rows_unsorted;
+                std::sort(raw.rows.begin(), raw.rows.end(),
+                          [](const auto& a, const auto& b) { return a.first < b.first; });
+                for (size_t i = 0; i < raw.rows.size(); ++i) {
+                    if (!row_index.emplace(raw.rows[i].first, (int)i).second) throw std::runtime_error("Duplicate row name");
+                }
+                if (raw.cost_row.empty()) throw std::runtime_error("No cost name read.");
+                if (row_index.count(raw.cost_row)) throw std::runtime_error("Cost row name found in other rows.");
+            }
+            continue;
+        }
+        if (section == "OBJSENSE") {
+            std::string w = trim(line);
+            raw.maximize = (w == "MAXIMIZE" || w == "MAX");
+        } else if (section == "ROWS") {
+            std::string type, name;
+            if (fixed) { type = field(line, 1); name = field(line, 2); }
+            else { auto t = split_ws(line); type = t.at(0); name = t.at(1); }
+            if (type == "N") {
+                if (!raw.cost_row.empty()) throw std::runtime_error("Second cost row detected.");
+                raw.cost_row = name;
+            } else if (type == "E") rows_unsorted.push_back({name, EQUAL});
+            else if (type == "L") rows_unsorted.push_back({name, LESS});
+            else if (type == "G") rows_unsorted.push_back({name, GREATER});
+            else throw std::runtime_error("unknown row type " + type);
+        } else if (section == "COLUMNS") {
+            if (line.find("'MARKER'") != std::string::npos) continue;
+            auto f = data_fields(line);
+            if (f.size() < 3) throw std::runtime_error("short COLUMNS line");
+            auto it = column_index.find(f[0]);
+            int j;
+            if (it == column_index.end()) {
+                j = (int)raw.column_names.size();
+                column_index.emplace(f[0], j);
+                raw.column_names.push_back(f[0]);
+                column_entries.emplace_back();
+            } else {
+                j = it->second;
+            }
+            column_entries[j].push_back({f[1], parse_number(f[2])});
+            if (f.size() >= 5 && !f[3].empty() && !f[4].empty()) column_entries[j].push_back({f[3], parse_number(f[4])});
+        } else if (section == "RHS" || section == "RANGES") {
+            bool is_rhs = section == "RHS";
+            auto f = data_fields(line);
+            if (!fixed && f.size() % 2 == 0) f.insert(f.begin(), "");
+            auto& groups = is_rhs ? raw.rhs_groups : raw.range_groups;
+            std::string& last = is_rhs ? last_rhs_name : last_range_name;
+            bool& have = is_rhs ? have_rhs_group : have_range_group;
+            if (!have || last != f[0]) { groups.emplace_back(); last = f[0]; have = true; }
+            auto add = [&](const std::string& row, const std::string& value) {
+                auto it = row_index.find(row);
+                if (it == row_index.end()) throw std::runtime_error("Row \"" + row + "\" not known.");  // parse/mod.rs:608-610
+                groups.back().push_back({it->second, parse_number(value)});
+            };
+            add(f.at(1), f.at(2));
+            if (f.size() >= 5 && !f[3].empty() && !f[4].empty()) add(f[3], f[4]);
+        } else if (section == "BOUNDS") {
+            std::string type, column, value;
+            if (fixed) { type = field(line, 1); column = field(line, 3); value = field(line, 4); }
+            else {
+                auto t = split_ws(line);
+                type = t.at(0);
+                bool valued = !(type == "FR" || type == "MI" || type == "PL" || type == "BV");
+                size_t need = valued ? 4 : 3;
+                size_t base = t.size() >= need ? 2 : 1;  // bound-set name may be omitted
+                column = t.at(base);
+                if (valued) value = t.at(base + 1);
+            }
+            auto it = column_index.find(column);
+            if (it == column_index.end()) throw std::runtime_error("Column name \"" + column + "\" unknown");
+            Raw::Bound bd{it->second, type, Rat(0)};
+            if (type == "LO" || type == "UP" || type == "FX" || type == "LI" || type == "UI") bd.value = parse_number(value);
+            raw.bounds.push_back(bd);
+        } else {
+            throw std::runtime_error("unexpected section " + section);
+        }
+    }
+
+    raw.columns.resize(raw.column_names.size());
+    raw.cost.assign(raw.column_names.size(), Rat(0));
+    for (size_t j = 0; j < column_entries.size(); ++j) {
+        std::vector<std::pair<int, Rat>> values;
+        for (auto& [row, value] : column_entries[j]) {
+            if (row == raw.cost_row) { raw.cost[j] = value; continue; }
+            auto it = row_index.find(row);
+            if (it == row_index.end()) throw std::runtime_error("Row \"" + row + "\" not known.");
+            values.push_back({it->second, value});
+        }
+        std::sort(values.begin(), values.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (size_t k = 0; k < values.size(); ++k) {
+            if (k > 0 && values[k].first == values[k - 1].first) throw std::runtime_error("Duplicate row for column");
+            if (!values[k].second.is_zero()) raw.columns[j].push(values[k].first, values[k].second);
+        }
+    }
+    return raw;
+}
+
+void replace_if(bool& has, Rat& current, const Rat& value, bool keep_greater) {
+    if (!has) { has = true; current = value; return; }
+    if (keep_greater ? (value > current) : (value < current)) current = value;
+}
+
+}  // namespace
+
+StandardForm load_mps(const std::string& text, bool fixed_format) {
+    Raw raw = parse(text, fixed_format);
+    const int nr_rows = (int)raw.rows.size();
+    int n = (int)raw.columns.size();
+
+    // ---- convert.rs:118-262 bounds --------------------------------------------------------------
+    std::vector<GeneralVariable> vars(n);
+    for (int j = 0; j < n; ++j) vars[j].cost = raw.cost[j];
+    std::vector<char> needs_default_lower(n, 1), is_free(n, 0);
+    for (const auto& bd : raw.bounds) {
+        GeneralVariable& v = vars[bd.column];
+        bool needs_lower = false;
+        const std::string& t = bd.type;
+        if (t == "LO" || t == "LI") replace_if(v.has_lower, v.lower, bd.value, true);
+        else if (t == "UP" || t == "UI") { replace_if(v.has_upper, v.upper, bd.value, false); needs_lower = true; }
+        else if (t == "FX") { replace_if(v.has_lower, v.lower, bd.value, true); replace_if(v.has_upper, v.upper, bd.value, false); }
+        else if (t == "FR") { if (v.has_lower || v.has_upper) throw std::runtime_error("Variable can't be bounded and free"); is_free[bd.column] = 1; }
+        else if (t == "MI") replace_if(v.has_upper, v.upper, Rat(0), false);  // sic: convert.rs:233-237
+        else if (t == "PL") replace_if(v.has_lower, v.lower, Rat(0), true);
+        else if (t == "BV") { replace_if(v.has_lower, v.lower, Rat(0), true); replace_if(v.has_upper, v.upper, Rat(1), false); }
+        else throw std::runtime_error("Bound type \"" + t + "\" unknown.");
+        needs_default_lower[bd.column] = needs_default_lower[bd.column] && needs_lower;
+    }
+    for (int j = 0; j < n; ++j) {
+        if (is_free[j] && (vars[j].has_lower || vars[j].has_upper)) throw std::runtime_error("A variable is both free and bounded.");
+        if (needs_default_lower[j]) { vars[j].has_lower = true; vars[j].lower = Rat(0); }
+    }
+
+    // ---- convert.rs:264-394 ranges, constraint types, b -----------------------------------------
+    std::vector<RowKind> kind(nr_rows);
+    std::vector<Rat> range(nr_rows);
+    std::vector<char> has_range(nr_rows, 0);
+    for (auto& group : raw.range_groups)
+        for (auto& [i, r] : group) {
+            if (has_range[i]) throw std::runtime_error("Only one range per row can be specified.");
+            has_range[i] = 1;
+            range[i] = r;
+        }
+    for (int i = 0; i < nr_rows; ++i) {
+        if (has_range[i]) kind[i] = range[i].is_zero() ? EQUAL : RANGE;
+        else kind[i] = raw.rows[i].second;
+    }
+    std::vector<Rat> b(nr_rows);
+    std::vector<char> has_b(nr_rows, 0);
+    for (auto& group : raw.rhs_groups) {
+        std::vector<std::pair<int, Rat>> sorted = group;
+        std::stable_sort(sorted.begin(), sorted.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (auto& [i, value] : sorted) {
+            RowKind original = raw.rows[i].second;
+            if (!has_b[i]) {
+                has_b[i] = 1;
+                if (kind[i] == RANGE) {
+                    int sign = range[i].sign();
+                    if (sign < 0) range[i] = -range[i];
+                    if (original == GREATER) b[i] = value + range[i];
+                    else if (original == LESS) b[i] = value;
+                    else b[i] = sign >= 0 ? value + range[i] : value;
+                } else {
+                    b[i] = value;
+                }
+            } else {
+                if (original == EQUAL) { if (value != b[i]) throw std::runtime_error("Trivial infeasibility"); }
+                else if (original == GREATER) { if (value > b[i]) b[i] = value; }
+                else { if (value < b[i]) b[i] = value; }
+            }
+        }
+    }
+
+    // ---- general_form/mod.rs:506-587 transform_variables ----------------------------------------
+    StandardForm out;
+    out.name = raw.name;
+    out.nr_original = n;
+    out.column_names = raw.column_names;
+    out.free_negative_part.assign(n, -1);
+    std::vector<SparseColumn> columns = raw.columns;
+    for (int j = 0; j < n; ++j) {
+        if (!vars[j].has_lower && !vars[j].has_upper) {
+            out.free_negative_part[j] = (int)columns.size();
+            SparseColumn neg = columns[j];
+            for (auto& v : neg.value) v = -v;
+            columns.push_back(neg);
+            GeneralVariable twin;
+            twin.cost = -vars[j].cost;
+            twin.has_lower = true;
+            vars.push_back(twin);
+            vars[j].has_lower = true;
+            vars[j].lower = Rat(0);
+        }
+    }
+    Rat fixed_cost(0);
+    for (size_t j = 0; j < vars.size(); ++j) {
+        GeneralVariable& v = vars[j];
+        if (!v.has_lower && v.has_upper) {
+            v.flipped = !v.flipped;
+            v.shift = -v.shift;
+            v.cost = -v.cost;
+            v.has_lower = true;
+            v.lower = -v.upper;
+            v.has_upper = false;
+            for (auto& c : columns[j].value) c = -c;
+        }
+        if (v.has_lower) {
+            v.shift = v.shift - v.lower;
+            if (v.has_upper) v.upper = v.upper - v.lower;
+            fixed_cost = fixed_cost + v.lower * v.cost;
+            if (!v.lower.is_zero())
+                for (size_t k = 0; k < columns[j].nnz(); ++k) b[columns[j].index[k]] = b[columns[j].index[k]] - columns[j].value[k] * v.lower;
+            v.lower = Rat(0);
+        }
+    }
+    // ---- general_form/mod.rs:592-618 make_b_non_negative -----------------------------------------
+    std::vector<char> negate(nr_rows, 0);
+    for (int i = 0; i < nr_rows; ++i) negate[i] = b[i].sign() < 0;
+    for (auto& column : columns)
+        for (size_t k = 0; k < column.nnz(); ++k)
+            if (negate[column.index[k]]) column.value[k] = -column.value[k];
+    for (int i = 0; i < nr_rows; ++i) {
+        if (!negate[i]) continue;
+        if (kind[i] == LESS) { kind[i] = GREATER; b[i] = -b[i]; }
+        else if (kind[i] == GREATER) { kind[i] = LESS; b[i] = -b[i]; }
+        else if (kind[i] == EQUAL) b[i] = -b[i];
+        else b[i] = range[i] - b[i];
+    }
+    // ---- general_form/mod.rs:623-633 ----------------------------------------------------------------
+    if (raw.maximize)
+        for (auto& v : vars) v.cost = -v.cost;
+    // ---- general_form/mod.rs:651-717 reorder_constraints_by_type (stable) ------------------------
+    std::vector<int> order(nr_rows);
+    for (int i = 0; i < nr_rows; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (int)kind[x] < (int)kind[y]; });
+    std::vector<int> destination(nr_rows);
+    for (int d = 0; d < nr_rows; ++d) destination[order[d]] = d;
+    MatrixData& data = out.data;
+    int counts[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nr_rows; ++i) counts[kind[i]]++;
+    data.nr_equality = counts[EQUAL];
+    data.nr_range = counts[RANGE];
+    data.nr_upper = counts[LESS];
+    data.nr_lower = counts[GREATER];
+    data.b.resize(nr_rows);
+    for (int i = 0; i < nr_rows; ++i) data.b[destination[i]] = b[i];
+    for (int d = 0; d < nr_rows; ++d)
+        if (kind[order[d]] == RANGE) data.ranges.push_back(range[order[d]]);
+    data.constraints.resize(columns.size());
+    for (size_t j = 0; j < columns.size(); ++j) {
+        std::vector<std::pair<int, Rat>> entries;
+        for (size_t k = 0; k < columns[j].nnz(); ++k) entries.push_back({destination[columns[j].index[k]], columns[j].value[k]});
+        std::sort(entries.begin(), entries.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (auto& [i, v] : entries) data.constraints[j].push(i, v);
+    }
+    data.variables.resize(vars.size());
+    for (size_t j = 0; j < vars.size(); ++j) {
+        data.variables[j].cost = vars[j].cost;
+        data.variables[j].has_upper = vars[j].has_upper;
+        data.variables[j].upper = vars[j].upper;
+        data.variables[j].shift = vars[j].shift;
+        data.variables[j].flipped = vars[j].flipped;
+    }
+    data.finalize();
+    out.fixed_cost = fixed_cost;
+    return out;
+}
+
+}  // namespace relp

@@ -1,0 +1,697 @@
+// Host driver of the device-resident simplex (see solver.hpp).  Replaces, for this path:
+//   two_phase/mod.rs:25-109        solve_relaxation (both the generic and the FullInitialBasis route)
+//   phase_one.rs:123-278           phase-one loop + zero-level pivots
+//   phase_two.rs:22-59             phase-two loop
+//   kind/artificial/partially.rs   virtual artificial columns (index space: artificials first)
+#include "solver.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace relp {
+
+// kernels.hip
+void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
+                  int n_chunks, hipStream_t s);
+void configure_price_lds(size_t lds);
+void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
+                        int skip_artificial_rows, int mode, hipStream_t s);
+void launch_update(const DeviceLP& d, int rows_per_chunk, int n_chunks, hipStream_t s);
+void launch_budget(const DeviceLP& d, long long add, hipStream_t s);
+void launch_pi(const DeviceLP& d, hipStream_t s);
+void launch_xb(const DeviceLP& d, hipStream_t s);
+void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s);
+void launch_identity(double* X, int m, int ld, hipStream_t s);
+void launch_residual(const DeviceLP& d, const double* X, double* R, hipStream_t s);
+void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s);
+void launch_transpose_basis(const DeviceLP& d, double* X, double scale, hipStream_t s);
+void launch_row_scan(const DeviceLP& d, int r, double tol, hipStream_t s);
+void launch_ftran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
+void launch_btran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
+void launch_relative_cost(const DeviceLP& d, double* out, hipStream_t s);
+// certify.hip
+void certify_basis(const StandardForm& form, const std::vector<int>& basis_provider_columns, int device,
+                   hipStream_t stream, std::string* objective, bool* certified, long long* repair_pivots,
+                   std::string* message);
+
+namespace {
+double now_seconds() {
+    using clock = std::chrono::steady_clock;
+    return std::chrono::duration<double>(clock::now().time_since_epoch()).count();
+}
+template <class T>
+T* dmalloc(size_t count) {
+    T* p = nullptr;
+    RELP_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    return p;
+}
+template <class T>
+void upload_vec(T* dst, const std::vector<T>& src, hipStream_t s) {
+    if (!src.empty()) RELP_HIP(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+}  // namespace
+
+Solver::Solver(const relp_options& options) : opt_(options) {
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count <= 0)
+        throw DeviceError("no HIP device available (relp_amd has no CPU fallback)");
+    if (opt_.device < 0 || opt_.device >= count) throw DeviceError("device ordinal out of range");
+    RELP_HIP(hipSetDevice(opt_.device));
+    RELP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    RELP_HIP(hipEventCreate(&ev_a_));
+    RELP_HIP(hipEventCreate(&ev_b_));
+}
+
+Solver::~Solver() {
+    free_device();
+    if (graph_exec_) hipGraphExecDestroy(graph_exec_);
+    if (graph_) hipGraphDestroy(graph_);
+    if (ev_a_) hipEventDestroy(ev_a_);
+    if (ev_b_) hipEventDestroy(ev_b_);
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+void Solver::free_device() {
+    void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
+                    d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
+                    d_.alpha, d_.rho, d_.wpart, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.scratch, d_.ctl};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    d_ = DeviceLP{};
+}
+
+void Solver::reset_stats() { stats_ = relp_stats{}; }
+
+void Solver::load(StandardForm&& form) {
+    RELP_HIP(hipSetDevice(opt_.device));
+    free_device();
+    if (graph_exec_) { hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    if (graph_) { hipGraphDestroy(graph_); graph_ = nullptr; }
+    form_ = std::move(form);
+    upload();
+    loaded_ = true;
+    phase_ = 0;
+}
+
+// Materialise [artificials | provider columns] once (CSC + CSR) and upload.  The artificial columns are the virtual
+// identity columns of `Partially::original_column` (kind/artificial/partially.rs:52-60); the slack columns are the
+// virtual columns of `MatrixData::column` (matrix_data.rs:308-327): 12 bytes each, so materialising them costs nothing
+// and makes the pricing pass one uniform CSC sweep.
+void Solver::upload() {
+    const MatrixData& md = form_.data;
+    const int m = md.nr_rows();
+    const int n_p = md.nr_columns();
+    if (m < 1) throw std::runtime_error("LP without rows");
+    auto pivots = md.pivot_element_indices();
+    std::vector<int> real_column_of_row(m, -1);
+    for (auto& [row, column] : pivots) real_column_of_row[row] = column;
+    std::vector<int> artificial_rows;
+    for (int i = 0; i < m; ++i)
+        if (real_column_of_row[i] < 0) artificial_rows.push_back(i);
+    const int n_art = (int)artificial_rows.size();
+    const int n = n_art + n_p;
+
+    std::vector<int> col_start(n + 1, 0), row_index;
+    std::vector<double> value;
+    for (int k = 0; k < n_art; ++k) {
+        row_index.push_back(artificial_rows[k]);
+        value.push_back(1.0);
+        col_start[k + 1] = (int)row_index.size();
+    }
+    for (int j = 0; j < n_p; ++j) {
+        SparseColumn c = md.column(j);
+        for (size_t e = 0; e < c.nnz(); ++e) {
+            row_index.push_back(c.index[e]);
+            value.push_back(c.value[e].to_double());
+        }
+        col_start[n_art + j + 1] = (int)row_index.size();
+    }
+    const size_t nnz = row_index.size();
+    std::vector<int> row_start(m + 1, 0), col_index(nnz);
+    std::vector<double> row_value(nnz);
+    for (size_t e = 0; e < nnz; ++e) row_start[row_index[e] + 1]++;
+    for (int i = 0; i < m; ++i) row_start[i + 1] += row_start[i];
+    {
+        std::vector<int> fill(row_start.begin(), row_start.end() - 1);
+        for (int j = 0; j < n; ++j)
+            for (int e = col_start[j]; e < col_start[j + 1]; ++e) {
+                int dst = fill[row_index[e]]++;
+                col_index[dst] = j;
+                row_value[dst] = value[e];
+            }
+    }
+    std::vector<double> cost1(n, 0.0), cost2(n, 0.0), rhs(m);
+    for (int k = 0; k < n_art; ++k) cost1[k] = 1.0;  // artificial::Cost::One (kind/artificial/partially.rs:42-50)
+    for (int j = 0; j < n_p; ++j) cost2[n_art + j] = md.cost_value(j).to_double();
+    auto rhs_exact = md.right_hand_side();
+    for (int i = 0; i < m; ++i) rhs[i] = rhs_exact[i].to_double();
+
+    d_.m = m;
+    d_.n = n;
+    d_.n_art = n_art;
+    d_.ld = m;
+    rows_per_chunk_ = 16;
+    update_chunks_ = (m + rows_per_chunk_ - 1) / rows_per_chunk_;
+    price_blocks_ = std::max(1, std::min(2048, (n - n_art + 255) / 256));
+    price_lds_ = (size_t)3 * m * sizeof(double);
+
+    d_.col_start = dmalloc<int>(n + 1);
+    d_.row_index = dmalloc<int>(nnz);
+    d_.value = dmalloc<double>(nnz);
+    d_.row_start = dmalloc<int>(m + 1);
+    d_.col_index = dmalloc<int>(nnz);
+    d_.row_value = dmalloc<double>(nnz);
+    d_.cost = dmalloc<double>(n);
+    d_.cost1 = dmalloc<double>(n);
+    d_.cost2 = dmalloc<double>(n);
+    d_.rhs = dmalloc<double>(m);
+    d_.xB = dmalloc<double>(m);
+    d_.minus_pi = dmalloc<double>(m);
+    d_.basis = dmalloc<int>(m);
+    d_.pos = dmalloc<int>(n);
+    d_.gamma = dmalloc<double>(n);
+    d_.Binv = dmalloc<double>((size_t)m * d_.ld);
+    d_.Binv2 = dmalloc<double>((size_t)m * d_.ld);
+    d_.R = dmalloc<double>((size_t)m * d_.ld);
+    d_.alpha = dmalloc<double>(m);
+    d_.rho = dmalloc<double>(m);
+    d_.wpart = dmalloc<double>((size_t)update_chunks_ * m);
+    d_.w = dmalloc<double>(m);
+    d_.cand_key = dmalloc<double>(price_blocks_);
+    d_.cand_j = dmalloc<int>(price_blocks_);
+    d_.cand_cbar = dmalloc<double>(price_blocks_);
+    d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 2 + 16);
+    d_.ctl = dmalloc<Ctl>(1);
+
+    upload_vec(d_.col_start, col_start, stream_);
+    upload_vec(d_.row_index, row_index, stream_);
+    upload_vec(d_.value, value, stream_);
+    upload_vec(d_.row_start, row_start, stream_);
+    upload_vec(d_.col_index, col_index, stream_);
+    upload_vec(d_.row_value, row_value, stream_);
+    upload_vec(d_.cost1, cost1, stream_);
+    upload_vec(d_.cost2, cost2, stream_);
+    upload_vec(d_.rhs, rhs, stream_);
+    RELP_HIP(hipMemsetAsync(d_.rho, 0, m * sizeof(double), stream_));
+    RELP_HIP(hipMemsetAsync(d_.w, 0, m * sizeof(double), stream_));
+    RELP_HIP(hipMemsetAsync(d_.alpha, 0, m * sizeof(double), stream_));
+    RELP_HIP(hipMemsetAsync(d_.gamma, 0, n * sizeof(double), stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    if (price_lds_ <= 160 * 1024 - 1024) configure_price_lds(price_lds_);
+
+    stats_.price_bytes = (long long)(nnz - n_art) * 12 + (long long)(n - n_art) * 24;
+    stats_.update_bytes = (long long)2 * m * m * 8;
+    h_basis_.assign(m, -1);
+    h_solution_.assign(n_p, 0.0);
+}
+
+Ctl Solver::read_ctl() {
+    Ctl c;
+    RELP_HIP(hipMemcpyAsync(&c, d_.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    return c;
+}
+void Solver::write_ctl(const Ctl& c) {
+    RELP_HIP(hipMemcpyAsync(d_.ctl, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+}
+
+// `Tableau::<_, Partially<_>>::new` + `Carry::create_for_partially_artificial` (partially.rs:125-205, carry/mod.rs:397-442):
+// B = I, basis = artificial k on its row / free slack pivot on the others, b = rhs.
+void Solver::begin_phase_one() {
+    if (!loaded_) throw std::runtime_error("no LP loaded");
+    RELP_HIP(hipSetDevice(opt_.device));
+    const MatrixData& md = form_.data;
+    const int m = d_.m, n = d_.n, n_art = d_.n_art;
+    std::vector<int> basis(m), pos(n, -1);
+    auto pivots = md.pivot_element_indices();
+    std::vector<int> real_column_of_row(m, -1);
+    for (auto& [row, column] : pivots) real_column_of_row[row] = column;
+    int k = 0;
+    for (int i = 0; i < m; ++i) {
+        basis[i] = real_column_of_row[i] < 0 ? k++ : n_art + real_column_of_row[i];
+        pos[basis[i]] = i;
+    }
+    upload_vec(d_.basis, basis, stream_);
+    upload_vec(d_.pos, pos, stream_);
+    RELP_HIP(hipMemcpyAsync(d_.xB, d_.rhs, m * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    launch_identity(d_.Binv, m, d_.ld, stream_);
+    binv_identity_ = true;
+    Ctl c{};
+    c.forced_q = c.forced_p = -1;
+    c.last_selected = -1;
+    c.scan_column = std::numeric_limits<int>::max();
+    write_ctl(c);
+    pivots_[0] = pivots_[1] = 0;
+    polishes_ = 0;
+    max_residual_ = 0.0;
+    since_polish_ = 0;
+    redundant_rows_.clear();
+    set_phase(n_art > 0 ? 1 : 2);
+}
+
+// `Tableau::from_artificial` (non_artificial.rs:99-120): same basis, provider costs; -pi, -obj and the weights are
+// recomputed from the resident inverse (carry/mod.rs:499-525; pivot_rule.rs:202-219).
+void Solver::begin_phase_two() { set_phase(2); }
+
+void Solver::set_phase(int phase) {
+    phase_ = phase;
+    RELP_HIP(hipMemcpyAsync(d_.cost, phase == 1 ? d_.cost1 : d_.cost2, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    launch_pi(d_, stream_);
+    if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE) launch_gamma_init(d_, binv_identity_ ? 1 : 0, stream_);
+    Ctl c = read_ctl();
+    double minus_obj = c.minus_obj;
+    c = Ctl{};
+    c.minus_obj = minus_obj;
+    c.forced_q = c.forced_p = -1;
+    c.last_selected = -1;
+    c.scan_column = std::numeric_limits<int>::max();
+    write_ctl(c);
+}
+
+// One batch of `count` iterations of the loop of phase_one.rs:134-178 / phase_two.rs:36-58.
+void Solver::launch_pivots(int count) {
+    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
+    const int skip_art = phase_ == 2 ? 1 : 0;
+    launch_budget(d_, count, stream_);
+    for (int it = 0; it < count; ++it) {
+        launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, update_chunks_, stream_);
+        launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, skip_art, 0, stream_);
+        launch_update(d_, rows_per_chunk_, update_chunks_, stream_);
+    }
+    stats_.launches += 1 + 4LL * count;
+    stats_.price_launches += count;
+}
+
+void Solver::build_graph(int count) {
+    if (graph_exec_ && graph_count_ == count && graph_phase_ == phase_) return;
+    if (graph_exec_) { hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    if (graph_) { hipGraphDestroy(graph_); graph_ = nullptr; }
+    long long launches = stats_.launches, price_launches = stats_.price_launches;
+    RELP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    launch_pivots(count);
+    RELP_HIP(hipStreamEndCapture(stream_, &graph_));
+    RELP_HIP(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
+    stats_.launches = launches;
+    stats_.price_launches = price_launches;
+    graph_count_ = count;
+    graph_phase_ = phase_;
+}
+
+// Newton-Schulz polish (see kernels.hip).  Two iterations at most; the residual before the polish is recorded.
+void Solver::polish(bool refresh_vectors) {
+    const int m = d_.m;
+    for (int it = 0; it < 2; ++it) {
+        RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
+        launch_residual(d_, d_.Binv, d_.R, stream_);
+        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, stream_);
+        RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+        Ctl c = read_ctl();
+        if (it == 0) max_residual_ = std::max(max_residual_, c.residual);
+        if (!(c.residual == c.residual)) throw std::runtime_error("NaN in basis inverse");
+        if (c.residual < 1e-8) break;
+        if (c.residual >= 0.5) {  // drifted too far for the quadratic iteration: rebuild from the basis columns
+            invert_from_scratch();
+            break;
+        }
+    }
+    binv_identity_ = false;
+    polishes_++;
+    since_polish_ = 0;
+    if (refresh_vectors) {
+        Ctl before = read_ctl();
+        launch_xb(d_, stream_);
+        launch_pi(d_, stream_);
+        Ctl after = read_ctl();  // pi_kernel rewrote minus_obj from the refreshed xB
+        (void)before;
+        (void)after;
+    }
+}
+
+// From-scratch inverse by Newton-Schulz from X0 = B' / (|B|_1 |B|_inf) (converges for every nonsingular B).
+// Plays the role of `BasisInverse::invert` (lower_upper/mod.rs:78-92) for `from_basis` / warm starts.
+void Solver::invert_from_scratch() {
+    const int m = d_.m;
+    std::vector<int> basis(m);
+    RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, m * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    const MatrixData& md = form_.data;
+    std::vector<double> row_sum(m, 0.0);
+    double norm1 = 0.0;
+    for (int k = 0; k < m; ++k) {
+        double col_sum = 0.0;
+        if (basis[k] < d_.n_art) {
+            col_sum = 1.0;  // identity column; its row is found below through pos/CSR, the bound is enough here
+        } else {
+            SparseColumn c = md.column(basis[k] - d_.n_art);
+            for (size_t e = 0; e < c.nnz(); ++e) {
+                double v = std::fabs(c.value[e].to_double());
+                col_sum += v;
+                row_sum[c.index[e]] += v;
+            }
+        }
+        norm1 = std::max(norm1, col_sum);
+    }
+    double norm_inf = 1.0;
+    for (double v : row_sum) norm_inf = std::max(norm_inf, v);
+    launch_transpose_basis(d_, d_.Binv, 1.0 / (norm1 * norm_inf), stream_);
+    double previous = std::numeric_limits<double>::infinity();
+    for (int it = 0; it < 200; ++it) {
+        RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
+        launch_residual(d_, d_.Binv, d_.R, stream_);
+        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, stream_);
+        RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+        Ctl c = read_ctl();
+        if (c.residual < 1e-11) break;
+        if (it > 60 && c.residual >= previous) break;
+        previous = c.residual;
+    }
+    binv_identity_ = false;
+}
+
+// `InverseMaintainer::from_basis` (carry/mod.rs:444-478) + `Tableau::new_with_inverse_maintainer`: phase two from a given basis.
+void Solver::set_basis(const int* basis_columns) {
+    if (!loaded_) throw std::runtime_error("no LP loaded");
+    RELP_HIP(hipSetDevice(opt_.device));
+    const int m = d_.m, n = d_.n;
+    std::vector<int> basis(m), pos(n, -1);
+    for (int i = 0; i < m; ++i) {
+        int c = basis_columns[i];
+        int dev = c >= 0 ? d_.n_art + c : (-1 - c);
+        if (dev < 0 || dev >= n || pos[dev] >= 0) throw std::invalid_argument("bad basis");
+        basis[i] = dev;
+        pos[dev] = i;
+    }
+    upload_vec(d_.basis, basis, stream_);
+    upload_vec(d_.pos, pos, stream_);
+    Ctl c{};
+    c.forced_q = c.forced_p = -1;
+    c.last_selected = -1;
+    c.scan_column = std::numeric_limits<int>::max();
+    write_ctl(c);
+    invert_from_scratch();
+    launch_xb(d_, stream_);
+    pivots_[0] = pivots_[1] = 0;
+    polishes_ = 0;
+    max_residual_ = 0.0;
+    since_polish_ = 0;
+    redundant_rows_.clear();
+    set_phase(2);
+}
+
+long long Solver::iterate(long long count, int* stop_reason) {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    RELP_HIP(hipSetDevice(opt_.device));
+    long long done = 0;
+    int reason = ST_BUDGET;
+    while (done < count) {
+        long long room = opt_.polish_period > 0 ? opt_.polish_period - since_polish_ : count;
+        if (room <= 0) { polish(true); continue; }
+        int batch = (int)std::min<long long>({count - done, room, (long long)std::max(1, opt_.pivots_per_launch)});
+        Ctl before = read_ctl();
+        if (opt_.use_graph && batch == opt_.pivots_per_launch) {
+            build_graph(batch);
+            RELP_HIP(hipGraphLaunch(graph_exec_, stream_));
+            stats_.launches += 1 + 4LL * batch;
+            stats_.price_launches += batch;
+        } else {
+            launch_pivots(batch);
+        }
+        Ctl after = read_ctl();
+        long long made = after.iters - before.iters;
+        done += made;
+        since_polish_ += made;
+        pivots_[phase_ - 1] += made;
+        if (after.status == ST_NO_ENTERING || after.status == ST_UNBOUNDED) { reason = after.status; break; }
+        if (made == 0 && after.status == ST_RUNNING) break;  // defensive: nothing happened
+    }
+    if (stop_reason) *stop_reason = reason;
+    return done;
+}
+
+// phase_one.rs:232-278.  Returns the number of redundant rows (artificials that cannot be pivoted out).
+int Solver::drive_out_artificials() {
+    const int m = d_.m;
+    std::vector<int> basis(m);
+    RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, m * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    int redundant = 0;
+    for (int r = 0; r < m; ++r) {
+        if (basis[r] >= d_.n_art) continue;
+        Ctl c = read_ctl();
+        c.scan_column = std::numeric_limits<int>::max();
+        write_ctl(c);
+        launch_row_scan(d_, r, 1e-7, stream_);
+        c = read_ctl();
+        if (c.scan_column == std::numeric_limits<int>::max()) {
+            redundant_rows_.push_back(r);
+            ++redundant;
+            continue;
+        }
+        c.forced_q = c.scan_column;
+        c.forced_p = r;
+        c.status = ST_RUNNING;
+        write_ctl(c);
+        launch_pivots(1);
+        Ctl after = read_ctl();
+        if (after.iters == c.iters) throw std::runtime_error("zero-level pivot failed");
+        pivots_[0] += 1;
+        since_polish_ += 1;
+    }
+    return redundant;
+}
+
+void Solver::solve(relp_result* result) {
+    if (!loaded_) throw std::runtime_error("no LP loaded");
+    RELP_HIP(hipSetDevice(opt_.device));
+    const double t0 = now_seconds();
+    relp_result res{};
+    exact_objective.clear();
+    begin_phase_one();
+    const long long cap = opt_.max_pivots > 0 ? opt_.max_pivots : (1LL << 40);
+    int kind = RELP_RESULT_NONE;
+    if (phase_ == 1) {
+        int reason = 0;
+        long long done = iterate(cap, &reason);
+        (void)done;
+        if (reason == ST_UNBOUNDED) throw std::runtime_error("Artificial cost can not be unbounded.");  // phase_one.rs:151
+        if (reason == ST_BUDGET) kind = RELP_RESULT_ITERATION_LIMIT;
+        if (kind == RELP_RESULT_NONE) {
+            polish(true);
+            Ctl c = read_ctl();
+            std::vector<double> xb(d_.m);
+            RELP_HIP(hipMemcpy(xb.data(), d_.xB, d_.m * sizeof(double), hipMemcpyDeviceToHost));
+            double scale = 1.0;
+            for (double v : xb) scale += std::fabs(v);
+            if (-c.minus_obj > opt_.tol_feasible * scale) {
+                kind = RELP_RESULT_INFEASIBLE;  // phase_one.rs:171-173
+            } else {
+                drive_out_artificials();
+                set_phase(2);
+            }
+        }
+    }
+    if (kind == RELP_RESULT_NONE) {
+        int reason = 0;
+        iterate(cap - pivots_[0], &reason);
+        if (reason == ST_UNBOUNDED) kind = RELP_RESULT_UNBOUNDED;  // phase_two.rs:53
+        else if (reason == ST_NO_ENTERING) {
+            kind = RELP_RESULT_FINITE_OPTIMUM;
+            polish(true);
+        } else kind = RELP_RESULT_ITERATION_LIMIT;
+    }
+    // results: Carry::current_bfs (carry/mod.rs:636-645) + reconstruct_solution (matrix_data.rs:402-411)
+    const int m = d_.m;
+    std::vector<int> basis(m);
+    std::vector<double> xb(m);
+    RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, m * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipMemcpyAsync(xb.data(), d_.xB, m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    Ctl c = read_ctl();
+    std::fill(h_solution_.begin(), h_solution_.end(), 0.0);
+    for (int i = 0; i < m; ++i) {
+        h_basis_[i] = basis[i] >= d_.n_art ? basis[i] - d_.n_art : -1 - basis[i];
+        if (basis[i] >= d_.n_art) h_solution_[basis[i] - d_.n_art] = xb[i];
+    }
+    res.kind = kind;
+    res.pivots_phase_one = pivots_[0];
+    res.pivots_phase_two = pivots_[1];
+    res.polishes = polishes_;
+    res.max_residual = max_residual_;
+    res.objective = (kind == RELP_RESULT_FINITE_OPTIMUM) ? -c.minus_obj + form_.fixed_cost.to_double()
+                                                         : std::numeric_limits<double>::quiet_NaN();
+    res.solve_seconds = now_seconds() - t0;
+    if (kind == RELP_RESULT_FINITE_OPTIMUM && opt_.certify) certify(&res);
+    last_result = res;
+    if (result) *result = res;
+}
+
+void Solver::certify(relp_result* result) {
+    const double t0 = now_seconds();
+    bool ok = false;
+    long long repairs = 0;
+    std::string message;
+    certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message);
+    result->certified = ok ? 1 : 0;
+    result->exact_repair_pivots = repairs;
+    result->certify_seconds = now_seconds() - t0;
+    if (!ok) last_error = message;
+}
+
+// ---- fine-grained ops -------------------------------------------------------------------------------
+void Solver::ftran(int nnz, const int* rows, const double* values, double* out) {
+    int* d_rows = reinterpret_cast<int*>(d_.scratch);
+    double* d_vals = d_.scratch + (d_.m + 1) / 2 + 1;
+    double* d_out = d_vals + d_.m;
+    if (nnz > d_.m) throw std::invalid_argument("nnz > m");
+    RELP_HIP(hipMemcpyAsync(d_rows, rows, nnz * sizeof(int), hipMemcpyHostToDevice, stream_));
+    RELP_HIP(hipMemcpyAsync(d_vals, values, nnz * sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_ftran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
+    RELP_HIP(hipMemcpyAsync(out, d_out, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+}
+void Solver::btran(int nnz, const int* rows, const double* values, double* out) {
+    int* d_rows = reinterpret_cast<int*>(d_.scratch);
+    double* d_vals = d_.scratch + (d_.m + 1) / 2 + 1;
+    double* d_out = d_vals + d_.m;
+    if (nnz > d_.m) throw std::invalid_argument("nnz > m");
+    RELP_HIP(hipMemcpyAsync(d_rows, rows, nnz * sizeof(int), hipMemcpyHostToDevice, stream_));
+    RELP_HIP(hipMemcpyAsync(d_vals, values, nnz * sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_btran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
+    RELP_HIP(hipMemcpyAsync(out, d_out, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+}
+void Solver::inverse_row(int row, double* out) {
+    if (row < 0 || row >= d_.m) throw std::invalid_argument("row out of range");
+    RELP_HIP(hipMemcpyAsync(out, d_.Binv + (size_t)row * d_.ld, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+}
+void Solver::relative_costs(double* out) {
+    launch_relative_cost(d_, d_.scratch, stream_);
+    RELP_HIP(hipMemcpyAsync(out, d_.scratch, d_.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+}
+void Solver::get_gamma(double* out) {
+    // apply a pending weight update first so that the values are those the next pricing pass would use
+    std::vector<int> pos(d_.n);
+    RELP_HIP(hipMemcpyAsync(out, d_.gamma, d_.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipMemcpyAsync(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    for (int j = 0; j < d_.n; ++j)
+        if (j < d_.n_art || pos[j] >= 0) out[j] = std::numeric_limits<double>::quiet_NaN();
+}
+// `PivotRule::select_primal_pivot_column`: the pricing kernel, then the entering-column reduction of the fused kernel
+// (mode 1: stop after the choice).  Applies a pending steepest-edge update exactly like the device loop does.
+void Solver::price(int* column, double* cbar) {
+    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
+    Ctl c = read_ctl();
+    const int saved = c.status;
+    c.status = ST_RUNNING;
+    c.forced_q = c.forced_p = -1;
+    write_ctl(c);
+    launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, update_chunks_, stream_);
+    launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 1, stream_);
+    c = read_ctl();
+    *column = c.q;
+    *cbar = c.q >= 0 ? c.cbar_q : 0.0;
+    c.status = saved;
+    write_ctl(c);
+}
+// `Tableau::generate_column` + `select_primal_pivot_row` without a basis change: the fused kernel in mode 2.
+void Solver::ratio(int column, int* row, double* alpha_out) {
+    if (column < 0 || column >= d_.n) throw std::invalid_argument("column out of range");
+    Ctl c = read_ctl();
+    const int saved = c.status;
+    const int saved_pending = c.pending;
+    c.status = ST_RUNNING;
+    c.forced_q = column;
+    c.forced_p = -1;
+    write_ctl(c);
+    launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 2, stream_);
+    c = read_ctl();
+    *row = c.p;
+    if (alpha_out) {
+        RELP_HIP(hipMemcpyAsync(alpha_out, d_.alpha, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
+    c.status = saved;
+    c.pending = saved_pending;
+    c.forced_q = c.forced_p = -1;
+    write_ctl(c);
+}
+// Average duration of one launch of a hot-loop kernel (HIP events on this handle's stream; bench.py's roofline leg).
+double Solver::profile_kernel(int which, int repetitions) {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    RELP_HIP(hipSetDevice(opt_.device));
+    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
+    const int m = d_.m;
+    Ctl saved = read_ctl();
+    Ctl c = saved;
+    c.status = ST_RUNNING;
+    c.pending = 1;
+    if (c.alpha_pq == 0.0) c.alpha_pq = 1.0;
+    if (c.q < d_.n_art || c.q >= d_.n) c.q = d_.n_art;
+    c.forced_q = c.q;
+    c.forced_p = -1;
+    write_ctl(c);
+    // keep the state the kernels overwrite
+    RELP_HIP(hipMemcpyAsync(d_.scratch, d_.gamma, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    RELP_HIP(hipMemcpyAsync(d_.Binv2, d_.Binv, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    auto launch = [&] {
+        if (which == 0) launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, update_chunks_, stream_);
+        else if (which == 1) launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, 0, 2, stream_);
+        else launch_update(d_, rows_per_chunk_, update_chunks_, stream_);
+    };
+    for (int k = 0; k < 3; ++k) {
+        if (which == 1) write_ctl(c);
+        launch();
+    }
+    RELP_HIP(hipStreamSynchronize(stream_));
+    double total_ms = 0.0;
+    if (which == 1) {
+        // the dry-run kernel clears the forced column, so time launches one by one
+        for (int k = 0; k < repetitions; ++k) {
+            write_ctl(c);
+            RELP_HIP(hipEventRecord(ev_a_, stream_));
+            launch();
+            RELP_HIP(hipEventRecord(ev_b_, stream_));
+            RELP_HIP(hipEventSynchronize(ev_b_));
+            float ms = 0.f;
+            RELP_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+            total_ms += ms;
+        }
+    } else {
+        RELP_HIP(hipEventRecord(ev_a_, stream_));
+        for (int k = 0; k < repetitions; ++k) launch();
+        RELP_HIP(hipEventRecord(ev_b_, stream_));
+        RELP_HIP(hipEventSynchronize(ev_b_));
+        float ms = 0.f;
+        RELP_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+        total_ms = ms;
+    }
+    RELP_HIP(hipMemcpyAsync(d_.gamma, d_.scratch, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    write_ctl(saved);
+    return total_ms * 1e-3 / repetitions;
+}
+
+void Solver::get_b(double* out) {
+    RELP_HIP(hipMemcpyAsync(out, d_.xB, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+}
+double Solver::objective() { return -read_ctl().minus_obj; }
+void Solver::get_basis(int* out) {
+    std::vector<int> basis(d_.m);
+    RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, d_.m * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < d_.m; ++i) out[i] = basis[i] >= d_.n_art ? basis[i] - d_.n_art : -1 - basis[i];
+}
+void Solver::get_solution(double* x) const {
+    const int n_struct = form_.data.nr_normal_variables();
+    for (int j = 0; j < n_struct; ++j) x[j] = h_solution_[j];
+}
+
+}  // namespace relp

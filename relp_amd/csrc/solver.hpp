@@ -1,0 +1,165 @@
+// Device-resident two-phase revised simplex for one LP: host-side class (one handle = one stream on one GPU).
+//
+// Mirrors the reference's `Tableau<Carry<F, BI>, Kind>` + `PivotRule` state (tableau/mod.rs:25-39,
+// carry/mod.rs:46-66, strategy/pivot_rule.rs:190-193) but keeps every array in HBM for the whole solve:
+// the host only enqueues kernels and polls a control word once per `pivots_per_launch` pivots.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/relp_amd.h"
+#include "model.hpp"
+
+namespace relp {
+
+// Device control block, written by single-workgroup kernels, polled by the host.
+struct Ctl {
+    int status;        // 0 running | 1 no entering column | 2 unbounded (ratio test empty) | 3 iteration budget used
+    int q;             // entering column (device index space: artificials first)
+    int p;             // pivot row
+    int leaving;       // column that left the basis at row p
+    int pending;       // 1: the steepest-edge update of the last pivot is applied by the next pricing pass
+    int forced_q;      // >= 0: next iteration must enter this column ...
+    int forced_p;      //       ... at this row (zero-level pivots of phase_one.rs:232-278)
+    int last_selected; // FirstProfitableWithMemory (pivot_rule.rs:113-150)
+    long long iters;   // pivots done in the current phase
+    long long budget;  // stop when iters reaches this
+    double cbar_q;
+    double alpha_pq;
+    double gamma_q;
+    double xp;
+    double minus_obj;  // carry/mod.rs `minus_objective`
+    double residual;   // max |I - B Binv| written by the polish
+    double scan_value;
+    int scan_column;
+    int pad;
+};
+
+enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3 };
+
+struct DeviceLP {
+    int m = 0, n = 0, n_art = 0, ld = 0;
+    // CSC of [artificial identity columns | provider columns] (matrix_data.rs:291-329 materialised once)
+    int* col_start = nullptr;
+    int* row_index = nullptr;
+    double* value = nullptr;
+    // CSR of the same matrix (for the residual I - B Binv)
+    int* row_start = nullptr;
+    int* col_index = nullptr;
+    double* row_value = nullptr;
+    double* cost = nullptr;      // current phase (n)
+    double* cost1 = nullptr;     // phase one: 1 on artificials
+    double* cost2 = nullptr;     // phase two: provider costs
+    double* rhs = nullptr;       // right_hand_side() (m)
+    double* xB = nullptr;        // Carry::b (m)
+    double* minus_pi = nullptr;  // Carry::minus_pi (m)
+    int* basis = nullptr;        // Carry::basis_indices (m)
+    int* pos = nullptr;          // column -> row or -1 (the Tableau's basis_columns set) (n)
+    double* gamma = nullptr;     // steepest-edge weights (n)
+    double* Binv = nullptr;      // explicit basis inverse, row-major m x ld
+    double* Binv2 = nullptr;     // second buffer for the polish
+    double* R = nullptr;         // residual I - B Binv
+    double* alpha = nullptr;     // B^-1 a_q (m)
+    double* rho = nullptr;       // row p of the NEW inverse (m)
+    double* wpart = nullptr;     // partial sums of w = alpha' Binv_old, [n_chunks][m]
+    double* w = nullptr;         // reduced (m)
+    double* cand_key = nullptr;  // per pricing block
+    int* cand_j = nullptr;
+    double* cand_cbar = nullptr;
+    double* scratch = nullptr;   // m or n doubles for the fine-grained ops
+    Ctl* ctl = nullptr;
+};
+
+class Solver {
+public:
+    explicit Solver(const relp_options& options);
+    ~Solver();
+
+    void load(StandardForm&& form);
+    bool loaded() const { return loaded_; }
+
+    void solve(relp_result* result);
+    void begin_phase_one();
+    void begin_phase_two();
+    void set_basis(const int* basis_columns);
+    long long iterate(long long count, int* stop_reason);
+
+    // fine-grained ops (trait parity)
+    void ftran(int nnz, const int* rows, const double* values, double* out);
+    void btran(int nnz, const int* rows, const double* values, double* out);
+    void inverse_row(int row, double* out);
+    void price(int* column, double* cbar);
+    void relative_costs(double* out);
+    void get_gamma(double* out);
+    void ratio(int column, int* row, double* alpha_out);
+    void get_b(double* out);
+    double objective();
+    void get_basis(int* out);
+    void get_solution(double* x) const;
+    double profile_kernel(int which, int repetitions);
+
+    const StandardForm& form() const { return form_; }
+    const DeviceLP& device() const { return d_; }
+    const relp_stats& stats() const { return stats_; }
+    void reset_stats();
+    int n_art() const { return d_.n_art; }
+    std::string exact_objective;  // filled by certify()
+    std::string last_error;
+    relp_result last_result{};
+
+private:
+    void upload();
+    void free_device();
+    void set_phase(int phase);
+    void launch_pivots(int count);
+    void build_graph(int count);
+    void polish(bool refresh_vectors);
+    void invert_from_scratch();
+    Ctl read_ctl();
+    void write_ctl(const Ctl& c);
+    int drive_out_artificials();
+    void certify(relp_result* result);
+
+    relp_options opt_;
+    StandardForm form_;
+    DeviceLP d_;
+    bool loaded_ = false;
+    bool binv_identity_ = true;
+    int phase_ = 0;
+    int price_blocks_ = 0;
+    int update_chunks_ = 0;
+    int rows_per_chunk_ = 16;
+    size_t price_lds_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t graph_exec_ = nullptr;
+    int graph_count_ = 0;
+    int graph_phase_ = -1;
+    hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
+    relp_stats stats_{};
+    std::vector<double> h_solution_;
+    std::vector<int> h_basis_;
+    std::vector<int> redundant_rows_;
+    long long pivots_[2] = {0, 0};
+    long long polishes_ = 0;
+    double max_residual_ = 0.0;
+    long long since_polish_ = 0;
+
+    friend struct SolverAccess;
+};
+
+struct DeviceError : std::runtime_error {
+    explicit DeviceError(const std::string& what) : std::runtime_error(what) {}
+};
+
+#define RELP_HIP(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t err__ = (call);                                                                       \
+        if (err__ != hipSuccess)                                                                         \
+            throw ::relp::DeviceError(std::string(#call) + ": " + hipGetErrorString(err__));             \
+    } while (0)
+
+}  // namespace relp
