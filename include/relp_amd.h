@@ -190,6 +190,9 @@ int32_t relp_reset_stats(relp_handle* handle);
  * which: 0 pricing pass (with the steepest-edge update) | 1 ftran+ratio | 2 inverse update (+ w partials). */
 int32_t relp_profile_kernel(relp_handle* handle, int32_t which, int32_t repetitions, double* seconds_per_launch);
 
+/* Diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of the fused kernel; zeros otherwise. */
+int32_t relp_debug_stamps(relp_handle* handle, uint64_t* out64);
+
 /* Version / build info ("relp_amd <ver> gfx950"). */
 const char* relp_version(void);
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librelp_amd.so")
+LIB_PATH = os.environ.get("RELP_AMD_LIB", os.path.join(_HERE, "librelp_amd.so"))  # override: diagnostic builds only
 
 OK, ERR_ARGUMENT, ERR_PARSE, ERR_DEVICE, ERR_OVERFLOW, ERR_STATE, ERR_NUMERICAL = range(7)
 FINITE_OPTIMUM, INFEASIBLE, UNBOUNDED, ITERATION_LIMIT = 1, 2, 3, 4
@@ -57,7 +57,7 @@ SYMBOLS = [
     "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
     "relp_get_gamma", "relp_ratio", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
-    "relp_reset_stats", "relp_profile_kernel",
+    "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps",
 ]
 
 
@@ -327,6 +327,11 @@ class Solver:
         stats = Stats()
         self._check(lib().relp_get_stats(self._h, C.byref(stats)))
         return stats
+
+    def debug_stamps(self):
+        out = np.zeros(64, dtype=np.uint64)
+        self._check(lib().relp_debug_stamps(self._h, _ptr(out, C.c_uint64)))
+        return out
 
     def profile_kernel(self, which, repetitions):
         """Average duration (seconds) of one launch of kernel ``which`` (0 price, 1 ftran+ratio (dry), 2 update)

@@ -53,7 +53,7 @@ int32_t relp_options_default(relp_options* o) {
     std::memset(o, 0, sizeof(*o));
     o->device = 0;
     o->pivot_rule = RELP_PIVOT_STEEPEST_EDGE;  // two_phase/mod.rs:57,68,107
-    o->polish_period = 64;
+    o->polish_period = 128;
     o->pivots_per_launch = 32;
     o->max_pivots = 0;
     o->tol_dual = 1e-9;
@@ -455,6 +455,11 @@ int32_t relp_profile_kernel(relp_handle* h, int32_t which, int32_t repetitions, 
     REQUIRE_LOADED(h);
     if (!seconds || repetitions < 1 || which < 0 || which > 2) return RELP_ERR_ARGUMENT;
     return guarded(h, [&] { *seconds = h->solver->profile_kernel(which, repetitions); });
+}
+int32_t relp_debug_stamps(relp_handle* h, uint64_t* out64) {
+    REQUIRE_LOADED(h);
+    if (!out64) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] { h->solver->debug_stamps(reinterpret_cast<unsigned long long*>(out64)); });
 }
 int32_t relp_reset_stats(relp_handle* h) {
     if (!h || !h->solver) return RELP_ERR_ARGUMENT;

@@ -1,8 +1,14 @@
 // HIP kernels of the revised-simplex inner loop for gfx950 (wave64, 256 CUs in 8 XCDs, 160 KB LDS per CU).
 //
-// One pivot = price -> ftran+ratio(+O(m) updates) -> inverse update (+ partial w) -> w reduce.
+// One pivot = K1 price (+steepest-edge update) -> K2 entering column / FTRAN / ratio test / x_B update
+//           -> K3 inverse update fused with w, rho_p and the -pi update.
 // All state stays in HBM / L2; every kernel starts by reading the control word, so that a launch sequence
 // enqueued past the end of a phase degenerates into no-ops (no host round trip per pivot).
+//
+// Layout of the explicit inverse: COLUMN-major.  `T[j*ld + i] = Binv(i, j)`.  With it
+//   * FTRAN  alpha = sum_k v_k Binv(:, r_k)          reads nnz(a_q) contiguous columns      (K2, coalesced)
+//   * the update of column j, w_j, rho_p[j], -pi_j   touch one contiguous column each       (K3, one wave per column)
+// so no kernel gathers with a stride (the row-major variant spent 20 us per pivot in strided FTRAN gathers).
 //
 // Reference functions each kernel replaces are cited at the kernel; paths relative to
 // /root/reference/src/algorithm/two_phase/.
@@ -16,8 +22,19 @@ namespace relp {
 
 constexpr int WAVE = 64;
 
+#ifdef RELP_STAMPS
+#define STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t__ = clock64(); lp.dbg[(k)] += t__ - t_prev__; t_prev__ = t__; } } while (0)
+#define STAMP_INIT unsigned long long t_prev__ = clock64(); if (threadIdx.x == 0) lp.dbg[63] += 1
+#else
+#define STAMP(k) do {} while (0)
+#define STAMP_INIT do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
-// reductions
+// reductions: wave64 DPP (data-parallel primitives) moves instead of ds_bpermute shuffles.  A __shfl_down chain is
+// six DEPENDENT LDS-crossbar round trips per value (measured: 3-4 k cycles per struct arg-max); the DPP sequence
+// quad_perm -> quad_perm -> row_ror:4 -> row_ror:8 -> row_bcast:15 -> row_bcast:31 runs at VALU speed and leaves the
+// result in lane 63.  Fixed combination order => deterministic results.
 // ---------------------------------------------------------------------------------------------------
 struct Cand {
     double key;
@@ -27,29 +44,78 @@ struct Cand {
 
 enum : int { TIE_LARGER_IDX = 0, TIE_SMALLER_IDX = 1, TIE_SMALLER_AUX = 2 };
 
+// Branch-free selection on scalar fields: keeps candidates in registers (a by-reference version put them in scratch
+// memory and cost 6-7 k cycles per block-wide arg-max).
 template <int TIE>
-__device__ __forceinline__ Cand better(const Cand& a, const Cand& b) {
-    if (a.idx < 0) return b;
-    if (b.idx < 0) return a;
-    if (a.key > b.key) return a;
-    if (a.key < b.key) return b;
-    if (TIE == TIE_LARGER_IDX) return a.idx > b.idx ? a : b;
-    if (TIE == TIE_SMALLER_IDX) return a.idx < b.idx ? a : b;
-    return a.aux < b.aux ? a : (a.aux > b.aux ? b : (a.idx < b.idx ? a : b));
+__device__ __forceinline__ Cand better(Cand a, Cand b) {
+    bool take_b;
+    if (TIE == TIE_LARGER_IDX) take_b = (b.key > a.key) | ((b.key == a.key) & (b.idx > a.idx));
+    else if (TIE == TIE_SMALLER_IDX) take_b = (b.key > a.key) | ((b.key == a.key) & (b.idx < a.idx));
+    else take_b = (b.key > a.key) | ((b.key == a.key) & ((b.aux < a.aux) | ((b.aux == a.aux) & (b.idx < a.idx))));
+    take_b = (a.idx < 0) | ((b.idx >= 0) & take_b);
+    Cand r;
+    r.key = take_b ? b.key : a.key;
+    r.idx = take_b ? b.idx : a.idx;
+    r.aux = take_b ? b.aux : a.aux;
+    return r;
 }
 
+constexpr int DPP_QUAD_1032 = 0xB1;    // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_2301 = 0x4E;    // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_ROR4 = 0x124;    // row_ror:4
+constexpr int DPP_ROW_ROR8 = 0x128;    // row_ror:8
+constexpr int DPP_ROW_BCAST15 = 0x142; // lane 15 of each row -> every lane of the next row
+constexpr int DPP_ROW_BCAST31 = 0x143; // lane 31 -> every lane of rows 2 and 3
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(old), __double2loint(v));
+    const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(old), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Cand dpp_cand(Cand v) {  // masked-off rows see their own value (idempotent op)
+    Cand o;
+    o.key = dpp_f64<CTRL, ROW_MASK>(v.key, v.key);
+    o.idx = dpp_i32<CTRL, ROW_MASK>(v.idx, v.idx);
+    o.aux = dpp_i32<CTRL, ROW_MASK>(v.aux, v.aux);
+    return o;
+}
+
+// result valid in lane 63
 template <int TIE>
 __device__ __forceinline__ Cand wave_best(Cand v) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) {
-        Cand o;
-        o.key = __shfl_down(v.key, off);
-        o.idx = __shfl_down(v.idx, off);
-        o.aux = __shfl_down(v.aux, off);
-        v = better<TIE>(v, o);
-    }
+    v = better<TIE>(v, dpp_cand<DPP_QUAD_1032, 0xF>(v));
+    v = better<TIE>(v, dpp_cand<DPP_QUAD_2301, 0xF>(v));
+    v = better<TIE>(v, dpp_cand<DPP_ROW_ROR4, 0xF>(v));
+    v = better<TIE>(v, dpp_cand<DPP_ROW_ROR8, 0xF>(v));
+    v = better<TIE>(v, dpp_cand<DPP_ROW_BCAST15, 0xA>(v));
+    v = better<TIE>(v, dpp_cand<DPP_ROW_BCAST31, 0xC>(v));
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) {  // lane 63
+    v += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, v);
+    v += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, v);
+    v += dpp_f64<DPP_ROW_ROR4, 0xF>(0.0, v);
+    v += dpp_f64<DPP_ROW_ROR8, 0xF>(0.0, v);
+    v += dpp_f64<DPP_ROW_BCAST15, 0xA>(0.0, v);
+    v += dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, v);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {  // lane 63
+    v = fmin(v, dpp_f64<DPP_QUAD_1032, 0xF>(v, v));
+    v = fmin(v, dpp_f64<DPP_QUAD_2301, 0xF>(v, v));
+    v = fmin(v, dpp_f64<DPP_ROW_ROR4, 0xF>(v, v));
+    v = fmin(v, dpp_f64<DPP_ROW_ROR8, 0xF>(v, v));
+    v = fmin(v, dpp_f64<DPP_ROW_BCAST15, 0xA>(v, v));
+    v = fmin(v, dpp_f64<DPP_ROW_BCAST31, 0xC>(v, v));
+    return v;
+}
+constexpr int LAST = WAVE - 1;
 
 // Block-wide argmax; result valid in every thread.  `s` holds at least blockDim.x/64 + 1 entries.
 template <int TIE>
@@ -59,30 +125,35 @@ __device__ __forceinline__ Cand block_best(Cand v, Cand* s) {
     const int nwaves = (blockDim.x + WAVE - 1) / WAVE;
     v = wave_best<TIE>(v);
     __syncthreads();
-    if (lane == 0) s[wave] = v;
+    if (lane == LAST) {
+        s[wave].key = v.key;
+        s[wave].idx = v.idx;
+        s[wave].aux = v.aux;
+    }
     __syncthreads();
     if (wave == 0) {
         Cand t;
         t.key = 0.0;
         t.idx = -1;
         t.aux = 0;
-        if (lane < nwaves) t = s[lane];
+        if (lane < nwaves) {
+            t.key = s[lane].key;
+            t.idx = s[lane].idx;
+            t.aux = s[lane].aux;
+        }
         t = wave_best<TIE>(t);
-        if (lane == 0) s[nwaves] = t;
+        if (lane == LAST) {
+            s[nwaves].key = t.key;
+            s[nwaves].idx = t.idx;
+            s[nwaves].aux = t.aux;
+        }
     }
     __syncthreads();
-    return s[nwaves];
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off));
-    return v;
+    Cand r;
+    r.key = s[nwaves].key;
+    r.idx = s[nwaves].idx;
+    r.aux = s[nwaves].aux;
+    return r;
 }
 
 // op: 0 sum, 1 min.  Deterministic order (fixed tree).  `s` holds blockDim.x/64 + 1 doubles.
@@ -93,13 +164,13 @@ __device__ __forceinline__ double block_reduce(double v, double* s) {
     const int nwaves = (blockDim.x + WAVE - 1) / WAVE;
     v = OP == 0 ? wave_sum(v) : wave_min(v);
     __syncthreads();
-    if (lane == 0) s[wave] = v;
+    if (lane == LAST) s[wave] = v;
     __syncthreads();
     if (wave == 0) {
         double t = OP == 0 ? 0.0 : INFINITY;
         if (lane < nwaves) t = s[lane];
         t = OP == 0 ? wave_sum(t) : wave_min(t);
-        if (lane == 0) s[nwaves] = t;
+        if (lane == LAST) s[nwaves] = t;
     }
     __syncthreads();
     return s[nwaves];
@@ -119,18 +190,23 @@ __global__ void budget_kernel(Ctl* ctl, long long add) {
 //             Tableau::relative_cost / Carry::cost_difference             tableau/mod.rs:106-112, carry/mod.rs:606-611
 //             SteepestDescentAlongObjective::after_basis_update            strategy/pivot_rule.rs:243-296
 //             MatrixData::column (no per-column clone)                     matrix_provider/matrix_data.rs:291-329
-// One thread per column (sparse CSC columns of ~5-10 entries); -pi, rho_p and w are staged in LDS once per
-// workgroup, so HBM/L2 traffic is the column data itself: nnz*(8+4) + 3*8 bytes per column.
+// LPC lanes share one sparse column (entries strided over the lanes, shuffle-reduced), so that the dependent
+// index -> LDS gather chain is 1-3 steps long whatever the column length; -pi, rho_p and w are staged in LDS once
+// per workgroup.  Traffic is the column data itself: nnz*(8+4) + 3*8 bytes per column.
 // The reference makes TWO passes over A per pivot (pricing, weight update) and clones every column twice.
 // ---------------------------------------------------------------------------------------------------
-template <int RULE, bool USE_LDS>
-__global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weights, double tol_dual, int n_chunks) {
+template <int RULE, bool USE_LDS, int LPC>
+__global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weights, double tol_dual) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[8];
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING) return;
     const int m = lp.m;
     const int pending = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? (ctl->pending && !skip_weights) : 0;
+    const double gamma_q = ctl->gamma_q;
+    const double alpha_pq = ctl->alpha_pq;
+    const int leaving = ctl->leaving;
+    const int last = ctl->last_selected;
     const double* v_pi = lp.minus_pi;
     const double* v_rho = lp.rho;
     const double* v_w = lp.w;
@@ -138,11 +214,23 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
         double* s_pi = smem;
         double* s_rho = smem + m;
         double* s_w = smem + 2 * m;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) {
-            s_pi[i] = lp.minus_pi[i];
-            if (pending) {
-                s_rho[i] = lp.rho[i];
-                s_w[i] = lp.w[i];
+        for (int base = threadIdx.x; base < m; base += 4 * 256) {
+            double t_pi[4], t_rho[4], t_w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 256;
+                t_pi[u] = i < m ? lp.minus_pi[i] : 0.0;
+                t_rho[u] = (pending && i < m) ? lp.rho[i] : 0.0;
+                t_w[u] = (pending && i < m) ? lp.w[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 256;
+                if (i < m) {
+                    s_pi[i] = t_pi[u];
+                    s_rho[i] = t_rho[u];
+                    s_w[i] = t_w[u];
+                }
             }
         }
         __syncthreads();
@@ -150,52 +238,64 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
         v_rho = s_rho;
         v_w = s_w;
     }
-    const double gamma_q = ctl->gamma_q;
-    const double alpha_pq = ctl->alpha_pq;
-    const int leaving = ctl->leaving;
-    const int last = ctl->last_selected;
+    constexpr int CPB = 256 / LPC;  // columns per workgroup pass
+    const int g = threadIdx.x / LPC, sub = threadIdx.x % LPC;
 
     Cand best;
     best.key = 0.0;
     best.idx = -1;
     best.aux = 0;
     double best_cbar = 0.0;
-    for (int j = lp.n_art + blockIdx.x * blockDim.x + threadIdx.x; j < lp.n; j += gridDim.x * blockDim.x) {
-        if (lp.pos[j] >= 0) continue;  // basic
-        const int a = lp.col_start[j], b = lp.col_start[j + 1];
+    for (int base = lp.n_art + blockIdx.x * CPB; base < lp.n; base += gridDim.x * CPB) {
+        const int j = base + g;
+        const bool valid = j < lp.n;
+        int a = 0, b = 0;
+        bool nonbasic = false;
+        double cost_j = 0.0, g_j = 1.0;
+        if (valid) {
+            nonbasic = lp.pos[j] < 0;
+            a = lp.col_start[j];
+            b = lp.col_start[j + 1];
+            cost_j = lp.cost[j];
+            if (RULE == RELP_PIVOT_STEEPEST_EDGE) g_j = lp.gamma[j];
+        }
+        if (!nonbasic) b = a;
         double d_pi = 0.0, d_rho = 0.0, d_w = 0.0;
-        if (pending) {
-            for (int e = a; e < b; ++e) {
-                const int r = lp.row_index[e];
-                const double v = lp.value[e];
-                d_pi += v * v_pi[r];
+        for (int e = a + sub; e < b; e += LPC) {
+            const int r = lp.row_index[e];
+            const double v = lp.value[e];
+            d_pi += v * v_pi[r];
+            if (pending) {
                 d_rho += v * v_rho[r];
                 d_w += v * v_w[r];
             }
-        } else {
-            for (int e = a; e < b; ++e) d_pi += lp.value[e] * v_pi[lp.row_index[e]];
         }
-        double g = 1.0;
-        if (RULE == RELP_PIVOT_STEEPEST_EDGE) {
-            g = lp.gamma[j];
-            if (pending) {
-                if (j == leaving) {
-                    g = gamma_q / (alpha_pq * alpha_pq);  // pivot_rule.rs:294-295
-                } else {
-                    // pivot_rule.rs:262-288 (Goldfarb-Reid)
-                    const double sq = d_rho * d_rho;
-                    g = g - 2.0 * d_rho * d_w + sq * gamma_q;
-                    g = fmax(g, 1.0 + sq);
-                }
-                lp.gamma[j] = g;
+#pragma unroll
+        for (int off = LPC / 2; off > 0; off >>= 1) {
+            d_pi += __shfl_xor(d_pi, off);
+            if (RULE == RELP_PIVOT_STEEPEST_EDGE) {
+                d_rho += __shfl_xor(d_rho, off);
+                d_w += __shfl_xor(d_w, off);
             }
         }
-        const double cbar = lp.cost[j] + d_pi;
+        if (sub != 0 || !nonbasic) continue;
+        double gam = g_j;
+        if (RULE == RELP_PIVOT_STEEPEST_EDGE && pending) {
+            if (j == leaving) {
+                gam = gamma_q / (alpha_pq * alpha_pq);  // pivot_rule.rs:294-295
+            } else {
+                const double sq = d_rho * d_rho;  // pivot_rule.rs:262-288 (Goldfarb-Reid)
+                gam = gam - 2.0 * d_rho * d_w + sq * gamma_q;
+                gam = fmax(gam, 1.0 + sq);
+            }
+            lp.gamma[j] = gam;
+        }
+        const double cbar = cost_j + d_pi;
         if (cbar < -tol_dual) {
             Cand c;
             c.idx = j;
             c.aux = 0;
-            if (RULE == RELP_PIVOT_STEEPEST_EDGE) c.key = cbar * cbar / g;
+            if (RULE == RELP_PIVOT_STEEPEST_EDGE) c.key = cbar * cbar / gam;
             else if (RULE == RELP_PIVOT_DANTZIG) c.key = -cbar;
             else if (RULE == RELP_PIVOT_FIRST_PROFITABLE) c.key = -(double)j;
             else {
@@ -219,23 +319,28 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2: entering column choice, FTRAN, ratio test and every O(m) state update, in ONE workgroup.
+// K2: entering column choice, FTRAN, ratio test, x_B update and the compacted non-zero list of alpha, in ONE
+// workgroup (the data it touches is nnz(a_q) columns of the inverse + O(m) vectors).
 //   replaces  Tableau::generate_column -> BasisInverse::left_multiply_by_basis_inverse   tableau/mod.rs:126-130,
 //                 lower_upper/mod.rs:180-210 (explicit inverse: basis_inverse_rows.rs:139-152)
 //             Tableau::select_primal_pivot_row                                           tableau/mod.rs:287-313
-//             Carry::update_b, update_minus_pi_and_obj, basis bookkeeping                carry/mod.rs:295-349,561-604
-//             BasisInverse::basis_inverse_row (row p of the NEW inverse)                 lower_upper/mod.rs:254-272
+//             Carry::update_b and the basis bookkeeping                                  carry/mod.rs:295-325,561-604
 // The ratio test is the two-pass Harris variant (f64 needs a pivot-size preference the exact reference does
 // not); ties keep the reference's Bland rule (lowest leaving column).
+// mode 0: full iteration | 1: stop after the entering-column choice | 2: stop after the ratio test (no update)
 // ---------------------------------------------------------------------------------------------------
+constexpr int K2_THREADS = 1024;
+constexpr int K2_COL_CHUNK = 1024;  // entries of the entering column staged per pass
 template <int RULE>
-__global__ void __launch_bounds__(1024) ftran_ratio_kernel(DeviceLP lp, int n_price_blocks, double tol_pivot,
-                                                         double harris_delta, int skip_artificial_rows, int mode) {
-    // mode 0: full iteration | 1: stop after the entering-column choice | 2: stop after the ratio test (no update)
+__global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, int n_price_blocks, double tol_pivot,
+                                                               double harris_delta, int skip_artificial_rows, int mode) {
     __shared__ Cand s_cand[18];
     __shared__ double s_red[18];
     __shared__ int s_q;
     __shared__ double s_cbar;
+    __shared__ int s_rows[K2_COL_CHUNK];
+    __shared__ double s_vals[K2_COL_CHUNK];
+    __shared__ int s_wcount[K2_THREADS / WAVE];
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING) return;
     if (mode == 0 && ctl->iters >= ctl->budget) {
@@ -286,7 +391,6 @@ __global__ void __launch_bounds__(1024) ftran_ratio_kernel(DeviceLP lp, int n_pr
         }
         return;
     }
-
     if (mode == 1) {
         if (threadIdx.x == 0) {
             ctl->q = q;
@@ -295,15 +399,39 @@ __global__ void __launch_bounds__(1024) ftran_ratio_kernel(DeviceLP lp, int n_pr
         }
         return;
     }
-    // ---- FTRAN: alpha = Binv a_q --------------------------------------------------------------------
+
+    // ---- FTRAN: alpha = sum_k v_k Binv(:, r_k): contiguous column reads, the column staged through LDS ----
     const int ca = lp.col_start[q], cb_ = lp.col_start[q + 1];
+    const bool single = (cb_ - ca) <= K2_COL_CHUNK;
+    if (!single)
+        for (int i = threadIdx.x; i < m; i += blockDim.x) lp.alpha[i] = 0.0;
+    for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
+        const int cnt = min(K2_COL_CHUNK, cb_ - c0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+            s_rows[e] = lp.row_index[c0 + e];
+            s_vals[e] = lp.value[c0 + e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const double* col = lp.Binv + i;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int e = 0;
+            for (; e + 4 <= cnt; e += 4) {
+                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
+                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
+                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+            }
+            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+            const double a = (a0 + a1) + (a2 + a3);
+            lp.alpha[i] = single ? a : lp.alpha[i] + a;
+        }
+    }
     double sumsq = 0.0;
     double theta = INFINITY;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const double* row = lp.Binv + (size_t)i * ld;
-        double a = 0.0;
-        for (int e = ca; e < cb_; ++e) a += row[lp.row_index[e]] * lp.value[e];
-        lp.alpha[i] = a;
+        const double a = lp.alpha[i];
         sumsq += a * a;
         const bool skip = skip_artificial_rows && lp.basis[i] < lp.n_art;
         if (a > tol_pivot && !skip) theta = fmin(theta, (fmax(lp.xB[i], 0.0) + harris_delta) / a);
@@ -342,7 +470,6 @@ __global__ void __launch_bounds__(1024) ftran_ratio_kernel(DeviceLP lp, int n_pr
         }
         return;
     }
-
     if (mode == 2) {
         if (threadIdx.x == 0) {
             ctl->q = q;
@@ -355,16 +482,34 @@ __global__ void __launch_bounds__(1024) ftran_ratio_kernel(DeviceLP lp, int n_pr
         }
         return;
     }
-    // ---- O(m) updates (carry/mod.rs:295-349) --------------------------------------------------------
+
+    // ---- x_B update (carry/mod.rs:295-325) and the ordered non-zero list of alpha for K3 ----------------
     const double alpha_pq = lp.alpha[p];
     const double xp = fmax(lp.xB[p], 0.0) / alpha_pq;
-    const double* row_p = lp.Binv + (size_t)p * ld;
-    __syncthreads();
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const double r = row_p[i] / alpha_pq;  // row p of the new inverse
-        lp.rho[i] = r;
-        lp.minus_pi[i] -= cbar_q * r;
-        lp.xB[i] = (i == p) ? xp : lp.xB[i] - lp.alpha[i] * xp;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    int total = 0;
+    __syncthreads();  // every thread has read xB[p] before it is overwritten
+    for (int base = 0; base < m; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        double a = 0.0;
+        if (i < m) {
+            a = lp.alpha[i];
+            lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
+        }
+        const bool keep = i < m && (a != 0.0 || i == p);
+        const unsigned long long mask = __ballot(keep);
+        __syncthreads();
+        if (lane == 0) s_wcount[wave] = __popcll(mask);
+        __syncthreads();
+        int offset = total;
+        for (int wv = 0; wv < wave; ++wv) offset += s_wcount[wv];
+        if (keep) {
+            const int slot = offset + __popcll(mask & ((1ull << lane) - 1ull));
+            lp.nz_index[slot] = i;
+            lp.nz_alpha[slot] = a;
+        }
+        for (int wv = 0; wv < K2_THREADS / WAVE; ++wv) total += s_wcount[wv];
     }
     if (threadIdx.x == 0) {
         const int leaving = lp.basis[p];
@@ -378,6 +523,7 @@ __global__ void __launch_bounds__(1024) ftran_ratio_kernel(DeviceLP lp, int n_pr
         ctl->alpha_pq = alpha_pq;
         ctl->gamma_q = gamma_q;
         ctl->xp = xp;
+        ctl->nz_count = total;
         ctl->minus_obj -= cbar_q * xp;
         ctl->iters += 1;
         ctl->pending = 1;
@@ -388,69 +534,379 @@ __global__ void __launch_bounds__(1024) ftran_ratio_kernel(DeviceLP lp, int n_pr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3: product-form update of the explicit inverse, fused with w = alpha_q' Binv_old (the BTRAN the
-// steepest-edge update needs).
-//   replaces  BasisInverse::change_basis                       basis_inverse_rows.rs:36-70,123-137
-//                 (role of the Forrest-Tomlin update            lower_upper/mod.rs:94-178)
-//             BasisInverse::right_multiply_by_basis_inverse    lower_upper/mod.rs:212-237 (work vector, carry/mod.rs:575)
-// Grid: (column strips of 256) x (row chunks).  Each element of Binv is read once and written at most once per
-// pivot; rows with alpha_i == 0 are skipped (no traffic).  Partial column sums go to wpart[chunk][j].
+// K2, register-resident variant for m <= R*K2F_THREADS (the common case).  Same contract as ftran_ratio_kernel, but
+// the dependent chain of global-memory round trips (~1.2 k cycles each when the data was produced by the previous
+// kernel on another XCD) is cut to four: {control word, candidates, own x_B/basis rows} -> {column extent} ->
+// {column entries} -> {inverse columns}.  alpha_i, x_B,i and basis_i of the rows a thread owns stay in registers;
+// scalars are exchanged through LDS.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) update_kernel(DeviceLP lp, int rows_per_chunk, long long iters_expected_parity) {
+constexpr int K2F_THREADS = 512;
+constexpr int K2F_MAX_BLOCKS = 2048;
+template <int RULE, int R>
+__global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP lp, int n_price_blocks, double tol_pivot,
+                                                                     double harris_delta, int skip_artificial_rows,
+                                                                     int mode) {
+    __shared__ Cand s_cand[K2F_THREADS / WAVE + 2];
+    __shared__ double s_red[K2F_THREADS / WAVE + 2];
+    __shared__ double s_red2[K2F_THREADS / WAVE + 2];
+    __shared__ double s_cbarv[K2F_MAX_BLOCKS];
+    __shared__ int s_rows[K2_COL_CHUNK];
+    __shared__ double s_vals[K2_COL_CHUNK];
+    __shared__ int s_wcount[R][K2F_THREADS / WAVE];
+    __shared__ double s_bcast[4];
+    __shared__ int s_ibcast[2];
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING || !ctl->pending) return;
-    (void)iters_expected_parity;
+    STAMP_INIT;
+    const int tid = threadIdx.x;
     const int m = lp.m, ld = lp.ld;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r0 = blockIdx.y * rows_per_chunk;
-    const int r1 = min(m, r0 + rows_per_chunk);
-    const int p = ctl->p;
-    const double alpha_pq = ctl->alpha_pq;
-    double wacc = 0.0;
-    if (j < m) {
-        const double rj = lp.rho[j];
-        for (int i = r0; i < r1; ++i) {
-            const double a = lp.alpha[i];  // wave-uniform
-            if (i == p) {
-                wacc += a * (rj * alpha_pq);  // old row p = rho * alpha_pq
-                lp.Binv[(size_t)i * ld + j] = rj;
-            } else if (a != 0.0) {
-                const double old = lp.Binv[(size_t)i * ld + j];
-                wacc += a * old;
-                lp.Binv[(size_t)i * ld + j] = old - a * rj;
+    // ---- round trip 1: everything that does not depend on q -----------------------------------------
+    const int status = ctl->status;
+    const long long iters = ctl->iters;
+    const long long budget = ctl->budget;
+    const int forced_q = ctl->forced_q;
+    const int forced_p = ctl->forced_p;
+    const double minus_obj = ctl->minus_obj;
+    double xb[R];
+    int bas[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * K2F_THREADS;
+        xb[r] = i < m ? lp.xB[i] : 0.0;
+        bas[r] = i < m ? lp.basis[i] : 0x7fffffff;
+    }
+    Cand c;
+    c.key = 0.0;
+    c.idx = -1;
+    c.aux = 0;
+    if (forced_q < 0) {
+        for (int b = tid; b < n_price_blocks; b += K2F_THREADS) {
+            Cand o;
+            o.idx = lp.cand_j[b];
+            o.key = lp.cand_key[b];
+            o.aux = b;
+            s_cbarv[b] = lp.cand_cbar[b];
+            c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
+        }
+    }
+    if (status != ST_RUNNING) return;
+    STAMP(0);
+    if (mode == 0 && iters >= budget) {
+        if (tid == 0) {
+            ctl->status = ST_BUDGET;
+            ctl->pending = 0;
+        }
+        return;
+    }
+    // ---- entering column --------------------------------------------------------------------------
+    int q;
+    double cbar_q;
+    if (forced_q < 0) {
+        c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
+        q = c.idx;
+        cbar_q = q >= 0 ? s_cbarv[c.aux] : 0.0;
+    } else {
+        q = forced_q;
+        if (tid == 0) {
+            double cb = lp.cost[forced_q];
+            for (int e = lp.col_start[forced_q]; e < lp.col_start[forced_q + 1]; ++e) cb += lp.value[e] * lp.minus_pi[lp.row_index[e]];
+            s_bcast[0] = cb;
+        }
+        __syncthreads();
+        cbar_q = s_bcast[0];
+        __syncthreads();
+    }
+    STAMP(1);
+    if (q < 0) {
+        if (tid == 0) {
+            if (mode == 0) ctl->status = ST_NO_ENTERING;
+            ctl->q = -1;
+            ctl->pending = 0;
+            if (mode == 0) ctl->last_selected = -1;
+        }
+        return;
+    }
+    if (mode == 1) {
+        if (tid == 0) {
+            ctl->q = q;
+            ctl->cbar_q = cbar_q;
+            ctl->pending = 0;
+        }
+        return;
+    }
+    // ---- FTRAN (round trips 2-4) --------------------------------------------------------------------
+    const int ca = lp.col_start[q], cb_ = lp.col_start[q + 1];
+    double al[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) al[r] = 0.0;
+    for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
+        const int cnt = min(K2_COL_CHUNK, cb_ - c0);
+        __syncthreads();
+        for (int e = tid; e < cnt; e += K2F_THREADS) {
+            s_rows[e] = lp.row_index[c0 + e];
+            s_vals[e] = lp.value[c0 + e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * K2F_THREADS;
+            if (i >= m) continue;
+            const double* col = lp.Binv + i;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int e = 0;
+            for (; e + 4 <= cnt; e += 4) {
+                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
+                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
+                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+            }
+            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+            al[r] += (a0 + a1) + (a2 + a3);
+        }
+    }
+    STAMP(2);
+    // ---- gamma_q and Harris pass 1, one combined block reduction ----------------------------------------
+    double sumsq = 0.0, theta = INFINITY;
+    bool eligible[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * K2F_THREADS;
+        const double a = al[r];
+        sumsq += a * a;
+        eligible[r] = i < m && a > tol_pivot && !(skip_artificial_rows && bas[r] < lp.n_art);
+        if (eligible[r]) theta = fmin(theta, (fmax(xb[r], 0.0) + harris_delta) / a);
+    }
+    {
+        const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+        sumsq = wave_sum(sumsq);
+        theta = wave_min(theta);
+        if (lane == LAST) {
+            s_red[wave] = sumsq;
+            s_red2[wave] = theta;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double t1 = lane < K2F_THREADS / WAVE ? s_red[lane] : 0.0;
+            double t2 = lane < K2F_THREADS / WAVE ? s_red2[lane] : INFINITY;
+            t1 = wave_sum(t1);
+            t2 = wave_min(t2);
+            if (lane == LAST) {
+                s_red[K2F_THREADS / WAVE] = t1;
+                s_red2[K2F_THREADS / WAVE] = t2;
             }
         }
-        lp.wpart[(size_t)blockIdx.y * m + j] = wacc;
+        __syncthreads();
     }
+    const double gamma_q = 1.0 + s_red[K2F_THREADS / WAVE];  // pivot_rule.rs:258
+    const double theta_max = s_red2[K2F_THREADS / WAVE];
+    STAMP(3);
+    // ---- Harris pass 2 ---------------------------------------------------------------------------------
+    int p = forced_p;
+    if (forced_p < 0) {
+        Cand h;
+        h.key = 0.0;
+        h.idx = -1;
+        h.aux = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (eligible[r] && fmax(xb[r], 0.0) / al[r] <= theta_max) {
+                Cand o;
+                o.key = al[r];
+                o.idx = tid + r * K2F_THREADS;
+                o.aux = bas[r];
+                h = better<TIE_SMALLER_AUX>(h, o);
+            }
+        }
+        h = block_best<TIE_SMALLER_AUX>(h, s_cand);
+        p = h.idx;
+    }
+    STAMP(4);
+    if (p < 0) {
+        if (tid == 0) {
+            if (mode == 0) ctl->status = ST_UNBOUNDED;
+            ctl->q = q;
+            ctl->p = -1;
+            ctl->pending = 0;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+        }
+        return;
+    }
+    if (mode == 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * K2F_THREADS;
+            if (i < m) lp.alpha[i] = al[r];
+        }
+        if (tid == 0) {
+            ctl->q = q;
+            ctl->p = p;
+            ctl->cbar_q = cbar_q;
+            ctl->gamma_q = gamma_q;
+            ctl->pending = 0;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+        }
+        return;
+    }
+    // ---- broadcast the pivot row's scalars (its owner has them in registers) ------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (tid + r * K2F_THREADS == p) {
+            s_bcast[1] = al[r];
+            s_bcast[2] = xb[r];
+            s_ibcast[0] = bas[r];
+        }
+    }
+    __syncthreads();
+    const double alpha_pq = s_bcast[1];
+    const double xp = fmax(s_bcast[2], 0.0) / alpha_pq;
+    const int leaving = s_ibcast[0];
+    // ---- x_B update (carry/mod.rs:295-325), alpha, and the ordered non-zero list for K3 -----------------
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+    unsigned long long masks[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * K2F_THREADS;
+        const bool keep = i < m && (al[r] != 0.0 || i == p);
+        masks[r] = __ballot(keep);
+        if (lane == 0) s_wcount[r][wave] = __popcll(masks[r]);
+        if (i < m) {
+            lp.alpha[i] = al[r];
+            lp.xB[i] = (i == p) ? xp : xb[r] - al[r] * xp;
+        }
+    }
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int offset = total;
+        for (int wv = 0; wv < K2F_THREADS / WAVE; ++wv) {
+            const int cnt = s_wcount[r][wv];
+            if (wv < wave) offset += cnt;
+            total += cnt;
+        }
+        const int i = tid + r * K2F_THREADS;
+        const bool keep = i < m && (al[r] != 0.0 || i == p);
+        if (keep) {
+            const int slot = offset + __popcll(masks[r] & ((1ull << lane) - 1ull));
+            lp.nz_index[slot] = i;
+            lp.nz_alpha[slot] = al[r];
+        }
+    }
+    STAMP(5);
+    if (tid == 0) {
+        lp.basis[p] = q;
+        lp.pos[q] = p;
+        lp.pos[leaving] = -1;
+        ctl->q = q;
+        ctl->p = p;
+        ctl->leaving = leaving;
+        ctl->cbar_q = cbar_q;
+        ctl->alpha_pq = alpha_pq;
+        ctl->gamma_q = gamma_q;
+        ctl->xp = xp;
+        ctl->nz_count = total;
+        ctl->minus_obj = minus_obj - cbar_q * xp;
+        ctl->iters = iters + 1;
+        ctl->pending = 1;
+        ctl->forced_q = -1;
+        ctl->forced_p = -1;
+        ctl->last_selected = q;
+    }
+    STAMP(6);
 }
 
-// K4: w[j] = sum over chunks (fixed order => deterministic).
-__global__ void __launch_bounds__(256) wreduce_kernel(DeviceLP lp, int n_chunks) {
+// ---------------------------------------------------------------------------------------------------
+// K3: product-form update of the explicit inverse, fused with everything that is "per column j of Binv":
+//     rho_p[j] (row p of the NEW inverse), -pi_j update, w_j = alpha_q' Binv_old(:, j).
+//   replaces  BasisInverse::change_basis                       basis_inverse_rows.rs:36-70,123-137
+//                 (role of the Forrest-Tomlin update            lower_upper/mod.rs:94-178)
+//             BasisInverse::basis_inverse_row                  lower_upper/mod.rs:254-272
+//             Carry::update_minus_pi_and_obj                   carry/mod.rs:338-349
+//             BasisInverse::right_multiply_by_basis_inverse    lower_upper/mod.rs:212-237 (work vector, carry/mod.rs:575)
+// One wave owns CPW contiguous columns; lanes sweep the ordered non-zero list of alpha (rows with alpha_i == 0 are
+// never read or written).  Every touched element is read once and written once, coalesced; w_j is a wave-shuffle
+// sum in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------
+constexpr int K3_THREADS = 256;
+constexpr int K3_CPW = 2;  // columns per wave
+__global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING || !ctl->pending) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= lp.m) return;
-    double acc = 0.0;
-    for (int c = 0; c < n_chunks; ++c) acc += lp.wpart[(size_t)c * lp.m + j];
-    lp.w[j] = acc;
+    const int m = lp.m, ld = lp.ld;
+    const int p = ctl->p;
+    const int count = ctl->nz_count;
+    const double alpha_pq = ctl->alpha_pq;
+    const double cbar_q = ctl->cbar_q;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    const int j0 = (blockIdx.x * (K3_THREADS / WAVE) + wave) * K3_CPW;
+    if (j0 >= m) return;
+    const bool two = j0 + 1 < m;
+    double* c0 = lp.Binv + (size_t)j0 * ld;
+    double* c1 = lp.Binv + (size_t)(two ? j0 + 1 : j0) * ld;
+    const double r0 = c0[p] / alpha_pq;  // row p of the new inverse
+    const double r1 = c1[p] / alpha_pq;
+    double w0 = 0.0, w1 = 0.0;
+    constexpr int U = 4;  // independent loads in flight per lane and column
+    for (int k0 = lane; k0 < count; k0 += U * WAVE) {
+        int idx[U];
+        double a[U], o0[U], o1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * WAVE;
+            idx[u] = k < count ? lp.nz_index[k] : -1;
+            a[u] = k < count ? lp.nz_alpha[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            o0[u] = idx[u] >= 0 ? c0[idx[u]] : 0.0;
+            o1[u] = idx[u] >= 0 ? c1[idx[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            w0 += a[u] * o0[u];
+            w1 += a[u] * o1[u];
+            if (idx[u] >= 0) {
+                c0[idx[u]] = (idx[u] == p) ? r0 : o0[u] - a[u] * r0;
+                if (two) c1[idx[u]] = (idx[u] == p) ? r1 : o1[u] - a[u] * r1;
+            }
+        }
+    }
+    w0 = wave_sum(w0);
+    w1 = wave_sum(w1);
+    if (lane == LAST) {
+        lp.w[j0] = w0;
+        lp.rho[j0] = r0;
+        lp.minus_pi[j0] -= cbar_q * r0;
+        if (two) {
+            lp.w[j0 + 1] = w1;
+            lp.rho[j0 + 1] = r1;
+            lp.minus_pi[j0 + 1] -= cbar_q * r1;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Phase set-up
 // ---------------------------------------------------------------------------------------------------
-// -pi_j = -sum_i c_{basis[i]} Binv[i][j]   (Carry::create_minus_pi_from_artificial, carry/mod.rs:226-260: the reference
-// forms all of B^-1 with m FTRANs; here B^-1 is resident).  Also -obj = -sum_i xB_i c_{basis[i]} (carry/mod.rs:270-283).
+// -pi_j = -sum_i c_{basis[i]} Binv(i, j)   (Carry::create_minus_pi_from_artificial, carry/mod.rs:226-260: the reference
+// forms all of B^-1 with m FTRANs; here B^-1 is resident).  One wave per column j (contiguous).
+// Block 0 also recomputes -obj = -sum_i xB_i c_{basis[i]} (carry/mod.rs:270-283).
 __global__ void __launch_bounds__(256) pi_kernel(DeviceLP lp) {
     __shared__ double s_red[6];
     const int m = lp.m, ld = lp.ld;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int j = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     if (j < m) {
+        const double* col = lp.Binv + (size_t)j * ld;
         double acc = 0.0;
-        for (int i = 0; i < m; ++i) {
+        for (int i = lane; i < m; i += WAVE) {
             const double c = lp.cost[lp.basis[i]];
-            if (c != 0.0) acc += c * lp.Binv[(size_t)i * ld + j];
+            if (c != 0.0) acc += c * col[i];
         }
-        lp.minus_pi[j] = -acc;
+        acc = wave_sum(acc);
+        if (lane == LAST) lp.minus_pi[j] = -acc;
     }
     if (blockIdx.x == 0) {
         double acc = 0.0;
@@ -460,16 +916,27 @@ __global__ void __launch_bounds__(256) pi_kernel(DeviceLP lp) {
     }
 }
 
-// xB = Binv rhs  (Carry::from_basis, carry/mod.rs:452-463): one wave per row, coalesced row reads.
+// xB = Binv rhs  (Carry::from_basis, carry/mod.rs:452-463): xB_i = sum_j T[j*ld+i] rhs_j.  A workgroup owns 64 rows;
+// its four waves split the columns (rhs_j == 0 skipped, wave-uniform), 8 independent loads in flight, LDS-combined
+// in a fixed order.
 __global__ void __launch_bounds__(256) xb_kernel(DeviceLP lp) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    if (row >= lp.m) return;
-    const double* r = lp.Binv + (size_t)row * lp.ld;
+    __shared__ double s_part[4][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int i = blockIdx.x * WAVE + lane;
+    const int m = lp.m;
     double acc = 0.0;
-    for (int j = lane; j < lp.m; j += WAVE) acc += r[j] * lp.rhs[j];
-    acc = wave_sum(acc);
-    if (lane == 0) lp.xB[row] = acc;
+    for (int j0 = wave * 8; j0 < m; j0 += 32) {
+        double r[8], t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = (j0 + u < m) ? lp.rhs[j0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (r[u] != 0.0 && i < m) ? lp.Binv[(size_t)(j0 + u) * lp.ld + i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += r[u] * t[u];
+    }
+    s_part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && i < m) lp.xB[i] = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
 }
 
 // gamma_j = 1 + ||Binv a_j||^2 for the non-basic, non-artificial columns (pivot_rule.rs:202-219, 299-305:
@@ -488,9 +955,8 @@ __global__ void __launch_bounds__(256) gamma_init_kernel(DeviceLP lp, int identi
         for (int e = a + threadIdx.x; e < b; e += blockDim.x) acc += lp.value[e] * lp.value[e];
     } else {
         for (int i = threadIdx.x; i < lp.m; i += blockDim.x) {
-            const double* row = lp.Binv + (size_t)i * lp.ld;
             double v = 0.0;
-            for (int e = a; e < b; ++e) v += row[lp.row_index[e]] * lp.value[e];
+            for (int e = a; e < b; ++e) v += lp.Binv[(size_t)lp.row_index[e] * lp.ld + i] * lp.value[e];
             acc += v * v;
         }
     }
@@ -505,28 +971,25 @@ __global__ void identity_kernel(double* X, int m, int ld) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Polish: Newton-Schulz  X <- X + X (I - B X).  Plays the role of BasisInverse::should_refactor + invert
-// (lower_upper/mod.rs:78-92,249-252; carry/mod.rs:584-591) for the explicit inverse: it removes the drift of
-// the product-form updates with GEMM-shaped work only.
+// Polish: Newton-Schulz  X <- X + (I - X B) X, i.e. in the stored transpose  T <- T + T S,  S = I - B' T.
+// Plays the role of BasisInverse::should_refactor + invert (lower_upper/mod.rs:78-92,249-252; carry/mod.rs:584-591)
+// for the explicit inverse: it removes the drift of the product-form updates with GEMM-shaped work only.
 // ---------------------------------------------------------------------------------------------------
-// R[i][:] = e_i - sum_{k} B[i][k] X[k][:] ; row i of B comes from the CSR of A restricted to basic columns.
-__global__ void __launch_bounds__(256) residual_kernel(DeviceLP lp, const double* X, double* R) {
+// S[k][:] = e_k - sum_{(r,v) in column basis[k] of A} v * T[r][:]   (CSC column of the basis, contiguous rows of T)
+__global__ void __launch_bounds__(256) residual_kernel(DeviceLP lp, const double* T, double* S) {
     __shared__ double s_red[6];
-    const int i = blockIdx.x;
+    const int k = blockIdx.x;
     const int m = lp.m, ld = lp.ld;
-    const int a = lp.row_start[i], b = lp.row_start[i + 1];
+    const int col = lp.basis[k];
+    const int a = lp.col_start[col], b = lp.col_start[col + 1];
     double local_max = 0.0;
-    for (int j = threadIdx.x; j < m; j += blockDim.x) {
-        double acc = (i == j) ? 1.0 : 0.0;
-        for (int e = a; e < b; ++e) {
-            const int k = lp.pos[lp.col_index[e]];
-            if (k >= 0) acc -= lp.row_value[e] * X[(size_t)k * ld + j];
-        }
-        R[(size_t)i * ld + j] = acc;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        double acc = (i == k) ? 1.0 : 0.0;
+        for (int e = a; e < b; ++e) acc -= lp.value[e] * T[(size_t)lp.row_index[e] * ld + i];
+        S[(size_t)k * ld + i] = acc;
         local_max = fmax(local_max, fabs(acc));
     }
-    // max via min of negatives
-    const double blk = -block_reduce<1>(-local_max, s_red);
+    const double blk = -block_reduce<1>(-local_max, s_red);  // max via min of negatives
     if (threadIdx.x == 0) {
         // non-negative doubles order like their bit patterns
         atomicMax(reinterpret_cast<unsigned long long*>(&lp.ctl->residual),
@@ -534,7 +997,7 @@ __global__ void __launch_bounds__(256) residual_kernel(DeviceLP lp, const double
     }
 }
 
-// C = X + X R  (m x m, f64).  LDS-tiled 64x64 per workgroup, 4x4 per thread.
+// C = X + X R  (m x m, f64, row-major with leading dimension ld).  LDS-tiled 64x64 per workgroup, 4x4 per thread.
 constexpr int GT = 64, GK = 16;
 __global__ void __launch_bounds__(256) gemm_polish_kernel(const double* __restrict__ X, const double* __restrict__ R,
                                                         double* __restrict__ C, int m, int ld) {
@@ -580,14 +1043,14 @@ __global__ void __launch_bounds__(256) gemm_polish_kernel(const double* __restri
     }
 }
 
-// X0 = s * B'  (row k of X0 = column basis[k] of A, scaled): start of a from-scratch Newton-Schulz inversion.
-__global__ void transpose_basis_kernel(DeviceLP lp, double* X, double scale) {
+// T0 = s * B  (T0[r][k] = s B[r][k]; X0 = T0' = s B'): start of a from-scratch Newton-Schulz inversion.
+__global__ void scaled_basis_kernel(DeviceLP lp, double* T, double scale) {
     const int k = blockIdx.x;
     const int col = lp.basis[k];
-    for (int j = threadIdx.x; j < lp.m; j += blockDim.x) X[(size_t)k * lp.ld + j] = 0.0;
+    for (int r = threadIdx.x; r < lp.m; r += blockDim.x) T[(size_t)r * lp.ld + k] = 0.0;
     __syncthreads();
     for (int e = lp.col_start[col] + threadIdx.x; e < lp.col_start[col + 1]; e += blockDim.x)
-        X[(size_t)k * lp.ld + lp.row_index[e]] = scale * lp.value[e];
+        T[(size_t)lp.row_index[e] * lp.ld + k] = scale * lp.value[e];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -595,11 +1058,11 @@ __global__ void transpose_basis_kernel(DeviceLP lp, double* X, double scale) {
 // tableau row r (generate_element, lower_upper/mod.rs:239-247, without a full FTRAN per candidate).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) row_scan_kernel(DeviceLP lp, int r, double tol) {
-    const double* row = lp.Binv + (size_t)r * lp.ld;
     for (int j = lp.n_art + blockIdx.x * blockDim.x + threadIdx.x; j < lp.n; j += gridDim.x * blockDim.x) {
         if (lp.pos[j] >= 0) continue;
         double acc = 0.0;
-        for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e) acc += lp.value[e] * row[lp.row_index[e]];
+        for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
+            acc += lp.value[e] * lp.Binv[(size_t)lp.row_index[e] * lp.ld + r];
         if (fabs(acc) > tol) atomicMin(&lp.ctl->scan_column, j);
     }
 }
@@ -611,17 +1074,16 @@ __global__ void __launch_bounds__(256) row_scan_kernel(DeviceLP lp, int r, doubl
 __global__ void ftran_vec_kernel(DeviceLP lp, const int* rows, const double* vals, int nnz, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lp.m) return;
-    const double* row = lp.Binv + (size_t)i * lp.ld;
     double acc = 0.0;
-    for (int e = 0; e < nnz; ++e) acc += row[rows[e]] * vals[e];
+    for (int e = 0; e < nnz; ++e) acc += lp.Binv[(size_t)rows[e] * lp.ld + i] * vals[e];
     out[i] = acc;
 }
-// out = v' Binv (BTRAN)
+// out = v' Binv (BTRAN): out_j = sum_e v_e Binv(r_e, j)
 __global__ void btran_vec_kernel(DeviceLP lp, const int* rows, const double* vals, int nnz, double* out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= lp.m) return;
     double acc = 0.0;
-    for (int e = 0; e < nnz; ++e) acc += vals[e] * lp.Binv[(size_t)rows[e] * lp.ld + j];
+    for (int e = 0; e < nnz; ++e) acc += vals[e] * lp.Binv[(size_t)j * lp.ld + rows[e]];
     out[j] = acc;
 }
 // cbar_j for every column (Tableau::relative_cost)
@@ -636,45 +1098,61 @@ __global__ void relative_cost_kernel(DeviceLP lp, double* out) {
 // ---------------------------------------------------------------------------------------------------
 // launch helpers used by solver.hip
 // ---------------------------------------------------------------------------------------------------
+constexpr int PRICE_LPC = 8;  // lanes per sparse column in the pricing kernel
+int price_columns_per_block() { return 256 / PRICE_LPC; }
+
 template <int RULE>
 static void launch_price_rule(const DeviceLP& d, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
-                              int n_chunks, hipStream_t s) {
+                              hipStream_t s) {
     if (use_lds)
-        hipLaunchKernelGGL((price_kernel<RULE, true>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol, n_chunks);
+        hipLaunchKernelGGL((price_kernel<RULE, true, PRICE_LPC>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol);
     else
-        hipLaunchKernelGGL((price_kernel<RULE, false>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, n_chunks);
+        hipLaunchKernelGGL((price_kernel<RULE, false, PRICE_LPC>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol);
 }
 
 void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
-                  int n_chunks, hipStream_t s) {
+                  hipStream_t s) {
     switch (rule) {
-        case RELP_PIVOT_DANTZIG: launch_price_rule<RELP_PIVOT_DANTZIG>(d, blocks, lds, use_lds, skip_weights, tol, n_chunks, s); break;
-        case RELP_PIVOT_FIRST_PROFITABLE: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE>(d, blocks, lds, use_lds, skip_weights, tol, n_chunks, s); break;
-        case RELP_PIVOT_FIRST_PROFITABLE_MEMORY: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE_MEMORY>(d, blocks, lds, use_lds, skip_weights, tol, n_chunks, s); break;
-        default: launch_price_rule<RELP_PIVOT_STEEPEST_EDGE>(d, blocks, lds, use_lds, skip_weights, tol, n_chunks, s); break;
+        case RELP_PIVOT_DANTZIG: launch_price_rule<RELP_PIVOT_DANTZIG>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
+        case RELP_PIVOT_FIRST_PROFITABLE: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
+        case RELP_PIVOT_FIRST_PROFITABLE_MEMORY: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE_MEMORY>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
+        default: launch_price_rule<RELP_PIVOT_STEEPEST_EDGE>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
     }
 }
 
-void configure_price_lds(size_t lds) {
+void configure_lds(size_t price_lds) {
     // opt in to > 64 KB of dynamic LDS (160 KB per CU on gfx950)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_STEEPEST_EDGE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_DANTZIG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_STEEPEST_EDGE, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_DANTZIG, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
+}
+
+template <int RULE>
+static void launch_ftran_ratio_rule(const DeviceLP& d, int n_price_blocks, double tol_pivot, double harris_delta,
+                                    int skip_artificial_rows, int mode, hipStream_t s) {
+    const bool fits = n_price_blocks <= K2F_MAX_BLOCKS;
+    if (fits && d.m <= 2 * K2F_THREADS)
+        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 2>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+    else if (fits && d.m <= 4 * K2F_THREADS)
+        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 4>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+    else if (fits && d.m <= 8 * K2F_THREADS)
+        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 8>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+    else
+        hipLaunchKernelGGL((ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
 }
 
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
                         int skip_artificial_rows, int mode, hipStream_t s) {
     if (rule == RELP_PIVOT_STEEPEST_EDGE)
-        hipLaunchKernelGGL((ftran_ratio_kernel<RELP_PIVOT_STEEPEST_EDGE>), dim3(1), dim3(1024), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+        launch_ftran_ratio_rule<RELP_PIVOT_STEEPEST_EDGE>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, s);
     else
-        hipLaunchKernelGGL((ftran_ratio_kernel<RELP_PIVOT_DANTZIG>), dim3(1), dim3(1024), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+        launch_ftran_ratio_rule<RELP_PIVOT_DANTZIG>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, s);
 }
 
-void launch_update(const DeviceLP& d, int rows_per_chunk, int n_chunks, hipStream_t s) {
-    dim3 grid((d.m + 255) / 256, n_chunks);
-    hipLaunchKernelGGL(update_kernel, grid, dim3(256), 0, s, d, rows_per_chunk, 0LL);
-    hipLaunchKernelGGL(wreduce_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d, n_chunks);
+void launch_update(const DeviceLP& d, hipStream_t s) {
+    const int cols_per_block = (K3_THREADS / WAVE) * K3_CPW;
+    hipLaunchKernelGGL(update_kernel, dim3((d.m + cols_per_block - 1) / cols_per_block), dim3(K3_THREADS), 0, s, d);
 }
 
 void launch_budget(const DeviceLP& d, long long add, hipStream_t s) {
@@ -682,10 +1160,10 @@ void launch_budget(const DeviceLP& d, long long add, hipStream_t s) {
 }
 
 void launch_pi(const DeviceLP& d, hipStream_t s) {
-    hipLaunchKernelGGL(pi_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(pi_kernel, dim3((d.m + 3) / 4), dim3(256), 0, s, d);
 }
 void launch_xb(const DeviceLP& d, hipStream_t s) {
-    hipLaunchKernelGGL(xb_kernel, dim3((d.m + 3) / 4), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(xb_kernel, dim3((d.m + WAVE - 1) / WAVE), dim3(256), 0, s, d);
 }
 void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s) {
     hipLaunchKernelGGL(gamma_init_kernel, dim3(d.n - d.n_art), dim3(256), 0, s, d, identity);
@@ -693,15 +1171,15 @@ void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s) {
 void launch_identity(double* X, int m, int ld, hipStream_t s) {
     hipLaunchKernelGGL(identity_kernel, dim3((m + 255) / 256, m), dim3(256), 0, s, X, m, ld);
 }
-void launch_residual(const DeviceLP& d, const double* X, double* R, hipStream_t s) {
-    hipLaunchKernelGGL(residual_kernel, dim3(d.m), dim3(256), 0, s, d, X, R);
+void launch_residual(const DeviceLP& d, const double* T, double* S, hipStream_t s) {
+    hipLaunchKernelGGL(residual_kernel, dim3(d.m), dim3(256), 0, s, d, T, S);
 }
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s) {
     dim3 grid((m + GT - 1) / GT, (m + GT - 1) / GT);
     hipLaunchKernelGGL(gemm_polish_kernel, grid, dim3(256), 0, s, X, R, C, m, ld);
 }
-void launch_transpose_basis(const DeviceLP& d, double* X, double scale, hipStream_t s) {
-    hipLaunchKernelGGL(transpose_basis_kernel, dim3(d.m), dim3(64), 0, s, d, X, scale);
+void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s) {
+    hipLaunchKernelGGL(scaled_basis_kernel, dim3(d.m), dim3(64), 0, s, d, T, scale);
 }
 void launch_row_scan(const DeviceLP& d, int r, double tol, hipStream_t s) {
     int blocks = (d.n - d.n_art + 255) / 256;

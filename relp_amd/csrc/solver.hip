@@ -15,11 +15,12 @@ namespace relp {
 
 // kernels.hip
 void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
-                  int n_chunks, hipStream_t s);
-void configure_price_lds(size_t lds);
+                  hipStream_t s);
+void configure_lds(size_t price_lds);
+int price_columns_per_block();
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
                         int skip_artificial_rows, int mode, hipStream_t s);
-void launch_update(const DeviceLP& d, int rows_per_chunk, int n_chunks, hipStream_t s);
+void launch_update(const DeviceLP& d, hipStream_t s);
 void launch_budget(const DeviceLP& d, long long add, hipStream_t s);
 void launch_pi(const DeviceLP& d, hipStream_t s);
 void launch_xb(const DeviceLP& d, hipStream_t s);
@@ -27,7 +28,7 @@ void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s);
 void launch_identity(double* X, int m, int ld, hipStream_t s);
 void launch_residual(const DeviceLP& d, const double* X, double* R, hipStream_t s);
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s);
-void launch_transpose_basis(const DeviceLP& d, double* X, double scale, hipStream_t s);
+void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s);
 void launch_row_scan(const DeviceLP& d, int r, double tol, hipStream_t s);
 void launch_ftran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
 void launch_btran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
@@ -68,19 +69,19 @@ Solver::Solver(const relp_options& options) : opt_(options) {
 
 Solver::~Solver() {
     free_device();
-    if (graph_exec_) hipGraphExecDestroy(graph_exec_);
-    if (graph_) hipGraphDestroy(graph_);
-    if (ev_a_) hipEventDestroy(ev_a_);
-    if (ev_b_) hipEventDestroy(ev_b_);
-    if (stream_) hipStreamDestroy(stream_);
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    if (ev_a_) (void)hipEventDestroy(ev_a_);
+    if (ev_b_) (void)hipEventDestroy(ev_b_);
+    if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.wpart, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.scratch, d_.ctl};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.scratch, d_.ctl, d_.dbg};
     for (void* p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     d_ = DeviceLP{};
 }
 
@@ -89,8 +90,8 @@ void Solver::reset_stats() { stats_ = relp_stats{}; }
 void Solver::load(StandardForm&& form) {
     RELP_HIP(hipSetDevice(opt_.device));
     free_device();
-    if (graph_exec_) { hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
-    if (graph_) { hipGraphDestroy(graph_); graph_ = nullptr; }
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
     form_ = std::move(form);
     upload();
     loaded_ = true;
@@ -154,9 +155,8 @@ void Solver::upload() {
     d_.n = n;
     d_.n_art = n_art;
     d_.ld = m;
-    rows_per_chunk_ = 16;
-    update_chunks_ = (m + rows_per_chunk_ - 1) / rows_per_chunk_;
-    price_blocks_ = std::max(1, std::min(2048, (n - n_art + 255) / 256));
+    const int cpb = price_columns_per_block();
+    price_blocks_ = std::max(1, std::min(2048, (n - n_art + cpb - 1) / cpb));
     price_lds_ = (size_t)3 * m * sizeof(double);
 
     d_.col_start = dmalloc<int>(n + 1);
@@ -179,13 +179,16 @@ void Solver::upload() {
     d_.R = dmalloc<double>((size_t)m * d_.ld);
     d_.alpha = dmalloc<double>(m);
     d_.rho = dmalloc<double>(m);
-    d_.wpart = dmalloc<double>((size_t)update_chunks_ * m);
+    d_.nz_index = dmalloc<int>(m);
+    d_.nz_alpha = dmalloc<double>(m);
     d_.w = dmalloc<double>(m);
     d_.cand_key = dmalloc<double>(price_blocks_);
     d_.cand_j = dmalloc<int>(price_blocks_);
     d_.cand_cbar = dmalloc<double>(price_blocks_);
     d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 2 + 16);
     d_.ctl = dmalloc<Ctl>(1);
+    d_.dbg = dmalloc<unsigned long long>(64);
+    RELP_HIP(hipMemsetAsync(d_.dbg, 0, 64 * sizeof(unsigned long long), stream_));
 
     upload_vec(d_.col_start, col_start, stream_);
     upload_vec(d_.row_index, row_index, stream_);
@@ -201,7 +204,7 @@ void Solver::upload() {
     RELP_HIP(hipMemsetAsync(d_.alpha, 0, m * sizeof(double), stream_));
     RELP_HIP(hipMemsetAsync(d_.gamma, 0, n * sizeof(double), stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
-    if (price_lds_ <= 160 * 1024 - 1024) configure_price_lds(price_lds_);
+    configure_lds(std::min<size_t>(price_lds_, 160 * 1024 - 1024));
 
     stats_.price_bytes = (long long)(nnz - n_art) * 12 + (long long)(n - n_art) * 24;
     stats_.update_bytes = (long long)2 * m * m * 8;
@@ -279,18 +282,18 @@ void Solver::launch_pivots(int count) {
     const int skip_art = phase_ == 2 ? 1 : 0;
     launch_budget(d_, count, stream_);
     for (int it = 0; it < count; ++it) {
-        launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, update_chunks_, stream_);
+        launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, stream_);
         launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, skip_art, 0, stream_);
-        launch_update(d_, rows_per_chunk_, update_chunks_, stream_);
+        launch_update(d_, stream_);
     }
-    stats_.launches += 1 + 4LL * count;
+    stats_.launches += 1 + 3LL * count;
     stats_.price_launches += count;
 }
 
 void Solver::build_graph(int count) {
     if (graph_exec_ && graph_count_ == count && graph_phase_ == phase_) return;
-    if (graph_exec_) { hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
-    if (graph_) { hipGraphDestroy(graph_); graph_ = nullptr; }
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
     long long launches = stats_.launches, price_launches = stats_.price_launches;
     RELP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
     launch_pivots(count);
@@ -358,7 +361,7 @@ void Solver::invert_from_scratch() {
     }
     double norm_inf = 1.0;
     for (double v : row_sum) norm_inf = std::max(norm_inf, v);
-    launch_transpose_basis(d_, d_.Binv, 1.0 / (norm1 * norm_inf), stream_);
+    launch_scaled_basis(d_, d_.Binv, 1.0 / (norm1 * norm_inf), stream_);
     double previous = std::numeric_limits<double>::infinity();
     for (int it = 0; it < 200; ++it) {
         RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
@@ -416,7 +419,7 @@ long long Solver::iterate(long long count, int* stop_reason) {
         if (opt_.use_graph && batch == opt_.pivots_per_launch) {
             build_graph(batch);
             RELP_HIP(hipGraphLaunch(graph_exec_, stream_));
-            stats_.launches += 1 + 4LL * batch;
+            stats_.launches += 1 + 3LL * batch;
             stats_.price_launches += batch;
         } else {
             launch_pivots(batch);
@@ -566,8 +569,8 @@ void Solver::btran(int nnz, const int* rows, const double* values, double* out) 
 }
 void Solver::inverse_row(int row, double* out) {
     if (row < 0 || row >= d_.m) throw std::invalid_argument("row out of range");
-    RELP_HIP(hipMemcpyAsync(out, d_.Binv + (size_t)row * d_.ld, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    RELP_HIP(hipStreamSynchronize(stream_));
+    const double one = 1.0;
+    btran(1, &row, &one, out);  // e_row' Binv: a strided read of the column-major inverse
 }
 void Solver::relative_costs(double* out) {
     launch_relative_cost(d_, d_.scratch, stream_);
@@ -592,7 +595,7 @@ void Solver::price(int* column, double* cbar) {
     c.status = ST_RUNNING;
     c.forced_q = c.forced_p = -1;
     write_ctl(c);
-    launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, update_chunks_, stream_);
+    launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, stream_);
     launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 1, stream_);
     c = read_ctl();
     *column = c.q;
@@ -641,9 +644,9 @@ double Solver::profile_kernel(int which, int repetitions) {
     RELP_HIP(hipMemcpyAsync(d_.scratch, d_.gamma, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     RELP_HIP(hipMemcpyAsync(d_.Binv2, d_.Binv, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     auto launch = [&] {
-        if (which == 0) launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, update_chunks_, stream_);
+        if (which == 0) launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, stream_);
         else if (which == 1) launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, 0, 2, stream_);
-        else launch_update(d_, rows_per_chunk_, update_chunks_, stream_);
+        else launch_update(d_, stream_);
     };
     for (int k = 0; k < 3; ++k) {
         if (which == 1) write_ctl(c);
@@ -676,6 +679,11 @@ double Solver::profile_kernel(int which, int repetitions) {
     RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     write_ctl(saved);
     return total_ms * 1e-3 / repetitions;
+}
+
+void Solver::debug_stamps(unsigned long long* out64) {
+    RELP_HIP(hipMemcpyAsync(out64, d_.dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
 }
 
 void Solver::get_b(double* out) {

@@ -35,7 +35,7 @@ struct Ctl {
     double residual;   // max |I - B Binv| written by the polish
     double scan_value;
     int scan_column;
-    int pad;
+    int nz_count;      // entries of the ordered non-zero list of alpha_q (written by K2, read by K3)
 };
 
 enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3 };
@@ -59,18 +59,20 @@ struct DeviceLP {
     int* basis = nullptr;        // Carry::basis_indices (m)
     int* pos = nullptr;          // column -> row or -1 (the Tableau's basis_columns set) (n)
     double* gamma = nullptr;     // steepest-edge weights (n)
-    double* Binv = nullptr;      // explicit basis inverse, row-major m x ld
+    double* Binv = nullptr;      // explicit basis inverse, COLUMN-major: Binv(i, j) at [j*ld + i]
     double* Binv2 = nullptr;     // second buffer for the polish
     double* R = nullptr;         // residual I - B Binv
     double* alpha = nullptr;     // B^-1 a_q (m)
     double* rho = nullptr;       // row p of the NEW inverse (m)
-    double* wpart = nullptr;     // partial sums of w = alpha' Binv_old, [n_chunks][m]
-    double* w = nullptr;         // reduced (m)
+    double* w = nullptr;         // w = alpha_q' Binv_old (m)
+    int* nz_index = nullptr;     // rows with alpha_i != 0 (plus p), ascending (m)
+    double* nz_alpha = nullptr;  // their alpha values (m)
     double* cand_key = nullptr;  // per pricing block
     int* cand_j = nullptr;
     double* cand_cbar = nullptr;
     double* scratch = nullptr;   // m or n doubles for the fine-grained ops
     Ctl* ctl = nullptr;
+    unsigned long long* dbg = nullptr;  // diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of K2
 };
 
 class Solver {
@@ -100,6 +102,7 @@ public:
     void get_basis(int* out);
     void get_solution(double* x) const;
     double profile_kernel(int which, int repetitions);
+    void debug_stamps(unsigned long long* out64);
 
     const StandardForm& form() const { return form_; }
     const DeviceLP& device() const { return d_; }
@@ -130,8 +133,6 @@ private:
     bool binv_identity_ = true;
     int phase_ = 0;
     int price_blocks_ = 0;
-    int update_chunks_ = 0;
-    int rows_per_chunk_ = 16;
     size_t price_lds_ = 0;
     hipStream_t stream_ = nullptr;
     hipGraph_t graph_ = nullptr;
