@@ -1,0 +1,54 @@
+"""Bit-exact rational optimum through the exact certificate (``options.certify``), on a real MI355X (``-m gpu``).
+
+The expected strings are the oracle's exact optima (tests/golden/*.json, produced by the Fraction restatement of
+relp's RationalBig path) and the exact values the reference's own tests assert (tests/reference_expectations.py).
+Bit-exact comparison of "numerator/denominator".
+"""
+import glob
+import json
+import os
+
+import pytest
+
+import relp_amd
+from reference_expectations import EXACT
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = {os.path.basename(p)[:-5]: json.load(open(p)) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.json"))
+          if not p.endswith("netlib_expected.json")}
+
+
+@pytest.mark.parametrize("name", sorted(n for n, g in GOLDEN.items() if g["status"] == "optimal"))
+def test_certified_objective_is_bit_exact(name):
+    golden = GOLDEN[name]
+    solver = relp_amd.Solver(certify=1).load_mps(os.path.join(ROOT, golden["file"]))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    assert solver.objective_exact() == golden["objective"]
+    if name in EXACT:  # the reference's own exact assertions
+        value = EXACT[name]
+        assert solver.objective_exact() == "%d/%d" % (value.numerator, value.denominator)
+    solver.close()
+
+
+def test_25fv47_exact_optimum_has_1791_bits():
+    golden = GOLDEN["25FV47"]
+    solver = relp_amd.Solver(certify=1).load_mps(os.path.join(ROOT, golden["file"]))
+    result = solver.solve_relaxation()
+    assert result.certified == 1
+    exact = solver.objective_exact()
+    assert exact == golden["objective"]
+    num, den = exact.split("/")
+    assert max(int(num).bit_length(), int(den).bit_length()) == golden["objective_bits"] == 1791
+    assert result.certify_seconds < 30
+    solver.close()
+
+
+def test_uncertified_solve_has_no_exact_objective():
+    solver = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", "AFIRO.SIF"))
+    solver.solve_relaxation()
+    with pytest.raises(relp_amd.RelpError):
+        solver.objective_exact()
