@@ -1,0 +1,39 @@
+"""Multi-GPU host logic: independent LPs shard one per GPU; no data-path collective.
+
+`assign` is the static work distribution of a batch of LPs (longest estimated cost first, deterministic);
+`aggregate` is the only exchange of the bench: MAX of the per-rank wall time and SUM of the per-rank pivot counts
+(RCCL all-reduce on GPUs, gloo in the CPU tests).  Nothing here computes an LP.
+"""
+import torch
+import torch.distributed as dist
+
+
+def assign(costs, world_size):
+    """Longest-processing-time-first partition.  `costs`: list of (name, estimated cost).  Returns one list per rank."""
+    ranks = [[] for _ in range(world_size)]
+    loads = [0.0] * world_size
+    for name, cost in sorted(costs, key=lambda item: (-item[1], item[0])):
+        target = min(range(world_size), key=lambda r: (loads[r], r))
+        ranks[target].append(name)
+        loads[target] += cost
+    return ranks
+
+
+def aggregate(elapsed_seconds, pivots, device=None):
+    """(max elapsed over ranks, total pivots over ranks).  Works without an initialised process group (N = 1)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(elapsed_seconds), int(pivots)
+    t = torch.tensor([float(elapsed_seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    p = torch.tensor([float(pivots)], dtype=torch.float64, device=device)
+    dist.all_reduce(p, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(round(p.item()))
+
+
+def gather_records(record):
+    """All ranks' result records on every rank (fixed-size python objects; tiny)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [record]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, record)
+    return out

@@ -41,7 +41,15 @@ def test_fixture_regenerates(name):
 def test_golden_objectives_meet_reference_tolerances(name):
     expected, tolerance, _ = NETLIB[name]
     num, den = GOLDEN[name]["objective"].split("/")
-    assert abs(Fraction(int(num), int(den)) - Fraction(expected)) < Fraction(tolerance)
+    value = Fraction(int(num), int(den))
+    if name == "25FV47":
+        # tests/netlib/test.rs:10 holds the optimum rounded to 8 digits (5.5018459e+03) with tolerance 1e-5, but the true
+        # optimum 5.5018458883E+03 (tests/netlib/problem_files/README:85) is 1.2e-5 away: that ignored test cannot pass as
+        # written.  The README value is the expectation here.
+        assert abs(value - Fraction("5501.8458883")) < Fraction(1, 10 ** 6)
+        assert abs(value - Fraction(expected)) < Fraction(2, 10 ** 5)
+        return
+    assert abs(value - Fraction(expected)) < Fraction(tolerance)
 
 
 def test_unbounded_nazareth():  # tests/burkardt/test.rs:157-167
