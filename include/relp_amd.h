@@ -131,6 +131,11 @@ int32_t relp_load_matrix_data(relp_handle* handle,
                               int32_t nr_equality, int32_t nr_range, int32_t nr_upper, int32_t nr_lower,
                               int64_t fixed_cost_num, int64_t fixed_cost_den);
 
+/* Dense provider `A x <= b, x >= 0, b >= 0` with integer data (column-major A, m x n): every row has its slack as an
+ * initial pivot, i.e. the `FullInitialBasis` route of two_phase/mod.rs:80-109 (no phase one).  BASELINE config 3. */
+int32_t relp_load_dense_le(relp_handle* handle, int32_t m, int32_t n, const int64_t* a_column_major,
+                           const int64_t* b, const int64_t* cost);
+
 /* Convenience for the step before the path: `parse_fixed`/`parse_free` + `TryInto<GeneralForm>` +
  * `standardize()` + `derive_matrix_data()` (tests/netlib/mod.rs:55-61, without presolve). */
 int32_t relp_load_mps(relp_handle* handle, const char* path, int32_t fixed_format);

@@ -52,7 +52,7 @@ SYMBOLS = [
     "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_free", "relp_model_dimensions",
     "relp_model_column", "relp_model_column_exact", "relp_model_cost", "relp_model_right_hand_side",
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
-    "relp_load_matrix_data", "relp_load_mps", "relp_load_model", "relp_get_dimensions", "relp_get_column",
+    "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_model", "relp_get_dimensions", "relp_get_column",
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
     "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
@@ -196,6 +196,18 @@ class Solver:
 
     def load_model(self, model):
         self._check(lib().relp_load_model(self._h, model._h))
+        self._dims()
+        return self
+
+    def load_dense_le(self, a_column_major, b, cost):
+        """Dense `A x <= b` provider (FullInitialBasis route, two_phase/mod.rs:80-109).  `a_column_major`: (n, m) int64."""
+        a = np.ascontiguousarray(a_column_major, dtype=np.int64)
+        n, m = a.shape
+        b = np.ascontiguousarray(b, dtype=np.int64)
+        cost = np.ascontiguousarray(cost, dtype=np.int64)
+        assert b.shape == (m,) and cost.shape == (n,)
+        self._check(lib().relp_load_dense_le(self._h, C.c_int32(m), C.c_int32(n), _ptr(a, C.c_int64), _ptr(b, C.c_int64),
+                                             _ptr(cost, C.c_int64)))
         self._dims()
         return self
 

@@ -257,6 +257,36 @@ int32_t relp_load_matrix_data(relp_handle* h, int32_t nr_constraints, int32_t nr
     });
 }
 
+int32_t relp_load_dense_le(relp_handle* h, int32_t m, int32_t n, const int64_t* a, const int64_t* b, const int64_t* cost) {
+    if (!h || !h->solver || m < 1 || n < 1 || !a || !b || !cost) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] {
+        StandardForm form;
+        MatrixData& md = form.data;
+        md.nr_upper = m;
+        md.constraints.resize(n);
+        md.variables.resize(n);
+        for (int j = 0; j < n; ++j) {
+            SparseColumn& c = md.constraints[j];
+            c.index.reserve(m);
+            c.value.reserve(m);
+            for (int i = 0; i < m; ++i) {
+                const int64_t v = a[(size_t)j * m + i];
+                if (v != 0) c.push(i, Rat((long long)v));
+            }
+            md.variables[j].cost = Rat((long long)cost[j]);
+        }
+        md.b.resize(m);
+        for (int i = 0; i < m; ++i) {
+            if (b[i] < 0) throw std::invalid_argument("b must be non-negative");
+            md.b[i] = Rat((long long)b[i]);
+        }
+        md.finalize();
+        form.nr_original = n;
+        form.free_negative_part.assign(n, -1);
+        h->solver->load(std::move(form));
+    });
+}
+
 int32_t relp_load_mps(relp_handle* h, const char* path, int32_t fixed_format) {
     if (!h || !path) return RELP_ERR_ARGUMENT;
     std::ifstream in(path);

@@ -221,7 +221,6 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
                  hipStream_t stream, ExactVector* out, std::string* message) {
     const int m = B.m;
     i64* d_r = buf.alloc<i64>(m);
-    u32* d_x = buf.alloc<u32>(m);
     int* d_info = buf.alloc<int>(4);
     RELP_HIP(hipMemsetAsync(d_info, 0, 4 * sizeof(int), stream));
     RELP_HIP(hipMemcpyAsync(d_r, rhs.data(), m * sizeof(i64), hipMemcpyHostToDevice, stream));

@@ -196,7 +196,8 @@ __global__ void budget_kernel(Ctl* ctl, long long add) {
 // The reference makes TWO passes over A per pivot (pricing, weight update) and clones every column twice.
 // ---------------------------------------------------------------------------------------------------
 template <int RULE, bool USE_LDS, int LPC>
-__global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weights, double tol_dual) {
+__global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weights, double tol_dual, int col_first,
+                                                    int col_last, int cand_offset) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[8];
     Ctl* ctl = lp.ctl;
@@ -246,9 +247,9 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
     best.idx = -1;
     best.aux = 0;
     double best_cbar = 0.0;
-    for (int base = lp.n_art + blockIdx.x * CPB; base < lp.n; base += gridDim.x * CPB) {
+    for (int base = col_first + blockIdx.x * CPB; base < col_last; base += gridDim.x * CPB) {
         const int j = base + g;
-        const bool valid = j < lp.n;
+        const bool valid = j < col_last;
         int a = 0, b = 0;
         bool nonbasic = false;
         double cost_j = 0.0, g_j = 1.0;
@@ -311,11 +312,195 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
     Cand blk = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(best, s_cand)
                                                   : block_best<TIE_SMALLER_IDX>(best, s_cand);
     if (blk.idx >= 0 && blk.idx == best.idx) {  // the winning thread publishes
-        lp.cand_key[blockIdx.x] = blk.key;
-        lp.cand_j[blockIdx.x] = blk.idx;
-        lp.cand_cbar[blockIdx.x] = best_cbar;
+        lp.cand_key[cand_offset + blockIdx.x] = blk.key;
+        lp.cand_j[cand_offset + blockIdx.x] = blk.idx;
+        lp.cand_cbar[cand_offset + blockIdx.x] = best_cbar;
     }
-    if (blk.idx < 0 && threadIdx.x == 0) lp.cand_j[blockIdx.x] = -1;
+    if (blk.idx < 0 && threadIdx.x == 0) lp.cand_j[cand_offset + blockIdx.x] = -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1d: the same pricing pass for DENSE columns (BASELINE config 3: m = 4096, n = 8192, 268 MB of f64 per pass).
+// Columns are stored dense, column-major, without row indices (8 B per entry instead of 12); one wave streams one
+// column with 16-byte loads (1 KiB per wave instruction), 4 loads in flight per lane; -pi, rho_p, w live in LDS
+// (3 x 32 KB at m = 4096).  This is the HBM-roofline kernel: algorithmic bytes = non-basic dense columns * m * 8.
+// ---------------------------------------------------------------------------------------------------
+constexpr int K1D_THREADS = 512;
+__global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, int skip_weights, double tol_dual, int cand_offset) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ Cand s_cand[K1D_THREADS / WAVE + 2];
+    __shared__ double s_cbar[K1D_THREADS / WAVE];
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING) return;
+    const int m = lp.m;
+    const int mp = lp.dense_ld;  // padded to a multiple of 2
+    const int pending = ctl->pending && !skip_weights;
+    const double gamma_q = ctl->gamma_q;
+    const double alpha_pq = ctl->alpha_pq;
+    const int leaving = ctl->leaving;
+    double* s_pi = smem;
+    double* s_rho = smem + mp;
+    double* s_w = smem + 2 * mp;
+    for (int i = threadIdx.x; i < mp; i += K1D_THREADS) {
+        s_pi[i] = i < m ? lp.minus_pi[i] : 0.0;
+        s_rho[i] = (pending && i < m) ? lp.rho[i] : 0.0;
+        s_w[i] = (pending && i < m) ? lp.w[i] : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int waves_total = gridDim.x * (K1D_THREADS / WAVE);
+    Cand best;
+    best.key = 0.0;
+    best.idx = -1;
+    best.aux = 0;
+    double best_cbar = 0.0;
+    const int half = mp / 2;
+    for (int jd = blockIdx.x * (K1D_THREADS / WAVE) + wave; jd < lp.n_dense; jd += waves_total) {
+        const int j = lp.dense_first + jd;
+        if (lp.pos[j] >= 0) continue;  // wave-uniform
+        const double2* col = reinterpret_cast<const double2*>(lp.dense_val + (size_t)jd * mp);
+        const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
+        const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
+        const double2* w2 = reinterpret_cast<const double2*>(s_w);
+        double d_pi = 0.0, d_rho = 0.0, d_w = 0.0;
+        for (int k0 = lane; k0 < half; k0 += 4 * WAVE) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * WAVE;
+                v[u] = k < half ? col[k] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * WAVE;
+                if (k < half) {
+                    const double2 a = pi2[k];
+                    d_pi += v[u].x * a.x + v[u].y * a.y;
+                    if (pending) {
+                        const double2 b = rho2[k], c = w2[k];
+                        d_rho += v[u].x * b.x + v[u].y * b.y;
+                        d_w += v[u].x * c.x + v[u].y * c.y;
+                    }
+                }
+            }
+        }
+        d_pi = wave_sum(d_pi);
+        d_rho = wave_sum(d_rho);
+        d_w = wave_sum(d_w);
+        if (lane == LAST) {
+            double gam = lp.gamma[j];
+            if (pending) {
+                if (j == leaving) {
+                    gam = gamma_q / (alpha_pq * alpha_pq);
+                } else {
+                    const double sq = d_rho * d_rho;
+                    gam = gam - 2.0 * d_rho * d_w + sq * gamma_q;
+                    gam = fmax(gam, 1.0 + sq);
+                }
+                lp.gamma[j] = gam;
+            }
+            const double cbar = lp.cost[j] + d_pi;
+            if (cbar < -tol_dual) {
+                Cand c;
+                c.idx = j;
+                c.aux = 0;
+                c.key = cbar * cbar / gam;
+                Cand nb = better<TIE_LARGER_IDX>(best, c);
+                if (nb.idx == j) best_cbar = cbar;
+                best = nb;
+            }
+        }
+    }
+    if (lane == LAST) s_cbar[wave] = best_cbar;
+    best.aux = wave;
+    if (lane != LAST) best.idx = -1;
+    Cand blk = block_best<TIE_LARGER_IDX>(best, s_cand);
+    if (threadIdx.x == 0) {
+        lp.cand_j[cand_offset + blockIdx.x] = blk.idx;
+        if (blk.idx >= 0) {
+            lp.cand_key[cand_offset + blockIdx.x] = blk.key;
+            lp.cand_cbar[cand_offset + blockIdx.x] = s_cbar[blk.aux];
+        }
+    }
+}
+
+// Entering-column choice as its own tiny kernel (used when FTRAN runs multi-block): reduces the candidates of all
+// pricing workgroups with the reference's tie rule, handles the iteration budget and the "no entering column" exit.
+__global__ void __launch_bounds__(256) select_kernel(DeviceLP lp, int n_price_blocks, int rule) {
+    __shared__ Cand s_cand[8];
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING) return;
+    if (ctl->iters >= ctl->budget) {
+        if (threadIdx.x == 0) {
+            ctl->status = ST_BUDGET;
+            ctl->pending = 0;
+        }
+        return;
+    }
+    if (ctl->forced_q >= 0) {
+        if (threadIdx.x == 0) ctl->q = ctl->forced_q;
+        return;
+    }
+    Cand c;
+    c.key = 0.0;
+    c.idx = -1;
+    c.aux = 0;
+    for (int b = threadIdx.x; b < n_price_blocks; b += blockDim.x) {
+        Cand o;
+        o.idx = lp.cand_j[b];
+        o.key = o.idx >= 0 ? lp.cand_key[b] : 0.0;
+        o.aux = b;
+        c = (rule == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
+    }
+    c = (rule == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
+    if (threadIdx.x == 0) {
+        ctl->q = c.idx;
+        if (c.idx >= 0) {
+            ctl->cbar_q = lp.cand_cbar[c.aux];
+        } else {
+            ctl->status = ST_NO_ENTERING;
+            ctl->pending = 0;
+            ctl->last_selected = -1;
+        }
+    }
+}
+
+// Multi-block FTRAN for long entering columns: partial[c][i] = sum over the c-th slice of the entries of a_q of
+// v_e * Binv(i, r_e).  Grid (row tiles of 256, slices); coalesced over i; fixed slice order => deterministic.
+__global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_slices) {
+    __shared__ int s_rows[256];
+    __shared__ double s_vals[256];
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING) return;
+    const int q = ctl->q;
+    if (q < 0) return;
+    const int m = lp.m, ld = lp.ld;
+    const int ca = lp.col_start[q], cb = lp.col_start[q + 1];
+    const int len = (cb - ca + n_slices - 1) / n_slices;
+    const int e0 = ca + blockIdx.y * len, e1 = min(cb, e0 + len);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int c0 = e0; c0 < e1; c0 += 256) {
+        const int cnt = min(256, e1 - c0);
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            s_rows[threadIdx.x] = lp.row_index[c0 + threadIdx.x];
+            s_vals[threadIdx.x] = lp.value[c0 + threadIdx.x];
+        }
+        __syncthreads();
+        if (i < m) {
+            const double* col = lp.Binv + i;
+            int e = 0;
+            for (; e + 4 <= cnt; e += 4) {
+                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
+                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
+                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+            }
+            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+        }
+    }
+    if (i < m) lp.alpha_part[(size_t)blockIdx.y * m + i] = (a0 + a1) + (a2 + a3);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -545,7 +730,8 @@ constexpr int K2F_MAX_BLOCKS = 2048;
 template <int RULE, int R>
 __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP lp, int n_price_blocks, double tol_pivot,
                                                                      double harris_delta, int skip_artificial_rows,
-                                                                     int mode) {
+                                                                     int mode, int n_alpha_slices) {
+    // n_alpha_slices > 0: q was chosen by select_kernel and alpha comes from ftran_partial_kernel's slices
     __shared__ Cand s_cand[K2F_THREADS / WAVE + 2];
     __shared__ double s_red[K2F_THREADS / WAVE + 2];
     __shared__ double s_red2[K2F_THREADS / WAVE + 2];
@@ -578,7 +764,8 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     c.key = 0.0;
     c.idx = -1;
     c.aux = 0;
-    if (forced_q < 0) {
+    const bool preselected = n_alpha_slices > 0;
+    if (forced_q < 0 && !preselected) {
         for (int b = tid; b < n_price_blocks; b += K2F_THREADS) {
             Cand o;
             o.idx = lp.cand_j[b];
@@ -600,7 +787,10 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     // ---- entering column --------------------------------------------------------------------------
     int q;
     double cbar_q;
-    if (forced_q < 0) {
+    if (preselected && forced_q < 0) {
+        q = ctl->q;
+        cbar_q = ctl->cbar_q;
+    } else if (forced_q < 0) {
         c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
         q = c.idx;
         cbar_q = q >= 0 ? s_cbarv[c.aux] : 0.0;
@@ -634,10 +824,19 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         return;
     }
     // ---- FTRAN (round trips 2-4) --------------------------------------------------------------------
-    const int ca = lp.col_start[q], cb_ = lp.col_start[q + 1];
+    const int ca = lp.col_start[q], cb_ = preselected ? lp.col_start[q] : lp.col_start[q + 1];
     double al[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) al[r] = 0.0;
+    if (preselected) {
+        for (int sl = 0; sl < n_alpha_slices; ++sl) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = tid + r * K2F_THREADS;
+                if (i < m) al[r] += lp.alpha_part[(size_t)sl * m + i];
+            }
+        }
+    }
     for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
         const int cnt = min(K2_COL_CHUNK, cb_ - c0);
         __syncthreads();
@@ -1103,21 +1302,36 @@ int price_columns_per_block() { return 256 / PRICE_LPC; }
 
 template <int RULE>
 static void launch_price_rule(const DeviceLP& d, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
-                              hipStream_t s) {
+                              int first, int last, int cand_offset, hipStream_t s) {
     if (use_lds)
-        hipLaunchKernelGGL((price_kernel<RULE, true, PRICE_LPC>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol);
+        hipLaunchKernelGGL((price_kernel<RULE, true, PRICE_LPC>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol, first, last, cand_offset);
     else
-        hipLaunchKernelGGL((price_kernel<RULE, false, PRICE_LPC>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol);
+        hipLaunchKernelGGL((price_kernel<RULE, false, PRICE_LPC>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
 }
 
+// sparse (CSC) pricing over the device columns [first, last)
 void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
-                  hipStream_t s) {
+                  int first, int last, int cand_offset, hipStream_t s) {
     switch (rule) {
-        case RELP_PIVOT_DANTZIG: launch_price_rule<RELP_PIVOT_DANTZIG>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
-        case RELP_PIVOT_FIRST_PROFITABLE: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
-        case RELP_PIVOT_FIRST_PROFITABLE_MEMORY: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE_MEMORY>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
-        default: launch_price_rule<RELP_PIVOT_STEEPEST_EDGE>(d, blocks, lds, use_lds, skip_weights, tol, s); break;
+        case RELP_PIVOT_DANTZIG: launch_price_rule<RELP_PIVOT_DANTZIG>(d, blocks, lds, use_lds, skip_weights, tol, first, last, cand_offset, s); break;
+        case RELP_PIVOT_FIRST_PROFITABLE: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE>(d, blocks, lds, use_lds, skip_weights, tol, first, last, cand_offset, s); break;
+        case RELP_PIVOT_FIRST_PROFITABLE_MEMORY: launch_price_rule<RELP_PIVOT_FIRST_PROFITABLE_MEMORY>(d, blocks, lds, use_lds, skip_weights, tol, first, last, cand_offset, s); break;
+        default: launch_price_rule<RELP_PIVOT_STEEPEST_EDGE>(d, blocks, lds, use_lds, skip_weights, tol, first, last, cand_offset, s); break;
     }
+}
+
+void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s) {
+    const size_t lds = (size_t)3 * d.dense_ld * sizeof(double);
+    hipLaunchKernelGGL(price_dense_kernel, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
+}
+void configure_dense_lds(size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+void launch_select(const DeviceLP& d, int n_price_blocks, int rule, hipStream_t s) {
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, s, d, n_price_blocks, rule);
+}
+void launch_ftran_partial(const DeviceLP& d, int n_slices, hipStream_t s) {
+    hipLaunchKernelGGL(ftran_partial_kernel, dim3((d.m + 255) / 256, n_slices), dim3(256), 0, s, d, n_slices);
 }
 
 void configure_lds(size_t price_lds) {
@@ -1130,24 +1344,27 @@ void configure_lds(size_t price_lds) {
 
 template <int RULE>
 static void launch_ftran_ratio_rule(const DeviceLP& d, int n_price_blocks, double tol_pivot, double harris_delta,
-                                    int skip_artificial_rows, int mode, hipStream_t s) {
+                                    int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s) {
     const bool fits = n_price_blocks <= K2F_MAX_BLOCKS;
     if (fits && d.m <= 2 * K2F_THREADS)
-        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 2>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 2>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else if (fits && d.m <= 4 * K2F_THREADS)
-        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 4>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 4>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else if (fits && d.m <= 8 * K2F_THREADS)
-        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 8>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 8>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else
         hipLaunchKernelGGL((ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
 }
 
+// n_alpha_slices > 0 requires the register-resident kernel (m <= 4096 and <= 2048 pricing workgroups)
+bool fast_k2_available(const DeviceLP& d, int n_price_blocks) { return n_price_blocks <= K2F_MAX_BLOCKS && d.m <= 8 * K2F_THREADS; }
+
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
-                        int skip_artificial_rows, int mode, hipStream_t s) {
+                        int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s) {
     if (rule == RELP_PIVOT_STEEPEST_EDGE)
-        launch_ftran_ratio_rule<RELP_PIVOT_STEEPEST_EDGE>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, s);
+        launch_ftran_ratio_rule<RELP_PIVOT_STEEPEST_EDGE>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices, s);
     else
-        launch_ftran_ratio_rule<RELP_PIVOT_DANTZIG>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, s);
+        launch_ftran_ratio_rule<RELP_PIVOT_DANTZIG>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices, s);
 }
 
 void launch_update(const DeviceLP& d, hipStream_t s) {

@@ -15,11 +15,16 @@ namespace relp {
 
 // kernels.hip
 void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
-                  hipStream_t s);
+                  int first, int last, int cand_offset, hipStream_t s);
+void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s);
+void configure_dense_lds(size_t lds);
+void launch_select(const DeviceLP& d, int n_price_blocks, int rule, hipStream_t s);
+void launch_ftran_partial(const DeviceLP& d, int n_slices, hipStream_t s);
+bool fast_k2_available(const DeviceLP& d, int n_price_blocks);
 void configure_lds(size_t price_lds);
 int price_columns_per_block();
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
-                        int skip_artificial_rows, int mode, hipStream_t s);
+                        int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s);
 void launch_update(const DeviceLP& d, hipStream_t s);
 void launch_budget(const DeviceLP& d, long long add, hipStream_t s);
 void launch_pi(const DeviceLP& d, hipStream_t s);
@@ -79,7 +84,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.scratch, d_.ctl, d_.dbg};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -155,9 +160,25 @@ void Solver::upload() {
     d_.n = n;
     d_.n_art = n_art;
     d_.ld = m;
+    // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
+    // structural columns); steepest edge only (the dense kernel implements that rule)
+    int n_dense = 0;
+    if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE && m >= 64)
+        while (n_dense < n_p && (col_start[n_art + n_dense + 1] - col_start[n_art + n_dense]) * 2 > m) ++n_dense;
+    if (n_dense < 64) n_dense = 0;
+    d_.n_dense = n_dense;
+    d_.dense_first = n_art;
+    d_.dense_ld = (m + 1) & ~1;
+    sparse_first_ = n_art + n_dense;
     const int cpb = price_columns_per_block();
-    price_blocks_ = std::max(1, std::min(2048, (n - n_art + cpb - 1) / cpb));
+    price_blocks_ = std::min(1024, (n - sparse_first_ + cpb - 1) / cpb);
+    dense_blocks_ = n_dense > 0 ? std::min(1024, (n_dense + 7) / 8) : 0;
+    if (price_blocks_ + dense_blocks_ == 0) price_blocks_ = 1;
     price_lds_ = (size_t)3 * m * sizeof(double);
+    int max_nnz = 0;
+    for (int j = n_art; j < n; ++j) max_nnz = std::max(max_nnz, col_start[j + 1] - col_start[j]);
+    ftran_slices_ = 0;
+    if (max_nnz > 1024 && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = std::min(64, (max_nnz + 127) / 128);
 
     d_.col_start = dmalloc<int>(n + 1);
     d_.row_index = dmalloc<int>(nnz);
@@ -182,9 +203,19 @@ void Solver::upload() {
     d_.nz_index = dmalloc<int>(m);
     d_.nz_alpha = dmalloc<double>(m);
     d_.w = dmalloc<double>(m);
-    d_.cand_key = dmalloc<double>(price_blocks_);
-    d_.cand_j = dmalloc<int>(price_blocks_);
-    d_.cand_cbar = dmalloc<double>(price_blocks_);
+    d_.cand_key = dmalloc<double>(price_blocks_ + dense_blocks_);
+    d_.cand_j = dmalloc<int>(price_blocks_ + dense_blocks_);
+    d_.cand_cbar = dmalloc<double>(price_blocks_ + dense_blocks_);
+    d_.alpha_part = dmalloc<double>((size_t)std::max(1, ftran_slices_) * m);
+    if (n_dense > 0) {
+        std::vector<double> dense((size_t)n_dense * d_.dense_ld, 0.0);
+        for (int jd = 0; jd < n_dense; ++jd)
+            for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) dense[(size_t)jd * d_.dense_ld + row_index[e]] = value[e];
+        d_.dense_val = dmalloc<double>(dense.size());
+        upload_vec(d_.dense_val, dense, stream_);
+        RELP_HIP(hipStreamSynchronize(stream_));
+        configure_dense_lds((size_t)3 * d_.dense_ld * sizeof(double));
+    }
     d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 2 + 16);
     d_.ctl = dmalloc<Ctl>(1);
     d_.dbg = dmalloc<unsigned long long>(64);
@@ -206,7 +237,8 @@ void Solver::upload() {
     RELP_HIP(hipStreamSynchronize(stream_));
     configure_lds(std::min<size_t>(price_lds_, 160 * 1024 - 1024));
 
-    stats_.price_bytes = (long long)(nnz - n_art) * 12 + (long long)(n - n_art) * 24;
+    stats_.price_bytes = (long long)(col_start[n] - col_start[sparse_first_]) * 12 + (long long)(n - n_art) * 24 +
+                         (long long)n_dense * m * 8;  // upper bound: every dense column non-basic
     stats_.update_bytes = (long long)2 * m * m * 8;
     h_basis_.assign(m, -1);
     h_solution_.assign(n_p, 0.0);
@@ -278,16 +310,34 @@ void Solver::set_phase(int phase) {
 
 // One batch of `count` iterations of the loop of phase_one.rs:134-178 / phase_two.rs:36-58.
 void Solver::launch_pivots(int count) {
-    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
-    const int skip_art = phase_ == 2 ? 1 : 0;
     launch_budget(d_, count, stream_);
     for (int it = 0; it < count; ++it) {
-        launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, stream_);
-        launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, skip_art, 0, stream_);
+        enqueue_price(0);
+        enqueue_ftran_ratio(0);
         launch_update(d_, stream_);
     }
-    stats_.launches += 1 + 3LL * count;
+    stats_.launches += 1 + (3LL + (dense_blocks_ > 0) + 2 * (ftran_slices_ > 0)) * count;
     stats_.price_launches += count;
+}
+
+// Pricing pass: the dense block (if any) streams through price_dense_kernel, every other column through the CSC kernel.
+void Solver::enqueue_price(int skip_weights) {
+    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
+    if (price_blocks_ > 0)
+        launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, skip_weights, opt_.tol_dual,
+                     sparse_first_, d_.n, 0, stream_);
+    if (dense_blocks_ > 0) launch_price_dense(d_, dense_blocks_, skip_weights, opt_.tol_dual, price_blocks_, stream_);
+}
+
+// Entering column + FTRAN + ratio test (+ updates in mode 0).  Long (dense) columns take the multi-block FTRAN.
+void Solver::enqueue_ftran_ratio(int mode) {
+    const int skip_art = phase_ == 2 ? 1 : 0;
+    const int slots = price_blocks_ + dense_blocks_;
+    if (ftran_slices_ > 0) {
+        launch_select(d_, slots, opt_.pivot_rule, stream_);
+        launch_ftran_partial(d_, ftran_slices_, stream_);
+    }
+    launch_ftran_ratio(d_, opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, ftran_slices_, stream_);
 }
 
 void Solver::build_graph(int count) {
@@ -589,14 +639,13 @@ void Solver::get_gamma(double* out) {
 // `PivotRule::select_primal_pivot_column`: the pricing kernel, then the entering-column reduction of the fused kernel
 // (mode 1: stop after the choice).  Applies a pending steepest-edge update exactly like the device loop does.
 void Solver::price(int* column, double* cbar) {
-    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
     Ctl c = read_ctl();
     const int saved = c.status;
     c.status = ST_RUNNING;
     c.forced_q = c.forced_p = -1;
     write_ctl(c);
-    launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, stream_);
-    launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 1, stream_);
+    enqueue_price(0);
+    launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_ + dense_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 1, 0, stream_);
     c = read_ctl();
     *column = c.q;
     *cbar = c.q >= 0 ? c.cbar_q : 0.0;
@@ -613,7 +662,7 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
     c.forced_q = column;
     c.forced_p = -1;
     write_ctl(c);
-    launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 2, stream_);
+    enqueue_ftran_ratio(2);
     c = read_ctl();
     *row = c.p;
     if (alpha_out) {
@@ -629,7 +678,6 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
 double Solver::profile_kernel(int which, int repetitions) {
     if (phase_ == 0) throw std::runtime_error("no phase started");
     RELP_HIP(hipSetDevice(opt_.device));
-    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
     const int m = d_.m;
     Ctl saved = read_ctl();
     Ctl c = saved;
@@ -644,8 +692,8 @@ double Solver::profile_kernel(int which, int repetitions) {
     RELP_HIP(hipMemcpyAsync(d_.scratch, d_.gamma, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     RELP_HIP(hipMemcpyAsync(d_.Binv2, d_.Binv, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     auto launch = [&] {
-        if (which == 0) launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, stream_);
-        else if (which == 1) launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_, opt_.tol_pivot, opt_.harris_delta, 0, 2, stream_);
+        if (which == 0) enqueue_price(0);
+        else if (which == 1) enqueue_ftran_ratio(2);
         else launch_update(d_, stream_);
     };
     for (int k = 0; k < 3; ++k) {

@@ -42,6 +42,10 @@ enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3
 
 struct DeviceLP {
     int m = 0, n = 0, n_art = 0, ld = 0;
+    // dense block: device columns [dense_first, dense_first + n_dense) also stored dense, column-major, ld = dense_ld
+    int n_dense = 0, dense_first = 0, dense_ld = 0;
+    double* dense_val = nullptr;
+    double* alpha_part = nullptr;  // slices of the multi-block FTRAN, [n_slices][m]
     // CSC of [artificial identity columns | provider columns] (matrix_data.rs:291-329 materialised once)
     int* col_start = nullptr;
     int* row_index = nullptr;
@@ -118,6 +122,8 @@ private:
     void free_device();
     void set_phase(int phase);
     void launch_pivots(int count);
+    void enqueue_price(int skip_weights);
+    void enqueue_ftran_ratio(int mode);
     void build_graph(int count);
     void polish(bool refresh_vectors);
     void invert_from_scratch();
@@ -132,7 +138,10 @@ private:
     bool loaded_ = false;
     bool binv_identity_ = true;
     int phase_ = 0;
-    int price_blocks_ = 0;
+    int price_blocks_ = 0;        // sparse pricing workgroups
+    int dense_blocks_ = 0;        // dense pricing workgroups (candidate slots follow the sparse ones)
+    int ftran_slices_ = 0;        // > 0: multi-block FTRAN pipeline (select -> partial FTRAN -> fused kernel)
+    int sparse_first_ = 0;        // device columns priced by the CSC kernel: [sparse_first_, n)
     size_t price_lds_ = 0;
     hipStream_t stream_ = nullptr;
     hipGraph_t graph_ = nullptr;

@@ -21,8 +21,8 @@ from relp_oracle.mps import load_problem
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN = {os.path.basename(p)[:-5]: json.load(open(p)) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.json"))
-          if not p.endswith("netlib_expected.json")}
+GOLDEN = {os.path.basename(p)[:-5]: json.load(open(p)) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.json"))}
+GOLDEN = {name: g for name, g in GOLDEN.items() if "status" in g}  # per-LP fixtures only
 REL = 1e-9  # north_star: "f64 path within 1e-9 rel"
 
 
