@@ -20,7 +20,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    "25fv47": os.path.join(ROOT, "data", "netlib", "25FV47.SIF"),
+    "25fv47": os.path.join(ROOT, "data", "netlib", "25FV47.SIF"),   # BASELINE configs[1]: the default, the metric's config
+    "dense4096": (4096, 8192),                                          # BASELINE configs[2]: the HBM-roofline config
+    "dense1024": (1024, 2048),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -86,7 +88,13 @@ def main():
 
     import relp_amd
     path = WORKLOADS[args.workload]
-    solver = relp_amd.Solver(device=local_rank).load_mps(path)
+    dense = not isinstance(path, str)
+    if dense:
+        from relp_amd.workloads import dense_lp
+        a, b, c = dense_lp(*path)
+        solver = relp_amd.Solver(device=local_rank, polish_period=512).load_dense_le(a, b, c)
+    else:
+        solver = relp_amd.Solver(device=local_rank).load_mps(path)
 
     def barrier():
         if distributed:
@@ -108,7 +116,7 @@ def main():
     elapsed, pivots = batch.aggregate(elapsed, pivots, device="cuda" if distributed else None)
 
     exact = None
-    if rank == 0:
+    if rank == 0 and not dense:
         # one extra, untimed, certified solve: bit-exact rational optimum (north_star parity requirement)
         certified = relp_amd.Solver(device=local_rank, certify=1).load_mps(path)
         cres = certified.solve_relaxation()
@@ -123,20 +131,26 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (pricing pass), measured live with HIP events on the solver's stream
         solver.begin_phase_one()
-        solver.iterate(200)
+        solver.iterate(600 if dense else 200)
         reps = 200
         seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(["price", "ftran_ratio", "update"])}
         stats = solver.stats()
         dominant = max(("price", "update"), key=lambda k: seconds[k])
         bytes_per_launch = stats.price_bytes if dominant == "price" else stats.update_bytes
         achieved = bytes_per_launch / seconds[dominant] / 1e9
+        if dense:
+            workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing" % path
+            data = "synthetic"
+        else:
+            workload = ("Netlib 25FV47 821x1876 (+520 virtual artificials), steepest-edge pricing, explicit-inverse carry, "
+                        "no presolve")
+            data = "Netlib 25FV47.SIF (shipped problem file), one copy per GPU"
         line = {
             "metric": "simplex pivots/sec + wall-clock to optimal, Netlib 25fv47 @1 GPU",
             "value": pivots / elapsed, "unit": "pivots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "Netlib 25FV47.SIF (shipped problem file), one copy per GPU",
-            "config": {"workload": "Netlib 25FV47 821x1876 (+520 virtual artificials), steepest-edge pricing, "
-                                   "explicit-inverse carry, no presolve",
+            "dtype": "f64", "data": data,
+            "config": {"workload": workload,
                        "pivots_per_solve": int(last.pivots_phase_one + last.pivots_phase_two),
                        "objective": last.objective, "wall_clock_to_optimal_s": last.solve_seconds,
                        "parallelism": "1 LP per GPU x%d" % world, "exact": exact},
@@ -144,7 +158,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not dense:
             line["cpu_baseline"] = cpu_baseline(path, args.cpu_seconds)
         print(json.dumps(line))
     if distributed:

@@ -363,15 +363,15 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
         const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
         const double2* w2 = reinterpret_cast<const double2*>(s_w);
         double d_pi = 0.0, d_rho = 0.0, d_w = 0.0;
-        for (int k0 = lane; k0 < half; k0 += 4 * WAVE) {
-            double2 v[4];
+        for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
+            double2 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int k = k0 + u * WAVE;
                 v[u] = k < half ? col[k] : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int k = k0 + u * WAVE;
                 if (k < half) {
                     const double2 a = pi2[k];
@@ -501,6 +501,22 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
         }
     }
     if (i < m) lp.alpha_part[(size_t)blockIdx.y * m + i] = (a0 + a1) + (a2 + a3);
+}
+
+// alpha_part[0][i] = sum_c alpha_part[c][i] (fixed order), so that the fused kernel reads one slice.
+__global__ void __launch_bounds__(256) alpha_reduce_kernel(DeviceLP lp, int n_slices) {
+    if (lp.ctl->status != ST_RUNNING) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= lp.m) return;
+    double acc = 0.0;
+    for (int c0 = 0; c0 < n_slices; c0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (c0 + u < n_slices) ? lp.alpha_part[(size_t)(c0 + u) * lp.m + i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    lp.alpha_part[i] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1197,9 +1213,11 @@ __global__ void __launch_bounds__(256) residual_kernel(DeviceLP lp, const double
 }
 
 // C = X + X R  (m x m, f64, row-major with leading dimension ld).  LDS-tiled 64x64 per workgroup, 4x4 per thread.
+// MODE 1: C = I - X R (the residual S = I - B' T for DENSE bases, X = B' gathered dense).
 constexpr int GT = 64, GK = 16;
+template <int MODE>
 __global__ void __launch_bounds__(256) gemm_polish_kernel(const double* __restrict__ X, const double* __restrict__ R,
-                                                        double* __restrict__ C, int m, int ld) {
+                                                        double* __restrict__ C, int m, int ld, double* residual_max) {
     __shared__ double sA[GK][GT + 1];
     __shared__ double sB[GK][GT + 1];
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
@@ -1230,6 +1248,7 @@ __global__ void __launch_bounds__(256) gemm_polish_kernel(const double* __restri
         }
         __syncthreads();
     }
+    double local_max = 0.0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int gr = row0 + ty * 4 + u;
@@ -1237,9 +1256,32 @@ __global__ void __launch_bounds__(256) gemm_polish_kernel(const double* __restri
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int gc = col0 + tx * 4 + v;
-            if (gc < m) C[(size_t)gr * ld + gc] = X[(size_t)gr * ld + gc] + acc[u][v];
+            if (gc < m) {
+                if (MODE == 0) {
+                    C[(size_t)gr * ld + gc] = X[(size_t)gr * ld + gc] + acc[u][v];
+                } else {
+                    const double r = (gr == gc ? 1.0 : 0.0) - acc[u][v];
+                    C[(size_t)gr * ld + gc] = r;
+                    local_max = fmax(local_max, fabs(r));
+                }
+            }
         }
     }
+    if (MODE == 1) {
+        __shared__ double s_red[6];
+        const double blk = -block_reduce<1>(-local_max, s_red);
+        if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(residual_max), (unsigned long long)__double_as_longlong(blk));
+    }
+}
+
+// Bd[k][r] = B[r][k]: row k of Bd is column basis[k] of A, dense (zero-filled).
+__global__ void gather_basis_kernel(DeviceLP lp, double* Bd) {
+    const int k = blockIdx.x;
+    const int col = lp.basis[k];
+    for (int r = threadIdx.x; r < lp.m; r += blockDim.x) Bd[(size_t)k * lp.ld + r] = 0.0;
+    __syncthreads();
+    for (int e = lp.col_start[col] + threadIdx.x; e < lp.col_start[col + 1]; e += blockDim.x)
+        Bd[(size_t)k * lp.ld + lp.row_index[e]] = lp.value[e];
 }
 
 // T0 = s * B  (T0[r][k] = s B[r][k]; X0 = T0' = s B'): start of a from-scratch Newton-Schulz inversion.
@@ -1393,7 +1435,16 @@ void launch_residual(const DeviceLP& d, const double* T, double* S, hipStream_t 
 }
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s) {
     dim3 grid((m + GT - 1) / GT, (m + GT - 1) / GT);
-    hipLaunchKernelGGL(gemm_polish_kernel, grid, dim3(256), 0, s, X, R, C, m, ld);
+    hipLaunchKernelGGL((gemm_polish_kernel<0>), grid, dim3(256), 0, s, X, R, C, m, ld, (double*)nullptr);
+}
+// S = I - B' T for a dense basis: gather B' into `Bd`, then one GEMM (also records max |S|)
+void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, hipStream_t s) {
+    hipLaunchKernelGGL(gather_basis_kernel, dim3(d.m), dim3(256), 0, s, d, Bd);
+    dim3 grid((d.m + GT - 1) / GT, (d.m + GT - 1) / GT);
+    hipLaunchKernelGGL((gemm_polish_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual);
+}
+void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s) {
+    hipLaunchKernelGGL(alpha_reduce_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d, n_slices);
 }
 void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s) {
     hipLaunchKernelGGL(scaled_basis_kernel, dim3(d.m), dim3(64), 0, s, d, T, scale);

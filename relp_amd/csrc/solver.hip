@@ -33,6 +33,8 @@ void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s);
 void launch_identity(double* X, int m, int ld, hipStream_t s);
 void launch_residual(const DeviceLP& d, const double* X, double* R, hipStream_t s);
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s);
+void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, hipStream_t s);
+void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s);
 void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s);
 void launch_row_scan(const DeviceLP& d, int r, double tol, hipStream_t s);
 void launch_ftran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
@@ -316,7 +318,7 @@ void Solver::launch_pivots(int count) {
         enqueue_ftran_ratio(0);
         launch_update(d_, stream_);
     }
-    stats_.launches += 1 + (3LL + (dense_blocks_ > 0) + 2 * (ftran_slices_ > 0)) * count;
+    stats_.launches += 1 + (3LL + (dense_blocks_ > 0) + 3 * (ftran_slices_ > 0)) * count;
     stats_.price_launches += count;
 }
 
@@ -336,8 +338,9 @@ void Solver::enqueue_ftran_ratio(int mode) {
     if (ftran_slices_ > 0) {
         launch_select(d_, slots, opt_.pivot_rule, stream_);
         launch_ftran_partial(d_, ftran_slices_, stream_);
+        launch_alpha_reduce(d_, ftran_slices_, stream_);
     }
-    launch_ftran_ratio(d_, opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, ftran_slices_, stream_);
+    launch_ftran_ratio(d_, opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, ftran_slices_ > 0 ? 1 : 0, stream_);
 }
 
 void Solver::build_graph(int count) {
@@ -360,7 +363,8 @@ void Solver::polish(bool refresh_vectors) {
     const int m = d_.m;
     for (int it = 0; it < 2; ++it) {
         RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
-        launch_residual(d_, d_.Binv, d_.R, stream_);
+        if (d_.n_dense > 0) launch_residual_dense(d_, d_.Binv2, d_.Binv, d_.R, stream_);
+        else launch_residual(d_, d_.Binv, d_.R, stream_);
         launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, stream_);
         RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
         Ctl c = read_ctl();
