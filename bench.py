@@ -138,6 +138,15 @@ def main():
         dominant = max(("price", "update"), key=lambda k: seconds[k])
         bytes_per_launch = stats.price_bytes if dominant == "price" else stats.update_bytes
         achieved = bytes_per_launch / seconds[dominant] / 1e9
+        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; see
+        # profiles/r1_dense4096_pmc_traffic.json and MI355X_MICROARCH.md section HBM); null when not collected
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_%s_pmc_traffic.json" % args.workload)
+        if os.path.exists(pmc):
+            names = {"price": "relp::price_dense_kernel" if dense else "void relp::price_kernel<0, true, 8>", "update": "relp::update_kernel"}
+            entry = json.load(open(pmc)).get(names[dominant])
+            if entry:
+                traffic = entry["hbm_bytes_corrected"]
         if dense:
             workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing" % path
             data = "synthetic"
@@ -155,7 +164,7 @@ def main():
                        "objective": last.objective, "wall_clock_to_optimal_s": last.solve_seconds,
                        "parallelism": "1 LP per GPU x%d" % world, "exact": exact},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline and not dense:
