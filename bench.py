@@ -23,6 +23,7 @@ WORKLOADS = {
     "25fv47": os.path.join(ROOT, "data", "netlib", "25FV47.SIF"),   # BASELINE configs[1]: the default, the metric's config
     "dense4096": (4096, 8192),                                          # BASELINE configs[2]: the HBM-roofline config
     "dense1024": (1024, 2048),
+    "netlib": "batch",   # BASELINE configs[3]: the Netlib problems the reference's suite enables, one LP per GPU at a time
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -66,6 +67,68 @@ def cpu_baseline(path, budget_seconds):
                       "relp's LU/Forrest-Tomlin steepest-edge path; early pivots are the cheap ones%s)" % (pivots, elapsed, full)}
 
 
+def netlib_batch(args, rank, local_rank, world, distributed):
+    """Config 4: independent LPs shard across ranks (static longest-first assignment, relp_amd.batch.assign); every LP
+    is resident in HBM before the timed region; value = pivots of all ranks / makespan (max over ranks)."""
+    import glob
+    import torch
+    import relp_amd
+    from relp_amd import batch
+    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))
+    names = sorted(n for n, e in expected.items() if os.path.exists(os.path.join(ROOT, "data", "netlib", n + ".SIF"))
+                   and (not e["ignored"] or "intensive" in e["ignored"]))
+    models = {}
+    costs = []
+    for name in names:
+        model = relp_amd.Model(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+        models[name] = model
+        costs.append((name, float(model.nr_rows) * float(model.nnz + model.nr_columns)))
+    mine = batch.assign(costs, world)[rank]
+    solvers = {name: relp_amd.Solver(device=local_rank).load_model(models[name]) for name in mine}
+    records = []
+
+    def run_all():
+        pivots = 0
+        for name in mine:
+            r = solvers[name].solve_relaxation()
+            pivots += r.pivots_phase_one + r.pivots_phase_two
+            records.append((name, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds))
+        return pivots
+
+    for _ in range(args.warmup):
+        run_all()
+    if distributed:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    pivots = 0
+    for _ in range(args.steps):
+        del records[:]
+        pivots += run_all()
+    if distributed:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed, pivots = batch.aggregate(time.perf_counter() - start, pivots, device="cuda" if distributed else None)
+    gathered = batch.gather_records(list(records))
+    if rank == 0:
+        wrong = []
+        for rank_records in gathered:
+            for name, objective, _, _ in rank_records:
+                e = expected[name]
+                tolerance = max(e["tolerance"], 2e-5 if name == "25FV47" else 0.0)
+                if abs(objective - e["expected"]) > tolerance:
+                    wrong.append(name)
+        print(json.dumps({
+            "metric": "simplex pivots/sec, Netlib suite batched one LP per GPU", "value": pivots / elapsed, "unit": "pivots/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "%d Netlib .SIF files shipped under data/netlib" % len(names),
+            "config": {"workload": "Netlib batch (%d LPs), static longest-first assignment, one LP per GPU at a time" % len(names),
+                       "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}}))
+    if distributed:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -88,6 +151,8 @@ def main():
 
     import relp_amd
     path = WORKLOADS[args.workload]
+    if path == "batch":
+        return netlib_batch(args, rank, local_rank, world, distributed)
     dense = not isinstance(path, str)
     if dense:
         from relp_amd.workloads import dense_lp

@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
         v_rho = s_rho;
         v_w = s_w;
     }
+    static_assert(LPC == ELL_W, "one lane per padded entry");
     constexpr int CPB = 256 / LPC;  // columns per workgroup pass
     const int g = threadIdx.x / LPC, sub = threadIdx.x % LPC;
 
@@ -247,22 +248,31 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
     best.idx = -1;
     best.aux = 0;
     double best_cbar = 0.0;
+    int best_row = 0, best_len = 0;  // this lane's padded entry of the group's best column so far
+    double best_val = 0.0;
     for (int base = col_first + blockIdx.x * CPB; base < col_last; base += gridDim.x * CPB) {
         const int j = base + g;
         const bool valid = j < col_last;
-        int a = 0, b = 0;
+        int a = 0, b = 0, r0 = 0;
+        double v0 = 0.0;
         bool nonbasic = false;
         double cost_j = 0.0, g_j = 1.0;
-        if (valid) {
+        if (valid) {  // every load below is independent of the others: one memory round trip
             nonbasic = lp.pos[j] < 0;
             a = lp.col_start[j];
             b = lp.col_start[j + 1];
+            r0 = lp.ell_rows[(size_t)j * ELL_W + sub];
+            v0 = lp.ell_vals[(size_t)j * ELL_W + sub];
             cost_j = lp.cost[j];
             if (RULE == RELP_PIVOT_STEEPEST_EDGE) g_j = lp.gamma[j];
         }
-        if (!nonbasic) b = a;
-        double d_pi = 0.0, d_rho = 0.0, d_w = 0.0;
-        for (int e = a + sub; e < b; e += LPC) {
+        if (!nonbasic) { b = a; v0 = 0.0; }
+        double d_pi = v0 * v_pi[r0], d_rho = 0.0, d_w = 0.0;
+        if (pending) {
+            d_rho = v0 * v_rho[r0];
+            d_w = v0 * v_w[r0];
+        }
+        for (int e = a + ELL_W + sub; e < b; e += LPC) {  // columns longer than the padded width (rare)
             const int r = lp.row_index[e];
             const double v = lp.value[e];
             d_pi += v * v_pi[r];
@@ -279,42 +289,62 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                 d_w += __shfl_xor(d_w, off);
             }
         }
-        if (sub != 0 || !nonbasic) continue;
-        double gam = g_j;
-        if (RULE == RELP_PIVOT_STEEPEST_EDGE && pending) {
-            if (j == leaving) {
-                gam = gamma_q / (alpha_pq * alpha_pq);  // pivot_rule.rs:294-295
-            } else {
-                const double sq = d_rho * d_rho;  // pivot_rule.rs:262-288 (Goldfarb-Reid)
-                gam = gam - 2.0 * d_rho * d_w + sq * gamma_q;
-                gam = fmax(gam, 1.0 + sq);
+        int improved = 0;
+        if (sub == 0 && nonbasic) {
+            double gam = g_j;
+            if (RULE == RELP_PIVOT_STEEPEST_EDGE && pending) {
+                if (j == leaving) {
+                    gam = gamma_q / (alpha_pq * alpha_pq);  // pivot_rule.rs:294-295
+                } else {
+                    const double sq = d_rho * d_rho;  // pivot_rule.rs:262-288 (Goldfarb-Reid)
+                    gam = gam - 2.0 * d_rho * d_w + sq * gamma_q;
+                    gam = fmax(gam, 1.0 + sq);
+                }
+                lp.gamma[j] = gam;
             }
-            lp.gamma[j] = gam;
-        }
-        const double cbar = cost_j + d_pi;
-        if (cbar < -tol_dual) {
+            const double cbar = cost_j + d_pi;
+            bool candidate = cbar < -tol_dual;
             Cand c;
             c.idx = j;
             c.aux = 0;
+            c.key = 0.0;
             if (RULE == RELP_PIVOT_STEEPEST_EDGE) c.key = cbar * cbar / gam;
             else if (RULE == RELP_PIVOT_DANTZIG) c.key = -cbar;
             else if (RULE == RELP_PIVOT_FIRST_PROFITABLE) c.key = -(double)j;
             else {
-                if (last >= 0 && j == last) continue;
+                if (last >= 0 && j == last) candidate = false;
                 const long long rank = (last < 0) ? j : (j > last ? (long long)j - last - 1 : (long long)j + lp.n - last);
                 c.key = -(double)rank;
             }
-            Cand nb = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(best, c) : better<TIE_SMALLER_IDX>(best, c);
-            if (nb.idx == j) best_cbar = cbar;
-            best = nb;
+            if (candidate) {
+                Cand nb = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(best, c) : better<TIE_SMALLER_IDX>(best, c);
+                if (nb.idx == j) {
+                    best_cbar = cbar;
+                    improved = 1;
+                }
+                best = nb;
+            }
+        }
+        improved = __shfl(improved, threadIdx.x & (WAVE - 1) & ~(LPC - 1));  // the group's lane 0 decides
+        if (improved) {
+            best_row = r0;
+            best_val = v0;
+            best_len = b - a;
         }
     }
     Cand blk = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(best, s_cand)
                                                   : block_best<TIE_SMALLER_IDX>(best, s_cand);
-    if (blk.idx >= 0 && blk.idx == best.idx) {  // the winning thread publishes
+    int winner = (sub == 0 && blk.idx >= 0 && blk.idx == best.idx) ? 1 : 0;
+    if (winner) {  // the winning thread publishes
         lp.cand_key[cand_offset + blockIdx.x] = blk.key;
         lp.cand_j[cand_offset + blockIdx.x] = blk.idx;
         lp.cand_cbar[cand_offset + blockIdx.x] = best_cbar;
+        lp.cand_len[cand_offset + blockIdx.x] = best_len;
+    }
+    winner = __shfl(winner, threadIdx.x & (WAVE - 1) & ~(LPC - 1));
+    if (winner) {  // its group publishes the column's padded entries
+        lp.cand_rows[(size_t)(cand_offset + blockIdx.x) * ELL_W + sub] = best_row;
+        lp.cand_vals[(size_t)(cand_offset + blockIdx.x) * ELL_W + sub] = best_val;
     }
     if (blk.idx < 0 && threadIdx.x == 0) lp.cand_j[cand_offset + blockIdx.x] = -1;
 }
@@ -417,6 +447,7 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
     Cand blk = block_best<TIE_LARGER_IDX>(best, s_cand);
     if (threadIdx.x == 0) {
         lp.cand_j[cand_offset + blockIdx.x] = blk.idx;
+        lp.cand_len[cand_offset + blockIdx.x] = -1;  // column not inlined with the candidate: K2 reads it from the CSC
         if (blk.idx >= 0) {
             lp.cand_key[cand_offset + blockIdx.x] = blk.key;
             lp.cand_cbar[cand_offset + blockIdx.x] = s_cbar[blk.aux];
@@ -743,6 +774,7 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
 // ---------------------------------------------------------------------------------------------------
 constexpr int K2F_THREADS = 512;
 constexpr int K2F_MAX_BLOCKS = 2048;
+constexpr int K2F_INLINE_BLOCKS = 128;  // candidate columns staged with the candidates when there are at most this many
 template <int RULE, int R>
 __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP lp, int n_price_blocks, double tol_pivot,
                                                                      double harris_delta, int skip_artificial_rows,
@@ -752,6 +784,9 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     __shared__ double s_red[K2F_THREADS / WAVE + 2];
     __shared__ double s_red2[K2F_THREADS / WAVE + 2];
     __shared__ double s_cbarv[K2F_MAX_BLOCKS];
+    __shared__ int s_crows[K2F_INLINE_BLOCKS * ELL_W];
+    __shared__ double s_cvals[K2F_INLINE_BLOCKS * ELL_W];
+    __shared__ int s_clen[K2F_INLINE_BLOCKS];
     __shared__ int s_rows[K2_COL_CHUNK];
     __shared__ double s_vals[K2_COL_CHUNK];
     __shared__ int s_wcount[R][K2F_THREADS / WAVE];
@@ -790,7 +825,15 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             s_cbarv[b] = lp.cand_cbar[b];
             c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
         }
+        if (n_price_blocks <= K2F_INLINE_BLOCKS) {
+            for (int e = tid; e < n_price_blocks * ELL_W; e += K2F_THREADS) {
+                s_crows[e] = lp.cand_rows[e];
+                s_cvals[e] = lp.cand_vals[e];
+            }
+            for (int b = tid; b < n_price_blocks; b += K2F_THREADS) s_clen[b] = lp.cand_len[b];
+        }
     }
+    const bool inline_column = forced_q < 0 && !preselected && n_price_blocks <= K2F_INLINE_BLOCKS;
     if (status != ST_RUNNING) return;
     STAMP(0);
     if (mode == 0 && iters >= budget) {
@@ -803,6 +846,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     // ---- entering column --------------------------------------------------------------------------
     int q;
     double cbar_q;
+    int winner_block = 0;
     if (preselected && forced_q < 0) {
         q = ctl->q;
         cbar_q = ctl->cbar_q;
@@ -810,6 +854,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
         q = c.idx;
         cbar_q = q >= 0 ? s_cbarv[c.aux] : 0.0;
+        winner_block = c.aux;
     } else {
         q = forced_q;
         if (tid == 0) {
@@ -840,10 +885,34 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         return;
     }
     // ---- FTRAN (round trips 2-4) --------------------------------------------------------------------
-    const int ca = lp.col_start[q], cb_ = preselected ? lp.col_start[q] : lp.col_start[q + 1];
     double al[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) al[r] = 0.0;
+    int ca = 0, cb_ = 0;
+    if (inline_column) {
+        // the padded entries of the winning column arrived with the candidates: FTRAN starts without another fetch
+        const int len = s_clen[winner_block];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * K2F_THREADS;
+            if (i >= m || len < 0) continue;
+            const double* col = lp.Binv + i;
+            double t[ELL_W];
+#pragma unroll
+            for (int e = 0; e < ELL_W; ++e) t[e] = col[(size_t)s_crows[winner_block * ELL_W + e] * ld];  // padding: row 0, value 0
+            double a0 = 0.0;
+#pragma unroll
+            for (int e = 0; e < ELL_W; ++e) a0 += t[e] * s_cvals[winner_block * ELL_W + e];
+            al[r] = a0;
+        }
+        if (len > ELL_W || len < 0) {  // rare: the rest of a long column (or all of a dense one) from the CSC
+            ca = lp.col_start[q] + (len < 0 ? 0 : ELL_W);
+            cb_ = lp.col_start[q + 1];
+        }
+    } else if (!preselected) {
+        ca = lp.col_start[q];
+        cb_ = lp.col_start[q + 1];
+    }
     if (preselected) {
         for (int sl = 0; sl < n_alpha_slices; ++sl) {
 #pragma unroll
@@ -1063,7 +1132,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     const double r0 = c0[p] / alpha_pq;  // row p of the new inverse
     const double r1 = c1[p] / alpha_pq;
     double w0 = 0.0, w1 = 0.0;
-    constexpr int U = 4;  // independent loads in flight per lane and column
+    constexpr int U = 8;  // independent loads in flight per lane and column
     for (int k0 = lane; k0 < count; k0 += U * WAVE) {
         int idx[U];
         double a[U], o0[U], o1[U];

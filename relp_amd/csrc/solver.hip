@@ -86,7 +86,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -208,6 +208,23 @@ void Solver::upload() {
     d_.cand_key = dmalloc<double>(price_blocks_ + dense_blocks_);
     d_.cand_j = dmalloc<int>(price_blocks_ + dense_blocks_);
     d_.cand_cbar = dmalloc<double>(price_blocks_ + dense_blocks_);
+    d_.cand_rows = dmalloc<int>((size_t)(price_blocks_ + dense_blocks_) * ELL_W);
+    d_.cand_vals = dmalloc<double>((size_t)(price_blocks_ + dense_blocks_) * ELL_W);
+    d_.cand_len = dmalloc<int>(price_blocks_ + dense_blocks_);
+    {
+        std::vector<int> er((size_t)n * ELL_W, 0);
+        std::vector<double> ev((size_t)n * ELL_W, 0.0);
+        for (int j = 0; j < n; ++j)
+            for (int e = col_start[j], k = 0; e < col_start[j + 1] && k < ELL_W; ++e, ++k) {
+                er[(size_t)j * ELL_W + k] = row_index[e];
+                ev[(size_t)j * ELL_W + k] = value[e];
+            }
+        d_.ell_rows = dmalloc<int>(er.size());
+        d_.ell_vals = dmalloc<double>(ev.size());
+        upload_vec(d_.ell_rows, er, stream_);
+        upload_vec(d_.ell_vals, ev, stream_);
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
     d_.alpha_part = dmalloc<double>((size_t)std::max(1, ftran_slices_) * m);
     if (n_dense > 0) {
         std::vector<double> dense((size_t)n_dense * d_.dense_ld, 0.0);

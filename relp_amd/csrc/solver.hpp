@@ -38,6 +38,8 @@ struct Ctl {
     int nz_count;      // entries of the ordered non-zero list of alpha_q (written by K2, read by K3)
 };
 
+constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
+
 enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3 };
 
 struct DeviceLP {
@@ -74,6 +76,12 @@ struct DeviceLP {
     double* cand_key = nullptr;  // per pricing block
     int* cand_j = nullptr;
     double* cand_cbar = nullptr;
+    int* cand_rows = nullptr;    // first ELL_W entries of each block's best column (so K2 needs no dependent fetch)
+    double* cand_vals = nullptr;
+    int* cand_len = nullptr;     // nnz of that column (> ELL_W: the rest comes from the CSC)
+    // padded copy of the first ELL_W entries of every column (value 0 padding): no col_start dependency in K1
+    int* ell_rows = nullptr;
+    double* ell_vals = nullptr;
     double* scratch = nullptr;   // m or n doubles for the fine-grained ops
     Ctl* ctl = nullptr;
     unsigned long long* dbg = nullptr;  // diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of K2
