@@ -143,7 +143,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("RELP_FORCE_DISTRIBUTED") == "1"  # the env switch exercises the RCCL path at N=1
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

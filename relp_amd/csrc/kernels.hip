@@ -62,6 +62,7 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
 
 constexpr int DPP_QUAD_1032 = 0xB1;    // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_2301 = 0x4E;    // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <-> 7 - i inside each group of 8
 constexpr int DPP_ROW_ROR4 = 0x124;    // row_ror:4
 constexpr int DPP_ROW_ROR8 = 0x128;    // row_ror:8
 constexpr int DPP_ROW_BCAST15 = 0x142; // lane 15 of each row -> every lane of the next row
@@ -200,64 +201,28 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                                                     int col_last, int cand_offset) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[8];
+    static_assert(LPC == ELL_W, "one lane per padded entry");
+    constexpr int CPB = 256 / LPC;  // columns per workgroup pass
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING) return;
     const int m = lp.m;
+    const int g = threadIdx.x / LPC, sub = threadIdx.x % LPC;
+    // ---- ONE memory round trip: control word, this workgroup's first columns, and the three vectors ----------
+    const int status = ctl->status;
     const int pending = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? (ctl->pending && !skip_weights) : 0;
     const double gamma_q = ctl->gamma_q;
     const double alpha_pq = ctl->alpha_pq;
     const int leaving = ctl->leaving;
     const int last = ctl->last_selected;
-    const double* v_pi = lp.minus_pi;
-    const double* v_rho = lp.rho;
-    const double* v_w = lp.w;
-    if (USE_LDS) {
-        double* s_pi = smem;
-        double* s_rho = smem + m;
-        double* s_w = smem + 2 * m;
-        for (int base = threadIdx.x; base < m; base += 4 * 256) {
-            double t_pi[4], t_rho[4], t_w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * 256;
-                t_pi[u] = i < m ? lp.minus_pi[i] : 0.0;
-                t_rho[u] = (pending && i < m) ? lp.rho[i] : 0.0;
-                t_w[u] = (pending && i < m) ? lp.w[i] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * 256;
-                if (i < m) {
-                    s_pi[i] = t_pi[u];
-                    s_rho[i] = t_rho[u];
-                    s_w[i] = t_w[u];
-                }
-            }
-        }
-        __syncthreads();
-        v_pi = s_pi;
-        v_rho = s_rho;
-        v_w = s_w;
-    }
-    static_assert(LPC == ELL_W, "one lane per padded entry");
-    constexpr int CPB = 256 / LPC;  // columns per workgroup pass
-    const int g = threadIdx.x / LPC, sub = threadIdx.x % LPC;
-
-    Cand best;
-    best.key = 0.0;
-    best.idx = -1;
-    best.aux = 0;
-    double best_cbar = 0.0;
-    int best_row = 0, best_len = 0;  // this lane's padded entry of the group's best column so far
-    double best_val = 0.0;
-    for (int base = col_first + blockIdx.x * CPB; base < col_last; base += gridDim.x * CPB) {
-        const int j = base + g;
-        const bool valid = j < col_last;
-        int a = 0, b = 0, r0 = 0;
-        double v0 = 0.0;
-        bool nonbasic = false;
-        double cost_j = 0.0, g_j = 1.0;
-        if (valid) {  // every load below is independent of the others: one memory round trip
+    int base = col_first + blockIdx.x * CPB;
+    int a = 0, b = 0, r0 = 0;
+    double v0 = 0.0, cost_j = 0.0, g_j = 1.0;
+    bool nonbasic = false;
+    auto load_column = [&](int j) {
+        a = b = r0 = 0;
+        v0 = cost_j = 0.0;
+        g_j = 1.0;
+        nonbasic = false;
+        if (j < col_last) {
             nonbasic = lp.pos[j] < 0;
             a = lp.col_start[j];
             b = lp.col_start[j + 1];
@@ -266,6 +231,50 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
             cost_j = lp.cost[j];
             if (RULE == RELP_PIVOT_STEEPEST_EDGE) g_j = lp.gamma[j];
         }
+    };
+    load_column(base + g);
+    const double* v_pi = lp.minus_pi;
+    const double* v_rho = lp.rho;
+    const double* v_w = lp.w;
+    if (USE_LDS) {
+        double* s_pi = smem;
+        double* s_rho = smem + m;
+        double* s_w = smem + 2 * m;
+        for (int i0 = threadIdx.x; i0 < m; i0 += 4 * 256) {
+            double t_pi[4], t_rho[4], t_w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                t_pi[u] = i < m ? lp.minus_pi[i] : 0.0;
+                t_rho[u] = i < m ? lp.rho[i] : 0.0;
+                t_w[u] = i < m ? lp.w[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < m) {
+                    s_pi[i] = t_pi[u];
+                    s_rho[i] = t_rho[u];
+                    s_w[i] = t_w[u];
+                }
+            }
+        }
+        v_pi = s_pi;
+        v_rho = s_rho;
+        v_w = s_w;
+    }
+    if (status != ST_RUNNING) return;  // uniform: every thread read the same word
+    if (USE_LDS) __syncthreads();
+
+    Cand best;
+    best.key = 0.0;
+    best.idx = -1;
+    best.aux = 0;
+    double best_cbar = 0.0;
+    int best_row = 0, best_len = 0;  // this lane's padded entry of the group's best column so far
+    double best_val = 0.0;
+    while (base < col_last) {
+        const int j = base + g;
         if (!nonbasic) { b = a; v0 = 0.0; }
         double d_pi = v0 * v_pi[r0], d_rho = 0.0, d_w = 0.0;
         if (pending) {
@@ -281,13 +290,17 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                 d_w += v * v_w[r];
             }
         }
-#pragma unroll
-        for (int off = LPC / 2; off > 0; off >>= 1) {
-            d_pi += __shfl_xor(d_pi, off);
-            if (RULE == RELP_PIVOT_STEEPEST_EDGE) {
-                d_rho += __shfl_xor(d_rho, off);
-                d_w += __shfl_xor(d_w, off);
-            }
+        // 8-lane group sums with DPP moves (quad_perm, quad_perm, row_half_mirror): every lane of the group gets the total
+        d_pi += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, d_pi);
+        d_pi += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_pi);
+        d_pi += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_pi);
+        if (RULE == RELP_PIVOT_STEEPEST_EDGE) {
+            d_rho += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, d_rho);
+            d_rho += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_rho);
+            d_rho += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_rho);
+            d_w += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, d_w);
+            d_w += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_w);
+            d_w += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_w);
         }
         int improved = 0;
         if (sub == 0 && nonbasic) {
@@ -331,6 +344,8 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
             best_val = v0;
             best_len = b - a;
         }
+        base += gridDim.x * CPB;
+        if (base < col_last) load_column(base + g);
     }
     Cand blk = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(best, s_cand)
                                                   : block_best<TIE_SMALLER_IDX>(best, s_cand);
@@ -572,7 +587,6 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     __shared__ double s_cbar;
     __shared__ int s_rows[K2_COL_CHUNK];
     __shared__ double s_vals[K2_COL_CHUNK];
-    __shared__ int s_wcount[K2_THREADS / WAVE];
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING) return;
     if (mode == 0 && ctl->iters >= ctl->budget) {
@@ -718,31 +732,9 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     // ---- x_B update (carry/mod.rs:295-325) and the ordered non-zero list of alpha for K3 ----------------
     const double alpha_pq = lp.alpha[p];
     const double xp = fmax(lp.xB[p], 0.0) / alpha_pq;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = threadIdx.x / WAVE;
-    int total = 0;
+    const int total = 0;
     __syncthreads();  // every thread has read xB[p] before it is overwritten
-    for (int base = 0; base < m; base += blockDim.x) {
-        const int i = base + threadIdx.x;
-        double a = 0.0;
-        if (i < m) {
-            a = lp.alpha[i];
-            lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
-        }
-        const bool keep = i < m && (a != 0.0 || i == p);
-        const unsigned long long mask = __ballot(keep);
-        __syncthreads();
-        if (lane == 0) s_wcount[wave] = __popcll(mask);
-        __syncthreads();
-        int offset = total;
-        for (int wv = 0; wv < wave; ++wv) offset += s_wcount[wv];
-        if (keep) {
-            const int slot = offset + __popcll(mask & ((1ull << lane) - 1ull));
-            lp.nz_index[slot] = i;
-            lp.nz_alpha[slot] = a;
-        }
-        for (int wv = 0; wv < K2_THREADS / WAVE; ++wv) total += s_wcount[wv];
-    }
+    for (int i = threadIdx.x; i < m; i += blockDim.x) lp.xB[i] = (i == p) ? xp : lp.xB[i] - lp.alpha[i] * xp;
     if (threadIdx.x == 0) {
         const int leaving = lp.basis[p];
         lp.basis[p] = q;
@@ -789,7 +781,6 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     __shared__ int s_clen[K2F_INLINE_BLOCKS];
     __shared__ int s_rows[K2_COL_CHUNK];
     __shared__ double s_vals[K2_COL_CHUNK];
-    __shared__ int s_wcount[R][K2F_THREADS / WAVE];
     __shared__ double s_bcast[4];
     __shared__ int s_ibcast[2];
     Ctl* ctl = lp.ctl;
@@ -1045,38 +1036,16 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     const double alpha_pq = s_bcast[1];
     const double xp = fmax(s_bcast[2], 0.0) / alpha_pq;
     const int leaving = s_ibcast[0];
-    // ---- x_B update (carry/mod.rs:295-325), alpha, and the ordered non-zero list for K3 -----------------
-    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
-    unsigned long long masks[R];
+    // ---- x_B update (carry/mod.rs:295-325) and alpha for K3 ------------------------------------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = tid + r * K2F_THREADS;
-        const bool keep = i < m && (al[r] != 0.0 || i == p);
-        masks[r] = __ballot(keep);
-        if (lane == 0) s_wcount[r][wave] = __popcll(masks[r]);
         if (i < m) {
             lp.alpha[i] = al[r];
             lp.xB[i] = (i == p) ? xp : xb[r] - al[r] * xp;
         }
     }
-    __syncthreads();
-    int total = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int offset = total;
-        for (int wv = 0; wv < K2F_THREADS / WAVE; ++wv) {
-            const int cnt = s_wcount[r][wv];
-            if (wv < wave) offset += cnt;
-            total += cnt;
-        }
-        const int i = tid + r * K2F_THREADS;
-        const bool keep = i < m && (al[r] != 0.0 || i == p);
-        if (keep) {
-            const int slot = offset + __popcll(masks[r] & ((1ull << lane) - 1ull));
-            lp.nz_index[slot] = i;
-            lp.nz_alpha[slot] = al[r];
-        }
-    }
+    const int total = 0;
     STAMP(5);
     if (tid == 0) {
         lp.basis[p] = q;
@@ -1114,14 +1083,13 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
 // ---------------------------------------------------------------------------------------------------
 constexpr int K3_THREADS = 256;
 constexpr int K3_CPW = 2;  // columns per wave
+// EAGER: alpha and both columns are loaded in the same memory round trip, unconditionally (m small: the kernel is
+// latency bound, the extra reads of rows with alpha_i == 0 hit L2); otherwise the column loads are predicated on
+// alpha_i != 0 (m large: HBM bound, untouched rows cost no traffic).
+template <bool EAGER>
 __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING || !ctl->pending) return;
     const int m = lp.m, ld = lp.ld;
-    const int p = ctl->p;
-    const int count = ctl->nz_count;
-    const double alpha_pq = ctl->alpha_pq;
-    const double cbar_q = ctl->cbar_q;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
     const int j0 = (blockIdx.x * (K3_THREADS / WAVE) + wave) * K3_CPW;
@@ -1129,31 +1097,55 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     const bool two = j0 + 1 < m;
     double* c0 = lp.Binv + (size_t)j0 * ld;
     double* c1 = lp.Binv + (size_t)(two ? j0 + 1 : j0) * ld;
+    // everything below is issued before the first use: one round trip
+    const int status = ctl->status;
+    const int pending = ctl->pending;
+    const int p = ctl->p;
+    const double alpha_pq = ctl->alpha_pq;
+    const double cbar_q = ctl->cbar_q;
+    double pi0 = 0.0, pi1 = 0.0;
+    if (lane == LAST) {
+        pi0 = lp.minus_pi[j0];
+        pi1 = two ? lp.minus_pi[j0 + 1] : 0.0;
+    }
+    constexpr int U = EAGER ? 16 : 8;  // EAGER: 1024 rows in the first round trip
+    double a[U], o0[U], o1[U];
+    if (EAGER) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = lane + u * WAVE;
+            a[u] = i < m ? lp.alpha[i] : 0.0;
+            o0[u] = i < m ? c0[i] : 0.0;
+            o1[u] = i < m ? c1[i] : 0.0;
+        }
+    }
+    if (status != ST_RUNNING || !pending) return;
     const double r0 = c0[p] / alpha_pq;  // row p of the new inverse
     const double r1 = c1[p] / alpha_pq;
     double w0 = 0.0, w1 = 0.0;
-    constexpr int U = 8;  // independent loads in flight per lane and column
-    for (int k0 = lane; k0 < count; k0 += U * WAVE) {
-        int idx[U];
-        double a[U], o0[U], o1[U];
+    for (int base = 0; base < m; base += U * WAVE) {
+        if (!EAGER || base > 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = k0 + u * WAVE;
-            idx[u] = k < count ? lp.nz_index[k] : -1;
-            a[u] = k < count ? lp.nz_alpha[k] : 0.0;
+            for (int u = 0; u < U; ++u) {
+                const int i = base + lane + u * WAVE;
+                a[u] = i < m ? lp.alpha[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + lane + u * WAVE;
+                const bool touch = i < m && (EAGER || a[u] != 0.0 || i == p);
+                o0[u] = touch ? c0[i] : 0.0;
+                o1[u] = touch ? c1[i] : 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            o0[u] = idx[u] >= 0 ? c0[idx[u]] : 0.0;
-            o1[u] = idx[u] >= 0 ? c1[idx[u]] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+            const int i = base + lane + u * WAVE;
             w0 += a[u] * o0[u];
             w1 += a[u] * o1[u];
-            if (idx[u] >= 0) {
-                c0[idx[u]] = (idx[u] == p) ? r0 : o0[u] - a[u] * r0;
-                if (two) c1[idx[u]] = (idx[u] == p) ? r1 : o1[u] - a[u] * r1;
+            if (i < m && (a[u] != 0.0 || i == p)) {
+                c0[i] = (i == p) ? r0 : o0[u] - a[u] * r0;
+                if (two) c1[i] = (i == p) ? r1 : o1[u] - a[u] * r1;
             }
         }
     }
@@ -1162,11 +1154,11 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     if (lane == LAST) {
         lp.w[j0] = w0;
         lp.rho[j0] = r0;
-        lp.minus_pi[j0] -= cbar_q * r0;
+        lp.minus_pi[j0] = pi0 - cbar_q * r0;
         if (two) {
             lp.w[j0 + 1] = w1;
             lp.rho[j0 + 1] = r1;
-            lp.minus_pi[j0 + 1] -= cbar_q * r1;
+            lp.minus_pi[j0 + 1] = pi1 - cbar_q * r1;
         }
     }
 }
@@ -1480,7 +1472,9 @@ void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double 
 
 void launch_update(const DeviceLP& d, hipStream_t s) {
     const int cols_per_block = (K3_THREADS / WAVE) * K3_CPW;
-    hipLaunchKernelGGL(update_kernel, dim3((d.m + cols_per_block - 1) / cols_per_block), dim3(K3_THREADS), 0, s, d);
+    const dim3 grid((d.m + cols_per_block - 1) / cols_per_block);
+    if (d.m <= 2048) hipLaunchKernelGGL((update_kernel<true>), grid, dim3(K3_THREADS), 0, s, d);
+    else hipLaunchKernelGGL((update_kernel<false>), grid, dim3(K3_THREADS), 0, s, d);
 }
 
 void launch_budget(const DeviceLP& d, long long add, hipStream_t s) {
