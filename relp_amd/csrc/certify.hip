@@ -368,121 +368,191 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         for (int i = 0; i < m; ++i)
             if (!has[i]) artificial_rows.push_back(i);
     }
-    IntegerBasis B;
-    B.m = m;
-    B.col_start.assign(m + 1, 0);
-    std::vector<i64> cost_basis(m, 0), rhs_int(m);
-    std::vector<char> in_basis(n_p, 0);
-    for (int k = 0; k < m; ++k) {
-        int c = basis_columns[k];
-        if (c >= 0) {
-            in_basis[c] = 1;
-            for (size_t e = 0; e < columns[c].nnz(); ++e) {
-                i128 v = scaled(columns[c].value[e], row_mult[columns[c].index[e]]);
-                if (!fits(v)) { *message = "scaled coefficient does not fit 62 bits"; return; }
-                B.row_index.push_back(columns[c].index[e]);
-                B.value.push_back((i64)v);
-            }
-            i128 cv = scaled(md.cost_value(c), cost_mult);
-            if (!fits(cv)) { *message = "scaled cost does not fit 62 bits"; return; }
-            cost_basis[k] = (i64)cv;
-        } else {
-            int row = artificial_rows.at(-1 - c);
-            if (!fits(row_mult[row])) { *message = "row multiplier does not fit 62 bits"; return; }
-            B.row_index.push_back(row);
-            B.value.push_back((i64)row_mult[row]);
-        }
-        B.col_start[k + 1] = (int)B.row_index.size();
-    }
+    std::vector<i64> rhs_int(m);
     for (int i = 0; i < m; ++i) {
         i128 v = scaled(rhs[i], row_mult[i]);
         if (!fits(v)) { *message = "scaled right-hand side does not fit 62 bits"; return; }
         rhs_int[i] = (i64)v;
     }
-    const size_t nnz = B.row_index.size();
-    B.row_start.assign(m + 1, 0);
-    B.col_index.resize(nnz);
-    B.row_value.resize(nnz);
-    for (size_t e = 0; e < nnz; ++e) B.row_start[B.row_index[e] + 1]++;
-    for (int i = 0; i < m; ++i) B.row_start[i + 1] += B.row_start[i];
-    {
-        std::vector<int> fill(B.row_start.begin(), B.row_start.end() - 1);
-        for (int k = 0; k < m; ++k)
-            for (int e = B.col_start[k]; e < B.col_start[k + 1]; ++e) {
-                int dst = fill[B.row_index[e]]++;
-                B.col_index[dst] = k;
-                B.row_value[dst] = B.value[e];
-            }
-    }
-
-    // ---- device: C = B^-1 mod p ---------------------------------------------------------------------
-    DeviceBuffers buf;
-    const int ld = 2 * m;
-    u32* dM = buf.alloc<u32>((size_t)m * ld);
-    u32* d_colk = buf.alloc<u32>(m);
-    int* d_info = buf.alloc<int>(4);
-    int* d_col_start = buf.alloc<int>(m + 1);
-    int* d_row_index = buf.alloc<int>(nnz);
-    i64* d_value = buf.alloc<i64>(nnz);
-    int* d_row_start = buf.alloc<int>(m + 1);
-    int* d_col_index = buf.alloc<int>(nnz);
-    i64* d_row_value = buf.alloc<i64>(nnz);
-    RELP_HIP(hipMemcpyAsync(d_col_start, B.col_start.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
-    RELP_HIP(hipMemcpyAsync(d_row_index, B.row_index.data(), nnz * sizeof(int), hipMemcpyHostToDevice, stream));
-    RELP_HIP(hipMemcpyAsync(d_value, B.value.data(), nnz * sizeof(i64), hipMemcpyHostToDevice, stream));
-    RELP_HIP(hipMemcpyAsync(d_row_start, B.row_start.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
-    RELP_HIP(hipMemcpyAsync(d_col_index, B.col_index.data(), nnz * sizeof(int), hipMemcpyHostToDevice, stream));
-    RELP_HIP(hipMemcpyAsync(d_row_value, B.row_value.data(), nnz * sizeof(i64), hipMemcpyHostToDevice, stream));
+    std::vector<int> basis = basis_columns;  // repaired in place by exact pivots when a check fails
+    const int max_repairs = 200;
     const u32 primes[] = {2147483647u, 2147483629u, 2147483587u, 2147483579u};
-    u32 p = 0;
-    for (u32 candidate : primes) {
-        RELP_HIP(hipMemsetAsync(d_info, 0, 4 * sizeof(int), stream));
-        hipLaunchKernelGGL(build_augmented_kernel, dim3(m), dim3(64), 0, stream, dM, m, ld, d_col_start, d_row_index, d_value, candidate);
+
+    for (int round = 0; round <= max_repairs; ++round) {
+        // ---- integer basis (CSC + CSR) ------------------------------------------------------------------
+        IntegerBasis B;
+        B.m = m;
+        B.col_start.assign(m + 1, 0);
+        std::vector<i64> cost_basis(m, 0);
+        std::vector<char> in_basis(n_p, 0);
         for (int k = 0; k < m; ++k) {
-            hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, stream, dM, m, ld, k, candidate, d_colk, d_info);
-            hipLaunchKernelGGL(gj_eliminate_kernel, dim3((ld + 255) / 256, m), dim3(256), 0, stream, dM, m, ld, k, candidate, d_colk, d_info);
+            int c = basis[k];
+            if (c >= 0) {
+                in_basis[c] = 1;
+                for (size_t e = 0; e < columns[c].nnz(); ++e) {
+                    i128 v = scaled(columns[c].value[e], row_mult[columns[c].index[e]]);
+                    if (!fits(v)) { *message = "scaled coefficient does not fit 62 bits"; return; }
+                    B.row_index.push_back(columns[c].index[e]);
+                    B.value.push_back((i64)v);
+                }
+                i128 cv = scaled(md.cost_value(c), cost_mult);
+                if (!fits(cv)) { *message = "scaled cost does not fit 62 bits"; return; }
+                cost_basis[k] = (i64)cv;
+            } else {
+                int row = artificial_rows.at(-1 - c);
+                if (!fits(row_mult[row])) { *message = "row multiplier does not fit 62 bits"; return; }
+                B.row_index.push_back(row);
+                B.value.push_back((i64)row_mult[row]);
+            }
+            B.col_start[k + 1] = (int)B.row_index.size();
         }
-        int info[4];
-        RELP_HIP(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, stream));
-        RELP_HIP(hipStreamSynchronize(stream));
-        if (!info[0]) { p = candidate; break; }
-    }
-    if (p == 0) { *message = "basis singular modulo every trial prime (singular basis?)"; return; }
+        const size_t nnz = B.row_index.size();
+        B.row_start.assign(m + 1, 0);
+        B.col_index.resize(nnz);
+        B.row_value.resize(nnz);
+        for (size_t e = 0; e < nnz; ++e) B.row_start[B.row_index[e] + 1]++;
+        for (int i = 0; i < m; ++i) B.row_start[i + 1] += B.row_start[i];
+        {
+            std::vector<int> fill(B.row_start.begin(), B.row_start.end() - 1);
+            for (int k = 0; k < m; ++k)
+                for (int e = B.col_start[k]; e < B.col_start[k + 1]; ++e) {
+                    int dst = fill[B.row_index[e]]++;
+                    B.col_index[dst] = k;
+                    B.row_value[dst] = B.value[e];
+                }
+        }
 
-    // ---- exact primal and dual solutions ----------------------------------------------------------------
-    ExactVector x, y;
-    if (!dixon_solve(B, rhs_int, 0, p, dM, ld, buf, d_row_start, d_col_index, d_row_value, stream, &x, message)) return;
-    // B' y = c_B: the rows of B' are the columns of B (CSC arrays as CSR)
-    if (!dixon_solve(B, cost_basis, 1, p, dM, ld, buf, d_col_start, d_row_index, d_value, stream, &y, message)) return;
+        // ---- device: C = B^-1 mod p ---------------------------------------------------------------------
+        DeviceBuffers buf;
+        const int ld = 2 * m;
+        u32* dM = buf.alloc<u32>((size_t)m * ld);
+        u32* d_colk = buf.alloc<u32>(m);
+        int* d_info = buf.alloc<int>(4);
+        int* d_col_start = buf.alloc<int>(m + 1);
+        int* d_row_index = buf.alloc<int>(nnz);
+        i64* d_value = buf.alloc<i64>(nnz);
+        int* d_row_start = buf.alloc<int>(m + 1);
+        int* d_col_index = buf.alloc<int>(nnz);
+        i64* d_row_value = buf.alloc<i64>(nnz);
+        RELP_HIP(hipMemcpyAsync(d_col_start, B.col_start.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_row_index, B.row_index.data(), nnz * sizeof(int), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_value, B.value.data(), nnz * sizeof(i64), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_row_start, B.row_start.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_col_index, B.col_index.data(), nnz * sizeof(int), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_row_value, B.row_value.data(), nnz * sizeof(i64), hipMemcpyHostToDevice, stream));
+        u32 p = 0;
+        for (u32 candidate : primes) {
+            RELP_HIP(hipMemsetAsync(d_info, 0, 4 * sizeof(int), stream));
+            hipLaunchKernelGGL(build_augmented_kernel, dim3(m), dim3(64), 0, stream, dM, m, ld, d_col_start, d_row_index, d_value, candidate);
+            for (int k = 0; k < m; ++k) {
+                hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, stream, dM, m, ld, k, candidate, d_colk, d_info);
+                hipLaunchKernelGGL(gj_eliminate_kernel, dim3((ld + 255) / 256, m), dim3(256), 0, stream, dM, m, ld, k, candidate, d_colk, d_info);
+            }
+            int info[4];
+            RELP_HIP(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, stream));
+            RELP_HIP(hipStreamSynchronize(stream));
+            if (!info[0]) { p = candidate; break; }
+        }
+        if (p == 0) { *message = "basis singular modulo every trial prime (singular basis?)"; return; }
+        auto solve = [&](const std::vector<i64>& r, int transpose, ExactVector* out) {
+            return transpose ? dixon_solve(B, r, 1, p, dM, ld, buf, d_col_start, d_row_index, d_value, stream, out, message)
+                             : dixon_solve(B, r, 0, p, dM, ld, buf, d_row_start, d_col_index, d_row_value, stream, out, message);
+        };
 
-    // ---- checks ---------------------------------------------------------------------------------------
-    for (int k = 0; k < m; ++k) {
-        if (x.numer[k].sign() < 0) { *message = "basis not primal feasible in exact arithmetic (row " + std::to_string(k) + ")"; return; }
-        if (basis_columns[k] < 0 && !x.numer[k].is_zero()) { *message = "artificial variable positive in exact arithmetic"; return; }
+        // ---- exact primal and dual solutions ------------------------------------------------------------
+        ExactVector x, y;
+        if (!solve(rhs_int, 0, &x)) return;
+        if (!solve(cost_basis, 1, &y)) return;  // B' y = c_B: the rows of B' are the columns of B
+
+        // ---- checks ---------------------------------------------------------------------------------------
+        int worst_row = -1;  // most negative x_B (all share the positive denominator)
+        for (int k = 0; k < m; ++k) {
+            if (basis[k] < 0 && x.numer[k].sign() > 0) { *message = "artificial variable positive in exact arithmetic"; return; }
+            if (x.numer[k].sign() < 0 && (worst_row < 0 || cmp(x.numer[k], x.numer[worst_row]) < 0)) worst_row = k;
+        }
+        // reduced costs (common positive denominator cost_mult * Dy):  c_j*cost_mult*Dy - sum_i a_ij*row_mult_i*Y_i
+        std::vector<BigInt> dhat(n_p);
+        int worst_col = -1;
+        for (int j = 0; j < n_p; ++j) {
+            if (in_basis[j]) continue;
+            BigInt acc = big_from_i128(scaled(md.cost_value(j), cost_mult)) * y.denom;
+            for (size_t e = 0; e < columns[j].nnz(); ++e)
+                acc = acc - big_from_i128(scaled(columns[j].value[e], row_mult[columns[j].index[e]])) * y.numer[columns[j].index[e]];
+            dhat[j] = acc;
+            if (acc.sign() < 0 && (worst_col < 0 || cmp(acc, dhat[worst_col]) < 0)) worst_col = j;
+        }
+        if (worst_row < 0 && worst_col < 0) {
+            // ---- optimal: objective = (sum_k cost_basis[k] X_k) / (cost_mult * Dx) + fixed ----------------------
+            BigInt num(0);
+            for (int k = 0; k < m; ++k)
+                if (cost_basis[k] != 0) num = num + BigInt(cost_basis[k]) * x.numer[k];
+            BigInt den = big_from_i128(cost_mult) * x.denom;
+            const Rat& fixed = form.fixed_cost;
+            num = num * big_from_i128(fixed.d) + big_from_i128(fixed.n) * den;
+            den = den * big_from_i128(fixed.d);
+            BigInt g = BigInt::gcd(num, den);
+            if (!g.is_zero() && !(g == BigInt(1))) {
+                num = num / g;
+                den = den / g;
+            }
+            *objective = num.to_string() + "/" + den.to_string();
+            *certified = true;
+            *repair_pivots = round;
+            return;
+        }
+        if (round == max_repairs) break;
+        auto scaled_column = [&](int j) {
+            std::vector<i64> r(m, 0);
+            for (size_t e = 0; e < columns[j].nnz(); ++e) r[columns[j].index[e]] = (i64)scaled(columns[j].value[e], row_mult[columns[j].index[e]]);
+            return r;
+        };
+        if (worst_row < 0) {
+            // ---- exact primal simplex pivot: entering = most negative reduced cost, ratio test with Bland ties
+            //      (tableau/mod.rs:287-313) -------------------------------------------------------------------
+            const int q = worst_col;
+            ExactVector alpha;
+            if (!solve(scaled_column(q), 0, &alpha)) return;
+            int leave = -1;
+            for (int k = 0; k < m; ++k) {
+                if (alpha.numer[k].sign() <= 0) continue;
+                if (leave < 0) { leave = k; continue; }
+                // x_k/alpha_k < x_l/alpha_l  <=>  X_k * A_l < X_l * A_k  (A > 0, common denominators cancel)
+                BigInt lhs = x.numer[k] * alpha.numer[leave], rhs2 = x.numer[leave] * alpha.numer[k];
+                int c = cmp(lhs, rhs2);
+                if (c < 0 || (c == 0 && basis[k] < basis[leave])) leave = k;
+            }
+            if (leave < 0) { *message = "exact repair: entering column is unbounded"; return; }
+            basis[leave] = q;
+        } else if (worst_col < 0) {
+            // ---- exact dual simplex pivot on the most infeasible row ---------------------------------------------
+            std::vector<i64> unit(m, 0);
+            unit[worst_row] = 1;
+            ExactVector rho;
+            if (!solve(unit, 1, &rho)) return;  // rho = e_p' B^-1 (scaled rows)
+            int enter = -1;
+            BigInt best_d, best_a;
+            for (int j = 0; j < n_p; ++j) {
+                if (in_basis[j]) continue;
+                BigInt a_pj(0);
+                for (size_t e = 0; e < columns[j].nnz(); ++e)
+                    a_pj = a_pj + big_from_i128(scaled(columns[j].value[e], row_mult[columns[j].index[e]])) * rho.numer[columns[j].index[e]];
+                if (a_pj.sign() >= 0) continue;
+                BigInt neg_a = -a_pj;
+                // d_j / (-a_pj) minimal: d_j * best_a < best_d * neg_a
+                if (enter < 0 || cmp(dhat[j] * best_a, best_d * neg_a) < 0) {
+                    enter = j;
+                    best_d = dhat[j];
+                    best_a = neg_a;
+                }
+            }
+            if (enter < 0) { *message = "exact repair: the LP is infeasible (dual ray)"; return; }
+            basis[worst_row] = enter;
+        } else {
+            *message = "basis neither primal nor dual feasible in exact arithmetic";
+            return;
+        }
     }
-    // reduced costs: (c_j * cost_mult) * Dy - sum_i (a_ij * row_mult_i) * Y_i >= 0   for non-basic provider columns
-    for (int j = 0; j < n_p; ++j) {
-        if (in_basis[j]) continue;
-        BigInt acc = big_from_i128(scaled(md.cost_value(j), cost_mult)) * y.denom;
-        for (size_t e = 0; e < columns[j].nnz(); ++e)
-            acc = acc - big_from_i128(scaled(columns[j].value[e], row_mult[columns[j].index[e]])) * y.numer[columns[j].index[e]];
-        if (acc.sign() < 0) { *message = "basis not dual feasible in exact arithmetic (column " + std::to_string(j) + ")"; return; }
-    }
-    // ---- objective = sum_k c_k x_k + fixed = (sum_k cost_basis[k] X_k) / (cost_mult * Dx) + fixed ----------------
-    BigInt num(0);
-    for (int k = 0; k < m; ++k)
-        if (cost_basis[k] != 0) num = num + BigInt(cost_basis[k]) * x.numer[k];
-    BigInt den = big_from_i128(cost_mult) * x.denom;
-    const Rat& fixed = form.fixed_cost;
-    num = num * big_from_i128(fixed.d) + big_from_i128(fixed.n) * den;
-    den = den * big_from_i128(fixed.d);
-    BigInt g = BigInt::gcd(num, den);
-    if (!g.is_zero() && !(g == BigInt(1))) {
-        num = num / g;
-        den = den / g;
-    }
-    *objective = num.to_string() + "/" + den.to_string();
-    *certified = true;
+    *message = "exact repair did not converge";
 }
 
 }  // namespace relp

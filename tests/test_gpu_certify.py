@@ -52,3 +52,21 @@ def test_uncertified_solve_has_no_exact_objective():
     solver.solve_relaxation()
     with pytest.raises(relp_amd.RelpError):
         solver.objective_exact()
+
+
+@pytest.mark.parametrize("name, tol", [("BLEND", 0.05), ("E226", 0.01), ("SC50A", 0.01), ("ADLITTLE", 0.01), ("SCAGR7", 0.01), ("BRANDY", 0.001)])
+def test_exact_repair_pivots_fix_a_suboptimal_f64_basis(name, tol):
+    """A deliberately sloppy f64 solve (huge dual tolerance) stops on a non-optimal basis; the certificate must notice
+    (exact signs) and repair it with exact simplex pivots, still returning the bit-exact optimum."""
+    golden = GOLDEN[name]
+    solver = relp_amd.Solver(certify=1, tol_dual=tol).load_mps(os.path.join(ROOT, golden["file"]))
+    result = solver.solve_relaxation()
+    if result.kind == relp_amd.INFEASIBLE:
+        pytest.skip("the sloppy tolerance already stops phase one")
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    assert solver.objective_exact() == golden["objective"]
+    expected = float(int(golden["objective"].split("/")[0])) / float(int(golden["objective"].split("/")[1]))
+    if abs(result.objective - expected) > 1e-9 * abs(expected):
+        assert result.exact_repair_pivots > 0  # the f64 vertex was not optimal, so exact pivots were needed
+    solver.close()
