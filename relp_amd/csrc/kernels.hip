@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
+#include <string>
 
 #include "solver.hpp"
 
@@ -1335,6 +1337,83 @@ __global__ void __launch_bounds__(256) gemm_polish_kernel(const double* __restri
     }
 }
 
+// The same two GEMMs on the matrix cores: v_mfma_f64_16x16x4_f64 (one f64 of A and of B per lane: A[row l&15][k l>>4],
+// B[k l>>4][col l&15]; D: col = l&15, row = (l>>4) + 4*reg).  Workgroup tile 64x64 (4 waves, 2x2), wave tile 32x32
+// (2x2 MFMA tiles), K staged 16 at a time through LDS stored k-major with an 80-double row pitch, so that the four
+// k-groups of a wave read disjoint bank halves (conflict-free ds_read_b64).
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int MT = 64, MK = 16, MPITCH = 80;
+template <int MODE>
+__global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict__ X, const double* __restrict__ R,
+                                                      double* __restrict__ C, int m, int ld, double* residual_max) {
+    __shared__ double sA[MK][MPITCH];
+    __shared__ double sB[MK][MPITCH];
+    __shared__ double s_red[6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row0 = blockIdx.y * MT, col0 = blockIdx.x * MT;
+    mfma_f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (mfma_f64x4){0.0, 0.0, 0.0, 0.0};
+    const int ar = tid >> 2, ak = (tid & 3) * 4;   // A tile: row ar, k ak..ak+3
+    const int bk = tid >> 4, bc = (tid & 15) * 4;  // B tile: k bk, col bc..bc+3
+    for (int k0 = 0; k0 < m; k0 += MK) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gr = row0 + ar, gk = k0 + ak + u;
+            av[u] = (gr < m && gk < m) ? X[(size_t)gr * ld + gk] : 0.0;
+            const int gk2 = k0 + bk, gc = col0 + bc + u;
+            bv[u] = (gk2 < m && gc < m) ? R[(size_t)gk2 * ld + gc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sA[ak + u][ar] = av[u];
+            sB[bk][bc + u] = bv[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < MK; kk += 4) {
+            double a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = sA[kk + (lane >> 4)][wr * 32 + t * 16 + (lane & 15)];
+                b[t] = sB[kk + (lane >> 4)][wc * 32 + t * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    double local_max = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gr = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * reg;
+                const int gc = col0 + wc * 32 + j * 16 + (lane & 15);
+                if (gr < m && gc < m) {
+                    if (MODE == 0) {
+                        C[(size_t)gr * ld + gc] = X[(size_t)gr * ld + gc] + acc[i][j][reg];
+                    } else {
+                        const double r = (gr == gc ? 1.0 : 0.0) - acc[i][j][reg];
+                        C[(size_t)gr * ld + gc] = r;
+                        local_max = fmax(local_max, fabs(r));
+                    }
+                }
+            }
+    if (MODE == 1) {
+        const double blk = -block_reduce<1>(-local_max, s_red);
+        if (tid == 0) atomicMax(reinterpret_cast<unsigned long long*>(residual_max), (unsigned long long)__double_as_longlong(blk));
+    }
+}
+
 // Bd[k][r] = B[r][k]: row k of Bd is column basis[k] of A, dense (zero-filled).
 __global__ void gather_basis_kernel(DeviceLP lp, double* Bd) {
     const int k = blockIdx.x;
@@ -1496,15 +1575,21 @@ void launch_identity(double* X, int m, int ld, hipStream_t s) {
 void launch_residual(const DeviceLP& d, const double* T, double* S, hipStream_t s) {
     hipLaunchKernelGGL(residual_kernel, dim3(d.m), dim3(256), 0, s, d, T, S);
 }
+static bool use_mfma_gemm() {
+    static const bool value = [] { const char* e = getenv("RELP_GEMM"); return !(e && std::string(e) == "vector"); }();
+    return value;  // RELP_GEMM=vector selects the plain-FMA kernel (A/B measurements)
+}
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s) {
     dim3 grid((m + GT - 1) / GT, (m + GT - 1) / GT);
-    hipLaunchKernelGGL((gemm_polish_kernel<0>), grid, dim3(256), 0, s, X, R, C, m, ld, (double*)nullptr);
+    if (use_mfma_gemm()) hipLaunchKernelGGL((gemm_mfma_kernel<0>), grid, dim3(256), 0, s, X, R, C, m, ld, (double*)nullptr);
+    else hipLaunchKernelGGL((gemm_polish_kernel<0>), grid, dim3(256), 0, s, X, R, C, m, ld, (double*)nullptr);
 }
 // S = I - B' T for a dense basis: gather B' into `Bd`, then one GEMM (also records max |S|)
 void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, hipStream_t s) {
     hipLaunchKernelGGL(gather_basis_kernel, dim3(d.m), dim3(256), 0, s, d, Bd);
     dim3 grid((d.m + GT - 1) / GT, (d.m + GT - 1) / GT);
-    hipLaunchKernelGGL((gemm_polish_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual);
+    if (use_mfma_gemm()) hipLaunchKernelGGL((gemm_mfma_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual);
+    else hipLaunchKernelGGL((gemm_polish_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual);
 }
 void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s) {
     hipLaunchKernelGGL(alpha_reduce_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d, n_slices);
