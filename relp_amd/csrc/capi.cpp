@@ -53,8 +53,8 @@ int32_t relp_options_default(relp_options* o) {
     std::memset(o, 0, sizeof(*o));
     o->device = 0;
     o->pivot_rule = RELP_PIVOT_STEEPEST_EDGE;  // two_phase/mod.rs:57,68,107
-    o->polish_period = 128;
-    o->pivots_per_launch = 32;
+    o->polish_period = 256;
+    o->pivots_per_launch = 64;
     o->max_pivots = 0;
     o->tol_dual = 1e-9;
     o->tol_pivot = 1e-9;
