@@ -200,8 +200,10 @@ def main():
         reps = 200
         seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(["price", "ftran_ratio", "update"])}
         stats = solver.stats()
-        dominant = max(("price", "update"), key=lambda k: seconds[k])
-        bytes_per_launch = stats.price_bytes if dominant == "price" else stats.update_bytes
+        # the roofline kernel is the pricing pass (the path's only mandatory full sweep over the constraint columns;
+        # its algorithmic bytes are exact: the columns that are non-basic at the profiled state)
+        dominant = "price"
+        bytes_per_launch = stats.price_bytes
         achieved = bytes_per_launch / seconds[dominant] / 1e9
         # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; see
         # profiles/r1_dense4096_pmc_traffic.json and MI355X_MICROARCH.md section HBM); null when not collected

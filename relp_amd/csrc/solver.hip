@@ -709,6 +709,20 @@ double Solver::profile_kernel(int which, int repetitions) {
     c.forced_q = c.q;
     c.forced_p = -1;
     write_ctl(c);
+    if (which == 0) {
+        // algorithmic bytes of THIS pricing pass: columns that are non-basic now
+        std::vector<int> pos(d_.n), cs(d_.n + 1);
+        RELP_HIP(hipMemcpy(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost));
+        RELP_HIP(hipMemcpy(cs.data(), d_.col_start, (d_.n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        long long bytes = 0;
+        for (int j = d_.n_art; j < d_.n; ++j) {
+            if (pos[j] >= 0) continue;
+            const bool dense_col = j >= d_.dense_first && j < d_.dense_first + d_.n_dense;
+            bytes += dense_col ? (long long)m * 8 : (long long)(cs[j + 1] - cs[j]) * 12;
+            bytes += 24;  // cost, gamma read + gamma write
+        }
+        stats_.price_bytes = bytes;
+    }
     // keep the state the kernels overwrite
     RELP_HIP(hipMemcpyAsync(d_.scratch, d_.gamma, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     RELP_HIP(hipMemcpyAsync(d_.Binv2, d_.Binv, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
