@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
 // column with 16-byte loads (1 KiB per wave instruction), 4 loads in flight per lane; -pi, rho_p, w live in LDS
 // (3 x 32 KB at m = 4096).  This is the HBM-roofline kernel: algorithmic bytes = non-basic dense columns * m * 8.
 // ---------------------------------------------------------------------------------------------------
-constexpr int K1D_THREADS = 512;
+constexpr int K1D_THREADS = 1024;
 __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, int skip_weights, double tol_dual, int cand_offset) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[K1D_THREADS / WAVE + 2];
@@ -404,7 +404,10 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
     const int half = mp / 2;
     for (int jd = blockIdx.x * (K1D_THREADS / WAVE) + wave; jd < lp.n_dense; jd += waves_total) {
         const int j = lp.dense_first + jd;
-        if (lp.pos[j] >= 0) continue;  // wave-uniform
+        const int pos_j = lp.pos[j];
+        const double gamma_j = lp.gamma[j];  // issued with the first column loads; used only in the tail
+        const double cost_j = lp.cost[j];
+        if (pos_j >= 0) continue;  // wave-uniform
         const double2* col = reinterpret_cast<const double2*>(lp.dense_val + (size_t)jd * mp);
         const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
         const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
         d_rho = wave_sum(d_rho);
         d_w = wave_sum(d_w);
         if (lane == LAST) {
-            double gam = lp.gamma[j];
+            double gam = gamma_j;
             if (pending) {
                 if (j == leaving) {
                     gam = gamma_q / (alpha_pq * alpha_pq);
@@ -446,7 +449,7 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
                 }
                 lp.gamma[j] = gam;
             }
-            const double cbar = lp.cost[j] + d_pi;
+            const double cbar = cost_j + d_pi;
             if (cbar < -tol_dual) {
                 Cand c;
                 c.idx = j;

@@ -174,7 +174,7 @@ void Solver::upload() {
     sparse_first_ = n_art + n_dense;
     const int cpb = price_columns_per_block();
     price_blocks_ = std::min(1024, (n - sparse_first_ + cpb - 1) / cpb);
-    dense_blocks_ = n_dense > 0 ? std::min(1024, (n_dense + 7) / 8) : 0;
+    dense_blocks_ = n_dense > 0 ? std::min(1024, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one column per wave
     if (price_blocks_ + dense_blocks_ == 0) price_blocks_ = 1;
     price_lds_ = (size_t)3 * m * sizeof(double);
     int max_nnz = 0;
