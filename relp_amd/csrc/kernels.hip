@@ -120,6 +120,73 @@ __device__ __forceinline__ double wave_min(double v) {  // lane 63
 }
 constexpr int LAST = WAVE - 1;
 
+// ---- cheap block-wide arg-max: max of the f64 key, then min of a 64-bit rank among the ties ----------------------
+// A candidate is (key, rank); an empty one has key = -inf.  Two scalar DPP reductions (18 + 30 VALU instructions)
+// replace the struct reduction (about 150), the wave results go through LDS once and EVERY thread scans them, so there is
+// one barrier instead of three.  rank encodes the tie rule (smaller wins) and may carry a payload in its low bits.
+__device__ __forceinline__ double wave_max(double v) {  // lane 63
+    v = fmax(v, dpp_f64<DPP_QUAD_1032, 0xF>(v, v));
+    v = fmax(v, dpp_f64<DPP_QUAD_2301, 0xF>(v, v));
+    v = fmax(v, dpp_f64<DPP_ROW_ROR4, 0xF>(v, v));
+    v = fmax(v, dpp_f64<DPP_ROW_ROR8, 0xF>(v, v));
+    v = fmax(v, dpp_f64<DPP_ROW_BCAST15, 0xA>(v, v));
+    v = fmax(v, dpp_f64<DPP_ROW_BCAST31, 0xC>(v, v));
+    return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const int lo = dpp_i32<CTRL, ROW_MASK>((int)(unsigned)v, (int)(unsigned)v);
+    const int hi = dpp_i32<CTRL, ROW_MASK>((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long umin64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {  // lane 63
+    v = umin64(v, dpp_u64<DPP_QUAD_1032, 0xF>(v));
+    v = umin64(v, dpp_u64<DPP_QUAD_2301, 0xF>(v));
+    v = umin64(v, dpp_u64<DPP_ROW_ROR4, 0xF>(v));
+    v = umin64(v, dpp_u64<DPP_ROW_ROR8, 0xF>(v));
+    v = umin64(v, dpp_u64<DPP_ROW_BCAST15, 0xA>(v));
+    v = umin64(v, dpp_u64<DPP_ROW_BCAST31, 0xC>(v));
+    return v;
+}
+__device__ __forceinline__ double lane63_f64(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned long long lane63_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+constexpr unsigned long long RANK_NONE = ~0ull;
+// s_key / s_rank: one slot per wave.  Returns the winner in (key, rank) for every thread; rank == RANK_NONE: none.
+__device__ __forceinline__ void block_argbest(double& key, unsigned long long& rank, double* s_key, unsigned long long* s_rank) {
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int nwaves = (blockDim.x + WAVE - 1) / WAVE;
+    const double k0 = rank == RANK_NONE ? -INFINITY : key;
+    const double wmax = lane63_f64(wave_max(k0));
+    const unsigned long long tie = (rank != RANK_NONE && k0 == wmax) ? rank : RANK_NONE;
+    const unsigned long long wmin = lane63_u64(wave_min_u64(tie));
+    __syncthreads();  // previous users of the slots are done
+    if (lane == 0) {
+        s_key[wave] = wmax;
+        s_rank[wave] = wmin;
+    }
+    __syncthreads();
+    double bk = -INFINITY;
+    unsigned long long br = RANK_NONE;
+    for (int wv = 0; wv < nwaves; ++wv) {
+        const double k = s_key[wv];
+        const unsigned long long r = s_rank[wv];
+        const bool take = r != RANK_NONE && (br == RANK_NONE || k > bk || (k == bk && r < br));
+        bk = take ? k : bk;
+        br = take ? r : br;
+    }
+    key = bk;
+    rank = br;
+}
+
 // Block-wide argmax; result valid in every thread.  `s` holds at least blockDim.x/64 + 1 entries.
 template <int TIE>
 __device__ __forceinline__ Cand block_best(Cand v, Cand* s) {
@@ -777,7 +844,8 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
                                                                      double harris_delta, int skip_artificial_rows,
                                                                      int mode, int n_alpha_slices) {
     // n_alpha_slices > 0: q was chosen by select_kernel and alpha comes from ftran_partial_kernel's slices
-    __shared__ Cand s_cand[K2F_THREADS / WAVE + 2];
+    __shared__ double s_akey[K2F_THREADS / WAVE];
+    __shared__ unsigned long long s_arank[K2F_THREADS / WAVE];
     __shared__ double s_red[K2F_THREADS / WAVE + 2];
     __shared__ double s_red2[K2F_THREADS / WAVE + 2];
     __shared__ double s_cbarv[K2F_MAX_BLOCKS];
@@ -807,19 +875,23 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         xb[r] = i < m ? lp.xB[i] : 0.0;
         bas[r] = i < m ? lp.basis[i] : 0x7fffffff;
     }
-    Cand c;
-    c.key = 0.0;
-    c.idx = -1;
-    c.aux = 0;
+    // candidate of this thread: key, rank = (tie rule on the column index) << 16 | pricing workgroup
+    double ckey = 0.0;
+    unsigned long long crank = RANK_NONE;
     const bool preselected = n_alpha_slices > 0;
     if (forced_q < 0 && !preselected) {
         for (int b = tid; b < n_price_blocks; b += K2F_THREADS) {
-            Cand o;
-            o.idx = lp.cand_j[b];
-            o.key = lp.cand_key[b];
-            o.aux = b;
+            const int j = lp.cand_j[b];
+            const double k = lp.cand_key[b];
             s_cbarv[b] = lp.cand_cbar[b];
-            c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
+            if (j >= 0) {
+                const unsigned long long order = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? (unsigned long long)(0x7fffffff - j) : (unsigned long long)j;
+                const unsigned long long r = (order << 16) | (unsigned long long)b;
+                if (crank == RANK_NONE || k > ckey || (k == ckey && r < crank)) {
+                    ckey = k;
+                    crank = r;
+                }
+            }
         }
         if (n_price_blocks <= K2F_INLINE_BLOCKS) {
             for (int e = tid; e < n_price_blocks * ELL_W; e += K2F_THREADS) {
@@ -847,10 +919,16 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         q = ctl->q;
         cbar_q = ctl->cbar_q;
     } else if (forced_q < 0) {
-        c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
-        q = c.idx;
-        cbar_q = q >= 0 ? s_cbarv[c.aux] : 0.0;
-        winner_block = c.aux;
+        block_argbest(ckey, crank, s_akey, s_arank);
+        if (crank == RANK_NONE) {
+            q = -1;
+            cbar_q = 0.0;
+        } else {
+            winner_block = (int)(crank & 0xffff);
+            const int order = (int)(crank >> 16);
+            q = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? 0x7fffffff - order : order;
+            cbar_q = s_cbarv[winner_block];
+        }
     } else {
         q = forced_q;
         if (tid == 0) {
@@ -982,22 +1060,21 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     // ---- Harris pass 2 ---------------------------------------------------------------------------------
     int p = forced_p;
     if (forced_p < 0) {
-        Cand h;
-        h.key = 0.0;
-        h.idx = -1;
-        h.aux = 0;
+        // largest eligible pivot, ties by the lowest leaving column (Bland, tableau/mod.rs:295), then the lowest row
+        double hkey = 0.0;
+        unsigned long long hrank = RANK_NONE;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (eligible[r] && fmax(xb[r], 0.0) / al[r] <= theta_max) {
-                Cand o;
-                o.key = al[r];
-                o.idx = tid + r * K2F_THREADS;
-                o.aux = bas[r];
-                h = better<TIE_SMALLER_AUX>(h, o);
+                const unsigned long long rk = ((unsigned long long)(unsigned)bas[r] << 32) | (unsigned)(tid + r * K2F_THREADS);
+                if (hrank == RANK_NONE || al[r] > hkey || (al[r] == hkey && rk < hrank)) {
+                    hkey = al[r];
+                    hrank = rk;
+                }
             }
         }
-        h = block_best<TIE_SMALLER_AUX>(h, s_cand);
-        p = h.idx;
+        block_argbest(hkey, hrank, s_akey, s_arank);
+        p = hrank == RANK_NONE ? -1 : (int)(hrank & 0xffffffffu);
     }
     STAMP(4);
     if (p < 0) {
