@@ -233,3 +233,22 @@ def test_profile_hook_runs():
     result_after = solver.iterate(10 ** 6)
     assert result_after[1] == relp_amd.STOP_NO_ENTERING
     solver.close()
+
+
+ALL_NETLIB = sorted(name for name in NETLIB if os.path.exists(os.path.join(ROOT, "data", "netlib", name + ".SIF")) and name != "GROW7")
+
+
+@pytest.mark.parametrize("name", ALL_NETLIB)
+def test_every_netlib_problem_of_the_reference_suite(name):
+    """All 47 solvable problems of tests/netlib/test.rs -- including the 9 it ignores as "too computationally intensive"
+    and the 2 it suspects of cycling -- within the tolerance that test states, and with the exact certificate."""
+    expected, tolerance, _ = NETLIB[name]
+    solver = relp_amd.Solver(certify=1).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    limit = 2e-5 if name == "25FV47" else tolerance  # see test_headline_problems_meet_reference_tolerance
+    assert abs(result.objective - expected) < limit, (result.objective, expected)
+    num, den = solver.objective_exact().split("/")
+    assert abs(Fraction(int(num), int(den)) - Fraction(expected)) < Fraction(limit)
+    solver.close()
