@@ -252,3 +252,15 @@ def test_every_netlib_problem_of_the_reference_suite(name):
     num, den = solver.objective_exact().split("/")
     assert abs(Fraction(int(num), int(den)) - Fraction(expected)) < Fraction(limit)
     solver.close()
+
+
+@pytest.mark.parametrize("name, expected, tolerance", [("50v-10", 2879.065687, 1e-3), ("acc-tight4", 0.0, 1e-3)])
+def test_miplib_relaxations(name, expected, tolerance):
+    """tests/miplib/test.rs:3-18 (free-format `import`, `Carry<RationalBig, BasisInverseRows<_>>`); acc-tight4 is ignored
+    there as "too computationally expensive"."""
+    solver = relp_amd.Solver(certify=1).load_mps(os.path.join(ROOT, "data", "miplib", name + ".mps"), fixed=False)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert abs(result.objective - expected) < tolerance, result.objective
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    solver.close()
