@@ -196,8 +196,8 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (pricing pass), measured live with HIP events on the solver's stream
         solver.begin_phase_one()
-        solver.iterate(600 if dense else 200)
-        reps = 200
+        solver.iterate(300 if dense else 200)
+        reps = 100 if dense else 200  # further real pivots, the profiled kernel of each bracketed by its own event pair
         seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(["price", "ftran_ratio", "update"])}
         stats = solver.stats()
         # the roofline kernel is the pricing pass (the path's only mandatory full sweep over the constraint columns;

@@ -190,9 +190,10 @@ int32_t relp_get_b(relp_handle* handle, double* out_m);
 int32_t relp_get_objective(relp_handle* handle, double* objective);
 int32_t relp_get_stats(const relp_handle* handle, relp_stats* stats);
 int32_t relp_reset_stats(relp_handle* handle);
-/* Measurement hook for bench.py: average seconds of ONE launch of a hot-loop kernel, timed with HIP events on the
- * handle's stream around `repetitions` back-to-back launches on the current device state (state is restored).
- * which: 0 pricing pass (with the steepest-edge update) | 1 ftran+ratio | 2 inverse update (+ w partials). */
+/* Measurement hook for bench.py: average execution time (seconds) of ONE launch of a hot-loop kernel INSIDE the real
+ * pivot sequence: `repetitions` further pivots of the current phase are run, the chosen kernel of each one bracketed by
+ * its own HIP start/stop event pair on the handle's stream (hipExtLaunchKernelGGL).  The solve advances.
+ * which: 0 pricing pass (with the steepest-edge update) | 1 fused ftran/ratio | 2 inverse update. */
 int32_t relp_profile_kernel(relp_handle* handle, int32_t which, int32_t repetitions, double* seconds_per_launch);
 
 /* Diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of the fused kernel; zeros otherwise. */

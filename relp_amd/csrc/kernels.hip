@@ -13,6 +13,7 @@
 // Reference functions each kernel replaces are cited at the kernel; paths relative to
 // /root/reference/src/algorithm/two_phase/.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -1559,16 +1560,38 @@ __global__ void relative_cost_kernel(DeviceLP lp, double* out) {
 // ---------------------------------------------------------------------------------------------------
 // launch helpers used by solver.hip
 // ---------------------------------------------------------------------------------------------------
+// Measurement hook (bench.py roofline leg): when armed, the NEXT launch of the named hot-loop kernel is bracketed by a
+// start/stop event pair through hipExtLaunchKernelGGL, i.e. its own execution time inside the real pivot sequence.
+struct LaunchTimer {
+    int which = -1;  // 0 price (sparse or dense), 1 fused ftran/ratio, 2 update
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+static thread_local LaunchTimer g_timer;
+void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop) {
+    g_timer.which = which;
+    g_timer.start = start;
+    g_timer.stop = stop;
+}
+#define RELP_LAUNCH(WHICH, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                            \
+    do {                                                                                                     \
+        if (g_timer.which == (WHICH)) {                                                                      \
+            g_timer.which = -1;                                                                              \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, (std::uint32_t)(LDS), STREAM, g_timer.start, g_timer.stop, 0, __VA_ARGS__); \
+        } else {                                                                                             \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                               \
+        }                                                                                                    \
+    } while (0)
 constexpr int PRICE_LPC = 8;  // lanes per sparse column in the pricing kernel
 int price_columns_per_block() { return 256 / PRICE_LPC; }
 
 template <int RULE>
 static void launch_price_rule(const DeviceLP& d, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
                               int first, int last, int cand_offset, hipStream_t s) {
+    const bool timed_elsewhere = d.n_dense > 0;  // with a dense block the dense kernel is the one that is timed
     if (use_lds)
-        hipLaunchKernelGGL((price_kernel<RULE, true, PRICE_LPC>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol, first, last, cand_offset);
+        RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, true, PRICE_LPC>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol, first, last, cand_offset);
     else
-        hipLaunchKernelGGL((price_kernel<RULE, false, PRICE_LPC>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
+        RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, false, PRICE_LPC>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
 }
 
 // sparse (CSC) pricing over the device columns [first, last)
@@ -1584,7 +1607,7 @@ void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_
 
 void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s) {
     const size_t lds = (size_t)3 * d.dense_ld * sizeof(double);
-    hipLaunchKernelGGL(price_dense_kernel, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
+    RELP_LAUNCH(0, price_dense_kernel, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
 }
 void configure_dense_lds(size_t lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1609,11 +1632,11 @@ static void launch_ftran_ratio_rule(const DeviceLP& d, int n_price_blocks, doubl
                                     int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s) {
     const bool fits = n_price_blocks <= K2F_MAX_BLOCKS;
     if (fits && d.m <= 2 * K2F_THREADS)
-        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 2>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
+        RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 2>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else if (fits && d.m <= 4 * K2F_THREADS)
-        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 4>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
+        RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 4>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else if (fits && d.m <= 8 * K2F_THREADS)
-        hipLaunchKernelGGL((ftran_ratio_fast_kernel<RULE, 8>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
+        RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 8>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else
         hipLaunchKernelGGL((ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
 }
@@ -1632,8 +1655,8 @@ void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double 
 void launch_update(const DeviceLP& d, hipStream_t s) {
     const int cols_per_block = (K3_THREADS / WAVE) * K3_CPW;
     const dim3 grid((d.m + cols_per_block - 1) / cols_per_block);
-    if (d.m <= 2048) hipLaunchKernelGGL((update_kernel<true>), grid, dim3(K3_THREADS), 0, s, d);
-    else hipLaunchKernelGGL((update_kernel<false>), grid, dim3(K3_THREADS), 0, s, d);
+    if (d.m <= 2048) RELP_LAUNCH(2, (update_kernel<true>), grid, dim3(K3_THREADS), 0, s, d);
+    else RELP_LAUNCH(2, (update_kernel<false>), grid, dim3(K3_THREADS), 0, s, d);
 }
 
 void launch_budget(const DeviceLP& d, long long add, hipStream_t s) {

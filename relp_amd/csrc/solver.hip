@@ -21,6 +21,7 @@ void configure_dense_lds(size_t lds);
 void launch_select(const DeviceLP& d, int n_price_blocks, int rule, hipStream_t s);
 void launch_ftran_partial(const DeviceLP& d, int n_slices, hipStream_t s);
 bool fast_k2_available(const DeviceLP& d, int n_price_blocks);
+void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop);
 void configure_lds(size_t price_lds);
 int price_columns_per_block();
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
@@ -695,22 +696,15 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
     c.forced_q = c.forced_p = -1;
     write_ctl(c);
 }
-// Average duration of one launch of a hot-loop kernel (HIP events on this handle's stream; bench.py's roofline leg).
+// Average execution time of one launch of a hot-loop kernel INSIDE the real pivot sequence (bench.py's roofline leg):
+// `repetitions` further pivots of the current phase are run un-graphed, and the chosen kernel of every pivot is
+// bracketed by its own start/stop event pair (hipExtLaunchKernelGGL) on this handle's stream.  The solve advances.
 double Solver::profile_kernel(int which, int repetitions) {
     if (phase_ == 0) throw std::runtime_error("no phase started");
     RELP_HIP(hipSetDevice(opt_.device));
     const int m = d_.m;
-    Ctl saved = read_ctl();
-    Ctl c = saved;
-    c.status = ST_RUNNING;
-    c.pending = 1;
-    if (c.alpha_pq == 0.0) c.alpha_pq = 1.0;
-    if (c.q < d_.n_art || c.q >= d_.n) c.q = d_.n_art;
-    c.forced_q = c.q;
-    c.forced_p = -1;
-    write_ctl(c);
     if (which == 0) {
-        // algorithmic bytes of THIS pricing pass: columns that are non-basic now
+        // algorithmic bytes of a pricing pass at this state: the columns that are non-basic now
         std::vector<int> pos(d_.n), cs(d_.n + 1);
         RELP_HIP(hipMemcpy(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost));
         RELP_HIP(hipMemcpy(cs.data(), d_.col_start, (d_.n + 1) * sizeof(int), hipMemcpyDeviceToHost));
@@ -723,45 +717,39 @@ double Solver::profile_kernel(int which, int repetitions) {
         }
         stats_.price_bytes = bytes;
     }
-    // keep the state the kernels overwrite
-    RELP_HIP(hipMemcpyAsync(d_.scratch, d_.gamma, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    RELP_HIP(hipMemcpyAsync(d_.Binv2, d_.Binv, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    auto launch = [&] {
-        if (which == 0) enqueue_price(0);
-        else if (which == 1) enqueue_ftran_ratio(2);
-        else launch_update(d_, stream_);
-    };
-    for (int k = 0; k < 3; ++k) {
-        if (which == 1) write_ctl(c);
-        launch();
+    std::vector<hipEvent_t> starts(repetitions), stops(repetitions);
+    for (int k = 0; k < repetitions; ++k) {
+        RELP_HIP(hipEventCreate(&starts[k]));
+        RELP_HIP(hipEventCreate(&stops[k]));
     }
-    RELP_HIP(hipStreamSynchronize(stream_));
+    Ctl before = read_ctl();
+    launch_budget(d_, repetitions, stream_);
+    for (int k = 0; k < repetitions; ++k) {
+        if (which == 0) arm_launch_timer(0, starts[k], stops[k]);
+        enqueue_price(0);
+        if (which == 1) arm_launch_timer(1, starts[k], stops[k]);
+        enqueue_ftran_ratio(0);
+        if (which == 2) arm_launch_timer(2, starts[k], stops[k]);
+        launch_update(d_, stream_);
+    }
+    arm_launch_timer(-1, nullptr, nullptr);
+    Ctl after = read_ctl();
+    const long long made = after.iters - before.iters;
+    pivots_[phase_ - 1] += made;
+    since_polish_ += made;
     double total_ms = 0.0;
-    if (which == 1) {
-        // the dry-run kernel clears the forced column, so time launches one by one
-        for (int k = 0; k < repetitions; ++k) {
-            write_ctl(c);
-            RELP_HIP(hipEventRecord(ev_a_, stream_));
-            launch();
-            RELP_HIP(hipEventRecord(ev_b_, stream_));
-            RELP_HIP(hipEventSynchronize(ev_b_));
-            float ms = 0.f;
-            RELP_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
-            total_ms += ms;
-        }
-    } else {
-        RELP_HIP(hipEventRecord(ev_a_, stream_));
-        for (int k = 0; k < repetitions; ++k) launch();
-        RELP_HIP(hipEventRecord(ev_b_, stream_));
-        RELP_HIP(hipEventSynchronize(ev_b_));
+    int counted = 0;
+    for (int k = 0; k < repetitions; ++k) {
         float ms = 0.f;
-        RELP_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
-        total_ms = ms;
+        if (k < made && hipEventElapsedTime(&ms, starts[k], stops[k]) == hipSuccess) {
+            total_ms += ms;
+            ++counted;
+        }
+        (void)hipEventDestroy(starts[k]);
+        (void)hipEventDestroy(stops[k]);
     }
-    RELP_HIP(hipMemcpyAsync(d_.gamma, d_.scratch, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    write_ctl(saved);
-    return total_ms * 1e-3 / repetitions;
+    if (counted == 0) throw std::runtime_error("no pivot was made while profiling (phase already finished)");
+    return total_ms * 1e-3 / counted;
 }
 
 void Solver::debug_stamps(unsigned long long* out64) {
