@@ -31,40 +31,43 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def cpu_baseline(path, budget_seconds):
     """relp-equivalent exact CPU path (the oracle: kind "port"), first pivots of the same workload, one core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from relp_oracle import solve_relaxation
+    from relp_oracle import cpu
     from relp_oracle.mps import load_problem
-    from relp_oracle.solve import PivotLimit, Trace
 
     _, data = load_problem(path)
-
-    class Timed(Trace):
-        def __init__(self):
-            super().__init__()
-            self.start = None
-
-        def record(self, q, p, leaving, cost):
-            super().record(q, p, leaving, cost)
-            if time.perf_counter() - self.start > budget_seconds:
-                raise PivotLimit()
-
-    trace = Timed()
-    trace.start = time.perf_counter()
-    try:
-        solve_relaxation(data, trace=trace)
-    except PivotLimit:
-        pass
-    elapsed = time.perf_counter() - trace.start
-    pivots = len(trace.pivots)
+    record = cpu.solve_provider(data, max_seconds=budget_seconds, trace=0)  # oracle/cpp/relp_cpu.cpp, g++ -O2, one thread
+    pivots = record["pivots_phase1"] + record["pivots_phase2"]
+    elapsed = record["seconds"]
     full = ""
-    golden = os.path.join(ROOT, "tests", "golden", "25FV47.json")
-    if os.path.exists(golden) and path.endswith("25FV47.SIF"):
-        g = json.load(open(golden))
-        total = g["pivots_phase1"] + g["pivots_phase2"]
-        full = "; the full exact solve took %d pivots in %.0f s = %.2f pivots/s in the build container" % (
-            total, g["oracle_seconds"], total / g["oracle_seconds"])
+    measured = os.path.join(ROOT, "profiles", "r1_cpu_oracle_full_solve.json")
+    if os.path.exists(measured) and path.endswith("25FV47.SIF"):
+        g = json.load(open(measured))
+        full = "; the full exact solve took %d pivots in %.0f s = %.2f pivots/s on %s" % (
+            g["pivots"], g["seconds"], g["pivots"] / g["seconds"], g["host"])
     return {"value": pivots / elapsed if elapsed > 0 else 0.0, "unit": "pivots/s", "cores": 1, "kind": "port",
-            "sample": "first %d pivots (%.1f s) of the same LP with exact rationals (Python Fraction restatement of "
-                      "relp's LU/Forrest-Tomlin steepest-edge path; early pivots are the cheap ones%s)" % (pivots, elapsed, full)}
+            "sample": "first %d pivots (%.1f s) of the same LP with exact rationals: C++ restatement of relp's "
+                      "Carry<RationalBig, LUDecomposition> steepest-edge path (oracle/cpp, same pivot sequence as the "
+                      "reference's algorithm; early pivots are the cheap ones, numbers grow to ~1800 bits%s)" % (pivots, elapsed, full)}
+
+
+def cpu_baseline_dense(dims, budget_seconds):
+    """f64 CPU restatement of the same loop for the dense workloads (oracle/f64_dense.py, numpy + its threaded BLAS);
+    the exact-rational path is infeasible at this size."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from f64_dense import DenseModel
+    from relp_amd.workloads import dense_lp
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([pool.get("num_threads", 1) for pool in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    model = DenseModel(*dense_lp(*dims))
+    start = time.perf_counter()
+    model.solve(max_seconds=budget_seconds)
+    elapsed = time.perf_counter() - start
+    return {"value": model.pivots / elapsed if elapsed > 0 else 0.0, "unit": "pivots/s", "cores": threads, "kind": "port",
+            "sample": "first %d pivots (%.1f s) of the same dense LP in f64: numpy restatement of the same steepest-edge "
+                      "explicit-inverse loop, BLAS on %d threads" % (model.pivots, elapsed, threads)}
 
 
 def netlib_batch(args, rank, local_rank, world, distributed):
@@ -234,8 +237,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if not args.no_cpu_baseline and not dense:
-            line["cpu_baseline"] = cpu_baseline(path, args.cpu_seconds)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_dense(path, args.cpu_seconds) if dense else cpu_baseline(path, args.cpu_seconds)
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()
