@@ -71,8 +71,9 @@ def cpu_baseline_dense(dims, budget_seconds):
 
 
 def netlib_batch(args, rank, local_rank, world, distributed):
-    """Config 4: independent LPs shard across ranks (static longest-first assignment, relp_amd.batch.assign); every LP
-    is resident in HBM before the timed region; value = pivots of all ranks / makespan (max over ranks)."""
+    """Config 4: independent LPs shard across ranks -- by default through a dynamic ticket queue over the cost-sorted list
+    (relp_amd.batch.TicketQueue), or the static longest-first partition (relp_amd.batch.assign); every LP is resident
+    in HBM before the timed region; value = pivots of all ranks / makespan (max over ranks)."""
     import glob
     import torch
     import relp_amd
@@ -86,13 +87,30 @@ def netlib_batch(args, rank, local_rank, world, distributed):
         model = relp_amd.Model(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
         models[name] = model
         costs.append((name, float(model.nr_rows) * float(model.nnz + model.nr_columns)))
-    mine = batch.assign(costs, world)[rank]
+    dynamic = args.schedule == "dynamic"
+    ordered = [name for name, _ in sorted(costs, key=lambda item: (-item[1], item[0]))]  # longest estimated first
+    # dynamic: any rank may draw any LP, so every rank keeps the whole suite resident (< 2 GB of 288 GB HBM)
+    mine = ordered if dynamic else batch.assign(costs, world)[rank]
     solvers = {name: relp_amd.Solver(device=local_rank).load_model(models[name]) for name in mine}
     records = []
+    passes = [0]
 
     def run_all():
         pivots = 0
-        for name in mine:
+        passes[0] += 1
+        tickets = batch.TicketQueue(len(ordered), tag="pass%d" % passes[0]) if dynamic else None
+        position = 0
+        while True:
+            if dynamic:
+                index = tickets.next()
+                if index is None:
+                    break
+                name = ordered[index]
+            else:
+                if position == len(mine):
+                    break
+                name = mine[position]
+                position += 1
             r = solvers[name].solve_relaxation()
             pivots += r.pivots_phase_one + r.pivots_phase_two
             records.append((name, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds))
@@ -126,7 +144,8 @@ def netlib_batch(args, rank, local_rank, world, distributed):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "%d Netlib .SIF files shipped under data/netlib" % len(names),
-            "config": {"workload": "Netlib batch (%d LPs), static longest-first assignment, one LP per GPU at a time" % len(names),
+            "config": {"workload": "Netlib batch (%d LPs), %s, one LP per GPU at a time" % (
+                len(names), "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
                        "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}}))
     if distributed:
         torch.distributed.destroy_process_group()
@@ -140,6 +159,7 @@ def main():
     parser.add_argument("--workload", default="25fv47")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
     args = parser.parse_args()
 
     import torch

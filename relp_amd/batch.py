@@ -37,3 +37,30 @@ def gather_records(record):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, record)
     return out
+
+
+class TicketQueue:
+    """Dynamic work queue over the LP ids 0..count-1 ("served by an atomic ticket").
+
+    Every rank holds the same cost-sorted list; `next()` hands out the next unclaimed index, or None when the list is
+    exhausted.  The ticket is an atomic fetch-add on the process group's key-value store (owned by rank 0; one host
+    round trip of ~0.1 ms per LP against solves of milliseconds to seconds) -- RCCL has no one-sided atomic, so the
+    collectives carry only the result gather and the time / pivot reductions.  `tag` separates successive passes over
+    the list (one per bench step), so no barrier is needed between them.  Without a process group it is a local counter.
+    """
+
+    def __init__(self, count, tag):
+        self.count = int(count)
+        self.key = "relp_amd/ticket/%s" % tag
+        self.local = 0
+        self.store = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.store = dist.distributed_c10d._get_default_store()
+
+    def next(self):
+        if self.store is None:
+            ticket = self.local
+            self.local += 1
+        else:
+            ticket = self.store.add(self.key, 1) - 1
+        return ticket if ticket < self.count else None

@@ -57,3 +57,55 @@ def test_two_ranks_aggregate_with_gloo():
     assert t0 == t1 == 12.0                                      # max over ranks
     assert p0 == p1 == 240                                       # sum over ranks
     assert rec0 == rec1 and [r["rank"] for r in rec0] == [0, 1]
+
+
+def _queue_worker(rank, world, port, queue):
+    sys.path.insert(0, ROOT)
+    import time
+    from relp_amd import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        durations = [0.20, 0.02, 0.02, 0.02, 0.02, 0.02, 0.02]   # the first (largest) LP occupies one rank for a while
+        taken = []
+        for epoch in range(2):
+            tickets = batch.TicketQueue(len(durations), tag="epoch%d" % epoch)
+            mine = []
+            while True:
+                index = tickets.next()
+                if index is None:
+                    break
+                mine.append(index)
+                time.sleep(durations[index])
+            taken.append(mine)
+            dist.barrier()
+        queue.put((rank, taken, batch.gather_records(taken)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ticket_queue_hands_out_every_lp_exactly_once():
+    sys.path.insert(0, ROOT)
+    from relp_amd import batch
+    local = batch.TicketQueue(3, tag="local")   # no process group: plain counter
+    assert [local.next() for _ in range(5)] == [0, 1, 2, None, None]
+
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = 30500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_queue_worker, args=(rank, 2, port, queue)) for rank in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(queue.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, taken0, gathered0), (_, taken1, gathered1) = results
+    assert gathered0 == gathered1 == [taken0, taken1]
+    for epoch in range(2):
+        assert sorted(taken0[epoch] + taken1[epoch]) == list(range(7))      # a partition, every pass
+        # dynamic balancing: whoever drew the long LP got few others
+        long_owner = taken0[epoch] if 0 in taken0[epoch] else taken1[epoch]
+        other = taken1[epoch] if long_owner is taken0[epoch] else taken0[epoch]
+        assert len(long_owner) < len(other)
