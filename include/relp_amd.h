@@ -97,6 +97,17 @@ int32_t relp_options_default(relp_options* options);
  * (parser, standardisation, virtual slack columns) is testable on CPU.  relp_load_model uploads it to a handle. */
 typedef struct relp_model relp_model;
 int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model** out, char* error, int32_t error_capacity);
+/* Graph providers (reference: examples/max_flow.rs:31-223 `Primal::new` + its MatrixProvider; examples/shortest_path.rs:20-118;
+ * incidence matrix data/linear_program/network/representation.rs:24-100).  Arcs in the order the reference's column-major
+ * adjacency matrix enumerates them: sorted by (tail, head), no self arcs.  `value` = capacity (max flow: arc j gets the
+ * bound row V-2+j and the slack column E+j, initial pivots (V-2+j, E+j)) or length (shortest path: row of s removed,
+ * b = e_t).  RELP_ERR_ARGUMENT for unsorted / duplicate / self arcs or bad terminals. */
+int32_t relp_model_max_flow(int32_t nr_vertices, int32_t nr_arcs, const int32_t* tail, const int32_t* head,
+                            const int64_t* capacity_num, const int64_t* capacity_den, int32_t s, int32_t t,
+                            relp_model** out, char* error, int32_t error_capacity);
+int32_t relp_model_shortest_path(int32_t nr_vertices, int32_t nr_arcs, const int32_t* tail, const int32_t* head,
+                                 const int64_t* length_num, const int64_t* length_den, int32_t s, int32_t t,
+                                 relp_model** out, char* error, int32_t error_capacity);
 int32_t relp_model_free(relp_model* model);
 int32_t relp_model_dimensions(const relp_model* model, int32_t* nr_rows, int32_t* nr_columns, int32_t* nr_constraints,
                               int32_t* nr_structural, int64_t* nnz, int32_t group_counts[4]);

@@ -49,7 +49,7 @@ _lib = None
 
 # every symbol include/relp_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_free", "relp_model_dimensions",
+    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
     "relp_model_column", "relp_model_column_exact", "relp_model_cost", "relp_model_right_hand_side",
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
     "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_model", "relp_get_dimensions", "relp_get_column",
@@ -99,12 +99,47 @@ class Model:
         status = lib().relp_model_from_mps(str(path).encode(), int(fixed), C.byref(self._h), error, 512)
         if status != OK:
             raise RelpError(status, error.value.decode())
+        self._read_dimensions()
+
+    def _read_dimensions(self):
         rows, cols, cons, struct = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         nnz = C.c_int64()
         groups = (C.c_int32 * 4)()
         lib().relp_model_dimensions(self._h, C.byref(rows), C.byref(cols), C.byref(cons), C.byref(struct), C.byref(nnz), groups)
         self.nr_rows, self.nr_columns, self.nr_constraints = rows.value, cols.value, cons.value
         self.nr_structural, self.nnz, self.group_counts = struct.value, nnz.value, list(groups)
+
+    @classmethod
+    def _from_graph(cls, entry, nr_vertices, arcs, s, t):
+        """``arcs``: iterable of ``(tail, head, value)``; value an int, a ``Fraction`` or a ``(num, den)`` pair.  Sorted
+        here by (tail, head): the order the reference's adjacency matrix enumerates them (representation.rs:40-44)."""
+        from fractions import Fraction
+        arcs = sorted(((int(a), int(b), Fraction(*v) if isinstance(v, tuple) else Fraction(v)) for a, b, v in arcs),
+                      key=lambda arc: arc[:2])
+        tail = np.array([a for a, _, _ in arcs], dtype=np.int32)
+        head = np.array([b for _, b, _ in arcs], dtype=np.int32)
+        num = np.array([v.numerator for _, _, v in arcs], dtype=np.int64)
+        den = np.array([v.denominator for _, _, v in arcs], dtype=np.int64)
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        error = C.create_string_buffer(512)
+        status = getattr(lib(), entry)(int(nr_vertices), len(arcs), _ptr(tail, C.c_int32), _ptr(head, C.c_int32),
+                                       _ptr(num, C.c_int64), _ptr(den, C.c_int64), int(s), int(t), C.byref(self._h), error, 512)
+        if status != OK:
+            raise RelpError(status, error.value.decode())
+        self._read_dimensions()
+        self.arcs = arcs
+        return self
+
+    @classmethod
+    def max_flow(cls, nr_vertices, arcs, s, t):
+        """The provider of examples/max_flow.rs (`Primal::new`): maximise the flow out of ``s``; value = capacity."""
+        return cls._from_graph("relp_model_max_flow", nr_vertices, arcs, s, t)
+
+    @classmethod
+    def shortest_path(cls, nr_vertices, arcs, s, t):
+        """The provider of examples/shortest_path.rs (`Primal::new`); value = arc length."""
+        return cls._from_graph("relp_model_shortest_path", nr_vertices, arcs, s, t)
 
     def __del__(self):
         if getattr(self, "_h", None):

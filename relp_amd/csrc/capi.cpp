@@ -4,6 +4,7 @@
 #include <new>
 #include <sstream>
 
+#include "network.hpp"
 #include "solver.hpp"
 
 using namespace relp;
@@ -91,6 +92,44 @@ int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model**
     } catch (const std::exception& e) {
         return fail(e.what(), RELP_ERR_PARSE);
     }
+}
+static int32_t model_from_graph(bool max_flow, int32_t nr_vertices, int32_t nr_arcs, const int32_t* tail, const int32_t* head,
+                                const int64_t* num, const int64_t* den, int32_t s, int32_t t, relp_model** out, char* error,
+                                int32_t error_capacity) {
+    if (!out || nr_arcs < 0 || (nr_arcs > 0 && (!tail || !head || !num || !den))) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    auto fail = [&](const std::string& what, int32_t code) {
+        if (error && error_capacity > 0) {
+            std::strncpy(error, what.c_str(), error_capacity - 1);
+            error[error_capacity - 1] = 0;
+        }
+        return code;
+    };
+    try {
+        std::vector<Arc> arcs((size_t)nr_arcs);
+        for (int32_t k = 0; k < nr_arcs; ++k) {
+            if (den[k] == 0) return fail("zero denominator", RELP_ERR_ARGUMENT);
+            arcs[k] = Arc{tail[k], head[k], make_rat(num[k], den[k])};
+        }
+        relp_model* model = new relp_model();
+        model->form = max_flow ? make_max_flow(nr_vertices, arcs, s, t) : make_shortest_path(nr_vertices, arcs, s, t);
+        *out = model;
+        return RELP_OK;
+    } catch (const RatOverflow& e) {
+        return fail(e.what(), RELP_ERR_OVERFLOW);
+    } catch (const std::exception& e) {
+        return fail(e.what(), RELP_ERR_ARGUMENT);
+    }
+}
+int32_t relp_model_max_flow(int32_t nr_vertices, int32_t nr_arcs, const int32_t* tail, const int32_t* head,
+                            const int64_t* capacity_num, const int64_t* capacity_den, int32_t s, int32_t t,
+                            relp_model** out, char* error, int32_t error_capacity) {
+    return model_from_graph(true, nr_vertices, nr_arcs, tail, head, capacity_num, capacity_den, s, t, out, error, error_capacity);
+}
+int32_t relp_model_shortest_path(int32_t nr_vertices, int32_t nr_arcs, const int32_t* tail, const int32_t* head,
+                                 const int64_t* length_num, const int64_t* length_den, int32_t s, int32_t t,
+                                 relp_model** out, char* error, int32_t error_capacity) {
+    return model_from_graph(false, nr_vertices, nr_arcs, tail, head, length_num, length_den, s, t, out, error, error_capacity);
 }
 int32_t relp_model_free(relp_model* model) {
     delete model;

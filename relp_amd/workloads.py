@@ -27,3 +27,27 @@ def dense_lp(m, n, seed=0x5EED0001):
     b = (100000 + (x[m * n:m * n + m] % np.uint64(100000))).astype(np.int64)
     c = -(1 + (x[m * n + m:] % np.uint64(100))).astype(np.int64)
     return np.ascontiguousarray(a_row_major.T), b, c
+
+
+def max_flow_graph(nr_vertices, nr_arcs, seed=0x5EED0005):
+    """Random directed graph of BASELINE config 5: splitmix64(seed); endpoints
+    ``u = x mod V``, ``v = x' mod V`` (self arcs and duplicates rejected), capacity ``1 + (x'' mod 100)``;
+    source 0, sink V-1.  Returns (tail, head, capacity) sorted by (tail, head)."""
+    seen = set()
+    tails, heads, capacities = [], [], []
+    offset = 0
+    while len(tails) < nr_arcs:
+        need = nr_arcs - len(tails)
+        x = splitmix64_stream(seed, offset + 3 * need)[offset:]
+        offset += 3 * need
+        for k in range(need):
+            u, v = int(x[3 * k] % np.uint64(nr_vertices)), int(x[3 * k + 1] % np.uint64(nr_vertices))
+            if u == v or (u, v) in seen:
+                continue
+            seen.add((u, v))
+            tails.append(u)
+            heads.append(v)
+            capacities.append(1 + int(x[3 * k + 2] % np.uint64(100)))
+    order = sorted(range(nr_arcs), key=lambda k: (tails[k], heads[k]))
+    return (np.array([tails[k] for k in order], dtype=np.int32), np.array([heads[k] for k in order], dtype=np.int32),
+            np.array([capacities[k] for k in order], dtype=np.int64))

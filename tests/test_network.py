@@ -1,0 +1,161 @@
+"""Graph providers: the `MatrixProvider`s of the reference's examples/max_flow.rs and
+examples/shortest_path.rs.  CPU part: the oracle reproduces the optima the examples assert, the C++ host model equals the
+oracle's provider column for column, the C++ oracle agrees.  GPU part: the device path solves them (exact certificate)."""
+import os
+import random
+import sys
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import relp_amd  # noqa: E402
+from relp_oracle import FiniteOptimum, solve_relaxation  # noqa: E402
+from relp_oracle import cpu  # noqa: E402
+from relp_oracle.inverse_rows import BasisInverseRows  # noqa: E402
+from relp_oracle.lu import LUDecomposition  # noqa: E402
+from relp_oracle.network import MaxFlowPrimal, ShortestPathPrimal, adjacency_from_rows  # noqa: E402
+
+# examples/max_flow.rs:264-272 and examples/shortest_path.rs:156-163 (Papadimitriou's example; rows[to][from])
+MAX_FLOW_ROWS = [[0, 0, 0, 0], [2, 0, 0, 0], [1, 1, 0, 0], [0, 1, 2, 0]]
+SHORTEST_PATH_ROWS = [[0, 0, 0, 0], [1, 0, 0, 0], [2, 2, 0, 0], [0, 3, 1, 0]]
+
+
+def _dense(solution, n):
+    out = [Fraction(0)] * n
+    for j, v in solution:
+        out[j] = v
+    return out
+
+
+@pytest.mark.parametrize("bi_cls", [BasisInverseRows, LUDecomposition])
+def test_oracle_reproduces_the_examples(bi_cls):
+    problem = MaxFlowPrimal(adjacency_from_rows(MAX_FLOW_ROWS), 0, 3)
+    result = solve_relaxation(problem, bi_cls=bi_cls)
+    assert _dense(result.solution, 10) == [2, 1, 1, 1, 2, 0, 0, 0, 0, 0]       # examples/max_flow.rs:279-282
+    problem = ShortestPathPrimal(adjacency_from_rows(SHORTEST_PATH_ROWS), 0, 3)
+    result = solve_relaxation(problem, bi_cls=bi_cls)
+    assert _dense(result.solution, 5) == [0, 1, 0, 0, 1]                       # examples/shortest_path.rs:165-168
+
+
+def random_graph(rng, nr_vertices, nr_arcs, max_value):
+    pairs = set()
+    while len(pairs) < nr_arcs:
+        a, b = rng.randrange(nr_vertices), rng.randrange(nr_vertices)
+        if a != b:
+            pairs.add((a, b))
+    arcs = [[] for _ in range(nr_vertices)]
+    for a, b in sorted(pairs):
+        arcs[a].append((b, Fraction(rng.randint(1, max_value))))
+    return arcs
+
+
+def arc_list(arcs):
+    return [(a, b, v) for a, outgoing in enumerate(arcs) for b, v in outgoing]
+
+
+def _same_provider(model, provider):
+    assert (model.nr_rows, model.nr_columns, model.nr_constraints) == (
+        provider.nr_rows(), provider.nr_columns(), provider.nr_constraints())
+    for j in range(provider.nr_columns()):
+        expected = sorted((i, v.numerator, v.denominator) for i, v in provider.column(j))
+        assert model.column_exact(j) == expected, j
+        assert model.cost_value(j) == float(provider.cost_value(j))
+    assert list(model.right_hand_side()) == [float(v) for v in provider.right_hand_side()]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_host_model_equals_oracle_provider(seed):
+    rng = random.Random(seed)
+    nr_vertices = rng.randint(4, 9)
+    arcs = random_graph(rng, nr_vertices, rng.randint(nr_vertices, 2 * nr_vertices), 9)
+    s, t = rng.sample(range(nr_vertices), 2)
+    flow = MaxFlowPrimal(arcs, s, t)
+    model = relp_amd.Model.max_flow(nr_vertices, arc_list(arcs), s, t)
+    _same_provider(model, flow)
+    assert model.pivot_element_indices() == flow.pivot_element_indices()
+    path = ShortestPathPrimal(arcs, s, t)
+    model = relp_amd.Model.shortest_path(nr_vertices, arc_list(arcs), s, t)
+    _same_provider(model, path)
+    assert model.pivot_element_indices() == []
+
+
+def test_graph_model_argument_errors():
+    with pytest.raises(relp_amd.RelpError):
+        relp_amd.Model.max_flow(3, [(0, 0, 1)], 0, 2)            # self arc
+    with pytest.raises(relp_amd.RelpError):
+        relp_amd.Model.max_flow(3, [(0, 1, 1), (0, 1, 2)], 0, 2)  # duplicate arc
+    with pytest.raises(relp_amd.RelpError):
+        relp_amd.Model.shortest_path(3, [(0, 1, 1)], 1, 1)        # s == t
+
+
+def test_cpp_oracle_agrees_on_graph_providers():
+    rng = random.Random(11)
+    arcs = random_graph(rng, 7, 16, 9)
+    for problem in (MaxFlowPrimal(arcs, 0, 6), ShortestPathPrimal(arcs, 0, 6)):
+        exact = solve_relaxation(problem)
+        record = cpu.solve_provider(problem)
+        if isinstance(exact, FiniteOptimum):
+            assert record["status"] == "optimal" and record["solution"] == exact.solution
+        else:
+            assert record["status"] == repr(exact).lower()
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_solves_the_examples_exactly():
+    model = relp_amd.Model.max_flow(4, arc_list(adjacency_from_rows(MAX_FLOW_ROWS)), 0, 3)
+    solver = relp_amd.Solver(certify=1).load_model(model)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified
+    assert Fraction(solver.objective_exact()) == -3
+    assert np.allclose(solver.solution(), [2, 1, 1, 1, 2], atol=1e-9)          # the vertex examples/max_flow.rs asserts
+    model = relp_amd.Model.shortest_path(4, arc_list(adjacency_from_rows(SHORTEST_PATH_ROWS)), 0, 3)
+    solver = relp_amd.Solver(certify=1).load_model(model)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified
+    assert Fraction(solver.objective_exact()) == 3
+    assert np.allclose(solver.solution(), [0, 1, 0, 0, 1], atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_random_graphs_match_oracle_exactly(seed):
+    rng = random.Random(100 + seed)
+    nr_vertices = rng.randint(5, 12)
+    arcs = random_graph(rng, nr_vertices, rng.randint(nr_vertices + 2, 3 * nr_vertices), 20)
+    s, t = 0, nr_vertices - 1
+    for provider, model in ((MaxFlowPrimal(arcs, s, t), relp_amd.Model.max_flow(nr_vertices, arc_list(arcs), s, t)),
+                            (ShortestPathPrimal(arcs, s, t), relp_amd.Model.shortest_path(nr_vertices, arc_list(arcs), s, t))):
+        exact = solve_relaxation(provider)
+        solver = relp_amd.Solver(certify=1).load_model(model)
+        result = solver.solve_relaxation()
+        if isinstance(exact, FiniteOptimum):
+            assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified
+            assert Fraction(solver.objective_exact()) == exact.objective
+        else:
+            assert result.kind == relp_amd.INFEASIBLE      # no s-t path: the shortest-path LP is infeasible
+
+
+@pytest.mark.gpu
+def test_gpu_max_flow_matches_scipy_at_scale():
+    """V = 256, E ~ 2030 (m ~ 2290 rows): the LP optimum equals the max-flow value of scipy's Dinic."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices, nr_arcs = 256, 2048
+    tail, head, capacity = max_flow_graph(nr_vertices, nr_arcs)
+    # the reference's objective is the GROSS flow on the arcs leaving s (examples/max_flow.rs:164-172) and the rows of s
+    # and t are removed, so it equals the max-flow value only when nothing enters s or leaves t: drop those arcs here
+    keep = (head != 0) & (tail != nr_vertices - 1)
+    tail, head, capacity = tail[keep], head[keep], capacity[keep]
+    graph = csr_matrix((capacity.astype(np.int32), (tail, head)), shape=(nr_vertices, nr_vertices))
+    expected = maximum_flow(graph, 0, nr_vertices - 1).flow_value
+    model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+    solver = relp_amd.Solver(certify=1).load_model(model)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified
+    assert Fraction(solver.objective_exact()) == -expected
