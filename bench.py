@@ -180,7 +180,7 @@ def main():
     if dense:
         from relp_amd.workloads import dense_lp
         a, b, c = dense_lp(*path)
-        solver = relp_amd.Solver(device=local_rank, polish_period=512).load_dense_le(a, b, c)
+        solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512"))).load_dense_le(a, b, c)
     else:
         solver = relp_amd.Solver(device=local_rank).load_mps(path)
 

@@ -441,6 +441,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
 // (3 x 32 KB at m = 4096).  This is the HBM-roofline kernel: algorithmic bytes = non-basic dense columns * m * 8.
 // ---------------------------------------------------------------------------------------------------
 constexpr int K1D_THREADS = 1024;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, int skip_weights, double tol_dual, int cand_offset) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[K1D_THREADS / WAVE + 2];
@@ -476,17 +477,19 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
         const double gamma_j = lp.gamma[j];  // issued with the first column loads; used only in the tail
         const double cost_j = lp.cost[j];
         if (pos_j >= 0) continue;  // wave-uniform
-        const double2* col = reinterpret_cast<const double2*>(lp.dense_val + (size_t)jd * mp);
+        // the column stream is read once per pass and is larger than the Infinity Cache: non-temporal loads keep it from
+        // competing with the lines other kernels left there (measured: 5.3 TB/s against 4.0 TB/s behind the inverse update)
+        const f64x2* col = reinterpret_cast<const f64x2*>(lp.dense_val + (size_t)jd * mp);
         const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
         const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
         const double2* w2 = reinterpret_cast<const double2*>(s_w);
         double d_pi = 0.0, d_rho = 0.0, d_w = 0.0;
         for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
-            double2 v[8];
+            f64x2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + u * WAVE;
-                v[u] = k < half ? col[k] : make_double2(0.0, 0.0);
+                v[u] = k < half ? __builtin_nontemporal_load(col + k) : f64x2{0.0, 0.0};
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -543,55 +546,53 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
     }
 }
 
-// Entering-column choice as its own tiny kernel (used when FTRAN runs multi-block): reduces the candidates of all
-// pricing workgroups with the reference's tie rule, handles the iteration budget and the "no entering column" exit.
-__global__ void __launch_bounds__(256) select_kernel(DeviceLP lp, int n_price_blocks, int rule) {
+// Multi-block FTRAN for long entering columns: partial[c][i] = sum over the c-th slice of the entries of a_q of
+// v_e * Binv(i, r_e).  Grid (row tiles of 256, slices); coalesced over i; fixed slice order => deterministic.
+// The entering-column choice is folded in: every workgroup reduces the pricing candidates itself (same data, same fixed
+// order, same result -- cheaper than a one-workgroup kernel plus a kernel boundary); workgroup (0, 0) publishes q and
+// c_q, handles the iteration budget and the "no entering column" exit (the reference's tie rule: last maximum).
+__global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_slices, int n_price_blocks, int rule) {
+    __shared__ int s_rows[256];
+    __shared__ double s_vals[256];
     __shared__ Cand s_cand[8];
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING) return;
+    const bool publisher = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     if (ctl->iters >= ctl->budget) {
-        if (threadIdx.x == 0) {
+        if (publisher) {
             ctl->status = ST_BUDGET;
             ctl->pending = 0;
         }
         return;
     }
-    if (ctl->forced_q >= 0) {
-        if (threadIdx.x == 0) ctl->q = ctl->forced_q;
-        return;
-    }
-    Cand c;
-    c.key = 0.0;
-    c.idx = -1;
-    c.aux = 0;
-    for (int b = threadIdx.x; b < n_price_blocks; b += blockDim.x) {
-        Cand o;
-        o.idx = lp.cand_j[b];
-        o.key = o.idx >= 0 ? lp.cand_key[b] : 0.0;
-        o.aux = b;
-        c = (rule == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
-    }
-    c = (rule == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
-    if (threadIdx.x == 0) {
-        ctl->q = c.idx;
-        if (c.idx >= 0) {
-            ctl->cbar_q = lp.cand_cbar[c.aux];
-        } else {
-            ctl->status = ST_NO_ENTERING;
-            ctl->pending = 0;
-            ctl->last_selected = -1;
+    int q = ctl->forced_q;
+    if (q >= 0) {
+        if (publisher) ctl->q = q;
+    } else {
+        Cand c;
+        c.key = 0.0;
+        c.idx = -1;
+        c.aux = 0;
+        for (int b = threadIdx.x; b < n_price_blocks; b += blockDim.x) {
+            Cand o;
+            o.idx = lp.cand_j[b];
+            o.key = o.idx >= 0 ? lp.cand_key[b] : 0.0;
+            o.aux = b;
+            c = (rule == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
+        }
+        c = (rule == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
+        q = c.idx;
+        if (publisher) {
+            ctl->q = q;
+            if (q >= 0) {
+                ctl->cbar_q = lp.cand_cbar[c.aux];
+            } else {
+                ctl->status = ST_NO_ENTERING;
+                ctl->pending = 0;
+                ctl->last_selected = -1;
+            }
         }
     }
-}
-
-// Multi-block FTRAN for long entering columns: partial[c][i] = sum over the c-th slice of the entries of a_q of
-// v_e * Binv(i, r_e).  Grid (row tiles of 256, slices); coalesced over i; fixed slice order => deterministic.
-__global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_slices) {
-    __shared__ int s_rows[256];
-    __shared__ double s_vals[256];
-    Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING) return;
-    const int q = ctl->q;
     if (q < 0) return;
     const int m = lp.m, ld = lp.ld;
     const int ca = lp.col_start[q], cb = lp.col_start[q + 1];
@@ -622,11 +623,10 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
     if (i < m) lp.alpha_part[(size_t)blockIdx.y * m + i] = (a0 + a1) + (a2 + a3);
 }
 
-// alpha_part[0][i] = sum_c alpha_part[c][i] (fixed order), so that the fused kernel reads one slice.
-__global__ void __launch_bounds__(256) alpha_reduce_kernel(DeviceLP lp, int n_slices) {
-    if (lp.ctl->status != ST_RUNNING) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= lp.m) return;
+// alpha_in[i] = sum_c alpha_part[c][i] (fixed order), so that the fused kernel reads one vector.  In the deferred product
+// form the pending etas are applied here, all at once and in parallel:  alpha = M y = y + sum_c (M[:, P_c] - e_{P_c}) y[P_c].
+constexpr int ETA_MAX = 32;
+__device__ __forceinline__ double sum_slices(const DeviceLP& lp, int n_slices, int i) {
     double acc = 0.0;
     for (int c0 = 0; c0 < n_slices; c0 += 8) {
         double t[8];
@@ -635,7 +635,249 @@ __global__ void __launch_bounds__(256) alpha_reduce_kernel(DeviceLP lp, int n_sl
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += t[u];
     }
-    lp.alpha_part[i] = acc;
+    return acc;
+}
+constexpr int AR_ROWS = 64, AR_GROUPS = 4;
+__global__ void __launch_bounds__(AR_ROWS * AR_GROUPS) alpha_reduce_kernel(DeviceLP lp, int n_slices) {
+    __shared__ double s_y[ETA_MAX];
+    __shared__ int s_p[ETA_MAX];
+    __shared__ double s_part[AR_GROUPS][AR_ROWS];
+    if (lp.ctl->status != ST_RUNNING || lp.ctl->q < 0) return;
+    const int m = lp.m;
+    const int k = lp.eta_cap > 0 ? lp.ctl->eta_count : 0;
+    if (k > 0) {  // y at the kept rows: 8 threads per row, 1/8 of the slices each, then a fixed-order combine
+        const int c = threadIdx.x / 8, sub = threadIdx.x % 8;
+        double part = 0.0;
+        int row = 0;
+        if (c < k) {
+            row = lp.eta_rows[c];
+            for (int sl = sub; sl < n_slices; sl += 8) part += lp.alpha_part[(size_t)sl * m + row];
+        }
+        part += __shfl_xor(part, 4, 8);
+        part += __shfl_xor(part, 2, 8);
+        part += __shfl_xor(part, 1, 8);
+        if (c < k && sub == 0) {
+            s_y[c] = part;
+            s_p[c] = row;
+        }
+        __syncthreads();
+    }
+    const int g = threadIdx.x / AR_ROWS, r = threadIdx.x % AR_ROWS;
+    const int i = blockIdx.x * AR_ROWS + r;
+    double acc = 0.0;
+    if (i < m) {
+        for (int sl = g; sl < n_slices; sl += AR_GROUPS) acc += lp.alpha_part[(size_t)sl * m + i];
+        for (int c = g; c < k; c += AR_GROUPS) acc += (lp.eta_cols[(size_t)c * lp.ld + i] - (i == s_p[c] ? 1.0 : 0.0)) * s_y[c];
+    }
+    s_part[g][r] = acc;
+    __syncthreads();
+    if (g == 0 && i < m) lp.alpha_in[i] = (s_part[0][r] + s_part[1][r]) + (s_part[2][r] + s_part[3][r]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Deferred product form of the inverse (dense pipeline; DeviceLP::eta_cap > 0).
+//   replaces  BasisInverse::change_basis + should_refactor/invert       lower_upper/mod.rs:94-178,249-252,78-92
+//                 (the reference keeps <= 30 Forrest-Tomlin etas beside L U and refactors; here <= eta_cap
+//                  product-form etas are kept beside the explicit inverse and folded in by one rank-k update)
+//             BasisInverse::basis_inverse_row, right_multiply_by_basis_inverse (w)    lower_upper/mod.rs:254-272,212-237
+//             Carry::update_minus_pi_and_obj                                           carry/mod.rs:338-349
+// With the etas kept as the columns M[:, P] of their product, applying them is a parallel (m x k) mat-vec (no
+// sequential eta loop), and a pivot costs two READ-ONLY passes over the stored inverse (FTRAN; rho_p and w together)
+// instead of a read pass plus a read-modify-write pass: 2 m^2 instead of 3 m^2 doubles of HBM traffic, no dirty lines
+// in front of the next pricing pass.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ETA_THREADS = 256;
+__device__ __forceinline__ double block_sum_256(double v, double* s_red) {  // fixed order; result in every thread
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    if (lane == WAVE - 1) s_red[wave] = v;
+    __syncthreads();
+    const double total = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __syncthreads();
+    return total;
+}
+
+// After K2 chose (q, p): fold the new eta E = I - (alpha - e_p) e_p'/alpha_p ... into the kept columns, and build the two
+// row vectors of the BTRAN pass.  Blocks [0, eta_cap): one kept column each; further blocks: the plain entries.
+//   rvec2 = alpha' M_old   (w   = rvec2 * Binv, old basis:  carry/mod.rs:575)
+//   rvec1 = e_p'  M_new    (rho = rvec1 * Binv, new basis:  lower_upper/mod.rs:254-272)
+__global__ void __launch_bounds__(ETA_THREADS) eta_update_kernel(DeviceLP lp) {
+    __shared__ double s_red[4];
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING || !ctl->pending) return;
+    const int m = lp.m, ld = lp.ld;
+    const int p = ctl->p;
+    const double alpha_pq = ctl->alpha_pq;
+    const int k = ctl->eta_count;
+    const int slot_p = lp.eta_slot[p];
+    if ((int)blockIdx.x < lp.eta_cap) {
+        const int c = blockIdx.x;
+        const bool is_new = slot_p < 0 && c == k;
+        if (c >= k && !is_new) return;
+        double* col = lp.eta_cols + (size_t)c * ld;
+        if (is_new) {  // column p of E itself
+            for (int i = threadIdx.x; i < m; i += ETA_THREADS) col[i] = (i == p) ? 1.0 / alpha_pq : -lp.alpha[i] / alpha_pq;
+            if (threadIdx.x == 0) {
+                lp.rvec2[p] = alpha_pq;  // p was not a kept column: M_old[:, p] = e_p
+                lp.rvec1[p] = 1.0 / alpha_pq;
+            }
+            return;
+        }
+        constexpr int PER = 16;  // m <= 4096
+        double a[PER], v[PER];
+        double dot = 0.0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = threadIdx.x + u * ETA_THREADS;
+            a[u] = i < m ? lp.alpha[i] : 0.0;
+            v[u] = i < m ? col[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) dot += a[u] * v[u];
+        dot = block_sum_256(dot, s_red);
+        const double t = col[p] / alpha_pq;  // read before any thread rewrites it: every thread reads, then a barrier
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = threadIdx.x + u * ETA_THREADS;
+            if (i < m) col[i] = (i == p) ? t : v[u] - a[u] * t;
+        }
+        if (threadIdx.x == 0) {
+            const int row = lp.eta_rows[c];
+            lp.rvec2[row] = dot;
+            lp.rvec1[row] = t;
+        }
+    } else {
+        const int i = ((int)blockIdx.x - lp.eta_cap) * ETA_THREADS + threadIdx.x;
+        if (i < m && i != p && lp.eta_slot[i] < 0) {
+            lp.rvec2[i] = lp.alpha[i];
+            lp.rvec1[i] = 0.0;
+        }
+    }
+}
+
+// The BTRAN pass: rho[j] = rvec1 . Binv(:, j), w[j] = rvec2 . Binv(:, j), -pi[j] -= cbar_q rho[j]; one wave per column,
+// 16-byte loads, both row vectors in LDS.  Block 0 also commits the bookkeeping of the eta that eta_update_kernel added.
+constexpr int BT_THREADS = 1024;
+__global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING || !ctl->pending) return;
+    const int m = lp.m, ld = lp.ld;
+    const int mp = (m + 1) & ~1;
+    double* s_r1 = smem;
+    double* s_r2 = smem + mp;
+    const double cbar_q = ctl->cbar_q;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int waves_total = gridDim.x * (BT_THREADS / WAVE);
+    for (int i = threadIdx.x; i < mp; i += BT_THREADS) {
+        s_r1[i] = i < m ? lp.rvec1[i] : 0.0;
+        s_r2[i] = i < m ? lp.rvec2[i] : 0.0;
+    }
+    __syncthreads();
+    const double2* r1 = reinterpret_cast<const double2*>(s_r1);
+    const double2* r2 = reinterpret_cast<const double2*>(s_r2);
+    const int half = m / 2;  // ld is even for the dense pipeline (m even is required by the caller)
+    for (int j = blockIdx.x * (BT_THREADS / WAVE) + wave; j < m; j += waves_total) {
+        const double2* col = reinterpret_cast<const double2*>(lp.Binv + (size_t)j * ld);
+        double d1 = 0.0, d2 = 0.0;
+        for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k0 + u * WAVE;
+                v[u] = kk < half ? col[kk] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k0 + u * WAVE;
+                if (kk < half) {
+                    const double2 x = r1[kk], y = r2[kk];
+                    d1 += v[u].x * x.x + v[u].y * x.y;
+                    d2 += v[u].x * y.x + v[u].y * y.y;
+                }
+            }
+        }
+        d1 = wave_sum(d1);
+        d2 = wave_sum(d2);
+        if (lane == WAVE - 1) {
+            lp.rho[j] = d1;
+            lp.w[j] = d2;
+            lp.minus_pi[j] -= cbar_q * d1;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int p = ctl->p;
+        if (lp.eta_slot[p] < 0) {
+            const int k = ctl->eta_count;
+            lp.eta_slot[p] = k;
+            lp.eta_rows[k] = p;
+            ctl->eta_count = k + 1;
+        }
+    }
+}
+
+// Consolidation, step 1: gather the rows P of the stored inverse (they are overwritten by step 2).
+__global__ void __launch_bounds__(256) eta_gather_kernel(DeviceLP lp) {
+    const int k = lp.ctl->eta_count;
+    const int c = blockIdx.y;
+    if (c >= k) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < lp.m) lp.eta_gather[(size_t)c * lp.m + j] = lp.Binv[(size_t)j * lp.ld + lp.eta_rows[c]];
+}
+// Step 2: Binv <- M Binv = Binv + (M[:, P] - I[:, P]) * Binv[P, :], a rank-k update; 128 x 64 tiles, 4 x 8 per thread.
+constexpr int EA_TI = 128, EA_TJ = 64;
+__global__ void __launch_bounds__(256) eta_apply_kernel(DeviceLP lp) {
+    __shared__ double s_a[ETA_MAX][EA_TI];  // (M - I)[rows of the tile, P_c]
+    __shared__ double s_b[ETA_MAX][EA_TJ];  // Binv_old[P_c, columns of the tile]
+    const int k = lp.ctl->eta_count;
+    if (k == 0) return;
+    const int m = lp.m, ld = lp.ld;
+    const int i0 = blockIdx.x * EA_TI, j0 = blockIdx.y * EA_TJ;
+    for (int e = threadIdx.x; e < k * EA_TI; e += 256) {
+        const int c = e / EA_TI, r = e % EA_TI;
+        const int i = i0 + r;
+        s_a[c][r] = i < m ? lp.eta_cols[(size_t)c * ld + i] - (i == lp.eta_rows[c] ? 1.0 : 0.0) : 0.0;
+    }
+    for (int e = threadIdx.x; e < k * EA_TJ; e += 256) {
+        const int c = e / EA_TJ, r = e % EA_TJ;
+        const int j = j0 + r;
+        s_b[c][r] = j < m ? lp.eta_gather[(size_t)c * m + j] : 0.0;
+    }
+    __syncthreads();
+    const int ri = (threadIdx.x % 32) * 4, cj = (threadIdx.x / 32) * 8;
+    double acc[8][4];
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[y][x] = 0.0;
+    for (int c = 0; c < k; ++c) {
+        double a[4], b[8];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) a[x] = s_a[c][ri + x];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) b[y] = s_b[c][cj + y];
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[y][x] += a[x] * b[y];
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const int j = j0 + cj + y;
+        if (j >= m) continue;
+        double* col = lp.Binv + (size_t)j * ld + i0 + ri;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            if (i0 + ri + x < m) col[x] += acc[y][x];
+    }
+}
+// Step 3: forget the etas.
+__global__ void eta_reset_kernel(DeviceLP lp) {
+    const int k = lp.ctl->eta_count;
+    if ((int)threadIdx.x < k) lp.eta_slot[lp.eta_rows[threadIdx.x]] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) lp.ctl->eta_count = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -988,13 +1230,11 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         ca = lp.col_start[q];
         cb_ = lp.col_start[q + 1];
     }
-    if (preselected) {
-        for (int sl = 0; sl < n_alpha_slices; ++sl) {
+    if (preselected) {  // alpha_reduce_kernel left the whole column (pending etas applied) in alpha_in
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int i = tid + r * K2F_THREADS;
-                if (i < m) al[r] += lp.alpha_part[(size_t)sl * m + i];
-            }
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * K2F_THREADS;
+            if (i < m) al[r] += lp.alpha_in[i];
         }
     }
     for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
@@ -1612,11 +1852,8 @@ void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double 
 void configure_dense_lds(size_t lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
-void launch_select(const DeviceLP& d, int n_price_blocks, int rule, hipStream_t s) {
-    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, s, d, n_price_blocks, rule);
-}
-void launch_ftran_partial(const DeviceLP& d, int n_slices, hipStream_t s) {
-    hipLaunchKernelGGL(ftran_partial_kernel, dim3((d.m + 255) / 256, n_slices), dim3(256), 0, s, d, n_slices);
+void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s) {
+    hipLaunchKernelGGL(ftran_partial_kernel, dim3((d.m + 255) / 256, n_slices), dim3(256), 0, s, d, n_slices, n_price_blocks, rule);
 }
 
 void configure_lds(size_t price_lds) {
@@ -1695,7 +1932,22 @@ void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, doubl
     else hipLaunchKernelGGL((gemm_polish_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual);
 }
 void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s) {
-    hipLaunchKernelGGL(alpha_reduce_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d, n_slices);
+    hipLaunchKernelGGL(alpha_reduce_kernel, dim3((d.m + AR_ROWS - 1) / AR_ROWS), dim3(AR_ROWS * AR_GROUPS), 0, s, d, n_slices);
+}
+int eta_max() { return ETA_MAX; }
+void configure_btran_lds(size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&btran_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+// deferred product form: fold the new eta into the kept columns, then one read-only pass for rho_p, w and -pi
+void launch_eta_update(const DeviceLP& d, hipStream_t s) {
+    hipLaunchKernelGGL(eta_update_kernel, dim3(d.eta_cap + (d.m + ETA_THREADS - 1) / ETA_THREADS), dim3(ETA_THREADS), 0, s, d);
+    const size_t lds = (size_t)2 * ((d.m + 1) & ~1) * sizeof(double);
+    RELP_LAUNCH(2, btran_pass_kernel, dim3(256), dim3(BT_THREADS), lds, s, d);
+}
+void launch_eta_consolidate(const DeviceLP& d, hipStream_t s) {
+    hipLaunchKernelGGL(eta_gather_kernel, dim3((d.m + 255) / 256, d.eta_cap), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(eta_apply_kernel, dim3((d.m + EA_TI - 1) / EA_TI, (d.m + EA_TJ - 1) / EA_TJ), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(eta_reset_kernel, dim3(1), dim3(ETA_MAX), 0, s, d);
 }
 void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s) {
     hipLaunchKernelGGL(scaled_basis_kernel, dim3(d.m), dim3(64), 0, s, d, T, scale);

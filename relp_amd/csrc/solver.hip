@@ -18,8 +18,7 @@ void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_
                   int first, int last, int cand_offset, hipStream_t s);
 void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s);
 void configure_dense_lds(size_t lds);
-void launch_select(const DeviceLP& d, int n_price_blocks, int rule, hipStream_t s);
-void launch_ftran_partial(const DeviceLP& d, int n_slices, hipStream_t s);
+void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s);
 bool fast_k2_available(const DeviceLP& d, int n_price_blocks);
 void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop);
 void configure_lds(size_t price_lds);
@@ -36,6 +35,10 @@ void launch_residual(const DeviceLP& d, const double* X, double* R, hipStream_t 
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s);
 void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, hipStream_t s);
 void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s);
+int eta_max();
+void configure_btran_lds(size_t lds);
+void launch_eta_update(const DeviceLP& d, hipStream_t s);
+void launch_eta_consolidate(const DeviceLP& d, hipStream_t s);
 void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s);
 void launch_row_scan(const DeviceLP& d, int r, double tol, hipStream_t s);
 void launch_ftran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
@@ -87,7 +90,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -227,6 +230,21 @@ void Solver::upload() {
         RELP_HIP(hipStreamSynchronize(stream_));
     }
     d_.alpha_part = dmalloc<double>((size_t)std::max(1, ftran_slices_) * m);
+    d_.alpha_in = dmalloc<double>(m);
+    // deferred product form of the inverse: the dense pipeline (multi-block FTRAN), m even and <= 4096 (eta_update_kernel)
+    const char* eta_env = getenv("RELP_ETA");  // RELP_ETA=0 keeps the per-pivot rank-one update (A/B measurements)
+    eta_mode_ = n_dense > 0 && ftran_slices_ > 0 && m % 2 == 0 && m <= 4096 && !(eta_env && std::string(eta_env) == "0");
+    d_.eta_cap = eta_mode_ ? eta_max() : 0;
+    if (eta_mode_) {
+        d_.eta_cols = dmalloc<double>((size_t)d_.eta_cap * d_.ld);
+        d_.eta_rows = dmalloc<int>(d_.eta_cap);
+        d_.eta_slot = dmalloc<int>(m);
+        d_.eta_gather = dmalloc<double>((size_t)d_.eta_cap * m);
+        d_.rvec1 = dmalloc<double>(m);
+        d_.rvec2 = dmalloc<double>(m);
+        RELP_HIP(hipMemsetAsync(d_.eta_slot, 0xff, m * sizeof(int), stream_));
+        configure_btran_lds((size_t)2 * ((m + 1) & ~1) * sizeof(double));
+    }
     if (n_dense > 0) {
         std::vector<double> dense((size_t)n_dense * d_.dense_ld, 0.0);
         for (int jd = 0; jd < n_dense; ++jd)
@@ -334,19 +352,35 @@ void Solver::launch_pivots(int count) {
     for (int it = 0; it < count; ++it) {
         enqueue_price(0);
         enqueue_ftran_ratio(0);
-        launch_update(d_, stream_);
+        enqueue_update();
+        if (eta_mode_ && ((it + 1) % d_.eta_cap == 0 || it + 1 == count)) enqueue_consolidate();
     }
-    stats_.launches += 1 + (3LL + (dense_blocks_ > 0) + 3 * (ftran_slices_ > 0)) * count;
+    stats_.launches += 1 + (3LL + (dense_blocks_ > 0) + 2 * (ftran_slices_ > 0) + (eta_mode_ ? 1 : 0)) * count;
     stats_.price_launches += count;
 }
 
 // Pricing pass: the dense block (if any) streams through price_dense_kernel, every other column through the CSC kernel.
 void Solver::enqueue_price(int skip_weights) {
-    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
+    // beside a dense block the CSC kernel only sees the short slack columns: staging -pi, rho_p, w in LDS (3 m doubles per
+    // workgroup) would cost more than the gathers it saves.  (Running it on a second stream beside the dense pass was
+    // measured too: the fork/join edges of the captured graph cost 15 us per pivot against the 8 us they hide.)
+    const bool use_lds = price_lds_ <= 160 * 1024 - 1024 && dense_blocks_ == 0;
     if (price_blocks_ > 0)
         launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, skip_weights, opt_.tol_dual,
                      sparse_first_, d_.n, 0, stream_);
     if (dense_blocks_ > 0) launch_price_dense(d_, dense_blocks_, skip_weights, opt_.tol_dual, price_blocks_, stream_);
+}
+
+// The basis update: rank-one update of the explicit inverse (K3), or -- deferred product form -- the eta bookkeeping plus
+// one read-only pass for rho_p, w and -pi.
+void Solver::enqueue_update() {
+    if (eta_mode_) launch_eta_update(d_, stream_);
+    else launch_update(d_, stream_);
+}
+// Fold the pending etas into the stored inverse (no-op kernels when there are none; runs whatever the status is, so that
+// everything outside the pivot loop sees the plain explicit inverse).
+void Solver::enqueue_consolidate() {
+    if (eta_mode_) launch_eta_consolidate(d_, stream_);
 }
 
 // Entering column + FTRAN + ratio test (+ updates in mode 0).  Long (dense) columns take the multi-block FTRAN.
@@ -354,8 +388,7 @@ void Solver::enqueue_ftran_ratio(int mode) {
     const int skip_art = phase_ == 2 ? 1 : 0;
     const int slots = price_blocks_ + dense_blocks_;
     if (ftran_slices_ > 0) {
-        launch_select(d_, slots, opt_.pivot_rule, stream_);
-        launch_ftran_partial(d_, ftran_slices_, stream_);
+        launch_ftran_partial(d_, ftran_slices_, slots, opt_.pivot_rule, stream_);
         launch_alpha_reduce(d_, ftran_slices_, stream_);
     }
     launch_ftran_ratio(d_, opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, ftran_slices_ > 0 ? 1 : 0, stream_);
@@ -730,7 +763,8 @@ double Solver::profile_kernel(int which, int repetitions) {
         if (which == 1) arm_launch_timer(1, starts[k], stops[k]);
         enqueue_ftran_ratio(0);
         if (which == 2) arm_launch_timer(2, starts[k], stops[k]);
-        launch_update(d_, stream_);
+        enqueue_update();
+        if (eta_mode_ && ((k + 1) % d_.eta_cap == 0 || k + 1 == repetitions)) enqueue_consolidate();
     }
     arm_launch_timer(-1, nullptr, nullptr);
     Ctl after = read_ctl();

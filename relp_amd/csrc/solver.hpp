@@ -36,6 +36,7 @@ struct Ctl {
     double scan_value;
     int scan_column;
     int nz_count;      // entries of the ordered non-zero list of alpha_q (written by K2, read by K3)
+    int eta_count;     // deferred product form (dense pipeline): pivots not yet folded into the stored inverse
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
@@ -48,6 +49,18 @@ struct DeviceLP {
     int n_dense = 0, dense_first = 0, dense_ld = 0;
     double* dense_val = nullptr;
     double* alpha_part = nullptr;  // slices of the multi-block FTRAN, [n_slices][m]
+    double* alpha_in = nullptr;    // their fixed-order sum (with the pending etas applied): what K2 reads when preselected
+    // Deferred product form (eta_cap > 0, dense pipeline only).  The current inverse is  M * Binv  with
+    //   M = E_k ... E_1 = I + sum_c (eta_cols[:, c] - e_{eta_rows[c]}) e_{eta_rows[c]}'        (k = ctl->eta_count <= eta_cap)
+    // i.e. eta_cols[:, c] is column eta_rows[c] of M.  Binv itself is only rewritten every eta_cap pivots (one rank-k
+    // update); per pivot the passes over it are read-only (FTRAN, and one BTRAN pass for rho_p and w together).
+    int eta_cap = 0;
+    double* eta_cols = nullptr;    // [eta_cap][ld]
+    int* eta_rows = nullptr;       // [eta_cap]
+    int* eta_slot = nullptr;       // [m]: slot of row i in eta_rows, or -1
+    double* eta_gather = nullptr;  // [eta_cap][m]: rows eta_rows[c] of Binv, gathered before the rank-k update
+    double* rvec1 = nullptr;       // e_p' M_new  (row vector whose product with Binv is rho_p)          [m]
+    double* rvec2 = nullptr;       // alpha' M_old (row vector whose product with Binv is w)             [m]
     // CSC of [artificial identity columns | provider columns] (matrix_data.rs:291-329 materialised once)
     int* col_start = nullptr;
     int* row_index = nullptr;
@@ -132,6 +145,8 @@ private:
     void launch_pivots(int count);
     void enqueue_price(int skip_weights);
     void enqueue_ftran_ratio(int mode);
+    void enqueue_update();
+    void enqueue_consolidate();
     void build_graph(int count);
     void polish(bool refresh_vectors);
     void invert_from_scratch();
@@ -150,6 +165,7 @@ private:
     int dense_blocks_ = 0;        // dense pricing workgroups (candidate slots follow the sparse ones)
     int ftran_slices_ = 0;        // > 0: multi-block FTRAN pipeline (select -> partial FTRAN -> fused kernel)
     int sparse_first_ = 0;        // device columns priced by the CSC kernel: [sparse_first_, n)
+    bool eta_mode_ = false;       // deferred product form of the inverse (DeviceLP::eta_cap > 0)
     size_t price_lds_ = 0;
     hipStream_t stream_ = nullptr;
     hipGraph_t graph_ = nullptr;

@@ -149,6 +149,123 @@ __global__ void __launch_bounds__(256) variant_e(const double2* p, size_t count,
     if (acc == 1.2345e-300) out[0] = acc;
 }
 
+// F: the whole workgroup streams one column at a time (adjacent waves read adjacent KiB), one LDS reduction per column
+__global__ void __launch_bounds__(THREADS) variant_f(Args a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double s_part[2][3][THREADS / WAVE];
+    double* s_pi = smem; double* s_rho = smem + a.mp; double* s_w = smem + 2 * a.mp;
+    for (int i = threadIdx.x; i < a.mp; i += THREADS) { s_pi[i] = a.pi[i]; s_rho[i] = a.rho[i]; s_w[i] = a.w[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / WAVE;
+    const int half = a.mp / 2;   // 2048 double2 = 2 per thread
+    const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
+    const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
+    const double2* w2 = reinterpret_cast<const double2*>(s_w);
+    // columns of this block: contiguous range
+    const int per = (a.n + gridDim.x - 1) / gridDim.x;
+    const int j0 = blockIdx.x * per, j1 = min(a.n, j0 + per);
+    int buf = 0;
+    int jprev = -1;
+    for (int jd = j0; jd < j1; ++jd) {
+        if (a.pos[jd] >= 0) continue;
+        const double2* col = reinterpret_cast<const double2*>(a.A + (size_t)jd * a.mp);
+        const int k0 = threadIdx.x, k1 = threadIdx.x + THREADS;
+        const double2 v0 = col[k0], v1 = k1 < half ? col[k1] : make_double2(0, 0);
+        // finish the previous column while these loads fly
+        if (jprev >= 0 && wave == 0) {
+            double t0 = lane < THREADS / WAVE ? s_part[buf ^ 1][0][lane] : 0, t1 = lane < THREADS / WAVE ? s_part[buf ^ 1][1][lane] : 0, t2 = lane < THREADS / WAVE ? s_part[buf ^ 1][2][lane] : 0;
+            t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+            if (lane == 0) { a.out[3 * jprev] = t0; a.out[3 * jprev + 1] = t1; a.out[3 * jprev + 2] = t2; }
+        }
+        double d0, d1, d2;
+        {
+            const double2 x = pi2[k0], y = rho2[k0], z = w2[k0];
+            d0 = v0.x * x.x + v0.y * x.y; d1 = v0.x * y.x + v0.y * y.y; d2 = v0.x * z.x + v0.y * z.y;
+        }
+        if (k1 < half) {
+            const double2 x = pi2[k1], y = rho2[k1], z = w2[k1];
+            d0 += v1.x * x.x + v1.y * x.y; d1 += v1.x * y.x + v1.y * y.y; d2 += v1.x * z.x + v1.y * z.y;
+        }
+        d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+        if (lane == 0) { s_part[buf][0][wave] = d0; s_part[buf][1][wave] = d1; s_part[buf][2][wave] = d2; }
+        __syncthreads();
+        jprev = jd;
+        buf ^= 1;
+    }
+    if (jprev >= 0 && wave == 0) {
+        double t0 = lane < THREADS / WAVE ? s_part[buf ^ 1][0][lane] : 0, t1 = lane < THREADS / WAVE ? s_part[buf ^ 1][1][lane] : 0, t2 = lane < THREADS / WAVE ? s_part[buf ^ 1][2][lane] : 0;
+        t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+        if (lane == 0) { a.out[3 * jprev] = t0; a.out[3 * jprev + 1] = t1; a.out[3 * jprev + 2] = t2; }
+    }
+}
+
+// G: variant A with non-temporal column loads
+__global__ void __launch_bounds__(THREADS) variant_g(Args a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* s_pi = smem; double* s_rho = smem + a.mp; double* s_w = smem + 2 * a.mp;
+    for (int i = threadIdx.x; i < a.mp; i += THREADS) { s_pi[i] = a.pi[i]; s_rho[i] = a.rho[i]; s_w[i] = a.w[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / WAVE;
+    const int waves_total = gridDim.x * (THREADS / WAVE);
+    const int half = a.mp / 2;
+    for (int jd = blockIdx.x * (THREADS / WAVE) + wave; jd < a.n; jd += waves_total) {
+        if (a.pos[jd] >= 0) continue;
+        const double* colp = a.A + (size_t)jd * a.mp;
+        const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
+        const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
+        const double2* w2 = reinterpret_cast<const double2*>(s_w);
+        double d0 = 0, d1 = 0, d2 = 0;
+        for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * WAVE;
+                v[u].x = __builtin_nontemporal_load(colp + 2 * k);
+                v[u].y = __builtin_nontemporal_load(colp + 2 * k + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * WAVE;
+                const double2 x = pi2[k], y = rho2[k], z = w2[k];
+                d0 += v[u].x * x.x + v[u].y * x.y; d1 += v[u].x * y.x + v[u].y * y.y; d2 += v[u].x * z.x + v[u].y * z.y;
+            }
+        }
+        d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+        if (lane == 0) { a.out[3 * jd] = d0; a.out[3 * jd + 1] = d1; a.out[3 * jd + 2] = d2; }
+    }
+}
+
+// H: two vectors only (64 KB LDS, two workgroups per CU), the shape of the BTRAN pass
+__global__ void __launch_bounds__(THREADS) variant_h(Args a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* s_pi = smem; double* s_rho = smem + a.mp;
+    for (int i = threadIdx.x; i < a.mp; i += THREADS) { s_pi[i] = a.pi[i]; s_rho[i] = a.rho[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / WAVE;
+    const int waves_total = gridDim.x * (THREADS / WAVE);
+    const int half = a.mp / 2;
+    for (int jd = blockIdx.x * (THREADS / WAVE) + wave; jd < a.n; jd += waves_total) {
+        if (a.pos[jd] >= 0) continue;
+        const double2* col = reinterpret_cast<const double2*>(a.A + (size_t)jd * a.mp);
+        const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
+        const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
+        double d0 = 0, d1 = 0;
+        for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[k0 + u * WAVE];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * WAVE;
+                const double2 x = pi2[k], y = rho2[k];
+                d0 += v[u].x * x.x + v[u].y * x.y; d1 += v[u].x * y.x + v[u].y * y.y;
+            }
+        }
+        d0 = wave_sum(d0); d1 = wave_sum(d1);
+        if (lane == 0) { a.out[3 * jd] = d0; a.out[3 * jd + 1] = d1; }
+    }
+}
+
 __global__ void dirty_kernel(double2* p, size_t count) {  // stands in for the inverse update: read-modify-write
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -180,20 +297,24 @@ int main(int argc, char** argv) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_a), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_b<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_b<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t s;
     CHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const double bytes = (double)nonbasic * mp * 8;
     std::vector<double> ref(3 * n), got(3 * n);
-    for (int dirty = 0; dirty < 2; ++dirty) {
-        for (int variant = 0; variant < 7; ++variant) {
+    for (int dirty = 1; dirty < 3; ++dirty) {
+        for (int variant = 0; variant < 10; ++variant) {
             for (int blocks : {256, 512}) {
-                if (variant >= 5 && blocks != 256) continue;
+                if ((variant == 5 || variant == 6) && blocks != 256) continue;
                 std::vector<float> times;
                 CHECK(hipMemset(out, 0, (size_t)3 * n * 8));
                 for (int r = 0; r < reps; ++r) {
-                    if (dirty) dirty_kernel<<<2048, 256, 0, s>>>(reinterpret_cast<double2*>(inv), (size_t)m * m / 2);
+                    if (dirty == 1) dirty_kernel<<<2048, 256, 0, s>>>(reinterpret_cast<double2*>(inv), (size_t)m * m / 2);
+                    if (dirty == 2) { variant_e<<<8192, 256, 0, s>>>(reinterpret_cast<const double2*>(inv), (size_t)m * m / 2, out); variant_e<<<8192, 256, 0, s>>>(reinterpret_cast<const double2*>(inv), (size_t)m * m / 2, out); }
                     switch (variant) {
                         case 0: hipExtLaunchKernelGGL(variant_a, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a); break;
                         case 1: hipExtLaunchKernelGGL(variant_b<8>, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a); break;
@@ -201,6 +322,9 @@ int main(int argc, char** argv) {
                         case 3: hipExtLaunchKernelGGL(variant_d, dim3(blocks), dim3(THREADS), 0, s, e0, e1, 0, a); break;
                         case 4: hipExtLaunchKernelGGL(variant_e, dim3(blocks * 8), dim3(256), 0, s, e0, e1, 0, reinterpret_cast<const double2*>(A), (size_t)n * mp / 2, out); break;
                         case 5: hipExtLaunchKernelGGL(variant_e, dim3(8192), dim3(256), 0, s, e0, e1, 0, reinterpret_cast<const double2*>(A), (size_t)n * mp / 2, out); break;
+                        case 7: hipExtLaunchKernelGGL(variant_f, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a); break;
+                        case 8: hipExtLaunchKernelGGL(variant_g, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a); break;
+                        case 9: hipExtLaunchKernelGGL(variant_h, dim3(blocks), dim3(THREADS), lds * 2 / 3, s, e0, e1, 0, a); break;
                         case 6: hipExtLaunchKernelGGL(variant_e, dim3(32768), dim3(256), 0, s, e0, e1, 0, reinterpret_cast<const double2*>(A), (size_t)n * mp / 2, out); break;
                     }
                     CHECK(hipStreamSynchronize(s));
@@ -210,11 +334,11 @@ int main(int argc, char** argv) {
                 }
                 std::sort(times.begin(), times.end());
                 const double med = times[times.size() / 2] * 1e-3;
-                const double b = variant >= 4 ? (double)n * mp * 8 : bytes;
-                const char* names[] = {"A current", "B pipelined x8", "B pipelined x4", "D stream/col", "E flat", "E flat 8192", "E flat 32768"};
-                if (variant <= 2) {
+                const double b = (variant >= 4 && variant <= 6) ? (double)n * mp * 8 : bytes;
+                const char* names[] = {"A current", "B pipelined x8", "B pipelined x4", "D stream/col", "E flat", "E flat 8192", "E flat 32768", "F block/col", "G nontemporal", "H 2 vectors"};
+                if (variant <= 2 || variant == 7 || variant == 8) {
                     CHECK(hipMemcpy(got.data(), out, (size_t)3 * n * 8, hipMemcpyDeviceToHost));
-                    if (variant == 0 && blocks == 256 && dirty == 0) ref = got;
+                    if (variant == 0 && blocks == 256 && dirty == 1) ref = got;
                     double worst = 0;
                     for (int j = 0; j < 3 * n; ++j) worst = std::max(worst, std::abs(got[j] - ref[j]) / (1e-300 + std::abs(ref[j])));
                     printf("dirty=%d %-16s blocks=%4d  %7.1f us  %6.0f GB/s  (max rel diff vs A %.1e)\n", dirty, names[variant], blocks, med * 1e6, b / med / 1e9, worst);
