@@ -252,6 +252,7 @@ def main():
             "config": {"workload": workload,
                        "pivots_per_solve": int(last.pivots_phase_one + last.pivots_phase_two),
                        "objective": last.objective, "wall_clock_to_optimal_s": last.solve_seconds,
+                       "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
                        "parallelism": "1 LP per GPU x%d" % world, "exact": exact},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -323,6 +323,7 @@ void Solver::begin_phase_one() {
     polishes_ = 0;
     max_residual_ = 0.0;
     since_polish_ = 0;
+    polish_scale_ = 1;
     redundant_rows_.clear();
     set_phase(n_art > 0 ? 1 : 2);
 }
@@ -416,16 +417,23 @@ void Solver::polish(bool refresh_vectors) {
         RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
         if (d_.n_dense > 0) launch_residual_dense(d_, d_.Binv2, d_.Binv, d_.R, stream_);
         else launch_residual(d_, d_.Binv, d_.R, stream_);
-        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, stream_);
-        RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-        Ctl c = read_ctl();
-        if (it == 0) max_residual_ = std::max(max_residual_, c.residual);
+        Ctl c = read_ctl();  // max |I - B' T|
         if (!(c.residual == c.residual)) throw std::runtime_error("NaN in basis inverse");
-        if (c.residual < 1e-8) break;
+        if (it == 0) {
+            max_residual_ = std::max(max_residual_, c.residual);
+            // the drift seen after this many pivots schedules the next polish: far below the working accuracy -> wait
+            // twice as long (up to 16 periods), close to it -> back to the configured period
+            if (c.residual < 1e-8) polish_scale_ = std::min(16, polish_scale_ * 2);
+            else if (c.residual > 1e-6) polish_scale_ = 1;
+        }
+        if (c.residual < 1e-12) break;  // nothing to correct: skip the second GEMM
         if (c.residual >= 0.5) {  // drifted too far for the quadratic iteration: rebuild from the basis columns
             invert_from_scratch();
             break;
         }
+        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, stream_);
+        RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+        if (c.residual < 1e-8) break;  // one quadratic step takes it to ~residual^2
     }
     binv_identity_ = false;
     polishes_++;
@@ -507,6 +515,7 @@ void Solver::set_basis(const int* basis_columns) {
     polishes_ = 0;
     max_residual_ = 0.0;
     since_polish_ = 0;
+    polish_scale_ = 1;
     redundant_rows_.clear();
     set_phase(2);
 }
@@ -517,7 +526,7 @@ long long Solver::iterate(long long count, int* stop_reason) {
     long long done = 0;
     int reason = ST_BUDGET;
     while (done < count) {
-        long long room = opt_.polish_period > 0 ? opt_.polish_period - since_polish_ : count;
+        long long room = opt_.polish_period > 0 ? (long long)opt_.polish_period * polish_scale_ - since_polish_ : count;
         if (room <= 0) { polish(true); continue; }
         int batch = (int)std::min<long long>({count - done, room, (long long)std::max(1, opt_.pivots_per_launch)});
         Ctl before = read_ctl();

@@ -181,6 +181,7 @@ private:
     long long polishes_ = 0;
     double max_residual_ = 0.0;
     long long since_polish_ = 0;
+    int polish_scale_ = 1;        // multiplier of polish_period, adapted to the drift measured at each polish
 
     friend struct SolverAccess;
 };
