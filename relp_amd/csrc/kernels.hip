@@ -557,6 +557,7 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
     __shared__ Cand s_cand[8];
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING) return;
+    const bool structured = lp.eta_cap > 0;  // unit columns of the stored inverse are known: skip their loads
     const bool publisher = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     if (ctl->iters >= ctl->budget) {
         if (publisher) {
@@ -604,20 +605,30 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
         const int cnt = min(256, e1 - c0);
         __syncthreads();
         if (threadIdx.x < cnt) {
-            s_rows[threadIdx.x] = lp.row_index[c0 + threadIdx.x];
+            const int row = lp.row_index[c0 + threadIdx.x];
+            // a unit column e_row contributes v_e to row `row` only: encode it as ~row, no load of the inverse needed
+            s_rows[threadIdx.x] = (structured && !lp.touched[row]) ? ~row : row;
             s_vals[threadIdx.x] = lp.value[c0 + threadIdx.x];
         }
         __syncthreads();
         if (i < m) {
             const double* col = lp.Binv + i;
-            int e = 0;
-            for (; e + 4 <= cnt; e += 4) {
-                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
-                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
-                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+            if (structured) {
+                for (int e = 0; e < cnt; ++e) {
+                    const int row = s_rows[e];  // wave-uniform branch
+                    if (row >= 0) a0 += col[(size_t)row * ld] * s_vals[e];
+                    else if (~row == i) a1 += s_vals[e];
+                }
+            } else {
+                int e = 0;
+                for (; e + 4 <= cnt; e += 4) {
+                    a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                    a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
+                    a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
+                    a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+                }
+                for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
             }
-            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
         }
     }
     if (i < m) lp.alpha_part[(size_t)blockIdx.y * m + i] = (a0 + a1) + (a2 + a3);
@@ -778,7 +789,18 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp) {
     const double2* r1 = reinterpret_cast<const double2*>(s_r1);
     const double2* r2 = reinterpret_cast<const double2*>(s_r2);
     const int half = m / 2;  // ld is even for the dense pipeline (m even is required by the caller)
-    for (int j = blockIdx.x * (BT_THREADS / WAVE) + wave; j < m; j += waves_total) {
+    // unit columns: rho_j = rvec1[j], w_j = rvec2[j]
+    for (int j = blockIdx.x * BT_THREADS + threadIdx.x; j < m; j += gridDim.x * BT_THREADS) {
+        if (!lp.touched[j]) {
+            const double d1 = s_r1[j];
+            lp.rho[j] = d1;
+            lp.w[j] = s_r2[j];
+            lp.minus_pi[j] -= cbar_q * d1;
+        }
+    }
+    const int n_touched = ctl->touched_count;
+    for (int idx = blockIdx.x * (BT_THREADS / WAVE) + wave; idx < n_touched; idx += waves_total) {
+        const int j = lp.tlist[idx];
         const double2* col = reinterpret_cast<const double2*>(lp.Binv + (size_t)j * ld);
         double d1 = 0.0, d2 = 0.0;
         for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
@@ -817,23 +839,52 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp) {
     }
 }
 
-// Consolidation, step 1: gather the rows P of the stored inverse (they are overwritten by step 2).
+// Consolidation, step 0: the pivot rows of the pending etas become touched columns.
+__global__ void eta_mark_kernel(DeviceLP lp) {
+    if (threadIdx.x != 0) return;
+    Ctl* ctl = lp.ctl;
+    const int k = ctl->eta_count;
+    int count = ctl->touched_count;
+    for (int c = 0; c < k; ++c) {
+        const int row = lp.eta_rows[c];
+        if (!lp.touched[row]) {
+            lp.touched[row] = 1;
+            lp.tlist[count++] = row;
+        }
+    }
+    ctl->touched_count = count;
+}
+__global__ void __launch_bounds__(256) mark_all_touched_kernel(DeviceLP lp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < lp.m) {
+        lp.touched[j] = 1;
+        lp.tlist[j] = j;
+    }
+    if (j == 0) lp.ctl->touched_count = lp.m;
+}
+// Step 1: gather the rows P of the stored inverse (they are overwritten by step 2); touched columns only (the others
+// are unit vectors of rows outside P: zero there).
 __global__ void __launch_bounds__(256) eta_gather_kernel(DeviceLP lp) {
     const int k = lp.ctl->eta_count;
     const int c = blockIdx.y;
     if (c >= k) return;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < lp.m) lp.eta_gather[(size_t)c * lp.m + j] = lp.Binv[(size_t)j * lp.ld + lp.eta_rows[c]];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= lp.ctl->touched_count) return;
+    const int j = lp.tlist[idx];
+    lp.eta_gather[(size_t)c * lp.m + idx] = lp.Binv[(size_t)j * lp.ld + lp.eta_rows[c]];
 }
-// Step 2: Binv <- M Binv = Binv + (M[:, P] - I[:, P]) * Binv[P, :], a rank-k update; 128 x 64 tiles, 4 x 8 per thread.
+// Step 2: Binv <- M Binv = Binv + (M[:, P] - I[:, P]) * Binv[P, :], a rank-k update of the touched columns;
+// 128 x 64 tiles, 4 x 8 per thread.
 constexpr int EA_TI = 128, EA_TJ = 64;
 __global__ void __launch_bounds__(256) eta_apply_kernel(DeviceLP lp) {
     __shared__ double s_a[ETA_MAX][EA_TI];  // (M - I)[rows of the tile, P_c]
     __shared__ double s_b[ETA_MAX][EA_TJ];  // Binv_old[P_c, columns of the tile]
+    __shared__ int s_j[EA_TJ];
     const int k = lp.ctl->eta_count;
-    if (k == 0) return;
-    const int m = lp.m, ld = lp.ld;
+    const int n_touched = lp.ctl->touched_count;
     const int i0 = blockIdx.x * EA_TI, j0 = blockIdx.y * EA_TJ;
+    if (k == 0 || j0 >= n_touched) return;
+    const int m = lp.m, ld = lp.ld;
     for (int e = threadIdx.x; e < k * EA_TI; e += 256) {
         const int c = e / EA_TI, r = e % EA_TI;
         const int i = i0 + r;
@@ -841,9 +892,9 @@ __global__ void __launch_bounds__(256) eta_apply_kernel(DeviceLP lp) {
     }
     for (int e = threadIdx.x; e < k * EA_TJ; e += 256) {
         const int c = e / EA_TJ, r = e % EA_TJ;
-        const int j = j0 + r;
-        s_b[c][r] = j < m ? lp.eta_gather[(size_t)c * m + j] : 0.0;
+        s_b[c][r] = j0 + r < n_touched ? lp.eta_gather[(size_t)c * m + j0 + r] : 0.0;
     }
+    if (threadIdx.x < EA_TJ) s_j[threadIdx.x] = j0 + threadIdx.x < n_touched ? lp.tlist[j0 + threadIdx.x] : -1;
     __syncthreads();
     const int ri = (threadIdx.x % 32) * 4, cj = (threadIdx.x / 32) * 8;
     double acc[8][4];
@@ -864,8 +915,8 @@ __global__ void __launch_bounds__(256) eta_apply_kernel(DeviceLP lp) {
     }
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-        const int j = j0 + cj + y;
-        if (j >= m) continue;
+        const int j = s_j[cj + y];
+        if (j < 0) continue;
         double* col = lp.Binv + (size_t)j * ld + i0 + ri;
 #pragma unroll
         for (int x = 0; x < 4; ++x)
@@ -1944,7 +1995,11 @@ void launch_eta_update(const DeviceLP& d, hipStream_t s) {
     const size_t lds = (size_t)2 * ((d.m + 1) & ~1) * sizeof(double);
     RELP_LAUNCH(2, btran_pass_kernel, dim3(256), dim3(BT_THREADS), lds, s, d);
 }
+void launch_mark_all_touched(const DeviceLP& d, hipStream_t s) {
+    hipLaunchKernelGGL(mark_all_touched_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d);
+}
 void launch_eta_consolidate(const DeviceLP& d, hipStream_t s) {
+    hipLaunchKernelGGL(eta_mark_kernel, dim3(1), dim3(64), 0, s, d);
     hipLaunchKernelGGL(eta_gather_kernel, dim3((d.m + 255) / 256, d.eta_cap), dim3(256), 0, s, d);
     hipLaunchKernelGGL(eta_apply_kernel, dim3((d.m + EA_TI - 1) / EA_TI, (d.m + EA_TJ - 1) / EA_TJ), dim3(256), 0, s, d);
     hipLaunchKernelGGL(eta_reset_kernel, dim3(1), dim3(ETA_MAX), 0, s, d);

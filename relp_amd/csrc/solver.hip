@@ -39,6 +39,7 @@ int eta_max();
 void configure_btran_lds(size_t lds);
 void launch_eta_update(const DeviceLP& d, hipStream_t s);
 void launch_eta_consolidate(const DeviceLP& d, hipStream_t s);
+void launch_mark_all_touched(const DeviceLP& d, hipStream_t s);
 void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s);
 void launch_row_scan(const DeviceLP& d, int r, double tol, hipStream_t s);
 void launch_ftran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
@@ -90,7 +91,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -242,6 +243,9 @@ void Solver::upload() {
         d_.eta_gather = dmalloc<double>((size_t)d_.eta_cap * m);
         d_.rvec1 = dmalloc<double>(m);
         d_.rvec2 = dmalloc<double>(m);
+        d_.touched = dmalloc<int>(m);
+        d_.tlist = dmalloc<int>(m);
+        RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));
         RELP_HIP(hipMemsetAsync(d_.eta_slot, 0xff, m * sizeof(int), stream_));
         configure_btran_lds((size_t)2 * ((m + 1) & ~1) * sizeof(double));
     }
@@ -313,6 +317,7 @@ void Solver::begin_phase_one() {
     upload_vec(d_.pos, pos, stream_);
     RELP_HIP(hipMemcpyAsync(d_.xB, d_.rhs, m * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     launch_identity(d_.Binv, m, d_.ld, stream_);
+    if (eta_mode_) RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));  // every column is a unit vector
     binv_identity_ = true;
     Ctl c{};
     c.forced_q = c.forced_p = -1;
@@ -338,9 +343,11 @@ void Solver::set_phase(int phase) {
     launch_pi(d_, stream_);
     if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE) launch_gamma_init(d_, binv_identity_ ? 1 : 0, stream_);
     Ctl c = read_ctl();
-    double minus_obj = c.minus_obj;
+    const double minus_obj = c.minus_obj;
+    const int touched_count = c.touched_count;
     c = Ctl{};
     c.minus_obj = minus_obj;
+    c.touched_count = touched_count;
     c.forced_q = c.forced_p = -1;
     c.last_selected = -1;
     c.scan_column = std::numeric_limits<int>::max();
@@ -486,6 +493,7 @@ void Solver::invert_from_scratch() {
         if (it > 60 && c.residual >= previous) break;
         previous = c.residual;
     }
+    if (eta_mode_) launch_mark_all_touched(d_, stream_);  // no column of a fresh inverse is known to be a unit vector
     binv_identity_ = false;
 }
 

@@ -37,6 +37,7 @@ struct Ctl {
     int scan_column;
     int nz_count;      // entries of the ordered non-zero list of alpha_q (written by K2, read by K3)
     int eta_count;     // deferred product form (dense pipeline): pivots not yet folded into the stored inverse
+    int touched_count; // columns of the stored inverse that are not unit vectors any more (entries of DeviceLP::tlist)
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
@@ -61,6 +62,11 @@ struct DeviceLP {
     double* eta_gather = nullptr;  // [eta_cap][m]: rows eta_rows[c] of Binv, gathered before the rank-k update
     double* rvec1 = nullptr;       // e_p' M_new  (row vector whose product with Binv is rho_p)          [m]
     double* rvec2 = nullptr;       // alpha' M_old (row vector whose product with Binv is w)             [m]
+    // Column j of the STORED inverse is still the unit vector e_j until a row-j pivot has been folded in (E e_j = e_j for
+    // every eta of another row; the polish keeps such columns exactly).  touched[j] / tlist record the others, so that the
+    // FTRAN and BTRAN passes and the rank-k update only stream columns that carry information.
+    int* touched = nullptr;        // [m] 0/1
+    int* tlist = nullptr;          // [m] touched columns in the order they were folded in
     // CSC of [artificial identity columns | provider columns] (matrix_data.rs:291-329 materialised once)
     int* col_start = nullptr;
     int* row_index = nullptr;
