@@ -554,10 +554,12 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
 __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_slices, int n_price_blocks, int rule) {
     __shared__ int s_rows[256];
     __shared__ double s_vals[256];
+    __shared__ double s_unit[256];
     __shared__ Cand s_cand[8];
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING) return;
     const bool structured = lp.eta_cap > 0;  // unit columns of the stored inverse are known: skip their loads
+    s_unit[threadIdx.x] = 0.0;
     const bool publisher = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     if (ctl->iters >= ctl->budget) {
         if (publisher) {
@@ -599,38 +601,61 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
     const int ca = lp.col_start[q], cb = lp.col_start[q + 1];
     const int len = (cb - ca + n_slices - 1) / n_slices;
     const int e0 = ca + blockIdx.y * len, e1 = min(cb, e0 + len);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int tile0 = blockIdx.x * 256;
+    const int i = tile0 + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    __shared__ int s_wave_count[4];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double unit = 0.0;  // contributions of unit columns e_row (rows are unique within a column)
     for (int c0 = e0; c0 < e1; c0 += 256) {
-        const int cnt = min(256, e1 - c0);
+        int cnt = min(256, e1 - c0);
         __syncthreads();
-        if (threadIdx.x < cnt) {
-            const int row = lp.row_index[c0 + threadIdx.x];
-            // a unit column e_row contributes v_e to row `row` only: encode it as ~row, no load of the inverse needed
-            s_rows[threadIdx.x] = (structured && !lp.touched[row]) ? ~row : row;
+        if (structured) {
+            // keep only the entries whose column of the stored inverse carries information; a unit column e_row adds its
+            // value to row `row` alone.  Order-preserving compaction (ballot + prefix) keeps the sums deterministic.
+            int row = -1;
+            double val = 0.0;
+            bool keep = false;
+            if (threadIdx.x < cnt) {
+                row = lp.row_index[c0 + threadIdx.x];
+                val = lp.value[c0 + threadIdx.x];
+                keep = lp.touched[row] != 0;
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) s_wave_count[wave] = __popcll(mask);
+            __syncthreads();
+            int base = 0;
+            for (int wv = 0; wv < wave; ++wv) base += s_wave_count[wv];
+            cnt = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+            if (keep) {
+                const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                s_rows[slot] = row;
+                s_vals[slot] = val;
+            } else if (row >= tile0 && row < tile0 + 256) {
+                s_unit[row - tile0] = val;
+            }
+        } else if (threadIdx.x < cnt) {
+            s_rows[threadIdx.x] = lp.row_index[c0 + threadIdx.x];
             s_vals[threadIdx.x] = lp.value[c0 + threadIdx.x];
         }
         __syncthreads();
         if (i < m) {
             const double* col = lp.Binv + i;
-            if (structured) {
-                for (int e = 0; e < cnt; ++e) {
-                    const int row = s_rows[e];  // wave-uniform branch
-                    if (row >= 0) a0 += col[(size_t)row * ld] * s_vals[e];
-                    else if (~row == i) a1 += s_vals[e];
-                }
-            } else {
-                int e = 0;
-                for (; e + 4 <= cnt; e += 4) {
-                    a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-                    a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
-                    a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
-                    a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
-                }
-                for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+            int e = 0;
+            for (; e + 4 <= cnt; e += 4) {
+                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
+                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
+                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
             }
+            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+        }
+        if (structured) {
+            unit += s_unit[threadIdx.x];
+            s_unit[threadIdx.x] = 0.0;
         }
     }
+    a0 += unit;
     if (i < m) lp.alpha_part[(size_t)blockIdx.y * m + i] = (a0 + a1) + (a2 + a3);
 }
 
@@ -653,32 +678,42 @@ __global__ void __launch_bounds__(AR_ROWS * AR_GROUPS) alpha_reduce_kernel(Devic
     __shared__ double s_y[ETA_MAX];
     __shared__ int s_p[ETA_MAX];
     __shared__ double s_part[AR_GROUPS][AR_ROWS];
-    if (lp.ctl->status != ST_RUNNING || lp.ctl->q < 0) return;
     const int m = lp.m;
+    // round trip 1: everything that needs no other result (control word, kept rows, this thread's slices and eta entries)
+    const int status = lp.ctl->status, q = lp.ctl->q;
     const int k = lp.eta_cap > 0 ? lp.ctl->eta_count : 0;
-    if (k > 0) {  // y at the kept rows: 8 threads per row, 1/8 of the slices each, then a fixed-order combine
-        const int c = threadIdx.x / 8, sub = threadIdx.x % 8;
-        double part = 0.0;
-        int row = 0;
-        if (c < k) {
-            row = lp.eta_rows[c];
-            for (int sl = sub; sl < n_slices; sl += 8) part += lp.alpha_part[(size_t)sl * m + row];
-        }
-        part += __shfl_xor(part, 4, 8);
-        part += __shfl_xor(part, 2, 8);
-        part += __shfl_xor(part, 1, 8);
-        if (c < k && sub == 0) {
-            s_y[c] = part;
-            s_p[c] = row;
-        }
-        __syncthreads();
-    }
+    const int c8 = threadIdx.x / 8, sub = threadIdx.x % 8;
+    const int kept_row = (lp.eta_cap > 0 && c8 < lp.eta_cap) ? lp.eta_rows[c8] : 0;
     const int g = threadIdx.x / AR_ROWS, r = threadIdx.x % AR_ROWS;
     const int i = blockIdx.x * AR_ROWS + r;
     double acc = 0.0;
-    if (i < m) {
+    if (i < m)
         for (int sl = g; sl < n_slices; sl += AR_GROUPS) acc += lp.alpha_part[(size_t)sl * m + i];
-        for (int c = g; c < k; c += AR_GROUPS) acc += (lp.eta_cols[(size_t)c * lp.ld + i] - (i == s_p[c] ? 1.0 : 0.0)) * s_y[c];
+    constexpr int EPT = ETA_MAX / AR_GROUPS;  // eta columns per thread
+    double mic[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int c = g + u * AR_GROUPS;
+        mic[u] = (lp.eta_cap > 0 && i < m) ? lp.eta_cols[(size_t)c * lp.ld + i] : 0.0;  // entries of unused slots are ignored below
+    }
+    if (status != ST_RUNNING || q < 0) return;
+    if (k > 0) {  // round trip 2: y at the kept rows: 8 threads per row, 1/8 of the slices each, fixed-order combine
+        double part = 0.0;
+        if (c8 < k)
+            for (int sl = sub; sl < n_slices; sl += 8) part += lp.alpha_part[(size_t)sl * m + kept_row];
+        part += __shfl_xor(part, 4, 8);
+        part += __shfl_xor(part, 2, 8);
+        part += __shfl_xor(part, 1, 8);
+        if (c8 < k && sub == 0) {
+            s_y[c8] = part;
+            s_p[c8] = kept_row;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int c = g + u * AR_GROUPS;
+            if (c < k) acc += (mic[u] - (i == s_p[c] ? 1.0 : 0.0)) * s_y[c];
+        }
     }
     s_part[g][r] = acc;
     __syncthreads();
