@@ -233,10 +233,11 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r1_%s_pmc_traffic.json" % args.workload)
         if os.path.exists(pmc):
-            names = {"price": "relp::price_dense_kernel" if dense else "void relp::price_kernel<0, true, 8>", "update": "relp::update_kernel"}
-            entry = json.load(open(pmc)).get(names[dominant])
-            if entry:
-                traffic = entry["hbm_bytes_corrected"]
+            wanted = "price_dense_kernel" if dense else "relp::price_kernel<0, true, 8>"
+            for name, entry in json.load(open(pmc)).items():
+                if wanted in name:
+                    traffic = entry["hbm_bytes_corrected"]
+                    break
         if dense:
             workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing" % path
             data = "synthetic"

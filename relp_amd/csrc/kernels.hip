@@ -442,6 +442,10 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
 // ---------------------------------------------------------------------------------------------------
 constexpr int K1D_THREADS = 1024;
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// F32: the dense block is stored as float because every entry is exactly representable in it (checked at upload); the
+// widening back is exact and all arithmetic stays f64, so results are bit-identical while the pass streams half the bytes.
+template <bool F32>
 __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, int skip_weights, double tol_dual, int cand_offset) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[K1D_THREADS / WAVE + 2];
@@ -479,28 +483,55 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
         if (pos_j >= 0) continue;  // wave-uniform
         // the column stream is read once per pass and is larger than the Infinity Cache: non-temporal loads keep it from
         // competing with the lines other kernels left there (measured: 5.3 TB/s against 4.0 TB/s behind the inverse update)
-        const f64x2* col = reinterpret_cast<const f64x2*>(lp.dense_val + (size_t)jd * mp);
         const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
         const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
         const double2* w2 = reinterpret_cast<const double2*>(s_w);
         double d_pi = 0.0, d_rho = 0.0, d_w = 0.0;
-        for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
-            f64x2 v[8];
+        if (F32) {
+            const f32x4* col = reinterpret_cast<const f32x4*>(lp.dense_val32 + (size_t)jd * mp);
+            const int quarter = mp / 4;
+            for (int k0 = lane; k0 < quarter; k0 += 8 * WAVE) {
+                f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * WAVE;
-                v[u] = k < half ? __builtin_nontemporal_load(col + k) : f64x2{0.0, 0.0};
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * WAVE;
+                    v[u] = k < quarter ? __builtin_nontemporal_load(col + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * WAVE;
+                    if (k < quarter) {
+                        const double x0 = v[u].x, x1 = v[u].y, x2 = v[u].z, x3 = v[u].w;
+                        const double2 a0 = pi2[2 * k], a1 = pi2[2 * k + 1];
+                        d_pi += (x0 * a0.x + x1 * a0.y) + (x2 * a1.x + x3 * a1.y);
+                        if (pending) {
+                            const double2 b0 = rho2[2 * k], b1 = rho2[2 * k + 1], c0 = w2[2 * k], c1 = w2[2 * k + 1];
+                            d_rho += (x0 * b0.x + x1 * b0.y) + (x2 * b1.x + x3 * b1.y);
+                            d_w += (x0 * c0.x + x1 * c0.y) + (x2 * c1.x + x3 * c1.y);
+                        }
+                    }
+                }
             }
+        } else {
+            const f64x2* col = reinterpret_cast<const f64x2*>(lp.dense_val + (size_t)jd * mp);
+            for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
+                f64x2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * WAVE;
-                if (k < half) {
-                    const double2 a = pi2[k];
-                    d_pi += v[u].x * a.x + v[u].y * a.y;
-                    if (pending) {
-                        const double2 b = rho2[k], c = w2[k];
-                        d_rho += v[u].x * b.x + v[u].y * b.y;
-                        d_w += v[u].x * c.x + v[u].y * c.y;
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * WAVE;
+                    v[u] = k < half ? __builtin_nontemporal_load(col + k) : f64x2{0.0, 0.0};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * WAVE;
+                    if (k < half) {
+                        const double2 a = pi2[k];
+                        d_pi += v[u].x * a.x + v[u].y * a.y;
+                        if (pending) {
+                            const double2 b = rho2[k], c = w2[k];
+                            d_rho += v[u].x * b.x + v[u].y * b.y;
+                            d_w += v[u].x * c.x + v[u].y * c.y;
+                        }
                     }
                 }
             }
@@ -1933,10 +1964,12 @@ void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_
 
 void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s) {
     const size_t lds = (size_t)3 * d.dense_ld * sizeof(double);
-    RELP_LAUNCH(0, price_dense_kernel, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
+    if (d.dense_val32) RELP_LAUNCH(0, price_dense_kernel<true>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
+    else RELP_LAUNCH(0, price_dense_kernel<false>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
 }
 void configure_dense_lds(size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s) {
     hipLaunchKernelGGL(ftran_partial_kernel, dim3((d.m + 255) / 256, n_slices), dim3(256), 0, s, d, n_slices, n_price_blocks, rule);

@@ -91,7 +91,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -175,11 +175,11 @@ void Solver::upload() {
     if (n_dense < 64) n_dense = 0;
     d_.n_dense = n_dense;
     d_.dense_first = n_art;
-    d_.dense_ld = (m + 1) & ~1;
+    d_.dense_ld = (m + 3) & ~3;
     sparse_first_ = n_art + n_dense;
     const int cpb = price_columns_per_block();
     price_blocks_ = std::min(1024, (n - sparse_first_ + cpb - 1) / cpb);
-    dense_blocks_ = n_dense > 0 ? std::min(1024, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one column per wave
+    dense_blocks_ = n_dense > 0 ? std::min(getenv("RELP_DENSE_BLOCKS") ? atoi(getenv("RELP_DENSE_BLOCKS")) : 256, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one workgroup per CU (96 KB of LDS each)
     if (price_blocks_ + dense_blocks_ == 0) price_blocks_ = 1;
     price_lds_ = (size_t)3 * m * sizeof(double);
     int max_nnz = 0;
@@ -253,8 +253,17 @@ void Solver::upload() {
         std::vector<double> dense((size_t)n_dense * d_.dense_ld, 0.0);
         for (int jd = 0; jd < n_dense; ++jd)
             for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) dense[(size_t)jd * d_.dense_ld + row_index[e]] = value[e];
-        d_.dense_val = dmalloc<double>(dense.size());
-        upload_vec(d_.dense_val, dense, stream_);
+        bool exact_in_float = !(getenv("RELP_DENSE_F64"));  // RELP_DENSE_F64=1 keeps the f64 block (A/B measurements)
+        for (size_t k = 0; exact_in_float && k < dense.size(); ++k) exact_in_float = (double)(float)dense[k] == dense[k];
+        if (exact_in_float) {
+            std::vector<float> dense32(dense.begin(), dense.end());
+            d_.dense_val32 = dmalloc<float>(dense32.size());
+            upload_vec(d_.dense_val32, dense32, stream_);
+        } else {
+            d_.dense_val = dmalloc<double>(dense.size());
+            upload_vec(d_.dense_val, dense, stream_);
+        }
+        dense_entry_bytes_ = exact_in_float ? 4 : 8;
         RELP_HIP(hipStreamSynchronize(stream_));
         configure_dense_lds((size_t)3 * d_.dense_ld * sizeof(double));
     }
@@ -280,7 +289,7 @@ void Solver::upload() {
     configure_lds(std::min<size_t>(price_lds_, 160 * 1024 - 1024));
 
     stats_.price_bytes = (long long)(col_start[n] - col_start[sparse_first_]) * 12 + (long long)(n - n_art) * 24 +
-                         (long long)n_dense * m * 8;  // upper bound: every dense column non-basic
+                         (long long)n_dense * m * dense_entry_bytes_;  // upper bound: every dense column non-basic
     stats_.update_bytes = (long long)2 * m * m * 8;
     h_basis_.assign(m, -1);
     h_solution_.assign(n_p, 0.0);
@@ -762,7 +771,7 @@ double Solver::profile_kernel(int which, int repetitions) {
         for (int j = d_.n_art; j < d_.n; ++j) {
             if (pos[j] >= 0) continue;
             const bool dense_col = j >= d_.dense_first && j < d_.dense_first + d_.n_dense;
-            bytes += dense_col ? (long long)m * 8 : (long long)(cs[j + 1] - cs[j]) * 12;
+            bytes += dense_col ? (long long)m * dense_entry_bytes_ : (long long)(cs[j + 1] - cs[j]) * 12;
             bytes += 24;  // cost, gamma read + gamma write
         }
         stats_.price_bytes = bytes;

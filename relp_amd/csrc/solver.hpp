@@ -49,6 +49,7 @@ struct DeviceLP {
     // dense block: device columns [dense_first, dense_first + n_dense) also stored dense, column-major, ld = dense_ld
     int n_dense = 0, dense_first = 0, dense_ld = 0;
     double* dense_val = nullptr;
+    float* dense_val32 = nullptr;  // the same block as float, when every entry is exactly representable (then dense_val is not allocated)
     double* alpha_part = nullptr;  // slices of the multi-block FTRAN, [n_slices][m]
     double* alpha_in = nullptr;    // their fixed-order sum (with the pending etas applied): what K2 reads when preselected
     // Deferred product form (eta_cap > 0, dense pipeline only).  The current inverse is  M * Binv  with
@@ -171,6 +172,7 @@ private:
     int dense_blocks_ = 0;        // dense pricing workgroups (candidate slots follow the sparse ones)
     int ftran_slices_ = 0;        // > 0: multi-block FTRAN pipeline (select -> partial FTRAN -> fused kernel)
     int sparse_first_ = 0;        // device columns priced by the CSC kernel: [sparse_first_, n)
+    int dense_entry_bytes_ = 8;   // 4 when the dense block is held as float (exactly representable entries)
     bool eta_mode_ = false;       // deferred product form of the inverse (DeviceLP::eta_cap > 0)
     size_t price_lds_ = 0;
     hipStream_t stream_ = nullptr;
