@@ -1164,9 +1164,32 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     // ---- x_B update (carry/mod.rs:295-325) and the ordered non-zero list of alpha for K3 ----------------
     const double alpha_pq = lp.alpha[p];
     const double xp = fmax(lp.xB[p], 0.0) / alpha_pq;
-    const int total = 0;
     __syncthreads();  // every thread has read xB[p] before it is overwritten
-    for (int i = threadIdx.x; i < m; i += blockDim.x) lp.xB[i] = (i == p) ? xp : lp.xB[i] - lp.alpha[i] * xp;
+    // ordered list of the rows K3 has to touch (alpha_i != 0, plus p): ballot + prefix per chunk of blockDim rows
+    __shared__ int s_nz_wave[K2_THREADS / WAVE];
+    int total = 0;
+    for (int i0 = 0; i0 < m; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const double a = i < m ? lp.alpha[i] : 0.0;
+        const bool keep = i < m && (a != 0.0 || i == p);
+        const unsigned long long mask = __ballot(keep);
+        const int lane_k2 = threadIdx.x & (WAVE - 1), wave_k2 = threadIdx.x / WAVE;
+        __syncthreads();
+        if (lane_k2 == 0) s_nz_wave[wave_k2] = __popcll(mask);
+        __syncthreads();
+        int base = total, chunk = 0;
+        for (int wv = 0; wv < (int)(blockDim.x / WAVE); ++wv) {
+            if (wv < wave_k2) base += s_nz_wave[wv];
+            chunk += s_nz_wave[wv];
+        }
+        if (keep) {
+            const int slot = base + __popcll(mask & ((1ull << lane_k2) - 1ull));
+            lp.nz_index[slot] = i;
+            lp.nz_alpha[slot] = a;
+        }
+        total += chunk;
+        if (i < m) lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
+    }
     if (threadIdx.x == 0) {
         const int leaving = lp.basis[p];
         lp.basis[p] = q;
@@ -1485,7 +1508,31 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             lp.xB[i] = (i == p) ? xp : xb[r] - al[r] * xp;
         }
     }
-    const int total = 0;
+    int total = 0;
+    if (R >= 8) {  // ordered list of the rows K3 has to touch (alpha_i != 0, plus p); rows ascend with (r, tid)
+        __shared__ int s_nz_count[R * (K2F_THREADS / WAVE)];
+        const int lane_k2 = tid & (WAVE - 1), wave_k2 = tid / WAVE;
+        unsigned long long masks[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * K2F_THREADS;
+            masks[r] = __ballot(i < m && (al[r] != 0.0 || i == p));
+            if (lane_k2 == 0) s_nz_count[r * (K2F_THREADS / WAVE) + wave_k2] = __popcll(masks[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int base = 0;
+            for (int e = 0; e < r * (K2F_THREADS / WAVE) + wave_k2; ++e) base += s_nz_count[e];
+            const int i = tid + r * K2F_THREADS;
+            if (i < m && (al[r] != 0.0 || i == p)) {
+                const int slot = base + __popcll(masks[r] & ((1ull << lane_k2) - 1ull));
+                lp.nz_index[slot] = i;
+                lp.nz_alpha[slot] = al[r];
+            }
+        }
+        for (int e = 0; e < R * (K2F_THREADS / WAVE); ++e) total += s_nz_count[e];
+    }
     STAMP(5);
     if (tid == 0) {
         lp.basis[p] = q;
@@ -1563,6 +1610,33 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     const double r0 = c0[p] / alpha_pq;  // row p of the new inverse
     const double r1 = c1[p] / alpha_pq;
     double w0 = 0.0, w1 = 0.0;
+    const int nz = EAGER ? 0 : ctl->nz_count;
+    if (!EAGER && nz > 0 && nz * 6 < m) {
+        // sparse alpha: lanes walk K2's ordered list of touched rows instead of sweeping all m of them
+        for (int base = 0; base < nz; base += U * WAVE) {
+            int idx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + lane + u * WAVE;
+                idx[u] = e < nz ? lp.nz_index[e] : -1;
+                a[u] = e < nz ? lp.nz_alpha[e] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                o0[u] = idx[u] >= 0 ? c0[idx[u]] : 0.0;
+                o1[u] = idx[u] >= 0 ? c1[idx[u]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                w0 += a[u] * o0[u];
+                w1 += a[u] * o1[u];
+                if (idx[u] >= 0) {
+                    c0[idx[u]] = (idx[u] == p) ? r0 : o0[u] - a[u] * r0;
+                    if (two) c1[idx[u]] = (idx[u] == p) ? r1 : o1[u] - a[u] * r1;
+                }
+            }
+        }
+    } else
     for (int base = 0; base < m; base += U * WAVE) {
         if (!EAGER || base > 0) {
 #pragma unroll

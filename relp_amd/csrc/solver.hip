@@ -185,7 +185,9 @@ void Solver::upload() {
     int max_nnz = 0;
     for (int j = n_art; j < n; ++j) max_nnz = std::max(max_nnz, col_start[j + 1] - col_start[j]);
     ftran_slices_ = 0;
-    if (max_nnz > 1024 && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = std::min(64, (max_nnz + 127) / 128);
+    // columns longer than this take the multi-block FTRAN pipeline (RELP_FTRAN_MIN_NNZ: test hook to exercise it on small LPs)
+    const int ftran_min_nnz = getenv("RELP_FTRAN_MIN_NNZ") ? atoi(getenv("RELP_FTRAN_MIN_NNZ")) : 1024;
+    if (max_nnz > ftran_min_nnz && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = std::min(64, (max_nnz + 127) / 128);
 
     d_.col_start = dmalloc<int>(n + 1);
     d_.row_index = dmalloc<int>(nnz);
