@@ -1857,13 +1857,19 @@ typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int MT = 64, MK = 16, MPITCH = 80;
 template <int MODE>
 __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict__ X, const double* __restrict__ R,
-                                                      double* __restrict__ C, int m, int ld, double* residual_max) {
+                                                      double* __restrict__ C, int m, int ld, double* residual_max,
+                                                      const int* __restrict__ row_list, int n_rows) {
+    // row_list != nullptr: only the storage rows row_list[0 .. n_rows) are computed (the columns of the stored inverse that
+    // are not unit vectors; the other rows of S are zero and the other rows of the polished inverse do not change)
     __shared__ double sA[MK][MPITCH];
     __shared__ double sB[MK][MPITCH];
     __shared__ double s_red[6];
+    __shared__ int s_row[MT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int row0 = blockIdx.y * MT, col0 = blockIdx.x * MT;
+    if (tid < MT) s_row[tid] = row_list ? (row0 + tid < n_rows ? row_list[row0 + tid] : -1) : (row0 + tid < m ? row0 + tid : -1);
+    __syncthreads();
     mfma_f64x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1875,8 +1881,8 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
         double av[4], bv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int gr = row0 + ar, gk = k0 + ak + u;
-            av[u] = (gr < m && gk < m) ? X[(size_t)gr * ld + gk] : 0.0;
+            const int gr = s_row[ar], gk = k0 + ak + u;
+            av[u] = (gr >= 0 && gk < m) ? X[(size_t)gr * ld + gk] : 0.0;
             const int gk2 = k0 + bk, gc = col0 + bc + u;
             bv[u] = (gk2 < m && gc < m) ? R[(size_t)gk2 * ld + gc] : 0.0;
         }
@@ -1908,9 +1914,9 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int gr = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * reg;
+                const int gr = s_row[wr * 32 + i * 16 + (lane >> 4) + 4 * reg];
                 const int gc = col0 + wc * 32 + j * 16 + (lane & 15);
-                if (gr < m && gc < m) {
+                if (gr >= 0 && gc < m) {
                     if (MODE == 0) {
                         C[(size_t)gr * ld + gc] = X[(size_t)gr * ld + gc] + acc[i][j][reg];
                     } else {
@@ -2108,20 +2114,37 @@ void launch_identity(double* X, int m, int ld, hipStream_t s) {
 void launch_residual(const DeviceLP& d, const double* T, double* S, hipStream_t s) {
     hipLaunchKernelGGL(residual_kernel, dim3(d.m), dim3(256), 0, s, d, T, S);
 }
+bool gemm_row_lists_supported();
 static bool use_mfma_gemm() {
     static const bool value = [] { const char* e = getenv("RELP_GEMM"); return !(e && std::string(e) == "vector"); }();
     return value;  // RELP_GEMM=vector selects the plain-FMA kernel (A/B measurements)
 }
-void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s) {
-    dim3 grid((m + GT - 1) / GT, (m + GT - 1) / GT);
-    if (use_mfma_gemm()) hipLaunchKernelGGL((gemm_mfma_kernel<0>), grid, dim3(256), 0, s, X, R, C, m, ld, (double*)nullptr);
+__global__ void __launch_bounds__(256) copy_rows_kernel(const double* src, double* dst, int m, int ld, const int* row_list, int n_rows) {
+    const int idx = blockIdx.y;
+    if (idx >= n_rows) return;
+    const size_t row = (size_t)row_list[idx] * ld;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) dst[row + i] = src[row + i];
+}
+bool gemm_row_lists_supported() { return use_mfma_gemm(); }  // the plain-FMA fallback kernels compute every row
+void launch_copy_rows(const double* src, double* dst, int m, int ld, const int* row_list, int n_rows, hipStream_t s) {
+    if (n_rows > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3((m + 255) / 256, n_rows), dim3(256), 0, s, src, dst, m, ld, row_list, n_rows);
+}
+// row_list (device, n_rows entries) restricts the computed storage rows; nullptr = all m
+void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, const int* row_list, int n_rows, hipStream_t s) {
+    const int rows = row_list ? n_rows : m;
+    if (rows <= 0) return;
+    dim3 grid((m + GT - 1) / GT, (rows + GT - 1) / GT);
+    if (use_mfma_gemm()) hipLaunchKernelGGL((gemm_mfma_kernel<0>), grid, dim3(256), 0, s, X, R, C, m, ld, (double*)nullptr, row_list, n_rows);
     else hipLaunchKernelGGL((gemm_polish_kernel<0>), grid, dim3(256), 0, s, X, R, C, m, ld, (double*)nullptr);
 }
 // S = I - B' T for a dense basis: gather B' into `Bd`, then one GEMM (also records max |S|)
-void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, hipStream_t s) {
+void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, const int* row_list, int n_rows, hipStream_t s) {
     hipLaunchKernelGGL(gather_basis_kernel, dim3(d.m), dim3(256), 0, s, d, Bd);
-    dim3 grid((d.m + GT - 1) / GT, (d.m + GT - 1) / GT);
-    if (use_mfma_gemm()) hipLaunchKernelGGL((gemm_mfma_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual);
+    const int rows = row_list ? n_rows : d.m;
+    if (rows <= 0) return;
+    dim3 grid((d.m + GT - 1) / GT, (rows + GT - 1) / GT);
+    if (use_mfma_gemm()) hipLaunchKernelGGL((gemm_mfma_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual, row_list, n_rows);
     else hipLaunchKernelGGL((gemm_polish_kernel<1>), grid, dim3(256), 0, s, Bd, T, S, d.m, d.ld, &d.ctl->residual);
 }
 void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s) {

@@ -32,8 +32,10 @@ void launch_xb(const DeviceLP& d, hipStream_t s);
 void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s);
 void launch_identity(double* X, int m, int ld, hipStream_t s);
 void launch_residual(const DeviceLP& d, const double* X, double* R, hipStream_t s);
-void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, hipStream_t s);
-void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, hipStream_t s);
+void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, const int* row_list, int n_rows, hipStream_t s);
+void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, const int* row_list, int n_rows, hipStream_t s);
+void launch_copy_rows(const double* src, double* dst, int m, int ld, const int* row_list, int n_rows, hipStream_t s);
+bool gemm_row_lists_supported();
 void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s);
 int eta_max();
 void configure_btran_lds(size_t lds);
@@ -187,7 +189,7 @@ void Solver::upload() {
     ftran_slices_ = 0;
     // columns longer than this take the multi-block FTRAN pipeline (RELP_FTRAN_MIN_NNZ: test hook to exercise it on small LPs)
     const int ftran_min_nnz = getenv("RELP_FTRAN_MIN_NNZ") ? atoi(getenv("RELP_FTRAN_MIN_NNZ")) : 1024;
-    if (max_nnz > ftran_min_nnz && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = std::min(64, (max_nnz + 127) / 128);
+    if (max_nnz > ftran_min_nnz && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = getenv("RELP_FTRAN_SLICES") ? atoi(getenv("RELP_FTRAN_SLICES")) : std::min(64, (max_nnz + 127) / 128);
 
     d_.col_start = dmalloc<int>(n + 1);
     d_.row_index = dmalloc<int>(nnz);
@@ -431,9 +433,16 @@ void Solver::build_graph(int count) {
 // Newton-Schulz polish (see kernels.hip).  Two iterations at most; the residual before the polish is recorded.
 void Solver::polish(bool refresh_vectors) {
     const int m = d_.m;
+    // dense pipeline: only the columns of the stored inverse that are not unit vectors take part (the corresponding
+    // rows of S are zero and those columns of the polished inverse do not change): both GEMMs shrink by m / touched
+    const bool by_rows = eta_mode_ && gemm_row_lists_supported();
+    const int* rows = by_rows ? d_.tlist : nullptr;
+    int n_rows = m;
+    if (by_rows) n_rows = read_ctl().touched_count;
     for (int it = 0; it < 2; ++it) {
         RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
-        if (d_.n_dense > 0) launch_residual_dense(d_, d_.Binv2, d_.Binv, d_.R, stream_);
+        if (by_rows) RELP_HIP(hipMemsetAsync(d_.R, 0, (size_t)m * d_.ld * sizeof(double), stream_));
+        if (d_.n_dense > 0) launch_residual_dense(d_, d_.Binv2, d_.Binv, d_.R, rows, n_rows, stream_);
         else launch_residual(d_, d_.Binv, d_.R, stream_);
         Ctl c = read_ctl();  // max |I - B' T|
         if (!(c.residual == c.residual)) throw std::runtime_error("NaN in basis inverse");
@@ -449,8 +458,9 @@ void Solver::polish(bool refresh_vectors) {
             invert_from_scratch();
             break;
         }
-        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, stream_);
-        RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, rows, n_rows, stream_);
+        if (by_rows) launch_copy_rows(d_.Binv2, d_.Binv, m, d_.ld, rows, n_rows, stream_);
+        else RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
         if (c.residual < 1e-8) break;  // one quadratic step takes it to ~residual^2
     }
     binv_identity_ = false;
@@ -497,7 +507,7 @@ void Solver::invert_from_scratch() {
     for (int it = 0; it < 200; ++it) {
         RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
         launch_residual(d_, d_.Binv, d_.R, stream_);
-        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, stream_);
+        launch_gemm_polish(d_.Binv, d_.R, d_.Binv2, m, d_.ld, nullptr, m, stream_);
         RELP_HIP(hipMemcpyAsync(d_.Binv, d_.Binv2, (size_t)m * d_.ld * sizeof(double), hipMemcpyDeviceToDevice, stream_));
         Ctl c = read_ctl();
         if (c.residual < 1e-11) break;
