@@ -1193,6 +1193,12 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     if (threadIdx.x == 0) {
         const int leaving = lp.basis[p];
         lp.basis[p] = q;
+        if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[p]) {  // column p of the inverse stops being a unit vector
+            const int count = ctl->touched_count;
+            lp.touched[p] = 1;
+            lp.tlist[count] = p;
+            ctl->touched_count = count + 1;
+        }
         lp.pos[q] = p;
         lp.pos[leaving] = -1;
         ctl->q = q;
@@ -1536,6 +1542,12 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     STAMP(5);
     if (tid == 0) {
         lp.basis[p] = q;
+        if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[p]) {  // column p of the inverse stops being a unit vector
+            const int count = ctl->touched_count;
+            lp.touched[p] = 1;
+            lp.tlist[count] = p;
+            ctl->touched_count = count + 1;
+        }
         lp.pos[q] = p;
         lp.pos[leaving] = -1;
         ctl->q = q;
@@ -1579,11 +1591,28 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     const int m = lp.m, ld = lp.ld;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
-    const int j0 = (blockIdx.x * (K3_THREADS / WAVE) + wave) * K3_CPW;
-    if (j0 >= m) return;
-    const bool two = j0 + 1 < m;
+    const int slot0 = (blockIdx.x * (K3_THREADS / WAVE) + wave) * K3_CPW;
+    int j0 = slot0, j1 = slot0 + 1;
+    bool two = slot0 + 1 < m;
+    if (!EAGER && lp.track_touched) {
+        // Only the columns that are not unit vectors any more need the update (E e_j = e_j for j != p; K2 has put p on
+        // the list).  For a unit column e_j:  w_j = alpha_j, rho_j = 0 and -pi_j does not change.
+        if (ctl->status != ST_RUNNING || !ctl->pending) return;
+        for (int j = blockIdx.x * K3_THREADS + threadIdx.x; j < m; j += gridDim.x * K3_THREADS)
+            if (!lp.touched[j]) {
+                lp.w[j] = lp.alpha[j];
+                lp.rho[j] = 0.0;
+            }
+        const int n_touched = ctl->touched_count;
+        if (slot0 >= n_touched) return;
+        two = slot0 + 1 < n_touched;
+        j0 = lp.tlist[slot0];
+        j1 = two ? lp.tlist[slot0 + 1] : j0;
+    } else if (slot0 >= m) {
+        return;
+    }
     double* c0 = lp.Binv + (size_t)j0 * ld;
-    double* c1 = lp.Binv + (size_t)(two ? j0 + 1 : j0) * ld;
+    double* c1 = lp.Binv + (size_t)(two ? j1 : j0) * ld;
     // everything below is issued before the first use: one round trip
     const int status = ctl->status;
     const int pending = ctl->pending;
@@ -1593,7 +1622,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     double pi0 = 0.0, pi1 = 0.0;
     if (lane == LAST) {
         pi0 = lp.minus_pi[j0];
-        pi1 = two ? lp.minus_pi[j0 + 1] : 0.0;
+        pi1 = two ? lp.minus_pi[j1] : 0.0;
     }
     constexpr int U = EAGER ? 16 : 8;  // EAGER: 1024 rows in the first round trip
     double a[U], o0[U], o1[U];
@@ -1670,9 +1699,9 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
         lp.rho[j0] = r0;
         lp.minus_pi[j0] = pi0 - cbar_q * r0;
         if (two) {
-            lp.w[j0 + 1] = w1;
-            lp.rho[j0 + 1] = r1;
-            lp.minus_pi[j0 + 1] = pi1 - cbar_q * r1;
+            lp.w[j1] = w1;
+            lp.rho[j1] = r1;
+            lp.minus_pi[j1] = pi1 - cbar_q * r1;
         }
     }
 }

@@ -240,6 +240,12 @@ void Solver::upload() {
     const char* eta_env = getenv("RELP_ETA");  // RELP_ETA=0 keeps the per-pivot rank-one update (A/B measurements)
     eta_mode_ = n_dense > 0 && ftran_slices_ > 0 && m % 2 == 0 && m <= 4096 && !(eta_env && std::string(eta_env) == "0");
     d_.eta_cap = eta_mode_ ? eta_max() : 0;
+    // unit columns of the inverse are tracked where skipping them pays: the dense pipeline and the larger sparse LPs
+    // (below that the update kernel is latency bound and the extra indirection would cost a round trip)
+    d_.track_touched = (eta_mode_ || m > 2048) && !getenv("RELP_NO_TOUCHED") ? 1 : 0;
+    d_.touched = dmalloc<int>(m);
+    d_.tlist = dmalloc<int>(m);
+    RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));
     if (eta_mode_) {
         d_.eta_cols = dmalloc<double>((size_t)d_.eta_cap * d_.ld);
         d_.eta_rows = dmalloc<int>(d_.eta_cap);
@@ -247,9 +253,6 @@ void Solver::upload() {
         d_.eta_gather = dmalloc<double>((size_t)d_.eta_cap * m);
         d_.rvec1 = dmalloc<double>(m);
         d_.rvec2 = dmalloc<double>(m);
-        d_.touched = dmalloc<int>(m);
-        d_.tlist = dmalloc<int>(m);
-        RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));
         RELP_HIP(hipMemsetAsync(d_.eta_slot, 0xff, m * sizeof(int), stream_));
         configure_btran_lds((size_t)2 * ((m + 1) & ~1) * sizeof(double));
     }
@@ -330,7 +333,7 @@ void Solver::begin_phase_one() {
     upload_vec(d_.pos, pos, stream_);
     RELP_HIP(hipMemcpyAsync(d_.xB, d_.rhs, m * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     launch_identity(d_.Binv, m, d_.ld, stream_);
-    if (eta_mode_) RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));  // every column is a unit vector
+    RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));  // every column is a unit vector
     binv_identity_ = true;
     Ctl c{};
     c.forced_q = c.forced_p = -1;
@@ -435,7 +438,7 @@ void Solver::polish(bool refresh_vectors) {
     const int m = d_.m;
     // dense pipeline: only the columns of the stored inverse that are not unit vectors take part (the corresponding
     // rows of S are zero and those columns of the polished inverse do not change): both GEMMs shrink by m / touched
-    const bool by_rows = eta_mode_ && gemm_row_lists_supported();
+    const bool by_rows = d_.track_touched && gemm_row_lists_supported();
     const int* rows = by_rows ? d_.tlist : nullptr;
     int n_rows = m;
     if (by_rows) n_rows = read_ctl().touched_count;
@@ -514,7 +517,7 @@ void Solver::invert_from_scratch() {
         if (it > 60 && c.residual >= previous) break;
         previous = c.residual;
     }
-    if (eta_mode_) launch_mark_all_touched(d_, stream_);  // no column of a fresh inverse is known to be a unit vector
+    launch_mark_all_touched(d_, stream_);  // no column of a fresh inverse is known to be a unit vector
     binv_identity_ = false;
 }
 

@@ -66,6 +66,7 @@ struct DeviceLP {
     // Column j of the STORED inverse is still the unit vector e_j until a row-j pivot has been folded in (E e_j = e_j for
     // every eta of another row; the polish keeps such columns exactly).  touched[j] / tlist record the others, so that the
     // FTRAN and BTRAN passes and the rank-k update only stream columns that carry information.
+    int track_touched = 0;         // 1: touched / tlist are maintained (deferred product form, or m > 2048)
     int* touched = nullptr;        // [m] 0/1
     int* tlist = nullptr;          // [m] touched columns in the order they were folded in
     // CSC of [artificial identity columns | provider columns] (matrix_data.rs:291-329 materialised once)
