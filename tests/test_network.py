@@ -159,3 +159,25 @@ def test_gpu_max_flow_matches_scipy_at_scale():
     result = solver.solve_relaxation()
     assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified
     assert Fraction(solver.objective_exact()) == -expected
+
+
+@pytest.mark.gpu
+def test_gpu_max_flow_m_9000():
+    """V = 1024, E ~ 8170 (m ~ 9190 rows: the general ratio-test kernel, unit-column skipping in the inverse update):
+    f64 optimum equals scipy's max-flow value."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices = 1024
+    tail, head, capacity = max_flow_graph(nr_vertices, 8192)
+    keep = (head != 0) & (tail != nr_vertices - 1)
+    tail, head, capacity = tail[keep], head[keep], capacity[keep]
+    graph = csr_matrix((capacity.astype(np.int32), (tail, head)), shape=(nr_vertices, nr_vertices))
+    expected = maximum_flow(graph, 0, nr_vertices - 1).flow_value
+    model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+    solver = relp_amd.Solver().load_model(model)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert abs(result.objective + expected) <= 1e-9 * max(1.0, abs(expected))
+    flow = solver.solution()
+    assert np.all(flow >= -1e-9) and np.all(flow <= capacity + 1e-9)

@@ -7,7 +7,8 @@ from relp_amd.workloads import max_flow_graph
 from scipy.sparse import csr_matrix
 from scipy.sparse.csgraph import maximum_flow
 
-for nr_vertices, nr_arcs in [(256, 2048), (512, 4096), (1024, 8192), (2048, 16384)]:
+sizes = [(256, 2048), (512, 4096), (1024, 8192), (2048, 16384)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for nr_vertices, nr_arcs in sizes:
     tail, head, capacity = max_flow_graph(nr_vertices, nr_arcs)
     keep = (head != 0) & (tail != nr_vertices - 1)
     tail, head, capacity = tail[keep], head[keep], capacity[keep]
