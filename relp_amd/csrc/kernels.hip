@@ -1515,29 +1515,38 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         }
     }
     int total = 0;
-    if (R >= 8) {  // ordered list of the rows K3 has to touch (alpha_i != 0, plus p); rows ascend with (r, tid)
-        __shared__ int s_nz_count[R * (K2F_THREADS / WAVE)];
+    if (R >= 8 && lp.eta_cap == 0) {  // ordered list of the rows K3 has to touch (alpha_i != 0, plus p); rows ascend with (r, tid)
+        constexpr int NW = K2F_THREADS / WAVE;
+        __shared__ int s_nz_count[R * NW + 1];
         const int lane_k2 = tid & (WAVE - 1), wave_k2 = tid / WAVE;
         unsigned long long masks[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = tid + r * K2F_THREADS;
             masks[r] = __ballot(i < m && (al[r] != 0.0 || i == p));
-            if (lane_k2 == 0) s_nz_count[r * (K2F_THREADS / WAVE) + wave_k2] = __popcll(masks[r]);
+            if (lane_k2 == 0) s_nz_count[r * NW + wave_k2] = __popcll(masks[r]);
+        }
+        __syncthreads();
+        if (tid == 0) {  // exclusive prefix over the R * NW (= 64) wave counts
+            int running = 0;
+            for (int e = 0; e < R * NW; ++e) {
+                const int c = s_nz_count[e];
+                s_nz_count[e] = running;
+                running += c;
+            }
+            s_nz_count[R * NW] = running;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            int base = 0;
-            for (int e = 0; e < r * (K2F_THREADS / WAVE) + wave_k2; ++e) base += s_nz_count[e];
             const int i = tid + r * K2F_THREADS;
             if (i < m && (al[r] != 0.0 || i == p)) {
-                const int slot = base + __popcll(masks[r] & ((1ull << lane_k2) - 1ull));
+                const int slot = s_nz_count[r * NW + wave_k2] + __popcll(masks[r] & ((1ull << lane_k2) - 1ull));
                 lp.nz_index[slot] = i;
                 lp.nz_alpha[slot] = al[r];
             }
         }
-        for (int e = 0; e < R * (K2F_THREADS / WAVE); ++e) total += s_nz_count[e];
+        total = s_nz_count[R * NW];
     }
     STAMP(5);
     if (tid == 0) {
