@@ -96,25 +96,35 @@ def netlib_batch(args, rank, local_rank, world, distributed):
     passes = [0]
 
     def run_all():
-        pivots = 0
+        """One pass over the suite.  `--concurrency K` keeps K LPs in flight on this GPU (K host threads, one stream each):
+        the small LPs are latency bound and use a fraction of the chip, so their kernels overlap."""
+        import threading
         passes[0] += 1
         tickets = batch.TicketQueue(len(ordered), tag="pass%d" % passes[0]) if dynamic else None
-        position = 0
-        while True:
-            if dynamic:
-                index = tickets.next()
+        static_tickets = batch.TicketQueue(len(mine), tag="static%d" % passes[0]) if not dynamic else None
+        if static_tickets is not None:
+            static_tickets.store = None  # a rank-local counter over this rank's own share
+        totals = []
+
+        def worker():
+            pivots = 0
+            while True:
+                index = tickets.next() if dynamic else static_tickets.next()
                 if index is None:
                     break
-                name = ordered[index]
-            else:
-                if position == len(mine):
-                    break
-                name = mine[position]
-                position += 1
-            r = solvers[name].solve_relaxation()
-            pivots += r.pivots_phase_one + r.pivots_phase_two
-            records.append((name, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds))
-        return pivots
+                name = ordered[index] if dynamic else mine[index]
+                r = solvers[name].solve_relaxation()
+                pivots += r.pivots_phase_one + r.pivots_phase_two
+                records.append((name, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds))
+            totals.append(pivots)
+
+        threads = [threading.Thread(target=worker) for _ in range(max(1, args.concurrency) - 1)]
+        for t in threads:
+            t.start()
+        worker()
+        for t in threads:
+            t.join()
+        return sum(totals)
 
     for _ in range(args.warmup):
         run_all()
@@ -146,6 +156,7 @@ def netlib_batch(args, rank, local_rank, world, distributed):
             "data": "%d Netlib .SIF files shipped under data/netlib" % len(names),
             "config": {"workload": "Netlib batch (%d LPs), %s, one LP per GPU at a time" % (
                 len(names), "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
+                       "lps_in_flight_per_gpu": max(1, args.concurrency),
                        "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}}))
     if distributed:
         torch.distributed.destroy_process_group()
@@ -159,6 +170,7 @@ def main():
     parser.add_argument("--workload", default="25fv47")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
     parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
     args = parser.parse_args()
 

@@ -4,6 +4,8 @@
 `aggregate` is the only exchange of the bench: MAX of the per-rank wall time and SUM of the per-rank pivot counts
 (RCCL all-reduce on GPUs, gloo in the CPU tests).  Nothing here computes an LP.
 """
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -53,14 +55,16 @@ class TicketQueue:
         self.count = int(count)
         self.key = "relp_amd/ticket/%s" % tag
         self.local = 0
+        self.lock = threading.Lock()  # several host threads of one rank may draw tickets (one LP in flight per thread)
         self.store = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self.store = dist.distributed_c10d._get_default_store()
 
     def next(self):
-        if self.store is None:
-            ticket = self.local
-            self.local += 1
-        else:
-            ticket = self.store.add(self.key, 1) - 1
+        with self.lock:
+            if self.store is None:
+                ticket = self.local
+                self.local += 1
+            else:
+                ticket = self.store.add(self.key, 1) - 1
         return ticket if ticket < self.count else None

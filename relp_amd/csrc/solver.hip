@@ -423,7 +423,7 @@ void Solver::build_graph(int count) {
     if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
     if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
     long long launches = stats_.launches, price_launches = stats_.price_launches;
-    RELP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    RELP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
     launch_pivots(count);
     RELP_HIP(hipStreamEndCapture(stream_, &graph_));
     RELP_HIP(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
@@ -633,7 +633,8 @@ void Solver::solve(relp_result* result) {
             polish(true);
             Ctl c = read_ctl();
             std::vector<double> xb(d_.m);
-            RELP_HIP(hipMemcpy(xb.data(), d_.xB, d_.m * sizeof(double), hipMemcpyDeviceToHost));
+            RELP_HIP(hipMemcpyAsync(xb.data(), d_.xB, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            RELP_HIP(hipStreamSynchronize(stream_));
             double scale = 1.0;
             for (double v : xb) scale += std::fabs(v);
             if (-c.minus_obj > opt_.tol_feasible * scale) {
@@ -780,8 +781,9 @@ double Solver::profile_kernel(int which, int repetitions) {
     if (which == 0) {
         // algorithmic bytes of a pricing pass at this state: the columns that are non-basic now
         std::vector<int> pos(d_.n), cs(d_.n + 1);
-        RELP_HIP(hipMemcpy(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost));
-        RELP_HIP(hipMemcpy(cs.data(), d_.col_start, (d_.n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        RELP_HIP(hipMemcpyAsync(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipMemcpyAsync(cs.data(), d_.col_start, (d_.n + 1) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
         long long bytes = 0;
         for (int j = d_.n_art; j < d_.n; ++j) {
             if (pos[j] >= 0) continue;
