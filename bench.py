@@ -70,6 +70,31 @@ def cpu_baseline_dense(dims, budget_seconds):
                       "explicit-inverse loop, BLAS on %d threads" % (model.pivots, elapsed, threads)}
 
 
+def dense_roofline(device):
+    """The pricing pass of BASELINE configs[2] (dense 4096 x 8192), timed with HIP events inside the pivot loop: the
+    HBM-bound kernel of the path, reported beside the default workload's (latency-bound) figure."""
+    import relp_amd
+    from relp_amd.workloads import dense_lp
+    a, b, c = dense_lp(4096, 8192)
+    solver = relp_amd.Solver(device=device, polish_period=512).load_dense_le(a, b, c)
+    solver.begin_phase_one()
+    solver.iterate(300)
+    seconds = solver.profile_kernel(0, 100)
+    bytes_per_launch = solver.stats().price_bytes
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1_dense4096_pmc_traffic.json")
+    if os.path.exists(pmc):
+        for name, entry in json.load(open(pmc)).items():
+            if "price_dense_kernel" in name:
+                traffic = entry["hbm_bytes_corrected"]
+    solver.close()
+    achieved = bytes_per_launch / seconds / 1e9
+    return {"workload": "synthetic dense random LP m=4096 n=8192 (python bench.py --workload dense4096 for its pivots/s)",
+            "bound": "hbm", "kernel": "price (dense block)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "seconds_per_launch": seconds,
+            "algorithmic_bytes_per_launch": bytes_per_launch}
+
+
 def netlib_batch(args, rank, local_rank, world, distributed):
     """Config 4: independent LPs shard across ranks -- by default through a dynamic ticket queue over the cost-sorted list
     (relp_amd.batch.TicketQueue), or the static longest-first partition (relp_amd.batch.assign); every LP is resident
@@ -154,7 +179,7 @@ def netlib_batch(args, rank, local_rank, world, distributed):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "%d Netlib .SIF files shipped under data/netlib" % len(names),
-            "config": {"workload": "Netlib batch (%d LPs), %s, one LP per GPU at a time" % (
+            "config": {"workload": "Netlib batch (%d LPs), %s, independent LPs sharded over the GPUs" % (
                 len(names), "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
                        "lps_in_flight_per_gpu": max(1, args.concurrency),
                        "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}}))
@@ -170,6 +195,8 @@ def main():
     parser.add_argument("--workload", default="25fv47")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-concurrency-probe", action="store_true")
+    parser.add_argument("--no-dense-roofline", action="store_true")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
     parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
     args = parser.parse_args()
@@ -214,6 +241,34 @@ def main():
     elapsed = time.perf_counter() - start
     from relp_amd import batch
     elapsed, pivots = batch.aggregate(elapsed, pivots, device="cuda" if distributed else None)
+
+    in_flight = None
+    if rank == 0 and not dense and not args.no_concurrency_probe:
+        # headroom: the same LP, 4 independent copies in flight on this GPU (one host thread and stream each); a single
+        # latency-bound solve uses a fraction of the chip.  Reported beside `value`, never as `value`.
+        import threading
+        copies = [solver] + [relp_amd.Solver(device=local_rank).load_mps(path) for _ in range(3)]
+        for extra in copies[1:]:
+            extra.solve_relaxation()
+        counts = [0] * len(copies)
+
+        def run(k):
+            for _ in range(args.steps):
+                r = copies[k].solve_relaxation()
+                counts[k] += r.pivots_phase_one + r.pivots_phase_two
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(1, len(copies))]
+        for t in threads:
+            t.start()
+        run(0)
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        in_flight = {"copies": len(copies), "pivots_per_s": sum(counts) / (time.perf_counter() - t0)}
+        for extra in copies[1:]:
+            extra.close()
 
     exact = None
     if rank == 0 and not dense:
@@ -266,11 +321,17 @@ def main():
                        "pivots_per_solve": int(last.pivots_phase_one + last.pivots_phase_two),
                        "objective": last.objective, "wall_clock_to_optimal_s": last.solve_seconds,
                        "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
-                       "parallelism": "1 LP per GPU x%d" % world, "exact": exact},
+                       "parallelism": "1 LP per GPU x%d" % world, "exact": exact,
+                       "aggregate_with_copies_in_flight": in_flight},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if not dense:
+            line["roofline"]["note"] = ("latency bound by construction: one pricing launch streams %d KB that live in L2 (SURVEY.md "
+                                        "section 8(d)); the HBM-roofline configuration is BASELINE configs[2], measured below") % (bytes_per_launch // 1024)
+            if world == 1 and not args.no_dense_roofline:
+                line["roofline_config3"] = dense_roofline(local_rank)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_dense(path, args.cpu_seconds) if dense else cpu_baseline(path, args.cpu_seconds)
         print(json.dumps(line))
