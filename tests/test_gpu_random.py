@@ -81,3 +81,79 @@ def test_iteration_limit_is_reported():
     assert result.kind == relp_amd.ITERATION_LIMIT
     assert result.pivots_phase_one + result.pivots_phase_two <= 10 + 64
     solver.close()
+
+
+def dense_mixed_lp(rng, m, n):
+    """Feasible, bounded LP with a dense coefficient block and all four row kinds (equality, range, <=, >=): built from a
+    primal point x0 >= 0 (feasibility) and dual multipliers of the right signs (boundedness)."""
+    counts = [m // 4, m // 8, m - m // 4 - m // 8 - m // 5, m // 5]  # E, R, <=, >=
+    a = [[rng.randint(1, 9) * rng.choice([1, 1, 1, -1]) for _ in range(n)] for _ in range(m)]
+    x0 = [rng.randint(0, 3) for _ in range(n)]
+    activity = [sum(a[i][j] * x0[j] for j in range(n)) for i in range(m)]
+    b, ranges = [], []
+    row = 0
+    for _ in range(counts[0]):
+        b.append(activity[row]); row += 1
+    for _ in range(counts[1]):
+        width = rng.randint(1, 9)
+        b.append(activity[row] + rng.randint(0, width)); ranges.append(width); row += 1   # b - range <= a x <= b
+    for _ in range(counts[2]):
+        b.append(activity[row] + rng.randint(0, 9)); row += 1
+    for _ in range(counts[3]):
+        b.append(activity[row] - rng.randint(0, 9)); row += 1
+    # the standard form needs b >= 0: flip equality / inequality rows with a negative right-hand side where allowed
+    for i in range(m):
+        if b[i] < 0 and i < counts[0]:
+            b[i] = -b[i]; a[i] = [-v for v in a[i]]
+    if any(v < 0 for v in b):
+        return None
+    # dual point: y free on E, <= 0 on '<=', >= 0 on '>=' (minimisation); c = A'y + s, s >= 0
+    y = [rng.randint(-2, 2) if i < counts[0] else (0 if i < counts[0] + counts[1] else (-rng.randint(0, 2) if i < m - counts[3] else rng.randint(0, 2)))
+         for i in range(m)]
+    cost = [sum(a[i][j] * y[i] for i in range(m)) + rng.randint(0, 4) for j in range(n)]
+    return counts, a, b, ranges, cost
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_block_with_mixed_rows_exact(seed, monkeypatch):
+    """Dense pipeline (forced by the test hook) on LPs with artificials, range rows and zero-level pivots.  The device's
+    exact certificate must hold (an independent proof of optimality in rational arithmetic), the optimum must agree with
+    HiGHS, and on the smallest size with the exact optimum of the C++ oracle (its rationals make larger dense LPs slow)."""
+    from scipy.optimize import linprog
+    monkeypatch.setenv("RELP_FTRAN_MIN_NNZ", "16")
+    rng = random.Random(7000 + seed)
+    m, n = rng.choice([(64, 96), (80, 128), (97, 130), (120, 200)])
+    lp = None
+    while lp is None:
+        lp = dense_mixed_lp(rng, m, n)
+    counts, a, b, ranges, cost = lp
+    columns = [[(i, a[i][j]) for i in range(m) if a[i][j] != 0] for j in range(n)]
+    column_start, rows, nums = [0], [], []
+    for col in columns:
+        for i, v in col:
+            rows.append(i); nums.append(v)
+        column_start.append(len(rows))
+    solver = relp_amd.Solver(certify=1, polish_period=32)
+    solver.load_matrix_data(column_start, rows, nums, [1] * len(nums), b=b, cost=cost, upper=[None] * n, ranges=ranges,
+                            counts=tuple(counts))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    exact = Fraction(solver.objective_exact())
+    # HiGHS on the same LP
+    am = np.array(a, dtype=float)
+    e, r = counts[0], counts[1]
+    le0, le1 = e + r, e + r + counts[2]
+    a_ub = np.vstack([am[e:e + r], -am[e:e + r], am[le0:le1], -am[le1:]])
+    b_ub = np.concatenate([np.array(b[e:e + r], float), -(np.array(b[e:e + r], float) - np.array(ranges, float)),
+                           np.array(b[le0:le1], float), -np.array(b[le1:], float)])
+    highs = linprog(cost, A_ub=a_ub, b_ub=b_ub, A_eq=am[:e], b_eq=np.array(b[:e], float), bounds=(0, None), method="highs")
+    assert highs.status == 0
+    assert abs(float(exact) - highs.fun) <= 1e-7 * max(1.0, abs(highs.fun))
+    if (m, n) == (64, 96):
+        from relp_oracle import cpu
+        data = MatrixData(columns, b, ranges, counts[0], counts[1], counts[2], counts[3], [Variable(c) for c in cost])
+        record = cpu.solve_provider(data, trace=0)
+        objective = sum((Fraction(cost[j]) * v for j, v in data.reconstruct_solution(record["solution"])), Fraction(0))
+        assert exact == objective
+    solver.close()
