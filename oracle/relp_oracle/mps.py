@@ -198,6 +198,8 @@ class GeneralForm:
         self.names = list(names)
         self.nr_original = len(self.variables)
         self.free_pairs = {}                             # positive column -> negative column
+        self.active_to_original = list(range(len(self.variables)))  # general_form/mod.rs `from_active_to_original`
+        self.removed = {}                                # original index -> RemovedVariable (filled by presolve)
 
     # ---- construction from MPS (io/mps/convert.rs:29-90) -------------------------------------------
     @classmethod
@@ -331,8 +333,8 @@ class GeneralForm:
     def full_solution(self, reduced_solution):
         """mod.rs:840-934 without presolve: un-shift, un-flip, recombine free variables."""
         values = dict(reduced_solution)
-        out = {}
-        for j in range(self.nr_original):
+        by_original = {}
+        for j, original in enumerate(self.active_to_original):
             variable = self.variables[j]
             x = values.get(j, ZERO)
             if j in self.free_pairs:
@@ -341,8 +343,19 @@ class GeneralForm:
             x = x - variable.shift
             if variable.flipped:
                 x = -x
-            out[self.names[j]] = x
-        return out
+            by_original[original] = x
+
+        def resolve(original):  # RemovedVariable (mod.rs:96-118): solved, or an affine function of other variables
+            if original not in by_original:
+                solution = self.removed[original]
+                if solution[0] == "Solved":
+                    by_original[original] = solution[1]
+                else:
+                    _, constant, coefficients = solution
+                    by_original[original] = constant - sum((c * resolve(k) for k, c in coefficients), ZERO)
+            return by_original[original]
+
+        return {self.names[j]: resolve(j) for j in range(self.nr_original)}
 
 
 def _process_bounds(variables, bounds):
@@ -389,8 +402,11 @@ def _process_bounds(variables, bounds):
             v.lower_bound = ZERO  # convert.rs:244-262
 
 
-def load_problem(path, fixed=None):
+def load_problem(path, fixed=None, presolve=False):
     """Read an MPS/SIF file -> ``(GeneralForm (standardised), MatrixData)``.
+
+    ``presolve=True`` applies ``GeneralForm::presolve`` first, as the reference's Netlib harness does
+    (tests/netlib/mod.rs:58).
 
     The Netlib harness uses ``parse_fixed`` (tests/netlib/mod.rs:55); ``io::import`` uses the free
     parser for ``.mps`` (io/mod.rs:46).
@@ -400,5 +416,8 @@ def load_problem(path, fixed=None):
     if fixed is None:
         fixed = str(path).upper().endswith(".SIF")
     general = GeneralForm.from_mps(parse(text, fixed=fixed))
+    if presolve:
+        from .presolve import presolve as run_presolve
+        run_presolve(general)
     counts = general.standardize()
     return general, general.derive_matrix_data(counts)
