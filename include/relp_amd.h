@@ -97,6 +97,14 @@ int32_t relp_options_default(relp_options* options);
  * (parser, standardisation, virtual slack columns) is testable on CPU.  relp_load_model uploads it to a handle. */
 typedef struct relp_model relp_model;
 int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model** out, char* error, int32_t error_capacity);
+/* The same with `GeneralForm::presolve` (general_form/mod.rs:335-358 and general_form/presolve/ of the reference: fixed
+ * variables, bound constraints, slack elimination, domain propagation) applied before `standardize()`, as the reference's
+ * Netlib harness does (tests/netlib/mod.rs:58).  RELP_ERR_STATE when the presolve itself proves the problem infeasible,
+ * unbounded or solves it completely (message in `error`). */
+int32_t relp_model_from_mps_ex(const char* path, int32_t fixed_format, int32_t presolve, relp_model** out, char* error,
+                               int32_t error_capacity);
+/* Number of variables of the file and how many of them the presolve removed (0 without presolve). */
+int32_t relp_model_original_variables(const relp_model* model, int32_t* nr_original, int32_t* nr_removed);
 /* Graph providers (reference: examples/max_flow.rs:31-223 `Primal::new` + its MatrixProvider; examples/shortest_path.rs:20-118;
  * incidence matrix data/linear_program/network/representation.rs:24-100).  Arcs in the order the reference's column-major
  * adjacency matrix enumerates them: sorted by (tail, head), no self arcs.  `value` = capacity (max flow: arc j gets the
@@ -150,6 +158,7 @@ int32_t relp_load_dense_le(relp_handle* handle, int32_t m, int32_t n, const int6
 /* Convenience for the step before the path: `parse_fixed`/`parse_free` + `TryInto<GeneralForm>` +
  * `standardize()` + `derive_matrix_data()` (tests/netlib/mod.rs:55-61, without presolve). */
 int32_t relp_load_mps(relp_handle* handle, const char* path, int32_t fixed_format);
+int32_t relp_load_mps_ex(relp_handle* handle, const char* path, int32_t fixed_format, int32_t presolve);
 int32_t relp_load_model(relp_handle* handle, const relp_model* model);
 
 /* `MatrixProvider::{nr_rows, nr_columns, nr_constraints, nr_variable_bounds}` (matrix_provider/mod.rs:37-134). */
@@ -167,6 +176,10 @@ int32_t relp_get_initial_pivots(const relp_handle* handle, int32_t capacity, int
 int32_t relp_solve_relaxation(relp_handle* handle, relp_result* result);
 /* OptimizationResult::FiniteOptimum(x) after `reconstruct_solution` (matrix_data.rs:402-411): structural columns. */
 int32_t relp_get_solution(const relp_handle* handle, double* x_structural);
+/* Values of the variables of the loaded file, in file order: un-shifted, un-flipped, free variables recombined and the
+ * variables a presolve removed evaluated (`GeneralForm::compute_full_solution_with_reduced_solution`,
+ * general_form/mod.rs:753-771, 840-934).  `count` receives their number; RELP_ERR_ARGUMENT if capacity is too small. */
+int32_t relp_get_original_solution(const relp_handle* handle, int32_t capacity, double* x, int32_t* count);
 /* Exact optimal objective "num/den" incl. fixed cost (needs options.certify); returns needed length in *length. */
 int32_t relp_get_objective_exact(const relp_handle* handle, char* buffer, int32_t capacity, int32_t* length);
 /* `InverseMaintainer::basis_column_index_for_row` for all rows (provider indices; -1-k for artificial k). */

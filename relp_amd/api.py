@@ -49,10 +49,10 @@ _lib = None
 
 # every symbol include/relp_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
+    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_from_mps_ex", "relp_model_original_variables", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
     "relp_model_column", "relp_model_column_exact", "relp_model_cost", "relp_model_right_hand_side",
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
-    "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_model", "relp_get_dimensions", "relp_get_column",
+    "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_mps_ex", "relp_get_original_solution", "relp_load_model", "relp_get_dimensions", "relp_get_column",
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
     "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
@@ -91,15 +91,21 @@ def default_options(**overrides):
 class Model:
     """Host-only provider (``MatrixData``; matrix_provider/matrix_data.rs:63-102).  Needs no GPU."""
 
-    def __init__(self, path, fixed=None):
+    def __init__(self, path, fixed=None, presolve=False):
         if fixed is None:
             fixed = str(path).upper().endswith(".SIF")  # tests/netlib/mod.rs:55 uses parse_fixed for the .SIF files
         self._h = C.c_void_p()
         error = C.create_string_buffer(512)
-        status = lib().relp_model_from_mps(str(path).encode(), int(fixed), C.byref(self._h), error, 512)
+        status = lib().relp_model_from_mps_ex(str(path).encode(), int(fixed), int(bool(presolve)), C.byref(self._h), error, 512)
         if status != OK:
             raise RelpError(status, error.value.decode())
         self._read_dimensions()
+
+    def original_variables(self):
+        """(number of variables of the file, how many the presolve removed)."""
+        total, removed = C.c_int32(), C.c_int32()
+        lib().relp_model_original_variables(self._h, C.byref(total), C.byref(removed))
+        return total.value, removed.value
 
     def _read_dimensions(self):
         rows, cols, cons, struct = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -222,10 +228,11 @@ class Solver:
         self.n = self.n_art + self.n_provider
 
     # ---- provider ------------------------------------------------------------------------------
-    def load_mps(self, path, fixed=None):
+    def load_mps(self, path, fixed=None, presolve=False):
+        """``presolve=True`` applies the reference's ``GeneralForm::presolve`` first (tests/netlib/mod.rs:58)."""
         if fixed is None:
             fixed = str(path).upper().endswith(".SIF")
-        self._check(lib().relp_load_mps(self._h, str(path).encode(), int(fixed)))
+        self._check(lib().relp_load_mps_ex(self._h, str(path).encode(), int(fixed), int(bool(presolve))))
         self._dims()
         return self
 
@@ -290,6 +297,15 @@ class Solver:
         """``FiniteOptimum`` vector after ``reconstruct_solution`` (structural columns only)."""
         out = np.zeros(self.n_structural)
         self._check(lib().relp_get_solution(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def original_solution(self):
+        """Values of the file's variables (shifts, flips, free splits and presolve removals undone), in file order."""
+        count = C.c_int32()
+        lib().relp_get_original_solution(self._h, 0, None, C.byref(count))
+        out = np.zeros(count.value)
+        if count.value:
+            self._check(lib().relp_get_original_solution(self._h, count.value, _ptr(out, C.c_double), C.byref(count)))
         return out
 
     def objective_exact(self):

@@ -5,6 +5,7 @@
 #include <sstream>
 
 #include "network.hpp"
+#include "presolve.hpp"
 #include "solver.hpp"
 
 using namespace relp;
@@ -68,7 +69,8 @@ int32_t relp_options_default(relp_options* o) {
 }
 
 // ---- host-only model ------------------------------------------------------------------------------------
-int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model** out, char* error, int32_t error_capacity) {
+int32_t relp_model_from_mps_ex(const char* path, int32_t fixed_format, int32_t presolve, relp_model** out, char* error,
+                               int32_t error_capacity) {
     if (!path || !out) return RELP_ERR_ARGUMENT;
     *out = nullptr;
     auto fail = [&](const std::string& what, int32_t code) {
@@ -84,14 +86,27 @@ int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model**
     buffer << in.rdbuf();
     try {
         relp_model* model = new relp_model();
-        model->form = load_mps(buffer.str(), fixed_format != 0);
+        model->form = load_mps(buffer.str(), fixed_format != 0, presolve != 0);
         *out = model;
         return RELP_OK;
     } catch (const RatOverflow& e) {
         return fail(e.what(), RELP_ERR_OVERFLOW);
+    } catch (const PresolveInfeasible& e) {
+        return fail(e.what(), RELP_ERR_STATE);
+    } catch (const PresolveUnbounded& e) {
+        return fail(e.what(), RELP_ERR_STATE);
     } catch (const std::exception& e) {
         return fail(e.what(), RELP_ERR_PARSE);
     }
+}
+int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model** out, char* error, int32_t error_capacity) {
+    return relp_model_from_mps_ex(path, fixed_format, 0, out, error, error_capacity);
+}
+int32_t relp_model_original_variables(const relp_model* model, int32_t* nr_original, int32_t* nr_removed) {
+    if (!model) return RELP_ERR_ARGUMENT;
+    if (nr_original) *nr_original = (int32_t)model->form.nr_file_variables();
+    if (nr_removed) *nr_removed = (int32_t)model->form.removed.size();
+    return RELP_OK;
 }
 static int32_t model_from_graph(bool max_flow, int32_t nr_vertices, int32_t nr_arcs, const int32_t* tail, const int32_t* head,
                                 const int64_t* num, const int64_t* den, int32_t s, int32_t t, relp_model** out, char* error,
@@ -326,7 +341,7 @@ int32_t relp_load_dense_le(relp_handle* h, int32_t m, int32_t n, const int64_t* 
     });
 }
 
-int32_t relp_load_mps(relp_handle* h, const char* path, int32_t fixed_format) {
+int32_t relp_load_mps_ex(relp_handle* h, const char* path, int32_t fixed_format, int32_t presolve) {
     if (!h || !path) return RELP_ERR_ARGUMENT;
     std::ifstream in(path);
     if (!in) {
@@ -337,16 +352,23 @@ int32_t relp_load_mps(relp_handle* h, const char* path, int32_t fixed_format) {
     buffer << in.rdbuf();
     StandardForm form;
     try {
-        form = load_mps(buffer.str(), fixed_format != 0);
+        form = load_mps(buffer.str(), fixed_format != 0, presolve != 0);
     } catch (const RatOverflow& e) {
         h->error = e.what();
         return RELP_ERR_OVERFLOW;
+    } catch (const PresolveInfeasible& e) {
+        h->error = e.what();
+        return RELP_ERR_STATE;
+    } catch (const PresolveUnbounded& e) {
+        h->error = e.what();
+        return RELP_ERR_STATE;
     } catch (const std::exception& e) {
         h->error = e.what();
         return RELP_ERR_PARSE;
     }
     return guarded(h, [&] { h->solver->load(std::move(form)); });
 }
+int32_t relp_load_mps(relp_handle* h, const char* path, int32_t fixed_format) { return relp_load_mps_ex(h, path, fixed_format, 0); }
 
 #define REQUIRE_LOADED(h)                                   \
     if (!(h) || !(h)->solver) return RELP_ERR_ARGUMENT;     \
@@ -405,13 +427,30 @@ int32_t relp_get_initial_pivots(const relp_handle* h, int32_t capacity, int32_t*
 
 int32_t relp_solve_relaxation(relp_handle* h, relp_result* result) {
     REQUIRE_LOADED(h);
-    return guarded(h, [&] { h->solver->solve(result); });
+    return guarded(h, [&] {
+        h->solver->last_error.clear();
+        h->solver->solve(result);
+        if (!h->solver->last_error.empty()) h->error = h->solver->last_error;  // e.g. why an exact certificate was not obtained
+    });
 }
 
 int32_t relp_get_solution(const relp_handle* h, double* x) {
     REQUIRE_LOADED(h);
     if (!x) return RELP_ERR_ARGUMENT;
     h->solver->get_solution(x);
+    return RELP_OK;
+}
+
+int32_t relp_get_original_solution(const relp_handle* h, int32_t capacity, double* x, int32_t* count) {
+    REQUIRE_LOADED(h);
+    const StandardForm& form = h->solver->form();
+    const int32_t total = (int32_t)form.nr_file_variables();
+    if (count) *count = total;
+    if (!x || capacity < total) return total == 0 ? RELP_OK : RELP_ERR_ARGUMENT;
+    std::vector<double> standardised((size_t)form.data.nr_normal_variables());
+    h->solver->get_solution(standardised.data());
+    const std::vector<double> original = form.original_solution(standardised);
+    for (int32_t j = 0; j < total; ++j) x[j] = original[j];
     return RELP_OK;
 }
 

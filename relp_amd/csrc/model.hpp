@@ -136,16 +136,67 @@ struct MatrixData {
 
 // What the steps either side of the path keep (general_form/mod.rs:41-81), reduced to what the product needs to
 // report the reference's objective: `objective = sum_j x_j c_j + fixed_cost` (general_form/mod.rs:840-851).
+// general_form/mod.rs `RemovedVariable` (filled by the presolve): a value, or an affine function of other ORIGINAL
+// variables, x = constant - sum_k coefficient_k x_k.
+struct RemovedOriginal {
+    bool function_of_others = false;
+    Rat constant;
+    std::vector<std::pair<int, Rat>> coefficients;
+};
+
 struct StandardForm {
     std::string name;
     MatrixData data;
     Rat fixed_cost;
-    std::vector<std::string> column_names;   // original variables
-    std::vector<int> free_negative_part;     // per original variable: index of its negated twin, or -1
-    int nr_original = 0;
+    std::vector<std::string> column_names;   // variables still in the problem (all of them without presolve)
+    std::vector<int> free_negative_part;     // per such variable: index of its negated twin, or -1
+    int nr_original = 0;                     // their number (the first nr_original columns of `data`)
+    // presolve bookkeeping (general_form/mod.rs `from_active_to_original`, `original_variables`)
+    std::vector<std::string> all_column_names;  // every variable of the file
+    std::vector<int> active_to_original;        // index into all_column_names per remaining variable
+    std::vector<std::pair<int, RemovedOriginal>> removed;  // (original index, how to recover its value)
+
+    // Values of the file's variables from the values of the standardised columns (general_form/mod.rs:753-771, 840-934):
+    // un-shift, un-flip, recombine free variables, then evaluate the variables the presolve removed.
+    int nr_file_variables() const { return all_column_names.empty() ? nr_original : (int)all_column_names.size(); }
+    std::vector<double> original_solution(const std::vector<double>& standardised) const {
+        const bool identity = active_to_original.empty();  // providers built without a file: no presolve, no renumbering
+        std::vector<double> out((size_t)nr_file_variables(), 0.0);
+        std::vector<char> known(out.size(), 0);
+        for (int j = 0; j < nr_original; ++j) {
+            double x = standardised[j];
+            if (j < (int)free_negative_part.size() && free_negative_part[j] >= 0) x -= standardised[free_negative_part[j]];
+            x -= data.variables[j].shift.to_double();
+            if (data.variables[j].flipped) x = -x;
+            const int original = identity ? j : active_to_original[j];
+            out[original] = x;
+            known[original] = 1;
+        }
+        // removed variables may refer to each other: resolve until nothing changes (the dependency graph is acyclic)
+        bool progress = true;
+        while (progress) {
+            progress = false;
+            for (const auto& [original, how] : removed) {
+                if (known[original]) continue;
+                bool ready = true;
+                double value = how.constant.to_double();
+                if (how.function_of_others)
+                    for (const auto& [k, c] : how.coefficients) {
+                        if (!known[k]) { ready = false; break; }
+                        value -= c.to_double() * out[k];
+                    }
+                if (ready) {
+                    out[original] = value;
+                    known[original] = 1;
+                    progress = true;
+                }
+            }
+        }
+        return out;
+    }
 };
 
 // mps.cpp
-StandardForm load_mps(const std::string& text, bool fixed_format);
+StandardForm load_mps(const std::string& text, bool fixed_format, bool presolve = false);
 
 }  // namespace relp

@@ -15,6 +15,7 @@
 #include <unordered_map>
 
 #include "model.hpp"
+#include "presolve.hpp"
 
 namespace relp {
 namespace {
@@ -68,15 +69,6 @@ std::vector<std::string> split_ws(const std::string& line) {
     while (in >> tok) out.push_back(tok);
     return out;
 }
-
-enum RowKind { EQUAL = 0, RANGE = 1, LESS = 2, GREATER = 3 };
-
-struct GeneralVariable {
-    Rat cost;
-    bool has_lower = false, has_upper = false;
-    Rat lower, upper, shift;
-    bool flipped = false;
-};
 
 struct Raw {
     std::string name;
@@ -232,9 +224,9 @@ void replace_if(bool& has, Rat& current, const Rat& value, bool keep_greater) {
 
 }  // namespace
 
-StandardForm load_mps(const std::string& text, bool fixed_format) {
+StandardForm load_mps(const std::string& text, bool fixed_format, bool presolve_first) {
     Raw raw = parse(text, fixed_format);
-    const int nr_rows = (int)raw.rows.size();
+    int nr_rows = (int)raw.rows.size();
     int n = (int)raw.columns.size();
 
     // ---- convert.rs:118-262 bounds --------------------------------------------------------------
@@ -300,13 +292,81 @@ StandardForm load_mps(const std::string& text, bool fixed_format) {
         }
     }
 
-    // ---- general_form/mod.rs:506-587 transform_variables ----------------------------------------
+    // ---- general_form/mod.rs:335-463 presolve (optional; the reference's harness applies it: tests/netlib/mod.rs:58) ----
     StandardForm out;
     out.name = raw.name;
-    out.nr_original = n;
-    out.column_names = raw.column_names;
-    out.free_negative_part.assign(n, -1);
+    out.all_column_names = raw.column_names;
     std::vector<SparseColumn> columns = raw.columns;
+    Rat fixed_cost(0);
+    {
+        if (presolve_first) {
+            GeneralProblem gp;  // arbitrary precision inside (presolve.hpp); back to 128-bit rationals afterwards
+            gp.maximize = raw.maximize;
+            for (int j = 0; j < n; ++j) {
+                PVariable v;
+                v.cost = Num(vars[j].cost);
+                v.has_lower = vars[j].has_lower;
+                v.has_upper = vars[j].has_upper;
+                v.lower = Num(vars[j].lower);
+                v.upper = Num(vars[j].upper);
+                gp.variables.push_back(v);
+                PColumn column;
+                for (size_t k = 0; k < columns[j].nnz(); ++k) column.push(columns[j].index[k], Num(columns[j].value[k]));
+                gp.columns.push_back(column);
+                gp.active_to_original.push_back(j);
+            }
+            for (int i = 0; i < nr_rows; ++i) {
+                gp.b.push_back(Num(b[i]));
+                ConstraintKind ck;
+                ck.kind = kind[i];
+                if (kind[i] == RANGE) ck.range = Num(range[i]);
+                gp.kinds.push_back(ck);
+            }
+            presolve(gp);
+            if (gp.variables.empty() || gp.b.empty())
+                throw std::runtime_error("presolve: the problem was solved completely (no rows or columns remain)");
+            std::vector<GeneralVariable> kept;
+            std::vector<SparseColumn> kept_columns;
+            for (size_t j = 0; j < gp.variables.size(); ++j) {
+                GeneralVariable v = vars[gp.active_to_original[j]];  // cost, shift, flipped are untouched by the presolve
+                v.has_lower = gp.variables[j].has_lower;
+                v.has_upper = gp.variables[j].has_upper;
+                v.lower = v.has_lower ? gp.variables[j].lower.to_rat() : Rat(0);
+                v.upper = v.has_upper ? gp.variables[j].upper.to_rat() : Rat(0);
+                kept.push_back(v);
+                SparseColumn column;
+                for (size_t k = 0; k < gp.columns[j].nnz(); ++k) column.push(gp.columns[j].index[k], gp.columns[j].value[k].to_rat());
+                kept_columns.push_back(column);
+            }
+            vars.swap(kept);
+            columns.swap(kept_columns);
+            b.clear();
+            kind.clear();
+            range.assign(gp.b.size(), Rat(0));
+            for (size_t i = 0; i < gp.b.size(); ++i) {
+                b.push_back(gp.b[i].to_rat());
+                kind.push_back(gp.kinds[i].kind);
+                if (gp.kinds[i].kind == RANGE) range[i] = gp.kinds[i].range.to_rat();
+            }
+            fixed_cost = gp.fixed_cost.to_rat();
+            out.active_to_original = gp.active_to_original;
+            for (auto& [original, how] : gp.removed) {
+                RemovedOriginal r;
+                r.function_of_others = how.function_of_others;
+                r.constant = how.constant.to_rat();
+                for (auto& [k, c] : how.coefficients) r.coefficients.push_back({k, c.to_rat()});
+                out.removed.push_back({original, r});
+            }
+        } else {
+            for (int j = 0; j < n; ++j) out.active_to_original.push_back(j);
+        }
+    }
+    nr_rows = (int)b.size();
+    n = (int)vars.size();
+    // ---- general_form/mod.rs:506-587 transform_variables ----------------------------------------
+    out.nr_original = n;
+    for (int j = 0; j < n; ++j) out.column_names.push_back(raw.column_names[out.active_to_original[j]]);
+    out.free_negative_part.assign(n, -1);
     for (int j = 0; j < n; ++j) {
         if (!vars[j].has_lower && !vars[j].has_upper) {
             out.free_negative_part[j] = (int)columns.size();
@@ -321,7 +381,6 @@ StandardForm load_mps(const std::string& text, bool fixed_format) {
             vars[j].lower = Rat(0);
         }
     }
-    Rat fixed_cost(0);
     for (size_t j = 0; j < vars.size(); ++j) {
         GeneralVariable& v = vars[j];
         if (!v.has_lower && v.has_upper) {

@@ -87,6 +87,8 @@ inline bool operator==(const Rat& a, const Rat& b) { return a.n == b.n && a.d ==
 inline bool operator!=(const Rat& a, const Rat& b) { return !(a == b); }
 inline bool operator<(const Rat& a, const Rat& b) { return cmp(a, b) < 0; }
 inline bool operator>(const Rat& a, const Rat& b) { return cmp(a, b) > 0; }
+inline bool operator<=(const Rat& a, const Rat& b) { return cmp(a, b) <= 0; }
+inline bool operator>=(const Rat& a, const Rat& b) { return cmp(a, b) >= 0; }
 
 inline std::string to_string128(i128 v) {
     if (v == 0) return "0";

@@ -52,3 +52,35 @@ def test_bigint_matches_python(driver):
         else:
             want = (a > b) - (a < b)
         assert int(got) == want, (op, a, b)
+
+
+def test_bigrat_matches_python_fractions(tmp_path):
+    """Arbitrary-precision rationals of the presolve (relp_amd/csrc/bigrat.hpp) against fractions.Fraction."""
+    from fractions import Fraction
+    exe = str(tmp_path / "bigrat_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "support", "bigrat_check.cpp"), "-o", exe])
+    rng = random.Random(777)
+    sizes = [1, 8, 30, 61, 62, 63, 64, 65, 100, 126, 127, 128, 200, 500, 2000]
+
+    def fraction():
+        return Fraction(rng.getrandbits(rng.choice(sizes)) * rng.choice([1, -1]), rng.getrandbits(rng.choice(sizes)) + 1)
+
+    lines, expected = [], []
+    for _ in range(2500):
+        op = rng.choice("+-*/cr")
+        x, y = fraction(), fraction()
+        if rng.random() < 0.1:
+            y = x * rng.choice([1, -1, 3])
+        if op == "/" and y == 0:
+            y = Fraction(1)
+        lines.append("%s %d/%d %d/%d" % (op, x.numerator, x.denominator, y.numerator, y.denominator))
+        if op == "c":
+            expected.append(str((x > y) - (x < y)))
+        elif op == "r":
+            fits = x.numerator.bit_length() <= 126 and x.denominator.bit_length() <= 126
+            expected.append("%d/%d" % (x.numerator, x.denominator) if fits else "overflow")
+        else:
+            r = x + y if op == "+" else x - y if op == "-" else x * y if op == "*" else x / y
+            expected.append("%d/%d" % (r.numerator, r.denominator))
+    out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split()
+    assert out == expected

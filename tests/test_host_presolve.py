@@ -1,0 +1,83 @@
+"""The product's C++ presolve (relp_amd/csrc/presolve.hpp) against the oracle's restatement, which the reference's own
+known-answer tests pin (tests/test_oracle_presolve.py).  CPU only.  Every shipped problem file is presolved by both and
+the standardised results are compared exactly: dimensions, row groups, initial pivots, columns, costs, right-hand side,
+fixed cost, and the number of removed variables."""
+import glob
+import os
+from fractions import Fraction
+
+import pytest
+
+import relp_amd
+from relp_oracle.mps import load_problem
+from relp_oracle.presolve import Infeasible, Unbounded
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILES = sorted(glob.glob(os.path.join(ROOT, "data", "*", "*.SIF")) + glob.glob(os.path.join(ROOT, "data", "*", "*.mps")))
+SKIP = {"quadratic_model_data_1.mps", "quadratic_model_data_2.mps", "mixed_model_data_1.mps", "mixed_model_data_2.mps",
+        "basis_data_1.mps"}
+# the Python oracle needs minutes on these (bound tightening with numerators of thousands of bits); RELP_SLOW_TESTS=1 runs them
+SLOW = {"GREENBEA.SIF", "GREENBEB.SIF", "STAIR.SIF", "CYCLE.SIF", "SCFXM1.SIF", "GROW7.SIF", "80BAU3B.SIF", "BNL2.SIF"}
+if os.environ.get("RELP_SLOW_TESTS") == "1":
+    SLOW = set()
+
+
+def exceeds_128_bits(general, data):
+    """True when the presolved LP holds a number the 128-bit rationals of the host model cannot represent."""
+    values = list(data.b) + list(data.ranges) + [general.fixed_cost]
+    for column in data.constraints:
+        values += [v for _, v in column]
+    for variable in data.variables:
+        values += [variable.cost] + ([variable.upper_bound] if variable.upper_bound is not None else [])
+    return any(v.numerator.bit_length() > 126 or v.denominator.bit_length() > 126 for v in values)
+
+
+def name_of(path):
+    return os.path.basename(path)
+
+
+@pytest.mark.parametrize("path", [p for p in FILES if name_of(p) not in SKIP | SLOW], ids=name_of)
+def test_presolved_model_equals_oracle(path):
+    try:
+        general, data = load_problem(path, presolve=True)
+    except (Infeasible, Unbounded) as outcome:
+        with pytest.raises(relp_amd.RelpError) as error:
+            relp_amd.Model(path, presolve=True)
+        assert type(outcome).__name__.lower() in str(error.value).lower()
+        return
+    except Exception as error:  # files the reference's parser rejects, or LPs the presolve solves completely
+        with pytest.raises(relp_amd.RelpError):
+            relp_amd.Model(path, presolve=True)
+        pytest.skip("rejected by both: %s" % error)
+    if data.nr_rows() == 0 or data.nr_columns() == 0:
+        with pytest.raises(relp_amd.RelpError):
+            relp_amd.Model(path, presolve=True)
+        pytest.skip("solved completely by the presolve")
+    if exceeds_128_bits(general, data):  # reported as RELP_ERR_OVERFLOW, like every other value that does not fit
+        with pytest.raises(relp_amd.RelpError) as error:
+            relp_amd.Model(path, presolve=True)
+        assert "overflow" in str(error.value)
+        return
+    model = relp_amd.Model(path, presolve=True)
+    assert (model.nr_rows, model.nr_columns, model.nr_constraints) == (data.nr_rows(), data.nr_columns(), data.nr_constraints())
+    assert model.nr_structural == data.nr_normal_variables()
+    assert model.group_counts == [data.nr_equality, data.nr_range, data.nr_upper, data.nr_lower]
+    assert model.pivot_element_indices() == data.pivot_element_indices()
+    total, removed = model.original_variables()
+    assert total == general.nr_original and removed == len(general.removed)
+    step = max(1, model.nr_columns // 400)
+    for j in list(range(0, model.nr_columns, step)) + [model.nr_columns - 1]:
+        assert [(i, Fraction(n, d)) for i, n, d in model.column_exact(j)] == data.column(j), j
+        assert model.cost_value(j) == pytest.approx(float(data.cost_value(j)), rel=1e-15, abs=0)
+    # the C ABI hands the right-hand side over as doubles: (double)num / (double)den can differ from the correctly rounded
+    # value in the last place when numerator or denominator exceed 53 bits
+    assert list(model.right_hand_side()) == pytest.approx([float(v) for v in data.right_hand_side()], rel=1e-14, abs=0)
+    assert model.fixed_cost() == pytest.approx(float(general.fixed_cost), rel=1e-14, abs=0)
+
+
+def test_presolve_shrinks_the_headline_problem():
+    plain = relp_amd.Model(os.path.join(ROOT, "data", "netlib", "25FV47.SIF"))
+    presolved = relp_amd.Model(os.path.join(ROOT, "data", "netlib", "25FV47.SIF"), presolve=True)
+    assert (plain.nr_rows, plain.nr_columns) == (821, 1876)
+    assert (presolved.nr_rows, presolved.nr_columns) == (790, 1843)
+    assert presolved.original_variables() == (1571, 32)
