@@ -197,6 +197,7 @@ def main():
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-concurrency-probe", action="store_true")
     parser.add_argument("--no-dense-roofline", action="store_true")
+    parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
     parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
     args = parser.parse_args()
@@ -221,7 +222,7 @@ def main():
         a, b, c = dense_lp(*path)
         solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512"))).load_dense_le(a, b, c)
     else:
-        solver = relp_amd.Solver(device=local_rank).load_mps(path)
+        solver = relp_amd.Solver(device=local_rank).load_mps(path, presolve=args.presolve)
 
     def barrier():
         if distributed:
@@ -247,7 +248,7 @@ def main():
         # headroom: the same LP, 4 independent copies in flight on this GPU (one host thread and stream each); a single
         # latency-bound solve uses a fraction of the chip.  Reported beside `value`, never as `value`.
         import threading
-        copies = [solver] + [relp_amd.Solver(device=local_rank).load_mps(path) for _ in range(3)]
+        copies = [solver] + [relp_amd.Solver(device=local_rank).load_mps(path, presolve=args.presolve) for _ in range(3)]
         for extra in copies[1:]:
             extra.solve_relaxation()
         counts = [0] * len(copies)
@@ -273,7 +274,7 @@ def main():
     exact = None
     if rank == 0 and not dense:
         # one extra, untimed, certified solve: bit-exact rational optimum (north_star parity requirement)
-        certified = relp_amd.Solver(device=local_rank, certify=1).load_mps(path)
+        certified = relp_amd.Solver(device=local_rank, certify=1).load_mps(path, presolve=args.presolve)
         cres = certified.solve_relaxation()
         if cres.certified:
             text = certified.objective_exact()
@@ -309,8 +310,8 @@ def main():
             workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing" % path
             data = "synthetic"
         else:
-            workload = ("Netlib 25FV47 821x1876 (+520 virtual artificials), steepest-edge pricing, explicit-inverse carry, "
-                        "no presolve")
+            workload = ("Netlib 25FV47 %dx%d, steepest-edge pricing, explicit-inverse carry, %s" % (
+                solver.m, solver.n_provider, "after the reference's presolve" if args.presolve else "no presolve (+520 virtual artificials)"))
             data = "Netlib 25FV47.SIF (shipped problem file), one copy per GPU"
         line = {
             "metric": "simplex pivots/sec + wall-clock to optimal, Netlib 25fv47 @1 GPU",
