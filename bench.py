@@ -174,7 +174,7 @@ def netlib_batch(args, rank, local_rank, world, distributed):
                 tolerance = max(e["tolerance"], 2e-5 if name == "25FV47" else 0.0)
                 if abs(objective - e["expected"]) > tolerance:
                     wrong.append(name)
-        print(json.dumps({
+        summary = json.dumps({
             "metric": "simplex pivots/sec, Netlib suite batched one LP per GPU", "value": pivots / elapsed, "unit": "pivots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -182,9 +182,11 @@ def netlib_batch(args, rank, local_rank, world, distributed):
             "config": {"workload": "Netlib batch (%d LPs), %s, independent LPs sharded over the GPUs" % (
                 len(names), "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
                        "lps_in_flight_per_gpu": max(1, args.concurrency),
-                       "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}}))
+                       "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}})
     if distributed:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(summary, flush=True)
 
 
 def main():
@@ -335,9 +337,11 @@ def main():
                 line["roofline_config3"] = dense_roofline(local_rank)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_dense(path, args.cpu_seconds) if dense else cpu_baseline(path, args.cpu_seconds)
-        print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)  # the ONE JSON line, after everything else this process may print
 
 
 if __name__ == "__main__":
