@@ -28,6 +28,18 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def emit(text):
+    """Print the ONE JSON line as the last line of stdout: RCCL writes a banner through C stdio, which is block buffered
+    when stdout is a pipe and would otherwise be flushed at exit, after the line."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(text, flush=True)
+
+
 def cpu_baseline(path, budget_seconds):
     """relp-equivalent exact CPU path (the oracle: kind "port"), first pivots of the same workload, one core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -186,7 +198,7 @@ def netlib_batch(args, rank, local_rank, world, distributed):
     if distributed:
         torch.distributed.destroy_process_group()
     if rank == 0:
-        print(summary, flush=True)
+        emit(summary)
 
 
 def main():
@@ -340,8 +352,7 @@ def main():
     if distributed:
         dist.destroy_process_group()
     if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(line), flush=True)  # the ONE JSON line, after everything else this process may print
+        emit(json.dumps(line))
 
 
 if __name__ == "__main__":
