@@ -2111,12 +2111,14 @@ static void launch_ftran_ratio_rule(const DeviceLP& d, int n_price_blocks, doubl
         RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 4>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else if (fits && d.m <= 8 * K2F_THREADS)
         RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 8>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
+    else if (fits && d.m <= 16 * K2F_THREADS)
+        RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 16>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else
         hipLaunchKernelGGL((ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
 }
 
-// n_alpha_slices > 0 requires the register-resident kernel (m <= 4096 and <= 2048 pricing workgroups)
-bool fast_k2_available(const DeviceLP& d, int n_price_blocks) { return n_price_blocks <= K2F_MAX_BLOCKS && d.m <= 8 * K2F_THREADS; }
+// n_alpha_slices > 0 requires the register-resident kernel (m <= 8192 and <= 2048 pricing workgroups)
+bool fast_k2_available(const DeviceLP& d, int n_price_blocks) { return n_price_blocks <= K2F_MAX_BLOCKS && d.m <= 16 * K2F_THREADS; }
 
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
                         int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s) {
