@@ -64,7 +64,9 @@ typedef struct relp_options {
                                   exact rational objective (bit-exact with the reference's RationalBig optimum) */
     int32_t use_graph;         /* 1: replay the pivot loop from a hipGraph */
     int32_t verbose;
-    int32_t reserved;
+    int32_t implicit_bounds;   /* 1: variable upper bounds (MatrixData's VariableBound / SlackBound rows, matrix_data.rs:104-112)
+                                  are handled by the bounded-variable ratio test instead of as rows: same optimum, fewer rows
+                                  (the basis and the fine-grained trait operations then refer to the reduced LP) */
 } relp_options;
 
 typedef struct relp_result {

@@ -29,7 +29,7 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("pivot_rule", C.c_int32), ("polish_period", C.c_int32),
                 ("pivots_per_launch", C.c_int32), ("max_pivots", C.c_int64), ("tol_dual", C.c_double),
                 ("tol_pivot", C.c_double), ("harris_delta", C.c_double), ("tol_feasible", C.c_double),
-                ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32)]
+                ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("implicit_bounds", C.c_int32)]
 
 
 class Result(C.Structure):

@@ -65,6 +65,7 @@ int32_t relp_options_default(relp_options* o) {
     o->certify = 0;
     o->use_graph = 1;
     o->verbose = 0;
+    o->implicit_bounds = 0;
     return RELP_OK;
 }
 

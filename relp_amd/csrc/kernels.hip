@@ -287,13 +287,17 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
     int a = 0, b = 0, r0 = 0;
     double v0 = 0.0, cost_j = 0.0, g_j = 1.0;
     bool nonbasic = false;
+    double sgn_j = 1.0;  // -1: the column is held in complemented form (implicit upper bounds)
     auto load_column = [&](int j) {
         a = b = r0 = 0;
         v0 = cost_j = 0.0;
         g_j = 1.0;
         nonbasic = false;
+        sgn_j = 1.0;
         if (j < col_last) {
-            nonbasic = lp.pos[j] < 0;
+            const int pos_j = lp.pos[j];
+            nonbasic = pos_j < 0;
+            sgn_j = pos_j == -2 ? -1.0 : 1.0;
             a = lp.col_start[j];
             b = lp.col_start[j + 1];
             r0 = lp.ell_rows[(size_t)j * ELL_W + sub];
@@ -385,7 +389,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                 }
                 lp.gamma[j] = gam;
             }
-            const double cbar = cost_j + d_pi;
+            const double cbar = sgn_j * (cost_j + d_pi);
             bool candidate = cbar < -tol_dual;
             Cand c;
             c.idx = j;
@@ -551,7 +555,7 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
                 }
                 lp.gamma[j] = gam;
             }
-            const double cbar = cost_j + d_pi;
+            const double cbar = (pos_j == -2 ? -1.0 : 1.0) * (cost_j + d_pi);
             if (cbar < -tol_dual) {
                 Cand c;
                 c.idx = j;
@@ -1106,13 +1110,24 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
             lp.alpha[i] = single ? a : lp.alpha[i] + a;
         }
     }
+    // Implicit upper bounds: see ftran_ratio_fast_kernel (same rules, alpha kept in global memory here).
+    const bool bounded = lp.ub != nullptr;
+    const double sgn_q = (bounded && lp.flipped[q]) ? -1.0 : 1.0;
+    const double ub_q = bounded ? lp.ub[q] : INFINITY;
+    const double cbar_signed = (bounded && forced_q >= 0) ? cbar_q * sgn_q : cbar_q;
     double sumsq = 0.0;
     double theta = INFINITY;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const double a = lp.alpha[i];
+        const double a = lp.alpha[i] * sgn_q;
+        lp.alpha[i] = a;
         sumsq += a * a;
         const bool skip = skip_artificial_rows && lp.basis[i] < lp.n_art;
-        if (a > tol_pivot && !skip) theta = fmin(theta, (fmax(lp.xB[i], 0.0) + harris_delta) / a);
+        if (skip) continue;
+        if (a > tol_pivot) theta = fmin(theta, (fmax(lp.xB[i], 0.0) + harris_delta) / a);
+        else if (bounded && a < -tol_pivot) {
+            const double up = lp.xub[i];
+            if (up < INFINITY) theta = fmin(theta, (fmax(up - lp.xB[i], 0.0) + harris_delta) / -a);
+        }
     }
     const double gamma_q = 1.0 + block_reduce<0>(sumsq, s_red);  // pivot_rule.rs:258 (1 + ||alpha_q||^2)
     int p = forced_p;
@@ -1126,9 +1141,13 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
             const double a = lp.alpha[i];
             const bool skip = skip_artificial_rows && lp.basis[i] < lp.n_art;
-            if (a > tol_pivot && !skip && fmax(lp.xB[i], 0.0) / a <= theta_max) {
+            if (skip) continue;
+            double room = -1.0;
+            if (a > tol_pivot) room = fmax(lp.xB[i], 0.0);
+            else if (bounded && a < -tol_pivot && lp.xub[i] < INFINITY) room = fmax(lp.xub[i] - lp.xB[i], 0.0);
+            if (room >= 0.0 && room / fabs(a) <= theta_max) {
                 Cand o;
-                o.key = a;
+                o.key = fabs(a);
                 o.idx = i;
                 o.aux = lp.basis[i];
                 c = better<TIE_SMALLER_AUX>(c, o);
@@ -1137,7 +1156,14 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
         c = block_best<TIE_SMALLER_AUX>(c, s_cand);
         p = c.idx;
     }
-    if (p < 0) {
+    const double alpha_pq = p >= 0 ? lp.alpha[p] : 1.0;
+    const double xb_p = p >= 0 ? lp.xB[p] : 0.0;
+    const double up_p = (bounded && p >= 0) ? lp.xub[p] : INFINITY;
+    const bool leaves_at_upper = bounded && forced_p < 0 && p >= 0 && alpha_pq < 0.0;
+    const double xp = (forced_p >= 0 || !bounded) ? fmax(xb_p, 0.0) / alpha_pq
+                                                  : (leaves_at_upper ? fmax(up_p - xb_p, 0.0) : fmax(xb_p, 0.0)) / fabs(alpha_pq);
+    const bool flip = bounded && forced_p < 0 && ub_q < INFINITY && (p < 0 || ub_q <= xp);
+    if (p < 0 && !flip) {
         if (threadIdx.x == 0) {
             if (mode == 0) ctl->status = ST_UNBOUNDED;
             ctl->q = q;
@@ -1151,8 +1177,8 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     if (mode == 2) {
         if (threadIdx.x == 0) {
             ctl->q = q;
-            ctl->p = p;
-            ctl->cbar_q = cbar_q;
+            ctl->p = flip ? -1 : p;
+            ctl->cbar_q = cbar_signed;
             ctl->gamma_q = gamma_q;
             ctl->pending = 0;
             ctl->forced_q = -1;
@@ -1160,11 +1186,34 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
         }
         return;
     }
+    const int leaving = p >= 0 ? lp.basis[p] : -1;
+    const int leaving_flipped = (bounded && leaving >= 0) ? lp.flipped[leaving] : 0;
+    __syncthreads();  // every thread has read xB[p], basis[p], flipped[..] before they are overwritten
+    if (flip) {
+        // bound flip: x_q runs from 0 to ub_q, the basis does not change; x_q is complemented so that it sits at 0 again
+        for (int i = threadIdx.x; i < m; i += blockDim.x) lp.xB[i] -= lp.alpha[i] * ub_q;
+        for (int e = lp.col_start[q] + threadIdx.x; e < lp.col_start[q + 1]; e += blockDim.x)
+            lp.rhs[lp.row_index[e]] -= ub_q * sgn_q * lp.value[e];
+        if (threadIdx.x == 0) {
+            const int now_flipped = (sgn_q < 0.0) ? 0 : 1;
+            lp.flipped[q] = now_flipped;
+            lp.pos[q] = now_flipped ? -2 : -1;
+            ctl->flip_cost += (now_flipped ? 1.0 : -1.0) * ub_q * lp.cost[q];
+            ctl->q = q;
+            ctl->p = -1;
+            ctl->cbar_q = cbar_signed;
+            ctl->minus_obj -= cbar_signed * ub_q;
+            ctl->iters += 1;
+            ctl->bound_flips += 1;
+            ctl->pending = 0;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+            ctl->last_selected = q;
+        }
+        return;
+    }
 
     // ---- x_B update (carry/mod.rs:295-325) and the ordered non-zero list of alpha for K3 ----------------
-    const double alpha_pq = lp.alpha[p];
-    const double xp = fmax(lp.xB[p], 0.0) / alpha_pq;
-    __syncthreads();  // every thread has read xB[p] before it is overwritten
     // ordered list of the rows K3 has to touch (alpha_i != 0, plus p): ballot + prefix per chunk of blockDim rows
     __shared__ int s_nz_wave[K2_THREADS / WAVE];
     int total = 0;
@@ -1190,8 +1239,12 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
         total += chunk;
         if (i < m) lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
     }
+    if (leaves_at_upper) {  // the leaving variable reached its upper bound: hold it in complemented form from now on
+        const double sgn_l = leaving_flipped ? -1.0 : 1.0;
+        for (int e = lp.col_start[leaving] + threadIdx.x; e < lp.col_start[leaving + 1]; e += blockDim.x)
+            lp.rhs[lp.row_index[e]] -= up_p * sgn_l * lp.value[e];
+    }
     if (threadIdx.x == 0) {
-        const int leaving = lp.basis[p];
         lp.basis[p] = q;
         if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[p]) {  // column p of the inverse stops being a unit vector
             const int count = ctl->touched_count;
@@ -1200,16 +1253,27 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
             ctl->touched_count = count + 1;
         }
         lp.pos[q] = p;
-        lp.pos[leaving] = -1;
+        if (bounded) {
+            int fl = leaving_flipped;
+            if (leaves_at_upper) {
+                fl ^= 1;
+                lp.flipped[leaving] = fl;
+                ctl->flip_cost += (fl ? 1.0 : -1.0) * up_p * lp.cost[leaving];
+            }
+            lp.pos[leaving] = fl ? -2 : -1;
+            lp.xub[p] = ub_q;
+        } else {
+            lp.pos[leaving] = -1;
+        }
         ctl->q = q;
         ctl->p = p;
         ctl->leaving = leaving;
-        ctl->cbar_q = cbar_q;
+        ctl->cbar_q = cbar_signed;
         ctl->alpha_pq = alpha_pq;
         ctl->gamma_q = gamma_q;
         ctl->xp = xp;
         ctl->nz_count = total;
-        ctl->minus_obj -= cbar_q * xp;
+        ctl->minus_obj -= cbar_signed * xp;
         ctl->iters += 1;
         ctl->pending = 1;
         ctl->forced_q = -1;
@@ -1410,15 +1474,36 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     }
     STAMP(2);
     // ---- gamma_q and Harris pass 1, one combined block reduction ----------------------------------------
+    // Implicit upper bounds (lp.ub): a basic variable may also leave at its upper bound -- rows with alpha_i < 0 whose
+    // basic variable has one -- and the entering variable may run into its own bound first (a "bound flip", no basis
+    // change).  Complemented columns enter with the opposite sign.
+    const bool bounded = lp.ub != nullptr;
+    double sgn_q = 1.0, ub_q = INFINITY;
+    if (bounded) {
+        sgn_q = lp.flipped[q] ? -1.0 : 1.0;
+        ub_q = lp.ub[q];
+        if (forced_q >= 0) cbar_q *= sgn_q;  // the candidates of the pricing pass carry the sign already
+    }
     double sumsq = 0.0, theta = INFINITY;
     bool eligible[R];
+    double room[R];  // distance of the basic variable to the bound it moves towards
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = tid + r * K2F_THREADS;
+        al[r] *= sgn_q;
         const double a = al[r];
         sumsq += a * a;
-        eligible[r] = i < m && a > tol_pivot && !(skip_artificial_rows && bas[r] < lp.n_art);
-        if (eligible[r]) theta = fmin(theta, (fmax(xb[r], 0.0) + harris_delta) / a);
+        const bool allowed = i < m && !(skip_artificial_rows && bas[r] < lp.n_art);
+        room[r] = fmax(xb[r], 0.0);
+        eligible[r] = allowed && a > tol_pivot;
+        if (bounded && allowed && a < -tol_pivot) {
+            const double up = lp.xub[i];
+            if (up < INFINITY) {
+                eligible[r] = true;
+                room[r] = fmax(up - xb[r], 0.0);
+            }
+        }
+        if (eligible[r]) theta = fmin(theta, (room[r] + harris_delta) / fabs(a));
     }
     {
         const int lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -1452,10 +1537,11 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         unsigned long long hrank = RANK_NONE;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (eligible[r] && fmax(xb[r], 0.0) / al[r] <= theta_max) {
+            const double mag = fabs(al[r]);
+            if (eligible[r] && room[r] / mag <= theta_max) {
                 const unsigned long long rk = ((unsigned long long)(unsigned)bas[r] << 32) | (unsigned)(tid + r * K2F_THREADS);
-                if (hrank == RANK_NONE || al[r] > hkey || (al[r] == hkey && rk < hrank)) {
-                    hkey = al[r];
+                if (hrank == RANK_NONE || mag > hkey || (mag == hkey && rk < hrank)) {
+                    hkey = mag;
                     hrank = rk;
                 }
             }
@@ -1464,7 +1550,31 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         p = hrank == RANK_NONE ? -1 : (int)(hrank & 0xffffffffu);
     }
     STAMP(4);
-    if (p < 0) {
+    // ---- broadcast the pivot row's scalars (its owner has them in registers) ------------------------------
+    if (tid == 0) {
+        s_bcast[1] = 1.0;
+        s_bcast[2] = 0.0;
+        s_bcast[3] = INFINITY;
+        s_ibcast[0] = -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (tid + r * K2F_THREADS == p) {
+            s_bcast[1] = al[r];
+            s_bcast[2] = xb[r];
+            s_bcast[3] = room[r];
+            s_ibcast[0] = bas[r];
+        }
+    }
+    __syncthreads();
+    const double alpha_pq = s_bcast[1];
+    const int leaving = s_ibcast[0];
+    // step length: to the bound of the leaving variable, or (forced zero-level pivots) as the reference computes it
+    double xp = (forced_p >= 0 || !bounded) ? fmax(s_bcast[2], 0.0) / alpha_pq : s_bcast[3] / fabs(alpha_pq);
+    const bool leaves_at_upper = bounded && forced_p < 0 && p >= 0 && alpha_pq < 0.0;
+    const bool flip = bounded && forced_p < 0 && ub_q < INFINITY && (p < 0 || ub_q <= xp);
+    if (p < 0 && !flip) {
         if (tid == 0) {
             if (mode == 0) ctl->status = ST_UNBOUNDED;
             ctl->q = q;
@@ -1483,7 +1593,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         }
         if (tid == 0) {
             ctl->q = q;
-            ctl->p = p;
+            ctl->p = flip ? -1 : p;
             ctl->cbar_q = cbar_q;
             ctl->gamma_q = gamma_q;
             ctl->pending = 0;
@@ -1492,19 +1602,33 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         }
         return;
     }
-    // ---- broadcast the pivot row's scalars (its owner has them in registers) ------------------------------
+    if (flip) {
+        // ---- bound flip: x_q runs from 0 to ub_q, the basis does not change; x_q is complemented so that it sits at 0 again
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (tid + r * K2F_THREADS == p) {
-            s_bcast[1] = al[r];
-            s_bcast[2] = xb[r];
-            s_ibcast[0] = bas[r];
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * K2F_THREADS;
+            if (i < m) lp.xB[i] = xb[r] - al[r] * ub_q;
         }
+        for (int e = lp.col_start[q] + tid; e < lp.col_start[q + 1]; e += K2F_THREADS)
+            lp.rhs[lp.row_index[e]] -= ub_q * sgn_q * lp.value[e];
+        if (tid == 0) {
+            const int now_flipped = lp.flipped[q] ^ 1;
+            lp.flipped[q] = now_flipped;
+            lp.pos[q] = now_flipped ? -2 : -1;
+            ctl->flip_cost += (now_flipped ? 1.0 : -1.0) * ub_q * lp.cost[q];
+            ctl->q = q;
+            ctl->p = -1;
+            ctl->cbar_q = cbar_q;
+            ctl->minus_obj = minus_obj - cbar_q * ub_q;
+            ctl->iters = iters + 1;
+            ctl->bound_flips += 1;
+            ctl->pending = 0;  // no basis change: no inverse update, no weight update
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+            ctl->last_selected = q;
+        }
+        return;
     }
-    __syncthreads();
-    const double alpha_pq = s_bcast[1];
-    const double xp = fmax(s_bcast[2], 0.0) / alpha_pq;
-    const int leaving = s_ibcast[0];
     // ---- x_B update (carry/mod.rs:295-325) and alpha for K3 ------------------------------------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1527,7 +1651,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             if (lane_k2 == 0) s_nz_count[r * NW + wave_k2] = __popcll(masks[r]);
         }
         __syncthreads();
-        if (tid == 0) {  // exclusive prefix over the R * NW (= 64) wave counts
+        if (tid == 0) {  // exclusive prefix over the R * NW wave counts
             int running = 0;
             for (int e = 0; e < R * NW; ++e) {
                 const int c = s_nz_count[e];
@@ -1549,6 +1673,14 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         total = s_nz_count[R * NW];
     }
     STAMP(5);
+    const int leaving_flipped = bounded ? lp.flipped[leaving] : 0;
+    if (leaves_at_upper) {  // the leaving variable reached its upper bound: hold it in complemented form from now on
+        const double ub_l = s_bcast[2] + s_bcast[3];  // x_p + room = its upper bound
+        const double sgn_l = leaving_flipped ? -1.0 : 1.0;
+        for (int e = lp.col_start[leaving] + tid; e < lp.col_start[leaving + 1]; e += K2F_THREADS)
+            lp.rhs[lp.row_index[e]] -= ub_l * sgn_l * lp.value[e];
+    }
+    if (bounded) __syncthreads();  // every thread has read flipped[leaving] before thread 0 rewrites it
     if (tid == 0) {
         lp.basis[p] = q;
         if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[p]) {  // column p of the inverse stops being a unit vector
@@ -1558,7 +1690,18 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             ctl->touched_count = count + 1;
         }
         lp.pos[q] = p;
-        lp.pos[leaving] = -1;
+        if (bounded) {
+            int fl = leaving_flipped;
+            if (leaves_at_upper) {
+                fl ^= 1;
+                lp.flipped[leaving] = fl;
+                ctl->flip_cost += (fl ? 1.0 : -1.0) * (s_bcast[2] + s_bcast[3]) * lp.cost[leaving];
+            }
+            lp.pos[leaving] = fl ? -2 : -1;
+            lp.xub[p] = ub_q;
+        } else {
+            lp.pos[leaving] = -1;
+        }
         ctl->q = q;
         ctl->p = p;
         ctl->leaving = leaving;
@@ -1730,7 +1873,8 @@ __global__ void __launch_bounds__(256) pi_kernel(DeviceLP lp) {
         const double* col = lp.Binv + (size_t)j * ld;
         double acc = 0.0;
         for (int i = lane; i < m; i += WAVE) {
-            const double c = lp.cost[lp.basis[i]];
+            const int bj = lp.basis[i];
+            const double c = (lp.flipped && lp.flipped[bj]) ? -lp.cost[bj] : lp.cost[bj];
             if (c != 0.0) acc += c * col[i];
         }
         acc = wave_sum(acc);
@@ -1738,7 +1882,13 @@ __global__ void __launch_bounds__(256) pi_kernel(DeviceLP lp) {
     }
     if (blockIdx.x == 0) {
         double acc = 0.0;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) acc += lp.xB[i] * lp.cost[lp.basis[i]];
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const int bj = lp.basis[i];
+            acc += lp.xB[i] * ((lp.flipped && lp.flipped[bj]) ? -lp.cost[bj] : lp.cost[bj]);
+        }
+        if (lp.flipped)  // constant of the complemented variables: sum ub_j c_j
+            for (int j = threadIdx.x; j < lp.n; j += blockDim.x)
+                if (lp.flipped[j]) acc += lp.ub[j] * lp.cost[j];
         acc = block_reduce<0>(acc, s_red);
         if (threadIdx.x == 0) lp.ctl->minus_obj = -acc;
     }
@@ -1810,10 +1960,11 @@ __global__ void __launch_bounds__(256) residual_kernel(DeviceLP lp, const double
     const int m = lp.m, ld = lp.ld;
     const int col = lp.basis[k];
     const int a = lp.col_start[col], b = lp.col_start[col + 1];
+    const double sgn = (lp.flipped && lp.flipped[col]) ? -1.0 : 1.0;  // complemented basic column: B' holds -a_j
     double local_max = 0.0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         double acc = (i == k) ? 1.0 : 0.0;
-        for (int e = a; e < b; ++e) acc -= lp.value[e] * T[(size_t)lp.row_index[e] * ld + i];
+        for (int e = a; e < b; ++e) acc -= sgn * lp.value[e] * T[(size_t)lp.row_index[e] * ld + i];
         S[(size_t)k * ld + i] = acc;
         local_max = fmax(local_max, fabs(acc));
     }
@@ -1976,8 +2127,9 @@ __global__ void gather_basis_kernel(DeviceLP lp, double* Bd) {
     const int col = lp.basis[k];
     for (int r = threadIdx.x; r < lp.m; r += blockDim.x) Bd[(size_t)k * lp.ld + r] = 0.0;
     __syncthreads();
+    const double sgn = (lp.flipped && lp.flipped[col]) ? -1.0 : 1.0;
     for (int e = lp.col_start[col] + threadIdx.x; e < lp.col_start[col + 1]; e += blockDim.x)
-        Bd[(size_t)k * lp.ld + lp.row_index[e]] = lp.value[e];
+        Bd[(size_t)k * lp.ld + lp.row_index[e]] = sgn * lp.value[e];
 }
 
 // T0 = s * B  (T0[r][k] = s B[r][k]; X0 = T0' = s B'): start of a from-scratch Newton-Schulz inversion.
@@ -1986,8 +2138,9 @@ __global__ void scaled_basis_kernel(DeviceLP lp, double* T, double scale) {
     const int col = lp.basis[k];
     for (int r = threadIdx.x; r < lp.m; r += blockDim.x) T[(size_t)r * lp.ld + k] = 0.0;
     __syncthreads();
+    const double sgn = (lp.flipped && lp.flipped[col]) ? -1.0 : 1.0;
     for (int e = lp.col_start[col] + threadIdx.x; e < lp.col_start[col + 1]; e += blockDim.x)
-        T[(size_t)lp.row_index[e] * lp.ld + k] = scale * lp.value[e];
+        T[(size_t)lp.row_index[e] * lp.ld + k] = scale * sgn * lp.value[e];
 }
 
 // ---------------------------------------------------------------------------------------------------

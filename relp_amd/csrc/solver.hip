@@ -93,7 +93,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -118,12 +118,17 @@ void Solver::load(StandardForm&& form) {
 // and makes the pricing pass one uniform CSC sweep.
 void Solver::upload() {
     const MatrixData& md = form_.data;
-    const int m = md.nr_rows();
-    const int n_p = md.nr_columns();
+    // Implicit upper bounds: the device LP has the constraint rows only (E | R | <= | >=) and the provider columns of the
+    // first four groups (structurals, range slacks, <= slacks, >= slacks); the VariableBound / SlackBound rows and their
+    // slack columns (matrix_data.rs:104-145) become upper bounds of the structurals and the range slacks.
+    bounded_ = opt_.implicit_bounds != 0 && md.nr_variable_bounds() > 0;
+    const int m = bounded_ ? md.nr_constraints() : md.nr_rows();
+    const int n_p = bounded_ ? md.col_end[3] : md.nr_columns();
     if (m < 1) throw std::runtime_error("LP without rows");
     auto pivots = md.pivot_element_indices();
     std::vector<int> real_column_of_row(m, -1);
-    for (auto& [row, column] : pivots) real_column_of_row[row] = column;
+    for (auto& [row, column] : pivots)
+        if (row < m && column < n_p) real_column_of_row[row] = column;
     std::vector<int> artificial_rows;
     for (int i = 0; i < m; ++i)
         if (real_column_of_row[i] < 0) artificial_rows.push_back(i);
@@ -140,6 +145,7 @@ void Solver::upload() {
     for (int j = 0; j < n_p; ++j) {
         SparseColumn c = md.column(j);
         for (size_t e = 0; e < c.nnz(); ++e) {
+            if (c.index[e] >= m) continue;  // the bound-row entry of a bounded column (implicit bounds)
             row_index.push_back(c.index[e]);
             value.push_back(c.value[e].to_double());
         }
@@ -174,7 +180,7 @@ void Solver::upload() {
     int n_dense = 0;
     if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE && m >= 64)
         while (n_dense < n_p && (col_start[n_art + n_dense + 1] - col_start[n_art + n_dense]) * 2 > m) ++n_dense;
-    if (n_dense < 64) n_dense = 0;
+    if (n_dense < 64 || bounded_) n_dense = 0;
     d_.n_dense = n_dense;
     d_.dense_first = n_art;
     d_.dense_ld = (m + 3) & ~3;
@@ -274,6 +280,18 @@ void Solver::upload() {
         RELP_HIP(hipStreamSynchronize(stream_));
         configure_dense_lds((size_t)3 * d_.dense_ld * sizeof(double));
     }
+    d_.rhs0 = dmalloc<double>(m);
+    if (bounded_) {
+        std::vector<double> ub(n, std::numeric_limits<double>::infinity());
+        for (int j = 0; j < md.nr_normal_variables(); ++j)
+            if (md.variables[j].has_upper) ub[n_art + j] = md.variables[j].upper.to_double();
+        for (int k = 0; k < md.nr_range; ++k) ub[n_art + md.col_end[0] + k] = md.ranges[k].to_double();
+        d_.ub = dmalloc<double>(n);
+        d_.xub = dmalloc<double>(m);
+        d_.flipped = dmalloc<int>(n);
+        upload_vec(d_.ub, ub, stream_);
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
     d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 2 + 16);
     d_.ctl = dmalloc<Ctl>(1);
     d_.dbg = dmalloc<unsigned long long>(64);
@@ -288,6 +306,7 @@ void Solver::upload() {
     upload_vec(d_.cost1, cost1, stream_);
     upload_vec(d_.cost2, cost2, stream_);
     upload_vec(d_.rhs, rhs, stream_);
+    upload_vec(d_.rhs0, rhs, stream_);
     RELP_HIP(hipMemsetAsync(d_.rho, 0, m * sizeof(double), stream_));
     RELP_HIP(hipMemsetAsync(d_.w, 0, m * sizeof(double), stream_));
     RELP_HIP(hipMemsetAsync(d_.alpha, 0, m * sizeof(double), stream_));
@@ -299,7 +318,7 @@ void Solver::upload() {
                          (long long)n_dense * m * dense_entry_bytes_;  // upper bound: every dense column non-basic
     stats_.update_bytes = (long long)2 * m * m * 8;
     h_basis_.assign(m, -1);
-    h_solution_.assign(n_p, 0.0);
+    h_solution_.assign(md.nr_columns(), 0.0);
 }
 
 Ctl Solver::read_ctl() {
@@ -323,7 +342,8 @@ void Solver::begin_phase_one() {
     std::vector<int> basis(m), pos(n, -1);
     auto pivots = md.pivot_element_indices();
     std::vector<int> real_column_of_row(m, -1);
-    for (auto& [row, column] : pivots) real_column_of_row[row] = column;
+    for (auto& [row, column] : pivots)
+        if (row < m && column < n - n_art) real_column_of_row[row] = column;
     int k = 0;
     for (int i = 0; i < m; ++i) {
         basis[i] = real_column_of_row[i] < 0 ? k++ : n_art + real_column_of_row[i];
@@ -331,6 +351,13 @@ void Solver::begin_phase_one() {
     }
     upload_vec(d_.basis, basis, stream_);
     upload_vec(d_.pos, pos, stream_);
+    RELP_HIP(hipMemcpyAsync(d_.rhs, d_.rhs0, m * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    if (bounded_) {  // nothing is complemented; the initial basic variables (artificials, <= slacks) have no upper bound
+        std::vector<double> xub(m, std::numeric_limits<double>::infinity());
+        upload_vec(d_.xub, xub, stream_);
+        RELP_HIP(hipMemsetAsync(d_.flipped, 0, n * sizeof(int), stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
     RELP_HIP(hipMemcpyAsync(d_.xB, d_.rhs, m * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     launch_identity(d_.Binv, m, d_.ld, stream_);
     RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));  // every column is a unit vector
@@ -361,9 +388,11 @@ void Solver::set_phase(int phase) {
     Ctl c = read_ctl();
     const double minus_obj = c.minus_obj;
     const int touched_count = c.touched_count;
+    const long long bound_flips = c.bound_flips;
     c = Ctl{};
     c.minus_obj = minus_obj;
     c.touched_count = touched_count;
+    c.bound_flips = bound_flips;
     c.forced_q = c.forced_p = -1;
     c.last_selected = -1;
     c.scan_column = std::numeric_limits<int>::max();
@@ -524,6 +553,7 @@ void Solver::invert_from_scratch() {
 // `InverseMaintainer::from_basis` (carry/mod.rs:444-478) + `Tableau::new_with_inverse_maintainer`: phase two from a given basis.
 void Solver::set_basis(const int* basis_columns) {
     if (!loaded_) throw std::runtime_error("no LP loaded");
+    if (bounded_) throw std::runtime_error("set_basis is not available with implicit_bounds (the device LP has fewer rows)");
     RELP_HIP(hipSetDevice(opt_.device));
     const int m = d_.m, n = d_.n;
     std::vector<int> basis(m), pos(n, -1);
@@ -662,9 +692,43 @@ void Solver::solve(relp_result* result) {
     RELP_HIP(hipMemcpyAsync(xb.data(), d_.xB, m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     Ctl c = read_ctl();
     std::fill(h_solution_.begin(), h_solution_.end(), 0.0);
-    for (int i = 0; i < m; ++i) {
-        h_basis_[i] = basis[i] >= d_.n_art ? basis[i] - d_.n_art : -1 - basis[i];
-        if (basis[i] >= d_.n_art) h_solution_[basis[i] - d_.n_art] = xb[i];
+    if (!bounded_) {
+        for (int i = 0; i < m; ++i) {
+            h_basis_[i] = basis[i] >= d_.n_art ? basis[i] - d_.n_art : -1 - basis[i];
+            if (basis[i] >= d_.n_art) h_solution_[basis[i] - d_.n_art] = xb[i];
+        }
+    } else {
+        // back to the reference's formulation: values of complemented variables are u_j - x'_j, a complemented non-basic
+        // variable sits at its upper bound, and the basis of the full MatrixData has, on every bound row, the bound slack
+        // (variable below its bound) or the variable itself (variable at its bound).
+        const MatrixData& md = form_.data;
+        std::vector<int> flipped(d_.n), pos(d_.n);
+        std::vector<double> ub(d_.n);
+        RELP_HIP(hipMemcpyAsync(flipped.data(), d_.flipped, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipMemcpyAsync(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipMemcpyAsync(ub.data(), d_.ub, d_.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+        h_basis_.assign(md.nr_rows(), -1);
+        for (int i = 0; i < m; ++i) {
+            const int dev = basis[i];
+            h_basis_[i] = dev >= d_.n_art ? dev - d_.n_art : -1 - dev;
+            if (dev >= d_.n_art) h_solution_[dev - d_.n_art] = flipped[dev] ? ub[dev] - xb[i] : xb[i];
+        }
+        for (int j = d_.n_art; j < d_.n; ++j)
+            if (pos[j] == -2) h_solution_[j - d_.n_art] = ub[j];
+        const int nb = (int)md.bound_to_variable.size();
+        for (int k2 = 0; k2 < nb; ++k2) {  // VariableBound rows
+            const int j = md.bound_to_variable[k2];
+            const bool at_upper = pos[d_.n_art + j] == -2;
+            h_basis_[md.row_end[3] + k2] = at_upper ? j : md.col_end[3] + k2;
+            if (!at_upper) h_solution_[md.col_end[3] + k2] = ub[d_.n_art + j] - h_solution_[j];
+        }
+        for (int k2 = 0; k2 < md.nr_range; ++k2) {  // SlackBound rows (range slacks)
+            const int j = md.col_end[0] + k2;
+            const bool at_upper = pos[d_.n_art + j] == -2;
+            h_basis_[md.row_end[4] + k2] = at_upper ? j : md.col_end[4] + k2;
+            if (!at_upper) h_solution_[md.col_end[4] + k2] = ub[d_.n_art + j] - h_solution_[j];
+        }
     }
     res.kind = kind;
     res.pivots_phase_one = pivots_[0];

@@ -38,6 +38,8 @@ struct Ctl {
     int nz_count;      // entries of the ordered non-zero list of alpha_q (written by K2, read by K3)
     int eta_count;     // deferred product form (dense pipeline): pivots not yet folded into the stored inverse
     int touched_count; // columns of the stored inverse that are not unit vectors any more (entries of DeviceLP::tlist)
+    double flip_cost;  // implicit bounds: sum of ub_j c_j over the complemented variables (current phase's costs)
+    long long bound_flips;  // iterations that moved the entering variable to its other bound without a basis change
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
@@ -103,6 +105,14 @@ struct DeviceLP {
     // padded copy of the first ELL_W entries of every column (value 0 padding): no col_start dependency in K1
     int* ell_rows = nullptr;
     double* ell_vals = nullptr;
+    // Implicit upper bounds (relp_options.implicit_bounds): the `VariableBound` / `SlackBound` rows of `MatrixData`
+    // (matrix_data.rs:104-112: x_j + s = u_j) are not rows of the device LP; a variable at its upper bound is held in
+    // complemented form x_j = u_j - x'_j, so every non-basic variable sits at zero and pricing is unchanged up to the
+    // sign of the column: pos[j] == -2 marks a complemented non-basic column, flipped[j] the complemented ones (basic too).
+    double* ub = nullptr;        // [n] upper bound of each device column (+inf without one); nullptr = mode off
+    double* xub = nullptr;       // [m] upper bound of the variable that is basic in row i
+    int* flipped = nullptr;      // [n] 1: the column is held in complemented form
+    double* rhs0 = nullptr;      // [m] right-hand side of the file (rhs holds b minus the complemented columns' u_j a_j)
     double* scratch = nullptr;   // m or n doubles for the fine-grained ops
     Ctl* ctl = nullptr;
     unsigned long long* dbg = nullptr;  // diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of K2
@@ -174,6 +184,7 @@ private:
     int ftran_slices_ = 0;        // > 0: multi-block FTRAN pipeline (select -> partial FTRAN -> fused kernel)
     int sparse_first_ = 0;        // device columns priced by the CSC kernel: [sparse_first_, n)
     int dense_entry_bytes_ = 8;   // 4 when the dense block is held as float (exactly representable entries)
+    bool bounded_ = false;        // implicit upper bounds are active for the loaded LP
     bool eta_mode_ = false;       // deferred product form of the inverse (DeviceLP::eta_cap > 0)
     size_t price_lds_ = 0;
     hipStream_t stream_ = nullptr;

@@ -266,6 +266,97 @@ __global__ void __launch_bounds__(THREADS) variant_h(Args a) {
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// I: float storage, one column per wave (the product's price_dense_kernel<true>)
+__global__ void __launch_bounds__(THREADS) variant_i(Args a, const float* A32) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* s_pi = smem; double* s_rho = smem + a.mp; double* s_w = smem + 2 * a.mp;
+    for (int i = threadIdx.x; i < a.mp; i += THREADS) { s_pi[i] = a.pi[i]; s_rho[i] = a.rho[i]; s_w[i] = a.w[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / WAVE;
+    const int waves_total = gridDim.x * (THREADS / WAVE);
+    const int quarter = a.mp / 4;
+    const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
+    const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
+    const double2* w2 = reinterpret_cast<const double2*>(s_w);
+    for (int jd = blockIdx.x * (THREADS / WAVE) + wave; jd < a.n; jd += waves_total) {
+        if (a.pos[jd] >= 0) continue;
+        const f32x4* col = reinterpret_cast<const f32x4*>(A32 + (size_t)jd * a.mp);
+        double d0 = 0, d1 = 0, d2 = 0;
+        for (int k0 = lane; k0 < quarter; k0 += 8 * WAVE) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(col + k0 + u * WAVE);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * WAVE;
+                const double x0 = v[u].x, x1 = v[u].y, x2 = v[u].z, x3 = v[u].w;
+                const double2 a0 = pi2[2 * k], a1 = pi2[2 * k + 1], b0 = rho2[2 * k], b1 = rho2[2 * k + 1], c0 = w2[2 * k], c1 = w2[2 * k + 1];
+                d0 += (x0 * a0.x + x1 * a0.y) + (x2 * a1.x + x3 * a1.y);
+                d1 += (x0 * b0.x + x1 * b0.y) + (x2 * b1.x + x3 * b1.y);
+                d2 += (x0 * c0.x + x1 * c0.y) + (x2 * c1.x + x3 * c1.y);
+            }
+        }
+        d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+        if (lane == 0) { a.out[3 * jd] = d0; a.out[3 * jd + 1] = d1; a.out[3 * jd + 2] = d2; }
+    }
+}
+// J: float storage, two columns per wave at a time sharing the LDS reads
+__global__ void __launch_bounds__(THREADS) variant_j(Args a, const float* A32) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* s_pi = smem; double* s_rho = smem + a.mp; double* s_w = smem + 2 * a.mp;
+    for (int i = threadIdx.x; i < a.mp; i += THREADS) { s_pi[i] = a.pi[i]; s_rho[i] = a.rho[i]; s_w[i] = a.w[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / WAVE;
+    const int waves_total = gridDim.x * (THREADS / WAVE);
+    const int quarter = a.mp / 4;
+    const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
+    const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
+    const double2* w2 = reinterpret_cast<const double2*>(s_w);
+    int jd = blockIdx.x * (THREADS / WAVE) + wave;
+    while (jd < a.n) {
+        // next two non-basic columns of this wave
+        int ja = jd;
+        while (ja < a.n && a.pos[ja] >= 0) ja += waves_total;
+        int jb = ja + waves_total;
+        while (jb < a.n && a.pos[jb] >= 0) jb += waves_total;
+        jd = jb + waves_total;
+        if (ja >= a.n) break;
+        const bool two = jb < a.n;
+        const f32x4* ca = reinterpret_cast<const f32x4*>(A32 + (size_t)ja * a.mp);
+        const f32x4* cb = reinterpret_cast<const f32x4*>(A32 + (size_t)(two ? jb : ja) * a.mp);
+        double p0 = 0, p1 = 0, p2 = 0, q0 = 0, q1 = 0, q2 = 0;
+        for (int k0 = lane; k0 < quarter; k0 += 4 * WAVE) {
+            f32x4 va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { va[u] = __builtin_nontemporal_load(ca + k0 + u * WAVE); vb[u] = __builtin_nontemporal_load(cb + k0 + u * WAVE); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * WAVE;
+                const double2 a0 = pi2[2 * k], a1 = pi2[2 * k + 1], b0 = rho2[2 * k], b1 = rho2[2 * k + 1], c0 = w2[2 * k], c1 = w2[2 * k + 1];
+                {
+                    const double x0 = va[u].x, x1 = va[u].y, x2 = va[u].z, x3 = va[u].w;
+                    p0 += (x0 * a0.x + x1 * a0.y) + (x2 * a1.x + x3 * a1.y);
+                    p1 += (x0 * b0.x + x1 * b0.y) + (x2 * b1.x + x3 * b1.y);
+                    p2 += (x0 * c0.x + x1 * c0.y) + (x2 * c1.x + x3 * c1.y);
+                }
+                {
+                    const double x0 = vb[u].x, x1 = vb[u].y, x2 = vb[u].z, x3 = vb[u].w;
+                    q0 += (x0 * a0.x + x1 * a0.y) + (x2 * a1.x + x3 * a1.y);
+                    q1 += (x0 * b0.x + x1 * b0.y) + (x2 * b1.x + x3 * b1.y);
+                    q2 += (x0 * c0.x + x1 * c0.y) + (x2 * c1.x + x3 * c1.y);
+                }
+            }
+        }
+        p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+        q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2);
+        if (lane == 0) {
+            a.out[3 * ja] = p0; a.out[3 * ja + 1] = p1; a.out[3 * ja + 2] = p2;
+            if (two) { a.out[3 * jb] = q0; a.out[3 * jb + 1] = q1; a.out[3 * jb + 2] = q2; }
+        }
+    }
+}
+
 __global__ void dirty_kernel(double2* p, size_t count) {  // stands in for the inverse update: read-modify-write
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -292,6 +383,12 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(pi, hv.data(), mp * 8, hipMemcpyHostToDevice)); CHECK(hipMemcpy(rho, hv.data(), mp * 8, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(w, hv.data(), mp * 8, hipMemcpyHostToDevice)); CHECK(hipMemcpy(pos, hpos.data(), n * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(inv, 0, (size_t)m * m * 8));
+    std::vector<float> hA32(hA.begin(), hA.end());
+    float* A32;
+    CHECK(hipMalloc(&A32, hA32.size() * 4));
+    CHECK(hipMemcpy(A32, hA32.data(), hA32.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_i), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * mp * 8)));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_j), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * mp * 8)));
     Args a = {A, pos, pi, rho, w, out, n, m, mp};
     const size_t lds = (size_t)3 * mp * 8;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&variant_a), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -307,7 +404,7 @@ int main(int argc, char** argv) {
     const double bytes = (double)nonbasic * mp * 8;
     std::vector<double> ref(3 * n), got(3 * n);
     for (int dirty = 1; dirty < 3; ++dirty) {
-        for (int variant = 0; variant < 10; ++variant) {
+        for (int variant = 0; variant < 12; ++variant) {
             for (int blocks : {256, 512}) {
                 if ((variant == 5 || variant == 6) && blocks != 256) continue;
                 std::vector<float> times;
@@ -325,6 +422,8 @@ int main(int argc, char** argv) {
                         case 7: hipExtLaunchKernelGGL(variant_f, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a); break;
                         case 8: hipExtLaunchKernelGGL(variant_g, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a); break;
                         case 9: hipExtLaunchKernelGGL(variant_h, dim3(blocks), dim3(THREADS), lds * 2 / 3, s, e0, e1, 0, a); break;
+                        case 10: hipExtLaunchKernelGGL(variant_i, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a, A32); break;
+                        case 11: hipExtLaunchKernelGGL(variant_j, dim3(blocks), dim3(THREADS), lds, s, e0, e1, 0, a, A32); break;
                         case 6: hipExtLaunchKernelGGL(variant_e, dim3(32768), dim3(256), 0, s, e0, e1, 0, reinterpret_cast<const double2*>(A), (size_t)n * mp / 2, out); break;
                     }
                     CHECK(hipStreamSynchronize(s));
@@ -334,9 +433,9 @@ int main(int argc, char** argv) {
                 }
                 std::sort(times.begin(), times.end());
                 const double med = times[times.size() / 2] * 1e-3;
-                const double b = (variant >= 4 && variant <= 6) ? (double)n * mp * 8 : bytes;
-                const char* names[] = {"A current", "B pipelined x8", "B pipelined x4", "D stream/col", "E flat", "E flat 8192", "E flat 32768", "F block/col", "G nontemporal", "H 2 vectors"};
-                if (variant <= 2 || variant == 7 || variant == 8) {
+                const double b = (variant >= 4 && variant <= 6) ? (double)n * mp * 8 : (variant >= 10 ? bytes / 2 : bytes);
+                const char* names[] = {"A current", "B pipelined x8", "B pipelined x4", "D stream/col", "E flat", "E flat 8192", "E flat 32768", "F block/col", "G nontemporal", "H 2 vectors", "I float", "J float x2 cols"};
+                if (variant <= 2 || variant == 7 || variant == 8 || variant >= 10) {
                     CHECK(hipMemcpy(got.data(), out, (size_t)3 * n * 8, hipMemcpyDeviceToHost));
                     if (variant == 0 && blocks == 256 && dirty == 1) ref = got;
                     double worst = 0;

@@ -7,7 +7,7 @@ exp = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json
 names = sorted(n for n, e in exp.items() if os.path.exists(os.path.join(ROOT, "data", "netlib", n + ".SIF")) and (not e["ignored"] or "intensive" in e["ignored"]))
 rows = []
 for name in names:
-    s = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    s = relp_amd.Solver(implicit_bounds=int(os.environ.get("RELP_IMPLICIT_BOUNDS", "0"))).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
     s.solve_relaxation()
     r = s.solve_relaxation()
     rows.append((r.solve_seconds, name, s.m, s.n_provider, r.pivots_phase_one + r.pivots_phase_two))
