@@ -381,10 +381,30 @@ void Solver::begin_phase_one() {
 void Solver::begin_phase_two() { set_phase(2); }
 
 void Solver::set_phase(int phase) {
+    const int phase_before = phase_;
     phase_ = phase;
     RELP_HIP(hipMemcpyAsync(d_.cost, phase == 1 ? d_.cost1 : d_.cost2, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     launch_pi(d_, stream_);
-    if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE) launch_gamma_init(d_, binv_identity_ ? 1 : 0, stream_);
+    // Steepest-edge weights gamma_j = 1 + |B^-1 a_j|^2 do not depend on the costs, and the recurrences that maintain them
+    // are exact: what phase one leaves is what `SteepestDescentAlongObjective::new` (pivot_rule.rs:202-219) would recompute
+    // for phase two.  Recomputing costs one pass over the inverse per column pair -- fine for Netlib, 1 TB for the 1 M-arc
+    // max-flow LP -- so large LPs keep the weights (after flushing the update of the last zero-level pivot).
+    const bool carry_weights = phase == 2 && phase_before == 1 && !binv_identity_ &&
+                               (double)(d_.n - d_.n_art) * (double)d_.m > 4e9;
+    if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE) {
+        if (carry_weights) {
+            Ctl pending = read_ctl();
+            if (pending.pending) {
+                pending.status = ST_RUNNING;
+                write_ctl(pending);
+                RELP_HIP(hipMemcpyAsync(d_.cost, d_.cost1, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+                enqueue_price(0);  // applies the pending Goldfarb-Reid update; its candidates are discarded
+                RELP_HIP(hipMemcpyAsync(d_.cost, d_.cost2, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+            }
+        } else {
+            launch_gamma_init(d_, binv_identity_ ? 1 : 0, stream_);
+        }
+    }
     Ctl c = read_ctl();
     const double minus_obj = c.minus_obj;
     const int touched_count = c.touched_count;
