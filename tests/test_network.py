@@ -181,3 +181,32 @@ def test_gpu_max_flow_m_9000():
     assert abs(result.objective + expected) <= 1e-9 * max(1.0, abs(expected))
     flow = solver.solution()
     assert np.all(flow >= -1e-9) and np.all(flow <= capacity + 1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_max_flow_131k_arcs_with_implicit_bounds():
+    """V = 16 384, E ~ 131 000 (1/8 of BASELINE config 5): with the capacity rows handled as implicit bounds the device LP has
+    V - 2 rows instead of V - 2 + E (147 436); the optimum equals scipy's max-flow value and every flow respects its capacity."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices = 16384
+    tail, head, capacity = max_flow_graph(nr_vertices, 131072)
+    keep = (head != 0) & (tail != nr_vertices - 1)
+    tail, head, capacity = tail[keep], head[keep], capacity[keep]
+    graph = csr_matrix((capacity.astype(np.int32), (tail, head)), shape=(nr_vertices, nr_vertices))
+    expected = maximum_flow(graph, 0, nr_vertices - 1).flow_value
+    model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+    solver = relp_amd.Solver(implicit_bounds=1).load_model(model)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert abs(result.objective + expected) <= 1e-9 * max(1.0, abs(expected))
+    flow = solver.solution()
+    assert len(flow) == len(tail)
+    assert np.all(flow >= -1e-9) and np.all(flow <= capacity + 1e-9)
+    # conservation at every inner vertex
+    net = np.zeros(nr_vertices)
+    np.add.at(net, head, flow)
+    np.subtract.at(net, tail, flow)
+    assert np.max(np.abs(net[1:-1])) <= 1e-7
+    assert abs(-net[0] - expected) <= 1e-7 and abs(net[-1] - expected) <= 1e-7
