@@ -23,6 +23,8 @@ WORKLOADS = {
     "25fv47": os.path.join(ROOT, "data", "netlib", "25FV47.SIF"),   # BASELINE configs[1]: the default, the metric's config
     "dense4096": (4096, 8192),                                          # BASELINE configs[2]: the HBM-roofline config
     "dense1024": (1024, 2048),
+    "maxflow": ("maxflow", 65536, 1048576),                          # BASELINE configs[4]: 1 M-arc max-flow LP, implicit capacity bounds
+    "maxflow64k": ("maxflow", 8192, 65536),
     "netlib": "batch",   # BASELINE configs[3]: the Netlib problems the reference's suite enables, one LP per GPU at a time
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -230,8 +232,17 @@ def main():
     path = WORKLOADS[args.workload]
     if path == "batch":
         return netlib_batch(args, rank, local_rank, world, distributed)
-    dense = not isinstance(path, str)
-    if dense:
+    graph = isinstance(path, tuple) and path[0] == "maxflow"
+    dense = not isinstance(path, str) and not graph
+    if graph:
+        # the MatrixProvider of examples/max_flow.rs on the random graph of SURVEY.md section 8(d); the capacity rows are
+        # handled as implicit bounds (the explicit formulation has V - 2 + E rows: no inverse of that size fits)
+        from relp_amd.workloads import max_flow_graph
+        _, nr_vertices, nr_arcs = path
+        tail, head, capacity = max_flow_graph(nr_vertices, nr_arcs)
+        model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+        solver = relp_amd.Solver(device=local_rank, implicit_bounds=1).load_model(model)
+    elif dense:
         from relp_amd.workloads import dense_lp
         a, b, c = dense_lp(*path)
         solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512"))).load_dense_le(a, b, c)
@@ -258,7 +269,7 @@ def main():
     elapsed, pivots = batch.aggregate(elapsed, pivots, device="cuda" if distributed else None)
 
     in_flight = None
-    if rank == 0 and not dense and not args.no_concurrency_probe:
+    if rank == 0 and not dense and not graph and not args.no_concurrency_probe:
         # headroom: the same LP, 4 independent copies in flight on this GPU (one host thread and stream each); a single
         # latency-bound solve uses a fraction of the chip.  Reported beside `value`, never as `value`.
         import threading
@@ -286,7 +297,7 @@ def main():
             extra.close()
 
     exact = None
-    if rank == 0 and not dense:
+    if rank == 0 and not dense and not graph:
         # one extra, untimed, certified solve: bit-exact rational optimum (north_star parity requirement)
         certified = relp_amd.Solver(device=local_rank, certify=1).load_mps(path, presolve=args.presolve)
         cres = certified.solve_relaxation()
@@ -321,7 +332,12 @@ def main():
                 if wanted in name:
                     traffic = entry["hbm_bytes_corrected"]
                     break
-        if dense:
+        if graph:
+            workload = ("max-flow LP (examples/max_flow.rs provider) on a random graph V=%d E=%d (splitmix64 seed 0x5EED0005): "
+                        "%d conservation rows on the device, the %d capacity rows as implicit bounds" % (
+                            path[1], path[2], path[1] - 2, path[2]))
+            data = "synthetic"
+        elif dense:
             workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing" % path
             data = "synthetic"
         else:
@@ -343,12 +359,15 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if not dense:
+        if graph:
+            line["metric"] = "simplex pivots/sec + wall-clock to optimal, max-flow LP @1 GPU"
+            line["roofline"]["note"] = "pricing pass over the arc columns (padded 8-entry columns, gathers of -pi, rho, w from L2)"
+        elif not dense:
             line["roofline"]["note"] = ("latency bound by construction: one pricing launch streams %d KB that live in L2 (SURVEY.md "
                                         "section 8(d)); the HBM-roofline configuration is BASELINE configs[2], measured below") % (bytes_per_launch // 1024)
             if world == 1 and not args.no_dense_roofline:
                 line["roofline_config3"] = dense_roofline(local_rank)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not graph:
             line["cpu_baseline"] = cpu_baseline_dense(path, args.cpu_seconds) if dense else cpu_baseline(path, args.cpu_seconds)
     if distributed:
         dist.destroy_process_group()
