@@ -312,9 +312,10 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (pricing pass), measured live with HIP events on the solver's stream
         solver.begin_phase_one()
-        solver.iterate(300 if dense else 200)
-        reps = 100 if dense else 200  # further real pivots, the profiled kernel of each bracketed by its own event pair
-        solver.profile_kernel(0, 50)   # discarded: brings clocks and caches to the state of a running solve
+        # (phase one of the flow LP has only a few hundred ordinary pivots before the zero-level ones: short samples there)
+        solver.iterate(20 if graph else (300 if dense else 200))
+        reps = 40 if graph else (100 if dense else 200)  # further real pivots, the profiled kernel of each bracketed by its own event pair
+        solver.profile_kernel(0, 10 if graph else 50)   # discarded: brings clocks and caches to the state of a running solve
         seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(["price", "ftran_ratio", "update"])}
         stats = solver.stats()
         # the roofline kernel is the pricing pass (the path's only mandatory full sweep over the constraint columns;

@@ -2267,7 +2267,7 @@ static void launch_ftran_ratio_rule(const DeviceLP& d, int n_price_blocks, doubl
     else if (fits && d.m <= 16 * K2F_THREADS)
         RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 16>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else
-        hipLaunchKernelGGL((ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
+        RELP_LAUNCH(1, (ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
 }
 
 // n_alpha_slices > 0 requires the register-resident kernel (m <= 8192 and <= 2048 pricing workgroups)
