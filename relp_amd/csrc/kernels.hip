@@ -1083,33 +1083,11 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     }
 
     // ---- FTRAN: alpha = sum_k v_k Binv(:, r_k): contiguous column reads, the column staged through LDS ----
+    // Every pass over the m rows handles K2_U rows per thread at a time so that their loads are in flight together (a
+    // one-row-per-iteration loop is a chain of ~m / 1024 dependent memory latencies: 190 us at m = 65 534).
+    constexpr int K2_U = 8;
     const int ca = lp.col_start[q], cb_ = lp.col_start[q + 1];
     const bool single = (cb_ - ca) <= K2_COL_CHUNK;
-    if (!single)
-        for (int i = threadIdx.x; i < m; i += blockDim.x) lp.alpha[i] = 0.0;
-    for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
-        const int cnt = min(K2_COL_CHUNK, cb_ - c0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
-            s_rows[e] = lp.row_index[c0 + e];
-            s_vals[e] = lp.value[c0 + e];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < m; i += blockDim.x) {
-            const double* col = lp.Binv + i;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            int e = 0;
-            for (; e + 4 <= cnt; e += 4) {
-                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
-                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
-                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
-            }
-            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-            const double a = (a0 + a1) + (a2 + a3);
-            lp.alpha[i] = single ? a : lp.alpha[i] + a;
-        }
-    }
     // Implicit upper bounds: see ftran_ratio_fast_kernel (same rules, alpha kept in global memory here).
     const bool bounded = lp.ub != nullptr;
     const double sgn_q = (bounded && lp.flipped[q]) ? -1.0 : 1.0;
@@ -1117,16 +1095,52 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     const double cbar_signed = (bounded && forced_q >= 0) ? cbar_q * sgn_q : cbar_q;
     double sumsq = 0.0;
     double theta = INFINITY;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const double a = lp.alpha[i] * sgn_q;
-        lp.alpha[i] = a;
-        sumsq += a * a;
-        const bool skip = skip_artificial_rows && lp.basis[i] < lp.n_art;
-        if (skip) continue;
-        if (a > tol_pivot) theta = fmin(theta, (fmax(lp.xB[i], 0.0) + harris_delta) / a);
-        else if (bounded && a < -tol_pivot) {
-            const double up = lp.xub[i];
-            if (up < INFINITY) theta = fmin(theta, (fmax(up - lp.xB[i], 0.0) + harris_delta) / -a);
+    if (!single)
+        for (int i = threadIdx.x; i < m; i += blockDim.x) lp.alpha[i] = 0.0;
+    for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
+        const int cnt = min(K2_COL_CHUNK, cb_ - c0);
+        const bool last_chunk = c0 + K2_COL_CHUNK >= cb_;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+            s_rows[e] = lp.row_index[c0 + e];
+            s_vals[e] = lp.value[c0 + e];
+        }
+        __syncthreads();
+        for (int i0 = threadIdx.x; i0 < m; i0 += K2_U * blockDim.x) {
+            double acc[K2_U], xbv[K2_U], upv[K2_U];
+            int basv[K2_U];
+#pragma unroll
+            for (int u = 0; u < K2_U; ++u) {
+                const int i = i0 + u * blockDim.x;
+                acc[u] = (!single && i < m) ? lp.alpha[i] : 0.0;
+                xbv[u] = (last_chunk && i < m) ? lp.xB[i] : 0.0;
+                basv[u] = (last_chunk && i < m) ? lp.basis[i] : 0;
+                upv[u] = (last_chunk && bounded && i < m) ? lp.xub[i] : INFINITY;
+            }
+            for (int e = 0; e < cnt; ++e) {
+                const size_t off = (size_t)s_rows[e] * ld;
+                const double v = s_vals[e];
+#pragma unroll
+                for (int u = 0; u < K2_U; ++u) {
+                    const int i = i0 + u * blockDim.x;
+                    if (i < m) acc[u] += lp.Binv[off + i] * v;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < K2_U; ++u) {
+                const int i = i0 + u * blockDim.x;
+                if (i >= m) continue;
+                if (!last_chunk) {
+                    lp.alpha[i] = acc[u];
+                    continue;
+                }
+                const double a = acc[u] * sgn_q;  // gamma_q and Harris pass 1 fused into the last FTRAN pass
+                lp.alpha[i] = a;
+                sumsq += a * a;
+                if (skip_artificial_rows && basv[u] < lp.n_art) continue;
+                if (a > tol_pivot) theta = fmin(theta, (fmax(xbv[u], 0.0) + harris_delta) / a);
+                else if (bounded && a < -tol_pivot && upv[u] < INFINITY) theta = fmin(theta, (fmax(upv[u] - xbv[u], 0.0) + harris_delta) / -a);
+            }
         }
     }
     const double gamma_q = 1.0 + block_reduce<0>(sumsq, s_red);  // pivot_rule.rs:258 (1 + ||alpha_q||^2)
@@ -1138,19 +1152,32 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
         c.key = 0.0;
         c.idx = -1;
         c.aux = 0;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) {
-            const double a = lp.alpha[i];
-            const bool skip = skip_artificial_rows && lp.basis[i] < lp.n_art;
-            if (skip) continue;
-            double room = -1.0;
-            if (a > tol_pivot) room = fmax(lp.xB[i], 0.0);
-            else if (bounded && a < -tol_pivot && lp.xub[i] < INFINITY) room = fmax(lp.xub[i] - lp.xB[i], 0.0);
-            if (room >= 0.0 && room / fabs(a) <= theta_max) {
-                Cand o;
-                o.key = fabs(a);
-                o.idx = i;
-                o.aux = lp.basis[i];
-                c = better<TIE_SMALLER_AUX>(c, o);
+        for (int i0 = threadIdx.x; i0 < m; i0 += K2_U * blockDim.x) {
+            double av[K2_U], xbv[K2_U], upv[K2_U];
+            int basv[K2_U];
+#pragma unroll
+            for (int u = 0; u < K2_U; ++u) {
+                const int i = i0 + u * blockDim.x;
+                av[u] = i < m ? lp.alpha[i] : 0.0;
+                xbv[u] = i < m ? lp.xB[i] : 0.0;
+                basv[u] = i < m ? lp.basis[i] : 0;
+                upv[u] = (bounded && i < m) ? lp.xub[i] : INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < K2_U; ++u) {
+                const int i = i0 + u * blockDim.x;
+                if (i >= m || (skip_artificial_rows && basv[u] < lp.n_art)) continue;
+                const double a = av[u];
+                double room = -1.0;
+                if (a > tol_pivot) room = fmax(xbv[u], 0.0);
+                else if (bounded && a < -tol_pivot && upv[u] < INFINITY) room = fmax(upv[u] - xbv[u], 0.0);
+                if (room >= 0.0 && room / fabs(a) <= theta_max) {
+                    Cand o;
+                    o.key = fabs(a);
+                    o.idx = i;
+                    o.aux = basv[u];
+                    c = better<TIE_SMALLER_AUX>(c, o);
+                }
             }
         }
         c = block_best<TIE_SMALLER_AUX>(c, s_cand);
@@ -1214,30 +1241,50 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
     }
 
     // ---- x_B update (carry/mod.rs:295-325) and the ordered non-zero list of alpha for K3 ----------------
-    // ordered list of the rows K3 has to touch (alpha_i != 0, plus p): ballot + prefix per chunk of blockDim rows
-    __shared__ int s_nz_wave[K2_THREADS / WAVE];
+    // ordered list of the rows K3 has to touch (alpha_i != 0, plus p): ballots + one prefix per round of K2_U * blockDim rows
+    constexpr int K2_NW = K2_THREADS / WAVE;
+    __shared__ int s_nz_wave[K2_U * K2_NW + 1];
     int total = 0;
-    for (int i0 = 0; i0 < m; i0 += blockDim.x) {
-        const int i = i0 + threadIdx.x;
-        const double a = i < m ? lp.alpha[i] : 0.0;
-        const bool keep = i < m && (a != 0.0 || i == p);
-        const unsigned long long mask = __ballot(keep);
+    for (int i0 = 0; i0 < m; i0 += K2_U * blockDim.x) {
         const int lane_k2 = threadIdx.x & (WAVE - 1), wave_k2 = threadIdx.x / WAVE;
-        __syncthreads();
-        if (lane_k2 == 0) s_nz_wave[wave_k2] = __popcll(mask);
-        __syncthreads();
-        int base = total, chunk = 0;
-        for (int wv = 0; wv < (int)(blockDim.x / WAVE); ++wv) {
-            if (wv < wave_k2) base += s_nz_wave[wv];
-            chunk += s_nz_wave[wv];
+        double av[K2_U], xbv[K2_U];
+        unsigned long long masks[K2_U];
+#pragma unroll
+        for (int u = 0; u < K2_U; ++u) {
+            const int i = i0 + u * blockDim.x + threadIdx.x;
+            av[u] = i < m ? lp.alpha[i] : 0.0;
+            xbv[u] = i < m ? lp.xB[i] : 0.0;
         }
-        if (keep) {
-            const int slot = base + __popcll(mask & ((1ull << lane_k2) - 1ull));
-            lp.nz_index[slot] = i;
-            lp.nz_alpha[slot] = a;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < K2_U; ++u) {
+            const int i = i0 + u * blockDim.x + threadIdx.x;
+            masks[u] = __ballot(i < m && (av[u] != 0.0 || i == p));
+            if (lane_k2 == 0) s_nz_wave[u * K2_NW + wave_k2] = __popcll(masks[u]);
         }
-        total += chunk;
-        if (i < m) lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
+        __syncthreads();
+        if (threadIdx.x == 0) {  // exclusive prefix over the K2_U * K2_NW wave counts (rows ascend with (u, wave, lane))
+            int running = 0;
+            for (int e = 0; e < K2_U * K2_NW; ++e) {
+                const int c = s_nz_wave[e];
+                s_nz_wave[e] = running;
+                running += c;
+            }
+            s_nz_wave[K2_U * K2_NW] = running;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < K2_U; ++u) {
+            const int i = i0 + u * blockDim.x + threadIdx.x;
+            if (i >= m) continue;
+            if (av[u] != 0.0 || i == p) {
+                const int slot = total + s_nz_wave[u * K2_NW + wave_k2] + __popcll(masks[u] & ((1ull << lane_k2) - 1ull));
+                lp.nz_index[slot] = i;
+                lp.nz_alpha[slot] = av[u];
+            }
+            lp.xB[i] = (i == p) ? xp : xbv[u] - av[u] * xp;
+        }
+        total += s_nz_wave[K2_U * K2_NW];
     }
     if (leaves_at_upper) {  // the leaving variable reached its upper bound: hold it in complemented form from now on
         const double sgn_l = leaving_flipped ? -1.0 : 1.0;
