@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                                                     int col_last, int cand_offset) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[8];
-    static_assert(LPC == ELL_W, "one lane per padded entry");
+    static_assert(LPC == ELL_W || LPC == 2, "one lane per padded entry (width 2 when no column has more than two entries: graph LPs)");
     constexpr int CPB = 256 / LPC;  // columns per workgroup pass
     Ctl* ctl = lp.ctl;
     const int m = lp.m;
@@ -300,8 +300,8 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
             sgn_j = pos_j == -2 ? -1.0 : 1.0;
             a = lp.col_start[j];
             b = lp.col_start[j + 1];
-            r0 = lp.ell_rows[(size_t)j * ELL_W + sub];
-            v0 = lp.ell_vals[(size_t)j * ELL_W + sub];
+            r0 = lp.ell_rows[(size_t)j * LPC + sub];
+            v0 = lp.ell_vals[(size_t)j * LPC + sub];
             cost_j = lp.cost[j];
             if (RULE == RELP_PIVOT_STEEPEST_EDGE) g_j = lp.gamma[j];
         }
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
             d_rho = v0 * v_rho[r0];
             d_w = v0 * v_w[r0];
         }
-        for (int e = a + ELL_W + sub; e < b; e += LPC) {  // columns longer than the padded width (rare)
+        for (int e = a + LPC + sub; e < b; e += LPC) {  // columns longer than the padded width (rare)
             const int r = lp.row_index[e];
             const double v = lp.value[e];
             d_pi += v * v_pi[r];
@@ -366,15 +366,19 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
         }
         // 8-lane group sums with DPP moves (quad_perm, quad_perm, row_half_mirror): every lane of the group gets the total
         d_pi += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, d_pi);
-        d_pi += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_pi);
-        d_pi += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_pi);
+        if (LPC > 2) {
+            d_pi += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_pi);
+            d_pi += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_pi);
+        }
         if (RULE == RELP_PIVOT_STEEPEST_EDGE) {
             d_rho += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, d_rho);
-            d_rho += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_rho);
-            d_rho += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_rho);
             d_w += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, d_w);
-            d_w += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_w);
-            d_w += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_w);
+            if (LPC > 2) {
+                d_rho += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_rho);
+                d_rho += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_rho);
+                d_w += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, d_w);
+                d_w += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, d_w);
+            }
         }
         int improved = 0;
         if (sub == 0 && nonbasic) {
@@ -1330,6 +1334,330 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2 for large m (beyond the register-resident kernel): the same steps spread over ceil(m / 1024) workgroups.  One
+// workgroup sustains ~60 GB/s, and the entering-column / ratio-test step moves ~8 MB at m = 65 534 (150 us in
+// ftran_ratio_kernel); four short kernels exchange per-workgroup partials instead:
+//   k2l_ftran   entering column (every workgroup reduces the candidates itself), alpha for its rows, partial
+//               |alpha|^2 and Harris pass-1 minimum
+//   k2l_harris  fold the partials, Harris pass 2 on its rows -> per-workgroup candidate, count of non-zero alpha
+//   k2l_decide  ONE workgroup: pivot row, step length, bound flip or pivot, all O(1) bookkeeping, list offsets
+//   k2l_apply   x_B update and the ordered list of touched rows for K3
+// Same rules and tie-breaks as ftran_ratio_kernel (mode 0 only; the fine-grained operations keep that kernel).
+// ---------------------------------------------------------------------------------------------------
+constexpr int K2L_THREADS = 1024;
+template <int RULE>
+__global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int n_price_blocks, double tol_pivot,
+                                                              double harris_delta, int skip_artificial_rows) {
+    __shared__ Cand s_cand[18];
+    __shared__ double s_red[18];
+    __shared__ int s_q;
+    __shared__ double s_cbar;
+    __shared__ int s_rows[K2_COL_CHUNK];
+    __shared__ double s_vals[K2_COL_CHUNK];
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING) return;
+    const bool publisher = blockIdx.x == 0 && threadIdx.x == 0;
+    if (publisher) ctl->k2_action = 0;
+    if (ctl->iters >= ctl->budget) {
+        if (publisher) {
+            ctl->status = ST_BUDGET;
+            ctl->pending = 0;
+        }
+        return;
+    }
+    const int m = lp.m, ld = lp.ld;
+    const int forced_q = ctl->forced_q;
+    if (forced_q < 0) {
+        Cand c;
+        c.key = 0.0;
+        c.idx = -1;
+        c.aux = 0;
+        for (int b = threadIdx.x; b < n_price_blocks; b += blockDim.x) {
+            Cand o;
+            o.idx = lp.cand_j[b];
+            o.key = o.idx >= 0 ? lp.cand_key[b] : 0.0;
+            o.aux = b;
+            c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
+        }
+        c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
+        if (threadIdx.x == 0) {
+            s_q = c.idx;
+            s_cbar = c.idx >= 0 ? lp.cand_cbar[c.aux] : 0.0;
+        }
+    } else if (threadIdx.x == 0) {
+        s_q = forced_q;
+        double cb = lp.cost[forced_q];
+        for (int e = lp.col_start[forced_q]; e < lp.col_start[forced_q + 1]; ++e) cb += lp.value[e] * lp.minus_pi[lp.row_index[e]];
+        if (lp.ub && lp.flipped[forced_q]) cb = -cb;
+        s_cbar = cb;
+    }
+    __syncthreads();
+    const int q = s_q;
+    if (publisher) {
+        ctl->q = q;
+        ctl->cbar_q = s_cbar;
+        if (q < 0) {
+            ctl->status = ST_NO_ENTERING;
+            ctl->pending = 0;
+            ctl->last_selected = -1;
+        }
+    }
+    if (q < 0) return;
+    const bool bounded = lp.ub != nullptr;
+    const double sgn_q = (bounded && lp.flipped[q]) ? -1.0 : 1.0;
+    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
+    const double xb = i < m ? lp.xB[i] : 0.0;
+    const int bas = i < m ? lp.basis[i] : 0;
+    const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
+    double acc = 0.0;
+    const int ca = lp.col_start[q], cb_ = lp.col_start[q + 1];
+    for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
+        const int cnt = min(K2_COL_CHUNK, cb_ - c0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+            s_rows[e] = lp.row_index[c0 + e];
+            s_vals[e] = lp.value[c0 + e];
+        }
+        __syncthreads();
+        if (i < m) {
+            double a0 = 0.0, a1 = 0.0;
+            int e = 0;
+            for (; e + 2 <= cnt; e += 2) {
+                a0 += lp.Binv[(size_t)s_rows[e] * ld + i] * s_vals[e];
+                a1 += lp.Binv[(size_t)s_rows[e + 1] * ld + i] * s_vals[e + 1];
+            }
+            for (; e < cnt; ++e) a0 += lp.Binv[(size_t)s_rows[e] * ld + i] * s_vals[e];
+            acc += a0 + a1;
+        }
+    }
+    const double a = acc * sgn_q;
+    double sumsq = 0.0, theta = INFINITY;
+    if (i < m) {
+        lp.alpha[i] = a;
+        sumsq = a * a;
+        if (!(skip_artificial_rows && bas < lp.n_art)) {
+            if (a > tol_pivot) theta = (fmax(xb, 0.0) + harris_delta) / a;
+            else if (bounded && a < -tol_pivot && up < INFINITY) theta = (fmax(up - xb, 0.0) + harris_delta) / -a;
+        }
+    }
+    sumsq = block_reduce<0>(sumsq, s_red);
+    __syncthreads();
+    theta = block_reduce<1>(theta, s_red);
+    if (threadIdx.x == 0) {
+        lp.k2_partd[4 * blockIdx.x] = sumsq;
+        lp.k2_partd[4 * blockIdx.x + 1] = theta;
+    }
+}
+
+__global__ void __launch_bounds__(K2L_THREADS) k2l_harris_kernel(DeviceLP lp, int n_blocks, double tol_pivot, int skip_artificial_rows) {
+    __shared__ Cand s_cand[18];
+    __shared__ double s_red[18];
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING || ctl->q < 0) return;
+    const int m = lp.m;
+    double v1 = 0.0, v2 = INFINITY;
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {  // fixed order: deterministic
+        v1 += lp.k2_partd[4 * b];
+        v2 = fmin(v2, lp.k2_partd[4 * b + 1]);
+    }
+    const double gamma_q = 1.0 + block_reduce<0>(v1, s_red);
+    __syncthreads();
+    const double theta_max = block_reduce<1>(v2, s_red);
+    __syncthreads();
+    const bool bounded = lp.ub != nullptr;
+    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
+    const double a = i < m ? lp.alpha[i] : 0.0;
+    Cand c;
+    c.key = 0.0;
+    c.idx = -1;
+    c.aux = 0;
+    if (i < m && ctl->forced_p < 0) {
+        const int bas = lp.basis[i];
+        if (!(skip_artificial_rows && bas < lp.n_art)) {
+            double room = -1.0;
+            if (a > tol_pivot) room = fmax(lp.xB[i], 0.0);
+            else if (bounded && a < -tol_pivot && lp.xub[i] < INFINITY) room = fmax(lp.xub[i] - lp.xB[i], 0.0);
+            if (room >= 0.0 && room / fabs(a) <= theta_max) {
+                c.key = fabs(a);
+                c.idx = i;
+                c.aux = bas;
+            }
+        }
+    }
+    c = block_best<TIE_SMALLER_AUX>(c, s_cand);
+    __syncthreads();
+    const double count = block_reduce<0>((i < m && a != 0.0) ? 1.0 : 0.0, s_red);
+    if (threadIdx.x == 0) {
+        lp.k2_partd[4 * blockIdx.x + 2] = c.key;
+        lp.k2_parti[4 * blockIdx.x] = c.idx;
+        lp.k2_parti[4 * blockIdx.x + 1] = c.aux;
+        lp.k2_parti[4 * blockIdx.x + 2] = (int)count;
+        if (blockIdx.x == 0) ctl->gamma_q = gamma_q;
+    }
+}
+
+__global__ void __launch_bounds__(256) k2l_decide_kernel(DeviceLP lp, int n_blocks) {
+    __shared__ Cand s_cand[8];
+    __shared__ int s_i[4];
+    __shared__ double s_d[4];
+    __shared__ int s_scan[256];
+    __shared__ int s_total;
+    Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING || ctl->q < 0) return;
+    const int q = ctl->q;
+    const int forced_p = ctl->forced_p;
+    const bool bounded = lp.ub != nullptr;
+    int p = forced_p;
+    if (forced_p < 0) {
+        Cand c;
+        c.key = 0.0;
+        c.idx = -1;
+        c.aux = 0;
+        for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+            Cand o;
+            o.idx = lp.k2_parti[4 * b];
+            o.key = lp.k2_partd[4 * b + 2];
+            o.aux = lp.k2_parti[4 * b + 1];
+            c = better<TIE_SMALLER_AUX>(c, o);
+        }
+        c = block_best<TIE_SMALLER_AUX>(c, s_cand);
+        p = c.idx;
+    }
+    {   // offsets of the per-workgroup pieces of the touched-row list (exclusive prefix of the counts, 256 at a time)
+        int carry = 0;
+        for (int b0 = 0; b0 < n_blocks; b0 += 256) {
+            const int b = b0 + threadIdx.x;
+            const int count = b < n_blocks ? lp.k2_parti[4 * b + 2] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] = count;
+            __syncthreads();
+            for (int step = 1; step < 256; step <<= 1) {
+                const int add = threadIdx.x >= step ? s_scan[threadIdx.x - step] : 0;
+                __syncthreads();
+                s_scan[threadIdx.x] += add;
+                __syncthreads();
+            }
+            if (b < n_blocks) lp.k2_parti[4 * b + 3] = carry + s_scan[threadIdx.x] - count;
+            carry += s_scan[255];
+        }
+        if (threadIdx.x == 0) s_total = carry;
+    }
+    if (threadIdx.x == 0) {
+        const double ub_q = bounded ? lp.ub[q] : INFINITY;
+        const double cbar_q = ctl->cbar_q;
+        const double alpha_pq = p >= 0 ? lp.alpha[p] : 1.0;
+        const double xb_p = p >= 0 ? lp.xB[p] : 0.0;
+        const double up_p = (bounded && p >= 0) ? lp.xub[p] : INFINITY;
+        const bool leaves_at_upper = bounded && forced_p < 0 && p >= 0 && alpha_pq < 0.0;
+        const double xp = (forced_p >= 0 || !bounded) ? fmax(xb_p, 0.0) / alpha_pq
+                                                      : (leaves_at_upper ? fmax(up_p - xb_p, 0.0) : fmax(xb_p, 0.0)) / fabs(alpha_pq);
+        const bool flip = bounded && forced_p < 0 && ub_q < INFINITY && (p < 0 || ub_q <= xp);
+        int action = 0, toggle = -1;
+        double toggle_amount = 0.0;
+        if (p < 0 && !flip) {
+            ctl->status = ST_UNBOUNDED;
+            ctl->p = -1;
+            ctl->pending = 0;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+        } else if (flip) {
+            const int was = lp.flipped[q];
+            toggle = q;
+            toggle_amount = ub_q * (was ? -1.0 : 1.0);  // rhs -= ub * (signed column)
+            lp.flipped[q] = was ^ 1;
+            lp.pos[q] = (was ^ 1) ? -2 : -1;
+            ctl->flip_cost += ((was ^ 1) ? 1.0 : -1.0) * ub_q * lp.cost[q];
+            ctl->p = -1;
+            ctl->xp = ub_q;
+            ctl->minus_obj -= cbar_q * ub_q;
+            ctl->iters += 1;
+            ctl->bound_flips += 1;
+            ctl->pending = 0;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+            ctl->last_selected = q;
+            action = 2;
+        } else {
+            const int leaving = lp.basis[p];
+            lp.basis[p] = q;
+            if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[p]) {
+                const int count = ctl->touched_count;
+                lp.touched[p] = 1;
+                lp.tlist[count] = p;
+                ctl->touched_count = count + 1;
+            }
+            lp.pos[q] = p;
+            if (bounded) {
+                int fl = lp.flipped[leaving];
+                if (leaves_at_upper) {
+                    toggle = leaving;
+                    toggle_amount = up_p * (fl ? -1.0 : 1.0);
+                    fl ^= 1;
+                    lp.flipped[leaving] = fl;
+                    ctl->flip_cost += (fl ? 1.0 : -1.0) * up_p * lp.cost[leaving];
+                }
+                lp.pos[leaving] = fl ? -2 : -1;
+                lp.xub[p] = ub_q;
+            } else {
+                lp.pos[leaving] = -1;
+            }
+            const int running = s_total;
+            ctl->p = p;
+            ctl->leaving = leaving;
+            ctl->alpha_pq = alpha_pq;
+            ctl->xp = xp;
+            ctl->nz_count = running;
+            ctl->minus_obj -= cbar_q * xp;
+            ctl->iters += 1;
+            ctl->pending = 1;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+            ctl->last_selected = q;
+            action = 1;
+        }
+        ctl->k2_action = action;
+        s_i[0] = toggle;
+        s_d[0] = toggle_amount;
+    }
+    __syncthreads();
+    const int toggle = s_i[0];
+    if (toggle >= 0) {  // the complemented column moves u_j a_j to the right-hand side
+        const double amount = s_d[0];
+        for (int e = lp.col_start[toggle] + threadIdx.x; e < lp.col_start[toggle + 1]; e += blockDim.x)
+            lp.rhs[lp.row_index[e]] -= amount * lp.value[e];
+    }
+}
+
+__global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp) {
+    __shared__ int s_count[K2L_THREADS / WAVE + 1];
+    Ctl* ctl = lp.ctl;
+    const int action = ctl->k2_action;
+    if (action == 0) return;
+    const int m = lp.m;
+    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
+    const double a = i < m ? lp.alpha[i] : 0.0;
+    const double xp = ctl->xp;
+    if (action == 2) {
+        if (i < m) lp.xB[i] -= a * xp;
+        return;
+    }
+    const int p = ctl->p;
+    const bool keep = i < m && a != 0.0;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) s_count[wave] = __popcll(mask);
+    __syncthreads();
+    int base = lp.k2_parti[4 * blockIdx.x + 3];
+    for (int wv = 0; wv < wave; ++wv) base += s_count[wv];
+    if (keep) {
+        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        lp.nz_index[slot] = i;
+        lp.nz_alpha[slot] = a;
+    }
+    if (i < m) lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2, register-resident variant for m <= R*K2F_THREADS (the common case).  Same contract as ftran_ratio_kernel, but
 // the dependent chain of global-memory round trips (~1.2 k cycles each when the data was produced by the previous
 // kernel on another XCD) is cut to four: {control word, candidates, own x_B/basis rows} -> {column extent} ->
@@ -1916,7 +2244,12 @@ __global__ void __launch_bounds__(256) pi_kernel(DeviceLP lp) {
     const int m = lp.m, ld = lp.ld;
     const int lane = threadIdx.x & (WAVE - 1);
     const int j = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    if (j < m) {
+    if (j < m && lp.track_touched && lp.eta_cap == 0 && !lp.touched[j]) {  // stored column j is still the unit vector e_j
+        if (lane == LAST) {
+            const int bj = lp.basis[j];
+            lp.minus_pi[j] = (lp.flipped && lp.flipped[bj]) ? lp.cost[bj] : -lp.cost[bj];
+        }
+    } else if (j < m) {
         const double* col = lp.Binv + (size_t)j * ld;
         double acc = 0.0;
         for (int i = lane; i < m; i += WAVE) {
@@ -2257,13 +2590,15 @@ void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop) {
         }                                                                                                    \
     } while (0)
 constexpr int PRICE_LPC = 8;  // lanes per sparse column in the pricing kernel
-int price_columns_per_block() { return 256 / PRICE_LPC; }
+int price_columns_per_block(int ell_w) { return 256 / ell_w; }
 
 template <int RULE>
 static void launch_price_rule(const DeviceLP& d, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
                               int first, int last, int cand_offset, hipStream_t s) {
     const bool timed_elsewhere = d.n_dense > 0;  // with a dense block the dense kernel is the one that is timed
-    if (use_lds)
+    if (d.ell_w == 2)  // graph LPs: two entries per column, 128 columns per workgroup pass (large m: vectors gathered from L2)
+        RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, false, 2>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
+    else if (use_lds)
         RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, true, PRICE_LPC>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol, first, last, cand_offset);
     else
         RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, false, PRICE_LPC>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
@@ -2313,7 +2648,13 @@ static void launch_ftran_ratio_rule(const DeviceLP& d, int n_price_blocks, doubl
         RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 8>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
     else if (fits && d.m <= 16 * K2F_THREADS)
         RELP_LAUNCH(1, (ftran_ratio_fast_kernel<RULE, 16>), dim3(1), dim3(K2F_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices);
-    else
+    else if (mode == 0 && d.k2_partd != nullptr) {
+        const int blocks = (d.m + K2L_THREADS - 1) / K2L_THREADS;
+        RELP_LAUNCH(1, (k2l_ftran_kernel<RULE>), dim3(blocks), dim3(K2L_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+        hipLaunchKernelGGL(k2l_harris_kernel, dim3(blocks), dim3(K2L_THREADS), 0, s, d, blocks, tol_pivot, skip_artificial_rows);
+        hipLaunchKernelGGL(k2l_decide_kernel, dim3(1), dim3(256), 0, s, d, blocks);
+        hipLaunchKernelGGL(k2l_apply_kernel, dim3(blocks), dim3(K2L_THREADS), 0, s, d);
+    } else
         RELP_LAUNCH(1, (ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
 }
 

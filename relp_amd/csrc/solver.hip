@@ -22,7 +22,7 @@ void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, i
 bool fast_k2_available(const DeviceLP& d, int n_price_blocks);
 void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop);
 void configure_lds(size_t price_lds);
-int price_columns_per_block();
+int price_columns_per_block(int ell_w);
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
                         int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s);
 void launch_update(const DeviceLP& d, hipStream_t s);
@@ -93,7 +93,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -185,8 +185,14 @@ void Solver::upload() {
     d_.dense_first = n_art;
     d_.dense_ld = (m + 3) & ~3;
     sparse_first_ = n_art + n_dense;
-    const int cpb = price_columns_per_block();
-    price_blocks_ = std::min(1024, (n - sparse_first_ + cpb - 1) / cpb);
+    price_lds_ = (size_t)3 * m * sizeof(double);
+    {   // graph LPs (at most two entries per column) beyond the LDS-resident size: width-2 padded copy, 4x less padding to stream
+        int longest = 0;
+        for (int j = 0; j < n; ++j) longest = std::max(longest, col_start[j + 1] - col_start[j]);
+        d_.ell_w = (longest <= 2 && n_dense == 0 && price_lds_ > 160 * 1024 - 1024 && !getenv("RELP_ELL_WIDE")) ? 2 : ELL_W;
+    }
+    const int cpb = price_columns_per_block(d_.ell_w);
+    price_blocks_ = std::min(d_.ell_w == 2 ? 2048 : 1024, (n - sparse_first_ + cpb - 1) / cpb);
     dense_blocks_ = n_dense > 0 ? std::min(getenv("RELP_DENSE_BLOCKS") ? atoi(getenv("RELP_DENSE_BLOCKS")) : 256, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one workgroup per CU (96 KB of LDS each)
     if (price_blocks_ + dense_blocks_ == 0) price_blocks_ = 1;
     price_lds_ = (size_t)3 * m * sizeof(double);
@@ -226,13 +232,16 @@ void Solver::upload() {
     d_.cand_rows = dmalloc<int>((size_t)(price_blocks_ + dense_blocks_) * ELL_W);
     d_.cand_vals = dmalloc<double>((size_t)(price_blocks_ + dense_blocks_) * ELL_W);
     d_.cand_len = dmalloc<int>(price_blocks_ + dense_blocks_);
+    RELP_HIP(hipMemsetAsync(d_.cand_rows, 0, (size_t)(price_blocks_ + dense_blocks_) * ELL_W * sizeof(int), stream_));  // width-2 pricing writes two of the ELL_W slots
+    RELP_HIP(hipMemsetAsync(d_.cand_vals, 0, (size_t)(price_blocks_ + dense_blocks_) * ELL_W * sizeof(double), stream_));
     {
-        std::vector<int> er((size_t)n * ELL_W, 0);
-        std::vector<double> ev((size_t)n * ELL_W, 0.0);
+        const int width = d_.ell_w;
+        std::vector<int> er((size_t)n * width, 0);
+        std::vector<double> ev((size_t)n * width, 0.0);
         for (int j = 0; j < n; ++j)
-            for (int e = col_start[j], k = 0; e < col_start[j + 1] && k < ELL_W; ++e, ++k) {
-                er[(size_t)j * ELL_W + k] = row_index[e];
-                ev[(size_t)j * ELL_W + k] = value[e];
+            for (int e = col_start[j], k = 0; e < col_start[j + 1] && k < width; ++e, ++k) {
+                er[(size_t)j * width + k] = row_index[e];
+                ev[(size_t)j * width + k] = value[e];
             }
         d_.ell_rows = dmalloc<int>(er.size());
         d_.ell_vals = dmalloc<double>(ev.size());
@@ -291,6 +300,10 @@ void Solver::upload() {
         d_.flipped = dmalloc<int>(n);
         upload_vec(d_.ub, ub, stream_);
         RELP_HIP(hipStreamSynchronize(stream_));
+    }
+    if (!fast_k2_available(d_, price_blocks_ + dense_blocks_) && !getenv("RELP_K2_SINGLE")) {  // m > 8192: multi-workgroup ratio test
+        d_.k2_partd = dmalloc<double>((size_t)4 * ((m + 1023) / 1024));
+        d_.k2_parti = dmalloc<int>((size_t)4 * ((m + 1023) / 1024));
     }
     d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 2 + 16);
     d_.ctl = dmalloc<Ctl>(1);
@@ -502,7 +515,9 @@ void Solver::polish(bool refresh_vectors) {
             max_residual_ = std::max(max_residual_, c.residual);
             // the drift seen after this many pivots schedules the next polish: far below the working accuracy -> wait
             // twice as long (up to 16 periods), close to it -> back to the configured period
-            if (c.residual < 1e-8) polish_scale_ = std::min(16, polish_scale_ * 2);
+            // (an inverse that is still EXACT, as on totally unimodular bases, has not drifted at all: four times as long, up to 256)
+            if (c.residual == 0.0) polish_scale_ = std::min(256, polish_scale_ * 4);
+            else if (c.residual < 1e-8) polish_scale_ = std::min(std::max(16, polish_scale_), polish_scale_ * 2);
             else if (c.residual > 1e-6) polish_scale_ = 1;
         }
         if (c.residual < 1e-12) break;  // nothing to correct: skip the second GEMM

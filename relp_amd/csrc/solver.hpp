@@ -40,6 +40,7 @@ struct Ctl {
     int touched_count; // columns of the stored inverse that are not unit vectors any more (entries of DeviceLP::tlist)
     double flip_cost;  // implicit bounds: sum of ub_j c_j over the complemented variables (current phase's costs)
     long long bound_flips;  // iterations that moved the entering variable to its other bound without a basis change
+    int k2_action;     // multi-workgroup ratio test: what the decision kernel chose this iteration (0 nothing | 1 pivot | 2 bound flip)
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
@@ -103,6 +104,7 @@ struct DeviceLP {
     double* cand_vals = nullptr;
     int* cand_len = nullptr;     // nnz of that column (> ELL_W: the rest comes from the CSC)
     // padded copy of the first ELL_W entries of every column (value 0 padding): no col_start dependency in K1
+    int ell_w = ELL_W;           // padded width in use: 2 when no column has more than two entries and m is large, else ELL_W
     int* ell_rows = nullptr;
     double* ell_vals = nullptr;
     // Implicit upper bounds (relp_options.implicit_bounds): the `VariableBound` / `SlackBound` rows of `MatrixData`
@@ -113,6 +115,8 @@ struct DeviceLP {
     double* xub = nullptr;       // [m] upper bound of the variable that is basic in row i
     int* flipped = nullptr;      // [n] 1: the column is held in complemented form
     double* rhs0 = nullptr;      // [m] right-hand side of the file (rhs holds b minus the complemented columns' u_j a_j)
+    double* k2_partd = nullptr;  // multi-workgroup ratio test (m > 8192): per-workgroup partial sums / minima / candidate keys
+    int* k2_parti = nullptr;     //   ... candidate rows, their basic columns, non-zero counts and list offsets
     double* scratch = nullptr;   // m or n doubles for the fine-grained ops
     Ctl* ctl = nullptr;
     unsigned long long* dbg = nullptr;  // diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of K2
