@@ -2186,9 +2186,9 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
             for (int u = 0; u < U; ++u) {
                 w0 += a[u] * o0[u];
                 w1 += a[u] * o1[u];
-                if (idx[u] >= 0) {
-                    c0[idx[u]] = (idx[u] == p) ? r0 : o0[u] - a[u] * r0;
-                    if (two) c1[idx[u]] = (idx[u] == p) ? r1 : o1[u] - a[u] * r1;
+                if (idx[u] >= 0) {  // r == 0: column j has no entry in row p and does not change (sparse inverses: most columns)
+                    if (r0 != 0.0) c0[idx[u]] = (idx[u] == p) ? r0 : o0[u] - a[u] * r0;
+                    if (two && r1 != 0.0) c1[idx[u]] = (idx[u] == p) ? r1 : o1[u] - a[u] * r1;
                 }
             }
         }
