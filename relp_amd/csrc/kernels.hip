@@ -1336,15 +1336,17 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
 // ---------------------------------------------------------------------------------------------------
 // K2 for large m (beyond the register-resident kernel): the same steps spread over ceil(m / 1024) workgroups.  One
 // workgroup sustains ~60 GB/s, and the entering-column / ratio-test step moves ~8 MB at m = 65 534 (150 us in
-// ftran_ratio_kernel); four short kernels exchange per-workgroup partials instead:
+// ftran_ratio_kernel); three short kernels exchange per-workgroup partials instead:
 //   k2l_ftran   entering column (every workgroup reduces the candidates itself), alpha for its rows, partial
 //               |alpha|^2 and Harris pass-1 minimum
 //   k2l_harris  fold the partials, Harris pass 2 on its rows -> per-workgroup candidate, count of non-zero alpha
-//   k2l_decide  ONE workgroup: pivot row, step length, bound flip or pivot, all O(1) bookkeeping, list offsets
-//   k2l_apply   x_B update and the ordered list of touched rows for K3
+//   k2l_apply   every workgroup takes the decision (pivot row, step length, bound flip or pivot) from those candidates,
+//               updates x_B on its rows and writes its piece of the ordered list of touched rows for K3;
+//               workgroup 0 does the O(1) bookkeeping
 // Same rules and tie-breaks as ftran_ratio_kernel (mode 0 only; the fine-grained operations keep that kernel).
 // ---------------------------------------------------------------------------------------------------
 constexpr int K2L_THREADS = 1024;
+constexpr int K2L_PD = 8;  // doubles per workgroup in k2_partd: |alpha|^2 sum, pass-1 minimum, candidate key, its alpha, x_B, upper bound
 template <int RULE>
 __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int n_price_blocks, double tol_pivot,
                                                               double harris_delta, int skip_artificial_rows) {
@@ -1357,7 +1359,6 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING) return;
     const bool publisher = blockIdx.x == 0 && threadIdx.x == 0;
-    if (publisher) ctl->k2_action = 0;
     if (ctl->iters >= ctl->budget) {
         if (publisher) {
             ctl->status = ST_BUDGET;
@@ -1444,8 +1445,8 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
     __syncthreads();
     theta = block_reduce<1>(theta, s_red);
     if (threadIdx.x == 0) {
-        lp.k2_partd[4 * blockIdx.x] = sumsq;
-        lp.k2_partd[4 * blockIdx.x + 1] = theta;
+        lp.k2_partd[K2L_PD * blockIdx.x] = sumsq;
+        lp.k2_partd[K2L_PD * blockIdx.x + 1] = theta;
     }
 }
 
@@ -1457,113 +1458,141 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_harris_kernel(DeviceLP lp, in
     const int m = lp.m;
     double v1 = 0.0, v2 = INFINITY;
     for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {  // fixed order: deterministic
-        v1 += lp.k2_partd[4 * b];
-        v2 = fmin(v2, lp.k2_partd[4 * b + 1]);
+        v1 += lp.k2_partd[K2L_PD * b];
+        v2 = fmin(v2, lp.k2_partd[K2L_PD * b + 1]);
     }
     const double gamma_q = 1.0 + block_reduce<0>(v1, s_red);
     __syncthreads();
     const double theta_max = block_reduce<1>(v2, s_red);
     __syncthreads();
     const bool bounded = lp.ub != nullptr;
+    const int forced_p = ctl->forced_p;
     const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
     const double a = i < m ? lp.alpha[i] : 0.0;
+    const double xb = i < m ? lp.xB[i] : 0.0;
+    const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
+    const int bas = i < m ? lp.basis[i] : 0;
     Cand c;
     c.key = 0.0;
     c.idx = -1;
     c.aux = 0;
-    if (i < m && ctl->forced_p < 0) {
-        const int bas = lp.basis[i];
-        if (!(skip_artificial_rows && bas < lp.n_art)) {
-            double room = -1.0;
-            if (a > tol_pivot) room = fmax(lp.xB[i], 0.0);
-            else if (bounded && a < -tol_pivot && lp.xub[i] < INFINITY) room = fmax(lp.xub[i] - lp.xB[i], 0.0);
-            if (room >= 0.0 && room / fabs(a) <= theta_max) {
-                c.key = fabs(a);
-                c.idx = i;
-                c.aux = bas;
-            }
+    if (forced_p >= 0) {  // Carry::bring_into_basis with a given row: that row is the only candidate
+        if (i == forced_p) {
+            c.key = 1.0;
+            c.idx = i;
+            c.aux = bas;
+        }
+    } else if (i < m && !(skip_artificial_rows && bas < lp.n_art)) {
+        double room = -1.0;
+        if (a > tol_pivot) room = fmax(xb, 0.0);
+        else if (bounded && a < -tol_pivot && up < INFINITY) room = fmax(up - xb, 0.0);
+        if (room >= 0.0 && room / fabs(a) <= theta_max) {
+            c.key = fabs(a);
+            c.idx = i;
+            c.aux = bas;
         }
     }
     c = block_best<TIE_SMALLER_AUX>(c, s_cand);
     __syncthreads();
     const double count = block_reduce<0>((i < m && a != 0.0) ? 1.0 : 0.0, s_red);
+    if (c.idx >= 0 && c.idx == i) {  // the row that won brings everything the decision needs
+        lp.k2_partd[K2L_PD * blockIdx.x + 2] = c.key;
+        lp.k2_partd[K2L_PD * blockIdx.x + 3] = a;
+        lp.k2_partd[K2L_PD * blockIdx.x + 4] = xb;
+        lp.k2_partd[K2L_PD * blockIdx.x + 5] = up;
+    }
     if (threadIdx.x == 0) {
-        lp.k2_partd[4 * blockIdx.x + 2] = c.key;
         lp.k2_parti[4 * blockIdx.x] = c.idx;
         lp.k2_parti[4 * blockIdx.x + 1] = c.aux;
         lp.k2_parti[4 * blockIdx.x + 2] = (int)count;
-        if (blockIdx.x == 0) ctl->gamma_q = gamma_q;
+        if (blockIdx.x == 0) {
+            ctl->gamma_q = gamma_q;
+            ctl->k2_forced = forced_p >= 0 ? 1 : 0;  // k2l_apply resets forced_p while other workgroups still decide
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) k2l_decide_kernel(DeviceLP lp, int n_blocks) {
-    __shared__ Cand s_cand[8];
-    __shared__ int s_i[4];
-    __shared__ double s_d[4];
-    __shared__ int s_scan[256];
-    __shared__ int s_total;
+// Every workgroup takes the same decision from the per-workgroup candidates (no row data is read again, so the x_B
+// writes of one workgroup cannot be seen by another's decision); workgroup 0 alone does the bookkeeping.
+__global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp, int n_blocks) {
+    __shared__ Cand s_cand[18];
+    __shared__ double s_red[18];
+    __shared__ int s_count[K2L_THREADS / WAVE + 1];
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING || ctl->q < 0) return;
+    if (ctl->status != ST_RUNNING) return;  // (workgroup 0 may set UNBOUNDED below: the others then have nothing to apply either)
     const int q = ctl->q;
-    const int forced_p = ctl->forced_p;
+    if (q < 0) return;
+    const bool forced = ctl->k2_forced != 0;
     const bool bounded = lp.ub != nullptr;
-    int p = forced_p;
-    if (forced_p < 0) {
-        Cand c;
-        c.key = 0.0;
-        c.idx = -1;
-        c.aux = 0;
-        for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
-            Cand o;
-            o.idx = lp.k2_parti[4 * b];
-            o.key = lp.k2_partd[4 * b + 2];
-            o.aux = lp.k2_parti[4 * b + 1];
-            c = better<TIE_SMALLER_AUX>(c, o);
-        }
-        c = block_best<TIE_SMALLER_AUX>(c, s_cand);
-        p = c.idx;
+    const int m = lp.m;
+    Cand c;
+    c.key = 0.0;
+    c.idx = -1;
+    c.aux = 0;
+    double before = 0.0, all = 0.0;  // list entries of the workgroups ahead of this one / of all of them
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+        Cand o;
+        o.idx = lp.k2_parti[4 * b];
+        o.key = o.idx >= 0 ? lp.k2_partd[K2L_PD * b + 2] : 0.0;
+        o.aux = lp.k2_parti[4 * b + 1];  // the basic column of that row: ties go to the smaller one
+        const int count = lp.k2_parti[4 * b + 2];
+        all += count;
+        if (b < (int)blockIdx.x) before += count;
+        if (o.idx >= 0) c = better<TIE_SMALLER_AUX>(c, o);
     }
-    {   // offsets of the per-workgroup pieces of the touched-row list (exclusive prefix of the counts, 256 at a time)
-        int carry = 0;
-        for (int b0 = 0; b0 < n_blocks; b0 += 256) {
-            const int b = b0 + threadIdx.x;
-            const int count = b < n_blocks ? lp.k2_parti[4 * b + 2] : 0;
+    c = block_best<TIE_SMALLER_AUX>(c, s_cand);
+    __syncthreads();
+    const int offset = (int)block_reduce<0>(before, s_red);
+    __syncthreads();
+    const int total = (int)block_reduce<0>(all, s_red);
+    const int p = c.idx;
+    const int wb = p >= 0 ? p / K2L_THREADS : 0;  // the workgroup that owns row p published its data
+    const double alpha_pq = p >= 0 ? lp.k2_partd[K2L_PD * wb + 3] : 1.0;
+    const double xb_p = p >= 0 ? lp.k2_partd[K2L_PD * wb + 4] : 0.0;
+    const double up_p = p >= 0 ? lp.k2_partd[K2L_PD * wb + 5] : INFINITY;
+    const int leaving = c.aux;
+    const double ub_q = bounded ? lp.ub[q] : INFINITY;
+    const bool leaves_at_upper = bounded && !forced && p >= 0 && alpha_pq < 0.0;
+    const double xp = (forced || !bounded) ? fmax(xb_p, 0.0) / alpha_pq
+                                           : (leaves_at_upper ? fmax(up_p - xb_p, 0.0) : fmax(xb_p, 0.0)) / fabs(alpha_pq);
+    const bool flip = bounded && !forced && ub_q < INFINITY && (p < 0 || ub_q <= xp);
+    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
+    if (p >= 0 || flip) {
+        const double a = i < m ? lp.alpha[i] : 0.0;
+        if (flip) {
+            if (i < m) lp.xB[i] -= a * ub_q;
+        } else {
+            const bool keep = i < m && a != 0.0;
+            const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) s_count[wave] = __popcll(mask);
             __syncthreads();
-            s_scan[threadIdx.x] = count;
-            __syncthreads();
-            for (int step = 1; step < 256; step <<= 1) {
-                const int add = threadIdx.x >= step ? s_scan[threadIdx.x - step] : 0;
-                __syncthreads();
-                s_scan[threadIdx.x] += add;
-                __syncthreads();
+            int base = offset;
+            for (int wv = 0; wv < wave; ++wv) base += s_count[wv];
+            if (keep) {
+                const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                lp.nz_index[slot] = i;
+                lp.nz_alpha[slot] = a;
             }
-            if (b < n_blocks) lp.k2_parti[4 * b + 3] = carry + s_scan[threadIdx.x] - count;
-            carry += s_scan[255];
+            if (i < m) lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
         }
-        if (threadIdx.x == 0) s_total = carry;
     }
+    if (blockIdx.x != 0) return;
+    // ---- bookkeeping (workgroup 0): same statements as the tail of ftran_ratio_kernel ----------------------------
+    __shared__ int s_toggle;
+    __shared__ double s_amount;
     if (threadIdx.x == 0) {
-        const double ub_q = bounded ? lp.ub[q] : INFINITY;
         const double cbar_q = ctl->cbar_q;
-        const double alpha_pq = p >= 0 ? lp.alpha[p] : 1.0;
-        const double xb_p = p >= 0 ? lp.xB[p] : 0.0;
-        const double up_p = (bounded && p >= 0) ? lp.xub[p] : INFINITY;
-        const bool leaves_at_upper = bounded && forced_p < 0 && p >= 0 && alpha_pq < 0.0;
-        const double xp = (forced_p >= 0 || !bounded) ? fmax(xb_p, 0.0) / alpha_pq
-                                                      : (leaves_at_upper ? fmax(up_p - xb_p, 0.0) : fmax(xb_p, 0.0)) / fabs(alpha_pq);
-        const bool flip = bounded && forced_p < 0 && ub_q < INFINITY && (p < 0 || ub_q <= xp);
-        int action = 0, toggle = -1;
-        double toggle_amount = 0.0;
+        int toggle = -1;
+        double amount = 0.0;
         if (p < 0 && !flip) {
             ctl->status = ST_UNBOUNDED;
             ctl->p = -1;
             ctl->pending = 0;
-            ctl->forced_q = -1;
-            ctl->forced_p = -1;
         } else if (flip) {
             const int was = lp.flipped[q];
             toggle = q;
-            toggle_amount = ub_q * (was ? -1.0 : 1.0);  // rhs -= ub * (signed column)
+            amount = ub_q * (was ? -1.0 : 1.0);  // rhs -= ub * (signed column)
             lp.flipped[q] = was ^ 1;
             lp.pos[q] = (was ^ 1) ? -2 : -1;
             ctl->flip_cost += ((was ^ 1) ? 1.0 : -1.0) * ub_q * lp.cost[q];
@@ -1573,14 +1602,10 @@ __global__ void __launch_bounds__(256) k2l_decide_kernel(DeviceLP lp, int n_bloc
             ctl->iters += 1;
             ctl->bound_flips += 1;
             ctl->pending = 0;
-            ctl->forced_q = -1;
-            ctl->forced_p = -1;
             ctl->last_selected = q;
-            action = 2;
         } else {
-            const int leaving = lp.basis[p];
             lp.basis[p] = q;
-            if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[p]) {
+            if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[p]) {  // column p of the inverse stops being a unit vector
                 const int count = ctl->touched_count;
                 lp.touched[p] = 1;
                 lp.tlist[count] = p;
@@ -1591,7 +1616,7 @@ __global__ void __launch_bounds__(256) k2l_decide_kernel(DeviceLP lp, int n_bloc
                 int fl = lp.flipped[leaving];
                 if (leaves_at_upper) {
                     toggle = leaving;
-                    toggle_amount = up_p * (fl ? -1.0 : 1.0);
+                    amount = up_p * (fl ? -1.0 : 1.0);
                     fl ^= 1;
                     lp.flipped[leaving] = fl;
                     ctl->flip_cost += (fl ? 1.0 : -1.0) * up_p * lp.cost[leaving];
@@ -1601,60 +1626,28 @@ __global__ void __launch_bounds__(256) k2l_decide_kernel(DeviceLP lp, int n_bloc
             } else {
                 lp.pos[leaving] = -1;
             }
-            const int running = s_total;
             ctl->p = p;
             ctl->leaving = leaving;
             ctl->alpha_pq = alpha_pq;
             ctl->xp = xp;
-            ctl->nz_count = running;
+            ctl->nz_count = total;
             ctl->minus_obj -= cbar_q * xp;
             ctl->iters += 1;
             ctl->pending = 1;
-            ctl->forced_q = -1;
-            ctl->forced_p = -1;
             ctl->last_selected = q;
-            action = 1;
         }
-        ctl->k2_action = action;
-        s_i[0] = toggle;
-        s_d[0] = toggle_amount;
+        ctl->forced_q = -1;
+        ctl->forced_p = -1;
+        s_toggle = toggle;
+        s_amount = amount;
     }
     __syncthreads();
-    const int toggle = s_i[0];
+    const int toggle = s_toggle;
     if (toggle >= 0) {  // the complemented column moves u_j a_j to the right-hand side
-        const double amount = s_d[0];
+        const double amount = s_amount;
         for (int e = lp.col_start[toggle] + threadIdx.x; e < lp.col_start[toggle + 1]; e += blockDim.x)
             lp.rhs[lp.row_index[e]] -= amount * lp.value[e];
     }
-}
-
-__global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp) {
-    __shared__ int s_count[K2L_THREADS / WAVE + 1];
-    Ctl* ctl = lp.ctl;
-    const int action = ctl->k2_action;
-    if (action == 0) return;
-    const int m = lp.m;
-    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
-    const double a = i < m ? lp.alpha[i] : 0.0;
-    const double xp = ctl->xp;
-    if (action == 2) {
-        if (i < m) lp.xB[i] -= a * xp;
-        return;
-    }
-    const int p = ctl->p;
-    const bool keep = i < m && a != 0.0;
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    const unsigned long long mask = __ballot(keep);
-    if (lane == 0) s_count[wave] = __popcll(mask);
-    __syncthreads();
-    int base = lp.k2_parti[4 * blockIdx.x + 3];
-    for (int wv = 0; wv < wave; ++wv) base += s_count[wv];
-    if (keep) {
-        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-        lp.nz_index[slot] = i;
-        lp.nz_alpha[slot] = a;
-    }
-    if (i < m) lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2652,8 +2645,7 @@ static void launch_ftran_ratio_rule(const DeviceLP& d, int n_price_blocks, doubl
         const int blocks = (d.m + K2L_THREADS - 1) / K2L_THREADS;
         RELP_LAUNCH(1, (k2l_ftran_kernel<RULE>), dim3(blocks), dim3(K2L_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
         hipLaunchKernelGGL(k2l_harris_kernel, dim3(blocks), dim3(K2L_THREADS), 0, s, d, blocks, tol_pivot, skip_artificial_rows);
-        hipLaunchKernelGGL(k2l_decide_kernel, dim3(1), dim3(256), 0, s, d, blocks);
-        hipLaunchKernelGGL(k2l_apply_kernel, dim3(blocks), dim3(K2L_THREADS), 0, s, d);
+        hipLaunchKernelGGL(k2l_apply_kernel, dim3(blocks), dim3(K2L_THREADS), 0, s, d, blocks);
     } else
         RELP_LAUNCH(1, (ftran_ratio_kernel<RULE>), dim3(1), dim3(K2_THREADS), 0, s, d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode);
 }

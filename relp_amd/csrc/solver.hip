@@ -302,7 +302,7 @@ void Solver::upload() {
         RELP_HIP(hipStreamSynchronize(stream_));
     }
     if (!fast_k2_available(d_, price_blocks_ + dense_blocks_) && !getenv("RELP_K2_SINGLE")) {  // m > 8192: multi-workgroup ratio test
-        d_.k2_partd = dmalloc<double>((size_t)4 * ((m + 1023) / 1024));
+        d_.k2_partd = dmalloc<double>((size_t)8 * ((m + 1023) / 1024));
         d_.k2_parti = dmalloc<int>((size_t)4 * ((m + 1023) / 1024));
     }
     d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 2 + 16);

@@ -40,7 +40,7 @@ struct Ctl {
     int touched_count; // columns of the stored inverse that are not unit vectors any more (entries of DeviceLP::tlist)
     double flip_cost;  // implicit bounds: sum of ub_j c_j over the complemented variables (current phase's costs)
     long long bound_flips;  // iterations that moved the entering variable to its other bound without a basis change
-    int k2_action;     // multi-workgroup ratio test: what the decision kernel chose this iteration (0 nothing | 1 pivot | 2 bound flip)
+    int k2_forced;     // multi-workgroup ratio test: the pivot row of this iteration was given by the caller
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
