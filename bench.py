@@ -362,7 +362,7 @@ def main():
         }
         if graph:
             line["metric"] = "simplex pivots/sec + wall-clock to optimal, max-flow LP @1 GPU"
-            line["roofline"]["note"] = "pricing pass over the arc columns (two padded entries per column; six 8-byte gathers of -pi, rho, w per column from L2 bound it, not the 48 B/column HBM stream)"
+            line["roofline"]["note"] = "pricing pass over the arc columns (two padded entries per column; per entry one 32-byte gather of the packed (-pi, rho, w) row from L2 beside the 48 B/column HBM stream)"
         elif not dense:
             line["roofline"]["note"] = ("latency bound by construction: one pricing launch streams %d KB that live in L2 (SURVEY.md "
                                         "section 8(d)); the HBM-roofline configuration is BASELINE configs[2], measured below") % (bytes_per_launch // 1024)

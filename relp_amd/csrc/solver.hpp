@@ -106,6 +106,7 @@ struct DeviceLP {
     // padded copy of the first ELL_W entries of every column (value 0 padding): no col_start dependency in K1
     int ell_w = ELL_W;           // padded width in use: 2 when no column has more than two entries and m is large, else ELL_W
     int* ell_rows = nullptr;
+    double* prw = nullptr;       // ell_w == 2: (-pi_r, rho_r, w_r, 0) packed per row, kept beside the three vectors by their writers
     double* ell_vals = nullptr;
     // Implicit upper bounds (relp_options.implicit_bounds): the `VariableBound` / `SlackBound` rows of `MatrixData`
     // (matrix_data.rs:104-112: x_j + s = u_j) are not rows of the device LP; a variable at its upper bound is held in
