@@ -2118,6 +2118,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
 // ---------------------------------------------------------------------------------------------------
 constexpr int K3_THREADS = 256;
 constexpr int K3_CPW = 2;  // columns per wave
+constexpr int K3_SMALL_NZ = 32;  // alpha with at most this many non-zeros: eight lanes per column (large sparse LPs)
 // EAGER: alpha and both columns are loaded in the same memory round trip, unconditionally (m small: the kernel is
 // latency bound, the extra reads of rows with alpha_i == 0 hit L2); otherwise the column loads are predicated on
 // alpha_i != 0 (m large: HBM bound, untouched rows cost no traffic).
@@ -2145,6 +2146,54 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
                 }
             }
         const int n_touched = ctl->touched_count;
+        const int nz_small = ctl->nz_count;
+        if (nz_small > 0 && nz_small <= K3_SMALL_NZ) {
+            // Short alpha (network bases: a path): EIGHT lanes per column, eight columns per wave, every entry of the list in
+            // flight at once.  With one wave per two columns 95 % of the lanes idle and the pass is a queue of waves that each
+            // wait on three dependent round trips (config 5: 19.6 us on average for ~32 k touched columns).
+            const int slot = (blockIdx.x * (K3_THREADS / WAVE) + wave) * 8 + (lane >> 3);
+            if ((slot & ~7) >= n_touched) return;  // wave-uniform
+            const bool active = slot < n_touched;
+            const int sub = lane & 7;
+            const int j = lp.tlist[active ? slot : 0];
+            double* c = lp.Binv + (size_t)j * ld;
+            const int p = ctl->p;
+            const double alpha_pq = ctl->alpha_pq;
+            const double cbar_q = ctl->cbar_q;
+            const double pi_old = sub == 0 ? lp.minus_pi[j] : 0.0;
+            int idx[K3_SMALL_NZ / 8];
+            double a[K3_SMALL_NZ / 8], o[K3_SMALL_NZ / 8];
+#pragma unroll
+            for (int u = 0; u < K3_SMALL_NZ / 8; ++u) {
+                const int e = u * 8 + sub;
+                idx[u] = e < nz_small ? lp.nz_index[e] : -1;
+                a[u] = e < nz_small ? lp.nz_alpha[e] : 0.0;
+            }
+            const double r = c[p] / alpha_pq;
+#pragma unroll
+            for (int u = 0; u < K3_SMALL_NZ / 8; ++u) o[u] = idx[u] >= 0 ? c[idx[u]] : 0.0;
+            double w = 0.0;
+#pragma unroll
+            for (int u = 0; u < K3_SMALL_NZ / 8; ++u) {
+                w += a[u] * o[u];
+                if (active && idx[u] >= 0 && r != 0.0) c[idx[u]] = (idx[u] == p) ? r : o[u] - a[u] * r;
+            }
+            w += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, w);
+            w += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, w);
+            w += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, w);
+            if (active && sub == 0) {
+                const double pi_new = pi_old - cbar_q * r;
+                lp.w[j] = w;
+                lp.rho[j] = r;
+                lp.minus_pi[j] = pi_new;
+                if (lp.prw) {
+                    lp.prw[(size_t)4 * j] = pi_new;
+                    lp.prw[(size_t)4 * j + 1] = r;
+                    lp.prw[(size_t)4 * j + 2] = w;
+                }
+            }
+            return;
+        }
         if (slot0 >= n_touched) return;
         two = slot0 + 1 < n_touched;
         j0 = lp.tlist[slot0];
