@@ -1368,7 +1368,7 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
                                                               double harris_delta, int skip_artificial_rows) {
     __shared__ Cand s_cand[18];
     __shared__ double s_red[18];
-    __shared__ int s_q;
+    __shared__ int s_q, s_inline;
     __shared__ double s_cbar;
     __shared__ int s_rows[K2_COL_CHUNK];
     __shared__ double s_vals[K2_COL_CHUNK];
@@ -1400,8 +1400,10 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
         if (threadIdx.x == 0) {
             s_q = c.idx;
             s_cbar = c.idx >= 0 ? lp.cand_cbar[c.aux] : 0.0;
+            s_inline = (c.idx >= 0 && lp.cand_len[c.aux] >= 0 && lp.cand_len[c.aux] <= ELL_W) ? c.aux : -1;
         }
     } else if (threadIdx.x == 0) {
+        s_inline = -1;
         s_q = forced_q;
         double cb = lp.cost[forced_q];
         for (int e = lp.col_start[forced_q]; e < lp.col_start[forced_q + 1]; ++e) cb += lp.value[e] * lp.minus_pi[lp.row_index[e]];
@@ -1427,7 +1429,22 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
     const int bas = i < m ? lp.basis[i] : 0;
     const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
     double acc = 0.0;
-    const int ca = lp.col_start[q], cb_ = lp.col_start[q + 1];
+    const int inline_block = s_inline;
+    if (inline_block >= 0) {
+        // the winning pricing workgroup published the column's padded entries: no col_start -> row_index -> value chain
+        int rows[ELL_W];
+        double vals[ELL_W], t[ELL_W];
+#pragma unroll
+        for (int e = 0; e < ELL_W; ++e) {
+            rows[e] = lp.cand_rows[(size_t)inline_block * ELL_W + e];
+            vals[e] = lp.cand_vals[(size_t)inline_block * ELL_W + e];
+        }
+#pragma unroll
+        for (int e = 0; e < ELL_W; ++e) t[e] = (i < m && vals[e] != 0.0) ? lp.Binv[(size_t)rows[e] * ld + i] : 0.0;
+#pragma unroll
+        for (int e = 0; e < ELL_W; ++e) acc += t[e] * vals[e];
+    }
+    const int ca = inline_block >= 0 ? 0 : lp.col_start[q], cb_ = inline_block >= 0 ? 0 : lp.col_start[q + 1];
     for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
         const int cnt = min(K2_COL_CHUNK, cb_ - c0);
         __syncthreads();
@@ -1472,6 +1489,14 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_harris_kernel(DeviceLP lp, in
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING || ctl->q < 0) return;
     const int m = lp.m;
+    // this thread's row first: those loads are in flight while the partials are folded
+    const bool bounded = lp.ub != nullptr;
+    const int forced_p = ctl->forced_p;
+    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
+    const double a = i < m ? lp.alpha[i] : 0.0;
+    const double xb = i < m ? lp.xB[i] : 0.0;
+    const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
+    const int bas = i < m ? lp.basis[i] : 0;
     double v1 = 0.0, v2 = INFINITY;
     for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {  // fixed order: deterministic
         v1 += lp.k2_partd[K2L_PD * b];
@@ -1481,13 +1506,6 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_harris_kernel(DeviceLP lp, in
     __syncthreads();
     const double theta_max = block_reduce<1>(v2, s_red);
     __syncthreads();
-    const bool bounded = lp.ub != nullptr;
-    const int forced_p = ctl->forced_p;
-    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
-    const double a = i < m ? lp.alpha[i] : 0.0;
-    const double xb = i < m ? lp.xB[i] : 0.0;
-    const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
-    const int bas = i < m ? lp.basis[i] : 0;
     Cand c;
     c.key = 0.0;
     c.idx = -1;
@@ -1541,6 +1559,9 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp, int
     const bool forced = ctl->k2_forced != 0;
     const bool bounded = lp.ub != nullptr;
     const int m = lp.m;
+    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
+    const double a = i < m ? lp.alpha[i] : 0.0;  // in flight while the decision is taken
+    const double xb_i = i < m ? lp.xB[i] : 0.0;
     Cand c;
     c.key = 0.0;
     c.idx = -1;
@@ -1572,11 +1593,9 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp, int
     const double xp = (forced || !bounded) ? fmax(xb_p, 0.0) / alpha_pq
                                            : (leaves_at_upper ? fmax(up_p - xb_p, 0.0) : fmax(xb_p, 0.0)) / fabs(alpha_pq);
     const bool flip = bounded && !forced && ub_q < INFINITY && (p < 0 || ub_q <= xp);
-    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
     if (p >= 0 || flip) {
-        const double a = i < m ? lp.alpha[i] : 0.0;
         if (flip) {
-            if (i < m) lp.xB[i] -= a * ub_q;
+            if (i < m) lp.xB[i] = xb_i - a * ub_q;
         } else {
             const bool keep = i < m && a != 0.0;
             const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
@@ -1590,7 +1609,7 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp, int
                 lp.nz_index[slot] = i;
                 lp.nz_alpha[slot] = a;
             }
-            if (i < m) lp.xB[i] = (i == p) ? xp : lp.xB[i] - a * xp;
+            if (i < m) lp.xB[i] = (i == p) ? xp : xb_i - a * xp;
         }
     }
     if (blockIdx.x != 0) return;
