@@ -328,7 +328,7 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r1_%s_pmc_traffic.json" % args.workload)
         if os.path.exists(pmc):
-            wanted = "price_dense_kernel" if dense else "relp::price_kernel<0, true, 8>"
+            wanted = "price_dense_kernel" if dense else "relp::price_kernel<"
             for name, entry in json.load(open(pmc)).items():
                 if wanted in name:
                     traffic = entry["hbm_bytes_corrected"]
@@ -364,8 +364,11 @@ def main():
             line["metric"] = "simplex pivots/sec + wall-clock to optimal, max-flow LP @1 GPU"
             line["roofline"]["note"] = "pricing pass over the arc columns (two padded entries per column; per entry one 32-byte gather of the packed (-pi, rho, w) row from L2 beside the 48 B/column HBM stream)"
         elif not dense:
-            line["roofline"]["note"] = ("latency bound by construction: one pricing launch streams %d KB that live in L2 (SURVEY.md "
-                                        "section 8(d)); the HBM-roofline configuration is BASELINE configs[2], measured below") % (bytes_per_launch // 1024)
+            line["roofline"]["note"] = ("latency bound by construction: one pricing launch streams %d KB that live in L2 / Infinity Cache "
+                                        "(SURVEY.md section 8(d)); traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes: the "
+                                        "kernel reads the columns from their 8-entry padded copy (230 KB) and the x2 correction for wide "
+                                        "streams over-counts these short gathers; the HBM-roofline configuration is BASELINE configs[2], "
+                                        "measured below") % (bytes_per_launch // 1024)
             if world == 1 and not args.no_dense_roofline:
                 line["roofline_config3"] = dense_roofline(local_rank)
         if not args.no_cpu_baseline and not graph:
