@@ -202,6 +202,16 @@ bool rational_reconstruct(const BigInt& a, const BigInt& M, BigInt& n, BigInt& d
     return true;
 }
 
+// bits [lo, lo + count) of |v|, count <= 60
+u64 extract_bits(const BigInt& v, size_t lo, int count) {
+    unsigned __int128 window = 0;
+    const size_t word = lo / 32;
+    for (int k = 0; k < 4; ++k)
+        if (word + k < v.mag.size()) window |= (unsigned __int128)v.mag[word + k] << (32 * k);
+    window >>= (lo % 32);
+    return (u64)(window & (((unsigned __int128)1 << count) - 1));
+}
+
 struct IntegerBasis {          // row-scaled integer basis, both orientations
     int m = 0;
     std::vector<int> col_start, row_index;   // CSC (columns = basis positions)
@@ -341,7 +351,8 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
     const int m = md.nr_rows();
     const int n_p = md.nr_columns();
 
-    // ---- integer scaling: row multipliers (lcm of the denominators of the row, rhs included), cost multiplier ----
+    // ---- integer scaling: row multipliers (lcm of the denominators of the row's coefficients), cost multiplier; the
+    //      right-hand side keeps its own common denominator and any width (presolve leaves ~100-bit values there) ----
     std::vector<SparseColumn> columns(n_p);
     for (int j = 0; j < n_p; ++j) columns[j] = md.column(j);
     std::vector<Rat> rhs = md.right_hand_side();
@@ -349,7 +360,6 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
     try {
         for (int j = 0; j < n_p; ++j)
             for (size_t e = 0; e < columns[j].nnz(); ++e) row_mult[columns[j].index[e]] = lcm128(row_mult[columns[j].index[e]], columns[j].value[e].d);
-        for (int i = 0; i < m; ++i) row_mult[i] = lcm128(row_mult[i], rhs[i].d);
     } catch (const RatOverflow&) {
         *message = "row scaling overflows 128 bits";
         return;
@@ -368,11 +378,20 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         for (int i = 0; i < m; ++i)
             if (!has[i]) artificial_rows.push_back(i);
     }
-    std::vector<i64> rhs_int(m);
-    for (int i = 0; i < m; ++i) {
-        i128 v = scaled(rhs[i], row_mult[i]);
-        if (!fits(v)) { *message = "scaled right-hand side does not fit 62 bits"; return; }
-        rhs_int[i] = (i64)v;
+    // b_i * row_mult_i = rhs_big[i] / rhs_den  (exact, arbitrary width)
+    std::vector<BigInt> rhs_big(m);
+    BigInt rhs_den(1);
+    {
+        std::vector<BigInt> numer(m);
+        std::vector<i128> denom(m);
+        for (int i = 0; i < m; ++i) {
+            const i128 g = gcd128(row_mult[i], rhs[i].d);
+            numer[i] = big_from_i128(rhs[i].n) * big_from_i128(row_mult[i] / g);
+            denom[i] = rhs[i].d / g;
+            const BigInt d = big_from_i128(denom[i]);
+            rhs_den = rhs_den / BigInt::gcd(rhs_den, d) * d;
+        }
+        for (int i = 0; i < m; ++i) rhs_big[i] = numer[i] * (rhs_den / big_from_i128(denom[i]));
     }
     std::vector<int> basis = basis_columns;  // repaired in place by exact pivots when a check fails
     const int max_repairs = 200;
@@ -460,8 +479,35 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         };
 
         // ---- exact primal and dual solutions ------------------------------------------------------------
+        // B x = rhs_big: one lifting when every entry fits the 62-bit residual path, else one per 60-bit limb of the
+        // right-hand side (the solve is linear; every partial solution is verified exactly, and so is their sum)
+        auto solve_wide = [&](const std::vector<BigInt>& r, ExactVector* out) {
+            size_t widest = 0;
+            for (const BigInt& v : r) widest = std::max(widest, v.bits());
+            const int limbs = std::max<int>(1, (int)((widest + 59) / 60));
+            out->numer.assign(m, BigInt(0));
+            out->denom = BigInt(1);
+            BigInt scale(1);
+            const BigInt step = big_from_i128((i128)1 << 60);
+            for (int k = 0; k < limbs; ++k) {
+                std::vector<i64> limb(m);
+                for (int i = 0; i < m; ++i) {
+                    const i64 v = (i64)extract_bits(r[i], (size_t)60 * k, 60);
+                    limb[i] = r[i].sign() < 0 ? -v : v;
+                }
+                ExactVector part;
+                if (!solve(limb, 0, &part)) return false;
+                const BigInt g = BigInt::gcd(out->denom, part.denom);
+                const BigInt grow = part.denom / g, part_factor = (out->denom / g) * scale;
+                for (int i = 0; i < m; ++i) out->numer[i] = out->numer[i] * grow + part.numer[i] * part_factor;
+                out->denom = out->denom * grow;
+                scale = scale * step;
+            }
+            return true;
+        };
         ExactVector x, y;
-        if (!solve(rhs_int, 0, &x)) return;
+        if (!solve_wide(rhs_big, &x)) return;
+        x.denom = x.denom * rhs_den;  // x_B = numer / (denom * rhs_den); all sign checks below only need denom > 0
         if (!solve(cost_basis, 1, &y)) return;  // B' y = c_B: the rows of B' are the columns of B
 
         // ---- checks ---------------------------------------------------------------------------------------
