@@ -210,3 +210,37 @@ def test_gpu_max_flow_131k_arcs_with_implicit_bounds():
     np.subtract.at(net, tail, flow)
     assert np.max(np.abs(net[1:-1])) <= 1e-7
     assert abs(-net[0] - expected) <= 1e-7 and abs(net[-1] - expected) <= 1e-7
+
+
+@pytest.mark.gpu
+def test_gpu_shortest_path_12k_vertices_matches_dijkstra():
+    """V = 12 000, E ~ 60 000 (one conservation row per vertex but the target, no bounds: the ratio test across workgroups
+    without the bounded-variable rules): the LP optimum equals scipy's Dijkstra distance and the solution is a unit s-t flow."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices = 12000
+    tail, head, weight = max_flow_graph(nr_vertices, 60000)
+    keep = tail != head
+    tail, head, weight = tail[keep], head[keep], weight[keep]
+    # parallel arcs: scipy's csr constructor would add their weights, the LP takes the cheapest
+    order = np.lexsort((weight, head, tail))
+    tail, head, weight = tail[order], head[order], weight[order]
+    first = np.ones(len(tail), dtype=bool)
+    first[1:] = (tail[1:] != tail[:-1]) | (head[1:] != head[:-1])
+    tail, head, weight = tail[first], head[first], weight[first]
+    graph = csr_matrix((weight.astype(np.float64), (tail, head)), shape=(nr_vertices, nr_vertices))
+    expected = dijkstra(graph, directed=True, indices=0)[nr_vertices - 1]
+    assert np.isfinite(expected)
+    model = relp_amd.Model.shortest_path(nr_vertices, list(zip(tail.tolist(), head.tolist(), weight.tolist())), 0, nr_vertices - 1)
+    solver = relp_amd.Solver().load_model(model)
+    assert solver.m > 8192
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert abs(result.objective - expected) <= 1e-9 * max(1.0, abs(expected))
+    flow = solver.solution()
+    net = np.zeros(nr_vertices)
+    np.add.at(net, head, flow)
+    np.subtract.at(net, tail, flow)
+    assert abs(net[0] + 1.0) <= 1e-7 and abs(net[-1] - 1.0) <= 1e-7 and np.max(np.abs(net[1:-1])) <= 1e-7
+    solver.close()
