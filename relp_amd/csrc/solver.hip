@@ -730,6 +730,8 @@ void Solver::solve(relp_result* result) {
     RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, m * sizeof(int), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipMemcpyAsync(xb.data(), d_.xB, m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     Ctl c = read_ctl();
+    for (int i = 0; i < m; ++i)  // never index host arrays with an unchecked device value
+        if (basis[i] < 0 || basis[i] >= d_.n) throw std::runtime_error("the device returned an invalid basis (row " + std::to_string(i) + ")");
     std::fill(h_solution_.begin(), h_solution_.end(), 0.0);
     if (!bounded_) {
         for (int i = 0; i < m; ++i) {
