@@ -2442,7 +2442,7 @@ __global__ void __launch_bounds__(256) residual_kernel(DeviceLP lp, const double
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         double acc = (i == k) ? 1.0 : 0.0;
         for (int e = a; e < b; ++e) acc -= sgn * lp.value[e] * T[(size_t)lp.row_index[e] * ld + i];
-        S[(size_t)k * ld + i] = acc;
+        if (S) S[(size_t)k * ld + i] = acc;  // S == nullptr: only the norm is wanted (polish of an inverse that may be exact)
         local_max = fmax(local_max, fabs(acc));
     }
     const double blk = -block_reduce<1>(-local_max, s_red);  // max via min of negatives

@@ -118,6 +118,14 @@ void Solver::load(StandardForm&& form) {
 // and makes the pricing pass one uniform CSC sweep.
 void Solver::upload() {
     const MatrixData& md = form_.data;
+    const bool timing = getenv("RELP_TIME_UPLOAD") != nullptr;  // diagnostic: where the one-off load time goes
+    double t_last = now_seconds();
+    auto tick = [&](const char* what) {
+        if (!timing) return;
+        const double t = now_seconds();
+        fprintf(stderr, "[upload] %-28s %.3f s\n", what, t - t_last);
+        t_last = t;
+    };
     // Implicit upper bounds: the device LP has the constraint rows only (E | R | <= | >=) and the provider columns of the
     // first four groups (structurals, range slacks, <= slacks, >= slacks); the VariableBound / SlackBound rows and their
     // slack columns (matrix_data.rs:104-145) become upper bounds of the structurals and the range slacks.
@@ -151,6 +159,7 @@ void Solver::upload() {
         }
         col_start[n_art + j + 1] = (int)row_index.size();
     }
+    tick("columns -> CSC");
     const size_t nnz = row_index.size();
     std::vector<int> row_start(m + 1, 0), col_index(nnz);
     std::vector<double> row_value(nnz);
@@ -171,6 +180,7 @@ void Solver::upload() {
     auto rhs_exact = md.right_hand_side();
     for (int i = 0; i < m; ++i) rhs[i] = rhs_exact[i].to_double();
 
+    tick("CSR, costs, rhs");
     d_.m = m;
     d_.n = n;
     d_.n_art = n_art;
@@ -218,9 +228,12 @@ void Solver::upload() {
     d_.basis = dmalloc<int>(m);
     d_.pos = dmalloc<int>(n);
     d_.gamma = dmalloc<double>(n);
+    tick("sparse arrays");
     d_.Binv = dmalloc<double>((size_t)m * d_.ld);
-    d_.Binv2 = dmalloc<double>((size_t)m * d_.ld);
-    d_.R = dmalloc<double>((size_t)m * d_.ld);
+    // The second copy of the inverse and the residual matrix are only needed once a polish finds something to correct
+    // (Solver::ensure_polish_buffers): at m = 65 534 each is 34 GB and about a second of hipMalloc, and the max-flow LP of
+    // config 5, whose bases are unimodular, never needs them.
+    tick("inverse buffers (hipMalloc)");
     d_.alpha = dmalloc<double>(m);
     d_.rho = dmalloc<double>(m);
     d_.nz_index = dmalloc<int>(m);
@@ -330,6 +343,7 @@ void Solver::upload() {
     RELP_HIP(hipMemsetAsync(d_.gamma, 0, n * sizeof(double), stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
     configure_lds(std::min<size_t>(price_lds_, 160 * 1024 - 1024));
+    tick("uploads");
 
     stats_.price_bytes = (long long)(col_start[n] - col_start[sparse_first_]) * 12 + (long long)(n - n_art) * 24 +
                          (long long)n_dense * m * dense_entry_bytes_;  // upper bound: every dense column non-basic
@@ -508,12 +522,20 @@ void Solver::polish(bool refresh_vectors) {
     const int* rows = by_rows ? d_.tlist : nullptr;
     int n_rows = m;
     if (by_rows) n_rows = read_ctl().touched_count;
+    if (d_.n_dense > 0) ensure_polish_buffers();  // the dense residual is a GEMM into R through Binv2
     for (int it = 0; it < 2; ++it) {
         RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
-        if (by_rows) RELP_HIP(hipMemsetAsync(d_.R, 0, (size_t)m * d_.ld * sizeof(double), stream_));
+        if (by_rows && d_.R) RELP_HIP(hipMemsetAsync(d_.R, 0, (size_t)m * d_.ld * sizeof(double), stream_));
         if (d_.n_dense > 0) launch_residual_dense(d_, d_.Binv2, d_.Binv, d_.R, rows, n_rows, stream_);
-        else launch_residual(d_, d_.Binv, d_.R, stream_);
+        else launch_residual(d_, d_.Binv, d_.R, stream_);  // R == nullptr: norm only
         Ctl c = read_ctl();  // max |I - B' T|
+        if (d_.R == nullptr && c.residual >= 1e-12 && c.residual < 0.5) {  // something to correct: now S itself is needed
+            ensure_polish_buffers();
+            if (by_rows) RELP_HIP(hipMemsetAsync(d_.R, 0, (size_t)m * d_.ld * sizeof(double), stream_));
+            RELP_HIP(hipMemsetAsync(&d_.ctl->residual, 0, sizeof(double), stream_));
+            launch_residual(d_, d_.Binv, d_.R, stream_);
+            c = read_ctl();
+        }
         if (!(c.residual == c.residual)) throw std::runtime_error("NaN in basis inverse");
         if (it == 0) {
             max_residual_ = std::max(max_residual_, c.residual);
@@ -549,8 +571,14 @@ void Solver::polish(bool refresh_vectors) {
 
 // From-scratch inverse by Newton-Schulz from X0 = B' / (|B|_1 |B|_inf) (converges for every nonsingular B).
 // Plays the role of `BasisInverse::invert` (lower_upper/mod.rs:78-92) for `from_basis` / warm starts.
+void Solver::ensure_polish_buffers() {
+    if (d_.Binv2 == nullptr) d_.Binv2 = dmalloc<double>((size_t)d_.m * d_.ld);
+    if (d_.R == nullptr) d_.R = dmalloc<double>((size_t)d_.m * d_.ld);
+}
+
 void Solver::invert_from_scratch() {
     const int m = d_.m;
+    ensure_polish_buffers();
     std::vector<int> basis(m);
     RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, m * sizeof(int), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
