@@ -105,6 +105,22 @@ int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model**
  * unbounded or solves it completely (message in `error`). */
 int32_t relp_model_from_mps_ex(const char* path, int32_t fixed_format, int32_t presolve, relp_model** out, char* error,
                                int32_t error_capacity);
+/* The provider of a caller that builds the general form itself: `GeneralForm::new` (general_form/mod.rs:211-237) followed by
+ * [`presolve` :335-463 ->] `standardize` (:325-332: split free variables, flip and shift to x >= 0 :506-587, b >= 0 :592-618,
+ * minimise :623-633, rows ordered E | R | <= | >= :651-717) -> `derive_matrix_data` (:262-304).
+ *   columns: CSC with ascending row indices and no explicit zeros, exact rationals value_num/value_den;
+ *   row_kind[i]: 0 Equal, 1 Range (b_i - range_i <= a_i x <= b_i, range_i >= 0), 2 Less, 3 Greater
+ *                (`RangedConstraintRelation`, data/linear_program/elements.rs); range_* is read for Range rows only;
+ *   variable j: cost, optional lower / upper bound (`Variable`, general_form/mod.rs:140-165; shift 0, not flipped);
+ *   variables are named X0, X1, ... ; relp_get_original_solution returns their values in this order. */
+int32_t relp_model_from_general_form(int32_t maximize, int32_t nr_rows, int32_t nr_columns, const int64_t* column_start,
+                                     const int32_t* row_index, const int64_t* value_num, const int64_t* value_den,
+                                     const int32_t* row_kind, const int64_t* range_num, const int64_t* range_den,
+                                     const int64_t* b_num, const int64_t* b_den, const int64_t* cost_num, const int64_t* cost_den,
+                                     const uint8_t* has_lower, const int64_t* lower_num, const int64_t* lower_den,
+                                     const uint8_t* has_upper, const int64_t* upper_num, const int64_t* upper_den,
+                                     int64_t fixed_cost_num, int64_t fixed_cost_den, int32_t presolve, relp_model** out,
+                                     char* error, int32_t error_capacity);
 /* Number of variables of the file and how many of them the presolve removed (0 without presolve). */
 int32_t relp_model_original_variables(const relp_model* model, int32_t* nr_original, int32_t* nr_removed);
 /* Graph providers (reference: examples/max_flow.rs:31-223 `Primal::new` + its MatrixProvider; examples/shortest_path.rs:20-118;

@@ -49,7 +49,7 @@ _lib = None
 
 # every symbol include/relp_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_from_mps_ex", "relp_model_original_variables", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
+    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_from_mps_ex", "relp_model_from_general_form", "relp_model_original_variables", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
     "relp_model_column", "relp_model_column_exact", "relp_model_cost", "relp_model_right_hand_side",
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
     "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_mps_ex", "relp_get_original_solution", "relp_load_model", "relp_get_dimensions", "relp_get_column",
@@ -146,6 +146,68 @@ class Model:
     def shortest_path(cls, nr_vertices, arcs, s, t):
         """The provider of examples/shortest_path.rs (`Primal::new`); value = arc length."""
         return cls._from_graph("relp_model_shortest_path", nr_vertices, arcs, s, t)
+
+    @classmethod
+    def from_general_form(cls, columns, constraint_types, b, variables, maximize=False, fixed_cost=0, presolve=False):
+        """``GeneralForm::new`` (general_form/mod.rs:211-237) + [presolve +] ``standardize`` + ``derive_matrix_data``.
+
+        ``columns``: per variable a list of ``(row, value)`` with ascending rows; ``constraint_types``: per row ``"Equal"``,
+        ``"Less"``, ``"Greater"`` or ``("Range", r)``; ``variables``: per variable ``(cost, lower, upper)`` with ``None`` for a
+        missing bound.  Numbers: int, ``Fraction`` or ``(num, den)``."""
+        from fractions import Fraction
+
+        def pair(v):
+            f = Fraction(*v) if isinstance(v, tuple) else Fraction(v)
+            return f.numerator, f.denominator
+        kinds = {"Equal": 0, "Range": 1, "Less": 2, "Greater": 3}
+        n, m = len(columns), len(b)
+        start = np.zeros(n + 1, dtype=np.int64)
+        rows, v_num, v_den = [], [], []
+        for j, column in enumerate(columns):
+            for i, value in column:
+                rows.append(i)
+                a, d = pair(value)
+                v_num.append(a)
+                v_den.append(d)
+            start[j + 1] = len(rows)
+        arrays = {
+            "rows": np.array(rows or [0], dtype=np.int32), "v_num": np.array(v_num or [0], dtype=np.int64),
+            "v_den": np.array(v_den or [1], dtype=np.int64),
+            "kind": np.array([kinds[k[0] if isinstance(k, tuple) else k] for k in constraint_types], dtype=np.int32),
+            "r_num": np.zeros(m, dtype=np.int64), "r_den": np.ones(m, dtype=np.int64),
+            "b_num": np.zeros(m, dtype=np.int64), "b_den": np.ones(m, dtype=np.int64),
+            "c_num": np.zeros(n, dtype=np.int64), "c_den": np.ones(n, dtype=np.int64),
+            "has_l": np.zeros(n, dtype=np.uint8), "l_num": np.zeros(n, dtype=np.int64), "l_den": np.ones(n, dtype=np.int64),
+            "has_u": np.zeros(n, dtype=np.uint8), "u_num": np.zeros(n, dtype=np.int64), "u_den": np.ones(n, dtype=np.int64),
+        }
+        for i, kind in enumerate(constraint_types):
+            if isinstance(kind, tuple):
+                arrays["r_num"][i], arrays["r_den"][i] = pair(kind[1])
+            arrays["b_num"][i], arrays["b_den"][i] = pair(b[i])
+        for j, (cost, lower, upper) in enumerate(variables):
+            arrays["c_num"][j], arrays["c_den"][j] = pair(cost)
+            if lower is not None:
+                arrays["has_l"][j] = 1
+                arrays["l_num"][j], arrays["l_den"][j] = pair(lower)
+            if upper is not None:
+                arrays["has_u"][j] = 1
+                arrays["u_num"][j], arrays["u_den"][j] = pair(upper)
+        f_num, f_den = pair(fixed_cost)
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        error = C.create_string_buffer(512)
+        a = arrays
+        status = lib().relp_model_from_general_form(
+            int(bool(maximize)), m, n, _ptr(start, C.c_int64), _ptr(a["rows"], C.c_int32), _ptr(a["v_num"], C.c_int64),
+            _ptr(a["v_den"], C.c_int64), _ptr(a["kind"], C.c_int32), _ptr(a["r_num"], C.c_int64), _ptr(a["r_den"], C.c_int64),
+            _ptr(a["b_num"], C.c_int64), _ptr(a["b_den"], C.c_int64), _ptr(a["c_num"], C.c_int64), _ptr(a["c_den"], C.c_int64),
+            _ptr(a["has_l"], C.c_uint8), _ptr(a["l_num"], C.c_int64), _ptr(a["l_den"], C.c_int64),
+            _ptr(a["has_u"], C.c_uint8), _ptr(a["u_num"], C.c_int64), _ptr(a["u_den"], C.c_int64),
+            C.c_int64(f_num), C.c_int64(f_den), int(bool(presolve)), C.byref(self._h), error, 512)
+        if status != OK:
+            raise RelpError(status, error.value.decode())
+        self._read_dimensions()
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -1,6 +1,7 @@
 // extern "C" boundary (include/relp_amd.h).  Plain pointers and sizes only; exceptions are mapped to status codes.
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <new>
 #include <sstream>
 
@@ -96,6 +97,77 @@ int32_t relp_model_from_mps_ex(const char* path, int32_t fixed_format, int32_t p
         return fail(e.what(), RELP_ERR_STATE);
     } catch (const PresolveUnbounded& e) {
         return fail(e.what(), RELP_ERR_STATE);
+    } catch (const std::exception& e) {
+        return fail(e.what(), RELP_ERR_PARSE);
+    }
+}
+int32_t relp_model_from_general_form(int32_t maximize, int32_t nr_rows, int32_t nr_columns, const int64_t* column_start,
+                                     const int32_t* row_index, const int64_t* value_num, const int64_t* value_den,
+                                     const int32_t* row_kind, const int64_t* range_num, const int64_t* range_den,
+                                     const int64_t* b_num, const int64_t* b_den, const int64_t* cost_num, const int64_t* cost_den,
+                                     const uint8_t* has_lower, const int64_t* lower_num, const int64_t* lower_den,
+                                     const uint8_t* has_upper, const int64_t* upper_num, const int64_t* upper_den,
+                                     int64_t fixed_cost_num, int64_t fixed_cost_den, int32_t presolve, relp_model** out,
+                                     char* error, int32_t error_capacity) {
+    if (!out) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    auto fail = [&](const std::string& what, int32_t code) {
+        if (error && error_capacity > 0) {
+            std::strncpy(error, what.c_str(), error_capacity - 1);
+            error[error_capacity - 1] = 0;
+        }
+        return code;
+    };
+    if (nr_rows < 1 || nr_columns < 1 || !column_start || !row_kind || !b_num || !b_den || !cost_num || !cost_den || !has_lower ||
+        !has_upper || fixed_cost_den == 0)
+        return fail("general form: missing array or empty problem", RELP_ERR_ARGUMENT);
+    try {
+        auto rational = [](int64_t n, int64_t d) {
+            if (d == 0) throw std::invalid_argument("general form: zero denominator");
+            return Rat((i128)n, (i128)d);
+        };
+        GeneralInput general;
+        general.maximize = maximize != 0;
+        general.fixed_cost = rational(fixed_cost_num, fixed_cost_den);
+        for (int32_t j = 0; j < nr_columns; ++j) {
+            GeneralVariable v;
+            v.cost = rational(cost_num[j], cost_den[j]);
+            v.has_lower = has_lower[j] != 0;
+            v.has_upper = has_upper[j] != 0;
+            if (v.has_lower) v.lower = rational(lower_num[j], lower_den[j]);
+            if (v.has_upper) v.upper = rational(upper_num[j], upper_den[j]);
+            if (v.has_lower && v.has_upper && v.lower > v.upper) throw std::invalid_argument("general form: lower bound above upper bound");
+            general.variables.push_back(v);
+            SparseColumn column;
+            if (column_start[j] > column_start[j + 1]) throw std::invalid_argument("general form: column_start must not decrease");
+            for (int64_t e = column_start[j]; e < column_start[j + 1]; ++e) column.push(row_index[e], rational(value_num[e], value_den[e]));
+            general.columns.push_back(column);
+            general.column_names.push_back("X" + std::to_string(j));
+        }
+        for (int32_t i = 0; i < nr_rows; ++i) {
+            if (row_kind[i] < 0 || row_kind[i] > 3) throw std::invalid_argument("general form: unknown row kind");
+            general.kind.push_back((RowKind)row_kind[i]);
+            Rat r(0);
+            if (row_kind[i] == RANGE) {
+                if (!range_num || !range_den) throw std::invalid_argument("general form: range rows without ranges");
+                r = rational(range_num[i], range_den[i]);
+                if (r.sign() < 0) throw std::invalid_argument("general form: negative range");
+            }
+            general.range.push_back(r);
+            general.b.push_back(rational(b_num[i], b_den[i]));
+        }
+        std::unique_ptr<relp_model> model(new relp_model());
+        model->form = standardize_general_form(std::move(general), presolve != 0);
+        *out = model.release();
+        return RELP_OK;
+    } catch (const RatOverflow& e) {
+        return fail(e.what(), RELP_ERR_OVERFLOW);
+    } catch (const PresolveInfeasible& e) {
+        return fail(e.what(), RELP_ERR_STATE);
+    } catch (const PresolveUnbounded& e) {
+        return fail(e.what(), RELP_ERR_STATE);
+    } catch (const std::invalid_argument& e) {
+        return fail(e.what(), RELP_ERR_ARGUMENT);
     } catch (const std::exception& e) {
         return fail(e.what(), RELP_ERR_PARSE);
     }

@@ -6,8 +6,9 @@
 //   io/mps/convert.rs:29-394           bounds (GLPK-like UP rule :211-216), ranges, rhs -> GeneralForm
 //   general_form/mod.rs:325-332        standardize(): split free, flip/shift to x>=0, b>=0, minimise, E|R|L|G order
 //   general_form/mod.rs:262-304        derive_matrix_data()
-// The reference's presolve (general_form/presolve/**) is out of scope this round; both this code and the oracle
-// solve the un-presolved standard form, whose optimum is the same.
+//   general_form/mod.rs:335-463        presolve() (optional: presolve.hpp)
+// `standardize_general_form` is the part after the MPS conversion: it is also the entry for a caller that builds the
+// general form itself (GeneralForm::new, general_form/mod.rs:211-237; C ABI relp_model_from_general_form).
 #include <algorithm>
 #include <map>
 #include <sstream>
@@ -292,16 +293,45 @@ StandardForm load_mps(const std::string& text, bool fixed_format, bool presolve_
         }
     }
 
+    GeneralInput general;
+    general.name = raw.name;
+    general.maximize = raw.maximize;
+    general.variables = std::move(vars);
+    general.columns = std::move(raw.columns);
+    general.kind = std::move(kind);
+    general.range = std::move(range);
+    general.b = std::move(b);
+    general.column_names = std::move(raw.column_names);
+    return standardize_general_form(std::move(general), presolve_first);
+}
+
+StandardForm standardize_general_form(GeneralInput general, bool presolve_first) {
+    std::vector<GeneralVariable>& vars = general.variables;
+    std::vector<RowKind>& kind = general.kind;
+    std::vector<Rat>& range = general.range;
+    std::vector<Rat>& b = general.b;
+    int nr_rows = (int)b.size();
+    int n = (int)vars.size();
+    if ((int)general.columns.size() != n || (int)kind.size() != nr_rows || (int)range.size() != nr_rows ||
+        (int)general.column_names.size() != n)
+        throw std::runtime_error("general form: inconsistent dimensions");
+    for (const auto& column : general.columns)
+        for (size_t k = 0; k < column.nnz(); ++k) {
+            if (column.index[k] < 0 || column.index[k] >= nr_rows) throw std::runtime_error("general form: row index out of range");
+            if (k > 0 && column.index[k] <= column.index[k - 1]) throw std::runtime_error("general form: column entries must ascend by row");
+            if (column.value[k].is_zero()) throw std::runtime_error("general form: explicit zero in a sparse column");
+        }
     // ---- general_form/mod.rs:335-463 presolve (optional; the reference's harness applies it: tests/netlib/mod.rs:58) ----
     StandardForm out;
-    out.name = raw.name;
-    out.all_column_names = raw.column_names;
-    std::vector<SparseColumn> columns = raw.columns;
-    Rat fixed_cost(0);
+    out.name = general.name;
+    out.all_column_names = general.column_names;
+    std::vector<SparseColumn> columns = std::move(general.columns);
+    Rat fixed_cost = general.fixed_cost;
     {
         if (presolve_first) {
             GeneralProblem gp;  // arbitrary precision inside (presolve.hpp); back to 128-bit rationals afterwards
-            gp.maximize = raw.maximize;
+            gp.maximize = general.maximize;
+            gp.fixed_cost = Num(general.fixed_cost);
             for (int j = 0; j < n; ++j) {
                 PVariable v;
                 v.cost = Num(vars[j].cost);
@@ -365,7 +395,7 @@ StandardForm load_mps(const std::string& text, bool fixed_format, bool presolve_
     n = (int)vars.size();
     // ---- general_form/mod.rs:506-587 transform_variables ----------------------------------------
     out.nr_original = n;
-    for (int j = 0; j < n; ++j) out.column_names.push_back(raw.column_names[out.active_to_original[j]]);
+    for (int j = 0; j < n; ++j) out.column_names.push_back(out.all_column_names[out.active_to_original[j]]);
     out.free_negative_part.assign(n, -1);
     for (int j = 0; j < n; ++j) {
         if (!vars[j].has_lower && !vars[j].has_upper) {
@@ -415,7 +445,7 @@ StandardForm load_mps(const std::string& text, bool fixed_format, bool presolve_
         else b[i] = range[i] - b[i];
     }
     // ---- general_form/mod.rs:623-633 ----------------------------------------------------------------
-    if (raw.maximize)
+    if (general.maximize)
         for (auto& v : vars) v.cost = -v.cost;
     // ---- general_form/mod.rs:651-717 reorder_constraints_by_type (stable) ------------------------
     std::vector<int> order(nr_rows);

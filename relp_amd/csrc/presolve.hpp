@@ -30,6 +30,22 @@ struct GeneralVariable {
     bool flipped = false;
 };
 
+// GeneralForm::new (general_form/mod.rs:211-237): what a caller hands over before any transformation.  Columns are sparse
+// with ascending row indices and no explicit zeros; `range[i]` is read for RANGE rows only (b - range <= a x <= b).
+struct GeneralInput {
+    std::string name;
+    bool maximize = false;
+    std::vector<GeneralVariable> variables;
+    std::vector<SparseColumn> columns;
+    std::vector<RowKind> kind;
+    std::vector<Rat> range;
+    std::vector<Rat> b;
+    std::vector<std::string> column_names;
+    Rat fixed_cost;
+};
+// [presolve ->] standardize -> derive_matrix_data (general_form/mod.rs:335-463, 325-332, 262-304); defined in mps.cpp
+StandardForm standardize_general_form(GeneralInput general, bool presolve_first);
+
 // The presolve computes in arbitrary precision (bigrat.hpp): bound tightening leaves the 128-bit range on larger LPs.
 typedef BigRat Num;
 
