@@ -65,8 +65,10 @@ typedef struct relp_options {
     int32_t use_graph;         /* 1: replay the pivot loop from a hipGraph */
     int32_t verbose;
     int32_t implicit_bounds;   /* 1: variable upper bounds (MatrixData's VariableBound / SlackBound rows, matrix_data.rs:104-112)
-                                  are handled by the bounded-variable ratio test instead of as rows: same optimum, fewer rows
-                                  (the basis and the fine-grained trait operations then refer to the reduced LP) */
+                                  are handled by the bounded-variable ratio test instead of as rows: same optimum, fewer rows.
+                                  relp_get_basis / relp_set_basis keep speaking the reference's formulation (one column per
+                                  row of MatrixData, bound rows included); the other fine-grained trait operations refer to
+                                  the reduced LP */
 } relp_options;
 
 typedef struct relp_result {

@@ -592,6 +592,7 @@ void Solver::invert_from_scratch() {
         } else {
             SparseColumn c = md.column(basis[k] - d_.n_art);
             for (size_t e = 0; e < c.nnz(); ++e) {
+                if (c.index[e] >= m) continue;  // the bound-row entry of a bounded column (implicit bounds)
                 double v = std::fabs(c.value[e].to_double());
                 col_sum += v;
                 row_sum[c.index[e]] += v;
@@ -620,16 +621,80 @@ void Solver::invert_from_scratch() {
 // `InverseMaintainer::from_basis` (carry/mod.rs:444-478) + `Tableau::new_with_inverse_maintainer`: phase two from a given basis.
 void Solver::set_basis(const int* basis_columns) {
     if (!loaded_) throw std::runtime_error("no LP loaded");
-    if (bounded_) throw std::runtime_error("set_basis is not available with implicit_bounds (the device LP has fewer rows)");
     RELP_HIP(hipSetDevice(opt_.device));
     const int m = d_.m, n = d_.n;
     std::vector<int> basis(m), pos(n, -1);
-    for (int i = 0; i < m; ++i) {
-        int c = basis_columns[i];
-        int dev = c >= 0 ? d_.n_art + c : (-1 - c);
-        if (dev < 0 || dev >= n || pos[dev] >= 0) throw std::invalid_argument("bad basis");
-        basis[i] = dev;
-        pos[dev] = i;
+    if (!bounded_) {
+        for (int i = 0; i < m; ++i) {
+            int c = basis_columns[i];
+            int dev = c >= 0 ? d_.n_art + c : (-1 - c);
+            if (dev < 0 || dev >= n || pos[dev] >= 0) throw std::invalid_argument("bad basis");
+            basis[i] = dev;
+            pos[dev] = i;
+        }
+    } else {
+        // Implicit bounds: `basis_columns` is a basis of the reference's formulation (one column per row of MatrixData).  A
+        // bounded variable whose bound slack is NOT basic sits at its bound: non-basic and complemented on the device; with
+        // the slack basic it is basic here exactly when it is basic there.
+        const MatrixData& md = form_.data;
+        const int rows_full = md.nr_rows(), cols_full = md.nr_columns(), n_dev = md.col_end[3];
+        std::vector<int> row_of(cols_full, -1);
+        std::vector<int> artificial_row_of(d_.n_art, -1);
+        for (int i = 0; i < rows_full; ++i) {
+            const int c = basis_columns[i];
+            if (c >= 0) {
+                if (c >= cols_full || row_of[c] >= 0) throw std::invalid_argument("bad basis");
+                row_of[c] = i;
+            } else {
+                const int k = -1 - c;
+                if (k >= d_.n_art || artificial_row_of[k] >= 0) throw std::invalid_argument("bad basis");
+                artificial_row_of[k] = i;
+            }
+        }
+        std::vector<int> flipped(n, 0);
+        auto bound_pair = [&](int variable, int slack) {
+            if (row_of[slack] < 0) {
+                if (row_of[variable] < 0) throw std::invalid_argument("bad basis: neither a bounded variable nor its bound slack is basic");
+                flipped[d_.n_art + variable] = 1;  // at its upper bound
+                row_of[variable] = -2;             // not basic on the device
+            }
+        };
+        for (int k2 = 0; k2 < (int)md.bound_to_variable.size(); ++k2) bound_pair(md.bound_to_variable[k2], md.col_end[3] + k2);
+        for (int k2 = 0; k2 < md.nr_range; ++k2) bound_pair(md.col_end[0] + k2, md.col_end[4] + k2);
+        std::vector<int> device_basic;  // device column, preferred row
+        std::vector<int> wanted_row;
+        for (int k = 0; k < d_.n_art; ++k)
+            if (artificial_row_of[k] >= 0) { device_basic.push_back(k); wanted_row.push_back(artificial_row_of[k]); }
+        for (int c = 0; c < n_dev; ++c)
+            if (row_of[c] >= 0) { device_basic.push_back(d_.n_art + c); wanted_row.push_back(row_of[c]); }
+        if ((int)device_basic.size() != m) throw std::invalid_argument("bad basis: it does not reduce to a basis of the constraint rows");
+        std::fill(basis.begin(), basis.end(), -1);
+        std::vector<int> homeless;
+        for (size_t t = 0; t < device_basic.size(); ++t) {
+            if (wanted_row[t] < m && basis[wanted_row[t]] < 0) basis[wanted_row[t]] = device_basic[t];
+            else homeless.push_back(device_basic[t]);
+        }
+        size_t next = 0;
+        for (int i = 0; i < m; ++i)
+            if (basis[i] < 0) basis[i] = homeless[next++];
+        for (int j = 0; j < n; ++j) pos[j] = flipped[j] ? -2 : -1;
+        for (int i = 0; i < m; ++i) pos[basis[i]] = i;
+        // right-hand side with the complemented columns moved over, bounds of the basic variables
+        std::vector<double> ub(n), rhs(m), xub(m);
+        RELP_HIP(hipMemcpyAsync(ub.data(), d_.ub, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipMemcpyAsync(rhs.data(), d_.rhs0, m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+        for (int j = d_.n_art; j < n; ++j) {
+            if (!flipped[j]) continue;
+            SparseColumn column = md.column(j - d_.n_art);
+            for (size_t e = 0; e < column.nnz(); ++e)
+                if (column.index[e] < m) rhs[column.index[e]] -= ub[j] * column.value[e].to_double();
+        }
+        for (int i = 0; i < m; ++i) xub[i] = ub[basis[i]];
+        upload_vec(d_.flipped, flipped, stream_);
+        upload_vec(d_.rhs, rhs, stream_);
+        upload_vec(d_.xub, xub, stream_);
+        RELP_HIP(hipStreamSynchronize(stream_));
     }
     upload_vec(d_.basis, basis, stream_);
     upload_vec(d_.pos, pos, stream_);
@@ -777,26 +842,21 @@ void Solver::solve(relp_result* result) {
         RELP_HIP(hipMemcpyAsync(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
         RELP_HIP(hipMemcpyAsync(ub.data(), d_.ub, d_.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
         RELP_HIP(hipStreamSynchronize(stream_));
-        h_basis_.assign(md.nr_rows(), -1);
+        h_basis_ = explicit_basis(basis, pos);
         for (int i = 0; i < m; ++i) {
             const int dev = basis[i];
-            h_basis_[i] = dev >= d_.n_art ? dev - d_.n_art : -1 - dev;
             if (dev >= d_.n_art) h_solution_[dev - d_.n_art] = flipped[dev] ? ub[dev] - xb[i] : xb[i];
         }
         for (int j = d_.n_art; j < d_.n; ++j)
             if (pos[j] == -2) h_solution_[j - d_.n_art] = ub[j];
         const int nb = (int)md.bound_to_variable.size();
-        for (int k2 = 0; k2 < nb; ++k2) {  // VariableBound rows
+        for (int k2 = 0; k2 < nb; ++k2) {  // VariableBound rows: the bound slack of a variable below its bound
             const int j = md.bound_to_variable[k2];
-            const bool at_upper = pos[d_.n_art + j] == -2;
-            h_basis_[md.row_end[3] + k2] = at_upper ? j : md.col_end[3] + k2;
-            if (!at_upper) h_solution_[md.col_end[3] + k2] = ub[d_.n_art + j] - h_solution_[j];
+            if (pos[d_.n_art + j] != -2) h_solution_[md.col_end[3] + k2] = ub[d_.n_art + j] - h_solution_[j];
         }
         for (int k2 = 0; k2 < md.nr_range; ++k2) {  // SlackBound rows (range slacks)
             const int j = md.col_end[0] + k2;
-            const bool at_upper = pos[d_.n_art + j] == -2;
-            h_basis_[md.row_end[4] + k2] = at_upper ? j : md.col_end[4] + k2;
-            if (!at_upper) h_solution_[md.col_end[4] + k2] = ub[d_.n_art + j] - h_solution_[j];
+            if (pos[d_.n_art + j] != -2) h_solution_[md.col_end[4] + k2] = ub[d_.n_art + j] - h_solution_[j];
         }
     }
     res.kind = kind;
@@ -810,6 +870,24 @@ void Solver::solve(relp_result* result) {
     if (kind == RELP_RESULT_FINITE_OPTIMUM && opt_.certify) certify(&res);
     last_result = res;
     if (result) *result = res;
+}
+
+// Implicit bounds: the basis of the reference's formulation (all rows of MatrixData) that the device state stands for.  On
+// every bound row the bound slack is basic when the variable is below its bound and the variable itself when it sits at it.
+std::vector<int> Solver::explicit_basis(const std::vector<int>& basis, const std::vector<int>& pos) const {
+    const MatrixData& md = form_.data;
+    std::vector<int> out(md.nr_rows(), -1);
+    for (int i = 0; i < d_.m; ++i) out[i] = basis[i] >= d_.n_art ? basis[i] - d_.n_art : -1 - basis[i];
+    const int nb = (int)md.bound_to_variable.size();
+    for (int k2 = 0; k2 < nb; ++k2) {
+        const int j = md.bound_to_variable[k2];
+        out[md.row_end[3] + k2] = pos[d_.n_art + j] == -2 ? j : md.col_end[3] + k2;
+    }
+    for (int k2 = 0; k2 < md.nr_range; ++k2) {
+        const int j = md.col_end[0] + k2;
+        out[md.row_end[4] + k2] = pos[d_.n_art + j] == -2 ? j : md.col_end[4] + k2;
+    }
+    return out;
 }
 
 void Solver::certify(relp_result* result) {
@@ -976,6 +1054,14 @@ void Solver::get_basis(int* out) {
     std::vector<int> basis(d_.m);
     RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, d_.m * sizeof(int), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
+    if (bounded_) {  // in the reference's formulation: one entry per row of MatrixData, bound rows included
+        std::vector<int> pos(d_.n);
+        RELP_HIP(hipMemcpyAsync(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+        const std::vector<int> full = explicit_basis(basis, pos);
+        std::copy(full.begin(), full.end(), out);
+        return;
+    }
     for (int i = 0; i < d_.m; ++i) out[i] = basis[i] >= d_.n_art ? basis[i] - d_.n_art : -1 - basis[i];
 }
 void Solver::get_solution(double* x) const {

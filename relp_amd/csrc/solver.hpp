@@ -173,6 +173,7 @@ private:
     void build_graph(int count);
     void polish(bool refresh_vectors);
     void invert_from_scratch();
+    std::vector<int> explicit_basis(const std::vector<int>& basis, const std::vector<int>& pos) const;  // implicit bounds -> basis of the reference's formulation
     void ensure_polish_buffers();  // second inverse + residual matrix, allocated when a polish first has something to correct
     Ctl read_ctl();
     void write_ctl(const Ctl& c);

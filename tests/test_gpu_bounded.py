@@ -90,3 +90,28 @@ def test_netlib_with_implicit_bounds(name):
         assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
         assert Fraction(solver.objective_exact()) == Fraction(golden["objective"])
     solver.close()
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "BOEING2", "KB2", "RECIPELP", "SCTAP1", "ETAMACRO", "80BAU3B"])
+def test_basis_round_trip_between_the_two_formulations(name):
+    """``relp_get_basis`` / ``relp_set_basis`` speak the reference's formulation in both modes: the optimal basis found with
+    the bound rows explicit warm-starts the implicit-bounds solver (and the other way round) with nothing left to pivot."""
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    solvers = {mode: relp_amd.Solver(implicit_bounds=mode, certify=0).load_mps(path) for mode in (0, 1)}
+    results = {mode: s.solve_relaxation() for mode, s in solvers.items()}
+    bases = {mode: s.basis() for mode, s in solvers.items()}
+    fixed_cost = relp_amd.Model(path).fixed_cost()  # the handle-level objective of the fine-grained operations excludes it
+    assert len(bases[0]) == len(bases[1]) == solvers[0].m
+    for source, target in ((0, 1), (1, 0), (1, 1)):
+        fresh = relp_amd.Solver(implicit_bounds=target, certify=0).load_mps(path)
+        fresh.set_basis(bases[source])
+        done, _ = fresh.iterate(1000)
+        objective = fresh.objective_function_value()
+        expected = results[source].objective
+        assert abs(objective + fixed_cost - expected) <= 1e-7 * max(1.0, abs(expected)), (source, target)
+        assert done <= 2, (source, target, done)  # optimal already (a tie in the tolerances may cost a degenerate pivot)
+        assert sorted(fresh.basis()) == sorted(bases[source]) or done > 0
+        fresh.close()
+    for s in solvers.values():
+        s.close()
+
