@@ -469,7 +469,13 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // F32: the dense block is stored as float because every entry is exactly representable in it (checked at upload); the
 // widening back is exact and all arithmetic stays f64, so results are bit-identical while the pass streams half the bytes.
-template <bool F32>
+// I8: the block as signed bytes when every entry is an integer in [-128, 127] (a quarter of the f32 stream).  Stored in
+// chunks of 1024 rows, bytes t, t+1 (t even) of lane l's 16-byte piece holding rows (t/2)*128 + 2l + {0, 1} of the chunk: one
+// 16-byte load per lane brings 16 entries, and for every byte pair the 64 lanes read 64 consecutive double2 of -pi / rho / w
+// from LDS (16-byte reads, no bank conflicts).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int K1D_I8_CHUNK = 1024;
+template <bool F32, bool I8 = false>
 __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, int skip_weights, double tol_dual, int cand_offset) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[K1D_THREADS / WAVE + 2];
@@ -499,6 +505,82 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
     best.aux = 0;
     double best_cbar = 0.0;
     const int half = mp / 2;
+    auto finish_column = [&](int j, int pos_j, double gamma_j, double cost_j, double d_pi, double d_rho, double d_w) {
+        d_pi = wave_sum(d_pi);
+        d_rho = wave_sum(d_rho);
+        d_w = wave_sum(d_w);
+        if (lane == LAST) {
+            double gam = gamma_j;
+            if (pending) {
+                if (j == leaving) {
+                    gam = gamma_q / (alpha_pq * alpha_pq);
+                } else {
+                    const double sq = d_rho * d_rho;
+                    gam = gam - 2.0 * d_rho * d_w + sq * gamma_q;
+                    gam = fmax(gam, 1.0 + sq);
+                }
+                lp.gamma[j] = gam;
+            }
+            const double cbar = (pos_j == -2 ? -1.0 : 1.0) * (cost_j + d_pi);
+            if (cbar < -tol_dual) {
+                Cand c;
+                c.idx = j;
+                c.aux = 0;
+                c.key = cbar * cbar / gam;
+                Cand nb = better<TIE_LARGER_IDX>(best, c);
+                if (nb.idx == j) best_cbar = cbar;
+                best = nb;
+            }
+        }
+    };
+    if (I8) {
+        // One 16-byte load per lane = 16 entries; per entry one widening and three f64 FMAs against -pi / rho / w from LDS
+        // (16-byte LDS reads).  33 MB instead of 131 MB per pass at 4096 x 8192, and the pass is then bound by the 800 MB
+        // that come out of LDS, not by HBM.  Measured and dropped (all spill at the 128 VGPRs a 1024-thread workgroup
+        // allows, or lose the loads in flight): two columns per wave to halve the LDS reads (33.8 us), prefetching the wave's
+        // next column (25.6 us), a rolled chunk loop (23.4 us), the 2^52 widening trick (22.3 us) -- against 19.2 us.
+        const int chunks = mp / K1D_I8_CHUNK;
+        const double2* pi2 = reinterpret_cast<const double2*>(s_pi);
+        const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
+        const double2* w2 = reinterpret_cast<const double2*>(s_w);
+        for (int jd = blockIdx.x * (K1D_THREADS / WAVE) + wave; jd < lp.n_dense; jd += waves_total) {
+            const int j = lp.dense_first + jd;
+            const int pos_j = lp.pos[j];
+            const double gamma_j = lp.gamma[j];
+            const double cost_j = lp.cost[j];
+            if (pos_j >= 0) continue;  // wave-uniform
+            const i32x4* col = reinterpret_cast<const i32x4*>(lp.dense_val8 + (size_t)jd * mp);
+            double p0 = 0.0, p1 = 0.0, r0 = 0.0, r1 = 0.0, w0 = 0.0, w1 = 0.0;  // two chains per sum
+            for (int c0 = 0; c0 < chunks; c0 += 4) {
+                i32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = c0 + u < chunks ? __builtin_nontemporal_load(col + (size_t)(c0 + u) * WAVE + lane) : i32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c0 + u >= chunks) continue;
+                    const int base2 = (c0 + u) * (K1D_I8_CHUNK / 2) + lane;  // in double2 units
+#pragma unroll
+                    for (int t = 0; t < 16; t += 2) {  // bytes t, t+1 <-> rows (t/2)*128 + 2*lane + {0, 1}: one 16-byte LDS read each
+                        const double x0 = (double)__builtin_amdgcn_sbfe(v[u][t / 4], 8 * (t % 4), 8);
+                        const double x1 = (double)__builtin_amdgcn_sbfe(v[u][(t + 1) / 4], 8 * ((t + 1) % 4), 8);
+                        const int at = base2 + (t / 2) * WAVE;
+                        const double2 vp = pi2[at];
+                        p0 += x0 * vp.x;
+                        p1 += x1 * vp.y;
+                        if (pending) {
+                            const double2 vr = rho2[at], vw = w2[at];
+                            r0 += x0 * vr.x;
+                            r1 += x1 * vr.y;
+                            w0 += x0 * vw.x;
+                            w1 += x1 * vw.y;
+                        }
+                    }
+                }
+            }
+            finish_column(j, pos_j, gamma_j, cost_j, p0 + p1, r0 + r1, w0 + w1);
+        }
+    } else
     for (int jd = blockIdx.x * (K1D_THREADS / WAVE) + wave; jd < lp.n_dense; jd += waves_total) {
         const int j = lp.dense_first + jd;
         const int pos_j = lp.pos[j];
@@ -511,7 +593,9 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
         const double2* rho2 = reinterpret_cast<const double2*>(s_rho);
         const double2* w2 = reinterpret_cast<const double2*>(s_w);
         double d_pi = 0.0, d_rho = 0.0, d_w = 0.0;
-        if (F32) {
+        if (I8) {
+            // (handled by the two-column loop above)
+        } else if (F32) {
             const f32x4* col = reinterpret_cast<const f32x4*>(lp.dense_val32 + (size_t)jd * mp);
             const int quarter = mp / 4;
             for (int k0 = lane; k0 < quarter; k0 += 8 * WAVE) {
@@ -2714,12 +2798,14 @@ void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_
 
 void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s) {
     const size_t lds = (size_t)3 * d.dense_ld * sizeof(double);
-    if (d.dense_val32) RELP_LAUNCH(0, price_dense_kernel<true>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
+    if (d.dense_val8) RELP_LAUNCH(0, (price_dense_kernel<false, true>), dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
+    else if (d.dense_val32) RELP_LAUNCH(0, price_dense_kernel<true>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
     else RELP_LAUNCH(0, price_dense_kernel<false>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
 }
 void configure_dense_lds(size_t lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s) {
     hipLaunchKernelGGL(ftran_partial_kernel, dim3((d.m + 255) / 256, n_slices), dim3(256), 0, s, d, n_slices, n_price_blocks, rule);

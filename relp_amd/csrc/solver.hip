@@ -93,7 +93,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -284,7 +284,26 @@ void Solver::upload() {
         RELP_HIP(hipMemsetAsync(d_.eta_slot, 0xff, m * sizeof(int), stream_));
         configure_btran_lds((size_t)2 * ((m + 1) & ~1) * sizeof(double));
     }
-    if (n_dense > 0) {
+    bool dense_bytes = n_dense > 0 && !getenv("RELP_DENSE_F64") && !getenv("RELP_DENSE_F32");  // narrowest exact storage type
+    for (int jd = 0; dense_bytes && jd < n_dense; ++jd)
+        for (int e = col_start[n_art + jd]; dense_bytes && e < col_start[n_art + jd + 1]; ++e)
+            dense_bytes = value[e] >= -128.0 && value[e] <= 127.0 && value[e] == std::floor(value[e]);
+    if (dense_bytes && (size_t)3 * ((m + 1023) & ~1023) * sizeof(double) > 160 * 1024 - 4096) dense_bytes = false;  // LDS holds the padded vectors
+    if (dense_bytes) {
+        d_.dense_ld = (m + 1023) & ~1023;
+        std::vector<signed char> bytes((size_t)n_dense * d_.dense_ld, 0);
+        for (int jd = 0; jd < n_dense; ++jd)
+            for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) {
+                const int row = row_index[e], chunk = row / 1024, within = row % 1024;
+                const int pair = within / 128, lane = (within % 128) / 2, t = 2 * pair + (within & 1);  // see price_dense_kernel
+                bytes[(size_t)jd * d_.dense_ld + (size_t)chunk * 1024 + lane * 16 + t] = (signed char)value[e];
+            }
+        d_.dense_val8 = dmalloc<signed char>(bytes.size());
+        upload_vec(d_.dense_val8, bytes, stream_);
+        dense_entry_bytes_ = 1;
+        RELP_HIP(hipStreamSynchronize(stream_));
+        configure_dense_lds((size_t)3 * d_.dense_ld * sizeof(double));
+    } else if (n_dense > 0) {
         std::vector<double> dense((size_t)n_dense * d_.dense_ld, 0.0);
         for (int jd = 0; jd < n_dense; ++jd)
             for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) dense[(size_t)jd * d_.dense_ld + row_index[e]] = value[e];
