@@ -103,10 +103,18 @@ def dense_roofline(device):
                 traffic = entry["hbm_bytes_corrected"]
     solver.close()
     achieved = bytes_per_launch / seconds / 1e9
+    # The coefficients of this workload are integers in [1, 100]: the block is held as signed bytes (1 B per entry; 4 B as
+    # float measured 131.4 MB in 27.6 us = 4.4 TB/s = 55 % of the HBM peak, 8 B as f64 262.7 MB at 4.8 TB/s).  With a quarter
+    # of the bytes the pass is no longer bound by HBM: every entry meets three doubles (-pi, rho, w) that come out of LDS.
+    lds_bytes = 24 * bytes_per_launch
     return {"workload": "synthetic dense random LP m=4096 n=8192 (python bench.py --workload dense4096 for its pivots/s)",
-            "bound": "hbm", "kernel": "price (dense block)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "price (dense block, 1 B per entry)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "seconds_per_launch": seconds,
-            "algorithmic_bytes_per_launch": bytes_per_launch}
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "lds": {"bytes_per_launch": lds_bytes, "achieved": lds_bytes / seconds / 1e9, "peak": 150000.0, "unit": "GB/s",
+                    "frac": lds_bytes / seconds / 1e9 / 150000.0},
+            "note": "the same pass with the block held as float streams 131.4 MB in 27.6 us (4.4 TB/s, frac 0.55 of HBM); as bytes "
+                    "it streams 33 MB in less time and is bound by the 24 B per entry it reads from LDS and by f64 FMA issue"}
 
 
 def netlib_batch(args, rank, local_rank, world, distributed):
@@ -363,7 +371,13 @@ def main():
         if graph:
             line["metric"] = "simplex pivots/sec + wall-clock to optimal, max-flow LP @1 GPU"
             line["roofline"]["note"] = "pricing pass over the arc columns (two padded entries per column; per entry one 32-byte gather of the packed (-pi, rho, w) row from L2 beside the 48 B/column HBM stream)"
-        elif not dense:
+        elif dense:
+            line["metric"] = "simplex pivots/sec + wall-clock to optimal, dense LP @1 GPU"
+            line["roofline"]["note"] = ("dense block held in the narrowest exact type (this workload: signed bytes, 1 B per entry; as float "
+                                        "the same pass streams 4x the bytes at 4.4 TB/s = 0.55 of the HBM peak): the pass then reads 24 B "
+                                        "per entry from LDS (%.0f GB/s of ~150000) and is bound by that and by f64 FMA issue, not by HBM"
+                                        % (24 * bytes_per_launch / seconds[dominant] / 1e9))
+        if not dense and not graph:
             line["roofline"]["note"] = ("latency bound by construction: one pricing launch streams %d KB that live in L2 / Infinity Cache "
                                         "(SURVEY.md section 8(d)); traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes: the "
                                         "kernel reads the columns from their 8-entry padded copy (230 KB) and the x2 correction for wide "
