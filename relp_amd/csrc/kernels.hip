@@ -562,8 +562,8 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
                     const int base2 = (c0 + u) * (K1D_I8_CHUNK / 2) + lane;  // in double2 units
 #pragma unroll
                     for (int t = 0; t < 16; t += 2) {  // bytes t, t+1 <-> rows (t/2)*128 + 2*lane + {0, 1}: one 16-byte LDS read each
-                        const double x0 = (double)__builtin_amdgcn_sbfe(v[u][t / 4], 8 * (t % 4), 8);
-                        const double x1 = (double)__builtin_amdgcn_sbfe(v[u][(t + 1) / 4], 8 * ((t + 1) % 4), 8);
+                        const double x0 = (double)((int)((unsigned)v[u][t / 4] << (24 - 8 * (t % 4))) >> 24);  // sign-extended byte
+                        const double x1 = (double)((int)((unsigned)v[u][(t + 1) / 4] << (24 - 8 * ((t + 1) % 4))) >> 24);
                         const int at = base2 + (t / 2) * WAVE;
                         const double2 vp = pi2[at];
                         p0 += x0 * vp.x;

@@ -114,13 +114,16 @@ def dense_mixed_lp(rng, m, n):
     return counts, a, b, ranges, cost
 
 
+@pytest.mark.parametrize("storage", ["bytes", "float", "f64"])  # the dense block in each of its exact storage types
 @pytest.mark.parametrize("seed", range(6))
-def test_dense_block_with_mixed_rows_exact(seed, monkeypatch):
+def test_dense_block_with_mixed_rows_exact(seed, storage, monkeypatch):
     """Dense pipeline (forced by the test hook) on LPs with artificials, range rows and zero-level pivots.  The device's
     exact certificate must hold (an independent proof of optimality in rational arithmetic), the optimum must agree with
     HiGHS, and on the smallest size with the exact optimum of the C++ oracle (its rationals make larger dense LPs slow)."""
     from scipy.optimize import linprog
     monkeypatch.setenv("RELP_FTRAN_MIN_NNZ", "16")
+    if storage != "bytes":  # coefficients here are integers in [-9, 9]: signed bytes unless told otherwise
+        monkeypatch.setenv("RELP_DENSE_F32" if storage == "float" else "RELP_DENSE_F64", "1")
     rng = random.Random(7000 + seed)
     m, n = rng.choice([(64, 96), (80, 128), (97, 130), (120, 200)])
     lp = None
