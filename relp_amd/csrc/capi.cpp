@@ -87,9 +87,9 @@ int32_t relp_model_from_mps_ex(const char* path, int32_t fixed_format, int32_t p
     std::stringstream buffer;
     buffer << in.rdbuf();
     try {
-        relp_model* model = new relp_model();
+        std::unique_ptr<relp_model> model(new relp_model());
         model->form = load_mps(buffer.str(), fixed_format != 0, presolve != 0);
-        *out = model;
+        *out = model.release();
         return RELP_OK;
     } catch (const RatOverflow& e) {
         return fail(e.what(), RELP_ERR_OVERFLOW);
@@ -199,9 +199,9 @@ static int32_t model_from_graph(bool max_flow, int32_t nr_vertices, int32_t nr_a
             if (den[k] == 0) return fail("zero denominator", RELP_ERR_ARGUMENT);
             arcs[k] = Arc{tail[k], head[k], make_rat(num[k], den[k])};
         }
-        relp_model* model = new relp_model();
+        std::unique_ptr<relp_model> model(new relp_model());
         model->form = max_flow ? make_max_flow(nr_vertices, arcs, s, t) : make_shortest_path(nr_vertices, arcs, s, t);
-        *out = model;
+        *out = model.release();
         return RELP_OK;
     } catch (const RatOverflow& e) {
         return fail(e.what(), RELP_ERR_OVERFLOW);
