@@ -123,6 +123,24 @@ int32_t relp_model_from_general_form(int32_t maximize, int32_t nr_rows, int32_t 
                                      const uint8_t* has_upper, const int64_t* upper_num, const int64_t* upper_den,
                                      int64_t fixed_cost_num, int64_t fixed_cost_den, int32_t presolve, relp_model** out,
                                      char* error, int32_t error_capacity);
+/* Any other `MatrixProvider` (matrix_provider/mod.rs:37-134), through the calls the reference's loops make on it: the host
+ * pulls every column once (the device keeps them resident; the reference generates columns lazily per pivot).
+ *   column(j): `MatrixProvider::column` -- writes at most `capacity` (row, num/den) entries, ascending rows, no zeros, and
+ *              returns the number of non-zeros of the column (called again with a larger buffer if that exceeds capacity);
+ *   cost_value(j): `MatrixProvider::cost_value`;  right_hand_side: `MatrixProvider::right_hand_side`, nr_rows values >= 0;
+ *   pivot_element_indices: `PartialInitialBasis::pivot_element_indices` (matrix_provider/mod.rs) -- (row, column) pairs whose
+ *              column is the unit vector of that row; NULL, or a count of 0, for a provider without an initial basis (phase one
+ *              then starts fully artificial: `Tableau::new` over `Fully`, tableau/kind/artificial/fully.rs).
+ * Variable bounds are rows of such a provider (as in examples/max_flow.rs); `implicit_bounds` has nothing to take out. */
+typedef struct relp_provider {
+    void* user;
+    int32_t nr_rows, nr_columns;
+    int32_t (*column)(void* user, int32_t j, int32_t capacity, int32_t* row, int64_t* num, int64_t* den);
+    void (*cost_value)(void* user, int32_t j, int64_t* num, int64_t* den);
+    void (*right_hand_side)(void* user, int64_t* num, int64_t* den);
+    int32_t (*pivot_element_indices)(void* user, int32_t capacity, int32_t* rows, int32_t* columns);
+} relp_provider;
+int32_t relp_model_from_provider(const relp_provider* provider, relp_model** out, char* error, int32_t error_capacity);
 /* Number of variables of the file and how many of them the presolve removed (0 without presolve). */
 int32_t relp_model_original_variables(const relp_model* model, int32_t* nr_original, int32_t* nr_removed);
 /* Graph providers (reference: examples/max_flow.rs:31-223 `Primal::new` + its MatrixProvider; examples/shortest_path.rs:20-118;

@@ -49,7 +49,7 @@ _lib = None
 
 # every symbol include/relp_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_from_mps_ex", "relp_model_from_general_form", "relp_model_original_variables", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
+    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_from_mps_ex", "relp_model_from_general_form", "relp_model_from_provider", "relp_model_original_variables", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
     "relp_model_column", "relp_model_column_exact", "relp_model_cost", "relp_model_right_hand_side",
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
     "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_mps_ex", "relp_get_original_solution", "relp_load_model", "relp_get_dimensions", "relp_get_column",
@@ -204,6 +204,55 @@ class Model:
             _ptr(a["has_l"], C.c_uint8), _ptr(a["l_num"], C.c_int64), _ptr(a["l_den"], C.c_int64),
             _ptr(a["has_u"], C.c_uint8), _ptr(a["u_num"], C.c_int64), _ptr(a["u_den"], C.c_int64),
             C.c_int64(f_num), C.c_int64(f_den), int(bool(presolve)), C.byref(self._h), error, 512)
+        if status != OK:
+            raise RelpError(status, error.value.decode())
+        self._read_dimensions()
+        return self
+
+    @classmethod
+    def from_provider(cls, provider):
+        """Any object with the reference's ``MatrixProvider`` interface (matrix_provider/mod.rs:37-134): ``nr_rows()``,
+        ``nr_columns()``, ``column(j)`` -> sorted ``[(row, value)]``, ``cost_value(j)``, ``right_hand_side()`` and, optionally,
+        ``pivot_element_indices()`` (``PartialInitialBasis``).  Handed to the C ABI as callbacks (``relp_model_from_provider``)."""
+        from fractions import Fraction
+
+        def pair(v):
+            f = Fraction(v)
+            return f.numerator, f.denominator
+        column_t = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+        cost_t = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+        rhs_t = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+        pivots_t = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32))
+
+        class Provider(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("nr_rows", C.c_int32), ("nr_columns", C.c_int32), ("column", column_t),
+                        ("cost_value", cost_t), ("right_hand_side", rhs_t), ("pivot_element_indices", pivots_t)]
+
+        def column(_, j, capacity, rows, nums, dens):
+            entries = provider.column(j)
+            for e, (i, v) in enumerate(entries[:capacity]):
+                rows[e] = i
+                nums[e], dens[e] = pair(v)
+            return len(entries)
+
+        def cost_value(_, j, num, den):
+            num[0], den[0] = pair(provider.cost_value(j))
+
+        def right_hand_side(_, nums, dens):
+            for i, v in enumerate(provider.right_hand_side()):
+                nums[i], dens[i] = pair(v)
+
+        def pivot_element_indices(_, capacity, rows, columns):
+            pivots = provider.pivot_element_indices()
+            for k, (r, c) in enumerate(pivots[:capacity]):
+                rows[k], columns[k] = r, c
+            return len(pivots)
+        record = Provider(None, provider.nr_rows(), provider.nr_columns(), column_t(column), cost_t(cost_value), rhs_t(right_hand_side),
+                          pivots_t(pivot_element_indices) if hasattr(provider, "pivot_element_indices") else pivots_t())
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        error = C.create_string_buffer(512)
+        status = lib().relp_model_from_provider(C.byref(record), C.byref(self._h), error, 512)
         if status != OK:
             raise RelpError(status, error.value.decode())
         self._read_dimensions()

@@ -172,6 +172,85 @@ int32_t relp_model_from_general_form(int32_t maximize, int32_t nr_rows, int32_t 
         return fail(e.what(), RELP_ERR_PARSE);
     }
 }
+int32_t relp_model_from_provider(const relp_provider* provider, relp_model** out, char* error, int32_t error_capacity) {
+    if (!out) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    auto fail = [&](const std::string& what, int32_t code) {
+        if (error && error_capacity > 0) {
+            std::strncpy(error, what.c_str(), error_capacity - 1);
+            error[error_capacity - 1] = 0;
+        }
+        return code;
+    };
+    if (!provider || !provider->column || !provider->cost_value || !provider->right_hand_side || provider->nr_rows < 1 ||
+        provider->nr_columns < 1)
+        return fail("provider: missing callback or empty problem", RELP_ERR_ARGUMENT);
+    try {
+        const int m = provider->nr_rows, n = provider->nr_columns;
+        auto rational = [](int64_t num, int64_t den) {
+            if (den == 0) throw std::invalid_argument("provider: zero denominator");
+            return Rat((i128)num, (i128)den);
+        };
+        std::unique_ptr<relp_model> model(new relp_model());
+        StandardForm& form = model->form;
+        MatrixData& data = form.data;
+        data.nr_equality = m;
+        data.constraints.resize(n);
+        data.variables.resize(n);
+        std::vector<int32_t> rows(16);
+        std::vector<int64_t> nums(16), dens(16);
+        for (int j = 0; j < n; ++j) {
+            int32_t nnz = provider->column(provider->user, j, (int32_t)rows.size(), rows.data(), nums.data(), dens.data());
+            if (nnz > (int32_t)rows.size()) {
+                rows.resize(nnz); nums.resize(nnz); dens.resize(nnz);
+                nnz = provider->column(provider->user, j, nnz, rows.data(), nums.data(), dens.data());
+            }
+            if (nnz < 0 || nnz > (int32_t)rows.size()) throw std::invalid_argument("provider: bad column length");
+            for (int32_t e = 0; e < nnz; ++e) {
+                if (rows[e] < 0 || rows[e] >= m || (e > 0 && rows[e] <= rows[e - 1])) throw std::invalid_argument("provider: column rows must ascend within [0, nr_rows)");
+                const Rat v = rational(nums[e], dens[e]);
+                if (v.is_zero()) throw std::invalid_argument("provider: explicit zero in a column");
+                data.constraints[j].push(rows[e], v);
+            }
+            int64_t cn = 0, cd = 1;
+            provider->cost_value(provider->user, j, &cn, &cd);
+            data.variables[j].cost = rational(cn, cd);
+            form.column_names.push_back("X" + std::to_string(j));
+            form.active_to_original.push_back(j);
+        }
+        form.all_column_names = form.column_names;
+        form.nr_original = n;
+        form.free_negative_part.assign(n, -1);
+        std::vector<int64_t> bn(m, 0), bd(m, 1);
+        provider->right_hand_side(provider->user, bn.data(), bd.data());
+        for (int i = 0; i < m; ++i) {
+            data.b.push_back(rational(bn[i], bd[i]));
+            if (data.b.back().sign() < 0) throw std::invalid_argument("provider: negative right-hand side");
+        }
+        data.finalize();
+        if (provider->pivot_element_indices) {
+            std::vector<int32_t> pr(m), pc(m);
+            const int32_t count = provider->pivot_element_indices(provider->user, m, pr.data(), pc.data());
+            if (count < 0 || count > m) throw std::invalid_argument("provider: bad number of initial pivots");
+            std::vector<char> row_used(m, 0), column_used(n, 0);
+            for (int32_t k = 0; k < count; ++k) {
+                const int r = pr[k], c = pc[k];
+                if (r < 0 || r >= m || c < 0 || c >= n || row_used[r] || column_used[c]) throw std::invalid_argument("provider: bad initial pivot");
+                const SparseColumn& column = data.constraints[c];
+                if (column.nnz() != 1 || column.index[0] != r || !(column.value[0] == Rat(1)))
+                    throw std::invalid_argument("provider: an initial pivot column must be the unit vector of its row");
+                row_used[r] = column_used[c] = 1;
+                data.provider_pivots.push_back({r, c});
+            }
+        }
+        *out = model.release();
+        return RELP_OK;
+    } catch (const RatOverflow& e) {
+        return fail(e.what(), RELP_ERR_OVERFLOW);
+    } catch (const std::exception& e) {
+        return fail(e.what(), RELP_ERR_ARGUMENT);
+    }
+}
 int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model** out, char* error, int32_t error_capacity) {
     return relp_model_from_mps_ex(path, fixed_format, 0, out, error, error_capacity);
 }

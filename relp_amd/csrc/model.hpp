@@ -6,6 +6,7 @@
 // `column(j)`, `cost_value(j)`, `right_hand_side()`, `bound_row_index(j)`, `nr_rows()`, `nr_columns()`,
 // `pivot_element_indices()` and `reconstruct_solution()` with identical results.
 #pragma once
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -124,12 +125,20 @@ struct MatrixData {
         return out;
     }
 
+    // A provider that is not a `MatrixData` (relp_model_from_provider): its columns are held as structural columns over
+    // equality rows, and the unit columns its `PartialInitialBasis::pivot_element_indices` names are listed here.
+    std::vector<std::pair<int, int>> provider_pivots;
+
     // matrix_data.rs:419-445: (row, column) pairs, sorted by row.
     std::vector<std::pair<int, int>> pivot_element_indices() const {
         std::vector<std::pair<int, int>> out;
         for (int j = 0; j < nr_upper; ++j) out.push_back({row_end[1] + j, col_end[1] + j});
         for (int j = 0; j < (int)bound_to_variable.size(); ++j) out.push_back({row_end[3] + j, col_end[3] + j});
         for (int j = 0; j < nr_range; ++j) out.push_back({row_end[4] + j, col_end[4] + j});
+        if (!provider_pivots.empty()) {
+            out.insert(out.end(), provider_pivots.begin(), provider_pivots.end());
+            std::sort(out.begin(), out.end());
+        }
         return out;
     }
 };
