@@ -245,6 +245,14 @@ int32_t relp_relative_costs(relp_handle* handle, double* out_n);
 int32_t relp_get_gamma(relp_handle* handle, double* out_n);
 /* `Tableau::generate_column` + `select_primal_pivot_row` (tableau/mod.rs:126-130, 287-313): *row = -1 when unbounded. */
 int32_t relp_ratio(relp_handle* handle, int32_t column, int32_t* row, double* out_alpha_m);
+/* `Tableau::bring_into_basis(pivot_column, pivot_row, ..)` (tableau/mod.rs:139-160; `InverseMaintainer::change_basis`,
+ * carry/mod.rs:561-604) with the pivot given by the caller, in the index space of relp_price / relp_ratio: the inverse, b, -pi,
+ * the objective and the steepest-edge weights are updated as in any pivot of the loop.  RELP_ERR_STATE when the pivot
+ * element is zero. */
+int32_t relp_bring_into_basis(relp_handle* handle, int32_t column, int32_t row);
+/* `BasisInverse::should_refactor` + `invert` on demand (lower_upper/mod.rs:78-92, 249-252): polishes the resident inverse and
+ * recomputes b, -pi and the objective from it; *residual_before = max |I - B^T T| found. */
+int32_t relp_refactor(relp_handle* handle, double* residual_before);
 /* One full iteration of phase_one.rs:134-178 / phase_two.rs:36-58, repeated `count` times on the device. */
 int32_t relp_iterate(relp_handle* handle, int64_t count, int64_t* done, int32_t* stop_reason);
 /* `InverseMaintainer::{b, get_objective_function_value}` (inverse_maintenance/mod.rs:240-264). */

@@ -56,7 +56,7 @@ SYMBOLS = [
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
     "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
-    "relp_get_gamma", "relp_ratio", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
+    "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
     "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps",
 ]
 
@@ -481,6 +481,16 @@ class Solver:
         alpha = np.zeros(self.m)
         self._check(lib().relp_ratio(self._h, int(column), C.byref(row), _ptr(alpha, C.c_double)))
         return (None if row.value < 0 else row.value), alpha
+
+    def bring_into_basis(self, column, row):
+        """``Tableau::bring_into_basis`` with a given pivot (index space of ``select_primal_pivot_column``)."""
+        self._check(lib().relp_bring_into_basis(self._h, int(column), int(row)))
+
+    def refactor(self):
+        """Polish the resident inverse now; returns the residual max|I - B'T| found before."""
+        out = C.c_double()
+        self._check(lib().relp_refactor(self._h, C.byref(out)))
+        return out.value
 
     def iterate(self, count):
         done, reason = C.c_int64(), C.c_int32()

@@ -687,6 +687,17 @@ int32_t relp_ratio(relp_handle* h, int32_t column, int32_t* row, double* out_alp
         *row = r;
     });
 }
+int32_t relp_bring_into_basis(relp_handle* h, int32_t column, int32_t row) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] { h->solver->bring_into_basis(column, row); });
+}
+int32_t relp_refactor(relp_handle* h, double* residual_before) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] {
+        const double r = h->solver->refactor();
+        if (residual_before) *residual_before = r;
+    });
+}
 int32_t relp_iterate(relp_handle* h, int64_t count, int64_t* done, int32_t* stop_reason) {
     REQUIRE_LOADED(h);
     return guarded(h, [&] {

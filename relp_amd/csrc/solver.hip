@@ -1001,6 +1001,36 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
     c.forced_q = c.forced_p = -1;
     write_ctl(c);
 }
+// `Tableau::bring_into_basis(pivot_column, pivot_row, column)` (tableau/mod.rs:139-160) with both indices given by the
+// caller: one iteration of the device loop whose pricing and ratio test are overridden (the steepest-edge weights, b,
+// -pi, the objective and the inverse are updated as in any other pivot).  Same index space as `price` / `ratio`.
+void Solver::bring_into_basis(int column, int row) {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    if (column < 0 || column >= d_.n) throw std::invalid_argument("column out of range");
+    if (row < 0 || row >= d_.m) throw std::invalid_argument("row out of range");
+    Ctl c = read_ctl();
+    const long long before = c.iters;
+    c.status = ST_RUNNING;
+    c.forced_q = column;
+    c.forced_p = row;
+    write_ctl(c);
+    launch_pivots(1);
+    c = read_ctl();
+    if (c.iters == before) throw std::runtime_error("bring_into_basis: the pivot element is zero (or the column is basic)");
+    pivots_[phase_ - 1] += 1;
+    since_polish_ += 1;
+}
+// `BasisInverse::should_refactor` + `invert` (lower_upper/mod.rs:78-92, 249-252) on demand: the Newton-Schulz polish of the
+// resident inverse, with b, -pi and the objective recomputed from it.  Returns the residual max|I - B'T| found before.
+double Solver::refactor() {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    const double before = max_residual_;
+    max_residual_ = 0.0;
+    polish(true);
+    const double found = max_residual_;
+    max_residual_ = std::max(before, found);
+    return found;
+}
 // Average execution time of one launch of a hot-loop kernel INSIDE the real pivot sequence (bench.py's roofline leg):
 // `repetitions` further pivots of the current phase are run un-graphed, and the chosen kernel of every pivot is
 // bracketed by its own start/stop event pair (hipExtLaunchKernelGGL) on this handle's stream.  The solve advances.

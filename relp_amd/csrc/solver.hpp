@@ -146,6 +146,8 @@ public:
     void relative_costs(double* out);
     void get_gamma(double* out);
     void ratio(int column, int* row, double* alpha_out);
+    void bring_into_basis(int column, int row);
+    double refactor();
     void get_b(double* out);
     double objective();
     void get_basis(int* out);

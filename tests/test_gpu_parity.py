@@ -264,3 +264,41 @@ def test_miplib_relaxations(name, expected, tolerance):
     assert abs(result.objective - expected) < tolerance, result.objective
     assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
     solver.close()
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE"])
+def test_loop_driven_from_outside_through_bring_into_basis(name):
+    """The reference's loop (phase_one.rs:134-178 / phase_two.rs:36-58) written by the caller with the fine-grained operations
+    -- select_primal_pivot_column, generate_column + select_primal_pivot_row, bring_into_basis -- reaches the same optimum
+    as ``solve_relaxation``; ``refactor`` in the middle leaves the state where it was."""
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    whole = relp_amd.Solver(certify=0).load_mps(path)
+    expected = whole.solve_relaxation()
+    assert expected.kind == relp_amd.FINITE_OPTIMUM
+    fixed_cost = relp_amd.Model(path).fixed_cost()
+    solver = relp_amd.Solver(certify=0).load_mps(path)
+    solver.begin_phase_one()
+    pivots = 0
+    for phase in (1, 2):
+        while True:
+            selected = solver.select_primal_pivot_column()
+            if selected is None:
+                break
+            column, _ = selected
+            row, _ = solver.select_primal_pivot_row(column)
+            assert row >= 0
+            solver.bring_into_basis(column, row)
+            pivots += 1
+            if pivots == 7:
+                before = solver.objective_function_value()
+                assert solver.refactor() < 1e-9
+                assert solver.objective_function_value() == pytest.approx(before, rel=1e-12, abs=1e-12)
+            assert pivots < 5000
+        if phase == 1:
+            assert abs(solver.objective_function_value()) <= 1e-7  # feasible: the artificial cost is zero
+            solver.begin_phase_two()  # artificials still basic at level zero stay where they are: phase two never prices them
+    assert solver.objective_function_value() + fixed_cost == pytest.approx(expected.objective, rel=1e-9, abs=1e-9)
+    with pytest.raises(relp_amd.RelpError):
+        solver.bring_into_basis(-1, 0)
+    whole.close()
+    solver.close()
