@@ -277,7 +277,7 @@ def main():
     elapsed, pivots = batch.aggregate(elapsed, pivots, device="cuda" if distributed else None)
 
     in_flight = None
-    if rank == 0 and not dense and not graph and not args.no_concurrency_probe:
+    if rank == 0 and world == 1 and not dense and not graph and not args.no_concurrency_probe:
         # headroom: the same LP, 4 independent copies in flight on this GPU (one host thread and stream each); a single
         # latency-bound solve uses a fraction of the chip.  Reported beside `value`, never as `value`.
         import threading
@@ -385,7 +385,7 @@ def main():
                                         "measured below") % (bytes_per_launch // 1024)
             if world == 1 and not args.no_dense_roofline:
                 line["roofline_config3"] = dense_roofline(local_rank)
-        if not args.no_cpu_baseline and not graph:
+        if world == 1 and not args.no_cpu_baseline and not graph:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline_dense(path, args.cpu_seconds) if dense else cpu_baseline(path, args.cpu_seconds)
     if distributed:
         dist.destroy_process_group()
