@@ -141,14 +141,17 @@ def netlib_batch(args, rank, local_rank, world, distributed):
     solvers = {name: relp_amd.Solver(device=local_rank).load_model(models[name]) for name in mine}
     records = []
     passes = [0]
+    import threading
+    handle_locks = {name: threading.Lock() for name in solvers}
 
-    def run_all():
-        """One pass over the suite.  `--concurrency K` keeps K LPs in flight on this GPU (K host threads, one stream each):
-        the small LPs are latency bound and use a fraction of the chip, so their kernels overlap."""
+    def run_all(repeat=1):
+        """`repeat` passes over the suite as ONE queue of repeat x 45 tickets (pass after pass, each longest-first): no rank
+        and no thread waits at a pass boundary.  `--concurrency K` keeps K LPs in flight on this GPU (K host threads, one
+        stream each): the small LPs are latency bound and use a fraction of the chip, so their kernels overlap."""
         import threading
         passes[0] += 1
-        tickets = batch.TicketQueue(len(ordered), tag="pass%d" % passes[0]) if dynamic else None
-        static_tickets = batch.TicketQueue(len(mine), tag="static%d" % passes[0]) if not dynamic else None
+        tickets = batch.TicketQueue(len(ordered) * repeat, tag="pass%d" % passes[0]) if dynamic else None
+        static_tickets = batch.TicketQueue(len(mine) * repeat, tag="static%d" % passes[0]) if not dynamic else None
         if static_tickets is not None:
             static_tickets.store = None  # a rank-local counter over this rank's own share
         totals = []
@@ -159,8 +162,9 @@ def netlib_batch(args, rank, local_rank, world, distributed):
                 index = tickets.next() if dynamic else static_tickets.next()
                 if index is None:
                     break
-                name = ordered[index] if dynamic else mine[index]
-                r = solvers[name].solve_relaxation()
+                name = ordered[index % len(ordered)] if dynamic else mine[index % len(mine)]
+                with handle_locks[name]:  # a handle is single-threaded; successive passes may reach the same LP at once
+                    r = solvers[name].solve_relaxation()
                 pivots += r.pivots_phase_one + r.pivots_phase_two
                 records.append((name, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds))
             totals.append(pivots)
@@ -179,10 +183,8 @@ def netlib_batch(args, rank, local_rank, world, distributed):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     start = time.perf_counter()
-    pivots = 0
-    for _ in range(args.steps):
-        del records[:]
-        pivots += run_all()
+    del records[:]
+    pivots = run_all(repeat=args.steps)
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
