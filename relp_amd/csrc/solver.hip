@@ -738,11 +738,11 @@ long long Solver::iterate(long long count, int* stop_reason) {
     RELP_HIP(hipSetDevice(opt_.device));
     long long done = 0;
     int reason = ST_BUDGET;
+    long long iters_before = read_ctl().iters;  // one control-word read per batch: the next batch starts where this one ended
     while (done < count) {
         long long room = opt_.polish_period > 0 ? (long long)opt_.polish_period * polish_scale_ - since_polish_ : count;
-        if (room <= 0) { polish(true); continue; }
+        if (room <= 0) { polish(true); continue; }  // (a polish does not touch the iteration counter)
         int batch = (int)std::min<long long>({count - done, room, (long long)std::max(1, opt_.pivots_per_launch)});
-        Ctl before = read_ctl();
         if (opt_.use_graph && batch == opt_.pivots_per_launch) {
             build_graph(batch);
             RELP_HIP(hipGraphLaunch(graph_exec_, stream_));
@@ -752,7 +752,8 @@ long long Solver::iterate(long long count, int* stop_reason) {
             launch_pivots(batch);
         }
         Ctl after = read_ctl();
-        long long made = after.iters - before.iters;
+        long long made = after.iters - iters_before;
+        iters_before = after.iters;
         done += made;
         since_polish_ += made;
         pivots_[phase_ - 1] += made;
