@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
         sgn_j = 1.0;
         if (j < col_last) {
             const int pos_j = lp.pos[j];
-            nonbasic = pos_j < 0;
+            nonbasic = pos_j == -1 || pos_j == -2;  // -3: fixed variable (implicit bounds), never priced
             sgn_j = pos_j == -2 ? -1.0 : 1.0;
             if (LPC != 2) {  // width 2: no column is longer than the padded copy, the CSC is not needed
                 a = lp.col_start[j];

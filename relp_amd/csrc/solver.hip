@@ -327,6 +327,8 @@ void Solver::upload() {
         for (int j = 0; j < md.nr_normal_variables(); ++j)
             if (md.variables[j].has_upper) ub[n_art + j] = md.variables[j].upper.to_double();
         for (int k = 0; k < md.nr_range; ++k) ub[n_art + md.col_end[0] + k] = md.ranges[k].to_double();
+        zero_width_.assign(n, 0);
+        for (int j = 0; j < n; ++j) zero_width_[j] = ub[j] == 0.0 ? 1 : 0;
         d_.ub = dmalloc<double>(n);
         d_.xub = dmalloc<double>(m);
         d_.flipped = dmalloc<int>(n);
@@ -390,6 +392,9 @@ void Solver::begin_phase_one() {
     const MatrixData& md = form_.data;
     const int m = d_.m, n = d_.n, n_art = d_.n_art;
     std::vector<int> basis(m), pos(n, -1);
+    if (bounded_)  // a variable whose two bounds coincide can never move: it is not priced (pos -3; see DeviceLP::pos)
+        for (int j = n_art; j < n; ++j)
+            if (zero_width_[j]) pos[j] = -3;
     auto pivots = md.pivot_element_indices();
     std::vector<int> real_column_of_row(m, -1);
     for (auto& [row, column] : pivots)
@@ -692,7 +697,10 @@ void Solver::set_basis(const int* basis_columns) {
         size_t next = 0;
         for (int i = 0; i < m; ++i)
             if (basis[i] < 0) basis[i] = homeless[next++];
-        for (int j = 0; j < n; ++j) pos[j] = flipped[j] ? -2 : -1;
+        for (int j = 0; j < n; ++j) {
+            if (zero_width_[j]) flipped[j] = 0;  // both bounds are the same point
+            pos[j] = zero_width_[j] ? -3 : (flipped[j] ? -2 : -1);
+        }
         for (int i = 0; i < m; ++i) pos[basis[i]] = i;
         // right-hand side with the complemented columns moved over, bounds of the basic variables
         std::vector<double> ub(n), rhs(m), xub(m);
@@ -858,6 +866,7 @@ void Solver::solve(relp_result* result) {
         RELP_HIP(hipMemcpyAsync(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
         RELP_HIP(hipMemcpyAsync(ub.data(), d_.ub, d_.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
         RELP_HIP(hipStreamSynchronize(stream_));
+        resolve_fixed_columns(pos);
         h_basis_ = explicit_basis(basis, pos);
         for (int i = 0; i < m; ++i) {
             const int dev = basis[i];
@@ -890,6 +899,19 @@ void Solver::solve(relp_result* result) {
 
 // Implicit bounds: the basis of the reference's formulation (all rows of MatrixData) that the device state stands for.  On
 // every bound row the bound slack is basic when the variable is below its bound and the variable itself when it sits at it.
+// A fixed variable (pos -3) sits at both of its bounds at once; which of the two the reference's formulation should see is
+// decided by its reduced cost, exactly as the bound flips of a zero step used to do: negative -> "at the upper bound" (the
+// variable itself basic on its bound row), else the bound slack.  Rewrites the -3 entries of `pos` to -2 / -1.
+void Solver::resolve_fixed_columns(std::vector<int>& pos) {
+    bool any = false;
+    for (int j = d_.n_art; j < d_.n && !any; ++j) any = pos[j] == -3;
+    if (!any) return;
+    std::vector<double> cbar(d_.n);
+    relative_costs(cbar.data());
+    for (int j = d_.n_art; j < d_.n; ++j)
+        if (pos[j] == -3) pos[j] = cbar[j] < 0.0 ? -2 : -1;
+}
+
 std::vector<int> Solver::explicit_basis(const std::vector<int>& basis, const std::vector<int>& pos) const {
     const MatrixData& md = form_.data;
     std::vector<int> out(md.nr_rows(), -1);
@@ -1104,6 +1126,7 @@ void Solver::get_basis(int* out) {
         std::vector<int> pos(d_.n);
         RELP_HIP(hipMemcpyAsync(pos.data(), d_.pos, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
         RELP_HIP(hipStreamSynchronize(stream_));
+        resolve_fixed_columns(pos);
         const std::vector<int> full = explicit_basis(basis, pos);
         std::copy(full.begin(), full.end(), out);
         return;

@@ -88,7 +88,8 @@ struct DeviceLP {
     double* xB = nullptr;        // Carry::b (m)
     double* minus_pi = nullptr;  // Carry::minus_pi (m)
     int* basis = nullptr;        // Carry::basis_indices (m)
-    int* pos = nullptr;          // column -> row or -1 (the Tableau's basis_columns set) (n)
+    int* pos = nullptr;          // column -> row (the Tableau's basis_columns set) (n); non-basic: -1 at 0 | -2 at its upper bound
+                                 // (held complemented) | -3 fixed, both bounds coincide: never priced (implicit bounds)
     double* gamma = nullptr;     // steepest-edge weights (n)
     double* Binv = nullptr;      // explicit basis inverse, COLUMN-major: Binv(i, j) at [j*ld + i]
     double* Binv2 = nullptr;     // second buffer for the polish
@@ -177,6 +178,8 @@ private:
     void polish(bool refresh_vectors);
     void invert_from_scratch();
     std::vector<int> explicit_basis(const std::vector<int>& basis, const std::vector<int>& pos) const;  // implicit bounds -> basis of the reference's formulation
+    void resolve_fixed_columns(std::vector<int>& pos);
+    std::vector<char> zero_width_;  // implicit bounds: device columns with upper bound 0 (fixed variables)
     void ensure_polish_buffers();  // second inverse + residual matrix, allocated when a polish first has something to correct
     Ctl read_ctl();
     void write_ctl(const Ctl& c);

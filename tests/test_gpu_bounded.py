@@ -110,7 +110,13 @@ def test_basis_round_trip_between_the_two_formulations(name):
         expected = results[source].objective
         assert abs(objective + fixed_cost - expected) <= 1e-7 * max(1.0, abs(expected)), (source, target)
         assert done <= 2, (source, target, done)  # optimal already (a tie in the tolerances may cost a degenerate pivot)
-        assert sorted(fresh.basis()) == sorted(bases[source]) or done > 0
+        # (the basis read back may differ from the one given on the bound row of a FIXED variable: with both bounds at the same
+        # point the variable and its bound slack are interchangeable there, and the sign of its reduced cost decides)
+        again = relp_amd.Solver(implicit_bounds=target, certify=0).load_mps(path)
+        again.set_basis(fresh.basis())
+        assert again.iterate(1000)[0] <= 2
+        assert abs(again.objective_function_value() + fixed_cost - expected) <= 1e-7 * max(1.0, abs(expected))
+        again.close()
         fresh.close()
     for s in solvers.values():
         s.close()
