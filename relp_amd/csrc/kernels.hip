@@ -2231,9 +2231,11 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     const int m = lp.m, ld = lp.ld;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
-    const int slot0 = (blockIdx.x * (K3_THREADS / WAVE) + wave) * K3_CPW;
+    int slot0 = (blockIdx.x * (K3_THREADS / WAVE) + wave) * K3_CPW;
     int j0 = slot0, j1 = slot0 + 1;
     bool two = slot0 + 1 < m;
+    int row_lo = 0, row_hi = m;  // rows this wave sweeps
+    bool split = false;
     if (!EAGER && lp.track_touched) {
         // Only the columns that are not unit vectors any more need the update (E e_j = e_j for j != p; K2 has put p on
         // the list).  For a unit column e_j:  w_j = alpha_j, rho_j = 0 and -pi_j does not change.
@@ -2297,7 +2299,17 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
             }
             return;
         }
-        if (slot0 >= n_touched) return;
+        if (!(nz_small > 0 && nz_small * 6 < m) && (int)gridDim.x * K3_CPW >= m) {  // (the launch sized the grid for it)
+            // Full sweep (alpha not sparse): ONE WORKGROUP per column pair, its four waves take a quarter of the rows each.
+            // With a wave per pair, m = 2785 means 1400 waves on 1024 SIMDs, each walking 6 chunks of two dependent round
+            // trips; split four ways the chip holds them all and a wave walks 1-2 chunks (GREENBEA: 49.1 -> 45.5 us per pivot).
+            split = true;
+            slot0 = blockIdx.x * K3_CPW;
+            const int quarter = (((m + 3) / 4) + 7) & ~7;
+            row_lo = wave * quarter;
+            row_hi = min(m, row_lo + quarter);
+        }
+        if (slot0 >= n_touched) return;  // (workgroup-uniform when split)
         two = slot0 + 1 < n_touched;
         j0 = lp.tlist[slot0];
         j1 = two ? lp.tlist[slot0 + 1] : j0;
@@ -2331,6 +2343,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     if (status != ST_RUNNING || !pending) return;
     const double r0 = c0[p] / alpha_pq;  // row p of the new inverse
     const double r1 = c1[p] / alpha_pq;
+    if (split) __syncthreads();  // every wave of the pair has read row p before the wave that owns it overwrites it
     double w0 = 0.0, w1 = 0.0;
     const int nz = EAGER ? 0 : ctl->nz_count;
     if (!EAGER && nz > 0 && nz * 6 < m) {
@@ -2359,17 +2372,17 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
             }
         }
     } else
-    for (int base = 0; base < m; base += U * WAVE) {
+    for (int base = row_lo; base < row_hi; base += U * WAVE) {
         if (!EAGER || base > 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = base + lane + u * WAVE;
-                a[u] = i < m ? lp.alpha[i] : 0.0;
+                a[u] = i < row_hi ? lp.alpha[i] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = base + lane + u * WAVE;
-                const bool touch = i < m && (EAGER || a[u] != 0.0 || i == p);
+                const bool touch = i < row_hi && (EAGER || a[u] != 0.0 || i == p);
                 o0[u] = touch ? c0[i] : 0.0;
                 o1[u] = touch ? c1[i] : 0.0;
             }
@@ -2379,7 +2392,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
             const int i = base + lane + u * WAVE;
             w0 += a[u] * o0[u];
             w1 += a[u] * o1[u];
-            if (i < m && (a[u] != 0.0 || i == p)) {
+            if (i < row_hi && (a[u] != 0.0 || i == p)) {
                 c0[i] = (i == p) ? r0 : o0[u] - a[u] * r0;
                 if (two) c1[i] = (i == p) ? r1 : o1[u] - a[u] * r1;
             }
@@ -2387,6 +2400,17 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
     }
     w0 = wave_sum(w0);
     w1 = wave_sum(w1);
+    if (split) {  // the four row quarters, added in a fixed order
+        __shared__ double s_w[K3_THREADS / WAVE][2];
+        if (lane == LAST) {
+            s_w[wave][0] = w0;
+            s_w[wave][1] = w1;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        w0 = (s_w[0][0] + s_w[1][0]) + (s_w[2][0] + s_w[3][0]);
+        w1 = (s_w[0][1] + s_w[1][1]) + (s_w[2][1] + s_w[3][1]);
+    }
     if (lane == LAST) {
         lp.w[j0] = w0;
         lp.rho[j0] = r0;
@@ -2854,8 +2878,10 @@ void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double 
 void launch_update(const DeviceLP& d, hipStream_t s) {
     const int cols_per_block = (K3_THREADS / WAVE) * K3_CPW;
     const dim3 grid((d.m + cols_per_block - 1) / cols_per_block);
+    // m > 2048: a full sweep runs one workgroup per column pair (the list-driven modes use the first quarter of the grid)
+    const dim3 grid_split((d.m + K3_CPW - 1) / K3_CPW);
     if (d.m <= 2048) RELP_LAUNCH(2, (update_kernel<true>), grid, dim3(K3_THREADS), 0, s, d);
-    else RELP_LAUNCH(2, (update_kernel<false>), grid, dim3(K3_THREADS), 0, s, d);
+    else RELP_LAUNCH(2, (update_kernel<false>), (d.track_touched && d.m <= 16384) ? grid_split : grid, dim3(K3_THREADS), 0, s, d);  // larger m: the list-driven modes dominate (graph LPs) and 4x the workgroups only cost launch time
 }
 
 void launch_budget(const DeviceLP& d, long long add, hipStream_t s) {
