@@ -55,7 +55,8 @@ typedef struct relp_options {
     int32_t polish_period;     /* pivots between Newton-Schulz polishes of the explicit inverse (role of
                                   BasisInverse::should_refactor, lower_upper/mod.rs:249-252) */
     int32_t pivots_per_launch; /* pivots enqueued per host round trip (hipGraph replay length) */
-    int64_t max_pivots;        /* iteration cap (the reference has none; cycling is acknowledged, tests/netlib/test.rs:221) */
+    int64_t max_pivots;        /* iteration cap (the reference has none; cycling is acknowledged, tests/netlib/test.rs:221);
+                                  0 = 200 (m + n) + 100 000, after which the result is RELP_RESULT_ITERATION_LIMIT */
     double tol_dual;           /* cbar_j < -tol_dual makes j a pricing candidate */
     double tol_pivot;          /* alpha_i > tol_pivot takes part in the ratio test */
     double harris_delta;       /* feasibility slack of the two-pass ratio test */

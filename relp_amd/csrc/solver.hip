@@ -807,7 +807,9 @@ void Solver::solve(relp_result* result) {
     relp_result res{};
     exact_objective.clear();
     begin_phase_one();
-    const long long cap = opt_.max_pivots > 0 ? opt_.max_pivots : (1LL << 40);
+    // 0: a safety cap far above anything a terminating solve needs (GREENBEA: 8349 pivots with m + n = 8776), so that an LP
+    // that cycles in f64 comes back as RELP_RESULT_ITERATION_LIMIT instead of never
+    const long long cap = opt_.max_pivots > 0 ? opt_.max_pivots : 200LL * (d_.m + d_.n) + 100000;
     int kind = RELP_RESULT_NONE;
     if (phase_ == 1) {
         int reason = 0;
