@@ -1,7 +1,7 @@
 """One-off fuzzing on the GPU box: random small LPs with every row kind and bounded variables, both formulations (bound rows
 explicit / implicit bounds), against the exact oracle.  Prints the seeds that disagree.
 
-    python tools/fuzz_gpu.py [first_seed] [count]
+    python tools/fuzz_gpu.py [first_seed] [count] [zero]
 """
 import os, random, sys, time
 from fractions import Fraction
@@ -10,6 +10,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import relp_amd
 from relp_oracle import FiniteOptimum, Infeasible, MatrixData, Unbounded, Variable, solve_relaxation
+
+
+ZERO_BOUNDS = len(sys.argv) > 3 and sys.argv[3] == "zero"  # also variables fixed at zero (upper bound 0)
 
 
 def make(rng):
@@ -28,7 +31,7 @@ def make(rng):
         b[1] = b[0]
     ranges = [rng.randint(1, 6) for _ in range(counts[1])]
     cost = [rng.randint(-6, 5) for _ in range(n)]
-    upper = [rng.choice([None, None, rng.randint(1, 9), rng.randint(1, 3)]) for _ in range(n)]
+    upper = [rng.choice([None, None, rng.randint(1, 9), rng.randint(1, 3)] + ([0] if ZERO_BOUNDS else [])) for _ in range(n)]
     return n, counts, columns, b, ranges, cost, upper
 
 
