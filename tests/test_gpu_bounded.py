@@ -36,10 +36,12 @@ def bounded_lp(rng):
     return n, counts, columns, b, ranges, cost, upper
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(100))
 def test_random_bounded_lp_matches_oracle_exactly(seed):
     rng = random.Random(5000 + seed)
     n, counts, columns, b, ranges, cost, upper = bounded_lp(rng)
+    if seed >= 80:  # variables FIXED at zero (both bounds at one point): never priced on the device, resolved at the end
+        upper = [0 if rng.random() < 0.35 else u for u in upper]
     data = MatrixData(columns, b, ranges, counts[0], counts[1], counts[2], counts[3],
                       [Variable(c, upper_bound=u) for c, u in zip(cost, upper)])
     try:
