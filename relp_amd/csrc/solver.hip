@@ -444,8 +444,9 @@ void Solver::set_phase(int phase) {
     // are exact: what phase one leaves is what `SteepestDescentAlongObjective::new` (pivot_rule.rs:202-219) would recompute
     // for phase two.  Recomputing costs one pass over the inverse per column pair -- fine for Netlib, 1 TB for the 1 M-arc
     // max-flow LP -- so large LPs keep the weights (after flushing the update of the last zero-level pivot).
+    const double carry_threshold = getenv("RELP_CARRY_WEIGHTS_MIN") ? atof(getenv("RELP_CARRY_WEIGHTS_MIN")) : 4e9;  // (test hook)
     const bool carry_weights = phase == 2 && phase_before == 1 && !binv_identity_ &&
-                               (double)(d_.n - d_.n_art) * (double)d_.m > 4e9;
+                               (double)(d_.n - d_.n_art) * (double)d_.m > carry_threshold;
     if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE) {
         if (carry_weights) {
             Ctl pending = read_ctl();

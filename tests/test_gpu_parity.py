@@ -302,3 +302,21 @@ def test_loop_driven_from_outside_through_bring_into_basis(name):
         solver.bring_into_basis(-1, 0)
     whole.close()
     solver.close()
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE", "BLEND", "25FV47"])
+def test_steepest_edge_weights_carried_from_phase_one(name, monkeypatch):
+    """Large LPs keep the steepest-edge weights of phase one for phase two instead of recomputing them (the recurrences are
+    exact, so they are what `SteepestDescentAlongObjective::new` would compute: pivot_rule.rs:202-219).  Forced here on small
+    LPs: same exact optimum, and weights that agree with a fresh computation at the hand-over."""
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    fresh = relp_amd.Solver(certify=1).load_mps(path)
+    expected = fresh.solve_relaxation()
+    monkeypatch.setenv("RELP_CARRY_WEIGHTS_MIN", "0")
+    carried = relp_amd.Solver(certify=1).load_mps(path)
+    result = carried.solve_relaxation()
+    assert result.kind == expected.kind == relp_amd.FINITE_OPTIMUM and result.certified == 1
+    assert carried.objective_exact() == fresh.objective_exact()
+    assert abs(result.pivots_phase_two - expected.pivots_phase_two) <= max(20, expected.pivots_phase_two // 5)
+    fresh.close()
+    carried.close()
