@@ -83,8 +83,7 @@ Solver::Solver(const relp_options& options) : opt_(options) {
 
 Solver::~Solver() {
     free_device();
-    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-    if (graph_) (void)hipGraphDestroy(graph_);
+    destroy_graphs();
     if (ev_a_) (void)hipEventDestroy(ev_a_);
     if (ev_b_) (void)hipEventDestroy(ev_b_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -104,8 +103,7 @@ void Solver::reset_stats() { stats_ = relp_stats{}; }
 void Solver::load(StandardForm&& form) {
     RELP_HIP(hipSetDevice(opt_.device));
     free_device();
-    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
-    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+    destroy_graphs();
     form_ = std::move(form);
     upload();
     loaded_ = true;
@@ -523,19 +521,27 @@ void Solver::enqueue_ftran_ratio(int mode) {
     launch_ftran_ratio(d_, opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, ftran_slices_ > 0 ? 1 : 0, stream_);
 }
 
+void Solver::destroy_graphs() {
+    for (int k = 0; k < 2; ++k) {
+        if (graph_exec_[k]) { (void)hipGraphExecDestroy(graph_exec_[k]); graph_exec_[k] = nullptr; }
+        if (graph_[k]) { (void)hipGraphDestroy(graph_[k]); graph_[k] = nullptr; }
+        graph_count_[k] = 0;
+    }
+}
+
 void Solver::build_graph(int count) {
-    if (graph_exec_ && graph_count_ == count && graph_phase_ == phase_) return;
-    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
-    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+    const int k = phase_ == 2 ? 1 : 0;
+    if (graph_exec_[k] && graph_count_[k] == count) return;
+    if (graph_exec_[k]) { (void)hipGraphExecDestroy(graph_exec_[k]); graph_exec_[k] = nullptr; }
+    if (graph_[k]) { (void)hipGraphDestroy(graph_[k]); graph_[k] = nullptr; }
     long long launches = stats_.launches, price_launches = stats_.price_launches;
     RELP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
     launch_pivots(count);
-    RELP_HIP(hipStreamEndCapture(stream_, &graph_));
-    RELP_HIP(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
+    RELP_HIP(hipStreamEndCapture(stream_, &graph_[k]));
+    RELP_HIP(hipGraphInstantiate(&graph_exec_[k], graph_[k], nullptr, nullptr, 0));
     stats_.launches = launches;
     stats_.price_launches = price_launches;
-    graph_count_ = count;
-    graph_phase_ = phase_;
+    graph_count_[k] = count;
 }
 
 // Newton-Schulz polish (see kernels.hip).  Two iterations at most; the residual before the polish is recorded.
@@ -750,7 +756,7 @@ long long Solver::iterate(long long count, int* stop_reason) {
         int batch = (int)std::min<long long>({count - done, room, (long long)std::max(1, opt_.pivots_per_launch)});
         if (opt_.use_graph && batch == opt_.pivots_per_launch) {
             build_graph(batch);
-            RELP_HIP(hipGraphLaunch(graph_exec_, stream_));
+            RELP_HIP(hipGraphLaunch(graph_exec_[phase_ == 2 ? 1 : 0], stream_));
             stats_.launches += 1 + 3LL * batch;
             stats_.price_launches += batch;
         } else {

@@ -201,10 +201,12 @@ private:
     bool eta_mode_ = false;       // deferred product form of the inverse (DeviceLP::eta_cap > 0)
     size_t price_lds_ = 0;
     hipStream_t stream_ = nullptr;
-    hipGraph_t graph_ = nullptr;
-    hipGraphExec_t graph_exec_ = nullptr;
-    int graph_count_ = 0;
-    int graph_phase_ = -1;
+    // one captured batch of pivots per phase (the phases differ in a kernel argument); both survive across solves of the
+    // same LP, so a solve pays for no capture or instantiation after the first
+    hipGraph_t graph_[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_exec_[2] = {nullptr, nullptr};
+    int graph_count_[2] = {0, 0};
+    void destroy_graphs();
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
     relp_stats stats_{};
     std::vector<double> h_solution_;
