@@ -813,7 +813,17 @@ void Solver::solve(relp_result* result) {
     const double t0 = now_seconds();
     relp_result res{};
     exact_objective.clear();
+    const bool timing = getenv("RELP_TIME_SOLVE") != nullptr;  // diagnostic: host-side timeline of one solve
+    double t_last = t0;
+    auto tick = [&](const char* what) {
+        if (!timing) return;
+        RELP_HIP(hipStreamSynchronize(stream_));
+        const double t = now_seconds();
+        fprintf(stderr, "[solve] %-24s %.3f ms\n", what, (t - t_last) * 1e3);
+        t_last = t;
+    };
     begin_phase_one();
+    tick("begin_phase_one");
     // 0: a safety cap far above anything a terminating solve needs (GREENBEA: 8349 pivots with m + n = 8776), so that an LP
     // that cycles in f64 comes back as RELP_RESULT_ITERATION_LIMIT instead of never
     const long long cap = opt_.max_pivots > 0 ? opt_.max_pivots : 200LL * (d_.m + d_.n) + 100000;
@@ -822,10 +832,12 @@ void Solver::solve(relp_result* result) {
         int reason = 0;
         long long done = iterate(cap, &reason);
         (void)done;
+        tick("phase one loop");
         if (reason == ST_UNBOUNDED) throw std::runtime_error("Artificial cost can not be unbounded.");  // phase_one.rs:151
         if (reason == ST_BUDGET) kind = RELP_RESULT_ITERATION_LIMIT;
         if (kind == RELP_RESULT_NONE) {
             polish(true);
+            tick("polish");
             Ctl c = read_ctl();
             std::vector<double> xb(d_.m);
             RELP_HIP(hipMemcpyAsync(xb.data(), d_.xB, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -835,18 +847,23 @@ void Solver::solve(relp_result* result) {
             if (-c.minus_obj > opt_.tol_feasible * scale) {
                 kind = RELP_RESULT_INFEASIBLE;  // phase_one.rs:171-173
             } else {
+                tick("feasibility check");
                 drive_out_artificials();
+                tick("drive out artificials");
                 set_phase(2);
+                tick("set_phase(2)");
             }
         }
     }
     if (kind == RELP_RESULT_NONE) {
         int reason = 0;
         iterate(cap - pivots_[0], &reason);
+        tick("phase two loop");
         if (reason == ST_UNBOUNDED) kind = RELP_RESULT_UNBOUNDED;  // phase_two.rs:53
         else if (reason == ST_NO_ENTERING) {
             kind = RELP_RESULT_FINITE_OPTIMUM;
             polish(true);
+            tick("final polish");
         } else kind = RELP_RESULT_ITERATION_LIMIT;
     }
     // results: Carry::current_bfs (carry/mod.rs:636-645) + reconstruct_solution (matrix_data.rs:402-411)
@@ -900,6 +917,7 @@ void Solver::solve(relp_result* result) {
     res.max_residual = max_residual_;
     res.objective = (kind == RELP_RESULT_FINITE_OPTIMUM) ? -c.minus_obj + form_.fixed_cost.to_double()
                                                          : std::numeric_limits<double>::quiet_NaN();
+    tick("results");
     res.solve_seconds = now_seconds() - t0;
     if (kind == RELP_RESULT_FINITE_OPTIMUM && opt_.certify) certify(&res);
     last_result = res;
