@@ -1819,7 +1819,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     double ckey = 0.0;
     unsigned long long crank = RANK_NONE;
     const bool preselected = n_alpha_slices > 0;
-    if (forced_q < 0 && !preselected) {
+    if (!preselected) {  // NOT conditional on forced_q (a value still in flight): that would put these loads a round trip later
         for (int b = tid; b < n_price_blocks; b += K2F_THREADS) {
             const int j = lp.cand_j[b];
             const double k = lp.cand_key[b];
