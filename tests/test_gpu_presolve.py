@@ -81,3 +81,19 @@ def test_original_solution_is_feasible_and_optimal_in_the_file(name):
             else:
                 assert b - float(kind[1]) - slack <= activity[i] <= b + slack
         solver.close()
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "ADLITTLE", "BOEING2", "KB2", "RECIPELP", "SCTAP1", "ETAMACRO", "FINNIS", "GFRD-PNC", "80BAU3B"])
+def test_presolve_and_implicit_bounds_together(name):
+    """The two options combined (the presolve tightens and adds bounds, the bounded-variable simplex then takes them out of the
+    rows): same certified rational optimum as without either."""
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    plain = relp_amd.Solver(certify=1).load_mps(path)
+    expected = plain.solve_relaxation()
+    both = relp_amd.Solver(certify=1, implicit_bounds=1).load_mps(path, presolve=True)
+    result = both.solve_relaxation()
+    assert expected.kind == result.kind == relp_amd.FINITE_OPTIMUM and expected.certified == result.certified == 1
+    assert both.objective_exact() == plain.objective_exact()
+    assert both.m <= plain.m
+    plain.close()
+    both.close()
