@@ -1,11 +1,11 @@
 """One-off fuzzing on the GPU box: random small LPs with every row kind and bounded variables, both formulations (bound rows
 explicit / implicit bounds), against the exact oracle.  Prints the seeds that disagree.
 
-    python tools/fuzz_gpu.py [first_seed] [count] [zero]
+    python tests/fuzz/fuzz_gpu.py [first_seed] [count] [zero]
 """
 import os, random, sys, time
 from fractions import Fraction
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import relp_amd

@@ -2,11 +2,11 @@
 solved WITH the presolve on the device path against the exact oracle WITHOUT presolve: the optimum must be the same rational,
 and whatever the presolve refuses (infeasible / unbounded / solved completely) must match the oracle's verdict.
 
-    python tools/fuzz_presolve_gpu.py [first_seed] [count]
+    python tests/fuzz/fuzz_presolve_gpu.py [first_seed] [count]
 """
 import os, random, sys, time
 from fractions import Fraction
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
