@@ -270,6 +270,80 @@ int32_t relp_profile_kernel(relp_handle* handle, int32_t which, int32_t repetiti
 /* Diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of the fused kernel; zeros otherwise. */
 int32_t relp_debug_stamps(relp_handle* handle, uint64_t* out64);
 
+/* ---- `BasisInverse` as an object of its own (no LP handle needed) ------------------------------------------------------
+ * The reference's trait `BasisInverse` (tableau/inverse_maintenance/carry/mod.rs:69-169) and its main implementor
+ * `LUDecomposition<F>` (carry/lower_upper/mod.rs:36-272): `P B Q = L U` by Markowitz pivoting
+ * (lower_upper/decomposition/{mod.rs:27-143, pivoting.rs:45-81}), FTRAN / BTRAN through the sparse triangular factors,
+ * Forrest-Tomlin row-eta updates (mod.rs:94-178, eta_file.rs:14-134), refactorisation after `refactor_period` updates
+ * (mod.rs:249-252: 31).  The factorisation is computed on the host (f64; `pivot_threshold` is the relative pivot
+ * tolerance floating point needs and the exact reference does not; `reference_ties` = 1 with threshold 0 reproduces the
+ * reference's pivot choice entry for entry) and lives on the device, where the solves and updates run.
+ * Vectors cross the boundary as the reference's sparse `(index, value)` pairs in, dense arrays of m doubles out.
+ * Index spaces: a column is indexed by the rows of the LP (`left_multiply_by_basis_inverse` takes a provider column); a
+ * row vector by the rows of the basis, i.e. by `Carry::basis_indices` positions (`right_multiply_by_basis_inverse`). */
+typedef struct relp_basis_inverse relp_basis_inverse;
+typedef struct relp_bi_options {
+    int32_t device;
+    int32_t refactor_period;   /* `should_refactor` turns true after this many `change_basis` calls (reference: 31) */
+    double pivot_threshold;    /* accept a_ij as a pivot only if |a_ij| >= threshold * max_k |a_ik| (0: any non-zero) */
+    int32_t reference_ties;    /* 1: pivoting.rs:60-80 exactly (minimum Markowitz count, ties by (column, row) position) */
+    int32_t reserved;
+} relp_bi_options;
+int32_t relp_bi_options_default(relp_bi_options* options);
+/* `BasisInverse::identity(m)` (carry/mod.rs:83; lower_upper/mod.rs:67-76). */
+int32_t relp_bi_identity(const relp_bi_options* options, int32_t m, relp_basis_inverse** out);
+/* `BasisInverse::invert(columns)` (carry/mod.rs:89-92; lower_upper/mod.rs:78-92): m columns in basis order, CSC over the
+ * LP's rows.  RELP_ERR_NUMERICAL when the columns are singular. */
+int32_t relp_bi_invert(const relp_bi_options* options, int32_t m, const int64_t* column_start, const int32_t* row_index,
+                       const double* value, relp_basis_inverse** out);
+int32_t relp_bi_free(relp_basis_inverse* bi);
+const char* relp_bi_last_error(const relp_basis_inverse* bi);  /* bi == NULL: the last constructor error of this thread */
+/* `BasisInverse::m()` (carry/mod.rs:168). */
+int32_t relp_bi_m(const relp_basis_inverse* bi, int32_t* m);
+/* `BasisInverse::left_multiply_by_basis_inverse(column)` (carry/mod.rs:123-129; lower_upper/mod.rs:180-210): B^-1 c.  The
+ * object keeps the column and its spike -- the `ColumnComputationInfo` (lower_upper/mod.rs:417-432) -- for change_basis. */
+int32_t relp_bi_left_multiply(relp_basis_inverse* bi, int32_t nnz, const int32_t* row_index, const double* value, double* out_m);
+/* `BasisInverse::right_multiply_by_basis_inverse(row)` (carry/mod.rs:135-141; lower_upper/mod.rs:212-237): r B^-1. */
+int32_t relp_bi_right_multiply(relp_basis_inverse* bi, int32_t nnz, const int32_t* index, const double* value, double* out_m);
+/* `BasisInverse::basis_inverse_row(row)` (carry/mod.rs:165; lower_upper/mod.rs:254-272). */
+int32_t relp_bi_basis_inverse_row(relp_basis_inverse* bi, int32_t row, double* out_m);
+/* `BasisInverse::generate_element(i, original_column)` (carry/mod.rs:150-157; lower_upper/mod.rs:239-247): element i of
+ * B^-1 c; *is_some = 0 when it is zero (the reference returns `None`). */
+int32_t relp_bi_generate_element(relp_basis_inverse* bi, int32_t i, int32_t nnz, const int32_t* row_index, const double* value,
+                                 double* element, int32_t* is_some);
+/* `BasisInverse::change_basis(pivot_row_index, column)` (carry/mod.rs:104-108; lower_upper/mod.rs:94-178): the column of the
+ * last relp_bi_left_multiply replaces the basis column of row `pivot_row_index` (Forrest-Tomlin update; ONLY the inverse
+ * changes -- b, -pi and the objective are `Carry`'s, carry/mod.rs:561-604).  RELP_ERR_STATE without a preceding
+ * left_multiply; RELP_ERR_NUMERICAL when the new basis is singular or the update area is full (poll should_refactor). */
+int32_t relp_bi_change_basis(relp_basis_inverse* bi, int32_t pivot_row_index);
+/* `BasisInverse::should_refactor()` (carry/mod.rs:163; lower_upper/mod.rs:249-252). */
+int32_t relp_bi_should_refactor(relp_basis_inverse* bi, int32_t* should);
+/* `RemoveBasisPart::remove_basis_part(indices)` (carry/mod.rs:176-180; basis_inverse_rows.rs:212-229): rows `indices` and
+ * the basis columns of those rows leave the basis (redundant rows found in phase one); the rest is refactorised. */
+int32_t relp_bi_remove_basis_part(relp_basis_inverse* bi, int32_t count, const int32_t* indices);
+/* Sizes of the resident factor: non-zeros of L and U at the last refactorisation, the longest dependency chain of each
+ * triangular solve (= LDS round trips on the device), updates since. */
+int32_t relp_bi_statistics(relp_basis_inverse* bi, int64_t* nnz_lower, int64_t* nnz_upper, int32_t* depth_lower,
+                           int32_t* depth_upper, int32_t* nr_updates);
+/* The factors in the reference's own layout, for parity tests against its known-answer tests (lower_upper/mod.rs:36-58):
+ * row/column permutation (forward), `lower_triangular` by column (lower_start has m + 1 entries), `upper_triangular` by
+ * column with the rotations of all updates applied to the indices (upper_start: m + 1), `upper_diagonal`, and the eta
+ * files (pivot, entries) with the indices each one had when it was made.  Every array holds at most `capacity` entries
+ * (RELP_ERR_ARGUMENT otherwise); NULL skips an output. */
+int32_t relp_bi_get_factors(relp_basis_inverse* bi, int64_t capacity, int32_t* row_permutation, int32_t* column_permutation,
+                            int64_t* lower_start, int32_t* lower_row, double* lower_value, int64_t* upper_start,
+                            int32_t* upper_row, double* upper_value, double* upper_diagonal, int32_t* nr_updates,
+                            int64_t* eta_start, int32_t* eta_pivot, int32_t* eta_index, double* eta_value);
+/* Host only (no device needed): the factorisation step of relp_bi_invert by itself -- `LUDecomposition::rows`
+ * (decomposition/mod.rs:27-143).  L and U come back by ROW of the position space (lower_start / upper_start: m + 1 entries),
+ * strictly triangular parts, U's diagonal apart; depth_* = longest dependency chain of the two triangular solves. */
+int32_t relp_lu_factor_host(int32_t m, const int64_t* column_start, const int32_t* row_index, const double* value,
+                            double pivot_threshold, int32_t reference_ties, int64_t capacity, int32_t* row_permutation,
+                            int32_t* column_permutation, int64_t* lower_start, int32_t* lower_column, double* lower_value,
+                            int64_t* upper_start, int32_t* upper_column, double* upper_value, double* upper_diagonal,
+                            int32_t* depth_lower, int32_t* depth_upper);
+
+
 /* Version / build info ("relp_amd <ver> gfx950"). */
 const char* relp_version(void);
 

@@ -1,0 +1,200 @@
+"""ctypes binding of the stand-alone ``BasisInverse`` object (``relp_bi_*`` in ``include/relp_amd.h``).
+
+Mirrors the reference's trait ``BasisInverse`` (tableau/inverse_maintenance/carry/mod.rs:69-169) as implemented by
+``LUDecomposition`` (carry/lower_upper/mod.rs): every method goes through the C ABI into the HIP kernels of
+``relp_amd/csrc/lu.hip``.  ``lu_factor_host`` is the host-only factorisation step (no device needed).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .api import OK, RelpError, _ptr, lib
+
+
+class BiOptions(C.Structure):
+    _fields_ = [("device", C.c_int32), ("refactor_period", C.c_int32), ("pivot_threshold", C.c_double),
+                ("reference_ties", C.c_int32), ("reserved", C.c_int32)]
+
+
+def default_bi_options(**overrides):
+    options = BiOptions()
+    lib().relp_bi_options_default(C.byref(options))
+    for key, value in overrides.items():
+        if not hasattr(options, key):
+            raise AttributeError(key)
+        setattr(options, key, value)
+    return options
+
+
+def _sparse(pairs):
+    pairs = list(pairs)
+    index = np.array([i for i, _ in pairs] or [0], dtype=np.int32)
+    value = np.array([float(v) for _, v in pairs] or [0.0], dtype=np.float64)
+    return len(pairs), index, value
+
+
+def _csc(columns):
+    start = np.zeros(len(columns) + 1, dtype=np.int64)
+    rows, vals = [], []
+    for j, column in enumerate(columns):
+        for i, v in column:
+            rows.append(int(i))
+            vals.append(float(v))
+        start[j + 1] = len(rows)
+    return start, np.array(rows or [0], dtype=np.int32), np.array(vals or [0.0], dtype=np.float64)
+
+
+class BasisInverse:
+    """``LUDecomposition`` on the device.  Construct with :meth:`identity` or :meth:`invert`."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lib().relp_bi_last_error.restype = C.c_char_p
+        lib().relp_bi_last_error.argtypes = [C.c_void_p]
+
+    # ---- constructors (carry/mod.rs:83-92) ----------------------------------------------------------------------
+    @classmethod
+    def identity(cls, m, **options):
+        handle = C.c_void_p()
+        opts = default_bi_options(**options)
+        status = lib().relp_bi_identity(C.byref(opts), int(m), C.byref(handle))
+        cls._check_static(status)
+        return cls(handle)
+
+    @classmethod
+    def invert(cls, columns, **options):
+        """``columns``: m sparse columns ``[(row, value), ...]`` in basis order."""
+        start, rows, vals = _csc(columns)
+        handle = C.c_void_p()
+        opts = default_bi_options(**options)
+        status = lib().relp_bi_invert(C.byref(opts), len(columns), _ptr(start, C.c_int64), _ptr(rows, C.c_int32),
+                                      _ptr(vals, C.c_double), C.byref(handle))
+        cls._check_static(status)
+        return cls(handle)
+
+    @staticmethod
+    def _check_static(status):
+        if status != OK:
+            lib().relp_bi_last_error.restype = C.c_char_p
+            lib().relp_bi_last_error.argtypes = [C.c_void_p]
+            raise RelpError(status, (lib().relp_bi_last_error(None) or b"").decode())
+
+    def _check(self, status):
+        if status != OK:
+            raise RelpError(status, (lib().relp_bi_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            lib().relp_bi_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the trait's operations -----------------------------------------------------------------------------------
+    def m(self):
+        m = C.c_int32()
+        self._check(lib().relp_bi_m(self._h, C.byref(m)))
+        return m.value
+
+    def left_multiply_by_basis_inverse(self, column):
+        nnz, index, value = _sparse(column)
+        out = np.zeros(self.m())
+        self._check(lib().relp_bi_left_multiply(self._h, nnz, _ptr(index, C.c_int32), _ptr(value, C.c_double), _ptr(out, C.c_double)))
+        return out
+
+    def right_multiply_by_basis_inverse(self, row):
+        nnz, index, value = _sparse(row)
+        out = np.zeros(self.m())
+        self._check(lib().relp_bi_right_multiply(self._h, nnz, _ptr(index, C.c_int32), _ptr(value, C.c_double), _ptr(out, C.c_double)))
+        return out
+
+    def basis_inverse_row(self, row):
+        out = np.zeros(self.m())
+        self._check(lib().relp_bi_basis_inverse_row(self._h, int(row), _ptr(out, C.c_double)))
+        return out
+
+    def generate_element(self, i, column):
+        nnz, index, value = _sparse(column)
+        element, some = C.c_double(), C.c_int32()
+        self._check(lib().relp_bi_generate_element(self._h, int(i), nnz, _ptr(index, C.c_int32), _ptr(value, C.c_double),
+                                                   C.byref(element), C.byref(some)))
+        return element.value if some.value else None
+
+    def change_basis(self, pivot_row_index):
+        self._check(lib().relp_bi_change_basis(self._h, int(pivot_row_index)))
+
+    def should_refactor(self):
+        flag = C.c_int32()
+        self._check(lib().relp_bi_should_refactor(self._h, C.byref(flag)))
+        return bool(flag.value)
+
+    def remove_basis_part(self, indices):
+        idx = np.array(list(indices) or [0], dtype=np.int32)
+        self._check(lib().relp_bi_remove_basis_part(self._h, len(list(indices)), _ptr(idx, C.c_int32)))
+
+    def statistics(self):
+        nl, nu = C.c_int64(), C.c_int64()
+        dl, du, upd = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(lib().relp_bi_statistics(self._h, C.byref(nl), C.byref(nu), C.byref(dl), C.byref(du), C.byref(upd)))
+        return {"nnz_lower": nl.value, "nnz_upper": nu.value, "depth_lower": dl.value, "depth_upper": du.value, "updates": upd.value}
+
+    def factors(self):
+        """The factors in the reference's layout (lower_upper/mod.rs:36-58) as plain Python lists."""
+        m = self.m()
+        stats = self.statistics()
+        cap = 4 * (stats["nnz_lower"] + stats["nnz_upper"] + (stats["updates"] + 2) * (m + 2)) + 64
+        rp, cp = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        ls, us, es = np.zeros(cap, np.int64), np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+        lr, ur, ep, ei = (np.zeros(cap, np.int32) for _ in range(4))
+        lv, uv, ud, ev = (np.zeros(cap, np.float64) for _ in range(4))
+        k = C.c_int32()
+        self._check(lib().relp_bi_get_factors(
+            self._h, cap, _ptr(rp, C.c_int32), _ptr(cp, C.c_int32), _ptr(ls, C.c_int64), _ptr(lr, C.c_int32), _ptr(lv, C.c_double),
+            _ptr(us, C.c_int64), _ptr(ur, C.c_int32), _ptr(uv, C.c_double), _ptr(ud, C.c_double), C.byref(k),
+            _ptr(es, C.c_int64), _ptr(ep, C.c_int32), _ptr(ei, C.c_int32), _ptr(ev, C.c_double)))
+        lower = [[(int(lr[e]), float(lv[e])) for e in range(ls[j], ls[j + 1])] for j in range(m)]
+        upper = [[(int(ur[e]), float(uv[e])) for e in range(us[j], us[j + 1])] for j in range(m)]
+        etas = [(int(ep[q]), [(int(ei[e]), float(ev[e])) for e in range(es[q], es[q + 1])]) for q in range(k.value)]
+        return {"row_permutation": [int(v) for v in rp[:m]], "column_permutation": [int(v) for v in cp[:m]],
+                "lower_triangular": lower[:m - 1], "upper_triangular": upper[1:], "upper_diagonal": [float(v) for v in ud[:m]],
+                "updates": etas}
+
+
+def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False):
+    """Host-only ``LUDecomposition::rows`` (decomposition/mod.rs:27-143).  Returns a dict: ``rowpos``, ``colpos``, L and U as
+    lists of rows ``[(column, value)]`` of the position space, ``diag`` and the dependency depths."""
+    m = len(columns)
+    start, rows, vals = _csc(columns)
+    nnz = int(start[-1])
+    cap = 64 + 4 * m + 16 * nnz
+    while True:
+        rp, cp = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        ls, us = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+        lc, uc = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        lv, uv, ud = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        dl, du = C.c_int32(), C.c_int32()
+        status = lib().relp_lu_factor_host(
+            m, _ptr(start, C.c_int64), _ptr(rows, C.c_int32), _ptr(vals, C.c_double), C.c_double(pivot_threshold),
+            int(bool(reference_ties)), cap, _ptr(rp, C.c_int32), _ptr(cp, C.c_int32), _ptr(ls, C.c_int64), _ptr(lc, C.c_int32),
+            _ptr(lv, C.c_double), _ptr(us, C.c_int64), _ptr(uc, C.c_int32), _ptr(uv, C.c_double), _ptr(ud, C.c_double),
+            C.byref(dl), C.byref(du))
+        if status == OK:
+            break
+        lib().relp_bi_last_error.restype = C.c_char_p
+        lib().relp_bi_last_error.argtypes = [C.c_void_p]
+        message = (lib().relp_bi_last_error(None) or b"").decode()
+        if "capacity" in message and cap < (1 << 28):
+            cap *= 4
+            continue
+        raise RelpError(status, message)
+    return {
+        "rowpos": [int(v) for v in rp[:m]], "colpos": [int(v) for v in cp[:m]],
+        "lower_rows": [[(int(lc[e]), float(lv[e])) for e in range(ls[i], ls[i + 1])] for i in range(m)],
+        "upper_rows": [[(int(uc[e]), float(uv[e])) for e in range(us[i], us[i + 1])] for i in range(m)],
+        "diag": [float(v) for v in ud[:m]], "depth_lower": dl.value, "depth_upper": du.value,
+        "nnz_lower": int(ls[m]), "nnz_upper": int(us[m]),
+    }

@@ -1,0 +1,202 @@
+// extern "C" boundary of the stand-alone `BasisInverse` (include/relp_amd.h, section "BasisInverse as an object").
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "lu.hpp"
+#include "solver.hpp"
+
+using namespace relp;
+
+struct relp_basis_inverse {
+    std::unique_ptr<LuBasis> lu;
+    std::string error;
+};
+
+namespace {
+thread_local std::string g_bi_error;
+
+template <class F>
+int32_t guarded_bi(relp_basis_inverse* h, F&& f) {
+    auto note = [&](const char* what) {
+        g_bi_error = what;
+        if (h) h->error = what;
+    };
+    try {
+        f();
+        return RELP_OK;
+    } catch (const DeviceError& e) {
+        note(e.what());
+        return RELP_ERR_DEVICE;
+    } catch (const std::invalid_argument& e) {
+        note(e.what());
+        return RELP_ERR_ARGUMENT;
+    } catch (const std::logic_error& e) {
+        note(e.what());
+        return RELP_ERR_STATE;
+    } catch (const std::bad_alloc& e) {
+        note(e.what());
+        return RELP_ERR_STATE;
+    } catch (const std::exception& e) {
+        note(e.what());
+        return RELP_ERR_NUMERICAL;
+    }
+}
+LuOptions lu_options_of(const relp_bi_options* o) {
+    LuOptions lo;
+    if (o) {
+        lo.threshold = o->pivot_threshold;
+        lo.reference_ties = o->reference_ties != 0;
+    }
+    return lo;
+}
+template <class T, class U>
+bool copy_out(const std::vector<T>& src, U* dst, int64_t capacity) {
+    if ((int64_t)src.size() > capacity) return false;
+    if (dst)
+        for (size_t k = 0; k < src.size(); ++k) dst[k] = (U)src[k];
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t relp_bi_options_default(relp_bi_options* o) {
+    if (!o) return RELP_ERR_ARGUMENT;
+    std::memset(o, 0, sizeof(*o));
+    o->device = 0;
+    o->refactor_period = 31;   // lower_upper/mod.rs:249-252
+    o->pivot_threshold = 0.1;
+    o->reference_ties = 0;
+    return RELP_OK;
+}
+const char* relp_bi_last_error(const relp_basis_inverse* bi) { return bi ? bi->error.c_str() : g_bi_error.c_str(); }
+
+int32_t relp_bi_identity(const relp_bi_options* options, int32_t m, relp_basis_inverse** out) {
+    if (!out) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<relp_basis_inverse> h(new relp_basis_inverse());
+    const int32_t status = guarded_bi(h.get(), [&] {
+        h->lu.reset(new LuBasis(options ? options->device : 0, m, lu_options_of(options), options ? options->refactor_period : 31));
+        h->lu->identity();
+    });
+    if (status == RELP_OK) *out = h.release();
+    return status;
+}
+int32_t relp_bi_invert(const relp_bi_options* options, int32_t m, const int64_t* column_start, const int32_t* row_index,
+                       const double* value, relp_basis_inverse** out) {
+    if (!out || !column_start || (column_start[m > 0 ? m : 0] > 0 && (!row_index || !value))) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<relp_basis_inverse> h(new relp_basis_inverse());
+    const int32_t status = guarded_bi(h.get(), [&] {
+        h->lu.reset(new LuBasis(options ? options->device : 0, m, lu_options_of(options), options ? options->refactor_period : 31));
+        static_assert(sizeof(long long) == sizeof(int64_t), "");
+        h->lu->invert(reinterpret_cast<const long long*>(column_start), row_index, value);
+    });
+    if (status == RELP_OK) *out = h.release();
+    return status;
+}
+int32_t relp_bi_free(relp_basis_inverse* bi) {
+    delete bi;
+    return RELP_OK;
+}
+int32_t relp_bi_m(const relp_basis_inverse* bi, int32_t* m) {
+    if (!bi || !m) return RELP_ERR_ARGUMENT;
+    *m = bi->lu->m();
+    return RELP_OK;
+}
+int32_t relp_bi_left_multiply(relp_basis_inverse* bi, int32_t nnz, const int32_t* row_index, const double* value, double* out_m) {
+    if (!bi || !out_m) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] { bi->lu->left_multiply(nnz, row_index, value, out_m); });
+}
+int32_t relp_bi_right_multiply(relp_basis_inverse* bi, int32_t nnz, const int32_t* index, const double* value, double* out_m) {
+    if (!bi || !out_m) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] { bi->lu->right_multiply(nnz, index, value, out_m); });
+}
+int32_t relp_bi_basis_inverse_row(relp_basis_inverse* bi, int32_t row, double* out_m) {
+    if (!bi || !out_m) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] {
+        if (row < 0 || row >= bi->lu->m()) throw std::invalid_argument("row out of range");
+        bi->lu->basis_inverse_row(row, out_m);
+    });
+}
+int32_t relp_bi_generate_element(relp_basis_inverse* bi, int32_t i, int32_t nnz, const int32_t* row_index, const double* value,
+                                 double* element, int32_t* is_some) {
+    if (!bi || !element) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] {
+        const bool some = bi->lu->generate_element(i, nnz, row_index, value, element);
+        if (is_some) *is_some = some ? 1 : 0;
+    });
+}
+int32_t relp_bi_change_basis(relp_basis_inverse* bi, int32_t pivot_row_index) {
+    if (!bi) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] { bi->lu->change_basis(pivot_row_index); });
+}
+int32_t relp_bi_should_refactor(relp_basis_inverse* bi, int32_t* should) {
+    if (!bi || !should) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] { *should = bi->lu->should_refactor() ? 1 : 0; });
+}
+int32_t relp_bi_remove_basis_part(relp_basis_inverse* bi, int32_t count, const int32_t* indices) {
+    if (!bi || (count > 0 && !indices) || count < 0) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] { bi->lu->remove_basis_part(count, indices); });
+}
+int32_t relp_bi_statistics(relp_basis_inverse* bi, int64_t* nnz_lower, int64_t* nnz_upper, int32_t* depth_lower,
+                           int32_t* depth_upper, int32_t* nr_updates) {
+    if (!bi) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] {
+        if (nnz_lower) *nnz_lower = bi->lu->nnz_l();
+        if (nnz_upper) *nnz_upper = bi->lu->nnz_u();
+        if (depth_lower) *depth_lower = bi->lu->depth_l();
+        if (depth_upper) *depth_upper = bi->lu->depth_u();
+        if (nr_updates) *nr_updates = bi->lu->updates();
+    });
+}
+
+int32_t relp_bi_get_factors(relp_basis_inverse* bi, int64_t capacity, int32_t* row_permutation, int32_t* column_permutation,
+                            int64_t* lower_start, int32_t* lower_row, double* lower_value, int64_t* upper_start,
+                            int32_t* upper_row, double* upper_value, double* upper_diagonal, int32_t* nr_updates,
+                            int64_t* eta_start, int32_t* eta_pivot, int32_t* eta_index, double* eta_value) {
+    if (!bi) return RELP_ERR_ARGUMENT;
+    return guarded_bi(bi, [&] {
+        const LuBasis::Factors f = bi->lu->factors();
+        const bool ok = copy_out(f.row_permutation, row_permutation, capacity) && copy_out(f.column_permutation, column_permutation, capacity) &&
+                        copy_out(f.l_start, lower_start, capacity) && copy_out(f.l_row, lower_row, capacity) && copy_out(f.l_val, lower_value, capacity) &&
+                        copy_out(f.u_start, upper_start, capacity) && copy_out(f.u_row, upper_row, capacity) && copy_out(f.u_val, upper_value, capacity) &&
+                        copy_out(f.upper_diagonal, upper_diagonal, capacity) && copy_out(f.eta_start, eta_start, capacity) &&
+                        copy_out(f.eta_pivot, eta_pivot, capacity) && copy_out(f.eta_index, eta_index, capacity) &&
+                        copy_out(f.eta_value, eta_value, capacity);
+        if (!ok) throw std::invalid_argument("capacity too small");
+        if (nr_updates) *nr_updates = (int32_t)f.eta_pivot.size();
+    });
+}
+
+// ---- host only: the factorisation step alone (no device) ----------------------------------------------------------------
+int32_t relp_lu_factor_host(int32_t m, const int64_t* column_start, const int32_t* row_index, const double* value,
+                            double pivot_threshold, int32_t reference_ties, int64_t capacity, int32_t* row_permutation,
+                            int32_t* column_permutation, int64_t* lower_start, int32_t* lower_column, double* lower_value,
+                            int64_t* upper_start, int32_t* upper_column, double* upper_value, double* upper_diagonal,
+                            int32_t* depth_lower, int32_t* depth_upper) {
+    if (m < 1 || !column_start) return RELP_ERR_ARGUMENT;
+    return guarded_bi(nullptr, [&] {
+        std::vector<int> cs(m + 1);
+        for (int j = 0; j <= m; ++j) cs[j] = (int)column_start[j];
+        for (int64_t e = 0; e < column_start[m]; ++e)
+            if (row_index[e] < 0 || row_index[e] >= m) throw std::invalid_argument("row index out of range");
+        LuOptions lo;
+        lo.threshold = pivot_threshold;
+        lo.reference_ties = reference_ties != 0;
+        const HostLU f = lu_factor(m, cs.data(), row_index, value, lo);
+        if (f.singular) throw std::runtime_error("singular basis");
+        const bool ok = copy_out(f.rowpos, row_permutation, capacity) && copy_out(f.colpos, column_permutation, capacity) &&
+                        copy_out(f.l_start, lower_start, capacity) && copy_out(f.l_col, lower_column, capacity) && copy_out(f.l_val, lower_value, capacity) &&
+                        copy_out(f.u_start, upper_start, capacity) && copy_out(f.u_col, upper_column, capacity) && copy_out(f.u_val, upper_value, capacity) &&
+                        copy_out(f.diag, upper_diagonal, capacity);
+        if (!ok) throw std::invalid_argument("capacity too small");
+        int dl = 0, du = 0;
+        lu_depths(f, &dl, &du);
+        if (depth_lower) *depth_lower = dl;
+        if (depth_upper) *depth_upper = du;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Device-resident LU basis factorisation with Forrest-Tomlin updates (the reference's `LUDecomposition`,
+// tableau/inverse_maintenance/carry/lower_upper/mod.rs:36-58) -- data layout and host handle.  Kernels: lu.hip.
+//
+// Position space: index k in [0, m) is the pivot position at refactorisation time (`P B Q = L U`: rowpos = P.forward,
+// colpos = Q.forward, decomposition/mod.rs:129-133).  It is STATIC between refactorisations: where the reference rotates
+// rows and columns physically after every update (`RotateToBack`, permutation/rotate_to_back.rs:15-122) the device keeps
+// the logical order in `rank` / `seq` (rank[k] = the reference's index of position k after all rotations so far).
+//
+// L never changes between refactorisations and is held in both orientations (rows for FTRAN, columns for BTRAN, each a
+// gather).  U changes with every update and is held in both orientations too:
+//   rows:    base segment [u_rstart[i], + u_rlen[i])  +  append segment [u_app_first + i * u_app_stride, + u_app_len[i])
+//            (an update appends at most one entry -- the spike's -- to a row, so the stride is the update capacity);
+//   columns: [u_cstart[j], + u_clen[j]); a replaced column (the spike) is written to the arena behind the base columns.
+// Row etas (eta_file.rs:14-18) live in one arena: eta k = pivot position eta_pivot[k], entries [eta_start[k], eta_start[k+1]).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "lu_host.hpp"
+
+namespace relp {
+
+enum : int { LU_N_UPDATES = 0, LU_UC_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_STATE_WORDS = 8 };
+enum : int { LU_FLAG_UNSTABLE = 1, LU_FLAG_OVERFLOW = 2 };
+
+struct DeviceLU {
+    int m = 0;
+    int max_updates = 0;  // capacity of the eta / append areas (the refactorisation period never exceeds it)
+    int* rowpos = nullptr;
+    int* colpos = nullptr;
+    int* l_rstart = nullptr; int* l_rcol = nullptr; double* l_rval = nullptr;  // strict L by rows   (FTRAN gather)
+    int* l_cstart = nullptr; int* l_crow = nullptr; double* l_cval = nullptr;  // strict L by columns (BTRAN gather)
+    int* u_rstart = nullptr; int* u_rlen = nullptr; int* u_rcol = nullptr; double* u_rval = nullptr;
+    int* u_app_len = nullptr; int u_app_first = 0; int u_app_stride = 0;
+    int* u_cstart = nullptr; int* u_clen = nullptr; int* u_crow = nullptr; double* u_cval = nullptr;
+    int u_c_capacity = 0;
+    double* diag = nullptr;
+    int* rank = nullptr;  // position -> logical index (the reference's rotated index)
+    int* seq = nullptr;   // logical index -> position
+    int* eta_start = nullptr; int* eta_pivot = nullptr; int* eta_idx = nullptr; double* eta_val = nullptr;
+    int eta_capacity = 0;
+    double* spike = nullptr;  // [m] position space: the FTRAN intermediate before the U solve (mod.rs:196 `spike`)
+    int* state = nullptr;     // LU_* words
+};
+
+// Owns the device (and pinned staging) memory of one factorisation; re-used across refactorisations.
+class LuFactors {
+public:
+    LuFactors() = default;
+    ~LuFactors();
+    LuFactors(const LuFactors&) = delete;
+    LuFactors& operator=(const LuFactors&) = delete;
+    // uploads the factors (one host-to-device copy) and resets the update state; stream-ordered
+    void upload(const HostLU& f, int max_updates, hipStream_t stream);
+    const DeviceLU& device() const { return d_; }
+    size_t lds_bytes(int nrhs) const;  // dynamic LDS of the solve kernels for this m
+    long long nnz_l = 0, nnz_u = 0;
+    int depth_l = 0, depth_u = 0;
+
+private:
+    void reserve(size_t device_bytes, size_t staging_bytes);
+    DeviceLU d_;
+    char* dev_ = nullptr;
+    size_t dev_capacity_ = 0;
+    char* staging_ = nullptr;
+    size_t staging_capacity_ = 0;
+};
+
+// kernels (lu.hip); all single-workgroup, stream-ordered
+constexpr int LU_THREADS = 1024;
+bool lu_fits_lds(int m);
+// FTRAN of a sparse column (device arrays rows / vals, original row indices): out[slot] (m doubles); the spike stays in lu.spike
+void launch_lu_ftran(const DeviceLU& lu, const int* rows, const double* vals, int nnz, double* out, int keep_spike, hipStream_t s);
+// FTRAN of a dense right-hand side (original row order)
+void launch_lu_ftran_dense(const DeviceLU& lu, const double* rhs, double* out, hipStream_t s);
+// BTRAN of a sparse / dense row vector given per basis slot; out per original row
+void launch_lu_btran(const DeviceLU& lu, const int* slots, const double* vals, int nnz, double* out, hipStream_t s);
+void launch_lu_btran_dense(const DeviceLU& lu, const double* in_slots, double* out, hipStream_t s);
+// Forrest-Tomlin update for pivot slot p with the spike of the last FTRAN (mod.rs:94-178)
+void launch_lu_update(const DeviceLU& lu, int p, hipStream_t s);
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A `BasisInverse` that exists without a loaded LP: the reference's `LUDecomposition<F>` as an object
+// (carry/mod.rs:69-169 trait; lower_upper/mod.rs:60-272 impl).  One handle = one HIP stream on one device.
+// ---------------------------------------------------------------------------------------------------------------------
+class LuBasis {
+public:
+    LuBasis(int device, int m, const LuOptions& options, int refactor_period);
+    ~LuBasis();
+    int m() const { return m_; }
+    void identity();                                                                     // BasisInverse::identity
+    void invert(const long long* col_start, const int* rows, const double* vals);       // BasisInverse::invert
+    void left_multiply(int nnz, const int* rows, const double* vals, double* out_m);    // FTRAN; keeps column + spike
+    void right_multiply(int nnz, const int* slots, const double* vals, double* out_m);  // BTRAN
+    void basis_inverse_row(int slot, double* out_m);
+    bool generate_element(int i, int nnz, const int* rows, const double* vals, double* out);  // false: structural zero
+    void change_basis(int pivot_row);                                                    // Forrest-Tomlin, last left_multiply
+    bool should_refactor();                                                              // updates > period - 1
+    void remove_basis_part(int count, const int* indices);                               // RemoveBasisPart (refactors)
+    int updates();
+    int flags();
+    // Factors in the reference's layout (indices through the rotations so far), for parity tests: see relp_bi_get_factors.
+    struct Factors {
+        std::vector<int> row_permutation, column_permutation;
+        std::vector<long long> l_start, u_start, eta_start;
+        std::vector<int> l_row, u_row, eta_pivot, eta_index;
+        std::vector<double> l_val, u_val, upper_diagonal, eta_value;
+    };
+    Factors factors();
+    long long nnz_l() const { return lu_.nnz_l; }
+    long long nnz_u() const { return lu_.nnz_u; }
+    int depth_l() const { return lu_.depth_l; }
+    int depth_u() const { return lu_.depth_u; }
+
+private:
+    void factor_and_upload();
+    int device_, m_, period_;
+    LuOptions options_;
+    hipStream_t stream_ = nullptr;
+    LuFactors lu_;
+    std::vector<std::vector<std::pair<int, double>>> columns_;  // current basis columns, slot order (original rows)
+    std::vector<std::pair<int, double>> last_column_;
+    bool have_spike_ = false;
+    int* d_idx_ = nullptr;
+    double* d_val_ = nullptr;
+    double* d_out_ = nullptr;
+};
+
+}  // namespace relp

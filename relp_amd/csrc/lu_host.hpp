@@ -1,0 +1,311 @@
+// Host side of the LU basis factorisation `P B Q = L U`: sparse right-looking Gaussian elimination with Markowitz pivoting.
+//
+// Replaces (paths relative to /root/reference/src/algorithm/two_phase/tableau/inverse_maintenance/carry/lower_upper/):
+//   LUDecomposition::invert / LUDecomposition::rows     mod.rs:78-92, decomposition/mod.rs:27-143
+//   Markowitz::choose_pivot                             decomposition/pivoting.rs:45-81
+//   subtract_multiple_of_row_from_other_row             decomposition/mod.rs:146-210
+//
+// The reference eliminates in exact arithmetic, so any non-zero pivot is acceptable and its rule is purely structural:
+// the minimum of (r_i - 1)(c_j - 1) over the remaining entries, ties to the first entry in (column, row) order of the
+// CURRENT (swapped) positions.  `reference_ties` reproduces that choice exactly (with threshold 0 the factors are the
+// reference's, entry for entry: tests/test_lu_host.py replays its exact-factor known-answer tests).  The f64 product adds
+// what floating point needs and the reference does not: a relative row threshold on the pivot magnitude and a limited
+// search (the rows / columns of the lowest counts), the standard sparse-LU practice.
+//
+// The symbolic work is inherently sequential and tiny (25FV47: m = 821, a few 10^4 operations), so it runs on the host once
+// per refactorisation; the numeric factors go to the device in one transfer (DeviceLU, lu.hip) where the per-pivot FTRAN /
+// BTRAN / Forrest-Tomlin update run.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace relp {
+
+struct LuOptions {
+    double threshold = 0.1;        // accept a_ij only if |a_ij| >= threshold * max_k |a_ik| (0: any non-zero, the reference)
+    bool reference_ties = false;   // full search with the reference's tie rule (pivoting.rs:60-80)
+    int search_limit = 4;          // rows + columns examined with an acceptable candidate before the search stops
+};
+
+struct HostLU {
+    int m = 0;
+    bool singular = false;
+    std::vector<int> rowpos;  // P.forward: original row  -> position in L / U   (decomposition/mod.rs:129-133)
+    std::vector<int> colpos;  // Q.forward: basis slot    -> position in L / U
+    // strictly lower part of L by rows of the position space (unit diagonal implied), entries (j < i, l_ij)
+    std::vector<int> l_start, l_col;
+    std::vector<double> l_val;
+    // strictly upper part of U by rows, entries (j > i, u_ij); separate diagonal (mod.rs:36-58 `upper_diagonal`)
+    std::vector<int> u_start, u_col;
+    std::vector<double> u_val;
+    std::vector<double> diag;
+    long long nnz_l() const { return (long long)l_col.size(); }
+    long long nnz_u() const { return (long long)u_col.size(); }
+};
+
+namespace lu_detail {
+struct Entry {
+    int col;
+    double val;
+};
+// doubly linked bucket lists of the active rows (or columns) by their current count
+struct Buckets {
+    std::vector<int> head, next, prev, count;
+    void init(int m) {
+        head.assign(m + 2, -1);
+        next.assign(m, -1);
+        prev.assign(m, -1);
+        count.assign(m, 0);
+    }
+    void insert(int x, int c) {
+        count[x] = c;
+        prev[x] = -1;
+        next[x] = head[c];
+        if (head[c] >= 0) prev[head[c]] = x;
+        head[c] = x;
+    }
+    void remove(int x) {
+        const int c = count[x];
+        if (prev[x] >= 0) next[prev[x]] = next[x];
+        else head[c] = next[x];
+        if (next[x] >= 0) prev[next[x]] = prev[x];
+        next[x] = prev[x] = -1;
+    }
+    void move(int x, int c) {
+        if (count[x] == c) return;
+        remove(x);
+        insert(x, c);
+    }
+};
+}  // namespace lu_detail
+
+// Basis columns in slot order, CSC (rows of a column in any order, no duplicates).
+inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const double* value, const LuOptions& opt) {
+    using lu_detail::Buckets;
+    using lu_detail::Entry;
+    HostLU f;
+    f.m = m;
+    f.rowpos.assign(m, -1);
+    f.colpos.assign(m, -1);
+    f.diag.assign(m, 0.0);
+    std::vector<std::vector<Entry>> R(m);   // active entries of the active rows
+    std::vector<std::vector<int>> C(m);     // active rows of every active column (pattern)
+    for (int j = 0; j < m; ++j)
+        for (int e = col_start[j]; e < col_start[j + 1]; ++e) {
+            if (value[e] == 0.0) continue;
+            R[row_index[e]].push_back({j, value[e]});
+            C[j].push_back(row_index[e]);
+        }
+    Buckets rb, cb;
+    rb.init(m);
+    cb.init(m);
+    for (int i = 0; i < m; ++i) {
+        if (R[i].empty() || C[i].empty()) f.singular = true;
+        rb.insert(i, (int)R[i].size());
+        cb.insert(i, (int)C[i].size());
+    }
+    if (f.singular) return f;
+    // current positions of the not yet pivoted rows / columns (the reference swaps the pivot to (k, k) at every step,
+    // decomposition/mod.rs:224-273; only the tie rule looks at them)
+    std::vector<int> rpos(m), cpos(m), row_at(m), col_at(m);
+    for (int i = 0; i < m; ++i) rpos[i] = cpos[i] = row_at[i] = col_at[i] = i;
+    std::vector<char> row_done(m, 0), col_done(m, 0);
+    // L by (row, step, ratio) and U rows by step, in original indices until the end
+    std::vector<std::vector<Entry>> Lrow(m);              // Lrow[orig row] = (step k, ratio)
+    std::vector<std::vector<Entry>> Urow(m);              // Urow[k] = (orig col, value)
+    std::vector<int> where(m, -1);                        // scatter workspace: column -> index in the row being edited
+
+    auto row_max = [&](int i) {
+        double mx = 0.0;
+        for (const Entry& e : R[i]) mx = std::max(mx, std::fabs(e.val));
+        return mx;
+    };
+
+    for (int k = 0; k < m; ++k) {
+        // ---- Markowitz search --------------------------------------------------------------------------------
+        long long best_score = std::numeric_limits<long long>::max();
+        int bi = -1, bj = -1, bjp = 0, bip = 0;
+        double bval = 0.0;
+        int examined = 0;
+        auto consider = [&](int i, int j, double v, long long score, double rmax) {
+            if (v == 0.0) return;
+            if (std::fabs(v) < opt.threshold * rmax) return;
+            bool take;
+            if (opt.reference_ties) {
+                take = score < best_score || (score == best_score && (cpos[j] < bjp || (cpos[j] == bjp && rpos[i] < bip)));
+            } else {
+                take = score < best_score || (score == best_score && std::fabs(v) > std::fabs(bval));
+            }
+            if (bi < 0 || take) {
+                best_score = score;
+                bi = i;
+                bj = j;
+                bjp = cpos[j];
+                bip = rpos[i];
+                bval = v;
+            }
+        };
+        for (int nz = 1; nz <= m - k; ++nz) {
+            const long long bound = (long long)(nz - 1) * (nz - 1);
+            if (bi >= 0 && (opt.reference_ties ? best_score < bound : best_score <= bound)) break;
+            for (int j = cb.head[nz]; j >= 0; j = cb.next[j]) {
+                for (int i : C[j]) {
+                    double v = 0.0;
+                    for (const Entry& e : R[i])
+                        if (e.col == j) { v = e.val; break; }
+                    // a column singleton needs no elimination: any non-zero is a stable pivot
+                    consider(i, j, v, (long long)(rb.count[i] - 1) * (nz - 1), nz == 1 ? 0.0 : row_max(i));
+                }
+                if (!opt.reference_ties && bi >= 0 && (best_score == 0 || ++examined >= opt.search_limit)) goto found;
+            }
+            for (int i = rb.head[nz]; i >= 0; i = rb.next[i]) {
+                const double rmax = row_max(i);
+                for (const Entry& e : R[i]) consider(i, e.col, e.val, (long long)(nz - 1) * (cb.count[e.col] - 1), rmax);
+                if (!opt.reference_ties && bi >= 0 && (best_score == 0 || ++examined >= opt.search_limit)) goto found;
+            }
+        }
+    found:
+        if (bi < 0) {
+            f.singular = true;
+            return f;
+        }
+        const int pi = bi, pj = bj;
+        const double pv = bval;
+        // ---- swap to (k, k): positions only (decomposition/mod.rs:224-273) ------------------------------------
+        {
+            const int other_row = row_at[k], pr = rpos[pi];
+            row_at[pr] = other_row;
+            rpos[other_row] = pr;
+            row_at[k] = pi;
+            rpos[pi] = k;
+            const int other_col = col_at[k], pc = cpos[pj];
+            col_at[pc] = other_col;
+            cpos[other_col] = pc;
+            col_at[k] = pj;
+            cpos[pj] = k;
+        }
+        f.rowpos[pi] = k;
+        f.colpos[pj] = k;
+        f.diag[k] = pv;
+        row_done[pi] = 1;
+        col_done[pj] = 1;
+        rb.remove(pi);
+        cb.remove(pj);
+        // ---- the pivot row becomes row k of U; it leaves the column patterns ----------------------------------
+        std::vector<Entry> prow;
+        prow.reserve(R[pi].size());
+        for (const Entry& e : R[pi]) {
+            if (e.col == pj) continue;
+            prow.push_back(e);
+            std::vector<int>& cj = C[e.col];
+            for (size_t t = 0; t < cj.size(); ++t)
+                if (cj[t] == pi) { cj[t] = cj.back(); cj.pop_back(); break; }
+            cb.move(e.col, (int)cj.size());
+        }
+        Urow[k] = prow;
+        // ---- eliminate column pj from the other rows (decomposition/mod.rs:71-100) ----------------------------
+        for (int i2 : C[pj]) {
+            if (i2 == pi) continue;
+            std::vector<Entry>& row = R[i2];
+            double a = 0.0;
+            for (size_t t = 0; t < row.size(); ++t)
+                if (row[t].col == pj) { a = row[t].val; row[t] = row.back(); row.pop_back(); break; }
+            const double ratio = a / pv;
+            Lrow[i2].push_back({k, ratio});
+            if (!prow.empty()) {
+                for (size_t t = 0; t < row.size(); ++t) where[row[t].col] = (int)t;
+                for (const Entry& e : prow) {
+                    const double product = ratio * e.val;
+                    const int t = where[e.col];
+                    if (t >= 0) {
+                        const double old = row[t].val;
+                        double updated = old - product;
+                        if (updated != 0.0 && !opt.reference_ties && std::fabs(updated) <= 1e-15 * (std::fabs(old) + std::fabs(product))) updated = 0.0;
+                        row[t].val = updated;  // zeros are swept below
+                    } else {
+                        row.push_back({e.col, -product});
+                        C[e.col].push_back(i2);
+                        cb.move(e.col, (int)C[e.col].size());
+                    }
+                }
+                for (size_t t = 0; t < row.size(); ++t) where[row[t].col] = -1;
+                for (size_t t = 0; t < row.size();) {  // exact cancellations leave the pattern (decomposition/mod.rs:176-186)
+                    if (row[t].val == 0.0) {
+                        std::vector<int>& cj = C[row[t].col];
+                        for (size_t s = 0; s < cj.size(); ++s)
+                            if (cj[s] == i2) { cj[s] = cj.back(); cj.pop_back(); break; }
+                        cb.move(row[t].col, (int)cj.size());
+                        row[t] = row.back();
+                        row.pop_back();
+                    } else {
+                        ++t;
+                    }
+                }
+            }
+            if (row.empty()) {
+                f.singular = true;
+                return f;
+            }
+            rb.move(i2, (int)row.size());
+        }
+        C[pj].clear();
+        R[pi].clear();
+    }
+    // ---- position space, row-major L and U ----------------------------------------------------------------------
+    f.l_start.assign(m + 1, 0);
+    f.u_start.assign(m + 1, 0);
+    for (int i = 0; i < m; ++i) f.l_start[f.rowpos[i] + 1] = (int)Lrow[i].size();
+    for (int k = 0; k < m; ++k) f.u_start[k + 1] = (int)Urow[k].size();
+    for (int k = 0; k < m; ++k) {
+        f.l_start[k + 1] += f.l_start[k];
+        f.u_start[k + 1] += f.u_start[k];
+    }
+    f.l_col.resize(f.l_start[m]);
+    f.l_val.resize(f.l_start[m]);
+    f.u_col.resize(f.u_start[m]);
+    f.u_val.resize(f.u_start[m]);
+    for (int i = 0; i < m; ++i) {
+        int dst = f.l_start[f.rowpos[i]];
+        std::sort(Lrow[i].begin(), Lrow[i].end(), [](const Entry& a, const Entry& b) { return a.col < b.col; });
+        for (const Entry& e : Lrow[i]) {
+            f.l_col[dst] = e.col;
+            f.l_val[dst++] = e.val;
+        }
+    }
+    for (int k = 0; k < m; ++k) {
+        int dst = f.u_start[k];
+        for (Entry& e : Urow[k]) e.col = f.colpos[e.col];
+        std::sort(Urow[k].begin(), Urow[k].end(), [](const Entry& a, const Entry& b) { return a.col < b.col; });
+        for (const Entry& e : Urow[k]) {
+            f.u_col[dst] = e.col;
+            f.u_val[dst++] = e.val;
+        }
+    }
+    return f;
+}
+
+// Longest dependency chain of the two triangular solves (each hop is one LDS round trip on the device, lu.hip).
+inline void lu_depths(const HostLU& f, int* depth_l, int* depth_u) {
+    std::vector<int> lev(f.m, 0);
+    int dl = 0, du = 0;
+    for (int i = 0; i < f.m; ++i) {
+        int l = 0;
+        for (int e = f.l_start[i]; e < f.l_start[i + 1]; ++e) l = std::max(l, lev[f.l_col[e]] + 1);
+        lev[i] = l;
+        dl = std::max(dl, l);
+    }
+    for (int i = f.m - 1; i >= 0; --i) {
+        int l = 0;
+        for (int e = f.u_start[i]; e < f.u_start[i + 1]; ++e) l = std::max(l, lev[f.u_col[e]] + 1);
+        lev[i] = l;
+        du = std::max(du, l);
+    }
+    // (the second loop reuses lev: rows above i were overwritten only after they were read as columns > i)
+    if (depth_l) *depth_l = dl;
+    if (depth_u) *depth_u = du;
+}
+
+}  // namespace relp

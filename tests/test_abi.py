@@ -50,3 +50,17 @@ def test_argument_errors():
     assert lib.relp_create(None, None) == relp_amd.api.ERR_ARGUMENT
     with pytest.raises(relp_amd.RelpError):
         relp_amd.Model(os.path.join(ROOT, "data", "does_not_exist.mps"))
+
+
+def test_basis_inverse_object_has_no_cpu_fallback():
+    """`relp_bi_identity` / `relp_bi_invert` need a HIP device too; only `relp_lu_factor_host` is host-only."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from relp_amd.basis_inverse import BasisInverse
+    with pytest.raises(relp_amd.RelpError) as info:
+        BasisInverse.identity(3)
+    assert info.value.status == relp_amd.api.ERR_DEVICE
+    with pytest.raises(relp_amd.RelpError) as info:
+        BasisInverse.invert([[(0, 1.0)], [(1, 1.0)]])
+    assert info.value.status == relp_amd.api.ERR_DEVICE
