@@ -49,6 +49,13 @@ typedef enum relp_pivot_rule {
     RELP_PIVOT_FIRST_PROFITABLE_MEMORY = 3 /* FirstProfitableWithMemory */
 } relp_pivot_rule;
 
+/* The two `BasisInverse` implementations of the reference (carry/mod.rs:69-169), both resident on the device. */
+typedef enum relp_carry {
+    RELP_CARRY_EXPLICIT = 0,   /* `BasisInverseRows` (carry/basis_inverse_rows.rs:21-229): explicit inverse, product-form update */
+    RELP_CARRY_LU = 1          /* `LUDecomposition` (carry/lower_upper/mod.rs:36-272): P B Q = L U, Forrest-Tomlin updates,
+                                  refactorisation every `refactor_period` updates */
+} relp_carry;
+
 typedef struct relp_options {
     int32_t device;            /* HIP device ordinal */
     int32_t pivot_rule;        /* relp_pivot_rule */
@@ -70,6 +77,12 @@ typedef struct relp_options {
                                   relp_get_basis / relp_set_basis keep speaking the reference's formulation (one column per
                                   row of MatrixData, bound rows included); the other fine-grained trait operations refer to
                                   the reduced LP */
+    int32_t carry;             /* relp_carry: which `BasisInverse` the loop maintains (the `BI` of `Carry<F, BI>`,
+                                  tests/netlib/mod.rs:62) */
+    int32_t refactor_period;   /* LU carry: Forrest-Tomlin updates between refactorisations (`should_refactor`,
+                                  lower_upper/mod.rs:249-252: the reference refactors after 31); 0 = 64 */
+    double lu_pivot_threshold; /* LU carry: relative pivot tolerance of the Markowitz factorisation (f64 needs one, the exact
+                                  reference does not); 0 = 0.1 */
 } relp_options;
 
 typedef struct relp_result {
@@ -83,6 +96,8 @@ typedef struct relp_result {
     double solve_seconds;      /* wall clock of solve_relaxation only (device-resident in, result out) */
     double certify_seconds;
     double max_residual;       /* largest |I - B Binv| entry seen by a polish */
+    int64_t refactors;         /* LU carry: refactorisations (`BasisInverse::invert`) made, and the host time they took */
+    double refactor_seconds;
 } relp_result;
 
 typedef struct relp_stats {

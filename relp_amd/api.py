@@ -17,6 +17,7 @@ OK, ERR_ARGUMENT, ERR_PARSE, ERR_DEVICE, ERR_OVERFLOW, ERR_STATE, ERR_NUMERICAL 
 FINITE_OPTIMUM, INFEASIBLE, UNBOUNDED, ITERATION_LIMIT = 1, 2, 3, 4
 STEEPEST_EDGE, DANTZIG, FIRST_PROFITABLE, FIRST_PROFITABLE_MEMORY = 0, 1, 2, 3
 STOP_NO_ENTERING, STOP_UNBOUNDED, STOP_BUDGET = 1, 2, 3
+CARRY_EXPLICIT, CARRY_LU = 0, 1
 
 
 class RelpError(RuntimeError):
@@ -29,14 +30,15 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("pivot_rule", C.c_int32), ("polish_period", C.c_int32),
                 ("pivots_per_launch", C.c_int32), ("max_pivots", C.c_int64), ("tol_dual", C.c_double),
                 ("tol_pivot", C.c_double), ("harris_delta", C.c_double), ("tol_feasible", C.c_double),
-                ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("implicit_bounds", C.c_int32)]
+                ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("implicit_bounds", C.c_int32),
+                ("carry", C.c_int32), ("refactor_period", C.c_int32), ("lu_pivot_threshold", C.c_double)]
 
 
 class Result(C.Structure):
     _fields_ = [("kind", C.c_int32), ("certified", C.c_int32), ("pivots_phase_one", C.c_int64),
                 ("pivots_phase_two", C.c_int64), ("polishes", C.c_int64), ("exact_repair_pivots", C.c_int64),
                 ("objective", C.c_double), ("solve_seconds", C.c_double), ("certify_seconds", C.c_double),
-                ("max_residual", C.c_double)]
+                ("max_residual", C.c_double), ("refactors", C.c_int64), ("refactor_seconds", C.c_double)]
 
 
 class Stats(C.Structure):

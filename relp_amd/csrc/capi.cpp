@@ -67,6 +67,9 @@ int32_t relp_options_default(relp_options* o) {
     o->use_graph = 1;
     o->verbose = 0;
     o->implicit_bounds = 0;
+    o->carry = RELP_CARRY_EXPLICIT;
+    o->refactor_period = 0;
+    o->lu_pivot_threshold = 0.0;
     return RELP_OK;
 }
 

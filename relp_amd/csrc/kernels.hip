@@ -2563,6 +2563,15 @@ void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop) {
     g_timer.start = start;
     g_timer.stop = stop;
 }
+// (kernels of another file: hand the armed event pair over, if it is meant for `which`)
+void take_launch_timer(int which, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (g_timer.which == which) {
+        g_timer.which = -1;
+        *start = g_timer.start;
+        *stop = g_timer.stop;
+    }
+}
 #define RELP_LAUNCH(WHICH, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                            \
     do {                                                                                                     \
         if (g_timer.which == (WHICH)) {                                                                      \

@@ -15,6 +15,10 @@
 // solve is a gather.  Everything is deterministic: a row adds its entries in storage order.
 #include "lu.hpp"
 
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cstdint>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         lu.state[LU_N_UPDATES] = 0;
-        lu.state[LU_UC_TOP] = lu.u_rstart[m];
+        lu.state[LU_UC_TOP] = lu.u_app_first;  // the arena of replaced columns starts behind the base capacity
         lu.state[LU_ETA_TOP] = 0;
         lu.state[LU_FLAGS] = 0;
         lu.eta_start[0] = 0;
@@ -77,25 +81,31 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
 }
 }  // namespace
 
-void LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
+bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const int m = f.m;
     const size_t nl = (size_t)f.nnz_l(), nu = (size_t)f.nnz_u();
     if (max_updates < 1) max_updates = 1;
-    // ---- uploaded prefix (compact) --------------------------------------------------------------------------------
+    // The layout depends on capacities only, so that the device addresses (and a captured hipGraph that holds them) survive
+    // a refactorisation; it changes when a factor outgrows its capacity (or m / the update capacity change).
+    bool layout_changed = m != d_.m || max_updates != d_.max_updates;
+    if (layout_changed) cap_l_ = cap_u_ = 0;
+    if (nl > cap_l_ || cap_l_ == 0) { cap_l_ = nl + nl / 2 + 256; layout_changed = true; }
+    if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
+    const size_t cl = cap_l_, cu = cap_u_;
+    // ---- uploaded prefix ----------------------------------------------------------------------------------------------
     Carver c;
     const size_t o_rowpos = c.take<int>(m), o_colpos = c.take<int>(m);
     const size_t o_lrs = c.take<int>(m + 1), o_lcs = c.take<int>(m + 1), o_urs = c.take<int>(m + 1), o_ucs = c.take<int>(m);
     const size_t o_uclen = c.take<int>(m);
-    const size_t o_lrcol = c.take<int>(nl), o_lcrow = c.take<int>(nl);
-    const size_t o_lrval = c.take<double>(nl), o_lcval = c.take<double>(nl);
     const size_t o_diag = c.take<double>(m);
+    const size_t o_lrcol = c.take<int>(cl), o_lcrow = c.take<int>(cl);
+    const size_t o_lrval = c.take<double>(cl), o_lcval = c.take<double>(cl);
     const size_t upload_bytes = c.offset;
-    // ---- device only ------------------------------------------------------------------------------------------------
-    // U rows: base entries then the append area; U columns: base entries then the arena of replaced columns.  Their base
-    // parts are uploaded compactly behind the prefix and need no expansion: the base segment IS the compact array.
+    // ---- device only (the base parts of the U arrays are uploaded one by one) ----------------------------------------
+    // U rows: base entries [0, cap_u) then the append area; U columns: base entries then the arena of replaced columns.
     const size_t app = (size_t)m * max_updates;
-    const size_t o_urcol = c.take<int>(nu + app), o_ucrow = c.take<int>(nu + app);
-    const size_t o_urval = c.take<double>(nu + app), o_ucval = c.take<double>(nu + app);
+    const size_t o_urcol = c.take<int>(cu + app), o_ucrow = c.take<int>(cu + app);
+    const size_t o_urval = c.take<double>(cu + app), o_ucval = c.take<double>(cu + app);
     const size_t o_urlen = c.take<int>(m), o_applen = c.take<int>(m), o_eta_pivot = c.take<int>(max_updates + 1);
     const size_t o_rank = c.take<int>(m), o_seq = c.take<int>(m);
     const size_t o_eta_start = c.take<int>(max_updates + 2);
@@ -107,7 +117,11 @@ void LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     Carver s;
     s.offset = upload_bytes;
     const size_t s_urcol = s.take<int>(nu), s_ucrow = s.take<int>(nu), s_urval = s.take<double>(nu), s_ucval = s.take<double>(nu);
-    reserve(device_bytes, s.offset);
+    {
+        char* before = dev_;
+        reserve(device_bytes, s.offset);
+        if (dev_ != before) layout_changed = true;
+    }
 
     char* h = staging_;
     std::memcpy(h + o_rowpos, f.rowpos.data(), m * sizeof(int));
@@ -174,9 +188,9 @@ void LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     d.l_rstart = I(o_lrs); d.l_rcol = I(o_lrcol); d.l_rval = D(o_lrval);
     d.l_cstart = I(o_lcs); d.l_crow = I(o_lcrow); d.l_cval = D(o_lcval);
     d.u_rstart = I(o_urs); d.u_rlen = I(o_urlen); d.u_rcol = I(o_urcol); d.u_rval = D(o_urval);
-    d.u_app_len = I(o_applen); d.u_app_first = (int)nu; d.u_app_stride = max_updates;
+    d.u_app_len = I(o_applen); d.u_app_first = (int)cu; d.u_app_stride = max_updates;
     d.u_cstart = I(o_ucs); d.u_clen = I(o_uclen); d.u_crow = I(o_ucrow); d.u_cval = D(o_ucval);
-    d.u_c_capacity = (int)(nu + app);
+    d.u_c_capacity = (int)(cu + app);
     d.diag = D(o_diag);
     d.rank = I(o_rank); d.seq = I(o_seq);
     d.eta_start = I(o_eta_start); d.eta_pivot = I(o_eta_pivot); d.eta_idx = I(o_eta_idx); d.eta_val = D(o_eta_val);
@@ -188,6 +202,7 @@ void LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     nnz_l = (long long)nl;
     nnz_u = (long long)nu;
     lu_depths(f, &depth_l, &depth_u);
+    return layout_changed;
 }
 
 // LDS of the solve kernels: x0, x1 (doubles), flags (ints), one count per 64 rows for the ordered compactions, reductions
@@ -196,7 +211,7 @@ static size_t lu_lds_bytes_for(int m) {
     return 2 * mm * sizeof(double) + mm * sizeof(int) + ((size_t)(m + 63) / 64 + 2) * sizeof(int) + 64 * sizeof(double);
 }
 size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_.m); }
-bool lu_fits_lds(int m) { return lu_lds_bytes_for(m) <= 160 * 1024 - 2048; }
+bool lu_fits_lds(int m) { return lu_lds_bytes_for(m) <= 160 * 1024 - 4096; }
 
 // =====================================================================================================
 // device: sync-free triangular solves in LDS
@@ -346,7 +361,18 @@ struct LuShared {
     volatile int* flag;
     int* group_count;  // one slot per 64 rows (+2)
     double* red;       // 64 doubles
+    unsigned long long* dbg;  // diagnostic builds (-DRELP_STAMPS): per-segment cycle sums; nullptr otherwise
+    unsigned long long* t_prev;
 };
+__device__ __forceinline__ void lu_stamp(const LuShared& sh, int k) {
+#ifdef RELP_STAMPS
+    if (sh.dbg && threadIdx.x == 0) {
+        const unsigned long long t = clock64();
+        sh.dbg[k] += t - *sh.t_prev;
+        *sh.t_prev = t;
+    }
+#endif
+}
 __device__ __forceinline__ LuShared lu_shared(char* smem, int m) {
     const int mm = (m + 1) & ~1;
     LuShared s;
@@ -355,6 +381,8 @@ __device__ __forceinline__ LuShared lu_shared(char* smem, int m) {
     s.red = const_cast<double*>(s.x1 + mm);
     s.flag = reinterpret_cast<volatile int*>(s.red + 64);
     s.group_count = const_cast<int*>(s.flag + mm);
+    s.dbg = nullptr;
+    s.t_prev = nullptr;
     return s;
 }
 
@@ -365,15 +393,18 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
     TriView L{lu.l_rstart, nullptr, lu.l_rcol, lu.l_rval, nullptr, 0, 0, nullptr, nullptr};
     solve_gather<1, false>(L, m, sh.x0, sh.x1, sh.flag, ++epoch);
     __syncthreads();
+    lu_stamp(sh, 2);
     if (n_updates > 0) {
         apply_etas_forward(lu, n_updates, sh.x0);
         __syncthreads();
     }
+    lu_stamp(sh, 3);
     if (spike_out)
         for (int i = threadIdx.x; i < m; i += blockDim.x) spike_out[i] = sh.x0[i];
     TriView U{lu.u_rstart, lu.u_rlen, lu.u_rcol, lu.u_rval, lu.u_app_len, lu.u_app_first, lu.u_app_stride, lu.diag, lu.seq};
     solve_gather<1, true>(U, m, sh.x0, sh.x1, sh.flag, ++epoch);
     __syncthreads();
+    lu_stamp(sh, 4);
 }
 
 // BTRAN on the vectors in sh.x0 (and sh.x1), position space with Q applied.  `after_upper` runs between the U solve and the
@@ -385,14 +416,18 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
     TriView U{lu.u_cstart, lu.u_clen, lu.u_crow, lu.u_cval, nullptr, 0, 0, lu.diag, lu.seq};
     solve_gather<NRHS, false>(U, m, sh.x0, sh.x1, sh.flag, ++epoch);
     __syncthreads();
+    lu_stamp(sh, 7);
     after_upper();
+    lu_stamp(sh, 8);
     if (n_updates > 0) {
         apply_etas_backward<NRHS>(lu, n_updates, sh.x0, sh.x1);
         __syncthreads();
     }
+    lu_stamp(sh, 9);
     TriView L{lu.l_cstart, nullptr, lu.l_crow, lu.l_cval, nullptr, 0, 0, nullptr, nullptr};
     solve_gather<NRHS, true>(L, m, sh.x0, sh.x1, sh.flag, ++epoch);
     __syncthreads();
+    lu_stamp(sh, 10);
 }
 
 // Ordered compaction: every row i with keep(i) gets the number of kept rows before it.  Returns the total.  Two barriers.
@@ -612,12 +647,12 @@ __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int 
 }
 
 static bool g_lu_lds_configured = false;
+static void allow_full_lds(const void* kernel);
 static void configure_lu_lds() {
     if (g_lu_lds_configured) return;
-    const int cap = 160 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_ftran_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_btran_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_update_kernel));
     g_lu_lds_configured = true;
 }
 static void check_launch(const char* what) {
@@ -649,6 +684,388 @@ void launch_lu_update(const DeviceLU& lu, int p, hipStream_t s) {
     configure_lu_lds();
     hipLaunchKernelGGL(lu_update_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, lu, p);
     check_launch("lu_update_kernel");
+}
+
+// =====================================================================================================
+// The LU carry inside the device-resident simplex loop (relp_options.carry = RELP_CARRY_LU)
+// =====================================================================================================
+// ONE single-workgroup kernel per pivot does everything that is not the pricing pass:
+//   entering column (reduction of the pricing workgroups' candidates)      pivot_rule.rs:221-241
+//   FTRAN alpha_q = B^-1 a_q, spike kept                                    tableau/mod.rs:126-130 -> lower_upper/mod.rs:180-210
+//   ratio test (Harris two-pass; ties: Bland, lowest leaving column)       tableau/mod.rs:287-313
+//   update_b                                                               carry/mod.rs:295-325
+//   ONE two-right-hand-side BTRAN: w = alpha_q' B^-1 (carry/mod.rs:575) and e_p' B^-1, from which
+//       rho_p of the NEW basis = (e_p' B_old^-1) / alpha_pq (lower_upper/mod.rs:254-272), the Forrest-Tomlin row eta
+//       (its U stage is e_t' U^-1; lower_upper/mod.rs:112-125 computes it with a third solve) and
+//       update_minus_pi_and_obj                                            carry/mod.rs:338-349
+//   Forrest-Tomlin update of U                                             lower_upper/mod.rs:94-178
+//   or, after `refactor_period` updates, status = ST_REFACTOR: the host factorises the new basis (carry/mod.rs:584-591:
+//   polled before the update; the new basis is inverted from scratch and no update is made).
+// The explicit-inverse pipeline needs two kernels for this (K2, K3) and rewrites an m x m matrix per pivot.
+template <int RULE>
+__global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, DeviceLU lu, int n_price_blocks, double tol_pivot,
+                                                               double harris_delta, int skip_artificial_rows, int mode,
+                                                               int refactor_period) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_akey[LU_THREADS / WAVE];
+    __shared__ unsigned long long s_arank[LU_THREADS / WAVE];
+    __shared__ double s_bcast[4];
+    Ctl* ctl = lp.ctl;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int m = lp.m;
+    LuShared sh = lu_shared(smem, m);
+#ifdef RELP_STAMPS
+    __shared__ unsigned long long s_tprev;
+    if (tid == 0) {
+        s_tprev = clock64();
+        lp.dbg[63] += 1;
+    }
+    sh.dbg = lp.dbg;
+    sh.t_prev = &s_tprev;
+#endif
+    // ---- round trip 1: control word, update count, the candidates ---------------------------------------------------
+    const int status = ctl->status;
+    const long long iters = ctl->iters;
+    const long long budget = ctl->budget;
+    const int forced_q = ctl->forced_q;
+    const int forced_p = ctl->forced_p;
+    const double minus_obj = ctl->minus_obj;
+    const int n_updates = lu.state[LU_N_UPDATES];
+    double ckey = 0.0;
+    unsigned long long crank = RANK_NONE;
+    for (int b = tid; b < n_price_blocks; b += T) {
+        const int j = lp.cand_j[b];
+        const double k = lp.cand_key[b];
+        if (j >= 0) {
+            const unsigned long long order = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? (unsigned long long)(0x7fffffff - j) : (unsigned long long)j;
+            const unsigned long long r = (order << 16) | (unsigned long long)b;
+            if (crank == RANK_NONE || k > ckey || (k == ckey && r < crank)) {
+                ckey = k;
+                crank = r;
+            }
+        }
+    }
+    if (status != ST_RUNNING) return;
+    if (mode == 0 && iters >= budget) {
+        if (tid == 0) {
+            ctl->status = ST_BUDGET;
+            ctl->pending = 0;
+        }
+        return;
+    }
+    // ---- entering column ----------------------------------------------------------------------------------------------
+    int q;
+    double cbar_q;
+    if (forced_q < 0) {
+        block_argbest(ckey, crank, s_akey, s_arank);
+        if (crank == RANK_NONE) {
+            q = -1;
+            cbar_q = 0.0;
+        } else {
+            const int order = (int)(crank >> 16);
+            q = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? 0x7fffffff - order : order;
+            cbar_q = lp.cand_cbar[(int)(crank & 0xffff)];
+        }
+    } else {
+        q = forced_q;
+        if (tid == 0) {
+            double cb = lp.cost[forced_q];
+            for (int e = lp.col_start[forced_q]; e < lp.col_start[forced_q + 1]; ++e) cb += lp.value[e] * lp.minus_pi[lp.row_index[e]];
+            s_bcast[0] = cb;
+        }
+        __syncthreads();
+        cbar_q = s_bcast[0];
+        __syncthreads();
+    }
+    if (q < 0) {
+        if (tid == 0) {
+            if (mode == 0) ctl->status = ST_NO_ENTERING;
+            ctl->q = -1;
+            ctl->pending = 0;
+            if (mode == 0) ctl->last_selected = -1;
+        }
+        return;
+    }
+    if (mode == 1) {
+        if (tid == 0) {
+            ctl->q = q;
+            ctl->cbar_q = cbar_q;
+            ctl->pending = 0;
+        }
+        return;
+    }
+    // ---- FTRAN ------------------------------------------------------------------------------------------------------------
+    lu_stamp(sh, 0);
+    lu_clear(sh, m, false);
+    for (int e = lp.col_start[q] + tid; e < lp.col_start[q + 1]; e += T) sh.x0[lu.rowpos[lp.row_index[e]]] = lp.value[e];
+    __syncthreads();
+    lu_stamp(sh, 1);
+    int epoch = 0;
+    lu_ftran_block(lu, sh, n_updates, epoch, lu.spike);
+    // ---- alpha per basis slot (kept in x1), gamma_q, Harris pass 1 ----------------------------------------------------------
+    double sumsq = 0.0, theta = INFINITY;
+    for (int s = tid; s < m; s += T) {
+        const double a = sh.x0[lu.colpos[s]];
+        sh.x1[s] = a;
+        lp.alpha[s] = a;
+        sumsq += a * a;
+        if (a > tol_pivot && !(skip_artificial_rows && lp.basis[s] < lp.n_art)) theta = fmin(theta, (fmax(lp.xB[s], 0.0) + harris_delta) / a);
+    }
+    const double gamma_q = 1.0 + block_reduce<0>(sumsq, sh.red);  // pivot_rule.rs:258
+    const double theta_max = block_reduce<1>(theta, sh.red + 32);
+    // ---- Harris pass 2: the largest eligible pivot, ties by the lowest leaving column (Bland, tableau/mod.rs:295) -------------
+    int p = forced_p;
+    if (forced_p < 0) {
+        double hkey = 0.0;
+        unsigned long long hrank = RANK_NONE;
+        for (int s = tid; s < m; s += T) {
+            const double a = sh.x1[s];
+            if (!(a > tol_pivot)) continue;
+            const int bs = lp.basis[s];
+            if (skip_artificial_rows && bs < lp.n_art) continue;
+            if (fmax(lp.xB[s], 0.0) / a <= theta_max) {
+                const unsigned long long rk = ((unsigned long long)(unsigned)bs << 32) | (unsigned)s;
+                if (hrank == RANK_NONE || a > hkey || (a == hkey && rk < hrank)) {
+                    hkey = a;
+                    hrank = rk;
+                }
+            }
+        }
+        block_argbest(hkey, hrank, s_akey, s_arank);
+        p = hrank == RANK_NONE ? -1 : (int)(hrank & 0xffffffffu);
+    }
+    if (p < 0) {
+        if (tid == 0) {
+            if (mode == 0) ctl->status = ST_UNBOUNDED;
+            ctl->q = q;
+            ctl->p = -1;
+            ctl->pending = 0;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+        }
+        return;
+    }
+    lu_stamp(sh, 5);
+    const double alpha_pq = sh.x1[p];
+    if (mode == 2) {
+        if (tid == 0) {
+            ctl->q = q;
+            ctl->p = p;
+            ctl->cbar_q = cbar_q;
+            ctl->gamma_q = gamma_q;
+            ctl->pending = 0;
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+        }
+        return;
+    }
+    if (alpha_pq == 0.0) return;  // (a forced pivot on a zero element: the host sees that nothing happened)
+    const int leaving = lp.basis[p];
+    const double xp = fmax(lp.xB[p], 0.0) / alpha_pq;
+    __syncthreads();  // every thread has read basis[p] / xB[p] before they change
+    // ---- x_B update (carry/mod.rs:295-325) ------------------------------------------------------------------------------
+    for (int s = tid; s < m; s += T) lp.xB[s] = (s == p) ? xp : lp.xB[s] - sh.x1[s] * xp;
+    // ---- BTRAN with two right-hand sides: x0 <- e_p, x1 <- alpha (both per basis slot -> position space) -----------------------
+    const int t = lu.colpos[p];
+    const bool do_update = n_updates < refactor_period && n_updates < lu.max_updates;
+    __syncthreads();
+    for (int s = tid; s < m; s += T) {
+        sh.x0[s] = 0.0;
+        sh.x1[lu.colpos[s]] = lp.alpha[s];  // (this thread wrote lp.alpha[s] itself)
+    }
+    __syncthreads();
+    if (tid == 0) sh.x0[t] = 1.0;
+    __syncthreads();
+    lu_stamp(sh, 6);
+    const double diag_t = lu.diag[t];
+    int eta_count = 0;
+    double new_diag = 0.0;
+    lu_btran_block<2>(lu, sh, n_updates, epoch, [&] {
+        if (do_update) eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag);
+    });
+    // ---- rho_p of the new basis, w, -pi (carry/mod.rs:338-349) ----------------------------------------------------------------
+    for (int i = tid; i < m; i += T) {
+        const int k = lu.rowpos[i];
+        const double r = sh.x0[k] / alpha_pq;
+        const double w = sh.x1[k];
+        const double pi_new = lp.minus_pi[i] - cbar_q * r;
+        lp.rho[i] = r;
+        lp.w[i] = w;
+        lp.minus_pi[i] = pi_new;
+        if (lp.prw) {
+            lp.prw[(size_t)4 * i] = pi_new;
+            lp.prw[(size_t)4 * i + 1] = r;
+            lp.prw[(size_t)4 * i + 2] = w;
+        }
+    }
+    lu_stamp(sh, 11);
+    // ---- Forrest-Tomlin update, or hand the new basis to the host ---------------------------------------------------------------
+    bool refactor = !do_update;
+    if (do_update) {
+        lu_ft_update_block(lu, sh, t, eta_count, new_diag, lu.spike);
+        // det(B_new) = alpha_pq det(B_old)  =>  the new diagonal element must equal alpha_pq * u_tt: a free accuracy check
+        const double expect = alpha_pq * diag_t;
+        if (!(fabs(new_diag - expect) <= 1e-7 * (fabs(new_diag) + fabs(expect)))) refactor = true;
+    }
+    if (tid == 0) {
+        lp.basis[p] = q;
+        lp.pos[q] = p;
+        lp.pos[leaving] = -1;
+        ctl->q = q;
+        ctl->p = p;
+        ctl->leaving = leaving;
+        ctl->cbar_q = cbar_q;
+        ctl->alpha_pq = alpha_pq;
+        ctl->gamma_q = gamma_q;
+        ctl->xp = xp;
+        ctl->nz_count = 0;
+        ctl->minus_obj = minus_obj - cbar_q * xp;
+        ctl->iters = iters + 1;
+        ctl->pending = 1;
+        ctl->forced_q = -1;
+        ctl->forced_p = -1;
+        ctl->last_selected = q;
+        if (refactor) ctl->status = ST_REFACTOR;
+    }
+    lu_stamp(sh, 12);
+}
+
+// x_B = B^-1 b  (InverseMaintainer::from_basis, carry/mod.rs:452-463) through the resident factors
+__global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU lu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m = lu.m;
+    const LuShared sh = lu_shared(smem, m);
+    const int n_updates = lu.state[LU_N_UPDATES];
+    lu_clear(sh, m, false);
+    for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = lp.rhs[i];
+    __syncthreads();
+    int epoch = 0;
+    lu_ftran_block(lu, sh, n_updates, epoch, nullptr);
+    for (int s = threadIdx.x; s < m; s += blockDim.x) lp.xB[s] = sh.x0[lu.colpos[s]];
+}
+// -pi = -c_B' B^-1 and -obj = -c_B' x_B  (carry/mod.rs:226-283: the reference forms all of B^-1 with m FTRANs)
+__global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU lu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m = lu.m;
+    const LuShared sh = lu_shared(smem, m);
+    const int n_updates = lu.state[LU_N_UPDATES];
+    lu_clear(sh, m, false);
+    double obj = 0.0;
+    for (int s = threadIdx.x; s < m; s += blockDim.x) {
+        const double c = lp.cost[lp.basis[s]];
+        sh.x0[lu.colpos[s]] = c;
+        obj += c * lp.xB[s];
+    }
+    __syncthreads();
+    int epoch = 0;
+    lu_btran_block<1>(lu, sh, n_updates, epoch, [] {});
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const double v = -sh.x0[lu.rowpos[i]];
+        lp.minus_pi[i] = v;
+        if (lp.prw) lp.prw[(size_t)4 * i] = v;
+    }
+    const double total = block_reduce<0>(obj, sh.red);
+    if (threadIdx.x == 0) lp.ctl->minus_obj = -total;
+}
+// gamma_j = 1 + |B^-1 a_j|^2 for every non-basic provider column (pivot_rule.rs:202-219, 299-305): one FTRAN per column,
+// a workgroup takes every gridDim.x-th column.  (Warm starts only: between the phases the weights are carried over.)
+__global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, DeviceLU lu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m = lu.m;
+    const LuShared sh = lu_shared(smem, m);
+    const int n_updates = lu.state[LU_N_UPDATES];
+    for (int j = lp.n_art + blockIdx.x; j < lp.n; j += gridDim.x) {
+        if (lp.pos[j] >= 0) continue;
+        __syncthreads();
+        lu_clear(sh, m, false);
+        for (int e = lp.col_start[j] + threadIdx.x; e < lp.col_start[j + 1]; e += blockDim.x) sh.x0[lu.rowpos[lp.row_index[e]]] = lp.value[e];
+        __syncthreads();
+        int epoch = 0;
+        lu_ftran_block(lu, sh, n_updates, epoch, nullptr);
+        double sumsq = 0.0;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const double a = sh.x0[i];
+            sumsq += a * a;
+        }
+        const double total = block_reduce<0>(sumsq, sh.red);
+        if (threadIdx.x == 0) lp.gamma[j] = 1.0 + total;
+    }
+}
+// Zero-level pivots (phase_one.rs:232-278): first non-basic provider column with a non-zero in tableau row r, given
+// row r of the inverse (`rowvec` = e_r' B^-1, one BTRAN) instead of one FTRAN per candidate (lower_upper/mod.rs:239-247).
+__global__ void __launch_bounds__(256) lu_row_scan_kernel(DeviceLP lp, const double* rowvec, double tol) {
+    for (int j = lp.n_art + blockIdx.x * blockDim.x + threadIdx.x; j < lp.n; j += gridDim.x * blockDim.x) {
+        if (lp.pos[j] >= 0) continue;
+        double acc = 0.0;
+        for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e) acc += lp.value[e] * rowvec[lp.row_index[e]];
+        if (fabs(acc) > tol) atomicMin(&lp.ctl->scan_column, j);
+    }
+}
+
+static bool g_lu_pivot_configured = false;
+static void allow_full_lds(const void* kernel) {
+    // dynamic + static LDS may reach the 160 KB of a CU; the attribute is process-wide, so it is set once to the maximum
+    hipFuncAttributes attr{};
+    size_t fixed = 0;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) fixed = attr.sharedSizeBytes;
+    const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fixed));
+    if (err != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: the launch itself reports a request that is too large
+    }
+}
+static void configure_lu_pivot_lds() {
+    if (g_lu_pivot_configured) return;
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_STEEPEST_EDGE>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_DANTZIG>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_xb_kernel));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pi_kernel));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_gamma_kernel));
+    g_lu_pivot_configured = true;
+}
+template <int RULE>
+static void launch_lu_pivot_rule(const DeviceLP& d, const DeviceLU& lu, int n_price_blocks, double tol_pivot, double harris_delta,
+                                 int skip_art, int mode, int refactor_period, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+    if (start)
+        hipExtLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), (std::uint32_t)lu_lds_bytes_for(lu.m), s, start, stop, 0,
+                              d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period);
+    else
+        hipLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu, n_price_blocks, tol_pivot,
+                           harris_delta, skip_art, mode, refactor_period);
+}
+// `capturing`: inside a stream capture hipGetLastError must not be polled per launch (the capture's end reports failures)
+void launch_lu_pivot(const DeviceLP& d, const DeviceLU& lu, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
+                     int skip_art, int mode, int refactor_period, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+    configure_lu_pivot_lds();
+    switch (rule) {
+        case RELP_PIVOT_DANTZIG: launch_lu_pivot_rule<RELP_PIVOT_DANTZIG>(d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period, s, start, stop); break;
+        case RELP_PIVOT_FIRST_PROFITABLE: launch_lu_pivot_rule<RELP_PIVOT_FIRST_PROFITABLE>(d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period, s, start, stop); break;
+        case RELP_PIVOT_FIRST_PROFITABLE_MEMORY: launch_lu_pivot_rule<RELP_PIVOT_FIRST_PROFITABLE_MEMORY>(d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period, s, start, stop); break;
+        default: launch_lu_pivot_rule<RELP_PIVOT_STEEPEST_EDGE>(d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period, s, start, stop); break;
+    }
+}
+void launch_lu_xb(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
+    configure_lu_pivot_lds();
+    hipLaunchKernelGGL(lu_xb_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu);
+    check_launch("lu_xb_kernel");
+}
+void launch_lu_pi(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
+    configure_lu_pivot_lds();
+    hipLaunchKernelGGL(lu_pi_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu);
+    check_launch("lu_pi_kernel");
+}
+void launch_lu_gamma(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
+    configure_lu_pivot_lds();
+    const int blocks = std::max(1, std::min(512, d.n - d.n_art));
+    hipLaunchKernelGGL(lu_gamma_kernel, dim3(blocks), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu);
+    check_launch("lu_gamma_kernel");
+}
+void launch_lu_row_scan(const DeviceLP& d, const double* rowvec, double tol, hipStream_t s) {
+    int blocks = (d.n - d.n_art + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(lu_row_scan_kernel, dim3(blocks), dim3(256), 0, s, d, rowvec, tol);
+    check_launch("lu_row_scan_kernel");
 }
 
 // =====================================================================================================

@@ -51,8 +51,9 @@ public:
     ~LuFactors();
     LuFactors(const LuFactors&) = delete;
     LuFactors& operator=(const LuFactors&) = delete;
-    // uploads the factors (one host-to-device copy) and resets the update state; stream-ordered
-    void upload(const HostLU& f, int max_updates, hipStream_t stream);
+    // uploads the factors and resets the update state; stream-ordered.  Returns true when the device layout (the addresses
+    // in device()) changed: it depends on capacities only, so a refactorisation normally keeps it.
+    bool upload(const HostLU& f, int max_updates, hipStream_t stream);
     const DeviceLU& device() const { return d_; }
     size_t lds_bytes(int nrhs) const;  // dynamic LDS of the solve kernels for this m
     long long nnz_l = 0, nnz_u = 0;
@@ -65,6 +66,7 @@ private:
     size_t dev_capacity_ = 0;
     char* staging_ = nullptr;
     size_t staging_capacity_ = 0;
+    size_t cap_l_ = 0, cap_u_ = 0;
 };
 
 // kernels (lu.hip); all single-workgroup, stream-ordered
@@ -79,6 +81,14 @@ void launch_lu_btran(const DeviceLU& lu, const int* slots, const double* vals, i
 void launch_lu_btran_dense(const DeviceLU& lu, const double* in_slots, double* out, hipStream_t s);
 // Forrest-Tomlin update for pivot slot p with the spike of the last FTRAN (mod.rs:94-178)
 void launch_lu_update(const DeviceLU& lu, int p, hipStream_t s);
+// the LU carry inside the device-resident loop (solver.hip)
+struct DeviceLP;
+void launch_lu_pivot(const DeviceLP& d, const DeviceLU& lu, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
+                     int skip_art, int mode, int refactor_period, hipStream_t s, hipEvent_t start, hipEvent_t stop);
+void launch_lu_xb(const DeviceLP& d, const DeviceLU& lu, hipStream_t s);
+void launch_lu_pi(const DeviceLP& d, const DeviceLU& lu, hipStream_t s);
+void launch_lu_gamma(const DeviceLP& d, const DeviceLU& lu, hipStream_t s);
+void launch_lu_row_scan(const DeviceLP& d, const double* rowvec, double tol, hipStream_t s);
 
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -21,6 +21,7 @@ void configure_dense_lds(size_t lds);
 void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s);
 bool fast_k2_available(const DeviceLP& d, int n_price_blocks);
 void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop);
+void take_launch_timer(int which, hipEvent_t* start, hipEvent_t* stop);
 void configure_lds(size_t price_lds);
 int price_columns_per_block(int ell_w);
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
@@ -63,6 +64,12 @@ T* dmalloc(size_t count) {
     RELP_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
     return p;
 }
+void check_sparse(int nnz, const int* rows, const double* values, int m) {
+    if (nnz < 0 || nnz > m) throw std::invalid_argument("nnz out of range");
+    if (nnz > 0 && (!rows || !values)) throw std::invalid_argument("null sparse vector");
+    for (int e = 0; e < nnz; ++e)
+        if (rows[e] < 0 || rows[e] >= m) throw std::invalid_argument("index out of range");
+}
 template <class T>
 void upload_vec(T* dst, const std::vector<T>& src, hipStream_t s) {
     if (!src.empty()) RELP_HIP(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
@@ -102,12 +109,18 @@ void Solver::reset_stats() { stats_ = relp_stats{}; }
 
 void Solver::load(StandardForm&& form) {
     RELP_HIP(hipSetDevice(opt_.device));
+    loaded_ = false;  // a failed upload must not leave a handle that looks loaded (its device pointers are gone)
+    phase_ = 0;
     free_device();
     destroy_graphs();
     form_ = std::move(form);
-    upload();
+    try {
+        upload();
+    } catch (...) {
+        free_device();
+        throw;
+    }
     loaded_ = true;
-    phase_ = 0;
 }
 
 // Materialise [artificials | provider columns] once (CSC + CSR) and upload.  The artificial columns are the virtual
@@ -183,12 +196,18 @@ void Solver::upload() {
     d_.n = n;
     d_.n_art = n_art;
     d_.ld = m;
+    lu_mode_ = opt_.carry == RELP_CARRY_LU;
+    refactor_period_ = opt_.refactor_period > 0 ? opt_.refactor_period : 64;
+    if (lu_mode_) {
+        if (bounded_) throw std::invalid_argument("the LU carry does not take implicit bounds (use carry = RELP_CARRY_EXPLICIT)");
+        if (!lu_fits_lds(m)) throw std::invalid_argument("the LU carry keeps its solve vectors in LDS: at most about 7000 rows");
+    }
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
     // structural columns); steepest edge only (the dense kernel implements that rule)
     int n_dense = 0;
     if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE && m >= 64)
         while (n_dense < n_p && (col_start[n_art + n_dense + 1] - col_start[n_art + n_dense]) * 2 > m) ++n_dense;
-    if (n_dense < 64 || bounded_) n_dense = 0;
+    if (n_dense < 64 || bounded_ || lu_mode_) n_dense = 0;  // (the dense pipeline belongs to the explicit inverse)
     d_.n_dense = n_dense;
     d_.dense_first = n_art;
     d_.dense_ld = (m + 3) & ~3;
@@ -227,7 +246,7 @@ void Solver::upload() {
     d_.pos = dmalloc<int>(n);
     d_.gamma = dmalloc<double>(n);
     tick("sparse arrays");
-    d_.Binv = dmalloc<double>((size_t)m * d_.ld);
+    if (!lu_mode_) d_.Binv = dmalloc<double>((size_t)m * d_.ld);  // the LU carry has no m x m array at all
     // The second copy of the inverse and the residual matrix are only needed once a polish finds something to correct
     // (Solver::ensure_polish_buffers): at m = 65 534 each is 34 GB and about a second of hipMalloc, and the max-flow LP of
     // config 5, whose bases are unimodular, never needs them.
@@ -268,7 +287,7 @@ void Solver::upload() {
     d_.eta_cap = eta_mode_ ? eta_max() : 0;
     // unit columns of the inverse are tracked where skipping them pays: the dense pipeline and the larger sparse LPs
     // (below that the update kernel is latency bound and the extra indirection would cost a round trip)
-    d_.track_touched = (eta_mode_ || m > 2048) && !getenv("RELP_NO_TOUCHED") ? 1 : 0;
+    d_.track_touched = (eta_mode_ || m > 2048) && !lu_mode_ && !getenv("RELP_NO_TOUCHED") ? 1 : 0;
     d_.touched = dmalloc<int>(m);
     d_.tlist = dmalloc<int>(m);
     RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));
@@ -337,7 +356,7 @@ void Solver::upload() {
         d_.k2_partd = dmalloc<double>((size_t)8 * ((m + 1023) / 1024));
         d_.k2_parti = dmalloc<int>((size_t)4 * ((m + 1023) / 1024));
     }
-    d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 2 + 16);
+    d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 3 + 16);  // fine-grained ops carve m ints + 2 m doubles out of it
     d_.ctl = dmalloc<Ctl>(1);
     d_.dbg = dmalloc<unsigned long long>(64);
     RELP_HIP(hipMemsetAsync(d_.dbg, 0, 64 * sizeof(unsigned long long), stream_));
@@ -369,6 +388,11 @@ void Solver::upload() {
     stats_.update_bytes = (long long)2 * m * m * 8;
     h_basis_.assign(m, -1);
     h_solution_.assign(md.nr_columns(), 0.0);
+    if (lu_mode_) {
+        h_col_start_ = col_start;
+        h_row_index_ = row_index;
+        h_value_ = value;
+    }
 }
 
 Ctl Solver::read_ctl() {
@@ -412,9 +436,12 @@ void Solver::begin_phase_one() {
         RELP_HIP(hipStreamSynchronize(stream_));
     }
     RELP_HIP(hipMemcpyAsync(d_.xB, d_.rhs, m * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    launch_identity(d_.Binv, m, d_.ld, stream_);
+    if (lu_mode_) lu_identity();
+    else launch_identity(d_.Binv, m, d_.ld, stream_);
     RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));  // every column is a unit vector
     binv_identity_ = true;
+    refactors_ = 0;
+    refactor_seconds_ = 0.0;
     Ctl c{};
     c.forced_q = c.forced_p = -1;
     c.last_selected = -1;
@@ -437,14 +464,16 @@ void Solver::set_phase(int phase) {
     const int phase_before = phase_;
     phase_ = phase;
     RELP_HIP(hipMemcpyAsync(d_.cost, phase == 1 ? d_.cost1 : d_.cost2, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    launch_pi(d_, stream_);
+    if (lu_mode_) launch_lu_pi(d_, lu_.device(), stream_);
+    else launch_pi(d_, stream_);
     // Steepest-edge weights gamma_j = 1 + |B^-1 a_j|^2 do not depend on the costs, and the recurrences that maintain them
     // are exact: what phase one leaves is what `SteepestDescentAlongObjective::new` (pivot_rule.rs:202-219) would recompute
     // for phase two.  Recomputing costs one pass over the inverse per column pair -- fine for Netlib, 1 TB for the 1 M-arc
     // max-flow LP -- so large LPs keep the weights (after flushing the update of the last zero-level pivot).
     const double carry_threshold = getenv("RELP_CARRY_WEIGHTS_MIN") ? atof(getenv("RELP_CARRY_WEIGHTS_MIN")) : 4e9;  // (test hook)
+    // (the LU carry always keeps them: recomputing is one FTRAN per non-basic column)
     const bool carry_weights = phase == 2 && phase_before == 1 && !binv_identity_ &&
-                               (double)(d_.n - d_.n_art) * (double)d_.m > carry_threshold;
+                               (lu_mode_ || (double)(d_.n - d_.n_art) * (double)d_.m > carry_threshold);
     if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE) {
         if (carry_weights) {
             Ctl pending = read_ctl();
@@ -455,6 +484,8 @@ void Solver::set_phase(int phase) {
                 enqueue_price(0);  // applies the pending Goldfarb-Reid update; its candidates are discarded
                 RELP_HIP(hipMemcpyAsync(d_.cost, d_.cost2, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
             }
+        } else if (lu_mode_ && !binv_identity_) {
+            launch_lu_gamma(d_, lu_.device(), stream_);
         } else {
             launch_gamma_init(d_, binv_identity_ ? 1 : 0, stream_);
         }
@@ -476,6 +507,15 @@ void Solver::set_phase(int phase) {
 // One batch of `count` iterations of the loop of phase_one.rs:134-178 / phase_two.rs:36-58.
 void Solver::launch_pivots(int count) {
     launch_budget(d_, count, stream_);
+    if (lu_mode_) {  // two kernels per pivot: the pricing pass and the single-workgroup LU kernel
+        for (int it = 0; it < count; ++it) {
+            enqueue_price(0);
+            enqueue_ftran_ratio(0);
+        }
+        stats_.launches += 1 + 2LL * count;
+        stats_.price_launches += count;
+        return;
+    }
     for (int it = 0; it < count; ++it) {
         enqueue_price(0);
         enqueue_ftran_ratio(0);
@@ -514,6 +554,12 @@ void Solver::enqueue_consolidate() {
 void Solver::enqueue_ftran_ratio(int mode) {
     const int skip_art = phase_ == 2 ? 1 : 0;
     const int slots = price_blocks_ + dense_blocks_;
+    if (lu_mode_) {
+        hipEvent_t start = nullptr, stop = nullptr;
+        take_launch_timer(1, &start, &stop);
+        launch_lu_pivot(d_, lu_.device(), opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, refactor_period_, stream_, start, stop);
+        return;
+    }
     if (ftran_slices_ > 0) {
         launch_ftran_partial(d_, ftran_slices_, slots, opt_.pivot_rule, stream_);
         launch_alpha_reduce(d_, ftran_slices_, stream_);
@@ -546,6 +592,10 @@ void Solver::build_graph(int count) {
 
 // Newton-Schulz polish (see kernels.hip).  Two iterations at most; the residual before the polish is recorded.
 void Solver::polish(bool refresh_vectors) {
+    if (lu_mode_) {  // the LU carry's refresh is a refactorisation
+        refactor_lu(refresh_vectors);
+        return;
+    }
     const int m = d_.m;
     // dense pipeline: only the columns of the stored inverse that are not unit vectors take part (the corresponding
     // rows of S are zero and those columns of the polished inverse do not change): both GEMMs shrink by m / touched
@@ -604,6 +654,10 @@ void Solver::ensure_polish_buffers() {
 }
 
 void Solver::invert_from_scratch() {
+    if (lu_mode_) {
+        refactor_lu(false);
+        return;
+    }
     const int m = d_.m;
     ensure_polish_buffers();
     std::vector<int> basis(m);
@@ -734,7 +788,11 @@ void Solver::set_basis(const int* basis_columns) {
     c.scan_column = std::numeric_limits<int>::max();
     write_ctl(c);
     invert_from_scratch();
-    launch_xb(d_, stream_);
+    if (lu_mode_) launch_lu_xb(d_, lu_.device(), stream_);
+    else launch_xb(d_, stream_);
+    binv_identity_ = false;
+    refactors_ = 0;
+    refactor_seconds_ = 0.0;
     pivots_[0] = pivots_[1] = 0;
     polishes_ = 0;
     max_residual_ = 0.0;
@@ -750,14 +808,16 @@ long long Solver::iterate(long long count, int* stop_reason) {
     long long done = 0;
     int reason = ST_BUDGET;
     long long iters_before = read_ctl().iters;  // one control-word read per batch: the next batch starts where this one ended
+    // LU carry: a batch is one refactorisation cycle (period updates + the pivot that asks for the refactorisation)
+    const int full_batch = lu_mode_ ? refactor_period_ + 1 : std::max(1, opt_.pivots_per_launch);
     while (done < count) {
-        long long room = opt_.polish_period > 0 ? (long long)opt_.polish_period * polish_scale_ - since_polish_ : count;
+        long long room = (!lu_mode_ && opt_.polish_period > 0) ? (long long)opt_.polish_period * polish_scale_ - since_polish_ : count;
         if (room <= 0) { polish(true); continue; }  // (a polish does not touch the iteration counter)
-        int batch = (int)std::min<long long>({count - done, room, (long long)std::max(1, opt_.pivots_per_launch)});
-        if (opt_.use_graph && batch == opt_.pivots_per_launch) {
+        int batch = (int)std::min<long long>({count - done, room, (long long)full_batch});
+        if (opt_.use_graph && batch == full_batch) {
             build_graph(batch);
             RELP_HIP(hipGraphLaunch(graph_exec_[phase_ == 2 ? 1 : 0], stream_));
-            stats_.launches += 1 + 3LL * batch;
+            stats_.launches += 1 + (lu_mode_ ? 2LL : 3LL) * batch;
             stats_.price_launches += batch;
         } else {
             launch_pivots(batch);
@@ -768,7 +828,12 @@ long long Solver::iterate(long long count, int* stop_reason) {
         done += made;
         since_polish_ += made;
         pivots_[phase_ - 1] += made;
+        if (made > 0) binv_identity_ = lu_mode_ ? false : binv_identity_;
         if (after.status == ST_NO_ENTERING || after.status == ST_UNBOUNDED) { reason = after.status; break; }
+        if (after.status == ST_REFACTOR) {  // LU carry: should_refactor (or an unstable update) -- BasisInverse::invert on the host
+            refactor_lu(true);
+            continue;
+        }
         if (made == 0 && after.status == ST_RUNNING) break;  // defensive: nothing happened
     }
     if (stop_reason) *stop_reason = reason;
@@ -787,7 +852,18 @@ int Solver::drive_out_artificials() {
         Ctl c = read_ctl();
         c.scan_column = std::numeric_limits<int>::max();
         write_ctl(c);
-        launch_row_scan(d_, r, 1e-7, stream_);
+        if (lu_mode_) {  // row r of the inverse by one BTRAN, then the scan of rho_r a_j over the non-basic columns
+            double* rowvec = d_.scratch + (d_.m + 1) / 2 + 1 + d_.m;
+            int* d_slot = reinterpret_cast<int*>(d_.scratch);
+            double* d_one = d_.scratch + (d_.m + 1) / 2 + 1;
+            const double one = 1.0;
+            RELP_HIP(hipMemcpyAsync(d_slot, &r, sizeof(int), hipMemcpyHostToDevice, stream_));
+            RELP_HIP(hipMemcpyAsync(d_one, &one, sizeof(double), hipMemcpyHostToDevice, stream_));
+            launch_lu_btran(lu_.device(), d_slot, d_one, 1, rowvec, stream_);
+            launch_lu_row_scan(d_, rowvec, 1e-7, stream_);
+        } else {
+            launch_row_scan(d_, r, 1e-7, stream_);
+        }
         c = read_ctl();
         if (c.scan_column == std::numeric_limits<int>::max()) {
             redundant_rows_.push_back(r);
@@ -798,11 +874,15 @@ int Solver::drive_out_artificials() {
         c.forced_p = r;
         c.status = ST_RUNNING;
         write_ctl(c);
+        // a zero-level pivot: the artificial that leaves IS zero (the phase-one objective vanished); whatever residue f64 left
+        // in x_B[r] must not be divided by a small pivot element and spread over x_B
+        RELP_HIP(hipMemsetAsync(d_.xB + r, 0, sizeof(double), stream_));
         launch_pivots(1);
         Ctl after = read_ctl();
         if (after.iters == c.iters) throw std::runtime_error("zero-level pivot failed");
         pivots_[0] += 1;
         since_polish_ += 1;
+        if (after.status == ST_REFACTOR) refactor_lu(true);
     }
     return redundant;
 }
@@ -915,6 +995,8 @@ void Solver::solve(relp_result* result) {
     res.pivots_phase_two = pivots_[1];
     res.polishes = polishes_;
     res.max_residual = max_residual_;
+    res.refactors = refactors_;
+    res.refactor_seconds = refactor_seconds_;
     res.objective = (kind == RELP_RESULT_FINITE_OPTIMUM) ? -c.minus_obj + form_.fixed_cost.to_double()
                                                          : std::numeric_limits<double>::quiet_NaN();
     tick("results");
@@ -967,15 +1049,76 @@ void Solver::certify(relp_result* result) {
     if (!ok) last_error = message;
 }
 
+// ---- LU carry ---------------------------------------------------------------------------------------
+// `BasisInverse::identity` (lower_upper/mod.rs:67-76) for the start of phase one.
+void Solver::lu_identity() {
+    const int m = d_.m;
+    HostLU f;
+    f.m = m;
+    f.rowpos.resize(m);
+    f.colpos.resize(m);
+    for (int i = 0; i < m; ++i) f.rowpos[i] = f.colpos[i] = i;
+    f.l_start.assign(m + 1, 0);
+    f.u_start.assign(m + 1, 0);
+    f.diag.assign(m, 1.0);
+    if (lu_.upload(f, refactor_period_ + 1, stream_)) destroy_graphs();  // the captured batches hold the old addresses
+}
+// `BasisInverse::invert(basis columns)` (lower_upper/mod.rs:78-92; called by `Carry::change_basis` when `should_refactor`,
+// carry/mod.rs:584-591): Markowitz factorisation of the current basis on the host, one upload, and -- `refresh_vectors` -- x_B,
+// -pi and the objective recomputed from the fresh factors (what the explicit carry's polish does too).
+void Solver::refactor_lu(bool refresh_vectors) {
+    const double t0 = now_seconds();
+    const int m = d_.m;
+    std::vector<int> basis(m);
+    RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, m * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    std::vector<int> cs(m + 1, 0);
+    size_t total = 0;
+    for (int k = 0; k < m; ++k) {
+        if (basis[k] < 0 || basis[k] >= d_.n) throw std::runtime_error("the device returned an invalid basis");
+        total += (size_t)(h_col_start_[basis[k] + 1] - h_col_start_[basis[k]]);
+        cs[k + 1] = (int)total;
+    }
+    std::vector<int> rows(total);
+    std::vector<double> vals(total);
+    for (int k = 0; k < m; ++k) {
+        const int a = h_col_start_[basis[k]], len = h_col_start_[basis[k] + 1] - a;
+        std::copy(h_row_index_.begin() + a, h_row_index_.begin() + a + len, rows.begin() + cs[k]);
+        std::copy(h_value_.begin() + a, h_value_.begin() + a + len, vals.begin() + cs[k]);
+    }
+    LuOptions lo;
+    lo.threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
+    HostLU f = lu_factor(m, cs.data(), rows.data(), vals.data(), lo);
+    if (f.singular) throw std::runtime_error("singular basis in the LU refactorisation");
+    if (lu_.upload(f, refactor_period_ + 1, stream_)) destroy_graphs();
+    binv_identity_ = false;
+    if (refresh_vectors) {
+        launch_lu_xb(d_, lu_.device(), stream_);
+        launch_lu_pi(d_, lu_.device(), stream_);  // also rewrites minus_obj from the refreshed x_B
+    }
+    Ctl c = read_ctl();
+    if (c.status == ST_REFACTOR) {
+        c.status = ST_RUNNING;
+        write_ctl(c);
+    }
+    refactors_++;
+    since_polish_ = 0;
+    refactor_seconds_ += now_seconds() - t0;
+    if (opt_.verbose > 1)
+        fprintf(stderr, "[lu] refactor %lld: nnz(L) %lld nnz(U) %lld depth %d + %d\n", refactors_, lu_.nnz_l, lu_.nnz_u, lu_.depth_l, lu_.depth_u);
+}
+
 // ---- fine-grained ops -------------------------------------------------------------------------------
 void Solver::ftran(int nnz, const int* rows, const double* values, double* out) {
     int* d_rows = reinterpret_cast<int*>(d_.scratch);
     double* d_vals = d_.scratch + (d_.m + 1) / 2 + 1;
     double* d_out = d_vals + d_.m;
-    if (nnz > d_.m) throw std::invalid_argument("nnz > m");
+    check_sparse(nnz, rows, values, d_.m);
+    RELP_HIP(hipSetDevice(opt_.device));
     RELP_HIP(hipMemcpyAsync(d_rows, rows, nnz * sizeof(int), hipMemcpyHostToDevice, stream_));
     RELP_HIP(hipMemcpyAsync(d_vals, values, nnz * sizeof(double), hipMemcpyHostToDevice, stream_));
-    launch_ftran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
+    if (lu_mode_) launch_lu_ftran(lu_.device(), d_rows, d_vals, nnz, d_out, 0, stream_);
+    else launch_ftran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
     RELP_HIP(hipMemcpyAsync(out, d_out, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
 }
@@ -983,10 +1126,12 @@ void Solver::btran(int nnz, const int* rows, const double* values, double* out) 
     int* d_rows = reinterpret_cast<int*>(d_.scratch);
     double* d_vals = d_.scratch + (d_.m + 1) / 2 + 1;
     double* d_out = d_vals + d_.m;
-    if (nnz > d_.m) throw std::invalid_argument("nnz > m");
+    check_sparse(nnz, rows, values, d_.m);
+    RELP_HIP(hipSetDevice(opt_.device));
     RELP_HIP(hipMemcpyAsync(d_rows, rows, nnz * sizeof(int), hipMemcpyHostToDevice, stream_));
     RELP_HIP(hipMemcpyAsync(d_vals, values, nnz * sizeof(double), hipMemcpyHostToDevice, stream_));
-    launch_btran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
+    if (lu_mode_) launch_lu_btran(lu_.device(), d_rows, d_vals, nnz, d_out, stream_);
+    else launch_btran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
     RELP_HIP(hipMemcpyAsync(out, d_out, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
 }
@@ -1018,7 +1163,8 @@ void Solver::price(int* column, double* cbar) {
     c.forced_q = c.forced_p = -1;
     write_ctl(c);
     enqueue_price(0);
-    launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_ + dense_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 1, 0, stream_);
+    if (lu_mode_) enqueue_ftran_ratio(1);
+    else launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_ + dense_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 1, 0, stream_);
     c = read_ctl();
     *column = c.q;
     *cbar = c.q >= 0 ? c.cbar_q : 0.0;
@@ -1082,6 +1228,7 @@ double Solver::refactor() {
 // bracketed by its own start/stop event pair (hipExtLaunchKernelGGL) on this handle's stream.  The solve advances.
 double Solver::profile_kernel(int which, int repetitions) {
     if (phase_ == 0) throw std::runtime_error("no phase started");
+    if (lu_mode_ && which == 2) throw std::invalid_argument("the LU carry has no separate update kernel (which = 1 covers it)");
     RELP_HIP(hipSetDevice(opt_.device));
     const int m = d_.m;
     if (which == 0) {
@@ -1112,11 +1259,12 @@ double Solver::profile_kernel(int which, int repetitions) {
         if (which == 1) arm_launch_timer(1, starts[k], stops[k]);
         enqueue_ftran_ratio(0);
         if (which == 2) arm_launch_timer(2, starts[k], stops[k]);
-        enqueue_update();
+        if (!lu_mode_) enqueue_update();
         if (eta_mode_ && ((k + 1) % d_.eta_cap == 0 || k + 1 == repetitions)) enqueue_consolidate();
     }
     arm_launch_timer(-1, nullptr, nullptr);
     Ctl after = read_ctl();
+    if (after.status == ST_REFACTOR) refactor_lu(true);
     const long long made = after.iters - before.iters;
     pivots_[phase_ - 1] += made;
     since_polish_ += made;

@@ -12,12 +12,13 @@
 
 #include "../../include/relp_amd.h"
 #include "model.hpp"
+#include "lu.hpp"
 
 namespace relp {
 
 // Device control block, written by single-workgroup kernels, polled by the host.
 struct Ctl {
-    int status;        // 0 running | 1 no entering column | 2 unbounded (ratio test empty) | 3 iteration budget used
+    int status;        // 0 running | 1 no entering column | 2 unbounded (ratio test empty) | 3 iteration budget used | 4 refactorise (LU carry)
     int q;             // entering column (device index space: artificials first)
     int p;             // pivot row
     int leaving;       // column that left the basis at row p
@@ -45,7 +46,7 @@ struct Ctl {
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
 
-enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3 };
+enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3, ST_REFACTOR = 4 };  // 4: LU carry, the host has to refactorise
 
 struct DeviceLP {
     int m = 0, n = 0, n_art = 0, ld = 0;
@@ -185,6 +186,17 @@ private:
     void write_ctl(const Ctl& c);
     int drive_out_artificials();
     void certify(relp_result* result);
+    // LU carry (relp_options.carry == RELP_CARRY_LU)
+    void refactor_lu(bool refresh_vectors);  // BasisInverse::invert of the current basis (host Markowitz + upload)
+    void lu_identity();                      // BasisInverse::identity
+    LuFactors lu_;
+    bool lu_mode_ = false;
+    bool lu_is_identity_ = true;
+    int refactor_period_ = 64;
+    long long refactors_ = 0;
+    double refactor_seconds_ = 0.0;
+    std::vector<int> h_col_start_, h_row_index_;  // host copy of the device CSC (basis columns for the refactorisation)
+    std::vector<double> h_value_;
 
     relp_options opt_;
     StandardForm form_;
