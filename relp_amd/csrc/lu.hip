@@ -63,19 +63,26 @@ struct Carver {
     }
 };
 
-__global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
+__global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu, const int* n_levels) {
     const int m = lu.m;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const int stride = blockDim.x * gridDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = first; i < m; i += stride) {
         lu.u_rlen[i] = lu.u_rstart[i + 1] - lu.u_rstart[i];
-        lu.u_app_len[i] = 0;
-        lu.rank[i] = i;
-        lu.seq[i] = i;
+        lu.app_len[i] = 0;
+        lu.slot_of[i] = -1;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = first; i < lu.max_updates * lu.ldt; i += stride) lu.T[i] = 0.0;
+    for (int i = first; i < lu.max_updates; i += stride) {
+        lu.trail_pos[i] = -1;
+        lu.s_clen[i] = 0;
+        lu.s_cstart[i] = 0;
+    }
+    if (first == 0) {
         lu.state[LU_N_UPDATES] = 0;
-        lu.state[LU_UC_TOP] = lu.u_app_first;  // the arena of replaced columns starts behind the base capacity
+        lu.state[LU_S_TOP] = 0;
         lu.state[LU_ETA_TOP] = 0;
         lu.state[LU_FLAGS] = 0;
+        for (int k = 0; k < 4; ++k) lu.state[LU_N_LEVELS + k] = n_levels[k];
         lu.eta_start[0] = 0;
     }
 }
@@ -85,6 +92,7 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const int m = f.m;
     const size_t nl = (size_t)f.nnz_l(), nu = (size_t)f.nnz_u();
     if (max_updates < 1) max_updates = 1;
+    if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
     // The layout depends on capacities only, so that the device addresses (and a captured hipGraph that holds them) survive
     // a refactorisation; it changes when a factor outgrows its capacity (or m / the update capacity change).
     bool layout_changed = m != d_.m || max_updates != d_.max_updates;
@@ -92,6 +100,7 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     if (nl > cap_l_ || cap_l_ == 0) { cap_l_ = nl + nl / 2 + 256; layout_changed = true; }
     if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
     const size_t cl = cap_l_, cu = cap_u_;
+    const int ldt = max_updates + 1;
     // ---- uploaded prefix ----------------------------------------------------------------------------------------------
     Carver c;
     const size_t o_rowpos = c.take<int>(m), o_colpos = c.take<int>(m);
@@ -100,15 +109,23 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t o_diag = c.take<double>(m);
     const size_t o_lrcol = c.take<int>(cl), o_lcrow = c.take<int>(cl);
     const size_t o_lrval = c.take<double>(cl), o_lcval = c.take<double>(cl);
+    size_t o_sched_start[4], o_sched_row[4];
+    for (int k = 0; k < 4; ++k) {
+        o_sched_start[k] = c.take<int>(m + 2);
+        o_sched_row[k] = c.take<int>(m);
+    }
+    const size_t o_nlev = c.take<int>(4);
     const size_t upload_bytes = c.offset;
-    // ---- device only (the base parts of the U arrays are uploaded one by one) ----------------------------------------
-    // U rows: base entries [0, cap_u) then the append area; U columns: base entries then the arena of replaced columns.
+    // ---- device only (the four U_bb arrays are uploaded one by one) ----------------------------------------------------
     const size_t app = (size_t)m * max_updates;
-    const size_t o_urcol = c.take<int>(cu + app), o_ucrow = c.take<int>(cu + app);
-    const size_t o_urval = c.take<double>(cu + app), o_ucval = c.take<double>(cu + app);
-    const size_t o_urlen = c.take<int>(m), o_applen = c.take<int>(m), o_eta_pivot = c.take<int>(max_updates + 1);
-    const size_t o_rank = c.take<int>(m), o_seq = c.take<int>(m);
-    const size_t o_eta_start = c.take<int>(max_updates + 2);
+    const size_t o_urcol = c.take<int>(cu), o_ucrow = c.take<int>(cu);
+    const size_t o_urval = c.take<double>(cu), o_ucval = c.take<double>(cu);
+    const size_t o_urlen = c.take<int>(m);
+    const size_t o_applen = c.take<int>(m), o_appslot = c.take<int>(app), o_appval = c.take<double>(app);
+    const size_t o_scs = c.take<int>(max_updates), o_scl = c.take<int>(max_updates), o_scrow = c.take<int>(app), o_scval = c.take<double>(app);
+    const size_t o_T = c.take<double>((size_t)max_updates * ldt);
+    const size_t o_trail = c.take<int>(max_updates), o_slotof = c.take<int>(m);
+    const size_t o_eta_start = c.take<int>(max_updates + 2), o_eta_pivot = c.take<int>(max_updates + 1);
     const size_t o_eta_idx = c.take<int>(app), o_eta_val = c.take<double>(app);
     const size_t o_spike = c.take<double>(m);
     const size_t o_state = c.take<int>(LU_STATE_WORDS);
@@ -133,6 +150,16 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         std::memcpy(h + o_lrval, f.l_val.data(), nl * sizeof(double));
     }
     std::memcpy(h + o_diag, f.diag.data(), m * sizeof(double));
+    {
+        HostLU& fs = const_cast<HostLU&>(f);
+        if (fs.lev_row[0].empty()) lu_schedules(fs);
+        int* nlev = reinterpret_cast<int*>(h + o_nlev);
+        for (int k = 0; k < 4; ++k) {
+            std::memcpy(h + o_sched_start[k], f.lev_start[k].data(), f.lev_start[k].size() * sizeof(int));
+            std::memcpy(h + o_sched_row[k], f.lev_row[k].data(), m * sizeof(int));
+            nlev[k] = (int)f.lev_start[k].size() - 1;
+        }
+    }
     // column orientation of L and U (counting transposes)
     {
         int* lcs = reinterpret_cast<int*>(h + o_lcs);
@@ -181,6 +208,7 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     DeviceLU d;
     d.m = m;
     d.max_updates = max_updates;
+    d.ldt = ldt;
     auto I = [&](size_t o) { return reinterpret_cast<int*>(dev_ + o); };
     auto D = [&](size_t o) { return reinterpret_cast<double*>(dev_ + o); };
     d.rowpos = I(o_rowpos);
@@ -188,141 +216,280 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     d.l_rstart = I(o_lrs); d.l_rcol = I(o_lrcol); d.l_rval = D(o_lrval);
     d.l_cstart = I(o_lcs); d.l_crow = I(o_lcrow); d.l_cval = D(o_lcval);
     d.u_rstart = I(o_urs); d.u_rlen = I(o_urlen); d.u_rcol = I(o_urcol); d.u_rval = D(o_urval);
-    d.u_app_len = I(o_applen); d.u_app_first = (int)cu; d.u_app_stride = max_updates;
     d.u_cstart = I(o_ucs); d.u_clen = I(o_uclen); d.u_crow = I(o_ucrow); d.u_cval = D(o_ucval);
-    d.u_c_capacity = (int)(cu + app);
+    d.app_len = I(o_applen); d.app_slot = I(o_appslot); d.app_val = D(o_appval);
+    d.s_cstart = I(o_scs); d.s_clen = I(o_scl); d.s_crow = I(o_scrow); d.s_cval = D(o_scval);
+    d.s_capacity = (int)app;
+    d.T = D(o_T);
+    d.trail_pos = I(o_trail);
+    d.slot_of = I(o_slotof);
     d.diag = D(o_diag);
-    d.rank = I(o_rank); d.seq = I(o_seq);
     d.eta_start = I(o_eta_start); d.eta_pivot = I(o_eta_pivot); d.eta_idx = I(o_eta_idx); d.eta_val = D(o_eta_val);
     d.eta_capacity = (int)app;
     d.spike = D(o_spike);
     d.state = I(o_state);
+    for (int k = 0; k < 4; ++k) {
+        d.sched_start[k] = I(o_sched_start[k]);
+        d.sched_row[k] = I(o_sched_row[k]);
+    }
     d_ = d;
-    hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_);
+    hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_, I(o_nlev));
     nnz_l = (long long)nl;
     nnz_u = (long long)nu;
     lu_depths(f, &depth_l, &depth_u);
     return layout_changed;
 }
 
-// LDS of the solve kernels: x0, x1 (doubles), flags (ints), one count per 64 rows for the ordered compactions, reductions
-static size_t lu_lds_bytes_for(int m) {
+// LDS of the solve kernels: x0, x1 (doubles); one count per 64 rows for the ordered compactions; reductions; T and the
+// trailing parts of the two vectors; and the factor area -- the headers of the triangular factor being solved with
+// (start, length, level order, 1/diagonal: 24 bytes per row) always, its entries (12 bytes each) when they fit.
+static size_t lu_lds_fixed_bytes(int m, int max_updates) {
     const size_t mm = (size_t)((m + 1) & ~1);
-    return 2 * mm * sizeof(double) + mm * sizeof(int) + ((size_t)(m + 63) / 64 + 2) * sizeof(int) + 64 * sizeof(double);
+    return 2 * mm * sizeof(double) + ((size_t)(m + 63) / 64 + 2) * sizeof(int) + 64 * sizeof(double) +
+           ((size_t)max_updates * (max_updates + 1) + 4 * LU_MAX_SLOTS) * sizeof(double) + 64 +
+           mm * sizeof(double) + 3 * mm * sizeof(int) + (size_t)(m + 2) * sizeof(int) + 64;
 }
-size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_.m); }
-bool lu_fits_lds(int m) { return lu_lds_bytes_for(m) <= 160 * 1024 - 4096; }
+constexpr size_t LU_LDS_TOTAL = 160 * 1024 - 1024;  // what a kernel may ask for (static LDS of the fused kernel comes on top)
+static size_t lu_lds_bytes_for(int m, int max_updates) {
+    (void)m;
+    (void)max_updates;
+    return LU_LDS_TOTAL - 2048;  // always the whole CU: one workgroup per solve, and the factor area takes what is left
+}
+size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_.m, d_.max_updates); }
+bool lu_fits_lds(int m) { return lu_lds_fixed_bytes(m, 32) + 16 * 1024 <= LU_LDS_TOTAL - 2048; }
 
 // =====================================================================================================
-// device: sync-free triangular solves in LDS
+// device: level-scheduled triangular solves out of LDS
 // =====================================================================================================
-struct TriView {
-    const int* start;      // first entry of row (column) i
-    const int* len;        // nullptr: start[i + 1] - start[i]
-    const int* idx;
-    const double* val;
-    const int* app_len;    // second segment (U rows): entries at app_first + i * app_stride; nullptr: none
-    int app_first, app_stride;
-    const double* diag;    // nullptr: unit diagonal
-    const int* seq;        // visiting order of the rows (nullptr: identity)
+// Explicit LDS pointer types.  A generic `volatile double*` that happens to point into LDS compiles to flat_load ... sc0 sc1
+// -- measured: about 2000 cycles per dependent access instead of the ~64 of a ds_read -- so every LDS array of this file is
+// typed by address space.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) char lds_i8;
+// One triangular factor in one orientation, staged for a solve.  The row records are LDS arrays in SCHEDULE order (record r
+// = the r-th row of the level order): position, first entry, length (-1: not part of this triangle), 1 / diagonal.  `idx` /
+// `val` are LDS copies of the entries when the factor fits, else the L2-resident arrays.
+template <class IdxPtr, class ValPtr>
+struct Factor {
+    const lds_i32* rec_i;
+    const lds_i32* rec_s;
+    const lds_i32* rec_n;
+    const lds_f64* rec_dinv;
+    IdxPtr idx;
+    ValPtr val;
+    const lds_i32* lev_start;
+    int n_levels;
 };
 
-// In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i].  Thread t owns the rows order(t), order(t + T), ...; a row
-// depends only on rows earlier in the visiting order (triangularity), so the thread that owns the first unfinished row can
-// always proceed: no deadlock.  A published row has flag[i] == epoch (the value is written before the flag; LDS keeps a
-// wave's accesses in order).  Lanes never spin inside a divergent branch: every trip of the loop each lane either consumes
-// its next entry or not, so a lane waiting on another lane of its own wave cannot block it.
-template <int NRHS, bool REVERSE>
-__device__ __forceinline__ void solve_gather(const TriView tv, const int m, volatile double* x0, volatile double* x1,
-                                             volatile int* flag, const int epoch) {
-    int k = threadIdx.x;
-    bool have = k < m;
-    int i = 0, e = 0, end = 0, e2 = 0, end2 = 0, c = 0;
-    double v = 0.0, a0 = 0.0, a1 = 0.0, dinv = 1.0;
-    auto begin_row = [&]() {
-        const int r = REVERSE ? m - 1 - k : k;
-        i = tv.seq ? tv.seq[r] : r;
-        e = tv.start[i];
-        end = e + (tv.len ? tv.len[i] : tv.start[i + 1] - e);
-        if (tv.app_len) {
-            e2 = tv.app_first + i * tv.app_stride;
-            end2 = e2 + tv.app_len[i];
-        } else {
-            e2 = end2 = 0;
+// In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i], level by level (the rows of a level are independent; the
+// host computed the levels at refactorisation time and Forrest-Tomlin updates only remove entries, so they stay valid).
+// A level wider than a wave is shared by all threads and followed by a barrier; a run of narrow levels -- the long tail of a
+// basis factor: chains of one or two rows -- is walked by wave 0 alone WITHOUT barriers (LDS keeps one wave's accesses in
+// order) as a three-stage software pipeline: while level l waits for its operands x[idx], the entries of level l + 1 and the
+// row records of level l + 2 are already in flight, so a level costs ONE LDS round trip.  Everything is branch-free (clamped
+// addresses, selected contributions): a branch per entry would put an s_waitcnt behind every load (measured: 3000 cycles per
+// level).  Deterministic: a row adds its entries in storage order.
+// sum over aligned groups of G = 2^k lanes by DPP moves; valid in the LAST lane of every group (G <= 16: in all its lanes)
+__device__ __forceinline__ double group_sum(double v, const int G) {
+    if (G >= 2) v += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, v);
+    if (G >= 4) v += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, v);
+    if (G == 8) v += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, v);
+    if (G >= 16) {
+        v += dpp_f64<DPP_ROW_ROR4, 0xF>(0.0, v);
+        v += dpp_f64<DPP_ROW_ROR8, 0xF>(0.0, v);
+    }
+    if (G >= 32) v += dpp_f64<DPP_ROW_BCAST15, 0xA>(0.0, v);
+    if (G == 64) v += dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, v);
+    return v;
+}
+__device__ __forceinline__ int lanes_per_row(int width) {
+    return width <= 1 ? 64 : width <= 2 ? 32 : width <= 4 ? 16 : width <= 8 ? 8 : width <= 16 ? 4 : width <= 32 ? 2 : 1;
+}
+
+template <int NRHS, bool HAS_DIAG, class F>
+__device__ __forceinline__ void solve_levels(const F fac, volatile lds_f64* x0, volatile lds_f64* x1, unsigned long long* dbg = nullptr) {
+    (void)dbg;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+    // ---- wide levels: a thread per row ---------------------------------------------------------------------------------
+    auto whole_row = [&](int r) {
+        const int i = fac.rec_i[r], st = fac.rec_s[r], n = fac.rec_n[r];
+        if (n < 0) return;
+        double a0 = x0[i], a1 = NRHS == 2 ? x1[i] : 0.0;
+        for (int k = 0; k < n; k += 4) {  // four entries per trip: two LDS round trips instead of eight
+            const int last = n - 1;
+            const int k0 = st + k, k1 = st + min(k + 1, last), k2 = st + min(k + 2, last), k3 = st + min(k + 3, last);
+            const int c0 = fac.idx[k0], c1 = fac.idx[k1], c2 = fac.idx[k2], c3 = fac.idx[k3];
+            const double v0 = fac.val[k0], v1 = fac.val[k1], v2 = fac.val[k2], v3 = fac.val[k3];
+            const double p0 = x0[c0], p1 = x0[c1], p2 = x0[c2], p3 = x0[c3];
+            a0 -= v0 * p0;
+            a0 -= k + 1 < n ? v1 * p1 : 0.0;
+            a0 -= k + 2 < n ? v2 * p2 : 0.0;
+            a0 -= k + 3 < n ? v3 * p3 : 0.0;
+            if (NRHS == 2) {
+                const double q0 = x1[c0], q1 = x1[c1], q2 = x1[c2], q3 = x1[c3];
+                a1 -= v0 * q0;
+                a1 -= k + 1 < n ? v1 * q1 : 0.0;
+                a1 -= k + 2 < n ? v2 * q2 : 0.0;
+                a1 -= k + 3 < n ? v3 * q3 : 0.0;
+            }
         }
-        if (e == end) {
-            e = e2;
-            end = end2;
-            e2 = end2;
-        }
-        dinv = tv.diag ? 1.0 / tv.diag[i] : 1.0;
-        a0 = x0[i];
-        if (NRHS == 2) a1 = x1[i];
-        if (e < end) {
-            c = tv.idx[e];
-            v = tv.val[e];
-        }
+        const double dinv = HAS_DIAG ? fac.rec_dinv[r] : 1.0;
+        x0[i] = a0 * dinv;
+        if (NRHS == 2) x1[i] = a1 * dinv;
     };
-    if (have) begin_row();
-    while (__any(have)) {
-        bool progressed = false;
-        if (have) {
-            if (e < end) {
-                const int f = flag[c];
-                const double xc0 = x0[c];
-                const double xc1 = NRHS == 2 ? x1[c] : 0.0;
-                if (f == epoch) {
-                    a0 -= v * xc0;
-                    if (NRHS == 2) a1 -= v * xc1;
-                    ++e;
-                    if (e == end) {
-                        e = e2;
-                        end = end2;
-                        e2 = end2;
+    // ---- narrow levels: G lanes per row, software pipeline over the levels of a run ---------------------------------------
+    struct Hdr {
+        int i, s, n, G;
+        double dinv;
+    };
+    struct Ent {
+        int i, s, n, G, c;
+        double v, a0, a1, dinv;
+    };
+    auto narrow = [&](int l) { return l < fac.n_levels && fac.lev_start[l + 1] - fac.lev_start[l] <= WAVE; };
+    int l = 0;
+    const int n_levels = fac.n_levels;
+    while (l < n_levels) {
+        const int ls = fac.lev_start[l], le = fac.lev_start[l + 1];
+        if (le - ls > WAVE) {
+            for (int r = ls + tid; r < le; r += T) whole_row(r);
+            __syncthreads();
+            ++l;
+        } else {
+            int l2 = l + 1;
+            while (narrow(l2)) ++l2;  // the run is [l, l2)
+            if (wave == 0) {
+                auto hdr_of = [&](int lev) {  // stage 1: the row record of this lane's row in level `lev`
+                    const bool in = lev < l2;
+                    const int s0 = in ? fac.lev_start[lev] : 0, s1 = in ? fac.lev_start[lev + 1] : 0;
+                    const int G = lanes_per_row(s1 - s0);
+                    const int row = lane / G;
+                    const bool active = in && row < s1 - s0;
+                    const int rr = active ? s0 + row : 0;
+                    Hdr h;
+                    h.i = fac.rec_i[rr];
+                    h.s = fac.rec_s[rr];
+                    const int n = fac.rec_n[rr];
+                    h.n = active ? n : -1;
+                    h.G = G;
+                    h.dinv = HAS_DIAG ? fac.rec_dinv[rr] : 1.0;
+                    return h;
+                };
+                auto ent = [&](const Hdr& h) {  // stage 2: this lane's first entry, the row's right-hand side
+                    Ent e;
+                    e.i = h.i;
+                    e.s = h.s;
+                    e.n = h.n;
+                    e.G = h.G;
+                    e.dinv = h.dinv;
+                    const int sub = lane & (h.G - 1);
+                    const int k = min(sub, max(h.n - 1, 0));
+                    e.c = fac.idx[h.s + k];
+                    e.v = fac.val[h.s + k];
+                    e.a0 = x0[h.i];
+                    e.a1 = NRHS == 2 ? x1[h.i] : 0.0;
+                    return e;
+                };
+                auto finish = [&](const Ent& e) {  // stage 3: operands, the rest of a long row, group sum, publish
+                    const int sub = lane & (e.G - 1);
+                    const double p = x0[e.c];
+                    const double q = NRHS == 2 ? x1[e.c] : 0.0;
+                    double s0 = sub < e.n ? e.v * p : 0.0;
+                    double s1 = (NRHS == 2 && sub < e.n) ? e.v * q : 0.0;
+                    if (e.n > e.G) {  // long rows: four more entries per lane and trip
+                        const int last = e.n - 1;
+                        for (int k = sub + e.G; k < e.n; k += 4 * e.G) {
+                            const int k0 = e.s + k, k1 = e.s + min(k + e.G, last), k2 = e.s + min(k + 2 * e.G, last), k3 = e.s + min(k + 3 * e.G, last);
+                            const int c0 = fac.idx[k0], c1 = fac.idx[k1], c2 = fac.idx[k2], c3 = fac.idx[k3];
+                            const double v0 = fac.val[k0], v1 = fac.val[k1], v2 = fac.val[k2], v3 = fac.val[k3];
+                            const double p0 = x0[c0], p1 = x0[c1], p2 = x0[c2], p3 = x0[c3];
+                            s0 += v0 * p0;
+                            s0 += k + e.G < e.n ? v1 * p1 : 0.0;
+                            s0 += k + 2 * e.G < e.n ? v2 * p2 : 0.0;
+                            s0 += k + 3 * e.G < e.n ? v3 * p3 : 0.0;
+                            if (NRHS == 2) {
+                                const double q0 = x1[c0], q1 = x1[c1], q2 = x1[c2], q3 = x1[c3];
+                                s1 += v0 * q0;
+                                s1 += k + e.G < e.n ? v1 * q1 : 0.0;
+                                s1 += k + 2 * e.G < e.n ? v2 * q2 : 0.0;
+                                s1 += k + 3 * e.G < e.n ? v3 * q3 : 0.0;
+                            }
+                        }
                     }
-                    if (e < end) {
-                        c = tv.idx[e];
-                        v = tv.val[e];
+                    s0 = group_sum(s0, e.G);
+                    if (NRHS == 2) s1 = group_sum(s1, e.G);
+                    if (e.n >= 0 && sub == e.G - 1) {
+                        x0[e.i] = (e.a0 - s0) * e.dinv;
+                        if (NRHS == 2) x1[e.i] = (e.a1 - s1) * e.dinv;
                     }
-                    progressed = true;
+                };
+                Ent e_cur = ent(hdr_of(l));
+                Hdr h_next = hdr_of(l + 1);
+                for (int lev = l; lev < l2; ++lev) {
+#ifdef RELP_STAMPS
+                    const unsigned long long ta = clock64();
+#endif
+                    const Hdr h_after = hdr_of(lev + 2);   // stage 1 of level lev + 2
+#ifdef RELP_STAMPS
+                    const unsigned long long tb = clock64();
+#endif
+                    const Ent e_next = ent(h_next);        // stage 2 of level lev + 1
+#ifdef RELP_STAMPS
+                    const unsigned long long tc = clock64();
+#endif
+                    finish(e_cur);                         // stage 3 of level lev
+#ifdef RELP_STAMPS
+                    if (dbg && tid == 0) {
+                        const unsigned long long td = clock64();
+                        dbg[40] += tb - ta;
+                        dbg[41] += tc - tb;
+                        dbg[42] += td - tc;
+                        dbg[43] += 1;
+                        dbg[44] += e_cur.n > e_cur.G ? 1 : 0;
+                        dbg[45] += e_cur.n > 0 ? e_cur.n : 0;
+                    }
+#endif
+                    e_cur = e_next;
+                    h_next = h_after;
                 }
             }
-            if (e >= end) {
-                x0[i] = a0 * dinv;
-                if (NRHS == 2) x1[i] = a1 * dinv;
-                flag[i] = epoch;
-                k += blockDim.x;
-                have = k < m;
-                if (have) begin_row();
-                progressed = true;
-            }
+            l = l2;
+            __syncthreads();
         }
-        if (!__any(progressed)) __builtin_amdgcn_s_sleep(1);
     }
 }
 
 // ---- eta files --------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_value(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 // FTRAN direction (eta_file.rs:72-105): for each update in order  v[t] -= sum_k r_k v[k].  One wave; a dot product per eta.
-__device__ __forceinline__ void apply_etas_forward(const DeviceLU& lu, const int n_updates, volatile double* x0) {
-    if (threadIdx.x >= WAVE) return;
+// Lane l keeps the bounds and the pivot of eta l (at most 64 of them), so the loop's only memory traffic are the entries,
+// and those are prefetched one eta ahead.
+__device__ __forceinline__ void apply_etas_forward(const DeviceLU& lu, const int n_updates, volatile lds_f64* x0) {
+    if (threadIdx.x >= WAVE || n_updates <= 0) return;
     const int lane = threadIdx.x;
-    int s = 0;
+    const int my_start = lane <= n_updates ? lu.eta_start[lane] : 0;
+    const int my_end = lane < n_updates ? lu.eta_start[lane + 1] : 0;
+    const int my_pivot = lane < n_updates ? lu.eta_pivot[lane] : 0;
+    int s = lane_value(my_start, 0), s_end = lane_value(my_end, 0);
     int nidx = 0;
     double nval = 0.0;
-    int s_end = n_updates > 0 ? lu.eta_start[1] : 0;
-    if (n_updates > 0 && s + lane < s_end) {
+    if (s + lane < s_end) {
         nidx = lu.eta_idx[s + lane];
         nval = lu.eta_val[s + lane];
     }
     for (int k = 0; k < n_updates; ++k) {
         const int e_end = s_end;
-        const int t = lu.eta_pivot[k];
+        const int t = lane_value(my_pivot, k);
         const int cidx = nidx;
         const double cval = nval;
         const bool chave = s + lane < e_end;
-        // prefetch the first chunk of the next eta while this one is reduced
         const int s_next = e_end;
-        s_end = k + 1 < n_updates ? lu.eta_start[k + 2] : e_end;
+        s_end = k + 1 < n_updates ? lane_value(my_end, k + 1) : e_end;
         if (k + 1 < n_updates && s_next + lane < s_end) {
             nidx = lu.eta_idx[s_next + lane];
             nval = lu.eta_val[s_next + lane];
@@ -336,31 +503,68 @@ __device__ __forceinline__ void apply_etas_forward(const DeviceLU& lu, const int
 }
 // BTRAN direction (eta_file.rs:49-65): for each update in reverse  v[j] -= r_j v[t].
 template <int NRHS>
-__device__ __forceinline__ void apply_etas_backward(const DeviceLU& lu, const int n_updates, volatile double* x0, volatile double* x1) {
-    if (threadIdx.x >= WAVE) return;
+__device__ __forceinline__ void apply_etas_backward(const DeviceLU& lu, const int n_updates, volatile lds_f64* x0, volatile lds_f64* x1) {
+    if (threadIdx.x >= WAVE || n_updates <= 0) return;
     const int lane = threadIdx.x;
+    const int my_start = lane < n_updates ? lu.eta_start[lane] : 0;
+    const int my_end = lane < n_updates ? lu.eta_start[lane + 1] : 0;
+    const int my_pivot = lane < n_updates ? lu.eta_pivot[lane] : 0;
+    int s = lane_value(my_start, n_updates - 1), e_end = lane_value(my_end, n_updates - 1);
+    int nidx = 0;
+    double nval = 0.0;
+    if (s + lane < e_end) {
+        nidx = lu.eta_idx[s + lane];
+        nval = lu.eta_val[s + lane];
+    }
     for (int k = n_updates - 1; k >= 0; --k) {
-        const int s = lu.eta_start[k], e_end = lu.eta_start[k + 1];
-        const int t = lu.eta_pivot[k];
-        const double v0 = x0[t];
-        const double v1 = NRHS == 2 ? x1[t] : 0.0;
-        if (v0 == 0.0 && v1 == 0.0) continue;
-        for (int e = s + lane; e < e_end; e += WAVE) {
+        const int t = lane_value(my_pivot, k);
+        const int cidx = nidx;
+        const double cval = nval;
+        const bool chave = s + lane < e_end;
+        const int cs = s, cend = e_end;
+        if (k > 0) {
+            s = lane_value(my_start, k - 1);
+            e_end = lane_value(my_end, k - 1);
+            if (s + lane < e_end) {
+                nidx = lu.eta_idx[s + lane];
+                nval = lu.eta_val[s + lane];
+            }
+        }
+        const double p0 = x0[t];
+        const double p1 = NRHS == 2 ? x1[t] : 0.0;
+        if (p0 == 0.0 && p1 == 0.0) continue;
+        if (chave) {
+            x0[cidx] = x0[cidx] - cval * p0;
+            if (NRHS == 2) x1[cidx] = x1[cidx] - cval * p1;
+        }
+        for (int e = cs + lane + WAVE; e < cend; e += WAVE) {
             const int j = lu.eta_idx[e];
             const double r = lu.eta_val[e];
-            x0[j] = x0[j] - r * v0;
-            if (NRHS == 2) x1[j] = x1[j] - r * v1;
+            x0[j] = x0[j] - r * p0;
+            if (NRHS == 2) x1[j] = x1[j] - r * p1;
         }
     }
 }
 
 // LDS carve-up shared by every kernel of this file
 struct LuShared {
-    volatile double* x0;
-    volatile double* x1;
-    volatile int* flag;
-    int* group_count;  // one slot per 64 rows (+2)
+    volatile lds_f64* x0;
+    volatile lds_f64* x1;
+    int* group_count;  // one slot per 64 rows (+2)   (generic pointers: used with barriers around, a handful of accesses)
     double* red;       // 64 doubles
+    volatile lds_f64* T;     // the trailing block, max_updates x ldt
+    volatile lds_f64* xt0;   // trailing values by slot (LU_MAX_SLOTS each)
+    volatile lds_f64* xt1;
+    volatile lds_f64* st0;   // BTRAN: right-hand sides of the trailing solve
+    volatile lds_f64* st1;
+    // factor area
+    lds_f64* f_dinv;    // [m]
+    lds_i32* f_start;   // [m]
+    lds_i32* f_len;     // [m]
+    lds_i32* f_levrow;  // [m]
+    lds_i32* f_levstart;  // [m + 2]
+    lds_i8* f_entries;  // what is left of the LDS
+    int f_entry_capacity;  // entries (12 bytes each) that fit there
     unsigned long long* dbg;  // diagnostic builds (-DRELP_STAMPS): per-segment cycle sums; nullptr otherwise
     unsigned long long* t_prev;
 };
@@ -373,26 +577,115 @@ __device__ __forceinline__ void lu_stamp(const LuShared& sh, int k) {
     }
 #endif
 }
-__device__ __forceinline__ LuShared lu_shared(char* smem, int m) {
+__device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max_updates, int lds_bytes) {
     const int mm = (m + 1) & ~1;
+    lds_i8* smem = (lds_i8*)smem_generic;
     LuShared s;
-    s.x0 = reinterpret_cast<volatile double*>(smem);
-    s.x1 = s.x0 + mm;
-    s.red = const_cast<double*>(s.x1 + mm);
-    s.flag = reinterpret_cast<volatile int*>(s.red + 64);
-    s.group_count = const_cast<int*>(s.flag + mm);
+    lds_f64* x0 = (lds_f64*)smem;
+    lds_f64* x1 = x0 + mm;
+    lds_f64* red = x1 + mm;
+    lds_f64* T = red + 64;
+    lds_f64* xt0 = T + max_updates * (max_updates + 1);
+    lds_f64* xt1 = xt0 + LU_MAX_SLOTS;
+    lds_f64* st0 = xt1 + LU_MAX_SLOTS;
+    lds_f64* st1 = st0 + LU_MAX_SLOTS;
+    s.x0 = x0;
+    s.x1 = x1;
+    s.red = (double*)red;
+    s.T = T;
+    s.xt0 = xt0;
+    s.xt1 = xt1;
+    s.st0 = st0;
+    s.st1 = st1;
+    s.f_dinv = st1 + LU_MAX_SLOTS;
+    s.f_start = (lds_i32*)(s.f_dinv + mm);
+    s.f_len = s.f_start + mm;
+    s.f_levrow = s.f_len + mm;
+    s.f_levstart = s.f_levrow + mm;
+    lds_i32* group_count = s.f_levstart + ((m + 2 + 1) & ~1);
+    s.group_count = (int*)group_count;
+    lds_i8* end = (lds_i8*)(group_count + (((m + 63) / 64 + 2 + 1) & ~1));
+    s.f_entries = end;
+    s.f_entry_capacity = (int)((lds_bytes - (int)(end - smem)) / 12);
+    if (s.f_entry_capacity < 0) s.f_entry_capacity = 0;
     s.dbg = nullptr;
     s.t_prev = nullptr;
     return s;
 }
+// x0 (x1) <- 0, T staged from global.  Ends with a barrier.
+__device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh, int n_updates, bool two) {
+    const int m = lu.m;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        sh.x0[i] = 0.0;
+        if (two) sh.x1[i] = 0.0;
+    }
+    for (int i = threadIdx.x; i < n_updates * lu.ldt; i += blockDim.x) sh.T[i] = lu.T[i];
+    __syncthreads();
+}
 
-// FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve.  Ends with a barrier.
+// Copy one orientation of one factor into the factor area (row records in schedule order always, entries when they fit)
+// and solve with it.
+//   g_start / g_len: first entry and length per row (g_len == nullptr: g_start has m + 1 entries); nnz: entries to copy;
+//   skip: rows with skip[i] >= 0 are not part of the triangle; diag: nullptr = unit; sched: which level schedule.
+// The caller's x0 / x1 must be complete (barrier) before; ends with a barrier (solve_levels does).
+template <int NRHS, bool HAS_DIAG>
+__device__ __forceinline__ void lu_stage_and_solve(const DeviceLU& lu, const LuShared& sh, const int* g_start, const int* g_len,
+                                                   const int* g_idx, const double* g_val, const int nnz, const int* skip,
+                                                   const double* diag, const int sched) {
+    const int m = lu.m;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int n_levels = lu.state[LU_N_LEVELS + sched];
+    for (int r = tid; r < m; r += T) {
+        const int i = lu.sched_row[sched][r];
+        const int st = g_start[i];
+        int n = g_len ? g_len[i] : g_start[i + 1] - st;
+        if (skip && skip[i] >= 0) n = -1;
+        sh.f_levrow[r] = i;
+        sh.f_start[r] = st;
+        sh.f_len[r] = n;
+        if (HAS_DIAG) sh.f_dinv[r] = 1.0 / diag[i];
+    }
+    for (int l = tid; l <= n_levels; l += T) sh.f_levstart[l] = lu.sched_start[sched][l];
+    const bool fits = nnz + 4 <= sh.f_entry_capacity;
+    lds_i32* e_idx = (lds_i32*)(sh.f_entries + sh.f_entry_capacity * 8);
+    lds_f64* e_val = (lds_f64*)sh.f_entries;
+    if (fits) {
+        for (int e = tid; e < nnz; e += T) {
+            e_idx[e] = g_idx[e];
+            e_val[e] = g_val[e];
+        }
+        if (tid < 4) {  // (the clamped reads of an empty last row land here)
+            e_idx[nnz + tid] = 0;
+            e_val[nnz + tid] = 0.0;
+        }
+    }
+    __syncthreads();
+    lu_stamp(sh, 13 + sched);
+#ifdef RELP_STAMPS
+    if (sh.dbg && threadIdx.x == 0) {
+        sh.dbg[20 + sched] += n_levels;
+        int wide = 0;
+        for (int l = 0; l < n_levels; ++l) wide += (sh.f_levstart[l + 1] - sh.f_levstart[l] > WAVE) ? 1 : 0;
+        sh.dbg[24 + sched] += wide;
+        sh.dbg[28 + sched] += fits ? 1 : 0;
+    }
+#endif
+    if (fits) {
+        Factor<const lds_i32*, const lds_f64*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, e_idx, e_val, sh.f_levstart, n_levels};
+        solve_levels<NRHS, HAS_DIAG>(f, sh.x0, sh.x1, sh.dbg);
+    } else {
+        Factor<const int*, const double*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, g_idx, g_val, sh.f_levstart, n_levels};
+        solve_levels<NRHS, HAS_DIAG>(f, sh.x0, sh.x1, sh.dbg);
+    }
+}
+
+// FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve (trailing block by one
+// wave, spike contributions, then the base rows).  Ends with a barrier.
 __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
                                                double* spike_out) {
+    (void)epoch;
     const int m = lu.m;
-    TriView L{lu.l_rstart, nullptr, lu.l_rcol, lu.l_rval, nullptr, 0, 0, nullptr, nullptr};
-    solve_gather<1, false>(L, m, sh.x0, sh.x1, sh.flag, ++epoch);
-    __syncthreads();
+    lu_stage_and_solve<1, false>(lu, sh, lu.l_rstart, nullptr, lu.l_rcol, lu.l_rval, lu.l_rstart[m], nullptr, nullptr, 0);
     lu_stamp(sh, 2);
     if (n_updates > 0) {
         apply_etas_forward(lu, n_updates, sh.x0);
@@ -401,9 +694,32 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
     lu_stamp(sh, 3);
     if (spike_out)
         for (int i = threadIdx.x; i < m; i += blockDim.x) spike_out[i] = sh.x0[i];
-    TriView U{lu.u_rstart, lu.u_rlen, lu.u_rcol, lu.u_rval, lu.u_app_len, lu.u_app_first, lu.u_app_stride, lu.diag, lu.seq};
-    solve_gather<1, true>(U, m, sh.x0, sh.x1, sh.flag, ++epoch);
-    __syncthreads();
+    if (n_updates > 0) {
+        if (threadIdx.x < WAVE) {  // T x_T = y_T, back substitution by slot (lower_upper/mod.rs:307-321 on the trailing block)
+            const int lane = threadIdx.x;
+            const int pos = lane < n_updates ? lu.trail_pos[lane] : -1;
+            double xk = pos >= 0 ? sh.x0[pos] : 0.0;
+            const double dk = pos >= 0 ? lu.diag[pos] : 1.0;
+            for (int b = n_updates - 1; b >= 0; --b) {
+                if (lane == b) xk = xk / dk;
+                const double xb = lane_value(xk, b);
+                if (lane < b && xb != 0.0) xk -= sh.T[lane * lu.ldt + b] * xb;
+            }
+            if (lane < n_updates) sh.xt0[lane] = xk;
+            if (pos >= 0) sh.x0[pos] = xk;
+        }
+        __syncthreads();
+        // y_b -= S x_T: a base row's spike entries (one per update at most), operands final
+        const int stride = lu.max_updates;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const int n_app = lu.app_len[i];
+            if (n_app <= 0) continue;
+            double acc = 0.0;
+            for (int e = 0; e < n_app; ++e) acc += lu.app_val[i * stride + e] * sh.xt0[lu.app_slot[i * stride + e]];
+            sh.x0[i] = sh.x0[i] - acc;
+        }
+    }
+    lu_stage_and_solve<1, true>(lu, sh, lu.u_rstart, lu.u_rlen, lu.u_rcol, lu.u_rval, lu.u_rstart[m], n_updates > 0 ? lu.slot_of : nullptr, lu.diag, 1);
     lu_stamp(sh, 4);
 }
 
@@ -412,10 +728,57 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
 template <int NRHS, class AfterUpper>
 __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
                                                AfterUpper after_upper) {
+    (void)epoch;
     const int m = lu.m;
-    TriView U{lu.u_cstart, lu.u_clen, lu.u_crow, lu.u_cval, nullptr, 0, 0, lu.diag, lu.seq};
-    solve_gather<NRHS, false>(U, m, sh.x0, sh.x1, sh.flag, ++epoch);
-    __syncthreads();
+    lu_stage_and_solve<NRHS, true>(lu, sh, lu.u_cstart, lu.u_clen, lu.u_crow, lu.u_cval, lu.u_rstart[m], n_updates > 0 ? lu.slot_of : nullptr, lu.diag, 2);
+    if (n_updates > 0) {
+        // right-hand side of the trailing solve: v_T - z_b S, one wave per spike column (lower_upper/mod.rs:373-397)
+        const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, nwaves = blockDim.x / WAVE;
+        for (int k = wave; k < n_updates; k += nwaves) {
+            const int pos = lu.trail_pos[k];
+            double p0 = 0.0, p1 = 0.0;
+            if (pos >= 0) {
+                const int cs = lu.s_cstart[k], cl = lu.s_clen[k];
+                for (int e = lane; e < cl; e += WAVE) {
+                    const int i = lu.s_crow[cs + e];
+                    const double v = lu.s_cval[cs + e];
+                    p0 += v * sh.x0[i];
+                    if (NRHS == 2) p1 += v * sh.x1[i];
+                }
+            }
+            p0 = wave_sum(p0);
+            if (NRHS == 2) p1 = wave_sum(p1);
+            if (lane == LAST) {
+                sh.st0[k] = pos >= 0 ? sh.x0[pos] - p0 : 0.0;
+                if (NRHS == 2) sh.st1[k] = pos >= 0 ? sh.x1[pos] - p1 : 0.0;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < WAVE) {  // z_T T = s_T, forward substitution by slot
+            const int pos = lane < n_updates ? lu.trail_pos[lane] : -1;
+            double s0 = lane < n_updates ? sh.st0[lane] : 0.0;
+            double s1 = (NRHS == 2 && lane < n_updates) ? sh.st1[lane] : 0.0;
+            const double dk = pos >= 0 ? lu.diag[pos] : 1.0;
+            for (int a = 0; a < n_updates; ++a) {
+                if (lane == a) {
+                    s0 = s0 / dk;
+                    if (NRHS == 2) s1 = s1 / dk;
+                }
+                const double z0 = lane_value(s0, a);
+                const double z1 = NRHS == 2 ? lane_value(s1, a) : 0.0;
+                if (lane > a && lane < n_updates && (z0 != 0.0 || z1 != 0.0)) {
+                    const double tv = sh.T[a * lu.ldt + lane];
+                    s0 -= z0 * tv;
+                    if (NRHS == 2) s1 -= z1 * tv;
+                }
+            }
+            if (pos >= 0) {
+                sh.x0[pos] = s0;
+                if (NRHS == 2) sh.x1[pos] = s1;
+            }
+        }
+        __syncthreads();
+    }
     lu_stamp(sh, 7);
     after_upper();
     lu_stamp(sh, 8);
@@ -424,9 +787,7 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
         __syncthreads();
     }
     lu_stamp(sh, 9);
-    TriView L{lu.l_cstart, nullptr, lu.l_crow, lu.l_cval, nullptr, 0, 0, nullptr, nullptr};
-    solve_gather<NRHS, true>(L, m, sh.x0, sh.x1, sh.flag, ++epoch);
-    __syncthreads();
+    lu_stage_and_solve<NRHS, false>(lu, sh, lu.l_cstart, nullptr, lu.l_crow, lu.l_cval, lu.l_rstart[m], nullptr, nullptr, 3);
     lu_stamp(sh, 10);
 }
 
@@ -485,91 +846,120 @@ __device__ __forceinline__ int lu_build_eta(const DeviceLU& lu, const LuShared& 
 }
 
 // Structural part of the Forrest-Tomlin update (mod.rs:127-176): row t leaves U, column t becomes the spike, position t
-// moves to the end of the logical order.  `eta_count` entries were already written by lu_build_eta.
+// moves to the end of the logical order -- i.e. it takes the next slot of the trailing block.  `eta_count` entries were
+// already written by lu_build_eta.
 __device__ __forceinline__ void lu_ft_update_block(const DeviceLU& lu, const LuShared& sh, const int t, const int eta_count,
                                                    const double new_diag, const double* spike) {
     const int m = lu.m;
     const int tid = threadIdx.x, T = blockDim.x;
     const int n_updates = lu.state[LU_N_UPDATES];
-    const int top = lu.state[LU_UC_TOP];
+    const int top = lu.state[LU_S_TOP];
     const int eta_top = lu.state[LU_ETA_TOP];
-    const int rank_t = lu.rank[t];
+    const int old_slot = lu.slot_of[t];
+    const int new_slot = n_updates;
+    const int stride = lu.max_updates;
     __syncthreads();  // everyone has read the state words
-    // 1. row t leaves the column orientation
-    {
-        const int rs = lu.u_rstart[t], rl = lu.u_rlen[t];
-        const int as = lu.u_app_first + t * lu.u_app_stride, al = lu.u_app_len[t];
-        for (int e = tid; e < rl + al; e += T) {
-            const int j = lu.u_rcol[e < rl ? rs + e : as + (e - rl)];
-            const int cs = lu.u_cstart[j], cl = lu.u_clen[j];
-            for (int s = 0; s < cl; ++s)
-                if (lu.u_crow[cs + s] == t) {
-                    lu.u_crow[cs + s] = lu.u_crow[cs + cl - 1];
-                    lu.u_cval[cs + s] = lu.u_cval[cs + cl - 1];
-                    lu.u_clen[j] = cl - 1;
-                    break;
-                }
-        }
-    }
-    // 2. the old column t leaves the row orientation
-    {
-        const int cs = lu.u_cstart[t], cl = lu.u_clen[t];
-        for (int e = tid; e < cl; e += T) {
-            const int i = lu.u_crow[cs + e];
-            const int rs = lu.u_rstart[i], rl = lu.u_rlen[i];
-            bool found = false;
-            for (int s = 0; s < rl; ++s)
-                if (lu.u_rcol[rs + s] == t) {
-                    lu.u_rcol[rs + s] = lu.u_rcol[rs + rl - 1];
-                    lu.u_rval[rs + s] = lu.u_rval[rs + rl - 1];
-                    lu.u_rlen[i] = rl - 1;
-                    found = true;
-                    break;
-                }
-            if (!found) {
-                const int as = lu.u_app_first + i * lu.u_app_stride, al = lu.u_app_len[i];
-                for (int s = 0; s < al; ++s)
-                    if (lu.u_rcol[as + s] == t) {
-                        lu.u_rcol[as + s] = lu.u_rcol[as + al - 1];
-                        lu.u_rval[as + s] = lu.u_rval[as + al - 1];
-                        lu.u_app_len[i] = al - 1;
+    if (old_slot < 0) {
+        // 1. row t leaves: its base entries leave the base columns, its spike entries leave the spike columns
+        {
+            const int rs = lu.u_rstart[t], rl = lu.u_rlen[t];
+            for (int e = tid; e < rl; e += T) {
+                const int j = lu.u_rcol[rs + e];
+                const int cs = lu.u_cstart[j], cl = lu.u_clen[j];
+                for (int s = 0; s < cl; ++s)
+                    if (lu.u_crow[cs + s] == t) {
+                        lu.u_crow[cs + s] = lu.u_crow[cs + cl - 1];
+                        lu.u_cval[cs + s] = lu.u_cval[cs + cl - 1];
+                        lu.u_clen[j] = cl - 1;
+                        break;
+                    }
+            }
+            const int al = lu.app_len[t];
+            for (int e = tid; e < al; e += T) {
+                const int k = lu.app_slot[t * stride + e];
+                const int cs = lu.s_cstart[k], cl = lu.s_clen[k];
+                for (int s = 0; s < cl; ++s)
+                    if (lu.s_crow[cs + s] == t) {
+                        lu.s_crow[cs + s] = lu.s_crow[cs + cl - 1];
+                        lu.s_cval[cs + s] = lu.s_cval[cs + cl - 1];
+                        lu.s_clen[k] = cl - 1;
                         break;
                     }
             }
         }
+        // 2. the old column t leaves the base rows
+        {
+            const int cs = lu.u_cstart[t], cl = lu.u_clen[t];
+            for (int e = tid; e < cl; e += T) {
+                const int i = lu.u_crow[cs + e];
+                const int rs = lu.u_rstart[i], rl = lu.u_rlen[i];
+                for (int s = 0; s < rl; ++s)
+                    if (lu.u_rcol[rs + s] == t) {
+                        lu.u_rcol[rs + s] = lu.u_rcol[rs + rl - 1];
+                        lu.u_rval[rs + s] = lu.u_rval[rs + rl - 1];
+                        lu.u_rlen[i] = rl - 1;
+                        break;
+                    }
+            }
+        }
+    } else {
+        // t was replaced before: its row and column live in T and S under `old_slot`, which dies
+        for (int b = tid; b < lu.max_updates; b += T) {
+            lu.T[old_slot * lu.ldt + b] = 0.0;   // row of T (the u_bar part)
+            lu.T[b * lu.ldt + old_slot] = 0.0;   // column of T
+        }
+        const int cs = lu.s_cstart[old_slot], cl = lu.s_clen[old_slot];
+        for (int e = tid; e < cl; e += T) {
+            const int i = lu.s_crow[cs + e];
+            const int al = lu.app_len[i];
+            for (int s = 0; s < al; ++s)
+                if (lu.app_slot[i * stride + s] == old_slot) {
+                    lu.app_slot[i * stride + s] = lu.app_slot[i * stride + al - 1];
+                    lu.app_val[i * stride + s] = lu.app_val[i * stride + al - 1];
+                    lu.app_len[i] = al - 1;
+                    break;
+                }
+        }
     }
     __syncthreads();
     if (tid == 0) {
-        lu.u_rlen[t] = 0;
-        lu.u_app_len[t] = 0;
+        if (old_slot < 0) {
+            lu.u_rlen[t] = 0;
+            lu.app_len[t] = 0;
+            lu.u_clen[t] = 0;
+        } else {
+            lu.s_clen[old_slot] = 0;
+            lu.trail_pos[old_slot] = -1;
+        }
     }
-    // 3. the spike becomes column t: arena of the column orientation, one appended entry per row
+    // 3. the spike becomes the column of the new slot: base rows -> S (column arena + one appended entry per row),
+    //    live trailing positions -> T
     const int count = ordered_compact(
-        m, sh.group_count, [&](int i) { return i != t && spike[i] != 0.0; },
-        [&](int i, int slot) {
+        m, sh.group_count, [&](int i) { return i != t && spike[i] != 0.0 && lu.slot_of[i] < 0; },
+        [&](int i, int offset) {
             const double v = spike[i];
-            lu.u_crow[top + slot] = i;
-            lu.u_cval[top + slot] = v;
-            const int a = lu.u_app_first + i * lu.u_app_stride + lu.u_app_len[i];
-            lu.u_rcol[a] = t;
-            lu.u_rval[a] = v;
-            lu.u_app_len[i] += 1;
+            lu.s_crow[top + offset] = i;
+            lu.s_cval[top + offset] = v;
+            const int a = i * stride + lu.app_len[i];
+            lu.app_slot[a] = new_slot;
+            lu.app_val[a] = v;
+            lu.app_len[i] += 1;
         });
-    // 4. logical order: t goes to the back (RotateToBack, permutation/rotate_to_back.rs:15-122)
-    for (int x = tid; x < m; x += T) {
-        const int r = lu.rank[x];
-        const int nr = x == t ? m - 1 : (r > rank_t ? r - 1 : r);
-        lu.rank[x] = nr;
-        lu.seq[nr] = x;
+    for (int i = tid; i < m; i += T) {
+        const int b = lu.slot_of[i];
+        if (i != t && b >= 0 && b != old_slot) lu.T[b * lu.ldt + new_slot] = spike[i];
     }
+    __syncthreads();
     if (tid == 0) {
-        lu.u_cstart[t] = top;
-        lu.u_clen[t] = count;
+        lu.s_cstart[new_slot] = top;
+        lu.s_clen[new_slot] = count;
+        lu.trail_pos[new_slot] = t;
+        lu.slot_of[t] = new_slot;
         lu.diag[t] = new_diag;
         lu.eta_pivot[n_updates] = t;
         lu.eta_start[n_updates + 1] = eta_top + eta_count;
         lu.state[LU_N_UPDATES] = n_updates + 1;
-        lu.state[LU_UC_TOP] = top + count;
+        lu.state[LU_S_TOP] = top + count;
         lu.state[LU_ETA_TOP] = eta_top + eta_count;
         if (!(fabs(new_diag) > 0.0) || new_diag != new_diag) lu.state[LU_FLAGS] |= LU_FLAG_UNSTABLE;
     }
@@ -579,23 +969,14 @@ __device__ __forceinline__ void lu_ft_update_block(const DeviceLU& lu, const LuS
 // =====================================================================================================
 // stand-alone kernels (fine-grained `BasisInverse` operations)
 // =====================================================================================================
-__device__ __forceinline__ void lu_clear(const LuShared& sh, int m, bool two) {
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        sh.x0[i] = 0.0;
-        if (two) sh.x1[i] = 0.0;
-        sh.flag[i] = 0;
-    }
-    __syncthreads();
-}
-
 // dense != nullptr: dense right-hand side in original row order; else the sparse (rows, vals)
 __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const int* rows, const double* vals, int nnz,
                                                                const double* dense, double* out, int keep_spike) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(sh, m, false);
+    lu_clear(lu, sh, n_updates, false);
     if (dense) {
         for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = dense[i];
     } else {
@@ -611,9 +992,9 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
                                                                const double* dense, double* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(sh, m, false);
+    lu_clear(lu, sh, n_updates, false);
     if (dense) {
         for (int s = threadIdx.x; s < m; s += blockDim.x) sh.x0[lu.colpos[s]] = dense[s];
     } else {
@@ -628,21 +1009,22 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
 __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
     const int t = lu.colpos[p];
-    if (lu.state[LU_N_UPDATES] >= lu.max_updates) {  // no room for another eta: the caller has to refactor
+    const int n_updates = lu.state[LU_N_UPDATES];
+    if (n_updates >= lu.max_updates) {  // no room for another eta: the caller has to refactor
         if (threadIdx.x == 0) lu.state[LU_FLAGS] |= LU_FLAG_OVERFLOW;
         return;
     }
-    lu_clear(sh, m, false);
+    lu_clear(lu, sh, n_updates, false);
     if (threadIdx.x == 0) sh.x0[t] = 1.0;
     __syncthreads();
-    // y = e_t' U^-1: the U stage of a BTRAN (mod.rs:373-397), then the eta from it
-    TriView U{lu.u_cstart, lu.u_clen, lu.u_crow, lu.u_cval, nullptr, 0, 0, lu.diag, lu.seq};
-    solve_gather<1, false>(U, m, sh.x0, sh.x1, sh.flag, 1);
-    __syncthreads();
+    // y = e_t' U^-1: the U stage of a BTRAN (mod.rs:373-397), then the eta from it.  (The etas and the L stage run too --
+    // they cost nothing next to a second code path -- but the eta is taken right behind the U stage.)
+    int epoch = 0;
+    int eta_count = 0;
     double new_diag = 0.0;
-    const int eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag);
+    lu_btran_block<1>(lu, sh, n_updates, epoch, [&] { eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag); });
     lu_ft_update_block(lu, sh, t, eta_count, new_diag, lu.spike);
 }
 
@@ -662,27 +1044,27 @@ static void check_launch(const char* what) {
 
 void launch_lu_ftran(const DeviceLU& lu, const int* rows, const double* vals, int nnz, double* out, int keep_spike, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_ftran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, lu, rows, vals, nnz, (const double*)nullptr, out, keep_spike);
+    hipLaunchKernelGGL(lu_ftran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, rows, vals, nnz, (const double*)nullptr, out, keep_spike);
     check_launch("lu_ftran_kernel");
 }
 void launch_lu_ftran_dense(const DeviceLU& lu, const double* rhs, double* out, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_ftran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, lu, (const int*)nullptr, (const double*)nullptr, 0, rhs, out, 0);
+    hipLaunchKernelGGL(lu_ftran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, (const int*)nullptr, (const double*)nullptr, 0, rhs, out, 0);
     check_launch("lu_ftran_kernel");
 }
 void launch_lu_btran(const DeviceLU& lu, const int* slots, const double* vals, int nnz, double* out, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_btran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, lu, slots, vals, nnz, (const double*)nullptr, out);
+    hipLaunchKernelGGL(lu_btran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, slots, vals, nnz, (const double*)nullptr, out);
     check_launch("lu_btran_kernel");
 }
 void launch_lu_btran_dense(const DeviceLU& lu, const double* in_slots, double* out, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_btran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, lu, (const int*)nullptr, (const double*)nullptr, 0, in_slots, out);
+    hipLaunchKernelGGL(lu_btran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, (const int*)nullptr, (const double*)nullptr, 0, in_slots, out);
     check_launch("lu_btran_kernel");
 }
 void launch_lu_update(const DeviceLU& lu, int p, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_update_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, lu, p);
+    hipLaunchKernelGGL(lu_update_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, p);
     check_launch("lu_update_kernel");
 }
 
@@ -713,7 +1095,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     Ctl* ctl = lp.ctl;
     const int tid = threadIdx.x, T = blockDim.x;
     const int m = lp.m;
-    LuShared sh = lu_shared(smem, m);
+    LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
 #ifdef RELP_STAMPS
     __shared__ unsigned long long s_tprev;
     if (tid == 0) {
@@ -796,7 +1178,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     }
     // ---- FTRAN ------------------------------------------------------------------------------------------------------------
     lu_stamp(sh, 0);
-    lu_clear(sh, m, false);
+    lu_clear(lu, sh, n_updates, false);
     for (int e = lp.col_start[q] + tid; e < lp.col_start[q + 1]; e += T) sh.x0[lu.rowpos[lp.row_index[e]]] = lp.value[e];
     __syncthreads();
     lu_stamp(sh, 1);
@@ -934,9 +1316,9 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
 __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(sh, m, false);
+    lu_clear(lu, sh, n_updates, false);
     for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = lp.rhs[i];
     __syncthreads();
     int epoch = 0;
@@ -947,9 +1329,9 @@ __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU
 __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(sh, m, false);
+    lu_clear(lu, sh, n_updates, false);
     double obj = 0.0;
     for (int s = threadIdx.x; s < m; s += blockDim.x) {
         const double c = lp.cost[lp.basis[s]];
@@ -972,12 +1354,12 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
 __global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
     const int n_updates = lu.state[LU_N_UPDATES];
     for (int j = lp.n_art + blockIdx.x; j < lp.n; j += gridDim.x) {
         if (lp.pos[j] >= 0) continue;
         __syncthreads();
-        lu_clear(sh, m, false);
+        lu_clear(lu, sh, n_updates, false);
         for (int e = lp.col_start[j] + threadIdx.x; e < lp.col_start[j + 1]; e += blockDim.x) sh.x0[lu.rowpos[lp.row_index[e]]] = lp.value[e];
         __syncthreads();
         int epoch = 0;
@@ -1028,10 +1410,10 @@ template <int RULE>
 static void launch_lu_pivot_rule(const DeviceLP& d, const DeviceLU& lu, int n_price_blocks, double tol_pivot, double harris_delta,
                                  int skip_art, int mode, int refactor_period, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     if (start)
-        hipExtLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), (std::uint32_t)lu_lds_bytes_for(lu.m), s, start, stop, 0,
+        hipExtLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), (std::uint32_t)lu_lds_bytes_for(lu.m, lu.max_updates), s, start, stop, 0,
                               d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period);
     else
-        hipLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu, n_price_blocks, tol_pivot,
+        hipLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu, n_price_blocks, tol_pivot,
                            harris_delta, skip_art, mode, refactor_period);
 }
 // `capturing`: inside a stream capture hipGetLastError must not be polled per launch (the capture's end reports failures)
@@ -1047,18 +1429,18 @@ void launch_lu_pivot(const DeviceLP& d, const DeviceLU& lu, int rule, int n_pric
 }
 void launch_lu_xb(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
     configure_lu_pivot_lds();
-    hipLaunchKernelGGL(lu_xb_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu);
+    hipLaunchKernelGGL(lu_xb_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu);
     check_launch("lu_xb_kernel");
 }
 void launch_lu_pi(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
     configure_lu_pivot_lds();
-    hipLaunchKernelGGL(lu_pi_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu);
+    hipLaunchKernelGGL(lu_pi_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu);
     check_launch("lu_pi_kernel");
 }
 void launch_lu_gamma(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
     configure_lu_pivot_lds();
     const int blocks = std::max(1, std::min(512, d.n - d.n_art));
-    hipLaunchKernelGGL(lu_gamma_kernel, dim3(blocks), dim3(LU_THREADS), lu_lds_bytes_for(lu.m), s, d, lu);
+    hipLaunchKernelGGL(lu_gamma_kernel, dim3(blocks), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu);
     check_launch("lu_gamma_kernel");
 }
 void launch_lu_row_scan(const DeviceLP& d, const double* rowvec, double tol, hipStream_t s) {
@@ -1072,7 +1454,7 @@ void launch_lu_row_scan(const DeviceLP& d, const double* rowvec, double tol, hip
 // LuBasis: the stand-alone `BasisInverse` object
 // =====================================================================================================
 LuBasis::LuBasis(int device, int m, const LuOptions& options, int refactor_period)
-    : device_(device), m_(m), period_(refactor_period > 0 ? refactor_period : 31), options_(options) {
+    : device_(device), m_(m), period_(std::min(refactor_period > 0 ? refactor_period : 31, LU_MAX_SLOTS - 1)), options_(options) {
     if (m < 1) throw std::invalid_argument("m < 1");
     if (!lu_fits_lds(m)) throw std::invalid_argument("m too large for the LDS-resident LU solve");
     int count = 0;
@@ -1256,7 +1638,14 @@ LuBasis::Factors LuBasis::factors() {
     Factors f;
     f.row_permutation = geti(d.rowpos, m);
     f.column_permutation = geti(d.colpos, m);
-    std::vector<int> rank = geti(d.rank, m), seq = geti(d.seq, m);
+    // logical order of the positions = the reference's rotated index: base positions in position order, then the live slots
+    std::vector<int> slot_of = geti(d.slot_of, m), trail_pos = geti(d.trail_pos, d.max_updates);
+    std::vector<int> rank(m, -1), seq;
+    for (int i = 0; i < m; ++i)
+        if (slot_of[i] < 0) { rank[i] = (int)seq.size(); seq.push_back(i); }
+    for (int k = 0; k < n_updates; ++k)
+        if (trail_pos[k] >= 0) { rank[trail_pos[k]] = (int)seq.size(); seq.push_back(trail_pos[k]); }
+    if ((int)seq.size() != m) throw std::runtime_error("inconsistent slot bookkeeping");
     // L by columns (never rotated: the rotations only act on U, mod.rs:141-161)
     std::vector<int> lcs = geti(d.l_cstart, m + 1), lcrow = geti(d.l_crow, lcs[m]);
     std::vector<double> lcval = getd(d.l_cval, lcs[m]);
@@ -1273,15 +1662,27 @@ LuBasis::Factors LuBasis::factors() {
         }
     }
     // U by logical column: entries (logical row, value), ascending
-    std::vector<int> ucs = geti(d.u_cstart, m), ucl = geti(d.u_clen, m), ucrow = geti(d.u_crow, state[LU_UC_TOP]);
-    std::vector<double> ucval = getd(d.u_cval, state[LU_UC_TOP]), diag = getd(d.diag, m);
+    std::vector<int> ucs = geti(d.u_cstart, m), ucl = geti(d.u_clen, m);
+    size_t used = 0;
+    for (int j = 0; j < m; ++j) used = std::max(used, (size_t)ucs[j] + (size_t)ucl[j]);
+    std::vector<int> ucrow = geti(d.u_crow, used);
+    std::vector<double> ucval = getd(d.u_cval, used), diag = getd(d.diag, m);
+    std::vector<int> scs = geti(d.s_cstart, d.max_updates), scl = geti(d.s_clen, d.max_updates), scrow = geti(d.s_crow, state[LU_S_TOP]);
+    std::vector<double> scval = getd(d.s_cval, state[LU_S_TOP]), T = getd(d.T, (size_t)d.max_updates * d.ldt);
     f.u_start.assign(m + 1, 0);
     f.upper_diagonal.resize(m);
     for (int c = 0; c < m; ++c) {
         const int j = seq[c];
         f.upper_diagonal[c] = diag[j];
         std::vector<std::pair<int, double>> col;
-        for (int e = ucs[j]; e < ucs[j] + ucl[j]; ++e) col.push_back({rank[ucrow[e]], ucval[e]});
+        if (slot_of[j] < 0) {
+            for (int e = ucs[j]; e < ucs[j] + ucl[j]; ++e) col.push_back({rank[ucrow[e]], ucval[e]});
+        } else {
+            const int k = slot_of[j];
+            for (int e = scs[k]; e < scs[k] + scl[k]; ++e) col.push_back({rank[scrow[e]], scval[e]});
+            for (int a2 = 0; a2 < k; ++a2)
+                if (trail_pos[a2] >= 0 && T[(size_t)a2 * d.ldt + k] != 0.0) col.push_back({rank[trail_pos[a2]], T[(size_t)a2 * d.ldt + k]});
+        }
         std::sort(col.begin(), col.end());
         for (auto& [r, v] : col) {
             f.u_row.push_back(r);

@@ -2,16 +2,23 @@
 // tableau/inverse_maintenance/carry/lower_upper/mod.rs:36-58) -- data layout and host handle.  Kernels: lu.hip.
 //
 // Position space: index k in [0, m) is the pivot position at refactorisation time (`P B Q = L U`: rowpos = P.forward,
-// colpos = Q.forward, decomposition/mod.rs:129-133).  It is STATIC between refactorisations: where the reference rotates
-// rows and columns physically after every update (`RotateToBack`, permutation/rotate_to_back.rs:15-122) the device keeps
-// the logical order in `rank` / `seq` (rank[k] = the reference's index of position k after all rotations so far).
+// colpos = Q.forward, decomposition/mod.rs:129-133).  It is STATIC between refactorisations.  Where the reference rotates
+// rows and columns physically after every update (`RotateToBack`, permutation/rotate_to_back.rs:15-122) the device keeps U
+// in BORDERED form.  A Forrest-Tomlin update moves its position to the end of the logical order, so after k updates
 //
+//            base positions   slots 0..k-1            base positions keep their relative order (= position order);
+//   U  =  [      U_bb             S       ]           slot j = the position replaced by update j (`trail_pos[j]`,
+//         [       0               T       ]           `slot_of[position]`); T is k x k upper triangular BY SLOT INDEX.
+//
+//   U_bb  what is left of the refactorised U: both orientations, entries only ever leave (swap-remove);
+//   S     the spikes' entries in base rows: by column (arena, for BTRAN's dot products) and by row (`app_*`: at most one
+//         entry per update and row, so a fixed stride; for FTRAN);
+//   T     dense, k <= 64: the part every spike chains through -- solved by ONE wave out of LDS, not by m rows waiting on
+//         each other.  A position replaced twice leaves a dead slot (zero row and column, trail_pos = -1).
+// The logical index of the reference (its rotated index) is: base positions in position order, then the live slots.
 // L never changes between refactorisations and is held in both orientations (rows for FTRAN, columns for BTRAN, each a
-// gather).  U changes with every update and is held in both orientations too:
-//   rows:    base segment [u_rstart[i], + u_rlen[i])  +  append segment [u_app_first + i * u_app_stride, + u_app_len[i])
-//            (an update appends at most one entry -- the spike's -- to a row, so the stride is the update capacity);
-//   columns: [u_cstart[j], + u_clen[j]); a replaced column (the spike) is written to the arena behind the base columns.
-// Row etas (eta_file.rs:14-18) live in one arena: eta k = pivot position eta_pivot[k], entries [eta_start[k], eta_start[k+1]).
+// gather).  Row etas (eta_file.rs:14-18) live in one arena: eta j = pivot position eta_pivot[j], entries
+// [eta_start[j], eta_start[j+1]) with POSITIONS as indices.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,26 +28,33 @@
 
 namespace relp {
 
-enum : int { LU_N_UPDATES = 0, LU_UC_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_STATE_WORDS = 8 };
+enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_N_LEVELS = 4 /* .. 7: one per schedule */, LU_STATE_WORDS = 16 };
 enum : int { LU_FLAG_UNSTABLE = 1, LU_FLAG_OVERFLOW = 2 };
+constexpr int LU_MAX_SLOTS = 64;  // one wave solves T
 
 struct DeviceLU {
     int m = 0;
-    int max_updates = 0;  // capacity of the eta / append areas (the refactorisation period never exceeds it)
+    int max_updates = 0;  // slots available (<= LU_MAX_SLOTS); the refactorisation period never exceeds it
+    int ldt = 0;          // leading dimension of T (max_updates + 1: odd, so that a column is conflict-free in LDS)
     int* rowpos = nullptr;
     int* colpos = nullptr;
     int* l_rstart = nullptr; int* l_rcol = nullptr; double* l_rval = nullptr;  // strict L by rows   (FTRAN gather)
     int* l_cstart = nullptr; int* l_crow = nullptr; double* l_cval = nullptr;  // strict L by columns (BTRAN gather)
-    int* u_rstart = nullptr; int* u_rlen = nullptr; int* u_rcol = nullptr; double* u_rval = nullptr;
-    int* u_app_len = nullptr; int u_app_first = 0; int u_app_stride = 0;
-    int* u_cstart = nullptr; int* u_clen = nullptr; int* u_crow = nullptr; double* u_cval = nullptr;
-    int u_c_capacity = 0;
+    int* u_rstart = nullptr; int* u_rlen = nullptr; int* u_rcol = nullptr; double* u_rval = nullptr;  // U_bb by rows
+    int* u_cstart = nullptr; int* u_clen = nullptr; int* u_crow = nullptr; double* u_cval = nullptr;  // U_bb by columns
+    int* app_len = nullptr; int* app_slot = nullptr; double* app_val = nullptr;                       // S by rows, stride max_updates
+    int* s_cstart = nullptr; int* s_clen = nullptr; int* s_crow = nullptr; double* s_cval = nullptr;  // S by columns (arena)
+    int s_capacity = 0;
+    double* T = nullptr;        // [max_updates * ldt], T[a * ldt + b] = U(slot a, slot b), a < b
+    int* trail_pos = nullptr;   // [max_updates] position of slot j, -1: dead
+    int* slot_of = nullptr;     // [m] live slot of a position, -1: base
     double* diag = nullptr;
-    int* rank = nullptr;  // position -> logical index (the reference's rotated index)
-    int* seq = nullptr;   // logical index -> position
     int* eta_start = nullptr; int* eta_pivot = nullptr; int* eta_idx = nullptr; double* eta_val = nullptr;
     int eta_capacity = 0;
     double* spike = nullptr;  // [m] position space: the FTRAN intermediate before the U solve (mod.rs:196 `spike`)
+    // level schedules (lu_host.hpp): 0 L by rows, 1 U by rows, 2 U by columns, 3 L by columns
+    int* sched_start[4] = {nullptr, nullptr, nullptr, nullptr};  // [levels + 1] each (capacity m + 2)
+    int* sched_row[4] = {nullptr, nullptr, nullptr, nullptr};    // [m] each
     int* state = nullptr;     // LU_* words
 };
 

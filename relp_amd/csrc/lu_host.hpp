@@ -42,6 +42,10 @@ struct HostLU {
     std::vector<int> u_start, u_col;
     std::vector<double> u_val;
     std::vector<double> diag;
+    // Level schedules of the four triangular solves (the DAG of each is static between refactorisations: Forrest-Tomlin
+    // updates only ever REMOVE entries of the refactorised U, see lu.hpp).  sched[k]: 0 = L by rows (FTRAN), 1 = U by rows
+    // (FTRAN), 2 = U by columns (BTRAN), 3 = L by columns (BTRAN).  Rows of one level are independent of each other.
+    std::vector<int> lev_start[4], lev_row[4];
     long long nnz_l() const { return (long long)l_col.size(); }
     long long nnz_u() const { return (long long)u_col.size(); }
 };
@@ -285,6 +289,46 @@ inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const
         }
     }
     return f;
+}
+
+// Level sets: level(i) = 1 + max level of the rows i reads (0 when it reads none); rows sorted by level.
+inline void lu_schedules(HostLU& f) {
+    const int m = f.m;
+    std::vector<int> lev(m);
+    auto finish = [&](int k) {
+        int depth = 0;
+        for (int i = 0; i < m; ++i) depth = std::max(depth, lev[i]);
+        f.lev_start[k].assign(depth + 2, 0);
+        for (int i = 0; i < m; ++i) f.lev_start[k][lev[i] + 1]++;
+        for (int l = 0; l <= depth; ++l) f.lev_start[k][l + 1] += f.lev_start[k][l];
+        f.lev_row[k].resize(m);
+        std::vector<int> fill(f.lev_start[k].begin(), f.lev_start[k].end() - 1);
+        for (int i = 0; i < m; ++i) f.lev_row[k][fill[lev[i]]++] = i;
+    };
+    // 0: L by rows, ascending (row i reads columns j < i)
+    for (int i = 0; i < m; ++i) {
+        int l = 0;
+        for (int e = f.l_start[i]; e < f.l_start[i + 1]; ++e) l = std::max(l, lev[f.l_col[e]] + 1);
+        lev[i] = l;
+    }
+    finish(0);
+    // 1: U by rows, descending (row i reads columns j > i)
+    for (int i = m - 1; i >= 0; --i) {
+        int l = 0;
+        for (int e = f.u_start[i]; e < f.u_start[i + 1]; ++e) l = std::max(l, lev[f.u_col[e]] + 1);
+        lev[i] = l;
+    }
+    finish(1);
+    // 2: U by columns, ascending (column j reads rows i < j): level(j) = 1 + max level(i) over the entries (i, j)
+    std::fill(lev.begin(), lev.end(), 0);
+    for (int i = 0; i < m; ++i)
+        for (int e = f.u_start[i]; e < f.u_start[i + 1]; ++e) lev[f.u_col[e]] = std::max(lev[f.u_col[e]], lev[i] + 1);
+    finish(2);
+    // 3: L by columns, descending (column j reads rows i > j)
+    std::fill(lev.begin(), lev.end(), 0);
+    for (int i = m - 1; i >= 0; --i)
+        for (int e = f.l_start[i]; e < f.l_start[i + 1]; ++e) lev[f.l_col[e]] = std::max(lev[f.l_col[e]], lev[i] + 1);
+    finish(3);
 }
 
 // Longest dependency chain of the two triangular solves (each hop is one LDS round trip on the device, lu.hip).

@@ -197,7 +197,7 @@ void Solver::upload() {
     d_.n_art = n_art;
     d_.ld = m;
     lu_mode_ = opt_.carry == RELP_CARRY_LU;
-    refactor_period_ = opt_.refactor_period > 0 ? opt_.refactor_period : 64;
+    refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : 31, LU_MAX_SLOTS - 1);  // T is solved by one wave
     if (lu_mode_) {
         if (bounded_) throw std::invalid_argument("the LU carry does not take implicit bounds (use carry = RELP_CARRY_EXPLICIT)");
         if (!lu_fits_lds(m)) throw std::invalid_argument("the LU carry keeps its solve vectors in LDS: at most about 7000 rows");
@@ -1211,6 +1211,8 @@ void Solver::bring_into_basis(int column, int row) {
     if (c.iters == before) throw std::runtime_error("bring_into_basis: the pivot element is zero (or the column is basic)");
     pivots_[phase_ - 1] += 1;
     since_polish_ += 1;
+    binv_identity_ = false;
+    if (c.status == ST_REFACTOR) refactor_lu(true);  // LU carry: `should_refactor` was true for this pivot
 }
 // `BasisInverse::should_refactor` + `invert` (lower_upper/mod.rs:78-92, 249-252) on demand: the Newton-Schulz polish of the
 // resident inverse, with b, -pi and the objective recomputed from it.  Returns the residual max|I - B'T| found before.

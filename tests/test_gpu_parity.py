@@ -91,21 +91,23 @@ def test_headline_problems_meet_reference_tolerance(name):
     solver.close()
 
 
-def test_unbounded_and_infeasible_are_reported():
-    solver = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "burkardt", "nazareth.mps"))
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+def test_unbounded_and_infeasible_are_reported(carry):
+    solver = relp_amd.Solver(carry=carry).load_mps(os.path.join(ROOT, "data", "burkardt", "nazareth.mps"))
     assert solver.solve_relaxation().kind == relp_amd.UNBOUNDED  # tests/burkardt/test.rs:157-167
     solver.close()
     # x0 >= 2 and x0 <= 1: infeasible (phase_one.rs:171-173)
-    solver = relp_amd.Solver()
+    solver = relp_amd.Solver(carry=carry)
     solver.load_matrix_data([0, 2], [0, 1], [1, 1], [1, 1], b=[1, 2], cost=[1], counts=(0, 0, 1, 1))
     assert solver.solve_relaxation().kind == relp_amd.INFEASIBLE
     solver.close()
 
 
 @pytest.mark.parametrize("rule", [relp_amd.DANTZIG, relp_amd.FIRST_PROFITABLE, relp_amd.FIRST_PROFITABLE_MEMORY])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
 @pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE", "BLEND"])
-def test_other_pivot_rules_reach_the_optimum(name, rule):
-    solver = relp_amd.Solver(pivot_rule=rule).load_mps(os.path.join(ROOT, GOLDEN[name]["file"]))
+def test_other_pivot_rules_reach_the_optimum(name, rule, carry):
+    solver = relp_amd.Solver(pivot_rule=rule, carry=carry).load_mps(os.path.join(ROOT, GOLDEN[name]["file"]))
     result = solver.solve_relaxation()
     expected = float(exact_objective(name))
     assert result.kind == relp_amd.FINITE_OPTIMUM
@@ -121,10 +123,11 @@ def test_graph_and_plain_launches_agree():
     assert (a.pivots_phase_one, a.pivots_phase_two) == (b.pivots_phase_one, b.pivots_phase_two)
 
 
-def test_redundant_rows_and_empty_rows():
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+def test_redundant_rows_and_empty_rows(carry):
     """two_phase/test.rs:96-212: redundant_row, empty_row_at_eq, empty_row_at_ineq -> x = (3/4, 1/4, ...)."""
     # three identical equality rows x0 + x1 = 1, x0 <= 3/4, min -2 x0 - x1
-    solver = relp_amd.Solver()
+    solver = relp_amd.Solver(carry=carry)
     solver.load_matrix_data([0, 3, 6], [0, 1, 2, 0, 1, 2], [1] * 6, [1] * 6, b=[1, 1, 1], cost=[-2, -1],
                             upper=[(3, 4), None], counts=(3, 0, 0, 0))
     result = solver.solve_relaxation()
@@ -132,7 +135,7 @@ def test_redundant_rows_and_empty_rows():
     assert np.allclose(solver.solution(), [0.75, 0.25], atol=1e-12)
     solver.close()
     for b, counts in (([1, 0], (2, 0, 0, 0)), ([1, 1], (1, 0, 1, 0))):
-        solver = relp_amd.Solver()
+        solver = relp_amd.Solver(carry=carry)
         solver.load_matrix_data([0, 1, 2], [0, 0], [1, 1], [1, 1], b=b, cost=[-2, -1], upper=[(3, 4), None], counts=counts)
         result = solver.solve_relaxation()
         assert result.kind == relp_amd.FINITE_OPTIMUM
@@ -140,14 +143,15 @@ def test_redundant_rows_and_empty_rows():
         solver.close()
 
 
-def test_set_basis_warm_start():
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+def test_set_basis_warm_start(carry):
     """`InverseMaintainer::from_basis` (carry/mod.rs:444-478): restart from the optimal basis => zero pivots."""
     path = os.path.join(ROOT, "data", "netlib", "SC50A.SIF")
-    solver = relp_amd.Solver().load_mps(path)
+    solver = relp_amd.Solver(carry=carry).load_mps(path)
     first = solver.solve_relaxation()
     basis = solver.basis()
     assert (basis >= 0).all()
-    other = relp_amd.Solver().load_mps(path)
+    other = relp_amd.Solver(carry=carry).load_mps(path)
     other.set_basis(basis)
     done, reason = other.iterate(1000)
     assert (done, reason) == (0, relp_amd.STOP_NO_ENTERING)
@@ -157,13 +161,15 @@ def test_set_basis_warm_start():
 # ---------------------------------------------------------------------------------------------------------
 # fine-grained trait ops, step by step against the oracle on the same basis
 # ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
 @pytest.mark.parametrize("name, steps", [("AFIRO", 19), ("SC50A", 30), ("ADLITTLE", 40), ("SHARE2B", 40)])
-def test_trait_ops_follow_the_oracle(name, steps):
+def test_trait_ops_follow_the_oracle(name, steps, carry):
     path = os.path.join(ROOT, GOLDEN[name]["file"])
     general, data = load_problem(path)
     tableau = Tableau.new_partially_artificial(data, LUDecomposition)
     rule = SteepestDescentAlongObjective(tableau)
-    solver = relp_amd.Solver(polish_period=0, use_graph=0).load_mps(path)
+    # (refactor_period 7: the LU carry goes through several refactorisations inside the compared steps)
+    solver = relp_amd.Solver(polish_period=0, use_graph=0, carry=carry, refactor_period=7).load_mps(path)
     solver.begin_phase_one()
     m, n = solver.m, solver.n
     assert n == tableau.nr_columns() and solver.n_art == tableau.nr_artificial_variables()
@@ -266,8 +272,9 @@ def test_miplib_relaxations(name, expected, tolerance):
     solver.close()
 
 
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
 @pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE"])
-def test_loop_driven_from_outside_through_bring_into_basis(name):
+def test_loop_driven_from_outside_through_bring_into_basis(name, carry):
     """The reference's loop (phase_one.rs:134-178 / phase_two.rs:36-58) written by the caller with the fine-grained operations
     -- select_primal_pivot_column, generate_column + select_primal_pivot_row, bring_into_basis -- reaches the same optimum
     as ``solve_relaxation``; ``refactor`` in the middle leaves the state where it was."""
@@ -276,7 +283,7 @@ def test_loop_driven_from_outside_through_bring_into_basis(name):
     expected = whole.solve_relaxation()
     assert expected.kind == relp_amd.FINITE_OPTIMUM
     fixed_cost = relp_amd.Model(path).fixed_cost()
-    solver = relp_amd.Solver(certify=0).load_mps(path)
+    solver = relp_amd.Solver(certify=0, carry=carry, refactor_period=9).load_mps(path)
     solver.begin_phase_one()
     pivots = 0
     for phase in (1, 2):
