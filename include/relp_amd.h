@@ -266,6 +266,11 @@ int32_t relp_ratio(relp_handle* handle, int32_t column, int32_t* row, double* ou
  * the objective and the steepest-edge weights are updated as in any pivot of the loop.  RELP_ERR_STATE when the pivot
  * element is zero. */
 int32_t relp_bring_into_basis(relp_handle* handle, int32_t column, int32_t row);
+/* `PivotRule::after_basis_update(info, tableau)` (strategy/pivot_rule.rs:23-54; `SteepestDescentAlongObjective` :243-296): the
+ * Goldfarb-Reid update of the steepest-edge weights for the last relp_bring_into_basis / relp_iterate pivot.  Inside the
+ * device loop the update rides on the next pricing pass; this entry applies it now (no-op when none is pending, or for the
+ * rules without state). */
+int32_t relp_se_after_basis_update(relp_handle* handle);
 /* `BasisInverse::should_refactor` + `invert` on demand (lower_upper/mod.rs:78-92, 249-252): polishes the resident inverse and
  * recomputes b, -pi and the objective from it; *residual_before = max |I - B^T T| found. */
 int32_t relp_refactor(relp_handle* handle, double* residual_before);

@@ -493,6 +493,10 @@ class Solver:
         """``Tableau::bring_into_basis`` with a given pivot (index space of ``select_primal_pivot_column``)."""
         self._check(lib().relp_bring_into_basis(self._h, int(column), int(row)))
 
+    def after_basis_update(self):
+        """``PivotRule::after_basis_update`` (strategy/pivot_rule.rs:243-296): apply the pending steepest-edge weight update."""
+        self._check(lib().relp_se_after_basis_update(self._h))
+
     def refactor(self):
         """Polish the resident inverse now; returns the residual max|I - B'T| found before."""
         out = C.c_double()

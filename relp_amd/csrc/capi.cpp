@@ -694,6 +694,10 @@ int32_t relp_bring_into_basis(relp_handle* h, int32_t column, int32_t row) {
     REQUIRE_LOADED(h);
     return guarded(h, [&] { h->solver->bring_into_basis(column, row); });
 }
+int32_t relp_se_after_basis_update(relp_handle* h) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] { h->solver->after_basis_update(); });
+}
 int32_t relp_refactor(relp_handle* h, double* residual_before) {
     REQUIRE_LOADED(h);
     return guarded(h, [&] {

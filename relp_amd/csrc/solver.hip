@@ -1175,6 +1175,7 @@ void Solver::price(int* column, double* cbar) {
 void Solver::ratio(int column, int* row, double* alpha_out) {
     if (column < 0 || column >= d_.n) throw std::invalid_argument("column out of range");
     Ctl c = read_ctl();
+    const Ctl before = c;  // a pending steepest-edge update still needs q, gamma_q, alpha_pq, leaving of the LAST pivot
     const int saved = c.status;
     const int saved_pending = c.pending;
     c.status = ST_RUNNING;
@@ -1190,7 +1191,30 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
     }
     c.status = saved;
     c.pending = saved_pending;
+    c.q = before.q;
+    c.p = before.p;
+    c.leaving = before.leaving;
+    c.cbar_q = before.cbar_q;
+    c.alpha_pq = before.alpha_pq;
+    c.gamma_q = before.gamma_q;
     c.forced_q = c.forced_p = -1;
+    write_ctl(c);
+}
+// `PivotRule::after_basis_update` (strategy/pivot_rule.rs:243-296): the Goldfarb-Reid update of the steepest-edge weights for
+// the last basis change.  Inside the device loop it rides on the next pricing pass; a caller that drives the loop itself can
+// ask for it here (one pass over the non-basic columns, candidates discarded).  No-op when nothing is pending.
+void Solver::after_basis_update() {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    RELP_HIP(hipSetDevice(opt_.device));
+    Ctl c = read_ctl();
+    if (!c.pending) return;
+    const int saved = c.status;
+    c.status = ST_RUNNING;
+    write_ctl(c);
+    enqueue_price(0);
+    c = read_ctl();
+    c.pending = 0;
+    c.status = saved;
     write_ctl(c);
 }
 // `Tableau::bring_into_basis(pivot_column, pivot_row, column)` (tableau/mod.rs:139-160) with both indices given by the

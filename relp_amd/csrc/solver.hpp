@@ -149,6 +149,7 @@ public:
     void get_gamma(double* out);
     void ratio(int column, int* row, double* alpha_out);
     void bring_into_basis(int column, int row);
+    void after_basis_update();
     double refactor();
     void get_b(double* out);
     double objective();

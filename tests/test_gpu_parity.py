@@ -327,3 +327,42 @@ def test_steepest_edge_weights_carried_from_phase_one(name, monkeypatch):
     assert abs(result.pivots_phase_two - expected.pivots_phase_two) <= max(20, expected.pivots_phase_two // 5)
     fresh.close()
     carried.close()
+
+
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+def test_after_basis_update_applies_the_pending_weight_update(carry):
+    """`PivotRule::after_basis_update` (pivot_rule.rs:243-296) as an entry of its own: the Goldfarb-Reid update is applied once,
+    whether the caller asks for it right after the pivot or lets the next pricing pass do it; asking twice changes nothing."""
+    path = os.path.join(ROOT, "data", "netlib", "ADLITTLE.SIF")
+    general, data = load_problem(path)
+    a = relp_amd.Solver(carry=carry, use_graph=0).load_mps(path)
+    b = relp_amd.Solver(carry=carry, use_graph=0).load_mps(path)
+    a.begin_phase_one()
+    b.begin_phase_one()
+    tableau = Tableau.new_partially_artificial(data, LUDecomposition)
+    rule = SteepestDescentAlongObjective(tableau)
+    for step in range(25):
+        qa, qb = a.select_primal_pivot_column(), b.select_primal_pivot_column()
+        assert qa == qb
+        assert np.array_equal(a.gamma(), b.gamma(), equal_nan=True)  # same weights, bit for bit, either way
+        if qa is None:
+            break
+        q = qa[0]
+        p, _ = a.select_primal_pivot_row(q)
+        pb, _ = b.select_primal_pivot_row(q)
+        assert p == pb
+        a.bring_into_basis(q, p)
+        b.bring_into_basis(q, p)
+        a.after_basis_update()
+        g1 = a.gamma()
+        a.after_basis_update()  # nothing pending any more
+        assert np.array_equal(g1, a.gamma(), equal_nan=True)
+        # and they are the reference's weights (exact oracle on the same pivots)
+        info = tableau.generate_column(q)
+        change = tableau.bring_into_basis(q, p, info, tableau.relative_cost(q))
+        rule.after_basis_update(change, tableau)
+        for j in range(a.n_art, a.n):
+            if rule.gamma[j] is not None and not tableau.is_in_basis(j):
+                assert g1[j] == pytest.approx(float(rule.gamma[j]), rel=1e-8), (step, j)
+    a.close()
+    b.close()
