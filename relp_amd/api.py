@@ -58,7 +58,7 @@ SYMBOLS = [
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
     "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
-    "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
+    "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
     "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps",
     # BasisInverse as an object of its own (relp_amd/basis_inverse.py)
     "relp_bi_options_default", "relp_bi_identity", "relp_bi_invert", "relp_bi_free", "relp_bi_last_error", "relp_bi_m",
