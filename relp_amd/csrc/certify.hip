@@ -7,14 +7,26 @@
 //     B' y  = c_B, c_j - a_j'y >= 0   (dual feasibility; Tableau::relative_cost, tableau/mod.rs:106-112)
 //     objective = c_B' x_B + fixed_cost  (general_form/mod.rs:840-851)
 // Fixed-width integer arithmetic on the device replaces arbitrary precision there (north_star): the two linear
-// systems are solved by Dixon p-adic lifting -- one modular inverse C = B^-1 mod p (Gauss-Jordan over Z_p, p < 2^31,
-// 64-bit products) and then, per p-adic digit, a modular mat-vec and an exact integer residual update carried in
-// 128-bit accumulators.  Only the assembly of the digits (Horner), the rational reconstruction and the sign checks use
+// systems are solved by Dixon p-adic lifting -- one modular inverse C = B^-1 mod p (p < 2^31, 64-bit products: the sparse LU
+// factors of B mod p from the host's Markowitz elimination, then all m columns of the inverse at once on the device, one
+// thread per column walking the same factor entries) and then, per p-adic digit, a modular mat-vec and an exact integer
+// residual update carried in 128-bit accumulators.  Only the assembly of the digits (Horner), the rational reconstruction and the sign checks use
 // host big integers (bigint.hpp).  Every reconstructed vector is VERIFIED by exact substitution before it is used.
 #include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 #include "bigint.hpp"
+#include "lu_host.hpp"
 #include "solver.hpp"
 
 namespace relp {
@@ -28,79 +40,65 @@ using i64 = long long;
 // ---------------------------------------------------------------------------------------------------
 // device: Z_p kernels
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 mod_inverse(u32 a, u32 p) {  // extended Euclid, a in [1, p)
-    i64 t = 0, nt = 1, r = p, nr = a;
-    while (nr != 0) {
-        i64 q = r / nr;
-        i64 tmp = t - q * nt; t = nt; nt = tmp;
-        tmp = r - q * nr; r = nr; nr = tmp;
+// v mod p for v < 2^64; p = 2^31 - 1 (the first trial prime) folds instead of dividing
+__device__ __forceinline__ u32 reduce64(u64 v, u32 p) {
+    if (p == 0x7fffffffu) {
+        v = (v & 0x7fffffffu) + (v >> 31);   // < 2^34
+        v = (v & 0x7fffffffu) + (v >> 31);   // < 2^31 + 8
+        u32 r = (u32)v;
+        return r >= p ? r - p : r;
     }
-    if (t < 0) t += p;
-    return (u32)t;
+    return (u32)(v % p);
 }
 
-// Gauss-Jordan step k on the augmented matrix M = [B | I] (m x ld, ld = 2m): pivot search, row swap, row scale, and a
-// copy of column k (so that the elimination kernel can overwrite it).  One workgroup.
-__global__ void __launch_bounds__(256) gj_pivot_kernel(u32* M, int m, int ld, int k, u32 p, u32* colk, int* info) {
-    __shared__ int s_row;
-    __shared__ u32 s_inv;
-    if (info[0]) return;
-    if (threadIdx.x == 0) s_row = 0x7fffffff;
-    __syncthreads();
-    for (int r = k + threadIdx.x; r < m; r += blockDim.x)
-        if (M[(size_t)r * ld + k] != 0) atomicMin(&s_row, r);
-    __syncthreads();
-    const int r = s_row;
-    if (r == 0x7fffffff) {
-        if (threadIdx.x == 0) info[0] = 1;  // singular modulo p
-        return;
-    }
-    if (r != k) {
-        for (int j = threadIdx.x; j < ld; j += blockDim.x) {
-            const u32 a = M[(size_t)r * ld + j];
-            M[(size_t)r * ld + j] = M[(size_t)k * ld + j];
-            M[(size_t)k * ld + j] = a;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_inv = mod_inverse(M[(size_t)k * ld + k], p);
-    __syncthreads();
-    const u32 inv = s_inv;
-    for (int j = threadIdx.x; j < ld; j += blockDim.x) M[(size_t)k * ld + j] = (u32)(((u64)M[(size_t)k * ld + j] * inv) % p);
-    __syncthreads();
-    for (int i = threadIdx.x; i < m; i += blockDim.x) colk[i] = (i == k) ? 0u : M[(size_t)i * ld + k];
-}
-
-// rows i != k: M[i][:] -= M[i][k] * M[k][:]  (mod p)
-__global__ void __launch_bounds__(256) gj_eliminate_kernel(u32* M, int m, int ld, int k, u32 p, const u32* colk, const int* info) {
-    if (info[0]) return;
-    const int i = blockIdx.y;
-    const u32 f = colk[i];
-    if (f == 0) return;
+// All m columns of C = B^-1 mod p from the sparse factors P B Q = L U mod p: column j is the solve of e_j, one thread per
+// column; every thread walks the SAME factor entries in the same order (no divergence, the entries are uniform loads) and
+// owns column j of the m x m work matrix X (position-major, so a wave touches 64 consecutive words per step).
+//   l_* / u_*: strictly triangular parts by rows of the position space; dinv = 1 / diag mod p.
+// Writes C (row-major: C[slot][j]) and its transpose CT.
+__global__ void __launch_bounds__(64) modular_inverse_kernel(int m, u32 p, const int* rowpos, const int* colpos, const int* l_start,
+                                                              const int* l_col, const u32* l_val, const int* u_start, const int* u_col,
+                                                              const u32* u_val, const u32* dinv, u32* X, u32* C, u32* CT) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ld) return;
-    const u64 neg = p - f;
-    M[(size_t)i * ld + j] = (u32)((M[(size_t)i * ld + j] + neg * M[(size_t)k * ld + j]) % p);
+    if (j >= m) return;
+    const int start = rowpos[j];  // e_j in position space
+    for (int i = 0; i < m; ++i) X[(size_t)i * m + j] = i == start ? 1u : 0u;
+    // L x = e (unit diagonal), rows ascending; rows before `start` stay zero
+    for (int i = start + 1; i < m; ++i) {
+        const int a = l_start[i], b = l_start[i + 1];
+        if (a == b) continue;
+        u64 lo = X[(size_t)i * m + j], hi = 0;
+        for (int e = a; e < b; ++e) {
+            const u64 prod = (u64)(p - l_val[e]) * X[(size_t)l_col[e] * m + j];  // -l x  (mod p)
+            lo += prod & 0xffffffffu;
+            hi += prod >> 32;
+        }
+        const u64 two32 = (1ull << 32) % p;
+        X[(size_t)i * m + j] = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
+    }
+    // U x = y, rows descending
+    for (int i = m - 1; i >= 0; --i) {
+        const int a = u_start[i], b = u_start[i + 1];
+        u64 lo = X[(size_t)i * m + j], hi = 0;
+        for (int e = a; e < b; ++e) {
+            const u64 prod = (u64)(p - u_val[e]) * X[(size_t)u_col[e] * m + j];
+            lo += prod & 0xffffffffu;
+            hi += prod >> 32;
+        }
+        const u64 two32 = (1ull << 32) % p;
+        const u32 v = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
+        X[(size_t)i * m + j] = reduce64((u64)v * dinv[i], p);
+    }
+    for (int s = 0; s < m; ++s) {
+        const u32 v = X[(size_t)colpos[s] * m + j];
+        C[(size_t)s * m + j] = v;
+        CT[(size_t)j * m + s] = v;
+    }
 }
 
-// [B | I] from the CSC of the (row-scaled, integer) basis columns.
-__global__ void build_augmented_kernel(u32* M, int m, int ld, const int* col_start, const int* row_index, const i64* value, u32 p) {
-    const int k = blockIdx.x;  // basis position = matrix column
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        M[(size_t)i * ld + k] = 0;
-        M[(size_t)i * ld + m + k] = (i == k) ? 1u : 0u;
-    }
-    __syncthreads();
-    for (int e = col_start[k] + threadIdx.x; e < col_start[k + 1]; e += blockDim.x) {
-        i64 v = value[e] % (i64)p;
-        if (v < 0) v += p;
-        M[(size_t)row_index[e] * ld + k] = (u32)v;
-    }
-}
-
-// Dixon digit: x = C (r mod p) mod p   (transpose = 0)   or   x = C' (r mod p) mod p   (transpose = 1),
-// C = right half of M.  One wave per output entry for the row-wise product, one thread per entry for the transposed one.
-__global__ void __launch_bounds__(256) dixon_digit_kernel(const u32* M, int m, int ld, u32 p, const i64* r, u32* x, int transpose) {
+// Dixon digit: x = A (r mod p) mod p for a row-major m x m matrix A (C for B x = b, C' for B' y = c).  One wave per output
+// entry; the products are accumulated in two 64-bit halves and reduced once (a `% p` per term was 25 x slower).
+__global__ void __launch_bounds__(256) dixon_digit_kernel(const u32* A, int m, u32 p, const i64* r, u32* x) {
     extern __shared__ u32 s_r[];
     for (int j = threadIdx.x; j < m; j += blockDim.x) {
         i64 v = r[j] % (i64)p;
@@ -108,21 +106,23 @@ __global__ void __launch_bounds__(256) dixon_digit_kernel(const u32* M, int m, i
         s_r[j] = (u32)v;
     }
     __syncthreads();
-    const u32* C = M + m;
-    if (!transpose) {
-        const int lane = threadIdx.x & 63;
-        const int i = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
-        if (i >= m) return;
-        u64 acc = 0;
-        for (int j = lane; j < m; j += 64) acc += ((u64)C[(size_t)i * ld + j] * s_r[j]) % p;
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) x[i] = (u32)(acc % p);
-    } else {
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= m) return;
-        u64 acc = 0;
-        for (int j = 0; j < m; ++j) acc += ((u64)C[(size_t)j * ld + i] * s_r[j]) % p;
-        x[i] = (u32)(acc % p);
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (i >= m) return;
+    const u32* row = A + (size_t)i * m;
+    u64 lo = 0, hi = 0;
+    for (int j = lane; j < m; j += 64) {
+        const u64 prod = (u64)row[j] * s_r[j];
+        lo += prod & 0xffffffffu;
+        hi += prod >> 32;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo += __shfl_down(lo, off);
+        hi += __shfl_down(hi, off);
+    }
+    if (lane == 0) {
+        const u64 two32 = (1ull << 32) % p;
+        x[i] = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
     }
 }
 
@@ -150,6 +150,99 @@ __global__ void __launch_bounds__(256) dixon_residual_kernel(int m, const int* r
     acc = negative ? -(__int128)quotient : (__int128)quotient;
     r[i] = (i64)acc;
 }
+
+// diagnostic timeline (RELP_TIME_CERTIFY=1): where the certificate's wall time goes
+struct CertifyTimes {
+    double device_digits = 0.0, host_assemble = 0.0, inverse = 0.0, setup = 0.0, checks = 0.0, reconstruct = 0.0, parallel = 0.0;
+    int digit_launches = 0, solves = 0, reconstructs = 0;
+};
+CertifyTimes g_times;
+double wall_now() {
+    using clock = std::chrono::steady_clock;
+    return std::chrono::duration<double>(clock::now().time_since_epoch()).count();
+}
+
+// Host threads for the big-integer part (Horner assembly of the p-adic digits, products with the common denominator, the
+// exact substitution check): m independent entries each.  A small persistent pool; the calling thread works too.
+class WorkerPool {
+public:
+    static WorkerPool& get() {
+        static WorkerPool pool;
+        return pool;
+    }
+    template <class F>
+    void run(int n, F&& fn) {
+        if (n <= 0) return;
+        if (threads_.empty() || n < 8) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::function<void(int)> job = std::forward<F>(fn);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            job_ = &job;
+            total_ = n;
+            next_.store(0);
+            done_.store(0);
+            ++generation_;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lock(mutex_);
+        finished_.wait(lock, [&] { return done_.load() >= total_ && active_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    WorkerPool() {
+        unsigned count = std::thread::hardware_concurrency();
+        if (const char* e = getenv("RELP_CERTIFY_THREADS")) count = (unsigned)atoi(e);
+        count = std::min(count, 32u);
+        for (unsigned t = 1; t < count; ++t) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    void work() {
+        while (true) {
+            const int i = next_.fetch_add(1);
+            if (i >= total_) break;
+            (*job_)(i);
+            done_.fetch_add(1);
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        while (true) {
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                wake_.wait(lock, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                ++active_;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                --active_;
+            }
+            finished_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mutex_;
+    std::condition_variable wake_, finished_;
+    std::function<void(int)>* job_ = nullptr;
+    int total_ = 0, active_ = 0;
+    std::atomic<int> next_{0}, done_{0};
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+};
 
 struct DeviceBuffers {
     std::vector<void*> ptrs;
@@ -226,9 +319,9 @@ struct ExactVector {           // numer[i] / denom
 };
 
 // Solve  A z = rhs  (transpose = 0: A = B;  transpose = 1: A = B')  by Dixon lifting; the result is verified exactly.
-bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpose, u32 p, u32* dM, int ld,
+bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpose, u32 p, const u32* dA,
                  DeviceBuffers& buf, const int* d_row_start, const int* d_col_index, const i64* d_row_value,
-                 hipStream_t stream, ExactVector* out, std::string* message) {
+                 hipStream_t stream, ExactVector* out, std::string* message, int first_target = 32) {
     const int m = B.m;
     i64* d_r = buf.alloc<i64>(m);
     int* d_info = buf.alloc<int>(4);
@@ -241,7 +334,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
 
     std::vector<std::vector<u32>> digits;  // digits[step][i]
     int steps_done = 0;
-    int target = 32;
+    int target = std::max(8, first_target);
     const int max_steps = 1 << 15;
     u32* d_digits = nullptr;
     int digits_capacity = 0;
@@ -253,10 +346,11 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             d_digits = nd;
             digits_capacity = target;
         }
+        const double t_digits = wall_now();
+        g_times.digit_launches += target - steps_done;
         for (int s = steps_done; s < target; ++s) {
             u32* xs = d_digits + (size_t)s * m;
-            const int blocks = transpose ? (m + 255) / 256 : (m + 3) / 4;
-            hipLaunchKernelGGL(dixon_digit_kernel, dim3(blocks), dim3(256), m * sizeof(u32), stream, dM, m, ld, p, d_r, xs, transpose);
+            hipLaunchKernelGGL(dixon_digit_kernel, dim3((m + 3) / 4), dim3(256), m * sizeof(u32), stream, dA, m, p, d_r, xs);
             hipLaunchKernelGGL(dixon_residual_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, m, d_row_start, d_col_index,
                                d_row_value, xs, d_r, p, d_info);
         }
@@ -265,6 +359,12 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
         RELP_HIP(hipMemcpyAsync(flat.data(), d_digits + (size_t)steps_done * m, flat.size() * sizeof(u32), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipStreamSynchronize(stream));
+        g_times.device_digits += wall_now() - t_digits;
+        const double t_host = wall_now();
+        struct HostTimer {
+            double t0;
+            ~HostTimer() { g_times.host_assemble += wall_now() - t0; }
+        } host_timer{t_host};
         if (info[1] || info[2]) {
             *message = info[2] ? "Dixon residual overflow (coefficients too large for the 128-bit path)" : "Dixon residual not divisible by p";
             return false;
@@ -274,45 +374,84 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
         steps_done = target;
 
         // ---- assemble, reconstruct with a common denominator, verify ---------------------------------
+        WorkerPool& pool = WorkerPool::get();
         BigInt modulus(1);
         for (int s = 0; s < steps_done; ++s) modulus.mul_add_small(p, 0);
         std::vector<BigInt> residue(m);
-        for (int i = 0; i < m; ++i) {
+        pool.run(m, [&](int i) {
             BigInt acc(0);
             for (int s = steps_done; s-- > 0;) acc.mul_add_small(p, digits[s][i]);
             acc.trim();
             residue[i] = acc;
-        }
+        });
         bool ok = true;
         BigInt denom(1);
         std::vector<BigInt> numer(m);
         const BigInt half = modulus / BigInt(2);
-        for (int i = 0; i < m && ok; ++i) {
-            BigInt t = (residue[i] * denom) % modulus;
-            if (cmp(t, half) > 0) t = t - modulus;
-            // accept t as the numerator when it is "small": |t| * 2^(32) < modulus / denom-size proxy; otherwise reconstruct
-            BigInt n, d;
-            if (cmp(t.abs() * t.abs() * BigInt(2), modulus) <= 0) {
-                numer[i] = t;
-                continue;
+        // numer_i = centred(residue_i * denom mod modulus) is the numerator as soon as denom is the common denominator: all
+        // entries in parallel; every entry that is still "large" contributes its own denominator (rational reconstruction,
+        // sequential: there are few), then the pass is repeated with the grown denominator.
+        std::vector<char> small(m);
+        {
+            // A random integer combination of the entries has, almost surely, the common denominator of all of them: ONE
+            // rational reconstruction instead of one per entry that brings a new factor (46 of them on 25FV47).  Whatever it
+            // misses is found by the loop below; every result is verified exactly anyway.
+            BigInt combo(0);
+            unsigned long long state = 0x9E3779B97F4A7C15ull;
+            for (int i = 0; i < m; ++i) {
+                state = state * 6364136223846793005ull + 1442695040888963407ull;
+                combo = combo + residue[i] * BigInt((i64)(1 + ((state >> 33) & 0xffff)));
             }
-            if (!rational_reconstruct(t, modulus, n, d)) { ok = false; break; }
-            // new common denominator: denom * d; earlier numerators scale by d
-            for (int k = 0; k < i; ++k) numer[k] = numer[k] * d;
-            denom = denom * d;
-            numer[i] = n;
-            if (cmp(denom * denom * BigInt(2), modulus) > 0) { ok = false; break; }
+            combo = combo % modulus;
+            BigInt n, d;
+            const double t_rr = wall_now();
+            const bool found = rational_reconstruct(combo, modulus, n, d);
+            g_times.reconstruct += wall_now() - t_rr;
+            g_times.reconstructs++;
+            if (found && cmp(d * d * BigInt(2), modulus) <= 0) denom = d;
+            else ok = false;  // not enough digits yet
+        }
+        for (int pass = 0; ok; ++pass) {
+            pool.run(m, [&](int i) {
+                BigInt t = (residue[i] * denom) % modulus;
+                if (cmp(t, half) > 0) t = t - modulus;
+                small[i] = cmp(t.abs() * t.abs() * BigInt(2), modulus) <= 0 ? 1 : 0;
+                numer[i] = t;
+            });
+            bool grown = false;
+            BigInt factor(1);  // what this pass multiplies the denominator by
+            for (int i = 0; i < m && ok; ++i) {
+                if (small[i]) continue;
+                BigInt t = grown ? (numer[i] * factor) % modulus : numer[i];
+                if (grown && cmp(t, half) > 0) t = t - modulus;
+                if (grown && t.sign() < 0 && cmp(t.abs(), half) > 0) t = t + modulus;
+                if (cmp(t.abs() * t.abs() * BigInt(2), modulus) <= 0) continue;  // the denominators found so far cover it
+                BigInt n, d;
+                const double t_rr = wall_now();
+                const bool found = rational_reconstruct(t, modulus, n, d);
+                g_times.reconstruct += wall_now() - t_rr;
+                g_times.reconstructs++;
+                if (!found) { ok = false; break; }
+                factor = factor * d;
+                denom = denom * d;
+                grown = true;
+                if (cmp(denom * denom * BigInt(2), modulus) > 0) { ok = false; break; }
+            }
+            if (!grown) break;
+            if (pass > 64) ok = false;
         }
         if (ok) {
             // exact verification: A numer == denom * rhs
-            for (int i = 0; i < m && ok; ++i) {
+            std::atomic<int> bad{0};
+            pool.run(m, [&](int i) {
                 BigInt acc(0);
                 if (!transpose)
                     for (int e = B.row_start[i]; e < B.row_start[i + 1]; ++e) acc = acc + BigInt(B.row_value[e]) * numer[B.col_index[e]];
                 else
                     for (int e = B.col_start[i]; e < B.col_start[i + 1]; ++e) acc = acc + BigInt(B.value[e]) * numer[B.row_index[e]];
-                if (!(acc == denom * BigInt(rhs[i]))) ok = false;
-            }
+                if (!(acc == denom * BigInt(rhs[i]))) bad.fetch_add(1);
+            });
+            if (bad.load() != 0) ok = false;
         }
         if (ok) {
             // normalise by the gcd of everything
@@ -350,6 +489,18 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
     const MatrixData& md = form.data;
     const int m = md.nr_rows();
     const int n_p = md.nr_columns();
+    g_times = CertifyTimes{};
+    const double t_begin = wall_now();
+    struct Report {
+        double t0;
+        ~Report() {
+            if (!getenv("RELP_TIME_CERTIFY")) return;
+            fprintf(stderr, "[certify] total %.2f ms: setup %.2f, inverse mod p %.2f, Dixon device %.2f (%d digit steps, %d solves), "
+                            "host assemble/reconstruct/verify %.2f (of which %d rational reconstructions %.2f), checks %.2f\n",
+                    (wall_now() - t0) * 1e3, g_times.setup * 1e3, g_times.inverse * 1e3, g_times.device_digits * 1e3, g_times.digit_launches,
+                    g_times.solves, g_times.host_assemble * 1e3, g_times.reconstructs, g_times.reconstruct * 1e3, g_times.checks * 1e3);
+        }
+    } report{t_begin};
 
     // ---- integer scaling: row multipliers (lcm of the denominators of the row's coefficients), cost multiplier; the
     //      right-hand side keeps its own common denominator and any width (presolve leaves ~100-bit values there) ----
@@ -441,12 +592,13 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                 }
         }
 
+        g_times.setup += wall_now() - t_begin - g_times.setup - g_times.inverse - g_times.device_digits - g_times.host_assemble - g_times.checks;
+        const double t_inverse = wall_now();
         // ---- device: C = B^-1 mod p ---------------------------------------------------------------------
         DeviceBuffers buf;
-        const int ld = 2 * m;
-        u32* dM = buf.alloc<u32>((size_t)m * ld);
-        u32* d_colk = buf.alloc<u32>(m);
-        int* d_info = buf.alloc<int>(4);
+        u32* dC = buf.alloc<u32>((size_t)m * m);
+        u32* dCT = buf.alloc<u32>((size_t)m * m);
+        u32* dX = buf.alloc<u32>((size_t)m * m);
         int* d_col_start = buf.alloc<int>(m + 1);
         int* d_row_index = buf.alloc<int>(nnz);
         i64* d_value = buf.alloc<i64>(nnz);
@@ -461,21 +613,54 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         RELP_HIP(hipMemcpyAsync(d_row_value, B.row_value.data(), nnz * sizeof(i64), hipMemcpyHostToDevice, stream));
         u32 p = 0;
         for (u32 candidate : primes) {
-            RELP_HIP(hipMemsetAsync(d_info, 0, 4 * sizeof(int), stream));
-            hipLaunchKernelGGL(build_augmented_kernel, dim3(m), dim3(64), 0, stream, dM, m, ld, d_col_start, d_row_index, d_value, candidate);
-            for (int k = 0; k < m; ++k) {
-                hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, stream, dM, m, ld, k, candidate, d_colk, d_info);
-                hipLaunchKernelGGL(gj_eliminate_kernel, dim3((ld + 255) / 256, m), dim3(256), 0, stream, dM, m, ld, k, candidate, d_colk, d_info);
+            // sparse LU of B mod p on the host (Markowitz order; any non-zero pivot is exact in Z_p): a few 10^4 operations
+            std::vector<u32> value_mod(nnz);
+            for (size_t e = 0; e < nnz; ++e) {
+                i64 v = B.value[e] % (i64)candidate;
+                if (v < 0) v += candidate;
+                value_mod[e] = (u32)v;
             }
-            int info[4];
-            RELP_HIP(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, stream));
-            RELP_HIP(hipStreamSynchronize(stream));
-            if (!info[0]) { p = candidate; break; }
+            LuOptions lo;
+            lo.threshold = 0.0;
+            const LuModOps ops{candidate};
+            const HostLUT<u32> f = lu_factor_t<LuModOps>(m, B.col_start.data(), B.row_index.data(), value_mod.data(), lo, ops);
+            if (f.singular) continue;  // singular modulo this prime (or singular): try the next one
+            std::vector<u32> dinv(m);
+            for (int i = 0; i < m; ++i) dinv[i] = ops.inverse(f.diag[i]);
+            const size_t nl = f.l_col.size(), nu = f.u_col.size();
+            int* d_rowpos = buf.alloc<int>(m);
+            int* d_colpos = buf.alloc<int>(m);
+            int* d_ls = buf.alloc<int>(m + 1);
+            int* d_us = buf.alloc<int>(m + 1);
+            int* d_lc = buf.alloc<int>(nl);
+            int* d_uc = buf.alloc<int>(nu);
+            u32* d_lv = buf.alloc<u32>(nl);
+            u32* d_uv = buf.alloc<u32>(nu);
+            u32* d_dinv = buf.alloc<u32>(m);
+            RELP_HIP(hipMemcpyAsync(d_rowpos, f.rowpos.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(d_colpos, f.colpos.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(d_ls, f.l_start.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(d_us, f.u_start.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (nl) RELP_HIP(hipMemcpyAsync(d_lc, f.l_col.data(), nl * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (nl) RELP_HIP(hipMemcpyAsync(d_lv, f.l_val.data(), nl * sizeof(u32), hipMemcpyHostToDevice, stream));
+            if (nu) RELP_HIP(hipMemcpyAsync(d_uc, f.u_col.data(), nu * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (nu) RELP_HIP(hipMemcpyAsync(d_uv, f.u_val.data(), nu * sizeof(u32), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(d_dinv, dinv.data(), m * sizeof(u32), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(modular_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, m, candidate, d_rowpos, d_colpos, d_ls, d_lc, d_lv,
+                               d_us, d_uc, d_uv, d_dinv, dX, dC, dCT);
+            RELP_HIP(hipStreamSynchronize(stream));  // (the staging vectors above go out of scope)
+            p = candidate;
+            break;
         }
         if (p == 0) { *message = "basis singular modulo every trial prime (singular basis?)"; return; }
+        // (The number of p-adic digits is found by doubling: Cramer's bound through |det B| of the row-scaled integer matrix
+        //  over-estimates it three-fold on 25FV47, and the cost of the reconstruction grows with the square of it.)
+        g_times.inverse += wall_now() - t_inverse;
         auto solve = [&](const std::vector<i64>& r, int transpose, ExactVector* out) {
-            return transpose ? dixon_solve(B, r, 1, p, dM, ld, buf, d_col_start, d_row_index, d_value, stream, out, message)
-                             : dixon_solve(B, r, 0, p, dM, ld, buf, d_row_start, d_col_index, d_row_value, stream, out, message);
+            g_times.solves++;
+            const int first = 32;
+            return transpose ? dixon_solve(B, r, 1, p, dCT, buf, d_col_start, d_row_index, d_value, stream, out, message, first)
+                             : dixon_solve(B, r, 0, p, dC, buf, d_row_start, d_col_index, d_row_value, stream, out, message, first);
         };
 
         // ---- exact primal and dual solutions ------------------------------------------------------------
@@ -511,6 +696,11 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         if (!solve(cost_basis, 1, &y)) return;  // B' y = c_B: the rows of B' are the columns of B
 
         // ---- checks ---------------------------------------------------------------------------------------
+        const double t_checks = wall_now();
+        struct ChecksTimer {
+            double t0;
+            ~ChecksTimer() { g_times.checks += wall_now() - t0; }
+        } checks_timer{t_checks};
         int worst_row = -1;  // most negative x_B (all share the positive denominator)
         for (int k = 0; k < m; ++k) {
             if (basis[k] < 0 && x.numer[k].sign() > 0) { *message = "artificial variable positive in exact arithmetic"; return; }

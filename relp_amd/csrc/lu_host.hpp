@@ -30,18 +30,53 @@ struct LuOptions {
     int search_limit = 4;          // rows + columns examined with an acceptable candidate before the search stops
 };
 
-struct HostLU {
+// Arithmetic of the factorisation: f64 for the solver's carry, Z_p for the exact certificate (certify.hip), where the
+// same elimination runs modulo a 31-bit prime and any non-zero pivot is as good as another.
+struct LuRealOps {
+    using value = double;
+    bool exact() const { return false; }
+    bool is_zero(double v) const { return v == 0.0; }
+    double magnitude(double v) const { return std::fabs(v); }
+    double div(double a, double b) const { return a / b; }
+    double mul(double a, double b) const { return a * b; }
+    double sub(double a, double b) const { return a - b; }
+    double neg(double a) const { return -a; }
+};
+struct LuModOps {
+    using value = uint32_t;
+    uint32_t p;
+    bool exact() const { return true; }
+    bool is_zero(uint32_t v) const { return v == 0; }
+    double magnitude(uint32_t v) const { return v ? 1.0 : 0.0; }
+    uint32_t inverse(uint32_t a) const {  // extended Euclid, a in [1, p)
+        int64_t t = 0, nt = 1, r = p, nr = a;
+        while (nr != 0) {
+            const int64_t q = r / nr;
+            int64_t tmp = t - q * nt; t = nt; nt = tmp;
+            tmp = r - q * nr; r = nr; nr = tmp;
+        }
+        if (t < 0) t += p;
+        return (uint32_t)t;
+    }
+    uint32_t mul(uint32_t a, uint32_t b) const { return (uint32_t)(((uint64_t)a * b) % p); }
+    uint32_t div(uint32_t a, uint32_t b) const { return mul(a, inverse(b)); }
+    uint32_t sub(uint32_t a, uint32_t b) const { return a >= b ? a - b : a + p - b; }
+    uint32_t neg(uint32_t a) const { return a ? p - a : 0; }
+};
+
+template <class V>
+struct HostLUT {
     int m = 0;
     bool singular = false;
     std::vector<int> rowpos;  // P.forward: original row  -> position in L / U   (decomposition/mod.rs:129-133)
     std::vector<int> colpos;  // Q.forward: basis slot    -> position in L / U
     // strictly lower part of L by rows of the position space (unit diagonal implied), entries (j < i, l_ij)
     std::vector<int> l_start, l_col;
-    std::vector<double> l_val;
+    std::vector<V> l_val;
     // strictly upper part of U by rows, entries (j > i, u_ij); separate diagonal (mod.rs:36-58 `upper_diagonal`)
     std::vector<int> u_start, u_col;
-    std::vector<double> u_val;
-    std::vector<double> diag;
+    std::vector<V> u_val;
+    std::vector<V> diag;
     // Level schedules of the four triangular solves (the DAG of each is static between refactorisations: Forrest-Tomlin
     // updates only ever REMOVE entries of the refactorised U, see lu.hpp).  sched[k]: 0 = L by rows (FTRAN), 1 = U by rows
     // (FTRAN), 2 = U by columns (BTRAN), 3 = L by columns (BTRAN).  Rows of one level are independent of each other.
@@ -49,11 +84,13 @@ struct HostLU {
     long long nnz_l() const { return (long long)l_col.size(); }
     long long nnz_u() const { return (long long)u_col.size(); }
 };
+using HostLU = HostLUT<double>;
 
 namespace lu_detail {
-struct Entry {
+template <class V>
+struct EntryT {
     int col;
-    double val;
+    V val;
 };
 // doubly linked bucket lists of the active rows (or columns) by their current count
 struct Buckets {
@@ -87,19 +124,22 @@ struct Buckets {
 }  // namespace lu_detail
 
 // Basis columns in slot order, CSC (rows of a column in any order, no duplicates).
-inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const double* value, const LuOptions& opt) {
+template <class Ops>
+inline HostLUT<typename Ops::value> lu_factor_t(int m, const int* col_start, const int* row_index, const typename Ops::value* value,
+                                                   const LuOptions& opt, const Ops& ops) {
+    using V = typename Ops::value;
+    using Entry = lu_detail::EntryT<V>;
     using lu_detail::Buckets;
-    using lu_detail::Entry;
-    HostLU f;
+    HostLUT<V> f;
     f.m = m;
     f.rowpos.assign(m, -1);
     f.colpos.assign(m, -1);
-    f.diag.assign(m, 0.0);
+    f.diag.assign(m, V(0));
     std::vector<std::vector<Entry>> R(m);   // active entries of the active rows
     std::vector<std::vector<int>> C(m);     // active rows of every active column (pattern)
     for (int j = 0; j < m; ++j)
         for (int e = col_start[j]; e < col_start[j + 1]; ++e) {
-            if (value[e] == 0.0) continue;
+            if (ops.is_zero(value[e])) continue;
             R[row_index[e]].push_back({j, value[e]});
             C[j].push_back(row_index[e]);
         }
@@ -124,7 +164,7 @@ inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const
 
     auto row_max = [&](int i) {
         double mx = 0.0;
-        for (const Entry& e : R[i]) mx = std::max(mx, std::fabs(e.val));
+        for (const Entry& e : R[i]) mx = std::max(mx, ops.magnitude(e.val));
         return mx;
     };
 
@@ -132,16 +172,16 @@ inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const
         // ---- Markowitz search --------------------------------------------------------------------------------
         long long best_score = std::numeric_limits<long long>::max();
         int bi = -1, bj = -1, bjp = 0, bip = 0;
-        double bval = 0.0;
+        V bval = V(0);
         int examined = 0;
-        auto consider = [&](int i, int j, double v, long long score, double rmax) {
-            if (v == 0.0) return;
-            if (std::fabs(v) < opt.threshold * rmax) return;
+        auto consider = [&](int i, int j, V v, long long score, double rmax) {
+            if (ops.is_zero(v)) return;
+            if (ops.magnitude(v) < opt.threshold * rmax) return;
             bool take;
             if (opt.reference_ties) {
                 take = score < best_score || (score == best_score && (cpos[j] < bjp || (cpos[j] == bjp && rpos[i] < bip)));
             } else {
-                take = score < best_score || (score == best_score && std::fabs(v) > std::fabs(bval));
+                take = score < best_score || (score == best_score && ops.magnitude(v) > ops.magnitude(bval));
             }
             if (bi < 0 || take) {
                 best_score = score;
@@ -157,7 +197,7 @@ inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const
             if (bi >= 0 && (opt.reference_ties ? best_score < bound : best_score <= bound)) break;
             for (int j = cb.head[nz]; j >= 0; j = cb.next[j]) {
                 for (int i : C[j]) {
-                    double v = 0.0;
+                    V v = V(0);
                     for (const Entry& e : R[i])
                         if (e.col == j) { v = e.val; break; }
                     // a column singleton needs no elimination: any non-zero is a stable pivot
@@ -177,7 +217,7 @@ inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const
             return f;
         }
         const int pi = bi, pj = bj;
-        const double pv = bval;
+        const V pv = bval;
         // ---- swap to (k, k): positions only (decomposition/mod.rs:224-273) ------------------------------------
         {
             const int other_row = row_at[k], pr = rpos[pi];
@@ -214,30 +254,31 @@ inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const
         for (int i2 : C[pj]) {
             if (i2 == pi) continue;
             std::vector<Entry>& row = R[i2];
-            double a = 0.0;
+            V a = V(0);
             for (size_t t = 0; t < row.size(); ++t)
                 if (row[t].col == pj) { a = row[t].val; row[t] = row.back(); row.pop_back(); break; }
-            const double ratio = a / pv;
+            const V ratio = ops.div(a, pv);
             Lrow[i2].push_back({k, ratio});
             if (!prow.empty()) {
                 for (size_t t = 0; t < row.size(); ++t) where[row[t].col] = (int)t;
                 for (const Entry& e : prow) {
-                    const double product = ratio * e.val;
+                    const V product = ops.mul(ratio, e.val);
                     const int t = where[e.col];
                     if (t >= 0) {
-                        const double old = row[t].val;
-                        double updated = old - product;
-                        if (updated != 0.0 && !opt.reference_ties && std::fabs(updated) <= 1e-15 * (std::fabs(old) + std::fabs(product))) updated = 0.0;
+                        const V old = row[t].val;
+                        V updated = ops.sub(old, product);
+                        if (!ops.exact() && !ops.is_zero(updated) && !opt.reference_ties &&
+                            ops.magnitude(updated) <= 1e-15 * (ops.magnitude(old) + ops.magnitude(product))) updated = V(0);
                         row[t].val = updated;  // zeros are swept below
                     } else {
-                        row.push_back({e.col, -product});
+                        row.push_back({e.col, ops.neg(product)});
                         C[e.col].push_back(i2);
                         cb.move(e.col, (int)C[e.col].size());
                     }
                 }
                 for (size_t t = 0; t < row.size(); ++t) where[row[t].col] = -1;
                 for (size_t t = 0; t < row.size();) {  // exact cancellations leave the pattern (decomposition/mod.rs:176-186)
-                    if (row[t].val == 0.0) {
+                    if (ops.is_zero(row[t].val)) {
                         std::vector<int>& cj = C[row[t].col];
                         for (size_t s = 0; s < cj.size(); ++s)
                             if (cj[s] == i2) { cj[s] = cj.back(); cj.pop_back(); break; }
@@ -291,8 +332,13 @@ inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const
     return f;
 }
 
+inline HostLU lu_factor(int m, const int* col_start, const int* row_index, const double* value, const LuOptions& opt) {
+    return lu_factor_t<LuRealOps>(m, col_start, row_index, value, opt, LuRealOps{});
+}
+
 // Level sets: level(i) = 1 + max level of the rows i reads (0 when it reads none); rows sorted by level.
-inline void lu_schedules(HostLU& f) {
+template <class V>
+inline void lu_schedules(HostLUT<V>& f) {
     const int m = f.m;
     std::vector<int> lev(m);
     auto finish = [&](int k) {
@@ -332,7 +378,8 @@ inline void lu_schedules(HostLU& f) {
 }
 
 // Longest dependency chain of the two triangular solves (each hop is one LDS round trip on the device, lu.hip).
-inline void lu_depths(const HostLU& f, int* depth_l, int* depth_u) {
+template <class V>
+inline void lu_depths(const HostLUT<V>& f, int* depth_l, int* depth_u) {
     std::vector<int> lev(f.m, 0);
     int dl = 0, du = 0;
     for (int i = 0; i < f.m; ++i) {
