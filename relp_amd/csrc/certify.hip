@@ -268,12 +268,16 @@ i128 lcm128(i128 a, i128 b) {
     return mul_checked(a / g, b);
 }
 
+// |v| <= sqrt(M / 2), decided by bit lengths: v < 2^k with 2k <= bits(M) - 2 gives v^2 < 2^(bits(M) - 2) <= M / 2.  (Sufficient,
+// not necessary: at most two bits stricter than Wang's bound, and free -- the exact test is a big multiplication per call.)
+bool within_wang_bound(const BigInt& v, const BigInt& M) { return 2 * v.bits() + 2 <= M.bits(); }
+
 // Rational reconstruction of a (mod M): n/d with |n|, d <= sqrt(M/2) (Wang's bound); returns false if none.
 bool rational_reconstruct(const BigInt& a, const BigInt& M, BigInt& n, BigInt& d) {
     BigInt r0 = M, r1 = a % M;
     if (r1.sign() < 0) r1 = r1 + M;
     BigInt t0(0), t1(1);
-    auto too_big = [&](const BigInt& r) { return cmp(r * r * BigInt(2), M) > 0; };
+    auto too_big = [&](const BigInt& r) { return !within_wang_bound(r, M); };
     while (too_big(r1)) {
         BigInt q, rem;
         BigInt::divmod(r0, r1, q, rem);
@@ -408,14 +412,14 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             const bool found = rational_reconstruct(combo, modulus, n, d);
             g_times.reconstruct += wall_now() - t_rr;
             g_times.reconstructs++;
-            if (found && cmp(d * d * BigInt(2), modulus) <= 0) denom = d;
+            if (found && within_wang_bound(d, modulus)) denom = d;
             else ok = false;  // not enough digits yet
         }
         for (int pass = 0; ok; ++pass) {
             pool.run(m, [&](int i) {
                 BigInt t = (residue[i] * denom) % modulus;
                 if (cmp(t, half) > 0) t = t - modulus;
-                small[i] = cmp(t.abs() * t.abs() * BigInt(2), modulus) <= 0 ? 1 : 0;
+                small[i] = within_wang_bound(t, modulus) ? 1 : 0;
                 numer[i] = t;
             });
             bool grown = false;
@@ -425,7 +429,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
                 BigInt t = grown ? (numer[i] * factor) % modulus : numer[i];
                 if (grown && cmp(t, half) > 0) t = t - modulus;
                 if (grown && t.sign() < 0 && cmp(t.abs(), half) > 0) t = t + modulus;
-                if (cmp(t.abs() * t.abs() * BigInt(2), modulus) <= 0) continue;  // the denominators found so far cover it
+                if (within_wang_bound(t, modulus)) continue;  // the denominators found so far cover it
                 BigInt n, d;
                 const double t_rr = wall_now();
                 const bool found = rational_reconstruct(t, modulus, n, d);
@@ -435,7 +439,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
                 factor = factor * d;
                 denom = denom * d;
                 grown = true;
-                if (cmp(denom * denom * BigInt(2), modulus) > 0) { ok = false; break; }
+                if (!within_wang_bound(denom, modulus)) { ok = false; break; }
             }
             if (!grown) break;
             if (pass > 64) ok = false;
