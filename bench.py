@@ -64,6 +64,55 @@ def cpu_baseline(path, budget_seconds):
                       "reference's algorithm; early pivots are the cheap ones, numbers grow to ~1800 bits%s)" % (pivots, elapsed, full)}
 
 
+def cpu_baseline_f64(path, budget_seconds):
+    """The SAME f64 algorithm on the CPU (oracle/f64_model.py: numpy twin of the device loop -- explicit inverse, steepest edge,
+    Harris ratio test, Newton-Schulz polish), bounded sample; and, as context, a tuned CPU f64 simplex (HiGHS through scipy)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from f64_model import Model, Options
+    from relp_oracle.mps import load_problem
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([pool.get("num_threads", 1) for pool in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    _, data = load_problem(path)
+    options = Options()
+    options.max_seconds = budget_seconds
+    model = Model(data, options)
+    start = time.perf_counter()
+    status = model.solve()
+    elapsed = time.perf_counter() - start
+    pivots = int(sum(model.iters))
+    record = {"value": pivots / elapsed if elapsed > 0 else 0.0, "unit": "pivots/s", "cores": threads, "kind": "port",
+              "sample": "%s of the same LP in f64 on the CPU: numpy restatement of the device algorithm (explicit inverse, steepest "
+                        "edge, polish), BLAS on %d threads: %d pivots in %.1f s (%s)" % (
+                            "the whole solve" if status == "optimal" else "the first pivots", threads, pivots, elapsed, status)}
+    try:  # context only: a production CPU simplex with its own presolve and pivoting rules (a different algorithm)
+        import numpy as np
+        from scipy.optimize import linprog
+        import relp_amd
+        mdl = relp_amd.Model(path)
+        m, n = mdl.nr_rows, mdl.nr_columns
+        import scipy.sparse as sp
+        rows, cols, vals = [], [], []
+        for j in range(n):
+            r, v = mdl.column(j)
+            rows.extend(r.tolist())
+            cols.extend([j] * len(r))
+            vals.extend(v.tolist())
+        a = sp.csc_matrix((vals, (rows, cols)), shape=(m, n))
+        c = np.array([mdl.cost_value(j) for j in range(n)])
+        t0 = time.perf_counter()
+        res = linprog(c, A_eq=a, b_eq=mdl.right_hand_side(), bounds=(0, None), method="highs-ds", options={"presolve": True})
+        seconds = time.perf_counter() - t0
+        record["tuned_cpu_solver"] = {"name": "HiGHS dual simplex (scipy.optimize.linprog, method highs-ds, presolve on)",
+                                      "seconds": seconds, "iterations": int(res.nit), "objective": float(res.fun) + mdl.fixed_cost(),
+                                      "status": int(res.status)}
+    except Exception as error:  # noqa: BLE001
+        record["tuned_cpu_solver"] = {"error": str(error)}
+    return record
+
+
 def cpu_baseline_dense(dims, budget_seconds):
     """f64 CPU restatement of the same loop for the dense workloads (oracle/f64_dense.py, numpy + its threaded BLAS);
     the exact-rational path is infeasible at this size."""
@@ -243,6 +292,8 @@ def main():
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-concurrency-probe", action="store_true")
     parser.add_argument("--no-dense-roofline", action="store_true")
+    parser.add_argument("--no-certify", action="store_true", help="25fv47: leave the exact certificate out of the timed step (A/B only)")
+    parser.add_argument("--carry", type=int, default=0, choices=[0, 1], help="0 explicit inverse, 1 LU + Forrest-Tomlin (relp_options.carry)")
     parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
     parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
@@ -277,7 +328,9 @@ def main():
         a, b, c = dense_lp(*path)
         solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512"))).load_dense_le(a, b, c)
     else:
-        solver = relp_amd.Solver(device=local_rank).load_mps(path, presolve=args.presolve)
+        # the step is `solve_relaxation` with the exact certificate INSIDE: the f64 loop alone is narrower arithmetic than the
+        # reference's, the bit-exact optimum is part of the job (BASELINE.json north_star)
+        solver = relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry).load_mps(path, presolve=args.presolve)
 
     def barrier():
         if distributed:
@@ -290,9 +343,14 @@ def main():
     start = time.perf_counter()
     pivots = 0
     last = None
+    loop_seconds = certify_seconds = 0.0
+    all_certified = True
     for _ in range(args.steps):
         last = solver.solve_relaxation()
         pivots += last.pivots_phase_one + last.pivots_phase_two
+        loop_seconds += last.solve_seconds
+        certify_seconds += last.certify_seconds
+        all_certified = all_certified and bool(last.certified)
     barrier()
     elapsed = time.perf_counter() - start
     from relp_amd import batch
@@ -303,7 +361,7 @@ def main():
         # headroom: the same LP, 4 independent copies in flight on this GPU (one host thread and stream each); a single
         # latency-bound solve uses a fraction of the chip.  Reported beside `value`, never as `value`.
         import threading
-        copies = [solver] + [relp_amd.Solver(device=local_rank).load_mps(path, presolve=args.presolve) for _ in range(3)]
+        copies = [solver] + [relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry).load_mps(path, presolve=args.presolve) for _ in range(3)]
         for extra in copies[1:]:
             extra.solve_relaxation()
         counts = [0] * len(copies)
@@ -327,18 +385,15 @@ def main():
             extra.close()
 
     exact = None
-    if rank == 0 and not dense and not graph:
-        # one extra, untimed, certified solve: bit-exact rational optimum (north_star parity requirement)
-        certified = relp_amd.Solver(device=local_rank, certify=1).load_mps(path, presolve=args.presolve)
-        cres = certified.solve_relaxation()
-        if cres.certified:
-            text = certified.objective_exact()
+    if rank == 0 and not dense and not graph and not args.no_certify:
+        # the exact optimum of the LAST TIMED solve (the certificate ran inside every timed step)
+        if all_certified:
+            text = solver.objective_exact()
             num, den = text.split("/")
             exact = {"certified": True, "objective_bits": max(int(num).bit_length(), int(den).bit_length()),
-                     "certify_seconds": cres.certify_seconds, "objective_exact_head": text[:40] + "..."}
+                     "certify_seconds_per_solve": certify_seconds / args.steps, "objective_exact_head": text[:40] + "..."}
         else:
             exact = {"certified": False}
-        certified.close()
     if rank == 0:
         # roofline of the dominant kernel (pricing pass), measured live with HIP events on the solver's stream
         solver.begin_phase_one()
@@ -346,23 +401,38 @@ def main():
         solver.iterate(20 if graph else (300 if dense else 200))
         reps = 40 if graph else (100 if dense else 200)  # further real pivots, the profiled kernel of each bracketed by its own event pair
         solver.profile_kernel(0, 10 if graph else 50)   # discarded: brings clocks and caches to the state of a running solve
-        seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(["price", "ftran_ratio", "update"])}
+        lu_carry = args.carry == 1 and not dense and not graph
+        kernels = ["price", "lu_pivot"] if lu_carry else ["price", "ftran_ratio", "update"]
+        seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
         stats = solver.stats()
-        # the roofline kernel is the pricing pass (the path's only mandatory full sweep over the constraint columns;
-        # its algorithmic bytes are exact: the columns that are non-basic at the profiled state)
-        dominant = "price"
-        bytes_per_launch = stats.price_bytes
+        # Algorithmic bytes per launch: pricing = the non-basic columns (exact, counted at the profiled
+        # state); K2 = nnz(a_q) columns of the inverse + six m-vectors; K3 = read + write of the touched part of the inverse
+        # (upper bound: all of it); the LU kernel = both orientations of the factors once each + twelve m-vectors.
+        m_rows = solver.m
+        mean_column = max(1.0, float(relp_amd.Model(path).nnz) / max(1, solver.n_provider)) if not dense and not graph else float(m_rows)
+        algorithmic = {"price": stats.price_bytes,
+                       "ftran_ratio": int(mean_column * m_rows * 8 + 6 * m_rows * 8),
+                       "update": stats.update_bytes,
+                       "lu_pivot": int(12 * m_rows * 8 + 2 * 12 * 3 * m_rows)}  # (factor entries: about 3 per row and triangle)
+        per_kernel = {name: {"seconds_per_launch": seconds[name], "algorithmic_bytes_per_launch": algorithmic[name],
+                             "achieved_gb_s": algorithmic[name] / seconds[name] / 1e9,
+                             "frac": algorithmic[name] / seconds[name] / 1e9 / HBM_PEAK_GBS,
+                             "share_of_pivot_time": seconds[name] / sum(seconds.values())} for name in kernels}
+        dominant = max(kernels, key=lambda name: seconds[name])  # by MEASURED time share, not by assumption
+        bytes_per_launch = algorithmic[dominant]
         achieved = bytes_per_launch / seconds[dominant] / 1e9
-        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; see
-        # profiles/r1_dense4096_pmc_traffic.json and MI355X_MICROARCH.md section HBM); null when not collected
+        # HBM traffic per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md
+        # section HBM); null when not collected for this kernel
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_%s_pmc_traffic.json" % args.workload)
-        if os.path.exists(pmc):
-            wanted = "price_dense_kernel" if dense else "relp::price_kernel<"
-            for name, entry in json.load(open(pmc)).items():
-                if wanted in name:
-                    traffic = entry["hbm_bytes_corrected"]
-                    break
+        pmc_names = {"price": "price_dense_kernel" if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
+                     "lu_pivot": "lu_pivot_kernel"}
+        for candidate in ("r2_%s_pmc_traffic.json" % args.workload, "r1_%s_pmc_traffic.json" % args.workload):
+            pmc = os.path.join(ROOT, "profiles", candidate)
+            if traffic is None and os.path.exists(pmc):
+                for name, entry in json.load(open(pmc)).items():
+                    if pmc_names[dominant] in name:
+                        traffic = entry["hbm_bytes_corrected"]
+                        break
         if graph:
             workload = ("max-flow LP (examples/max_flow.rs provider) on a random graph V=%d E=%d (splitmix64 seed 0x5EED0005): "
                         "%d conservation rows on the device, the %d capacity rows as implicit bounds" % (
@@ -372,8 +442,10 @@ def main():
             workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing" % path
             data = "synthetic"
         else:
-            workload = ("Netlib 25FV47 %dx%d, steepest-edge pricing, explicit-inverse carry, %s" % (
-                solver.m, solver.n_provider, "after the reference's presolve" if args.presolve else "no presolve (+520 virtual artificials)"))
+            workload = ("Netlib 25FV47 %dx%d, steepest-edge pricing, %s carry, exact certificate %s the timed step, %s" % (
+                solver.m, solver.n_provider, "LU + Forrest-Tomlin" if args.carry == 1 else "explicit-inverse",
+                "outside" if args.no_certify else "inside",
+                "after the reference's presolve" if args.presolve else "no presolve (+520 virtual artificials)"))
             data = "Netlib 25FV47.SIF (shipped problem file), one copy per GPU"
         line = {
             "metric": "simplex pivots/sec + wall-clock to optimal, Netlib 25fv47 @1 GPU",
@@ -382,13 +454,18 @@ def main():
             "dtype": "f64", "data": data,
             "config": {"workload": workload,
                        "pivots_per_solve": int(last.pivots_phase_one + last.pivots_phase_two),
-                       "objective": last.objective, "wall_clock_to_optimal_s": last.solve_seconds,
+                       "objective": last.objective,
+                       "wall_clock_to_exact_optimum_s": (loop_seconds + certify_seconds) / args.steps,
+                       "wall_clock_f64_loop_s": loop_seconds / args.steps,
+                       "pivots_per_s_f64_loop_only": pivots / world / loop_seconds if loop_seconds > 0 else None,
+                       "carry": "lu" if args.carry == 1 else "explicit", "refactors": int(last.refactors),
                        "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
                        "parallelism": "1 LP per GPU x%d" % world, "exact": exact,
                        "aggregate_with_copies_in_flight": in_flight},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernels": per_kernel},
         }
         if graph:
             line["metric"] = "simplex pivots/sec + wall-clock to optimal, max-flow LP @1 GPU"
@@ -400,15 +477,17 @@ def main():
                                         "per entry from LDS (%.0f GB/s of ~150000) and is bound by that and by f64 FMA issue, not by HBM"
                                         % (24 * bytes_per_launch / seconds[dominant] / 1e9))
         if not dense and not graph:
-            line["roofline"]["note"] = ("latency bound by construction: one pricing launch streams %d KB that live in L2 / Infinity Cache "
-                                        "(SURVEY.md section 8(d)); traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes: the "
-                                        "kernel reads the columns from their 8-entry padded copy (230 KB) and the x2 correction for wide "
-                                        "streams over-counts these short gathers; the HBM-roofline configuration is BASELINE configs[2], "
-                                        "measured below") % (bytes_per_launch // 1024)
+            line["roofline"]["note"] = ("latency bound by construction: the dominant kernel BY MEASURED TIME is '%s' (%d KB of algorithmic "
+                                        "bytes per launch, all of it resident in L2 / Infinity Cache; SURVEY.md section 8(d)); every kernel of "
+                                        "the pivot is listed under 'kernels' with its share of the pivot time; traffic = 2 x FETCH_SIZE + "
+                                        "WRITE_SIZE of the committed PMC passes for that kernel; the HBM-roofline configuration is BASELINE "
+                                        "configs[2], measured below") % (dominant, bytes_per_launch // 1024)
             if world == 1 and not args.no_dense_roofline:
                 line["roofline_config3"] = dense_roofline(local_rank)
         if world == 1 and not args.no_cpu_baseline and not graph:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline_dense(path, args.cpu_seconds) if dense else cpu_baseline(path, args.cpu_seconds)
+            if not dense:
+                line["cpu_baseline_f64"] = cpu_baseline_f64(path, args.cpu_seconds)
     if distributed:
         dist.destroy_process_group()
     if rank == 0:

@@ -22,6 +22,7 @@ class Options:
     tol_feas = 1e-7      # phase-one objective above this (relative to 1+|b|_1) => infeasible
     polish_period = 64   # Newton-Schulz polish of the explicit inverse every this many pivots
     max_iters = 200000
+    max_seconds = None   # wall-clock budget of `solve` (bench.py's bounded cpu_baseline sample); None: none
 
 
 OPTIMAL, UNBOUNDED, INFEASIBLE, ITER_LIMIT = "optimal", "unbounded", "infeasible", "iteration_limit"
@@ -156,9 +157,12 @@ class Model:
 
     # ---- driver ----------------------------------------------------------------------------------
     def run_phase(self, phase):
+        import time
         since = 0
         while True:
             if sum(self.iters) >= self.opt.max_iters:
+                return ITER_LIMIT
+            if self.opt.max_seconds is not None and time.perf_counter() - self.started > self.opt.max_seconds:
                 return ITER_LIMIT
             sel = self.price()
             if sel is None:
@@ -195,6 +199,8 @@ class Model:
         return removed
 
     def solve(self):
+        import time
+        self.started = time.perf_counter()
         if self.n_art > 0:
             self.set_phase(self.cost1)
             status = self.run_phase(1)
