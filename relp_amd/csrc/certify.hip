@@ -483,8 +483,13 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
 // ---------------------------------------------------------------------------------------------------
 // entry point
 // ---------------------------------------------------------------------------------------------------
+// mode 0: the basis is optimal (x_B >= 0, zero artificials, every reduced cost >= 0) -> exact objective.
+// mode 1: the LP is INFEASIBLE: the same checks for the phase-one costs (1 on the artificial columns, 0 elsewhere;
+//         phase_one.rs:123-179) with a POSITIVE optimum -- the dual solution y is a Farkas certificate (y'A <= 0, y'b > 0).
+// mode 2: the LP is UNBOUNDED along provider column `entering`: x_B >= 0, cbar_q < 0 and B^-1 a_q <= 0 exactly
+//         (phase_two.rs:53; zero on the rows whose basic variable is a zero-level artificial).
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_columns, int device, hipStream_t stream,
-                   std::string* objective, bool* certified, long long* repair_pivots, std::string* message) {
+                   std::string* objective, bool* certified, long long* repair_pivots, std::string* message, int mode, int entering) {
     objective->clear();
     *certified = false;
     *repair_pivots = 0;
@@ -520,8 +525,10 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         return;
     }
     i128 cost_mult = 1;
-    for (int j = 0; j < n_p; ++j) cost_mult = lcm128(cost_mult, md.cost_value(j).d);
+    if (mode != 1)
+        for (int j = 0; j < n_p; ++j) cost_mult = lcm128(cost_mult, md.cost_value(j).d);
     auto scaled = [&](const Rat& v, i128 mult) { return mul_checked(v.n, mult / v.d); };
+    auto scaled_cost = [&](int j) -> i128 { return mode == 1 ? (i128)0 : scaled(md.cost_value(j), cost_mult); };
     auto fits = [](i128 v) { return v < ((i128)1 << 62) && v > -((i128)1 << 62); };
 
     // basis columns: provider column c >= 0, or artificial -1-k (unit column on its row, cost 0; redundant rows)
@@ -569,7 +576,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                     B.row_index.push_back(columns[c].index[e]);
                     B.value.push_back((i64)v);
                 }
-                i128 cv = scaled(md.cost_value(c), cost_mult);
+                i128 cv = scaled_cost(c);
                 if (!fits(cv)) { *message = "scaled cost does not fit 62 bits"; return; }
                 cost_basis[k] = (i64)cv;
             } else {
@@ -577,6 +584,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                 if (!fits(row_mult[row])) { *message = "row multiplier does not fit 62 bits"; return; }
                 B.row_index.push_back(row);
                 B.value.push_back((i64)row_mult[row]);
+                cost_basis[k] = mode == 1 ? 1 : 0;  // artificial::Cost::One in phase one (kind/artificial/partially.rs:42-50)
             }
             B.col_start[k + 1] = (int)B.row_index.size();
         }
@@ -707,7 +715,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         } checks_timer{t_checks};
         int worst_row = -1;  // most negative x_B (all share the positive denominator)
         for (int k = 0; k < m; ++k) {
-            if (basis[k] < 0 && x.numer[k].sign() > 0) { *message = "artificial variable positive in exact arithmetic"; return; }
+            if (mode != 1 && basis[k] < 0 && x.numer[k].sign() > 0) { *message = "artificial variable positive in exact arithmetic"; return; }
             if (x.numer[k].sign() < 0 && (worst_row < 0 || cmp(x.numer[k], x.numer[worst_row]) < 0)) worst_row = k;
         }
         // reduced costs (common positive denominator cost_mult * Dy):  c_j*cost_mult*Dy - sum_i a_ij*row_mult_i*Y_i
@@ -715,12 +723,50 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         int worst_col = -1;
         for (int j = 0; j < n_p; ++j) {
             if (in_basis[j]) continue;
-            BigInt acc = big_from_i128(scaled(md.cost_value(j), cost_mult)) * y.denom;
+            BigInt acc = big_from_i128(scaled_cost(j)) * y.denom;
             for (size_t e = 0; e < columns[j].nnz(); ++e)
                 acc = acc - big_from_i128(scaled(columns[j].value[e], row_mult[columns[j].index[e]])) * y.numer[columns[j].index[e]];
             dhat[j] = acc;
             if (acc.sign() < 0 && (worst_col < 0 || cmp(acc, dhat[worst_col]) < 0)) worst_col = j;
         }
+        if (mode == 2) {
+            // ---- unbounded ray: x_B >= 0, cbar_q < 0, alpha = B^-1 a_q <= 0 (zero where an artificial is basic) ------------
+            if (worst_row >= 0) { *message = "unbounded: the basis is not primal feasible in exact arithmetic"; return; }
+            if (entering < 0 || entering >= n_p || in_basis[entering]) { *message = "unbounded: no entering column"; return; }
+            if (dhat[entering].sign() >= 0) { *message = "unbounded: the entering column's reduced cost is not negative in exact arithmetic"; return; }
+            std::vector<i64> aq(m, 0);
+            for (size_t e = 0; e < columns[entering].nnz(); ++e) {
+                const i128 v = scaled(columns[entering].value[e], row_mult[columns[entering].index[e]]);
+                if (!fits(v)) { *message = "scaled coefficient does not fit 62 bits"; return; }
+                aq[columns[entering].index[e]] = (i64)v;
+            }
+            ExactVector alpha;
+            if (!solve(aq, 0, &alpha)) return;
+            for (int k = 0; k < m; ++k) {
+                const int sgn = alpha.numer[k].sign();
+                if (sgn > 0 || (basis[k] < 0 && sgn != 0)) { *message = "unbounded: the ray leaves the feasible region in exact arithmetic"; return; }
+            }
+            *objective = "-inf";
+            *certified = true;
+            return;
+        }
+        if (mode == 1 && worst_row < 0 && worst_col < 0) {
+            // ---- infeasible: the phase-one optimum (sum of the artificial variables) is positive -------------------------
+            BigInt num(0);
+            for (int k = 0; k < m; ++k)
+                if (cost_basis[k] != 0) num = num + x.numer[k];
+            if (num.sign() <= 0) { *message = "infeasible: the phase-one optimum is zero in exact arithmetic (the LP is feasible)"; return; }
+            BigInt den = x.denom;
+            BigInt g = BigInt::gcd(num, den);
+            if (!g.is_zero() && !(g == BigInt(1))) {
+                num = num / g;
+                den = den / g;
+            }
+            *objective = num.to_string() + "/" + den.to_string();  // the exact phase-one optimum: the certified infeasibility
+            *certified = true;
+            return;
+        }
+        if (mode == 1) { *message = "infeasible: the final phase-one basis is not optimal in exact arithmetic"; return; }
         if (worst_row < 0 && worst_col < 0) {
             // ---- optimal: objective = (sum_k cost_basis[k] X_k) / (cost_mult * Dx) + fixed ----------------------
             BigInt num(0);

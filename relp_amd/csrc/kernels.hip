@@ -2305,10 +2305,10 @@ __global__ void __launch_bounds__(256) gamma_init_kernel(DeviceLP lp, int identi
     if (threadIdx.x == 0) lp.gamma[j] = 1.0 + acc;
 }
 
-__global__ void identity_kernel(double* X, int m, int ld) {
+__global__ void identity_kernel(double* X, int m, int ld) {  // grid-stride over the columns: gridDim.y is capped at 65535
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j < m) X[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
+    if (j >= m) return;
+    for (int i = blockIdx.y; i < m; i += gridDim.y) X[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2613,21 +2613,35 @@ void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double 
     else if (d.dense_val32) RELP_LAUNCH(0, price_dense_kernel<true>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
     else RELP_LAUNCH(0, price_dense_kernel<false>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
 }
-void configure_dense_lds(size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_dense_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PROCESS-WIDE property of a kernel: setting it to the current LP's size would
+// let the last loaded handle decide for every other one.  It is set once, to what the CU has (160 KB minus the kernel's static LDS).
+static void allow_full_lds(const void* kernel) {
+    hipFuncAttributes attr{};
+    size_t fixed = 0;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) fixed = attr.sharedSizeBytes;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fixed)) != hipSuccess) (void)hipGetLastError();
+}
+void configure_dense_lds(size_t) {
+    static bool done = false;
+    if (done) return;
+    allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<false>));
+    allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<true>));
+    allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<false, true>));
+    done = true;
 }
 void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s) {
     hipLaunchKernelGGL(ftran_partial_kernel, dim3((d.m + 255) / 256, n_slices), dim3(256), 0, s, d, n_slices, n_price_blocks, rule);
 }
 
-void configure_lds(size_t price_lds) {
-    // opt in to > 64 KB of dynamic LDS (160 KB per CU on gfx950)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_STEEPEST_EDGE, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_DANTZIG, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, true, PRICE_LPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)price_lds);
+void configure_lds(size_t) {
+    // opt in to > 64 KB of dynamic LDS (160 KB per CU on gfx950), once
+    static bool done = false;
+    if (done) return;
+    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_STEEPEST_EDGE, true, PRICE_LPC>));
+    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_DANTZIG, true, PRICE_LPC>));
+    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE, true, PRICE_LPC>));
+    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, true, PRICE_LPC>));
+    done = true;
 }
 
 template <int RULE>
@@ -2685,7 +2699,7 @@ void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s) {
     hipLaunchKernelGGL(gamma_init_kernel, dim3(d.n - d.n_art), dim3(256), 0, s, d, identity);
 }
 void launch_identity(double* X, int m, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(identity_kernel, dim3((m + 255) / 256, m), dim3(256), 0, s, X, m, ld);
+    hipLaunchKernelGGL(identity_kernel, dim3((m + 255) / 256, std::min(m, 65535)), dim3(256), 0, s, X, m, ld);
 }
 void launch_residual(const DeviceLP& d, const double* T, double* S, hipStream_t s) {
     hipLaunchKernelGGL(residual_kernel, dim3(d.m), dim3(256), 0, s, d, T, S);
@@ -2696,15 +2710,16 @@ static bool use_mfma_gemm() {
     return value;  // RELP_GEMM=vector selects the plain-FMA kernel (A/B measurements)
 }
 __global__ void __launch_bounds__(256) copy_rows_kernel(const double* src, double* dst, int m, int ld, const int* row_list, int n_rows) {
-    const int idx = blockIdx.y;
-    if (idx >= n_rows) return;
-    const size_t row = (size_t)row_list[idx] * ld;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < m) dst[row + i] = src[row + i];
+    if (i >= m) return;
+    for (int idx = blockIdx.y; idx < n_rows; idx += gridDim.y) {  // (gridDim.y is capped at 65535)
+        const size_t row = (size_t)row_list[idx] * ld;
+        dst[row + i] = src[row + i];
+    }
 }
 bool gemm_row_lists_supported() { return use_mfma_gemm(); }  // the plain-FMA fallback kernels compute every row
 void launch_copy_rows(const double* src, double* dst, int m, int ld, const int* row_list, int n_rows, hipStream_t s) {
-    if (n_rows > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3((m + 255) / 256, n_rows), dim3(256), 0, s, src, dst, m, ld, row_list, n_rows);
+    if (n_rows > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3((m + 255) / 256, std::min(n_rows, 65535)), dim3(256), 0, s, src, dst, m, ld, row_list, n_rows);
 }
 // row_list (device, n_rows entries) restricts the computed storage rows; nullptr = all m
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, const int* row_list, int n_rows, hipStream_t s) {
@@ -2727,8 +2742,11 @@ void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s) {
     hipLaunchKernelGGL(alpha_reduce_kernel, dim3((d.m + AR_ROWS - 1) / AR_ROWS), dim3(AR_ROWS * AR_GROUPS), 0, s, d, n_slices);
 }
 int eta_max() { return ETA_MAX; }
-void configure_btran_lds(size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&btran_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+void configure_btran_lds(size_t) {
+    static bool done = false;
+    if (done) return;
+    allow_full_lds(reinterpret_cast<const void*>(&btran_pass_kernel));
+    done = true;
 }
 // deferred product form: fold the new eta into the kept columns, then one read-only pass for rho_p, w and -pi
 void launch_eta_update(const DeviceLP& d, hipStream_t s) {

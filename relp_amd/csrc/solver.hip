@@ -51,7 +51,7 @@ void launch_relative_cost(const DeviceLP& d, double* out, hipStream_t s);
 // certify.hip
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_provider_columns, int device,
                    hipStream_t stream, std::string* objective, bool* certified, long long* repair_pivots,
-                   std::string* message);
+                   std::string* message, int mode, int entering);
 
 namespace {
 double now_seconds() {
@@ -396,6 +396,9 @@ void Solver::upload() {
 }
 
 Ctl Solver::read_ctl() {
+    // Every batch of launches ends in a read of the control block (never inside a stream capture): the place where a
+    // rejected launch -- a grid or an LDS request the device refuses -- surfaces instead of leaving stale device state behind.
+    RELP_HIP(hipGetLastError());
     Ctl c;
     RELP_HIP(hipMemcpyAsync(&c, d_.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
@@ -1001,7 +1004,12 @@ void Solver::solve(relp_result* result) {
                                                          : std::numeric_limits<double>::quiet_NaN();
     tick("results");
     res.solve_seconds = now_seconds() - t0;
-    if (kind == RELP_RESULT_FINITE_OPTIMUM && opt_.certify) certify(&res);
+    // The exact certificate: optimality of the final basis; for the two other verdicts of `OptimizationResult`
+    // (algorithm/mod.rs:43-47), which the reference decides exactly, a Farkas certificate / an unbounded ray.
+    unbounded_column_ = kind == RELP_RESULT_UNBOUNDED ? c.q - d_.n_art : -1;
+    if (opt_.certify && !bounded_ &&
+        (kind == RELP_RESULT_FINITE_OPTIMUM || kind == RELP_RESULT_INFEASIBLE || kind == RELP_RESULT_UNBOUNDED)) certify(&res);
+    else if (opt_.certify && kind == RELP_RESULT_FINITE_OPTIMUM) certify(&res);
     last_result = res;
     if (result) *result = res;
 }
@@ -1042,7 +1050,13 @@ void Solver::certify(relp_result* result) {
     bool ok = false;
     long long repairs = 0;
     std::string message;
-    certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message);
+    try {
+        const int mode = result->kind == RELP_RESULT_INFEASIBLE ? 1 : result->kind == RELP_RESULT_UNBOUNDED ? 2 : 0;
+        certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message, mode, unbounded_column_);
+    } catch (const RatOverflow& e) {  // the f64 result stands; it is reported uncertified with the reason
+        ok = false;
+        message = std::string("exact certificate: ") + e.what();
+    }
     result->certified = ok ? 1 : 0;
     result->exact_repair_pivots = repairs;
     result->certify_seconds = now_seconds() - t0;

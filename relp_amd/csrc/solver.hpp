@@ -194,6 +194,7 @@ private:
     bool lu_mode_ = false;
     bool lu_is_identity_ = true;
     int refactor_period_ = 64;
+    int unbounded_column_ = -1;  // provider column of the ray when the result is UNBOUNDED
     long long refactors_ = 0;
     double refactor_seconds_ = 0.0;
     std::vector<int> h_col_start_, h_row_index_;  // host copy of the device CSC (basis columns for the refactorisation)

@@ -70,3 +70,38 @@ def test_exact_repair_pivots_fix_a_suboptimal_f64_basis(name, tol):
     if abs(result.objective - expected) > 1e-9 * abs(expected):
         assert result.exact_repair_pivots > 0  # the f64 vertex was not optimal, so exact pivots were needed
     solver.close()
+
+
+def test_unbounded_is_certified_by_an_exact_ray():
+    """The reference decides `Unbounded` exactly (phase_two.rs:53; tests/burkardt/test.rs:157-167).  With `certify` the f64
+    verdict is proved: x_B >= 0, cbar_q < 0 and B^-1 a_q <= 0 in exact arithmetic."""
+    solver = relp_amd.Solver(certify=1).load_mps(os.path.join(ROOT, "data", "burkardt", "nazareth.mps"))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.UNBOUNDED
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    assert solver.objective_exact() == "-inf"
+    solver.close()
+
+
+@pytest.mark.parametrize("b, expected", [([1, 2], "1/1"), ([3, 10], "7/1"), ([(1, 3), (5, 7)], "8/21")])
+def test_infeasible_is_certified_by_a_farkas_vector(b, expected):
+    """x0 <= b0 and x0 >= b1 > b0: infeasible (phase_one.rs:171-173, decided exactly by the reference).  With `certify` the
+    phase-one dual solution is checked exactly -- y'A <= 0, y'b > 0 -- and the exact phase-one optimum (the distance b1 - b0)
+    comes back."""
+    solver = relp_amd.Solver(certify=1)
+    solver.load_matrix_data([0, 2], [0, 1], [1, 1], [1, 1], b=b, cost=[1], counts=(0, 0, 1, 1))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.INFEASIBLE
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    assert solver.objective_exact() == expected
+    solver.close()
+
+
+def test_a_wrong_infeasible_verdict_is_not_certified():
+    """A sloppy feasibility tolerance turns a feasible LP into an f64 `Infeasible`; the exact check refuses to confirm it."""
+    golden = GOLDEN["SC50A"]
+    solver = relp_amd.Solver(certify=1, tol_dual=50.0).load_mps(os.path.join(ROOT, golden["file"]))
+    result = solver.solve_relaxation()
+    if result.kind == relp_amd.INFEASIBLE:
+        assert result.certified == 0
+    solver.close()
