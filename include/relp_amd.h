@@ -56,6 +56,14 @@ typedef enum relp_carry {
                                   refactorisation every `refactor_period` updates */
 } relp_carry;
 
+/* `Tableau::select_primal_pivot_row` (tableau/mod.rs:287-313). */
+typedef enum relp_ratio_rule {
+    RELP_RATIO_HARRIS = 0,     /* two-pass Harris test with slack `harris_delta`, largest pivot among the near-ties (what f64
+                                  needs on real data), ties to the lowest leaving column */
+    RELP_RATIO_TEXTBOOK = 1    /* the reference's rule: the exact minimum ratio, ties to the lowest leaving column (Bland).  For
+                                  data on which f64 is exact (small integers); rows <= 8192 */
+} relp_ratio_rule;
+
 typedef struct relp_options {
     int32_t device;            /* HIP device ordinal */
     int32_t pivot_rule;        /* relp_pivot_rule */
@@ -83,6 +91,8 @@ typedef struct relp_options {
                                   lower_upper/mod.rs:249-252: the reference refactors after 31); at most 63; 0 = 31 */
     double lu_pivot_threshold; /* LU carry: relative pivot tolerance of the Markowitz factorisation (f64 needs one, the exact
                                   reference does not); 0 = 0.1 */
+    int32_t ratio_rule;        /* relp_ratio_rule */
+    int32_t reserved;
 } relp_options;
 
 typedef struct relp_result {
@@ -266,6 +276,9 @@ int32_t relp_ratio(relp_handle* handle, int32_t column, int32_t* row, double* ou
  * the objective and the steepest-edge weights are updated as in any pivot of the loop.  RELP_ERR_STATE when the pivot
  * element is zero. */
 int32_t relp_bring_into_basis(relp_handle* handle, int32_t column, int32_t row);
+/* The last basis change: `BasisChangeComputationInfo::{pivot_row_index, pivot_column_index, leaving_column_index}`
+ * (tableau/mod.rs:205-234) in the index space of relp_price, and the phase it was made in.  -1 when none was made yet. */
+int32_t relp_get_last_pivot(relp_handle* handle, int32_t* phase, int32_t* column, int32_t* row, int32_t* leaving);
 /* `PivotRule::after_basis_update(info, tableau)` (strategy/pivot_rule.rs:23-54; `SteepestDescentAlongObjective` :243-296): the
  * Goldfarb-Reid update of the steepest-edge weights for the last relp_bring_into_basis / relp_iterate pivot.  Inside the
  * device loop the update rides on the next pricing pass; this entry applies it now (no-op when none is pending, or for the

@@ -18,6 +18,7 @@ FINITE_OPTIMUM, INFEASIBLE, UNBOUNDED, ITERATION_LIMIT = 1, 2, 3, 4
 STEEPEST_EDGE, DANTZIG, FIRST_PROFITABLE, FIRST_PROFITABLE_MEMORY = 0, 1, 2, 3
 STOP_NO_ENTERING, STOP_UNBOUNDED, STOP_BUDGET = 1, 2, 3
 CARRY_EXPLICIT, CARRY_LU = 0, 1
+RATIO_HARRIS, RATIO_TEXTBOOK = 0, 1
 
 
 class RelpError(RuntimeError):
@@ -31,7 +32,8 @@ class Options(C.Structure):
                 ("pivots_per_launch", C.c_int32), ("max_pivots", C.c_int64), ("tol_dual", C.c_double),
                 ("tol_pivot", C.c_double), ("harris_delta", C.c_double), ("tol_feasible", C.c_double),
                 ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("implicit_bounds", C.c_int32),
-                ("carry", C.c_int32), ("refactor_period", C.c_int32), ("lu_pivot_threshold", C.c_double)]
+                ("carry", C.c_int32), ("refactor_period", C.c_int32), ("lu_pivot_threshold", C.c_double),
+                ("ratio_rule", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -58,7 +60,7 @@ SYMBOLS = [
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
     "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
-    "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
+    "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_get_last_pivot", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
     "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps",
     # BasisInverse as an object of its own (relp_amd/basis_inverse.py)
     "relp_bi_options_default", "relp_bi_identity", "relp_bi_invert", "relp_bi_free", "relp_bi_last_error", "relp_bi_m",
@@ -492,6 +494,12 @@ class Solver:
     def bring_into_basis(self, column, row):
         """``Tableau::bring_into_basis`` with a given pivot (index space of ``select_primal_pivot_column``)."""
         self._check(lib().relp_bring_into_basis(self._h, int(column), int(row)))
+
+    def last_pivot(self):
+        """``BasisChangeComputationInfo`` of the last pivot: ``(phase, pivot_column, pivot_row, leaving_column)``."""
+        phase, q, p, leaving = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(lib().relp_get_last_pivot(self._h, C.byref(phase), C.byref(q), C.byref(p), C.byref(leaving)))
+        return phase.value, q.value, p.value, leaving.value
 
     def after_basis_update(self):
         """``PivotRule::after_basis_update`` (strategy/pivot_rule.rs:243-296): apply the pending steepest-edge weight update."""

@@ -70,6 +70,7 @@ int32_t relp_options_default(relp_options* o) {
     o->carry = RELP_CARRY_EXPLICIT;
     o->refactor_period = 0;
     o->lu_pivot_threshold = 0.0;
+    o->ratio_rule = RELP_RATIO_HARRIS;
     return RELP_OK;
 }
 
@@ -693,6 +694,17 @@ int32_t relp_ratio(relp_handle* h, int32_t column, int32_t* row, double* out_alp
 int32_t relp_bring_into_basis(relp_handle* h, int32_t column, int32_t row) {
     REQUIRE_LOADED(h);
     return guarded(h, [&] { h->solver->bring_into_basis(column, row); });
+}
+int32_t relp_get_last_pivot(relp_handle* h, int32_t* phase, int32_t* column, int32_t* row, int32_t* leaving) {
+    REQUIRE_LOADED(h);
+    return guarded(h, [&] {
+        int ph = 0, q = -1, p = -1, l = -1;
+        h->solver->last_pivot(&ph, &q, &p, &l);
+        if (phase) *phase = ph;
+        if (column) *column = q;
+        if (row) *row = p;
+        if (leaving) *leaving = l;
+    });
 }
 int32_t relp_se_after_basis_update(relp_handle* h) {
     REQUIRE_LOADED(h);

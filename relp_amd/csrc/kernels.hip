@@ -1749,6 +1749,10 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         ub_q = lp.ub[q];
         if (forced_q >= 0) cbar_q *= sgn_q;  // the candidates of the pricing pass carry the sign already
     }
+    // harris_delta < 0 selects the reference's ratio test (tableau/mod.rs:287-313): the exact minimum ratio, ties to the lowest
+    // leaving column (Bland) -- for data on which f64 is exact; the default is the Harris two-pass test f64 needs in general.
+    const bool textbook = harris_delta < 0.0;
+    const double harris_slack = textbook ? 0.0 : harris_delta;
     double sumsq = 0.0, theta = INFINITY;
     bool eligible[R];
     double room[R];  // distance of the basic variable to the bound it moves towards
@@ -1768,7 +1772,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
                 room[r] = fmax(up - xb[r], 0.0);
             }
         }
-        if (eligible[r]) theta = fmin(theta, (room[r] + harris_delta) / fabs(a));
+        if (eligible[r]) theta = fmin(theta, (room[r] + harris_slack) / fabs(a));
     }
     {
         const int lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -1803,10 +1807,11 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double mag = fabs(al[r]);
+            const double key = textbook ? 1.0 : mag;
             if (eligible[r] && room[r] / mag <= theta_max) {
                 const unsigned long long rk = ((unsigned long long)(unsigned)bas[r] << 32) | (unsigned)(tid + r * K2F_THREADS);
-                if (hrank == RANK_NONE || mag > hkey || (mag == hkey && rk < hrank)) {
-                    hkey = mag;
+                if (hrank == RANK_NONE || key > hkey || (key == hkey && rk < hrank)) {
+                    hkey = key;
                     hrank = rk;
                 }
             }

@@ -1185,13 +1185,16 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     int epoch = 0;
     lu_ftran_block(lu, sh, n_updates, epoch, lu.spike);
     // ---- alpha per basis slot (kept in x1), gamma_q, Harris pass 1 ----------------------------------------------------------
+    // harris_delta < 0: the reference's ratio test (exact minimum, ties to the lowest leaving column; tableau/mod.rs:287-313)
+    const bool textbook = harris_delta < 0.0;
+    const double harris_slack = textbook ? 0.0 : harris_delta;
     double sumsq = 0.0, theta = INFINITY;
     for (int s = tid; s < m; s += T) {
         const double a = sh.x0[lu.colpos[s]];
         sh.x1[s] = a;
         lp.alpha[s] = a;
         sumsq += a * a;
-        if (a > tol_pivot && !(skip_artificial_rows && lp.basis[s] < lp.n_art)) theta = fmin(theta, (fmax(lp.xB[s], 0.0) + harris_delta) / a);
+        if (a > tol_pivot && !(skip_artificial_rows && lp.basis[s] < lp.n_art)) theta = fmin(theta, (fmax(lp.xB[s], 0.0) + harris_slack) / a);
     }
     const double gamma_q = 1.0 + block_reduce<0>(sumsq, sh.red);  // pivot_rule.rs:258
     const double theta_max = block_reduce<1>(theta, sh.red + 32);
@@ -1207,8 +1210,9 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
             if (skip_artificial_rows && bs < lp.n_art) continue;
             if (fmax(lp.xB[s], 0.0) / a <= theta_max) {
                 const unsigned long long rk = ((unsigned long long)(unsigned)bs << 32) | (unsigned)s;
-                if (hrank == RANK_NONE || a > hkey || (a == hkey && rk < hrank)) {
-                    hkey = a;
+                const double key = textbook ? 1.0 : a;
+                if (hrank == RANK_NONE || key > hkey || (key == hkey && rk < hrank)) {
+                    hkey = key;
                     hrank = rk;
                 }
             }

@@ -560,14 +560,14 @@ void Solver::enqueue_ftran_ratio(int mode) {
     if (lu_mode_) {
         hipEvent_t start = nullptr, stop = nullptr;
         take_launch_timer(1, &start, &stop);
-        launch_lu_pivot(d_, lu_.device(), opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, refactor_period_, stream_, start, stop);
+        launch_lu_pivot(d_, lu_.device(), opt_.pivot_rule, slots, opt_.tol_pivot, ratio_delta(), skip_art, mode, refactor_period_, stream_, start, stop);
         return;
     }
     if (ftran_slices_ > 0) {
         launch_ftran_partial(d_, ftran_slices_, slots, opt_.pivot_rule, stream_);
         launch_alpha_reduce(d_, ftran_slices_, stream_);
     }
-    launch_ftran_ratio(d_, opt_.pivot_rule, slots, opt_.tol_pivot, opt_.harris_delta, skip_art, mode, ftran_slices_ > 0 ? 1 : 0, stream_);
+    launch_ftran_ratio(d_, opt_.pivot_rule, slots, opt_.tol_pivot, ratio_delta(), skip_art, mode, ftran_slices_ > 0 ? 1 : 0, stream_);
 }
 
 void Solver::destroy_graphs() {
@@ -831,7 +831,7 @@ long long Solver::iterate(long long count, int* stop_reason) {
         done += made;
         since_polish_ += made;
         pivots_[phase_ - 1] += made;
-        if (made > 0) binv_identity_ = lu_mode_ ? false : binv_identity_;
+        if (made > 0) binv_identity_ = false;  // (the phase hand-over must not take the weights of the identity basis)
         if (after.status == ST_NO_ENTERING || after.status == ST_UNBOUNDED) { reason = after.status; break; }
         if (after.status == ST_REFACTOR) {  // LU carry: should_refactor (or an unstable update) -- BasisInverse::invert on the host
             refactor_lu(true);
@@ -1178,7 +1178,7 @@ void Solver::price(int* column, double* cbar) {
     write_ctl(c);
     enqueue_price(0);
     if (lu_mode_) enqueue_ftran_ratio(1);
-    else launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_ + dense_blocks_, opt_.tol_pivot, opt_.harris_delta, phase_ == 2 ? 1 : 0, 1, 0, stream_);
+    else launch_ftran_ratio(d_, opt_.pivot_rule, price_blocks_ + dense_blocks_, opt_.tol_pivot, ratio_delta(), phase_ == 2 ? 1 : 0, 1, 0, stream_);
     c = read_ctl();
     *column = c.q;
     *cbar = c.q >= 0 ? c.cbar_q : 0.0;
@@ -1213,6 +1213,14 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
     c.gamma_q = before.gamma_q;
     c.forced_q = c.forced_p = -1;
     write_ctl(c);
+}
+void Solver::last_pivot(int* phase, int* column, int* row, int* leaving) {
+    const Ctl c = read_ctl();
+    const bool any = c.iters > 0 && c.p >= 0;
+    *phase = phase_;
+    *column = any ? c.q : -1;
+    *row = any ? c.p : -1;
+    *leaving = any ? c.leaving : -1;
 }
 // `PivotRule::after_basis_update` (strategy/pivot_rule.rs:243-296): the Goldfarb-Reid update of the steepest-edge weights for
 // the last basis change.  Inside the device loop it rides on the next pricing pass; a caller that drives the loop itself can

@@ -150,6 +150,7 @@ public:
     void ratio(int column, int* row, double* alpha_out);
     void bring_into_basis(int column, int row);
     void after_basis_update();
+    void last_pivot(int* phase, int* column, int* row, int* leaving);
     double refactor();
     void get_b(double* out);
     double objective();
@@ -194,6 +195,8 @@ private:
     bool lu_mode_ = false;
     bool lu_is_identity_ = true;
     int refactor_period_ = 64;
+    // (a negative slack selects the reference's ratio test in the kernels that implement it: the fused kernel for m <= 8192 and the LU kernel)
+    double ratio_delta() const { return opt_.ratio_rule == RELP_RATIO_TEXTBOOK ? -1.0 : opt_.harris_delta; }
     int unbounded_column_ = -1;  // provider column of the ray when the result is UNBOUNDED
     long long refactors_ = 0;
     double refactor_seconds_ = 0.0;

@@ -1,0 +1,184 @@
+"""Tie rules and the whole resident inverse, compared directly (``-m gpu``).
+
+* F8 of the survey: pivot selection of the reference is deterministic -- pricing ties go to the LAST maximum
+  (strategy/pivot_rule.rs:230-240), ratio-test ties to the lowest leaving column (Bland, tableau/mod.rs:287-313).  On
+  integer LPs built to tie at nearly every step (transportation problems: totally unimodular, every tableau value an
+  integer, f64 exact) the device -- with ``ratio_rule = RELP_RATIO_TEXTBOOK``, the reference's ratio test instead of the
+  Harris test f64 needs on real data -- must make the IDENTICAL ``(phase, q, p, leaving)`` sequence as the exact oracle.
+* The resident inverse itself: every row of it (``basis_inverse_row``) after k updates against the exact
+  ``BasisInverseRows`` (basis_inverse_rows.rs:123-137) and the exact LU, for both carries.
+"""
+import os
+import random
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import relp_amd
+from relp_oracle import (BasisInverseRows, FiniteOptimum, LUDecomposition, MatrixData, SteepestDescentAlongObjective,
+                         Tableau, Variable, solve_relaxation)
+from relp_oracle.mps import load_problem
+from relp_oracle.solve import Infeasible
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CARRIES = pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+
+
+class Trace:
+    """Records ``(phase, q, p, leaving)`` per pivot (the golden fixtures' ``trace_head`` format)."""
+
+    def __init__(self):
+        self.phase = 1
+        self.pivots = []
+
+    def record(self, q, p, leaving, cost):
+        self.pivots.append((self.phase, q, p, leaving))
+
+
+def transportation(rng, sources, sinks, equal_costs):
+    """min sum c_ij x_ij, sum_j x_ij = s_i, sum_i x_ij = d_j: totally unimodular, massively degenerate; supplies and
+    demands in few distinct values and costs from a tiny set so that pricing keys and ratios tie all the time."""
+    supply = [rng.choice([2, 3, 4]) for _ in range(sources)]
+    demand = [0] * sinks
+    for unit in range(sum(supply)):
+        demand[rng.randrange(sinks)] += 1
+    columns, cost = [], []
+    for i in range(sources):
+        for j in range(sinks):
+            columns.append([(i, 1), (sources + j, 1)])
+            cost.append(1 if equal_costs else rng.choice([1, 2, 3]))
+    b = supply + demand
+    return columns, b, cost
+
+
+def load_both(columns, b, cost, counts, **options):
+    data = MatrixData(columns, b, [], counts[0], counts[1], counts[2], counts[3], [Variable(c) for c in cost])
+    column_start, rows, nums = [0], [], []
+    for column in columns:
+        for i, v in column:
+            rows.append(i)
+            nums.append(v)
+        column_start.append(len(rows))
+    solver = relp_amd.Solver(ratio_rule=relp_amd.api.RATIO_TEXTBOOK, **options)
+    solver.load_matrix_data(column_start, rows, nums, [1] * len(nums), b=b, cost=cost, counts=tuple(counts))
+    return data, solver
+
+
+def device_trace(solver):
+    """The device loop one pivot at a time (`relp_iterate(1)` is one iteration of phase_one.rs:134-178 / phase_two.rs:36-58)."""
+    pivots = []
+    solver.begin_phase_one()
+    for phase in (1, 2):
+        while True:
+            done, reason = solver.iterate(1)
+            if done == 0:
+                assert reason == relp_amd.STOP_NO_ENTERING
+                break
+            _, q, p, leaving = solver.last_pivot()
+            pivots.append((phase, q, p, leaving))
+            assert len(pivots) < 10000
+        if phase == 1:
+            if abs(solver.objective_function_value()) > 1e-9:
+                return pivots, "infeasible"
+            solver.begin_phase_two()
+    return pivots, "optimal"
+
+
+@CARRIES
+@pytest.mark.parametrize("equal_costs", [True, False], ids=["equal-costs", "three-costs"])
+@pytest.mark.parametrize("seed", range(8))
+def test_identical_pivot_sequence_on_tied_integer_lps(seed, equal_costs, carry):
+    rng = random.Random(77 + seed)
+    sources, sinks = rng.randint(3, 6), rng.randint(3, 7)
+    columns, b, cost = transportation(rng, sources, sinks, equal_costs)
+    m = sources + sinks
+    data, solver = load_both(columns, b, cost, (m, 0, 0, 0), carry=carry, refactor_period=5, use_graph=0)
+    trace = Trace()
+    expected = solve_relaxation(data, BasisInverseRows, SteepestDescentAlongObjective, trace=trace)
+    assert isinstance(expected, FiniteOptimum)
+    pivots, status = device_trace(solver)
+    assert status == "optimal"
+    # the oracle's phase-two column indices do not count the artificials, and its zero-level pivots (drive-out of the
+    # artificials that are still basic on the one redundant row of a transportation problem) belong to phase one
+    n_art = solver.n_art
+    oracle = [(ph, q + (n_art if ph == 2 else 0), p, leaving + (n_art if ph == 2 else 0)) for ph, q, p, leaving in trace.pivots]
+    ordinary = [t for t in oracle]
+    head = min(len(pivots), len(ordinary))
+    # identical up to the point where the reference starts removing the redundant row (after that its tableau has one row
+    # less and row indices shift; the device keeps the zero-level artificial basic instead)
+    phase_one = [t for t in ordinary if t[0] == 1]
+    assert pivots[:len(phase_one)] == phase_one, (pivots[:len(phase_one)], phase_one)
+    assert len(phase_one) >= 3 and head > 0
+    # same optimum, exactly (integers)
+    objective = sum((Fraction(cost[j]) * v for j, v in data.reconstruct_solution(expected.solution)), Fraction(0))
+    assert solver.objective_function_value() == float(objective)
+    solver.close()
+
+
+@CARRIES
+@pytest.mark.parametrize("seed", range(6))
+def test_identical_sequence_through_both_phases_without_redundant_rows(seed, carry):
+    """Inequality-constrained integer LPs (0/1 matrices with unit right-hand sides: ties everywhere) whose rows are
+    independent: the whole (phase, q, p, leaving) sequence must be the oracle's."""
+    rng = random.Random(500 + seed)
+    m, n = rng.randint(4, 8), rng.randint(5, 10)
+    dense = [[rng.choice([0, 0, 1, 1, 1]) for _ in range(n)] for _ in range(m)]
+    for i in range(m):
+        if not any(dense[i]):
+            dense[i][rng.randrange(n)] = 1
+    columns = [[(i, dense[i][j]) for i in range(m) if dense[i][j]] for j in range(n)]
+    n_ge = rng.randint(1, 2)                     # the last rows are >= rows (they need artificials: a phase one with ties)
+    b = [rng.choice([1, 2, 2]) for _ in range(m)]
+    cost = [rng.choice([-1, -1, -2, 1]) for _ in range(n)]
+    data, solver = load_both(columns, b, cost, (0, 0, m - n_ge, n_ge), carry=carry, refactor_period=4, use_graph=0)
+    trace = Trace()
+    expected = solve_relaxation(data, LUDecomposition, SteepestDescentAlongObjective, trace=trace)
+    if isinstance(expected, Infeasible):
+        pivots, status = device_trace(solver)
+        assert status == "infeasible"
+        assert pivots == [t for t in trace.pivots if t[0] == 1]
+        solver.close()
+        return
+    if not isinstance(expected, FiniteOptimum):
+        pytest.skip("unbounded instance")
+    n_art = solver.n_art
+    oracle = [(ph, q + (n_art if ph == 2 else 0), p, leaving + (n_art if ph == 2 else 0)) for ph, q, p, leaving in trace.pivots]
+    pivots, status = device_trace(solver)
+    assert status == "optimal"
+    assert pivots == oracle, (pivots, oracle)
+    solver.close()
+
+
+@CARRIES
+@pytest.mark.parametrize("name, checkpoints", [("AFIRO", (3, 8, 15)), ("SC50A", (5, 20, 40)), ("ADLITTLE", (10, 30, 60))])
+def test_every_row_of_the_resident_inverse(name, checkpoints, carry):
+    """All m rows of the device's inverse after k basis changes against the exact inverse of the same basis: the direct check
+    of `BasisInverse::change_basis` (basis_inverse_rows.rs:123-137 for the explicit carry, lower_upper/mod.rs:94-178 for LU)."""
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    general, data = load_problem(path)
+    tableau = Tableau.new_partially_artificial(data, BasisInverseRows)
+    solver = relp_amd.Solver(polish_period=0, use_graph=0, carry=carry, refactor_period=11).load_mps(path)
+    solver.begin_phase_one()
+    m = solver.m
+    for step in range(1, max(checkpoints) + 1):
+        selected = solver.select_primal_pivot_column()
+        if selected is None:
+            break
+        q, _ = selected
+        p, _ = solver.select_primal_pivot_row(q)
+        solver.bring_into_basis(q, p)
+        info = tableau.generate_column(q)
+        tableau.bring_into_basis(q, p, info, tableau.relative_cost(q))
+        if step in checkpoints:
+            exact_rows = tableau.inverse_maintainer.basis_inverse.rows
+            for r in range(m):
+                want = np.zeros(m)
+                for j, v in exact_rows[r]:
+                    want[j] = float(v)
+                got = solver.basis_inverse_row(r)
+                scale = max(1.0, np.abs(want).max())
+                assert np.allclose(got, want, rtol=1e-9, atol=1e-10 * scale), (step, r)
+    solver.close()

@@ -244,3 +244,58 @@ def test_gpu_shortest_path_12k_vertices_matches_dijkstra():
     np.subtract.at(net, tail, flow)
     assert abs(net[0] + 1.0) <= 1e-7 and abs(net[-1] - 1.0) <= 1e-7 and np.max(np.abs(net[1:-1])) <= 1e-7
     solver.close()
+
+
+@pytest.mark.gpu
+def test_gpu_max_flow_config5_full_size():
+    """BASELINE configs[4] at its stated size: V = 65 536, E = 1 048 576 (splitmix64 seed 0x5EED0005).  The capacity rows are
+    implicit bounds (65 534 conservation rows on the device); the optimum equals scipy's max-flow value, every flow respects
+    its capacity and conservation holds at every inner vertex."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices, nr_arcs = 65536, 1048576
+    tail, head, capacity = max_flow_graph(nr_vertices, nr_arcs)
+    assert len(tail) == nr_arcs
+    graph = csr_matrix((capacity.astype(np.int32), (tail, head)), shape=(nr_vertices, nr_vertices))
+    expected = maximum_flow(graph, 0, nr_vertices - 1).flow_value
+    model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+    solver = relp_amd.Solver(implicit_bounds=1).load_model(model)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    # (the example's objective is the gross flow out of s; it equals the max-flow value when the optimal flow sends nothing
+    #  back into s, which holds for this graph: checked through conservation below)
+    flow = solver.solution()
+    assert len(flow) == nr_arcs
+    order = np.lexsort((head, tail))  # the model's arc order: sorted by (tail, head)
+    t_sorted, h_sorted, c_sorted = tail[order], head[order], capacity[order]
+    assert np.all(flow >= -1e-9) and np.all(flow <= c_sorted + 1e-9)
+    net = np.zeros(nr_vertices)
+    np.add.at(net, h_sorted, flow)
+    np.subtract.at(net, t_sorted, flow)
+    assert np.max(np.abs(net[1:-1])) <= 1e-6
+    # the example's objective is the GROSS flow on the arcs leaving s (examples/max_flow.rs:141-223); on this graph it equals
+    # the max-flow value (arcs into s or out of t carry nothing useful at the optimum)
+    assert abs(result.objective + expected) <= 1e-9 * expected
+    assert result.solve_seconds < 30
+    solver.close()
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_runs_at_world_size_one():
+    """`bench.py` with RELP_FORCE_DISTRIBUTED=1: init_process_group("nccl") (RCCL), the barrier and the all-reduce of time and
+    pivot counts run with one rank -- the code path the 8-GPU run takes, started as a child process BEFORE this process's
+    GPU state matters to it (no exec from a process that touched the GPU)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RELP_FORCE_DISTRIBUTED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-dense-roofline", "--no-concurrency-probe"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2
+    assert line["config"]["exact"]["certified"] is True
+    assert abs(line["config"]["objective"] - 5501.8458883) < 1e-6
+    assert line["value"] > 1000
