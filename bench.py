@@ -192,6 +192,8 @@ def netlib_batch(args, rank, local_rank, world, distributed):
     import threading
     handle_locks = {name: threading.Lock() for name in solvers}  # a handle is single-threaded
     records = []
+    lp_records = []   # one JSON object per solved LP (--records FILE)
+    record_file = args.records
     passes = [0]
     # Order of the K x 45 tickets.  1-2 GPUs: pass after pass, each longest-first.  4+ GPUs: the cost-sorted list in chunks of
     # eight LPs, all K passes of a chunk before the next chunk -- close to longest-first over everything (the long solves of
@@ -234,6 +236,8 @@ def netlib_batch(args, rank, local_rank, world, distributed):
                 name = ordered[position] if dynamic else mine[position]
                 with handle_locks[name]:
                     r = solvers[name].solve_relaxation()
+                    if record_file is not None:
+                        lp_records.append(solvers[name].record())
                 pivots += r.pivots_phase_one + r.pivots_phase_two
                 records.append((name, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds))
             totals.append(pivots)
@@ -276,6 +280,10 @@ def netlib_batch(args, rank, local_rank, world, distributed):
                 len(names), "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
                        "lps_in_flight_per_gpu": max(1, args.concurrency),
                        "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}})
+    if record_file is not None:
+        with open(record_file if world == 1 else "%s.rank%d" % (record_file, rank), "w") as handle:
+            for entry in lp_records:
+                handle.write(json.dumps(entry) + "\n")
     if distributed:
         torch.distributed.destroy_process_group()
     if rank == 0:
@@ -296,6 +304,7 @@ def main():
     parser.add_argument("--carry", type=int, default=0, choices=[0, 1], help="0 explicit inverse, 1 LU + Forrest-Tomlin (relp_options.carry)")
     parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
+    parser.add_argument("--records", default=None, help="netlib batch: write one JSON line per solved LP to this file")
     parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
     args = parser.parse_args()
 

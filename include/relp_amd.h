@@ -246,6 +246,11 @@ int32_t relp_get_solution(const relp_handle* handle, double* x_structural);
 int32_t relp_get_original_solution(const relp_handle* handle, int32_t capacity, double* x, int32_t* count);
 /* Exact optimal objective "num/den" incl. fixed cost (needs options.certify); returns needed length in *length. */
 int32_t relp_get_objective_exact(const relp_handle* handle, char* buffer, int32_t capacity, int32_t* length);
+/* One JSON object describing the last relp_solve_relaxation of this handle (the per-LP record of SURVEY.md section 5; the
+ * reference has no logging at all): name, m, n, nnz, result, pivots per phase, polishes / refactorisations, wall times,
+ * pivots/s, algorithmic bytes per pivot, objective (f64) and objective_exact ("num/den" when certified).  *length receives
+ * the full length; at most capacity - 1 bytes are written. */
+int32_t relp_get_record_json(const relp_handle* handle, char* buffer, int32_t capacity, int32_t* length);
 /* `InverseMaintainer::basis_column_index_for_row` for all rows (provider indices; -1-k for artificial k). */
 int32_t relp_get_basis(const relp_handle* handle, int32_t* basis);
 

@@ -58,7 +58,7 @@ SYMBOLS = [
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
     "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_mps_ex", "relp_get_original_solution", "relp_load_model", "relp_get_dimensions", "relp_get_column",
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
-    "relp_get_solution", "relp_get_objective_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
+    "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
     "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_get_last_pivot", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
     "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps",
@@ -427,6 +427,15 @@ class Solver:
         if count.value:
             self._check(lib().relp_get_original_solution(self._h, count.value, _ptr(out, C.c_double), C.byref(count)))
         return out
+
+    def record(self):
+        """The per-LP record of the last solve as a dict (``relp_get_record_json``)."""
+        import json
+        length = C.c_int32()
+        self._check(lib().relp_get_record_json(self._h, None, 0, C.byref(length)))
+        buf = C.create_string_buffer(length.value + 1)
+        self._check(lib().relp_get_record_json(self._h, buf, length.value + 1, C.byref(length)))
+        return json.loads(buf.value.decode())
 
     def objective_exact(self):
         length = C.c_int32()

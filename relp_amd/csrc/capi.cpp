@@ -626,6 +626,46 @@ int32_t relp_get_objective_exact(const relp_handle* h, char* buffer, int32_t cap
     return RELP_OK;
 }
 
+// One JSON object per solved LP (metrics / observability -- the reference has none): dimensions, pivots per
+// phase, refreshes of the inverse, wall times, pivots/s, algorithmic bytes moved by the loop, f64 and exact objective.
+int32_t relp_get_record_json(const relp_handle* h, char* buffer, int32_t capacity, int32_t* length) {
+    REQUIRE_LOADED(h);
+    const Solver& sv = *h->solver;
+    const relp_result& r = sv.last_result;
+    const DeviceLP& d = sv.device();
+    const relp_stats& st = sv.stats();
+    const MatrixData& md = sv.form().data;
+    long long nnz = 0;
+    for (int j = 0; j < md.nr_columns(); ++j) nnz += (long long)md.column(j).nnz();
+    const long long pivots = r.pivots_phase_one + r.pivots_phase_two;
+    static const char* kinds[] = {"none", "finite_optimum", "infeasible", "unbounded", "iteration_limit"};
+    std::ostringstream out;
+    out.precision(17);
+    out << "{\"name\": \"" << sv.form().name << "\", \"m\": " << md.nr_rows() << ", \"n\": " << md.nr_columns() << ", \"nnz\": " << nnz
+        << ", \"device_rows\": " << d.m << ", \"artificials\": " << d.n_art << ", \"result\": \"" << kinds[r.kind >= 0 && r.kind <= 4 ? r.kind : 0]
+        << "\", \"carry\": \"" << (h->options.carry == RELP_CARRY_LU ? "lu" : "explicit") << "\", \"pivots_phase_one\": " << r.pivots_phase_one
+        << ", \"pivots_phase_two\": " << r.pivots_phase_two << ", \"polishes\": " << r.polishes << ", \"refactors\": " << r.refactors
+        << ", \"solve_seconds\": " << r.solve_seconds << ", \"certify_seconds\": " << r.certify_seconds
+        << ", \"pivots_per_second\": " << (r.solve_seconds > 0 ? (double)pivots / r.solve_seconds : 0.0)
+        << ", \"pricing_bytes_per_pivot\": " << st.price_bytes << ", \"inverse_bytes_per_pivot_bound\": " << (h->options.carry == RELP_CARRY_LU ? 0 : st.update_bytes)
+        << ", \"kernel_launches\": " << st.launches << ", \"certified\": " << (r.certified ? "true" : "false")
+        << ", \"exact_repair_pivots\": " << r.exact_repair_pivots << ", \"objective\": ";
+    if (r.kind == RELP_RESULT_FINITE_OPTIMUM) out << r.objective;
+    else out << "null";
+    out << ", \"objective_exact\": ";
+    if (r.certified && !sv.exact_objective.empty()) out << "\"" << sv.exact_objective << "\"";
+    else out << "null";
+    out << "}";
+    const std::string text = out.str();
+    if (length) *length = (int32_t)text.size();
+    if (buffer && capacity > 0) {
+        const int32_t nbytes = std::min<int32_t>((int32_t)text.size(), capacity - 1);
+        std::memcpy(buffer, text.data(), nbytes);
+        buffer[nbytes] = 0;
+    }
+    return RELP_OK;
+}
+
 int32_t relp_get_basis(const relp_handle* h, int32_t* basis) {
     REQUIRE_LOADED(h);
     if (!basis) return RELP_ERR_ARGUMENT;

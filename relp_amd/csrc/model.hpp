@@ -164,6 +164,7 @@ struct StandardForm {
     std::vector<std::string> all_column_names;  // every variable of the file
     std::vector<int> active_to_original;        // index into all_column_names per remaining variable
     std::vector<std::pair<int, RemovedOriginal>> removed;  // (original index, how to recover its value)
+    bool presolve_dropped = false;  // the presolve was asked for but its result did not fit the 128-bit host model: loaded as in the file
 
     // Values of the file's variables from the values of the standardised columns (general_form/mod.rs:753-771, 840-934):
     // un-shift, un-flip, recombine free variables, then evaluate the variables the presolve removed.

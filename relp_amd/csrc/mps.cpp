@@ -355,37 +355,51 @@ StandardForm standardize_general_form(GeneralInput general, bool presolve_first)
             presolve(gp);
             if (gp.variables.empty() || gp.b.empty())
                 throw std::runtime_error("presolve: the problem was solved completely (no rows or columns remain)");
-            std::vector<GeneralVariable> kept;
-            std::vector<SparseColumn> kept_columns;
-            for (size_t j = 0; j < gp.variables.size(); ++j) {
-                GeneralVariable v = vars[gp.active_to_original[j]];  // cost, shift, flipped are untouched by the presolve
-                v.has_lower = gp.variables[j].has_lower;
-                v.has_upper = gp.variables[j].has_upper;
-                v.lower = v.has_lower ? gp.variables[j].lower.to_rat() : Rat(0);
-                v.upper = v.has_upper ? gp.variables[j].upper.to_rat() : Rat(0);
-                kept.push_back(v);
-                SparseColumn column;
-                for (size_t k = 0; k < gp.columns[j].nnz(); ++k) column.push(gp.columns[j].index[k], gp.columns[j].value[k].to_rat());
-                kept_columns.push_back(column);
-            }
-            vars.swap(kept);
-            columns.swap(kept_columns);
-            b.clear();
-            kind.clear();
-            range.assign(gp.b.size(), Rat(0));
-            for (size_t i = 0; i < gp.b.size(); ++i) {
-                b.push_back(gp.b[i].to_rat());
-                kind.push_back(gp.kinds[i].kind);
-                if (gp.kinds[i].kind == RANGE) range[i] = gp.kinds[i].range.to_rat();
-            }
-            fixed_cost = gp.fixed_cost.to_rat();
-            out.active_to_original = gp.active_to_original;
-            for (auto& [original, how] : gp.removed) {
-                RemovedOriginal r;
-                r.function_of_others = how.function_of_others;
-                r.constant = how.constant.to_rat();
-                for (auto& [k, c] : how.coefficients) r.coefficients.push_back({k, c.to_rat()});
-                out.removed.push_back({original, r});
+            // Back to the 128-bit rationals of the host model -- everything is converted BEFORE anything is committed: bound
+            // tightening can leave values beyond 128 bits (BORE3D, CYCLE, GREENBEB), and then the LP is loaded as the file
+            // states it (the presolve is an optional reduction; the optimum is the same) instead of failing with OVERFLOW.
+            try {
+                std::vector<GeneralVariable> kept;
+                std::vector<SparseColumn> kept_columns;
+                for (size_t j = 0; j < gp.variables.size(); ++j) {
+                    GeneralVariable v = vars[gp.active_to_original[j]];  // cost, shift, flipped are untouched by the presolve
+                    v.has_lower = gp.variables[j].has_lower;
+                    v.has_upper = gp.variables[j].has_upper;
+                    v.lower = v.has_lower ? gp.variables[j].lower.to_rat() : Rat(0);
+                    v.upper = v.has_upper ? gp.variables[j].upper.to_rat() : Rat(0);
+                    kept.push_back(v);
+                    SparseColumn column;
+                    for (size_t k = 0; k < gp.columns[j].nnz(); ++k) column.push(gp.columns[j].index[k], gp.columns[j].value[k].to_rat());
+                    kept_columns.push_back(column);
+                }
+                std::vector<Rat> new_b, new_range(gp.b.size(), Rat(0));
+                std::vector<RowKind> new_kind;
+                for (size_t i = 0; i < gp.b.size(); ++i) {
+                    new_b.push_back(gp.b[i].to_rat());
+                    new_kind.push_back(gp.kinds[i].kind);
+                    if (gp.kinds[i].kind == RANGE) new_range[i] = gp.kinds[i].range.to_rat();
+                }
+                const Rat new_fixed_cost = gp.fixed_cost.to_rat();
+                std::vector<std::pair<int, RemovedOriginal>> removed;
+                for (auto& [original, how] : gp.removed) {
+                    RemovedOriginal r;
+                    r.function_of_others = how.function_of_others;
+                    r.constant = how.constant.to_rat();
+                    for (auto& [k, c] : how.coefficients) r.coefficients.push_back({k, c.to_rat()});
+                    removed.push_back({original, r});
+                }
+                vars.swap(kept);
+                columns.swap(kept_columns);
+                b.swap(new_b);
+                kind.swap(new_kind);
+                range.swap(new_range);
+                fixed_cost = new_fixed_cost;
+                out.active_to_original = gp.active_to_original;
+                out.removed = std::move(removed);
+            } catch (const RatOverflow&) {
+                out.presolve_dropped = true;
+                out.active_to_original.clear();
+                for (int j = 0; j < n; ++j) out.active_to_original.push_back(j);
             }
         } else {
             for (int j = 0; j < n; ++j) out.active_to_original.push_back(j);
