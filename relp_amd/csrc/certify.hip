@@ -58,39 +58,44 @@ __device__ __forceinline__ u32 reduce64(u64 v, u32 p) {
 // Writes C (row-major: C[slot][j]) and its transpose CT.
 __global__ void __launch_bounds__(64) modular_inverse_kernel(int m, u32 p, const int* rowpos, const int* colpos, const int* l_start,
                                                               const int* l_col, const u32* l_val, const int* u_start, const int* u_col,
-                                                              const u32* u_val, const u32* dinv, u32* X, u32* C, u32* CT) {
+                                                              const u32* u_val, const u32* dinv, u32* X, u32* C, u32* CT, int in_lds) {
+    // in_lds: the work columns of this workgroup live in LDS (xs[position][column]: blockDim.x columns side by side) -- a solve
+    // is a chain of m dependent rows, and a row costs an LDS round trip there instead of two trips to L2 (measured: 5.7 ms -> 0.4 ms
+    // at m = 821).  Otherwise (m too large for even one column per workgroup) the global work matrix X is used.
+    extern __shared__ u32 xs[];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
+    const int width = in_lds ? (int)blockDim.x : m;
+    u32* x = in_lds ? xs + threadIdx.x : X + j;  // element i at x[i * width]
     const int start = rowpos[j];  // e_j in position space
-    for (int i = 0; i < m; ++i) X[(size_t)i * m + j] = i == start ? 1u : 0u;
+    for (int i = 0; i < m; ++i) x[(size_t)i * width] = i == start ? 1u : 0u;
+    const u64 two32 = (1ull << 32) % p;
     // L x = e (unit diagonal), rows ascending; rows before `start` stay zero
     for (int i = start + 1; i < m; ++i) {
         const int a = l_start[i], b = l_start[i + 1];
         if (a == b) continue;
-        u64 lo = X[(size_t)i * m + j], hi = 0;
+        u64 lo = x[(size_t)i * width], hi = 0;
         for (int e = a; e < b; ++e) {
-            const u64 prod = (u64)(p - l_val[e]) * X[(size_t)l_col[e] * m + j];  // -l x  (mod p)
+            const u64 prod = (u64)(p - l_val[e]) * x[(size_t)l_col[e] * width];  // -l x  (mod p)
             lo += prod & 0xffffffffu;
             hi += prod >> 32;
         }
-        const u64 two32 = (1ull << 32) % p;
-        X[(size_t)i * m + j] = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
+        x[(size_t)i * width] = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
     }
     // U x = y, rows descending
     for (int i = m - 1; i >= 0; --i) {
         const int a = u_start[i], b = u_start[i + 1];
-        u64 lo = X[(size_t)i * m + j], hi = 0;
+        u64 lo = x[(size_t)i * width], hi = 0;
         for (int e = a; e < b; ++e) {
-            const u64 prod = (u64)(p - u_val[e]) * X[(size_t)u_col[e] * m + j];
+            const u64 prod = (u64)(p - u_val[e]) * x[(size_t)u_col[e] * width];
             lo += prod & 0xffffffffu;
             hi += prod >> 32;
         }
-        const u64 two32 = (1ull << 32) % p;
         const u32 v = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
-        X[(size_t)i * m + j] = reduce64((u64)v * dinv[i], p);
+        x[(size_t)i * width] = reduce64((u64)v * dinv[i], p);
     }
     for (int s = 0; s < m; ++s) {
-        const u32 v = X[(size_t)colpos[s] * m + j];
+        const u32 v = x[(size_t)colpos[s] * width];
         C[(size_t)s * m + j] = v;
         CT[(size_t)j * m + s] = v;
     }
@@ -658,8 +663,20 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             if (nu) RELP_HIP(hipMemcpyAsync(d_uc, f.u_col.data(), nu * sizeof(int), hipMemcpyHostToDevice, stream));
             if (nu) RELP_HIP(hipMemcpyAsync(d_uv, f.u_val.data(), nu * sizeof(u32), hipMemcpyHostToDevice, stream));
             RELP_HIP(hipMemcpyAsync(d_dinv, dinv.data(), m * sizeof(u32), hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(modular_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, m, candidate, d_rowpos, d_colpos, d_ls, d_lc, d_lv,
-                               d_us, d_uc, d_uv, d_dinv, dX, dC, dCT);
+            {
+                // columns per workgroup: as many (a power of two, at most 32) as fit the LDS next to each other
+                int columns = 32;
+                while (columns > 1 && (size_t)columns * m * sizeof(u32) > 150 * 1024) columns /= 2;
+                const bool in_lds = (size_t)columns * m * sizeof(u32) <= 150 * 1024;
+                static bool configured = false;
+                if (!configured) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modular_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    configured = true;
+                }
+                if (!in_lds) columns = 64;
+                hipLaunchKernelGGL(modular_inverse_kernel, dim3((m + columns - 1) / columns), dim3(columns), in_lds ? (size_t)columns * m * sizeof(u32) : 0,
+                                   stream, m, candidate, d_rowpos, d_colpos, d_ls, d_lc, d_lv, d_us, d_uc, d_uv, d_dinv, dX, dC, dCT, in_lds ? 1 : 0);
+            }
             RELP_HIP(hipStreamSynchronize(stream));  // (the staging vectors above go out of scope)
             p = candidate;
             break;
