@@ -251,6 +251,28 @@ int32_t relp_get_objective_exact(const relp_handle* handle, char* buffer, int32_
  * pivots/s, algorithmic bytes per pivot, objective (f64) and objective_exact ("num/den" when certified).  *length receives
  * the full length; at most capacity - 1 bytes are written. */
 int32_t relp_get_record_json(const relp_handle* handle, char* buffer, int32_t capacity, int32_t* length);
+/* ---- the loop in exact fixed-width integer arithmetic on the device ------------------------------------------------------
+ * `solve_relaxation::<Carry<RationalBig, _>>` with the reference's arbitrary-precision rationals replaced by LIMBS x 64-bit
+ * integers over a common denominator (exact.hip; int128 = 2 limbs, int256 = 4, ... up to 32): the SAME pivot sequence as the
+ * reference (steepest edge with its tie rules, exact ratio test with Bland ties, zero-level pivots) for as long as the
+ * numbers fit.  The solve starts with `first_limbs` limbs and restarts with twice as many whenever a value may not fit
+ * (status 4 when `max_limbs` <= 32 is not enough).  For small LPs: one workgroup owns the whole solve.
+ *   trace: (phase, entering column, pivot row, leaving column) per pivot, in the index space of relp_price;
+ *   objective: the exact optimum "num/den" incl. fixed cost; basis: as relp_get_basis.
+ * status: 1 optimal | 2 infeasible | 3 unbounded | 4 overflow | 5 pivot limit | 6 redundant rows (the reference removes such
+ * rows and re-indexes, `RemoveRows`; this path does not). */
+typedef struct relp_exact_result {
+    int32_t status;
+    int32_t limbs;              /* limbs of the run that finished */
+    int64_t pivots_phase_one;
+    int64_t pivots_phase_two;
+    int32_t trace_entries;
+    int32_t objective_length;
+    int32_t limbs_tried[6];     /* every width that was tried, in order ... */
+    int64_t pivots_survived[6]; /* ... and the pivots it made before a value might not fit (or until it finished) */
+} relp_exact_result;
+int32_t relp_solve_exact(relp_handle* handle, int32_t first_limbs, int32_t max_limbs, int64_t max_pivots, relp_exact_result* result,
+                         int32_t trace_capacity, int32_t* trace, char* objective, int32_t objective_capacity, int32_t* basis);
 /* `InverseMaintainer::basis_column_index_for_row` for all rows (provider indices; -1-k for artificial k). */
 int32_t relp_get_basis(const relp_handle* handle, int32_t* basis);
 

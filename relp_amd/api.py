@@ -43,6 +43,12 @@ class Result(C.Structure):
                 ("max_residual", C.c_double), ("refactors", C.c_int64), ("refactor_seconds", C.c_double)]
 
 
+class ExactResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("limbs", C.c_int32), ("pivots_phase_one", C.c_int64), ("pivots_phase_two", C.c_int64),
+                ("trace_entries", C.c_int32), ("objective_length", C.c_int32), ("limbs_tried", C.c_int32 * 6),
+                ("pivots_survived", C.c_int64 * 6)]
+
+
 class Stats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("price_launches", C.c_int64), ("price_seconds", C.c_double),
                 ("update_seconds", C.c_double), ("ftran_seconds", C.c_double), ("price_bytes", C.c_int64),
@@ -58,7 +64,7 @@ SYMBOLS = [
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
     "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_mps_ex", "relp_get_original_solution", "relp_load_model", "relp_get_dimensions", "relp_get_column",
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
-    "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
+    "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_solve_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
     "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_get_last_pivot", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
     "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps",
@@ -427,6 +433,23 @@ class Solver:
         if count.value:
             self._check(lib().relp_get_original_solution(self._h, count.value, _ptr(out, C.c_double), C.byref(count)))
         return out
+
+    def solve_exact(self, first_limbs=2, max_limbs=32, max_pivots=0, trace_capacity=1 << 16):
+        """The loop in exact fixed-width integer arithmetic on the device (``relp_solve_exact``).  Returns a dict: ``status``
+        (1 optimal, 2 infeasible, 3 unbounded, 4 overflow, 5 pivot limit, 6 redundant rows), ``limbs``, pivots per phase,
+        ``trace`` = [(phase, q, p, leaving)], ``objective`` "num/den", ``basis`` and ``survived`` = [(limbs, pivots)] per width tried."""
+        result = ExactResult()
+        trace = np.zeros(4 * max(1, trace_capacity), dtype=np.int32)
+        objective = C.create_string_buffer(1 << 16)
+        basis = np.zeros(self.m, dtype=np.int32)
+        self._check(lib().relp_solve_exact(self._h, int(first_limbs), int(max_limbs), C.c_int64(int(max_pivots)), C.byref(result),
+                                           int(trace_capacity), _ptr(trace, C.c_int32), objective, len(objective), _ptr(basis, C.c_int32)))
+        entries = result.trace_entries
+        return {"status": result.status, "limbs": result.limbs, "pivots_phase_one": result.pivots_phase_one,
+                "pivots_phase_two": result.pivots_phase_two,
+                "trace": [tuple(int(v) for v in trace[4 * k:4 * k + 4]) for k in range(entries)],
+                "objective": objective.value.decode(), "basis": basis,
+                "survived": [(int(result.limbs_tried[k]), int(result.pivots_survived[k])) for k in range(6) if result.limbs_tried[k]]}
 
     def record(self):
         """The per-LP record of the last solve as a dict (``relp_get_record_json``)."""

@@ -666,6 +666,38 @@ int32_t relp_get_record_json(const relp_handle* h, char* buffer, int32_t capacit
     return RELP_OK;
 }
 
+int32_t relp_solve_exact(relp_handle* h, int32_t first_limbs, int32_t max_limbs, int64_t max_pivots, relp_exact_result* result,
+                         int32_t trace_capacity, int32_t* trace, char* objective, int32_t objective_capacity, int32_t* basis) {
+    REQUIRE_LOADED(h);
+    if (!result || first_limbs < 1 || max_limbs < first_limbs || max_limbs > 32 || trace_capacity < 0) return RELP_ERR_ARGUMENT;
+    return guarded(h, [&] {
+        std::memset(result, 0, sizeof(*result));
+        std::vector<int> tr, final_basis;
+        std::string text;
+        std::vector<std::pair<int, long long>> survived;
+        int status = 0, limbs = 0;
+        long long p1 = 0, p2 = 0;
+        h->solver->solve_exact(first_limbs, max_limbs, max_pivots, std::max(trace_capacity, 1), &status, &limbs, &p1, &p2, &tr, &text, &final_basis, &survived);
+        result->status = status;
+        result->limbs = limbs;
+        result->pivots_phase_one = p1;
+        result->pivots_phase_two = p2;
+        result->trace_entries = (int32_t)(tr.size() / 4);
+        for (size_t k = 0; k < survived.size() && k < 6; ++k) {
+            result->limbs_tried[k] = survived[k].first;
+            result->pivots_survived[k] = survived[k].second;
+        }
+        if (trace) std::memcpy(trace, tr.data(), std::min<size_t>(tr.size(), (size_t)4 * trace_capacity) * sizeof(int));
+        if (objective && objective_capacity > 0) {
+            const size_t nbytes = std::min<size_t>(text.size(), (size_t)objective_capacity - 1);
+            std::memcpy(objective, text.data(), nbytes);
+            objective[nbytes] = 0;
+        }
+        result->objective_length = (int32_t)text.size();
+        if (basis && !final_basis.empty()) std::memcpy(basis, final_basis.data(), final_basis.size() * sizeof(int));
+    });
+}
+
 int32_t relp_get_basis(const relp_handle* h, int32_t* basis) {
     REQUIRE_LOADED(h);
     if (!basis) return RELP_ERR_ARGUMENT;

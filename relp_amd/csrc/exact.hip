@@ -1,0 +1,831 @@
+// The revised simplex loop in EXACT fixed-width integer arithmetic on the device (BASELINE.json north_star: "fixed-width
+// int128/int256 rational arithmetic replaces arbitrary-precision on device").
+//
+// Every rational of the reference's `Carry<RationalBig, _>` at a basis B is held over ONE common denominator -- Edmonds'
+// integer-preserving pivoting: with the rows of the LP scaled to integers,
+//     N = D * B^-1,   D = |det B|,        (all entries of N are integers)
+//     alpha~_q = N a_q,  x~_B = N b,  c~_j = D c_j - c_B' N a_j,  gamma~_j = D^2 + |N a_j|^2       (numerators over D, D, D, D^2)
+// and a pivot on row p is   D' = alpha~_p,   N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (i != p),  N'_p = N_p,
+// where the division is EXACT.  Integers are LIMBS x 64-bit two's complement words, LIMBS in {2, 4, 8, 16, 32} (int128 and
+// int256 are the two smallest instantiations).  No gcd and no long division ever runs on the device: an exact quotient is one
+// truncated multiplication with the inverse of D modulo 2^(64 LIMBS) (Newton iteration, once per pivot).  Every result is
+// guarded by a floating-point magnitude bound; when a value might not fit, the solve stops with status OVERFLOW and the host
+// restarts it with twice the limbs.
+//
+// The decisions are the reference's own, exactly: steepest-edge pricing with the LAST maximum on ties
+// (strategy/pivot_rule.rs:221-241), the minimum ratio with Bland's rule on ties (tableau/mod.rs:287-313), zero-level pivots
+// (phase_one.rs:232-278).  Candidates are ranked with double-precision estimates of the exact quantities and every near-tie is
+// decided by exact cross-multiplication, so the pivot sequence is the oracle's (tests/test_gpu_exact.py: whole golden traces).
+// One workgroup owns one LP (these are the small LPs; the whole solve is one kernel, no host round trip per pivot).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bigint.hpp"
+#include "solver.hpp"
+#include "wave_ops.hpp"
+
+namespace relp {
+
+namespace {
+
+using u64 = unsigned long long;
+using i64 = long long;
+using u128 = unsigned __int128;
+
+constexpr int EX_THREADS = 256;
+enum : int { EX_RUNNING = 0, EX_OPTIMAL = 1, EX_INFEASIBLE = 2, EX_UNBOUNDED = 3, EX_OVERFLOW = 4, EX_PIVOT_LIMIT = 5, EX_REDUNDANT_ROWS = 6 };
+
+// ---------------------------------------------------------------------------------------------------
+// LIMBS x 64-bit two's complement integers
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+struct Big {
+    u64 w[L];
+};
+
+template <int L>
+__device__ __forceinline__ Big<L> big_from(i64 v) {
+    Big<L> r;
+    r.w[0] = (u64)v;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 1; k < L; ++k) r.w[k] = v < 0 ? ~0ull : 0ull;
+    return r;
+}
+template <int L>
+__device__ __forceinline__ bool big_neg(const Big<L>& a) { return (i64)a.w[L - 1] < 0; }
+template <int L>
+__device__ __forceinline__ bool big_zero(const Big<L>& a) {
+    u64 acc = 0;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) acc |= a.w[k];
+    return acc == 0;
+}
+template <int L>
+__device__ __forceinline__ Big<L> big_add(const Big<L>& a, const Big<L>& b) {
+    Big<L> r;
+    u64 carry = 0;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) {
+        const u128 s = (u128)a.w[k] + b.w[k] + carry;
+        r.w[k] = (u64)s;
+        carry = (u64)(s >> 64);
+    }
+    return r;
+}
+template <int L>
+__device__ __forceinline__ Big<L> big_negate(const Big<L>& a) {
+    Big<L> r;
+    u64 carry = 1;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) {
+        const u128 s = (u128)(~a.w[k]) + carry;
+        r.w[k] = (u64)s;
+        carry = (u64)(s >> 64);
+    }
+    return r;
+}
+template <int L>
+__device__ __forceinline__ Big<L> big_sub(const Big<L>& a, const Big<L>& b) { return big_add(a, big_negate(b)); }
+// a * b mod 2^(64 L), b a signed 64-bit value
+template <int L>
+__device__ __forceinline__ Big<L> big_mul_small(const Big<L>& a, i64 b) {
+    const u64 mag = b < 0 ? (u64)(-(b + 1)) + 1 : (u64)b;
+    Big<L> r;
+    u64 carry = 0;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) {
+        const u128 t = (u128)a.w[k] * mag + carry;
+        r.w[k] = (u64)t;
+        carry = (u64)(t >> 64);
+    }
+    return b < 0 ? big_negate(r) : r;
+}
+// a * b mod 2^(64 L)  (the low half of the product: exact whenever the true product fits)
+template <int L>
+__device__ __forceinline__ Big<L> big_mul_lo(const Big<L>& a, const Big<L>& b) {
+    Big<L> r;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) r.w[k] = 0;
+#pragma unroll L <= 8 ? L : 1
+    for (int i = 0; i < L; ++i) {
+        u64 carry = 0;
+#pragma unroll L <= 8 ? L : 1
+        for (int j = 0; j < L - i; ++j) {
+            const u128 t = (u128)a.w[i] * b.w[j] + r.w[i + j] + carry;
+            r.w[i + j] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+    }
+    return r;
+}
+template <int L>
+__device__ __forceinline__ double big_to_double(const Big<L>& a) {
+    const bool neg = big_neg(a);
+    const Big<L> m = neg ? big_negate(a) : a;
+    int top = -1;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k)
+        if (m.w[k] != 0) top = k;
+    if (top < 0) return 0.0;
+    double v = (double)m.w[top];
+    if (top > 0) v = v * 18446744073709551616.0 + (double)m.w[top - 1];
+    v = ldexp(v, 64 * (top > 0 ? top - 1 : 0));
+    return neg ? -v : v;
+}
+template <int L>
+__device__ __forceinline__ int big_ctz(const Big<L>& a) {  // a != 0
+    int bits = 0;
+    bool done = false;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) {
+        if (!done) {
+            if (a.w[k] == 0) bits += 64;
+            else { bits += __ffsll((long long)a.w[k]) - 1; done = true; }
+        }
+    }
+    return bits;
+}
+template <int L>
+__device__ __forceinline__ Big<L> big_sar(const Big<L>& a, int bits) {  // arithmetic shift right
+    const int words = bits >> 6, rem = bits & 63;
+    const u64 fill = big_neg(a) ? ~0ull : 0ull;
+    Big<L> r;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) {
+        const int lo = k + words, hi = k + words + 1;
+        const u64 wl = lo < L ? a.w[lo < L ? lo : 0] : fill;
+        const u64 wh = hi < L ? a.w[hi < L ? hi : 0] : fill;
+        r.w[k] = rem ? (wl >> rem) | (wh << (64 - rem)) : wl;
+    }
+    return r;
+}
+template <int L>
+__device__ __forceinline__ Big<L> big_shl(const Big<L>& a, int bits) {
+    const int words = bits >> 6, rem = bits & 63;
+    Big<L> r;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) {
+        const int lo = k - words, lower = k - words - 1;
+        const u64 wl = lo >= 0 ? a.w[lo >= 0 ? lo : 0] : 0ull;
+        const u64 wp = lower >= 0 ? a.w[lower >= 0 ? lower : 0] : 0ull;
+        r.w[k] = rem ? (wl << rem) | (wp >> (64 - rem)) : wl;
+    }
+    return r;
+}
+// inverse of an ODD value modulo 2^(64 L): Newton  x <- x (2 - d x), the number of correct bits doubles per step
+template <int L>
+__device__ __forceinline__ Big<L> big_inverse_odd(const Big<L>& d) {
+    Big<L> x = d;  // d * d = 1 (mod 8): three correct bits
+    const Big<L> two = big_from<L>(2);
+    for (int correct = 3; correct < 64 * L; correct *= 2) x = big_mul_lo(x, big_sub(two, big_mul_lo(d, x)));
+    return x;
+}
+template <int L>
+__device__ __forceinline__ Big<L> big_load(const u64* p) {
+    Big<L> r;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) r.w[k] = p[k];
+    return r;
+}
+template <int L>
+__device__ __forceinline__ void big_store(u64* p, const Big<L>& a) {
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) p[k] = a.w[k];
+}
+// sign of a * b - c * d, exactly (2 L limbs): the tie breaker of the ratio test and of the pricing rule
+template <int L>
+__device__ int sign_of_difference(const Big<L>& a, const Big<L>& b, const Big<L>& c, const Big<L>& d) {
+    // magnitudes and signs apart: |a||b| and |c||d| as 2 L-limb unsigned numbers
+    auto product = [](const Big<L>& x, const Big<L>& y, u64* out, bool* negative) {
+        const bool nx = big_neg(x), ny = big_neg(y);
+        const Big<L> mx = nx ? big_negate(x) : x, my = ny ? big_negate(y) : y;
+        for (int k = 0; k < 2 * L; ++k) out[k] = 0;
+        for (int i = 0; i < L; ++i) {
+            u64 carry = 0;
+            for (int j = 0; j < L; ++j) {
+                const u128 t = (u128)mx.w[i] * my.w[j] + out[i + j] + carry;
+                out[i + j] = (u64)t;
+                carry = (u64)(t >> 64);
+            }
+            out[i + L] += carry;
+        }
+        bool zero = true;
+        for (int k = 0; k < 2 * L; ++k) zero = zero && out[k] == 0;
+        *negative = !zero && (nx != ny);
+        return zero;
+    };
+    u64 p1[2 * L], p2[2 * L];
+    bool n1 = false, n2 = false;
+    const bool z1 = product(a, b, p1, &n1), z2 = product(c, d, p2, &n2);
+    const int s1 = z1 ? 0 : (n1 ? -1 : 1), s2 = z2 ? 0 : (n2 ? -1 : 1);
+    if (s1 != s2) return s1 > s2 ? 1 : -1;
+    if (s1 == 0) return 0;
+    int cmp = 0;
+    for (int k = 2 * L - 1; k >= 0 && cmp == 0; --k)
+        if (p1[k] != p2[k]) cmp = p1[k] > p2[k] ? 1 : -1;
+    return s1 > 0 ? cmp : -cmp;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the LP on the device: integer columns (rows scaled), [artificials | provider columns] as in solver.hip
+// ---------------------------------------------------------------------------------------------------
+struct ExactLP {
+    int m, n, n_art, limbs;
+    const int* col_start;
+    const int* row_index;
+    const i64* value;
+    const i64* cost2;     // phase-two costs (scaled to integers); phase one: 1 on the artificial columns
+    const i64* rhs;       // scaled right-hand side
+    int* basis;           // [m]
+    int* pos;             // [n]
+    u64* N;               // [m][m] Big
+    u64* D;               // Big (followed by its odd part's inverse, and the scratch of the tie breakers)
+    u64* xt;              // [m] Big: x~_B
+    u64* alpha;           // [m] Big: alpha~_q
+    u64* ctil;            // [n] Big: c~_j
+    double* key;          // [n] estimate of c~_j^2 / gamma~_j (0: not a candidate)
+    int* trace;           // [4 * trace_capacity]: phase, q, p, leaving
+    int trace_capacity;
+    long long max_pivots;
+    int* out;             // [8]: status, pivots phase one, pivots phase two, limbs, trace entries, redundant rows
+};
+
+// Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
+// (2 L + 1)-limb numbers in scratch memory (one thread; rare).
+template <int L>
+__device__ void exact_weight(const ExactLP& lp, const Big<L>& D, int j, u64* gamma /* 2L+1 */) {
+    for (int k = 0; k < 2 * L + 1; ++k) gamma[k] = 0;
+    auto add_square = [&](const Big<L>& v) {
+        const Big<L> mag = big_neg(v) ? big_negate(v) : v;
+        u64 sq[2 * L];
+        for (int k = 0; k < 2 * L; ++k) sq[k] = 0;
+        for (int i = 0; i < L; ++i) {
+            u64 carry = 0;
+            for (int t = 0; t < L; ++t) {
+                const u128 prod = (u128)mag.w[i] * mag.w[t] + sq[i + t] + carry;
+                sq[i + t] = (u64)prod;
+                carry = (u64)(prod >> 64);
+            }
+            sq[i + L] += carry;
+        }
+        u64 carry = 0;
+        for (int k = 0; k < 2 * L; ++k) {
+            const u128 s = (u128)gamma[k] + sq[k] + carry;
+            gamma[k] = (u64)s;
+            carry = (u64)(s >> 64);
+        }
+        gamma[2 * L] += carry;
+    };
+    add_square(D);
+    for (int i = 0; i < lp.m; ++i) {
+        Big<L> a = big_from<L>(0);
+        for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
+            a = big_add(a, big_mul_small(big_load<L>(lp.N + ((size_t)i * lp.m + lp.row_index[e]) * L), lp.value[e]));
+        add_square(a);
+    }
+}
+// c_a^2 * gamma_b  vs  c_b^2 * gamma_a  (unsigned, (4 L + 1) limbs): +1 when column a has the larger key
+template <int L>
+__device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& cb, const u64* gamma_b) {
+    auto square = [](const Big<L>& v, u64* sq) {
+        const Big<L> mag = big_neg(v) ? big_negate(v) : v;
+        for (int k = 0; k < 2 * L; ++k) sq[k] = 0;
+        for (int i = 0; i < L; ++i) {
+            u64 carry = 0;
+            for (int t = 0; t < L; ++t) {
+                const u128 prod = (u128)mag.w[i] * mag.w[t] + sq[i + t] + carry;
+                sq[i + t] = (u64)prod;
+                carry = (u64)(prod >> 64);
+            }
+            sq[i + L] += carry;
+        }
+    };
+    u64 sa[2 * L], sb[2 * L], left[4 * L + 1], right[4 * L + 1];
+    square(ca, sa);
+    square(cb, sb);
+    auto multiply = [](const u64* x, const u64* g, u64* out) {  // x: 2L limbs, g: 2L + 1 limbs
+        for (int k = 0; k < 4 * L + 1; ++k) out[k] = 0;
+        for (int i = 0; i < 2 * L; ++i) {
+            u64 carry = 0;
+            for (int t = 0; t < 2 * L + 1; ++t) {
+                const u128 prod = (u128)x[i] * g[t] + out[i + t] + carry;
+                out[i + t] = (u64)prod;
+                carry = (u64)(prod >> 64);
+            }
+            if (i + 2 * L + 1 < 4 * L + 1) out[i + 2 * L + 1] += carry;
+        }
+    };
+    multiply(sa, gamma_b, left);
+    multiply(sb, gamma_a, right);
+    for (int k = 4 * L; k >= 0; --k)
+        if (left[k] != right[k]) return left[k] > right[k] ? 1 : -1;
+    return 0;
+}
+
+template <int L>
+__global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
+    __shared__ double s_key[EX_THREADS / WAVE];
+    __shared__ unsigned long long s_rank[EX_THREADS / WAVE];
+    __shared__ int s_int[8];
+    __shared__ int s_overflow;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int m = lp.m, n = lp.n;
+    const double LIMIT = ldexp(1.0, 64 * L - 3);  // magnitudes at or above this might not fit
+    u64* gD = lp.D;
+    u64* gDinv = lp.D + L;
+    u64* scratch = lp.D + 2 * L;  // tie breakers (one thread): 2 x (2L + 1) limbs
+    int phase = lp.n_art > 0 ? 1 : 2;
+    long long pivots[2] = {0, 0};
+    int trace_count = 0;
+    int status = EX_RUNNING;
+    if (tid == 0) s_overflow = 0;
+    __syncthreads();
+    auto flag_overflow = [&](double magnitude) {
+        if (!(magnitude < LIMIT)) s_overflow = 1;
+    };
+    // drive_row >= 0: the zero-level pivots of phase_one.rs:232-278 are under way, this is the next row to look at
+    int drive_row = -1;
+    while (status == EX_RUNNING) {
+        if (pivots[0] + pivots[1] >= lp.max_pivots) { status = EX_PIVOT_LIMIT; break; }
+        const Big<L> D = big_load<L>(gD);
+        const double Dd = big_to_double(D);
+        // ---- x~_B = N b -------------------------------------------------------------------------------------------------
+        for (int i = tid; i < m; i += T) {
+            Big<L> acc = big_from<L>(0);
+            double mag = 0.0;
+            for (int k = 0; k < m; ++k) {
+                const i64 b = lp.rhs[k];
+                if (b == 0) continue;
+                const Big<L> nik = big_load<L>(lp.N + ((size_t)i * m + k) * L);
+                acc = big_add(acc, big_mul_small(nik, b));
+                mag += fabs(big_to_double(nik)) * fabs((double)b);
+            }
+            flag_overflow(mag);
+            big_store(lp.xt + (size_t)i * L, acc);
+        }
+        __syncthreads();
+        int q = -1, p = -1;
+        if (drive_row < 0) {
+            // ---- pricing: c~_j and the key estimate for every non-basic, non-artificial column (pivot_rule.rs:221-241) --------
+            for (int j = lp.n_art + tid; j < n; j += T) {
+                double key = 0.0;
+                if (lp.pos[j] < 0) {
+                    const i64 cj = phase == 1 ? 0 : lp.cost2[j];
+                    Big<L> ct = big_mul_small(D, cj);
+                    double sumsq = Dd * Dd, mag = fabs(Dd) * fabs((double)cj);
+                    for (int i = 0; i < m; ++i) {
+                        Big<L> a = big_from<L>(0);
+                        double amag = 0.0;
+                        for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e) {
+                            const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
+                            a = big_add(a, big_mul_small(nir, lp.value[e]));
+                            amag += fabs(big_to_double(nir)) * fabs((double)lp.value[e]);
+                        }
+                        flag_overflow(amag);
+                        const int bi = lp.basis[i];
+                        const i64 cb = phase == 1 ? (bi < lp.n_art ? 1 : 0) : lp.cost2[bi];
+                        if (cb != 0) {
+                            ct = big_sub(ct, big_mul_small(a, cb));
+                            mag += amag * fabs((double)cb);
+                        }
+                        const double ad = big_to_double(a);
+                        sumsq += ad * ad;
+                    }
+                    flag_overflow(mag);
+                    big_store(lp.ctil + (size_t)j * L, ct);
+                    if (big_neg(ct)) {  // D > 0: the sign of c~_j is the sign of the relative cost
+                        const double cd = big_to_double(ct);
+                        key = cd * cd / sumsq;
+                    }
+                }
+                lp.key[j] = key;
+            }
+            __syncthreads();
+            // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
+            double best = 0.0;
+            unsigned long long rank = RANK_NONE;
+            for (int j = lp.n_art + tid; j < n; j += T) {
+                const double k = lp.key[j];
+                if (k > 0.0) {
+                    const unsigned long long r = (unsigned long long)(0x7fffffff - j);
+                    if (rank == RANK_NONE || k > best || (k == best && r < rank)) { best = k; rank = r; }
+                }
+            }
+            block_argbest(best, rank, s_key, s_rank);
+            if (rank != RANK_NONE) {
+                q = 0x7fffffff - (int)rank;
+                if (tid == 0) {
+                    // every column whose estimate is within 1e-9 of the best is compared exactly (c~^2 gamma~ cross products)
+                    u64* gq = scratch;
+                    u64* gj = scratch + 2 * L + 1;
+                    bool have_q = false;
+                    int winner = q;
+                    for (int j = lp.n_art; j < n; ++j) {
+                        if (j == q || !(lp.key[j] >= best * (1.0 - 1e-9))) continue;
+                        if (!have_q) {
+                            exact_weight<L>(lp, D, winner, gq);
+                            have_q = true;
+                        }
+                        exact_weight<L>(lp, D, j, gj);
+                        const int c = compare_keys<L>(big_load<L>(lp.ctil + (size_t)j * L), gj, big_load<L>(lp.ctil + (size_t)winner * L), gq);
+                        if (c > 0 || (c == 0 && j > winner)) {
+                            winner = j;
+                            for (int k = 0; k < 2 * L + 1; ++k) gq[k] = gj[k];
+                        }
+                    }
+                    s_int[0] = winner;
+                }
+                __syncthreads();
+                q = s_int[0];
+                __syncthreads();
+            }
+            if (q < 0) {  // no candidate: the end of this phase
+                if (phase == 2) { status = EX_OPTIMAL; break; }
+                // phase one is over: feasible iff the artificial variables sum to zero (phase_one.rs:160-176)
+                if (tid == 0) {
+                    int positive = 0, basic_artificials = 0;
+                    for (int i = 0; i < m; ++i)
+                        if (lp.basis[i] < lp.n_art) {
+                            ++basic_artificials;
+                            if (!big_zero(big_load<L>(lp.xt + (size_t)i * L))) positive = 1;
+                        }
+                    s_int[0] = positive;
+                    s_int[1] = basic_artificials;
+                }
+                __syncthreads();
+                const int positive = s_int[0], basic_artificials = s_int[1];
+                __syncthreads();
+                if (positive) { status = EX_INFEASIBLE; break; }
+                if (basic_artificials > 0) { drive_row = 0; continue; }
+                phase = 2;
+                continue;
+            }
+        } else {
+            // ---- zero-level pivots: the next row whose basic variable is artificial, the first non-basic column with a
+            //      non-zero entry in that row of the tableau (phase_one.rs:232-278) ----------------------------------------
+            if (tid == 0) {
+                int r = drive_row;
+                while (r < m && lp.basis[r] >= lp.n_art) ++r;
+                s_int[0] = r;
+            }
+            __syncthreads();
+            const int r = s_int[0];
+            __syncthreads();
+            if (r >= m) {
+                drive_row = -1;
+                phase = 2;
+                continue;
+            }
+            // (N a_j)_r for every candidate column; the first non-zero wins
+            unsigned long long first = RANK_NONE;
+            double dummy = 0.0;
+            for (int j = lp.n_art + tid; j < n; j += T) {
+                if (lp.pos[j] >= 0) continue;
+                Big<L> a = big_from<L>(0);
+                for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
+                    a = big_add(a, big_mul_small(big_load<L>(lp.N + ((size_t)r * m + lp.row_index[e]) * L), lp.value[e]));
+                if (!big_zero(a) && (first == RANK_NONE || (unsigned long long)j < first)) { first = (unsigned long long)j; dummy = 1.0; }
+            }
+            block_argbest(dummy, first, s_key, s_rank);
+            if (first == RANK_NONE) { status = EX_REDUNDANT_ROWS; break; }  // the reference removes such rows (RemoveRows): not here
+            q = (int)first;
+            p = r;
+            drive_row = r + 1;
+        }
+        // ---- alpha~_q = N a_q (tableau/mod.rs:126-130) -----------------------------------------------------------------------
+        for (int i = tid; i < m; i += T) {
+            Big<L> a = big_from<L>(0);
+            double amag = 0.0;
+            for (int e = lp.col_start[q]; e < lp.col_start[q + 1]; ++e) {
+                const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
+                a = big_add(a, big_mul_small(nir, lp.value[e]));
+                amag += fabs(big_to_double(nir)) * fabs((double)lp.value[e]);
+            }
+            flag_overflow(amag);
+            big_store(lp.alpha + (size_t)i * L, a);
+        }
+        __syncthreads();
+        if (p < 0) {
+            // ---- ratio test: min x~_i / alpha~_i over alpha~_i > 0, ties to the lowest basic column (tableau/mod.rs:287-313) --
+            double best = 0.0;
+            unsigned long long rank = RANK_NONE;
+            for (int i = tid; i < m; i += T) {
+                const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
+                if (big_neg(a) || big_zero(a)) continue;
+                const double ratio = big_to_double(big_load<L>(lp.xt + (size_t)i * L)) / big_to_double(a);
+                const unsigned long long r = ((unsigned long long)(unsigned)lp.basis[i] << 32) | (unsigned)i;
+                const double k = -ratio;  // block_argbest maximises
+                if (rank == RANK_NONE || k > best || (k == best && r < rank)) { best = k; rank = r; }
+            }
+            block_argbest(best, rank, s_key, s_rank);
+            if (rank == RANK_NONE) { status = EX_UNBOUNDED; break; }
+            p = (int)(rank & 0xffffffffu);
+            if (tid == 0) {
+                int winner = p;
+                const double ratio_p = -best;
+                for (int i = 0; i < m; ++i) {
+                    if (i == p) continue;
+                    const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
+                    if (big_neg(a) || big_zero(a)) continue;
+                    const double ratio = big_to_double(big_load<L>(lp.xt + (size_t)i * L)) / big_to_double(a);
+                    if (!(ratio <= ratio_p + 1e-9 * fabs(ratio_p) + 1e-300)) continue;
+                    // x_i / a_i  vs  x_w / a_w   <=>   x_i a_w  vs  x_w a_i   (both a > 0)
+                    const int c = sign_of_difference<L>(big_load<L>(lp.xt + (size_t)i * L), big_load<L>(lp.alpha + (size_t)winner * L),
+                                                        big_load<L>(lp.xt + (size_t)winner * L), a);
+                    if (c < 0 || (c == 0 && lp.basis[i] < lp.basis[winner])) winner = i;
+                }
+                s_int[0] = winner;
+            }
+            __syncthreads();
+            p = s_int[0];
+            __syncthreads();
+        }
+        // ---- the pivot: D' = alpha~_p, N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays ---------------------------
+        Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
+        const bool flip = big_neg(ap);  // (only a zero-level pivot can have a negative pivot element): keep D > 0
+        if (tid == 0) {
+            const int shift = big_ctz(D);
+            big_store(gDinv, big_inverse_odd(big_sar(D, shift)));
+            s_int[2] = shift;
+        }
+        __syncthreads();
+        const int shift = s_int[2];
+        const double quotient_limit = ldexp(1.0, 64 * L - 3 - shift);
+        const Big<L> Dinv = big_load<L>(gDinv);
+        const double apd = fabs(big_to_double(ap));
+        for (int idx = tid; idx < m * m; idx += T) {
+            const int i = idx / m, k = idx - i * m;
+            if (i == p) continue;
+            const Big<L> ai = big_load<L>(lp.alpha + (size_t)i * L);
+            const Big<L> nik = big_load<L>(lp.N + (size_t)idx * L);
+            const Big<L> npk = big_load<L>(lp.N + ((size_t)p * m + k) * L);
+            // The numerator only has to be right modulo 2^(64 L): with D = 2^s D_odd the quotient is known modulo 2^(64 L - s)
+            // (q D_odd = numerator / 2^s holds on the low 64 L - s bits), so it is sign-extended from there and must fit there.
+            const Big<L> numerator = big_sub(big_mul_lo(ap, nik), big_mul_lo(ai, npk));
+            const double estimate = (apd * fabs(big_to_double(nik)) + fabs(big_to_double(ai)) * fabs(big_to_double(npk))) / fabs(Dd);
+            if (!(estimate < quotient_limit)) s_overflow = 1;
+            Big<L> quotient = big_mul_lo(big_sar(numerator, shift), Dinv);
+            quotient = big_sar(big_shl(quotient, shift), shift);
+            if (flip) quotient = big_negate(quotient);
+            big_store(lp.N + (size_t)idx * L, quotient);
+        }
+        if (flip) {
+            for (int k = tid; k < m; k += T) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
+            ap = big_negate(ap);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int leaving = lp.basis[p];
+            big_store(gD, ap);
+            lp.basis[p] = q;
+            lp.pos[q] = p;
+            lp.pos[leaving] = -1;
+            if (trace_count < lp.trace_capacity) {
+                lp.trace[4 * trace_count] = phase;
+                lp.trace[4 * trace_count + 1] = q;
+                lp.trace[4 * trace_count + 2] = p;
+                lp.trace[4 * trace_count + 3] = leaving;
+            }
+        }
+        ++trace_count;
+        pivots[phase - 1]++;
+        __syncthreads();
+        if (s_overflow) { status = EX_OVERFLOW; break; }
+    }
+    __syncthreads();
+    if (s_overflow && status != EX_OVERFLOW) status = EX_OVERFLOW;
+    // the final x~_B belongs to the final basis: recompute it (the loop computes it at the top of an iteration)
+    {
+        for (int i = tid; i < m; i += T) {
+            Big<L> acc = big_from<L>(0);
+            for (int k = 0; k < m; ++k) {
+                const i64 b = lp.rhs[k];
+                if (b != 0) acc = big_add(acc, big_mul_small(big_load<L>(lp.N + ((size_t)i * m + k) * L), b));
+            }
+            big_store(lp.xt + (size_t)i * L, acc);
+        }
+    }
+    if (tid == 0) {
+        lp.out[0] = status;
+        lp.out[1] = (int)pivots[0];
+        lp.out[2] = (int)pivots[1];
+        lp.out[3] = L;
+        lp.out[4] = trace_count < lp.trace_capacity ? trace_count : lp.trace_capacity;
+    }
+}
+
+template <class T>
+T* dalloc(size_t count, std::vector<void*>& owned) {
+    void* p = nullptr;
+    RELP_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    owned.push_back(p);
+    return reinterpret_cast<T*>(p);
+}
+
+BigInt big_from_words(const u64* w, int limbs) {  // two's complement words -> sign-magnitude
+    const bool neg = (i64)w[limbs - 1] < 0;
+    std::vector<u64> mag(w, w + limbs);
+    if (neg) {
+        u64 carry = 1;
+        for (int k = 0; k < limbs; ++k) {
+            const u128 s = (u128)(~mag[k]) + carry;
+            mag[k] = (u64)s;
+            carry = (u64)(s >> 64);
+        }
+    }
+    BigInt r;
+    for (int k = 0; k < limbs; ++k) {
+        r.mag.push_back((uint32_t)mag[k]);
+        r.mag.push_back((uint32_t)(mag[k] >> 32));
+    }
+    r.neg = neg;
+    r.trim();
+    return r;
+}
+
+}  // namespace
+
+// Host driver: scales the LP to integers, runs the kernel with 2, 4, ... limbs until it does not overflow.
+//   status: 1 optimal | 2 infeasible | 3 unbounded | 4 overflow at the largest width | 5 pivot limit | 6 redundant rows
+void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
+                   int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
+                   std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
+                   std::vector<std::pair<int, long long>>* pivots_survived) {
+    RELP_HIP(hipSetDevice(device));
+    const MatrixData& md = form.data;
+    const int m = md.nr_rows(), n_p = md.nr_columns();
+    std::vector<SparseColumn> columns(n_p);
+    for (int j = 0; j < n_p; ++j) columns[j] = md.column(j);
+    std::vector<Rat> rhs = md.right_hand_side();
+    // row multipliers: lcm of the denominators of the row's coefficients and of its right-hand side
+    std::vector<i128> row_mult(m, 1);
+    auto lcm = [](i128 a, i128 b) { return mul_checked(a / gcd128(a, b), b); };
+    for (int j = 0; j < n_p; ++j)
+        for (size_t e = 0; e < columns[j].nnz(); ++e) row_mult[columns[j].index[e]] = lcm(row_mult[columns[j].index[e]], columns[j].value[e].d);
+    for (int i = 0; i < m; ++i) row_mult[i] = lcm(row_mult[i], rhs[i].d);
+    i128 cost_mult = 1;
+    for (int j = 0; j < n_p; ++j) cost_mult = lcm(cost_mult, md.cost_value(j).d);
+    auto small = [](i128 v) {
+        if (v >= ((i128)1 << 62) || v <= -((i128)1 << 62)) throw RatOverflow();
+        return (i64)v;
+    };
+    // index space of the device loop: artificials first (one per row without an initial pivot), then the provider columns
+    auto pivots = md.pivot_element_indices();
+    std::vector<int> real_column_of_row(m, -1);
+    for (auto& [row, column] : pivots) real_column_of_row[row] = column;
+    std::vector<int> artificial_rows;
+    for (int i = 0; i < m; ++i)
+        if (real_column_of_row[i] < 0) artificial_rows.push_back(i);
+    const int n_art = (int)artificial_rows.size(), n = n_art + n_p;
+    std::vector<int> col_start(n + 1, 0), row_index;
+    std::vector<i64> value, cost2(n, 0), rhs_scaled(m);
+    for (int k = 0; k < n_art; ++k) {
+        row_index.push_back(artificial_rows[k]);
+        value.push_back(small(row_mult[artificial_rows[k]]));
+        col_start[k + 1] = (int)row_index.size();
+    }
+    for (int j = 0; j < n_p; ++j) {
+        for (size_t e = 0; e < columns[j].nnz(); ++e) {
+            row_index.push_back(columns[j].index[e]);
+            value.push_back(small(mul_checked(columns[j].value[e].n, row_mult[columns[j].index[e]] / columns[j].value[e].d)));
+        }
+        col_start[n_art + j + 1] = (int)row_index.size();
+        const Rat c = md.cost_value(j);
+        cost2[n_art + j] = small(mul_checked(c.n, cost_mult / c.d));
+    }
+    for (int i = 0; i < m; ++i) rhs_scaled[i] = small(mul_checked(rhs[i].n, row_mult[i] / rhs[i].d));
+    std::vector<int> basis0(m), pos0(n, -1);
+    {
+        int k = 0;
+        for (int i = 0; i < m; ++i) {
+            basis0[i] = real_column_of_row[i] < 0 ? k++ : n_art + real_column_of_row[i];
+            pos0[basis0[i]] = i;
+        }
+    }
+    // B_0 = diag(d_i) with d_i the (scaled) unit entry of row i's initial basic column: D_0 = prod d_i, N_0 = D_0 diag(1 / d_i)
+    std::vector<i64> diag0(m);
+    for (int i = 0; i < m; ++i) {
+        const int c = basis0[i];
+        if (col_start[c + 1] - col_start[c] != 1 || row_index[col_start[c]] != i || value[col_start[c]] <= 0)
+            throw std::runtime_error("exact simplex: the initial basis is not a positive diagonal");
+        diag0[i] = value[col_start[c]];
+    }
+    BigInt D0(1);
+    for (int i = 0; i < m; ++i) D0 = D0 * BigInt(diag0[i]);
+
+    std::vector<void*> owned;
+    struct Free {
+        std::vector<void*>& p;
+        ~Free() { for (void* q : p) (void)hipFree(q); }
+    } free_all{owned};
+    int* d_col_start = dalloc<int>(n + 1, owned);
+    int* d_row_index = dalloc<int>(row_index.size(), owned);
+    i64* d_value = dalloc<i64>(value.size(), owned);
+    i64* d_cost2 = dalloc<i64>(n, owned);
+    i64* d_rhs = dalloc<i64>(m, owned);
+    int* d_basis = dalloc<int>(m, owned);
+    int* d_pos = dalloc<int>(n, owned);
+    double* d_key = dalloc<double>(n, owned);
+    int* d_trace = dalloc<int>((size_t)4 * trace_capacity, owned);
+    int* d_out = dalloc<int>(8, owned);
+    RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_cost2, cost2.data(), n * sizeof(i64), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_rhs, rhs_scaled.data(), m * sizeof(i64), hipMemcpyHostToDevice, stream));
+
+    *status = EX_OVERFLOW;
+    *limbs_used = 0;
+    if (pivots_survived) pivots_survived->clear();
+    for (int limbs = std::max(1, first_limbs); limbs <= max_limbs; limbs *= 2) {
+        const size_t big = (size_t)limbs;
+        u64* d_N = dalloc<u64>((size_t)m * m * big, owned);
+        u64* d_D = dalloc<u64>(2 * big + 2 * (2 * big + 1) + 8, owned);
+        u64* d_xt = dalloc<u64>((size_t)m * big, owned);
+        u64* d_alpha = dalloc<u64>((size_t)m * big, owned);
+        u64* d_ctil = dalloc<u64>((size_t)n * big, owned);
+        // N_0 and D_0 as two's complement words (positive values)
+        auto words = [&](const BigInt& v, u64* out) {
+            for (int k = 0; k < limbs; ++k) {
+                const uint64_t lo = 2 * k < (int)v.mag.size() ? v.mag[2 * k] : 0, hi = 2 * k + 1 < (int)v.mag.size() ? v.mag[2 * k + 1] : 0;
+                out[k] = lo | (hi << 32);
+            }
+        };
+        if (D0.bits() + 3 > (size_t)64 * limbs) {  // does not even hold the first determinant
+            if (pivots_survived) pivots_survived->push_back({limbs, 0});
+            continue;
+        }
+        std::vector<u64> hN((size_t)m * m * big, 0), hD(big);
+        words(D0, hD.data());
+        for (int i = 0; i < m; ++i) {
+            BigInt q, r;
+            BigInt::divmod(D0, BigInt(diag0[i]), q, r);
+            words(q, hN.data() + ((size_t)i * m + i) * big);
+        }
+        RELP_HIP(hipMemcpyAsync(d_N, hN.data(), hN.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_D, hD.data(), big * sizeof(u64), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_basis, basis0.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
+        ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out};
+        switch (limbs) {
+            case 1: hipLaunchKernelGGL(exact_simplex_kernel<1>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
+            case 2: hipLaunchKernelGGL(exact_simplex_kernel<2>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
+            case 4: hipLaunchKernelGGL(exact_simplex_kernel<4>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
+            case 8: hipLaunchKernelGGL(exact_simplex_kernel<8>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
+            case 16: hipLaunchKernelGGL(exact_simplex_kernel<16>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
+            case 32: hipLaunchKernelGGL(exact_simplex_kernel<32>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
+            default: throw std::invalid_argument("limbs must be a power of two between 1 and 32");
+        }
+        RELP_HIP(hipGetLastError());
+        int out[8];
+        RELP_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream));
+        RELP_HIP(hipStreamSynchronize(stream));
+        *status = out[0];
+        *limbs_used = limbs;
+        *pivots_phase_one = out[1];
+        *pivots_phase_two = out[2];
+        if (pivots_survived) pivots_survived->push_back({limbs, (long long)out[1] + out[2]});
+        if (out[0] == EX_OVERFLOW) continue;
+        // results of the run that did not overflow
+        if (trace) {
+            trace->assign((size_t)4 * out[4], 0);
+            if (out[4] > 0) RELP_HIP(hipMemcpy(trace->data(), d_trace, trace->size() * sizeof(int), hipMemcpyDeviceToHost));
+        }
+        std::vector<int> basis(m);
+        RELP_HIP(hipMemcpy(basis.data(), d_basis, m * sizeof(int), hipMemcpyDeviceToHost));
+        if (final_basis) {
+            final_basis->resize(m);
+            for (int i = 0; i < m; ++i) (*final_basis)[i] = basis[i] >= n_art ? basis[i] - n_art : -1 - basis[i];
+        }
+        if (objective && out[0] == EX_OPTIMAL) {
+            // objective = sum_i c_{B_i} x~_i / (D cost_mult) + fixed cost   (general_form/mod.rs:840-851)
+            std::vector<u64> hx((size_t)m * big), hd(big);
+            RELP_HIP(hipMemcpy(hx.data(), d_xt, hx.size() * sizeof(u64), hipMemcpyDeviceToHost));
+            RELP_HIP(hipMemcpy(hd.data(), d_D, big * sizeof(u64), hipMemcpyDeviceToHost));
+            BigInt num(0);
+            for (int i = 0; i < m; ++i)
+                if (basis[i] >= n_art && cost2[basis[i]] != 0) num = num + BigInt(cost2[basis[i]]) * big_from_words(hx.data() + (size_t)i * big, limbs);
+            BigInt den = big_from_words(hd.data(), limbs) * BigInt::from_i128(cost_mult);
+            const Rat& fixed = form.fixed_cost;
+            num = num * BigInt::from_i128(fixed.d) + BigInt::from_i128(fixed.n) * den;
+            den = den * BigInt::from_i128(fixed.d);
+            if (den.sign() < 0) { num = -num; den = -den; }
+            BigInt g = BigInt::gcd(num, den);
+            if (!g.is_zero() && !(g == BigInt(1))) {
+                num = num / g;
+                den = den / g;
+            }
+            *objective = num.to_string() + "/" + den.to_string();
+        }
+        return;
+    }
+}
+
+}  // namespace relp
