@@ -6,7 +6,10 @@
 //     N = D * B^-1,   D = |det B|,        (all entries of N are integers)
 //     alpha~_q = N a_q,  x~_B = N b,  c~_j = D c_j - c_B' N a_j,  gamma~_j = D^2 + |N a_j|^2       (numerators over D, D, D, D^2)
 // and a pivot on row p is   D' = alpha~_p,   N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (i != p),  N'_p = N_p,
-// where the division is EXACT.  Integers are LIMBS x 64-bit two's complement words, LIMBS in {2, 4, 8, 16, 32} (int128 and
+// where the division is EXACT.  The rows are scaled to integers (r_i = lcm of the row's denominators); the unit columns -- slacks and
+// artificials -- are scaled BACK by 1 / r_i, so that the first basis is the identity and D starts at 1 instead of at prod r_i
+// (14 000 bits on 25FV47).  Column scaling is invisible to the ratio test; the pricing rule sees it and is corrected exactly:
+// with sigma_j the column factors and W = lcm(r)^2,  key_j = c~_j^2 / (w_j D^2 + sum_i w_{B_i} (N a_j)_i^2),  w_j = W sigma_j^2.  Integers are LIMBS x 64-bit two's complement words, LIMBS in {2, 4, 8, 16, 32} (int128 and
 // int256 are the two smallest instantiations).  No gcd and no long division ever runs on the device: an exact quotient is one
 // truncated multiplication with the inverse of D modulo 2^(64 LIMBS) (Newton iteration, once per pivot).  Every result is
 // guarded by a floating-point magnitude bound; when a value might not fit, the solve stops with status OVERFLOW and the host
@@ -138,6 +141,42 @@ __device__ __forceinline__ double big_to_double(const Big<L>& a) {
     v = ldexp(v, 64 * (top > 0 ? top - 1 : 0));
     return neg ? -v : v;
 }
+// bit length of |a| (0 for zero): the magnitude bounds that guard every operation are sums of these
+template <int L>
+__device__ __forceinline__ int big_bits(const Big<L>& a) {
+    const Big<L> m = big_neg(a) ? big_negate(a) : a;
+    int top = -1;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k)
+        if (m.w[k] != 0) top = k;
+    if (top < 0) return 0;
+    return 64 * top + (64 - __clzll((long long)m.w[top]));
+}
+__device__ __forceinline__ int small_bits(i64 v) {
+    const u64 mag = v < 0 ? (u64)(-(v + 1)) + 1 : (u64)v;
+    return mag == 0 ? 0 : 64 - __clzll((long long)mag);
+}
+// a / b as a double for values that are themselves far outside the range of a double (2048-bit integers): mantissas from the two
+// leading limbs, exponents apart
+template <int L>
+__device__ __forceinline__ double big_ratio(const Big<L>& a, const Big<L>& b) {
+    auto split = [](const Big<L>& v, int* exponent) {
+        const bool neg = big_neg(v);
+        const Big<L> m = neg ? big_negate(v) : v;
+        int top = -1;
+#pragma unroll L <= 8 ? L : 1
+        for (int k = 0; k < L; ++k)
+            if (m.w[k] != 0) top = k;
+        if (top < 0) { *exponent = 0; return 0.0; }
+        double x = (double)m.w[top];
+        if (top > 0) x = x * 18446744073709551616.0 + (double)m.w[top - 1];
+        *exponent = 64 * (top > 0 ? top - 1 : 0);
+        return neg ? -x : x;
+    };
+    int ea = 0, eb = 0;
+    const double ma = split(a, &ea), mb = split(b, &eb);
+    return ldexp(ma / mb, ea - eb);
+}
 template <int L>
 __device__ __forceinline__ int big_ctz(const Big<L>& a) {  // a != 0
     int bits = 0;
@@ -240,7 +279,9 @@ struct ExactLP {
     const int* col_start;
     const int* row_index;
     const i64* value;
-    const i64* cost2;     // phase-two costs (scaled to integers); phase one: 1 on the artificial columns
+    const i64* cost2;     // phase-two costs (scaled to integers)
+    const i64* cost1;     // phase-one costs: lcm(r over the artificial rows) / r_i on the artificial of row i, 0 elsewhere
+    const i64* weight;    // w_j = W sigma_j^2 (see the header): W for a structural column, (lcm(r) / r_i)^2 for a unit column of row i
     const i64* rhs;       // scaled right-hand side
     int* basis;           // [m]
     int* pos;             // [n]
@@ -259,9 +300,9 @@ struct ExactLP {
 // Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
 // (2 L + 1)-limb numbers in scratch memory (one thread; rare).
 template <int L>
-__device__ void exact_weight(const ExactLP& lp, const Big<L>& D, int j, u64* gamma /* 2L+1 */) {
-    for (int k = 0; k < 2 * L + 1; ++k) gamma[k] = 0;
-    auto add_square = [&](const Big<L>& v) {
+__device__ void exact_weight(const ExactLP& lp, const Big<L>& D, int j, u64* gamma /* 2L+2 */) {
+    for (int k = 0; k < 2 * L + 2; ++k) gamma[k] = 0;
+    auto add_square = [&](const Big<L>& v, u64 w) {
         const Big<L> mag = big_neg(v) ? big_negate(v) : v;
         u64 sq[2 * L];
         for (int k = 0; k < 2 * L; ++k) sq[k] = 0;
@@ -274,20 +315,22 @@ __device__ void exact_weight(const ExactLP& lp, const Big<L>& D, int j, u64* gam
             }
             sq[i + L] += carry;
         }
-        u64 carry = 0;
+        u64 carry = 0;  // gamma += w * sq
         for (int k = 0; k < 2 * L; ++k) {
-            const u128 s = (u128)gamma[k] + sq[k] + carry;
+            const u128 s = (u128)sq[k] * w + gamma[k] + carry;
             gamma[k] = (u64)s;
             carry = (u64)(s >> 64);
         }
-        gamma[2 * L] += carry;
+        const u128 s = (u128)gamma[2 * L] + carry;
+        gamma[2 * L] = (u64)s;
+        gamma[2 * L + 1] += (u64)(s >> 64);
     };
-    add_square(D);
+    add_square(D, (u64)lp.weight[j]);
     for (int i = 0; i < lp.m; ++i) {
         Big<L> a = big_from<L>(0);
         for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
             a = big_add(a, big_mul_small(big_load<L>(lp.N + ((size_t)i * lp.m + lp.row_index[e]) * L), lp.value[e]));
-        add_square(a);
+        add_square(a, (u64)lp.weight[lp.basis[i]]);
     }
 }
 // c_a^2 * gamma_b  vs  c_b^2 * gamma_a  (unsigned, (4 L + 1) limbs): +1 when column a has the larger key
@@ -306,24 +349,23 @@ __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& 
             sq[i + L] += carry;
         }
     };
-    u64 sa[2 * L], sb[2 * L], left[4 * L + 1], right[4 * L + 1];
+    u64 sa[2 * L], sb[2 * L], left[4 * L + 2], right[4 * L + 2];
     square(ca, sa);
     square(cb, sb);
-    auto multiply = [](const u64* x, const u64* g, u64* out) {  // x: 2L limbs, g: 2L + 1 limbs
-        for (int k = 0; k < 4 * L + 1; ++k) out[k] = 0;
+    auto multiply = [](const u64* x, const u64* g, u64* out) {  // x: 2L limbs, g: 2L + 2 limbs
+        for (int k = 0; k < 4 * L + 2; ++k) out[k] = 0;
         for (int i = 0; i < 2 * L; ++i) {
             u64 carry = 0;
-            for (int t = 0; t < 2 * L + 1; ++t) {
+            for (int t = 0; t < 2 * L + 2; ++t) {
                 const u128 prod = (u128)x[i] * g[t] + out[i + t] + carry;
                 out[i + t] = (u64)prod;
                 carry = (u64)(prod >> 64);
             }
-            if (i + 2 * L + 1 < 4 * L + 1) out[i + 2 * L + 1] += carry;
         }
     };
     multiply(sa, gamma_b, left);
     multiply(sb, gamma_a, right);
-    for (int k = 4 * L; k >= 0; --k)
+    for (int k = 4 * L + 1; k >= 0; --k)
         if (left[k] != right[k]) return left[k] > right[k] ? 1 : -1;
     return 0;
 }
@@ -336,37 +378,38 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
     __shared__ int s_overflow;
     const int tid = threadIdx.x, T = blockDim.x;
     const int m = lp.m, n = lp.n;
-    const double LIMIT = ldexp(1.0, 64 * L - 3);  // magnitudes at or above this might not fit
+    const int LIMIT_BITS = 64 * L - 3;  // a value whose magnitude bound reaches this many bits might not fit
     u64* gD = lp.D;
     u64* gDinv = lp.D + L;
-    u64* scratch = lp.D + 2 * L;  // tie breakers (one thread): 2 x (2L + 1) limbs
+    u64* scratch = lp.D + 2 * L;  // tie breakers (one thread): 2 x (2L + 2) limbs
     int phase = lp.n_art > 0 ? 1 : 2;
     long long pivots[2] = {0, 0};
     int trace_count = 0;
     int status = EX_RUNNING;
     if (tid == 0) s_overflow = 0;
     __syncthreads();
-    auto flag_overflow = [&](double magnitude) {
-        if (!(magnitude < LIMIT)) s_overflow = 1;
+    auto flag_overflow = [&](int bits) {
+        if (bits >= LIMIT_BITS) s_overflow = 1;
     };
+    auto log2_ceil = [](int count) { return 32 - __clz(count > 1 ? count - 1 : 1) + 1; };
     // drive_row >= 0: the zero-level pivots of phase_one.rs:232-278 are under way, this is the next row to look at
     int drive_row = -1;
     while (status == EX_RUNNING) {
         if (pivots[0] + pivots[1] >= lp.max_pivots) { status = EX_PIVOT_LIMIT; break; }
         const Big<L> D = big_load<L>(gD);
-        const double Dd = big_to_double(D);
+        const int D_bits = big_bits(D);
         // ---- x~_B = N b -------------------------------------------------------------------------------------------------
         for (int i = tid; i < m; i += T) {
             Big<L> acc = big_from<L>(0);
-            double mag = 0.0;
+            int widest = 0;
             for (int k = 0; k < m; ++k) {
                 const i64 b = lp.rhs[k];
                 if (b == 0) continue;
                 const Big<L> nik = big_load<L>(lp.N + ((size_t)i * m + k) * L);
                 acc = big_add(acc, big_mul_small(nik, b));
-                mag += fabs(big_to_double(nik)) * fabs((double)b);
+                widest = max(widest, big_bits(nik) + small_bits(b));
             }
-            flag_overflow(mag);
+            flag_overflow(widest + log2_ceil(m));
             big_store(lp.xt + (size_t)i * L, acc);
         }
         __syncthreads();
@@ -376,37 +419,42 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             for (int j = lp.n_art + tid; j < n; j += T) {
                 double key = 0.0;
                 if (lp.pos[j] < 0) {
-                    const i64 cj = phase == 1 ? 0 : lp.cost2[j];
+                    const i64 cj = phase == 1 ? lp.cost1[j] : lp.cost2[j];
                     Big<L> ct = big_mul_small(D, cj);
-                    double sumsq = Dd * Dd, mag = fabs(Dd) * fabs((double)cj);
+                    // (everything relative to D: the quotients are the reference's rationals, of moderate size, whatever the limbs hold)
+                    double sumsq = (double)lp.weight[j];
+                    int widest = D_bits + small_bits(cj);
+                    const int entries = lp.col_start[j + 1] - lp.col_start[j];
                     for (int i = 0; i < m; ++i) {
                         Big<L> a = big_from<L>(0);
-                        double amag = 0.0;
+                        int awide = 0;
                         for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e) {
                             const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
                             a = big_add(a, big_mul_small(nir, lp.value[e]));
-                            amag += fabs(big_to_double(nir)) * fabs((double)lp.value[e]);
+                            awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
                         }
-                        flag_overflow(amag);
+                        awide += log2_ceil(entries);
+                        flag_overflow(awide);
                         const int bi = lp.basis[i];
-                        const i64 cb = phase == 1 ? (bi < lp.n_art ? 1 : 0) : lp.cost2[bi];
+                        const i64 cb = phase == 1 ? lp.cost1[bi] : lp.cost2[bi];
                         if (cb != 0) {
                             ct = big_sub(ct, big_mul_small(a, cb));
-                            mag += amag * fabs((double)cb);
+                            widest = max(widest, awide + small_bits(cb));
                         }
-                        const double ad = big_to_double(a);
-                        sumsq += ad * ad;
+                        const double ad = big_ratio(a, D);
+                        sumsq += ad * ad * (double)lp.weight[bi];
                     }
-                    flag_overflow(mag);
+                    flag_overflow(widest + log2_ceil(m + 1));
                     big_store(lp.ctil + (size_t)j * L, ct);
                     if (big_neg(ct)) {  // D > 0: the sign of c~_j is the sign of the relative cost
-                        const double cd = big_to_double(ct);
+                        const double cd = big_ratio(ct, D);
                         key = cd * cd / sumsq;
                     }
                 }
                 lp.key[j] = key;
             }
             __syncthreads();
+            if (s_overflow) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
             // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
             double best = 0.0;
             unsigned long long rank = RANK_NONE;
@@ -423,7 +471,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 if (tid == 0) {
                     // every column whose estimate is within 1e-9 of the best is compared exactly (c~^2 gamma~ cross products)
                     u64* gq = scratch;
-                    u64* gj = scratch + 2 * L + 1;
+                    u64* gj = scratch + 2 * L + 2;
                     bool have_q = false;
                     int winner = q;
                     for (int j = lp.n_art; j < n; ++j) {
@@ -436,7 +484,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                         const int c = compare_keys<L>(big_load<L>(lp.ctil + (size_t)j * L), gj, big_load<L>(lp.ctil + (size_t)winner * L), gq);
                         if (c > 0 || (c == 0 && j > winner)) {
                             winner = j;
-                            for (int k = 0; k < 2 * L + 1; ++k) gq[k] = gj[k];
+                            for (int k = 0; k < 2 * L + 2; ++k) gq[k] = gj[k];
                         }
                     }
                     s_int[0] = winner;
@@ -501,16 +549,17 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         // ---- alpha~_q = N a_q (tableau/mod.rs:126-130) -----------------------------------------------------------------------
         for (int i = tid; i < m; i += T) {
             Big<L> a = big_from<L>(0);
-            double amag = 0.0;
+            int awide = 0;
             for (int e = lp.col_start[q]; e < lp.col_start[q + 1]; ++e) {
                 const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
                 a = big_add(a, big_mul_small(nir, lp.value[e]));
-                amag += fabs(big_to_double(nir)) * fabs((double)lp.value[e]);
+                awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
             }
-            flag_overflow(amag);
+            flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
             big_store(lp.alpha + (size_t)i * L, a);
         }
         __syncthreads();
+        if (s_overflow) { status = EX_OVERFLOW; break; }
         if (p < 0) {
             // ---- ratio test: min x~_i / alpha~_i over alpha~_i > 0, ties to the lowest basic column (tableau/mod.rs:287-313) --
             double best = 0.0;
@@ -518,7 +567,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             for (int i = tid; i < m; i += T) {
                 const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
                 if (big_neg(a) || big_zero(a)) continue;
-                const double ratio = big_to_double(big_load<L>(lp.xt + (size_t)i * L)) / big_to_double(a);
+                const double ratio = big_ratio(big_load<L>(lp.xt + (size_t)i * L), a);
                 const unsigned long long r = ((unsigned long long)(unsigned)lp.basis[i] << 32) | (unsigned)i;
                 const double k = -ratio;  // block_argbest maximises
                 if (rank == RANK_NONE || k > best || (k == best && r < rank)) { best = k; rank = r; }
@@ -533,7 +582,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                     if (i == p) continue;
                     const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
                     if (big_neg(a) || big_zero(a)) continue;
-                    const double ratio = big_to_double(big_load<L>(lp.xt + (size_t)i * L)) / big_to_double(a);
+                    const double ratio = big_ratio(big_load<L>(lp.xt + (size_t)i * L), a);
                     if (!(ratio <= ratio_p + 1e-9 * fabs(ratio_p) + 1e-300)) continue;
                     // x_i / a_i  vs  x_w / a_w   <=>   x_i a_w  vs  x_w a_i   (both a > 0)
                     const int c = sign_of_difference<L>(big_load<L>(lp.xt + (size_t)i * L), big_load<L>(lp.alpha + (size_t)winner * L),
@@ -556,9 +605,8 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         }
         __syncthreads();
         const int shift = s_int[2];
-        const double quotient_limit = ldexp(1.0, 64 * L - 3 - shift);
         const Big<L> Dinv = big_load<L>(gDinv);
-        const double apd = fabs(big_to_double(ap));
+        const int ap_bits = big_bits(ap);
         for (int idx = tid; idx < m * m; idx += T) {
             const int i = idx / m, k = idx - i * m;
             if (i == p) continue;
@@ -568,8 +616,8 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             // The numerator only has to be right modulo 2^(64 L): with D = 2^s D_odd the quotient is known modulo 2^(64 L - s)
             // (q D_odd = numerator / 2^s holds on the low 64 L - s bits), so it is sign-extended from there and must fit there.
             const Big<L> numerator = big_sub(big_mul_lo(ap, nik), big_mul_lo(ai, npk));
-            const double estimate = (apd * fabs(big_to_double(nik)) + fabs(big_to_double(ai)) * fabs(big_to_double(npk))) / fabs(Dd);
-            if (!(estimate < quotient_limit)) s_overflow = 1;
+            const int estimate = max(ap_bits + big_bits(nik), big_bits(ai) + big_bits(npk)) + 1 - (D_bits - 1);
+            if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
             Big<L> quotient = big_mul_lo(big_sar(numerator, shift), Dinv);
             quotient = big_sar(big_shl(quotient, shift), shift);
             if (flip) quotient = big_negate(quotient);
@@ -683,21 +731,33 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     for (int i = 0; i < m; ++i)
         if (real_column_of_row[i] < 0) artificial_rows.push_back(i);
     const int n_art = (int)artificial_rows.size(), n = n_art + n_p;
+    // lcm of the row multipliers (W = lcm^2 weights the squared norms) and of those of the artificial rows (phase-one costs)
+    i128 lcm_all = 1, lcm_art = 1;
+    for (int i = 0; i < m; ++i) lcm_all = lcm(lcm_all, row_mult[i]);
+    for (int i : artificial_rows) lcm_art = lcm(lcm_art, row_mult[i]);
     std::vector<int> col_start(n + 1, 0), row_index;
-    std::vector<i64> value, cost2(n, 0), rhs_scaled(m);
-    for (int k = 0; k < n_art; ++k) {
-        row_index.push_back(artificial_rows[k]);
-        value.push_back(small(row_mult[artificial_rows[k]]));
+    std::vector<i64> value, cost2(n, 0), cost1(n, 0), weight(n, 0), rhs_scaled(m);
+    for (int k = 0; k < n_art; ++k) {  // artificial of row i: the unit column, scaled by sigma = 1 / r_i => entry 1
+        const int i = artificial_rows[k];
+        row_index.push_back(i);
+        value.push_back(1);
         col_start[k + 1] = (int)row_index.size();
+        cost1[k] = small(lcm_art / row_mult[i]);
+        weight[k] = small(mul_checked(lcm_all / row_mult[i], lcm_all / row_mult[i]));
     }
     for (int j = 0; j < n_p; ++j) {
+        const Rat c = md.cost_value(j);
+        // a column with a single entry +-1 and no cost (a slack) is scaled by sigma = 1 / r_i like the artificial columns
+        const bool unit = columns[j].nnz() == 1 && columns[j].value[0].d == 1 && (columns[j].value[0].n == 1 || columns[j].value[0].n == -1) && c.is_zero();
         for (size_t e = 0; e < columns[j].nnz(); ++e) {
-            row_index.push_back(columns[j].index[e]);
-            value.push_back(small(mul_checked(columns[j].value[e].n, row_mult[columns[j].index[e]] / columns[j].value[e].d)));
+            const int i = columns[j].index[e];
+            row_index.push_back(i);
+            value.push_back(unit ? (i64)columns[j].value[e].n : small(mul_checked(columns[j].value[e].n, row_mult[i] / columns[j].value[e].d)));
         }
         col_start[n_art + j + 1] = (int)row_index.size();
-        const Rat c = md.cost_value(j);
         cost2[n_art + j] = small(mul_checked(c.n, cost_mult / c.d));
+        const i128 ratio = unit ? lcm_all / row_mult[columns[j].index[0]] : lcm_all;
+        weight[n_art + j] = small(mul_checked(ratio, ratio));
     }
     for (int i = 0; i < m; ++i) rhs_scaled[i] = small(mul_checked(rhs[i].n, row_mult[i] / rhs[i].d));
     std::vector<int> basis0(m), pos0(n, -1);
@@ -708,7 +768,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
             pos0[basis0[i]] = i;
         }
     }
-    // B_0 = diag(d_i) with d_i the (scaled) unit entry of row i's initial basic column: D_0 = prod d_i, N_0 = D_0 diag(1 / d_i)
+    // B_0 = diag(d_i) with d_i the unit entry of row i's initial basic column (1 after the scaling above): D_0 = prod d_i
     std::vector<i64> diag0(m);
     for (int i = 0; i < m; ++i) {
         const int c = basis0[i];
@@ -728,6 +788,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_row_index = dalloc<int>(row_index.size(), owned);
     i64* d_value = dalloc<i64>(value.size(), owned);
     i64* d_cost2 = dalloc<i64>(n, owned);
+    i64* d_cost1 = dalloc<i64>(n, owned);
+    i64* d_weight = dalloc<i64>(n, owned);
     i64* d_rhs = dalloc<i64>(m, owned);
     int* d_basis = dalloc<int>(m, owned);
     int* d_pos = dalloc<int>(n, owned);
@@ -738,6 +800,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_cost2, cost2.data(), n * sizeof(i64), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_cost1, cost1.data(), n * sizeof(i64), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_weight, weight.data(), n * sizeof(i64), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_rhs, rhs_scaled.data(), m * sizeof(i64), hipMemcpyHostToDevice, stream));
 
     *status = EX_OVERFLOW;
@@ -746,7 +810,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     for (int limbs = std::max(1, first_limbs); limbs <= max_limbs; limbs *= 2) {
         const size_t big = (size_t)limbs;
         u64* d_N = dalloc<u64>((size_t)m * m * big, owned);
-        u64* d_D = dalloc<u64>(2 * big + 2 * (2 * big + 1) + 8, owned);
+        u64* d_D = dalloc<u64>(2 * big + 2 * (2 * big + 2) + 8, owned);
         u64* d_xt = dalloc<u64>((size_t)m * big, owned);
         u64* d_alpha = dalloc<u64>((size_t)m * big, owned);
         u64* d_ctil = dalloc<u64>((size_t)n * big, owned);
@@ -772,7 +836,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemcpyAsync(d_D, hD.data(), big * sizeof(u64), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(d_basis, basis0.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
-        ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
+        ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out};
         switch (limbs) {
             case 1: hipLaunchKernelGGL(exact_simplex_kernel<1>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
