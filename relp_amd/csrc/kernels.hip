@@ -45,9 +45,13 @@ __global__ void budget_kernel(Ctl* ctl, long long add) {
 // The reference makes TWO passes over A per pivot (pricing, weight update) and clones every column twice.
 // ---------------------------------------------------------------------------------------------------
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
-template <int RULE, bool USE_LDS, int LPC>
+// UNIT (graph LPs, LPC == 2): the columns are GENERATED from the arcs' endpoints instead of streamed -- MatrixProvider::column(j)
+// of examples/max_flow.rs:174-200 evaluated on the device: `ell_rows` holds 8 bytes per arc (row of each end, bit 31 = the -1
+// end, 0x7fffffff = that end is s or t: no entry), every value is +-1 and the cost a signed byte (-1 on the arcs leaving s).
+template <int RULE, bool USE_LDS, int LPC, bool UNIT = false>
 __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weights, double tol_dual, int col_first,
                                                     int col_last, int cand_offset) {
+    static_assert(!UNIT || LPC == 2, "generated columns are incidence columns");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[8];
     static_assert(LPC == ELL_W || LPC == 2, "one lane per padded entry (width 2 when no column has more than two entries: graph LPs)");
@@ -81,9 +85,17 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                 a = lp.col_start[j];
                 b = lp.col_start[j + 1];
             }
-            r0 = lp.ell_rows[(size_t)j * LPC + sub];
-            v0 = lp.ell_vals[(size_t)j * LPC + sub];
-            cost_j = lp.cost[j];
+            if (UNIT) {
+                const unsigned code = (unsigned)lp.ell_rows[(size_t)j * LPC + sub];
+                const bool absent = code == 0x7fffffffu;
+                r0 = absent ? 0 : (int)(code & 0x7fffffffu);
+                v0 = absent ? 0.0 : ((code >> 31) ? -1.0 : 1.0);
+                cost_j = (double)lp.cost8[j];
+            } else {
+                r0 = lp.ell_rows[(size_t)j * LPC + sub];
+                v0 = lp.ell_vals[(size_t)j * LPC + sub];
+                cost_j = lp.cost[j];
+            }
             if (RULE == RELP_PIVOT_STEEPEST_EDGE) g_j = lp.gamma[j];
         }
     };
@@ -2593,7 +2605,9 @@ template <int RULE>
 static void launch_price_rule(const DeviceLP& d, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
                               int first, int last, int cand_offset, hipStream_t s) {
     const bool timed_elsewhere = d.n_dense > 0;  // with a dense block the dense kernel is the one that is timed
-    if (d.ell_w == 2)  // graph LPs: two entries per column, 128 columns per workgroup pass (large m: vectors gathered from L2)
+    if (d.ell_w == 2 && d.cost8)  // incidence columns generated from the arcs' endpoints (8 B per arc)
+        RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, false, 2, true>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
+    else if (d.ell_w == 2)  // graph LPs: two entries per column, 128 columns per workgroup pass (large m: vectors gathered from L2)
         RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, false, 2>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
     else if (use_lds)
         RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, true, PRICE_LPC>), dim3(blocks), dim3(256), lds, s, d, skip_weights, tol, first, last, cand_offset);

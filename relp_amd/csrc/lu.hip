@@ -8,11 +8,14 @@
 //   EtaFile::{apply_right, apply_left, update_spike_pivot_value}   eta_file.rs:49-134
 //
 // Design (MI355X): one LP's factor is a few 10^4 non-zeros; a triangular solve with it is a dependency DAG, not a stream.
-// ONE workgroup (16 waves on one CU) owns the solve; the vector lives in LDS; every row is a thread that gathers its
-// entries and waits -- without blocking its wave -- for the entries' own rows to be published ("sync-free" solve: a
-// dependency costs one LDS write + one LDS read, no barrier, no level sets to rebuild after an update).  The reference walks
-// ordered maps (`BTreeMap`) with a column scan per popped entry; here both orientations of L and U are resident so every
-// solve is a gather.  Everything is deterministic: a row adds its entries in storage order.
+// ONE workgroup (16 waves on one CU) owns the solve; the vector(s) and the factor being solved with are staged in LDS
+// (`lu_stage_and_solve`).  The host's refactorisation also produces the level sets of L, U, U' and L' (`lu_schedules`); a
+// WIDE level is solved by all threads followed by one barrier, a run of NARROW levels (the long tail every sparse factor has)
+// by wave 0 alone without barriers, several lanes per row, as a software pipeline over the levels.  Forrest-Tomlin updates do
+// not touch those schedules: the spiked columns are bordered into a dense trailing block T (<= 64 x 64) that one wave solves
+// out of registers (lu.hpp).  The reference walks ordered maps (`BTreeMap`) with a column scan per popped entry; here both
+// orientations of L and U are resident so every solve is a gather.  Everything is deterministic: a row adds its entries in
+// storage order, reductions have a fixed tree.
 #include "lu.hpp"
 
 #include <hip/hip_ext.h>

@@ -99,7 +99,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -200,7 +200,7 @@ void Solver::upload() {
     refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : 31, LU_MAX_SLOTS - 1);  // T is solved by one wave
     if (lu_mode_) {
         if (bounded_) throw std::invalid_argument("the LU carry does not take implicit bounds (use carry = RELP_CARRY_EXPLICIT)");
-        if (!lu_fits_lds(m)) throw std::invalid_argument("the LU carry keeps its solve vectors in LDS: at most about 7000 rows");
+        if (!lu_fits_lds(m)) throw std::invalid_argument("the LU carry keeps its solve vectors and factor headers in LDS: at most about 3200 rows (use the explicit carry beyond)");
     }
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
     // structural columns); steepest edge only (the dense kernel implements that rule)
@@ -273,10 +273,29 @@ void Solver::upload() {
                 er[(size_t)j * width + k] = row_index[e];
                 ev[(size_t)j * width + k] = value[e];
             }
+        // incidence columns (graph providers, examples/max_flow.rs:174-200): every value +-1 and small integer costs -- the
+        // pricing pass then GENERATES the column from 8 bytes per arc (row | sign) instead of streaming 24 + 8 bytes of it
+        bool unit = width == 2 && !getenv("RELP_NO_GENERATED_COLUMNS");
+        for (size_t e = 0; unit && e < value.size(); ++e) unit = value[e] == 1.0 || value[e] == -1.0;
+        for (int j = 0; unit && j < n; ++j) unit = cost2[j] == std::floor(cost2[j]) && std::fabs(cost2[j]) <= 127.0;
+        if (unit) {
+            for (int j = 0; j < n; ++j)
+                for (int k = 0; k < width; ++k) {
+                    const int len = col_start[j + 1] - col_start[j];
+                    er[(size_t)j * width + k] = k < len ? (int)((unsigned)row_index[col_start[j] + k] | (value[col_start[j] + k] < 0.0 ? 0x80000000u : 0u))
+                                                        : 0x7fffffff;
+                }
+            std::vector<signed char> c8(n);
+            for (int j = 0; j < n; ++j) c8[j] = (signed char)cost2[j];
+            d_.cost8 = dmalloc<signed char>(n);
+            d_.cost8_2 = dmalloc<signed char>(n);
+            upload_vec(d_.cost8_2, c8, stream_);
+        } else {
+            d_.ell_vals = dmalloc<double>(ev.size());
+            upload_vec(d_.ell_vals, ev, stream_);
+        }
         d_.ell_rows = dmalloc<int>(er.size());
-        d_.ell_vals = dmalloc<double>(ev.size());
         upload_vec(d_.ell_rows, er, stream_);
-        upload_vec(d_.ell_vals, ev, stream_);
         RELP_HIP(hipStreamSynchronize(stream_));
     }
     d_.alpha_part = dmalloc<double>((size_t)std::max(1, ftran_slices_) * m);
@@ -385,6 +404,7 @@ void Solver::upload() {
 
     stats_.price_bytes = (long long)(col_start[n] - col_start[sparse_first_]) * 12 + (long long)(n - n_art) * 24 +
                          (long long)n_dense * m * dense_entry_bytes_;  // upper bound: every dense column non-basic
+    if (d_.cost8) stats_.price_bytes = (long long)(n - n_art) * (8 + 1 + 4 + 8 + 8);  // endpoints, cost byte, pos, gamma read + write
     stats_.update_bytes = (long long)2 * m * m * 8;
     h_basis_.assign(m, -1);
     h_solution_.assign(md.nr_columns(), 0.0);
@@ -467,6 +487,10 @@ void Solver::set_phase(int phase) {
     const int phase_before = phase_;
     phase_ = phase;
     RELP_HIP(hipMemcpyAsync(d_.cost, phase == 1 ? d_.cost1 : d_.cost2, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    if (d_.cost8) {  // generated columns: the priced columns (never the artificials) cost 0 in phase one
+        if (phase == 1) RELP_HIP(hipMemsetAsync(d_.cost8, 0, d_.n, stream_));
+        else RELP_HIP(hipMemcpyAsync(d_.cost8, d_.cost8_2, d_.n, hipMemcpyDeviceToDevice, stream_));
+    }
     if (lu_mode_) launch_lu_pi(d_, lu_.device(), stream_);
     else launch_pi(d_, stream_);
     // Steepest-edge weights gamma_j = 1 + |B^-1 a_j|^2 do not depend on the costs, and the recurrences that maintain them

@@ -111,6 +111,10 @@ struct DeviceLP {
     int* ell_rows = nullptr;
     double* prw = nullptr;       // ell_w == 2: (-pi_r, rho_r, w_r, 0) packed per row, kept beside the three vectors by their writers
     double* ell_vals = nullptr;
+    // generated incidence columns (ell_w == 2, every value +-1, integer costs in [-127, 127]): ell_rows carries the sign in
+    // bit 31 (0x7fffffff: no entry), ell_vals is not allocated, and pricing reads the cost as a signed byte
+    signed char* cost8 = nullptr;   // current phase (n)
+    signed char* cost8_2 = nullptr; // phase two (phase one: zeros on every priced column)
     // Implicit upper bounds (relp_options.implicit_bounds): the `VariableBound` / `SlackBound` rows of `MatrixData`
     // (matrix_data.rs:104-112: x_j + s = u_j) are not rows of the device LP; a variable at its upper bound is held in
     // complemented form x_j = u_j - x'_j, so every non-basic variable sits at zero and pricing is unchanged up to the
