@@ -92,7 +92,11 @@ typedef struct relp_options {
     double lu_pivot_threshold; /* LU carry: relative pivot tolerance of the Markowitz factorisation (f64 needs one, the exact
                                   reference does not); 0 = 0.1 */
     int32_t ratio_rule;        /* relp_ratio_rule */
-    int32_t reserved;
+    int32_t crash;             /* 1: phase one starts from a triangular crash basis instead of one artificial per row without a
+                                  slack pivot (an extension; the reference has none, kind/artificial/partially.rs:125-205):
+                                  columns with a single entry in the rows still on an artificial are assigned breadth first
+                                  -- a spanning forest on the graph providers -- and the crash is kept when it is primal
+                                  feasible.  Same optimum, different (much shorter) pivot sequence; explicit carry only */
 } relp_options;
 
 typedef struct relp_result {

@@ -33,7 +33,7 @@ class Options(C.Structure):
                 ("tol_pivot", C.c_double), ("harris_delta", C.c_double), ("tol_feasible", C.c_double),
                 ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("implicit_bounds", C.c_int32),
                 ("carry", C.c_int32), ("refactor_period", C.c_int32), ("lu_pivot_threshold", C.c_double),
-                ("ratio_rule", C.c_int32), ("reserved", C.c_int32)]
+                ("ratio_rule", C.c_int32), ("crash", C.c_int32)]
 
 
 class Result(C.Structure):

@@ -71,6 +71,7 @@ int32_t relp_options_default(relp_options* o) {
     o->refactor_period = 0;
     o->lu_pivot_threshold = 0.0;
     o->ratio_rule = RELP_RATIO_HARRIS;
+    o->crash = 0;
     return RELP_OK;
 }
 

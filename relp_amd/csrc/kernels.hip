@@ -96,7 +96,9 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                 v0 = lp.ell_vals[(size_t)j * LPC + sub];
                 cost_j = lp.cost[j];
             }
-            if (RULE == RELP_PIVOT_STEEPEST_EDGE) g_j = lp.gamma[j];
+            // (generated columns: the weight is fetched only by the columns that need it -- candidates and columns with an
+            //  entry in the pivot row -- 16 of the 29 bytes per arc otherwise)
+            if (RULE == RELP_PIVOT_STEEPEST_EDGE && !UNIT) g_j = lp.gamma[j];
         }
     };
     load_column(base + g);
@@ -187,9 +189,13 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
             }
         }
         int improved = 0;
-        if (sub == 0 && nonbasic) {
+        const double cbar = sgn_j * (cost_j + d_pi);
+        // a weight with no entry in the pivot row does not change (gamma - 0 + 0, and gamma >= 1): not read, not written
+        const bool weight_changes = RULE == RELP_PIVOT_STEEPEST_EDGE && pending && (!UNIT || j == leaving || d_rho != 0.0);
+        if (sub == 0 && nonbasic && (!UNIT || weight_changes || cbar < -tol_dual)) {
             double gam = g_j;
-            if (RULE == RELP_PIVOT_STEEPEST_EDGE && pending) {
+            if (UNIT && RULE == RELP_PIVOT_STEEPEST_EDGE) gam = lp.gamma[j];
+            if (weight_changes) {
                 if (j == leaving) {
                     gam = gamma_q / (alpha_pq * alpha_pq);  // pivot_rule.rs:294-295
                 } else {
@@ -199,7 +205,6 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                 }
                 lp.gamma[j] = gam;
             }
-            const double cbar = sgn_j * (cost_j + d_pi);
             bool candidate = cbar < -tol_dual;
             Cand c;
             c.idx = j;
@@ -2232,46 +2237,110 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
 // Phase set-up
 // ---------------------------------------------------------------------------------------------------
 // -pi_j = -sum_i c_{basis[i]} Binv(i, j)   (Carry::create_minus_pi_from_artificial, carry/mod.rs:226-260: the reference
-// forms all of B^-1 with m FTRANs; here B^-1 is resident).  One wave per column j (contiguous).
-// Block 0 also recomputes -obj = -sum_i xB_i c_{basis[i]} (carry/mod.rs:270-283).
+// forms all of B^-1 with m FTRANs; here B^-1 is resident).  Three kernels:
+//   cb_kernel         c_B once (the costs of the basic columns, complemented ones negated) and the ORDERED list of its
+//                     non-zeros; also -obj = -sum_i xB_i c_{basis[i]} (carry/mod.rs:270-283)
+//   pi_kernel         one wave per column j of the inverse (contiguous), c_B streamed beside it
+//   pi_sparse_kernel  when c_B has few non-zeros (max-flow: only the arcs leaving s cost anything): one THREAD per column
+//                     gathers those rows -- k cache lines per column instead of the whole column (34 GB at m = 65 534)
+constexpr int CB_THREADS = 1024;
+__global__ void __launch_bounds__(CB_THREADS) cb_kernel(DeviceLP lp) {
+    __shared__ double s_red[CB_THREADS / WAVE + 2];
+    __shared__ int s_wave_count[CB_THREADS / WAVE];
+    __shared__ int s_base;
+    const int m = lp.m;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    double acc = 0.0;
+    for (int i0 = 0; i0 < m; i0 += CB_THREADS) {
+        const int i = i0 + threadIdx.x;
+        double c = 0.0;
+        if (i < m) {
+            const int bj = lp.basis[i];
+            c = (lp.flipped && lp.flipped[bj]) ? -lp.cost[bj] : lp.cost[bj];
+            lp.cb[i] = c;
+            acc += lp.xB[i] * c;
+        }
+        const unsigned long long mask = __ballot(c != 0.0);
+        if (lane == 0) s_wave_count[wave] = __popcll(mask);
+        __syncthreads();
+        int before = s_base;
+        for (int w2 = 0; w2 < wave; ++w2) before += s_wave_count[w2];
+        if (c != 0.0) lp.cb_idx[before + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = s_base;
+            for (int w2 = 0; w2 < CB_THREADS / WAVE; ++w2) total += s_wave_count[w2];
+            s_base = total;
+        }
+        __syncthreads();
+    }
+    if (lp.flipped)  // constant of the complemented variables: sum ub_j c_j
+        for (int j = threadIdx.x; j < lp.n; j += CB_THREADS)
+            if (lp.flipped[j]) acc += lp.ub[j] * lp.cost[j];
+    acc = block_reduce<0>(acc, s_red);
+    if (threadIdx.x == 0) {
+        lp.ctl->minus_obj = -acc;
+        lp.cb_idx[m] = s_base;  // number of non-zeros of c_B
+    }
+}
+__device__ __forceinline__ bool pi_takes_sparse_path(int k, int m) { return k * 16 <= m && k <= 4096; }
 __global__ void __launch_bounds__(256) pi_kernel(DeviceLP lp) {
-    __shared__ double s_red[6];
     const int m = lp.m, ld = lp.ld;
+    if (pi_takes_sparse_path(lp.cb_idx[m], m)) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const int j = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    if (j < m && lp.track_touched && lp.eta_cap == 0 && !lp.touched[j]) {  // stored column j is still the unit vector e_j
+    if (j >= m) return;
+    if (lp.track_touched && lp.eta_cap == 0 && !lp.touched[j]) {  // stored column j is still the unit vector e_j
         if (lane == LAST) {
-            const int bj = lp.basis[j];
-            const double v = (lp.flipped && lp.flipped[bj]) ? lp.cost[bj] : -lp.cost[bj];
+            const double v = -lp.cb[j];
             lp.minus_pi[j] = v;
             if (lp.prw) lp.prw[(size_t)4 * j] = v;
         }
-    } else if (j < m) {
-        const double* col = lp.Binv + (size_t)j * ld;
-        double acc = 0.0;
-        for (int i = lane; i < m; i += WAVE) {
-            const int bj = lp.basis[i];
-            const double c = (lp.flipped && lp.flipped[bj]) ? -lp.cost[bj] : lp.cost[bj];
-            if (c != 0.0) acc += c * col[i];
-        }
-        acc = wave_sum(acc);
-        if (lane == LAST) {
-            lp.minus_pi[j] = -acc;
-            if (lp.prw) lp.prw[(size_t)4 * j] = -acc;
-        }
+        return;
     }
-    if (blockIdx.x == 0) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) {
-            const int bj = lp.basis[i];
-            acc += lp.xB[i] * ((lp.flipped && lp.flipped[bj]) ? -lp.cost[bj] : lp.cost[bj]);
-        }
-        if (lp.flipped)  // constant of the complemented variables: sum ub_j c_j
-            for (int j = threadIdx.x; j < lp.n; j += blockDim.x)
-                if (lp.flipped[j]) acc += lp.ub[j] * lp.cost[j];
-        acc = block_reduce<0>(acc, s_red);
-        if (threadIdx.x == 0) lp.ctl->minus_obj = -acc;
+    const double* col = lp.Binv + (size_t)j * ld;
+    double acc = 0.0;
+    int i = lane;
+    for (; i + 3 * WAVE < m; i += 4 * WAVE) {  // four independent loads of the column in flight
+        const double t0 = col[i], t1 = col[i + WAVE], t2 = col[i + 2 * WAVE], t3 = col[i + 3 * WAVE];
+        const double c0 = lp.cb[i], c1 = lp.cb[i + WAVE], c2 = lp.cb[i + 2 * WAVE], c3 = lp.cb[i + 3 * WAVE];
+        acc += c0 * t0;
+        acc += c1 * t1;
+        acc += c2 * t2;
+        acc += c3 * t3;
     }
+    for (; i < m; i += WAVE) acc += lp.cb[i] * col[i];
+    acc = wave_sum(acc);
+    if (lane == LAST) {
+        lp.minus_pi[j] = -acc;
+        if (lp.prw) lp.prw[(size_t)4 * j] = -acc;
+    }
+}
+__global__ void __launch_bounds__(256) pi_sparse_kernel(DeviceLP lp) {
+    const int m = lp.m, ld = lp.ld;
+    const int k = lp.cb_idx[m];
+    if (!pi_takes_sparse_path(k, m)) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const double* col = lp.Binv + (size_t)j * ld;
+    double acc = 0.0;
+    int t = 0;
+    for (; t + 3 < k; t += 4) {
+        const int i0 = lp.cb_idx[t], i1 = lp.cb_idx[t + 1], i2 = lp.cb_idx[t + 2], i3 = lp.cb_idx[t + 3];
+        const double v0 = col[i0], v1 = col[i1], v2 = col[i2], v3 = col[i3];
+        acc += lp.cb[i0] * v0;
+        acc += lp.cb[i1] * v1;
+        acc += lp.cb[i2] * v2;
+        acc += lp.cb[i3] * v3;
+    }
+    for (; t < k; ++t) {
+        const int i = lp.cb_idx[t];
+        acc += lp.cb[i] * col[i];
+    }
+    lp.minus_pi[j] = -acc;
+    if (lp.prw) lp.prw[(size_t)4 * j] = -acc;
 }
 
 // xB = Binv rhs  (Carry::from_basis, carry/mod.rs:452-463): xB_i = sum_j T[j*ld+i] rhs_j.  A workgroup owns 64 rows;
@@ -2709,7 +2778,9 @@ void launch_budget(const DeviceLP& d, long long add, hipStream_t s) {
 }
 
 void launch_pi(const DeviceLP& d, hipStream_t s) {
-    hipLaunchKernelGGL(pi_kernel, dim3((d.m + 3) / 4), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(cb_kernel, dim3(1), dim3(CB_THREADS), 0, s, d);
+    hipLaunchKernelGGL(pi_kernel, dim3((d.m + 3) / 4), dim3(256), 0, s, d);       // (one of the two returns at once:
+    hipLaunchKernelGGL(pi_sparse_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d);  //  decided on the device by nnz(c_B))
 }
 void launch_xb(const DeviceLP& d, hipStream_t s) {
     hipLaunchKernelGGL(xb_kernel, dim3((d.m + WAVE - 1) / WAVE), dim3(256), 0, s, d);
@@ -2719,6 +2790,15 @@ void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s) {
 }
 void launch_identity(double* X, int m, int ld, hipStream_t s) {
     hipLaunchKernelGGL(identity_kernel, dim3((m + 255) / 256, std::min(m, 65535)), dim3(256), 0, s, X, m, ld);
+}
+__global__ void __launch_bounds__(256) scatter_kernel(double* X, const long long* index, const double* value, long long count) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += stride) X[index[e]] = value[e];
+}
+// sparse entries into a resident matrix (the crash basis' inverse into the identity)
+void launch_scatter(double* X, const long long* index, const double* value, long long count, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)std::min<long long>(4096, (count + 255) / 256)), dim3(256), 0, s, X, index, value, count);
 }
 void launch_residual(const DeviceLP& d, const double* T, double* S, hipStream_t s) {
     hipLaunchKernelGGL(residual_kernel, dim3(d.m), dim3(256), 0, s, d, T, S);

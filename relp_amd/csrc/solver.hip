@@ -32,6 +32,7 @@ void launch_pi(const DeviceLP& d, hipStream_t s);
 void launch_xb(const DeviceLP& d, hipStream_t s);
 void launch_gamma_init(const DeviceLP& d, int identity, hipStream_t s);
 void launch_identity(double* X, int m, int ld, hipStream_t s);
+void launch_scatter(double* X, const long long* index, const double* value, long long count, hipStream_t s);
 void launch_residual(const DeviceLP& d, const double* X, double* R, hipStream_t s);
 void launch_gemm_polish(const double* X, const double* R, double* C, int m, int ld, const int* row_list, int n_rows, hipStream_t s);
 void launch_residual_dense(const DeviceLP& d, double* Bd, const double* T, double* S, const int* row_list, int n_rows, hipStream_t s);
@@ -99,7 +100,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -245,6 +246,8 @@ void Solver::upload() {
     d_.basis = dmalloc<int>(m);
     d_.pos = dmalloc<int>(n);
     d_.gamma = dmalloc<double>(n);
+    d_.cb = dmalloc<double>(m);
+    d_.cb_idx = dmalloc<int>(m + 1);
     tick("sparse arrays");
     if (!lu_mode_) d_.Binv = dmalloc<double>((size_t)m * d_.ld);  // the LU carry has no m x m array at all
     // The second copy of the inverse and the residual matrix are only needed once a polish finds something to correct
@@ -404,14 +407,15 @@ void Solver::upload() {
 
     stats_.price_bytes = (long long)(col_start[n] - col_start[sparse_first_]) * 12 + (long long)(n - n_art) * 24 +
                          (long long)n_dense * m * dense_entry_bytes_;  // upper bound: every dense column non-basic
-    if (d_.cost8) stats_.price_bytes = (long long)(n - n_art) * (8 + 1 + 4 + 8 + 8);  // endpoints, cost byte, pos, gamma read + write
+    if (d_.cost8) stats_.price_bytes = (long long)(n - n_art) * (8 + 1 + 4);  // endpoints, cost byte, pos (+ the weight of the few columns that need it)
     stats_.update_bytes = (long long)2 * m * m * 8;
     h_basis_.assign(m, -1);
     h_solution_.assign(md.nr_columns(), 0.0);
-    if (lu_mode_) {
+    if (lu_mode_ || opt_.crash) {
         h_col_start_ = col_start;
         h_row_index_ = row_index;
         h_value_ = value;
+        h_rhs_ = rhs;
     }
 }
 
@@ -476,7 +480,205 @@ void Solver::begin_phase_one() {
     since_polish_ = 0;
     polish_scale_ = 1;
     redundant_rows_.clear();
+    gamma_ready_ = false;
+    if (opt_.crash && n_art > 0) crash_basis();
     set_phase(n_art > 0 ? 1 : 2);
+}
+
+
+// Triangular crash basis (relp_options.crash; an EXTENSION: the reference starts every row without a slack pivot on an
+// artificial, partially.rs:125-205, and on the max-flow LP of examples/max_flow.rs pivots all V - 2 of them out one
+// degenerate pivot at a time).  Columns that have exactly ONE entry in the rows still covered by an artificial are assigned to
+// that row, breadth first -- on an incidence matrix that is a spanning forest grown from s and t.  The basis is triangular
+// by construction, so its inverse comes from sparse back-substitution on the host (no factorisation) and is scattered into
+// the identity that `begin_phase_one` has just written; x_B, the touched-column list and the steepest-edge weights
+// gamma_j = 1 + |B^-1 a_j|^2 (pivot_rule.rs:202-219) are computed from the same sparse columns.  The crash is only kept when
+// it is primal feasible; phase one then starts from it (with zero artificials left it ends without a pivot).
+bool Solver::crash_basis() {
+    if (lu_mode_ || eta_mode_ || d_.n_dense > 0 || h_col_start_.empty()) return false;
+    const int m = d_.m, n = d_.n, n_art = d_.n_art;
+    std::vector<int> basis(m);
+    RELP_HIP(hipMemcpyAsync(basis.data(), d_.basis, m * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    const std::vector<int>& cs = h_col_start_;
+    const std::vector<int>& ri = h_row_index_;
+    const std::vector<double>& va = h_value_;
+    std::vector<char> uncovered(m, 0);
+    for (int i = 0; i < m; ++i) uncovered[i] = basis[i] < n_art ? 1 : 0;
+    // rows -> structural columns (only the uncovered rows matter)
+    std::vector<int> row_start(m + 1, 0);
+    for (int j = n_art; j < n; ++j)
+        for (int e = cs[j]; e < cs[j + 1]; ++e)
+            if (uncovered[ri[e]]) row_start[ri[e] + 1]++;
+    for (int i = 0; i < m; ++i) row_start[i + 1] += row_start[i];
+    std::vector<int> row_cols(row_start[m]), fill(row_start.begin(), row_start.end() - 1);
+    std::vector<int> count(n, 0);
+    for (int j = n_art; j < n; ++j)
+        for (int e = cs[j]; e < cs[j + 1]; ++e)
+            if (uncovered[ri[e]]) {
+                row_cols[fill[ri[e]]++] = j;
+                count[j]++;
+            }
+    std::vector<int> queue;
+    queue.reserve(n - n_art);
+    std::vector<char> is_basic(n, 0);
+    for (int i = 0; i < m; ++i) is_basic[basis[i]] = 1;
+    for (int j = n_art; j < n; ++j)
+        if (count[j] == 1 && !is_basic[j] && !(bounded_ && zero_width_[j])) queue.push_back(j);
+    std::vector<int> order_of_row(m, -1), crash_rows;  // order in which the rows were covered
+    std::vector<double> diagonal(m, 1.0);
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const int j = queue[head];
+        if (count[j] != 1 || is_basic[j]) continue;
+        int r = -1;
+        double pivot = 0.0, largest = 0.0;
+        for (int e = cs[j]; e < cs[j + 1]; ++e) {
+            largest = std::max(largest, std::fabs(va[e]));
+            if (uncovered[ri[e]]) { r = ri[e]; pivot = va[e]; }
+        }
+        if (r < 0 || std::fabs(pivot) < 0.1 * largest) continue;  // (a small diagonal would make the triangular basis ill conditioned)
+        is_basic[basis[r]] = 0;
+        basis[r] = j;
+        is_basic[j] = 1;
+        uncovered[r] = 0;
+        order_of_row[r] = (int)crash_rows.size();
+        crash_rows.push_back(r);
+        diagonal[r] = pivot;
+        for (int e = row_start[r]; e < row_start[r + 1]; ++e) {
+            const int j2 = row_cols[e];
+            if (--count[j2] == 1 && !is_basic[j2] && !(bounded_ && zero_width_[j2])) queue.push_back(j2);
+        }
+    }
+    const int covered = (int)crash_rows.size();
+    if (covered == 0) return false;
+    // Inverse by back-substitution: B (rows x positions, position of a crash column = its row) is upper triangular in the
+    // order [rows that kept a unit column | crash rows in covering order].  Column r of B^-1 (r a crash row) solves B v = e_r.
+    const size_t entry_cap = (size_t)64 * m + (1u << 22);
+    std::vector<size_t> inv_start(covered + 1, 0);
+    std::vector<int> inv_pos;
+    std::vector<double> inv_val;
+    std::vector<double> work(m, 0.0);
+    std::vector<char> in_heap(m, 0);
+    std::vector<std::pair<int, int>> heap;  // (covering order, row): max-heap
+    for (int k = 0; k < covered; ++k) {
+        const int r = crash_rows[k];
+        work[r] = 1.0;
+        heap.clear();
+        heap.push_back({k, r});
+        in_heap[r] = 1;
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end());
+            const int row = heap.back().second;
+            heap.pop_back();
+            in_heap[row] = 0;
+            const double residual = work[row];
+            work[row] = 0.0;
+            if (residual == 0.0) continue;
+            const double v = residual / diagonal[row];
+            inv_pos.push_back(row);
+            inv_val.push_back(v);
+            if (order_of_row[row] < 0) continue;  // a unit column: nothing to propagate
+            const int j = basis[row];
+            for (int e = cs[j]; e < cs[j + 1]; ++e) {
+                const int r2 = ri[e];
+                if (r2 == row) continue;
+                work[r2] -= va[e] * v;
+                if (!in_heap[r2]) {
+                    in_heap[r2] = 1;
+                    heap.push_back({order_of_row[r2], r2});
+                    std::push_heap(heap.begin(), heap.end());
+                }
+            }
+        }
+        inv_start[k + 1] = inv_pos.size();
+        if (inv_pos.size() > entry_cap) return false;  // not a sparse inverse: leave the start to phase one
+    }
+    // x_B = B^-1 b, must be a basic feasible solution of the phase-one problem
+    std::vector<double> xb(m, 0.0);
+    for (int i = 0; i < m; ++i)
+        if (order_of_row[i] < 0) xb[i] = h_rhs_[i];
+    for (int k = 0; k < covered; ++k) {
+        const double b = h_rhs_[crash_rows[k]];
+        if (b == 0.0) continue;
+        for (size_t e = inv_start[k]; e < inv_start[k + 1]; ++e) xb[inv_pos[e]] += inv_val[e] * b;
+    }
+    std::vector<double> ub;
+    if (bounded_) {
+        ub.resize(n);
+        RELP_HIP(hipMemcpyAsync(ub.data(), d_.ub, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
+    double scale = 1.0;
+    for (int i = 0; i < m; ++i) scale = std::max(scale, std::fabs(h_rhs_[i]));
+    for (int i = 0; i < m; ++i) {
+        if (xb[i] < -1e-9 * scale) return false;
+        if (bounded_ && xb[i] > ub[basis[i]] + 1e-9 * scale) return false;
+        if (xb[i] < 0.0) xb[i] = 0.0;
+    }
+    // steepest-edge weights of the non-basic columns from the sparse inverse columns
+    std::vector<double> gamma(n, 1.0);
+    if (opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE) {
+        std::vector<int> touched_list, mark(m, -1);
+        auto add = [&](int p, double v, int j) {
+            if (mark[p] != j) {
+                mark[p] = j;
+                work[p] = 0.0;
+                touched_list.push_back(p);
+            }
+            work[p] += v;
+        };
+        for (int j = n_art; j < n; ++j) {
+            if (is_basic[j]) continue;
+            touched_list.clear();
+            for (int e = cs[j]; e < cs[j + 1]; ++e) {
+                const int r = ri[e], k = order_of_row[r];
+                if (k < 0) add(r, va[e], j);
+                else
+                    for (size_t t = inv_start[k]; t < inv_start[k + 1]; ++t) add(inv_pos[t], va[e] * inv_val[t], j);
+            }
+            double sum = 1.0;
+            for (int p : touched_list) sum += work[p] * work[p];
+            gamma[j] = sum;
+        }
+        std::fill(work.begin(), work.end(), 0.0);
+    }
+    // ---- device state -------------------------------------------------------------------------------------------
+    std::vector<long long> scatter_index(inv_pos.size());
+    for (int k = 0; k < covered; ++k)
+        for (size_t e = inv_start[k]; e < inv_start[k + 1]; ++e) scatter_index[e] = (long long)crash_rows[k] * d_.ld + inv_pos[e];
+    long long* d_index = nullptr;
+    double* d_value = nullptr;
+    RELP_HIP(hipMalloc(reinterpret_cast<void**>(&d_index), scatter_index.size() * sizeof(long long)));
+    RELP_HIP(hipMalloc(reinterpret_cast<void**>(&d_value), inv_val.size() * sizeof(double)));
+    RELP_HIP(hipMemcpyAsync(d_index, scatter_index.data(), scatter_index.size() * sizeof(long long), hipMemcpyHostToDevice, stream_));
+    RELP_HIP(hipMemcpyAsync(d_value, inv_val.data(), inv_val.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_scatter(d_.Binv, d_index, d_value, (long long)inv_val.size(), stream_);
+    std::vector<int> pos(n, -1), touched(m, 0);
+    if (bounded_)
+        for (int j = n_art; j < n; ++j)
+            if (zero_width_[j]) pos[j] = -3;
+    for (int i = 0; i < m; ++i) pos[basis[i]] = i;
+    for (int r : crash_rows) touched[r] = 1;
+    upload_vec(d_.basis, basis, stream_);
+    upload_vec(d_.pos, pos, stream_);
+    upload_vec(d_.xB, xb, stream_);
+    upload_vec(d_.gamma, gamma, stream_);
+    upload_vec(d_.touched, touched, stream_);
+    upload_vec(d_.tlist, crash_rows, stream_);
+    if (bounded_) {
+        std::vector<double> xub(m);
+        for (int i = 0; i < m; ++i) xub[i] = ub[basis[i]];
+        upload_vec(d_.xub, xub, stream_);
+    }
+    Ctl c = read_ctl();  // (also waits for the uploads)
+    c.touched_count = covered;
+    write_ctl(c);
+    (void)hipFree(d_index);
+    (void)hipFree(d_value);
+    binv_identity_ = false;
+    gamma_ready_ = opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE;
+    crash_rows_covered_ = covered;
+    return true;
 }
 
 // `Tableau::from_artificial` (non_artificial.rs:99-120): same basis, provider costs; -pi, -obj and the weights are
@@ -511,6 +713,8 @@ void Solver::set_phase(int phase) {
                 enqueue_price(0);  // applies the pending Goldfarb-Reid update; its candidates are discarded
                 RELP_HIP(hipMemcpyAsync(d_.cost, d_.cost2, d_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
             }
+        } else if (gamma_ready_) {
+            gamma_ready_ = false;  // the crash computed them on the host from its sparse inverse
         } else if (lu_mode_ && !binv_identity_) {
             launch_lu_gamma(d_, lu_.device(), stream_);
         } else {
@@ -618,11 +822,14 @@ void Solver::build_graph(int count) {
 }
 
 // Newton-Schulz polish (see kernels.hip).  Two iterations at most; the residual before the polish is recorded.
-void Solver::polish(bool refresh_vectors) {
+void Solver::polish(bool refresh_vectors, bool force) {
     if (lu_mode_) {  // the LU carry's refresh is a refactorisation
         refactor_lu(refresh_vectors);
         return;
     }
+    // nothing has changed since the inverse was last made exact (identity, crash basis, set_basis, the previous polish): at
+    // m = 65 534 the residual pass and the two refresh passes are 34 GB each
+    if (since_polish_ == 0 && !force && !getenv("RELP_POLISH_ALWAYS")) return;
     const int m = d_.m;
     // dense pipeline: only the columns of the stored inverse that are not unit vectors take part (the corresponding
     // rows of S are zero and those columns of the polished inverse do not change): both GEMMs shrink by m / touched
@@ -1301,7 +1508,7 @@ double Solver::refactor() {
     if (phase_ == 0) throw std::runtime_error("no phase started");
     const double before = max_residual_;
     max_residual_ = 0.0;
-    polish(true);
+    polish(true, true);
     const double found = max_residual_;
     max_residual_ = std::max(before, found);
     return found;
@@ -1347,6 +1554,9 @@ double Solver::profile_kernel(int which, int repetitions) {
     }
     arm_launch_timer(-1, nullptr, nullptr);
     Ctl after = read_ctl();
+    // K3's algorithmic bytes at the profiled state when unit columns are skipped: read + write of (non-zero rows of alpha) x
+    // (columns of the stored inverse that carry information)
+    if (d_.track_touched && !eta_mode_) stats_.update_bytes = 16LL * std::max(1, after.nz_count) * std::max(1, after.touched_count);
     if (after.status == ST_REFACTOR) refactor_lu(true);
     const long long made = after.iters - before.iters;
     pivots_[phase_ - 1] += made;

@@ -92,6 +92,8 @@ struct DeviceLP {
     int* pos = nullptr;          // column -> row (the Tableau's basis_columns set) (n); non-basic: -1 at 0 | -2 at its upper bound
                                  // (held complemented) | -3 fixed, both bounds coincide: never priced (implicit bounds)
     double* gamma = nullptr;     // steepest-edge weights (n)
+    double* cb = nullptr;        // c_B (m): costs of the basic columns, written by cb_kernel for the -pi refresh
+    int* cb_idx = nullptr;       // (m + 1) ordered non-zero positions of c_B; [m] = their number
     double* Binv = nullptr;      // explicit basis inverse, COLUMN-major: Binv(i, j) at [j*ld + i]
     double* Binv2 = nullptr;     // second buffer for the polish
     double* R = nullptr;         // residual I - B Binv
@@ -185,7 +187,7 @@ private:
     void enqueue_update();
     void enqueue_consolidate();
     void build_graph(int count);
-    void polish(bool refresh_vectors);
+    void polish(bool refresh_vectors, bool force = false);
     void invert_from_scratch();
     std::vector<int> explicit_basis(const std::vector<int>& basis, const std::vector<int>& pos) const;  // implicit bounds -> basis of the reference's formulation
     void resolve_fixed_columns(std::vector<int>& pos);
@@ -208,7 +210,10 @@ private:
     long long refactors_ = 0;
     double refactor_seconds_ = 0.0;
     std::vector<int> h_col_start_, h_row_index_;  // host copy of the device CSC (basis columns for the refactorisation)
-    std::vector<double> h_value_;
+    std::vector<double> h_value_, h_rhs_;
+    bool crash_basis();           // relp_options.crash: triangular crash basis as the start of phase one
+    bool gamma_ready_ = false;    // the next set_phase keeps the uploaded steepest-edge weights
+    int crash_rows_covered_ = 0;
 
     relp_options opt_;
     StandardForm form_;

@@ -247,6 +247,62 @@ def test_gpu_shortest_path_12k_vertices_matches_dijkstra():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("implicit", [0, 1], ids=["bound-rows", "implicit-bounds"])
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_crash_basis_same_exact_optimum_on_random_graphs(seed, implicit):
+    """`relp_options.crash`: the spanning-forest start must not change what is reported -- the certified exact optimum of
+    the oracle -- and on a max-flow LP (b = 0 on every conservation row) it leaves nothing to do for phase one."""
+    rng = random.Random(900 + seed)
+    nr_vertices = rng.randint(6, 14)
+    arcs = random_graph(rng, nr_vertices, rng.randint(nr_vertices + 4, 3 * nr_vertices), 20)
+    s, t = 0, nr_vertices - 1
+    for provider, model, is_flow in ((MaxFlowPrimal(arcs, s, t), relp_amd.Model.max_flow(nr_vertices, arc_list(arcs), s, t), True),
+                                     (ShortestPathPrimal(arcs, s, t), relp_amd.Model.shortest_path(nr_vertices, arc_list(arcs), s, t), False)):
+        exact = solve_relaxation(provider)
+        solver = relp_amd.Solver(certify=1, crash=1, implicit_bounds=implicit).load_model(model)
+        plain = relp_amd.Solver(certify=1, implicit_bounds=implicit).load_model(model)
+        result, reference = solver.solve_relaxation(), plain.solve_relaxation()
+        assert result.kind == reference.kind
+        if isinstance(exact, FiniteOptimum):
+            assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified
+            assert Fraction(solver.objective_exact()) == exact.objective
+            if is_flow:
+                assert result.pivots_phase_one <= reference.pivots_phase_one
+        else:
+            assert result.kind == relp_amd.INFEASIBLE
+        solver.close()
+        plain.close()
+
+
+@pytest.mark.gpu
+def test_gpu_crash_basis_and_generated_columns_131k_arcs():
+    """V = 16 384, E ~ 131 000 with the crash basis: every conservation row is covered by a tree arc, phase one makes no
+    pivot, the pricing pass generates the incidence columns from the arcs' endpoints, and the optimum is scipy's."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices = 16384
+    tail, head, capacity = max_flow_graph(nr_vertices, 131072)
+    keep = (head != 0) & (tail != nr_vertices - 1)
+    tail, head, capacity = tail[keep], head[keep], capacity[keep]
+    graph = csr_matrix((capacity.astype(np.int32), (tail, head)), shape=(nr_vertices, nr_vertices))
+    expected = maximum_flow(graph, 0, nr_vertices - 1).flow_value
+    model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+    solver = relp_amd.Solver(implicit_bounds=1, crash=1).load_model(model)
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert abs(result.objective + expected) <= 1e-9 * max(1.0, abs(expected))
+    assert result.pivots_phase_one == 0
+    flow = solver.solution()
+    assert np.all(flow >= -1e-9) and np.all(flow <= capacity + 1e-9)
+    net = np.zeros(nr_vertices)
+    np.add.at(net, head, flow)
+    np.subtract.at(net, tail, flow)
+    assert np.max(np.abs(net[1:-1])) <= 1e-7
+    solver.close()
+
+
+@pytest.mark.gpu
 def test_gpu_max_flow_config5_full_size():
     """BASELINE configs[4] at its stated size: V = 65 536, E = 1 048 576 (splitmix64 seed 0x5EED0005).  The capacity rows are
     implicit bounds (65 534 conservation rows on the device); the optimum equals scipy's max-flow value, every flow respects
@@ -278,6 +334,19 @@ def test_gpu_max_flow_config5_full_size():
     # the max-flow value (arcs into s or out of t carry nothing useful at the optimum)
     assert abs(result.objective + expected) <= 1e-9 * expected
     assert result.solve_seconds < 30
+    solver.close()
+    # the same LP from the crash basis (spanning forest grown from s and t): no phase-one pivot, same optimum
+    solver = relp_amd.Solver(implicit_bounds=1, crash=1).load_model(model)
+    crashed = solver.solve_relaxation()
+    assert crashed.kind == relp_amd.FINITE_OPTIMUM and crashed.pivots_phase_one == 0
+    assert abs(crashed.objective + expected) <= 1e-9 * expected
+    flow = solver.solution()
+    assert np.all(flow >= -1e-9) and np.all(flow <= c_sorted + 1e-9)
+    net = np.zeros(nr_vertices)
+    np.add.at(net, h_sorted, flow)
+    np.subtract.at(net, t_sorted, flow)
+    assert np.max(np.abs(net[1:-1])) <= 1e-6
+    assert crashed.solve_seconds < result.solve_seconds
     solver.close()
 
 

@@ -16,7 +16,7 @@ for nr_vertices, nr_arcs in sizes:
     t0 = time.time()
     model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
     t1 = time.time()
-    solver = relp_amd.Solver(certify=0, implicit_bounds=int(os.environ.get("RELP_IMPLICIT_BOUNDS", "0")), use_graph=int(os.environ.get("RELP_GRAPH", "1"))).load_model(model)
+    solver = relp_amd.Solver(certify=0, implicit_bounds=int(os.environ.get("RELP_IMPLICIT_BOUNDS", "0")), use_graph=int(os.environ.get("RELP_GRAPH", "1")), crash=int(os.environ.get("RELP_CRASH", "0"))).load_model(model)
     t2 = time.time()
     r = solver.solve_relaxation()
     t3 = time.time()
