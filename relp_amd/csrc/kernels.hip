@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
                 b = lp.col_start[j + 1];
             }
             if (UNIT) {
-                const unsigned code = (unsigned)lp.ell_rows[(size_t)j * LPC + sub];
+                const unsigned code = (unsigned)lp.ell_rows[(size_t)j * LPC + sub];  // (non-temporal loads of the three streams: measured, no gain)
                 const bool absent = code == 0x7fffffffu;
                 r0 = absent ? 0 : (int)(code & 0x7fffffffu);
                 v0 = absent ? 0.0 : ((code >> 31) ? -1.0 : 1.0);
