@@ -279,7 +279,10 @@ def netlib_batch(args, rank, local_rank, world, distributed):
             "config": {"workload": "Netlib batch (%d LPs), %s, independent LPs sharded over the GPUs" % (
                 len(names), "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
                        "lps_in_flight_per_gpu": max(1, args.concurrency),
-                       "problems_per_rank": [len(r) for r in gathered], "objectives_outside_reference_tolerance": wrong}})
+                       "problems_per_rank": [len(r) for r in gathered],
+                       "pivots_per_rank": [sum(entry[2] for entry in r) for r in gathered],
+                       "solve_seconds_per_rank": [sum(entry[3] for entry in r) for r in gathered],
+                       "makespan_s": elapsed, "objectives_outside_reference_tolerance": wrong}})
     if record_file is not None:
         with open(record_file if world == 1 else "%s.rank%d" % (record_file, rank), "w") as handle:
             for entry in lp_records:
@@ -364,6 +367,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - start
     from relp_amd import batch
+    # one record per rank (what each GPU did); the makespan is the max over ranks of the barrier-to-barrier time
+    per_rank = batch.gather_records({"rank": rank, "solves": args.steps, "pivots": int(pivots), "busy_seconds": loop_seconds + certify_seconds,
+                                     "elapsed_seconds": elapsed})
     elapsed, pivots = batch.aggregate(elapsed, pivots, device="cuda" if distributed else None)
 
     in_flight = None
@@ -416,7 +422,12 @@ def main():
         solver.profile_kernel(0, 10 if graph else 50)   # discarded: brings clocks and caches to the state of a running solve
         lu_carry = args.carry == 1 and not dense and not graph
         kernels = ["price", "lu_pivot"] if lu_carry else ["price", "ftran_ratio", "update"]
-        seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
+        try:
+            seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
+        except relp_amd.api.RelpError:
+            # m <= 1024: ratio test and inverse update are ONE launch (pivot_fused_kernel): two kernels per pivot
+            kernels = ["price", "pivot_fused"]
+            seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
         stats = solver.stats()
         # Algorithmic bytes per launch: pricing = the non-basic columns (exact, counted at the profiled
         # state); K2 = nnz(a_q) columns of the inverse + six m-vectors; K3 = read + write of the touched part of the inverse
@@ -426,7 +437,9 @@ def main():
         algorithmic = {"price": stats.price_bytes,
                        "ftran_ratio": int(mean_column * m_rows * 8 + 6 * m_rows * 8),
                        "update": stats.update_bytes,
-                       "lu_pivot": int(12 * m_rows * 8 + 2 * 12 * 3 * m_rows)}  # (factor entries: about 3 per row and triangle)
+                       "lu_pivot": int(12 * m_rows * 8 + 2 * 12 * 3 * m_rows),  # (factor entries: about 3 per row and triangle)
+                       # fused: one workgroup's FTRAN + ratio test, and ONE read + one write of the whole inverse (out of place)
+                       "pivot_fused": int(mean_column * m_rows * 8 + 6 * m_rows * 8 + 2 * m_rows * m_rows * 8)}
         per_kernel = {name: {"seconds_per_launch": seconds[name], "algorithmic_bytes_per_launch": algorithmic[name],
                              "achieved_gb_s": algorithmic[name] / seconds[name] / 1e9,
                              "frac": algorithmic[name] / seconds[name] / 1e9 / HBM_PEAK_GBS,
@@ -438,7 +451,7 @@ def main():
         # section HBM); null when not collected for this kernel
         traffic = None
         pmc_names = {"price": "price_dense_kernel" if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
-                     "lu_pivot": "lu_pivot_kernel"}
+                     "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
         for candidate in ("r2_%s_pmc_traffic.json" % args.workload, "r1_%s_pmc_traffic.json" % args.workload):
             pmc = os.path.join(ROOT, "profiles", candidate)
             if traffic is None and os.path.exists(pmc):
@@ -474,7 +487,8 @@ def main():
                        "pivots_per_s_f64_loop_only": pivots / world / loop_seconds if loop_seconds > 0 else None,
                        "carry": "lu" if args.carry == 1 else "explicit", "refactors": int(last.refactors),
                        "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
-                       "parallelism": "1 LP per GPU x%d" % world, "exact": exact,
+                       "parallelism": "1 LP per GPU x%d" % world,
+                       "makespan_s": elapsed, "per_rank": sorted(per_rank, key=lambda r: r["rank"]), "exact": exact,
                        "aggregate_with_copies_in_flight": in_flight},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

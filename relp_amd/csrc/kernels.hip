@@ -2008,6 +2008,382 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K23: ratio test AND inverse update in ONE launch (m <= 1024, explicit carry, no implicit bounds, no forced pivot): two
+// kernels per pivot instead of three.  Every workgroup repeats the whole of K2 -- entering column, FTRAN, ratio test: 60 KB
+// of L2 reads and three block reductions, identical bits in every workgroup -- and then its eight waves update one column of
+// the inverse each, so the kernel boundary between K2 and K3 (a cold start on data written by another XCD, 1.5-2 us) and
+// K3's own first round trip disappear.  Workgroups are not synchronised, so nothing a workgroup reads at its start may be
+// written by another one before its end:
+//   * x_B, the basis and the control block exist twice (`lp.state[2]`); pivot k of a batch reads copy k & 1 (the pricing pass
+//     before it too) and workgroup 0 writes copy (k + 1) & 1 -- also when nothing happens (status != running: copied through);
+//   * the inverse is updated OUT OF PLACE (T_old = buffer ctl->t_buf, T_new = the other one; every entry is written);
+//   * -pi_j, rho_j, w_j are touched by the owner of column j only; column positions are written by workgroup 0 and read by the
+//     next pricing pass;
+//   * `begin_batch_kernel` / `commit_kernel` move the canonical arrays into copy 0 and the last copy (and the inverse) back, so
+//     everything outside a batch of pivots sees the canonical arrays only.
+// Same arithmetic in the same order as ftran_ratio_fast_kernel<RULE, 2> + update_kernel<true>: the pivot sequence and every
+// number are BIT-IDENTICAL with the three-kernel pivot (tests/test_gpu_fused.py).
+// Measured and dropped: one wave per workgroup with all rows in registers (a wave cannot keep enough loads in
+// flight: 25 us), wave-local decisions out of LDS (16 rows and 32 divisions per lane: 14 us), and ONE launch per pivot with
+// every workgroup pricing all columns (360 KB of conflicting LDS gathers per workgroup: 21 us).
+// ---------------------------------------------------------------------------------------------------
+constexpr int KF_THREADS = 512;
+constexpr int KF_NW = KF_THREADS / WAVE;  // waves = columns of the inverse per workgroup
+constexpr int KF_R = 2;                   // rows per thread
+constexpr int KF_U = 16;                  // 16 x 64 rows of a column per lane
+constexpr int KF_MAX_M = KF_R * KF_THREADS;
+template <int RULE>
+__global__ void __launch_bounds__(KF_THREADS) pivot_fused_kernel(DeviceLP lp, DeviceLP::State in, DeviceLP::State out, int n_price_blocks,
+                                                                 double tol_pivot, double harris_delta, int skip_artificial_rows) {
+    constexpr int R = KF_R;
+    __shared__ double s_akey[KF_NW];
+    __shared__ unsigned long long s_arank[KF_NW];
+    __shared__ double s_red[KF_NW + 2];
+    __shared__ double s_red2[KF_NW + 2];
+    __shared__ double s_cbarv[K2F_MAX_BLOCKS];
+    __shared__ int s_crows[K2F_INLINE_BLOCKS * ELL_W];
+    __shared__ double s_cvals[K2F_INLINE_BLOCKS * ELL_W];
+    __shared__ int s_clen[K2F_INLINE_BLOCKS];
+    __shared__ int s_rows[K2_COL_CHUNK];
+    __shared__ double s_vals[K2_COL_CHUNK];
+    __shared__ double s_alpha[KF_MAX_M];
+    __shared__ double s_bcast[4];
+    __shared__ int s_ibcast[2];
+    const Ctl* ctl = in.ctl;  // (the two copies are kernel arguments: no dependent load to find them)
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+#ifdef RELP_STAMPS
+    unsigned long long t_prev__ = clock64();
+    if (tid == 0 && blockIdx.x == 0) lp.dbg[63] += 1;
+#define FSTAMP(k) do { if (tid == 0 && blockIdx.x == 0) { unsigned long long t__ = clock64(); lp.dbg[(k)] += t__ - t_prev__; t_prev__ = t__; } } while (0)
+#else
+#define FSTAMP(k) do {} while (0)
+#endif
+    const int m = lp.m, ld = lp.ld;
+    const bool writer = blockIdx.x == 0;
+    // ---- round trip 1: everything that does not depend on q -----------------------------------------
+    const int status = ctl->status;
+    const long long iters = ctl->iters;
+    const long long budget = ctl->budget;
+    const double minus_obj = ctl->minus_obj;
+    const int t_buf = ctl->t_buf;
+    double xb[R];
+    int bas[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * KF_THREADS;
+        xb[r] = i < m ? in.xB[i] : 0.0;
+        bas[r] = i < m ? in.basis[i] : 0x7fffffff;
+    }
+    double ckey = 0.0;
+    unsigned long long crank = RANK_NONE;
+    for (int b = tid; b < n_price_blocks; b += KF_THREADS) {
+        const int j = lp.cand_j[b];
+        const double k = lp.cand_key[b];
+        s_cbarv[b] = lp.cand_cbar[b];
+        if (j >= 0) {
+            const unsigned long long order = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? (unsigned long long)(0x7fffffff - j) : (unsigned long long)j;
+            const unsigned long long r = (order << 16) | (unsigned long long)b;
+            if (crank == RANK_NONE || k > ckey || (k == ckey && r < crank)) {
+                ckey = k;
+                crank = r;
+            }
+        }
+    }
+    const bool inline_column = n_price_blocks <= K2F_INLINE_BLOCKS;
+    if (inline_column) {
+        for (int e = tid; e < n_price_blocks * ELL_W; e += KF_THREADS) {
+            s_crows[e] = lp.cand_rows[e];
+            s_cvals[e] = lp.cand_vals[e];
+        }
+        for (int b = tid; b < n_price_blocks; b += KF_THREADS) s_clen[b] = lp.cand_len[b];
+    }
+    // workgroup 0 hands the state on when no pivot is made: x_B and the basis unchanged, the control block edited
+    auto hand_on = [&](int new_status, int new_q, bool clear_last) {
+        if (!writer) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * KF_THREADS;
+            if (i < m) {
+                out.xB[i] = xb[r];
+                out.basis[i] = bas[r];
+            }
+        }
+        if (tid == 0) {
+            Ctl c = *ctl;  // (read again by one thread: preloading the whole block in round trip 1 was measured slower)
+            if (new_status >= 0) {
+                c.status = new_status;
+                c.pending = 0;
+                c.q = new_q;
+                if (new_status == ST_UNBOUNDED) c.p = -1;
+                if (clear_last) c.last_selected = -1;
+            }
+            c.forced_q = -1;
+            c.forced_p = -1;
+            *out.ctl = c;
+        }
+    };
+    if (status != ST_RUNNING) {
+        hand_on(-1, 0, false);
+        return;
+    }
+    FSTAMP(0);
+    if (iters >= budget) {
+        hand_on(ST_BUDGET, ctl->q, false);
+        return;
+    }
+    // ---- entering column --------------------------------------------------------------------------
+    block_argbest(ckey, crank, s_akey, s_arank);
+    if (crank == RANK_NONE) {
+        hand_on(ST_NO_ENTERING, -1, true);
+        return;
+    }
+    const int winner_block = (int)(crank & 0xffff);
+    const int order = (int)(crank >> 16);
+    const int q = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? 0x7fffffff - order : order;
+    const double cbar_q = s_cbarv[winner_block];
+    FSTAMP(1);
+    // ---- this wave's column of the inverse: issued together with the FTRAN loads (both only needed round trip 1) ---
+    const int j_own = blockIdx.x * KF_NW + wave;
+    const bool own = j_own < m;
+    const double* t_old = (t_buf ? lp.Binv2 : lp.Binv);
+    double* t_new = (t_buf ? lp.Binv : lp.Binv2);
+    const double* c_old = t_old + (size_t)(own ? j_own : 0) * ld;
+    double o[KF_U];
+#pragma unroll
+    for (int u = 0; u < KF_U; ++u) {
+        const int i = lane + u * WAVE;
+        o[u] = (own && i < m) ? c_old[i] : 0.0;
+    }
+    const double pi_old = (own && lane == LAST) ? lp.minus_pi[j_own] : 0.0;
+    // ---- FTRAN -------------------------------------------------------------------------------------
+    double al[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) al[r] = 0.0;
+    int ca = 0, cb_ = 0;
+    if (inline_column) {
+        const int len = s_clen[winner_block];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * KF_THREADS;
+            if (i >= m || len < 0) continue;
+            const double* col = t_old + i;
+            double t[ELL_W];
+#pragma unroll
+            for (int e = 0; e < ELL_W; ++e) t[e] = col[(size_t)s_crows[winner_block * ELL_W + e] * ld];  // padding: row 0, value 0
+            double a0 = 0.0;
+#pragma unroll
+            for (int e = 0; e < ELL_W; ++e) a0 += t[e] * s_cvals[winner_block * ELL_W + e];
+            al[r] = a0;
+        }
+        if (len > ELL_W || len < 0) {
+            ca = lp.col_start[q] + (len < 0 ? 0 : ELL_W);
+            cb_ = lp.col_start[q + 1];
+        }
+    } else {
+        ca = lp.col_start[q];
+        cb_ = lp.col_start[q + 1];
+    }
+    for (int c0_ = ca; c0_ < cb_; c0_ += K2_COL_CHUNK) {
+        const int cnt = min(K2_COL_CHUNK, cb_ - c0_);
+        __syncthreads();
+        for (int e = tid; e < cnt; e += KF_THREADS) {
+            s_rows[e] = lp.row_index[c0_ + e];
+            s_vals[e] = lp.value[c0_ + e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * KF_THREADS;
+            if (i >= m) continue;
+            const double* col = t_old + i;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int e = 0;
+            for (; e + 4 <= cnt; e += 4) {
+                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
+                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
+                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+            }
+            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+            al[r] += (a0 + a1) + (a2 + a3);
+        }
+    }
+    FSTAMP(2);
+    // ---- gamma_q and Harris pass 1, one combined block reduction (see ftran_ratio_fast_kernel) ---------------------
+    const bool textbook = harris_delta < 0.0;
+    const double harris_slack = textbook ? 0.0 : harris_delta;
+    double sumsq = 0.0, theta = INFINITY;
+    bool eligible[R];
+    double room[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * KF_THREADS;
+        const double a = al[r];
+        sumsq += a * a;
+        const bool allowed = i < m && !(skip_artificial_rows && bas[r] < lp.n_art);
+        room[r] = fmax(xb[r], 0.0);
+        eligible[r] = allowed && a > tol_pivot;
+        if (eligible[r]) theta = fmin(theta, (room[r] + harris_slack) / fabs(a));
+        s_alpha[i] = a;
+    }
+    sumsq = wave_sum(sumsq);
+    theta = wave_min(theta);
+    if (lane == LAST) {
+        s_red[wave] = sumsq;
+        s_red2[wave] = theta;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double t1 = lane < KF_NW ? s_red[lane] : 0.0;
+        double t2 = lane < KF_NW ? s_red2[lane] : INFINITY;
+        t1 = wave_sum(t1);
+        t2 = wave_min(t2);
+        if (lane == LAST) {
+            s_red[KF_NW] = t1;
+            s_red2[KF_NW] = t2;
+        }
+    }
+    __syncthreads();
+    const double gamma_q = 1.0 + s_red[KF_NW];  // pivot_rule.rs:258
+    const double theta_max = s_red2[KF_NW];
+    FSTAMP(3);
+    // ---- Harris pass 2: largest eligible pivot, ties by the lowest leaving column (Bland), then the lowest row ----------
+    double hkey = 0.0;
+    unsigned long long hrank = RANK_NONE;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double mag = fabs(al[r]);
+        const double key = textbook ? 1.0 : mag;
+        if (eligible[r] && room[r] / mag <= theta_max) {
+            const unsigned long long rk = ((unsigned long long)(unsigned)bas[r] << 32) | (unsigned)(tid + r * KF_THREADS);
+            if (hrank == RANK_NONE || key > hkey || (key == hkey && rk < hrank)) {
+                hkey = key;
+                hrank = rk;
+            }
+        }
+    }
+    block_argbest(hkey, hrank, s_akey, s_arank);
+    const int p = hrank == RANK_NONE ? -1 : (int)(hrank & 0xffffffffu);
+    if (p < 0) {
+        hand_on(ST_UNBOUNDED, q, false);
+        return;
+    }
+    FSTAMP(4);
+    // ---- the pivot row's scalars (its owner has them in registers) --------------------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (tid + r * KF_THREADS == p) {
+            s_bcast[1] = al[r];
+            s_bcast[2] = xb[r];
+            s_ibcast[0] = bas[r];
+        }
+    }
+    __syncthreads();
+    const double alpha_pq = s_bcast[1];
+    const int leaving = s_ibcast[0];
+    const double xp = fmax(s_bcast[2], 0.0) / alpha_pq;
+    // ---- workgroup 0: x_B update (carry/mod.rs:295-325), basis bookkeeping, control block -----------------------
+    if (writer) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid + r * KF_THREADS;
+            if (i < m) {
+                lp.alpha[i] = al[r];
+                out.xB[i] = (i == p) ? xp : xb[r] - al[r] * xp;
+                out.basis[i] = (i == p) ? q : bas[r];
+            }
+        }
+        if (tid == 0) {
+            lp.pos[q] = p;
+            lp.pos[leaving] = -1;
+            Ctl c = *ctl;  // (read again by one thread: preloading the whole block in round trip 1 was measured slower)
+            c.q = q;
+            c.p = p;
+            c.leaving = leaving;
+            c.cbar_q = cbar_q;
+            c.alpha_pq = alpha_pq;
+            c.gamma_q = gamma_q;
+            c.xp = xp;
+            c.nz_count = 0;
+            c.minus_obj = minus_obj - cbar_q * xp;
+            c.iters = iters + 1;
+            c.pending = 1;
+            c.forced_q = -1;
+            c.forced_p = -1;
+            c.last_selected = q;
+            c.t_buf = t_buf ^ 1;
+            *out.ctl = c;
+        }
+    }
+    FSTAMP(5);
+    // ---- this wave's column: rho_p[j], w_j, -pi_j and the rank-one update, written to the other buffer ------------
+    if (!own) return;
+    const int u_p = p >> 6, lane_p = p & (WAVE - 1);
+    double o_p = 0.0;
+#pragma unroll
+    for (int u = 0; u < KF_U; ++u) o_p = (u == u_p) ? o[u] : o_p;
+    const double r_j = __shfl(o_p, lane_p) / alpha_pq;  // row p of the new inverse
+    double* c_new = t_new + (size_t)j_own * ld;
+    double w_j = 0.0;
+#pragma unroll
+    for (int u = 0; u < KF_U; ++u) {
+        const int i = lane + u * WAVE;
+        const double a = s_alpha[i];
+        w_j += a * o[u];
+        if (i < m) c_new[i] = (i == p) ? r_j : ((a != 0.0) ? o[u] - a * r_j : o[u]);
+    }
+    w_j = wave_sum(w_j);
+    if (lane == LAST) {
+        lp.w[j_own] = w_j;
+        lp.rho[j_own] = r_j;
+        lp.minus_pi[j_own] = pi_old - cbar_q * r_j;
+    }
+    FSTAMP(6);
+}
+#undef FSTAMP
+// Batch start in the fused mode: the budget, and copy 0 of the state made equal to the canonical arrays.
+__global__ void __launch_bounds__(256) begin_batch_kernel(DeviceLP lp, long long add) {
+    const DeviceLP::State s0 = lp.state[0];
+    for (int i = threadIdx.x; i < lp.m; i += 256) {
+        s0.xB[i] = lp.xB[i];
+        s0.basis[i] = lp.basis[i];
+    }
+    if (threadIdx.x == 0) {
+        Ctl c = *lp.ctl;
+        if (c.status == ST_BUDGET) c.status = ST_RUNNING;
+        c.budget = c.iters + add;
+        *lp.ctl = c;
+        *s0.ctl = c;
+    }
+}
+// Batch end: copy `parity` of the state back into the canonical arrays, the inverse back into the first buffer.
+__global__ void __launch_bounds__(256) commit_kernel(DeviceLP lp, int parity) {
+    const DeviceLP::State last = lp.state[parity];
+    const int t_buf = last.ctl->t_buf;
+    const int m = lp.m, ld = lp.ld;
+    if (t_buf) {
+        const int lane = threadIdx.x & (WAVE - 1);
+        for (int j = blockIdx.x * 4 + threadIdx.x / WAVE; j < m; j += gridDim.x * 4) {
+            const double* src = lp.Binv2 + (size_t)j * ld;
+            double* dst = lp.Binv + (size_t)j * ld;
+            for (int i = lane; i < m; i += WAVE) dst[i] = src[i];
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < m; i += 256) {
+            lp.xB[i] = last.xB[i];
+            lp.basis[i] = last.basis[i];
+        }
+        if (threadIdx.x == 0) {
+            Ctl c = *last.ctl;
+            c.t_buf = 0;
+            *lp.ctl = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K3: product-form update of the explicit inverse, fused with everything that is "per column j of Binv":
 //     rho_p[j] (row p of the NEW inverse), -pi_j update, w_j = alpha_q' Binv_old(:, j).
 //   replaces  BasisInverse::change_basis                       basis_inverse_rows.rs:36-70,123-137
@@ -2762,6 +3138,22 @@ void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double 
         launch_ftran_ratio_rule<RELP_PIVOT_STEEPEST_EDGE>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices, s);
     else
         launch_ftran_ratio_rule<RELP_PIVOT_DANTZIG>(d, n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows, mode, n_alpha_slices, s);
+}
+
+bool fused_pivot_available(const DeviceLP& d, int n_price_blocks) { return d.m <= KF_MAX_M && n_price_blocks <= K2F_MAX_BLOCKS; }
+void launch_pivot_fused(const DeviceLP& d, int rule, int parity, int n_price_blocks, double tol_pivot, double harris_delta,
+                        int skip_artificial_rows, hipStream_t s) {
+    const dim3 grid((d.m + KF_NW - 1) / KF_NW);
+    if (rule == RELP_PIVOT_STEEPEST_EDGE)
+        RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_STEEPEST_EDGE>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+    else
+        RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_DANTZIG>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+}
+void launch_begin_batch(const DeviceLP& d, long long add, hipStream_t s) {
+    hipLaunchKernelGGL(begin_batch_kernel, dim3(1), dim3(256), 0, s, d, add);
+}
+void launch_commit(const DeviceLP& d, int parity, hipStream_t s) {
+    hipLaunchKernelGGL(commit_kernel, dim3(std::min(256, (d.m + 3) / 4)), dim3(256), 0, s, d, parity);
 }
 
 void launch_update(const DeviceLP& d, hipStream_t s) {

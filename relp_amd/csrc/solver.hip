@@ -27,6 +27,11 @@ int price_columns_per_block(int ell_w);
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
                         int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s);
 void launch_update(const DeviceLP& d, hipStream_t s);
+bool fused_pivot_available(const DeviceLP& d, int n_price_blocks);
+void launch_pivot_fused(const DeviceLP& d, int rule, int parity, int n_price_blocks, double tol_pivot, double harris_delta,
+                        int skip_artificial_rows, hipStream_t s);
+void launch_begin_batch(const DeviceLP& d, long long add, hipStream_t s);
+void launch_commit(const DeviceLP& d, int parity, hipStream_t s);
 void launch_budget(const DeviceLP& d, long long add, hipStream_t s);
 void launch_pi(const DeviceLP& d, hipStream_t s);
 void launch_xb(const DeviceLP& d, hipStream_t s);
@@ -100,7 +105,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx, d_.state[0].ctl, d_.state[0].xB, d_.state[0].basis, d_.state[1].ctl, d_.state[1].xB, d_.state[1].basis};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -377,6 +382,17 @@ void Solver::upload() {
     if (!fast_k2_available(d_, price_blocks_ + dense_blocks_) && !getenv("RELP_K2_SINGLE")) {  // m > 8192: multi-workgroup ratio test
         d_.k2_partd = dmalloc<double>((size_t)8 * ((m + 1023) / 1024));
         d_.k2_parti = dmalloc<int>((size_t)4 * ((m + 1023) / 1024));
+    }
+    // small LPs: ratio test and inverse update in one launch (pivot_fused_kernel; RELP_NO_FUSED=1 keeps the three-kernel pivot)
+    fused_ = !lu_mode_ && !bounded_ && !eta_mode_ && n_dense == 0 && ftran_slices_ == 0 && !d_.track_touched && d_.ell_w == ELL_W &&
+             fused_pivot_available(d_, price_blocks_) && !getenv("RELP_NO_FUSED");
+    if (fused_) {
+        for (int k = 0; k < 2; ++k) {
+            d_.state[k].ctl = dmalloc<Ctl>(1);
+            d_.state[k].xB = dmalloc<double>(m);
+            d_.state[k].basis = dmalloc<int>(m);
+        }
+        ensure_polish_buffers();  // the second buffer of the out-of-place update
     }
     d_.scratch = dmalloc<double>((size_t)std::max(m, n) * 3 + 16);  // fine-grained ops carve m ints + 2 m doubles out of it
     d_.ctl = dmalloc<Ctl>(1);
@@ -736,7 +752,18 @@ void Solver::set_phase(int phase) {
 }
 
 // One batch of `count` iterations of the loop of phase_one.rs:134-178 / phase_two.rs:36-58.
-void Solver::launch_pivots(int count) {
+void Solver::launch_pivots(int count, bool forced) {
+    if (fused_ && !forced) {  // two kernels per pivot; x_B, basis and control block alternate between their two copies (kernels.hip, K23)
+        launch_begin_batch(d_, count, stream_);
+        for (int it = 0; it < count; ++it) {
+            enqueue_price_fused(it & 1);
+            enqueue_pivot_fused(it & 1);
+        }
+        launch_commit(d_, count & 1, stream_);
+        stats_.launches += 2 + 2LL * count;
+        stats_.price_launches += count;
+        return;
+    }
     launch_budget(d_, count, stream_);
     if (lu_mode_) {  // two kernels per pivot: the pricing pass and the single-workgroup LU kernel
         for (int it = 0; it < count; ++it) {
@@ -767,6 +794,17 @@ void Solver::enqueue_price(int skip_weights) {
         launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, skip_weights, opt_.tol_dual,
                      sparse_first_, d_.n, 0, stream_);
     if (dense_blocks_ > 0) launch_price_dense(d_, dense_blocks_, skip_weights, opt_.tol_dual, price_blocks_, stream_);
+}
+
+// Fused mode: the pricing pass before pivot k reads the control block of copy k & 1 (it writes nothing of the twin state).
+void Solver::enqueue_price_fused(int parity) {
+    DeviceLP d = d_;
+    d.ctl = d_.state[parity].ctl;
+    const bool use_lds = price_lds_ <= 160 * 1024 - 1024;
+    launch_price(d, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, 0, opt_.tol_dual, sparse_first_, d_.n, 0, stream_);
+}
+void Solver::enqueue_pivot_fused(int parity) {
+    launch_pivot_fused(d_, opt_.pivot_rule, parity, price_blocks_, opt_.tol_pivot, ratio_delta(), phase_ == 2 ? 1 : 0, stream_);
 }
 
 // The basis update: rank-one update of the explicit inverse (K3), or -- deferred product form -- the eta bookkeeping plus
@@ -1111,7 +1149,7 @@ int Solver::drive_out_artificials() {
         // a zero-level pivot: the artificial that leaves IS zero (the phase-one objective vanished); whatever residue f64 left
         // in x_B[r] must not be divided by a small pivot element and spread over x_B
         RELP_HIP(hipMemsetAsync(d_.xB + r, 0, sizeof(double), stream_));
-        launch_pivots(1);
+        launch_pivots(1, true);
         Ctl after = read_ctl();
         if (after.iters == c.iters) throw std::runtime_error("zero-level pivot failed");
         pivots_[0] += 1;
@@ -1494,7 +1532,7 @@ void Solver::bring_into_basis(int column, int row) {
     c.forced_q = column;
     c.forced_p = row;
     write_ctl(c);
-    launch_pivots(1);
+    launch_pivots(1, true);
     c = read_ctl();
     if (c.iters == before) throw std::runtime_error("bring_into_basis: the pivot element is zero (or the column is basic)");
     pivots_[phase_ - 1] += 1;
@@ -1519,6 +1557,7 @@ double Solver::refactor() {
 double Solver::profile_kernel(int which, int repetitions) {
     if (phase_ == 0) throw std::runtime_error("no phase started");
     if (lu_mode_ && which == 2) throw std::invalid_argument("the LU carry has no separate update kernel (which = 1 covers it)");
+    if (fused_ && which == 2) throw std::invalid_argument("the update is part of kernel 1 (fused pivot kernel): which = 1 covers it");
     RELP_HIP(hipSetDevice(opt_.device));
     const int m = d_.m;
     if (which == 0) {
@@ -1542,6 +1581,16 @@ double Solver::profile_kernel(int which, int repetitions) {
         RELP_HIP(hipEventCreate(&stops[k]));
     }
     Ctl before = read_ctl();
+    if (fused_) {
+        launch_begin_batch(d_, repetitions, stream_);
+        for (int k = 0; k < repetitions; ++k) {
+            if (which == 0) arm_launch_timer(0, starts[k], stops[k]);
+            enqueue_price_fused(k & 1);
+            if (which == 1) arm_launch_timer(1, starts[k], stops[k]);
+            enqueue_pivot_fused(k & 1);
+        }
+        launch_commit(d_, repetitions & 1, stream_);
+    } else {
     launch_budget(d_, repetitions, stream_);
     for (int k = 0; k < repetitions; ++k) {
         if (which == 0) arm_launch_timer(0, starts[k], stops[k]);
@@ -1551,6 +1600,7 @@ double Solver::profile_kernel(int which, int repetitions) {
         if (which == 2) arm_launch_timer(2, starts[k], stops[k]);
         if (!lu_mode_) enqueue_update();
         if (eta_mode_ && ((k + 1) % d_.eta_cap == 0 || k + 1 == repetitions)) enqueue_consolidate();
+    }
     }
     arm_launch_timer(-1, nullptr, nullptr);
     Ctl after = read_ctl();

@@ -42,6 +42,7 @@ struct Ctl {
     double flip_cost;  // implicit bounds: sum of ub_j c_j over the complemented variables (current phase's costs)
     long long bound_flips;  // iterations that moved the entering variable to its other bound without a basis change
     int k2_forced;     // multi-workgroup ratio test: the pivot row of this iteration was given by the caller
+    int t_buf;         // fused pivot kernel: which of the two buffers holds the current inverse (0 outside a batch)
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
@@ -129,6 +130,14 @@ struct DeviceLP {
     int* k2_parti = nullptr;     //   ... candidate rows, their basic columns, non-zero counts and list offsets
     double* scratch = nullptr;   // m or n doubles for the fine-grained ops
     Ctl* ctl = nullptr;
+    // fused pivot kernel (pivot_fused_kernel, small LPs): x_B, basis and control block exist twice; pivot k of a batch reads copy
+    // k & 1 and writes the other (kernels.hip, K23)
+    struct State {
+        Ctl* ctl = nullptr;
+        double* xB = nullptr;
+        int* basis = nullptr;
+    };
+    State state[2];
     unsigned long long* dbg = nullptr;  // diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of K2
 };
 
@@ -181,7 +190,10 @@ private:
     void upload();
     void free_device();
     void set_phase(int phase);
-    void launch_pivots(int count);
+    void launch_pivots(int count, bool forced = false);
+    void enqueue_price_fused(int parity);
+    void enqueue_pivot_fused(int parity);  // forced: the caller set forced_q / forced_p (three-kernel pivot)
+    bool fused_ = false;          // ratio test + inverse update in one launch (pivot_fused_kernel: m <= 1024, explicit carry, no implicit bounds)
     void enqueue_price(int skip_weights);
     void enqueue_ftran_ratio(int mode);
     void enqueue_update();

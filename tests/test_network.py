@@ -368,3 +368,33 @@ def test_bench_rccl_path_runs_at_world_size_one():
     assert line["config"]["exact"]["certified"] is True
     assert abs(line["config"]["objective"] - 5501.8458883) < 1e-6
     assert line["value"] > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["25fv47", "netlib"])
+def test_bench_two_ranks_over_rccl(workload):
+    """Two ranks, one per GPU, under `torch.distributed.run` exactly as the driver launches the scaling bench (started as a
+    child process; this process has made no GPU call that the child could inherit).  Needs two GPUs: skipped on a 1-GPU box
+    (`device_count` does not initialise the GPU on this image)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--workload", workload, "--no-cpu-baseline", "--no-dense-roofline", "--no-concurrency-probe"]
+    out = subprocess.run(command, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2
+    config = line["config"]
+    assert config["makespan_s"] > 0
+    if workload == "netlib":
+        assert len(config["problems_per_rank"]) == 2 and sum(config["problems_per_rank"]) == 2 * 45
+        assert config["objectives_outside_reference_tolerance"] == []
+    else:
+        assert [r["rank"] for r in config["per_rank"]] == [0, 1]
+        assert all(r["solves"] == 2 and r["pivots"] > 4000 for r in config["per_rank"])
