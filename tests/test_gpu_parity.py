@@ -228,11 +228,21 @@ def test_trait_ops_follow_the_oracle(name, steps, carry):
     solver.close()
 
 
-def test_profile_hook_runs():
-    solver = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", "SC105.SIF"))
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-pivot", "three-kernel-pivot"])
+def test_profile_hook_runs(fused):
+    if not fused:
+        os.environ["RELP_NO_FUSED"] = "1"
+    try:
+        solver = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", "SC105.SIF"))
+    finally:
+        os.environ.pop("RELP_NO_FUSED", None)
     solver.begin_phase_one()
     solver.iterate(5)
     for which in (0, 1, 2):
+        if fused and which == 2:  # small LPs: the update is part of kernel 1 (pivot_fused_kernel)
+            with pytest.raises(relp_amd.api.RelpError):
+                solver.profile_kernel(which, 10)
+            continue
         seconds = solver.profile_kernel(which, 10)
         assert 0 < seconds < 1e-2
     # state is restored: the solve still reaches the optimum
