@@ -739,10 +739,69 @@ __global__ void __launch_bounds__(ETA_THREADS) eta_update_kernel(DeviceLP lp) {
 // The BTRAN pass: rho[j] = rvec1 . Binv(:, j), w[j] = rvec2 . Binv(:, j), -pi[j] -= cbar_q rho[j]; one wave per column,
 // 16-byte loads, both row vectors in LDS.  Block 0 also commits the bookkeeping of the eta that eta_update_kernel added.
 constexpr int BT_THREADS = 1024;
-__global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp) {
+// When the sparse part of the LP is one unit-like column per row (the slack columns of the dense LP), their pricing for the
+// NEXT pivot is done here as well: (-pi_j, rho_j, w_j) of row j are in registers when they are written, and the slack column of
+// row j needs nothing else -- the separate pricing launch over the slack columns disappears (`lp.slack_of_row`; same
+// arithmetic as price_kernel: weight update, reduced cost, key, last-maximum tie rule).
+__global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, double tol_dual) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ Cand s_cand[BT_THREADS / WAVE + 2];
     Ctl* ctl = lp.ctl;
     if (ctl->status != ST_RUNNING || !ctl->pending) return;
+    const bool price_slacks = lp.slack_of_row != nullptr;
+    const double gamma_q = ctl->gamma_q, alpha_pq_c = ctl->alpha_pq;
+    const int leaving = ctl->leaving;
+    Cand best;
+    best.key = 0.0;
+    best.idx = -1;
+    best.aux = 0;
+    double best_cbar = 0.0, best_val = 0.0;
+    int best_row = 0;
+    // the slack column's own data is fetched BEFORE the column sweep it belongs to (no dependent round trip at the end)
+    struct SlackData {
+        int js;
+        int pos;
+        double v, gam, cost;
+    };
+    auto slack_fetch = [&](int j) {
+        SlackData d;
+        d.js = lp.slack_of_row[j];
+        const int jj = d.js < 0 ? 0 : d.js;
+        d.pos = d.js < 0 ? 0 : lp.pos[jj];
+        d.v = lp.ell_vals[(size_t)jj * ELL_W];
+        d.gam = lp.gamma[jj];
+        d.cost = lp.cost[jj];
+        return d;
+    };
+    auto slack = [&](const SlackData& d, int j, double pi_new, double rho_j, double w_j) {
+        const int js = d.js;
+        if (js < 0 || d.pos != -1) return;
+        const double v = d.v;
+        const double d_pi = v * pi_new, d_rho = v * rho_j, d_w = v * w_j;
+        double gam = d.gam;
+        if (js == leaving) {
+            gam = gamma_q / (alpha_pq_c * alpha_pq_c);  // pivot_rule.rs:294-295
+        } else {
+            const double sq = d_rho * d_rho;  // pivot_rule.rs:262-288 (Goldfarb-Reid)
+            gam = gam - 2.0 * d_rho * d_w + sq * gamma_q;
+            gam = fmax(gam, 1.0 + sq);
+        }
+        lp.gamma[js] = gam;
+        const double cbar = d.cost + d_pi;
+        if (cbar < -tol_dual) {
+            Cand c;
+            c.idx = js;
+            c.aux = 0;
+            c.key = cbar * cbar / gam;
+            const Cand nb = better<TIE_LARGER_IDX>(best, c);
+            if (nb.idx == js) {
+                best_cbar = cbar;
+                best_row = j;
+                best_val = v;
+            }
+            best = nb;
+        }
+    };
     const int m = lp.m, ld = lp.ld;
     const int mp = (m + 1) & ~1;
     double* s_r1 = smem;
@@ -761,16 +820,28 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp) {
     // unit columns: rho_j = rvec1[j], w_j = rvec2[j]
     for (int j = blockIdx.x * BT_THREADS + threadIdx.x; j < m; j += gridDim.x * BT_THREADS) {
         if (!lp.touched[j]) {
+            SlackData sd;
+            sd.js = -1;
+            if (price_slacks) sd = slack_fetch(j);
             const double d1 = s_r1[j];
+            const double pi_new = lp.minus_pi[j] - cbar_q * d1;
             lp.rho[j] = d1;
             lp.w[j] = s_r2[j];
-            lp.minus_pi[j] -= cbar_q * d1;
+            lp.minus_pi[j] = pi_new;
+            if (price_slacks) slack(sd, j, pi_new, d1, s_r2[j]);
         }
     }
     const int n_touched = ctl->touched_count;
     for (int idx = blockIdx.x * (BT_THREADS / WAVE) + wave; idx < n_touched; idx += waves_total) {
         const int j = lp.tlist[idx];
         const double2* col = reinterpret_cast<const double2*>(lp.Binv + (size_t)j * ld);
+        SlackData sd;
+        sd.js = -1;
+        double pi_old = 0.0;
+        if (lane == WAVE - 1) {
+            if (price_slacks) sd = slack_fetch(j);
+            pi_old = lp.minus_pi[j];
+        }
         double d1 = 0.0, d2 = 0.0;
         for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
             double2 v[8];
@@ -792,10 +863,27 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp) {
         d1 = wave_sum(d1);
         d2 = wave_sum(d2);
         if (lane == WAVE - 1) {
+            const double pi_new = pi_old - cbar_q * d1;
             lp.rho[j] = d1;
             lp.w[j] = d2;
-            lp.minus_pi[j] -= cbar_q * d1;
+            lp.minus_pi[j] = pi_new;
+            if (price_slacks) slack(sd, j, pi_new, d1, d2);
         }
+    }
+    if (price_slacks) {  // this workgroup's best slack column for the next pivot, in price_kernel's candidate format
+        const Cand blk = block_best<TIE_LARGER_IDX>(best, s_cand);
+        if (blk.idx >= 0 && blk.idx == best.idx) {
+            lp.cand_key[blockIdx.x] = blk.key;
+            lp.cand_j[blockIdx.x] = blk.idx;
+            lp.cand_cbar[blockIdx.x] = best_cbar;
+            lp.cand_len[blockIdx.x] = 1;
+#pragma unroll
+            for (int e = 0; e < ELL_W; ++e) {
+                lp.cand_rows[(size_t)blockIdx.x * ELL_W + e] = e == 0 ? best_row : 0;
+                lp.cand_vals[(size_t)blockIdx.x * ELL_W + e] = e == 0 ? best_val : 0.0;
+            }
+        }
+        if (blk.idx < 0 && threadIdx.x == 0) lp.cand_j[blockIdx.x] = -1;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int p = ctl->p;
@@ -3240,10 +3328,11 @@ void configure_btran_lds(size_t) {
     done = true;
 }
 // deferred product form: fold the new eta into the kept columns, then one read-only pass for rho_p, w and -pi
-void launch_eta_update(const DeviceLP& d, hipStream_t s) {
+int btran_pass_blocks() { return 256; }
+void launch_eta_update(const DeviceLP& d, double tol_dual, hipStream_t s) {
     hipLaunchKernelGGL(eta_update_kernel, dim3(d.eta_cap + (d.m + ETA_THREADS - 1) / ETA_THREADS), dim3(ETA_THREADS), 0, s, d);
     const size_t lds = (size_t)2 * ((d.m + 1) & ~1) * sizeof(double);
-    RELP_LAUNCH(2, btran_pass_kernel, dim3(256), dim3(BT_THREADS), lds, s, d);
+    RELP_LAUNCH(2, btran_pass_kernel, dim3(btran_pass_blocks()), dim3(BT_THREADS), lds, s, d, tol_dual);
 }
 void launch_mark_all_touched(const DeviceLP& d, hipStream_t s) {
     hipLaunchKernelGGL(mark_all_touched_kernel, dim3((d.m + 255) / 256), dim3(256), 0, s, d);

@@ -46,7 +46,8 @@ bool gemm_row_lists_supported();
 void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s);
 int eta_max();
 void configure_btran_lds(size_t lds);
-void launch_eta_update(const DeviceLP& d, hipStream_t s);
+void launch_eta_update(const DeviceLP& d, double tol_dual, hipStream_t s);
+int btran_pass_blocks();
 void launch_eta_consolidate(const DeviceLP& d, hipStream_t s);
 void launch_mark_all_touched(const DeviceLP& d, hipStream_t s);
 void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s);
@@ -105,7 +106,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx, d_.state[0].ctl, d_.state[0].xB, d_.state[0].basis, d_.state[1].ctl, d_.state[1].xB, d_.state[1].basis};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx, d_.slack_of_row, d_.state[0].ctl, d_.state[0].xB, d_.state[0].basis, d_.state[1].ctl, d_.state[1].xB, d_.state[1].basis};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -226,6 +227,28 @@ void Solver::upload() {
     }
     const int cpb = price_columns_per_block(d_.ell_w);
     price_blocks_ = std::min(d_.ell_w == 2 ? 2048 : 1024, (n - sparse_first_ + cpb - 1) / cpb);
+    // Dense pipeline whose sparse columns are one single-entry column per row at most (the slack columns of config 3): the BTRAN
+    // pass of a pivot prices them for the next one (btran_pass_kernel), one candidate slot per workgroup of that pass.
+    std::vector<int> slack_of_row;
+    {
+        const char* eta_env0 = getenv("RELP_ETA");
+        bool eligible = n_dense > 0 && opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE && m % 2 == 0 && m <= 4096 &&
+                        !(eta_env0 && std::string(eta_env0) == "0") && !getenv("RELP_NO_SLACK_IN_BTRAN") && n > sparse_first_;
+        if (eligible) {  // (the deferred product form needs the multi-block FTRAN: a column longer than its threshold)
+            int longest = 0;
+            for (int j = n_art; j < n; ++j) longest = std::max(longest, col_start[j + 1] - col_start[j]);
+            eligible = longest > (getenv("RELP_FTRAN_MIN_NNZ") ? atoi(getenv("RELP_FTRAN_MIN_NNZ")) : 1024);
+        }
+        if (eligible) {
+            slack_of_row.assign(m, -1);
+            for (int j = sparse_first_; eligible && j < n; ++j) {
+                eligible = col_start[j + 1] - col_start[j] == 1 && slack_of_row[row_index[col_start[j]]] < 0;
+                if (eligible) slack_of_row[row_index[col_start[j]]] = j;
+            }
+        }
+        if (!eligible) slack_of_row.clear();
+        else price_blocks_ = btran_pass_blocks();
+    }
     dense_blocks_ = n_dense > 0 ? std::min(getenv("RELP_DENSE_BLOCKS") ? atoi(getenv("RELP_DENSE_BLOCKS")) : 256, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one workgroup per CU (96 KB of LDS each)
     if (price_blocks_ + dense_blocks_ == 0) price_blocks_ = 1;
     price_lds_ = (size_t)3 * m * sizeof(double);
@@ -312,6 +335,12 @@ void Solver::upload() {
     const char* eta_env = getenv("RELP_ETA");  // RELP_ETA=0 keeps the per-pivot rank-one update (A/B measurements)
     eta_mode_ = n_dense > 0 && ftran_slices_ > 0 && m % 2 == 0 && m <= 4096 && !(eta_env && std::string(eta_env) == "0");
     d_.eta_cap = eta_mode_ ? eta_max() : 0;
+    slack_in_btran_ = eta_mode_ && !slack_of_row.empty();
+    if (slack_in_btran_) {
+        d_.slack_of_row = dmalloc<int>(m);
+        upload_vec(d_.slack_of_row, slack_of_row, stream_);
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
     // unit columns of the inverse are tracked where skipping them pays: the dense pipeline and the larger sparse LPs
     // (below that the update kernel is latency bound and the extra indirection would cost a round trip)
     d_.track_touched = (eta_mode_ || m > 2048) && !lu_mode_ && !getenv("RELP_NO_TOUCHED") ? 1 : 0;
@@ -775,7 +804,7 @@ void Solver::launch_pivots(int count, bool forced) {
         return;
     }
     for (int it = 0; it < count; ++it) {
-        enqueue_price(0);
+        enqueue_price(0, it == 0);
         enqueue_ftran_ratio(0);
         enqueue_update();
         if (eta_mode_ && ((it + 1) % d_.eta_cap == 0 || it + 1 == count)) enqueue_consolidate();
@@ -785,13 +814,15 @@ void Solver::launch_pivots(int count, bool forced) {
 }
 
 // Pricing pass: the dense block (if any) streams through price_dense_kernel, every other column through the CSC kernel.
-void Solver::enqueue_price(int skip_weights) {
+void Solver::enqueue_price(int skip_weights, bool first_of_batch) {
     // beside a dense block the CSC kernel only sees the short slack columns: staging -pi, rho_p, w in LDS (3 m doubles per
     // workgroup) would cost more than the gathers it saves.  (Running it on a second stream beside the dense pass was
     // measured too: the fork/join edges of the captured graph cost 15 us per pivot against the 8 us they hide.)
     const bool use_lds = price_lds_ <= 160 * 1024 - 1024 && dense_blocks_ == 0;
-    if (price_blocks_ > 0)
-        launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, skip_weights, opt_.tol_dual,
+    // slack_in_btran_: the BTRAN pass of the previous pivot has priced the slack columns (weights included); only the first
+    // pivot of a batch has no predecessor in the batch, and its pass must not apply the weight update a second time
+    if (price_blocks_ > 0 && (!slack_in_btran_ || first_of_batch))
+        launch_price(d_, opt_.pivot_rule, price_blocks_, use_lds ? price_lds_ : 0, use_lds, slack_in_btran_ ? 1 : skip_weights, opt_.tol_dual,
                      sparse_first_, d_.n, 0, stream_);
     if (dense_blocks_ > 0) launch_price_dense(d_, dense_blocks_, skip_weights, opt_.tol_dual, price_blocks_, stream_);
 }
@@ -810,7 +841,7 @@ void Solver::enqueue_pivot_fused(int parity) {
 // The basis update: rank-one update of the explicit inverse (K3), or -- deferred product form -- the eta bookkeeping plus
 // one read-only pass for rho_p, w and -pi.
 void Solver::enqueue_update() {
-    if (eta_mode_) launch_eta_update(d_, stream_);
+    if (eta_mode_) launch_eta_update(d_, opt_.tol_dual, stream_);
     else launch_update(d_, stream_);
 }
 // Fold the pending etas into the stored inverse (no-op kernels when there are none; runs whatever the status is, so that
@@ -1594,7 +1625,7 @@ double Solver::profile_kernel(int which, int repetitions) {
     launch_budget(d_, repetitions, stream_);
     for (int k = 0; k < repetitions; ++k) {
         if (which == 0) arm_launch_timer(0, starts[k], stops[k]);
-        enqueue_price(0);
+        enqueue_price(0, k == 0);
         if (which == 1) arm_launch_timer(1, starts[k], stops[k]);
         enqueue_ftran_ratio(0);
         if (which == 2) arm_launch_timer(2, starts[k], stops[k]);

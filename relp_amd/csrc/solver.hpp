@@ -72,6 +72,8 @@ struct DeviceLP {
     // Column j of the STORED inverse is still the unit vector e_j until a row-j pivot has been folded in (E e_j = e_j for
     // every eta of another row; the polish keeps such columns exactly).  touched[j] / tlist record the others, so that the
     // FTRAN and BTRAN passes and the rank-k update only stream columns that carry information.
+    int* slack_of_row = nullptr;   // [m] dense pipeline whose sparse part is one single-entry column per row: that column (or -1); the
+                                   // BTRAN pass then prices those columns itself (btran_pass_kernel) and no separate launch does
     int track_touched = 0;         // 1: touched / tlist are maintained (deferred product form, or m > 2048)
     int* touched = nullptr;        // [m] 0/1
     int* tlist = nullptr;          // [m] touched columns in the order they were folded in
@@ -194,7 +196,8 @@ private:
     void enqueue_price_fused(int parity);
     void enqueue_pivot_fused(int parity);  // forced: the caller set forced_q / forced_p (three-kernel pivot)
     bool fused_ = false;          // ratio test + inverse update in one launch (pivot_fused_kernel: m <= 1024, explicit carry, no implicit bounds)
-    void enqueue_price(int skip_weights);
+    void enqueue_price(int skip_weights, bool first_of_batch = true);
+    bool slack_in_btran_ = false; // the slack columns of the dense pipeline are priced by the BTRAN pass of the previous pivot
     void enqueue_ftran_ratio(int mode);
     void enqueue_update();
     void enqueue_consolidate();
