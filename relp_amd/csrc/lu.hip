@@ -314,7 +314,6 @@ template <int NRHS, bool HAS_DIAG, class F>
 __device__ __forceinline__ void solve_levels(const F fac, volatile lds_f64* x0, volatile lds_f64* x1, unsigned long long* dbg = nullptr) {
     (void)dbg;
     const int tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
     // ---- wide levels: a thread per row ---------------------------------------------------------------------------------
     auto whole_row = [&](int r) {
         const int i = fac.rec_i[r], st = fac.rec_s[r], n = fac.rec_n[r];
@@ -342,125 +341,44 @@ __device__ __forceinline__ void solve_levels(const F fac, volatile lds_f64* x0, 
         x0[i] = a0 * dinv;
         if (NRHS == 2) x1[i] = a1 * dinv;
     };
-    // ---- narrow levels: G lanes per row, software pipeline over the levels of a run ---------------------------------------
-    struct Hdr {
-        int i, s, n, G;
-        double dinv;
-    };
-    struct Ent {
-        int i, s, n, G, c;
-        double v, a0, a1, dinv;
-    };
-    auto narrow = [&](int l) { return l < fac.n_levels && fac.lev_start[l + 1] - fac.lev_start[l] <= WAVE; };
-    int l = 0;
-    const int n_levels = fac.n_levels;
-    while (l < n_levels) {
-        const int ls = fac.lev_start[l], le = fac.lev_start[l + 1];
-        if (le - ls > WAVE) {
-            for (int r = ls + tid; r < le; r += T) whole_row(r);
-            __syncthreads();
-            ++l;
-        } else {
-            int l2 = l + 1;
-            while (narrow(l2)) ++l2;  // the run is [l, l2)
-            if (wave == 0) {
-                auto hdr_of = [&](int lev) {  // stage 1: the row record of this lane's row in level `lev`
-                    const bool in = lev < l2;
-                    const int s0 = in ? fac.lev_start[lev] : 0, s1 = in ? fac.lev_start[lev + 1] : 0;
-                    const int G = lanes_per_row(s1 - s0);
-                    const int row = lane / G;
-                    const bool active = in && row < s1 - s0;
-                    const int rr = active ? s0 + row : 0;
-                    Hdr h;
-                    h.i = fac.rec_i[rr];
-                    h.s = fac.rec_s[rr];
-                    const int n = fac.rec_n[rr];
-                    h.n = active ? n : -1;
-                    h.G = G;
-                    h.dinv = HAS_DIAG ? fac.rec_dinv[rr] : 1.0;
-                    return h;
-                };
-                auto ent = [&](const Hdr& h) {  // stage 2: this lane's first entry, the row's right-hand side
-                    Ent e;
-                    e.i = h.i;
-                    e.s = h.s;
-                    e.n = h.n;
-                    e.G = h.G;
-                    e.dinv = h.dinv;
-                    const int sub = lane & (h.G - 1);
-                    const int k = min(sub, max(h.n - 1, 0));
-                    e.c = fac.idx[h.s + k];
-                    e.v = fac.val[h.s + k];
-                    e.a0 = x0[h.i];
-                    e.a1 = NRHS == 2 ? x1[h.i] : 0.0;
-                    return e;
-                };
-                auto finish = [&](const Ent& e) {  // stage 3: operands, the rest of a long row, group sum, publish
-                    const int sub = lane & (e.G - 1);
-                    const double p = x0[e.c];
-                    const double q = NRHS == 2 ? x1[e.c] : 0.0;
-                    double s0 = sub < e.n ? e.v * p : 0.0;
-                    double s1 = (NRHS == 2 && sub < e.n) ? e.v * q : 0.0;
-                    if (e.n > e.G) {  // long rows: four more entries per lane and trip
-                        const int last = e.n - 1;
-                        for (int k = sub + e.G; k < e.n; k += 4 * e.G) {
-                            const int k0 = e.s + k, k1 = e.s + min(k + e.G, last), k2 = e.s + min(k + 2 * e.G, last), k3 = e.s + min(k + 3 * e.G, last);
-                            const int c0 = fac.idx[k0], c1 = fac.idx[k1], c2 = fac.idx[k2], c3 = fac.idx[k3];
-                            const double v0 = fac.val[k0], v1 = fac.val[k1], v2 = fac.val[k2], v3 = fac.val[k3];
-                            const double p0 = x0[c0], p1 = x0[c1], p2 = x0[c2], p3 = x0[c3];
-                            s0 += v0 * p0;
-                            s0 += k + e.G < e.n ? v1 * p1 : 0.0;
-                            s0 += k + 2 * e.G < e.n ? v2 * p2 : 0.0;
-                            s0 += k + 3 * e.G < e.n ? v3 * p3 : 0.0;
-                            if (NRHS == 2) {
-                                const double q0 = x1[c0], q1 = x1[c1], q2 = x1[c2], q3 = x1[c3];
-                                s1 += v0 * q0;
-                                s1 += k + e.G < e.n ? v1 * q1 : 0.0;
-                                s1 += k + 2 * e.G < e.n ? v2 * q2 : 0.0;
-                                s1 += k + 3 * e.G < e.n ? v3 * q3 : 0.0;
-                            }
-                        }
-                    }
-                    s0 = group_sum(s0, e.G);
-                    if (NRHS == 2) s1 = group_sum(s1, e.G);
-                    if (e.n >= 0 && sub == e.G - 1) {
-                        x0[e.i] = (e.a0 - s0) * e.dinv;
-                        if (NRHS == 2) x1[e.i] = (e.a1 - s1) * e.dinv;
-                    }
-                };
-                Ent e_cur = ent(hdr_of(l));
-                Hdr h_next = hdr_of(l + 1);
-                for (int lev = l; lev < l2; ++lev) {
-#ifdef RELP_STAMPS
-                    const unsigned long long ta = clock64();
-#endif
-                    const Hdr h_after = hdr_of(lev + 2);   // stage 1 of level lev + 2
-#ifdef RELP_STAMPS
-                    const unsigned long long tb = clock64();
-#endif
-                    const Ent e_next = ent(h_next);        // stage 2 of level lev + 1
-#ifdef RELP_STAMPS
-                    const unsigned long long tc = clock64();
-#endif
-                    finish(e_cur);                         // stage 3 of level lev
-#ifdef RELP_STAMPS
-                    if (dbg && tid == 0) {
-                        const unsigned long long td = clock64();
-                        dbg[40] += tb - ta;
-                        dbg[41] += tc - tb;
-                        dbg[42] += td - tc;
-                        dbg[43] += 1;
-                        dbg[44] += e_cur.n > e_cur.G ? 1 : 0;
-                        dbg[45] += e_cur.n > 0 ? e_cur.n : 0;
-                    }
-#endif
-                    e_cur = e_next;
-                    h_next = h_after;
-                }
-            }
-            l = l2;
-            __syncthreads();
+    // ---- levels of at most a wave's worth of rows: blockDim / 64 threads per row (entries split among them, DPP group sum) ------
+    // One LDS round trip per level whatever the row lengths, then the barrier.  (A barrier-free software pipeline of wave 0 over
+    // runs of such levels was measured at 1.8-2.3 k cycles per level -- every level is a dependent header -> entry -> operand ->
+    // sum -> publish chain for ONE wave; the chains of tiny levels at the end of the schedule are solved as a dense block
+    // instead, solve_dense_tail.)
+    auto group_rows = [&](int ls, int le) {
+        const int G = T / WAVE;
+        const int row = tid / G, sub = tid % G;
+        const bool in = row < le - ls;
+        const int r = ls + (in ? row : 0);
+        const int i = fac.rec_i[r], st = fac.rec_s[r];
+        const int n = in ? fac.rec_n[r] : -1;
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = sub; k < n; k += G) {
+            const int c = fac.idx[st + k];
+            const double v = fac.val[st + k];
+            s0 += v * x0[c];
+            if (NRHS == 2) s1 += v * x1[c];
         }
+        s0 = group_sum(s0, G);
+        if (NRHS == 2) s1 = group_sum(s1, G);
+        if (n >= 0 && sub == G - 1) {
+            const double dinv = HAS_DIAG ? fac.rec_dinv[r] : 1.0;
+            x0[i] = (x0[i] - s0) * dinv;
+            if (NRHS == 2) x1[i] = (x1[i] - s1) * dinv;
+        }
+    };
+    // (fetching the next level's row records and first entries while a level waits for its operands was measured: no gain --
+    //  LDS returns in order, so the operand read waits for the prefetch anyway)
+    const int n_levels = fac.n_levels;
+    for (int l = 0; l < n_levels; ++l) {
+        const int ls = fac.lev_start[l], le = fac.lev_start[l + 1];
+        if (le - ls > WAVE || T < 2 * WAVE) {
+            for (int r = ls + tid; r < le; r += T) whole_row(r);
+        } else {
+            group_rows(ls, le);
+        }
+        __syncthreads();
     }
 }
 
@@ -549,6 +467,7 @@ __device__ __forceinline__ void apply_etas_backward(const DeviceLU& lu, const in
     }
 }
 
+constexpr int TAIL_MAX = 64;  // rows of the dense tail: one lane each
 // LDS carve-up shared by every kernel of this file
 struct LuShared {
     volatile lds_f64* x0;
@@ -568,6 +487,12 @@ struct LuShared {
     lds_i32* f_levstart;  // [m + 2]
     lds_i8* f_entries;  // what is left of the LDS
     int f_entry_capacity;  // entries (12 bytes each) that fit there
+    // dense tail of a triangular solve (solve_dense_tail): nullptr when the LDS has no room for it
+    lds_f64* tail_M;     // [64 x 64], M[k * 64 + i] = entry (tail row i, tail column k)
+    lds_i32* tail_map;   // [m] position -> index in the tail, or -1
+    lds_f64* tail_r0;    // [64] right-hand sides
+    lds_f64* tail_r1;
+    lds_i32* tail_info;  // [2] first level of the tail, its first record
     unsigned long long* dbg;  // diagnostic builds (-DRELP_STAMPS): per-segment cycle sums; nullptr otherwise
     unsigned long long* t_prev;
 };
@@ -608,6 +533,21 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
     lds_i32* group_count = s.f_levstart + ((m + 2 + 1) & ~1);
     s.group_count = (int*)group_count;
     lds_i8* end = (lds_i8*)(group_count + (((m + 63) / 64 + 2 + 1) & ~1));
+    s.tail_M = nullptr;
+    s.tail_map = nullptr;
+    s.tail_r0 = s.tail_r1 = nullptr;
+    s.tail_info = nullptr;
+    {   // the dense tail takes 33 KB + 4 m bytes when at least 24 KB stay for the factor's entries
+        const int tail_bytes = (TAIL_MAX * TAIL_MAX + 2 * TAIL_MAX) * 8 + ((mm + 2) * 4);
+        if (lds_bytes - (int)(end - smem) - tail_bytes >= 24 * 1024) {
+            s.tail_M = (lds_f64*)end;
+            s.tail_r0 = s.tail_M + TAIL_MAX * TAIL_MAX;
+            s.tail_r1 = s.tail_r0 + TAIL_MAX;
+            s.tail_map = (lds_i32*)(s.tail_r1 + TAIL_MAX);
+            s.tail_info = s.tail_map + mm;
+            end = (lds_i8*)(s.tail_info + 2);
+        }
+    }
     s.f_entries = end;
     s.f_entry_capacity = (int)((lds_bytes - (int)(end - smem)) / 12);
     if (s.f_entry_capacity < 0) s.f_entry_capacity = 0;
@@ -623,6 +563,69 @@ __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh,
         if (two) sh.x1[i] = 0.0;
     }
     for (int i = threadIdx.x; i < n_updates * lu.ldt; i += blockDim.x) sh.T[i] = lu.T[i];
+    __syncthreads();
+}
+
+// The last `n_tail` <= 64 records of the schedule as one dense triangular block.  All threads: every tail row, blockDim / 64
+// threads each, walks its entries -- an entry whose column is a tail row goes into the dense block (LDS, column-major by
+// dependency), the others are multiplied with their operands, which the head levels have finished -- and leaves the row's
+// right-hand side.  Then ONE wave substitutes through the block: lane i owns row i, step k broadcasts x_k by readlane -- n_tail
+// steps of a few instructions instead of one LDS round trip per level.  Rows that are not part of the triangle (len < 0) stay
+// as they are.  x0 / x1 of the head must be complete (barrier); ends with a barrier.
+template <int NRHS, bool HAS_DIAG, class F>
+__device__ __forceinline__ void solve_dense_tail(const F fac, const LuShared& sh, const int tail_first, const int n_tail) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int G = T / TAIL_MAX;  // threads per tail row (a power of two: 16 at 1024 threads)
+    const int row = tid / G, sub = tid % G;
+    {
+        const bool active = row < n_tail;
+        const int rr = tail_first + (active ? row : 0);
+        const int st = fac.rec_s[rr];
+        const int n = active ? fac.rec_n[rr] : -1;
+        const int pos = fac.rec_i[rr];
+        double p0 = 0.0, p1 = 0.0;
+        for (int k = sub; k < n; k += G) {
+            const int c = fac.idx[st + k];
+            const double v = fac.val[st + k];
+            const int ti = sh.tail_map[c];
+            if (ti >= 0) {
+                sh.tail_M[ti * TAIL_MAX + row] = v;
+            } else {
+                p0 += v * sh.x0[c];
+                if (NRHS == 2) p1 += v * sh.x1[c];
+            }
+        }
+        p0 = group_sum(p0, G);
+        if (NRHS == 2) p1 = group_sum(p1, G);
+        if (active && sub == G - 1) {
+            sh.tail_r0[row] = sh.x0[pos] - p0;
+            if (NRHS == 2) sh.tail_r1[row] = sh.x1[pos] - p1;
+        }
+    }
+    __syncthreads();
+    if (tid < WAVE) {
+        const int lane = tid;
+        const bool in = lane < n_tail;
+        const int rr = tail_first + (in ? lane : 0);
+        const bool active = in && fac.rec_n[rr] >= 0;
+        const int pos = fac.rec_i[rr];
+        const double dinv = (HAS_DIAG && active) ? fac.rec_dinv[rr] : 1.0;
+        double r0 = active ? sh.tail_r0[lane] : 0.0;
+        double r1 = (NRHS == 2 && active) ? sh.tail_r1[lane] : 0.0;
+        for (int k = 0; k < n_tail; ++k) {
+            const double mk = sh.tail_M[k * TAIL_MAX + lane];
+            const double xk0 = lane_value(r0 * dinv, k);
+            if (lane > k) r0 -= mk * xk0;
+            if (NRHS == 2) {
+                const double xk1 = lane_value(r1 * dinv, k);
+                if (lane > k) r1 -= mk * xk1;
+            }
+        }
+        if (active) {
+            sh.x0[pos] = r0 * dinv;
+            if (NRHS == 2) sh.x1[pos] = r1 * dinv;
+        }
+    }
     __syncthreads();
 }
 
@@ -647,8 +650,19 @@ __device__ __forceinline__ void lu_stage_and_solve(const DeviceLU& lu, const LuS
         sh.f_start[r] = st;
         sh.f_len[r] = n;
         if (HAS_DIAG) sh.f_dinv[r] = 1.0 / diag[i];
+        if (sh.tail_map) sh.tail_map[i] = -1;
     }
-    for (int l = tid; l <= n_levels; l += T) sh.f_levstart[l] = lu.sched_start[sched][l];
+    for (int l = tid; l <= n_levels; l += T) {
+        const int first = lu.sched_start[sched][l];
+        sh.f_levstart[l] = first;
+        if (sh.tail_info) {  // the tail: the last levels with at most TAIL_MAX rows altogether
+            const int before = l > 0 ? lu.sched_start[sched][l - 1] : -1;
+            if (m - first <= TAIL_MAX && (l == 0 || m - before > TAIL_MAX)) {
+                sh.tail_info[0] = l;
+                sh.tail_info[1] = first;
+            }
+        }
+    }
     const bool fits = nnz + 4 <= sh.f_entry_capacity;
     lds_i32* e_idx = (lds_i32*)(sh.f_entries + sh.f_entry_capacity * 8);
     lds_f64* e_val = (lds_f64*)sh.f_entries;
@@ -673,12 +687,28 @@ __device__ __forceinline__ void lu_stage_and_solve(const DeviceLU& lu, const LuS
         sh.dbg[28 + sched] += fits ? 1 : 0;
     }
 #endif
+    // The narrow levels at the end of the schedule -- chains of a few rows each, 10-30 levels of them on a basis of 25FV47, every
+    // level one dependent LDS round trip for one wave -- are solved as ONE DENSE triangular block instead (solve_dense_tail).
+    int head_levels = n_levels, tail_first = m;
+    if (sh.tail_info) {
+        const int l_tail = sh.tail_info[0];
+        tail_first = sh.tail_info[1];
+        if (n_levels - l_tail >= 3 && m - tail_first >= 4) head_levels = l_tail;  // (a short tail is not worth the set-up)
+        else tail_first = m;
+    }
+    if (tail_first < m) {
+        for (int e = tid; e < TAIL_MAX * TAIL_MAX; e += T) sh.tail_M[e] = 0.0;
+        if (tid < m - tail_first) sh.tail_map[sh.f_levrow[tail_first + tid]] = tid;
+        __syncthreads();
+    }
     if (fits) {
-        Factor<const lds_i32*, const lds_f64*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, e_idx, e_val, sh.f_levstart, n_levels};
+        Factor<const lds_i32*, const lds_f64*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, e_idx, e_val, sh.f_levstart, head_levels};
         solve_levels<NRHS, HAS_DIAG>(f, sh.x0, sh.x1, sh.dbg);
+        if (tail_first < m) solve_dense_tail<NRHS, HAS_DIAG>(f, sh, tail_first, m - tail_first);
     } else {
-        Factor<const int*, const double*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, g_idx, g_val, sh.f_levstart, n_levels};
+        Factor<const int*, const double*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, g_idx, g_val, sh.f_levstart, head_levels};
         solve_levels<NRHS, HAS_DIAG>(f, sh.x0, sh.x1, sh.dbg);
+        if (tail_first < m) solve_dense_tail<NRHS, HAS_DIAG>(f, sh, tail_first, m - tail_first);
     }
 }
 

@@ -20,7 +20,3 @@ for k, nm in enumerate(names):
 print("%-16s %9.0f cycles/launch" % ("sum", total))
 for k, nm in enumerate(["stage L rows", "stage U rows", "stage U cols", "stage L cols"]):
     print("%-16s %9.0f cycles/launch  levels %.1f  wide %.1f  in LDS %.2f" % (nm, d[13 + k] / max(n, 1), d[20 + k] / max(n, 1), d[24 + k] / max(n, 1), d[28 + k] / max(n, 1)))
-
-
-c = max(d[43], 1)
-print("narrow level trip: hdr %.0f  ent %.0f  finish %.0f cycles;  %d trips, long-row trips %.3f, entries of lane 0's row %.1f" % (d[40] / c, d[41] / c, d[42] / c, d[43], d[44] / c, d[45] / c))
