@@ -300,6 +300,8 @@ def main():
     parser.add_argument("--warmup", type=int, default=1)
     parser.add_argument("--workload", default="25fv47")
     parser.add_argument("--crash", type=int, default=1, help="graph workloads: start phase one from the spanning-forest crash basis")
+    parser.add_argument("--dense-storage", choices=["narrowest", "f32", "f64"], default="narrowest",
+                        help="dense workloads: storage type of the dense block (narrowest exact type: signed bytes for this generator)")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-concurrency-probe", action="store_true")
@@ -339,6 +341,8 @@ def main():
     elif dense:
         from relp_amd.workloads import dense_lp
         a, b, c = dense_lp(*path)
+        if args.dense_storage != "narrowest":  # generic data: the block as float / double (the library reads this at load time)
+            os.environ["RELP_DENSE_F32" if args.dense_storage == "f32" else "RELP_DENSE_F64"] = "1"
         solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512"))).load_dense_le(a, b, c)
     else:
         # the step is `solve_relaxation` with the exact certificate INSIDE: the f64 loop alone is narrower arithmetic than the
@@ -466,7 +470,8 @@ def main():
                             "phase one from the spanning-forest crash basis" if args.crash else "artificial start as in the reference"))
             data = "synthetic"
         elif dense:
-            workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing" % path
+            workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing, dense block stored as %s" % (
+                path + ({"narrowest": "signed bytes (narrowest exact type)", "f32": "float", "f64": "double"}[args.dense_storage],))
             data = "synthetic"
         else:
             workload = ("Netlib 25FV47 %dx%d, steepest-edge pricing, %s carry, exact certificate %s the timed step, %s" % (
