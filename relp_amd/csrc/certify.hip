@@ -178,6 +178,7 @@ public:
     template <class F>
     void run(int n, F&& fn) {
         if (n <= 0) return;
+        std::lock_guard<std::mutex> one_caller(run_mutex_);  // (the two Dixon solves of a certificate run on two host threads)
         if (threads_.empty() || n < 8) {
             for (int i = 0; i < n; ++i) fn(i);
             return;
@@ -199,6 +200,7 @@ public:
     }
 
 private:
+    std::mutex run_mutex_;
     WorkerPool() {
         unsigned count = std::thread::hardware_concurrency();
         if (const char* e = getenv("RELP_CERTIFY_THREADS")) count = (unsigned)atoi(e);
@@ -330,7 +332,7 @@ struct ExactVector {           // numer[i] / denom
 // Solve  A z = rhs  (transpose = 0: A = B;  transpose = 1: A = B')  by Dixon lifting; the result is verified exactly.
 bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpose, u32 p, const u32* dA,
                  DeviceBuffers& buf, const int* d_row_start, const int* d_col_index, const i64* d_row_value,
-                 hipStream_t stream, ExactVector* out, std::string* message, int first_target = 32) {
+                 hipStream_t stream, ExactVector* out, std::string* message, CertifyTimes& times, int first_target = 32) {
     const int m = B.m;
     i64* d_r = buf.alloc<i64>(m);
     int* d_info = buf.alloc<int>(4);
@@ -356,7 +358,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             digits_capacity = target;
         }
         const double t_digits = wall_now();
-        g_times.digit_launches += target - steps_done;
+        times.digit_launches += target - steps_done;
         for (int s = steps_done; s < target; ++s) {
             u32* xs = d_digits + (size_t)s * m;
             hipLaunchKernelGGL(dixon_digit_kernel, dim3((m + 3) / 4), dim3(256), m * sizeof(u32), stream, dA, m, p, d_r, xs);
@@ -368,12 +370,13 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
         RELP_HIP(hipMemcpyAsync(flat.data(), d_digits + (size_t)steps_done * m, flat.size() * sizeof(u32), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipStreamSynchronize(stream));
-        g_times.device_digits += wall_now() - t_digits;
+        times.device_digits += wall_now() - t_digits;
         const double t_host = wall_now();
         struct HostTimer {
             double t0;
-            ~HostTimer() { g_times.host_assemble += wall_now() - t0; }
-        } host_timer{t_host};
+            double* sum;
+            ~HostTimer() { *sum += wall_now() - t0; }
+        } host_timer{t_host, &times.host_assemble};
         if (info[1] || info[2]) {
             *message = info[2] ? "Dixon residual overflow (coefficients too large for the 128-bit path)" : "Dixon residual not divisible by p";
             return false;
@@ -415,8 +418,8 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             BigInt n, d;
             const double t_rr = wall_now();
             const bool found = rational_reconstruct(combo, modulus, n, d);
-            g_times.reconstruct += wall_now() - t_rr;
-            g_times.reconstructs++;
+            times.reconstruct += wall_now() - t_rr;
+            times.reconstructs++;
             if (found && within_wang_bound(d, modulus)) denom = d;
             else ok = false;  // not enough digits yet
         }
@@ -438,8 +441,8 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
                 BigInt n, d;
                 const double t_rr = wall_now();
                 const bool found = rational_reconstruct(t, modulus, n, d);
-                g_times.reconstruct += wall_now() - t_rr;
-                g_times.reconstructs++;
+                times.reconstruct += wall_now() - t_rr;
+                times.reconstructs++;
                 if (!found) { ok = false; break; }
                 factor = factor * d;
                 denom = denom * d;
@@ -688,8 +691,8 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         auto solve = [&](const std::vector<i64>& r, int transpose, ExactVector* out) {
             g_times.solves++;
             const int first = 32;
-            return transpose ? dixon_solve(B, r, 1, p, dCT, buf, d_col_start, d_row_index, d_value, stream, out, message, first)
-                             : dixon_solve(B, r, 0, p, dC, buf, d_row_start, d_col_index, d_row_value, stream, out, message, first);
+            return transpose ? dixon_solve(B, r, 1, p, dCT, buf, d_col_start, d_row_index, d_value, stream, out, message, g_times, first)
+                             : dixon_solve(B, r, 0, p, dC, buf, d_row_start, d_col_index, d_row_value, stream, out, message, g_times, first);
         };
 
         // ---- exact primal and dual solutions ------------------------------------------------------------
@@ -720,9 +723,56 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             return true;
         };
         ExactVector x, y;
-        if (!solve_wide(rhs_big, &x)) return;
+        {
+            // The dual solve B' y = c_B (the rows of B' are the columns of B) runs on a second host thread and stream beside the
+            // primal one: the liftings are chains of small kernels that leave most of the GPU idle, and while one solve
+            // assembles its digits on the host the other one's kernels run.
+            bool dual_ok = false;
+            std::string dual_message;
+            std::exception_ptr dual_error;
+            CertifyTimes dual_times;
+            std::thread dual([&] {
+                try {
+                    RELP_HIP(hipSetDevice(device));
+                    hipStream_t second = nullptr;
+                    RELP_HIP(hipStreamCreateWithFlags(&second, hipStreamNonBlocking));
+                    try {
+                        DeviceBuffers dual_buffers;
+                        dual_ok = dixon_solve(B, cost_basis, 1, p, dCT, dual_buffers, d_col_start, d_row_index, d_value, second, &y,
+                                              &dual_message, dual_times, 32);
+                        RELP_HIP(hipStreamSynchronize(second));
+                    } catch (...) {
+                        (void)hipStreamDestroy(second);
+                        throw;
+                    }
+                    (void)hipStreamDestroy(second);
+                } catch (...) {
+                    dual_error = std::current_exception();
+                }
+            });
+            bool primal_ok = false;
+            std::exception_ptr primal_error;
+            try {
+                primal_ok = solve_wide(rhs_big, &x);
+            } catch (...) {
+                primal_error = std::current_exception();
+            }
+            dual.join();
+            g_times.solves++;
+            g_times.device_digits += dual_times.device_digits;
+            g_times.host_assemble += dual_times.host_assemble;
+            g_times.digit_launches += dual_times.digit_launches;
+            g_times.reconstruct += dual_times.reconstruct;
+            g_times.reconstructs += dual_times.reconstructs;
+            if (primal_error) std::rethrow_exception(primal_error);
+            if (dual_error) std::rethrow_exception(dual_error);
+            if (!primal_ok) return;
+            if (!dual_ok) {
+                *message = dual_message;
+                return;
+            }
+        }
         x.denom = x.denom * rhs_den;  // x_B = numer / (denom * rhs_den); all sign checks below only need denom > 0
-        if (!solve(cost_basis, 1, &y)) return;  // B' y = c_B: the rows of B' are the columns of B
 
         // ---- checks ---------------------------------------------------------------------------------------
         const double t_checks = wall_now();
@@ -738,14 +788,15 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         // reduced costs (common positive denominator cost_mult * Dy):  c_j*cost_mult*Dy - sum_i a_ij*row_mult_i*Y_i
         std::vector<BigInt> dhat(n_p);
         int worst_col = -1;
-        for (int j = 0; j < n_p; ++j) {
-            if (in_basis[j]) continue;
+        WorkerPool::get().run(n_p, [&](int j) {  // (independent columns; the most negative one is picked in order below)
+            if (in_basis[j]) return;
             BigInt acc = big_from_i128(scaled_cost(j)) * y.denom;
             for (size_t e = 0; e < columns[j].nnz(); ++e)
                 acc = acc - big_from_i128(scaled(columns[j].value[e], row_mult[columns[j].index[e]])) * y.numer[columns[j].index[e]];
             dhat[j] = acc;
-            if (acc.sign() < 0 && (worst_col < 0 || cmp(acc, dhat[worst_col]) < 0)) worst_col = j;
-        }
+        });
+        for (int j = 0; j < n_p; ++j)
+            if (!in_basis[j] && dhat[j].sign() < 0 && (worst_col < 0 || cmp(dhat[j], dhat[worst_col]) < 0)) worst_col = j;
         if (mode == 2) {
             // ---- unbounded ray: x_B >= 0, cbar_q < 0, alpha = B^-1 a_q <= 0 (zero where an artificial is basic) ------------
             if (worst_row >= 0) { *message = "unbounded: the basis is not primal feasible in exact arithmetic"; return; }
