@@ -52,20 +52,53 @@ __device__ __forceinline__ u32 reduce64(u64 v, u32 p) {
 }
 
 // All m columns of C = B^-1 mod p from the sparse factors P B Q = L U mod p: column j is the solve of e_j, one thread per
-// column; every thread walks the SAME factor entries in the same order (no divergence, the entries are uniform loads) and
-// owns column j of the m x m work matrix X (position-major, so a wave touches 64 consecutive words per step).
+// column; every thread walks the SAME factor entries in the same order (no divergence) and owns column j of the work matrix.
 //   l_* / u_*: strictly triangular parts by rows of the position space; dinv = 1 / diag mod p.
+// in_lds: the `columns` work columns of a workgroup live in LDS (xs[position][column], side by side) -- a solve is a chain of m
+// dependent rows, and a row costs an LDS round trip there instead of two trips to L2; staged: the FACTORS are copied to LDS as
+// well by all 256 threads of the workgroup first -- read from global memory every entry was a dependent uniform load of its
+// own (index -> operand address), 3 ms at m = 821 for 4.5 k entries; out of LDS the same walk takes 0.2 ms.
 // Writes C (row-major: C[slot][j]) and its transpose CT.
-__global__ void __launch_bounds__(64) modular_inverse_kernel(int m, u32 p, const int* rowpos, const int* colpos, const int* l_start,
-                                                              const int* l_col, const u32* l_val, const int* u_start, const int* u_col,
-                                                              const u32* u_val, const u32* dinv, u32* X, u32* C, u32* CT, int in_lds) {
-    // in_lds: the work columns of this workgroup live in LDS (xs[position][column]: blockDim.x columns side by side) -- a solve
-    // is a chain of m dependent rows, and a row costs an LDS round trip there instead of two trips to L2 (measured: 5.7 ms -> 0.4 ms
-    // at m = 821).  Otherwise (m too large for even one column per workgroup) the global work matrix X is used.
+__global__ void __launch_bounds__(256) modular_inverse_kernel(int m, u32 p, const int* rowpos, const int* colpos, const int* l_start,
+                                                               const int* l_col, const u32* l_val, const int* u_start, const int* u_col,
+                                                               const u32* u_val, const u32* dinv, u32* X, u32* C, u32* CT, int in_lds,
+                                                               int columns, int staged) {
     extern __shared__ u32 xs[];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (staged) {
+        const int nl = l_start[m], nu = u_start[m];
+        int* s_ls = reinterpret_cast<int*>(xs + (size_t)columns * m);
+        int* s_us = s_ls + (m + 1);
+        int* s_lc = s_us + (m + 1);
+        u32* s_lv = reinterpret_cast<u32*>(s_lc + nl);
+        int* s_uc = reinterpret_cast<int*>(s_lv + nl);
+        u32* s_uv = reinterpret_cast<u32*>(s_uc + nu);
+        u32* s_dinv = s_uv + nu;
+        for (int i = threadIdx.x; i <= m; i += blockDim.x) {
+            s_ls[i] = l_start[i];
+            s_us[i] = u_start[i];
+        }
+        for (int e = threadIdx.x; e < nl; e += blockDim.x) {
+            s_lc[e] = l_col[e];
+            s_lv[e] = l_val[e];
+        }
+        for (int e = threadIdx.x; e < nu; e += blockDim.x) {
+            s_uc[e] = u_col[e];
+            s_uv[e] = u_val[e];
+        }
+        for (int i = threadIdx.x; i < m; i += blockDim.x) s_dinv[i] = dinv[i];
+        __syncthreads();
+        l_start = s_ls;
+        u_start = s_us;
+        l_col = s_lc;
+        l_val = s_lv;
+        u_col = s_uc;
+        u_val = s_uv;
+        dinv = s_dinv;
+    }
+    if ((int)threadIdx.x >= columns) return;
+    const int j = blockIdx.x * columns + threadIdx.x;
     if (j >= m) return;
-    const int width = in_lds ? (int)blockDim.x : m;
+    const int width = in_lds ? columns : m;
     u32* x = in_lds ? xs + threadIdx.x : X + j;  // element i at x[i * width]
     const int start = rowpos[j];  // e_j in position space
     for (int i = 0; i < m; ++i) x[(size_t)i * width] = i == start ? 1u : 0u;
@@ -99,6 +132,107 @@ __global__ void __launch_bounds__(64) modular_inverse_kernel(int m, u32 p, const
         C[(size_t)s * m + j] = v;
         CT[(size_t)j * m + s] = v;
     }
+}
+
+// The same inverse, level scheduled: ONE WAVE per column of C.  The solves of different columns are independent, but 821
+// columns are 13 waves of the 1024 the chip holds when a thread walks a whole solve; the rows of one LEVEL of a factor are
+// independent too (lu_host.hpp `lu_schedules`: 25-40 levels per triangle on a basis of 25FV47, the first holding half of the
+// rows), so the 64 lanes of a wave take the rows of a level side by side and a column costs ~60 short steps instead of 4.6 k
+// dependent entries.  Factors and schedules are staged in LDS once per workgroup (4 waves = 4 columns); each wave keeps its
+// column there.  Writes CT (row j of CT = column j of C, coalesced); C is its transpose (transpose_kernel).
+struct ModularFactors {
+    const int* rowpos; const int* colpos;
+    const int* l_start; const int* l_col; const u32* l_val;
+    const int* u_start; const int* u_col; const u32* u_val;
+    const u32* dinv;
+    const int* lev_start_l; const int* lev_row_l; int levels_l;
+    const int* lev_start_u; const int* lev_row_u; int levels_u;
+};
+__global__ void __launch_bounds__(256) modular_inverse_levels_kernel(int m, u32 p, ModularFactors f, u32* CT) {
+    extern __shared__ u32 smem[];
+    const int nl = f.l_start[m], nu = f.u_start[m];
+    int* s_ls = reinterpret_cast<int*>(smem);
+    int* s_us = s_ls + (m + 1);
+    int* s_lc = s_us + (m + 1);
+    u32* s_lv = reinterpret_cast<u32*>(s_lc + nl);
+    int* s_uc = reinterpret_cast<int*>(s_lv + nl);
+    u32* s_uv = reinterpret_cast<u32*>(s_uc + nu);
+    u32* s_dinv = s_uv + nu;
+    int* s_levl = reinterpret_cast<int*>(s_dinv + m);   // levels_l + 1
+    int* s_rowl = s_levl + (f.levels_l + 1);            // m
+    int* s_levu = s_rowl + m;                            // levels_u + 1
+    int* s_rowu = s_levu + (f.levels_u + 1);             // m
+    int* s_colpos = s_rowu + m;                          // m
+    u32* s_x = reinterpret_cast<u32*>(s_colpos + m);     // 4 columns of m
+    for (int i = threadIdx.x; i <= m; i += 256) {
+        s_ls[i] = f.l_start[i];
+        s_us[i] = f.u_start[i];
+    }
+    for (int e = threadIdx.x; e < nl; e += 256) {
+        s_lc[e] = f.l_col[e];
+        s_lv[e] = f.l_val[e];
+    }
+    for (int e = threadIdx.x; e < nu; e += 256) {
+        s_uc[e] = f.u_col[e];
+        s_uv[e] = f.u_val[e];
+    }
+    for (int i = threadIdx.x; i < m; i += 256) {
+        s_dinv[i] = f.dinv[i];
+        s_rowl[i] = f.lev_row_l[i];
+        s_rowu[i] = f.lev_row_u[i];
+        s_colpos[i] = f.colpos[i];
+    }
+    for (int l = threadIdx.x; l <= f.levels_l; l += 256) s_levl[l] = f.lev_start_l[l];
+    for (int l = threadIdx.x; l <= f.levels_u; l += 256) s_levu[l] = f.lev_start_u[l];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= m) return;
+    u32* x = s_x + (size_t)wave * m;
+    const int start = f.rowpos[j];  // e_j in position space
+    for (int i = lane; i < m; i += 64) x[i] = i == start ? 1u : 0u;
+    const u64 two32 = (1ull << 32) % p;
+    __builtin_amdgcn_wave_barrier();
+    // L x = e (unit diagonal): level 0 has no entries
+    for (int l = 1; l < f.levels_l; ++l) {
+        for (int r = s_levl[l] + lane; r < s_levl[l + 1]; r += 64) {
+            const int i = s_rowl[r];
+            u64 lo = x[i], hi = 0;
+            for (int e = s_ls[i]; e < s_ls[i + 1]; ++e) {
+                const u64 prod = (u64)(p - s_lv[e]) * x[s_lc[e]];  // -l x  (mod p)
+                lo += prod & 0xffffffffu;
+                hi += prod >> 32;
+            }
+            x[i] = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // U x = y
+    for (int l = 0; l < f.levels_u; ++l) {
+        for (int r = s_levu[l] + lane; r < s_levu[l + 1]; r += 64) {
+            const int i = s_rowu[r];
+            u64 lo = x[i], hi = 0;
+            for (int e = s_us[i]; e < s_us[i + 1]; ++e) {
+                const u64 prod = (u64)(p - s_uv[e]) * x[s_uc[e]];
+                lo += prod & 0xffffffffu;
+                hi += prod >> 32;
+            }
+            const u32 v = reduce64((u64)reduce64(hi, p) * two32 + reduce64(lo, p), p);
+            x[i] = reduce64((u64)v * s_dinv[i], p);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int sl = lane; sl < m; sl += 64) CT[(size_t)j * m + sl] = x[s_colpos[sl]];
+}
+__global__ void __launch_bounds__(256) transpose_u32_kernel(int m, const u32* in, u32* out) {
+    __shared__ u32 tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8)
+        if (by + k < m && bx + tx < m) tile[k][tx] = in[(size_t)(by + k) * m + bx + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (bx + k < m && by + tx < m) out[(size_t)(bx + k) * m + by + tx] = tile[tx][k];
 }
 
 // Dixon digit: x = A (r mod p) mod p for a row-major m x m matrix A (C for B x = b, C' for B' y = c).  One wave per output
@@ -643,7 +777,9 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             LuOptions lo;
             lo.threshold = 0.0;
             const LuModOps ops{candidate};
+            const double t_lu = wall_now();
             const HostLUT<u32> f = lu_factor_t<LuModOps>(m, B.col_start.data(), B.row_index.data(), value_mod.data(), lo, ops);
+            if (getenv("RELP_TIME_CERTIFY")) fprintf(stderr, "[certify]   modular LU on the host %.2f ms (L %zu, U %zu entries)\n", (wall_now() - t_lu) * 1e3, f.l_col.size(), f.u_col.size());
             if (f.singular) continue;  // singular modulo this prime (or singular): try the next one
             std::vector<u32> dinv(m);
             for (int i = 0; i < m; ++i) dinv[i] = ops.inverse(f.diag[i]);
@@ -666,21 +802,52 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             if (nu) RELP_HIP(hipMemcpyAsync(d_uc, f.u_col.data(), nu * sizeof(int), hipMemcpyHostToDevice, stream));
             if (nu) RELP_HIP(hipMemcpyAsync(d_uv, f.u_val.data(), nu * sizeof(u32), hipMemcpyHostToDevice, stream));
             RELP_HIP(hipMemcpyAsync(d_dinv, dinv.data(), m * sizeof(u32), hipMemcpyHostToDevice, stream));
-            {
-                // columns per workgroup: as many (a power of two, at most 32) as fit the LDS next to each other
+            HostLUT<u32> fs = f;
+            lu_schedules(fs);
+            const int levels_l = (int)fs.lev_start[0].size() - 1, levels_u = (int)fs.lev_start[1].size() - 1;
+            const size_t level_lds = ((size_t)2 * (m + 1) + 2 * nl + 2 * nu + m + (levels_l + 1) + m + (levels_u + 1) + m + m + (size_t)4 * m) * sizeof(u32);
+            if (level_lds <= 150 * 1024 && !getenv("RELP_CERTIFY_NO_LEVELS")) {
+                // one wave per column, level by level (modular_inverse_levels_kernel)
+                int* d_levl = buf.alloc<int>(levels_l + 1);
+                int* d_rowl = buf.alloc<int>(m);
+                int* d_levu = buf.alloc<int>(levels_u + 1);
+                int* d_rowu = buf.alloc<int>(m);
+                RELP_HIP(hipMemcpyAsync(d_levl, fs.lev_start[0].data(), (levels_l + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+                RELP_HIP(hipMemcpyAsync(d_rowl, fs.lev_row[0].data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
+                RELP_HIP(hipMemcpyAsync(d_levu, fs.lev_start[1].data(), (levels_u + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+                RELP_HIP(hipMemcpyAsync(d_rowu, fs.lev_row[1].data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
+                static bool configured_levels = false;
+                if (!configured_levels) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modular_inverse_levels_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    configured_levels = true;
+                }
+                ModularFactors mf{d_rowpos, d_colpos, d_ls, d_lc, d_lv, d_us, d_uc, d_uv, d_dinv, d_levl, d_rowl, levels_l, d_levu, d_rowu, levels_u};
+                hipLaunchKernelGGL(modular_inverse_levels_kernel, dim3((m + 3) / 4), dim3(256), level_lds, stream, m, candidate, mf, dCT);
+                hipLaunchKernelGGL(transpose_u32_kernel, dim3((m + 31) / 32, (m + 31) / 32), dim3(256), 0, stream, m, dCT, dC);
+            } else {
+                // columns per workgroup: as many (a power of two, at most 32) as fit the LDS next to each other -- beside the
+                // factors themselves when those fit too
+                const size_t factor_bytes = ((size_t)2 * (m + 1) + 2 * nl + 2 * nu + m) * sizeof(u32);
+                const size_t lds_cap = 150 * 1024;
                 int columns = 32;
-                while (columns > 1 && (size_t)columns * m * sizeof(u32) > 150 * 1024) columns /= 2;
-                const bool in_lds = (size_t)columns * m * sizeof(u32) <= 150 * 1024;
+                bool staged = factor_bytes + (size_t)8 * m * sizeof(u32) <= lds_cap;  // at least 8 columns beside the factors
+                const size_t room = staged ? lds_cap - factor_bytes : lds_cap;
+                while (columns > 1 && (size_t)columns * m * sizeof(u32) > room) columns /= 2;
+                const bool in_lds = (size_t)columns * m * sizeof(u32) <= room;
+                if (!in_lds) staged = false;
                 static bool configured = false;
                 if (!configured) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modular_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     configured = true;
                 }
                 if (!in_lds) columns = 64;
-                hipLaunchKernelGGL(modular_inverse_kernel, dim3((m + columns - 1) / columns), dim3(columns), in_lds ? (size_t)columns * m * sizeof(u32) : 0,
-                                   stream, m, candidate, d_rowpos, d_colpos, d_ls, d_lc, d_lv, d_us, d_uc, d_uv, d_dinv, dX, dC, dCT, in_lds ? 1 : 0);
+                const size_t lds = in_lds ? (size_t)columns * m * sizeof(u32) + (staged ? factor_bytes : 0) : 0;
+                hipLaunchKernelGGL(modular_inverse_kernel, dim3((m + columns - 1) / columns), dim3(staged ? 256 : columns), lds, stream, m, candidate,
+                                   d_rowpos, d_colpos, d_ls, d_lc, d_lv, d_us, d_uc, d_uv, d_dinv, dX, dC, dCT, in_lds ? 1 : 0, columns, staged ? 1 : 0);
             }
+            const double t_sync = wall_now();
             RELP_HIP(hipStreamSynchronize(stream));  // (the staging vectors above go out of scope)
+            if (getenv("RELP_TIME_CERTIFY")) fprintf(stderr, "[certify]   waited %.2f ms for the uploads and the inverse kernel\n", (wall_now() - t_sync) * 1e3);
             p = candidate;
             break;
         }
