@@ -76,3 +76,37 @@ def test_fused_path_certifies_the_exact_optimum():
         assert r.kind == relp_amd.FINITE_OPTIMUM and r.certified
         assert Fraction(s.objective_exact()) == Fraction(golden["objective"])
         s.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fused_pivot_with_more_than_128_pricing_workgroups(seed):
+    """> 4096 columns: the candidates' columns are not staged with them and the entering column comes from the CSC (the other
+    FTRAN path of the fused kernel); columns of up to 12 entries also take the long-column tail.  Same bits as the
+    three-kernel pivot, and the exact optimum through the certificate of both."""
+    import random
+    rng = random.Random(31000 + seed)
+    m, n = 48, 5000 + 37 * seed
+    columns, column_start, rows, nums = [], [0], [], []
+    for j in range(n):
+        support = sorted(rng.sample(range(m), rng.randint(1, 12)))
+        for i in support:
+            rows.append(i)
+            nums.append(rng.choice([1, 2, 3, 5, 7]))  # non-negative rows: bounded
+        column_start.append(len(rows))
+    b = [rng.randint(1, 40) for _ in range(m)]
+    cost = [rng.randint(-30, 5) for _ in range(n)]
+    results = []
+    for fused in (True, False):
+        if not fused:
+            os.environ["RELP_NO_FUSED"] = "1"
+        try:
+            solver = relp_amd.Solver(certify=1)
+            solver.load_matrix_data(column_start, rows, nums, [1] * len(nums), b=b, cost=cost, counts=(0, 0, m, 0))
+        finally:
+            os.environ.pop("RELP_NO_FUSED", None)
+        r = solver.solve_relaxation()
+        results.append((r.kind, r.pivots_phase_one, r.pivots_phase_two, r.objective, tuple(solver.basis()),
+                        solver.objective_exact() if r.kind == relp_amd.FINITE_OPTIMUM else None, r.certified))
+        solver.close()
+    assert results[0] == results[1]
+    assert results[0][0] == relp_amd.FINITE_OPTIMUM and results[0][6] and results[0][2] > 10
