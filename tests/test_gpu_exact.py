@@ -95,3 +95,60 @@ def test_infeasible_and_unbounded_exactly():
     solver.load_matrix_data([0, 2], [0, 1], [1, 1], [1, 1], b=[1, 2], cost=[1], counts=(0, 0, 1, 1))
     assert solver.solve_exact()["status"] == 2          # x <= 1 and x >= 2
     solver.close()
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_lps_pivot_for_pivot(seed):
+    """Random LPs with every row kind and rational data: verdict, pivot counts, the WHOLE (phase, q, p, leaving) sequence and the
+    exact optimum of the device equal the oracle's.  (Rank-deficient instances end with status 6 on the device -- the reference
+    removes rows there, this path does not -- and are only checked for not returning a wrong answer.)"""
+    import random
+    from fractions import Fraction
+    from relp_oracle import FiniteOptimum, Infeasible, MatrixData, Unbounded, Variable
+    rng = random.Random(77000 + seed)
+    n = rng.randint(3, 9)
+    counts = [rng.randint(0, 3), 0, rng.randint(0, 4), rng.randint(0, 3)]
+    if sum(counts) < 2:
+        counts[2] += 2
+    m = sum(counts)
+    dense = [[rng.choice([1, 2, 3, -1, -2, 5, 7, -4]) if rng.random() < 0.6 else 0 for _ in range(n)] for _ in range(m)]
+    for i in range(m):
+        if not any(dense[i]):
+            dense[i][rng.randrange(n)] = 1
+    dens = [[rng.choice([1, 1, 1, 2, 3]) for _ in range(n)] for _ in range(m)]   # coefficients v / d
+    columns = [[(i, Fraction(dense[i][j], dens[i][j])) for i in range(m) if dense[i][j]] for j in range(n)]
+    b = [Fraction(rng.randint(0, 12), rng.choice([1, 1, 2, 3])) for _ in range(m)]
+    cost = [Fraction(rng.randint(-6, 8), rng.choice([1, 1, 2])) for _ in range(n)]
+    data = MatrixData(columns, b, [], counts[0], counts[1], counts[2], counts[3], [Variable(c) for c in cost])
+    trace = Trace()
+    try:
+        exact = solve_relaxation(data, trace=trace)
+    except IndexError:
+        pytest.skip("single-row LP: the reference's LU update indexes an empty Vec (lower_upper/mod.rs:150)")
+    column_start, rows, nums, dnms = [0], [], [], []
+    for column in columns:
+        for i, v in column:
+            rows.append(i)
+            nums.append(v.numerator)
+            dnms.append(v.denominator)
+        column_start.append(len(rows))
+    solver = relp_amd.Solver()
+    solver.load_matrix_data(column_start, rows, nums, dnms, b=[(v.numerator, v.denominator) for v in b],
+                            cost=[(v.numerator, v.denominator) for v in cost], counts=tuple(counts))
+    got = solver.solve_exact(first_limbs=1, max_limbs=32)
+    if got["status"] == 6:
+        solver.close()
+        return
+    n_art = solver.n_art
+    if isinstance(exact, FiniteOptimum):
+        assert got["status"] == 1, got
+        objective = sum((cost[j] * v for j, v in data.reconstruct_solution(exact.solution)), Fraction(0))
+        assert Fraction(got["objective"]) == objective
+        assert got["trace"] == device_indices(trace.pivots, n_art)
+    elif isinstance(exact, Infeasible):
+        assert got["status"] == 2
+        assert got["trace"] == device_indices([t for t in trace.pivots if t[0] == 1], n_art)
+    else:
+        assert isinstance(exact, Unbounded) and got["status"] == 3
+        assert got["trace"] == device_indices(trace.pivots, n_art)
+    solver.close()
