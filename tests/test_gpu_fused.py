@@ -110,3 +110,19 @@ def test_fused_pivot_with_more_than_128_pricing_workgroups(seed):
         solver.close()
     assert results[0] == results[1]
     assert results[0][0] == relp_amd.FINITE_OPTIMUM and results[0][6] and results[0][2] > 10
+
+
+def test_fused_path_is_the_one_that_runs():
+    """Two kernel launches per pivot (pricing, fused pivot kernel) instead of three: counted by the library itself."""
+    a = load("25FV47", True, use_graph=0)
+    b = load("25FV47", False, use_graph=0)
+    ra, rb = a.solve_relaxation(), b.solve_relaxation()
+    pivots = ra.pivots_phase_one + ra.pivots_phase_two
+    assert pivots == rb.pivots_phase_one + rb.pivots_phase_two
+    launches_a, launches_b = a.stats().launches, b.stats().launches
+    # (batches run past the end of a phase: at most one batch of 64 no-op pivots per phase and per polish interval)
+    assert 2 * pivots <= launches_a <= 2 * (pivots + 64 * 12) + 200
+    assert 3 * pivots <= launches_b <= 3 * (pivots + 64 * 12) + 200
+    assert launches_a < launches_b
+    a.close()
+    b.close()
