@@ -126,3 +126,18 @@ def test_fused_path_is_the_one_that_runs():
     assert launches_a < launches_b
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("cap", [1, 7, 64, 65, 200])
+def test_iteration_cap_and_partial_batches_agree(cap):
+    """`max_pivots` smaller than a batch, equal to one, one more: the budget logic of the fused batches (begin / commit kernels,
+    copies alternating per pivot) ends in the same state as the three-kernel pivot."""
+    a = load("SHARE2B", True, max_pivots=cap)
+    b = load("SHARE2B", False, max_pivots=cap)
+    ra, rb = a.solve_relaxation(), b.solve_relaxation()
+    assert ra.kind == rb.kind
+    assert (ra.pivots_phase_one, ra.pivots_phase_two) == (rb.pivots_phase_one, rb.pivots_phase_two)
+    assert ra.pivots_phase_one + ra.pivots_phase_two <= cap or ra.kind == relp_amd.FINITE_OPTIMUM
+    assert np.array_equal(a.basis(), b.basis())
+    a.close()
+    b.close()
