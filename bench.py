@@ -324,6 +324,9 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if world > 1:
+        # the exact certificate assembles its digits on host threads (up to 32 per process): share the cores between the ranks
+        os.environ.setdefault("RELP_CERTIFY_THREADS", str(max(2, (os.cpu_count() or 8) // world)))
     import relp_amd
     path = WORKLOADS[args.workload]
     if path == "batch":
