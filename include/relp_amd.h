@@ -263,8 +263,7 @@ int32_t relp_get_record_json(const relp_handle* handle, char* buffer, int32_t ca
  * (status 4 when `max_limbs` <= 32 is not enough).  For small LPs: one workgroup owns the whole solve.
  *   trace: (phase, entering column, pivot row, leaving column) per pivot, in the index space of relp_price;
  *   objective: the exact optimum "num/den" incl. fixed cost; basis: as relp_get_basis.
- * status: 1 optimal | 2 infeasible | 3 unbounded | 4 overflow | 5 pivot limit | 6 redundant rows (the reference removes such
- * rows and re-indexes, `RemoveRows`; this path does not). */
+ * status: 1 optimal | 2 infeasible | 3 unbounded | 4 overflow | 5 pivot limit. */
 typedef struct relp_exact_result {
     int32_t status;
     int32_t limbs;              /* limbs of the run that finished */
@@ -273,6 +272,10 @@ typedef struct relp_exact_result {
     int32_t trace_entries;
     int32_t objective_length;
     int32_t limbs_tried[6];     /* every width that was tried, in order ... */
+    int32_t redundant_rows;     /* rows found redundant at the end of phase one: the reference removes them (`RemoveRows`), here
+                                   each keeps its zero-level artificial basic (-1 - k in `basis`) and the phase-two row indices of
+                                   `trace` count the remaining rows, as the reference's do */
+    int32_t reserved;
     int64_t pivots_survived[6]; /* ... and the pivots it made before a value might not fit (or until it finished) */
 } relp_exact_result;
 int32_t relp_solve_exact(relp_handle* handle, int32_t first_limbs, int32_t max_limbs, int64_t max_pivots, relp_exact_result* result,

@@ -46,7 +46,7 @@ class Result(C.Structure):
 class ExactResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("limbs", C.c_int32), ("pivots_phase_one", C.c_int64), ("pivots_phase_two", C.c_int64),
                 ("trace_entries", C.c_int32), ("objective_length", C.c_int32), ("limbs_tried", C.c_int32 * 6),
-                ("pivots_survived", C.c_int64 * 6)]
+                ("redundant_rows", C.c_int32), ("reserved", C.c_int32), ("pivots_survived", C.c_int64 * 6)]
 
 
 class Stats(C.Structure):
@@ -448,7 +448,7 @@ class Solver:
         return {"status": result.status, "limbs": result.limbs, "pivots_phase_one": result.pivots_phase_one,
                 "pivots_phase_two": result.pivots_phase_two,
                 "trace": [tuple(int(v) for v in trace[4 * k:4 * k + 4]) for k in range(entries)],
-                "objective": objective.value.decode(), "basis": basis,
+                "objective": objective.value.decode(), "basis": basis, "redundant_rows": int(result.redundant_rows),
                 "survived": [(int(result.limbs_tried[k]), int(result.pivots_survived[k])) for k in range(6) if result.limbs_tried[k]]}
 
     def record(self):

@@ -678,8 +678,11 @@ int32_t relp_solve_exact(relp_handle* h, int32_t first_limbs, int32_t max_limbs,
         std::vector<std::pair<int, long long>> survived;
         int status = 0, limbs = 0;
         long long p1 = 0, p2 = 0;
-        h->solver->solve_exact(first_limbs, max_limbs, max_pivots, std::max(trace_capacity, 1), &status, &limbs, &p1, &p2, &tr, &text, &final_basis, &survived);
+        int redundant = 0;
+        h->solver->solve_exact(first_limbs, max_limbs, max_pivots, std::max(trace_capacity, 1), &status, &limbs, &p1, &p2, &tr, &text, &final_basis, &survived,
+                               &redundant);
         result->status = status;
+        result->redundant_rows = redundant;
         result->limbs = limbs;
         result->pivots_phase_one = p1;
         result->pivots_phase_two = p2;

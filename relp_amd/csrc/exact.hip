@@ -295,6 +295,7 @@ struct ExactLP {
     int trace_capacity;
     long long max_pivots;
     int* out;             // [8]: status, pivots phase one, pivots phase two, limbs, trace entries, redundant rows
+    int* removed;         // [m] 1: the row is redundant -- its artificial cannot be pivoted out (`RemoveRows` of the reference)
 };
 
 // Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
@@ -394,6 +395,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
     auto log2_ceil = [](int count) { return 32 - __clz(count > 1 ? count - 1 : 1) + 1; };
     // drive_row >= 0: the zero-level pivots of phase_one.rs:232-278 are under way, this is the next row to look at
     int drive_row = -1;
+    int n_removed = 0;  // redundant rows found there
     while (status == EX_RUNNING) {
         if (pivots[0] + pivots[1] >= lp.max_pivots) { status = EX_PIVOT_LIMIT; break; }
         const Big<L> D = big_load<L>(gD);
@@ -541,7 +543,17 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 if (!big_zero(a) && (first == RANK_NONE || (unsigned long long)j < first)) { first = (unsigned long long)j; dummy = 1.0; }
             }
             block_argbest(dummy, first, s_key, s_rank);
-            if (first == RANK_NONE) { status = EX_REDUNDANT_ROWS; break; }  // the reference removes such rows (RemoveRows): not here
+            if (first == RANK_NONE) {
+                // The row of the tableau is zero on every column that could enter: the constraint is redundant and the reference
+                // REMOVES it (phase_one.rs:232-278 collects such rows, `RemoveRows` re-indexes the rest,
+                // filter/generic_wrapper.rs:98-205).  Here the row stays, with its zero-level artificial basic: alpha_r = 0 for
+                // every entering column from now on, so it never takes part in a ratio test and adds nothing to a steepest-edge
+                // weight; only the ROW INDICES reported for phase two are shifted as the removal shifts them.
+                if (tid == 0) lp.removed[r] = 1;
+                ++n_removed;
+                drive_row = r + 1;
+                continue;
+            }
             q = (int)first;
             p = r;
             drive_row = r + 1;
@@ -635,9 +647,12 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             lp.pos[q] = p;
             lp.pos[leaving] = -1;
             if (trace_count < lp.trace_capacity) {
+                int p_reported = p;
+                if (phase == 2 && n_removed > 0)  // the reference's phase two counts the rows that are left
+                    for (int i = 0; i < p; ++i) p_reported -= lp.removed[i];
                 lp.trace[4 * trace_count] = phase;
                 lp.trace[4 * trace_count + 1] = q;
-                lp.trace[4 * trace_count + 2] = p;
+                lp.trace[4 * trace_count + 2] = p_reported;
                 lp.trace[4 * trace_count + 3] = leaving;
             }
         }
@@ -665,6 +680,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         lp.out[2] = (int)pivots[1];
         lp.out[3] = L;
         lp.out[4] = trace_count < lp.trace_capacity ? trace_count : lp.trace_capacity;
+        lp.out[5] = n_removed;
     }
 }
 
@@ -700,12 +716,13 @@ BigInt big_from_words(const u64* w, int limbs) {  // two's complement words -> s
 }  // namespace
 
 // Host driver: scales the LP to integers, runs the kernel with 2, 4, ... limbs until it does not overflow.
-//   status: 1 optimal | 2 infeasible | 3 unbounded | 4 overflow at the largest width | 5 pivot limit | 6 redundant rows
+//   status: 1 optimal | 2 infeasible | 3 unbounded | 4 overflow at the largest width | 5 pivot limit   (6 is no longer produced)
 void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
                    int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
                    std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
-                   std::vector<std::pair<int, long long>>* pivots_survived) {
+                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows) {
     RELP_HIP(hipSetDevice(device));
+    if (redundant_rows) *redundant_rows = 0;
     const MatrixData& md = form.data;
     const int m = md.nr_rows(), n_p = md.nr_columns();
     std::vector<SparseColumn> columns(n_p);
@@ -796,6 +813,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     double* d_key = dalloc<double>(n, owned);
     int* d_trace = dalloc<int>((size_t)4 * trace_capacity, owned);
     int* d_out = dalloc<int>(8, owned);
+    int* d_removed = dalloc<int>(m, owned);
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
@@ -836,8 +854,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemcpyAsync(d_D, hD.data(), big * sizeof(u64), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(d_basis, basis0.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemsetAsync(d_removed, 0, m * sizeof(int), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_removed};
         switch (limbs) {
             case 1: hipLaunchKernelGGL(exact_simplex_kernel<1>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
             case 2: hipLaunchKernelGGL(exact_simplex_kernel<2>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
@@ -857,6 +876,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         *pivots_phase_two = out[2];
         if (pivots_survived) pivots_survived->push_back({limbs, (long long)out[1] + out[2]});
         if (out[0] == EX_OVERFLOW) continue;
+        if (redundant_rows) *redundant_rows = out[5];
         // results of the run that did not overflow
         if (trace) {
             trace->assign((size_t)4 * out[4], 0);

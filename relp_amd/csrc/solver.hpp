@@ -169,7 +169,7 @@ public:
     void after_basis_update();
     void solve_exact(int first_limbs, int max_limbs, long long max_pivots, int trace_capacity, int* status, int* limbs, long long* p1,
                      long long* p2, std::vector<int>* trace, std::string* objective, std::vector<int>* basis,
-                     std::vector<std::pair<int, long long>>* survived);
+                     std::vector<std::pair<int, long long>>* survived, int* redundant_rows = nullptr);
     void last_pivot(int* phase, int* column, int* row, int* leaving);
     double refactor();
     void get_b(double* out);

@@ -100,8 +100,8 @@ def test_infeasible_and_unbounded_exactly():
 @pytest.mark.parametrize("seed", range(80))
 def test_random_lps_pivot_for_pivot(seed):
     """Random LPs with every row kind and rational data: verdict, pivot counts, the WHOLE (phase, q, p, leaving) sequence and the
-    exact optimum of the device equal the oracle's.  (Rank-deficient instances end with status 6 on the device -- the reference
-    removes rows there, this path does not -- and are only checked for not returning a wrong answer.)"""
+    exact optimum of the device equal the oracle's -- also on rank-deficient instances, where the reference removes the
+    redundant rows after phase one and counts the remaining ones in phase two (`RemoveRows`)."""
     import random
     from fractions import Fraction
     from relp_oracle import FiniteOptimum, Infeasible, MatrixData, Unbounded, Variable
@@ -136,9 +136,7 @@ def test_random_lps_pivot_for_pivot(seed):
     solver.load_matrix_data(column_start, rows, nums, dnms, b=[(v.numerator, v.denominator) for v in b],
                             cost=[(v.numerator, v.denominator) for v in cost], counts=tuple(counts))
     got = solver.solve_exact(first_limbs=1, max_limbs=32)
-    if got["status"] == 6:
-        solver.close()
-        return
+    assert got["status"] != 6          # rank-deficient LPs are carried through (the redundant rows keep their artificial)
     n_art = solver.n_art
     if isinstance(exact, FiniteOptimum):
         assert got["status"] == 1, got
@@ -151,4 +149,28 @@ def test_random_lps_pivot_for_pivot(seed):
     else:
         assert isinstance(exact, Unbounded) and got["status"] == 3
         assert got["trace"] == device_indices(trace.pivots, n_art)
+    solver.close()
+
+
+@pytest.mark.parametrize("name, limbs", [("unicamp_model_data_6", 8)])  # (SCORPION, 30 redundant rows of 388: the same at 32 limbs, 6 minutes -- tools/exact_probe.py)
+def test_rank_deficient_lps_follow_the_reference_through_row_removal(name, limbs):
+    """LPs whose phase one ends with redundant rows (3 of 13, 30 of 388): the reference removes them and re-indexes the rows of
+    phase two (phase_one.rs:232-278, filter/generic_wrapper.rs:98-205); the device keeps them with their zero-level artificial
+    and reports the reference's indices.  Whole golden trace head, pivot counts, basis of the remaining rows, exact optimum."""
+    golden = GOLDEN[name]
+    solver = relp_amd.Solver().load_mps(os.path.join(ROOT, golden["file"]))
+    got = solver.solve_exact(first_limbs=1, max_limbs=limbs)
+    assert got["status"] == 1, got
+    assert got["redundant_rows"] == golden["m"] - len(golden["basis"]) > 0
+    assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"])
+    assert got["objective"] == golden["objective"]
+    head = device_indices([tuple(t) for t in golden["trace_head"]], solver.n_art)
+    assert got["trace"][:len(head)] == head
+    assert sorted(int(c) for c in got["basis"] if c >= 0) == sorted(golden["basis"])
+    assert sum(1 for c in got["basis"] if c < 0) == got["redundant_rows"]
+    if golden.get("oracle_seconds", 1e9) < 20:
+        general, data = load_problem(os.path.join(ROOT, golden["file"]))
+        trace = Trace()
+        solve_relaxation(data, trace=trace)
+        assert got["trace"] == device_indices(trace.pivots, solver.n_art)
     solver.close()
