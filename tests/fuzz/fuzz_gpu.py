@@ -53,8 +53,9 @@ for seed in range(first, first + count):
         for i, v in col:
             rows.append(i); nums.append(v)
         column_start.append(len(rows))
-    for mode in (0, 1):
-        solver = relp_amd.Solver(certify=1, implicit_bounds=mode)
+    CARRY = int(os.environ.get("RELP_FUZZ_CARRY", "0"))  # 1: the LU + Forrest-Tomlin carry (bound rows explicit only)
+    for mode in ((0,) if CARRY else (0, 1)):
+        solver = relp_amd.Solver(certify=1, implicit_bounds=mode, carry=CARRY)
         try:
             solver.load_matrix_data(column_start, rows or [0], nums or [0], [1] * max(1, len(nums)), b=b, cost=cost, upper=upper,
                                     ranges=ranges, counts=tuple(counts))
