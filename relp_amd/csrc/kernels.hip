@@ -2109,7 +2109,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
 //     next pricing pass;
 //   * `begin_batch_kernel` / `commit_kernel` move the canonical arrays into copy 0 and the last copy (and the inverse) back, so
 //     everything outside a batch of pivots sees the canonical arrays only.
-// Same arithmetic in the same order as ftran_ratio_fast_kernel<RULE, 2> + update_kernel<true>: the pivot sequence and every
+// Same arithmetic in the same order as ftran_ratio_fast_kernel<RULE, R> + update_kernel<true>: the pivot sequence and every
 // number are BIT-IDENTICAL with the three-kernel pivot (tests/test_gpu_fused.py).
 // Measured and dropped: one wave per workgroup with all rows in registers (a wave cannot keep enough loads in
 // flight: 25 us), wave-local decisions out of LDS (16 rows and 32 divisions per lane: 14 us), and ONE launch per pivot with
@@ -2117,13 +2117,14 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
 // ---------------------------------------------------------------------------------------------------
 constexpr int KF_THREADS = 512;
 constexpr int KF_NW = KF_THREADS / WAVE;  // waves = columns of the inverse per workgroup
-constexpr int KF_R = 2;                   // rows per thread
-constexpr int KF_U = 16;                  // 16 x 64 rows of a column per lane
-constexpr int KF_MAX_M = KF_R * KF_THREADS;
-template <int RULE>
+constexpr int KF_MAX_R = 4;               // rows per thread: 2 up to 1024 rows, 4 up to 2048 (as ftran_ratio_fast_kernel<RULE, R>)
+constexpr int KF_MAX_M = KF_MAX_R * KF_THREADS;
+template <int RULE, int KF_R>
 __global__ void __launch_bounds__(KF_THREADS) pivot_fused_kernel(DeviceLP lp, DeviceLP::State in, DeviceLP::State out, int n_price_blocks,
                                                                  double tol_pivot, double harris_delta, int skip_artificial_rows) {
     constexpr int R = KF_R;
+    constexpr int KF_U = KF_R * KF_THREADS / WAVE;  // rows of a column per lane
+    constexpr int KF_M = KF_R * KF_THREADS;
     __shared__ double s_akey[KF_NW];
     __shared__ unsigned long long s_arank[KF_NW];
     __shared__ double s_red[KF_NW + 2];
@@ -2134,7 +2135,7 @@ __global__ void __launch_bounds__(KF_THREADS) pivot_fused_kernel(DeviceLP lp, De
     __shared__ int s_clen[K2F_INLINE_BLOCKS];
     __shared__ int s_rows[K2_COL_CHUNK];
     __shared__ double s_vals[K2_COL_CHUNK];
-    __shared__ double s_alpha[KF_MAX_M];
+    __shared__ double s_alpha[KF_M];
     __shared__ double s_bcast[4];
     __shared__ int s_ibcast[2];
     const Ctl* ctl = in.ctl;  // (the two copies are kernel arguments: no dependent load to find them)
@@ -3232,10 +3233,14 @@ bool fused_pivot_available(const DeviceLP& d, int n_price_blocks) { return d.m <
 void launch_pivot_fused(const DeviceLP& d, int rule, int parity, int n_price_blocks, double tol_pivot, double harris_delta,
                         int skip_artificial_rows, hipStream_t s) {
     const dim3 grid((d.m + KF_NW - 1) / KF_NW);
-    if (rule == RELP_PIVOT_STEEPEST_EDGE)
-        RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_STEEPEST_EDGE>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
-    else
-        RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_DANTZIG>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+    const bool small = d.m <= 2 * KF_THREADS;
+    if (rule == RELP_PIVOT_STEEPEST_EDGE) {
+        if (small) RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_STEEPEST_EDGE, 2>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+        else RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_STEEPEST_EDGE, 4>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+    } else {
+        if (small) RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_DANTZIG, 2>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+        else RELP_LAUNCH(1, (pivot_fused_kernel<RELP_PIVOT_DANTZIG, 4>), grid, dim3(KF_THREADS), 0, s, d, d.state[parity], d.state[parity ^ 1], n_price_blocks, tol_pivot, harris_delta, skip_artificial_rows);
+    }
 }
 void launch_begin_batch(const DeviceLP& d, long long add, hipStream_t s) {
     hipLaunchKernelGGL(begin_batch_kernel, dim3(1), dim3(256), 0, s, d, add);

@@ -12,7 +12,8 @@ import relp_amd
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = ["AFIRO", "SC50A", "ADLITTLE", "SHARE2B", "BLEND", "SCAGR7", "BRANDY", "E226", "SCFXM1", "BANDM", "25FV47"]
+NAMES = ["AFIRO", "SC50A", "ADLITTLE", "SHARE2B", "BLEND", "SCAGR7", "BRANDY", "E226", "SCFXM1", "BANDM", "25FV47",
+         "CZPROB", "CYCLE"]  # (the last two: 1024 < m <= 2048, four rows per thread)
 
 
 def load(name, fused, **options):
