@@ -2096,7 +2096,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K23: ratio test AND inverse update in ONE launch (m <= 1024, explicit carry, no implicit bounds, no forced pivot): two
+// K23: ratio test AND inverse update in ONE launch (m <= 2048, explicit carry, no implicit bounds, no forced pivot): two
 // kernels per pivot instead of three.  Every workgroup repeats the whole of K2 -- entering column, FTRAN, ratio test: 60 KB
 // of L2 reads and three block reductions, identical bits in every workgroup -- and then its eight waves update one column of
 // the inverse each, so the kernel boundary between K2 and K3 (a cold start on data written by another XCD, 1.5-2 us) and

@@ -195,7 +195,7 @@ private:
     void launch_pivots(int count, bool forced = false);
     void enqueue_price_fused(int parity);
     void enqueue_pivot_fused(int parity);  // forced: the caller set forced_q / forced_p (three-kernel pivot)
-    bool fused_ = false;          // ratio test + inverse update in one launch (pivot_fused_kernel: m <= 1024, explicit carry, no implicit bounds)
+    bool fused_ = false;          // ratio test + inverse update in one launch (pivot_fused_kernel: m <= 2048, explicit carry, no implicit bounds)
     void enqueue_price(int skip_weights, bool first_of_batch = true);
     bool slack_in_btran_ = false; // the slack columns of the dense pipeline are priced by the BTRAN pass of the previous pivot
     void enqueue_ftran_ratio(int mode);
