@@ -1455,11 +1455,14 @@ void Solver::inverse_row(int row, double* out) {
     btran(1, &row, &one, out);  // e_row' Binv: a strided read of the column-major inverse
 }
 void Solver::relative_costs(double* out) {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    RELP_HIP(hipSetDevice(opt_.device));
     launch_relative_cost(d_, d_.scratch, stream_);
     RELP_HIP(hipMemcpyAsync(out, d_.scratch, d_.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
 }
 void Solver::get_gamma(double* out) {
+    RELP_HIP(hipSetDevice(opt_.device));
     // apply a pending weight update first so that the values are those the next pricing pass would use
     std::vector<int> pos(d_.n);
     RELP_HIP(hipMemcpyAsync(out, d_.gamma, d_.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -1471,6 +1474,8 @@ void Solver::get_gamma(double* out) {
 // `PivotRule::select_primal_pivot_column`: the pricing kernel, then the entering-column reduction of the fused kernel
 // (mode 1: stop after the choice).  Applies a pending steepest-edge update exactly like the device loop does.
 void Solver::price(int* column, double* cbar) {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    RELP_HIP(hipSetDevice(opt_.device));
     Ctl c = read_ctl();
     const int saved = c.status;
     c.status = ST_RUNNING;
@@ -1487,6 +1492,8 @@ void Solver::price(int* column, double* cbar) {
 }
 // `Tableau::generate_column` + `select_primal_pivot_row` without a basis change: the fused kernel in mode 2.
 void Solver::ratio(int column, int* row, double* alpha_out) {
+    if (phase_ == 0) throw std::runtime_error("no phase started");
+    RELP_HIP(hipSetDevice(opt_.device));
     if (column < 0 || column >= d_.n) throw std::invalid_argument("column out of range");
     Ctl c = read_ctl();
     const Ctl before = c;  // a pending steepest-edge update still needs q, gamma_q, alpha_pq, leaving of the LAST pivot
@@ -1664,6 +1671,7 @@ void Solver::debug_stamps(unsigned long long* out64) {
 }
 
 void Solver::get_b(double* out) {
+    RELP_HIP(hipSetDevice(opt_.device));
     RELP_HIP(hipMemcpyAsync(out, d_.xB, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
 }
