@@ -808,7 +808,6 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
     double* s_r2 = smem + mp;
     const double cbar_q = ctl->cbar_q;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    const int waves_total = gridDim.x * (BT_THREADS / WAVE);
     for (int i = threadIdx.x; i < mp; i += BT_THREADS) {
         s_r1[i] = i < m ? lp.rvec1[i] : 0.0;
         s_r2[i] = i < m ? lp.rvec2[i] : 0.0;
@@ -832,28 +831,38 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
         }
     }
     const int n_touched = ctl->touched_count;
-    for (int idx = blockIdx.x * (BT_THREADS / WAVE) + wave; idx < n_touched; idx += waves_total) {
-        const int j = lp.tlist[idx];
+    // FOUR waves per touched column (a quarter of its rows each: one batch of loads per lane at m = 4096 instead of four dependent
+    // ones), the four partial sums added in a fixed order by the first of them.  Early in a solve there are far fewer touched
+    // columns than waves, so the pass was a handful of waves each waiting on four round trips.
+    __shared__ double s_quarter[BT_THREADS / WAVE][2];
+    constexpr int GROUPS = BT_THREADS / WAVE / 4;  // columns per workgroup pass
+    const int part = wave & 3, group = wave >> 2;
+    const int quarter = (half + 3) / 4;
+    const int k_first = part * quarter, k_last = min(half, k_first + quarter);
+    for (int base = blockIdx.x * GROUPS; base < n_touched; base += gridDim.x * GROUPS) {
+        const int idx = base + group;
+        const bool active = idx < n_touched;
+        const int j = lp.tlist[active ? idx : 0];
         const double2* col = reinterpret_cast<const double2*>(lp.Binv + (size_t)j * ld);
         SlackData sd;
         sd.js = -1;
         double pi_old = 0.0;
-        if (lane == WAVE - 1) {
+        if (active && part == 0 && lane == WAVE - 1) {
             if (price_slacks) sd = slack_fetch(j);
             pi_old = lp.minus_pi[j];
         }
         double d1 = 0.0, d2 = 0.0;
-        for (int k0 = lane; k0 < half; k0 += 8 * WAVE) {
+        for (int k0 = k_first + lane; active && k0 < k_last; k0 += 8 * WAVE) {
             double2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int kk = k0 + u * WAVE;
-                v[u] = kk < half ? col[kk] : make_double2(0.0, 0.0);
+                v[u] = kk < k_last ? col[kk] : make_double2(0.0, 0.0);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int kk = k0 + u * WAVE;
-                if (kk < half) {
+                if (kk < k_last) {
                     const double2 x = r1[kk], y = r2[kk];
                     d1 += v[u].x * x.x + v[u].y * x.y;
                     d2 += v[u].x * y.x + v[u].y * y.y;
@@ -863,12 +872,20 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
         d1 = wave_sum(d1);
         d2 = wave_sum(d2);
         if (lane == WAVE - 1) {
+            s_quarter[wave][0] = d1;
+            s_quarter[wave][1] = d2;
+        }
+        __syncthreads();
+        if (active && part == 0 && lane == WAVE - 1) {
+            d1 = (s_quarter[wave][0] + s_quarter[wave + 1][0]) + (s_quarter[wave + 2][0] + s_quarter[wave + 3][0]);
+            d2 = (s_quarter[wave][1] + s_quarter[wave + 1][1]) + (s_quarter[wave + 2][1] + s_quarter[wave + 3][1]);
             const double pi_new = pi_old - cbar_q * d1;
             lp.rho[j] = d1;
             lp.w[j] = d2;
             lp.minus_pi[j] = pi_new;
             if (price_slacks) slack(sd, j, pi_new, d1, d2);
         }
+        __syncthreads();
     }
     if (price_slacks) {  // this workgroup's best slack column for the next pivot, in price_kernel's candidate format
         const Cand blk = block_best<TIE_LARGER_IDX>(best, s_cand);
