@@ -226,6 +226,7 @@ private:
     double refactor_seconds_ = 0.0;
     std::vector<int> h_col_start_, h_row_index_;  // host copy of the device CSC (basis columns for the refactorisation)
     std::vector<double> h_value_, h_rhs_;
+    std::vector<int> h_row_start_, h_col_index_;  // the same matrix by rows (kept for the crash basis)
     bool crash_basis();           // relp_options.crash: triangular crash basis as the start of phase one
     bool gamma_ready_ = false;    // the next set_phase keeps the uploaded steepest-edge weights
     int crash_rows_covered_ = 0;
