@@ -398,3 +398,26 @@ def test_bench_two_ranks_over_rccl(workload):
     else:
         assert [r["rank"] for r in config["per_rank"]] == [0, 1]
         assert all(r["solves"] == 2 and r["pivots"] > 4000 for r in config["per_rank"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("crash", [1, 0], ids=["crash-basis", "reference-start"])
+def test_bench_max_flow_workload_line(crash):
+    """`bench.py --workload maxflow64k` (the 64 k-arc twin of BASELINE config 5) end to end as a child process: one JSON line with the
+    roofline of every kernel of the pivot, with and without the crash basis (the roofline leg profiles phase two when phase one has
+    nothing to do)."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "maxflow64k", "--steps", "1", "--warmup", "1",
+                          "--crash", str(crash), "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "pivots/s" and line["n_gpus"] == 1 and line["value"] > 0
+    assert abs(line["config"]["objective"] + 421.0) < 1e-9            # scipy's max-flow value on this graph
+    assert set(line["roofline"]["kernels"]) == {"price", "ftran_ratio", "update"}
+    assert all(k["seconds_per_launch"] > 0 and k["algorithmic_bytes_per_launch"] > 0 for k in line["roofline"]["kernels"].values())
+    if crash:
+        assert line["config"]["pivots_per_solve"] < 1000
+    else:
+        assert line["config"]["pivots_per_solve"] > 8000
