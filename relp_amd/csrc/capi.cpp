@@ -642,7 +642,8 @@ int32_t relp_get_record_json(const relp_handle* h, char* buffer, int32_t capacit
     static const char* kinds[] = {"none", "finite_optimum", "infeasible", "unbounded", "iteration_limit"};
     std::ostringstream out;
     out.precision(17);
-    out << "{\"name\": \"" << sv.form().name << "\", \"m\": " << md.nr_rows() << ", \"n\": " << md.nr_columns() << ", \"nnz\": " << nnz
+    static const char* presolve_states[] = {"off", "applied", "applied without the implied bounds beyond 126 bits", "dropped (did not fit the host model)"};
+    out << "{\"name\": \"" << sv.form().name << "\", \"presolve\": \"" << presolve_states[sv.form().presolve_state & 3] << "\", \"m\": " << md.nr_rows() << ", \"n\": " << md.nr_columns() << ", \"nnz\": " << nnz
         << ", \"device_rows\": " << d.m << ", \"artificials\": " << d.n_art << ", \"result\": \"" << kinds[r.kind >= 0 && r.kind <= 4 ? r.kind : 0]
         << "\", \"carry\": \"" << (h->options.carry == RELP_CARRY_LU ? "lu" : "explicit") << "\", \"pivots_phase_one\": " << r.pivots_phase_one
         << ", \"pivots_phase_two\": " << r.pivots_phase_two << ", \"polishes\": " << r.polishes << ", \"refactors\": " << r.refactors

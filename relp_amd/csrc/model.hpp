@@ -165,6 +165,10 @@ struct StandardForm {
     std::vector<int> active_to_original;        // index into all_column_names per remaining variable
     std::vector<std::pair<int, RemovedOriginal>> removed;  // (original index, how to recover its value)
     bool presolve_dropped = false;  // the presolve was asked for but its result did not fit the 128-bit host model: loaded as in the file
+    // what became of a requested presolve: applied as the reference does it | applied without the implied bounds of more than 126
+    // bits (the OVERFLOW escalation of the host model) | dropped (the LP of the file)
+    enum PresolveState { PRESOLVE_OFF = 0, PRESOLVE_APPLIED = 1, PRESOLVE_BOUNDED = 2, PRESOLVE_DROPPED = 3 };
+    int presolve_state = PRESOLVE_OFF;
 
     // Values of the file's variables from the values of the standardised columns (general_form/mod.rs:753-771, 840-934):
     // un-shift, un-flip, recombine free variables, then evaluate the variables the presolve removed.

@@ -305,7 +305,10 @@ StandardForm load_mps(const std::string& text, bool fixed_format, bool presolve_
     return standardize_general_form(std::move(general), presolve_first);
 }
 
-StandardForm standardize_general_form(GeneralInput general, bool presolve_first) {
+// presolve_level: 0 none | 1 the reference's presolve as it is | 2, 3 the same without the implied bounds that need more than 126 / 60
+// bits.  Throws RatOverflow when a value leaves the 128-bit rationals of the host model anywhere on the way.
+static StandardForm standardize_at_level(GeneralInput general, int presolve_level) {
+    const bool presolve_first = presolve_level > 0;
     std::vector<GeneralVariable>& vars = general.variables;
     std::vector<RowKind>& kind = general.kind;
     std::vector<Rat>& range = general.range;
@@ -329,78 +332,110 @@ StandardForm standardize_general_form(GeneralInput general, bool presolve_first)
     Rat fixed_cost = general.fixed_cost;
     {
         if (presolve_first) {
-            GeneralProblem gp;  // arbitrary precision inside (presolve.hpp); back to 128-bit rationals afterwards
-            gp.maximize = general.maximize;
-            gp.fixed_cost = Num(general.fixed_cost);
-            for (int j = 0; j < n; ++j) {
-                PVariable v;
-                v.cost = Num(vars[j].cost);
-                v.has_lower = vars[j].has_lower;
-                v.has_upper = vars[j].has_upper;
-                v.lower = Num(vars[j].lower);
-                v.upper = Num(vars[j].upper);
-                gp.variables.push_back(v);
-                PColumn column;
-                for (size_t k = 0; k < columns[j].nnz(); ++k) column.push(columns[j].index[k], Num(columns[j].value[k]));
-                gp.columns.push_back(column);
-                gp.active_to_original.push_back(j);
-            }
-            for (int i = 0; i < nr_rows; ++i) {
-                gp.b.push_back(Num(b[i]));
-                ConstraintKind ck;
-                ck.kind = kind[i];
-                if (kind[i] == RANGE) ck.range = Num(range[i]);
-                gp.kinds.push_back(ck);
-            }
-            presolve(gp);
-            if (gp.variables.empty() || gp.b.empty())
-                throw std::runtime_error("presolve: the problem was solved completely (no rows or columns remain)");
-            // Back to the 128-bit rationals of the host model -- everything is converted BEFORE anything is committed: bound
-            // tightening can leave values beyond 128 bits (BORE3D, CYCLE, GREENBEB), and then the LP is loaded as the file
-            // states it (the presolve is an optional reduction; the optimum is the same) instead of failing with OVERFLOW.
-            try {
-                std::vector<GeneralVariable> kept;
-                std::vector<SparseColumn> kept_columns;
-                for (size_t j = 0; j < gp.variables.size(); ++j) {
-                    GeneralVariable v = vars[gp.active_to_original[j]];  // cost, shift, flipped are untouched by the presolve
-                    v.has_lower = gp.variables[j].has_lower;
-                    v.has_upper = gp.variables[j].has_upper;
-                    v.lower = v.has_lower ? gp.variables[j].lower.to_rat() : Rat(0);
-                    v.upper = v.has_upper ? gp.variables[j].upper.to_rat() : Rat(0);
-                    kept.push_back(v);
-                    SparseColumn column;
-                    for (size_t k = 0; k < gp.columns[j].nnz(); ++k) column.push(gp.columns[j].index[k], gp.columns[j].value[k].to_rat());
-                    kept_columns.push_back(column);
+            // The presolve in arbitrary precision (presolve.hpp), then back to the 128-bit rationals of the host model -- everything
+            // is converted BEFORE anything is committed.  (The levels: standardize_general_form below.)
+            auto attempt = [&](size_t bit_limit) -> bool {
+                GeneralProblem gp;
+                gp.maximize = general.maximize;
+                gp.fixed_cost = Num(general.fixed_cost);
+                for (int j = 0; j < n; ++j) {
+                    PVariable v;
+                    v.cost = Num(vars[j].cost);
+                    v.has_lower = vars[j].has_lower;
+                    v.has_upper = vars[j].has_upper;
+                    v.lower = Num(vars[j].lower);
+                    v.upper = Num(vars[j].upper);
+                    gp.variables.push_back(v);
+                    PColumn column;
+                    for (size_t k = 0; k < columns[j].nnz(); ++k) column.push(columns[j].index[k], Num(columns[j].value[k]));
+                    gp.columns.push_back(column);
+                    gp.active_to_original.push_back(j);
                 }
-                std::vector<Rat> new_b, new_range(gp.b.size(), Rat(0));
-                std::vector<RowKind> new_kind;
-                for (size_t i = 0; i < gp.b.size(); ++i) {
-                    new_b.push_back(gp.b[i].to_rat());
-                    new_kind.push_back(gp.kinds[i].kind);
-                    if (gp.kinds[i].kind == RANGE) new_range[i] = gp.kinds[i].range.to_rat();
+                for (int i = 0; i < nr_rows; ++i) {
+                    gp.b.push_back(Num(b[i]));
+                    ConstraintKind ck;
+                    ck.kind = kind[i];
+                    if (kind[i] == RANGE) ck.range = Num(range[i]);
+                    gp.kinds.push_back(ck);
                 }
-                const Rat new_fixed_cost = gp.fixed_cost.to_rat();
-                std::vector<std::pair<int, RemovedOriginal>> removed;
-                for (auto& [original, how] : gp.removed) {
-                    RemovedOriginal r;
-                    r.function_of_others = how.function_of_others;
-                    r.constant = how.constant.to_rat();
-                    for (auto& [k, c] : how.coefficients) r.coefficients.push_back({k, c.to_rat()});
-                    removed.push_back({original, r});
+                presolve(gp, bit_limit);
+                if (gp.variables.empty() || gp.b.empty())
+                    throw std::runtime_error("presolve: the problem was solved completely (no rows or columns remain)");
+                if (getenv("RELP_PRESOLVE_DEBUG")) {  // diagnostic: which quantities of the presolved LP do not fit 128-bit rationals
+                    int bounds = 0, coefficients = 0, rhs = 0, ranges = 0, fixed = 0, removed_n = 0;
+                    size_t widest = 0;
+                    auto fits = [&](const BigRat& v, int& counter) {
+                        try {
+                            (void)v.to_rat();
+                        } catch (const RatOverflow&) {
+                            ++counter;
+                            widest = std::max(widest, v.bits());
+                        }
+                    };
+                    for (size_t j = 0; j < gp.variables.size(); ++j) {
+                        if (gp.variables[j].has_lower) fits(gp.variables[j].lower, bounds);
+                        if (gp.variables[j].has_upper) fits(gp.variables[j].upper, bounds);
+                        for (size_t k = 0; k < gp.columns[j].nnz(); ++k) fits(gp.columns[j].value[k], coefficients);
+                    }
+                    for (size_t i = 0; i < gp.b.size(); ++i) {
+                        fits(gp.b[i], rhs);
+                        if (gp.kinds[i].kind == RANGE) fits(gp.kinds[i].range, ranges);
+                    }
+                    fits(gp.fixed_cost, fixed);
+                    for (auto& [original, how] : gp.removed) {
+                        fits(how.constant, removed_n);
+                        for (auto& [k, c] : how.coefficients) fits(c, removed_n);
+                    }
+                    fprintf(stderr, "[presolve] bit limit %zu: %zu x %zu left; not representable: bounds %d, coefficients %d, rhs %d, ranges %d, fixed cost %d, "
+                                    "removed-variable records %d (widest %zu bits)\n",
+                            bit_limit, gp.b.size(), gp.variables.size(), bounds, coefficients, rhs, ranges, fixed, removed_n, widest);
                 }
-                vars.swap(kept);
-                columns.swap(kept_columns);
-                b.swap(new_b);
-                kind.swap(new_kind);
-                range.swap(new_range);
-                fixed_cost = new_fixed_cost;
-                out.active_to_original = gp.active_to_original;
-                out.removed = std::move(removed);
-            } catch (const RatOverflow&) {
-                out.presolve_dropped = true;
-                out.active_to_original.clear();
-                for (int j = 0; j < n; ++j) out.active_to_original.push_back(j);
-            }
+                try {
+                    std::vector<GeneralVariable> kept;
+                    std::vector<SparseColumn> kept_columns;
+                    for (size_t j = 0; j < gp.variables.size(); ++j) {
+                        GeneralVariable v = vars[gp.active_to_original[j]];  // cost, shift, flipped are untouched by the presolve
+                        v.has_lower = gp.variables[j].has_lower;
+                        v.has_upper = gp.variables[j].has_upper;
+                        v.lower = v.has_lower ? gp.variables[j].lower.to_rat() : Rat(0);
+                        v.upper = v.has_upper ? gp.variables[j].upper.to_rat() : Rat(0);
+                        kept.push_back(v);
+                        SparseColumn column;
+                        for (size_t k = 0; k < gp.columns[j].nnz(); ++k) column.push(gp.columns[j].index[k], gp.columns[j].value[k].to_rat());
+                        kept_columns.push_back(column);
+                    }
+                    std::vector<Rat> new_b, new_range(gp.b.size(), Rat(0));
+                    std::vector<RowKind> new_kind;
+                    for (size_t i = 0; i < gp.b.size(); ++i) {
+                        new_b.push_back(gp.b[i].to_rat());
+                        new_kind.push_back(gp.kinds[i].kind);
+                        if (gp.kinds[i].kind == RANGE) new_range[i] = gp.kinds[i].range.to_rat();
+                    }
+                    const Rat new_fixed_cost = gp.fixed_cost.to_rat();
+                    std::vector<std::pair<int, RemovedOriginal>> removed;
+                    for (auto& [original, how] : gp.removed) {
+                        RemovedOriginal r;
+                        r.function_of_others = how.function_of_others;
+                        r.constant = how.constant.to_rat();
+                        for (auto& [k, c] : how.coefficients) r.coefficients.push_back({k, c.to_rat()});
+                        removed.push_back({original, r});
+                    }
+                    vars.swap(kept);
+                    columns.swap(kept_columns);
+                    b.swap(new_b);
+                    kind.swap(new_kind);
+                    range.swap(new_range);
+                    fixed_cost = new_fixed_cost;
+                    out.active_to_original = gp.active_to_original;
+                    out.removed = std::move(removed);
+                    return true;
+                } catch (const RatOverflow&) {
+                    return false;
+                }
+            };
+            const size_t limits[] = {0, 0, 126, 60};
+            if (!attempt(limits[presolve_level])) throw RatOverflow();
+            out.presolve_state = presolve_level == 1 ? StandardForm::PRESOLVE_APPLIED : StandardForm::PRESOLVE_BOUNDED;
         } else {
             for (int j = 0; j < n; ++j) out.active_to_original.push_back(j);
         }
@@ -495,6 +530,27 @@ StandardForm standardize_general_form(GeneralInput general, bool presolve_first)
     }
     data.finalize();
     out.fixed_cost = fixed_cost;
+    return out;
+}
+
+// `standardize()` of the reference's pipeline, with its presolve in front when asked for.  The OVERFLOW escalation of the host
+// model: the presolve computes in arbitrary precision, the model is 128-bit rationals.  Level 1 is the
+// reference's presolve as it is.  When a value does not fit anywhere between the presolve and the standard form -- BORE3D, CYCLE,
+// GREENBEB: a handful of variable bounds that domain propagation tightens to hundreds or thousands of bits, and what the shifts
+// make of them -- the presolve runs again WITHOUT the implied bounds that need more than 126 bits, then more than 60 (valid,
+// slightly weaker reductions: an implied bound of a constraint that stays in the problem can always be left out); only when
+// those fail too is the LP loaded as the file states it.  The optimum is the same at every level.
+StandardForm standardize_general_form(GeneralInput general, bool presolve_first) {
+    if (!presolve_first) return standardize_at_level(std::move(general), 0);
+    for (int level = 1; level <= 3; ++level) {
+        try {
+            return standardize_at_level(general, level);  // (a copy: the next level starts from the same input)
+        } catch (const RatOverflow&) {
+        }
+    }
+    StandardForm out = standardize_at_level(std::move(general), 0);
+    out.presolve_state = StandardForm::PRESOLVE_DROPPED;
+    out.presolve_dropped = true;
     return out;
 }
 

@@ -280,7 +280,13 @@ public:
         }
         return compare_and_update(key, fresh, compare_with, bounds);
     }
+    // 0: none (the reference's behaviour).  Otherwise a bound that domain propagation IMPLIES from a constraint which stays in the
+    // problem is not recorded when its numerator or denominator needs more bits than this: skipping an implied tightening keeps
+    // every later step valid (nothing was removed because of it), and it is how a presolved LP stays inside the fixed-width
+    // host model when the exact tightenings of a few variables run to thousands of bits (BORE3D, CYCLE, GREENBEB).
+    size_t activity_bound_bit_limit = 0;
     BoundChange update_activity_variable_bound(int j, Direction d, const Num& fresh) {  // updates.rs:212-253
+        if (activity_bound_bit_limit > 0 && fresh.bits() > activity_bound_bit_limit) return BoundChange();
         const Key key{j, d};
         auto act = activity_variable_bounds.find(key);
         if (act != activity_variable_bounds.end()) return compare_and_update(key, fresh, Num(act->second), activity_variable_bounds);
@@ -675,7 +681,7 @@ public:
 
 // `GeneralForm::presolve` (general_form/mod.rs:335-463): compute the changes, apply them, drop rows and columns.
 // Throws PresolveInfeasible / PresolveUnbounded.
-inline void presolve(GeneralProblem& gf) {
+inline void presolve(GeneralProblem& gf, size_t activity_bound_bit_limit = 0) {
     using namespace presolve_detail;
     std::map<int, Num> b_changes;
     std::map<int, ConstraintKind> constraint_changes;
@@ -685,6 +691,7 @@ inline void presolve(GeneralProblem& gf) {
     Num fixed_cost;
     {
         Index index(gf);  // compute_presolve_changes (mod.rs:360-386)
+        index.activity_bound_bit_limit = activity_bound_bit_limit;
         size_t without_change = 0;
         while (!index.queues_empty() && without_change < index.nr_variables_remaining() + index.nr_constraints_remaining()) {
             const Change change = index.presolve_step();

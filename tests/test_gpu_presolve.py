@@ -23,11 +23,14 @@ def test_presolved_netlib_problem_reaches_the_reference_optimum(name):
     path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
     golden_path = os.path.join(ROOT, "tests", "golden", name + ".json")
     solver = relp_amd.Solver(certify=1 if os.path.exists(golden_path) else 0)
-    # (BORE3D, CYCLE, GREENBEB: bound tightening leaves values beyond the 128-bit host model; those are loaded as the file
-    #  states them -- the presolve is an optional reduction -- instead of failing with RELP_ERR_OVERFLOW)
+    # (BORE3D, CYCLE, GREENBEB: the reference's bound tightening leaves the 128-bit host model; the product presolves them again
+    #  without the implied bounds that need more than 126 / 60 bits -- still presolved, same optimum -- instead of failing with
+    #  RELP_ERR_OVERFLOW)
     solver.load_mps(path, presolve=True)
     plain = relp_amd.Model(path)
     assert solver.m <= plain.nr_rows
+    if name in ("BORE3D", "CYCLE", "GREENBEB"):
+        assert solver.m < plain.nr_rows
     result = solver.solve_relaxation()
     assert result.kind == relp_amd.FINITE_OPTIMUM
     entry = EXPECTED[name]
@@ -110,4 +113,10 @@ def test_per_lp_record():
     assert record["objective_exact"] == "-406659/875"           # tests/burkardt/test.rs:75
     assert record["objective"] == pytest.approx(-464.753142857, rel=1e-9)
     assert record["pivots_per_second"] > 0 and record["solve_seconds"] > 0
+    assert record["presolve"] == "off"
     solver.close()
+    for name, state in (("AFIRO", "applied"), ("BORE3D", "applied without the implied bounds beyond 126 bits")):
+        solver = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"), presolve=True)
+        solver.solve_relaxation()
+        assert solver.record()["presolve"] == state
+        solver.close()

@@ -54,12 +54,17 @@ def test_presolved_model_equals_oracle(path):
             relp_amd.Model(path, presolve=True)
         pytest.skip("solved completely by the presolve")
     if exceeds_128_bits(general, data):
-        # the host model is 128-bit: such an LP is loaded as the file states it (the presolve is an optional reduction with
-        # the same optimum) instead of failing with RELP_ERR_OVERFLOW
+        # The host model is 128-bit rationals and the reference's presolve leaves it on this LP (a handful of variable bounds
+        # that domain propagation tightens to hundreds or thousands of bits).  The product then runs the presolve again without
+        # the implied bounds that need more than 126 (then 60) bits -- a valid, slightly weaker reduction -- instead of failing
+        # with RELP_ERR_OVERFLOW or dropping the presolve: fewer rows and columns than the file, at least as many as the
+        # reference's presolved LP, and (tests/test_gpu_presolve.py) the reference's optimum with an exact certificate.
         model = relp_amd.Model(path, presolve=True)
         plain = relp_amd.Model(path)
-        assert (model.nr_rows, model.nr_columns, model.nnz) == (plain.nr_rows, plain.nr_columns, plain.nnz)
-        assert model.original_variables()[1] == 0
+        assert model.nr_rows < plain.nr_rows and model.nr_columns < plain.nr_columns
+        assert model.nr_rows >= data.nr_rows() and model.nr_columns >= data.nr_columns()
+        total, removed = model.original_variables()
+        assert total == general.nr_original and 0 < removed <= len(general.removed)
         return
     model = relp_amd.Model(path, presolve=True)
     assert (model.nr_rows, model.nr_columns, model.nr_constraints) == (data.nr_rows(), data.nr_columns(), data.nr_constraints())
