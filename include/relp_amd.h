@@ -134,7 +134,10 @@ int32_t relp_model_from_mps(const char* path, int32_t fixed_format, relp_model**
 /* The same with `GeneralForm::presolve` (general_form/mod.rs:335-358 and general_form/presolve/ of the reference: fixed
  * variables, bound constraints, slack elimination, domain propagation) applied before `standardize()`, as the reference's
  * Netlib harness does (tests/netlib/mod.rs:58).  RELP_ERR_STATE when the presolve itself proves the problem infeasible,
- * unbounded or solves it completely (message in `error`). */
+ * unbounded or solves it completely (message in `error`).  The presolve computes in arbitrary precision, the host model is
+ * 128-bit rationals: when a presolved value does not fit, the presolve is run again without the implied bounds that need
+ * more than 126 (then 60) bits, and only if that fails as well is the LP loaded as the file states it -- never
+ * RELP_ERR_OVERFLOW because of the presolve (relp_get_record_json reports the level). */
 int32_t relp_model_from_mps_ex(const char* path, int32_t fixed_format, int32_t presolve, relp_model** out, char* error,
                                int32_t error_capacity);
 /* The provider of a caller that builds the general form itself: `GeneralForm::new` (general_form/mod.rs:211-237) followed by
