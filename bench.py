@@ -180,7 +180,7 @@ def netlib_batch(args, rank, local_rank, world, distributed):
     models = {}
     costs = []
     for name in names:
-        model = relp_amd.Model(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+        model = relp_amd.Model(os.path.join(ROOT, "data", "netlib", name + ".SIF"), presolve=args.presolve)  # --presolve: the reference's harness order
         models[name] = model
         costs.append((name, float(model.nr_rows) * float(model.nnz + model.nr_columns)))
     dynamic = args.schedule == "dynamic"
@@ -276,8 +276,9 @@ def netlib_batch(args, rank, local_rank, world, distributed):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "%d Netlib .SIF files shipped under data/netlib" % len(names),
-            "config": {"workload": "Netlib batch (%d LPs), %s, independent LPs sharded over the GPUs" % (
-                len(names), "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
+            "config": {"workload": "Netlib batch (%d LPs%s), %s, independent LPs sharded over the GPUs" % (
+                len(names), ", after the reference's presolve" if args.presolve else "",
+                "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
                        "lps_in_flight_per_gpu": max(1, args.concurrency),
                        "problems_per_rank": [len(r) for r in gathered],
                        "pivots_per_rank": [sum(entry[2] for entry in r) for r in gathered],
