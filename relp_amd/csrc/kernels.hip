@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <utility>
 
 #include "solver.hpp"
 #include "wave_ops.hpp"
@@ -479,6 +480,143 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
         }
     }
 }
+
+// K1c: the int8 dense block priced with ONE COLUMN PER LANE.  price_dense_kernel<.., I8> reads 24 B of -pi / rho / w out of LDS
+// for every 1-byte entry (805 MB a pass at 4096 x 8192) and is bound by that, not by the 33 MB that come from HBM.  Here the
+// block is stored in tiles of 16 columns x 64 rows (1 KiB): lane l's 16 bytes are rows 64B + 16(l >> 4) .. + 15 of column
+// 16G + (l & 15).  A wave streams a run of such tiles of one column group, one 16-byte load per lane and tile, and the 16
+// lanes of a DPP row work on the SAME 16 matrix rows: lane l holds -pi / rho / w of row 64B + l in a register pair (one
+// coalesced 512-byte load), and entry t of the piece is multiplied by lane t's value through the DPP row broadcast of the f64 FMA
+// (v_fmac_f64_dpp row_newbcast:t) -- no LDS traffic, no cross-lane reduction, 5 VALU instructions per entry (extract,
+// convert, three FMAs; tools/microbench/valu_rates.hip: all five issue at the full rate, DPP included).  A workgroup owns one
+// group of 16 columns, its waves split the rows; their partial sums meet in LDS, and a thread per column adds them in a fixed
+// order, updates the column's weight and tests it: one candidate slot per workgroup, 512 workgroups of 8 waves at n = 8192
+// (two per CU, so that one's tail overlaps the other's stream; 32 columns per group and 16 waves: 12.5 us against 9.6 + 4.8).
+// Measured on the way (4096 x 8192, per pass): the vectors in registers with a wave per 1024 rows and DPP wave sums per
+// column, 20.5 us; 64 columns per wave with the vectors as SGPR operands from scalar loads (s_load latency exposed, and rows
+// split over workgroups that meet behind a per-group counter: the __threadfence() on either side writes back and
+// invalidates the XCD's whole L2, 3x slower per pivot), 11.8 us + 5.3 us for a second kernel that adds the splits.
+constexpr int K1C_MAX_THREADS = 512, K1C_U = 4, K1C_COLS = 16, K1C_TILE_ROWS = 64;
+template <int T>
+__device__ __forceinline__ void fmac_row_broadcast(double& acc, double a, double x) {  // acc += (a of lane T of this lane's row of 16) * x
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(x), "n"(T));
+}
+template <int T>
+__device__ __forceinline__ void dense_lane_entry(const i32x4& v, double a_pi, double a_rho, double a_w, double (&acc)[6]) {
+    const double x = (double)((int)((unsigned)v[T / 4] << (24 - 8 * (T % 4))) >> 24);  // sign-extended byte T
+    fmac_row_broadcast<T>(acc[T & 1], a_pi, x);  // two chains per sum
+    fmac_row_broadcast<T>(acc[2 + (T & 1)], a_rho, x);
+    fmac_row_broadcast<T>(acc[4 + (T & 1)], a_w, x);
+}
+template <int... T>
+__device__ __forceinline__ void dense_lane_block(const i32x4& v, double a_pi, double a_rho, double a_w, double (&acc)[6], std::integer_sequence<int, T...>) {
+    (dense_lane_entry<T>(v, a_pi, a_rho, a_w, acc), ...);
+}
+struct DenseLaneBatch {  // K1C_U tiles of one lane: the column pieces and the lane's -pi / rho / w of each
+    i32x4 v[K1C_U];
+    double vp[K1C_U], vr[K1C_U], vw[K1C_U];
+};
+__device__ __forceinline__ void dense_lane_load(DenseLaneBatch& t, const i32x4* piece, const double* a_pi, const double* a_rho, const double* a_w, int b0) {
+    // (33 MB at 4096 x 8192: non-temporal loads make no difference here, 18.05k against 18.13k pivots/s)
+#pragma unroll
+    for (int u = 0; u < K1C_U; ++u) t.v[u] = piece[(size_t)(b0 + u) * WAVE];
+#pragma unroll
+    for (int u = 0; u < K1C_U; ++u) {
+        t.vp[u] = a_pi[(b0 + u) * K1C_TILE_ROWS];
+        t.vr[u] = a_rho[(b0 + u) * K1C_TILE_ROWS];
+        t.vw[u] = a_w[(b0 + u) * K1C_TILE_ROWS];
+    }
+}
+// dense_ld is a multiple of K1C_TILE_ROWS * (blockDim.x / 64) * K1C_U; the next batch's loads are in flight while one is worked on
+__global__ void __launch_bounds__(K1C_MAX_THREADS) price_dense_lane_kernel(DeviceLP lp, int skip_weights, double tol_dual, int cand_offset) {
+    __shared__ double s_part[K1C_MAX_THREADS / WAVE][3][WAVE];
+    const int mp = lp.dense_ld;
+    const int group = blockIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+    const int ntiles = mp / (K1C_TILE_ROWS * nw);  // tiles of 64 rows per wave
+    const int first_tile = wave * ntiles;
+    const i32x4* piece = reinterpret_cast<const i32x4*>(lp.dense_val8) + ((size_t)group * (mp / K1C_TILE_ROWS) + first_tile) * WAVE + lane;
+    const size_t my_row = (size_t)first_tile * K1C_TILE_ROWS + lane;
+    const double* a_pi = lp.minus_pi + my_row;
+    const double* a_rho = lp.rho + my_row;
+    const double* a_w = lp.w + my_row;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    DenseLaneBatch next;
+    dense_lane_load(next, piece, a_pi, a_rho, a_w, 0);  // requested before the control block is looked at
+    // the thread that finishes column 16 * group + threadIdx.x asks for what it needs there now
+    const int jd = group * K1C_COLS + threadIdx.x;
+    const bool finisher = threadIdx.x < K1C_COLS && jd < lp.n_dense;
+    const int j = lp.dense_first + jd;
+    const int pos_j = finisher ? lp.pos[j] : 0;
+    const double gamma_j = finisher ? lp.gamma[j] : 1.0, cost_j = finisher ? lp.cost[j] : 0.0;
+    const Ctl* ctl = lp.ctl;
+    if (ctl->status != ST_RUNNING) return;
+    const int pending = ctl->pending && !skip_weights;
+    const int leaving = ctl->leaving;
+    const double alpha_pq = ctl->alpha_pq, gamma_q = ctl->gamma_q;
+    for (int b0 = 0; b0 < ntiles; b0 += K1C_U) {
+        const DenseLaneBatch cur = next;
+        if (b0 + K1C_U < ntiles) dense_lane_load(next, piece, a_pi, a_rho, a_w, b0 + K1C_U);
+        // (all three sums whether or not a weight update is pending -- two code paths make the compiler hoist the
+        // conversions they share above the branch, and spill)
+#pragma unroll
+        for (int u = 0; u < K1C_U; ++u) dense_lane_block(cur.v[u], cur.vp[u], cur.vr[u], cur.vw[u], acc, std::make_integer_sequence<int, 16>{});
+    }
+    s_part[wave][0][lane] = acc[0] + acc[1];
+    s_part[wave][1][lane] = acc[2] + acc[3];
+    s_part[wave][2][lane] = acc[4] + acc[5];
+    __syncthreads();
+    if (wave != 0) return;
+    // wave 0: lane 16 * which + c adds sum `which` of column c (wave order, and the four row quarters of a tile in theirs);
+    // lanes 0 .. 15 then hold -pi.a_j, fetch rho.a_j and w.a_j from lanes 16 + c and 32 + c, and finish their column
+    double sum = 0.0;
+    {
+        const int which = min(lane >> 4, 2), c = lane & 15;
+        for (int k = 0; k < nw; ++k) {
+            const double* part = &s_part[k][which][c];
+            sum += (part[0] + part[16]) + (part[32] + part[48]);
+        }
+    }
+    const double d_pi = sum, d_rho = __shfl(sum, (lane & 15) + 16), d_w = __shfl(sum, (lane & 15) + 32);
+    Cand best;
+    best.key = 0.0;
+    best.idx = -1;
+    best.aux = lane;
+    double best_cbar = 0.0;
+    if (finisher && pos_j < 0) {
+        double gam = gamma_j;
+        if (pending) {
+            if (j == leaving) {
+                gam = gamma_q / (alpha_pq * alpha_pq);
+            } else {
+                const double sq = d_rho * d_rho;
+                gam = gam - 2.0 * d_rho * d_w + sq * gamma_q;
+                gam = fmax(gam, 1.0 + sq);
+            }
+            lp.gamma[j] = gam;
+        }
+        const double cbar = (pos_j == -2 ? -1.0 : 1.0) * (cost_j + d_pi);
+        if (cbar < -tol_dual) {
+            best.idx = j;
+            best.key = cbar * cbar / gam;
+            best_cbar = cbar;
+        }
+    }
+    const Cand blk = wave_best<TIE_LARGER_IDX>(best);  // lane 63
+    const int winner = __shfl(blk.aux, LAST);
+    best_cbar = __shfl(best_cbar, winner);
+    if (lane == LAST) {
+        lp.cand_j[cand_offset + blockIdx.x] = blk.idx;
+        lp.cand_len[cand_offset + blockIdx.x] = -1;  // column not inlined with the candidate: K2 reads it from the CSC
+        if (blk.idx >= 0) {
+            lp.cand_key[cand_offset + blockIdx.x] = blk.key;
+            lp.cand_cbar[cand_offset + blockIdx.x] = best_cbar;
+        }
+    }
+}
+int dense_lane_slots(int n_dense) { return (n_dense + K1C_COLS - 1) / K1C_COLS; }
+int dense_lane_threads(int m) { return m > 1024 ? 512 : 256; }
+int dense_lane_ld(int m) { const int unit = K1C_TILE_ROWS * (dense_lane_threads(m) / WAVE) * K1C_U; return (m + unit - 1) / unit * unit; }
 
 // Multi-block FTRAN for long entering columns: partial[c][i] = sum over the c-th slice of the entries of a_q of
 // v_e * Binv(i, r_e).  Grid (row tiles of 256, slices); coalesced over i; fixed slice order => deterministic.
@@ -3179,7 +3317,9 @@ void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_
 
 void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s) {
     const size_t lds = (size_t)3 * d.dense_ld * sizeof(double);
-    if (d.dense_val8) RELP_LAUNCH(0, (price_dense_kernel<false, true>), dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
+    if (d.dense_lane) {
+        RELP_LAUNCH(0, price_dense_lane_kernel, dim3(blocks), dim3(dense_lane_threads(d.m)), 0, s, d, skip_weights, tol, cand_offset);
+    } else if (d.dense_val8) RELP_LAUNCH(0, (price_dense_kernel<false, true>), dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
     else if (d.dense_val32) RELP_LAUNCH(0, price_dense_kernel<true>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
     else RELP_LAUNCH(0, price_dense_kernel<false>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
 }

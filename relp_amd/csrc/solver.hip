@@ -19,6 +19,8 @@ void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_
                   int first, int last, int cand_offset, hipStream_t s);
 void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s);
 void configure_dense_lds(size_t lds);
+int dense_lane_slots(int n_dense);
+int dense_lane_ld(int m);
 void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s);
 bool fast_k2_available(const DeviceLP& d, int n_price_blocks);
 void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop);
@@ -251,6 +253,18 @@ void Solver::upload() {
         else price_blocks_ = btran_pass_blocks();
     }
     dense_blocks_ = n_dense > 0 ? std::min(getenv("RELP_DENSE_BLOCKS") ? atoi(getenv("RELP_DENSE_BLOCKS")) : 256, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one workgroup per CU (96 KB of LDS each)
+    bool dense_bytes = n_dense > 0 && !getenv("RELP_DENSE_F64") && !getenv("RELP_DENSE_F32");  // narrowest exact storage type
+    for (int jd = 0; dense_bytes && jd < n_dense; ++jd)
+        for (int e = col_start[n_art + jd]; dense_bytes && e < col_start[n_art + jd + 1]; ++e)
+            dense_bytes = value[e] >= -128.0 && value[e] <= 127.0 && value[e] == std::floor(value[e]);
+    int vector_len = m;  // -pi, rho, w: zero-padded to the dense block's row count when the column-per-lane pricing reads them
+    if (dense_bytes && dense_lane_slots(n_dense) <= 1024 && !getenv("RELP_NO_DENSE_LANE")) {
+        // column-per-lane pricing: one workgroup and one candidate slot per group of 16 columns
+        d_.dense_lane = 1;
+        d_.dense_ld = dense_lane_ld(m);
+        dense_blocks_ = dense_lane_slots(n_dense);
+        vector_len = d_.dense_ld;
+    }
     if (price_blocks_ + dense_blocks_ == 0) price_blocks_ = 1;
     price_lds_ = (size_t)3 * m * sizeof(double);
     int max_nnz = 0;
@@ -271,7 +285,8 @@ void Solver::upload() {
     d_.cost2 = dmalloc<double>(n);
     d_.rhs = dmalloc<double>(m);
     d_.xB = dmalloc<double>(m);
-    d_.minus_pi = dmalloc<double>(m);
+    d_.minus_pi = dmalloc<double>(vector_len);
+    RELP_HIP(hipMemsetAsync(d_.minus_pi, 0, (size_t)vector_len * sizeof(double), stream_));
     d_.basis = dmalloc<int>(m);
     d_.pos = dmalloc<int>(n);
     d_.gamma = dmalloc<double>(n);
@@ -284,10 +299,12 @@ void Solver::upload() {
     // config 5, whose bases are unimodular, never needs them.
     tick("inverse buffers (hipMalloc)");
     d_.alpha = dmalloc<double>(m);
-    d_.rho = dmalloc<double>(m);
+    d_.rho = dmalloc<double>(vector_len);
+    RELP_HIP(hipMemsetAsync(d_.rho, 0, (size_t)vector_len * sizeof(double), stream_));
     d_.nz_index = dmalloc<int>(m);
     d_.nz_alpha = dmalloc<double>(m);
-    d_.w = dmalloc<double>(m);
+    d_.w = dmalloc<double>(vector_len);
+    RELP_HIP(hipMemsetAsync(d_.w, 0, (size_t)vector_len * sizeof(double), stream_));
     d_.cand_key = dmalloc<double>(price_blocks_ + dense_blocks_);
     d_.cand_j = dmalloc<int>(price_blocks_ + dense_blocks_);
     d_.cand_cbar = dmalloc<double>(price_blocks_ + dense_blocks_);
@@ -358,12 +375,23 @@ void Solver::upload() {
         RELP_HIP(hipMemsetAsync(d_.eta_slot, 0xff, m * sizeof(int), stream_));
         configure_btran_lds((size_t)2 * ((m + 1) & ~1) * sizeof(double));
     }
-    bool dense_bytes = n_dense > 0 && !getenv("RELP_DENSE_F64") && !getenv("RELP_DENSE_F32");  // narrowest exact storage type
-    for (int jd = 0; dense_bytes && jd < n_dense; ++jd)
-        for (int e = col_start[n_art + jd]; dense_bytes && e < col_start[n_art + jd + 1]; ++e)
-            dense_bytes = value[e] >= -128.0 && value[e] <= 127.0 && value[e] == std::floor(value[e]);
-    if (dense_bytes && (size_t)3 * ((m + 1023) & ~1023) * sizeof(double) > 160 * 1024 - 4096) dense_bytes = false;  // LDS holds the padded vectors
-    if (dense_bytes) {
+    if (dense_bytes && d_.dense_lane) {
+        const int groups = dense_blocks_, tiles_per_group = d_.dense_ld / 64;
+        std::vector<signed char> bytes((size_t)groups * 16 * d_.dense_ld, 0);
+        for (int jd = 0; jd < n_dense; ++jd)
+            for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) {
+                const int row = row_index[e], within = row % 64;  // tile (group, row / 64): 64 lanes x 16 bytes; see price_dense_lane_kernel
+                bytes[(((size_t)(jd / 16) * tiles_per_group + row / 64) * 64 + 16 * (within / 16) + jd % 16) * 16 + within % 16] = (signed char)value[e];
+            }
+        d_.dense_val8 = dmalloc<signed char>(bytes.size());
+        upload_vec(d_.dense_val8, bytes, stream_);
+        dense_entry_bytes_ = 1;
+        RELP_HIP(hipStreamSynchronize(stream_));
+    } else if (dense_bytes && (size_t)3 * ((m + 1023) & ~1023) * sizeof(double) > 160 * 1024 - 4096) {
+        dense_bytes = false;  // (the row-permuted form keeps the padded vectors in LDS)
+    }
+    if (dense_bytes && d_.dense_lane) {
+    } else if (dense_bytes) {
         d_.dense_ld = (m + 1023) & ~1023;
         std::vector<signed char> bytes((size_t)n_dense * d_.dense_ld, 0);
         for (int jd = 0; jd < n_dense; ++jd)
