@@ -513,10 +513,15 @@ def main():
                                         "gathers, one cache line each: PMC traffic is line-granular)")
         elif dense:
             line["metric"] = "simplex pivots/sec + wall-clock to optimal, dense LP @1 GPU"
-            line["roofline"]["note"] = ("dense block held in the narrowest exact type (this workload: signed bytes, 1 B per entry; as float "
-                                        "the same pass streams 4x the bytes at 4.4 TB/s = 0.55 of the HBM peak): the pass then reads 24 B "
-                                        "per entry from LDS (%.0f GB/s of ~150000) and is bound by that and by f64 FMA issue, not by HBM"
-                                        % (24 * bytes_per_launch / seconds[dominant] / 1e9))
+            if args.dense_storage == "narrowest":
+                line["roofline"]["note"] = ("dense block held in the narrowest exact type (this workload: signed bytes, 1 B per entry; as float the "
+                                            "pass streams 4x the bytes at 4.4 TB/s = 0.55 of the HBM peak): one column per lane, -pi / rho / w "
+                                            "broadcast through DPP inside the f64 FMA (no LDS traffic); 5 VALU instructions per entry = %.1f us "
+                                            "of issue time on 1024 SIMDs (tools/microbench/valu_rates.hip: 1.9 ns each), the rest of the launch is "
+                                            "the first load's latency and the per-workgroup tail" % (bytes_per_launch * 5 * 1.9e-3 / 64 / 1024))
+            else:
+                line["roofline"]["note"] = ("dense block streamed as %s, one wave per column with 16-byte non-temporal loads, -pi / rho / w in LDS"
+                                            % {"f32": "float (exact for this data; all arithmetic f64)", "f64": "double"}[args.dense_storage])
         if not dense and not graph:
             line["roofline"]["note"] = ("latency bound by construction: the dominant kernel BY MEASURED TIME is '%s' (%d KB of algorithmic "
                                         "bytes per launch, all of it resident in L2 / Infinity Cache; SURVEY.md section 8(d)); every kernel of "
