@@ -745,6 +745,8 @@ __device__ __forceinline__ double sum_slices(const DeviceLP& lp, int n_slices, i
     }
     return acc;
 }
+// the kept columns of M exist twice; ctl->eta_version (one more per pivot, counted by K2) says which copy is current
+__device__ __forceinline__ double* eta_columns(const DeviceLP& lp, int version) { return lp.eta_cols + (size_t)(version & 1) * lp.eta_cap * lp.ld; }
 constexpr int AR_ROWS = 64, AR_GROUPS = 4;
 __global__ void __launch_bounds__(AR_ROWS * AR_GROUPS) alpha_reduce_kernel(DeviceLP lp, int n_slices) {
     __shared__ double s_y[ETA_MAX];
@@ -754,6 +756,7 @@ __global__ void __launch_bounds__(AR_ROWS * AR_GROUPS) alpha_reduce_kernel(Devic
     // round trip 1: everything that needs no other result (control word, kept rows, this thread's slices and eta entries)
     const int status = lp.ctl->status, q = lp.ctl->q;
     const int k = lp.eta_cap > 0 ? lp.ctl->eta_count : 0;
+    const double* kept = lp.eta_cap > 0 ? eta_columns(lp, lp.ctl->eta_version) : nullptr;
     const int c8 = threadIdx.x / 8, sub = threadIdx.x % 8;
     const int kept_row = (lp.eta_cap > 0 && c8 < lp.eta_cap) ? lp.eta_rows[c8] : 0;
     const int g = threadIdx.x / AR_ROWS, r = threadIdx.x % AR_ROWS;
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(AR_ROWS * AR_GROUPS) alpha_reduce_kernel(Devic
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int c = g + u * AR_GROUPS;
-        mic[u] = (lp.eta_cap > 0 && i < m) ? lp.eta_cols[(size_t)c * lp.ld + i] : 0.0;  // entries of unused slots are ignored below
+        mic[u] = (lp.eta_cap > 0 && i < m) ? kept[(size_t)c * lp.ld + i] : 0.0;  // entries of unused slots are ignored below
     }
     if (status != ST_RUNNING || q < 0) return;
     if (k > 0) {  // round trip 2: y at the kept rows: 8 threads per row, 1/8 of the slices each, fixed-order combine
@@ -789,7 +792,19 @@ __global__ void __launch_bounds__(AR_ROWS * AR_GROUPS) alpha_reduce_kernel(Devic
     }
     s_part[g][r] = acc;
     __syncthreads();
-    if (g == 0 && i < m) lp.alpha_in[i] = (s_part[0][r] + s_part[1][r]) + (s_part[2][r] + s_part[3][r]);
+    const double alpha_i = (s_part[0][r] + s_part[1][r]) + (s_part[2][r] + s_part[3][r]);
+    if (g == 0 && i < m) lp.alpha_in[i] = alpha_i;
+    // this block of rows' share of alpha' M[:, c] for every kept column (the BTRAN pass needs the whole products: they are
+    // the entries of the row vector behind w at the kept rows); wave g takes the columns g, g + 4, ...
+    if (k > 0) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int c = g + u * AR_GROUPS;
+            if (c >= k) break;  // wave-uniform
+            const double share = wave_sum(i < m ? alpha_i * mic[u] : 0.0);
+            if (r == WAVE - 1) lp.eta_dot_part[(size_t)c * gridDim.x + blockIdx.x] = share;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -804,78 +819,18 @@ __global__ void __launch_bounds__(AR_ROWS * AR_GROUPS) alpha_reduce_kernel(Devic
 // instead of a read pass plus a read-modify-write pass: 2 m^2 instead of 3 m^2 doubles of HBM traffic, no dirty lines
 // in front of the next pricing pass.
 // ---------------------------------------------------------------------------------------------------
-constexpr int ETA_THREADS = 256;
-__device__ __forceinline__ double block_sum_256(double v, double* s_red) {  // fixed order; result in every thread
-    v = wave_sum(v);
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    if (lane == WAVE - 1) s_red[wave] = v;
-    __syncthreads();
-    const double total = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    __syncthreads();
-    return total;
-}
-
-// After K2 chose (q, p): fold the new eta E = I - (alpha - e_p) e_p'/alpha_p ... into the kept columns, and build the two
-// row vectors of the BTRAN pass.  Blocks [0, eta_cap): one kept column each; further blocks: the plain entries.
+// After K2 chose (q, p) the new eta E = I - (alpha - e_p) e_p'/alpha_p has to be folded into the kept columns, and the BTRAN
+// pass needs two row vectors:
 //   rvec2 = alpha' M_old   (w   = rvec2 * Binv, old basis:  carry/mod.rs:575)
 //   rvec1 = e_p'  M_new    (rho = rvec1 * Binv, new basis:  lower_upper/mod.rs:254-272)
-__global__ void __launch_bounds__(ETA_THREADS) eta_update_kernel(DeviceLP lp) {
-    __shared__ double s_red[4];
-    Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING || !ctl->pending) return;
-    const int m = lp.m, ld = lp.ld;
-    const int p = ctl->p;
-    const double alpha_pq = ctl->alpha_pq;
-    const int k = ctl->eta_count;
-    const int slot_p = lp.eta_slot[p];
-    if ((int)blockIdx.x < lp.eta_cap) {
-        const int c = blockIdx.x;
-        const bool is_new = slot_p < 0 && c == k;
-        if (c >= k && !is_new) return;
-        double* col = lp.eta_cols + (size_t)c * ld;
-        if (is_new) {  // column p of E itself
-            for (int i = threadIdx.x; i < m; i += ETA_THREADS) col[i] = (i == p) ? 1.0 / alpha_pq : -lp.alpha[i] / alpha_pq;
-            if (threadIdx.x == 0) {
-                lp.rvec2[p] = alpha_pq;  // p was not a kept column: M_old[:, p] = e_p
-                lp.rvec1[p] = 1.0 / alpha_pq;
-            }
-            return;
-        }
-        constexpr int PER = 16;  // m <= 4096
-        double a[PER], v[PER];
-        double dot = 0.0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = threadIdx.x + u * ETA_THREADS;
-            a[u] = i < m ? lp.alpha[i] : 0.0;
-            v[u] = i < m ? col[i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) dot += a[u] * v[u];
-        dot = block_sum_256(dot, s_red);
-        const double t = col[p] / alpha_pq;  // read before any thread rewrites it: every thread reads, then a barrier
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = threadIdx.x + u * ETA_THREADS;
-            if (i < m) col[i] = (i == p) ? t : v[u] - a[u] * t;
-        }
-        if (threadIdx.x == 0) {
-            const int row = lp.eta_rows[c];
-            lp.rvec2[row] = dot;
-            lp.rvec1[row] = t;
-        }
-    } else {
-        const int i = ((int)blockIdx.x - lp.eta_cap) * ETA_THREADS + threadIdx.x;
-        if (i < m && i != p && lp.eta_slot[i] < 0) {
-            lp.rvec2[i] = lp.alpha[i];
-            lp.rvec1[i] = 0.0;
-        }
-    }
-}
-
+// Off the kept rows they are alpha and 0; at kept row eta_rows[c] they are alpha' M_old[:, c] and M_old[p, c] / alpha_p; at p,
+// when p had no kept column, alpha_p and 1 / alpha_p.  Round 1 had a kernel of its own for this between K2 and the BTRAN
+// pass; now alpha_reduce_kernel leaves the products alpha' M_old[:, c] behind (per block of 64 rows), K2 does the
+// bookkeeping of the new kept column, and every workgroup of the BTRAN pass builds the two vectors in LDS itself (32 KB of
+// alpha and 16 KB of partial products out of L2 instead of the 64 KB of the two vectors) and rewrites its share of the kept
+// columns into the OTHER copy of them -- its neighbours still read M_old[p, c] from the current one.
 // The BTRAN pass: rho[j] = rvec1 . Binv(:, j), w[j] = rvec2 . Binv(:, j), -pi[j] -= cbar_q rho[j]; one wave per column,
-// 16-byte loads, both row vectors in LDS.  Block 0 also commits the bookkeeping of the eta that eta_update_kernel added.
+// 16-byte loads, both row vectors in LDS (built by every workgroup, see above).
 constexpr int BT_THREADS = 1024;
 // When the sparse part of the LP is one unit-like column per row (the slack columns of the dense LP), their pricing for the
 // NEXT pivot is done here as well: (-pi_j, rho_j, w_j) of row j are in registers when they are written, and the slack column of
@@ -946,11 +901,55 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
     double* s_r2 = smem + mp;
     const double cbar_q = ctl->cbar_q;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    for (int i = threadIdx.x; i < mp; i += BT_THREADS) {
-        s_r1[i] = i < m ? lp.rvec1[i] : 0.0;
-        s_r2[i] = i < m ? lp.rvec2[i] : 0.0;
+    {
+        __shared__ double s_dot[ETA_MAX][32];
+        const int version = ctl->eta_version;  // K2 counted this pivot already: the columns as they were are in copy version - 1
+        const int is_new = ctl->eta_new;
+        const int k_old = ctl->eta_count - is_new;
+        const int p = ctl->p;
+        const double* kept_old = eta_columns(lp, version - 1);
+        double* kept_new = eta_columns(lp, version);
+        // this thread's element of the kept columns (column c_el, row i_el), requested first
+        const int el = blockIdx.x * BT_THREADS + threadIdx.x;
+        const int c_el = el / m, i_el = el - c_el * m;
+        const bool el_kept = c_el < k_old, el_new = is_new && c_el == k_old;
+        const double el_old = el_kept ? kept_old[(size_t)c_el * ld + i_el] : 0.0;
+        const double el_at_p = el_kept ? kept_old[(size_t)c_el * ld + p] : 0.0;
+        const double el_alpha = (el_kept || el_new) ? lp.alpha[i_el] : 0.0;
+        // thread (c, s) of the first 32 * k_old: two of the 64-row blocks' shares of alpha' M_old[:, c]
+        const int n_shares = (m + AR_ROWS - 1) / AR_ROWS;  // <= 64
+        const int dc = threadIdx.x / 32, ds = threadIdx.x % 32;
+        double share = 0.0;
+        if (dc < k_old) {
+            const double* part = lp.eta_dot_part + (size_t)dc * n_shares;
+            share = (ds < n_shares ? part[ds] : 0.0) + (ds + 32 < n_shares ? part[ds + 32] : 0.0);
+        }
+        const double at_p = (int)threadIdx.x < k_old ? kept_old[(size_t)threadIdx.x * ld + p] : 0.0;
+        const int kept_row = (int)threadIdx.x < k_old ? lp.eta_rows[threadIdx.x] : 0;
+        for (int i = threadIdx.x; i < mp; i += BT_THREADS) {
+            s_r1[i] = 0.0;
+            s_r2[i] = i < m ? lp.alpha[i] : 0.0;
+        }
+        if (dc < ETA_MAX) s_dot[dc][ds] = share;
+        __syncthreads();
+        if ((int)threadIdx.x < k_old) {
+            double dot = 0.0;
+            for (int e = 0; e < 32; ++e) dot += s_dot[threadIdx.x][e];  // fixed order
+            s_r2[kept_row] = dot;
+            s_r1[kept_row] = at_p / alpha_pq_c;
+        }
+        if (threadIdx.x == 0 && is_new) {  // p was not a kept column: M_old[:, p] = e_p
+            s_r2[p] = alpha_pq_c;
+            s_r1[p] = 1.0 / alpha_pq_c;
+        }
+        if (el_kept) {
+            const double t = el_at_p / alpha_pq_c;
+            kept_new[(size_t)c_el * ld + i_el] = (i_el == p) ? t : el_old - el_alpha * t;
+        } else if (el_new) {  // column p of E itself
+            kept_new[(size_t)c_el * ld + i_el] = (i_el == p) ? 1.0 / alpha_pq_c : -el_alpha / alpha_pq_c;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const double2* r1 = reinterpret_cast<const double2*>(s_r1);
     const double2* r2 = reinterpret_cast<const double2*>(s_r2);
     const int half = m / 2;  // ld is even for the dense pipeline (m even is required by the caller)
@@ -1040,15 +1039,6 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
         }
         if (blk.idx < 0 && threadIdx.x == 0) lp.cand_j[blockIdx.x] = -1;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int p = ctl->p;
-        if (lp.eta_slot[p] < 0) {
-            const int k = ctl->eta_count;
-            lp.eta_slot[p] = k;
-            lp.eta_rows[k] = p;
-            ctl->eta_count = k + 1;
-        }
-    }
 }
 
 // Consolidation, step 0: the pivot rows of the pending etas become touched columns.
@@ -1097,10 +1087,11 @@ __global__ void __launch_bounds__(256) eta_apply_kernel(DeviceLP lp) {
     const int i0 = blockIdx.x * EA_TI, j0 = blockIdx.y * EA_TJ;
     if (k == 0 || j0 >= n_touched) return;
     const int m = lp.m, ld = lp.ld;
+    const double* kept = eta_columns(lp, lp.ctl->eta_version);
     for (int e = threadIdx.x; e < k * EA_TI; e += 256) {
         const int c = e / EA_TI, r = e % EA_TI;
         const int i = i0 + r;
-        s_a[c][r] = i < m ? lp.eta_cols[(size_t)c * ld + i] - (i == lp.eta_rows[c] ? 1.0 : 0.0) : 0.0;
+        s_a[c][r] = i < m ? kept[(size_t)c * ld + i] - (i == lp.eta_rows[c] ? 1.0 : 0.0) : 0.0;
     }
     for (int e = threadIdx.x; e < k * EA_TJ; e += 256) {
         const int c = e / EA_TJ, r = e % EA_TJ;
@@ -2160,6 +2151,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         return;
     }
     // ---- x_B update (carry/mod.rs:295-325) and alpha for K3 ------------------------------------------------
+    const int eta_slot_p = (lp.eta_cap > 0 && tid == 0) ? lp.eta_slot[p] : 0;  // (requested here, used at the end)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = tid + r * K2F_THREADS;
@@ -2220,6 +2212,18 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             ctl->touched_count = count + 1;
         }
         lp.pos[q] = p;
+        if (lp.eta_cap > 0) {  // deferred product form: row p gets a kept column of M unless it has one; one more version of them
+            int is_new = 0;
+            if (eta_slot_p < 0) {
+                const int k = ctl->eta_count;
+                lp.eta_slot[p] = k;
+                lp.eta_rows[k] = p;
+                ctl->eta_count = k + 1;
+                is_new = 1;
+            }
+            ctl->eta_new = is_new;
+            ctl->eta_version = ctl->eta_version + 1;
+        }
         if (bounded) {
             int fl = leaving_flipped;
             if (leaves_at_upper) {
@@ -3492,7 +3496,6 @@ void configure_btran_lds(size_t) {
 // deferred product form: fold the new eta into the kept columns, then one read-only pass for rho_p, w and -pi
 int btran_pass_blocks() { return 256; }
 void launch_eta_update(const DeviceLP& d, double tol_dual, hipStream_t s) {
-    hipLaunchKernelGGL(eta_update_kernel, dim3(d.eta_cap + (d.m + ETA_THREADS - 1) / ETA_THREADS), dim3(ETA_THREADS), 0, s, d);
     const size_t lds = (size_t)2 * ((d.m + 1) & ~1) * sizeof(double);
     RELP_LAUNCH(2, btran_pass_kernel, dim3(btran_pass_blocks()), dim3(BT_THREADS), lds, s, d, tol_dual);
 }

@@ -109,7 +109,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.rvec1, d_.rvec2, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx, d_.slack_of_row, d_.state[0].ctl, d_.state[0].xB, d_.state[0].basis, d_.state[1].ctl, d_.state[1].xB, d_.state[1].basis};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.eta_dot_part, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx, d_.slack_of_row, d_.state[0].ctl, d_.state[0].xB, d_.state[0].basis, d_.state[1].ctl, d_.state[1].xB, d_.state[1].basis};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -349,7 +349,7 @@ void Solver::upload() {
     }
     d_.alpha_part = dmalloc<double>((size_t)std::max(1, ftran_slices_) * m);
     d_.alpha_in = dmalloc<double>(m);
-    // deferred product form of the inverse: the dense pipeline (multi-block FTRAN), m even and <= 4096 (eta_update_kernel)
+    // deferred product form of the inverse: the dense pipeline (multi-block FTRAN), m even and <= 4096 (alpha_reduce_kernel, btran_pass_kernel)
     const char* eta_env = getenv("RELP_ETA");  // RELP_ETA=0 keeps the per-pivot rank-one update (A/B measurements)
     eta_mode_ = n_dense > 0 && ftran_slices_ > 0 && m % 2 == 0 && m <= 4096 && !(eta_env && std::string(eta_env) == "0");
     d_.eta_cap = eta_mode_ ? eta_max() : 0;
@@ -366,12 +366,11 @@ void Solver::upload() {
     d_.tlist = dmalloc<int>(m);
     RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));
     if (eta_mode_) {
-        d_.eta_cols = dmalloc<double>((size_t)d_.eta_cap * d_.ld);
+        d_.eta_cols = dmalloc<double>((size_t)2 * d_.eta_cap * d_.ld);
+        d_.eta_dot_part = dmalloc<double>((size_t)d_.eta_cap * ((m + 63) / 64));
         d_.eta_rows = dmalloc<int>(d_.eta_cap);
         d_.eta_slot = dmalloc<int>(m);
         d_.eta_gather = dmalloc<double>((size_t)d_.eta_cap * m);
-        d_.rvec1 = dmalloc<double>(m);
-        d_.rvec2 = dmalloc<double>(m);
         RELP_HIP(hipMemsetAsync(d_.eta_slot, 0xff, m * sizeof(int), stream_));
         configure_btran_lds((size_t)2 * ((m + 1) & ~1) * sizeof(double));
     }
@@ -864,7 +863,7 @@ void Solver::launch_pivots(int count, bool forced) {
         enqueue_update();
         if (eta_mode_ && ((it + 1) % d_.eta_cap == 0 || it + 1 == count)) enqueue_consolidate();
     }
-    stats_.launches += 1 + (3LL + (dense_blocks_ > 0) + 2 * (ftran_slices_ > 0) + (eta_mode_ ? 1 : 0)) * count;
+    stats_.launches += 1 + (3LL + (dense_blocks_ > 0) + 2 * (ftran_slices_ > 0)) * count;
     stats_.price_launches += count;
 }
 

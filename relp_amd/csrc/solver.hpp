@@ -43,6 +43,8 @@ struct Ctl {
     long long bound_flips;  // iterations that moved the entering variable to its other bound without a basis change
     int k2_forced;     // multi-workgroup ratio test: the pivot row of this iteration was given by the caller
     int t_buf;         // fused pivot kernel: which of the two buffers holds the current inverse (0 outside a batch)
+    int eta_version;   // deferred product form: pivots made; the kept columns of M live in eta_cols buffer (eta_version & 1)
+    int eta_new;       // ... and whether the last pivot added a kept column (its row had none) -- both written by K2
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
@@ -64,12 +66,11 @@ struct DeviceLP {
     // i.e. eta_cols[:, c] is column eta_rows[c] of M.  Binv itself is only rewritten every eta_cap pivots (one rank-k
     // update); per pivot the passes over it are read-only (FTRAN, and one BTRAN pass for rho_p and w together).
     int eta_cap = 0;
-    double* eta_cols = nullptr;    // [eta_cap][ld]
+    double* eta_cols = nullptr;    // [2][eta_cap][ld]: two copies, the current one is copy ctl->eta_version & 1 (each pivot writes the other)
     int* eta_rows = nullptr;       // [eta_cap]
     int* eta_slot = nullptr;       // [m]: slot of row i in eta_rows, or -1
     double* eta_gather = nullptr;  // [eta_cap][m]: rows eta_rows[c] of Binv, gathered before the rank-k update
-    double* rvec1 = nullptr;       // e_p' M_new  (row vector whose product with Binv is rho_p)          [m]
-    double* rvec2 = nullptr;       // alpha' M_old (row vector whose product with Binv is w)             [m]
+    double* eta_dot_part = nullptr;  // [eta_cap][ceil(m / 64)]: alpha_reduce_kernel's per-block shares of alpha' M[:, c]
     // Column j of the STORED inverse is still the unit vector e_j until a row-j pivot has been folded in (E e_j = e_j for
     // every eta of another row; the polish keeps such columns exactly).  touched[j] / tlist record the others, so that the
     // FTRAN and BTRAN passes and the rank-k update only stream columns that carry information.
