@@ -517,7 +517,7 @@ def main():
                 line["roofline"]["note"] = ("dense block held in the narrowest exact type (this workload: signed bytes, 1 B per entry; as float the "
                                             "pass streams 4x the bytes at 4.4 TB/s = 0.55 of the HBM peak): one column per lane, -pi / rho / w "
                                             "broadcast through DPP inside the f64 FMA (no LDS traffic); 5 VALU instructions per entry = %.1f us "
-                                            "of issue time on 1024 SIMDs (tools/microbench/valu_rates.hip: 1.9 ns each), the rest of the launch is "
+                                            "of issue time on 1024 SIMDs (tools/micro/valu_rates.hip: 1.9 ns each), the rest of the launch is "
                                             "the first load's latency and the per-workgroup tail" % (bytes_per_launch * 5 * 1.9e-3 / 64 / 1024))
             else:
                 line["roofline"]["note"] = ("dense block streamed as %s, one wave per column with 16-byte non-temporal loads, -pi / rho / w in LDS"

@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(K1D_THREADS) price_dense_kernel(DeviceLP lp, i
 // lanes of a DPP row work on the SAME 16 matrix rows: lane l holds -pi / rho / w of row 64B + l in a register pair (one
 // coalesced 512-byte load), and entry t of the piece is multiplied by lane t's value through the DPP row broadcast of the f64 FMA
 // (v_fmac_f64_dpp row_newbcast:t) -- no LDS traffic, no cross-lane reduction, 5 VALU instructions per entry (extract,
-// convert, three FMAs; tools/microbench/valu_rates.hip: all five issue at the full rate, DPP included).  A workgroup owns one
+// convert, three FMAs; tools/micro/valu_rates.hip: all five issue at the full rate, DPP included).  A workgroup owns one
 // group of 16 columns, its waves split the rows; their partial sums meet in LDS, and a thread per column adds them in a fixed
 // order, updates the column's weight and tests it: one candidate slot per workgroup, 512 workgroups of 8 waves at n = 8192
 // (two per CU, so that one's tail overlaps the other's stream; 32 columns per group and 16 waves: 12.5 us against 9.6 + 4.8).

@@ -1,5 +1,5 @@
 // Issue rates of the VALU instructions the dense pricing kernel is made of, on one SIMD: cycles per wave instruction.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rates tools/microbench/valu_rates.hip && /tmp/valu_rates
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rates tools/micro/valu_rates.hip && /tmp/valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define REP8(X) X X X X X X X X
