@@ -1971,21 +1971,73 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             s_vals[e] = lp.value[c0 + e];
         }
         __syncthreads();
+        // Per row: four chains over the entries e = 0, 1, 2, 3 (mod 4), leftovers onto the first, (a0 + a1) + (a2 + a3) -- the
+        // arithmetic of pivot_fused_kernel, bit for bit.  The rows of a thread go through the entry loop TOGETHER, up to eight at a
+        // time: 32 loads in flight per thread instead of 4 (a row at a time, this one-workgroup FTRAN was a chain of round trips:
+        // 7 of the 17 us of this kernel on GREENBEA).
+        constexpr int RG = R <= 8 ? R : 1;
+        if constexpr (R <= 8) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = tid + r * K2F_THREADS;
-            if (i >= m) continue;
-            const double* col = lp.Binv + i;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int r0 = 0; r0 < R; r0 += RG) {
+            double acc[RG][4];
+            int row[RG];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const int i = tid + (r0 + r) * K2F_THREADS;
+                row[r] = i < m ? i : 0;  // (rows past m read row 0 and are dropped below)
+                acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0;
+            }
+            const double* T = lp.Binv;
             int e = 0;
             for (; e + 4 <= cnt; e += 4) {
-                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
-                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
-                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+                const size_t o0 = (size_t)s_rows[e] * ld, o1 = (size_t)s_rows[e + 1] * ld, o2 = (size_t)s_rows[e + 2] * ld, o3 = (size_t)s_rows[e + 3] * ld;
+                const double v0 = s_vals[e], v1 = s_vals[e + 1], v2 = s_vals[e + 2], v3 = s_vals[e + 3];
+                double x[RG][4];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    x[r][0] = T[o0 + row[r]];
+                    x[r][1] = T[o1 + row[r]];
+                    x[r][2] = T[o2 + row[r]];
+                    x[r][3] = T[o3 + row[r]];
+                }
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    acc[r][0] += x[r][0] * v0;
+                    acc[r][1] += x[r][1] * v1;
+                    acc[r][2] += x[r][2] * v2;
+                    acc[r][3] += x[r][3] * v3;
+                }
             }
-            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-            al[r] += (a0 + a1) + (a2 + a3);
+            for (; e < cnt; ++e) {
+                const size_t o = (size_t)s_rows[e] * ld;
+                const double v = s_vals[e];
+                double x[RG];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) x[r] = T[o + row[r]];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) acc[r][0] += x[r] * v;
+            }
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                if (tid + (r0 + r) * K2F_THREADS < m) al[r0 + r] += (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+        }
+        } else {  // (16 rows per thread: the grouped form spills)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = tid + r * K2F_THREADS;
+                if (i >= m) continue;
+                const double* col = lp.Binv + i;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                int e = 0;
+                for (; e + 4 <= cnt; e += 4) {
+                    a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                    a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
+                    a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
+                    a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
+                }
+                for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
+                al[r] += (a0 + a1) + (a2 + a3);
+            }
         }
     }
     STAMP(2);
@@ -2152,14 +2204,6 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     }
     // ---- x_B update (carry/mod.rs:295-325) and alpha for K3 ------------------------------------------------
     const int eta_slot_p = (lp.eta_cap > 0 && tid == 0) ? lp.eta_slot[p] : 0;  // (requested here, used at the end)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = tid + r * K2F_THREADS;
-        if (i < m) {
-            lp.alpha[i] = al[r];
-            lp.xB[i] = (i == p) ? xp : xb[r] - al[r] * xp;
-        }
-    }
     int total = 0;
     if (R >= 8 && lp.eta_cap == 0) {  // ordered list of the rows K3 has to touch (alpha_i != 0, plus p); rows ascend with (r, tid)
         constexpr int NW = K2F_THREADS / WAVE;
@@ -2173,14 +2217,22 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             if (lane_k2 == 0) s_nz_count[r * NW + wave_k2] = __popcll(masks[r]);
         }
         __syncthreads();
-        if (tid == 0) {  // exclusive prefix over the R * NW wave counts
-            int running = 0;
-            for (int e = 0; e < R * NW; ++e) {
-                const int c = s_nz_count[e];
-                s_nz_count[e] = running;
-                running += c;
+        if (wave_k2 == 0) {  // exclusive prefix over the R * NW wave counts: wave 0, 64 counts at a time (a serial loop of one
+                             // thread over 64 - 128 LDS reads was 2 - 4 us of this kernel on the mid-size LPs)
+            int carry = 0;
+#pragma unroll
+            for (int base = 0; base < R * NW; base += WAVE) {
+                const int c = base + lane_k2 < R * NW ? s_nz_count[base + lane_k2] : 0;
+                int incl = c;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const int up = __shfl_up(incl, d);
+                    if (lane_k2 >= d) incl += up;
+                }
+                if (base + lane_k2 < R * NW) s_nz_count[base + lane_k2] = carry + incl - c;
+                carry += __shfl(incl, WAVE - 1);
             }
-            s_nz_count[R * NW] = running;
+            if (lane_k2 == 0) s_nz_count[R * NW] = carry;
         }
         __syncthreads();
 #pragma unroll
@@ -2193,6 +2245,15 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
             }
         }
         total = s_nz_count[R * NW];
+    }
+    // (the stores come after the barriers of the list above: a barrier waits for every store in flight)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * K2F_THREADS;
+        if (i < m) {
+            lp.alpha[i] = al[r];
+            lp.xB[i] = (i == p) ? xp : xb[r] - al[r] * xp;
+        }
     }
     STAMP(5);
     const int leaving_flipped = bounded ? lp.flipped[leaving] : 0;
