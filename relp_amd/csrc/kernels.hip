@@ -541,8 +541,8 @@ __global__ void __launch_bounds__(K1C_MAX_THREADS) price_dense_lane_kernel(Devic
     const double* a_rho = lp.rho + my_row;
     const double* a_w = lp.w + my_row;
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    DenseLaneBatch next;
-    dense_lane_load(next, piece, a_pi, a_rho, a_w, 0);  // requested before the control block is looked at
+    DenseLaneBatch A, B;  // two batches alternate: the loads of one are in flight while the other is worked on
+    dense_lane_load(A, piece, a_pi, a_rho, a_w, 0);  // requested before the control block is looked at
     // the thread that finishes column 16 * group + threadIdx.x asks for what it needs there now
     const int jd = group * K1C_COLS + threadIdx.x;
     const bool finisher = threadIdx.x < K1C_COLS && jd < lp.n_dense;
@@ -554,13 +554,24 @@ __global__ void __launch_bounds__(K1C_MAX_THREADS) price_dense_lane_kernel(Devic
     const int pending = ctl->pending && !skip_weights;
     const int leaving = ctl->leaving;
     const double alpha_pq = ctl->alpha_pq, gamma_q = ctl->gamma_q;
-    for (int b0 = 0; b0 < ntiles; b0 += K1C_U) {
-        const DenseLaneBatch cur = next;
-        if (b0 + K1C_U < ntiles) dense_lane_load(next, piece, a_pi, a_rho, a_w, b0 + K1C_U);
-        // (all three sums whether or not a weight update is pending -- two code paths make the compiler hoist the
-        // conversions they share above the branch, and spill)
+    // (all three sums whether or not a weight update is pending -- two code paths make the compiler hoist the conversions they
+    // share above the branch, and spill)
+    auto work = [&](DenseLaneBatch& t) {
 #pragma unroll
-        for (int u = 0; u < K1C_U; ++u) dense_lane_block(cur.v[u], cur.vp[u], cur.vr[u], cur.vw[u], acc, std::make_integer_sequence<int, 16>{});
+        for (int u = 0; u < K1C_U; ++u) {
+            // A VGPR written by a VALU instruction must not be read through DPP for two wait states, and the compiler does not
+            // see the DPP reads inside the asm statements: whatever it does to the three vector registers (copies) happens
+            // before this statement, which owns them and waits.
+            asm volatile("s_nop 1" : "+v"(t.vp[u]), "+v"(t.vr[u]), "+v"(t.vw[u]));
+            dense_lane_block(t.v[u], t.vp[u], t.vr[u], t.vw[u], acc, std::make_integer_sequence<int, 16>{});
+        }
+    };
+    for (int b0 = 0; b0 < ntiles; b0 += 2 * K1C_U) {
+        const bool second = b0 + K1C_U < ntiles;
+        if (second) dense_lane_load(B, piece, a_pi, a_rho, a_w, b0 + K1C_U);
+        work(A);
+        if (b0 + 2 * K1C_U < ntiles) dense_lane_load(A, piece, a_pi, a_rho, a_w, b0 + 2 * K1C_U);
+        if (second) work(B);
     }
     s_part[wave][0][lane] = acc[0] + acc[1];
     s_part[wave][1][lane] = acc[2] + acc[3];
