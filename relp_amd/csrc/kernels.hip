@@ -2888,9 +2888,9 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
             const int i = base + lane + u * WAVE;
             w0 += a[u] * o0[u];
             w1 += a[u] * o1[u];
-            if (i < row_hi && (a[u] != 0.0 || i == p)) {
-                c0[i] = (i == p) ? r0 : o0[u] - a[u] * r0;
-                if (two) c1[i] = (i == p) ? r1 : o1[u] - a[u] * r1;
+            if (i < row_hi && (a[u] != 0.0 || i == p)) {  // (r == 0: the column has no entry in row p and does not change)
+                if (r0 != 0.0) c0[i] = (i == p) ? r0 : o0[u] - a[u] * r0;
+                if (two && r1 != 0.0) c1[i] = (i == p) ? r1 : o1[u] - a[u] * r1;
             }
         }
     }
