@@ -2512,22 +2512,48 @@ __global__ void __launch_bounds__(KF_THREADS) pivot_fused_kernel(DeviceLP lp, De
             s_vals[e] = lp.value[c0_ + e];
         }
         __syncthreads();
+        // (the rows of a thread share the entry loop -- 4 R loads in flight -- with the per-row arithmetic of
+        // ftran_ratio_fast_kernel, bit for bit: four chains over e mod 4, leftovers onto the first, (a0 + a1) + (a2 + a3))
+        double acc[R][4];
+        int row[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = tid + r * KF_THREADS;
-            if (i >= m) continue;
-            const double* col = t_old + i;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            int e = 0;
-            for (; e + 4 <= cnt; e += 4) {
-                a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-                a1 += col[(size_t)s_rows[e + 1] * ld] * s_vals[e + 1];
-                a2 += col[(size_t)s_rows[e + 2] * ld] * s_vals[e + 2];
-                a3 += col[(size_t)s_rows[e + 3] * ld] * s_vals[e + 3];
-            }
-            for (; e < cnt; ++e) a0 += col[(size_t)s_rows[e] * ld] * s_vals[e];
-            al[r] += (a0 + a1) + (a2 + a3);
+            row[r] = i < m ? i : 0;  // (rows past m read row 0 and are dropped below)
+            acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0;
         }
+        int e = 0;
+        for (; e + 4 <= cnt; e += 4) {
+            const size_t o0 = (size_t)s_rows[e] * ld, o1 = (size_t)s_rows[e + 1] * ld, o2 = (size_t)s_rows[e + 2] * ld, o3 = (size_t)s_rows[e + 3] * ld;
+            const double v0 = s_vals[e], v1 = s_vals[e + 1], v2 = s_vals[e + 2], v3 = s_vals[e + 3];
+            double x[R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                x[r][0] = t_old[o0 + row[r]];
+                x[r][1] = t_old[o1 + row[r]];
+                x[r][2] = t_old[o2 + row[r]];
+                x[r][3] = t_old[o3 + row[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r][0] += x[r][0] * v0;
+                acc[r][1] += x[r][1] * v1;
+                acc[r][2] += x[r][2] * v2;
+                acc[r][3] += x[r][3] * v3;
+            }
+        }
+        for (; e < cnt; ++e) {
+            const size_t o_e = (size_t)s_rows[e] * ld;
+            const double v = s_vals[e];
+            double x[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[r] = t_old[o_e + row[r]];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][0] += x[r] * v;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (tid + r * KF_THREADS < m) al[r] += (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
     }
     FSTAMP(2);
     // ---- gamma_q and Harris pass 1, one combined block reduction (see ftran_ratio_fast_kernel) ---------------------
