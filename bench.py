@@ -145,25 +145,26 @@ def dense_roofline(device):
     seconds = solver.profile_kernel(0, 100)
     bytes_per_launch = solver.stats().price_bytes
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r1_dense4096_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r2_dense4096_pmc_traffic.json")
     if os.path.exists(pmc):
         for name, entry in json.load(open(pmc)).items():
-            if "price_dense_kernel" in name:
+            if "price_dense_lane_kernel" in name:
                 traffic = entry["hbm_bytes_corrected"]
     solver.close()
     achieved = bytes_per_launch / seconds / 1e9
     # The coefficients of this workload are integers in [1, 100]: the block is held as signed bytes (1 B per entry; 4 B as
-    # float measured 131.4 MB in 27.6 us = 4.4 TB/s = 55 % of the HBM peak, 8 B as f64 262.7 MB at 4.8 TB/s).  With a quarter
-    # of the bytes the pass is no longer bound by HBM: every entry meets three doubles (-pi, rho, w) that come out of LDS.
-    lds_bytes = 24 * bytes_per_launch
+    # float measured 131.4 MB in 29.7 us = 4.4 TB/s = 55 % of the HBM peak, 8 B as f64 262.7 MB at 5.1 TB/s).  With a quarter
+    # of the bytes the pass is no longer bound by HBM but by f64 issue: 5 VALU instructions per entry (extract, convert, three
+    # FMAs whose second operand comes through the DPP row broadcast), 1.9 ns per wave instruction per SIMD.
+    valu_seconds = bytes_per_launch * 5 * 1.9e-9 / 64 / 1024
     return {"workload": "synthetic dense random LP m=4096 n=8192 (python bench.py --workload dense4096 for its pivots/s)",
             "bound": "hbm", "kernel": "price (dense block, 1 B per entry)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "seconds_per_launch": seconds,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "lds": {"bytes_per_launch": lds_bytes, "achieved": lds_bytes / seconds / 1e9, "peak": 150000.0, "unit": "GB/s",
-                    "frac": lds_bytes / seconds / 1e9 / 150000.0},
-            "note": "the same pass with the block held as float streams 131.4 MB in 27.6 us (4.4 TB/s, frac 0.55 of HBM); as bytes "
-                    "it streams 33 MB in less time and is bound by the 24 B per entry it reads from LDS and by f64 FMA issue"}
+            "valu": {"instructions_per_entry": 5, "issue_seconds_per_launch": valu_seconds, "frac_of_launch": valu_seconds / seconds},
+            "note": "the same pass with the block held as float streams 131.4 MB in 29.7 us (4.4 TB/s, frac 0.55 of HBM); as bytes "
+                    "it streams 33 MB in less time, one column per lane with -pi / rho / w broadcast through DPP inside the f64 FMA "
+                    "(no LDS traffic), and is bound by f64 issue and the launch's fixed latencies"}
 
 
 def netlib_batch(args, rank, local_rank, world, distributed):
@@ -458,7 +459,8 @@ def main():
         # HBM traffic per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md
         # section HBM); null when not collected for this kernel
         traffic = None
-        pmc_names = {"price": "price_dense_kernel" if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
+        dense_price = "price_dense_lane_kernel" if args.dense_storage == "narrowest" else "price_dense_kernel"
+        pmc_names = {"price": dense_price if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
                      "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
         for candidate in ("r2_%s_pmc_traffic.json" % args.workload, "r1_%s_pmc_traffic.json" % args.workload):
             pmc = os.path.join(ROOT, "profiles", candidate)
