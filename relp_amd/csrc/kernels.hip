@@ -640,18 +640,30 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
     __shared__ double s_unit[256];
     __shared__ Cand s_cand[8];
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING) return;
+    // round trip 1: the control block AND this thread's first four candidate slots (they do not depend on it)
+    constexpr int PRE = 4;
+    int pre_j[PRE];
+    double pre_key[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int b = threadIdx.x + u * 256;
+        pre_j[u] = b < n_price_blocks ? lp.cand_j[b] : -1;
+        pre_key[u] = b < n_price_blocks ? lp.cand_key[b] : 0.0;  // (not written when the slot is empty: ignored below)
+    }
+    const int status = ctl->status;
+    const long long iters_now = ctl->iters, budget = ctl->budget;
+    int q = ctl->forced_q;
+    if (status != ST_RUNNING) return;
     const bool structured = lp.eta_cap > 0;  // unit columns of the stored inverse are known: skip their loads
     s_unit[threadIdx.x] = 0.0;
     const bool publisher = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
-    if (ctl->iters >= ctl->budget) {
+    if (iters_now >= budget) {
         if (publisher) {
             ctl->status = ST_BUDGET;
             ctl->pending = 0;
         }
         return;
     }
-    int q = ctl->forced_q;
     if (q >= 0) {
         if (publisher) ctl->q = q;
     } else {
@@ -659,7 +671,18 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
         c.key = 0.0;
         c.idx = -1;
         c.aux = 0;
-        for (int b = threadIdx.x; b < n_price_blocks; b += blockDim.x) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int b = threadIdx.x + u * 256;
+            if (b < n_price_blocks) {
+                Cand o;
+                o.idx = pre_j[u];
+                o.key = o.idx >= 0 ? pre_key[u] : 0.0;
+                o.aux = b;
+                c = (rule == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
+            }
+        }
+        for (int b = threadIdx.x + PRE * 256; b < n_price_blocks; b += 256) {
             Cand o;
             o.idx = lp.cand_j[b];
             o.key = o.idx >= 0 ? lp.cand_key[b] : 0.0;
@@ -681,7 +704,10 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
     }
     if (q < 0) return;
     const int m = lp.m, ld = lp.ld;
-    const int ca = lp.col_start[q], cb = lp.col_start[q + 1];
+    // a column of a dense block whose columns all have m entries: its place in the CSC and its row indices are known
+    const bool full = lp.dense_full && q >= lp.dense_first && q < lp.dense_first + lp.n_dense;
+    const int ca = full ? lp.dense_csc_start + (q - lp.dense_first) * m : lp.col_start[q];
+    const int cb = full ? ca + m : lp.col_start[q + 1];
     const int len = (cb - ca + n_slices - 1) / n_slices;
     const int e0 = ca + blockIdx.y * len, e1 = min(cb, e0 + len);
     const int tile0 = blockIdx.x * 256;
@@ -700,7 +726,7 @@ __global__ void __launch_bounds__(256) ftran_partial_kernel(DeviceLP lp, int n_s
             double val = 0.0;
             bool keep = false;
             if (threadIdx.x < cnt) {
-                row = lp.row_index[c0 + threadIdx.x];
+                row = full ? c0 + (int)threadIdx.x - ca : lp.row_index[c0 + threadIdx.x];
                 val = lp.value[c0 + threadIdx.x];
                 keep = lp.touched[row] != 0;
             }

@@ -257,6 +257,15 @@ void Solver::upload() {
     for (int jd = 0; dense_bytes && jd < n_dense; ++jd)
         for (int e = col_start[n_art + jd]; dense_bytes && e < col_start[n_art + jd + 1]; ++e)
             dense_bytes = value[e] >= -128.0 && value[e] <= 127.0 && value[e] == std::floor(value[e]);
+    {
+        bool full = n_dense > 0;
+        for (int jd = 0; full && jd < n_dense; ++jd) {
+            full = col_start[n_art + jd + 1] - col_start[n_art + jd] == m;
+            for (int e = col_start[n_art + jd], i = 0; full && i < m; ++e, ++i) full = row_index[e] == i;
+        }
+        d_.dense_full = full ? 1 : 0;
+        d_.dense_csc_start = n_dense > 0 ? col_start[n_art] : 0;
+    }
     int vector_len = m;  // -pi, rho, w: zero-padded to the dense block's row count when the column-per-lane pricing reads them
     if (dense_bytes && dense_lane_slots(n_dense) <= 1024 && !getenv("RELP_NO_DENSE_LANE")) {
         // column-per-lane pricing: one workgroup and one candidate slot per group of 16 columns

@@ -57,6 +57,7 @@ struct DeviceLP {
     int n_dense = 0, dense_first = 0, dense_ld = 0;
     double* dense_val = nullptr;
     signed char* dense_val8 = nullptr;  // the same block as signed bytes (every entry an integer in [-128, 127]); rows permuted within 1024-row chunks, dense_ld a multiple of 1024
+    int dense_full = 0, dense_csc_start = 0;  // 1: every column of the dense block has m entries (rows 0 .. m-1 in order), the first of them at dense_csc_start in the CSC
     int dense_lane = 0;  // 1: dense_val8 in tiles of 16 columns x 64 rows instead (price_dense_lane_kernel), -pi / rho / w zero-padded to dense_ld
     float* dense_val32 = nullptr;  // the same block as float, when every entry is exactly representable (then dense_val is not allocated)
     double* alpha_part = nullptr;  // slices of the multi-block FTRAN, [n_slices][m]
