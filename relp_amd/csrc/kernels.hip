@@ -877,10 +877,31 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Cand s_cand[BT_THREADS / WAVE + 2];
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING || !ctl->pending) return;
     const bool price_slacks = lp.slack_of_row != nullptr;
+    const int m = lp.m, ld = lp.ld;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    // Round trip 1 carries, beside the control block, everything whose ADDRESS does not depend on it: this thread's unit-column
+    // candidate (column j_u: is it touched, its -pi, its slack column) and the entries of the touched-column
+    // list its wave will visit (the list only grows; entries past touched_count are not used).
+    constexpr int GROUPS = BT_THREADS / WAVE / 4;  // touched columns per workgroup pass: four waves each
+    const int part = wave & 3, group = wave >> 2;
+    const int j_u = blockIdx.x * BT_THREADS + threadIdx.x;
+    const bool has_u = j_u < m;
+    const int touched_u = has_u ? lp.touched[j_u] : 1;
+    const double pi_u = has_u ? lp.minus_pi[j_u] : 0.0;
+    const int sor_u = (has_u && price_slacks) ? lp.slack_of_row[j_u] : -1;
+    constexpr int TL = 4;
+    int tl[TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+        const int idx = (blockIdx.x + t * gridDim.x) * GROUPS + group;
+        tl[t] = idx < m ? lp.tlist[idx] : 0;
+    }
+    const int status = ctl->status, pending_now = ctl->pending;
     const double gamma_q = ctl->gamma_q, alpha_pq_c = ctl->alpha_pq;
     const int leaving = ctl->leaving;
+    const int n_touched = ctl->touched_count;
+    if (status != ST_RUNNING || !pending_now) return;
     Cand best;
     best.key = 0.0;
     best.idx = -1;
@@ -893,16 +914,17 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
         int pos;
         double v, gam, cost;
     };
-    auto slack_fetch = [&](int j) {
+    auto slack_data = [&](int js) {
         SlackData d;
-        d.js = lp.slack_of_row[j];
-        const int jj = d.js < 0 ? 0 : d.js;
-        d.pos = d.js < 0 ? 0 : lp.pos[jj];
+        d.js = js;
+        const int jj = js < 0 ? 0 : js;
+        d.pos = js < 0 ? 0 : lp.pos[jj];
         d.v = lp.ell_vals[(size_t)jj * ELL_W];
         d.gam = lp.gamma[jj];
         d.cost = lp.cost[jj];
         return d;
     };
+    auto slack_fetch = [&](int j) { return slack_data(lp.slack_of_row[j]); };
     auto slack = [&](const SlackData& d, int j, double pi_new, double rho_j, double w_j) {
         const int js = d.js;
         if (js < 0 || d.pos != -1) return;
@@ -932,12 +954,45 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
             best = nb;
         }
     };
-    const int m = lp.m, ld = lp.ld;
     const int mp = (m + 1) & ~1;
     double* s_r1 = smem;
     double* s_r2 = smem + mp;
     const double cbar_q = ctl->cbar_q;
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int half = m / 2;  // ld is even for the dense pipeline (m even is required by the caller)
+    const int quarter = (half + 3) / 4;
+    const int k_first = part * quarter, k_last = min(half, k_first + quarter);
+    // round trip 2, all of it requested before anything of it is used: the unit-column candidate's slack column, the first
+    // touched column of this wave (the first batch of its quarter) with its slack column, and the prologue's loads below
+    SlackData sd_u;
+    sd_u.js = -1;
+    if (has_u && !touched_u && price_slacks) sd_u = slack_data(sor_u);
+    struct Visit {  // one touched column of this wave: the first batch of its rows, and what the wave that finishes it needs
+        bool active;
+        int j;
+        double2 v[8];
+        SlackData sd;
+        double pi_old;
+    };
+    auto issue = [&](int t, int base, Visit& x) {
+        const int idx = base + group;
+        x.active = idx < n_touched;
+        const int listed = t == 0 ? tl[0] : t == 1 ? tl[1] : t == 2 ? tl[2] : t == 3 ? tl[3] : (x.active ? lp.tlist[idx] : 0);
+        x.j = x.active ? listed : 0;
+        const double2* col = reinterpret_cast<const double2*>(lp.Binv + (size_t)x.j * ld);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k_first + lane + u * WAVE;
+            x.v[u] = (x.active && kk < k_last) ? col[kk] : make_double2(0.0, 0.0);
+        }
+        x.sd.js = -1;
+        x.pi_old = 0.0;
+        if (x.active && part == 0 && lane == WAVE - 1) {
+            if (price_slacks) x.sd = slack_fetch(x.j);
+            x.pi_old = lp.minus_pi[x.j];
+        }
+    };
+    Visit cur;
+    issue(0, blockIdx.x * GROUPS, cur);
     {
         __shared__ double s_dot[ETA_MAX][32];
         const int version = ctl->eta_version;  // K2 counted this pivot already: the columns as they were are in copy version - 1
@@ -989,9 +1044,16 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
     }
     const double2* r1 = reinterpret_cast<const double2*>(s_r1);
     const double2* r2 = reinterpret_cast<const double2*>(s_r2);
-    const int half = m / 2;  // ld is even for the dense pipeline (m even is required by the caller)
     // unit columns: rho_j = rvec1[j], w_j = rvec2[j]
-    for (int j = blockIdx.x * BT_THREADS + threadIdx.x; j < m; j += gridDim.x * BT_THREADS) {
+    if (has_u && !touched_u) {
+        const double d1 = s_r1[j_u];
+        const double pi_new = pi_u - cbar_q * d1;
+        lp.rho[j_u] = d1;
+        lp.w[j_u] = s_r2[j_u];
+        lp.minus_pi[j_u] = pi_new;
+        if (price_slacks) slack(sd_u, j_u, pi_new, d1, s_r2[j_u]);
+    }
+    for (int j = j_u + gridDim.x * BT_THREADS; j < m; j += gridDim.x * BT_THREADS) {  // (m beyond the grid: not the case today)
         if (!lp.touched[j]) {
             SlackData sd;
             sd.js = -1;
@@ -1004,29 +1066,28 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
             if (price_slacks) slack(sd, j, pi_new, d1, s_r2[j]);
         }
     }
-    const int n_touched = ctl->touched_count;
     // FOUR waves per touched column (a quarter of its rows each: one batch of loads per lane at m = 4096 instead of four dependent
     // ones), the four partial sums added in a fixed order by the first of them.  Early in a solve there are far fewer touched
     // columns than waves, so the pass was a handful of waves each waiting on four round trips.
     __shared__ double s_quarter[BT_THREADS / WAVE][2];
-    constexpr int GROUPS = BT_THREADS / WAVE / 4;  // columns per workgroup pass
-    const int part = wave & 3, group = wave >> 2;
-    const int quarter = (half + 3) / 4;
-    const int k_first = part * quarter, k_last = min(half, k_first + quarter);
-    for (int base = blockIdx.x * GROUPS; base < n_touched; base += gridDim.x * GROUPS) {
-        const int idx = base + group;
-        const bool active = idx < n_touched;
-        const int j = lp.tlist[active ? idx : 0];
+    int visit = 0;
+    for (int base = blockIdx.x * GROUPS; base < n_touched; base += gridDim.x * GROUPS, ++visit) {
+        if (visit > 0) issue(visit, base, cur);  // (requesting a wave's next column before the sums and barriers of the current one
+                                                 // was measured: the second set of registers spills at 1024 threads, 11.3 us against 10.3)
+        const bool active = cur.active;
+        const int j = cur.j;
         const double2* col = reinterpret_cast<const double2*>(lp.Binv + (size_t)j * ld);
-        SlackData sd;
-        sd.js = -1;
-        double pi_old = 0.0;
-        if (active && part == 0 && lane == WAVE - 1) {
-            if (price_slacks) sd = slack_fetch(j);
-            pi_old = lp.minus_pi[j];
-        }
         double d1 = 0.0, d2 = 0.0;
-        for (int k0 = k_first + lane; active && k0 < k_last; k0 += 8 * WAVE) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k_first + lane + u * WAVE;
+            if (active && kk < k_last) {
+                const double2 x = r1[kk], y = r2[kk];
+                d1 += cur.v[u].x * x.x + cur.v[u].y * x.y;
+                d2 += cur.v[u].x * y.x + cur.v[u].y * y.y;
+            }
+        }
+        for (int k0 = k_first + lane + 8 * WAVE; active && k0 < k_last; k0 += 8 * WAVE) {  // (quarters beyond one batch: m > 4096)
             double2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1053,11 +1114,11 @@ __global__ void __launch_bounds__(BT_THREADS) btran_pass_kernel(DeviceLP lp, dou
         if (active && part == 0 && lane == WAVE - 1) {
             d1 = (s_quarter[wave][0] + s_quarter[wave + 1][0]) + (s_quarter[wave + 2][0] + s_quarter[wave + 3][0]);
             d2 = (s_quarter[wave][1] + s_quarter[wave + 1][1]) + (s_quarter[wave + 2][1] + s_quarter[wave + 3][1]);
-            const double pi_new = pi_old - cbar_q * d1;
+            const double pi_new = cur.pi_old - cbar_q * d1;
             lp.rho[j] = d1;
             lp.w[j] = d2;
             lp.minus_pi[j] = pi_new;
-            if (price_slacks) slack(sd, j, pi_new, d1, d2);
+            if (price_slacks) slack(cur.sd, j, pi_new, d1, d2);
         }
         __syncthreads();
     }
@@ -1885,6 +1946,15 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     double ckey = 0.0;
     unsigned long long crank = RANK_NONE;
     const bool preselected = n_alpha_slices > 0;
+    // preselected: q, its reduced cost and the whole column alpha_in were left by earlier kernels -- requested in this round trip too
+    const int q_pre = preselected ? ctl->q : -1;
+    const double cbar_pre = preselected ? ctl->cbar_q : 0.0;
+    double ain[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * K2F_THREADS;
+        ain[r] = (preselected && i < m) ? lp.alpha_in[i] : 0.0;
+    }
     if (!preselected) {  // NOT conditional on forced_q (a value still in flight): that would put these loads a round trip later
         for (int b = tid; b < n_price_blocks; b += K2F_THREADS) {
             const int j = lp.cand_j[b];
@@ -1922,8 +1992,8 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     double cbar_q;
     int winner_block = 0;
     if (preselected && forced_q < 0) {
-        q = ctl->q;
-        cbar_q = ctl->cbar_q;
+        q = q_pre;
+        cbar_q = cbar_pre;
     } else if (forced_q < 0) {
         block_argbest(ckey, crank, s_akey, s_arank);
         if (crank == RANK_NONE) {
@@ -1995,10 +2065,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
     }
     if (preselected) {  // alpha_reduce_kernel left the whole column (pending etas applied) in alpha_in
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = tid + r * K2F_THREADS;
-            if (i < m) al[r] += lp.alpha_in[i];
-        }
+        for (int r = 0; r < R; ++r) al[r] += ain[r];
     }
     for (int c0 = ca; c0 < cb_; c0 += K2_COL_CHUNK) {
         const int cnt = min(K2_COL_CHUNK, cb_ - c0);
