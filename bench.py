@@ -153,7 +153,7 @@ def dense_roofline(device):
     solver.close()
     achieved = bytes_per_launch / seconds / 1e9
     # The coefficients of this workload are integers in [1, 100]: the block is held as signed bytes (1 B per entry; 4 B as
-    # float measured 131.4 MB in 29.7 us = 4.4 TB/s = 55 % of the HBM peak, 8 B as f64 262.7 MB at 5.1 TB/s).  With a quarter
+    # float measured 131.4 MB in 25.1 us = 5.2 TB/s = 65 % of the HBM peak, 8 B as f64 262.7 MB in 45.9 us = 5.7 TB/s = 72 %).  With a quarter
     # of the bytes the pass is no longer bound by HBM but by f64 issue: 5 VALU instructions per entry (extract, convert, three
     # FMAs whose second operand comes through the DPP row broadcast), 1.9 ns per wave instruction per SIMD.
     valu_seconds = bytes_per_launch * 5 * 1.9e-9 / 64 / 1024
@@ -162,7 +162,7 @@ def dense_roofline(device):
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "seconds_per_launch": seconds,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "valu": {"instructions_per_entry": 5, "issue_seconds_per_launch": valu_seconds, "frac_of_launch": valu_seconds / seconds},
-            "note": "the same pass with the block held as float streams 131.4 MB in 29.7 us (4.4 TB/s, frac 0.55 of HBM); as bytes "
+            "note": "the same pass with the block held as float streams 131.4 MB in 25.1 us (5.2 TB/s, frac 0.65 of HBM); as bytes "
                     "it streams 33 MB in less time, one column per lane with -pi / rho / w broadcast through DPP inside the f64 FMA "
                     "(no LDS traffic), and is bound by f64 issue and the launch's fixed latencies"}
 
@@ -517,13 +517,16 @@ def main():
             line["metric"] = "simplex pivots/sec + wall-clock to optimal, dense LP @1 GPU"
             if args.dense_storage == "narrowest":
                 line["roofline"]["note"] = ("dense block held in the narrowest exact type (this workload: signed bytes, 1 B per entry; as float the "
-                                            "pass streams 4x the bytes at 4.4 TB/s = 0.55 of the HBM peak): one column per lane, -pi / rho / w "
+                                            "pass streams 4x the bytes at 5.2 TB/s = 0.65 of the HBM peak): one column per lane, -pi / rho / w "
                                             "broadcast through DPP inside the f64 FMA (no LDS traffic); 5 VALU instructions per entry = %.1f us "
                                             "of issue time on 1024 SIMDs (tools/micro/valu_rates.hip: 1.9 ns each), the rest of the launch is "
                                             "the first load's latency and the per-workgroup tail" % (bytes_per_launch * 5 * 1.9e-3 / 64 / 1024))
             else:
-                line["roofline"]["note"] = ("dense block streamed as %s, one wave per column with 16-byte non-temporal loads, -pi / rho / w in LDS"
-                                            % {"f32": "float (exact for this data; all arithmetic f64)", "f64": "double"}[args.dense_storage])
+                line["roofline"]["note"] = {
+                    "f32": "dense block streamed as float (exact for this data; all arithmetic f64): one column per lane, 16-byte "
+                           "non-temporal loads, -pi / rho / w broadcast through DPP inside the f64 FMA (no LDS traffic); bound by HBM",
+                    "f64": "dense block streamed as double: one column per lane, 16-byte non-temporal loads, -pi / rho / w broadcast "
+                           "through DPP inside the f64 FMA (no LDS traffic); bound by HBM"}[args.dense_storage]
         if not dense and not graph:
             line["roofline"]["note"] = ("latency bound by construction: the dominant kernel BY MEASURED TIME is '%s' (%d KB of algorithmic "
                                         "bytes per launch, all of it resident in L2 / Infinity Cache; SURVEY.md section 8(d)); every kernel of "

@@ -512,22 +512,57 @@ template <int... T>
 __device__ __forceinline__ void dense_lane_block(const i32x4& v, double a_pi, double a_rho, double a_w, double (&acc)[6], std::integer_sequence<int, T...>) {
     (dense_lane_entry<T>(v, a_pi, a_rho, a_w, acc), ...);
 }
-struct DenseLaneBatch {  // K1C_U tiles of one lane: the column pieces and the lane's -pi / rho / w of each
-    i32x4 v[K1C_U];
-    double vp[K1C_U], vr[K1C_U], vw[K1C_U];
+// The same with the block as float (data that float holds exactly, all arithmetic f64): a tile of 16 columns x 64 rows is
+// 4 KiB, FOUR 16-byte pieces per lane -- piece u of lane l holds rows 64B + 16(l >> 4) + 4u .. + 3 of column 16G + (l & 15) --
+// and entry e of piece u meets lane 4u + e of the lane's DPP row.  4 VALU instructions per entry; the pass is bound by HBM.
+template <int T>
+__device__ __forceinline__ void dense_lane_entry_f32(float f, double a_pi, double a_rho, double a_w, double (&acc)[6]) {
+    const double x = (double)f;
+    fmac_row_broadcast<T>(acc[T & 1], a_pi, x);
+    fmac_row_broadcast<T>(acc[2 + (T & 1)], a_rho, x);
+    fmac_row_broadcast<T>(acc[4 + (T & 1)], a_w, x);
+}
+template <int U4>
+__device__ __forceinline__ void dense_lane_piece_f32(const f32x4& v, double a_pi, double a_rho, double a_w, double (&acc)[6]) {
+    dense_lane_entry_f32<U4>(v[0], a_pi, a_rho, a_w, acc);
+    dense_lane_entry_f32<U4 + 1>(v[1], a_pi, a_rho, a_w, acc);
+    dense_lane_entry_f32<U4 + 2>(v[2], a_pi, a_rho, a_w, acc);
+    dense_lane_entry_f32<U4 + 3>(v[3], a_pi, a_rho, a_w, acc);
+}
+// ... and as double: EIGHT pieces of two rows per lane and tile (8 KiB), entry e of piece u meets lane 2u + e; 3 VALU per entry.
+template <int U2>
+__device__ __forceinline__ void dense_lane_piece_f64(const f64x2& v, double a_pi, double a_rho, double a_w, double (&acc)[6]) {
+    fmac_row_broadcast<U2>(acc[0], a_pi, v[0]);
+    fmac_row_broadcast<U2>(acc[2], a_rho, v[0]);
+    fmac_row_broadcast<U2>(acc[4], a_w, v[0]);
+    fmac_row_broadcast<U2 + 1>(acc[1], a_pi, v[1]);
+    fmac_row_broadcast<U2 + 1>(acc[3], a_rho, v[1]);
+    fmac_row_broadcast<U2 + 1>(acc[5], a_w, v[1]);
+}
+template <int BYTES>  // bytes per entry: 1 (signed bytes), 4 (float), 8 (double)
+struct DenseLaneBatch {  // the tiles of one lane and batch: the column pieces and the lane's -pi / rho / w of each
+    static constexpr int TILES = BYTES == 1 ? K1C_U : BYTES == 4 ? 2 : 1, PIECES = BYTES;  // (a tile is BYTES KiB: BYTES pieces per lane)
+    i32x4 v[TILES][PIECES];
+    double vp[TILES], vr[TILES], vw[TILES];
 };
-__device__ __forceinline__ void dense_lane_load(DenseLaneBatch& t, const i32x4* piece, const double* a_pi, const double* a_rho, const double* a_w, int b0) {
-    // (33 MB at 4096 x 8192: non-temporal loads make no difference here, 18.05k against 18.13k pivots/s)
+template <int BYTES>
+__device__ __forceinline__ void dense_lane_load(DenseLaneBatch<BYTES>& t, const i32x4* piece, const double* a_pi, const double* a_rho, const double* a_w, int b0) {
+    // (33 MB of bytes at 4096 x 8192: non-temporal loads make no difference there, 18.05k against 18.13k pivots/s)
+    constexpr int TILES = DenseLaneBatch<BYTES>::TILES, PIECES = DenseLaneBatch<BYTES>::PIECES;
 #pragma unroll
-    for (int u = 0; u < K1C_U; ++u) t.v[u] = piece[(size_t)(b0 + u) * WAVE];
+    for (int u = 0; u < TILES; ++u)
 #pragma unroll
-    for (int u = 0; u < K1C_U; ++u) {
+        for (int q = 0; q < PIECES; ++q)
+            t.v[u][q] = BYTES > 1 ? __builtin_nontemporal_load(piece + ((size_t)(b0 + u) * PIECES + q) * WAVE) : piece[((size_t)(b0 + u) * PIECES + q) * WAVE];
+#pragma unroll
+    for (int u = 0; u < TILES; ++u) {
         t.vp[u] = a_pi[(b0 + u) * K1C_TILE_ROWS];
         t.vr[u] = a_rho[(b0 + u) * K1C_TILE_ROWS];
         t.vw[u] = a_w[(b0 + u) * K1C_TILE_ROWS];
     }
 }
 // dense_ld is a multiple of K1C_TILE_ROWS * (blockDim.x / 64) * K1C_U; the next batch's loads are in flight while one is worked on
+template <int BYTES>
 __global__ void __launch_bounds__(K1C_MAX_THREADS) price_dense_lane_kernel(DeviceLP lp, int skip_weights, double tol_dual, int cand_offset) {
     __shared__ double s_part[K1C_MAX_THREADS / WAVE][3][WAVE];
     const int mp = lp.dense_ld;
@@ -535,13 +570,15 @@ __global__ void __launch_bounds__(K1C_MAX_THREADS) price_dense_lane_kernel(Devic
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
     const int ntiles = mp / (K1C_TILE_ROWS * nw);  // tiles of 64 rows per wave
     const int first_tile = wave * ntiles;
-    const i32x4* piece = reinterpret_cast<const i32x4*>(lp.dense_val8) + ((size_t)group * (mp / K1C_TILE_ROWS) + first_tile) * WAVE + lane;
+    constexpr int TILES = DenseLaneBatch<BYTES>::TILES, PIECES = DenseLaneBatch<BYTES>::PIECES;
+    const i32x4* piece = (BYTES == 8 ? reinterpret_cast<const i32x4*>(lp.dense_val) : BYTES == 4 ? reinterpret_cast<const i32x4*>(lp.dense_val32) : reinterpret_cast<const i32x4*>(lp.dense_val8)) +
+                         ((size_t)group * (mp / K1C_TILE_ROWS) + first_tile) * PIECES * WAVE + lane;
     const size_t my_row = (size_t)first_tile * K1C_TILE_ROWS + lane;
     const double* a_pi = lp.minus_pi + my_row;
     const double* a_rho = lp.rho + my_row;
     const double* a_w = lp.w + my_row;
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    DenseLaneBatch A, B;  // two batches alternate: the loads of one are in flight while the other is worked on
+    DenseLaneBatch<BYTES> A, B;  // two batches alternate: the loads of one are in flight while the other is worked on
     dense_lane_load(A, piece, a_pi, a_rho, a_w, 0);  // requested before the control block is looked at
     // the thread that finishes column 16 * group + threadIdx.x asks for what it needs there now
     const int jd = group * K1C_COLS + threadIdx.x;
@@ -556,21 +593,37 @@ __global__ void __launch_bounds__(K1C_MAX_THREADS) price_dense_lane_kernel(Devic
     const double alpha_pq = ctl->alpha_pq, gamma_q = ctl->gamma_q;
     // (all three sums whether or not a weight update is pending -- two code paths make the compiler hoist the conversions they
     // share above the branch, and spill)
-    auto work = [&](DenseLaneBatch& t) {
+    auto work = [&](DenseLaneBatch<BYTES>& t) {
 #pragma unroll
-        for (int u = 0; u < K1C_U; ++u) {
+        for (int u = 0; u < TILES; ++u) {
             // A VGPR written by a VALU instruction must not be read through DPP for two wait states, and the compiler does not
             // see the DPP reads inside the asm statements: whatever it does to the three vector registers (copies) happens
             // before this statement, which owns them and waits.
             asm volatile("s_nop 1" : "+v"(t.vp[u]), "+v"(t.vr[u]), "+v"(t.vw[u]));
-            dense_lane_block(t.v[u], t.vp[u], t.vr[u], t.vw[u], acc, std::make_integer_sequence<int, 16>{});
+            if constexpr (BYTES == 8) {
+                dense_lane_piece_f64<0>(__builtin_bit_cast(f64x2, t.v[u][0]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f64<2>(__builtin_bit_cast(f64x2, t.v[u][1]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f64<4>(__builtin_bit_cast(f64x2, t.v[u][2]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f64<6>(__builtin_bit_cast(f64x2, t.v[u][3]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f64<8>(__builtin_bit_cast(f64x2, t.v[u][4]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f64<10>(__builtin_bit_cast(f64x2, t.v[u][5]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f64<12>(__builtin_bit_cast(f64x2, t.v[u][6]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f64<14>(__builtin_bit_cast(f64x2, t.v[u][7]), t.vp[u], t.vr[u], t.vw[u], acc);
+            } else if constexpr (BYTES == 4) {
+                dense_lane_piece_f32<0>(__builtin_bit_cast(f32x4, t.v[u][0]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f32<4>(__builtin_bit_cast(f32x4, t.v[u][1]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f32<8>(__builtin_bit_cast(f32x4, t.v[u][2]), t.vp[u], t.vr[u], t.vw[u], acc);
+                dense_lane_piece_f32<12>(__builtin_bit_cast(f32x4, t.v[u][3]), t.vp[u], t.vr[u], t.vw[u], acc);
+            } else {
+                dense_lane_block(t.v[u][0], t.vp[u], t.vr[u], t.vw[u], acc, std::make_integer_sequence<int, 16>{});
+            }
         }
     };
-    for (int b0 = 0; b0 < ntiles; b0 += 2 * K1C_U) {
-        const bool second = b0 + K1C_U < ntiles;
-        if (second) dense_lane_load(B, piece, a_pi, a_rho, a_w, b0 + K1C_U);
+    for (int b0 = 0; b0 < ntiles; b0 += 2 * TILES) {
+        const bool second = b0 + TILES < ntiles;
+        if (second) dense_lane_load(B, piece, a_pi, a_rho, a_w, b0 + TILES);
         work(A);
-        if (b0 + 2 * K1C_U < ntiles) dense_lane_load(A, piece, a_pi, a_rho, a_w, b0 + 2 * K1C_U);
+        if (b0 + 2 * TILES < ntiles) dense_lane_load(A, piece, a_pi, a_rho, a_w, b0 + 2 * TILES);
         if (second) work(B);
     }
     s_part[wave][0][lane] = acc[0] + acc[1];
@@ -3513,7 +3566,9 @@ void launch_price(const DeviceLP& d, int rule, int blocks, size_t lds, bool use_
 void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double tol, int cand_offset, hipStream_t s) {
     const size_t lds = (size_t)3 * d.dense_ld * sizeof(double);
     if (d.dense_lane) {
-        RELP_LAUNCH(0, price_dense_lane_kernel, dim3(blocks), dim3(dense_lane_threads(d.m)), 0, s, d, skip_weights, tol, cand_offset);
+        if (d.dense_val) RELP_LAUNCH(0, price_dense_lane_kernel<8>, dim3(blocks), dim3(dense_lane_threads(d.m)), 0, s, d, skip_weights, tol, cand_offset);
+        else if (d.dense_val32) RELP_LAUNCH(0, price_dense_lane_kernel<4>, dim3(blocks), dim3(dense_lane_threads(d.m)), 0, s, d, skip_weights, tol, cand_offset);
+        else RELP_LAUNCH(0, price_dense_lane_kernel<1>, dim3(blocks), dim3(dense_lane_threads(d.m)), 0, s, d, skip_weights, tol, cand_offset);
     } else if (d.dense_val8) RELP_LAUNCH(0, (price_dense_kernel<false, true>), dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
     else if (d.dense_val32) RELP_LAUNCH(0, price_dense_kernel<true>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
     else RELP_LAUNCH(0, price_dense_kernel<false>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);

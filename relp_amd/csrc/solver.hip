@@ -266,8 +266,11 @@ void Solver::upload() {
         d_.dense_full = full ? 1 : 0;
         d_.dense_csc_start = n_dense > 0 ? col_start[n_art] : 0;
     }
+    bool dense_floats = n_dense > 0 && !dense_bytes && !getenv("RELP_DENSE_F64");  // float holds every entry exactly
+    for (int jd = 0; dense_floats && jd < n_dense; ++jd)
+        for (int e = col_start[n_art + jd]; dense_floats && e < col_start[n_art + jd + 1]; ++e) dense_floats = (double)(float)value[e] == value[e];
     int vector_len = m;  // -pi, rho, w: zero-padded to the dense block's row count when the column-per-lane pricing reads them
-    if (dense_bytes && dense_lane_slots(n_dense) <= 1024 && !getenv("RELP_NO_DENSE_LANE")) {
+    if (n_dense > 0 && dense_lane_slots(n_dense) <= 1024 && !getenv("RELP_NO_DENSE_LANE")) {
         // column-per-lane pricing: one workgroup and one candidate slot per group of 16 columns
         d_.dense_lane = 1;
         d_.dense_ld = dense_lane_ld(m);
@@ -398,7 +401,33 @@ void Solver::upload() {
     } else if (dense_bytes && (size_t)3 * ((m + 1023) & ~1023) * sizeof(double) > 160 * 1024 - 4096) {
         dense_bytes = false;  // (the row-permuted form keeps the padded vectors in LDS)
     }
-    if (dense_bytes && d_.dense_lane) {
+    if (dense_floats && d_.dense_lane) {
+        const int groups = dense_blocks_, tiles_per_group = d_.dense_ld / 64;
+        std::vector<float> floats((size_t)groups * 16 * d_.dense_ld, 0.f);
+        for (int jd = 0; jd < n_dense; ++jd)
+            for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) {
+                // tile (group, row / 64): four pieces of 64 lanes x 4 floats; see price_dense_lane_kernel<true>
+                const int row = row_index[e], within = row % 64, t = within % 16;
+                floats[((((size_t)(jd / 16) * tiles_per_group + row / 64) * 4 + t / 4) * 64 + 16 * (within / 16) + jd % 16) * 4 + t % 4] = (float)value[e];
+            }
+        d_.dense_val32 = dmalloc<float>(floats.size());
+        upload_vec(d_.dense_val32, floats, stream_);
+        dense_entry_bytes_ = 4;
+        RELP_HIP(hipStreamSynchronize(stream_));
+    } else if (dense_bytes && d_.dense_lane) {
+    } else if (d_.dense_lane) {
+        const int groups = dense_blocks_, tiles_per_group = d_.dense_ld / 64;
+        std::vector<double> doubles((size_t)groups * 16 * d_.dense_ld, 0.0);
+        for (int jd = 0; jd < n_dense; ++jd)
+            for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) {
+                // tile (group, row / 64): eight pieces of 64 lanes x 2 doubles; see price_dense_lane_kernel<8>
+                const int row = row_index[e], within = row % 64, t = within % 16;
+                doubles[((((size_t)(jd / 16) * tiles_per_group + row / 64) * 8 + t / 2) * 64 + 16 * (within / 16) + jd % 16) * 2 + t % 2] = value[e];
+            }
+        d_.dense_val = dmalloc<double>(doubles.size());
+        upload_vec(d_.dense_val, doubles, stream_);
+        dense_entry_bytes_ = 8;
+        RELP_HIP(hipStreamSynchronize(stream_));
     } else if (dense_bytes) {
         d_.dense_ld = (m + 1023) & ~1023;
         std::vector<signed char> bytes((size_t)n_dense * d_.dense_ld, 0);
