@@ -910,7 +910,11 @@ void Solver::enqueue_price(int skip_weights, bool first_of_batch) {
     // beside a dense block the CSC kernel only sees the short slack columns: staging -pi, rho_p, w in LDS (3 m doubles per
     // workgroup) would cost more than the gathers it saves.  (Running it on a second stream beside the dense pass was
     // measured too: the fork/join edges of the captured graph cost 15 us per pivot against the 8 us they hide.)
-    const bool use_lds = price_lds_ <= 160 * 1024 - 1024 && dense_blocks_ == 0;
+    // ... and beyond 4096 rows as well: a workgroup prices 32 columns and would stage 3 m doubles for them, one workgroup per CU
+    // (80BAU3B, m = 5746: 486 workgroups x 138 KB = 67 MB of staging against 1.5 MB of gathers; 53.8 -> 45.7 us per pivot without).
+    // Between 2000 and 2800 rows the two forms are within the run-to-run noise (BNL2, CYCLE, GREENBEA).  RELP_PRICE_LDS_MAX: A/B hook.
+    static const size_t lds_max = getenv("RELP_PRICE_LDS_MAX") ? (size_t)atol(getenv("RELP_PRICE_LDS_MAX")) : (size_t)96 * 1024;
+    const bool use_lds = price_lds_ <= lds_max && dense_blocks_ == 0;
     // slack_in_btran_: the BTRAN pass of the previous pivot has priced the slack columns (weights included); only the first
     // pivot of a batch has no predecessor in the batch, and its pass must not apply the weight update a second time
     if (price_blocks_ > 0 && (!slack_in_btran_ || first_of_batch))
