@@ -18,7 +18,8 @@ for name in sorted(expected):
     r = s.solve_relaxation()
     e = expected[name]
     tol = max(e["tolerance"], 2e-5 if name == "25FV47" else 0.0)
-    ok = r.kind == relp_amd.FINITE_OPTIMUM and abs(r.objective - e["expected"]) <= tol
+    comparable = not (e["ignored"] and "intensive" not in e["ignored"])  # (GROW7: the reference's harness does not support it; certified only)
+    ok = r.kind == relp_amd.FINITE_OPTIMUM and (abs(r.objective - e["expected"]) <= tol if comparable else r.certified == 1)
     done += 1
     print("%-9s m %5d kind %d certified %d obj %.10g (expected %.10g) pivots %6d %7.1f ms refactors %d %s" % (
         name, s.m, r.kind, r.certified, r.objective, e["expected"], r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds * 1e3, r.refactors, "" if ok else "<-- MISMATCH"), flush=True)
