@@ -1,4 +1,4 @@
-"""bench.py -- simplex pivots/sec on Netlib 25FV47 (BASELINE.json configs[1]) on MI355X.
+"""bench.py -- simplex pivots/sec on Netlib 25FV47 (BASELINE.json configs[1]) on MI355X, and every other BASELINE config beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 25fv47]
 
@@ -7,12 +7,20 @@ One "step" = one complete ``solve_relaxation`` of the workload, LP resident in H
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank solves its own copy -- independent LPs shard
 one per GPU with no data-path collective (weak scaling); the barrier + max-over-ranks timing is the only exchange.
 
-The JSON line also carries ``roofline`` (pricing kernel: algorithmic bytes / HIP-event time per launch vs 8 TB/s HBM)
-and ``cpu_baseline`` (the exact-rational restatement of relp's own algorithm on one host core, bounded sample).
+The JSON line carries ``roofline`` (the dominant kernel by measured time: SURVEY.md section 8(d)'s algorithmic bytes of that
+kernel / its HIP-event time per launch vs 8 TB/s HBM; the kernel's own byte count beside it) and ``cpu_baseline`` (the
+exact-rational restatement of relp's own algorithm on one host core, bounded sample).  The default run (N = 1) also measures
+the other BASELINE configs in the same process and reports them under ``configs``: the LU carry on 25FV47, the dense LP of
+config 3 with the block stored as double and in the narrowest exact type, the Netlib batch of config 4 without and with the
+reference's presolve, and the max-flow LP of config 5 from the reference's artificial start and from the crash basis --
+each with its own ``value``, ``ms_per_step``, ``roofline`` and ``cpu_baseline``.  CPU legs run as child processes beside
+the GPU measurements (one core each; the all-cores Netlib leg runs alone at the end).
 """
 import argparse
+import copy
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -42,39 +50,53 @@ def emit(text):
     print(text, flush=True)
 
 
-def cpu_baseline(path, budget_seconds):
-    """relp-equivalent exact CPU path (the oracle: kind "port"), first pivots of the same workload, one core."""
+def host_description():
+    """CPU model and core count of the bench host (stated in every report)."""
+    model = "unknown"
+    try:
+        for row in open("/proc/cpuinfo"):
+            if row.startswith("model name"):
+                model = row.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1}
+
+
+# =====================================================================================================================
+# CPU legs (child processes: `python bench.py --cpu-leg NAME --cpu-seconds S`; each prints one JSON object)
+# =====================================================================================================================
+def cpu_leg_exact(path, budget_seconds, tuned):
+    """relp-equivalent exact CPU path (the oracle: kind "port"), first pivots of the same workload, one core.  Faithful mode
+    keeps the reference's data structures and asymptotics; `tuned` only adds a row index to the BTRAN scans."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from relp_oracle import cpu
     from relp_oracle.mps import load_problem
 
     _, data = load_problem(path)
-    record = cpu.solve_provider(data, max_seconds=budget_seconds, trace=0)  # oracle/cpp/relp_cpu.cpp, g++ -O2, one thread
+    record = cpu.solve_provider(data, max_seconds=budget_seconds, trace=0, tuned=tuned)  # oracle/cpp/relp_cpu.cpp, g++ -O2, one thread
     pivots = record["pivots_phase1"] + record["pivots_phase2"]
     elapsed = record["seconds"]
     full = ""
     measured = os.path.join(ROOT, "profiles", "r1_cpu_oracle_full_solve.json")
-    if os.path.exists(measured) and path.endswith("25FV47.SIF"):
+    if os.path.exists(measured) and path.endswith("25FV47.SIF") and not tuned:
         g = json.load(open(measured))
         full = "; the full exact solve took %d pivots in %.0f s = %.2f pivots/s on %s" % (
             g["pivots"], g["seconds"], g["pivots"] / g["seconds"], g["host"])
-    return {"value": pivots / elapsed if elapsed > 0 else 0.0, "unit": "pivots/s", "cores": 1, "kind": "port",
+    return {"value": pivots / elapsed if elapsed > 0 else 0.0, "unit": "pivots/s", "cores": 1, "kind": "port", "mode": "tuned" if tuned else "faithful",
             "sample": "first %d pivots (%.1f s) of the same LP with exact rationals: C++ restatement of relp's "
-                      "Carry<RationalBig, LUDecomposition> steepest-edge path (oracle/cpp, same pivot sequence as the "
-                      "reference's algorithm; early pivots are the cheap ones, numbers grow to ~1800 bits%s)" % (pivots, elapsed, full)}
+                      "Carry<RationalBig, LUDecomposition> steepest-edge path (oracle/cpp%s, same pivot sequence as the "
+                      "reference's algorithm; early pivots are the cheap ones, numbers grow to ~1800 bits%s)" % (
+                          pivots, elapsed, " --tuned: row index for the BTRAN scans" if tuned else ", faithful data structures", full)}
 
 
-def cpu_baseline_f64(path, budget_seconds):
+def cpu_leg_f64(path, budget_seconds):
     """The SAME f64 algorithm on the CPU (oracle/f64_model.py: numpy twin of the device loop -- explicit inverse, steepest edge,
     Harris ratio test, Newton-Schulz polish), bounded sample; and, as context, a tuned CPU f64 simplex (HiGHS through scipy)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from f64_model import Model, Options
     from relp_oracle.mps import load_problem
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([pool.get("num_threads", 1) for pool in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    threads = blas_threads()
     _, data = load_problem(path)
     options = Options()
     options.max_seconds = budget_seconds
@@ -113,17 +135,22 @@ def cpu_baseline_f64(path, budget_seconds):
     return record
 
 
-def cpu_baseline_dense(dims, budget_seconds):
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([pool.get("num_threads", 1) for pool in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        return os.cpu_count() or 1
+
+
+def cpu_leg_dense(dims, budget_seconds):
     """f64 CPU restatement of the same loop for the dense workloads (oracle/f64_dense.py, numpy + its threaded BLAS);
     the exact-rational path is infeasible at this size."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from f64_dense import DenseModel
     from relp_amd.workloads import dense_lp
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([pool.get("num_threads", 1) for pool in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    import numpy  # noqa: F401  (so that the BLAS pool exists when its size is read)
+    threads = blas_threads()
     model = DenseModel(*dense_lp(*dims))
     start = time.perf_counter()
     model.solve(max_seconds=budget_seconds)
@@ -133,230 +160,205 @@ def cpu_baseline_dense(dims, budget_seconds):
                       "explicit-inverse loop, BLAS on %d threads" % (model.pivots, elapsed, threads)}
 
 
-def dense_roofline(device):
-    """The pricing pass of BASELINE configs[2] (dense 4096 x 8192), timed with HIP events inside the pivot loop: the
-    HBM-bound kernel of the path, reported beside the default workload's (latency-bound) figure."""
+def netlib_names(expected):
+    return sorted(n for n, e in expected.items() if os.path.exists(os.path.join(ROOT, "data", "netlib", n + ".SIF"))
+                  and (not e["ignored"] or "intensive" in e["ignored"]))
+
+
+def _netlib_one(job):
+    name, budget = job
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from relp_oracle import cpu
+    from relp_oracle.mps import load_problem
+    _, data = load_problem(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    t0 = time.perf_counter()
+    record = cpu.solve_provider(data, max_seconds=budget, trace=0)
+    return name, record["pivots_phase1"] + record["pivots_phase2"], record["seconds"], time.perf_counter() - t0, record.get("status", "")
+
+
+def cpu_leg_netlib(budget_seconds):
+    """Config 4 on the host: the exact C++ restatement, ONE LP PER CORE over all host cores (the reference itself is single-threaded;
+    this is what its harness could do with a process per LP), every LP bounded to `budget_seconds` of solve time -- the long
+    ones (25FV47: ~1000 s to the optimum) are sampled over their first pivots.  value = pivots of all LPs / wall time of the pool."""
+    from concurrent.futures import ProcessPoolExecutor
+    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))
+    names = netlib_names(expected)
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, len(names)))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from relp_oracle import cpu
+    cpu.ensure_built()
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(max_workers=workers) as pool:
+        done = list(pool.map(_netlib_one, [(n, budget_seconds) for n in names]))
+    wall = time.perf_counter() - t0
+    pivots = sum(d[1] for d in done)
+    solve_seconds = sum(d[2] for d in done)
+    finished = sum(1 for d in done if d[4] in ("optimal", "infeasible", "unbounded"))
+    return {"value": pivots / wall if wall > 0 else 0.0, "unit": "pivots/s", "cores": workers, "kind": "port",
+            "sample": "the %d LPs of the batch with exact rationals (oracle/cpp, faithful), one LP per core on %d cores, each bounded to %.0f s: "
+                      "%d pivots in %.1f s of wall time (%.1f core-seconds of solving; %d LPs reached their optimum inside the bound, the rest "
+                      "are sampled over their first pivots, the cheap ones)" % (len(names), workers, budget_seconds, pivots, wall, solve_seconds, finished)}
+
+
+def cpu_leg_maxflow(budget_seconds):
+    """Config 5 on the host: scipy's max-flow (a combinatorial algorithm on the same graph: the value the LP must reach) at the
+    full size, and the exact C++ restatement of relp's path on a 16 k-arc twin of the LP (the provider of examples/max_flow.rs)."""
+    import numpy as np
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    from relp_amd.workloads import max_flow_graph
+    out = {}
+    tail, head, capacity = max_flow_graph(65536, 1048576)
+    keep = (head != 0) & (tail != 65535)
+    t0 = time.perf_counter()
+    flow = maximum_flow(csr_matrix((capacity[keep].astype(np.int32), (tail[keep], head[keep])), shape=(65536, 65536)), 0, 65535).flow_value
+    out["scipy_max_flow"] = {"seconds": time.perf_counter() - t0, "flow_value": int(flow), "cores": 1,
+                             "name": "scipy.sparse.csgraph.maximum_flow on the same 1 M-arc graph (combinatorial, not an LP solve)"}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from fractions import Fraction
+    from relp_oracle import cpu
+    from relp_oracle.network import MaxFlowPrimal
+    twin_v, twin_e = 2048, 16384
+    tail, head, capacity = max_flow_graph(twin_v, twin_e)
+    keep = (head != 0) & (tail != twin_v - 1)
+    arcs = [[] for _ in range(twin_v)]
+    for u, v, c in zip(tail[keep].tolist(), head[keep].tolist(), capacity[keep].tolist()):
+        arcs[u].append((v, Fraction(c)))
+    provider = MaxFlowPrimal(arcs, 0, twin_v - 1)
+    record = cpu.solve_provider(provider, max_seconds=budget_seconds, trace=0)
+    pivots = record["pivots_phase1"] + record["pivots_phase2"]
+    out.update({"value": pivots / record["seconds"] if record["seconds"] > 0 else 0.0, "unit": "pivots/s", "cores": 1, "kind": "port",
+                "sample": "first %d pivots (%.1f s) of a 16 k-arc twin of the LP (V = %d, E = %d: %d rows in the reference's formulation; same generator) "
+                          "with exact rationals, oracle/cpp faithful -- at 1 M arcs the reference's ordered-map LU does not finish a pivot in the budget" % (
+                              pivots, record["seconds"], twin_v, int(keep.sum()), provider.nr_rows())})
+    return out
+
+
+def run_cpu_leg(name, seconds):
+    if name == "exact_faithful":
+        return cpu_leg_exact(WORKLOADS["25fv47"], seconds, False)
+    if name == "exact_tuned":
+        return cpu_leg_exact(WORKLOADS["25fv47"], seconds, True)
+    if name == "f64":
+        return cpu_leg_f64(WORKLOADS["25fv47"], seconds)
+    if name.startswith("dense:"):
+        m, n = (int(v) for v in name.split(":")[1].split("x"))
+        return cpu_leg_dense((m, n), seconds)
+    if name == "netlib":
+        return cpu_leg_netlib(seconds)
+    if name == "maxflow":
+        return cpu_leg_maxflow(seconds)
+    raise SystemExit("unknown cpu leg " + name)
+
+
+class CpuLegs:
+    """CPU baselines as child processes beside the GPU measurements (bounded BLAS pools, so that they do not crowd the host threads
+    that feed the GPU); `collect` waits for them."""
+
+    def __init__(self):
+        self.children = {}
+
+    def start(self, key, name, seconds, blas=8):
+        env = dict(os.environ)
+        for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[var] = str(blas)
+        env["HIP_VISIBLE_DEVICES"] = ""  # a CPU leg never touches the GPU
+        env["ROCR_VISIBLE_DEVICES"] = ""
+        self.children[key] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-leg", name, "--cpu-seconds", str(seconds)],
+                                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+
+    def collect(self, key, timeout=600):
+        child = self.children.pop(key, None)
+        if child is None:
+            return None
+        try:
+            out, err = child.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            return {"error": "timed out"}
+        if child.returncode != 0:
+            return {"error": err.strip()[-400:]}
+        record = json.loads(out.strip().splitlines()[-1])
+        record.update(host_description())
+        return record
+
+
+# =====================================================================================================================
+# section 8(d) of SURVEY.md: algorithmic bytes per pivot, the figure the roofline fraction is quoted on
+# =====================================================================================================================
+def factor_nonzeros(model, basis, art_rows):
+    """nnzF = nnz(L) + nnz(U) + m of the basis the solve ended on (host factorisation, relp_lu_factor_host)."""
+    import ctypes as C
+    import numpy as np
     import relp_amd
-    from relp_amd.workloads import dense_lp
-    a, b, c = dense_lp(4096, 8192)
-    solver = relp_amd.Solver(device=device, polish_period=512).load_dense_le(a, b, c)
-    solver.begin_phase_one()
-    solver.iterate(300)
-    seconds = solver.profile_kernel(0, 100)
-    bytes_per_launch = solver.stats().price_bytes
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r2_dense4096_pmc_traffic.json")
-    if os.path.exists(pmc):
-        for name, entry in json.load(open(pmc)).items():
-            if "price_dense_lane_kernel" in name:
-                traffic = entry["hbm_bytes_corrected"]
-    solver.close()
-    achieved = bytes_per_launch / seconds / 1e9
-    # The coefficients of this workload are integers in [1, 100]: the block is held as signed bytes (1 B per entry; 4 B as
-    # float measured 131.4 MB in 25.1 us = 5.2 TB/s = 65 % of the HBM peak, 8 B as f64 262.7 MB in 45.9 us = 5.7 TB/s = 72 %).  With a quarter
-    # of the bytes the pass is no longer bound by HBM but by f64 issue: 5 VALU instructions per entry (extract, convert, three
-    # FMAs whose second operand comes through the DPP row broadcast), 1.9 ns per wave instruction per SIMD.
-    valu_seconds = bytes_per_launch * 5 * 1.9e-9 / 64 / 1024
-    return {"workload": "synthetic dense random LP m=4096 n=8192 (python bench.py --workload dense4096 for its pivots/s)",
-            "bound": "hbm", "kernel": "price (dense block, 1 B per entry)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "seconds_per_launch": seconds,
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "valu": {"instructions_per_entry": 5, "issue_seconds_per_launch": valu_seconds, "frac_of_launch": valu_seconds / seconds},
-            "note": "the same pass with the block held as float streams 131.4 MB in 25.1 us (5.2 TB/s, frac 0.65 of HBM); as bytes "
-                    "it streams 33 MB in less time, one column per lane with -pi / rho / w broadcast through DPP inside the f64 FMA "
-                    "(no LDS traffic), and is bound by f64 issue and the launch's fixed latencies"}
+    from relp_amd.basis_inverse import lu_factor_host
+    buf_rows, buf_vals = np.zeros(model.nr_rows, np.int32), np.zeros(model.nr_rows, np.float64)
+    count = C.c_int32()
+    columns = []
+    for c in basis:
+        if c >= 0:
+            relp_amd.lib().relp_model_column(model._h, int(c), model.nr_rows, C.byref(count), buf_rows.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             buf_vals.ctypes.data_as(C.POINTER(C.c_double)))
+            columns.append([(int(buf_rows[e]), float(buf_vals[e])) for e in range(count.value) if buf_rows[e] < len(basis)])
+        else:
+            columns.append([(art_rows[-1 - int(c)], 1.0)])
+    factors = lu_factor_host(columns)
+    return factors["nnz_lower"] + factors["nnz_upper"] + len(basis)
 
 
-def netlib_batch(args, rank, local_rank, world, distributed):
-    """Config 4: independent LPs shard across ranks -- by default through a dynamic ticket queue over the cost-sorted list
-    (relp_amd.batch.TicketQueue), or the static longest-first partition (relp_amd.batch.assign); every LP is resident
-    in HBM before the timed region; value = pivots of all ranks / makespan (max over ranks)."""
-    import glob
+def contract_bytes(price_bytes, nnz_f, m):
+    """one fused pricing + steepest-edge pass, one FTRAN + one shared-pass two-RHS BTRAN over the factor
+    (12 B per entry: f64 value + 32-bit index), twelve m-vectors."""
+    solve = 2 * nnz_f * 12 + 12 * m * 8
+    return {"pricing": int(price_bytes), "ftran_btran_vectors": int(solve), "per_pivot": int(price_bytes + solve)}
+
+
+# =====================================================================================================================
+# one LP resident on the GPU: 25FV47, the dense LPs, the max-flow LPs
+# =====================================================================================================================
+def single_lp(args, ctx):
+    """Times `steps` solves of one workload (barrier + synchronize on both sides, max over ranks) and measures the kernels of a
+    pivot with HIP events inside the real pivot sequence.  Returns the line (rank 0) or None."""
     import torch
     import relp_amd
     from relp_amd import batch
-    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))
-    names = sorted(n for n, e in expected.items() if os.path.exists(os.path.join(ROOT, "data", "netlib", n + ".SIF"))
-                   and (not e["ignored"] or "intensive" in e["ignored"]))
-    models = {}
-    costs = []
-    for name in names:
-        model = relp_amd.Model(os.path.join(ROOT, "data", "netlib", name + ".SIF"), presolve=args.presolve)  # --presolve: the reference's harness order
-        models[name] = model
-        costs.append((name, float(model.nr_rows) * float(model.nnz + model.nr_columns)))
-    dynamic = args.schedule == "dynamic"
-    ordered = [name for name, _ in sorted(costs, key=lambda item: (-item[1], item[0]))]  # longest estimated first
-    # dynamic: any rank may draw any LP, so every rank keeps the whole suite resident (< 2 GB of 288 GB HBM)
-    mine = ordered if dynamic else batch.assign(costs, world)[rank]
-    workers = max(1, args.concurrency)
-    solvers = {name: relp_amd.Solver(device=local_rank).load_model(models[name]) for name in mine}
-    import threading
-    handle_locks = {name: threading.Lock() for name in solvers}  # a handle is single-threaded
-    records = []
-    lp_records = []   # one JSON object per solved LP (--records FILE; SURVEY.md section 5)
-    record_file = args.records
-    passes = [0]
-    # Order of the K x 45 tickets.  1-2 GPUs: pass after pass, each longest-first.  4+ GPUs: the cost-sorted list in chunks of
-    # eight LPs, all K passes of a chunk before the next chunk -- close to longest-first over everything (the long solves of
-    # the last pass do not start late) while consecutive tickets are still different LPs, so the host threads of one rank
-    # do not queue on one handle.  (Tried at 1 GPU and dropped: longest-first over all passes, 1.07 s per pass against 0.95 s --
-    # copies of the same long LP side by side on one GPU; one set of handles per host thread, 1.23 s.)
-    chunk = 8 if world >= 4 else len(ordered)
-    chunk = int(os.environ.get("RELP_BATCH_CHUNK", chunk))  # diagnostic override
-
-    def ticket_to_index(ticket, repeat, count):
-        chunk_index, within = divmod(ticket, chunk * repeat)
-        size = min(chunk, count - chunk_index * chunk)  # the last chunk may be short
-        if size <= 0:
-            return None
-        return chunk_index * chunk + within % size if within < size * repeat else None
-
-    def run_all(repeat=1):
-        """`repeat` passes over the suite as ONE queue of tickets (order: see `chunk` above): no rank or thread waits at a
-        pass boundary.  `--concurrency K` keeps K LPs in flight on this GPU (K host threads, one stream each): the small LPs
-        are latency bound and use a fraction of the chip, so their kernels overlap."""
-        import threading
-        passes[0] += 1
-        def slots(count):  # tickets of a short last chunk that fall outside it are skipped by the workers
-            return (count + chunk - 1) // chunk * chunk * repeat
-        tickets = batch.TicketQueue(slots(len(ordered)), tag="pass%d" % passes[0]) if dynamic else None
-        static_tickets = batch.TicketQueue(slots(len(mine)), tag="static%d" % passes[0]) if not dynamic else None
-        if static_tickets is not None:
-            static_tickets.store = None  # a rank-local counter over this rank's own share
-        totals = []
-
-        def worker():
-            pivots = 0
-            while True:
-                index = tickets.next() if dynamic else static_tickets.next()
-                if index is None:
-                    break
-                position = ticket_to_index(index, repeat, len(ordered) if dynamic else len(mine))
-                if position is None:
-                    continue
-                name = ordered[position] if dynamic else mine[position]
-                with handle_locks[name]:
-                    r = solvers[name].solve_relaxation()
-                    if record_file is not None:
-                        lp_records.append(solvers[name].record())
-                pivots += r.pivots_phase_one + r.pivots_phase_two
-                records.append((name, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.solve_seconds))
-            totals.append(pivots)
-
-        threads = [threading.Thread(target=worker) for _ in range(workers - 1)]
-        for t in threads:
-            t.start()
-        worker()
-        for t in threads:
-            t.join()
-        return sum(totals)
-
-    for _ in range(args.warmup):
-        run_all()
-    if distributed:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    start = time.perf_counter()
-    del records[:]
-    pivots = run_all(repeat=args.steps)
-    if distributed:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed, pivots = batch.aggregate(time.perf_counter() - start, pivots, device="cuda" if distributed else None)
-    gathered = batch.gather_records(list(records))
-    if rank == 0:
-        wrong = []
-        for rank_records in gathered:
-            for name, objective, _, _ in rank_records:
-                e = expected[name]
-                tolerance = max(e["tolerance"], 2e-5 if name == "25FV47" else 0.0)
-                if abs(objective - e["expected"]) > tolerance:
-                    wrong.append(name)
-        summary = json.dumps({
-            "metric": "simplex pivots/sec, Netlib suite batched one LP per GPU", "value": pivots / elapsed, "unit": "pivots/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "%d Netlib .SIF files shipped under data/netlib" % len(names),
-            "config": {"workload": "Netlib batch (%d LPs%s), %s, independent LPs sharded over the GPUs" % (
-                len(names), ", after the reference's presolve" if args.presolve else "",
-                "dynamic ticket queue over the cost-sorted list" if dynamic else "static longest-first assignment"),
-                       "lps_in_flight_per_gpu": max(1, args.concurrency),
-                       "problems_per_rank": [len(r) for r in gathered],
-                       "pivots_per_rank": [sum(entry[2] for entry in r) for r in gathered],
-                       "solve_seconds_per_rank": [sum(entry[3] for entry in r) for r in gathered],
-                       "makespan_s": elapsed, "objectives_outside_reference_tolerance": wrong}})
-    if record_file is not None:
-        with open(record_file if world == 1 else "%s.rank%d" % (record_file, rank), "w") as handle:
-            for entry in lp_records:
-                handle.write(json.dumps(entry) + "\n")
-    if distributed:
-        torch.distributed.destroy_process_group()
-    if rank == 0:
-        emit(summary)
-
-
-def main():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=5)
-    parser.add_argument("--warmup", type=int, default=1)
-    parser.add_argument("--workload", default="25fv47")
-    parser.add_argument("--crash", type=int, default=1, help="graph workloads: start phase one from the spanning-forest crash basis")
-    parser.add_argument("--dense-storage", choices=["narrowest", "f32", "f64"], default="narrowest",
-                        help="dense workloads: storage type of the dense block (narrowest exact type: signed bytes for this generator)")
-    parser.add_argument("--cpu-seconds", type=float, default=15.0)
-    parser.add_argument("--no-cpu-baseline", action="store_true")
-    parser.add_argument("--no-concurrency-probe", action="store_true")
-    parser.add_argument("--no-dense-roofline", action="store_true")
-    parser.add_argument("--no-certify", action="store_true", help="25fv47: leave the exact certificate out of the timed step (A/B only)")
-    parser.add_argument("--carry", type=int, default=0, choices=[0, 1], help="0 explicit inverse, 1 LU + Forrest-Tomlin (relp_options.carry)")
-    parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
-    parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
-    parser.add_argument("--records", default=None, help="netlib batch: write one JSON line per solved LP to this file")
-    parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
-    args = parser.parse_args()
-
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1 or os.environ.get("RELP_FORCE_DISTRIBUTED") == "1"  # the env switch exercises the RCCL path at N=1
-    if distributed:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    if world > 1:
-        # the exact certificate assembles its digits on host threads (up to 32 per process): share the cores between the ranks
-        os.environ.setdefault("RELP_CERTIFY_THREADS", str(max(2, (os.cpu_count() or 8) // world)))
-    import relp_amd
+    rank, local_rank, world, distributed = ctx["rank"], ctx["local_rank"], ctx["world"], ctx["distributed"]
     path = WORKLOADS[args.workload]
-    if path == "batch":
-        return netlib_batch(args, rank, local_rank, world, distributed)
     graph = isinstance(path, tuple) and path[0] == "maxflow"
     dense = not isinstance(path, str) and not graph
+    model = None
     if graph:
         # the MatrixProvider of examples/max_flow.rs on the random graph of SURVEY.md section 8(d); the capacity rows are
         # handled as implicit bounds (the explicit formulation has V - 2 + E rows: no inverse of that size fits)
         from relp_amd.workloads import max_flow_graph
         _, nr_vertices, nr_arcs = path
-        tail, head, capacity = max_flow_graph(nr_vertices, nr_arcs)
-        model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+        key = ("maxflow_model", nr_vertices, nr_arcs)
+        if key not in ctx["cache"]:
+            tail, head, capacity = max_flow_graph(nr_vertices, nr_arcs)
+            ctx["cache"][key] = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+        model = ctx["cache"][key]
         solver = relp_amd.Solver(device=local_rank, implicit_bounds=1, crash=args.crash).load_model(model)
     elif dense:
         from relp_amd.workloads import dense_lp
-        a, b, c = dense_lp(*path)
+        key = ("dense_lp",) + tuple(path)
+        if key not in ctx["cache"]:
+            ctx["cache"][key] = dense_lp(*path)
+        a, b, c = ctx["cache"][key]
+        for var in ("RELP_DENSE_F32", "RELP_DENSE_F64"):
+            os.environ.pop(var, None)
         if args.dense_storage != "narrowest":  # generic data: the block as float / double (the library reads this at load time)
             os.environ["RELP_DENSE_F32" if args.dense_storage == "f32" else "RELP_DENSE_F64"] = "1"
         solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512"))).load_dense_le(a, b, c)
     else:
         # the step is `solve_relaxation` with the exact certificate INSIDE: the f64 loop alone is narrower arithmetic than the
         # reference's, the bit-exact optimum is part of the job (BASELINE.json north_star)
-        solver = relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry).load_mps(path, presolve=args.presolve)
+        model = relp_amd.Model(path, presolve=args.presolve)
+        solver = relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry).load_model(model)
 
     def barrier():
         if distributed:
-            dist.barrier()
+            torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -375,7 +377,7 @@ def main():
         all_certified = all_certified and bool(last.certified)
     barrier()
     elapsed = time.perf_counter() - start
-    from relp_amd import batch
+    final_basis = solver.basis() if rank == 0 else None
     # one record per rank (what each GPU did); the makespan is the max over ranks of the barrier-to-barrier time
     per_rank = batch.gather_records({"rank": rank, "solves": args.steps, "pivots": int(pivots), "busy_seconds": loop_seconds + certify_seconds,
                                      "elapsed_seconds": elapsed})
@@ -386,7 +388,7 @@ def main():
         # headroom: the same LP, 4 independent copies in flight on this GPU (one host thread and stream each); a single
         # latency-bound solve uses a fraction of the chip.  Reported beside `value`, never as `value`.
         import threading
-        copies = [solver] + [relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry).load_mps(path, presolve=args.presolve) for _ in range(3)]
+        copies = [solver] + [relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry).load_model(model) for _ in range(3)]
         for extra in copies[1:]:
             extra.solve_relaxation()
         counts = [0] * len(copies)
@@ -409,138 +411,443 @@ def main():
         for extra in copies[1:]:
             extra.close()
 
+    if rank != 0:
+        solver.close()
+        return None
     exact = None
-    if rank == 0 and not dense and not graph and not args.no_certify:
+    if not dense and not graph and not args.no_certify:
         # the exact optimum of the LAST TIMED solve (the certificate ran inside every timed step)
         if all_certified:
             text = solver.objective_exact()
             num, den = text.split("/")
             exact = {"certified": True, "objective_bits": max(int(num).bit_length(), int(den).bit_length()),
-                     "certify_seconds_per_solve": certify_seconds / args.steps, "objective_exact_head": text[:40] + "..."}
+                     "certify_seconds_per_solve": certify_seconds / args.steps, "objective_exact_head": text[:40] + "...",
+                     "solution_exact_nonzeros": len(solver.solution_exact())}
         else:
             exact = {"certified": False}
-    if rank == 0:
-        # roofline of the dominant kernel (pricing pass), measured live with HIP events on the solver's stream
-        solver.begin_phase_one()
-        # (phase one of the flow LP has only a few hundred ordinary pivots before the zero-level ones: short samples there)
-        _, reason = solver.iterate(20 if graph else (300 if dense else 200))
-        if graph and reason == relp_amd.STOP_NO_ENTERING:  # crash basis: phase one ends without a pivot -- profile phase two
-            solver.begin_phase_two()
-            solver.iterate(20)
-        reps = 40 if graph else (100 if dense else 200)  # further real pivots, the profiled kernel of each bracketed by its own event pair
-        solver.profile_kernel(0, 10 if graph else 50)   # discarded: brings clocks and caches to the state of a running solve
-        lu_carry = args.carry == 1 and not dense and not graph
-        kernels = ["price", "lu_pivot"] if lu_carry else ["price", "ftran_ratio", "update"]
+    # ---- roofline of the dominant kernel, measured live with HIP events on the solver's stream -------------------------------
+    solver.begin_phase_one()
+    # (phase one of the flow LP has only a few hundred ordinary pivots before the zero-level ones: short samples there)
+    _, reason = solver.iterate(20 if graph else (300 if dense else 200))
+    if graph and reason == relp_amd.STOP_NO_ENTERING:  # crash basis: phase one ends without a pivot -- profile phase two
+        solver.begin_phase_two()
+        solver.iterate(20)
+    reps = 40 if graph else (100 if dense else 200)  # further real pivots, the profiled kernel of each bracketed by its own event pair
+    solver.profile_kernel(0, 10 if graph else 50)   # discarded: brings clocks and caches to the state of a running solve
+    lu_carry = args.carry == 1 and not dense and not graph
+    kernels = ["price", "lu_pivot"] if lu_carry else ["price", "ftran_ratio", "update"]
+    try:
+        seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
+    except relp_amd.api.RelpError:
+        # m <= 2048: ratio test and inverse update are ONE launch (pivot_fused_kernel): two kernels per pivot
+        kernels = ["price", "pivot_fused"]
+        seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
+    stats = solver.stats()
+    m_rows = solver.m
+    # ---- algorithmic bytes: the contract's and each kernel's own ---------------------
+    # the kernel's own: pricing = the non-basic columns (exact, counted at the profiled state); K2 = nnz(a_q) columns of the inverse
+    # + six m-vectors; K3 = read + write of the touched part of the inverse (upper bound: all of it); the LU kernel = both
+    # orientations of the factors once each + twelve m-vectors.
+    if dense:
+        basic_structurals = int(sum(1 for c in final_basis if 0 <= c < path[1]))
+        nnz_f = basic_structurals * m_rows + m_rows  # SURVEY.md section 8(d), worked example: a dense k x k block plus k (m - k) entries
+        mean_column = float(m_rows)
+    else:
+        pivots_initial = model.pivot_element_indices()
+        art_rows = sorted(set(range(model.nr_rows)) - {r for r, _ in pivots_initial})
         try:
-            seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
-        except relp_amd.api.RelpError:
-            # m <= 1024: ratio test and inverse update are ONE launch (pivot_fused_kernel): two kernels per pivot
-            kernels = ["price", "pivot_fused"]
-            seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
-        stats = solver.stats()
-        # Algorithmic bytes per launch: pricing = the non-basic columns (exact, counted at the profiled
-        # state); K2 = nnz(a_q) columns of the inverse + six m-vectors; K3 = read + write of the touched part of the inverse
-        # (upper bound: all of it); the LU kernel = both orientations of the factors once each + twelve m-vectors.
-        m_rows = solver.m
-        mean_column = 2.0 if graph else (max(1.0, float(relp_amd.Model(path).nnz) / max(1, solver.n_provider)) if not dense else float(m_rows))
-        algorithmic = {"price": stats.price_bytes,
-                       "ftran_ratio": int(mean_column * m_rows * 8 + 6 * m_rows * 8),
-                       "update": stats.update_bytes,
-                       "lu_pivot": int(12 * m_rows * 8 + 2 * 12 * 3 * m_rows),  # (factor entries: about 3 per row and triangle)
-                       # fused: one workgroup's FTRAN + ratio test, and ONE read + one write of the whole inverse (out of place)
-                       "pivot_fused": int(mean_column * m_rows * 8 + 6 * m_rows * 8 + 2 * m_rows * m_rows * 8)}
-        per_kernel = {name: {"seconds_per_launch": seconds[name], "algorithmic_bytes_per_launch": algorithmic[name],
-                             "achieved_gb_s": algorithmic[name] / seconds[name] / 1e9,
-                             "frac": algorithmic[name] / seconds[name] / 1e9 / HBM_PEAK_GBS,
-                             "share_of_pivot_time": seconds[name] / sum(seconds.values())} for name in kernels}
-        dominant = max(kernels, key=lambda name: seconds[name])  # by MEASURED time share, not by assumption
-        bytes_per_launch = algorithmic[dominant]
-        achieved = bytes_per_launch / seconds[dominant] / 1e9
-        # HBM traffic per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md
-        # section HBM); null when not collected for this kernel
-        traffic = None
-        dense_price = "price_dense_lane_kernel" if args.dense_storage == "narrowest" else "price_dense_kernel"
-        pmc_names = {"price": dense_price if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
-                     "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
-        for candidate in ("r2_%s_pmc_traffic.json" % args.workload, "r1_%s_pmc_traffic.json" % args.workload):
-            pmc = os.path.join(ROOT, "profiles", candidate)
-            if traffic is None and os.path.exists(pmc):
-                for name, entry in json.load(open(pmc)).items():
-                    if pmc_names[dominant] in name:
-                        traffic = entry["hbm_bytes_corrected"]
-                        break
-        if graph:
-            workload = ("max-flow LP (examples/max_flow.rs provider) on a random graph V=%d E=%d (splitmix64 seed 0x5EED0005): "
-                        "%d conservation rows on the device, the %d capacity rows as implicit bounds, %s" % (
-                            path[1], path[2], path[1] - 2, path[2],
-                            "phase one from the spanning-forest crash basis" if args.crash else "artificial start as in the reference"))
-            data = "synthetic"
-        elif dense:
-            workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing, dense block stored as %s" % (
-                path + ({"narrowest": "signed bytes (narrowest exact type)", "f32": "float", "f64": "double"}[args.dense_storage],))
-            data = "synthetic"
+            # (graph LPs: a tree basis -- at most two entries per arc column -- is counted, not factorised on the host, at a million rows)
+            nnz_f = 3 * m_rows if graph else factor_nonzeros(model, final_basis, art_rows)
+        except Exception:  # noqa: BLE001  (a basis the host factorisation rejects: fall back to 3 entries per row and triangle)
+            nnz_f = 7 * m_rows
+        mean_column = 2.0 if graph else max(1.0, float(model.nnz) / max(1, solver.n_provider))
+    contract = contract_bytes(stats.price_bytes, nnz_f, m_rows)
+    own = {"price": stats.price_bytes,
+           "ftran_ratio": int(mean_column * m_rows * 8 + 6 * m_rows * 8),
+           "update": stats.update_bytes,
+           "lu_pivot": int(2 * nnz_f * 12 + 12 * m_rows * 8),
+           # fused: one workgroup's FTRAN + ratio test, and ONE read + one write of the whole inverse (out of place)
+           "pivot_fused": int(mean_column * m_rows * 8 + 6 * m_rows * 8 + 2 * m_rows * m_rows * 8)}
+    # the contract's share per kernel: the pricing pass is the pricing kernel's; everything else belongs to the kernel(s) that do
+    # the FTRAN / ratio test / BTRAN / update of a pivot, split by their measured time
+    rest = [k for k in kernels if k != "price"]
+    rest_seconds = sum(seconds[k] for k in rest)
+    contract_share = {"price": contract["pricing"]}
+    for k in rest:
+        contract_share[k] = int(contract["ftran_btran_vectors"] * (seconds[k] / rest_seconds if rest_seconds > 0 else 1.0 / len(rest)))
+    per_kernel = {name: {"seconds_per_launch": seconds[name],
+                         "contract_bytes_per_launch": contract_share[name], "kernel_bytes_per_launch": own[name],
+                         "achieved_gb_s": contract_share[name] / seconds[name] / 1e9, "frac": contract_share[name] / seconds[name] / 1e9 / HBM_PEAK_GBS,
+                         "kernel_bytes_gb_s": own[name] / seconds[name] / 1e9, "kernel_bytes_frac": own[name] / seconds[name] / 1e9 / HBM_PEAK_GBS,
+                         "share_of_pivot_time": seconds[name] / sum(seconds.values())} for name in kernels}
+    dominant = max(kernels, key=lambda name: seconds[name])  # by MEASURED time share, not by assumption
+    achieved = per_kernel[dominant]["achieved_gb_s"]
+    # HBM traffic per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md
+    # section HBM); null when not collected for this kernel
+    traffic = None
+    dense_price = "price_dense_lane_kernel" if args.dense_storage == "narrowest" else "price_dense_kernel"
+    pmc_names = {"price": dense_price if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
+                 "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
+    tag = args.workload + ("_lu" if lu_carry else "")
+    for candidate in ("r3_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % args.workload,
+                      "r1_%s_pmc_traffic.json" % args.workload):
+        pmc = os.path.join(ROOT, "profiles", candidate)
+        if traffic is None and os.path.exists(pmc):
+            for name, entry in json.load(open(pmc)).items():
+                if pmc_names[dominant] in name:
+                    traffic = entry["hbm_bytes_corrected"]
+                    break
+    if graph:
+        workload = ("max-flow LP (examples/max_flow.rs provider) on a random graph V=%d E=%d (splitmix64 seed 0x5EED0005): "
+                    "%d conservation rows on the device, the %d capacity rows as implicit bounds, %s" % (
+                        path[1], path[2], path[1] - 2, path[2],
+                        "phase one from the spanning-forest crash basis" if args.crash else "artificial start as in the reference"))
+        data = "synthetic"
+    elif dense:
+        workload = "synthetic dense random LP m=%d n=%d f64 (splitmix64 seed 0x5EED0001), steepest-edge pricing, dense block stored as %s" % (
+            path + ({"narrowest": "signed bytes (narrowest exact type)", "f32": "float", "f64": "double"}[args.dense_storage],))
+        data = "synthetic"
+    else:
+        workload = ("Netlib 25FV47 %dx%d, steepest-edge pricing, %s carry, exact certificate %s the timed step, %s" % (
+            solver.m, solver.n_provider, "LU + Forrest-Tomlin" if args.carry == 1 else "explicit-inverse",
+            "outside" if args.no_certify else "inside",
+            "after the reference's presolve" if args.presolve else "no presolve (+520 virtual artificials)"))
+        data = "Netlib 25FV47.SIF (shipped problem file), one copy per GPU"
+    options = solver.options
+    seconds_per_pivot = loop_seconds / max(1, pivots // max(1, world))
+    line = {
+        "metric": "simplex pivots/sec + wall-clock to optimal, Netlib 25fv47 @1 GPU",
+        "value": pivots / elapsed, "unit": "pivots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": data,
+        "config": {"workload": workload,
+                   "pivots_per_solve": int(last.pivots_phase_one + last.pivots_phase_two),
+                   "objective": last.objective,
+                   "wall_clock_to_exact_optimum_s": (loop_seconds + certify_seconds) / args.steps,
+                   "wall_clock_f64_loop_s": loop_seconds / args.steps,
+                   "pivots_per_s_f64_loop_only": pivots / world / loop_seconds if loop_seconds > 0 else None,
+                   "carry": "lu" if args.carry == 1 else "explicit", "refactors": int(last.refactors),
+                   "refactor_seconds_per_solve": float(last.refactor_seconds),
+                   "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
+                   # the reference is exact and has neither tolerances nor a Harris test: what f64 adds, and what it changes
+                   "ratio_rule": "harris two-pass (default; the reference's textbook rule with Bland ties is relp_options.ratio_rule = 1)"
+                                 if options.ratio_rule == 0 else "textbook minimum ratio, Bland ties (the reference's)",
+                   "tolerances": {"tol_dual": options.tol_dual, "tol_pivot": options.tol_pivot, "harris_delta": options.harris_delta,
+                                  "tol_feasible": options.tol_feasible},
+                   "pivot_sequence": "f64 + Harris: 2383 pivots on 25FV47 where the exact reference rule makes 2392 (tests/golden/25FV47.json); "
+                                     "the certified optimum is the same rational" if not dense and not graph else None,
+                   "parallelism": "1 LP per GPU x%d" % world,
+                   "makespan_s": elapsed, "per_rank": sorted(per_rank, key=lambda r: r["rank"]), "exact": exact,
+                   "aggregate_with_copies_in_flight": in_flight},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "seconds_per_launch": seconds,
+                     "algorithmic_bytes_per_launch": per_kernel[dominant]["contract_bytes_per_launch"],
+                     "kernel_bytes_per_launch": per_kernel[dominant]["kernel_bytes_per_launch"],
+                     "kernel_bytes_frac": per_kernel[dominant]["kernel_bytes_frac"],
+                     "contract_bytes_per_pivot": contract, "factor_nonzeros": int(nnz_f),
+                     "per_pivot": {"seconds": seconds_per_pivot, "contract_gb_s": contract["per_pivot"] / seconds_per_pivot / 1e9 if seconds_per_pivot > 0 else None,
+                                   "contract_frac": contract["per_pivot"] / seconds_per_pivot / 1e9 / HBM_PEAK_GBS if seconds_per_pivot > 0 else None},
+                     "kernels": per_kernel},
+    }
+    if graph:
+        line["metric"] = "simplex pivots/sec + wall-clock to optimal, max-flow LP @1 GPU"
+        line["roofline"]["note"] = ("the dominant kernel by measured time is listed first; 'price' generates each incidence column from the 8 bytes of "
+                                    "its arc's endpoints (+ 1 B cost, 4 B basis position: 13 B per arc; a steepest-edge weight is read/written only by candidates "
+                                    "and by columns with an entry in the pivot row) and gathers one packed 32-byte (-pi, rho, w) record per entry from "
+                                    "L2; 'update' walks the non-zero rows of alpha in every column of the inverse that is not a unit vector (8-byte "
+                                    "gathers, one cache line each: PMC traffic is line-granular)")
+    elif dense:
+        line["metric"] = "simplex pivots/sec + wall-clock to optimal, dense LP @1 GPU"
+        if args.dense_storage == "narrowest":
+            line["roofline"]["note"] = ("dense block held in the narrowest exact type (this workload: signed bytes, 1 B per entry -- data specific; the "
+                                        "generic figure is the f64-storage config): one column per lane, -pi / rho / w "
+                                        "broadcast through DPP inside the f64 FMA (no LDS traffic); 5 VALU instructions per entry = %.1f us "
+                                        "of issue time on 1024 SIMDs (tools/micro/valu_rates.hip: 1.9 ns each), the rest of the launch is "
+                                        "the first load's latency and the per-workgroup tail" % (stats.price_bytes * 5 * 1.9e-3 / 64 / 1024))
         else:
-            workload = ("Netlib 25FV47 %dx%d, steepest-edge pricing, %s carry, exact certificate %s the timed step, %s" % (
-                solver.m, solver.n_provider, "LU + Forrest-Tomlin" if args.carry == 1 else "explicit-inverse",
-                "outside" if args.no_certify else "inside",
-                "after the reference's presolve" if args.presolve else "no presolve (+520 virtual artificials)"))
-            data = "Netlib 25FV47.SIF (shipped problem file), one copy per GPU"
-        line = {
-            "metric": "simplex pivots/sec + wall-clock to optimal, Netlib 25fv47 @1 GPU",
-            "value": pivots / elapsed, "unit": "pivots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": data,
-            "config": {"workload": workload,
-                       "pivots_per_solve": int(last.pivots_phase_one + last.pivots_phase_two),
-                       "objective": last.objective,
-                       "wall_clock_to_exact_optimum_s": (loop_seconds + certify_seconds) / args.steps,
-                       "wall_clock_f64_loop_s": loop_seconds / args.steps,
-                       "pivots_per_s_f64_loop_only": pivots / world / loop_seconds if loop_seconds > 0 else None,
-                       "carry": "lu" if args.carry == 1 else "explicit", "refactors": int(last.refactors),
-                       "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
-                       "parallelism": "1 LP per GPU x%d" % world,
-                       "makespan_s": elapsed, "per_rank": sorted(per_rank, key=lambda r: r["rank"]), "exact": exact,
-                       "aggregate_with_copies_in_flight": in_flight},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "seconds_per_launch": seconds, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernels": per_kernel},
-        }
-        if graph:
-            line["metric"] = "simplex pivots/sec + wall-clock to optimal, max-flow LP @1 GPU"
-            line["roofline"]["note"] = ("the dominant kernel by measured time is listed first; 'price' generates each incidence column from the 8 bytes of "
-                                        "its arc's endpoints (+ 1 B cost, 4 B basis position; a steepest-edge weight is read/written only by candidates "
-                                        "and by columns with an entry in the pivot row) and gathers one packed 32-byte (-pi, rho, w) record per entry from "
-                                        "L2; 'update' walks the non-zero rows of alpha in every column of the inverse that is not a unit vector (8-byte "
-                                        "gathers, one cache line each: PMC traffic is line-granular)")
-        elif dense:
-            line["metric"] = "simplex pivots/sec + wall-clock to optimal, dense LP @1 GPU"
-            if args.dense_storage == "narrowest":
-                line["roofline"]["note"] = ("dense block held in the narrowest exact type (this workload: signed bytes, 1 B per entry; as float the "
-                                            "pass streams 4x the bytes at 5.2 TB/s = 0.65 of the HBM peak): one column per lane, -pi / rho / w "
-                                            "broadcast through DPP inside the f64 FMA (no LDS traffic); 5 VALU instructions per entry = %.1f us "
-                                            "of issue time on 1024 SIMDs (tools/micro/valu_rates.hip: 1.9 ns each), the rest of the launch is "
-                                            "the first load's latency and the per-workgroup tail" % (bytes_per_launch * 5 * 1.9e-3 / 64 / 1024))
-            else:
-                line["roofline"]["note"] = {
-                    "f32": "dense block streamed as float (exact for this data; all arithmetic f64): one column per lane, 16-byte "
-                           "non-temporal loads, -pi / rho / w broadcast through DPP inside the f64 FMA (no LDS traffic); bound by HBM",
-                    "f64": "dense block streamed as double: one column per lane, 16-byte non-temporal loads, -pi / rho / w broadcast "
-                           "through DPP inside the f64 FMA (no LDS traffic); bound by HBM"}[args.dense_storage]
-        if not dense and not graph:
-            line["roofline"]["note"] = ("latency bound by construction: the dominant kernel BY MEASURED TIME is '%s' (%d KB of algorithmic "
-                                        "bytes per launch, all of it resident in L2 / Infinity Cache; SURVEY.md section 8(d)); every kernel of "
-                                        "the pivot is listed under 'kernels' with its share of the pivot time; traffic = 2 x FETCH_SIZE + "
-                                        "WRITE_SIZE of the committed PMC passes for that kernel; the HBM-roofline configuration is BASELINE "
-                                        "configs[2], measured below") % (dominant, bytes_per_launch // 1024)
-            if world == 1 and not args.no_dense_roofline:
-                line["roofline_config3"] = dense_roofline(local_rank)
-        if world == 1 and not args.no_cpu_baseline and not graph:  # reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline_dense(path, args.cpu_seconds) if dense else cpu_baseline(path, args.cpu_seconds)
-            if not dense:
-                line["cpu_baseline_f64"] = cpu_baseline_f64(path, args.cpu_seconds)
+            line["roofline"]["note"] = {
+                "f32": "dense block streamed as float (exact for this data; all arithmetic f64): one column per lane, 16-byte "
+                       "non-temporal loads, -pi / rho / w broadcast through DPP inside the f64 FMA (no LDS traffic); bound by HBM",
+                "f64": "dense block streamed as double (SURVEY.md section 8(d)'s bytes: 8 B per entry): one column per lane, 16-byte non-temporal "
+                       "loads, -pi / rho / w broadcast through DPP inside the f64 FMA (no LDS traffic); bound by HBM"}[args.dense_storage]
+    else:
+        line["roofline"]["note"] = ("latency bound by construction: the dominant kernel BY MEASURED TIME is '%s'; `frac` prices it on the contract's "
+                                    "bytes (SURVEY.md section 8(d): the factor entries twice + twelve m-vectors, %d KB per pivot outside pricing), "
+                                    "`kernel_bytes_frac` on what the kernel itself streams (%d KB per launch, resident in L2 / Infinity Cache); every kernel of "
+                                    "the pivot is listed under 'kernels' with its share of the pivot time; traffic = 2 x FETCH_SIZE + "
+                                    "WRITE_SIZE of the committed PMC passes for that kernel; the HBM-roofline configuration is BASELINE "
+                                    "configs[2], under configs.dense4096_f64") % (dominant, contract["ftran_btran_vectors"] // 1024,
+                                                                                  per_kernel[dominant]["kernel_bytes_per_launch"] // 1024)
+    solver.close()
+    return line
+
+
+# =====================================================================================================================
+# config 4: the Netlib batch through the library's batch entry (relp_batch_*)
+# =====================================================================================================================
+def netlib_batch(args, ctx):
+    """Independent LPs shard across ranks through ONE ticket queue over K passes of the cost-sorted suite: inside a process the
+    library's worker threads draw tickets (relp_batch_run), across processes the queue is an atomic counter on the process
+    group's store (relp_amd.batch.TicketQueue handed to the library as `next_ticket`).  Every LP is resident in HBM on every
+    worker before the timed region.  value = pivots of all ranks / makespan (max over ranks) = SUITE THROUGHPUT; a single pass
+    is bounded below by its longest LP, reported as `single_pass_makespan_s`."""
+    import torch
+    import relp_amd
+    from relp_amd import batch
+    rank, local_rank, world, distributed = ctx["rank"], ctx["local_rank"], ctx["world"], ctx["distributed"]
+    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))
+    names = netlib_names(expected)
+    key = ("netlib_models", bool(args.presolve))
+    if key not in ctx["cache"]:
+        ctx["cache"][key] = [relp_amd.Model(os.path.join(ROOT, "data", "netlib", name + ".SIF"), presolve=args.presolve) for name in names]
+    models = ctx["cache"][key]
+    costs = [float(mdl.nr_rows) * float(mdl.nnz + mdl.nr_columns) for mdl in models]
+    ordered = sorted(range(len(names)), key=lambda k: (-costs[k], names[k]))  # longest estimated first
+    workers = max(1, args.concurrency)
+    static = args.schedule == "static"
+    if static:  # longest-first partition: this rank's batch holds (and serves) its own share only
+        mine = set(batch.assign([(names[k], costs[k]) for k in range(len(names))], world)[rank])
+        ordered = [k for k in ordered if names[k] in mine]
+    pool = relp_amd.Batch(models, devices=(local_rank,), workers_per_device=workers)
+    # Order of the K x 45 tickets.  1-2 GPUs: pass after pass, each longest-first.  4+ GPUs: the cost-sorted list in chunks of
+    # eight LPs, all K passes of a chunk before the next chunk -- close to longest-first over everything (the long solves of
+    # the last pass do not start late) while consecutive tickets are still different LPs.
+    chunk = 8 if world >= 4 else len(ordered)
+    chunk = max(1, int(os.environ.get("RELP_BATCH_CHUNK", chunk)))  # diagnostic override
+
+    def schedule(repeat):
+        out = []
+        for first in range(0, len(ordered), chunk):
+            part = ordered[first:first + chunk]
+            for _ in range(repeat):
+                out.extend(part)
+        return out
+
+    counter = [0]
+
+    def run(repeat):
+        counter[0] += 1
+        sched = schedule(repeat)
+        queue = None
+        if distributed and world > 1 and not static:
+            tickets = batch.TicketQueue(len(sched), tag="r3pass%d" % counter[0])
+            queue = lambda: (lambda t: len(sched) if t is None else t)(tickets.next())  # noqa: E731
+        return sched, pool.run(sched, next_ticket=queue)
+
+    for _ in range(args.warmup):
+        run(1)
     if distributed:
-        dist.destroy_process_group()
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    sched, (entries, worker_stats, _) = run(args.steps)
+    if distributed:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - start
+    served = [e for e in entries if e.status == 0]
+    pivots_local = sum(e.result.pivots_phase_one + e.result.pivots_phase_two for e in served)
+    elapsed, pivots = batch.aggregate(elapsed_local, pivots_local, device="cuda" if distributed else None)
+    record = {"rank": rank, "tickets": len(served), "pivots": int(pivots_local), "solve_seconds": sum(e.result.solve_seconds for e in served),
+              "elapsed_seconds": elapsed_local,
+              "workers": [{"tickets": int(w.tickets), "pivots": int(w.pivots), "busy_seconds": w.busy_seconds, "idle_seconds": w.idle_seconds,
+                           "queue_seconds": w.queue_seconds} for w in worker_stats],
+              "results": [(names[e.model], e.result.objective, int(e.result.pivots_phase_one + e.result.pivots_phase_two), e.result.solve_seconds)
+                          for e in served]}
+    lp_records = []
+    if args.records is not None:
+        import ctypes as C
+        for e in served:  # the resident handle's record of its last solve
+            h = C.c_void_p()
+            relp_amd.lib().relp_batch_handle(pool._h, e.worker, e.model, C.byref(h))
+            length = C.c_int32()
+            relp_amd.lib().relp_get_record_json(h, None, 0, C.byref(length))
+            buf = C.create_string_buffer(length.value + 1)
+            relp_amd.lib().relp_get_record_json(h, buf, length.value + 1, C.byref(length))
+            lp_records.append(json.loads(buf.value.decode()))
+        with open(args.records if world == 1 else "%s.rank%d" % (args.records, rank), "w") as handle:
+            for entry in lp_records:
+                handle.write(json.dumps(entry) + "\n")
+    # bytes the suite moves on the contract's terms: the per-LP record's pricing bytes per pivot x its pivots (one pass each)
+    contract_total = 0
+    if rank == 0 and world == 1:
+        import ctypes as C
+        for e in served:
+            h = C.c_void_p()
+            relp_amd.lib().relp_batch_handle(pool._h, e.worker, e.model, C.byref(h))
+            stats = relp_amd.api.Stats()
+            relp_amd.lib().relp_get_stats(h, C.byref(stats))
+            m_rows = models[e.model].nr_rows
+            contract_total += (e.result.pivots_phase_one + e.result.pivots_phase_two) * (stats.price_bytes + 2 * 7 * m_rows * 12 + 12 * m_rows * 8)
+    gathered = batch.gather_records(record)
+    pool.close()
+    if rank != 0:
+        return None
+    wrong = []
+    longest = {}
+    for rank_record in gathered:
+        for name, objective, _, seconds in rank_record["results"]:
+            e = expected[name]
+            tolerance = max(e["tolerance"], 2e-5 if name == "25FV47" else 0.0)
+            if abs(objective - e["expected"]) > tolerance:
+                wrong.append(name)
+            longest[name] = max(longest.get(name, 0.0), seconds)
+    slowest = max(longest, key=longest.get) if longest else None
+    line = {
+        "metric": "simplex pivots/sec, Netlib suite batched one LP per GPU", "value": pivots / elapsed, "unit": "pivots/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        # suite throughput over ONE queue of K passes: the work is fixed as N grows (strong scaling of the K x 45 tickets); a single
+        # pass cannot scale past its longest LP (`single_pass_makespan_s`)
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "%d Netlib .SIF files shipped under data/netlib" % len(names),
+        "config": {"workload": "Netlib batch (%d LPs%s), %s, independent LPs sharded over the GPUs through relp_batch_run" % (
+            len(names), ", after the reference's presolve" if args.presolve else "",
+            "static longest-first assignment" if static else "dynamic ticket queue over the cost-sorted list"),
+                   "throughput_kind": "suite throughput: %d passes over the suite as one ticket queue" % args.steps,
+                   "lps_in_flight_per_gpu": workers,
+                   "single_pass_makespan_s": longest.get(slowest) if slowest else None, "longest_lp": slowest,
+                   "tickets_per_rank": [r["tickets"] for r in gathered],
+                   "pivots_per_rank": [r["pivots"] for r in gathered],
+                   "solve_seconds_per_rank": [r["solve_seconds"] for r in gathered],
+                   "elapsed_seconds_per_rank": [r["elapsed_seconds"] for r in gathered],
+                   "workers_per_rank": [r["workers"] for r in gathered],
+                   "makespan_s": elapsed, "objectives_outside_reference_tolerance": wrong}}
+    if world == 1 and contract_total:
+        achieved = contract_total / elapsed / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": "whole batch", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "note": "latency / L2 bound (SURVEY.md section 8(d)): contract bytes of every pivot of the run (pricing pass of the "
+                                    "LP + 2 x ~7 factor entries per row x 12 B + twelve m-vectors) / makespan; not roofline-meaningful"}
+    return line
+
+
+# =====================================================================================================================
+def all_configs(args, ctx, legs):
+    """The other BASELINE configs, measured in this process after the headline (default run, N = 1)."""
+    out = {}
+
+    def variant(**overrides):
+        v = copy.copy(args)
+        v.no_concurrency_probe = True
+        for k, val in overrides.items():
+            setattr(v, k, val)
+        return v
+
+    def attempt(key, fn):
+        t0 = time.perf_counter()
+        try:
+            line = fn()
+            line["bench_wall_seconds"] = time.perf_counter() - t0
+            out[key] = line
+        except Exception as error:  # noqa: BLE001  (one config must not take the headline down)
+            out[key] = {"error": "%s: %s" % (type(error).__name__, error)}
+
+    steps = max(1, min(args.steps, 3))
+    attempt("lu_carry_25fv47", lambda: single_lp(variant(carry=1, steps=steps, warmup=1), ctx))
+    attempt("dense4096_f64", lambda: single_lp(variant(workload="dense4096", dense_storage="f64", steps=steps, warmup=1), ctx))
+    attempt("dense4096_narrowest", lambda: single_lp(variant(workload="dense4096", dense_storage="narrowest", steps=steps, warmup=1), ctx))
+    attempt("netlib_batch", lambda: netlib_batch(variant(workload="netlib", presolve=False, steps=2, warmup=1), ctx))
+    attempt("netlib_batch_presolve", lambda: netlib_batch(variant(workload="netlib", presolve=True, steps=2, warmup=1), ctx))
+    attempt("maxflow_reference_start", lambda: single_lp(variant(workload="maxflow", crash=0, steps=1, warmup=1), ctx))
+    attempt("maxflow_crash", lambda: single_lp(variant(workload="maxflow", crash=1, steps=steps, warmup=1), ctx))
+    if not args.no_cpu_baseline:
+        dense_cpu = legs.collect("dense")
+        for key in ("dense4096_f64", "dense4096_narrowest"):
+            if "error" not in out[key]:
+                out[key]["cpu_baseline"] = dense_cpu
+        flow_cpu = legs.collect("maxflow")
+        for key in ("maxflow_reference_start", "maxflow_crash"):
+            if "error" not in out[key]:
+                out[key]["cpu_baseline"] = flow_cpu
+        # the all-cores leg runs alone, after every other CPU leg and GPU measurement
+        legs.start("netlib", "netlib", max(2.0, args.cpu_seconds), blas=1)
+        netlib_cpu = legs.collect("netlib", timeout=900)
+        for key in ("netlib_batch", "netlib_batch_presolve"):
+            if "error" not in out[key]:
+                out[key]["cpu_baseline"] = netlib_cpu
+    return out
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=5)
+    parser.add_argument("--warmup", type=int, default=1)
+    parser.add_argument("--workload", default="25fv47")
+    parser.add_argument("--crash", type=int, default=1, help="graph workloads: start phase one from the spanning-forest crash basis")
+    parser.add_argument("--dense-storage", choices=["narrowest", "f32", "f64"], default="narrowest",
+                        help="dense workloads: storage type of the dense block (narrowest exact type: signed bytes for this generator)")
+    parser.add_argument("--cpu-seconds", type=float, default=15.0)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-concurrency-probe", action="store_true")
+    parser.add_argument("--no-dense-roofline", action="store_true", help="(kept for compatibility: the dense roofline now lives under configs)")
+    parser.add_argument("--no-configs", action="store_true", help="default workload only: skip the other BASELINE configs")
+    parser.add_argument("--no-certify", action="store_true", help="25fv47: leave the exact certificate out of the timed step (A/B only)")
+    parser.add_argument("--carry", type=int, default=0, choices=[0, 1], help="0 explicit inverse, 1 LU + Forrest-Tomlin (relp_options.carry)")
+    parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
+    parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
+    parser.add_argument("--records", default=None, help="netlib batch: write one JSON line per solved LP to this file")
+    parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
+    parser.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
+    args = parser.parse_args()
+
+    if args.cpu_leg:  # child process: one CPU baseline, no GPU
+        print(json.dumps(run_cpu_leg(args.cpu_leg, args.cpu_seconds)), flush=True)
+        return
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1 or os.environ.get("RELP_FORCE_DISTRIBUTED") == "1"  # the env switch exercises the RCCL path at N=1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1:
+        # the exact certificate assembles its digits on host threads (up to 32 per process): share the cores between the ranks
+        os.environ.setdefault("RELP_CERTIFY_THREADS", str(max(2, (os.cpu_count() or 8) // world)))
+    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "distributed": distributed, "cache": {}}
+    path = WORKLOADS[args.workload]
+    batch_workload = path == "batch"
+    graph = isinstance(path, tuple) and path[0] == "maxflow"
+    dense = not isinstance(path, str) and not graph
+    full = rank == 0 and world == 1 and args.workload == "25fv47" and not args.no_configs and not args.presolve and args.carry == 0
+
+    # CPU legs start now and run beside the GPU work (reported at N = 1 only)
+    legs = CpuLegs()
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_cpu and not batch_workload and not graph and not dense:
+        legs.start("exact_faithful", "exact_faithful", args.cpu_seconds)
+        legs.start("exact_tuned", "exact_tuned", args.cpu_seconds)
+        legs.start("f64", "f64", args.cpu_seconds)
+    if want_cpu and (dense or full):
+        dims = path if dense else WORKLOADS["dense4096"]
+        legs.start("dense", "dense:%dx%d" % dims, args.cpu_seconds)
+    if want_cpu and (graph or full):
+        legs.start("maxflow", "maxflow", args.cpu_seconds)
+
+    line = netlib_batch(args, ctx) if batch_workload else single_lp(args, ctx)
+    if rank == 0:
+        if full:
+            line["configs"] = all_configs(args, ctx, legs)
+        if want_cpu:
+            if batch_workload:
+                legs.start("netlib", "netlib", max(2.0, args.cpu_seconds), blas=1)
+                line["cpu_baseline"] = legs.collect("netlib", timeout=900)
+            elif dense:
+                line["cpu_baseline"] = legs.collect("dense")
+            elif graph:
+                line["cpu_baseline"] = legs.collect("maxflow")
+            else:
+                line["cpu_baseline"] = legs.collect("exact_faithful")
+                line["cpu_baseline_tuned"] = legs.collect("exact_tuned")
+                line["cpu_baseline_f64"] = legs.collect("f64")
+        line["host"] = host_description()
+    if distributed:
+        torch.distributed.destroy_process_group()
     if rank == 0:
         emit(json.dumps(line))
 

@@ -253,6 +253,21 @@ int32_t relp_get_solution(const relp_handle* handle, double* x_structural);
 int32_t relp_get_original_solution(const relp_handle* handle, int32_t capacity, double* x, int32_t* count);
 /* Exact optimal objective "num/den" incl. fixed cost (needs options.certify); returns needed length in *length. */
 int32_t relp_get_objective_exact(const relp_handle* handle, char* buffer, int32_t capacity, int32_t* length);
+/* `OptimizationResult::FiniteOptimum(SparseVector<RationalBig>)` (algorithm/mod.rs:43-47) in EXACT form, from the certificate's
+ * solve of B x_B = b (needs options.certify and a certified finite optimum; RELP_ERR_STATE otherwise).
+ *   original == 0: the sparse vector the reference's `solve_relaxation` returns, after `reconstruct_solution`
+ *                  (matrix_data.rs:402-411): index = structural column of the standard form;
+ *   original != 0: the `Solution` of `GeneralForm::compute_full_solution_with_reduced_solution` (general_form/mod.rs:840-934;
+ *                  asserted value by value in tests/burkardt/test.rs:60-112, 143, 185): index = variable of the file, in
+ *                  file order (shifts, flips, free splits and presolve removals undone in exact arithmetic).
+ * Only the non-zero values are returned, ascending index: index[k] and, in `buffer`, their "num/den" texts (reduced, den > 0)
+ * separated by '\n' and terminated by 0.  *count = their number, *length = bytes needed in `buffer`; with index == NULL and
+ * buffer == NULL the call only reports the two sizes. */
+int32_t relp_get_solution_exact(const relp_handle* handle, int32_t original, int32_t capacity, int32_t* count, int32_t* index,
+                                char* buffer, int64_t buffer_capacity, int64_t* length);
+/* Name of variable j of the loaded file (the `String` of `Solution::solution_values`, data/linear_program/solution.rs:15-24);
+ * "Xj" for providers built without names.  *length receives the full length. */
+int32_t relp_get_variable_name(const relp_handle* handle, int32_t j, char* buffer, int32_t capacity, int32_t* length);
 /* One JSON object describing the last relp_solve_relaxation of this handle (the per-LP record of SURVEY.md section 5; the
  * reference has no logging at all): name, m, n, nnz, result, pivots per phase, polishes / refactorisations, wall times,
  * pivots/s, algorithmic bytes per pivot, objective (f64) and objective_exact ("num/den" when certified).  *length receives
@@ -413,6 +428,43 @@ int32_t relp_lu_factor_host(int32_t m, const int64_t* column_start, const int32_
                             int64_t* upper_start, int32_t* upper_column, double* upper_value, double* upper_diagonal,
                             int32_t* depth_lower, int32_t* depth_upper);
 
+
+/* ---- batches of independent LPs (BASELINE config 4) -------------------------------------------
+ * The reference solves one LP per call on one thread (tests/netlib/mod.rs:47-71); independent LPs are the unit that shards.
+ * A batch keeps every LP resident on every worker: `workers_per_device` host threads per listed device, each owning one
+ * handle (= one HIP stream) per model.  relp_batch_run serves a queue of `n_tickets` tickets -- ticket t solves model
+ * schedule[t] (so K passes over a suite are ONE queue and the caller chooses the order, e.g. longest first) -- drawn with an
+ * atomic fetch-add, or through `next_ticket` when several processes (one rank per GPU) share one queue: it must return a
+ * fresh ticket number per call (values outside [0, n_tickets) end the worker).  No data-path collective exists.
+ *   entries[t]: result of ticket t (status -1: not served by this batch); workers[w]: tickets, pivots, busy / idle seconds of
+ *   worker w (relp_batch_workers of them); *makespan_seconds: wall clock of the run. */
+typedef struct relp_batch relp_batch;
+typedef struct relp_batch_entry {
+    int32_t status;            /* relp_status of relp_solve_relaxation, or -1 */
+    int32_t model;             /* schedule[t] */
+    int32_t worker, device;
+    relp_result result;
+    double start_seconds, end_seconds;  /* relative to the start of the run */
+} relp_batch_entry;
+typedef struct relp_batch_worker {
+    int32_t device;
+    int32_t tickets;
+    int64_t pivots;
+    double busy_seconds;       /* inside relp_solve_relaxation */
+    double queue_seconds;      /* drawing tickets */
+    double idle_seconds;       /* makespan - busy */
+    double finish_seconds;     /* when this worker found the queue empty */
+} relp_batch_worker;
+int32_t relp_batch_create(const relp_model* const* models, int32_t n_models, const relp_options* options, const int32_t* devices,
+                          int32_t n_devices, int32_t workers_per_device, relp_batch** out, char* error, int32_t error_capacity);
+int32_t relp_batch_destroy(relp_batch* batch);
+int32_t relp_batch_workers(const relp_batch* batch, int32_t* n_workers);
+int32_t relp_batch_run(relp_batch* batch, const int32_t* schedule, int64_t n_tickets, int64_t (*next_ticket)(void* user), void* user,
+                       relp_batch_entry* entries, relp_batch_worker* workers, double* makespan_seconds);
+/* exact optimum "num/den" of ticket t of the last run (options.certify; RELP_ERR_STATE when there is none) */
+int32_t relp_batch_get_objective_exact(const relp_batch* batch, int64_t ticket, char* buffer, int32_t capacity, int32_t* length);
+/* the resident handle of (worker, model), e.g. for relp_get_record_json / relp_get_solution_exact after a run */
+int32_t relp_batch_handle(const relp_batch* batch, int32_t worker, int32_t model, relp_handle** out);
 
 /* Version / build info ("relp_amd <ver> gfx950"). */
 const char* relp_version(void);

@@ -49,6 +49,16 @@ class ExactResult(C.Structure):
                 ("redundant_rows", C.c_int32), ("reserved", C.c_int32), ("pivots_survived", C.c_int64 * 6)]
 
 
+class BatchEntry(C.Structure):
+    _fields_ = [("status", C.c_int32), ("model", C.c_int32), ("worker", C.c_int32), ("device", C.c_int32), ("result", Result),
+                ("start_seconds", C.c_double), ("end_seconds", C.c_double)]
+
+
+class BatchWorker(C.Structure):
+    _fields_ = [("device", C.c_int32), ("tickets", C.c_int32), ("pivots", C.c_int64), ("busy_seconds", C.c_double),
+                ("queue_seconds", C.c_double), ("idle_seconds", C.c_double), ("finish_seconds", C.c_double)]
+
+
 class Stats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("price_launches", C.c_int64), ("price_seconds", C.c_double),
                 ("update_seconds", C.c_double), ("ftran_seconds", C.c_double), ("price_bytes", C.c_int64),
@@ -73,6 +83,9 @@ SYMBOLS = [
     "relp_bi_left_multiply", "relp_bi_right_multiply", "relp_bi_basis_inverse_row", "relp_bi_generate_element",
     "relp_bi_change_basis", "relp_bi_should_refactor", "relp_bi_remove_basis_part", "relp_bi_statistics",
     "relp_bi_get_factors", "relp_lu_factor_host",
+    # exact solution vector, variable names, batches of independent LPs
+    "relp_get_solution_exact", "relp_get_variable_name",
+    "relp_batch_create", "relp_batch_destroy", "relp_batch_workers", "relp_batch_run", "relp_batch_get_objective_exact", "relp_batch_handle",
 ]
 
 
@@ -467,6 +480,29 @@ class Solver:
         self._check(lib().relp_get_objective_exact(self._h, buf, length.value + 1, C.byref(length)))
         return buf.value.decode()
 
+    def solution_exact(self, original=False):
+        """``OptimizationResult::FiniteOptimum(SparseVector<RationalBig>)`` in exact form (``relp_get_solution_exact``): a dict
+        index -> ``Fraction``.  ``original=False``: structural columns of the standard form after ``reconstruct_solution``;
+        ``original=True``: the variables of the file (``compute_full_solution_with_reduced_solution``), by file order."""
+        from fractions import Fraction
+        count, length = C.c_int32(), C.c_int64()
+        self._check(lib().relp_get_solution_exact(self._h, int(bool(original)), 0, C.byref(count), None, None, C.c_int64(0), C.byref(length)))
+        if count.value == 0:
+            return {}
+        index = np.zeros(count.value, dtype=np.int32)
+        buf = C.create_string_buffer(length.value)
+        self._check(lib().relp_get_solution_exact(self._h, int(bool(original)), count.value, C.byref(count), _ptr(index, C.c_int32), buf,
+                                                  C.c_int64(length.value), C.byref(length)))
+        texts = buf.value.decode().split("\n")
+        return {int(index[k]): Fraction(texts[k]) for k in range(count.value)}
+
+    def variable_name(self, j):
+        length = C.c_int32()
+        self._check(lib().relp_get_variable_name(self._h, int(j), None, 0, C.byref(length)))
+        buf = C.create_string_buffer(length.value + 1)
+        self._check(lib().relp_get_variable_name(self._h, int(j), buf, length.value + 1, C.byref(length)))
+        return buf.value.decode()
+
     def basis(self):
         out = np.zeros(self.m, dtype=np.int32)
         self._check(lib().relp_get_basis(self._h, _ptr(out, C.c_int32)))
@@ -574,3 +610,57 @@ class Solver:
         out = C.c_double()
         self._check(lib().relp_profile_kernel(self._h, int(which), int(repetitions), C.byref(out)))
         return out.value
+
+
+class Batch:
+    """``relp_batch_*``: independent LPs resident on the workers of one or more devices, served from one ticket queue by host
+    threads inside the library.  ``models``: ``Model`` objects (kept alive here)."""
+
+    TICKET_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p)
+
+    def __init__(self, models, devices=(0,), workers_per_device=1, options=None, **overrides):
+        self.models = list(models)
+        self.options = options or default_options(**overrides)
+        self._h = C.c_void_p()
+        handles = (C.c_void_p * len(self.models))(*[m._h for m in self.models])
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        error = C.create_string_buffer(512)
+        status = lib().relp_batch_create(handles, len(self.models), C.byref(self.options), _ptr(devs, C.c_int32), len(devs),
+                                         int(workers_per_device), C.byref(self._h), error, 512)
+        if status != OK:
+            self._h = None
+            raise RelpError(status, error.value.decode() or "relp_batch_create failed")
+        n = C.c_int32()
+        lib().relp_batch_workers(self._h, C.byref(n))
+        self.n_workers = n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().relp_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def run(self, schedule, next_ticket=None):
+        """Serve the tickets ``0 .. len(schedule)-1`` (ticket t = model ``schedule[t]``).  ``next_ticket``: optional callable
+        returning a fresh ticket per call (a queue shared with other processes).  Returns (entries, workers, makespan)."""
+        sched = np.ascontiguousarray(schedule, dtype=np.int32)
+        entries = (BatchEntry * len(sched))()
+        workers = (BatchWorker * self.n_workers)()
+        makespan = C.c_double()
+        callback = self.TICKET_FN(lambda _user: int(next_ticket())) if next_ticket is not None else None
+        fn = lib().relp_batch_run
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        status = fn(self._h, _ptr(sched, C.c_int32), len(sched), C.cast(callback, C.c_void_p) if callback else None, None,
+                    C.cast(entries, C.c_void_p), C.cast(workers, C.c_void_p), C.byref(makespan))
+        if status != OK:
+            raise RelpError(status, "relp_batch_run")
+        return list(entries), list(workers), makespan.value
+
+    def objective_exact(self, ticket):
+        length = C.c_int32()
+        if lib().relp_batch_get_objective_exact(self._h, C.c_int64(ticket), None, 0, C.byref(length)) != OK:
+            return None
+        buf = C.create_string_buffer(length.value + 1)
+        lib().relp_batch_get_objective_exact(self._h, C.c_int64(ticket), buf, length.value + 1, C.byref(length))
+        return buf.value.decode()

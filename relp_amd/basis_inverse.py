@@ -133,8 +133,9 @@ class BasisInverse:
         return bool(flag.value)
 
     def remove_basis_part(self, indices):
-        idx = np.array(list(indices) or [0], dtype=np.int32)
-        self._check(lib().relp_bi_remove_basis_part(self._h, len(list(indices)), _ptr(idx, C.c_int32)))
+        idx_list = list(indices)  # (a generator must be walked once only)
+        idx = np.array(idx_list or [0], dtype=np.int32)
+        self._check(lib().relp_bi_remove_basis_part(self._h, len(idx_list), _ptr(idx, C.c_int32)))
 
     def statistics(self):
         nl, nu = C.c_int64(), C.c_int64()

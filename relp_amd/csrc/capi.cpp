@@ -1,4 +1,5 @@
 // extern "C" boundary (include/relp_amd.h).  Plain pointers and sizes only; exceptions are mapped to status codes.
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -611,6 +612,102 @@ int32_t relp_get_original_solution(const relp_handle* h, int32_t capacity, doubl
     return RELP_OK;
 }
 
+// Exact back-mapping of general_form/mod.rs:753-771, 840-934 (the f64 twin is StandardForm::original_solution).
+static std::vector<BigRat> original_solution_exact(const StandardForm& form, const std::vector<BigRat>& standardised) {
+    const bool identity = form.active_to_original.empty();
+    std::vector<BigRat> out((size_t)form.nr_file_variables());
+    std::vector<char> known(out.size(), 0);
+    for (int j = 0; j < form.nr_original; ++j) {
+        BigRat x = standardised[j];
+        if (j < (int)form.free_negative_part.size() && form.free_negative_part[j] >= 0) x -= standardised[form.free_negative_part[j]];
+        x -= BigRat(form.data.variables[j].shift);
+        if (form.data.variables[j].flipped) x = -x;
+        const int original = identity ? j : form.active_to_original[j];
+        out[original] = x;
+        known[original] = 1;
+    }
+    bool progress = true;
+    while (progress) {
+        progress = false;
+        for (const auto& [original, how] : form.removed) {
+            if (known[original]) continue;
+            bool ready = true;
+            BigRat value(how.constant);
+            if (how.function_of_others)
+                for (const auto& [k, c] : how.coefficients) {
+                    if (!known[k]) { ready = false; break; }
+                    value -= BigRat(c) * out[k];
+                }
+            if (ready) {
+                out[original] = value;
+                known[original] = 1;
+                progress = true;
+            }
+        }
+    }
+    return out;
+}
+
+int32_t relp_get_solution_exact(const relp_handle* h, int32_t original, int32_t capacity, int32_t* count, int32_t* index,
+                                char* buffer, int64_t buffer_capacity, int64_t* length) {
+    REQUIRE_LOADED(h);
+    if (!count || capacity < 0 || buffer_capacity < 0) return RELP_ERR_ARGUMENT;
+    const Solver& sv = *h->solver;
+    if (!sv.exact_primal || sv.last_result.kind != RELP_RESULT_FINITE_OPTIMUM || !sv.last_result.certified) {
+        const_cast<relp_handle*>(h)->error = "no exact solution (set options.certify and solve to a certified finite optimum)";
+        return RELP_ERR_STATE;
+    }
+    try {
+        const StandardForm& form = sv.form();
+        const int n_structural = form.data.nr_normal_variables();
+        std::vector<std::pair<int, std::string>> values;
+        const auto basics = exact_primal_values(*sv.exact_primal);  // every provider column, slacks included
+        if (!original) {
+            for (const auto& entry : basics)  // reconstruct_solution (matrix_data.rs:402-411): the slack columns are dropped
+                if (entry.first < n_structural) values.push_back(entry);
+        } else {
+            std::vector<BigRat> standardised((size_t)n_structural);
+            for (const auto& [j, text] : basics)
+                if (j < n_structural) standardised[j] = BigRat::parse(text);
+            const std::vector<BigRat> full = original_solution_exact(form, standardised);
+            for (size_t j = 0; j < full.size(); ++j)
+                if (!full[j].is_zero()) values.push_back({(int)j, full[j].to_string()});
+        }
+        *count = (int32_t)values.size();
+        int64_t needed = 0;
+        for (const auto& entry : values) needed += (int64_t)entry.second.size() + 1;
+        if (length) *length = needed;
+        if (!index && !buffer) return RELP_OK;  // size query
+        if (capacity < *count || buffer_capacity < needed || !index || !buffer) return RELP_ERR_ARGUMENT;
+        int64_t at = 0;
+        for (size_t k = 0; k < values.size(); ++k) {
+            index[k] = values[k].first;
+            std::memcpy(buffer + at, values[k].second.data(), values[k].second.size());
+            at += (int64_t)values[k].second.size();
+            buffer[at++] = k + 1 < values.size() ? '\n' : '\0';
+        }
+        return RELP_OK;
+    } catch (const std::exception& e) {
+        const_cast<relp_handle*>(h)->error = e.what();
+        return RELP_ERR_NUMERICAL;
+    }
+}
+
+int32_t relp_get_variable_name(const relp_handle* h, int32_t j, char* buffer, int32_t capacity, int32_t* length) {
+    REQUIRE_LOADED(h);
+    const StandardForm& form = h->solver->form();
+    if (j < 0 || j >= form.nr_file_variables()) return RELP_ERR_ARGUMENT;
+    const std::string name = !form.all_column_names.empty() ? form.all_column_names[j]
+                             : j < (int)form.column_names.size() ? form.column_names[j] : "X" + std::to_string(j);
+    if (length) *length = (int32_t)name.size();
+    if (buffer && capacity > 0) {
+        const int32_t nbytes = std::min<int32_t>((int32_t)name.size(), capacity - 1);
+        std::memcpy(buffer, name.data(), nbytes);
+        buffer[nbytes] = 0;
+    }
+    return RELP_OK;
+}
+
 int32_t relp_get_objective_exact(const relp_handle* h, char* buffer, int32_t capacity, int32_t* length) {
     REQUIRE_LOADED(h);
     const std::string& s = h->solver->exact_objective;
@@ -625,6 +722,17 @@ int32_t relp_get_objective_exact(const relp_handle* h, char* buffer, int32_t cap
         buffer[nbytes] = 0;
     }
     return RELP_OK;
+}
+
+// (the name comes from the NAME record of an MPS file: untrusted text)
+static std::string json_escaped(const std::string& text) {
+    std::string out;
+    for (unsigned char ch : text) {
+        if (ch == '"' || ch == '\\') { out.push_back('\\'); out.push_back((char)ch); }
+        else if (ch < 0x20) { char buf[8]; std::snprintf(buf, sizeof buf, "\\u%04x", ch); out += buf; }
+        else out.push_back((char)ch);
+    }
+    return out;
 }
 
 // One JSON object per solved LP (metrics / observability -- the reference has none): dimensions, pivots per
@@ -643,7 +751,7 @@ int32_t relp_get_record_json(const relp_handle* h, char* buffer, int32_t capacit
     std::ostringstream out;
     out.precision(17);
     static const char* presolve_states[] = {"off", "applied", "applied without the implied bounds beyond 126 bits", "dropped (did not fit the host model)"};
-    out << "{\"name\": \"" << sv.form().name << "\", \"presolve\": \"" << presolve_states[sv.form().presolve_state & 3] << "\", \"m\": " << md.nr_rows() << ", \"n\": " << md.nr_columns() << ", \"nnz\": " << nnz
+    out << "{\"name\": \"" << json_escaped(sv.form().name) << "\", \"presolve\": \"" << presolve_states[sv.form().presolve_state & 3] << "\", \"m\": " << md.nr_rows() << ", \"n\": " << md.nr_columns() << ", \"nnz\": " << nnz
         << ", \"device_rows\": " << d.m << ", \"artificials\": " << d.n_art << ", \"result\": \"" << kinds[r.kind >= 0 && r.kind <= 4 ? r.kind : 0]
         << "\", \"carry\": \"" << (h->options.carry == RELP_CARRY_LU ? "lu" : "explicit") << "\", \"pivots_phase_one\": " << r.pivots_phase_one
         << ", \"pivots_phase_two\": " << r.pivots_phase_two << ", \"polishes\": " << r.polishes << ", \"refactors\": " << r.refactors
@@ -687,7 +795,7 @@ int32_t relp_solve_exact(relp_handle* h, int32_t first_limbs, int32_t max_limbs,
         result->limbs = limbs;
         result->pivots_phase_one = p1;
         result->pivots_phase_two = p2;
-        result->trace_entries = (int32_t)(tr.size() / 4);
+        result->trace_entries = (int32_t)std::min<size_t>(tr.size() / 4, (size_t)trace_capacity);  // never more than were copied
         for (size_t k = 0; k < survived.size() && k < 6; ++k) {
             result->limbs_tried[k] = survived[k].first;
             result->pivots_survived[k] = survived[k].second;

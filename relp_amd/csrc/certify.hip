@@ -639,8 +639,29 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
 //         phase_one.rs:123-179) with a POSITIVE optimum -- the dual solution y is a Farkas certificate (y'A <= 0, y'b > 0).
 // mode 2: the LP is UNBOUNDED along provider column `entering`: x_B >= 0, cbar_q < 0 and B^-1 a_q <= 0 exactly
 //         (phase_two.rs:53; zero on the rows whose basic variable is a zero-level artificial).
+struct ExactPrimal {  // (declared in solver.hpp)
+    std::vector<int> basis;     // provider column per row (-1-k: artificial k, value 0)
+    std::vector<BigInt> numer;  // x_B[k] = numer[k] / denom
+    BigInt denom;
+};
+std::vector<std::pair<int, std::string>> exact_primal_values(const ExactPrimal& primal) {
+    std::vector<std::pair<int, std::string>> out;
+    for (size_t k = 0; k < primal.basis.size(); ++k) {
+        if (primal.basis[k] < 0 || primal.numer[k].sign() == 0) continue;
+        BigInt n = primal.numer[k], d = primal.denom;
+        if (d.sign() < 0) { n = -n; d = -d; }
+        const BigInt g = BigInt::gcd(n, d);
+        if (!g.is_zero() && !(g == BigInt(1))) { n = n / g; d = d / g; }
+        out.push_back({primal.basis[k], n.to_string() + "/" + d.to_string()});
+    }
+    std::sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    return out;
+}
+
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_columns, int device, hipStream_t stream,
-                   std::string* objective, bool* certified, long long* repair_pivots, std::string* message, int mode, int entering) {
+                   std::string* objective, bool* certified, long long* repair_pivots, std::string* message, int mode, int entering,
+                   std::shared_ptr<const ExactPrimal>* primal) {
+    if (primal) primal->reset();
     objective->clear();
     *certified = false;
     *repair_pivots = 0;
@@ -1028,6 +1049,13 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             *objective = num.to_string() + "/" + den.to_string();
             *certified = true;
             *repair_pivots = round;
+            if (primal) {  // OptimizationResult::FiniteOptimum(x) in exact form (algorithm/mod.rs:43-47), kept as integers over one denominator
+                auto kept = std::make_shared<ExactPrimal>();
+                kept->basis = basis;
+                kept->numer = std::move(x.numer);
+                kept->denom = x.denom;
+                *primal = kept;
+            }
             return;
         }
         if (round == max_repairs) break;

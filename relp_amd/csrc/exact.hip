@@ -636,6 +636,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             big_store(lp.N + (size_t)idx * L, quotient);
         }
         if (flip) {
+            __syncthreads();  // row p is an operand of every other row above: nobody may still be reading it
             for (int k = tid; k < m; k += T) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
             ap = big_negate(ap);
         }

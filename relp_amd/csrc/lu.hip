@@ -259,7 +259,11 @@ static size_t lu_lds_bytes_for(int m, int max_updates) {
     return LU_LDS_TOTAL - 2048;  // always the whole CU: one workgroup per solve, and the factor area takes what is left
 }
 size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_.m, d_.max_updates); }
-bool lu_fits_lds(int m) { return lu_lds_fixed_bytes(m, 32) + 16 * 1024 <= LU_LDS_TOTAL - 2048; }
+bool lu_fits_lds(int m, int max_updates) {
+    if (max_updates < 1) max_updates = 1;
+    if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
+    return lu_lds_fixed_bytes(m, max_updates) + 16 * 1024 <= LU_LDS_TOTAL - 2048;
+}
 
 // =====================================================================================================
 // device: level-scheduled triangular solves out of LDS
@@ -1493,7 +1497,7 @@ void launch_lu_row_scan(const DeviceLP& d, const double* rowvec, double tol, hip
 LuBasis::LuBasis(int device, int m, const LuOptions& options, int refactor_period)
     : device_(device), m_(m), period_(std::min(refactor_period > 0 ? refactor_period : 31, LU_MAX_SLOTS - 1)), options_(options) {
     if (m < 1) throw std::invalid_argument("m < 1");
-    if (!lu_fits_lds(m)) throw std::invalid_argument("m too large for the LDS-resident LU solve");
+    if (!lu_fits_lds(m, period_ + 1)) throw std::invalid_argument("m too large for the LDS-resident LU solve with this refactor period");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw DeviceError("no HIP device available (relp_amd has no CPU fallback)");
     if (device < 0 || device >= count) throw DeviceError("device ordinal out of range");
@@ -1614,10 +1618,14 @@ void LuBasis::change_basis(int pivot_row) {  // lower_upper/mod.rs:94-178
     RELP_HIP(hipSetDevice(device_));
     launch_lu_update(lu_.device(), pivot_row, stream_);
     RELP_HIP(hipStreamSynchronize(stream_));
+    const int fl = flags();
+    if (fl & LU_FLAG_OVERFLOW) {  // the kernel made no update: the host copy of the basis must not move either
+        const int zero = 0;
+        RELP_HIP(hipMemcpy(lu_.device().state + LU_FLAGS, &zero, sizeof(int), hipMemcpyHostToDevice));
+        throw std::runtime_error("no room for another update: refactor first (should_refactor)");
+    }
     columns_[pivot_row] = last_column_;
     have_spike_ = false;
-    const int fl = flags();
-    if (fl & LU_FLAG_OVERFLOW) throw std::runtime_error("no room for another update: refactor first (should_refactor)");
     if (fl & LU_FLAG_UNSTABLE) throw std::runtime_error("singular basis after the update");
 }
 int LuBasis::updates() {

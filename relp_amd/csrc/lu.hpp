@@ -85,7 +85,7 @@ private:
 
 // kernels (lu.hip); all single-workgroup, stream-ordered
 constexpr int LU_THREADS = 1024;
-bool lu_fits_lds(int m);
+bool lu_fits_lds(int m, int max_updates);  // max_updates: the update slots the kernels will be given (T is max_updates^2 doubles of LDS)
 // FTRAN of a sparse column (device arrays rows / vals, original row indices): out[slot] (m doubles); the spike stays in lu.spike
 void launch_lu_ftran(const DeviceLU& lu, const int* rows, const double* vals, int nnz, double* out, int keep_spike, hipStream_t s);
 // FTRAN of a dense right-hand side (original row order)

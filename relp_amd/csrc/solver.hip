@@ -61,7 +61,7 @@ void launch_relative_cost(const DeviceLP& d, double* out, hipStream_t s);
 // certify.hip
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_provider_columns, int device,
                    hipStream_t stream, std::string* objective, bool* certified, long long* repair_pivots,
-                   std::string* message, int mode, int entering);
+                   std::string* message, int mode, int entering, std::shared_ptr<const ExactPrimal>* primal);
 
 namespace {
 double now_seconds() {
@@ -210,7 +210,7 @@ void Solver::upload() {
     refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : 31, LU_MAX_SLOTS - 1);  // T is solved by one wave
     if (lu_mode_) {
         if (bounded_) throw std::invalid_argument("the LU carry does not take implicit bounds (use carry = RELP_CARRY_EXPLICIT)");
-        if (!lu_fits_lds(m)) throw std::invalid_argument("the LU carry keeps its solve vectors and factor headers in LDS: at most about 3200 rows (use the explicit carry beyond)");
+        if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its solve vectors and factor headers in LDS: at most about 3200 rows (use the explicit carry beyond)");
     }
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
     // structural columns); steepest edge only (the dense kernel implements that rule)
@@ -1292,6 +1292,7 @@ void Solver::solve(relp_result* result) {
     const double t0 = now_seconds();
     relp_result res{};
     exact_objective.clear();
+    exact_primal.reset();
     const bool timing = getenv("RELP_TIME_SOLVE") != nullptr;  // diagnostic: host-side timeline of one solve
     double t_last = t0;
     auto tick = [&](const char* what) {
@@ -1448,7 +1449,7 @@ void Solver::certify(relp_result* result) {
     std::string message;
     try {
         const int mode = result->kind == RELP_RESULT_INFEASIBLE ? 1 : result->kind == RELP_RESULT_UNBOUNDED ? 2 : 0;
-        certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message, mode, unbounded_column_);
+        certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message, mode, unbounded_column_, &exact_primal);
     } catch (const RatOverflow& e) {  // the f64 result stands; it is reported uncertified with the reason
         ok = false;
         message = std::string("exact certificate: ") + e.what();
@@ -1704,6 +1705,10 @@ double Solver::profile_kernel(int which, int repetitions) {
         long long bytes = 0;
         for (int j = d_.n_art; j < d_.n; ++j) {
             if (pos[j] >= 0) continue;
+            if (d_.cost8) {  // generated incidence column: 8 B of endpoints, 1 B cost, 4 B position
+                bytes += 13;
+                continue;
+            }
             const bool dense_col = j >= d_.dense_first && j < d_.dense_first + d_.n_dense;
             bytes += dense_col ? (long long)m * dense_entry_bytes_ : (long long)(cs[j + 1] - cs[j]) * 12;
             bytes += 24;  // cost, gamma read + gamma write

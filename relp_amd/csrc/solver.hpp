@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -15,6 +16,11 @@
 #include "lu.hpp"
 
 namespace relp {
+
+// Exact primal solution of a certified basis: x_B[k] = numer[k] / denom for the provider column basis[k] (certify.hip).
+struct ExactPrimal;
+// (provider column, "num/den" reduced) for every basic provider column with a non-zero exact value, ascending column
+std::vector<std::pair<int, std::string>> exact_primal_values(const ExactPrimal& primal);
 
 // Device control block, written by single-workgroup kernels, polled by the host.
 struct Ctl {
@@ -188,6 +194,8 @@ public:
     void reset_stats();
     int n_art() const { return d_.n_art; }
     std::string exact_objective;  // filled by certify()
+    // exact x_B of the certified optimal basis (certify.hip keeps the big integers; strings are made on demand)
+    std::shared_ptr<const ExactPrimal> exact_primal;
     std::string last_error;
     relp_result last_result{};
 

@@ -64,3 +64,14 @@ def test_basis_inverse_object_has_no_cpu_fallback():
     with pytest.raises(relp_amd.RelpError) as info:
         BasisInverse.invert([[(0, 1.0)], [(1, 1.0)]])
     assert info.value.status == relp_amd.api.ERR_DEVICE
+
+
+def test_batch_needs_a_device_too():
+    """`relp_batch_create` builds handles with `relp_create`: no device, no batch (and nothing leaks)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    model = relp_amd.Model(os.path.join(ROOT, "data", "netlib", "AFIRO.SIF"))
+    with pytest.raises(relp_amd.RelpError) as info:
+        relp_amd.Batch([model])
+    assert info.value.status == relp_amd.api.ERR_DEVICE

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_default_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2",
-                          "--no-dense-roofline", "--no-concurrency-probe"], capture_output=True, text=True, timeout=900)
+                          "--no-configs", "--no-concurrency-probe"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -33,6 +33,53 @@ def test_default_bench_line_contract():
     assert roofline["peak"] == 8000.0 and abs(roofline["frac"] - roofline["achieved"] / roofline["peak"]) < 1e-12
     assert roofline["kernel"] == max(roofline["kernels"], key=lambda k: roofline["kernels"][k]["seconds_per_launch"])  # by measured time
     assert roofline["traffic"] is None or roofline["traffic"] > 0
+    # `frac` is priced on the contract's bytes; the kernel's own bytes are reported beside it
+    assert roofline["contract_bytes_per_pivot"]["per_pivot"] == roofline["contract_bytes_per_pivot"]["pricing"] + roofline["contract_bytes_per_pivot"]["ftran_btran_vectors"]
+    assert roofline["kernel_bytes_per_launch"] > 0 and roofline["factor_nonzeros"] > 821
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert cpu["nproc"] >= 1 and cpu["cpu_model"]  # stated in every report
+    assert line["cpu_baseline_tuned"]["mode"] == "tuned" and line["cpu_baseline_tuned"]["value"] > 0
     assert line["value"] > cpu["value"]  # (no fixed factor: the suite may share the GPU with another test process)
+    assert line["config"]["tolerances"]["tol_dual"] == 1e-9 and "harris" in line["config"]["ratio_rule"]
+    assert line["config"]["exact"]["solution_exact_nonzeros"] > 0
+
+
+def test_netlib_batch_line_through_the_library_batch_entry():
+    """`bench.py --workload netlib --steps 1`: the batch runner (relp_batch_run, four LPs in flight) on one GPU."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "netlib", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    config = line["config"]
+    assert line["n_gpus"] == 1 and config["tickets_per_rank"] == [45] and config["objectives_outside_reference_tolerance"] == []
+    assert config["lps_in_flight_per_gpu"] == 4 and len(config["workers_per_rank"][0]) == 4
+    assert sum(w["tickets"] for w in config["workers_per_rank"][0]) == 45
+    assert 0 < config["single_pass_makespan_s"] <= config["makespan_s"] and config["longest_lp"]
+    assert line["value"] > 1000 and "suite throughput" in config["throughput_kind"]
+
+
+def test_default_bench_line_carries_every_baseline_config():
+    """The driver's default invocation: the headline and, under `configs`, every other BASELINE config with its own value, roofline
+    and CPU baseline (short CPU legs here)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    configs = line["configs"]
+    assert set(configs) == {"lu_carry_25fv47", "dense4096_f64", "dense4096_narrowest", "netlib_batch", "netlib_batch_presolve",
+                            "maxflow_reference_start", "maxflow_crash"}
+    for name, entry in configs.items():
+        assert "error" not in entry, (name, entry)
+        assert entry["value"] > 0 and entry["ms_per_step"] > 0 and entry["unit"] == "pivots/s", name
+        assert entry["roofline"]["frac"] > 0 and entry["roofline"]["peak"] == 8000.0, name
+        assert entry["cpu_baseline"]["value"] > 0 and entry["cpu_baseline"]["nproc"] >= 1, name
+    assert configs["lu_carry_25fv47"]["config"]["carry"] == "lu" and configs["lu_carry_25fv47"]["config"]["exact"]["certified"] is True
+    assert abs(configs["dense4096_f64"]["config"]["objective"] + 202885.40946447) < 1e-4
+    assert abs(configs["dense4096_narrowest"]["config"]["objective"] + 202885.40946447) < 1e-4
+    assert configs["dense4096_f64"]["roofline"]["kernel"] == "price" and configs["dense4096_f64"]["roofline"]["frac"] > 0.4
+    assert configs["netlib_batch"]["config"]["objectives_outside_reference_tolerance"] == []
+    assert configs["netlib_batch_presolve"]["config"]["objectives_outside_reference_tolerance"] == []
+    assert abs(configs["maxflow_reference_start"]["config"]["objective"] + 778.0) < 1e-9
+    assert abs(configs["maxflow_crash"]["config"]["objective"] + 778.0) < 1e-9
+    assert configs["maxflow_crash"]["cpu_baseline"]["scipy_max_flow"]["flow_value"] == 778

@@ -361,7 +361,7 @@ def test_bench_rccl_path_runs_at_world_size_one():
     env = dict(os.environ, RELP_FORCE_DISTRIBUTED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                          "--no-dense-roofline", "--no-concurrency-probe"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-configs", "--no-concurrency-probe"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2
@@ -393,7 +393,7 @@ def test_bench_two_ranks_over_rccl(workload):
     config = line["config"]
     assert config["makespan_s"] > 0
     if workload == "netlib":
-        assert len(config["problems_per_rank"]) == 2 and sum(config["problems_per_rank"]) == 2 * 45
+        assert len(config["tickets_per_rank"]) == 2 and sum(config["tickets_per_rank"]) == 2 * 45
         assert config["objectives_outside_reference_tolerance"] == []
     else:
         assert [r["rank"] for r in config["per_rank"]] == [0, 1]
@@ -416,7 +416,8 @@ def test_bench_max_flow_workload_line(crash):
     assert line["unit"] == "pivots/s" and line["n_gpus"] == 1 and line["value"] > 0
     assert abs(line["config"]["objective"] + 421.0) < 1e-9            # scipy's max-flow value on this graph
     assert set(line["roofline"]["kernels"]) == {"price", "ftran_ratio", "update"}
-    assert all(k["seconds_per_launch"] > 0 and k["algorithmic_bytes_per_launch"] > 0 for k in line["roofline"]["kernels"].values())
+    assert all(k["seconds_per_launch"] > 0 and k["contract_bytes_per_launch"] > 0 and k["kernel_bytes_per_launch"] > 0
+               for k in line["roofline"]["kernels"].values())
     if crash:
         assert line["config"]["pivots_per_solve"] < 1000
     else:
