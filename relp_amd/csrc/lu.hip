@@ -7,13 +7,17 @@
 //   change_basis (Forrest-Tomlin)               mod.rs:94-178
 //   EtaFile::{apply_right, apply_left, update_spike_pivot_value}   eta_file.rs:49-134
 //
-// Design (MI355X): one LP's factor is a few 10^4 non-zeros; a triangular solve with it is a dependency DAG, not a stream.
-// ONE workgroup (16 waves on one CU) owns the solve; the vector(s) and the factor being solved with are staged in LDS
-// (`lu_stage_and_solve`).  The host's refactorisation also produces the level sets of L, U, U' and L' (`lu_schedules`); a
-// WIDE level is solved by all threads followed by one barrier, a run of NARROW levels (the long tail every sparse factor has)
-// by wave 0 alone without barriers, several lanes per row, as a software pipeline over the levels.  Forrest-Tomlin updates do
-// not touch those schedules: the spiked columns are bordered into a dense trailing block T (<= 64 x 64) that one wave solves
-// out of registers (lu.hpp).  The reference walks ordered maps (`BTreeMap`) with a column scan per popped entry; here both
+// Design (MI355X): one LP's factor is a few 10^4 non-zeros; a triangular solve with it is a dependency DAG, not a stream, and
+// its cost is the LENGTH of its longest chain times the latency of one hop.  ONE workgroup (16 waves on one CU) owns a solve
+// with the vector(s) in LDS, where a hop is a ds_read (~100 cycles) -- across workgroups a hop is an L2 / fabric round trip
+// (0.8-1 us, MI355X_MICROARCH.md "handoff"), ten times as much, so more CUs would only make a Netlib-sized solve slower.  The
+// solve is SYNCHRONISATION-FREE (`lu_solve_tasks`): every row of the factor is a task owned by a lane (or, a long row, by a
+// wave); a task polls its operands in LDS -- an unsolved component holds a sentinel NaN -- and publishes its own component
+// the moment the last operand arrives.  No barrier and no level loop inside a solve: a level costs one LDS round trip
+// instead of the ~1 k cycles of round 2's barrier-per-level schedule.  The host's refactorisation lays the tasks out in
+// dependency order (`LuTasks`, lu.hpp).  Forrest-Tomlin updates do not touch the task lists: a replaced position is
+// bordered into a dense trailing block T (<= 64 x 64) that one wave solves out of registers, and its old row and column are
+// MASKED, not removed (lu.hpp).  The reference walks ordered maps (`BTreeMap`) with a column scan per popped entry; here both
 // orientations of L and U are resident so every solve is a gather.  Everything is deterministic: a row adds its entries in
 // storage order, reductions have a fixed tree.
 #include "lu.hpp"
@@ -66,11 +70,10 @@ struct Carver {
     }
 };
 
-__global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu, const int* n_levels) {
+__global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
     const int m = lu.m;
     const int stride = blockDim.x * gridDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = first; i < m; i += stride) {
-        lu.u_rlen[i] = lu.u_rstart[i + 1] - lu.u_rstart[i];
         lu.app_len[i] = 0;
         lu.slot_of[i] = -1;
     }
@@ -85,9 +88,57 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu, const int* n_
         lu.state[LU_S_TOP] = 0;
         lu.state[LU_ETA_TOP] = 0;
         lu.state[LU_FLAGS] = 0;
-        for (int k = 0; k < 4; ++k) lu.state[LU_N_LEVELS + k] = n_levels[k];
         lu.eta_start[0] = 0;
     }
+}
+
+// One orientation of one triangular factor -> task list (lu.hpp `LuTasks`).  `start` / `idx` / `val`: its rows (CSR over the
+// position space), `level[i]`: dependency level of row i (0: reads nothing).  Rows are taken in level order; the epochs cut
+// that order wherever the owners' registers are full, so a task's operands are always tasks of its own or an earlier epoch.
+struct HostTasks {
+    std::vector<int> z_pos, t_pos, t_n, t_col, w_pos, w_start, w_n, w_idx, ep_t, ep_w;
+    std::vector<double> t_val, w_val;
+};
+void build_tasks(int m, int stride, const int* start, const int* idx, const double* val, const std::vector<int>& order, HostTasks& out) {
+    out = HostTasks{};
+    out.t_col.assign((size_t)LU_TE * stride, 0);
+    out.t_val.assign((size_t)LU_TE * stride, 0.0);
+    out.ep_t.push_back(0);
+    out.ep_w.push_back(0);
+    int in_epoch_t = 0, in_epoch_w = 0;
+    for (int r = 0; r < m; ++r) {
+        const int i = order[r];
+        const int n = start[i + 1] - start[i];
+        if (n == 0) {
+            out.z_pos.push_back(i);
+            continue;
+        }
+        const bool thread_task = n <= LU_TE;
+        if ((thread_task && in_epoch_t == LU_EPOCH_T) || (!thread_task && in_epoch_w == LU_EPOCH_W)) {
+            out.ep_t.push_back((int)out.t_pos.size());
+            out.ep_w.push_back((int)out.w_pos.size());
+            in_epoch_t = in_epoch_w = 0;
+        }
+        if (thread_task) {
+            const int k = (int)out.t_pos.size();
+            out.t_pos.push_back(i);
+            out.t_n.push_back(n);
+            for (int e = 0; e < n; ++e) {
+                out.t_col[(size_t)e * stride + k] = idx[start[i] + e];
+                out.t_val[(size_t)e * stride + k] = val[start[i] + e];
+            }
+            ++in_epoch_t;
+        } else {
+            out.w_pos.push_back(i);
+            out.w_start.push_back((int)out.w_idx.size());
+            out.w_n.push_back(n);
+            out.w_idx.insert(out.w_idx.end(), idx + start[i], idx + start[i] + n);
+            out.w_val.insert(out.w_val.end(), val + start[i], val + start[i] + n);
+            ++in_epoch_w;
+        }
+    }
+    out.ep_t.push_back((int)out.t_pos.size());
+    out.ep_w.push_back((int)out.w_pos.size());
 }
 }  // namespace
 
@@ -104,26 +155,71 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
     const size_t cl = cap_l_, cu = cap_u_;
     const int ldt = max_updates + 1;
+    const int stride = (m + 63) & ~63;
+    // ---- host: the four orientations and their task lists -----------------------------------------------------------------
+    HostLU& fs = const_cast<HostLU&>(f);
+    if (fs.lev_row[0].empty()) lu_schedules(fs);
+    std::vector<int> lcs(m + 1, 0), lcrow(nl), ucs(m + 1, 0), ucrow(nu);
+    std::vector<double> lcval(nl), ucval(nu);
+    {   // column orientation of L and U (counting transposes)
+        for (size_t e = 0; e < nl; ++e) lcs[f.l_col[e] + 1]++;
+        for (size_t e = 0; e < nu; ++e) ucs[f.u_col[e] + 1]++;
+        for (int j = 0; j < m; ++j) {
+            lcs[j + 1] += lcs[j];
+            ucs[j + 1] += ucs[j];
+        }
+        std::vector<int> fill_l(lcs.begin(), lcs.end() - 1), fill_u(ucs.begin(), ucs.end() - 1);
+        for (int i = 0; i < m; ++i) {
+            for (int e = f.l_start[i]; e < f.l_start[i + 1]; ++e) {
+                const int dst = fill_l[f.l_col[e]]++;
+                lcrow[dst] = i;
+                lcval[dst] = f.l_val[e];
+            }
+            for (int e = f.u_start[i]; e < f.u_start[i + 1]; ++e) {
+                const int dst = fill_u[f.u_col[e]]++;
+                ucrow[dst] = i;
+                ucval[dst] = f.u_val[e];
+            }
+        }
+    }
+    HostTasks tasks[4];
+    build_tasks(m, stride, f.l_start.data(), f.l_col.data(), f.l_val.data(), f.lev_row[0], tasks[0]);
+    build_tasks(m, stride, f.u_start.data(), f.u_col.data(), f.u_val.data(), f.lev_row[1], tasks[1]);
+    build_tasks(m, stride, ucs.data(), ucrow.data(), ucval.data(), f.lev_row[2], tasks[2]);
+    build_tasks(m, stride, lcs.data(), lcrow.data(), lcval.data(), f.lev_row[3], tasks[3]);
     // ---- uploaded prefix ----------------------------------------------------------------------------------------------
     Carver c;
     const size_t o_rowpos = c.take<int>(m), o_colpos = c.take<int>(m);
-    const size_t o_lrs = c.take<int>(m + 1), o_lcs = c.take<int>(m + 1), o_urs = c.take<int>(m + 1), o_ucs = c.take<int>(m);
-    const size_t o_uclen = c.take<int>(m);
+    const size_t o_lrs = c.take<int>(m + 1), o_lcs = c.take<int>(m + 1), o_urs = c.take<int>(m + 1), o_ucs = c.take<int>(m + 1);
     const size_t o_diag = c.take<double>(m);
-    const size_t o_lrcol = c.take<int>(cl), o_lcrow = c.take<int>(cl);
-    const size_t o_lrval = c.take<double>(cl), o_lcval = c.take<double>(cl);
-    size_t o_sched_start[4], o_sched_row[4];
+    const size_t o_counts = c.take<int>(4 * LU_CNT_WORDS);
+    const size_t o_tasks = c.take<LuTasks>(4);
+    struct TaskOffsets {
+        size_t z_pos, t_pos, t_n, w_pos, w_start, w_n, ep_t, ep_w, t_col, t_val, w_idx, w_val;
+    } to[4];
     for (int k = 0; k < 4; ++k) {
-        o_sched_start[k] = c.take<int>(m + 2);
-        o_sched_row[k] = c.take<int>(m);
+        to[k].z_pos = c.take<int>(m);
+        to[k].t_pos = c.take<int>(m);
+        to[k].t_n = c.take<int>(m);
+        to[k].w_pos = c.take<int>(m);
+        to[k].w_start = c.take<int>(m);
+        to[k].w_n = c.take<int>(m);
+        to[k].ep_t = c.take<int>(LU_MAX_EPOCHS + 2);
+        to[k].ep_w = c.take<int>(LU_MAX_EPOCHS + 2);
     }
-    const size_t o_nlev = c.take<int>(4);
+    const size_t small_bytes = c.offset;  // everything up to here goes in one copy
+    for (int k = 0; k < 4; ++k) {
+        const size_t cap = (k == 0 || k == 3) ? cl : cu;
+        to[k].t_col = c.take<int>((size_t)LU_TE * stride);
+        to[k].t_val = c.take<double>((size_t)LU_TE * stride);
+        to[k].w_idx = c.take<int>(cap);
+        to[k].w_val = c.take<double>(cap);
+    }
+    const size_t o_lrcol = c.take<int>(cl), o_lcrow = c.take<int>(cl), o_lrval = c.take<double>(cl), o_lcval = c.take<double>(cl);
+    const size_t o_urcol = c.take<int>(cu), o_ucrow = c.take<int>(cu), o_urval = c.take<double>(cu), o_ucval = c.take<double>(cu);
     const size_t upload_bytes = c.offset;
-    // ---- device only (the four U_bb arrays are uploaded one by one) ----------------------------------------------------
+    // ---- device only ----------------------------------------------------------------------------------------------------------
     const size_t app = (size_t)m * max_updates;
-    const size_t o_urcol = c.take<int>(cu), o_ucrow = c.take<int>(cu);
-    const size_t o_urval = c.take<double>(cu), o_ucval = c.take<double>(cu);
-    const size_t o_urlen = c.take<int>(m);
     const size_t o_applen = c.take<int>(m), o_appslot = c.take<int>(app), o_appval = c.take<double>(app);
     const size_t o_scs = c.take<int>(max_updates), o_scl = c.take<int>(max_updates), o_scrow = c.take<int>(app), o_scval = c.take<double>(app);
     const size_t o_T = c.take<double>((size_t)max_updates * ldt);
@@ -133,81 +229,89 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t o_spike = c.take<double>(m);
     const size_t o_state = c.take<int>(LU_STATE_WORDS);
     const size_t device_bytes = c.offset;
-    // staging: prefix + the four compact U arrays
-    Carver s;
-    s.offset = upload_bytes;
-    const size_t s_urcol = s.take<int>(nu), s_ucrow = s.take<int>(nu), s_urval = s.take<double>(nu), s_ucval = s.take<double>(nu);
     {
         char* before = dev_;
-        reserve(device_bytes, s.offset);
+        reserve(device_bytes, upload_bytes);
         if (dev_ != before) layout_changed = true;
     }
 
     char* h = staging_;
-    std::memcpy(h + o_rowpos, f.rowpos.data(), m * sizeof(int));
-    std::memcpy(h + o_colpos, f.colpos.data(), m * sizeof(int));
-    std::memcpy(h + o_lrs, f.l_start.data(), (m + 1) * sizeof(int));
-    std::memcpy(h + o_urs, f.u_start.data(), (m + 1) * sizeof(int));
-    if (nl) {
-        std::memcpy(h + o_lrcol, f.l_col.data(), nl * sizeof(int));
-        std::memcpy(h + o_lrval, f.l_val.data(), nl * sizeof(double));
-    }
-    std::memcpy(h + o_diag, f.diag.data(), m * sizeof(double));
+    auto put_i = [&](size_t at, const std::vector<int>& v) { if (!v.empty()) std::memcpy(h + at, v.data(), v.size() * sizeof(int)); };
+    auto put_d = [&](size_t at, const std::vector<double>& v) { if (!v.empty()) std::memcpy(h + at, v.data(), v.size() * sizeof(double)); };
+    put_i(o_rowpos, f.rowpos);
+    put_i(o_colpos, f.colpos);
+    put_i(o_lrs, f.l_start);
+    put_i(o_lcs, lcs);
+    put_i(o_urs, f.u_start);
+    put_i(o_ucs, ucs);
+    put_d(o_diag, f.diag);
     {
-        HostLU& fs = const_cast<HostLU&>(f);
-        if (fs.lev_row[0].empty()) lu_schedules(fs);
-        int* nlev = reinterpret_cast<int*>(h + o_nlev);
+        auto I = [&](size_t o) { return reinterpret_cast<int*>(dev_ + o); };
+        auto D = [&](size_t o) { return reinterpret_cast<double*>(dev_ + o); };
+        LuTasks* table = reinterpret_cast<LuTasks*>(h + o_tasks);
         for (int k = 0; k < 4; ++k) {
-            std::memcpy(h + o_sched_start[k], f.lev_start[k].data(), f.lev_start[k].size() * sizeof(int));
-            std::memcpy(h + o_sched_row[k], f.lev_row[k].data(), m * sizeof(int));
-            nlev[k] = (int)f.lev_start[k].size() - 1;
+            LuTasks t;
+            t.z_pos = I(to[k].z_pos);
+            t.t_pos = I(to[k].t_pos); t.t_n = I(to[k].t_n); t.t_col = I(to[k].t_col); t.t_val = D(to[k].t_val);
+            t.w_pos = I(to[k].w_pos); t.w_start = I(to[k].w_start); t.w_n = I(to[k].w_n); t.w_idx = I(to[k].w_idx); t.w_val = D(to[k].w_val);
+            t.ep_t = I(to[k].ep_t); t.ep_w = I(to[k].ep_w);
+            std::memcpy(&table[k], &t, sizeof(LuTasks));
         }
     }
-    // column orientation of L and U (counting transposes)
-    {
-        int* lcs = reinterpret_cast<int*>(h + o_lcs);
-        int* lcrow = reinterpret_cast<int*>(h + o_lcrow);
-        double* lcval = reinterpret_cast<double*>(h + o_lcval);
-        std::fill(lcs, lcs + m + 1, 0);
-        for (size_t e = 0; e < nl; ++e) lcs[f.l_col[e] + 1]++;
-        for (int j = 0; j < m; ++j) lcs[j + 1] += lcs[j];
-        std::vector<int> fill(lcs, lcs + m);
-        for (int i = 0; i < m; ++i)
-            for (int e = f.l_start[i]; e < f.l_start[i + 1]; ++e) {
-                const int dst = fill[f.l_col[e]]++;
-                lcrow[dst] = i;
-                lcval[dst] = f.l_val[e];
+    int* counts = reinterpret_cast<int*>(h + o_counts);
+    for (int k = 0; k < 4; ++k) {
+        const HostTasks& t = tasks[k];
+        const int epochs = (int)t.ep_t.size() - 1;
+        if (epochs > LU_MAX_EPOCHS) throw std::runtime_error("LU task list: too many epochs");
+        counts[k * LU_CNT_WORDS + LU_CNT_Z] = (int)t.z_pos.size();
+        counts[k * LU_CNT_WORDS + LU_CNT_T] = (int)t.t_pos.size();
+        counts[k * LU_CNT_WORDS + LU_CNT_W] = (int)t.w_pos.size();
+        counts[k * LU_CNT_WORDS + LU_CNT_EPOCHS] = epochs;
+        put_i(to[k].z_pos, t.z_pos);
+        put_i(to[k].t_pos, t.t_pos);
+        put_i(to[k].t_n, t.t_n);
+        put_i(to[k].w_pos, t.w_pos);
+        put_i(to[k].w_start, t.w_start);
+        put_i(to[k].w_n, t.w_n);
+        put_i(to[k].ep_t, t.ep_t);
+        put_i(to[k].ep_w, t.ep_w);
+        put_i(to[k].t_col, t.t_col);
+        put_d(to[k].t_val, t.t_val);
+        put_i(to[k].w_idx, t.w_idx);
+        put_d(to[k].w_val, t.w_val);
+    }
+    put_i(o_lrcol, f.l_col);
+    put_d(o_lrval, f.l_val);
+    put_i(o_lcrow, lcrow);
+    put_d(o_lcval, lcval);
+    put_i(o_urcol, f.u_col);
+    put_d(o_urval, f.u_val);
+    put_i(o_ucrow, ucrow);
+    put_d(o_ucval, ucval);
+    // one copy for the headers; the entry arrays are copied up to what is used (their capacities are 1.5 x larger)
+    RELP_HIP(hipMemcpyAsync(dev_, h, small_bytes, hipMemcpyHostToDevice, stream));
+    auto copy = [&](size_t at, size_t bytes) {
+        if (bytes) RELP_HIP(hipMemcpyAsync(dev_ + at, h + at, bytes, hipMemcpyHostToDevice, stream));
+    };
+    for (int k = 0; k < 4; ++k) {
+        const size_t nt = tasks[k].t_pos.size();
+        if (nt) {  // ELL: rows e of the two arrays, each used up to nt
+            for (int e = 0; e < LU_TE; ++e) {
+                copy(to[k].t_col + (size_t)e * stride * sizeof(int), nt * sizeof(int));
+                copy(to[k].t_val + (size_t)e * stride * sizeof(double), nt * sizeof(double));
             }
-        int* ucs = reinterpret_cast<int*>(h + o_ucs);
-        int* uclen = reinterpret_cast<int*>(h + o_uclen);
-        int* ucrow = reinterpret_cast<int*>(h + s_ucrow);
-        double* ucval = reinterpret_cast<double*>(h + s_ucval);
-        std::vector<int> count(m + 1, 0);
-        for (size_t e = 0; e < nu; ++e) count[f.u_col[e] + 1]++;
-        for (int j = 0; j < m; ++j) count[j + 1] += count[j];
-        for (int j = 0; j < m; ++j) {
-            ucs[j] = count[j];
-            uclen[j] = count[j + 1] - count[j];
         }
-        std::vector<int> fillu(count.begin(), count.end() - 1);
-        for (int i = 0; i < m; ++i)
-            for (int e = f.u_start[i]; e < f.u_start[i + 1]; ++e) {
-                const int dst = fillu[f.u_col[e]]++;
-                ucrow[dst] = i;
-                ucval[dst] = f.u_val[e];
-            }
-        if (nu) {
-            std::memcpy(h + s_urcol, f.u_col.data(), nu * sizeof(int));
-            std::memcpy(h + s_urval, f.u_val.data(), nu * sizeof(double));
-        }
+        copy(to[k].w_idx, tasks[k].w_idx.size() * sizeof(int));
+        copy(to[k].w_val, tasks[k].w_val.size() * sizeof(double));
     }
-    RELP_HIP(hipMemcpyAsync(dev_, h, upload_bytes, hipMemcpyHostToDevice, stream));
-    if (nu) {
-        RELP_HIP(hipMemcpyAsync(dev_ + o_urcol, h + s_urcol, nu * sizeof(int), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemcpyAsync(dev_ + o_ucrow, h + s_ucrow, nu * sizeof(int), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemcpyAsync(dev_ + o_urval, h + s_urval, nu * sizeof(double), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemcpyAsync(dev_ + o_ucval, h + s_ucval, nu * sizeof(double), hipMemcpyHostToDevice, stream));
-    }
+    copy(o_lrcol, nl * sizeof(int));
+    copy(o_lrval, nl * sizeof(double));
+    copy(o_lcrow, nl * sizeof(int));
+    copy(o_lcval, nl * sizeof(double));
+    copy(o_urcol, nu * sizeof(int));
+    copy(o_urval, nu * sizeof(double));
+    copy(o_ucrow, nu * sizeof(int));
+    copy(o_ucval, nu * sizeof(double));
     DeviceLU d;
     d.m = m;
     d.max_updates = max_updates;
@@ -218,8 +322,8 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     d.colpos = I(o_colpos);
     d.l_rstart = I(o_lrs); d.l_rcol = I(o_lrcol); d.l_rval = D(o_lrval);
     d.l_cstart = I(o_lcs); d.l_crow = I(o_lcrow); d.l_cval = D(o_lcval);
-    d.u_rstart = I(o_urs); d.u_rlen = I(o_urlen); d.u_rcol = I(o_urcol); d.u_rval = D(o_urval);
-    d.u_cstart = I(o_ucs); d.u_clen = I(o_uclen); d.u_crow = I(o_ucrow); d.u_cval = D(o_ucval);
+    d.u_rstart = I(o_urs); d.u_rcol = I(o_urcol); d.u_rval = D(o_urval);
+    d.u_cstart = I(o_ucs); d.u_crow = I(o_ucrow); d.u_cval = D(o_ucval);
     d.app_len = I(o_applen); d.app_slot = I(o_appslot); d.app_val = D(o_appval);
     d.s_cstart = I(o_scs); d.s_clen = I(o_scl); d.s_crow = I(o_scrow); d.s_cval = D(o_scval);
     d.s_capacity = (int)app;
@@ -231,160 +335,53 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     d.eta_capacity = (int)app;
     d.spike = D(o_spike);
     d.state = I(o_state);
-    for (int k = 0; k < 4; ++k) {
-        d.sched_start[k] = I(o_sched_start[k]);
-        d.sched_row[k] = I(o_sched_row[k]);
-    }
+    d.counts = I(o_counts);
+    d.task_stride = stride;
+    d.tasks = reinterpret_cast<const LuTasks*>(dev_ + o_tasks);
     d_ = d;
-    hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_, I(o_nlev));
+    hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_);
     nnz_l = (long long)nl;
     nnz_u = (long long)nu;
     lu_depths(f, &depth_l, &depth_u);
     return layout_changed;
 }
 
-// LDS of the solve kernels: x0, x1 (doubles); one count per 64 rows for the ordered compactions; reductions; T and the
-// trailing parts of the two vectors; and the factor area -- the headers of the triangular factor being solved with
-// (start, length, level order, 1/diagonal: 24 bytes per row) always, its entries (12 bytes each) when they fit.
+// LDS of the solve kernels: the two vectors (16 bytes per row), the mask of the replaced positions, one count per 64 rows for
+// the ordered compactions, reductions, and the trailing block T with its four slot vectors.
 static size_t lu_lds_fixed_bytes(int m, int max_updates) {
     const size_t mm = (size_t)((m + 1) & ~1);
-    return 2 * mm * sizeof(double) + ((size_t)(m + 63) / 64 + 2) * sizeof(int) + 64 * sizeof(double) +
-           ((size_t)max_updates * (max_updates + 1) + 4 * LU_MAX_SLOTS) * sizeof(double) + 64 +
-           mm * sizeof(double) + 3 * mm * sizeof(int) + (size_t)(m + 2) * sizeof(int) + 64;
+    return 2 * mm * sizeof(double) + ((size_t)(m + 31) / 32 + 2) * sizeof(int) + ((size_t)(m + 63) / 64 + 4) * sizeof(int) + 64 * sizeof(double) +
+           ((size_t)max_updates * (max_updates + 1) + 4 * LU_MAX_SLOTS) * sizeof(double) + 256;
 }
 constexpr size_t LU_LDS_TOTAL = 160 * 1024 - 1024;  // what a kernel may ask for (static LDS of the fused kernel comes on top)
-static size_t lu_lds_bytes_for(int m, int max_updates) {
-    (void)m;
-    (void)max_updates;
-    return LU_LDS_TOTAL - 2048;  // always the whole CU: one workgroup per solve, and the factor area takes what is left
-}
+static size_t lu_lds_bytes_for(int m, int max_updates) { return std::min(LU_LDS_TOTAL - 2048, lu_lds_fixed_bytes(m, max_updates)); }
 size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_.m, d_.max_updates); }
 bool lu_fits_lds(int m, int max_updates) {
     if (max_updates < 1) max_updates = 1;
     if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
-    return lu_lds_fixed_bytes(m, max_updates) + 16 * 1024 <= LU_LDS_TOTAL - 2048;
+    return lu_lds_fixed_bytes(m, max_updates) <= LU_LDS_TOTAL - 2048;
 }
 
 // =====================================================================================================
-// device: level-scheduled triangular solves out of LDS
+// device: synchronisation-free triangular solves out of LDS
 // =====================================================================================================
 // Explicit LDS pointer types.  A generic `volatile double*` that happens to point into LDS compiles to flat_load ... sc0 sc1
 // -- measured: about 2000 cycles per dependent access instead of the ~64 of a ds_read -- so every LDS array of this file is
 // typed by address space.
 typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
 typedef __attribute__((address_space(3))) char lds_i8;
-// One triangular factor in one orientation, staged for a solve.  The row records are LDS arrays in SCHEDULE order (record r
-// = the r-th row of the level order): position, first entry, length (-1: not part of this triangle), 1 / diagonal.  `idx` /
-// `val` are LDS copies of the entries when the factor fits, else the L2-resident arrays.
-template <class IdxPtr, class ValPtr>
-struct Factor {
-    const lds_i32* rec_i;
-    const lds_i32* rec_s;
-    const lds_i32* rec_n;
-    const lds_f64* rec_dinv;
-    IdxPtr idx;
-    ValPtr val;
-    const lds_i32* lev_start;
-    int n_levels;
-};
 
-// In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i], level by level (the rows of a level are independent; the
-// host computed the levels at refactorisation time and Forrest-Tomlin updates only remove entries, so they stay valid).
-// A level wider than a wave is shared by all threads and followed by a barrier; a run of narrow levels -- the long tail of a
-// basis factor: chains of one or two rows -- is walked by wave 0 alone WITHOUT barriers (LDS keeps one wave's accesses in
-// order) as a three-stage software pipeline: while level l waits for its operands x[idx], the entries of level l + 1 and the
-// row records of level l + 2 are already in flight, so a level costs ONE LDS round trip.  Everything is branch-free (clamped
-// addresses, selected contributions): a branch per entry would put an s_waitcnt behind every load (measured: 3000 cycles per
-// level).  Deterministic: a row adds its entries in storage order.
-// sum over aligned groups of G = 2^k lanes by DPP moves; valid in the LAST lane of every group (G <= 16: in all its lanes)
-__device__ __forceinline__ double group_sum(double v, const int G) {
-    if (G >= 2) v += dpp_f64<DPP_QUAD_1032, 0xF>(0.0, v);
-    if (G >= 4) v += dpp_f64<DPP_QUAD_2301, 0xF>(0.0, v);
-    if (G == 8) v += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, v);
-    if (G >= 16) {
-        v += dpp_f64<DPP_ROW_ROR4, 0xF>(0.0, v);
-        v += dpp_f64<DPP_ROW_ROR8, 0xF>(0.0, v);
-    }
-    if (G >= 32) v += dpp_f64<DPP_ROW_BCAST15, 0xA>(0.0, v);
-    if (G == 64) v += dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, v);
-    return v;
-}
-__device__ __forceinline__ int lanes_per_row(int width) {
-    return width <= 1 ? 64 : width <= 2 ? 32 : width <= 4 ? 16 : width <= 8 ? 8 : width <= 16 ? 4 : width <= 32 ? 2 : 1;
-}
-
-template <int NRHS, bool HAS_DIAG, class F>
-__device__ __forceinline__ void solve_levels(const F fac, volatile lds_f64* x0, volatile lds_f64* x1, unsigned long long* dbg = nullptr) {
-    (void)dbg;
-    const int tid = threadIdx.x, T = blockDim.x;
-    // ---- wide levels: a thread per row ---------------------------------------------------------------------------------
-    auto whole_row = [&](int r) {
-        const int i = fac.rec_i[r], st = fac.rec_s[r], n = fac.rec_n[r];
-        if (n < 0) return;
-        double a0 = x0[i], a1 = NRHS == 2 ? x1[i] : 0.0;
-        for (int k = 0; k < n; k += 4) {  // four entries per trip: two LDS round trips instead of eight
-            const int last = n - 1;
-            const int k0 = st + k, k1 = st + min(k + 1, last), k2 = st + min(k + 2, last), k3 = st + min(k + 3, last);
-            const int c0 = fac.idx[k0], c1 = fac.idx[k1], c2 = fac.idx[k2], c3 = fac.idx[k3];
-            const double v0 = fac.val[k0], v1 = fac.val[k1], v2 = fac.val[k2], v3 = fac.val[k3];
-            const double p0 = x0[c0], p1 = x0[c1], p2 = x0[c2], p3 = x0[c3];
-            a0 -= v0 * p0;
-            a0 -= k + 1 < n ? v1 * p1 : 0.0;
-            a0 -= k + 2 < n ? v2 * p2 : 0.0;
-            a0 -= k + 3 < n ? v3 * p3 : 0.0;
-            if (NRHS == 2) {
-                const double q0 = x1[c0], q1 = x1[c1], q2 = x1[c2], q3 = x1[c3];
-                a1 -= v0 * q0;
-                a1 -= k + 1 < n ? v1 * q1 : 0.0;
-                a1 -= k + 2 < n ? v2 * q2 : 0.0;
-                a1 -= k + 3 < n ? v3 * q3 : 0.0;
-            }
-        }
-        const double dinv = HAS_DIAG ? fac.rec_dinv[r] : 1.0;
-        x0[i] = a0 * dinv;
-        if (NRHS == 2) x1[i] = a1 * dinv;
-    };
-    // ---- levels of at most a wave's worth of rows: blockDim / 64 threads per row (entries split among them, DPP group sum) ------
-    // One LDS round trip per level whatever the row lengths, then the barrier.  (A barrier-free software pipeline of wave 0 over
-    // runs of such levels was measured at 1.8-2.3 k cycles per level -- every level is a dependent header -> entry -> operand ->
-    // sum -> publish chain for ONE wave; the chains of tiny levels at the end of the schedule are solved as a dense block
-    // instead, solve_dense_tail.)
-    auto group_rows = [&](int ls, int le) {
-        const int G = T / WAVE;
-        const int row = tid / G, sub = tid % G;
-        const bool in = row < le - ls;
-        const int r = ls + (in ? row : 0);
-        const int i = fac.rec_i[r], st = fac.rec_s[r];
-        const int n = in ? fac.rec_n[r] : -1;
-        double s0 = 0.0, s1 = 0.0;
-        for (int k = sub; k < n; k += G) {
-            const int c = fac.idx[st + k];
-            const double v = fac.val[st + k];
-            s0 += v * x0[c];
-            if (NRHS == 2) s1 += v * x1[c];
-        }
-        s0 = group_sum(s0, G);
-        if (NRHS == 2) s1 = group_sum(s1, G);
-        if (n >= 0 && sub == G - 1) {
-            const double dinv = HAS_DIAG ? fac.rec_dinv[r] : 1.0;
-            x0[i] = (x0[i] - s0) * dinv;
-            if (NRHS == 2) x1[i] = (x1[i] - s1) * dinv;
-        }
-    };
-    // (fetching the next level's row records and first entries while a level waits for its operands was measured: no gain --
-    //  LDS returns in order, so the operand read waits for the prefetch anyway)
-    const int n_levels = fac.n_levels;
-    for (int l = 0; l < n_levels; ++l) {
-        const int ls = fac.lev_start[l], le = fac.lev_start[l + 1];
-        if (le - ls > WAVE || T < 2 * WAVE) {
-            for (int r = ls + tid; r < le; r += T) whole_row(r);
-        } else {
-            group_rows(ls, le);
-        }
-        __syncthreads();
-    }
-}
+// A component of the solution vector that is not solved yet holds this quiet NaN (a payload no arithmetic produces); an
+// operand is ready when it reads as anything else.  Round 2 solved level by level with a workgroup barrier per level: ~1 k
+// cycles per level whatever its width (record -> entry -> operand -> sum -> publish are five dependent LDS round trips, plus
+// the barrier), 20-45 levels per triangle, four triangles per pivot.  Here every row is owned by a lane (or, a long row, by a
+// wave) that POLLS its operands in LDS and publishes its component the moment the last one arrives: a dependency costs one
+// LDS round trip (~100-150 cycles), waves whose rows are done stop polling, and there is no barrier inside a solve.
+constexpr unsigned long long LU_SENTINEL = 0x7ff85eed5eed5eedull;
+__device__ __forceinline__ bool lu_ready(double v) { return (unsigned long long)__double_as_longlong(v) != LU_SENTINEL; }
+__device__ __forceinline__ double lu_sentinel() { return __longlong_as_double((long long)LU_SENTINEL); }
 
 // ---- eta files --------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_value(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -470,12 +467,11 @@ __device__ __forceinline__ void apply_etas_backward(const DeviceLU& lu, const in
         }
     }
 }
-
-constexpr int TAIL_MAX = 64;  // rows of the dense tail: one lane each
 // LDS carve-up shared by every kernel of this file
 struct LuShared {
     volatile lds_f64* x0;
     volatile lds_f64* x1;
+    lds_u32* mask;     // one bit per position: replaced by a Forrest-Tomlin update (no row of U_bb any more; operand held at zero)
     int* group_count;  // one slot per 64 rows (+2)   (generic pointers: used with barriers around, a handful of accesses)
     double* red;       // 64 doubles
     volatile lds_f64* T;     // the trailing block, max_updates x ldt
@@ -483,20 +479,6 @@ struct LuShared {
     volatile lds_f64* xt1;
     volatile lds_f64* st0;   // BTRAN: right-hand sides of the trailing solve
     volatile lds_f64* st1;
-    // factor area
-    lds_f64* f_dinv;    // [m]
-    lds_i32* f_start;   // [m]
-    lds_i32* f_len;     // [m]
-    lds_i32* f_levrow;  // [m]
-    lds_i32* f_levstart;  // [m + 2]
-    lds_i8* f_entries;  // what is left of the LDS
-    int f_entry_capacity;  // entries (12 bytes each) that fit there
-    // dense tail of a triangular solve (solve_dense_tail): nullptr when the LDS has no room for it
-    lds_f64* tail_M;     // [64 x 64], M[k * 64 + i] = entry (tail row i, tail column k)
-    lds_i32* tail_map;   // [m] position -> index in the tail, or -1
-    lds_f64* tail_r0;    // [64] right-hand sides
-    lds_f64* tail_r1;
-    lds_i32* tail_info;  // [2] first level of the tail, its first record
     unsigned long long* dbg;  // diagnostic builds (-DRELP_STAMPS): per-segment cycle sums; nullptr otherwise
     unsigned long long* t_prev;
 };
@@ -509,7 +491,7 @@ __device__ __forceinline__ void lu_stamp(const LuShared& sh, int k) {
     }
 #endif
 }
-__device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max_updates, int lds_bytes) {
+__device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max_updates) {
     const int mm = (m + 1) & ~1;
     lds_i8* smem = (lds_i8*)smem_generic;
     LuShared s;
@@ -529,200 +511,246 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
     s.xt1 = xt1;
     s.st0 = st0;
     s.st1 = st1;
-    s.f_dinv = st1 + LU_MAX_SLOTS;
-    s.f_start = (lds_i32*)(s.f_dinv + mm);
-    s.f_len = s.f_start + mm;
-    s.f_levrow = s.f_len + mm;
-    s.f_levstart = s.f_levrow + mm;
-    lds_i32* group_count = s.f_levstart + ((m + 2 + 1) & ~1);
-    s.group_count = (int*)group_count;
-    lds_i8* end = (lds_i8*)(group_count + (((m + 63) / 64 + 2 + 1) & ~1));
-    s.tail_M = nullptr;
-    s.tail_map = nullptr;
-    s.tail_r0 = s.tail_r1 = nullptr;
-    s.tail_info = nullptr;
-    {   // the dense tail takes 33 KB + 4 m bytes when at least 24 KB stay for the factor's entries
-        const int tail_bytes = (TAIL_MAX * TAIL_MAX + 2 * TAIL_MAX) * 8 + ((mm + 2) * 4);
-        if (lds_bytes - (int)(end - smem) - tail_bytes >= 24 * 1024) {
-            s.tail_M = (lds_f64*)end;
-            s.tail_r0 = s.tail_M + TAIL_MAX * TAIL_MAX;
-            s.tail_r1 = s.tail_r0 + TAIL_MAX;
-            s.tail_map = (lds_i32*)(s.tail_r1 + TAIL_MAX);
-            s.tail_info = s.tail_map + mm;
-            end = (lds_i8*)(s.tail_info + 2);
-        }
-    }
-    s.f_entries = end;
-    s.f_entry_capacity = (int)((lds_bytes - (int)(end - smem)) / 12);
-    if (s.f_entry_capacity < 0) s.f_entry_capacity = 0;
+    lds_u32* mask = (lds_u32*)(st1 + LU_MAX_SLOTS);
+    s.mask = mask;
+    s.group_count = (int*)(mask + (((m + 31) / 32 + 2 + 1) & ~1));
     s.dbg = nullptr;
     s.t_prev = nullptr;
     return s;
 }
-// x0 (x1) <- 0, T staged from global.  Ends with a barrier.
+__device__ __forceinline__ bool lu_masked(const LuShared& sh, int pos) { return (sh.mask[pos >> 5] >> (pos & 31)) & 1u; }
+// x0 (x1) <- 0, T staged from global, the mask of the replaced positions built.  Ends with a barrier.
 __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh, int n_updates, bool two) {
     const int m = lu.m;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         sh.x0[i] = 0.0;
         if (two) sh.x1[i] = 0.0;
     }
+    for (int i = threadIdx.x; i < (m + 31) / 32; i += blockDim.x) sh.mask[i] = 0u;
     for (int i = threadIdx.x; i < n_updates * lu.ldt; i += blockDim.x) sh.T[i] = lu.T[i];
     __syncthreads();
-}
-
-// The last `n_tail` <= 64 records of the schedule as one dense triangular block.  All threads: every tail row, blockDim / 64
-// threads each, walks its entries -- an entry whose column is a tail row goes into the dense block (LDS, column-major by
-// dependency), the others are multiplied with their operands, which the head levels have finished -- and leaves the row's
-// right-hand side.  Then ONE wave substitutes through the block: lane i owns row i, step k broadcasts x_k by readlane -- n_tail
-// steps of a few instructions instead of one LDS round trip per level.  Rows that are not part of the triangle (len < 0) stay
-// as they are.  x0 / x1 of the head must be complete (barrier); ends with a barrier.
-template <int NRHS, bool HAS_DIAG, class F>
-__device__ __forceinline__ void solve_dense_tail(const F fac, const LuShared& sh, const int tail_first, const int n_tail) {
-    const int tid = threadIdx.x, T = blockDim.x;
-    const int G = T / TAIL_MAX;  // threads per tail row (a power of two: 16 at 1024 threads)
-    const int row = tid / G, sub = tid % G;
-    {
-        const bool active = row < n_tail;
-        const int rr = tail_first + (active ? row : 0);
-        const int st = fac.rec_s[rr];
-        const int n = active ? fac.rec_n[rr] : -1;
-        const int pos = fac.rec_i[rr];
-        double p0 = 0.0, p1 = 0.0;
-        for (int k = sub; k < n; k += G) {
-            const int c = fac.idx[st + k];
-            const double v = fac.val[st + k];
-            const int ti = sh.tail_map[c];
-            if (ti >= 0) {
-                sh.tail_M[ti * TAIL_MAX + row] = v;
-            } else {
-                p0 += v * sh.x0[c];
-                if (NRHS == 2) p1 += v * sh.x1[c];
-            }
-        }
-        p0 = group_sum(p0, G);
-        if (NRHS == 2) p1 = group_sum(p1, G);
-        if (active && sub == G - 1) {
-            sh.tail_r0[row] = sh.x0[pos] - p0;
-            if (NRHS == 2) sh.tail_r1[row] = sh.x1[pos] - p1;
-        }
-    }
-    __syncthreads();
-    if (tid < WAVE) {
-        const int lane = tid;
-        const bool in = lane < n_tail;
-        const int rr = tail_first + (in ? lane : 0);
-        const bool active = in && fac.rec_n[rr] >= 0;
-        const int pos = fac.rec_i[rr];
-        const double dinv = (HAS_DIAG && active) ? fac.rec_dinv[rr] : 1.0;
-        double r0 = active ? sh.tail_r0[lane] : 0.0;
-        double r1 = (NRHS == 2 && active) ? sh.tail_r1[lane] : 0.0;
-        for (int k = 0; k < n_tail; ++k) {
-            const double mk = sh.tail_M[k * TAIL_MAX + lane];
-            const double xk0 = lane_value(r0 * dinv, k);
-            if (lane > k) r0 -= mk * xk0;
-            if (NRHS == 2) {
-                const double xk1 = lane_value(r1 * dinv, k);
-                if (lane > k) r1 -= mk * xk1;
-            }
-        }
-        if (active) {
-            sh.x0[pos] = r0 * dinv;
-            if (NRHS == 2) sh.x1[pos] = r1 * dinv;
-        }
+    if ((int)threadIdx.x < n_updates) {
+        const int pos = lu.trail_pos[threadIdx.x];
+        if (pos >= 0) __hip_atomic_fetch_or((unsigned int*)(sh.mask + (pos >> 5)), 1u << (pos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
 }
 
-// Copy one orientation of one factor into the factor area (row records in schedule order always, entries when they fit)
-// and solve with it.
-//   g_start / g_len: first entry and length per row (g_len == nullptr: g_start has m + 1 entries); nnz: entries to copy;
-//   skip: rows with skip[i] >= 0 are not part of the triangle; diag: nullptr = unit; sched: which level schedule.
-// The caller's x0 / x1 must be complete (barrier) before; ends with a barrier (solve_levels does).
+// In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i]  for every row i of one triangular factor in one orientation
+// (`sched`: 0 L by rows, 1 U by rows, 2 U by columns, 3 L by columns), without barriers between dependent rows.
+//   rows without entries      all threads, one pass (only the division by the diagonal, if any);
+//   rows of <= LU_TE entries  THREAD tasks: lane k of the twelve task waves owns task k, k + 768, ... (dependency order, so a
+//                             task never waits for a later task of its own lane); entries in registers; every polling round
+//                             reads all still-missing operands at once and consumes the ready prefix in storage order;
+//   longer rows               WAVE tasks on the other four waves: a lane per entry (64 at a time), fixed DPP tree for the sum.
+// Right-hand sides are taken into the owners' registers first, then the components to be solved are overwritten by the
+// sentinel; a replaced position (mask) is no task and keeps its value (the callers hold it at zero during a U solve).
+// x0 / x1 must be complete (barrier) on entry; ends with a barrier.
 template <int NRHS, bool HAS_DIAG>
-__device__ __forceinline__ void lu_stage_and_solve(const DeviceLU& lu, const LuShared& sh, const int* g_start, const int* g_len,
-                                                   const int* g_idx, const double* g_val, const int nnz, const int* skip,
-                                                   const double* diag, const int sched) {
-    const int m = lu.m;
-    const int tid = threadIdx.x, T = blockDim.x;
-    const int n_levels = lu.state[LU_N_LEVELS + sched];
-    for (int r = tid; r < m; r += T) {
-        const int i = lu.sched_row[sched][r];
-        const int st = g_start[i];
-        int n = g_len ? g_len[i] : g_start[i + 1] - st;
-        if (skip && skip[i] >= 0) n = -1;
-        sh.f_levrow[r] = i;
-        sh.f_start[r] = st;
-        sh.f_len[r] = n;
-        if (HAS_DIAG) sh.f_dinv[r] = 1.0 / diag[i];
-        if (sh.tail_map) sh.tail_map[i] = -1;
+__device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShared& sh, const int sched) {
+    const LuTasks tk = lu.tasks[sched];
+    const int nz = lu.counts[sched * LU_CNT_WORDS + LU_CNT_Z];
+    const int n_epochs = lu.counts[sched * LU_CNT_WORDS + LU_CNT_EPOCHS];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const bool task_wave = wave < LU_TASK_WAVES;  // (wave-uniform role; every barrier below is outside the role branches)
+    const int ww = wave - LU_TASK_WAVES;
+    const int stride = lu.task_stride;
+    constexpr int TT = LU_TASK_WAVES * WAVE;
+    volatile lds_f64* x0 = sh.x0;
+    volatile lds_f64* x1 = sh.x1;
+    if (HAS_DIAG) {
+        for (int k = tid; k < nz; k += blockDim.x) {
+            const int pos = tk.z_pos[k];
+            if (lu_masked(sh, pos)) continue;
+            const double dinv = 1.0 / lu.diag[pos];
+            x0[pos] = x0[pos] * dinv;
+            if (NRHS == 2) x1[pos] = x1[pos] * dinv;
+        }
     }
-    for (int l = tid; l <= n_levels; l += T) {
-        const int first = lu.sched_start[sched][l];
-        sh.f_levstart[l] = first;
-        if (sh.tail_info) {  // the tail: the last levels with at most TAIL_MAX rows altogether
-            const int before = l > 0 ? lu.sched_start[sched][l - 1] : -1;
-            if (m - first <= TAIL_MAX && (l == 0 || m - before > TAIL_MAX)) {
-                sh.tail_info[0] = l;
-                sh.tail_info[1] = first;
+    const double sentinel = lu_sentinel();
+    for (int ep = 0; ep < n_epochs; ++ep) {
+        const int t_first = tk.ep_t[ep], t_end = tk.ep_t[ep + 1];
+        const int w_first = tk.ep_w[ep], w_end = tk.ep_w[ep + 1];
+        // ---- owners take position, right-hand side, 1 / diagonal (and, wave tasks, entry range) of their tasks -------------------
+        // thread tasks: slot r = task t_first + r * 768 + tid;  wave tasks: slot q = this wave's task q * 64 + lane of the epoch
+        int own_pos[LU_ROUNDS], own_st[2], own_n[2];
+        double own_b0[LU_ROUNDS], own_b1[LU_ROUNDS], own_dinv[LU_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < LU_ROUNDS; ++r) {
+            own_pos[r] = -1;
+            own_b0[r] = own_b1[r] = 0.0;
+            own_dinv[r] = 1.0;
+            int k = -1;
+            if (task_wave) {
+                k = t_first + r * TT + tid;
+                if (k >= t_end) k = -1;
+            } else if (r < 2) {
+                k = w_first + (r * WAVE + lane) * LU_WAVE_WAVES + ww;
+                if (k >= w_end) k = -1;
+            }
+            if (k >= 0) {
+                const int p = task_wave ? tk.t_pos[k] : tk.w_pos[k];
+                if (!task_wave) {
+                    own_st[r < 2 ? r : 0] = tk.w_start[k];
+                    own_n[r < 2 ? r : 0] = tk.w_n[k];
+                }
+                if (!lu_masked(sh, p)) {
+                    own_pos[r] = p;
+                    own_b0[r] = x0[p];
+                    if (NRHS == 2) own_b1[r] = x1[p];
+                    if (HAS_DIAG) own_dinv[r] = 1.0 / lu.diag[p];
+                }
             }
         }
-    }
-    const bool fits = nnz + 4 <= sh.f_entry_capacity;
-    lds_i32* e_idx = (lds_i32*)(sh.f_entries + sh.f_entry_capacity * 8);
-    lds_f64* e_val = (lds_f64*)sh.f_entries;
-    if (fits) {
-        for (int e = tid; e < nnz; e += T) {
-            e_idx[e] = g_idx[e];
-            e_val[e] = g_val[e];
+        // the first round's entries travel while the barriers below pass
+        int col[LU_TE], n_entries = 0;
+        double val[LU_TE];
+        {
+            const int k0 = t_first + tid < t_end ? t_first + tid : (t_first < t_end ? t_first : 0);
+            if (task_wave && own_pos[0] >= 0) n_entries = tk.t_n[k0];
+#pragma unroll
+            for (int e = 0; e < LU_TE; ++e) {
+                col[e] = task_wave ? tk.t_col[(size_t)e * stride + k0] : 0;
+                val[e] = task_wave ? tk.t_val[(size_t)e * stride + k0] : 0.0;
+            }
         }
-        if (tid < 4) {  // (the clamped reads of an empty last row land here)
-            e_idx[nnz + tid] = 0;
-            e_val[nnz + tid] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < LU_ROUNDS; ++r)
+            if (own_pos[r] >= 0) x0[own_pos[r]] = sentinel;
+        __syncthreads();
+        if (task_wave) {
+            // ---- thread tasks ------------------------------------------------------------------------------------------------
+            const int rounds = (t_end - t_first + TT - 1) / TT;
+#pragma unroll
+            for (int r = 0; r < LU_ROUNDS; ++r) {
+                if (r >= rounds) break;
+                const bool have = own_pos[r] >= 0;
+                if (r > 0) {
+                    const int k = t_first + r * TT + tid;
+                    const int kk = k < t_end ? k : t_first;  // (clamped: the loads are unconditional)
+                    n_entries = have ? tk.t_n[kk] : 0;
+#pragma unroll
+                    for (int e = 0; e < LU_TE; ++e) {
+                        col[e] = tk.t_col[(size_t)e * stride + kk];
+                        val[e] = tk.t_val[(size_t)e * stride + kk];
+                    }
+                }
+                const int n = n_entries;
+                double a0 = own_b0[r], a1 = own_b1[r];
+                int done_entries = 0;
+                bool done = !have;
+                for (;;) {
+                    // every round reads all eight operand slots (padding points at position 0): one batch of ds_reads, no branch
+                    double xv[LU_TE];
+#pragma unroll
+                    for (int e = 0; e < LU_TE; ++e) xv[e] = x0[col[e]];
+                    int ready_until = done_entries;
+#pragma unroll
+                    for (int e = 0; e < LU_TE; ++e)
+                        if (e == ready_until && e < n && lu_ready(xv[e])) ready_until = e + 1;
+                    const bool progressed = !done && ready_until > done_entries;
+                    if (__any(progressed)) {
+                        double yv[LU_TE];
+                        if (NRHS == 2) {
+#pragma unroll
+                            for (int e = 0; e < LU_TE; ++e) yv[e] = x1[col[e]];
+                        }
+                        if (progressed) {
+#pragma unroll
+                            for (int e = 0; e < LU_TE; ++e)
+                                if (e >= done_entries && e < ready_until) {
+                                    a0 -= val[e] * xv[e];
+                                    if (NRHS == 2) a1 -= val[e] * yv[e];
+                                }
+                            done_entries = ready_until;
+                            if (done_entries >= n) {
+                                if (NRHS == 2) x1[own_pos[r]] = a1 * own_dinv[r];  // (before x0: whoever sees x0 ready reads x1 afterwards)
+                                x0[own_pos[r]] = a0 * own_dinv[r];
+                                done = true;
+                            }
+                        }
+                    } else {
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (__all(done)) break;
+                }
+            }
+        } else {
+            // ---- wave tasks: a lane per entry, the next task's entries in flight while this one polls ---------------------------
+            const int count = w_end > w_first + ww ? (w_end - w_first - ww + LU_WAVE_WAVES - 1) / LU_WAVE_WAVES : 0;
+            int c_next = 0;
+            double v_next = 0.0;
+            if (count > 0) {
+                const int st = lane_value(own_st[0], 0), n = lane_value(own_n[0], 0);
+                if (lane < n) {
+                    c_next = tk.w_idx[st + lane];
+                    v_next = tk.w_val[st + lane];
+                }
+            }
+            for (int j = 0; j < count; ++j) {
+                const int slot = j & (WAVE - 1);
+                const int p = lane_value(j < WAVE ? own_pos[0] : own_pos[1], slot);
+                const int st = lane_value(j < WAVE ? own_st[0] : own_st[1], slot), n = lane_value(j < WAVE ? own_n[0] : own_n[1], slot);
+                const double rhs0 = lane_value(j < WAVE ? own_b0[0] : own_b0[1], slot);
+                const double rhs1 = NRHS == 2 ? lane_value(j < WAVE ? own_b1[0] : own_b1[1], slot) : 0.0;
+                const double dinv = lane_value(j < WAVE ? own_dinv[0] : own_dinv[1], slot);
+                int c = c_next;
+                double v = v_next;
+                if (j + 1 < count) {
+                    const int slot2 = (j + 1) & (WAVE - 1);
+                    const int st2 = lane_value(j + 1 < WAVE ? own_st[0] : own_st[1], slot2), n2 = lane_value(j + 1 < WAVE ? own_n[0] : own_n[1], slot2);
+                    c_next = 0;
+                    v_next = 0.0;
+                    if (lane < n2) {
+                        c_next = tk.w_idx[st2 + lane];
+                        v_next = tk.w_val[st2 + lane];
+                    }
+                }
+                if (p < 0) continue;  // (a replaced position: no row of the triangle any more)
+                double s0 = 0.0, s1 = 0.0;
+                for (int base = 0; base < n; base += WAVE) {
+                    const bool in = base + lane < n;
+                    if (base > 0) {
+                        c = in ? tk.w_idx[st + base + lane] : 0;
+                        v = in ? tk.w_val[st + base + lane] : 0.0;
+                    }
+                    double xv = 0.0;
+                    bool got = !in;
+                    for (;;) {
+                        if (!got) {
+                            xv = x0[c];
+                            got = lu_ready(xv);
+                        }
+                        if (__all(got)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (in) {
+                        s0 += v * xv;
+                        if (NRHS == 2) s1 += v * x1[c];
+                    }
+                }
+                s0 = wave_sum(s0);
+                if (NRHS == 2) s1 = wave_sum(s1);
+                if (lane == LAST) {
+                    if (NRHS == 2) x1[p] = (rhs1 - s1) * dinv;
+                    x0[p] = (rhs0 - s0) * dinv;
+                }
+            }
         }
-    }
-    __syncthreads();
-    lu_stamp(sh, 13 + sched);
-#ifdef RELP_STAMPS
-    if (sh.dbg && threadIdx.x == 0) {
-        sh.dbg[20 + sched] += n_levels;
-        int wide = 0;
-        for (int l = 0; l < n_levels; ++l) wide += (sh.f_levstart[l + 1] - sh.f_levstart[l] > WAVE) ? 1 : 0;
-        sh.dbg[24 + sched] += wide;
-        sh.dbg[28 + sched] += fits ? 1 : 0;
-    }
-#endif
-    // The narrow levels at the end of the schedule -- chains of a few rows each, 10-30 levels of them on a basis of 25FV47, every
-    // level one dependent LDS round trip for one wave -- are solved as ONE DENSE triangular block instead (solve_dense_tail).
-    int head_levels = n_levels, tail_first = m;
-    if (sh.tail_info) {
-        const int l_tail = sh.tail_info[0];
-        tail_first = sh.tail_info[1];
-        if (n_levels - l_tail >= 3 && m - tail_first >= 4) head_levels = l_tail;  // (a short tail is not worth the set-up)
-        else tail_first = m;
-    }
-    if (tail_first < m) {
-        for (int e = tid; e < TAIL_MAX * TAIL_MAX; e += T) sh.tail_M[e] = 0.0;
-        if (tid < m - tail_first) sh.tail_map[sh.f_levrow[tail_first + tid]] = tid;
         __syncthreads();
     }
-    if (fits) {
-        Factor<const lds_i32*, const lds_f64*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, e_idx, e_val, sh.f_levstart, head_levels};
-        solve_levels<NRHS, HAS_DIAG>(f, sh.x0, sh.x1, sh.dbg);
-        if (tail_first < m) solve_dense_tail<NRHS, HAS_DIAG>(f, sh, tail_first, m - tail_first);
-    } else {
-        Factor<const int*, const double*> f{sh.f_levrow, sh.f_start, sh.f_len, sh.f_dinv, g_idx, g_val, sh.f_levstart, head_levels};
-        solve_levels<NRHS, HAS_DIAG>(f, sh.x0, sh.x1, sh.dbg);
-        if (tail_first < m) solve_dense_tail<NRHS, HAS_DIAG>(f, sh, tail_first, m - tail_first);
-    }
+    if (n_epochs == 0) __syncthreads();
 }
 
 // FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve (trailing block by one
-// wave, spike contributions, then the base rows).  Ends with a barrier.
+// wave, spike contributions, then the base rows with the replaced positions held at zero).  Ends with a barrier.
 __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
                                                double* spike_out) {
     (void)epoch;
     const int m = lu.m;
-    lu_stage_and_solve<1, false>(lu, sh, lu.l_rstart, nullptr, lu.l_rcol, lu.l_rval, lu.l_rstart[m], nullptr, nullptr, 0);
+    lu_solve_tasks<1, false>(lu, sh, 0);
     lu_stamp(sh, 2);
     if (n_updates > 0) {
         apply_etas_forward(lu, n_updates, sh.x0);
@@ -732,6 +760,7 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
     if (spike_out)
         for (int i = threadIdx.x; i < m; i += blockDim.x) spike_out[i] = sh.x0[i];
     if (n_updates > 0) {
+        if (spike_out) __syncthreads();  // (the spike is read from x0 before the trailing positions are zeroed)
         if (threadIdx.x < WAVE) {  // T x_T = y_T, back substitution by slot (lower_upper/mod.rs:307-321 on the trailing block)
             const int lane = threadIdx.x;
             const int pos = lane < n_updates ? lu.trail_pos[lane] : -1;
@@ -743,7 +772,7 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
                 if (lane < b && xb != 0.0) xk -= sh.T[lane * lu.ldt + b] * xb;
             }
             if (lane < n_updates) sh.xt0[lane] = xk;
-            if (pos >= 0) sh.x0[pos] = xk;
+            if (pos >= 0) sh.x0[pos] = 0.0;  // masked: the stale entries of its old column multiply nothing in the base solve
         }
         __syncthreads();
         // y_b -= S x_T: a base row's spike entries (one per update at most), operands final
@@ -755,8 +784,16 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
             for (int e = 0; e < n_app; ++e) acc += lu.app_val[i * stride + e] * sh.xt0[lu.app_slot[i * stride + e]];
             sh.x0[i] = sh.x0[i] - acc;
         }
+        __syncthreads();
     }
-    lu_stage_and_solve<1, true>(lu, sh, lu.u_rstart, lu.u_rlen, lu.u_rcol, lu.u_rval, lu.u_rstart[m], n_updates > 0 ? lu.slot_of : nullptr, lu.diag, 1);
+    lu_solve_tasks<1, true>(lu, sh, 1);
+    if (n_updates > 0) {
+        if ((int)threadIdx.x < n_updates) {
+            const int pos = lu.trail_pos[threadIdx.x];
+            if (pos >= 0) sh.x0[pos] = sh.xt0[threadIdx.x];
+        }
+        __syncthreads();
+    }
     lu_stamp(sh, 4);
 }
 
@@ -766,8 +803,20 @@ template <int NRHS, class AfterUpper>
 __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
                                                AfterUpper after_upper) {
     (void)epoch;
-    const int m = lu.m;
-    lu_stage_and_solve<NRHS, true>(lu, sh, lu.u_cstart, lu.u_clen, lu.u_crow, lu.u_cval, lu.u_rstart[m], n_updates > 0 ? lu.slot_of : nullptr, lu.diag, 2);
+    if (n_updates > 0) {
+        // the replaced positions leave the base solve: their right-hand sides wait in xt0 / xt1, their components read as zero
+        if ((int)threadIdx.x < n_updates) {
+            const int pos = lu.trail_pos[threadIdx.x];
+            sh.xt0[threadIdx.x] = pos >= 0 ? sh.x0[pos] : 0.0;
+            if (NRHS == 2) sh.xt1[threadIdx.x] = pos >= 0 ? sh.x1[pos] : 0.0;
+            if (pos >= 0) {
+                sh.x0[pos] = 0.0;
+                if (NRHS == 2) sh.x1[pos] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+    lu_solve_tasks<NRHS, true>(lu, sh, 2);
     if (n_updates > 0) {
         // right-hand side of the trailing solve: v_T - z_b S, one wave per spike column (lower_upper/mod.rs:373-397)
         const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, nwaves = blockDim.x / WAVE;
@@ -779,15 +828,15 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
                 for (int e = lane; e < cl; e += WAVE) {
                     const int i = lu.s_crow[cs + e];
                     const double v = lu.s_cval[cs + e];
-                    p0 += v * sh.x0[i];
+                    p0 += v * sh.x0[i];  // (a row replaced since reads as zero)
                     if (NRHS == 2) p1 += v * sh.x1[i];
                 }
             }
             p0 = wave_sum(p0);
             if (NRHS == 2) p1 = wave_sum(p1);
             if (lane == LAST) {
-                sh.st0[k] = pos >= 0 ? sh.x0[pos] - p0 : 0.0;
-                if (NRHS == 2) sh.st1[k] = pos >= 0 ? sh.x1[pos] - p1 : 0.0;
+                sh.st0[k] = pos >= 0 ? sh.xt0[k] - p0 : 0.0;
+                if (NRHS == 2) sh.st1[k] = pos >= 0 ? sh.xt1[k] - p1 : 0.0;
             }
         }
         __syncthreads();
@@ -824,7 +873,7 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
         __syncthreads();
     }
     lu_stamp(sh, 9);
-    lu_stage_and_solve<NRHS, false>(lu, sh, lu.l_cstart, nullptr, lu.l_crow, lu.l_cval, lu.l_rstart[m], nullptr, nullptr, 3);
+    lu_solve_tasks<NRHS, false>(lu, sh, 3);
     lu_stamp(sh, 10);
 }
 
@@ -883,8 +932,9 @@ __device__ __forceinline__ int lu_build_eta(const DeviceLU& lu, const LuShared& 
 }
 
 // Structural part of the Forrest-Tomlin update (mod.rs:127-176): row t leaves U, column t becomes the spike, position t
-// moves to the end of the logical order -- i.e. it takes the next slot of the trailing block.  `eta_count` entries were
-// already written by lu_build_eta.
+// moves to the end of the logical order -- i.e. it takes the next slot of the trailing block.  The base part of U is not
+// rewritten: from now on position t is masked in every solve (lu.hpp).  `eta_count` entries were already written by
+// lu_build_eta.
 __device__ __forceinline__ void lu_ft_update_block(const DeviceLU& lu, const LuShared& sh, const int t, const int eta_count,
                                                    const double new_diag, const double* spike) {
     const int m = lu.m;
@@ -896,50 +946,7 @@ __device__ __forceinline__ void lu_ft_update_block(const DeviceLU& lu, const LuS
     const int new_slot = n_updates;
     const int stride = lu.max_updates;
     __syncthreads();  // everyone has read the state words
-    if (old_slot < 0) {
-        // 1. row t leaves: its base entries leave the base columns, its spike entries leave the spike columns
-        {
-            const int rs = lu.u_rstart[t], rl = lu.u_rlen[t];
-            for (int e = tid; e < rl; e += T) {
-                const int j = lu.u_rcol[rs + e];
-                const int cs = lu.u_cstart[j], cl = lu.u_clen[j];
-                for (int s = 0; s < cl; ++s)
-                    if (lu.u_crow[cs + s] == t) {
-                        lu.u_crow[cs + s] = lu.u_crow[cs + cl - 1];
-                        lu.u_cval[cs + s] = lu.u_cval[cs + cl - 1];
-                        lu.u_clen[j] = cl - 1;
-                        break;
-                    }
-            }
-            const int al = lu.app_len[t];
-            for (int e = tid; e < al; e += T) {
-                const int k = lu.app_slot[t * stride + e];
-                const int cs = lu.s_cstart[k], cl = lu.s_clen[k];
-                for (int s = 0; s < cl; ++s)
-                    if (lu.s_crow[cs + s] == t) {
-                        lu.s_crow[cs + s] = lu.s_crow[cs + cl - 1];
-                        lu.s_cval[cs + s] = lu.s_cval[cs + cl - 1];
-                        lu.s_clen[k] = cl - 1;
-                        break;
-                    }
-            }
-        }
-        // 2. the old column t leaves the base rows
-        {
-            const int cs = lu.u_cstart[t], cl = lu.u_clen[t];
-            for (int e = tid; e < cl; e += T) {
-                const int i = lu.u_crow[cs + e];
-                const int rs = lu.u_rstart[i], rl = lu.u_rlen[i];
-                for (int s = 0; s < rl; ++s)
-                    if (lu.u_rcol[rs + s] == t) {
-                        lu.u_rcol[rs + s] = lu.u_rcol[rs + rl - 1];
-                        lu.u_rval[rs + s] = lu.u_rval[rs + rl - 1];
-                        lu.u_rlen[i] = rl - 1;
-                        break;
-                    }
-            }
-        }
-    } else {
+    if (old_slot >= 0) {
         // t was replaced before: its row and column live in T and S under `old_slot`, which dies
         for (int b = tid; b < lu.max_updates; b += T) {
             lu.T[old_slot * lu.ldt + b] = 0.0;   // row of T (the u_bar part)
@@ -961,16 +968,14 @@ __device__ __forceinline__ void lu_ft_update_block(const DeviceLU& lu, const LuS
     __syncthreads();
     if (tid == 0) {
         if (old_slot < 0) {
-            lu.u_rlen[t] = 0;
-            lu.app_len[t] = 0;
-            lu.u_clen[t] = 0;
+            lu.app_len[t] = 0;  // row t leaves: its spike entries are not applied any more (the column copies of S are masked)
         } else {
             lu.s_clen[old_slot] = 0;
             lu.trail_pos[old_slot] = -1;
         }
     }
-    // 3. the spike becomes the column of the new slot: base rows -> S (column arena + one appended entry per row),
-    //    live trailing positions -> T
+    // the spike becomes the column of the new slot: base rows -> S (column arena + one appended entry per row),
+    // live trailing positions -> T
     const int count = ordered_compact(
         m, sh.group_count, [&](int i) { return i != t && spike[i] != 0.0 && lu.slot_of[i] < 0; },
         [&](int i, int offset) {
@@ -1011,7 +1016,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const
                                                                const double* dense, double* out, int keep_spike) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
     if (dense) {
@@ -1029,7 +1034,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
                                                                const double* dense, double* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
     if (dense) {
@@ -1046,7 +1051,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
 __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int t = lu.colpos[p];
     const int n_updates = lu.state[LU_N_UPDATES];
     if (n_updates >= lu.max_updates) {  // no room for another eta: the caller has to refactor
@@ -1132,7 +1137,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     Ctl* ctl = lp.ctl;
     const int tid = threadIdx.x, T = blockDim.x;
     const int m = lp.m;
-    LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
+    LuShared sh = lu_shared(smem, m, lu.max_updates);
 #ifdef RELP_STAMPS
     __shared__ unsigned long long s_tprev;
     if (tid == 0) {
@@ -1357,7 +1362,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
 __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
     for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = lp.rhs[i];
@@ -1370,7 +1375,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU
 __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
     double obj = 0.0;
@@ -1395,7 +1400,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
 __global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, (int)LU_LDS_TOTAL - 2048);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     for (int j = lp.n_art + blockIdx.x; j < lp.n; j += gridDim.x) {
         if (lp.pos[j] >= 0) continue;
@@ -1707,9 +1712,8 @@ LuBasis::Factors LuBasis::factors() {
         }
     }
     // U by logical column: entries (logical row, value), ascending
-    std::vector<int> ucs = geti(d.u_cstart, m), ucl = geti(d.u_clen, m);
-    size_t used = 0;
-    for (int j = 0; j < m; ++j) used = std::max(used, (size_t)ucs[j] + (size_t)ucl[j]);
+    std::vector<int> ucs = geti(d.u_cstart, m + 1);
+    const size_t used = (size_t)ucs[m];
     std::vector<int> ucrow = geti(d.u_crow, used);
     std::vector<double> ucval = getd(d.u_cval, used), diag = getd(d.diag, m);
     std::vector<int> scs = geti(d.s_cstart, d.max_updates), scl = geti(d.s_clen, d.max_updates), scrow = geti(d.s_crow, state[LU_S_TOP]);
@@ -1721,10 +1725,12 @@ LuBasis::Factors LuBasis::factors() {
         f.upper_diagonal[c] = diag[j];
         std::vector<std::pair<int, double>> col;
         if (slot_of[j] < 0) {
-            for (int e = ucs[j]; e < ucs[j] + ucl[j]; ++e) col.push_back({rank[ucrow[e]], ucval[e]});
+            for (int e = ucs[j]; e < ucs[j + 1]; ++e)
+                if (slot_of[ucrow[e]] < 0) col.push_back({rank[ucrow[e]], ucval[e]});  // (the row of a replaced position has left U: masked, not removed)
         } else {
             const int k = slot_of[j];
-            for (int e = scs[k]; e < scs[k] + scl[k]; ++e) col.push_back({rank[scrow[e]], scval[e]});
+            for (int e = scs[k]; e < scs[k] + scl[k]; ++e)
+                if (slot_of[scrow[e]] < 0) col.push_back({rank[scrow[e]], scval[e]});  // (a row replaced since: masked)
             for (int a2 = 0; a2 < k; ++a2)
                 if (trail_pos[a2] >= 0 && T[(size_t)a2 * d.ldt + k] != 0.0) col.push_back({rank[trail_pos[a2]], T[(size_t)a2 * d.ldt + k]});
         }

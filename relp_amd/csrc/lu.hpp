@@ -10,7 +10,9 @@
 //   U  =  [      U_bb             S       ]           slot j = the position replaced by update j (`trail_pos[j]`,
 //         [       0               T       ]           `slot_of[position]`); T is k x k upper triangular BY SLOT INDEX.
 //
-//   U_bb  what is left of the refactorised U: both orientations, entries only ever leave (swap-remove);
+//   U_bb  the refactorised U, both orientations, NEVER rewritten: the row and the column of a replaced position are masked
+//         instead -- its row is no task of the solves any more, and the solves hold its component at zero while the base
+//         block is solved, so that the stale entries of its column multiply nothing;
 //   S     the spikes' entries in base rows: by column (arena, for BTRAN's dot products) and by row (`app_*`: at most one
 //         entry per update and row, so a fixed stride; for FTRAN);
 //   T     dense, k <= 64: the part every spike chains through -- solved by ONE wave out of LDS, not by m rows waiting on
@@ -28,9 +30,35 @@
 
 namespace relp {
 
-enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_N_LEVELS = 4 /* .. 7: one per schedule */, LU_STATE_WORDS = 16 };
+enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_STATE_WORDS = 16 };
 enum : int { LU_FLAG_UNSTABLE = 1, LU_FLAG_OVERFLOW = 2 };
 constexpr int LU_MAX_SLOTS = 64;  // one wave solves T
+
+// A triangular factor in one orientation as a TASK LIST for the synchronisation-free solve (lu.hip: lu_solve_tasks).  The rows
+// (columns) of the factor are sorted by dependency level; a row without entries needs no solve (`z_pos`), a row of at most
+// LU_TE entries is a THREAD task (entries inline, ELL layout: entry e of task k at [e * stride + k]), a longer one a WAVE task
+// (entries in a packed arena, the 64 lanes share them).  Tasks wait for their operands by polling the solution vector in LDS
+// (a not-yet-solved component holds a sentinel), not at barriers.  `ep_t` / `ep_w` cut both lists into epochs whose right-hand
+// sides fit the owners' registers (all of a normal basis is one epoch).
+#ifndef RELP_LU_TE
+#define RELP_LU_TE 6
+#endif
+constexpr int LU_TE = RELP_LU_TE;   // (a macro only so that micro-variants can be compiled side by side)
+constexpr int LU_TASK_WAVES = 12;   // waves 0 .. 11 of the 16 run thread tasks, one task per lane and round
+constexpr int LU_WAVE_WAVES = 4;    // waves 12 .. 15 run wave tasks
+constexpr int LU_ROUNDS = 2;        // thread tasks per lane and epoch
+constexpr int LU_EPOCH_T = LU_ROUNDS * LU_TASK_WAVES * 64;
+constexpr int LU_EPOCH_W = 2 * 64 * LU_WAVE_WAVES;
+constexpr int LU_MAX_EPOCHS = 62;
+struct LuTasks {
+    int* z_pos = nullptr;                                        // [nz]
+    int* t_pos = nullptr; int* t_n = nullptr;                    // [nt]
+    int* t_col = nullptr; double* t_val = nullptr;               // [LU_TE][stride]
+    int* w_pos = nullptr; int* w_start = nullptr; int* w_n = nullptr;  // [nw]
+    int* w_idx = nullptr; double* w_val = nullptr;               // arena
+    int* ep_t = nullptr; int* ep_w = nullptr;                    // [epochs + 1] each
+};
+enum : int { LU_CNT_Z = 0, LU_CNT_T = 1, LU_CNT_W = 2, LU_CNT_EPOCHS = 3, LU_CNT_WORDS = 4 };
 
 struct DeviceLU {
     int m = 0;
@@ -40,8 +68,8 @@ struct DeviceLU {
     int* colpos = nullptr;
     int* l_rstart = nullptr; int* l_rcol = nullptr; double* l_rval = nullptr;  // strict L by rows   (FTRAN gather)
     int* l_cstart = nullptr; int* l_crow = nullptr; double* l_cval = nullptr;  // strict L by columns (BTRAN gather)
-    int* u_rstart = nullptr; int* u_rlen = nullptr; int* u_rcol = nullptr; double* u_rval = nullptr;  // U_bb by rows
-    int* u_cstart = nullptr; int* u_clen = nullptr; int* u_crow = nullptr; double* u_cval = nullptr;  // U_bb by columns
+    int* u_rstart = nullptr; int* u_rcol = nullptr; double* u_rval = nullptr;  // U_bb by rows    (CSR, m + 1 starts; never rewritten)
+    int* u_cstart = nullptr; int* u_crow = nullptr; double* u_cval = nullptr;  // U_bb by columns
     int* app_len = nullptr; int* app_slot = nullptr; double* app_val = nullptr;                       // S by rows, stride max_updates
     int* s_cstart = nullptr; int* s_clen = nullptr; int* s_crow = nullptr; double* s_cval = nullptr;  // S by columns (arena)
     int s_capacity = 0;
@@ -52,9 +80,10 @@ struct DeviceLU {
     int* eta_start = nullptr; int* eta_pivot = nullptr; int* eta_idx = nullptr; double* eta_val = nullptr;
     int eta_capacity = 0;
     double* spike = nullptr;  // [m] position space: the FTRAN intermediate before the U solve (mod.rs:196 `spike`)
-    // level schedules (lu_host.hpp): 0 L by rows, 1 U by rows, 2 U by columns, 3 L by columns
-    int* sched_start[4] = {nullptr, nullptr, nullptr, nullptr};  // [levels + 1] each (capacity m + 2)
-    int* sched_row[4] = {nullptr, nullptr, nullptr, nullptr};    // [m] each
+    // task lists of the four triangular solves: 0 L by rows, 1 U by rows (FTRAN), 2 U by columns, 3 L by columns (BTRAN)
+    const LuTasks* tasks = nullptr;  // [4], in device memory (forty-eight pointers would not fit the kernel's scalar registers)
+    int task_stride = 0;      // ELL stride of the thread tasks (m rounded up to a multiple of 64)
+    int* counts = nullptr;    // [4][LU_CNT_WORDS]: device-resident, so that a captured graph survives a refactorisation
     int* state = nullptr;     // LU_* words
 };
 
