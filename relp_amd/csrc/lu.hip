@@ -288,30 +288,36 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     put_d(o_urval, f.u_val);
     put_i(o_ucrow, ucrow);
     put_d(o_ucval, ucval);
-    // one copy for the headers; the entry arrays are copied up to what is used (their capacities are 1.5 x larger)
-    RELP_HIP(hipMemcpyAsync(dev_, h, small_bytes, hipMemcpyHostToDevice, stream));
-    auto copy = [&](size_t at, size_t bytes) {
-        if (bytes) RELP_HIP(hipMemcpyAsync(dev_ + at, h + at, bytes, hipMemcpyHostToDevice, stream));
-    };
-    for (int k = 0; k < 4; ++k) {
-        const size_t nt = tasks[k].t_pos.size();
-        if (nt) {  // ELL: rows e of the two arrays, each used up to nt
-            for (int e = 0; e < LU_TE; ++e) {
-                copy(to[k].t_col + (size_t)e * stride * sizeof(int), nt * sizeof(int));
-                copy(to[k].t_val + (size_t)e * stride * sizeof(double), nt * sizeof(double));
+    // A small factor goes over in ONE copy, gaps and unused capacity included: every hipMemcpyAsync costs 5-10 us of host time,
+    // which at Netlib sizes is more than the bytes do.  A large one copies the headers at once and each entry array up to what
+    // is used (the capacities are 1.5 x larger, the ELL rows m wide).
+    if (upload_bytes <= (size_t)(2u << 20)) {
+        RELP_HIP(hipMemcpyAsync(dev_, h, upload_bytes, hipMemcpyHostToDevice, stream));
+    } else {
+        RELP_HIP(hipMemcpyAsync(dev_, h, small_bytes, hipMemcpyHostToDevice, stream));
+        auto copy = [&](size_t at, size_t bytes) {
+            if (bytes) RELP_HIP(hipMemcpyAsync(dev_ + at, h + at, bytes, hipMemcpyHostToDevice, stream));
+        };
+        for (int k = 0; k < 4; ++k) {
+            const size_t nt = tasks[k].t_pos.size();
+            if (nt) {  // ELL: rows e of the two arrays, each used up to nt
+                for (int e = 0; e < LU_TE; ++e) {
+                    copy(to[k].t_col + (size_t)e * stride * sizeof(int), nt * sizeof(int));
+                    copy(to[k].t_val + (size_t)e * stride * sizeof(double), nt * sizeof(double));
+                }
             }
+            copy(to[k].w_idx, tasks[k].w_idx.size() * sizeof(int));
+            copy(to[k].w_val, tasks[k].w_val.size() * sizeof(double));
         }
-        copy(to[k].w_idx, tasks[k].w_idx.size() * sizeof(int));
-        copy(to[k].w_val, tasks[k].w_val.size() * sizeof(double));
+        copy(o_lrcol, nl * sizeof(int));
+        copy(o_lrval, nl * sizeof(double));
+        copy(o_lcrow, nl * sizeof(int));
+        copy(o_lcval, nl * sizeof(double));
+        copy(o_urcol, nu * sizeof(int));
+        copy(o_urval, nu * sizeof(double));
+        copy(o_ucrow, nu * sizeof(int));
+        copy(o_ucval, nu * sizeof(double));
     }
-    copy(o_lrcol, nl * sizeof(int));
-    copy(o_lrval, nl * sizeof(double));
-    copy(o_lcrow, nl * sizeof(int));
-    copy(o_lcval, nl * sizeof(double));
-    copy(o_urcol, nu * sizeof(int));
-    copy(o_urval, nu * sizeof(double));
-    copy(o_ucrow, nu * sizeof(int));
-    copy(o_ucval, nu * sizeof(double));
     DeviceLU d;
     d.m = m;
     d.max_updates = max_updates;
@@ -544,7 +550,7 @@ __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh,
 //                             reads all still-missing operands at once and consumes the ready prefix in storage order;
 //   longer rows               WAVE tasks on the other four waves: a lane per entry (64 at a time), fixed DPP tree for the sum.
 // Right-hand sides are taken into the owners' registers first, then the components to be solved are overwritten by the
-// sentinel; a replaced position (mask) is no task and keeps its value (the callers hold it at zero during a U solve).
+// sentinel; in a U solve (HAS_DIAG) a replaced position (mask) is no task and keeps its value (the callers hold it at zero).
 // x0 / x1 must be complete (barrier) on entry; ends with a barrier.
 template <int NRHS, bool HAS_DIAG>
 __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShared& sh, const int sched) {
@@ -562,7 +568,7 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
     if (HAS_DIAG) {
         for (int k = tid; k < nz; k += blockDim.x) {
             const int pos = tk.z_pos[k];
-            if (lu_masked(sh, pos)) continue;
+            if (lu_masked(sh, pos)) continue;  // (only U has replaced positions, and only U has a diagonal)
             const double dinv = 1.0 / lu.diag[pos];
             x0[pos] = x0[pos] * dinv;
             if (NRHS == 2) x1[pos] = x1[pos] * dinv;
@@ -595,7 +601,7 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
                     own_st[r < 2 ? r : 0] = tk.w_start[k];
                     own_n[r < 2 ? r : 0] = tk.w_n[k];
                 }
-                if (!lu_masked(sh, p)) {
+                if (!(HAS_DIAG && lu_masked(sh, p))) {  // L never changes: its rows are never masked
                     own_pos[r] = p;
                     own_b0[r] = x0[p];
                     if (NRHS == 2) own_b1[r] = x1[p];
@@ -1219,24 +1225,52 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         return;
     }
     // ---- FTRAN ------------------------------------------------------------------------------------------------------------
+    // Implicit upper bounds (lp.ub): a column held in complemented form (x_j = u_j - x'_j) enters, and sits in the basis, with
+    // the opposite sign -- the factors hold sgn * a_j, so the sign goes into the FTRAN's input and the spike inherits it.
+    const bool bounded = lp.ub != nullptr;
+    double sgn_q = 1.0, ub_q = INFINITY;
+    if (bounded) {
+        sgn_q = lp.flipped[q] ? -1.0 : 1.0;
+        ub_q = lp.ub[q];
+        if (forced_q >= 0) cbar_q *= sgn_q;  // the candidates of the pricing pass carry the sign already
+    }
     lu_stamp(sh, 0);
     lu_clear(lu, sh, n_updates, false);
-    for (int e = lp.col_start[q] + tid; e < lp.col_start[q + 1]; e += T) sh.x0[lu.rowpos[lp.row_index[e]]] = lp.value[e];
+    for (int e = lp.col_start[q] + tid; e < lp.col_start[q + 1]; e += T) sh.x0[lu.rowpos[lp.row_index[e]]] = sgn_q * lp.value[e];
     __syncthreads();
     lu_stamp(sh, 1);
     int epoch = 0;
     lu_ftran_block(lu, sh, n_updates, epoch, lu.spike);
     // ---- alpha per basis slot (kept in x1), gamma_q, Harris pass 1 ----------------------------------------------------------
-    // harris_delta < 0: the reference's ratio test (exact minimum, ties to the lowest leaving column; tableau/mod.rs:287-313)
+    // harris_delta < 0: the reference's ratio test (exact minimum, ties to the lowest leaving column; tableau/mod.rs:287-313).
+    // With implicit bounds a basic variable may also leave at its upper bound -- rows with alpha_i < 0 whose basic variable has
+    // one -- and the entering variable may run into its own bound first (a bound flip, no basis change): the rules of
+    // ftran_ratio_fast_kernel (kernels.hip).
     const bool textbook = harris_delta < 0.0;
     const double harris_slack = textbook ? 0.0 : harris_delta;
+    // eligibility of row s and the distance of its basic variable to the bound it moves towards
+    auto row_room = [&](int s, double a, double* room) {
+        const bool allowed = !(skip_artificial_rows && lp.basis[s] < lp.n_art);
+        const double xs = lp.xB[s];
+        *room = fmax(xs, 0.0);
+        bool eligible = allowed && a > tol_pivot;
+        if (bounded && allowed && a < -tol_pivot) {
+            const double up = lp.xub[s];
+            if (up < INFINITY) {
+                eligible = true;
+                *room = fmax(up - xs, 0.0);
+            }
+        }
+        return eligible;
+    };
     double sumsq = 0.0, theta = INFINITY;
     for (int s = tid; s < m; s += T) {
         const double a = sh.x0[lu.colpos[s]];
         sh.x1[s] = a;
         lp.alpha[s] = a;
         sumsq += a * a;
-        if (a > tol_pivot && !(skip_artificial_rows && lp.basis[s] < lp.n_art)) theta = fmin(theta, (fmax(lp.xB[s], 0.0) + harris_slack) / a);
+        double room;
+        if (row_room(s, a, &room)) theta = fmin(theta, (room + harris_slack) / fabs(a));
     }
     const double gamma_q = 1.0 + block_reduce<0>(sumsq, sh.red);  // pivot_rule.rs:258
     const double theta_max = block_reduce<1>(theta, sh.red + 32);
@@ -1247,12 +1281,12 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         unsigned long long hrank = RANK_NONE;
         for (int s = tid; s < m; s += T) {
             const double a = sh.x1[s];
-            if (!(a > tol_pivot)) continue;
-            const int bs = lp.basis[s];
-            if (skip_artificial_rows && bs < lp.n_art) continue;
-            if (fmax(lp.xB[s], 0.0) / a <= theta_max) {
-                const unsigned long long rk = ((unsigned long long)(unsigned)bs << 32) | (unsigned)s;
-                const double key = textbook ? 1.0 : a;
+            double room;
+            if (!row_room(s, a, &room)) continue;
+            const double mag = fabs(a);
+            if (room / mag <= theta_max) {
+                const unsigned long long rk = ((unsigned long long)(unsigned)lp.basis[s] << 32) | (unsigned)s;
+                const double key = textbook ? 1.0 : mag;
                 if (hrank == RANK_NONE || key > hkey || (key == hkey && rk < hrank)) {
                     hkey = key;
                     hrank = rk;
@@ -1262,7 +1296,14 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         block_argbest(hkey, hrank, s_akey, s_arank);
         p = hrank == RANK_NONE ? -1 : (int)(hrank & 0xffffffffu);
     }
-    if (p < 0) {
+    const double alpha_pq = p >= 0 ? sh.x1[p] : 1.0;
+    double room_p = 0.0;
+    if (p >= 0) (void)row_room(p, alpha_pq, &room_p);
+    // step length: to the bound of the leaving variable, or (forced zero-level pivots) as the reference computes it
+    double xp = p < 0 ? INFINITY : ((forced_p >= 0 || !bounded) ? fmax(lp.xB[p], 0.0) / alpha_pq : room_p / fabs(alpha_pq));
+    const bool leaves_at_upper = bounded && forced_p < 0 && p >= 0 && alpha_pq < 0.0;
+    const bool flip = bounded && forced_p < 0 && ub_q < INFINITY && (p < 0 || ub_q <= xp);
+    if (p < 0 && !flip) {
         if (tid == 0) {
             if (mode == 0) ctl->status = ST_UNBOUNDED;
             ctl->q = q;
@@ -1274,11 +1315,10 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         return;
     }
     lu_stamp(sh, 5);
-    const double alpha_pq = sh.x1[p];
     if (mode == 2) {
         if (tid == 0) {
             ctl->q = q;
-            ctl->p = p;
+            ctl->p = flip ? -1 : p;
             ctl->cbar_q = cbar_q;
             ctl->gamma_q = gamma_q;
             ctl->pending = 0;
@@ -1287,12 +1327,41 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         }
         return;
     }
+    if (flip) {
+        // ---- bound flip: x_q runs from 0 to ub_q, the basis does not change; x_q is complemented so that it sits at 0 again ------
+        __syncthreads();
+        for (int s = tid; s < m; s += T) lp.xB[s] = lp.xB[s] - sh.x1[s] * ub_q;
+        for (int e = lp.col_start[q] + tid; e < lp.col_start[q + 1]; e += T) lp.rhs[lp.row_index[e]] -= ub_q * sgn_q * lp.value[e];
+        if (tid == 0) {
+            const int now_flipped = lp.flipped[q] ^ 1;
+            lp.flipped[q] = now_flipped;
+            lp.pos[q] = now_flipped ? -2 : -1;
+            ctl->flip_cost += (now_flipped ? 1.0 : -1.0) * ub_q * lp.cost[q];
+            ctl->q = q;
+            ctl->p = -1;
+            ctl->cbar_q = cbar_q;
+            ctl->minus_obj = minus_obj - cbar_q * ub_q;
+            ctl->iters = iters + 1;
+            ctl->bound_flips += 1;
+            ctl->pending = 0;  // no basis change: no update of the factors, no weight update
+            ctl->forced_q = -1;
+            ctl->forced_p = -1;
+            ctl->last_selected = q;
+        }
+        return;
+    }
     if (alpha_pq == 0.0) return;  // (a forced pivot on a zero element: the host sees that nothing happened)
     const int leaving = lp.basis[p];
-    const double xp = fmax(lp.xB[p], 0.0) / alpha_pq;
-    __syncthreads();  // every thread has read basis[p] / xB[p] before they change
+    const double xb_p = lp.xB[p];
+    const int leaving_flipped = bounded ? lp.flipped[leaving] : 0;
+    __syncthreads();  // every thread has read basis[p] / xB[p] / flipped[leaving] before they change
     // ---- x_B update (carry/mod.rs:295-325) ------------------------------------------------------------------------------
     for (int s = tid; s < m; s += T) lp.xB[s] = (s == p) ? xp : lp.xB[s] - sh.x1[s] * xp;
+    if (leaves_at_upper) {  // the leaving variable reached its upper bound: it is held in complemented form from now on
+        const double ub_l = xb_p + room_p;
+        const double sgn_l = leaving_flipped ? -1.0 : 1.0;
+        for (int e = lp.col_start[leaving] + tid; e < lp.col_start[leaving + 1]; e += T) lp.rhs[lp.row_index[e]] -= ub_l * sgn_l * lp.value[e];
+    }
     // ---- BTRAN with two right-hand sides: x0 <- e_p, x1 <- alpha (both per basis slot -> position space) -----------------------
     const int t = lu.colpos[p];
     const bool do_update = n_updates < refactor_period && n_updates < lu.max_updates;
@@ -1338,7 +1407,18 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     if (tid == 0) {
         lp.basis[p] = q;
         lp.pos[q] = p;
-        lp.pos[leaving] = -1;
+        if (bounded) {
+            int fl = leaving_flipped;
+            if (leaves_at_upper) {
+                fl ^= 1;
+                lp.flipped[leaving] = fl;
+                ctl->flip_cost += (fl ? 1.0 : -1.0) * (xb_p + room_p) * lp.cost[leaving];
+            }
+            lp.pos[leaving] = fl ? -2 : -1;
+            lp.xub[p] = ub_q;
+        } else {
+            lp.pos[leaving] = -1;
+        }
         ctl->q = q;
         ctl->p = p;
         ctl->leaving = leaving;
@@ -1380,10 +1460,14 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
     lu_clear(lu, sh, n_updates, false);
     double obj = 0.0;
     for (int s = threadIdx.x; s < m; s += blockDim.x) {
-        const double c = lp.cost[lp.basis[s]];
+        const int bj = lp.basis[s];
+        const double c = (lp.flipped && lp.flipped[bj]) ? -lp.cost[bj] : lp.cost[bj];  // a complemented basic column: B holds -a_j
         sh.x0[lu.colpos[s]] = c;
         obj += c * lp.xB[s];
     }
+    if (lp.flipped)  // constant of the complemented variables: sum ub_j c_j (cb_kernel, kernels.hip)
+        for (int j = threadIdx.x; j < lp.n; j += blockDim.x)
+            if (lp.flipped[j]) obj += lp.ub[j] * lp.cost[j];
     __syncthreads();
     int epoch = 0;
     lu_btran_block<1>(lu, sh, n_updates, epoch, [] {});

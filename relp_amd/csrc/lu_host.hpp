@@ -135,8 +135,23 @@ inline HostLUT<typename Ops::value> lu_factor_t(int m, const int* col_start, con
     f.rowpos.assign(m, -1);
     f.colpos.assign(m, -1);
     f.diag.assign(m, V(0));
-    std::vector<std::vector<Entry>> R(m);   // active entries of the active rows
-    std::vector<std::vector<int>> C(m);     // active rows of every active column (pattern)
+    // Working storage is kept per host thread and per arithmetic: a solve refactorises every few dozen pivots, and the ~4 m
+    // small vectors below cost more to allocate than the elimination of a Netlib basis costs to run (their capacity survives).
+    struct Workspace {
+        std::vector<std::vector<Entry>> R, Lrow, Urow;
+        std::vector<std::vector<int>> C;
+    };
+    static thread_local Workspace ws;
+    auto fresh = [m](auto& vv) {
+        if ((int)vv.size() < m) vv.resize(m);
+        for (int i = 0; i < m; ++i) vv[i].clear();
+    };
+    fresh(ws.R);
+    fresh(ws.C);
+    fresh(ws.Lrow);
+    fresh(ws.Urow);
+    std::vector<std::vector<Entry>>& R = ws.R;   // active entries of the active rows
+    std::vector<std::vector<int>>& C = ws.C;     // active rows of every active column (pattern)
     for (int j = 0; j < m; ++j)
         for (int e = col_start[j]; e < col_start[j + 1]; ++e) {
             if (ops.is_zero(value[e])) continue;
@@ -158,8 +173,8 @@ inline HostLUT<typename Ops::value> lu_factor_t(int m, const int* col_start, con
     for (int i = 0; i < m; ++i) rpos[i] = cpos[i] = row_at[i] = col_at[i] = i;
     std::vector<char> row_done(m, 0), col_done(m, 0);
     // L by (row, step, ratio) and U rows by step, in original indices until the end
-    std::vector<std::vector<Entry>> Lrow(m);              // Lrow[orig row] = (step k, ratio)
-    std::vector<std::vector<Entry>> Urow(m);              // Urow[k] = (orig col, value)
+    std::vector<std::vector<Entry>>& Lrow = ws.Lrow;      // Lrow[orig row] = (step k, ratio)
+    std::vector<std::vector<Entry>>& Urow = ws.Urow;      // Urow[k] = (orig col, value)
     std::vector<int> where(m, -1);                        // scatter workspace: column -> index in the row being edited
 
     auto row_max = [&](int i) {
@@ -239,8 +254,7 @@ inline HostLUT<typename Ops::value> lu_factor_t(int m, const int* col_start, con
         rb.remove(pi);
         cb.remove(pj);
         // ---- the pivot row becomes row k of U; it leaves the column patterns ----------------------------------
-        std::vector<Entry> prow;
-        prow.reserve(R[pi].size());
+        std::vector<Entry>& prow = Urow[k];
         for (const Entry& e : R[pi]) {
             if (e.col == pj) continue;
             prow.push_back(e);
@@ -249,7 +263,6 @@ inline HostLUT<typename Ops::value> lu_factor_t(int m, const int* col_start, con
                 if (cj[t] == pi) { cj[t] = cj.back(); cj.pop_back(); break; }
             cb.move(e.col, (int)cj.size());
         }
-        Urow[k] = prow;
         // ---- eliminate column pj from the other rows (decomposition/mod.rs:71-100) ----------------------------
         for (int i2 : C[pj]) {
             if (i2 == pi) continue;

@@ -209,8 +209,7 @@ void Solver::upload() {
     lu_mode_ = opt_.carry == RELP_CARRY_LU;
     refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : 31, LU_MAX_SLOTS - 1);  // T is solved by one wave
     if (lu_mode_) {
-        if (bounded_) throw std::invalid_argument("the LU carry does not take implicit bounds (use carry = RELP_CARRY_EXPLICIT)");
-        if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its solve vectors and factor headers in LDS: at most about 3200 rows (use the explicit carry beyond)");
+        if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its two solve vectors in LDS (16 bytes per row): at most about 8000 rows with this refactor period (use the explicit carry beyond)");
     }
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
     // structural columns); steepest edge only (the dense kernel implements that rule)
@@ -1492,10 +1491,18 @@ void Solver::refactor_lu(bool refresh_vectors) {
     }
     std::vector<int> rows(total);
     std::vector<double> vals(total);
+    std::vector<int> flipped;
+    if (bounded_) {  // implicit bounds: a complemented column sits in the basis with the opposite sign
+        flipped.resize(d_.n);
+        RELP_HIP(hipMemcpyAsync(flipped.data(), d_.flipped, d_.n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
     for (int k = 0; k < m; ++k) {
         const int a = h_col_start_[basis[k]], len = h_col_start_[basis[k] + 1] - a;
         std::copy(h_row_index_.begin() + a, h_row_index_.begin() + a + len, rows.begin() + cs[k]);
         std::copy(h_value_.begin() + a, h_value_.begin() + a + len, vals.begin() + cs[k]);
+        if (bounded_ && flipped[basis[k]])
+            for (int e = cs[k]; e < cs[k] + len; ++e) vals[e] = -vals[e];
     }
     LuOptions lo;
     lo.threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;

@@ -60,9 +60,43 @@ def test_graph_and_plain_launches_agree_with_the_lu_carry():
     assert (a.pivots_phase_one, a.pivots_phase_two) == (b.pivots_phase_one, b.pivots_phase_two)
 
 
-def test_lu_carry_rejects_what_it_does_not_support():
+BOUNDED = ["BOEING1", "BOEING2", "ETAMACRO", "FINNIS", "GFRD-PNC", "STANDATA", "STANDMPS", "VTP-BASE", "RECIPELP", "CAPRI", "80BAU3B", "BORE3D"]
+
+
+@pytest.mark.parametrize("name", BOUNDED)
+def test_lu_carry_with_implicit_bounds(name):
+    """The bounded ratio test (leaving at the upper bound, bound flips, complemented columns with the opposite sign in the
+    factors) inside the LU pivot kernel: the reference's optimum within its tolerance, certified on the basis mapped back to
+    the reference's formulation."""
+    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))[name]
+    solver = relp_amd.Solver(carry=LU, implicit_bounds=1, certify=1).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM
+    assert abs(result.objective - expected["expected"]) <= max(expected["tolerance"], 1e-9 * abs(expected["expected"])), (result.objective, expected)
+    assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
+    plain = relp_amd.Solver(carry=relp_amd.api.CARRY_EXPLICIT, certify=1).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    plain.solve_relaxation()
+    assert solver.objective_exact() == plain.objective_exact()
+    solver.close()
+    plain.close()
+
+
+def test_lu_carry_takes_the_rows_the_old_lds_limit_excluded():
+    """80BAU3B in the reference's formulation: 5746 rows (round 2's LU kernels stopped at about 3200)."""
+    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))["80BAU3B"]
+    solver = relp_amd.Solver(carry=LU).load_mps(os.path.join(ROOT, "data", "netlib", "80BAU3B.SIF"))
+    assert solver.m > 5000
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM and abs(result.objective - expected["expected"]) <= expected["tolerance"]
+    solver.close()
+
+
+def test_lu_carry_rejects_what_does_not_fit_its_lds():
+    from relp_amd.workloads import max_flow_graph
+    tail, head, capacity = max_flow_graph(2048, 16384)
+    model = relp_amd.Model.max_flow(2048, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, 2047)  # 18 k rows
     with pytest.raises(relp_amd.RelpError) as e:
-        relp_amd.Solver(carry=LU, implicit_bounds=1).load_mps(os.path.join(ROOT, "data", "netlib", "BOEING1.SIF"))
+        relp_amd.Solver(carry=LU).load_model(model)
     assert e.value.status == relp_amd.api.ERR_ARGUMENT
 
 
