@@ -93,52 +93,72 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
 }
 
 // One orientation of one triangular factor -> task list (lu.hpp `LuTasks`).  `start` / `idx` / `val`: its rows (CSR over the
-// position space), `level[i]`: dependency level of row i (0: reads nothing).  Rows are taken in level order; the epochs cut
-// that order wherever the owners' registers are full, so a task's operands are always tasks of its own or an earlier epoch.
+// position space); `lev_start` / `order`: the rows in dependency-level order (lu_schedules: a row of level l reads rows of
+// lower levels only).  Inside a level the rows are packed widest group first, so only the first group of a level can need
+// padding slots to reach its alignment.
 struct HostTasks {
-    std::vector<int> z_pos, t_pos, t_n, t_col, w_pos, w_start, w_n, w_idx, ep_t, ep_w;
-    std::vector<double> t_val, w_val;
+    std::vector<int> z_pos, s_pos, s_lev, s_info, s_xstart, s_xn, x_idx;
+    std::vector<double> x_val;
+    std::vector<std::vector<int>> col;      // [LU_TE][ns]
+    std::vector<std::vector<double>> val;
+    int levels = 0;
 };
-void build_tasks(int m, int stride, const int* start, const int* idx, const double* val, const std::vector<int>& order, HostTasks& out) {
+int group_log2(int n) {  // smallest g with LU_TE << g >= n, at most 6
+    int g = 0;
+    while (g < 6 && (LU_TE << g) < n) ++g;
+    return g;
+}
+void build_tasks(const int* start, const int* idx, const double* val, const std::vector<int>& lev_start, const std::vector<int>& order,
+                 HostTasks& out) {
     out = HostTasks{};
-    out.t_col.assign((size_t)LU_TE * stride, 0);
-    out.t_val.assign((size_t)LU_TE * stride, 0.0);
-    out.ep_t.push_back(0);
-    out.ep_w.push_back(0);
-    int in_epoch_t = 0, in_epoch_w = 0;
-    for (int r = 0; r < m; ++r) {
-        const int i = order[r];
-        const int n = start[i + 1] - start[i];
-        if (n == 0) {
-            out.z_pos.push_back(i);
-            continue;
+    out.col.assign(LU_TE, {});
+    out.val.assign(LU_TE, {});
+    out.levels = (int)lev_start.size() - 1;
+    auto push_slot = [&](int pos, int lev, int info, int xstart, int xn) {
+        out.s_pos.push_back(pos);
+        out.s_lev.push_back(lev);
+        out.s_info.push_back(info);
+        out.s_xstart.push_back(xstart);
+        out.s_xn.push_back(xn);
+        for (int e = 0; e < LU_TE; ++e) {
+            out.col[e].push_back(0);
+            out.val[e].push_back(0.0);
         }
-        const bool thread_task = n <= LU_TE;
-        if ((thread_task && in_epoch_t == LU_EPOCH_T) || (!thread_task && in_epoch_w == LU_EPOCH_W)) {
-            out.ep_t.push_back((int)out.t_pos.size());
-            out.ep_w.push_back((int)out.w_pos.size());
-            in_epoch_t = in_epoch_w = 0;
+    };
+    std::vector<int> rows;
+    for (int l = 0; l < out.levels; ++l) {
+        rows.clear();
+        for (int r = lev_start[l]; r < lev_start[l + 1]; ++r) {
+            const int i = order[r];
+            if (start[i + 1] == start[i]) out.z_pos.push_back(i);
+            else rows.push_back(i);
         }
-        if (thread_task) {
-            const int k = (int)out.t_pos.size();
-            out.t_pos.push_back(i);
-            out.t_n.push_back(n);
-            for (int e = 0; e < n; ++e) {
-                out.t_col[(size_t)e * stride + k] = idx[start[i] + e];
-                out.t_val[(size_t)e * stride + k] = val[start[i] + e];
+        std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return group_log2(start[a + 1] - start[a]) > group_log2(start[b + 1] - start[b]); });
+        for (int i : rows) {
+            const int n = start[i + 1] - start[i];
+            const int g = group_log2(n), G = 1 << g;
+            while ((int)out.s_pos.size() % G) push_slot(0, l, 0, 0, 0);  // padding: a slot of this level that does nothing
+            const int first = (int)out.s_pos.size();
+            const int inline_n = std::min(n, LU_TE * G);
+            const int xn = n - inline_n;
+            const int xstart = (int)out.x_idx.size();
+            for (int j = 0; j < G; ++j) {
+                // slot j of the group takes the entries j, j + G, j + 2 G, ... of the first LU_TE * G
+                int mine = 0;
+                push_slot(i, l, 0, xstart, xn);
+                for (int e = j; e < inline_n; e += G) {
+                    out.col[mine][first + j] = idx[start[i] + e];
+                    out.val[mine][first + j] = val[start[i] + e];
+                    ++mine;
+                }
+                out.s_info[first + j] = mine | (g << 8) | ((j == G - 1) ? 1 << 16 : 0) | (xn > 0 ? 1 << 17 : 0);
             }
-            ++in_epoch_t;
-        } else {
-            out.w_pos.push_back(i);
-            out.w_start.push_back((int)out.w_idx.size());
-            out.w_n.push_back(n);
-            out.w_idx.insert(out.w_idx.end(), idx + start[i], idx + start[i] + n);
-            out.w_val.insert(out.w_val.end(), val + start[i], val + start[i] + n);
-            ++in_epoch_w;
+            for (int e = inline_n; e < n; ++e) {
+                out.x_idx.push_back(idx[start[i] + e]);
+                out.x_val.push_back(val[start[i] + e]);
+            }
         }
     }
-    out.ep_t.push_back((int)out.t_pos.size());
-    out.ep_w.push_back((int)out.w_pos.size());
 }
 }  // namespace
 
@@ -155,7 +175,6 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
     const size_t cl = cap_l_, cu = cap_u_;
     const int ldt = max_updates + 1;
-    const int stride = (m + 63) & ~63;
     // ---- host: the four orientations and their task lists -----------------------------------------------------------------
     HostLU& fs = const_cast<HostLU&>(f);
     if (fs.lev_row[0].empty()) lu_schedules(fs);
@@ -183,10 +202,17 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         }
     }
     HostTasks tasks[4];
-    build_tasks(m, stride, f.l_start.data(), f.l_col.data(), f.l_val.data(), f.lev_row[0], tasks[0]);
-    build_tasks(m, stride, f.u_start.data(), f.u_col.data(), f.u_val.data(), f.lev_row[1], tasks[1]);
-    build_tasks(m, stride, ucs.data(), ucrow.data(), ucval.data(), f.lev_row[2], tasks[2]);
-    build_tasks(m, stride, lcs.data(), lcrow.data(), lcval.data(), f.lev_row[3], tasks[3]);
+    build_tasks(f.l_start.data(), f.l_col.data(), f.l_val.data(), f.lev_start[0], f.lev_row[0], tasks[0]);
+    build_tasks(f.u_start.data(), f.u_col.data(), f.u_val.data(), f.lev_start[1], f.lev_row[1], tasks[1]);
+    build_tasks(ucs.data(), ucrow.data(), ucval.data(), f.lev_start[2], f.lev_row[2], tasks[2]);
+    build_tasks(lcs.data(), lcrow.data(), lcval.data(), f.lev_start[3], f.lev_row[3], tasks[3]);
+    size_t max_slots = 0;
+    for (int k = 0; k < 4; ++k) max_slots = std::max(max_slots, tasks[k].s_pos.size());
+    if (max_slots > cap_slots_ || cap_slots_ == 0 || layout_changed) {
+        if (max_slots > cap_slots_ || cap_slots_ == 0) layout_changed = true;
+        cap_slots_ = std::max(cap_slots_, ((max_slots + max_slots / 2 + 1024) + 63) & ~size_t(63));
+    }
+    const int stride = (int)cap_slots_;
     // ---- uploaded prefix ----------------------------------------------------------------------------------------------
     Carver c;
     const size_t o_rowpos = c.take<int>(m), o_colpos = c.take<int>(m);
@@ -195,25 +221,23 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t o_counts = c.take<int>(4 * LU_CNT_WORDS);
     const size_t o_tasks = c.take<LuTasks>(4);
     struct TaskOffsets {
-        size_t z_pos, t_pos, t_n, w_pos, w_start, w_n, ep_t, ep_w, t_col, t_val, w_idx, w_val;
+        size_t z_pos, s_pos, s_lev, s_info, s_xstart, s_xn, s_col, s_val, x_idx, x_val;
     } to[4];
     for (int k = 0; k < 4; ++k) {
         to[k].z_pos = c.take<int>(m);
-        to[k].t_pos = c.take<int>(m);
-        to[k].t_n = c.take<int>(m);
-        to[k].w_pos = c.take<int>(m);
-        to[k].w_start = c.take<int>(m);
-        to[k].w_n = c.take<int>(m);
-        to[k].ep_t = c.take<int>(LU_MAX_EPOCHS + 2);
-        to[k].ep_w = c.take<int>(LU_MAX_EPOCHS + 2);
+        to[k].s_pos = c.take<int>(stride);
+        to[k].s_lev = c.take<int>(stride);
+        to[k].s_info = c.take<int>(stride);
+        to[k].s_xstart = c.take<int>(stride);
+        to[k].s_xn = c.take<int>(stride);
     }
     const size_t small_bytes = c.offset;  // everything up to here goes in one copy
     for (int k = 0; k < 4; ++k) {
         const size_t cap = (k == 0 || k == 3) ? cl : cu;
-        to[k].t_col = c.take<int>((size_t)LU_TE * stride);
-        to[k].t_val = c.take<double>((size_t)LU_TE * stride);
-        to[k].w_idx = c.take<int>(cap);
-        to[k].w_val = c.take<double>(cap);
+        to[k].s_col = c.take<int>((size_t)LU_TE * stride);
+        to[k].s_val = c.take<double>((size_t)LU_TE * stride);
+        to[k].x_idx = c.take<int>(cap);
+        to[k].x_val = c.take<double>(cap);
     }
     const size_t o_lrcol = c.take<int>(cl), o_lcrow = c.take<int>(cl), o_lrval = c.take<double>(cl), o_lcval = c.take<double>(cl);
     const size_t o_urcol = c.take<int>(cu), o_ucrow = c.take<int>(cu), o_urval = c.take<double>(cu), o_ucval = c.take<double>(cu);
@@ -252,33 +276,32 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         for (int k = 0; k < 4; ++k) {
             LuTasks t;
             t.z_pos = I(to[k].z_pos);
-            t.t_pos = I(to[k].t_pos); t.t_n = I(to[k].t_n); t.t_col = I(to[k].t_col); t.t_val = D(to[k].t_val);
-            t.w_pos = I(to[k].w_pos); t.w_start = I(to[k].w_start); t.w_n = I(to[k].w_n); t.w_idx = I(to[k].w_idx); t.w_val = D(to[k].w_val);
-            t.ep_t = I(to[k].ep_t); t.ep_w = I(to[k].ep_w);
+            t.s_pos = I(to[k].s_pos); t.s_lev = I(to[k].s_lev); t.s_info = I(to[k].s_info);
+            t.s_xstart = I(to[k].s_xstart); t.s_xn = I(to[k].s_xn);
+            t.s_col = I(to[k].s_col); t.s_val = D(to[k].s_val);
+            t.x_idx = I(to[k].x_idx); t.x_val = D(to[k].x_val);
             std::memcpy(&table[k], &t, sizeof(LuTasks));
         }
     }
     int* counts = reinterpret_cast<int*>(h + o_counts);
     for (int k = 0; k < 4; ++k) {
         const HostTasks& t = tasks[k];
-        const int epochs = (int)t.ep_t.size() - 1;
-        if (epochs > LU_MAX_EPOCHS) throw std::runtime_error("LU task list: too many epochs");
         counts[k * LU_CNT_WORDS + LU_CNT_Z] = (int)t.z_pos.size();
-        counts[k * LU_CNT_WORDS + LU_CNT_T] = (int)t.t_pos.size();
-        counts[k * LU_CNT_WORDS + LU_CNT_W] = (int)t.w_pos.size();
-        counts[k * LU_CNT_WORDS + LU_CNT_EPOCHS] = epochs;
+        counts[k * LU_CNT_WORDS + LU_CNT_SLOTS] = (int)t.s_pos.size();
+        counts[k * LU_CNT_WORDS + LU_CNT_LEVELS] = t.levels;
+        counts[k * LU_CNT_WORDS + 3] = 0;
         put_i(to[k].z_pos, t.z_pos);
-        put_i(to[k].t_pos, t.t_pos);
-        put_i(to[k].t_n, t.t_n);
-        put_i(to[k].w_pos, t.w_pos);
-        put_i(to[k].w_start, t.w_start);
-        put_i(to[k].w_n, t.w_n);
-        put_i(to[k].ep_t, t.ep_t);
-        put_i(to[k].ep_w, t.ep_w);
-        put_i(to[k].t_col, t.t_col);
-        put_d(to[k].t_val, t.t_val);
-        put_i(to[k].w_idx, t.w_idx);
-        put_d(to[k].w_val, t.w_val);
+        put_i(to[k].s_pos, t.s_pos);
+        put_i(to[k].s_lev, t.s_lev);
+        put_i(to[k].s_info, t.s_info);
+        put_i(to[k].s_xstart, t.s_xstart);
+        put_i(to[k].s_xn, t.s_xn);
+        for (int e = 0; e < LU_TE; ++e) {
+            put_i(to[k].s_col + (size_t)e * stride * sizeof(int), t.col[e]);
+            put_d(to[k].s_val + (size_t)e * stride * sizeof(double), t.val[e]);
+        }
+        put_i(to[k].x_idx, t.x_idx);
+        put_d(to[k].x_val, t.x_val);
     }
     put_i(o_lrcol, f.l_col);
     put_d(o_lrval, f.l_val);
@@ -299,15 +322,15 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
             if (bytes) RELP_HIP(hipMemcpyAsync(dev_ + at, h + at, bytes, hipMemcpyHostToDevice, stream));
         };
         for (int k = 0; k < 4; ++k) {
-            const size_t nt = tasks[k].t_pos.size();
-            if (nt) {  // ELL: rows e of the two arrays, each used up to nt
+            const size_t ns = tasks[k].s_pos.size();
+            if (ns) {  // ELL: rows e of the two arrays, each used up to ns
                 for (int e = 0; e < LU_TE; ++e) {
-                    copy(to[k].t_col + (size_t)e * stride * sizeof(int), nt * sizeof(int));
-                    copy(to[k].t_val + (size_t)e * stride * sizeof(double), nt * sizeof(double));
+                    copy(to[k].s_col + (size_t)e * stride * sizeof(int), ns * sizeof(int));
+                    copy(to[k].s_val + (size_t)e * stride * sizeof(double), ns * sizeof(double));
                 }
             }
-            copy(to[k].w_idx, tasks[k].w_idx.size() * sizeof(int));
-            copy(to[k].w_val, tasks[k].w_val.size() * sizeof(double));
+            copy(to[k].x_idx, tasks[k].x_idx.size() * sizeof(int));
+            copy(to[k].x_val, tasks[k].x_val.size() * sizeof(double));
         }
         copy(o_lrcol, nl * sizeof(int));
         copy(o_lrval, nl * sizeof(double));
@@ -378,16 +401,8 @@ typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) int lds_i32;
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 typedef __attribute__((address_space(3))) char lds_i8;
-
-// A component of the solution vector that is not solved yet holds this quiet NaN (a payload no arithmetic produces); an
-// operand is ready when it reads as anything else.  Round 2 solved level by level with a workgroup barrier per level: ~1 k
-// cycles per level whatever its width (record -> entry -> operand -> sum -> publish are five dependent LDS round trips, plus
-// the barrier), 20-45 levels per triangle, four triangles per pivot.  Here every row is owned by a lane (or, a long row, by a
-// wave) that POLLS its operands in LDS and publishes its component the moment the last one arrives: a dependency costs one
-// LDS round trip (~100-150 cycles), waves whose rows are done stop polling, and there is no barrier inside a solve.
-constexpr unsigned long long LU_SENTINEL = 0x7ff85eed5eed5eedull;
-__device__ __forceinline__ bool lu_ready(double v) { return (unsigned long long)__double_as_longlong(v) != LU_SENTINEL; }
-__device__ __forceinline__ double lu_sentinel() { return __longlong_as_double((long long)LU_SENTINEL); }
+typedef const __attribute__((address_space(1))) int* gptr_i32;
+typedef const __attribute__((address_space(1))) double* gptr_f64;
 
 // ---- eta files --------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_value(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -524,6 +539,10 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
     s.t_prev = nullptr;
     return s;
 }
+// Barrier for data exchanged through LDS only: this wave's LDS operations have completed, global loads may stay in flight.
+// (__syncthreads() also drains vmcnt: with the next task's record on its way from L2 that put a global round trip -- 2-3 k
+// cycles -- into every level of a solve.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ bool lu_masked(const LuShared& sh, int pos) { return (sh.mask[pos >> 5] >> (pos & 31)) & 1u; }
 // x0 (x1) <- 0, T staged from global, the mask of the replaced positions built.  Ends with a barrier.
 __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh, int n_updates, bool two) {
@@ -542,212 +561,146 @@ __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh,
     __syncthreads();
 }
 
+// Sums over aligned groups of 2^g lanes (g per lane: the groups of one wave differ), valid in the LAST lane of each group.
+__device__ __forceinline__ double group_sum_by(double v, const int g) {
+    const double s1 = v + dpp_f64<DPP_QUAD_1032, 0xF>(0.0, v);
+    const double s2 = s1 + dpp_f64<DPP_QUAD_2301, 0xF>(0.0, s1);
+    const double s3 = s2 + dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, s2);
+    double s4 = s2 + dpp_f64<DPP_ROW_ROR4, 0xF>(0.0, s2);
+    s4 += dpp_f64<DPP_ROW_ROR8, 0xF>(0.0, s4);
+    const double s5 = s4 + dpp_f64<DPP_ROW_BCAST15, 0xA>(0.0, s4);
+    const double s6 = s5 + dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, s5);
+    return g == 0 ? v : g == 1 ? s1 : g == 2 ? s2 : g == 3 ? s3 : g == 4 ? s4 : g == 5 ? s5 : s6;
+}
+
 // In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i]  for every row i of one triangular factor in one orientation
-// (`sched`: 0 L by rows, 1 U by rows, 2 U by columns, 3 L by columns), without barriers between dependent rows.
-//   rows without entries      all threads, one pass (only the division by the diagonal, if any);
-//   rows of <= LU_TE entries  THREAD tasks: lane k of the twelve task waves owns task k, k + 768, ... (dependency order, so a
-//                             task never waits for a later task of its own lane); entries in registers; every polling round
-//                             reads all still-missing operands at once and consumes the ready prefix in storage order;
-//   longer rows               WAVE tasks on the other four waves: a lane per entry (64 at a time), fixed DPP tree for the sum.
-// Right-hand sides are taken into the owners' registers first, then the components to be solved are overwritten by the
-// sentinel; in a U solve (HAS_DIAG) a replaced position (mask) is no task and keeps its value (the callers hold it at zero).
+// (`sched`: 0 L by rows, 1 U by rows, 2 U by columns, 3 L by columns), level by level, one barrier per level.
+//   rows without entries   all threads, one pass (only the division by the diagonal, if any);
+//   every other row        1, 2, 4 ... 64 consecutive SLOTS of at most LU_TE entries each (lu.hpp); slot s belongs to thread
+//                          s mod 1024, which holds the slot's record and entries in registers; at the row's level its lanes read
+//                          their operands from LDS in one batch, multiply-add, combine by a fixed DPP tree, and the last lane
+//                          writes the component.
+// Round 2 kept records and entries in LDS too (record -> entries -> operands: three dependent round trips per level, ~1 k
+// cycles with the barrier).  Two other forms were built this round, measured and dropped: (i) barrier-free, every row
+// polling its operands (a sentinel NaN for "not solved yet"): 25-50 k cycles per triangle on 25FV47 against round 2's 18-35 k --
+// a spinning wave64 costs 4 cycles of its SIMD per instruction, and four such waves per SIMD starve the one wave the chain
+// waits for, whereas a wave parked at s_barrier costs nothing; (ii) long rows as one wave task each with their entries read
+// from L2 in the level: 44-90 k cycles, every such row paid a global round trip.
+// In a U solve (HAS_DIAG) a replaced position (mask) is no task and keeps its value (the callers hold it at zero).
 // x0 / x1 must be complete (barrier) on entry; ends with a barrier.
 template <int NRHS, bool HAS_DIAG>
 __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShared& sh, const int sched) {
-    const LuTasks tk = lu.tasks[sched];
+    // The task arrays come out of a table in device memory: typed as GLOBAL pointers here.  As generic pointers they compile to
+    // flat_load, which counts in lgkmcnt as well as vmcnt -- every LDS wait (and the s_waitcnt lgkmcnt(0) of the level barrier)
+    // then waits for whatever slot record is still on its way from L2: 1.5 k cycles per level instead of 300.
+    const LuTasks tk_generic = lu.tasks[sched];
+    struct {
+        gptr_i32 z_pos, s_pos, s_lev, s_info, s_col, s_xstart, s_xn, x_idx;
+        gptr_f64 s_val, x_val;
+    } tk = {(gptr_i32)tk_generic.z_pos, (gptr_i32)tk_generic.s_pos, (gptr_i32)tk_generic.s_lev, (gptr_i32)tk_generic.s_info,
+            (gptr_i32)tk_generic.s_col, (gptr_i32)tk_generic.s_xstart, (gptr_i32)tk_generic.s_xn, (gptr_i32)tk_generic.x_idx,
+            (gptr_f64)tk_generic.s_val, (gptr_f64)tk_generic.x_val};
+    const gptr_f64 diag = (gptr_f64)lu.diag;
     const int nz = lu.counts[sched * LU_CNT_WORDS + LU_CNT_Z];
-    const int n_epochs = lu.counts[sched * LU_CNT_WORDS + LU_CNT_EPOCHS];
-    const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const bool task_wave = wave < LU_TASK_WAVES;  // (wave-uniform role; every barrier below is outside the role branches)
-    const int ww = wave - LU_TASK_WAVES;
+    const int ns = lu.counts[sched * LU_CNT_WORDS + LU_CNT_SLOTS];
+    const int n_levels = lu.counts[sched * LU_CNT_WORDS + LU_CNT_LEVELS];
+    const int tid = threadIdx.x, T = blockDim.x;
     const int stride = lu.task_stride;
-    constexpr int TT = LU_TASK_WAVES * WAVE;
     volatile lds_f64* x0 = sh.x0;
     volatile lds_f64* x1 = sh.x1;
-    if (HAS_DIAG) {
-        for (int k = tid; k < nz; k += blockDim.x) {
-            const int pos = tk.z_pos[k];
-            if (lu_masked(sh, pos)) continue;  // (only U has replaced positions, and only U has a diagonal)
-            const double dinv = 1.0 / lu.diag[pos];
-            x0[pos] = x0[pos] * dinv;
-            if (NRHS == 2) x1[pos] = x1[pos] * dinv;
-        }
-    }
-    const double sentinel = lu_sentinel();
-    for (int ep = 0; ep < n_epochs; ++ep) {
-        const int t_first = tk.ep_t[ep], t_end = tk.ep_t[ep + 1];
-        const int w_first = tk.ep_w[ep], w_end = tk.ep_w[ep + 1];
-        // ---- owners take position, right-hand side, 1 / diagonal (and, wave tasks, entry range) of their tasks -------------------
-        // thread tasks: slot r = task t_first + r * 768 + tid;  wave tasks: slot q = this wave's task q * 64 + lane of the epoch
-        int own_pos[LU_ROUNDS], own_st[2], own_n[2];
-        double own_b0[LU_ROUNDS], own_b1[LU_ROUNDS], own_dinv[LU_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < LU_ROUNDS; ++r) {
-            own_pos[r] = -1;
-            own_b0[r] = own_b1[r] = 0.0;
-            own_dinv[r] = 1.0;
-            int k = -1;
-            if (task_wave) {
-                k = t_first + r * TT + tid;
-                if (k >= t_end) k = -1;
-            } else if (r < 2) {
-                k = w_first + (r * WAVE + lane) * LU_WAVE_WAVES + ww;
-                if (k >= w_end) k = -1;
-            }
-            if (k >= 0) {
-                const int p = task_wave ? tk.t_pos[k] : tk.w_pos[k];
-                if (!task_wave) {
-                    own_st[r < 2 ? r : 0] = tk.w_start[k];
-                    own_n[r < 2 ? r : 0] = tk.w_n[k];
-                }
-                if (!(HAS_DIAG && lu_masked(sh, p))) {  // L never changes: its rows are never masked
-                    own_pos[r] = p;
-                    own_b0[r] = x0[p];
-                    if (NRHS == 2) own_b1[r] = x1[p];
-                    if (HAS_DIAG) own_dinv[r] = 1.0 / lu.diag[p];
-                }
-            }
-        }
-        // the first round's entries travel while the barriers below pass
-        int col[LU_TE], n_entries = 0;
+    // ---- this thread's first two slots travel while the rows without entries are done ---------------------------------------------
+    struct Slot {
+        int pos, lev, info;  // lev: -1 when there is none
+        double dinv;
+        int col[LU_TE];
         double val[LU_TE];
-        {
-            const int k0 = t_first + tid < t_end ? t_first + tid : (t_first < t_end ? t_first : 0);
-            if (task_wave && own_pos[0] >= 0) n_entries = tk.t_n[k0];
+    };
+    auto load_slot = [&](int k, Slot& r) {
+        r.pos = 0;
+        r.lev = -1;
+        r.info = 0;
+        r.dinv = 1.0;
+#pragma unroll
+        for (int e = 0; e < LU_TE; ++e) {
+            r.col[e] = 0;
+            r.val[e] = 0.0;
+        }
+        if (k < ns) {  // (no loads in flight for a thread that has no further slot: nothing for a later level to wait for)
 #pragma unroll
             for (int e = 0; e < LU_TE; ++e) {
-                col[e] = task_wave ? tk.t_col[(size_t)e * stride + k0] : 0;
-                val[e] = task_wave ? tk.t_val[(size_t)e * stride + k0] : 0.0;
+                r.col[e] = tk.s_col[(size_t)e * stride + k];
+                r.val[e] = tk.s_val[(size_t)e * stride + k];
+            }
+            r.pos = tk.s_pos[k];
+            r.lev = tk.s_lev[k];
+            r.info = tk.s_info[k];
+            if (HAS_DIAG) {
+                r.dinv = 1.0 / diag[r.pos];
+                if (lu_masked(sh, r.pos)) r.info = 0;  // a replaced position: no row of the triangle any more
             }
         }
-        __syncthreads();
+    };
+    Slot cur, nxt;
+    int k_mine = tid;
+    load_slot(k_mine, cur);
+    load_slot(k_mine + T, nxt);
+    if (HAS_DIAG) {
+        for (int k = tid; k < nz; k += T) {
+            const int p = tk.z_pos[k];
+            if (lu_masked(sh, p)) continue;
+            const double d = 1.0 / diag[p];
+            x0[p] = x0[p] * d;
+            if (NRHS == 2) x1[p] = x1[p] * d;
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < n_levels; ++l) {
+        while (__any(cur.lev == l)) {  // (more than one turn only when the level is wider than the workgroup)
+            const bool active = cur.lev == l;
+            const int n_mine = active ? (cur.info & 0xff) : 0;
+            const int g = (cur.info >> 8) & 0xff;
+            double xv[LU_TE];
 #pragma unroll
-        for (int r = 0; r < LU_ROUNDS; ++r)
-            if (own_pos[r] >= 0) x0[own_pos[r]] = sentinel;
-        __syncthreads();
-        if (task_wave) {
-            // ---- thread tasks ------------------------------------------------------------------------------------------------
-            const int rounds = (t_end - t_first + TT - 1) / TT;
+            for (int e = 0; e < LU_TE; ++e) xv[e] = x0[cur.col[e]];  // (padding: position 0, value 0)
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int r = 0; r < LU_ROUNDS; ++r) {
-                if (r >= rounds) break;
-                const bool have = own_pos[r] >= 0;
-                if (r > 0) {
-                    const int k = t_first + r * TT + tid;
-                    const int kk = k < t_end ? k : t_first;  // (clamped: the loads are unconditional)
-                    n_entries = have ? tk.t_n[kk] : 0;
+            for (int e = 0; e < LU_TE; ++e)
+                if (e < n_mine) s0 += cur.val[e] * xv[e];
+            if (NRHS == 2) {
 #pragma unroll
-                    for (int e = 0; e < LU_TE; ++e) {
-                        col[e] = tk.t_col[(size_t)e * stride + kk];
-                        val[e] = tk.t_val[(size_t)e * stride + kk];
-                    }
-                }
-                const int n = n_entries;
-                double a0 = own_b0[r], a1 = own_b1[r];
-                int done_entries = 0;
-                bool done = !have;
-                for (;;) {
-                    // every round reads all eight operand slots (padding points at position 0): one batch of ds_reads, no branch
-                    double xv[LU_TE];
+                for (int e = 0; e < LU_TE; ++e) xv[e] = x1[cur.col[e]];
 #pragma unroll
-                    for (int e = 0; e < LU_TE; ++e) xv[e] = x0[col[e]];
-                    int ready_until = done_entries;
-#pragma unroll
-                    for (int e = 0; e < LU_TE; ++e)
-                        if (e == ready_until && e < n && lu_ready(xv[e])) ready_until = e + 1;
-                    const bool progressed = !done && ready_until > done_entries;
-                    if (__any(progressed)) {
-                        double yv[LU_TE];
-                        if (NRHS == 2) {
-#pragma unroll
-                            for (int e = 0; e < LU_TE; ++e) yv[e] = x1[col[e]];
-                        }
-                        if (progressed) {
-#pragma unroll
-                            for (int e = 0; e < LU_TE; ++e)
-                                if (e >= done_entries && e < ready_until) {
-                                    a0 -= val[e] * xv[e];
-                                    if (NRHS == 2) a1 -= val[e] * yv[e];
-                                }
-                            done_entries = ready_until;
-                            if (done_entries >= n) {
-                                if (NRHS == 2) x1[own_pos[r]] = a1 * own_dinv[r];  // (before x0: whoever sees x0 ready reads x1 afterwards)
-                                x0[own_pos[r]] = a0 * own_dinv[r];
-                                done = true;
-                            }
-                        }
-                    } else {
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (__all(done)) break;
-                }
+                for (int e = 0; e < LU_TE; ++e)
+                    if (e < n_mine) s1 += cur.val[e] * xv[e];
             }
-        } else {
-            // ---- wave tasks: a lane per entry, the next task's entries in flight while this one polls ---------------------------
-            const int count = w_end > w_first + ww ? (w_end - w_first - ww + LU_WAVE_WAVES - 1) / LU_WAVE_WAVES : 0;
-            int c_next = 0;
-            double v_next = 0.0;
-            if (count > 0) {
-                const int st = lane_value(own_st[0], 0), n = lane_value(own_n[0], 0);
-                if (lane < n) {
-                    c_next = tk.w_idx[st + lane];
-                    v_next = tk.w_val[st + lane];
-                }
-            }
-            for (int j = 0; j < count; ++j) {
-                const int slot = j & (WAVE - 1);
-                const int p = lane_value(j < WAVE ? own_pos[0] : own_pos[1], slot);
-                const int st = lane_value(j < WAVE ? own_st[0] : own_st[1], slot), n = lane_value(j < WAVE ? own_n[0] : own_n[1], slot);
-                const double rhs0 = lane_value(j < WAVE ? own_b0[0] : own_b0[1], slot);
-                const double rhs1 = NRHS == 2 ? lane_value(j < WAVE ? own_b1[0] : own_b1[1], slot) : 0.0;
-                const double dinv = lane_value(j < WAVE ? own_dinv[0] : own_dinv[1], slot);
-                int c = c_next;
-                double v = v_next;
-                if (j + 1 < count) {
-                    const int slot2 = (j + 1) & (WAVE - 1);
-                    const int st2 = lane_value(j + 1 < WAVE ? own_st[0] : own_st[1], slot2), n2 = lane_value(j + 1 < WAVE ? own_n[0] : own_n[1], slot2);
-                    c_next = 0;
-                    v_next = 0.0;
-                    if (lane < n2) {
-                        c_next = tk.w_idx[st2 + lane];
-                        v_next = tk.w_val[st2 + lane];
-                    }
-                }
-                if (p < 0) continue;  // (a replaced position: no row of the triangle any more)
-                double s0 = 0.0, s1 = 0.0;
-                for (int base = 0; base < n; base += WAVE) {
-                    const bool in = base + lane < n;
-                    if (base > 0) {
-                        c = in ? tk.w_idx[st + base + lane] : 0;
-                        v = in ? tk.w_val[st + base + lane] : 0.0;
-                    }
-                    double xv = 0.0;
-                    bool got = !in;
-                    for (;;) {
-                        if (!got) {
-                            xv = x0[c];
-                            got = lu_ready(xv);
-                        }
-                        if (__all(got)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (in) {
-                        s0 += v * xv;
+            if (__any(active && ((cur.info >> 17) & 1))) {  // rows of more than 64 LU_TE entries: the rest from the arena (rare)
+                if (active && ((cur.info >> 17) & 1)) {
+                    const int xs = tk.s_xstart[k_mine], xn = tk.s_xn[k_mine];
+                    for (int e = (tid & (WAVE - 1)); e < xn; e += WAVE) {
+                        const int c = tk.x_idx[xs + e];
+                        const double v = tk.x_val[xs + e];
+                        s0 += v * x0[c];
                         if (NRHS == 2) s1 += v * x1[c];
                     }
                 }
-                s0 = wave_sum(s0);
-                if (NRHS == 2) s1 = wave_sum(s1);
-                if (lane == LAST) {
-                    if (NRHS == 2) x1[p] = (rhs1 - s1) * dinv;
-                    x0[p] = (rhs0 - s0) * dinv;
-                }
+            }
+            if (__any(active && g > 0)) {  // some row of this turn spans several lanes
+                s0 = group_sum_by(s0, active ? g : 0);
+                if (NRHS == 2) s1 = group_sum_by(s1, active ? g : 0);
+            }
+            if (active && ((cur.info >> 16) & 1) && (cur.info & 0xff) > 0) {
+                x0[cur.pos] = (x0[cur.pos] - s0) * cur.dinv;
+                if (NRHS == 2) x1[cur.pos] = (x1[cur.pos] - s1) * cur.dinv;
+            }
+            if (active) {  // on to this thread's next slot: it arrived long ago; the one after it starts travelling now
+                k_mine += T;
+                cur = nxt;
+                load_slot(k_mine + T, nxt);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
-    if (n_epochs == 0) __syncthreads();
+    __syncthreads();
 }
 
 // FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve (trailing block by one

@@ -34,31 +34,27 @@ enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_ST
 enum : int { LU_FLAG_UNSTABLE = 1, LU_FLAG_OVERFLOW = 2 };
 constexpr int LU_MAX_SLOTS = 64;  // one wave solves T
 
-// A triangular factor in one orientation as a TASK LIST for the synchronisation-free solve (lu.hip: lu_solve_tasks).  The rows
-// (columns) of the factor are sorted by dependency level; a row without entries needs no solve (`z_pos`), a row of at most
-// LU_TE entries is a THREAD task (entries inline, ELL layout: entry e of task k at [e * stride + k]), a longer one a WAVE task
-// (entries in a packed arena, the 64 lanes share them).  Tasks wait for their operands by polling the solution vector in LDS
-// (a not-yet-solved component holds a sentinel), not at barriers.  `ep_t` / `ep_w` cut both lists into epochs whose right-hand
-// sides fit the owners' registers (all of a normal basis is one epoch).
+// A triangular factor in one orientation as a TASK LIST for the level-synchronous solve (lu.hip: lu_solve_tasks).  The rows
+// (columns) of the factor are sorted by dependency level.  A row without entries needs no solve (`z_pos`).  Every other row is
+// packed into G = 1, 2, 4, ... 64 consecutive SLOTS (G = the power of two that gives each slot at most LU_TE entries; aligned to
+// G, so a row never straddles a wave); slot s belongs to thread s mod 1024, which keeps the slot's entries in REGISTERS (ELL
+// layout: entry e of slot s at [e * stride + s]).  One barrier per level, and between two barriers ONE dependent LDS round trip
+// (the operands), the multiply-adds, a DPP sum over the row's lanes and one LDS write.  A row of more than 64 LU_TE entries
+// keeps the rest in `x_idx` / `x_val` (read in the level; rare).
 #ifndef RELP_LU_TE
-#define RELP_LU_TE 6
+#define RELP_LU_TE 4
 #endif
 constexpr int LU_TE = RELP_LU_TE;   // (a macro only so that micro-variants can be compiled side by side)
-constexpr int LU_TASK_WAVES = 12;   // waves 0 .. 11 of the 16 run thread tasks, one task per lane and round
-constexpr int LU_WAVE_WAVES = 4;    // waves 12 .. 15 run wave tasks
-constexpr int LU_ROUNDS = 2;        // thread tasks per lane and epoch
-constexpr int LU_EPOCH_T = LU_ROUNDS * LU_TASK_WAVES * 64;
-constexpr int LU_EPOCH_W = 2 * 64 * LU_WAVE_WAVES;
-constexpr int LU_MAX_EPOCHS = 62;
 struct LuTasks {
-    int* z_pos = nullptr;                                        // [nz]
-    int* t_pos = nullptr; int* t_n = nullptr;                    // [nt]
-    int* t_col = nullptr; double* t_val = nullptr;               // [LU_TE][stride]
-    int* w_pos = nullptr; int* w_start = nullptr; int* w_n = nullptr;  // [nw]
-    int* w_idx = nullptr; double* w_val = nullptr;               // arena
-    int* ep_t = nullptr; int* ep_w = nullptr;                    // [epochs + 1] each
+    int* z_pos = nullptr;        // [nz]
+    int* s_pos = nullptr;        // [ns] position of the slot's row
+    int* s_lev = nullptr;        // [ns] its level (>= 1)
+    int* s_info = nullptr;       // [ns] entries in this slot | log2(G) << 8 | (last lane of the group) << 16 | (row has extra entries) << 17
+    int* s_col = nullptr; double* s_val = nullptr;   // [LU_TE][stride]
+    int* s_xstart = nullptr; int* s_xn = nullptr;    // [ns] extra entries of the row (G = 64 only): range in x_idx / x_val
+    int* x_idx = nullptr; double* x_val = nullptr;
 };
-enum : int { LU_CNT_Z = 0, LU_CNT_T = 1, LU_CNT_W = 2, LU_CNT_EPOCHS = 3, LU_CNT_WORDS = 4 };
+enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_WORDS = 4 };
 
 struct DeviceLU {
     int m = 0;
@@ -82,7 +78,7 @@ struct DeviceLU {
     double* spike = nullptr;  // [m] position space: the FTRAN intermediate before the U solve (mod.rs:196 `spike`)
     // task lists of the four triangular solves: 0 L by rows, 1 U by rows (FTRAN), 2 U by columns, 3 L by columns (BTRAN)
     const LuTasks* tasks = nullptr;  // [4], in device memory (forty-eight pointers would not fit the kernel's scalar registers)
-    int task_stride = 0;      // ELL stride of the thread tasks (m rounded up to a multiple of 64)
+    int task_stride = 0;      // ELL stride of the slots (their capacity: a multiple of 64)
     int* counts = nullptr;    // [4][LU_CNT_WORDS]: device-resident, so that a captured graph survives a refactorisation
     int* state = nullptr;     // LU_* words
 };
@@ -109,7 +105,7 @@ private:
     size_t dev_capacity_ = 0;
     char* staging_ = nullptr;
     size_t staging_capacity_ = 0;
-    size_t cap_l_ = 0, cap_u_ = 0;
+    size_t cap_l_ = 0, cap_u_ = 0, cap_slots_ = 0;
 };
 
 // kernels (lu.hip); all single-workgroup, stream-ordered
