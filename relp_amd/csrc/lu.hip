@@ -93,12 +93,12 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
 }
 
 // One orientation of one triangular factor -> task list (lu.hpp `LuTasks`).  `start` / `idx` / `val`: its rows (CSR over the
-// position space); `lev_start` / `order`: the rows in dependency-level order (lu_schedules: a row of level l reads rows of
-// lower levels only).  Inside a level the rows are packed widest group first, so only the first group of a level can need
-// padding slots to reach its alignment.
+// position space); `diag`: nullptr for L; `lev_start` / `order`: the rows in dependency-level order (lu_schedules: a row of
+// level l reads rows of lower levels only).  Inside a level the rows are packed widest group first, so only the first group of
+// a level can need padding slots to reach its alignment.
 struct HostTasks {
-    std::vector<int> z_pos, s_pos, s_lev, s_info, s_xstart, s_xn, x_idx;
-    std::vector<double> x_val;
+    std::vector<int> z_pos, s_pos, s_lev, s_flags, s_xstart, s_xn, x_idx, chunk;
+    std::vector<double> z_dinv, s_dinv, x_val;
     std::vector<std::vector<int>> col;      // [LU_TE][ns]
     std::vector<std::vector<double>> val;
     int levels = 0;
@@ -108,16 +108,17 @@ int group_log2(int n) {  // smallest g with LU_TE << g >= n, at most 6
     while (g < 6 && (LU_TE << g) < n) ++g;
     return g;
 }
-void build_tasks(const int* start, const int* idx, const double* val, const std::vector<int>& lev_start, const std::vector<int>& order,
-                 HostTasks& out) {
+void build_tasks(const int* start, const int* idx, const double* val, const double* diag, const std::vector<int>& lev_start,
+                 const std::vector<int>& order, HostTasks& out) {
     out = HostTasks{};
     out.col.assign(LU_TE, {});
     out.val.assign(LU_TE, {});
     out.levels = (int)lev_start.size() - 1;
-    auto push_slot = [&](int pos, int lev, int info, int xstart, int xn) {
+    auto push_slot = [&](int pos, int lev, int flags, double dinv, int xstart, int xn) {
         out.s_pos.push_back(pos);
         out.s_lev.push_back(lev);
-        out.s_info.push_back(info);
+        out.s_flags.push_back(flags);
+        out.s_dinv.push_back(dinv);
         out.s_xstart.push_back(xstart);
         out.s_xn.push_back(xn);
         for (int e = 0; e < LU_TE; ++e) {
@@ -125,33 +126,54 @@ void build_tasks(const int* start, const int* idx, const double* val, const std:
             out.val[e].push_back(0.0);
         }
     };
+    // chunk under construction: [first slot, first level); closed at a level boundary -- or inside a level wider than a chunk,
+    // whose rows are independent of each other
+    int chunk_first = 0, chunk_level = 1;
+    auto close_chunk = [&](int end_level, int next_level) {
+        if ((int)out.s_pos.size() > chunk_first) {
+            out.chunk.insert(out.chunk.end(), {chunk_first, (int)out.s_pos.size(), chunk_level, end_level});
+            while ((int)out.s_pos.size() % WAVE) push_slot(0, 0x7fffffff, 0, 1.0, 0, 0);  // the next chunk starts on a wave boundary
+        }
+        chunk_first = (int)out.s_pos.size();
+        chunk_level = next_level;
+    };
     std::vector<int> rows;
     for (int l = 0; l < out.levels; ++l) {
         rows.clear();
         for (int r = lev_start[l]; r < lev_start[l + 1]; ++r) {
             const int i = order[r];
-            if (start[i + 1] == start[i]) out.z_pos.push_back(i);
-            else rows.push_back(i);
+            if (start[i + 1] == start[i]) {
+                out.z_pos.push_back(i);
+                out.z_dinv.push_back(diag ? 1.0 / diag[i] : 1.0);
+            } else {
+                rows.push_back(i);
+            }
         }
+        if (rows.empty()) continue;
         std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return group_log2(start[a + 1] - start[a]) > group_log2(start[b + 1] - start[b]); });
+        int level_slots = 0;  // (an upper bound with the alignment padding of the first group)
+        for (int i : rows) level_slots += 1 << group_log2(start[i + 1] - start[i]);
+        if ((int)out.s_pos.size() - chunk_first + level_slots + WAVE > LU_CHUNK_SLOTS) close_chunk(l, l);
         for (int i : rows) {
             const int n = start[i + 1] - start[i];
             const int g = group_log2(n), G = 1 << g;
-            while ((int)out.s_pos.size() % G) push_slot(0, l, 0, 0, 0);  // padding: a slot of this level that does nothing
+            if ((int)out.s_pos.size() - chunk_first + 2 * G > LU_CHUNK_SLOTS) {  // a level wider than a chunk: continue it in the next one
+                close_chunk(l + 1, l);
+            }
+            while ((int)out.s_pos.size() % G) push_slot(0, l, 0, 1.0, 0, 0);  // padding: a slot of this level that does nothing
             const int first = (int)out.s_pos.size();
             const int inline_n = std::min(n, LU_TE * G);
             const int xn = n - inline_n;
             const int xstart = (int)out.x_idx.size();
             for (int j = 0; j < G; ++j) {
                 // slot j of the group takes the entries j, j + G, j + 2 G, ... of the first LU_TE * G
+                push_slot(i, l, g | ((j == G - 1) ? 1 << 8 : 0) | (xn > 0 ? 1 << 9 : 0), diag ? 1.0 / diag[i] : 1.0, xstart, xn);
                 int mine = 0;
-                push_slot(i, l, 0, xstart, xn);
                 for (int e = j; e < inline_n; e += G) {
                     out.col[mine][first + j] = idx[start[i] + e];
                     out.val[mine][first + j] = val[start[i] + e];
                     ++mine;
                 }
-                out.s_info[first + j] = mine | (g << 8) | ((j == G - 1) ? 1 << 16 : 0) | (xn > 0 ? 1 << 17 : 0);
             }
             for (int e = inline_n; e < n; ++e) {
                 out.x_idx.push_back(idx[start[i] + e]);
@@ -159,6 +181,8 @@ void build_tasks(const int* start, const int* idx, const double* val, const std:
             }
         }
     }
+    close_chunk(out.levels, out.levels);
+    if ((int)out.chunk.size() / 4 > LU_MAX_CHUNKS) throw std::runtime_error("LU task list: too many chunks");
 }
 }  // namespace
 
@@ -202,10 +226,10 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         }
     }
     HostTasks tasks[4];
-    build_tasks(f.l_start.data(), f.l_col.data(), f.l_val.data(), f.lev_start[0], f.lev_row[0], tasks[0]);
-    build_tasks(f.u_start.data(), f.u_col.data(), f.u_val.data(), f.lev_start[1], f.lev_row[1], tasks[1]);
-    build_tasks(ucs.data(), ucrow.data(), ucval.data(), f.lev_start[2], f.lev_row[2], tasks[2]);
-    build_tasks(lcs.data(), lcrow.data(), lcval.data(), f.lev_start[3], f.lev_row[3], tasks[3]);
+    build_tasks(f.l_start.data(), f.l_col.data(), f.l_val.data(), nullptr, f.lev_start[0], f.lev_row[0], tasks[0]);
+    build_tasks(f.u_start.data(), f.u_col.data(), f.u_val.data(), f.diag.data(), f.lev_start[1], f.lev_row[1], tasks[1]);
+    build_tasks(ucs.data(), ucrow.data(), ucval.data(), f.diag.data(), f.lev_start[2], f.lev_row[2], tasks[2]);
+    build_tasks(lcs.data(), lcrow.data(), lcval.data(), nullptr, f.lev_start[3], f.lev_row[3], tasks[3]);
     size_t max_slots = 0;
     for (int k = 0; k < 4; ++k) max_slots = std::max(max_slots, tasks[k].s_pos.size());
     if (max_slots > cap_slots_ || cap_slots_ == 0 || layout_changed) {
@@ -221,15 +245,18 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t o_counts = c.take<int>(4 * LU_CNT_WORDS);
     const size_t o_tasks = c.take<LuTasks>(4);
     struct TaskOffsets {
-        size_t z_pos, s_pos, s_lev, s_info, s_xstart, s_xn, s_col, s_val, x_idx, x_val;
+        size_t z_pos, z_dinv, s_pos, s_lev, s_flags, s_dinv, s_xstart, s_xn, chunk, s_col, s_val, x_idx, x_val;
     } to[4];
     for (int k = 0; k < 4; ++k) {
         to[k].z_pos = c.take<int>(m);
+        to[k].z_dinv = c.take<double>(m);
         to[k].s_pos = c.take<int>(stride);
         to[k].s_lev = c.take<int>(stride);
-        to[k].s_info = c.take<int>(stride);
+        to[k].s_flags = c.take<int>(stride);
+        to[k].s_dinv = c.take<double>(stride);
         to[k].s_xstart = c.take<int>(stride);
         to[k].s_xn = c.take<int>(stride);
+        to[k].chunk = c.take<int>(4 * LU_MAX_CHUNKS);
     }
     const size_t small_bytes = c.offset;  // everything up to here goes in one copy
     for (int k = 0; k < 4; ++k) {
@@ -275,9 +302,9 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         LuTasks* table = reinterpret_cast<LuTasks*>(h + o_tasks);
         for (int k = 0; k < 4; ++k) {
             LuTasks t;
-            t.z_pos = I(to[k].z_pos);
-            t.s_pos = I(to[k].s_pos); t.s_lev = I(to[k].s_lev); t.s_info = I(to[k].s_info);
-            t.s_xstart = I(to[k].s_xstart); t.s_xn = I(to[k].s_xn);
+            t.z_pos = I(to[k].z_pos); t.z_dinv = D(to[k].z_dinv);
+            t.s_pos = I(to[k].s_pos); t.s_lev = I(to[k].s_lev); t.s_flags = I(to[k].s_flags); t.s_dinv = D(to[k].s_dinv);
+            t.s_xstart = I(to[k].s_xstart); t.s_xn = I(to[k].s_xn); t.chunk = I(to[k].chunk);
             t.s_col = I(to[k].s_col); t.s_val = D(to[k].s_val);
             t.x_idx = I(to[k].x_idx); t.x_val = D(to[k].x_val);
             std::memcpy(&table[k], &t, sizeof(LuTasks));
@@ -289,11 +316,14 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         counts[k * LU_CNT_WORDS + LU_CNT_Z] = (int)t.z_pos.size();
         counts[k * LU_CNT_WORDS + LU_CNT_SLOTS] = (int)t.s_pos.size();
         counts[k * LU_CNT_WORDS + LU_CNT_LEVELS] = t.levels;
-        counts[k * LU_CNT_WORDS + 3] = 0;
+        counts[k * LU_CNT_WORDS + LU_CNT_CHUNKS] = (int)t.chunk.size() / 4;
         put_i(to[k].z_pos, t.z_pos);
+        put_d(to[k].z_dinv, t.z_dinv);
         put_i(to[k].s_pos, t.s_pos);
         put_i(to[k].s_lev, t.s_lev);
-        put_i(to[k].s_info, t.s_info);
+        put_i(to[k].s_flags, t.s_flags);
+        put_d(to[k].s_dinv, t.s_dinv);
+        put_i(to[k].chunk, t.chunk);
         put_i(to[k].s_xstart, t.s_xstart);
         put_i(to[k].s_xn, t.s_xn);
         for (int e = 0; e < LU_TE; ++e) {
@@ -561,146 +591,178 @@ __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh,
     __syncthreads();
 }
 
-// Sums over aligned groups of 2^g lanes (g per lane: the groups of one wave differ), valid in the LAST lane of each group.
-__device__ __forceinline__ double group_sum_by(double v, const int g) {
-    const double s1 = v + dpp_f64<DPP_QUAD_1032, 0xF>(0.0, v);
-    const double s2 = s1 + dpp_f64<DPP_QUAD_2301, 0xF>(0.0, s1);
-    const double s3 = s2 + dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, s2);
-    double s4 = s2 + dpp_f64<DPP_ROW_ROR4, 0xF>(0.0, s2);
-    s4 += dpp_f64<DPP_ROW_ROR8, 0xF>(0.0, s4);
-    const double s5 = s4 + dpp_f64<DPP_ROW_BCAST15, 0xA>(0.0, s4);
-    const double s6 = s5 + dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, s5);
-    return g == 0 ? v : g == 1 ? s1 : g == 2 ? s2 : g == 3 ? s3 : g == 4 ? s4 : g == 5 ? s5 : s6;
+// Sum over aligned groups of 2^g lanes (g per lane: the groups of one wave differ), valid in the LAST lane of each group.
+// `gbits`: bit j set when some lane of the wave has g > j (wave-uniform), so that a wave of single-lane rows skips all of it.
+__device__ __forceinline__ double group_sum_by(double v, const int g, const unsigned gbits) {
+    if (gbits == 0) return v;
+    double s1 = v + dpp_f64<DPP_QUAD_1032, 0xF>(0.0, v);
+    double out = g >= 1 ? s1 : v;
+    if (gbits & 2u) {
+        const double s2 = s1 + dpp_f64<DPP_QUAD_2301, 0xF>(0.0, s1);
+        out = g >= 2 ? s2 : out;
+        if (gbits & 4u) {
+            const double s3 = s2 + dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(0.0, s2);
+            out = g == 3 ? s3 : out;
+            if (gbits & 8u) {
+                double s4 = s2 + dpp_f64<DPP_ROW_ROR4, 0xF>(0.0, s2);
+                s4 += dpp_f64<DPP_ROW_ROR8, 0xF>(0.0, s4);
+                out = g >= 4 ? s4 : out;
+                if (gbits & 16u) {
+                    const double s5 = s4 + dpp_f64<DPP_ROW_BCAST15, 0xA>(0.0, s4);
+                    out = g >= 5 ? s5 : out;
+                    if (gbits & 32u) {
+                        const double s6 = s5 + dpp_f64<DPP_ROW_BCAST31, 0xC>(0.0, s5);
+                        out = g >= 6 ? s6 : out;
+                    }
+                }
+            }
+        }
+    }
+    return out;
 }
 
 // In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i]  for every row i of one triangular factor in one orientation
 // (`sched`: 0 L by rows, 1 U by rows, 2 U by columns, 3 L by columns), level by level, one barrier per level.
 //   rows without entries   all threads, one pass (only the division by the diagonal, if any);
-//   every other row        1, 2, 4 ... 64 consecutive SLOTS of at most LU_TE entries each (lu.hpp); slot s belongs to thread
-//                          s mod 1024, which holds the slot's record and entries in registers; at the row's level its lanes read
-//                          their operands from LDS in one batch, multiply-add, combine by a fixed DPP tree, and the last lane
-//                          writes the component.
+//   every other row        1, 2, 4 ... 64 consecutive SLOTS of at most LU_TE entries each (lu.hpp).  Before the first level of a
+//                          chunk every thread loads its (up to LU_ROUNDS) slots into registers; in a level the lanes of its rows
+//                          read their operands from LDS in one batch, multiply-add (padding entries are zeros: no predicates),
+//                          combine by a fixed DPP tree, and the last lane of a row writes the component.  The slots of a wave
+//                          and round are consecutive in level order, so "which level is this wave's next" is ONE scalar: a
+//                          wave with nothing to do in a level executes a scalar compare and the barrier, no vector
+//                          instruction (a wave64 vector instruction costs 4 cycles of its SIMD: 16 waves evaluating even a
+//                          short vector condition per level cost more than the level's arithmetic).
+// Measured (tools/micro/barrier_bench.hip): s_barrier of 16 waves 72 cycles; barrier + 4 reads + 4 FMAs + write 270.
 // Round 2 kept records and entries in LDS too (record -> entries -> operands: three dependent round trips per level, ~1 k
-// cycles with the barrier).  Two other forms were built this round, measured and dropped: (i) barrier-free, every row
-// polling its operands (a sentinel NaN for "not solved yet"): 25-50 k cycles per triangle on 25FV47 against round 2's 18-35 k --
-// a spinning wave64 costs 4 cycles of its SIMD per instruction, and four such waves per SIMD starve the one wave the chain
-// waits for, whereas a wave parked at s_barrier costs nothing; (ii) long rows as one wave task each with their entries read
-// from L2 in the level: 44-90 k cycles, every such row paid a global round trip.
+// cycles with the barrier).  Forms built this round, measured and dropped: (i) barrier-free, every row polling its operands
+// (a sentinel NaN for "not solved yet"): 25-50 k cycles per triangle on 25FV47 against round 2's 18-35 k -- four spinning
+// waves per SIMD starve the wave the chain waits for, whereas a wave parked at s_barrier costs nothing; (ii) long rows as one
+// wave task each, entries read from L2 in the level: every such row paid a global round trip; (iii) one slot per thread at a
+// time with the next one prefetched: ~250 vector instructions per level (register shuffles, decode, reloads).
 // In a U solve (HAS_DIAG) a replaced position (mask) is no task and keeps its value (the callers hold it at zero).
 // x0 / x1 must be complete (barrier) on entry; ends with a barrier.
 template <int NRHS, bool HAS_DIAG>
 __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShared& sh, const int sched) {
-    // The task arrays come out of a table in device memory: typed as GLOBAL pointers here.  As generic pointers they compile to
-    // flat_load, which counts in lgkmcnt as well as vmcnt -- every LDS wait (and the s_waitcnt lgkmcnt(0) of the level barrier)
-    // then waits for whatever slot record is still on its way from L2: 1.5 k cycles per level instead of 300.
+    // The task arrays come out of a table in device memory: typed as GLOBAL pointers here (as generic pointers they compile to
+    // flat_load, which counts in lgkmcnt as well as vmcnt, so that every LDS wait would also wait for global loads in flight).
     const LuTasks tk_generic = lu.tasks[sched];
-    struct {
-        gptr_i32 z_pos, s_pos, s_lev, s_info, s_col, s_xstart, s_xn, x_idx;
-        gptr_f64 s_val, x_val;
-    } tk = {(gptr_i32)tk_generic.z_pos, (gptr_i32)tk_generic.s_pos, (gptr_i32)tk_generic.s_lev, (gptr_i32)tk_generic.s_info,
-            (gptr_i32)tk_generic.s_col, (gptr_i32)tk_generic.s_xstart, (gptr_i32)tk_generic.s_xn, (gptr_i32)tk_generic.x_idx,
-            (gptr_f64)tk_generic.s_val, (gptr_f64)tk_generic.x_val};
-    const gptr_f64 diag = (gptr_f64)lu.diag;
+    const gptr_i32 z_pos = (gptr_i32)tk_generic.z_pos, s_pos = (gptr_i32)tk_generic.s_pos, s_lev = (gptr_i32)tk_generic.s_lev,
+                   s_flags = (gptr_i32)tk_generic.s_flags, s_col = (gptr_i32)tk_generic.s_col, s_xstart = (gptr_i32)tk_generic.s_xstart,
+                   s_xn = (gptr_i32)tk_generic.s_xn, x_idx = (gptr_i32)tk_generic.x_idx, chunk = (gptr_i32)tk_generic.chunk;
+    const gptr_f64 z_dinv = (gptr_f64)tk_generic.z_dinv, s_dinv = (gptr_f64)tk_generic.s_dinv, s_val = (gptr_f64)tk_generic.s_val,
+                   x_val = (gptr_f64)tk_generic.x_val;
     const int nz = lu.counts[sched * LU_CNT_WORDS + LU_CNT_Z];
-    const int ns = lu.counts[sched * LU_CNT_WORDS + LU_CNT_SLOTS];
-    const int n_levels = lu.counts[sched * LU_CNT_WORDS + LU_CNT_LEVELS];
+    const int n_chunks = lu.counts[sched * LU_CNT_WORDS + LU_CNT_CHUNKS];
     const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & (WAVE - 1);
     const int stride = lu.task_stride;
+    constexpr int NONE = 0x7fffffff;
     volatile lds_f64* x0 = sh.x0;
     volatile lds_f64* x1 = sh.x1;
-    // ---- this thread's first two slots travel while the rows without entries are done ---------------------------------------------
-    struct Slot {
-        int pos, lev, info;  // lev: -1 when there is none
-        double dinv;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int first_slot = chunk[4 * ch], end_slot = chunk[4 * ch + 1], first_level = chunk[4 * ch + 2], end_level = chunk[4 * ch + 3];
+        // ---- this thread's slot of the chunk into registers -----------------------------------------------------------------------
+        const int k = first_slot + tid;
+        const bool have = k < end_slot;
+        const int kk = have ? k : first_slot;  // (clamped: the loads are unconditional)
+        const int pos = s_pos[kk];
+        const int lev = have ? s_lev[kk] : NONE;
+        int flags = have ? s_flags[kk] : 0;
+        const double dinv = s_dinv[kk];
         int col[LU_TE];
         double val[LU_TE];
-    };
-    auto load_slot = [&](int k, Slot& r) {
-        r.pos = 0;
-        r.lev = -1;
-        r.info = 0;
-        r.dinv = 1.0;
 #pragma unroll
         for (int e = 0; e < LU_TE; ++e) {
-            r.col[e] = 0;
-            r.val[e] = 0.0;
+            col[e] = s_col[(size_t)e * stride + kk];
+            val[e] = have ? s_val[(size_t)e * stride + kk] : 0.0;
         }
-        if (k < ns) {  // (no loads in flight for a thread that has no further slot: nothing for a later level to wait for)
-#pragma unroll
-            for (int e = 0; e < LU_TE; ++e) {
-                r.col[e] = tk.s_col[(size_t)e * stride + k];
-                r.val[e] = tk.s_val[(size_t)e * stride + k];
-            }
-            r.pos = tk.s_pos[k];
-            r.lev = tk.s_lev[k];
-            r.info = tk.s_info[k];
-            if (HAS_DIAG) {
-                r.dinv = 1.0 / diag[r.pos];
-                if (lu_masked(sh, r.pos)) r.info = 0;  // a replaced position: no row of the triangle any more
+        if (ch == 0 && HAS_DIAG) {  // (the rows without entries: while the slots travel)
+            for (int z = tid; z < nz; z += T) {
+                const int p = z_pos[z];
+                if (lu_masked(sh, p)) continue;
+                const double d = z_dinv[z];
+                x0[p] = x0[p] * d;
+                if (NRHS == 2) x1[p] = x1[p] * d;
             }
         }
-    };
-    Slot cur, nxt;
-    int k_mine = tid;
-    load_slot(k_mine, cur);
-    load_slot(k_mine + T, nxt);
-    if (HAS_DIAG) {
-        for (int k = tid; k < nz; k += T) {
-            const int p = tk.z_pos[k];
-            if (lu_masked(sh, p)) continue;
-            const double d = 1.0 / diag[p];
-            x0[p] = x0[p] * d;
-            if (NRHS == 2) x1[p] = x1[p] * d;
+        if (HAS_DIAG && have && lu_masked(sh, pos)) flags &= ~(1 << 8);  // a replaced position: computed, never written
+        const int g = flags & 0xff;
+        const unsigned gbits = (__any(g > 0) ? 1u : 0u) | (__any(g > 1) ? 2u : 0u) | (__any(g > 2) ? 4u : 0u) | (__any(g > 3) ? 8u : 0u) |
+                               (__any(g > 4) ? 16u : 0u) | (__any(g > 5) ? 32u : 0u);
+        const bool any_extra = __any((flags >> 9) & 1);
+        __syncthreads();
+#ifdef RELP_STAMPS
+        if (sh.dbg && tid == 0) {  // diagnostic: the solve's preamble (loads, rows without entries) apart from its level loop
+            const unsigned long long t = clock64();
+            sh.dbg[32 + sched] += t - *sh.t_prev;
+            sh.dbg[36 + sched] += end_level - first_level;
+            sh.dbg[40 + sched] += end_slot - first_slot;
+            *sh.t_prev = t;
         }
-    }
-    __syncthreads();
-    for (int l = 1; l < n_levels; ++l) {
-        while (__any(cur.lev == l)) {  // (more than one turn only when the level is wider than the workgroup)
-            const bool active = cur.lev == l;
-            const int n_mine = active ? (cur.info & 0xff) : 0;
-            const int g = (cur.info >> 8) & 0xff;
-            double xv[LU_TE];
+#endif
+        // ---- the levels of the chunk: the slots of a wave are consecutive in level order, so its next level is one scalar -------------
+        int first_lane = 0;                                       // wave-uniform: this wave's next pending lane
+        int wave_next = __builtin_amdgcn_readfirstlane(lev);      // ... and its level
+        for (int l = first_level; l < end_level; ++l) {
+            while (wave_next == l) {
+                const bool active = lane >= first_lane && lev == l;
+                double xv[LU_TE];
 #pragma unroll
-            for (int e = 0; e < LU_TE; ++e) xv[e] = x0[cur.col[e]];  // (padding: position 0, value 0)
-            double s0 = 0.0, s1 = 0.0;
+                for (int e = 0; e < LU_TE; ++e) xv[e] = x0[col[e]];
+                const double own0 = x0[pos];
+                double s0 = 0.0, s1 = 0.0, own1 = 0.0;
 #pragma unroll
-            for (int e = 0; e < LU_TE; ++e)
-                if (e < n_mine) s0 += cur.val[e] * xv[e];
-            if (NRHS == 2) {
+                for (int e = 0; e < LU_TE; ++e) s0 += val[e] * xv[e];
+                if (NRHS == 2) {
 #pragma unroll
-                for (int e = 0; e < LU_TE; ++e) xv[e] = x1[cur.col[e]];
+                    for (int e = 0; e < LU_TE; ++e) xv[e] = x1[col[e]];
+                    own1 = x1[pos];
 #pragma unroll
-                for (int e = 0; e < LU_TE; ++e)
-                    if (e < n_mine) s1 += cur.val[e] * xv[e];
-            }
-            if (__any(active && ((cur.info >> 17) & 1))) {  // rows of more than 64 LU_TE entries: the rest from the arena (rare)
-                if (active && ((cur.info >> 17) & 1)) {
-                    const int xs = tk.s_xstart[k_mine], xn = tk.s_xn[k_mine];
-                    for (int e = (tid & (WAVE - 1)); e < xn; e += WAVE) {
-                        const int c = tk.x_idx[xs + e];
-                        const double v = tk.x_val[xs + e];
-                        s0 += v * x0[c];
-                        if (NRHS == 2) s1 += v * x1[c];
+                    for (int e = 0; e < LU_TE; ++e) s1 += val[e] * xv[e];
+                }
+                if (any_extra) {  // rows of more than 64 LU_TE entries: the rest from the arena (rare)
+                    if (active && ((flags >> 9) & 1)) {
+                        const int xs = s_xstart[k], xn = s_xn[k];
+                        for (int e = lane; e < xn; e += WAVE) {
+                            const int c = x_idx[xs + e];
+                            const double v = x_val[xs + e];
+                            s0 += v * x0[c];
+                            if (NRHS == 2) s1 += v * x1[c];
+                        }
                     }
                 }
+                s0 = group_sum_by(s0, g, gbits);
+                if (NRHS == 2) s1 = group_sum_by(s1, g, gbits);
+                if (active && ((flags >> 8) & 1)) {
+                    x0[pos] = (own0 - s0) * dinv;
+                    if (NRHS == 2) x1[pos] = (own1 - s1) * dinv;
+                }
+                first_lane += __popcll(__ballot(active));
+                wave_next = first_lane < WAVE ? __builtin_amdgcn_readlane(lev, first_lane < WAVE ? first_lane : 0) : NONE;
             }
-            if (__any(active && g > 0)) {  // some row of this turn spans several lanes
-                s0 = group_sum_by(s0, active ? g : 0);
-                if (NRHS == 2) s1 = group_sum_by(s1, active ? g : 0);
-            }
-            if (active && ((cur.info >> 16) & 1) && (cur.info & 0xff) > 0) {
-                x0[cur.pos] = (x0[cur.pos] - s0) * cur.dinv;
-                if (NRHS == 2) x1[cur.pos] = (x1[cur.pos] - s1) * cur.dinv;
-            }
-            if (active) {  // on to this thread's next slot: it arrived long ago; the one after it starts travelling now
-                k_mine += T;
-                cur = nxt;
-                load_slot(k_mine + T, nxt);
+            lds_barrier();
+        }
+        __syncthreads();
+#ifdef RELP_STAMPS
+        if (sh.dbg && tid == 0) {
+            const unsigned long long t = clock64();
+            sh.dbg[44 + sched] += t - *sh.t_prev;
+            *sh.t_prev = t;
+        }
+#endif
+    }
+    if (n_chunks == 0) {
+        if (HAS_DIAG) {
+            for (int k = tid; k < nz; k += T) {
+                const int p = z_pos[k];
+                if (lu_masked(sh, p)) continue;
+                const double d = z_dinv[k];
+                x0[p] = x0[p] * d;
+                if (NRHS == 2) x1[p] = x1[p] * d;
             }
         }
-        lds_barrier();
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve (trailing block by one

@@ -35,26 +35,36 @@ enum : int { LU_FLAG_UNSTABLE = 1, LU_FLAG_OVERFLOW = 2 };
 constexpr int LU_MAX_SLOTS = 64;  // one wave solves T
 
 // A triangular factor in one orientation as a TASK LIST for the level-synchronous solve (lu.hip: lu_solve_tasks).  The rows
-// (columns) of the factor are sorted by dependency level.  A row without entries needs no solve (`z_pos`).  Every other row is
-// packed into G = 1, 2, 4, ... 64 consecutive SLOTS (G = the power of two that gives each slot at most LU_TE entries; aligned to
-// G, so a row never straddles a wave); slot s belongs to thread s mod 1024, which keeps the slot's entries in REGISTERS (ELL
-// layout: entry e of slot s at [e * stride + s]).  One barrier per level, and between two barriers ONE dependent LDS round trip
-// (the operands), the multiply-adds, a DPP sum over the row's lanes and one LDS write.  A row of more than 64 LU_TE entries
-// keeps the rest in `x_idx` / `x_val` (read in the level; rare).
+// (columns) of the factor are sorted by dependency level.  A row without entries needs no solve (`z_pos`, `z_dinv`).  Every
+// other row is packed into G = 1, 2, 4, ... 64 consecutive SLOTS of at most LU_TE entries (G = the power of two that gives each
+// slot at most LU_TE entries; aligned to G, so a row never straddles a wave).  The slots are cut into CHUNKS of whole levels
+// with at most LU_ROUNDS * 1024 slots (all of a Netlib-sized factor is one chunk); inside a chunk slot k belongs to thread
+// k mod 1024, round k / 1024, and a thread holds ALL its slots of the chunk in registers before the first level starts (ELL
+// layout: entry e of slot s at [e * stride + s]).  One barrier per level, and between two barriers ONE dependent LDS round
+// trip (the operands), the multiply-adds, a DPP sum over the row's lanes and one LDS write; no global load inside a chunk.
+// A row of more than 64 LU_TE entries keeps the rest in `x_idx` / `x_val` (read in the level; rare).
 #ifndef RELP_LU_TE
 #define RELP_LU_TE 4
 #endif
 constexpr int LU_TE = RELP_LU_TE;   // (a macro only so that micro-variants can be compiled side by side)
+#ifndef RELP_LU_ROUNDS
+#define RELP_LU_ROUNDS 1
+#endif
+constexpr int LU_ROUNDS = RELP_LU_ROUNDS;   // slots per thread and chunk
+constexpr int LU_CHUNK_SLOTS = LU_ROUNDS * 1024;
 struct LuTasks {
-    int* z_pos = nullptr;        // [nz]
+    int* z_pos = nullptr; double* z_dinv = nullptr;  // [nz]
     int* s_pos = nullptr;        // [ns] position of the slot's row
-    int* s_lev = nullptr;        // [ns] its level (>= 1)
-    int* s_info = nullptr;       // [ns] entries in this slot | log2(G) << 8 | (last lane of the group) << 16 | (row has extra entries) << 17
-    int* s_col = nullptr; double* s_val = nullptr;   // [LU_TE][stride]
+    int* s_lev = nullptr;        // [ns] its level (>= 1); 0x7fffffff: none
+    int* s_flags = nullptr;      // [ns] log2(G) | (last lane of the group: writes the component) << 8 | (row has extra entries) << 9
+    double* s_dinv = nullptr;    // [ns] 1 / diagonal of the row (U), 1 (L)
+    int* s_col = nullptr; double* s_val = nullptr;   // [LU_TE][stride]; padding: position 0, value 0
     int* s_xstart = nullptr; int* s_xn = nullptr;    // [ns] extra entries of the row (G = 64 only): range in x_idx / x_val
     int* x_idx = nullptr; double* x_val = nullptr;
+    int* chunk = nullptr;        // [chunks][4]: first slot, end slot, first level, end level
 };
-enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_WORDS = 4 };
+enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_CHUNKS = 3, LU_CNT_WORDS = 4 };
+constexpr int LU_MAX_CHUNKS = 256;
 
 struct DeviceLU {
     int m = 0;

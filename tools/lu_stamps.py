@@ -18,5 +18,6 @@ for k, nm in enumerate(names):
     print("%-16s %9.0f cycles/launch" % (nm, d[k] / max(n, 1)))
     total += d[k] / max(n, 1)
 print("%-16s %9.0f cycles/launch" % ("sum", total))
-for k, nm in enumerate(["stage L rows", "stage U rows", "stage U cols", "stage L cols"]):
-    print("%-16s %9.0f cycles/launch  levels %.1f  wide %.1f  in LDS %.2f" % (nm, d[13 + k] / max(n, 1), d[20 + k] / max(n, 1), d[24 + k] / max(n, 1), d[28 + k] / max(n, 1)))
+for k, nm in enumerate(["L rows (FTRAN)", "U rows (FTRAN)", "U cols (BTRAN)", "L cols (BTRAN)"]):
+    print("%-16s preamble %7.0f  level loop %7.0f cycles/launch  levels %.1f  slots %.0f  -> %.0f cycles per level" % (
+        nm, d[32 + k] / max(n, 1), d[44 + k] / max(n, 1), d[36 + k] / max(n, 1), d[40 + k] / max(n, 1), d[44 + k] / max(d[36 + k], 1)))
