@@ -232,9 +232,10 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     build_tasks(lcs.data(), lcrow.data(), lcval.data(), nullptr, f.lev_start[3], f.lev_row[3], tasks[3]);
     size_t max_slots = 0;
     for (int k = 0; k < 4; ++k) max_slots = std::max(max_slots, tasks[k].s_pos.size());
-    if (max_slots > cap_slots_ || cap_slots_ == 0 || layout_changed) {
-        if (max_slots > cap_slots_ || cap_slots_ == 0) layout_changed = true;
-        cap_slots_ = std::max(cap_slots_, ((max_slots + max_slots / 2 + 1024) + 63) & ~size_t(63));
+    if (max_slots + 1024 > cap_slots_ || (size_t)m + 1024 > cap_slots_ || cap_slots_ == 0 || layout_changed) {
+        if (max_slots + 1024 > cap_slots_ || (size_t)m + 1024 > cap_slots_ || cap_slots_ == 0) layout_changed = true;
+        max_slots = std::max(max_slots, (size_t)m);
+        cap_slots_ = std::max(cap_slots_, ((max_slots + max_slots / 2 + 2048) + 1023) & ~size_t(1023));
     }
     const int stride = (int)cap_slots_;
     // ---- uploaded prefix ----------------------------------------------------------------------------------------------
@@ -243,13 +244,12 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t o_lrs = c.take<int>(m + 1), o_lcs = c.take<int>(m + 1), o_urs = c.take<int>(m + 1), o_ucs = c.take<int>(m + 1);
     const size_t o_diag = c.take<double>(m);
     const size_t o_counts = c.take<int>(4 * LU_CNT_WORDS);
-    const size_t o_tasks = c.take<LuTasks>(4);
     struct TaskOffsets {
         size_t z_pos, z_dinv, s_pos, s_lev, s_flags, s_dinv, s_xstart, s_xn, chunk, s_col, s_val, x_idx, x_val;
     } to[4];
     for (int k = 0; k < 4; ++k) {
-        to[k].z_pos = c.take<int>(m);
-        to[k].z_dinv = c.take<double>(m);
+        to[k].z_pos = c.take<int>(stride);
+        to[k].z_dinv = c.take<double>(stride);
         to[k].s_pos = c.take<int>(stride);
         to[k].s_lev = c.take<int>(stride);
         to[k].s_flags = c.take<int>(stride);
@@ -296,20 +296,6 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     put_i(o_urs, f.u_start);
     put_i(o_ucs, ucs);
     put_d(o_diag, f.diag);
-    {
-        auto I = [&](size_t o) { return reinterpret_cast<int*>(dev_ + o); };
-        auto D = [&](size_t o) { return reinterpret_cast<double*>(dev_ + o); };
-        LuTasks* table = reinterpret_cast<LuTasks*>(h + o_tasks);
-        for (int k = 0; k < 4; ++k) {
-            LuTasks t;
-            t.z_pos = I(to[k].z_pos); t.z_dinv = D(to[k].z_dinv);
-            t.s_pos = I(to[k].s_pos); t.s_lev = I(to[k].s_lev); t.s_flags = I(to[k].s_flags); t.s_dinv = D(to[k].s_dinv);
-            t.s_xstart = I(to[k].s_xstart); t.s_xn = I(to[k].s_xn); t.chunk = I(to[k].chunk);
-            t.s_col = I(to[k].s_col); t.s_val = D(to[k].s_val);
-            t.x_idx = I(to[k].x_idx); t.x_val = D(to[k].x_val);
-            std::memcpy(&table[k], &t, sizeof(LuTasks));
-        }
-    }
     int* counts = reinterpret_cast<int*>(h + o_counts);
     for (int k = 0; k < 4; ++k) {
         const HostTasks& t = tasks[k];
@@ -317,18 +303,33 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         counts[k * LU_CNT_WORDS + LU_CNT_SLOTS] = (int)t.s_pos.size();
         counts[k * LU_CNT_WORDS + LU_CNT_LEVELS] = t.levels;
         counts[k * LU_CNT_WORDS + LU_CNT_CHUNKS] = (int)t.chunk.size() / 4;
-        put_i(to[k].z_pos, t.z_pos);
-        put_d(to[k].z_dinv, t.z_dinv);
-        put_i(to[k].s_pos, t.s_pos);
-        put_i(to[k].s_lev, t.s_lev);
-        put_i(to[k].s_flags, t.s_flags);
-        put_d(to[k].s_dinv, t.s_dinv);
+        counts[k * LU_CNT_WORDS + LU_CNT_C0_END] = t.chunk.empty() ? 0 : t.chunk[1];
+        counts[k * LU_CNT_WORDS + LU_CNT_C0_L0] = t.chunk.empty() ? 0 : t.chunk[2];
+        counts[k * LU_CNT_WORDS + LU_CNT_C0_L1] = t.chunk.empty() ? 0 : t.chunk[3];
+        counts[k * LU_CNT_WORDS + 7] = 0;
+        // every per-slot array is written up to `stride`: a thread reads slot first + tid without knowing where the slots end
+        auto put_i_padded = [&](size_t at, const std::vector<int>& v, int pad) {
+            int* dst = reinterpret_cast<int*>(h + at);
+            if (!v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(int));
+            std::fill(dst + v.size(), dst + stride, pad);
+        };
+        auto put_d_padded = [&](size_t at, const std::vector<double>& v, double pad) {
+            double* dst = reinterpret_cast<double*>(h + at);
+            if (!v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(double));
+            std::fill(dst + v.size(), dst + stride, pad);
+        };
+        put_i_padded(to[k].z_pos, t.z_pos, 0);
+        put_d_padded(to[k].z_dinv, t.z_dinv, 1.0);
+        put_i_padded(to[k].s_pos, t.s_pos, 0);
+        put_i_padded(to[k].s_lev, t.s_lev, 0x7fffffff);
+        put_i_padded(to[k].s_flags, t.s_flags, 0);
+        put_d_padded(to[k].s_dinv, t.s_dinv, 1.0);
+        put_i_padded(to[k].s_xstart, t.s_xstart, 0);
+        put_i_padded(to[k].s_xn, t.s_xn, 0);
         put_i(to[k].chunk, t.chunk);
-        put_i(to[k].s_xstart, t.s_xstart);
-        put_i(to[k].s_xn, t.s_xn);
         for (int e = 0; e < LU_TE; ++e) {
-            put_i(to[k].s_col + (size_t)e * stride * sizeof(int), t.col[e]);
-            put_d(to[k].s_val + (size_t)e * stride * sizeof(double), t.val[e]);
+            put_i_padded(to[k].s_col + (size_t)e * stride * sizeof(int), t.col[e], 0);
+            put_d_padded(to[k].s_val + (size_t)e * stride * sizeof(double), t.val[e], 0.0);
         }
         put_i(to[k].x_idx, t.x_idx);
         put_d(to[k].x_val, t.x_val);
@@ -352,13 +353,8 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
             if (bytes) RELP_HIP(hipMemcpyAsync(dev_ + at, h + at, bytes, hipMemcpyHostToDevice, stream));
         };
         for (int k = 0; k < 4; ++k) {
-            const size_t ns = tasks[k].s_pos.size();
-            if (ns) {  // ELL: rows e of the two arrays, each used up to ns
-                for (int e = 0; e < LU_TE; ++e) {
-                    copy(to[k].s_col + (size_t)e * stride * sizeof(int), ns * sizeof(int));
-                    copy(to[k].s_val + (size_t)e * stride * sizeof(double), ns * sizeof(double));
-                }
-            }
+            copy(to[k].s_col, (size_t)LU_TE * stride * sizeof(int));  // (whole: the padding is part of the contract)
+            copy(to[k].s_val, (size_t)LU_TE * stride * sizeof(double));
             copy(to[k].x_idx, tasks[k].x_idx.size() * sizeof(int));
             copy(to[k].x_val, tasks[k].x_val.size() * sizeof(double));
         }
@@ -394,9 +390,18 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     d.eta_capacity = (int)app;
     d.spike = D(o_spike);
     d.state = I(o_state);
-    d.counts = I(o_counts);
     d.task_stride = stride;
-    d.tasks = reinterpret_cast<const LuTasks*>(dev_ + o_tasks);
+    for (int k = 0; k < 4; ++k) {
+        LuTasks& t = d.tasks[k];
+        auto GI = [&](size_t o) { return (lu_gptr_i32) reinterpret_cast<const int*>(dev_ + o); };
+        auto GD = [&](size_t o) { return (lu_gptr_f64) reinterpret_cast<const double*>(dev_ + o); };
+        t.z_pos = GI(to[k].z_pos); t.z_dinv = GD(to[k].z_dinv);
+        t.s_pos = GI(to[k].s_pos); t.s_lev = GI(to[k].s_lev); t.s_flags = GI(to[k].s_flags); t.s_dinv = GD(to[k].s_dinv);
+        t.s_xstart = GI(to[k].s_xstart); t.s_xn = GI(to[k].s_xn); t.chunk = GI(to[k].chunk);
+        t.s_col = GI(to[k].s_col); t.s_val = GD(to[k].s_val);
+        t.x_idx = GI(to[k].x_idx); t.x_val = GD(to[k].x_val);
+        t.counts = GI(o_counts + (size_t)k * LU_CNT_WORDS * sizeof(int));
+    }
     d_ = d;
     hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_);
     nnz_l = (long long)nl;
@@ -621,71 +626,101 @@ __device__ __forceinline__ double group_sum_by(double v, const int g, const unsi
     return out;
 }
 
+// What a thread needs of one triangular solve before its first level: its slot of chunk 0, its first row without entries, and
+// the solve's counts.  Nothing here depends on anything but the thread index (the arrays are padded up to their stride), so a
+// kernel asks for the NEXT solve's record while the current phase runs: by the time the solve starts its loads have landed.
+struct LuSlot {
+    int pos, lev, flags;
+    double dinv;
+    int col[LU_TE];
+    double val[LU_TE];
+    int z_pos;
+    double z_dinv;
+    int nz, n_chunks, c_end, l0, l1;  // (the same in every lane; read through readfirstlane)
+};
+__device__ __forceinline__ LuSlot lu_load_slot(const DeviceLU& lu, const int sched, const int k) {
+    const LuTasks& tk = lu.tasks[sched];
+    const int stride = lu.task_stride;
+    LuSlot r;
+    r.pos = tk.s_pos[k];
+    r.lev = tk.s_lev[k];
+    r.flags = tk.s_flags[k];
+    r.dinv = tk.s_dinv[k];
+#pragma unroll
+    for (int e = 0; e < LU_TE; ++e) {
+        r.col[e] = tk.s_col[(size_t)e * stride + k];
+        r.val[e] = tk.s_val[(size_t)e * stride + k];
+    }
+    r.z_pos = tk.z_pos[threadIdx.x];
+    r.z_dinv = tk.z_dinv[threadIdx.x];
+    r.nz = tk.counts[LU_CNT_Z];
+    r.n_chunks = tk.counts[LU_CNT_CHUNKS];
+    r.c_end = tk.counts[LU_CNT_C0_END];
+    r.l0 = tk.counts[LU_CNT_C0_L0];
+    r.l1 = tk.counts[LU_CNT_C0_L1];
+    return r;
+}
+
 // In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i]  for every row i of one triangular factor in one orientation
 // (`sched`: 0 L by rows, 1 U by rows, 2 U by columns, 3 L by columns), level by level, one barrier per level.
 //   rows without entries   all threads, one pass (only the division by the diagonal, if any);
-//   every other row        1, 2, 4 ... 64 consecutive SLOTS of at most LU_TE entries each (lu.hpp).  Before the first level of a
-//                          chunk every thread loads its (up to LU_ROUNDS) slots into registers; in a level the lanes of its rows
-//                          read their operands from LDS in one batch, multiply-add (padding entries are zeros: no predicates),
-//                          combine by a fixed DPP tree, and the last lane of a row writes the component.  The slots of a wave
-//                          and round are consecutive in level order, so "which level is this wave's next" is ONE scalar: a
-//                          wave with nothing to do in a level executes a scalar compare and the barrier, no vector
-//                          instruction (a wave64 vector instruction costs 4 cycles of its SIMD: 16 waves evaluating even a
-//                          short vector condition per level cost more than the level's arithmetic).
+//   every other row        1, 2, 4 ... 64 consecutive SLOTS of at most LU_TE entries each (lu.hpp); thread t holds slot
+//                          first + t of the current chunk in registers (`first_record`: chunk 0, requested by the caller a phase
+//                          earlier).  In a level the lanes of its rows read their operands from LDS in one batch, multiply-add
+//                          (padding entries are zeros: no predicates), combine by a fixed DPP tree, and the last lane of a row
+//                          writes the component.  The slots of a wave are consecutive in level order, so "which level is this
+//                          wave's next" is ONE scalar: a wave with nothing to do in a level executes a scalar compare and the
+//                          barrier, no vector instruction (a wave64 vector instruction costs 4 cycles of its SIMD: 16 waves
+//                          evaluating even a short vector condition per level cost more than the level's arithmetic).
 // Measured (tools/micro/barrier_bench.hip): s_barrier of 16 waves 72 cycles; barrier + 4 reads + 4 FMAs + write 270.
 // Round 2 kept records and entries in LDS too (record -> entries -> operands: three dependent round trips per level, ~1 k
 // cycles with the barrier).  Forms built this round, measured and dropped: (i) barrier-free, every row polling its operands
 // (a sentinel NaN for "not solved yet"): 25-50 k cycles per triangle on 25FV47 against round 2's 18-35 k -- four spinning
 // waves per SIMD starve the wave the chain waits for, whereas a wave parked at s_barrier costs nothing; (ii) long rows as one
-// wave task each, entries read from L2 in the level: every such row paid a global round trip; (iii) one slot per thread at a
-// time with the next one prefetched: ~250 vector instructions per level (register shuffles, decode, reloads).
+// wave task each, entries read from L2 in the level: every such row paid a global round trip; (iii) several slots per thread
+// in registers: the compiler merges the per-round code into one body with ~150 register selects per level.
 // In a U solve (HAS_DIAG) a replaced position (mask) is no task and keeps its value (the callers hold it at zero).
 // x0 / x1 must be complete (barrier) on entry; ends with a barrier.
 template <int NRHS, bool HAS_DIAG>
-__device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShared& sh, const int sched) {
-    // The task arrays come out of a table in device memory: typed as GLOBAL pointers here (as generic pointers they compile to
-    // flat_load, which counts in lgkmcnt as well as vmcnt, so that every LDS wait would also wait for global loads in flight).
-    const LuTasks tk_generic = lu.tasks[sched];
-    const gptr_i32 z_pos = (gptr_i32)tk_generic.z_pos, s_pos = (gptr_i32)tk_generic.s_pos, s_lev = (gptr_i32)tk_generic.s_lev,
-                   s_flags = (gptr_i32)tk_generic.s_flags, s_col = (gptr_i32)tk_generic.s_col, s_xstart = (gptr_i32)tk_generic.s_xstart,
-                   s_xn = (gptr_i32)tk_generic.s_xn, x_idx = (gptr_i32)tk_generic.x_idx, chunk = (gptr_i32)tk_generic.chunk;
-    const gptr_f64 z_dinv = (gptr_f64)tk_generic.z_dinv, s_dinv = (gptr_f64)tk_generic.s_dinv, s_val = (gptr_f64)tk_generic.s_val,
-                   x_val = (gptr_f64)tk_generic.x_val;
-    const int nz = lu.counts[sched * LU_CNT_WORDS + LU_CNT_Z];
-    const int n_chunks = lu.counts[sched * LU_CNT_WORDS + LU_CNT_CHUNKS];
+__device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShared& sh, const int sched, const LuSlot& first_record) {
+    const LuTasks& tk = lu.tasks[sched];
+    const int nz = __builtin_amdgcn_readfirstlane(first_record.nz);
+    const int n_chunks = __builtin_amdgcn_readfirstlane(first_record.n_chunks);
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & (WAVE - 1);
-    const int stride = lu.task_stride;
     constexpr int NONE = 0x7fffffff;
     volatile lds_f64* x0 = sh.x0;
     volatile lds_f64* x1 = sh.x1;
+    if (HAS_DIAG) {  // the rows without entries
+        if (tid < nz && !lu_masked(sh, first_record.z_pos)) {
+            x0[first_record.z_pos] = x0[first_record.z_pos] * first_record.z_dinv;
+            if (NRHS == 2) x1[first_record.z_pos] = x1[first_record.z_pos] * first_record.z_dinv;
+        }
+        for (int z = tid + T; z < nz; z += T) {
+            const int p = tk.z_pos[z];
+            if (lu_masked(sh, p)) continue;
+            const double d = tk.z_dinv[z];
+            x0[p] = x0[p] * d;
+            if (NRHS == 2) x1[p] = x1[p] * d;
+        }
+    }
+    LuSlot rec = first_record;
+    int first_slot = 0, end_slot = __builtin_amdgcn_readfirstlane(first_record.c_end);
+    int first_level = __builtin_amdgcn_readfirstlane(first_record.l0), end_level = __builtin_amdgcn_readfirstlane(first_record.l1);
     for (int ch = 0; ch < n_chunks; ++ch) {
-        const int first_slot = chunk[4 * ch], end_slot = chunk[4 * ch + 1], first_level = chunk[4 * ch + 2], end_level = chunk[4 * ch + 3];
-        // ---- this thread's slot of the chunk into registers -----------------------------------------------------------------------
+        if (ch > 0) {  // (a factor of more than 1024 slots: the later chunks are fetched here)
+            first_slot = tk.chunk[4 * ch];
+            end_slot = tk.chunk[4 * ch + 1];
+            first_level = tk.chunk[4 * ch + 2];
+            end_level = tk.chunk[4 * ch + 3];
+            rec = lu_load_slot(lu, sched, first_slot + tid);
+        }
         const int k = first_slot + tid;
-        const bool have = k < end_slot;
-        const int kk = have ? k : first_slot;  // (clamped: the loads are unconditional)
-        const int pos = s_pos[kk];
-        const int lev = have ? s_lev[kk] : NONE;
-        int flags = have ? s_flags[kk] : 0;
-        const double dinv = s_dinv[kk];
-        int col[LU_TE];
-        double val[LU_TE];
-#pragma unroll
-        for (int e = 0; e < LU_TE; ++e) {
-            col[e] = s_col[(size_t)e * stride + kk];
-            val[e] = have ? s_val[(size_t)e * stride + kk] : 0.0;
-        }
-        if (ch == 0 && HAS_DIAG) {  // (the rows without entries: while the slots travel)
-            for (int z = tid; z < nz; z += T) {
-                const int p = z_pos[z];
-                if (lu_masked(sh, p)) continue;
-                const double d = z_dinv[z];
-                x0[p] = x0[p] * d;
-                if (NRHS == 2) x1[p] = x1[p] * d;
-            }
-        }
-        if (HAS_DIAG && have && lu_masked(sh, pos)) flags &= ~(1 << 8);  // a replaced position: computed, never written
+        const int pos = rec.pos;
+        const int lev = k < end_slot ? rec.lev : NONE;  // (the slots behind this chunk belong to the next one)
+        int flags = rec.flags;
+        const double dinv = rec.dinv;
+        if (HAS_DIAG && lev != NONE && lu_masked(sh, pos)) flags &= ~(1 << 8);  // a replaced position: computed, never written
         const int g = flags & 0xff;
         const unsigned gbits = (__any(g > 0) ? 1u : 0u) | (__any(g > 1) ? 2u : 0u) | (__any(g > 2) ? 4u : 0u) | (__any(g > 3) ? 8u : 0u) |
                                (__any(g > 4) ? 16u : 0u) | (__any(g > 5) ? 32u : 0u);
@@ -700,7 +735,7 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
             *sh.t_prev = t;
         }
 #endif
-        // ---- the levels of the chunk: the slots of a wave are consecutive in level order, so its next level is one scalar -------------
+        // ---- the levels of the chunk ---------------------------------------------------------------------------------------------
         int first_lane = 0;                                       // wave-uniform: this wave's next pending lane
         int wave_next = __builtin_amdgcn_readfirstlane(lev);      // ... and its level
         for (int l = first_level; l < end_level; ++l) {
@@ -708,24 +743,24 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
                 const bool active = lane >= first_lane && lev == l;
                 double xv[LU_TE];
 #pragma unroll
-                for (int e = 0; e < LU_TE; ++e) xv[e] = x0[col[e]];
+                for (int e = 0; e < LU_TE; ++e) xv[e] = x0[rec.col[e]];
                 const double own0 = x0[pos];
                 double s0 = 0.0, s1 = 0.0, own1 = 0.0;
 #pragma unroll
-                for (int e = 0; e < LU_TE; ++e) s0 += val[e] * xv[e];
+                for (int e = 0; e < LU_TE; ++e) s0 += rec.val[e] * xv[e];
                 if (NRHS == 2) {
 #pragma unroll
-                    for (int e = 0; e < LU_TE; ++e) xv[e] = x1[col[e]];
+                    for (int e = 0; e < LU_TE; ++e) xv[e] = x1[rec.col[e]];
                     own1 = x1[pos];
 #pragma unroll
-                    for (int e = 0; e < LU_TE; ++e) s1 += val[e] * xv[e];
+                    for (int e = 0; e < LU_TE; ++e) s1 += rec.val[e] * xv[e];
                 }
                 if (any_extra) {  // rows of more than 64 LU_TE entries: the rest from the arena (rare)
                     if (active && ((flags >> 9) & 1)) {
-                        const int xs = s_xstart[k], xn = s_xn[k];
+                        const int xs = tk.s_xstart[k], xn = tk.s_xn[k];
                         for (int e = lane; e < xn; e += WAVE) {
-                            const int c = x_idx[xs + e];
-                            const double v = x_val[xs + e];
+                            const int c = tk.x_idx[xs + e];
+                            const double v = tk.x_val[xs + e];
                             s0 += v * x0[c];
                             if (NRHS == 2) s1 += v * x1[c];
                         }
@@ -751,37 +786,28 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
         }
 #endif
     }
-    if (n_chunks == 0) {
-        if (HAS_DIAG) {
-            for (int k = tid; k < nz; k += T) {
-                const int p = z_pos[k];
-                if (lu_masked(sh, p)) continue;
-                const double d = z_dinv[k];
-                x0[p] = x0[p] * d;
-                if (NRHS == 2) x1[p] = x1[p] * d;
-            }
-        }
-        __syncthreads();
-    }
+    if (n_chunks == 0) __syncthreads();
 }
 
 // FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve (trailing block by one
 // wave, spike contributions, then the base rows with the replaced positions held at zero).  Ends with a barrier.
 __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
-                                               double* spike_out) {
+                                               double* spike_out, const LuSlot& lower_record) {
     (void)epoch;
     const int m = lu.m;
-    lu_solve_tasks<1, false>(lu, sh, 0);
+    const LuSlot upper_record = lu_load_slot(lu, 1, threadIdx.x);  // (lands while L and the etas are done)
+    lu_solve_tasks<1, false>(lu, sh, 0, lower_record);
     lu_stamp(sh, 2);
     if (n_updates > 0) {
         apply_etas_forward(lu, n_updates, sh.x0);
         __syncthreads();
     }
     lu_stamp(sh, 3);
-    if (spike_out)
+    if (spike_out) {
         for (int i = threadIdx.x; i < m; i += blockDim.x) spike_out[i] = sh.x0[i];
+        __syncthreads();  // (the spike is read from x0 before anybody rewrites it: the trailing solve, or the U solve's first pass)
+    }
     if (n_updates > 0) {
-        if (spike_out) __syncthreads();  // (the spike is read from x0 before the trailing positions are zeroed)
         if (threadIdx.x < WAVE) {  // T x_T = y_T, back substitution by slot (lower_upper/mod.rs:307-321 on the trailing block)
             const int lane = threadIdx.x;
             const int pos = lane < n_updates ? lu.trail_pos[lane] : -1;
@@ -807,7 +833,7 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
         }
         __syncthreads();
     }
-    lu_solve_tasks<1, true>(lu, sh, 1);
+    lu_solve_tasks<1, true>(lu, sh, 1, upper_record);
     if (n_updates > 0) {
         if ((int)threadIdx.x < n_updates) {
             const int pos = lu.trail_pos[threadIdx.x];
@@ -822,8 +848,9 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
 // etas, when x0 = (e_t' U^-1) for a unit input (the Forrest-Tomlin row comes from there).  Ends with a barrier.
 template <int NRHS, class AfterUpper>
 __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
-                                               AfterUpper after_upper) {
+                                               AfterUpper after_upper, const LuSlot& upper_record) {
     (void)epoch;
+    const LuSlot lower_record = lu_load_slot(lu, 3, threadIdx.x);  // (lands while U' and the etas are done)
     if (n_updates > 0) {
         // the replaced positions leave the base solve: their right-hand sides wait in xt0 / xt1, their components read as zero
         if ((int)threadIdx.x < n_updates) {
@@ -837,7 +864,7 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
         }
         __syncthreads();
     }
-    lu_solve_tasks<NRHS, true>(lu, sh, 2);
+    lu_solve_tasks<NRHS, true>(lu, sh, 2, upper_record);
     if (n_updates > 0) {
         // right-hand side of the trailing solve: v_T - z_b S, one wave per spike column (lower_upper/mod.rs:373-397)
         const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, nwaves = blockDim.x / WAVE;
@@ -894,7 +921,7 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
         __syncthreads();
     }
     lu_stamp(sh, 9);
-    lu_solve_tasks<NRHS, false>(lu, sh, 3);
+    lu_solve_tasks<NRHS, false>(lu, sh, 3, lower_record);
     lu_stamp(sh, 10);
 }
 
@@ -1037,6 +1064,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const
                                                                const double* dense, double* out, int keep_spike) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
+    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
@@ -1047,7 +1075,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const
     }
     __syncthreads();
     int epoch = 0;
-    lu_ftran_block(lu, sh, n_updates, epoch, keep_spike ? lu.spike : nullptr);
+    lu_ftran_block(lu, sh, n_updates, epoch, keep_spike ? lu.spike : nullptr, lower_record);
     for (int s = threadIdx.x; s < m; s += blockDim.x) out[s] = sh.x0[lu.colpos[s]];
 }
 
@@ -1055,6 +1083,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
                                                                const double* dense, double* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
+    const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
@@ -1065,13 +1094,14 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
     }
     __syncthreads();
     int epoch = 0;
-    lu_btran_block<1>(lu, sh, n_updates, epoch, [] {});
+    lu_btran_block<1>(lu, sh, n_updates, epoch, [] {}, upper_record);
     for (int i = threadIdx.x; i < m; i += blockDim.x) out[i] = sh.x0[lu.rowpos[i]];
 }
 
 __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
+    const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int t = lu.colpos[p];
     const int n_updates = lu.state[LU_N_UPDATES];
@@ -1087,7 +1117,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int 
     int epoch = 0;
     int eta_count = 0;
     double new_diag = 0.0;
-    lu_btran_block<1>(lu, sh, n_updates, epoch, [&] { eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag); });
+    lu_btran_block<1>(lu, sh, n_updates, epoch, [&] { eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag); }, upper_record);
     lu_ft_update_block(lu, sh, t, eta_count, new_diag, lu.spike);
 }
 
@@ -1156,6 +1186,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     __shared__ unsigned long long s_arank[LU_THREADS / WAVE];
     __shared__ double s_bcast[4];
     Ctl* ctl = lp.ctl;
+    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // FTRAN's first solve: lands while the entering column is chosen
     const int tid = threadIdx.x, T = blockDim.x;
     const int m = lp.m;
     LuShared sh = lu_shared(smem, m, lu.max_updates);
@@ -1255,7 +1286,8 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     __syncthreads();
     lu_stamp(sh, 1);
     int epoch = 0;
-    lu_ftran_block(lu, sh, n_updates, epoch, lu.spike);
+    lu_ftran_block(lu, sh, n_updates, epoch, lu.spike, lower_record);
+    const LuSlot upper_record = lu_load_slot(lu, 2, tid);  // BTRAN's first solve: lands during the ratio test
     // ---- alpha per basis slot (kept in x1), gamma_q, Harris pass 1 ----------------------------------------------------------
     // harris_delta < 0: the reference's ratio test (exact minimum, ties to the lowest leaving column; tableau/mod.rs:287-313).
     // With implicit bounds a basic variable may also leave at its upper bound -- rows with alpha_i < 0 whose basic variable has
@@ -1394,7 +1426,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     double new_diag = 0.0;
     lu_btran_block<2>(lu, sh, n_updates, epoch, [&] {
         if (do_update) eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag);
-    });
+    }, upper_record);
     // ---- rho_p of the new basis, w, -pi (carry/mod.rs:338-349) ----------------------------------------------------------------
     for (int i = tid; i < m; i += T) {
         const int k = lu.rowpos[i];
@@ -1457,19 +1489,21 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
 __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
+    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
     for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = lp.rhs[i];
     __syncthreads();
     int epoch = 0;
-    lu_ftran_block(lu, sh, n_updates, epoch, nullptr);
+    lu_ftran_block(lu, sh, n_updates, epoch, nullptr, lower_record);
     for (int s = threadIdx.x; s < m; s += blockDim.x) lp.xB[s] = sh.x0[lu.colpos[s]];
 }
 // -pi = -c_B' B^-1 and -obj = -c_B' x_B  (carry/mod.rs:226-283: the reference forms all of B^-1 with m FTRANs)
 __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
+    const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear(lu, sh, n_updates, false);
@@ -1485,7 +1519,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
             if (lp.flipped[j]) obj += lp.ub[j] * lp.cost[j];
     __syncthreads();
     int epoch = 0;
-    lu_btran_block<1>(lu, sh, n_updates, epoch, [] {});
+    lu_btran_block<1>(lu, sh, n_updates, epoch, [] {}, upper_record);
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         const double v = -sh.x0[lu.rowpos[i]];
         lp.minus_pi[i] = v;
@@ -1499,6 +1533,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
 __global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
+    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates);
     const int n_updates = lu.state[LU_N_UPDATES];
     for (int j = lp.n_art + blockIdx.x; j < lp.n; j += gridDim.x) {
@@ -1508,7 +1543,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, Devic
         for (int e = lp.col_start[j] + threadIdx.x; e < lp.col_start[j + 1]; e += blockDim.x) sh.x0[lu.rowpos[lp.row_index[e]]] = lp.value[e];
         __syncthreads();
         int epoch = 0;
-        lu_ftran_block(lu, sh, n_updates, epoch, nullptr);
+        lu_ftran_block(lu, sh, n_updates, epoch, nullptr, lower_record);
         double sumsq = 0.0;
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
             const double a = sh.x0[i];

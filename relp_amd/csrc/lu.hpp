@@ -52,18 +52,23 @@ constexpr int LU_TE = RELP_LU_TE;   // (a macro only so that micro-variants can 
 #endif
 constexpr int LU_ROUNDS = RELP_LU_ROUNDS;   // slots per thread and chunk
 constexpr int LU_CHUNK_SLOTS = LU_ROUNDS * 1024;
+// (global-address-space pointers: through generic pointers the compiler emits flat_load, which counts in lgkmcnt as well as vmcnt,
+//  so that every LDS wait of a solve would also wait for the records still on their way from L2)
+typedef const __attribute__((address_space(1))) int* lu_gptr_i32;
+typedef const __attribute__((address_space(1))) double* lu_gptr_f64;
 struct LuTasks {
-    int* z_pos = nullptr; double* z_dinv = nullptr;  // [nz]
-    int* s_pos = nullptr;        // [ns] position of the slot's row
-    int* s_lev = nullptr;        // [ns] its level (>= 1); 0x7fffffff: none
-    int* s_flags = nullptr;      // [ns] log2(G) | (last lane of the group: writes the component) << 8 | (row has extra entries) << 9
-    double* s_dinv = nullptr;    // [ns] 1 / diagonal of the row (U), 1 (L)
-    int* s_col = nullptr; double* s_val = nullptr;   // [LU_TE][stride]; padding: position 0, value 0
-    int* s_xstart = nullptr; int* s_xn = nullptr;    // [ns] extra entries of the row (G = 64 only): range in x_idx / x_val
-    int* x_idx = nullptr; double* x_val = nullptr;
-    int* chunk = nullptr;        // [chunks][4]: first slot, end slot, first level, end level
+    lu_gptr_i32 z_pos = nullptr; lu_gptr_f64 z_dinv = nullptr;  // [stride] rows without entries (padding: position 0, factor 1 ... never used past nz)
+    lu_gptr_i32 s_pos = nullptr;     // [stride] position of the slot's row
+    lu_gptr_i32 s_lev = nullptr;     // [stride] its level (>= 1); 0x7fffffff: no slot (all of the padding up to `stride`)
+    lu_gptr_i32 s_flags = nullptr;   // [stride] log2(G) | (last lane of the group: writes the component) << 8 | (row has extra entries) << 9
+    lu_gptr_f64 s_dinv = nullptr;    // [stride] 1 / diagonal of the row (U), 1 (L)
+    lu_gptr_i32 s_col = nullptr; lu_gptr_f64 s_val = nullptr;   // [LU_TE][stride]; padding: position 0, value 0
+    lu_gptr_i32 s_xstart = nullptr; lu_gptr_i32 s_xn = nullptr;  // [stride] extra entries of the row (G = 64 only): range in x_idx / x_val
+    lu_gptr_i32 x_idx = nullptr; lu_gptr_f64 x_val = nullptr;
+    lu_gptr_i32 chunk = nullptr;     // [chunks][4]: first slot, end slot, first level, end level (chunk 0 starts at slot 0)
+    lu_gptr_i32 counts = nullptr;    // [LU_CNT_WORDS]: device-resident, so that a captured graph survives a refactorisation
 };
-enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_CHUNKS = 3, LU_CNT_WORDS = 4 };
+enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_CHUNKS = 3, LU_CNT_C0_END = 4, LU_CNT_C0_L0 = 5, LU_CNT_C0_L1 = 6, LU_CNT_WORDS = 8 };
 constexpr int LU_MAX_CHUNKS = 256;
 
 struct DeviceLU {
@@ -87,9 +92,8 @@ struct DeviceLU {
     int eta_capacity = 0;
     double* spike = nullptr;  // [m] position space: the FTRAN intermediate before the U solve (mod.rs:196 `spike`)
     // task lists of the four triangular solves: 0 L by rows, 1 U by rows (FTRAN), 2 U by columns, 3 L by columns (BTRAN)
-    const LuTasks* tasks = nullptr;  // [4], in device memory (forty-eight pointers would not fit the kernel's scalar registers)
-    int task_stride = 0;      // ELL stride of the slots (their capacity: a multiple of 64)
-    int* counts = nullptr;    // [4][LU_CNT_WORDS]: device-resident, so that a captured graph survives a refactorisation
+    LuTasks tasks[4];         // (kernel arguments: read from the kernarg segment where they are used, no dependent round trip)
+    int task_stride = 0;      // ELL stride of the slots (their capacity: a multiple of 1024, at least 1024 past the last slot)
     int* state = nullptr;     // LU_* words
 };
 
