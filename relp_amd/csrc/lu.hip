@@ -76,8 +76,14 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
     for (int i = first; i < m; i += stride) {
         lu.app_len[i] = 0;
         lu.slot_of[i] = -1;
+        lu.eta_of_pos[i] = -1;
+        lu.eta_first[i] = -1;
+        lu.eapp_len[i] = 0;
     }
-    for (int i = first; i < lu.max_updates * lu.ldt; i += stride) lu.T[i] = 0.0;
+    for (int i = first; i < lu.max_updates * lu.ldt; i += stride) {
+        lu.T[i] = 0.0;
+        lu.eta_mf[i] = 0.0;
+    }
     for (int i = first; i < lu.max_updates; i += stride) {
         lu.trail_pos[i] = -1;
         lu.s_clen[i] = 0;
@@ -131,7 +137,16 @@ void build_tasks(const int* start, const int* idx, const double* val, const doub
     int chunk_first = 0, chunk_level = 1;
     auto close_chunk = [&](int end_level, int next_level) {
         if ((int)out.s_pos.size() > chunk_first) {
-            out.chunk.insert(out.chunk.end(), {chunk_first, (int)out.s_pos.size(), chunk_level, end_level});
+            // tail: the levels whose slots all lie in the chunk's last wave (LDS keeps one wave's accesses in order: no barrier needed)
+            const int end = (int)out.s_pos.size();
+            const int last_wave_first = chunk_first + ((end - 1 - chunk_first) / WAVE) * WAVE;
+            int tail = end_level;
+            if (last_wave_first > chunk_first || end - chunk_first <= WAVE) {
+                tail = out.s_lev[last_wave_first];
+                if (last_wave_first > chunk_first && out.s_lev[last_wave_first - 1] == tail) ++tail;  // that level starts in an earlier wave
+            }
+            tail = std::max(chunk_level, std::min(tail, end_level));
+            out.chunk.insert(out.chunk.end(), {chunk_first, end, chunk_level, end_level, tail, 0, 0, 0});
             while ((int)out.s_pos.size() % WAVE) push_slot(0, 0x7fffffff, 0, 1.0, 0, 0);  // the next chunk starts on a wave boundary
         }
         chunk_first = (int)out.s_pos.size();
@@ -182,7 +197,7 @@ void build_tasks(const int* start, const int* idx, const double* val, const doub
         }
     }
     close_chunk(out.levels, out.levels);
-    if ((int)out.chunk.size() / 4 > LU_MAX_CHUNKS) throw std::runtime_error("LU task list: too many chunks");
+    if ((int)out.chunk.size() / 8 > LU_MAX_CHUNKS) throw std::runtime_error("LU task list: too many chunks");
 }
 }  // namespace
 
@@ -256,7 +271,7 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         to[k].s_dinv = c.take<double>(stride);
         to[k].s_xstart = c.take<int>(stride);
         to[k].s_xn = c.take<int>(stride);
-        to[k].chunk = c.take<int>(4 * LU_MAX_CHUNKS);
+        to[k].chunk = c.take<int>(8 * LU_MAX_CHUNKS);
     }
     const size_t small_bytes = c.offset;  // everything up to here goes in one copy
     for (int k = 0; k < 4; ++k) {
@@ -277,6 +292,8 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t o_trail = c.take<int>(max_updates), o_slotof = c.take<int>(m);
     const size_t o_eta_start = c.take<int>(max_updates + 2), o_eta_pivot = c.take<int>(max_updates + 1);
     const size_t o_eta_idx = c.take<int>(app), o_eta_val = c.take<double>(app);
+    const size_t o_eta_mf = c.take<double>((size_t)max_updates * ldt), o_eta_of = c.take<int>(m), o_eta_first = c.take<int>(m), o_eta_prev = c.take<int>(max_updates + 1);
+    const size_t o_eapp_len = c.take<int>(m), o_eapp_eta = c.take<int>(app), o_eapp_val = c.take<double>(app);
     const size_t o_spike = c.take<double>(m);
     const size_t o_state = c.take<int>(LU_STATE_WORDS);
     const size_t device_bytes = c.offset;
@@ -302,11 +319,11 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         counts[k * LU_CNT_WORDS + LU_CNT_Z] = (int)t.z_pos.size();
         counts[k * LU_CNT_WORDS + LU_CNT_SLOTS] = (int)t.s_pos.size();
         counts[k * LU_CNT_WORDS + LU_CNT_LEVELS] = t.levels;
-        counts[k * LU_CNT_WORDS + LU_CNT_CHUNKS] = (int)t.chunk.size() / 4;
+        counts[k * LU_CNT_WORDS + LU_CNT_CHUNKS] = (int)t.chunk.size() / 8;
         counts[k * LU_CNT_WORDS + LU_CNT_C0_END] = t.chunk.empty() ? 0 : t.chunk[1];
         counts[k * LU_CNT_WORDS + LU_CNT_C0_L0] = t.chunk.empty() ? 0 : t.chunk[2];
         counts[k * LU_CNT_WORDS + LU_CNT_C0_L1] = t.chunk.empty() ? 0 : t.chunk[3];
-        counts[k * LU_CNT_WORDS + 7] = 0;
+        counts[k * LU_CNT_WORDS + LU_CNT_C0_TAIL] = t.chunk.empty() ? 0 : t.chunk[4];
         // every per-slot array is written up to `stride`: a thread reads slot first + tid without knowing where the slots end
         auto put_i_padded = [&](size_t at, const std::vector<int>& v, int pad) {
             int* dst = reinterpret_cast<int*>(h + at);
@@ -388,6 +405,8 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     d.diag = D(o_diag);
     d.eta_start = I(o_eta_start); d.eta_pivot = I(o_eta_pivot); d.eta_idx = I(o_eta_idx); d.eta_val = D(o_eta_val);
     d.eta_capacity = (int)app;
+    d.eta_mf = D(o_eta_mf); d.eta_of_pos = I(o_eta_of); d.eta_first = I(o_eta_first); d.eta_prev = I(o_eta_prev);
+    d.eapp_len = I(o_eapp_len); d.eapp_eta = I(o_eapp_eta); d.eapp_val = D(o_eapp_val);
     d.spike = D(o_spike);
     d.state = I(o_state);
     d.task_stride = stride;
@@ -415,7 +434,7 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
 static size_t lu_lds_fixed_bytes(int m, int max_updates) {
     const size_t mm = (size_t)((m + 1) & ~1);
     return 2 * mm * sizeof(double) + ((size_t)(m + 31) / 32 + 2) * sizeof(int) + ((size_t)(m + 63) / 64 + 4) * sizeof(int) + 64 * sizeof(double) +
-           ((size_t)max_updates * (max_updates + 1) + 4 * LU_MAX_SLOTS) * sizeof(double) + 256;
+           ((size_t)2 * max_updates * (max_updates + 1) + 4 * LU_MAX_SLOTS) * sizeof(double) + 256;
 }
 constexpr size_t LU_LDS_TOTAL = 160 * 1024 - 1024;  // what a kernel may ask for (static LDS of the fused kernel comes on top)
 static size_t lu_lds_bytes_for(int m, int max_updates) { return std::min(LU_LDS_TOTAL - 2048, lu_lds_fixed_bytes(m, max_updates)); }
@@ -444,85 +463,6 @@ __device__ __forceinline__ int lane_value(int v, int lane) { return __builtin_am
 __device__ __forceinline__ double lane_value(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-// FTRAN direction (eta_file.rs:72-105): for each update in order  v[t] -= sum_k r_k v[k].  One wave; a dot product per eta.
-// Lane l keeps the bounds and the pivot of eta l (at most 64 of them), so the loop's only memory traffic are the entries,
-// and those are prefetched one eta ahead.
-__device__ __forceinline__ void apply_etas_forward(const DeviceLU& lu, const int n_updates, volatile lds_f64* x0) {
-    if (threadIdx.x >= WAVE || n_updates <= 0) return;
-    const int lane = threadIdx.x;
-    const int my_start = lane <= n_updates ? lu.eta_start[lane] : 0;
-    const int my_end = lane < n_updates ? lu.eta_start[lane + 1] : 0;
-    const int my_pivot = lane < n_updates ? lu.eta_pivot[lane] : 0;
-    int s = lane_value(my_start, 0), s_end = lane_value(my_end, 0);
-    int nidx = 0;
-    double nval = 0.0;
-    if (s + lane < s_end) {
-        nidx = lu.eta_idx[s + lane];
-        nval = lu.eta_val[s + lane];
-    }
-    for (int k = 0; k < n_updates; ++k) {
-        const int e_end = s_end;
-        const int t = lane_value(my_pivot, k);
-        const int cidx = nidx;
-        const double cval = nval;
-        const bool chave = s + lane < e_end;
-        const int s_next = e_end;
-        s_end = k + 1 < n_updates ? lane_value(my_end, k + 1) : e_end;
-        if (k + 1 < n_updates && s_next + lane < s_end) {
-            nidx = lu.eta_idx[s_next + lane];
-            nval = lu.eta_val[s_next + lane];
-        }
-        double partial = chave ? cval * x0[cidx] : 0.0;
-        for (int e = s + lane + WAVE; e < e_end; e += WAVE) partial += lu.eta_val[e] * x0[lu.eta_idx[e]];
-        const double total = wave_sum(partial);
-        if (lane == LAST && total != 0.0) x0[t] = x0[t] - total;
-        s = s_next;
-    }
-}
-// BTRAN direction (eta_file.rs:49-65): for each update in reverse  v[j] -= r_j v[t].
-template <int NRHS>
-__device__ __forceinline__ void apply_etas_backward(const DeviceLU& lu, const int n_updates, volatile lds_f64* x0, volatile lds_f64* x1) {
-    if (threadIdx.x >= WAVE || n_updates <= 0) return;
-    const int lane = threadIdx.x;
-    const int my_start = lane < n_updates ? lu.eta_start[lane] : 0;
-    const int my_end = lane < n_updates ? lu.eta_start[lane + 1] : 0;
-    const int my_pivot = lane < n_updates ? lu.eta_pivot[lane] : 0;
-    int s = lane_value(my_start, n_updates - 1), e_end = lane_value(my_end, n_updates - 1);
-    int nidx = 0;
-    double nval = 0.0;
-    if (s + lane < e_end) {
-        nidx = lu.eta_idx[s + lane];
-        nval = lu.eta_val[s + lane];
-    }
-    for (int k = n_updates - 1; k >= 0; --k) {
-        const int t = lane_value(my_pivot, k);
-        const int cidx = nidx;
-        const double cval = nval;
-        const bool chave = s + lane < e_end;
-        const int cs = s, cend = e_end;
-        if (k > 0) {
-            s = lane_value(my_start, k - 1);
-            e_end = lane_value(my_end, k - 1);
-            if (s + lane < e_end) {
-                nidx = lu.eta_idx[s + lane];
-                nval = lu.eta_val[s + lane];
-            }
-        }
-        const double p0 = x0[t];
-        const double p1 = NRHS == 2 ? x1[t] : 0.0;
-        if (p0 == 0.0 && p1 == 0.0) continue;
-        if (chave) {
-            x0[cidx] = x0[cidx] - cval * p0;
-            if (NRHS == 2) x1[cidx] = x1[cidx] - cval * p1;
-        }
-        for (int e = cs + lane + WAVE; e < cend; e += WAVE) {
-            const int j = lu.eta_idx[e];
-            const double r = lu.eta_val[e];
-            x0[j] = x0[j] - r * p0;
-            if (NRHS == 2) x1[j] = x1[j] - r * p1;
-        }
-    }
-}
 // LDS carve-up shared by every kernel of this file
 struct LuShared {
     volatile lds_f64* x0;
@@ -531,6 +471,7 @@ struct LuShared {
     int* group_count;  // one slot per 64 rows (+2)   (generic pointers: used with barriers around, a handful of accesses)
     double* red;       // 64 doubles
     volatile lds_f64* T;     // the trailing block, max_updates x ldt
+    volatile lds_f64* MF;    // the etas' chaining matrix (lu.hpp), max_updates x ldt
     volatile lds_f64* xt0;   // trailing values by slot (LU_MAX_SLOTS each)
     volatile lds_f64* xt1;
     volatile lds_f64* st0;   // BTRAN: right-hand sides of the trailing solve
@@ -555,7 +496,8 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
     lds_f64* x1 = x0 + mm;
     lds_f64* red = x1 + mm;
     lds_f64* T = red + 64;
-    lds_f64* xt0 = T + max_updates * (max_updates + 1);
+    lds_f64* MF = T + max_updates * (max_updates + 1);
+    lds_f64* xt0 = MF + max_updates * (max_updates + 1);
     lds_f64* xt1 = xt0 + LU_MAX_SLOTS;
     lds_f64* st0 = xt1 + LU_MAX_SLOTS;
     lds_f64* st1 = st0 + LU_MAX_SLOTS;
@@ -563,6 +505,7 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
     s.x1 = x1;
     s.red = (double*)red;
     s.T = T;
+    s.MF = MF;
     s.xt0 = xt0;
     s.xt1 = xt1;
     s.st0 = st0;
@@ -587,7 +530,10 @@ __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh,
         if (two) sh.x1[i] = 0.0;
     }
     for (int i = threadIdx.x; i < (m + 31) / 32; i += blockDim.x) sh.mask[i] = 0u;
-    for (int i = threadIdx.x; i < n_updates * lu.ldt; i += blockDim.x) sh.T[i] = lu.T[i];
+    for (int i = threadIdx.x; i < n_updates * lu.ldt; i += blockDim.x) {
+        sh.T[i] = lu.T[i];
+        sh.MF[i] = lu.eta_mf[i];
+    }
     __syncthreads();
     if ((int)threadIdx.x < n_updates) {
         const int pos = lu.trail_pos[threadIdx.x];
@@ -636,7 +582,7 @@ struct LuSlot {
     double val[LU_TE];
     int z_pos;
     double z_dinv;
-    int nz, n_chunks, c_end, l0, l1;  // (the same in every lane; read through readfirstlane)
+    int nz, n_chunks, c_end, l0, l1, l_tail;  // (the same in every lane; read through readfirstlane)
 };
 __device__ __forceinline__ LuSlot lu_load_slot(const DeviceLU& lu, const int sched, const int k) {
     const LuTasks& tk = lu.tasks[sched];
@@ -658,6 +604,7 @@ __device__ __forceinline__ LuSlot lu_load_slot(const DeviceLU& lu, const int sch
     r.c_end = tk.counts[LU_CNT_C0_END];
     r.l0 = tk.counts[LU_CNT_C0_L0];
     r.l1 = tk.counts[LU_CNT_C0_L1];
+    r.l_tail = tk.counts[LU_CNT_C0_TAIL];
     return r;
 }
 
@@ -707,12 +654,14 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
     LuSlot rec = first_record;
     int first_slot = 0, end_slot = __builtin_amdgcn_readfirstlane(first_record.c_end);
     int first_level = __builtin_amdgcn_readfirstlane(first_record.l0), end_level = __builtin_amdgcn_readfirstlane(first_record.l1);
+    int tail_level = __builtin_amdgcn_readfirstlane(first_record.l_tail);
     for (int ch = 0; ch < n_chunks; ++ch) {
         if (ch > 0) {  // (a factor of more than 1024 slots: the later chunks are fetched here)
-            first_slot = tk.chunk[4 * ch];
-            end_slot = tk.chunk[4 * ch + 1];
-            first_level = tk.chunk[4 * ch + 2];
-            end_level = tk.chunk[4 * ch + 3];
+            first_slot = tk.chunk[8 * ch];
+            end_slot = tk.chunk[8 * ch + 1];
+            first_level = tk.chunk[8 * ch + 2];
+            end_level = tk.chunk[8 * ch + 3];
+            tail_level = tk.chunk[8 * ch + 4];
             rec = lu_load_slot(lu, sched, first_slot + tid);
         }
         const int k = first_slot + tid;
@@ -738,7 +687,7 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
         // ---- the levels of the chunk ---------------------------------------------------------------------------------------------
         int first_lane = 0;                                       // wave-uniform: this wave's next pending lane
         int wave_next = __builtin_amdgcn_readfirstlane(lev);      // ... and its level
-        for (int l = first_level; l < end_level; ++l) {
+        auto level = [&](const int l) {  // this wave's slots of level l
             while (wave_next == l) {
                 const bool active = lane >= first_lane && lev == l;
                 double xv[LU_TE];
@@ -766,8 +715,11 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
                         }
                     }
                 }
-                s0 = group_sum_by(s0, g, gbits);
-                if (NRHS == 2) s1 = group_sum_by(s1, g, gbits);
+                // (only when a row of THIS level in this wave spans several lanes: most levels are single-lane rows, and a stage of the
+                //  tree is ~8 wave instructions = 32 cycles of the one wave the level waits for)
+                const unsigned level_bits = __ballot(active && g > 0) ? gbits : 0u;
+                s0 = group_sum_by(s0, g, level_bits);
+                if (NRHS == 2) s1 = group_sum_by(s1, g, level_bits);
                 if (active && ((flags >> 8) & 1)) {
                     x0[pos] = (own0 - s0) * dinv;
                     if (NRHS == 2) x1[pos] = (own1 - s1) * dinv;
@@ -775,8 +727,14 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
                 first_lane += __popcll(__ballot(active));
                 wave_next = first_lane < WAVE ? __builtin_amdgcn_readlane(lev, first_lane < WAVE ? first_lane : 0) : NONE;
             }
+        };
+        for (int l = first_level; l < tail_level; ++l) {
+            level(l);
             lds_barrier();
         }
+        // the tail: every remaining slot sits in ONE wave, and LDS keeps one wave's accesses in order -- no barrier between its levels
+        // (a level here costs its LDS round trip; with the barrier and the bookkeeping of sixteen waves it costs three times that)
+        for (int l = tail_level; l < end_level; ++l) level(l);
         __syncthreads();
 #ifdef RELP_STAMPS
         if (sh.dbg && tid == 0) {
@@ -789,6 +747,88 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
     if (n_chunks == 0) __syncthreads();
 }
 
+// ---- eta files, applied in parallel -------------------------------------------------------------------------------------------
+// FTRAN direction (eta_file.rs:72-105): for each update j in order  v[t_j] -= sum_k r_jk v[k].  With V_j the value of v[t_j]
+// right after step j:  V_j = base_j - sum_{i<j} MF[j][i] V_i,  base_j = (v[t_j] unless an earlier eta pivots there) - the dot
+// product over the arena entries (positions no earlier eta pivots on: their v is still the input).  The dot products are
+// independent -- one wave per eta, all sixteen waves --; the k x k chain is solved by one wave with readlane broadcasts; the
+// last V of every position is written back.  (Round 2: one wave, one dependent dot product per eta, 11 k cycles at k ~ 16.)
+// x0 complete on entry; ends with a barrier.
+__device__ __forceinline__ void lu_etas_forward(const DeviceLU& lu, const LuShared& sh, const int n_updates) {
+    if (n_updates <= 0) return;
+    volatile lds_f64* x0 = sh.x0;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, nwaves = blockDim.x / WAVE;
+    for (int j = wave; j < n_updates; j += nwaves) {
+        const int start = lu.eta_start[j], end = lu.eta_start[j + 1];
+        double partial = 0.0;
+        for (int e = start + lane; e < end; e += WAVE) partial += lu.eta_val[e] * x0[lu.eta_idx[e]];
+        const double total = wave_sum(partial);
+        if (lane == LAST) sh.st0[j] = (lu.eta_prev[j] < 0 ? x0[lu.eta_pivot[j]] : 0.0) - total;
+    }
+    __syncthreads();
+    if (threadIdx.x < WAVE) {
+        const bool mine = lane < n_updates;
+        double v = mine ? sh.st0[lane] : 0.0;
+        const int t = mine ? lu.eta_pivot[lane] : 0;
+        const bool latest = mine && lu.eta_of_pos[t] == lane;
+        for (int i = 0; i + 1 < n_updates; ++i) {
+            const double vi = lane_value(v, i);
+            if (lane > i && mine) v -= sh.MF[lane * lu.ldt + i] * vi;
+        }
+        if (latest) x0[t] = v;
+    }
+    __syncthreads();
+}
+// BTRAN direction (eta_file.rs:49-65): for each update j in reverse  v[k] -= r_jk v[t_j].  With c_j the value of v[t_j] when
+// step j is applied:  c_j = (v[t_j] unless a later eta pivots there) - sum_{l>j} MF[l][j] c_l  (one wave, readlane chain), and
+// then every position gathers  v[k] = (c of the first eta that pivots on k, else v[k]) - sum over its arena entries r_lk c_l.
+template <int NRHS>
+__device__ __forceinline__ void lu_etas_backward(const DeviceLU& lu, const LuShared& sh, const int n_updates) {
+    if (n_updates <= 0) return;
+    volatile lds_f64* x0 = sh.x0;
+    volatile lds_f64* x1 = sh.x1;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (threadIdx.x < WAVE) {
+        const bool mine = lane < n_updates;
+        const int t = mine ? lu.eta_pivot[lane] : 0;
+        const bool last_of_position = mine && lu.eta_of_pos[t] == lane;
+        double c0 = last_of_position ? x0[t] : 0.0;
+        double c1 = (NRHS == 2 && last_of_position) ? x1[t] : 0.0;
+        for (int l = n_updates - 1; l > 0; --l) {
+            const double cl0 = lane_value(c0, l);
+            const double cl1 = NRHS == 2 ? lane_value(c1, l) : 0.0;
+            if (lane < l) {
+                const double f = sh.MF[l * lu.ldt + lane];
+                c0 -= f * cl0;
+                if (NRHS == 2) c1 -= f * cl1;
+            }
+        }
+        if (mine) {
+            sh.st0[lane] = c0;
+            if (NRHS == 2) sh.st1[lane] = c1;
+        }
+    }
+    __syncthreads();
+    const int stride = lu.max_updates;
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) {
+        const int n = lu.eapp_len[k];
+        const int first = lu.eta_first[k];
+        if (n <= 0 && first < 0) continue;
+        double v0 = first >= 0 ? sh.st0[first] : x0[k];
+        double v1 = NRHS == 2 ? (first >= 0 ? sh.st1[first] : x1[k]) : 0.0;
+        for (int e = 0; e < n; ++e) {
+            const int l = lu.eapp_eta[k * stride + e];
+            if (l >= n_updates) break;  // (the eta being built in this very pivot: not part of the current basis yet)
+            const double r = lu.eapp_val[k * stride + e];
+            v0 -= r * sh.st0[l];
+            if (NRHS == 2) v1 -= r * sh.st1[l];
+        }
+        x0[k] = v0;
+        if (NRHS == 2) x1[k] = v1;
+    }
+    __syncthreads();
+}
+
 // FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve (trailing block by one
 // wave, spike contributions, then the base rows with the replaced positions held at zero).  Ends with a barrier.
 __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
@@ -798,10 +838,7 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
     const LuSlot upper_record = lu_load_slot(lu, 1, threadIdx.x);  // (lands while L and the etas are done)
     lu_solve_tasks<1, false>(lu, sh, 0, lower_record);
     lu_stamp(sh, 2);
-    if (n_updates > 0) {
-        apply_etas_forward(lu, n_updates, sh.x0);
-        __syncthreads();
-    }
+    lu_etas_forward(lu, sh, n_updates);
     lu_stamp(sh, 3);
     if (spike_out) {
         for (int i = threadIdx.x; i < m; i += blockDim.x) spike_out[i] = sh.x0[i];
@@ -916,10 +953,7 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
     lu_stamp(sh, 7);
     after_upper();
     lu_stamp(sh, 8);
-    if (n_updates > 0) {
-        apply_etas_backward<NRHS>(lu, n_updates, sh.x0, sh.x1);
-        __syncthreads();
-    }
+    lu_etas_backward<NRHS>(lu, sh, n_updates);
     lu_stamp(sh, 9);
     lu_solve_tasks<NRHS, false>(lu, sh, 3, lower_record);
     lu_stamp(sh, 10);
@@ -964,16 +998,39 @@ __device__ __forceinline__ int lu_build_eta(const DeviceLU& lu, const LuShared& 
                                             double* new_diag) {
     const int m = lu.m;
     const int eta_top = lu.state[LU_ETA_TOP];
+    const int j = lu.state[LU_N_UPDATES];  // the eta being built
+    const int stride = lu.max_updates;
     const double yt = sh.x0[t];
     double dot = 0.0;
+    // entries at positions no eta pivots on yet: the arena, and the by-position lists of the BTRAN gather
     const int count = ordered_compact(
-        m, sh.group_count, [&](int i) { return i != t && sh.x0[i] != 0.0; },
+        m, sh.group_count, [&](int i) { return i != t && sh.x0[i] != 0.0 && lu.eta_of_pos[i] < 0; },
         [&](int i, int slot) {
             const double r = -sh.x0[i] / yt;
             lu.eta_idx[eta_top + slot] = i;
             lu.eta_val[eta_top + slot] = r;
+            const int at = i * stride + lu.eapp_len[i];
+            lu.eapp_eta[at] = j;
+            lu.eapp_val[at] = r;
+            lu.eapp_len[i] += 1;
             dot += r * spike[i];
         });
+    // entries at positions an earlier eta pivots on: row j of the chaining matrix (lu.hpp), against the LATEST such eta; -1 where
+    // that eta pivots on this eta's own position (its value is what this step starts from)
+    if ((int)threadIdx.x < j) {
+        const int i = threadIdx.x;
+        const int pos = lu.eta_pivot[i];
+        double f = 0.0;
+        if (lu.eta_of_pos[pos] == i) {
+            if (pos == t) {
+                f = -1.0;
+            } else if (sh.x0[pos] != 0.0) {
+                f = -sh.x0[pos] / yt;
+                dot += f * spike[pos];
+            }
+        }
+        lu.eta_mf[j * lu.ldt + i] = f;
+    }
     const double total = block_reduce<0>(dot, sh.red);
     *new_diag = spike[t] - total;
     return count;
@@ -1047,6 +1104,9 @@ __device__ __forceinline__ void lu_ft_update_block(const DeviceLU& lu, const LuS
         lu.slot_of[t] = new_slot;
         lu.diag[t] = new_diag;
         lu.eta_pivot[n_updates] = t;
+        lu.eta_prev[n_updates] = lu.eta_of_pos[t];
+        if (lu.eta_first[t] < 0) lu.eta_first[t] = n_updates;
+        lu.eta_of_pos[t] = n_updates;
         lu.eta_start[n_updates + 1] = eta_top + eta_count;
         lu.state[LU_N_UPDATES] = n_updates + 1;
         lu.state[LU_S_TOP] = top + count;
@@ -1607,6 +1667,13 @@ void launch_lu_pivot(const DeviceLP& d, const DeviceLU& lu, int rule, int n_pric
         default: launch_lu_pivot_rule<RELP_PIVOT_STEEPEST_EDGE>(d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period, s, start, stop); break;
     }
 }
+__global__ void lu_clear_refactor_status_kernel(Ctl* ctl) {
+    if (ctl->status == ST_REFACTOR) ctl->status = ST_RUNNING;
+}
+void launch_clear_refactor_status(const DeviceLP& d, hipStream_t s) {
+    hipLaunchKernelGGL(lu_clear_refactor_status_kernel, dim3(1), dim3(1), 0, s, d.ctl);
+    check_launch("lu_clear_refactor_status_kernel");
+}
 void launch_lu_xb(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
     configure_lu_pivot_lds();
     hipLaunchKernelGGL(lu_xb_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu);
@@ -1877,13 +1944,15 @@ LuBasis::Factors LuBasis::factors() {
     }
     // etas: indices as the reference saw them when each one was made (before its own rotation)
     std::vector<int> es = geti(d.eta_start, n_updates + 1), ep = geti(d.eta_pivot, n_updates), ei = geti(d.eta_idx, state[LU_ETA_TOP]);
-    std::vector<double> ev = getd(d.eta_val, state[LU_ETA_TOP]);
+    std::vector<double> ev = getd(d.eta_val, state[LU_ETA_TOP]), mf = getd(d.eta_mf, (size_t)d.max_updates * d.ldt);
     std::vector<int> r(m);
     for (int i = 0; i < m; ++i) r[i] = i;
     f.eta_start.assign(1, 0);
     for (int k = 0; k < n_updates; ++k) {
         std::vector<std::pair<int, double>> entries;
         for (int e = es[k]; e < es[k + 1]; ++e) entries.push_back({r[ei[e]], ev[e]});
+        for (int i = 0; i < k; ++i)  // the entries held in the chaining matrix: positions an earlier eta pivots on (not its own)
+            if (mf[(size_t)k * d.ldt + i] != 0.0 && ep[i] != ep[k]) entries.push_back({r[ep[i]], mf[(size_t)k * d.ldt + i]});
         std::sort(entries.begin(), entries.end());
         for (auto& [i, v] : entries) {
             f.eta_index.push_back(i);

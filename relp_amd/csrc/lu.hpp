@@ -65,10 +65,11 @@ struct LuTasks {
     lu_gptr_i32 s_col = nullptr; lu_gptr_f64 s_val = nullptr;   // [LU_TE][stride]; padding: position 0, value 0
     lu_gptr_i32 s_xstart = nullptr; lu_gptr_i32 s_xn = nullptr;  // [stride] extra entries of the row (G = 64 only): range in x_idx / x_val
     lu_gptr_i32 x_idx = nullptr; lu_gptr_f64 x_val = nullptr;
-    lu_gptr_i32 chunk = nullptr;     // [chunks][4]: first slot, end slot, first level, end level (chunk 0 starts at slot 0)
+    lu_gptr_i32 chunk = nullptr;     // [chunks][8]: first slot, end slot, first level, end level, tail level (chunk 0 starts at slot 0).
+                                     // From the tail level on every slot of the chunk sits in its LAST wave, which then runs on alone without barriers
     lu_gptr_i32 counts = nullptr;    // [LU_CNT_WORDS]: device-resident, so that a captured graph survives a refactorisation
 };
-enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_CHUNKS = 3, LU_CNT_C0_END = 4, LU_CNT_C0_L0 = 5, LU_CNT_C0_L1 = 6, LU_CNT_WORDS = 8 };
+enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_CHUNKS = 3, LU_CNT_C0_END = 4, LU_CNT_C0_L0 = 5, LU_CNT_C0_L1 = 6, LU_CNT_C0_TAIL = 7, LU_CNT_WORDS = 8 };
 constexpr int LU_MAX_CHUNKS = 256;
 
 struct DeviceLU {
@@ -90,6 +91,15 @@ struct DeviceLU {
     double* diag = nullptr;
     int* eta_start = nullptr; int* eta_pivot = nullptr; int* eta_idx = nullptr; double* eta_val = nullptr;
     int eta_capacity = 0;
+    // The etas are applied in parallel (lu.hip: lu_etas_forward / lu_etas_backward).  An entry of eta j at a position that an
+    // EARLIER eta i pivots on does not go to the arena but to MF[j][i] (i the latest such eta; -1 there when i pivots on eta j's
+    // own position): what chains the etas together is then a k x k unit lower-triangular matrix, solved by one wave out of
+    // registers, and everything else of an eta is an independent dot product (FTRAN) or a gather by position (BTRAN).
+    double* eta_mf = nullptr;     // [max_updates * ldt], MF[j * ldt + i], i < j
+    int* eta_of_pos = nullptr;    // [m] latest eta that pivots on the position, -1: none
+    int* eta_first = nullptr;     // [m] first such eta, -1: none
+    int* eta_prev = nullptr;      // [max_updates] per eta: the previous eta with the same pivot, -1: none
+    int* eapp_len = nullptr; int* eapp_eta = nullptr; double* eapp_val = nullptr;  // arena entries by POSITION, stride max_updates
     double* spike = nullptr;  // [m] position space: the FTRAN intermediate before the U solve (mod.rs:196 `spike`)
     // task lists of the four triangular solves: 0 L by rows, 1 U by rows (FTRAN), 2 U by columns, 3 L by columns (BTRAN)
     LuTasks tasks[4];         // (kernel arguments: read from the kernarg segment where they are used, no dependent round trip)

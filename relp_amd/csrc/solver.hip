@@ -53,6 +53,7 @@ void launch_eta_update(const DeviceLP& d, double tol_dual, hipStream_t s);
 int btran_pass_blocks();
 void launch_eta_consolidate(const DeviceLP& d, hipStream_t s);
 void launch_mark_all_touched(const DeviceLP& d, hipStream_t s);
+void launch_clear_refactor_status(const DeviceLP& d, hipStream_t s);
 void launch_scaled_basis(const DeviceLP& d, double* T, double scale, hipStream_t s);
 void launch_row_scan(const DeviceLP& d, int r, double tol, hipStream_t s);
 void launch_ftran_vec(const DeviceLP& d, const int* rows, const double* vals, int nnz, double* out, hipStream_t s);
@@ -1514,11 +1515,9 @@ void Solver::refactor_lu(bool refresh_vectors) {
         launch_lu_xb(d_, lu_.device(), stream_);
         launch_lu_pi(d_, lu_.device(), stream_);  // also rewrites minus_obj from the refreshed x_B
     }
-    Ctl c = read_ctl();
-    if (c.status == ST_REFACTOR) {
-        c.status = ST_RUNNING;
-        write_ctl(c);
-    }
+    // status: REFACTOR -> RUNNING, stream-ordered (no host round trip: the refresh kernels above are still running; whoever reads
+    // the control block next synchronises anyway).  A refactorisation is only ever asked for in the RUNNING state.
+    launch_clear_refactor_status(d_, stream_);
     refactors_++;
     since_polish_ = 0;
     refactor_seconds_ += now_seconds() - t0;
