@@ -475,7 +475,8 @@ struct ExactVector {           // numer[i] / denom
 // Solve  A z = rhs  (transpose = 0: A = B;  transpose = 1: A = B')  by Dixon lifting; the result is verified exactly.
 bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpose, u32 p, const u32* dA,
                  DeviceBuffers& buf, const int* d_row_start, const int* d_col_index, const i64* d_row_value,
-                 hipStream_t stream, ExactVector* out, std::string* message, CertifyTimes& times, int first_target = 32) {
+                 hipStream_t stream, ExactVector* out, std::string* message, CertifyTimes& times, int first_target = 32,
+                 int* digits_used = nullptr) {
     const int m = B.m;
     i64* d_r = buf.alloc<i64>(m);
     int* d_info = buf.alloc<int>(4);
@@ -619,6 +620,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             }
             out->numer = std::move(numer);
             out->denom = denom;
+            if (digits_used) *digits_used = steps_done;
             return true;
         }
         if (steps_done >= max_steps) {
@@ -660,7 +662,13 @@ std::vector<std::pair<int, std::string>> exact_primal_values(const ExactPrimal& 
 
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_columns, int device, hipStream_t stream,
                    std::string* objective, bool* certified, long long* repair_pivots, std::string* message, int mode, int entering,
-                   std::shared_ptr<const ExactPrimal>* primal) {
+                   std::shared_ptr<const ExactPrimal>* primal, int* digit_hints) {
+    // digit_hints[0 / 1]: p-adic digits the primal / dual solve of this LP needed last time (0: unknown).  The number of digits is
+    // found by doubling from 32 (Cramer's bound over-estimates it three-fold); a handle that solves the same LP again -- a warm
+    // start, a batch pass, a re-solve after a bound change -- starts where the last certificate ended instead of paying for the
+    // two failed reconstructions on the way up.  A wrong hint costs time only: every result is verified by exact substitution.
+    int no_hints[2] = {0, 0};
+    if (!digit_hints) digit_hints = no_hints;
     if (primal) primal->reset();
     objective->clear();
     *certified = false;
@@ -885,11 +893,15 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         // (The number of p-adic digits is found by doubling: Cramer's bound through |det B| of the row-scaled integer matrix
         //  over-estimates it three-fold on 25FV47, and the cost of the reconstruction grows with the square of it.)
         g_times.inverse += wall_now() - t_inverse;
+        int primal_digits = 0;
         auto solve = [&](const std::vector<i64>& r, int transpose, ExactVector* out) {
             g_times.solves++;
-            const int first = 32;
-            return transpose ? dixon_solve(B, r, 1, p, dCT, buf, d_col_start, d_row_index, d_value, stream, out, message, g_times, first)
-                             : dixon_solve(B, r, 0, p, dC, buf, d_row_start, d_col_index, d_row_value, stream, out, message, g_times, first);
+            const int first = (!transpose && digit_hints[0] > 0) ? digit_hints[0] : 32;
+            int used = 0;
+            const bool solved = transpose ? dixon_solve(B, r, 1, p, dCT, buf, d_col_start, d_row_index, d_value, stream, out, message, g_times, 32)
+                                          : dixon_solve(B, r, 0, p, dC, buf, d_row_start, d_col_index, d_row_value, stream, out, message, g_times, first, &used);
+            if (solved && !transpose && round == 0) primal_digits = std::max(primal_digits, used);
+            return solved;
         };
 
         // ---- exact primal and dual solutions ------------------------------------------------------------
@@ -935,8 +947,10 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                     RELP_HIP(hipStreamCreateWithFlags(&second, hipStreamNonBlocking));
                     try {
                         DeviceBuffers dual_buffers;
+                        int used = 0;
                         dual_ok = dixon_solve(B, cost_basis, 1, p, dCT, dual_buffers, d_col_start, d_row_index, d_value, second, &y,
-                                              &dual_message, dual_times, 32);
+                                              &dual_message, dual_times, digit_hints[1] > 0 ? digit_hints[1] : 32, &used);
+                        if (dual_ok && round == 0) digit_hints[1] = used;
                         RELP_HIP(hipStreamSynchronize(second));
                     } catch (...) {
                         (void)hipStreamDestroy(second);
@@ -961,6 +975,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             g_times.digit_launches += dual_times.digit_launches;
             g_times.reconstruct += dual_times.reconstruct;
             g_times.reconstructs += dual_times.reconstructs;
+            if (primal_ok && round == 0 && primal_digits > 0) digit_hints[0] = primal_digits;
             if (primal_error) std::rethrow_exception(primal_error);
             if (dual_error) std::rethrow_exception(dual_error);
             if (!primal_ok) return;

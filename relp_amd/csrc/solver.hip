@@ -62,7 +62,7 @@ void launch_relative_cost(const DeviceLP& d, double* out, hipStream_t s);
 // certify.hip
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_provider_columns, int device,
                    hipStream_t stream, std::string* objective, bool* certified, long long* repair_pivots,
-                   std::string* message, int mode, int entering, std::shared_ptr<const ExactPrimal>* primal);
+                   std::string* message, int mode, int entering, std::shared_ptr<const ExactPrimal>* primal, int* digit_hints);
 
 namespace {
 double now_seconds() {
@@ -125,6 +125,7 @@ void Solver::load(StandardForm&& form) {
     free_device();
     destroy_graphs();
     form_ = std::move(form);
+    certify_digit_hints_[0] = certify_digit_hints_[1] = 0;  // (a new LP: nothing is known about its certificate)
     try {
         upload();
     } catch (...) {
@@ -1449,7 +1450,7 @@ void Solver::certify(relp_result* result) {
     std::string message;
     try {
         const int mode = result->kind == RELP_RESULT_INFEASIBLE ? 1 : result->kind == RELP_RESULT_UNBOUNDED ? 2 : 0;
-        certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message, mode, unbounded_column_, &exact_primal);
+        certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message, mode, unbounded_column_, &exact_primal, mode == 0 ? certify_digit_hints_ : nullptr);
     } catch (const RatOverflow& e) {  // the f64 result stands; it is reported uncertified with the reason
         ok = false;
         message = std::string("exact certificate: ") + e.what();

@@ -223,6 +223,7 @@ private:
     void write_ctl(const Ctl& c);
     int drive_out_artificials();
     void certify(relp_result* result);
+    int certify_digit_hints_[2] = {0, 0};  // p-adic digits the last certificate of this LP needed (primal, dual): where the next one starts
     // LU carry (relp_options.carry == RELP_CARRY_LU)
     void refactor_lu(bool refresh_vectors);  // BasisInverse::invert of the current basis (host Markowitz + upload)
     void lu_identity();                      // BasisInverse::identity
