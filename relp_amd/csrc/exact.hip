@@ -31,6 +31,8 @@
 
 #include "bigint.hpp"
 #include "solver.hpp"
+#include <hip/hip_cooperative_groups.h>
+
 #include "wave_ops.hpp"
 
 namespace relp {
@@ -296,6 +298,9 @@ struct ExactLP {
     long long max_pivots;
     int* out;             // [8]: status, pivots phase one, pivots phase two, limbs, trace entries, redundant rows
     int* removed;         // [m] 1: the row is redundant -- its artificial cannot be pivoted out (`RemoveRows` of the reference)
+    int* shared_words;    // [8] grid-wide overflow flag, decisions of workgroup 0's thread 0
+    double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
+    unsigned long long* part_rank;
 };
 
 // Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
@@ -371,28 +376,77 @@ __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& 
     return 0;
 }
 
+// The loop on the WHOLE grid (round 3; round 2 ran it in one workgroup: E226 took 100 s for 342 pivots on 2048-bit integers while
+// 255 CUs idled).  The two heavy steps of a pivot -- the pricing pass (every non-basic column against every row of N) and the
+// integer-preserving update of the m x m matrix N -- are independent per column / per entry and are spread over all workgroups of
+// a COOPERATIVE launch; between steps the workgroups meet at a grid barrier (cooperative groups: ~2 us at 8 workgroups, 7.5 at 64,
+// 25 at 256, tools/micro/grid_sync_bench.hip -- the host picks the grid by the work of a pivot).  Every workgroup runs the same
+// control flow on the same decisions: arg-max / arg-min reductions go through per-workgroup partials in global memory that every
+// workgroup reduces again in the same order; what one thread decides (exact tie breaks, bookkeeping) is decided by thread 0 of
+// workgroup 0 and read by everybody after the barrier.  The decisions, and therefore the pivot sequence, are those of the
+// one-workgroup kernel bit for bit (tests/test_gpu_exact.py: whole golden traces).
 template <int L>
 __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
+    namespace cg = cooperative_groups;
+    cg::grid_group grid = cg::this_grid();
     __shared__ double s_key[EX_THREADS / WAVE];
     __shared__ unsigned long long s_rank[EX_THREADS / WAVE];
-    __shared__ int s_int[8];
     __shared__ int s_overflow;
+    __shared__ u64 s_dinv[L];
+    __shared__ int s_shift;
     const int tid = threadIdx.x, T = blockDim.x;
+    const int G = gridDim.x, block = blockIdx.x;
+    const int gtid = block * T + tid, GT = G * T;
+    const bool leader = block == 0 && tid == 0;
     const int m = lp.m, n = lp.n;
     const int LIMIT_BITS = 64 * L - 3;  // a value whose magnitude bound reaches this many bits might not fit
     u64* gD = lp.D;
-    u64* gDinv = lp.D + L;
     u64* scratch = lp.D + 2 * L;  // tie breakers (one thread): 2 x (2L + 2) limbs
+    int* word = lp.shared_words;  // [0] overflow flag of the grid, [1..] what the leader decides
     int phase = lp.n_art > 0 ? 1 : 2;
     long long pivots[2] = {0, 0};
     int trace_count = 0;
     int status = EX_RUNNING;
+    int parity = 0;  // the partial arrays of the grid reductions alternate, so that a fast workgroup never overwrites what a slow one still reads
     if (tid == 0) s_overflow = 0;
     __syncthreads();
     auto flag_overflow = [&](int bits) {
         if (bits >= LIMIT_BITS) s_overflow = 1;
     };
     auto log2_ceil = [](int count) { return 32 - __clz(count > 1 ? count - 1 : 1) + 1; };
+    // grid barrier that also tells every workgroup whether any of them saw a value that might not fit
+    auto sync_overflow = [&]() {
+        __syncthreads();
+        if (tid == 0 && s_overflow) atomicOr(&word[0], 1);
+        grid.sync();
+        return word[0] != 0;
+    };
+    // arg-max of (key, smallest rank) over the grid: the winner in every thread of every workgroup
+    auto grid_argbest = [&](double& key, unsigned long long& rank) {
+        block_argbest(key, rank, s_key, s_rank);
+        if (tid == 0) {
+            lp.part_key[parity * G + block] = key;
+            lp.part_rank[parity * G + block] = rank;
+        }
+        grid.sync();
+        double bk = 0.0;
+        unsigned long long br = RANK_NONE;
+        for (int b = tid; b < G; b += T) {
+            const double k = lp.part_key[parity * G + b];
+            const unsigned long long r = lp.part_rank[parity * G + b];
+            if (r != RANK_NONE && (br == RANK_NONE || k > bk || (k == bk && r < br))) { bk = k; br = r; }
+        }
+        block_argbest(bk, br, s_key, s_rank);
+        key = bk;
+        rank = br;
+        parity ^= 1;
+    };
+    // a value decided by the leader, for everybody (each call site has its own slot; a slot is rewritten one pivot later at the earliest)
+    auto broadcast = [&](int slot, int value_of_leader) {
+        if (leader) word[slot] = value_of_leader;
+        grid.sync();
+        return word[slot];
+    };
     // drive_row >= 0: the zero-level pivots of phase_one.rs:232-278 are under way, this is the next row to look at
     int drive_row = -1;
     int n_removed = 0;  // redundant rows found there
@@ -401,7 +455,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         const Big<L> D = big_load<L>(gD);
         const int D_bits = big_bits(D);
         // ---- x~_B = N b -------------------------------------------------------------------------------------------------
-        for (int i = tid; i < m; i += T) {
+        for (int i = gtid; i < m; i += GT) {
             Big<L> acc = big_from<L>(0);
             int widest = 0;
             for (int k = 0; k < m; ++k) {
@@ -414,11 +468,10 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             flag_overflow(widest + log2_ceil(m));
             big_store(lp.xt + (size_t)i * L, acc);
         }
-        __syncthreads();
         int q = -1, p = -1;
         if (drive_row < 0) {
             // ---- pricing: c~_j and the key estimate for every non-basic, non-artificial column (pivot_rule.rs:221-241) --------
-            for (int j = lp.n_art + tid; j < n; j += T) {
+            for (int j = lp.n_art + gtid; j < n; j += GT) {
                 double key = 0.0;
                 if (lp.pos[j] < 0) {
                     const i64 cj = phase == 1 ? lp.cost1[j] : lp.cost2[j];
@@ -455,27 +508,26 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 }
                 lp.key[j] = key;
             }
-            __syncthreads();
-            if (s_overflow) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
+            if (sync_overflow()) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
             // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
             double best = 0.0;
             unsigned long long rank = RANK_NONE;
-            for (int j = lp.n_art + tid; j < n; j += T) {
+            for (int j = lp.n_art + gtid; j < n; j += GT) {
                 const double k = lp.key[j];
                 if (k > 0.0) {
                     const unsigned long long r = (unsigned long long)(0x7fffffff - j);
                     if (rank == RANK_NONE || k > best || (k == best && r < rank)) { best = k; rank = r; }
                 }
             }
-            block_argbest(best, rank, s_key, s_rank);
+            grid_argbest(best, rank);
             if (rank != RANK_NONE) {
                 q = 0x7fffffff - (int)rank;
-                if (tid == 0) {
+                int winner = q;
+                if (leader) {
                     // every column whose estimate is within 1e-9 of the best is compared exactly (c~^2 gamma~ cross products)
                     u64* gq = scratch;
                     u64* gj = scratch + 2 * L + 2;
                     bool have_q = false;
-                    int winner = q;
                     for (int j = lp.n_art; j < n; ++j) {
                         if (j == q || !(lp.key[j] >= best * (1.0 - 1e-9))) continue;
                         if (!have_q) {
@@ -489,67 +541,57 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                             for (int k = 0; k < 2 * L + 2; ++k) gq[k] = gj[k];
                         }
                     }
-                    s_int[0] = winner;
                 }
-                __syncthreads();
-                q = s_int[0];
-                __syncthreads();
+                q = broadcast(1, winner);
             }
             if (q < 0) {  // no candidate: the end of this phase
                 if (phase == 2) { status = EX_OPTIMAL; break; }
                 // phase one is over: feasible iff the artificial variables sum to zero (phase_one.rs:160-176)
-                if (tid == 0) {
+                int verdict = 0;  // bit 0: an artificial is positive; bits 1..: the number of basic artificials
+                if (leader) {
                     int positive = 0, basic_artificials = 0;
                     for (int i = 0; i < m; ++i)
                         if (lp.basis[i] < lp.n_art) {
                             ++basic_artificials;
                             if (!big_zero(big_load<L>(lp.xt + (size_t)i * L))) positive = 1;
                         }
-                    s_int[0] = positive;
-                    s_int[1] = basic_artificials;
+                    verdict = positive | (basic_artificials << 1);
                 }
-                __syncthreads();
-                const int positive = s_int[0], basic_artificials = s_int[1];
-                __syncthreads();
-                if (positive) { status = EX_INFEASIBLE; break; }
-                if (basic_artificials > 0) { drive_row = 0; continue; }
+                verdict = broadcast(2, verdict);
+                if (verdict & 1) { status = EX_INFEASIBLE; break; }
+                if ((verdict >> 1) > 0) { drive_row = 0; continue; }
                 phase = 2;
                 continue;
             }
         } else {
             // ---- zero-level pivots: the next row whose basic variable is artificial, the first non-basic column with a
             //      non-zero entry in that row of the tableau (phase_one.rs:232-278) ----------------------------------------
-            if (tid == 0) {
-                int r = drive_row;
-                while (r < m && lp.basis[r] >= lp.n_art) ++r;
-                s_int[0] = r;
-            }
-            __syncthreads();
-            const int r = s_int[0];
-            __syncthreads();
+            int r = drive_row;  // (the basis is the same for everybody: the previous pivot's bookkeeping is behind a barrier)
+            while (r < m && lp.basis[r] >= lp.n_art) ++r;
             if (r >= m) {
                 drive_row = -1;
                 phase = 2;
+                grid.sync();  // (x~_B of this turn is complete before the next turn rewrites it)
                 continue;
             }
             // (N a_j)_r for every candidate column; the first non-zero wins
             unsigned long long first = RANK_NONE;
             double dummy = 0.0;
-            for (int j = lp.n_art + tid; j < n; j += T) {
+            for (int j = lp.n_art + gtid; j < n; j += GT) {
                 if (lp.pos[j] >= 0) continue;
                 Big<L> a = big_from<L>(0);
                 for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
                     a = big_add(a, big_mul_small(big_load<L>(lp.N + ((size_t)r * m + lp.row_index[e]) * L), lp.value[e]));
                 if (!big_zero(a) && (first == RANK_NONE || (unsigned long long)j < first)) { first = (unsigned long long)j; dummy = 1.0; }
             }
-            block_argbest(dummy, first, s_key, s_rank);
+            grid_argbest(dummy, first);
             if (first == RANK_NONE) {
                 // The row of the tableau is zero on every column that could enter: the constraint is redundant and the reference
                 // REMOVES it (phase_one.rs:232-278 collects such rows, `RemoveRows` re-indexes the rest,
                 // filter/generic_wrapper.rs:98-205).  Here the row stays, with its zero-level artificial basic: alpha_r = 0 for
                 // every entering column from now on, so it never takes part in a ratio test and adds nothing to a steepest-edge
                 // weight; only the ROW INDICES reported for phase two are shifted as the removal shifts them.
-                if (tid == 0) lp.removed[r] = 1;
+                if (leader) lp.removed[r] = 1;
                 ++n_removed;
                 drive_row = r + 1;
                 continue;
@@ -559,7 +601,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             drive_row = r + 1;
         }
         // ---- alpha~_q = N a_q (tableau/mod.rs:126-130) -----------------------------------------------------------------------
-        for (int i = tid; i < m; i += T) {
+        for (int i = gtid; i < m; i += GT) {
             Big<L> a = big_from<L>(0);
             int awide = 0;
             for (int e = lp.col_start[q]; e < lp.col_start[q + 1]; ++e) {
@@ -570,13 +612,12 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
             big_store(lp.alpha + (size_t)i * L, a);
         }
-        __syncthreads();
-        if (s_overflow) { status = EX_OVERFLOW; break; }
+        if (sync_overflow()) { status = EX_OVERFLOW; break; }
         if (p < 0) {
             // ---- ratio test: min x~_i / alpha~_i over alpha~_i > 0, ties to the lowest basic column (tableau/mod.rs:287-313) --
             double best = 0.0;
             unsigned long long rank = RANK_NONE;
-            for (int i = tid; i < m; i += T) {
+            for (int i = gtid; i < m; i += GT) {
                 const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
                 if (big_neg(a) || big_zero(a)) continue;
                 const double ratio = big_ratio(big_load<L>(lp.xt + (size_t)i * L), a);
@@ -584,11 +625,11 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 const double k = -ratio;  // block_argbest maximises
                 if (rank == RANK_NONE || k > best || (k == best && r < rank)) { best = k; rank = r; }
             }
-            block_argbest(best, rank, s_key, s_rank);
+            grid_argbest(best, rank);
             if (rank == RANK_NONE) { status = EX_UNBOUNDED; break; }
             p = (int)(rank & 0xffffffffu);
-            if (tid == 0) {
-                int winner = p;
+            int winner = p;
+            if (leader) {
                 const double ratio_p = -best;
                 for (int i = 0; i < m; ++i) {
                     if (i == p) continue;
@@ -601,25 +642,24 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                                                         big_load<L>(lp.xt + (size_t)winner * L), a);
                     if (c < 0 || (c == 0 && lp.basis[i] < lp.basis[winner])) winner = i;
                 }
-                s_int[0] = winner;
             }
-            __syncthreads();
-            p = s_int[0];
-            __syncthreads();
+            p = broadcast(3, winner);
         }
         // ---- the pivot: D' = alpha~_p, N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays ---------------------------
         Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
         const bool flip = big_neg(ap);  // (only a zero-level pivot can have a negative pivot element): keep D > 0
-        if (tid == 0) {
+        if (tid == 0) {  // (every workgroup for itself: the inverse of the odd part of D is cheap and needs no exchange this way)
             const int shift = big_ctz(D);
-            big_store(gDinv, big_inverse_odd(big_sar(D, shift)));
-            s_int[2] = shift;
+            const Big<L> inverse = big_inverse_odd(big_sar(D, shift));
+            for (int k = 0; k < L; ++k) s_dinv[k] = inverse.w[k];
+            s_shift = shift;
         }
         __syncthreads();
-        const int shift = s_int[2];
-        const Big<L> Dinv = big_load<L>(gDinv);
+        const int shift = s_shift;
+        Big<L> Dinv;
+        for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
         const int ap_bits = big_bits(ap);
-        for (int idx = tid; idx < m * m; idx += T) {
+        for (int idx = gtid; idx < m * m; idx += GT) {
             const int i = idx / m, k = idx - i * m;
             if (i == p) continue;
             const Big<L> ai = big_load<L>(lp.alpha + (size_t)i * L);
@@ -635,13 +675,12 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             if (flip) quotient = big_negate(quotient);
             big_store(lp.N + (size_t)idx * L, quotient);
         }
+        const bool overflow = sync_overflow();  // (also: row p is an operand of every other row above -- nobody may still be reading it)
         if (flip) {
-            __syncthreads();  // row p is an operand of every other row above: nobody may still be reading it
-            for (int k = tid; k < m; k += T) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
+            for (int k = gtid; k < m; k += GT) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
             ap = big_negate(ap);
         }
-        __syncthreads();
-        if (tid == 0) {
+        if (leader) {
             const int leaving = lp.basis[p];
             big_store(gD, ap);
             lp.basis[p] = q;
@@ -659,23 +698,20 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         }
         ++trace_count;
         pivots[phase - 1]++;
-        __syncthreads();
-        if (s_overflow) { status = EX_OVERFLOW; break; }
+        grid.sync();  // the new basis, D and (flip) row p for everybody
+        if (overflow) { status = EX_OVERFLOW; break; }
     }
-    __syncthreads();
-    if (s_overflow && status != EX_OVERFLOW) status = EX_OVERFLOW;
+    grid.sync();
     // the final x~_B belongs to the final basis: recompute it (the loop computes it at the top of an iteration)
-    {
-        for (int i = tid; i < m; i += T) {
-            Big<L> acc = big_from<L>(0);
-            for (int k = 0; k < m; ++k) {
-                const i64 b = lp.rhs[k];
-                if (b != 0) acc = big_add(acc, big_mul_small(big_load<L>(lp.N + ((size_t)i * m + k) * L), b));
-            }
-            big_store(lp.xt + (size_t)i * L, acc);
+    for (int i = gtid; i < m; i += GT) {
+        Big<L> acc = big_from<L>(0);
+        for (int k = 0; k < m; ++k) {
+            const i64 b = lp.rhs[k];
+            if (b != 0) acc = big_add(acc, big_mul_small(big_load<L>(lp.N + ((size_t)i * m + k) * L), b));
         }
+        big_store(lp.xt + (size_t)i * L, acc);
     }
-    if (tid == 0) {
+    if (leader) {
         lp.out[0] = status;
         lp.out[1] = (int)pivots[0];
         lp.out[2] = (int)pivots[1];
@@ -815,6 +851,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_trace = dalloc<int>((size_t)4 * trace_capacity, owned);
     int* d_out = dalloc<int>(8, owned);
     int* d_removed = dalloc<int>(m, owned);
+    int* d_words = dalloc<int>(8, owned);
+    double* d_part_key = dalloc<double>(2 * 256, owned);
+    unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * 256, owned);
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
@@ -856,17 +895,31 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemcpyAsync(d_basis, basis0.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemsetAsync(d_removed, 0, m * sizeof(int), stream));
+        RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_removed};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_removed, d_words, d_part_key, d_part_rank};
+        // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
+        // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
+        int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
+        if (const char* forced = getenv("RELP_EXACT_GRID")) grid = std::max(1, std::min(256, atoi(forced)));
+        void* kernel = nullptr;
         switch (limbs) {
-            case 1: hipLaunchKernelGGL(exact_simplex_kernel<1>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
-            case 2: hipLaunchKernelGGL(exact_simplex_kernel<2>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
-            case 4: hipLaunchKernelGGL(exact_simplex_kernel<4>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
-            case 8: hipLaunchKernelGGL(exact_simplex_kernel<8>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
-            case 16: hipLaunchKernelGGL(exact_simplex_kernel<16>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
-            case 32: hipLaunchKernelGGL(exact_simplex_kernel<32>, dim3(1), dim3(EX_THREADS), 0, stream, lp); break;
+            case 1: kernel = (void*)exact_simplex_kernel<1>; break;
+            case 2: kernel = (void*)exact_simplex_kernel<2>; break;
+            case 4: kernel = (void*)exact_simplex_kernel<4>; break;
+            case 8: kernel = (void*)exact_simplex_kernel<8>; break;
+            case 16: kernel = (void*)exact_simplex_kernel<16>; break;
+            case 32: kernel = (void*)exact_simplex_kernel<32>; break;
             default: throw std::invalid_argument("limbs must be a power of two between 1 and 32");
         }
+        {
+            int per_cu = 0, cus = 0;
+            RELP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, EX_THREADS, 0));
+            RELP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            grid = std::max(1, std::min(grid, per_cu * cus));  // (a cooperative launch needs every workgroup resident)
+        }
+        void* args[] = {(void*)&lp};
+        RELP_HIP(hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(EX_THREADS), args, 0, stream));
         RELP_HIP(hipGetLastError());
         int out[8];
         RELP_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream));
