@@ -301,6 +301,16 @@ struct ExactLP {
     int* shared_words;    // [8] grid-wide overflow flag, decisions of workgroup 0's thread 0
     double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
     unsigned long long* part_rank;
+    unsigned long long* prof;  // [16] diagnostic (RELP_EXACT_PROFILE): the leader's cycle sums per phase of the loop, candidate counts
+    u64* price_a;         // [n - n_art][m] Big: (N a_j)_i of the pricing pass
+    int* price_bits;      // ... its bit bound
+    double* price_term;   // ... its share of the steepest-edge estimate
+    int* bracket;         // [max(n, m) + 1] the tournament brackets over the candidates
+    int* cand;            // [max(n, m) + 1] columns whose key estimate is within 1e-9 of the best (pricing); near-tied rows (ratio test)
+    u64* gamma;           // [n][2 limbs + 2] their exact weights
+    u64* gamma_terms;     // [candidates][m + 1][2 limbs + 2] the terms of those sums (capacity: see the host)
+    u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b
+    int* x_bits;          // ... their bit bounds
 };
 
 // Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
@@ -338,6 +348,30 @@ __device__ void exact_weight(const ExactLP& lp, const Big<L>& D, int j, u64* gam
             a = big_add(a, big_mul_small(big_load<L>(lp.N + ((size_t)i * lp.m + lp.row_index[e]) * L), lp.value[e]));
         add_square(a, (u64)lp.weight[lp.basis[i]]);
     }
+}
+// out = w * v^2, unsigned, 2 L + 2 limbs (one term of the exact weight above)
+template <int L>
+__device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
+    const Big<L> mag = big_neg(v) ? big_negate(v) : v;
+    u64 sq[2 * L];
+    for (int k = 0; k < 2 * L; ++k) sq[k] = 0;
+    for (int i = 0; i < L; ++i) {
+        u64 carry = 0;
+        for (int t = 0; t < L; ++t) {
+            const u128 prod = (u128)mag.w[i] * mag.w[t] + sq[i + t] + carry;
+            sq[i + t] = (u64)prod;
+            carry = (u64)(prod >> 64);
+        }
+        sq[i + L] += carry;
+    }
+    u64 carry = 0;
+    for (int k = 0; k < 2 * L; ++k) {
+        const u128 s = (u128)sq[k] * w + carry;
+        out[k] = (u64)s;
+        carry = (u64)(s >> 64);
+    }
+    out[2 * L] = carry;
+    out[2 * L + 1] = 0;
 }
 // c_a^2 * gamma_b  vs  c_b^2 * gamma_a  (unsigned, (4 L + 1) limbs): +1 when column a has the larger key
 template <int L>
@@ -401,12 +435,19 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
     const int m = lp.m, n = lp.n;
     const int LIMIT_BITS = 64 * L - 3;  // a value whose magnitude bound reaches this many bits might not fit
     u64* gD = lp.D;
-    u64* scratch = lp.D + 2 * L;  // tie breakers (one thread): 2 x (2L + 2) limbs
     int* word = lp.shared_words;  // [0] overflow flag of the grid, [1..] what the leader decides
     int phase = lp.n_art > 0 ? 1 : 2;
     long long pivots[2] = {0, 0};
     int trace_count = 0;
     int status = EX_RUNNING;
+    unsigned long long t_last = clock64();
+    auto stamp = [&](int k) {
+        if (leader && lp.prof) {
+            const unsigned long long t = clock64();
+            lp.prof[k] += t - t_last;
+            t_last = t;
+        }
+    };
     int parity = 0;  // the partial arrays of the grid reductions alternate, so that a fast workgroup never overwrites what a slow one still reads
     if (tid == 0) s_overflow = 0;
     __syncthreads();
@@ -454,23 +495,64 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         if (pivots[0] + pivots[1] >= lp.max_pivots) { status = EX_PIVOT_LIMIT; break; }
         const Big<L> D = big_load<L>(gD);
         const int D_bits = big_bits(D);
-        // ---- x~_B = N b -------------------------------------------------------------------------------------------------
-        for (int i = gtid; i < m; i += GT) {
-            Big<L> acc = big_from<L>(0);
-            int widest = 0;
-            for (int k = 0; k < m; ++k) {
-                const i64 b = lp.rhs[k];
-                if (b == 0) continue;
-                const Big<L> nik = big_load<L>(lp.N + ((size_t)i * m + k) * L);
-                acc = big_add(acc, big_mul_small(nik, b));
-                widest = max(widest, big_bits(nik) + small_bits(b));
+        // ---- x~_B = N b: a thread per (row, chunk of 32 columns), then a thread per row over its chunks (same bounds as the serial loop) ----
+        {
+            constexpr int XC = 32;
+            const int chunks = (m + XC - 1) / XC;
+            for (long long pair = gtid; pair < (long long)m * chunks; pair += GT) {
+                const int i = (int)(pair / chunks), c = (int)(pair - (long long)i * chunks);
+                Big<L> acc = big_from<L>(0);
+                int widest = 0;
+                for (int k = c * XC; k < min(m, (c + 1) * XC); ++k) {
+                    const i64 b = lp.rhs[k];
+                    if (b == 0) continue;
+                    const Big<L> nik = big_load<L>(lp.N + ((size_t)i * m + k) * L);
+                    acc = big_add(acc, big_mul_small(nik, b));
+                    widest = max(widest, big_bits(nik) + small_bits(b));
+                }
+                big_store(lp.x_part + (size_t)pair * L, acc);
+                lp.x_bits[pair] = widest;
             }
-            flag_overflow(widest + log2_ceil(m));
-            big_store(lp.xt + (size_t)i * L, acc);
+            grid.sync();
+            for (int i = gtid; i < m; i += GT) {
+                Big<L> acc = big_from<L>(0);
+                int widest = 0;
+                for (int c = 0; c < chunks; ++c) {
+                    acc = big_add(acc, big_load<L>(lp.x_part + ((size_t)i * chunks + c) * L));
+                    widest = max(widest, lp.x_bits[(size_t)i * chunks + c]);
+                }
+                flag_overflow(widest + log2_ceil(m));
+                big_store(lp.xt + (size_t)i * L, acc);
+            }
         }
         int q = -1, p = -1;
+        stamp(0);
         if (drive_row < 0) {
             // ---- pricing: c~_j and the key estimate for every non-basic, non-artificial column (pivot_rule.rs:221-241) --------
+            // Pass A, a thread per (column j, row i): a_ij = (N a_j)_i exactly, its share of the weight estimate as a double, its bit
+            // bound.  (One thread per column walking all m rows -- the one-workgroup form -- was 80 % of the run on the grid: 126 ms
+            // per pass on E226, a few hundred busy threads.)  Pass B, a thread per column: c~_j and the weight from the stored terms,
+            // in the order and with the bounds of the serial loop -- the estimates are the same bits as before.
+            const int n_priced = n - lp.n_art;
+            for (long long pair = gtid; pair < (long long)n_priced * m; pair += GT) {
+                const int jj = (int)(pair / m), i = (int)(pair - (long long)jj * m);
+                const int j = lp.n_art + jj;
+                if (lp.pos[j] >= 0) continue;
+                Big<L> a = big_from<L>(0);
+                int awide = 0;
+                for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e) {
+                    const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
+                    a = big_add(a, big_mul_small(nir, lp.value[e]));
+                    awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
+                }
+                awide += log2_ceil(lp.col_start[j + 1] - lp.col_start[j]);
+                flag_overflow(awide);
+                big_store(lp.price_a + (size_t)pair * L, a);
+                lp.price_bits[pair] = awide;
+                const double ad = big_ratio(a, D);
+                lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
+            }
+            grid.sync();
             for (int j = lp.n_art + gtid; j < n; j += GT) {
                 double key = 0.0;
                 if (lp.pos[j] < 0) {
@@ -479,25 +561,15 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                     // (everything relative to D: the quotients are the reference's rationals, of moderate size, whatever the limbs hold)
                     double sumsq = (double)lp.weight[j];
                     int widest = D_bits + small_bits(cj);
-                    const int entries = lp.col_start[j + 1] - lp.col_start[j];
+                    const size_t base = (size_t)(j - lp.n_art) * m;
                     for (int i = 0; i < m; ++i) {
-                        Big<L> a = big_from<L>(0);
-                        int awide = 0;
-                        for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e) {
-                            const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
-                            a = big_add(a, big_mul_small(nir, lp.value[e]));
-                            awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
-                        }
-                        awide += log2_ceil(entries);
-                        flag_overflow(awide);
                         const int bi = lp.basis[i];
                         const i64 cb = phase == 1 ? lp.cost1[bi] : lp.cost2[bi];
                         if (cb != 0) {
-                            ct = big_sub(ct, big_mul_small(a, cb));
-                            widest = max(widest, awide + small_bits(cb));
+                            ct = big_sub(ct, big_mul_small(big_load<L>(lp.price_a + (base + i) * L), cb));
+                            widest = max(widest, lp.price_bits[base + i] + small_bits(cb));
                         }
-                        const double ad = big_ratio(a, D);
-                        sumsq += ad * ad * (double)lp.weight[bi];
+                        sumsq += lp.price_term[base + i];
                     }
                     flag_overflow(widest + log2_ceil(m + 1));
                     big_store(lp.ctil + (size_t)j * L, ct);
@@ -509,6 +581,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 lp.key[j] = key;
             }
             if (sync_overflow()) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
+            stamp(1);
             // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
             double best = 0.0;
             unsigned long long rank = RANK_NONE;
@@ -522,27 +595,62 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             grid_argbest(best, rank);
             if (rank != RANK_NONE) {
                 q = 0x7fffffff - (int)rank;
+                // Every column whose estimate is within 1e-9 of the best is compared exactly (c~^2 gamma~ cross products).  The exact
+                // weight of a candidate is m squarings of L-limb integers -- a millisecond for one thread at 32 limbs, and degenerate
+                // LPs have a hundred candidates per pivot (round 2 did them one after the other: most of E226's 100 s) -- so every
+                // candidate gets a thread of its own, anywhere on the grid; the tournament over the finished weights is the leader's.
+                for (int j = lp.n_art + gtid; j < n; j += GT)
+                    if (lp.key[j] >= best * (1.0 - 1e-9)) lp.cand[atomicAdd(&word[4], 1)] = j;
+                grid.sync();
+                stamp(2);
+                const int n_cand = word[4];
+                if (leader && lp.prof) lp.prof[12] += n_cand;
                 int winner = q;
-                if (leader) {
-                    // every column whose estimate is within 1e-9 of the best is compared exactly (c~^2 gamma~ cross products)
-                    u64* gq = scratch;
-                    u64* gj = scratch + 2 * L + 2;
-                    bool have_q = false;
-                    for (int j = lp.n_art; j < n; ++j) {
-                        if (j == q || !(lp.key[j] >= best * (1.0 - 1e-9))) continue;
-                        if (!have_q) {
-                            exact_weight<L>(lp, D, winner, gq);
-                            have_q = true;
-                        }
-                        exact_weight<L>(lp, D, j, gj);
-                        const int c = compare_keys<L>(big_load<L>(lp.ctil + (size_t)j * L), gj, big_load<L>(lp.ctil + (size_t)winner * L), gq);
-                        if (c > 0 || (c == 0 && j > winner)) {
-                            winner = j;
-                            for (int k = 0; k < 2 * L + 2; ++k) gq[k] = gj[k];
+                if (n_cand > 1) {
+                    // gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 exactly ((2 L + 2)-limb sums of squares).  The (N a_j)_i are the ones
+                    // the pricing pass stored; a thread per (candidate, row) squares one of them, a thread per candidate adds them up.
+                    constexpr int GW = 2 * L + 2;
+                    for (long long pair = gtid; pair < (long long)n_cand * (m + 1); pair += GT) {
+                        const int c = (int)(pair / (m + 1)), i = (int)(pair - (long long)c * (m + 1));
+                        const int j = lp.cand[c];
+                        u64* out = lp.gamma_terms + ((size_t)c * (m + 1) + i) * GW;
+                        if (i == m) weighted_square<L>(D, (u64)lp.weight[j], out);
+                        else weighted_square<L>(big_load<L>(lp.price_a + ((size_t)(j - lp.n_art) * m + i) * L), (u64)lp.weight[lp.basis[i]], out);
+                    }
+                    grid.sync();
+                    for (int c = gtid; c < n_cand; c += GT) {
+                        u64* g = lp.gamma + (size_t)c * GW;
+                        for (int k = 0; k < GW; ++k) g[k] = 0;
+                        for (int i = 0; i <= m; ++i) {
+                            const u64* term = lp.gamma_terms + ((size_t)c * (m + 1) + i) * GW;
+                            u64 carry = 0;
+                            for (int k = 0; k < GW; ++k) {
+                                const u128 sum = (u128)g[k] + term[k] + carry;
+                                g[k] = (u64)sum;
+                                carry = (u64)(sum >> 64);
+                            }
                         }
                     }
+                    grid.sync();
+                    stamp(3);
+                    // the tournament as a tree over the grid: the order "larger exact key, then larger column" is total, so any bracket
+                    // gives the winner of the serial scan (which was 0.1 ms per comparison at 32 limbs, hundreds of candidates on SCORPION)
+                    for (int c = gtid; c < n_cand; c += GT) lp.bracket[c] = c;
+                    grid.sync();
+                    for (int stride = 1; stride < n_cand; stride *= 2) {
+                        for (long long c = (long long)gtid * 2 * stride; c + stride < n_cand; c += (long long)GT * 2 * stride) {
+                            const int ca = lp.bracket[c], cb2 = lp.bracket[c + stride];
+                            const int ja = lp.cand[ca], jb = lp.cand[cb2];
+                            const int cmp = compare_keys<L>(big_load<L>(lp.ctil + (size_t)jb * L), lp.gamma + (size_t)cb2 * (2 * L + 2),
+                                                            big_load<L>(lp.ctil + (size_t)ja * L), lp.gamma + (size_t)ca * (2 * L + 2));
+                            if (cmp > 0 || (cmp == 0 && jb > ja)) lp.bracket[c] = cb2;
+                        }
+                        grid.sync();
+                    }
+                    winner = lp.cand[lp.bracket[0]];
                 }
                 q = broadcast(1, winner);
+                stamp(4);
             }
             if (q < 0) {  // no candidate: the end of this phase
                 if (phase == 2) { status = EX_OPTIMAL; break; }
@@ -613,6 +721,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             big_store(lp.alpha + (size_t)i * L, a);
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
+        stamp(5);
         if (p < 0) {
             // ---- ratio test: min x~_i / alpha~_i over alpha~_i > 0, ties to the lowest basic column (tableau/mod.rs:287-313) --
             double best = 0.0;
@@ -628,23 +737,43 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             grid_argbest(best, rank);
             if (rank == RANK_NONE) { status = EX_UNBOUNDED; break; }
             p = (int)(rank & 0xffffffffu);
-            int winner = p;
-            if (leader) {
+            // the rows whose ratio estimate is within 1e-9 of the smallest: found by everybody, compared exactly by the leader
+            {
                 const double ratio_p = -best;
-                for (int i = 0; i < m; ++i) {
+                for (int i = gtid; i < m; i += GT) {
                     if (i == p) continue;
                     const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
                     if (big_neg(a) || big_zero(a)) continue;
                     const double ratio = big_ratio(big_load<L>(lp.xt + (size_t)i * L), a);
                     if (!(ratio <= ratio_p + 1e-9 * fabs(ratio_p) + 1e-300)) continue;
-                    // x_i / a_i  vs  x_w / a_w   <=>   x_i a_w  vs  x_w a_i   (both a > 0)
-                    const int c = sign_of_difference<L>(big_load<L>(lp.xt + (size_t)i * L), big_load<L>(lp.alpha + (size_t)winner * L),
-                                                        big_load<L>(lp.xt + (size_t)winner * L), a);
-                    if (c < 0 || (c == 0 && lp.basis[i] < lp.basis[winner])) winner = i;
+                    lp.cand[atomicAdd(&word[5], 1)] = i;
                 }
+            }
+            grid.sync();
+            // the exact minimum ratio among the near-tied rows (and p itself), ties to the lowest basic column: a total order again,
+            // decided by a bracket over the grid
+            const int n_near = word[5];
+            int winner = p;
+            if (n_near > 0) {
+                if (leader) lp.cand[n_near] = p;
+                for (int c = gtid; c <= n_near; c += GT) lp.bracket[c] = c;
+                grid.sync();
+                for (int stride = 1; stride <= n_near; stride *= 2) {
+                    for (long long c = (long long)gtid * 2 * stride; c + stride <= n_near; c += (long long)GT * 2 * stride) {
+                        const int ia = lp.cand[lp.bracket[c]], ib = lp.cand[lp.bracket[c + stride]];
+                        // x_b / a_b  vs  x_a / a_a   <=>   x_b a_a  vs  x_a a_b   (both alpha > 0)
+                        const int cmp = sign_of_difference<L>(big_load<L>(lp.xt + (size_t)ib * L), big_load<L>(lp.alpha + (size_t)ia * L),
+                                                              big_load<L>(lp.xt + (size_t)ia * L), big_load<L>(lp.alpha + (size_t)ib * L));
+                        if (cmp < 0 || (cmp == 0 && lp.basis[ib] < lp.basis[ia])) lp.bracket[c] = lp.bracket[c + stride];
+                    }
+                    grid.sync();
+                }
+                winner = lp.cand[lp.bracket[0]];
+                if (leader) word[5] = 0;
             }
             p = broadcast(3, winner);
         }
+        stamp(6);
         // ---- the pivot: D' = alpha~_p, N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays ---------------------------
         Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
         const bool flip = big_neg(ap);  // (only a zero-level pivot can have a negative pivot element): keep D > 0
@@ -675,12 +804,14 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             if (flip) quotient = big_negate(quotient);
             big_store(lp.N + (size_t)idx * L, quotient);
         }
+        stamp(7);
         const bool overflow = sync_overflow();  // (also: row p is an operand of every other row above -- nobody may still be reading it)
         if (flip) {
             for (int k = gtid; k < m; k += GT) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
             ap = big_negate(ap);
         }
         if (leader) {
+            word[4] = 0;  // (the candidate counter of the next pricing pass)
             const int leaving = lp.basis[p];
             big_store(gD, ap);
             lp.basis[p] = q;
@@ -699,6 +830,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         ++trace_count;
         pivots[phase - 1]++;
         grid.sync();  // the new basis, D and (flip) row p for everybody
+        stamp(8);
         if (overflow) { status = EX_OVERFLOW; break; }
     }
     grid.sync();
@@ -854,6 +986,14 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_words = dalloc<int>(8, owned);
     double* d_part_key = dalloc<double>(2 * 256, owned);
     unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * 256, owned);
+    unsigned long long* d_prof = getenv("RELP_EXACT_PROFILE") ? dalloc<unsigned long long>(16, owned) : nullptr;
+    const size_t pairs = (size_t)std::max(1, n - n_art) * m;
+    u64* d_price_a = nullptr;   // (sized per limb count below)
+    int* d_price_bits = dalloc<int>(pairs, owned);
+    double* d_price_term = dalloc<double>(pairs, owned);
+    int* d_bracket = dalloc<int>(std::max(n, m) + 1, owned);
+    int* d_cand = dalloc<int>(std::max(n, m) + 1, owned);
+    u64* d_gamma = dalloc<u64>((size_t)n * (2 * 32 + 2), owned);
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
@@ -872,6 +1012,10 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_xt = dalloc<u64>((size_t)m * big, owned);
         u64* d_alpha = dalloc<u64>((size_t)m * big, owned);
         u64* d_ctil = dalloc<u64>((size_t)n * big, owned);
+        d_price_a = dalloc<u64>(pairs * big, owned);
+        u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), owned);
+        u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, owned);
+        int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), owned);
         // N_0 and D_0 as two's complement words (positive values)
         auto words = [&](const BigInt& v, u64* out) {
             for (int k = 0; k < limbs; ++k) {
@@ -896,8 +1040,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemsetAsync(d_removed, 0, m * sizeof(int), stream));
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
+        if (d_prof) RELP_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_removed, d_words, d_part_key, d_part_rank};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
@@ -924,6 +1069,14 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         int out[8];
         RELP_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipStreamSynchronize(stream));
+        if (d_prof) {
+            unsigned long long prof[16];
+            RELP_HIP(hipMemcpy(prof, d_prof, sizeof(prof), hipMemcpyDeviceToHost));
+            static const char* names[] = {"x_B", "pricing", "arg-max + candidates", "exact weights", "tournament", "alpha", "ratio test", "update", "bookkeeping"};
+            fprintf(stderr, "[exact] %d limbs, grid %d, %d pivots, candidates %llu:", limbs, grid, out[1] + out[2], prof[12]);
+            for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 2.4e6);
+            fprintf(stderr, "\n");
+        }
         *status = out[0];
         *limbs_used = limbs;
         *pivots_phase_one = out[1];
