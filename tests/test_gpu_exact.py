@@ -38,7 +38,9 @@ def device_indices(pivots, n_art):
 
 
 # the four LPs the round-1 verdict names, plus more small ones; (name, largest limb count allowed)
-WHOLE_TRACE = ["AFIRO", "SC50A", "SC50B", "SC105", "SCAGR7", "ADLITTLE", "SHARE2B", "KB2", "burkardt_afiro", "burkardt_testprob"]
+WHOLE_TRACE = ["AFIRO", "SC50A", "SC50B", "SC105", "SCAGR7", "ADLITTLE", "SHARE2B", "KB2", "burkardt_afiro", "burkardt_testprob",
+               # round 3 (the loop on the whole grid): the 16- and 32-limb LPs finish in seconds, so they are part of every run
+               "BLEND", "ISRAEL", "STOCFOR1", "SHARE1B", "E226"]
 
 
 @pytest.mark.parametrize("name", WHOLE_TRACE)
@@ -152,14 +154,15 @@ def test_random_lps_pivot_for_pivot(seed):
     solver.close()
 
 
-@pytest.mark.parametrize("name, limbs", [("unicamp_model_data_6", 8)])  # (SCORPION, 30 redundant rows of 388: the same at 32 limbs, 6 minutes -- tools/exact_probe.py)
+# (round 2 ran SCORPION in 6 minutes and could not finish BRANDY / BORE3D; with the loop on the whole grid they take 8, 6 and 4 s)
+@pytest.mark.parametrize("name, limbs", [("unicamp_model_data_6", 8), ("BORE3D", 32), ("BRANDY", 32), ("SCORPION", 32)])
 def test_rank_deficient_lps_follow_the_reference_through_row_removal(name, limbs):
     """LPs whose phase one ends with redundant rows (3 of 13, 30 of 388): the reference removes them and re-indexes the rows of
     phase two (phase_one.rs:232-278, filter/generic_wrapper.rs:98-205); the device keeps them with their zero-level artificial
     and reports the reference's indices.  Whole golden trace head, pivot counts, basis of the remaining rows, exact optimum."""
     golden = GOLDEN[name]
     solver = relp_amd.Solver().load_mps(os.path.join(ROOT, golden["file"]))
-    got = solver.solve_exact(first_limbs=1, max_limbs=limbs)
+    got = solver.solve_exact(first_limbs=1 if limbs <= 8 else limbs, max_limbs=limbs)
     assert got["status"] == 1, got
     assert got["redundant_rows"] == golden["m"] - len(golden["basis"]) > 0
     assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"])
@@ -174,3 +177,18 @@ def test_rank_deficient_lps_follow_the_reference_through_row_removal(name, limbs
         solve_relaxation(data, trace=trace)
         assert got["trace"] == device_indices(trace.pivots, solver.n_art)
     solver.close()
+
+
+def test_the_grid_size_does_not_change_the_pivot_sequence(monkeypatch):
+    """One workgroup, a few, one per CU: the same decisions (partial reductions and tournaments are order-independent)."""
+    golden = GOLDEN["BLEND"]
+    path = os.path.join(ROOT, golden["file"])
+    runs = []
+    for grid in ("1", "7", "256"):
+        monkeypatch.setenv("RELP_EXACT_GRID", grid)
+        solver = relp_amd.Solver().load_mps(path)
+        got = solver.solve_exact(first_limbs=16, max_limbs=16)
+        assert got["status"] == 1 and got["objective"] == golden["objective"]
+        runs.append(got["trace"])
+        solver.close()
+    assert runs[0] == runs[1] == runs[2]
