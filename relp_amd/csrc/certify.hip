@@ -26,6 +26,7 @@
 #include <thread>
 
 #include "bigint.hpp"
+#include "rational_reconstruct.hpp"
 #include "lu_host.hpp"
 #include "solver.hpp"
 
@@ -302,6 +303,7 @@ __global__ void __launch_bounds__(256) dixon_residual_kernel(int m, const int* r
 // diagnostic timeline (RELP_TIME_CERTIFY=1): where the certificate's wall time goes
 struct CertifyTimes {
     double device_digits = 0.0, host_assemble = 0.0, inverse = 0.0, setup = 0.0, checks = 0.0, reconstruct = 0.0, parallel = 0.0;
+    double unpack = 0.0, horner = 0.0, combine = 0.0, numerators = 0.0, verify = 0.0, normalise = 0.0;  // parts of host_assemble
     int digit_launches = 0, solves = 0, reconstructs = 0;
 };
 CertifyTimes g_times;
@@ -314,9 +316,10 @@ double wall_now() {
 // exact substitution check): m independent entries each.  A small persistent pool; the calling thread works too.
 class WorkerPool {
 public:
-    static WorkerPool& get() {
-        static WorkerPool pool;
-        return pool;
+    // Two pools: the primal and the dual lifting of a certificate assemble their digits at the same time (transpose = which).
+    static WorkerPool& get(int which = 0) {
+        static WorkerPool pools[2];
+        return pools[which & 1];
     }
     template <class F>
     void run(int n, F&& fn) {
@@ -347,7 +350,7 @@ private:
     WorkerPool() {
         unsigned count = std::thread::hardware_concurrency();
         if (const char* e = getenv("RELP_CERTIFY_THREADS")) count = (unsigned)atoi(e);
-        count = std::min(count, 32u);
+        count = std::min(count, 32u) / 2;  // (per pool)
         for (unsigned t = 1; t < count; ++t) threads_.emplace_back([this] { loop(); });
     }
     ~WorkerPool() {
@@ -394,17 +397,30 @@ private:
     bool stop_ = false;
 };
 
-struct DeviceBuffers {
+struct DeviceBuffers {  // device memory of one certificate, drawn from and returned to the handle's scratch (no hipMalloc / hipFree per call)
+    CertifyScratch* scratch = nullptr;
+    std::mutex* guard = nullptr;  // (the dual lifting allocates from a second host thread)
     std::vector<void*> ptrs;
     template <class T>
     T* alloc(size_t count) {
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
         void* p = nullptr;
-        RELP_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+        if (scratch) {
+            std::lock_guard<std::mutex> lock(*guard);
+            p = scratch->take(bytes);
+        } else {
+            RELP_HIP(hipMalloc(&p, bytes));
+        }
         ptrs.push_back(p);
         return reinterpret_cast<T*>(p);
     }
     ~DeviceBuffers() {
-        for (void* p : ptrs) (void)hipFree(p);
+        if (scratch) {
+            std::lock_guard<std::mutex> lock(*guard);
+            for (void* p : ptrs) scratch->give_back(p);
+        } else {
+            for (void* p : ptrs) (void)hipFree(p);
+        }
     }
 };
 
@@ -416,37 +432,6 @@ BigInt big_from_i128(i128 v) { return BigInt::from_i128(v); }
 i128 lcm128(i128 a, i128 b) {
     i128 g = gcd128(a, b);
     return mul_checked(a / g, b);
-}
-
-// |v| <= sqrt(M / 2), decided by bit lengths: v < 2^k with 2k <= bits(M) - 2 gives v^2 < 2^(bits(M) - 2) <= M / 2.  (Sufficient,
-// not necessary: at most two bits stricter than Wang's bound, and free -- the exact test is a big multiplication per call.)
-bool within_wang_bound(const BigInt& v, const BigInt& M) { return 2 * v.bits() + 2 <= M.bits(); }
-
-// Rational reconstruction of a (mod M): n/d with |n|, d <= sqrt(M/2) (Wang's bound); returns false if none.
-bool rational_reconstruct(const BigInt& a, const BigInt& M, BigInt& n, BigInt& d) {
-    BigInt r0 = M, r1 = a % M;
-    if (r1.sign() < 0) r1 = r1 + M;
-    BigInt t0(0), t1(1);
-    auto too_big = [&](const BigInt& r) { return !within_wang_bound(r, M); };
-    while (too_big(r1)) {
-        BigInt q, rem;
-        BigInt::divmod(r0, r1, q, rem);
-        BigInt t2 = t0 - q * t1;
-        r0 = r1;
-        r1 = rem;
-        t0 = t1;
-        t1 = t2;
-    }
-    if (t1.is_zero() || too_big(t1.abs())) return false;
-    n = t1.sign() < 0 ? -r1 : r1;
-    d = t1.abs();
-    BigInt g = BigInt::gcd(n, d);
-    if (!(g == BigInt(1))) {
-        if (g.is_zero()) return false;
-        n = n / g;
-        d = d / g;
-    }
-    return true;
 }
 
 // bits [lo, lo + count) of |v|, count <= 60
@@ -530,7 +515,14 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
         steps_done = target;
 
         // ---- assemble, reconstruct with a common denominator, verify ---------------------------------
-        WorkerPool& pool = WorkerPool::get();
+        WorkerPool& pool = WorkerPool::get(transpose);
+        double t_part = t_host;
+        auto part = [&](double& sum) {
+            const double now = wall_now();
+            sum += now - t_part;
+            t_part = now;
+        };
+        part(times.unpack);
         BigInt modulus(1);
         for (int s = 0; s < steps_done; ++s) modulus.mul_add_small(p, 0);
         std::vector<BigInt> residue(m);
@@ -540,6 +532,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             acc.trim();
             residue[i] = acc;
         });
+        part(times.horner);
         bool ok = true;
         BigInt denom(1);
         std::vector<BigInt> numer(m);
@@ -552,50 +545,89 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             // A random integer combination of the entries has, almost surely, the common denominator of all of them: ONE
             // rational reconstruction instead of one per entry that brings a new factor (46 of them on 25FV47).  Whatever it
             // misses is found by the loop below; every result is verified exactly anyway.
-            BigInt combo(0);
+            // (Formed on the digits: column sums of weight x digit stay below 2^57, one carry sweep in base p, one Horner pass --
+            // no big-integer arithmetic per entry.)
+            std::vector<unsigned long long> column(steps_done, 0);
+            std::vector<uint32_t> weight(m);
             unsigned long long state = 0x9E3779B97F4A7C15ull;
             for (int i = 0; i < m; ++i) {
                 state = state * 6364136223846793005ull + 1442695040888963407ull;
-                combo = combo + residue[i] * BigInt((i64)(1 + ((state >> 33) & 0xffff)));
+                weight[i] = (uint32_t)(1 + ((state >> 33) & 0xffff));
             }
-            combo = combo % modulus;
+            for (int s = 0; s < steps_done; ++s) {
+                const u32* row = digits[s].data();
+                unsigned long long sum = 0;
+                for (int i = 0; i < m; ++i) sum += (unsigned long long)weight[i] * row[i];
+                column[s] = sum;
+            }
+            unsigned long long carry = 0;
+            for (int s = 0; s < steps_done; ++s) {  // (what is carried out of the top digit is a multiple of the modulus)
+                const unsigned long long v = column[s] + carry;
+                column[s] = v % p;
+                carry = v / p;
+            }
+            BigInt combo(0);
+            for (int s = steps_done; s-- > 0;) combo.mul_add_small(p, (uint32_t)column[s]);
+            combo.trim();
             BigInt n, d;
             const double t_rr = wall_now();
-            const bool found = rational_reconstruct(combo, modulus, n, d);
+            const bool found = rational_reconstruct(combo, modulus, n, d, true, p);
             times.reconstruct += wall_now() - t_rr;
             times.reconstructs++;
             if (found && within_wang_bound(d, modulus)) denom = d;
             else ok = false;  // not enough digits yet
         }
-        for (int pass = 0; ok; ++pass) {
+        part(times.combine);
+        // First pass: every entry against the denominator of the combination, in parallel.  What is still "large" then has a
+        // factor the combination lost (a small prime that happened to divide its numerator): one reconstruction finds it, the
+        // denominator grows by it, and the entries are multiplied by the factor -- the small ones stay small (no reduction), the
+        // others are reduced again.  denom is the lcm of reduced denominators at every point, so the result is in lowest terms
+        // (gcd(denom, all numerators) = 1: a prime power q^e || denom divides exactly the denominator of some entry, whose
+        // numerator q does not divide) and no gcd pass is needed afterwards.
+        if (ok)
             pool.run(m, [&](int i) {
                 BigInt t = (residue[i] * denom) % modulus;
                 if (cmp(t, half) > 0) t = t - modulus;
                 small[i] = within_wang_bound(t, modulus) ? 1 : 0;
                 numer[i] = t;
             });
-            bool grown = false;
-            BigInt factor(1);  // what this pass multiplies the denominator by
+        if (ok) {
+            BigInt factor(1);  // product of the factors the combination lost
+            auto centred = [&](BigInt t) {
+                t = t % modulus;
+                if (cmp(t, half) > 0) t = t - modulus;
+                else if (t.sign() < 0 && cmp(t.abs(), half) > 0) t = t + modulus;
+                return t;
+            };
             for (int i = 0; i < m && ok; ++i) {
                 if (small[i]) continue;
-                BigInt t = grown ? (numer[i] * factor) % modulus : numer[i];
-                if (grown && cmp(t, half) > 0) t = t - modulus;
-                if (grown && t.sign() < 0 && cmp(t.abs(), half) > 0) t = t + modulus;
-                if (within_wang_bound(t, modulus)) continue;  // the denominators found so far cover it
+                const BigInt t = centred(numer[i] * factor);
+                if (within_wang_bound(t, modulus)) continue;  // the factors found so far cover it
                 BigInt n, d;
                 const double t_rr = wall_now();
-                const bool found = rational_reconstruct(t, modulus, n, d);
+                const bool found = rational_reconstruct(t, modulus, n, d, true, p);
                 times.reconstruct += wall_now() - t_rr;
                 times.reconstructs++;
-                if (!found) { ok = false; break; }
+                if (!found || d == BigInt(1)) { ok = false; break; }  // (d = 1 with a large numerator: not enough digits)
                 factor = factor * d;
                 denom = denom * d;
-                grown = true;
-                if (!within_wang_bound(denom, modulus)) { ok = false; break; }
+                if (!within_wang_bound(denom, modulus)) ok = false;
             }
-            if (!grown) break;
-            if (pass > 64) ok = false;
+            if (ok && !(factor == BigInt(1))) {
+                std::atomic<int> large{0};
+                pool.run(m, [&](int i) {
+                    if (numer[i].is_zero()) return;
+                    BigInt t = numer[i] * factor;
+                    if (!small[i] || !within_wang_bound(t, modulus)) {
+                        t = centred(t);
+                        if (!within_wang_bound(t, modulus)) large.fetch_add(1);
+                    }
+                    numer[i] = t;
+                });
+                if (large.load() != 0) ok = false;
+            }
         }
+        part(times.numerators);
         if (ok) {
             // exact verification: A numer == denom * rhs
             std::atomic<int> bad{0};
@@ -609,18 +641,12 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             });
             if (bad.load() != 0) ok = false;
         }
+        part(times.verify);
         if (ok) {
-            // normalise by the gcd of everything
-            BigInt g = denom;
-            for (int i = 0; i < m && !(g == BigInt(1)); ++i)
-                if (!numer[i].is_zero()) g = BigInt::gcd(g, numer[i]);
-            if (!(g == BigInt(1)) && !g.is_zero()) {
-                for (auto& v : numer) v = v / g;
-                denom = denom / g;
-            }
             out->numer = std::move(numer);
             out->denom = denom;
             if (digits_used) *digits_used = steps_done;
+            part(times.normalise);
             return true;
         }
         if (steps_done >= max_steps) {
@@ -633,9 +659,44 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
 
 }  // namespace
 
+void* CertifyScratch::take(size_t bytes) {
+    Block* best = nullptr;
+    for (Block& b : blocks)
+        if (!b.busy && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best && best->bytes <= 4 * bytes + 4096) {  // (a far larger block stays free for a request of its own size)
+        best->busy = true;
+        return best->ptr;
+    }
+    void* p = nullptr;
+    RELP_HIP(hipMalloc(&p, bytes));
+    blocks.push_back(Block{p, bytes, true});
+    return p;
+}
+void CertifyScratch::give_back(void* ptr) {
+    for (Block& b : blocks)
+        if (b.ptr == ptr) b.busy = false;
+}
+void CertifyScratch::release() {
+    for (Block& b : blocks) (void)hipFree(b.ptr);
+    blocks.clear();
+    if (second) (void)hipStreamDestroy(second);
+    second = nullptr;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // entry point
 // ---------------------------------------------------------------------------------------------------
+// What depends on the loaded LP only (kept by the handle between certificates, CertifyScratch::statics).
+struct CertifyStatic {
+    std::vector<SparseColumn> columns;
+    std::vector<Rat> rhs;
+    std::vector<i128> row_mult;
+    i128 cost_mult = 1;
+    std::vector<int> artificial_rows;
+    std::vector<BigInt> rhs_big;
+    BigInt rhs_den = BigInt(1);
+};
+
 // mode 0: the basis is optimal (x_B >= 0, zero artificials, every reduced cost >= 0) -> exact objective.
 // mode 1: the LP is INFEASIBLE: the same checks for the phase-one costs (1 on the artificial columns, 0 elsewhere;
 //         phase_one.rs:123-179) with a POSITIVE optimum -- the dual solution y is a Farkas certificate (y'A <= 0, y'b > 0).
@@ -662,13 +723,14 @@ std::vector<std::pair<int, std::string>> exact_primal_values(const ExactPrimal& 
 
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_columns, int device, hipStream_t stream,
                    std::string* objective, bool* certified, long long* repair_pivots, std::string* message, int mode, int entering,
-                   std::shared_ptr<const ExactPrimal>* primal, int* digit_hints) {
+                   std::shared_ptr<const ExactPrimal>* primal, CertifyScratch* scratch) {
     // digit_hints[0 / 1]: p-adic digits the primal / dual solve of this LP needed last time (0: unknown).  The number of digits is
     // found by doubling from 32 (Cramer's bound over-estimates it three-fold); a handle that solves the same LP again -- a warm
     // start, a batch pass, a re-solve after a bound change -- starts where the last certificate ended instead of paying for the
     // two failed reconstructions on the way up.  A wrong hint costs time only: every result is verified by exact substitution.
     int no_hints[2] = {0, 0};
-    if (!digit_hints) digit_hints = no_hints;
+    int* digit_hints = scratch && mode == 0 ? scratch->digit_hints : no_hints;
+    std::mutex scratch_guard;
     if (primal) primal->reset();
     objective->clear();
     *certified = false;
@@ -688,53 +750,77 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                             "host assemble/reconstruct/verify %.2f (of which %d rational reconstructions %.2f), checks %.2f\n",
                     (wall_now() - t0) * 1e3, g_times.setup * 1e3, g_times.inverse * 1e3, g_times.device_digits * 1e3, g_times.digit_launches,
                     g_times.solves, g_times.host_assemble * 1e3, g_times.reconstructs, g_times.reconstruct * 1e3, g_times.checks * 1e3);
+            fprintf(stderr, "[certify]   host parts (summed over the solves): Horner %.2f, combined unknown + its reconstruction %.2f, numerators %.2f, "
+                            "exact substitution %.2f, gcd %.2f ms\n", g_times.horner * 1e3, g_times.combine * 1e3, g_times.numerators * 1e3,
+                    g_times.verify * 1e3, g_times.normalise * 1e3);
         }
     } report{t_begin};
+    const bool timeline = getenv("RELP_TIME_CERTIFY") != nullptr;
+    auto stamp = [&](const char* what) {
+        if (timeline) fprintf(stderr, "[certify]   +%.2f ms %s\n", (wall_now() - t_begin) * 1e3, what);
+    };
 
     // ---- integer scaling: row multipliers (lcm of the denominators of the row's coefficients), cost multiplier; the
-    //      right-hand side keeps its own common denominator and any width (presolve leaves ~100-bit values there) ----
-    std::vector<SparseColumn> columns(n_p);
-    for (int j = 0; j < n_p; ++j) columns[j] = md.column(j);
-    std::vector<Rat> rhs = md.right_hand_side();
-    std::vector<i128> row_mult(m, 1);
-    try {
-        for (int j = 0; j < n_p; ++j)
-            for (size_t e = 0; e < columns[j].nnz(); ++e) row_mult[columns[j].index[e]] = lcm128(row_mult[columns[j].index[e]], columns[j].value[e].d);
-    } catch (const RatOverflow&) {
-        *message = "row scaling overflows 128 bits";
+    //      right-hand side keeps its own common denominator and any width (presolve leaves ~100-bit values there).  It depends
+    //      on the LP only: built once per loaded LP and kept by the handle (0.5 ms of every certificate of 25FV47 otherwise) ----
+    std::shared_ptr<const CertifyStatic> statics = scratch ? std::static_pointer_cast<const CertifyStatic>(scratch->statics) : nullptr;
+    if (!statics) {
+        auto built = std::make_shared<CertifyStatic>();
+        built->columns.resize(n_p);
+        for (int j = 0; j < n_p; ++j) built->columns[j] = md.column(j);
+        built->rhs = md.right_hand_side();
+        built->row_mult.assign(m, 1);
+        try {
+            for (int j = 0; j < n_p; ++j)
+                for (size_t e = 0; e < built->columns[j].nnz(); ++e)
+                    built->row_mult[built->columns[j].index[e]] = lcm128(built->row_mult[built->columns[j].index[e]], built->columns[j].value[e].d);
+        } catch (const RatOverflow&) {
+            *message = "row scaling overflows 128 bits";
+            return;
+        }
+        try {
+            for (int j = 0; j < n_p; ++j) built->cost_mult = lcm128(built->cost_mult, md.cost_value(j).d);
+        } catch (const RatOverflow&) {
+            built->cost_mult = 0;  // (only the phase-one certificate, which has its own costs, can do without)
+        }
+        // basis columns: provider column c >= 0, or artificial -1-k (unit column on its row, cost 0; redundant rows)
+        {
+            auto pivots = md.pivot_element_indices();
+            std::vector<char> has(m, 0);
+            for (auto& [row, column] : pivots) has[row] = 1;
+            for (int i = 0; i < m; ++i)
+                if (!has[i]) built->artificial_rows.push_back(i);
+        }
+        // b_i * row_mult_i = rhs_big[i] / rhs_den  (exact, arbitrary width)
+        built->rhs_big.resize(m);
+        {
+            std::vector<BigInt> numer(m);
+            std::vector<i128> denom(m);
+            for (int i = 0; i < m; ++i) {
+                const i128 g = gcd128(built->row_mult[i], built->rhs[i].d);
+                numer[i] = big_from_i128(built->rhs[i].n) * big_from_i128(built->row_mult[i] / g);
+                denom[i] = built->rhs[i].d / g;
+                const BigInt d = big_from_i128(denom[i]);
+                built->rhs_den = built->rhs_den / BigInt::gcd(built->rhs_den, d) * d;
+            }
+            for (int i = 0; i < m; ++i) built->rhs_big[i] = numer[i] * (built->rhs_den / big_from_i128(denom[i]));
+        }
+        statics = built;
+        if (scratch) scratch->statics = statics;
+    }
+    const std::vector<SparseColumn>& columns = statics->columns;
+    const std::vector<i128>& row_mult = statics->row_mult;
+    if (mode != 1 && statics->cost_mult == 0) {
+        *message = "cost scaling overflows 128 bits";
         return;
     }
-    i128 cost_mult = 1;
-    if (mode != 1)
-        for (int j = 0; j < n_p; ++j) cost_mult = lcm128(cost_mult, md.cost_value(j).d);
+    const i128 cost_mult = mode == 1 ? (i128)1 : statics->cost_mult;
+    const std::vector<int>& artificial_rows = statics->artificial_rows;
+    const std::vector<BigInt>& rhs_big = statics->rhs_big;
+    const BigInt& rhs_den = statics->rhs_den;
     auto scaled = [&](const Rat& v, i128 mult) { return mul_checked(v.n, mult / v.d); };
     auto scaled_cost = [&](int j) -> i128 { return mode == 1 ? (i128)0 : scaled(md.cost_value(j), cost_mult); };
     auto fits = [](i128 v) { return v < ((i128)1 << 62) && v > -((i128)1 << 62); };
-
-    // basis columns: provider column c >= 0, or artificial -1-k (unit column on its row, cost 0; redundant rows)
-    std::vector<int> artificial_rows;
-    {
-        auto pivots = md.pivot_element_indices();
-        std::vector<char> has(m, 0);
-        for (auto& [row, column] : pivots) has[row] = 1;
-        for (int i = 0; i < m; ++i)
-            if (!has[i]) artificial_rows.push_back(i);
-    }
-    // b_i * row_mult_i = rhs_big[i] / rhs_den  (exact, arbitrary width)
-    std::vector<BigInt> rhs_big(m);
-    BigInt rhs_den(1);
-    {
-        std::vector<BigInt> numer(m);
-        std::vector<i128> denom(m);
-        for (int i = 0; i < m; ++i) {
-            const i128 g = gcd128(row_mult[i], rhs[i].d);
-            numer[i] = big_from_i128(rhs[i].n) * big_from_i128(row_mult[i] / g);
-            denom[i] = rhs[i].d / g;
-            const BigInt d = big_from_i128(denom[i]);
-            rhs_den = rhs_den / BigInt::gcd(rhs_den, d) * d;
-        }
-        for (int i = 0; i < m; ++i) rhs_big[i] = numer[i] * (rhs_den / big_from_i128(denom[i]));
-    }
     std::vector<int> basis = basis_columns;  // repaired in place by exact pivots when a check fails
     const int max_repairs = 200;
     const u32 primes[] = {2147483647u, 2147483629u, 2147483587u, 2147483579u};
@@ -787,7 +873,10 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         g_times.setup += wall_now() - t_begin - g_times.setup - g_times.inverse - g_times.device_digits - g_times.host_assemble - g_times.checks;
         const double t_inverse = wall_now();
         // ---- device: C = B^-1 mod p ---------------------------------------------------------------------
+        stamp("integer basis built");
         DeviceBuffers buf;
+        buf.scratch = scratch;
+        buf.guard = &scratch_guard;
         u32* dC = buf.alloc<u32>((size_t)m * m);
         u32* dCT = buf.alloc<u32>((size_t)m * m);
         u32* dX = buf.alloc<u32>((size_t)m * m);
@@ -803,6 +892,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         RELP_HIP(hipMemcpyAsync(d_row_start, B.row_start.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(d_col_index, B.col_index.data(), nnz * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(d_row_value, B.row_value.data(), nnz * sizeof(i64), hipMemcpyHostToDevice, stream));
+        stamp("device buffers allocated, uploads enqueued");
         u32 p = 0;
         for (u32 candidate : primes) {
             // sparse LU of B mod p on the host (Markowitz order; any non-zero pivot is exact in Z_p): a few 10^4 operations
@@ -893,6 +983,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
         // (The number of p-adic digits is found by doubling: Cramer's bound through |det B| of the row-scaled integer matrix
         //  over-estimates it three-fold on 25FV47, and the cost of the reconstruction grows with the square of it.)
         g_times.inverse += wall_now() - t_inverse;
+        stamp("inverse mod p ready");
         int primal_digits = 0;
         auto solve = [&](const std::vector<i64>& r, int transpose, ExactVector* out) {
             g_times.solves++;
@@ -923,6 +1014,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                 }
                 ExactVector part;
                 if (!solve(limb, 0, &part)) return false;
+                stamp("primal lifting returned");
                 const BigInt g = BigInt::gcd(out->denom, part.denom);
                 const BigInt grow = part.denom / g, part_factor = (out->denom / g) * scale;
                 for (int i = 0; i < m; ++i) out->numer[i] = out->numer[i] * grow + part.numer[i] * part_factor;
@@ -943,20 +1035,25 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             std::thread dual([&] {
                 try {
                     RELP_HIP(hipSetDevice(device));
-                    hipStream_t second = nullptr;
-                    RELP_HIP(hipStreamCreateWithFlags(&second, hipStreamNonBlocking));
+                    hipStream_t second = scratch ? scratch->second : nullptr;
+                    if (!second) RELP_HIP(hipStreamCreateWithFlags(&second, hipStreamNonBlocking));
+                    if (scratch) scratch->second = second;  // kept by the handle: the next certificate finds it
+                    stamp("dual thread has its stream");
                     try {
                         DeviceBuffers dual_buffers;
+                        dual_buffers.scratch = scratch;
+                        dual_buffers.guard = &scratch_guard;
                         int used = 0;
                         dual_ok = dixon_solve(B, cost_basis, 1, p, dCT, dual_buffers, d_col_start, d_row_index, d_value, second, &y,
                                               &dual_message, dual_times, digit_hints[1] > 0 ? digit_hints[1] : 32, &used);
                         if (dual_ok && round == 0) digit_hints[1] = used;
+                        stamp("dual solve done");
                         RELP_HIP(hipStreamSynchronize(second));
                     } catch (...) {
-                        (void)hipStreamDestroy(second);
+                        if (!scratch) (void)hipStreamDestroy(second);
                         throw;
                     }
-                    (void)hipStreamDestroy(second);
+                    if (!scratch) (void)hipStreamDestroy(second);
                 } catch (...) {
                     dual_error = std::current_exception();
                 }
@@ -968,13 +1065,27 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             } catch (...) {
                 primal_error = std::current_exception();
             }
+            stamp("primal solve done");
             dual.join();
+            stamp("dual solve joined");
+            if (timeline)
+                fprintf(stderr, "[certify]   unpack %.2f / %.2f; primal: device %.2f host %.2f (Horner %.2f combine %.2f numerators %.2f verify %.2f gcd %.2f, %d reconstructions %.2f); "
+                                "dual: device %.2f host %.2f (Horner %.2f combine %.2f numerators %.2f verify %.2f gcd %.2f, %d reconstructions %.2f) ms\n",
+                        g_times.unpack * 1e3, dual_times.unpack * 1e3, g_times.device_digits * 1e3, g_times.host_assemble * 1e3, g_times.horner * 1e3, g_times.combine * 1e3, g_times.numerators * 1e3,
+                        g_times.verify * 1e3, g_times.normalise * 1e3, g_times.reconstructs, g_times.reconstruct * 1e3, dual_times.device_digits * 1e3,
+                        dual_times.host_assemble * 1e3, dual_times.horner * 1e3, dual_times.combine * 1e3, dual_times.numerators * 1e3, dual_times.verify * 1e3,
+                        dual_times.normalise * 1e3, dual_times.reconstructs, dual_times.reconstruct * 1e3);
             g_times.solves++;
             g_times.device_digits += dual_times.device_digits;
             g_times.host_assemble += dual_times.host_assemble;
             g_times.digit_launches += dual_times.digit_launches;
             g_times.reconstruct += dual_times.reconstruct;
             g_times.reconstructs += dual_times.reconstructs;
+            g_times.horner += dual_times.horner;
+            g_times.combine += dual_times.combine;
+            g_times.numerators += dual_times.numerators;
+            g_times.verify += dual_times.verify;
+            g_times.normalise += dual_times.normalise;
             if (primal_ok && round == 0 && primal_digits > 0) digit_hints[0] = primal_digits;
             if (primal_error) std::rethrow_exception(primal_error);
             if (dual_error) std::rethrow_exception(dual_error);
@@ -1061,7 +1172,9 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                 num = num / g;
                 den = den / g;
             }
+            stamp("checks done, objective reduced");
             *objective = num.to_string() + "/" + den.to_string();
+            stamp("objective as decimal text");
             *certified = true;
             *repair_pivots = round;
             if (primal) {  // OptimizationResult::FiniteOptimum(x) in exact form (algorithm/mod.rs:43-47), kept as integers over one denominator

@@ -62,7 +62,7 @@ void launch_relative_cost(const DeviceLP& d, double* out, hipStream_t s);
 // certify.hip
 void certify_basis(const StandardForm& form, const std::vector<int>& basis_provider_columns, int device,
                    hipStream_t stream, std::string* objective, bool* certified, long long* repair_pivots,
-                   std::string* message, int mode, int entering, std::shared_ptr<const ExactPrimal>* primal, int* digit_hints);
+                   std::string* message, int mode, int entering, std::shared_ptr<const ExactPrimal>* primal, CertifyScratch* scratch);
 
 namespace {
 double now_seconds() {
@@ -100,6 +100,8 @@ Solver::Solver(const relp_options& options) : opt_(options) {
 }
 
 Solver::~Solver() {
+    (void)hipSetDevice(opt_.device);
+    certify_scratch_.release();
     free_device();
     destroy_graphs();
     if (ev_a_) (void)hipEventDestroy(ev_a_);
@@ -125,7 +127,8 @@ void Solver::load(StandardForm&& form) {
     free_device();
     destroy_graphs();
     form_ = std::move(form);
-    certify_digit_hints_[0] = certify_digit_hints_[1] = 0;  // (a new LP: nothing is known about its certificate)
+    certify_scratch_.digit_hints[0] = certify_scratch_.digit_hints[1] = 0;  // (a new LP: nothing is known about its certificate)
+    certify_scratch_.statics.reset();
     try {
         upload();
     } catch (...) {
@@ -1450,7 +1453,7 @@ void Solver::certify(relp_result* result) {
     std::string message;
     try {
         const int mode = result->kind == RELP_RESULT_INFEASIBLE ? 1 : result->kind == RELP_RESULT_UNBOUNDED ? 2 : 0;
-        certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message, mode, unbounded_column_, &exact_primal, mode == 0 ? certify_digit_hints_ : nullptr);
+        certify_basis(form_, h_basis_, opt_.device, stream_, &exact_objective, &ok, &repairs, &message, mode, unbounded_column_, &exact_primal, &certify_scratch_);
     } catch (const RatOverflow& e) {  // the f64 result stands; it is reported uncertified with the reason
         ok = false;
         message = std::string("exact certificate: ") + e.what();

@@ -19,6 +19,23 @@ namespace relp {
 
 // Exact primal solution of a certified basis: x_B[k] = numer[k] / denom for the provider column basis[k] (certify.hip).
 struct ExactPrimal;
+// What a handle keeps between its certificates (certify.hip): the second stream of the dual lifting (creating and destroying a
+// stream costs 4 + 2 ms, as much as the rest of a certificate), the device buffers (returned to the handle, not to the driver) and
+// the p-adic digit counts the last certificate of the loaded LP needed.
+struct CertifyScratch {
+    hipStream_t second = nullptr;
+    struct Block {
+        void* ptr;
+        size_t bytes;
+        bool busy;
+    };
+    std::vector<Block> blocks;
+    int digit_hints[2] = {0, 0};  // (primal, dual); 0: unknown.  Reset when another LP is loaded.
+    std::shared_ptr<const void> statics;  // the LP's integer scaling (certify.hip: CertifyStatic); reset when another LP is loaded
+    void* take(size_t bytes);     // smallest free block that fits, else a new allocation
+    void give_back(void* ptr);
+    void release();               // frees everything (the handle's destructor; device must be current)
+};
 // (provider column, "num/den" reduced) for every basic provider column with a non-zero exact value, ascending column
 std::vector<std::pair<int, std::string>> exact_primal_values(const ExactPrimal& primal);
 
@@ -223,7 +240,7 @@ private:
     void write_ctl(const Ctl& c);
     int drive_out_artificials();
     void certify(relp_result* result);
-    int certify_digit_hints_[2] = {0, 0};  // p-adic digits the last certificate of this LP needed (primal, dual): where the next one starts
+    CertifyScratch certify_scratch_;
     // LU carry (relp_options.carry == RELP_CARRY_LU)
     void refactor_lu(bool refresh_vectors);  // BasisInverse::invert of the current basis (host Markowitz + upload)
     void lu_identity();                      // BasisInverse::identity

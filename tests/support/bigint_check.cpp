@@ -5,6 +5,7 @@
 #include <string>
 
 #include "../../relp_amd/csrc/bigint.hpp"
+#include "../../relp_amd/csrc/rational_reconstruct.hpp"
 
 using relp::BigInt;
 
@@ -28,6 +29,11 @@ int main() {
         else if (op == "mod") std::cout << (x % y).to_string() << "\n";
         else if (op == "gcd") std::cout << BigInt::gcd(x, y).to_string() << "\n";
         else if (op == "cmp") std::cout << cmp(x, y) << "\n";
+        else if (op == "rr" || op == "rrplain" || op == "rrprime") {  // rational reconstruction of x (mod y): "n/d" or "none"
+            BigInt n, d;                                               // (rrprime: y is a power of 2^31 - 1)
+            if (relp::rational_reconstruct(x, y, n, d, op != "rrplain", op == "rrprime" ? 2147483647u : 0u)) std::cout << n.to_string() << "/" << d.to_string() << "\n";
+            else std::cout << "none\n";
+        }
         else return 2;
     }
     return 0;

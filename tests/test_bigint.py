@@ -84,3 +84,60 @@ def test_bigrat_matches_python_fractions(tmp_path):
             expected.append("%d/%d" % (r.numerator, r.denominator))
     out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split()
     assert out == expected
+
+
+def reconstruct_reference(a, M):
+    """The definition relp_amd/csrc/rational_reconstruct.hpp implements: the extended Euclidean sequence of (M, a mod M), stopped at
+    the first remainder r with 2 bits(r) + 2 <= bits(M); the cofactor must satisfy the same bound."""
+    small = lambda v: 2 * abs(v).bit_length() + 2 <= M.bit_length()
+    r0, r1, t0, t1 = M, a % M, 0, 1
+    while not small(r1):
+        q = r0 // r1
+        r0, r1, t0, t1 = r1, r0 - q * r1, t1, t0 - q * t1
+    if t1 == 0 or not small(t1):
+        return None
+    n, d = (-r1 if t1 < 0 else r1), abs(t1)
+    g = math.gcd(n, d)
+    return (n // g, d // g) if g else None
+
+
+def test_rational_reconstruction_lehmer_equals_plain_equals_python(driver):
+    """Lehmer's batched sequence is the plain sequence: same answer on every input, including the ones with no answer."""
+    rng = random.Random(2024)
+    p = 2147483647
+    cases = []
+    for k in (2, 4, 8, 9, 16, 32, 33, 64, 128, 130):
+        M = p ** k
+        for _ in range(12):
+            bits = rng.randrange(1, max(2, (M.bit_length() - 2) // 2))
+            n = rng.getrandbits(bits) * rng.choice([1, -1])
+            d = rng.getrandbits(rng.randrange(1, bits + 1)) | 1
+            while math.gcd(d, p) != 1:
+                d += 2
+            cases.append((n * pow(d, -1, M) % M, M))      # a reconstructible residue
+            cases.append((rng.randrange(M), M))            # a random one (almost surely none)
+        cases.append((0, M))
+        cases.append((1, M))
+        cases.append((M - 1, M))
+    for _ in range(60):                                      # moduli that are not prime powers, odd sizes
+        M = rng.getrandbits(rng.choice([70, 129, 131, 200, 257, 1000])) | (1 << 69) | 1
+        cases.append((rng.randrange(M), M))
+        n, d = rng.getrandbits(30), rng.getrandbits(28) | 1
+        if math.gcd(d, M) == 1:
+            cases.append((n * pow(d, -1, M) % M, M))
+    is_prime_power = lambda M: M % p == 0 or M == 1
+    text = "".join("%s %d %d\n" % (op if op != "rrprime" or is_prime_power(M) else "rr", a, M) for a, M in cases for op in ("rr", "rrplain", "rrprime"))
+    out = subprocess.run([driver], input=text, capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == 3 * len(cases)
+    found = 0
+    for k, (a, M) in enumerate(cases):
+        want = reconstruct_reference(a, M)
+        want_text = "none" if want is None else "%d/%d" % want
+        assert out[3 * k] == want_text, ("lehmer", a, M)
+        assert out[3 * k + 1] == want_text, ("plain", a, M)
+        # with the prime given the gcd is replaced by a divisibility test of the cofactor: "none" where the gcd would have been > 1
+        assert out[3 * k + 2] == want_text or (out[3 * k + 2] == "none" and is_prime_power(M)), ("prime", a, M)
+        if is_prime_power(M) and out[3 * k + 2] == "none" and want is not None:
+            assert want[1] % p == 0 or (a * want[1] - want[0]) % M != 0  # what was dropped was not a fraction of a (mod M)
+        found += want is not None
+    assert found >= 100
