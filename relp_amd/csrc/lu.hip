@@ -26,9 +26,11 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 #include "solver.hpp"
 #include "wave_ops.hpp"
@@ -116,9 +118,15 @@ int group_log2(int n) {  // smallest g with LU_TE << g >= n, at most 6
 }
 void build_tasks(const int* start, const int* idx, const double* val, const double* diag, const std::vector<int>& lev_start,
                  const std::vector<int>& order, HostTasks& out) {
-    out = HostTasks{};
-    out.col.assign(LU_TE, {});
-    out.val.assign(LU_TE, {});
+    // (the vectors keep their capacity from one refactorisation to the next: thousands of push_backs, no allocation)
+    out.z_pos.clear(); out.s_pos.clear(); out.s_lev.clear(); out.s_flags.clear(); out.s_xstart.clear(); out.s_xn.clear();
+    out.x_idx.clear(); out.chunk.clear(); out.z_dinv.clear(); out.s_dinv.clear(); out.x_val.clear();
+    out.col.resize(LU_TE);
+    out.val.resize(LU_TE);
+    for (int e = 0; e < LU_TE; ++e) {
+        out.col[e].clear();
+        out.val[e].clear();
+    }
     out.levels = (int)lev_start.size() - 1;
     auto push_slot = [&](int pos, int lev, int flags, double dinv, int xstart, int xn) {
         out.s_pos.push_back(pos);
@@ -215,8 +223,20 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t cl = cap_l_, cu = cap_u_;
     const int ldt = max_updates + 1;
     // ---- host: the four orientations and their task lists -----------------------------------------------------------------
+    static const bool time_parts = getenv("RELP_TIME_REFACTOR") != nullptr;
+    static double part_seconds[5] = {0, 0, 0, 0, 0};
+    static long long uploads = 0;
+    auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = time_parts ? wall() : 0.0;
+    auto mark = [&](int which) {
+        if (!time_parts) return;
+        const double now = wall();
+        part_seconds[which] += now - t_mark;
+        t_mark = now;
+    };
     HostLU& fs = const_cast<HostLU&>(f);
     if (fs.lev_row[0].empty()) lu_schedules(fs);
+    mark(0);
     std::vector<int> lcs(m + 1, 0), lcrow(nl), ucs(m + 1, 0), ucrow(nu);
     std::vector<double> lcval(nl), ucval(nu);
     {   // column orientation of L and U (counting transposes)
@@ -240,11 +260,16 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
             }
         }
     }
-    HostTasks tasks[4];
+    mark(1);
+    // (Built one after the other on the calling thread: helper threads were measured -- the thread start alone costs more than a
+    // list does at Netlib sizes, 8.5 -> 11.9 ms over the 75 refactorisations of 25FV47.)
+    thread_local HostTasks task_storage[4];  // (per calling thread: handles of a batch refactorise concurrently; capacity is kept)
+    HostTasks* tasks = task_storage;
     build_tasks(f.l_start.data(), f.l_col.data(), f.l_val.data(), nullptr, f.lev_start[0], f.lev_row[0], tasks[0]);
     build_tasks(f.u_start.data(), f.u_col.data(), f.u_val.data(), f.diag.data(), f.lev_start[1], f.lev_row[1], tasks[1]);
     build_tasks(ucs.data(), ucrow.data(), ucval.data(), f.diag.data(), f.lev_start[2], f.lev_row[2], tasks[2]);
     build_tasks(lcs.data(), lcrow.data(), lcval.data(), nullptr, f.lev_start[3], f.lev_row[3], tasks[3]);
+    mark(2);
     size_t max_slots = 0;
     for (int k = 0; k < 4; ++k) max_slots = std::max(max_slots, tasks[k].s_pos.size());
     if (max_slots + 1024 > cap_slots_ || (size_t)m + 1024 > cap_slots_ || cap_slots_ == 0 || layout_changed) {
@@ -362,6 +387,7 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     // A small factor goes over in ONE copy, gaps and unused capacity included: every hipMemcpyAsync costs 5-10 us of host time,
     // which at Netlib sizes is more than the bytes do.  A large one copies the headers at once and each entry array up to what
     // is used (the capacities are 1.5 x larger, the ELL rows m wide).
+    mark(3);
     if (upload_bytes <= (size_t)(2u << 20)) {
         RELP_HIP(hipMemcpyAsync(dev_, h, upload_bytes, hipMemcpyHostToDevice, stream));
     } else {
@@ -384,6 +410,10 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         copy(o_ucrow, nu * sizeof(int));
         copy(o_ucval, nu * sizeof(double));
     }
+    mark(4);
+    if (time_parts && ++uploads % 25 == 0)
+        fprintf(stderr, "[refactor]   upload parts, %lld so far: level schedules %.2f, column orientations %.2f, slot lists %.2f, staging %.2f (%zu bytes), copies %.2f ms\n",
+                uploads, part_seconds[0] * 1e3, part_seconds[1] * 1e3, part_seconds[2] * 1e3, part_seconds[3] * 1e3, upload_bytes, part_seconds[4] * 1e3);
     DeviceLU d;
     d.m = m;
     d.max_updates = max_updates;

@@ -1511,9 +1511,21 @@ void Solver::refactor_lu(bool refresh_vectors) {
     }
     LuOptions lo;
     lo.threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
+    static const bool time_parts = getenv("RELP_TIME_REFACTOR") != nullptr;
+    static double part_seconds[3] = {0.0, 0.0, 0.0};
+    const double t1 = now_seconds();
     HostLU f = lu_factor(m, cs.data(), rows.data(), vals.data(), lo);
     if (f.singular) throw std::runtime_error("singular basis in the LU refactorisation");
+    const double t2 = now_seconds();
     if (lu_.upload(f, refactor_period_ + 1, stream_)) destroy_graphs();
+    if (time_parts) {
+        part_seconds[0] += t1 - t0;
+        part_seconds[1] += t2 - t1;
+        part_seconds[2] += now_seconds() - t2;
+        if ((refactors_ + 1) % 25 == 0)
+            fprintf(stderr, "[refactor] %lld so far: basis fetch + gather %.2f ms, Markowitz LU %.2f ms, schedules + upload %.2f ms (sums)\n", refactors_ + 1,
+                    part_seconds[0] * 1e3, part_seconds[1] * 1e3, part_seconds[2] * 1e3);
+    }
     binv_identity_ = false;
     if (refresh_vectors) {
         launch_lu_xb(d_, lu_.device(), stream_);
