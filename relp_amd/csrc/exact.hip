@@ -296,7 +296,10 @@ struct ExactLP {
     int* trace;           // [4 * trace_capacity]: phase, q, p, leaving
     int trace_capacity;
     long long max_pivots;
-    int* out;             // [8]: status, pivots phase one, pivots phase two, limbs, trace entries, redundant rows
+    int* out;             // [16]: status, pivots phase one, pivots phase two, limbs, trace entries, redundant rows; after an overflow
+                          //       also [6..9] = phase, trace count, drive row, removed rows at the START of the pivot that did not fit
+    const int* resume;    // [8]: [0] != 0: continue a run that overflowed at a narrower width (N, D, basis, pos, removed are its state
+                          //      before the pivot that did not fit); [1..6] = phase, pivots one, pivots two, trace count, drive row, removed
     int* removed;         // [m] 1: the row is redundant -- its artificial cannot be pivoted out (`RemoveRows` of the reference)
     int* shared_words;    // [8] grid-wide overflow flag, decisions of workgroup 0's thread 0
     double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
@@ -491,8 +494,20 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
     // drive_row >= 0: the zero-level pivots of phase_one.rs:232-278 are under way, this is the next row to look at
     int drive_row = -1;
     int n_removed = 0;  // redundant rows found there
+    if (lp.resume[0] != 0) {  // the loop-carried state of the run this one continues (see the host driver)
+        phase = lp.resume[1];
+        pivots[0] = lp.resume[2];
+        pivots[1] = lp.resume[3];
+        trace_count = lp.resume[4];
+        drive_row = lp.resume[5];
+        n_removed = lp.resume[6];
+    }
+    int at_phase = phase, at_drive_row = drive_row, at_removed = n_removed;  // ... at the start of the current turn of the loop
     while (status == EX_RUNNING) {
         if (pivots[0] + pivots[1] >= lp.max_pivots) { status = EX_PIVOT_LIMIT; break; }
+        at_phase = phase;
+        at_drive_row = drive_row;
+        at_removed = n_removed;
         const Big<L> D = big_load<L>(gD);
         const int D_bits = big_bits(D);
         // ---- x~_B = N b: a thread per (row, chunk of 32 columns), then a thread per row over its chunks (same bounds as the serial loop) ----
@@ -788,6 +803,17 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         Big<L> Dinv;
         for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
         const int ap_bits = big_bits(ap);
+        // Will every new entry fit?  Decided from the bit lengths of the operands BEFORE anything is written (one more read of N:
+        // microseconds beside the multiplications below), so that a run that does not fit stops with N, D and the basis as they
+        // were at the start of this pivot -- the state the next width continues from (host driver).
+        for (int idx = gtid; idx < m * m; idx += GT) {
+            const int i = idx / m, k = idx - i * m;
+            if (i == p) continue;
+            const int estimate = max(ap_bits + big_bits(big_load<L>(lp.N + (size_t)idx * L)),
+                                     big_bits(big_load<L>(lp.alpha + (size_t)i * L)) + big_bits(big_load<L>(lp.N + ((size_t)p * m + k) * L))) + 1 - (D_bits - 1);
+            if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
+        }
+        if (sync_overflow()) { status = EX_OVERFLOW; break; }
         for (int idx = gtid; idx < m * m; idx += GT) {
             const int i = idx / m, k = idx - i * m;
             if (i == p) continue;
@@ -797,15 +823,13 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             // The numerator only has to be right modulo 2^(64 L): with D = 2^s D_odd the quotient is known modulo 2^(64 L - s)
             // (q D_odd = numerator / 2^s holds on the low 64 L - s bits), so it is sign-extended from there and must fit there.
             const Big<L> numerator = big_sub(big_mul_lo(ap, nik), big_mul_lo(ai, npk));
-            const int estimate = max(ap_bits + big_bits(nik), big_bits(ai) + big_bits(npk)) + 1 - (D_bits - 1);
-            if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
             Big<L> quotient = big_mul_lo(big_sar(numerator, shift), Dinv);
             quotient = big_sar(big_shl(quotient, shift), shift);
             if (flip) quotient = big_negate(quotient);
             big_store(lp.N + (size_t)idx * L, quotient);
         }
         stamp(7);
-        const bool overflow = sync_overflow();  // (also: row p is an operand of every other row above -- nobody may still be reading it)
+        grid.sync();  // (row p is an operand of every other row above -- nobody may still be reading it)
         if (flip) {
             for (int k = gtid; k < m; k += GT) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
             ap = big_negate(ap);
@@ -831,7 +855,6 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         pivots[phase - 1]++;
         grid.sync();  // the new basis, D and (flip) row p for everybody
         stamp(8);
-        if (overflow) { status = EX_OVERFLOW; break; }
     }
     grid.sync();
     // the final x~_B belongs to the final basis: recompute it (the loop computes it at the top of an iteration)
@@ -850,6 +873,20 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         lp.out[3] = L;
         lp.out[4] = trace_count < lp.trace_capacity ? trace_count : lp.trace_capacity;
         lp.out[5] = n_removed;
+        lp.out[6] = at_phase;
+        lp.out[7] = trace_count;
+        lp.out[8] = at_drive_row;
+        lp.out[9] = at_removed;
+    }
+}
+
+// Sign extension of `count` integers from `from` to `to` words each (a run that overflowed continues at the next width).
+__global__ void __launch_bounds__(256) exact_widen_kernel(const u64* src, u64* dst, long long count, int from, int to) {
+    const long long total = count * to;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long v = idx / to;
+        const int k = (int)(idx - v * to);
+        dst[idx] = k < from ? src[v * from + k] : (u64)((i64)src[v * from + from - 1] >> 63);
     }
 }
 
@@ -981,7 +1018,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_pos = dalloc<int>(n, owned);
     double* d_key = dalloc<double>(n, owned);
     int* d_trace = dalloc<int>((size_t)4 * trace_capacity, owned);
-    int* d_out = dalloc<int>(8, owned);
+    int* d_out = dalloc<int>(16, owned);
+    int* d_resume = dalloc<int>(8, owned);
     int* d_removed = dalloc<int>(m, owned);
     int* d_words = dalloc<int>(8, owned);
     double* d_part_key = dalloc<double>(2 * 256, owned);
@@ -1005,17 +1043,39 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     *status = EX_OVERFLOW;
     *limbs_used = 0;
     if (pivots_survived) pivots_survived->clear();
+    // A width that overflows hands its state to the next one: the kernel decides whether a pivot fits BEFORE it writes anything, so
+    // N, D, the basis and the bookkeeping are those at the start of that pivot; they are sign-extended to twice the words and the
+    // loop continues there.  (Rounds 2 and 3a started every width from the initial basis: SCORPION made 45 + 74 + 91 + 142 + 253 +
+    // 366 pivots for its 366.)  The arithmetic is exact, so the pivot sequence does not depend on where the widths change.
+    u64* previous_N = nullptr;
+    u64* previous_D = nullptr;
+    int previous_limbs = 0;
+    int resume_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RELP_HIP(hipMemcpyAsync(d_basis, basis0.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemsetAsync(d_removed, 0, m * sizeof(int), stream));
+    std::vector<void*> width_owned;  // the big-integer buffers of the current width (the previous width's are freed once widened)
+    struct FreeWidth {
+        std::vector<void*>& p;
+        ~FreeWidth() { for (void* q : p) (void)hipFree(q); }
+    } free_width{width_owned};
     for (int limbs = std::max(1, first_limbs); limbs <= max_limbs; limbs *= 2) {
         const size_t big = (size_t)limbs;
-        u64* d_N = dalloc<u64>((size_t)m * m * big, owned);
-        u64* d_D = dalloc<u64>(2 * big + 2 * (2 * big + 2) + 8, owned);
-        u64* d_xt = dalloc<u64>((size_t)m * big, owned);
-        u64* d_alpha = dalloc<u64>((size_t)m * big, owned);
-        u64* d_ctil = dalloc<u64>((size_t)n * big, owned);
-        d_price_a = dalloc<u64>(pairs * big, owned);
-        u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), owned);
-        u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, owned);
-        int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), owned);
+        std::vector<void*> fresh;
+        u64* d_N = dalloc<u64>((size_t)m * m * big, fresh);
+        u64* d_D = dalloc<u64>(2 * big + 2 * (2 * big + 2) + 8, fresh);
+        u64* d_xt = dalloc<u64>((size_t)m * big, fresh);
+        u64* d_alpha = dalloc<u64>((size_t)m * big, fresh);
+        u64* d_ctil = dalloc<u64>((size_t)n * big, fresh);
+        d_price_a = dalloc<u64>(pairs * big, fresh);
+        u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), fresh);
+        u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
+        int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
+        auto adopt = [&]() {  // the new width's buffers replace the previous width's
+            RELP_HIP(hipStreamSynchronize(stream));
+            for (void* q : width_owned) (void)hipFree(q);
+            width_owned = fresh;
+        };
         // N_0 and D_0 as two's complement words (positive values)
         auto words = [&](const BigInt& v, u64* out) {
             for (int k = 0; k < limbs; ++k) {
@@ -1023,26 +1083,33 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                 out[k] = lo | (hi << 32);
             }
         };
-        if (D0.bits() + 3 > (size_t)64 * limbs) {  // does not even hold the first determinant
+        if (!previous_N && D0.bits() + 3 > (size_t)64 * limbs) {  // does not even hold the first determinant
             if (pivots_survived) pivots_survived->push_back({limbs, 0});
+            for (void* q : fresh) (void)hipFree(q);
             continue;
         }
-        std::vector<u64> hN((size_t)m * m * big, 0), hD(big);
-        words(D0, hD.data());
-        for (int i = 0; i < m; ++i) {
-            BigInt q, r;
-            BigInt::divmod(D0, BigInt(diag0[i]), q, r);
-            words(q, hN.data() + ((size_t)i * m + i) * big);
+        if (previous_N) {
+            hipLaunchKernelGGL(exact_widen_kernel, dim3(1024), dim3(256), 0, stream, previous_N, d_N, (long long)m * m, previous_limbs, limbs);
+            hipLaunchKernelGGL(exact_widen_kernel, dim3(1), dim3(64), 0, stream, previous_D, d_D, 1LL, previous_limbs, limbs);
+            resume_state[0] = 1;
+        } else {
+            std::vector<u64> hN((size_t)m * m * big, 0), hD(big);
+            words(D0, hD.data());
+            for (int i = 0; i < m; ++i) {
+                BigInt q, r;
+                BigInt::divmod(D0, BigInt(diag0[i]), q, r);
+                words(q, hN.data() + ((size_t)i * m + i) * big);
+            }
+            RELP_HIP(hipMemcpyAsync(d_N, hN.data(), hN.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(d_D, hD.data(), big * sizeof(u64), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipStreamSynchronize(stream));  // (hN and hD leave scope)
         }
-        RELP_HIP(hipMemcpyAsync(d_N, hN.data(), hN.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemcpyAsync(d_D, hD.data(), big * sizeof(u64), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemcpyAsync(d_basis, basis0.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemsetAsync(d_removed, 0, m * sizeof(int), stream));
+        adopt();
+        RELP_HIP(hipMemcpyAsync(d_resume, resume_state, sizeof(resume_state), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
         if (d_prof) RELP_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
@@ -1066,7 +1133,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         void* args[] = {(void*)&lp};
         RELP_HIP(hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(EX_THREADS), args, 0, stream));
         RELP_HIP(hipGetLastError());
-        int out[8];
+        int out[16];
         RELP_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipStreamSynchronize(stream));
         if (d_prof) {
@@ -1082,7 +1149,18 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         *pivots_phase_one = out[1];
         *pivots_phase_two = out[2];
         if (pivots_survived) pivots_survived->push_back({limbs, (long long)out[1] + out[2]});
-        if (out[0] == EX_OVERFLOW) continue;
+        if (out[0] == EX_OVERFLOW) {
+            previous_N = d_N;
+            previous_D = d_D;
+            previous_limbs = limbs;
+            resume_state[1] = out[6];
+            resume_state[2] = out[1];
+            resume_state[3] = out[2];
+            resume_state[4] = out[7];
+            resume_state[5] = out[8];
+            resume_state[6] = out[9];
+            continue;
+        }
         if (redundant_rows) *redundant_rows = out[5];
         // results of the run that did not overflow
         if (trace) {
