@@ -227,6 +227,46 @@ __device__ __forceinline__ Big<L> big_inverse_odd(const Big<L>& d) {
     for (int correct = 3; correct < 64 * L; correct *= 2) x = big_mul_lo(x, big_sub(two, big_mul_lo(d, x)));
     return x;
 }
+// The same on word arrays in shared memory, for ONE thread per workgroup (once per pivot): a Big<32> in a thread's private arrays
+// lives in scratch memory, where the ten full-width Newton steps above took 1.9 ms per pivot on E226 -- a third of the pivot.  Here
+// the precision doubles with the words that are already right (1, 2, 4, ... words: 4 have^2 word products per step, 1.4 k instead
+// of 10.5 k at 32 limbs) and a product is formed column by column in three accumulator registers (no read-modify-write of memory).
+__device__ __forceinline__ void words_mul_lo(const u64* a, int la, const u64* b, int lb, u64* out, int lo) {  // out may not alias a, b
+    u64 c0 = 0, c1 = 0, c2 = 0;
+    for (int k = 0; k < lo; ++k) {
+        const int j0 = k - la + 1 > 0 ? k - la + 1 : 0, j1 = k < lb - 1 ? k : lb - 1;
+        for (int j = j0; j <= j1; ++j) {
+            const u128 prod = (u128)a[k - j] * b[j];
+            const u128 low = (u128)c0 + (u64)prod;
+            c0 = (u64)low;
+            const u128 mid = (u128)c1 + (u64)(prod >> 64) + (u64)(low >> 64);
+            c1 = (u64)mid;
+            c2 += (u64)(mid >> 64);
+        }
+        out[k] = c0;
+        c0 = c1;
+        c1 = c2;
+        c2 = 0;
+    }
+}
+template <int L>
+__device__ void words_inverse_odd(const u64* d, u64* x, u64* t, u64* x2) {  // x = 1 / d modulo 2^(64 L), d odd; t, x2: L words of scratch
+    u64 inv = d[0];  // d * d = 1 (mod 8): three correct bits, doubled five times
+    for (int k = 0; k < 5; ++k) inv *= 2 - d[0] * inv;
+    x[0] = inv;
+    for (int have = 1; have < L; have *= 2) {
+        const int want = 2 * have < L ? 2 * have : L;
+        words_mul_lo(d, want, x, have, t, want);
+        u64 carry = 3;  // t <- 2 - t = ~t + 3
+        for (int k = 0; k < want; ++k) {
+            const u128 sum = (u128)(~t[k]) + carry;
+            t[k] = (u64)sum;
+            carry = (u64)(sum >> 64);
+        }
+        words_mul_lo(t, want, x, have, x2, want);
+        for (int k = 0; k < want; ++k) x[k] = x2[k];
+    }
+}
 template <int L>
 __device__ __forceinline__ Big<L> big_load(const u64* p) {
     Big<L> r;
@@ -312,8 +352,10 @@ struct ExactLP {
     int* cand;            // [max(n, m) + 1] columns whose key estimate is within 1e-9 of the best (pricing); near-tied rows (ratio test)
     u64* gamma;           // [n][2 limbs + 2] their exact weights
     u64* gamma_terms;     // [candidates][m + 1][2 limbs + 2] the terms of those sums (capacity: see the host)
-    u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b
+    u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b (first turn of a run); afterwards [m] Big: alpha~_i / D_odd
     int* x_bits;          // ... their bit bounds
+    u64* c_part;          // [n - n_art][ceil(m / 32)] Big: partial sums of c_B' N a_j of the pricing pass
+    int* c_bits;          // ... their bit bounds
 };
 
 // Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
@@ -430,6 +472,8 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
     __shared__ unsigned long long s_rank[EX_THREADS / WAVE];
     __shared__ int s_overflow;
     __shared__ u64 s_dinv[L];
+    __shared__ u64 s_c1[L];
+    __shared__ u64 s_words[3][L];  // operands and scratch of thread 0's word-array arithmetic
     __shared__ int s_shift;
     const int tid = threadIdx.x, T = blockDim.x;
     const int G = gridDim.x, block = blockIdx.x;
@@ -503,6 +547,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         n_removed = lp.resume[6];
     }
     int at_phase = phase, at_drive_row = drive_row, at_removed = n_removed;  // ... at the start of the current turn of the loop
+    bool have_xb = false;  // x~_B belongs to the current basis
     while (status == EX_RUNNING) {
         if (pivots[0] + pivots[1] >= lp.max_pivots) { status = EX_PIVOT_LIMIT; break; }
         at_phase = phase;
@@ -510,8 +555,23 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         at_removed = n_removed;
         const Big<L> D = big_load<L>(gD);
         const int D_bits = big_bits(D);
-        // ---- x~_B = N b: a thread per (row, chunk of 32 columns), then a thread per row over its chunks (same bounds as the serial loop) ----
-        {
+        // 1 / D_odd modulo 2^(64 L) (D = 2^shift D_odd): every exact quotient of this turn is a truncated product with it.  Every
+        // workgroup for itself: cheap, and no exchange is needed this way.
+        if (tid == 0) {
+            const int shift = big_ctz(D);
+            const Big<L> odd = big_sar(D, shift);
+            for (int k = 0; k < L; ++k) s_words[0][k] = odd.w[k];
+            words_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2]);
+            s_shift = shift;
+        }
+        __syncthreads();
+        const int shift = s_shift;
+        Big<L> Dinv;
+        for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
+        // ---- x~_B = N b: a thread per (row, chunk of 32 columns), then a thread per row over its chunks (same bounds as the serial loop).
+        //      Only on the first turn of a run: a pivot updates x~_B like one more column of N (below) -- recomputing it was 15 % of E226. ----
+        if (!have_xb) {
+            have_xb = true;
             constexpr int XC = 32;
             const int chunks = (m + XC - 1) / XC;
             for (long long pair = gtid; pair < (long long)m * chunks; pair += GT) {
@@ -568,6 +628,30 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
             }
             grid.sync();
+            stamp(9);
+            // Pass B in two steps as well (a thread per column over all m rows was the longest step of a pivot at 32 limbs: 472
+            // busy threads on E226): c_B' N a_j by (column, chunk of 32 rows), then a thread per column over its chunks.  The weight
+            // estimate is summed over the rows in order by that one thread: the same double as before, bit for bit.
+            constexpr int PC = 32;
+            const int pchunks = (m + PC - 1) / PC;
+            for (long long pair = gtid; pair < (long long)n_priced * pchunks; pair += GT) {
+                const int jj = (int)(pair / pchunks), c = (int)(pair - (long long)jj * pchunks);
+                if (lp.pos[lp.n_art + jj] >= 0) continue;
+                const size_t base = (size_t)jj * m;
+                Big<L> acc = big_from<L>(0);
+                int widest = 0;
+                for (int i = c * PC; i < min(m, (c + 1) * PC); ++i) {
+                    const int bi = lp.basis[i];
+                    const i64 cb = phase == 1 ? lp.cost1[bi] : lp.cost2[bi];
+                    if (cb != 0) {
+                        acc = big_add(acc, big_mul_small(big_load<L>(lp.price_a + (base + i) * L), cb));
+                        widest = max(widest, lp.price_bits[base + i] + small_bits(cb));
+                    }
+                }
+                big_store(lp.c_part + (size_t)pair * L, acc);
+                lp.c_bits[pair] = widest;
+            }
+            grid.sync();
             for (int j = lp.n_art + gtid; j < n; j += GT) {
                 double key = 0.0;
                 if (lp.pos[j] < 0) {
@@ -577,15 +661,11 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                     double sumsq = (double)lp.weight[j];
                     int widest = D_bits + small_bits(cj);
                     const size_t base = (size_t)(j - lp.n_art) * m;
-                    for (int i = 0; i < m; ++i) {
-                        const int bi = lp.basis[i];
-                        const i64 cb = phase == 1 ? lp.cost1[bi] : lp.cost2[bi];
-                        if (cb != 0) {
-                            ct = big_sub(ct, big_mul_small(big_load<L>(lp.price_a + (base + i) * L), cb));
-                            widest = max(widest, lp.price_bits[base + i] + small_bits(cb));
-                        }
-                        sumsq += lp.price_term[base + i];
+                    for (int c = 0; c < pchunks; ++c) {
+                        ct = big_sub(ct, big_load<L>(lp.c_part + ((size_t)(j - lp.n_art) * pchunks + c) * L));
+                        widest = max(widest, lp.c_bits[(size_t)(j - lp.n_art) * pchunks + c]);
                     }
+                    for (int i = 0; i < m; ++i) sumsq += lp.price_term[base + i];
                     flag_overflow(widest + log2_ceil(m + 1));
                     big_store(lp.ctil + (size_t)j * L, ct);
                     if (big_neg(ct)) {  // D > 0: the sign of c~_j is the sign of the relative cost
@@ -734,6 +814,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             }
             flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
             big_store(lp.alpha + (size_t)i * L, a);
+            big_store(lp.x_part + (size_t)i * L, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         stamp(5);
@@ -792,16 +873,17 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         // ---- the pivot: D' = alpha~_p, N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays ---------------------------
         Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
         const bool flip = big_neg(ap);  // (only a zero-level pivot can have a negative pivot element): keep D > 0
-        if (tid == 0) {  // (every workgroup for itself: the inverse of the odd part of D is cheap and needs no exchange this way)
-            const int shift = big_ctz(D);
-            const Big<L> inverse = big_inverse_odd(big_sar(D, shift));
-            for (int k = 0; k < L; ++k) s_dinv[k] = inverse.w[k];
-            s_shift = shift;
+        // With D = 2^s D_odd and u = 1 / D_odd modulo 2^(64 L):  (alpha~_p u) N_ik - (alpha~_i u) N_pk = 2^s N'_ik modulo 2^(64 L), so the
+        // new entry is that value shifted right by s -- known modulo 2^(64 L - s), sign-extended from there, and it must fit there.
+        // TWO truncated products per entry (the numerator first and then its product with u were three); alpha~_p u once per
+        // workgroup, alpha~_i u once per row (the alpha step).
+        if (tid == 0) {
+            for (int k = 0; k < L; ++k) s_words[0][k] = ap.w[k];
+            words_mul_lo(s_words[0], L, s_dinv, L, s_c1, L);
         }
         __syncthreads();
-        const int shift = s_shift;
-        Big<L> Dinv;
-        for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
+        Big<L> c1;
+        for (int k = 0; k < L; ++k) c1.w[k] = s_c1[k];
         const int ap_bits = big_bits(ap);
         // Will every new entry fit?  Decided from the bit lengths of the operands BEFORE anything is written (one more read of N:
         // microseconds beside the multiplications below), so that a run that does not fit stops with N, D and the basis as they
@@ -813,25 +895,40 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                                      big_bits(big_load<L>(lp.alpha + (size_t)i * L)) + big_bits(big_load<L>(lp.N + ((size_t)p * m + k) * L))) + 1 - (D_bits - 1);
             if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
         }
+        {
+            const int xp_bits = big_bits(big_load<L>(lp.xt + (size_t)p * L));
+            for (int i = gtid; i < m; i += GT) {
+                if (i == p) continue;
+                const int estimate = max(ap_bits + big_bits(big_load<L>(lp.xt + (size_t)i * L)), big_bits(big_load<L>(lp.alpha + (size_t)i * L)) + xp_bits) + 1 - (D_bits - 1);
+                if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
+            }
+        }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         for (int idx = gtid; idx < m * m; idx += GT) {
             const int i = idx / m, k = idx - i * m;
             if (i == p) continue;
-            const Big<L> ai = big_load<L>(lp.alpha + (size_t)i * L);
+            const Big<L> ri = big_load<L>(lp.x_part + (size_t)i * L);
             const Big<L> nik = big_load<L>(lp.N + (size_t)idx * L);
             const Big<L> npk = big_load<L>(lp.N + ((size_t)p * m + k) * L);
-            // The numerator only has to be right modulo 2^(64 L): with D = 2^s D_odd the quotient is known modulo 2^(64 L - s)
-            // (q D_odd = numerator / 2^s holds on the low 64 L - s bits), so it is sign-extended from there and must fit there.
-            const Big<L> numerator = big_sub(big_mul_lo(ap, nik), big_mul_lo(ai, npk));
-            Big<L> quotient = big_mul_lo(big_sar(numerator, shift), Dinv);
-            quotient = big_sar(big_shl(quotient, shift), shift);
+            Big<L> quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
             if (flip) quotient = big_negate(quotient);
             big_store(lp.N + (size_t)idx * L, quotient);
+        }
+        {   // x~_B = N b is one more column of N: x~'_i = (alpha~_p x~_i - alpha~_i x~_p) / D, row p stays
+            const Big<L> xp = big_load<L>(lp.xt + (size_t)p * L);
+            for (int i = gtid; i < m; i += GT) {
+                if (i == p) continue;
+                const Big<L> ri = big_load<L>(lp.x_part + (size_t)i * L);
+                Big<L> quotient = big_sar(big_sub(big_mul_lo(c1, big_load<L>(lp.xt + (size_t)i * L)), big_mul_lo(ri, xp)), shift);
+                if (flip) quotient = big_negate(quotient);
+                big_store(lp.xt + (size_t)i * L, quotient);
+            }
         }
         stamp(7);
         grid.sync();  // (row p is an operand of every other row above -- nobody may still be reading it)
         if (flip) {
             for (int k = gtid; k < m; k += GT) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
+            if (gtid == 0) big_store(lp.xt + (size_t)p * L, big_negate(big_load<L>(lp.xt + (size_t)p * L)));
             ap = big_negate(ap);
         }
         if (leader) {
@@ -1071,6 +1168,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), fresh);
         u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
+        u64* d_c_part = dalloc<u64>((size_t)std::max(1, n - n_art) * ((m + 31) / 32) * big, fresh);
+        int* d_c_bits = dalloc<int>((size_t)std::max(1, n - n_art) * ((m + 31) / 32), fresh);
         auto adopt = [&]() {  // the new width's buffers replace the previous width's
             RELP_HIP(hipStreamSynchronize(stream));
             for (void* q : width_owned) (void)hipFree(q);
@@ -1109,7 +1208,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
         if (d_prof) RELP_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_c_part, d_c_bits};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
@@ -1139,9 +1238,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         if (d_prof) {
             unsigned long long prof[16];
             RELP_HIP(hipMemcpy(prof, d_prof, sizeof(prof), hipMemcpyDeviceToHost));
-            static const char* names[] = {"x_B", "pricing", "arg-max + candidates", "exact weights", "tournament", "alpha", "ratio test", "update", "bookkeeping"};
+            static const char* names[] = {"x_B", "pricing pass B", "arg-max + candidates", "exact weights", "tournament", "alpha", "ratio test", "update", "bookkeeping", "pricing pass A"};
             fprintf(stderr, "[exact] %d limbs, grid %d, %d pivots, candidates %llu:", limbs, grid, out[1] + out[2], prof[12]);
-            for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 2.4e6);
+            for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 2.4e6);
             fprintf(stderr, "\n");
         }
         *status = out[0];
