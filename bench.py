@@ -390,7 +390,7 @@ def single_lp(args, ctx):
     # one record per rank (what each GPU did); the makespan is the max over ranks of the barrier-to-barrier time
     per_rank = batch.gather_records({"rank": rank, "solves": args.steps, "pivots": int(pivots), "busy_seconds": loop_seconds + certify_seconds,
                                      "elapsed_seconds": elapsed})
-    elapsed, pivots = batch.aggregate(elapsed, pivots, device="cuda" if distributed else None)
+    elapsed, pivots = batch.aggregate(elapsed, pivots, device=ctx["reduce_device"])
 
     in_flight = None
     if rank == 0 and world == 1 and not dense and not graph and not args.no_concurrency_probe:
@@ -657,7 +657,7 @@ def netlib_batch(args, ctx):
     elapsed_local = time.perf_counter() - start
     served = [e for e in entries if e.status == 0]
     pivots_local = sum(e.result.pivots_phase_one + e.result.pivots_phase_two for e in served)
-    elapsed, pivots = batch.aggregate(elapsed_local, pivots_local, device="cuda" if distributed else None)
+    elapsed, pivots = batch.aggregate(elapsed_local, pivots_local, device=ctx["reduce_device"])
     record = {"rank": rank, "tickets": len(served), "pivots": int(pivots_local), "solve_seconds": sum(e.result.solve_seconds for e in served),
               "elapsed_seconds": elapsed_local,
               "workers": [{"tickets": int(w.tickets), "pivots": int(w.pivots), "busy_seconds": w.busy_seconds, "idle_seconds": w.idle_seconds,
@@ -813,14 +813,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or os.environ.get("RELP_FORCE_DISTRIBUTED") == "1"  # the env switch exercises the RCCL path at N=1
+    # RELP_BENCH_SHARED_DEVICE=1 (tests on a 1-GPU box): every rank solves on device 0 and the ranks talk over gloo -- RCCL refuses two
+    # ranks on one device.  Everything above the collectives (barriers, MAX / SUM reductions, the shared ticket queue, the gathered
+    # records) is the code of the real multi-GPU run.
+    shared_device = os.environ.get("RELP_BENCH_SHARED_DEVICE") == "1"
+    if shared_device:
+        local_rank = 0
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if world > 1:
         # the exact certificate assembles its digits on host threads (up to 32 per process): share the cores between the ranks
         os.environ.setdefault("RELP_CERTIFY_THREADS", str(max(2, (os.cpu_count() or 8) // world)))
-    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "distributed": distributed, "cache": {}}
+    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "distributed": distributed, "cache": {},
+           "reduce_device": None if (shared_device or not distributed) else "cuda"}
     path = WORKLOADS[args.workload]
     batch_workload = path == "batch"
     graph = isinstance(path, tuple) and path[0] == "maxflow"

@@ -422,3 +422,38 @@ def test_bench_max_flow_workload_line(crash):
         assert line["config"]["pivots_per_solve"] < 1000
     else:
         assert line["config"]["pivots_per_solve"] > 8000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["25fv47", "netlib", "dense4096"])
+def test_bench_two_ranks_sharing_one_device(workload):
+    """The N > 1 logic of `bench.py` on a 1-GPU box: two ranks under `torch.distributed.run` as the driver launches them, both solving
+    on device 0 (RELP_BENCH_SHARED_DEVICE=1) and talking over gloo -- RCCL refuses two ranks on one device, everything above the
+    collectives (barriers, MAX / SUM reductions, the ticket queue shared through the store, the gathered records, rank 0's ONE
+    line) is the code the multi-GPU run executes."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELP_BENCH_SHARED_DEVICE="1")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--workload", workload]
+    out = subprocess.run(command, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints the one line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert "configs" not in line and "cpu_baseline" not in line  # N = 1 only
+    config = line["config"]
+    if workload == "netlib":
+        assert line["scaling"] == "strong"
+        assert len(config["tickets_per_rank"]) == 2 and sum(config["tickets_per_rank"]) == 2 * 45
+        assert all(t > 0 for t in config["tickets_per_rank"])  # one queue, both ranks drew from it
+        assert config["objectives_outside_reference_tolerance"] == []
+    else:
+        assert line["scaling"] == "weak"
+        assert [r["rank"] for r in config["per_rank"]] == [0, 1]
+        assert all(r["solves"] == 2 for r in config["per_rank"])
+        total = sum(r["pivots"] for r in config["per_rank"])
+        assert abs(line["value"] - total / config["makespan_s"]) <= 1e-6 * line["value"]  # whole-job aggregate over max-over-ranks time
