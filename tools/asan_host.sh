@@ -8,8 +8,9 @@ OUT=/tmp/relp_asan
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer"
 cd $ROOT/relp_amd/csrc
-for f in kernels.hip solver.hip certify.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OUT/${f%.hip}.o; done
-for f in capi.cpp mps.cpp; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o $OUT/${f%.cpp}.o; done
+rm -f $OUT/*.o
+for f in kernels.hip solver.hip certify.hip lu.hip exact.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OUT/${f%.hip}.o & done; wait
+for f in capi.cpp capi_bi.cpp batch.cpp mps.cpp; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o $OUT/${f%.cpp}.o & done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -o $OUT/librelp_amd.so $OUT/*.o
 cd $ROOT
 ASAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
