@@ -52,8 +52,14 @@ typedef enum relp_pivot_rule {
 /* The two `BasisInverse` implementations of the reference (carry/mod.rs:69-169), both resident on the device. */
 typedef enum relp_carry {
     RELP_CARRY_EXPLICIT = 0,   /* `BasisInverseRows` (carry/basis_inverse_rows.rs:21-229): explicit inverse, product-form update */
-    RELP_CARRY_LU = 1          /* `LUDecomposition` (carry/lower_upper/mod.rs:36-272): P B Q = L U, Forrest-Tomlin updates,
+    RELP_CARRY_LU = 1,         /* `LUDecomposition` (carry/lower_upper/mod.rs:36-272): P B Q = L U, Forrest-Tomlin updates,
                                   refactorisation every `refactor_period` updates */
+    RELP_CARRY_LU_INVERSE = 2  /* the same factorisation (`LUDecomposition::invert`, lower_upper/mod.rs:78-92, at every
+                                  refactorisation) applied through the sparse INVERSES of its two triangles: FTRAN / BTRAN
+                                  (mod.rs:180-237) are two sparse matrix-vector products each instead of two level-by-level
+                                  triangular solves, and the basis changes between refactorisations are kept in product form on
+                                  top (the etas of `BasisInverseRows`, basis_inverse_rows.rs:96-135, as at most `refactor_period`
+                                  columns) instead of Forrest-Tomlin row etas.  At most about 4300 rows. */
 } relp_carry;
 
 /* `Tableau::select_primal_pivot_row` (tableau/mod.rs:287-313). */

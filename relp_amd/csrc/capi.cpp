@@ -753,11 +753,11 @@ int32_t relp_get_record_json(const relp_handle* h, char* buffer, int32_t capacit
     static const char* presolve_states[] = {"off", "applied", "applied without the implied bounds beyond 126 bits", "dropped (did not fit the host model)"};
     out << "{\"name\": \"" << json_escaped(sv.form().name) << "\", \"presolve\": \"" << presolve_states[sv.form().presolve_state & 3] << "\", \"m\": " << md.nr_rows() << ", \"n\": " << md.nr_columns() << ", \"nnz\": " << nnz
         << ", \"device_rows\": " << d.m << ", \"artificials\": " << d.n_art << ", \"result\": \"" << kinds[r.kind >= 0 && r.kind <= 4 ? r.kind : 0]
-        << "\", \"carry\": \"" << (h->options.carry == RELP_CARRY_LU ? "lu" : "explicit") << "\", \"pivots_phase_one\": " << r.pivots_phase_one
+        << "\", \"carry\": \"" << (h->options.carry == RELP_CARRY_LU ? "lu" : h->options.carry == RELP_CARRY_LU_INVERSE ? "lu_inverse" : "explicit") << "\", \"pivots_phase_one\": " << r.pivots_phase_one
         << ", \"pivots_phase_two\": " << r.pivots_phase_two << ", \"polishes\": " << r.polishes << ", \"refactors\": " << r.refactors
         << ", \"solve_seconds\": " << r.solve_seconds << ", \"certify_seconds\": " << r.certify_seconds
         << ", \"pivots_per_second\": " << (r.solve_seconds > 0 ? (double)pivots / r.solve_seconds : 0.0)
-        << ", \"pricing_bytes_per_pivot\": " << st.price_bytes << ", \"inverse_bytes_per_pivot_bound\": " << (h->options.carry == RELP_CARRY_LU ? 0 : st.update_bytes)
+        << ", \"pricing_bytes_per_pivot\": " << st.price_bytes << ", \"inverse_bytes_per_pivot_bound\": " << (h->options.carry != RELP_CARRY_EXPLICIT ? 0 : st.update_bytes)
         << ", \"kernel_launches\": " << st.launches << ", \"certified\": " << (r.certified ? "true" : "false")
         << ", \"exact_repair_pivots\": " << r.exact_repair_pivots << ", \"objective\": ";
     if (r.kind == RELP_RESULT_FINITE_OPTIMUM) out << r.objective;

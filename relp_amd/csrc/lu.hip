@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
         lu.eta_of_pos[i] = -1;
         lu.eta_first[i] = -1;
         lu.eapp_len[i] = 0;
+        if (lu.pf_col_of) lu.pf_col_of[i] = -1;
     }
     for (int i = first; i < lu.max_updates * lu.ldt; i += stride) {
         lu.T[i] = 0.0;
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
         lu.state[LU_S_TOP] = 0;
         lu.state[LU_ETA_TOP] = 0;
         lu.state[LU_FLAGS] = 0;
+        lu.state[LU_PF_COUNT] = 0;
         lu.eta_start[0] = 0;
     }
 }
@@ -206,17 +208,110 @@ void build_tasks(const int* start, const int* idx, const double* val, const doub
     }
     close_chunk(out.levels, out.levels);
     if ((int)out.chunk.size() / 8 > LU_MAX_CHUNKS) throw std::runtime_error("LU task list: too many chunks");
+    // Wave summaries, the same in every slot of a wave (64 consecutive slots): bits 16-21 = "some row of this wave spans more than
+    // 2^j lanes", bit 22 = "some row of this wave has extra entries" -- what the products of the inverse-factor form would
+    // otherwise find out with seven ballots per slot (the level solves ask per level and keep their own ballots).
+    for (size_t w0 = 0; w0 < out.s_flags.size(); w0 += WAVE) {
+        const size_t w1 = std::min(out.s_flags.size(), w0 + WAVE);
+        int summary = 0;
+        for (size_t k = w0; k < w1; ++k) {
+            const int g = out.s_flags[k] & 0xff;
+            for (int j = 0; j < 6; ++j)
+                if (g > j) summary |= 1 << (16 + j);
+            if ((out.s_flags[k] >> 9) & 1) summary |= 1 << 22;
+        }
+        for (size_t k = w0; k < w1; ++k) out.s_flags[k] |= summary;
+    }
+}
+// The task list of one orientation of an INVERTED factor (lu.hpp): no levels and no chunks -- a product reads its input only, so
+// the rows are simply packed widest group first (which keeps every group aligned to its size without padding slots) and thread
+// t of the product takes the slots t, t + 1024, ...  Sizes are known up front: the arrays are sized once and filled in place
+// (the general builder above appends slot by slot: 0.21 ms per refactorisation of 25FV47 for the four inverse lists).
+void build_inverse_tasks(const int m, const int* start, const int* idx, const double* val, HostTasks& out) {
+    out.z_pos.clear(); out.z_dinv.clear(); out.s_lev.clear(); out.s_dinv.clear(); out.x_idx.clear(); out.x_val.clear();
+    out.col.resize(LU_TE);
+    out.val.resize(LU_TE);
+    out.levels = 1;
+    int count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < m; ++i) {
+        const int n = start[i + 1] - start[i];
+        if (n == 0) {
+            out.z_pos.push_back(i);
+            out.z_dinv.push_back(1.0);
+        } else {
+            count[group_log2(n)]++;
+        }
+    }
+    int first_of[8];  // first slot of the rows with group size 2^g, g = 6 first
+    int slots = 0;
+    for (int g = 6; g >= 0; --g) {
+        first_of[g] = slots;
+        slots += count[g] << g;
+    }
+    out.s_pos.assign(slots, 0);
+    out.s_flags.assign(slots, 0);
+    out.s_xstart.assign(slots, 0);
+    out.s_xn.assign(slots, 0);
+    for (int e = 0; e < LU_TE; ++e) {
+        out.col[e].assign(slots, 0);
+        out.val[e].assign(slots, 0.0);
+    }
+    for (int i = 0; i < m; ++i) {
+        const int n = start[i + 1] - start[i];
+        if (n == 0) continue;
+        const int g = group_log2(n), G = 1 << g;
+        const int first = first_of[g];
+        first_of[g] += G;
+        const int inline_n = std::min(n, LU_TE * G);
+        const int xn = n - inline_n, xstart = (int)out.x_idx.size();
+        for (int j = 0; j < G; ++j) {
+            out.s_pos[first + j] = i;
+            out.s_flags[first + j] = g | ((j == G - 1) ? 1 << 8 : 0) | (xn > 0 ? 1 << 9 : 0);
+            out.s_xstart[first + j] = xstart;
+            out.s_xn[first + j] = xn;
+        }
+        for (int e = 0; e < inline_n; ++e) {  // slot j of the group takes the entries j, j + G, j + 2 G, ...
+            out.col[e / G][first + e % G] = idx[start[i] + e];
+            out.val[e / G][first + e % G] = val[start[i] + e];
+        }
+        for (int e = inline_n; e < n; ++e) {
+            out.x_idx.push_back(idx[start[i] + e]);
+            out.x_val.push_back(val[start[i] + e]);
+        }
+    }
+    out.chunk.assign({0, slots, 0, 1, 1, 0, 0, 0});
+    for (int w0 = 0; w0 < slots; w0 += WAVE) {  // the wave summaries (see build_tasks)
+        const int w1 = std::min(slots, w0 + WAVE);
+        int summary = 0;
+        for (int k = w0; k < w1; ++k) {
+            const int g = out.s_flags[k] & 0xff;
+            for (int j = 0; j < 6; ++j)
+                if (g > j) summary |= 1 << (16 + j);
+            if ((out.s_flags[k] >> 9) & 1) summary |= 1 << 22;
+        }
+        for (int k = w0; k < w1; ++k) out.s_flags[k] |= summary;
+    }
 }
 }  // namespace
 
-bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
+bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t stream, bool inverse_factors) {
+    // The inverse-factor form uploads L^-1 and U^-1 through the same task lists (every row in one level; lu.hpp).
+    thread_local HostLU inverted;
+    if (inverse_factors) {
+        const size_t limit = std::max<size_t>(1u << 16, 64 * (size_t)(factors.nnz_l() + factors.nnz_u() + factors.m));
+        if (!lu_invert_factors(factors, std::min<size_t>(limit, (size_t)LU_MAX_CHUNKS * LU_CHUNK_SLOTS * LU_TE / 4), inverted))
+            throw std::runtime_error("the inverse-factor carry: L^-1 and U^-1 of this basis are too dense (use the LU or the explicit carry)");
+        nnz_l_inverse = inverted.nnz_l();
+        nnz_u_inverse = inverted.nnz_u();
+    }
+    const HostLU& f = inverse_factors ? inverted : factors;
     const int m = f.m;
     const size_t nl = (size_t)f.nnz_l(), nu = (size_t)f.nnz_u();
     if (max_updates < 1) max_updates = 1;
     if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
     // The layout depends on capacities only, so that the device addresses (and a captured hipGraph that holds them) survive
     // a refactorisation; it changes when a factor outgrows its capacity (or m / the update capacity change).
-    bool layout_changed = m != d_.m || max_updates != d_.max_updates;
+    bool layout_changed = m != d_.m || max_updates != d_.max_updates || (inverse_factors ? 1 : 0) != d_.inverse_factors;
     if (layout_changed) cap_l_ = cap_u_ = 0;
     if (nl > cap_l_ || cap_l_ == 0) { cap_l_ = nl + nl / 2 + 256; layout_changed = true; }
     if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
@@ -265,17 +360,26 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     // list does at Netlib sizes, 8.5 -> 11.9 ms over the 75 refactorisations of 25FV47.)
     thread_local HostTasks task_storage[4];  // (per calling thread: handles of a batch refactorise concurrently; capacity is kept)
     HostTasks* tasks = task_storage;
-    build_tasks(f.l_start.data(), f.l_col.data(), f.l_val.data(), nullptr, f.lev_start[0], f.lev_row[0], tasks[0]);
-    build_tasks(f.u_start.data(), f.u_col.data(), f.u_val.data(), f.diag.data(), f.lev_start[1], f.lev_row[1], tasks[1]);
-    build_tasks(ucs.data(), ucrow.data(), ucval.data(), f.diag.data(), f.lev_start[2], f.lev_row[2], tasks[2]);
-    build_tasks(lcs.data(), lcrow.data(), lcval.data(), nullptr, f.lev_start[3], f.lev_row[3], tasks[3]);
+    if (inverse_factors) {  // (U^-1 carries its diagonal as entries)
+        build_inverse_tasks(m, f.l_start.data(), f.l_col.data(), f.l_val.data(), tasks[0]);
+        build_inverse_tasks(m, f.u_start.data(), f.u_col.data(), f.u_val.data(), tasks[1]);
+        build_inverse_tasks(m, ucs.data(), ucrow.data(), ucval.data(), tasks[2]);
+        build_inverse_tasks(m, lcs.data(), lcrow.data(), lcval.data(), tasks[3]);
+    } else {
+        build_tasks(f.l_start.data(), f.l_col.data(), f.l_val.data(), nullptr, f.lev_start[0], f.lev_row[0], tasks[0]);
+        build_tasks(f.u_start.data(), f.u_col.data(), f.u_val.data(), f.diag.data(), f.lev_start[1], f.lev_row[1], tasks[1]);
+        build_tasks(ucs.data(), ucrow.data(), ucval.data(), f.diag.data(), f.lev_start[2], f.lev_row[2], tasks[2]);
+        build_tasks(lcs.data(), lcrow.data(), lcval.data(), nullptr, f.lev_start[3], f.lev_row[3], tasks[3]);
+    }
     mark(2);
     size_t max_slots = 0;
     for (int k = 0; k < 4; ++k) max_slots = std::max(max_slots, tasks[k].s_pos.size());
     if (max_slots + 1024 > cap_slots_ || (size_t)m + 1024 > cap_slots_ || cap_slots_ == 0 || layout_changed) {
         if (max_slots + 1024 > cap_slots_ || (size_t)m + 1024 > cap_slots_ || cap_slots_ == 0) layout_changed = true;
         max_slots = std::max(max_slots, (size_t)m);
-        cap_slots_ = std::max(cap_slots_, ((max_slots + max_slots / 2 + 2048) + 1023) & ~size_t(1023));
+        // (the inverse-factor lists are four times longer and every per-slot array is uploaded up to the stride: a tighter margin)
+        const size_t margin = inverse_factors ? max_slots / 4 + 1024 : max_slots / 2 + 2048;
+        cap_slots_ = std::max(cap_slots_, ((max_slots + margin) + 1023) & ~size_t(1023));
     }
     const int stride = (int)cap_slots_;
     // ---- uploaded prefix ----------------------------------------------------------------------------------------------
@@ -320,6 +424,9 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     const size_t o_eta_mf = c.take<double>((size_t)max_updates * ldt), o_eta_of = c.take<int>(m), o_eta_first = c.take<int>(m), o_eta_prev = c.take<int>(max_updates + 1);
     const size_t o_eapp_len = c.take<int>(m), o_eapp_eta = c.take<int>(app), o_eapp_val = c.take<double>(app);
     const size_t o_spike = c.take<double>(m);
+    const size_t pf_ld = ((size_t)m + 15) & ~(size_t)15;
+    const size_t o_pf_m = c.take<double>(inverse_factors ? pf_ld * max_updates : 0);
+    const size_t o_pf_slot = c.take<int>(max_updates), o_pf_col_of = c.take<int>(m);
     const size_t o_state = c.take<int>(LU_STATE_WORDS);
     const size_t device_bytes = c.offset;
     {
@@ -376,14 +483,16 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
         put_i(to[k].x_idx, t.x_idx);
         put_d(to[k].x_val, t.x_val);
     }
-    put_i(o_lrcol, f.l_col);
-    put_d(o_lrval, f.l_val);
-    put_i(o_lcrow, lcrow);
-    put_d(o_lcval, lcval);
-    put_i(o_urcol, f.u_col);
-    put_d(o_urval, f.u_val);
-    put_i(o_ucrow, ucrow);
-    put_d(o_ucval, ucval);
+    if (!inverse_factors) {  // (the plain orientations serve the Forrest-Tomlin update only)
+        put_i(o_lrcol, f.l_col);
+        put_d(o_lrval, f.l_val);
+        put_i(o_lcrow, lcrow);
+        put_d(o_lcval, lcval);
+        put_i(o_urcol, f.u_col);
+        put_d(o_urval, f.u_val);
+        put_i(o_ucrow, ucrow);
+        put_d(o_ucval, ucval);
+    }
     // A small factor goes over in ONE copy, gaps and unused capacity included: every hipMemcpyAsync costs 5-10 us of host time,
     // which at Netlib sizes is more than the bytes do.  A large one copies the headers at once and each entry array up to what
     // is used (the capacities are 1.5 x larger, the ELL rows m wide).
@@ -401,14 +510,16 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
             copy(to[k].x_idx, tasks[k].x_idx.size() * sizeof(int));
             copy(to[k].x_val, tasks[k].x_val.size() * sizeof(double));
         }
-        copy(o_lrcol, nl * sizeof(int));
-        copy(o_lrval, nl * sizeof(double));
-        copy(o_lcrow, nl * sizeof(int));
-        copy(o_lcval, nl * sizeof(double));
-        copy(o_urcol, nu * sizeof(int));
-        copy(o_urval, nu * sizeof(double));
-        copy(o_ucrow, nu * sizeof(int));
-        copy(o_ucval, nu * sizeof(double));
+        if (!inverse_factors) {
+            copy(o_lrcol, nl * sizeof(int));
+            copy(o_lrval, nl * sizeof(double));
+            copy(o_lcrow, nl * sizeof(int));
+            copy(o_lcval, nl * sizeof(double));
+            copy(o_urcol, nu * sizeof(int));
+            copy(o_urval, nu * sizeof(double));
+            copy(o_ucrow, nu * sizeof(int));
+            copy(o_ucval, nu * sizeof(double));
+        }
     }
     mark(4);
     if (time_parts && ++uploads % 25 == 0)
@@ -440,6 +551,11 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     d.spike = D(o_spike);
     d.state = I(o_state);
     d.task_stride = stride;
+    d.inverse_factors = inverse_factors ? 1 : 0;
+    d.pf_M = inverse_factors ? D(o_pf_m) : nullptr;
+    d.pf_ld = (int)pf_ld;
+    d.pf_slot = I(o_pf_slot);
+    d.pf_col_of = I(o_pf_col_of);
     for (int k = 0; k < 4; ++k) {
         LuTasks& t = d.tasks[k];
         auto GI = [&](size_t o) { return (lu_gptr_i32) reinterpret_cast<const int*>(dev_ + o); };
@@ -453,26 +569,31 @@ bool LuFactors::upload(const HostLU& f, int max_updates, hipStream_t stream) {
     }
     d_ = d;
     hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_);
-    nnz_l = (long long)nl;
-    nnz_u = (long long)nu;
-    lu_depths(f, &depth_l, &depth_u);
+    nnz_l = factors.nnz_l();
+    nnz_u = factors.nnz_u();
+    lu_depths(factors, &depth_l, &depth_u);
     return layout_changed;
 }
 
 // LDS of the solve kernels: the two vectors (16 bytes per row), the mask of the replaced positions, one count per 64 rows for
 // the ordered compactions, reductions, and the trailing block T with its four slot vectors.
-static size_t lu_lds_fixed_bytes(int m, int max_updates) {
+static size_t lu_lds_fixed_bytes(int m, int max_updates, bool inverse_factors = false) {
     const size_t mm = (size_t)((m + 1) & ~1);
+    if (inverse_factors)  // four vectors (a product is out of place, BTRAN has two right-hand sides), no T / MF; the per-wave partials of M' r
+        return 4 * mm * sizeof(double) + ((size_t)(m + 31) / 32 + 2) * sizeof(int) + ((size_t)(m + 63) / 64 + 4) * sizeof(int) + 64 * sizeof(double) +
+               ((size_t)4 * LU_MAX_SLOTS + (size_t)2 * (LU_THREADS / 64) * LU_MAX_SLOTS) * sizeof(double) + 256;
     return 2 * mm * sizeof(double) + ((size_t)(m + 31) / 32 + 2) * sizeof(int) + ((size_t)(m + 63) / 64 + 4) * sizeof(int) + 64 * sizeof(double) +
            ((size_t)2 * max_updates * (max_updates + 1) + 4 * LU_MAX_SLOTS) * sizeof(double) + 256;
 }
 constexpr size_t LU_LDS_TOTAL = 160 * 1024 - 1024;  // what a kernel may ask for (static LDS of the fused kernel comes on top)
-static size_t lu_lds_bytes_for(int m, int max_updates) { return std::min(LU_LDS_TOTAL - 2048, lu_lds_fixed_bytes(m, max_updates)); }
-size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_.m, d_.max_updates); }
-bool lu_fits_lds(int m, int max_updates) {
+static size_t lu_lds_bytes_for(const DeviceLU& lu) {
+    return std::min(LU_LDS_TOTAL - 2048, lu_lds_fixed_bytes(lu.m, lu.max_updates, lu.inverse_factors != 0));
+}
+size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_); }
+bool lu_fits_lds(int m, int max_updates, bool inverse_factors) {
     if (max_updates < 1) max_updates = 1;
     if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
-    return lu_lds_fixed_bytes(m, max_updates) <= LU_LDS_TOTAL - 2048;
+    return lu_lds_fixed_bytes(m, max_updates, inverse_factors) <= LU_LDS_TOTAL - 2048;
 }
 
 // =====================================================================================================
@@ -506,6 +627,9 @@ struct LuShared {
     volatile lds_f64* xt1;
     volatile lds_f64* st0;   // BTRAN: right-hand sides of the trailing solve
     volatile lds_f64* st1;
+    volatile lds_f64* x2;    // inverse-factor form only: the other two vectors of the out-of-place products
+    volatile lds_f64* x3;
+    volatile lds_f64* pfpart;  // ... and [2][waves][LU_MAX_SLOTS] per-wave partial sums of M' r
     unsigned long long* dbg;  // diagnostic builds (-DRELP_STAMPS): per-segment cycle sums; nullptr otherwise
     unsigned long long* t_prev;
 };
@@ -518,21 +642,29 @@ __device__ __forceinline__ void lu_stamp(const LuShared& sh, int k) {
     }
 #endif
 }
-__device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max_updates) {
+__device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max_updates, bool inverse_factors = false) {
     const int mm = (m + 1) & ~1;
+    if (inverse_factors) max_updates = 0;  // no T, no MF
     lds_i8* smem = (lds_i8*)smem_generic;
     LuShared s;
     lds_f64* x0 = (lds_f64*)smem;
     lds_f64* x1 = x0 + mm;
-    lds_f64* red = x1 + mm;
+    lds_f64* x2 = inverse_factors ? x1 + mm : x1;
+    lds_f64* x3 = inverse_factors ? x2 + mm : x1;
+    lds_f64* red = x3 + mm;
     lds_f64* T = red + 64;
     lds_f64* MF = T + max_updates * (max_updates + 1);
     lds_f64* xt0 = MF + max_updates * (max_updates + 1);
     lds_f64* xt1 = xt0 + LU_MAX_SLOTS;
     lds_f64* st0 = xt1 + LU_MAX_SLOTS;
     lds_f64* st1 = st0 + LU_MAX_SLOTS;
+    lds_f64* pfpart = st1 + LU_MAX_SLOTS;
+    lds_f64* after = inverse_factors ? pfpart + 2 * (LU_THREADS / 64) * LU_MAX_SLOTS : pfpart;
     s.x0 = x0;
     s.x1 = x1;
+    s.x2 = x2;
+    s.x3 = x3;
+    s.pfpart = pfpart;
     s.red = (double*)red;
     s.T = T;
     s.MF = MF;
@@ -540,7 +672,7 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
     s.xt1 = xt1;
     s.st0 = st0;
     s.st1 = st1;
-    lds_u32* mask = (lds_u32*)(st1 + LU_MAX_SLOTS);
+    lds_u32* mask = (lds_u32*)after;
     s.mask = mask;
     s.group_count = (int*)(mask + (((m + 31) / 32 + 2 + 1) & ~1));
     s.dbg = nullptr;
@@ -553,11 +685,16 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ bool lu_masked(const LuShared& sh, int pos) { return (sh.mask[pos >> 5] >> (pos & 31)) & 1u; }
 // x0 (x1) <- 0, T staged from global, the mask of the replaced positions built.  Ends with a barrier.
+template <bool INV>
 __device__ __forceinline__ void lu_clear(const DeviceLU& lu, const LuShared& sh, int n_updates, bool two) {
     const int m = lu.m;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         sh.x0[i] = 0.0;
         if (two) sh.x1[i] = 0.0;
+    }
+    if constexpr (INV) {  // no trailing block, no etas, no masked positions
+        __syncthreads();
+        return;
     }
     for (int i = threadIdx.x; i < (m + 31) / 32; i += blockDim.x) sh.mask[i] = 0u;
     for (int i = threadIdx.x; i < n_updates * lu.ldt; i += blockDim.x) {
@@ -613,6 +750,7 @@ struct LuSlot {
     int z_pos;
     double z_dinv;
     int nz, n_chunks, c_end, l0, l1, l_tail;  // (the same in every lane; read through readfirstlane)
+    int n_slots;
 };
 __device__ __forceinline__ LuSlot lu_load_slot(const DeviceLU& lu, const int sched, const int k) {
     const LuTasks& tk = lu.tasks[sched];
@@ -635,7 +773,20 @@ __device__ __forceinline__ LuSlot lu_load_slot(const DeviceLU& lu, const int sch
     r.l0 = tk.counts[LU_CNT_C0_L0];
     r.l1 = tk.counts[LU_CNT_C0_L1];
     r.l_tail = tk.counts[LU_CNT_C0_TAIL];
+    r.n_slots = tk.counts[LU_CNT_SLOTS];
     return r;
+}
+// (only what a product needs of a slot: no solve counts, no diagonal)
+__device__ __forceinline__ void lui_load_slot(const DeviceLU& lu, const int sched, const int k, LuSlot& r) {
+    const LuTasks& tk = lu.tasks[sched];
+    const int stride = lu.task_stride;
+    r.pos = tk.s_pos[k];
+    r.flags = tk.s_flags[k];
+#pragma unroll
+    for (int e = 0; e < LU_TE; ++e) {
+        r.col[e] = tk.s_col[(size_t)e * stride + k];
+        r.val[e] = tk.s_val[(size_t)e * stride + k];
+    }
 }
 
 // In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i]  for every row i of one triangular factor in one orientation
@@ -777,6 +928,198 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
     if (n_chunks == 0) __syncthreads();
 }
 
+// ---- the inverse-factor form (lu.hpp): products with L^-1 / U^-1 and the product-form updates on top ------------------------------
+// out <- A in for one of the four task lists (`sched`: 0 L^-1 by rows, 1 U^-1 by rows, 2 U^-1 by columns, 3 L^-1 by columns), OUT OF
+// PLACE: every row reads `in` only, so there is no level loop and no barrier between the chunks -- one pass over the slots, the
+// same packed slots and DPP group sums as the solves.  UNIT: the factor has an implied unit diagonal (the L lists); the U lists
+// carry their diagonal as entries.  in0 / in1 complete (barrier) on entry; ends with a barrier.
+template <int NRHS, bool UNIT>
+__device__ __forceinline__ void lui_apply(const DeviceLU& lu, const int sched, const LuSlot& first_record, volatile lds_f64* in0,
+                                          volatile lds_f64* in1, volatile lds_f64* out0, volatile lds_f64* out1) {
+    const LuTasks& tk = lu.tasks[sched];
+    const int nz = __builtin_amdgcn_readfirstlane(first_record.nz);
+    const int n_slots = __builtin_amdgcn_readfirstlane(first_record.n_slots);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & (WAVE - 1);
+    if (UNIT) {  // rows without entries: a copy
+        if (tid < nz) {
+            out0[first_record.z_pos] = in0[first_record.z_pos];
+            if (NRHS == 2) out1[first_record.z_pos] = in1[first_record.z_pos];
+        }
+        for (int z = tid + T; z < nz; z += T) {
+            const int p = tk.z_pos[z];
+            out0[p] = in0[p];
+            if (NRHS == 2) out1[p] = in1[p];
+        }
+    }
+    // Thread t takes the slots t, t + T, t + 2 T, ...: the chunk boundaries of the level solves mean nothing here (a row's slots
+    // never straddle a wave, and T is a multiple of the wave).  FOUR records are requested before the first is used -- the passes
+    // over a factor are a handful, and each was a global round trip of its own when they were fetched one by one (7-12 k cycles
+    // per product on 25FV47 against ~4 k).  Slots past the end are padding up to the stride: level 0x7fffffff, no flags, zeros.
+    constexpr int BATCH = 4;
+    const int rounds = (n_slots + T - 1) / T;
+    const int padding_slot = lu.task_stride - 1;
+    auto work = [&](const LuSlot& rec, const int k) {
+        const int flags = rec.flags;  // (padding slots: 0 -- no group, no write)
+        const int g = flags & 0xff;
+        const int summary = __builtin_amdgcn_readfirstlane(flags);  // the host's wave summary (build_tasks)
+        const unsigned gbits = (unsigned)(summary >> 16) & 63u;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int e = 0; e < LU_TE; ++e) s0 += rec.val[e] * in0[rec.col[e]];
+        if (NRHS == 2) {
+#pragma unroll
+            for (int e = 0; e < LU_TE; ++e) s1 += rec.val[e] * in1[rec.col[e]];
+        }
+        if ((summary >> 22) & 1) {  // rows of more than 64 LU_TE entries: the rest from the arena, by the lanes of the row's wave
+            if ((flags >> 9) & 1) {
+                const int xs = tk.s_xstart[k], xn = tk.s_xn[k];
+                for (int e = lane; e < xn; e += WAVE) {
+                    const int c = tk.x_idx[xs + e];
+                    const double v = tk.x_val[xs + e];
+                    s0 += v * in0[c];
+                    if (NRHS == 2) s1 += v * in1[c];
+                }
+            }
+        }
+        s0 = group_sum_by(s0, g, gbits);
+        if (NRHS == 2) s1 = group_sum_by(s1, g, gbits);
+        if ((flags >> 8) & 1) {
+            const int pos = rec.pos;
+            out0[pos] = UNIT ? in0[pos] + s0 : s0;
+            if (NRHS == 2) out1[pos] = UNIT ? in1[pos] + s1 : s1;
+        }
+    };
+    for (int r0 = 0; r0 < rounds; r0 += BATCH) {
+        LuSlot rec[BATCH];
+        int slot[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            slot[u] = (r0 + u < rounds) ? (r0 + u) * T + tid : padding_slot;
+            if (r0 + u == 0) rec[u] = first_record;
+            else lui_load_slot(lu, sched, slot[u], rec[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) work(rec[u], slot[u]);
+    }
+    __syncthreads();
+}
+
+// alpha <- M y in place on the position-space vector x0 (component of basis slot s at x0[colpos[s]]):
+//   alpha_s = y_s + sum_c (M[s][c] - [s == slot_c]) y[slot_c].
+// The k operands y[slot_c] are read first (xt0), then every row adds its k terms -- rows are independent.  Ends with a barrier.
+__device__ __forceinline__ void lui_apply_updates_forward(const DeviceLU& lu, const LuShared& sh, const int k) {
+    if (k <= 0) return;
+    const int m = lu.m;
+    const gptr_f64 M = (gptr_f64)lu.pf_M;
+    const gptr_i32 slot_of = (gptr_i32)lu.pf_slot;
+    if ((int)threadIdx.x < k) sh.xt0[threadIdx.x] = sh.x0[lu.colpos[slot_of[threadIdx.x]]];
+    __syncthreads();
+    for (int s = threadIdx.x; s < m; s += blockDim.x) {
+        double acc = 0.0;
+        for (int c0 = 0; c0 < k; c0 += 8) {  // (eight loads in flight: one after the other they were a round trip each)
+            double mc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mc[u] = (c0 + u < k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < k) acc += (mc[u] - (slot_of[c0 + u] == s ? 1.0 : 0.0)) * sh.xt0[c0 + u];
+        }
+        const int pos = lu.colpos[s];
+        sh.x0[pos] = sh.x0[pos] + acc;
+    }
+    __syncthreads();
+}
+
+// r <- r M in place on the position-space vectors x0 (x1), basis slot s at x[colpos[s]]:  only the k components at the kept slots
+// change,  r'[slot_c] = sum_s r_s M[s][c].  Every thread forms its rows' share of the k sums, a wave reduces them by DPP, the
+// sixteen partials per sum are added in wave order by one thread (fixed order: deterministic).  Ends with a barrier.
+template <int NRHS>
+__device__ __forceinline__ void lui_apply_updates_backward(const DeviceLU& lu, const LuShared& sh, const int k) {
+    if (k <= 0) return;
+    const int m = lu.m;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, nwaves = blockDim.x / WAVE;
+    const gptr_f64 M = (gptr_f64)lu.pf_M;
+    for (int c0 = 0; c0 < k; c0 += 8) {  // eight sums at a time: their loads in flight together, their wave reductions back to back
+        double p0[8], p1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p0[u] = p1[u] = 0.0;
+        for (int s = threadIdx.x; s < m; s += blockDim.x) {
+            const int pos = lu.colpos[s];
+            const double r0 = sh.x0[pos], r1 = NRHS == 2 ? sh.x1[pos] : 0.0;
+            double mc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mc[u] = (c0 + u < k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                p0[u] += r0 * mc[u];
+                if (NRHS == 2) p1[u] += r1 * mc[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + u >= k) break;  // wave-uniform
+            const double w0 = wave_sum(p0[u]);
+            const double w1 = NRHS == 2 ? wave_sum(p1[u]) : 0.0;
+            if (lane == LAST) {
+                sh.pfpart[wave * LU_MAX_SLOTS + c0 + u] = w0;
+                if (NRHS == 2) sh.pfpart[(nwaves + wave) * LU_MAX_SLOTS + c0 + u] = w1;
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < k) {
+        const int c = threadIdx.x;
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < nwaves; ++w) {
+            t0 += sh.pfpart[w * LU_MAX_SLOTS + c];
+            if (NRHS == 2) t1 += sh.pfpart[(nwaves + w) * LU_MAX_SLOTS + c];
+        }
+        const int pos = lu.colpos[lu.pf_slot[c]];
+        sh.x0[pos] = t0;
+        if (NRHS == 2) sh.x1[pos] = t1;
+    }
+    __syncthreads();
+}
+
+// The eta of a pivot on basis slot p with the FTRAN result alpha (per basis slot, global memory) folded into the kept columns:
+//   M <- E M,  E = I - (alpha - e_p) e_p' / alpha_p:   M[s][c] -= (alpha_s - [s == p]) M[p][c] / alpha_p,
+// and a new kept column for p when it had none (M[:, p] was e_p).  Row p of the old M is read first (st0).
+__device__ __forceinline__ void lui_fold_eta(const DeviceLU& lu, const LuShared& sh, const int k, const int p, const double* alpha,
+                                             const double alpha_p) {
+    const int m = lu.m;
+    typedef __attribute__((address_space(1))) double* gmut_f64;
+    const gmut_f64 M = (gmut_f64)lu.pf_M;
+    const int have = lu.pf_col_of[p];
+    const int k_new = have >= 0 ? k : k + 1;
+    if ((int)threadIdx.x < k_new) {
+        const int c = threadIdx.x;
+        sh.st0[c] = (c < k) ? M[(size_t)c * lu.pf_ld + p] : 1.0;  // (the new column starts as e_p)
+    }
+    __syncthreads();
+    const double inv = 1.0 / alpha_p;
+    for (int s = threadIdx.x; s < m; s += blockDim.x) {
+        const double factor = (alpha[s] - (s == p ? 1.0 : 0.0)) * inv;
+        for (int c0 = 0; c0 < k_new; c0 += 8) {
+            double old[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) old[u] = (c0 + u < k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : (s == p ? 1.0 : 0.0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * sh.st0[c0 + u];
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (have < 0) {
+            lu.pf_slot[k] = p;
+            lu.pf_col_of[p] = k;
+        }
+        lu.state[LU_PF_COUNT] = k_new;
+        lu.state[LU_N_UPDATES] = lu.state[LU_N_UPDATES] + 1;
+    }
+    __syncthreads();
+}
+
 // ---- eta files, applied in parallel -------------------------------------------------------------------------------------------
 // FTRAN direction (eta_file.rs:72-105): for each update j in order  v[t_j] -= sum_k r_jk v[k].  With V_j the value of v[t_j]
 // right after step j:  V_j = base_j - sum_{i<j} MF[j][i] V_i,  base_j = (v[t_j] unless an earlier eta pivots there) - the dot
@@ -861,11 +1204,21 @@ __device__ __forceinline__ void lu_etas_backward(const DeviceLU& lu, const LuSha
 
 // FTRAN on the vector in sh.x0 (position space, P already applied): L solve, etas, [spike], U solve (trailing block by one
 // wave, spike contributions, then the base rows with the replaced positions held at zero).  Ends with a barrier.
+template <bool INV>
 __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
                                                double* spike_out, const LuSlot& lower_record) {
     (void)epoch;
     const int m = lu.m;
     const LuSlot upper_record = lu_load_slot(lu, 1, threadIdx.x);  // (lands while L and the etas are done)
+    if constexpr (INV) {  // x1 <- L^-1 x0, x0 <- U^-1 x1, then the product-form updates (x1 is scratch)
+        lui_apply<1, true>(lu, 0, lower_record, sh.x0, sh.x0, sh.x1, sh.x1);
+        lu_stamp(sh, 2);
+        lui_apply<1, false>(lu, 1, upper_record, sh.x1, sh.x1, sh.x0, sh.x0);
+        lu_stamp(sh, 3);
+        lui_apply_updates_forward(lu, sh, lu.state[LU_PF_COUNT]);
+        lu_stamp(sh, 4);
+        return;
+    }
     lu_solve_tasks<1, false>(lu, sh, 0, lower_record);
     lu_stamp(sh, 2);
     lu_etas_forward(lu, sh, n_updates);
@@ -913,11 +1266,21 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
 
 // BTRAN on the vectors in sh.x0 (and sh.x1), position space with Q applied.  `after_upper` runs between the U solve and the
 // etas, when x0 = (e_t' U^-1) for a unit input (the Forrest-Tomlin row comes from there).  Ends with a barrier.
-template <int NRHS, class AfterUpper>
+template <int NRHS, bool INV, class AfterUpper>
 __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
                                                AfterUpper after_upper, const LuSlot& upper_record) {
     (void)epoch;
     const LuSlot lower_record = lu_load_slot(lu, 3, threadIdx.x);  // (lands while U' and the etas are done)
+    if constexpr (INV) {  // r <- r M, then (x2, x3) <- (x0, x1) U^-1, (x0, x1) <- (x2, x3) L^-1
+        lui_apply_updates_backward<NRHS>(lu, sh, lu.state[LU_PF_COUNT]);
+        lu_stamp(sh, 7);
+        lui_apply<NRHS, false>(lu, 2, upper_record, sh.x0, sh.x1, sh.x2, sh.x3);
+        lu_stamp(sh, 8);
+        after_upper();
+        lui_apply<NRHS, true>(lu, 3, lower_record, sh.x2, sh.x3, sh.x0, sh.x1);
+        lu_stamp(sh, 10);
+        return;
+    }
     if (n_updates > 0) {
         // the replaced positions leave the base solve: their right-hand sides wait in xt0 / xt1, their components read as zero
         if ((int)threadIdx.x < n_updates) {
@@ -1150,14 +1513,15 @@ __device__ __forceinline__ void lu_ft_update_block(const DeviceLU& lu, const LuS
 // stand-alone kernels (fine-grained `BasisInverse` operations)
 // =====================================================================================================
 // dense != nullptr: dense right-hand side in original row order; else the sparse (rows, vals)
+template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const int* rows, const double* vals, int nnz,
                                                                const double* dense, double* out, int keep_spike) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(lu, sh, n_updates, false);
+    lu_clear<INV>(lu, sh, n_updates, false);
     if (dense) {
         for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = dense[i];
     } else {
@@ -1165,18 +1529,19 @@ __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const
     }
     __syncthreads();
     int epoch = 0;
-    lu_ftran_block(lu, sh, n_updates, epoch, keep_spike ? lu.spike : nullptr, lower_record);
+    lu_ftran_block<INV>(lu, sh, n_updates, epoch, keep_spike ? lu.spike : nullptr, lower_record);
     for (int s = threadIdx.x; s < m; s += blockDim.x) out[s] = sh.x0[lu.colpos[s]];
 }
 
+template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const int* slots, const double* vals, int nnz,
                                                                const double* dense, double* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(lu, sh, n_updates, false);
+    lu_clear<INV>(lu, sh, n_updates, false);
     if (dense) {
         for (int s = threadIdx.x; s < m; s += blockDim.x) sh.x0[lu.colpos[s]] = dense[s];
     } else {
@@ -1184,7 +1549,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
     }
     __syncthreads();
     int epoch = 0;
-    lu_btran_block<1>(lu, sh, n_updates, epoch, [] {}, upper_record);
+    lu_btran_block<1, INV>(lu, sh, n_updates, epoch, [] {}, upper_record);
     for (int i = threadIdx.x; i < m; i += blockDim.x) out[i] = sh.x0[lu.rowpos[i]];
 }
 
@@ -1192,14 +1557,14 @@ __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int t = lu.colpos[p];
     const int n_updates = lu.state[LU_N_UPDATES];
     if (n_updates >= lu.max_updates) {  // no room for another eta: the caller has to refactor
         if (threadIdx.x == 0) lu.state[LU_FLAGS] |= LU_FLAG_OVERFLOW;
         return;
     }
-    lu_clear(lu, sh, n_updates, false);
+    lu_clear<false>(lu, sh, n_updates, false);
     if (threadIdx.x == 0) sh.x0[t] = 1.0;
     __syncthreads();
     // y = e_t' U^-1: the U stage of a BTRAN (mod.rs:373-397), then the eta from it.  (The etas and the L stage run too --
@@ -1207,7 +1572,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int 
     int epoch = 0;
     int eta_count = 0;
     double new_diag = 0.0;
-    lu_btran_block<1>(lu, sh, n_updates, epoch, [&] { eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag); }, upper_record);
+    lu_btran_block<1, false>(lu, sh, n_updates, epoch, [&] { eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag); }, upper_record);
     lu_ft_update_block(lu, sh, t, eta_count, new_diag, lu.spike);
 }
 
@@ -1215,8 +1580,10 @@ static bool g_lu_lds_configured = false;
 static void allow_full_lds(const void* kernel);
 static void configure_lu_lds() {
     if (g_lu_lds_configured) return;
-    allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel<false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel<true>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel<false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel<true>));
     allow_full_lds(reinterpret_cast<const void*>(&lu_update_kernel));
     g_lu_lds_configured = true;
 }
@@ -1227,27 +1594,27 @@ static void check_launch(const char* what) {
 
 void launch_lu_ftran(const DeviceLU& lu, const int* rows, const double* vals, int nnz, double* out, int keep_spike, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_ftran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, rows, vals, nnz, (const double*)nullptr, out, keep_spike);
+    hipLaunchKernelGGL((lu.inverse_factors ? lu_ftran_kernel<true> : lu_ftran_kernel<false>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, lu, rows, vals, nnz, (const double*)nullptr, out, keep_spike);
     check_launch("lu_ftran_kernel");
 }
 void launch_lu_ftran_dense(const DeviceLU& lu, const double* rhs, double* out, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_ftran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, (const int*)nullptr, (const double*)nullptr, 0, rhs, out, 0);
+    hipLaunchKernelGGL((lu.inverse_factors ? lu_ftran_kernel<true> : lu_ftran_kernel<false>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, lu, (const int*)nullptr, (const double*)nullptr, 0, rhs, out, 0);
     check_launch("lu_ftran_kernel");
 }
 void launch_lu_btran(const DeviceLU& lu, const int* slots, const double* vals, int nnz, double* out, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_btran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, slots, vals, nnz, (const double*)nullptr, out);
+    hipLaunchKernelGGL((lu.inverse_factors ? lu_btran_kernel<true> : lu_btran_kernel<false>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, lu, slots, vals, nnz, (const double*)nullptr, out);
     check_launch("lu_btran_kernel");
 }
 void launch_lu_btran_dense(const DeviceLU& lu, const double* in_slots, double* out, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_btran_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, (const int*)nullptr, (const double*)nullptr, 0, in_slots, out);
+    hipLaunchKernelGGL((lu.inverse_factors ? lu_btran_kernel<true> : lu_btran_kernel<false>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, lu, (const int*)nullptr, (const double*)nullptr, 0, in_slots, out);
     check_launch("lu_btran_kernel");
 }
 void launch_lu_update(const DeviceLU& lu, int p, hipStream_t s) {
     configure_lu_lds();
-    hipLaunchKernelGGL(lu_update_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, lu, p);
+    hipLaunchKernelGGL(lu_update_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, lu, p);
     check_launch("lu_update_kernel");
 }
 
@@ -1267,7 +1634,7 @@ void launch_lu_update(const DeviceLU& lu, int p, hipStream_t s) {
 //   or, after `refactor_period` updates, status = ST_REFACTOR: the host factorises the new basis (carry/mod.rs:584-591:
 //   polled before the update; the new basis is inverted from scratch and no update is made).
 // The explicit-inverse pipeline needs two kernels for this (K2, K3) and rewrites an m x m matrix per pivot.
-template <int RULE>
+template <int RULE, bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, DeviceLU lu, int n_price_blocks, double tol_pivot,
                                                                double harris_delta, int skip_artificial_rows, int mode,
                                                                int refactor_period) {
@@ -1279,7 +1646,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // FTRAN's first solve: lands while the entering column is chosen
     const int tid = threadIdx.x, T = blockDim.x;
     const int m = lp.m;
-    LuShared sh = lu_shared(smem, m, lu.max_updates);
+    LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
 #ifdef RELP_STAMPS
     __shared__ unsigned long long s_tprev;
     if (tid == 0) {
@@ -1297,6 +1664,15 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     const int forced_p = ctl->forced_p;
     const double minus_obj = ctl->minus_obj;
     const int n_updates = lu.state[LU_N_UPDATES];
+    // inverse-factor form: the kept columns of M (lu.hpp) -- their basis slots and positions go to LDS now, so that no phase below
+    // starts with this chain of three dependent loads
+    __shared__ int s_pf_slot[LU_MAX_SLOTS], s_pf_pos[LU_MAX_SLOTS];
+    const int pf_k = INV ? lu.state[LU_PF_COUNT] : 0;
+    if (INV && tid < pf_k) {
+        const int slot = lu.pf_slot[tid];
+        s_pf_slot[tid] = slot;
+        s_pf_pos[tid] = lu.colpos[slot];
+    }
     double ckey = 0.0;
     unsigned long long crank = RANK_NONE;
     for (int b = tid; b < n_price_blocks; b += T) {
@@ -1371,12 +1747,41 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         if (forced_q >= 0) cbar_q *= sgn_q;  // the candidates of the pricing pass carry the sign already
     }
     lu_stamp(sh, 0);
-    lu_clear(lu, sh, n_updates, false);
+    lu_clear<INV>(lu, sh, n_updates, false);
     for (int e = lp.col_start[q] + tid; e < lp.col_start[q + 1]; e += T) sh.x0[lu.rowpos[lp.row_index[e]]] = sgn_q * lp.value[e];
     __syncthreads();
     lu_stamp(sh, 1);
     int epoch = 0;
-    lu_ftran_block(lu, sh, n_updates, epoch, lu.spike, lower_record);
+    if constexpr (INV) {
+        // x1 <- L^-1 x0, x0 <- U^-1 x1, alpha = M (that), the operands y[slot_c] read first
+        const LuSlot upper_rows = lu_load_slot(lu, 1, tid);
+        lui_apply<1, true>(lu, 0, lower_record, sh.x0, sh.x0, sh.x1, sh.x1);
+        lu_stamp(sh, 2);
+        lui_apply<1, false>(lu, 1, upper_rows, sh.x1, sh.x1, sh.x0, sh.x0);
+        lu_stamp(sh, 3);
+        if (pf_k > 0) {
+            if (tid < pf_k) sh.xt0[tid] = sh.x0[s_pf_pos[tid]];
+            __syncthreads();
+            const gptr_f64 M = (gptr_f64)lu.pf_M;
+            for (int s = tid; s < m; s += T) {
+                double acc = 0.0;
+                for (int c0 = 0; c0 < pf_k; c0 += 8) {
+                    double mc[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) mc[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (c0 + u < pf_k) acc += (mc[u] - (s_pf_slot[c0 + u] == s ? 1.0 : 0.0)) * sh.xt0[c0 + u];
+                }
+                const int pos = lu.colpos[s];
+                sh.x0[pos] = sh.x0[pos] + acc;
+            }
+            __syncthreads();
+        }
+        lu_stamp(sh, 4);
+    } else {
+        lu_ftran_block<INV>(lu, sh, n_updates, epoch, lu.spike, lower_record);
+    }
     const LuSlot upper_record = lu_load_slot(lu, 2, tid);  // BTRAN's first solve: lands during the ratio test
     // ---- alpha per basis slot (kept in x1), gamma_q, Harris pass 1 ----------------------------------------------------------
     // harris_delta < 0: the reference's ratio test (exact minimum, ties to the lowest leaving column; tableau/mod.rs:287-313).
@@ -1511,12 +1916,74 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     if (tid == 0) sh.x0[t] = 1.0;
     __syncthreads();
     lu_stamp(sh, 6);
-    const double diag_t = lu.diag[t];
+    const double diag_t = INV ? 1.0 : lu.diag[t];
     int eta_count = 0;
     double new_diag = 0.0;
-    lu_btran_block<2>(lu, sh, n_updates, epoch, [&] {
-        if (do_update) eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag);
-    }, upper_record);
+    if constexpr (INV) {
+        // The two row vectors of the BTRAN in front of the factors (old basis):  e_p' M  (row p of M: its k kept entries, and 1 at p
+        // when p has no kept column) and  alpha' M  (alpha off the kept slots, the k sums  sum_s alpha_s M[s][c]  on them) -- and,
+        // in the same pass over M, the eta of this pivot folded in:  M[s][c] -= (alpha_s - [s == p]) M[p][c] / alpha_p, plus a new
+        // column for p when it had none.  One read of M serves both; row p of the old M is read first (st0).
+        typedef __attribute__((address_space(1))) double* gmut_f64;
+        const gmut_f64 M = (gmut_f64)lu.pf_M;
+        const int have = lu.pf_col_of[p];
+        const int k_new = (do_update && have < 0) ? pf_k + 1 : pf_k;
+        if (tid < pf_k) sh.st0[tid] = M[(size_t)tid * lu.pf_ld + p];
+        if (tid == pf_k) sh.st0[pf_k] = 1.0;  // (the new column starts as e_p)
+        __syncthreads();
+        const double inv_ap = 1.0 / alpha_pq;
+        const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = T / WAVE;
+        for (int c0 = 0; c0 < k_new; c0 += 8) {
+            double part[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] = 0.0;
+            for (int s = tid; s < m; s += T) {
+                const double a = lp.alpha[s];
+                const double factor = (a - (s == p ? 1.0 : 0.0)) * inv_ap;
+                double old[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) old[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : (s == p ? 1.0 : 0.0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    part[u] += a * old[u];
+                    if (do_update && c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * sh.st0[c0 + u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (c0 + u >= pf_k) break;  // wave-uniform (the new column's sum is alpha_p: already at p's position)
+                const double w0 = wave_sum(part[u]);
+                if (lane == LAST) sh.pfpart[wave * LU_MAX_SLOTS + c0 + u] = w0;
+            }
+        }
+        __syncthreads();
+        if (tid < pf_k) {
+            double sum = 0.0;
+            for (int w = 0; w < nwaves; ++w) sum += sh.pfpart[w * LU_MAX_SLOTS + tid];
+            const int pos = s_pf_pos[tid];
+            sh.x1[pos] = sum;
+            sh.x0[pos] = sh.st0[tid];  // (row p of M at its kept slots; p's own position holds the 1 set above unless p is kept)
+        }
+        __syncthreads();
+        lu_stamp(sh, 7);
+        const LuSlot lower_cols = lu_load_slot(lu, 3, tid);
+        lui_apply<2, false>(lu, 2, upper_record, sh.x0, sh.x1, sh.x2, sh.x3);
+        lu_stamp(sh, 8);
+        lui_apply<2, true>(lu, 3, lower_cols, sh.x2, sh.x3, sh.x0, sh.x1);
+        lu_stamp(sh, 10);
+        if (do_update && tid == 0) {
+            if (have < 0) {
+                lu.pf_slot[pf_k] = p;
+                lu.pf_col_of[p] = pf_k;
+            }
+            lu.state[LU_PF_COUNT] = k_new;
+            lu.state[LU_N_UPDATES] = n_updates + 1;
+        }
+    } else {
+        lu_btran_block<2, INV>(lu, sh, n_updates, epoch, [&] {
+            if (do_update) eta_count = lu_build_eta(lu, sh, t, lu.spike, &new_diag);
+        }, upper_record);
+    }
     // ---- rho_p of the new basis, w, -pi (carry/mod.rs:338-349) ----------------------------------------------------------------
     for (int i = tid; i < m; i += T) {
         const int k = lu.rowpos[i];
@@ -1535,7 +2002,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     lu_stamp(sh, 11);
     // ---- Forrest-Tomlin update, or hand the new basis to the host ---------------------------------------------------------------
     bool refactor = !do_update;
-    if (do_update) {
+    if (!INV && do_update) {  // (inverse-factor form: the eta went into M with the BTRAN set-up above)
         lu_ft_update_block(lu, sh, t, eta_count, new_diag, lu.spike);
         // det(B_new) = alpha_pq det(B_old)  =>  the new diagonal element must equal alpha_pq * u_tt: a free accuracy check
         const double expect = alpha_pq * diag_t;
@@ -1576,27 +2043,29 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
 }
 
 // x_B = B^-1 b  (InverseMaintainer::from_basis, carry/mod.rs:452-463) through the resident factors
+template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(lu, sh, n_updates, false);
+    lu_clear<INV>(lu, sh, n_updates, false);
     for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = lp.rhs[i];
     __syncthreads();
     int epoch = 0;
-    lu_ftran_block(lu, sh, n_updates, epoch, nullptr, lower_record);
+    lu_ftran_block<INV>(lu, sh, n_updates, epoch, nullptr, lower_record);
     for (int s = threadIdx.x; s < m; s += blockDim.x) lp.xB[s] = sh.x0[lu.colpos[s]];
 }
 // -pi = -c_B' B^-1 and -obj = -c_B' x_B  (carry/mod.rs:226-283: the reference forms all of B^-1 with m FTRANs)
+template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
-    lu_clear(lu, sh, n_updates, false);
+    lu_clear<INV>(lu, sh, n_updates, false);
     double obj = 0.0;
     for (int s = threadIdx.x; s < m; s += blockDim.x) {
         const int bj = lp.basis[s];
@@ -1609,7 +2078,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
             if (lp.flipped[j]) obj += lp.ub[j] * lp.cost[j];
     __syncthreads();
     int epoch = 0;
-    lu_btran_block<1>(lu, sh, n_updates, epoch, [] {}, upper_record);
+    lu_btran_block<1, INV>(lu, sh, n_updates, epoch, [] {}, upper_record);
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         const double v = -sh.x0[lu.rowpos[i]];
         lp.minus_pi[i] = v;
@@ -1620,20 +2089,21 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
 }
 // gamma_j = 1 + |B^-1 a_j|^2 for every non-basic provider column (pivot_rule.rs:202-219, 299-305): one FTRAN per column,
 // a workgroup takes every gridDim.x-th column.  (Warm starts only: between the phases the weights are carried over.)
+template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
     for (int j = lp.n_art + blockIdx.x; j < lp.n; j += gridDim.x) {
         if (lp.pos[j] >= 0) continue;
         __syncthreads();
-        lu_clear(lu, sh, n_updates, false);
+        lu_clear<INV>(lu, sh, n_updates, false);
         for (int e = lp.col_start[j] + threadIdx.x; e < lp.col_start[j + 1]; e += blockDim.x) sh.x0[lu.rowpos[lp.row_index[e]]] = lp.value[e];
         __syncthreads();
         int epoch = 0;
-        lu_ftran_block(lu, sh, n_updates, epoch, nullptr, lower_record);
+        lu_ftran_block<INV>(lu, sh, n_updates, epoch, nullptr, lower_record);
         double sumsq = 0.0;
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
             const double a = sh.x0[i];
@@ -1667,23 +2137,31 @@ static void allow_full_lds(const void* kernel) {
 }
 static void configure_lu_pivot_lds() {
     if (g_lu_pivot_configured) return;
-    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_STEEPEST_EDGE>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_DANTZIG>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_xb_kernel));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_pi_kernel));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_gamma_kernel));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_STEEPEST_EDGE, false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_STEEPEST_EDGE, true>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_DANTZIG, false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_DANTZIG, true>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE, false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE, true>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, true>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_xb_kernel<false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_xb_kernel<true>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pi_kernel<false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_pi_kernel<true>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_gamma_kernel<false>));
+    allow_full_lds(reinterpret_cast<const void*>(&lu_gamma_kernel<true>));
     g_lu_pivot_configured = true;
 }
 template <int RULE>
 static void launch_lu_pivot_rule(const DeviceLP& d, const DeviceLU& lu, int n_price_blocks, double tol_pivot, double harris_delta,
                                  int skip_art, int mode, int refactor_period, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+    auto kernel = lu.inverse_factors ? lu_pivot_kernel<RULE, true> : lu_pivot_kernel<RULE, false>;
     if (start)
-        hipExtLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), (std::uint32_t)lu_lds_bytes_for(lu.m, lu.max_updates), s, start, stop, 0,
+        hipExtLaunchKernelGGL(kernel, dim3(1), dim3(LU_THREADS), (std::uint32_t)lu_lds_bytes_for(lu), s, start, stop, 0,
                               d, lu, n_price_blocks, tol_pivot, harris_delta, skip_art, mode, refactor_period);
     else
-        hipLaunchKernelGGL((lu_pivot_kernel<RULE>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu, n_price_blocks, tol_pivot,
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, d, lu, n_price_blocks, tol_pivot,
                            harris_delta, skip_art, mode, refactor_period);
 }
 // `capturing`: inside a stream capture hipGetLastError must not be polled per launch (the capture's end reports failures)
@@ -1706,18 +2184,18 @@ void launch_clear_refactor_status(const DeviceLP& d, hipStream_t s) {
 }
 void launch_lu_xb(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
     configure_lu_pivot_lds();
-    hipLaunchKernelGGL(lu_xb_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu);
+    hipLaunchKernelGGL((lu.inverse_factors ? lu_xb_kernel<true> : lu_xb_kernel<false>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, d, lu);
     check_launch("lu_xb_kernel");
 }
 void launch_lu_pi(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
     configure_lu_pivot_lds();
-    hipLaunchKernelGGL(lu_pi_kernel, dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu);
+    hipLaunchKernelGGL((lu.inverse_factors ? lu_pi_kernel<true> : lu_pi_kernel<false>), dim3(1), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, d, lu);
     check_launch("lu_pi_kernel");
 }
 void launch_lu_gamma(const DeviceLP& d, const DeviceLU& lu, hipStream_t s) {
     configure_lu_pivot_lds();
     const int blocks = std::max(1, std::min(512, d.n - d.n_art));
-    hipLaunchKernelGGL(lu_gamma_kernel, dim3(blocks), dim3(LU_THREADS), lu_lds_bytes_for(lu.m, lu.max_updates), s, d, lu);
+    hipLaunchKernelGGL((lu.inverse_factors ? lu_gamma_kernel<true> : lu_gamma_kernel<false>), dim3(blocks), dim3(LU_THREADS), lu_lds_bytes_for(lu), s, d, lu);
     check_launch("lu_gamma_kernel");
 }
 void launch_lu_row_scan(const DeviceLP& d, const double* rowvec, double tol, hipStream_t s) {

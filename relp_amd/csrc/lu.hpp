@@ -30,7 +30,7 @@
 
 namespace relp {
 
-enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_STATE_WORDS = 16 };
+enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_PF_COUNT = 4, LU_STATE_WORDS = 16 };
 enum : int { LU_FLAG_UNSTABLE = 1, LU_FLAG_OVERFLOW = 2 };
 constexpr int LU_MAX_SLOTS = 64;  // one wave solves T
 
@@ -105,6 +105,20 @@ struct DeviceLU {
     LuTasks tasks[4];         // (kernel arguments: read from the kernarg segment where they are used, no dependent round trip)
     int task_stride = 0;      // ELL stride of the slots (their capacity: a multiple of 1024, at least 1024 past the last slot)
     int* state = nullptr;     // LU_* words
+    // ---- the inverse-factor form (relp_options.carry = RELP_CARRY_LU_INVERSE) -------------------------------------------------------
+    // The four task lists then hold L^-1 (strict part) and U^-1 (diagonal included) instead of L and U -- every row in ONE level:
+    // a solve is a sparse matrix-vector product out of place (x0 -> x1 -> x0), no level loop, no barrier between its rows.  The
+    // factors are never touched between refactorisations; the updates are kept in PRODUCT FORM on top of them,
+    //     B_k^-1 = M B_0^-1,   M = E_k ... E_1,   E = I - (alpha - e_p) e_p' / alpha_p   (the eta of a pivot on basis slot p),
+    // with M held as the (at most max_updates) columns in which it differs from the identity (`pf_M`, column c belongs to basis
+    // slot pf_slot[c]): applying M or M' is k multiply-adds per row, all rows at once -- no sequential eta loop --, and a pivot
+    // folds its eta into the kept columns (m x k multiply-adds).  state[LU_PF_COUNT] = k, state[LU_N_UPDATES] = pivots since the
+    // refactorisation.
+    int inverse_factors = 0;
+    double* pf_M = nullptr;     // [max_updates][pf_ld]
+    int pf_ld = 0;
+    int* pf_slot = nullptr;     // [max_updates] basis slot of kept column c
+    int* pf_col_of = nullptr;   // [m] kept column of a basis slot, -1: none
 };
 
 // Owns the device (and pinned staging) memory of one factorisation; re-used across refactorisations.
@@ -116,10 +130,11 @@ public:
     LuFactors& operator=(const LuFactors&) = delete;
     // uploads the factors and resets the update state; stream-ordered.  Returns true when the device layout (the addresses
     // in device()) changed: it depends on capacities only, so a refactorisation normally keeps it.
-    bool upload(const HostLU& f, int max_updates, hipStream_t stream);
+    bool upload(const HostLU& f, int max_updates, hipStream_t stream, bool inverse_factors = false);
     const DeviceLU& device() const { return d_; }
     size_t lds_bytes(int nrhs) const;  // dynamic LDS of the solve kernels for this m
     long long nnz_l = 0, nnz_u = 0;
+    long long nnz_l_inverse = 0, nnz_u_inverse = 0;  // (inverse-factor form)
     int depth_l = 0, depth_u = 0;
 
 private:
@@ -134,7 +149,7 @@ private:
 
 // kernels (lu.hip); all single-workgroup, stream-ordered
 constexpr int LU_THREADS = 1024;
-bool lu_fits_lds(int m, int max_updates);  // max_updates: the update slots the kernels will be given (T is max_updates^2 doubles of LDS)
+bool lu_fits_lds(int m, int max_updates, bool inverse_factors = false);  // max_updates: the update slots the kernels will be given (T is max_updates^2 doubles of LDS)
 // FTRAN of a sparse column (device arrays rows / vals, original row indices): out[slot] (m doubles); the spike stays in lu.spike
 void launch_lu_ftran(const DeviceLU& lu, const int* rows, const double* vals, int nnz, double* out, int keep_spike, hipStream_t s);
 // FTRAN of a dense right-hand side (original row order)

@@ -211,9 +211,12 @@ void Solver::upload() {
     d_.n = n;
     d_.n_art = n_art;
     d_.ld = m;
-    lu_mode_ = opt_.carry == RELP_CARRY_LU;
+    lu_mode_ = opt_.carry == RELP_CARRY_LU || opt_.carry == RELP_CARRY_LU_INVERSE;
+    lu_inverse_ = opt_.carry == RELP_CARRY_LU_INVERSE;
     refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : 31, LU_MAX_SLOTS - 1);  // T is solved by one wave
-    if (lu_mode_) {
+    if (lu_inverse_ && !lu_fits_lds(m, refactor_period_ + 1, true))
+        throw std::invalid_argument("the inverse-factor carry keeps four vectors in LDS (32 bytes per row): at most about 4300 rows (use the LU or the explicit carry beyond)");
+    if (lu_mode_ && !lu_inverse_) {
         if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its two solve vectors in LDS (16 bytes per row): at most about 8000 rows with this refactor period (use the explicit carry beyond)");
     }
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
@@ -1476,7 +1479,7 @@ void Solver::lu_identity() {
     f.l_start.assign(m + 1, 0);
     f.u_start.assign(m + 1, 0);
     f.diag.assign(m, 1.0);
-    if (lu_.upload(f, refactor_period_ + 1, stream_)) destroy_graphs();  // the captured batches hold the old addresses
+    if (lu_.upload(f, refactor_period_ + 1, stream_, lu_inverse_)) destroy_graphs();  // the captured batches hold the old addresses
 }
 // `BasisInverse::invert(basis columns)` (lower_upper/mod.rs:78-92; called by `Carry::change_basis` when `should_refactor`,
 // carry/mod.rs:584-591): Markowitz factorisation of the current basis on the host, one upload, and -- `refresh_vectors` -- x_B,
@@ -1517,7 +1520,7 @@ void Solver::refactor_lu(bool refresh_vectors) {
     HostLU f = lu_factor(m, cs.data(), rows.data(), vals.data(), lo);
     if (f.singular) throw std::runtime_error("singular basis in the LU refactorisation");
     const double t2 = now_seconds();
-    if (lu_.upload(f, refactor_period_ + 1, stream_)) destroy_graphs();
+    if (lu_.upload(f, refactor_period_ + 1, stream_, lu_inverse_)) destroy_graphs();
     if (time_parts) {
         part_seconds[0] += t1 - t0;
         part_seconds[1] += t2 - t1;

@@ -246,6 +246,7 @@ private:
     void lu_identity();                      // BasisInverse::identity
     LuFactors lu_;
     bool lu_mode_ = false;
+    bool lu_inverse_ = false;  // ... in its inverse-factor form (lu.hpp: L^-1, U^-1 and product-form updates)
     bool lu_is_identity_ = true;
     int refactor_period_ = 64;
     // (a negative slack selects the reference's ratio test in the kernels that implement it: the fused kernel for m <= 8192 and the LU kernel)

@@ -91,7 +91,7 @@ def test_headline_problems_meet_reference_tolerance(name):
     solver.close()
 
 
-@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 def test_unbounded_and_infeasible_are_reported(carry):
     solver = relp_amd.Solver(carry=carry).load_mps(os.path.join(ROOT, "data", "burkardt", "nazareth.mps"))
     assert solver.solve_relaxation().kind == relp_amd.UNBOUNDED  # tests/burkardt/test.rs:157-167
@@ -104,7 +104,7 @@ def test_unbounded_and_infeasible_are_reported(carry):
 
 
 @pytest.mark.parametrize("rule", [relp_amd.DANTZIG, relp_amd.FIRST_PROFITABLE, relp_amd.FIRST_PROFITABLE_MEMORY])
-@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 @pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE", "BLEND"])
 def test_other_pivot_rules_reach_the_optimum(name, rule, carry):
     solver = relp_amd.Solver(pivot_rule=rule, carry=carry).load_mps(os.path.join(ROOT, GOLDEN[name]["file"]))
@@ -123,7 +123,7 @@ def test_graph_and_plain_launches_agree():
     assert (a.pivots_phase_one, a.pivots_phase_two) == (b.pivots_phase_one, b.pivots_phase_two)
 
 
-@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 def test_redundant_rows_and_empty_rows(carry):
     """two_phase/test.rs:96-212: redundant_row, empty_row_at_eq, empty_row_at_ineq -> x = (3/4, 1/4, ...)."""
     # three identical equality rows x0 + x1 = 1, x0 <= 3/4, min -2 x0 - x1
@@ -143,7 +143,7 @@ def test_redundant_rows_and_empty_rows(carry):
         solver.close()
 
 
-@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 def test_set_basis_warm_start(carry):
     """`InverseMaintainer::from_basis` (carry/mod.rs:444-478): restart from the optimal basis => zero pivots."""
     path = os.path.join(ROOT, "data", "netlib", "SC50A.SIF")
@@ -161,7 +161,7 @@ def test_set_basis_warm_start(carry):
 # ---------------------------------------------------------------------------------------------------------
 # fine-grained trait ops, step by step against the oracle on the same basis
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 @pytest.mark.parametrize("name, steps", [("AFIRO", 19), ("SC50A", 30), ("ADLITTLE", 40), ("SHARE2B", 40)])
 def test_trait_ops_follow_the_oracle(name, steps, carry):
     path = os.path.join(ROOT, GOLDEN[name]["file"])
@@ -282,7 +282,7 @@ def test_miplib_relaxations(name, expected, tolerance):
     solver.close()
 
 
-@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 @pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE"])
 def test_loop_driven_from_outside_through_bring_into_basis(name, carry):
     """The reference's loop (phase_one.rs:134-178 / phase_two.rs:36-58) written by the caller with the fine-grained operations
@@ -339,7 +339,7 @@ def test_steepest_edge_weights_carried_from_phase_one(name, monkeypatch):
     carried.close()
 
 
-@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+@pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 def test_after_basis_update_applies_the_pending_weight_update(carry):
     """`PivotRule::after_basis_update` (pivot_rule.rs:243-296) as an entry of its own: the Goldfarb-Reid update is applied once,
     whether the caller asks for it right after the pivot or lets the next pricing pass do it; asking twice changes nothing."""

@@ -24,7 +24,7 @@ from relp_oracle.solve import Infeasible
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CARRIES = pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU], ids=["explicit", "lu"])
+CARRIES = pytest.mark.parametrize("carry", [relp_amd.api.CARRY_EXPLICIT, relp_amd.api.CARRY_LU, relp_amd.api.CARRY_LU_INVERSE], ids=["explicit", "lu", "lu_inverse"])
 
 
 class Trace:

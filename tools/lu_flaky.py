@@ -6,7 +6,7 @@ import relp_amd
 for name in ["GREENBEA", "BNL2", "CYCLE", "GREENBEB", "25FV47"]:
     for rep in range(3):
         try:
-            s = relp_amd.Solver(carry=1).load_mps('/root/repo/data/netlib/%s.SIF' % name)
+            s = relp_amd.Solver(carry=int(os.environ.get("RELP_FLAKY_CARRY", "1"))).load_mps('/root/repo/data/netlib/%s.SIF' % name)
             r = s.solve_relaxation()
             print(name, rep, r.kind, r.objective, r.pivots_phase_one + r.pivots_phase_two, r.refactors, flush=True)
             s.close()

@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 import relp_amd
 name = sys.argv[1] if len(sys.argv) > 1 else "25FV47"
 period = int(sys.argv[2]) if len(sys.argv) > 2 else 31
-s = relp_amd.Solver(carry=1, refactor_period=period).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+carry = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # 2: the inverse-factor form (the segments are then: L^-1, U^-1, M; M', U^-1', -, -, L^-1')
+s = relp_amd.Solver(carry=carry, refactor_period=period).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
 r = s.solve_relaxation()
 d = s.debug_stamps()
 n = int(d[63])
