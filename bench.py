@@ -296,7 +296,7 @@ class CpuLegs:
 # =====================================================================================================================
 # section 8(d) of SURVEY.md: algorithmic bytes per pivot, the figure the roofline fraction is quoted on
 # =====================================================================================================================
-def factor_nonzeros(model, basis, art_rows):
+def factor_nonzeros(model, basis, art_rows, inverse_entries=None):
     """nnzF = nnz(L) + nnz(U) + m of the basis the solve ended on (host factorisation, relp_lu_factor_host)."""
     import ctypes as C
     import numpy as np
@@ -313,6 +313,18 @@ def factor_nonzeros(model, basis, art_rows):
         else:
             columns.append([(art_rows[-1 - int(c)], 1.0)])
     factors = lu_factor_host(columns)
+    if inverse_entries is not None:  # the inverse-factor carry streams L^-1 and U^-1: their entries, counted on the dense inverses
+        import scipy.linalg
+        m = len(basis)
+        lower, upper = np.eye(m), np.diag(np.asarray(factors["diag"], dtype=np.float64))
+        for i, row in enumerate(factors["lower_rows"]):
+            for j, v in row:
+                lower[i, j] = v
+        for i, row in enumerate(factors["upper_rows"]):
+            for j, v in row:
+                upper[i, j] = v
+        inverse_entries.append(int(np.count_nonzero(scipy.linalg.solve_triangular(lower, np.eye(m), lower=True, unit_diagonal=True))) - m +
+                               int(np.count_nonzero(scipy.linalg.solve_triangular(upper, np.eye(m), lower=False))))
     return factors["nnz_lower"] + factors["nnz_upper"] + len(basis)
 
 
@@ -443,7 +455,7 @@ def single_lp(args, ctx):
         solver.iterate(20)
     reps = 40 if graph else (100 if dense else 200)  # further real pivots, the profiled kernel of each bracketed by its own event pair
     solver.profile_kernel(0, 10 if graph else 50)   # discarded: brings clocks and caches to the state of a running solve
-    lu_carry = args.carry == 1 and not dense and not graph
+    lu_carry = args.carry in (1, 2) and not dense and not graph
     kernels = ["price", "lu_pivot"] if lu_carry else ["price", "ftran_ratio", "update"]
     try:
         seconds = {name: solver.profile_kernel(which, reps) for which, name in enumerate(kernels)}
@@ -466,7 +478,8 @@ def single_lp(args, ctx):
         art_rows = sorted(set(range(model.nr_rows)) - {r for r, _ in pivots_initial})
         try:
             # (graph LPs: a tree basis -- at most two entries per arc column -- is counted, not factorised on the host, at a million rows)
-            nnz_f = 3 * m_rows if graph else factor_nonzeros(model, final_basis, art_rows)
+            inverse_entries = [] if (lu_carry and args.carry == 2) else None
+            nnz_f = 3 * m_rows if graph else factor_nonzeros(model, final_basis, art_rows, inverse_entries)
         except Exception:  # noqa: BLE001  (a basis the host factorisation rejects: fall back to 3 entries per row and triangle)
             nnz_f = 7 * m_rows
         mean_column = 2.0 if graph else max(1.0, float(model.nnz) / max(1, solver.n_provider))
@@ -474,7 +487,10 @@ def single_lp(args, ctx):
     own = {"price": stats.price_bytes,
            "ftran_ratio": int(mean_column * m_rows * 8 + 6 * m_rows * 8),
            "update": stats.update_bytes,
-           "lu_pivot": int(2 * nnz_f * 12 + 12 * m_rows * 8),
+           # (the inverse-factor form: both inverted triangles twice, 11 B per entry in its compact records, the kept columns of M --
+           #  about half a period of them -- read twice and written once, the same twelve vectors)
+           "lu_pivot": int(2 * nnz_f * 12 + 12 * m_rows * 8) if not (lu_carry and args.carry == 2 and not graph)
+                       else int(2 * inverse_entries[0] * 11 + 3 * 16 * m_rows * 8 + 12 * m_rows * 8),
            # fused: one workgroup's FTRAN + ratio test, and ONE read + one write of the whole inverse (out of place)
            "pivot_fused": int(mean_column * m_rows * 8 + 6 * m_rows * 8 + 2 * m_rows * m_rows * 8)}
     # the contract's share per kernel: the pricing pass is the pricing kernel's; everything else belongs to the kernel(s) that do
@@ -497,7 +513,7 @@ def single_lp(args, ctx):
     dense_price = "price_dense_lane_kernel" if args.dense_storage == "narrowest" else "price_dense_kernel"
     pmc_names = {"price": dense_price if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
                  "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
-    tag = args.workload + ("_lu" if lu_carry else "")
+    tag = args.workload + (("_lu" if args.carry == 1 else "_lui") if lu_carry else "")
     for candidate in ("r3_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % args.workload,
                       "r1_%s_pmc_traffic.json" % args.workload):
         pmc = os.path.join(ROOT, "profiles", candidate)
@@ -518,7 +534,7 @@ def single_lp(args, ctx):
         data = "synthetic"
     else:
         workload = ("Netlib 25FV47 %dx%d, steepest-edge pricing, %s carry, exact certificate %s the timed step, %s" % (
-            solver.m, solver.n_provider, "LU + Forrest-Tomlin" if args.carry == 1 else "explicit-inverse",
+            solver.m, solver.n_provider, {1: "LU + Forrest-Tomlin", 2: "LU inverse factors + product-form updates"}.get(args.carry, "explicit-inverse"),
             "outside" if args.no_certify else "inside",
             "after the reference's presolve" if args.presolve else "no presolve (+520 virtual artificials)"))
         data = "Netlib 25FV47.SIF (shipped problem file), one copy per GPU"
@@ -535,7 +551,7 @@ def single_lp(args, ctx):
                    "wall_clock_to_exact_optimum_s": (loop_seconds + certify_seconds) / args.steps,
                    "wall_clock_f64_loop_s": loop_seconds / args.steps,
                    "pivots_per_s_f64_loop_only": pivots / world / loop_seconds if loop_seconds > 0 else None,
-                   "carry": "lu" if args.carry == 1 else "explicit", "refactors": int(last.refactors),
+                   "carry": {1: "lu", 2: "lu_inverse"}.get(args.carry, "explicit"), "refactors": int(last.refactors),
                    "refactor_seconds_per_solve": float(last.refactor_seconds),
                    "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
                    # the reference is exact and has neither tolerances nor a Harris test: what f64 adds, and what it changes
@@ -755,6 +771,7 @@ def all_configs(args, ctx, legs):
 
     steps = max(1, min(args.steps, 3))
     attempt("lu_carry_25fv47", lambda: single_lp(variant(carry=1, steps=steps, warmup=1), ctx))
+    attempt("lu_inverse_carry_25fv47", lambda: single_lp(variant(carry=2, steps=steps, warmup=1), ctx))
     attempt("dense4096_f64", lambda: single_lp(variant(workload="dense4096", dense_storage="f64", steps=steps, warmup=1), ctx))
     attempt("dense4096_narrowest", lambda: single_lp(variant(workload="dense4096", dense_storage="narrowest", steps=steps, warmup=1), ctx))
     attempt("netlib_batch", lambda: netlib_batch(variant(workload="netlib", presolve=False, steps=2, warmup=1), ctx))
@@ -762,8 +779,9 @@ def all_configs(args, ctx, legs):
     attempt("maxflow_reference_start", lambda: single_lp(variant(workload="maxflow", crash=0, steps=1, warmup=1), ctx))
     attempt("maxflow_crash", lambda: single_lp(variant(workload="maxflow", crash=1, steps=steps, warmup=1), ctx))
     if not args.no_cpu_baseline:
-        if "error" not in out["lu_carry_25fv47"]:  # the same LP as the headline: the same exact CPU path beside it
-            out["lu_carry_25fv47"]["cpu_baseline"] = legs.peek("exact_faithful")
+        for key in ("lu_carry_25fv47", "lu_inverse_carry_25fv47"):  # the same LP as the headline: the same exact CPU path beside it
+            if "error" not in out[key]:
+                out[key]["cpu_baseline"] = legs.peek("exact_faithful")
         dense_cpu = legs.collect("dense")
         for key in ("dense4096_f64", "dense4096_narrowest"):
             if "error" not in out[key]:
@@ -796,7 +814,8 @@ def main():
     parser.add_argument("--no-dense-roofline", action="store_true", help="(kept for compatibility: the dense roofline now lives under configs)")
     parser.add_argument("--no-configs", action="store_true", help="default workload only: skip the other BASELINE configs")
     parser.add_argument("--no-certify", action="store_true", help="25fv47: leave the exact certificate out of the timed step (A/B only)")
-    parser.add_argument("--carry", type=int, default=0, choices=[0, 1], help="0 explicit inverse, 1 LU + Forrest-Tomlin (relp_options.carry)")
+    parser.add_argument("--carry", type=int, default=0, choices=[0, 1, 2],
+                        help="0 explicit inverse, 1 LU + Forrest-Tomlin, 2 LU through the inverses of its triangles + product-form updates (relp_options.carry)")
     parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
     parser.add_argument("--records", default=None, help="netlib batch: write one JSON line per solved LP to this file")

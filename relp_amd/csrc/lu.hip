@@ -412,6 +412,20 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     }
     const size_t o_lrcol = c.take<int>(cl), o_lcrow = c.take<int>(cl), o_lrval = c.take<double>(cl), o_lcval = c.take<double>(cl);
     const size_t o_urcol = c.take<int>(cu), o_ucrow = c.take<int>(cu), o_urval = c.take<double>(cu), o_ucval = c.take<double>(cu);
+    // the compact records of the inverse-factor form (lu.hpp), the four lists in ONE region (one copy per refactorisation)
+    struct CompactOffsets {
+        size_t hdr, col, val, zpos;
+    } co[4];
+    const size_t compact_begin = (c.offset + 63) & ~size_t(63);
+    c.offset = compact_begin;
+    for (int k = 0; k < 4; ++k) {
+        co[k].hdr = c.take<unsigned int>(inverse_factors ? stride : 0);
+        co[k].zpos = c.take<int>(inverse_factors ? stride : 0);
+        co[k].col = c.take<unsigned long long>(inverse_factors ? stride : 0);
+        c.offset = (c.offset + 31) & ~size_t(31);
+        co[k].val = c.take<double>(inverse_factors ? (size_t)4 * stride : 0);
+    }
+    const size_t compact_end = c.offset;
     const size_t upload_bytes = c.offset;
     // ---- device only ----------------------------------------------------------------------------------------------------------
     const size_t app = (size_t)m * max_updates;
@@ -467,6 +481,38 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
             if (!v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(double));
             std::fill(dst + v.size(), dst + stride, pad);
         };
+        if (inverse_factors) {
+            static_assert(LU_TE == 4, "the compact records of the inverse-factor form hold four entries per slot");
+            if (m > 65535) throw std::runtime_error("the inverse-factor carry: more than 65535 rows");
+            const size_t ns = t.s_pos.size();
+            unsigned int* hdr = reinterpret_cast<unsigned int*>(h + co[k].hdr);
+            unsigned long long* col = reinterpret_cast<unsigned long long*>(h + co[k].col);
+            double* val = reinterpret_cast<double*>(h + co[k].val);
+            int* zpos = reinterpret_cast<int*>(h + co[k].zpos);
+            for (size_t s2 = 0; s2 < ns; ++s2) {
+                const int fl = t.s_flags[s2];
+                hdr[s2] = (unsigned)t.s_pos[s2] | ((unsigned)(fl & 7) << 16) | ((unsigned)((fl >> 8) & 1) << 19) | ((unsigned)((fl >> 9) & 1) << 20) |
+                          ((unsigned)((fl >> 16) & 127) << 21);
+                col[s2] = (unsigned long long)(unsigned)t.col[0][s2] | ((unsigned long long)(unsigned)t.col[1][s2] << 16) |
+                          ((unsigned long long)(unsigned)t.col[2][s2] << 32) | ((unsigned long long)(unsigned)t.col[3][s2] << 48);
+                val[4 * s2] = t.val[0][s2];
+                val[4 * s2 + 1] = t.val[1][s2];
+                val[4 * s2 + 2] = t.val[2][s2];
+                val[4 * s2 + 3] = t.val[3][s2];
+            }
+            // padding up to the stride: no group, no write, operands at position 0 (values: whatever -- never written anywhere)
+            std::fill(hdr + ns, hdr + stride, 0u);
+            std::fill(col + ns, col + stride, 0ull);
+            if (!t.z_pos.empty()) std::memcpy(zpos, t.z_pos.data(), t.z_pos.size() * sizeof(int));
+            std::fill(zpos + t.z_pos.size(), zpos + stride, 0);
+            if (!t.x_idx.empty()) {  // rows of more than 256 entries (rare): their ranges and the arena
+                put_i_padded(to[k].s_xstart, t.s_xstart, 0);
+                put_i_padded(to[k].s_xn, t.s_xn, 0);
+                put_i(to[k].x_idx, t.x_idx);
+                put_d(to[k].x_val, t.x_val);
+            }
+            continue;
+        }
         put_i_padded(to[k].z_pos, t.z_pos, 0);
         put_d_padded(to[k].z_dinv, t.z_dinv, 1.0);
         put_i_padded(to[k].s_pos, t.s_pos, 0);
@@ -497,7 +543,17 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     // which at Netlib sizes is more than the bytes do.  A large one copies the headers at once and each entry array up to what
     // is used (the capacities are 1.5 x larger, the ELL rows m wide).
     mark(3);
-    if (upload_bytes <= (size_t)(2u << 20)) {
+    if (inverse_factors) {  // the header (permutations, counts), the compact records, and the extras of the few very long rows
+        RELP_HIP(hipMemcpyAsync(dev_, h, o_counts + 4 * LU_CNT_WORDS * sizeof(int), hipMemcpyHostToDevice, stream));
+        RELP_HIP(hipMemcpyAsync(dev_ + compact_begin, h + compact_begin, compact_end - compact_begin, hipMemcpyHostToDevice, stream));
+        for (int k = 0; k < 4; ++k) {
+            if (tasks[k].x_idx.empty()) continue;
+            RELP_HIP(hipMemcpyAsync(dev_ + to[k].s_xstart, h + to[k].s_xstart, (size_t)stride * sizeof(int), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(dev_ + to[k].s_xn, h + to[k].s_xn, (size_t)stride * sizeof(int), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(dev_ + to[k].x_idx, h + to[k].x_idx, tasks[k].x_idx.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(dev_ + to[k].x_val, h + to[k].x_val, tasks[k].x_val.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        }
+    } else if (upload_bytes <= (size_t)(2u << 20)) {
         RELP_HIP(hipMemcpyAsync(dev_, h, upload_bytes, hipMemcpyHostToDevice, stream));
     } else {
         RELP_HIP(hipMemcpyAsync(dev_, h, small_bytes, hipMemcpyHostToDevice, stream));
@@ -566,6 +622,12 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
         t.s_col = GI(to[k].s_col); t.s_val = GD(to[k].s_val);
         t.x_idx = GI(to[k].x_idx); t.x_val = GD(to[k].x_val);
         t.counts = GI(o_counts + (size_t)k * LU_CNT_WORDS * sizeof(int));
+        if (inverse_factors) {
+            t.c_hdr = (const __attribute__((address_space(1))) unsigned int*)reinterpret_cast<const unsigned int*>(dev_ + co[k].hdr);
+            t.c_col = (const __attribute__((address_space(1))) unsigned long long*)reinterpret_cast<const unsigned long long*>(dev_ + co[k].col);
+            t.c_val = GD(co[k].val);
+            t.c_zpos = GI(co[k].zpos);
+        }
     }
     d_ = d;
     hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_);
@@ -776,17 +838,34 @@ __device__ __forceinline__ LuSlot lu_load_slot(const DeviceLU& lu, const int sch
     r.n_slots = tk.counts[LU_CNT_SLOTS];
     return r;
 }
-// (only what a product needs of a slot: no solve counts, no diagonal)
-__device__ __forceinline__ void lui_load_slot(const DeviceLU& lu, const int sched, const int k, LuSlot& r) {
+// The inverse-factor form: a slot as its compact record (lu.hpp), and what a product needs besides its slots.
+typedef double lui_f64x2 __attribute__((ext_vector_type(2)));
+struct LuiSlot {
+    unsigned hdr;
+    unsigned long long cols;
+    lui_f64x2 v01, v23;
+};
+struct LuiHead {
+    int nz, n_slots, z_pos;  // rows without entries (this thread's first), slots of the list
+};
+__device__ __forceinline__ LuiSlot lui_load_slot(const DeviceLU& lu, const int sched, const int k) {
     const LuTasks& tk = lu.tasks[sched];
-    const int stride = lu.task_stride;
-    r.pos = tk.s_pos[k];
-    r.flags = tk.s_flags[k];
-#pragma unroll
-    for (int e = 0; e < LU_TE; ++e) {
-        r.col[e] = tk.s_col[(size_t)e * stride + k];
-        r.val[e] = tk.s_val[(size_t)e * stride + k];
-    }
+    typedef const __attribute__((address_space(1))) lui_f64x2* gptr_f64x2;
+    const gptr_f64x2 vals = (gptr_f64x2)tk.c_val;
+    LuiSlot r;
+    r.hdr = tk.c_hdr[k];
+    r.cols = tk.c_col[k];
+    r.v01 = vals[2 * (size_t)k];
+    r.v23 = vals[2 * (size_t)k + 1];
+    return r;
+}
+__device__ __forceinline__ LuiHead lui_load_head(const DeviceLU& lu, const int sched) {
+    const LuTasks& tk = lu.tasks[sched];
+    LuiHead h;
+    h.nz = tk.counts[LU_CNT_Z];
+    h.n_slots = tk.counts[LU_CNT_SLOTS];
+    h.z_pos = tk.c_zpos[threadIdx.x];
+    return h;
 }
 
 // In place:  x[i] <- (x[i] - sum_e val[e] x[idx[e]]) / diag[i]  for every row i of one triangular factor in one orientation
@@ -934,45 +1013,41 @@ __device__ __forceinline__ void lu_solve_tasks(const DeviceLU& lu, const LuShare
 // same packed slots and DPP group sums as the solves.  UNIT: the factor has an implied unit diagonal (the L lists); the U lists
 // carry their diagonal as entries.  in0 / in1 complete (barrier) on entry; ends with a barrier.
 template <int NRHS, bool UNIT>
-__device__ __forceinline__ void lui_apply(const DeviceLU& lu, const int sched, const LuSlot& first_record, volatile lds_f64* in0,
-                                          volatile lds_f64* in1, volatile lds_f64* out0, volatile lds_f64* out1) {
+__device__ __forceinline__ void lui_apply(const DeviceLU& lu, const int sched, const LuiHead& head, const LuiSlot& first_record,
+                                          volatile lds_f64* in0, volatile lds_f64* in1, volatile lds_f64* out0, volatile lds_f64* out1) {
     const LuTasks& tk = lu.tasks[sched];
-    const int nz = __builtin_amdgcn_readfirstlane(first_record.nz);
-    const int n_slots = __builtin_amdgcn_readfirstlane(first_record.n_slots);
+    const int nz = __builtin_amdgcn_readfirstlane(head.nz);
+    const int n_slots = __builtin_amdgcn_readfirstlane(head.n_slots);
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & (WAVE - 1);
     if (UNIT) {  // rows without entries: a copy
         if (tid < nz) {
-            out0[first_record.z_pos] = in0[first_record.z_pos];
-            if (NRHS == 2) out1[first_record.z_pos] = in1[first_record.z_pos];
+            out0[head.z_pos] = in0[head.z_pos];
+            if (NRHS == 2) out1[head.z_pos] = in1[head.z_pos];
         }
         for (int z = tid + T; z < nz; z += T) {
-            const int p = tk.z_pos[z];
+            const int p = tk.c_zpos[z];
             out0[p] = in0[p];
             if (NRHS == 2) out1[p] = in1[p];
         }
     }
-    // Thread t takes the slots t, t + T, t + 2 T, ...: the chunk boundaries of the level solves mean nothing here (a row's slots
-    // never straddle a wave, and T is a multiple of the wave).  FOUR records are requested before the first is used -- the passes
-    // over a factor are a handful, and each was a global round trip of its own when they were fetched one by one (7-12 k cycles
-    // per product on 25FV47 against ~4 k).  Slots past the end are padding up to the stride: level 0x7fffffff, no flags, zeros.
+    // Thread t takes the slots t, t + T, t + 2 T, ... (a row's slots never straddle a wave, and T is a multiple of the wave).  FOUR
+    // records are requested before the first is used -- the passes over a factor are a handful, and each was a global round trip of
+    // its own when they were fetched one by one.  Slots past the end are padding up to the stride: header 0, operands at position 0.
     constexpr int BATCH = 4;
     const int rounds = (n_slots + T - 1) / T;
     const int padding_slot = lu.task_stride - 1;
-    auto work = [&](const LuSlot& rec, const int k) {
-        const int flags = rec.flags;  // (padding slots: 0 -- no group, no write)
-        const int g = flags & 0xff;
-        const int summary = __builtin_amdgcn_readfirstlane(flags);  // the host's wave summary (build_tasks)
-        const unsigned gbits = (unsigned)(summary >> 16) & 63u;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int e = 0; e < LU_TE; ++e) s0 += rec.val[e] * in0[rec.col[e]];
-        if (NRHS == 2) {
-#pragma unroll
-            for (int e = 0; e < LU_TE; ++e) s1 += rec.val[e] * in1[rec.col[e]];
-        }
-        if ((summary >> 22) & 1) {  // rows of more than 64 LU_TE entries: the rest from the arena, by the lanes of the row's wave
-            if ((flags >> 9) & 1) {
+    auto work = [&](const LuiSlot& rec, const int k) {
+        const unsigned hdr = rec.hdr;
+        const int g = (int)(hdr >> 16) & 7;
+        const unsigned summary = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr);  // the host's wave summary
+        const unsigned gbits = (summary >> 21) & 63u;
+        const int c0 = (int)(rec.cols & 0xffffu), c1 = (int)((rec.cols >> 16) & 0xffffu), c2 = (int)((rec.cols >> 32) & 0xffffu), c3 = (int)(rec.cols >> 48);
+        double s0 = rec.v01.x * in0[c0] + rec.v01.y * in0[c1] + rec.v23.x * in0[c2] + rec.v23.y * in0[c3];
+        double s1 = 0.0;
+        if (NRHS == 2) s1 = rec.v01.x * in1[c0] + rec.v01.y * in1[c1] + rec.v23.x * in1[c2] + rec.v23.y * in1[c3];
+        if ((summary >> 27) & 1u) {  // rows of more than 256 entries: the rest from the arena, by the lanes of the row's wave
+            if ((hdr >> 20) & 1u) {
                 const int xs = tk.s_xstart[k], xn = tk.s_xn[k];
                 for (int e = lane; e < xn; e += WAVE) {
                     const int c = tk.x_idx[xs + e];
@@ -984,20 +1059,20 @@ __device__ __forceinline__ void lui_apply(const DeviceLU& lu, const int sched, c
         }
         s0 = group_sum_by(s0, g, gbits);
         if (NRHS == 2) s1 = group_sum_by(s1, g, gbits);
-        if ((flags >> 8) & 1) {
-            const int pos = rec.pos;
+        if ((hdr >> 19) & 1u) {
+            const int pos = (int)(hdr & 0xffffu);
             out0[pos] = UNIT ? in0[pos] + s0 : s0;
             if (NRHS == 2) out1[pos] = UNIT ? in1[pos] + s1 : s1;
         }
     };
     for (int r0 = 0; r0 < rounds; r0 += BATCH) {
-        LuSlot rec[BATCH];
+        LuiSlot rec[BATCH];
         int slot[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             slot[u] = (r0 + u < rounds) ? (r0 + u) * T + tid : padding_slot;
             if (r0 + u == 0) rec[u] = first_record;
-            else lui_load_slot(lu, sched, slot[u], rec[u]);
+            else rec[u] = lui_load_slot(lu, sched, slot[u]);
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) work(rec[u], slot[u]);
@@ -1209,11 +1284,13 @@ __device__ __forceinline__ void lu_ftran_block(const DeviceLU& lu, const LuShare
                                                double* spike_out, const LuSlot& lower_record) {
     (void)epoch;
     const int m = lu.m;
-    const LuSlot upper_record = lu_load_slot(lu, 1, threadIdx.x);  // (lands while L and the etas are done)
+    const LuSlot upper_record = INV ? LuSlot{} : lu_load_slot(lu, 1, threadIdx.x);  // (lands while L and the etas are done)
     if constexpr (INV) {  // x1 <- L^-1 x0, x0 <- U^-1 x1, then the product-form updates (x1 is scratch)
-        lui_apply<1, true>(lu, 0, lower_record, sh.x0, sh.x0, sh.x1, sh.x1);
+        (void)lower_record;
+        (void)upper_record;
+        lui_apply<1, true>(lu, 0, lui_load_head(lu, 0), lui_load_slot(lu, 0, threadIdx.x), sh.x0, sh.x0, sh.x1, sh.x1);
         lu_stamp(sh, 2);
-        lui_apply<1, false>(lu, 1, upper_record, sh.x1, sh.x1, sh.x0, sh.x0);
+        lui_apply<1, false>(lu, 1, lui_load_head(lu, 1), lui_load_slot(lu, 1, threadIdx.x), sh.x1, sh.x1, sh.x0, sh.x0);
         lu_stamp(sh, 3);
         lui_apply_updates_forward(lu, sh, lu.state[LU_PF_COUNT]);
         lu_stamp(sh, 4);
@@ -1270,14 +1347,16 @@ template <int NRHS, bool INV, class AfterUpper>
 __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShared& sh, const int n_updates, int& epoch,
                                                AfterUpper after_upper, const LuSlot& upper_record) {
     (void)epoch;
-    const LuSlot lower_record = lu_load_slot(lu, 3, threadIdx.x);  // (lands while U' and the etas are done)
+    const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 3, threadIdx.x);  // (lands while U' and the etas are done)
     if constexpr (INV) {  // r <- r M, then (x2, x3) <- (x0, x1) U^-1, (x0, x1) <- (x2, x3) L^-1
         lui_apply_updates_backward<NRHS>(lu, sh, lu.state[LU_PF_COUNT]);
         lu_stamp(sh, 7);
-        lui_apply<NRHS, false>(lu, 2, upper_record, sh.x0, sh.x1, sh.x2, sh.x3);
+        (void)lower_record;
+        (void)upper_record;
+        lui_apply<NRHS, false>(lu, 2, lui_load_head(lu, 2), lui_load_slot(lu, 2, threadIdx.x), sh.x0, sh.x1, sh.x2, sh.x3);
         lu_stamp(sh, 8);
         after_upper();
-        lui_apply<NRHS, true>(lu, 3, lower_record, sh.x2, sh.x3, sh.x0, sh.x1);
+        lui_apply<NRHS, true>(lu, 3, lui_load_head(lu, 3), lui_load_slot(lu, 3, threadIdx.x), sh.x2, sh.x3, sh.x0, sh.x1);
         lu_stamp(sh, 10);
         return;
     }
@@ -1518,7 +1597,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const
                                                                const double* dense, double* out, int keep_spike) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
+    const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
@@ -1538,7 +1617,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
                                                                const double* dense, double* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
+    const LuSlot upper_record = INV ? LuSlot{} : lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
@@ -1643,7 +1722,14 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     __shared__ unsigned long long s_arank[LU_THREADS / WAVE];
     __shared__ double s_bcast[4];
     Ctl* ctl = lp.ctl;
-    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // FTRAN's first solve: lands while the entering column is chosen
+    const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 0, threadIdx.x);  // FTRAN's first solve: lands while the entering column is chosen
+    // (the inverse-factor form: its compact records, the same way)
+    LuiSlot inv_lower_rows{}, inv_upper_cols{};
+    LuiHead inv_head[4] = {};
+    if constexpr (INV) {
+        inv_lower_rows = lui_load_slot(lu, 0, threadIdx.x);
+        for (int k = 0; k < 4; ++k) inv_head[k] = lui_load_head(lu, k);
+    }
     const int tid = threadIdx.x, T = blockDim.x;
     const int m = lp.m;
     LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
@@ -1754,15 +1840,19 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     int epoch = 0;
     if constexpr (INV) {
         // x1 <- L^-1 x0, x0 <- U^-1 x1, alpha = M (that), the operands y[slot_c] read first
-        const LuSlot upper_rows = lu_load_slot(lu, 1, tid);
-        lui_apply<1, true>(lu, 0, lower_record, sh.x0, sh.x0, sh.x1, sh.x1);
+        const LuiSlot upper_rows = lui_load_slot(lu, 1, tid);
+        lui_apply<1, true>(lu, 0, inv_head[0], inv_lower_rows, sh.x0, sh.x0, sh.x1, sh.x1);
         lu_stamp(sh, 2);
-        lui_apply<1, false>(lu, 1, upper_rows, sh.x1, sh.x1, sh.x0, sh.x0);
+        lui_apply<1, false>(lu, 1, inv_head[1], upper_rows, sh.x1, sh.x1, sh.x0, sh.x0);
         lu_stamp(sh, 3);
         if (pf_k > 0) {
             if (tid < pf_k) sh.xt0[tid] = sh.x0[s_pf_pos[tid]];
             __syncthreads();
+            // alpha_s = y_s + sum_c M[s][c] y[slot_c]  -  (y_s when s is a kept slot: done by the k owners afterwards).  The k operands
+            // sit one per lane and reach the multiply-adds through readlane -- as LDS broadcasts they were two reads per term.
             const gptr_f64 M = (gptr_f64)lu.pf_M;
+            const int lane = tid & (WAVE - 1);
+            const double y_lane = lane < pf_k ? sh.xt0[lane] : 0.0;
             for (int s = tid; s < m; s += T) {
                 double acc = 0.0;
                 for (int c0 = 0; c0 < pf_k; c0 += 8) {
@@ -1771,18 +1861,21 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
                     for (int u = 0; u < 8; ++u) mc[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : 0.0;
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (c0 + u < pf_k) acc += (mc[u] - (s_pf_slot[c0 + u] == s ? 1.0 : 0.0)) * sh.xt0[c0 + u];
+                        if (c0 + u < pf_k) acc += mc[u] * lane_value(y_lane, c0 + u);
                 }
                 const int pos = lu.colpos[s];
                 sh.x0[pos] = sh.x0[pos] + acc;
             }
+            __syncthreads();
+            if (tid < pf_k) sh.x0[s_pf_pos[tid]] = sh.x0[s_pf_pos[tid]] - sh.xt0[tid];
             __syncthreads();
         }
         lu_stamp(sh, 4);
     } else {
         lu_ftran_block<INV>(lu, sh, n_updates, epoch, lu.spike, lower_record);
     }
-    const LuSlot upper_record = lu_load_slot(lu, 2, tid);  // BTRAN's first solve: lands during the ratio test
+    const LuSlot upper_record = INV ? LuSlot{} : lu_load_slot(lu, 2, tid);  // BTRAN's first solve: lands during the ratio test
+    if constexpr (INV) inv_upper_cols = lui_load_slot(lu, 2, tid);
     // ---- alpha per basis slot (kept in x1), gamma_q, Harris pass 1 ----------------------------------------------------------
     // harris_delta < 0: the reference's ratio test (exact minimum, ties to the lowest leaving column; tableau/mod.rs:287-313).
     // With implicit bounds a basic variable may also leave at its upper bound -- rows with alpha_i < 0 whose basic variable has
@@ -1933,6 +2026,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         __syncthreads();
         const double inv_ap = 1.0 / alpha_pq;
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = T / WAVE;
+        const double mp_lane = lane < k_new ? sh.st0[lane] : 0.0;  // row p of the old M, one kept column per lane (readlane below)
         for (int c0 = 0; c0 < k_new; c0 += 8) {
             double part[8];
 #pragma unroll
@@ -1946,7 +2040,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     part[u] += a * old[u];
-                    if (do_update && c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * sh.st0[c0 + u];
+                    if (do_update && c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * lane_value(mp_lane, c0 + u);
                 }
             }
 #pragma unroll
@@ -1966,10 +2060,10 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         }
         __syncthreads();
         lu_stamp(sh, 7);
-        const LuSlot lower_cols = lu_load_slot(lu, 3, tid);
-        lui_apply<2, false>(lu, 2, upper_record, sh.x0, sh.x1, sh.x2, sh.x3);
+        const LuiSlot lower_cols = lui_load_slot(lu, 3, tid);
+        lui_apply<2, false>(lu, 2, inv_head[2], inv_upper_cols, sh.x0, sh.x1, sh.x2, sh.x3);
         lu_stamp(sh, 8);
-        lui_apply<2, true>(lu, 3, lower_cols, sh.x2, sh.x3, sh.x0, sh.x1);
+        lui_apply<2, true>(lu, 3, inv_head[3], lower_cols, sh.x2, sh.x3, sh.x0, sh.x1);
         lu_stamp(sh, 10);
         if (do_update && tid == 0) {
             if (have < 0) {
@@ -2047,7 +2141,7 @@ template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
+    const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
@@ -2062,7 +2156,7 @@ template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
+    const LuSlot upper_record = INV ? LuSlot{} : lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
@@ -2093,7 +2187,7 @@ template <bool INV>
 __global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, DeviceLU lu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
-    const LuSlot lower_record = lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
+    const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
     const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
     const int n_updates = lu.state[LU_N_UPDATES];
     for (int j = lp.n_art + blockIdx.x; j < lp.n; j += gridDim.x) {

@@ -68,6 +68,15 @@ struct LuTasks {
     lu_gptr_i32 chunk = nullptr;     // [chunks][8]: first slot, end slot, first level, end level, tail level (chunk 0 starts at slot 0).
                                      // From the tail level on every slot of the chunk sits in its LAST wave, which then runs on alone without barriers
     lu_gptr_i32 counts = nullptr;    // [LU_CNT_WORDS]: device-resident, so that a captured graph survives a refactorisation
+    // The inverse-factor form reads its slots in a COMPACT record instead (a product streams every entry of the factor into one CU,
+    // whose L1 moves 64 bytes per cycle: bytes are what a product costs).  44 bytes per slot instead of 56 in ten arrays:
+    //   c_hdr   position of the row (16 bits) | log2 G << 16 | writes << 19 | has extra entries << 20 | wave summary << 21
+    //           (bits 21-26: some row of the slot's wave spans more than 2^j lanes; bit 27: some row of it has extra entries)
+    //   c_col   the four operand positions, 16 bits each;   c_val   the four values, one 32-byte piece per slot
+    const __attribute__((address_space(1))) unsigned int* c_hdr = nullptr;
+    const __attribute__((address_space(1))) unsigned long long* c_col = nullptr;
+    lu_gptr_f64 c_val = nullptr;
+    lu_gptr_i32 c_zpos = nullptr;    // rows without entries (the same list as z_pos, inside the one uploaded region)
 };
 enum : int { LU_CNT_Z = 0, LU_CNT_SLOTS = 1, LU_CNT_LEVELS = 2, LU_CNT_CHUNKS = 3, LU_CNT_C0_END = 4, LU_CNT_C0_L0 = 5, LU_CNT_C0_L1 = 6, LU_CNT_C0_TAIL = 7, LU_CNT_WORDS = 8 };
 constexpr int LU_MAX_CHUNKS = 256;

@@ -67,7 +67,7 @@ def test_default_bench_line_carries_every_baseline_config():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     configs = line["configs"]
-    assert set(configs) == {"lu_carry_25fv47", "dense4096_f64", "dense4096_narrowest", "netlib_batch", "netlib_batch_presolve",
+    assert set(configs) == {"lu_carry_25fv47", "lu_inverse_carry_25fv47", "dense4096_f64", "dense4096_narrowest", "netlib_batch", "netlib_batch_presolve",
                             "maxflow_reference_start", "maxflow_crash"}
     for name, entry in configs.items():
         assert "error" not in entry, (name, entry)
@@ -75,6 +75,8 @@ def test_default_bench_line_carries_every_baseline_config():
         assert entry["roofline"]["frac"] > 0 and entry["roofline"]["peak"] == 8000.0, name
         assert entry["cpu_baseline"]["value"] > 0 and entry["cpu_baseline"]["nproc"] >= 1, name
     assert configs["lu_carry_25fv47"]["config"]["carry"] == "lu" and configs["lu_carry_25fv47"]["config"]["exact"]["certified"] is True
+    assert configs["lu_inverse_carry_25fv47"]["config"]["carry"] == "lu_inverse" and configs["lu_inverse_carry_25fv47"]["config"]["exact"]["certified"] is True
+    assert configs["lu_inverse_carry_25fv47"]["roofline"]["kernel"] == "lu_pivot"
     assert abs(configs["dense4096_f64"]["config"]["objective"] + 202885.40946447) < 1e-4
     assert abs(configs["dense4096_narrowest"]["config"]["objective"] + 202885.40946447) < 1e-4
     assert configs["dense4096_f64"]["roofline"]["kernel"] == "price" and configs["dense4096_f64"]["roofline"]["frac"] > 0.4

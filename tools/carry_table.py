@@ -7,7 +7,7 @@ import relp_amd
 names = sys.argv[1:] or ["25FV47", "GREENBEA", "80BAU3B", "SCFXM2", "PILOT4", "BNL1"]
 for name in names:
     path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
-    for label, options in (("explicit", dict(carry=0)), ("explicit+implicit bounds", dict(carry=0, implicit_bounds=1)), ("lu", dict(carry=1))):
+    for label, options in (("explicit", dict(carry=0)), ("explicit+implicit bounds", dict(carry=0, implicit_bounds=1)), ("lu", dict(carry=1)), ("lu inverse factors", dict(carry=2))):
         try:
             s = relp_amd.Solver(**options).load_mps(path)
         except relp_amd.api.RelpError as e:
