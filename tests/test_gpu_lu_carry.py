@@ -77,8 +77,6 @@ def test_lu_carry_with_implicit_bounds(name, carry):
     factors) inside the LU pivot kernel: the reference's optimum within its tolerance, certified on the basis mapped back to
     the reference's formulation."""
     expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))[name]
-    if carry == LU_INVERSE and name == "80BAU3B":
-        pytest.skip("5746 rows: beyond the four LDS vectors of the inverse-factor form")
     solver = relp_amd.Solver(carry=carry, implicit_bounds=1, certify=1).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
     result = solver.solve_relaxation()
     assert result.kind == relp_amd.FINITE_OPTIMUM
