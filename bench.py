@@ -510,7 +510,8 @@ def single_lp(args, ctx):
     # HBM traffic per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md
     # section HBM); null when not collected for this kernel
     traffic = None
-    dense_price = "price_dense_lane_kernel" if args.dense_storage == "narrowest" else "price_dense_kernel"
+    # (the dense pricing kernel is one template per storage type: bytes, float, double -- the traffic of another instance is not this one's)
+    dense_price = "price_dense_lane_kernel<%d>" % {"narrowest": 1, "f32": 4, "f64": 8}[args.dense_storage]
     pmc_names = {"price": dense_price if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
                  "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
     tag = args.workload + (("_lu" if args.carry == 1 else "_lui") if lu_carry else "")

@@ -472,7 +472,8 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
     out->denom = BigInt(1);
     if (all_zero) return true;
 
-    std::vector<std::vector<u32>> digits;  // digits[step][i]
+    std::vector<const u32*> digits;             // digits[step][i]: rows of the downloaded blocks below (no copy)
+    std::vector<std::vector<u32>> blocks;       // one block of digit steps per round of the doubling
     int steps_done = 0;
     int target = std::max(8, first_target);
     const int max_steps = 1 << 15;
@@ -494,7 +495,8 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             hipLaunchKernelGGL(dixon_residual_kernel, dim3((m + 3) / 4), dim3(256), 0, stream, m, d_row_start, d_col_index,
                                d_row_value, xs, d_r, p, d_info);
         }
-        std::vector<u32> flat((size_t)(target - steps_done) * m);
+        blocks.emplace_back((size_t)(target - steps_done) * m);
+        std::vector<u32>& flat = blocks.back();
         int info[4];
         RELP_HIP(hipMemcpyAsync(flat.data(), d_digits + (size_t)steps_done * m, flat.size() * sizeof(u32), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, stream));
@@ -510,8 +512,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             *message = info[2] ? "Dixon residual overflow (coefficients too large for the 128-bit path)" : "Dixon residual not divisible by p";
             return false;
         }
-        for (int s = steps_done; s < target; ++s)
-            digits.emplace_back(flat.begin() + (size_t)(s - steps_done) * m, flat.begin() + (size_t)(s - steps_done + 1) * m);
+        for (int s = steps_done; s < target; ++s) digits.push_back(flat.data() + (size_t)(s - steps_done) * m);
         steps_done = target;
 
         // ---- assemble, reconstruct with a common denominator, verify ---------------------------------
@@ -555,7 +556,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
                 weight[i] = (uint32_t)(1 + ((state >> 33) & 0xffff));
             }
             for (int s = 0; s < steps_done; ++s) {
-                const u32* row = digits[s].data();
+                const u32* row = digits[s];
                 unsigned long long sum = 0;
                 for (int i = 0; i < m; ++i) sum += (unsigned long long)weight[i] * row[i];
                 column[s] = sum;
@@ -645,7 +646,16 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
         if (ok) {
             out->numer = std::move(numer);
             out->denom = denom;
-            if (digits_used) *digits_used = steps_done;
+            if (digits_used) {
+                // What the NEXT lifting of the same system should start with: the digits this solution needs by the bound used above
+                // (2 bits(v) + 2 <= bits(p^K) for its largest numerator and the denominator), plus a margin of four -- not the power
+                // of two the doubling happened to stop at (128 where 25FV47 needs 117: a tenth of the device steps and a fifth of the
+                // host's quadratic work).
+                size_t widest = denom.bits();
+                for (const BigInt& v : out->numer) widest = std::max(widest, v.bits());
+                const int needed = (int)((2 * widest + 2 + 30) / 31) + 1;  // p > 2^30.99: K digits hold more than 30.99 K bits
+                *digits_used = std::min(steps_done, needed + 4);
+            }
             part(times.normalise);
             return true;
         }
@@ -653,7 +663,8 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
             *message = "Dixon lifting did not converge";
             return false;
         }
-        target = steps_done * 2;
+        // not enough digits: double from a cold start; a hinted start that fell short (another basis of the same LP) grows by a quarter
+        target = (first_target > 32 && steps_done < 2 * first_target) ? steps_done + std::max(8, first_target / 4) : steps_done * 2;
     }
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 profiles: rocprofv3 kernel stats and the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no trace domain beside
-# --pmc) of bench.py for both carries on 25FV47, for the dense LP of config 3 with the block as double, and for the max-flow LP;
+# --pmc) of bench.py for the three carries on 25FV47, for the dense LP of config 3 with the block as double, and for the max-flow LP;
 # then the default bench line (every BASELINE config) and the carry table.  Run on the GPU box from the repo root; the summaries
 # land in gpurun_out/prof_r3 and are copied into profiles/ by hand.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -20,6 +20,7 @@ profile() {  # name, bench arguments
 }
 profile 25fv47 --carry 0
 profile 25fv47_lu --carry 1
+profile 25fv47_lui --carry 2
 profile dense4096_f64 --workload dense4096 --dense-storage f64
 profile maxflow --workload maxflow --crash 0
 cd $R
