@@ -526,14 +526,7 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
         part(times.unpack);
         BigInt modulus(1);
         for (int s = 0; s < steps_done; ++s) modulus.mul_add_small(p, 0);
-        std::vector<BigInt> residue(m);
-        pool.run(m, [&](int i) {
-            BigInt acc(0);
-            for (int s = steps_done; s-- > 0;) acc.mul_add_small(p, digits[s][i]);
-            acc.trim();
-            residue[i] = acc;
-        });
-        part(times.horner);
+        part(times.horner);  // (no Horner pass any more: the numerators are formed from the digits directly, below)
         bool ok = true;
         BigInt denom(1);
         std::vector<BigInt> numer(m);
@@ -585,13 +578,53 @@ bool dixon_solve(const IntegerBasis& B, const std::vector<i64>& rhs, int transpo
         // others are reduced again.  denom is the lcm of reduced denominators at every point, so the result is in lowest terms
         // (gcd(denom, all numerators) = 1: a prime power q^e || denom divides exactly the denominator of some entry, whose
         // numerator q does not divide) and no gcd pass is needed afterwards.
-        if (ok)
+        // numer_i = (sum_s digit_s[i] p^s) denom  mod p^K  =  sum_s digit_s[i] W_s  mod p^K   with  W_s = denom p^s mod p^K:  the K
+        // multipliers are made once (each from the last by one small multiplication and a one-word quotient), and an entry is K
+        // multiply-adds of a 31-bit digit into 128-bit accumulators per 64-bit word, one carry sweep and one reduction by a two-word
+        // quotient -- instead of a Horner pass, a 4000 x 2000-bit product and a 6000 / 4000-bit division per entry on 32-bit limbs.
+        if (ok) {
+            typedef unsigned __int128 u128;
+            const int words = (int)((modulus.bits() + 63) / 64);
+            std::vector<u64> table((size_t)steps_done * words, 0);
+            {
+                BigInt w = denom % modulus;
+                for (int s = 0; s < steps_done; ++s) {
+                    u64* row = table.data() + (size_t)s * words;
+                    for (size_t l = 0; l < w.mag.size(); ++l) row[l / 2] |= (u64)w.mag[l] << (32 * (l % 2));
+                    if (s + 1 < steps_done) {
+                        w.mul_add_small(p, 0);
+                        w = w % modulus;
+                    }
+                }
+            }
             pool.run(m, [&](int i) {
-                BigInt t = (residue[i] * denom) % modulus;
+                std::vector<u128> acc(words, 0);
+                for (int s = 0; s < steps_done; ++s) {
+                    const u64 d = digits[s][i];
+                    if (d == 0) continue;
+                    const u64* row = table.data() + (size_t)s * words;
+                    for (int l = 0; l < words; ++l) acc[l] += (u128)d * row[l];
+                }
+                BigInt t;
+                t.mag.reserve(2 * words + 4);
+                u128 carry = 0;
+                for (int l = 0; l < words; ++l) {
+                    const u128 v = acc[l] + carry;  // (acc < 2^102, carry < 2^64)
+                    t.mag.push_back((uint32_t)(u64)v);
+                    t.mag.push_back((uint32_t)((u64)v >> 32));
+                    carry = v >> 64;
+                }
+                while (carry != 0) {
+                    t.mag.push_back((uint32_t)(u64)carry);
+                    carry >>= 32;
+                }
+                t.trim();
+                t = t % modulus;
                 if (cmp(t, half) > 0) t = t - modulus;
                 small[i] = within_wang_bound(t, modulus) ? 1 : 0;
                 numer[i] = t;
             });
+        }
         if (ok) {
             BigInt factor(1);  // product of the factors the combination lost
             auto centred = [&](BigInt t) {
