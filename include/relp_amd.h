@@ -94,7 +94,8 @@ typedef struct relp_options {
     int32_t carry;             /* relp_carry: which `BasisInverse` the loop maintains (the `BI` of `Carry<F, BI>`,
                                   tests/netlib/mod.rs:62) */
     int32_t refactor_period;   /* LU carry: Forrest-Tomlin updates between refactorisations (`should_refactor`,
-                                  lower_upper/mod.rs:249-252: the reference refactors after 31); at most 63; 0 = 31 */
+                                  lower_upper/mod.rs:249-252: the reference refactors after 31); at most 63; 0 = the default:
+                                  31, and 47 product-form updates for RELP_CARRY_LU_INVERSE */
     double lu_pivot_threshold; /* LU carry: relative pivot tolerance of the Markowitz factorisation (f64 needs one, the exact
                                   reference does not); 0 = 0.1 */
     int32_t ratio_rule;        /* relp_ratio_rule */

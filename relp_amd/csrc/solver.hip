@@ -213,7 +213,9 @@ void Solver::upload() {
     d_.ld = m;
     lu_mode_ = opt_.carry == RELP_CARRY_LU || opt_.carry == RELP_CARRY_LU_INVERSE;
     lu_inverse_ = opt_.carry == RELP_CARRY_LU_INVERSE;
-    refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : 31, LU_MAX_SLOTS - 1);  // T is solved by one wave
+    // (default: the reference's `should_refactor`, > 30 updates, for its Forrest-Tomlin form; 47 for the inverse-factor form, whose
+    //  kept columns cost less per update than its refactorisation per pivot: 25FV47 63 -> 59 us per pivot, CYCLE 87 -> 81)
+    refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : (lu_inverse_ ? 47 : 31), LU_MAX_SLOTS - 1);  // T is solved by one wave
     if (lu_inverse_ && !lu_fits_lds(m, refactor_period_ + 1, true))
         throw std::invalid_argument("the inverse-factor carry keeps four vectors in LDS (32 bytes per row): at most about 4300 rows (use the LU or the explicit carry beyond)");
     if (lu_mode_ && !lu_inverse_) {

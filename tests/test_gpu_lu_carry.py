@@ -39,7 +39,8 @@ def test_lu_carry_reaches_the_exact_optimum(name, carry):
     assert result.certified == 1, relp_amd.lib().relp_last_error(solver._h)
     assert solver.objective_exact() == golden["objective"]  # bit-exact with the reference's RationalBig optimum
     pivots = result.pivots_phase_one + result.pivots_phase_two
-    assert result.refactors >= pivots // 32  # `should_refactor` every 31 updates (lower_upper/mod.rs:249-252)
+    # `should_refactor` every 31 updates (lower_upper/mod.rs:249-252); the inverse-factor form's default is 47
+    assert result.refactors >= pivots // (32 if carry == LU else 48)
     solver.close()
 
 
@@ -131,7 +132,7 @@ def test_lu_carry_on_the_largest_lps_it_takes(name, carry):
     result = solver.solve_relaxation()
     assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified == 1
     assert abs(result.objective - expected["expected"]) <= max(expected["tolerance"], REL * abs(expected["expected"]))
-    assert result.refactors >= (result.pivots_phase_one + result.pivots_phase_two) // 32
+    assert result.refactors >= (result.pivots_phase_one + result.pivots_phase_two) // (32 if carry == LU else 48)
     solver.close()
 
 
