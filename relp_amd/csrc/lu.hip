@@ -2027,35 +2027,72 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         const double inv_ap = 1.0 / alpha_pq;
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = T / WAVE;
         const double mp_lane = lane < k_new ? sh.st0[lane] : 0.0;  // row p of the old M, one kept column per lane (readlane below)
-        for (int c0 = 0; c0 < k_new; c0 += 8) {
-            double part[8];
+        // alpha per basis slot into LDS (x2 is free until the products): the k sums run over it a wave per kept column
+        for (int s = tid; s < m; s += T) sh.x2[s] = lp.alpha[s];
+        __syncthreads();
+        if (m <= 1536) {
+            // (1) the k sums  sum_s alpha_s M[s][c]:  ONE wave per kept column walks the column (coalesced) and reduces once -- a
+            //     thread per row with eight sums at a time has every wave reduce every sum: 18 instructions per sum and wave
+            for (int c = wave; c < pf_k; c += nwaves) {
+                const gmut_f64 column = M + (size_t)c * lu.pf_ld;
+                double part = 0.0;
+#pragma unroll 4
+                for (int s = lane; s < m; s += WAVE) part += sh.x2[s] * column[s];
+                part = wave_sum(part);
+                if (lane == LAST) sh.xt1[c] = part;
+            }
+            __syncthreads();  // (the sums read the old M: nobody rewrites it before they are done)
+            // (2) the eta folded in, a thread per row
+            if (do_update) {
+                for (int s = tid; s < m; s += T) {
+                    const double a = sh.x2[s];
+                    const double factor = (a - (s == p ? 1.0 : 0.0)) * inv_ap;
+                    for (int c0 = 0; c0 < k_new; c0 += 8) {
+                        double old[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) part[u] = 0.0;
-            for (int s = tid; s < m; s += T) {
-                const double a = lp.alpha[s];
-                const double factor = (a - (s == p ? 1.0 : 0.0)) * inv_ap;
-                double old[8];
+                        for (int u = 0; u < 8; ++u) old[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : (s == p ? 1.0 : 0.0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) old[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : (s == p ? 1.0 : 0.0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    part[u] += a * old[u];
-                    if (do_update && c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * lane_value(mp_lane, c0 + u);
+                        for (int u = 0; u < 8; ++u)
+                            if (c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * lane_value(mp_lane, c0 + u);
+                    }
                 }
             }
+        } else {
+            // More than one row per thread and some: the sums and the fold in ONE pass over M, eight kept columns at a time (a column
+            // walked by a single wave is 40+ dependent iterations there; the wave reductions are shared by a thread's rows here)
+            for (int c0 = 0; c0 < k_new; c0 += 8) {
+                double part[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (c0 + u >= pf_k) break;  // wave-uniform (the new column's sum is alpha_p: already at p's position)
-                const double w0 = wave_sum(part[u]);
-                if (lane == LAST) sh.pfpart[wave * LU_MAX_SLOTS + c0 + u] = w0;
+                for (int u = 0; u < 8; ++u) part[u] = 0.0;
+                for (int s = tid; s < m; s += T) {
+                    const double a = sh.x2[s];
+                    const double factor = (a - (s == p ? 1.0 : 0.0)) * inv_ap;
+                    double old[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) old[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : (s == p ? 1.0 : 0.0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        part[u] += a * old[u];
+                        if (do_update && c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * lane_value(mp_lane, c0 + u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (c0 + u >= pf_k) break;  // wave-uniform (the new column's sum is alpha_p: already at p's position)
+                    const double w0 = wave_sum(part[u]);
+                    if (lane == LAST) sh.pfpart[wave * LU_MAX_SLOTS + c0 + u] = w0;
+                }
+            }
+            __syncthreads();
+            if (tid < pf_k) {
+                double sum = 0.0;
+                for (int w = 0; w < nwaves; ++w) sum += sh.pfpart[w * LU_MAX_SLOTS + tid];
+                sh.xt1[tid] = sum;
             }
         }
-        __syncthreads();
         if (tid < pf_k) {
-            double sum = 0.0;
-            for (int w = 0; w < nwaves; ++w) sum += sh.pfpart[w * LU_MAX_SLOTS + tid];
             const int pos = s_pf_pos[tid];
-            sh.x1[pos] = sum;
+            sh.x1[pos] = sh.xt1[tid];
             sh.x0[pos] = sh.st0[tid];  // (row p of M at its kept slots; p's own position holds the 1 set above unless p is kept)
         }
         __syncthreads();
