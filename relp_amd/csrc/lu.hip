@@ -2024,39 +2024,53 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         if (tid < pf_k) sh.st0[tid] = M[(size_t)tid * lu.pf_ld + p];
         if (tid == pf_k) sh.st0[pf_k] = 1.0;  // (the new column starts as e_p)
         __syncthreads();
+        lu_stamp(sh, 13);
         const double inv_ap = 1.0 / alpha_pq;
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = T / WAVE;
         const double mp_lane = lane < k_new ? sh.st0[lane] : 0.0;  // row p of the old M, one kept column per lane (readlane below)
         // alpha per basis slot into LDS (x2 is free until the products): the k sums run over it a wave per kept column
         for (int s = tid; s < m; s += T) sh.x2[s] = lp.alpha[s];
         __syncthreads();
+        lu_stamp(sh, 14);
         if (m <= 1536) {
-            // (1) the k sums  sum_s alpha_s M[s][c]:  ONE wave per kept column walks the column (coalesced) and reduces once -- a
-            //     thread per row with eight sums at a time has every wave reduce every sum: 18 instructions per sum and wave
-            for (int c = wave; c < pf_k; c += nwaves) {
+            // ONE wave per kept column: it walks the column once (coalesced, all its loads in flight), adds up  sum_s alpha_s M[s][c]
+            // (one wave reduction per column -- a thread per row with eight sums at a time has every wave reduce every sum: 18
+            // instructions per sum and wave) and writes the column back with the eta folded in; a column belongs to one wave, so
+            // the sums and the fold need no barrier between them.  The row factors (alpha_s - [s == p]) / alpha_p wait in x3.
+            if (do_update)
+                for (int s = tid; s < m; s += T) sh.x3[s] = (sh.x2[s] - (s == p ? 1.0 : 0.0)) * inv_ap;
+            __syncthreads();
+            for (int c = wave; c < k_new; c += nwaves) {
                 const gmut_f64 column = M + (size_t)c * lu.pf_ld;
+                const bool fresh = c >= pf_k;  // (the new column starts as e_p)
+                const double mp_c = sh.st0[c];
                 double part = 0.0;
-#pragma unroll 4
-                for (int s = lane; s < m; s += WAVE) part += sh.x2[s] * column[s];
-                part = wave_sum(part);
-                if (lane == LAST) sh.xt1[c] = part;
-            }
-            __syncthreads();  // (the sums read the old M: nobody rewrites it before they are done)
-            // (2) the eta folded in, a thread per row
-            if (do_update) {
-                for (int s = tid; s < m; s += T) {
-                    const double a = sh.x2[s];
-                    const double factor = (a - (s == p ? 1.0 : 0.0)) * inv_ap;
-                    for (int c0 = 0; c0 < k_new; c0 += 8) {
-                        double old[8];
+                // (twelve loads first, then their uses and the stores: with loads and stores of one array in one loop body the
+                //  compiler keeps their order, and every load became a round trip of its own -- 12 k cycles per column.  Two columns
+                //  of a wave at a time, so that their loads travel together, was measured too: slower, 17 k against 14.5 k cycles)
+                for (int s0 = lane; s0 < m; s0 += 12 * WAVE) {
+                    double old[12];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) old[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : (s == p ? 1.0 : 0.0);
+                    for (int u = 0; u < 12; ++u) {
+                        const int s = s0 + u * WAVE;
+                        old[u] = (s < m && !fresh) ? column[s] : ((s == p && fresh) ? 1.0 : 0.0);
+                    }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * lane_value(mp_lane, c0 + u);
+                    for (int u = 0; u < 12; ++u) {
+                        const int s = s0 + u * WAVE;
+                        if (s < m) {
+                            part += sh.x2[s] * old[u];
+                            if (do_update) column[s] = old[u] - sh.x3[s] * mp_c;
+                        }
                     }
                 }
+                if (!fresh) {
+                    part = wave_sum(part);
+                    if (lane == LAST) sh.xt1[c] = part;
+                }
             }
+            __syncthreads();
+            lu_stamp(sh, 15);
         } else {
             // More than one row per thread and some: the sums and the fold in ONE pass over M, eight kept columns at a time (a column
             // walked by a single wave is 40+ dependent iterations there; the wave reductions are shared by a thread's rows here)

@@ -19,6 +19,8 @@ for k, nm in enumerate(names):
     print("%-16s %9.0f cycles/launch" % (nm, d[k] / max(n, 1)))
     total += d[k] / max(n, 1)
 print("%-16s %9.0f cycles/launch" % ("sum", total))
+if carry == 2:
+    print("inside the pass over M (before its end stamp):  row p of M staged %.0f, alpha to LDS %.0f, the k sums %.0f cycles/launch (the rest of 'BTRAN U': the fold and the set-up of the two row vectors)" % (d[13] / max(n, 1), d[14] / max(n, 1), d[15] / max(n, 1)))
 for k, nm in enumerate(["L rows (FTRAN)", "U rows (FTRAN)", "U cols (BTRAN)", "L cols (BTRAN)"]):
     print("%-16s preamble %7.0f  level loop %7.0f cycles/launch  levels %.1f  slots %.0f  -> %.0f cycles per level" % (
         nm, d[32 + k] / max(n, 1), d[44 + k] / max(n, 1), d[36 + k] / max(n, 1), d[40 + k] / max(n, 1), d[44 + k] / max(d[36 + k], 1)))
