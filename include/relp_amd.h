@@ -434,6 +434,13 @@ int32_t relp_lu_factor_host(int32_t m, const int64_t* column_start, const int32_
                             int32_t* column_permutation, int64_t* lower_start, int32_t* lower_column, double* lower_value,
                             int64_t* upper_start, int32_t* upper_column, double* upper_value, double* upper_diagonal,
                             int32_t* depth_lower, int32_t* depth_upper);
+/* The same factorisation with both triangles inverted as sparse matrices -- what RELP_CARRY_LU_INVERSE uploads at a
+ * refactorisation (`LUDecomposition::invert`, lower_upper/mod.rs:78-92, then L^-1 and U^-1): lower_* = strict part of L^-1 by rows
+ * (unit diagonal implied), upper_* = U^-1 by rows with its diagonal, upper_diagonal = ones.  Host only, for tests. */
+int32_t relp_lu_invert_host(int32_t m, const int64_t* column_start, const int32_t* row_index, const double* value,
+                            double pivot_threshold, int64_t capacity, int32_t* row_permutation, int32_t* column_permutation,
+                            int64_t* lower_start, int32_t* lower_column, double* lower_value, int64_t* upper_start,
+                            int32_t* upper_column, double* upper_value, double* upper_diagonal);
 
 
 /* ---- batches of independent LPs (BASELINE config 4) -------------------------------------------

@@ -165,9 +165,11 @@ class BasisInverse:
                 "updates": etas}
 
 
-def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False):
+def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False, inverted=False):
     """Host-only ``LUDecomposition::rows`` (decomposition/mod.rs:27-143).  Returns a dict: ``rowpos``, ``colpos``, L and U as
-    lists of rows ``[(column, value)]`` of the position space, ``diag`` and the dependency depths."""
+    lists of rows ``[(column, value)]`` of the position space, ``diag`` and the dependency depths.  ``inverted``: the two triangles
+    inverted as sparse matrices instead (``relp_lu_invert_host``: what the inverse-factor carry uploads) -- ``lower_rows`` the strict
+    part of L^-1, ``upper_rows`` U^-1 with its diagonal, ``diag`` ones."""
     m = len(columns)
     start, rows, vals = _csc(columns)
     nnz = int(start[-1])
@@ -178,11 +180,17 @@ def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False):
         lc, uc = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
         lv, uv, ud = np.zeros(cap), np.zeros(cap), np.zeros(cap)
         dl, du = C.c_int32(), C.c_int32()
-        status = lib().relp_lu_factor_host(
-            m, _ptr(start, C.c_int64), _ptr(rows, C.c_int32), _ptr(vals, C.c_double), C.c_double(pivot_threshold),
-            int(bool(reference_ties)), cap, _ptr(rp, C.c_int32), _ptr(cp, C.c_int32), _ptr(ls, C.c_int64), _ptr(lc, C.c_int32),
-            _ptr(lv, C.c_double), _ptr(us, C.c_int64), _ptr(uc, C.c_int32), _ptr(uv, C.c_double), _ptr(ud, C.c_double),
-            C.byref(dl), C.byref(du))
+        if inverted:
+            status = lib().relp_lu_invert_host(
+                m, _ptr(start, C.c_int64), _ptr(rows, C.c_int32), _ptr(vals, C.c_double), C.c_double(pivot_threshold), cap,
+                _ptr(rp, C.c_int32), _ptr(cp, C.c_int32), _ptr(ls, C.c_int64), _ptr(lc, C.c_int32), _ptr(lv, C.c_double),
+                _ptr(us, C.c_int64), _ptr(uc, C.c_int32), _ptr(uv, C.c_double), _ptr(ud, C.c_double))
+        else:
+            status = lib().relp_lu_factor_host(
+                m, _ptr(start, C.c_int64), _ptr(rows, C.c_int32), _ptr(vals, C.c_double), C.c_double(pivot_threshold),
+                int(bool(reference_ties)), cap, _ptr(rp, C.c_int32), _ptr(cp, C.c_int32), _ptr(ls, C.c_int64), _ptr(lc, C.c_int32),
+                _ptr(lv, C.c_double), _ptr(us, C.c_int64), _ptr(uc, C.c_int32), _ptr(uv, C.c_double), _ptr(ud, C.c_double),
+                C.byref(dl), C.byref(du))
         if status == OK:
             break
         lib().relp_bi_last_error.restype = C.c_char_p

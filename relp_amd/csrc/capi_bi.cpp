@@ -199,4 +199,32 @@ int32_t relp_lu_factor_host(int32_t m, const int64_t* column_start, const int32_
     });
 }
 
+// ... and the same factorisation with both triangles INVERTED as sparse matrices, what the inverse-factor carry uploads (lu.hpp;
+// `lu_invert_factors`): lower_* = the strict part of L^-1 by rows (unit diagonal implied), upper_* = U^-1 by rows WITH its diagonal,
+// upper_diagonal = ones.  Host only, for tests.
+int32_t relp_lu_invert_host(int32_t m, const int64_t* column_start, const int32_t* row_index, const double* value,
+                            double pivot_threshold, int64_t capacity, int32_t* row_permutation, int32_t* column_permutation,
+                            int64_t* lower_start, int32_t* lower_column, double* lower_value, int64_t* upper_start,
+                            int32_t* upper_column, double* upper_value, double* upper_diagonal) {
+    if (m < 1 || !column_start) return RELP_ERR_ARGUMENT;
+    return guarded_bi(nullptr, [&] {
+        std::vector<int> cs(m + 1);
+        for (int j = 0; j <= m; ++j) cs[j] = (int)column_start[j];
+        for (int64_t e = 0; e < column_start[m]; ++e)
+            if (row_index[e] < 0 || row_index[e] >= m) throw std::invalid_argument("row index out of range");
+        LuOptions lo;
+        lo.threshold = pivot_threshold;
+        const HostLU f = lu_factor(m, cs.data(), row_index, value, lo);
+        if (f.singular) throw std::runtime_error("singular basis");
+        HostLU inverted;
+        if (!lu_invert_factors(f, (size_t)capacity, inverted)) throw std::invalid_argument("capacity too small");
+        const bool ok = copy_out(inverted.rowpos, row_permutation, capacity) && copy_out(inverted.colpos, column_permutation, capacity) &&
+                        copy_out(inverted.l_start, lower_start, capacity) && copy_out(inverted.l_col, lower_column, capacity) &&
+                        copy_out(inverted.l_val, lower_value, capacity) && copy_out(inverted.u_start, upper_start, capacity) &&
+                        copy_out(inverted.u_col, upper_column, capacity) && copy_out(inverted.u_val, upper_value, capacity) &&
+                        copy_out(inverted.diag, upper_diagonal, capacity);
+        if (!ok) throw std::invalid_argument("capacity too small");
+    });
+}
+
 }  // extern "C"

@@ -167,3 +167,57 @@ def test_netlib_basis_factor_is_small_and_shallow():
     assert np.allclose(reconstruct(f, model.nr_rows), A, atol=1e-9 * np.abs(A).max())
     assert f["nnz_lower"] + f["nnz_upper"] < 4 * sum(len(c) for c in columns)
     assert f["depth_lower"] + f["depth_upper"] < model.nr_rows // 4
+
+
+def dense_of(rows, m, unit_diagonal=False, diag=None):
+    a = np.eye(m) if unit_diagonal else np.zeros((m, m))
+    for i, row in enumerate(rows):
+        for j, v in row:
+            a[i, j] = v
+    if diag is not None:
+        a[np.arange(m), np.arange(m)] = diag
+    return a
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_inverted_triangles_are_the_inverses_of_the_factors(seed):
+    """What the inverse-factor carry uploads at a refactorisation (`relp_lu_invert_host` = `lu_invert_factors`, lu_host.hpp): the
+    strict part of L^-1 and U^-1 with its diagonal, as sparse rows of the position space.  On random sparse non-singular matrices --
+    near-triangular ones like simplex bases, and denser ones -- the products with the factors are the identity, the permutations are
+    those of the factorisation, and nothing above / below the diagonal appears in the wrong triangle."""
+    rng = random.Random(4100 + seed)
+    m = rng.choice([1, 2, 7, 40, 150, 400])
+    density = rng.choice([1.5, 3.0, 6.0]) / max(m, 1)
+    columns = []
+    for j in range(m):
+        column = {j: rng.choice([-3.0, -1.0, 0.5, 1.0, 2.0, 7.0])}  # a non-zero diagonal keeps it non-singular with high probability
+        for i in range(m):
+            if i != j and rng.random() < density:
+                column[i] = rng.choice([-2.0, -1.0, 1.0, 3.0, 0.25])
+        columns.append(sorted(column.items()))
+    dense = np.zeros((m, m))
+    for j, column in enumerate(columns):
+        for i, v in column:
+            dense[i, j] = v
+    if abs(np.linalg.det(dense)) < 1e-9:
+        pytest.skip("singular sample")
+    f = lu_factor_host(columns)
+    g = lu_factor_host(columns, inverted=True)
+    assert g["rowpos"] == f["rowpos"] and g["colpos"] == f["colpos"]
+    lower = dense_of(f["lower_rows"], m, unit_diagonal=True)
+    upper = dense_of(f["upper_rows"], m, diag=f["diag"])
+    lower_inverse = dense_of(g["lower_rows"], m, unit_diagonal=True)
+    upper_inverse = dense_of(g["upper_rows"], m)
+    assert all(j < i for i, row in enumerate(g["lower_rows"]) for j, _ in row)    # strictly lower
+    assert all(j >= i for i, row in enumerate(g["upper_rows"]) for j, _ in row)   # upper, diagonal included
+    assert all(any(j == i for j, _ in row) for i, row in enumerate(g["upper_rows"]))
+    assert g["diag"] == [1.0] * m
+    scale = max(1.0, np.abs(lower_inverse).max(), np.abs(upper_inverse).max())
+    assert np.allclose(lower @ lower_inverse, np.eye(m), atol=1e-10 * scale)
+    assert np.allclose(upper @ upper_inverse, np.eye(m), atol=1e-10 * scale)
+    # ... and together they are the inverse of the permuted matrix:  P B Q = L U  =>  (P B Q)^-1 = U^-1 L^-1
+    permuted = np.zeros((m, m))
+    for i in range(m):
+        for j in range(m):
+            permuted[f["rowpos"][i], f["colpos"][j]] = dense[i, j]
+    assert np.allclose(upper_inverse @ lower_inverse @ permuted, np.eye(m), atol=1e-8 * scale * scale)
