@@ -59,7 +59,8 @@ typedef enum relp_carry {
                                   (mod.rs:180-237) are two sparse matrix-vector products each instead of two level-by-level
                                   triangular solves, and the basis changes between refactorisations are kept in product form on
                                   top (the etas of `BasisInverseRows`, basis_inverse_rows.rs:96-135, as at most `refactor_period`
-                                  columns) instead of Forrest-Tomlin row etas.  At most about 4300 rows. */
+                                  columns) instead of Forrest-Tomlin row etas.  At most about 5800 rows (four vectors in LDS up to
+                                  about 4300 rows, three beyond). */
 } relp_carry;
 
 /* `Tableau::select_primal_pivot_row` (tableau/mod.rs:287-313). */

@@ -294,6 +294,8 @@ void build_inverse_tasks(const int m, const int* start, const int* idx, const do
 }
 }  // namespace
 
+static int lu_inverse_vectors(int m, int max_updates);  // (below, with the LDS sizes)
+
 bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t stream, bool inverse_factors) {
     // The inverse-factor form uploads L^-1 and U^-1 through the same task lists (every row in one level; lu.hpp).
     thread_local HostLU inverted;
@@ -311,7 +313,9 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
     // The layout depends on capacities only, so that the device addresses (and a captured hipGraph that holds them) survive
     // a refactorisation; it changes when a factor outgrows its capacity (or m / the update capacity change).
-    bool layout_changed = m != d_.m || max_updates != d_.max_updates || (inverse_factors ? 1 : 0) != d_.inverse_factors;
+    const int inverse_vectors = inverse_factors ? lu_inverse_vectors(m, max_updates) : 0;
+    if (inverse_factors && inverse_vectors == 0) throw std::invalid_argument("the inverse-factor carry: too many rows for its vectors in LDS");
+    bool layout_changed = m != d_.m || max_updates != d_.max_updates || inverse_vectors != d_.inverse_factors;
     if (layout_changed) cap_l_ = cap_u_ = 0;
     if (nl > cap_l_ || cap_l_ == 0) { cap_l_ = nl + nl / 2 + 256; layout_changed = true; }
     if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
@@ -607,7 +611,7 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     d.spike = D(o_spike);
     d.state = I(o_state);
     d.task_stride = stride;
-    d.inverse_factors = inverse_factors ? 1 : 0;
+    d.inverse_factors = inverse_vectors;
     d.pf_M = inverse_factors ? D(o_pf_m) : nullptr;
     d.pf_ld = (int)pf_ld;
     d.pf_slot = I(o_pf_slot);
@@ -639,23 +643,32 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
 
 // LDS of the solve kernels: the two vectors (16 bytes per row), the mask of the replaced positions, one count per 64 rows for
 // the ordered compactions, reductions, and the trailing block T with its four slot vectors.
-static size_t lu_lds_fixed_bytes(int m, int max_updates, bool inverse_factors = false) {
+// `inverse_vectors`: 0 = the Forrest-Tomlin form; 4 / 3 = the inverse-factor form with four vectors in LDS (a product is out of
+// place and the BTRAN has two right-hand sides) or, for the rows that leaves no room for, with three (the two right-hand sides go
+// through the factors one after the other: twice the passes over them).
+static size_t lu_lds_fixed_bytes(int m, int max_updates, int inverse_vectors = 0) {
     const size_t mm = (size_t)((m + 1) & ~1);
-    if (inverse_factors)  // four vectors (a product is out of place, BTRAN has two right-hand sides), no T / MF; the per-wave partials of M' r
-        return 4 * mm * sizeof(double) + ((size_t)(m + 31) / 32 + 2) * sizeof(int) + ((size_t)(m + 63) / 64 + 4) * sizeof(int) + 64 * sizeof(double) +
+    if (inverse_vectors)  // no T / MF; the per-wave partials of M' r
+        return (size_t)inverse_vectors * mm * sizeof(double) + ((size_t)(m + 31) / 32 + 2) * sizeof(int) + ((size_t)(m + 63) / 64 + 4) * sizeof(int) + 64 * sizeof(double) +
                ((size_t)4 * LU_MAX_SLOTS + (size_t)2 * (LU_THREADS / 64) * LU_MAX_SLOTS) * sizeof(double) + 256;
     return 2 * mm * sizeof(double) + ((size_t)(m + 31) / 32 + 2) * sizeof(int) + ((size_t)(m + 63) / 64 + 4) * sizeof(int) + 64 * sizeof(double) +
            ((size_t)2 * max_updates * (max_updates + 1) + 4 * LU_MAX_SLOTS) * sizeof(double) + 256;
 }
 constexpr size_t LU_LDS_TOTAL = 160 * 1024 - 1024;  // what a kernel may ask for (static LDS of the fused kernel comes on top)
 static size_t lu_lds_bytes_for(const DeviceLU& lu) {
-    return std::min(LU_LDS_TOTAL - 2048, lu_lds_fixed_bytes(lu.m, lu.max_updates, lu.inverse_factors != 0));
+    return std::min(LU_LDS_TOTAL - 2048, lu_lds_fixed_bytes(lu.m, lu.max_updates, lu.inverse_factors));
 }
 size_t LuFactors::lds_bytes(int) const { return lu_lds_bytes_for(d_); }
+static int lu_inverse_vectors(int m, int max_updates) {  // 4 when they fit, else 3, else 0 (does not fit at all)
+    for (int vectors = 4; vectors >= 3; --vectors)
+        if (lu_lds_fixed_bytes(m, max_updates, vectors) <= LU_LDS_TOTAL - 2048) return vectors;
+    return 0;
+}
 bool lu_fits_lds(int m, int max_updates, bool inverse_factors) {
     if (max_updates < 1) max_updates = 1;
     if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
-    return lu_lds_fixed_bytes(m, max_updates, inverse_factors) <= LU_LDS_TOTAL - 2048;
+    if (inverse_factors) return lu_inverse_vectors(m, max_updates) != 0;
+    return lu_lds_fixed_bytes(m, max_updates, 0) <= LU_LDS_TOTAL - 2048;
 }
 
 // =====================================================================================================
@@ -704,7 +717,7 @@ __device__ __forceinline__ void lu_stamp(const LuShared& sh, int k) {
     }
 #endif
 }
-__device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max_updates, bool inverse_factors = false) {
+__device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max_updates, int inverse_factors = 0) {
     const int mm = (m + 1) & ~1;
     if (inverse_factors) max_updates = 0;  // no T, no MF
     lds_i8* smem = (lds_i8*)smem_generic;
@@ -712,7 +725,7 @@ __device__ __forceinline__ LuShared lu_shared(char* smem_generic, int m, int max
     lds_f64* x0 = (lds_f64*)smem;
     lds_f64* x1 = x0 + mm;
     lds_f64* x2 = inverse_factors ? x1 + mm : x1;
-    lds_f64* x3 = inverse_factors ? x2 + mm : x1;
+    lds_f64* x3 = inverse_factors == 4 ? x2 + mm : x2;  // (three vectors: x3 is x2 -- the callers know)
     lds_f64* red = x3 + mm;
     lds_f64* T = red + 64;
     lds_f64* MF = T + max_updates * (max_updates + 1);
@@ -1353,6 +1366,16 @@ __device__ __forceinline__ void lu_btran_block(const DeviceLU& lu, const LuShare
         lu_stamp(sh, 7);
         (void)lower_record;
         (void)upper_record;
+        if (NRHS == 2 && lu.inverse_factors == 3) {  // three vectors: the right-hand sides one after the other
+            lui_apply<1, false>(lu, 2, lui_load_head(lu, 2), lui_load_slot(lu, 2, threadIdx.x), sh.x0, sh.x0, sh.x2, sh.x2);
+            lui_apply<1, true>(lu, 3, lui_load_head(lu, 3), lui_load_slot(lu, 3, threadIdx.x), sh.x2, sh.x2, sh.x0, sh.x0);
+            lui_apply<1, false>(lu, 2, lui_load_head(lu, 2), lui_load_slot(lu, 2, threadIdx.x), sh.x1, sh.x1, sh.x2, sh.x2);
+            lu_stamp(sh, 8);
+            after_upper();
+            lui_apply<1, true>(lu, 3, lui_load_head(lu, 3), lui_load_slot(lu, 3, threadIdx.x), sh.x2, sh.x2, sh.x1, sh.x1);
+            lu_stamp(sh, 10);
+            return;
+        }
         lui_apply<NRHS, false>(lu, 2, lui_load_head(lu, 2), lui_load_slot(lu, 2, threadIdx.x), sh.x0, sh.x1, sh.x2, sh.x3);
         lu_stamp(sh, 8);
         after_upper();
@@ -1598,7 +1621,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_ftran_kernel(DeviceLU lu, const
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
     if (dense) {
@@ -1618,7 +1641,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_btran_kernel(DeviceLU lu, const
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot upper_record = INV ? LuSlot{} : lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
     if (dense) {
@@ -1636,7 +1659,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot upper_record = lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors);
     const int t = lu.colpos[p];
     const int n_updates = lu.state[LU_N_UPDATES];
     if (n_updates >= lu.max_updates) {  // no room for another eta: the caller has to refactor
@@ -1732,7 +1755,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
     }
     const int tid = threadIdx.x, T = blockDim.x;
     const int m = lp.m;
-    LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
+    LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors);
 #ifdef RELP_STAMPS
     __shared__ unsigned long long s_tprev;
     if (tid == 0) {
@@ -2032,7 +2055,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         for (int s = tid; s < m; s += T) sh.x2[s] = lp.alpha[s];
         __syncthreads();
         lu_stamp(sh, 14);
-        if (m <= 1536) {
+        if (m <= 1536) {  // (always the four-vector layout: x3 is a vector of its own)
             // ONE wave per kept column: it walks the column once (coalesced, all its loads in flight), adds up  sum_s alpha_s M[s][c]
             // (one wave reduction per column -- a thread per row with eight sums at a time has every wave reduce every sum: 18
             // instructions per sum and wave) and writes the column back with the eta folded in; a column belongs to one wave, so
@@ -2112,9 +2135,17 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         __syncthreads();
         lu_stamp(sh, 7);
         const LuiSlot lower_cols = lui_load_slot(lu, 3, tid);
-        lui_apply<2, false>(lu, 2, inv_head[2], inv_upper_cols, sh.x0, sh.x1, sh.x2, sh.x3);
-        lu_stamp(sh, 8);
-        lui_apply<2, true>(lu, 3, inv_head[3], lower_cols, sh.x2, sh.x3, sh.x0, sh.x1);
+        if (lu.inverse_factors == 4) {
+            lui_apply<2, false>(lu, 2, inv_head[2], inv_upper_cols, sh.x0, sh.x1, sh.x2, sh.x3);
+            lu_stamp(sh, 8);
+            lui_apply<2, true>(lu, 3, inv_head[3], lower_cols, sh.x2, sh.x3, sh.x0, sh.x1);
+        } else {  // three vectors in LDS (more than ~4300 rows): the two right-hand sides through the factors one after the other
+            lui_apply<1, false>(lu, 2, inv_head[2], inv_upper_cols, sh.x0, sh.x0, sh.x2, sh.x2);
+            lui_apply<1, true>(lu, 3, inv_head[3], lower_cols, sh.x2, sh.x2, sh.x0, sh.x0);
+            lui_apply<1, false>(lu, 2, inv_head[2], lui_load_slot(lu, 2, tid), sh.x1, sh.x1, sh.x2, sh.x2);
+            lu_stamp(sh, 8);
+            lui_apply<1, true>(lu, 3, inv_head[3], lui_load_slot(lu, 3, tid), sh.x2, sh.x2, sh.x1, sh.x1);
+        }
         lu_stamp(sh, 10);
         if (do_update && tid == 0) {
             if (have < 0) {
@@ -2193,7 +2224,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_xb_kernel(DeviceLP lp, DeviceLU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
     for (int i = threadIdx.x; i < m; i += blockDim.x) sh.x0[lu.rowpos[i]] = lp.rhs[i];
@@ -2208,7 +2239,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pi_kernel(DeviceLP lp, DeviceLU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot upper_record = INV ? LuSlot{} : lu_load_slot(lu, 2, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors);
     const int n_updates = lu.state[LU_N_UPDATES];
     lu_clear<INV>(lu, sh, n_updates, false);
     double obj = 0.0;
@@ -2239,7 +2270,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_gamma_kernel(DeviceLP lp, Devic
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m = lu.m;
     const LuSlot lower_record = INV ? LuSlot{} : lu_load_slot(lu, 0, threadIdx.x);  // the first solve's record starts travelling at once
-    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors != 0);
+    const LuShared sh = lu_shared(smem, m, lu.max_updates, lu.inverse_factors);
     const int n_updates = lu.state[LU_N_UPDATES];
     for (int j = lp.n_art + blockIdx.x; j < lp.n; j += gridDim.x) {
         if (lp.pos[j] >= 0) continue;

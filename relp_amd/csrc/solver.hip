@@ -217,7 +217,7 @@ void Solver::upload() {
     //  kept columns cost less per update than its refactorisation per pivot: 25FV47 63 -> 59 us per pivot, CYCLE 87 -> 81)
     refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : (lu_inverse_ ? 47 : 31), LU_MAX_SLOTS - 1);  // T is solved by one wave
     if (lu_inverse_ && !lu_fits_lds(m, refactor_period_ + 1, true))
-        throw std::invalid_argument("the inverse-factor carry keeps four vectors in LDS (32 bytes per row): at most about 4300 rows (use the LU or the explicit carry beyond)");
+        throw std::invalid_argument("the inverse-factor carry keeps its vectors in LDS (32 bytes per row, 24 beyond ~4300 rows): at most about 5800 rows (use the LU or the explicit carry beyond)");
     if (lu_mode_ && !lu_inverse_) {
         if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its two solve vectors in LDS (16 bytes per row): at most about 8000 rows with this refactor period (use the explicit carry beyond)");
     }

@@ -136,8 +136,23 @@ def test_lu_carry_on_the_largest_lps_it_takes(name, carry):
     solver.close()
 
 
+def test_inverse_factor_carry_with_three_vectors_in_lds():
+    """Beyond about 4300 rows the four LDS vectors of the inverse-factor form do not fit; up to about 5800 it runs with three (the
+    two right-hand sides of the BTRAN go through the factors one after the other): 80BAU3B in the reference's formulation, 5746 rows."""
+    expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))["80BAU3B"]
+    solver = relp_amd.Solver(carry=LU_INVERSE, certify=1).load_mps(os.path.join(ROOT, "data", "netlib", "80BAU3B.SIF"))
+    assert solver.m > 5000
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified == 1
+    assert abs(result.objective - expected["expected"]) <= expected["tolerance"]
+    solver.close()
+
+
 def test_inverse_factor_carry_rejects_what_does_not_fit_its_lds():
-    """Four vectors of 8 bytes per row in LDS: 80BAU3B (5746 rows) is the LU carry's, not this one's -- an error, no silent switch."""
+    """... and beyond that: an error, no silent switch."""
+    from relp_amd.workloads import max_flow_graph
+    tail, head, capacity = max_flow_graph(1024, 8192)
+    model = relp_amd.Model.max_flow(1024, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, 1023)  # ~9 k rows
     with pytest.raises(relp_amd.RelpError) as e:
-        relp_amd.Solver(carry=LU_INVERSE).load_mps(os.path.join(ROOT, "data", "netlib", "80BAU3B.SIF"))
+        relp_amd.Solver(carry=LU_INVERSE).load_model(model)
     assert e.value.status == relp_amd.api.ERR_ARGUMENT
