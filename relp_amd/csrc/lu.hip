@@ -2055,7 +2055,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         for (int s = tid; s < m; s += T) sh.x2[s] = lp.alpha[s];
         __syncthreads();
         lu_stamp(sh, 14);
-        if (m <= 1536) {  // (always the four-vector layout: x3 is a vector of its own)
+        if (lu.inverse_factors == 4) {  // (the four-vector layout: x3 is a vector of its own)
             // ONE wave per kept column: it walks the column once (coalesced, all its loads in flight), adds up  sum_s alpha_s M[s][c]
             // (one wave reduction per column -- a thread per row with eight sums at a time has every wave reduce every sum: 18
             // instructions per sum and wave) and writes the column back with the eta folded in; a column belongs to one wave, so
