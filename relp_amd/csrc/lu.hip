@@ -223,73 +223,85 @@ void build_tasks(const int* start, const int* idx, const double* val, const doub
         for (size_t k = w0; k < w1; ++k) out.s_flags[k] |= summary;
     }
 }
-// The task list of one orientation of an INVERTED factor (lu.hpp): no levels and no chunks -- a product reads its input only, so
-// the rows are simply packed widest group first (which keeps every group aligned to its size without padding slots) and thread
-// t of the product takes the slots t, t + 1024, ...  Sizes are known up front: the arrays are sized once and filled in place
-// (the general builder above appends slot by slot: 0.21 ms per refactorisation of 25FV47 for the four inverse lists).
-void build_inverse_tasks(const int m, const int* start, const int* idx, const double* val, HostTasks& out) {
-    out.z_pos.clear(); out.z_dinv.clear(); out.s_lev.clear(); out.s_dinv.clear(); out.x_idx.clear(); out.x_val.clear();
-    out.col.resize(LU_TE);
-    out.val.resize(LU_TE);
-    out.levels = 1;
+// The slots of one orientation of an INVERTED factor (lu.hpp): no levels and no chunks -- a product reads its input only, so the
+// rows are simply packed widest group first (which keeps every group aligned to its size without padding slots) and thread t of
+// the product takes the slots t, t + 1024, ...  Sizes are known from the row lengths alone (`count_inverse_slots`), so the compact
+// records are written straight into the staging buffer (`fill_inverse_records`): the general builder above appends slot by slot
+// into vectors that are copied afterwards -- 0.18 ms per refactorisation of 25FV47 for the four inverse lists, 0.38 of GREENBEA.
+struct InverseListInfo {
+    int slots = 0, empty_rows = 0;
+    size_t extras = 0;
+    int first_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // first slot of the rows with group size 2^g
+};
+InverseListInfo count_inverse_slots(const int m, const int* start) {
+    InverseListInfo info;
     int count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < m; ++i) {
         const int n = start[i + 1] - start[i];
         if (n == 0) {
-            out.z_pos.push_back(i);
-            out.z_dinv.push_back(1.0);
-        } else {
-            count[group_log2(n)]++;
+            ++info.empty_rows;
+            continue;
         }
+        count[group_log2(n)]++;
+        if (n > LU_TE * 64) info.extras += (size_t)(n - LU_TE * 64);
     }
-    int first_of[8];  // first slot of the rows with group size 2^g, g = 6 first
-    int slots = 0;
     for (int g = 6; g >= 0; --g) {
-        first_of[g] = slots;
-        slots += count[g] << g;
+        info.first_of[g] = info.slots;
+        info.slots += count[g] << g;
     }
-    out.s_pos.assign(slots, 0);
-    out.s_flags.assign(slots, 0);
-    out.s_xstart.assign(slots, 0);
-    out.s_xn.assign(slots, 0);
-    for (int e = 0; e < LU_TE; ++e) {
-        out.col[e].assign(slots, 0);
-        out.val[e].assign(slots, 0.0);
-    }
+    return info;
+}
+void fill_inverse_records(const int m, const int* start, const int* idx, const double* val, InverseListInfo info, const int stride,
+                          unsigned int* hdr, unsigned long long* col, double* values, int* zpos, int* xstart, int* xn, int* x_idx,
+                          double* x_val) {
+    static_assert(LU_TE == 4, "the compact records of the inverse-factor form hold four entries per slot");
+    const int slots = info.slots;
+    std::fill(hdr, hdr + stride, 0u);   // padding: no group, no write ...
+    std::fill(col, col + stride, 0ull);  // ... operands at position 0 (values: whatever -- a padding slot writes nowhere)
+    std::memset(values, 0, (size_t)4 * slots * sizeof(double));
+    int nz = 0;
+    size_t nx = 0;
     for (int i = 0; i < m; ++i) {
         const int n = start[i + 1] - start[i];
-        if (n == 0) continue;
-        const int g = group_log2(n), G = 1 << g;
-        const int first = first_of[g];
-        first_of[g] += G;
-        const int inline_n = std::min(n, LU_TE * G);
-        const int xn = n - inline_n, xstart = (int)out.x_idx.size();
-        for (int j = 0; j < G; ++j) {
-            out.s_pos[first + j] = i;
-            out.s_flags[first + j] = g | ((j == G - 1) ? 1 << 8 : 0) | (xn > 0 ? 1 << 9 : 0);
-            out.s_xstart[first + j] = xstart;
-            out.s_xn[first + j] = xn;
+        if (n == 0) {
+            zpos[nz++] = i;
+            continue;
         }
+        const int g = group_log2(n), G = 1 << g;
+        const int first = info.first_of[g];
+        info.first_of[g] += G;
+        const int inline_n = std::min(n, LU_TE * G);
+        const int extra = n - inline_n;
+        for (int j = 0; j < G; ++j) {
+            hdr[first + j] = (unsigned)i | ((unsigned)g << 16) | ((j == G - 1) ? 1u << 19 : 0u) | (extra > 0 ? 1u << 20 : 0u);
+            if (extra > 0) {
+                xstart[first + j] = (int)nx;
+                xn[first + j] = extra;
+            }
+        }
+        const int* ri = idx + start[i];
+        const double* rv = val + start[i];
         for (int e = 0; e < inline_n; ++e) {  // slot j of the group takes the entries j, j + G, j + 2 G, ...
-            out.col[e / G][first + e % G] = idx[start[i] + e];
-            out.val[e / G][first + e % G] = val[start[i] + e];
+            const int slot = first + e % G, lane_entry = e / G;
+            col[slot] |= (unsigned long long)(unsigned)ri[e] << (16 * lane_entry);
+            values[4 * (size_t)slot + lane_entry] = rv[e];
         }
         for (int e = inline_n; e < n; ++e) {
-            out.x_idx.push_back(idx[start[i] + e]);
-            out.x_val.push_back(val[start[i] + e]);
+            x_idx[nx] = ri[e];
+            x_val[nx++] = rv[e];
         }
     }
-    out.chunk.assign({0, slots, 0, 1, 1, 0, 0, 0});
-    for (int w0 = 0; w0 < slots; w0 += WAVE) {  // the wave summaries (see build_tasks)
+    std::fill(zpos + nz, zpos + stride, 0);
+    for (int w0 = 0; w0 < slots; w0 += WAVE) {  // the wave summaries: bits 21-26 group sizes present, bit 27 extras present
         const int w1 = std::min(slots, w0 + WAVE);
-        int summary = 0;
+        unsigned summary = 0;
         for (int k = w0; k < w1; ++k) {
-            const int g = out.s_flags[k] & 0xff;
+            const int g = (int)(hdr[k] >> 16) & 7;
             for (int j = 0; j < 6; ++j)
-                if (g > j) summary |= 1 << (16 + j);
-            if ((out.s_flags[k] >> 9) & 1) summary |= 1 << 22;
+                if (g > j) summary |= 1u << (21 + j);
+            if ((hdr[k] >> 20) & 1u) summary |= 1u << 27;
         }
-        for (int k = w0; k < w1; ++k) out.s_flags[k] |= summary;
+        for (int k = w0; k < w1; ++k) hdr[k] |= summary;
     }
 }
 }  // namespace
@@ -364,11 +376,13 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     // list does at Netlib sizes, 8.5 -> 11.9 ms over the 75 refactorisations of 25FV47.)
     thread_local HostTasks task_storage[4];  // (per calling thread: handles of a batch refactorise concurrently; capacity is kept)
     HostTasks* tasks = task_storage;
-    if (inverse_factors) {  // (U^-1 carries its diagonal as entries)
-        build_inverse_tasks(m, f.l_start.data(), f.l_col.data(), f.l_val.data(), tasks[0]);
-        build_inverse_tasks(m, f.u_start.data(), f.u_col.data(), f.u_val.data(), tasks[1]);
-        build_inverse_tasks(m, ucs.data(), ucrow.data(), ucval.data(), tasks[2]);
-        build_inverse_tasks(m, lcs.data(), lcrow.data(), lcval.data(), tasks[3]);
+    InverseListInfo inverse_list[4];
+    const int* list_start[4] = {f.l_start.data(), f.u_start.data(), ucs.data(), lcs.data()};
+    const int* list_idx[4] = {f.l_col.data(), f.u_col.data(), ucrow.data(), lcrow.data()};
+    const double* list_val[4] = {f.l_val.data(), f.u_val.data(), ucval.data(), lcval.data()};
+    if (inverse_factors) {  // (U^-1 carries its diagonal as entries; the records are written into the staging buffer below)
+        if (m > 65535) throw std::runtime_error("the inverse-factor carry: more than 65535 rows");
+        for (int k = 0; k < 4; ++k) inverse_list[k] = count_inverse_slots(m, list_start[k]);
     } else {
         build_tasks(f.l_start.data(), f.l_col.data(), f.l_val.data(), nullptr, f.lev_start[0], f.lev_row[0], tasks[0]);
         build_tasks(f.u_start.data(), f.u_col.data(), f.u_val.data(), f.diag.data(), f.lev_start[1], f.lev_row[1], tasks[1]);
@@ -377,7 +391,7 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     }
     mark(2);
     size_t max_slots = 0;
-    for (int k = 0; k < 4; ++k) max_slots = std::max(max_slots, tasks[k].s_pos.size());
+    for (int k = 0; k < 4; ++k) max_slots = std::max(max_slots, inverse_factors ? (size_t)inverse_list[k].slots : tasks[k].s_pos.size());
     if (max_slots + 1024 > cap_slots_ || (size_t)m + 1024 > cap_slots_ || cap_slots_ == 0 || layout_changed) {
         if (max_slots + 1024 > cap_slots_ || (size_t)m + 1024 > cap_slots_ || cap_slots_ == 0) layout_changed = true;
         max_slots = std::max(max_slots, (size_t)m);
@@ -486,35 +500,17 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
             std::fill(dst + v.size(), dst + stride, pad);
         };
         if (inverse_factors) {
-            static_assert(LU_TE == 4, "the compact records of the inverse-factor form hold four entries per slot");
-            if (m > 65535) throw std::runtime_error("the inverse-factor carry: more than 65535 rows");
-            const size_t ns = t.s_pos.size();
-            unsigned int* hdr = reinterpret_cast<unsigned int*>(h + co[k].hdr);
-            unsigned long long* col = reinterpret_cast<unsigned long long*>(h + co[k].col);
-            double* val = reinterpret_cast<double*>(h + co[k].val);
-            int* zpos = reinterpret_cast<int*>(h + co[k].zpos);
-            for (size_t s2 = 0; s2 < ns; ++s2) {
-                const int fl = t.s_flags[s2];
-                hdr[s2] = (unsigned)t.s_pos[s2] | ((unsigned)(fl & 7) << 16) | ((unsigned)((fl >> 8) & 1) << 19) | ((unsigned)((fl >> 9) & 1) << 20) |
-                          ((unsigned)((fl >> 16) & 127) << 21);
-                col[s2] = (unsigned long long)(unsigned)t.col[0][s2] | ((unsigned long long)(unsigned)t.col[1][s2] << 16) |
-                          ((unsigned long long)(unsigned)t.col[2][s2] << 32) | ((unsigned long long)(unsigned)t.col[3][s2] << 48);
-                val[4 * s2] = t.val[0][s2];
-                val[4 * s2 + 1] = t.val[1][s2];
-                val[4 * s2 + 2] = t.val[2][s2];
-                val[4 * s2 + 3] = t.val[3][s2];
-            }
-            // padding up to the stride: no group, no write, operands at position 0 (values: whatever -- never written anywhere)
-            std::fill(hdr + ns, hdr + stride, 0u);
-            std::fill(col + ns, col + stride, 0ull);
-            if (!t.z_pos.empty()) std::memcpy(zpos, t.z_pos.data(), t.z_pos.size() * sizeof(int));
-            std::fill(zpos + t.z_pos.size(), zpos + stride, 0);
-            if (!t.x_idx.empty()) {  // rows of more than 256 entries (rare): their ranges and the arena
-                put_i_padded(to[k].s_xstart, t.s_xstart, 0);
-                put_i_padded(to[k].s_xn, t.s_xn, 0);
-                put_i(to[k].x_idx, t.x_idx);
-                put_d(to[k].x_val, t.x_val);
-            }
+            const InverseListInfo& info = inverse_list[k];
+            counts[k * LU_CNT_WORDS + LU_CNT_Z] = info.empty_rows;
+            counts[k * LU_CNT_WORDS + LU_CNT_SLOTS] = info.slots;
+            counts[k * LU_CNT_WORDS + LU_CNT_LEVELS] = 1;
+            counts[k * LU_CNT_WORDS + LU_CNT_CHUNKS] = 1;
+            if (info.extras > ((k == 0 || k == 3) ? cl : cu)) throw std::runtime_error("LU inverse lists: extra entries exceed their capacity");
+            fill_inverse_records(m, list_start[k], list_idx[k], list_val[k], info, stride, reinterpret_cast<unsigned int*>(h + co[k].hdr),
+                                 reinterpret_cast<unsigned long long*>(h + co[k].col), reinterpret_cast<double*>(h + co[k].val),
+                                 reinterpret_cast<int*>(h + co[k].zpos), reinterpret_cast<int*>(h + to[k].s_xstart),
+                                 reinterpret_cast<int*>(h + to[k].s_xn), reinterpret_cast<int*>(h + to[k].x_idx),
+                                 reinterpret_cast<double*>(h + to[k].x_val));
             continue;
         }
         put_i_padded(to[k].z_pos, t.z_pos, 0);
@@ -551,11 +547,11 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
         RELP_HIP(hipMemcpyAsync(dev_, h, o_counts + 4 * LU_CNT_WORDS * sizeof(int), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemcpyAsync(dev_ + compact_begin, h + compact_begin, compact_end - compact_begin, hipMemcpyHostToDevice, stream));
         for (int k = 0; k < 4; ++k) {
-            if (tasks[k].x_idx.empty()) continue;
+            if (inverse_list[k].extras == 0) continue;
             RELP_HIP(hipMemcpyAsync(dev_ + to[k].s_xstart, h + to[k].s_xstart, (size_t)stride * sizeof(int), hipMemcpyHostToDevice, stream));
             RELP_HIP(hipMemcpyAsync(dev_ + to[k].s_xn, h + to[k].s_xn, (size_t)stride * sizeof(int), hipMemcpyHostToDevice, stream));
-            RELP_HIP(hipMemcpyAsync(dev_ + to[k].x_idx, h + to[k].x_idx, tasks[k].x_idx.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-            RELP_HIP(hipMemcpyAsync(dev_ + to[k].x_val, h + to[k].x_val, tasks[k].x_val.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(dev_ + to[k].x_idx, h + to[k].x_idx, inverse_list[k].extras * sizeof(int), hipMemcpyHostToDevice, stream));
+            RELP_HIP(hipMemcpyAsync(dev_ + to[k].x_val, h + to[k].x_val, inverse_list[k].extras * sizeof(double), hipMemcpyHostToDevice, stream));
         }
     } else if (upload_bytes <= (size_t)(2u << 20)) {
         RELP_HIP(hipMemcpyAsync(dev_, h, upload_bytes, hipMemcpyHostToDevice, stream));
