@@ -1872,18 +1872,31 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
             const gptr_f64 M = (gptr_f64)lu.pf_M;
             const int lane = tid & (WAVE - 1);
             const double y_lane = lane < pf_k ? sh.xt0[lane] : 0.0;
-            for (int s = tid; s < m; s += T) {
-                double acc = 0.0;
+            for (int s = tid; s < m; s += 2 * T) {  // two of a thread's rows at a time: sixteen loads in flight (m > 1024 only matters)
+                const int s2 = s + T;
+                const bool has2 = s2 < m;
+                double acc = 0.0, acc2 = 0.0;
                 for (int c0 = 0; c0 < pf_k; c0 += 8) {
-                    double mc[8];
+                    double mc[8], mc2[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) mc[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : 0.0;
+                    for (int u = 0; u < 8; ++u) {
+                        mc[u] = (c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : 0.0;
+                        mc2[u] = (has2 && c0 + u < pf_k) ? M[(size_t)(c0 + u) * lu.pf_ld + s2] : 0.0;
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (c0 + u < pf_k) acc += mc[u] * lane_value(y_lane, c0 + u);
+                        if (c0 + u < pf_k) {
+                            const double y = lane_value(y_lane, c0 + u);
+                            acc += mc[u] * y;
+                            acc2 += mc2[u] * y;
+                        }
                 }
                 const int pos = lu.colpos[s];
                 sh.x0[pos] = sh.x0[pos] + acc;
+                if (has2) {
+                    const int pos2 = lu.colpos[s2];
+                    sh.x0[pos2] = sh.x0[pos2] + acc2;
+                }
             }
             __syncthreads();
             if (tid < pf_k) sh.x0[s_pf_pos[tid]] = sh.x0[s_pf_pos[tid]] - sh.xt0[tid];
