@@ -775,8 +775,6 @@ def all_configs(args, ctx, legs):
     attempt("lu_inverse_carry_25fv47", lambda: single_lp(variant(carry=2, steps=steps, warmup=1), ctx))
     attempt("dense4096_f64", lambda: single_lp(variant(workload="dense4096", dense_storage="f64", steps=steps, warmup=1), ctx))
     attempt("dense4096_narrowest", lambda: single_lp(variant(workload="dense4096", dense_storage="narrowest", steps=steps, warmup=1), ctx))
-    attempt("netlib_batch", lambda: netlib_batch(variant(workload="netlib", presolve=False, steps=2, warmup=1), ctx))
-    attempt("netlib_batch_presolve", lambda: netlib_batch(variant(workload="netlib", presolve=True, steps=2, warmup=1), ctx))
     attempt("maxflow_reference_start", lambda: single_lp(variant(workload="maxflow", crash=0, steps=1, warmup=1), ctx))
     attempt("maxflow_crash", lambda: single_lp(variant(workload="maxflow", crash=1, steps=steps, warmup=1), ctx))
     if not args.no_cpu_baseline:
@@ -791,6 +789,11 @@ def all_configs(args, ctx, legs):
         for key in ("maxflow_reference_start", "maxflow_crash"):
             if "error" not in out[key]:
                 out[key]["cpu_baseline"] = flow_cpu
+    # The batch lines last, when the CPU legs above have finished: a batch has four host threads that factorise, certify and feed
+    # four streams, and shared the cores with three busy CPU legs before (0.59-0.75 s per presolved pass from run to run).
+    attempt("netlib_batch", lambda: netlib_batch(variant(workload="netlib", presolve=False, steps=2, warmup=1), ctx))
+    attempt("netlib_batch_presolve", lambda: netlib_batch(variant(workload="netlib", presolve=True, steps=2, warmup=1), ctx))
+    if not args.no_cpu_baseline:
         # the all-cores leg runs alone, after every other CPU leg and GPU measurement
         legs.start("netlib", "netlib", max(2.0, args.cpu_seconds), blas=1)
         netlib_cpu = legs.collect("netlib", timeout=900)
