@@ -8,7 +8,7 @@ def free():
 base = None
 for rnd in range(6):
     for name in ("AFIRO", "SC105", "ADLITTLE", "25FV47"):
-        for carry in (0, 1):
+        for carry in (0, 1, 2):
             s = relp_amd.Solver(certify=1, carry=carry).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
             for _ in range(3):
                 s.solve_relaxation()
