@@ -1166,44 +1166,6 @@ __device__ __forceinline__ void lui_apply_updates_backward(const DeviceLU& lu, c
     __syncthreads();
 }
 
-// The eta of a pivot on basis slot p with the FTRAN result alpha (per basis slot, global memory) folded into the kept columns:
-//   M <- E M,  E = I - (alpha - e_p) e_p' / alpha_p:   M[s][c] -= (alpha_s - [s == p]) M[p][c] / alpha_p,
-// and a new kept column for p when it had none (M[:, p] was e_p).  Row p of the old M is read first (st0).
-__device__ __forceinline__ void lui_fold_eta(const DeviceLU& lu, const LuShared& sh, const int k, const int p, const double* alpha,
-                                             const double alpha_p) {
-    const int m = lu.m;
-    typedef __attribute__((address_space(1))) double* gmut_f64;
-    const gmut_f64 M = (gmut_f64)lu.pf_M;
-    const int have = lu.pf_col_of[p];
-    const int k_new = have >= 0 ? k : k + 1;
-    if ((int)threadIdx.x < k_new) {
-        const int c = threadIdx.x;
-        sh.st0[c] = (c < k) ? M[(size_t)c * lu.pf_ld + p] : 1.0;  // (the new column starts as e_p)
-    }
-    __syncthreads();
-    const double inv = 1.0 / alpha_p;
-    for (int s = threadIdx.x; s < m; s += blockDim.x) {
-        const double factor = (alpha[s] - (s == p ? 1.0 : 0.0)) * inv;
-        for (int c0 = 0; c0 < k_new; c0 += 8) {
-            double old[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) old[u] = (c0 + u < k) ? M[(size_t)(c0 + u) * lu.pf_ld + s] : (s == p ? 1.0 : 0.0);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c0 + u < k_new) M[(size_t)(c0 + u) * lu.pf_ld + s] = old[u] - factor * sh.st0[c0 + u];
-        }
-    }
-    if (threadIdx.x == 0) {
-        if (have < 0) {
-            lu.pf_slot[k] = p;
-            lu.pf_col_of[p] = k;
-        }
-        lu.state[LU_PF_COUNT] = k_new;
-        lu.state[LU_N_UPDATES] = lu.state[LU_N_UPDATES] + 1;
-    }
-    __syncthreads();
-}
-
 // ---- eta files, applied in parallel -------------------------------------------------------------------------------------------
 // FTRAN direction (eta_file.rs:72-105): for each update j in order  v[t_j] -= sum_k r_jk v[k].  With V_j the value of v[t_j]
 // right after step j:  V_j = base_j - sum_{i<j} MF[j][i] V_i,  base_j = (v[t_j] unless an earlier eta pivots there) - the dot
