@@ -208,20 +208,6 @@ void build_tasks(const int* start, const int* idx, const double* val, const doub
     }
     close_chunk(out.levels, out.levels);
     if ((int)out.chunk.size() / 8 > LU_MAX_CHUNKS) throw std::runtime_error("LU task list: too many chunks");
-    // Wave summaries, the same in every slot of a wave (64 consecutive slots): bits 16-21 = "some row of this wave spans more than
-    // 2^j lanes", bit 22 = "some row of this wave has extra entries" -- what the products of the inverse-factor form would
-    // otherwise find out with seven ballots per slot (the level solves ask per level and keep their own ballots).
-    for (size_t w0 = 0; w0 < out.s_flags.size(); w0 += WAVE) {
-        const size_t w1 = std::min(out.s_flags.size(), w0 + WAVE);
-        int summary = 0;
-        for (size_t k = w0; k < w1; ++k) {
-            const int g = out.s_flags[k] & 0xff;
-            for (int j = 0; j < 6; ++j)
-                if (g > j) summary |= 1 << (16 + j);
-            if ((out.s_flags[k] >> 9) & 1) summary |= 1 << 22;
-        }
-        for (size_t k = w0; k < w1; ++k) out.s_flags[k] |= summary;
-    }
 }
 // The slots of one orientation of an INVERTED factor (lu.hpp): no levels and no chunks -- a product reads its input only, so the
 // rows are simply packed widest group first (which keeps every group aligned to its size without padding slots) and thread t of
