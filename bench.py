@@ -13,8 +13,13 @@ exact-rational restatement of relp's own algorithm on one host core, bounded sam
 the other BASELINE configs in the same process and reports them under ``configs``: the LU carry on 25FV47, the dense LP of
 config 3 with the block stored as double and in the narrowest exact type, the Netlib batch of config 4 without and with the
 reference's presolve, and the max-flow LP of config 5 from the reference's artificial start and from the crash basis --
-each with its own ``value``, ``ms_per_step``, ``roofline`` and ``cpu_baseline``.  CPU legs run as child processes beside
-the GPU measurements (one core each; the all-cores Netlib leg runs alone at the end).
+each with its own ``value``, ``ms_per_step``, ``roofline`` and ``cpu_baseline``.  CPU legs run as child processes, started after
+the headline's timed region (one core each; the all-cores Netlib leg runs alone at the end).
+
+Output: the LAST stdout line is ONE COMPACT JSON object (< 4 KB: the driver's capture is bounded) with every contract field, the
+roofline of the dominant kernel, the CPU baselines, ``value_lu_carry`` / ``value_lu_inverse_carry`` (the same LP and step under the
+LU carries: BASELINE configs[1] as written) and ``configs_summary`` {name: [value, ms_per_step, roofline.frac]}; the full record --
+per-kernel tables, every config object, CPU samples, per-rank records -- is written to ``bench_configs.json`` (``--detail``).
 """
 import argparse
 import copy
@@ -48,6 +53,123 @@ def emit(text):
     except OSError:
         pass
     print(text, flush=True)
+
+
+def _round(value, digits=6):
+    """Floats of the compact line: six significant digits (the full precision is in the detail file)."""
+    if isinstance(value, float):
+        return float("%.*g" % (digits, value))
+    if isinstance(value, dict):
+        return {k: _round(v, 12 if k == "objective" else digits) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [_round(v, digits) for v in value]
+    return value
+
+
+def _short(text, limit):
+    text = "" if text is None else str(text)
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def compact_cpu(record, sample_limit=200):
+    """A CPU baseline as it appears in the compact line."""
+    if not isinstance(record, dict):
+        return None
+    if "error" in record:
+        return {"error": _short(record["error"], 120)}
+    out = {k: record.get(k) for k in ("value", "unit", "cores", "kind", "mode", "cpu_model", "nproc") if k in record}
+    out["sample"] = _short(record.get("sample"), sample_limit)
+    return out
+
+
+def summary_triple(entry):
+    """[value, ms_per_step, roofline.frac] of one config of the detail file."""
+    if not isinstance(entry, dict) or "error" in entry:
+        return {"error": _short((entry or {}).get("error"), 80)}
+    return [entry.get("value"), entry.get("ms_per_step"), (entry.get("roofline") or {}).get("frac")]
+
+
+COMPACT_LIMIT = 4000  # bytes: the driver keeps the last 8 KB of stdout; the LAST line must parse on its own from its final 4 KB
+
+
+def compact_line(line, detail_name):
+    """The ONE line the driver parses: every contract field, the roofline of the dominant kernel and the CPU baseline in
+    short form, the other BASELINE configs as `configs_summary` {name: [value, ms_per_step, roofline.frac]} and the LU carries'
+    figures on the same LP at top level.  Everything else (per-kernel tables, per-rank records, notes, the full config
+    objects) goes to `detail_name` (written next to bench.py)."""
+    config, roofline = line.get("config", {}), line.get("roofline")
+    exact = config.get("exact") or {}
+    out = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    keep = ("carry", "pivots_per_solve", "objective", "wall_clock_to_exact_optimum_s", "wall_clock_f64_loop_s", "refactors",
+            "refactor_seconds_per_solve", "parallelism", "makespan_s", "throughput_kind", "lps_in_flight_per_gpu", "single_pass_makespan_s",
+            "longest_lp", "tickets_per_rank", "pivots_per_rank", "objectives_outside_reference_tolerance", "carry_per_lp")
+    out["config"] = {"workload": _short(config.get("workload"), 260)}
+    out["config"].update({k: config[k] for k in keep if k in config and config[k] is not None})
+    if exact:
+        out["config"]["certified"] = bool(exact.get("certified"))
+        if "objective_bits" in exact:
+            out["config"]["objective_bits"] = exact["objective_bits"]
+    if "ratio_rule" in config:
+        out["config"]["ratio_rule"] = _short(config["ratio_rule"], 40)
+    if config.get("aggregate_with_copies_in_flight"):
+        out["config"]["pivots_per_s_4_copies_in_flight"] = config["aggregate_with_copies_in_flight"]["pivots_per_s"]
+    if roofline:
+        seconds = roofline.get("seconds_per_launch")
+        if isinstance(seconds, dict):
+            seconds = seconds.get(roofline.get("kernel"))
+        out["roofline"] = {k: roofline.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                        "algorithmic_bytes_per_launch", "kernel_bytes_per_launch") if k in roofline}
+        out["roofline"]["seconds_per_launch"] = seconds
+        per_pivot = roofline.get("per_pivot") or {}
+        if per_pivot.get("contract_frac") is not None:
+            out["roofline"]["per_pivot_contract_frac"] = per_pivot["contract_frac"]
+    for key in ("cpu_baseline", "cpu_baseline_tuned"):
+        if key in line:
+            out[key] = compact_cpu(line[key], 220 if key == "cpu_baseline" else 60)
+    f64 = line.get("cpu_baseline_f64")
+    if isinstance(f64, dict) and "error" not in f64:
+        out["cpu_baseline_f64_port"] = {"value": f64.get("value"), "unit": f64.get("unit"), "cores": f64.get("cores"),
+                                        "what": "numpy twin of the device's f64 loop, whole solve"}
+        tuned = f64.get("tuned_cpu_solver") or {}
+        if "seconds" in tuned:
+            gpu_seconds = config.get("wall_clock_to_exact_optimum_s")
+            out["cpu_baseline_f64_tuned"] = {"name": "HiGHS dual simplex (scipy highs-ds, presolve on), same LP", "seconds": tuned["seconds"],
+                                             "iterations": tuned.get("iterations"), "cores": 1,
+                                             "gpu_seconds_to_exact_optimum": gpu_seconds,
+                                             "cpu_over_gpu": tuned["seconds"] / gpu_seconds if gpu_seconds else None}
+    for key in ("value_lu_carry", "value_lu_inverse_carry", "same_work_exact"):
+        if key in line:
+            out[key] = line[key]
+    if "configs" in line:
+        out["configs_summary"] = {name: summary_triple(entry) for name, entry in line["configs"].items()}
+        out["configs_summary_fields"] = ["value (pivots/s)", "ms_per_step", "roofline.frac"]
+    if "host" in line:
+        out["host"] = line["host"]
+    out["detail_file"] = detail_name
+    out = _round(out)
+    text = json.dumps(out, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:  # never let the line outgrow the driver's capture again: drop the prose first, then the summaries
+        for victim in (("cpu_baseline", "sample"), ("cpu_baseline_tuned", None), ("config", "workload"), ("configs_summary", None)):
+            if victim[1] is None:
+                out.pop(victim[0], None)
+            elif isinstance(out.get(victim[0]), dict):
+                out[victim[0]][victim[1]] = _short(out[victim[0]].get(victim[1]), 60)
+            text = json.dumps(out, separators=(",", ":"))
+            if len(text) <= COMPACT_LIMIT:
+                break
+    return text
+
+
+def write_detail(line, path):
+    """The full record (what round 3 printed as one 35 KB line): every config with its per-kernel roofline table, CPU legs with
+    their samples, per-rank records."""
+    try:
+        with open(path, "w") as handle:
+            json.dump(line, handle, indent=1)
+            handle.write("\n")
+    except OSError as error:  # a read-only checkout must not take the bench line down
+        sys.stderr.write("bench.py: cannot write %s: %s\n" % (path, error))
 
 
 def host_description():
@@ -824,6 +946,8 @@ def main():
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
     parser.add_argument("--records", default=None, help="netlib batch: write one JSON line per solved LP to this file")
     parser.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"], help="netlib batch: work distribution")
+    parser.add_argument("--detail", default=os.path.join(ROOT, "bench_configs.json"),
+                        help="file that receives the full record (per-kernel tables, every config, CPU samples); the stdout line is compact")
     parser.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
     args = parser.parse_args()
 
@@ -860,9 +984,13 @@ def main():
     dense = not isinstance(path, str) and not graph
     full = rank == 0 and world == 1 and args.workload == "25fv47" and not args.no_configs and not args.presolve and args.carry == 0
 
-    # CPU legs start now and run beside the GPU work (reported at N = 1 only)
+    # CPU legs (reported at N = 1 only) start AFTER the headline's timed region -- nothing competes with the host thread that feeds the
+    # GPU while `value` is measured -- and run beside the other configs
     legs = CpuLegs()
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+
+    line = netlib_batch(args, ctx) if batch_workload else single_lp(args, ctx)
+
     if want_cpu and not batch_workload and not graph and not dense:
         legs.start("exact_faithful", "exact_faithful", args.cpu_seconds)
         legs.start("exact_tuned", "exact_tuned", args.cpu_seconds)
@@ -872,11 +1000,13 @@ def main():
         legs.start("dense", "dense:%dx%d" % dims, args.cpu_seconds)
     if want_cpu and (graph or full):
         legs.start("maxflow", "maxflow", args.cpu_seconds)
-
-    line = netlib_batch(args, ctx) if batch_workload else single_lp(args, ctx)
     if rank == 0:
         if full:
             line["configs"] = all_configs(args, ctx, legs)
+            # BASELINE configs[1] as written ("LU carry BasisInverse"): the same LP, same step, under the two LU carries
+            for key, name in (("value_lu_carry", "lu_carry_25fv47"), ("value_lu_inverse_carry", "lu_inverse_carry_25fv47")):
+                if "error" not in line["configs"].get(name, {"error": 1}):
+                    line[key] = line["configs"][name]["value"]
         if want_cpu:
             if batch_workload:
                 legs.start("netlib", "netlib", max(2.0, args.cpu_seconds), blas=1)
@@ -893,7 +1023,8 @@ def main():
     if distributed:
         torch.distributed.destroy_process_group()
     if rank == 0:
-        emit(json.dumps(line))
+        write_detail(line, args.detail)
+        emit(compact_line(line, os.path.relpath(args.detail, ROOT) if args.detail.startswith(ROOT) else args.detail))
 
 
 if __name__ == "__main__":

@@ -1,11 +1,10 @@
 """The driver's contract for ``bench.py`` (``-m gpu``): one JSON line as the LAST line of stdout with the named fields, the
 roofline object of the dominant kernel and the CPU baseline -- the default workload, end to end as a child process."""
-import json
 import os
-import subprocess
-import sys
 
 import pytest
+
+from bench_support import run_bench
 
 pytestmark = pytest.mark.gpu
 
@@ -13,13 +12,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_default_bench_line_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2",
-                          "--no-configs", "--no-concurrency-probe"], capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    short, line, _ = run_bench(["--steps", "2", "--warmup", "1", "--cpu-seconds", "2", "--no-configs", "--no-concurrency-probe"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
+        assert key in short, key
+    # the compact line (what the driver parses) agrees with the detail file
+    assert abs(short["value"] - line["value"]) <= 1e-5 * line["value"] and short["unit"] == "pivots/s" and short["dtype"] == "f64"
+    assert short["config"]["carry"] == "explicit" and short["config"]["certified"] is True and short["config"]["objective_bits"] == 1791
+    assert abs(short["config"]["objective"] - 5501.8458883) < 1e-6 and short["config"]["pivots_per_solve"] == line["config"]["pivots_per_solve"]
+    assert short["roofline"]["kernel"] == line["roofline"]["kernel"] and short["roofline"]["peak"] == 8000.0
+    assert abs(short["roofline"]["frac"] - short["roofline"]["achieved"] / 8000.0) < 1e-6 * short["roofline"]["frac"] + 1e-12
+    assert short["roofline"]["seconds_per_launch"] > 0 and short["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert short["cpu_baseline"]["kind"] == "port" and short["cpu_baseline"]["mode"] == "faithful" and short["cpu_baseline"]["cores"] == 1
+    assert short["cpu_baseline"]["value"] > 0 and short["cpu_baseline"]["nproc"] >= 1 and short["cpu_baseline"]["cpu_model"] and short["cpu_baseline"]["sample"]
+    assert short["cpu_baseline_f64_tuned"]["seconds"] > 0 and "HiGHS" in short["cpu_baseline_f64_tuned"]["name"]
     assert line["unit"] == "pivots/s" and line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f64"
     assert "25FV47" in line["config"]["workload"] and "model" not in line["config"]
@@ -47,11 +54,10 @@ def test_default_bench_line_contract():
 
 def test_netlib_batch_line_through_the_library_batch_entry():
     """`bench.py --workload netlib --steps 1`: the batch runner (relp_batch_run, four LPs in flight) on one GPU."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "netlib", "--steps", "1", "--warmup", "1",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    short, line, _ = run_bench(["--workload", "netlib", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     config = line["config"]
+    assert short["config"]["tickets_per_rank"] == [45] and short["config"]["objectives_outside_reference_tolerance"] == []
+    assert short["config"]["lps_in_flight_per_gpu"] == 4 and short["value"] > 1000
     assert line["n_gpus"] == 1 and config["tickets_per_rank"] == [45] and config["objectives_outside_reference_tolerance"] == []
     assert config["lps_in_flight_per_gpu"] == 4 and len(config["workers_per_rank"][0]) == 4
     assert sum(w["tickets"] for w in config["workers_per_rank"][0]) == 45
@@ -59,14 +65,19 @@ def test_netlib_batch_line_through_the_library_batch_entry():
     assert line["value"] > 1000 and "suite throughput" in config["throughput_kind"]
 
 
-def test_default_bench_line_carries_every_baseline_config():
-    """The driver's default invocation: the headline and, under `configs`, every other BASELINE config with its own value, roofline
-    and CPU baseline (short CPU legs here)."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
-                         capture_output=True, text=True, timeout=1500)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+def test_default_bench_compact_line_and_detail_file_with_every_baseline_config():
+    """The driver's default invocation: the LAST stdout line is compact (parses from the final 4096 bytes: checked by run_bench) and
+    carries the headline, its roofline and CPU baseline, the LU carries' figures on the same LP at top level and a summary of every
+    other BASELINE config; the detail file carries every config with its own value, roofline and CPU baseline (short CPU legs here)."""
+    short, line, _ = run_bench(["--steps", "2", "--warmup", "1", "--cpu-seconds", "2"], timeout=1500)
     configs = line["configs"]
+    assert set(short["configs_summary"]) == set(configs)
+    for name, triple in short["configs_summary"].items():
+        assert isinstance(triple, list) and len(triple) == 3 and triple[0] > 0 and triple[1] > 0 and triple[2] > 0, (name, triple)
+        assert abs(triple[0] - configs[name]["value"]) <= 1e-5 * triple[0]
+    assert abs(short["value_lu_carry"] - configs["lu_carry_25fv47"]["value"]) <= 1e-5 * short["value_lu_carry"]
+    assert abs(short["value_lu_inverse_carry"] - configs["lu_inverse_carry_25fv47"]["value"]) <= 1e-5 * short["value_lu_inverse_carry"]
+    assert short["roofline"]["frac"] > 0 and short["cpu_baseline"]["value"] > 0 and short["value"] > short["cpu_baseline"]["value"]
     assert set(configs) == {"lu_carry_25fv47", "lu_inverse_carry_25fv47", "dense4096_f64", "dense4096_narrowest", "netlib_batch", "netlib_batch_presolve",
                             "maxflow_reference_start", "maxflow_crash"}
     for name, entry in configs.items():

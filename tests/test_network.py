@@ -360,10 +360,9 @@ def test_bench_rccl_path_runs_at_world_size_one():
     import sys
     env = dict(os.environ, RELP_FORCE_DISTRIBUTED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                          "--no-configs", "--no-concurrency-probe"], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    from bench_support import run_bench
+    short, line, _ = run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--no-concurrency-probe"], env=env, timeout=600)
+    assert short["n_gpus"] == 1 and short["config"]["certified"] is True
     assert line["n_gpus"] == 1 and line["steps"] == 2
     assert line["config"]["exact"]["certified"] is True
     assert abs(line["config"]["objective"] - 5501.8458883) < 1e-6
@@ -383,12 +382,12 @@ def test_bench_two_ranks_over_rccl(workload):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-               "--workload", workload, "--no-cpu-baseline", "--no-dense-roofline", "--no-concurrency-probe"]
-    out = subprocess.run(command, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    from bench_support import run_bench
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29533"]
+    short, line, _ = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--no-cpu-baseline",
+                                "--no-dense-roofline", "--no-concurrency-probe"], env=env, launcher=launcher)
+    assert short["n_gpus"] == 2 and short["value"] > 0
     assert line["n_gpus"] == 2 and line["steps"] == 2
     config = line["config"]
     assert config["makespan_s"] > 0
@@ -409,10 +408,9 @@ def test_bench_max_flow_workload_line(crash):
     import json
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "maxflow64k", "--steps", "1", "--warmup", "1",
-                          "--crash", str(crash), "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    from bench_support import run_bench
+    short, line, _ = run_bench(["--workload", "maxflow64k", "--steps", "1", "--warmup", "1", "--crash", str(crash), "--no-cpu-baseline"], timeout=600)
+    assert abs(short["config"]["objective"] + 421.0) < 1e-9 and short["roofline"]["frac"] > 0
     assert line["unit"] == "pivots/s" and line["n_gpus"] == 1 and line["value"] > 0
     assert abs(line["config"]["objective"] + 421.0) < 1e-9            # scipy's max-flow value on this graph
     assert set(line["roofline"]["kernels"]) == {"price", "ftran_ratio", "update"}
@@ -435,14 +433,13 @@ def test_bench_two_ranks_sharing_one_device(workload):
     import subprocess
     import sys
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELP_BENCH_SHARED_DEVICE="1")
-    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-               "--workload", workload]
-    out = subprocess.run(command, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
+    from bench_support import run_bench
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29537"]
+    short, line, out = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload], env=env, launcher=launcher)
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints the one line
-    line = json.loads(lines[0])
+    assert short["n_gpus"] == 2 and short["value"] > 0 and "configs_summary" not in short and "cpu_baseline" not in short
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert "configs" not in line and "cpu_baseline" not in line  # N = 1 only
     config = line["config"]
