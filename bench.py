@@ -488,11 +488,9 @@ def single_lp(args, ctx):
         if key not in ctx["cache"]:
             ctx["cache"][key] = dense_lp(*path)
         a, b, c = ctx["cache"][key]
-        for var in ("RELP_DENSE_F32", "RELP_DENSE_F64"):
-            os.environ.pop(var, None)
-        if args.dense_storage != "narrowest":  # generic data: the block as float / double (the library reads this at load time)
-            os.environ["RELP_DENSE_F32" if args.dense_storage == "f32" else "RELP_DENSE_F64"] = "1"
-        solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512"))).load_dense_le(a, b, c)
+        # generic data: the block as float / double through relp_options.dense_storage (the narrowest exact type is the default)
+        solver = relp_amd.Solver(device=local_rank, polish_period=int(os.environ.get("RELP_POLISH", "512")),
+                                 dense_storage={"narrowest": 0, "f32": 1, "f64": 2}[args.dense_storage]).load_dense_le(a, b, c)
     else:
         # the step is `solve_relaxation` with the exact certificate INSIDE: the f64 loop alone is narrower arithmetic than the
         # reference's, the bit-exact optimum is part of the job (BASELINE.json north_star)

@@ -71,6 +71,13 @@ typedef enum relp_ratio_rule {
                                   data on which f64 is exact (small integers); rows <= 8192 */
 } relp_ratio_rule;
 
+/* Storage type of a dense column block (`relp_options.dense_storage`). */
+typedef enum relp_dense_storage {
+    RELP_DENSE_NARROWEST = 0,  /* the narrowest type that holds every entry exactly: signed bytes, else float, else double */
+    RELP_DENSE_FLOAT = 1,      /* float when every entry is exactly representable, else double */
+    RELP_DENSE_DOUBLE = 2      /* double (SURVEY.md section 8(d)'s 8 bytes per entry) */
+} relp_dense_storage;
+
 typedef struct relp_options {
     int32_t device;            /* HIP device ordinal */
     int32_t pivot_rule;        /* relp_pivot_rule */
@@ -105,6 +112,19 @@ typedef struct relp_options {
                                   columns with a single entry in the rows still on an artificial are assigned breadth first
                                   -- a spanning forest on the graph providers -- and the crash is kept when it is primal
                                   feasible.  Same optimum, different (much shorter) pivot sequence; explicit carry only */
+    /* ---- appended in round 4: what was reachable only through the environment before (the variables still override) ---- */
+    int32_t dense_storage;     /* relp_dense_storage: storage type of a dense column block (relp_load_dense_le; BASELINE config 3
+                                  names the f64 block); RELP_DENSE_F32 / RELP_DENSE_F64 in the environment override */
+    int32_t pivot_kernels;     /* 0 = automatic (ratio test and inverse update fused into one launch for m <= 2048, explicit
+                                  carry), 1 = the three separate kernels (bit-identical results); env RELP_NO_FUSED */
+    int32_t product_form;      /* dense pipeline: 0 = automatic (updates deferred in product form, one rank-k update every 32
+                                  pivots), 1 = a rank-one update of the stored inverse per pivot; env RELP_ETA=0 */
+    int32_t ftran_min_nnz;     /* columns longer than this take the multi-block FTRAN pipeline; 0 = 1024; env
+                                  RELP_FTRAN_MIN_NNZ */
+    int32_t refactor_on_host;  /* LU carries: 0 = `BasisInverse::invert` (Markowitz factorisation, triangle inversion, task
+                                  lists; lower_upper/mod.rs:78-92, decomposition/mod.rs:27-143) runs as kernels on the device,
+                                  1 = on one host core (round 3's path, kept for A/B runs); env RELP_REFACTOR_HOST=1 */
+    int32_t reserved0;         /* 0 */
 } relp_options;
 
 typedef struct relp_result {

@@ -33,7 +33,9 @@ class Options(C.Structure):
                 ("tol_pivot", C.c_double), ("harris_delta", C.c_double), ("tol_feasible", C.c_double),
                 ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("implicit_bounds", C.c_int32),
                 ("carry", C.c_int32), ("refactor_period", C.c_int32), ("lu_pivot_threshold", C.c_double),
-                ("ratio_rule", C.c_int32), ("crash", C.c_int32)]
+                ("ratio_rule", C.c_int32), ("crash", C.c_int32),
+                ("dense_storage", C.c_int32), ("pivot_kernels", C.c_int32), ("product_form", C.c_int32), ("ftran_min_nnz", C.c_int32),
+                ("refactor_on_host", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -648,13 +650,24 @@ class Batch:
         entries = (BatchEntry * len(sched))()
         workers = (BatchWorker * self.n_workers)()
         makespan = C.c_double()
-        callback = self.TICKET_FN(lambda _user: int(next_ticket())) if next_ticket is not None else None
+        failure = []
+
+        def draw(_user):  # (an exception inside a ctypes callback would be printed and turned into ticket 0)
+            try:
+                return int(next_ticket())
+            except BaseException as error:  # noqa: BLE001
+                failure.append(error)
+                return -1
+
+        callback = self.TICKET_FN(draw) if next_ticket is not None else None
         fn = lib().relp_batch_run
         fn.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         status = fn(self._h, _ptr(sched, C.c_int32), len(sched), C.cast(callback, C.c_void_p) if callback else None, None,
                     C.cast(entries, C.c_void_p), C.cast(workers, C.c_void_p), C.byref(makespan))
+        if failure:
+            raise failure[0]
         if status != OK:
-            raise RelpError(status, "relp_batch_run")
+            raise RelpError(status, "relp_batch_run (a ticket handed out twice?)")
         return list(entries), list(workers), makespan.value
 
     def objective_exact(self, ticket):

@@ -111,6 +111,11 @@ int32_t relp_batch_run(relp_batch* batch, const int32_t* schedule, int64_t n_tic
     }
     batch->exact.assign((size_t)n_tickets, std::string());
     std::atomic<int64_t> head{0};
+    // a ticket is served once: a `next_ticket` that repeats one (or a binding whose callback failed and returned 0 every time) ends
+    // the worker that drew the repeat instead of letting two threads write entries[t] and the same handle's state concurrently
+    std::vector<std::atomic<char>> claimed((size_t)n_tickets);
+    for (auto& c : claimed) c.store(0, std::memory_order_relaxed);
+    std::atomic<int> repeats{0};
     std::vector<relp_batch_worker> stats(n_workers);
     const double t0 = now_seconds();
     std::vector<std::thread> threads;
@@ -124,6 +129,10 @@ int32_t relp_batch_run(relp_batch* batch, const int32_t* schedule, int64_t n_tic
                 const int64_t t = next_ticket ? next_ticket(user) : head.fetch_add(1, std::memory_order_relaxed);
                 me.queue_seconds += now_seconds() - t_ask;
                 if (t < 0 || t >= n_tickets) break;
+                if (claimed[(size_t)t].exchange(1, std::memory_order_acq_rel)) {
+                    repeats.fetch_add(1, std::memory_order_relaxed);
+                    break;
+                }
                 relp_handle* h = batch->handles[w][schedule[t]];
                 relp_batch_entry& e = entries[t];
                 e.worker = w;
@@ -154,7 +163,7 @@ int32_t relp_batch_run(relp_batch* batch, const int32_t* schedule, int64_t n_tic
             workers[w] = stats[w];
             workers[w].idle_seconds = makespan - stats[w].busy_seconds;
         }
-    return RELP_OK;
+    return repeats.load() ? RELP_ERR_ARGUMENT : RELP_OK;  // the entries served so far are valid; the source handed a ticket out twice
 }
 
 int32_t relp_batch_get_objective_exact(const relp_batch* batch, int64_t ticket, char* buffer, int32_t capacity, int32_t* length) {

@@ -73,6 +73,12 @@ int32_t relp_options_default(relp_options* o) {
     o->lu_pivot_threshold = 0.0;
     o->ratio_rule = RELP_RATIO_HARRIS;
     o->crash = 0;
+    o->dense_storage = RELP_DENSE_NARROWEST;
+    o->pivot_kernels = 0;
+    o->product_form = 0;
+    o->ftran_min_nnz = 0;
+    o->refactor_on_host = 0;
+    o->reserved0 = 0;
     return RELP_OK;
 }
 

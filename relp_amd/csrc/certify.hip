@@ -306,7 +306,7 @@ struct CertifyTimes {
     double unpack = 0.0, horner = 0.0, combine = 0.0, numerators = 0.0, verify = 0.0, normalise = 0.0;  // parts of host_assemble
     int digit_launches = 0, solves = 0, reconstructs = 0;
 };
-CertifyTimes g_times;
+thread_local CertifyTimes g_times;  // (per host thread: certificates of a batch run concurrently on its worker threads)
 double wall_now() {
     using clock = std::chrono::steady_clock;
     return std::chrono::duration<double>(clock::now().time_since_epoch()).count();
@@ -988,11 +988,10 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                 RELP_HIP(hipMemcpyAsync(d_rowl, fs.lev_row[0].data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
                 RELP_HIP(hipMemcpyAsync(d_levu, fs.lev_start[1].data(), (levels_u + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
                 RELP_HIP(hipMemcpyAsync(d_rowu, fs.lev_row[1].data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
-                static bool configured_levels = false;
-                if (!configured_levels) {
+                static PerDeviceOnce configured_levels;  // (certificates run from the worker threads of a batch, possibly on several devices)
+                configured_levels.run([] {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modular_inverse_levels_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    configured_levels = true;
-                }
+                });
                 ModularFactors mf{d_rowpos, d_colpos, d_ls, d_lc, d_lv, d_us, d_uc, d_uv, d_dinv, d_levl, d_rowl, levels_l, d_levu, d_rowu, levels_u};
                 hipLaunchKernelGGL(modular_inverse_levels_kernel, dim3((m + 3) / 4), dim3(256), level_lds, stream, m, candidate, mf, dCT);
                 hipLaunchKernelGGL(transpose_u32_kernel, dim3((m + 31) / 32, (m + 31) / 32), dim3(256), 0, stream, m, dCT, dC);
@@ -1007,11 +1006,10 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                 while (columns > 1 && (size_t)columns * m * sizeof(u32) > room) columns /= 2;
                 const bool in_lds = (size_t)columns * m * sizeof(u32) <= room;
                 if (!in_lds) staged = false;
-                static bool configured = false;
-                if (!configured) {
+                static PerDeviceOnce configured;
+                configured.run([] {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modular_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    configured = true;
-                }
+                });
                 if (!in_lds) columns = 64;
                 const size_t lds = in_lds ? (size_t)columns * m * sizeof(u32) + (staged ? factor_bytes : 0) : 0;
                 hipLaunchKernelGGL(modular_inverse_kernel, dim3((m + columns - 1) / columns), dim3(staged ? 256 : columns), lds, stream, m, candidate,

@@ -3573,8 +3573,9 @@ void launch_price_dense(const DeviceLP& d, int blocks, int skip_weights, double 
     else if (d.dense_val32) RELP_LAUNCH(0, price_dense_kernel<true>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
     else RELP_LAUNCH(0, price_dense_kernel<false>, dim3(blocks), dim3(K1D_THREADS), lds, s, d, skip_weights, tol, cand_offset);
 }
-// hipFuncAttributeMaxDynamicSharedMemorySize is a PROCESS-WIDE property of a kernel: setting it to the current LP's size would
-// let the last loaded handle decide for every other one.  It is set once, to what the CU has (160 KB minus the kernel's static LDS).
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel on the CURRENT device: setting it to the current LP's size would
+// let the last loaded handle decide for every other one.  It is set once per device (PerDeviceOnce, solver.hpp), to what the CU has
+// (160 KB minus the kernel's static LDS).
 static void allow_full_lds(const void* kernel) {
     hipFuncAttributes attr{};
     size_t fixed = 0;
@@ -3582,26 +3583,26 @@ static void allow_full_lds(const void* kernel) {
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fixed)) != hipSuccess) (void)hipGetLastError();
 }
 void configure_dense_lds(size_t) {
-    static bool done = false;
-    if (done) return;
-    allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<false>));
-    allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<true>));
-    allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<false, true>));
-    done = true;
+    static PerDeviceOnce once;
+    once.run([] {
+        allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<false>));
+        allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<true>));
+        allow_full_lds(reinterpret_cast<const void*>(&price_dense_kernel<false, true>));
+    });
 }
 void launch_ftran_partial(const DeviceLP& d, int n_slices, int n_price_blocks, int rule, hipStream_t s) {
     hipLaunchKernelGGL(ftran_partial_kernel, dim3((d.m + 255) / 256, n_slices), dim3(256), 0, s, d, n_slices, n_price_blocks, rule);
 }
 
 void configure_lds(size_t) {
-    // opt in to > 64 KB of dynamic LDS (160 KB per CU on gfx950), once
-    static bool done = false;
-    if (done) return;
-    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_STEEPEST_EDGE, true, PRICE_LPC>));
-    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_DANTZIG, true, PRICE_LPC>));
-    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE, true, PRICE_LPC>));
-    allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, true, PRICE_LPC>));
-    done = true;
+    // opt in to > 64 KB of dynamic LDS (160 KB per CU on gfx950), once per device
+    static PerDeviceOnce once;
+    once.run([] {
+        allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_STEEPEST_EDGE, true, PRICE_LPC>));
+        allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_DANTZIG, true, PRICE_LPC>));
+        allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE, true, PRICE_LPC>));
+        allow_full_lds(reinterpret_cast<const void*>(&price_kernel<RELP_PIVOT_FIRST_PROFITABLE_MEMORY, true, PRICE_LPC>));
+    });
 }
 
 template <int RULE>
@@ -3734,10 +3735,8 @@ void launch_alpha_reduce(const DeviceLP& d, int n_slices, hipStream_t s) {
 }
 int eta_max() { return ETA_MAX; }
 void configure_btran_lds(size_t) {
-    static bool done = false;
-    if (done) return;
-    allow_full_lds(reinterpret_cast<const void*>(&btran_pass_kernel));
-    done = true;
+    static PerDeviceOnce once;
+    once.run([] { allow_full_lds(reinterpret_cast<const void*>(&btran_pass_kernel)); });
 }
 // deferred product form: fold the new eta into the kept columns, then one read-only pass for rho_p, w and -pi
 int btran_pass_blocks() { return 256; }

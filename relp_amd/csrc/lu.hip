@@ -244,7 +244,7 @@ void fill_inverse_records(const int m, const int* start, const int* idx, const d
     const int slots = info.slots;
     std::fill(hdr, hdr + stride, 0u);   // padding: no group, no write ...
     std::fill(col, col + stride, 0ull);  // ... operands at position 0 (values: whatever -- a padding slot writes nowhere)
-    std::memset(values, 0, (size_t)4 * slots * sizeof(double));
+    std::memset(values, 0, (size_t)4 * stride * sizeof(double));  // the padding records too: their values reach the FMAs of the product (header 0 only suppresses the write)
     int nz = 0;
     size_t nx = 0;
     for (int i = 0; i < m; ++i) {
@@ -321,8 +321,8 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     const int ldt = max_updates + 1;
     // ---- host: the four orientations and their task lists -----------------------------------------------------------------
     static const bool time_parts = getenv("RELP_TIME_REFACTOR") != nullptr;
-    static double part_seconds[5] = {0, 0, 0, 0, 0};
-    static long long uploads = 0;
+    thread_local double part_seconds[5] = {0, 0, 0, 0, 0};  // (diagnostic sums per calling thread: handles of a batch refactorise concurrently)
+    thread_local long long uploads = 0;
     auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_mark = time_parts ? wall() : 0.0;
     auto mark = [&](int which) {
@@ -491,6 +491,10 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
             counts[k * LU_CNT_WORDS + LU_CNT_SLOTS] = info.slots;
             counts[k * LU_CNT_WORDS + LU_CNT_LEVELS] = 1;
             counts[k * LU_CNT_WORDS + LU_CNT_CHUNKS] = 1;
+            counts[k * LU_CNT_WORDS + LU_CNT_C0_END] = info.slots;  // (one chunk, one level: nothing stale from another handle's task_storage)
+            counts[k * LU_CNT_WORDS + LU_CNT_C0_L0] = 0;
+            counts[k * LU_CNT_WORDS + LU_CNT_C0_L1] = 1;
+            counts[k * LU_CNT_WORDS + LU_CNT_C0_TAIL] = 1;
             if (info.extras > ((k == 0 || k == 3) ? cl : cu)) throw std::runtime_error("LU inverse lists: extra entries exceed their capacity");
             fill_inverse_records(m, list_start[k], list_idx[k], list_val[k], info, stride, reinterpret_cast<unsigned int*>(h + co[k].hdr),
                                  reinterpret_cast<unsigned long long*>(h + co[k].col), reinterpret_cast<double*>(h + co[k].val),
@@ -1622,16 +1626,16 @@ __global__ void __launch_bounds__(LU_THREADS) lu_update_kernel(DeviceLU lu, int 
     lu_ft_update_block(lu, sh, t, eta_count, new_diag, lu.spike);
 }
 
-static bool g_lu_lds_configured = false;
+static PerDeviceOnce g_lu_lds_configured;  // (per device: solver.hpp)
 static void allow_full_lds(const void* kernel);
 static void configure_lu_lds() {
-    if (g_lu_lds_configured) return;
-    allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel<false>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel<true>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel<false>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel<true>));
-    allow_full_lds(reinterpret_cast<const void*>(&lu_update_kernel));
-    g_lu_lds_configured = true;
+    g_lu_lds_configured.run([] {
+        allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel<false>));
+        allow_full_lds(reinterpret_cast<const void*>(&lu_ftran_kernel<true>));
+        allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel<false>));
+        allow_full_lds(reinterpret_cast<const void*>(&lu_btran_kernel<true>));
+        allow_full_lds(reinterpret_cast<const void*>(&lu_update_kernel));
+    });
 }
 static void check_launch(const char* what) {
     const hipError_t err = hipGetLastError();
@@ -2257,9 +2261,10 @@ __global__ void __launch_bounds__(256) lu_row_scan_kernel(DeviceLP lp, const dou
     }
 }
 
-static bool g_lu_pivot_configured = false;
+static PerDeviceOnce g_lu_pivot_configured;
 static void allow_full_lds(const void* kernel) {
-    // dynamic + static LDS may reach the 160 KB of a CU; the attribute is process-wide, so it is set once to the maximum
+    // dynamic + static LDS may reach the 160 KB of a CU; the attribute belongs to the kernel on the current device, so it is set
+    // once per device to the maximum (not to the current LP's size: the last loaded handle would decide for every other one)
     hipFuncAttributes attr{};
     size_t fixed = 0;
     if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) fixed = attr.sharedSizeBytes;
@@ -2269,7 +2274,7 @@ static void allow_full_lds(const void* kernel) {
     }
 }
 static void configure_lu_pivot_lds() {
-    if (g_lu_pivot_configured) return;
+  g_lu_pivot_configured.run([] {
     allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_STEEPEST_EDGE, false>));
     allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_STEEPEST_EDGE, true>));
     allow_full_lds(reinterpret_cast<const void*>(&lu_pivot_kernel<RELP_PIVOT_DANTZIG, false>));
@@ -2284,7 +2289,7 @@ static void configure_lu_pivot_lds() {
     allow_full_lds(reinterpret_cast<const void*>(&lu_pi_kernel<true>));
     allow_full_lds(reinterpret_cast<const void*>(&lu_gamma_kernel<false>));
     allow_full_lds(reinterpret_cast<const void*>(&lu_gamma_kernel<true>));
-    g_lu_pivot_configured = true;
+  });
 }
 template <int RULE>
 static void launch_lu_pivot_rule(const DeviceLP& d, const DeviceLU& lu, int n_price_blocks, double tol_pivot, double harris_delta,

@@ -156,6 +156,11 @@ void Solver::upload() {
     // first four groups (structurals, range slacks, <= slacks, >= slacks); the VariableBound / SlackBound rows and their
     // slack columns (matrix_data.rs:104-145) become upper bounds of the structurals and the range slacks.
     bounded_ = opt_.implicit_bounds != 0 && md.nr_variable_bounds() > 0;
+    // relp_options first; the environment variables of rounds 1-3 still override (A/B runs without a new handle's options)
+    const bool want_f64_block = getenv("RELP_DENSE_F64") != nullptr || (opt_.dense_storage == RELP_DENSE_DOUBLE && !getenv("RELP_DENSE_F32"));
+    const bool want_f32_block = !want_f64_block && (getenv("RELP_DENSE_F32") != nullptr || opt_.dense_storage == RELP_DENSE_FLOAT);
+    const bool product_form_off = opt_.product_form == 1 || (getenv("RELP_ETA") && std::string(getenv("RELP_ETA")) == "0");
+    const int ftran_min_nnz_opt = getenv("RELP_FTRAN_MIN_NNZ") ? atoi(getenv("RELP_FTRAN_MIN_NNZ")) : (opt_.ftran_min_nnz > 0 ? opt_.ftran_min_nnz : 1024);
     const int m = bounded_ ? md.nr_constraints() : md.nr_rows();
     const int n_p = bounded_ ? md.col_end[3] : md.nr_columns();
     if (m < 1) throw std::runtime_error("LP without rows");
@@ -243,13 +248,12 @@ void Solver::upload() {
     // pass of a pivot prices them for the next one (btran_pass_kernel), one candidate slot per workgroup of that pass.
     std::vector<int> slack_of_row;
     {
-        const char* eta_env0 = getenv("RELP_ETA");
         bool eligible = n_dense > 0 && opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE && m % 2 == 0 && m <= 4096 &&
-                        !(eta_env0 && std::string(eta_env0) == "0") && !getenv("RELP_NO_SLACK_IN_BTRAN") && n > sparse_first_;
+                        !product_form_off && !getenv("RELP_NO_SLACK_IN_BTRAN") && n > sparse_first_;
         if (eligible) {  // (the deferred product form needs the multi-block FTRAN: a column longer than its threshold)
             int longest = 0;
             for (int j = n_art; j < n; ++j) longest = std::max(longest, col_start[j + 1] - col_start[j]);
-            eligible = longest > (getenv("RELP_FTRAN_MIN_NNZ") ? atoi(getenv("RELP_FTRAN_MIN_NNZ")) : 1024);
+            eligible = longest > ftran_min_nnz_opt;
         }
         if (eligible) {
             slack_of_row.assign(m, -1);
@@ -262,7 +266,7 @@ void Solver::upload() {
         else price_blocks_ = btran_pass_blocks();
     }
     dense_blocks_ = n_dense > 0 ? std::min(getenv("RELP_DENSE_BLOCKS") ? atoi(getenv("RELP_DENSE_BLOCKS")) : 256, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one workgroup per CU (96 KB of LDS each)
-    bool dense_bytes = n_dense > 0 && !getenv("RELP_DENSE_F64") && !getenv("RELP_DENSE_F32");  // narrowest exact storage type
+    bool dense_bytes = n_dense > 0 && !want_f64_block && !want_f32_block;  // narrowest exact storage type
     for (int jd = 0; dense_bytes && jd < n_dense; ++jd)
         for (int e = col_start[n_art + jd]; dense_bytes && e < col_start[n_art + jd + 1]; ++e)
             dense_bytes = value[e] >= -128.0 && value[e] <= 127.0 && value[e] == std::floor(value[e]);
@@ -275,7 +279,7 @@ void Solver::upload() {
         d_.dense_full = full ? 1 : 0;
         d_.dense_csc_start = n_dense > 0 ? col_start[n_art] : 0;
     }
-    bool dense_floats = n_dense > 0 && !dense_bytes && !getenv("RELP_DENSE_F64");  // float holds every entry exactly
+    bool dense_floats = n_dense > 0 && !dense_bytes && !want_f64_block;  // float holds every entry exactly
     for (int jd = 0; dense_floats && jd < n_dense; ++jd)
         for (int e = col_start[n_art + jd]; dense_floats && e < col_start[n_art + jd + 1]; ++e) dense_floats = (double)(float)value[e] == value[e];
     int vector_len = m;  // -pi, rho, w: zero-padded to the dense block's row count when the column-per-lane pricing reads them
@@ -292,7 +296,7 @@ void Solver::upload() {
     for (int j = n_art; j < n; ++j) max_nnz = std::max(max_nnz, col_start[j + 1] - col_start[j]);
     ftran_slices_ = 0;
     // columns longer than this take the multi-block FTRAN pipeline (RELP_FTRAN_MIN_NNZ: test hook to exercise it on small LPs)
-    const int ftran_min_nnz = getenv("RELP_FTRAN_MIN_NNZ") ? atoi(getenv("RELP_FTRAN_MIN_NNZ")) : 1024;
+    const int ftran_min_nnz = ftran_min_nnz_opt;
     if (max_nnz > ftran_min_nnz && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = getenv("RELP_FTRAN_SLICES") ? atoi(getenv("RELP_FTRAN_SLICES")) : std::min(64, (max_nnz + 255) / 256);  // (4096 x 8192: 8 / 16 / 32 / 64 slices = 20.8k / 21.2k / 20.8k / 19.7k pivots/s)
 
     d_.col_start = dmalloc<int>(n + 1);
@@ -371,8 +375,8 @@ void Solver::upload() {
     d_.alpha_part = dmalloc<double>((size_t)std::max(1, ftran_slices_) * m);
     d_.alpha_in = dmalloc<double>(m);
     // deferred product form of the inverse: the dense pipeline (multi-block FTRAN), m even and <= 4096 (alpha_reduce_kernel, btran_pass_kernel)
-    const char* eta_env = getenv("RELP_ETA");  // RELP_ETA=0 keeps the per-pivot rank-one update (A/B measurements)
-    eta_mode_ = n_dense > 0 && ftran_slices_ > 0 && m % 2 == 0 && m <= 4096 && !(eta_env && std::string(eta_env) == "0");
+    // (relp_options.product_form = 1 / RELP_ETA=0 keeps the per-pivot rank-one update: A/B measurements)
+    eta_mode_ = n_dense > 0 && ftran_slices_ > 0 && m % 2 == 0 && m <= 4096 && !product_form_off;
     d_.eta_cap = eta_mode_ ? eta_max() : 0;
     slack_in_btran_ = eta_mode_ && !slack_of_row.empty();
     if (slack_in_btran_) {
@@ -455,7 +459,7 @@ void Solver::upload() {
         std::vector<double> dense((size_t)n_dense * d_.dense_ld, 0.0);
         for (int jd = 0; jd < n_dense; ++jd)
             for (int e = col_start[n_art + jd]; e < col_start[n_art + jd + 1]; ++e) dense[(size_t)jd * d_.dense_ld + row_index[e]] = value[e];
-        bool exact_in_float = !(getenv("RELP_DENSE_F64"));  // RELP_DENSE_F64=1 keeps the f64 block (A/B measurements)
+        bool exact_in_float = !want_f64_block;  // relp_options.dense_storage = RELP_DENSE_DOUBLE keeps the f64 block
         for (size_t k = 0; exact_in_float && k < dense.size(); ++k) exact_in_float = (double)(float)dense[k] == dense[k];
         if (exact_in_float) {
             std::vector<float> dense32(dense.begin(), dense.end());
@@ -489,7 +493,7 @@ void Solver::upload() {
     }
     // small LPs: ratio test and inverse update in one launch (pivot_fused_kernel; RELP_NO_FUSED=1 keeps the three-kernel pivot)
     fused_ = !lu_mode_ && !bounded_ && !eta_mode_ && n_dense == 0 && ftran_slices_ == 0 && !d_.track_touched && d_.ell_w == ELL_W &&
-             fused_pivot_available(d_, price_blocks_) && !getenv("RELP_NO_FUSED");
+             fused_pivot_available(d_, price_blocks_) && !getenv("RELP_NO_FUSED") && opt_.pivot_kernels != 1;
     if (fused_) {
         for (int k = 0; k < 2; ++k) {
             d_.state[k].ctl = dmalloc<Ctl>(1);
@@ -1517,7 +1521,7 @@ void Solver::refactor_lu(bool refresh_vectors) {
     LuOptions lo;
     lo.threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
     static const bool time_parts = getenv("RELP_TIME_REFACTOR") != nullptr;
-    static double part_seconds[3] = {0.0, 0.0, 0.0};
+    thread_local double part_seconds[3] = {0.0, 0.0, 0.0};
     const double t1 = now_seconds();
     HostLU f = lu_factor(m, cs.data(), rows.data(), vals.data(), lo);
     if (f.singular) throw std::runtime_error("singular basis in the LU refactorisation");

@@ -6,7 +6,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -294,6 +296,28 @@ private:
     int polish_scale_ = 1;        // multiplier of polish_period, adapted to the drift measured at each polish
 
     friend struct SolverAccess;
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) acts on the CURRENT device's copy of a kernel, and a batch (relp_batch_create) may
+// hold handles on several devices, created and driven by worker threads: one configuration per device, race-free.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mutex;
+    template <class F>
+    void run(F&& configure) {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) {  // (no bit to remember it by: configure every time)
+            std::lock_guard<std::mutex> lock(mutex);
+            configure();
+            return;
+        }
+        const unsigned long long bit = 1ull << device;
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lock(mutex);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        configure();
+        done.fetch_or(bit, std::memory_order_release);
+    }
 };
 
 struct DeviceError : std::runtime_error {

@@ -56,3 +56,24 @@ def test_batch_rejects_a_bad_schedule():
     with pytest.raises(relp_amd.RelpError):
         batch.run([0, 1])
     batch.close()
+
+
+def test_a_failing_ticket_source_ends_the_run_and_reaches_the_caller():
+    """An exception inside the `next_ticket` callback is not swallowed into "ticket 0 forever": the workers stop and it is re-raised."""
+    models = [relp_amd.Model(os.path.join(ROOT, "data", "netlib", n + ".SIF")) for n in NAMES[:2]]
+    batch = relp_amd.Batch(models, devices=(0,), workers_per_device=2)
+
+    def broken():
+        raise KeyError("no tickets today")
+    with pytest.raises(KeyError):
+        batch.run([0, 1, 0, 1], next_ticket=broken)
+    batch.close()
+
+
+def test_a_ticket_handed_out_twice_is_served_once():
+    """A source that repeats a ticket: the second draw ends its worker, the run reports the misuse, no entry is written twice."""
+    models = [relp_amd.Model(os.path.join(ROOT, "data", "netlib", n + ".SIF")) for n in NAMES[:2]]
+    batch = relp_amd.Batch(models, devices=(0,), workers_per_device=2)
+    with pytest.raises(relp_amd.RelpError):
+        batch.run([0, 1, 0, 1], next_ticket=lambda: 0)
+    batch.close()

@@ -1,0 +1,100 @@
+"""The three hand-written mirrors of the C structs -- the `#[repr(C)]` structs of INTEGRATION.md (what a maintainer of the
+reference would paste into the Rust shim), the ctypes classes of relp_amd/api.py and include/relp_amd.h itself -- must agree in
+field order, names and widths (CPU; no library needed)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "relp_amd.h")).read()
+INTEGRATION = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+C_WIDTH = {"int32_t": ("i", 4), "int64_t": ("i", 8), "double": ("f", 8), "uint8_t": ("u", 1)}
+RUST_WIDTH = {"i32": ("i", 4), "i64": ("i", 8), "c_double": ("f", 8), "f64": ("f", 8), "c_int": ("i", 4), "u8": ("u", 1)}
+
+
+def strip_c_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def c_struct(name):
+    """[(field, kind, bytes, count)] of `typedef struct name { ... } name;`, scalar and array fields only."""
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), HEADER, flags=re.S).group(1)
+    fields = []
+    for declaration in strip_c_comments(body).split(";"):
+        declaration = " ".join(declaration.split())
+        if not declaration:
+            continue
+        type_name, _, rest = declaration.partition(" ")
+        declarators = [d.strip() for d in rest.split(",")]
+        if type_name not in C_WIDTH or not all(re.fullmatch(r"\w+(\[\d+\])?", d) for d in declarators):
+            fields.append((declaration, "other", 0, 1))  # pointers, callbacks, nested structs: compared by name only
+            continue
+        kind, width = C_WIDTH[type_name]
+        for d in declarators:  # `int32_t worker, device;`
+            match = re.fullmatch(r"(\w+)(?:\[(\d+)\])?", d)
+            fields.append((match.group(1), kind, width, int(match.group(2) or 1)))
+    return fields
+
+
+def rust_struct(name):
+    body = re.search(r"pub struct %s \{(.*?)\n?\}" % name, INTEGRATION, flags=re.S).group(1)
+    body = re.sub(r"//[^\n]*", "", body)
+    fields = []
+    for declaration in body.split(","):
+        declaration = " ".join(declaration.split())
+        if not declaration:
+            continue
+        match = re.fullmatch(r"pub (\w+): (?:\[(\w+); (\d+)\]|(\w+))", declaration)
+        assert match, declaration
+        type_name = match.group(2) or match.group(4)
+        kind, width = RUST_WIDTH[type_name]
+        fields.append((match.group(1), kind, width, int(match.group(3) or 1)))
+    return fields
+
+
+def ctypes_struct(cls):
+    kinds = {C.c_int32: ("i", 4), C.c_int64: ("i", 8), C.c_double: ("f", 8)}
+    fields = []
+    for name, ctype in cls._fields_:
+        count = 1
+        if hasattr(ctype, "_length_"):
+            count, ctype = ctype._length_, ctype._type_
+        if ctype not in kinds:
+            fields.append((name, "other", 0, 1))
+            continue
+        fields.append((name,) + kinds[ctype] + (count,))
+    return fields
+
+
+@pytest.mark.parametrize("c_name,rust_name", [("relp_options", "RelpOptions"), ("relp_result", "RelpResult"),
+                                              ("relp_exact_result", "RelpExactResult"), ("relp_bi_options", "RelpBiOptions")])
+def test_integration_md_repr_c_structs_match_the_header(c_name, rust_name):
+    assert rust_struct(rust_name) == c_struct(c_name)
+
+
+def test_ctypes_classes_match_the_header():
+    from relp_amd import api
+    pairs = [("relp_options", api.Options), ("relp_result", api.Result), ("relp_exact_result", api.ExactResult), ("relp_stats", api.Stats),
+             ("relp_batch_worker", api.BatchWorker)]
+    for c_name, cls in pairs:
+        assert ctypes_struct(cls) == c_struct(c_name), c_name
+    # relp_batch_entry embeds a relp_result: names in order, and the sizes add up
+    entry = [f[0].split()[-1] for f in c_struct("relp_batch_entry")]
+    assert entry == [name for name, _ in api.BatchEntry._fields_]
+    assert C.sizeof(api.BatchEntry) == 4 * 4 + C.sizeof(api.Result) + 2 * 8
+
+
+def test_struct_sizes_have_no_hidden_padding_surprises():
+    """Natural alignment of the declared fields, computed independently, equals ctypes' size (so Rust's repr(C) agrees as well)."""
+    from relp_amd import api
+    for c_name, cls in [("relp_options", api.Options), ("relp_result", api.Result), ("relp_exact_result", api.ExactResult)]:
+        offset, largest = 0, 1
+        for _, _, width, count in c_struct(c_name):
+            offset = (offset + width - 1) // width * width
+            offset += width * count
+            largest = max(largest, width)
+        offset = (offset + largest - 1) // largest * largest
+        assert offset == C.sizeof(cls), c_name
