@@ -463,6 +463,18 @@ int32_t relp_lu_invert_host(int32_t m, const int64_t* column_start, const int32_
                             int64_t* lower_start, int32_t* lower_column, double* lower_value, int64_t* upper_start,
                             int32_t* upper_column, double* upper_value, double* upper_diagonal);
 
+/* The factorisation step as the DEVICE runs it (round 4: `BasisInverse::invert` is a kernel, relp_amd/csrc/lu_factor.hip --
+ * parallel independent pivots by Markowitz score with the same threshold test; with `reference_ties` one pivot per round, the
+ * reference's, so the factors equal relp_lu_factor_host's and the reference's known answers entry for entry).  Same outputs as
+ * relp_lu_factor_host, produced on HIP device `device` and copied back; `dense_tail`: the last rows (at most 64; 0 = none) go
+ * through a dense LU out of LDS; info[32]: status, nnz(L), nnz(U), rounds, rows of the dense tail, arena peak, nnz(B), ...
+ * `inverted` = 1: the two triangles inverted on the device as well (relp_lu_invert_host's outputs). */
+int32_t relp_lu_factor_device(int32_t device, int32_t m, const int64_t* column_start, const int32_t* row_index, const double* value,
+                              double pivot_threshold, int32_t reference_ties, int32_t dense_tail, int32_t inverted, int64_t capacity,
+                              int32_t* row_permutation, int32_t* column_permutation, int64_t* lower_start, int32_t* lower_column,
+                              double* lower_value, int64_t* upper_start, int32_t* upper_column, double* upper_value,
+                              double* upper_diagonal, int32_t* info);
+
 
 /* ---- batches of independent LPs (BASELINE config 4) -------------------------------------------
  * The reference solves one LP per call on one thread (tests/netlib/mod.rs:47-71); independent LPs are the unit that shards.

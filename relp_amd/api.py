@@ -84,7 +84,7 @@ SYMBOLS = [
     "relp_bi_options_default", "relp_bi_identity", "relp_bi_invert", "relp_bi_free", "relp_bi_last_error", "relp_bi_m",
     "relp_bi_left_multiply", "relp_bi_right_multiply", "relp_bi_basis_inverse_row", "relp_bi_generate_element",
     "relp_bi_change_basis", "relp_bi_should_refactor", "relp_bi_remove_basis_part", "relp_bi_statistics",
-    "relp_bi_get_factors", "relp_lu_factor_host", "relp_lu_invert_host",
+    "relp_bi_get_factors", "relp_lu_factor_host", "relp_lu_invert_host", "relp_lu_factor_device",
     # exact solution vector, variable names, batches of independent LPs
     "relp_get_solution_exact", "relp_get_variable_name",
     "relp_batch_create", "relp_batch_destroy", "relp_batch_workers", "relp_batch_run", "relp_batch_get_objective_exact", "relp_batch_handle",

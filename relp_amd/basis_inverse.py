@@ -165,7 +165,13 @@ class BasisInverse:
                 "updates": etas}
 
 
-def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False, inverted=False):
+def lu_factor_device(columns, pivot_threshold=0.1, reference_ties=False, inverted=False, dense_tail=32, device=0):
+    """The same factorisation as the DEVICE runs it (``relp_lu_factor_device``: the kernels of lu_factor.hip that the LU carries'
+    refactorisation launches).  Same dict as ``lu_factor_host`` plus ``info`` (status, nnz(L), nnz(U), rounds, dense-tail rows, ...)."""
+    return lu_factor_host(columns, pivot_threshold, reference_ties, inverted, _device=(device, dense_tail))
+
+
+def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False, inverted=False, _device=None):
     """Host-only ``LUDecomposition::rows`` (decomposition/mod.rs:27-143).  Returns a dict: ``rowpos``, ``colpos``, L and U as
     lists of rows ``[(column, value)]`` of the position space, ``diag`` and the dependency depths.  ``inverted``: the two triangles
     inverted as sparse matrices instead (``relp_lu_invert_host``: what the inverse-factor carry uploads) -- ``lower_rows`` the strict
@@ -180,7 +186,14 @@ def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False, inverted=
         lc, uc = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
         lv, uv, ud = np.zeros(cap), np.zeros(cap), np.zeros(cap)
         dl, du = C.c_int32(), C.c_int32()
-        if inverted:
+        info = np.zeros(32, np.int32)
+        if _device is not None:
+            status = lib().relp_lu_factor_device(
+                int(_device[0]), m, _ptr(start, C.c_int64), _ptr(rows, C.c_int32), _ptr(vals, C.c_double), C.c_double(pivot_threshold),
+                int(bool(reference_ties)), int(_device[1]), int(bool(inverted)), C.c_int64(cap), _ptr(rp, C.c_int32), _ptr(cp, C.c_int32),
+                _ptr(ls, C.c_int64), _ptr(lc, C.c_int32), _ptr(lv, C.c_double), _ptr(us, C.c_int64), _ptr(uc, C.c_int32), _ptr(uv, C.c_double),
+                _ptr(ud, C.c_double), _ptr(info, C.c_int32))
+        elif inverted:
             status = lib().relp_lu_invert_host(
                 m, _ptr(start, C.c_int64), _ptr(rows, C.c_int32), _ptr(vals, C.c_double), C.c_double(pivot_threshold), cap,
                 _ptr(rp, C.c_int32), _ptr(cp, C.c_int32), _ptr(ls, C.c_int64), _ptr(lc, C.c_int32), _ptr(lv, C.c_double),
@@ -205,5 +218,5 @@ def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False, inverted=
         "lower_rows": [[(int(lc[e]), float(lv[e])) for e in range(ls[i], ls[i + 1])] for i in range(m)],
         "upper_rows": [[(int(uc[e]), float(uv[e])) for e in range(us[i], us[i + 1])] for i in range(m)],
         "diag": [float(v) for v in ud[:m]], "depth_lower": dl.value, "depth_upper": du.value,
-        "nnz_lower": int(ls[m]), "nnz_upper": int(us[m]),
+        "nnz_lower": int(ls[m]), "nnz_upper": int(us[m]), "info": [int(v) for v in info],
     }

@@ -4,6 +4,7 @@
 #include <string>
 
 #include "lu.hpp"
+#include "lu_factor.hpp"
 #include "solver.hpp"
 
 using namespace relp;
@@ -224,6 +225,88 @@ int32_t relp_lu_invert_host(int32_t m, const int64_t* column_start, const int32_
                         copy_out(inverted.u_col, upper_column, capacity) && copy_out(inverted.u_val, upper_value, capacity) &&
                         copy_out(inverted.diag, upper_diagonal, capacity);
         if (!ok) throw std::invalid_argument("capacity too small");
+    });
+}
+
+
+// ---- the factorisation step as the device runs it (lu_factor.hip), for tests -------------------------------------------------
+int32_t relp_lu_factor_device(int32_t device, int32_t m, const int64_t* column_start, const int32_t* row_index, const double* value,
+                              double pivot_threshold, int32_t reference_ties, int32_t dense_tail, int32_t inverted, int64_t capacity,
+                              int32_t* row_permutation, int32_t* column_permutation, int64_t* lower_start, int32_t* lower_column,
+                              double* lower_value, int64_t* upper_start, int32_t* upper_column, double* upper_value,
+                              double* upper_diagonal, int32_t* info) {
+    if (m < 1 || !column_start || capacity < m + 1) return RELP_ERR_ARGUMENT;
+    return guarded_bi(nullptr, [&] {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) throw DeviceError("no HIP device");
+        RELP_HIP(hipSetDevice(device));
+        const size_t nnz = (size_t)column_start[m];
+        std::vector<int> cs(m + 1);
+        for (int j = 0; j <= m; ++j) cs[j] = (int)column_start[j];
+        for (size_t e = 0; e < nnz; ++e)
+            if (row_index[e] < 0 || row_index[e] >= m) throw std::invalid_argument("row index out of range");
+        const size_t cap = (size_t)capacity;
+        struct Buffers {
+            int *cs = nullptr, *ri = nullptr, *rowpos = nullptr, *colpos = nullptr, *ls = nullptr, *lc = nullptr, *us = nullptr, *uc = nullptr;
+            double *va = nullptr, *diag = nullptr, *lv = nullptr, *uv = nullptr;
+            ~Buffers() {
+                for (void* p : {(void*)cs, (void*)ri, (void*)rowpos, (void*)colpos, (void*)ls, (void*)lc, (void*)us, (void*)uc, (void*)va, (void*)diag, (void*)lv, (void*)uv})
+                    if (p) (void)hipFree(p);
+            }
+        } b;
+        auto alloc_i = [&](int** p, size_t n) { RELP_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(1, n) * sizeof(int))); };
+        auto alloc_d = [&](double** p, size_t n) { RELP_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(1, n) * sizeof(double))); };
+        alloc_i(&b.cs, m + 1); alloc_i(&b.ri, nnz); alloc_d(&b.va, nnz);
+        alloc_i(&b.rowpos, m); alloc_i(&b.colpos, m); alloc_d(&b.diag, m);
+        alloc_i(&b.ls, m + 1); alloc_i(&b.lc, cap); alloc_d(&b.lv, cap);
+        alloc_i(&b.us, m + 1); alloc_i(&b.uc, cap); alloc_d(&b.uv, cap);
+        RELP_HIP(hipMemcpy(b.cs, cs.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice));
+        if (nnz) {
+            RELP_HIP(hipMemcpy(b.ri, row_index, nnz * sizeof(int), hipMemcpyHostToDevice));
+            RELP_HIP(hipMemcpy(b.va, value, nnz * sizeof(double), hipMemcpyHostToDevice));
+        }
+        LuFactorScratch scratch;
+        scratch.reserve(m, nnz, cap, cap);
+        LuFactorSource src;
+        src.col_start = b.cs;
+        src.row_index = b.ri;
+        src.value = b.va;
+        LuFactorOut out;
+        out.rowpos = b.rowpos; out.colpos = b.colpos; out.diag = b.diag;
+        out.l_start = b.ls; out.l_col = b.lc; out.l_val = b.lv;
+        out.u_start = b.us; out.u_col = b.uc; out.u_val = b.uv;
+        out.cap_l = out.cap_u = (int)std::min<size_t>(cap, (size_t)1 << 30);
+        launch_lu_factor(src, scratch.work(), out, pivot_threshold, reference_ties, dense_tail, nullptr);
+        if (inverted) throw std::logic_error("relp_lu_factor_device: the device inversion is not built into this library");
+        RELP_HIP(hipDeviceSynchronize());
+        std::vector<int> h_info(LUF_INFO_WORDS);
+        RELP_HIP(hipMemcpy(h_info.data(), scratch.work().info, LUF_INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost));
+        if (info) std::copy(h_info.begin(), h_info.end(), info);
+        if (h_info[LUF_STATUS] == LUF_ERR_SINGULAR) throw std::runtime_error("singular basis");
+        if (h_info[LUF_STATUS] == LUF_ERR_L_CAPACITY || h_info[LUF_STATUS] == LUF_ERR_U_CAPACITY || h_info[LUF_STATUS] == LUF_ERR_INVERSE_CAPACITY)
+            throw std::invalid_argument("capacity too small");
+        if (h_info[LUF_STATUS] != LUF_OK) throw std::runtime_error("device LU factorisation failed with status " + std::to_string(h_info[LUF_STATUS]));
+        std::vector<int> hi(std::max<size_t>(cap, (size_t)m + 1));
+        std::vector<double> hd(std::max<size_t>(cap, (size_t)m + 1));
+        auto get_i = [&](const int* dev, size_t n, auto* dst) {
+            if (!dst || n == 0) return;
+            RELP_HIP(hipMemcpy(hi.data(), dev, n * sizeof(int), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < n; ++k) dst[k] = hi[k];
+        };
+        auto get_d = [&](const double* dev, size_t n, double* dst) {
+            if (!dst || n == 0) return;
+            RELP_HIP(hipMemcpy(dst, dev, n * sizeof(double), hipMemcpyDeviceToHost));
+        };
+        const size_t nl = (size_t)h_info[inverted ? LUF_NNZ_LI : LUF_NNZ_L], nu = (size_t)h_info[inverted ? LUF_NNZ_UI : LUF_NNZ_U];
+        get_i(b.rowpos, m, row_permutation);
+        get_i(b.colpos, m, column_permutation);
+        get_i(b.ls, m + 1, lower_start);
+        get_i(b.lc, nl, lower_column);
+        get_d(b.lv, nl, lower_value);
+        get_i(b.us, m + 1, upper_start);
+        get_i(b.uc, nu, upper_column);
+        get_d(b.uv, nu, upper_value);
+        get_d(b.diag, m, upper_diagonal);
     });
 }
 
