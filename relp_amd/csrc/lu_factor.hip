@@ -283,6 +283,16 @@ __device__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuF
     }
 }
 
+// cycle sums per phase (thread 0, shader clock) into info[LUF_STAMPS + k]: diagnostic, a few s_memtime per round
+#define LUF_STAMP(k)                                                   \
+    do {                                                               \
+        if (tid == 0) {                                                \
+            const long long now__ = clock64();                         \
+            stamp_sum[(k)] += now__ - stamp_prev;                      \
+            stamp_prev = now__;                                        \
+        }                                                              \
+    } while (0)
+
 __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource src, LuFactorWork w, LuFactorOut out, double threshold,
                                                                 int reference_ties, int dense_tail) {
     __shared__ FactorShared sh;
@@ -293,6 +303,8 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
     const int m = w.m;
     const bool ref = reference_ties != 0;
     if (ref) threshold = 0.0;
+    long long stamp_prev = clock64();
+    long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (tid == 0) {
         sh.n_active = m;
         sh.kbase = 0;
@@ -373,6 +385,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         }
     }
     __syncthreads();
+    LUF_STAMP(0);
 
     // ---- rounds ----------------------------------------------------------------------------------------------------------------
     while (sh.error == LUF_OK && sh.n_active > 0) {
@@ -411,6 +424,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
             if (lane == 0 && mine != NONE64) atomicMin(&sh.best64, mine);
         }
         __syncthreads();
+        LUF_STAMP(1);
         int limit = 0;
         if (!ref) {
             // (2) the round's minimum score; candidates within a slack of it compete (4 x, at least + 4: lu_factor.hpp)
@@ -441,6 +455,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
                 atomicMin(&w.colmark[c], priority_of(best, r));
             }
             __syncthreads();
+            LUF_STAMP(2);
             // (4) conflicts: an entry (r, c) with c the pivot column of another row's candidate and r a candidate row itself -- the
             //     two pivots are not compatible, the worse one waits for a later round
             for (int e = tid; e < top; e += T) {
@@ -473,6 +488,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
                 if (acol[e] == cw && arow[e] == rw) w.best_e[rw] = e;
             __syncthreads();
         }
+        LUF_STAMP(3);
         // (5) the accepted pivots take consecutive positions in row order; their rows become rows of U
         {
             unsigned long long carry = 0;
@@ -528,6 +544,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         }
         __syncthreads();
         if (sh.error != LUF_OK) break;
+        LUF_STAMP(4);
         // (6) pivot rows -> U (decomposition/mod.rs:60-70); the rows with an entry in a pivot column are this round's targets
         for (int e = tid; e < top; e += T) {
             const int c = acol[e];
@@ -551,6 +568,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
             }
         }
         __syncthreads();
+        LUF_STAMP(5);
         // (7) layout of the next arena: the remaining rows in order, a target row with room for its fill-in
         {
             unsigned long long carry = 0;
@@ -587,6 +605,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         }
         __syncthreads();
         if (sh.error != LUF_OK) break;
+        LUF_STAMP(6);
         // (8) the untouched rows are copied, the targets eliminated (decomposition/mod.rs:71-100,146-210) -- into the other arena
         {
             int* __restrict__ ncol = w.a_col[cur ^ 1];
@@ -606,6 +625,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
             for (int t = wave; t < n_targets; t += LUF_WAVES) eliminate_row(w, sh, out, w.targets[t], cur, ref);
         }
         __syncthreads();
+        LUF_STAMP(7);
         // (9) the next round's state
         {
             const int n_new = sh.n_active_new;
@@ -630,8 +650,10 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
             sh.rounds += 1;
         }
         __syncthreads();
+        LUF_STAMP(8);
     }
     __syncthreads();
+    LUF_STAMP(8);
 
     // ---- dense tail: the last rows by partial pivoting out of LDS, one wave ------------------------------------------------------
     if (sh.error == LUF_OK && sh.n_active > 0) {
@@ -737,6 +759,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         __syncthreads();
     }
 
+    LUF_STAMP(9);
     // ---- finalisation: L by rows of the position space, U with positions as columns, every row sorted -----------------------------
     if (sh.error == LUF_OK && sh.l_top > w.cap_l) sh.error = LUF_ERR_L_CAPACITY;
     __syncthreads();
@@ -787,7 +810,9 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         }
     }
     __syncthreads();
+    LUF_STAMP(10);
     if (tid == 0) {
+        for (int k = 0; k < 11; ++k) w.info[LUF_STAMPS + k] = (int)(stamp_sum[k] >> 4);  // units of 16 cycles
         w.info[LUF_STATUS] = sh.error;
         w.info[LUF_NNZ_L] = sh.l_top;
         w.info[LUF_NNZ_U] = sh.ubase;

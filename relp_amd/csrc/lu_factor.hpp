@@ -56,6 +56,8 @@ enum : int {
     LUF_NNZ_LI = 7,      // entries of L^-1 (strict) and U^-1 (with diagonal): written by the inversion kernels
     LUF_NNZ_UI = 8,
     LUF_LAYOUT = 9,      // scratch for the task builders
+    LUF_STAMPS = 12,     // 11 cycle sums (units of 16 shader cycles): load | candidates | competition | conflicts | accept | U rows +
+                         // targets | layout | copy + eliminate | reset | dense tail | finalisation
     LUF_INFO_WORDS = 32
 };
 enum : int {

@@ -140,7 +140,9 @@ def test_device_factorises_real_bases(name, fraction):
     check_factors(f, A, columns)
     host = lu_factor_host(columns)
     fill_device, fill_host = f["nnz_lower"] + f["nnz_upper"], host["nnz_lower"] + host["nnz_upper"]
-    print("%s at %.0f %%: m %d nnz(B) %d | device: %d rounds + %d dense rows, nnz(L) + nnz(U) %d | host %d" % (
-        name, 100 * fraction, m, f["info"][6], f["info"][3], f["info"][4], fill_device, fill_host))
+    print("%s at %.0f %%: m %d nnz(B) %d | device: %d rounds + %d dense rows, nnz(L) + nnz(U) %d, %.1f us | host %d" % (
+        name, 100 * fraction, m, f["info"][6], f["info"][3], f["info"][4], fill_device, f["info"][31] / 10.0, fill_host))
+    print("   kcycles: load %d | candidates %d | competition %d | conflicts %d | accept %d | U rows + targets %d | layout %d | copy + eliminate %d | "
+          "reset %d | dense tail %d | finalisation %d" % tuple(16 * v // 1000 for v in f["info"][12:23]))
     assert fill_device <= 1.35 * fill_host + 64
     assert f["info"][3] <= max(8, m // 8)
