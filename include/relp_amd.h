@@ -303,10 +303,10 @@ int32_t relp_get_variable_name(const relp_handle* handle, int32_t j, char* buffe
 int32_t relp_get_record_json(const relp_handle* handle, char* buffer, int32_t capacity, int32_t* length);
 /* ---- the loop in exact fixed-width integer arithmetic on the device ------------------------------------------------------
  * `solve_relaxation::<Carry<RationalBig, _>>` with the reference's arbitrary-precision rationals replaced by LIMBS x 64-bit
- * integers over a common denominator (exact.hip; int128 = 2 limbs, int256 = 4, ... up to 32): the SAME pivot sequence as the
+ * integers over a common denominator (exact.hip; int128 = 2 limbs, int256 = 4, ... up to 128 = 8192 bits): the SAME pivot sequence as the
  * reference (steepest edge with its tie rules, exact ratio test with Bland ties, zero-level pivots) for as long as the
  * numbers fit.  The solve starts with `first_limbs` limbs and restarts with twice as many whenever a value may not fit
- * (status 4 when `max_limbs` <= 32 is not enough).  For small LPs: one workgroup owns the whole solve.
+ * (status 4 when `max_limbs` <= 128 is not enough).  For small LPs: one workgroup owns the whole solve.
  *   trace: (phase, entering column, pivot row, leaving column) per pivot, in the index space of relp_price;
  *   objective: the exact optimum "num/den" incl. fixed cost; basis: as relp_get_basis.
  * status: 1 optimal | 2 infeasible | 3 unbounded | 4 overflow | 5 pivot limit. */

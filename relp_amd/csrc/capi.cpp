@@ -785,7 +785,7 @@ int32_t relp_get_record_json(const relp_handle* h, char* buffer, int32_t capacit
 int32_t relp_solve_exact(relp_handle* h, int32_t first_limbs, int32_t max_limbs, int64_t max_pivots, relp_exact_result* result,
                          int32_t trace_capacity, int32_t* trace, char* objective, int32_t objective_capacity, int32_t* basis) {
     REQUIRE_LOADED(h);
-    if (!result || first_limbs < 1 || max_limbs < first_limbs || max_limbs > 32 || trace_capacity < 0) return RELP_ERR_ARGUMENT;
+    if (!result || first_limbs < 1 || max_limbs < first_limbs || max_limbs > 128 || trace_capacity < 0) return RELP_ERR_ARGUMENT;
     return guarded(h, [&] {
         std::memset(result, 0, sizeof(*result));
         std::vector<int> tr, final_basis;
@@ -802,9 +802,11 @@ int32_t relp_solve_exact(relp_handle* h, int32_t first_limbs, int32_t max_limbs,
         result->pivots_phase_one = p1;
         result->pivots_phase_two = p2;
         result->trace_entries = (int32_t)std::min<size_t>(tr.size() / 4, (size_t)trace_capacity);  // never more than were copied
-        for (size_t k = 0; k < survived.size() && k < 6; ++k) {
-            result->limbs_tried[k] = survived[k].first;
-            result->pivots_survived[k] = survived[k].second;
+        // (six slots: the LAST six widths tried -- 1, 2, ... 128 are eight, a run that needs the widest ones starts above one limb)
+        const size_t first_kept = survived.size() > 6 ? survived.size() - 6 : 0;
+        for (size_t k = first_kept; k < survived.size(); ++k) {
+            result->limbs_tried[k - first_kept] = survived[k].first;
+            result->pivots_survived[k - first_kept] = survived[k].second;
         }
         if (trace) std::memcpy(trace, tr.data(), std::min<size_t>(tr.size(), (size_t)4 * trace_capacity) * sizeof(int));
         if (objective && objective_capacity > 0) {

@@ -1221,7 +1221,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
             case 8: kernel = (void*)exact_simplex_kernel<8>; break;
             case 16: kernel = (void*)exact_simplex_kernel<16>; break;
             case 32: kernel = (void*)exact_simplex_kernel<32>; break;
-            default: throw std::invalid_argument("limbs must be a power of two between 1 and 32");
+            case 64: kernel = (void*)exact_simplex_kernel<64>; break;
+            case 128: kernel = (void*)exact_simplex_kernel<128>; break;
+            default: throw std::invalid_argument("limbs must be a power of two between 1 and 128");
         }
         {
             int per_cu = 0, cus = 0;

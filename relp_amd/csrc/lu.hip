@@ -72,6 +72,21 @@ struct Carver {
     }
 };
 
+struct LuLayout {
+    size_t o_rowpos, o_colpos, o_lrs, o_lcs, o_urs, o_ucs, o_diag, o_counts, small_bytes;
+    struct TaskOffsets {
+        size_t z_pos, z_dinv, s_pos, s_lev, s_flags, s_dinv, s_xstart, s_xn, chunk, s_col, s_val, x_idx, x_val;
+    } to[4];
+    size_t o_lrcol, o_lcrow, o_lrval, o_lcval, o_urcol, o_ucrow, o_urval, o_ucval;
+    struct CompactOffsets {
+        size_t hdr, col, val, zpos;
+    } co[4];
+    size_t compact_begin, compact_end, upload_bytes;
+    size_t app, o_applen, o_appslot, o_appval, o_scs, o_scl, o_scrow, o_scval, o_T, o_trail, o_slotof, o_eta_start, o_eta_pivot, o_eta_idx, o_eta_val;
+    size_t o_eta_mf, o_eta_of, o_eta_first, o_eta_prev, o_eapp_len, o_eapp_eta, o_eapp_val, o_spike, pf_ld, o_pf_m, o_pf_slot, o_pf_col_of, o_state;
+    size_t device_bytes;
+};
+
 __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
     const int m = lu.m;
     const int stride = blockDim.x * gridDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,6 +305,122 @@ void fill_inverse_records(const int m, const int* start, const int* idx, const d
         for (int k = w0; k < w1; ++k) hdr[k] |= summary;
     }
 }
+
+// ---- device layout of one factorisation: offsets into ONE allocation, by capacities only (so that the addresses -- and a captured
+// hipGraph that holds them -- survive a refactorisation).  The uploaded prefix first, then the arrays only kernels touch.
+LuLayout compute_layout(int m, int max_updates, bool inverse_factors, size_t cl, size_t cu, int stride) {
+    LuLayout L;
+    Carver c;
+    L.o_rowpos = c.take<int>(m); L.o_colpos = c.take<int>(m);
+    L.o_lrs = c.take<int>(m + 1); L.o_lcs = c.take<int>(m + 1); L.o_urs = c.take<int>(m + 1); L.o_ucs = c.take<int>(m + 1);
+    L.o_diag = c.take<double>(m);
+    L.o_counts = c.take<int>(4 * LU_CNT_WORDS);
+    for (int k = 0; k < 4; ++k) {
+        L.to[k].z_pos = c.take<int>(stride);
+        L.to[k].z_dinv = c.take<double>(stride);
+        L.to[k].s_pos = c.take<int>(stride);
+        L.to[k].s_lev = c.take<int>(stride);
+        L.to[k].s_flags = c.take<int>(stride);
+        L.to[k].s_dinv = c.take<double>(stride);
+        L.to[k].s_xstart = c.take<int>(stride);
+        L.to[k].s_xn = c.take<int>(stride);
+        L.to[k].chunk = c.take<int>(8 * LU_MAX_CHUNKS);
+    }
+    L.small_bytes = c.offset;  // everything up to here goes in one copy
+    for (int k = 0; k < 4; ++k) {
+        const size_t cap = (k == 0 || k == 3) ? cl : cu;
+        L.to[k].s_col = c.take<int>((size_t)LU_TE * stride);
+        L.to[k].s_val = c.take<double>((size_t)LU_TE * stride);
+        L.to[k].x_idx = c.take<int>(cap);
+        L.to[k].x_val = c.take<double>(cap);
+    }
+    L.o_lrcol = c.take<int>(cl); L.o_lcrow = c.take<int>(cl); L.o_lrval = c.take<double>(cl); L.o_lcval = c.take<double>(cl);
+    L.o_urcol = c.take<int>(cu); L.o_ucrow = c.take<int>(cu); L.o_urval = c.take<double>(cu); L.o_ucval = c.take<double>(cu);
+    // the compact records of the inverse-factor form (lu.hpp), the four lists in ONE region (one copy per refactorisation)
+    L.compact_begin = (c.offset + 63) & ~size_t(63);
+    c.offset = L.compact_begin;
+    for (int k = 0; k < 4; ++k) {
+        L.co[k].hdr = c.take<unsigned int>(inverse_factors ? stride : 0);
+        L.co[k].zpos = c.take<int>(inverse_factors ? stride : 0);
+        L.co[k].col = c.take<unsigned long long>(inverse_factors ? stride : 0);
+        c.offset = (c.offset + 31) & ~size_t(31);
+        L.co[k].val = c.take<double>(inverse_factors ? (size_t)4 * stride : 0);
+    }
+    L.compact_end = c.offset;
+    L.upload_bytes = c.offset;
+    // ---- device only ----------------------------------------------------------------------------------------------------------
+    const int ldt = max_updates + 1;
+    const size_t app = (size_t)m * max_updates;
+    L.app = app;
+    L.o_applen = c.take<int>(m); L.o_appslot = c.take<int>(app); L.o_appval = c.take<double>(app);
+    L.o_scs = c.take<int>(max_updates); L.o_scl = c.take<int>(max_updates); L.o_scrow = c.take<int>(app); L.o_scval = c.take<double>(app);
+    L.o_T = c.take<double>((size_t)max_updates * ldt);
+    L.o_trail = c.take<int>(max_updates); L.o_slotof = c.take<int>(m);
+    L.o_eta_start = c.take<int>(max_updates + 2); L.o_eta_pivot = c.take<int>(max_updates + 1);
+    L.o_eta_idx = c.take<int>(app); L.o_eta_val = c.take<double>(app);
+    L.o_eta_mf = c.take<double>((size_t)max_updates * ldt); L.o_eta_of = c.take<int>(m); L.o_eta_first = c.take<int>(m); L.o_eta_prev = c.take<int>(max_updates + 1);
+    L.o_eapp_len = c.take<int>(m); L.o_eapp_eta = c.take<int>(app); L.o_eapp_val = c.take<double>(app);
+    L.o_spike = c.take<double>(m);
+    L.pf_ld = ((size_t)m + 15) & ~(size_t)15;
+    L.o_pf_m = c.take<double>(inverse_factors ? L.pf_ld * max_updates : 0);
+    L.o_pf_slot = c.take<int>(max_updates); L.o_pf_col_of = c.take<int>(m);
+    L.o_state = c.take<int>(LU_STATE_WORDS);
+    L.device_bytes = c.offset;
+    return L;
+}
+DeviceLU bind_layout(const LuLayout& L, char* dev_, int m, int max_updates, int inverse_vectors, int stride) {
+    const bool inverse_factors = inverse_vectors != 0;
+    const int ldt = max_updates + 1;
+    DeviceLU d;
+    d.m = m;
+    d.max_updates = max_updates;
+    d.ldt = ldt;
+    auto I = [&](size_t o) { return reinterpret_cast<int*>(dev_ + o); };
+    auto D = [&](size_t o) { return reinterpret_cast<double*>(dev_ + o); };
+    d.rowpos = I(L.o_rowpos);
+    d.colpos = I(L.o_colpos);
+    d.l_rstart = I(L.o_lrs); d.l_rcol = I(L.o_lrcol); d.l_rval = D(L.o_lrval);
+    d.l_cstart = I(L.o_lcs); d.l_crow = I(L.o_lcrow); d.l_cval = D(L.o_lcval);
+    d.u_rstart = I(L.o_urs); d.u_rcol = I(L.o_urcol); d.u_rval = D(L.o_urval);
+    d.u_cstart = I(L.o_ucs); d.u_crow = I(L.o_ucrow); d.u_cval = D(L.o_ucval);
+    d.app_len = I(L.o_applen); d.app_slot = I(L.o_appslot); d.app_val = D(L.o_appval);
+    d.s_cstart = I(L.o_scs); d.s_clen = I(L.o_scl); d.s_crow = I(L.o_scrow); d.s_cval = D(L.o_scval);
+    d.s_capacity = (int)L.app;
+    d.T = D(L.o_T);
+    d.trail_pos = I(L.o_trail);
+    d.slot_of = I(L.o_slotof);
+    d.diag = D(L.o_diag);
+    d.eta_start = I(L.o_eta_start); d.eta_pivot = I(L.o_eta_pivot); d.eta_idx = I(L.o_eta_idx); d.eta_val = D(L.o_eta_val);
+    d.eta_capacity = (int)L.app;
+    d.eta_mf = D(L.o_eta_mf); d.eta_of_pos = I(L.o_eta_of); d.eta_first = I(L.o_eta_first); d.eta_prev = I(L.o_eta_prev);
+    d.eapp_len = I(L.o_eapp_len); d.eapp_eta = I(L.o_eapp_eta); d.eapp_val = D(L.o_eapp_val);
+    d.spike = D(L.o_spike);
+    d.state = I(L.o_state);
+    d.task_stride = stride;
+    d.inverse_factors = inverse_vectors;
+    d.pf_M = inverse_factors ? D(L.o_pf_m) : nullptr;
+    d.pf_ld = (int)L.pf_ld;
+    d.pf_slot = I(L.o_pf_slot);
+    d.pf_col_of = I(L.o_pf_col_of);
+    for (int k = 0; k < 4; ++k) {
+        LuTasks& t = d.tasks[k];
+        auto GI = [&](size_t o) { return (lu_gptr_i32) reinterpret_cast<const int*>(dev_ + o); };
+        auto GD = [&](size_t o) { return (lu_gptr_f64) reinterpret_cast<const double*>(dev_ + o); };
+        t.z_pos = GI(L.to[k].z_pos); t.z_dinv = GD(L.to[k].z_dinv);
+        t.s_pos = GI(L.to[k].s_pos); t.s_lev = GI(L.to[k].s_lev); t.s_flags = GI(L.to[k].s_flags); t.s_dinv = GD(L.to[k].s_dinv);
+        t.s_xstart = GI(L.to[k].s_xstart); t.s_xn = GI(L.to[k].s_xn); t.chunk = GI(L.to[k].chunk);
+        t.s_col = GI(L.to[k].s_col); t.s_val = GD(L.to[k].s_val);
+        t.x_idx = GI(L.to[k].x_idx); t.x_val = GD(L.to[k].x_val);
+        t.counts = GI(L.o_counts + (size_t)k * LU_CNT_WORDS * sizeof(int));
+        if (inverse_factors) {
+            t.c_hdr = (const __attribute__((address_space(1))) unsigned int*)reinterpret_cast<const unsigned int*>(dev_ + L.co[k].hdr);
+            t.c_col = (const __attribute__((address_space(1))) unsigned long long*)reinterpret_cast<const unsigned long long*>(dev_ + L.co[k].col);
+            t.c_val = GD(L.co[k].val);
+            t.c_zpos = GI(L.co[k].zpos);
+        }
+    }
+    return d;
+}
 }  // namespace
 
 static int lu_inverse_vectors(int m, int max_updates);  // (below, with the LDS sizes)
@@ -386,67 +517,15 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
         cap_slots_ = std::max(cap_slots_, ((max_slots + margin) + 1023) & ~size_t(1023));
     }
     const int stride = (int)cap_slots_;
-    // ---- uploaded prefix ----------------------------------------------------------------------------------------------
-    Carver c;
-    const size_t o_rowpos = c.take<int>(m), o_colpos = c.take<int>(m);
-    const size_t o_lrs = c.take<int>(m + 1), o_lcs = c.take<int>(m + 1), o_urs = c.take<int>(m + 1), o_ucs = c.take<int>(m + 1);
-    const size_t o_diag = c.take<double>(m);
-    const size_t o_counts = c.take<int>(4 * LU_CNT_WORDS);
-    struct TaskOffsets {
-        size_t z_pos, z_dinv, s_pos, s_lev, s_flags, s_dinv, s_xstart, s_xn, chunk, s_col, s_val, x_idx, x_val;
-    } to[4];
-    for (int k = 0; k < 4; ++k) {
-        to[k].z_pos = c.take<int>(stride);
-        to[k].z_dinv = c.take<double>(stride);
-        to[k].s_pos = c.take<int>(stride);
-        to[k].s_lev = c.take<int>(stride);
-        to[k].s_flags = c.take<int>(stride);
-        to[k].s_dinv = c.take<double>(stride);
-        to[k].s_xstart = c.take<int>(stride);
-        to[k].s_xn = c.take<int>(stride);
-        to[k].chunk = c.take<int>(8 * LU_MAX_CHUNKS);
-    }
-    const size_t small_bytes = c.offset;  // everything up to here goes in one copy
-    for (int k = 0; k < 4; ++k) {
-        const size_t cap = (k == 0 || k == 3) ? cl : cu;
-        to[k].s_col = c.take<int>((size_t)LU_TE * stride);
-        to[k].s_val = c.take<double>((size_t)LU_TE * stride);
-        to[k].x_idx = c.take<int>(cap);
-        to[k].x_val = c.take<double>(cap);
-    }
-    const size_t o_lrcol = c.take<int>(cl), o_lcrow = c.take<int>(cl), o_lrval = c.take<double>(cl), o_lcval = c.take<double>(cl);
-    const size_t o_urcol = c.take<int>(cu), o_ucrow = c.take<int>(cu), o_urval = c.take<double>(cu), o_ucval = c.take<double>(cu);
-    // the compact records of the inverse-factor form (lu.hpp), the four lists in ONE region (one copy per refactorisation)
-    struct CompactOffsets {
-        size_t hdr, col, val, zpos;
-    } co[4];
-    const size_t compact_begin = (c.offset + 63) & ~size_t(63);
-    c.offset = compact_begin;
-    for (int k = 0; k < 4; ++k) {
-        co[k].hdr = c.take<unsigned int>(inverse_factors ? stride : 0);
-        co[k].zpos = c.take<int>(inverse_factors ? stride : 0);
-        co[k].col = c.take<unsigned long long>(inverse_factors ? stride : 0);
-        c.offset = (c.offset + 31) & ~size_t(31);
-        co[k].val = c.take<double>(inverse_factors ? (size_t)4 * stride : 0);
-    }
-    const size_t compact_end = c.offset;
-    const size_t upload_bytes = c.offset;
-    // ---- device only ----------------------------------------------------------------------------------------------------------
-    const size_t app = (size_t)m * max_updates;
-    const size_t o_applen = c.take<int>(m), o_appslot = c.take<int>(app), o_appval = c.take<double>(app);
-    const size_t o_scs = c.take<int>(max_updates), o_scl = c.take<int>(max_updates), o_scrow = c.take<int>(app), o_scval = c.take<double>(app);
-    const size_t o_T = c.take<double>((size_t)max_updates * ldt);
-    const size_t o_trail = c.take<int>(max_updates), o_slotof = c.take<int>(m);
-    const size_t o_eta_start = c.take<int>(max_updates + 2), o_eta_pivot = c.take<int>(max_updates + 1);
-    const size_t o_eta_idx = c.take<int>(app), o_eta_val = c.take<double>(app);
-    const size_t o_eta_mf = c.take<double>((size_t)max_updates * ldt), o_eta_of = c.take<int>(m), o_eta_first = c.take<int>(m), o_eta_prev = c.take<int>(max_updates + 1);
-    const size_t o_eapp_len = c.take<int>(m), o_eapp_eta = c.take<int>(app), o_eapp_val = c.take<double>(app);
-    const size_t o_spike = c.take<double>(m);
-    const size_t pf_ld = ((size_t)m + 15) & ~(size_t)15;
-    const size_t o_pf_m = c.take<double>(inverse_factors ? pf_ld * max_updates : 0);
-    const size_t o_pf_slot = c.take<int>(max_updates), o_pf_col_of = c.take<int>(m);
-    const size_t o_state = c.take<int>(LU_STATE_WORDS);
-    const size_t device_bytes = c.offset;
+    // ---- uploaded prefix + device-only part: the layout (compute_layout above) ------------------------------------------------
+    const LuLayout lay = compute_layout(m, max_updates, inverse_factors, cl, cu, stride);
+    const size_t o_rowpos = lay.o_rowpos, o_colpos = lay.o_colpos, o_lrs = lay.o_lrs, o_lcs = lay.o_lcs, o_urs = lay.o_urs, o_ucs = lay.o_ucs;
+    const size_t o_diag = lay.o_diag, o_counts = lay.o_counts, small_bytes = lay.small_bytes;
+    const LuLayout::TaskOffsets* to = lay.to;
+    const LuLayout::CompactOffsets* co = lay.co;
+    const size_t o_lrcol = lay.o_lrcol, o_lcrow = lay.o_lcrow, o_lrval = lay.o_lrval, o_lcval = lay.o_lcval;
+    const size_t o_urcol = lay.o_urcol, o_ucrow = lay.o_ucrow, o_urval = lay.o_urval, o_ucval = lay.o_ucval;
+    const size_t compact_begin = lay.compact_begin, compact_end = lay.compact_end, upload_bytes = lay.upload_bytes, device_bytes = lay.device_bytes;
     {
         char* before = dev_;
         reserve(device_bytes, upload_bytes);
@@ -571,54 +650,7 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     if (time_parts && ++uploads % 25 == 0)
         fprintf(stderr, "[refactor]   upload parts, %lld so far: level schedules %.2f, column orientations %.2f, slot lists %.2f, staging %.2f (%zu bytes), copies %.2f ms\n",
                 uploads, part_seconds[0] * 1e3, part_seconds[1] * 1e3, part_seconds[2] * 1e3, part_seconds[3] * 1e3, upload_bytes, part_seconds[4] * 1e3);
-    DeviceLU d;
-    d.m = m;
-    d.max_updates = max_updates;
-    d.ldt = ldt;
-    auto I = [&](size_t o) { return reinterpret_cast<int*>(dev_ + o); };
-    auto D = [&](size_t o) { return reinterpret_cast<double*>(dev_ + o); };
-    d.rowpos = I(o_rowpos);
-    d.colpos = I(o_colpos);
-    d.l_rstart = I(o_lrs); d.l_rcol = I(o_lrcol); d.l_rval = D(o_lrval);
-    d.l_cstart = I(o_lcs); d.l_crow = I(o_lcrow); d.l_cval = D(o_lcval);
-    d.u_rstart = I(o_urs); d.u_rcol = I(o_urcol); d.u_rval = D(o_urval);
-    d.u_cstart = I(o_ucs); d.u_crow = I(o_ucrow); d.u_cval = D(o_ucval);
-    d.app_len = I(o_applen); d.app_slot = I(o_appslot); d.app_val = D(o_appval);
-    d.s_cstart = I(o_scs); d.s_clen = I(o_scl); d.s_crow = I(o_scrow); d.s_cval = D(o_scval);
-    d.s_capacity = (int)app;
-    d.T = D(o_T);
-    d.trail_pos = I(o_trail);
-    d.slot_of = I(o_slotof);
-    d.diag = D(o_diag);
-    d.eta_start = I(o_eta_start); d.eta_pivot = I(o_eta_pivot); d.eta_idx = I(o_eta_idx); d.eta_val = D(o_eta_val);
-    d.eta_capacity = (int)app;
-    d.eta_mf = D(o_eta_mf); d.eta_of_pos = I(o_eta_of); d.eta_first = I(o_eta_first); d.eta_prev = I(o_eta_prev);
-    d.eapp_len = I(o_eapp_len); d.eapp_eta = I(o_eapp_eta); d.eapp_val = D(o_eapp_val);
-    d.spike = D(o_spike);
-    d.state = I(o_state);
-    d.task_stride = stride;
-    d.inverse_factors = inverse_vectors;
-    d.pf_M = inverse_factors ? D(o_pf_m) : nullptr;
-    d.pf_ld = (int)pf_ld;
-    d.pf_slot = I(o_pf_slot);
-    d.pf_col_of = I(o_pf_col_of);
-    for (int k = 0; k < 4; ++k) {
-        LuTasks& t = d.tasks[k];
-        auto GI = [&](size_t o) { return (lu_gptr_i32) reinterpret_cast<const int*>(dev_ + o); };
-        auto GD = [&](size_t o) { return (lu_gptr_f64) reinterpret_cast<const double*>(dev_ + o); };
-        t.z_pos = GI(to[k].z_pos); t.z_dinv = GD(to[k].z_dinv);
-        t.s_pos = GI(to[k].s_pos); t.s_lev = GI(to[k].s_lev); t.s_flags = GI(to[k].s_flags); t.s_dinv = GD(to[k].s_dinv);
-        t.s_xstart = GI(to[k].s_xstart); t.s_xn = GI(to[k].s_xn); t.chunk = GI(to[k].chunk);
-        t.s_col = GI(to[k].s_col); t.s_val = GD(to[k].s_val);
-        t.x_idx = GI(to[k].x_idx); t.x_val = GD(to[k].x_val);
-        t.counts = GI(o_counts + (size_t)k * LU_CNT_WORDS * sizeof(int));
-        if (inverse_factors) {
-            t.c_hdr = (const __attribute__((address_space(1))) unsigned int*)reinterpret_cast<const unsigned int*>(dev_ + co[k].hdr);
-            t.c_col = (const __attribute__((address_space(1))) unsigned long long*)reinterpret_cast<const unsigned long long*>(dev_ + co[k].col);
-            t.c_val = GD(co[k].val);
-            t.c_zpos = GI(co[k].zpos);
-        }
-    }
+    const DeviceLU d = bind_layout(lay, dev_, m, max_updates, inverse_vectors, stride);
     d_ = d;
     hipLaunchKernelGGL(lu_init_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_);
     nnz_l = factors.nnz_l();

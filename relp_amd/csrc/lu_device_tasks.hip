@@ -1,0 +1,481 @@
+// What `BasisInverse::invert` produces for the inverse-factor carry, built ON THE DEVICE from the factors lu_factor.hip left there:
+//   * L^-1 (strict part) and U^-1 (with its diagonal) as sparse matrices of the position space -- the role of `lu_invert_factors`
+//     (lu_host.hpp):  row_i(L^-1) = e_i - sum_{j<i} l_ij row_j(L^-1),   row_i(U^-1) = (e_i - sum_{j>i} u_ij row_j(U^-1)) / u_ii;
+//   * both inverses in both orientations as the COMPACT SLOT RECORDS the product kernels stream (`LuTasks::c_hdr / c_col / c_val`,
+//     lu.hpp; the role of count_inverse_slots / fill_inverse_records in lu.hip): rows packed widest group first, a row = 1, 2, 4 ...
+//     64 aligned slots of four entries, per-wave summaries in the headers, rows of more than 256 entries with their tail in the
+//     extras arena, rows without entries in the z list.
+// Reference lines this stands for: lower_upper/mod.rs:78-92 (`invert`), :180-237 (what the solves read).
+//
+// The inversion is a DATAFLOW over rows, one workgroup: wave w takes the rows w, w + 16, ... of L^-1 in ascending order (then the
+// rows of U^-1 in descending order); a row waits for the rows it reads by polling their length word (workgroup-scope acquire: the
+// waves of one workgroup share the CU's L1, so a release is a wait for the stores, not a cache write-back), accumulates
+// `- l_ij row_j` into a dense accumulator of its wave (LDS when sixteen of them fit, else global) with a bitmap of the touched
+// columns, and emits its entries in COLUMN ORDER by walking the bitmap -- no sort, and nothing depends on which wave finished first.
+// The smallest unfinished row never waits (everything it reads is finished), so the schedule cannot deadlock.
+#include "lu_factor.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+
+#include "lu.hpp"
+#include "solver.hpp"
+#include "wave_ops.hpp"
+
+namespace relp {
+
+namespace {
+
+constexpr int LUT_THREADS = LUF_THREADS;
+constexpr int LUT_WAVES = LUT_THREADS / WAVE;
+
+typedef __attribute__((address_space(3))) double lds_f64_t;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+
+struct TaskShared {
+    unsigned long long scan[LUT_WAVES + 2];
+    int cursor;
+    int error;
+    int totals[16];
+};
+
+__device__ __forceinline__ unsigned long long t_wave_inclusive_scan(unsigned long long v) {
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned lo = (unsigned)__shfl_up((int)(unsigned)v, d, WAVE);
+        const unsigned hi = (unsigned)__shfl_up((int)(unsigned)(v >> 32), d, WAVE);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        if (lane >= d) v += other;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long t_block_exclusive_scan(unsigned long long v, TaskShared& sh, unsigned long long* total) {
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const unsigned long long incl = t_wave_inclusive_scan(v);
+    __syncthreads();
+    if (lane == WAVE - 1) sh.scan[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned long long w = lane < LUT_WAVES ? sh.scan[lane] : 0ull;
+        const unsigned long long wi = t_wave_inclusive_scan(w);
+        if (lane < LUT_WAVES) sh.scan[lane] = wi - w;
+        if (lane == LUT_WAVES - 1) sh.scan[LUT_WAVES] = wi;
+    }
+    __syncthreads();
+    *total = sh.scan[LUT_WAVES];
+    return sh.scan[wave] + incl - v;
+}
+__device__ __forceinline__ int t_lanes_below(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ __forceinline__ int t_group_log2(int n) {  // smallest g with 4 << g >= n, at most 6 (group_log2 of lu.hip)
+    int g = 0;
+    while (g < 6 && (LU_TE << g) < n) ++g;
+    return g;
+}
+__device__ __forceinline__ int load_acquire_wg(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void store_release_wg(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// One row of an inverse by one wave.  `src_*`: the entries (j, f_ij) of row i of the factor; `UPPER`: row of U^-1 (starts from e_i,
+// scaled by 1 / u_ii at the end, the rows it reads carry their diagonal) or of L^-1 (strict part: the rows it reads have an implied 1).
+template <bool ACC_LDS, bool UPPER>
+__device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i, const int* src_col, const double* src_val, const int s, const int e,
+                           const double scale, volatile lds_f64_t* acc_lds, double* acc_glb, volatile lds_u64_t* bits, const int words) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int f = UPPER ? 1 : 0;
+    auto add = [&](int c, double delta) {  // (the lanes of one step hold distinct columns)
+        if (ACC_LDS) acc_lds[c] = acc_lds[c] + delta;
+        else acc_glb[c] = acc_glb[c] + delta;
+        atomicOr((unsigned long long*)(bits + (c >> 6)), 1ull << (c & 63));
+    };
+    if (UPPER && lane == 0) add(i, 1.0);
+    for (int x0 = s; x0 < e; x0 += WAVE) {
+        // the descriptors of up to 64 rows this one reads: wait until each is finished (they are: lower rows of L^-1, higher of U^-1)
+        int j = 0, sj = 0, nj = 0;
+        double fij = 0.0;
+        if (x0 + lane < e) {
+            j = src_col[x0 + lane];
+            fij = src_val[x0 + lane];
+            while ((nj = load_acquire_wg(&iw.raw_len[f][j])) < 0) __builtin_amdgcn_s_sleep(2);
+            sj = iw.raw_start[f][j];
+        }
+        const int cnt = min(WAVE, e - x0);
+        for (int y = 0; y < cnt; ++y) {
+            const int jj = __shfl(j, y, WAVE), sjj = __shfl(sj, y, WAVE), njj = __shfl(nj, y, WAVE);
+            const double factor = __shfl(fij, y, WAVE);
+            if (!UPPER && lane == 0) add(jj, -factor);  // the unit diagonal of row jj of L^-1
+            for (int z0 = 0; z0 < njj; z0 += WAVE)
+                if (z0 + lane < njj) add(iw.raw_col[sjj + z0 + lane], -factor * iw.raw_val[sjj + z0 + lane]);
+            // (global accumulators: the next row's read-modify-writes must see these stores -- another lane may hold the column then)
+            if (!ACC_LDS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    // emit in column order: the set bits of the bitmap, word by word
+    int total = 0;
+    for (int w0 = 0; w0 < words; w0 += WAVE) {
+        const int w = w0 + lane;
+        const unsigned long long word = w < words ? bits[w] : 0ull;
+        total += __popcll(word);
+    }
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) total += __shfl_xor(total, d, WAVE);
+    int at = 0;
+    if (lane == 0) at = atomicAdd(&sh.cursor, total);
+    at = __shfl(at, 0, WAVE);
+    if (at + total > iw.raw_cap) {
+        if (lane == 0) sh.error = LUF_ERR_INVERSE_CAPACITY;
+        total = 0;
+    }
+    int written = 0;
+    for (int w0 = 0; w0 < words; w0 += WAVE) {
+        const int w = w0 + lane;
+        unsigned long long word = w < words ? bits[w] : 0ull;
+        if (w < words) bits[w] = 0ull;
+        const int mine = __popcll(word);
+        // exclusive prefix of `mine` over the lanes
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int other = __shfl_up(incl, d, WAVE);
+            if (lane >= d) incl += other;
+        }
+        int dst = at + written + incl - mine;
+        while (word) {
+            const int b = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            const int c = (w << 6) | b;
+            double v;
+            if (ACC_LDS) { v = acc_lds[c]; acc_lds[c] = 0.0; }
+            else { v = acc_glb[c]; acc_glb[c] = 0.0; }
+            if (total) {  // (exact zeros from cancellation stay as explicit entries: they are rare and harmless to a product)
+                iw.raw_col[dst] = c;
+                iw.raw_val[dst] = v * scale;
+            }
+            ++dst;
+        }
+        written += __shfl(incl, WAVE - 1, WAVE);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane's stores have left before the length is published
+    if (lane == 0) {
+        iw.raw_start[f][i] = at;
+        store_release_wg(&iw.raw_len[f][i], total);
+    }
+}
+
+template <bool ACC_LDS>
+__global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac, LuInverseWork iw, const int* status_in) {
+    extern __shared__ unsigned char dyn_lds[];
+    __shared__ TaskShared sh;
+    const int tid = threadIdx.x, T = LUT_THREADS;
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int m = iw.m;
+    const int words = (m + 63) / 64;
+    if (status_in && status_in[LUF_STATUS] != LUF_OK) return;  // the factorisation failed: nothing to invert (the host falls back)
+    volatile lds_u64_t* bits_all = (volatile lds_u64_t*)dyn_lds;
+    volatile lds_f64_t* acc_all = (volatile lds_f64_t*)(dyn_lds + (size_t)LUT_WAVES * words * sizeof(unsigned long long));
+    if (tid == 0) {
+        sh.cursor = 0;
+        sh.error = LUF_OK;
+    }
+    for (int x = tid; x < LUT_WAVES * words; x += T) bits_all[x] = 0ull;
+    if (ACC_LDS)
+        for (int x = tid; x < LUT_WAVES * m; x += T) acc_all[x] = 0.0;
+    else
+        for (int x = tid; x < LUT_WAVES * m; x += T) iw.acc[x] = 0.0;
+    for (int i = tid; i < m; i += T) {
+        iw.raw_len[0][i] = -1;
+        iw.raw_len[1][i] = -1;
+    }
+    __syncthreads();
+    volatile lds_u64_t* bits = bits_all + (size_t)wave * words;
+    volatile lds_f64_t* acc_lds = acc_all + (size_t)wave * m;
+    double* acc_glb = iw.acc + (size_t)wave * m;
+    for (int i = wave; i < m; i += LUT_WAVES) {  // L^-1, ascending
+        const int s = fac.l_start[i], e = fac.l_start[i + 1];
+        if (s == e) {
+            if (lane == 0) {
+                iw.raw_start[0][i] = 0;
+                store_release_wg(&iw.raw_len[0][i], 0);
+            }
+            continue;
+        }
+        invert_row<ACC_LDS, false>(iw, sh, i, fac.l_col, fac.l_val, s, e, 1.0, acc_lds, acc_glb, bits, words);
+    }
+    for (int i = m - 1 - wave; i >= 0; i -= LUT_WAVES)  // U^-1, descending
+        invert_row<ACC_LDS, true>(iw, sh, i, fac.u_col, fac.u_val, fac.u_start[i], fac.u_start[i + 1], 1.0 / fac.diag[i], acc_lds, acc_glb, bits, words);
+    __syncthreads();
+    // ---- the two inverses by rows, compact, in row order (rows are already sorted by column) ----------------------------------
+    for (int f = 0; f < 2; ++f) {
+        unsigned long long carry = 0;
+        for (int base = 0; base < m; base += T) {
+            const int i = base + tid;
+            const unsigned long long v = i < m ? (unsigned long long)iw.raw_len[f][i] : 0ull;
+            unsigned long long total;
+            const unsigned long long ex = t_block_exclusive_scan(v, sh, &total) + carry;
+            if (i < m) iw.csr_start[f][i] = (int)ex;
+            carry += total;
+        }
+        if (tid == 0) {
+            iw.csr_start[f][m] = (int)carry;
+            iw.info[f == 0 ? LUF_NNZ_LI : LUF_NNZ_UI] = (int)carry;
+            if (carry > (unsigned long long)iw.cap) sh.error = LUF_ERR_INVERSE_CAPACITY;
+        }
+        __syncthreads();
+        if (sh.error == LUF_OK) {
+            for (int i = wave; i < m; i += LUT_WAVES) {
+                const int n = iw.raw_len[f][i], s = iw.raw_start[f][i], d = iw.csr_start[f][i];
+                for (int t = lane; t < n; t += WAVE) {
+                    iw.csr_idx[f][d + t] = iw.raw_col[s + t];
+                    iw.csr_val[f][d + t] = iw.raw_val[s + t];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && sh.error != LUF_OK) iw.info[LUF_STATUS] = sh.error;
+}
+
+// Transposes of the two inverses (lists 2 and 3) and the compact records of all four lists.
+__global__ void __launch_bounds__(LUT_THREADS) lu_pack_inverse_kernel(DeviceLU lu, LuInverseWork iw, Ctl* ctl, int failed_status) {
+    __shared__ TaskShared sh;
+    const int tid = threadIdx.x, T = LUT_THREADS;
+    const int lane = tid & (WAVE - 1);
+    const int m = iw.m;
+    if (iw.info[LUF_STATUS] != LUF_OK) {
+        if (tid == 0 && ctl) ctl->status = failed_status;  // the pivots enqueued behind this become no-ops; the host refactorises
+        return;
+    }
+    if (tid == 0) sh.error = LUF_OK;
+    // ---- column orientations: list 2 = U^-1 by columns (from list 1), list 3 = L^-1 by columns (from list 0) -------------------
+    for (int f = 0; f < 2; ++f) {
+        const int dst = f == 0 ? 3 : 2;
+        const int* __restrict__ rs = iw.csr_start[f];
+        const int* __restrict__ ri = iw.csr_idx[f];
+        const double* __restrict__ rv = iw.csr_val[f];
+        const int nnz = rs[m];
+        for (int c = tid; c <= m; c += T) iw.cursor[c] = 0;
+        __syncthreads();
+        for (int x = tid; x < nnz; x += T) atomicAdd(&iw.cursor[ri[x]], 1);
+        __syncthreads();
+        {
+            unsigned long long carry = 0;
+            for (int base = 0; base < m; base += T) {
+                const int c = base + tid;
+                const unsigned long long v = c < m ? (unsigned long long)iw.cursor[c] : 0ull;
+                unsigned long long total;
+                const unsigned long long ex = t_block_exclusive_scan(v, sh, &total) + carry;
+                if (c < m) iw.csr_start[dst][c] = (int)ex;
+                carry += total;
+            }
+            if (tid == 0) iw.csr_start[dst][m] = nnz;
+        }
+        __syncthreads();
+        // scatter with an atomic cursor, then rank-sort every column by row: the order in which the atomics land leaves no trace
+        for (int c = tid; c < m; c += T) iw.cursor[c] = 0;
+        __syncthreads();
+        for (int i = tid / WAVE; i < m; i += LUT_WAVES)
+            for (int x = rs[i] + lane; x < rs[i + 1]; x += WAVE) {
+                const int c = ri[x];
+                const int at = iw.csr_start[dst][c] + atomicAdd(&iw.cursor[c], 1);
+                iw.tmp_idx[at] = i;
+                iw.tmp_val[at] = rv[x];
+                iw.tmp_col[at] = c;
+            }
+        __syncthreads();
+        for (int x = tid; x < nnz; x += T) {
+            const int c = iw.tmp_col[x], i = iw.tmp_idx[x];
+            const int cs = iw.csr_start[dst][c], ce = iw.csr_start[dst][c + 1];
+            int rank = 0;
+            for (int y = cs; y < ce; ++y) rank += iw.tmp_idx[y] < i ? 1 : 0;
+            iw.csr_idx[dst][cs + rank] = i;
+            iw.csr_val[dst][cs + rank] = iw.tmp_val[x];
+        }
+        __syncthreads();
+    }
+    // ---- the compact records, list by list ------------------------------------------------------------------------------------------
+    const int stride = lu.task_stride;
+    for (int k = 0; k < 4; ++k) {
+        const LuTasks& tk = lu.tasks[k];
+        unsigned* hdr = (unsigned*)tk.c_hdr;
+        unsigned long long* colw = (unsigned long long*)tk.c_col;
+        double* vals = (double*)tk.c_val;
+        int* zpos = (int*)tk.c_zpos;
+        int* xstart = (int*)tk.s_xstart;
+        int* xn = (int*)tk.s_xn;
+        int* xidx = (int*)tk.x_idx;
+        double* xval = (double*)tk.x_val;
+        int* counts = (int*)tk.counts;
+        const int xcap = (k == 0 || k == 3) ? iw.cap_extra_l : iw.cap_extra_u;
+        const int* __restrict__ rs = iw.csr_start[k];
+        const int* __restrict__ ri = iw.csr_idx[k];
+        const double* __restrict__ rv = iw.csr_val[k];
+        // (a) rank of every row inside its group class (ordered), rows without entries, extras: three packed scans
+        unsigned long long ca = 0, cb = 0, cx = 0;
+        for (int base = 0; base < m; base += T) {
+            const int i = base + tid;
+            int n = 0, g = -1;
+            if (i < m) {
+                n = rs[i + 1] - rs[i];
+                g = n > 0 ? t_group_log2(n) : 7;  // 7: the z list
+            }
+            const unsigned long long va = (i < m && g < 4) ? 1ull << (16 * g) : 0ull;
+            const unsigned long long vb = (i < m && g >= 4) ? 1ull << (16 * (g - 4)) : 0ull;
+            const unsigned long long vx = n > LU_TE * 64 ? (unsigned long long)(n - LU_TE * 64) : 0ull;
+            unsigned long long ta, tb, tx;
+            const unsigned long long ea = t_block_exclusive_scan(va, sh, &ta) + ca;
+            const unsigned long long eb = t_block_exclusive_scan(vb, sh, &tb) + cb;
+            const unsigned long long ex = t_block_exclusive_scan(vx, sh, &tx) + cx;
+            if (i < m) {
+                const unsigned long long field = g < 4 ? ea >> (16 * g) : eb >> (16 * (g - 4));
+                iw.row_rank[i] = (int)(field & 0xffffull);
+                iw.row_xoff[i] = (int)ex;
+            }
+            ca += ta;
+            cb += tb;
+            cx += tx;
+        }
+        if (tid == 0) {
+            int count[8];
+            for (int g = 0; g < 4; ++g) count[g] = (int)((ca >> (16 * g)) & 0xffffull);
+            for (int g = 4; g < 8; ++g) count[g] = (int)((cb >> (16 * (g - 4))) & 0xffffull);
+            int slots = 0;
+            for (int g = 6; g >= 0; --g) {
+                sh.totals[g] = slots;  // first slot of the class
+                slots += count[g] << g;
+            }
+            sh.totals[7] = count[7];   // rows without entries
+            sh.totals[8] = slots;
+            sh.totals[9] = (int)cx;
+            if (slots + 1024 > stride) sh.error = LUF_ERR_TASK_CAPACITY;
+            if ((int)cx > xcap) sh.error = LUF_ERR_TASK_CAPACITY;
+        }
+        __syncthreads();
+        if (sh.error != LUF_OK) break;
+        const int n_slots = sh.totals[8];
+        // (b) headers of every row's slots, the z list
+        for (int i = tid; i < m; i += T) {
+            const int n = rs[i + 1] - rs[i];
+            if (n == 0) {
+                zpos[iw.row_rank[i]] = i;
+                continue;
+            }
+            const int g = t_group_log2(n), G = 1 << g;
+            const int first = sh.totals[g] + iw.row_rank[i] * G;
+            const int extra = n - min(n, LU_TE * G);
+            iw.row_first[i] = first;
+            for (int j = 0; j < G; ++j) {
+                hdr[first + j] = (unsigned)i | ((unsigned)g << 16) | ((j == G - 1) ? 1u << 19 : 0u) | (extra > 0 ? 1u << 20 : 0u);
+                if (extra > 0) {
+                    xstart[first + j] = iw.row_xoff[i];
+                    xn[first + j] = extra;
+                }
+            }
+        }
+        __syncthreads();
+        // (c) the entries of every slot: slot j of a row takes its entries j, j + G, j + 2 G, j + 3 G; the wave summaries
+        for (int base = 0; base < n_slots; base += T) {
+            const int sl = base + tid;
+            unsigned h = 0;
+            int g = 0;
+            if (sl < n_slots) {
+                h = hdr[sl];
+                g = (int)(h >> 16) & 7;
+                const int i = (int)(h & 0xffffu), G = 1 << g, j = sl & (G - 1);
+                const int s = rs[i], n = rs[i + 1] - s;
+                const int inline_n = min(n, LU_TE * G);
+                unsigned long long cw = 0;
+                double v[LU_TE] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < LU_TE; ++t) {
+                    const int e = j + t * G;
+                    if (e < inline_n) {
+                        cw |= (unsigned long long)(unsigned)ri[s + e] << (16 * t);
+                        v[t] = rv[s + e];
+                    }
+                }
+                colw[sl] = cw;
+#pragma unroll
+                for (int t = 0; t < LU_TE; ++t) vals[(size_t)LU_TE * sl + t] = v[t];
+                if ((h >> 20) & 1u) {  // the tail of a row of more than 256 entries, by the 64 slots of the row
+                    const int xo = iw.row_xoff[i];
+                    for (int e = inline_n + j; e < n; e += G) {
+                        xidx[xo + e - inline_n] = ri[s + e];
+                        xval[xo + e - inline_n] = rv[s + e];
+                    }
+                }
+            }
+            // bits 21-26: some row of this wave's 64 slots spans more than 2^j lanes; bit 27: some row of it has extras
+            int gmax = sl < n_slots ? g : 0;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) gmax = max(gmax, __shfl_xor(gmax, d, WAVE));
+            const unsigned long long any_extra = __ballot(sl < n_slots && ((h >> 20) & 1u));
+            unsigned summary = 0;
+            for (int j = 0; j < 6; ++j)
+                if (gmax > j) summary |= 1u << (21 + j);
+            if (any_extra) summary |= 1u << 27;
+            if (sl < n_slots) hdr[sl] = h | summary;
+        }
+        // (d) padding the product reads: up to the next multiple of the workgroup, and the last slot of the stride
+        {
+            const int pad_end = min(stride, ((n_slots + T - 1) / T) * T + T);
+            for (int sl = n_slots + tid; sl < pad_end; sl += T) {
+                hdr[sl] = 0u;
+                colw[sl] = 0ull;
+#pragma unroll
+                for (int t = 0; t < LU_TE; ++t) vals[(size_t)LU_TE * sl + t] = 0.0;
+            }
+            if (tid == 0) {
+                hdr[stride - 1] = 0u;
+                colw[stride - 1] = 0ull;
+                for (int t = 0; t < LU_TE; ++t) vals[(size_t)LU_TE * (stride - 1) + t] = 0.0;
+                counts[LU_CNT_Z] = sh.totals[7];
+                counts[LU_CNT_SLOTS] = n_slots;
+                counts[LU_CNT_LEVELS] = 1;
+                counts[LU_CNT_CHUNKS] = 1;
+                counts[LU_CNT_C0_END] = n_slots;
+                counts[LU_CNT_C0_L0] = 0;
+                counts[LU_CNT_C0_L1] = 1;
+                counts[LU_CNT_C0_TAIL] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    // the inverse-factor form keeps U's diagonal inside U^-1: the diagonal array the kernels see is ones (as lu_invert_factors' out.diag)
+    for (int i = tid; i < m; i += T) lu.diag[i] = 1.0;
+    __syncthreads();
+    if (tid == 0 && sh.error != LUF_OK) {
+        iw.info[LUF_STATUS] = sh.error;
+        if (ctl) ctl->status = failed_status;
+    }
+    (void)lane;
+}
+
+}  // namespace
+
+size_t lu_invert_lds_bytes(int m, bool* acc_in_lds) {
+    const size_t words = (size_t)(m + 63) / 64;
+    const size_t bitmap = (size_t)LUT_WAVES * words * sizeof(unsigned long long);
+    const size_t acc = (size_t)LUT_WAVES * m * sizeof(double);
+    const bool fits = bitmap + acc <= (size_t)120 * 1024;
+    if (acc_in_lds) *acc_in_lds = fits;
+    return bitmap + (fits ? acc : 0);
+}
+
+void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw, const int* status_in, hipStream_t stream) {
+    bool in_lds = false;
+    const size_t lds = lu_invert_lds_bytes(iw.m, &in_lds);
+    static PerDeviceOnce once;
+    once.run([] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_invert_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_invert_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    });
+    if (in_lds) hipLaunchKernelGGL(lu_invert_kernel<true>, dim3(1), dim3(LUT_THREADS), lds, stream, factors, iw, status_in);
+    else hipLaunchKernelGGL(lu_invert_kernel<false>, dim3(1), dim3(LUT_THREADS), lds, stream, factors, iw, status_in);
+}
+
+void launch_lu_pack_inverse(const DeviceLU& lu, const LuInverseWork& iw, Ctl* ctl, int failed_status, hipStream_t stream) {
+    hipLaunchKernelGGL(lu_pack_inverse_kernel, dim3(1), dim3(LUT_THREADS), 0, stream, lu, iw, ctl, failed_status);
+}
+
+}  // namespace relp

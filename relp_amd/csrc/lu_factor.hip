@@ -18,12 +18,14 @@ LuFactorScratch::~LuFactorScratch() {
     if (dev_) (void)hipFree(dev_);
 }
 
-void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_u) {
-    if (dev_ && m == m_ && nnz_basis <= nnz_ && cap_l <= cap_l_ && cap_u <= cap_u_) return;
+void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_u, size_t cap_inverse) {
+    if (dev_ && m == m_ && nnz_basis <= nnz_ && cap_l <= cap_l_ && cap_u <= cap_u_ && cap_inverse <= cap_inv_) return;
+    if (m != m_) nnz_ = cap_l_ = cap_u_ = cap_inv_ = 0;
     m_ = m;
     nnz_ = std::max(nnz_, nnz_basis);
     cap_l_ = std::max(cap_l_, cap_l);
     cap_u_ = std::max(cap_u_, cap_u);
+    cap_inv_ = std::max(cap_inv_, cap_inverse);
     const size_t cap_w = std::min<size_t>((size_t)1 << 27, 6 * nnz_ + 16 * (size_t)m + 4096);
     size_t offset = 0;
     auto take = [&](size_t bytes) {
@@ -52,6 +54,23 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     const size_t o_tidx = take(cap_t * sizeof(int)), o_tval = take(cap_t * sizeof(double)), o_trow = take(cap_t * sizeof(int));
     const size_t o_rpos = take(mi), o_cpos = take(mi), o_rowat = take(mi), o_colat = take(mi);
     const size_t o_info = take(LUF_INFO_WORDS * sizeof(int));
+    // the inversion of the two triangles and the record packing (lu_device_tasks.hip)
+    const size_t ci = cap_inv_;
+    const size_t o_rawcol = take(2 * ci * sizeof(int)), o_rawval = take(2 * ci * sizeof(double));
+    size_t o_rawstart[2], o_rawlen[2], o_cstart[4], o_cidx[4], o_cval[4];
+    for (int f = 0; f < 2; ++f) {
+        o_rawstart[f] = take(mi);
+        o_rawlen[f] = take(mi);
+    }
+    const size_t o_acc = take(ci ? (size_t)16 * m * sizeof(double) : 0);
+    for (int k = 0; k < 4; ++k) {
+        o_cstart[k] = take(mi + sizeof(int));
+        o_cidx[k] = take(ci * sizeof(int));
+        o_cval[k] = take(ci * sizeof(double));
+    }
+    const size_t o_icursor = take(mi + sizeof(int));
+    const size_t o_itidx = take(ci * sizeof(int)), o_itcol = take(ci * sizeof(int)), o_itval = take(ci * sizeof(double));
+    const size_t o_rrank = take(mi), o_rxoff = take(mi), o_rfirst = take(mi);
     if (dev_) (void)hipFree(dev_);
     dev_ = nullptr;
     RELP_HIP(hipMalloc(reinterpret_cast<void**>(&dev_), offset));
@@ -82,6 +101,27 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     w.rpos = I(o_rpos); w.cpos = I(o_cpos); w.row_at = I(o_rowat); w.col_at = I(o_colat);
     w.info = I(o_info);
     w_ = w;
+    LuInverseWork iw;
+    iw.m = m;
+    iw.cap = (int)std::min<size_t>(ci, (size_t)1 << 30);
+    iw.raw_col = I(o_rawcol);
+    iw.raw_val = D(o_rawval);
+    iw.raw_cap = (int)std::min<size_t>(2 * ci, (size_t)1 << 30);
+    for (int f = 0; f < 2; ++f) {
+        iw.raw_start[f] = I(o_rawstart[f]);
+        iw.raw_len[f] = I(o_rawlen[f]);
+    }
+    iw.acc = D(o_acc);
+    for (int k = 0; k < 4; ++k) {
+        iw.csr_start[k] = I(o_cstart[k]);
+        iw.csr_idx[k] = I(o_cidx[k]);
+        iw.csr_val[k] = D(o_cval[k]);
+    }
+    iw.cursor = I(o_icursor);
+    iw.tmp_idx = I(o_itidx); iw.tmp_col = I(o_itcol); iw.tmp_val = D(o_itval);
+    iw.row_rank = I(o_rrank); iw.row_xoff = I(o_rxoff); iw.row_first = I(o_rfirst);
+    iw.info = w.info;
+    iw_ = iw;
 }
 
 // =====================================================================================================

@@ -128,6 +128,25 @@ struct LuFactorOut {
     int cap_l = 0, cap_u = 0;
 };
 
+// Work memory of the device-side inversion of the two triangles and of the record packing (lu_device_tasks.hip).
+struct LuInverseWork {
+    int m = 0;
+    int cap = 0;                       // entries per inverse and orientation
+    int* raw_col = nullptr; double* raw_val = nullptr; int raw_cap = 0;   // rows of both inverses as they are finished
+    int* raw_start[2] = {nullptr, nullptr};
+    int* raw_len[2] = {nullptr, nullptr};     // -1: the row is not finished yet (the dataflow's flags)
+    double* acc = nullptr;             // [16][m] accumulators of the waves when they do not fit the LDS
+    // canonical: 0 L^-1 by rows (strict), 1 U^-1 by rows (with diagonal), 2 U^-1 by columns, 3 L^-1 by columns; m + 1 starts each
+    int* csr_start[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* csr_idx[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* csr_val[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* cursor = nullptr;             // [m + 1]
+    int* tmp_idx = nullptr; int* tmp_col = nullptr; double* tmp_val = nullptr;   // [cap]
+    int* row_rank = nullptr; int* row_xoff = nullptr; int* row_first = nullptr;  // [m]
+    int cap_extra_l = 0, cap_extra_u = 0;   // capacity of the extras arenas of the task lists (DeviceLU: x_idx / x_val)
+    int* info = nullptr;               // the factorisation's info words (LuFactorWork::info)
+};
+
 class LuFactorScratch {
 public:
     LuFactorScratch() = default;
@@ -135,12 +154,15 @@ public:
     LuFactorScratch(const LuFactorScratch&) = delete;
     LuFactorScratch& operator=(const LuFactorScratch&) = delete;
     // (re)allocates for m rows, a basis of at most nnz_basis entries and factors of at most cap_l / cap_u entries
-    void reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_u);
+    void reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_u, size_t cap_inverse = 0);
     const LuFactorWork& work() const { return w_; }
+    const LuInverseWork& inverse_work() const { return iw_; }
     size_t bytes() const { return bytes_; }
 
 private:
     LuFactorWork w_;
+    LuInverseWork iw_;
+    size_t cap_inv_ = 0;
     char* dev_ = nullptr;
     size_t bytes_ = 0;
     int m_ = 0;
@@ -151,5 +173,15 @@ private:
 // 0 with `reference_ties`.
 void launch_lu_factor(const LuFactorSource& src, const LuFactorWork& w, const LuFactorOut& out, double threshold, int reference_ties,
                       int dense_tail, hipStream_t stream);
+
+
+// The inverse-factor carry's share of a refactorisation on the device (lu_device_tasks.hip): L^-1 and U^-1 from the factors, then
+// the compact slot records of all four lists into the DeviceLU's task arrays.  `status_in`: the factorisation's info words
+// (nothing runs when it failed); a failure anywhere leaves its code in info[LUF_STATUS] and, with `ctl`, `failed_status` in the
+// control block so that the pivots enqueued behind it become no-ops and the host can fall back.
+struct DeviceLU;
+struct Ctl;
+void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw, const int* status_in, hipStream_t stream);
+void launch_lu_pack_inverse(const DeviceLU& lu, const LuInverseWork& iw, Ctl* ctl, int failed_status, hipStream_t stream);
 
 }  // namespace relp

@@ -43,6 +43,29 @@ WHOLE_TRACE = ["AFIRO", "SC50A", "SC50B", "SC105", "SCAGR7", "ADLITTLE", "SHARE2
                "BLEND", "ISRAEL", "STOCFOR1", "SHARE1B", "E226"]
 
 
+@pytest.mark.slow
+def test_25fv47_whole_reference_pivot_sequence_in_fixed_width_integers():
+    """BASELINE configs[1], the metric's LP, pivot for pivot in fixed-width integers on the device: `Carry<RationalBig, LUDecomposition>`
+    on 25FV47 (tests/netlib/test.rs:6-12, tests/netlib/mod.rs:62) makes 1133 + 1259 pivots to a 1791-bit optimum; the device walks
+    the same sequence (the first 64 pivots, both counts, the final basis and the optimum of tests/golden/25FV47.json, which the
+    Fraction oracle took 1726 s to produce), widening 4 -> 8 -> 16 -> 32 -> 64 -> 128 limbs of 64 bits where a value might not fit
+    and resuming at the pivot it stopped at (profiles/r4_exact_25fv47_128_limbs.txt: 20 / 45 / 96 / 207 / 534 pivots survive the
+    narrower widths; 257 s in all, 9.3 pivots/s against 2.3 for the exact CPU restatement on the same pivots)."""
+    golden = GOLDEN["25FV47"]
+    solver = relp_amd.Solver().load_mps(os.path.join(ROOT, golden["file"]))
+    got = solver.solve_exact(first_limbs=4, max_limbs=128)
+    assert got["status"] == 1, (got["status"], got["survived"])
+    assert got["limbs"] == 128 and [w for w, _ in got["survived"]] == [4, 8, 16, 32, 64, 128]
+    assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"]) == (1133, 1259)
+    assert got["objective"] == golden["objective"]
+    num, den = (int(t) for t in got["objective"].split("/"))
+    assert max(num.bit_length(), den.bit_length()) == golden["objective_bits"] == 1791
+    head = device_indices([tuple(t) for t in golden["trace_head"]], solver.n_art)
+    assert got["trace"][:len(head)] == head
+    assert sorted(int(c) for c in got["basis"]) == sorted(golden["basis"])
+    solver.close()
+
+
 @pytest.mark.parametrize("name", WHOLE_TRACE)
 def test_whole_pivot_sequence_is_the_reference_algorithms(name):
     golden = GOLDEN[name]

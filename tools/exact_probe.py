@@ -9,8 +9,8 @@ for name in names:
     g = json.load(open(golden)) if os.path.exists(golden) else None
     s = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
     t0 = time.time()
-    max_limbs = 8 if name == "25FV47" else 32
-    r = s.solve_exact(first_limbs=1, max_limbs=max_limbs, max_pivots=20000)
+    max_limbs = int(os.environ.get("RELP_PROBE_MAX_LIMBS", "128" if name == "25FV47" else "32"))
+    r = s.solve_exact(first_limbs=int(os.environ.get("RELP_PROBE_FIRST_LIMBS", "1")), max_limbs=max_limbs, max_pivots=20000)
     dt = time.time() - t0
     ok = g is not None and r["status"] == 1 and r["objective"] == g["objective"] and (r["pivots_phase_one"], r["pivots_phase_two"]) == (g["pivots_phase1"], g["pivots_phase2"])
     print("%-9s m %4d status %d limbs %2d pivots %5d+%5d  %.2f s  survived %s  %s" % (
