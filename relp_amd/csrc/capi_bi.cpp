@@ -266,7 +266,7 @@ int32_t relp_lu_factor_device(int32_t device, int32_t m, const int64_t* column_s
             RELP_HIP(hipMemcpy(b.va, value, nnz * sizeof(double), hipMemcpyHostToDevice));
         }
         LuFactorScratch scratch;
-        scratch.reserve(m, nnz, cap, cap);
+        scratch.reserve(m, nnz, cap, cap, inverted ? cap : 0);
         LuFactorSource src;
         src.col_start = b.cs;
         src.row_index = b.ri;
@@ -276,7 +276,6 @@ int32_t relp_lu_factor_device(int32_t device, int32_t m, const int64_t* column_s
         out.l_start = b.ls; out.l_col = b.lc; out.l_val = b.lv;
         out.u_start = b.us; out.u_col = b.uc; out.u_val = b.uv;
         out.cap_l = out.cap_u = (int)std::min<size_t>(cap, (size_t)1 << 30);
-        if (inverted) throw std::logic_error("relp_lu_factor_device: the device inversion is not built into this library");
         // twice: the second run (warm caches, the kernel's code resident) is timed with HIP events -> info[31] in units of 0.1 us
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         RELP_HIP(hipEventCreate(&ev0));
@@ -284,6 +283,7 @@ int32_t relp_lu_factor_device(int32_t device, int32_t m, const int64_t* column_s
         launch_lu_factor(src, scratch.work(), out, pivot_threshold, reference_ties, dense_tail, nullptr);
         RELP_HIP(hipEventRecord(ev0, nullptr));
         launch_lu_factor(src, scratch.work(), out, pivot_threshold, reference_ties, dense_tail, nullptr);
+        if (inverted) launch_lu_invert(out, scratch.inverse_work(), scratch.work().info, nullptr);  // (timed with the factorisation)
         RELP_HIP(hipEventRecord(ev1, nullptr));
         RELP_HIP(hipDeviceSynchronize());
         float elapsed_ms = 0.0f;
@@ -312,13 +312,24 @@ int32_t relp_lu_factor_device(int32_t device, int32_t m, const int64_t* column_s
         const size_t nl = (size_t)h_info[inverted ? LUF_NNZ_LI : LUF_NNZ_L], nu = (size_t)h_info[inverted ? LUF_NNZ_UI : LUF_NNZ_U];
         get_i(b.rowpos, m, row_permutation);
         get_i(b.colpos, m, column_permutation);
-        get_i(b.ls, m + 1, lower_start);
-        get_i(b.lc, nl, lower_column);
-        get_d(b.lv, nl, lower_value);
-        get_i(b.us, m + 1, upper_start);
-        get_i(b.uc, nu, upper_column);
-        get_d(b.uv, nu, upper_value);
-        get_d(b.diag, m, upper_diagonal);
+        if (inverted) {  // L^-1 (strict) and U^-1 (with its diagonal) by rows; the diagonal array of this form is ones
+            const LuInverseWork& iw = scratch.inverse_work();
+            get_i(iw.csr_start[0], m + 1, lower_start);
+            get_i(iw.csr_idx[0], nl, lower_column);
+            get_d(iw.csr_val[0], nl, lower_value);
+            get_i(iw.csr_start[1], m + 1, upper_start);
+            get_i(iw.csr_idx[1], nu, upper_column);
+            get_d(iw.csr_val[1], nu, upper_value);
+            if (upper_diagonal) std::fill(upper_diagonal, upper_diagonal + m, 1.0);
+        } else {
+            get_i(b.ls, m + 1, lower_start);
+            get_i(b.lc, nl, lower_column);
+            get_d(b.lv, nl, lower_value);
+            get_i(b.us, m + 1, upper_start);
+            get_i(b.uc, nu, upper_column);
+            get_d(b.uv, nu, upper_value);
+            get_d(b.diag, m, upper_diagonal);
+        }
     });
 }
 

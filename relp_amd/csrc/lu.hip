@@ -449,7 +449,6 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     if (nl > cap_l_ || cap_l_ == 0) { cap_l_ = nl + nl / 2 + 256; layout_changed = true; }
     if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
     const size_t cl = cap_l_, cu = cap_u_;
-    const int ldt = max_updates + 1;
     // ---- host: the four orientations and their task lists -----------------------------------------------------------------
     static const bool time_parts = getenv("RELP_TIME_REFACTOR") != nullptr;
     thread_local double part_seconds[5] = {0, 0, 0, 0, 0};  // (diagnostic sums per calling thread: handles of a batch refactorise concurrently)
@@ -657,6 +656,55 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     nnz_u = factors.nnz_u();
     lu_depths(factors, &depth_l, &depth_u);
     return layout_changed;
+}
+
+// ---- the refactorisation as kernels --------------------------------------------------------------------------------------------
+bool LuFactors::prepare_device(int m, int max_updates, bool inverse_factors, size_t nnz_bound) {
+    if (max_updates < 1) max_updates = 1;
+    if (max_updates > LU_MAX_SLOTS) max_updates = LU_MAX_SLOTS;
+    const int inverse_vectors = inverse_factors ? lu_inverse_vectors(m, max_updates) : 0;
+    if (inverse_factors && inverse_vectors == 0) throw std::invalid_argument("the inverse-factor carry: too many rows for its vectors in LDS");
+    if (!inverse_factors) throw std::invalid_argument("the device refactorisation builds the inverse-factor form only");
+    if (m > 65535) throw std::invalid_argument("the device refactorisation: more than 65535 rows");
+    bool layout_changed = m != d_.m || max_updates != d_.max_updates || inverse_vectors != d_.inverse_factors;
+    if (layout_changed) cap_l_ = cap_u_ = cap_slots_ = 0;
+    // bounds instead of sizes: L + U of a simplex basis hold 1.0-1.5 x its entries (4 x here), the two inverted triangles 3-10 x
+    // those of L + U (lu_host.hpp) -- 6 x the bound here; what does not fit is reported by the kernels and redone by the host path
+    const size_t want_factor = 4 * nnz_bound + 8 * (size_t)m + 4096;
+    const size_t want_inverse = 6 * nnz_bound + 8 * (size_t)m + 4096;
+    const size_t want_slots = ((want_inverse / 2 + 2 * (size_t)m + 2048) + 1023) & ~size_t(1023);
+    if (want_factor > cap_l_) { cap_l_ = want_factor; layout_changed = true; }
+    if (want_factor > cap_u_) { cap_u_ = want_factor; layout_changed = true; }
+    if (want_slots > cap_slots_) { cap_slots_ = want_slots; layout_changed = true; }
+    const int stride = (int)cap_slots_;
+    const LuLayout lay = compute_layout(m, max_updates, inverse_factors, cap_l_, cap_u_, stride);
+    {
+        char* before = dev_;
+        reserve(lay.device_bytes, 0);
+        if (dev_ != before) layout_changed = true;
+    }
+    d_ = bind_layout(lay, dev_, m, max_updates, inverse_vectors, stride);
+    scratch_.reserve(m, nnz_bound, cap_l_, cap_u_, want_inverse);
+    device_prepared_ = true;
+    return layout_changed;
+}
+
+void LuFactors::refactor_device(const LuFactorSource& src, double threshold, int reference_ties, int dense_tail, Ctl* ctl, int failed_status,
+                                hipStream_t stream) {
+    if (!device_prepared_) throw std::logic_error("LuFactors::refactor_device before prepare_device");
+    LuFactorOut out;
+    out.rowpos = d_.rowpos; out.colpos = d_.colpos; out.diag = d_.diag;
+    out.l_start = d_.l_rstart; out.l_col = d_.l_rcol; out.l_val = d_.l_rval;
+    out.u_start = d_.u_rstart; out.u_col = d_.u_rcol; out.u_val = d_.u_rval;
+    out.cap_l = (int)std::min<size_t>(cap_l_, (size_t)1 << 30);
+    out.cap_u = (int)std::min<size_t>(cap_u_, (size_t)1 << 30);
+    launch_lu_factor(src, scratch_.work(), out, threshold, reference_ties, dense_tail, stream);
+    LuInverseWork iw = scratch_.inverse_work();
+    iw.cap_extra_l = out.cap_l;
+    iw.cap_extra_u = out.cap_u;
+    launch_lu_invert(out, iw, scratch_.work().info, stream);
+    launch_lu_pack_inverse(d_, iw, ctl, failed_status, stream);
+    hipLaunchKernelGGL(lu_init_kernel, dim3((d_.m + 255) / 256), dim3(256), 0, stream, d_);
 }
 
 // LDS of the solve kernels: the two vectors (16 bytes per row), the mask of the replaced positions, one count per 64 rows for

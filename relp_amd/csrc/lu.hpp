@@ -26,6 +26,7 @@
 
 #include <vector>
 
+#include "lu_factor.hpp"
 #include "lu_host.hpp"
 
 namespace relp {
@@ -140,6 +141,15 @@ public:
     // uploads the factors and resets the update state; stream-ordered.  Returns true when the device layout (the addresses
     // in device()) changed: it depends on capacities only, so a refactorisation normally keeps it.
     bool upload(const HostLU& f, int max_updates, hipStream_t stream, bool inverse_factors = false);
+    // The refactorisation as kernels (lu_factor.hip, lu_device_tasks.hip).  prepare_device sizes every array by BOUNDS (the factors
+    // do not exist on the host): `nnz_bound` = entries a basis can have.  Returns true when the device layout changed.
+    bool prepare_device(int m, int max_updates, bool inverse_factors, size_t nnz_bound);
+    // Enqueues factorisation -> (inverse-factor form: inversion of the triangles, compact records) -> reset of the update state.
+    // A failure leaves `failed_status` in *ctl (the pivots enqueued behind become no-ops) and its code in the info words.
+    void refactor_device(const LuFactorSource& src, double threshold, int reference_ties, int dense_tail, Ctl* ctl, int failed_status,
+                         hipStream_t stream);
+    bool device_prepared() const { return device_prepared_; }
+    const int* device_info() const { return scratch_.work().info; }  // LUF_* words of the last device refactorisation
     const DeviceLU& device() const { return d_; }
     size_t lds_bytes(int nrhs) const;  // dynamic LDS of the solve kernels for this m
     long long nnz_l = 0, nnz_u = 0;
@@ -154,6 +164,8 @@ private:
     char* staging_ = nullptr;
     size_t staging_capacity_ = 0;
     size_t cap_l_ = 0, cap_u_ = 0, cap_slots_ = 0;
+    LuFactorScratch scratch_;
+    bool device_prepared_ = false;
 };
 
 // kernels (lu.hip); all single-workgroup, stream-ordered

@@ -226,6 +226,8 @@ void Solver::upload() {
     if (lu_mode_ && !lu_inverse_) {
         if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its two solve vectors in LDS (16 bytes per row): at most about 8000 rows with this refactor period (use the explicit carry beyond)");
     }
+    // `BasisInverse::invert` as kernels (the inverse-factor form; relp_options.refactor_on_host / RELP_REFACTOR_HOST=1: one host core)
+    device_refactor_ = lu_inverse_ && opt_.refactor_on_host == 0 && !(getenv("RELP_REFACTOR_HOST") && atoi(getenv("RELP_REFACTOR_HOST")) != 0) && m <= 65535;
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
     // structural columns); steepest edge only (the dense kernel implements that rule)
     int n_dense = 0;
@@ -554,6 +556,23 @@ Ctl Solver::read_ctl() {
     Ctl c;
     RELP_HIP(hipMemcpyAsync(&c, d_.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
+    if (c.status == ST_REFACTOR_FAILED) {
+        // the refactorisation kernels gave up (a capacity, a row too long for the eliminating wave): nothing has pivoted since, the
+        // basis on the device is the one they were given -- factorise it on the host (which also grows what was too small)
+        ++device_refactor_failures_;
+        if (opt_.verbose > 0) {
+            int info[LUF_INFO_WORDS];
+            RELP_HIP(hipMemcpy(info, lu_.device_info(), sizeof(info), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[lu] the device refactorisation gave up with status %d (m %d): host fallback\n", info[LUF_STATUS], d_.m);
+        }
+        c.status = ST_REFACTOR;
+        RELP_HIP(hipMemcpyAsync(d_.ctl, &c, sizeof(Ctl), hipMemcpyHostToDevice, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+        refactor_lu_host(true);
+        refactors_--;  // (counted once, by the attempt on the device)
+        RELP_HIP(hipMemcpyAsync(&c, d_.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+    }
     return c;
 }
 void Solver::write_ctl(const Ctl& c) {
@@ -1485,12 +1504,41 @@ void Solver::lu_identity() {
     f.l_start.assign(m + 1, 0);
     f.u_start.assign(m + 1, 0);
     f.diag.assign(m, 1.0);
+    // (device refactorisation: every array sized by bounds first, so that the layout -- and the captured graphs -- stay put)
+    if (device_refactor_ && lu_.prepare_device(m, refactor_period_ + 1, true, (size_t)h_col_start_.back())) destroy_graphs();
     if (lu_.upload(f, refactor_period_ + 1, stream_, lu_inverse_)) destroy_graphs();  // the captured batches hold the old addresses
 }
 // `BasisInverse::invert(basis columns)` (lower_upper/mod.rs:78-92; called by `Carry::change_basis` when `should_refactor`,
 // carry/mod.rs:584-591): Markowitz factorisation of the current basis on the host, one upload, and -- `refresh_vectors` -- x_B,
 // -pi and the objective recomputed from the fresh factors (what the explicit carry's polish does too).
 void Solver::refactor_lu(bool refresh_vectors) {
+    if (!device_refactor_) {
+        refactor_lu_host(refresh_vectors);
+        return;
+    }
+    // Round 4: factorisation, inversion of the two triangles and the slot records are kernels on this handle's stream -- no basis
+    // read-back, no upload, the host only enqueues (its time below is launch overhead).  What the kernels cannot take comes back
+    // as ST_REFACTOR_FAILED at the next read of the control block (read_ctl: host fallback).
+    const double t0 = now_seconds();
+    LuFactorSource src;
+    src.col_start = d_.col_start;
+    src.row_index = d_.row_index;
+    src.value = d_.value;
+    src.basis = d_.basis;
+    src.flipped = bounded_ ? d_.flipped : nullptr;
+    const double threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
+    lu_.refactor_device(src, threshold, 0, 32, d_.ctl, ST_REFACTOR_FAILED, stream_);
+    binv_identity_ = false;
+    if (refresh_vectors) {
+        launch_lu_xb(d_, lu_.device(), stream_);
+        launch_lu_pi(d_, lu_.device(), stream_);
+    }
+    launch_clear_refactor_status(d_, stream_);
+    refactors_++;
+    since_polish_ = 0;
+    refactor_seconds_ += now_seconds() - t0;
+}
+void Solver::refactor_lu_host(bool refresh_vectors) {
     const double t0 = now_seconds();
     const int m = d_.m;
     std::vector<int> basis(m);

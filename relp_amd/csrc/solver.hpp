@@ -74,7 +74,8 @@ struct Ctl {
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
 
-enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3, ST_REFACTOR = 4 };  // 4: LU carry, the host has to refactorise
+enum : int { ST_RUNNING = 0, ST_NO_ENTERING = 1, ST_UNBOUNDED = 2, ST_BUDGET = 3, ST_REFACTOR = 4, ST_REFACTOR_FAILED = 5 };  // 4: LU carry, refactorise now;
+// 5: the refactorisation kernels gave up (a capacity, a row too long for the eliminating wave): the pivots behind them are no-ops, the host factorises
 
 struct DeviceLP {
     int m = 0, n = 0, n_art = 0, ld = 0;
@@ -244,7 +245,10 @@ private:
     void certify(relp_result* result);
     CertifyScratch certify_scratch_;
     // LU carry (relp_options.carry == RELP_CARRY_LU)
-    void refactor_lu(bool refresh_vectors);  // BasisInverse::invert of the current basis (host Markowitz + upload)
+    void refactor_lu(bool refresh_vectors);  // BasisInverse::invert of the current basis: kernels on the device (lu_factor.hip), or ...
+    void refactor_lu_host(bool refresh_vectors);  // ... host Markowitz + upload (relp_options.refactor_on_host; carry LU + Forrest-Tomlin; the fallback)
+    bool device_refactor_ = false;
+    long long device_refactor_failures_ = 0;
     void lu_identity();                      // BasisInverse::identity
     LuFactors lu_;
     bool lu_mode_ = false;

@@ -146,3 +146,62 @@ def test_device_factorises_real_bases(name, fraction):
           "reset %d | dense tail %d | finalisation %d" % tuple(16 * v // 1000 for v in f["info"][12:23]))
     assert fill_device <= 1.35 * fill_host + 64
     assert f["info"][3] <= max(8, m // 8)
+
+
+def dense_triangles(f, m):
+    L, U = np.eye(m), np.diag(np.array(f["diag"], dtype=float))
+    for i, row in enumerate(f["lower_rows"]):
+        for j, v in row:
+            L[i, j] = v
+    for i, row in enumerate(f["upper_rows"]):
+        for j, v in row:
+            U[i, j] = v
+    return L, U
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_device_inverts_both_triangles(seed):
+    """`lu_invert_kernel` (lu_device_tasks.hip): the strict part of L^-1 and U^-1 with its diagonal, rows sorted by column, from the
+    factors the factorisation kernel left on the device -- products with those factors are the identity; small matrices take the
+    LDS accumulators, m = 1200 the global ones."""
+    rng = random.Random(5200 + seed)
+    m = rng.choice([1, 2, 7, 40, 150, 400, 1200])
+    A = random_sparse(rng, m, (3.0 if m < 500 else 1.5) / m)
+    columns = columns_of_dense(A)
+    f = lu_factor_device(columns)
+    inv = lu_factor_device(columns, inverted=True)
+    assert inv["rowpos"] == f["rowpos"] and inv["colpos"] == f["colpos"] and inv["diag"] == [1.0] * m
+    L, U = dense_triangles(f, m)
+    Li, Ui = np.eye(m), np.zeros((m, m))
+    for i, row in enumerate(inv["lower_rows"]):
+        assert [j for j, _ in row] == sorted(j for j, _ in row) and all(j < i for j, _ in row)
+        for j, v in row:
+            Li[i, j] = v
+    for i, row in enumerate(inv["upper_rows"]):
+        assert [j for j, _ in row] == sorted(j for j, _ in row) and all(j >= i for j, _ in row) and row[0][0] == i
+        for j, v in row:
+            Ui[i, j] = v
+    scale = max(1.0, np.abs(Li).max(), np.abs(Ui).max())
+    assert np.allclose(Li @ L, np.eye(m), atol=1e-9 * scale) and np.allclose(Ui @ U, np.eye(m), atol=1e-9 * scale)
+    assert inv["info"][7] == sum(len(r) for r in inv["lower_rows"]) and inv["info"][8] == sum(len(r) for r in inv["upper_rows"])
+    again = lu_factor_device(columns, inverted=True)
+    assert again["lower_rows"] == inv["lower_rows"] and again["upper_rows"] == inv["upper_rows"]
+
+
+@pytest.mark.parametrize("name,fraction", [("25FV47", 1.0), ("GREENBEA", 0.5)])
+def test_device_inverts_the_triangles_of_real_bases(name, fraction):
+    columns = basis_columns(name, fraction)
+    m = len(columns)
+    f = lu_factor_device(columns)
+    inv = lu_factor_device(columns, inverted=True)
+    L, U = dense_triangles(f, m)
+    Li, Ui = np.eye(m), np.zeros((m, m))
+    for i, row in enumerate(inv["lower_rows"]):
+        for j, v in row:
+            Li[i, j] = v
+    for i, row in enumerate(inv["upper_rows"]):
+        for j, v in row:
+            Ui[i, j] = v
+    assert np.abs(Li @ L - np.eye(m)).max() < 1e-7 and np.abs(Ui @ U - np.eye(m)).max() < 1e-7
+    print("%s at %.0f %%: nnz(L) + nnz(U) + m %d -> nnz(L^-1) + nnz(U^-1) %d, factorisation + inversion %.1f us" % (
+        name, 100 * fraction, f["nnz_lower"] + f["nnz_upper"] + m, inv["info"][7] + inv["info"][8], inv["info"][31] / 10.0))
