@@ -74,14 +74,17 @@ __device__ __forceinline__ int t_group_log2(int n) {  // smallest g with 4 << g 
     while (g < 6 && (LU_TE << g) < n) ++g;
     return g;
 }
-__device__ __forceinline__ int load_acquire_wg(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void store_release_wg(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// a finished row's descriptor: (length + 1) << 32 | first entry in the raw arena; 0: not finished yet
+__device__ __forceinline__ unsigned long long load_acquire_wg(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void store_release_wg(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned long long row_descriptor(int start, int len) { return ((unsigned long long)(unsigned)(len + 1) << 32) | (unsigned)start; }
 
 // One row of an inverse by one wave.  `src_*`: the entries (j, f_ij) of row i of the factor; `UPPER`: row of U^-1 (starts from e_i,
 // scaled by 1 / u_ii at the end, the rows it reads carry their diagonal) or of L^-1 (strict part: the rows it reads have an implied 1).
 template <bool ACC_LDS, bool UPPER>
 __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i, const int* src_col, const double* src_val, const int s, const int e,
-                           const double scale, volatile lds_f64_t* acc_lds, double* acc_glb, volatile lds_u64_t* bits, const int words) {
+                           const double scale, volatile lds_f64_t* acc_lds, double* acc_glb, volatile lds_u64_t* bits, const int words,
+                           const int arena_first) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int f = UPPER ? 1 : 0;
     auto add = [&](int c, double delta) {  // (the lanes of one step hold distinct columns)
@@ -97,8 +100,10 @@ __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i,
         if (x0 + lane < e) {
             j = src_col[x0 + lane];
             fij = src_val[x0 + lane];
-            while ((nj = load_acquire_wg(&iw.raw_len[f][j])) < 0) __builtin_amdgcn_s_sleep(2);
-            sj = iw.raw_start[f][j];
+            unsigned long long d;
+            while ((d = load_acquire_wg(&iw.raw_desc[f][j])) == 0ull) __builtin_amdgcn_s_sleep(1);
+            nj = (int)(d >> 32) - 1;
+            sj = (int)(unsigned)d;
         }
         const int cnt = min(WAVE, e - x0);
         for (int y = 0; y < cnt; ++y) {
@@ -121,9 +126,9 @@ __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i,
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) total += __shfl_xor(total, d, WAVE);
     int at = 0;
-    if (lane == 0) at = atomicAdd(&sh.cursor, total);
+    if (lane == 0) at = arena_first + atomicAdd(&sh.cursor, total);
     at = __shfl(at, 0, WAVE);
-    if (at + total > iw.raw_cap) {
+    if (at + total > arena_first + iw.raw_cap / 2) {
         if (lane == 0) sh.error = LUF_ERR_INVERSE_CAPACITY;
         total = 0;
     }
@@ -158,11 +163,13 @@ __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i,
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane's stores have left before the length is published
     if (lane == 0) {
+        iw.raw_len[f][i] = total;
         iw.raw_start[f][i] = at;
-        store_release_wg(&iw.raw_len[f][i], total);
+        store_release_wg(&iw.raw_desc[f][i], row_descriptor(at, total));
     }
 }
 
+// Two workgroups: block 0 inverts L, block 1 inverts U (independent; each has its own half of the raw arena and its own waves).
 template <bool ACC_LDS>
 __global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac, LuInverseWork iw, const int* status_in) {
     extern __shared__ unsigned char dyn_lds[];
@@ -171,9 +178,11 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac,
     const int lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int m = iw.m;
     const int words = (m + 63) / 64;
+    const int f = blockIdx.x;  // 0: L^-1, 1: U^-1
     if (status_in && status_in[LUF_STATUS] != LUF_OK) return;  // the factorisation failed: nothing to invert (the host falls back)
     volatile lds_u64_t* bits_all = (volatile lds_u64_t*)dyn_lds;
     volatile lds_f64_t* acc_all = (volatile lds_f64_t*)(dyn_lds + (size_t)LUT_WAVES * words * sizeof(unsigned long long));
+    double* acc_block = iw.acc + (size_t)f * LUT_WAVES * m;
     if (tid == 0) {
         sh.cursor = 0;
         sh.error = LUF_OK;
@@ -182,31 +191,34 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac,
     if (ACC_LDS)
         for (int x = tid; x < LUT_WAVES * m; x += T) acc_all[x] = 0.0;
     else
-        for (int x = tid; x < LUT_WAVES * m; x += T) iw.acc[x] = 0.0;
-    for (int i = tid; i < m; i += T) {
-        iw.raw_len[0][i] = -1;
-        iw.raw_len[1][i] = -1;
-    }
+        for (int x = tid; x < LUT_WAVES * m; x += T) acc_block[x] = 0.0;
+    for (int i = tid; i < m; i += T) iw.raw_desc[f][i] = 0ull;
     __syncthreads();
     volatile lds_u64_t* bits = bits_all + (size_t)wave * words;
     volatile lds_f64_t* acc_lds = acc_all + (size_t)wave * m;
-    double* acc_glb = iw.acc + (size_t)wave * m;
-    for (int i = wave; i < m; i += LUT_WAVES) {  // L^-1, ascending
-        const int s = fac.l_start[i], e = fac.l_start[i + 1];
-        if (s == e) {
-            if (lane == 0) {
-                iw.raw_start[0][i] = 0;
-                store_release_wg(&iw.raw_len[0][i], 0);
+    double* acc_glb = acc_block + (size_t)wave * m;
+    const int arena_first = f * (iw.raw_cap / 2);
+    if (f == 0) {
+        for (int i = wave; i < m; i += LUT_WAVES) {  // L^-1, ascending
+            const int s = fac.l_start[i], e = fac.l_start[i + 1];
+            if (s == e) {
+                if (lane == 0) {
+                    iw.raw_len[0][i] = 0;
+                    iw.raw_start[0][i] = arena_first;
+                    store_release_wg(&iw.raw_desc[0][i], row_descriptor(arena_first, 0));
+                }
+                continue;
             }
-            continue;
+            invert_row<ACC_LDS, false>(iw, sh, i, fac.l_col, fac.l_val, s, e, 1.0, acc_lds, acc_glb, bits, words, arena_first);
         }
-        invert_row<ACC_LDS, false>(iw, sh, i, fac.l_col, fac.l_val, s, e, 1.0, acc_lds, acc_glb, bits, words);
+    } else {
+        for (int i = m - 1 - wave; i >= 0; i -= LUT_WAVES)  // U^-1, descending
+            invert_row<ACC_LDS, true>(iw, sh, i, fac.u_col, fac.u_val, fac.u_start[i], fac.u_start[i + 1], 1.0 / fac.diag[i], acc_lds, acc_glb, bits, words,
+                                      arena_first);
     }
-    for (int i = m - 1 - wave; i >= 0; i -= LUT_WAVES)  // U^-1, descending
-        invert_row<ACC_LDS, true>(iw, sh, i, fac.u_col, fac.u_val, fac.u_start[i], fac.u_start[i + 1], 1.0 / fac.diag[i], acc_lds, acc_glb, bits, words);
     __syncthreads();
-    // ---- the two inverses by rows, compact, in row order (rows are already sorted by column) ----------------------------------
-    for (int f = 0; f < 2; ++f) {
+    // ---- this inverse by rows, compact, in row order (rows are already sorted by column) ----------------------------------------
+    {
         unsigned long long carry = 0;
         for (int base = 0; base < m; base += T) {
             const int i = base + tid;
@@ -470,8 +482,8 @@ void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_invert_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_invert_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     });
-    if (in_lds) hipLaunchKernelGGL(lu_invert_kernel<true>, dim3(1), dim3(LUT_THREADS), lds, stream, factors, iw, status_in);
-    else hipLaunchKernelGGL(lu_invert_kernel<false>, dim3(1), dim3(LUT_THREADS), lds, stream, factors, iw, status_in);
+    if (in_lds) hipLaunchKernelGGL(lu_invert_kernel<true>, dim3(2), dim3(LUT_THREADS), lds, stream, factors, iw, status_in);
+    else hipLaunchKernelGGL(lu_invert_kernel<false>, dim3(2), dim3(LUT_THREADS), lds, stream, factors, iw, status_in);
 }
 
 void launch_lu_pack_inverse(const DeviceLU& lu, const LuInverseWork& iw, Ctl* ctl, int failed_status, hipStream_t stream) {

@@ -3,6 +3,7 @@
 #include "lu_factor.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -43,7 +44,7 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
         o_active[b] = take(mi);
     }
     const size_t o_rstart = take(mi), o_rlen = take(mi), o_rnew = take(mi), o_growth = take(mi), o_targets = take(mi), o_ccount = take(mi);
-    const size_t o_rmax = take((size_t)m * sizeof(unsigned long long));
+    const size_t o_rmax = take((size_t)m * sizeof(unsigned long long)), o_rmaxd = take((size_t)m * sizeof(double));
     const size_t o_rowbest = take(mi), o_beste = take(mi), o_colmark = take(mi), o_kill = take(mi), o_tflag = take(mi);
     const size_t o_pkr = take(mi), o_pkc = take(mi);
     const size_t o_utstart = take(mi + sizeof(int));
@@ -57,12 +58,13 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     // the inversion of the two triangles and the record packing (lu_device_tasks.hip)
     const size_t ci = cap_inv_;
     const size_t o_rawcol = take(2 * ci * sizeof(int)), o_rawval = take(2 * ci * sizeof(double));
-    size_t o_rawstart[2], o_rawlen[2], o_cstart[4], o_cidx[4], o_cval[4];
+    size_t o_rawstart[2], o_rawlen[2], o_rawdesc[2], o_cstart[4], o_cidx[4], o_cval[4];
     for (int f = 0; f < 2; ++f) {
         o_rawstart[f] = take(mi);
         o_rawlen[f] = take(mi);
+        o_rawdesc[f] = take((size_t)m * sizeof(unsigned long long));
     }
-    const size_t o_acc = take(ci ? (size_t)16 * m * sizeof(double) : 0);
+    const size_t o_acc = take(ci ? (size_t)2 * 16 * m * sizeof(double) : 0);
     for (int k = 0; k < 4; ++k) {
         o_cstart[k] = take(mi + sizeof(int));
         o_cidx[k] = take(ci * sizeof(int));
@@ -89,6 +91,7 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     w.r_start = I(o_rstart); w.r_len = I(o_rlen); w.r_newstart = I(o_rnew); w.growth = I(o_growth); w.targets = I(o_targets);
     w.ccount = I(o_ccount);
     w.rmax = reinterpret_cast<unsigned long long*>(dev_ + o_rmax);
+    w.rmaxd = D(o_rmaxd);
     w.rowbest = reinterpret_cast<unsigned*>(dev_ + o_rowbest);
     w.best_e = I(o_beste);
     w.colmark = reinterpret_cast<unsigned*>(dev_ + o_colmark);
@@ -110,6 +113,7 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     for (int f = 0; f < 2; ++f) {
         iw.raw_start[f] = I(o_rawstart[f]);
         iw.raw_len[f] = I(o_rawlen[f]);
+        iw.raw_desc[f] = reinterpret_cast<unsigned long long*>(dev_ + o_rawdesc[f]);
     }
     iw.acc = D(o_acc);
     for (int k = 0; k < 4; ++k) {
@@ -185,7 +189,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {  // set bi
 
 __device__ __forceinline__ unsigned candidate_key(const LuFactorWork& w, int r, int c, double v, double threshold) {
     const int cnt = w.ccount[c];
-    const double rmax = __longlong_as_double((long long)w.rmax[r]);
+    const double rmax = w.rmaxd[r];
     const double mag = fabs(v);
     if (!(cnt == 1 || mag >= threshold * rmax)) return NONE32;  // (a column singleton needs no elimination: any non-zero is stable)
     long long score = (long long)(w.r_len[r] - 1) * (long long)(cnt - 1);
@@ -198,12 +202,12 @@ __device__ __forceinline__ unsigned priority_of(unsigned key, int row) { return 
 
 // Row `r` of the active sub-matrix minus its multiples of the pivot rows of this round, by one wave: the row in registers
 // (LUF_ROW_SLOTS entries per lane), a pivot row's entries broadcast one at a time.  Writes the new row compactly to the other arena.
-__device__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuFactorOut& out, const int r, const int cur, const bool exact_mode) {
+__device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuFactorOut& out, const int r, const int cur, const bool exact_mode) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int s0 = w.r_start[r];
     int len = w.r_len[r];
-    const int* __restrict__ acol = w.a_col[cur];
-    const double* __restrict__ aval = w.a_val[cur];
+    const int* __restrict__ acol = (cur ? w.a_col[1] : w.a_col[0]);
+    const double* __restrict__ aval = (cur ? w.a_val[1] : w.a_val[0]);
     int col[LUF_ROW_SLOTS], pk[LUF_ROW_SLOTS];
     double val[LUF_ROW_SLOTS];
 #pragma unroll
@@ -293,9 +297,9 @@ __device__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuF
     // the new row, holes squeezed out, into the other arena; its largest magnitude for the next rounds' threshold test
     const int d0 = w.r_newstart[r];
     const int capacity = max(0, w.r_len[r] + w.growth[r]);
-    int* __restrict__ ncol = w.a_col[cur ^ 1];
-    int* __restrict__ nrow = w.a_row[cur ^ 1];
-    double* __restrict__ nval = w.a_val[cur ^ 1];
+    int* __restrict__ ncol = (cur ? w.a_col[0] : w.a_col[1]);
+    int* __restrict__ nrow = (cur ? w.a_row[0] : w.a_row[1]);
+    double* __restrict__ nval = (cur ? w.a_val[0] : w.a_val[1]);
     int written = 0;
     double biggest = 0.0;
 #pragma unroll
@@ -319,7 +323,7 @@ __device__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuF
         if (written == 0) sh.error = LUF_ERR_SINGULAR;
         if (written > capacity) sh.error = LUF_ERR_ARENA;  // (cannot happen: the capacity is the bound old - pivots + sum of the pivot rows)
         w.r_len[r] = written;
-        w.rmax[r] = (unsigned long long)__double_as_longlong(biggest);
+        w.rmaxd[r] = biggest;
     }
 }
 
@@ -333,9 +337,43 @@ __device__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuF
         }                                                              \
     } while (0)
 
-__global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource src, LuFactorWork w, LuFactorOut out, double threshold,
+// `lds_level`: which of the per-row work arrays live in LDS instead of global memory (2: all of them, m <= ~1900; 1: the ones the
+// entry passes gather from, m <= ~3500; 0: none).  The kernel reaches them through generic pointers either way: a round is a chain of
+// dependent gathers and atomics on these arrays, ~150 cycles each out of LDS against ~800 through L2.
+template <int lds_level>
+__global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource src, LuFactorWork w_in, LuFactorOut out, double threshold,
                                                                 int reference_ties, int dense_tail) {
+    extern __shared__ unsigned char luf_dynamic_lds[];
     __shared__ FactorShared sh;
+    LuFactorWork w = w_in;
+    if constexpr (lds_level >= 1) {
+        unsigned char* at = luf_dynamic_lds;
+        auto carve = [&](size_t bytes) {
+            unsigned char* p = at;
+            at += (bytes + 7) & ~size_t(7);
+            return p;
+        };
+        const size_t mi = (size_t)w.m * sizeof(int);
+        w.rmaxd = (double*)carve((size_t)w.m * sizeof(double));
+        w.ccount = (int*)carve(mi);
+        w.rowbest = (unsigned*)carve(mi);
+        w.colmark = (unsigned*)carve(mi);
+        w.kill = (int*)carve(mi);
+        w.tflag = (int*)carve(mi);
+        w.growth = (int*)carve(mi);
+        w.r_len = (int*)carve(mi);
+        w.pivk_col = (int*)carve(mi);
+        if constexpr (lds_level >= 2) {
+            w.r_start = (int*)carve(mi);
+            w.r_newstart = (int*)carve(mi);
+            w.targets = (int*)carve(mi);
+            w.best_e = (int*)carve(mi);
+            w.pivk_row = (int*)carve(mi);
+            w.active[0] = (int*)carve(mi);
+            w.active[1] = (int*)carve(mi);
+            w.ut_start = (int*)carve(mi + sizeof(int));
+        }
+    }
     __shared__ double dense[LUF_DENSE_MAX][LUF_DENSE_MAX + 1];
     __shared__ int dense_cols[LUF_DENSE_MAX];
     const int tid = threadIdx.x, T = LUF_THREADS;
@@ -425,16 +463,18 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         }
     }
     __syncthreads();
+    for (int i = tid; i < m; i += T) w.rmaxd[i] = __longlong_as_double((long long)w.rmax[i]);
+    __syncthreads();
     LUF_STAMP(0);
 
     // ---- rounds ----------------------------------------------------------------------------------------------------------------
     while (sh.error == LUF_OK && sh.n_active > 0) {
         const int n_active = sh.n_active, cur = sh.cur, top = sh.top, kbase = sh.kbase, ubase = sh.ubase;
         if (!ref && n_active <= dense_tail) break;  // the rest goes through the dense tail
-        const int* __restrict__ act = w.active[cur];
-        const int* __restrict__ acol = w.a_col[cur];
-        const int* __restrict__ arow = w.a_row[cur];
-        const double* __restrict__ aval = w.a_val[cur];
+        const int* __restrict__ act = (cur ? w.active[1] : w.active[0]);
+        const int* __restrict__ acol = (cur ? w.a_col[1] : w.a_col[0]);
+        const int* __restrict__ arow = (cur ? w.a_row[1] : w.a_row[0]);
+        const double* __restrict__ aval = (cur ? w.a_val[1] : w.a_val[0]);
         if (tid == 0) {
             sh.smin = 0x7fffffff;
             sh.best64 = NONE64;
@@ -612,7 +652,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         // (7) layout of the next arena: the remaining rows in order, a target row with room for its fill-in
         {
             unsigned long long carry = 0;
-            int* __restrict__ act_new = w.active[cur ^ 1];
+            int* __restrict__ act_new = (cur ? w.active[0] : w.active[1]);
             for (int base = 0; base < n_active; base += T) {
                 const int t = base + tid;
                 int i = -1;
@@ -648,9 +688,9 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         LUF_STAMP(6);
         // (8) the untouched rows are copied, the targets eliminated (decomposition/mod.rs:71-100,146-210) -- into the other arena
         {
-            int* __restrict__ ncol = w.a_col[cur ^ 1];
-            int* __restrict__ nrow = w.a_row[cur ^ 1];
-            double* __restrict__ nval = w.a_val[cur ^ 1];
+            int* __restrict__ ncol = (cur ? w.a_col[0] : w.a_col[1]);
+            int* __restrict__ nrow = (cur ? w.a_row[0] : w.a_row[1]);
+            double* __restrict__ nval = (cur ? w.a_val[0] : w.a_val[1]);
             for (int e = tid; e < top; e += T) {
                 const int c = acol[e];
                 if (c < 0) continue;
@@ -669,7 +709,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         // (9) the next round's state
         {
             const int n_new = sh.n_active_new;
-            const int* __restrict__ act_new = w.active[cur ^ 1];
+            const int* __restrict__ act_new = (cur ? w.active[0] : w.active[1]);
             for (int t = tid; t < n_new; t += T) {
                 const int i = act_new[t];
                 w.r_start[i] = w.r_newstart[i];
@@ -698,7 +738,7 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
     // ---- dense tail: the last rows by partial pivoting out of LDS, one wave ------------------------------------------------------
     if (sh.error == LUF_OK && sh.n_active > 0) {
         const int n = sh.n_active, cur = sh.cur, top = sh.top, kbase = sh.kbase;
-        const int* __restrict__ act = w.active[cur];
+        const int* __restrict__ act = (cur ? w.active[1] : w.active[0]);
         // local column numbers: the unpivoted columns in ascending order (ordered compaction over all columns)
         {
             unsigned long long carry = 0;
@@ -720,9 +760,9 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         __syncthreads();
         if (sh.error == LUF_OK) {
             for (int e = tid; e < top; e += T) {
-                const int c = w.a_col[cur][e];
+                const int c = (cur ? w.a_col[1] : w.a_col[0])[e];
                 if (c < 0) continue;
-                dense[w.tflag[w.a_row[cur][e]]][w.growth[c]] = w.a_val[cur][e];
+                dense[w.tflag[(cur ? w.a_row[1] : w.a_row[0])[e]]][w.growth[c]] = (cur ? w.a_val[1] : w.a_val[0])[e];
             }
         }
         __syncthreads();
@@ -875,7 +915,20 @@ void launch_lu_factor(const LuFactorSource& src, const LuFactorWork& w, const Lu
     LuFactorWork ww = w;
     ww.cap_l = o.cap_l;
     ww.cap_u = o.cap_u;
-    hipLaunchKernelGGL(lu_factor_kernel, dim3(1), dim3(LUF_THREADS), 0, stream, src, ww, o, threshold, reference_ties, dense_tail);
+    static PerDeviceOnce once;
+    once.run([] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_factor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_factor_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    });
+    const size_t m8 = ((size_t)w.m * sizeof(int) + 7) & ~size_t(7);
+    const size_t level1 = (size_t)w.m * sizeof(double) + 8 * m8, level2 = level1 + 7 * m8 + m8 + 8;
+    static const int forced = getenv("RELP_LUF_LDS") ? atoi(getenv("RELP_LUF_LDS")) : -1;  // diagnostic: 0 keeps every work array in global memory
+    int lds_level = level2 <= (size_t)140 * 1024 ? 2 : level1 <= (size_t)140 * 1024 ? 1 : 0;
+    if (forced >= 0) lds_level = std::min(lds_level, forced);
+    const size_t lds = lds_level == 2 ? level2 : lds_level == 1 ? level1 : 0;
+    if (lds_level == 2) hipLaunchKernelGGL(lu_factor_kernel<2>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail);
+    else if (lds_level == 1) hipLaunchKernelGGL(lu_factor_kernel<1>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail);
+    else hipLaunchKernelGGL(lu_factor_kernel<0>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail);
 }
 
 }  // namespace relp

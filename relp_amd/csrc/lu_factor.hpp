@@ -74,7 +74,7 @@ enum : int {
 constexpr int LUF_THREADS = 1024;
 constexpr int LUF_ROW_SLOTS = 4;                  // register entries per lane of the eliminating wave
 constexpr int LUF_MAX_ROW = 64 * LUF_ROW_SLOTS;   // longest row the elimination takes
-constexpr int LUF_DENSE_MAX = 64;                 // the dense tail: one lane per row
+constexpr int LUF_DENSE_MAX = 32;                 // the dense tail: one lane per row (its matrix sits in static LDS)
 
 // Work memory of one factorisation (device pointers; LuFactorScratch owns them).
 struct LuFactorWork {
@@ -90,7 +90,8 @@ struct LuFactorWork {
     int* active[2] = {nullptr, nullptr};  // [m] the rows not yet pivoted, ascending
     int* targets = nullptr;        // [m]
     int* ccount = nullptr;         // [m] active entries per column
-    unsigned long long* rmax = nullptr;   // [m] bits of the largest magnitude of the row
+    unsigned long long* rmax = nullptr;   // [m] bits of the largest magnitude of the row (atomic max while the basis is loaded)
+    double* rmaxd = nullptr;       // [m] ... and as a double from then on
     unsigned* rowbest = nullptr;   // [m] best candidate of the row: score << 20 | magnitude rank << 16 | column
     int* best_e = nullptr;         // [m] arena index of that entry
     unsigned* colmark = nullptr;   // [m] the best candidate that wants the column: score << 16 | row
@@ -134,8 +135,9 @@ struct LuInverseWork {
     int cap = 0;                       // entries per inverse and orientation
     int* raw_col = nullptr; double* raw_val = nullptr; int raw_cap = 0;   // rows of both inverses as they are finished
     int* raw_start[2] = {nullptr, nullptr};
-    int* raw_len[2] = {nullptr, nullptr};     // -1: the row is not finished yet (the dataflow's flags)
-    double* acc = nullptr;             // [16][m] accumulators of the waves when they do not fit the LDS
+    int* raw_len[2] = {nullptr, nullptr};
+    unsigned long long* raw_desc[2] = {nullptr, nullptr};   // (length + 1) << 32 | start of a finished row, 0: not finished (the dataflow's flags)
+    double* acc = nullptr;             // [2][16][m] accumulators of the waves when they do not fit the LDS
     // canonical: 0 L^-1 by rows (strict), 1 U^-1 by rows (with diagonal), 2 U^-1 by columns, 3 L^-1 by columns; m + 1 starts each
     int* csr_start[4] = {nullptr, nullptr, nullptr, nullptr};
     int* csr_idx[4] = {nullptr, nullptr, nullptr, nullptr};
