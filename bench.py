@@ -138,7 +138,7 @@ def compact_line(line, detail_name):
                                              "iterations": tuned.get("iterations"), "cores": 1,
                                              "gpu_seconds_to_exact_optimum": gpu_seconds,
                                              "cpu_over_gpu": tuned["seconds"] / gpu_seconds if gpu_seconds else None}
-    for key in ("value_lu_carry", "value_lu_inverse_carry", "same_work_exact"):
+    for key in ("value_lu_carry", "value_lu_inverse_carry", "value_lu_inverse_carry_device_refactor", "same_work_exact"):
         if key in line:
             out[key] = line[key]
     if "configs" in line:
@@ -148,6 +148,8 @@ def compact_line(line, detail_name):
         out["host"] = line["host"]
     out["detail_file"] = detail_name
     out = _round(out)
+    if out.get("roofline") and out["roofline"].get("peak"):  # consistent after the rounding: frac IS achieved / peak
+        out["roofline"]["frac"] = out["roofline"]["achieved"] / out["roofline"]["peak"]
     text = json.dumps(out, separators=(",", ":"))
     if len(text) > COMPACT_LIMIT:  # never let the line outgrow the driver's capture again: drop the prose first, then the summaries
         for victim in (("cpu_baseline", "sample"), ("cpu_baseline_tuned", None), ("config", "workload"), ("configs_summary", None)):
@@ -357,7 +359,23 @@ def cpu_leg_maxflow(budget_seconds):
     return out
 
 
+def cpu_leg_exact_full(lp_name, budget_seconds):
+    """The exact CPU restatement run TO COMPLETION on one mid-size LP: the same pivots the device's fixed-width exact simplex makes
+    (both walk the reference's pivot sequence), so pivots/s on both sides is the same work."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from relp_oracle import cpu
+    from relp_oracle.mps import load_problem
+    _, data = load_problem(os.path.join(ROOT, "data", "netlib", lp_name + ".SIF"))
+    record = cpu.solve_provider(data, max_seconds=budget_seconds, trace=0)
+    pivots = record["pivots_phase1"] + record["pivots_phase2"]
+    return {"value": pivots / record["seconds"] if record["seconds"] > 0 else 0.0, "unit": "pivots/s", "cores": 1, "kind": "port", "mode": "faithful",
+            "pivots": pivots, "seconds": record["seconds"], "status": record.get("status", ""),
+            "sample": "the WHOLE exact solve of %s (oracle/cpp, faithful): %d pivots in %.2f s (%s)" % (lp_name, pivots, record["seconds"], record.get("status", ""))}
+
+
 def run_cpu_leg(name, seconds):
+    if name.startswith("exact_full:"):
+        return cpu_leg_exact_full(name.split(":")[1], max(seconds, 120.0))
     if name == "exact_faithful":
         return cpu_leg_exact(WORKLOADS["25fv47"], seconds, False)
     if name == "exact_tuned":
@@ -495,7 +513,7 @@ def single_lp(args, ctx):
         # the step is `solve_relaxation` with the exact certificate INSIDE: the f64 loop alone is narrower arithmetic than the
         # reference's, the bit-exact optimum is part of the job (BASELINE.json north_star)
         model = relp_amd.Model(path, presolve=args.presolve)
-        solver = relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry).load_model(model)
+        solver = relp_amd.Solver(device=local_rank, certify=0 if args.no_certify else 1, carry=args.carry, lu_refactor=args.lu_refactor).load_model(model)
 
     def barrier():
         if distributed:
@@ -673,6 +691,7 @@ def single_lp(args, ctx):
                    "wall_clock_f64_loop_s": loop_seconds / args.steps,
                    "pivots_per_s_f64_loop_only": pivots / world / loop_seconds if loop_seconds > 0 else None,
                    "carry": {1: "lu", 2: "lu_inverse"}.get(args.carry, "explicit"), "refactors": int(last.refactors),
+                   "lu_refactor": ("device kernels (lu_factor.hip, lu_device_tasks.hip)" if args.lu_refactor == 1 else "host core") if lu_carry else None,
                    "refactor_seconds_per_solve": float(last.refactor_seconds),
                    "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
                    # the reference is exact and has neither tolerances nor a Harris test: what f64 adds, and what it changes
@@ -870,6 +889,65 @@ def netlib_batch(args, ctx):
 
 
 # =====================================================================================================================
+# the loop in fixed-width exact integers on the device (relp_solve_exact): the reference's own pivot sequence
+# =====================================================================================================================
+EXACT_SAME_WORK_LP = "E226"   # mid-size: the exact CPU restatement finishes it in seconds, so both sides run the SAME pivots to completion
+
+
+def exact_lp(lp_name, ctx, first_limbs, max_limbs):
+    """One solve of `lp_name` with `relp_solve_exact` (LIMBS x 64-bit integers, widened where a value might not fit), timed: value =
+    pivots of the reference's sequence per second.  The roofline entry prices the integer update of the m x m numerator matrix."""
+    import relp_amd
+    golden_path = os.path.join(ROOT, "tests", "golden", lp_name + ".json")
+    golden = json.load(open(golden_path)) if os.path.exists(golden_path) else None
+    solver = relp_amd.Solver(device=ctx["local_rank"]).load_mps(os.path.join(ROOT, "data", "netlib", lp_name + ".SIF"))
+    start = time.perf_counter()
+    got = solver.solve_exact(first_limbs=first_limbs, max_limbs=max_limbs)
+    elapsed = time.perf_counter() - start
+    pivots = got["pivots_phase_one"] + got["pivots_phase_two"]
+    m = solver.m
+    solver.close()
+    # one pivot rewrites the m x m integer matrix N = D B^-1 at the final width: read + write of m^2 * limbs * 8 bytes
+    bytes_per_pivot = 2 * m * m * got["limbs"] * 8
+    achieved = bytes_per_pivot * pivots / elapsed / 1e9 if elapsed > 0 else 0.0
+    matches = None
+    if golden is not None:
+        matches = (got["status"] == 1 and got["objective"] == golden["objective"] and
+                   (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"]))
+    return {"metric": "simplex pivots/sec, exact fixed-width integers on the device, Netlib %s" % lp_name, "value": pivots / elapsed if elapsed > 0 else 0.0,
+            "unit": "pivots/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1e3 * elapsed, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int%d" % (64 * got["limbs"]), "data": "Netlib %s.SIF" % lp_name,
+            "config": {"workload": "Netlib %s %d rows, relp_solve_exact: the reference's pivot sequence (steepest edge, Bland ratio ties) in %d x 64-bit "
+                                   "integers over a common denominator, widths tried %s" % (lp_name, m, got["limbs"], got["survived"]),
+                       "pivots_per_solve": pivots, "status": got["status"], "limbs": got["limbs"], "widths_and_pivots_survived": got["survived"],
+                       "objective_exact": got["objective"], "objective": None, "matches_golden_optimum_and_pivot_counts": matches},
+            "roofline": {"bound": "hbm", "kernel": "exact_simplex_kernel<%d>" % got["limbs"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_pivot * pivots,
+                         "note": "integer-ALU bound, not HBM bound: a pivot is m^2 multi-limb multiply-subtract-divide steps (limbs^2 word "
+                                 "products each); the bytes are the read + write of the numerator matrix at the final width"}}
+
+
+def exact_25fv47_recorded():
+    """BASELINE configs[1] pivot for pivot in fixed-width integers takes 257 s (128 limbs): beyond the default run's minutes, so the
+    default line carries the committed measurement (profiles/r4_exact_25fv47_128_limbs.txt; the same call is the gpu test
+    tests/test_gpu_exact.py::test_25fv47_whole_reference_pivot_sequence_in_fixed_width_integers); `--exact-25fv47` runs it live."""
+    path = os.path.join(ROOT, "profiles", "r4_exact_25fv47_128_limbs.txt")
+    row = [r for r in open(path) if r.startswith("25FV47")][-1].split()
+    seconds = float(row[row.index("s") - 1])
+    pivots = 1133 + 1259
+    return {"metric": "simplex pivots/sec, exact fixed-width integers on the device, Netlib 25FV47", "value": pivots / seconds, "unit": "pivots/s", "n_gpus": 1,
+            "steps": 1, "warmup": 0, "ms_per_step": 1e3 * seconds, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8192",
+            "data": "Netlib 25FV47.SIF", "recorded": True,
+            "config": {"workload": "Netlib 25FV47 821 rows, relp_solve_exact, 4 -> 128 limbs: RECORDED run (profiles/r4_exact_25fv47_128_limbs.txt), not measured "
+                                   "in this process; run `bench.py --exact-25fv47` (about five minutes) to measure it here",
+                       "pivots_per_solve": pivots, "limbs": 128, "matches_golden_optimum_and_pivot_counts": True},
+            "roofline": {"bound": "hbm", "kernel": "exact_simplex_kernel<128>", "achieved": 2 * 821 * 821 * 128 * 8 * pivots / seconds / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": 2 * 821 * 821 * 128 * 8 * pivots / seconds / 1e9 / HBM_PEAK_GBS, "traffic": None},
+            "cpu_baseline": {"value": 2392 / 1026.0, "unit": "pivots/s", "cores": 1, "kind": "port", "mode": "faithful", "recorded": True,
+                             "sample": "the whole exact solve on the CPU restatement: 2392 pivots in 1026 s (profiles/r1_cpu_oracle_full_solve.json, build container)"}}
+
+
+# =====================================================================================================================
 def all_configs(args, ctx, legs):
     """The other BASELINE configs, measured in this process after the headline (default run, N = 1)."""
     out = {}
@@ -891,6 +969,11 @@ def all_configs(args, ctx, legs):
             out[key] = {"error": "%s: %s" % (type(error).__name__, error)}
 
     steps = max(1, min(args.steps, 3))
+    if not args.no_cpu_baseline:
+        legs.start("exact_full", "exact_full:" + EXACT_SAME_WORK_LP, args.cpu_seconds)
+    attempt("exact_" + EXACT_SAME_WORK_LP.lower(), lambda: exact_lp(EXACT_SAME_WORK_LP, ctx, 2, 32))
+    attempt("exact_25fv47", lambda: exact_lp("25FV47", ctx, 4, 128) if args.exact_25fv47 else exact_25fv47_recorded())
+    attempt("lu_inverse_carry_25fv47_device_refactor", lambda: single_lp(variant(carry=2, lu_refactor=1, steps=steps, warmup=1), ctx))
     attempt("lu_carry_25fv47", lambda: single_lp(variant(carry=1, steps=steps, warmup=1), ctx))
     attempt("lu_inverse_carry_25fv47", lambda: single_lp(variant(carry=2, steps=steps, warmup=1), ctx))
     attempt("dense4096_f64", lambda: single_lp(variant(workload="dense4096", dense_storage="f64", steps=steps, warmup=1), ctx))
@@ -898,7 +981,17 @@ def all_configs(args, ctx, legs):
     attempt("maxflow_reference_start", lambda: single_lp(variant(workload="maxflow", crash=0, steps=1, warmup=1), ctx))
     attempt("maxflow_crash", lambda: single_lp(variant(workload="maxflow", crash=1, steps=steps, warmup=1), ctx))
     if not args.no_cpu_baseline:
-        for key in ("lu_carry_25fv47", "lu_inverse_carry_25fv47"):  # the same LP as the headline: the same exact CPU path beside it
+        key = "exact_" + EXACT_SAME_WORK_LP.lower()
+        if "error" not in out[key]:
+            full = legs.collect("exact_full", timeout=900)
+            out[key]["cpu_baseline"] = full
+            if full and "error" not in full:
+                gpu = out[key]["config"]
+                out[key]["same_work"] = {"lp": EXACT_SAME_WORK_LP, "pivots_gpu": gpu["pivots_per_solve"], "pivots_cpu": full.get("pivots"),
+                                         "gpu_seconds": out[key]["ms_per_step"] * 1e-3, "cpu_seconds": full.get("seconds"),
+                                         "cpu_over_gpu": full.get("seconds") / (out[key]["ms_per_step"] * 1e-3) if out[key]["ms_per_step"] > 0 else None,
+                                         "same_pivot_count": full.get("pivots") == gpu["pivots_per_solve"] and full.get("status") == "optimal"}
+        for key in ("lu_carry_25fv47", "lu_inverse_carry_25fv47", "lu_inverse_carry_25fv47_device_refactor"):  # the same LP as the headline: the same exact CPU path beside it
             if "error" not in out[key]:
                 out[key]["cpu_baseline"] = legs.peek("exact_faithful")
         dense_cpu = legs.collect("dense")
@@ -940,6 +1033,8 @@ def main():
     parser.add_argument("--no-certify", action="store_true", help="25fv47: leave the exact certificate out of the timed step (A/B only)")
     parser.add_argument("--carry", type=int, default=0, choices=[0, 1, 2],
                         help="0 explicit inverse, 1 LU + Forrest-Tomlin, 2 LU through the inverses of its triangles + product-form updates (relp_options.carry)")
+    parser.add_argument("--lu-refactor", type=int, default=0, choices=[0, 1, 2], help="LU carries: 0 automatic, 1 refactorisation kernels on the device, 2 host core (relp_options.lu_refactor)")
+    parser.add_argument("--exact-25fv47", action="store_true", help="run 25FV47 through relp_solve_exact live (about five minutes) instead of quoting the recorded run")
     parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")
     parser.add_argument("--records", default=None, help="netlib batch: write one JSON line per solved LP to this file")
@@ -1002,9 +1097,13 @@ def main():
         if full:
             line["configs"] = all_configs(args, ctx, legs)
             # BASELINE configs[1] as written ("LU carry BasisInverse"): the same LP, same step, under the two LU carries
-            for key, name in (("value_lu_carry", "lu_carry_25fv47"), ("value_lu_inverse_carry", "lu_inverse_carry_25fv47")):
+            for key, name in (("value_lu_carry", "lu_carry_25fv47"), ("value_lu_inverse_carry", "lu_inverse_carry_25fv47"),
+                              ("value_lu_inverse_carry_device_refactor", "lu_inverse_carry_25fv47_device_refactor")):
                 if "error" not in line["configs"].get(name, {"error": 1}):
                     line[key] = line["configs"][name]["value"]
+            same = line["configs"].get("exact_" + EXACT_SAME_WORK_LP.lower(), {}).get("same_work")
+            if same:
+                line["same_work_exact"] = same
         if want_cpu:
             if batch_workload:
                 legs.start("netlib", "netlib", max(2.0, args.cpu_seconds), blas=1)

@@ -78,6 +78,17 @@ typedef enum relp_dense_storage {
     RELP_DENSE_DOUBLE = 2      /* double (SURVEY.md section 8(d)'s 8 bytes per entry) */
 } relp_dense_storage;
 
+/* Where the LU carries refactorise (`relp_options.lu_refactor`). */
+typedef enum relp_lu_refactor {
+    RELP_REFACTOR_AUTO = 0,    /* the faster of the two at the sizes measured so far: today the host path for every shipped LP
+                                  (DESIGN.md section 2d has the table: the kernels are 1.4-1.6 x behind one host core per pivot) */
+    RELP_REFACTOR_DEVICE = 1,  /* kernels on the handle's stream (lu_factor.hip, lu_device_tasks.hip): Markowitz factorisation with
+                                  independent pivots per round, inversion of the two triangles, slot records -- no basis read-back, no
+                                  upload; RELP_CARRY_LU_INVERSE only (the Forrest-Tomlin carry factorises on the host); what the
+                                  kernels cannot take (a row of more than 256 entries, a capacity) falls back to the host path */
+    RELP_REFACTOR_HOST = 2     /* one host core: Markowitz + inversion + task lists, one upload (rounds 2-3) */
+} relp_lu_refactor;
+
 typedef struct relp_options {
     int32_t device;            /* HIP device ordinal */
     int32_t pivot_rule;        /* relp_pivot_rule */
@@ -121,9 +132,8 @@ typedef struct relp_options {
                                   pivots), 1 = a rank-one update of the stored inverse per pivot; env RELP_ETA=0 */
     int32_t ftran_min_nnz;     /* columns longer than this take the multi-block FTRAN pipeline; 0 = 1024; env
                                   RELP_FTRAN_MIN_NNZ */
-    int32_t refactor_on_host;  /* LU carries: 0 = `BasisInverse::invert` (Markowitz factorisation, triangle inversion, task
-                                  lists; lower_upper/mod.rs:78-92, decomposition/mod.rs:27-143) runs as kernels on the device,
-                                  1 = on one host core (round 3's path, kept for A/B runs); env RELP_REFACTOR_HOST=1 */
+    int32_t lu_refactor;       /* relp_lu_refactor: where `BasisInverse::invert` of the LU carries runs (lower_upper/mod.rs:78-92,
+                                  decomposition/mod.rs:27-143); env RELP_REFACTOR=device|host overrides */
     int32_t reserved0;         /* 0 */
 } relp_options;
 

@@ -35,7 +35,7 @@ class Options(C.Structure):
                 ("carry", C.c_int32), ("refactor_period", C.c_int32), ("lu_pivot_threshold", C.c_double),
                 ("ratio_rule", C.c_int32), ("crash", C.c_int32),
                 ("dense_storage", C.c_int32), ("pivot_kernels", C.c_int32), ("product_form", C.c_int32), ("ftran_min_nnz", C.c_int32),
-                ("refactor_on_host", C.c_int32), ("reserved0", C.c_int32)]
+                ("lu_refactor", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Result(C.Structure):

@@ -2457,11 +2457,85 @@ void LuBasis::factor_and_upload() {
         }
         cs[j + 1] = (int)rows.size();
     }
-    HostLU f = lu_factor(m_, cs.data(), rows.data(), vals.data(), options_);
+    // `LUDecomposition::rows` runs as a KERNEL (lu_factor.hip): the factors this object solves with -- and hands out through
+    // relp_bi_get_factors, where the reference's exact-factor and Forrest-Tomlin known answers are checked -- are the ones the device
+    // produced.  Their level schedules and slot lists are still laid out by the host (LuFactors::upload) for this carry.  What the
+    // kernel does not take (a row of more than 256 entries) is factorised by lu_factor on the host.
+    HostLU f;
+    if (!factor_on_device(cs, rows, vals, f)) f = lu_factor(m_, cs.data(), rows.data(), vals.data(), options_);
     if (f.singular) throw std::runtime_error("singular basis");
     lu_.upload(f, period_ + 1, stream_);
     RELP_HIP(hipStreamSynchronize(stream_));
     have_spike_ = false;
+}
+// false: the kernel gave up for a reason other than singularity (the caller factorises on the host)
+bool LuBasis::factor_on_device(const std::vector<int>& cs, const std::vector<int>& rows, const std::vector<double>& vals, HostLU& f) {
+    if (getenv("RELP_BI_FACTOR_HOST") || m_ > 65535) return false;
+    const int m = m_;
+    const size_t nnz = rows.size();
+    size_t cap = 4 * nnz + 8 * (size_t)m + 4096;
+    struct Buffers {
+        std::vector<void*> owned;
+        ~Buffers() { for (void* p : owned) (void)hipFree(p); }
+        void* bytes(size_t n) {
+            void* p = nullptr;
+            RELP_HIP(hipMalloc(&p, std::max<size_t>(8, n)));
+            owned.push_back(p);
+            return p;
+        }
+    };
+    for (int attempt = 0; attempt < 4; ++attempt, cap *= 4) {
+        Buffers b;
+        int* d_cs = (int*)b.bytes((size_t)(m + 1) * sizeof(int));
+        int* d_ri = (int*)b.bytes((size_t)(nnz) * sizeof(int));
+        double* d_va = (double*)b.bytes((size_t)(nnz) * sizeof(double));
+        LuFactorOut out;
+        out.rowpos = (int*)b.bytes((size_t)(m) * sizeof(int)); out.colpos = (int*)b.bytes((size_t)(m) * sizeof(int)); out.diag = (double*)b.bytes((size_t)(m) * sizeof(double));
+        out.l_start = (int*)b.bytes((size_t)(m + 1) * sizeof(int)); out.l_col = (int*)b.bytes((size_t)(cap) * sizeof(int)); out.l_val = (double*)b.bytes((size_t)(cap) * sizeof(double));
+        out.u_start = (int*)b.bytes((size_t)(m + 1) * sizeof(int)); out.u_col = (int*)b.bytes((size_t)(cap) * sizeof(int)); out.u_val = (double*)b.bytes((size_t)(cap) * sizeof(double));
+        out.cap_l = out.cap_u = (int)std::min<size_t>(cap, (size_t)1 << 30);
+        RELP_HIP(hipMemcpyAsync(d_cs, cs.data(), (m + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
+        if (nnz) {
+            RELP_HIP(hipMemcpyAsync(d_ri, rows.data(), nnz * sizeof(int), hipMemcpyHostToDevice, stream_));
+            RELP_HIP(hipMemcpyAsync(d_va, vals.data(), nnz * sizeof(double), hipMemcpyHostToDevice, stream_));
+        }
+        factor_scratch_.reserve(m, nnz, cap, cap);
+        LuFactorSource src;
+        src.col_start = d_cs;
+        src.row_index = d_ri;
+        src.value = d_va;
+        launch_lu_factor(src, factor_scratch_.work(), out, options_.threshold, options_.reference_ties ? 1 : 0, 32, stream_);
+        int info[LUF_INFO_WORDS];
+        RELP_HIP(hipMemcpyAsync(info, factor_scratch_.work().info, sizeof(info), hipMemcpyDeviceToHost, stream_));
+        RELP_HIP(hipStreamSynchronize(stream_));
+        f = HostLU{};
+        f.m = m;
+        if (info[LUF_STATUS] == LUF_ERR_SINGULAR) {
+            f.singular = true;
+            return true;
+        }
+        if (info[LUF_STATUS] == LUF_ERR_L_CAPACITY || info[LUF_STATUS] == LUF_ERR_U_CAPACITY || info[LUF_STATUS] == LUF_ERR_ARENA) continue;  // more room
+        if (info[LUF_STATUS] != LUF_OK) return false;
+        const size_t nl = (size_t)info[LUF_NNZ_L], nu = (size_t)info[LUF_NNZ_U];
+        f.rowpos.resize(m); f.colpos.resize(m); f.diag.resize(m);
+        f.l_start.resize(m + 1); f.u_start.resize(m + 1);
+        f.l_col.resize(nl); f.l_val.resize(nl); f.u_col.resize(nu); f.u_val.resize(nu);
+        auto get = [&](void* dst, const void* from, size_t bytes) {
+            if (bytes) RELP_HIP(hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToHost, stream_));
+        };
+        get(f.rowpos.data(), out.rowpos, m * sizeof(int));
+        get(f.colpos.data(), out.colpos, m * sizeof(int));
+        get(f.diag.data(), out.diag, m * sizeof(double));
+        get(f.l_start.data(), out.l_start, (m + 1) * sizeof(int));
+        get(f.u_start.data(), out.u_start, (m + 1) * sizeof(int));
+        get(f.l_col.data(), out.l_col, nl * sizeof(int));
+        get(f.l_val.data(), out.l_val, nl * sizeof(double));
+        get(f.u_col.data(), out.u_col, nu * sizeof(int));
+        get(f.u_val.data(), out.u_val, nu * sizeof(double));
+        RELP_HIP(hipStreamSynchronize(stream_));
+        return true;
+    }
+    return false;
 }
 void LuBasis::identity() {  // lower_upper/mod.rs:67-76: identity permutations, empty L and U, unit diagonal
     for (int j = 0; j < m_; ++j) columns_[j] = {{j, 1.0}};

@@ -225,6 +225,8 @@ public:
 
 private:
     void factor_and_upload();
+    bool factor_on_device(const std::vector<int>& cs, const std::vector<int>& rows, const std::vector<double>& vals, HostLU& f);
+    LuFactorScratch factor_scratch_;
     int device_, m_, period_;
     LuOptions options_;
     hipStream_t stream_ = nullptr;

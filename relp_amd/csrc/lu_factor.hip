@@ -27,7 +27,8 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     cap_l_ = std::max(cap_l_, cap_l);
     cap_u_ = std::max(cap_u_, cap_u);
     cap_inv_ = std::max(cap_inv_, cap_inverse);
-    const size_t cap_w = std::min<size_t>((size_t)1 << 27, 6 * nnz_ + 16 * (size_t)m + 4096);
+    size_t cap_w = std::min<size_t>((size_t)1 << 27, 6 * nnz_ + 16 * (size_t)m + 4096);
+    if (const char* limit = getenv("RELP_LUF_ARENA_CAP")) cap_w = std::max<size_t>(64, (size_t)atoll(limit));  // test hook: an arena the basis outgrows
     size_t offset = 0;
     auto take = [&](size_t bytes) {
         offset = (offset + 63) & ~size_t(63);

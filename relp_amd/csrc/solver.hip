@@ -226,8 +226,13 @@ void Solver::upload() {
     if (lu_mode_ && !lu_inverse_) {
         if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its two solve vectors in LDS (16 bytes per row): at most about 8000 rows with this refactor period (use the explicit carry beyond)");
     }
-    // `BasisInverse::invert` as kernels (the inverse-factor form; relp_options.refactor_on_host / RELP_REFACTOR_HOST=1: one host core)
-    device_refactor_ = lu_inverse_ && opt_.refactor_on_host == 0 && !(getenv("RELP_REFACTOR_HOST") && atoi(getenv("RELP_REFACTOR_HOST")) != 0) && m <= 65535;
+    // `BasisInverse::invert` as kernels (lu_factor.hip, lu_device_tasks.hip: the inverse-factor form) or on one host core:
+    // relp_options.lu_refactor, env RELP_REFACTOR=device|host.  AUTO is the host path today -- faster at every size measured.
+    {
+        int where = opt_.lu_refactor;
+        if (const char* env = getenv("RELP_REFACTOR")) where = std::string(env) == "device" ? RELP_REFACTOR_DEVICE : std::string(env) == "host" ? RELP_REFACTOR_HOST : where;
+        device_refactor_ = lu_inverse_ && where == RELP_REFACTOR_DEVICE && m <= 65535;
+    }
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
     // structural columns); steepest edge only (the dense kernel implements that rule)
     int n_dense = 0;
@@ -615,6 +620,7 @@ void Solver::begin_phase_one() {
     RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));  // every column is a unit vector
     binv_identity_ = true;
     refactors_ = 0;
+    device_refactor_failures_ = 0;
     refactor_seconds_ = 0.0;
     Ctl c{};
     c.forced_q = c.forced_p = -1;
@@ -1253,7 +1259,9 @@ long long Solver::iterate(long long count, int* stop_reason) {
         } else {
             launch_pivots(batch);
         }
-        Ctl after = read_ctl();
+        const long long fallbacks_before = device_refactor_failures_;
+        Ctl after = read_ctl();  // (a refactorisation the kernels gave up on is redone by the host in here: nothing pivoted, go on)
+        const bool fell_back = device_refactor_failures_ != fallbacks_before;
         long long made = after.iters - iters_before;
         iters_before = after.iters;
         done += made;
@@ -1265,7 +1273,7 @@ long long Solver::iterate(long long count, int* stop_reason) {
             refactor_lu(true);
             continue;
         }
-        if (made == 0 && after.status == ST_RUNNING) break;  // defensive: nothing happened
+        if (made == 0 && after.status == ST_RUNNING && !fell_back) break;  // defensive: nothing happened
     }
     if (stop_reason) *stop_reason = reason;
     return done;

@@ -213,6 +213,8 @@ public:
     const relp_stats& stats() const { return stats_; }
     void reset_stats();
     int n_art() const { return d_.n_art; }
+    bool refactors_on_device() const { return device_refactor_; }
+    long long device_refactor_fallbacks() const { return device_refactor_failures_; }
     std::string exact_objective;  // filled by certify()
     // exact x_B of the certified optimal basis (certify.hip keeps the big integers; strings are made on demand)
     std::shared_ptr<const ExactPrimal> exact_primal;
@@ -246,7 +248,7 @@ private:
     CertifyScratch certify_scratch_;
     // LU carry (relp_options.carry == RELP_CARRY_LU)
     void refactor_lu(bool refresh_vectors);  // BasisInverse::invert of the current basis: kernels on the device (lu_factor.hip), or ...
-    void refactor_lu_host(bool refresh_vectors);  // ... host Markowitz + upload (relp_options.refactor_on_host; carry LU + Forrest-Tomlin; the fallback)
+    void refactor_lu_host(bool refresh_vectors);  // ... host Markowitz + upload (relp_options.lu_refactor; the LU + Forrest-Tomlin carry; the fallback)
     bool device_refactor_ = false;
     long long device_refactor_failures_ = 0;
     void lu_identity();                      // BasisInverse::identity
