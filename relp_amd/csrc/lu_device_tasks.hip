@@ -66,6 +66,10 @@ __device__ __forceinline__ unsigned long long t_block_exclusive_scan(unsigned lo
     *total = sh.scan[LUT_WAVES];
     return sh.scan[wave] + incl - v;
 }
+__device__ __forceinline__ int t_lane_value(int v, int y) { return __builtin_amdgcn_readlane(v, y); }  // (y wave-uniform: an SGPR move, not a ds_bpermute)
+__device__ __forceinline__ double t_lane_value(double v, int y) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), y), __builtin_amdgcn_readlane(__double2loint(v), y));
+}
 __device__ __forceinline__ int t_lanes_below(unsigned long long mask) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
@@ -107,8 +111,8 @@ __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i,
         }
         const int cnt = min(WAVE, e - x0);
         for (int y = 0; y < cnt; ++y) {
-            const int jj = __shfl(j, y, WAVE), sjj = __shfl(sj, y, WAVE), njj = __shfl(nj, y, WAVE);
-            const double factor = __shfl(fij, y, WAVE);
+            const int jj = t_lane_value(j, y), sjj = t_lane_value(sj, y), njj = t_lane_value(nj, y);
+            const double factor = t_lane_value(fij, y);
             if (!UPPER && lane == 0) add(jj, -factor);  // the unit diagonal of row jj of L^-1
             for (int z0 = 0; z0 < njj; z0 += WAVE)
                 if (z0 + lane < njj) add(iw.raw_col[sjj + z0 + lane], -factor * iw.raw_val[sjj + z0 + lane]);
@@ -127,7 +131,7 @@ __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i,
     for (int d = 1; d < WAVE; d <<= 1) total += __shfl_xor(total, d, WAVE);
     int at = 0;
     if (lane == 0) at = arena_first + atomicAdd(&sh.cursor, total);
-    at = __shfl(at, 0, WAVE);
+    at = t_lane_value(at, 0);
     if (at + total > arena_first + iw.raw_cap / 2) {
         if (lane == 0) sh.error = LUF_ERR_INVERSE_CAPACITY;
         total = 0;

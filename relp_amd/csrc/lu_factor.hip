@@ -184,6 +184,11 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     for (int d = 1; d < WAVE; d <<= 1) v = fmax(v, __shfl_xor(v, d, WAVE));
     return v;
 }
+// broadcast of lane `y` (wave-uniform): v_readlane, an SGPR move -- __shfl is a ds_bpermute, an LDS-crossbar round trip
+__device__ __forceinline__ int lane_value(int v, int y) { return __builtin_amdgcn_readlane(v, y); }
+__device__ __forceinline__ double lane_value(double v, int y) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), y), __builtin_amdgcn_readlane(__double2loint(v), y));
+}
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {  // set bits of `mask` below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
@@ -238,7 +243,7 @@ __device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShare
             }
         const unsigned long long who = __ballot(holder);
         const int src = __ffsll((long long)who) - 1;
-        a = __shfl(a, src, WAVE);
+        a = lane_value(a, src);
         const double ratio = a / out.diag[k];
         if (lane == 0) {
             const int at = atomicAdd(&sh.l_top, 1);
@@ -256,8 +261,8 @@ __device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShare
             const double pv = y0 + lane < un ? w.ut_val[us + y0 + lane] : 0.0;
             const int cnt = min(WAVE, un - y0);
             for (int y = 0; y < cnt; ++y) {
-                const int cc = __shfl(pc, y, WAVE);
-                const double product = ratio * __shfl(pv, y, WAVE);
+                const int cc = lane_value(pc, y);
+                const double product = ratio * lane_value(pv, y);
                 bool found = false;
 #pragma unroll
                 for (int s = 0; s < LUF_ROW_SLOTS; ++s)

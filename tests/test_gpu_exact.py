@@ -62,7 +62,10 @@ def test_25fv47_whole_reference_pivot_sequence_in_fixed_width_integers():
     assert max(num.bit_length(), den.bit_length()) == golden["objective_bits"] == 1791
     head = device_indices([tuple(t) for t in golden["trace_head"]], solver.n_art)
     assert got["trace"][:len(head)] == head
-    assert sorted(int(c) for c in got["basis"]) == sorted(golden["basis"])
+    # (one row of 25FV47 is redundant: the reference removes it -- 820 basic columns in the fixture --, the device keeps its zero-level
+    #  artificial basic, -1 - k in `basis`)
+    assert got["redundant_rows"] == golden["m"] - len(golden["basis"]) == 1
+    assert sorted(int(c) for c in got["basis"] if c >= 0) == sorted(golden["basis"])
     solver.close()
 
 
