@@ -37,10 +37,9 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
         return at;
     };
     const size_t mi = (size_t)m * sizeof(int);
-    size_t o_acol[2], o_arow[2], o_aval[2], o_active[2];
+    size_t o_acr[2], o_aval[2], o_active[2];
     for (int b = 0; b < 2; ++b) {
-        o_acol[b] = take(cap_w * sizeof(int));
-        o_arow[b] = take(cap_w * sizeof(int));
+        o_acr[b] = take(cap_w * sizeof(unsigned));
         o_aval[b] = take(cap_w * sizeof(double));
         o_active[b] = take(mi);
     }
@@ -84,8 +83,7 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     w.m = m;
     w.cap_w = (int)cap_w;
     for (int b = 0; b < 2; ++b) {
-        w.a_col[b] = I(o_acol[b]);
-        w.a_row[b] = I(o_arow[b]);
+        w.a_cr[b] = reinterpret_cast<unsigned*>(dev_ + o_acr[b]);
         w.a_val[b] = D(o_aval[b]);
         w.active[b] = I(o_active[b]);
     }
@@ -135,38 +133,47 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
 namespace {
 
 constexpr unsigned NONE32 = 0xffffffffu;
+constexpr unsigned HOLE = 0xffffffffu;   // arena entry without content; a live one is row << 16 | column
 constexpr unsigned long long NONE64 = ~0ull;
 constexpr int LUF_WAVES = LUF_THREADS / WAVE;
 
 struct FactorShared {
-    unsigned long long scan[LUF_WAVES + 2];
+    unsigned scan[LUF_WAVES + 2];
     unsigned long long best64;
     int smin;
     int n_active, kbase, ubase, top, n_targets, cur, error, n_acc, rounds, l_top, top_new, n_active_new, u_round, ref_row, ref_col, peak;
-    int dense_rows;
+    int dense_rows, lds_rounds, spilled;
+    unsigned long long dbg[6];  // diagnostic cycle sums of the eliminating waves (lane 0): preamble | pivot set-up | entry loop | write-out | pairs | targets
 };
 
-__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v) {
-    const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const unsigned lo = (unsigned)__shfl_up((int)(unsigned)v, d, WAVE);
-        const unsigned hi = (unsigned)__shfl_up((int)(unsigned)(v >> 32), d, WAVE);
-        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-        if (lane >= d) v += other;
-    }
+// The active sub-matrix of a round: entries (row << 16 | column, value), rows contiguous (r_start / r_len), in global memory or --
+// once it is small enough -- in LDS (the same code: the pointers' address space is known at each call site after inlining).
+struct Arena {
+    unsigned* cr;
+    double* val;
+};
+
+// Inclusive scan over the wave by DPP row shifts and row broadcasts: ten VALU instructions, no LDS crossbar (a __shfl_up scan is six
+// dependent ds_bpermute round trips).
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1 (lanes without a source read 0)
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8  -> inclusive inside each row of 16
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, true);  // rows 1, 3 += last lane of rows 0, 2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, true);  // rows 2, 3 += lane 31
     return v;
 }
 // exclusive prefix of `v` over the workgroup's threads in thread order; *total = the sum.  Three barriers.
-__device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long long v, FactorShared& sh, unsigned long long* total) {
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, FactorShared& sh, unsigned* total) {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    const unsigned long long incl = wave_inclusive_scan(v);
+    const unsigned incl = wave_inclusive_scan(v);
     __syncthreads();  // earlier readers of sh.scan are done
     if (lane == WAVE - 1) sh.scan[wave] = incl;
     __syncthreads();
     if (wave == 0) {
-        const unsigned long long w = lane < LUF_WAVES ? sh.scan[lane] : 0ull;
-        const unsigned long long wi = wave_inclusive_scan(w);
+        const unsigned w = lane < LUF_WAVES ? sh.scan[lane] : 0u;
+        const unsigned wi = wave_inclusive_scan(w);
         if (lane < LUF_WAVES) sh.scan[lane] = wi - w;
         if (lane == LUF_WAVES - 1) sh.scan[LUF_WAVES] = wi;
     }
@@ -175,15 +182,15 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long
     return sh.scan[wave] + incl - v;
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) v = min(v, __shfl_xor(v, d, WAVE));
-    return v;
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, DPP_QUAD_1032, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, DPP_QUAD_2301, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR4, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR8, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_BCAST15, 0xA, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_BCAST31, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, WAVE - 1);
 }
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) v = fmax(v, __shfl_xor(v, d, WAVE));
-    return v;
-}
+__device__ __forceinline__ double wave_max_f64(double v) { return lane63_f64(wave_max(v)); }
 // broadcast of lane `y` (wave-uniform): v_readlane, an SGPR move -- __shfl is a ds_bpermute, an LDS-crossbar round trip
 __device__ __forceinline__ int lane_value(int v, int y) { return __builtin_amdgcn_readlane(v, y); }
 __device__ __forceinline__ double lane_value(double v, int y) {
@@ -208,43 +215,70 @@ __device__ __forceinline__ unsigned priority_of(unsigned key, int row) { return 
 
 // Row `r` of the active sub-matrix minus its multiples of the pivot rows of this round, by one wave: the row in registers
 // (LUF_ROW_SLOTS entries per lane), a pivot row's entries broadcast one at a time.  Writes the new row compactly to the other arena.
-__device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuFactorOut& out, const int r, const int cur, const bool exact_mode) {
+// SLOTS: register entries per lane -- 1 for the rows that cannot outgrow 64 entries in this round (nearly all of them: every
+// instruction of the inner loop is issued per slot, and sixteen waves on four SIMDs make the loop issue-bound), LUF_ROW_SLOTS otherwise.
+template <int SLOTS>
+__device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShared& sh, const LuFactorOut& out, const int r, const Arena old, const Arena nw,
+                                              const bool exact_mode) {
     const int lane = threadIdx.x & (WAVE - 1);
+#ifdef RELP_STAMPS  // (diagnostic build: cycle sums of the eliminating waves, tests/test_gpu_lu_factor_device.py prints them)
+    long long t_mark = clock64();
+    auto mark = [&](int k) {
+        const long long now = clock64();
+        if (lane == 0) atomicAdd(&sh.dbg[k], (unsigned long long)(now - t_mark));
+        t_mark = now;
+    };
+    auto count = [&](int k) { if (lane == 0) atomicAdd(&sh.dbg[k], 1ull); };
+#else
+    auto mark = [](int) {};
+    auto count = [](int) {};
+#endif
     const int s0 = w.r_start[r];
     int len = w.r_len[r];
-    const int* __restrict__ acol = (cur ? w.a_col[1] : w.a_col[0]);
-    const double* __restrict__ aval = (cur ? w.a_val[1] : w.a_val[0]);
-    int col[LUF_ROW_SLOTS], pk[LUF_ROW_SLOTS];
-    double val[LUF_ROW_SLOTS];
+    const int d0 = w.r_newstart[r];
+    const int capacity = max(0, len + w.growth[r]);
+    int col[SLOTS], pk[SLOTS];
+    double val[SLOTS];
 #pragma unroll
-    for (int s = 0; s < LUF_ROW_SLOTS; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
         const int x = s * WAVE + lane;
-        col[s] = x < len ? acol[s0 + x] : -1;
-        val[s] = x < len ? aval[s0 + x] : 0.0;
+        col[s] = x < len ? (int)(old.cr[s0 + x] & 0xffffu) : -1;
+        val[s] = x < len ? old.val[s0 + x] : 0.0;
     }
 #pragma unroll
-    for (int s = 0; s < LUF_ROW_SLOTS; ++s) pk[s] = col[s] >= 0 ? w.pivk_col[col[s]] : -1;
+    for (int s = 0; s < SLOTS; ++s) pk[s] = col[s] >= 0 ? w.pivk_col[col[s]] : -1;
+    mark(0);
+    count(5);
     for (;;) {
         int mine = 0x7fffffff;
 #pragma unroll
-        for (int s = 0; s < LUF_ROW_SLOTS; ++s)
+        for (int s = 0; s < SLOTS; ++s)
             if (pk[s] >= 0) mine = min(mine, pk[s]);
         const int k = wave_min_i32(mine);
         if (k == 0x7fffffff) break;
+        count(4);
         double a = 0.0;
-        bool holder = false;
+        int pivot_column = -1;
 #pragma unroll
-        for (int s = 0; s < LUF_ROW_SLOTS; ++s)
+        for (int s = 0; s < SLOTS; ++s)
             if (pk[s] == k) {
                 a = val[s];
+                pivot_column = col[s];
                 col[s] = -1;
                 pk[s] = -1;
-                holder = true;
             }
-        const unsigned long long who = __ballot(holder);
+        const unsigned long long who = __ballot(pivot_column >= 0);
         const int src = __ffsll((long long)who) - 1;
         a = lane_value(a, src);
-        const double ratio = a / out.diag[k];
+        pivot_column = lane_value(pivot_column, src);
+        // the pivot row is read where it still lies in the OLD arena (its entries but the pivot are row k of U): out of LDS once the
+        // active sub-matrix lives there, so that an elimination makes no global round trip at all
+        const int pivot_row = (int)w.colmark[pivot_column];  // (written when the pivot was accepted; the markers are reset after the round)
+        const int us = w.r_start[pivot_row], un = w.r_len[pivot_row], pe = w.best_e[pivot_row] - us;
+        const double diagonal = old.val[us + pe];
+        int pc = lane < un && lane != pe ? (int)(old.cr[us + lane] & 0xffffu) : -1;
+        double pv = lane < un ? old.val[us + lane] : 0.0;
+        const double ratio = a / diagonal;
         if (lane == 0) {
             const int at = atomicAdd(&sh.l_top, 1);
             if (at < w.cap_l) {
@@ -255,22 +289,25 @@ __device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShare
                 sh.error = LUF_ERR_L_CAPACITY;
             }
         }
-        const int us = w.ut_start[k], un = w.ut_start[k + 1] - us;
+        mark(1);
         for (int y0 = 0; y0 < un; y0 += WAVE) {
-            const int pc = y0 + lane < un ? w.ut_col[us + y0 + lane] : -1;
-            const double pv = y0 + lane < un ? w.ut_val[us + y0 + lane] : 0.0;
+            if (y0 > 0) {
+                pc = y0 + lane < un && y0 + lane != pe ? (int)(old.cr[us + y0 + lane] & 0xffffu) : -1;
+                pv = y0 + lane < un ? old.val[us + y0 + lane] : 0.0;
+            }
             const int cnt = min(WAVE, un - y0);
             for (int y = 0; y < cnt; ++y) {
                 const int cc = lane_value(pc, y);
+                if (cc < 0) continue;  // the pivot entry itself
                 const double product = ratio * lane_value(pv, y);
                 bool found = false;
 #pragma unroll
-                for (int s = 0; s < LUF_ROW_SLOTS; ++s)
+                for (int s = 0; s < SLOTS; ++s)
                     if (col[s] == cc) {
-                        const double old = val[s];
-                        double updated = old - product;
+                        const double before = val[s];
+                        double updated = before - product;
                         // (what floating point adds to the reference's exact cancellation, as lu_host.hpp: decomposition/mod.rs:176-186)
-                        if (!exact_mode && updated != 0.0 && fabs(updated) <= 1e-15 * (fabs(old) + fabs(product))) updated = 0.0;
+                        if (!exact_mode && updated != 0.0 && fabs(updated) <= 1e-15 * (fabs(before) + fabs(product))) updated = 0.0;
                         if (updated == 0.0) {
                             col[s] = -1;
                             atomicSub(&w.ccount[cc], 1);
@@ -280,13 +317,13 @@ __device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShare
                         found = true;
                     }
                 if (__ballot(found) == 0ull) {  // fill-in: the next free slot
-                    if (len >= LUF_MAX_ROW) {
+                    if (len >= WAVE * SLOTS) {
                         if (lane == 0) sh.error = LUF_ERR_LONG_ROW;
                     } else {
                         const int slot = len >> 6;
                         if (lane == (len & (WAVE - 1))) {
 #pragma unroll
-                            for (int s = 0; s < LUF_ROW_SLOTS; ++s)
+                            for (int s = 0; s < SLOTS; ++s)
                                 if (s == slot) {
                                     col[s] = cc;
                                     val[s] = -product;
@@ -300,30 +337,25 @@ __device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShare
             }
         }
     }
+    mark(2);
     // the new row, holes squeezed out, into the other arena; its largest magnitude for the next rounds' threshold test
-    const int d0 = w.r_newstart[r];
-    const int capacity = max(0, w.r_len[r] + w.growth[r]);
-    int* __restrict__ ncol = (cur ? w.a_col[0] : w.a_col[1]);
-    int* __restrict__ nrow = (cur ? w.a_row[0] : w.a_row[1]);
-    double* __restrict__ nval = (cur ? w.a_val[0] : w.a_val[1]);
     int written = 0;
     double biggest = 0.0;
 #pragma unroll
-    for (int s = 0; s < LUF_ROW_SLOTS; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
         const bool live = col[s] >= 0;
         const unsigned long long mask = __ballot(live);
         if (live) {
             const int at = written + lanes_below(mask);
             if (at < capacity) {
-                ncol[d0 + at] = col[s];
-                nrow[d0 + at] = r;
-                nval[d0 + at] = val[s];
+                nw.cr[d0 + at] = ((unsigned)r << 16) | (unsigned)col[s];
+                nw.val[d0 + at] = val[s];
             }
             biggest = fmax(biggest, fabs(val[s]));
         }
         written += __popcll(mask);
     }
-    for (int x = written + lane; x < capacity; x += WAVE) ncol[d0 + x] = -1;
+    for (int x = written + lane; x < capacity; x += WAVE) nw.cr[d0 + x] = HOLE;
     biggest = wave_max_f64(biggest);
     if (lane == 0) {
         if (written == 0) sh.error = LUF_ERR_SINGULAR;
@@ -331,6 +363,7 @@ __device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShare
         w.r_len[r] = written;
         w.rmaxd[r] = biggest;
     }
+    mark(3);
 }
 
 // cycle sums per phase (thread 0, shader clock) into info[LUF_STAMPS + k]: diagnostic, a few s_memtime per round
@@ -343,15 +376,300 @@ __device__ __forceinline__ void eliminate_row(const LuFactorWork& w, FactorShare
         }                                                              \
     } while (0)
 
+// ONE round: candidates -> competition -> conflicts -> accepted pivots -> U rows and targets -> layout -> copy + elimination -> reset.
+// `old` holds the active sub-matrix, `nw` receives the next one; `cap` is the capacity of `nw`.  Every thread of the workgroup calls
+// it; returns with the shared round state (sh.top, n_active, kbase, ubase, cur) advanced, or sh.error set.
+// `spill` (capacity `spill_cap`): where the next sub-matrix goes when `nw` is too small for it (an LDS arena that the round's fill-in
+// bound outgrows: the sub-matrix moves back to global memory; sh.spilled tells the caller).
+__device__ __forceinline__ void factor_round(LuFactorWork& w, FactorShared& sh, const LuFactorOut& out, const Arena old, const Arena nw, const int cap,
+                                             const Arena spill, const int spill_cap, const double threshold, const bool ref, const int m,
+                                             long long* stamp_sum, long long& stamp_prev) {
+    const int tid = threadIdx.x, T = LUF_THREADS;
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int n_active = sh.n_active, cur = sh.cur, top = sh.top, kbase = sh.kbase, ubase = sh.ubase;
+    const int* __restrict__ act = (cur ? w.active[1] : w.active[0]);
+    int* __restrict__ act_new = (cur ? w.active[0] : w.active[1]);
+    if (tid == 0) {
+        sh.smin = 0x7fffffff;
+        sh.best64 = NONE64;
+    }
+    __syncthreads();
+    // (1) every active row's best admissible entry
+    if (!ref) {
+        for (int e = tid; e < top; e += T) {
+            const unsigned cr = old.cr[e];
+            if (cr == HOLE) continue;
+            const int c = (int)(cr & 0xffffu), r = (int)(cr >> 16);
+            const unsigned key = candidate_key(w, r, c, old.val[e], threshold);
+            if (key != NONE32) atomicMin(&w.rowbest[r], key);
+        }
+    } else {  // the reference's rule: ONE pivot, minimum score, ties by current column position, then row position
+        unsigned long long mine = NONE64;
+        for (int e = tid; e < top; e += T) {
+            const unsigned cr = old.cr[e];
+            if (cr == HOLE) continue;
+            const int c = (int)(cr & 0xffffu), r = (int)(cr >> 16);
+            unsigned long long score = (unsigned long long)(w.r_len[r] - 1) * (unsigned long long)(w.ccount[c] - 1);
+            if (score > 0x7fffffffull) score = 0x7fffffffull;
+            const unsigned long long key = (score << 32) | ((unsigned long long)w.cpos[c] << 16) | (unsigned long long)w.rpos[r];
+            mine = key < mine ? key : mine;
+        }
+        mine = lane63_u64(wave_min_u64(mine));
+        if (lane == 0 && mine != NONE64) atomicMin(&sh.best64, mine);
+    }
+    __syncthreads();
+    LUF_STAMP(1);
+    int limit = 0;
+    if (!ref) {
+        // (2) the round's minimum score; candidates within a slack of it compete (4 x, at least + 4: lu_factor.hpp)
+        int mine = 0x7fffffff;
+        for (int t = tid; t < n_active; t += T) {
+            const unsigned key = w.rowbest[act[t]];
+            if (key != NONE32) mine = min(mine, (int)(key >> 20));
+        }
+        mine = wave_min_i32(mine);
+        if (lane == 0 && mine != 0x7fffffff) atomicMin(&sh.smin, mine);
+        __syncthreads();
+        const int smin = sh.smin;
+        if (smin == 0x7fffffff) {
+            if (tid == 0) sh.error = LUF_ERR_SINGULAR;
+            __syncthreads();
+            return;
+        }
+        limit = max(4 * smin, smin + 4);
+        // (3) the entry of each competing candidate; the best candidate per column
+        for (int e = tid; e < top; e += T) {
+            const unsigned cr = old.cr[e];
+            if (cr == HOLE) continue;
+            const int c = (int)(cr & 0xffffu), r = (int)(cr >> 16);
+            const unsigned best = w.rowbest[r];
+            if ((int)(best >> 20) > limit || (int)(best & 0xffffu) != c) continue;
+            if (candidate_key(w, r, c, old.val[e], threshold) != best) continue;
+            w.best_e[r] = e;
+            atomicMin(&w.colmark[c], priority_of(best, r));
+        }
+        __syncthreads();
+        LUF_STAMP(2);
+        // (4) conflicts: an entry (r, c) with c the pivot column of another row's candidate and r a candidate row itself -- the
+        //     two pivots are not compatible, the worse one waits for a later round
+        for (int e = tid; e < top; e += T) {
+            const unsigned cr = old.cr[e];
+            if (cr == HOLE) continue;
+            const int c = (int)(cr & 0xffffu), r = (int)(cr >> 16);
+            const unsigned pc = w.colmark[c];
+            if (pc == NONE32 || (int)(pc & 0xffffu) == r) continue;
+            const unsigned kr = w.rowbest[r];
+            if (kr == NONE32 || (int)(kr >> 20) > limit) continue;
+            const unsigned pr = priority_of(kr, r);
+            if (w.colmark[kr & 0xffffu] != pr) continue;  // row r lost its own column: no candidate
+            const unsigned loser = pc > pr ? pc : pr;
+            w.kill[loser & 0xffffu] = 1;
+        }
+        __syncthreads();
+    } else {
+        const unsigned long long best = sh.best64;
+        if (best == NONE64) {
+            if (tid == 0) sh.error = LUF_ERR_SINGULAR;
+            __syncthreads();
+            return;
+        }
+        const int rw = w.row_at[best & 0xffffull], cw = w.col_at[(best >> 16) & 0xffffull];
+        if (tid == 0) {
+            sh.ref_row = rw;
+            sh.ref_col = cw;
+        }
+        const unsigned wanted = ((unsigned)rw << 16) | (unsigned)cw;
+        for (int e = tid; e < top; e += T)
+            if (old.cr[e] == wanted) w.best_e[rw] = e;
+        __syncthreads();
+    }
+    LUF_STAMP(3);
+    // (5) the accepted pivots take consecutive positions in row order; their rows become rows of U
+    {
+        unsigned carry_n = 0, carry_u = 0;
+        for (int base = 0; base < n_active; base += T) {
+            const int t = base + tid;
+            int i = -1;
+            bool accepted = false;
+            if (t < n_active) {
+                i = act[t];
+                if (ref) {
+                    accepted = i == sh.ref_row;
+                } else {
+                    const unsigned key = w.rowbest[i];
+                    accepted = key != NONE32 && (int)(key >> 20) <= limit && w.colmark[key & 0xffffu] == priority_of(key, i) && !w.kill[i];
+                }
+            }
+            // (two fields in one word: pivots of a chunk <= 1024 in the top bits, their U entries below -- a row holds <= 256)
+            const unsigned v = accepted ? ((1u << 20) | (unsigned)(w.r_len[i] - 1)) : 0u;
+            unsigned total;
+            const unsigned ex = block_exclusive_scan(v, sh, &total);
+            if (accepted) {
+                const int k = kbase + (int)carry_n + (int)(ex >> 20);
+                const int e = w.best_e[i];
+                const int c = (int)(old.cr[e] & 0xffffu);
+                w.pivk_row[i] = k;
+                w.pivk_col[c] = k;
+                w.colmark[c] = (unsigned)i;  // from here to the end of the round: the pivot row of a pivot column (eliminate_row)
+                out.rowpos[i] = k;
+                out.colpos[c] = k;
+                out.diag[k] = old.val[e];
+                w.ut_start[k] = ubase + (int)carry_u + (int)(ex & 0xfffffu);
+            }
+            carry_n += total >> 20;
+            carry_u += total & 0xfffffu;
+        }
+        if (tid == 0) {
+            sh.n_acc = (int)carry_n;
+            sh.u_round = (int)carry_u;
+            w.ut_start[kbase + sh.n_acc] = ubase + sh.u_round;
+            if (sh.n_acc == 0) sh.error = LUF_ERR_SINGULAR;
+            if (ubase + sh.u_round > w.cap_u) sh.error = LUF_ERR_U_CAPACITY;
+            if (ref && sh.n_acc == 1) {  // swap the pivot to (k, k): positions only (decomposition/mod.rs:224-273)
+                const int k = kbase, pi = sh.ref_row, pj = sh.ref_col;
+                const int other_row = w.row_at[k], pr = w.rpos[pi];
+                w.row_at[pr] = other_row;
+                w.rpos[other_row] = pr;
+                w.row_at[k] = pi;
+                w.rpos[pi] = k;
+                const int other_col = w.col_at[k], pc = w.cpos[pj];
+                w.col_at[pc] = other_col;
+                w.cpos[other_col] = pc;
+                w.col_at[k] = pj;
+                w.cpos[pj] = k;
+            }
+        }
+    }
+    __syncthreads();
+    if (sh.error != LUF_OK) return;
+    LUF_STAMP(4);
+    // (6) pivot rows -> U (decomposition/mod.rs:60-70); the rows with an entry in a pivot column are this round's targets
+    for (int e = tid; e < top; e += T) {
+        const unsigned cr = old.cr[e];
+        if (cr == HOLE) continue;
+        const int c = (int)(cr & 0xffffu), r = (int)(cr >> 16);
+        const int k = w.pivk_row[r];
+        if (k >= 0) {
+            const int be = w.best_e[r];
+            if (e == be) continue;
+            const int at = w.ut_start[k] + (e - w.r_start[r]) - (e > be ? 1 : 0);
+            w.ut_col[at] = c;
+            w.ut_val[at] = old.val[e];
+            w.ut_row[at] = k;
+            atomicSub(&w.ccount[c], 1);
+        } else {
+            const int kc = w.pivk_col[c];
+            if (kc >= kbase) {  // (a column pivoted in an earlier round has no active entry left)
+                w.tflag[r] = 1;
+                atomicAdd(&w.growth[r], w.ut_start[kc + 1] - w.ut_start[kc] - 1);
+            }
+        }
+    }
+    __syncthreads();
+    LUF_STAMP(5);
+    // (7) layout of the next arena: the remaining rows in order, a target row with room for its fill-in
+    {
+        unsigned carry_cap = 0, carry_cnt = 0;
+        for (int base = 0; base < n_active; base += T) {
+            const int t = base + tid;
+            int i = -1;
+            bool stays = false, target = false;
+            int capacity = 0;
+            if (t < n_active) {
+                i = act[t];
+                if (w.pivk_row[i] < 0) {
+                    stays = true;
+                    target = w.tflag[i] != 0;
+                    capacity = max(0, w.r_len[i] + w.growth[i]);
+                }
+            }
+            unsigned total_cap, total_cnt;
+            const unsigned ex_cap = block_exclusive_scan((unsigned)capacity, sh, &total_cap);
+            const unsigned ex_cnt = block_exclusive_scan(stays ? ((1u << 16) | (target ? 1u : 0u)) : 0u, sh, &total_cnt);
+            if (stays) {
+                w.r_newstart[i] = (int)(carry_cap + ex_cap);
+                act_new[(carry_cnt >> 16) + (ex_cnt >> 16)] = i;
+                if (target) w.targets[(carry_cnt & 0xffffu) + (ex_cnt & 0xffffu)] = i;
+            }
+            carry_cap += total_cap;
+            carry_cnt += total_cnt;  // (rows <= 65535: neither 16-bit field overflows)
+        }
+        if (tid == 0) {
+            sh.top_new = (int)carry_cap;
+            sh.n_active_new = (int)(carry_cnt >> 16);
+            sh.n_targets = (int)(carry_cnt & 0xffffu);
+            sh.spilled = sh.top_new > cap ? 1 : 0;
+            if (sh.top_new > (sh.spilled ? spill_cap : cap)) sh.error = LUF_ERR_ARENA;
+            sh.peak = max(sh.peak, sh.top_new);
+        }
+    }
+    __syncthreads();
+    if (sh.error != LUF_OK) return;
+    LUF_STAMP(6);
+    // (8) the untouched rows are copied, the targets eliminated (decomposition/mod.rs:71-100,146-210) -- into the other arena
+    {
+        auto rewrite = [&](const Arena to) {
+            for (int e = tid; e < top; e += T) {
+                const unsigned cr = old.cr[e];
+                if (cr == HOLE) continue;
+                const int r = (int)(cr >> 16);
+                if (w.pivk_row[r] >= 0 || w.tflag[r]) continue;
+                const int at = w.r_newstart[r] + (e - w.r_start[r]);
+                to.cr[at] = cr;
+                to.val[at] = old.val[e];
+            }
+            const int n_targets = sh.n_targets;
+            for (int t = wave; t < n_targets; t += LUF_WAVES) {
+                const int r = w.targets[t];
+                const int len = w.r_len[r];
+                // (slots appended <= the pivot rows' entries = growth + pivots of the row <= growth + len)
+                if (2 * len + max(0, w.growth[r]) <= WAVE) eliminate_row<1>(w, sh, out, r, old, to, ref);
+                else eliminate_row<LUF_ROW_SLOTS>(w, sh, out, r, old, to, ref);
+            }
+        };
+        if (sh.spilled) rewrite(spill);
+        else rewrite(nw);
+    }
+    __syncthreads();
+    LUF_STAMP(7);
+    // (9) the next round's state
+    {
+        const int n_new = sh.n_active_new;
+        for (int t = tid; t < n_new; t += T) {
+            const int i = act_new[t];
+            w.r_start[i] = w.r_newstart[i];
+            w.rowbest[i] = NONE32;
+            w.kill[i] = 0;
+            w.tflag[i] = 0;
+            w.growth[i] = 0;
+        }
+        for (int c = tid; c < m; c += T) w.colmark[c] = NONE32;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        sh.top = sh.top_new;
+        sh.n_active = sh.n_active_new;
+        sh.kbase = kbase + sh.n_acc;
+        sh.ubase = ubase + sh.u_round;
+        sh.cur = cur ^ 1;
+        sh.rounds += 1;
+    }
+    __syncthreads();
+    LUF_STAMP(8);
+}
+
 // `lds_level`: which of the per-row work arrays live in LDS instead of global memory (2: all of them, m <= ~1900; 1: the ones the
-// entry passes gather from, m <= ~3500; 0: none).  The kernel reaches them through generic pointers either way: a round is a chain of
-// dependent gathers and atomics on these arrays, ~150 cycles each out of LDS against ~800 through L2.
+// entry passes gather from, m <= ~3500; 0: none); at level 2 whatever LDS is left holds the two arenas of the active sub-matrix once
+// it fits (`arena_lds` entries each).  A round is a chain of dependent gathers and atomics on these arrays: ~150 cycles each out of
+// LDS against ~800 through L2.  The pointers are derived from the dynamic LDS block unconditionally per instantiation, so that the
+// compiler emits ds_ instructions (a pointer that MAY be global or LDS compiles to flat_ accesses, which are slower than either).
 template <int lds_level>
 __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource src, LuFactorWork w_in, LuFactorOut out, double threshold,
-                                                                int reference_ties, int dense_tail) {
+                                                                int reference_ties, int dense_tail, int arena_lds) {
     extern __shared__ unsigned char luf_dynamic_lds[];
     __shared__ FactorShared sh;
     LuFactorWork w = w_in;
+    Arena lds_arena[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     if constexpr (lds_level >= 1) {
         unsigned char* at = luf_dynamic_lds;
         auto carve = [&](size_t bytes) {
@@ -378,6 +696,10 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
             w.active[0] = (int*)carve(mi);
             w.active[1] = (int*)carve(mi);
             w.ut_start = (int*)carve(mi + sizeof(int));
+            lds_arena[0].val = (double*)carve((size_t)arena_lds * sizeof(double));
+            lds_arena[1].val = (double*)carve((size_t)arena_lds * sizeof(double));
+            lds_arena[0].cr = (unsigned*)carve((size_t)arena_lds * sizeof(unsigned));
+            lds_arena[1].cr = (unsigned*)carve((size_t)arena_lds * sizeof(unsigned));
         }
     }
     __shared__ double dense[LUF_DENSE_MAX][LUF_DENSE_MAX + 1];
@@ -400,6 +722,9 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         sh.l_top = 0;
         sh.peak = 0;
         sh.dense_rows = 0;
+        sh.lds_rounds = 0;
+        sh.spilled = 0;
+        for (int k = 0; k < 6; ++k) sh.dbg[k] = 0ull;
     }
     // ---- load: the basis columns by rows into arena 0 ------------------------------------------------------------------------
     for (int i = tid; i < m; i += T) {
@@ -432,15 +757,16 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
     }
     __syncthreads();
     {
-        unsigned long long carry = 0;
+        unsigned carry = 0;
         for (int base = 0; base < m; base += T) {
             const int i = base + tid;
-            const unsigned long long v = i < m ? (unsigned long long)w.r_len[i] : 0ull;
-            unsigned long long total;
-            const unsigned long long ex = block_exclusive_scan(v, sh, &total) + carry;
+            const unsigned v = i < m ? (unsigned)w.r_len[i] : 0u;
+            unsigned total;
+            const unsigned ex = block_exclusive_scan(v, sh, &total) + carry;
             if (i < m) {
                 w.r_start[i] = (int)ex;
                 if (v == 0) sh.error = LUF_ERR_SINGULAR;
+                if (v > (unsigned)LUF_MAX_ROW) sh.error = LUF_ERR_LONG_ROW;
             }
             carry += total;
         }
@@ -448,10 +774,11 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
             sh.top = (int)carry;
             sh.peak = (int)carry;
             w.info[LUF_NNZ_B] = (int)carry;
-            if (carry > (unsigned long long)w.cap_w) sh.error = LUF_ERR_ARENA;
+            if (carry > (unsigned)w.cap_w) sh.error = LUF_ERR_ARENA;
         }
     }
     __syncthreads();
+    const Arena g0 = {w.a_cr[0], w.a_val[0]}, g1 = {w.a_cr[1], w.a_val[1]};
     if (sh.error == LUF_OK) {
         for (int j = tid; j < m; j += T) {
             const int cj = src.basis ? src.basis[j] : j;
@@ -461,9 +788,8 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
                 if (v == 0.0) continue;
                 const int row = src.row_index[e];
                 const int at = w.r_start[row] + atomicAdd(&w.tmp_cursor[row], 1);
-                w.a_col[0][at] = j;
-                w.a_row[0][at] = row;
-                w.a_val[0][at] = sign * v;
+                g0.cr[at] = ((unsigned)row << 16) | (unsigned)j;
+                g0.val[at] = sign * v;
                 atomicMax(&w.rmax[row], (unsigned long long)__double_as_longlong(fabs(v)));
             }
         }
@@ -474,269 +800,30 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
     LUF_STAMP(0);
 
     // ---- rounds ----------------------------------------------------------------------------------------------------------------
+    bool in_lds = false;  // where the active sub-matrix lives (uniform over the workgroup)
     while (sh.error == LUF_OK && sh.n_active > 0) {
-        const int n_active = sh.n_active, cur = sh.cur, top = sh.top, kbase = sh.kbase, ubase = sh.ubase;
-        if (!ref && n_active <= dense_tail) break;  // the rest goes through the dense tail
-        const int* __restrict__ act = (cur ? w.active[1] : w.active[0]);
-        const int* __restrict__ acol = (cur ? w.a_col[1] : w.a_col[0]);
-        const int* __restrict__ arow = (cur ? w.a_row[1] : w.a_row[0]);
-        const double* __restrict__ aval = (cur ? w.a_val[1] : w.a_val[0]);
-        if (tid == 0) {
-            sh.smin = 0x7fffffff;
-            sh.best64 = NONE64;
-        }
-        __syncthreads();
-        // (1) every active row's best admissible entry
-        if (!ref) {
-            for (int e = tid; e < top; e += T) {
-                const int c = acol[e];
-                if (c < 0) continue;
-                const int r = arow[e];
-                const unsigned key = candidate_key(w, r, c, aval[e], threshold);
-                if (key != NONE32) atomicMin(&w.rowbest[r], key);
-            }
-        } else {  // the reference's rule: ONE pivot, minimum score, ties by current column position, then row position
-            unsigned long long mine = NONE64;
-            for (int e = tid; e < top; e += T) {
-                const int c = acol[e];
-                if (c < 0) continue;
-                const int r = arow[e];
-                unsigned long long score = (unsigned long long)(w.r_len[r] - 1) * (unsigned long long)(w.ccount[c] - 1);
-                if (score > 0x7fffffffull) score = 0x7fffffffull;
-                const unsigned long long key = (score << 32) | ((unsigned long long)w.cpos[c] << 16) | (unsigned long long)w.rpos[r];
-                mine = key < mine ? key : mine;
-            }
-            mine = lane63_u64(wave_min_u64(mine));
-            if (lane == 0 && mine != NONE64) atomicMin(&sh.best64, mine);
-        }
-        __syncthreads();
-        LUF_STAMP(1);
-        int limit = 0;
-        if (!ref) {
-            // (2) the round's minimum score; candidates within a slack of it compete (4 x, at least + 4: lu_factor.hpp)
-            int mine = 0x7fffffff;
-            for (int t = tid; t < n_active; t += T) {
-                const unsigned key = w.rowbest[act[t]];
-                if (key != NONE32) mine = min(mine, (int)(key >> 20));
-            }
-            mine = wave_min_i32(mine);
-            if (lane == 0 && mine != 0x7fffffff) atomicMin(&sh.smin, mine);
-            __syncthreads();
-            const int smin = sh.smin;
-            if (smin == 0x7fffffff) {
-                if (tid == 0) sh.error = LUF_ERR_SINGULAR;
+        if (!ref && sh.n_active <= dense_tail) break;  // the rest goes through the dense tail
+        const int cur = sh.cur;
+        if constexpr (lds_level >= 2) {
+            if (!in_lds && arena_lds >= 256 && 4 * sh.top <= 3 * arena_lds) {  // it fits with room for a round's fill-in: move it into LDS
+                const Arena from = cur ? g1 : g0, to = cur ? lds_arena[1] : lds_arena[0];
+                const int top = sh.top;
+                for (int e = tid; e < top; e += T) {
+                    to.cr[e] = from.cr[e];
+                    to.val[e] = from.val[e];
+                }
+                in_lds = true;
                 __syncthreads();
-                break;
             }
-            limit = max(4 * smin, smin + 4);
-            // (3) the entry of each competing candidate; the best candidate per column
-            for (int e = tid; e < top; e += T) {
-                const int c = acol[e];
-                if (c < 0) continue;
-                const int r = arow[e];
-                const unsigned best = w.rowbest[r];
-                if ((int)(best >> 20) > limit || (int)(best & 0xffffu) != c) continue;
-                if (candidate_key(w, r, c, aval[e], threshold) != best) continue;
-                w.best_e[r] = e;
-                atomicMin(&w.colmark[c], priority_of(best, r));
-            }
-            __syncthreads();
-            LUF_STAMP(2);
-            // (4) conflicts: an entry (r, c) with c the pivot column of another row's candidate and r a candidate row itself -- the
-            //     two pivots are not compatible, the worse one waits for a later round
-            for (int e = tid; e < top; e += T) {
-                const int c = acol[e];
-                if (c < 0) continue;
-                const int r = arow[e];
-                const unsigned pc = w.colmark[c];
-                if (pc == NONE32 || (int)(pc & 0xffffu) == r) continue;
-                const unsigned kr = w.rowbest[r];
-                if (kr == NONE32 || (int)(kr >> 20) > limit) continue;
-                const unsigned pr = priority_of(kr, r);
-                if (w.colmark[kr & 0xffffu] != pr) continue;  // row r lost its own column: no candidate
-                const unsigned loser = pc > pr ? pc : pr;
-                w.kill[loser & 0xffffu] = 1;
-            }
-            __syncthreads();
-        } else {
-            const unsigned long long best = sh.best64;
-            if (best == NONE64) {
-                if (tid == 0) sh.error = LUF_ERR_SINGULAR;
-                __syncthreads();
-                break;
-            }
-            const int rw = w.row_at[best & 0xffffull], cw = w.col_at[(best >> 16) & 0xffffull];
-            if (tid == 0) {
-                sh.ref_row = rw;
-                sh.ref_col = cw;
-            }
-            for (int e = tid; e < top; e += T)
-                if (acol[e] == cw && arow[e] == rw) w.best_e[rw] = e;
-            __syncthreads();
-        }
-        LUF_STAMP(3);
-        // (5) the accepted pivots take consecutive positions in row order; their rows become rows of U
-        {
-            unsigned long long carry = 0;
-            for (int base = 0; base < n_active; base += T) {
-                const int t = base + tid;
-                int i = -1;
-                bool accepted = false;
-                if (t < n_active) {
-                    i = act[t];
-                    if (ref) {
-                        accepted = i == sh.ref_row;
-                    } else {
-                        const unsigned key = w.rowbest[i];
-                        accepted = key != NONE32 && (int)(key >> 20) <= limit && w.colmark[key & 0xffffu] == priority_of(key, i) && !w.kill[i];
-                    }
-                }
-                const unsigned long long v = accepted ? ((1ull << 32) | (unsigned long long)(w.r_len[i] - 1)) : 0ull;
-                unsigned long long total;
-                const unsigned long long ex = block_exclusive_scan(v, sh, &total) + carry;
-                if (accepted) {
-                    const int k = kbase + (int)(ex >> 32);
-                    const int e = w.best_e[i];
-                    const int c = acol[e];
-                    w.pivk_row[i] = k;
-                    w.pivk_col[c] = k;
-                    out.rowpos[i] = k;
-                    out.colpos[c] = k;
-                    out.diag[k] = aval[e];
-                    w.ut_start[k] = ubase + (int)(ex & 0xffffffffull);
-                }
-                carry += total;
-            }
-            if (tid == 0) {
-                sh.n_acc = (int)(carry >> 32);
-                sh.u_round = (int)(carry & 0xffffffffull);
-                w.ut_start[kbase + sh.n_acc] = ubase + sh.u_round;
-                if (sh.n_acc == 0) sh.error = LUF_ERR_SINGULAR;
-                if (ubase + sh.u_round > w.cap_u) sh.error = LUF_ERR_U_CAPACITY;
-                if (ref && sh.n_acc == 1) {  // swap the pivot to (k, k): positions only (decomposition/mod.rs:224-273)
-                    const int k = kbase, pi = sh.ref_row, pj = sh.ref_col;
-                    const int other_row = w.row_at[k], pr = w.rpos[pi];
-                    w.row_at[pr] = other_row;
-                    w.rpos[other_row] = pr;
-                    w.row_at[k] = pi;
-                    w.rpos[pi] = k;
-                    const int other_col = w.col_at[k], pc = w.cpos[pj];
-                    w.col_at[pc] = other_col;
-                    w.cpos[other_col] = pc;
-                    w.col_at[k] = pj;
-                    w.cpos[pj] = k;
-                }
+            if (in_lds) {
+                if (tid == 0) sh.lds_rounds += 1;
+                factor_round(w, sh, out, cur ? lds_arena[1] : lds_arena[0], cur ? lds_arena[0] : lds_arena[1], arena_lds, cur ? g0 : g1, w.cap_w, threshold, ref, m,
+                             stamp_sum, stamp_prev);
+                if (sh.spilled) in_lds = false;  // (uniform: written before the round's last barriers) the next sub-matrix is in global memory again
+                continue;
             }
         }
-        __syncthreads();
-        if (sh.error != LUF_OK) break;
-        LUF_STAMP(4);
-        // (6) pivot rows -> U (decomposition/mod.rs:60-70); the rows with an entry in a pivot column are this round's targets
-        for (int e = tid; e < top; e += T) {
-            const int c = acol[e];
-            if (c < 0) continue;
-            const int r = arow[e];
-            const int k = w.pivk_row[r];
-            if (k >= 0) {
-                const int be = w.best_e[r];
-                if (e == be) continue;
-                const int at = w.ut_start[k] + (e - w.r_start[r]) - (e > be ? 1 : 0);
-                w.ut_col[at] = c;
-                w.ut_val[at] = aval[e];
-                w.ut_row[at] = k;
-                atomicSub(&w.ccount[c], 1);
-            } else {
-                const int kc = w.pivk_col[c];
-                if (kc >= kbase) {  // (a column pivoted in an earlier round has no active entry left)
-                    w.tflag[r] = 1;
-                    atomicAdd(&w.growth[r], w.ut_start[kc + 1] - w.ut_start[kc] - 1);
-                }
-            }
-        }
-        __syncthreads();
-        LUF_STAMP(5);
-        // (7) layout of the next arena: the remaining rows in order, a target row with room for its fill-in
-        {
-            unsigned long long carry = 0;
-            int* __restrict__ act_new = (cur ? w.active[0] : w.active[1]);
-            for (int base = 0; base < n_active; base += T) {
-                const int t = base + tid;
-                int i = -1;
-                unsigned long long v = 0;
-                bool target = false;
-                if (t < n_active) {
-                    i = act[t];
-                    if (w.pivk_row[i] < 0) {
-                        target = w.tflag[i] != 0;
-                        const int capacity = max(0, w.r_len[i] + w.growth[i]);
-                        v = (unsigned long long)capacity | (1ull << 28) | (target ? 1ull << 46 : 0ull);
-                    }
-                }
-                unsigned long long total;
-                const unsigned long long ex = block_exclusive_scan(v, sh, &total) + carry;
-                if (v != 0) {
-                    w.r_newstart[i] = (int)(ex & 0xfffffffull);
-                    act_new[(ex >> 28) & 0x3ffffull] = i;
-                    if (target) w.targets[ex >> 46] = i;
-                }
-                carry += total;
-            }
-            if (tid == 0) {
-                sh.top_new = (int)(carry & 0xfffffffull);
-                sh.n_active_new = (int)((carry >> 28) & 0x3ffffull);
-                sh.n_targets = (int)(carry >> 46);
-                if (sh.top_new > w.cap_w) sh.error = LUF_ERR_ARENA;
-                sh.peak = max(sh.peak, sh.top_new);
-            }
-        }
-        __syncthreads();
-        if (sh.error != LUF_OK) break;
-        LUF_STAMP(6);
-        // (8) the untouched rows are copied, the targets eliminated (decomposition/mod.rs:71-100,146-210) -- into the other arena
-        {
-            int* __restrict__ ncol = (cur ? w.a_col[0] : w.a_col[1]);
-            int* __restrict__ nrow = (cur ? w.a_row[0] : w.a_row[1]);
-            double* __restrict__ nval = (cur ? w.a_val[0] : w.a_val[1]);
-            for (int e = tid; e < top; e += T) {
-                const int c = acol[e];
-                if (c < 0) continue;
-                const int r = arow[e];
-                if (w.pivk_row[r] >= 0 || w.tflag[r]) continue;
-                const int at = w.r_newstart[r] + (e - w.r_start[r]);
-                ncol[at] = c;
-                nrow[at] = r;
-                nval[at] = aval[e];
-            }
-            const int n_targets = sh.n_targets;
-            for (int t = wave; t < n_targets; t += LUF_WAVES) eliminate_row(w, sh, out, w.targets[t], cur, ref);
-        }
-        __syncthreads();
-        LUF_STAMP(7);
-        // (9) the next round's state
-        {
-            const int n_new = sh.n_active_new;
-            const int* __restrict__ act_new = (cur ? w.active[0] : w.active[1]);
-            for (int t = tid; t < n_new; t += T) {
-                const int i = act_new[t];
-                w.r_start[i] = w.r_newstart[i];
-                w.rowbest[i] = NONE32;
-                w.kill[i] = 0;
-                w.tflag[i] = 0;
-                w.growth[i] = 0;
-            }
-            for (int c = tid; c < m; c += T) w.colmark[c] = NONE32;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            sh.top = sh.top_new;
-            sh.n_active = sh.n_active_new;
-            sh.kbase = kbase + sh.n_acc;
-            sh.ubase = ubase + sh.u_round;
-            sh.cur = cur ^ 1;
-            sh.rounds += 1;
-        }
-        __syncthreads();
-        LUF_STAMP(8);
+        factor_round(w, sh, out, cur ? g1 : g0, cur ? g0 : g1, w.cap_w, cur ? g0 : g1, w.cap_w, threshold, ref, m, stamp_sum, stamp_prev);
     }
     __syncthreads();
     LUF_STAMP(8);
@@ -747,15 +834,15 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         const int* __restrict__ act = (cur ? w.active[1] : w.active[0]);
         // local column numbers: the unpivoted columns in ascending order (ordered compaction over all columns)
         {
-            unsigned long long carry = 0;
+            unsigned carry = 0;
             for (int base = 0; base < m; base += T) {
                 const int c = base + tid;
                 const bool open = c < m && out.colpos[c] < 0;
-                unsigned long long total;
-                const unsigned long long ex = block_exclusive_scan(open ? 1ull : 0ull, sh, &total) + carry;
+                unsigned total;
+                const unsigned ex = block_exclusive_scan(open ? 1u : 0u, sh, &total) + carry;
                 if (open) {
                     w.growth[c] = (int)ex;  // (growth: free between rounds) local number of column c
-                    if (ex < (unsigned long long)LUF_DENSE_MAX) dense_cols[ex] = c;
+                    if (ex < (unsigned)LUF_DENSE_MAX) dense_cols[ex] = c;
                 }
                 carry += total;
             }
@@ -765,10 +852,18 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         for (int x = tid; x < LUF_DENSE_MAX * (LUF_DENSE_MAX + 1); x += T) (&dense[0][0])[x] = 0.0;
         __syncthreads();
         if (sh.error == LUF_OK) {
-            for (int e = tid; e < top; e += T) {
-                const int c = (cur ? w.a_col[1] : w.a_col[0])[e];
-                if (c < 0) continue;
-                dense[w.tflag[(cur ? w.a_row[1] : w.a_row[0])[e]]][w.growth[c]] = (cur ? w.a_val[1] : w.a_val[0])[e];
+            auto gather = [&](const Arena from) {
+                for (int e = tid; e < top; e += T) {
+                    const unsigned cr = from.cr[e];
+                    if (cr == HOLE) continue;
+                    dense[w.tflag[cr >> 16]][w.growth[cr & 0xffffu]] = from.val[e];
+                }
+            };
+            if constexpr (lds_level >= 2) {
+                if (in_lds) gather(cur ? lds_arena[1] : lds_arena[0]);
+                else gather(cur ? g1 : g0);
+            } else {
+                gather(cur ? g1 : g0);
             }
         }
         __syncthreads();
@@ -826,9 +921,9 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
                         for (int j = s + 1; j < n; ++j) {
                             const double pj = dense[p][j];
                             if (pj == 0.0) continue;
-                            const double old = dense[lane][j], product = ratio * pj;
-                            double updated = old - product;
-                            if (updated != 0.0 && fabs(updated) <= 1e-15 * (fabs(old) + fabs(product))) updated = 0.0;
+                            const double before = dense[lane][j], product = ratio * pj;
+                            double updated = before - product;
+                            if (updated != 0.0 && fabs(updated) <= 1e-15 * (fabs(before) + fabs(product))) updated = 0.0;
                             dense[lane][j] = updated;
                         }
                     }
@@ -856,12 +951,12 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         for (int t = tid; t < nl; t += T) atomicAdd(&w.tmp_cursor[out.rowpos[w.lt_row[t]]], 1);
         __syncthreads();
         {
-            unsigned long long carry = 0;
+            unsigned carry = 0;
             for (int base = 0; base < m; base += T) {
                 const int p = base + tid;
-                const unsigned long long v = p < m ? (unsigned long long)w.tmp_cursor[p] : 0ull;
-                unsigned long long total;
-                const unsigned long long ex = block_exclusive_scan(v, sh, &total) + carry;
+                const unsigned v = p < m ? (unsigned)w.tmp_cursor[p] : 0u;
+                unsigned total;
+                const unsigned ex = block_exclusive_scan(v, sh, &total) + carry;
                 if (p < m) out.l_start[p] = (int)ex;
                 carry += total;
             }
@@ -905,6 +1000,10 @@ __global__ void __launch_bounds__(LUF_THREADS) lu_factor_kernel(LuFactorSource s
         w.info[LUF_ROUNDS] = sh.rounds;
         w.info[LUF_DENSE_ROWS] = sh.dense_rows;
         w.info[LUF_ARENA_PEAK] = sh.peak;
+        w.info[LUF_LDS_ROUNDS] = sh.lds_rounds;
+        for (int k = 0; k < 4; ++k) w.info[23 + k] = (int)(sh.dbg[k] >> 10);  // kilo-cycles summed over the eliminating waves
+        w.info[27] = (int)sh.dbg[4];
+        w.info[28] = (int)sh.dbg[5];
     }
 }
 
@@ -923,18 +1022,24 @@ void launch_lu_factor(const LuFactorSource& src, const LuFactorWork& w, const Lu
     ww.cap_u = o.cap_u;
     static PerDeviceOnce once;
     once.run([] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_factor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_factor_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_factor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_factor_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
     });
     const size_t m8 = ((size_t)w.m * sizeof(int) + 7) & ~size_t(7);
     const size_t level1 = (size_t)w.m * sizeof(double) + 8 * m8, level2 = level1 + 7 * m8 + m8 + 8;
+    const size_t budget = (size_t)140 * 1024;
     static const int forced = getenv("RELP_LUF_LDS") ? atoi(getenv("RELP_LUF_LDS")) : -1;  // diagnostic: 0 keeps every work array in global memory
-    int lds_level = level2 <= (size_t)140 * 1024 ? 2 : level1 <= (size_t)140 * 1024 ? 1 : 0;
+    int lds_level = level2 <= budget ? 2 : level1 <= budget ? 1 : 0;
     if (forced >= 0) lds_level = std::min(lds_level, forced);
-    const size_t lds = lds_level == 2 ? level2 : lds_level == 1 ? level1 : 0;
-    if (lds_level == 2) hipLaunchKernelGGL(lu_factor_kernel<2>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail);
-    else if (lds_level == 1) hipLaunchKernelGGL(lu_factor_kernel<1>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail);
-    else hipLaunchKernelGGL(lu_factor_kernel<0>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail);
+    // what LDS the per-row arrays leave holds the two arenas of the active sub-matrix (12 bytes per entry and arena) once it fits
+    int arena_lds = 0;
+    if (lds_level == 2 && !getenv("RELP_LUF_NO_LDS_ARENA")) arena_lds = (int)(((budget - level2) / 24) & ~size_t(63));
+    if (const char* limit = getenv("RELP_LUF_LDS_ARENA")) arena_lds = std::min(arena_lds, atoi(limit) & ~63);  // test hook: a small arena (spills)
+    if (arena_lds < 256) arena_lds = 0;
+    const size_t lds = (lds_level == 2 ? level2 : lds_level == 1 ? level1 : 0) + (size_t)arena_lds * 24 + 64;
+    if (lds_level == 2) hipLaunchKernelGGL(lu_factor_kernel<2>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail, arena_lds);
+    else if (lds_level == 1) hipLaunchKernelGGL(lu_factor_kernel<1>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail, 0);
+    else hipLaunchKernelGGL(lu_factor_kernel<0>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail, 0);
 }
 
 }  // namespace relp

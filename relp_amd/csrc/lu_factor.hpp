@@ -56,6 +56,7 @@ enum : int {
     LUF_NNZ_LI = 7,      // entries of L^-1 (strict) and U^-1 (with diagonal): written by the inversion kernels
     LUF_NNZ_UI = 8,
     LUF_LAYOUT = 9,      // scratch for the task builders
+    LUF_LDS_ROUNDS = 10, // rounds made with the active sub-matrix in LDS
     LUF_STAMPS = 12,     // 11 cycle sums (units of 16 shader cycles): load | candidates | competition | conflicts | accept | U rows +
                          // targets | layout | copy + eliminate | reset | dense tail | finalisation
     LUF_INFO_WORDS = 32
@@ -80,8 +81,7 @@ constexpr int LUF_DENSE_MAX = 32;                 // the dense tail: one lane pe
 struct LuFactorWork {
     int m = 0;
     int cap_w = 0;                 // entries per arena
-    int* a_col[2] = {nullptr, nullptr};   // arena: column (basis slot) of the entry, -1: hole
-    int* a_row[2] = {nullptr, nullptr};
+    unsigned* a_cr[2] = {nullptr, nullptr};   // arena: row << 16 | column (basis slot) of the entry, 0xffffffff: hole
     double* a_val[2] = {nullptr, nullptr};
     int* r_start = nullptr;        // [m] first entry of the row in the current arena
     int* r_len = nullptr;          // [m]

@@ -141,9 +141,10 @@ def test_device_factorises_real_bases(name, fraction):
     host = lu_factor_host(columns)
     fill_device, fill_host = f["nnz_lower"] + f["nnz_upper"], host["nnz_lower"] + host["nnz_upper"]
     print("%s at %.0f %%: m %d nnz(B) %d | device: %d rounds + %d dense rows, nnz(L) + nnz(U) %d, %.1f us | host %d" % (
-        name, 100 * fraction, m, f["info"][6], f["info"][3], f["info"][4], fill_device, f["info"][31] / 10.0, fill_host))
+        name, 100 * fraction, m, f["info"][6], f["info"][3], f["info"][4], fill_device, f["info"][31] / 10.0, fill_host) + " (%d rounds in LDS)" % f["info"][10])
     print("   kcycles: load %d | candidates %d | competition %d | conflicts %d | accept %d | U rows + targets %d | layout %d | copy + eliminate %d | "
           "reset %d | dense tail %d | finalisation %d" % tuple(16 * v // 1000 for v in f["info"][12:23]))
+    print("   eliminating waves, kcycles summed: preamble %d | pivot set-up %d | entry loop %d | write-out %d; %d (target, pivot) pairs, %d targets" % tuple(f["info"][23:29]))
     assert fill_device <= 1.35 * fill_host + 64
     assert f["info"][3] <= max(8, m // 8)
 
@@ -205,3 +206,26 @@ def test_device_inverts_the_triangles_of_real_bases(name, fraction):
     assert np.abs(Li @ L - np.eye(m)).max() < 1e-7 and np.abs(Ui @ U - np.eye(m)).max() < 1e-7
     print("%s at %.0f %%: nnz(L) + nnz(U) + m %d -> nnz(L^-1) + nnz(U^-1) %d, factorisation + inversion %.1f us" % (
         name, 100 * fraction, f["nnz_lower"] + f["nnz_upper"] + m, inv["info"][7] + inv["info"][8], inv["info"][31] / 10.0))
+
+
+@pytest.mark.parametrize("arena", [1024, 1536, 2048])
+def test_the_lds_arena_spills_back_to_global_memory(monkeypatch, arena):
+    """The active sub-matrix moves into LDS once it fits (3/4 of the arena) and back to global memory when a round's fill-in bound
+    outgrows the arena: with a small arena (RELP_LUF_LDS_ARENA) both moves happen, repeatedly; the factors are the same bits as with
+    the sub-matrix in global memory throughout (RELP_LUF_NO_LDS_ARENA)."""
+    columns = basis_columns("25FV47", 1.0)
+    m = len(columns)
+    A = np.zeros((m, m))
+    for j, column in enumerate(columns):
+        for i, v in column:
+            A[i, j] = v
+    monkeypatch.setenv("RELP_LUF_NO_LDS_ARENA", "1")
+    plain = lu_factor_device(columns)
+    assert plain["info"][10] == 0
+    monkeypatch.delenv("RELP_LUF_NO_LDS_ARENA")
+    monkeypatch.setenv("RELP_LUF_LDS_ARENA", str(arena))
+    f = lu_factor_device(columns)
+    check_factors(f, A, columns)
+    assert 0 < f["info"][10] <= f["info"][3]
+    for key in ("rowpos", "colpos", "lower_rows", "upper_rows", "diag"):
+        assert f[key] == plain[key], key
