@@ -16,6 +16,7 @@
 #include "lu_factor.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "lu.hpp"
@@ -35,8 +36,11 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 struct TaskShared {
     unsigned long long scan[LUT_WAVES + 2];
     int cursor;
+    int next_row;
+    int stuck_row, stuck_on;
     int error;
     int totals[16];
+    unsigned long long dbg[4];  // cycle sums over the waves (lane 0): waiting for rows | streaming + accumulating | emitting | rows
 };
 
 __device__ __forceinline__ unsigned long long t_wave_inclusive_scan(unsigned long long v) {
@@ -79,8 +83,13 @@ __device__ __forceinline__ int t_group_log2(int n) {  // smallest g with 4 << g 
     return g;
 }
 // a finished row's descriptor: (length + 1) << 32 | first entry in the raw arena; 0: not finished yet
-__device__ __forceinline__ unsigned long long load_acquire_wg(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void store_release_wg(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (the descriptors live in LDS: a poll is a ds_read, ~100 cycles, where a word in global memory cost an L2 round trip per look.
+//  Plain volatile LDS accesses with explicit fences: the row's entries are global stores, the release waits for them.)
+__device__ __forceinline__ unsigned long long poll_descriptor(volatile lds_u64_t* p) { return *p; }
+__device__ __forceinline__ void publish_descriptor(volatile lds_u64_t* p, unsigned long long v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    *p = v;
+}
 __device__ __forceinline__ unsigned long long row_descriptor(int start, int len) { return ((unsigned long long)(unsigned)(len + 1) << 32) | (unsigned)start; }
 
 // One row of an inverse by one wave.  `src_*`: the entries (j, f_ij) of row i of the factor; `UPPER`: row of U^-1 (starts from e_i,
@@ -88,9 +97,15 @@ __device__ __forceinline__ unsigned long long row_descriptor(int start, int len)
 template <bool ACC_LDS, bool UPPER>
 __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i, const int* src_col, const double* src_val, const int s, const int e,
                            const double scale, volatile lds_f64_t* acc_lds, double* acc_glb, volatile lds_u64_t* bits, const int words,
-                           const int arena_first) {
+                           const int arena_first, volatile lds_u64_t* desc) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int f = UPPER ? 1 : 0;
+    long long t_mark = clock64();
+    auto mark = [&](int k) {
+        const long long now = clock64();
+        if (lane == 0) atomicAdd(&sh.dbg[k], (unsigned long long)(now - t_mark));
+        t_mark = now;
+    };
     auto add = [&](int c, double delta) {  // (the lanes of one step hold distinct columns)
         if (ACC_LDS) acc_lds[c] = acc_lds[c] + delta;
         else acc_glb[c] = acc_glb[c] + delta;
@@ -105,21 +120,65 @@ __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i,
             j = src_col[x0 + lane];
             fij = src_val[x0 + lane];
             unsigned long long d;
-            while ((d = load_acquire_wg(&iw.raw_desc[f][j])) == 0ull) __builtin_amdgcn_s_sleep(1);
+            int spins = 0;
+            while ((d = poll_descriptor(desc + j)) == 0ull) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 21)) {  // (a row that never arrives: reported, not waited for -- about 0.1 s)
+                    sh.error = LUF_ERR_DATAFLOW;
+                    sh.stuck_row = i;
+                    sh.stuck_on = j;
+                    d = row_descriptor(0, 0);
+                    break;
+                }
+            }
             nj = (int)(d >> 32) - 1;
             sj = (int)(unsigned)d;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the rows read below were written before their descriptors
+        mark(0);
         const int cnt = min(WAVE, e - x0);
-        for (int y = 0; y < cnt; ++y) {
-            const int jj = t_lane_value(j, y), sjj = t_lane_value(sj, y), njj = t_lane_value(nj, y);
-            const double factor = t_lane_value(fij, y);
-            if (!UPPER && lane == 0) add(jj, -factor);  // the unit diagonal of row jj of L^-1
-            for (int z0 = 0; z0 < njj; z0 += WAVE)
-                if (z0 + lane < njj) add(iw.raw_col[sjj + z0 + lane], -factor * iw.raw_val[sjj + z0 + lane]);
-            // (global accumulators: the next row's read-modify-writes must see these stores -- another lane may hold the column then)
-            if (!ACC_LDS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // The rows read are streamed FOUR at a time: their first 64 entries are requested together (one global round trip for four
+        // source rows instead of four), then accumulated one source row after the other -- in source order, so that a column's sum has
+        // one order whatever the timing.  The rest of a long source row follows in batches of four pieces.
+        constexpr int PF = 4;
+        for (int y0 = 0; y0 < cnt; y0 += PF) {
+            int jj[PF], sjj[PF], njj[PF], c0[PF];
+            double factor[PF], v0[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const bool live = y0 + u < cnt;
+                const int y = live ? y0 + u : y0;
+                jj[u] = t_lane_value(j, y);
+                sjj[u] = t_lane_value(sj, y);
+                njj[u] = live ? t_lane_value(nj, y) : -1;  // -1: no such source
+                factor[u] = t_lane_value(fij, y);
+                c0[u] = lane < njj[u] ? iw.raw_col[sjj[u] + lane] : -1;
+                v0[u] = lane < njj[u] ? iw.raw_val[sjj[u] + lane] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (njj[u] < 0) continue;  // (wave-uniform)
+                if (!UPPER && lane == 0) add(jj[u], -factor[u]);  // the unit diagonal of row jj of L^-1
+                if (c0[u] >= 0) add(c0[u], -factor[u] * v0[u]);
+                for (int z0 = WAVE; z0 < njj[u]; z0 += PF * WAVE) {
+                    int cz[PF];
+                    double vz[PF];
+#pragma unroll
+                    for (int t = 0; t < PF; ++t) {
+                        const int z = z0 + t * WAVE + lane;
+                        cz[t] = z < njj[u] ? iw.raw_col[sjj[u] + z] : -1;
+                        vz[t] = z < njj[u] ? iw.raw_val[sjj[u] + z] : 0.0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < PF; ++t)
+                        if (cz[t] >= 0) add(cz[t], -factor[u] * vz[t]);
+                }
+                // (global accumulators: the next row's read-modify-writes must see these stores -- another lane may hold the column then)
+                if (!ACC_LDS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
         }
     }
+    mark(1);
     // emit in column order: the set bits of the bitmap, word by word
     int total = 0;
     for (int w0 = 0; w0 < words; w0 += WAVE) {
@@ -169,8 +228,10 @@ __device__ void invert_row(const LuInverseWork& iw, TaskShared& sh, const int i,
     if (lane == 0) {
         iw.raw_len[f][i] = total;
         iw.raw_start[f][i] = at;
-        store_release_wg(&iw.raw_desc[f][i], row_descriptor(at, total));
+        publish_descriptor(desc + i, row_descriptor(at, total));
+        atomicAdd(&sh.dbg[3], 1ull);
     }
+    mark(2);
 }
 
 // Two workgroups: block 0 inverts L, block 1 inverts U (independent; each has its own half of the raw arena and its own waves).
@@ -184,41 +245,57 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac,
     const int words = (m + 63) / 64;
     const int f = blockIdx.x;  // 0: L^-1, 1: U^-1
     if (status_in && status_in[LUF_STATUS] != LUF_OK) return;  // the factorisation failed: nothing to invert (the host falls back)
-    volatile lds_u64_t* bits_all = (volatile lds_u64_t*)dyn_lds;
-    volatile lds_f64_t* acc_all = (volatile lds_f64_t*)(dyn_lds + (size_t)LUT_WAVES * words * sizeof(unsigned long long));
+    volatile lds_u64_t* desc = (volatile lds_u64_t*)dyn_lds;      // [m] descriptors of the finished rows
+    volatile lds_u64_t* bits_all = (volatile lds_u64_t*)(dyn_lds + (size_t)m * sizeof(unsigned long long));
+    volatile lds_f64_t* acc_all = (volatile lds_f64_t*)(dyn_lds + ((size_t)m + (size_t)LUT_WAVES * words) * sizeof(unsigned long long));
     double* acc_block = iw.acc + (size_t)f * LUT_WAVES * m;
     if (tid == 0) {
         sh.cursor = 0;
+        sh.next_row = 0;
         sh.error = LUF_OK;
+        for (int k = 0; k < 4; ++k) sh.dbg[k] = 0ull;
     }
+    const long long t_kernel = clock64();
     for (int x = tid; x < LUT_WAVES * words; x += T) bits_all[x] = 0ull;
     if (ACC_LDS)
         for (int x = tid; x < LUT_WAVES * m; x += T) acc_all[x] = 0.0;
     else
         for (int x = tid; x < LUT_WAVES * m; x += T) acc_block[x] = 0.0;
-    for (int i = tid; i < m; i += T) iw.raw_desc[f][i] = 0ull;
+    for (int i = tid; i < m; i += T) desc[i] = 0ull;
     __syncthreads();
     volatile lds_u64_t* bits = bits_all + (size_t)wave * words;
     volatile lds_f64_t* acc_lds = acc_all + (size_t)wave * m;
     double* acc_glb = acc_block + (size_t)wave * m;
     const int arena_first = f * (iw.raw_cap / 2);
-    if (f == 0) {
-        for (int i = wave; i < m; i += LUT_WAVES) {  // L^-1, ascending
+    // Rows are CLAIMED in dependency order from one counter (a wave that waits for a row holds up nothing but its own row; with a fixed
+    // row -> wave map a stalled wave delayed every later row of its own).  The smallest unfinished row is always in progress.
+    const bool static_rows = iw.static_rows != 0;
+    for (int turn = 0;; ++turn) {
+        int k = 0;
+        if (static_rows) {
+            k = wave + turn * LUT_WAVES;
+        } else {
+            if (lane == 0) k = atomicAdd(&sh.next_row, 1);
+            k = t_lane_value(k, 0);
+        }
+        if (k >= m) break;
+        if (f == 0) {  // L^-1, ascending
+            const int i = k;
             const int s = fac.l_start[i], e = fac.l_start[i + 1];
             if (s == e) {
                 if (lane == 0) {
                     iw.raw_len[0][i] = 0;
                     iw.raw_start[0][i] = arena_first;
-                    store_release_wg(&iw.raw_desc[0][i], row_descriptor(arena_first, 0));
+                    publish_descriptor(desc + i, row_descriptor(arena_first, 0));
                 }
                 continue;
             }
-            invert_row<ACC_LDS, false>(iw, sh, i, fac.l_col, fac.l_val, s, e, 1.0, acc_lds, acc_glb, bits, words, arena_first);
-        }
-    } else {
-        for (int i = m - 1 - wave; i >= 0; i -= LUT_WAVES)  // U^-1, descending
+            invert_row<ACC_LDS, false>(iw, sh, i, fac.l_col, fac.l_val, s, e, 1.0, acc_lds, acc_glb, bits, words, arena_first, desc);
+        } else {       // U^-1, descending
+            const int i = m - 1 - k;
             invert_row<ACC_LDS, true>(iw, sh, i, fac.u_col, fac.u_val, fac.u_start[i], fac.u_start[i + 1], 1.0 / fac.diag[i], acc_lds, acc_glb, bits, words,
-                                      arena_first);
+                                      arena_first, desc);
+        }
     }
     __syncthreads();
     // ---- this inverse by rows, compact, in row order (rows are already sorted by column) ----------------------------------------
@@ -250,6 +327,15 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac,
         __syncthreads();
     }
     if (tid == 0 && sh.error != LUF_OK) iw.info[LUF_STATUS] = sh.error;
+    if (tid == 0) {  // diagnostic: kilo-cycles of this block -- whole kernel | waiting | streaming + accumulating | emitting (summed over the waves)
+        int* out = iw.info + 23 - 4 * f;  // words 23.. for L^-1 (block 0), 19.. for U^-1 (block 1)
+        out[0] = (int)((clock64() - t_kernel) >> 10);
+        if (sh.error == LUF_ERR_DATAFLOW) {
+            iw.info[29] = sh.stuck_row;
+            iw.info[30] = sh.stuck_on;
+        }
+        for (int k = 0; k < 3; ++k) out[1 + k] = (int)(sh.dbg[k] >> 10);
+    }
 }
 
 // Transposes of the two inverses (lists 2 and 3) and the compact records of all four lists.
@@ -471,14 +557,17 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_pack_inverse_kernel(DeviceLU l
 
 size_t lu_invert_lds_bytes(int m, bool* acc_in_lds) {
     const size_t words = (size_t)(m + 63) / 64;
+    const size_t descriptors = (size_t)m * sizeof(unsigned long long);
     const size_t bitmap = (size_t)LUT_WAVES * words * sizeof(unsigned long long);
     const size_t acc = (size_t)LUT_WAVES * m * sizeof(double);
-    const bool fits = bitmap + acc <= (size_t)120 * 1024;
+    const bool fits = descriptors + bitmap + acc <= (size_t)140 * 1024;
     if (acc_in_lds) *acc_in_lds = fits;
-    return bitmap + (fits ? acc : 0);
+    return descriptors + bitmap + (fits ? acc : 0);
 }
 
-void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw, const int* status_in, hipStream_t stream) {
+void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw_in, const int* status_in, hipStream_t stream) {
+    LuInverseWork iw = iw_in;
+    iw.static_rows = getenv("RELP_LUI_STATIC_ROWS") ? 1 : 0;  // diagnostic: the fixed row -> wave map
     bool in_lds = false;
     const size_t lds = lu_invert_lds_bytes(iw.m, &in_lds);
     static PerDeviceOnce once;

@@ -69,7 +69,8 @@ enum : int {
     LUF_ERR_L_CAPACITY = 4,
     LUF_ERR_U_CAPACITY = 5,
     LUF_ERR_INVERSE_CAPACITY = 6,
-    LUF_ERR_TASK_CAPACITY = 7
+    LUF_ERR_TASK_CAPACITY = 7,
+    LUF_ERR_DATAFLOW = 8    // the inversion waited for a row that never arrived (a bug, reported instead of hanging)
 };
 
 constexpr int LUF_THREADS = 1024;
@@ -145,6 +146,7 @@ struct LuInverseWork {
     int* cursor = nullptr;             // [m + 1]
     int* tmp_idx = nullptr; int* tmp_col = nullptr; double* tmp_val = nullptr;   // [cap]
     int* row_rank = nullptr; int* row_xoff = nullptr; int* row_first = nullptr;  // [m]
+    int static_rows = 0;               // diagnostic: rows by a fixed row -> wave map instead of being claimed
     int cap_extra_l = 0, cap_extra_u = 0;   // capacity of the extras arenas of the task lists (DeviceLU: x_idx / x_val)
     int* info = nullptr;               // the factorisation's info words (LuFactorWork::info)
 };

@@ -1535,7 +1535,10 @@ void Solver::refactor_lu(bool refresh_vectors) {
     src.basis = d_.basis;
     src.flipped = bounded_ ? d_.flipped : nullptr;
     const double threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
-    lu_.refactor_device(src, threshold, 0, 32, d_.ctl, ST_REFACTOR_FAILED, stream_);
+    // (dense tail: the last rows through a dense LU out of LDS.  It saves the factorisation its slowest rounds but makes the ends of both
+    //  triangles dense, and the INVERTED triangles pay for that -- more entries per product and a serial chain in the inversion)
+    static const int dense_tail = getenv("RELP_LUF_DENSE_TAIL") ? atoi(getenv("RELP_LUF_DENSE_TAIL")) : 8;
+    lu_.refactor_device(src, threshold, 0, dense_tail, d_.ctl, ST_REFACTOR_FAILED, stream_);
     binv_identity_ = false;
     if (refresh_vectors) {
         launch_lu_xb(d_, lu_.device(), stream_);

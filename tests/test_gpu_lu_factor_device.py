@@ -206,6 +206,8 @@ def test_device_inverts_the_triangles_of_real_bases(name, fraction):
     assert np.abs(Li @ L - np.eye(m)).max() < 1e-7 and np.abs(Ui @ U - np.eye(m)).max() < 1e-7
     print("%s at %.0f %%: nnz(L) + nnz(U) + m %d -> nnz(L^-1) + nnz(U^-1) %d, factorisation + inversion %.1f us" % (
         name, 100 * fraction, f["nnz_lower"] + f["nnz_upper"] + m, inv["info"][7] + inv["info"][8], inv["info"][31] / 10.0))
+    print("   inversion, kcycles: L^-1 block %d wall (waves summed: waiting %d | streaming + accumulating %d | emitting %d); U^-1 block %d wall (%d | %d | %d)" % (
+        tuple(inv["info"][23:27]) + tuple(inv["info"][19:23])))
 
 
 @pytest.mark.parametrize("arena", [1024, 1536, 2048])
