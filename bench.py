@@ -653,7 +653,9 @@ def single_lp(args, ctx):
     pmc_names = {"price": dense_price if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
                  "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
     tag = args.workload + (("_lu" if args.carry == 1 else "_lui") if lu_carry else "")
-    for candidate in ("r3_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % args.workload,
+    if lu_carry and args.lu_refactor == 1:
+        tag += "_device_refactor"
+    for candidate in ("r4_%s_pmc_traffic.json" % tag, "r3_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % args.workload,
                       "r1_%s_pmc_traffic.json" % args.workload):
         pmc = os.path.join(ROOT, "profiles", candidate)
         if traffic is None and os.path.exists(pmc):

@@ -267,16 +267,16 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac,
     volatile lds_f64_t* acc_lds = acc_all + (size_t)wave * m;
     double* acc_glb = acc_block + (size_t)wave * m;
     const int arena_first = f * (iw.raw_cap / 2);
-    // Rows are CLAIMED in dependency order from one counter (a wave that waits for a row holds up nothing but its own row; with a fixed
-    // row -> wave map a stalled wave delayed every later row of its own).  The smallest unfinished row is always in progress.
+    // Rows are taken in dependency order, row k by wave k mod 16 (or claimed from a counter: see launch_lu_invert).  The smallest
+    // unfinished row is always in progress, and everything it reads is finished.
     const bool static_rows = iw.static_rows != 0;
     for (int turn = 0;; ++turn) {
         int k = 0;
         if (static_rows) {
             k = wave + turn * LUT_WAVES;
         } else {
-            if (lane == 0) k = atomicAdd(&sh.next_row, 1);
-            k = t_lane_value(k, 0);
+            k = atomicAdd(&sh.next_row, lane == 0 ? 1 : 0);  // (every lane takes part, lane 0 adds the one: see lu_factor.hip)
+            k = __builtin_amdgcn_readfirstlane(k);
         }
         if (k >= m) break;
         if (f == 0) {  // L^-1, ascending
@@ -567,7 +567,9 @@ size_t lu_invert_lds_bytes(int m, bool* acc_in_lds) {
 
 void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw_in, const int* status_in, hipStream_t stream) {
     LuInverseWork iw = iw_in;
-    iw.static_rows = getenv("RELP_LUI_STATIC_ROWS") ? 1 : 0;  // diagnostic: the fixed row -> wave map
+    // (rows go to the waves by a fixed map, row k to wave k mod 16; RELP_LUI_CLAIM_ROWS=1: claimed from a counter instead -- measured slower,
+    //  the claim is an LDS atomic every lane of the wave takes part in: 1.42 M against 1.22 M cycles for the L^-1 block of 25FV47)
+    iw.static_rows = getenv("RELP_LUI_CLAIM_ROWS") ? 0 : 1;
     bool in_lds = false;
     const size_t lds = lu_invert_lds_bytes(iw.m, &in_lds);
     static PerDeviceOnce once;

@@ -142,7 +142,7 @@ struct FactorShared {
     unsigned long long best64;
     int smin;
     int n_active, kbase, ubase, top, n_targets, cur, error, n_acc, rounds, l_top, top_new, n_active_new, u_round, ref_row, ref_col, peak;
-    int dense_rows, lds_rounds, spilled;
+    int dense_rows, lds_rounds, spilled, next_target;
     unsigned long long dbg[6];  // diagnostic cycle sums of the eliminating waves (lane 0): preamble | pivot set-up | entry loop | write-out | pairs | targets
 };
 
@@ -385,7 +385,7 @@ __device__ __forceinline__ void factor_round(LuFactorWork& w, FactorShared& sh, 
                                              const Arena spill, const int spill_cap, const double threshold, const bool ref, const int m,
                                              long long* stamp_sum, long long& stamp_prev) {
     const int tid = threadIdx.x, T = LUF_THREADS;
-    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int lane = tid & (WAVE - 1);
     const int n_active = sh.n_active, cur = sh.cur, top = sh.top, kbase = sh.kbase, ubase = sh.ubase;
     const int* __restrict__ act = (cur ? w.active[1] : w.active[0]);
     int* __restrict__ act_new = (cur ? w.active[0] : w.active[1]);
@@ -598,6 +598,7 @@ __device__ __forceinline__ void factor_round(LuFactorWork& w, FactorShared& sh, 
             sh.top_new = (int)carry_cap;
             sh.n_active_new = (int)(carry_cnt >> 16);
             sh.n_targets = (int)(carry_cnt & 0xffffu);
+            sh.next_target = 0;
             sh.spilled = sh.top_new > cap ? 1 : 0;
             if (sh.top_new > (sh.spilled ? spill_cap : cap)) sh.error = LUF_ERR_ARENA;
             sh.peak = max(sh.peak, sh.top_new);
@@ -618,8 +619,20 @@ __device__ __forceinline__ void factor_round(LuFactorWork& w, FactorShared& sh, 
                 to.cr[at] = cr;
                 to.val[at] = old.val[e];
             }
+            // (nothing a target produces depends on which wave eliminated it)
             const int n_targets = sh.n_targets;
-            for (int t = wave; t < n_targets; t += LUF_WAVES) {
+            const bool fixed_map = w.fixed_target_map != 0;
+            for (int turn = 0;; ++turn) {
+                int t = 0;
+                if (fixed_map) {
+                    t = (int)(threadIdx.x / WAVE) + turn * LUF_WAVES;
+                } else {
+                    // (every lane takes part, lane 0 adds the one: `if (lane == 0) t = atomicAdd(..); t = readlane(t, 0)` at the head of a
+                    //  for (;;) loop compiled to a loop that never ends with this toolchain -- twice, here and in the inversion)
+                    t = atomicAdd(&sh.next_target, lane == 0 ? 1 : 0);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                }
+                if (t >= n_targets) break;
                 const int r = w.targets[t];
                 const int len = w.r_len[r];
                 // (slots appended <= the pivot rows' entries = growth + pivots of the row <= growth + len)
@@ -1018,6 +1031,9 @@ void launch_lu_factor(const LuFactorSource& src, const LuFactorWork& w, const Lu
     o.cap_l = std::min(out.cap_l, w.cap_l);
     o.cap_u = std::min(out.cap_u, w.cap_u);
     LuFactorWork ww = w;
+    // (targets go to the waves by a fixed map; RELP_LUF_CLAIM_TARGETS=1 lets the waves claim them from a counter instead -- balanced, but
+    //  the claim, an LDS atomic every lane of the wave takes part in, costs more than the imbalance: 2.0 M against 0.96 M cycles on 25FV47)
+    ww.fixed_target_map = getenv("RELP_LUF_CLAIM_TARGETS") ? 0 : 1;
     ww.cap_l = o.cap_l;
     ww.cap_u = o.cap_u;
     static PerDeviceOnce once;
