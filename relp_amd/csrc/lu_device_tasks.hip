@@ -338,67 +338,108 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_invert_kernel(LuFactorOut fac,
     }
 }
 
-// Transposes of the two inverses (lists 2 and 3) and the compact records of all four lists.
-__global__ void __launch_bounds__(LUT_THREADS) lu_pack_inverse_kernel(DeviceLU lu, LuInverseWork iw, Ctl* ctl, int failed_status) {
+// Transposes of the two inverses (lists 2 and 3): two workgroups, block f turns list f (by rows) into its column orientation.
+__global__ void __launch_bounds__(LUT_THREADS) lu_transpose_inverse_kernel(LuInverseWork iw_in, Ctl* ctl, int failed_status) {
     __shared__ TaskShared sh;
     const int tid = threadIdx.x, T = LUT_THREADS;
     const int lane = tid & (WAVE - 1);
+    LuInverseWork iw = iw_in;
     const int m = iw.m;
     if (iw.info[LUF_STATUS] != LUF_OK) {
         if (tid == 0 && ctl) ctl->status = failed_status;  // the pivots enqueued behind this become no-ops; the host refactorises
         return;
     }
-    if (tid == 0) sh.error = LUF_OK;
+    iw.cursor += (size_t)blockIdx.x * LUT_WAVES * m;  // (each block its own counters)
     // ---- column orientations: list 2 = U^-1 by columns (from list 1), list 3 = L^-1 by columns (from list 0) -------------------
-    for (int f = 0; f < 2; ++f) {
-        const int dst = f == 0 ? 3 : 2;
-        const int* __restrict__ rs = iw.csr_start[f];
-        const int* __restrict__ ri = iw.csr_idx[f];
-        const double* __restrict__ rv = iw.csr_val[f];
+    {
+        const int f = blockIdx.x;
+        const int* __restrict__ rs = f == 0 ? iw.csr_start[0] : iw.csr_start[1];
+        const int* __restrict__ ri = f == 0 ? iw.csr_idx[0] : iw.csr_idx[1];
+        const double* __restrict__ rv = f == 0 ? iw.csr_val[0] : iw.csr_val[1];
+        int* __restrict__ ds = f == 0 ? iw.csr_start[3] : iw.csr_start[2];
+        int* __restrict__ di = f == 0 ? iw.csr_idx[3] : iw.csr_idx[2];
+        double* __restrict__ dv = f == 0 ? iw.csr_val[3] : iw.csr_val[2];
         const int nnz = rs[m];
-        for (int c = tid; c <= m; c += T) iw.cursor[c] = 0;
+        // A STABLE transpose without a sort: the rows are cut into sixteen consecutive chunks, one per wave; a wave counts its chunk's
+        // entries per column (its own row of counters), a thread per column turns the sixteen counts into the chunks' first positions
+        // inside the column, and every wave then walks its rows IN ORDER handing out positions from its own counters -- the rows of a
+        // column come out ascending whatever the timing.  (Round 4's first form scattered with one atomic cursor per column and
+        // rank-sorted every column afterwards: 193 us per refactorisation of 25FV47.)
+        const int wave = tid / WAVE;
+        const int chunk_rows = (m + LUT_WAVES - 1) / LUT_WAVES;
+        const int row0 = min(m, wave * chunk_rows), row1 = min(m, row0 + chunk_rows);
+        int* __restrict__ counts = iw.cursor;   // [16][m]
+        int* __restrict__ mine = counts + (size_t)wave * m;
+        for (int x = tid; x < LUT_WAVES * m; x += T) counts[x] = 0;
         __syncthreads();
-        for (int x = tid; x < nnz; x += T) atomicAdd(&iw.cursor[ri[x]], 1);
+        // (the counting pass needs no order: the chunk's entries are one contiguous range, walked flat)
+        for (int x = rs[row0] + lane; x < rs[row1]; x += WAVE) atomicAdd(&mine[ri[x]], 1);  // (no value returned: nothing to wait for)
         __syncthreads();
         {
             unsigned long long carry = 0;
             for (int base = 0; base < m; base += T) {
                 const int c = base + tid;
-                const unsigned long long v = c < m ? (unsigned long long)iw.cursor[c] : 0ull;
+                unsigned long long v = 0;
+                if (c < m) {
+                    int running = 0;
+                    for (int w = 0; w < LUT_WAVES; ++w) {
+                        const int t = counts[(size_t)w * m + c];
+                        counts[(size_t)w * m + c] = running;
+                        running += t;
+                    }
+                    v = (unsigned long long)running;
+                }
                 unsigned long long total;
                 const unsigned long long ex = t_block_exclusive_scan(v, sh, &total) + carry;
-                if (c < m) iw.csr_start[dst][c] = (int)ex;
+                if (c < m) ds[c] = (int)ex;
                 carry += total;
             }
-            if (tid == 0) iw.csr_start[dst][m] = nnz;
+            if (tid == 0) {
+                ds[m] = nnz;
+                if ((int)carry != nnz) iw.info[LUF_STATUS] = LUF_ERR_DATAFLOW;
+            }
         }
         __syncthreads();
-        // scatter with an atomic cursor, then rank-sort every column by row: the order in which the atomics land leaves no trace
-        for (int c = tid; c < m; c += T) iw.cursor[c] = 0;
-        __syncthreads();
-        for (int i = tid / WAVE; i < m; i += LUT_WAVES)
-            for (int x = rs[i] + lane; x < rs[i + 1]; x += WAVE) {
-                const int c = ri[x];
-                const int at = iw.csr_start[dst][c] + atomicAdd(&iw.cursor[c], 1);
-                iw.tmp_idx[at] = i;
-                iw.tmp_val[at] = rv[x];
-                iw.tmp_col[at] = c;
+        for (int i0 = row0; i0 < row1; i0 += WAVE) {  // (the row starts of 64 rows in one load, then row after row)
+            const int my_start = i0 + lane <= row1 ? rs[min(i0 + lane, m)] : 0;
+            const int my_end = i0 + lane < row1 ? rs[i0 + lane + 1] : 0;
+            const int rows_here = min(WAVE, row1 - i0);
+            for (int y = 0; y < rows_here; ++y) {
+                const int a = t_lane_value(my_start, y), b = t_lane_value(my_end, y);
+                for (int x = a + lane; x < b; x += WAVE) {
+                    const int c = ri[x];
+                    const int at = ds[c] + atomicAdd(&mine[c], 1);  // (this wave's counter only: positions in row order)
+                    di[at] = i0 + y;
+                    dv[at] = rv[x];
+                }
             }
-        __syncthreads();
-        for (int x = tid; x < nnz; x += T) {
-            const int c = iw.tmp_col[x], i = iw.tmp_idx[x];
-            const int cs = iw.csr_start[dst][c], ce = iw.csr_start[dst][c + 1];
-            int rank = 0;
-            for (int y = cs; y < ce; ++y) rank += iw.tmp_idx[y] < i ? 1 : 0;
-            iw.csr_idx[dst][cs + rank] = i;
-            iw.csr_val[dst][cs + rank] = iw.tmp_val[x];
         }
         __syncthreads();
     }
+    (void)lane;
+    (void)sh;
+}
+
+// The compact records: four workgroups, block k packs list k (0 L^-1 by rows, 1 U^-1 by rows, 2 U^-1 by columns, 3 L^-1 by columns).
+__global__ void __launch_bounds__(LUT_THREADS) lu_pack_inverse_kernel(DeviceLU lu, LuInverseWork iw_in, Ctl* ctl, int failed_status) {
+    __shared__ TaskShared sh;
+    const int tid = threadIdx.x, T = LUT_THREADS;
+    const int lane = tid & (WAVE - 1);
+    LuInverseWork iw = iw_in;
+    const int m = iw.m;
+    if (iw.info[LUF_STATUS] != LUF_OK) {
+        if (tid == 0 && ctl) ctl->status = failed_status;
+        return;
+    }
+    if (tid == 0) sh.error = LUF_OK;
+    __syncthreads();
+    iw.row_rank += (size_t)blockIdx.x * m;
+    iw.row_xoff += (size_t)blockIdx.x * m;
+    iw.row_first += (size_t)blockIdx.x * m;
     // ---- the compact records, list by list ------------------------------------------------------------------------------------------
     const int stride = lu.task_stride;
-    for (int k = 0; k < 4; ++k) {
-        const LuTasks& tk = lu.tasks[k];
+    for (int k = blockIdx.x; k == (int)blockIdx.x; ++k) {  // (one list per workgroup; a loop so that an error leaves through `break`)
+        const LuTasks tk = k == 0 ? lu.tasks[0] : k == 1 ? lu.tasks[1] : k == 2 ? lu.tasks[2] : lu.tasks[3];
         unsigned* hdr = (unsigned*)tk.c_hdr;
         unsigned long long* colw = (unsigned long long*)tk.c_col;
         double* vals = (double*)tk.c_val;
@@ -409,9 +450,9 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_pack_inverse_kernel(DeviceLU l
         double* xval = (double*)tk.x_val;
         int* counts = (int*)tk.counts;
         const int xcap = (k == 0 || k == 3) ? iw.cap_extra_l : iw.cap_extra_u;
-        const int* __restrict__ rs = iw.csr_start[k];
-        const int* __restrict__ ri = iw.csr_idx[k];
-        const double* __restrict__ rv = iw.csr_val[k];
+        const int* __restrict__ rs = k == 0 ? iw.csr_start[0] : k == 1 ? iw.csr_start[1] : k == 2 ? iw.csr_start[2] : iw.csr_start[3];
+        const int* __restrict__ ri = k == 0 ? iw.csr_idx[0] : k == 1 ? iw.csr_idx[1] : k == 2 ? iw.csr_idx[2] : iw.csr_idx[3];
+        const double* __restrict__ rv = k == 0 ? iw.csr_val[0] : k == 1 ? iw.csr_val[1] : k == 2 ? iw.csr_val[2] : iw.csr_val[3];
         // (a) rank of every row inside its group class (ordered), rows without entries, extras: three packed scans
         unsigned long long ca = 0, cb = 0, cx = 0;
         for (int base = 0; base < m; base += T) {
@@ -544,7 +585,8 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_pack_inverse_kernel(DeviceLU l
         __syncthreads();
     }
     // the inverse-factor form keeps U's diagonal inside U^-1: the diagonal array the kernels see is ones (as lu_invert_factors' out.diag)
-    for (int i = tid; i < m; i += T) lu.diag[i] = 1.0;
+    if (blockIdx.x == 0)
+        for (int i = tid; i < m; i += T) lu.diag[i] = 1.0;
     __syncthreads();
     if (tid == 0 && sh.error != LUF_OK) {
         iw.info[LUF_STATUS] = sh.error;
@@ -582,7 +624,8 @@ void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw_in, co
 }
 
 void launch_lu_pack_inverse(const DeviceLU& lu, const LuInverseWork& iw, Ctl* ctl, int failed_status, hipStream_t stream) {
-    hipLaunchKernelGGL(lu_pack_inverse_kernel, dim3(1), dim3(LUT_THREADS), 0, stream, lu, iw, ctl, failed_status);
+    hipLaunchKernelGGL(lu_transpose_inverse_kernel, dim3(2), dim3(LUT_THREADS), 0, stream, iw, ctl, failed_status);
+    hipLaunchKernelGGL(lu_pack_inverse_kernel, dim3(4), dim3(LUT_THREADS), 0, stream, lu, iw, ctl, failed_status);
 }
 
 }  // namespace relp

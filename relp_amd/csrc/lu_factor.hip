@@ -70,9 +70,10 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
         o_cidx[k] = take(ci * sizeof(int));
         o_cval[k] = take(ci * sizeof(double));
     }
-    const size_t o_icursor = take(mi + sizeof(int));
-    const size_t o_itidx = take(ci * sizeof(int)), o_itcol = take(ci * sizeof(int)), o_itval = take(ci * sizeof(double));
-    const size_t o_rrank = take(mi), o_rxoff = take(mi), o_rfirst = take(mi);
+    // (per workgroup of the kernels that use them: two transposing, four packing)
+    const size_t o_icursor = take(2 * 16 * mi + sizeof(int));
+    const size_t o_itidx = take(2 * ci * sizeof(int)), o_itcol = take(2 * ci * sizeof(int)), o_itval = take(2 * ci * sizeof(double));
+    const size_t o_rrank = take(4 * mi), o_rxoff = take(4 * mi), o_rfirst = take(4 * mi);
     if (dev_) (void)hipFree(dev_);
     dev_ = nullptr;
     RELP_HIP(hipMalloc(reinterpret_cast<void**>(&dev_), offset));
