@@ -81,7 +81,7 @@ typedef enum relp_dense_storage {
 /* Where the LU carries refactorise (`relp_options.lu_refactor`). */
 typedef enum relp_lu_refactor {
     RELP_REFACTOR_AUTO = 0,    /* the faster of the two at the sizes measured so far: today the host path for every shipped LP
-                                  (DESIGN.md section 2d has the table: the kernels are 1.1-1.4 x behind one host core per pivot) */
+                                  (DESIGN.md section 2d has the table: the kernels are 7-25 % behind the host path per pivot) */
     RELP_REFACTOR_DEVICE = 1,  /* kernels on the handle's stream (lu_factor.hip, lu_device_tasks.hip): Markowitz factorisation with
                                   independent pivots per round, inversion of the two triangles, slot records -- no basis read-back, no
                                   upload; RELP_CARRY_LU_INVERSE only (the Forrest-Tomlin carry factorises on the host); what the

@@ -422,7 +422,7 @@ __device__ __forceinline__ void factor_round(LuFactorWork& w, FactorShared& sh, 
     LUF_STAMP(1);
     int limit = 0;
     if (!ref) {
-        // (2) the round's minimum score; candidates within a slack of it compete (4 x, at least + 4: lu_factor.hpp)
+        // (2) the round's minimum score; candidates within a slack of it compete (16 x, at least + 16: lu_factor.hpp)
         int mine = 0x7fffffff;
         for (int t = tid; t < n_active; t += T) {
             const unsigned key = w.rowbest[act[t]];
@@ -437,7 +437,7 @@ __device__ __forceinline__ void factor_round(LuFactorWork& w, FactorShared& sh, 
             __syncthreads();
             return;
         }
-        limit = max(4 * smin, smin + 4);
+        limit = max(w.score_slack * smin, smin + w.score_slack);
         // (3) the entry of each competing candidate; the best candidate per column
         for (int e = tid; e < top; e += T) {
             const unsigned cr = old.cr[e];
@@ -1035,6 +1035,7 @@ void launch_lu_factor(const LuFactorSource& src, const LuFactorWork& w, const Lu
     // (targets go to the waves by a fixed map; RELP_LUF_CLAIM_TARGETS=1 lets the waves claim them from a counter instead -- balanced, but
     //  the claim, an LDS atomic every lane of the wave takes part in, costs more than the imbalance: 2.0 M against 0.96 M cycles on 25FV47)
     ww.fixed_target_map = getenv("RELP_LUF_CLAIM_TARGETS") ? 0 : 1;
+    ww.score_slack = getenv("RELP_LUF_SLACK") ? std::max(1, atoi(getenv("RELP_LUF_SLACK"))) : 16;  // (A/B hook; see lu_factor.hpp)
     ww.cap_l = o.cap_l;
     ww.cap_u = o.cap_u;
     static PerDeviceOnce once;

@@ -82,6 +82,7 @@ constexpr int LUF_DENSE_MAX = 32;                 // the dense tail: one lane pe
 struct LuFactorWork {
     int m = 0;
     int cap_w = 0;                 // entries per arena
+    int score_slack = 16;          // candidates with a score <= max(slack x s_min, s_min + slack) compete in a round (25FV47: 47 rounds at 4, 34 at 16, the same fill)
     int fixed_target_map = 0;      // diagnostic: the eliminating waves take targets by a fixed map instead of claiming them
     unsigned* a_cr[2] = {nullptr, nullptr};   // arena: row << 16 | column (basis slot) of the entry, 0xffffffff: hole
     double* a_val[2] = {nullptr, nullptr};

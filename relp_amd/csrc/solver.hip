@@ -221,17 +221,20 @@ void Solver::upload() {
     // (default: the reference's `should_refactor`, > 30 updates, for its Forrest-Tomlin form; 47 for the inverse-factor form, whose
     //  kept columns cost less per update than its refactorisation per pivot: 25FV47 63 -> 59 us per pivot, CYCLE 87 -> 81)
     refactor_period_ = std::min(opt_.refactor_period > 0 ? opt_.refactor_period : (lu_inverse_ ? 47 : 31), LU_MAX_SLOTS - 1);  // T is solved by one wave
-    if (lu_inverse_ && !lu_fits_lds(m, refactor_period_ + 1, true))
-        throw std::invalid_argument("the inverse-factor carry keeps its vectors in LDS (32 bytes per row, 24 beyond ~4300 rows): at most about 5800 rows (use the LU or the explicit carry beyond)");
-    if (lu_mode_ && !lu_inverse_) {
-        if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its two solve vectors in LDS (16 bytes per row): at most about 8000 rows with this refactor period (use the explicit carry beyond)");
-    }
     // `BasisInverse::invert` as kernels (lu_factor.hip, lu_device_tasks.hip: the inverse-factor form) or on one host core:
     // relp_options.lu_refactor, env RELP_REFACTOR=device|host.  AUTO is the host path today -- faster at every size measured.
     {
         int where = opt_.lu_refactor;
         if (const char* env = getenv("RELP_REFACTOR")) where = std::string(env) == "device" ? RELP_REFACTOR_DEVICE : std::string(env) == "host" ? RELP_REFACTOR_HOST : where;
         device_refactor_ = lu_inverse_ && where == RELP_REFACTOR_DEVICE && m <= 65535;
+    }
+    // (a refactorisation on the device costs about twice the host's, so its period is the longest the kept columns allow: 25FV47 64.8 us
+    //  per pivot at 47, 60.3 at 63; GREENBEA 154.5 -> 142.3)
+    if (device_refactor_ && opt_.refactor_period <= 0) refactor_period_ = LU_MAX_SLOTS - 1;
+    if (lu_inverse_ && !lu_fits_lds(m, refactor_period_ + 1, true))
+        throw std::invalid_argument("the inverse-factor carry keeps its vectors in LDS (32 bytes per row, 24 beyond ~4300 rows): at most about 5800 rows (use the LU or the explicit carry beyond)");
+    if (lu_mode_ && !lu_inverse_) {
+        if (!lu_fits_lds(m, refactor_period_ + 1)) throw std::invalid_argument("the LU carry keeps its two solve vectors in LDS (16 bytes per row): at most about 8000 rows with this refactor period (use the explicit carry beyond)");
     }
     // dense block: the longest run of provider columns, starting at the first one, with nnz > m/2 (config 3: all
     // structural columns); steepest edge only (the dense kernel implements that rule)

@@ -4,12 +4,15 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import relp_amd
+extra = {}
+if os.environ.get("RELP_TABLE_PERIOD"):  # A/B: another refactor period for the LU carries
+    extra["refactor_period"] = int(os.environ["RELP_TABLE_PERIOD"])
 names = sys.argv[1:] or ["25FV47", "GREENBEA", "80BAU3B", "SCFXM2", "PILOT4", "BNL1"]
 for name in names:
     path = os.path.join(ROOT, "data", "netlib", name + ".SIF")
     for label, options in (("explicit", dict(carry=0)), ("explicit+implicit bounds", dict(carry=0, implicit_bounds=1)), ("lu", dict(carry=1)), ("lu inverse factors", dict(carry=2))):
         try:
-            s = relp_amd.Solver(**options).load_mps(path)
+            s = relp_amd.Solver(**dict(options, **(extra if options["carry"] else {}))).load_mps(path)
         except relp_amd.api.RelpError as e:
             print("%-9s %-26s not available: %s" % (name, label, str(e)[:110]), flush=True)
             continue
