@@ -25,6 +25,7 @@ parser.add_argument("--carries", default="0,1,2")
 parser.add_argument("--workers", default="4,8,16,32,64")
 parser.add_argument("--mixed", type=int, default=5)
 parser.add_argument("--certify", type=int, default=1)
+parser.add_argument("--lu-refactor", type=int, default=0, help="relp_options.lu_refactor for the LU carries: 1 = the refactorisation kernels on the device")
 args = parser.parse_args()
 
 expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))
@@ -48,7 +49,8 @@ def check(entries, subset):
 def run_batch(subset, carry, workers, passes, out):
     """subset: model indices (cost-sorted).  Runs one warm-up pass and `passes` timed passes as one queue."""
     try:
-        pool = relp_amd.Batch([models[k] for k in subset], devices=(0,), workers_per_device=workers, carry=carry, certify=args.certify)
+        pool = relp_amd.Batch([models[k] for k in subset], devices=(0,), workers_per_device=workers, carry=carry, certify=args.certify,
+                              lu_refactor=args.lu_refactor if carry == 2 else 0)
     except relp_amd.api.RelpError as error:
         out.update({"error": str(error)})
         return
@@ -65,8 +67,9 @@ def run_batch(subset, carry, workers, passes, out):
     pool.close()
 
 
-print("Netlib batch, %d LPs%s, one GPU, %d timed passes per line, certificate %s" % (len(names), " (presolved)" if args.presolve else "", args.passes,
-                                                                                        "inside" if args.certify else "off"), flush=True)
+print("Netlib batch, %d LPs%s, one GPU, %d timed passes per line, certificate %s%s" % (
+    len(names), " (presolved)" if args.presolve else "", args.passes, "inside" if args.certify else "off",
+    ", LU-inverse carry refactorised on the device" if args.lu_refactor == 1 else ""), flush=True)
 print("%-28s %8s %10s %12s %10s %10s  %s" % ("carry", "in flight", "s / pass", "pivots/s", "sum solve", "refactor", "longest LP; wrong"), flush=True)
 label = {0: "explicit", 1: "LU + Forrest-Tomlin", 2: "LU inverse factors"}
 for carry in [int(c) for c in args.carries.split(",") if c != ""]:
