@@ -650,7 +650,7 @@ def single_lp(args, ctx):
     traffic = None
     # (the dense pricing kernel is one template per storage type: bytes, float, double -- the traffic of another instance is not this one's)
     dense_price = "price_dense_lane_kernel<%d>" % {"narrowest": 1, "f32": 4, "f64": 8}[args.dense_storage]
-    pmc_names = {"price": dense_price if dense else "relp::price_kernel<", "ftran_ratio": "ftran_ratio", "update": "update_kernel",
+    pmc_names = {"price": dense_price if dense else ("relp::price_unit_kernel<" if graph else "relp::price_kernel<"), "ftran_ratio": "ftran_ratio", "update": "update_kernel",
                  "lu_pivot": "lu_pivot_kernel", "pivot_fused": "pivot_fused_kernel"}
     tag = args.workload + (("_lu" if args.carry == 1 else "_lui") if lu_carry else "")
     if lu_carry and args.lu_refactor == 1:

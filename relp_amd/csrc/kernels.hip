@@ -147,7 +147,22 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
         const int j = base + g;
         if (!nonbasic) { b = a; v0 = 0.0; }
         double d_pi, d_rho = 0.0, d_w = 0.0;
-        if (LPC == 2) {  // (-pi_r, rho_r, w_r) packed per row: one 32-byte gather instead of three from three cache lines
+        if (UNIT) {
+            // Generated columns (config 5: 65 534 rows, a million arcs): the 32-byte records are 2 MB that each of the eight L2s
+            // pulls in a 128-byte line at a time -- more bytes than the arcs themselves (PMC 39 MB per pass for 13.6 MB of arcs).
+            // -pi comes from its own 8-byte vector, and rho_p -- row p of the inverse, a handful of non-zeros on these bases --
+            // is looked up in a byte per row first; rho and w are fetched only by the columns that have an entry there (both
+            // entries of such a column fetch w: the sum is the one the packed gather made).
+            d_pi = v0 * lp.minus_pi[r0];
+            if (pending) {
+                int hit = lp.rho_nz[r0] != 0 && v0 != 0.0;
+                hit |= __shfl_xor(hit, 1);
+                if (hit) {
+                    d_rho = v0 * lp.rho[r0];
+                    d_w = v0 * lp.w[r0];
+                }
+            }
+        } else if (LPC == 2) {  // (-pi_r, rho_r, w_r) packed per row: one 32-byte gather instead of three from three cache lines
             const double* t = lp.prw + (size_t)4 * r0;
             if (pending) {
                 const f64x2_t lo = *reinterpret_cast<const f64x2_t*>(t);
@@ -252,6 +267,190 @@ __global__ void __launch_bounds__(256) price_kernel(DeviceLP lp, int skip_weight
         lp.cand_vals[(size_t)(cand_offset + blockIdx.x) * ELL_W + sub] = best_val;
     }
     if (blk.idx < 0 && threadIdx.x == 0) lp.cand_j[cand_offset + blockIdx.x] = -1;
+}
+
+constexpr int PRICE_UNIT_ARCS = 4;  // arcs per lane of price_unit_kernel
+// ---------------------------------------------------------------------------------------------------
+// K1u: the pricing pass over GENERATED incidence columns (graph providers: examples/max_flow.rs:174-200, every value +-1, integer
+// costs), one LANE per arc and PRICE_UNIT_ARCS arcs per lane.  The two-lanes-per-arc form above kept one arc per lane pair in
+// flight and walked four dependent passes per workgroup (14 us for 13.6 MB on config 5: 12 % of HBM, all of it latency); here a
+// lane loads the 8 bytes of four arcs, their positions and cost bytes in one round trip, gathers the eight -pi entries in the
+// next, and a million arcs are ONE pass of 1024 workgroups.  Same arithmetic, same order of every sum (a column's two
+// products are added as the lane pair added them), same total order on the candidates: the pivot sequence does not change.
+// rho_p and w are fetched only where row p of the inverse is non-zero: a bit per row, copied into LDS (DeviceLP::rho_bits; the
+// byte table rho_nz of price_kernel when the LP has more rows than bits fit).  A gather costs the L1 a cycle per lane whatever it
+// brings: with the byte table beside -pi the pass spent 6-7 of its 14 us on 4 M lane gathers (tools/stamps_maxflow.py).
+// ---------------------------------------------------------------------------------------------------
+template <int RULE>
+__global__ void __launch_bounds__(256) price_unit_kernel(DeviceLP lp, int skip_weights, double tol_dual, int col_first,
+                                                         int col_last, int cand_offset) {
+    constexpr int U = PRICE_UNIT_ARCS;
+    extern __shared__ __attribute__((aligned(16))) unsigned s_rho_bits[];  // lp.rho_words words (none: the byte table is gathered)
+    __shared__ Cand s_cand[8];
+    Ctl* ctl = lp.ctl;
+#ifdef RELP_STAMPS  // (tools/stamps_maxflow.py: wall-clock ticks of 10 ns, first workgroup in dbg[32..], last in dbg[40..])
+    unsigned long long t_prev__ = wall_clock64();
+    const int stamp_base__ = blockIdx.x == 0 ? 32 : (blockIdx.x == gridDim.x - 1 ? 40 : -1);
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        lp.dbg[48] += 1;
+        *(volatile unsigned long long*)(lp.dbg + 49) = t_prev__;
+    }
+#define USTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && stamp_base__ >= 0) { unsigned long long t__ = wall_clock64(); lp.dbg[stamp_base__ + (k)] += t__ - t_prev__; t_prev__ = t__; } } while (0)
+#else
+#define USTAMP(k) do {} while (0)
+#endif
+    const int status = ctl->status;
+    const int pending = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? (ctl->pending && !skip_weights) : 0;
+    const double gamma_q = ctl->gamma_q;
+    const double alpha_pq = ctl->alpha_pq;
+    const int leaving = ctl->leaving;
+    const int last = ctl->last_selected;
+    // ---- ONE memory round trip: the control word and this workgroup's first arcs, positions and cost bytes ----------
+    const uint2* arcs = reinterpret_cast<const uint2*>(lp.ell_rows);
+    unsigned ca[U], cb[U];
+    int pos[U];
+    double cost[U];
+    auto load_arcs = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * 256 + threadIdx.x;
+            ca[u] = cb[u] = 0x7fffffffu;
+            pos[u] = 0;
+            cost[u] = 0.0;
+            if (j < col_last) {
+                const uint2 c = arcs[j];
+                ca[u] = c.x;
+                cb[u] = c.y;
+                pos[u] = lp.pos[j];
+                cost[u] = (double)lp.cost8[j];
+            }
+        }
+    };
+    load_arcs(col_first + blockIdx.x * (256 * U));
+    // ... and the bits of rho_p's non-zero rows (see DeviceLP::rho_bits): this pivot's half into LDS, the other half cleared for the next
+    const int rho_words = lp.rho_words;
+    if (rho_words) {
+        const uint4* mine = reinterpret_cast<const uint4*>(lp.rho_bits + (size_t)ctl->rho_buf * rho_words);
+        uint4* other = reinterpret_cast<uint4*>(lp.rho_bits + (size_t)(ctl->rho_buf ^ 1) * rho_words);
+        if (pending)
+            for (int i = threadIdx.x; i < rho_words / 4; i += 256) reinterpret_cast<uint4*>(s_rho_bits)[i] = mine[i];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < rho_words / 4; i += gridDim.x * 256) other[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (status != ST_RUNNING) return;  // uniform
+    if (rho_words && pending) __syncthreads();
+    USTAMP(0);
+    Cand best;
+    best.key = 0.0;
+    best.idx = -1;
+    best.aux = 0;
+    double best_cbar = 0.0;
+    int best_ra = 0, best_rb = 0;
+    double best_va = 0.0, best_vb = 0.0;
+    for (int base = col_first + blockIdx.x * (256 * U); base < col_last; base += gridDim.x * (256 * U)) {
+        if (base != col_first + (int)blockIdx.x * (256 * U)) load_arcs(base);
+        USTAMP(1);
+        int ra[U], rb[U];
+        double va[U], vb[U], pa[U], pb[U];
+        bool nonbasic[U];
+        int hit[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            nonbasic[u] = pos[u] == -1 || pos[u] == -2;  // -3: fixed variable (implicit bounds), never priced
+            const bool has_a = nonbasic[u] && ca[u] != 0x7fffffffu, has_b = nonbasic[u] && cb[u] != 0x7fffffffu;
+            ra[u] = ca[u] == 0x7fffffffu ? 0 : (int)(ca[u] & 0x7fffffffu);
+            rb[u] = cb[u] == 0x7fffffffu ? 0 : (int)(cb[u] & 0x7fffffffu);
+            va[u] = ca[u] == 0x7fffffffu ? 0.0 : ((ca[u] >> 31) ? -1.0 : 1.0);
+            vb[u] = cb[u] == 0x7fffffffu ? 0.0 : ((cb[u] >> 31) ? -1.0 : 1.0);
+            pa[u] = has_a ? lp.minus_pi[ra[u]] : 0.0;
+            pb[u] = has_b ? lp.minus_pi[rb[u]] : 0.0;
+            hit[u] = 0;
+            if (pending && rho_words)
+                hit[u] = (has_a && ((s_rho_bits[ra[u] >> 5] >> (ra[u] & 31)) & 1u)) | (has_b && ((s_rho_bits[rb[u] >> 5] >> (rb[u] & 31)) & 1u));
+            else if (pending)
+                hit[u] = (has_a && lp.rho_nz[ra[u]] != 0) | (has_b && lp.rho_nz[rb[u]] != 0);
+        }
+        USTAMP(2);
+        double cbar[U], d_rho[U], d_w[U], gam[U];
+        bool weight_changes[U], wanted[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * 256 + threadIdx.x;
+            const bool has_a = nonbasic[u] && ca[u] != 0x7fffffffu, has_b = nonbasic[u] && cb[u] != 0x7fffffffu;
+            const double sgn = pos[u] == -2 ? -1.0 : 1.0;  // the column is held in complemented form (implicit upper bounds)
+            cbar[u] = sgn * (cost[u] + ((has_a ? va[u] * pa[u] : 0.0) + (has_b ? vb[u] * pb[u] : 0.0)));
+            d_rho[u] = d_w[u] = 0.0;
+            if (hit[u]) {  // (rare: the columns with an entry where rho_p is non-zero)
+                d_rho[u] = (has_a ? va[u] * lp.rho[ra[u]] : 0.0) + (has_b ? vb[u] * lp.rho[rb[u]] : 0.0);
+                d_w[u] = (has_a ? va[u] * lp.w[ra[u]] : 0.0) + (has_b ? vb[u] * lp.w[rb[u]] : 0.0);
+            }
+            // a weight with no entry in the pivot row does not change (gamma - 0 + 0, and gamma >= 1): not read, not written
+            weight_changes[u] = RULE == RELP_PIVOT_STEEPEST_EDGE && pending && (j == leaving || d_rho[u] != 0.0);
+            wanted[u] = nonbasic[u] && (weight_changes[u] || cbar[u] < -tol_dual);
+            gam[u] = 1.0;
+            if (RULE == RELP_PIVOT_STEEPEST_EDGE && wanted[u]) gam[u] = lp.gamma[j];
+        }
+        USTAMP(3);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * 256 + threadIdx.x;
+            if (!wanted[u]) continue;
+            double g = gam[u];
+            if (weight_changes[u]) {
+                if (j == leaving) {
+                    g = gamma_q / (alpha_pq * alpha_pq);  // pivot_rule.rs:294-295
+                } else {
+                    const double sq = d_rho[u] * d_rho[u];  // pivot_rule.rs:262-288 (Goldfarb-Reid)
+                    g = g - 2.0 * d_rho[u] * d_w[u] + sq * gamma_q;
+                    g = fmax(g, 1.0 + sq);
+                }
+                lp.gamma[j] = g;
+            }
+            bool candidate = cbar[u] < -tol_dual;
+            Cand c;
+            c.idx = j;
+            c.aux = 0;
+            c.key = 0.0;
+            if (RULE == RELP_PIVOT_STEEPEST_EDGE) c.key = cbar[u] * cbar[u] / g;
+            else if (RULE == RELP_PIVOT_DANTZIG) c.key = -cbar[u];
+            else if (RULE == RELP_PIVOT_FIRST_PROFITABLE) c.key = -(double)j;
+            else {
+                if (last >= 0 && j == last) candidate = false;
+                const long long rank = (last < 0) ? j : (j > last ? (long long)j - last - 1 : (long long)j + lp.n - last);
+                c.key = -(double)rank;
+            }
+            if (candidate) {
+                const Cand nb = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(best, c) : better<TIE_SMALLER_IDX>(best, c);
+                if (nb.idx == j) {
+                    best_cbar = cbar[u];
+                    best_ra = ra[u];
+                    best_rb = rb[u];
+                    best_va = va[u];
+                    best_vb = vb[u];
+                }
+                best = nb;
+            }
+        }
+    }
+    USTAMP(4);
+    const Cand blk = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(best, s_cand)
+                                                        : block_best<TIE_SMALLER_IDX>(best, s_cand);
+    if (blk.idx >= 0 && blk.idx == best.idx) {  // the winning thread publishes the candidate and its column's two entries
+        const size_t slot = (size_t)(cand_offset + blockIdx.x);
+        lp.cand_key[slot] = blk.key;
+        lp.cand_j[slot] = blk.idx;
+        lp.cand_cbar[slot] = best_cbar;
+        lp.cand_len[slot] = 2;
+        lp.cand_rows[slot * ELL_W] = best_ra;
+        lp.cand_rows[slot * ELL_W + 1] = best_rb;
+        lp.cand_vals[slot * ELL_W] = best_va;
+        lp.cand_vals[slot * ELL_W + 1] = best_vb;
+    }
+    if (blk.idx < 0 && threadIdx.x == 0) lp.cand_j[cand_offset + blockIdx.x] = -1;
+    USTAMP(5);
+#ifdef RELP_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) lp.dbg[50] += wall_clock64() - *(volatile unsigned long long*)(lp.dbg + 49);
+#endif
+#undef USTAMP
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1607,6 +1806,7 @@ __global__ void __launch_bounds__(K2_THREADS) ftran_ratio_kernel(DeviceLP lp, in
         ctl->minus_obj -= cbar_signed * xp;
         ctl->iters += 1;
         ctl->pending = 1;
+        ctl->rho_buf ^= 1;  // (the update of this pivot marks the other half of rho_bits)
         ctl->forced_q = -1;
         ctl->forced_p = -1;
         ctl->last_selected = q;
@@ -1933,6 +2133,7 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp, int
             ctl->minus_obj -= cbar_q * xp;
             ctl->iters += 1;
             ctl->pending = 1;
+            ctl->rho_buf ^= 1;  // (the update of this pivot marks the other half of rho_bits)
             ctl->last_selected = q;
         }
         ctl->forced_q = -1;
@@ -2465,6 +2666,7 @@ __global__ void __launch_bounds__(K2F_THREADS) ftran_ratio_fast_kernel(DeviceLP 
         ctl->minus_obj = minus_obj - cbar_q * xp;
         ctl->iters = iters + 1;
         ctl->pending = 1;
+        ctl->rho_buf ^= 1;  // (the update of this pivot marks the other half of rho_bits)
         ctl->forced_q = -1;
         ctl->forced_p = -1;
         ctl->last_selected = q;
@@ -2917,6 +3119,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
                     lp.prw[(size_t)4 * j + 1] = 0.0;
                     lp.prw[(size_t)4 * j + 2] = a_j;
                 }
+                if (lp.rho_nz) lp.rho_nz[j] = 0;
             }
         const int n_touched = ctl->touched_count;
         const int nz_small = ctl->nz_count;
@@ -2964,6 +3167,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
                     lp.prw[(size_t)4 * j + 1] = r;
                     lp.prw[(size_t)4 * j + 2] = w;
                 }
+                mark_rho_row(lp, ctl->rho_buf, j, r);
             }
             return;
         }
@@ -3088,6 +3292,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
             lp.prw[(size_t)4 * j0 + 1] = r0;
             lp.prw[(size_t)4 * j0 + 2] = w0;
         }
+        mark_rho_row(lp, ctl->rho_buf, j0, r0);
         if (two) {
             lp.w[j1] = w1;
             lp.rho[j1] = r1;
@@ -3097,6 +3302,7 @@ __global__ void __launch_bounds__(K3_THREADS) update_kernel(DeviceLP lp) {
                 lp.prw[(size_t)4 * j1 + 1] = r1;
                 lp.prw[(size_t)4 * j1 + 2] = w1;
             }
+            mark_rho_row(lp, ctl->rho_buf, j1, r1);
         }
     }
 }
@@ -3536,14 +3742,16 @@ void take_launch_timer(int which, hipEvent_t* start, hipEvent_t* stop) {
         }                                                                                                    \
     } while (0)
 constexpr int PRICE_LPC = 8;  // lanes per sparse column in the pricing kernel
-int price_columns_per_block(int ell_w) { return 256 / ell_w; }
+int price_columns_per_block(int ell_w, bool generated) { return generated ? 256 * PRICE_UNIT_ARCS : 256 / ell_w; }
 
 template <int RULE>
 static void launch_price_rule(const DeviceLP& d, int blocks, size_t lds, bool use_lds, int skip_weights, double tol,
                               int first, int last, int cand_offset, hipStream_t s) {
     const bool timed_elsewhere = d.n_dense > 0;  // with a dense block the dense kernel is the one that is timed
-    if (d.ell_w == 2 && d.cost8)  // incidence columns generated from the arcs' endpoints (8 B per arc)
+    if (d.ell_w == 2 && d.cost8 && d.price_unit_pairs)  // (the round-2 form, two lanes per arc: A/B)
         RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, false, 2, true>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
+    else if (d.ell_w == 2 && d.cost8)  // incidence columns generated from the arcs' endpoints (8 B per arc)
+        RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_unit_kernel<RULE>), dim3(blocks), dim3(256), (size_t)d.rho_words * sizeof(unsigned), s, d, skip_weights, tol, first, last, cand_offset);
     else if (d.ell_w == 2)  // graph LPs: two entries per column, 128 columns per workgroup pass (large m: vectors gathered from L2)
         RELP_LAUNCH(timed_elsewhere ? -2 : 0, (price_kernel<RULE, false, 2>), dim3(blocks), dim3(256), 0, s, d, skip_weights, tol, first, last, cand_offset);
     else if (use_lds)

@@ -1795,6 +1795,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
 #endif
     // ---- round trip 1: control word, update count, the candidates ---------------------------------------------------
     const int status = ctl->status;
+    const int rho_buf = ctl->rho_buf ^ 1;  // generated columns: the half of rho_bits this pivot marks (published with the pivot)
     const long long iters = ctl->iters;
     const long long budget = ctl->budget;
     const int forced_q = ctl->forced_q;
@@ -2215,6 +2216,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
             lp.prw[(size_t)4 * i + 1] = r;
             lp.prw[(size_t)4 * i + 2] = w;
         }
+        mark_rho_row(lp, rho_buf, i, r);
     }
     lu_stamp(sh, 11);
     // ---- Forrest-Tomlin update, or hand the new basis to the host ---------------------------------------------------------------
@@ -2251,6 +2253,7 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
         ctl->minus_obj = minus_obj - cbar_q * xp;
         ctl->iters = iters + 1;
         ctl->pending = 1;
+        ctl->rho_buf = rho_buf;
         ctl->forced_q = -1;
         ctl->forced_p = -1;
         ctl->last_selected = q;

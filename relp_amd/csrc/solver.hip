@@ -26,7 +26,7 @@ bool fast_k2_available(const DeviceLP& d, int n_price_blocks);
 void arm_launch_timer(int which, hipEvent_t start, hipEvent_t stop);
 void take_launch_timer(int which, hipEvent_t* start, hipEvent_t* stop);
 void configure_lds(size_t price_lds);
-int price_columns_per_block(int ell_w);
+int price_columns_per_block(int ell_w, bool generated);
 void launch_ftran_ratio(const DeviceLP& d, int rule, int n_price_blocks, double tol_pivot, double harris_delta,
                         int skip_artificial_rows, int mode, int n_alpha_slices, hipStream_t s);
 void launch_update(const DeviceLP& d, hipStream_t s);
@@ -112,7 +112,7 @@ Solver::~Solver() {
 void Solver::free_device() {
     void* ptrs[] = {d_.col_start, d_.row_index, d_.value, d_.row_start, d_.col_index, d_.row_value, d_.cost, d_.cost1,
                     d_.cost2, d_.rhs, d_.xB, d_.minus_pi, d_.basis, d_.pos, d_.gamma, d_.Binv, d_.Binv2, d_.R,
-                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.eta_dot_part, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx, d_.slack_of_row, d_.state[0].ctl, d_.state[0].xB, d_.state[0].basis, d_.state[1].ctl, d_.state[1].xB, d_.state[1].basis};
+                    d_.alpha, d_.rho, d_.nz_index, d_.nz_alpha, d_.w, d_.cand_key, d_.cand_j, d_.cand_cbar, d_.cand_rows, d_.cand_vals, d_.cand_len, d_.ell_rows, d_.ell_vals, d_.scratch, d_.ctl, d_.dbg, d_.dense_val, d_.dense_val32, d_.dense_val8, d_.alpha_part, d_.alpha_in, d_.eta_cols, d_.eta_rows, d_.eta_slot, d_.eta_gather, d_.eta_dot_part, d_.touched, d_.tlist, d_.ub, d_.xub, d_.flipped, d_.rhs0, d_.k2_partd, d_.k2_parti, d_.prw, d_.rho_nz, d_.rho_bits, d_.cost8, d_.cost8_2, d_.cb, d_.cb_idx, d_.slack_of_row, d_.state[0].ctl, d_.state[0].xB, d_.state[0].basis, d_.state[1].ctl, d_.state[1].xB, d_.state[1].basis};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     d_ = DeviceLP{};
@@ -252,8 +252,13 @@ void Solver::upload() {
         for (int j = 0; j < n; ++j) longest = std::max(longest, col_start[j + 1] - col_start[j]);
         d_.ell_w = (longest <= 2 && n_dense == 0 && price_lds_ > 160 * 1024 - 1024 && !getenv("RELP_ELL_WIDE")) ? 2 : ELL_W;
     }
-    const int cpb = price_columns_per_block(d_.ell_w);
-    price_blocks_ = std::min(d_.ell_w == 2 ? 2048 : 1024, (n - sparse_first_ + cpb - 1) / cpb);
+    // incidence columns (graph providers, examples/max_flow.rs:174-200): every value +-1 and small integer costs -- the
+    // pricing pass then GENERATES the column from 8 bytes per arc (row | sign) instead of streaming 24 + 8 bytes of it
+    bool unit = d_.ell_w == 2 && !getenv("RELP_NO_GENERATED_COLUMNS");
+    for (size_t e = 0; unit && e < value.size(); ++e) unit = value[e] == 1.0 || value[e] == -1.0;
+    for (int j = 0; unit && j < n; ++j) unit = cost2[j] == std::floor(cost2[j]) && std::fabs(cost2[j]) <= 127.0;
+    const int cpb = price_columns_per_block(d_.ell_w, unit);
+    price_blocks_ = std::min(d_.ell_w == 2 && !unit ? 2048 : 1024, (n - sparse_first_ + cpb - 1) / cpb);
     // Dense pipeline whose sparse columns are one single-entry column per row at most (the slack columns of config 3): the BTRAN
     // pass of a pivot prices them for the next one (btran_pass_kernel), one candidate slot per workgroup of that pass.
     std::vector<int> slack_of_row;
@@ -357,12 +362,7 @@ void Solver::upload() {
                 er[(size_t)j * width + k] = row_index[e];
                 ev[(size_t)j * width + k] = value[e];
             }
-        // incidence columns (graph providers, examples/max_flow.rs:174-200): every value +-1 and small integer costs -- the
-        // pricing pass then GENERATES the column from 8 bytes per arc (row | sign) instead of streaming 24 + 8 bytes of it
-        bool unit = width == 2 && !getenv("RELP_NO_GENERATED_COLUMNS");
-        for (size_t e = 0; unit && e < value.size(); ++e) unit = value[e] == 1.0 || value[e] == -1.0;
-        for (int j = 0; unit && j < n; ++j) unit = cost2[j] == std::floor(cost2[j]) && std::fabs(cost2[j]) <= 127.0;
-        if (unit) {
+        if (unit) {  // (generated incidence columns: decided where the pricing grid was sized)
             for (int j = 0; j < n; ++j)
                 for (int k = 0; k < width; ++k) {
                     const int len = col_start[j + 1] - col_start[j];
@@ -527,9 +527,20 @@ void Solver::upload() {
     upload_vec(d_.cost2, cost2, stream_);
     upload_vec(d_.rhs, rhs, stream_);
     upload_vec(d_.rhs0, rhs, stream_);
-    if (d_.ell_w == 2) {
+    if (d_.ell_w == 2 && !d_.cost8) {  // columns with values: the packed records of price_kernel<.., 2>
         d_.prw = dmalloc<double>((size_t)4 * m);
         RELP_HIP(hipMemsetAsync(d_.prw, 0, (size_t)4 * m * sizeof(double), stream_));
+    } else if (d_.ell_w == 2) {  // generated columns: -pi from its own vector, rho_p's non-zero rows as bits (bytes beyond LDS)
+        d_.price_unit_pairs = getenv("RELP_PRICE_UNIT_PAIRS") != nullptr;
+        d_.rho_words = ((m + 127) / 128) * 4;
+        if ((size_t)d_.rho_words * 4 > 64 * 1024 || getenv("RELP_NO_RHO_BITS") || d_.price_unit_pairs) d_.rho_words = 0;
+        if (d_.rho_words) {
+            d_.rho_bits = dmalloc<unsigned>((size_t)2 * d_.rho_words);
+            RELP_HIP(hipMemsetAsync(d_.rho_bits, 0, (size_t)2 * d_.rho_words * sizeof(unsigned), stream_));
+        } else {
+            d_.rho_nz = dmalloc<unsigned char>(m);
+            RELP_HIP(hipMemsetAsync(d_.rho_nz, 0, m, stream_));
+        }
     }
     RELP_HIP(hipMemsetAsync(d_.rho, 0, m * sizeof(double), stream_));
     RELP_HIP(hipMemsetAsync(d_.w, 0, m * sizeof(double), stream_));

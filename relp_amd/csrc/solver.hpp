@@ -70,6 +70,7 @@ struct Ctl {
     int t_buf;         // fused pivot kernel: which of the two buffers holds the current inverse (0 outside a batch)
     int eta_version;   // deferred product form: pivots made; the kept columns of M live in eta_cols buffer (eta_version & 1)
     int eta_new;       // ... and whether the last pivot added a kept column (its row had none) -- both written by K2
+    int rho_buf;       // generated columns: which half of DeviceLP::rho_bits the writers of rho_p mark (flipped by the kernel that decides a pivot)
 };
 
 constexpr int ELL_W = 8;  // padded entries per column = lanes per column in the pricing kernel
@@ -143,7 +144,14 @@ struct DeviceLP {
     // padded copy of the first ELL_W entries of every column (value 0 padding): no col_start dependency in K1
     int ell_w = ELL_W;           // padded width in use: 2 when no column has more than two entries and m is large, else ELL_W
     int* ell_rows = nullptr;
-    double* prw = nullptr;       // ell_w == 2: (-pi_r, rho_r, w_r, 0) packed per row, kept beside the three vectors by their writers
+    double* prw = nullptr;       // ell_w == 2, columns with values: (-pi_r, rho_r, w_r, 0) packed per row, kept beside the three vectors by their writers
+    // ... and the same as one BIT per row, two buffers of rho_words words: the writers of rho_p set bits in buffer Ctl::rho_buf,
+    // the pricing pass copies that buffer into LDS (8 KB for config 5) and clears the other one, the kernel that decides the next
+    // pivot flips Ctl::rho_buf.  Bits are only ever a superset of the non-zeros (a stale bit costs one gather of an exact zero).
+    unsigned* rho_bits = nullptr;
+    int price_unit_pairs = 0;  // RELP_PRICE_UNIT_PAIRS: the round-2 pricing pass (two lanes per arc, byte table), for A/B and the parity test
+    int rho_words = 0;  // per buffer, a multiple of 4; 0: no bit table (too many rows for LDS: the byte table is gathered instead)
+    unsigned char* rho_nz = nullptr;  // generated columns without the bit table: rho_r != 0, one byte per row (rho and w are gathered only where this says so)
     double* ell_vals = nullptr;
     // generated incidence columns (ell_w == 2, every value +-1, integer costs in [-127, 127]): ell_rows carries the sign in
     // bit 31 (0x7fffffff: no entry), ell_vals is not allocated, and pricing reads the cost as a signed byte
@@ -171,6 +179,15 @@ struct DeviceLP {
     State state[2];
     unsigned long long* dbg = nullptr;  // diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of K2
 };
+
+#ifdef __HIPCC__
+// Generated incidence columns: row j of the new rho_p for the pricing pass -- its bit in this pivot's half of rho_bits (set only:
+// the pricing pass clears the other half), its byte in rho_nz where that table is kept.
+__device__ __forceinline__ void mark_rho_row(const DeviceLP& lp, int rho_buf, int j, double r) {
+    if (lp.rho_nz) lp.rho_nz[j] = r != 0.0;
+    if (r != 0.0 && lp.rho_words) atomicOr(lp.rho_bits + (size_t)rho_buf * lp.rho_words + (j >> 5), 1u << (j & 31));
+}
+#endif
 
 class Solver {
 public:

@@ -213,6 +213,34 @@ def test_gpu_max_flow_131k_arcs_with_implicit_bounds():
 
 
 @pytest.mark.gpu
+def test_gpu_generated_column_pricing_variants_make_the_same_pivots(monkeypatch):
+    """The pricing pass over generated incidence columns (`price_unit_kernel`: a lane per arc, rho_p's non-zero rows as a bit
+    table in LDS) against its two predecessors -- the byte table gathered from memory (RELP_NO_RHO_BITS) and the two-lanes-per-arc
+    kernel (RELP_PRICE_UNIT_PAIRS): every sum is formed in the same order and the candidates have a total order, so the three
+    make the same pivots and end on the same numbers, bit for bit (pivot_rule.rs:221-296 is one sequential pass)."""
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices = 16384
+    tail, head, capacity = max_flow_graph(nr_vertices, 131072)
+    keep = (head != 0) & (tail != nr_vertices - 1)
+    tail, head, capacity = tail[keep], head[keep], capacity[keep]
+    model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+    outcomes = []
+    for switch in (None, "RELP_NO_RHO_BITS", "RELP_PRICE_UNIT_PAIRS"):
+        if switch:
+            monkeypatch.setenv(switch, "1")
+        solver = relp_amd.Solver(implicit_bounds=1).load_model(model)
+        result = solver.solve_relaxation()
+        outcomes.append((result.kind, result.pivots_phase_one, result.pivots_phase_two, result.objective, solver.solution().tobytes()))
+        solver.close()
+        if switch:
+            monkeypatch.delenv(switch)
+    assert outcomes[0][0] == relp_amd.FINITE_OPTIMUM
+    assert outcomes[0][1] + outcomes[0][2] > 1000
+    assert outcomes[1] == outcomes[0]
+    assert outcomes[2] == outcomes[0]
+
+
+@pytest.mark.gpu
 def test_gpu_shortest_path_12k_vertices_matches_dijkstra():
     """V = 12 000, E ~ 60 000 (one conservation row per vertex but the target, no bounds: the ratio test across workgroups
     without the bounded-variable rules): the LP optimum equals scipy's Dijkstra distance and the solution is a unit s-t flow."""
