@@ -111,9 +111,58 @@ __device__ __forceinline__ Big<L> big_mul_small(const Big<L>& a, i64 b) {
     }
     return b < 0 ? big_negate(r) : r;
 }
+// The same product for the wide types (16 limbs and more), whose operands live in scratch memory.  The loop below reads b.w[j] and
+// r.w[i + j] and writes r.w[i + j] for every word product: three scratch accesses per product, and at 128 limbs the update of N
+// ran at 4 % of the multiplier's rate (25FV47: 132 of 252 s).  Here the product is formed four output words at a time
+// (product scanning by 4 x 4 blocks): a block pair costs eight scratch reads for sixteen word products, the running sum is a
+// window of nine words in registers, and nothing is written but the result.  Same value: the product modulo 2^(64 L).
+template <int L>
+__device__ __forceinline__ Big<L> big_mul_lo_blocked(const Big<L>& a, const Big<L>& b) {
+    static_assert(L % 4 == 0, "four words per block");
+    constexpr int NB = L / 4;
+    Big<L> r;
+    u64 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0;
+    for (int K = 0; K < NB; ++K) {
+        for (int I = 0; I <= K; ++I) {
+            const int J = K - I;
+            u64 a4[4], b4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a4[t] = a.w[4 * I + t];
+                b4[t] = b.w[4 * J + t];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                u64 carry = 0;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const u128 t = (u128)a4[ii] * b4[jj] + acc[ii + jj] + carry;
+                    acc[ii + jj] = (u64)t;
+                    carry = (u64)(t >> 64);
+                }
+#pragma unroll
+                for (int k = ii + 4; k < 9; ++k) {
+                    const u128 t = (u128)acc[k] + carry;
+                    acc[k] = (u64)t;
+                    carry = (u64)(t >> 64);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r.w[4 * K + t] = acc[t];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc[t] = acc[t + 4];
+#pragma unroll
+        for (int t = 5; t < 9; ++t) acc[t] = 0;
+    }
+    return r;
+}
 // a * b mod 2^(64 L)  (the low half of the product: exact whenever the true product fits)
 template <int L>
 __device__ __forceinline__ Big<L> big_mul_lo(const Big<L>& a, const Big<L>& b) {
+    if constexpr (L >= 16) return big_mul_lo_blocked(a, b);
     Big<L> r;
 #pragma unroll L <= 8 ? L : 1
     for (int k = 0; k < L; ++k) r.w[k] = 0;
@@ -178,6 +227,38 @@ __device__ __forceinline__ double big_ratio(const Big<L>& a, const Big<L>& b) {
     int ea = 0, eb = 0;
     const double ma = split(a, &ea), mb = split(b, &eb);
     return ldexp(ma / mb, ea - eb);
+}
+// The two leading words of |v| as a double and the exponent that goes with them (the `split` of big_ratio), for a value whose
+// words arrive one at a time, least significant first, and are never held together: both readings are carried along -- the value
+// itself and its two's complement negation, whose carry runs while the words are zero -- and the sign (the last word) picks one.
+struct LeadingWords {
+    int top_p = -1, top_n = -1;
+    u64 p_top = 0, p_below = 0, n_top = 0, n_below = 0, prev = 0, prev_n = 0;
+    bool carry = true;
+    __device__ __forceinline__ void feed(int k, u64 word) {
+        if (word != 0) { top_p = k; p_top = word; p_below = prev; }
+        prev = word;
+        const u64 negated = ~word + (carry ? 1ull : 0ull);
+        carry = carry && word == 0;
+        if (negated != 0) { top_n = k; n_top = negated; n_below = prev_n; }
+        prev_n = negated;
+    }
+    // (after the last word)
+    __device__ __forceinline__ double mantissa(int* exponent) const {
+        const bool neg = (i64)prev < 0;
+        const int top = neg ? top_n : top_p;
+        if (top < 0) { *exponent = 0; return 0.0; }
+        double x = (double)(neg ? n_top : p_top);
+        if (top > 0) x = x * 18446744073709551616.0 + (double)(neg ? n_below : p_below);
+        *exponent = 64 * (top > 0 ? top - 1 : 0);
+        return neg ? -x : x;
+    }
+};
+template <int L>
+__device__ __forceinline__ double big_mantissa(const Big<L>& v, int* exponent) {  // (the same numbers from a value held whole)
+    LeadingWords lead;
+    for (int k = 0; k < L; ++k) lead.feed(k, v.w[k]);
+    return lead.mantissa(exponent);
 }
 template <int L>
 __device__ __forceinline__ int big_ctz(const Big<L>& a) {  // a != 0
@@ -267,6 +348,65 @@ __device__ void words_inverse_odd(const u64* d, u64* x, u64* t, u64* x2) {  // x
         for (int k = 0; k < want; ++k) x[k] = x2[k];
     }
 }
+// The same two on the whole workgroup (round 4: at 128 limbs the Newton iteration by one thread was 1.5 ms of every pivot).  A
+// product is formed by columns: thread k sums the word products of output word k in three words, one thread then runs the carries
+// through the columns -- two barriers a product, about 3 k cycles at 128 limbs instead of 100 k.  Called by every thread of the
+// workgroup (the arrays are in LDS); `part` holds 3 words per output word.
+__device__ __forceinline__ void block_mul_lo(const u64* a, int la, const u64* b, int lb, u64* out, int lo, u64* part) {  // out may not alias a, b
+    const int k = threadIdx.x;
+    if (k < lo) {
+        u64 c0 = 0, c1 = 0, c2 = 0;
+        const int j0 = k - la + 1 > 0 ? k - la + 1 : 0, j1 = k < lb - 1 ? k : lb - 1;
+        for (int j = j0; j <= j1; ++j) {
+            const u128 prod = (u128)a[k - j] * b[j];
+            const u128 low = (u128)c0 + (u64)prod;
+            c0 = (u64)low;
+            const u128 mid = (u128)c1 + (u64)(prod >> 64) + (u64)(low >> 64);
+            c1 = (u64)mid;
+            c2 += (u64)(mid >> 64);
+        }
+        part[3 * k] = c0;
+        part[3 * k + 1] = c1;
+        part[3 * k + 2] = c2;
+    }
+    __syncthreads();
+    if (k == 0) {
+        u64 r1 = 0, r2 = 0;  // what the lower columns carry into this one (two words)
+        for (int c = 0; c < lo; ++c) {
+            const u128 low = (u128)part[3 * c] + r1;
+            out[c] = (u64)low;
+            const u128 mid = (u128)part[3 * c + 1] + r2 + (u64)(low >> 64);
+            r1 = (u64)mid;
+            r2 = part[3 * c + 2] + (u64)(mid >> 64);
+        }
+    }
+    __syncthreads();
+}
+template <int L>
+__device__ void block_inverse_odd(const u64* d, u64* x, u64* t, u64* x2, u64* part) {  // x = 1 / d modulo 2^(64 L), d odd; every thread of the workgroup
+    if (threadIdx.x == 0) {
+        u64 inv = d[0];  // d * d = 1 (mod 8): three correct bits, doubled five times
+        for (int k = 0; k < 5; ++k) inv *= 2 - d[0] * inv;
+        x[0] = inv;
+    }
+    __syncthreads();
+    for (int have = 1; have < L; have *= 2) {
+        const int want = 2 * have < L ? 2 * have : L;
+        block_mul_lo(d, want, x, have, t, want, part);
+        if (threadIdx.x == 0) {
+            u64 carry = 3;  // t <- 2 - t = ~t + 3
+            for (int k = 0; k < want; ++k) {
+                const u128 sum = (u128)(~t[k]) + carry;
+                t[k] = (u64)sum;
+                carry = (u64)(sum >> 64);
+            }
+        }
+        __syncthreads();
+        block_mul_lo(t, want, x, have, x2, want, part);
+        if ((int)threadIdx.x < want) x[threadIdx.x] = x2[threadIdx.x];
+        __syncthreads();
+    }
+}
 template <int L>
 __device__ __forceinline__ Big<L> big_load(const u64* p) {
     Big<L> r;
@@ -278,6 +418,22 @@ template <int L>
 __device__ __forceinline__ void big_store(u64* p, const Big<L>& a) {
 #pragma unroll L <= 8 ? L : 1
     for (int k = 0; k < L; ++k) p[k] = a.w[k];
+}
+// The m x m matrix N, the pricing pass's products N a_j and the rows' update factors are stored WORD-MAJOR: word k of entry e at
+// base[k * entries + e], with the row index running fastest through the entries.  The threads of a wave work on neighbouring
+// entries, so a load of word k is one coalesced 512-byte access; with an integer's words side by side (round 3: 1 KB apart from
+// lane to lane at 128 limbs) every lane pulled its own cache lines and the passes over N ran at a tenth of the memory's rate.
+template <int L>
+__device__ __forceinline__ Big<L> big_load_s(const u64* p, size_t stride) {
+    Big<L> r;
+#pragma unroll L <= 8 ? L : 4
+    for (int k = 0; k < L; ++k) r.w[k] = p[(size_t)k * stride];
+    return r;
+}
+template <int L>
+__device__ __forceinline__ void big_store_s(u64* p, size_t stride, const Big<L>& a) {
+#pragma unroll L <= 8 ? L : 4
+    for (int k = 0; k < L; ++k) p[(size_t)k * stride] = a.w[k];
 }
 // sign of a * b - c * d, exactly (2 L limbs): the tie breaker of the ratio test and of the pricing rule
 template <int L>
@@ -327,7 +483,7 @@ struct ExactLP {
     const i64* rhs;       // scaled right-hand side
     int* basis;           // [m]
     int* pos;             // [n]
-    u64* N;               // [m][m] Big
+    u64* N;               // [limbs][m columns][m rows]: word-major, entry (row i, column c) = c * m + i (see big_load_s)
     u64* D;               // Big (followed by its odd part's inverse, and the scratch of the tie breakers)
     u64* xt;              // [m] Big: x~_B
     u64* alpha;           // [m] Big: alpha~_q
@@ -345,17 +501,20 @@ struct ExactLP {
     double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
     unsigned long long* part_rank;
     unsigned long long* prof;  // [16] diagnostic (RELP_EXACT_PROFILE): the leader's cycle sums per phase of the loop, candidate counts
-    u64* price_a;         // [n - n_art][m] Big: (N a_j)_i of the pricing pass
+    u64* price_a;         // [limbs][n - n_art][m]: (N a_j)_i of the pricing pass, word-major
     int* price_bits;      // ... its bit bound
     double* price_term;   // ... its share of the steepest-edge estimate
     int* bracket;         // [max(n, m) + 1] the tournament brackets over the candidates
     int* cand;            // [max(n, m) + 1] columns whose key estimate is within 1e-9 of the best (pricing); near-tied rows (ratio test)
     u64* gamma;           // [n][2 limbs + 2] their exact weights
     u64* gamma_terms;     // [candidates][m + 1][2 limbs + 2] the terms of those sums (capacity: see the host)
-    u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b (first turn of a run); afterwards [m] Big: alpha~_i / D_odd
+    u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b (first turn of a run); afterwards [limbs][m]: alpha~_i / D_odd, word-major
     int* x_bits;          // ... their bit bounds
     u64* c_part;          // [n - n_art][ceil(m / 32)] Big: partial sums of c_B' N a_j of the pricing pass
     int* c_bits;          // ... their bit bounds
+    i64* cb_row;          // [m] cost of the basic column of each row in the current phase (pricing pass B)
+    int debug_flags;      // RELP_EXACT_DEBUG (bisecting aid)
+    int* N_bits;          // [m columns][m rows] bit length of |N(i, c)|, kept by whoever writes an entry (the bounds of the passes over N read 4 bytes instead of the integer)
 };
 
 // Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
@@ -390,7 +549,7 @@ __device__ void exact_weight(const ExactLP& lp, const Big<L>& D, int j, u64* gam
     for (int i = 0; i < lp.m; ++i) {
         Big<L> a = big_from<L>(0);
         for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
-            a = big_add(a, big_mul_small(big_load<L>(lp.N + ((size_t)i * lp.m + lp.row_index[e]) * L), lp.value[e]));
+            a = big_add(a, big_mul_small(big_load_s<L>(lp.N + (size_t)lp.row_index[e] * lp.m + i, (size_t)lp.m * lp.m), lp.value[e]));
         add_square(a, (u64)lp.weight[lp.basis[i]]);
     }
 }
@@ -455,6 +614,103 @@ __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& 
     return 0;
 }
 
+// Pricing pass B for one column, by one wave (see the call site): c~_j word by word into ctil, its key estimate returned (0: not a
+// candidate).
+template <int L>
+__device__ __forceinline__ double price_column_wave(const ExactLP& lp, const Big<L>& D, int j, int phase, int lane, double mD, int eD, int D_bits,
+                                                  size_t PP, int* bits_bound) {
+    const int m = lp.m;
+    const int jj = j - lp.n_art;
+    double key = 0.0;
+    const i64 cj = phase == 1 ? lp.cost1[j] : lp.cost2[j];
+    const u64 cj_mag = cj < 0 ? (u64)(-(cj + 1)) + 1 : (u64)cj;
+    const size_t base = (size_t)jj * m;
+    int widest = 0;
+    for (int i = lane; i < m; i += WAVE) {
+        const i64 cb = lp.cb_row[i];
+        if (cb != 0) widest = max(widest, lp.price_bits[base + i] + small_bits(cb));
+    }
+    for (int d = 1; d < WAVE; d *= 2) widest = max(widest, __shfl_xor(widest, d));
+    widest = max(widest, D_bits + small_bits(cj));
+    *bits_bound = widest;  // (the caller adds the log of the number of terms and flags what might not fit)
+    // (everything relative to D: the quotients are the reference's rationals, of moderate size, whatever the limbs hold)
+    double sumsq = (double)lp.weight[j];
+    for (int i0 = 0; i0 < m; i0 += WAVE) {  // in the order of the rows, by every lane alike
+        const double term = i0 + lane < m ? lp.price_term[base + i0 + lane] : 0.0;
+        const int count = min(WAVE, m - i0);
+        for (int t = 0; t < count; ++t) sumsq += __shfl(term, t);
+    }
+    u128 acc_p = 0, acc_q = 0;
+    u64 top_p = 0, top_q = 0, borrow_lane = 0;
+    u128 carry_sum = 0;
+    u64 carry_x = 0, chain = 0;
+    bool negation_carry = true;
+    LeadingWords lead;
+    for (int k = 0; k < L; ++k) {
+        const u64* word_k = lp.price_a + (size_t)k * PP + base;
+        for (int i0 = lane; i0 < m; i0 += 4 * WAVE) {  // four rows in flight
+            u64 w[4];
+            i64 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * WAVE;
+                v[u] = i < m ? lp.cb_row[i] : 0;
+                w[u] = i < m ? word_k[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
+                const u128 prod = (u128)w[u] * mag;
+                if (v[u] >= 0) {
+                    acc_p += prod;
+                    top_p += acc_p < prod ? 1 : 0;
+                } else {
+                    acc_q += prod;
+                    top_q += acc_q < prod ? 1 : 0;
+                }
+            }
+        }
+        const u64 pk = (u64)acc_p, qk = (u64)acc_q;
+        acc_p = (acc_p >> 64) | ((u128)top_p << 64);
+        acc_q = (acc_q >> 64) | ((u128)top_q << 64);
+        top_p = top_q = 0;
+        const u64 t = pk - qk;
+        const u64 mine = t - borrow_lane;  // word k of this lane's rows (two's complement, modulo 2^(64 L))
+        borrow_lane = ((pk < qk) || (t < borrow_lane)) ? 1 : 0;
+        u64 lo = mine & 0xffffffffull, hi = mine >> 32;
+        for (int d = 1; d < WAVE; d *= 2) {
+            lo += __shfl_xor(lo, d);
+            hi += __shfl_xor(hi, d);
+        }
+        const u128 total = carry_sum + lo + ((u128)hi << 32);
+        const u64 sum_word = (u64)total;  // word k of sum_i c_B(i) (N a_j)_i
+        carry_sum = total >> 64;
+        const u128 multiple = (u128)D.w[k] * cj_mag + carry_x;  // word k of |c_j| D
+        const u64 x_word = (u64)multiple;
+        carry_x = (u64)(multiple >> 64);
+        u64 word;
+        if (cj >= 0) {  // c_j D - sum
+            const u64 t2 = x_word - sum_word;
+            word = t2 - chain;
+            chain = ((x_word < sum_word) || (t2 < chain)) ? 1 : 0;
+        } else {  // -(|c_j| D + sum)
+            const u128 y = (u128)x_word + sum_word + chain;
+            chain = (u64)(y >> 64);
+            word = ~(u64)y + (negation_carry ? 1ull : 0ull);
+            negation_carry = negation_carry && (u64)y == 0;
+        }
+        if (lane == 0) lp.ctil[(size_t)j * L + k] = word;
+        lead.feed(k, word);
+    }
+    if ((i64)lead.prev < 0) {  // D > 0: the sign of c~_j is the sign of the relative cost
+        int ec = 0;
+        const double mc = lead.mantissa(&ec);
+        const double cd = ldexp(mc / mD, ec - eD);
+        key = cd * cd / sumsq;
+    }
+    return key;
+}
+
 // The loop on the WHOLE grid (round 3; round 2 ran it in one workgroup: E226 took 100 s for 342 pivots on 2048-bit integers while
 // 255 CUs idled).  The two heavy steps of a pivot -- the pricing pass (every non-basic column against every row of N) and the
 // integer-preserving update of the m x m matrix N -- are independent per column / per entry and are spread over all workgroups of
@@ -464,8 +720,11 @@ __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& 
 // workgroup reduces again in the same order; what one thread decides (exact tie breaks, bookkeeping) is decided by thread 0 of
 // workgroup 0 and read by everybody after the barrier.  The decisions, and therefore the pivot sequence, are those of the
 // one-workgroup kernel bit for bit (tests/test_gpu_exact.py: whole golden traces).
+// (amdgpu_waves_per_eu(2, 2): at most 256 registers per lane.  Left to itself the 64-limb instance took 256 VGPRs and 114 AGPRs,
+//  one wave per SIMD, and faulted on its first pricing pass on gfx950 / ROCm 7.2 while the 32- and 128-limb instances -- no AGPRs --
+//  ran; held to two waves it spills 141 registers to scratch memory instead and runs.)
 template <int L>
-__global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
+__global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) exact_simplex_kernel(ExactLP lp) {
     namespace cg = cooperative_groups;
     cg::grid_group grid = cg::this_grid();
     __shared__ double s_key[EX_THREADS / WAVE];
@@ -473,13 +732,18 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
     __shared__ int s_overflow;
     __shared__ u64 s_dinv[L];
     __shared__ u64 s_c1[L];
-    __shared__ u64 s_words[3][L];  // operands and scratch of thread 0's word-array arithmetic
+    __shared__ u64 s_words[3][L];  // operands and scratch of the workgroup's word-array arithmetic
+    __shared__ u64 s_part[3 * L];  // ... the columns of its products (block_mul_lo)
+    static_assert(L <= EX_THREADS, "a thread per output word");
     __shared__ int s_shift;
     const int tid = threadIdx.x, T = blockDim.x;
     const int G = gridDim.x, block = blockIdx.x;
     const int gtid = block * T + tid, GT = G * T;
     const bool leader = block == 0 && tid == 0;
     const int m = lp.m, n = lp.n;
+    const size_t MM = (size_t)m * m;                                      // entries of N = its word stride
+    const size_t PP = (size_t)(n - lp.n_art > 0 ? n - lp.n_art : 1) * m;  // ... and of the pricing pass's products
+    auto N_at = [&](int i, int c) { return lp.N + (size_t)c * m + i; };   // word 0 of N(row i, column c)
     const int LIMIT_BITS = 64 * L - 3;  // a value whose magnitude bound reaches this many bits might not fit
     u64* gD = lp.D;
     int* word = lp.shared_words;  // [0] overflow flag of the grid, [1..] what the leader decides
@@ -546,6 +810,8 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         drive_row = lp.resume[5];
         n_removed = lp.resume[6];
     }
+    if (!(lp.debug_flags & 4)) for (size_t e = gtid; e < MM; e += GT) lp.N_bits[e] = big_bits(big_load_s<L>(lp.N + e, MM));
+    grid.sync();
     int at_phase = phase, at_drive_row = drive_row, at_removed = n_removed;  // ... at the start of the current turn of the loop
     bool have_xb = false;  // x~_B belongs to the current basis
     while (status == EX_RUNNING) {
@@ -561,10 +827,10 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             const int shift = big_ctz(D);
             const Big<L> odd = big_sar(D, shift);
             for (int k = 0; k < L; ++k) s_words[0][k] = odd.w[k];
-            words_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2]);
             s_shift = shift;
         }
         __syncthreads();
+        block_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2], s_part);
         const int shift = s_shift;
         Big<L> Dinv;
         for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
@@ -581,7 +847,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 for (int k = c * XC; k < min(m, (c + 1) * XC); ++k) {
                     const i64 b = lp.rhs[k];
                     if (b == 0) continue;
-                    const Big<L> nik = big_load<L>(lp.N + ((size_t)i * m + k) * L);
+                    const Big<L> nik = big_load_s<L>(N_at(i, k), MM);
                     acc = big_add(acc, big_mul_small(nik, b));
                     widest = max(widest, big_bits(nik) + small_bits(b));
                 }
@@ -609,72 +875,94 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             // per pass on E226, a few hundred busy threads.)  Pass B, a thread per column: c~_j and the weight from the stored terms,
             // in the order and with the bounds of the serial loop -- the estimates are the same bits as before.
             const int n_priced = n - lp.n_art;
-            for (long long pair = gtid; pair < (long long)n_priced * m; pair += GT) {
-                const int jj = (int)(pair / m), i = (int)(pair - (long long)jj * m);
+            // (Round 4.  A thread per pair that held N(i, r), its multiple and the running sum as three integers in scratch memory
+            //  made ~400 scratch accesses for every 32 words it read from N: 72 of 25FV47's 147 s at 128 limbs.  Now a WAVE takes a
+            //  column and 64 neighbouring rows and the sum is formed word by word, least significant first: the words of the
+            //  N(i, r_e) come straight from memory (word-major: one coalesced access per operand), the positive and the negative
+            //  multiples run in two carry-save accumulators, their difference is stored as it appears, and nothing is held but the
+            //  carries.  The bit bound comes from N_bits, the double from the two leading words gathered on the way: same numbers.)
+            for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];  // (read after pass A's barrier)
+            int eD = 0;
+            const double mD = big_mantissa(D, &eD);
+            const int row_blocks = (m + WAVE - 1) / WAVE;
+            const int lane = tid & (WAVE - 1);
+            for (long long item = gtid / WAVE; item < (long long)n_priced * row_blocks; item += GT / WAVE) {
+                const int jj = (int)(item / row_blocks), i = (int)(item - (long long)jj * row_blocks) * WAVE + lane;
                 const int j = lp.n_art + jj;
-                if (lp.pos[j] >= 0) continue;
-                Big<L> a = big_from<L>(0);
+                if (lp.pos[j] >= 0 || (lp.debug_flags & 1)) continue;  // (the whole wave)
+                const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
+                const bool active = i < m;
+                const size_t pair = (size_t)jj * m + (active ? i : 0);
                 int awide = 0;
-                for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e) {
-                    const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
-                    a = big_add(a, big_mul_small(nir, lp.value[e]));
-                    awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
+                for (int e = e0; e < e1; ++e)
+                    if (active) awide = max(awide, lp.N_bits[(size_t)lp.row_index[e] * m + i] + small_bits(lp.value[e]));
+                awide += log2_ceil(e1 - e0);
+                if (active) flag_overflow(awide);
+                u128 acc_p = 0, acc_q = 0;  // running sums of the positive / the negative multiples (192 bits with the words below)
+                u64 top_p = 0, top_q = 0;
+                u64 borrow = 0;
+                LeadingWords lead;
+                for (int k = 0; k < L; ++k) {
+                    const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
+                    for (int e = e0; e < e1; e += 4) {  // four operands in flight
+                        u64 w[4];
+                        i64 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int eu = e + u < e1 ? e + u : e1 - 1;
+                            v[u] = e + u < e1 ? lp.value[eu] : 0;
+                            w[u] = word_k[(size_t)lp.row_index[eu] * m];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
+                            const u128 prod = (u128)w[u] * mag;
+                            if (v[u] >= 0) {
+                                acc_p += prod;
+                                top_p += acc_p < prod ? 1 : 0;
+                            } else {
+                                acc_q += prod;
+                                top_q += acc_q < prod ? 1 : 0;
+                            }
+                        }
+                    }
+                    const u64 pk = (u64)acc_p, qk = (u64)acc_q;
+                    acc_p = (acc_p >> 64) | ((u128)top_p << 64);
+                    acc_q = (acc_q >> 64) | ((u128)top_q << 64);
+                    top_p = top_q = 0;
+                    const u64 t = pk - qk;
+                    const u64 word = t - borrow;
+                    borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
+                    if (active) lp.price_a[(size_t)k * PP + pair] = word;
+                    lead.feed(k, word);
                 }
-                awide += log2_ceil(lp.col_start[j + 1] - lp.col_start[j]);
-                flag_overflow(awide);
-                big_store(lp.price_a + (size_t)pair * L, a);
-                lp.price_bits[pair] = awide;
-                const double ad = big_ratio(a, D);
-                lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
+                if (active) {
+                    lp.price_bits[pair] = awide;
+                    int ea = 0;
+                    const double ma = lead.mantissa(&ea);
+                    const double ad = ldexp(ma / mD, ea - eD);
+                    lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
+                }
             }
+            if (lp.debug_flags & 16) { grid.sync(); status = EX_PIVOT_LIMIT; break; }
             grid.sync();
             stamp(9);
-            // Pass B in two steps as well (a thread per column over all m rows was the longest step of a pivot at 32 limbs: 472
-            // busy threads on E226): c_B' N a_j by (column, chunk of 32 rows), then a thread per column over its chunks.  The weight
-            // estimate is summed over the rows in order by that one thread: the same double as before, bit for bit.
-            constexpr int PC = 32;
-            const int pchunks = (m + PC - 1) / PC;
-            for (long long pair = gtid; pair < (long long)n_priced * pchunks; pair += GT) {
-                const int jj = (int)(pair / pchunks), c = (int)(pair - (long long)jj * pchunks);
-                if (lp.pos[lp.n_art + jj] >= 0) continue;
-                const size_t base = (size_t)jj * m;
-                Big<L> acc = big_from<L>(0);
-                int widest = 0;
-                for (int i = c * PC; i < min(m, (c + 1) * PC); ++i) {
-                    const int bi = lp.basis[i];
-                    const i64 cb = phase == 1 ? lp.cost1[bi] : lp.cost2[bi];
-                    if (cb != 0) {
-                        acc = big_add(acc, big_mul_small(big_load<L>(lp.price_a + (base + i) * L), cb));
-                        widest = max(widest, lp.price_bits[base + i] + small_bits(cb));
-                    }
-                }
-                big_store(lp.c_part + (size_t)pair * L, acc);
-                lp.c_bits[pair] = widest;
-            }
-            grid.sync();
-            for (int j = lp.n_art + gtid; j < n; j += GT) {
+            // Pass B, a WAVE per column (round 4; rounds 2-3: a thread per (column, 32 rows) and then a thread per column, each adding
+            // integers held in scratch memory): c~_j = c_j D - sum_i c_B(i) (N a_j)_i word by word.  Every lane streams the words of
+            // its rows (i = lane, lane + 64, ...) through its own carry-save accumulators; the 64 partial words are added across the
+            // wave as two sums of 32-bit halves, the carry of that sum, the multiple of D and the borrow of the difference run in
+            // registers, and word k of c~_j is stored when it appears.  The weight estimate is the same sequential sum of doubles.
+            for (long long item = gtid / WAVE; item < n_priced; item += GT / WAVE) {
+                const int j = lp.n_art + (int)item;
                 double key = 0.0;
-                if (lp.pos[j] < 0) {
-                    const i64 cj = phase == 1 ? lp.cost1[j] : lp.cost2[j];
-                    Big<L> ct = big_mul_small(D, cj);
-                    // (everything relative to D: the quotients are the reference's rationals, of moderate size, whatever the limbs hold)
-                    double sumsq = (double)lp.weight[j];
-                    int widest = D_bits + small_bits(cj);
-                    const size_t base = (size_t)(j - lp.n_art) * m;
-                    for (int c = 0; c < pchunks; ++c) {
-                        ct = big_sub(ct, big_load<L>(lp.c_part + ((size_t)(j - lp.n_art) * pchunks + c) * L));
-                        widest = max(widest, lp.c_bits[(size_t)(j - lp.n_art) * pchunks + c]);
-                    }
-                    for (int i = 0; i < m; ++i) sumsq += lp.price_term[base + i];
-                    flag_overflow(widest + log2_ceil(m + 1));
-                    big_store(lp.ctil + (size_t)j * L, ct);
-                    if (big_neg(ct)) {  // D > 0: the sign of c~_j is the sign of the relative cost
-                        const double cd = big_ratio(ct, D);
-                        key = cd * cd / sumsq;
-                    }
+                if (lp.pos[j] < 0 && !(lp.debug_flags & 2)) {  // (the whole wave)
+                    int widest = 0;
+                    key = price_column_wave<L>(lp, D, j, phase, lane, mD, eD, D_bits, PP, &widest);
+                    if (lane == 0) flag_overflow(widest + log2_ceil(m + 1));
                 }
-                lp.key[j] = key;
+                if (lane == 0) lp.key[j] = key;
             }
+            if (lp.debug_flags & 8) { grid.sync(); status = EX_PIVOT_LIMIT; break; }
             if (sync_overflow()) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
             stamp(1);
             // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
@@ -710,7 +998,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                         const int j = lp.cand[c];
                         u64* out = lp.gamma_terms + ((size_t)c * (m + 1) + i) * GW;
                         if (i == m) weighted_square<L>(D, (u64)lp.weight[j], out);
-                        else weighted_square<L>(big_load<L>(lp.price_a + ((size_t)(j - lp.n_art) * m + i) * L), (u64)lp.weight[lp.basis[i]], out);
+                        else weighted_square<L>(big_load_s<L>(lp.price_a + (size_t)(j - lp.n_art) * m + i, PP), (u64)lp.weight[lp.basis[i]], out);
                     }
                     grid.sync();
                     for (int c = gtid; c < n_cand; c += GT) {
@@ -784,7 +1072,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
                 if (lp.pos[j] >= 0) continue;
                 Big<L> a = big_from<L>(0);
                 for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
-                    a = big_add(a, big_mul_small(big_load<L>(lp.N + ((size_t)r * m + lp.row_index[e]) * L), lp.value[e]));
+                    a = big_add(a, big_mul_small(big_load_s<L>(N_at(r, lp.row_index[e]), MM), lp.value[e]));
                 if (!big_zero(a) && (first == RANK_NONE || (unsigned long long)j < first)) { first = (unsigned long long)j; dummy = 1.0; }
             }
             grid_argbest(dummy, first);
@@ -808,13 +1096,14 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
             Big<L> a = big_from<L>(0);
             int awide = 0;
             for (int e = lp.col_start[q]; e < lp.col_start[q + 1]; ++e) {
-                const Big<L> nir = big_load<L>(lp.N + ((size_t)i * m + lp.row_index[e]) * L);
+                const Big<L> nir = big_load_s<L>(N_at(i, lp.row_index[e]), MM);
                 a = big_add(a, big_mul_small(nir, lp.value[e]));
                 awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
             }
             flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
             big_store(lp.alpha + (size_t)i * L, a);
-            big_store(lp.x_part + (size_t)i * L, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
+            lp.x_bits[i] = big_bits(a);  // (the fit test of the update below wants it once per ENTRY of N)
+            big_store_s(lp.x_part + i, (size_t)m, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         stamp(5);
@@ -879,46 +1168,55 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         // workgroup, alpha~_i u once per row (the alpha step).
         if (tid == 0) {
             for (int k = 0; k < L; ++k) s_words[0][k] = ap.w[k];
-            words_mul_lo(s_words[0], L, s_dinv, L, s_c1, L);
         }
         __syncthreads();
+        block_mul_lo(s_words[0], L, s_dinv, L, s_c1, L, s_part);
         Big<L> c1;
         for (int k = 0; k < L; ++k) c1.w[k] = s_c1[k];
         const int ap_bits = big_bits(ap);
         // Will every new entry fit?  Decided from the bit lengths of the operands BEFORE anything is written (one more read of N:
         // microseconds beside the multiplications below), so that a run that does not fit stops with N, D and the basis as they
         // were at the start of this pivot -- the state the next width continues from (host driver).
-        for (int idx = gtid; idx < m * m; idx += GT) {
-            const int i = idx / m, k = idx - i * m;
+        for (int idx = gtid; idx < m * m; idx += GT) {  // (entry idx = column k, row i: the rows run through a wave, N(p, k) is the same word for all of it)
+            const int k = idx / m, i = idx - k * m;
             if (i == p) continue;
-            const int estimate = max(ap_bits + big_bits(big_load<L>(lp.N + (size_t)idx * L)),
-                                     big_bits(big_load<L>(lp.alpha + (size_t)i * L)) + big_bits(big_load<L>(lp.N + ((size_t)p * m + k) * L))) + 1 - (D_bits - 1);
+            const int estimate = max(ap_bits + lp.N_bits[idx], lp.x_bits[i] + lp.N_bits[(size_t)k * m + p]) + 1 - (D_bits - 1);
             if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
         }
         {
             const int xp_bits = big_bits(big_load<L>(lp.xt + (size_t)p * L));
             for (int i = gtid; i < m; i += GT) {
                 if (i == p) continue;
-                const int estimate = max(ap_bits + big_bits(big_load<L>(lp.xt + (size_t)i * L)), big_bits(big_load<L>(lp.alpha + (size_t)i * L)) + xp_bits) + 1 - (D_bits - 1);
+                const int estimate = max(ap_bits + big_bits(big_load<L>(lp.xt + (size_t)i * L)), lp.x_bits[i] + xp_bits) + 1 - (D_bits - 1);
                 if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
             }
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         for (int idx = gtid; idx < m * m; idx += GT) {
-            const int i = idx / m, k = idx - i * m;
+            const int k = idx / m, i = idx - k * m;
             if (i == p) continue;
-            const Big<L> ri = big_load<L>(lp.x_part + (size_t)i * L);
-            const Big<L> nik = big_load<L>(lp.N + (size_t)idx * L);
-            const Big<L> npk = big_load<L>(lp.N + ((size_t)p * m + k) * L);
-            Big<L> quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
+            // (N(p, k) is the same word for the whole wave -- the rows run through it -- and row p of N is sparse: where it is zero the
+            //  entry is only rescaled, one product instead of two, and a zero entry stays what it is)
+            const bool row_p_zero = lp.N_bits[(size_t)k * m + p] == 0;
+            if (row_p_zero && lp.N_bits[idx] == 0) continue;
+            const Big<L> nik = big_load_s<L>(lp.N + (size_t)idx, MM);
+            Big<L> quotient;
+            if (row_p_zero) {
+                quotient = big_sar(big_mul_lo(c1, nik), shift);
+            } else {
+                const Big<L> ri = big_load_s<L>(lp.x_part + i, (size_t)m);
+                const Big<L> npk = big_load_s<L>(N_at(p, k), MM);
+                quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
+            }
             if (flip) quotient = big_negate(quotient);
-            big_store(lp.N + (size_t)idx * L, quotient);
+            big_store_s(lp.N + (size_t)idx, MM, quotient);
+            lp.N_bits[idx] = big_bits(quotient);
         }
         {   // x~_B = N b is one more column of N: x~'_i = (alpha~_p x~_i - alpha~_i x~_p) / D, row p stays
             const Big<L> xp = big_load<L>(lp.xt + (size_t)p * L);
             for (int i = gtid; i < m; i += GT) {
                 if (i == p) continue;
-                const Big<L> ri = big_load<L>(lp.x_part + (size_t)i * L);
+                const Big<L> ri = big_load_s<L>(lp.x_part + i, (size_t)m);
                 Big<L> quotient = big_sar(big_sub(big_mul_lo(c1, big_load<L>(lp.xt + (size_t)i * L)), big_mul_lo(ri, xp)), shift);
                 if (flip) quotient = big_negate(quotient);
                 big_store(lp.xt + (size_t)i * L, quotient);
@@ -927,7 +1225,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         stamp(7);
         grid.sync();  // (row p is an operand of every other row above -- nobody may still be reading it)
         if (flip) {
-            for (int k = gtid; k < m; k += GT) big_store(lp.N + ((size_t)p * m + k) * L, big_negate(big_load<L>(lp.N + ((size_t)p * m + k) * L)));
+            for (int k = gtid; k < m; k += GT) big_store_s(N_at(p, k), MM, big_negate(big_load_s<L>(N_at(p, k), MM)));
             if (gtid == 0) big_store(lp.xt + (size_t)p * L, big_negate(big_load<L>(lp.xt + (size_t)p * L)));
             ap = big_negate(ap);
         }
@@ -959,7 +1257,7 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
         Big<L> acc = big_from<L>(0);
         for (int k = 0; k < m; ++k) {
             const i64 b = lp.rhs[k];
-            if (b != 0) acc = big_add(acc, big_mul_small(big_load<L>(lp.N + ((size_t)i * m + k) * L), b));
+            if (b != 0) acc = big_add(acc, big_mul_small(big_load_s<L>(N_at(i, k), MM), b));
         }
         big_store(lp.xt + (size_t)i * L, acc);
     }
@@ -979,11 +1277,11 @@ __global__ void __launch_bounds__(EX_THREADS) exact_simplex_kernel(ExactLP lp) {
 
 // Sign extension of `count` integers from `from` to `to` words each (a run that overflowed continues at the next width).
 __global__ void __launch_bounds__(256) exact_widen_kernel(const u64* src, u64* dst, long long count, int from, int to) {
-    const long long total = count * to;
+    const long long total = count * to;  // (word-major on both sides: word k of integer v at [k * count + v])
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const long long v = idx / to;
-        const int k = (int)(idx - v * to);
-        dst[idx] = k < from ? src[v * from + k] : (u64)((i64)src[v * from + from - 1] >> 63);
+        const int k = (int)(idx / count);
+        const long long v = idx - (long long)k * count;
+        dst[idx] = k < from ? src[idx] : (u64)((i64)src[(long long)(from - 1) * count + v] >> 63);
     }
 }
 
@@ -1128,7 +1426,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     double* d_price_term = dalloc<double>(pairs, owned);
     int* d_bracket = dalloc<int>(std::max(n, m) + 1, owned);
     int* d_cand = dalloc<int>(std::max(n, m) + 1, owned);
-    u64* d_gamma = dalloc<u64>((size_t)n * (2 * 32 + 2), owned);
+    int* d_N_bits = dalloc<int>((size_t)m * m, owned);
+    i64* d_cb_row = dalloc<i64>(m, owned);
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
@@ -1165,6 +1464,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_alpha = dalloc<u64>((size_t)m * big, fresh);
         u64* d_ctil = dalloc<u64>((size_t)n * big, fresh);
         d_price_a = dalloc<u64>(pairs * big, fresh);
+        u64* d_gamma = dalloc<u64>((size_t)n * (2 * big + 2), fresh);  // (round 3 sized it for 32 limbs: a wider run with many tied candidates wrote past it)
         u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), fresh);
         u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
@@ -1197,7 +1497,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
             for (int i = 0; i < m; ++i) {
                 BigInt q, r;
                 BigInt::divmod(D0, BigInt(diag0[i]), q, r);
-                words(q, hN.data() + ((size_t)i * m + i) * big);
+                std::vector<u64> w(big);
+                words(q, w.data());
+                for (int k = 0; k < limbs; ++k) hN[(size_t)k * m * m + (size_t)i * m + i] = w[k];  // word-major (big_load_s)
             }
             RELP_HIP(hipMemcpyAsync(d_N, hN.data(), hN.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
             RELP_HIP(hipMemcpyAsync(d_D, hD.data(), big * sizeof(u64), hipMemcpyHostToDevice, stream));
@@ -1208,7 +1510,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
         if (d_prof) RELP_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_c_part, d_c_bits};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_c_part, d_c_bits, d_cb_row, getenv("RELP_EXACT_DEBUG") ? atoi(getenv("RELP_EXACT_DEBUG")) : 0, d_N_bits};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
