@@ -898,43 +898,88 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     if (active) awide = max(awide, lp.N_bits[(size_t)lp.row_index[e] * m + i] + small_bits(lp.value[e]));
                 awide += log2_ceil(e1 - e0);
                 if (active) flag_overflow(awide);
-                u128 acc_p = 0, acc_q = 0;  // running sums of the positive / the negative multiples (192 bits with the words below)
-                u64 top_p = 0, top_q = 0;
+                // The column's entries are read once, one per lane, and handed round with readlane (columns of more than 64 entries read
+                // them from memory at every use); two words of the result are formed per turn, the operands of both in flight
+                // together -- with one wave per SIMD on the grid the pass waits on memory, not on arithmetic.
+                const int len = e1 - e0;
+                const bool in_lanes = len <= WAVE;
+                int my_offset = 0;  // row_index * m of entry e0 + lane
+                i64 my_value = 0;
+                if (in_lanes && lane < len) {
+                    my_offset = lp.row_index[e0 + lane] * m;
+                    my_value = lp.value[e0 + lane];
+                }
+                auto entry = [&](int e, int* offset, i64* value) {  // e - e0 uniform over the wave
+                    if (in_lanes) {
+                        *offset = __builtin_amdgcn_readlane(my_offset, e);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u64)my_value, e);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((u64)my_value >> 32), e);
+                        *value = (i64)(((u64)hi << 32) | lo);
+                    } else {
+                        *offset = lp.row_index[e0 + e] * m;
+                        *value = lp.value[e0 + e];
+                    }
+                };
+                struct Sum {  // 192 bits, carry-save
+                    u128 acc = 0;
+                    u64 top = 0;
+                    __device__ __forceinline__ void add(u128 v) {
+                        acc += v;
+                        top += acc < v ? 1 : 0;
+                    }
+                    __device__ __forceinline__ u64 pop() {  // the lowest word leaves, the rest moves down
+                        const u64 word = (u64)acc;
+                        acc = (acc >> 64) | ((u128)top << 64);
+                        top = 0;
+                        return word;
+                    }
+                };
+                Sum pos, neg;  // running sums of the positive / the negative multiples
                 u64 borrow = 0;
                 LeadingWords lead;
-                for (int k = 0; k < L; ++k) {
-                    const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
-                    for (int e = e0; e < e1; e += 4) {  // four operands in flight
-                        u64 w[4];
-                        i64 v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int eu = e + u < e1 ? e + u : e1 - 1;
-                            v[u] = e + u < e1 ? lp.value[eu] : 0;
-                            w[u] = word_k[(size_t)lp.row_index[eu] * m];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
-                            const u128 prod = (u128)w[u] * mag;
-                            if (v[u] >= 0) {
-                                acc_p += prod;
-                                top_p += acc_p < prod ? 1 : 0;
-                            } else {
-                                acc_q += prod;
-                                top_q += acc_q < prod ? 1 : 0;
-                            }
-                        }
-                    }
-                    const u64 pk = (u64)acc_p, qk = (u64)acc_q;
-                    acc_p = (acc_p >> 64) | ((u128)top_p << 64);
-                    acc_q = (acc_q >> 64) | ((u128)top_q << 64);
-                    top_p = top_q = 0;
+                auto emit = [&](int k) {
+                    const u64 pk = pos.pop(), qk = neg.pop();
                     const u64 t = pk - qk;
                     const u64 word = t - borrow;
                     borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
                     if (active) lp.price_a[(size_t)k * PP + pair] = word;
                     lead.feed(k, word);
+                };
+                constexpr int KU = L >= 2 ? 2 : 1;
+                for (int k = 0; k < L; k += KU) {
+                    const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
+                    Sum pos_next, neg_next;  // the multiples of word k + 1
+                    for (int e = 0; e < len; e += 4) {  // four operands (of both words) in flight
+                        u64 w0[4], w1[4];
+                        i64 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            int offset;
+                            entry(e + u < len ? e + u : len - 1, &offset, &v[u]);
+                            if (e + u >= len) v[u] = 0;
+                            w0[u] = word_k[offset];
+                            w1[u] = KU == 2 ? word_k[MM + offset] : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
+                            if (v[u] >= 0) {
+                                pos.add((u128)w0[u] * mag);
+                                if (KU == 2) pos_next.add((u128)w1[u] * mag);
+                            } else {
+                                neg.add((u128)w0[u] * mag);
+                                if (KU == 2) neg_next.add((u128)w1[u] * mag);
+                            }
+                        }
+                    }
+                    emit(k);
+                    if (KU == 2) {
+                        pos.add(pos_next.acc);
+                        pos.top += pos_next.top;
+                        neg.add(neg_next.acc);
+                        neg.top += neg_next.top;
+                        emit(k + 1);
+                    }
                 }
                 if (active) {
                     lp.price_bits[pair] = awide;
@@ -1191,25 +1236,62 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
             }
         }
-        if (sync_overflow()) { status = EX_OVERFLOW; break; }
-        for (int idx = gtid; idx < m * m; idx += GT) {
-            const int k = idx / m, i = idx - k * m;
-            if (i == p) continue;
-            // (N(p, k) is the same word for the whole wave -- the rows run through it -- and row p of N is sparse: where it is zero the
-            //  entry is only rescaled, one product instead of two, and a zero entry stays what it is)
-            const bool row_p_zero = lp.N_bits[(size_t)k * m + p] == 0;
-            if (row_p_zero && lp.N_bits[idx] == 0) continue;
-            const Big<L> nik = big_load_s<L>(lp.N + (size_t)idx, MM);
-            Big<L> quotient;
-            if (row_p_zero) {
-                quotient = big_sar(big_mul_lo(c1, nik), shift);
-            } else {
-                const Big<L> ri = big_load_s<L>(lp.x_part + i, (size_t)m);
-                const Big<L> npk = big_load_s<L>(N_at(p, k), MM);
-                quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
+        // The columns of N by what their entries cost below: N(p, k) != 0 (two products an entry) first, then the others (one product,
+        // or nothing where the entry is zero as well).  Each class is spread over the whole grid by itself: with the columns taken
+        // as they come a wave drew ten of them and the slowest wave's draw set the pace (a fifth of the update at 128 limbs).
+        if (block == 0) {
+            __shared__ int s_class_count[EX_THREADS / WAVE][2];
+            int done[2] = {0, 0};
+            for (int base = 0; base < m; base += T) {
+                const int k = base + tid;
+                const bool valid = k < m;
+                const bool heavy = valid && lp.N_bits[(size_t)k * m + p] != 0;
+                const unsigned long long heavy_mask = __ballot(heavy), light_mask = __ballot(valid && !heavy);
+                const int wave = tid / WAVE, ln = tid & (WAVE - 1);
+                __syncthreads();
+                if (ln == 0) {
+                    s_class_count[wave][0] = __popcll(heavy_mask);
+                    s_class_count[wave][1] = __popcll(light_mask);
+                }
+                __syncthreads();
+                int before[2] = {done[0], done[1]}, all[2] = {0, 0};
+                for (int wv = 0; wv < T / WAVE; ++wv)
+                    for (int c = 0; c < 2; ++c) {
+                        if (wv < wave) before[c] += s_class_count[wv][c];
+                        all[c] += s_class_count[wv][c];
+                    }
+                const unsigned long long below = (1ull << ln) - 1ull;
+                if (heavy) lp.bracket[before[0] + __popcll(heavy_mask & below)] = k;
+                else if (valid) lp.cand[before[1] + __popcll(light_mask & below)] = k;
+                done[0] += all[0];
+                done[1] += all[1];
             }
+            if (tid == 0) word[7] = done[0];
+        }
+        if (sync_overflow()) { status = EX_OVERFLOW; break; }
+        const int n_heavy = word[7];
+        for (long long unit = gtid; unit < (long long)n_heavy * m; unit += GT) {  // N(p, k) != 0: two products
+            const int kk = (int)(unit / m), i = (int)(unit - (long long)kk * m);
+            if (i == p) continue;
+            const int k = lp.bracket[kk];
+            const size_t idx = (size_t)k * m + i;
+            const Big<L> ri = big_load_s<L>(lp.x_part + i, (size_t)m);
+            const Big<L> nik = big_load_s<L>(lp.N + idx, MM);
+            const Big<L> npk = big_load_s<L>(N_at(p, k), MM);
+            Big<L> quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
             if (flip) quotient = big_negate(quotient);
-            big_store_s(lp.N + (size_t)idx, MM, quotient);
+            big_store_s(lp.N + idx, MM, quotient);
+            lp.N_bits[idx] = big_bits(quotient);
+        }
+        for (long long unit = gtid; unit < (long long)(m - n_heavy) * m; unit += GT) {  // N(p, k) == 0: the entry is only rescaled
+            const int kk = (int)(unit / m), i = (int)(unit - (long long)kk * m);
+            if (i == p) continue;
+            const int k = lp.cand[kk];
+            const size_t idx = (size_t)k * m + i;
+            if (lp.N_bits[idx] == 0) continue;  // (and a zero stays a zero)
+            Big<L> quotient = big_sar(big_mul_lo(c1, big_load_s<L>(lp.N + idx, MM)), shift);
+            if (flip) quotient = big_negate(quotient);
+            big_store_s(lp.N + idx, MM, quotient);
             lp.N_bits[idx] = big_bits(quotient);
         }
         {   // x~_B = N b is one more column of N: x~'_i = (alpha~_p x~_i - alpha~_i x~_p) / D, row p stays

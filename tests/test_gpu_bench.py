@@ -95,7 +95,11 @@ def test_default_bench_compact_line_and_detail_file_with_every_baseline_config()
     exact = configs["exact_e226"]
     assert exact["config"]["matches_golden_optimum_and_pivot_counts"] is True and exact["same_work"]["same_pivot_count"] is True
     assert short["same_work_exact"]["lp"] == "E226" and short["same_work_exact"]["cpu_over_gpu"] > 0
-    assert configs["exact_25fv47"]["recorded"] is True and configs["exact_25fv47"]["config"]["limbs"] == 128
+    # ... and of the metric's LP itself, measured in this run: 1133 + 1259 pivots at 128 limbs, optimum and counts those of the golden file
+    whole = configs["exact_25fv47"]
+    assert whole["recorded"] is False and whole["config"]["limbs"] == 128 and whole["config"]["pivots_per_solve"] == 2392
+    assert whole["config"]["matches_golden_optimum_and_pivot_counts"] is True
+    assert short["same_work_exact_25fv47"]["cpu_over_gpu"] > 4.0 and short["same_work_exact_25fv47"]["matches_golden"] is True
     assert abs(configs["dense4096_f64"]["config"]["objective"] + 202885.40946447) < 1e-4
     assert abs(configs["dense4096_narrowest"]["config"]["objective"] + 202885.40946447) < 1e-4
     assert configs["dense4096_f64"]["roofline"]["kernel"] == "price" and configs["dense4096_f64"]["roofline"]["frac"] > 0.4
