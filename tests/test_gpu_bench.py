@@ -84,7 +84,7 @@ def test_default_bench_compact_line_and_detail_file_with_every_baseline_config()
         assert "error" not in entry, (name, entry)
         assert entry["value"] > 0 and entry["ms_per_step"] > 0 and entry["unit"] == "pivots/s", name
         assert entry["roofline"]["frac"] > 0 and entry["roofline"]["peak"] == 8000.0, name
-        assert entry["cpu_baseline"]["value"] > 0 and (entry.get("recorded") or entry["cpu_baseline"]["nproc"] >= 1), name
+        assert entry["cpu_baseline"]["value"] > 0 and (entry.get("recorded") or entry["cpu_baseline"].get("recorded") or entry["cpu_baseline"]["nproc"] >= 1), name
     assert configs["lu_carry_25fv47"]["config"]["carry"] == "lu" and configs["lu_carry_25fv47"]["config"]["exact"]["certified"] is True
     assert configs["lu_inverse_carry_25fv47"]["config"]["carry"] == "lu_inverse" and configs["lu_inverse_carry_25fv47"]["config"]["exact"]["certified"] is True
     assert configs["lu_inverse_carry_25fv47"]["roofline"]["kernel"] == "lu_pivot"
