@@ -1499,8 +1499,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_resume = dalloc<int>(8, owned);
     int* d_removed = dalloc<int>(m, owned);
     int* d_words = dalloc<int>(8, owned);
-    double* d_part_key = dalloc<double>(2 * 256, owned);
-    unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * 256, owned);
+    constexpr int EX_MAX_GRID = 1024;
+    double* d_part_key = dalloc<double>(2 * EX_MAX_GRID, owned);
+    unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * EX_MAX_GRID, owned);
     unsigned long long* d_prof = getenv("RELP_EXACT_PROFILE") ? dalloc<unsigned long long>(16, owned) : nullptr;
     const size_t pairs = (size_t)std::max(1, n - n_art) * m;
     u64* d_price_a = nullptr;   // (sized per limb count below)
@@ -1596,7 +1597,10 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
-        if (const char* forced = getenv("RELP_EXACT_GRID")) grid = std::max(1, std::min(256, atoi(forced)));
+        // ... and two per CU where a pivot is milliseconds of arithmetic (25FV47 from 64 limbs on: 50 -> 39 s; at one wave per SIMD the
+        // passes wait on memory and on scratch) -- not below: the barriers of 512 workgroups cost SCORPION and E226 a tenth of a second.
+        if ((double)m * m * limbs * limbs >= 1e9) grid = 512;
+        if (const char* forced = getenv("RELP_EXACT_GRID")) grid = std::max(1, std::min(EX_MAX_GRID, atoi(forced)));
         void* kernel = nullptr;
         switch (limbs) {
             case 1: kernel = (void*)exact_simplex_kernel<1>; break;
