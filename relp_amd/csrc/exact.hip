@@ -116,10 +116,12 @@ __device__ __forceinline__ Big<L> big_mul_small(const Big<L>& a, i64 b) {
 // ran at 4 % of the multiplier's rate (25FV47: 132 of 252 s).  Here the product is formed four output words at a time
 // (product scanning by 4 x 4 blocks): a block pair costs eight scratch reads for sixteen word products, the running sum is a
 // window of nine words in registers, and nothing is written but the result.  Same value: the product modulo 2^(64 L).
+// `blocks` < L / 4: only the low 4 * blocks words of the product are formed (the words above are left zero) -- the caller knows
+// that the value it is after fits there (see the update of N).
 template <int L>
-__device__ __forceinline__ Big<L> big_mul_lo_blocked(const Big<L>& a, const Big<L>& b) {
+__device__ __forceinline__ Big<L> big_mul_lo_blocked(const Big<L>& a, const Big<L>& b, int blocks = L / 4) {
     static_assert(L % 4 == 0, "four words per block");
-    constexpr int NB = L / 4;
+    const int NB = blocks;
     Big<L> r;
     u64 acc[9];
 #pragma unroll
@@ -157,6 +159,17 @@ __device__ __forceinline__ Big<L> big_mul_lo_blocked(const Big<L>& a, const Big<
 #pragma unroll
         for (int t = 5; t < 9; ++t) acc[t] = 0;
     }
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 4 * NB; k < L; ++k) r.w[k] = 0;
+    return r;
+}
+// the value of the low `words` words of a, as a signed number of that length, in all L words
+template <int L>
+__device__ __forceinline__ Big<L> big_sign_extend(const Big<L>& a, int words) {
+    Big<L> r = a;
+    const u64 fill = (i64)a.w[words - 1] < 0 ? ~0ull : 0ull;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = words; k < L; ++k) r.w[k] = fill;
     return r;
 }
 // a * b mod 2^(64 L)  (the low half of the product: exact whenever the true product fits)
@@ -257,6 +270,7 @@ struct LeadingWords {
 template <int L>
 __device__ __forceinline__ double big_mantissa(const Big<L>& v, int* exponent) {  // (the same numbers from a value held whole)
     LeadingWords lead;
+#pragma unroll L <= 8 ? L : 1
     for (int k = 0; k < L; ++k) lead.feed(k, v.w[k]);
     return lead.mantissa(exponent);
 }
@@ -426,13 +440,13 @@ __device__ __forceinline__ void big_store(u64* p, const Big<L>& a) {
 template <int L>
 __device__ __forceinline__ Big<L> big_load_s(const u64* p, size_t stride) {
     Big<L> r;
-#pragma unroll L <= 8 ? L : 4
+#pragma unroll L <= 8 ? L : 1
     for (int k = 0; k < L; ++k) r.w[k] = p[(size_t)k * stride];
     return r;
 }
 template <int L>
 __device__ __forceinline__ void big_store_s(u64* p, size_t stride, const Big<L>& a) {
-#pragma unroll L <= 8 ? L : 4
+#pragma unroll L <= 8 ? L : 1
     for (int k = 0; k < L; ++k) p[(size_t)k * stride] = a.w[k];
 }
 // sign of a * b - c * d, exactly (2 L limbs): the tie breaker of the ratio test and of the pricing rule
@@ -646,6 +660,7 @@ __device__ __forceinline__ double price_column_wave(const ExactLP& lp, const Big
     u64 carry_x = 0, chain = 0;
     bool negation_carry = true;
     LeadingWords lead;
+#pragma unroll L <= 8 ? L : 1
     for (int k = 0; k < L; ++k) {
         const u64* word_k = lp.price_a + (size_t)k * PP + base;
         for (int i0 = lane; i0 < m; i0 += 4 * WAVE) {  // four rows in flight
@@ -826,6 +841,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if (tid == 0) {
             const int shift = big_ctz(D);
             const Big<L> odd = big_sar(D, shift);
+#pragma unroll L <= 8 ? L : 1
             for (int k = 0; k < L; ++k) s_words[0][k] = odd.w[k];
             s_shift = shift;
         }
@@ -833,6 +849,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         block_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2], s_part);
         const int shift = s_shift;
         Big<L> Dinv;
+#pragma unroll L <= 8 ? L : 1
         for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
         // ---- x~_B = N b: a thread per (row, chunk of 32 columns), then a thread per row over its chunks (same bounds as the serial loop).
         //      Only on the first turn of a run: a pivot updates x~_B like one more column of N (below) -- recomputing it was 15 % of E226. ----
@@ -946,7 +963,11 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     lead.feed(k, word);
                 };
                 constexpr int KU = L >= 2 ? 2 : 1;
-                for (int k = 0; k < L; k += KU) {
+                // (the sum fits `awide` bits: the words above that many are its sign, not worth their operands' loads)
+                int words = active ? min(L, (awide + 2 + 63) / 64) : 1;
+                for (int d = 1; d < WAVE; d *= 2) words = max(words, __shfl_xor(words, d));
+                words = min(L, (words + KU - 1) / KU * KU);
+                for (int k = 0; k < words; k += KU) {
                     const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
                     Sum pos_next, neg_next;  // the multiples of word k + 1
                     for (int e = 0; e < len; e += 4) {  // four operands (of both words) in flight
@@ -979,6 +1000,14 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                         neg.add(neg_next.acc);
                         neg.top += neg_next.top;
                         emit(k + 1);
+                    }
+                }
+                {
+                    const u64 fill = (i64)lead.prev < 0 ? ~0ull : 0ull;
+#pragma unroll L <= 8 ? L : 1
+                    for (int k = words; k < L; ++k) {
+                        if (active) lp.price_a[(size_t)k * PP + pair] = fill;
+                        lead.feed(k, fill);
                     }
                 }
                 if (active) {
@@ -1212,11 +1241,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         // TWO truncated products per entry (the numerator first and then its product with u were three); alpha~_p u once per
         // workgroup, alpha~_i u once per row (the alpha step).
         if (tid == 0) {
+#pragma unroll L <= 8 ? L : 1
             for (int k = 0; k < L; ++k) s_words[0][k] = ap.w[k];
         }
         __syncthreads();
         block_mul_lo(s_words[0], L, s_dinv, L, s_c1, L, s_part);
         Big<L> c1;
+#pragma unroll L <= 8 ? L : 1
         for (int k = 0; k < L; ++k) c1.w[k] = s_c1[k];
         const int ap_bits = big_bits(ap);
         // Will every new entry fit?  Decided from the bit lengths of the operands BEFORE anything is written (one more read of N:
@@ -1278,7 +1309,20 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const Big<L> ri = big_load_s<L>(lp.x_part + i, (size_t)m);
             const Big<L> nik = big_load_s<L>(lp.N + idx, MM);
             const Big<L> npk = big_load_s<L>(N_at(p, k), MM);
-            Big<L> quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
+            Big<L> quotient;
+            if constexpr (L >= 16) {
+                // 2^shift N'_ik is known to fit `needed` bits (the bound of the fit test above) and the products are exact modulo any
+                // power of two: only the 4-word blocks that hold it are formed, the largest count of the wave for all of it (the
+                // integers of a run rarely fill the width its largest one forced: 16.5 -> 11.8 s of 25FV47's update at 128 limbs).
+                const int needed = max(ap_bits + lp.N_bits[idx], lp.x_bits[i] + lp.N_bits[(size_t)k * m + p]) + 1 - (D_bits - 1) + shift + 2;
+                int blocks = min(L / 4, max(1, (needed + 255) / 256));
+                for (int d = 1; d < WAVE; d *= 2) blocks = max(blocks, __shfl_xor(blocks, d));
+                blocks = min(L / 4, blocks);  // (a lane that sits this turn out contributes whatever its register holds)
+                const Big<L> numerator = big_sub(big_mul_lo_blocked(c1, nik, blocks), big_mul_lo_blocked(ri, npk, blocks));
+                quotient = big_sar(big_sign_extend(numerator, 4 * blocks), shift);
+            } else {
+                quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
+            }
             if (flip) quotient = big_negate(quotient);
             big_store_s(lp.N + idx, MM, quotient);
             lp.N_bits[idx] = big_bits(quotient);
@@ -1288,8 +1332,19 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             if (i == p) continue;
             const int k = lp.cand[kk];
             const size_t idx = (size_t)k * m + i;
-            if (lp.N_bits[idx] == 0) continue;  // (and a zero stays a zero)
-            Big<L> quotient = big_sar(big_mul_lo(c1, big_load_s<L>(lp.N + idx, MM)), shift);
+            const bool zero = lp.N_bits[idx] == 0;  // (a zero stays a zero)
+            Big<L> quotient;
+            if constexpr (L >= 16) {
+                const int needed = zero ? 0 : ap_bits + lp.N_bits[idx] + 1 - (D_bits - 1) + shift + 2;
+                int blocks = min(L / 4, max(1, (needed + 255) / 256));
+                for (int d = 1; d < WAVE; d *= 2) blocks = max(blocks, __shfl_xor(blocks, d));
+                blocks = min(L / 4, blocks);
+                if (zero) continue;
+                quotient = big_sar(big_sign_extend(big_mul_lo_blocked(c1, big_load_s<L>(lp.N + idx, MM), blocks), 4 * blocks), shift);
+            } else {
+                if (zero) continue;
+                quotient = big_sar(big_mul_lo(c1, big_load_s<L>(lp.N + idx, MM)), shift);
+            }
             if (flip) quotient = big_negate(quotient);
             big_store_s(lp.N + idx, MM, quotient);
             lp.N_bits[idx] = big_bits(quotient);
