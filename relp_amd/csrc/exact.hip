@@ -163,6 +163,69 @@ __device__ __forceinline__ Big<L> big_mul_lo_blocked(const Big<L>& a, const Big<
     for (int k = 4 * NB; k < L; ++k) r.w[k] = 0;
     return r;
 }
+// a * b modulo 2^(64 L) by one WAVE, stored word-major at out[k * stride]: lane K < L / 4 forms the block products that land in
+// output block K (the same 4 x 4 blocks, a window of nine words with nothing carried in), then the windows are chained in
+// order -- every lane alike, from the other lanes' registers -- and lane 0 stores the words.  a in memory (L words side by side),
+// b in LDS.  (The rows' factors alpha~_i u of the update: a product per row by one thread each was 1.3 ms of every pivot at 128 limbs.)
+template <int L>
+__device__ __noinline__ void wave_mul_lo_store(const u64* a, const u64* b, u64* out, size_t stride, int lane) {
+    static_assert(L % 4 == 0 && L / 4 <= WAVE, "a lane per block of four words");
+    constexpr int NB = L / 4;
+    u64 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0;
+    if (lane < NB) {
+#pragma unroll 1
+        for (int I = 0; I <= lane; ++I) {
+            const int J = lane - I;
+            u64 a4[4], b4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a4[t] = a[4 * I + t];
+                b4[t] = b[4 * J + t];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                u64 carry = 0;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const u128 t = (u128)a4[ii] * b4[jj] + acc[ii + jj] + carry;
+                    acc[ii + jj] = (u64)t;
+                    carry = (u64)(t >> 64);
+                }
+#pragma unroll
+                for (int k = ii + 4; k < 9; ++k) {
+                    const u128 t = (u128)acc[k] + carry;
+                    acc[k] = (u64)t;
+                    carry = (u64)(t >> 64);
+                }
+            }
+        }
+    }
+    u64 over[5] = {0, 0, 0, 0, 0};  // what the blocks below carry into the current one
+#pragma unroll 1
+    for (int K = 0; K < NB; ++K) {
+        u64 window[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)acc[k], K), hi = (unsigned)__builtin_amdgcn_readlane((int)(acc[k] >> 32), K);
+            window[k] = ((u64)hi << 32) | lo;
+        }
+        u64 carry = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const u128 t = (u128)window[k] + (k < 5 ? over[k] : 0ull) + carry;
+            window[k] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) out[(size_t)(4 * K + t) * stride] = window[t];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) over[k] = window[k + 4];
+    }
+}
 // the value of the low `words` words of a, as a signed number of that length, in all L words
 template <int L>
 __device__ __forceinline__ Big<L> big_sign_extend(const Big<L>& a, int words) {
@@ -457,6 +520,10 @@ __device__ int sign_of_difference(const Big<L>& a, const Big<L>& b, const Big<L>
         const bool nx = big_neg(x), ny = big_neg(y);
         const Big<L> mx = nx ? big_negate(x) : x, my = ny ? big_negate(y) : y;
         for (int k = 0; k < 2 * L; ++k) out[k] = 0;
+        if (big_zero(x) || big_zero(y)) {  // (the ties of a degenerate pivot are x~_i = 0 against x~_j = 0: no L^2 word products for those)
+            *negative = false;
+            return true;
+        }
         for (int i = 0; i < L; ++i) {
             u64 carry = 0;
             for (int j = 0; j < L; ++j) {
@@ -1177,7 +1244,11 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
             big_store(lp.alpha + (size_t)i * L, a);
             lp.x_bits[i] = big_bits(a);  // (the fit test of the update below wants it once per ENTRY of N)
-            big_store_s(lp.x_part + i, (size_t)m, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
+            if constexpr (L < 16) big_store_s(lp.x_part + i, (size_t)m, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
+        }
+        if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store)
+            grid.sync();
+            for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         stamp(5);
