@@ -1832,22 +1832,46 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
                                                               double harris_delta, int skip_artificial_rows) {
     __shared__ Cand s_cand[18];
     __shared__ double s_red[18];
-    __shared__ int s_q, s_inline;
+    __shared__ int s_q, s_inline, s_short;
     __shared__ double s_cbar;
     __shared__ int s_rows[K2_COL_CHUNK];
     __shared__ double s_vals[K2_COL_CHUNK];
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING) return;
+    // ---- ONE memory round trip: the control word, this thread's row, and the candidate of "its" pricing workgroup with everything
+    //      the winner will need (reduced cost, length, the first two entries of the column: all of an incidence column).  Round 3
+    //      read them one after the other -- control word, candidates, the winner's reduced cost and length, its entries, the
+    //      inverse: five dependent trips of ~1.5 us in a 9.7 us kernel (config 5).
+    const int m = lp.m, ld = lp.ld;
+    const bool bounded = lp.ub != nullptr;
+    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
+    const double xb = i < m ? lp.xB[i] : 0.0;
+    const int bas = i < m ? lp.basis[i] : 0;
+    const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
+    const int b_mine = threadIdx.x;
+    int mine_j = -1, mine_len = -1, mine_row0 = 0, mine_row1 = 0;
+    double mine_key = 0.0, mine_cbar = 0.0, mine_val0 = 0.0, mine_val1 = 0.0;
+    if (b_mine < n_price_blocks) {
+        mine_j = lp.cand_j[b_mine];
+        mine_key = lp.cand_key[b_mine];
+        mine_cbar = lp.cand_cbar[b_mine];
+        mine_len = lp.cand_len[b_mine];
+        mine_row0 = lp.cand_rows[(size_t)b_mine * ELL_W];
+        mine_row1 = lp.cand_rows[(size_t)b_mine * ELL_W + 1];
+        mine_val0 = lp.cand_vals[(size_t)b_mine * ELL_W];
+        mine_val1 = lp.cand_vals[(size_t)b_mine * ELL_W + 1];
+    }
+    const int status = ctl->status;
+    const long long iters = ctl->iters, budget = ctl->budget;
+    const int forced_q = ctl->forced_q;
+    if (status != ST_RUNNING) return;
     const bool publisher = blockIdx.x == 0 && threadIdx.x == 0;
-    if (ctl->iters >= ctl->budget) {
+    if (iters >= budget) {
         if (publisher) {
             ctl->status = ST_BUDGET;
             ctl->pending = 0;
         }
         return;
     }
-    const int m = lp.m, ld = lp.ld;
-    const int forced_q = ctl->forced_q;
     if (forced_q < 0) {
         Cand c;
         c.key = 0.0;
@@ -1855,19 +1879,39 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
         c.aux = 0;
         for (int b = threadIdx.x; b < n_price_blocks; b += blockDim.x) {
             Cand o;
-            o.idx = lp.cand_j[b];
-            o.key = o.idx >= 0 ? lp.cand_key[b] : 0.0;
+            o.idx = b == b_mine ? mine_j : lp.cand_j[b];
+            o.key = o.idx >= 0 ? (b == b_mine ? mine_key : lp.cand_key[b]) : 0.0;
             o.aux = b;
             c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? better<TIE_LARGER_IDX>(c, o) : better<TIE_SMALLER_IDX>(c, o);
         }
         c = (RULE == RELP_PIVOT_STEEPEST_EDGE) ? block_best<TIE_LARGER_IDX>(c, s_cand) : block_best<TIE_SMALLER_IDX>(c, s_cand);
-        if (threadIdx.x == 0) {
+        if (c.idx < 0) {
+            if (threadIdx.x == 0) {
+                s_q = -1;
+                s_cbar = 0.0;
+                s_inline = -1;
+                s_short = 0;
+            }
+        } else if (c.aux < (int)blockDim.x) {  // the winner is some thread's preloaded candidate: that thread publishes it
+            if ((int)threadIdx.x == c.aux) {
+                s_q = c.idx;
+                s_cbar = mine_cbar;
+                s_inline = (mine_len >= 0 && mine_len <= ELL_W) ? c.aux : -1;
+                s_short = mine_len >= 0 && mine_len <= 2;
+                s_rows[0] = mine_row0;
+                s_rows[1] = mine_row1;
+                s_vals[0] = mine_len >= 1 ? mine_val0 : 0.0;
+                s_vals[1] = mine_len >= 2 ? mine_val1 : 0.0;
+            }
+        } else if (threadIdx.x == 0) {  // (more pricing workgroups than threads here: the later ones are read now)
             s_q = c.idx;
-            s_cbar = c.idx >= 0 ? lp.cand_cbar[c.aux] : 0.0;
-            s_inline = (c.idx >= 0 && lp.cand_len[c.aux] >= 0 && lp.cand_len[c.aux] <= ELL_W) ? c.aux : -1;
+            s_cbar = lp.cand_cbar[c.aux];
+            s_inline = (lp.cand_len[c.aux] >= 0 && lp.cand_len[c.aux] <= ELL_W) ? c.aux : -1;
+            s_short = 0;
         }
     } else if (threadIdx.x == 0) {
         s_inline = -1;
+        s_short = 0;
         s_q = forced_q;
         double cb = lp.cost[forced_q];
         for (int e = lp.col_start[forced_q]; e < lp.col_start[forced_q + 1]; ++e) cb += lp.value[e] * lp.minus_pi[lp.row_index[e]];
@@ -1886,15 +1930,18 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_ftran_kernel(DeviceLP lp, int
         }
     }
     if (q < 0) return;
-    const bool bounded = lp.ub != nullptr;
     const double sgn_q = (bounded && lp.flipped[q]) ? -1.0 : 1.0;
-    const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
-    const double xb = i < m ? lp.xB[i] : 0.0;
-    const int bas = i < m ? lp.basis[i] : 0;
-    const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
     double acc = 0.0;
     const int inline_block = s_inline;
-    if (inline_block >= 0) {
+    if (inline_block >= 0 && s_short) {
+        // at most two entries, already here (every column of a graph provider): straight to the two columns of the inverse
+        const int r0 = s_rows[0], r1 = s_rows[1];
+        const double v0 = s_vals[0], v1 = s_vals[1];
+        const double t0 = (i < m && v0 != 0.0) ? lp.Binv[(size_t)r0 * ld + i] : 0.0;
+        const double t1 = (i < m && v1 != 0.0) ? lp.Binv[(size_t)r1 * ld + i] : 0.0;
+        acc += t0 * v0;
+        acc += t1 * v1;
+    } else if (inline_block >= 0) {
         // the winning pricing workgroup published the column's padded entries: no col_start -> row_index -> value chain
         int rows[ELL_W];
         double vals[ELL_W], t[ELL_W];
@@ -1951,18 +1998,26 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_harris_kernel(DeviceLP lp, in
     __shared__ Cand s_cand[18];
     __shared__ double s_red[18];
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING || ctl->q < 0) return;
     const int m = lp.m;
-    // this thread's row first: those loads are in flight while the partials are folded
+    // this thread's row and its first partials in the same round trip as the control word (round 3: after it)
     const bool bounded = lp.ub != nullptr;
-    const int forced_p = ctl->forced_p;
     const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
     const double a = i < m ? lp.alpha[i] : 0.0;
     const double xb = i < m ? lp.xB[i] : 0.0;
     const double up = (bounded && i < m) ? lp.xub[i] : INFINITY;
     const int bas = i < m ? lp.basis[i] : 0;
+    const bool has_first = (int)threadIdx.x < n_blocks;
+    const double first_sum = has_first ? lp.k2_partd[K2L_PD * threadIdx.x] : 0.0;
+    const double first_min = has_first ? lp.k2_partd[K2L_PD * threadIdx.x + 1] : INFINITY;
+    const int status = ctl->status, q_now = ctl->q;
+    const int forced_p = ctl->forced_p;
+    if (status != ST_RUNNING || q_now < 0) return;
     double v1 = 0.0, v2 = INFINITY;
-    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {  // fixed order: deterministic
+    if (has_first) {
+        v1 += first_sum;
+        v2 = fmin(v2, first_min);
+    }
+    for (int b = threadIdx.x + blockDim.x; b < n_blocks; b += blockDim.x) {  // fixed order: deterministic
         v1 += lp.k2_partd[K2L_PD * b];
         v2 = fmin(v2, lp.k2_partd[K2L_PD * b + 1]);
     }
@@ -2017,26 +2072,34 @@ __global__ void __launch_bounds__(K2L_THREADS) k2l_apply_kernel(DeviceLP lp, int
     __shared__ double s_red[18];
     __shared__ int s_count[K2L_THREADS / WAVE + 1];
     Ctl* ctl = lp.ctl;
-    if (ctl->status != ST_RUNNING) return;  // (workgroup 0 may set UNBOUNDED below: the others then have nothing to apply either)
-    const int q = ctl->q;
-    if (q < 0) return;
-    const bool forced = ctl->k2_forced != 0;
+    // (this thread's row and its first candidate in the same round trip as the control word)
     const bool bounded = lp.ub != nullptr;
     const int m = lp.m;
     const int i = blockIdx.x * K2L_THREADS + threadIdx.x;
     const double a = i < m ? lp.alpha[i] : 0.0;  // in flight while the decision is taken
     const double xb_i = i < m ? lp.xB[i] : 0.0;
+    const bool has_first = (int)threadIdx.x < n_blocks;
+    const int first_idx = has_first ? lp.k2_parti[4 * threadIdx.x] : -1;
+    const int first_aux = has_first ? lp.k2_parti[4 * threadIdx.x + 1] : 0;
+    const int first_count = has_first ? lp.k2_parti[4 * threadIdx.x + 2] : 0;
+    const double first_key = has_first ? lp.k2_partd[K2L_PD * threadIdx.x + 2] : 0.0;
+    const int status = ctl->status;
+    const int q = ctl->q;
+    const bool forced = ctl->k2_forced != 0;
+    if (status != ST_RUNNING) return;  // (workgroup 0 may set UNBOUNDED below: the others then have nothing to apply either)
+    if (q < 0) return;
     Cand c;
     c.key = 0.0;
     c.idx = -1;
     c.aux = 0;
     double before = 0.0, all = 0.0;  // list entries of the workgroups ahead of this one / of all of them
     for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+        const bool first = b == (int)threadIdx.x;
         Cand o;
-        o.idx = lp.k2_parti[4 * b];
-        o.key = o.idx >= 0 ? lp.k2_partd[K2L_PD * b + 2] : 0.0;
-        o.aux = lp.k2_parti[4 * b + 1];  // the basic column of that row: ties go to the smaller one
-        const int count = lp.k2_parti[4 * b + 2];
+        o.idx = first ? first_idx : lp.k2_parti[4 * b];
+        o.key = o.idx >= 0 ? (first ? first_key : lp.k2_partd[K2L_PD * b + 2]) : 0.0;
+        o.aux = first ? first_aux : lp.k2_parti[4 * b + 1];  // the basic column of that row: ties go to the smaller one
+        const int count = first ? first_count : lp.k2_parti[4 * b + 2];
         all += count;
         if (b < (int)blockIdx.x) before += count;
         if (o.idx >= 0) c = better<TIE_SMALLER_AUX>(c, o);
