@@ -695,6 +695,114 @@ __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& 
     return 0;
 }
 
+// sum_e v_e N(i, r_e) over the entries [e0, e1) of one column for 64 neighbouring rows, by one wave, word by word (the first pricing
+// pass for every column, the entering column once more): word k of row i's sum goes to out[k * out_stride] (out is this lane's), its
+// leading words to `lead`, and the bit bound of the operands (the fit test's) is returned.
+template <int L>
+__device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0, int e1, int i, bool active, int lane, size_t MM, u64* out, size_t out_stride,
+                                                       LeadingWords& lead) {
+    const int m = lp.m;
+    int awide = 0;
+    for (int e = e0; e < e1; ++e)
+        if (active) awide = max(awide, lp.N_bits[(size_t)lp.row_index[e] * m + i] + small_bits(lp.value[e]));
+    awide += 32 - __clz(e1 - e0 > 1 ? e1 - e0 - 1 : 1) + 1;  // (log2_ceil of the kernel)
+    // The column's entries are read once, one per lane, and handed round with readlane (columns of more than 64 entries read
+    // them from memory at every use); two words of the result are formed per turn, the operands of both in flight
+    // together -- with one wave per SIMD on the grid the pass waits on memory, not on arithmetic.
+    const int len = e1 - e0;
+    const bool in_lanes = len <= WAVE;
+    int my_offset = 0;  // row_index * m of entry e0 + lane
+    i64 my_value = 0;
+    if (in_lanes && lane < len) {
+        my_offset = lp.row_index[e0 + lane] * m;
+        my_value = lp.value[e0 + lane];
+    }
+    auto entry = [&](int e, int* offset, i64* value) {  // e - e0 uniform over the wave
+        if (in_lanes) {
+            *offset = __builtin_amdgcn_readlane(my_offset, e);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u64)my_value, e);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((u64)my_value >> 32), e);
+            *value = (i64)(((u64)hi << 32) | lo);
+        } else {
+            *offset = lp.row_index[e0 + e] * m;
+            *value = lp.value[e0 + e];
+        }
+    };
+    struct Sum {  // 192 bits, carry-save
+        u128 acc = 0;
+        u64 top = 0;
+        __device__ __forceinline__ void add(u128 v) {
+            acc += v;
+            top += acc < v ? 1 : 0;
+        }
+        __device__ __forceinline__ u64 pop() {  // the lowest word leaves, the rest moves down
+            const u64 word = (u64)acc;
+            acc = (acc >> 64) | ((u128)top << 64);
+            top = 0;
+            return word;
+        }
+    };
+    Sum pos, neg;  // running sums of the positive / the negative multiples
+    u64 borrow = 0;
+    auto emit = [&](int k) {
+        const u64 pk = pos.pop(), qk = neg.pop();
+        const u64 t = pk - qk;
+        const u64 word = t - borrow;
+        borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
+        if (active) out[(size_t)k * out_stride] = word;
+        lead.feed(k, word);
+    };
+    constexpr int KU = L >= 2 ? 2 : 1;
+    // (the sum fits `awide` bits: the words above that many are its sign, not worth their operands' loads)
+    int words = active ? min(L, (awide + 2 + 63) / 64) : 1;
+    for (int d = 1; d < WAVE; d *= 2) words = max(words, __shfl_xor(words, d));
+    words = min(L, (words + KU - 1) / KU * KU);
+    for (int k = 0; k < words; k += KU) {
+        const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
+        Sum pos_next, neg_next;  // the multiples of word k + 1
+        for (int e = 0; e < len; e += 4) {  // four operands (of both words) in flight
+            u64 w0[4], w1[4];
+            i64 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int offset;
+                entry(e + u < len ? e + u : len - 1, &offset, &v[u]);
+                if (e + u >= len) v[u] = 0;
+                w0[u] = word_k[offset];
+                w1[u] = KU == 2 ? word_k[MM + offset] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
+                if (v[u] >= 0) {
+                    pos.add((u128)w0[u] * mag);
+                    if (KU == 2) pos_next.add((u128)w1[u] * mag);
+                } else {
+                    neg.add((u128)w0[u] * mag);
+                    if (KU == 2) neg_next.add((u128)w1[u] * mag);
+                }
+            }
+        }
+        emit(k);
+        if (KU == 2) {
+            pos.add(pos_next.acc);
+            pos.top += pos_next.top;
+            neg.add(neg_next.acc);
+            neg.top += neg_next.top;
+            emit(k + 1);
+        }
+    }
+    {
+        const u64 fill = (i64)lead.prev < 0 ? ~0ull : 0ull;
+#pragma unroll L <= 8 ? L : 1
+        for (int k = words; k < L; ++k) {
+            if (active) out[(size_t)k * out_stride] = fill;
+            lead.feed(k, fill);
+        }
+    }
+    return awide;
+}
+
 // Pricing pass B for one column, by one wave (see the call site): c~_j word by word into ctil, its key estimate returned (0: not a
 // candidate).
 template <int L>
@@ -977,106 +1085,9 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
                 const bool active = i < m;
                 const size_t pair = (size_t)jj * m + (active ? i : 0);
-                int awide = 0;
-                for (int e = e0; e < e1; ++e)
-                    if (active) awide = max(awide, lp.N_bits[(size_t)lp.row_index[e] * m + i] + small_bits(lp.value[e]));
-                awide += log2_ceil(e1 - e0);
-                if (active) flag_overflow(awide);
-                // The column's entries are read once, one per lane, and handed round with readlane (columns of more than 64 entries read
-                // them from memory at every use); two words of the result are formed per turn, the operands of both in flight
-                // together -- with one wave per SIMD on the grid the pass waits on memory, not on arithmetic.
-                const int len = e1 - e0;
-                const bool in_lanes = len <= WAVE;
-                int my_offset = 0;  // row_index * m of entry e0 + lane
-                i64 my_value = 0;
-                if (in_lanes && lane < len) {
-                    my_offset = lp.row_index[e0 + lane] * m;
-                    my_value = lp.value[e0 + lane];
-                }
-                auto entry = [&](int e, int* offset, i64* value) {  // e - e0 uniform over the wave
-                    if (in_lanes) {
-                        *offset = __builtin_amdgcn_readlane(my_offset, e);
-                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u64)my_value, e);
-                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((u64)my_value >> 32), e);
-                        *value = (i64)(((u64)hi << 32) | lo);
-                    } else {
-                        *offset = lp.row_index[e0 + e] * m;
-                        *value = lp.value[e0 + e];
-                    }
-                };
-                struct Sum {  // 192 bits, carry-save
-                    u128 acc = 0;
-                    u64 top = 0;
-                    __device__ __forceinline__ void add(u128 v) {
-                        acc += v;
-                        top += acc < v ? 1 : 0;
-                    }
-                    __device__ __forceinline__ u64 pop() {  // the lowest word leaves, the rest moves down
-                        const u64 word = (u64)acc;
-                        acc = (acc >> 64) | ((u128)top << 64);
-                        top = 0;
-                        return word;
-                    }
-                };
-                Sum pos, neg;  // running sums of the positive / the negative multiples
-                u64 borrow = 0;
                 LeadingWords lead;
-                auto emit = [&](int k) {
-                    const u64 pk = pos.pop(), qk = neg.pop();
-                    const u64 t = pk - qk;
-                    const u64 word = t - borrow;
-                    borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
-                    if (active) lp.price_a[(size_t)k * PP + pair] = word;
-                    lead.feed(k, word);
-                };
-                constexpr int KU = L >= 2 ? 2 : 1;
-                // (the sum fits `awide` bits: the words above that many are its sign, not worth their operands' loads)
-                int words = active ? min(L, (awide + 2 + 63) / 64) : 1;
-                for (int d = 1; d < WAVE; d *= 2) words = max(words, __shfl_xor(words, d));
-                words = min(L, (words + KU - 1) / KU * KU);
-                for (int k = 0; k < words; k += KU) {
-                    const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
-                    Sum pos_next, neg_next;  // the multiples of word k + 1
-                    for (int e = 0; e < len; e += 4) {  // four operands (of both words) in flight
-                        u64 w0[4], w1[4];
-                        i64 v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            int offset;
-                            entry(e + u < len ? e + u : len - 1, &offset, &v[u]);
-                            if (e + u >= len) v[u] = 0;
-                            w0[u] = word_k[offset];
-                            w1[u] = KU == 2 ? word_k[MM + offset] : 0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
-                            if (v[u] >= 0) {
-                                pos.add((u128)w0[u] * mag);
-                                if (KU == 2) pos_next.add((u128)w1[u] * mag);
-                            } else {
-                                neg.add((u128)w0[u] * mag);
-                                if (KU == 2) neg_next.add((u128)w1[u] * mag);
-                            }
-                        }
-                    }
-                    emit(k);
-                    if (KU == 2) {
-                        pos.add(pos_next.acc);
-                        pos.top += pos_next.top;
-                        neg.add(neg_next.acc);
-                        neg.top += neg_next.top;
-                        emit(k + 1);
-                    }
-                }
-                {
-                    const u64 fill = (i64)lead.prev < 0 ? ~0ull : 0ull;
-#pragma unroll L <= 8 ? L : 1
-                    for (int k = words; k < L; ++k) {
-                        if (active) lp.price_a[(size_t)k * PP + pair] = fill;
-                        lead.feed(k, fill);
-                    }
-                }
+                const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane, MM, lp.price_a + pair, PP, lead);
+                if (active) flag_overflow(awide);
                 if (active) {
                     lp.price_bits[pair] = awide;
                     int ea = 0;
@@ -1233,18 +1244,35 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             drive_row = r + 1;
         }
         // ---- alpha~_q = N a_q (tableau/mod.rs:126-130) -----------------------------------------------------------------------
-        for (int i = gtid; i < m; i += GT) {
-            Big<L> a = big_from<L>(0);
-            int awide = 0;
-            for (int e = lp.col_start[q]; e < lp.col_start[q + 1]; ++e) {
-                const Big<L> nir = big_load_s<L>(N_at(i, lp.row_index[e]), MM);
-                a = big_add(a, big_mul_small(nir, lp.value[e]));
-                awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
+        if constexpr (L >= 16) {  // the wide types: streamed like the pricing pass, a wave per 64 rows (a thread per row with its integers in scratch: 1.2 ms a pivot at 128 limbs)
+            const int e0 = lp.col_start[q], e1 = lp.col_start[q + 1];
+            const int lane_a = tid & (WAVE - 1);
+            for (int block_a = gtid / WAVE; block_a * WAVE < m; block_a += GT / WAVE) {
+                const int i = block_a * WAVE + lane_a;
+                const bool active = i < m;
+                LeadingWords lead;
+                const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane_a, MM, lp.alpha + (size_t)(active ? i : 0) * L, 1, lead);
+                if (active) {
+                    flag_overflow(awide);
+                    const bool negative = (i64)lead.prev < 0;  // bit length of |alpha~_i| from its leading word
+                    const int top = negative ? lead.top_n : lead.top_p;
+                    lp.x_bits[i] = top < 0 ? 0 : 64 * top + (64 - __clzll((long long)(negative ? lead.n_top : lead.p_top)));  // (the fit test of the update below wants it once per ENTRY of N)
+                }
             }
-            flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
-            big_store(lp.alpha + (size_t)i * L, a);
-            lp.x_bits[i] = big_bits(a);  // (the fit test of the update below wants it once per ENTRY of N)
-            if constexpr (L < 16) big_store_s(lp.x_part + i, (size_t)m, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
+        } else {
+            for (int i = gtid; i < m; i += GT) {
+                Big<L> a = big_from<L>(0);
+                int awide = 0;
+                for (int e = lp.col_start[q]; e < lp.col_start[q + 1]; ++e) {
+                    const Big<L> nir = big_load_s<L>(N_at(i, lp.row_index[e]), MM);
+                    a = big_add(a, big_mul_small(nir, lp.value[e]));
+                    awide = max(awide, big_bits(nir) + small_bits(lp.value[e]));
+                }
+                flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
+                big_store(lp.alpha + (size_t)i * L, a);
+                lp.x_bits[i] = big_bits(a);  // (the fit test of the update below wants it once per ENTRY of N)
+                if constexpr (L < 16) big_store_s(lp.x_part + i, (size_t)m, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
+            }
         }
         if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store)
             grid.sync();
