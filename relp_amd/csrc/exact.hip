@@ -594,6 +594,7 @@ struct ExactLP {
     u64* c_part;          // [n - n_art][ceil(m / 32)] Big: partial sums of c_B' N a_j of the pricing pass
     int* c_bits;          // ... their bit bounds
     i64* cb_row;          // [m] cost of the basic column of each row in the current phase (pricing pass B)
+    int* row_list;        // [2 m] the rows with alpha~_i != 0, in order, and from [m] on the others (the update of N)
     int debug_flags;      // RELP_EXACT_DEBUG (bisecting aid)
     int* N_bits;          // [m columns][m rows] bit length of |N(i, c)|, kept by whoever writes an entry (the bounds of the passes over N read 4 bytes instead of the integer)
 };
@@ -1366,42 +1367,52 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
             }
         }
-        // The columns of N by what their entries cost below: N(p, k) != 0 (two products an entry) first, then the others (one product,
-        // or nothing where the entry is zero as well).  Each class is spread over the whole grid by itself: with the columns taken
-        // as they come a wave drew ten of them and the slowest wave's draw set the pace (a fifth of the update at 128 limbs).
+        // The entries of N by what they cost below.  N'_ik = (alpha~_p N_ik - alpha~_i N_pk) / D: two products where N(p, k) != 0 AND
+        // alpha~_i != 0, one (the entry is only rescaled) where either is zero, nothing where N_ik is zero as well.  Columns and rows
+        // are each split into the two kinds (workgroup 0, ordered lists) and every class of entries is spread over the whole grid by
+        // itself: with the entries taken as they come a wave drew ten columns and the slowest wave's draw set the pace, and a row
+        // with alpha~_i = 0 inside a wave of rows with alpha~_i != 0 saved nothing.
         if (block == 0) {
             __shared__ int s_class_count[EX_THREADS / WAVE][2];
-            int done[2] = {0, 0};
-            for (int base = 0; base < m; base += T) {
-                const int k = base + tid;
-                const bool valid = k < m;
-                const bool heavy = valid && lp.N_bits[(size_t)k * m + p] != 0;
-                const unsigned long long heavy_mask = __ballot(heavy), light_mask = __ballot(valid && !heavy);
-                const int wave = tid / WAVE, ln = tid & (WAVE - 1);
-                __syncthreads();
-                if (ln == 0) {
-                    s_class_count[wave][0] = __popcll(heavy_mask);
-                    s_class_count[wave][1] = __popcll(light_mask);
-                }
-                __syncthreads();
-                int before[2] = {done[0], done[1]}, all[2] = {0, 0};
-                for (int wv = 0; wv < T / WAVE; ++wv)
-                    for (int c = 0; c < 2; ++c) {
-                        if (wv < wave) before[c] += s_class_count[wv][c];
-                        all[c] += s_class_count[wv][c];
+            auto split = [&](auto&& is_first, int* first_list, int* second_list) {  // indices 0 .. m - 1 in order into the two lists; returns the first's length
+                int done[2] = {0, 0};
+                for (int base = 0; base < m; base += T) {
+                    const int k = base + tid;
+                    const bool valid = k < m;
+                    const bool first = valid && is_first(k);
+                    const unsigned long long first_mask = __ballot(first), second_mask = __ballot(valid && !first);
+                    const int wave = tid / WAVE, ln = tid & (WAVE - 1);
+                    __syncthreads();
+                    if (ln == 0) {
+                        s_class_count[wave][0] = __popcll(first_mask);
+                        s_class_count[wave][1] = __popcll(second_mask);
                     }
-                const unsigned long long below = (1ull << ln) - 1ull;
-                if (heavy) lp.bracket[before[0] + __popcll(heavy_mask & below)] = k;
-                else if (valid) lp.cand[before[1] + __popcll(light_mask & below)] = k;
-                done[0] += all[0];
-                done[1] += all[1];
+                    __syncthreads();
+                    int before[2] = {done[0], done[1]}, all[2] = {0, 0};
+                    for (int wv = 0; wv < T / WAVE; ++wv)
+                        for (int c = 0; c < 2; ++c) {
+                            if (wv < wave) before[c] += s_class_count[wv][c];
+                            all[c] += s_class_count[wv][c];
+                        }
+                    const unsigned long long below = (1ull << ln) - 1ull;
+                    if (first) first_list[before[0] + __popcll(first_mask & below)] = k;
+                    else if (valid) second_list[before[1] + __popcll(second_mask & below)] = k;
+                    done[0] += all[0];
+                    done[1] += all[1];
+                }
+                return done[0];
+            };
+            const int heavy_columns = split([&](int k) { return lp.N_bits[(size_t)k * m + p] != 0; }, lp.bracket, lp.cand);
+            const int rows_with_alpha = split([&](int i) { return lp.x_bits[i] != 0; }, lp.row_list, lp.row_list + m);
+            if (tid == 0) {
+                word[7] = heavy_columns;
+                word[6] = rows_with_alpha;
             }
-            if (tid == 0) word[7] = done[0];
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
-        const int n_heavy = word[7];
-        for (long long unit = gtid; unit < (long long)n_heavy * m; unit += GT) {  // N(p, k) != 0: two products
-            const int kk = (int)(unit / m), i = (int)(unit - (long long)kk * m);
+        const int n_heavy = word[7], n_rows_alpha = word[6];
+        for (long long unit = gtid; unit < (long long)n_heavy * n_rows_alpha; unit += GT) {  // N(p, k) != 0 and alpha~_i != 0: two products
+            const int kk = (int)(unit / n_rows_alpha), i = lp.row_list[(int)(unit - (long long)kk * n_rows_alpha)];
             if (i == p) continue;
             const int k = lp.bracket[kk];
             const size_t idx = (size_t)k * m + i;
@@ -1426,10 +1437,21 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             big_store_s(lp.N + idx, MM, quotient);
             lp.N_bits[idx] = big_bits(quotient);
         }
-        for (long long unit = gtid; unit < (long long)(m - n_heavy) * m; unit += GT) {  // N(p, k) == 0: the entry is only rescaled
-            const int kk = (int)(unit / m), i = (int)(unit - (long long)kk * m);
+        // ... and the entries that are only rescaled: the rows with alpha~_i = 0 of those columns, then every row of the other columns
+        const long long rescaled_a = (long long)n_heavy * (m - n_rows_alpha), rescaled_b = (long long)(m - n_heavy) * m;
+        for (long long unit = gtid; unit < rescaled_a + rescaled_b; unit += GT) {
+            int k, i;
+            if (unit < rescaled_a) {
+                const int kk = (int)(unit / (m - n_rows_alpha));
+                k = lp.bracket[kk];
+                i = lp.row_list[m + (int)(unit - (long long)kk * (m - n_rows_alpha))];
+            } else {
+                const long long rest = unit - rescaled_a;
+                const int kk = (int)(rest / m);
+                k = lp.cand[kk];
+                i = (int)(rest - (long long)kk * m);
+            }
             if (i == p) continue;
-            const int k = lp.cand[kk];
             const size_t idx = (size_t)k * m + i;
             const bool zero = lp.N_bits[idx] == 0;  // (a zero stays a zero)
             Big<L> quotient;
@@ -1665,6 +1687,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_cand = dalloc<int>(std::max(n, m) + 1, owned);
     int* d_N_bits = dalloc<int>((size_t)m * m, owned);
     i64* d_cb_row = dalloc<i64>(m, owned);
+    int* d_row_list = dalloc<int>((size_t)2 * m, owned);
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
@@ -1747,7 +1770,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
         if (d_prof) RELP_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_c_part, d_c_bits, d_cb_row, getenv("RELP_EXACT_DEBUG") ? atoi(getenv("RELP_EXACT_DEBUG")) : 0, d_N_bits};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_c_part, d_c_bits, d_cb_row, d_row_list, getenv("RELP_EXACT_DEBUG") ? atoi(getenv("RELP_EXACT_DEBUG")) : 0, d_N_bits};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
