@@ -1777,6 +1777,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         // ... and two per CU where a pivot is milliseconds of arithmetic (25FV47 from 64 limbs on: 50 -> 39 s; at one wave per SIMD the
         // passes wait on memory and on scratch) -- not below: the barriers of 512 workgroups cost SCORPION and E226 a tenth of a second.
         if ((double)m * m * limbs * limbs >= 1e9) grid = 512;
+        // ... and at most one per two CUs for the mid-size LPs, whose pivot is a fraction of a millisecond since the round-4 rework: the
+        // barriers of 256 workgroups (25 us each, fifteen a pivot) were a third of it (E226 0.38 -> 0.33 s, BRANDY 0.52 -> 0.41 s).
+        else if ((double)m * m * limbs < 8e6) grid = std::min(grid, 128);
         if (const char* forced = getenv("RELP_EXACT_GRID")) grid = std::max(1, std::min(EX_MAX_GRID, atoi(forced)));
         void* kernel = nullptr;
         switch (limbs) {
