@@ -662,6 +662,17 @@ __device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
 // c_a^2 * gamma_b  vs  c_b^2 * gamma_a  (unsigned, (4 L + 1) limbs): +1 when column a has the larger key
 template <int L>
 __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& cb, const u64* gamma_b) {
+    {   // |c_a| = |c_b| (the tied candidates of a degenerate pivot, as a rule): the larger key has the smaller gamma -- no products
+        const Big<L> ma = big_neg(ca) ? big_negate(ca) : ca, mb = big_neg(cb) ? big_negate(cb) : cb;
+        bool same = true;
+        for (int k = 0; k < L; ++k) same = same && ma.w[k] == mb.w[k];
+        if (same) {
+            if (big_zero(ma)) return 0;
+            for (int k = 2 * L + 1; k >= 0; --k)
+                if (gamma_a[k] != gamma_b[k]) return gamma_b[k] > gamma_a[k] ? 1 : -1;
+            return 0;
+        }
+    }
     auto square = [](const Big<L>& v, u64* sq) {
         const Big<L> mag = big_neg(v) ? big_negate(v) : v;
         for (int k = 0; k < 2 * L; ++k) sq[k] = 0;
@@ -1154,16 +1165,35 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                         else weighted_square<L>(big_load_s<L>(lp.price_a + (size_t)(j - lp.n_art) * m + i, PP), (u64)lp.weight[lp.basis[i]], out);
                     }
                     grid.sync();
-                    for (int c = gtid; c < n_cand; c += GT) {
-                        u64* g = lp.gamma + (size_t)c * GW;
-                        for (int k = 0; k < GW; ++k) g[k] = 0;
+                    // (a wave per candidate, a lane per word of the sum: the terms are read a whole row of words at a time, the carries
+                    //  run through the words once at the end.  One thread per candidate walked (m + 1) (2 L + 2) dependent additions:
+                    //  a third of SCORPION's solve, whose degenerate pivots tie a hundred candidates at a time.)
+                    constexpr int WPL = (GW + WAVE - 1) / WAVE;  // words per lane
+                    for (int c = gtid / WAVE; c < n_cand; c += GT / WAVE) {
+                        const int ln = tid & (WAVE - 1);
+                        const u64* terms = lp.gamma_terms + (size_t)c * (m + 1) * GW;
+                        u128 total[WPL];
+#pragma unroll
+                        for (int u = 0; u < WPL; ++u) total[u] = 0;
                         for (int i = 0; i <= m; ++i) {
-                            const u64* term = lp.gamma_terms + ((size_t)c * (m + 1) + i) * GW;
-                            u64 carry = 0;
-                            for (int k = 0; k < GW; ++k) {
-                                const u128 sum = (u128)g[k] + term[k] + carry;
-                                g[k] = (u64)sum;
-                                carry = (u64)(sum >> 64);
+#pragma unroll
+                            for (int u = 0; u < WPL; ++u) {
+                                const int k = ln + u * WAVE;
+                                if (k < GW) total[u] += terms[(size_t)i * GW + k];
+                            }
+                        }
+                        u64* g = lp.gamma + (size_t)c * GW;
+                        u128 carry = 0;
+#pragma unroll
+                        for (int u = 0; u < WPL; ++u) {
+                            const int count = GW - u * WAVE < WAVE ? GW - u * WAVE : WAVE;
+                            for (int src = 0; src < count; ++src) {
+                                const u64 lo = (u64)total[u], hi = (u64)(total[u] >> 64);
+                                const u64 word_lo = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(lo >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+                                const u64 word_hi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(hi >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)hi, src);
+                                const u128 t = (((u128)word_hi << 64) | word_lo) + carry;
+                                if (ln == 0) g[u * WAVE + src] = (u64)t;
+                                carry = t >> 64;
                             }
                         }
                     }
