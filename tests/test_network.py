@@ -241,6 +241,34 @@ def test_gpu_generated_column_pricing_variants_make_the_same_pivots(monkeypatch)
 
 
 @pytest.mark.gpu
+def test_gpu_generated_columns_under_the_lu_carry():
+    """Generated incidence columns priced by `price_unit_kernel` while the LU + Forrest-Tomlin carry maintains the basis: between
+    6 800 rows (where the width-2 padded copy and the generated columns start) and 8 000 (the LU carry's LDS limit) it is
+    `lu_pivot_kernel` that writes rho_p and marks its non-zero rows in the bit table the pricing pass reads.  Same optimum as the
+    explicit carry and as scipy's max-flow."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    from relp_amd.workloads import max_flow_graph
+    nr_vertices = 7400
+    tail, head, capacity = max_flow_graph(nr_vertices, 40000)
+    keep = (head != 0) & (tail != nr_vertices - 1)
+    tail, head, capacity = tail[keep], head[keep], capacity[keep]
+    expected = maximum_flow(csr_matrix((capacity.astype(np.int32), (tail, head)), shape=(nr_vertices, nr_vertices)), 0, nr_vertices - 1).flow_value
+    model = relp_amd.Model.max_flow(nr_vertices, list(zip(tail.tolist(), head.tolist(), capacity.tolist())), 0, nr_vertices - 1)
+    objectives = []
+    for carry in (0, 1):
+        solver = relp_amd.Solver(implicit_bounds=1, carry=carry).load_model(model)
+        result = solver.solve_relaxation()
+        assert result.kind == relp_amd.FINITE_OPTIMUM, (carry, result.kind)
+        objectives.append(result.objective)
+        flow = solver.solution()
+        assert np.all(flow >= -1e-9) and np.all(flow <= capacity + 1e-9)
+        solver.close()
+    assert abs(objectives[0] + expected) <= 1e-9 * max(1.0, abs(expected))
+    assert abs(objectives[1] + expected) <= 1e-7 * max(1.0, abs(expected))
+
+
+@pytest.mark.gpu
 def test_gpu_shortest_path_12k_vertices_matches_dijkstra():
     """V = 12 000, E ~ 60 000 (one conservation row per vertex but the target, no bounds: the ratio test across workgroups
     without the bounded-variable rules): the LP optimum equals scipy's Dijkstra distance and the solution is a unit s-t flow."""
