@@ -163,7 +163,58 @@ __device__ __forceinline__ Big<L> big_mul_lo_blocked(const Big<L>& a, const Big<
     for (int k = 4 * NB; k < L; ++k) r.w[k] = 0;
     return r;
 }
-// a * b modulo 2^(64 L) by one WAVE, stored word-major at out[k * stride]: lane K < L / 4 forms the block products that land in
+// a * b + c * d modulo 2^(64 * 4 * blocks) in ONE pass over the blocks: both block products of a pair (I, J) go into the same window (the
+// update of N: alpha~_p u N_ik + (-alpha~_i u) N_pk, the second factor stored negated so that the difference is a sum).  a is read
+// through a pointer -- the caller passes the workgroup's copy in LDS, the same words for every thread -- b, c, d are the thread's own.
+template <int L>
+__device__ __forceinline__ Big<L> big_mul_add_lo_blocked(const u64* a, const Big<L>& b, const Big<L>& c, const Big<L>& d, int blocks) {
+    static_assert(L % 4 == 0, "four words per block");
+    const int NB = blocks;
+    Big<L> r;
+    u64 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0;
+    for (int K = 0; K < NB; ++K) {
+        for (int I = 0; I <= K; ++I) {
+            const int J = K - I;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                u64 a4[4], b4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a4[t] = which == 0 ? a[4 * I + t] : c.w[4 * I + t];
+                    b4[t] = which == 0 ? b.w[4 * J + t] : d.w[4 * J + t];
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    u64 carry = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const u128 t = (u128)a4[ii] * b4[jj] + acc[ii + jj] + carry;
+                        acc[ii + jj] = (u64)t;
+                        carry = (u64)(t >> 64);
+                    }
+#pragma unroll
+                    for (int k = ii + 4; k < 9; ++k) {
+                        const u128 t = (u128)acc[k] + carry;
+                        acc[k] = (u64)t;
+                        carry = (u64)(t >> 64);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r.w[4 * K + t] = acc[t];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc[t] = acc[t + 4];
+#pragma unroll
+        for (int t = 5; t < 9; ++t) acc[t] = 0;
+    }
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 4 * NB; k < L; ++k) r.w[k] = 0;
+    return r;
+}
+// -(a * b) modulo 2^(64 L) by one WAVE, stored word-major at out[k * stride]: lane K < L / 4 forms the block products that land in
 // output block K (the same 4 x 4 blocks, a window of nine words with nothing carried in), then the windows are chained in
 // order -- every lane alike, from the other lanes' registers -- and lane 0 stores the words.  a in memory (L words side by side),
 // b in LDS.  (The rows' factors alpha~_i u of the update: a product per row by one thread each was 1.3 ms of every pivot at 128 limbs.)
@@ -203,6 +254,7 @@ __device__ __noinline__ void wave_mul_lo_store(const u64* a, const u64* b, u64* 
         }
     }
     u64 over[5] = {0, 0, 0, 0, 0};  // what the blocks below carry into the current one
+    bool negation_carry = true;
 #pragma unroll 1
     for (int K = 0; K < NB; ++K) {
         u64 window[9];
@@ -218,9 +270,12 @@ __device__ __noinline__ void wave_mul_lo_store(const u64* a, const u64* b, u64* 
             window[k] = (u64)t;
             carry = (u64)(t >> 64);
         }
-        if (lane == 0) {
+        if (lane == 0) {  // (stored NEGATED, modulo 2^(64 L): ~w + 1 with the carry running while the words are zero)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) out[(size_t)(4 * K + t) * stride] = window[t];
+            for (int t = 0; t < 4; ++t) {
+                out[(size_t)(4 * K + t) * stride] = ~window[t] + (negation_carry ? 1ull : 0ull);
+                negation_carry = negation_carry && window[t] == 0;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 5; ++k) over[k] = window[k + 4];
@@ -589,7 +644,7 @@ struct ExactLP {
     int* cand;            // [max(n, m) + 1] columns whose key estimate is within 1e-9 of the best (pricing); near-tied rows (ratio test)
     u64* gamma;           // [n][2 limbs + 2] their exact weights
     u64* gamma_terms;     // [candidates][m + 1][2 limbs + 2] the terms of those sums (capacity: see the host)
-    u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b (first turn of a run); afterwards [limbs][m]: alpha~_i / D_odd, word-major
+    u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b (first turn of a run); afterwards [limbs][m]: -alpha~_i / D_odd (negated: the update adds), word-major
     int* x_bits;          // ... their bit bounds
     u64* c_part;          // [n - n_art][ceil(m / 32)] Big: partial sums of c_B' N a_j of the pricing pass
     int* c_bits;          // ... their bit bounds
@@ -1302,7 +1357,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 flag_overflow(awide + log2_ceil(lp.col_start[q + 1] - lp.col_start[q]));
                 big_store(lp.alpha + (size_t)i * L, a);
                 lp.x_bits[i] = big_bits(a);  // (the fit test of the update below wants it once per ENTRY of N)
-                if constexpr (L < 16) big_store_s(lp.x_part + i, (size_t)m, big_mul_lo(a, Dinv));  // alpha~_i / D_odd: the row's factor of the update below
+                if constexpr (L < 16) big_store_s(lp.x_part + i, (size_t)m, big_negate(big_mul_lo(a, Dinv)));  // -alpha~_i / D_odd: the row's factor of the update below
             }
         }
         if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store)
@@ -1458,10 +1513,10 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 int blocks = min(L / 4, max(1, (needed + 255) / 256));
                 for (int d = 1; d < WAVE; d *= 2) blocks = max(blocks, __shfl_xor(blocks, d));
                 blocks = min(L / 4, blocks);  // (a lane that sits this turn out contributes whatever its register holds)
-                const Big<L> numerator = big_sub(big_mul_lo_blocked(c1, nik, blocks), big_mul_lo_blocked(ri, npk, blocks));
+                const Big<L> numerator = big_mul_add_lo_blocked<L>(s_c1, nik, ri, npk, blocks);  // (ri is stored negated)
                 quotient = big_sar(big_sign_extend(numerator, 4 * blocks), shift);
             } else {
-                quotient = big_sar(big_sub(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
+                quotient = big_sar(big_add(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
             }
             if (flip) quotient = big_negate(quotient);
             big_store_s(lp.N + idx, MM, quotient);
@@ -1505,7 +1560,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             for (int i = gtid; i < m; i += GT) {
                 if (i == p) continue;
                 const Big<L> ri = big_load_s<L>(lp.x_part + i, (size_t)m);
-                Big<L> quotient = big_sar(big_sub(big_mul_lo(c1, big_load<L>(lp.xt + (size_t)i * L)), big_mul_lo(ri, xp)), shift);
+                Big<L> quotient = big_sar(big_add(big_mul_lo(c1, big_load<L>(lp.xt + (size_t)i * L)), big_mul_lo(ri, xp)), shift);  // (ri is stored negated)
                 if (flip) quotient = big_negate(quotient);
                 big_store(lp.xt + (size_t)i * L, quotient);
             }
