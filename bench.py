@@ -934,7 +934,7 @@ EXACT_25FV47_CPU = {"value": 2392 / 1026.0, "unit": "pivots/s", "cores": 1, "kin
 
 
 def exact_25fv47_live(ctx):
-    """BASELINE configs[1] pivot for pivot in fixed-width integers, measured in this process (about 25 s since the round-4 rework of the
+    """BASELINE configs[1] pivot for pivot in fixed-width integers, measured in this process (about 20 s since the round-4 rework of the
     exact kernel; 257 s before, when the default run quoted a recorded figure).  The CPU side of the ratio is the recorded whole solve
     of the exact CPU restatement (17 minutes: not repeated here)."""
     entry = exact_lp("25FV47", ctx, 4, 128)
@@ -1052,7 +1052,7 @@ def main():
     parser.add_argument("--carry", type=int, default=0, choices=[0, 1, 2],
                         help="0 explicit inverse, 1 LU + Forrest-Tomlin, 2 LU through the inverses of its triangles + product-form updates (relp_options.carry)")
     parser.add_argument("--lu-refactor", type=int, default=0, choices=[0, 1, 2], help="LU carries: 0 automatic, 1 refactorisation kernels on the device, 2 host core (relp_options.lu_refactor)")
-    parser.add_argument("--exact-25fv47", action="store_true", help="(kept for compatibility: the default run now measures 25FV47 through relp_solve_exact live, about 25 s)")
+    parser.add_argument("--exact-25fv47", action="store_true", help="(kept for compatibility: the default run now measures 25FV47 through relp_solve_exact live, about 20 s)")
     parser.add_argument("--recorded-exact-25fv47", action="store_true", help="quote the recorded 25FV47 exact run (profiles/r4_exact_25fv47_128_limbs.txt) instead of measuring it")
     parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")

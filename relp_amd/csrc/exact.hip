@@ -819,44 +819,43 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
         if (active) out[(size_t)k * out_stride] = word;
         lead.feed(k, word);
     };
-    constexpr int KU = L >= 2 ? 2 : 1;
+    constexpr int KU = L >= 4 ? 4 : (L >= 2 ? 2 : 1);  // words of the result per turn
     // (the sum fits `awide` bits: the words above that many are its sign, not worth their operands' loads)
     int words = active ? min(L, (awide + 2 + 63) / 64) : 1;
     for (int d = 1; d < WAVE; d *= 2) words = max(words, __shfl_xor(words, d));
     words = min(L, (words + KU - 1) / KU * KU);
     for (int k = 0; k < words; k += KU) {
         const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
-        Sum pos_next, neg_next;  // the multiples of word k + 1
-        for (int e = 0; e < len; e += 4) {  // four operands (of both words) in flight
-            u64 w0[4], w1[4];
+        Sum pos_next[KU > 1 ? KU - 1 : 1], neg_next[KU > 1 ? KU - 1 : 1];  // the multiples of the words k + 1 ...
+        for (int e = 0; e < len; e += 4) {  // four operands (of every word of the turn) in flight
+            u64 w[KU][4];
             i64 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int offset;
                 entry(e + u < len ? e + u : len - 1, &offset, &v[u]);
                 if (e + u >= len) v[u] = 0;
-                w0[u] = word_k[offset];
-                w1[u] = KU == 2 ? word_k[MM + offset] : 0;
+#pragma unroll
+                for (int t = 0; t < KU; ++t) w[t][u] = word_k[(size_t)t * MM + offset];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
-                if (v[u] >= 0) {
-                    pos.add((u128)w0[u] * mag);
-                    if (KU == 2) pos_next.add((u128)w1[u] * mag);
-                } else {
-                    neg.add((u128)w0[u] * mag);
-                    if (KU == 2) neg_next.add((u128)w1[u] * mag);
+#pragma unroll
+                for (int t = 0; t < KU; ++t) {
+                    Sum& target = v[u] >= 0 ? (t == 0 ? pos : pos_next[t > 0 ? t - 1 : 0]) : (t == 0 ? neg : neg_next[t > 0 ? t - 1 : 0]);
+                    target.add((u128)w[t][u] * mag);
                 }
             }
         }
         emit(k);
-        if (KU == 2) {
-            pos.add(pos_next.acc);
-            pos.top += pos_next.top;
-            neg.add(neg_next.acc);
-            neg.top += neg_next.top;
-            emit(k + 1);
+#pragma unroll
+        for (int t = 1; t < KU; ++t) {
+            pos.add(pos_next[t - 1].acc);
+            pos.top += pos_next[t - 1].top;
+            neg.add(neg_next[t - 1].acc);
+            neg.top += neg_next[t - 1].top;
+            emit(k + t);
         }
     }
     {

@@ -50,7 +50,7 @@ def test_25fv47_whole_reference_pivot_sequence_in_fixed_width_integers():
     the same sequence (the first 64 pivots, both counts, the final basis and the optimum of tests/golden/25FV47.json, which the
     Fraction oracle took 1726 s to produce), widening 4 -> 8 -> 16 -> 32 -> 64 -> 128 limbs of 64 bits where a value might not fit
     and resuming at the pivot it stopped at (profiles/r4_exact_25fv47_128_limbs.txt: 20 / 45 / 96 / 207 / 534 pivots survive the
-    narrower widths; 21.5 s in all -- 257 s before the rework of the kernel -- 111 pivots/s against 2.3 for the exact CPU restatement on the same pivots)."""
+    narrower widths; 20 s in all -- 257 s before the rework of the kernel -- 119 pivots/s against 2.3 for the exact CPU restatement on the same pivots)."""
     golden = GOLDEN["25FV47"]
     solver = relp_amd.Solver().load_mps(os.path.join(ROOT, golden["file"]))
     got = solver.solve_exact(first_limbs=4, max_limbs=128)
