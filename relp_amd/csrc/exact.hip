@@ -163,6 +163,52 @@ __device__ __forceinline__ Big<L> big_mul_lo_blocked(const Big<L>& a, const Big<
     for (int k = 4 * NB; k < L; ++k) r.w[k] = 0;
     return r;
 }
+// (the same with a read through a pointer: the workgroup's copy of alpha~_p u in LDS)
+template <int L>
+__device__ __forceinline__ Big<L> big_mul_lo_blocked_p(const u64* a, const Big<L>& b, int blocks) {
+    static_assert(L % 4 == 0, "four words per block");
+    const int NB = blocks;
+    Big<L> r;
+    u64 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0;
+    for (int K = 0; K < NB; ++K) {
+        for (int I = 0; I <= K; ++I) {
+            const int J = K - I;
+            u64 a4[4], b4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a4[t] = a[4 * I + t];
+                b4[t] = b.w[4 * J + t];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                u64 carry = 0;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const u128 t = (u128)a4[ii] * b4[jj] + acc[ii + jj] + carry;
+                    acc[ii + jj] = (u64)t;
+                    carry = (u64)(t >> 64);
+                }
+#pragma unroll
+                for (int k = ii + 4; k < 9; ++k) {
+                    const u128 t = (u128)acc[k] + carry;
+                    acc[k] = (u64)t;
+                    carry = (u64)(t >> 64);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r.w[4 * K + t] = acc[t];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc[t] = acc[t + 4];
+#pragma unroll
+        for (int t = 5; t < 9; ++t) acc[t] = 0;
+    }
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 4 * NB; k < L; ++k) r.w[k] = 0;
+    return r;
+}
 // a * b + c * d modulo 2^(64 * 4 * blocks) in ONE pass over the blocks: both block products of a pair (I, J) go into the same window (the
 // update of N: alpha~_p u N_ik + (-alpha~_i u) N_pk, the second factor stored negated so that the difference is a sum).  a is read
 // through a pointer -- the caller passes the workgroup's copy in LDS, the same words for every thread -- b, c, d are the thread's own.
@@ -1545,7 +1591,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 for (int d = 1; d < WAVE; d *= 2) blocks = max(blocks, __shfl_xor(blocks, d));
                 blocks = min(L / 4, blocks);
                 if (zero) continue;
-                quotient = big_sar(big_sign_extend(big_mul_lo_blocked(c1, big_load_s<L>(lp.N + idx, MM), blocks), 4 * blocks), shift);
+                quotient = big_sar(big_sign_extend(big_mul_lo_blocked_p<L>(s_c1, big_load_s<L>(lp.N + idx, MM), blocks), 4 * blocks), shift);
             } else {
                 if (zero) continue;
                 quotient = big_sar(big_mul_lo(c1, big_load_s<L>(lp.N + idx, MM)), shift);
