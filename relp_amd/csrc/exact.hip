@@ -355,20 +355,6 @@ __device__ __forceinline__ Big<L> big_mul_lo(const Big<L>& a, const Big<L>& b) {
     }
     return r;
 }
-template <int L>
-__device__ __forceinline__ double big_to_double(const Big<L>& a) {
-    const bool neg = big_neg(a);
-    const Big<L> m = neg ? big_negate(a) : a;
-    int top = -1;
-#pragma unroll L <= 8 ? L : 1
-    for (int k = 0; k < L; ++k)
-        if (m.w[k] != 0) top = k;
-    if (top < 0) return 0.0;
-    double v = (double)m.w[top];
-    if (top > 0) v = v * 18446744073709551616.0 + (double)m.w[top - 1];
-    v = ldexp(v, 64 * (top > 0 ? top - 1 : 0));
-    return neg ? -v : v;
-}
 // bit length of |a| (0 for zero): the magnitude bounds that guard every operation are sums of these
 template <int L>
 __device__ __forceinline__ int big_bits(const Big<L>& a) {
@@ -465,68 +451,8 @@ __device__ __forceinline__ Big<L> big_sar(const Big<L>& a, int bits) {  // arith
     }
     return r;
 }
-template <int L>
-__device__ __forceinline__ Big<L> big_shl(const Big<L>& a, int bits) {
-    const int words = bits >> 6, rem = bits & 63;
-    Big<L> r;
-#pragma unroll L <= 8 ? L : 1
-    for (int k = 0; k < L; ++k) {
-        const int lo = k - words, lower = k - words - 1;
-        const u64 wl = lo >= 0 ? a.w[lo >= 0 ? lo : 0] : 0ull;
-        const u64 wp = lower >= 0 ? a.w[lower >= 0 ? lower : 0] : 0ull;
-        r.w[k] = rem ? (wl << rem) | (wp >> (64 - rem)) : wl;
-    }
-    return r;
-}
-// inverse of an ODD value modulo 2^(64 L): Newton  x <- x (2 - d x), the number of correct bits doubles per step
-template <int L>
-__device__ __forceinline__ Big<L> big_inverse_odd(const Big<L>& d) {
-    Big<L> x = d;  // d * d = 1 (mod 8): three correct bits
-    const Big<L> two = big_from<L>(2);
-    for (int correct = 3; correct < 64 * L; correct *= 2) x = big_mul_lo(x, big_sub(two, big_mul_lo(d, x)));
-    return x;
-}
-// The same on word arrays in shared memory, for ONE thread per workgroup (once per pivot): a Big<32> in a thread's private arrays
-// lives in scratch memory, where the ten full-width Newton steps above took 1.9 ms per pivot on E226 -- a third of the pivot.  Here
-// the precision doubles with the words that are already right (1, 2, 4, ... words: 4 have^2 word products per step, 1.4 k instead
-// of 10.5 k at 32 limbs) and a product is formed column by column in three accumulator registers (no read-modify-write of memory).
-__device__ __forceinline__ void words_mul_lo(const u64* a, int la, const u64* b, int lb, u64* out, int lo) {  // out may not alias a, b
-    u64 c0 = 0, c1 = 0, c2 = 0;
-    for (int k = 0; k < lo; ++k) {
-        const int j0 = k - la + 1 > 0 ? k - la + 1 : 0, j1 = k < lb - 1 ? k : lb - 1;
-        for (int j = j0; j <= j1; ++j) {
-            const u128 prod = (u128)a[k - j] * b[j];
-            const u128 low = (u128)c0 + (u64)prod;
-            c0 = (u64)low;
-            const u128 mid = (u128)c1 + (u64)(prod >> 64) + (u64)(low >> 64);
-            c1 = (u64)mid;
-            c2 += (u64)(mid >> 64);
-        }
-        out[k] = c0;
-        c0 = c1;
-        c1 = c2;
-        c2 = 0;
-    }
-}
-template <int L>
-__device__ void words_inverse_odd(const u64* d, u64* x, u64* t, u64* x2) {  // x = 1 / d modulo 2^(64 L), d odd; t, x2: L words of scratch
-    u64 inv = d[0];  // d * d = 1 (mod 8): three correct bits, doubled five times
-    for (int k = 0; k < 5; ++k) inv *= 2 - d[0] * inv;
-    x[0] = inv;
-    for (int have = 1; have < L; have *= 2) {
-        const int want = 2 * have < L ? 2 * have : L;
-        words_mul_lo(d, want, x, have, t, want);
-        u64 carry = 3;  // t <- 2 - t = ~t + 3
-        for (int k = 0; k < want; ++k) {
-            const u128 sum = (u128)(~t[k]) + carry;
-            t[k] = (u64)sum;
-            carry = (u64)(sum >> 64);
-        }
-        words_mul_lo(t, want, x, have, x2, want);
-        for (int k = 0; k < want; ++k) x[k] = x2[k];
-    }
-}
-// The same two on the whole workgroup (round 4: at 128 limbs the Newton iteration by one thread was 1.5 ms of every pivot).  A
+// 1 / d modulo 2^(64 L) and truncated products on word arrays in LDS, by the whole workgroup (round 3 had ONE thread do them, once per
+// pivot, with the precision doubling word by word: at 128 limbs that Newton iteration was 1.5 ms of every pivot).  A
 // product is formed by columns: thread k sums the word products of output word k in three words, one thread then runs the carries
 // through the columns -- two barriers a product, about 3 k cycles at 128 limbs instead of 100 k.  Called by every thread of the
 // workgroup (the arrays are in LDS); `part` holds 3 words per output word.
@@ -692,51 +618,12 @@ struct ExactLP {
     u64* gamma_terms;     // [candidates][m + 1][2 limbs + 2] the terms of those sums (capacity: see the host)
     u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b (first turn of a run); afterwards [limbs][m]: -alpha~_i / D_odd (negated: the update adds), word-major
     int* x_bits;          // ... their bit bounds
-    u64* c_part;          // [n - n_art][ceil(m / 32)] Big: partial sums of c_B' N a_j of the pricing pass
-    int* c_bits;          // ... their bit bounds
     i64* cb_row;          // [m] cost of the basic column of each row in the current phase (pricing pass B)
     int* row_list;        // [2 m] the rows with alpha~_i != 0, in order, and from [m] on the others (the update of N)
-    int debug_flags;      // RELP_EXACT_DEBUG (bisecting aid)
     int* N_bits;          // [m columns][m rows] bit length of |N(i, c)|, kept by whoever writes an entry (the bounds of the passes over N read 4 bytes instead of the integer)
 };
 
-// Exact gamma~_j = D^2 + sum_i (N a_j)_i^2 and c~_j^2 for the tie breaker of the pricing rule: sums of squares as unsigned
-// (2 L + 1)-limb numbers in scratch memory (one thread; rare).
-template <int L>
-__device__ void exact_weight(const ExactLP& lp, const Big<L>& D, int j, u64* gamma /* 2L+2 */) {
-    for (int k = 0; k < 2 * L + 2; ++k) gamma[k] = 0;
-    auto add_square = [&](const Big<L>& v, u64 w) {
-        const Big<L> mag = big_neg(v) ? big_negate(v) : v;
-        u64 sq[2 * L];
-        for (int k = 0; k < 2 * L; ++k) sq[k] = 0;
-        for (int i = 0; i < L; ++i) {
-            u64 carry = 0;
-            for (int t = 0; t < L; ++t) {
-                const u128 prod = (u128)mag.w[i] * mag.w[t] + sq[i + t] + carry;
-                sq[i + t] = (u64)prod;
-                carry = (u64)(prod >> 64);
-            }
-            sq[i + L] += carry;
-        }
-        u64 carry = 0;  // gamma += w * sq
-        for (int k = 0; k < 2 * L; ++k) {
-            const u128 s = (u128)sq[k] * w + gamma[k] + carry;
-            gamma[k] = (u64)s;
-            carry = (u64)(s >> 64);
-        }
-        const u128 s = (u128)gamma[2 * L] + carry;
-        gamma[2 * L] = (u64)s;
-        gamma[2 * L + 1] += (u64)(s >> 64);
-    };
-    add_square(D, (u64)lp.weight[j]);
-    for (int i = 0; i < lp.m; ++i) {
-        Big<L> a = big_from<L>(0);
-        for (int e = lp.col_start[j]; e < lp.col_start[j + 1]; ++e)
-            a = big_add(a, big_mul_small(big_load_s<L>(lp.N + (size_t)lp.row_index[e] * lp.m + i, (size_t)lp.m * lp.m), lp.value[e]));
-        add_square(a, (u64)lp.weight[lp.basis[i]]);
-    }
-}
-// out = w * v^2, unsigned, 2 L + 2 limbs (one term of the exact weight above)
+// out = w * v^2, unsigned, 2 L + 2 limbs: one term of the exact weight gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 of a tied candidate
 template <int L>
 __device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
     const Big<L> mag = big_neg(v) ? big_negate(v) : v;
@@ -1112,7 +999,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         drive_row = lp.resume[5];
         n_removed = lp.resume[6];
     }
-    if (!(lp.debug_flags & 4)) for (size_t e = gtid; e < MM; e += GT) lp.N_bits[e] = big_bits(big_load_s<L>(lp.N + e, MM));
+    for (size_t e = gtid; e < MM; e += GT) lp.N_bits[e] = big_bits(big_load_s<L>(lp.N + e, MM));
     grid.sync();
     int at_phase = phase, at_drive_row = drive_row, at_removed = n_removed;  // ... at the start of the current turn of the loop
     bool have_xb = false;  // x~_B belongs to the current basis
@@ -1193,7 +1080,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             for (long long item = gtid / WAVE; item < (long long)n_priced * row_blocks; item += GT / WAVE) {
                 const int jj = (int)(item / row_blocks), i = (int)(item - (long long)jj * row_blocks) * WAVE + lane;
                 const int j = lp.n_art + jj;
-                if (lp.pos[j] >= 0 || (lp.debug_flags & 1)) continue;  // (the whole wave)
+                if (lp.pos[j] >= 0) continue;  // (the whole wave)
                 const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
                 const bool active = i < m;
                 const size_t pair = (size_t)jj * m + (active ? i : 0);
@@ -1208,7 +1095,6 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
                 }
             }
-            if (lp.debug_flags & 16) { grid.sync(); status = EX_PIVOT_LIMIT; break; }
             grid.sync();
             stamp(9);
             // Pass B, a WAVE per column (round 4; rounds 2-3: a thread per (column, 32 rows) and then a thread per column, each adding
@@ -1219,14 +1105,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             for (long long item = gtid / WAVE; item < n_priced; item += GT / WAVE) {
                 const int j = lp.n_art + (int)item;
                 double key = 0.0;
-                if (lp.pos[j] < 0 && !(lp.debug_flags & 2)) {  // (the whole wave)
+                if (lp.pos[j] < 0) {  // (the whole wave)
                     int widest = 0;
                     key = price_column_wave<L>(lp, D, j, phase, lane, mD, eD, D_bits, PP, &widest);
                     if (lane == 0) flag_overflow(widest + log2_ceil(m + 1));
                 }
                 if (lane == 0) lp.key[j] = key;
             }
-            if (lp.debug_flags & 8) { grid.sync(); status = EX_PIVOT_LIMIT; break; }
             if (sync_overflow()) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
             stamp(1);
             // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
@@ -1858,8 +1743,6 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), fresh);
         u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
-        u64* d_c_part = dalloc<u64>((size_t)std::max(1, n - n_art) * ((m + 31) / 32) * big, fresh);
-        int* d_c_bits = dalloc<int>((size_t)std::max(1, n - n_art) * ((m + 31) / 32), fresh);
         auto adopt = [&]() {  // the new width's buffers replace the previous width's
             RELP_HIP(hipStreamSynchronize(stream));
             for (void* q : width_owned) (void)hipFree(q);
@@ -1900,7 +1783,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
         if (d_prof) RELP_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream));
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_c_part, d_c_bits, d_cb_row, d_row_list, getenv("RELP_EXACT_DEBUG") ? atoi(getenv("RELP_EXACT_DEBUG")) : 0, d_N_bits};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
