@@ -551,14 +551,19 @@ __device__ int sign_of_difference(const Big<L>& a, const Big<L>& b, const Big<L>
             *negative = false;
             return true;
         }
-        for (int i = 0; i < L; ++i) {
+        int lx = 0, ly = 0;  // words in use: the integers of a run rarely fill the width its largest one forced
+        for (int k = 0; k < L; ++k) {
+            if (mx.w[k] != 0) lx = k + 1;
+            if (my.w[k] != 0) ly = k + 1;
+        }
+        for (int i = 0; i < lx; ++i) {
             u64 carry = 0;
-            for (int j = 0; j < L; ++j) {
+            for (int j = 0; j < ly; ++j) {
                 const u128 t = (u128)mx.w[i] * my.w[j] + out[i + j] + carry;
                 out[i + j] = (u64)t;
                 carry = (u64)(t >> 64);
             }
-            out[i + L] += carry;
+            out[i + ly] += carry;
         }
         bool zero = true;
         for (int k = 0; k < 2 * L; ++k) zero = zero && out[k] == 0;
