@@ -92,6 +92,31 @@ def test_whole_pivot_sequence_is_the_reference_algorithms(name):
     solver.close()
 
 
+# Round 4 (limbs up to 128 and the reworked kernel: a few seconds each): the rest of the golden Netlib LPs that load without presolve.
+# Limbs each one needs: 2 STANDATA | 4 SC205 RECIPELP VTP-BASE CZPROB | 8 SCTAP1 BOEING2 | 16 LOTFI BEACONFD BOEING1 STANDMPS |
+# 32 AGG AGG2 AGG3 SCFXM1 | 64 BANDM SCSD1 SCRS8 GFRD-PNC.
+WIDER = ["LOTFI", "SC205", "RECIPELP", "SCTAP1", "BEACONFD", "AGG", "AGG2", "AGG3", "BANDM", "BOEING2", "BOEING1", "SCSD1", "STANDATA",
+         "STANDMPS", "VTP-BASE", "SCFXM1", "SCRS8", "GFRD-PNC", "CZPROB"]
+
+
+@pytest.mark.parametrize("name", WIDER)
+def test_more_netlib_lps_follow_the_reference_pivot_for_pivot(name):
+    """The reference's pivot counts, the first 64 pivots, the basis (of the rows the reference keeps) and the bit-exact optimum of
+    tests/golden/<name>.json, in fixed-width integers of up to 128 limbs on the device."""
+    golden = GOLDEN[name]
+    solver = relp_amd.Solver().load_mps(os.path.join(ROOT, golden["file"]))
+    got = solver.solve_exact(first_limbs=2, max_limbs=128)
+    assert got["status"] == 1, (got["status"], got["survived"])
+    assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"])
+    assert got["objective"] == golden["objective"]
+    head = device_indices([tuple(t) for t in golden["trace_head"]], solver.n_art)
+    assert got["trace"][:len(head)] == head
+    assert got["redundant_rows"] == golden["m"] - len(golden["basis"])
+    assert sorted(int(c) for c in got["basis"] if c >= 0) == sorted(golden["basis"])
+    assert got["survived"][-1][0] == got["limbs"]
+    solver.close()
+
+
 def test_limb_counts_needed():
     """int128 (2 limbs) is enough for the smallest LPs only; the escalation finds the width each one needs."""
     needed = {}
