@@ -117,6 +117,21 @@ def test_more_netlib_lps_follow_the_reference_pivot_for_pivot(name):
     solver.close()
 
 
+@pytest.mark.parametrize("name", ["GROW7", "BNL1"])
+def test_exact_simplex_and_exact_certificate_meet_where_no_golden_file_exists(name):
+    """Shipped Netlib LPs the Fraction oracle is too slow for: the reference's rule in fixed-width integers (relp_solve_exact: 171 and
+    1036 pivots at 64 limbs) and the f64 loop with its exact certificate are two independent exact computations; they end on the
+    same rational optimum, digit for digit."""
+    solver = relp_amd.Solver(certify=1).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    relaxed = solver.solve_relaxation()
+    assert relaxed.kind == relp_amd.FINITE_OPTIMUM and relaxed.certified
+    certified = solver.objective_exact()
+    got = solver.solve_exact(first_limbs=2, max_limbs=128, max_pivots=100000)
+    assert got["status"] == 1, (got["status"], got["survived"])
+    assert got["objective"] == certified
+    solver.close()
+
+
 def test_limb_counts_needed():
     """int128 (2 limbs) is enough for the smallest LPs only; the escalation finds the width each one needs."""
     needed = {}
