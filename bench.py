@@ -1034,6 +1034,91 @@ def all_configs(args, ctx, legs):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        return probe.getsockname()[1]
+
+
+def launch_ranks(gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process (which never initialises the GPU:
+    no torch import, no HIP call, no exec), each with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment exactly as
+    `torch.distributed.run --nnodes=1 --nproc-per-node N` would set them, wait for all of them, and relay rank 0's stdout (its last line
+    is the bench line).  Returns the exit code: non-zero when any rank failed -- a run that cannot give N ranks must not print a line."""
+    import tempfile
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    children = []
+    with tempfile.TemporaryFile(mode="w+") as rank0_stdout:
+        for rank in range(gpus):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus), GROUP_RANK="0",
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                             stdout=rank0_stdout if rank == 0 else subprocess.DEVNULL))
+        codes = [None] * gpus
+        while any(code is None for code in codes):
+            for k, child in enumerate(children):
+                if codes[k] is None:
+                    codes[k] = child.poll()
+            if any(code for code in codes):  # one rank died: the others would wait for it in the rendezvous -- stop them (by their own pids)
+                for k, child in enumerate(children):
+                    if codes[k] is None:
+                        child.terminate()
+                        try:
+                            codes[k] = child.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            child.kill()
+                            codes[k] = child.wait()
+                break
+            time.sleep(0.05)
+        rank0_stdout.seek(0)
+        out = rank0_stdout.read()
+    lines = [row for row in (out or "").splitlines() if row.strip()]
+    for row in lines[:-1]:
+        print(row)
+    if any(codes):
+        sys.stderr.write("bench.py: --gpus %d: exit codes of the ranks %s\n" % (gpus, codes))
+        for row in lines[-1:]:
+            print(row)
+        return next(code for code in codes if code) or 1
+    try:
+        line = json.loads(lines[-1])
+    except (IndexError, ValueError):
+        sys.stderr.write("bench.py: --gpus %d: rank 0 printed no JSON line\n" % gpus)
+        return 1
+    if line.get("n_gpus") != gpus:
+        sys.stderr.write("bench.py: --gpus %d but the ranks report n_gpus %s\n" % (gpus, line.get("n_gpus")))
+        return 1
+    emit(lines[-1])
+    return 0
+
+
+def launch_check(rank, local_rank, world):
+    """`--launch-check`: the rendezvous, a barrier and a SUM of the ranks -- what every workload's timing does around its solves -- and
+    nothing else.  gloo where there is no device per rank (the CPU tests), RCCL otherwise."""
+    import torch
+    shared = os.environ.get("RELP_BENCH_SHARED_DEVICE") == "1" or torch.cuda.device_count() < world
+    ranks = [0]
+    if world > 1:
+        import torch.distributed as dist
+        if shared:
+            dist.init_process_group(backend="gloo")
+            device = "cpu"
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            device = "cuda"
+        dist.barrier()
+        seen = torch.zeros(world, dtype=torch.int64, device=device)
+        seen[rank] = rank + 1
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ranks = [int(v) - 1 for v in seen.tolist()]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit(json.dumps({"launch_check": True, "n_gpus": world, "ranks": ranks, "backend": "gloo" if shared else "nccl"}))
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -1061,16 +1146,31 @@ def main():
     parser.add_argument("--detail", default=os.path.join(ROOT, "bench_configs.json"),
                         help="file that receives the full record (per-kernel tables, every config, CPU samples); the stdout line is compact")
     parser.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
+    parser.add_argument("--launch-check", action="store_true",
+                        help="no solve: the ranks rendezvous, reduce their ranks and rank 0 prints {n_gpus, ranks} (runs without a GPU over gloo)")
     args = parser.parse_args()
 
     if args.cpu_leg:  # child process: one CPU baseline, no GPU
         print(json.dumps(run_cpu_leg(args.cpu_leg, args.cpu_seconds)), flush=True)
         return
 
+    if args.gpus < 1:
+        parser.error("--gpus must be at least 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher -- it has not imported torch or touched HIP -- and the N
+        # ranks are its children (one per GPU, rendezvous on 127.0.0.1); rank 0's line is relayed as the last line of stdout
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:  # never report n_gpus of a job that is not the one asked for
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: launch with --nproc-per-node %d (or without a launcher)\n" % (args.gpus, world, args.gpus))
+        sys.exit(2)
+    if args.launch_check:
+        launch_check(rank, local_rank, world)
+        return
     distributed = world > 1 or os.environ.get("RELP_FORCE_DISTRIBUTED") == "1"  # the env switch exercises the RCCL path at N=1
     # RELP_BENCH_SHARED_DEVICE=1 (tests on a 1-GPU box): every rank solves on device 0 and the ranks talk over gloo -- RCCL refuses two
     # ranks on one device.  Everything above the collectives (barriers, MAX / SUM reductions, the shared ticket queue, the gathered

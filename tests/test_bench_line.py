@@ -54,3 +54,26 @@ def test_batch_record_fits_the_compact_line():
     full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_default.json")))["configs"]["netlib_batch"]
     line = json.loads(bench.compact_line(full, "bench_configs.json"))
     assert line["scaling"] == "strong" and line["config"]["tickets_per_rank"] == [90] and line["config"]["longest_lp"]
+
+
+def test_gpus_flag_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with NO torch.distributed.run around it (the shape of the driver's N = 1 command with another N): the
+    process starts the two ranks itself and rank 0 reports n_gpus == 2.  `--launch-check` is the rendezvous + barrier + reduction of every
+    workload without the solves, so it runs here over gloo; the GPU twin with a real workload is
+    tests/test_network.py::test_bench_two_ranks_without_a_launcher."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == [0, 1]
+
+
+def test_gpus_flag_that_disagrees_with_the_launcher_fails_loudly():
+    """A launcher that gave another world size than --gpus asks for: non-zero exit and no bench line (round 4 printed n_gpus 1)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr and out.stdout.strip() == ""

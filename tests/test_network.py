@@ -456,6 +456,42 @@ def test_bench_two_ranks_over_rccl(workload):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["25fv47", "netlib"])
+def test_bench_two_ranks_without_a_launcher(workload):
+    """`python bench.py --gpus 2 ...` with nothing around it: bench.py starts its two ranks itself (before it imports torch) and relays
+    rank 0's line with n_gpus == 2.  On a 1-GPU box the two ranks share device 0 and talk over gloo (RELP_BENCH_SHARED_DEVICE=1);
+    with two GPUs they take one each over RCCL."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if torch.cuda.device_count() < 2:
+        env["RELP_BENCH_SHARED_DEVICE"] = "1"
+    from bench_support import run_bench
+    short, line, _ = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--no-cpu-baseline",
+                                "--no-concurrency-probe"], env=env)
+    assert short["n_gpus"] == 2 and short["value"] > 0
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["makespan_s"] > 0
+    if workload == "netlib":
+        assert len(line["config"]["tickets_per_rank"]) == 2 and sum(line["config"]["tickets_per_rank"]) == 2 * 45
+    else:
+        assert [r["rank"] for r in line["config"]["per_rank"]] == [0, 1]
+
+
+@pytest.mark.gpu
+def test_bench_more_ranks_than_devices_fails_loudly():
+    """`--gpus N` on a box with fewer devices: non-zero exit, no line that claims N GPUs."""
+    import subprocess
+    import sys
+    import torch
+    wanted = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "RELP_BENCH_SHARED_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(wanted), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                          "--no-configs", "--no-concurrency-probe"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not any(row.startswith("{") and '"n_gpus"' in row for row in out.stdout.splitlines())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("crash", [1, 0], ids=["crash-basis", "reference-start"])
 def test_bench_max_flow_workload_line(crash):
     """`bench.py --workload maxflow64k` (the 64 k-arc twin of BASELINE config 5) end to end as a child process: one JSON line with the
