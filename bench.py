@@ -148,11 +148,13 @@ def compact_line(line, detail_name):
         out["host"] = line["host"]
     out["detail_file"] = detail_name
     out = _round(out)
-    if out.get("roofline") and out["roofline"].get("peak"):  # consistent after the rounding: frac IS achieved / peak
-        out["roofline"]["frac"] = out["roofline"]["achieved"] / out["roofline"]["peak"]
+    if out.get("roofline") and out["roofline"].get("peak") and out["roofline"].get("achieved") is not None:
+        out["roofline"]["frac"] = out["roofline"]["achieved"] / out["roofline"]["peak"]  # consistent after the rounding: frac IS achieved / peak
     text = json.dumps(out, separators=(",", ":"))
     if len(text) > COMPACT_LIMIT:  # never let the line outgrow the driver's capture again: drop the prose first, then the summaries
-        for victim in (("cpu_baseline", "sample"), ("cpu_baseline_tuned", None), ("config", "workload"), ("configs_summary", None)):
+        for victim in (("cpu_baseline", "sample"), ("cpu_baseline_tuned", None), ("config", "workload"), ("configs_summary", None),
+                       ("configs_summary_fields", None), ("cpu_baseline_f64_tuned", None), ("cpu_baseline_f64_port", None),
+                       ("same_work_exact", None), ("same_work_exact_25fv47", None), ("host", None)):
             if victim[1] is None:
                 out.pop(victim[0], None)
             elif isinstance(out.get(victim[0]), dict):
@@ -160,6 +162,17 @@ def compact_line(line, detail_name):
             text = json.dumps(out, separators=(",", ":"))
             if len(text) <= COMPACT_LIMIT:
                 break
+    if len(text) > COMPACT_LIMIT:  # last resort: the contract's fields and nothing else
+        contract = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                            "vs_baseline", "dtype", "data", "detail_file")}
+        contract["metric"] = _short(contract["metric"], 200)
+        contract["data"] = _short(contract["data"], 200)
+        contract["config"] = {"workload": _short((out.get("config") or {}).get("workload"), 60)}
+        for key in ("roofline", "cpu_baseline"):
+            if isinstance(out.get(key), dict):
+                contract[key] = {k: (v if not isinstance(v, str) else _short(v, 60)) for k, v in out[key].items() if not isinstance(v, (dict, list))}
+        text = json.dumps(contract, separators=(",", ":"))
+    assert len(text) <= COMPACT_LIMIT, len(text)
     return text
 
 
@@ -373,7 +386,25 @@ def cpu_leg_exact_full(lp_name, budget_seconds):
             "sample": "the WHOLE exact solve of %s (oracle/cpp, faithful): %d pivots in %.2f s (%s)" % (lp_name, pivots, record["seconds"], record.get("status", ""))}
 
 
+def cpu_leg_exact_prefix(lp_name, budget_seconds):
+    """The exact CPU restatement on the metric's own LP for `budget_seconds` on THIS host (or to the optimum if that comes first): the
+    pivot count P it reached is what the device's exact path is then timed on (`relp_solve_exact(max_pivots = P)`), so the ratio compares
+    the same first P pivots of the reference's sequence, measured in the same run on the same machine."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from relp_oracle import cpu
+    from relp_oracle.mps import load_problem
+    _, data = load_problem(os.path.join(ROOT, "data", "netlib", lp_name + ".SIF"))
+    record = cpu.solve_provider(data, max_seconds=budget_seconds, trace=0)
+    pivots = record["pivots_phase1"] + record["pivots_phase2"]
+    return {"value": pivots / record["seconds"] if record["seconds"] > 0 else 0.0, "unit": "pivots/s", "cores": 1, "kind": "port", "mode": "faithful",
+            "pivots": pivots, "seconds": record["seconds"], "status": record.get("status", ""), "stamps": record.get("stamps", []),
+            "sample": "the first %d pivots of %s's exact solve (oracle/cpp, faithful, %s) in %.1f s on this host" % (
+                pivots, lp_name, record.get("status", ""), record["seconds"])}
+
+
 def run_cpu_leg(name, seconds):
+    if name.startswith("exact_prefix:"):
+        return cpu_leg_exact_prefix(name.split(":")[1], seconds)
     if name.startswith("exact_full:"):
         return cpu_leg_exact_full(name.split(":")[1], max(seconds, 120.0))
     if name == "exact_faithful":
@@ -896,7 +927,7 @@ def netlib_batch(args, ctx):
 EXACT_SAME_WORK_LP = "E226"   # mid-size: the exact CPU restatement finishes it in seconds, so both sides run the SAME pivots to completion
 
 
-def exact_lp(lp_name, ctx, first_limbs, max_limbs):
+def exact_lp(lp_name, ctx, first_limbs, max_limbs, max_pivots=0):
     """One solve of `lp_name` with `relp_solve_exact` (LIMBS x 64-bit integers, widened where a value might not fit), timed: value =
     pivots of the reference's sequence per second.  The roofline entry prices the integer update of the m x m numerator matrix."""
     import relp_amd
@@ -904,7 +935,7 @@ def exact_lp(lp_name, ctx, first_limbs, max_limbs):
     golden = json.load(open(golden_path)) if os.path.exists(golden_path) else None
     solver = relp_amd.Solver(device=ctx["local_rank"]).load_mps(os.path.join(ROOT, "data", "netlib", lp_name + ".SIF"))
     start = time.perf_counter()
-    got = solver.solve_exact(first_limbs=first_limbs, max_limbs=max_limbs)
+    got = solver.solve_exact(first_limbs=first_limbs, max_limbs=max_limbs, max_pivots=max_pivots)
     elapsed = time.perf_counter() - start
     pivots = got["pivots_phase_one"] + got["pivots_phase_two"]
     m = solver.m
@@ -930,21 +961,37 @@ def exact_lp(lp_name, ctx, first_limbs, max_limbs):
 
 
 EXACT_25FV47_CPU = {"value": 2392 / 1026.0, "unit": "pivots/s", "cores": 1, "kind": "port", "mode": "faithful", "recorded": True, "seconds": 1026.0,
-                    "sample": "the whole exact solve on the CPU restatement: 2392 pivots in 1026 s (profiles/r1_cpu_oracle_full_solve.json, build container)"}
+                    "recorded_on_other_host": True,
+                    "sample": "the whole exact solve on the CPU restatement: 2392 pivots in 1026 s (profiles/r1_cpu_oracle_full_solve.json, build container, "
+                              "NOT the bench host: see same_work for the measured pair)"}
 
 
 def exact_25fv47_live(ctx):
-    """BASELINE configs[1] pivot for pivot in fixed-width integers, measured in this process (about 20 s since the round-4 rework of the
-    exact kernel; 257 s before, when the default run quoted a recorded figure).  The CPU side of the ratio is the recorded whole solve
-    of the exact CPU restatement (17 minutes: not repeated here)."""
+    """BASELINE configs[1] pivot for pivot in fixed-width integers, measured in this process.  The CPU side of `same_work` is measured in the
+    same run on the same host (`exact_same_work_25fv47`); the whole CPU solve recorded in round 1 on another machine is kept only as a
+    labelled extra."""
     entry = exact_lp("25FV47", ctx, 4, 128)
     entry["recorded"] = False
     entry["cpu_baseline"] = dict(EXACT_25FV47_CPU)
-    seconds = entry["ms_per_step"] / 1e3
-    entry["same_work"] = {"lp": "25FV47", "pivots": entry["config"]["pivots_per_solve"], "gpu_seconds": seconds, "cpu_seconds_recorded": EXACT_25FV47_CPU["seconds"],
-                          "cpu_over_gpu": EXACT_25FV47_CPU["seconds"] / seconds if seconds > 0 else None, "limbs": entry["config"]["limbs"],
-                          "matches_golden": entry["config"]["matches_golden_optimum_and_pivot_counts"]}
     return entry
+
+
+def exact_same_work_25fv47(ctx, entry, cpu):
+    """`same_work_exact_25fv47`: the exact CPU port ran P pivots of 25FV47 on this host in this run (`cpu`, the exact_prefix leg); the
+    device path is timed on the same first P pivots (`relp_solve_exact(max_pivots = P)`, widths escalating from 4 limbs as in the whole
+    solve) -- or the whole solve on both sides when the CPU leg reached the optimum."""
+    whole = cpu.get("status") == "optimal"
+    pivots = cpu["pivots"]
+    if whole:
+        seconds, limbs, got_pivots = entry["ms_per_step"] / 1e3, entry["config"]["limbs"], entry["config"]["pivots_per_solve"]
+    else:
+        prefix = exact_lp("25FV47", ctx, 4, 128, max_pivots=pivots)
+        seconds, limbs, got_pivots = prefix["ms_per_step"] / 1e3, prefix["config"]["limbs"], prefix["config"]["pivots_per_solve"]
+    return {"lp": "25FV47", "pivots": pivots, "pivots_gpu": got_pivots, "whole_solve": whole, "gpu_seconds": seconds, "cpu_seconds_measured": cpu["seconds"],
+            "cpu_over_gpu": cpu["seconds"] / seconds if seconds > 0 else None, "limbs": limbs, "host": cpu.get("cpu_model"), "cpu_cores": 1,
+            "same_run_same_host": True, "cpu_stamps_pivot_seconds": cpu.get("stamps", [])[-6:],
+            "gpu_whole_solve_seconds": entry["ms_per_step"] / 1e3, "matches_golden": entry["config"]["matches_golden_optimum_and_pivot_counts"],
+            "cpu_whole_solve_seconds_recorded_other_host": EXACT_25FV47_CPU["seconds"]}
 
 
 def exact_25fv47_recorded():
@@ -988,6 +1035,8 @@ def all_configs(args, ctx, legs):
 
     steps = max(1, min(args.steps, 3))
     if not args.no_cpu_baseline:
+        # the longest CPU leg first: the exact port on the metric's LP, for --exact-cpu-seconds on this host, beside all the GPU work below
+        legs.start("exact_prefix", "exact_prefix:25FV47", args.exact_cpu_seconds)
         legs.start("exact_full", "exact_full:" + EXACT_SAME_WORK_LP, args.cpu_seconds)
     attempt("exact_" + EXACT_SAME_WORK_LP.lower(), lambda: exact_lp(EXACT_SAME_WORK_LP, ctx, 2, 32))
     attempt("exact_25fv47", lambda: exact_25fv47_recorded() if args.recorded_exact_25fv47 else exact_25fv47_live(ctx))
@@ -1020,6 +1069,16 @@ def all_configs(args, ctx, legs):
         for key in ("maxflow_reference_start", "maxflow_crash"):
             if "error" not in out[key]:
                 out[key]["cpu_baseline"] = flow_cpu
+        if "error" not in out["exact_25fv47"] and not out["exact_25fv47"].get("recorded"):
+            prefix = legs.collect("exact_prefix", timeout=args.exact_cpu_seconds + 600)
+            if prefix and "error" not in prefix and prefix.get("pivots"):
+                try:
+                    out["exact_25fv47"]["same_work"] = exact_same_work_25fv47(ctx, out["exact_25fv47"], prefix)
+                    out["exact_25fv47"]["cpu_baseline_same_host"] = {k: v for k, v in prefix.items() if k != "stamps"}
+                except Exception as error:  # noqa: BLE001
+                    out["exact_25fv47"]["same_work"] = {"error": "%s: %s" % (type(error).__name__, error)}
+            else:
+                out["exact_25fv47"]["same_work"] = {"error": (prefix or {}).get("error", "no CPU leg")}
     # The batch lines last, when the CPU legs above have finished: a batch has four host threads that factorise, certify and feed
     # four streams, and shared the cores with three busy CPU legs before (0.59-0.75 s per presolved pass from run to run).
     attempt("netlib_batch", lambda: netlib_batch(variant(workload="netlib", presolve=False, steps=2, warmup=1), ctx))
@@ -1129,6 +1188,9 @@ def main():
     parser.add_argument("--dense-storage", choices=["narrowest", "f32", "f64"], default="narrowest",
                         help="dense workloads: storage type of the dense block (narrowest exact type: signed bytes for this generator)")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
+    parser.add_argument("--exact-cpu-seconds", type=float, default=150.0,
+                        help="budget of the exact CPU port on 25FV47 (same_work_exact_25fv47: the device is timed on the pivots it reached; "
+                             "about 400 s reach the optimum on the bench host)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-concurrency-probe", action="store_true")
     parser.add_argument("--no-dense-roofline", action="store_true", help="(kept for compatibility: the dense roofline now lives under configs)")
@@ -1137,7 +1199,6 @@ def main():
     parser.add_argument("--carry", type=int, default=0, choices=[0, 1, 2],
                         help="0 explicit inverse, 1 LU + Forrest-Tomlin, 2 LU through the inverses of its triangles + product-form updates (relp_options.carry)")
     parser.add_argument("--lu-refactor", type=int, default=0, choices=[0, 1, 2], help="LU carries: 0 automatic, 1 refactorisation kernels on the device, 2 host core (relp_options.lu_refactor)")
-    parser.add_argument("--exact-25fv47", action="store_true", help="(kept for compatibility: the default run now measures 25FV47 through relp_solve_exact live, about 20 s)")
     parser.add_argument("--recorded-exact-25fv47", action="store_true", help="quote the recorded 25FV47 exact run (profiles/r4_exact_25fv47_128_limbs.txt) instead of measuring it")
     parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")

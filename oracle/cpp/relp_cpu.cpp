@@ -780,8 +780,12 @@ struct Trace {
     size_t keep = 64;
     size_t max_bits = 0;
     std::vector<std::vector<int>> head;
+    long stamp_every = 100;                               // cumulative seconds after every `stamp_every` pivots (bench.py: same-work ratios)
+    std::vector<std::pair<long, double>> stamps;
     void record(int q, int p, int leaving, const Tableau& t) {
         ++count[phase];
+        if (stamp_every > 0 && (count[1] + count[2]) % stamp_every == 0)
+            stamps.push_back(std::make_pair(count[1] + count[2], std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count()));
         if (head.size() < keep) head.push_back({phase, q, p, leaving});
         if (t.im.minus_objective.is_big()) max_bits = std::max(max_bits, t.im.minus_objective.bits());
         if (limit >= 0 && count[1] + count[2] >= limit) throw PivotLimit();
@@ -883,6 +887,7 @@ int main(int argc, char** argv) {
         if (a == "--max-pivots" && i + 1 < argc) trace.limit = atol(argv[++i]);
         else if (a == "--max-seconds" && i + 1 < argc) trace.max_seconds = atof(argv[++i]);
         else if (a == "--trace" && i + 1 < argc) trace.keep = (size_t)atol(argv[++i]);
+        else if (a == "--stamp-every" && i + 1 < argc) trace.stamp_every = atol(argv[++i]);
         else if (a == "--tuned") g_tuned = true;
         else if (a == "--rule" && i + 1 < argc) {
             std::string r = argv[++i];
@@ -1006,6 +1011,8 @@ int main(int argc, char** argv) {
             << ",\"trace_head\":[";
         for (size_t i = 0; i < trace.head.size(); ++i)
             out << (i ? "," : "") << "[" << trace.head[i][0] << "," << trace.head[i][1] << "," << trace.head[i][2] << "," << trace.head[i][3] << "]";
+        out << "],\"stamps\":[";
+        for (size_t i = 0; i < trace.stamps.size(); ++i) out << (i ? "," : "") << "[" << trace.stamps[i].first << "," << trace.stamps[i].second << "]";
         out << "]";
         if (status == "optimal" && have_final) {
             out << ",\"objective\":\"" << (-final_tableau.im.minus_objective).to_string() << "\",\"basis\":[";

@@ -77,3 +77,19 @@ def test_gpus_flag_that_disagrees_with_the_launcher_fails_loudly():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr and out.stdout.strip() == ""
+
+
+def test_compact_line_is_bounded_whatever_the_record_holds():
+    """Fields the trimming loop never looked at (config values, host, the f64 baselines) blown up: the line still fits and still
+    carries the contract's fields; a roofline with a peak and no achieved figure does not raise."""
+    bench = load_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_default.json")))
+    full["host"] = {"cpu_model": "z" * 6000, "nproc": 256}
+    full["metric"] = "m" * 3000
+    full["config"]["carry_per_lp"] = {("LP%04d" % k): "explicit" for k in range(600)}
+    full["roofline"]["achieved"] = None
+    text = bench.compact_line(full, "bench_configs.json")
+    assert len(text.encode()) <= bench.COMPACT_LIMIT
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
