@@ -336,6 +336,21 @@ typedef struct relp_exact_result {
 } relp_exact_result;
 int32_t relp_solve_exact(relp_handle* handle, int32_t first_limbs, int32_t max_limbs, int64_t max_pivots, relp_exact_result* result,
                          int32_t trace_capacity, int32_t* trace, char* objective, int32_t objective_capacity, int32_t* basis);
+/* Measurement of the last relp_solve_exact on this handle, one record per width tried (no reference counterpart: the reference's
+ * RationalBig has no fixed width).  `update_word_products_*` count the 64 x 64 -> 128-bit multiplications of the integer-preserving
+ * update of N = D B^-1 (the dominant step): `needed` by the entries' bit bounds, `issued` by the waves (the integer-multiply roofline
+ * of bench.py divides `issued` by `step_seconds[7]`).  step_seconds: x_B, pricing pass B, arg-max, exact weights, tournament, entering
+ * column, ratio test, update of N, bookkeeping, pricing pass A.  Returns the number of records through *count (at most `capacity` copied). */
+typedef struct relp_exact_width_record {
+    int32_t limbs;
+    int32_t grid;                          /* workgroups of the cooperative launch */
+    int64_t pivots_total_at_end;           /* pivots of the solve when this width stopped */
+    double seconds;                        /* host wall time of this width */
+    double step_seconds[10];
+    int64_t update_word_products_needed;
+    int64_t update_word_products_issued;
+} relp_exact_width_record;
+int32_t relp_get_exact_counters(const relp_handle* handle, relp_exact_width_record* records, int32_t capacity, int32_t* count);
 /* `InverseMaintainer::basis_column_index_for_row` for all rows (provider indices; -1-k for artificial k). */
 int32_t relp_get_basis(const relp_handle* handle, int32_t* basis);
 

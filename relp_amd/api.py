@@ -51,6 +51,14 @@ class ExactResult(C.Structure):
                 ("redundant_rows", C.c_int32), ("reserved", C.c_int32), ("pivots_survived", C.c_int64 * 6)]
 
 
+class ExactWidthRecord(C.Structure):
+    _fields_ = [("limbs", C.c_int32), ("grid", C.c_int32), ("pivots_total_at_end", C.c_int64), ("seconds", C.c_double),
+                ("step_seconds", C.c_double * 10), ("update_word_products_needed", C.c_int64), ("update_word_products_issued", C.c_int64)]
+
+
+EXACT_STEPS = ("x_B", "pricing pass B", "arg-max", "exact weights", "tournament", "entering column", "ratio test", "update of N", "bookkeeping", "pricing pass A")
+
+
 class BatchEntry(C.Structure):
     _fields_ = [("status", C.c_int32), ("model", C.c_int32), ("worker", C.c_int32), ("device", C.c_int32), ("result", Result),
                 ("start_seconds", C.c_double), ("end_seconds", C.c_double)]
@@ -76,7 +84,7 @@ SYMBOLS = [
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
     "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_mps_ex", "relp_get_original_solution", "relp_load_model", "relp_get_dimensions", "relp_get_column",
     "relp_get_cost", "relp_get_right_hand_side", "relp_get_initial_pivots", "relp_solve_relaxation",
-    "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_solve_exact", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
+    "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_solve_exact", "relp_get_exact_counters", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
     "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_get_last_pivot", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
     "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps",
@@ -465,6 +473,17 @@ class Solver:
                 "trace": [tuple(int(v) for v in trace[4 * k:4 * k + 4]) for k in range(entries)],
                 "objective": objective.value.decode(), "basis": basis, "redundant_rows": int(result.redundant_rows),
                 "survived": [(int(result.limbs_tried[k]), int(result.pivots_survived[k])) for k in range(6) if result.limbs_tried[k]]}
+
+    def exact_counters(self):
+        """Per width tried by the last ``solve_exact``: seconds, seconds per step of the loop, and the word products (64 x 64 -> 128 bit)
+        of the update of N, needed and issued (``relp_get_exact_counters``)."""
+        records = (ExactWidthRecord * 16)()
+        count = C.c_int32()
+        self._check(lib().relp_get_exact_counters(self._h, records, 16, C.byref(count)))
+        return [{"limbs": r.limbs, "grid": r.grid, "pivots_total_at_end": r.pivots_total_at_end, "seconds": r.seconds,
+                 "step_seconds": dict(zip(EXACT_STEPS, list(r.step_seconds))),
+                 "update_word_products_needed": r.update_word_products_needed, "update_word_products_issued": r.update_word_products_issued}
+                for r in records[:min(16, count.value)]]
 
     def record(self):
         """The per-LP record of the last solve as a dict (``relp_get_record_json``)."""

@@ -821,6 +821,25 @@ int32_t relp_solve_exact(relp_handle* h, int32_t first_limbs, int32_t max_limbs,
     });
 }
 
+int32_t relp_get_exact_counters(const relp_handle* h, relp_exact_width_record* records, int32_t capacity, int32_t* count) {
+    REQUIRE_LOADED(h);
+    if (!count || capacity < 0 || (capacity > 0 && !records)) return RELP_ERR_ARGUMENT;
+    return guarded(const_cast<relp_handle*>(h), [&] {
+        const std::vector<relp::ExactWidthRecord>& all = h->solver->exact_records();
+        *count = (int32_t)all.size();
+        for (size_t k = 0; k < all.size() && k < (size_t)capacity; ++k) {
+            relp_exact_width_record& out = records[k];
+            out.limbs = all[k].limbs;
+            out.grid = all[k].grid;
+            out.pivots_total_at_end = all[k].pivots_total_at_end;
+            out.seconds = all[k].seconds;
+            for (int t = 0; t < 10; ++t) out.step_seconds[t] = all[k].step_seconds[t];
+            out.update_word_products_needed = all[k].update_products_needed;
+            out.update_word_products_issued = all[k].update_products_issued;
+        }
+    });
+}
+
 int32_t relp_get_basis(const relp_handle* h, int32_t* basis) {
     REQUIRE_LOADED(h);
     if (!basis) return RELP_ERR_ARGUMENT;

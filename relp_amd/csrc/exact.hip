@@ -613,7 +613,8 @@ struct ExactLP {
     int* shared_words;    // [8] grid-wide overflow flag, decisions of workgroup 0's thread 0
     double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
     unsigned long long* part_rank;
-    unsigned long long* prof;  // [16] diagnostic (RELP_EXACT_PROFILE): the leader's cycle sums per phase of the loop, candidate counts
+    unsigned long long* prof;  // [EX_PROF_WORDS] the leader's time per step of the loop in ticks of the 100 MHz wall clock [0..9], candidate counts [12],
+                               // and the word products (64 x 64 -> 128 bit) of the update of N: [16] those the entries need, [17] those the waves issue
     u64* price_a;         // [limbs][n - n_art][m]: (N a_j)_i of the pricing pass, word-major
     int* price_bits;      // ... its bit bound
     double* price_term;   // ... its share of the steepest-edge estimate
@@ -945,14 +946,15 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     long long pivots[2] = {0, 0};
     int trace_count = 0;
     int status = EX_RUNNING;
-    unsigned long long t_last = clock64();
-    auto stamp = [&](int k) {
-        if (leader && lp.prof) {
-            const unsigned long long t = clock64();
+    unsigned long long t_last = wall_clock64();
+    auto stamp = [&](int k) {  // (one thread, ten reads of the constant 100 MHz counter per pivot)
+        if (leader) {
+            const unsigned long long t = wall_clock64();
             lp.prof[k] += t - t_last;
             t_last = t;
         }
     };
+    unsigned long long products_needed = 0, products_issued = 0;  // this thread's word products in the update of N, whole run
     int parity = 0;  // the partial arrays of the grid reductions alternate, so that a fast workgroup never overwrites what a slow one still reads
     if (tid == 0) s_overflow = 0;
     __syncthreads();
@@ -1141,7 +1143,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 grid.sync();
                 stamp(2);
                 const int n_cand = word[4];
-                if (leader && lp.prof) lp.prof[12] += n_cand;
+                if (leader) lp.prof[12] += n_cand;
                 int winner = q;
                 if (n_cand > 1) {
                     // gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 exactly ((2 L + 2)-limb sums of squares).  The (N a_j)_i are the ones
@@ -1446,11 +1448,15 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 // integers of a run rarely fill the width its largest one forced: 16.5 -> 11.8 s of 25FV47's update at 128 limbs).
                 const int needed = max(ap_bits + lp.N_bits[idx], lp.x_bits[i] + lp.N_bits[(size_t)k * m + p]) + 1 - (D_bits - 1) + shift + 2;
                 int blocks = min(L / 4, max(1, (needed + 255) / 256));
+                products_needed += 16ull * blocks * (blocks + 1);  // two truncated products of 4 x 4-word blocks
                 for (int d = 1; d < WAVE; d *= 2) blocks = max(blocks, __shfl_xor(blocks, d));
                 blocks = min(L / 4, blocks);  // (a lane that sits this turn out contributes whatever its register holds)
+                products_issued += 16ull * blocks * (blocks + 1);
                 const Big<L> numerator = big_mul_add_lo_blocked<L>(s_c1, nik, ri, npk, blocks);  // (ri is stored negated)
                 quotient = big_sar(big_sign_extend(numerator, 4 * blocks), shift);
             } else {
+                products_needed += (unsigned long long)L * (L + 1);
+                products_issued += (unsigned long long)L * (L + 1);
                 quotient = big_sar(big_add(big_mul_lo(c1, nik), big_mul_lo(ri, npk)), shift);
             }
             if (flip) quotient = big_negate(quotient);
@@ -1478,12 +1484,17 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             if constexpr (L >= 16) {
                 const int needed = zero ? 0 : ap_bits + lp.N_bits[idx] + 1 - (D_bits - 1) + shift + 2;
                 int blocks = min(L / 4, max(1, (needed + 255) / 256));
+                const int own_blocks = blocks;
                 for (int d = 1; d < WAVE; d *= 2) blocks = max(blocks, __shfl_xor(blocks, d));
                 blocks = min(L / 4, blocks);
                 if (zero) continue;
+                products_needed += 8ull * own_blocks * (own_blocks + 1);
+                products_issued += 8ull * blocks * (blocks + 1);
                 quotient = big_sar(big_sign_extend(big_mul_lo_blocked_p<L>(s_c1, big_load_s<L>(lp.N + idx, MM), blocks), 4 * blocks), shift);
             } else {
                 if (zero) continue;
+                products_needed += (unsigned long long)L * (L + 1) / 2;
+                products_issued += (unsigned long long)L * (L + 1) / 2;
                 quotient = big_sar(big_mul_lo(c1, big_load_s<L>(lp.N + idx, MM)), shift);
             }
             if (flip) quotient = big_negate(quotient);
@@ -1538,6 +1549,24 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             if (b != 0) acc = big_add(acc, big_mul_small(big_load_s<L>(N_at(i, k), MM), b));
         }
         big_store(lp.xt + (size_t)i * L, acc);
+    }
+    {   // the word products of the run: one sum per workgroup, one atomic per workgroup
+        __shared__ unsigned long long s_products[2];
+        if (tid == 0) s_products[0] = s_products[1] = 0;
+        __syncthreads();
+        for (int d = WAVE / 2; d > 0; d /= 2) {
+            products_needed += __shfl_xor(products_needed, d);
+            products_issued += __shfl_xor(products_issued, d);
+        }
+        if ((tid & (WAVE - 1)) == 0) {
+            atomicAdd(&s_products[0], products_needed);
+            atomicAdd(&s_products[1], products_issued);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&lp.prof[16], s_products[0]);
+            atomicAdd(&lp.prof[17], s_products[1]);
+        }
     }
     if (leader) {
         lp.out[0] = status;
@@ -1599,8 +1628,9 @@ BigInt big_from_words(const u64* w, int limbs) {  // two's complement words -> s
 void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
                    int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
                    std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
-                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows) {
+                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters) {
     RELP_HIP(hipSetDevice(device));
+    if (counters) counters->clear();
     if (redundant_rows) *redundant_rows = 0;
     const MatrixData& md = form.data;
     const int m = md.nr_rows(), n_p = md.nr_columns();
@@ -1698,7 +1728,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     constexpr int EX_MAX_GRID = 1024;
     double* d_part_key = dalloc<double>(2 * EX_MAX_GRID, owned);
     unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * EX_MAX_GRID, owned);
-    unsigned long long* d_prof = getenv("RELP_EXACT_PROFILE") ? dalloc<unsigned long long>(16, owned) : nullptr;
+    unsigned long long* d_prof = dalloc<unsigned long long>(EX_PROF_WORDS, owned);
+    const bool print_profile = getenv("RELP_EXACT_PROFILE") != nullptr;
     const size_t pairs = (size_t)std::max(1, n - n_art) * m;
     u64* d_price_a = nullptr;   // (sized per limb count below)
     int* d_price_bits = dalloc<int>(pairs, owned);
@@ -1786,7 +1817,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         adopt();
         RELP_HIP(hipMemcpyAsync(d_resume, resume_state, sizeof(resume_state), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
-        if (d_prof) RELP_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream));
+        RELP_HIP(hipMemsetAsync(d_prof, 0, EX_PROF_WORDS * sizeof(unsigned long long), stream));
+        const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
@@ -1823,13 +1855,27 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         int out[16];
         RELP_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipStreamSynchronize(stream));
-        if (d_prof) {
-            unsigned long long prof[16];
+        {
+            unsigned long long prof[EX_PROF_WORDS];
             RELP_HIP(hipMemcpy(prof, d_prof, sizeof(prof), hipMemcpyDeviceToHost));
             static const char* names[] = {"x_B", "pricing pass B", "arg-max + candidates", "exact weights", "tournament", "alpha", "ratio test", "update", "bookkeeping", "pricing pass A"};
-            fprintf(stderr, "[exact] %d limbs, grid %d, %d pivots, candidates %llu:", limbs, grid, out[1] + out[2], prof[12]);
-            for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 2.4e6);
-            fprintf(stderr, "\n");
+            if (print_profile) {
+                fprintf(stderr, "[exact] %d limbs, grid %d, %d pivots, candidates %llu, update word products %.3e needed / %.3e issued:", limbs, grid, out[1] + out[2],
+                        prof[12], (double)prof[16], (double)prof[17]);
+                for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 1e5);
+                fprintf(stderr, "\n");
+            }
+            if (counters) {
+                ExactWidthRecord record;
+                record.limbs = limbs;
+                record.grid = grid;
+                record.pivots_total_at_end = (long long)out[1] + out[2];
+                record.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - width_start).count();
+                for (int k = 0; k < 10; ++k) record.step_seconds[k] = prof[k] * 1e-8;  // ticks of 10 ns
+                record.update_products_needed = (long long)prof[16];
+                record.update_products_issued = (long long)prof[17];
+                counters->push_back(record);
+            }
         }
         *status = out[0];
         *limbs_used = limbs;

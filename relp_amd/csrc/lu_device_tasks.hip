@@ -427,12 +427,15 @@ __global__ void __launch_bounds__(LUT_THREADS) lu_pack_inverse_kernel(DeviceLU l
     const int lane = tid & (WAVE - 1);
     LuInverseWork iw = iw_in;
     const int m = iw.m;
-    if (iw.info[LUF_STATUS] != LUF_OK) {
+    // one read of the status word per workgroup, then a block-uniform branch: another workgroup of this launch may write its own pack
+    // error into the same word when it finishes (the lists are independent; a failed list is repaired by the host fallback the caller
+    // runs on failed_status before anything solves with these records)
+    if (tid == 0) sh.error = iw.info[LUF_STATUS];
+    __syncthreads();
+    if (sh.error != LUF_OK) {
         if (tid == 0 && ctl) ctl->status = failed_status;
         return;
     }
-    if (tid == 0) sh.error = LUF_OK;
-    __syncthreads();
     iw.row_rank += (size_t)blockIdx.x * m;
     iw.row_xoff += (size_t)blockIdx.x * m;
     iw.row_first += (size_t)blockIdx.x * m;

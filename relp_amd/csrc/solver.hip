@@ -1283,8 +1283,8 @@ long long Solver::iterate(long long count, int* stop_reason) {
         pivots_[phase_ - 1] += made;
         if (made > 0) binv_identity_ = false;  // (the phase hand-over must not take the weights of the identity basis)
         if (after.status == ST_NO_ENTERING || after.status == ST_UNBOUNDED) { reason = after.status; break; }
-        if (after.status == ST_REFACTOR) {  // LU carry: should_refactor (or an unstable update) -- BasisInverse::invert on the host
-            refactor_lu(true);
+        if (after.status == ST_REFACTOR) {  // LU carry: should_refactor (or an unstable update) -- BasisInverse::invert
+            refactor_lu(true, /*settle=*/false);  // (the next batch ends in read_ctl)
             continue;
         }
         if (made == 0 && after.status == ST_RUNNING && !fell_back) break;  // defensive: nothing happened
@@ -1533,7 +1533,7 @@ void Solver::lu_identity() {
 // `BasisInverse::invert(basis columns)` (lower_upper/mod.rs:78-92; called by `Carry::change_basis` when `should_refactor`,
 // carry/mod.rs:584-591): Markowitz factorisation of the current basis on the host, one upload, and -- `refresh_vectors` -- x_B,
 // -pi and the objective recomputed from the fresh factors (what the explicit carry's polish does too).
-void Solver::refactor_lu(bool refresh_vectors) {
+void Solver::refactor_lu(bool refresh_vectors, bool settle) {
     if (!device_refactor_) {
         refactor_lu_host(refresh_vectors);
         return;
@@ -1562,6 +1562,10 @@ void Solver::refactor_lu(bool refresh_vectors) {
     refactors_++;
     since_polish_ = 0;
     refactor_seconds_ += now_seconds() - t0;
+    // Kernels that gave up leave ST_REFACTOR_FAILED in the control block and half-written factors behind.  The pivot loop reads the block
+    // after its next batch (whose kernels do nothing under that status); every other caller hands control back to code that may read x_B,
+    // -pi or solve with the factors directly, so the host fallback of read_ctl runs before it does.
+    if (settle) read_ctl();
 }
 void Solver::refactor_lu_host(bool refresh_vectors) {
     const double t0 = now_seconds();
@@ -1725,14 +1729,14 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
 void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
                    int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
                    std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
-                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows);
+                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters);
 void Solver::solve_exact(int first_limbs, int max_limbs, long long max_pivots, int trace_capacity, int* status, int* limbs, long long* p1,
                          long long* p2, std::vector<int>* trace, std::string* objective, std::vector<int>* basis,
                          std::vector<std::pair<int, long long>>* survived, int* redundant_rows) {
     if (!loaded_) throw std::runtime_error("no LP loaded");
     const long long cap = max_pivots > 0 ? max_pivots : 200LL * (d_.m + d_.n) + 100000;
     exact_simplex(form_, opt_.device, stream_, first_limbs, max_limbs, cap, trace_capacity, status, limbs, p1, p2, trace, objective, basis, survived,
-                  redundant_rows);
+                  redundant_rows, &exact_records_);
 }
 void Solver::last_pivot(int* phase, int* column, int* row, int* leaving) {
     const Ctl c = read_ctl();

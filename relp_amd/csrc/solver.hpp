@@ -189,6 +189,17 @@ __device__ __forceinline__ void mark_rho_row(const DeviceLP& lp, int rho_buf, in
 }
 #endif
 
+// One run of the exact fixed-width simplex kernel (exact.hip) at one width: what `relp_get_exact_counters` reports.
+constexpr int EX_PROF_WORDS = 32;
+struct ExactWidthRecord {
+    int limbs = 0, grid = 0;
+    long long pivots_total_at_end = 0;            // pivots of the solve so far when this width stopped (overflow) or finished
+    double seconds = 0.0;                         // host wall time of this width (upload or widening + kernel)
+    double step_seconds[10] = {0};                // the leader's time per step of the loop (x_B, pass B, arg-max, exact weights, tournament, alpha, ratio, update, bookkeeping, pass A)
+    long long update_products_needed = 0;         // 64 x 64 -> 128-bit word products of the update of N: what the entries' bit bounds ask for ...
+    long long update_products_issued = 0;         // ... and what the waves execute (every lane of a wave runs the longest count among its entries)
+};
+
 class Solver {
 public:
     explicit Solver(const relp_options& options);
@@ -216,6 +227,7 @@ public:
     void solve_exact(int first_limbs, int max_limbs, long long max_pivots, int trace_capacity, int* status, int* limbs, long long* p1,
                      long long* p2, std::vector<int>* trace, std::string* objective, std::vector<int>* basis,
                      std::vector<std::pair<int, long long>>* survived, int* redundant_rows = nullptr);
+    const std::vector<ExactWidthRecord>& exact_records() const { return exact_records_; }  // of the last solve_exact, one per width tried
     void last_pivot(int* phase, int* column, int* row, int* leaving);
     double refactor();
     void get_b(double* out);
@@ -264,8 +276,9 @@ private:
     void certify(relp_result* result);
     CertifyScratch certify_scratch_;
     // LU carry (relp_options.carry == RELP_CARRY_LU)
-    void refactor_lu(bool refresh_vectors);  // BasisInverse::invert of the current basis: kernels on the device (lu_factor.hip), or ...
+    void refactor_lu(bool refresh_vectors, bool settle = true);  // BasisInverse::invert of the current basis: kernels on the device (lu_factor.hip), or ...
     void refactor_lu_host(bool refresh_vectors);  // ... host Markowitz + upload (relp_options.lu_refactor; the LU + Forrest-Tomlin carry; the fallback)
+    std::vector<ExactWidthRecord> exact_records_;
     bool device_refactor_ = false;
     long long device_refactor_failures_ = 0;
     void lu_identity();                      // BasisInverse::identity
