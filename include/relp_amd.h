@@ -407,6 +407,13 @@ int32_t relp_profile_kernel(relp_handle* handle, int32_t which, int32_t repetiti
 
 /* Diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of the fused kernel; zeros otherwise. */
 int32_t relp_debug_stamps(relp_handle* handle, uint64_t* out64);
+/* Test hook of the exact simplex's update on the matrix cores (exact.hip, finish_update_entry): `count` numerators as the MFMA tiles
+ * leave them -- `limbs` words each, word-major (word w of entry e at T[w * count + e]), one carry per pair of words
+ * (carry[pair * count + e], added to the pair above), words[e] of them valid (a multiple of 8) -- become the entries of N: carries run
+ * through, sign-extended from 64 * words[e] bits, shifted right by `shift` bits, negated where `flip`; N_out word-major, bits_out the
+ * bit length of each magnitude.  limbs in {16, 32, 64, 128}.  No reference counterpart (tests only). */
+int32_t relp_debug_exact_finish(int32_t device, int32_t limbs, int32_t count, const uint64_t* T, const int32_t* carry, const int32_t* words,
+                                int32_t shift, int32_t flip, uint64_t* N_out, int32_t* bits_out);
 
 /* ---- `BasisInverse` as an object of its own (no LP handle needed) ------------------------------------------------------
  * The reference's trait `BasisInverse` (tableau/inverse_maintenance/carry/mod.rs:69-169) and its main implementor

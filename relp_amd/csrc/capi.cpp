@@ -10,6 +10,10 @@
 #include "presolve.hpp"
 #include "solver.hpp"
 
+namespace relp {
+void exact_finish_entries(int device, int limbs, int count, const unsigned long long* T, const int* carry, const int* words, int shift, int flip,
+                          unsigned long long* N_out, int* bits_out);
+}
 using namespace relp;
 
 struct relp_model {
@@ -960,6 +964,18 @@ int32_t relp_profile_kernel(relp_handle* h, int32_t which, int32_t repetitions, 
     if (!seconds || repetitions < 1 || which < 0 || which > 2) return RELP_ERR_ARGUMENT;
     return guarded(h, [&] { *seconds = h->solver->profile_kernel(which, repetitions); });
 }
+int32_t relp_debug_exact_finish(int32_t device, int32_t limbs, int32_t count, const uint64_t* T, const int32_t* carry, const int32_t* words,
+                                int32_t shift, int32_t flip, uint64_t* N_out, int32_t* bits_out) {
+    if (!T || !carry || !words || !N_out || !bits_out || count < 1 || shift < 0) return RELP_ERR_ARGUMENT;
+    if (limbs != 16 && limbs != 32 && limbs != 64 && limbs != 128) return RELP_ERR_ARGUMENT;
+    try {
+        relp::exact_finish_entries(device, limbs, count, (const unsigned long long*)T, carry, words, shift, flip, (unsigned long long*)N_out, bits_out);
+        return RELP_OK;
+    } catch (const std::exception&) {
+        return RELP_ERR_DEVICE;
+    }
+}
+
 int32_t relp_debug_stamps(relp_handle* h, uint64_t* out64) {
     REQUIRE_LOADED(h);
     if (!out64) return RELP_ERR_ARGUMENT;

@@ -627,6 +627,15 @@ struct ExactLP {
     i64* cb_row;          // [m] cost of the basic column of each row in the current phase (pricing pass B)
     int* row_list;        // [2 m] the rows with alpha~_i != 0, in order, and from [m] on the others (the update of N)
     int* N_bits;          // [m columns][m rows] bit length of |N(i, c)|, kept by whoever writes an entry (the bounds of the passes over N read 4 bytes instead of the integer)
+    // the update of N on the matrix cores (limbs >= 16, see mfma_update_tile): the numerators 2^s N'_ik as the tiles leave them --
+    u64* T;               // [limbs][m columns][m rows] words (each 128-bit pair of an entry summed by one lane) ...
+    int* T_carry;         // [limbs / 2][m columns][m rows] ... and what a pair carries into the next one
+    int* T_words;         // [m columns][m rows] words of the entry that T holds (0: the entry was not touched; reset by the pass that reads T)
+    u64* Tx;              // [limbs][m], Tx_carry [limbs / 2][m], Tx_words [m]: the same for x~_B, the column after the last
+    int* Tx_carry;
+    int* Tx_words;
+    int* xt_bits;         // [m] bit length of |x~_i| (null on the vector path)
+    int mfma_update;      // 1: the update runs on the matrix cores
 };
 
 // out = w * v^2, unsigned, 2 L + 2 limbs: one term of the exact weight gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 of a tied candidate
@@ -904,6 +913,417 @@ __device__ __forceinline__ double price_column_wave(const ExactLP& lp, const Big
         key = cd * cd / sumsq;
     }
     return key;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the update of N on the matrix cores.  2^s N'_ik = (alpha~_p u) N_ik + (-alpha~_i u) N_pk modulo 2^(64 L) is, in the bytes of
+// the integers, a product with Toeplitz matrices: digit d of x * y is sum_k x_k y_(d-k).  For one column k and 16 rows a wave forms
+//     C[digit d][entry e] = sum_k T_A[d][k] E1[k][e] + sum_k T_K[d][k] E2[k][e]
+// with v_mfma_i32_16x16x64_i8: E1 = the bytes of the entries N_ik, E2 = the bytes of the rows' factors -alpha~_i u, T_A[d][k] = byte
+// d - k of alpha~_p u (zero for d < k), T_K the same of N_pk -- the same matrix for every entry (T_A) or for every entry of a column
+// (T_K), so its fragments come out of a few KB of LDS (four copies of the reversed byte string, one per alignment modulo 4).  The
+// instruction multiplies SIGNED bytes: every byte travels as b ^ 0x80 = b - 128 and the identity
+//     sum_k u_k t_k = sum_k (u_k - 128)(t_k - 128) + 128 sum_k (u_k - 128) + 128 sum_k t_k
+// gives the unsigned sum back: the middle term is one more MFMA per block of k against a matrix of ones, the last one a prefix sum of
+// the bytes of alpha~_p u / N_pk (per digit, kept in LDS).  The 16 rows of a tile are mapped to digits so that a lane ends up with 16
+// neighbouring digits of one entry (row 4 G + r of tile t' <-> digit 64 B + 16 G + 4 t' + r): it adds them into two 64-bit words and
+// what they carry on, and a second pass (a thread per entry) runs the carries through, shifts, negates and stores.  All integer,
+// all exact: the sums stay below 2^28 in the 32-bit accumulators.  2.39 P MAC/s of i8 are 37 T word products/s; the multiplier of
+// the vector unit (v_mad_u64_u32, full rate) gives 2.1 T/s to the compiled block products above and the update ran at 0.34
+// (tools/micro/intmul_rates.hip, profiles/r5_micro_intmul_rates.txt).
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int L>
+struct alignas(16) UpdateLds {
+    static constexpr int WB = 8 * L;        // bytes of an integer
+    static constexpr int STRIDE = WB + 64;  // of one copy: index y <-> byte WB - 1 - y of the integer, zeros above
+    int prefix[2][WB];                      // [operand] 128 * sum_{x <= d} byte x      (operand 0: alpha~_p u, 1: N(p, k))
+    unsigned toeplitz[2][4][STRIDE / 4];    // [operand][shift s][..]: byte y of copy s = (byte WB - 1 - (y + s) of the integer) ^ 0x80
+    u64 words[L];                           // N(p, k) on its way in
+    int scan[EX_THREADS / WAVE];
+};
+
+// the LDS image of one Toeplitz operand from its words (in LDS), by the whole workgroup; the caller puts barriers around it
+template <int L>
+__device__ __forceinline__ void build_toeplitz(UpdateLds<L>& lds, int op, const u64* xw) {
+    constexpr int WB = UpdateLds<L>::WB, STRIDE = UpdateLds<L>::STRIDE;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const unsigned char* xb = (const unsigned char*)xw;
+    for (int q = tid; q < STRIDE; q += T) {  // (4 copies of STRIDE / 4 dwords)
+        const int shift = q / (STRIDE / 4), y = 4 * (q - shift * (STRIDE / 4));
+        unsigned v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int index = y + shift + j;
+            const unsigned byte = index < WB ? xb[WB - 1 - index] : 0u;
+            v |= (byte ^ 0x80u) << (8 * j);
+        }
+        lds.toeplitz[op][shift][y / 4] = v;
+    }
+    // 128 * inclusive prefix sums of the bytes: four bytes per thread, a scan over the threads
+    const bool mine = 4 * tid < WB;
+    int s[4] = {0, 0, 0, 0};
+    if (mine) {
+        const unsigned v = ((const unsigned*)xw)[tid];
+        s[0] = v & 255;
+        s[1] = s[0] + ((v >> 8) & 255);
+        s[2] = s[1] + ((v >> 16) & 255);
+        s[3] = s[2] + (v >> 24);
+    }
+    int inclusive = s[3];
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+    for (int d = 1; d < WAVE; d *= 2) {
+        const int other = __shfl_up(inclusive, d);
+        if (lane >= d) inclusive += other;
+    }
+    if (lane == WAVE - 1) lds.scan[wave] = inclusive;
+    __syncthreads();
+    int before = inclusive - s[3];
+    for (int wv = 0; wv < wave; ++wv) before += lds.scan[wv];
+    if (mine) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds.prefix[op][4 * tid + j] = 128 * (before + s[j]);
+    }
+}
+
+// One tile: column k, the rows `row` of the 16 entries (lane & 15 selects the entry; row < 0: none), `terms` = 2 where N(p, k) != 0
+// and the rows have alpha~_i != 0, else 1 (the entry is only rescaled).  `nb64`: 64-byte blocks of the result that are formed (the
+// largest need among the 16 entries).  Writes the words and carries of the numerators to lp.T / lp.T_carry; returns the MFMAs issued.
+// (A function of its own, not inlined: its 128 accumulator registers are allocated apart from the loop's state, which the compiler
+//  otherwise spills around every MFMA; the LDS operands arrive as address-space pointers so that their loads stay ds_read.)
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(3))) int lds_i32;
+struct UpdateTileArgs {
+    const u64* x_part;  // the rows' factors -alpha~_i u, word-major with stride m
+    int m;
+};
+// what a lane reads and writes for its entry: word w of the entry at entry[w * entry_stride], of the numerator at numerator[w * numerator_stride]
+struct UpdateTileEntry {
+    const u64* entry;
+    size_t entry_stride;
+    u64* numerator;
+    int* carry;
+    int* words;
+    size_t numerator_stride;
+};
+template <int L>
+__device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const UpdateTileEntry at_entry, const lds_u32* toeplitz_lds, const lds_i32* prefix_lds, int row,
+                                             bool store, int terms, int nb64, int lane) {
+    constexpr int WB = UpdateLds<L>::WB, STRIDE = UpdateLds<L>::STRIDE;
+    const int m = lp.m;
+    const int g = lane >> 4;                         // k-group of the operands, digit group of the results
+    const int gq = (lane & 15) >> 2, rq = lane & 3;  // this lane's row of the Toeplitz tile: 4 gq + rq
+    const bool have = row >= 0;
+    const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+    int issued = 0;
+    for (int bp = 0; bp < nb64; bp += 8) {  // eight blocks of 64 digits per pass: 32 accumulator tiles
+        v4i acc[8][4];
+#pragma unroll
+        for (int bl = 0; bl < 8; ++bl)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) acc[bl][tq] = v4i{0, 0, 0, 0};
+        const int kb_end = min(nb64, bp + 8);
+        // The steps of the pass are (term, block of 64 bytes of the entries' operand) in order; eight steps' words are in flight at any
+        // time (a ring of registers): with one block requested per step the tile waited for memory at every step.
+        const int steps = terms * kb_end;
+        auto fetch = [&](int step, u64& w0, u64& w1) {
+            const int term = step >= kb_end ? 1 : 0, kb = step - term * kb_end;
+            const u64* src = term == 0 ? at_entry.entry : lp.x_part + (have ? row : 0);
+            const size_t stride = term == 0 ? at_entry.entry_stride : (size_t)m;
+            const bool wanted = have && step < steps;
+            w0 = wanted ? src[(size_t)(8 * kb + 2 * g) * stride] : 0ull;
+            w1 = wanted ? src[(size_t)(8 * kb + 2 * g + 1) * stride] : 0ull;
+        };
+        u64 ring[8][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fetch(j, ring[j][0], ring[j][1]);
+        v4i ones_acc = {0, 0, 0, 0};
+        for (int step0 = 0; step0 < steps; step0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int step = step0 + j;
+                if (step < steps) {
+                    const int term = step >= kb_end ? 1 : 0, kb = step - term * kb_end;
+                    const lds_u32* image = toeplitz_lds + (term * 4 + (3 - rq)) * (STRIDE / 4);  // copy 3 - rq of this term's operand
+                    if (kb == 0) ones_acc = v4i{0, 0, 0, 0};
+                    v4i entries;  // bytes 64 kb + 16 g .. + 15 of this lane's entry, each minus 128
+                    entries[0] = (int)((unsigned)ring[j][0] ^ 0x80808080u);
+                    entries[1] = (int)((unsigned)(ring[j][0] >> 32) ^ 0x80808080u);
+                    entries[2] = (int)((unsigned)ring[j][1] ^ 0x80808080u);
+                    entries[3] = (int)((unsigned)(ring[j][1] >> 32) ^ 0x80808080u);
+                    fetch(step + 8, ring[j][0], ring[j][1]);
+                    ones_acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, entries, ones_acc, 0, 0, 0);
+                    ++issued;
+#pragma unroll
+                    for (int bl = 0; bl < 8; ++bl) {
+                        const int b = bp + bl;
+                        if (b >= kb && b < nb64) {
+                            // row 4 gq + rq of tile tq is digit d = 64 b + 16 gq + 4 tq + rq; its k-th byte is byte d - (64 kb + 16 g + j) of
+                            // the integer = index WB - 1 - d + 64 kb + 16 g + j of the reversed string: a 4-aligned offset in copy 3 - rq
+                            const int base = WB - 16 - 64 * (b - kb) - 16 * (gq - g);
+#pragma unroll
+                            for (int tq = 0; tq < 4; ++tq) {
+                                const lds_u32* at = image + (base + 4 * (3 - tq)) / 4;
+                                const v4i toeplitz = {(int)at[0], (int)at[1], (int)at[2], (int)at[3]};
+                                acc[bl][tq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(toeplitz, entries, acc[bl][tq], 0, 0, 0);
+                            }
+                            issued += 4;
+                            if (b == kb) {  // the block is complete for this term: 128 * (sum of the entry's bytes - 128 each, so far)
+#pragma unroll
+                                for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) acc[bl][tq][r] += 128 * ones_acc[r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // this lane holds digits 64 b + 16 g + (4 tq + r) of entry (lane & 15): two words and a carry per block
+#pragma unroll
+        for (int bl = 0; bl < 8; ++bl) {
+            const int b = bp + bl;
+            if (b < nb64) {
+                i64 quad[4];
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    const lds_i32* pa = prefix_lds + 64 * b + 16 * g + 4 * tq;
+                    v4i digit = acc[bl][tq] + v4i{pa[0], pa[1], pa[2], pa[3]};
+                    if (terms == 2) digit += v4i{pa[WB], pa[WB + 1], pa[WB + 2], pa[WB + 3]};
+                    quad[tq] = (i64)digit[0] + ((i64)digit[1] << 8) + ((i64)digit[2] << 16) + ((i64)digit[3] << 24);
+                }
+                // words: V0 = quad0 + 2^32 quad1, V1 = quad2 + 2^32 quad3 (each below 2^86 in magnitude)
+                const __int128 v0 = (__int128)quad[0] + ((__int128)quad[1] << 32);
+                const __int128 v1 = (__int128)quad[2] + ((__int128)quad[3] << 32) + (v0 >> 64);
+                if (store) {
+                    at_entry.numerator[(size_t)(8 * b + 2 * g) * at_entry.numerator_stride] = (u64)v0;
+                    at_entry.numerator[(size_t)(8 * b + 2 * g + 1) * at_entry.numerator_stride] = (u64)v1;
+                    at_entry.carry[(size_t)(4 * b + g) * at_entry.numerator_stride] = (int)(v1 >> 64);
+                }
+            }
+        }
+    }
+    if (store && g == 0) *at_entry.words = 8 * nb64;
+    return issued;
+}
+
+// The numerator of one entry as the tiles left it (word w at numerator[w * numerator_stride], the carry of pair P at carries[P *
+// numerator_stride]): carries run through the pairs, shifted right by `shift` (sign-extended from its 64 * words bits), negated where
+// `flip`; the L words of the new entry stored at result[w * result_stride], its bit length returned.
+template <int L>
+__device__ __forceinline__ int finish_update_entry(const u64* numerator, const int* carries, size_t numerator_stride, u64* result, size_t result_stride, int words, int shift,
+                                                   bool flip) {
+    const int ws = min(shift >> 6, L), bs = shift & 63;
+    i64 carry = 0;
+    u64 fill = 0;
+    bool negation_carry = true;
+    int top_nonzero = -1, top_not_ones = -1;
+    u64 word_nonzero = 0, word_not_ones = 0;
+    bool zeros_so_far = true, zeros_below_not_ones = true;
+    auto emit = [&](int j, u64 v) {  // word j of the shifted numerator: tracked for the bit length, negated where asked, stored
+        if (v != 0) { top_nonzero = j; word_nonzero = v; }
+        if (v != ~0ull) { top_not_ones = j; word_not_ones = ~v; zeros_below_not_ones = zeros_so_far; }
+        zeros_so_far = zeros_so_far && v == 0;
+        u64 stored = v;
+        if (flip) {
+            stored = ~v + (negation_carry ? 1ull : 0ull);
+            negation_carry = negation_carry && v == 0;
+        }
+        result[(size_t)j * result_stride] = stored;
+    };
+    // eight words and four carries are requested together, then the carries run; word j of the result is word j + ws of the
+    // numerator shifted down by bs bits with the word above it (the sign above the numerator's top)
+    u64 current = 0;
+#pragma unroll 1
+    for (int group = 0; group < L / 8; ++group) {
+        u64 r[8];
+        if (8 * group < words) {
+            u64 w[8];
+            i64 out[4];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) w[t] = numerator[(size_t)(8 * group + t) * numerator_stride];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) out[t] = carries[(size_t)(4 * group + t) * numerator_stride];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u64 r0 = w[2 * t] + (u64)carry;
+                const i64 k0 = carry >= 0 ? (r0 < w[2 * t] ? 1 : 0) : (r0 > w[2 * t] ? -1 : 0);
+                const u64 r1 = w[2 * t + 1] + (u64)k0;
+                const i64 k1 = k0 >= 0 ? (r1 < w[2 * t + 1] ? 1 : 0) : (r1 > w[2 * t + 1] ? -1 : 0);
+                carry = out[t] + k1;
+                r[2 * t] = r0;
+                r[2 * t + 1] = r1;
+            }
+            if (8 * group + 8 >= words) fill = (i64)r[7] < 0 ? ~0ull : 0ull;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) r[t] = fill;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = 8 * group + t - 1 - ws;
+            if (j >= 0) emit(j, bs ? (current >> bs) | (r[t] << (64 - bs)) : current);
+            current = r[t];
+        }
+    }
+    for (int j = max(0, L - 1 - ws); j < L; ++j) {
+        emit(j, bs ? (current >> bs) | (fill << (64 - bs)) : current);
+        current = fill;
+    }
+    // bit length of the magnitude (the same for the value and its negation)
+    if (fill == 0) return top_nonzero < 0 ? 0 : 64 * top_nonzero + (64 - __clzll((long long)word_nonzero));
+    if (top_not_ones < 0) return 1;  // -1
+    int bits = 64 * top_not_ones + (64 - __clzll((long long)word_not_ones));
+    if (zeros_below_not_ones && (word_not_ones & (word_not_ones + 1)) == 0) bits += 1;  // -(2^k): ~v + 1 carries into a new bit
+    return bits;
+}
+
+// The whole update of a pivot on the matrix cores (every workgroup of the cooperative grid calls it): a function of its own so that its
+// registers -- and those its tiles force the caller to save -- are allocated apart from the other steps of the loop (inlined, the
+// pricing passes lost a quarter of their speed to spills).
+struct UpdateScalars {
+    int p, shift, flip, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha;
+};
+template <int L>
+__device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const UpdateScalars sc, const u64* s_c1, unsigned long long& products_needed,
+                                                    unsigned long long& products_issued) {
+    namespace cg = cooperative_groups;
+    cg::grid_group grid = cg::this_grid();
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int G = gridDim.x, block = blockIdx.x;
+    const int gtid = block * T + tid, GT = G * T;
+    const bool leader = block == 0 && tid == 0;
+    const int m = lp.m;
+    const size_t MM = (size_t)m * m;
+    auto N_at = [&](int i, int c) { return lp.N + (size_t)c * m + i; };
+    const int p = sc.p, shift = sc.shift, ap_bits = sc.ap_bits, D_bits = sc.D_bits, xp_bits = sc.xp_bits, n_heavy = sc.n_heavy, n_rows_alpha = sc.n_rows_alpha;
+    const bool flip = sc.flip != 0;
+        // ---- the update on the matrix cores (see mfma_update_tile): tiles of 16 entries of a column, a wave each ----
+        __shared__ UpdateLds<L> s_update;
+        const int lane = tid & (WAVE - 1), wave = tid / WAVE, waves = T / WAVE;
+        const int e16 = lane & 15;
+        int issued = 0;
+        const UpdateTileArgs tile_args{lp.x_part, m};
+        const lds_u32* toeplitz_lds = (const lds_u32*)&s_update.toeplitz[0][0][0];
+        const lds_i32* prefix_lds = (const lds_i32*)&s_update.prefix[0][0];
+        __syncthreads();
+        build_toeplitz<L>(s_update, 0, s_c1);  // alpha~_p u: the same operand for every entry of N
+        __syncthreads();
+        unsigned long long t_sub = wall_clock64();
+        auto substamp = [&](int slot) {  // (diagnostic: the leader's time inside the update: [20] both-term tiles, [21] rescaled tiles, [22] barrier, [23] second pass)
+            if (leader) {
+                const unsigned long long t = wall_clock64();
+                lp.prof[slot] += t - t_sub;
+                t_sub = t;
+            }
+        };
+        // the need of an entry, in 64-byte blocks of the numerator (the fit test's bound, as the vector path's `blocks`)
+        auto blocks64 = [&](int needed_bits) { return min(L / 8, max(1, (needed_bits + 511) / 512)); };
+        auto wave_max = [&](int v) {
+            for (int d = 1; d < WAVE; d *= 2) v = max(v, __shfl_xor(v, d));
+            return v;
+        };
+        // (a) N(p, k) != 0 and alpha~_i != 0: both terms.  A workgroup takes a run of tiles, column after column, and keeps the
+        //     column's N(p, k) as the second Toeplitz operand in LDS while its four waves work through the column's tiles.
+        {
+            // (x~_B is one more column of N -- x~'_i = (alpha~_p x~_i - alpha~_i x~_p) / D, every row but p -- and is taken here as the
+            //  column after the last: a thread per row with two whole products of its own was 2 ms at the end of every pivot at 128 limbs)
+            const int tiles_per_column = (n_rows_alpha + 15) / 16, tiles_of_x = (m + 15) / 16;
+            const long long total_N = (long long)n_heavy * tiles_per_column, total = total_N + tiles_of_x;
+            const long long per_block = (total + G - 1) / G;
+            long long u = min(total, (long long)block * per_block);
+            const long long u_end = min(total, u + per_block);
+            while (u < u_end) {
+                const bool x_column = u >= total_N;
+                const int kk = x_column ? n_heavy : (int)(u / tiles_per_column);
+                const int k = x_column ? -1 : lp.bracket[kk];
+                const long long column_first = (long long)kk * tiles_per_column;
+                const long long column_end = x_column ? u_end : min(u_end, column_first + tiles_per_column);
+                __syncthreads();  // (the previous column's tiles are done with the image)
+                for (int w = tid; w < L; w += T) s_update.words[w] = x_column ? lp.xt[(size_t)p * L + w] : N_at(p, k)[(size_t)w * MM];
+                __syncthreads();
+                build_toeplitz<L>(s_update, 1, s_update.words);
+                __syncthreads();
+                const int npk_bits = x_column ? xp_bits : lp.N_bits[(size_t)k * m + p];
+                for (long long t = u + wave; t < column_end; t += waves) {
+                    const int first = 16 * (int)(t - column_first);
+                    int row;
+                    if (x_column) row = first + e16 < m ? first + e16 : -1;
+                    else row = first + e16 < n_rows_alpha ? lp.row_list[first + e16] : -1;
+                    const bool store = row >= 0 && row != p;
+                    int nb = 1;
+                    UpdateTileEntry at_entry{lp.N, MM, lp.T, lp.T_carry, lp.T_words, MM};
+                    if (store) {
+                        const size_t idx = x_column ? (size_t)row : (size_t)k * m + row;
+                        const int entry_bits = x_column ? lp.xt_bits[row] : lp.N_bits[idx];
+                        const int needed = max(ap_bits + entry_bits, lp.x_bits[row] + npk_bits) + 1 - (D_bits - 1) + shift + 2;
+                        nb = blocks64(needed);
+                        if (lane < 16) {
+                            const int blocks = min(L / 4, max(1, (needed + 255) / 256));
+                            products_needed += 16ull * blocks * (blocks + 1);
+                        }
+                        if (x_column) at_entry = UpdateTileEntry{lp.xt + idx * L, 1, lp.Tx + idx, lp.Tx_carry + idx, lp.Tx_words + idx, (size_t)m};
+                        else at_entry = UpdateTileEntry{lp.N + idx, MM, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                    }
+                    nb = wave_max(nb);
+                    issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 2, nb, lane);
+                }
+                u = column_end;
+            }
+        }
+        substamp(20);
+        // (b) the entries that are only rescaled: the rows with alpha~_i = 0 of those columns, then every row of the other columns
+        {
+            const int rest_rows = m - n_rows_alpha;
+            const int tiles_a = (rest_rows + 15) / 16, tiles_b = (m + 15) / 16;
+            const long long total_a = (long long)n_heavy * tiles_a, total_b = (long long)(m - n_heavy) * tiles_b;
+            for (long long t = (long long)block * waves + wave; t < total_a + total_b; t += (long long)G * waves) {
+                int k, row;
+                if (t < total_a) {
+                    const int kk = (int)(t / tiles_a), first = 16 * (int)(t - (long long)kk * tiles_a);
+                    k = lp.bracket[kk];
+                    row = first + e16 < rest_rows ? lp.row_list[m + first + e16] : -1;
+                } else {
+                    const long long rest = t - total_a;
+                    const int kk = (int)(rest / tiles_b), first = 16 * (int)(rest - (long long)kk * tiles_b);
+                    k = lp.cand[kk];
+                    row = first + e16 < m ? first + e16 : -1;
+                }
+                const int entry_bits = row >= 0 ? lp.N_bits[(size_t)k * m + row] : 0;
+                const bool store = row >= 0 && row != p && entry_bits != 0;  // (a zero stays a zero)
+                int nb = 0;
+                if (store) {
+                    const int needed = ap_bits + entry_bits + 1 - (D_bits - 1) + shift + 2;
+                    nb = blocks64(needed);
+                    if (lane < 16) {
+                        const int blocks = min(L / 4, max(1, (needed + 255) / 256));
+                        products_needed += 8ull * blocks * (blocks + 1);
+                    }
+                }
+                nb = wave_max(nb);
+                if (nb == 0) continue;  // sixteen zeros
+                const size_t idx = (size_t)k * m + (row >= 0 ? row : 0);
+                const UpdateTileEntry at_entry{lp.N + idx, MM, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 1, nb, lane);
+            }
+        }
+        if (lane == 0) products_issued += 256ull * issued;  // an MFMA is 16 x 16 x 64 byte products = 256 word products
+        substamp(21);
+        grid.sync();  // every numerator is in lp.T
+        substamp(22);
+        for (size_t idx = gtid; idx < MM; idx += GT) {
+            const int words = lp.T_words[idx];
+            if (words == 0) continue;
+            lp.T_words[idx] = 0;
+            lp.N_bits[idx] = finish_update_entry<L>(lp.T + idx, lp.T_carry + idx, MM, lp.N + idx, MM, words, shift, flip);
+        }
+        for (int i = gtid; i < m; i += GT) {
+            const int words = lp.Tx_words[i];
+            if (words == 0) continue;
+            lp.Tx_words[i] = 0;
+            (void)finish_update_entry<L>(lp.Tx + i, lp.Tx_carry + i, (size_t)m, lp.xt + (size_t)i * L, 1, words, shift, flip);
+        }
+        substamp(23);
 }
 
 // The loop on the WHOLE grid (round 3; round 2 ran it in one workgroup: E226 took 100 s for 342 pivots on 2048-bit integers while
@@ -1381,13 +1801,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const int estimate = max(ap_bits + lp.N_bits[idx], lp.x_bits[i] + lp.N_bits[(size_t)k * m + p]) + 1 - (D_bits - 1);
             if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
         }
-        {
-            const int xp_bits = big_bits(big_load<L>(lp.xt + (size_t)p * L));
-            for (int i = gtid; i < m; i += GT) {
-                if (i == p) continue;
-                const int estimate = max(ap_bits + big_bits(big_load<L>(lp.xt + (size_t)i * L)), lp.x_bits[i] + xp_bits) + 1 - (D_bits - 1);
-                if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
-            }
+        const int xp_bits = big_bits(big_load<L>(lp.xt + (size_t)p * L));
+        for (int i = gtid; i < m; i += GT) {
+            if (i == p) continue;
+            const int xi_bits = big_bits(big_load<L>(lp.xt + (size_t)i * L));
+            if (lp.xt_bits) lp.xt_bits[i] = xi_bits;  // (the update on the matrix cores sizes x~_B's tiles by it)
+            const int estimate = max(ap_bits + xi_bits, lp.x_bits[i] + xp_bits) + 1 - (D_bits - 1);
+            if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
         }
         // The entries of N by what they cost below.  N'_ik = (alpha~_p N_ik - alpha~_i N_pk) / D: two products where N(p, k) != 0 AND
         // alpha~_i != 0, one (the entry is only rescaled) where either is zero, nothing where N_ik is zero as well.  Columns and rows
@@ -1433,6 +1853,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         const int n_heavy = word[7], n_rows_alpha = word[6];
+        bool on_matrix_cores = false;
+        if constexpr (L >= 16) on_matrix_cores = lp.mfma_update != 0;
+        if constexpr (L >= 16) if (on_matrix_cores) {
+            const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha};
+            update_on_matrix_cores<L>(lp, scalars, s_c1, products_needed, products_issued);
+        }
+        if (!on_matrix_cores)
         for (long long unit = gtid; unit < (long long)n_heavy * n_rows_alpha; unit += GT) {  // N(p, k) != 0 and alpha~_i != 0: two products
             const int kk = (int)(unit / n_rows_alpha), i = lp.row_list[(int)(unit - (long long)kk * n_rows_alpha)];
             if (i == p) continue;
@@ -1465,6 +1892,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         // ... and the entries that are only rescaled: the rows with alpha~_i = 0 of those columns, then every row of the other columns
         const long long rescaled_a = (long long)n_heavy * (m - n_rows_alpha), rescaled_b = (long long)(m - n_heavy) * m;
+        if (!on_matrix_cores)
         for (long long unit = gtid; unit < rescaled_a + rescaled_b; unit += GT) {
             int k, i;
             if (unit < rescaled_a) {
@@ -1501,7 +1929,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             big_store_s(lp.N + idx, MM, quotient);
             lp.N_bits[idx] = big_bits(quotient);
         }
-        {   // x~_B = N b is one more column of N: x~'_i = (alpha~_p x~_i - alpha~_i x~_p) / D, row p stays
+        if (!on_matrix_cores) {   // x~_B = N b is one more column of N: x~'_i = (alpha~_p x~_i - alpha~_i x~_p) / D, row p stays
             const Big<L> xp = big_load<L>(lp.xt + (size_t)p * L);
             for (int i = gtid; i < m; i += GT) {
                 if (i == p) continue;
@@ -1621,6 +2049,12 @@ BigInt big_from_words(const u64* w, int limbs) {  // two's complement words -> s
     return r;
 }
 
+// finish_update_entry on `count` entries given as they would leave the tiles (tests: carries, shifts of 64 bits and more, negation, bit lengths)
+template <int L>
+__global__ void __launch_bounds__(256) exact_finish_test_kernel(ExactLP lp, int count, const int* words, int shift, int flip, int* bits) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) bits[e] = finish_update_entry<L>(lp.T + e, lp.T_carry + e, (size_t)count, lp.N + e, (size_t)count, words[e], shift, flip != 0);
+}
 }  // namespace
 
 // Host driver: scales the LP to integers, runs the kernel with 2, 4, ... limbs until it does not overflow.
@@ -1628,7 +2062,7 @@ BigInt big_from_words(const u64* w, int limbs) {  // two's complement words -> s
 void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
                    int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
                    std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
-                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters) {
+                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters, int update_mode) {
     RELP_HIP(hipSetDevice(device));
     if (counters) counters->clear();
     if (redundant_rows) *redundant_rows = 0;
@@ -1779,6 +2213,19 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), fresh);
         u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
+        // the update of N on the matrix cores (mfma_update_tile): from 32 limbs on by itself; 16 limbs where asked for
+        const bool mfma_update = limbs >= 16 && update_mode != 1 && (update_mode == 2 || limbs >= 32);
+        u64* d_T = mfma_update ? dalloc<u64>((size_t)m * m * big, fresh) : nullptr;
+        int* d_T_carry = mfma_update ? dalloc<int>((size_t)m * m * (big / 2), fresh) : nullptr;
+        int* d_T_words = mfma_update ? dalloc<int>((size_t)m * m, fresh) : nullptr;
+        u64* d_Tx = mfma_update ? dalloc<u64>((size_t)m * big, fresh) : nullptr;
+        int* d_Tx_carry = mfma_update ? dalloc<int>((size_t)m * (big / 2), fresh) : nullptr;
+        int* d_Tx_words = mfma_update ? dalloc<int>((size_t)m, fresh) : nullptr;
+        int* d_xt_bits = mfma_update ? dalloc<int>((size_t)m, fresh) : nullptr;
+        if (mfma_update) {
+            RELP_HIP(hipMemsetAsync(d_T_words, 0, (size_t)m * m * sizeof(int), stream));
+            RELP_HIP(hipMemsetAsync(d_Tx_words, 0, (size_t)m * sizeof(int), stream));
+        }
         auto adopt = [&]() {  // the new width's buffers replace the previous width's
             RELP_HIP(hipStreamSynchronize(stream));
             for (void* q : width_owned) (void)hipFree(q);
@@ -1820,7 +2267,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemsetAsync(d_prof, 0, EX_PROF_WORDS * sizeof(unsigned long long), stream));
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits};
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
+                   d_T, d_T_carry, d_T_words, d_Tx, d_Tx_carry, d_Tx_words, d_xt_bits, mfma_update ? 1 : 0};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
@@ -1863,7 +2311,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                 fprintf(stderr, "[exact] %d limbs, grid %d, %d pivots, candidates %llu, update word products %.3e needed / %.3e issued:", limbs, grid, out[1] + out[2],
                         prof[12], (double)prof[16], (double)prof[17]);
                 for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 1e5);
-                fprintf(stderr, "\n");
+                fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f\n", prof[20] / 1e5, prof[21] / 1e5, prof[22] / 1e5, prof[23] / 1e5);
             }
             if (counters) {
                 ExactWidthRecord record;
@@ -1928,6 +2376,48 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         }
         return;
     }
+}
+
+// `finish_update_entry` by itself: count entries, word-major operands as lp.T / lp.T_carry hold them (entry stride = count)
+void exact_finish_entries(int device, int limbs, int count, const unsigned long long* T, const int* carry, const int* words, int shift, int flip,
+                          unsigned long long* N_out, int* bits_out) {
+    RELP_HIP(hipSetDevice(device));
+    std::vector<void*> owned;
+    struct Free {
+        std::vector<void*>& p;
+        ~Free() { for (void* q : p) (void)hipFree(q); }
+    } free_all{owned};
+    auto dalloc_bytes = [&](size_t bytes) {
+        void* p = nullptr;
+        RELP_HIP(hipMalloc(&p, std::max<size_t>(bytes, 8)));
+        owned.push_back(p);
+        return p;
+    };
+    const size_t entries = (size_t)count;
+    u64* d_T = (u64*)dalloc_bytes(entries * limbs * sizeof(u64));
+    int* d_carry = (int*)dalloc_bytes(entries * (limbs / 2) * sizeof(int));
+    int* d_words = (int*)dalloc_bytes(entries * sizeof(int));
+    u64* d_N = (u64*)dalloc_bytes(entries * limbs * sizeof(u64));
+    int* d_bits = (int*)dalloc_bytes(entries * sizeof(int));
+    RELP_HIP(hipMemcpy(d_T, T, entries * limbs * sizeof(u64), hipMemcpyHostToDevice));
+    RELP_HIP(hipMemcpy(d_carry, carry, entries * (limbs / 2) * sizeof(int), hipMemcpyHostToDevice));
+    RELP_HIP(hipMemcpy(d_words, words, entries * sizeof(int), hipMemcpyHostToDevice));
+    ExactLP lp{};
+    lp.N = d_N;
+    lp.T = d_T;
+    lp.T_carry = d_carry;
+    const dim3 grid((count + 255) / 256), block(256);
+    switch (limbs) {
+        case 16: hipLaunchKernelGGL(exact_finish_test_kernel<16>, grid, block, 0, 0, lp, count, d_words, shift, flip, d_bits); break;
+        case 32: hipLaunchKernelGGL(exact_finish_test_kernel<32>, grid, block, 0, 0, lp, count, d_words, shift, flip, d_bits); break;
+        case 64: hipLaunchKernelGGL(exact_finish_test_kernel<64>, grid, block, 0, 0, lp, count, d_words, shift, flip, d_bits); break;
+        case 128: hipLaunchKernelGGL(exact_finish_test_kernel<128>, grid, block, 0, 0, lp, count, d_words, shift, flip, d_bits); break;
+        default: throw std::invalid_argument("limbs must be 16, 32, 64 or 128");
+    }
+    RELP_HIP(hipGetLastError());
+    RELP_HIP(hipDeviceSynchronize());
+    RELP_HIP(hipMemcpy(N_out, d_N, entries * limbs * sizeof(u64), hipMemcpyDeviceToHost));
+    RELP_HIP(hipMemcpy(bits_out, d_bits, entries * sizeof(int), hipMemcpyDeviceToHost));
 }
 
 }  // namespace relp

@@ -1729,14 +1729,14 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
 void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
                    int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
                    std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
-                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters);
+                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters, int update_mode);
 void Solver::solve_exact(int first_limbs, int max_limbs, long long max_pivots, int trace_capacity, int* status, int* limbs, long long* p1,
                          long long* p2, std::vector<int>* trace, std::string* objective, std::vector<int>* basis,
                          std::vector<std::pair<int, long long>>* survived, int* redundant_rows) {
     if (!loaded_) throw std::runtime_error("no LP loaded");
     const long long cap = max_pivots > 0 ? max_pivots : 200LL * (d_.m + d_.n) + 100000;
     exact_simplex(form_, opt_.device, stream_, first_limbs, max_limbs, cap, trace_capacity, status, limbs, p1, p2, trace, objective, basis, survived,
-                  redundant_rows, &exact_records_);
+                  redundant_rows, &exact_records_, getenv("RELP_EXACT_UPDATE") ? atoi(getenv("RELP_EXACT_UPDATE")) : 0);
 }
 void Solver::last_pivot(int* phase, int* column, int* row, int* leaving) {
     const Ctl c = read_ctl();

@@ -1,0 +1,123 @@
+"""The exact simplex's update of N on the matrix cores (round 5, relp_amd/csrc/exact.hip): the pass that turns what the MFMA tiles leave
+(pairs of words plus a carry per pair) into the entries of N, checked against Python integers -- carries of both signs that ripple
+through words and pairs, shifts of 64 bits and more, negation, the bit length of every magnitude (zero, -1, -(2^k) included).  The
+tiles themselves are pinned end to end by the golden pivot sequences (tests/test_gpu_exact.py runs on the matrix cores from 32 limbs on,
+and from 16 limbs under RELP_EXACT_UPDATE=2: test_whole_traces_on_the_matrix_cores_from_sixteen_limbs below)."""
+import ctypes as C
+import json
+import os
+import random
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import relp_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def decompose(value, words, rng, ripple):
+    """`value` (signed, fits 64 * words bits) as the tiles would leave it: unsigned 128-bit pairs X_P and carries c_P with
+    sum_P (X_P + c_(P-1)) 2^(128 P) == value modulo 2^(64 words), built pair by pair with random carries."""
+    modulus = 1 << (64 * words)
+    digits = [(value % modulus >> (128 * p)) & ((1 << 128) - 1) for p in range(words // 2)]
+    pairs, carries, carry_in = [], [], 0
+    for p, digit in enumerate(digits):
+        x = (digit - carry_in) % (1 << 128)
+        ripple_out = (x + carry_in) >> 128  # floor: -1, 0 or 1
+        assert (x + carry_in) % (1 << 128) == digit and ripple_out in (-1, 0, 1)
+        stored = rng.choice([0, 1, -1, rng.randrange(-(1 << 20), 1 << 20)]) if ripple else rng.randrange(-(1 << 20), 1 << 20)
+        pairs.append(x)
+        carries.append(stored)
+        carry_in = stored + ripple_out
+    return pairs, carries
+
+
+def run_finish(limbs, values, words, shift, flip, rng, ripple):
+    count = len(values)
+    T = np.zeros((limbs, count), dtype=np.uint64)
+    carry = np.zeros((limbs // 2, count), dtype=np.int32)
+    for e, (value, w) in enumerate(zip(values, words)):
+        pairs, carries = decompose(value, w, rng, ripple)
+        for p, (x, c) in enumerate(zip(pairs, carries)):
+            T[2 * p, e] = x & ((1 << 64) - 1)
+            T[2 * p + 1, e] = x >> 64
+            carry[p, e] = c
+        # words above the valid ones hold whatever an earlier, wider numerator left there
+        for k in range(w, limbs):
+            T[k, e] = rng.getrandbits(64)
+        for p in range(w // 2, limbs // 2):
+            carry[p, e] = rng.randrange(-5, 5)
+    words_arr = np.array(words, dtype=np.int32)
+    N = np.zeros((limbs, count), dtype=np.uint64)
+    bits = np.zeros(count, dtype=np.int32)
+    status = relp_amd.lib().relp_debug_exact_finish(0, limbs, count, T.ctypes.data_as(C.POINTER(C.c_uint64)), carry.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    words_arr.ctypes.data_as(C.POINTER(C.c_int32)), shift, int(flip),
+                                                    N.ctypes.data_as(C.POINTER(C.c_uint64)), bits.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert status == 0
+    out = []
+    for e in range(count):
+        v = sum(int(N[k, e]) << (64 * k) for k in range(limbs))
+        if v >> (64 * limbs - 1):
+            v -= 1 << (64 * limbs)
+        out.append(v)
+    return out, [int(b) for b in bits]
+
+
+@pytest.mark.parametrize("limbs", [16, 32, 64, 128])
+@pytest.mark.parametrize("shift", [0, 1, 7, 63, 64, 65, 130, 200])
+@pytest.mark.parametrize("flip", [False, True])
+def test_finish_pass_against_python_integers(limbs, shift, flip):
+    rng = random.Random(1000 * limbs + 10 * shift + int(flip))
+    values, words = [], []
+    special = [0, -1, 1, -(1 << 64), 1 << 64, -(1 << 63), (1 << 63), -(1 << 127), (1 << 128) - 1, -(1 << 128), (1 << 200), -(1 << 200) + 1, -(1 << 255)]
+    for trial in range(400):
+        w = 8 * rng.randrange(1, limbs // 8 + 1)
+        if trial < len(special) * 2:
+            value = special[trial // 2] << (shift if trial % 2 else 0)
+            if not -(1 << (64 * w - 1)) <= value < (1 << (64 * w - 1)):
+                value = special[trial // 2]
+                w = max(w, 8 * ((value.bit_length() + 1 + 511) // 512))
+                if w > limbs:
+                    value, w = 0, 8
+        else:
+            bits = rng.randrange(1, 64 * w - 1)
+            value = rng.getrandbits(bits) * rng.choice([1, -1])
+            if rng.random() < 0.3:  # long runs of zeros / ones: carries that travel
+                value = (value >> (bits // 2)) << (bits // 2)
+            if rng.random() < 0.2:
+                value = -(1 << rng.randrange(0, 64 * w - 1))
+        values.append(value)
+        words.append(w)
+    for ripple in (False, True):
+        got, bits = run_finish(limbs, values, words, shift, flip, rng, ripple)
+        for value, g, b in zip(values, got, bits):
+            expected = value >> shift  # floor = arithmetic shift
+            if flip:
+                expected = -expected
+            assert g == expected, (value, shift, flip)
+            assert b == abs(expected).bit_length(), (value, shift, flip, b)
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("name", ["BLEND", "ISRAEL", "STOCFOR1", "E226"])
+def test_whole_traces_on_the_matrix_cores_from_sixteen_limbs(name, monkeypatch):
+    """The same golden pivot sequences with the update on the matrix cores from the first width that has them (16 limbs) and with the
+    vector path only: identical traces, pivot counts, final bases and optima."""
+    golden = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    results = []
+    for mode in ("2", "1"):
+        monkeypatch.setenv("RELP_EXACT_UPDATE", mode)
+        solver = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+        got = solver.solve_exact(first_limbs=4, max_limbs=64)
+        counters = solver.exact_counters()
+        solver.close()
+        assert got["status"] == 1 and Fraction(got["objective"]) == Fraction(golden["objective"])
+        assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"])
+        results.append((got["trace"], list(got["basis"]), got["objective"]))
+        assert counters and counters[-1]["update_word_products_issued"] > 0
+    assert results[0] == results[1]
