@@ -634,7 +634,7 @@ struct ExactLP {
     u64* Tx;              // [limbs][m], Tx_carry [limbs / 2][m], Tx_words [m]: the same for x~_B, the column after the last
     int* Tx_carry;
     int* Tx_words;
-    int* xt_bits;         // [m] bit length of |x~_i| (null on the vector path)
+    int* xt_bits;         // [m] bit length of |x~_i|, kept by whoever writes an entry
     int mfma_update;      // 1: the update runs on the matrix cores
 };
 
@@ -820,7 +820,7 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
 // Pricing pass B for one column, by one wave (see the call site): c~_j word by word into ctil, its key estimate returned (0: not a
 // candidate).
 template <int L>
-__device__ __forceinline__ double price_column_wave(const ExactLP& lp, const Big<L>& D, int j, int phase, int lane, double mD, int eD, int D_bits,
+__device__ __forceinline__ double price_column_wave(const ExactLP& lp, const u64* D, int j, int phase, int lane, double mD, int eD, int D_bits,
                                                   size_t PP, int* bits_bound) {
     const int m = lp.m;
     const int jj = j - lp.n_art;
@@ -889,7 +889,7 @@ __device__ __forceinline__ double price_column_wave(const ExactLP& lp, const Big
         const u128 total = carry_sum + lo + ((u128)hi << 32);
         const u64 sum_word = (u64)total;  // word k of sum_i c_B(i) (N a_j)_i
         carry_sum = total >> 64;
-        const u128 multiple = (u128)D.w[k] * cj_mag + carry_x;  // word k of |c_j| D
+        const u128 multiple = (u128)D[k] * cj_mag + carry_x;  // word k of |c_j| D
         const u64 x_word = (u64)multiple;
         carry_x = (u64)(multiple >> 64);
         u64 word;
@@ -1321,7 +1321,7 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             const int words = lp.Tx_words[i];
             if (words == 0) continue;
             lp.Tx_words[i] = 0;
-            (void)finish_update_entry<L>(lp.Tx + i, lp.Tx_carry + i, (size_t)m, lp.xt + (size_t)i * L, 1, words, shift, flip);
+            lp.xt_bits[i] = finish_update_entry<L>(lp.Tx + i, lp.Tx_carry + i, (size_t)m, lp.xt + (size_t)i * L, 1, words, shift, flip);
         }
         substamp(23);
 }
@@ -1350,7 +1350,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ u64 s_words[3][L];  // operands and scratch of the workgroup's word-array arithmetic
     __shared__ u64 s_part[3 * L];  // ... the columns of its products (block_mul_lo)
     static_assert(L <= EX_THREADS, "a thread per output word");
-    __shared__ int s_shift;
+    __shared__ int s_shift, s_D_bits, s_eD, s_ap_bits, s_flip;
+    __shared__ double s_mD;
     const int tid = threadIdx.x, T = blockDim.x;
     const int G = gridDim.x, block = blockIdx.x;
     const int gtid = block * T + tid, GT = G * T;
@@ -1375,6 +1376,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     };
     unsigned long long products_needed = 0, products_issued = 0;  // this thread's word products in the update of N, whole run
+    bool on_matrix_cores = false;  // the update of N by mfma_update_tile
+    if constexpr (L >= 16) on_matrix_cores = lp.mfma_update != 0;
     int parity = 0;  // the partial arrays of the grid reductions alternate, so that a fast workgroup never overwrites what a slow one still reads
     if (tid == 0) s_overflow = 0;
     __syncthreads();
@@ -1435,23 +1438,39 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         at_phase = phase;
         at_drive_row = drive_row;
         at_removed = n_removed;
-        const Big<L> D = big_load<L>(gD);
-        const int D_bits = big_bits(D);
+        // (From 16 limbs on no thread holds a copy of D, of 1 / D_odd, of alpha~_p or of alpha~_p u: an integer is 128 to 1024 bytes of
+        //  scratch memory per thread, 134 MB a copy over the grid at 128 limbs -- four of them cost 25FV47 0.4 ms of every pivot.  One
+        //  thread of the workgroup reads what is needed of them into LDS; the words of D are read from memory where they are used.)
+        Big<L> D;
+        int D_bits = 0;
+        if constexpr (L < 16) {
+            D = big_load<L>(gD);
+            D_bits = big_bits(D);
+        }
         // 1 / D_odd modulo 2^(64 L) (D = 2^shift D_odd): every exact quotient of this turn is a truncated product with it.  Every
         // workgroup for itself: cheap, and no exchange is needed this way.
         if (tid == 0) {
-            const int shift = big_ctz(D);
-            const Big<L> odd = big_sar(D, shift);
+            const Big<L> D0 = big_load<L>(gD);
+            const int shift = big_ctz(D0);
+            const Big<L> odd = big_sar(D0, shift);
 #pragma unroll L <= 8 ? L : 1
             for (int k = 0; k < L; ++k) s_words[0][k] = odd.w[k];
             s_shift = shift;
+            s_D_bits = big_bits(D0);
+            int exponent = 0;
+            s_mD = big_mantissa(D0, &exponent);
+            s_eD = exponent;
         }
         __syncthreads();
+        if constexpr (L >= 16) D_bits = s_D_bits;
+        const u64* Dw = gD;  // the words of D for whoever streams them
         block_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2], s_part);
         const int shift = s_shift;
         Big<L> Dinv;
+        if constexpr (L < 16) {
 #pragma unroll L <= 8 ? L : 1
-        for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
+            for (int k = 0; k < L; ++k) Dinv.w[k] = s_dinv[k];
+        }
         // ---- x~_B = N b: a thread per (row, chunk of 32 columns), then a thread per row over its chunks (same bounds as the serial loop).
         //      Only on the first turn of a run: a pivot updates x~_B like one more column of N (below) -- recomputing it was 15 % of E226. ----
         if (!have_xb) {
@@ -1482,6 +1501,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 }
                 flag_overflow(widest + log2_ceil(m));
                 big_store(lp.xt + (size_t)i * L, acc);
+                lp.xt_bits[i] = big_bits(acc);
             }
         }
         int q = -1, p = -1;
@@ -1500,8 +1520,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             //  multiples run in two carry-save accumulators, their difference is stored as it appears, and nothing is held but the
             //  carries.  The bit bound comes from N_bits, the double from the two leading words gathered on the way: same numbers.)
             for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];  // (read after pass A's barrier)
-            int eD = 0;
-            const double mD = big_mantissa(D, &eD);
+            const int eD = s_eD;
+            const double mD = s_mD;
             const int row_blocks = (m + WAVE - 1) / WAVE;
             const int lane = tid & (WAVE - 1);
             for (long long item = gtid / WAVE; item < (long long)n_priced * row_blocks; item += GT / WAVE) {
@@ -1534,7 +1554,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 double key = 0.0;
                 if (lp.pos[j] < 0) {  // (the whole wave)
                     int widest = 0;
-                    key = price_column_wave<L>(lp, D, j, phase, lane, mD, eD, D_bits, PP, &widest);
+                    key = price_column_wave<L>(lp, Dw, j, phase, lane, mD, eD, D_bits, PP, &widest);
                     if (lane == 0) flag_overflow(widest + log2_ceil(m + 1));
                 }
                 if (lane == 0) lp.key[j] = key;
@@ -1573,7 +1593,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                         const int c = (int)(pair / (m + 1)), i = (int)(pair - (long long)c * (m + 1));
                         const int j = lp.cand[c];
                         u64* out = lp.gamma_terms + ((size_t)c * (m + 1) + i) * GW;
-                        if (i == m) weighted_square<L>(D, (u64)lp.weight[j], out);
+                        if (i == m) weighted_square<L>(big_load<L>(gD), (u64)lp.weight[j], out);
                         else weighted_square<L>(big_load_s<L>(lp.price_a + (size_t)(j - lp.n_art) * m + i, PP), (u64)lp.weight[lp.basis[i]], out);
                     }
                     grid.sync();
@@ -1776,22 +1796,26 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         stamp(6);
         // ---- the pivot: D' = alpha~_p, N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays ---------------------------
-        Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
-        const bool flip = big_neg(ap);  // (only a zero-level pivot can have a negative pivot element): keep D > 0
+        if (tid == 0) {
+            const Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
+#pragma unroll L <= 8 ? L : 1
+            for (int k = 0; k < L; ++k) s_words[0][k] = ap.w[k];
+            s_ap_bits = big_bits(ap);
+            s_flip = big_neg(ap) ? 1 : 0;
+        }
+        __syncthreads();
+        const bool flip = s_flip != 0;  // (only a zero-level pivot can have a negative pivot element): keep D > 0
+        const int ap_bits = s_ap_bits;
         // With D = 2^s D_odd and u = 1 / D_odd modulo 2^(64 L):  (alpha~_p u) N_ik - (alpha~_i u) N_pk = 2^s N'_ik modulo 2^(64 L), so the
         // new entry is that value shifted right by s -- known modulo 2^(64 L - s), sign-extended from there, and it must fit there.
         // TWO truncated products per entry (the numerator first and then its product with u were three); alpha~_p u once per
         // workgroup, alpha~_i u once per row (the alpha step).
-        if (tid == 0) {
-#pragma unroll L <= 8 ? L : 1
-            for (int k = 0; k < L; ++k) s_words[0][k] = ap.w[k];
-        }
-        __syncthreads();
         block_mul_lo(s_words[0], L, s_dinv, L, s_c1, L, s_part);
         Big<L> c1;
+        if (!on_matrix_cores) {
 #pragma unroll L <= 8 ? L : 1
-        for (int k = 0; k < L; ++k) c1.w[k] = s_c1[k];
-        const int ap_bits = big_bits(ap);
+            for (int k = 0; k < L; ++k) c1.w[k] = s_c1[k];
+        }
         // Will every new entry fit?  Decided from the bit lengths of the operands BEFORE anything is written (one more read of N:
         // microseconds beside the multiplications below), so that a run that does not fit stops with N, D and the basis as they
         // were at the start of this pivot -- the state the next width continues from (host driver).
@@ -1801,12 +1825,10 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const int estimate = max(ap_bits + lp.N_bits[idx], lp.x_bits[i] + lp.N_bits[(size_t)k * m + p]) + 1 - (D_bits - 1);
             if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
         }
-        const int xp_bits = big_bits(big_load<L>(lp.xt + (size_t)p * L));
+        const int xp_bits = lp.xt_bits[p];  // (bit lengths of x~_B: kept by whoever writes an entry, like N_bits)
         for (int i = gtid; i < m; i += GT) {
             if (i == p) continue;
-            const int xi_bits = big_bits(big_load<L>(lp.xt + (size_t)i * L));
-            if (lp.xt_bits) lp.xt_bits[i] = xi_bits;  // (the update on the matrix cores sizes x~_B's tiles by it)
-            const int estimate = max(ap_bits + xi_bits, lp.x_bits[i] + xp_bits) + 1 - (D_bits - 1);
+            const int estimate = max(ap_bits + lp.xt_bits[i], lp.x_bits[i] + xp_bits) + 1 - (D_bits - 1);
             if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
         }
         // The entries of N by what they cost below.  N'_ik = (alpha~_p N_ik - alpha~_i N_pk) / D: two products where N(p, k) != 0 AND
@@ -1853,8 +1875,6 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         const int n_heavy = word[7], n_rows_alpha = word[6];
-        bool on_matrix_cores = false;
-        if constexpr (L >= 16) on_matrix_cores = lp.mfma_update != 0;
         if constexpr (L >= 16) if (on_matrix_cores) {
             const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha};
             update_on_matrix_cores<L>(lp, scalars, s_c1, products_needed, products_issued);
@@ -1937,6 +1957,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 Big<L> quotient = big_sar(big_add(big_mul_lo(c1, big_load<L>(lp.xt + (size_t)i * L)), big_mul_lo(ri, xp)), shift);  // (ri is stored negated)
                 if (flip) quotient = big_negate(quotient);
                 big_store(lp.xt + (size_t)i * L, quotient);
+                lp.xt_bits[i] = big_bits(quotient);
             }
         }
         stamp(7);
@@ -1944,12 +1965,12 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if (flip) {
             for (int k = gtid; k < m; k += GT) big_store_s(N_at(p, k), MM, big_negate(big_load_s<L>(N_at(p, k), MM)));
             if (gtid == 0) big_store(lp.xt + (size_t)p * L, big_negate(big_load<L>(lp.xt + (size_t)p * L)));
-            ap = big_negate(ap);
         }
         if (leader) {
             word[4] = 0;  // (the candidate counter of the next pricing pass)
             const int leaving = lp.basis[p];
-            big_store(gD, ap);
+            const Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
+            big_store(gD, flip ? big_negate(ap) : ap);
             lp.basis[p] = q;
             lp.pos[q] = p;
             lp.pos[leaving] = -1;
@@ -2221,7 +2242,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_Tx = mfma_update ? dalloc<u64>((size_t)m * big, fresh) : nullptr;
         int* d_Tx_carry = mfma_update ? dalloc<int>((size_t)m * (big / 2), fresh) : nullptr;
         int* d_Tx_words = mfma_update ? dalloc<int>((size_t)m, fresh) : nullptr;
-        int* d_xt_bits = mfma_update ? dalloc<int>((size_t)m, fresh) : nullptr;
+        int* d_xt_bits = dalloc<int>((size_t)m, fresh);
         if (mfma_update) {
             RELP_HIP(hipMemsetAsync(d_T_words, 0, (size_t)m * m * sizeof(int), stream));
             RELP_HIP(hipMemsetAsync(d_Tx_words, 0, (size_t)m * sizeof(int), stream));
