@@ -41,6 +41,8 @@ WORKLOADS = {
     "netlib": "batch",   # BASELINE configs[3]: the Netlib problems the reference's suite enables, one LP per GPU at a time
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+I8_MFMA_PEAK_TMACS = 2500.0     # dense i8 MFMA: 2x the bf16 rate (same guide, matrix cores table) = 5 POP/s = 2.5 P MAC/s; measured 2.39 here
+VALU_WORD_PRODUCT_PEAK = 2.1    # T word products/s: the 4 x 4-word block product of exact.hip on the vector multiplier, operands in registers (measured)
 
 
 def emit(text):
@@ -939,25 +941,48 @@ def exact_lp(lp_name, ctx, first_limbs, max_limbs, max_pivots=0):
     elapsed = time.perf_counter() - start
     pivots = got["pivots_phase_one"] + got["pivots_phase_two"]
     m = solver.m
+    widths = solver.exact_counters()
     solver.close()
-    # one pivot rewrites the m x m integer matrix N = D B^-1 at the final width: read + write of m^2 * limbs * 8 bytes
-    bytes_per_pivot = 2 * m * m * got["limbs"] * 8
-    achieved = bytes_per_pivot * pivots / elapsed / 1e9 if elapsed > 0 else 0.0
+    # The roofline of the dominant step at the final width: the integer-preserving update of N = D B^-1.  Its work is counted in the
+    # kernel in 64 x 64 -> 128-bit word products: `needed` by the entries' bit bounds (the algorithmic count) and `issued` by the waves
+    # (whole 64-byte blocks, the widest entry of a tile for all sixteen).  From 32 limbs on the products run on the matrix cores as byte
+    # products (v_mfma_i32_16x16x64_i8: 64 byte MACs = one word product), so the peak is the chip's dense i8 MFMA rate; below 32 limbs
+    # they run on the vector multiplier (v_mad_u64_u32; the compiled 4 x 4-word block product reaches 2.1 T word products/s:
+    # profiles/r5_micro_intmul_rates.txt).
+    last = widths[-1] if widths else None
+    roofline = {"bound": "mfma", "kernel": "exact_simplex_kernel<%d>: update of N" % got["limbs"], "achieved": None, "peak": None, "unit": "T word products/s",
+                "frac": None, "traffic": None}
+    if last:
+        update_seconds = last["step_seconds"]["update of N"]
+        on_matrix_cores = got["limbs"] >= 32
+        peak = I8_MFMA_PEAK_TMACS / 64.0 if on_matrix_cores else VALU_WORD_PRODUCT_PEAK
+        achieved = last["update_word_products_needed"] / update_seconds / 1e12 if update_seconds > 0 else 0.0
+        roofline.update({
+            "bound": "mfma" if on_matrix_cores else "int-mul (valu)", "achieved": achieved, "peak": peak, "frac": achieved / peak,
+            "word_products_needed": last["update_word_products_needed"], "word_products_issued": last["update_word_products_issued"],
+            "issued_per_second_T": last["update_word_products_issued"] / update_seconds / 1e12 if update_seconds > 0 else None,
+            "update_seconds_at_final_width": update_seconds, "seconds_at_final_width": last["seconds"],
+            "step_seconds_at_final_width": last["step_seconds"],
+            "note": "achieved = word products the entries need / seconds of the update step at the final width (%d limbs); peak = %s"
+                    % (got["limbs"], "dense i8 MFMA, 2.5 P MAC/s / 64 (measured 2.39: profiles/r5_micro_intmul_rates.txt)" if on_matrix_cores
+                       else "the compiled block product on v_mad_u64_u32, measured")})
     matches = None
     if golden is not None:
         matches = (got["status"] == 1 and got["objective"] == golden["objective"] and
                    (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"]))
+    if max_pivots and golden is not None:  # a prefix of the solve: the pivots made must be the golden trace's first ones
+        reference = [tuple(t) for t in golden.get("trace", golden["trace_head"])]
+        shared = min(len(reference), len(got["trace"]))
+        matches = got["trace"][:shared] == reference[:shared]
     return {"metric": "simplex pivots/sec, exact fixed-width integers on the device, Netlib %s" % lp_name, "value": pivots / elapsed if elapsed > 0 else 0.0,
             "unit": "pivots/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1e3 * elapsed, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int%d" % (64 * got["limbs"]), "data": "Netlib %s.SIF" % lp_name,
             "config": {"workload": "Netlib %s %d rows, relp_solve_exact: the reference's pivot sequence (steepest edge, Bland ratio ties) in %d x 64-bit "
                                    "integers over a common denominator, widths tried %s" % (lp_name, m, got["limbs"], got["survived"]),
                        "pivots_per_solve": pivots, "status": got["status"], "limbs": got["limbs"], "widths_and_pivots_survived": got["survived"],
-                       "objective_exact": got["objective"], "objective": None, "matches_golden_optimum_and_pivot_counts": matches},
-            "roofline": {"bound": "hbm", "kernel": "exact_simplex_kernel<%d>" % got["limbs"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_pivot * pivots,
-                         "note": "integer-ALU bound, not HBM bound: a pivot is m^2 multi-limb multiply-subtract-divide steps (limbs^2 word "
-                                 "products each); the bytes are the read + write of the numerator matrix at the final width"}}
+                       "objective_exact": got["objective"], "objective": None, "matches_golden_optimum_and_pivot_counts": matches,
+                       "seconds_per_width": [[w["limbs"], w["seconds"]] for w in widths]},
+            "roofline": roofline}
 
 
 EXACT_25FV47_CPU = {"value": 2392 / 1026.0, "unit": "pivots/s", "cores": 1, "kind": "port", "mode": "faithful", "recorded": True, "seconds": 1026.0,

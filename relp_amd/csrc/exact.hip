@@ -1449,19 +1449,51 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         // 1 / D_odd modulo 2^(64 L) (D = 2^shift D_odd): every exact quotient of this turn is a truncated product with it.  Every
         // workgroup for itself: cheap, and no exchange is needed this way.
-        if (tid == 0) {
-            const Big<L> D0 = big_load<L>(gD);
-            const int shift = big_ctz(D0);
-            const Big<L> odd = big_sar(D0, shift);
+        if constexpr (L < 16) {
+            if (tid == 0) {
+                const Big<L> D0 = big_load<L>(gD);
+                const int shift = big_ctz(D0);
+                const Big<L> odd = big_sar(D0, shift);
 #pragma unroll L <= 8 ? L : 1
-            for (int k = 0; k < L; ++k) s_words[0][k] = odd.w[k];
-            s_shift = shift;
-            s_D_bits = big_bits(D0);
-            int exponent = 0;
-            s_mD = big_mantissa(D0, &exponent);
-            s_eD = exponent;
+                for (int k = 0; k < L; ++k) s_words[0][k] = odd.w[k];
+                s_shift = shift;
+                s_D_bits = big_bits(D0);
+                int exponent = 0;
+                s_mD = big_mantissa(D0, &exponent);
+                s_eD = exponent;
+            }
+            __syncthreads();
+        } else {
+            // a thread per word of D (D > 0): its lowest and its highest non-zero word from the waves' ballots, the odd part shifted down
+            // by every thread for its own word (one thread with the integer in scratch memory took a tenth of a millisecond per pivot)
+            __shared__ unsigned long long s_nonzero[EX_THREADS / WAVE];
+            const u64 w = tid < L ? gD[tid] : 0ull;
+            const unsigned long long nonzero = __ballot(w != 0);
+            if ((tid & (WAVE - 1)) == 0) s_nonzero[tid / WAVE] = nonzero;
+            if (tid < L) s_words[1][tid] = w;
+            __syncthreads();
+            int low = 0, top = 0;
+            for (int wv = EX_THREADS / WAVE - 1; wv >= 0; --wv)
+                if (s_nonzero[wv] != 0) low = WAVE * wv + __ffsll((long long)s_nonzero[wv]) - 1;
+            for (int wv = 0; wv < EX_THREADS / WAVE; ++wv)
+                if (s_nonzero[wv] != 0) top = WAVE * wv + 63 - __clzll((long long)s_nonzero[wv]);
+            const u64 w_low = s_words[1][low], w_top = s_words[1][top];
+            const int shift_bits = 64 * low + __ffsll((long long)w_low) - 1;
+            if (tid < L) {
+                const int ws = shift_bits >> 6, bs = shift_bits & 63;
+                const u64 lo = tid + ws < L ? s_words[1][tid + ws] : 0ull, hi = tid + ws + 1 < L ? s_words[1][tid + ws + 1] : 0ull;
+                s_words[0][tid] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+            }
+            if (tid == 0) {
+                s_shift = shift_bits;
+                s_D_bits = 64 * top + (64 - __clzll((long long)w_top));
+                double x = (double)w_top;  // (big_mantissa's numbers: the two leading words, the exponent of the lower one)
+                if (top > 0) x = x * 18446744073709551616.0 + (double)s_words[1][top - 1];
+                s_mD = x;
+                s_eD = 64 * (top > 0 ? top - 1 : 0);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if constexpr (L >= 16) D_bits = s_D_bits;
         const u64* Dw = gD;  // the words of D for whoever streams them
         block_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2], s_part);
@@ -1796,14 +1828,36 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         stamp(6);
         // ---- the pivot: D' = alpha~_p, N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays ---------------------------
-        if (tid == 0) {
-            const Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
+        if constexpr (L < 16) {
+            if (tid == 0) {
+                const Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
 #pragma unroll L <= 8 ? L : 1
-            for (int k = 0; k < L; ++k) s_words[0][k] = ap.w[k];
-            s_ap_bits = big_bits(ap);
-            s_flip = big_neg(ap) ? 1 : 0;
+                for (int k = 0; k < L; ++k) s_words[0][k] = ap.w[k];
+                s_ap_bits = big_bits(ap);
+                s_flip = big_neg(ap) ? 1 : 0;
+            }
+            __syncthreads();
+        } else {  // (a thread per word, as for D above; a negative pivot element -- zero-level pivots only -- goes the one-thread way)
+            __shared__ unsigned long long s_ap_nonzero[EX_THREADS / WAVE];
+            const u64 w = tid < L ? lp.alpha[(size_t)p * L + tid] : 0ull;
+            const unsigned long long nonzero = __ballot(w != 0);
+            if ((tid & (WAVE - 1)) == 0) s_ap_nonzero[tid / WAVE] = nonzero;
+            if (tid < L) s_words[0][tid] = w;
+            __syncthreads();
+            if (tid == 0) {
+                const bool negative = (i64)s_words[0][L - 1] < 0;
+                s_flip = negative ? 1 : 0;
+                if (negative) {
+                    s_ap_bits = big_bits(big_load<L>(lp.alpha + (size_t)p * L));
+                } else {
+                    int top = -1;
+                    for (int wv = 0; wv < EX_THREADS / WAVE; ++wv)
+                        if (s_ap_nonzero[wv] != 0) top = WAVE * wv + 63 - __clzll((long long)s_ap_nonzero[wv]);
+                    s_ap_bits = top < 0 ? 0 : 64 * top + (64 - __clzll((long long)s_words[0][top]));
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         const bool flip = s_flip != 0;  // (only a zero-level pivot can have a negative pivot element): keep D > 0
         const int ap_bits = s_ap_bits;
         // With D = 2^s D_odd and u = 1 / D_odd modulo 2^(64 L):  (alpha~_p u) N_ik - (alpha~_i u) N_pk = 2^s N'_ik modulo 2^(64 L), so the
