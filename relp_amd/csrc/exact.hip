@@ -1779,10 +1779,34 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             // ---- ratio test: min x~_i / alpha~_i over alpha~_i > 0, ties to the lowest basic column (tableau/mod.rs:287-313) --
             double best = 0.0;
             unsigned long long rank = RANK_NONE;
+            // The estimate x~_i / alpha~_i from the two leading words of each: their places are known from the bit lengths kept beside the
+            // integers (x_bits for alpha~, xt_bits for x~_B) -- four loads per row instead of two integers scanned in scratch memory
+            // twice per pivot.  Same double as big_ratio for non-negative x~_i (anything else takes the long way).
+            auto ratio_estimate = [&](int i, double* ratio) {  // false: alpha~_i <= 0, the row does not take part
+                const int a_bits = lp.x_bits[i];
+                const u64* a = lp.alpha + (size_t)i * L;
+                if (a_bits == 0 || (i64)a[L - 1] < 0) return false;
+                const u64* x = lp.xt + (size_t)i * L;
+                if ((i64)x[L - 1] < 0) {
+                    *ratio = big_ratio(big_load<L>(x), big_load<L>(a));
+                    return true;
+                }
+                auto leading = [](const u64* v, int bits, int* exponent) {
+                    if (bits == 0) { *exponent = 0; return 0.0; }
+                    const int top = (bits - 1) >> 6;
+                    double value = (double)v[top];
+                    if (top > 0) value = value * 18446744073709551616.0 + (double)v[top - 1];
+                    *exponent = 64 * (top > 0 ? top - 1 : 0);
+                    return value;
+                };
+                int ex = 0, ea = 0;
+                const double mx = leading(x, lp.xt_bits[i], &ex), ma = leading(a, a_bits, &ea);
+                *ratio = ldexp(mx / ma, ex - ea);
+                return true;
+            };
             for (int i = gtid; i < m; i += GT) {
-                const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
-                if (big_neg(a) || big_zero(a)) continue;
-                const double ratio = big_ratio(big_load<L>(lp.xt + (size_t)i * L), a);
+                double ratio;
+                if (!ratio_estimate(i, &ratio)) continue;
                 const unsigned long long r = ((unsigned long long)(unsigned)lp.basis[i] << 32) | (unsigned)i;
                 const double k = -ratio;  // block_argbest maximises
                 if (rank == RANK_NONE || k > best || (k == best && r < rank)) { best = k; rank = r; }
@@ -1795,9 +1819,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 const double ratio_p = -best;
                 for (int i = gtid; i < m; i += GT) {
                     if (i == p) continue;
-                    const Big<L> a = big_load<L>(lp.alpha + (size_t)i * L);
-                    if (big_neg(a) || big_zero(a)) continue;
-                    const double ratio = big_ratio(big_load<L>(lp.xt + (size_t)i * L), a);
+                    double ratio;
+                    if (!ratio_estimate(i, &ratio)) continue;
                     if (!(ratio <= ratio_p + 1e-9 * fabs(ratio_p) + 1e-300)) continue;
                     lp.cand[atomicAdd(&word[5], 1)] = i;
                 }
@@ -1808,7 +1831,11 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const int n_near = word[5];
             int winner = p;
             if (n_near > 0) {
-                if (leader) lp.cand[n_near] = p;
+                if (leader) {
+                    lp.cand[n_near] = p;
+                    lp.prof[24] += 1;         // (diagnostic: pivots with near-tied rows, and how many of those rows)
+                    lp.prof[25] += n_near;
+                }
                 for (int c = gtid; c <= n_near; c += GT) lp.bracket[c] = c;
                 grid.sync();
                 for (int stride = 1; stride <= n_near; stride *= 2) {
@@ -2386,6 +2413,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                 fprintf(stderr, "[exact] %d limbs, grid %d, %d pivots, candidates %llu, update word products %.3e needed / %.3e issued:", limbs, grid, out[1] + out[2],
                         prof[12], (double)prof[16], (double)prof[17]);
                 for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 1e5);
+                fprintf(stderr, " | ratio test: %llu pivots with near-tied rows (%llu rows in all)", prof[24], prof[25]);
                 fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f\n", prof[20] / 1e5, prof[21] / 1e5, prof[22] / 1e5, prof[23] / 1e5);
             }
             if (counters) {
