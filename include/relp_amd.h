@@ -89,7 +89,32 @@ typedef enum relp_lu_refactor {
     RELP_REFACTOR_HOST = 2     /* one host core: Markowitz + inversion + task lists, one upload (rounds 2-3) */
 } relp_lu_refactor;
 
+/* A/B switches of the kernels (`relp_options.switches`; tests and measurements -- all clear = what the library would choose).
+ * Round 5: these were environment variables of the same names (RELP_NO_TOUCHED ...); the library no longer reads the environment
+ * for anything that changes a kernel or a result, so a caller's options cannot be overruled from outside. */
+typedef enum relp_switch {
+    RELP_SW_NO_TOUCHED = 1 << 0,            /* no bookkeeping of the non-unit columns of the inverse (m > 2048) */
+    RELP_SW_K2_SINGLE = 1 << 1,             /* the one-workgroup ratio test beyond 8192 rows as well */
+    RELP_SW_ELL_WIDE = 1 << 2,              /* graph LPs: the 8-wide padded copy of the columns */
+    RELP_SW_NO_GENERATED_COLUMNS = 1 << 3,  /* graph LPs: materialised instead of generated incidence columns */
+    RELP_SW_NO_SLACK_IN_BTRAN = 1 << 4,     /* dense pipeline: slack columns priced by a launch of their own */
+    RELP_SW_NO_DENSE_LANE = 1 << 5,         /* dense block priced by one wave per column instead of a column per lane */
+    RELP_SW_POLISH_ALWAYS = 1 << 6,         /* polish at every opportunity */
+    RELP_SW_NO_RHO_BITS = 1 << 7,           /* generated columns: no bit table of rho_p's rows */
+    RELP_SW_PRICE_UNIT_PAIRS = 1 << 8,      /* generated columns: the pair-per-lane pricing kernel */
+    RELP_SW_CERTIFY_NO_LEVELS = 1 << 9,     /* exact certificate: modular inverse without level scheduling */
+    RELP_SW_GEMM_VECTOR = 1 << 10,          /* polish: the plain-FMA GEMM instead of v_mfma_f64_16x16x4_f64 */
+    RELP_SW_LUF_CLAIM_TARGETS = 1 << 11,    /* device refactorisation: target rows claimed from a counter */
+    RELP_SW_LUF_NO_LDS_ARENA = 1 << 12,     /* ... the active sub-matrix in global memory throughout */
+    RELP_SW_LUI_CLAIM_ROWS = 1 << 13,       /* ... inversion of the triangles: rows claimed from a counter */
+    RELP_SW_BI_FACTOR_HOST = 1 << 14        /* stand-alone BasisInverse: `invert` on a host core */
+} relp_switch;
+
 typedef struct relp_options {
+    int32_t struct_size;       /* sizeof(relp_options) as the CALLER compiled it; relp_options_default() sets it and is the only
+                                  supported way to initialise the struct.  relp_create / relp_batch_create read that many bytes and
+                                  take the defaults for the fields a caller built against an older header does not have; 0 or a
+                                  size larger than the library's is RELP_ERR_ARGUMENT */
     int32_t device;            /* HIP device ordinal */
     int32_t pivot_rule;        /* relp_pivot_rule */
     int32_t polish_period;     /* pivots between Newton-Schulz polishes of the explicit inverse (role of
@@ -123,18 +148,31 @@ typedef struct relp_options {
                                   columns with a single entry in the rows still on an artificial are assigned breadth first
                                   -- a spanning forest on the graph providers -- and the crash is kept when it is primal
                                   feasible.  Same optimum, different (much shorter) pivot sequence; explicit carry only */
-    /* ---- appended in round 4: what was reachable only through the environment before (the variables still override) ---- */
+    /* ---- appended in round 4: what was reachable only through the environment before ---- */
     int32_t dense_storage;     /* relp_dense_storage: storage type of a dense column block (relp_load_dense_le; BASELINE config 3
-                                  names the f64 block); RELP_DENSE_F32 / RELP_DENSE_F64 in the environment override */
+                                  names the f64 block) */
     int32_t pivot_kernels;     /* 0 = automatic (ratio test and inverse update fused into one launch for m <= 2048, explicit
-                                  carry), 1 = the three separate kernels (bit-identical results); env RELP_NO_FUSED */
+                                  carry), 1 = the three separate kernels (bit-identical results) */
     int32_t product_form;      /* dense pipeline: 0 = automatic (updates deferred in product form, one rank-k update every 32
-                                  pivots), 1 = a rank-one update of the stored inverse per pivot; env RELP_ETA=0 */
-    int32_t ftran_min_nnz;     /* columns longer than this take the multi-block FTRAN pipeline; 0 = 1024; env
-                                  RELP_FTRAN_MIN_NNZ */
+                                  pivots), 1 = a rank-one update of the stored inverse per pivot */
+    int32_t ftran_min_nnz;     /* columns longer than this take the multi-block FTRAN pipeline; 0 = 1024 */
     int32_t lu_refactor;       /* relp_lu_refactor: where `BasisInverse::invert` of the LU carries runs (lower_upper/mod.rs:78-92,
-                                  decomposition/mod.rs:27-143); env RELP_REFACTOR=device|host overrides */
-    int32_t reserved0;         /* 0 */
+                                  decomposition/mod.rs:27-143) */
+    /* ---- appended in round 5: the remaining A/B hooks (0 = the library's choice everywhere) ---- */
+    uint32_t switches;         /* relp_switch bits */
+    int32_t dense_blocks;      /* workgroups of the one-wave-per-column dense pricing kernel (256) */
+    int32_t ftran_slices;      /* slices of the multi-block FTRAN (by the longest column, at most 64) */
+    int32_t price_lds_max;     /* pricing stages -pi / rho / w in LDS up to this many bytes of the three vectors (96 KB) */
+    int32_t certify_threads;   /* host threads of the exact certificate (by the core count, at most 32) */
+    int32_t exact_grid;        /* relp_solve_exact: workgroups of the cooperative launch (by the work of a pivot) */
+    int32_t exact_update;      /* relp_solve_exact, the update of N = D B^-1: 0 = on the matrix cores from 32 limbs on, 1 = vector
+                                  unit only, 2 = matrix cores from 16 limbs on */
+    int32_t luf_dense_tail;    /* device refactorisation: rows of the dense tail (8); -1 = none */
+    int32_t luf_slack;         /* ... Markowitz score slack of a round (16) */
+    int32_t luf_lds;           /* ... 1 + the LDS level forced (1: every work array in global memory) */
+    int32_t luf_lds_arena;     /* ... cap on the entries of the active sub-matrix held in LDS (test hook: spills) */
+    int32_t luf_arena_cap;     /* ... cap on the words of the global arena (test hook: a basis that outgrows it) */
+    double carry_weights_min;  /* steepest-edge weights carried from phase one into phase two from this many columns (4e9) */
 } relp_options;
 
 typedef struct relp_result {
@@ -407,6 +445,9 @@ int32_t relp_profile_kernel(relp_handle* handle, int32_t which, int32_t repetiti
 
 /* Diagnostic builds only (-DRELP_STAMPS): per-segment cycle sums of the fused kernel; zeros otherwise. */
 int32_t relp_debug_stamps(relp_handle* handle, uint64_t* out64);
+/* The switches and sizes of `options` for the test hooks that take no options of their own (relp_lu_factor_device), on the calling
+ * thread, until the next call.  NULL restores the defaults. */
+int32_t relp_debug_set_tuning(const relp_options* options);
 /* Test hook of the exact simplex's update on the matrix cores (exact.hip, finish_update_entry): `count` numerators as the MFMA tiles
  * leave them -- `limbs` words each, word-major (word w of entry e at T[w * count + e]), one carry per pair of words
  * (carry[pair * count + e], added to the pair above), words[e] of them valid (a multiple of 8) -- become the entries of N: carries run
@@ -432,7 +473,7 @@ typedef struct relp_bi_options {
     int32_t refactor_period;   /* `should_refactor` turns true after this many `change_basis` calls (reference: 31) */
     double pivot_threshold;    /* accept a_ij as a pivot only if |a_ij| >= threshold * max_k |a_ik| (0: any non-zero) */
     int32_t reference_ties;    /* 1: pivoting.rs:60-80 exactly (minimum Markowitz count, ties by (column, row) position) */
-    int32_t reserved;
+    int32_t switches;          /* relp_switch bits (RELP_SW_BI_FACTOR_HOST, the RELP_SW_LUF_* hooks): in force during every call on the object */
 } relp_bi_options;
 int32_t relp_bi_options_default(relp_bi_options* options);
 /* `BasisInverse::identity(m)` (carry/mod.rs:83; lower_upper/mod.rs:67-76). */

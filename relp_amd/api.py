@@ -28,14 +28,69 @@ class RelpError(RuntimeError):
 
 
 class Options(C.Structure):
-    _fields_ = [("device", C.c_int32), ("pivot_rule", C.c_int32), ("polish_period", C.c_int32),
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("pivot_rule", C.c_int32), ("polish_period", C.c_int32),
                 ("pivots_per_launch", C.c_int32), ("max_pivots", C.c_int64), ("tol_dual", C.c_double),
                 ("tol_pivot", C.c_double), ("harris_delta", C.c_double), ("tol_feasible", C.c_double),
                 ("certify", C.c_int32), ("use_graph", C.c_int32), ("verbose", C.c_int32), ("implicit_bounds", C.c_int32),
                 ("carry", C.c_int32), ("refactor_period", C.c_int32), ("lu_pivot_threshold", C.c_double),
                 ("ratio_rule", C.c_int32), ("crash", C.c_int32),
                 ("dense_storage", C.c_int32), ("pivot_kernels", C.c_int32), ("product_form", C.c_int32), ("ftran_min_nnz", C.c_int32),
-                ("lu_refactor", C.c_int32), ("reserved0", C.c_int32)]
+                ("lu_refactor", C.c_int32),
+                ("switches", C.c_uint32), ("dense_blocks", C.c_int32), ("ftran_slices", C.c_int32), ("price_lds_max", C.c_int32),
+                ("certify_threads", C.c_int32), ("exact_grid", C.c_int32), ("exact_update", C.c_int32), ("luf_dense_tail", C.c_int32),
+                ("luf_slack", C.c_int32), ("luf_lds", C.c_int32), ("luf_lds_arena", C.c_int32), ("luf_arena_cap", C.c_int32),
+                ("carry_weights_min", C.c_double)]
+
+
+# relp_switch bits of Options.switches (include/relp_amd.h)
+SW_NO_TOUCHED, SW_K2_SINGLE, SW_ELL_WIDE, SW_NO_GENERATED_COLUMNS, SW_NO_SLACK_IN_BTRAN, SW_NO_DENSE_LANE, SW_POLISH_ALWAYS, SW_NO_RHO_BITS, \
+    SW_PRICE_UNIT_PAIRS, SW_CERTIFY_NO_LEVELS, SW_GEMM_VECTOR, SW_LUF_CLAIM_TARGETS, SW_LUF_NO_LDS_ARENA, SW_LUI_CLAIM_ROWS, SW_BI_FACTOR_HOST = (1 << k for k in range(15))
+
+# The library reads no environment variable that changes a kernel or a result (round 5).  This BINDING -- test and bench plumbing --
+# still maps the old variable names onto option fields for the tools that A/B them; an option given by the caller always wins.
+_ENV_SWITCHES = {"RELP_NO_TOUCHED": SW_NO_TOUCHED, "RELP_K2_SINGLE": SW_K2_SINGLE, "RELP_ELL_WIDE": SW_ELL_WIDE,
+                 "RELP_NO_GENERATED_COLUMNS": SW_NO_GENERATED_COLUMNS, "RELP_NO_SLACK_IN_BTRAN": SW_NO_SLACK_IN_BTRAN,
+                 "RELP_NO_DENSE_LANE": SW_NO_DENSE_LANE, "RELP_POLISH_ALWAYS": SW_POLISH_ALWAYS, "RELP_NO_RHO_BITS": SW_NO_RHO_BITS,
+                 "RELP_PRICE_UNIT_PAIRS": SW_PRICE_UNIT_PAIRS, "RELP_CERTIFY_NO_LEVELS": SW_CERTIFY_NO_LEVELS,
+                 "RELP_LUF_CLAIM_TARGETS": SW_LUF_CLAIM_TARGETS, "RELP_LUF_NO_LDS_ARENA": SW_LUF_NO_LDS_ARENA,
+                 "RELP_LUI_CLAIM_ROWS": SW_LUI_CLAIM_ROWS, "RELP_BI_FACTOR_HOST": SW_BI_FACTOR_HOST}
+_ENV_INTEGERS = {"RELP_DENSE_BLOCKS": "dense_blocks", "RELP_FTRAN_SLICES": "ftran_slices", "RELP_FTRAN_MIN_NNZ": "ftran_min_nnz",
+                 "RELP_PRICE_LDS_MAX": "price_lds_max", "RELP_CERTIFY_THREADS": "certify_threads", "RELP_EXACT_GRID": "exact_grid",
+                 "RELP_EXACT_UPDATE": "exact_update", "RELP_LUF_SLACK": "luf_slack", "RELP_LUF_LDS_ARENA": "luf_lds_arena",
+                 "RELP_LUF_ARENA_CAP": "luf_arena_cap"}
+
+
+def options_from_environment(options, given=()):
+    """The old environment hooks onto the fields of `options` that the caller did not set (`given`)."""
+    env = os.environ
+    if "switches" not in given:
+        for name, bit in _ENV_SWITCHES.items():
+            if env.get(name):
+                options.switches |= bit
+        if env.get("RELP_GEMM") == "vector":
+            options.switches |= SW_GEMM_VECTOR
+    for name, field in _ENV_INTEGERS.items():
+        if field not in given and env.get(name):
+            setattr(options, field, int(env[name]))
+    if "carry_weights_min" not in given and env.get("RELP_CARRY_WEIGHTS_MIN"):
+        options.carry_weights_min = float(env["RELP_CARRY_WEIGHTS_MIN"])
+    if "luf_dense_tail" not in given and env.get("RELP_LUF_DENSE_TAIL"):
+        tail = int(env["RELP_LUF_DENSE_TAIL"])
+        options.luf_dense_tail = tail if tail > 0 else -1
+    if "luf_lds" not in given and env.get("RELP_LUF_LDS"):
+        options.luf_lds = int(env["RELP_LUF_LDS"]) + 1
+    if "dense_storage" not in given:
+        if env.get("RELP_DENSE_F64"):
+            options.dense_storage = 2
+        elif env.get("RELP_DENSE_F32"):
+            options.dense_storage = 1
+    if "pivot_kernels" not in given and env.get("RELP_NO_FUSED"):
+        options.pivot_kernels = 1
+    if "product_form" not in given and env.get("RELP_ETA") == "0":
+        options.product_form = 1
+    if "lu_refactor" not in given and env.get("RELP_REFACTOR") in ("device", "host"):
+        options.lu_refactor = 1 if env["RELP_REFACTOR"] == "device" else 2
+    return options
 
 
 class Result(C.Structure):
@@ -87,7 +142,7 @@ SYMBOLS = [
     "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_solve_exact", "relp_get_exact_counters", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
     "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_get_last_pivot", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
-    "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps", "relp_debug_exact_finish",
+    "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps", "relp_debug_set_tuning", "relp_debug_exact_finish",
     # BasisInverse as an object of its own (relp_amd/basis_inverse.py)
     "relp_bi_options_default", "relp_bi_identity", "relp_bi_invert", "relp_bi_free", "relp_bi_last_error", "relp_bi_m",
     "relp_bi_left_multiply", "relp_bi_right_multiply", "relp_bi_basis_inverse_row", "relp_bi_generate_element",
@@ -123,7 +178,7 @@ def default_options(**overrides):
         if not hasattr(options, key):
             raise AttributeError(key)
         setattr(options, key, value)
-    return options
+    return options_from_environment(options, given=overrides)
 
 
 class Model:

@@ -13,7 +13,7 @@ from .api import OK, RelpError, _ptr, lib
 
 class BiOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("refactor_period", C.c_int32), ("pivot_threshold", C.c_double),
-                ("reference_ties", C.c_int32), ("reserved", C.c_int32)]
+                ("reference_ties", C.c_int32), ("switches", C.c_int32)]
 
 
 def default_bi_options(**overrides):
@@ -23,6 +23,9 @@ def default_bi_options(**overrides):
         if not hasattr(options, key):
             raise AttributeError(key)
         setattr(options, key, value)
+    if "switches" not in overrides:  # (the binding maps the old environment hooks; the library reads none)
+        from .api import default_options
+        options.switches = int(default_options().switches)
     return options
 
 
@@ -188,6 +191,8 @@ def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False, inverted=
         dl, du = C.c_int32(), C.c_int32()
         info = np.zeros(32, np.int32)
         if _device is not None:
+            from .api import default_options
+            lib().relp_debug_set_tuning(C.byref(default_options()))  # (the RELP_LUF_* test hooks reach the kernels as options)
             status = lib().relp_lu_factor_device(
                 int(_device[0]), m, _ptr(start, C.c_int64), _ptr(rows, C.c_int32), _ptr(vals, C.c_double), C.c_double(pivot_threshold),
                 int(bool(reference_ties)), int(_device[1]), int(bool(inverted)), C.c_int64(cap), _ptr(rp, C.c_int32), _ptr(cp, C.c_int32),

@@ -6,6 +6,7 @@
 // schedule[t], tickets are drawn by an atomic fetch-add -- or by the caller's `next_ticket`, so that several processes (one
 // rank per GPU under torch.distributed) can share ONE queue.  No collective and no data exchange between workers.
 // Built on the public C ABI only (relp_create / relp_load_model / relp_solve_relaxation): what a caller could write itself.
+#include "solver.hpp"
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -42,6 +43,8 @@ extern "C" {
 int32_t relp_batch_create(const relp_model* const* models, int32_t n_models, const relp_options* options, const int32_t* devices,
                           int32_t n_devices, int32_t workers_per_device, relp_batch** out, char* error, int32_t error_capacity) {
     if (!models || n_models <= 0 || !options || !devices || n_devices <= 0 || workers_per_device <= 0 || !out) return RELP_ERR_ARGUMENT;
+    relp_options adopted;  // (as many bytes as the caller's header had: relp_options.struct_size)
+    if (relp::adopt_options(options, &adopted) != RELP_OK) return RELP_ERR_ARGUMENT;
     auto batch = std::make_unique<relp_batch>();
     batch->n_models = n_models;
     for (int d = 0; d < n_devices; ++d)
@@ -54,7 +57,7 @@ int32_t relp_batch_create(const relp_model* const* models, int32_t n_models, con
     std::vector<std::thread> threads;
     for (int w = 0; w < n_workers; ++w)
         threads.emplace_back([&, w] {
-            relp_options o = *options;
+            relp_options o = adopted;
             o.device = batch->worker_device[w];
             for (int k = 0; k < n_models && status[w] == RELP_OK; ++k) {
                 relp_handle* h = nullptr;

@@ -31,6 +31,7 @@ namespace {
 template <class F>
 int32_t guarded(relp_handle* h, F&& f) {
     try {
+        const TuningScope tuning(h ? tuning_of(h->options) : thread_tuning());  // the handle's switches, for the helpers that have no handle in reach
         f();
         return RELP_OK;
     } catch (const DeviceError& e) {
@@ -82,9 +83,10 @@ int32_t relp_options_default(relp_options* o) {
     o->product_form = 0;
     o->ftran_min_nnz = 0;
     o->lu_refactor = RELP_REFACTOR_AUTO;
-    o->reserved0 = 0;
+    o->struct_size = (int32_t)sizeof(relp_options);  // (the switches and sizes appended in round 5 stay 0: the library's choices)
     return RELP_OK;
 }
+
 
 // ---- host-only model ------------------------------------------------------------------------------------
 int32_t relp_model_from_mps_ex(const char* path, int32_t fixed_format, int32_t presolve, relp_model** out, char* error,
@@ -406,8 +408,10 @@ int32_t relp_create(const relp_options* options, relp_handle** out) {
     *out = nullptr;
     relp_handle* h = new (std::nothrow) relp_handle();
     if (!h) return RELP_ERR_STATE;
-    if (options) h->options = *options;
-    else relp_options_default(&h->options);
+    if (adopt_options(options, &h->options) != RELP_OK) {
+        delete h;
+        return RELP_ERR_ARGUMENT;
+    }
     int32_t status = guarded(h, [&] { h->solver = new Solver(h->options); });
     if (status != RELP_OK) {
         // keep the message reachable: the handle is returned only on success
@@ -976,6 +980,12 @@ int32_t relp_debug_exact_finish(int32_t device, int32_t limbs, int32_t count, co
     }
 }
 
+int32_t relp_debug_set_tuning(const relp_options* options) {
+    relp_options adopted;
+    if (adopt_options(options, &adopted) != RELP_OK) return RELP_ERR_ARGUMENT;
+    thread_tuning() = tuning_of(adopted);
+    return RELP_OK;
+}
 int32_t relp_debug_stamps(relp_handle* h, uint64_t* out64) {
     REQUIRE_LOADED(h);
     if (!out64) return RELP_ERR_ARGUMENT;

@@ -12,6 +12,7 @@ using namespace relp;
 struct relp_basis_inverse {
     std::unique_ptr<LuBasis> lu;
     std::string error;
+    unsigned switches = 0;  // relp_bi_options.switches: in force on the calling thread during every call on this object
 };
 
 namespace {
@@ -24,6 +25,9 @@ int32_t guarded_bi(relp_basis_inverse* h, F&& f) {
         if (h) h->error = what;
     };
     try {
+        Tuning tuning = thread_tuning();
+        if (h) tuning.switches |= h->switches;
+        const TuningScope scope(tuning);
         f();
         return RELP_OK;
     } catch (const DeviceError& e) {
@@ -77,6 +81,7 @@ int32_t relp_bi_identity(const relp_bi_options* options, int32_t m, relp_basis_i
     if (!out) return RELP_ERR_ARGUMENT;
     *out = nullptr;
     std::unique_ptr<relp_basis_inverse> h(new relp_basis_inverse());
+    h->switches = options ? (unsigned)options->switches : 0u;
     const int32_t status = guarded_bi(h.get(), [&] {
         h->lu.reset(new LuBasis(options ? options->device : 0, m, lu_options_of(options), options ? options->refactor_period : 31));
         h->lu->identity();
@@ -89,6 +94,7 @@ int32_t relp_bi_invert(const relp_bi_options* options, int32_t m, const int64_t*
     if (!out || !column_start || (column_start[m > 0 ? m : 0] > 0 && (!row_index || !value))) return RELP_ERR_ARGUMENT;
     *out = nullptr;
     std::unique_ptr<relp_basis_inverse> h(new relp_basis_inverse());
+    h->switches = options ? (unsigned)options->switches : 0u;
     const int32_t status = guarded_bi(h.get(), [&] {
         h->lu.reset(new LuBasis(options ? options->device : 0, m, lu_options_of(options), options ? options->refactor_period : 31));
         static_assert(sizeof(long long) == sizeof(int64_t), "");

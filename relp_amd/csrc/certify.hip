@@ -349,7 +349,7 @@ private:
     std::mutex run_mutex_;
     WorkerPool() {
         unsigned count = std::thread::hardware_concurrency();
-        if (const char* e = getenv("RELP_CERTIFY_THREADS")) count = (unsigned)atoi(e);
+        if (thread_tuning().certify_threads > 0) count = (unsigned)thread_tuning().certify_threads;  // (the pool is made once: the first certificate of the process decides)
         count = std::min(count, 32u) / 2;  // (per pool)
         for (unsigned t = 1; t < count; ++t) threads_.emplace_back([this] { loop(); });
     }
@@ -789,7 +789,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
     struct Report {
         double t0;
         ~Report() {
-            if (!getenv("RELP_TIME_CERTIFY")) return;
+            if (!diagnostic("RELP_TIME_CERTIFY")) return;
             fprintf(stderr, "[certify] total %.2f ms: setup %.2f, inverse mod p %.2f, Dixon device %.2f (%d digit steps, %d solves), "
                             "host assemble/reconstruct/verify %.2f (of which %d rational reconstructions %.2f), checks %.2f\n",
                     (wall_now() - t0) * 1e3, g_times.setup * 1e3, g_times.inverse * 1e3, g_times.device_digits * 1e3, g_times.digit_launches,
@@ -799,7 +799,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
                     g_times.verify * 1e3, g_times.normalise * 1e3);
         }
     } report{t_begin};
-    const bool timeline = getenv("RELP_TIME_CERTIFY") != nullptr;
+    const bool timeline = diagnostic("RELP_TIME_CERTIFY");
     auto stamp = [&](const char* what) {
         if (timeline) fprintf(stderr, "[certify]   +%.2f ms %s\n", (wall_now() - t_begin) * 1e3, what);
     };
@@ -951,7 +951,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             const LuModOps ops{candidate};
             const double t_lu = wall_now();
             const HostLUT<u32> f = lu_factor_t<LuModOps>(m, B.col_start.data(), B.row_index.data(), value_mod.data(), lo, ops);
-            if (getenv("RELP_TIME_CERTIFY")) fprintf(stderr, "[certify]   modular LU on the host %.2f ms (L %zu, U %zu entries)\n", (wall_now() - t_lu) * 1e3, f.l_col.size(), f.u_col.size());
+            if (timeline) fprintf(stderr, "[certify]   modular LU on the host %.2f ms (L %zu, U %zu entries)\n", (wall_now() - t_lu) * 1e3, f.l_col.size(), f.u_col.size());
             if (f.singular) continue;  // singular modulo this prime (or singular): try the next one
             std::vector<u32> dinv(m);
             for (int i = 0; i < m; ++i) dinv[i] = ops.inverse(f.diag[i]);
@@ -978,7 +978,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             lu_schedules(fs);
             const int levels_l = (int)fs.lev_start[0].size() - 1, levels_u = (int)fs.lev_start[1].size() - 1;
             const size_t level_lds = ((size_t)2 * (m + 1) + 2 * nl + 2 * nu + m + (levels_l + 1) + m + (levels_u + 1) + m + m + (size_t)4 * m) * sizeof(u32);
-            if (level_lds <= 150 * 1024 && !getenv("RELP_CERTIFY_NO_LEVELS")) {
+            if (level_lds <= 150 * 1024 && !thread_tuning().has(RELP_SW_CERTIFY_NO_LEVELS)) {
                 // one wave per column, level by level (modular_inverse_levels_kernel)
                 int* d_levl = buf.alloc<int>(levels_l + 1);
                 int* d_rowl = buf.alloc<int>(m);
@@ -1017,7 +1017,7 @@ void certify_basis(const StandardForm& form, const std::vector<int>& basis_colum
             }
             const double t_sync = wall_now();
             RELP_HIP(hipStreamSynchronize(stream));  // (the staging vectors above go out of scope)
-            if (getenv("RELP_TIME_CERTIFY")) fprintf(stderr, "[certify]   waited %.2f ms for the uploads and the inverse kernel\n", (wall_now() - t_sync) * 1e3);
+            if (timeline) fprintf(stderr, "[certify]   waited %.2f ms for the uploads and the inverse kernel\n", (wall_now() - t_sync) * 1e3);
             p = candidate;
             break;
         }

@@ -2164,7 +2164,7 @@ __global__ void __launch_bounds__(256) exact_finish_test_kernel(ExactLP lp, int 
 void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
                    int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
                    std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
-                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters, int update_mode) {
+                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters, int update_mode, int forced_grid) {
     RELP_HIP(hipSetDevice(device));
     if (counters) counters->clear();
     if (redundant_rows) *redundant_rows = 0;
@@ -2265,7 +2265,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     double* d_part_key = dalloc<double>(2 * EX_MAX_GRID, owned);
     unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * EX_MAX_GRID, owned);
     unsigned long long* d_prof = dalloc<unsigned long long>(EX_PROF_WORDS, owned);
-    const bool print_profile = getenv("RELP_EXACT_PROFILE") != nullptr;
+    const bool print_profile = diagnostic("RELP_EXACT_PROFILE");
     const size_t pairs = (size_t)std::max(1, n - n_art) * m;
     u64* d_price_a = nullptr;   // (sized per limb count below)
     int* d_price_bits = dalloc<int>(pairs, owned);
@@ -2372,7 +2372,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
                    d_T, d_T_carry, d_T_words, d_Tx, d_Tx_carry, d_Tx_words, d_xt_bits, mfma_update ? 1 : 0};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
-        // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  RELP_EXACT_GRID: A/B hook.
+        // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
         // ... and two per CU where a pivot is milliseconds of arithmetic (25FV47 from 64 limbs on: 50 -> 39 s; at one wave per SIMD the
         // passes wait on memory and on scratch) -- not below: the barriers of 512 workgroups cost SCORPION and E226 a tenth of a second.
@@ -2380,7 +2380,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         // ... and at most one per two CUs for the mid-size LPs, whose pivot is a fraction of a millisecond since the round-4 rework: the
         // barriers of 256 workgroups (25 us each, fifteen a pivot) were a third of it (E226 0.38 -> 0.33 s, BRANDY 0.52 -> 0.41 s).
         else if ((double)m * m * limbs < 8e6) grid = std::min(grid, 128);
-        if (const char* forced = getenv("RELP_EXACT_GRID")) grid = std::max(1, std::min(EX_MAX_GRID, atoi(forced)));
+        if (forced_grid > 0) grid = std::max(1, std::min(EX_MAX_GRID, forced_grid));
         void* kernel = nullptr;
         switch (limbs) {
             case 1: kernel = (void*)exact_simplex_kernel<1>; break;

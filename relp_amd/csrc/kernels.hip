@@ -3968,10 +3968,7 @@ void launch_residual(const DeviceLP& d, const double* T, double* S, hipStream_t 
     hipLaunchKernelGGL(residual_kernel, dim3(d.m), dim3(256), 0, s, d, T, S);
 }
 bool gemm_row_lists_supported();
-static bool use_mfma_gemm() {
-    static const bool value = [] { const char* e = getenv("RELP_GEMM"); return !(e && std::string(e) == "vector"); }();
-    return value;  // RELP_GEMM=vector selects the plain-FMA kernel (A/B measurements)
-}
+static bool use_mfma_gemm() { return !thread_tuning().has(RELP_SW_GEMM_VECTOR); }  // (the switch selects the plain-FMA kernel: A/B measurements)
 __global__ void __launch_bounds__(256) copy_rows_kernel(const double* src, double* dst, int m, int ld, const int* row_list, int n_rows) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;

@@ -450,7 +450,7 @@ bool LuFactors::upload(const HostLU& factors, int max_updates, hipStream_t strea
     if (nu > cap_u_ || cap_u_ == 0) { cap_u_ = nu + nu / 2 + 256; layout_changed = true; }
     const size_t cl = cap_l_, cu = cap_u_;
     // ---- host: the four orientations and their task lists -----------------------------------------------------------------
-    static const bool time_parts = getenv("RELP_TIME_REFACTOR") != nullptr;
+    static const bool time_parts = diagnostic("RELP_TIME_REFACTOR");
     thread_local double part_seconds[5] = {0, 0, 0, 0, 0};  // (diagnostic sums per calling thread: handles of a batch refactorise concurrently)
     thread_local long long uploads = 0;
     auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -2473,7 +2473,7 @@ void LuBasis::factor_and_upload() {
 }
 // false: the kernel gave up for a reason other than singularity (the caller factorises on the host)
 bool LuBasis::factor_on_device(const std::vector<int>& cs, const std::vector<int>& rows, const std::vector<double>& vals, HostLU& f) {
-    if (getenv("RELP_BI_FACTOR_HOST") || m_ > 65535) return false;
+    if (thread_tuning().has(RELP_SW_BI_FACTOR_HOST) || m_ > 65535) return false;
     const int m = m_;
     const size_t nnz = rows.size();
     size_t cap = 4 * nnz + 8 * (size_t)m + 4096;

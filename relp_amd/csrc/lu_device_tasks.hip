@@ -614,7 +614,7 @@ void launch_lu_invert(const LuFactorOut& factors, const LuInverseWork& iw_in, co
     LuInverseWork iw = iw_in;
     // (rows go to the waves by a fixed map, row k to wave k mod 16; RELP_LUI_CLAIM_ROWS=1: claimed from a counter instead -- measured slower,
     //  the claim is an LDS atomic every lane of the wave takes part in: 1.42 M against 1.22 M cycles for the L^-1 block of 25FV47)
-    iw.static_rows = getenv("RELP_LUI_CLAIM_ROWS") ? 0 : 1;
+    iw.static_rows = thread_tuning().has(RELP_SW_LUI_CLAIM_ROWS) ? 0 : 1;
     bool in_lds = false;
     const size_t lds = lu_invert_lds_bytes(iw.m, &in_lds);
     static PerDeviceOnce once;

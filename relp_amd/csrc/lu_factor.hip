@@ -28,7 +28,7 @@ void LuFactorScratch::reserve(int m, size_t nnz_basis, size_t cap_l, size_t cap_
     cap_u_ = std::max(cap_u_, cap_u);
     cap_inv_ = std::max(cap_inv_, cap_inverse);
     size_t cap_w = std::min<size_t>((size_t)1 << 27, 6 * nnz_ + 16 * (size_t)m + 4096);
-    if (const char* limit = getenv("RELP_LUF_ARENA_CAP")) cap_w = std::max<size_t>(64, (size_t)atoll(limit));  // test hook: an arena the basis outgrows
+    if (thread_tuning().luf_arena_cap > 0) cap_w = std::max<size_t>(64, (size_t)thread_tuning().luf_arena_cap);  // test hook: an arena the basis outgrows
     size_t offset = 0;
     auto take = [&](size_t bytes) {
         offset = (offset + 63) & ~size_t(63);
@@ -1034,8 +1034,8 @@ void launch_lu_factor(const LuFactorSource& src, const LuFactorWork& w, const Lu
     LuFactorWork ww = w;
     // (targets go to the waves by a fixed map; RELP_LUF_CLAIM_TARGETS=1 lets the waves claim them from a counter instead -- balanced, but
     //  the claim, an LDS atomic every lane of the wave takes part in, costs more than the imbalance: 2.0 M against 0.96 M cycles on 25FV47)
-    ww.fixed_target_map = getenv("RELP_LUF_CLAIM_TARGETS") ? 0 : 1;
-    ww.score_slack = getenv("RELP_LUF_SLACK") ? std::max(1, atoi(getenv("RELP_LUF_SLACK"))) : 16;  // (A/B hook; see lu_factor.hpp)
+    ww.fixed_target_map = thread_tuning().has(RELP_SW_LUF_CLAIM_TARGETS) ? 0 : 1;
+    ww.score_slack = thread_tuning().luf_slack > 0 ? thread_tuning().luf_slack : 16;  // (A/B hook; see lu_factor.hpp)
     ww.cap_l = o.cap_l;
     ww.cap_u = o.cap_u;
     static PerDeviceOnce once;
@@ -1046,13 +1046,13 @@ void launch_lu_factor(const LuFactorSource& src, const LuFactorWork& w, const Lu
     const size_t m8 = ((size_t)w.m * sizeof(int) + 7) & ~size_t(7);
     const size_t level1 = (size_t)w.m * sizeof(double) + 8 * m8, level2 = level1 + 7 * m8 + m8 + 8;
     const size_t budget = (size_t)140 * 1024;
-    static const int forced = getenv("RELP_LUF_LDS") ? atoi(getenv("RELP_LUF_LDS")) : -1;  // diagnostic: 0 keeps every work array in global memory
+    const int forced = thread_tuning().luf_lds > 0 ? thread_tuning().luf_lds - 1 : -1;  // diagnostic: 0 keeps every work array in global memory
     int lds_level = level2 <= budget ? 2 : level1 <= budget ? 1 : 0;
     if (forced >= 0) lds_level = std::min(lds_level, forced);
     // what LDS the per-row arrays leave holds the two arenas of the active sub-matrix (12 bytes per entry and arena) once it fits
     int arena_lds = 0;
-    if (lds_level == 2 && !getenv("RELP_LUF_NO_LDS_ARENA")) arena_lds = (int)(((budget - level2) / 24) & ~size_t(63));
-    if (const char* limit = getenv("RELP_LUF_LDS_ARENA")) arena_lds = std::min(arena_lds, atoi(limit) & ~63);  // test hook: a small arena (spills)
+    if (lds_level == 2 && !thread_tuning().has(RELP_SW_LUF_NO_LDS_ARENA)) arena_lds = (int)(((budget - level2) / 24) & ~size_t(63));
+    if (thread_tuning().luf_lds_arena > 0) arena_lds = std::min(arena_lds, thread_tuning().luf_lds_arena & ~63);  // test hook: a small arena (spills)
     if (arena_lds < 256) arena_lds = 0;
     const size_t lds = (lds_level == 2 ? level2 : lds_level == 1 ? level1 : 0) + (size_t)arena_lds * 24 + 64;
     if (lds_level == 2) hipLaunchKernelGGL(lu_factor_kernel<2>, dim3(1), dim3(LUF_THREADS), lds, stream, src, ww, o, threshold, reference_ties, dense_tail, arena_lds);

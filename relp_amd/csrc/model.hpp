@@ -6,6 +6,7 @@
 // `column(j)`, `cost_value(j)`, `right_hand_side()`, `bound_row_index(j)`, `nr_rows()`, `nr_columns()`,
 // `pivot_element_indices()` and `reconstruct_solution()` with identical results.
 #pragma once
+#include <cstdlib>
 #include <algorithm>
 #include <string>
 #include <utility>
@@ -14,6 +15,10 @@
 #include "rat.hpp"
 
 namespace relp {
+// Diagnostics on stderr (timelines, the presolve's overflow report): the ONE place the library reads the environment.  They print;
+// they never change what is computed.  RELP_TIME_SOLVE, RELP_TIME_UPLOAD, RELP_TIME_CERTIFY, RELP_TIME_REFACTOR, RELP_PRESOLVE_DEBUG,
+// RELP_EXACT_PROFILE.
+inline bool diagnostic(const char* name) { return std::getenv(name) != nullptr; }
 
 struct SparseColumn {
     std::vector<int> index;  // sorted, unique rows

@@ -361,7 +361,7 @@ static StandardForm standardize_at_level(GeneralInput general, int presolve_leve
                 presolve(gp, bit_limit);
                 if (gp.variables.empty() || gp.b.empty())
                     throw std::runtime_error("presolve: the problem was solved completely (no rows or columns remain)");
-                if (getenv("RELP_PRESOLVE_DEBUG")) {  // diagnostic: which quantities of the presolved LP do not fit 128-bit rationals
+                if (diagnostic("RELP_PRESOLVE_DEBUG")) {  // diagnostic: which quantities of the presolved LP do not fit 128-bit rationals
                     int bounds = 0, coefficients = 0, rhs = 0, ranges = 0, fixed = 0, removed_n = 0;
                     size_t widest = 0;
                     auto fits = [&](const BigRat& v, int& counter) {

@@ -144,7 +144,7 @@ void Solver::load(StandardForm&& form) {
 // and makes the pricing pass one uniform CSC sweep.
 void Solver::upload() {
     const MatrixData& md = form_.data;
-    const bool timing = getenv("RELP_TIME_UPLOAD") != nullptr;  // diagnostic: where the one-off load time goes
+    const bool timing = diagnostic("RELP_TIME_UPLOAD");  // diagnostic: where the one-off load time goes
     double t_last = now_seconds();
     auto tick = [&](const char* what) {
         if (!timing) return;
@@ -157,10 +157,11 @@ void Solver::upload() {
     // slack columns (matrix_data.rs:104-145) become upper bounds of the structurals and the range slacks.
     bounded_ = opt_.implicit_bounds != 0 && md.nr_variable_bounds() > 0;
     // relp_options first; the environment variables of rounds 1-3 still override (A/B runs without a new handle's options)
-    const bool want_f64_block = getenv("RELP_DENSE_F64") != nullptr || (opt_.dense_storage == RELP_DENSE_DOUBLE && !getenv("RELP_DENSE_F32"));
-    const bool want_f32_block = !want_f64_block && (getenv("RELP_DENSE_F32") != nullptr || opt_.dense_storage == RELP_DENSE_FLOAT);
-    const bool product_form_off = opt_.product_form == 1 || (getenv("RELP_ETA") && std::string(getenv("RELP_ETA")) == "0");
-    const int ftran_min_nnz_opt = getenv("RELP_FTRAN_MIN_NNZ") ? atoi(getenv("RELP_FTRAN_MIN_NNZ")) : (opt_.ftran_min_nnz > 0 ? opt_.ftran_min_nnz : 1024);
+    const bool want_f64_block = opt_.dense_storage == RELP_DENSE_DOUBLE;
+    const bool want_f32_block = opt_.dense_storage == RELP_DENSE_FLOAT;
+    const bool product_form_off = opt_.product_form == 1;
+    const int ftran_min_nnz_opt = opt_.ftran_min_nnz > 0 ? opt_.ftran_min_nnz : 1024;
+    const auto sw = [&](unsigned bit) { return (opt_.switches & bit) != 0; };
     const int m = bounded_ ? md.nr_constraints() : md.nr_rows();
     const int n_p = bounded_ ? md.col_end[3] : md.nr_columns();
     if (m < 1) throw std::runtime_error("LP without rows");
@@ -225,7 +226,6 @@ void Solver::upload() {
     // relp_options.lu_refactor, env RELP_REFACTOR=device|host.  AUTO is the host path today -- faster at every size measured.
     {
         int where = opt_.lu_refactor;
-        if (const char* env = getenv("RELP_REFACTOR")) where = std::string(env) == "device" ? RELP_REFACTOR_DEVICE : std::string(env) == "host" ? RELP_REFACTOR_HOST : where;
         device_refactor_ = lu_inverse_ && where == RELP_REFACTOR_DEVICE && m <= 65535;
     }
     // (a refactorisation on the device costs about twice the host's, so its period is the longest the kept columns allow: 25FV47 64.8 us
@@ -250,11 +250,11 @@ void Solver::upload() {
     {   // graph LPs (at most two entries per column) beyond the LDS-resident size: width-2 padded copy, 4x less padding to stream
         int longest = 0;
         for (int j = 0; j < n; ++j) longest = std::max(longest, col_start[j + 1] - col_start[j]);
-        d_.ell_w = (longest <= 2 && n_dense == 0 && price_lds_ > 160 * 1024 - 1024 && !getenv("RELP_ELL_WIDE")) ? 2 : ELL_W;
+        d_.ell_w = (longest <= 2 && n_dense == 0 && price_lds_ > 160 * 1024 - 1024 && !sw(RELP_SW_ELL_WIDE)) ? 2 : ELL_W;
     }
     // incidence columns (graph providers, examples/max_flow.rs:174-200): every value +-1 and small integer costs -- the
     // pricing pass then GENERATES the column from 8 bytes per arc (row | sign) instead of streaming 24 + 8 bytes of it
-    bool unit = d_.ell_w == 2 && !getenv("RELP_NO_GENERATED_COLUMNS");
+    bool unit = d_.ell_w == 2 && !sw(RELP_SW_NO_GENERATED_COLUMNS);
     for (size_t e = 0; unit && e < value.size(); ++e) unit = value[e] == 1.0 || value[e] == -1.0;
     for (int j = 0; unit && j < n; ++j) unit = cost2[j] == std::floor(cost2[j]) && std::fabs(cost2[j]) <= 127.0;
     const int cpb = price_columns_per_block(d_.ell_w, unit);
@@ -264,7 +264,7 @@ void Solver::upload() {
     std::vector<int> slack_of_row;
     {
         bool eligible = n_dense > 0 && opt_.pivot_rule == RELP_PIVOT_STEEPEST_EDGE && m % 2 == 0 && m <= 4096 &&
-                        !product_form_off && !getenv("RELP_NO_SLACK_IN_BTRAN") && n > sparse_first_;
+                        !product_form_off && !sw(RELP_SW_NO_SLACK_IN_BTRAN) && n > sparse_first_;
         if (eligible) {  // (the deferred product form needs the multi-block FTRAN: a column longer than its threshold)
             int longest = 0;
             for (int j = n_art; j < n; ++j) longest = std::max(longest, col_start[j + 1] - col_start[j]);
@@ -280,7 +280,7 @@ void Solver::upload() {
         if (!eligible) slack_of_row.clear();
         else price_blocks_ = btran_pass_blocks();
     }
-    dense_blocks_ = n_dense > 0 ? std::min(getenv("RELP_DENSE_BLOCKS") ? atoi(getenv("RELP_DENSE_BLOCKS")) : 256, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one workgroup per CU (96 KB of LDS each)
+    dense_blocks_ = n_dense > 0 ? std::min(opt_.dense_blocks > 0 ? opt_.dense_blocks : 256, (n_dense + 15) / 16) : 0;  // 16 waves per workgroup, one workgroup per CU (96 KB of LDS each)
     bool dense_bytes = n_dense > 0 && !want_f64_block && !want_f32_block;  // narrowest exact storage type
     for (int jd = 0; dense_bytes && jd < n_dense; ++jd)
         for (int e = col_start[n_art + jd]; dense_bytes && e < col_start[n_art + jd + 1]; ++e)
@@ -298,7 +298,7 @@ void Solver::upload() {
     for (int jd = 0; dense_floats && jd < n_dense; ++jd)
         for (int e = col_start[n_art + jd]; dense_floats && e < col_start[n_art + jd + 1]; ++e) dense_floats = (double)(float)value[e] == value[e];
     int vector_len = m;  // -pi, rho, w: zero-padded to the dense block's row count when the column-per-lane pricing reads them
-    if (n_dense > 0 && dense_lane_slots(n_dense) <= 1024 && !getenv("RELP_NO_DENSE_LANE")) {
+    if (n_dense > 0 && dense_lane_slots(n_dense) <= 1024 && !sw(RELP_SW_NO_DENSE_LANE)) {
         // column-per-lane pricing: one workgroup and one candidate slot per group of 16 columns
         d_.dense_lane = 1;
         d_.dense_ld = dense_lane_ld(m);
@@ -312,7 +312,7 @@ void Solver::upload() {
     ftran_slices_ = 0;
     // columns longer than this take the multi-block FTRAN pipeline (RELP_FTRAN_MIN_NNZ: test hook to exercise it on small LPs)
     const int ftran_min_nnz = ftran_min_nnz_opt;
-    if (max_nnz > ftran_min_nnz && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = getenv("RELP_FTRAN_SLICES") ? atoi(getenv("RELP_FTRAN_SLICES")) : std::min(64, (max_nnz + 255) / 256);  // (4096 x 8192: 8 / 16 / 32 / 64 slices = 20.8k / 21.2k / 20.8k / 19.7k pivots/s)
+    if (max_nnz > ftran_min_nnz && fast_k2_available(d_, price_blocks_ + dense_blocks_)) ftran_slices_ = opt_.ftran_slices > 0 ? opt_.ftran_slices : std::min(64, (max_nnz + 255) / 256);  // (4096 x 8192: 8 / 16 / 32 / 64 slices = 20.8k / 21.2k / 20.8k / 19.7k pivots/s)
 
     d_.col_start = dmalloc<int>(n + 1);
     d_.row_index = dmalloc<int>(nnz);
@@ -396,7 +396,7 @@ void Solver::upload() {
     }
     // unit columns of the inverse are tracked where skipping them pays: the dense pipeline and the larger sparse LPs
     // (below that the update kernel is latency bound and the extra indirection would cost a round trip)
-    d_.track_touched = (eta_mode_ || m > 2048) && !lu_mode_ && !getenv("RELP_NO_TOUCHED") ? 1 : 0;
+    d_.track_touched = (eta_mode_ || m > 2048) && !lu_mode_ && !sw(RELP_SW_NO_TOUCHED) ? 1 : 0;
     d_.touched = dmalloc<int>(m);
     d_.tlist = dmalloc<int>(m);
     RELP_HIP(hipMemsetAsync(d_.touched, 0, m * sizeof(int), stream_));
@@ -497,13 +497,13 @@ void Solver::upload() {
         upload_vec(d_.ub, ub, stream_);
         RELP_HIP(hipStreamSynchronize(stream_));
     }
-    if (!fast_k2_available(d_, price_blocks_ + dense_blocks_) && !getenv("RELP_K2_SINGLE")) {  // m > 8192: multi-workgroup ratio test
+    if (!fast_k2_available(d_, price_blocks_ + dense_blocks_) && !sw(RELP_SW_K2_SINGLE)) {  // m > 8192: multi-workgroup ratio test
         d_.k2_partd = dmalloc<double>((size_t)8 * ((m + 1023) / 1024));
         d_.k2_parti = dmalloc<int>((size_t)4 * ((m + 1023) / 1024));
     }
     // small LPs: ratio test and inverse update in one launch (pivot_fused_kernel; RELP_NO_FUSED=1 keeps the three-kernel pivot)
     fused_ = !lu_mode_ && !bounded_ && !eta_mode_ && n_dense == 0 && ftran_slices_ == 0 && !d_.track_touched && d_.ell_w == ELL_W &&
-             fused_pivot_available(d_, price_blocks_) && !getenv("RELP_NO_FUSED") && opt_.pivot_kernels != 1;
+             fused_pivot_available(d_, price_blocks_) && opt_.pivot_kernels != 1;
     if (fused_) {
         for (int k = 0; k < 2; ++k) {
             d_.state[k].ctl = dmalloc<Ctl>(1);
@@ -531,9 +531,9 @@ void Solver::upload() {
         d_.prw = dmalloc<double>((size_t)4 * m);
         RELP_HIP(hipMemsetAsync(d_.prw, 0, (size_t)4 * m * sizeof(double), stream_));
     } else if (d_.ell_w == 2) {  // generated columns: -pi from its own vector, rho_p's non-zero rows as bits (bytes beyond LDS)
-        d_.price_unit_pairs = getenv("RELP_PRICE_UNIT_PAIRS") != nullptr;
+        d_.price_unit_pairs = sw(RELP_SW_PRICE_UNIT_PAIRS);
         d_.rho_words = ((m + 127) / 128) * 4;
-        if ((size_t)d_.rho_words * 4 > 64 * 1024 || getenv("RELP_NO_RHO_BITS") || d_.price_unit_pairs) d_.rho_words = 0;
+        if ((size_t)d_.rho_words * 4 > 64 * 1024 || sw(RELP_SW_NO_RHO_BITS) || d_.price_unit_pairs) d_.rho_words = 0;
         if (d_.rho_words) {
             d_.rho_bits = dmalloc<unsigned>((size_t)2 * d_.rho_words);
             RELP_HIP(hipMemsetAsync(d_.rho_bits, 0, (size_t)2 * d_.rho_words * sizeof(unsigned), stream_));
@@ -664,7 +664,7 @@ void Solver::begin_phase_one() {
 bool Solver::crash_basis() {
     if (lu_mode_ || eta_mode_ || d_.n_dense > 0 || h_col_start_.empty() || h_row_start_.empty()) return false;
     const int m = d_.m, n = d_.n, n_art = d_.n_art;
-    const bool timing = getenv("RELP_TIME_SOLVE") != nullptr;
+    const bool timing = diagnostic("RELP_TIME_SOLVE");
     double t_last = now_seconds();
     auto tick = [&](const char* what) {
         if (!timing) return;
@@ -888,7 +888,7 @@ void Solver::set_phase(int phase) {
     // are exact: what phase one leaves is what `SteepestDescentAlongObjective::new` (pivot_rule.rs:202-219) would recompute
     // for phase two.  Recomputing costs one pass over the inverse per column pair -- fine for Netlib, 1 TB for the 1 M-arc
     // max-flow LP -- so large LPs keep the weights (after flushing the update of the last zero-level pivot).
-    const double carry_threshold = getenv("RELP_CARRY_WEIGHTS_MIN") ? atof(getenv("RELP_CARRY_WEIGHTS_MIN")) : 4e9;  // (test hook)
+    const double carry_threshold = opt_.carry_weights_min > 0.0 ? opt_.carry_weights_min : 4e9;  // (test hook)
     // (the LU carry always keeps them: recomputing is one FTRAN per non-basic column)
     const bool carry_weights = phase == 2 && phase_before == 1 && !binv_identity_ &&
                                (lu_mode_ || (double)(d_.n - d_.n_art) * (double)d_.m > carry_threshold);
@@ -965,7 +965,7 @@ void Solver::enqueue_price(int skip_weights, bool first_of_batch) {
     // ... and beyond 4096 rows as well: a workgroup prices 32 columns and would stage 3 m doubles for them, one workgroup per CU
     // (80BAU3B, m = 5746: 486 workgroups x 138 KB = 67 MB of staging against 1.5 MB of gathers; 53.8 -> 45.7 us per pivot without).
     // Between 2000 and 2800 rows the two forms are within the run-to-run noise (BNL2, CYCLE, GREENBEA).  RELP_PRICE_LDS_MAX: A/B hook.
-    static const size_t lds_max = getenv("RELP_PRICE_LDS_MAX") ? (size_t)atol(getenv("RELP_PRICE_LDS_MAX")) : (size_t)96 * 1024;
+    const size_t lds_max = opt_.price_lds_max > 0 ? (size_t)opt_.price_lds_max : (size_t)96 * 1024;
     const bool use_lds = price_lds_ <= lds_max && dense_blocks_ == 0;
     // slack_in_btran_: the BTRAN pass of the previous pivot has priced the slack columns (weights included); only the first
     // pivot of a batch has no predecessor in the batch, and its pass must not apply the weight update a second time
@@ -1046,7 +1046,7 @@ void Solver::polish(bool refresh_vectors, bool force) {
     }
     // nothing has changed since the inverse was last made exact (identity, crash basis, set_basis, the previous polish): at
     // m = 65 534 the residual pass and the two refresh passes are 34 GB each
-    if (since_polish_ == 0 && !force && !getenv("RELP_POLISH_ALWAYS")) return;
+    if (since_polish_ == 0 && !force && !(opt_.switches & RELP_SW_POLISH_ALWAYS)) return;
     const int m = d_.m;
     // dense pipeline: only the columns of the stored inverse that are not unit vectors take part (the corresponding
     // rows of S are zero and those columns of the polished inverse do not change): both GEMMs shrink by m / touched
@@ -1347,7 +1347,7 @@ void Solver::solve(relp_result* result) {
     relp_result res{};
     exact_objective.clear();
     exact_primal.reset();
-    const bool timing = getenv("RELP_TIME_SOLVE") != nullptr;  // diagnostic: host-side timeline of one solve
+    const bool timing = diagnostic("RELP_TIME_SOLVE");  // diagnostic: host-side timeline of one solve
     double t_last = t0;
     auto tick = [&](const char* what) {
         if (!timing) return;
@@ -1551,7 +1551,7 @@ void Solver::refactor_lu(bool refresh_vectors, bool settle) {
     const double threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
     // (dense tail: the last rows through a dense LU out of LDS.  It saves the factorisation its slowest rounds but makes the ends of both
     //  triangles dense, and the INVERTED triangles pay for that -- more entries per product and a serial chain in the inversion)
-    static const int dense_tail = getenv("RELP_LUF_DENSE_TAIL") ? atoi(getenv("RELP_LUF_DENSE_TAIL")) : 8;
+    const int dense_tail = opt_.luf_dense_tail > 0 ? opt_.luf_dense_tail : (opt_.luf_dense_tail < 0 ? 0 : 8);
     lu_.refactor_device(src, threshold, 0, dense_tail, d_.ctl, ST_REFACTOR_FAILED, stream_);
     binv_identity_ = false;
     if (refresh_vectors) {
@@ -1597,7 +1597,7 @@ void Solver::refactor_lu_host(bool refresh_vectors) {
     }
     LuOptions lo;
     lo.threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
-    static const bool time_parts = getenv("RELP_TIME_REFACTOR") != nullptr;
+    static const bool time_parts = diagnostic("RELP_TIME_REFACTOR");
     thread_local double part_seconds[3] = {0.0, 0.0, 0.0};
     const double t1 = now_seconds();
     HostLU f = lu_factor(m, cs.data(), rows.data(), vals.data(), lo);
@@ -1729,14 +1729,14 @@ void Solver::ratio(int column, int* row, double* alpha_out) {
 void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int first_limbs, int max_limbs, long long max_pivots,
                    int trace_capacity, int* status, int* limbs_used, long long* pivots_phase_one, long long* pivots_phase_two,
                    std::vector<int>* trace, std::string* objective, std::vector<int>* final_basis,
-                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters, int update_mode);
+                   std::vector<std::pair<int, long long>>* pivots_survived, int* redundant_rows, std::vector<ExactWidthRecord>* counters, int update_mode, int forced_grid);
 void Solver::solve_exact(int first_limbs, int max_limbs, long long max_pivots, int trace_capacity, int* status, int* limbs, long long* p1,
                          long long* p2, std::vector<int>* trace, std::string* objective, std::vector<int>* basis,
                          std::vector<std::pair<int, long long>>* survived, int* redundant_rows) {
     if (!loaded_) throw std::runtime_error("no LP loaded");
     const long long cap = max_pivots > 0 ? max_pivots : 200LL * (d_.m + d_.n) + 100000;
     exact_simplex(form_, opt_.device, stream_, first_limbs, max_limbs, cap, trace_capacity, status, limbs, p1, p2, trace, objective, basis, survived,
-                  redundant_rows, &exact_records_, getenv("RELP_EXACT_UPDATE") ? atoi(getenv("RELP_EXACT_UPDATE")) : 0);
+                  redundant_rows, &exact_records_, opt_.exact_update, opt_.exact_grid);
 }
 void Solver::last_pivot(int* phase, int* column, int* row, int* leaving) {
     const Ctl c = read_ctl();

@@ -4,6 +4,9 @@
 // carry/mod.rs:46-66, strategy/pivot_rule.rs:190-193) but keeps every array in HBM for the whole solve:
 // the host only enqueues kernels and polls a control word once per `pivots_per_launch` pivots.
 #pragma once
+#include <cstdlib>
+#include <cstring>
+#include <cstddef>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -188,6 +191,47 @@ __device__ __forceinline__ void mark_rho_row(const DeviceLP& lp, int rho_buf, in
     if (r != 0.0 && lp.rho_words) atomicOr(lp.rho_bits + (size_t)rho_buf * lp.rho_words + (j >> 5), 1u << (j & 31));
 }
 #endif
+
+// The calling thread's A/B switches and sizes (relp_options.switches and the fields beside it): set by the C ABI from the handle's
+// options for the duration of a call (capi.cpp `guarded`), read by the launch helpers that have no handle in reach (lu_factor.hip,
+// lu_device_tasks.hip, certify.hip).  Round 5: these were getenv calls; nothing that changes a kernel or a result reads the
+// environment any more.
+struct Tuning {
+    unsigned switches = 0;
+    int certify_threads = 0, luf_dense_tail = 0, luf_slack = 0, luf_lds = 0, luf_lds_arena = 0, luf_arena_cap = 0;
+    bool has(unsigned bit) const { return (switches & bit) != 0; }
+};
+inline Tuning& thread_tuning() {
+    static thread_local Tuning tuning;
+    return tuning;
+}
+inline Tuning tuning_of(const relp_options& o) {
+    Tuning t;
+    t.switches = o.switches;
+    t.certify_threads = o.certify_threads;
+    t.luf_dense_tail = o.luf_dense_tail;
+    t.luf_slack = o.luf_slack;
+    t.luf_lds = o.luf_lds;
+    t.luf_lds_arena = o.luf_lds_arena;
+    t.luf_arena_cap = o.luf_arena_cap;
+    return t;
+}
+// The caller's options into the library's struct: as many bytes as the caller's header had (relp_options.struct_size), the
+// defaults for the rest.  RELP_ERR_ARGUMENT when the struct was not initialised by relp_options_default or comes from a newer header.
+inline int32_t adopt_options(const relp_options* options, relp_options* out) {
+    relp_options_default(out);
+    if (!options) return RELP_OK;
+    const int32_t round4_size = (int32_t)(offsetof(relp_options, lu_refactor) + sizeof(int32_t));
+    if (options->struct_size < round4_size || options->struct_size > (int32_t)sizeof(relp_options)) return RELP_ERR_ARGUMENT;
+    std::memcpy(out, options, (size_t)options->struct_size);
+    out->struct_size = (int32_t)sizeof(relp_options);
+    return RELP_OK;
+}
+struct TuningScope {  // the thread's tuning for the lifetime of the object
+    Tuning saved;
+    explicit TuningScope(const Tuning& t) : saved(thread_tuning()) { thread_tuning() = t; }
+    ~TuningScope() { thread_tuning() = saved; }
+};
 
 // One run of the exact fixed-width simplex kernel (exact.hip) at one width: what `relp_get_exact_counters` reports.
 constexpr int EX_PROF_WORDS = 32;

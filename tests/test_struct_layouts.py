@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = open(os.path.join(ROOT, "include", "relp_amd.h")).read()
 INTEGRATION = open(os.path.join(ROOT, "INTEGRATION.md")).read()
 
-C_WIDTH = {"int32_t": ("i", 4), "int64_t": ("i", 8), "double": ("f", 8), "uint8_t": ("u", 1)}
-RUST_WIDTH = {"i32": ("i", 4), "i64": ("i", 8), "c_double": ("f", 8), "f64": ("f", 8), "c_int": ("i", 4), "u8": ("u", 1)}
+C_WIDTH = {"int32_t": ("i", 4), "uint32_t": ("u", 4), "int64_t": ("i", 8), "double": ("f", 8), "uint8_t": ("u", 1)}
+RUST_WIDTH = {"i32": ("i", 4), "u32": ("u", 4), "i64": ("i", 8), "c_double": ("f", 8), "f64": ("f", 8), "c_int": ("i", 4), "u8": ("u", 1)}
 
 
 def strip_c_comments(text):
@@ -56,7 +56,7 @@ def rust_struct(name):
 
 
 def ctypes_struct(cls):
-    kinds = {C.c_int32: ("i", 4), C.c_int64: ("i", 8), C.c_double: ("f", 8)}
+    kinds = {C.c_int32: ("i", 4), C.c_uint32: ("u", 4), C.c_int64: ("i", 8), C.c_double: ("f", 8)}
     fields = []
     for name, ctype in cls._fields_:
         count = 1
@@ -78,7 +78,7 @@ def test_integration_md_repr_c_structs_match_the_header(c_name, rust_name):
 def test_ctypes_classes_match_the_header():
     from relp_amd import api
     pairs = [("relp_options", api.Options), ("relp_result", api.Result), ("relp_exact_result", api.ExactResult), ("relp_stats", api.Stats),
-             ("relp_batch_worker", api.BatchWorker)]
+             ("relp_batch_worker", api.BatchWorker), ("relp_exact_width_record", api.ExactWidthRecord)]
     for c_name, cls in pairs:
         assert ctypes_struct(cls) == c_struct(c_name), c_name
     # relp_batch_entry embeds a relp_result: names in order, and the sizes add up
@@ -98,3 +98,29 @@ def test_struct_sizes_have_no_hidden_padding_surprises():
             largest = max(largest, width)
         offset = (offset + largest - 1) // largest * largest
         assert offset == C.sizeof(cls), c_name
+
+
+def test_options_struct_size_is_checked_and_an_explicit_option_beats_the_environment(monkeypatch):
+    """relp_options_default writes struct_size = sizeof(relp_options); relp_create refuses a struct that was not initialised by it
+    (advisor, round 4: an older, shorter struct used to be over-read).  The binding's mapping of the old environment hooks never
+    overrides a field the caller set -- and the library itself reads no such variable (grep: one getenv, the diagnostics switch)."""
+    from relp_amd import api
+    options = api.default_options()
+    assert options.struct_size == C.sizeof(api.Options)
+    handle = C.c_void_p()
+    stale = api.default_options()
+    stale.struct_size = 0
+    assert api.lib().relp_create(C.byref(stale), C.byref(handle)) == api.ERR_ARGUMENT
+    newer = api.default_options()
+    newer.struct_size = C.sizeof(api.Options) + 8
+    assert api.lib().relp_create(C.byref(newer), C.byref(handle)) == api.ERR_ARGUMENT
+    monkeypatch.setenv("RELP_FTRAN_MIN_NNZ", "77")
+    monkeypatch.setenv("RELP_NO_FUSED", "1")
+    monkeypatch.setenv("RELP_NO_DENSE_LANE", "1")
+    from_environment = api.default_options()
+    assert (from_environment.ftran_min_nnz, from_environment.pivot_kernels) == (77, 1) and from_environment.switches & api.SW_NO_DENSE_LANE
+    explicit = api.default_options(ftran_min_nnz=5, pivot_kernels=0, switches=0)
+    assert (explicit.ftran_min_nnz, explicit.pivot_kernels, explicit.switches) == (5, 0, 0)
+    sources = os.path.join(ROOT, "relp_amd", "csrc")
+    calls = sum(open(os.path.join(sources, name)).read().count("getenv(") for name in os.listdir(sources) if name.endswith((".hip", ".cpp", ".hpp")))
+    assert calls <= 2, calls  # model.hpp's `diagnostic` (stderr timelines only)
