@@ -932,6 +932,10 @@ __device__ __forceinline__ double price_column_wave(const ExactLP& lp, const u64
 // the vector unit (v_mad_u64_u32, full rate) gives 2.1 T/s to the compiled block products above and the update ran at 0.34
 // (tools/micro/intmul_rates.hip, profiles/r5_micro_intmul_rates.txt).
 typedef int v4i __attribute__((ext_vector_type(4)));
+#ifndef RELP_UPDATE_PASS_BLOCKS
+#define RELP_UPDATE_PASS_BLOCKS 4
+#endif
+constexpr int UPDATE_PASS_BLOCKS = RELP_UPDATE_PASS_BLOCKS;  // (build-time A/B: 4 halves the accumulators of a tile and doubles its passes)
 
 template <int L>
 struct alignas(16) UpdateLds {
@@ -996,7 +1000,13 @@ typedef __attribute__((address_space(3))) int lds_i32;
 struct UpdateTileArgs {
     const u64* x_part;  // the rows' factors -alpha~_i u, word-major with stride m
     int m;
+    unsigned long long* stamps;  // diagnostic build (-DRELP_TILE_STAMPS): cycles of one wave inside its tiles, else unused
 };
+#ifdef RELP_TILE_STAMPS
+#define TILE_STAMP(k) do { if (lane == 0 && blockIdx.x == 0 && threadIdx.x < 64) { const unsigned long long t__ = clock64(); lp.stamps[k] += t__ - t_tile; t_tile = t__; } } while (0)
+#else
+#define TILE_STAMP(k) do {} while (0)
+#endif
 // what a lane reads and writes for its entry: word w of the entry at entry[w * entry_stride], of the numerator at numerator[w * numerator_stride]
 struct UpdateTileEntry {
     const u64* entry;
@@ -1011,18 +1021,26 @@ __device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const Upda
                                              bool store, int terms, int nb64, int lane) {
     constexpr int WB = UpdateLds<L>::WB, STRIDE = UpdateLds<L>::STRIDE;
     const int m = lp.m;
+    // (the same for every lane -- and said so: left as vector values, every "is this block wanted" below became an exec mask with a
+    //  full wait on LDS behind it instead of a scalar branch)
+    nb64 = __builtin_amdgcn_readfirstlane(nb64);
+    terms = __builtin_amdgcn_readfirstlane(terms);
+#ifdef RELP_TILE_STAMPS
+    unsigned long long t_tile = clock64();
+#endif
     const int g = lane >> 4;                         // k-group of the operands, digit group of the results
     const int gq = (lane & 15) >> 2, rq = lane & 3;  // this lane's row of the Toeplitz tile: 4 gq + rq
     const bool have = row >= 0;
     const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
     int issued = 0;
-    for (int bp = 0; bp < nb64; bp += 8) {  // eight blocks of 64 digits per pass: 32 accumulator tiles
-        v4i acc[8][4];
+    constexpr int PB = UPDATE_PASS_BLOCKS;  // blocks of 64 digits per pass: 4 PB accumulator tiles
+    for (int bp = 0; bp < nb64; bp += PB) {
+        v4i acc[PB][4];
 #pragma unroll
-        for (int bl = 0; bl < 8; ++bl)
+        for (int bl = 0; bl < PB; ++bl)
 #pragma unroll
             for (int tq = 0; tq < 4; ++tq) acc[bl][tq] = v4i{0, 0, 0, 0};
-        const int kb_end = min(nb64, bp + 8);
+        const int kb_end = min(nb64, bp + PB);
         // The steps of the pass are (term, block of 64 bytes of the entries' operand) in order; eight steps' words are in flight at any
         // time (a ring of registers): with one block requested per step the tile waited for memory at every step.
         const int steps = terms * kb_end;
@@ -1038,6 +1056,7 @@ __device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const Upda
 #pragma unroll
         for (int j = 0; j < 8; ++j) fetch(j, ring[j][0], ring[j][1]);
         v4i ones_acc = {0, 0, 0, 0};
+        TILE_STAMP(26);  // the requests of the first eight steps are out
         for (int step0 = 0; step0 < steps; step0 += 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1054,21 +1073,31 @@ __device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const Upda
                     fetch(step + 8, ring[j][0], ring[j][1]);
                     ones_acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, entries, ones_acc, 0, 0, 0);
                     ++issued;
+                    // row 4 gq + rq of tile tq of block b is digit d = 64 b + 16 gq + 4 tq + rq; its k-th byte is byte d - (64 kb + 16 g + j)
+                    // of the integer = index WB - 1 - d + 64 kb + 16 g + j of the reversed string: a 4-aligned offset in copy 3 - rq.
+                    // The four fragments of block b + 1 are requested before the MFMAs of block b are issued (two sets of registers,
+                    // by the parity of the block): with a block's loads and its MFMAs back to back every block waited out the LDS
+                    // latency, 13 of the 27 us of a tile.
+                    v4i toeplitz[2][4];
+                    auto request = [&](int bl, v4i* into) {
+                        const int base = WB - 16 - 64 * (bp + bl - kb) - 16 * (gq - g);
 #pragma unroll
-                    for (int bl = 0; bl < 8; ++bl) {
-                        const int b = bp + bl;
-                        if (b >= kb && b < nb64) {
-                            // row 4 gq + rq of tile tq is digit d = 64 b + 16 gq + 4 tq + rq; its k-th byte is byte d - (64 kb + 16 g + j) of
-                            // the integer = index WB - 1 - d + 64 kb + 16 g + j of the reversed string: a 4-aligned offset in copy 3 - rq
-                            const int base = WB - 16 - 64 * (b - kb) - 16 * (gq - g);
+                        for (int tq = 0; tq < 4; ++tq) {
+                            const lds_u32* at = image + (base + 4 * (3 - tq)) / 4;
+                            into[tq] = v4i{(int)at[0], (int)at[1], (int)at[2], (int)at[3]};
+                        }
+                    };
+                    auto wanted = [&](int bl) { return bp + bl >= kb && bp + bl < nb64; };
+                    if (wanted(0)) request(0, toeplitz[0]);
 #pragma unroll
-                            for (int tq = 0; tq < 4; ++tq) {
-                                const lds_u32* at = image + (base + 4 * (3 - tq)) / 4;
-                                const v4i toeplitz = {(int)at[0], (int)at[1], (int)at[2], (int)at[3]};
-                                acc[bl][tq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(toeplitz, entries, acc[bl][tq], 0, 0, 0);
-                            }
+                    for (int bl = 0; bl < PB; ++bl) {
+                        if (bl + 1 < PB && wanted(bl + 1)) request(bl + 1, toeplitz[(bl + 1) & 1]);
+                        if (wanted(bl)) {
+#pragma unroll
+                            for (int tq = 0; tq < 4; ++tq)
+                                acc[bl][tq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(toeplitz[bl & 1][tq], entries, acc[bl][tq], 0, 0, 0);
                             issued += 4;
-                            if (b == kb) {  // the block is complete for this term: 128 * (sum of the entry's bytes - 128 each, so far)
+                            if (bp + bl == kb) {  // the block is complete for this term: 128 * (sum of the entry's bytes - 128 each, so far)
 #pragma unroll
                                 for (int tq = 0; tq < 4; ++tq)
 #pragma unroll
@@ -1079,9 +1108,10 @@ __device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const Upda
                 }
             }
         }
+        TILE_STAMP(27);  // the steps of the pass
         // this lane holds digits 64 b + 16 g + (4 tq + r) of entry (lane & 15): two words and a carry per block
 #pragma unroll
-        for (int bl = 0; bl < 8; ++bl) {
+        for (int bl = 0; bl < PB; ++bl) {
             const int b = bp + bl;
             if (b < nb64) {
                 i64 quad[4];
@@ -1103,6 +1133,7 @@ __device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const Upda
             }
         }
     }
+    TILE_STAMP(28);  // words and carries out
     if (store && g == 0) *at_entry.words = 8 * nb64;
     return issued;
 }
@@ -1203,7 +1234,7 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, waves = T / WAVE;
         const int e16 = lane & 15;
         int issued = 0;
-        const UpdateTileArgs tile_args{lp.x_part, m};
+        const UpdateTileArgs tile_args{lp.x_part, m, lp.prof};
         const lds_u32* toeplitz_lds = (const lds_u32*)&s_update.toeplitz[0][0][0];
         const lds_i32* prefix_lds = (const lds_i32*)&s_update.prefix[0][0];
         __syncthreads();
@@ -2414,6 +2445,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                         prof[12], (double)prof[16], (double)prof[17]);
                 for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 1e5);
                 fprintf(stderr, " | ratio test: %llu pivots with near-tied rows (%llu rows in all)", prof[24], prof[25]);
+#ifdef RELP_TILE_STAMPS
+                fprintf(stderr, " | one wave's tiles, M cycles: requests %.1f, steps %.1f, epilogue %.1f, tiles %llu", prof[26] / 1e6, prof[27] / 1e6, prof[28] / 1e6, prof[29]);
+#endif
                 fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f\n", prof[20] / 1e5, prof[21] / 1e5, prof[22] / 1e5, prof[23] / 1e5);
             }
             if (counters) {
