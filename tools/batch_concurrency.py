@@ -28,6 +28,7 @@ parser.add_argument("--certify", type=int, default=1)
 parser.add_argument("--lu-refactor", type=int, default=0, help="relp_options.lu_refactor for the LU carries: 1 = the refactorisation kernels on the device")
 args = parser.parse_args()
 
+relp_amd.Solver().close()  # (HIP comes up on this thread: under rocprofv3 the workers' concurrent first calls crash the tool)
 expected = json.load(open(os.path.join(ROOT, "tests", "golden", "netlib_expected.json")))
 names = sorted(n for n, e in expected.items() if os.path.exists(os.path.join(ROOT, "data", "netlib", n + ".SIF"))
                and (not e["ignored"] or "intensive" in e["ignored"]))
