@@ -70,7 +70,8 @@ def ctypes_struct(cls):
 
 
 @pytest.mark.parametrize("c_name,rust_name", [("relp_options", "RelpOptions"), ("relp_result", "RelpResult"),
-                                              ("relp_exact_result", "RelpExactResult"), ("relp_bi_options", "RelpBiOptions")])
+                                              ("relp_exact_result", "RelpExactResult"), ("relp_bi_options", "RelpBiOptions"),
+                                              ("relp_exact_width_record", "RelpExactWidthRecord")])
 def test_integration_md_repr_c_structs_match_the_header(c_name, rust_name):
     assert rust_struct(rust_name) == c_struct(c_name)
 
