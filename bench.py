@@ -1229,7 +1229,7 @@ def main():
     parser.add_argument("--no-certify", action="store_true", help="25fv47: leave the exact certificate out of the timed step (A/B only)")
     parser.add_argument("--carry", type=int, default=0, choices=[0, 1, 2],
                         help="0 explicit inverse, 1 LU + Forrest-Tomlin, 2 LU through the inverses of its triangles + product-form updates (relp_options.carry)")
-    parser.add_argument("--lu-refactor", type=int, default=0, choices=[0, 1, 2], help="LU carries: 0 automatic, 1 refactorisation kernels on the device, 2 host core (relp_options.lu_refactor)")
+    parser.add_argument("--lu-refactor", type=int, default=0, choices=[0, 1, 2, 3], help="LU carries: 0 automatic, 1 refactorisation kernels on the device, 2 host core (relp_options.lu_refactor)")
     parser.add_argument("--recorded-exact-25fv47", action="store_true", help="quote the recorded 25FV47 exact run (profiles/r4_exact_25fv47_128_limbs.txt) instead of measuring it")
     parser.add_argument("--presolve", action="store_true", help="apply the reference's presolve before standardisation (its harness order)")
     parser.add_argument("--concurrency", type=int, default=4, help="netlib batch: LPs in flight per GPU")

@@ -86,7 +86,13 @@ typedef enum relp_lu_refactor {
                                   independent pivots per round, inversion of the two triangles, slot records -- no basis read-back, no
                                   upload; RELP_CARRY_LU_INVERSE only (the Forrest-Tomlin carry factorises on the host); what the
                                   kernels cannot take (a row of more than 256 entries, a capacity) falls back to the host path */
-    RELP_REFACTOR_HOST = 2     /* one host core: Markowitz + inversion + task lists, one upload (rounds 2-3) */
+    RELP_REFACTOR_HOST = 2,    /* one host core: Markowitz + inversion + task lists, one upload (rounds 2-3) */
+    RELP_REFACTOR_DEVICE_ASYNC = 3  /* round 5: the same kernels on a SECOND stream, into a second set of factor arrays, while the
+                                  pivots go on with the old factors: the pivot kernel logs the row factors of its etas from the
+                                  moment the basis is snapshotted, and when the new factors are ready a replay kernel folds the
+                                  logged etas (at most 40) into their product form -- B_now^-1 = E_k ... E_1 B_snapshot^-1 -- and the
+                                  handle swaps sets.  RELP_CARRY_LU_INVERSE with its four vectors in LDS (m <= ~4300); anything
+                                  else, and any refactorisation the kernels give up on, takes the synchronous paths above */
 } relp_lu_refactor;
 
 /* A/B switches of the kernels (`relp_options.switches`; tests and measurements -- all clear = what the library would choose).

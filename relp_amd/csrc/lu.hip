@@ -83,7 +83,7 @@ struct LuLayout {
     } co[4];
     size_t compact_begin, compact_end, upload_bytes;
     size_t app, o_applen, o_appslot, o_appval, o_scs, o_scl, o_scrow, o_scval, o_T, o_trail, o_slotof, o_eta_start, o_eta_pivot, o_eta_idx, o_eta_val;
-    size_t o_eta_mf, o_eta_of, o_eta_first, o_eta_prev, o_eapp_len, o_eapp_eta, o_eapp_val, o_spike, pf_ld, o_pf_m, o_pf_slot, o_pf_col_of, o_state;
+    size_t o_eta_mf, o_eta_of, o_eta_first, o_eta_prev, o_eapp_len, o_eapp_eta, o_eapp_val, o_spike, pf_ld, o_pf_m, o_pf_slot, o_pf_col_of, o_state, o_log_factor, o_log_p;
     size_t device_bytes;
 };
 
@@ -113,7 +113,57 @@ __global__ void __launch_bounds__(256) lu_init_kernel(DeviceLU lu) {
         lu.state[LU_ETA_TOP] = 0;
         lu.state[LU_FLAGS] = 0;
         lu.state[LU_PF_COUNT] = 0;
+        lu.state[LU_LOG_ON] = 0;
+        lu.state[LU_LOG_COUNT] = 0;
         lu.eta_start[0] = 0;
+    }
+}
+
+// ---- the refactorisation beside the pivots (round 5) ---------------------------------------------------------------------------
+__global__ void lu_start_log_kernel(DeviceLU lu) {
+    lu.state[LU_LOG_COUNT] = 0;
+    lu.state[LU_LOG_ON] = 1;
+}
+// The etas logged on `old` folded into the product form of `fresh` (factors of the basis at the start of the log; its M is the
+// identity): for every logged pivot (row factors f, slot p)  M[s][c] -= f_s M[p][c]  over the kept columns, and a new column
+// e_p - f for p when it has none -- the same arithmetic, in the same order, as the pivot kernel's fold.  One workgroup.
+__global__ void __launch_bounds__(1024) lu_replay_kernel(DeviceLU fresh, DeviceLU old) {
+    __shared__ double s_row_p[LU_MAX_SLOTS + 1];
+    __shared__ int s_k;
+    const int tid = threadIdx.x, T = blockDim.x, m = fresh.m;
+    const int count = min(old.state[LU_LOG_COUNT], LU_LOG_CAPACITY);
+    if (tid == 0) s_k = fresh.state[LU_PF_COUNT];
+    __syncthreads();
+    for (int e = 0; e < count; ++e) {
+        const int p = old.log_p[e];
+        const double* f = old.log_factor + (size_t)e * old.pf_ld;
+        const int k = s_k;
+        const int have = fresh.pf_col_of[p];
+        const int k_new = have < 0 ? k + 1 : k;
+        if (tid < k) s_row_p[tid] = fresh.pf_M[(size_t)tid * fresh.pf_ld + p];
+        if (tid == k) s_row_p[k] = 1.0;  // (the new column starts as e_p)
+        __syncthreads();
+        for (int c = 0; c < k_new; ++c) {
+            double* column = fresh.pf_M + (size_t)c * fresh.pf_ld;
+            const double mp_c = s_row_p[c];
+            for (int s = tid; s < m; s += T) {
+                const double before = c < k ? column[s] : (s == p ? 1.0 : 0.0);
+                column[s] = before - f[s] * mp_c;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (have < 0) {
+                fresh.pf_slot[k] = p;
+                fresh.pf_col_of[p] = k;
+            }
+            s_k = k_new;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        fresh.state[LU_PF_COUNT] = s_k;
+        fresh.state[LU_N_UPDATES] = count;
     }
 }
 
@@ -365,6 +415,8 @@ LuLayout compute_layout(int m, int max_updates, bool inverse_factors, size_t cl,
     L.o_pf_m = c.take<double>(inverse_factors ? L.pf_ld * max_updates : 0);
     L.o_pf_slot = c.take<int>(max_updates); L.o_pf_col_of = c.take<int>(m);
     L.o_state = c.take<int>(LU_STATE_WORDS);
+    L.o_log_factor = c.take<double>(inverse_factors ? L.pf_ld * LU_LOG_CAPACITY : 0);
+    L.o_log_p = c.take<int>(LU_LOG_CAPACITY);
     L.device_bytes = c.offset;
     return L;
 }
@@ -402,6 +454,8 @@ DeviceLU bind_layout(const LuLayout& L, char* dev_, int m, int max_updates, int 
     d.pf_ld = (int)L.pf_ld;
     d.pf_slot = I(L.o_pf_slot);
     d.pf_col_of = I(L.o_pf_col_of);
+    d.log_factor = inverse_factors ? D(L.o_log_factor) : nullptr;
+    d.log_p = I(L.o_log_p);
     for (int k = 0; k < 4; ++k) {
         LuTasks& t = d.tasks[k];
         auto GI = [&](size_t o) { return (lu_gptr_i32) reinterpret_cast<const int*>(dev_ + o); };
@@ -705,6 +759,47 @@ void LuFactors::refactor_device(const LuFactorSource& src, double threshold, int
     launch_lu_invert(out, iw, scratch_.work().info, stream);
     launch_lu_pack_inverse(d_, iw, ctl, failed_status, stream);
     hipLaunchKernelGGL(lu_init_kernel, dim3((d_.m + 255) / 256), dim3(256), 0, stream, d_);
+}
+
+// |B x - v| for the basis as it stands: one workgroup, the products accumulated in LDS (m doubles), x = what the new factors and
+// the replayed etas make of the probe v.  The replayed etas were computed with the OLD factors, so their rounding errors reach the
+// new inverse and from there the next cycle's etas: left alone the residual grows from cycle to cycle (25FV47: 1e-10 -> 1e-4 in
+// thirty swaps, then a singular basis); the host swaps only while this stays small and factorises synchronously when it does not.
+__global__ void __launch_bounds__(1024) lu_probe_fill_kernel(double* v, int m) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) v[i] = 1.0 + 0.01 * (i % 17);
+}
+__global__ void __launch_bounds__(1024) lu_basis_residual_kernel(const int* col_start, const int* row_index, const double* value, const int* basis, const int* flipped,
+                                                                const double* x, const double* v, int m, double* out) {
+    extern __shared__ double s_back[];
+    __shared__ double s_max[1024 / WAVE];
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int i = tid; i < m; i += T) s_back[i] = -v[i];
+    __syncthreads();
+    for (int k = tid; k < m; k += T) {
+        const int j = basis[k];
+        const double xk = (flipped && flipped[j]) ? -x[k] : x[k];
+        for (int e = col_start[j]; e < col_start[j + 1]; ++e) atomicAdd(&s_back[row_index[e]], value[e] * xk);
+    }
+    __syncthreads();
+    double worst = 0.0;
+    for (int i = tid; i < m; i += T) worst = fmax(worst, fabs(s_back[i]));
+    for (int d = WAVE / 2; d > 0; d /= 2) worst = fmax(worst, __shfl_xor(worst, d));
+    if ((tid & (WAVE - 1)) == 0) s_max[tid / WAVE] = worst;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < T / WAVE; ++w) worst = fmax(worst, s_max[w]);
+        out[0] = worst;
+    }
+}
+void launch_lu_probe_fill(double* v, int m, hipStream_t s) { hipLaunchKernelGGL(lu_probe_fill_kernel, dim3(4), dim3(1024), 0, s, v, m); }
+void launch_lu_basis_residual(const int* col_start, const int* row_index, const double* value, const int* basis, const int* flipped, const double* x, const double* v,
+                              int m, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(lu_basis_residual_kernel, dim3(1), dim3(1024), (size_t)m * sizeof(double), s, col_start, row_index, value, basis, flipped, x, v, m, out);
+}
+
+void LuFactors::start_log(hipStream_t stream) { hipLaunchKernelGGL(lu_start_log_kernel, dim3(1), dim3(1), 0, stream, d_); }
+void LuFactors::replay_log_of(const LuFactors& old, hipStream_t stream) {
+    hipLaunchKernelGGL(lu_replay_kernel, dim3(1), dim3(1024), 0, stream, d_, old.d_);
 }
 
 // LDS of the solve kernels: the two vectors (16 bytes per row), the mask of the replaced positions, one count per 64 rows for
@@ -2102,8 +2197,15 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
             // (one wave reduction per column -- a thread per row with eight sums at a time has every wave reduce every sum: 18
             // instructions per sum and wave) and writes the column back with the eta folded in; a column belongs to one wave, so
             // the sums and the fold need no barrier between them.  The row factors (alpha_s - [s == p]) / alpha_p wait in x3.
-            if (do_update)
-                for (int s = tid; s < m; s += T) sh.x3[s] = (sh.x2[s] - (s == p ? 1.0 : 0.0)) * inv_ap;
+            // (the eta is logged for every pivot made on the BASIS while the next factors are on their way -- also for the one that
+            //  finds the update slots full: it changes the basis and leaves the factors as they are, lu.hpp)
+            const bool logging = lu.state[LU_LOG_ON] != 0 && lu.state[LU_LOG_COUNT] < LU_LOG_CAPACITY;
+            if (do_update || logging)
+                for (int s = tid; s < m; s += T) {
+                    const double factor = (sh.x2[s] - (s == p ? 1.0 : 0.0)) * inv_ap;
+                    if (do_update) sh.x3[s] = factor;
+                    if (logging) lu.log_factor[(size_t)lu.state[LU_LOG_COUNT] * lu.pf_ld + s] = factor;
+                }
             __syncthreads();
             for (int c = wave; c < k_new; c += nwaves) {
                 const gmut_f64 column = M + (size_t)c * lu.pf_ld;
@@ -2196,6 +2298,11 @@ __global__ void __launch_bounds__(LU_THREADS) lu_pivot_kernel(DeviceLP lp, Devic
             }
             lu.state[LU_PF_COUNT] = k_new;
             lu.state[LU_N_UPDATES] = n_updates + 1;
+        }
+        if (tid == 0 && lu.state[LU_LOG_ON] != 0) {  // (past the capacity the count keeps running: the host sees that the log is incomplete)
+            const int logged = lu.state[LU_LOG_COUNT];
+            if (logged < LU_LOG_CAPACITY) lu.log_p[logged] = p;
+            lu.state[LU_LOG_COUNT] = logged + 1;
         }
     } else {
         lu_btran_block<2, INV>(lu, sh, n_updates, epoch, [&] {

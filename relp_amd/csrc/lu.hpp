@@ -31,7 +31,8 @@
 
 namespace relp {
 
-enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_PF_COUNT = 4, LU_STATE_WORDS = 16 };
+enum : int { LU_N_UPDATES = 0, LU_S_TOP = 1, LU_ETA_TOP = 2, LU_FLAGS = 3, LU_PF_COUNT = 4, LU_LOG_ON = 5, LU_LOG_COUNT = 6, LU_STATE_WORDS = 16 };
+constexpr int LU_LOG_CAPACITY = 40;  // pivots whose etas are logged while the next factors are built on another stream (round 5)
 enum : int { LU_FLAG_UNSTABLE = 1, LU_FLAG_OVERFLOW = 2 };
 constexpr int LU_MAX_SLOTS = 64;  // one wave solves T
 
@@ -125,6 +126,12 @@ struct DeviceLU {
     // folds its eta into the kept columns (m x k multiply-adds).  state[LU_PF_COUNT] = k, state[LU_N_UPDATES] = pivots since the
     // refactorisation.
     int inverse_factors = 0;
+    // Round 5, the refactorisation beside the pivots: while state[LU_LOG_ON] the pivot kernel also writes the row factors
+    // (alpha_s - [s == p]) / alpha_p of its eta and p to log_factor[state[LU_LOG_COUNT]] / log_p[..]; when the new factors (of the
+    // basis as it was when the log began) are ready, lu_replay_kernel folds the logged etas into THEIR product form:
+    // B_now^-1 = E_k ... E_1 B_snapshot^-1 whatever factors the alphas were computed with.
+    double* log_factor = nullptr;  // [LU_LOG_CAPACITY][pf_ld]
+    int* log_p = nullptr;          // [LU_LOG_CAPACITY]
     double* pf_M = nullptr;     // [max_updates][pf_ld]
     int pf_ld = 0;
     int* pf_slot = nullptr;     // [max_updates] basis slot of kept column c
@@ -148,6 +155,10 @@ public:
     // A failure leaves `failed_status` in *ctl (the pivots enqueued behind become no-ops) and its code in the info words.
     void refactor_device(const LuFactorSource& src, double threshold, int reference_ties, int dense_tail, Ctl* ctl, int failed_status,
                          hipStream_t stream);
+    // Round 5: the log of the pivots' etas on this object's factors (see DeviceLU::log_factor) and their replay onto a fresh
+    // factorisation of the basis the log began at.
+    void start_log(hipStream_t stream);
+    void replay_log_of(const LuFactors& old, hipStream_t stream);
     bool device_prepared() const { return device_prepared_; }
     const int* device_info() const { return scratch_.work().info; }  // LUF_* words of the last device refactorisation
     const DeviceLU& device() const { return d_; }
@@ -175,6 +186,10 @@ bool lu_fits_lds(int m, int max_updates, bool inverse_factors = false);  // max_
 void launch_lu_ftran(const DeviceLU& lu, const int* rows, const double* vals, int nnz, double* out, int keep_spike, hipStream_t s);
 // FTRAN of a dense right-hand side (original row order)
 void launch_lu_ftran_dense(const DeviceLU& lu, const double* rhs, double* out, hipStream_t s);
+// round 5 (the refactorisation beside the pivots): a fixed probe vector, and max |B x - v| over the basis as it stands
+void launch_lu_probe_fill(double* v, int m, hipStream_t s);
+void launch_lu_basis_residual(const int* col_start, const int* row_index, const double* value, const int* basis, const int* flipped, const double* x, const double* v,
+                              int m, double* out, hipStream_t s);
 // BTRAN of a sparse / dense row vector given per basis slot; out per original row
 void launch_lu_btran(const DeviceLU& lu, const int* slots, const double* vals, int nnz, double* out, hipStream_t s);
 void launch_lu_btran_dense(const DeviceLU& lu, const double* in_slots, double* out, hipStream_t s);

@@ -106,6 +106,12 @@ Solver::~Solver() {
     destroy_graphs();
     if (ev_a_) (void)hipEventDestroy(ev_a_);
     if (ev_b_) (void)hipEventDestroy(ev_b_);
+    if (ev_snapshot_) (void)hipEventDestroy(ev_snapshot_);
+    if (ev_refactored_) (void)hipEventDestroy(ev_refactored_);
+    if (refactor_stream_) (void)hipStreamDestroy(refactor_stream_);
+    if (d_basis_snapshot_) (void)hipFree(d_basis_snapshot_);
+    if (d_probe_) (void)hipFree(d_probe_);
+    if (d_flipped_snapshot_) (void)hipFree(d_flipped_snapshot_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -226,7 +232,8 @@ void Solver::upload() {
     // relp_options.lu_refactor, env RELP_REFACTOR=device|host.  AUTO is the host path today -- faster at every size measured.
     {
         int where = opt_.lu_refactor;
-        device_refactor_ = lu_inverse_ && where == RELP_REFACTOR_DEVICE && m <= 65535;
+        device_refactor_ = lu_inverse_ && (where == RELP_REFACTOR_DEVICE || where == RELP_REFACTOR_DEVICE_ASYNC) && m <= 65535;
+        async_refactor_ = device_refactor_ && where == RELP_REFACTOR_DEVICE_ASYNC;  // (only with the four-vector layout: checked where it starts)
     }
     // (a refactorisation on the device costs about twice the host's, so its period is the longest the kept columns allow: 25FV47 64.8 us
     //  per pivot at 47, 60.3 at 63; GREENBEA 154.5 -> 142.3)
@@ -581,7 +588,7 @@ Ctl Solver::read_ctl() {
         ++device_refactor_failures_;
         if (opt_.verbose > 0) {
             int info[LUF_INFO_WORDS];
-            RELP_HIP(hipMemcpy(info, lu_.device_info(), sizeof(info), hipMemcpyDeviceToHost));
+            RELP_HIP(hipMemcpy(info, lu().device_info(), sizeof(info), hipMemcpyDeviceToHost));
             fprintf(stderr, "[lu] the device refactorisation gave up with status %d (m %d): host fallback\n", info[LUF_STATUS], d_.m);
         }
         c.status = ST_REFACTOR;
@@ -882,7 +889,7 @@ void Solver::set_phase(int phase) {
         if (phase == 1) RELP_HIP(hipMemsetAsync(d_.cost8, 0, d_.n, stream_));
         else RELP_HIP(hipMemcpyAsync(d_.cost8, d_.cost8_2, d_.n, hipMemcpyDeviceToDevice, stream_));
     }
-    if (lu_mode_) launch_lu_pi(d_, lu_.device(), stream_);
+    if (lu_mode_) launch_lu_pi(d_, lu().device(), stream_);
     else launch_pi(d_, stream_);
     // Steepest-edge weights gamma_j = 1 + |B^-1 a_j|^2 do not depend on the costs, and the recurrences that maintain them
     // are exact: what phase one leaves is what `SteepestDescentAlongObjective::new` (pivot_rule.rs:202-219) would recompute
@@ -905,7 +912,7 @@ void Solver::set_phase(int phase) {
         } else if (gamma_ready_) {
             gamma_ready_ = false;  // the crash computed them on the host from its sparse inverse
         } else if (lu_mode_ && !binv_identity_) {
-            launch_lu_gamma(d_, lu_.device(), stream_);
+            launch_lu_gamma(d_, lu().device(), stream_);
         } else {
             launch_gamma_init(d_, binv_identity_ ? 1 : 0, stream_);
         }
@@ -1005,7 +1012,7 @@ void Solver::enqueue_ftran_ratio(int mode) {
     if (lu_mode_) {
         hipEvent_t start = nullptr, stop = nullptr;
         take_launch_timer(1, &start, &stop);
-        launch_lu_pivot(d_, lu_.device(), opt_.pivot_rule, slots, opt_.tol_pivot, ratio_delta(), skip_art, mode, refactor_period_, stream_, start, stop);
+        launch_lu_pivot(d_, lu().device(), opt_.pivot_rule, slots, opt_.tol_pivot, ratio_delta(), skip_art, mode, refactor_period_, stream_, start, stop);
         return;
     }
     if (ftran_slices_ > 0) {
@@ -1016,7 +1023,7 @@ void Solver::enqueue_ftran_ratio(int mode) {
 }
 
 void Solver::destroy_graphs() {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 4; ++k) {
         if (graph_exec_[k]) { (void)hipGraphExecDestroy(graph_exec_[k]); graph_exec_[k] = nullptr; }
         if (graph_[k]) { (void)hipGraphDestroy(graph_[k]); graph_[k] = nullptr; }
         graph_count_[k] = 0;
@@ -1024,7 +1031,7 @@ void Solver::destroy_graphs() {
 }
 
 void Solver::build_graph(int count) {
-    const int k = phase_ == 2 ? 1 : 0;
+    const int k = graph_index();
     if (graph_exec_[k] && graph_count_[k] == count) return;
     if (graph_exec_[k]) { (void)hipGraphExecDestroy(graph_exec_[k]); graph_exec_[k] = nullptr; }
     if (graph_[k]) { (void)hipGraphDestroy(graph_[k]); graph_[k] = nullptr; }
@@ -1239,7 +1246,7 @@ void Solver::set_basis(const int* basis_columns) {
     c.scan_column = std::numeric_limits<int>::max();
     write_ctl(c);
     invert_from_scratch();
-    if (lu_mode_) launch_lu_xb(d_, lu_.device(), stream_);
+    if (lu_mode_) launch_lu_xb(d_, lu().device(), stream_);
     else launch_xb(d_, stream_);
     binv_identity_ = false;
     refactors_ = 0;
@@ -1260,14 +1267,16 @@ long long Solver::iterate(long long count, int* stop_reason) {
     int reason = ST_BUDGET;
     long long iters_before = read_ctl().iters;  // one control-word read per batch: the next batch starts where this one ended
     // LU carry: a batch is one refactorisation cycle (period updates + the pivot that asks for the refactorisation)
-    const int full_batch = lu_mode_ ? refactor_period_ + 1 : std::max(1, opt_.pivots_per_launch);
+    // (the refactorisation beside the pivots needs the host's attention more often than once per cycle: batches of 16 pivots)
+    const int full_batch = async_refactor_ ? (opt_.pivots_per_launch > 0 && opt_.pivots_per_launch < 64 ? opt_.pivots_per_launch : 16) : lu_mode_ ? refactor_period_ + 1 : std::max(1, opt_.pivots_per_launch);
     while (done < count) {
+        if (async_in_flight_ && hipEventQuery(ev_refactored_) == hipSuccess) finish_async_refactor(iters_before);
         long long room = (!lu_mode_ && opt_.polish_period > 0) ? (long long)opt_.polish_period * polish_scale_ - since_polish_ : count;
         if (room <= 0) { polish(true); continue; }  // (a polish does not touch the iteration counter)
         int batch = (int)std::min<long long>({count - done, room, (long long)full_batch});
         if (opt_.use_graph && batch == full_batch) {
             build_graph(batch);
-            RELP_HIP(hipGraphLaunch(graph_exec_[phase_ == 2 ? 1 : 0], stream_));
+            RELP_HIP(hipGraphLaunch(graph_exec_[graph_index()], stream_));
             stats_.launches += 1 + (lu_mode_ ? 2LL : 3LL) * batch;
             stats_.price_launches += batch;
         } else {
@@ -1284,9 +1293,15 @@ long long Solver::iterate(long long count, int* stop_reason) {
         if (made > 0) binv_identity_ = false;  // (the phase hand-over must not take the weights of the identity basis)
         if (after.status == ST_NO_ENTERING || after.status == ST_UNBOUNDED) { reason = after.status; break; }
         if (after.status == ST_REFACTOR) {  // LU carry: should_refactor (or an unstable update) -- BasisInverse::invert
-            refactor_lu(true, /*settle=*/false);  // (the next batch ends in read_ctl)
+            // (the new factors may be on their way on the other stream: wait for them, replay, go on; else factorise now)
+            if (async_in_flight_ && finish_async_refactor(after.iters)) launch_clear_refactor_status(d_, stream_);
+            else refactor_lu(true, /*settle=*/false);  // (the next batch ends in read_ctl)
             continue;
         }
+        // the next factors are started early enough that the pivots made meanwhile fit the log of their etas
+        if (async_refactor_ && !async_in_flight_ && after.status == ST_RUNNING && lu().device().inverse_factors == 4 &&
+            since_polish_ + LU_LOG_CAPACITY + full_batch > refactor_period_)
+            start_async_refactor(after.iters);
         if (made == 0 && after.status == ST_RUNNING && !fell_back) break;  // defensive: nothing happened
     }
     if (stop_reason) *stop_reason = reason;
@@ -1312,7 +1327,7 @@ int Solver::drive_out_artificials() {
             const double one = 1.0;
             RELP_HIP(hipMemcpyAsync(d_slot, &r, sizeof(int), hipMemcpyHostToDevice, stream_));
             RELP_HIP(hipMemcpyAsync(d_one, &one, sizeof(double), hipMemcpyHostToDevice, stream_));
-            launch_lu_btran(lu_.device(), d_slot, d_one, 1, rowvec, stream_);
+            launch_lu_btran(lu().device(), d_slot, d_one, 1, rowvec, stream_);
             launch_lu_row_scan(d_, rowvec, 1e-7, stream_);
         } else {
             launch_row_scan(d_, r, 1e-7, stream_);
@@ -1517,6 +1532,7 @@ void Solver::certify(relp_result* result) {
 // ---- LU carry ---------------------------------------------------------------------------------------
 // `BasisInverse::identity` (lower_upper/mod.rs:67-76) for the start of phase one.
 void Solver::lu_identity() {
+    async_in_flight_ = false;
     const int m = d_.m;
     HostLU f;
     f.m = m;
@@ -1527,13 +1543,14 @@ void Solver::lu_identity() {
     f.u_start.assign(m + 1, 0);
     f.diag.assign(m, 1.0);
     // (device refactorisation: every array sized by bounds first, so that the layout -- and the captured graphs -- stay put)
-    if (device_refactor_ && lu_.prepare_device(m, refactor_period_ + 1, true, (size_t)h_col_start_.back())) destroy_graphs();
-    if (lu_.upload(f, refactor_period_ + 1, stream_, lu_inverse_)) destroy_graphs();  // the captured batches hold the old addresses
+    if (device_refactor_ && lu().prepare_device(m, refactor_period_ + 1, true, (size_t)h_col_start_.back())) destroy_graphs();
+    if (lu().upload(f, refactor_period_ + 1, stream_, lu_inverse_)) destroy_graphs();  // the captured batches hold the old addresses
 }
 // `BasisInverse::invert(basis columns)` (lower_upper/mod.rs:78-92; called by `Carry::change_basis` when `should_refactor`,
 // carry/mod.rs:584-591): Markowitz factorisation of the current basis on the host, one upload, and -- `refresh_vectors` -- x_B,
 // -pi and the objective recomputed from the fresh factors (what the explicit carry's polish does too).
 void Solver::refactor_lu(bool refresh_vectors, bool settle) {
+    async_in_flight_ = false;  // (factors on their way on the other stream belong to a basis this call supersedes: never swapped in)
     if (!device_refactor_) {
         refactor_lu_host(refresh_vectors);
         return;
@@ -1552,11 +1569,11 @@ void Solver::refactor_lu(bool refresh_vectors, bool settle) {
     // (dense tail: the last rows through a dense LU out of LDS.  It saves the factorisation its slowest rounds but makes the ends of both
     //  triangles dense, and the INVERTED triangles pay for that -- more entries per product and a serial chain in the inversion)
     const int dense_tail = opt_.luf_dense_tail > 0 ? opt_.luf_dense_tail : (opt_.luf_dense_tail < 0 ? 0 : 8);
-    lu_.refactor_device(src, threshold, 0, dense_tail, d_.ctl, ST_REFACTOR_FAILED, stream_);
+    lu().refactor_device(src, threshold, 0, dense_tail, d_.ctl, ST_REFACTOR_FAILED, stream_);
     binv_identity_ = false;
     if (refresh_vectors) {
-        launch_lu_xb(d_, lu_.device(), stream_);
-        launch_lu_pi(d_, lu_.device(), stream_);
+        launch_lu_xb(d_, lu().device(), stream_);
+        launch_lu_pi(d_, lu().device(), stream_);
     }
     launch_clear_refactor_status(d_, stream_);
     refactors_++;
@@ -1567,7 +1584,91 @@ void Solver::refactor_lu(bool refresh_vectors, bool settle) {
     // -pi or solve with the factors directly, so the host fallback of read_ctl runs before it does.
     if (settle) read_ctl();
 }
+// Round 5: `BasisInverse::invert` beside the pivots.  The basis is copied as it stands (stream-ordered behind the pivots made so
+// far), the pivot kernel starts logging the row factors of its etas, and the factorisation kernels run on a second stream into
+// the OTHER set of factor arrays, on other compute units than the one-workgroup pivot kernel.
+void Solver::start_async_refactor(long long iters_now) {
+    const int m = d_.m;
+    LuFactors& next = lu_sets_[lu_cur_ ^ 1];
+    if (!refactor_stream_) {
+        RELP_HIP(hipStreamCreateWithFlags(&refactor_stream_, hipStreamNonBlocking));
+        RELP_HIP(hipEventCreateWithFlags(&ev_snapshot_, hipEventDisableTiming));
+        RELP_HIP(hipEventCreateWithFlags(&ev_refactored_, hipEventDisableTiming));
+        RELP_HIP(hipMalloc(&d_basis_snapshot_, (size_t)m * sizeof(int)));
+        RELP_HIP(hipMalloc(&d_probe_, ((size_t)2 * m + 2) * sizeof(double)));  // the guard's probe v, B^-1 v and the residual
+        launch_lu_probe_fill(d_probe_, m, stream_);
+        if (bounded_) RELP_HIP(hipMalloc(&d_flipped_snapshot_, (size_t)d_.n * sizeof(*d_.flipped)));
+    }
+    if (!next.device_prepared()) next.prepare_device(m, refactor_period_ + 1, true, (size_t)h_col_start_.back());
+    RELP_HIP(hipMemcpyAsync(d_basis_snapshot_, d_.basis, (size_t)m * sizeof(int), hipMemcpyDeviceToDevice, stream_));
+    if (bounded_) RELP_HIP(hipMemcpyAsync(d_flipped_snapshot_, d_.flipped, (size_t)d_.n * sizeof(*d_.flipped), hipMemcpyDeviceToDevice, stream_));
+    lu().start_log(stream_);
+    RELP_HIP(hipEventRecord(ev_snapshot_, stream_));
+    RELP_HIP(hipStreamWaitEvent(refactor_stream_, ev_snapshot_, 0));
+    LuFactorSource src;
+    src.col_start = d_.col_start;
+    src.row_index = d_.row_index;
+    src.value = d_.value;
+    src.basis = d_basis_snapshot_;
+    src.flipped = bounded_ ? reinterpret_cast<decltype(src.flipped)>(d_flipped_snapshot_) : nullptr;
+    const double threshold = opt_.lu_pivot_threshold > 0.0 ? opt_.lu_pivot_threshold : 0.1;
+    const int dense_tail = opt_.luf_dense_tail > 0 ? opt_.luf_dense_tail : (opt_.luf_dense_tail < 0 ? 0 : 8);
+    next.refactor_device(src, threshold, 0, dense_tail, nullptr, ST_REFACTOR_FAILED, refactor_stream_);  // (a failure stays in its info words)
+    RELP_HIP(hipEventRecord(ev_refactored_, refactor_stream_));
+    async_in_flight_ = true;
+    async_iters_at_snapshot_ = iters_now;
+    if (diagnostic("RELP_TIME_REFACTOR")) fprintf(stderr, "[async] snapshot at iteration %lld, %lld updates since the last factors, set %d -> %d\n", iters_now, since_polish_, lu_cur_, lu_cur_ ^ 1);
+}
+// The new factors are ready (or are waited for): replay the logged etas onto them and swap sets.  false: they cannot be used (the
+// kernels gave up, or more pivots were made than the log holds) -- the handle stays on the old factors and the caller takes the
+// synchronous path when the device asks for a refactorisation.
+bool Solver::finish_async_refactor(long long iters_now) {
+    const double t0 = now_seconds();
+    async_in_flight_ = false;
+    LuFactors& next = lu_sets_[lu_cur_ ^ 1];
+    RELP_HIP(hipStreamWaitEvent(stream_, ev_refactored_, 0));
+    int info[LUF_INFO_WORDS];
+    int state[LU_STATE_WORDS];
+    RELP_HIP(hipMemcpyAsync(info, next.device_info(), sizeof(info), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipMemcpyAsync(state, lu().device().state, sizeof(state), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    const long long made = iters_now - async_iters_at_snapshot_;
+    if (diagnostic("RELP_TIME_REFACTOR")) {
+        fprintf(stderr, "[async] ready: status %d, pivots since the snapshot %lld, logged %d, updates on the old factors %d (kept columns %d), iters %lld\n", info[LUF_STATUS], made,
+                state[LU_LOG_COUNT], state[LU_N_UPDATES], state[LU_PF_COUNT], iters_now);
+    }
+    // (every basis change since the snapshot must be in the log: the count the kernels kept says so, the iteration counter is a
+    //  cross-check -- bound flips make iterations without basis changes)
+    if (info[LUF_STATUS] != LUF_OK || state[LU_LOG_COUNT] > LU_LOG_CAPACITY || state[LU_LOG_COUNT] > made) {
+        ++async_abandoned_;
+        if (info[LUF_STATUS] != LUF_OK) ++device_refactor_failures_;
+        return false;
+    }
+    next.replay_log_of(lu(), stream_);
+    // the guard (see lu_basis_residual_kernel): x = B^-1 v through the new factors and the replayed etas, |B x - v| over the basis now
+    launch_lu_ftran_dense(next.device(), d_probe_, d_probe_ + d_.m, stream_);
+    launch_lu_basis_residual(d_.col_start, d_.row_index, d_.value, d_.basis, bounded_ ? d_.flipped : nullptr, d_probe_ + d_.m, d_probe_, d_.m, d_probe_ + 2 * (size_t)d_.m, stream_);
+    double residual = 0.0;
+    RELP_HIP(hipMemcpyAsync(&residual, d_probe_ + 2 * (size_t)d_.m, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    RELP_HIP(hipStreamSynchronize(stream_));
+    async_worst_residual_ = std::max(async_worst_residual_, residual);
+    if (diagnostic("RELP_TIME_REFACTOR")) fprintf(stderr, "[async] |B (B^-1 v) - v| through the new factors + %d replayed etas: %.3e\n", state[LU_LOG_COUNT], residual);
+    if (!(residual <= 1e-8)) {  // (the chain of swaps has drifted: this cycle ends with a factorisation of the basis as it is)
+        ++async_abandoned_;
+        return false;
+    }
+    lu_cur_ ^= 1;
+    launch_lu_xb(d_, lu().device(), stream_);
+    launch_lu_pi(d_, lu().device(), stream_);
+    binv_identity_ = false;
+    refactors_++;
+    async_refactors_++;
+    since_polish_ = state[LU_LOG_COUNT];
+    refactor_seconds_ += now_seconds() - t0;
+    return true;
+}
 void Solver::refactor_lu_host(bool refresh_vectors) {
+    async_in_flight_ = false;
     const double t0 = now_seconds();
     const int m = d_.m;
     std::vector<int> basis(m);
@@ -1603,7 +1704,7 @@ void Solver::refactor_lu_host(bool refresh_vectors) {
     HostLU f = lu_factor(m, cs.data(), rows.data(), vals.data(), lo);
     if (f.singular) throw std::runtime_error("singular basis in the LU refactorisation");
     const double t2 = now_seconds();
-    if (lu_.upload(f, refactor_period_ + 1, stream_, lu_inverse_)) destroy_graphs();
+    if (lu().upload(f, refactor_period_ + 1, stream_, lu_inverse_)) destroy_graphs();
     if (time_parts) {
         part_seconds[0] += t1 - t0;
         part_seconds[1] += t2 - t1;
@@ -1614,8 +1715,8 @@ void Solver::refactor_lu_host(bool refresh_vectors) {
     }
     binv_identity_ = false;
     if (refresh_vectors) {
-        launch_lu_xb(d_, lu_.device(), stream_);
-        launch_lu_pi(d_, lu_.device(), stream_);  // also rewrites minus_obj from the refreshed x_B
+        launch_lu_xb(d_, lu().device(), stream_);
+        launch_lu_pi(d_, lu().device(), stream_);  // also rewrites minus_obj from the refreshed x_B
     }
     // status: REFACTOR -> RUNNING, stream-ordered (no host round trip: the refresh kernels above are still running; whoever reads
     // the control block next synchronises anyway).  A refactorisation is only ever asked for in the RUNNING state.
@@ -1624,7 +1725,7 @@ void Solver::refactor_lu_host(bool refresh_vectors) {
     since_polish_ = 0;
     refactor_seconds_ += now_seconds() - t0;
     if (opt_.verbose > 1)
-        fprintf(stderr, "[lu] refactor %lld: nnz(L) %lld nnz(U) %lld depth %d + %d\n", refactors_, lu_.nnz_l, lu_.nnz_u, lu_.depth_l, lu_.depth_u);
+        fprintf(stderr, "[lu] refactor %lld: nnz(L) %lld nnz(U) %lld depth %d + %d\n", refactors_, lu().nnz_l, lu().nnz_u, lu().depth_l, lu().depth_u);
 }
 
 // ---- fine-grained ops -------------------------------------------------------------------------------
@@ -1636,7 +1737,7 @@ void Solver::ftran(int nnz, const int* rows, const double* values, double* out) 
     RELP_HIP(hipSetDevice(opt_.device));
     RELP_HIP(hipMemcpyAsync(d_rows, rows, nnz * sizeof(int), hipMemcpyHostToDevice, stream_));
     RELP_HIP(hipMemcpyAsync(d_vals, values, nnz * sizeof(double), hipMemcpyHostToDevice, stream_));
-    if (lu_mode_) launch_lu_ftran(lu_.device(), d_rows, d_vals, nnz, d_out, 0, stream_);
+    if (lu_mode_) launch_lu_ftran(lu().device(), d_rows, d_vals, nnz, d_out, 0, stream_);
     else launch_ftran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
     RELP_HIP(hipMemcpyAsync(out, d_out, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));
@@ -1649,7 +1750,7 @@ void Solver::btran(int nnz, const int* rows, const double* values, double* out) 
     RELP_HIP(hipSetDevice(opt_.device));
     RELP_HIP(hipMemcpyAsync(d_rows, rows, nnz * sizeof(int), hipMemcpyHostToDevice, stream_));
     RELP_HIP(hipMemcpyAsync(d_vals, values, nnz * sizeof(double), hipMemcpyHostToDevice, stream_));
-    if (lu_mode_) launch_lu_btran(lu_.device(), d_rows, d_vals, nnz, d_out, stream_);
+    if (lu_mode_) launch_lu_btran(lu().device(), d_rows, d_vals, nnz, d_out, stream_);
     else launch_btran_vec(d_, d_rows, d_vals, nnz, d_out, stream_);
     RELP_HIP(hipMemcpyAsync(out, d_out, d_.m * sizeof(double), hipMemcpyDeviceToHost, stream_));
     RELP_HIP(hipStreamSynchronize(stream_));

@@ -288,6 +288,10 @@ public:
     int n_art() const { return d_.n_art; }
     bool refactors_on_device() const { return device_refactor_; }
     long long device_refactor_fallbacks() const { return device_refactor_failures_; }
+    bool refactors_asynchronously() const { return async_refactor_; }
+    long long async_refactors() const { return async_refactors_; }
+    long long async_refactors_abandoned() const { return async_abandoned_; }
+    double async_worst_residual() const { return async_worst_residual_; }
     std::string exact_objective;  // filled by certify()
     // exact x_B of the certified optimal basis (certify.hip keeps the big integers; strings are made on demand)
     std::shared_ptr<const ExactPrimal> exact_primal;
@@ -326,7 +330,22 @@ private:
     bool device_refactor_ = false;
     long long device_refactor_failures_ = 0;
     void lu_identity();                      // BasisInverse::identity
-    LuFactors lu_;
+    LuFactors lu_sets_[2];  // (two sets of factor arrays: the asynchronous refactorisation builds the next factors in the other one)
+    int lu_cur_ = 0;
+    LuFactors& lu() { return lu_sets_[lu_cur_]; }
+    const LuFactors& lu() const { return lu_sets_[lu_cur_]; }
+    // the refactorisation beside the pivots (relp_options.lu_refactor = RELP_REFACTOR_DEVICE_ASYNC; solver.hip: start_async_refactor)
+    bool async_refactor_ = false, async_in_flight_ = false;
+    hipStream_t refactor_stream_ = nullptr;
+    hipEvent_t ev_snapshot_ = nullptr, ev_refactored_ = nullptr;
+    long long async_iters_at_snapshot_ = 0;
+    int* d_basis_snapshot_ = nullptr;
+    double* d_probe_ = nullptr;          // [2 m + 2] the swap guard's probe vector, its image, the residual
+    double async_worst_residual_ = 0.0;
+    unsigned char* d_flipped_snapshot_ = nullptr;
+    long long async_refactors_ = 0, async_abandoned_ = 0;
+    void start_async_refactor(long long iters_now);
+    bool finish_async_refactor(long long iters_now);  // true: the handle now runs on the new factors
     bool lu_mode_ = false;
     bool lu_inverse_ = false;  // ... in its inverse-factor form (lu.hpp: L^-1, U^-1 and product-form updates)
     bool lu_is_identity_ = true;
@@ -360,9 +379,10 @@ private:
     hipStream_t stream_ = nullptr;
     // one captured batch of pivots per phase (the phases differ in a kernel argument); both survive across solves of the
     // same LP, so a solve pays for no capture or instantiation after the first
-    hipGraph_t graph_[2] = {nullptr, nullptr};
-    hipGraphExec_t graph_exec_[2] = {nullptr, nullptr};
-    int graph_count_[2] = {0, 0};
+    hipGraph_t graph_[4] = {nullptr, nullptr, nullptr, nullptr};      // [phase + 2 * set of LU factors]
+    hipGraphExec_t graph_exec_[4] = {nullptr, nullptr, nullptr, nullptr};
+    int graph_count_[4] = {0, 0, 0, 0};
+    int graph_index() const { return (phase_ == 2 ? 1 : 0) + 2 * lu_cur_; }
     void destroy_graphs();
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
     relp_stats stats_{};

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = {os.path.basename(p)[:-5]: json.load(open(p)) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.json"))}
 OPTIMAL = sorted(name for name, g in GOLDEN.items() if g.get("status") == "optimal" and "file" in g)
-REFACTOR_DEVICE, REFACTOR_HOST = 1, 2
+REFACTOR_DEVICE, REFACTOR_HOST, REFACTOR_DEVICE_ASYNC = 1, 2, 3
 
 
 @pytest.mark.parametrize("name", OPTIMAL)
@@ -78,4 +78,24 @@ def test_auto_is_the_host_path_today():
     solver = relp_amd.Solver(carry=CARRY_LU_INVERSE).load_mps(os.path.join(ROOT, "data", "netlib", "AFIRO.SIF"))
     solver.solve_relaxation()
     assert solver.record()["lu_refactor"] == "host"
+    solver.close()
+
+
+@pytest.mark.parametrize("name", OPTIMAL)
+def test_certified_optimum_with_the_refactorisation_beside_the_pivots(name):
+    """Round 5 (`RELP_REFACTOR_DEVICE_ASYNC`): the next factors are built on a second stream from a snapshot of the basis while the
+    pivots go on, the etas made meanwhile are logged and replayed onto the new factors, the handle swaps sets.  Every golden LP
+    reaches its bit-exact certified optimum; on the LPs long enough to need it, refactorisations really were taken that way."""
+    golden = GOLDEN[name]
+    solver = relp_amd.Solver(carry=CARRY_LU_INVERSE, lu_refactor=REFACTOR_DEVICE_ASYNC, certify=1).load_mps(os.path.join(ROOT, golden["file"]))
+    result = solver.solve_relaxation()
+    assert result.kind == relp_amd.FINITE_OPTIMUM and result.certified
+    assert solver.objective_exact() == golden["objective"]
+    record = solver.record()
+    assert "beside the pivots" in record["lu_refactor"]
+    pivots = result.pivots_phase_one + result.pivots_phase_two
+    if pivots > 200 and solver.m <= 4000:
+        assert record["async_refactors"] >= 2, record
+    again = solver.solve_relaxation()  # the handle is reusable, and what it does is deterministic in its result
+    assert again.kind == relp_amd.FINITE_OPTIMUM and again.certified and solver.objective_exact() == golden["objective"]
     solver.close()
