@@ -172,7 +172,7 @@ typedef struct relp_options {
     int32_t certify_threads;   /* host threads of the exact certificate (by the core count, at most 32) */
     int32_t exact_grid;        /* relp_solve_exact: workgroups of the cooperative launch (by the work of a pivot) */
     int32_t exact_update;      /* relp_solve_exact, the update of N = D B^-1: 0 = on the matrix cores from 32 limbs on, 1 = vector
-                                  unit only, 2 = matrix cores from 16 limbs on */
+                                  unit only */
     int32_t luf_dense_tail;    /* device refactorisation: rows of the dense tail (8); -1 = none */
     int32_t luf_slack;         /* ... Markowitz score slack of a round (16) */
     int32_t luf_lds;           /* ... 1 + the LDS level forced (1: every work array in global memory) */
@@ -383,8 +383,8 @@ int32_t relp_solve_exact(relp_handle* handle, int32_t first_limbs, int32_t max_l
 /* Measurement of the last relp_solve_exact on this handle, one record per width tried (no reference counterpart: the reference's
  * RationalBig has no fixed width).  `update_word_products_*` count the 64 x 64 -> 128-bit multiplications of the integer-preserving
  * update of N = D B^-1 (the dominant step): `needed` by the entries' bit bounds, `issued` by the waves (the integer-multiply roofline
- * of bench.py divides `issued` by `step_seconds[7]`).  step_seconds: x_B, pricing pass B, arg-max, exact weights, tournament, entering
- * column, ratio test, update of N, bookkeeping, pricing pass A.  Returns the number of records through *count (at most `capacity` copied). */
+ * of bench.py divides `issued` by `step_seconds[7]`).  step_seconds: x_B, reduced costs (y = c_B' N and every c~_j), arg-max, exact weights, tournament, entering
+ * column, ratio test, update of N, bookkeeping, products N a_j and keys of the columns with c~_j < 0.  Returns the number of records through *count (at most `capacity` copied). */
 typedef struct relp_exact_width_record {
     int32_t limbs;
     int32_t grid;                          /* workgroups of the cooperative launch */

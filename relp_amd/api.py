@@ -111,7 +111,7 @@ class ExactWidthRecord(C.Structure):
                 ("step_seconds", C.c_double * 10), ("update_word_products_needed", C.c_int64), ("update_word_products_issued", C.c_int64)]
 
 
-EXACT_STEPS = ("x_B", "pricing pass B", "arg-max", "exact weights", "tournament", "entering column", "ratio test", "update of N", "bookkeeping", "pricing pass A")
+EXACT_STEPS = ("x_B", "reduced costs", "arg-max", "exact weights", "tournament", "entering column", "ratio test", "update of N", "bookkeeping", "products and keys of the candidates")
 
 
 class BatchEntry(C.Structure):

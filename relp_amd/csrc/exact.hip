@@ -631,6 +631,11 @@ struct ExactLP {
     u64* T;               // [limbs][m columns][m rows] words (each 128-bit pair of an entry summed by one lane) ...
     int* T_carry;         // [limbs / 2][m columns][m rows] ... and what a pair carries into the next one
     int* T_words;         // [m columns][m rows] words of the entry that T holds (0: the entry was not touched; reset by the pass that reads T)
+    // round 5, pricing through y = c_B' N: c~_j = c_j D - y a_j for every column, the products N a_j only for the columns with c~_j < 0
+    u64* y;               // [m][limbs] y_k = sum_i c_B(i) N(i, k), entry-major
+    int* y_bits;          // [m] bound on the bit length of y_k
+    double* cd;           // [n] c~_j / D as a double (the key's numerator) for the columns with c~_j < 0
+    int* neg_list;        // [n] those columns, in no particular order; neg_list[n] = their count
     u64* Tx;              // [limbs][m], Tx_carry [limbs / 2][m], Tx_words [m]: the same for x~_B, the column after the last
     int* Tx_carry;
     int* Tx_words;
@@ -817,52 +822,36 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
     return awide;
 }
 
-// Pricing pass B for one column, by one wave (see the call site): c~_j word by word into ctil, its key estimate returned (0: not a
-// candidate).
-template <int L>
-__device__ __forceinline__ double price_column_wave(const ExactLP& lp, const u64* D, int j, int phase, int lane, double mD, int eD, int D_bits,
-                                                  size_t PP, int* bits_bound) {
-    const int m = lp.m;
-    const int jj = j - lp.n_art;
-    double key = 0.0;
-    const i64 cj = phase == 1 ? lp.cost1[j] : lp.cost2[j];
-    const u64 cj_mag = cj < 0 ? (u64)(-(cj + 1)) + 1 : (u64)cj;
-    const size_t base = (size_t)jj * m;
-    int widest = 0;
-    for (int i = lane; i < m; i += WAVE) {
-        const i64 cb = lp.cb_row[i];
-        if (cb != 0) widest = max(widest, lp.price_bits[base + i] + small_bits(cb));
-    }
-    for (int d = 1; d < WAVE; d *= 2) widest = max(widest, __shfl_xor(widest, d));
-    widest = max(widest, D_bits + small_bits(cj));
-    *bits_bound = widest;  // (the caller adds the log of the number of terms and flags what might not fit)
-    // (everything relative to D: the quotients are the reference's rationals, of moderate size, whatever the limbs hold)
-    double sumsq = (double)lp.weight[j];
-    for (int i0 = 0; i0 < m; i0 += WAVE) {  // in the order of the rows, by every lane alike
-        const double term = i0 + lane < m ? lp.price_term[base + i0 + lane] : 0.0;
-        const int count = min(WAVE, m - i0);
-        for (int t = 0; t < count; ++t) sumsq += __shfl(term, t);
-    }
+// sum_i cb(i) X_i for one word-major column of m integers (word k of row i at column[k * word_stride + i]), by one wave: every lane
+// streams the words of its rows through its own carry-save accumulators, the 64 partial words are added across the wave as two sums of
+// 32-bit halves; emit(k, word) is called by every lane with word k of the sum (two's complement, modulo 2^(64 L)).
+template <int L, class Emit>
+__device__ __forceinline__ void wave_cost_dot(const u64* column, size_t word_stride, const i64* cb_row, int m, int lane, int words, Emit emit) {
+    // (`words`: the sum fits that many words -- the caller's bit bound; the words above are its sign.  Sixteen rows of a word are
+    //  requested together: with four, a word of an 821-row column was four round trips one after the other, 1.3 ms per column.)
     u128 acc_p = 0, acc_q = 0;
     u64 top_p = 0, top_q = 0, borrow_lane = 0;
     u128 carry_sum = 0;
-    u64 carry_x = 0, chain = 0;
-    bool negation_carry = true;
-    LeadingWords lead;
+    u64 last = 0;
+    words = min(words, L);
 #pragma unroll L <= 8 ? L : 1
-    for (int k = 0; k < L; ++k) {
-        const u64* word_k = lp.price_a + (size_t)k * PP + base;
-        for (int i0 = lane; i0 < m; i0 += 4 * WAVE) {  // four rows in flight
-            u64 w[4];
-            i64 v[4];
+    for (int k = 0; k < words; ++k) {
+        const u64* word_k = column + (size_t)k * word_stride;
+        for (int i0 = lane; i0 < m; i0 += 16 * WAVE) {
+            u64 w[16];
+            i64 v[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int i = i0 + u * WAVE;
-                v[u] = i < m ? lp.cb_row[i] : 0;
-                w[u] = i < m ? word_k[i] : 0;
+                v[u] = i < m ? cb_row[i] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 16; ++u) {
+                const int i = i0 + u * WAVE;
+                w[u] = (i < m && v[u] != 0) ? word_k[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
                 const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
                 const u128 prod = (u128)w[u] * mag;
                 if (v[u] >= 0) {
@@ -887,8 +876,82 @@ __device__ __forceinline__ double price_column_wave(const ExactLP& lp, const u64
             hi += __shfl_xor(hi, d);
         }
         const u128 total = carry_sum + lo + ((u128)hi << 32);
-        const u64 sum_word = (u64)total;  // word k of sum_i c_B(i) (N a_j)_i
         carry_sum = total >> 64;
+        last = (u64)total;
+        emit(k, last);
+    }
+    const u64 fill = (i64)last < 0 ? ~0ull : 0ull;
+    for (int k = words; k < L; ++k) emit(k, fill);
+}
+
+// c~_j = c_j D - sum_e v_e y[r_e] for one column, by one wave, a lane per word of the sum (two words per lane at 128 limbs): the
+// lane adds the multiples of ITS word of the y's in carry-save form, then the carries, the multiple of D and the difference run
+// through the words in order (every lane the same scalar chain, the partial words fetched from their lanes).  Stores c~_j; returns
+// c~_j / D as a double when c~_j < 0 (else 0) and the bit bound of the operands.
+template <int L>
+__device__ __forceinline__ double reduced_cost_wave(const ExactLP& lp, const u64* D, int j, int phase, int lane, double mD, int eD, int D_bits, int* bits_bound) {
+    constexpr int SLOTS = (L + WAVE - 1) / WAVE;  // words per lane
+    const i64 cj = phase == 1 ? lp.cost1[j] : lp.cost2[j];
+    const u64 cj_mag = cj < 0 ? (u64)(-(cj + 1)) + 1 : (u64)cj;
+    const int e0 = lp.col_start[j], e1 = lp.col_start[j + 1];
+    u128 acc_p[SLOTS], acc_q[SLOTS];
+    u64 top_p[SLOTS], top_q[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) { acc_p[t] = acc_q[t] = 0; top_p[t] = top_q[t] = 0; }
+    int widest = 0;
+    for (int e = e0; e < e1; ++e) {  // (the same entries for every lane)
+        const int r = lp.row_index[e];
+        const i64 v = lp.value[e];
+        widest = max(widest, lp.y_bits[r] + small_bits(v));
+        const u64 mag = v < 0 ? (u64)(-(v + 1)) + 1 : (u64)v;
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const int k = lane + t * WAVE;
+            const u64 w = k < L ? lp.y[(size_t)r * L + k] : 0ull;
+            const u128 prod = (u128)w * mag;
+            if (v >= 0) {
+                acc_p[t] += prod;
+                top_p[t] += acc_p[t] < prod ? 1 : 0;
+            } else {
+                acc_q[t] += prod;
+                top_q[t] += acc_q[t] < prod ? 1 : 0;
+            }
+        }
+    }
+    widest += 32 - __clz(e1 - e0 > 1 ? e1 - e0 - 1 : 1) + 1;
+    widest = max(widest, D_bits + small_bits(cj));
+    *bits_bound = widest;
+    // the words in order: running 192-bit sums of the positive and of the negative multiples, their difference, then c_j D - that
+    u128 run_p = 0, run_q = 0;
+    u64 run_p_top = 0, run_q_top = 0, borrow = 0, carry_x = 0, chain = 0;
+    bool negation_carry = true;
+    LeadingWords lead;
+#pragma unroll L <= 8 ? L : 1
+    for (int k = 0; k < L; ++k) {
+        const int owner = k & (WAVE - 1), slot = k / WAVE;
+        u64 part[6];
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t)
+            if (t == slot) {
+                part[0] = (u64)acc_p[t]; part[1] = (u64)(acc_p[t] >> 64); part[2] = top_p[t];
+                part[3] = (u64)acc_q[t]; part[4] = (u64)(acc_q[t] >> 64); part[5] = top_q[t];
+            }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) part[c] = __shfl(part[c], owner);
+        auto add192 = [](u128& low, u64& top, u64 a0, u64 a1, u64 a2) {  // (low, top) += a0 + 2^64 a1 + 2^128 a2
+            const u128 add = (u128)a0 | ((u128)a1 << 64);
+            low += add;
+            top += a2 + (low < add ? 1 : 0);
+        };
+        add192(run_p, run_p_top, part[0], part[1], part[2]);
+        add192(run_q, run_q_top, part[3], part[4], part[5]);
+        const u64 pk = (u64)run_p, qk = (u64)run_q;
+        run_p = (run_p >> 64) | ((u128)run_p_top << 64);
+        run_q = (run_q >> 64) | ((u128)run_q_top << 64);
+        run_p_top = run_q_top = 0;
+        const u64 t = pk - qk;
+        const u64 sum_word = t - borrow;  // word k of sum_e v_e y[r_e]
+        borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
         const u128 multiple = (u128)D[k] * cj_mag + carry_x;  // word k of |c_j| D
         const u64 x_word = (u64)multiple;
         carry_x = (u64)(multiple >> 64);
@@ -909,10 +972,9 @@ __device__ __forceinline__ double price_column_wave(const ExactLP& lp, const u64
     if ((i64)lead.prev < 0) {  // D > 0: the sign of c~_j is the sign of the relative cost
         int ec = 0;
         const double mc = lead.mantissa(&ec);
-        const double cd = ldexp(mc / mD, ec - eD);
-        key = cd * cd / sumsq;
+        return ldexp(mc / mD, ec - eD);
     }
-    return key;
+    return 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1408,7 +1470,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     };
     unsigned long long products_needed = 0, products_issued = 0;  // this thread's word products in the update of N, whole run
     bool on_matrix_cores = false;  // the update of N by mfma_update_tile
-    if constexpr (L >= 16) on_matrix_cores = lp.mfma_update != 0;
+    if constexpr (L >= 32) on_matrix_cores = lp.mfma_update != 0;
     int parity = 0;  // the partial arrays of the grid reductions alternate, so that a fast workgroup never overwrites what a slow one still reads
     if (tid == 0) s_overflow = 0;
     __syncthreads();
@@ -1582,15 +1644,60 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             //  N(i, r_e) come straight from memory (word-major: one coalesced access per operand), the positive and the negative
             //  multiples run in two carry-save accumulators, their difference is stored as it appears, and nothing is held but the
             //  carries.  The bit bound comes from N_bits, the double from the two leading words gathered on the way: same numbers.)
-            for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];  // (read after pass A's barrier)
+            // Round 5: c~_j = c_j D - (c_B' N) a_j.  The row vector y = c_B' N is ONE pass over N (a wave per column); with it every
+            // c~_j is a handful of small multiples of y's entries, and the products N a_j -- what the weights need, the expensive pass: every
+            // column of N once per non-zero of its row of A -- are formed only for the columns with c~_j < 0, the only ones that can
+            // enter.  (Rounds 2-4 formed N a_j for EVERY non-basic column and c~_j from those: 3.0 + 1.5 of 25FV47's 9.7 s.)  The
+            // same integers c~_j, the same doubles for the keys of the candidates, so the same pivots.
+            for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];
+            if (leader) lp.neg_list[n] = 0;
             const int eD = s_eD;
             const double mD = s_mD;
             const int row_blocks = (m + WAVE - 1) / WAVE;
             const int lane = tid & (WAVE - 1);
-            for (long long item = gtid / WAVE; item < (long long)n_priced * row_blocks; item += GT / WAVE) {
-                const int jj = (int)(item / row_blocks), i = (int)(item - (long long)jj * row_blocks) * WAVE + lane;
-                const int j = lp.n_art + jj;
-                if (lp.pos[j] >= 0) continue;  // (the whole wave)
+            grid.sync();
+            for (int k = gtid / WAVE; k < m; k += GT / WAVE) {  // y_k, a wave per column of N
+                int widest = 0;
+                for (int i = lane; i < m; i += WAVE) {
+                    const i64 cb = lp.cb_row[i];
+                    if (cb != 0) widest = max(widest, lp.N_bits[(size_t)k * m + i] + small_bits(cb));
+                }
+                for (int d = 1; d < WAVE; d *= 2) widest = max(widest, __shfl_xor(widest, d));
+                widest += log2_ceil(m);
+                if (lane == 0) {
+                    lp.y_bits[k] = widest;
+                    flag_overflow(widest);
+                }
+                u64* yk = lp.y + (size_t)k * L;
+                wave_cost_dot<L>(lp.N + (size_t)k * m, MM, lp.cb_row, m, lane, (widest + 2 + 63) / 64, [&](int word, u64 value) {
+                    if (lane == 0) yk[word] = value;
+                });
+            }
+            grid.sync();
+            for (long long item = gtid / WAVE; item < n_priced; item += GT / WAVE) {  // c~_j, a wave per column
+                const int j = lp.n_art + (int)item;
+                double cd = 0.0;
+                if (lp.pos[j] < 0) {  // (the whole wave)
+                    int widest = 0;
+                    cd = reduced_cost_wave<L>(lp, Dw, j, phase, lane, mD, eD, D_bits, &widest);
+                    if (lane == 0) flag_overflow(widest + 1);
+                }
+                if (lane == 0) {
+                    lp.key[j] = 0.0;
+                    lp.cd[j] = cd;
+                    if (cd != 0.0) lp.neg_list[atomicAdd(&lp.neg_list[n], 1)] = j;
+                }
+            }
+            grid.sync();
+            stamp(1);
+            // Pass A for the candidates: a wave takes a column and 64 neighbouring rows and forms (N a_j)_i word by word, least significant
+            // first -- the words of the N(i, r_e) straight from memory (word-major: one coalesced access per operand), the positive and
+            // the negative multiples in two carry-save accumulators, their difference stored as it appears.  The bit bound comes from
+            // N_bits, the double from the two leading words gathered on the way.
+            const int n_negative = lp.neg_list[n];
+            for (long long item = gtid / WAVE; item < (long long)n_negative * row_blocks; item += GT / WAVE) {
+                const int c = (int)(item / row_blocks), i = (int)(item - (long long)c * row_blocks) * WAVE + lane;
+                const int j = lp.neg_list[c], jj = j - lp.n_art;
                 const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
                 const bool active = i < m;
                 const size_t pair = (size_t)jj * m + (active ? i : 0);
@@ -1606,24 +1713,26 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 }
             }
             grid.sync();
-            stamp(9);
-            // Pass B, a WAVE per column (round 4; rounds 2-3: a thread per (column, 32 rows) and then a thread per column, each adding
-            // integers held in scratch memory): c~_j = c_j D - sum_i c_B(i) (N a_j)_i word by word.  Every lane streams the words of
-            // its rows (i = lane, lane + 64, ...) through its own carry-save accumulators; the 64 partial words are added across the
-            // wave as two sums of 32-bit halves, the carry of that sum, the multiple of D and the borrow of the difference run in
-            // registers, and word k of c~_j is stored when it appears.  The weight estimate is the same sequential sum of doubles.
-            for (long long item = gtid / WAVE; item < n_priced; item += GT / WAVE) {
-                const int j = lp.n_art + (int)item;
-                double key = 0.0;
-                if (lp.pos[j] < 0) {  // (the whole wave)
-                    int widest = 0;
-                    key = price_column_wave<L>(lp, Dw, j, phase, lane, mD, eD, D_bits, PP, &widest);
-                    if (lane == 0) flag_overflow(widest + log2_ceil(m + 1));
+            // ... and their keys: the weight estimate is the sequential sum of the stored terms in the order of the rows (the same doubles
+            // as the one-workgroup form's), key = (c~_j / D)^2 / that
+            for (int c = gtid / WAVE; c < n_negative; c += GT / WAVE) {
+                const int j = lp.neg_list[c];
+                const size_t base = (size_t)(j - lp.n_art) * m;
+                double sumsq = (double)lp.weight[j];
+                for (int i0 = 0; i0 < m; i0 += WAVE) {  // in the order of the rows, by every lane alike
+                    const double term = i0 + lane < m ? lp.price_term[base + i0 + lane] : 0.0;
+                    const int count = min(WAVE, m - i0);
+                    for (int t = 0; t < count; ++t) sumsq += __shfl(term, t);
                 }
-                if (lane == 0) lp.key[j] = key;
+                const double cd = lp.cd[j];
+                if (lane == 0) lp.key[j] = cd * cd / sumsq;
+            }
+            if (leader) {  // (diagnostic: how many of the priced columns have a negative reduced cost)
+                lp.prof[30] += n_negative;
+                lp.prof[31] += 1;
             }
             if (sync_overflow()) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
-            stamp(1);
+            stamp(9);
             // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
             double best = 0.0;
             unsigned long long rank = RANK_NONE;
@@ -1987,7 +2096,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         const int n_heavy = word[7], n_rows_alpha = word[6];
-        if constexpr (L >= 16) if (on_matrix_cores) {
+        if constexpr (L >= 32) if (on_matrix_cores) {
             const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha};
             update_on_matrix_cores<L>(lp, scalars, s_c1, products_needed, products_issued);
         }
@@ -2304,6 +2413,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_bracket = dalloc<int>(std::max(n, m) + 1, owned);
     int* d_cand = dalloc<int>(std::max(n, m) + 1, owned);
     int* d_N_bits = dalloc<int>((size_t)m * m, owned);
+    int* d_y_bits = dalloc<int>((size_t)m, owned);
+    double* d_cd = dalloc<double>((size_t)n, owned);
+    int* d_neg_list = dalloc<int>((size_t)n + 1, owned);
     i64* d_cb_row = dalloc<i64>(m, owned);
     int* d_row_list = dalloc<int>((size_t)2 * m, owned);
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -2346,11 +2458,13 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), fresh);
         u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
-        // the update of N on the matrix cores (mfma_update_tile): from 32 limbs on by itself; 16 limbs where asked for
-        const bool mfma_update = limbs >= 16 && update_mode != 1 && (update_mode == 2 || limbs >= 32);
+        // the update of N on the matrix cores (mfma_update_tile): from 32 limbs on (update_mode 1: never).  (At 16 limbs -- two
+        // 64-byte blocks per integer -- the path was tried and hung on ISRAEL, unexplained; it is not compiled for that width.)
+        const bool mfma_update = limbs >= 32 && update_mode != 1;
         u64* d_T = mfma_update ? dalloc<u64>((size_t)m * m * big, fresh) : nullptr;
         int* d_T_carry = mfma_update ? dalloc<int>((size_t)m * m * (big / 2), fresh) : nullptr;
         int* d_T_words = mfma_update ? dalloc<int>((size_t)m * m, fresh) : nullptr;
+        u64* d_y = dalloc<u64>((size_t)m * big, fresh);
         u64* d_Tx = mfma_update ? dalloc<u64>((size_t)m * big, fresh) : nullptr;
         int* d_Tx_carry = mfma_update ? dalloc<int>((size_t)m * (big / 2), fresh) : nullptr;
         int* d_Tx_words = mfma_update ? dalloc<int>((size_t)m, fresh) : nullptr;
@@ -2401,7 +2515,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
-                   d_T, d_T_carry, d_T_words, d_Tx, d_Tx_carry, d_Tx_words, d_xt_bits, mfma_update ? 1 : 0};
+                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_xt_bits, mfma_update ? 1 : 0};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
@@ -2439,12 +2553,13 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         {
             unsigned long long prof[EX_PROF_WORDS];
             RELP_HIP(hipMemcpy(prof, d_prof, sizeof(prof), hipMemcpyDeviceToHost));
-            static const char* names[] = {"x_B", "pricing pass B", "arg-max + candidates", "exact weights", "tournament", "alpha", "ratio test", "update", "bookkeeping", "pricing pass A"};
+            static const char* names[] = {"x_B", "reduced costs (y = c_B' N)", "arg-max + candidates", "exact weights", "tournament", "alpha", "ratio test", "update", "bookkeeping", "products + keys of the columns with c~ < 0"};
             if (print_profile) {
                 fprintf(stderr, "[exact] %d limbs, grid %d, %d pivots, candidates %llu, update word products %.3e needed / %.3e issued:", limbs, grid, out[1] + out[2],
                         prof[12], (double)prof[16], (double)prof[17]);
                 for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f ms", names[k], prof[k] / 1e5);
                 fprintf(stderr, " | ratio test: %llu pivots with near-tied rows (%llu rows in all)", prof[24], prof[25]);
+                fprintf(stderr, " | columns with a negative reduced cost per pivot: %.1f", prof[31] ? (double)prof[30] / prof[31] : 0.0);
 #ifdef RELP_TILE_STAMPS
                 fprintf(stderr, " | one wave's tiles, M cycles: requests %.1f, steps %.1f, epilogue %.1f, tiles %llu", prof[26] / 1e6, prof[27] / 1e6, prof[28] / 1e6, prof[29]);
 #endif

@@ -2,7 +2,7 @@
 (pairs of words plus a carry per pair) into the entries of N, checked against Python integers -- carries of both signs that ripple
 through words and pairs, shifts of 64 bits and more, negation, the bit length of every magnitude (zero, -1, -(2^k) included).  The
 tiles themselves are pinned end to end by the golden pivot sequences (tests/test_gpu_exact.py runs on the matrix cores from 32 limbs on,
-and from 16 limbs under RELP_EXACT_UPDATE=2: test_whole_traces_on_the_matrix_cores_from_sixteen_limbs below)."""
+and on the vector unit only under exact_update = 1: test_whole_traces_on_the_matrix_cores_and_on_the_vector_unit below)."""
 import ctypes as C
 import json
 import os
@@ -104,19 +104,18 @@ def test_finish_pass_against_python_integers(limbs, shift, flip):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-@pytest.mark.parametrize("name", ["BLEND", "ISRAEL", "STOCFOR1", "E226"])
-def test_whole_traces_on_the_matrix_cores_from_sixteen_limbs(name, monkeypatch):
-    """The same golden pivot sequences with the update on the matrix cores from the first width that has them (16 limbs) and with the
-    vector path only: identical traces, pivot counts, final bases and optima."""
+@pytest.mark.parametrize("name", ["STOCFOR1", "SHARE1B", "E226", "BANDM", "SCSD1"])
+def test_whole_traces_on_the_matrix_cores_and_on_the_vector_unit(name, monkeypatch):
+    """The same golden pivot sequences with the update on the matrix cores (from 32 limbs on: these LPs need 32 or 64) and on the vector
+    unit only (`relp_options.exact_update = 1`): identical traces, pivot counts, final bases and optima."""
     golden = json.load(open(os.path.join(GOLDEN, name + ".json")))
     results = []
-    for mode in ("2", "1"):
-        monkeypatch.setenv("RELP_EXACT_UPDATE", mode)
-        solver = relp_amd.Solver().load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+    for mode in (0, 1):
+        solver = relp_amd.Solver(exact_update=mode).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
         got = solver.solve_exact(first_limbs=4, max_limbs=64)
         counters = solver.exact_counters()
         solver.close()
-        assert got["status"] == 1 and Fraction(got["objective"]) == Fraction(golden["objective"])
+        assert got["status"] == 1 and got["limbs"] >= 32 and Fraction(got["objective"]) == Fraction(golden["objective"])
         assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"])
         results.append((got["trace"], list(got["basis"]), got["objective"]))
         assert counters and counters[-1]["update_word_products_issued"] > 0
