@@ -582,6 +582,33 @@ __device__ int sign_of_difference(const Big<L>& a, const Big<L>& b, const Big<L>
     return s1 > 0 ? cmp : -cmp;
 }
 
+// The grid barrier of the cooperative launch.  cooperative_groups' grid.sync() costs 0.1 us per workgroup on gfx950 -- every arrival
+// is an atomic on one word: 26 us at 256 workgroups, 53 at 512 (tools/micro/grid_barrier_bench.hip, profiles/r5_micro_grid_barrier.txt)
+// -- and a pivot makes about twenty of them.  Two levels instead: the workgroups count in groups of 32 on a word of their own (64-byte
+// spaced), the last arrival of a group counts on the top word, the last arrival there publishes the generation every workgroup polls:
+// 6.6 us at 256 workgroups, 11.5 at 512.  Counters only grow (no reset to race with); thread 0 releases the workgroup's stores at
+// agent scope before it arrives and acquires after the generation moved, with the workgroup's own barrier on both sides -- the same
+// exchange test as for grid.sync() sees no stale value.  Every workgroup must call it the same number of times (`epoch` counts them).
+constexpr int EX_BARRIER_GROUP = 32;
+constexpr int EX_BARRIER_WORDS = 32 + 16 * 64;  // [0] generation, [16] top, [32 + 16 g] group g
+__device__ __forceinline__ void grid_barrier(unsigned* words, unsigned& epoch) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned g = blockIdx.x / EX_BARRIER_GROUP, groups = (gridDim.x + EX_BARRIER_GROUP - 1) / EX_BARRIER_GROUP;
+        const unsigned members = min((unsigned)EX_BARRIER_GROUP, gridDim.x - g * EX_BARRIER_GROUP);
+        const unsigned arrived = __hip_atomic_fetch_add(words + 32 + 16 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (epoch + 1) * members - 1) {  // the last of its group
+            const unsigned at_top = __hip_atomic_fetch_add(words + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (at_top == (epoch + 1) * groups - 1) __hip_atomic_store(words, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        while (__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    ++epoch;
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the LP on the device: integer columns (rows scaled), [artificials | provider columns] as in solver.hip
 // ---------------------------------------------------------------------------------------------------
@@ -641,6 +668,7 @@ struct ExactLP {
     int* Tx_words;
     int* xt_bits;         // [m] bit length of |x~_i|, kept by whoever writes an entry
     int mfma_update;      // 1: the update runs on the matrix cores
+    unsigned* barrier;    // [EX_BARRIER_WORDS] the grid barrier's counters (grid_barrier), zero at the launch
 };
 
 // out = w * v^2, unsigned, 2 L + 2 limbs: one term of the exact weight gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 of a tied candidate
@@ -1279,9 +1307,12 @@ struct UpdateScalars {
 };
 template <int L>
 __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const UpdateScalars sc, const u64* s_c1, unsigned long long& products_needed,
-                                                    unsigned long long& products_issued) {
-    namespace cg = cooperative_groups;
-    cg::grid_group grid = cg::this_grid();
+                                                    unsigned long long& products_issued, unsigned& barrier_epoch) {
+    struct {
+        unsigned* words;
+        unsigned& epoch;
+        __device__ void sync() { grid_barrier(words, epoch); }
+    } grid{lp.barrier, barrier_epoch};
     const int tid = threadIdx.x, T = blockDim.x;
     const int G = gridDim.x, block = blockIdx.x;
     const int gtid = block * T + tid, GT = G * T;
@@ -1433,8 +1464,12 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
 //  ran; held to two waves it spills 141 registers to scratch memory instead and runs.)
 template <int L>
 __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) exact_simplex_kernel(ExactLP lp) {
-    namespace cg = cooperative_groups;
-    cg::grid_group grid = cg::this_grid();
+    unsigned barrier_epoch = 0;  // grid barriers made so far (grid_barrier: the same count in every workgroup)
+    struct {
+        unsigned* words;
+        unsigned& epoch;
+        __device__ void sync() { grid_barrier(words, epoch); }
+    } grid{lp.barrier, barrier_epoch};
     __shared__ double s_key[EX_THREADS / WAVE];
     __shared__ unsigned long long s_rank[EX_THREADS / WAVE];
     __shared__ int s_overflow;
@@ -2098,7 +2133,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         const int n_heavy = word[7], n_rows_alpha = word[6];
         if constexpr (L >= 32) if (on_matrix_cores) {
             const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha};
-            update_on_matrix_cores<L>(lp, scalars, s_c1, products_needed, products_issued);
+            update_on_matrix_cores<L>(lp, scalars, s_c1, products_needed, products_issued, barrier_epoch);
         }
         if (!on_matrix_cores)
         for (long long unit = gtid; unit < (long long)n_heavy * n_rows_alpha; unit += GT) {  // N(p, k) != 0 and alpha~_i != 0: two products
@@ -2405,6 +2440,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     double* d_part_key = dalloc<double>(2 * EX_MAX_GRID, owned);
     unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * EX_MAX_GRID, owned);
     unsigned long long* d_prof = dalloc<unsigned long long>(EX_PROF_WORDS, owned);
+    unsigned* d_barrier = dalloc<unsigned>(EX_BARRIER_WORDS, owned);
     const bool print_profile = diagnostic("RELP_EXACT_PROFILE");
     const size_t pairs = (size_t)std::max(1, n - n_art) * m;
     u64* d_price_a = nullptr;   // (sized per limb count below)
@@ -2512,10 +2548,11 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemcpyAsync(d_resume, resume_state, sizeof(resume_state), hipMemcpyHostToDevice, stream));
         RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
         RELP_HIP(hipMemsetAsync(d_prof, 0, EX_PROF_WORDS * sizeof(unsigned long long), stream));
+        RELP_HIP(hipMemsetAsync(d_barrier, 0, EX_BARRIER_WORDS * sizeof(unsigned), stream));
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
-                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_xt_bits, mfma_update ? 1 : 0};
+                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_xt_bits, mfma_update ? 1 : 0, d_barrier};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
