@@ -582,6 +582,68 @@ __device__ int sign_of_difference(const Big<L>& a, const Big<L>& b, const Big<L>
     return s1 > 0 ? cmp : -cmp;
 }
 
+// sign of a b - c d for NON-NEGATIVE integers of la, lb, lc, ld words, by one wave: a lane forms the column sums of the words
+// w = lane, lane + 64, ... of both products (three words each), then the borrow of the difference runs through the words in order,
+// every lane the same chain with the sums fetched from their lanes.  (The exact tie-breaks of the ratio test: one thread forming two
+// whole products in scratch memory was two milliseconds per tied pivot at 128 limbs.)
+template <int L>
+__device__ __forceinline__ int wave_sign_of_difference(const u64* a, int la, const u64* b, int lb, const u64* c, int lc, const u64* d, int ld, int lane) {
+    constexpr int SLOTS = (2 * L + WAVE - 1) / WAVE;
+    u64 sum[2][SLOTS][3];
+    auto column_sums = [&](const u64* x, int lx, const u64* y, int ly, u64 (*out)[3]) {
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const int w = lane + t * WAVE;
+            u64 s0 = 0, s1 = 0, s2 = 0;
+            if (lx > 0 && ly > 0 && w < lx + ly) {
+                const int j0 = max(0, w - lx + 1), j1 = min(w, ly - 1);
+                for (int j = j0; j <= j1; ++j) {
+                    const u128 prod = (u128)x[w - j] * y[j];
+                    const u128 low = (u128)s0 + (u64)prod;
+                    s0 = (u64)low;
+                    const u128 mid = (u128)s1 + (u64)(prod >> 64) + (u64)(low >> 64);
+                    s1 = (u64)mid;
+                    s2 += (u64)(mid >> 64);
+                }
+            }
+            out[t][0] = s0;
+            out[t][1] = s1;
+            out[t][2] = s2;
+        }
+    };
+    column_sums(a, la, b, lb, sum[0]);
+    column_sums(c, lc, d, ld, sum[1]);
+    const int words = max(la + lb, lc + ld);
+    u128 run[2] = {0, 0};
+    u64 run_top[2] = {0, 0};
+    u64 borrow = 0;
+    bool nonzero = false;
+    for (int w = 0; w < words; ++w) {
+        const int owner = w & (WAVE - 1), slot = w / WAVE;
+        u64 word[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            u64 part[3] = {0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t)
+                if (t == slot) { part[0] = sum[k][t][0]; part[1] = sum[k][t][1]; part[2] = sum[k][t][2]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) part[q] = __shfl(part[q], owner);
+            const u128 add = (u128)part[0] | ((u128)part[1] << 64);
+            run[k] += add;
+            run_top[k] += part[2] + (run[k] < add ? 1 : 0);
+            word[k] = (u64)run[k];
+            run[k] = (run[k] >> 64) | ((u128)run_top[k] << 64);
+            run_top[k] = 0;
+        }
+        const u64 t = word[0] - word[1];
+        const u64 diff = t - borrow;
+        borrow = ((word[0] < word[1]) || (t < borrow)) ? 1 : 0;
+        nonzero = nonzero || diff != 0;
+    }
+    return borrow ? -1 : (nonzero ? 1 : 0);
+}
+
 // The grid barrier of the cooperative launch.  cooperative_groups' grid.sync() costs 0.1 us per workgroup on gfx950 -- every arrival
 // is an atomic on one word: 26 us at 256 workgroups, 53 at 512 (tools/micro/grid_barrier_bench.hip, profiles/r5_micro_grid_barrier.txt)
 // -- and a pivot makes about twenty of them.  Two levels instead: the workgroups count in groups of 32 on a word of their own (64-byte
@@ -2014,12 +2076,32 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 for (int c = gtid; c <= n_near; c += GT) lp.bracket[c] = c;
                 grid.sync();
                 for (int stride = 1; stride <= n_near; stride *= 2) {
-                    for (long long c = (long long)gtid * 2 * stride; c + stride <= n_near; c += (long long)GT * 2 * stride) {
-                        const int ia = lp.cand[lp.bracket[c]], ib = lp.cand[lp.bracket[c + stride]];
-                        // x_b / a_b  vs  x_a / a_a   <=>   x_b a_a  vs  x_a a_b   (both alpha > 0)
-                        const int cmp = sign_of_difference<L>(big_load<L>(lp.xt + (size_t)ib * L), big_load<L>(lp.alpha + (size_t)ia * L),
-                                                              big_load<L>(lp.xt + (size_t)ia * L), big_load<L>(lp.alpha + (size_t)ib * L));
-                        if (cmp < 0 || (cmp == 0 && lp.basis[ib] < lp.basis[ia])) lp.bracket[c] = lp.bracket[c + stride];
+                    if constexpr (L >= 16) {  // a WAVE per comparison (wave_sign_of_difference); anything negative goes the one-thread way
+                        const int lane_r = tid & (WAVE - 1);
+                        for (long long c = (long long)(gtid / WAVE) * 2 * stride; c + stride <= n_near; c += (long long)(GT / WAVE) * 2 * stride) {
+                            const int ia = lp.cand[lp.bracket[c]], ib = lp.cand[lp.bracket[c + stride]];
+                            const u64 *xa = lp.xt + (size_t)ia * L, *xb = lp.xt + (size_t)ib * L, *aa = lp.alpha + (size_t)ia * L, *ab = lp.alpha + (size_t)ib * L;
+                            int cmp;
+                            if ((i64)xa[L - 1] < 0 || (i64)xb[L - 1] < 0 || (i64)aa[L - 1] < 0 || (i64)ab[L - 1] < 0) {
+                                cmp = 0;
+                                if (lane_r == 0) cmp = sign_of_difference<L>(big_load<L>(xb), big_load<L>(aa), big_load<L>(xa), big_load<L>(ab));
+                                cmp = __shfl(cmp, 0);
+                            } else {
+                                auto words_of = [](int bits) { return (bits + 63) >> 6; };
+                                // x_b / a_b  vs  x_a / a_a   <=>   x_b a_a  vs  x_a a_b   (both alpha > 0)
+                                cmp = wave_sign_of_difference<L>(xb, words_of(lp.xt_bits[ib]), aa, words_of(lp.x_bits[ia]), xa, words_of(lp.xt_bits[ia]), ab,
+                                                                 words_of(lp.x_bits[ib]), lane_r);
+                            }
+                            if (lane_r == 0 && (cmp < 0 || (cmp == 0 && lp.basis[ib] < lp.basis[ia]))) lp.bracket[c] = lp.bracket[c + stride];
+                        }
+                    } else {
+                        for (long long c = (long long)gtid * 2 * stride; c + stride <= n_near; c += (long long)GT * 2 * stride) {
+                            const int ia = lp.cand[lp.bracket[c]], ib = lp.cand[lp.bracket[c + stride]];
+                            // x_b / a_b  vs  x_a / a_a   <=>   x_b a_a  vs  x_a a_b   (both alpha > 0)
+                            const int cmp = sign_of_difference<L>(big_load<L>(lp.xt + (size_t)ib * L), big_load<L>(lp.alpha + (size_t)ia * L),
+                                                                  big_load<L>(lp.xt + (size_t)ia * L), big_load<L>(lp.alpha + (size_t)ib * L));
+                            if (cmp < 0 || (cmp == 0 && lp.basis[ib] < lp.basis[ia])) lp.bracket[c] = lp.bracket[c + stride];
+                        }
                     }
                     grid.sync();
                 }
@@ -2222,11 +2304,16 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             for (int k = gtid; k < m; k += GT) big_store_s(N_at(p, k), MM, big_negate(big_load_s<L>(N_at(p, k), MM)));
             if (gtid == 0) big_store(lp.xt + (size_t)p * L, big_negate(big_load<L>(lp.xt + (size_t)p * L)));
         }
+        if constexpr (L >= 16)
+            if (block == 0 && !flip)  // (one thread with the integer in scratch memory took 0.1 ms of every pivot at 128 limbs)
+                for (int k = tid; k < L; k += T) gD[k] = lp.alpha[(size_t)p * L + k];
         if (leader) {
             word[4] = 0;  // (the candidate counter of the next pricing pass)
             const int leaving = lp.basis[p];
-            const Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
-            big_store(gD, flip ? big_negate(ap) : ap);
+            if (L < 16 || flip) {  // (the usual case at the wide types -- D' = alpha~_p as it is -- is copied a thread per word below)
+                const Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
+                big_store(gD, flip ? big_negate(ap) : ap);
+            }
             lp.basis[p] = q;
             lp.pos[q] = p;
             lp.pos[leaving] = -1;
