@@ -1979,6 +1979,54 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if constexpr (L >= 16) {  // the wide types: streamed like the pricing pass, a wave per 64 rows (a thread per row with its integers in scratch: 1.2 ms a pivot at 128 limbs)
             const int e0 = lp.col_start[q], e1 = lp.col_start[q + 1];
             const int lane_a = tid & (WAVE - 1);
+            if (p < 0) {
+                // q came out of the pricing pass: its products (N a_q)_i are in price_a already (a candidate: c~_q < 0) -- a wave per row
+                // copies the words (a lane per word) and finds the bit length from the highest word that is not the sign.  (Thirteen
+                // waves streaming the column again, ~100 us of dependent turns, were most of this step.)
+                const u64* column_q = lp.price_a + (size_t)(q - lp.n_art) * m;
+                for (int i = gtid / WAVE; i < m; i += GT / WAVE) {
+                    constexpr int SLOTS = (L + WAVE - 1) / WAVE;
+                    u64 w[SLOTS];
+#pragma unroll
+                    for (int t = 0; t < SLOTS; ++t) {
+                        const int k = lane_a + t * WAVE;
+                        w[t] = k < L ? column_q[(size_t)k * PP + i] : 0ull;
+                        if (k < L) lp.alpha[(size_t)i * L + k] = w[t];
+                    }
+                    const u64 top_word = __shfl(w[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
+                    const bool negative = (i64)top_word < 0;
+                    const u64 sign = negative ? ~0ull : 0ull;
+                    int top = -1;  // the highest word that differs from the sign
+                    u64 at_top = 0;
+#pragma unroll
+                    for (int t = SLOTS - 1; t >= 0; --t) {
+                        const unsigned long long differs = __ballot(lane_a + t * WAVE < L && w[t] != sign);
+                        if (top < 0 && differs != 0) {
+                            const int owner = 63 - __clzll((long long)differs);
+                            top = owner + t * WAVE;
+                            at_top = __shfl(w[t], owner);
+                        }
+                    }
+                    // (|v| = ~v + 1 for a negative v: the bits of ~v, one more when the + 1 carries into a new bit: v = -(2^k), all words
+                    //  below the top one zero and the top word of ~v of the form 2^j - 1)
+                    bool zeros_below = true;
+#pragma unroll
+                    for (int t = 0; t < SLOTS; ++t) zeros_below = zeros_below && __ballot(lane_a + t * WAVE < top && w[t] != 0) == 0;
+                    if (lane_a == 0) {
+                        int bits = 0;
+                        if (!negative) {
+                            if (top >= 0) bits = 64 * top + (64 - __clzll((long long)at_top));
+                        } else if (top < 0) {
+                            bits = 1;  // -1
+                        } else {
+                            const u64 inverted = ~at_top;  // (non-zero: the word differs from the sign)
+                            bits = 64 * top + (64 - __clzll((long long)inverted));
+                            if (zeros_below && (inverted & (inverted + 1)) == 0) bits += 1;
+                        }
+                        lp.x_bits[i] = bits;
+                    }
+                }
+            } else
             for (int block_a = gtid / WAVE; block_a * WAVE < m; block_a += GT / WAVE) {
                 const int i = block_a * WAVE + lane_a;
                 const bool active = i < m;
