@@ -260,12 +260,12 @@ __device__ __forceinline__ Big<L> big_mul_add_lo_blocked(const u64* a, const Big
     for (int k = 4 * NB; k < L; ++k) r.w[k] = 0;
     return r;
 }
-// -(a * b) modulo 2^(64 L) by one WAVE, stored word-major at out[k * stride]: lane K < L / 4 forms the block products that land in
+// -(a * b) (negate) or a * b modulo 2^(64 L) by one WAVE, stored word-major at out[k * stride]: lane K < L / 4 forms the block products that land in
 // output block K (the same 4 x 4 blocks, a window of nine words with nothing carried in), then the windows are chained in
 // order -- every lane alike, from the other lanes' registers -- and lane 0 stores the words.  a in memory (L words side by side),
 // b in LDS.  (The rows' factors alpha~_i u of the update: a product per row by one thread each was 1.3 ms of every pivot at 128 limbs.)
 template <int L>
-__device__ __noinline__ void wave_mul_lo_store(const u64* a, const u64* b, u64* out, size_t stride, int lane) {
+__device__ __noinline__ void wave_mul_lo_store(const u64* a, const u64* b, u64* out, size_t stride, int lane, bool negate = true) {
     static_assert(L % 4 == 0 && L / 4 <= WAVE, "a lane per block of four words");
     constexpr int NB = L / 4;
     u64 acc[9];
@@ -316,10 +316,10 @@ __device__ __noinline__ void wave_mul_lo_store(const u64* a, const u64* b, u64* 
             window[k] = (u64)t;
             carry = (u64)(t >> 64);
         }
-        if (lane == 0) {  // (stored NEGATED, modulo 2^(64 L): ~w + 1 with the carry running while the words are zero)
+        if (lane == 0) {  // (stored NEGATED where asked, modulo 2^(64 L): ~w + 1 with the carry running while the words are zero)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                out[(size_t)(4 * K + t) * stride] = ~window[t] + (negation_carry ? 1ull : 0ull);
+                out[(size_t)(4 * K + t) * stride] = negate ? ~window[t] + (negation_carry ? 1ull : 0ull) : window[t];
                 negation_carry = negation_carry && window[t] == 0;
             }
         }
@@ -699,7 +699,7 @@ struct ExactLP {
     const int* resume;    // [8]: [0] != 0: continue a run that overflowed at a narrower width (N, D, basis, pos, removed are its state
                           //      before the pivot that did not fit); [1..6] = phase, pivots one, pivots two, trace count, drive row, removed
     int* removed;         // [m] 1: the row is redundant -- its artificial cannot be pivoted out (`RemoveRows` of the reference)
-    int* shared_words;    // [8] grid-wide overflow flag, decisions of workgroup 0's thread 0
+    int* shared_words;    // [16] grid-wide overflow flag, decisions of workgroup 0's thread 0
     double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
     unsigned long long* part_rank;
     unsigned long long* prof;  // [EX_PROF_WORDS] the leader's time per step of the loop in ticks of the 100 MHz wall clock [0..9], candidate counts [12],
@@ -725,9 +725,10 @@ struct ExactLP {
     int* y_bits;          // [m] bound on the bit length of y_k
     double* cd;           // [n] c~_j / D as a double (the key's numerator) for the columns with c~_j < 0
     int* neg_list;        // [n] those columns, in no particular order; neg_list[n] = their count
-    u64* Tx;              // [limbs][m], Tx_carry [limbs / 2][m], Tx_words [m]: the same for x~_B, the column after the last
-    int* Tx_carry;
+    u64* Tx;              // [limbs][2 m], Tx_carry [limbs / 2][2 m], Tx_words [2 m]: the same for x~_B, the column after the last (entries 0 .. m - 1),
+    int* Tx_carry;        //   and for y, one more ROW of N (entries m .. 2 m - 1: y'_k = (alpha~_p y_k + c~_q N(p, k)) / D)
     int* Tx_words;
+    u64* y_part;          // [limbs] c~_q / D_odd modulo 2^(64 limbs): y's factor of the update, as x_part holds the rows'
     int* xt_bits;         // [m] bit length of |x~_i|, kept by whoever writes an entry
     int mfma_update;      // 1: the update runs on the matrix cores
     unsigned* barrier;    // [EX_BARRIER_WORDS] the grid barrier's counters (grid_barrier), zero at the launch
@@ -838,38 +839,47 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
             *value = lp.value[e0 + e];
         }
     };
-    struct Sum {  // 192 bits, carry-save
+    // (Round 5: ONE signed running sum per word of the turn -- 192 bits, two's complement, the multiples of the negative entries
+    //  subtracted -- where there were two unsigned ones and a borrow between them: half the registers, which pay for eight words of
+    //  the result per turn instead of four.  The pass waits for memory -- a turn is a round trip per four entries of the column --
+    //  and now makes half as many turns.)
+    struct Sum {
         u128 acc = 0;
-        u64 top = 0;
+        i64 top = 0;
         __device__ __forceinline__ void add(u128 v) {
             acc += v;
             top += acc < v ? 1 : 0;
         }
-        __device__ __forceinline__ u64 pop() {  // the lowest word leaves, the rest moves down
+        __device__ __forceinline__ void sub(u128 v) {
+            const bool borrows = acc < v;
+            acc -= v;
+            top -= borrows ? 1 : 0;
+        }
+        __device__ __forceinline__ void add(const Sum& other) {
+            acc += other.acc;
+            top += other.top + (acc < other.acc ? 1 : 0);
+        }
+        __device__ __forceinline__ u64 pop() {  // the lowest word leaves, the rest moves down (the sign stays)
             const u64 word = (u64)acc;
-            acc = (acc >> 64) | ((u128)top << 64);
-            top = 0;
+            acc = (acc >> 64) | ((u128)(u64)top << 64);
+            top >>= 63;
             return word;
         }
     };
-    Sum pos, neg;  // running sums of the positive / the negative multiples
-    u64 borrow = 0;
+    Sum running;
     auto emit = [&](int k) {
-        const u64 pk = pos.pop(), qk = neg.pop();
-        const u64 t = pk - qk;
-        const u64 word = t - borrow;
-        borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
+        const u64 word = running.pop();
         if (active) out[(size_t)k * out_stride] = word;
         lead.feed(k, word);
     };
-    constexpr int KU = L >= 4 ? 4 : (L >= 2 ? 2 : 1);  // words of the result per turn
+    constexpr int KU = L >= 8 ? 8 : (L >= 4 ? 4 : (L >= 2 ? 2 : 1));  // words of the result per turn
     // (the sum fits `awide` bits: the words above that many are its sign, not worth their operands' loads)
     int words = active ? min(L, (awide + 2 + 63) / 64) : 1;
     for (int d = 1; d < WAVE; d *= 2) words = max(words, __shfl_xor(words, d));
     words = min(L, (words + KU - 1) / KU * KU);
     for (int k = 0; k < words; k += KU) {
         const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
-        Sum pos_next[KU > 1 ? KU - 1 : 1], neg_next[KU > 1 ? KU - 1 : 1];  // the multiples of the words k + 1 ...
+        Sum next[KU > 1 ? KU - 1 : 1];  // the multiples of the words k + 1 ...
         for (int e = 0; e < len; e += 4) {  // four operands (of every word of the turn) in flight
             u64 w[KU][4];
             i64 v[4];
@@ -886,18 +896,16 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
                 const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
 #pragma unroll
                 for (int t = 0; t < KU; ++t) {
-                    Sum& target = v[u] >= 0 ? (t == 0 ? pos : pos_next[t > 0 ? t - 1 : 0]) : (t == 0 ? neg : neg_next[t > 0 ? t - 1 : 0]);
-                    target.add((u128)w[t][u] * mag);
+                    Sum& target = t == 0 ? running : next[t > 0 ? t - 1 : 0];
+                    if (v[u] >= 0) target.add((u128)w[t][u] * mag);
+                    else target.sub((u128)w[t][u] * mag);
                 }
             }
         }
         emit(k);
 #pragma unroll
         for (int t = 1; t < KU; ++t) {
-            pos.add(pos_next[t - 1].acc);
-            pos.top += pos_next[t - 1].top;
-            neg.add(neg_next[t - 1].acc);
-            neg.top += neg_next[t - 1].top;
+            running.add(next[t - 1]);
             emit(k + t);
         }
     }
@@ -910,6 +918,41 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
         }
     }
     return awide;
+}
+
+// Bit length of |v| for an integer of L words side by side in memory, by one wave (a lane per word, two at 128 limbs): the highest word
+// that differs from the sign decides.  (One thread scanning its own copy from the top is a chain of L dependent scratch reads: 0.1 ms
+// at 128 limbs.)  The same value in every lane.
+template <int L>
+__device__ __forceinline__ int wave_bit_length(const u64* v, int lane) {
+    constexpr int SLOTS = (L + WAVE - 1) / WAVE;
+    u64 w[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) w[t] = lane + t * WAVE < L ? v[lane + t * WAVE] : 0ull;
+    const u64 top_word = __shfl(w[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
+    const bool negative = (i64)top_word < 0;
+    const u64 sign = negative ? ~0ull : 0ull;
+    int top = -1;  // the highest word that differs from the sign
+    u64 at_top = 0;
+#pragma unroll
+    for (int t = SLOTS - 1; t >= 0; --t) {
+        const unsigned long long differs = __ballot(lane + t * WAVE < L && w[t] != sign);
+        if (top < 0 && differs != 0) {
+            const int owner = 63 - __clzll((long long)differs);
+            top = owner + t * WAVE;
+            at_top = __shfl(w[t], owner);
+        }
+    }
+    if (!negative) return top < 0 ? 0 : 64 * top + (64 - __clzll((long long)at_top));
+    if (top < 0) return 1;  // -1
+    // |v| = ~v + 1: the bits of ~v, one more when the + 1 carries into a new bit (v = -(2^k): zeros below, the top word of ~v = 2^j - 1)
+    bool zeros_below = true;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) zeros_below = zeros_below && __ballot(lane + t * WAVE < top && w[t] != 0) == 0;
+    const u64 inverted = ~at_top;
+    int bits = 64 * top + (64 - __clzll((long long)inverted));
+    if (zeros_below && (inverted & (inverted + 1)) == 0) bits += 1;
+    return bits;
 }
 
 // sum_i cb(i) X_i for one word-major column of m integers (word k of row i at column[k * word_stride + i]), by one wave: every lane
@@ -1160,19 +1203,45 @@ struct UpdateTileArgs {
 #define TILE_STAMP(k) do {} while (0)
 #endif
 // what a lane reads and writes for its entry: word w of the entry at entry[w * entry_stride], of the numerator at numerator[w * numerator_stride]
+// (pointers into device memory, and typed so: through generic pointers every load of the ring below was a flat_load that the compiler
+//  could only wait for with vmcnt(0) -- everything in flight, the prefetched steps included)
+typedef __attribute__((address_space(1))) u64 global_u64;
+typedef __attribute__((address_space(1))) const u64 global_cu64;
+typedef __attribute__((address_space(1))) int global_i32;
 struct UpdateTileEntry {
-    const u64* entry;
+    global_cu64* entry;
     size_t entry_stride;
-    u64* numerator;
-    int* carry;
-    int* words;
+    global_cu64* second;  // the factor of the second term (two-term tiles): the row's -alpha~_i u of x_part; N(p, k) for an entry of y
+    size_t second_stride;
+    global_u64* numerator;
+    global_i32* carry;
+    global_i32* words;
     size_t numerator_stride;
+    __device__ UpdateTileEntry(const u64* entry_, size_t entry_stride_, const u64* second_, size_t second_stride_, u64* numerator_, int* carry_, int* words_, size_t numerator_stride_)
+        : entry((global_cu64*)entry_), entry_stride(entry_stride_), second((global_cu64*)second_), second_stride(second_stride_), numerator((global_u64*)numerator_),
+          carry((global_i32*)carry_), words((global_i32*)words_), numerator_stride(numerator_stride_) {}
 };
+// (the fields of UpdateTileEntry one by one: as a struct the argument travelled through the stack, and every tile began by waiting for
+//  four scratch loads before its first request could go out -- a third of the time of the "requests" section, tools: -DRELP_TILE_STAMPS)
 template <int L>
-__device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const UpdateTileEntry at_entry, const lds_u32* toeplitz_lds, const lds_i32* prefix_lds, int row,
-                                             bool store, int terms, int nb64, int lane) {
+__device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_of_lp, global_cu64* entry_of, size_t entry_stride, global_cu64* second_of, size_t second_stride,
+                                                    global_u64* numerator_of, global_i32* carry_of, global_i32* words_of, size_t numerator_stride, const lds_u32* toeplitz_lds,
+                                                    const lds_i32* prefix_lds, int row, bool store, int terms, int nb64, int lane) {
+    struct {
+        unsigned long long* stamps;
+    } lp{stamps_of_lp};
+    struct {
+        global_cu64* entry;
+        size_t entry_stride;
+        global_cu64* second;
+        size_t second_stride;
+        global_u64* numerator;
+        global_i32* carry;
+        global_i32* words;
+        size_t numerator_stride;
+    } at_entry{entry_of, entry_stride, second_of, second_stride, numerator_of, carry_of, words_of, numerator_stride};
+    (void)lp;
     constexpr int WB = UpdateLds<L>::WB, STRIDE = UpdateLds<L>::STRIDE;
-    const int m = lp.m;
     // (the same for every lane -- and said so: left as vector values, every "is this block wanted" below became an exec mask with a
     //  full wait on LDS behind it instead of a scalar branch)
     nb64 = __builtin_amdgcn_readfirstlane(nb64);
@@ -1198,8 +1267,8 @@ __device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const Upda
         const int steps = terms * kb_end;
         auto fetch = [&](int step, u64& w0, u64& w1) {
             const int term = step >= kb_end ? 1 : 0, kb = step - term * kb_end;
-            const u64* src = term == 0 ? at_entry.entry : lp.x_part + (have ? row : 0);
-            const size_t stride = term == 0 ? at_entry.entry_stride : (size_t)m;
+            global_cu64* src = term == 0 ? at_entry.entry : at_entry.second;
+            const size_t stride = term == 0 ? at_entry.entry_stride : at_entry.second_stride;
             const bool wanted = have && step < steps;
             w0 = wanted ? src[(size_t)(8 * kb + 2 * g) * stride] : 0ull;
             w1 = wanted ? src[(size_t)(8 * kb + 2 * g + 1) * stride] : 0ull;
@@ -1289,6 +1358,12 @@ __device__ __noinline__ int mfma_update_tile(const UpdateTileArgs lp, const Upda
     if (store && g == 0) *at_entry.words = 8 * nb64;
     return issued;
 }
+template <int L>
+__device__ __forceinline__ int mfma_update_tile(const UpdateTileArgs lp, const UpdateTileEntry at_entry, const lds_u32* toeplitz_lds, const lds_i32* prefix_lds, int row, bool store,
+                                                int terms, int nb64, int lane) {
+    return mfma_update_tile_fields<L>(lp.stamps, at_entry.entry, at_entry.entry_stride, at_entry.second, at_entry.second_stride, at_entry.numerator, at_entry.carry, at_entry.words,
+                                      at_entry.numerator_stride, toeplitz_lds, prefix_lds, row, store, terms, nb64, lane);
+}
 
 // The numerator of one entry as the tiles left it (word w at numerator[w * numerator_stride], the carry of pair P at carries[P *
 // numerator_stride]): carries run through the pairs, shifted right by `shift` (sign-extended from its 64 * words bits), negated where
@@ -1361,11 +1436,116 @@ __device__ __forceinline__ int finish_update_entry(const u64* numerator, const i
     return bits;
 }
 
+// The three passes of the pricing step, each a function of its own -- not inlined, so that the registers of its loop are allocated apart
+// from the state of the pivot loop (as for the update below: with everything in one body, a new variable ANYWHERE in the loop moved the
+// spills of a kernel that is held to 256 registers into these loops -- the pass over N went from 0.8 to 2.1 s of 25FV47's solve and the
+// products from 1.2 to 2.2 when the loop learnt to carry y along).  Every workgroup of the grid calls them; `overflow` is the
+// workgroup's flag (LDS) for a value whose bound reaches `limit_bits`.
+// y_k = sum_i c_B(i) N(i, k) and the bit length of |y_k|: a wave per column of N
+template <int L>
+__device__ __noinline__ void price_form_y(const ExactLP& lp, int limit_bits, int* overflow) {
+    const int m = lp.m, lane = threadIdx.x & (WAVE - 1);
+    const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    const size_t MM = (size_t)m * m;
+    const int log_m = 32 - __clz(m > 1 ? m - 1 : 1) + 1;
+    for (int k = wave_of_grid; k < m; k += waves_of_grid) {
+        int widest = 0;
+        for (int i = lane; i < m; i += WAVE) {
+            const i64 cb = lp.cb_row[i];
+            if (cb != 0) widest = max(widest, lp.N_bits[(size_t)k * m + i] + small_bits(cb));
+        }
+        for (int d = 1; d < WAVE; d *= 2) widest = max(widest, __shfl_xor(widest, d));
+        widest += log_m;
+        if (lane == 0 && widest >= limit_bits) *overflow = 1;
+        u64* yk = lp.y + (size_t)k * L;
+        // (the bit length of |y_k| from the words as they pass, as finish_update_entry finds an entry's: the update's fit test and the
+        //  bounds of the next pass read it, and a pivot on the matrix cores leaves the exact length there as well)
+        int top_nonzero = -1, top_not_ones = -1;
+        u64 word_nonzero = 0, word_not_ones = 0, last = 0;
+        bool zeros_below_not_ones = true, zeros_so_far = true;
+        wave_cost_dot<L>(lp.N + (size_t)k * m, MM, lp.cb_row, m, lane, (widest + 2 + 63) / 64, [&](int word, u64 value) {
+            if (lane == 0) yk[word] = value;
+            if (value != 0) { top_nonzero = word; word_nonzero = value; }
+            if (value != ~0ull) { top_not_ones = word; word_not_ones = ~value; zeros_below_not_ones = zeros_so_far; }
+            zeros_so_far = zeros_so_far && value == 0;
+            last = value;
+        });
+        if (lane == 0) {
+            int bits;
+            if ((i64)last >= 0) bits = top_nonzero < 0 ? 0 : 64 * top_nonzero + (64 - __clzll((long long)word_nonzero));
+            else if (top_not_ones < 0) bits = 1;
+            else {
+                bits = 64 * top_not_ones + (64 - __clzll((long long)word_not_ones));
+                if (zeros_below_not_ones && (word_not_ones & (word_not_ones + 1)) == 0) bits += 1;
+            }
+            lp.y_bits[k] = bits;
+        }
+    }
+}
+// c~_j for every non-basic, non-artificial column (a wave per column); the columns with c~_j < 0 into neg_list
+template <int L>
+__device__ __noinline__ void price_reduced_costs(const ExactLP& lp, int phase, double mD, int eD, int D_bits, int limit_bits, int* overflow) {
+    const int n = lp.n, lane = threadIdx.x & (WAVE - 1);
+    const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    const int n_priced = n - lp.n_art;
+    for (int item = wave_of_grid; item < n_priced; item += waves_of_grid) {
+        const int j = lp.n_art + item;
+        double cd = 0.0;
+        if (lp.pos[j] < 0) {  // (the whole wave)
+            int widest = 0;
+            cd = reduced_cost_wave<L>(lp, lp.D, j, phase, lane, mD, eD, D_bits, &widest);
+            if (lane == 0 && widest + 1 >= limit_bits) *overflow = 1;
+        }
+        if (lane == 0) {
+            lp.key[j] = 0.0;
+            lp.cd[j] = cd;
+            if (cd != 0.0) lp.neg_list[atomicAdd(&lp.neg_list[n], 1)] = j;
+        }
+    }
+}
+// Pass A for the columns of neg_list: a wave takes a column and 64 neighbouring rows and forms (N a_j)_i word by word, least significant
+// first -- the words of the N(i, r_e) straight from memory (word-major: one coalesced access per operand), the positive and the
+// negative multiples in two carry-save accumulators, their difference stored as it appears.  The bit bound comes from N_bits, the
+// double from the two leading words gathered on the way.
+template <int L>
+__device__ __noinline__ void price_products(const ExactLP& lp, double mD, int eD, int limit_bits, int* overflow) {
+    const int m = lp.m, n = lp.n, lane = threadIdx.x & (WAVE - 1);
+    const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    const size_t MM = (size_t)m * m;
+    const size_t PP = (size_t)(n - lp.n_art > 0 ? n - lp.n_art : 1) * m;
+    const int row_blocks = (m + WAVE - 1) / WAVE;
+    const int n_negative = lp.neg_list[n];
+    for (long long item = wave_of_grid; item < (long long)n_negative * row_blocks; item += waves_of_grid) {
+#ifdef RELP_PRICE_COLUMN_MAJOR
+        const int c = (int)(item / row_blocks), i = (int)(item - (long long)c * row_blocks) * WAVE + lane;
+#else
+        // (the waves in flight share a few blocks of rows and run through the columns: what they read of N -- every column of it 3.6
+        //  times over a pass on 25FV47 -- is then a couple of hundred MB at a time and is served again from the last-level cache)
+        const int rb = (int)(item / n_negative), c = (int)(item - (long long)rb * n_negative), i = rb * WAVE + lane;
+#endif
+        const int j = lp.neg_list[c], jj = j - lp.n_art;
+        const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
+        const bool active = i < m;
+        const size_t pair = (size_t)jj * m + (active ? i : 0);
+        LeadingWords lead;
+        const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane, MM, lp.price_a + pair, PP, lead);
+        if (active) {
+            if (awide >= limit_bits) *overflow = 1;
+            lp.price_bits[pair] = awide;
+            int ea = 0;
+            const double ma = lead.mantissa(&ea);
+            const double ad = ldexp(ma / mD, ea - eD);
+            lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
+        }
+    }
+}
+
 // The whole update of a pivot on the matrix cores (every workgroup of the cooperative grid calls it): a function of its own so that its
 // registers -- and those its tiles force the caller to save -- are allocated apart from the other steps of the loop (inlined, the
 // pricing passes lost a quarter of their speed to spills).
 struct UpdateScalars {
     int p, shift, flip, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha;
+    int with_y, cq_bits;  // y = c_B' N rides along as one more row of N (its factor c~_q u in lp.y_part), |c~_q| has that many bits
 };
 template <int L>
 __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const UpdateScalars sc, const u64* s_c1, unsigned long long& products_needed,
@@ -1414,42 +1594,48 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
         {
             // (x~_B is one more column of N -- x~'_i = (alpha~_p x~_i - alpha~_i x~_p) / D, every row but p -- and is taken here as the
             //  column after the last: a thread per row with two whole products of its own was 2 ms at the end of every pivot at 128 limbs)
-            const int tiles_per_column = (n_rows_alpha + 15) / 16, tiles_of_x = (m + 15) / 16;
-            const long long total_N = (long long)n_heavy * tiles_per_column, total = total_N + tiles_of_x;
+            // (... and y = c_B' N is one more ROW of it: y'_k = (alpha~_p y_k + c~_q N(p, k)) / D for every column k -- the roles turned
+            //  round, c~_q u is the Toeplitz operand and N(p, k) the entry's factor.  Carried along like this the pricing pass no
+            //  longer reads the whole of N once per pivot to form it: 0.8 of 25FV47's 5.4 s.)
+            const int tiles_per_column = (n_rows_alpha + 15) / 16, tiles_of_x = (m + 15) / 16, tiles_of_y = sc.with_y ? (m + 15) / 16 : 0;
+            const long long total_N = (long long)n_heavy * tiles_per_column, total = total_N + tiles_of_x + tiles_of_y;
             const long long per_block = (total + G - 1) / G;
             long long u = min(total, (long long)block * per_block);
             const long long u_end = min(total, u + per_block);
+            const size_t M2 = 2 * (size_t)m;  // stride of the numerators of x~_B and y
             while (u < u_end) {
-                const bool x_column = u >= total_N;
-                const int kk = x_column ? n_heavy : (int)(u / tiles_per_column);
-                const int k = x_column ? -1 : lp.bracket[kk];
-                const long long column_first = (long long)kk * tiles_per_column;
-                const long long column_end = x_column ? u_end : min(u_end, column_first + tiles_per_column);
+                const int kind = u < total_N ? 0 : u < total_N + tiles_of_x ? 1 : 2;  // a column of N, x~_B, y
+                const int kk = kind == 0 ? (int)(u / tiles_per_column) : n_heavy;
+                const int k = kind == 0 ? lp.bracket[kk] : -1;
+                const long long column_first = kind == 0 ? (long long)kk * tiles_per_column : kind == 1 ? total_N : total_N + tiles_of_x;
+                const long long column_end = min(u_end, column_first + (kind == 0 ? tiles_per_column : kind == 1 ? tiles_of_x : tiles_of_y));
                 __syncthreads();  // (the previous column's tiles are done with the image)
-                for (int w = tid; w < L; w += T) s_update.words[w] = x_column ? lp.xt[(size_t)p * L + w] : N_at(p, k)[(size_t)w * MM];
+                for (int w = tid; w < L; w += T) s_update.words[w] = kind == 0 ? N_at(p, k)[(size_t)w * MM] : kind == 1 ? lp.xt[(size_t)p * L + w] : lp.y_part[w];
                 __syncthreads();
                 build_toeplitz<L>(s_update, 1, s_update.words);
                 __syncthreads();
-                const int npk_bits = x_column ? xp_bits : lp.N_bits[(size_t)k * m + p];
+                const int operand_bits = kind == 0 ? lp.N_bits[(size_t)k * m + p] : kind == 1 ? xp_bits : sc.cq_bits;
                 for (long long t = u + wave; t < column_end; t += waves) {
                     const int first = 16 * (int)(t - column_first);
-                    int row;
-                    if (x_column) row = first + e16 < m ? first + e16 : -1;
-                    else row = first + e16 < n_rows_alpha ? lp.row_list[first + e16] : -1;
-                    const bool store = row >= 0 && row != p;
+                    int row;  // (for y: the column of N)
+                    if (kind == 0) row = first + e16 < n_rows_alpha ? lp.row_list[first + e16] : -1;
+                    else row = first + e16 < m ? first + e16 : -1;
+                    const bool store = row >= 0 && (kind == 2 || row != p);
                     int nb = 1;
-                    UpdateTileEntry at_entry{lp.N, MM, lp.T, lp.T_carry, lp.T_words, MM};
+                    UpdateTileEntry at_entry{lp.N, MM, lp.x_part, (size_t)m, lp.T, lp.T_carry, lp.T_words, MM};
                     if (store) {
-                        const size_t idx = x_column ? (size_t)row : (size_t)k * m + row;
-                        const int entry_bits = x_column ? lp.xt_bits[row] : lp.N_bits[idx];
-                        const int needed = max(ap_bits + entry_bits, lp.x_bits[row] + npk_bits) + 1 - (D_bits - 1) + shift + 2;
+                        const size_t idx = kind == 0 ? (size_t)k * m + row : (size_t)row;
+                        const int entry_bits = kind == 0 ? lp.N_bits[idx] : kind == 1 ? lp.xt_bits[row] : lp.y_bits[row];
+                        const int factor_bits = kind == 2 ? lp.N_bits[(size_t)row * m + p] : lp.x_bits[row];
+                        const int needed = max(ap_bits + entry_bits, factor_bits + operand_bits) + 1 - (D_bits - 1) + shift + 2;
                         nb = blocks64(needed);
                         if (lane < 16) {
                             const int blocks = min(L / 4, max(1, (needed + 255) / 256));
                             products_needed += 16ull * blocks * (blocks + 1);
                         }
-                        if (x_column) at_entry = UpdateTileEntry{lp.xt + idx * L, 1, lp.Tx + idx, lp.Tx_carry + idx, lp.Tx_words + idx, (size_t)m};
-                        else at_entry = UpdateTileEntry{lp.N + idx, MM, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                        if (kind == 0) at_entry = UpdateTileEntry{lp.N + idx, MM, lp.x_part + row, (size_t)m, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                        else if (kind == 1) at_entry = UpdateTileEntry{lp.xt + idx * L, 1, lp.x_part + row, (size_t)m, lp.Tx + idx, lp.Tx_carry + idx, lp.Tx_words + idx, M2};
+                        else at_entry = UpdateTileEntry{lp.y + idx * L, 1, N_at(p, row), MM, lp.Tx + m + idx, lp.Tx_carry + m + idx, lp.Tx_words + m + idx, M2};
                     }
                     nb = wave_max(nb);
                     issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 2, nb, lane);
@@ -1489,7 +1675,7 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
                 nb = wave_max(nb);
                 if (nb == 0) continue;  // sixteen zeros
                 const size_t idx = (size_t)k * m + (row >= 0 ? row : 0);
-                const UpdateTileEntry at_entry{lp.N + idx, MM, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                const UpdateTileEntry at_entry{lp.N + idx, MM, lp.x_part, (size_t)m, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
                 issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 1, nb, lane);
             }
         }
@@ -1503,11 +1689,13 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             lp.T_words[idx] = 0;
             lp.N_bits[idx] = finish_update_entry<L>(lp.T + idx, lp.T_carry + idx, MM, lp.N + idx, MM, words, shift, flip);
         }
-        for (int i = gtid; i < m; i += GT) {
+        for (int i = gtid; i < 2 * m; i += GT) {  // x~_B, then y
             const int words = lp.Tx_words[i];
             if (words == 0) continue;
             lp.Tx_words[i] = 0;
-            lp.xt_bits[i] = finish_update_entry<L>(lp.Tx + i, lp.Tx_carry + i, (size_t)m, lp.xt + (size_t)i * L, 1, words, shift, flip);
+            const int bits = finish_update_entry<L>(lp.Tx + i, lp.Tx_carry + i, 2 * (size_t)m, (i < m ? lp.xt + (size_t)i * L : lp.y + (size_t)(i - m) * L), 1, words, shift, flip);
+            if (i < m) lp.xt_bits[i] = bits;
+            else lp.y_bits[i - m] = bits;
         }
         substamp(23);
 }
@@ -1623,6 +1811,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     grid.sync();
     int at_phase = phase, at_drive_row = drive_row, at_removed = n_removed;  // ... at the start of the current turn of the loop
     bool have_xb = false;  // x~_B belongs to the current basis
+    int y_phase = 0;       // lp.y = c_B' N belongs to the current basis and to this phase's costs (0: to neither); on the matrix cores a pivot
+                           // carries it along as one more row of N, otherwise every pricing pass forms it
     while (status == EX_RUNNING) {
         if (pivots[0] + pivots[1] >= lp.max_pivots) { status = EX_PIVOT_LIMIT; break; }
         at_phase = phase;
@@ -1685,7 +1875,6 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             __syncthreads();
         }
         if constexpr (L >= 16) D_bits = s_D_bits;
-        const u64* Dw = gD;  // the words of D for whoever streams them
         block_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2], s_part);
         const int shift = s_shift;
         Big<L> Dinv;
@@ -1734,7 +1923,6 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             // bound.  (One thread per column walking all m rows -- the one-workgroup form -- was 80 % of the run on the grid: 126 ms
             // per pass on E226, a few hundred busy threads.)  Pass B, a thread per column: c~_j and the weight from the stored terms,
             // in the order and with the bounds of the serial loop -- the estimates are the same bits as before.
-            const int n_priced = n - lp.n_art;
             // (Round 4.  A thread per pair that held N(i, r), its multiple and the running sum as three integers in scratch memory
             //  made ~400 scratch accesses for every 32 words it read from N: 72 of 25FV47's 147 s at 128 limbs.  Now a WAVE takes a
             //  column and 64 neighbouring rows and the sum is formed word by word, least significant first: the words of the
@@ -1746,69 +1934,28 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             // column of N once per non-zero of its row of A -- are formed only for the columns with c~_j < 0, the only ones that can
             // enter.  (Rounds 2-4 formed N a_j for EVERY non-basic column and c~_j from those: 3.0 + 1.5 of 25FV47's 9.7 s.)  The
             // same integers c~_j, the same doubles for the keys of the candidates, so the same pivots.
-            for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];
+#ifdef RELP_Y_ALWAYS
+            const bool form_y = true;  // (diagnostic build: the pass over N every pivot, as before round 5)
+#else
+            const bool form_y = y_phase != phase;  // (the same in every workgroup)
+#endif
+            if (form_y)
+                for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];
             if (leader) lp.neg_list[n] = 0;
             const int eD = s_eD;
             const double mD = s_mD;
-            const int row_blocks = (m + WAVE - 1) / WAVE;
             const int lane = tid & (WAVE - 1);
             grid.sync();
-            for (int k = gtid / WAVE; k < m; k += GT / WAVE) {  // y_k, a wave per column of N
-                int widest = 0;
-                for (int i = lane; i < m; i += WAVE) {
-                    const i64 cb = lp.cb_row[i];
-                    if (cb != 0) widest = max(widest, lp.N_bits[(size_t)k * m + i] + small_bits(cb));
-                }
-                for (int d = 1; d < WAVE; d *= 2) widest = max(widest, __shfl_xor(widest, d));
-                widest += log2_ceil(m);
-                if (lane == 0) {
-                    lp.y_bits[k] = widest;
-                    flag_overflow(widest);
-                }
-                u64* yk = lp.y + (size_t)k * L;
-                wave_cost_dot<L>(lp.N + (size_t)k * m, MM, lp.cb_row, m, lane, (widest + 2 + 63) / 64, [&](int word, u64 value) {
-                    if (lane == 0) yk[word] = value;
-                });
+            if (form_y) {
+                price_form_y<L>(lp, LIMIT_BITS, &s_overflow);
+                grid.sync();
+                y_phase = phase;
             }
-            grid.sync();
-            for (long long item = gtid / WAVE; item < n_priced; item += GT / WAVE) {  // c~_j, a wave per column
-                const int j = lp.n_art + (int)item;
-                double cd = 0.0;
-                if (lp.pos[j] < 0) {  // (the whole wave)
-                    int widest = 0;
-                    cd = reduced_cost_wave<L>(lp, Dw, j, phase, lane, mD, eD, D_bits, &widest);
-                    if (lane == 0) flag_overflow(widest + 1);
-                }
-                if (lane == 0) {
-                    lp.key[j] = 0.0;
-                    lp.cd[j] = cd;
-                    if (cd != 0.0) lp.neg_list[atomicAdd(&lp.neg_list[n], 1)] = j;
-                }
-            }
+            price_reduced_costs<L>(lp, phase, mD, eD, D_bits, LIMIT_BITS, &s_overflow);
             grid.sync();
             stamp(1);
-            // Pass A for the candidates: a wave takes a column and 64 neighbouring rows and forms (N a_j)_i word by word, least significant
-            // first -- the words of the N(i, r_e) straight from memory (word-major: one coalesced access per operand), the positive and
-            // the negative multiples in two carry-save accumulators, their difference stored as it appears.  The bit bound comes from
-            // N_bits, the double from the two leading words gathered on the way.
             const int n_negative = lp.neg_list[n];
-            for (long long item = gtid / WAVE; item < (long long)n_negative * row_blocks; item += GT / WAVE) {
-                const int c = (int)(item / row_blocks), i = (int)(item - (long long)c * row_blocks) * WAVE + lane;
-                const int j = lp.neg_list[c], jj = j - lp.n_art;
-                const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
-                const bool active = i < m;
-                const size_t pair = (size_t)jj * m + (active ? i : 0);
-                LeadingWords lead;
-                const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane, MM, lp.price_a + pair, PP, lead);
-                if (active) flag_overflow(awide);
-                if (active) {
-                    lp.price_bits[pair] = awide;
-                    int ea = 0;
-                    const double ma = lead.mantissa(&ea);
-                    const double ad = ldexp(ma / mD, ea - eD);
-                    lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
-                }
-            }
+            price_products<L>(lp, mD, eD, LIMIT_BITS, &s_overflow);  // pass A for the candidates
             grid.sync();
             // ... and their keys: the weight estimate is the sequential sum of the stored terms in the order of the rows (the same doubles
             // as the one-workgroup form's), key = (c~_j / D)^2 / that
@@ -1975,6 +2122,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             p = r;
             drive_row = r + 1;
         }
+        // y = c_B' N is carried through this pivot when the update runs on the matrix cores and q came out of the pricing pass (whose
+        // c~_q is the factor; a zero-level pivot of phase one leaves y to the next pricing pass)
+#ifdef RELP_NO_Y_RIDE
+        const bool y_rides = false;  // (diagnostic build)
+#else
+        const bool y_rides = on_matrix_cores && p < 0 && y_phase == phase;
+#endif
         // ---- alpha~_q = N a_q (tableau/mod.rs:126-130) -----------------------------------------------------------------------
         if constexpr (L >= 16) {  // the wide types: streamed like the pricing pass, a wave per 64 rows (a thread per row with its integers in scratch: 1.2 ms a pivot at 128 limbs)
             const int e0 = lp.col_start[q], e1 = lp.col_start[q + 1];
@@ -2057,6 +2211,12 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store)
             grid.sync();
             for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
+            // ... and y's factor c~_q u, by the last wave of the grid (y rides along with the update of N, see update_on_matrix_cores)
+            if (y_rides && gtid / WAVE == GT / WAVE - 1) {
+                wave_mul_lo_store<L>(lp.ctil + (size_t)q * L, s_dinv, lp.y_part, 1, tid & (WAVE - 1), false);
+                const int bits = wave_bit_length<L>(lp.ctil + (size_t)q * L, tid & (WAVE - 1));
+                if ((tid & (WAVE - 1)) == 0) word[8] = bits;
+            }
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         stamp(5);
@@ -2217,6 +2377,12 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const int estimate = max(ap_bits + lp.xt_bits[i], lp.x_bits[i] + xp_bits) + 1 - (D_bits - 1);
             if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
         }
+        const int cq_bits = y_rides ? word[8] : 0;
+        if (y_rides)
+            for (int k = gtid; k < m; k += GT) {
+                const int estimate = max(ap_bits + lp.y_bits[k], cq_bits + lp.N_bits[(size_t)k * m + p]) + 1 - (D_bits - 1);
+                if (estimate >= LIMIT_BITS - shift) s_overflow = 1;
+            }
         // The entries of N by what they cost below.  N'_ik = (alpha~_p N_ik - alpha~_i N_pk) / D: two products where N(p, k) != 0 AND
         // alpha~_i != 0, one (the entry is only rescaled) where either is zero, nothing where N_ik is zero as well.  Columns and rows
         // are each split into the two kinds (workgroup 0, ordered lists) and every class of entries is spread over the whole grid by
@@ -2262,7 +2428,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         const int n_heavy = word[7], n_rows_alpha = word[6];
         if constexpr (L >= 32) if (on_matrix_cores) {
-            const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha};
+            const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha, y_rides ? 1 : 0, cq_bits};
             update_on_matrix_cores<L>(lp, scalars, s_c1, products_needed, products_issued, barrier_epoch);
         }
         if (!on_matrix_cores)
@@ -2375,6 +2541,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 lp.trace[4 * trace_count + 3] = leaving;
             }
         }
+        if (!y_rides) y_phase = 0;  // y belongs to the basis that was
         ++trace_count;
         pivots[phase - 1]++;
         grid.sync();  // the new basis, D and (flip) row p for everybody
@@ -2570,7 +2737,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_out = dalloc<int>(16, owned);
     int* d_resume = dalloc<int>(8, owned);
     int* d_removed = dalloc<int>(m, owned);
-    int* d_words = dalloc<int>(8, owned);
+    int* d_words = dalloc<int>(16, owned);
     constexpr int EX_MAX_GRID = 1024;
     double* d_part_key = dalloc<double>(2 * EX_MAX_GRID, owned);
     unsigned long long* d_part_rank = dalloc<unsigned long long>(2 * EX_MAX_GRID, owned);
@@ -2636,13 +2803,14 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         int* d_T_carry = mfma_update ? dalloc<int>((size_t)m * m * (big / 2), fresh) : nullptr;
         int* d_T_words = mfma_update ? dalloc<int>((size_t)m * m, fresh) : nullptr;
         u64* d_y = dalloc<u64>((size_t)m * big, fresh);
-        u64* d_Tx = mfma_update ? dalloc<u64>((size_t)m * big, fresh) : nullptr;
-        int* d_Tx_carry = mfma_update ? dalloc<int>((size_t)m * (big / 2), fresh) : nullptr;
-        int* d_Tx_words = mfma_update ? dalloc<int>((size_t)m, fresh) : nullptr;
+        u64* d_Tx = mfma_update ? dalloc<u64>(2 * (size_t)m * big, fresh) : nullptr;
+        int* d_Tx_carry = mfma_update ? dalloc<int>(2 * (size_t)m * (big / 2), fresh) : nullptr;
+        int* d_Tx_words = mfma_update ? dalloc<int>(2 * (size_t)m, fresh) : nullptr;
+        u64* d_y_part = dalloc<u64>(big, fresh);
         int* d_xt_bits = dalloc<int>((size_t)m, fresh);
         if (mfma_update) {
             RELP_HIP(hipMemsetAsync(d_T_words, 0, (size_t)m * m * sizeof(int), stream));
-            RELP_HIP(hipMemsetAsync(d_Tx_words, 0, (size_t)m * sizeof(int), stream));
+            RELP_HIP(hipMemsetAsync(d_Tx_words, 0, 2 * (size_t)m * sizeof(int), stream));
         }
         auto adopt = [&]() {  // the new width's buffers replace the previous width's
             RELP_HIP(hipStreamSynchronize(stream));
@@ -2687,7 +2855,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
-                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_xt_bits, mfma_update ? 1 : 0, d_barrier};
+                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_xt_bits, mfma_update ? 1 : 0, d_barrier};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
