@@ -705,7 +705,7 @@ struct ExactLP {
     unsigned long long* prof;  // [EX_PROF_WORDS] the leader's time per step of the loop in ticks of the 100 MHz wall clock [0..9], candidate counts [12],
                                // and the word products (64 x 64 -> 128 bit) of the update of N: [16] those the entries need, [17] those the waves issue
     u64* price_a;         // [limbs][n - n_art][m]: (N a_j)_i of the pricing pass, word-major
-    int* price_bits;      // ... its bit bound
+    double* price_err;    // ... and a bound on that share's error (price_estimates: the products are formed from leading words)
     double* price_term;   // ... its share of the steepest-edge estimate
     int* bracket;         // [max(n, m) + 1] the tournament brackets over the candidates
     int* cand;            // [max(n, m) + 1] columns whose key estimate is within 1e-9 of the best (pricing); near-tied rows (ratio test)
@@ -809,14 +809,54 @@ __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& 
 // sum_e v_e N(i, r_e) over the entries [e0, e1) of one column for 64 neighbouring rows, by one wave, word by word (the first pricing
 // pass for every column, the entering column once more): word k of row i's sum goes to out[k * out_stride] (out is this lane's), its
 // leading words to `lead`, and the bit bound of the operands (the fit test's) is returned.
+// (the bit bound of row i's sum -- the operands' bit lengths, no word of N is read -- and the words of the result that the wave forms:
+//  the sum fits `awide` bits, the words above that many are its sign, not worth their operands' loads)
 template <int L>
-__device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0, int e1, int i, bool active, int lane, size_t MM, u64* out, size_t out_stride,
-                                                       LeadingWords& lead) {
+__device__ __forceinline__ int column_products_bound(const ExactLP& lp, int e0, int e1, int i, bool active, int* words_of_wave) {
+    constexpr int KU = L >= 8 ? 8 : (L >= 4 ? 4 : (L >= 2 ? 2 : 1));  // words of the result per turn (stream_column_products)
     const int m = lp.m;
     int awide = 0;
     for (int e = e0; e < e1; ++e)
         if (active) awide = max(awide, lp.N_bits[(size_t)lp.row_index[e] * m + i] + small_bits(lp.value[e]));
     awide += 32 - __clz(e1 - e0 > 1 ? e1 - e0 - 1 : 1) + 1;  // (log2_ceil of the kernel)
+    int words = active ? min(L, (awide + 2 + 63) / 64) : 1;
+    for (int d = 1; d < WAVE; d *= 2) words = max(words, __shfl_xor(words, d));
+    *words_of_wave = min(L, (words + KU - 1) / KU * KU);
+    return awide;
+}
+// 192 bits, two's complement: the running sum of the multiples that reach a word of the result and the words above it
+struct SignedSum {
+    u128 acc = 0;
+    i64 top = 0;
+    __device__ __forceinline__ void add(u128 v) {
+        acc += v;
+        top += acc < v ? 1 : 0;
+    }
+    __device__ __forceinline__ void sub(u128 v) {
+        const bool borrows = acc < v;
+        acc -= v;
+        top -= borrows ? 1 : 0;
+    }
+    __device__ __forceinline__ void add(const SignedSum& other) {
+        acc += other.acc;
+        top += other.top + (acc < other.acc ? 1 : 0);
+    }
+    __device__ __forceinline__ u64 pop() {  // the lowest word leaves, the rest moves down (the sign stays)
+        const u64 word = (u64)acc;
+        acc = (acc >> 64) | ((u128)(u64)top << 64);
+        top >>= 63;
+        return word;
+    }
+};
+// CHUNK: only the words [k_begin, k_limit) of the sum are formed, from those words of the operands alone -- word k - k_begin goes to
+// out[(k - k_begin) * out_stride] and the three words that the chunk carries into the words above it to the places (k_limit - k_begin)
+// + 0, 1, 2 (entering_column_combine adds the chunks up); `lead` is not fed.
+template <int L, bool CHUNK = false>
+__device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0, int e1, int i, bool active, int lane, size_t MM, u64* out, size_t out_stride,
+                                                       LeadingWords& lead, int k_begin = 0, int k_limit = L) {
+    const int m = lp.m;
+    int words = 0;
+    const int awide = column_products_bound<L>(lp, e0, e1, i, active, &words);
     // The column's entries are read once, one per lane, and handed round with readlane (columns of more than 64 entries read
     // them from memory at every use); two words of the result are formed per turn, the operands of both in flight
     // together -- with one wave per SIMD on the grid the pass waits on memory, not on arithmetic.
@@ -843,41 +883,16 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
     //  subtracted -- where there were two unsigned ones and a borrow between them: half the registers, which pay for eight words of
     //  the result per turn instead of four.  The pass waits for memory -- a turn is a round trip per four entries of the column --
     //  and now makes half as many turns.)
-    struct Sum {
-        u128 acc = 0;
-        i64 top = 0;
-        __device__ __forceinline__ void add(u128 v) {
-            acc += v;
-            top += acc < v ? 1 : 0;
-        }
-        __device__ __forceinline__ void sub(u128 v) {
-            const bool borrows = acc < v;
-            acc -= v;
-            top -= borrows ? 1 : 0;
-        }
-        __device__ __forceinline__ void add(const Sum& other) {
-            acc += other.acc;
-            top += other.top + (acc < other.acc ? 1 : 0);
-        }
-        __device__ __forceinline__ u64 pop() {  // the lowest word leaves, the rest moves down (the sign stays)
-            const u64 word = (u64)acc;
-            acc = (acc >> 64) | ((u128)(u64)top << 64);
-            top >>= 63;
-            return word;
-        }
-    };
+    using Sum = SignedSum;
     Sum running;
+    const int k_first = CHUNK ? k_begin : 0, k_end = CHUNK ? min(words, k_limit) : words;
     auto emit = [&](int k) {
         const u64 word = running.pop();
-        if (active) out[(size_t)k * out_stride] = word;
-        lead.feed(k, word);
+        if (active) out[(size_t)(k - k_first) * out_stride] = word;
+        if (!CHUNK) lead.feed(k, word);
     };
     constexpr int KU = L >= 8 ? 8 : (L >= 4 ? 4 : (L >= 2 ? 2 : 1));  // words of the result per turn
-    // (the sum fits `awide` bits: the words above that many are its sign, not worth their operands' loads)
-    int words = active ? min(L, (awide + 2 + 63) / 64) : 1;
-    for (int d = 1; d < WAVE; d *= 2) words = max(words, __shfl_xor(words, d));
-    words = min(L, (words + KU - 1) / KU * KU);
-    for (int k = 0; k < words; k += KU) {
+    for (int k = k_first; k < k_end; k += KU) {
         const u64* word_k = lp.N + (size_t)k * MM + (active ? i : 0);
         Sum next[KU > 1 ? KU - 1 : 1];  // the multiples of the words k + 1 ...
         for (int e = 0; e < len; e += 4) {  // four operands (of every word of the turn) in flight
@@ -909,7 +924,14 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
             emit(k + t);
         }
     }
-    {
+    if (CHUNK) {
+        if (active && k_end > k_first) {
+            u64* carried = out + (size_t)(k_limit - k_first) * out_stride;
+            carried[0] = (u64)running.acc;
+            carried[out_stride] = (u64)(running.acc >> 64);
+            carried[2 * out_stride] = (u64)running.top;
+        }
+    } else {
         const u64 fill = (i64)lead.prev < 0 ? ~0ull : 0ull;
 #pragma unroll L <= 8 ? L : 1
         for (int k = words; k < L; ++k) {
@@ -1436,6 +1458,75 @@ __device__ __forceinline__ int finish_update_entry(const u64* numerator, const i
     return bits;
 }
 
+// The entering column alpha~_q = N a_q, exactly, at the wide types.  One wave per 64 rows streaming the column's operands from word 0 to the
+// last is 13 waves on 25FV47 and 32 round trips one after the other, 0.3 ms a pivot with the rest of the grid waiting.  So the words
+// are cut into chunks of ENTER_CHUNK: a wave forms the words of one chunk for 64 rows from those words of the operands alone
+// (entering_column_chunks: eight times the waves at 128 limbs, an eighth of the turns each), and after a barrier a wave per 64 rows adds
+// the chunks up -- each carries three words into the next -- stores alpha~_i and finds its bit length (entering_column_combine).  The
+// chunks' words lie in price_a, which nobody needs at this point of a pivot ((ENTER_CHUNK + 3) words per chunk and row, word-major).
+constexpr int ENTER_CHUNK = 16;
+template <int L>
+__device__ __noinline__ void entering_column_chunks(const ExactLP& lp, int q) {
+    constexpr int CHUNKS = L / ENTER_CHUNK;
+    const int m = lp.m, lane = threadIdx.x & (WAVE - 1);
+    const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    const size_t MM = (size_t)m * m;
+    const int row_blocks = (m + WAVE - 1) / WAVE;
+    const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[q]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[q + 1]);
+    for (int item = wave_of_grid; item < row_blocks * CHUNKS; item += waves_of_grid) {
+        const int chunk = item / row_blocks, i = (item - chunk * row_blocks) * WAVE + lane;
+        const bool active = i < m;
+        LeadingWords unused;
+        stream_column_products<L, true>(lp, e0, e1, i, active, lane, MM, lp.price_a + (size_t)chunk * (ENTER_CHUNK + 3) * m + (active ? i : 0), (size_t)m, unused,
+                                        chunk * ENTER_CHUNK, (chunk + 1) * ENTER_CHUNK);
+    }
+}
+template <int L>
+__device__ __noinline__ void entering_column_combine(const ExactLP& lp, int q, int limit_bits, int* overflow) {
+    const int m = lp.m, lane = threadIdx.x & (WAVE - 1);
+    const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[q]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[q + 1]);
+    for (int block_a = wave_of_grid; block_a * WAVE < m; block_a += waves_of_grid) {
+        const int i = block_a * WAVE + lane;
+        const bool active = i < m;
+        int words = 0;
+        const int awide = column_products_bound<L>(lp, e0, e1, i, active, &words);
+        u64* alpha_i = lp.alpha + (size_t)(active ? i : 0) * L;
+        LeadingWords lead;
+        SignedSum carried;  // what the chunks below carry into the current word
+        for (int k0 = 0; k0 < words; k0 += ENTER_CHUNK) {
+            const u64* part = lp.price_a + (size_t)(k0 / ENTER_CHUNK) * (ENTER_CHUNK + 3) * m + (active ? i : 0);
+            const int count = min(ENTER_CHUNK, words - k0);  // (a multiple of the eight words of a turn)
+            u64 w[ENTER_CHUNK + 3];
+#pragma unroll
+            for (int t = 0; t < ENTER_CHUNK + 3; ++t) w[t] = (t < count || t >= ENTER_CHUNK) ? part[(size_t)t * m] : 0ull;
+#pragma unroll
+            for (int t = 0; t < ENTER_CHUNK; ++t)
+                if (t < count) {
+                    carried.add((u128)w[t]);
+                    const u64 word = carried.pop();
+                    if (active) alpha_i[k0 + t] = word;
+                    lead.feed(k0 + t, word);
+                }
+            SignedSum above;
+            above.acc = (u128)w[ENTER_CHUNK] | ((u128)w[ENTER_CHUNK + 1] << 64);
+            above.top = (i64)w[ENTER_CHUNK + 2];
+            carried.add(above);
+        }
+        const u64 fill = (i64)lead.prev < 0 ? ~0ull : 0ull;
+        for (int k = words; k < L; ++k) {
+            if (active) alpha_i[k] = fill;
+            lead.feed(k, fill);
+        }
+        if (active) {
+            if (awide >= limit_bits) *overflow = 1;
+            const bool negative = (i64)lead.prev < 0;  // bit length of |alpha~_i| from its leading word
+            const int top = negative ? lead.top_n : lead.top_p;
+            lp.x_bits[i] = top < 0 ? 0 : 64 * top + (64 - __clzll((long long)(negative ? lead.n_top : lead.p_top)));  // (the fit test of the update wants it once per ENTRY of N)
+        }
+    }
+}
+
 // The three passes of the pricing step, each a function of its own -- not inlined, so that the registers of its loop are allocated apart
 // from the state of the pivot loop (as for the update below: with everything in one body, a new variable ANYWHERE in the loop moved the
 // spills of a kernel that is held to 256 registers into these loops -- the pass over N went from 0.8 to 2.1 s of 25FV47's solve and the
@@ -1503,27 +1594,21 @@ __device__ __noinline__ void price_reduced_costs(const ExactLP& lp, int phase, d
         }
     }
 }
-// Pass A for the columns of neg_list: a wave takes a column and 64 neighbouring rows and forms (N a_j)_i word by word, least significant
-// first -- the words of the N(i, r_e) straight from memory (word-major: one coalesced access per operand), the positive and the
-// negative multiples in two carry-save accumulators, their difference stored as it appears.  The bit bound comes from N_bits, the
-// double from the two leading words gathered on the way.
+// The EXACT products (N a_j)_i for the columns of `list` into price_a: a wave takes a column and 64 neighbouring rows and forms the sum
+// word by word, least significant first (stream_column_products); its share of the weight estimate from the two leading words, with no
+// error.  Rounds 2 to 5 ran this for every column that could enter -- each column of N read 3.6 times per pass on 25FV47, 2 GB a pivot,
+// 1.2 of 4.4 s; now it runs for the columns whose estimate could not be bounded (none, so far) and for tied candidates, whose exact
+// weights are sums of these squares.
 template <int L>
-__device__ __noinline__ void price_products(const ExactLP& lp, double mD, int eD, int limit_bits, int* overflow) {
+__device__ __noinline__ void price_products(const ExactLP& lp, const int* list, int count, double mD, int eD, int limit_bits, int* overflow) {
     const int m = lp.m, n = lp.n, lane = threadIdx.x & (WAVE - 1);
     const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
     const size_t MM = (size_t)m * m;
     const size_t PP = (size_t)(n - lp.n_art > 0 ? n - lp.n_art : 1) * m;
     const int row_blocks = (m + WAVE - 1) / WAVE;
-    const int n_negative = lp.neg_list[n];
-    for (long long item = wave_of_grid; item < (long long)n_negative * row_blocks; item += waves_of_grid) {
-#ifdef RELP_PRICE_COLUMN_MAJOR
+    for (long long item = wave_of_grid; item < (long long)count * row_blocks; item += waves_of_grid) {
         const int c = (int)(item / row_blocks), i = (int)(item - (long long)c * row_blocks) * WAVE + lane;
-#else
-        // (the waves in flight share a few blocks of rows and run through the columns: what they read of N -- every column of it 3.6
-        //  times over a pass on 25FV47 -- is then a couple of hundred MB at a time and is served again from the last-level cache)
-        const int rb = (int)(item / n_negative), c = (int)(item - (long long)rb * n_negative), i = rb * WAVE + lane;
-#endif
-        const int j = lp.neg_list[c], jj = j - lp.n_art;
+        const int j = list[c], jj = j - lp.n_art;
         const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
         const bool active = i < m;
         const size_t pair = (size_t)jj * m + (active ? i : 0);
@@ -1531,11 +1616,135 @@ __device__ __noinline__ void price_products(const ExactLP& lp, double mD, int eD
         const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane, MM, lp.price_a + pair, PP, lead);
         if (active) {
             if (awide >= limit_bits) *overflow = 1;
-            lp.price_bits[pair] = awide;
             int ea = 0;
             const double ma = lead.mantissa(&ea);
             const double ad = ldexp(ma / mD, ea - eD);
             lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
+            lp.price_err[pair] = 0.0;
+        }
+    }
+}
+// The weight ESTIMATES of the columns of neg_list from the leading words of the operands only.  key_j = (c~_j / D)^2 / (w_j + sum_i
+// w_i ((N a_j)_i / D)^2) is compared as a double -- every column within 1e-9 of the best goes on to an exact comparison -- so all it
+// needs of (N a_j)_i = sum_e v_e N(i, r_e) is a dozen digits.  A wave takes a column and 64 neighbouring rows; with B the largest bit
+// length among its operands' products (N_bits: no word of N is read for that) it reads the KW = 4 words of every operand that end at B's
+// word -- one round trip, 2 KB per entry of the column where the exact sum reads 64 KB at 128 limbs -- and adds the multiples of those
+// windows exactly (two's complement, KW + 2 words).  What is cut off below the window is less than one unit per operand: the sum is
+// (N a_j)_i / 2^(64 k0) up to sum_e |v_e|, at least 180 - bits(v) bits below the largest product.  That bound is not taken on trust: every
+// term comes with the error it may carry ((2 |a| eps + eps^2) w_i, stored beside it), the pass over the terms adds both up, and a
+// column whose error could reach 1e-11 of its weight is formed exactly (price_products) before anything is decided.  When the window
+// reaches down to word 0 the estimate IS the exact sum's (same leading words, same double).
+template <int L>
+__device__ __noinline__ void price_estimates(const ExactLP& lp, double mD, int eD) {
+    constexpr int KW = L < 4 ? L : 4;  // words of every operand that are read
+    constexpr int SW = KW + 2;         // words of the sum
+    const int m = lp.m, n = lp.n, lane = threadIdx.x & (WAVE - 1);
+    const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    const size_t MM = (size_t)m * m;
+    const int row_blocks = (m + WAVE - 1) / WAVE;
+    const int n_negative = lp.neg_list[n];
+    for (long long item = wave_of_grid; item < (long long)n_negative * row_blocks; item += waves_of_grid) {
+        const int c = (int)(item / row_blocks), i = (int)(item - (long long)c * row_blocks) * WAVE + lane;
+        const int j = lp.neg_list[c], jj = j - lp.n_art;
+        const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[j]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[j + 1]);
+        const bool active = i < m;
+        const int row = active ? i : 0;
+        const size_t pair = (size_t)jj * m + row;
+        // the column's entries, one per lane, handed round with readlane (longer columns read them from memory at every use)
+        const int len = e1 - e0;
+        const bool in_lanes = len <= WAVE;
+        int my_offset = 0;  // row_index * m of entry e0 + lane
+        i64 my_value = 0;
+        if (in_lanes && lane < len) {
+            my_offset = lp.row_index[e0 + lane] * m;
+            my_value = lp.value[e0 + lane];
+        }
+        auto entry = [&](int e, int* offset, i64* value) {  // e uniform over the wave
+            if (in_lanes) {
+                *offset = __builtin_amdgcn_readlane(my_offset, e);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u64)my_value, e);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((u64)my_value >> 32), e);
+                *value = (i64)(((u64)hi << 32) | lo);
+            } else {
+                *offset = lp.row_index[e0 + e] * m;
+                *value = lp.value[e0 + e];
+            }
+        };
+        int B = 0;  // the largest bit length of a product v_e N(i, r_e) over the wave's rows
+        double v_sum = 0.0;  // sum_e |v_e|
+        for (int e = 0; e < len; ++e) {
+            int offset;
+            i64 v;
+            entry(e, &offset, &v);
+            const int bits = active ? lp.N_bits[(size_t)offset + row] : 0;
+            if (bits != 0) B = max(B, bits + small_bits(v));
+            v_sum += fabs((double)v);
+        }
+        for (int d = 1; d < WAVE; d *= 2) B = max(B, __shfl_xor(B, d));
+        B = __builtin_amdgcn_readfirstlane(B);
+        // the window: words k0 .. k0 + KW - 1, the last one holding the sign of every operand (B + 8 bits fit below its top, or it is the
+        // last word of the integers)
+        const int k_top = min(L - 1, max(KW - 1, (B + 8) / 64)), k0 = k_top - (KW - 1);
+        u64 S[SW];
+#pragma unroll
+        for (int t = 0; t < SW; ++t) S[t] = 0;
+        const u64* window = lp.N + (size_t)k0 * MM + row;
+        for (int e = 0; e < len; e += 4) {  // four operands in flight
+            u64 w[4][KW];
+            i64 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int offset;
+                entry(e + u < len ? e + u : len - 1, &offset, &v[u]);
+                if (e + u >= len) v[u] = 0;
+#pragma unroll
+                for (int t = 0; t < KW; ++t) w[u][t] = window[(size_t)t * MM + offset];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
+                const bool x_negative = (i64)w[u][KW - 1] < 0;
+                // |v| X as SW words, two's complement: |v| U - [X < 0] |v| 2^(64 KW) for the unsigned reading U of the window
+                u64 prod[SW];
+                u64 carry = 0;
+#pragma unroll
+                for (int t = 0; t < KW; ++t) {
+                    const u128 pr = (u128)w[u][t] * mag + carry;
+                    prod[t] = (u64)pr;
+                    carry = (u64)(pr >> 64);
+                }
+                prod[KW] = carry - (x_negative ? mag : 0ull);
+                prod[KW + 1] = x_negative && mag != 0 ? ~0ull : 0ull;
+                if (v[u] >= 0) {
+                    u64 cy = 0;
+#pragma unroll
+                    for (int t = 0; t < SW; ++t) {
+                        const u128 sum = (u128)S[t] + prod[t] + cy;
+                        S[t] = (u64)sum;
+                        cy = (u64)(sum >> 64);
+                    }
+                } else {
+                    u64 borrow = 0;
+#pragma unroll
+                    for (int t = 0; t < SW; ++t) {
+                        const u128 diff = (u128)S[t] - prod[t] - borrow;
+                        S[t] = (u64)diff;
+                        borrow = (u64)(diff >> 64) & 1ull;
+                    }
+                }
+            }
+        }
+        if (active) {
+            LeadingWords lead;
+#pragma unroll
+            for (int t = 0; t < SW; ++t) lead.feed(t, S[t]);
+            int ea = 0;
+            const double ma = lead.mantissa(&ea);
+            const double ad = ldexp(ma / mD, ea + 64 * k0 - eD);
+            const double eps = k0 > 0 ? ldexp(v_sum / mD, 64 * k0 - eD) : 0.0;  // what the cut-off words could add to |a_i / D|
+            const double w = (double)lp.weight[lp.basis[i]];
+            lp.price_term[pair] = ad * ad * w;
+            lp.price_err[pair] = (2.0 * fabs(ad) * eps + eps * eps) * w;
         }
     }
 }
@@ -1941,7 +2150,10 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
 #endif
             if (form_y)
                 for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];
-            if (leader) lp.neg_list[n] = 0;
+            if (leader) {
+                lp.neg_list[n] = 0;
+                word[9] = 0;  // (the columns whose estimated weight has to be formed exactly)
+            }
             const int eD = s_eD;
             const double mD = s_mD;
             const int lane = tid & (WAVE - 1);
@@ -1955,27 +2167,46 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             grid.sync();
             stamp(1);
             const int n_negative = lp.neg_list[n];
-            price_products<L>(lp, mD, eD, LIMIT_BITS, &s_overflow);  // pass A for the candidates
+            price_estimates<L>(lp, mD, eD);  // the terms of the weight estimates of the columns that can enter, from the leading words of N
             grid.sync();
-            // ... and their keys: the weight estimate is the sequential sum of the stored terms in the order of the rows (the same doubles
-            // as the one-workgroup form's), key = (c~_j / D)^2 / that
-            for (int c = gtid / WAVE; c < n_negative; c += GT / WAVE) {
-                const int j = lp.neg_list[c];
-                const size_t base = (size_t)(j - lp.n_art) * m;
-                double sumsq = (double)lp.weight[j];
-                for (int i0 = 0; i0 < m; i0 += WAVE) {  // in the order of the rows, by every lane alike
-                    const double term = i0 + lane < m ? lp.price_term[base + i0 + lane] : 0.0;
-                    const int count = min(WAVE, m - i0);
-                    for (int t = 0; t < count; ++t) sumsq += __shfl(term, t);
+            // ... and their keys: the weight estimate is the sequential sum of the stored terms in the order of the rows, key = (c~_j / D)^2
+            // / that; a column whose terms may be off by more than 1e-11 of the sum in all goes on the list of those to be formed exactly
+            auto form_keys = [&](const int* list, int count) {
+                for (int c = gtid / WAVE; c < count; c += GT / WAVE) {
+                    const int j = list[c];
+                    const size_t base = (size_t)(j - lp.n_art) * m;
+                    double sumsq = (double)lp.weight[j], errors = 0.0;
+                    for (int i0 = 0; i0 < m; i0 += WAVE) {  // in the order of the rows, by every lane alike
+                        const double term = i0 + lane < m ? lp.price_term[base + i0 + lane] : 0.0;
+                        errors += i0 + lane < m ? lp.price_err[base + i0 + lane] : 0.0;
+                        const int count_rows = min(WAVE, m - i0);
+                        for (int t = 0; t < count_rows; ++t) sumsq += __shfl(term, t);
+                    }
+                    for (int d = 1; d < WAVE; d *= 2) errors += __shfl_xor(errors, d);
+                    const double cd = lp.cd[j];
+                    if (lane == 0) {
+                        lp.key[j] = cd * cd / sumsq;
+                        if (!(errors <= 1e-11 * sumsq)) lp.bracket[atomicAdd(&word[9], 1)] = j;
+                    }
                 }
-                const double cd = lp.cd[j];
-                if (lane == 0) lp.key[j] = cd * cd / sumsq;
-            }
+            };
+            form_keys(lp.neg_list, n_negative);
             if (leader) {  // (diagnostic: how many of the priced columns have a negative reduced cost)
                 lp.prof[30] += n_negative;
                 lp.prof[31] += 1;
             }
             if (sync_overflow()) { status = EX_OVERFLOW; break; }  // (before any decision is taken on values that may not have fit)
+            const int n_inexact = word[9];
+            if (n_inexact > 0) {  // the columns whose estimate is not good enough: their products exactly, their keys from those
+                price_products<L>(lp, lp.bracket, n_inexact, mD, eD, LIMIT_BITS, &s_overflow);
+                grid.sync();
+                if (leader) {
+                    lp.prof[13] += n_inexact;
+                    word[9] = 0;
+                }
+                form_keys(lp.bracket, n_inexact);  // (exact terms carry no error: nothing is listed again)
+                if (sync_overflow()) { status = EX_OVERFLOW; break; }
+            }
             stamp(9);
             // the largest estimate; ties to the larger index ("last maximum", pivot_rule.rs:230-240)
             double best = 0.0;
@@ -2005,6 +2236,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     // gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 exactly ((2 L + 2)-limb sums of squares).  The (N a_j)_i are the ones
                     // the pricing pass stored; a thread per (candidate, row) squares one of them, a thread per candidate adds them up.
                     constexpr int GW = 2 * L + 2;
+                    price_products<L>(lp, lp.cand, n_cand, mD, eD, LIMIT_BITS, &s_overflow);  // (the estimates left nothing in price_a)
+                    grid.sync();
                     for (long long pair = gtid; pair < (long long)n_cand * (m + 1); pair += GT) {
                         const int c = (int)(pair / (m + 1)), i = (int)(pair - (long long)c * (m + 1));
                         const int j = lp.cand[c];
@@ -2133,54 +2366,15 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if constexpr (L >= 16) {  // the wide types: streamed like the pricing pass, a wave per 64 rows (a thread per row with its integers in scratch: 1.2 ms a pivot at 128 limbs)
             const int e0 = lp.col_start[q], e1 = lp.col_start[q + 1];
             const int lane_a = tid & (WAVE - 1);
-            if (p < 0) {
-                // q came out of the pricing pass: its products (N a_q)_i are in price_a already (a candidate: c~_q < 0) -- a wave per row
-                // copies the words (a lane per word) and finds the bit length from the highest word that is not the sign.  (Thirteen
-                // waves streaming the column again, ~100 us of dependent turns, were most of this step.)
-                const u64* column_q = lp.price_a + (size_t)(q - lp.n_art) * m;
-                for (int i = gtid / WAVE; i < m; i += GT / WAVE) {
-                    constexpr int SLOTS = (L + WAVE - 1) / WAVE;
-                    u64 w[SLOTS];
-#pragma unroll
-                    for (int t = 0; t < SLOTS; ++t) {
-                        const int k = lane_a + t * WAVE;
-                        w[t] = k < L ? column_q[(size_t)k * PP + i] : 0ull;
-                        if (k < L) lp.alpha[(size_t)i * L + k] = w[t];
-                    }
-                    const u64 top_word = __shfl(w[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
-                    const bool negative = (i64)top_word < 0;
-                    const u64 sign = negative ? ~0ull : 0ull;
-                    int top = -1;  // the highest word that differs from the sign
-                    u64 at_top = 0;
-#pragma unroll
-                    for (int t = SLOTS - 1; t >= 0; --t) {
-                        const unsigned long long differs = __ballot(lane_a + t * WAVE < L && w[t] != sign);
-                        if (top < 0 && differs != 0) {
-                            const int owner = 63 - __clzll((long long)differs);
-                            top = owner + t * WAVE;
-                            at_top = __shfl(w[t], owner);
-                        }
-                    }
-                    // (|v| = ~v + 1 for a negative v: the bits of ~v, one more when the + 1 carries into a new bit: v = -(2^k), all words
-                    //  below the top one zero and the top word of ~v of the form 2^j - 1)
-                    bool zeros_below = true;
-#pragma unroll
-                    for (int t = 0; t < SLOTS; ++t) zeros_below = zeros_below && __ballot(lane_a + t * WAVE < top && w[t] != 0) == 0;
-                    if (lane_a == 0) {
-                        int bits = 0;
-                        if (!negative) {
-                            if (top >= 0) bits = 64 * top + (64 - __clzll((long long)at_top));
-                        } else if (top < 0) {
-                            bits = 1;  // -1
-                        } else {
-                            const u64 inverted = ~at_top;  // (non-zero: the word differs from the sign)
-                            bits = 64 * top + (64 - __clzll((long long)inverted));
-                            if (zeros_below && (inverted & (inverted + 1)) == 0) bits += 1;
-                        }
-                        lp.x_bits[i] = bits;
-                    }
+            // (rounds 4-5 copied a priced column's products out of price_a; the pricing pass now forms estimates only)
+            if constexpr (L >= 2 * ENTER_CHUNK) {
+                if (n - lp.n_art >= 2) {  // (price_a holds the chunks: (L / 16) 19 m words)
+                    entering_column_chunks<L>(lp, q);
+                    grid.sync();
+                    entering_column_combine<L>(lp, q, LIMIT_BITS, &s_overflow);
                 }
-            } else
+            }
+            if (L < 2 * ENTER_CHUNK || n - lp.n_art < 2)
             for (int block_a = gtid / WAVE; block_a * WAVE < m; block_a += GT / WAVE) {
                 const int i = block_a * WAVE + lane_a;
                 const bool active = i < m;
@@ -2746,7 +2940,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     const bool print_profile = diagnostic("RELP_EXACT_PROFILE");
     const size_t pairs = (size_t)std::max(1, n - n_art) * m;
     u64* d_price_a = nullptr;   // (sized per limb count below)
-    int* d_price_bits = dalloc<int>(pairs, owned);
+    double* d_price_err = dalloc<double>(pairs, owned);
     double* d_price_term = dalloc<double>(pairs, owned);
     int* d_bracket = dalloc<int>(std::max(n, m) + 1, owned);
     int* d_cand = dalloc<int>(std::max(n, m) + 1, owned);
@@ -2854,7 +3048,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemsetAsync(d_barrier, 0, EX_BARRIER_WORDS * sizeof(unsigned), stream));
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_bits, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_err, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
                    d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_xt_bits, mfma_update ? 1 : 0, d_barrier};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
