@@ -1053,23 +1053,62 @@ __device__ __forceinline__ double reduced_cost_wave(const ExactLP& lp, const u64
     u64 top_p[SLOTS], top_q[SLOTS];
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) { acc_p[t] = acc_q[t] = 0; top_p[t] = top_q[t] = 0; }
-    int widest = 0;
-    for (int e = e0; e < e1; ++e) {  // (the same entries for every lane)
-        const int r = lp.row_index[e];
-        const i64 v = lp.value[e];
-        widest = max(widest, lp.y_bits[r] + small_bits(v));
-        const u64 mag = v < 0 ? (u64)(-(v + 1)) + 1 : (u64)v;
+    // (The column's entries are read once, one per lane -- row, value and the bit length of that y -- and handed round with readlane;
+    //  the words of four y's are requested together.  Entry after entry, each with its row index, then y's bit length, then y's words
+    //  one after the other, a column of seven entries was fourteen round trips: a third of this pass.)
+    const int len = e1 - e0;
+    const bool in_lanes = len <= WAVE;
+    int my_row = 0, my_bits = 0;
+    i64 my_value = 0;
+    if (in_lanes && lane < len) {
+        my_row = lp.row_index[e0 + lane];
+        my_value = lp.value[e0 + lane];
+        my_bits = lp.y_bits[my_row] + small_bits(my_value);
+    }
+    int widest = my_bits;
+    if (in_lanes) {
+        for (int d = 1; d < WAVE; d *= 2) widest = max(widest, __shfl_xor(widest, d));
+    } else {
+        for (int e = e0; e < e1; ++e) widest = max(widest, lp.y_bits[lp.row_index[e]] + small_bits(lp.value[e]));
+    }
+    auto entry = [&](int e, int* row, i64* value) {  // e uniform over the wave
+        if (in_lanes) {
+            *row = __builtin_amdgcn_readlane(my_row, e);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u64)my_value, e);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((u64)my_value >> 32), e);
+            *value = (i64)(((u64)hi << 32) | lo);
+        } else {
+            *row = lp.row_index[e0 + e];
+            *value = lp.value[e0 + e];
+        }
+    };
+    for (int e = 0; e < len; e += 4) {
+        u64 w[4][SLOTS];
+        i64 v[4];
 #pragma unroll
-        for (int t = 0; t < SLOTS; ++t) {
-            const int k = lane + t * WAVE;
-            const u64 w = k < L ? lp.y[(size_t)r * L + k] : 0ull;
-            const u128 prod = (u128)w * mag;
-            if (v >= 0) {
-                acc_p[t] += prod;
-                top_p[t] += acc_p[t] < prod ? 1 : 0;
-            } else {
-                acc_q[t] += prod;
-                top_q[t] += acc_q[t] < prod ? 1 : 0;
+        for (int u = 0; u < 4; ++u) {
+            int r;
+            entry(e + u < len ? e + u : len - 1, &r, &v[u]);
+            if (e + u >= len) v[u] = 0;
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t) {
+                const int k = lane + t * WAVE;
+                w[u][t] = k < L ? lp.y[(size_t)r * L + k] : 0ull;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u64 mag = v[u] < 0 ? (u64)(-(v[u] + 1)) + 1 : (u64)v[u];
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t) {
+                const u128 prod = (u128)w[u][t] * mag;
+                if (v[u] >= 0) {
+                    acc_p[t] += prod;
+                    top_p[t] += acc_p[t] < prod ? 1 : 0;
+                } else {
+                    acc_q[t] += prod;
+                    top_q[t] += acc_q[t] < prod ? 1 : 0;
+                }
             }
         }
     }
@@ -1077,6 +1116,14 @@ __device__ __forceinline__ double reduced_cost_wave(const ExactLP& lp, const u64
     widest = max(widest, D_bits + small_bits(cj));
     *bits_bound = widest;
     // the words in order: running 192-bit sums of the positive and of the negative multiples, their difference, then c_j D - that
+    // (the words of D: a lane holds its own and hands them out -- read from memory inside the chain they were 128 round trips of its 16 us)
+    u64 d_lane[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) d_lane[t] = lane + t * WAVE < L ? D[lane + t * WAVE] : 0ull;
+    auto from_lane = [](u64 v, int source) {  // (source uniform: two v_readlane, no trip through LDS)
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, source), hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), source);
+        return ((u64)hi << 32) | lo;
+    };
     u128 run_p = 0, run_q = 0;
     u64 run_p_top = 0, run_q_top = 0, borrow = 0, carry_x = 0, chain = 0;
     bool negation_carry = true;
@@ -1084,15 +1131,17 @@ __device__ __forceinline__ double reduced_cost_wave(const ExactLP& lp, const u64
 #pragma unroll L <= 8 ? L : 1
     for (int k = 0; k < L; ++k) {
         const int owner = k & (WAVE - 1), slot = k / WAVE;
-        u64 part[6];
+        u64 part[6], d_word = 0;
 #pragma unroll
         for (int t = 0; t < SLOTS; ++t)
             if (t == slot) {
                 part[0] = (u64)acc_p[t]; part[1] = (u64)(acc_p[t] >> 64); part[2] = top_p[t];
                 part[3] = (u64)acc_q[t]; part[4] = (u64)(acc_q[t] >> 64); part[5] = top_q[t];
+                d_word = d_lane[t];
             }
 #pragma unroll
-        for (int c = 0; c < 6; ++c) part[c] = __shfl(part[c], owner);
+        for (int c = 0; c < 6; ++c) part[c] = from_lane(part[c], owner);
+        d_word = from_lane(d_word, owner);
         auto add192 = [](u128& low, u64& top, u64 a0, u64 a1, u64 a2) {  // (low, top) += a0 + 2^64 a1 + 2^128 a2
             const u128 add = (u128)a0 | ((u128)a1 << 64);
             low += add;
@@ -1107,7 +1156,7 @@ __device__ __forceinline__ double reduced_cost_wave(const ExactLP& lp, const u64
         const u64 t = pk - qk;
         const u64 sum_word = t - borrow;  // word k of sum_e v_e y[r_e]
         borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
-        const u128 multiple = (u128)D[k] * cj_mag + carry_x;  // word k of |c_j| D
+        const u128 multiple = (u128)d_word * cj_mag + carry_x;  // word k of |c_j| D
         const u64 x_word = (u64)multiple;
         carry_x = (u64)(multiple >> 64);
         u64 word;
@@ -1672,13 +1721,21 @@ __device__ __noinline__ void price_estimates(const ExactLP& lp, double mD, int e
         };
         int B = 0;  // the largest bit length of a product v_e N(i, r_e) over the wave's rows
         double v_sum = 0.0;  // sum_e |v_e|
-        for (int e = 0; e < len; ++e) {
-            int offset;
-            i64 v;
-            entry(e, &offset, &v);
-            const int bits = active ? lp.N_bits[(size_t)offset + row] : 0;
-            if (bits != 0) B = max(B, bits + small_bits(v));
-            v_sum += fabs((double)v);
+        for (int e = 0; e < len; e += 4) {  // (four bit lengths in flight)
+            int bits[4];
+            i64 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int offset;
+                entry(e + u < len ? e + u : len - 1, &offset, &v[u]);
+                if (e + u >= len) v[u] = 0;
+                bits[u] = active ? lp.N_bits[(size_t)offset + row] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (bits[u] != 0 && v[u] != 0) B = max(B, bits[u] + small_bits(v[u]));
+                v_sum += fabs((double)v[u]);
+            }
         }
         for (int d = 1; d < WAVE; d *= 2) B = max(B, __shfl_xor(B, d));
         B = __builtin_amdgcn_readfirstlane(B);
