@@ -731,6 +731,7 @@ struct ExactLP {
     u64* y_part;          // [limbs] c~_q / D_odd modulo 2^(64 limbs): y's factor of the update, as x_part holds the rows'
     int* xt_bits;         // [m] bit length of |x~_i|, kept by whoever writes an entry
     int mfma_update;      // 1: the update runs on the matrix cores
+    int price_exactly;    // 1: every column that can enter has its products formed exactly (test hook: the path of a column whose estimate is not good enough)
     unsigned* barrier;    // [EX_BARRIER_WORDS] the grid barrier's counters (grid_barrier), zero at the launch
 };
 
@@ -2228,6 +2229,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             grid.sync();
             // ... and their keys: the weight estimate is the sequential sum of the stored terms in the order of the rows, key = (c~_j / D)^2
             // / that; a column whose terms may be off by more than 1e-11 of the sum in all goes on the list of those to be formed exactly
+            const double error_allowed = lp.price_exactly ? -1.0 : 1e-11;
             auto form_keys = [&](const int* list, int count) {
                 for (int c = gtid / WAVE; c < count; c += GT / WAVE) {
                     const int j = list[c];
@@ -2243,7 +2245,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     const double cd = lp.cd[j];
                     if (lane == 0) {
                         lp.key[j] = cd * cd / sumsq;
-                        if (!(errors <= 1e-11 * sumsq)) lp.bracket[atomicAdd(&word[9], 1)] = j;
+                        if (!(errors <= error_allowed * sumsq)) lp.bracket[atomicAdd(&word[9], 1)] = j;
                     }
                 }
             };
@@ -2261,7 +2263,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     lp.prof[13] += n_inexact;
                     word[9] = 0;
                 }
-                form_keys(lp.bracket, n_inexact);  // (exact terms carry no error: nothing is listed again)
+                form_keys(lp.bracket, n_inexact);  // (exact terms carry no error: nothing is listed again -- the test hook lists them all again, to no effect)
                 if (sync_overflow()) { status = EX_OVERFLOW; break; }
             }
             stamp(9);
@@ -3049,7 +3051,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
         // the update of N on the matrix cores (mfma_update_tile): from 32 limbs on (update_mode 1: never).  (At 16 limbs -- two
         // 64-byte blocks per integer -- the path was tried and hung on ISRAEL, unexplained; it is not compiled for that width.)
-        const bool mfma_update = limbs >= 32 && update_mode != 1;
+        const bool mfma_update = limbs >= 32 && (update_mode & 1) == 0;
         u64* d_T = mfma_update ? dalloc<u64>((size_t)m * m * big, fresh) : nullptr;
         int* d_T_carry = mfma_update ? dalloc<int>((size_t)m * m * (big / 2), fresh) : nullptr;
         int* d_T_words = mfma_update ? dalloc<int>((size_t)m * m, fresh) : nullptr;
@@ -3106,7 +3108,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_err, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
-                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_xt_bits, mfma_update ? 1 : 0, d_barrier};
+                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_xt_bits, mfma_update ? 1 : 0, (update_mode & 2) ? 1 : 0, d_barrier};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));

@@ -120,3 +120,20 @@ def test_whole_traces_on_the_matrix_cores_and_on_the_vector_unit(name, monkeypat
         results.append((got["trace"], list(got["basis"]), got["objective"]))
         assert counters and counters[-1]["update_word_products_issued"] > 0
     assert results[0] == results[1]
+
+
+@pytest.mark.parametrize("name", ["STOCFOR1", "SHARE1B", "E226", "BANDM", "SCSD1", "ISRAEL"])
+def test_weight_estimates_from_leading_words_and_exact_products_choose_the_same_pivots(name):
+    """The pricing pass estimates the steepest-edge weights from the four leading words of every operand of N a_j, with an error bound per
+    term, and forms a column's products exactly only where the bound asks (price_estimates / price_products in exact.hip).  Bit 2 of
+    `relp_options.exact_update` sends EVERY column that can enter down the exact path: same golden trace, basis and optimum either way."""
+    golden = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    results = []
+    for mode in (0, 2):
+        solver = relp_amd.Solver(exact_update=mode).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
+        got = solver.solve_exact(first_limbs=4, max_limbs=64)
+        solver.close()
+        assert got["status"] == 1 and Fraction(got["objective"]) == Fraction(golden["objective"])
+        assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"])
+        results.append((got["trace"], list(got["basis"]), got["objective"]))
+    assert results[0] == results[1]
