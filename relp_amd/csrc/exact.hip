@@ -271,16 +271,23 @@ __device__ __noinline__ void wave_mul_lo_store(const u64* a, const u64* b, u64* 
     u64 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0;
-    if (lane < NB) {
+    // (block I of a is read ONCE, by lane I, and handed to everybody with readlane when its turn comes: read from memory inside the
+    //  loop, every turn was a round trip -- 32 of them at 128 limbs, 40 us for a product that is 3 us of arithmetic)
+    u64 a_mine[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_mine[t] = lane < NB ? a[4 * lane + t] : 0ull;
+    {
 #pragma unroll 1
-        for (int I = 0; I <= lane; ++I) {
+        for (int I = 0; I < NB; ++I) {
             const int J = lane - I;
             u64 a4[4], b4[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                a4[t] = a[4 * I + t];
-                b4[t] = b[4 * J + t];
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)a_mine[t], I), hi = (unsigned)__builtin_amdgcn_readlane((int)(a_mine[t] >> 32), I);
+                a4[t] = ((u64)hi << 32) | lo;
+                b4[t] = (J >= 0 && lane < NB) ? b[4 * J + t] : 0ull;
             }
+            if (J < 0 || lane >= NB) continue;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 u64 carry = 0;
@@ -483,6 +490,141 @@ __device__ __forceinline__ void block_mul_lo(const u64* a, int la, const u64* b,
             r1 = (u64)mid;
             r2 = part[3 * c + 2] + (u64)(mid >> 64);
         }
+    }
+    __syncthreads();
+}
+// a * b modulo 2^(256 nb) -- or 2 minus that -- for word arrays in LDS (a: 4 nb words, b: 4 nb_b words, out: 4 nb words, distinct from
+// both), by ONE wave: lane K < nb forms the block products that land in output block K, then the windows are chained in order by every
+// lane alike (as wave_mul_lo_store).  The caller puts workgroup barriers around it.
+__device__ __forceinline__ void wave_mul_lo_lds(const u64* a, const u64* b, int nb_b, u64* out, int nb, int lane, bool two_minus) {
+    u64 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0;
+#pragma unroll 1
+    for (int J = 0; J < nb_b; ++J) {  // (J the same for every lane: b's block is one broadcast read)
+        const int I = lane - J;
+        if (I < 0 || lane >= nb) continue;
+        u64 a4[4], b4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a4[t] = a[4 * I + t];
+            b4[t] = b[4 * J + t];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            u64 carry = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const u128 t = (u128)a4[ii] * b4[jj] + acc[ii + jj] + carry;
+                acc[ii + jj] = (u64)t;
+                carry = (u64)(t >> 64);
+            }
+#pragma unroll
+            for (int k = ii + 4; k < 9; ++k) {
+                const u128 t = (u128)acc[k] + carry;
+                acc[k] = (u64)t;
+                carry = (u64)(t >> 64);
+            }
+        }
+    }
+    u64 over[5] = {0, 0, 0, 0, 0};  // what the blocks below carry into the current one
+    u64 complement_carry = 3;        // 2 - v = ~v + 3
+#pragma unroll 1
+    for (int K = 0; K < nb; ++K) {
+        u64 window[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)acc[k], K), hi = (unsigned)__builtin_amdgcn_readlane((int)(acc[k] >> 32), K);
+            window[k] = ((u64)hi << 32) | lo;
+        }
+        u64 carry = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const u128 t = (u128)window[k] + (k < 5 ? over[k] : 0ull) + carry;
+            window[k] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u64 word = window[t];
+            if (two_minus) {
+                const u128 sum = (u128)(~word) + complement_carry;
+                word = (u64)sum;
+                complement_carry = (u64)(sum >> 64);
+            }
+            if (lane == 0) out[4 * K + t] = word;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) over[k] = window[k + 4];
+    }
+}
+// 1 / d modulo 2^(64 L) for the wide types (L >= 16), d odd, all arrays in LDS: the first four words by one thread (Newton's doubling on
+// 64-bit and 128-bit arithmetic), then every doubling is two truncated products by the FIRST WAVE of the workgroup (wave_mul_lo_lds).
+// (block_inverse_odd's products -- a thread per column of the product, its operands read from LDS term by term, then one thread
+//  running the carries through 128 columns -- made 105 us of every pivot at 128 limbs; this is 15.)
+template <int L>
+__device__ void wave_inverse_odd(const u64* d, u64* x, u64* t, u64* x2) {
+    static_assert(L >= 16 && L % 4 == 0, "blocks of four words");
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    if (tid == 0) {
+        auto mul_lo = [](const u64* p, const u64* q, u64* r, int n) {  // r = p q modulo 2^(64 n), n <= 4
+            u64 w[4] = {0, 0, 0, 0};
+            for (int i = 0; i < n; ++i) {
+                u64 carry = 0;
+                for (int j = 0; i + j < n; ++j) {
+                    const u128 pr = (u128)p[i] * q[j] + w[i + j] + carry;
+                    w[i + j] = (u64)pr;
+                    carry = (u64)(pr >> 64);
+                }
+            }
+            for (int i = 0; i < n; ++i) r[i] = w[i];
+        };
+        u64 d4[4] = {d[0], d[1], d[2], d[3]}, x4[4] = {0, 0, 0, 0};
+        u64 inv = d4[0];  // d * d = 1 (mod 8): three correct bits, doubled five times
+        for (int k = 0; k < 5; ++k) inv *= 2 - d4[0] * inv;
+        x4[0] = inv;
+        for (int want = 2; want <= 4; want *= 2) {
+            u64 t4[4], y4[4];
+            mul_lo(d4, x4, t4, want);
+            u64 carry = 3;  // t <- 2 - t = ~t + 3
+            for (int k = 0; k < want; ++k) {
+                const u128 sum = (u128)(~t4[k]) + carry;
+                t4[k] = (u64)sum;
+                carry = (u64)(sum >> 64);
+            }
+            mul_lo(t4, x4, y4, want);
+            for (int k = 0; k < want; ++k) x4[k] = y4[k];
+        }
+        for (int k = 0; k < 4; ++k) x[k] = x4[k];
+    }
+    __syncthreads();
+    for (int have = 4; have < L; have *= 2) {
+        const int want = 2 * have < L ? 2 * have : L;
+        if (tid < WAVE) wave_mul_lo_lds(d, x, have / 4, t, want / 4, lane, true);  // t = 2 - d x
+        __syncthreads();
+        if (tid < WAVE) wave_mul_lo_lds(t, x, have / 4, x2, want / 4, lane, false);
+        __syncthreads();
+        if (tid < want) x[tid] = x2[tid];
+        __syncthreads();
+    }
+}
+// odd = v >> ctz(v) for a positive integer of L words in LDS (v != 0), by the whole workgroup: a thread per word, the lowest non-zero
+// word from the waves' ballots (`scratch`: a word per wave, LDS); the caller's barrier before, one after
+template <int L>
+__device__ __forceinline__ void block_odd_part(const u64* v, u64* odd, u64* scratch) {
+    const int tid = threadIdx.x;
+    const u64 w = tid < L ? v[tid] : 0ull;
+    const unsigned long long nonzero = __ballot(w != 0);
+    if ((tid & (WAVE - 1)) == 0) scratch[tid / WAVE] = nonzero;
+    __syncthreads();
+    int low = 0;
+    for (int wv = (int)blockDim.x / WAVE - 1; wv >= 0; --wv)
+        if (scratch[wv] != 0) low = WAVE * wv + __ffsll((long long)scratch[wv]) - 1;
+    const int shift_bits = 64 * low + __ffsll((long long)v[low]) - 1;
+    if (tid < L) {
+        const int ws = shift_bits >> 6, bs = shift_bits & 63;
+        const u64 lo = tid + ws < L ? v[tid + ws] : 0ull, hi = tid + ws + 1 < L ? v[tid + ws + 1] : 0ull;
+        odd[tid] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
     }
     __syncthreads();
 }
@@ -729,6 +871,7 @@ struct ExactLP {
     int* Tx_carry;        //   and for y, one more ROW of N (entries m .. 2 m - 1: y'_k = (alpha~_p y_k + c~_q N(p, k)) / D)
     int* Tx_words;
     u64* y_part;          // [limbs] c~_q / D_odd modulo 2^(64 limbs): y's factor of the update, as x_part holds the rows'
+    u64* next_dinv;       // [limbs] 1 / D'_odd for the NEXT pivot, formed by the last workgroup while the others update N (update_on_matrix_cores)
     int* xt_bits;         // [m] bit length of |x~_i|, kept by whoever writes an entry
     int mfma_update;      // 1: the update runs on the matrix cores
     int price_exactly;    // 1: every column that can enter has its products formed exactly (test hook: the path of a column whose estimate is not good enough)
@@ -1815,7 +1958,7 @@ struct UpdateScalars {
     int with_y, cq_bits;  // y = c_B' N rides along as one more row of N (its factor c~_q u in lp.y_part), |c~_q| has that many bits
 };
 template <int L>
-__device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const UpdateScalars sc, const u64* s_c1, unsigned long long& products_needed,
+__device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const UpdateScalars sc, const u64* s_c1, const u64* s_ap, unsigned long long& products_needed,
                                                     unsigned long long& products_issued, unsigned& barrier_epoch) {
     struct {
         unsigned* words;
@@ -1839,8 +1982,31 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
         const UpdateTileArgs tile_args{lp.x_part, m, lp.prof};
         const lds_u32* toeplitz_lds = (const lds_u32*)&s_update.toeplitz[0][0][0];
         const lds_i32* prefix_lds = (const lds_i32*)&s_update.prefix[0][0];
+        // The LAST workgroup takes no tiles: it forms 1 / D'_odd (D' = |alpha~_p|) for the next pivot meanwhile -- five doublings of two
+        // truncated products each, 0.1 ms at 128 limbs that every workgroup spent at the top of every pivot with nothing beside it.
+        const bool inverse_duty = G > 1 && block == G - 1;
+        const int tile_blocks = G > 1 ? G - 1 : G;  // workgroups that take tiles
         __syncthreads();
-        build_toeplitz<L>(s_update, 0, s_c1);  // alpha~_p u: the same operand for every entry of N
+        if (inverse_duty) {
+            u64* buffer = (u64*)&s_update.prefix[0][0];  // (8 L words: this workgroup builds no operand images)
+            u64 *d_odd = buffer, *x = buffer + L, *t = buffer + 2 * L, *x2 = buffer + 3 * L, *scratch = buffer + 4 * L;
+            if (tid < L) x2[tid] = s_ap[tid];
+            __syncthreads();
+            if (flip && tid == 0) {  // (a zero-level pivot on a negative element: D' = -alpha~_p)
+                bool carry = true;
+                for (int k = 0; k < L; ++k) {
+                    const u64 w = ~x2[k] + (carry ? 1ull : 0ull);
+                    carry = carry && x2[k] == 0;
+                    x2[k] = w;
+                }
+            }
+            __syncthreads();
+            block_odd_part<L>(x2, d_odd, scratch);
+            wave_inverse_odd<L>(d_odd, x, t, x2);
+            if (tid < L) lp.next_dinv[tid] = x[tid];
+        } else {
+            build_toeplitz<L>(s_update, 0, s_c1);  // alpha~_p u: the same operand for every entry of N
+        }
         __syncthreads();
         unsigned long long t_sub = wall_clock64();
         auto substamp = [&](int slot) {  // (diagnostic: the leader's time inside the update: [20] both-term tiles, [21] rescaled tiles, [22] barrier, [23] second pass)
@@ -1866,8 +2032,8 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             //  longer reads the whole of N once per pivot to form it: 0.8 of 25FV47's 5.4 s.)
             const int tiles_per_column = (n_rows_alpha + 15) / 16, tiles_of_x = (m + 15) / 16, tiles_of_y = sc.with_y ? (m + 15) / 16 : 0;
             const long long total_N = (long long)n_heavy * tiles_per_column, total = total_N + tiles_of_x + tiles_of_y;
-            const long long per_block = (total + G - 1) / G;
-            long long u = min(total, (long long)block * per_block);
+            const long long per_block = (total + tile_blocks - 1) / tile_blocks;
+            long long u = inverse_duty ? total : min(total, (long long)block * per_block);
             const long long u_end = min(total, u + per_block);
             const size_t M2 = 2 * (size_t)m;  // stride of the numerators of x~_B and y
             while (u < u_end) {
@@ -1916,7 +2082,7 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             const int rest_rows = m - n_rows_alpha;
             const int tiles_a = (rest_rows + 15) / 16, tiles_b = (m + 15) / 16;
             const long long total_a = (long long)n_heavy * tiles_a, total_b = (long long)(m - n_heavy) * tiles_b;
-            for (long long t = (long long)block * waves + wave; t < total_a + total_b; t += (long long)G * waves) {
+            for (long long t = inverse_duty ? total_a + total_b : (long long)block * waves + wave; t < total_a + total_b; t += (long long)tile_blocks * waves) {
                 int k, row;
                 if (t < total_a) {
                     const int kk = (int)(t / tiles_a), first = 16 * (int)(t - (long long)kk * tiles_a);
@@ -2020,6 +2186,15 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             t_last = t;
         }
     };
+    unsigned long long t_mark = 0;
+    auto mark = [&]() { if (leader) t_mark = wall_clock64(); };  // (diagnostic: parts of a step, prof[10, 11, 14, 15, 18, 19])
+    auto lap = [&](int k) {
+        if (leader) {
+            const unsigned long long t = wall_clock64();
+            lp.prof[k] += t - t_mark;
+            t_mark = t;
+        }
+    };
     unsigned long long products_needed = 0, products_issued = 0;  // this thread's word products in the update of N, whole run
     bool on_matrix_cores = false;  // the update of N by mfma_update_tile
     if constexpr (L >= 32) on_matrix_cores = lp.mfma_update != 0;
@@ -2078,6 +2253,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     grid.sync();
     int at_phase = phase, at_drive_row = drive_row, at_removed = n_removed;  // ... at the start of the current turn of the loop
     bool have_xb = false;  // x~_B belongs to the current basis
+    bool dinv_ready = false;  // lp.next_dinv holds 1 / D_odd of the current D
     int y_phase = 0;       // lp.y = c_B' N belongs to the current basis and to this phase's costs (0: to neither); on the matrix cores a pivot
                            // carries it along as one more row of N, otherwise every pricing pass forms it
     while (status == EX_RUNNING) {
@@ -2142,7 +2318,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             __syncthreads();
         }
         if constexpr (L >= 16) D_bits = s_D_bits;
-        block_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2], s_part);
+        mark();
+        if (dinv_ready) {  // (formed beside the previous pivot's update)
+            if (tid < L) s_dinv[tid] = lp.next_dinv[tid];
+            __syncthreads();
+        } else if constexpr (L >= 16) wave_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2]);
+        else block_inverse_odd<L>(s_words[0], s_dinv, s_words[1], s_words[2], s_part);
+        lap(14);
         const int shift = s_shift;
         Big<L> Dinv;
         if constexpr (L < 16) {
@@ -2428,9 +2610,12 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             // (rounds 4-5 copied a priced column's products out of price_a; the pricing pass now forms estimates only)
             if constexpr (L >= 2 * ENTER_CHUNK) {
                 if (n - lp.n_art >= 2) {  // (price_a holds the chunks: (L / 16) 19 m words)
+                    mark();
                     entering_column_chunks<L>(lp, q);
                     grid.sync();
+                    lap(10);
                     entering_column_combine<L>(lp, q, LIMIT_BITS, &s_overflow);
+                    lap(11);
                 }
             }
             if (L < 2 * ENTER_CHUNK || n - lp.n_art < 2)
@@ -2463,7 +2648,9 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store)
             grid.sync();
+            lap(18);  // (the barrier after the entering column)
             for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
+            lap(19);
             // ... and y's factor c~_q u, by the last wave of the grid (y rides along with the update of N, see update_on_matrix_cores)
             if (y_rides && gtid / WAVE == GT / WAVE - 1) {
                 wave_mul_lo_store<L>(lp.ctil + (size_t)q * L, s_dinv, lp.y_part, 1, tid & (WAVE - 1), false);
@@ -2682,7 +2869,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         const int n_heavy = word[7], n_rows_alpha = word[6];
         if constexpr (L >= 32) if (on_matrix_cores) {
             const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha, y_rides ? 1 : 0, cq_bits};
-            update_on_matrix_cores<L>(lp, scalars, s_c1, products_needed, products_issued, barrier_epoch);
+            update_on_matrix_cores<L>(lp, scalars, s_c1, s_words[0], products_needed, products_issued, barrier_epoch);
+            dinv_ready = G > 1;  // (the last workgroup left 1 / D'_odd in lp.next_dinv)
         }
         if (!on_matrix_cores)
         for (long long unit = gtid; unit < (long long)n_heavy * n_rows_alpha; unit += GT) {  // N(p, k) != 0 and alpha~_i != 0: two products
@@ -3060,6 +3248,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         int* d_Tx_carry = mfma_update ? dalloc<int>(2 * (size_t)m * (big / 2), fresh) : nullptr;
         int* d_Tx_words = mfma_update ? dalloc<int>(2 * (size_t)m, fresh) : nullptr;
         u64* d_y_part = dalloc<u64>(big, fresh);
+        u64* d_next_dinv = dalloc<u64>(big, fresh);
         int* d_xt_bits = dalloc<int>((size_t)m, fresh);
         if (mfma_update) {
             RELP_HIP(hipMemsetAsync(d_T_words, 0, (size_t)m * m * sizeof(int), stream));
@@ -3108,7 +3297,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_err, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
-                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_xt_bits, mfma_update ? 1 : 0, (update_mode & 2) ? 1 : 0, d_barrier};
+                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_next_dinv, d_xt_bits, mfma_update ? 1 : 0, (update_mode & 2) ? 1 : 0, d_barrier};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
@@ -3156,6 +3345,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
 #ifdef RELP_TILE_STAMPS
                 fprintf(stderr, " | one wave's tiles, M cycles: requests %.1f, steps %.1f, epilogue %.1f, tiles %llu", prof[26] / 1e6, prof[27] / 1e6, prof[28] / 1e6, prof[29]);
 #endif
+                fprintf(stderr, " | 1 / D_odd %.1f ms | entering column: chunks + barrier %.1f, adding up %.1f, barrier %.1f, row factors %.1f", prof[14] / 1e5, prof[10] / 1e5, prof[11] / 1e5,
+                        prof[18] / 1e5, prof[19] / 1e5);
                 fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f\n", prof[20] / 1e5, prof[21] / 1e5, prof[22] / 1e5, prof[23] / 1e5);
             }
             if (counters) {
