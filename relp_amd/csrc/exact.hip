@@ -1259,70 +1259,131 @@ __device__ __forceinline__ double reduced_cost_wave(const ExactLP& lp, const u64
     widest += 32 - __clz(e1 - e0 > 1 ? e1 - e0 - 1 : 1) + 1;
     widest = max(widest, D_bits + small_bits(cj));
     *bits_bound = widest;
-    // the words in order: running 192-bit sums of the positive and of the negative multiples, their difference, then c_j D - that
-    // (the words of D: a lane holds its own and hands them out -- read from memory inside the chain they were 128 round trips of its 16 us)
-    u64 d_lane[SLOTS];
+    // c~_j = c_j D - sum, a lane per word (two at 128 limbs).  Lane k's share is the signed four-word value V_k = c_j D_k - P_k + Q_k
+    // (P, Q: its carry-save sums of the positive and of the negative multiples); word k of the result is the sum of word 0 of V_k,
+    // word 1 of V_(k-1), word 2 of V_(k-2), word 3 of V_(k-3), less one for a negative V_(k-4) -- its neighbours' registers -- and what is
+    // carried on, small and of either sign, goes from lane to lane until none is left (a round or two; through a run of 0x00.. / 0xFF..
+    // words one more per word).  (Rounds 4-5 ran ONE chain through the words, every lane the same scalar arithmetic: 150 instructions a
+    // word, 60 to 120 us for a column at 128 limbs -- most of the reduced-cost pass.)
+    u64 value[SLOTS][4];
+    bool value_negative[SLOTS];
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) d_lane[t] = lane + t * WAVE < L ? D[lane + t * WAVE] : 0ull;
-    auto from_lane = [](u64 v, int source) {  // (source uniform: two v_readlane, no trip through LDS)
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, source), hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), source);
-        return ((u64)hi << 32) | lo;
-    };
-    u128 run_p = 0, run_q = 0;
-    u64 run_p_top = 0, run_q_top = 0, borrow = 0, carry_x = 0, chain = 0;
-    bool negation_carry = true;
-    LeadingWords lead;
-#pragma unroll L <= 8 ? L : 1
-    for (int k = 0; k < L; ++k) {
-        const int owner = k & (WAVE - 1), slot = k / WAVE;
-        u64 part[6], d_word = 0;
-#pragma unroll
-        for (int t = 0; t < SLOTS; ++t)
-            if (t == slot) {
-                part[0] = (u64)acc_p[t]; part[1] = (u64)(acc_p[t] >> 64); part[2] = top_p[t];
-                part[3] = (u64)acc_q[t]; part[4] = (u64)(acc_q[t] >> 64); part[5] = top_q[t];
-                d_word = d_lane[t];
-            }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) part[c] = from_lane(part[c], owner);
-        d_word = from_lane(d_word, owner);
-        auto add192 = [](u128& low, u64& top, u64 a0, u64 a1, u64 a2) {  // (low, top) += a0 + 2^64 a1 + 2^128 a2
-            const u128 add = (u128)a0 | ((u128)a1 << 64);
-            low += add;
-            top += a2 + (low < add ? 1 : 0);
+    for (int t = 0; t < SLOTS; ++t) {
+        const int k = lane + t * WAVE;
+        const u64 d_word = k < L ? D[k] : 0ull;
+        const u128 multiple = (u128)d_word * cj_mag;
+        u64 v[4] = {0, 0, 0, 0};
+        auto add_words = [&](u64 a0, u64 a1, u64 a2) {  // v += a0 + 2^64 a1 + 2^128 a2
+            u128 sum = (u128)v[0] + a0;
+            v[0] = (u64)sum;
+            sum = (u128)v[1] + a1 + (u64)(sum >> 64);
+            v[1] = (u64)sum;
+            sum = (u128)v[2] + a2 + (u64)(sum >> 64);
+            v[2] = (u64)sum;
+            v[3] += (u64)(sum >> 64);
         };
-        add192(run_p, run_p_top, part[0], part[1], part[2]);
-        add192(run_q, run_q_top, part[3], part[4], part[5]);
-        const u64 pk = (u64)run_p, qk = (u64)run_q;
-        run_p = (run_p >> 64) | ((u128)run_p_top << 64);
-        run_q = (run_q >> 64) | ((u128)run_q_top << 64);
-        run_p_top = run_q_top = 0;
-        const u64 t = pk - qk;
-        const u64 sum_word = t - borrow;  // word k of sum_e v_e y[r_e]
-        borrow = ((pk < qk) || (t < borrow)) ? 1 : 0;
-        const u128 multiple = (u128)d_word * cj_mag + carry_x;  // word k of |c_j| D
-        const u64 x_word = (u64)multiple;
-        carry_x = (u64)(multiple >> 64);
-        u64 word;
-        if (cj >= 0) {  // c_j D - sum
-            const u64 t2 = x_word - sum_word;
-            word = t2 - chain;
-            chain = ((x_word < sum_word) || (t2 < chain)) ? 1 : 0;
-        } else {  // -(|c_j| D + sum)
-            const u128 y = (u128)x_word + sum_word + chain;
-            chain = (u64)(y >> 64);
-            word = ~(u64)y + (negation_carry ? 1ull : 0ull);
-            negation_carry = negation_carry && (u64)y == 0;
+        auto sub_words = [&](u64 a0, u64 a1, u64 a2) {  // v -= a0 + 2^64 a1 + 2^128 a2
+            u128 diff = (u128)v[0] - a0;
+            v[0] = (u64)diff;
+            diff = (u128)v[1] - a1 - ((u64)(diff >> 64) & 1ull);
+            v[1] = (u64)diff;
+            diff = (u128)v[2] - a2 - ((u64)(diff >> 64) & 1ull);
+            v[2] = (u64)diff;
+            v[3] -= (u64)(diff >> 64) & 1ull;
+        };
+        if (cj >= 0) add_words((u64)multiple, (u64)(multiple >> 64), 0ull);
+        else sub_words((u64)multiple, (u64)(multiple >> 64), 0ull);
+        sub_words((u64)acc_p[t], (u64)(acc_p[t] >> 64), top_p[t]);
+        add_words((u64)acc_q[t], (u64)(acc_q[t] >> 64), top_q[t]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) value[t][c] = v[c];
+        value_negative[t] = (i64)v[3] < 0;
+    }
+    // word k - d of a per-word quantity, in the lane of word k (zero below word 0): slot t's comes from the lane d below, or -- in the
+    // first d lanes -- from the top lanes of the slot below
+    auto from_below = [&](const u64 (&x)[SLOTS], int d, u64 (&out)[SLOTS]) {
+        u64 wrapped[SLOTS];
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) wrapped[t] = __shfl(x[t], (lane - d) & (WAVE - 1));
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) out[t] = lane >= d ? wrapped[t] : (t > 0 ? wrapped[t > 0 ? t - 1 : 0] : 0ull);
+    };
+    u64 word[SLOTS];
+    i64 carried[SLOTS];  // what word k hands to word k + 1
+    {
+        u64 part[4][SLOTS], neg[SLOTS], shifted[SLOTS];
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            part[0][t] = value[t][0];
+            neg[t] = value_negative[t] ? 1ull : 0ull;
         }
-        if (lane == 0) lp.ctil[(size_t)j * L + k] = word;
-        lead.feed(k, word);
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t) shifted[t] = value[t][c];
+            from_below(shifted, c, part[c]);
+        }
+        u64 neg_below[SLOTS];
+        from_below(neg, 4, neg_below);
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const __int128 sum = (__int128)((u128)part[0][t] + part[1][t] + part[2][t] + part[3][t]) - (__int128)neg_below[t];
+            word[t] = (u64)sum;
+            carried[t] = (i64)(sum >> 64);
+        }
     }
-    if ((i64)lead.prev < 0) {  // D > 0: the sign of c~_j is the sign of the relative cost
-        int ec = 0;
-        const double mc = lead.mantissa(&ec);
-        return ldexp(mc / mD, ec - eD);
+    for (;;) {
+        u64 out_going[SLOTS], incoming[SLOTS];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            out_going[t] = (u64)carried[t];
+            any = any || (carried[t] != 0 && lane + t * WAVE + 1 < L);  // (what leaves the last word is dropped: modulo 2^(64 L))
+        }
+        if (__ballot(any) == 0) break;
+        from_below(out_going, 1, incoming);
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const __int128 sum = (__int128)(u128)word[t] + (__int128)(i64)incoming[t];
+            word[t] = (u64)sum;
+            carried[t] = (i64)(sum >> 64);
+        }
     }
-    return 0.0;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t)
+        if (lane + t * WAVE < L) lp.ctil[(size_t)j * L + lane + t * WAVE] = word[t];
+    // D > 0: the sign of c~_j is the sign of the relative cost; a negative one as a double from the two leading words of its magnitude
+    // (~w + 1: zero up to the lowest non-zero word, that word's two's complement, the others' complements)
+    const u64 top_word = __shfl(word[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
+    if ((i64)top_word >= 0) return 0.0;
+    int lowest = L;
+#pragma unroll
+    for (int t = SLOTS - 1; t >= 0; --t) {
+        const unsigned long long nonzero = __ballot(lane + t * WAVE < L && word[t] != 0);
+        if (nonzero != 0) lowest = t * WAVE + __ffsll((long long)nonzero) - 1;
+    }
+    u64 magnitude[SLOTS];
+    int top = -1;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+        const int k = lane + t * WAVE;
+        magnitude[t] = k >= L || k < lowest ? 0ull : k == lowest ? ~word[t] + 1ull : ~word[t];
+    }
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+        const unsigned long long nonzero = __ballot(magnitude[t] != 0);
+        if (nonzero != 0) top = t * WAVE + 63 - __clzll((long long)nonzero);
+    }
+    u64 m_top = 0, m_below = 0;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+        const u64 a = __shfl(magnitude[t], top & (WAVE - 1)), b = __shfl(magnitude[t], (top - 1) & (WAVE - 1));
+        if (t == top / WAVE) m_top = a;
+        if (top > 0 && t == (top - 1) / WAVE) m_below = b;
+    }
+    double x = (double)m_top;  // (LeadingWords::mantissa's numbers)
+    if (top > 0) x = x * 18446744073709551616.0 + (double)m_below;
+    return ldexp(-x / mD, 64 * (top > 0 ? top - 1 : 0) - eD);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -2397,18 +2458,36 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const int eD = s_eD;
             const double mD = s_mD;
             const int lane = tid & (WAVE - 1);
+            mark();
             grid.sync();
+            lap(26);
             if (form_y) {
                 price_form_y<L>(lp, LIMIT_BITS, &s_overflow);
                 grid.sync();
                 y_phase = phase;
             }
+            mark();
+#ifdef RELP_PRICE_BLOCK_TIMES
+            const unsigned long long t_block0 = wall_clock64();
+#endif
             price_reduced_costs<L>(lp, phase, mD, eD, D_bits, LIMIT_BITS, &s_overflow);
+#ifdef RELP_PRICE_BLOCK_TIMES
+            if (L == 128 && (tid & 63) == 0) {  // (diagnostic build: histogram of the waves' times in the pass, in prof[3, 4, 10, 11, 18] of the 128-limb run)
+                const unsigned long long dt = wall_clock64() - t_block0;  // ticks of 10 ns
+                const int slots[5] = {3, 4, 10, 11, 18};
+                const int bin = dt < 1500 ? 0 : dt < 3000 ? 1 : dt < 6000 ? 2 : dt < 12000 ? 3 : 4;
+                atomicAdd(&lp.prof[slots[bin]], 1ull);
+            }
+#endif
+            lap(27);
             grid.sync();
+            lap(28);
             stamp(1);
             const int n_negative = lp.neg_list[n];
             price_estimates<L>(lp, mD, eD);  // the terms of the weight estimates of the columns that can enter, from the leading words of N
+            lap(29);
             grid.sync();
+            lap(15);
             // ... and their keys: the weight estimate is the sequential sum of the stored terms in the order of the rows, key = (c~_j / D)^2
             // / that; a column whose terms may be off by more than 1e-11 of the sum in all goes on the list of those to be formed exactly
             const double error_allowed = lp.price_exactly ? -1.0 : 1e-11;
@@ -3344,6 +3423,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                 fprintf(stderr, " | columns with a negative reduced cost per pivot: %.1f", prof[31] ? (double)prof[30] / prof[31] : 0.0);
 #ifdef RELP_TILE_STAMPS
                 fprintf(stderr, " | one wave's tiles, M cycles: requests %.1f, steps %.1f, epilogue %.1f, tiles %llu", prof[26] / 1e6, prof[27] / 1e6, prof[28] / 1e6, prof[29]);
+#endif
+#ifndef RELP_TILE_STAMPS
+                fprintf(stderr, " | pricing: first barrier %.1f ms, c~ pass %.1f, barrier %.1f, estimates %.1f, barrier %.1f", prof[26] / 1e5, prof[27] / 1e5, prof[28] / 1e5, prof[29] / 1e5, prof[15] / 1e5);
 #endif
                 fprintf(stderr, " | 1 / D_odd %.1f ms | entering column: chunks + barrier %.1f, adding up %.1f, barrier %.1f, row factors %.1f", prof[14] / 1e5, prof[10] / 1e5, prof[11] / 1e5,
                         prof[18] / 1e5, prof[19] / 1e5);
