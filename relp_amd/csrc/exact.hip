@@ -2311,6 +2311,10 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         n_removed = lp.resume[6];
     }
     for (size_t e = gtid; e < MM; e += GT) lp.N_bits[e] = big_bits(big_load_s<L>(lp.N + e, MM));
+    if (leader) {
+        lp.neg_list[n] = 0;
+        word[9] = 0;
+    }
     grid.sync();
     int at_phase = phase, at_drive_row = drive_row, at_removed = n_removed;  // ... at the start of the current turn of the loop
     bool have_xb = false;  // x~_B belongs to the current basis
@@ -2451,15 +2455,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
 #endif
             if (form_y)
                 for (int i = gtid; i < m; i += GT) lp.cb_row[i] = phase == 1 ? lp.cost1[lp.basis[i]] : lp.cost2[lp.basis[i]];
-            if (leader) {
-                lp.neg_list[n] = 0;
-                word[9] = 0;  // (the columns whose estimated weight has to be formed exactly)
-            }
+            // (the counters of neg_list and of the columns to be formed exactly are zero here: reset at the launch and by the bookkeeping of
+            //  every pivot, behind a barrier -- a barrier of its own for that was one of twenty a pivot, 11 us each on 512 workgroups)
             const int eD = s_eD;
             const double mD = s_mD;
             const int lane = tid & (WAVE - 1);
             mark();
-            grid.sync();
+            if (form_y) grid.sync();  // (cb_row)
             lap(26);
             if (form_y) {
                 price_form_y<L>(lp, LIMIT_BITS, &s_overflow);
@@ -2488,21 +2490,25 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             lap(29);
             grid.sync();
             lap(15);
-            // ... and their keys: the weight estimate is the sequential sum of the stored terms in the order of the rows, key = (c~_j / D)^2
+            // ... and their keys: the weight estimate is the sum of the stored terms, key = (c~_j / D)^2
             // / that; a column whose terms may be off by more than 1e-11 of the sum in all goes on the list of those to be formed exactly
             const double error_allowed = lp.price_exactly ? -1.0 : 1e-11;
             auto form_keys = [&](const int* list, int count) {
                 for (int c = gtid / WAVE; c < count; c += GT / WAVE) {
                     const int j = list[c];
                     const size_t base = (size_t)(j - lp.n_art) * m;
-                    double sumsq = (double)lp.weight[j], errors = 0.0;
-                    for (int i0 = 0; i0 < m; i0 += WAVE) {  // in the order of the rows, by every lane alike
-                        const double term = i0 + lane < m ? lp.price_term[base + i0 + lane] : 0.0;
-                        errors += i0 + lane < m ? lp.price_err[base + i0 + lane] : 0.0;
-                        const int count_rows = min(WAVE, m - i0);
-                        for (int t = 0; t < count_rows; ++t) sumsq += __shfl(term, t);
+                    // (a lane adds every 64th row, the lanes' sums are added as a tree -- the same order on any grid; the sum in the order of
+                    //  the rows, every term handed round the wave, was a chain of m dependent additions: 30 us of a pivot on 25FV47)
+                    double terms = 0.0, errors = 0.0;
+                    for (int i = lane; i < m; i += WAVE) {
+                        terms += lp.price_term[base + i];
+                        errors += lp.price_err[base + i];
                     }
-                    for (int d = 1; d < WAVE; d *= 2) errors += __shfl_xor(errors, d);
+                    for (int d = 1; d < WAVE; d *= 2) {
+                        terms += __shfl_xor(terms, d);
+                        errors += __shfl_xor(errors, d);
+                    }
+                    const double sumsq = (double)lp.weight[j] + terms;
                     const double cd = lp.cd[j];
                     if (lane == 0) {
                         lp.key[j] = cd * cd / sumsq;
@@ -2616,7 +2622,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     }
                     winner = lp.cand[lp.bracket[0]];
                 }
-                q = broadcast(1, winner);
+                q = winner;  // (every workgroup read the same bracket behind the tournament's last barrier)
                 stamp(4);
             }
             if (q < 0) {  // no candidate: the end of this phase
@@ -2835,7 +2841,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 winner = lp.cand[lp.bracket[0]];
                 if (leader) word[5] = 0;
             }
-            p = broadcast(3, winner);
+            p = winner;  // (as for q)
         }
         stamp(6);
         // ---- the pivot: D' = alpha~_p, N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays ---------------------------
@@ -3033,7 +3039,9 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             }
         }
         stamp(7);
-        grid.sync();  // (row p is an operand of every other row above -- nobody may still be reading it)
+        // (row p is an operand of every other row above -- nobody may still be reading it; on the matrix cores the barrier between the tiles
+        //  and the second pass has seen to that, and the second pass reads and writes nothing that is touched below)
+        if (!on_matrix_cores) grid.sync();
         if (flip) {
             for (int k = gtid; k < m; k += GT) big_store_s(N_at(p, k), MM, big_negate(big_load_s<L>(N_at(p, k), MM)));
             if (gtid == 0) big_store(lp.xt + (size_t)p * L, big_negate(big_load<L>(lp.xt + (size_t)p * L)));
@@ -3043,6 +3051,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 for (int k = tid; k < L; k += T) gD[k] = lp.alpha[(size_t)p * L + k];
         if (leader) {
             word[4] = 0;  // (the candidate counter of the next pricing pass)
+            word[9] = 0;  // (... of the columns whose estimated weight has to be formed exactly)
+            lp.neg_list[n] = 0;
             const int leaving = lp.basis[p];
             if (L < 16 || flip) {  // (the usual case at the wide types -- D' = alpha~_p as it is -- is copied a thread per word below)
                 const Big<L> ap = big_load<L>(lp.alpha + (size_t)p * L);
