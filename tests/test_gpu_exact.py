@@ -43,8 +43,7 @@ WHOLE_TRACE = ["AFIRO", "SC50A", "SC50B", "SC105", "SCAGR7", "ADLITTLE", "SHARE2
                "BLEND", "ISRAEL", "STOCFOR1", "SHARE1B", "E226"]
 
 
-@pytest.mark.slow
-def test_25fv47_whole_reference_pivot_sequence_in_fixed_width_integers():
+def test_25fv47_whole_reference_pivot_sequence_in_fixed_width_integers():  # (3 s since round 5: no longer marked slow)
     """BASELINE configs[1], the metric's LP, pivot for pivot in fixed-width integers on the device: `Carry<RationalBig, LUDecomposition>`
     on 25FV47 (tests/netlib/test.rs:6-12, tests/netlib/mod.rs:62) makes 1133 + 1259 pivots to a 1791-bit optimum; the device walks
     the same sequence (the first 64 pivots, both counts, the final basis and the optimum of tests/golden/25FV47.json, which the
