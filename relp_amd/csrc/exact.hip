@@ -1646,15 +1646,21 @@ __device__ __forceinline__ int mfma_update_tile(const UpdateTileArgs lp, const U
 // `flip`; the L words of the new entry stored at result[w * result_stride], its bit length returned.
 template <int L>
 __device__ __forceinline__ int finish_update_entry(const u64* numerator, const int* carries, size_t numerator_stride, u64* result, size_t result_stride, int words, int shift,
-                                                   bool flip) {
+                                                   bool flip, int old_bits = -1) {
     const int ws = min(shift >> 6, L), bs = shift & 63;
+    // (old_bits >= 0: `result` holds an integer of that bit length -- the entry before this pivot.  Above its words and the new value's,
+    //  memory already holds the sign's fill wherever the sign stays: those words are not written again, a fifth of the pass's stores
+    //  at 128 limbs.  Not on a flipped pivot.)
+    const int old_words = old_bits < 0 ? L : min(L, (old_bits + 1 + 63) >> 6);
+    const bool old_negative = old_bits >= 0 && !flip ? (i64)result[(size_t)(L - 1) * result_stride] < 0 : false;
+    const bool may_skip = old_bits >= 0 && !flip;
     i64 carry = 0;
     u64 fill = 0;
     bool negation_carry = true;
     int top_nonzero = -1, top_not_ones = -1;
     u64 word_nonzero = 0, word_not_ones = 0;
     bool zeros_so_far = true, zeros_below_not_ones = true;
-    auto emit = [&](int j, u64 v) {  // word j of the shifted numerator: tracked for the bit length, negated where asked, stored
+    auto emit = [&](int j, u64 v, bool pure_fill = false) {  // word j of the shifted numerator: tracked for the bit length, negated where asked, stored
         if (v != 0) { top_nonzero = j; word_nonzero = v; }
         if (v != ~0ull) { top_not_ones = j; word_not_ones = ~v; zeros_below_not_ones = zeros_so_far; }
         zeros_so_far = zeros_so_far && v == 0;
@@ -1663,6 +1669,7 @@ __device__ __forceinline__ int finish_update_entry(const u64* numerator, const i
             stored = ~v + (negation_carry ? 1ull : 0ull);
             negation_carry = negation_carry && v == 0;
         }
+        if (pure_fill && may_skip && j >= old_words && (fill != 0) == old_negative) return;  // (already there)
         result[(size_t)j * result_stride] = stored;
     };
     // eight words and four carries are requested together, then the carries run; word j of the result is word j + ws of the
@@ -1671,6 +1678,7 @@ __device__ __forceinline__ int finish_update_entry(const u64* numerator, const i
 #pragma unroll 1
     for (int group = 0; group < L / 8; ++group) {
         u64 r[8];
+        const bool beyond = 8 * group >= words;  // (this group's words are the sign's fill)
         if (8 * group < words) {
             u64 w[8];
             i64 out[4];
@@ -1696,12 +1704,12 @@ __device__ __forceinline__ int finish_update_entry(const u64* numerator, const i
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int j = 8 * group + t - 1 - ws;
-            if (j >= 0) emit(j, bs ? (current >> bs) | (r[t] << (64 - bs)) : current);
+            if (j >= 0) emit(j, bs ? (current >> bs) | (r[t] << (64 - bs)) : current, beyond && t > 0);
             current = r[t];
         }
     }
     for (int j = max(0, L - 1 - ws); j < L; ++j) {
-        emit(j, bs ? (current >> bs) | (fill << (64 - bs)) : current);
+        emit(j, bs ? (current >> bs) | (fill << (64 - bs)) : current, j > max(0, L - 1 - ws) || words < L);
         current = fill;
     }
     // bit length of the magnitude (the same for the value and its negation)
@@ -2181,7 +2189,7 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             const int words = lp.T_words[idx];
             if (words == 0) continue;
             lp.T_words[idx] = 0;
-            lp.N_bits[idx] = finish_update_entry<L>(lp.T + idx, lp.T_carry + idx, MM, lp.N + idx, MM, words, shift, flip);
+            lp.N_bits[idx] = finish_update_entry<L>(lp.T + idx, lp.T_carry + idx, MM, lp.N + idx, MM, words, shift, flip, lp.N_bits[idx]);
         }
         for (int i = gtid; i < 2 * m; i += GT) {  // x~_B, then y
             const int words = lp.Tx_words[i];
