@@ -994,7 +994,7 @@ struct SignedSum {
 };
 // CHUNK: only the words [k_begin, k_limit) of the sum are formed, from those words of the operands alone -- word k - k_begin goes to
 // out[(k - k_begin) * out_stride] and the three words that the chunk carries into the words above it to the places (k_limit - k_begin)
-// + 0, 1, 2 (entering_column_combine adds the chunks up); `lead` is not fed.
+// + 0, 1, 2 (entering_column_rows adds the chunks up); `lead` is not fed.
 template <int L, bool CHUNK = false>
 __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0, int e1, int i, bool active, int lane, size_t MM, u64* out, size_t out_stride,
                                                        LeadingWords& lead, int k_begin = 0, int k_limit = L) {
@@ -1090,11 +1090,18 @@ __device__ __forceinline__ int stream_column_products(const ExactLP& lp, int e0,
 // that differs from the sign decides.  (One thread scanning its own copy from the top is a chain of L dependent scratch reads: 0.1 ms
 // at 128 limbs.)  The same value in every lane.
 template <int L>
+__device__ __forceinline__ int wave_bit_length_words(const u64 (&w)[(L + WAVE - 1) / WAVE], int lane);
+template <int L>
 __device__ __forceinline__ int wave_bit_length(const u64* v, int lane) {
     constexpr int SLOTS = (L + WAVE - 1) / WAVE;
     u64 w[SLOTS];
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) w[t] = lane + t * WAVE < L ? v[lane + t * WAVE] : 0ull;
+    return wave_bit_length_words<L>(w, lane);
+}
+template <int L>
+__device__ __forceinline__ int wave_bit_length_words(const u64 (&w)[(L + WAVE - 1) / WAVE], int lane) {  // (word lane + 64 t in slot t; zero beyond L)
+    constexpr int SLOTS = (L + WAVE - 1) / WAVE;
     const u64 top_word = __shfl(w[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
     const bool negative = (i64)top_word < 0;
     const u64 sign = negative ? ~0ull : 0ull;
@@ -1723,8 +1730,8 @@ __device__ __forceinline__ int finish_update_entry(const u64* numerator, const i
 // The entering column alpha~_q = N a_q, exactly, at the wide types.  One wave per 64 rows streaming the column's operands from word 0 to the
 // last is 13 waves on 25FV47 and 32 round trips one after the other, 0.3 ms a pivot with the rest of the grid waiting.  So the words
 // are cut into chunks of ENTER_CHUNK: a wave forms the words of one chunk for 64 rows from those words of the operands alone
-// (entering_column_chunks: eight times the waves at 128 limbs, an eighth of the turns each), and after a barrier a wave per 64 rows adds
-// the chunks up -- each carries three words into the next -- stores alpha~_i and finds its bit length (entering_column_combine).  The
+// (entering_column_chunks: eight times the waves at 128 limbs, an eighth of the turns each), and after a barrier a wave per ROW adds
+// the chunks up -- each carries three words into the next --, stores alpha~_i, its bit length and the row's factor (entering_column_rows).  The
 // chunks' words lie in price_a, which nobody needs at this point of a pivot ((ENTER_CHUNK + 3) words per chunk and row, word-major).
 constexpr int ENTER_CHUNK = 16;
 template <int L>
@@ -1743,49 +1750,194 @@ __device__ __noinline__ void entering_column_chunks(const ExactLP& lp, int q) {
                                         chunk * ENTER_CHUNK, (chunk + 1) * ENTER_CHUNK);
     }
 }
+// word k - d of a per-word quantity held a lane per word (slot t of lane l: word l + 64 t), in the lane of word k; zero below word 0
+template <int SLOTS>
+__device__ __forceinline__ void words_from_below(const u64 (&x)[SLOTS], int d, u64 (&out)[SLOTS], int lane) {
+    u64 wrapped[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) wrapped[t] = __shfl(x[t], (lane - d) & (WAVE - 1));
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) out[t] = lane >= d ? wrapped[t] : (t > 0 ? wrapped[t > 0 ? t - 1 : 0] : 0ull);
+}
+// -(a * b) modulo 2^(64 L), a and b in LDS (a: this wave's), stored word-major at out[k * stride], by ONE wave with every lane at work:
+// WAVE / (L / 4) lanes share the block products of an output block (wave_mul_lo_store gives a block to one lane: half the lanes idle,
+// the others in step with the longest sum), their nine-word windows are added across the lanes, the windows are laid over each other
+// a lane per block -- what a block carries on goes from lane to lane until none is left --, and the two's complement is taken by the
+// lanes together (zero up to the lowest non-zero word).  (The row factors -alpha~_i u of the update: 48 -> 15 us a pivot at 128 limbs.)
 template <int L>
-__device__ __noinline__ void entering_column_combine(const ExactLP& lp, int q, int limit_bits, int* overflow) {
-    const int m = lp.m, lane = threadIdx.x & (WAVE - 1);
+__device__ __forceinline__ void wave_mul_lo_negated(const u64* a, const u64* b, u64* out, size_t stride, int lane) {
+    static_assert(L % 4 == 0 && L / 4 <= WAVE && WAVE % (L / 4) == 0, "a lane per block of four words, or several");
+    constexpr int NB = L / 4, SHARE = WAVE / NB;  // lanes per output block
+    const int K = lane % NB, part = lane / NB;
+    u64 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0;
+#pragma unroll 1
+    for (int I = part; I <= K; I += SHARE) {
+        const int J = K - I;
+        u64 a4[4], b4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a4[t] = a[4 * I + t];
+            b4[t] = b[4 * J + t];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            u64 carry = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const u128 t = (u128)a4[ii] * b4[jj] + acc[ii + jj] + carry;
+                acc[ii + jj] = (u64)t;
+                carry = (u64)(t >> 64);
+            }
+#pragma unroll
+            for (int k = ii + 4; k < 9; ++k) {
+                const u128 t = (u128)acc[k] + carry;
+                acc[k] = (u64)t;
+                carry = (u64)(t >> 64);
+            }
+        }
+    }
+    for (int d = NB; d < WAVE; d *= 2) {  // the windows of the lanes that share a block, added up (the same sum in all of them)
+        u64 carry = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const u128 t = (u128)acc[k] + __shfl_xor(acc[k], d) + carry;
+            acc[k] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+    }
+    // block K's four words: its window's first four, the next four of block K - 1's, the ninth of block K - 2's (lanes 0 .. NB - 1)
+    u64 word[4];
+    u64 carried;  // into block K + 1
+    {
+        u64 below[4], below2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const u64 v = __shfl_up(acc[4 + r], 1);
+            below[r] = K >= 1 ? v : 0ull;
+        }
+        {
+            const u64 v = __shfl_up(acc[8], 2);
+            below2 = K >= 2 ? v : 0ull;
+        }
+        u64 carry = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const u128 t = (u128)acc[r] + below[r] + (r == 0 ? below2 : 0ull) + carry;
+            word[r] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+        carried = carry;
+    }
+    for (;;) {
+        const bool hands_on = carried != 0 && lane < NB - 1;  // (what leaves the last block is dropped: modulo 2^(64 L))
+        if (__ballot(hands_on && lane < NB) == 0) break;
+        const u64 v = __shfl_up(carried, 1);
+        u64 carry = lane >= 1 && lane < NB ? v : 0ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const u128 t = (u128)word[r] + carry;
+            word[r] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+        carried = carry;
+    }
+    // the two's complement: zero up to the lowest non-zero word, that word's complement plus one, the complements above
+    bool nonzero = false;
+    int first = 4;
+#pragma unroll
+    for (int r = 3; r >= 0; --r)
+        if (word[r] != 0) { nonzero = true; first = r; }
+    const unsigned long long lanes_nonzero = __ballot(nonzero && lane < NB);
+    const int lowest_lane = lanes_nonzero ? __ffsll((long long)lanes_nonzero) - 1 : NB;
+    if (lane < NB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u64 v = word[r];
+            if (lane > lowest_lane || (lane == lowest_lane && r > first)) v = ~v;
+            else if (lane == lowest_lane && r == first) v = ~v + 1ull;
+            out[(size_t)(4 * lane + r) * stride] = v;
+        }
+    }
+}
+// The second half of the entering column (after entering_column_chunks and a barrier), a WAVE PER ROW: the chunks of row i are added up
+// a lane per word -- a word, what the chunk below carries into it, less one where that is negative; the small signed carries from lane
+// to lane until none is left --, alpha~_i and its bit length are stored, and the row's factor of the update -alpha~_i u follows at
+// once from the words the wave holds (through LDS).  (A wave per 64 rows adding the chunks up word after word, a barrier, and a
+// wave per row multiplying were three steps: 36 + 6 + 48 us of every pivot at 128 limbs.)
+template <int L>
+__device__ __noinline__ void entering_column_rows(const ExactLP& lp, int q, const u64* dinv, int limit_bits, int* overflow) {
+    constexpr int SLOTS = (L + WAVE - 1) / WAVE;
+    __shared__ u64 s_row[EX_THREADS / WAVE][L];
+    const int m = lp.m, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
     const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[q]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[q + 1]);
-    for (int block_a = wave_of_grid; block_a * WAVE < m; block_a += waves_of_grid) {
-        const int i = block_a * WAVE + lane;
-        const bool active = i < m;
+    for (int row = wave_of_grid; row < m; row += waves_of_grid) {
+        // (the words the chunks were formed to: the bound of the row's block of 64, as entering_column_chunks found it)
+        const int base = row & ~(WAVE - 1);
         int words = 0;
-        const int awide = column_products_bound<L>(lp, e0, e1, i, active, &words);
-        u64* alpha_i = lp.alpha + (size_t)(active ? i : 0) * L;
-        LeadingWords lead;
-        SignedSum carried;  // what the chunks below carry into the current word
-        for (int k0 = 0; k0 < words; k0 += ENTER_CHUNK) {
-            const u64* part = lp.price_a + (size_t)(k0 / ENTER_CHUNK) * (ENTER_CHUNK + 3) * m + (active ? i : 0);
-            const int count = min(ENTER_CHUNK, words - k0);  // (a multiple of the eight words of a turn)
-            u64 w[ENTER_CHUNK + 3];
+        const int awide_lane = column_products_bound<L>(lp, e0, e1, base + lane, base + lane < m, &words);
+        const int awide = __shfl(awide_lane, row - base);
+        u64 word[SLOTS];
+        i64 carried[SLOTS];
 #pragma unroll
-            for (int t = 0; t < ENTER_CHUNK + 3; ++t) w[t] = (t < count || t >= ENTER_CHUNK) ? part[(size_t)t * m] : 0ull;
+        for (int t = 0; t < SLOTS; ++t) {
+            const int k = lane + t * WAVE, chunk = k / ENTER_CHUNK, at = k % ENTER_CHUNK;
+            const bool valid = k < words;
+            const u64* part = lp.price_a + (size_t)chunk * (ENTER_CHUNK + 3) * m + row;
+            const u64* below = part - (size_t)(ENTER_CHUNK + 3) * m + (size_t)ENTER_CHUNK * m;  // the three words the chunk below carries on
+            const u64 own = valid ? part[(size_t)at * m] : 0ull;
+            const u64 from_below = valid && chunk > 0 && at < 3 ? below[(size_t)at * m] : 0ull;
+            const u64 sign_below = valid && chunk > 0 && at == 3 ? below[(size_t)2 * m] >> 63 : 0ull;
+            const __int128 sum = (__int128)((u128)own + from_below) - (__int128)sign_below;
+            word[t] = (u64)sum;
+            carried[t] = (i64)(sum >> 64);
+        }
+        for (;;) {
+            u64 out_going[SLOTS], incoming[SLOTS];
+            bool any = false;
 #pragma unroll
-            for (int t = 0; t < ENTER_CHUNK; ++t)
-                if (t < count) {
-                    carried.add((u128)w[t]);
-                    const u64 word = carried.pop();
-                    if (active) alpha_i[k0 + t] = word;
-                    lead.feed(k0 + t, word);
-                }
-            SignedSum above;
-            above.acc = (u128)w[ENTER_CHUNK] | ((u128)w[ENTER_CHUNK + 1] << 64);
-            above.top = (i64)w[ENTER_CHUNK + 2];
-            carried.add(above);
+            for (int t = 0; t < SLOTS; ++t) {
+                out_going[t] = (u64)carried[t];
+                any = any || (carried[t] != 0 && lane + t * WAVE + 1 < words);
+            }
+            if (__ballot(any) == 0) break;
+            words_from_below<SLOTS>(out_going, 1, incoming, lane);
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t) {
+                const __int128 sum = (__int128)(u128)word[t] + (__int128)(i64)incoming[t];
+                word[t] = lane + t * WAVE < words ? (u64)sum : 0ull;
+                carried[t] = lane + t * WAVE < words ? (i64)(sum >> 64) : 0;
+            }
         }
-        const u64 fill = (i64)lead.prev < 0 ? ~0ull : 0ull;
-        for (int k = words; k < L; ++k) {
-            if (active) alpha_i[k] = fill;
-            lead.feed(k, fill);
+        // the words above the bound are the sign's
+        u64 top_word = 0;
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const u64 v = __shfl(word[t], (words - 1) & (WAVE - 1));
+            if (t == (words - 1) / WAVE) top_word = v;
         }
-        if (active) {
+        const u64 fill = (i64)top_word < 0 ? ~0ull : 0ull;
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const int k = lane + t * WAVE;
+            if (k >= words) word[t] = fill;
+            if (k < L) {
+                lp.alpha[(size_t)row * L + k] = word[t];
+                s_row[wave][k] = word[t];
+            }
+        }
+        const int bits = wave_bit_length_words<L>(word, lane);
+        if (lane == 0) {
+            lp.x_bits[row] = bits;  // (the fit test of the update wants it once per ENTRY of N)
             if (awide >= limit_bits) *overflow = 1;
-            const bool negative = (i64)lead.prev < 0;  // bit length of |alpha~_i| from its leading word
-            const int top = negative ? lead.top_n : lead.top_p;
-            lp.x_bits[i] = top < 0 ? 0 : 64 * top + (64 - __clzll((long long)(negative ? lead.n_top : lead.p_top)));  // (the fit test of the update wants it once per ENTRY of N)
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wave_mul_lo_negated<L>(s_row[wave], dinv, lp.x_part + row, (size_t)m, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -2707,7 +2859,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     entering_column_chunks<L>(lp, q);
                     grid.sync();
                     lap(10);
-                    entering_column_combine<L>(lp, q, LIMIT_BITS, &s_overflow);
+                    entering_column_rows<L>(lp, q, s_dinv, LIMIT_BITS, &s_overflow);  // ... added up, and the rows' factors -alpha~_i u
                     lap(11);
                 }
             }
@@ -2739,11 +2891,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 if constexpr (L < 16) big_store_s(lp.x_part + i, (size_t)m, big_negate(big_mul_lo(a, Dinv)));  // -alpha~_i / D_odd: the row's factor of the update below
             }
         }
-        if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store)
-            grid.sync();
-            lap(18);  // (the barrier after the entering column)
-            for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
-            lap(19);
+        if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store; from 32 limbs on entering_column_rows has formed them)
+            if (L < 2 * ENTER_CHUNK || n - lp.n_art < 2) {
+                grid.sync();
+                lap(18);  // (the barrier after the entering column)
+                for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
+                lap(19);
+            }
             // ... and y's factor c~_q u, by the last wave of the grid (y rides along with the update of N, see update_on_matrix_cores)
             if (y_rides && gtid / WAVE == GT / WAVE - 1) {
                 wave_mul_lo_store<L>(lp.ctil + (size_t)q * L, s_dinv, lp.y_part, 1, tid & (WAVE - 1), false);
