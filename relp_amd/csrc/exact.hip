@@ -857,6 +857,8 @@ struct ExactLP {
     int* x_bits;          // ... their bit bounds
     i64* cb_row;          // [m] cost of the basic column of each row in the current phase (pricing pass B)
     int* row_list;        // [2 m] the rows with alpha~_i != 0, in order, and from [m] on the others (the update of N)
+    int* col_heavy;       // [m] the columns with N(p, k) != 0, in order, and col_light [m] the others (the update of N).  (Lists of their own:
+    int* col_light;       //  in `bracket` / `cand` a workgroup late out of the ratio test's last barrier could have read the winner's slot overwritten)
     int* N_bits;          // [m columns][m rows] bit length of |N(i, c)|, kept by whoever writes an entry (the bounds of the passes over N read 4 bytes instead of the integer)
     // the update of N on the matrix cores (limbs >= 16, see mfma_update_tile): the numerators 2^s N'_ik as the tiles leave them --
     u64* T;               // [limbs][m columns][m rows] words (each 128-bit pair of an entry summed by one lane) ...
@@ -2260,7 +2262,7 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             while (u < u_end) {
                 const int kind = u < total_N ? 0 : u < total_N + tiles_of_x ? 1 : 2;  // a column of N, x~_B, y
                 const int kk = kind == 0 ? (int)(u / tiles_per_column) : n_heavy;
-                const int k = kind == 0 ? lp.bracket[kk] : -1;
+                const int k = kind == 0 ? lp.col_heavy[kk] : -1;
                 const long long column_first = kind == 0 ? (long long)kk * tiles_per_column : kind == 1 ? total_N : total_N + tiles_of_x;
                 const long long column_end = min(u_end, column_first + (kind == 0 ? tiles_per_column : kind == 1 ? tiles_of_x : tiles_of_y));
                 __syncthreads();  // (the previous column's tiles are done with the image)
@@ -2307,12 +2309,12 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
                 int k, row;
                 if (t < total_a) {
                     const int kk = (int)(t / tiles_a), first = 16 * (int)(t - (long long)kk * tiles_a);
-                    k = lp.bracket[kk];
+                    k = lp.col_heavy[kk];
                     row = first + e16 < rest_rows ? lp.row_list[m + first + e16] : -1;
                 } else {
                     const long long rest = t - total_a;
                     const int kk = (int)(rest / tiles_b), first = 16 * (int)(rest - (long long)kk * tiles_b);
-                    k = lp.cand[kk];
+                    k = lp.col_light[kk];
                     row = first + e16 < m ? first + e16 : -1;
                 }
                 const int entry_bits = row >= 0 ? lp.N_bits[(size_t)k * m + row] : 0;
@@ -3105,7 +3107,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 }
                 return done[0];
             };
-            const int heavy_columns = split([&](int k) { return lp.N_bits[(size_t)k * m + p] != 0; }, lp.bracket, lp.cand);
+            const int heavy_columns = split([&](int k) { return lp.N_bits[(size_t)k * m + p] != 0; }, lp.col_heavy, lp.col_light);
             const int rows_with_alpha = split([&](int i) { return lp.x_bits[i] != 0; }, lp.row_list, lp.row_list + m);
             if (tid == 0) {
                 word[7] = heavy_columns;
@@ -3123,7 +3125,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         for (long long unit = gtid; unit < (long long)n_heavy * n_rows_alpha; unit += GT) {  // N(p, k) != 0 and alpha~_i != 0: two products
             const int kk = (int)(unit / n_rows_alpha), i = lp.row_list[(int)(unit - (long long)kk * n_rows_alpha)];
             if (i == p) continue;
-            const int k = lp.bracket[kk];
+            const int k = lp.col_heavy[kk];
             const size_t idx = (size_t)k * m + i;
             const Big<L> ri = big_load_s<L>(lp.x_part + i, (size_t)m);
             const Big<L> nik = big_load_s<L>(lp.N + idx, MM);
@@ -3157,12 +3159,12 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             int k, i;
             if (unit < rescaled_a) {
                 const int kk = (int)(unit / (m - n_rows_alpha));
-                k = lp.bracket[kk];
+                k = lp.col_heavy[kk];
                 i = lp.row_list[m + (int)(unit - (long long)kk * (m - n_rows_alpha))];
             } else {
                 const long long rest = unit - rescaled_a;
                 const int kk = (int)(rest / m);
-                k = lp.cand[kk];
+                k = lp.col_light[kk];
                 i = (int)(rest - (long long)kk * m);
             }
             if (i == p) continue;
@@ -3448,6 +3450,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_neg_list = dalloc<int>((size_t)n + 1, owned);
     i64* d_cb_row = dalloc<i64>(m, owned);
     int* d_row_list = dalloc<int>((size_t)2 * m, owned);
+    int* d_col_heavy = dalloc<int>((size_t)m + 1, owned);
+    int* d_col_light = dalloc<int>((size_t)m + 1, owned);
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
@@ -3547,7 +3551,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         RELP_HIP(hipMemsetAsync(d_barrier, 0, EX_BARRIER_WORDS * sizeof(unsigned), stream));
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
-                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_err, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_N_bits,
+                   d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_err, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_col_heavy, d_col_light, d_N_bits,
                    d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_next_dinv, d_xt_bits, mfma_update ? 1 : 0, (update_mode & 2) ? 1 : 0, d_barrier};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
