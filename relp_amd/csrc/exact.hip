@@ -788,17 +788,30 @@ __device__ __forceinline__ int wave_sign_of_difference(const u64* a, int la, con
 
 // The grid barrier of the cooperative launch.  cooperative_groups' grid.sync() costs 0.1 us per workgroup on gfx950 -- every arrival
 // is an atomic on one word: 26 us at 256 workgroups, 53 at 512 (tools/micro/grid_barrier_bench.hip, profiles/r5_micro_grid_barrier.txt)
-// -- and a pivot makes about twenty of them.  Two levels instead: the workgroups count in groups of 32 on a word of their own (64-byte
-// spaced), the last arrival of a group counts on the top word, the last arrival there publishes the generation every workgroup polls:
-// 6.6 us at 256 workgroups, 11.5 at 512.  Counters only grow (no reset to race with); thread 0 releases the workgroup's stores at
-// agent scope before it arrives and acquires after the generation moved, with the workgroup's own barrier on both sides -- the same
-// exchange test as for grid.sync() sees no stale value.  Every workgroup must call it the same number of times (`epoch` counts them).
+// -- and a pivot makes about sixteen of them.  First two levels (grid_barrier_two_level: groups of 32 workgroups on a word of their
+// own, the last arrival of a group on the top word, the last arrival there publishes the generation everybody polls: 6.6 us at 256
+// workgroups, 11.5 at 512), now the levels of the chip (grid_barrier): what makes a barrier expensive is not the counting -- 2 us
+// without fences -- but 512 release fences, each the write-back of a die's L2.  The workgroups of one XCD (HW_REG_XCC_ID: nothing is
+// assumed about the placement) count on a word of their die; their stores are in THAT die's L2 when they arrive (every wave waits for
+// its stores in front of the workgroup barrier), so ONE release by the die's last arrival serves them all: 8 write-backs a barrier.
+// That workgroup counts on the top word, waits for the generation and passes it on to its die's generation word, which the others
+// poll; every workgroup invalidates its own CU's L1 (the acquire).  6.5 us at 512 workgroups, 4.6 at 256, no stale value in the
+// exchange test.  Counters only grow (no reset to race with); every workgroup must call it the same number of times (`epoch`).
+// (The explicit waits: the compiler may drop the wait behind a release fence that follows a returned atomic, and the invalidate of an
+//  acquire completes asynchronously -- MI355X guide, inter-workgroup visibility.)
 constexpr int EX_BARRIER_GROUP = 32;
-constexpr int EX_BARRIER_WORDS = 32 + 16 * 64;  // [0] generation, [16] top, [32 + 16 g] group g
-__device__ __forceinline__ void grid_barrier(unsigned* words, unsigned& epoch) {
+constexpr int EX_BARRIER_DIE_WORDS = 2048;  // the words of the per-die barrier: [+0] generation, [+16] top, [+32 + 16 x] arrivals of die x,
+                                            // [+32 + 16 (8 + x)] its generation, [+32 + 16 (16 + x)] the workgroups on it
+constexpr int EX_BARRIER_WORDS = EX_BARRIER_DIE_WORDS + 32 + 16 * 24;  // [0] generation, [16] top, [32 + 16 g] group g of the two-level barrier (the launch's first)
+struct BarrierPlace {  // where this workgroup stands: its die, the workgroups on it, the dies in use
+    unsigned die = 0, members = 0, dies = 0;
+};
+__device__ __forceinline__ void grid_barrier_two_level(unsigned* words, unsigned& epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned g = blockIdx.x / EX_BARRIER_GROUP, groups = (gridDim.x + EX_BARRIER_GROUP - 1) / EX_BARRIER_GROUP;
         const unsigned members = min((unsigned)EX_BARRIER_GROUP, gridDim.x - g * EX_BARRIER_GROUP);
         const unsigned arrived = __hip_atomic_fetch_add(words + 32 + 16 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -808,6 +821,43 @@ __device__ __forceinline__ void grid_barrier(unsigned* words, unsigned& epoch) {
         }
         while (__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    ++epoch;
+    __syncthreads();
+}
+// (once per launch: who shares a die, counted behind a barrier of the other kind)
+__device__ __forceinline__ BarrierPlace grid_barrier_place(unsigned* words) {
+    BarrierPlace place;
+    place.die = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID
+    unsigned* die_words = words + EX_BARRIER_DIE_WORDS;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(die_words + 32 + 16 * (16 + place.die), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned first = 0;
+    grid_barrier_two_level(words, first);
+    place.members = __hip_atomic_load(die_words + 32 + 16 * (16 + place.die), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned x = 0; x < 8; ++x)
+        place.dies += __hip_atomic_load(die_words + 32 + 16 * (16 + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u;
+    return place;
+}
+__device__ __forceinline__ void grid_barrier(unsigned* words, unsigned& epoch, const BarrierPlace place) {
+    unsigned* die_words = words + EX_BARRIER_DIE_WORDS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave: its stores are in the die's L2)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* generation_of_die = die_words + 32 + 16 * (8 + place.die);
+        const unsigned arrived = __hip_atomic_fetch_add(die_words + 32 + 16 * place.die, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (epoch + 1) * place.members - 1) {  // the last of its die
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned at_top = __hip_atomic_fetch_add(die_words + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (at_top == (epoch + 1) * place.dies - 1) __hip_atomic_store(die_words, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(die_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1) __builtin_amdgcn_s_sleep(1);
+            __hip_atomic_store(generation_of_die, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(generation_of_die, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     ++epoch;
     __syncthreads();
@@ -2182,12 +2232,13 @@ struct UpdateScalars {
 };
 template <int L>
 __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const UpdateScalars sc, const u64* s_c1, const u64* s_ap, unsigned long long& products_needed,
-                                                    unsigned long long& products_issued, unsigned& barrier_epoch) {
+                                                    unsigned long long& products_issued, unsigned& barrier_epoch, const BarrierPlace barrier_place) {
     struct {
         unsigned* words;
         unsigned& epoch;
-        __device__ void sync() { grid_barrier(words, epoch); }
-    } grid{lp.barrier, barrier_epoch};
+        BarrierPlace place;
+        __device__ void sync() { grid_barrier(words, epoch, place); }
+    } grid{lp.barrier, barrier_epoch, barrier_place};
     const int tid = threadIdx.x, T = blockDim.x;
     const int G = gridDim.x, block = blockIdx.x;
     const int gtid = block * T + tid, GT = G * T;
@@ -2371,11 +2422,13 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
 template <int L>
 __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) exact_simplex_kernel(ExactLP lp) {
     unsigned barrier_epoch = 0;  // grid barriers made so far (grid_barrier: the same count in every workgroup)
+    const BarrierPlace barrier_place = grid_barrier_place(lp.barrier);
     struct {
         unsigned* words;
         unsigned& epoch;
-        __device__ void sync() { grid_barrier(words, epoch); }
-    } grid{lp.barrier, barrier_epoch};
+        BarrierPlace place;
+        __device__ void sync() { grid_barrier(words, epoch, place); }
+    } grid{lp.barrier, barrier_epoch, barrier_place};
     __shared__ double s_key[EX_THREADS / WAVE];
     __shared__ unsigned long long s_rank[EX_THREADS / WAVE];
     __shared__ int s_overflow;
@@ -3118,7 +3171,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         const int n_heavy = word[7], n_rows_alpha = word[6];
         if constexpr (L >= 32) if (on_matrix_cores) {
             const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha, y_rides ? 1 : 0, cq_bits};
-            update_on_matrix_cores<L>(lp, scalars, s_c1, s_words[0], products_needed, products_issued, barrier_epoch);
+            update_on_matrix_cores<L>(lp, scalars, s_c1, s_words[0], products_needed, products_issued, barrier_epoch, barrier_place);
             dinv_ready = G > 1;  // (the last workgroup left 1 / D'_odd in lp.next_dinv)
         }
         if (!on_matrix_cores)
