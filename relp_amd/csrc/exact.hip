@@ -3130,7 +3130,9 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         // are each split into the two kinds (workgroup 0, ordered lists) and every class of entries is spread over the whole grid by
         // itself: with the entries taken as they come a wave drew ten columns and the slowest wave's draw set the pace, and a row
         // with alpha~_i = 0 inside a wave of rows with alpha~_i != 0 saved nothing.
-        if (block == 0) {
+        // (two workgroups, a list each: one workgroup building both while the grid waited at the barrier below was 20 us of every pivot)
+        const int column_splitter = G >= 3 ? 1 : 0, row_splitter = G >= 3 ? 2 : 0;
+        if (block == column_splitter || block == row_splitter) {
             __shared__ int s_class_count[EX_THREADS / WAVE][2];
             auto split = [&](auto&& is_first, int* first_list, int* second_list) {  // indices 0 .. m - 1 in order into the two lists; returns the first's length
                 int done[2] = {0, 0};
@@ -3160,11 +3162,13 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 }
                 return done[0];
             };
-            const int heavy_columns = split([&](int k) { return lp.N_bits[(size_t)k * m + p] != 0; }, lp.col_heavy, lp.col_light);
-            const int rows_with_alpha = split([&](int i) { return lp.x_bits[i] != 0; }, lp.row_list, lp.row_list + m);
-            if (tid == 0) {
-                word[7] = heavy_columns;
-                word[6] = rows_with_alpha;
+            if (block == column_splitter) {
+                const int heavy_columns = split([&](int k) { return lp.N_bits[(size_t)k * m + p] != 0; }, lp.col_heavy, lp.col_light);
+                if (tid == 0) word[7] = heavy_columns;
+            }
+            if (block == row_splitter) {
+                const int rows_with_alpha = split([&](int i) { return lp.x_bits[i] != 0; }, lp.row_list, lp.row_list + m);
+                if (tid == 0) word[6] = rows_with_alpha;
             }
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
