@@ -799,6 +799,8 @@ __device__ __forceinline__ int wave_sign_of_difference(const u64* a, int la, con
 // exchange test.  Counters only grow (no reset to race with); every workgroup must call it the same number of times (`epoch`).
 // (The explicit waits: the compiler may drop the wait behind a release fence that follows a returned atomic, and the invalidate of an
 //  acquire completes asynchronously -- MI355X guide, inter-workgroup visibility.)
+constexpr int EX_GAMMA_BATCH = 64;  // tied candidates whose exact weights are formed at a time (gamma_terms)
+constexpr int EX_PRODUCT_SLOTS = EX_GAMMA_BATCH;  // columns whose exact products N a_j price_a holds at a time
 constexpr int EX_BARRIER_GROUP = 32;
 constexpr int EX_BARRIER_DIE_WORDS = 2048;  // the words of the per-die barrier: [+0] generation, [+16] top, [+32 + 16 x] arrivals of die x,
                                             // [+32 + 16 (8 + x)] its generation, [+32 + 16 (16 + x)] the workgroups on it
@@ -890,19 +892,19 @@ struct ExactLP {
                           //       also [6..9] = phase, trace count, drive row, removed rows at the START of the pivot that did not fit
     const int* resume;    // [8]: [0] != 0: continue a run that overflowed at a narrower width (N, D, basis, pos, removed are its state
                           //      before the pivot that did not fit); [1..6] = phase, pivots one, pivots two, trace count, drive row, removed
-    int* removed;         // [m] 1: the row is redundant -- its artificial cannot be pivoted out (`RemoveRows` of the reference)
+    int* removed;         // [m] 1: the row is redundant -- its artificial cannot be pivoted out (`RemoveRows` of the reference); [m + i]: such rows above row i
     int* shared_words;    // [16] grid-wide overflow flag, decisions of workgroup 0's thread 0
     double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
     unsigned long long* part_rank;
     unsigned long long* prof;  // [EX_PROF_WORDS] the leader's time per step of the loop in ticks of the 100 MHz wall clock [0..9], candidate counts [12],
                                // and the word products (64 x 64 -> 128 bit) of the update of N: [16] those the entries need, [17] those the waves issue
-    u64* price_a;         // [limbs][n - n_art][m]: (N a_j)_i of the pricing pass, word-major
+    u64* price_a;         // [limbs][EX_PRODUCT_SLOTS][m]: exact products (N a_j)_i, word-major, of the columns of a list (price_products); scratch of the entering column's chunks
     double* price_err;    // ... and a bound on that share's error (price_estimates: the products are formed from leading words)
     double* price_term;   // ... its share of the steepest-edge estimate
     int* bracket;         // [max(n, m) + 1] the tournament brackets over the candidates
     int* cand;            // [max(n, m) + 1] columns whose key estimate is within 1e-9 of the best (pricing); near-tied rows (ratio test)
     u64* gamma;           // [n][2 limbs + 2] their exact weights
-    u64* gamma_terms;     // [candidates][m + 1][2 limbs + 2] the terms of those sums (capacity: see the host)
+    u64* gamma_terms;     // [EX_GAMMA_BATCH candidates][m + 1][2 limbs + 2] the terms of those sums
     u64* x_part;          // [m][ceil(m / 32)] Big: partial sums of x~_B = N b (first turn of a run); afterwards [limbs][m]: -alpha~_i / D_odd (negated: the update adds), word-major
     int* x_bits;          // ... their bit bounds
     i64* cb_row;          // [m] cost of the basic column of each row in the current phase (pricing pass B)
@@ -2067,11 +2069,11 @@ __device__ __noinline__ void price_reduced_costs(const ExactLP& lp, int phase, d
 // weights are sums of these squares.
 template <int L>
 __device__ __noinline__ void price_products(const ExactLP& lp, const int* list, int count, double mD, int eD, int limit_bits, int* overflow) {
-    const int m = lp.m, n = lp.n, lane = threadIdx.x & (WAVE - 1);
+    const int m = lp.m, lane = threadIdx.x & (WAVE - 1);
     const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
     const size_t MM = (size_t)m * m;
-    const size_t PP = (size_t)(n - lp.n_art > 0 ? n - lp.n_art : 1) * m;
-    const int row_blocks = (m + WAVE - 1) / WAVE;
+    const size_t PP = (size_t)EX_PRODUCT_SLOTS * m;  // (price_a: column c of the list in slot c modulo EX_PRODUCT_SLOTS -- a caller that reads the products
+    const int row_blocks = (m + WAVE - 1) / WAVE;    //  passes no more columns than that at a time)
     for (long long item = wave_of_grid; item < (long long)count * row_blocks; item += waves_of_grid) {
         const int c = (int)(item / row_blocks), i = (int)(item - (long long)c * row_blocks) * WAVE + lane;
         const int j = list[c], jj = j - lp.n_art;
@@ -2079,7 +2081,7 @@ __device__ __noinline__ void price_products(const ExactLP& lp, const int* list, 
         const bool active = i < m;
         const size_t pair = (size_t)jj * m + (active ? i : 0);
         LeadingWords lead;
-        const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane, MM, lp.price_a + pair, PP, lead);
+        const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane, MM, lp.price_a + (size_t)(c % EX_PRODUCT_SLOTS) * m + (active ? i : 0), PP, lead);
         if (active) {
             if (awide >= limit_bits) *overflow = 1;
             int ea = 0;
@@ -2445,7 +2447,6 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     const bool leader = block == 0 && tid == 0;
     const int m = lp.m, n = lp.n;
     const size_t MM = (size_t)m * m;                                      // entries of N = its word stride
-    const size_t PP = (size_t)(n - lp.n_art > 0 ? n - lp.n_art : 1) * m;  // ... and of the pricing pass's products
     auto N_at = [&](int i, int c) { return lp.N + (size_t)c * m + i; };   // word 0 of N(row i, column c)
     const int LIMIT_BITS = 64 * L - 3;  // a value whose magnitude bound reaches this many bits might not fit
     u64* gD = lp.D;
@@ -2777,23 +2778,27 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     // gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 exactly ((2 L + 2)-limb sums of squares).  The (N a_j)_i are the ones
                     // the pricing pass stored; a thread per (candidate, row) squares one of them, a thread per candidate adds them up.
                     constexpr int GW = 2 * L + 2;
-                    price_products<L>(lp, lp.cand, n_cand, mD, eD, LIMIT_BITS, &s_overflow);  // (the estimates left nothing in price_a)
+                    // (the terms of GAMMA_BATCH candidates at a time: room for the terms of EVERY column that could tie was 2.6 GB at 128
+                    //  limbs on 25FV47, allocated and freed at every width for the handful of ties a pivot has)
+                    for (int c0 = 0; c0 < n_cand; c0 += EX_GAMMA_BATCH) {
+                    const int batch = min(EX_GAMMA_BATCH, n_cand - c0);
+                    price_products<L>(lp, lp.cand + c0, batch, mD, eD, LIMIT_BITS, &s_overflow);  // (the estimates left nothing in price_a)
                     grid.sync();
-                    for (long long pair = gtid; pair < (long long)n_cand * (m + 1); pair += GT) {
-                        const int c = (int)(pair / (m + 1)), i = (int)(pair - (long long)c * (m + 1));
+                    for (long long pair = gtid; pair < (long long)batch * (m + 1); pair += GT) {
+                        const int c = c0 + (int)(pair / (m + 1)), i = (int)(pair - (long long)(c - c0) * (m + 1));
                         const int j = lp.cand[c];
-                        u64* out = lp.gamma_terms + ((size_t)c * (m + 1) + i) * GW;
+                        u64* out = lp.gamma_terms + ((size_t)(c - c0) * (m + 1) + i) * GW;
                         if (i == m) weighted_square<L>(big_load<L>(gD), (u64)lp.weight[j], out);
-                        else weighted_square<L>(big_load_s<L>(lp.price_a + (size_t)(j - lp.n_art) * m + i, PP), (u64)lp.weight[lp.basis[i]], out);
+                        else weighted_square<L>(big_load_s<L>(lp.price_a + (size_t)(c - c0) * m + i, (size_t)EX_PRODUCT_SLOTS * m), (u64)lp.weight[lp.basis[i]], out);
                     }
                     grid.sync();
                     // (a wave per candidate, a lane per word of the sum: the terms are read a whole row of words at a time, the carries
                     //  run through the words once at the end.  One thread per candidate walked (m + 1) (2 L + 2) dependent additions:
                     //  a third of SCORPION's solve, whose degenerate pivots tie a hundred candidates at a time.)
                     constexpr int WPL = (GW + WAVE - 1) / WAVE;  // words per lane
-                    for (int c = gtid / WAVE; c < n_cand; c += GT / WAVE) {
+                    for (int c = c0 + gtid / WAVE; c < c0 + batch; c += GT / WAVE) {
                         const int ln = tid & (WAVE - 1);
-                        const u64* terms = lp.gamma_terms + (size_t)c * (m + 1) * GW;
+                        const u64* terms = lp.gamma_terms + (size_t)(c - c0) * (m + 1) * GW;
                         u128 total[WPL];
 #pragma unroll
                         for (int u = 0; u < WPL; ++u) total[u] = 0;
@@ -2820,6 +2825,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                         }
                     }
                     grid.sync();
+                    }
                     stamp(3);
                     // the tournament as a tree over the grid: the order "larger exact key, then larger column" is total, so any bracket
                     // gives the winner of the serial scan (which was 0.1 ms per comparison at 32 limbs, hundreds of candidates on SCORPION)
@@ -2887,7 +2893,10 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 // filter/generic_wrapper.rs:98-205).  Here the row stays, with its zero-level artificial basic: alpha_r = 0 for
                 // every entering column from now on, so it never takes part in a ratio test and adds nothing to a steepest-edge
                 // weight; only the ROW INDICES reported for phase two are shifted as the removal shifts them.
-                if (leader) lp.removed[r] = 1;
+                if (leader) {
+                    lp.removed[r] = 1;
+                    for (int i = r + 1; i < m; ++i) lp.removed[m + i] += 1;  // (the count the trace of phase two subtracts: kept here, once per
+                }                                                            //  removed row, not summed over the rows above p at every pivot)
                 ++n_removed;
                 drive_row = r + 1;
                 continue;
@@ -2909,7 +2918,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const int lane_a = tid & (WAVE - 1);
             // (rounds 4-5 copied a priced column's products out of price_a; the pricing pass now forms estimates only)
             if constexpr (L >= 2 * ENTER_CHUNK) {
-                if (n - lp.n_art >= 2) {  // (price_a holds the chunks: (L / 16) 19 m words)
+                {  // (price_a holds the chunks: (L / 16) 19 m words)
                     mark();
                     entering_column_chunks<L>(lp, q);
                     grid.sync();
@@ -2918,7 +2927,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     lap(11);
                 }
             }
-            if (L < 2 * ENTER_CHUNK || n - lp.n_art < 2)
+            if (L < 2 * ENTER_CHUNK)
             for (int block_a = gtid / WAVE; block_a * WAVE < m; block_a += GT / WAVE) {
                 const int i = block_a * WAVE + lane_a;
                 const bool active = i < m;
@@ -2947,7 +2956,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             }
         }
         if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store; from 32 limbs on entering_column_rows has formed them)
-            if (L < 2 * ENTER_CHUNK || n - lp.n_art < 2) {
+            if (L < 2 * ENTER_CHUNK) {
                 grid.sync();
                 lap(18);  // (the barrier after the entering column)
                 for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
@@ -3285,7 +3294,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             if (trace_count < lp.trace_capacity) {
                 int p_reported = p;
                 if (phase == 2 && n_removed > 0)  // the reference's phase two counts the rows that are left
-                    for (int i = 0; i < p; ++i) p_reported -= lp.removed[i];
+                    p_reported -= lp.removed[m + p];  // (the leader walking up to m flags was 50 us of every pivot of phase two on 25FV47)
                 lp.trace[4 * trace_count] = phase;
                 lp.trace[4 * trace_count + 1] = q;
                 lp.trace[4 * trace_count + 2] = p_reported;
@@ -3487,7 +3496,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_trace = dalloc<int>((size_t)4 * trace_capacity, owned);
     int* d_out = dalloc<int>(16, owned);
     int* d_resume = dalloc<int>(8, owned);
-    int* d_removed = dalloc<int>(m, owned);
+    int* d_removed = dalloc<int>(2 * (size_t)m, owned);  // [m] the flags, [m] how many removed rows lie above each row
     int* d_words = dalloc<int>(16, owned);
     constexpr int EX_MAX_GRID = 1024;
     double* d_part_key = dalloc<double>(2 * EX_MAX_GRID, owned);
@@ -3530,7 +3539,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int resume_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RELP_HIP(hipMemcpyAsync(d_basis, basis0.data(), m * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_pos, pos0.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
-    RELP_HIP(hipMemsetAsync(d_removed, 0, m * sizeof(int), stream));
+    RELP_HIP(hipMemsetAsync(d_removed, 0, 2 * (size_t)m * sizeof(int), stream));
     std::vector<void*> width_owned;  // the big-integer buffers of the current width (the previous width's are freed once widened)
     struct FreeWidth {
         std::vector<void*>& p;
@@ -3544,9 +3553,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_xt = dalloc<u64>((size_t)m * big, fresh);
         u64* d_alpha = dalloc<u64>((size_t)m * big, fresh);
         u64* d_ctil = dalloc<u64>((size_t)n * big, fresh);
-        d_price_a = dalloc<u64>(pairs * big, fresh);
+        d_price_a = dalloc<u64>((size_t)EX_PRODUCT_SLOTS * m * big, fresh);  // (also the chunks of the entering column: (big / 16) 19 m words)
         u64* d_gamma = dalloc<u64>((size_t)n * (2 * big + 2), fresh);  // (round 3 sized it for 32 limbs: a wider run with many tied candidates wrote past it)
-        u64* d_gamma_terms = dalloc<u64>((size_t)std::max(1, n - n_art) * (m + 1) * (2 * big + 2), fresh);
+        u64* d_gamma_terms = dalloc<u64>((size_t)EX_GAMMA_BATCH * (m + 1) * (2 * big + 2), fresh);
         u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
         // the update of N on the matrix cores (mfma_update_tile): from 32 limbs on (update_mode 1: never).  (At 16 limbs -- two
@@ -3603,7 +3612,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         }
         adopt();
         RELP_HIP(hipMemcpyAsync(d_resume, resume_state, sizeof(resume_state), hipMemcpyHostToDevice, stream));
-        RELP_HIP(hipMemsetAsync(d_words, 0, 8 * sizeof(int), stream));
+        RELP_HIP(hipMemsetAsync(d_words, 0, 16 * sizeof(int), stream));
         RELP_HIP(hipMemsetAsync(d_prof, 0, EX_PROF_WORDS * sizeof(unsigned long long), stream));
         RELP_HIP(hipMemsetAsync(d_barrier, 0, EX_BARRIER_WORDS * sizeof(unsigned), stream));
         const auto width_start = std::chrono::steady_clock::now();
