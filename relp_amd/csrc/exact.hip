@@ -1818,7 +1818,7 @@ __device__ __forceinline__ void words_from_below(const u64 (&x)[SLOTS], int d, u
 // the others in step with the longest sum), their nine-word windows are added across the lanes, the windows are laid over each other
 // a lane per block -- what a block carries on goes from lane to lane until none is left --, and the two's complement is taken by the
 // lanes together (zero up to the lowest non-zero word).  (The row factors -alpha~_i u of the update: 48 -> 15 us a pivot at 128 limbs.)
-template <int L>
+template <int L, bool NEGATE = true>
 __device__ __forceinline__ void wave_mul_lo_negated(const u64* a, const u64* b, u64* out, size_t stride, int lane) {
     static_assert(L % 4 == 0 && L / 4 <= WAVE && WAVE % (L / 4) == 0, "a lane per block of four words, or several");
     constexpr int NB = L / 4, SHARE = WAVE / NB;  // lanes per output block
@@ -1897,6 +1897,13 @@ __device__ __forceinline__ void wave_mul_lo_negated(const u64* a, const u64* b, 
         }
         carried = carry;
     }
+    if (!NEGATE) {  // (a * b itself)
+        if (lane < NB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(4 * lane + r) * stride] = word[r];
+        }
+        return;
+    }
     // the two's complement: zero up to the lowest non-zero word, that word's complement plus one, the complements above
     bool nonzero = false;
     int first = 4;
@@ -1921,7 +1928,7 @@ __device__ __forceinline__ void wave_mul_lo_negated(const u64* a, const u64* b, 
 // once from the words the wave holds (through LDS).  (A wave per 64 rows adding the chunks up word after word, a barrier, and a
 // wave per row multiplying were three steps: 36 + 6 + 48 us of every pivot at 128 limbs.)
 template <int L>
-__device__ __noinline__ void entering_column_rows(const ExactLP& lp, int q, const u64* dinv, int limit_bits, int* overflow) {
+__device__ __noinline__ void entering_column_rows(const ExactLP& lp, int q, const u64* dinv, int limit_bits, int* overflow, bool with_y, int* cq_bits_out) {
     constexpr int SLOTS = (L + WAVE - 1) / WAVE;
     __shared__ u64 s_row[EX_THREADS / WAVE][L];
     const int m = lp.m, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
@@ -1992,6 +1999,22 @@ __device__ __noinline__ void entering_column_rows(const ExactLP& lp, int q, cons
         wave_mul_lo_negated<L>(s_row[wave], dinv, lp.x_part + row, (size_t)m, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    // ... and y's factor c~_q u with the bit length of c~_q, by the last wave of the grid (y rides along with the update of N, see
+    // update_on_matrix_cores; on 25FV47 that wave has no row)
+    if (with_y && wave_of_grid == waves_of_grid - 1) {
+        u64 word[SLOTS];
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const int k = lane + t * WAVE;
+            word[t] = k < L ? lp.ctil[(size_t)q * L + k] : 0ull;
+            if (k < L) s_row[wave][k] = word[t];
+        }
+        const int bits = wave_bit_length_words<L>(word, lane);
+        if (lane == 0) *cq_bits_out = bits;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wave_mul_lo_negated<L, false>(s_row[wave], dinv, lp.y_part, 1, lane);
     }
 }
 
@@ -2923,7 +2946,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     entering_column_chunks<L>(lp, q);
                     grid.sync();
                     lap(10);
-                    entering_column_rows<L>(lp, q, s_dinv, LIMIT_BITS, &s_overflow);  // ... added up, and the rows' factors -alpha~_i u
+                    entering_column_rows<L>(lp, q, s_dinv, LIMIT_BITS, &s_overflow, y_rides, word + 8);  // ... added up, and the rows' factors -alpha~_i u
                     lap(11);
                 }
             }
@@ -2961,12 +2984,6 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 lap(18);  // (the barrier after the entering column)
                 for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
                 lap(19);
-            }
-            // ... and y's factor c~_q u, by the last wave of the grid (y rides along with the update of N, see update_on_matrix_cores)
-            if (y_rides && gtid / WAVE == GT / WAVE - 1) {
-                wave_mul_lo_store<L>(lp.ctil + (size_t)q * L, s_dinv, lp.y_part, 1, tid & (WAVE - 1), false);
-                const int bits = wave_bit_length<L>(lp.ctil + (size_t)q * L, tid & (WAVE - 1));
-                if ((tid & (WAVE - 1)) == 0) word[8] = bits;
             }
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
@@ -3107,7 +3124,23 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         // new entry is that value shifted right by s -- known modulo 2^(64 L - s), sign-extended from there, and it must fit there.
         // TWO truncated products per entry (the numerator first and then its product with u were three); alpha~_p u once per
         // workgroup, alpha~_i u once per row (the alpha step).
-        block_mul_lo(s_words[0], L, s_dinv, L, s_c1, L, s_part);
+        if constexpr (L >= 2 * ENTER_CHUNK) {
+            // (alpha~_p u is the negative of row p's factor, which entering_column_rows has just stored: a thread per word takes the two's
+            //  complement -- zero up to the lowest non-zero word, that word's complement plus one, the complements above -- instead of
+            //  one more truncated product by every workgroup, 8 us of every pivot at 128 limbs)
+            __shared__ unsigned long long s_c1_nonzero[EX_THREADS / WAVE];
+            const u64 w = tid < L ? lp.x_part[(size_t)tid * m + p] : 0ull;
+            const unsigned long long nonzero = __ballot(w != 0);
+            if ((tid & (WAVE - 1)) == 0) s_c1_nonzero[tid / WAVE] = nonzero;
+            __syncthreads();
+            int lowest = L;
+            for (int wv = EX_THREADS / WAVE - 1; wv >= 0; --wv)
+                if (s_c1_nonzero[wv] != 0) lowest = WAVE * wv + __ffsll((long long)s_c1_nonzero[wv]) - 1;
+            if (tid < L) s_c1[tid] = tid < lowest ? 0ull : tid == lowest ? ~w + 1ull : ~w;
+            __syncthreads();
+        } else {
+            block_mul_lo(s_words[0], L, s_dinv, L, s_c1, L, s_part);
+        }
         Big<L> c1;
         if (!on_matrix_cores) {
 #pragma unroll L <= 8 ? L : 1
