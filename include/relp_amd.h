@@ -462,6 +462,10 @@ int32_t relp_debug_set_tuning(const relp_options* options);
  * bit length of each magnitude.  limbs in {16, 32, 64, 128}.  No reference counterpart (tests only). */
 int32_t relp_debug_exact_finish(int32_t device, int32_t limbs, int32_t count, const uint64_t* T, const int32_t* carry, const int32_t* words,
                                 int32_t shift, int32_t flip, uint64_t* N_out, int32_t* bits_out);
+/* Test hook of the word arithmetic behind a pivot's scalars (exact.hip): `count` pairs of `limbs`-word integers (entry e at a[e * limbs ..],
+ * least significant word first), mode 0: out = 1 / a modulo 2^(64 limbs) for odd a (wave_inverse_odd: the inverse of D's odd part);
+ * 1: out = -(a b) modulo 2^(64 limbs) (wave_mul_lo_negated: the rows' update factors); 2: out = a b.  No reference counterpart. */
+int32_t relp_debug_exact_words(int32_t device, int32_t limbs, int32_t mode, int32_t count, const uint64_t* a, const uint64_t* b, uint64_t* out);
 
 /* ---- `BasisInverse` as an object of its own (no LP handle needed) ------------------------------------------------------
  * The reference's trait `BasisInverse` (tableau/inverse_maintenance/carry/mod.rs:69-169) and its main implementor

@@ -13,6 +13,7 @@
 namespace relp {
 void exact_finish_entries(int device, int limbs, int count, const unsigned long long* T, const int* carry, const int* words, int shift, int flip,
                           unsigned long long* N_out, int* bits_out);
+void exact_words_test(int device, int limbs, int mode, int count, const unsigned long long* a, const unsigned long long* b, unsigned long long* out);
 }
 using namespace relp;
 
@@ -975,6 +976,17 @@ int32_t relp_debug_exact_finish(int32_t device, int32_t limbs, int32_t count, co
     if (limbs != 16 && limbs != 32 && limbs != 64 && limbs != 128) return RELP_ERR_ARGUMENT;
     try {
         relp::exact_finish_entries(device, limbs, count, (const unsigned long long*)T, carry, words, shift, flip, (unsigned long long*)N_out, bits_out);
+        return RELP_OK;
+    } catch (const std::exception&) {
+        return RELP_ERR_DEVICE;
+    }
+}
+
+int32_t relp_debug_exact_words(int32_t device, int32_t limbs, int32_t mode, int32_t count, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    if (!a || !b || !out || count < 1 || mode < 0 || mode > 2) return RELP_ERR_ARGUMENT;
+    if (limbs != 16 && limbs != 32 && limbs != 64 && limbs != 128) return RELP_ERR_ARGUMENT;
+    try {
+        relp::exact_words_test(device, limbs, mode, count, (const unsigned long long*)a, (const unsigned long long*)b, (unsigned long long*)out);
         return RELP_OK;
     } catch (const std::exception&) {
         return RELP_ERR_DEVICE;

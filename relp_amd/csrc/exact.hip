@@ -3772,6 +3772,52 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
 }
 
 // `finish_update_entry` by itself: count entries, word-major operands as lp.T / lp.T_carry hold them (entry stride = count)
+// the word arithmetic of the pivot's scalars on `count` operand pairs, a workgroup each (tests): mode 0: 1 / a modulo 2^(64 L), a odd
+// (wave_inverse_odd); 1: -(a b) modulo 2^(64 L) (wave_mul_lo_negated, the rows' factors); 2: a b (y's factor)
+template <int L>
+__global__ void __launch_bounds__(EX_THREADS) exact_words_test_kernel(int mode, const u64* a, const u64* b, u64* out) {
+    __shared__ u64 s_a[L], s_b[L], s_x[L], s_t[L], s_x2[L];
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * L;
+    if (tid < L) {
+        s_a[tid] = a[base + tid];
+        s_b[tid] = b[base + tid];
+    }
+    __syncthreads();
+    if (mode == 0) {
+        wave_inverse_odd<L>(s_a, s_x, s_t, s_x2);
+        if (tid < L) out[base + tid] = s_x[tid];
+    } else if (tid < WAVE) {
+        if (mode == 1) wave_mul_lo_negated<L, true>(s_a, s_b, out + base, 1, tid);
+        else wave_mul_lo_negated<L, false>(s_a, s_b, out + base, 1, tid);
+    }
+}
+void exact_words_test(int device, int limbs, int mode, int count, const unsigned long long* a, const unsigned long long* b, unsigned long long* out) {
+    RELP_HIP(hipSetDevice(device));
+    std::vector<void*> owned;
+    struct Free {
+        std::vector<void*>& p;
+        ~Free() { for (void* q : p) (void)hipFree(q); }
+    } free_all{owned};
+    const size_t bytes = (size_t)count * limbs * sizeof(u64);
+    u64 *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
+    RELP_HIP(hipMalloc((void**)&d_a, bytes)); owned.push_back(d_a);
+    RELP_HIP(hipMalloc((void**)&d_b, bytes)); owned.push_back(d_b);
+    RELP_HIP(hipMalloc((void**)&d_out, bytes)); owned.push_back(d_out);
+    RELP_HIP(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+    RELP_HIP(hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice));
+    const dim3 grid(count), block(EX_THREADS);
+    switch (limbs) {
+        case 16: hipLaunchKernelGGL(exact_words_test_kernel<16>, grid, block, 0, 0, mode, d_a, d_b, d_out); break;
+        case 32: hipLaunchKernelGGL(exact_words_test_kernel<32>, grid, block, 0, 0, mode, d_a, d_b, d_out); break;
+        case 64: hipLaunchKernelGGL(exact_words_test_kernel<64>, grid, block, 0, 0, mode, d_a, d_b, d_out); break;
+        case 128: hipLaunchKernelGGL(exact_words_test_kernel<128>, grid, block, 0, 0, mode, d_a, d_b, d_out); break;
+        default: throw std::invalid_argument("limbs must be 16, 32, 64 or 128");
+    }
+    RELP_HIP(hipGetLastError());
+    RELP_HIP(hipDeviceSynchronize());
+    RELP_HIP(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+}
 void exact_finish_entries(int device, int limbs, int count, const unsigned long long* T, const int* carry, const int* words, int shift, int flip,
                           unsigned long long* N_out, int* bits_out) {
     RELP_HIP(hipSetDevice(device));

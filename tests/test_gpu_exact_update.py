@@ -137,3 +137,43 @@ def test_weight_estimates_from_leading_words_and_exact_products_choose_the_same_
         assert (got["pivots_phase_one"], got["pivots_phase_two"]) == (golden["pivots_phase1"], golden["pivots_phase2"])
         results.append((got["trace"], list(got["basis"]), got["objective"]))
     assert results[0] == results[1]
+
+
+def _words_of(value, limbs):
+    return [(value >> (64 * k)) & ((1 << 64) - 1) for k in range(limbs)]
+
+
+@pytest.mark.parametrize("limbs", [16, 32, 64, 128])
+def test_word_arithmetic_of_the_pivots_scalars_against_python_integers(limbs):
+    """`wave_inverse_odd` (1 / D_odd modulo 2^(64 L): Newton's doublings by one wave on blocks of four words) and `wave_mul_lo_negated` (the
+    rows' factors -alpha_i u and y's factor, every lane at work, carries from lane to lane, the two's complement by the lanes together)
+    through `relp_debug_exact_words`, against Python's integers: random operands and the ones that stress the carries (0, 1, -1, 2^k,
+    all ones, runs of zero words)."""
+    rng = np.random.default_rng(limbs)
+    modulus = 1 << (64 * limbs)
+    specials = [0, 1, modulus - 1, 1 << 63, (1 << 64) - 1, 1 << 64, 1 << (64 * limbs - 1), (1 << (64 * (limbs // 2))) - 1,
+                ((1 << 64) - 1) << (64 * (limbs - 1)), modulus - (1 << 64), 3, (1 << 192) + 1]
+    randoms = [int.from_bytes(rng.bytes(8 * limbs), "little") for _ in range(20)]
+    sparse = [sum(int(rng.integers(0, 1 << 63)) << (64 * int(k)) for k in rng.choice(limbs, size=3, replace=False)) for _ in range(6)]
+    operands = specials + randoms + sparse
+    pairs = [(x, y) for x in operands for y in (operands[:6] + randoms[:4])]
+    for mode in (1, 2):
+        a = np.array([w for x, _ in pairs for w in _words_of(x, limbs)], dtype=np.uint64)
+        b = np.array([w for _, y in pairs for w in _words_of(y, limbs)], dtype=np.uint64)
+        out = np.zeros_like(a)
+        status = relp_amd.lib().relp_debug_exact_words(0, limbs, mode, len(pairs), a.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                       b.ctypes.data_as(C.POINTER(C.c_uint64)), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        assert status == 0
+        for e, (x, y) in enumerate(pairs):
+            got = sum(int(out[e * limbs + k]) << (64 * k) for k in range(limbs))
+            want = (x * y) % modulus if mode == 2 else (-(x * y)) % modulus
+            assert got == want, (limbs, mode, hex(x)[:40], hex(y)[:40])
+    odd = [x | 1 for x in operands]
+    a = np.array([w for x in odd for w in _words_of(x, limbs)], dtype=np.uint64)
+    out = np.zeros_like(a)
+    status = relp_amd.lib().relp_debug_exact_words(0, limbs, 0, len(odd), a.ctypes.data_as(C.POINTER(C.c_uint64)), a.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert status == 0
+    for e, x in enumerate(odd):
+        got = sum(int(out[e * limbs + k]) << (64 * k) for k in range(limbs))
+        assert (got * x) % modulus == 1, (limbs, hex(x)[:40])
