@@ -956,6 +956,134 @@ __device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
     out[2 * L] = carry;
     out[2 * L + 1] = 0;
 }
+// The exact comparison of two tied candidates' keys c~^2 / gamma~ by ONE WAVE: + 1 when column a has the larger key, as compare_keys (one
+// thread forming two squares and two (2 L) x (2 L + 2)-word products in scratch memory: 0.4 ms a comparison at 32 limbs, 60 % of
+// BANDM's solve, whose pivots tie two or three candidates as a rule -- and 12 KB of scratch per lane of the whole kernel at 128 limbs).
+// The magnitudes |c~| and the weights go to the wave's words in LDS (`room`: 10 L + 4 words); |c~_a| = |c~_b| decides on the weights
+// alone; otherwise the squares are formed a lane per word (column sums, the carries in one chain) and the sign of c~_a^2 gamma~_b -
+// c~_b^2 gamma~_a by wave_sign_of_difference.
+template <int L>
+__device__ __forceinline__ int wave_compare_keys(const u64* ca, const u64* gamma_a, const u64* cb, const u64* gamma_b, u64* room, int lane) {
+    constexpr int GW = 2 * L + 2, SLOTS = (L + WAVE - 1) / WAVE, SLOTS2 = (2 * L + WAVE - 1) / WAVE, SLOTSG = (GW + WAVE - 1) / WAVE;
+    u64 *mag_a = room, *mag_b = room + L, *sq_a = room + 2 * L, *sq_b = room + 4 * L, *ga = room + 6 * L, *gb = room + 8 * L + 2;
+    // |c~| a lane per word: the two's complement of a negative value is zero up to its lowest non-zero word, that word's complement plus
+    // one, the complements above
+    auto magnitude = [&](const u64* v, u64* out) {
+        u64 w[SLOTS];
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) w[t] = lane + t * WAVE < L ? v[lane + t * WAVE] : 0ull;
+        const u64 top_word = __shfl(w[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
+        const bool negative = (i64)top_word < 0;
+        int lowest = L;
+#pragma unroll
+        for (int t = SLOTS - 1; t >= 0; --t) {
+            const unsigned long long nonzero = __ballot(lane + t * WAVE < L && w[t] != 0);
+            if (nonzero != 0) lowest = t * WAVE + __ffsll((long long)nonzero) - 1;
+        }
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const int k = lane + t * WAVE;
+            if (k < L) out[k] = !negative ? w[t] : k < lowest ? 0ull : k == lowest ? ~w[t] + 1ull : ~w[t];
+        }
+        return lowest < L;  // non-zero
+    };
+    const bool a_nonzero = magnitude(ca, mag_a);
+    magnitude(cb, mag_b);
+#pragma unroll
+    for (int t = 0; t < SLOTSG; ++t) {
+        const int k = lane + t * WAVE;
+        if (k < GW) {
+            ga[k] = gamma_a[k];
+            gb[k] = gamma_b[k];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool same = true;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) same = same && __ballot(lane + t * WAVE < L && mag_a[lane + t * WAVE < L ? lane + t * WAVE : 0] != mag_b[lane + t * WAVE < L ? lane + t * WAVE : 0]) == 0;
+    if (same) {  // (the tied candidates of a degenerate pivot, as a rule): the larger key has the smaller gamma -- no products
+        if (!a_nonzero) return 0;
+        int result = 0;
+#pragma unroll
+        for (int t = SLOTSG - 1; t >= 0; --t) {
+            const int k = lane + t * WAVE;
+            const u64 wa = k < GW ? ga[k] : 0ull, wb = k < GW ? gb[k] : 0ull;
+            const unsigned long long differs = __ballot(wa != wb);
+            if (result == 0 && differs != 0) {
+                const int owner = 63 - __clzll((long long)differs);
+                const u64 xa = __shfl(wa, owner), xb = __shfl(wb, owner);
+                result = xb > xa ? 1 : -1;
+            }
+        }
+        return result;
+    }
+    // the squares: a lane per word of the result forms its column sum (three words), one chain runs the carries through
+    auto square = [&](const u64* x, u64* out) {
+        u64 sum[SLOTS2][3];
+#pragma unroll
+        for (int t = 0; t < SLOTS2; ++t) {
+            const int w = lane + t * WAVE;
+            u64 s0 = 0, s1 = 0, s2 = 0;
+            if (w < 2 * L) {
+                const int j0 = max(0, w - L + 1), j1 = min(w, L - 1);
+                for (int j = j0; j <= j1; ++j) {
+                    const u128 prod = (u128)x[w - j] * x[j];
+                    const u128 low = (u128)s0 + (u64)prod;
+                    s0 = (u64)low;
+                    const u128 mid = (u128)s1 + (u64)(prod >> 64) + (u64)(low >> 64);
+                    s1 = (u64)mid;
+                    s2 += (u64)(mid >> 64);
+                }
+            }
+            sum[t][0] = s0;
+            sum[t][1] = s1;
+            sum[t][2] = s2;
+        }
+        u128 run = 0;
+        u64 run_top = 0;
+        for (int w = 0; w < 2 * L; ++w) {
+            const int owner = w & (WAVE - 1), slot = w / WAVE;
+            u64 part[3] = {0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < SLOTS2; ++t)
+                if (t == slot) { part[0] = sum[t][0]; part[1] = sum[t][1]; part[2] = sum[t][2]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)part[q], owner), hi = (unsigned)__builtin_amdgcn_readlane((int)(part[q] >> 32), owner);
+                part[q] = ((u64)hi << 32) | lo;
+            }
+            const u128 add = (u128)part[0] | ((u128)part[1] << 64);
+            run += add;
+            run_top += part[2] + (run < add ? 1 : 0);
+            if (lane == 0) out[w] = (u64)run;
+            run = (run >> 64) | ((u128)run_top << 64);
+            run_top = 0;
+        }
+    };
+    square(mag_a, sq_a);
+    square(mag_b, sq_b);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return wave_sign_of_difference<2 * L + 1>(sq_a, 2 * L, gb, GW, sq_b, 2 * L, ga, GW, lane);
+}
+// one round of the tournament over the tied candidates (the brackets `stride` apart), a wave per comparison; a function of its own for
+// its registers' sake (the sums of a 4 L-word product a lane per word)
+template <int L>
+__device__ __noinline__ void tournament_round(const ExactLP& lp, int n_cand, int stride) {
+    __shared__ u64 s_keys[EX_THREADS / WAVE][10 * L + 4];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long long wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    for (long long c = wave_of_grid * 2 * stride; c + stride < n_cand; c += waves_of_grid * 2 * stride) {
+        const int ca = lp.bracket[c], cb2 = lp.bracket[c + stride];
+        const int ja = lp.cand[ca], jb = lp.cand[cb2];
+        const int cmp = wave_compare_keys<L>(lp.ctil + (size_t)jb * L, lp.gamma + (size_t)cb2 * (2 * L + 2), lp.ctil + (size_t)ja * L, lp.gamma + (size_t)ca * (2 * L + 2),
+                                             s_keys[threadIdx.x / WAVE], lane);
+        if (lane == 0 && (cmp > 0 || (cmp == 0 && jb > ja))) lp.bracket[c] = cb2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 // c_a^2 * gamma_b  vs  c_b^2 * gamma_a  (unsigned, (4 L + 1) limbs): +1 when column a has the larger key
 template <int L>
 __device__ int compare_keys(const Big<L>& ca, const u64* gamma_a, const Big<L>& cb, const u64* gamma_b) {
@@ -2855,12 +2983,16 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     for (int c = gtid; c < n_cand; c += GT) lp.bracket[c] = c;
                     grid.sync();
                     for (int stride = 1; stride < n_cand; stride *= 2) {
+                        if constexpr (L >= 16) {  // a WAVE per comparison
+                            tournament_round<L>(lp, n_cand, stride);
+                        } else {
                         for (long long c = (long long)gtid * 2 * stride; c + stride < n_cand; c += (long long)GT * 2 * stride) {
                             const int ca = lp.bracket[c], cb2 = lp.bracket[c + stride];
                             const int ja = lp.cand[ca], jb = lp.cand[cb2];
                             const int cmp = compare_keys<L>(big_load<L>(lp.ctil + (size_t)jb * L), lp.gamma + (size_t)cb2 * (2 * L + 2),
                                                             big_load<L>(lp.ctil + (size_t)ja * L), lp.gamma + (size_t)ca * (2 * L + 2));
                             if (cmp > 0 || (cmp == 0 && jb > ja)) lp.bracket[c] = cb2;
+                        }
                         }
                         grid.sync();
                     }
