@@ -122,7 +122,8 @@ def test_whole_traces_on_the_matrix_cores_and_on_the_vector_unit(name, monkeypat
     assert results[0] == results[1]
 
 
-@pytest.mark.parametrize("name", ["STOCFOR1", "SHARE1B", "E226", "BANDM", "SCSD1", "ISRAEL"])
+@pytest.mark.parametrize("name", ["STOCFOR1", "SHARE1B", "E226", "BANDM", "SCSD1", "ISRAEL", "AFIRO", "ADLITTLE", "BLEND", "SCAGR7", "SHARE2B", "KB2",
+                                  "SCRS8", "CZPROB", "GFRD-PNC", "SC205", "LOTFI", "BRANDY", "SCTAP1", "AGG"])
 def test_weight_estimates_from_leading_words_and_exact_products_choose_the_same_pivots(name):
     """The pricing pass estimates the steepest-edge weights from the four leading words of every operand of N a_j, with an error bound per
     term, and forms a column's products exactly only where the bound asks (price_estimates / price_products in exact.hip).  Bit 2 of
