@@ -956,6 +956,75 @@ __device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
     out[2 * L] = carry;
     out[2 * L + 1] = 0;
 }
+// |v| of an L-word two's complement integer (word k at v[k * stride]) into out[0 .. L) (LDS), a lane per word: the two's complement of a
+// negative value is zero up to its lowest non-zero word, that word's complement plus one, the complements above.  Returns v != 0.
+template <int L>
+__device__ __forceinline__ bool wave_magnitude(const u64* v, size_t stride, u64* out, int lane) {
+    constexpr int SLOTS = (L + WAVE - 1) / WAVE;
+    u64 w[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) w[t] = lane + t * WAVE < L ? v[(size_t)(lane + t * WAVE) * stride] : 0ull;
+    const u64 top_word = __shfl(w[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
+    const bool negative = (i64)top_word < 0;
+    int lowest = L;
+#pragma unroll
+    for (int t = SLOTS - 1; t >= 0; --t) {
+        const unsigned long long nonzero = __ballot(lane + t * WAVE < L && w[t] != 0);
+        if (nonzero != 0) lowest = t * WAVE + __ffsll((long long)nonzero) - 1;
+    }
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+        const int k = lane + t * WAVE;
+        if (k < L) out[k] = !negative ? w[t] : k < lowest ? 0ull : k == lowest ? ~w[t] + 1ull : ~w[t];
+    }
+    return lowest < L;
+}
+// x^2 for an unsigned integer of L words in LDS, by one wave: a lane per word of the result forms its column sum (three words), one chain
+// runs the carries through; emit(w, word) is called by every lane alike, w = 0 .. 2 L - 1 in order
+template <int L, class Emit>
+__device__ __forceinline__ void wave_square(const u64* x, int lane, Emit emit) {
+    constexpr int SLOTS2 = (2 * L + WAVE - 1) / WAVE;
+    u64 sum[SLOTS2][3];
+#pragma unroll
+    for (int t = 0; t < SLOTS2; ++t) {
+        const int w = lane + t * WAVE;
+        u64 s0 = 0, s1 = 0, s2 = 0;
+        if (w < 2 * L) {
+            const int j0 = max(0, w - L + 1), j1 = min(w, L - 1);
+            for (int j = j0; j <= j1; ++j) {
+                const u128 prod = (u128)x[w - j] * x[j];
+                const u128 low = (u128)s0 + (u64)prod;
+                s0 = (u64)low;
+                const u128 mid = (u128)s1 + (u64)(prod >> 64) + (u64)(low >> 64);
+                s1 = (u64)mid;
+                s2 += (u64)(mid >> 64);
+            }
+        }
+        sum[t][0] = s0;
+        sum[t][1] = s1;
+        sum[t][2] = s2;
+    }
+    u128 run = 0;
+    u64 run_top = 0;
+    for (int w = 0; w < 2 * L; ++w) {
+        const int owner = w & (WAVE - 1), slot = w / WAVE;
+        u64 part[3] = {0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < SLOTS2; ++t)
+            if (t == slot) { part[0] = sum[t][0]; part[1] = sum[t][1]; part[2] = sum[t][2]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)part[q], owner), hi = (unsigned)__builtin_amdgcn_readlane((int)(part[q] >> 32), owner);
+            part[q] = ((u64)hi << 32) | lo;
+        }
+        const u128 add = (u128)part[0] | ((u128)part[1] << 64);
+        run += add;
+        run_top += part[2] + (run < add ? 1 : 0);
+        emit(w, (u64)run);
+        run = (run >> 64) | ((u128)run_top << 64);
+        run_top = 0;
+    }
+}
 // The exact comparison of two tied candidates' keys c~^2 / gamma~ by ONE WAVE: + 1 when column a has the larger key, as compare_keys (one
 // thread forming two squares and two (2 L) x (2 L + 2)-word products in scratch memory: 0.4 ms a comparison at 32 limbs, 60 % of
 // BANDM's solve, whose pivots tie two or three candidates as a rule -- and 12 KB of scratch per lane of the whole kernel at 128 limbs).
@@ -964,31 +1033,10 @@ __device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
 // c~_b^2 gamma~_a by wave_sign_of_difference.
 template <int L>
 __device__ __forceinline__ int wave_compare_keys(const u64* ca, const u64* gamma_a, const u64* cb, const u64* gamma_b, u64* room, int lane) {
-    constexpr int GW = 2 * L + 2, SLOTS = (L + WAVE - 1) / WAVE, SLOTS2 = (2 * L + WAVE - 1) / WAVE, SLOTSG = (GW + WAVE - 1) / WAVE;
+    constexpr int GW = 2 * L + 2, SLOTS = (L + WAVE - 1) / WAVE, SLOTSG = (GW + WAVE - 1) / WAVE;
     u64 *mag_a = room, *mag_b = room + L, *sq_a = room + 2 * L, *sq_b = room + 4 * L, *ga = room + 6 * L, *gb = room + 8 * L + 2;
-    // |c~| a lane per word: the two's complement of a negative value is zero up to its lowest non-zero word, that word's complement plus
-    // one, the complements above
-    auto magnitude = [&](const u64* v, u64* out) {
-        u64 w[SLOTS];
-#pragma unroll
-        for (int t = 0; t < SLOTS; ++t) w[t] = lane + t * WAVE < L ? v[lane + t * WAVE] : 0ull;
-        const u64 top_word = __shfl(w[(L - 1) / WAVE], (L - 1) & (WAVE - 1));
-        const bool negative = (i64)top_word < 0;
-        int lowest = L;
-#pragma unroll
-        for (int t = SLOTS - 1; t >= 0; --t) {
-            const unsigned long long nonzero = __ballot(lane + t * WAVE < L && w[t] != 0);
-            if (nonzero != 0) lowest = t * WAVE + __ffsll((long long)nonzero) - 1;
-        }
-#pragma unroll
-        for (int t = 0; t < SLOTS; ++t) {
-            const int k = lane + t * WAVE;
-            if (k < L) out[k] = !negative ? w[t] : k < lowest ? 0ull : k == lowest ? ~w[t] + 1ull : ~w[t];
-        }
-        return lowest < L;  // non-zero
-    };
-    const bool a_nonzero = magnitude(ca, mag_a);
-    magnitude(cb, mag_b);
+    const bool a_nonzero = wave_magnitude<L>(ca, 1, mag_a, lane);
+    wave_magnitude<L>(cb, 1, mag_b, lane);
 #pragma unroll
     for (int t = 0; t < SLOTSG; ++t) {
         const int k = lane + t * WAVE;
@@ -1018,54 +1066,45 @@ __device__ __forceinline__ int wave_compare_keys(const u64* ca, const u64* gamma
         }
         return result;
     }
-    // the squares: a lane per word of the result forms its column sum (three words), one chain runs the carries through
-    auto square = [&](const u64* x, u64* out) {
-        u64 sum[SLOTS2][3];
-#pragma unroll
-        for (int t = 0; t < SLOTS2; ++t) {
-            const int w = lane + t * WAVE;
-            u64 s0 = 0, s1 = 0, s2 = 0;
-            if (w < 2 * L) {
-                const int j0 = max(0, w - L + 1), j1 = min(w, L - 1);
-                for (int j = j0; j <= j1; ++j) {
-                    const u128 prod = (u128)x[w - j] * x[j];
-                    const u128 low = (u128)s0 + (u64)prod;
-                    s0 = (u64)low;
-                    const u128 mid = (u128)s1 + (u64)(prod >> 64) + (u64)(low >> 64);
-                    s1 = (u64)mid;
-                    s2 += (u64)(mid >> 64);
-                }
-            }
-            sum[t][0] = s0;
-            sum[t][1] = s1;
-            sum[t][2] = s2;
-        }
-        u128 run = 0;
-        u64 run_top = 0;
-        for (int w = 0; w < 2 * L; ++w) {
-            const int owner = w & (WAVE - 1), slot = w / WAVE;
-            u64 part[3] = {0, 0, 0};
-#pragma unroll
-            for (int t = 0; t < SLOTS2; ++t)
-                if (t == slot) { part[0] = sum[t][0]; part[1] = sum[t][1]; part[2] = sum[t][2]; }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)part[q], owner), hi = (unsigned)__builtin_amdgcn_readlane((int)(part[q] >> 32), owner);
-                part[q] = ((u64)hi << 32) | lo;
-            }
-            const u128 add = (u128)part[0] | ((u128)part[1] << 64);
-            run += add;
-            run_top += part[2] + (run < add ? 1 : 0);
-            if (lane == 0) out[w] = (u64)run;
-            run = (run >> 64) | ((u128)run_top << 64);
-            run_top = 0;
-        }
-    };
-    square(mag_a, sq_a);
-    square(mag_b, sq_b);
+    wave_square<L>(mag_a, lane, [&](int w, u64 word) { if (lane == 0) sq_a[w] = word; });
+    wave_square<L>(mag_b, lane, [&](int w, u64 word) { if (lane == 0) sq_b[w] = word; });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return wave_sign_of_difference<2 * L + 1>(sq_a, 2 * L, gb, GW, sq_b, 2 * L, ga, GW, lane);
+}
+// The terms w_i (N a_j)_i^2 (and w_j D^2, "row" m) of the exact weights of `batch` tied candidates, a WAVE per term: the magnitude a
+// lane per word into the wave's LDS, the square a lane per word of the result (wave_square), the small weight multiplied in as the
+// words leave the chain.  (A thread per term with its square in scratch memory: L^2 dependent multiply-adds, a millisecond at 128
+// limbs, and 2 KB of the kernel's scratch per lane.)
+template <int L>
+__device__ __noinline__ void exact_weight_terms(const ExactLP& lp, int c0, int batch) {
+    constexpr int GW = 2 * L + 2;
+    __shared__ u64 s_magnitude[EX_THREADS / WAVE][L];
+    const int m = lp.m, lane = threadIdx.x & (WAVE - 1);
+    const long long wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
+    u64* magnitude = s_magnitude[threadIdx.x / WAVE];
+    for (long long item = wave_of_grid; item < (long long)batch * (m + 1); item += waves_of_grid) {
+        const int local = (int)(item / (m + 1)), i = (int)(item - (long long)local * (m + 1));
+        const int j = lp.cand[c0 + local];
+        u64* out = lp.gamma_terms + ((size_t)local * (m + 1) + i) * GW;
+        const u64 weight = i == m ? (u64)lp.weight[j] : (u64)lp.weight[lp.basis[i]];
+        if (i == m) wave_magnitude<L>(lp.D, 1, magnitude, lane);
+        else wave_magnitude<L>(lp.price_a + (size_t)local * m + i, (size_t)EX_PRODUCT_SLOTS * m, magnitude, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u64 carry = 0;
+        wave_square<L>(magnitude, lane, [&](int w, u64 word) {
+            const u128 scaled = (u128)word * weight + carry;
+            if (lane == 0) out[w] = (u64)scaled;
+            carry = (u64)(scaled >> 64);
+        });
+        if (lane == 0) {
+            out[2 * L] = carry;
+            out[2 * L + 1] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 // one round of the tournament over the tied candidates (the brackets `stride` apart), a wave per comparison; a function of its own for
 // its registers' sake (the sums of a 4 L-word product a lane per word)
@@ -2935,6 +2974,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     const int batch = min(EX_GAMMA_BATCH, n_cand - c0);
                     price_products<L>(lp, lp.cand + c0, batch, mD, eD, LIMIT_BITS, &s_overflow);  // (the estimates left nothing in price_a)
                     grid.sync();
+                    if constexpr (L >= 16) exact_weight_terms<L>(lp, c0, batch);  // a wave per term
+                    else
                     for (long long pair = gtid; pair < (long long)batch * (m + 1); pair += GT) {
                         const int c = c0 + (int)(pair / (m + 1)), i = (int)(pair - (long long)(c - c0) * (m + 1));
                         const int j = lp.cand[c];
