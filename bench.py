@@ -1164,13 +1164,13 @@ def launch_ranks(gpus, argv):
         rank0_stdout.seek(0)
         out = rank0_stdout.read()
     lines = [row for row in (out or "").splitlines() if row.strip()]
+    if any(codes):  # (nothing of rank 0's goes to stdout: a rank that died late -- in destroy_process_group, say -- must not leave a bench line behind)
+        sys.stderr.write("bench.py: --gpus %d: exit codes of the ranks %s\n" % (gpus, codes))
+        for row in lines:
+            sys.stderr.write("[rank 0] " + row + "\n")
+        return next(code for code in codes if code) or 1
     for row in lines[:-1]:
         print(row)
-    if any(codes):
-        sys.stderr.write("bench.py: --gpus %d: exit codes of the ranks %s\n" % (gpus, codes))
-        for row in lines[-1:]:
-            print(row)
-        return next(code for code in codes if code) or 1
     try:
         line = json.loads(lines[-1])
     except (IndexError, ValueError):

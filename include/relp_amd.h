@@ -117,10 +117,11 @@ typedef enum relp_switch {
 } relp_switch;
 
 typedef struct relp_options {
-    int32_t struct_size;       /* sizeof(relp_options) as the CALLER compiled it; relp_options_default() sets it and is the only
-                                  supported way to initialise the struct.  relp_create / relp_batch_create read that many bytes and
-                                  take the defaults for the fields a caller built against an older header does not have; 0 or a
-                                  size larger than the library's is RELP_ERR_ARGUMENT */
+    int32_t struct_size;       /* sizeof(relp_options) as the CALLER compiled it; relp_options_default() -- through the header's
+                                  macro relp_options_default_sized(o, sizeof(relp_options)) -- sets it and is the only supported
+                                  way to initialise the struct.  relp_create / relp_batch_create read that many bytes and take the
+                                  defaults for the fields a caller built against an older header does not have; anything but
+                                  a size this struct has had in some round is RELP_ERR_ARGUMENT */
     int32_t device;            /* HIP device ordinal */
     int32_t pivot_rule;        /* relp_pivot_rule */
     int32_t polish_period;     /* pivots between Newton-Schulz polishes of the explicit inverse (role of
@@ -172,7 +173,7 @@ typedef struct relp_options {
     int32_t certify_threads;   /* host threads of the exact certificate (by the core count, at most 32) */
     int32_t exact_grid;        /* relp_solve_exact: workgroups of the cooperative launch (by the work of a pivot) */
     int32_t exact_update;      /* relp_solve_exact, bits: 1 = the update of N = D B^-1 on the vector unit only (default: on the matrix
-                                  cores from 32 limbs on); 2 = the pricing pass forms the products N a_j of every column that can enter
+                                  cores from 16 limbs on); 2 = the pricing pass forms the products N a_j of every column that can enter
                                   exactly (default: weight estimates from the leading words, exact only where their error bound asks) */
     int32_t luf_dense_tail;    /* device refactorisation: rows of the dense tail (8); -1 = none */
     int32_t luf_slack;         /* ... Markowitz score slack of a round (16) */
@@ -207,7 +208,16 @@ typedef struct relp_stats {
     int64_t update_bytes;
 } relp_stats;
 
+/* The defaults, written into a struct of `caller_size` bytes -- sizeof(relp_options) as the CALLER compiled it: not a byte more is
+ * touched, and struct_size is set to that size, so a program built against an older, shorter header keeps working with a newer
+ * library (relp_create / relp_batch_create read struct_size bytes and take the defaults for the rest).  The only supported
+ * initialiser; a size no header of this library ever had is RELP_ERR_ARGUMENT.  Bindings by symbol (ctypes, Rust `extern`)
+ * call this one with their own struct's size. */
+int32_t relp_options_default_sized(relp_options* options, int32_t caller_size);
+/* The exported symbol of rounds 1-5: assumes the LIBRARY's sizeof(relp_options) -- right only for a caller built against the header the
+ * library was built with.  C and C++ callers get the sized call through the macro below without changing a line. */
 int32_t relp_options_default(relp_options* options);
+#define relp_options_default(options) relp_options_default_sized((options), (int32_t)sizeof(relp_options))
 
 /* ---- host-only model: the provider without a device (usable on a machine with no GPU) ------------------------
  * `relp_model` is the `MatrixData` a provider call sequence would see; it needs no HIP device, so the host logic
@@ -384,7 +394,7 @@ int32_t relp_solve_exact(relp_handle* handle, int32_t first_limbs, int32_t max_l
 /* Measurement of the last relp_solve_exact on this handle, one record per width tried (no reference counterpart: the reference's
  * RationalBig has no fixed width).  `update_word_products_*` count the 64 x 64 -> 128-bit multiplications of the integer-preserving
  * update of N = D B^-1 (the dominant step): `needed` by the entries' bit bounds, `issued` by the waves (the integer-multiply roofline
- * of bench.py divides `issued` by `step_seconds[7]`).  step_seconds: x_B, reduced costs (y = c_B' N and every c~_j), arg-max, exact weights, tournament, entering
+ * of bench.py divides `needed` -- the algorithmic figure -- by `step_seconds[7]`; issued / needed is the waste of whole blocks).  step_seconds: x_B, reduced costs (y = c_B' N and every c~_j), arg-max, exact weights, tournament, entering
  * column, ratio test, update of N, bookkeeping, products N a_j and keys of the columns with c~_j < 0.  Returns the number of records through *count (at most `capacity` copied). */
 typedef struct relp_exact_width_record {
     int32_t limbs;
@@ -466,6 +476,15 @@ int32_t relp_debug_exact_finish(int32_t device, int32_t limbs, int32_t count, co
  * least significant word first), mode 0: out = 1 / a modulo 2^(64 limbs) for odd a (wave_inverse_odd: the inverse of D's odd part);
  * 1: out = -(a b) modulo 2^(64 limbs) (wave_mul_lo_negated: the rows' update factors); 2: out = a b.  No reference counterpart. */
 int32_t relp_debug_exact_words(int32_t device, int32_t limbs, int32_t mode, int32_t count, const uint64_t* a, const uint64_t* b, uint64_t* out);
+/* Test hook of the grid barrier that lets ONE cooperative launch run a whole exact solve (grid_barrier.hpp: arrivals counted per XCD,
+ * one release fence per die, a watchdog that ends the launch instead of hanging the device).  mode 0, the exchange test: `rounds`
+ * rounds on `grid` workgroups of 256 threads; in each, every thread stores a fresh value, the grid meets at the barrier, every thread
+ * reads the values of `reads` other workgroups (rotating through all pairs; every round reads from every die) and counts what is not
+ * this round's value.  mode 1: the last workgroup leaves one barrier out -- the watchdog (`limit_ticks` of 10 ns; 0 = ten seconds)
+ * has to end the launch.  out8: [0] stale values seen, [1] the first as round << 32 | reader << 16 | writer (-1: none), [2] dies in use,
+ * [3] ticks of 10 ns for workgroup 0's loop, [4] rounds, [5] workgroups that ran to the end, [6] the abort word (0: nobody gave up; else the
+ * barrier's number), [7] workgroups found waiting then.  No reference counterpart (relp is single-threaded). */
+int32_t relp_debug_grid_barrier(int32_t device, int32_t grid, int32_t rounds, int32_t reads, int32_t mode, int64_t limit_ticks, int64_t* out8);
 
 /* ---- `BasisInverse` as an object of its own (no LP handle needed) ------------------------------------------------------
  * The reference's trait `BasisInverse` (tableau/inverse_maintenance/carry/mod.rs:69-169) and its main implementor

@@ -134,7 +134,7 @@ _lib = None
 
 # every symbol include/relp_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "relp_version", "relp_options_default", "relp_model_from_mps", "relp_model_from_mps_ex", "relp_model_from_general_form", "relp_model_from_provider", "relp_model_original_variables", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
+    "relp_version", "relp_options_default", "relp_options_default_sized", "relp_model_from_mps", "relp_model_from_mps_ex", "relp_model_from_general_form", "relp_model_from_provider", "relp_model_original_variables", "relp_model_max_flow", "relp_model_shortest_path", "relp_model_free", "relp_model_dimensions",
     "relp_model_column", "relp_model_column_exact", "relp_model_cost", "relp_model_right_hand_side",
     "relp_model_initial_pivots", "relp_model_fixed_cost", "relp_create", "relp_destroy", "relp_last_error",
     "relp_load_matrix_data", "relp_load_dense_le", "relp_load_mps", "relp_load_mps_ex", "relp_get_original_solution", "relp_load_model", "relp_get_dimensions", "relp_get_column",
@@ -142,7 +142,7 @@ SYMBOLS = [
     "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_solve_exact", "relp_get_exact_counters", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
     "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_get_last_pivot", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
-    "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps", "relp_debug_set_tuning", "relp_debug_exact_finish", "relp_debug_exact_words",
+    "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps", "relp_debug_set_tuning", "relp_debug_exact_finish", "relp_debug_exact_words", "relp_debug_grid_barrier",
     # BasisInverse as an object of its own (relp_amd/basis_inverse.py)
     "relp_bi_options_default", "relp_bi_identity", "relp_bi_invert", "relp_bi_free", "relp_bi_last_error", "relp_bi_m",
     "relp_bi_left_multiply", "relp_bi_right_multiply", "relp_bi_basis_inverse_row", "relp_bi_generate_element",
@@ -173,7 +173,9 @@ def _ptr(array, ctype):
 
 def default_options(**overrides):
     options = Options()
-    lib().relp_options_default(C.byref(options))
+    status = lib().relp_options_default_sized(C.byref(options), C.sizeof(Options))  # (the caller states the size it was built with)
+    if status != OK:
+        raise RelpError(status, "relp_options_default_sized refused sizeof(Options) = %d: the binding and the library disagree" % C.sizeof(Options))
     for key, value in overrides.items():
         if not hasattr(options, key):
             raise AttributeError(key)

@@ -14,6 +14,7 @@ namespace relp {
 void exact_finish_entries(int device, int limbs, int count, const unsigned long long* T, const int* carry, const int* words, int shift, int flip,
                           unsigned long long* N_out, int* bits_out);
 void exact_words_test(int device, int limbs, int mode, int count, const unsigned long long* a, const unsigned long long* b, unsigned long long* out);
+void grid_barrier_test(int device, int grid, int rounds, int reads, int mode, long long limit_ticks, long long* out8);
 }
 using namespace relp;
 
@@ -58,8 +59,8 @@ extern "C" {
 
 const char* relp_version(void) { return "relp_amd 0.1 gfx950"; }
 
-int32_t relp_options_default(relp_options* o) {
-    if (!o) return RELP_ERR_ARGUMENT;
+// The library's defaults in the library's own struct (every field of every round).
+static void library_defaults(relp_options* o) {
     std::memset(o, 0, sizeof(*o));
     o->device = 0;
     o->pivot_rule = RELP_PIVOT_STEEPEST_EDGE;  // two_phase/mod.rs:57,68,107
@@ -85,8 +86,23 @@ int32_t relp_options_default(relp_options* o) {
     o->ftran_min_nnz = 0;
     o->lu_refactor = RELP_REFACTOR_AUTO;
     o->struct_size = (int32_t)sizeof(relp_options);  // (the switches and sizes appended in round 5 stay 0: the library's choices)
+}
+
+// Round 6 (advisor, medium): the CALLER states the size of the struct it compiled.  Only that many bytes are written -- a caller built
+// against an older, shorter header gets no byte past the end of its struct -- and struct_size is the caller's size, which relp_create /
+// relp_batch_create then read.  The sizes a header has ever had are the only ones accepted (a field is never copied in half).
+int32_t relp_options_default_sized(relp_options* o, int32_t caller_size) {
+    if (!o || !known_options_size(caller_size)) return RELP_ERR_ARGUMENT;
+    relp_options full;
+    library_defaults(&full);
+    full.struct_size = caller_size;
+    std::memcpy(o, &full, (size_t)caller_size);
     return RELP_OK;
 }
+// The exported symbol of rounds 1-5 for callers that bind by name (ctypes, a Rust `extern` block) and are built against THIS header: it
+// assumes the library's size.  C callers never reach it: the header maps the name to relp_options_default_sized(o, sizeof(relp_options)).
+#undef relp_options_default
+int32_t relp_options_default(relp_options* o) { return relp_options_default_sized(o, (int32_t)sizeof(relp_options)); }
 
 
 // ---- host-only model ------------------------------------------------------------------------------------
@@ -988,6 +1004,18 @@ int32_t relp_debug_exact_words(int32_t device, int32_t limbs, int32_t mode, int3
     try {
         relp::exact_words_test(device, limbs, mode, count, (const unsigned long long*)a, (const unsigned long long*)b, (unsigned long long*)out);
         return RELP_OK;
+    } catch (const std::exception&) {
+        return RELP_ERR_DEVICE;
+    }
+}
+
+int32_t relp_debug_grid_barrier(int32_t device, int32_t grid, int32_t rounds, int32_t reads, int32_t mode, int64_t limit_ticks, int64_t* out8) {
+    if (!out8 || grid < 1 || rounds < 1 || reads < 0 || mode < 0 || mode > 1 || limit_ticks < 0) return RELP_ERR_ARGUMENT;
+    try {
+        relp::grid_barrier_test(device, grid, rounds, reads, mode, (long long)limit_ticks, (long long*)out8);
+        return RELP_OK;
+    } catch (const std::invalid_argument&) {
+        return RELP_ERR_ARGUMENT;
     } catch (const std::exception&) {
         return RELP_ERR_DEVICE;
     }

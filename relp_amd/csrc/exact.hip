@@ -33,6 +33,7 @@
 #include "solver.hpp"
 #include <hip/hip_cooperative_groups.h>
 
+#include "grid_barrier.hpp"
 #include "wave_ops.hpp"
 
 namespace relp {
@@ -786,84 +787,10 @@ __device__ __forceinline__ int wave_sign_of_difference(const u64* a, int la, con
     return borrow ? -1 : (nonzero ? 1 : 0);
 }
 
-// The grid barrier of the cooperative launch.  cooperative_groups' grid.sync() costs 0.1 us per workgroup on gfx950 -- every arrival
-// is an atomic on one word: 26 us at 256 workgroups, 53 at 512 (tools/micro/grid_barrier_bench.hip, profiles/r5_micro_grid_barrier.txt)
-// -- and a pivot makes about sixteen of them.  First two levels (grid_barrier_two_level: groups of 32 workgroups on a word of their
-// own, the last arrival of a group on the top word, the last arrival there publishes the generation everybody polls: 6.6 us at 256
-// workgroups, 11.5 at 512), now the levels of the chip (grid_barrier): what makes a barrier expensive is not the counting -- 2 us
-// without fences -- but 512 release fences, each the write-back of a die's L2.  The workgroups of one XCD (HW_REG_XCC_ID: nothing is
-// assumed about the placement) count on a word of their die; their stores are in THAT die's L2 when they arrive (every wave waits for
-// its stores in front of the workgroup barrier), so ONE release by the die's last arrival serves them all: 8 write-backs a barrier.
-// That workgroup counts on the top word, waits for the generation and passes it on to its die's generation word, which the others
-// poll; every workgroup invalidates its own CU's L1 (the acquire).  6.5 us at 512 workgroups, 4.6 at 256, no stale value in the
-// exchange test.  Counters only grow (no reset to race with); every workgroup must call it the same number of times (`epoch`).
-// (The explicit waits: the compiler may drop the wait behind a release fence that follows a returned atomic, and the invalidate of an
-//  acquire completes asynchronously -- MI355X guide, inter-workgroup visibility.)
+// The grid barrier of the cooperative launch: grid_barrier.hpp (per-die counting, one release fence per XCD, a watchdog that ends the
+// launch instead of hanging the device when the workgroups' barrier counts ever differ).
 constexpr int EX_GAMMA_BATCH = 64;  // tied candidates whose exact weights are formed at a time (gamma_terms)
 constexpr int EX_PRODUCT_SLOTS = EX_GAMMA_BATCH;  // columns whose exact products N a_j price_a holds at a time
-constexpr int EX_BARRIER_GROUP = 32;
-constexpr int EX_BARRIER_DIE_WORDS = 2048;  // the words of the per-die barrier: [+0] generation, [+16] top, [+32 + 16 x] arrivals of die x,
-                                            // [+32 + 16 (8 + x)] its generation, [+32 + 16 (16 + x)] the workgroups on it
-constexpr int EX_BARRIER_WORDS = EX_BARRIER_DIE_WORDS + 32 + 16 * 24;  // [0] generation, [16] top, [32 + 16 g] group g of the two-level barrier (the launch's first)
-struct BarrierPlace {  // where this workgroup stands: its die, the workgroups on it, the dies in use
-    unsigned die = 0, members = 0, dies = 0;
-};
-__device__ __forceinline__ void grid_barrier_two_level(unsigned* words, unsigned& epoch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned g = blockIdx.x / EX_BARRIER_GROUP, groups = (gridDim.x + EX_BARRIER_GROUP - 1) / EX_BARRIER_GROUP;
-        const unsigned members = min((unsigned)EX_BARRIER_GROUP, gridDim.x - g * EX_BARRIER_GROUP);
-        const unsigned arrived = __hip_atomic_fetch_add(words + 32 + 16 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == (epoch + 1) * members - 1) {  // the last of its group
-            const unsigned at_top = __hip_atomic_fetch_add(words + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (at_top == (epoch + 1) * groups - 1) __hip_atomic_store(words, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        while (__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    ++epoch;
-    __syncthreads();
-}
-// (once per launch: who shares a die, counted behind a barrier of the other kind)
-__device__ __forceinline__ BarrierPlace grid_barrier_place(unsigned* words) {
-    BarrierPlace place;
-    place.die = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID
-    unsigned* die_words = words + EX_BARRIER_DIE_WORDS;
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(die_words + 32 + 16 * (16 + place.die), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned first = 0;
-    grid_barrier_two_level(words, first);
-    place.members = __hip_atomic_load(die_words + 32 + 16 * (16 + place.die), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (unsigned x = 0; x < 8; ++x)
-        place.dies += __hip_atomic_load(die_words + 32 + 16 * (16 + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u;
-    return place;
-}
-__device__ __forceinline__ void grid_barrier(unsigned* words, unsigned& epoch, const BarrierPlace place) {
-    unsigned* die_words = words + EX_BARRIER_DIE_WORDS;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave: its stores are in the die's L2)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned* generation_of_die = die_words + 32 + 16 * (8 + place.die);
-        const unsigned arrived = __hip_atomic_fetch_add(die_words + 32 + 16 * place.die, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == (epoch + 1) * place.members - 1) {  // the last of its die
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned at_top = __hip_atomic_fetch_add(die_words + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (at_top == (epoch + 1) * place.dies - 1) __hip_atomic_store(die_words, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(die_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1) __builtin_amdgcn_s_sleep(1);
-            __hip_atomic_store(generation_of_die, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            while (__hip_atomic_load(generation_of_die, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1) __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    ++epoch;
-    __syncthreads();
-}
 
 // ---------------------------------------------------------------------------------------------------
 // the LP on the device: integer columns (rows scaled), [artificials | provider columns] as in solver.hip
@@ -893,7 +820,7 @@ struct ExactLP {
     const int* resume;    // [8]: [0] != 0: continue a run that overflowed at a narrower width (N, D, basis, pos, removed are its state
                           //      before the pivot that did not fit); [1..6] = phase, pivots one, pivots two, trace count, drive row, removed
     int* removed;         // [m] 1: the row is redundant -- its artificial cannot be pivoted out (`RemoveRows` of the reference); [m + i]: such rows above row i
-    int* shared_words;    // [16] grid-wide overflow flag, decisions of workgroup 0's thread 0
+    int* shared_words;    // [16] grid-wide overflow flags, decisions of workgroup 0's thread 0, counters of the candidate lists
     double* part_key;     // [2][grid] per-workgroup partials of the grid arg-max reductions
     unsigned long long* part_rank;
     unsigned long long* prof;  // [EX_PROF_WORDS] the leader's time per step of the loop in ticks of the 100 MHz wall clock [0..9], candidate counts [12],
@@ -2640,7 +2567,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     auto N_at = [&](int i, int c) { return lp.N + (size_t)c * m + i; };   // word 0 of N(row i, column c)
     const int LIMIT_BITS = 64 * L - 3;  // a value whose magnitude bound reaches this many bits might not fit
     u64* gD = lp.D;
-    int* word = lp.shared_words;  // [0] overflow flag of the grid, [1..] what the leader decides
+    int* word = lp.shared_words;  // [10], [11] overflow flags of the grid (sync_overflow), [1..9] what the leader decides and the counters of the lists
     int phase = lp.n_art > 0 ? 1 : 2;
     long long pivots[2] = {0, 0};
     int trace_count = 0;
@@ -2664,7 +2591,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     };
     unsigned long long products_needed = 0, products_issued = 0;  // this thread's word products in the update of N, whole run
     bool on_matrix_cores = false;  // the update of N by mfma_update_tile
-    if constexpr (L >= 32) on_matrix_cores = lp.mfma_update != 0;
+    if constexpr (L >= 16) on_matrix_cores = lp.mfma_update != 0;
     int parity = 0;  // the partial arrays of the grid reductions alternate, so that a fast workgroup never overwrites what a slow one still reads
     if (tid == 0) s_overflow = 0;
     __syncthreads();
@@ -2673,11 +2600,18 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
     };
     auto log2_ceil = [](int count) { return 32 - __clz(count > 1 ? count - 1 : 1) + 1; };
     // grid barrier that also tells every workgroup whether any of them saw a value that might not fit
+    // (Two flags, taken in turn: with one, a workgroup that left call k early and raised the flag on its way to call k + 1 -- the zero-level
+    //  pivots make two calls with no other barrier between them -- could be seen by a slow workgroup still reading the flag of call k; that one
+    //  stopped a barrier earlier than the rest and the launch hung.  A raised flag ends the run at the call it was raised for, in every
+    //  workgroup, so nothing is ever cleared.)
+    int overflow_calls = 0;
     auto sync_overflow = [&]() {
+        int* flag = word + 10 + (overflow_calls & 1);
+        ++overflow_calls;
         __syncthreads();
-        if (tid == 0 && s_overflow) atomicOr(&word[0], 1);
+        if (tid == 0 && s_overflow) atomicOr(flag, 1);
         grid.sync();
-        return word[0] != 0;
+        return *(volatile int*)flag != 0;
     };
     // arg-max of (key, smallest rank) over the grid: the winner in every thread of every workgroup
     auto grid_argbest = [&](double& key, unsigned long long& rank) {
@@ -2899,7 +2833,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             // ... and their keys: the weight estimate is the sum of the stored terms, key = (c~_j / D)^2
             // / that; a column whose terms may be off by more than 1e-11 of the sum in all goes on the list of those to be formed exactly
             const double error_allowed = lp.price_exactly ? -1.0 : 1e-11;
-            auto form_keys = [&](const int* list, int count) {
+            auto form_keys = [&](const int* list, int count, bool list_inexact) {
                 for (int c = gtid / WAVE; c < count; c += GT / WAVE) {
                     const int j = list[c];
                     const size_t base = (size_t)(j - lp.n_art) * m;
@@ -2918,11 +2852,11 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                     const double cd = lp.cd[j];
                     if (lane == 0) {
                         lp.key[j] = cd * cd / sumsq;
-                        if (!(errors <= error_allowed * sumsq)) lp.bracket[atomicAdd(&word[9], 1)] = j;
+                        if (list_inexact && !(errors <= error_allowed * sumsq)) lp.bracket[atomicAdd(&word[9], 1)] = j;
                     }
                 }
             };
-            form_keys(lp.neg_list, n_negative);
+            form_keys(lp.neg_list, n_negative, true);
             if (leader) {  // (diagnostic: how many of the priced columns have a negative reduced cost)
                 lp.prof[30] += n_negative;
                 lp.prof[31] += 1;
@@ -2932,11 +2866,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             if (n_inexact > 0) {  // the columns whose estimate is not good enough: their products exactly, their keys from those
                 price_products<L>(lp, lp.bracket, n_inexact, mD, eD, LIMIT_BITS, &s_overflow);
                 grid.sync();
-                if (leader) {
-                    lp.prof[13] += n_inexact;
-                    word[9] = 0;
-                }
-                form_keys(lp.bracket, n_inexact);  // (exact terms carry no error: nothing is listed again -- the test hook lists them all again, to no effect)
+                if (leader) lp.prof[13] += n_inexact;
+                form_keys(lp.bracket, n_inexact, false);  // (exact terms carry no error; the list is this call's input: nothing is listed again, its counter is reset by the pivot's bookkeeping)
                 if (sync_overflow()) { status = EX_OVERFLOW; break; }
             }
             stamp(9);
@@ -3109,33 +3040,15 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         const bool y_rides = on_matrix_cores && p < 0 && y_phase == phase;
 #endif
         // ---- alpha~_q = N a_q (tableau/mod.rs:126-130) -----------------------------------------------------------------------
-        if constexpr (L >= 16) {  // the wide types: streamed like the pricing pass, a wave per 64 rows (a thread per row with its integers in scratch: 1.2 ms a pivot at 128 limbs)
-            const int e0 = lp.col_start[q], e1 = lp.col_start[q + 1];
-            const int lane_a = tid & (WAVE - 1);
-            // (rounds 4-5 copied a priced column's products out of price_a; the pricing pass now forms estimates only)
-            if constexpr (L >= 2 * ENTER_CHUNK) {
-                {  // (price_a holds the chunks: (L / 16) 19 m words)
-                    mark();
-                    entering_column_chunks<L>(lp, q);
-                    grid.sync();
-                    lap(10);
-                    entering_column_rows<L>(lp, q, s_dinv, LIMIT_BITS, &s_overflow, y_rides, word + 8);  // ... added up, and the rows' factors -alpha~_i u
-                    lap(11);
-                }
-            }
-            if (L < 2 * ENTER_CHUNK)
-            for (int block_a = gtid / WAVE; block_a * WAVE < m; block_a += GT / WAVE) {
-                const int i = block_a * WAVE + lane_a;
-                const bool active = i < m;
-                LeadingWords lead;
-                const int awide = stream_column_products<L>(lp, e0, e1, i, active, lane_a, MM, lp.alpha + (size_t)(active ? i : 0) * L, 1, lead);
-                if (active) {
-                    flag_overflow(awide);
-                    const bool negative = (i64)lead.prev < 0;  // bit length of |alpha~_i| from its leading word
-                    const int top = negative ? lead.top_n : lead.top_p;
-                    lp.x_bits[i] = top < 0 ? 0 : 64 * top + (64 - __clzll((long long)(negative ? lead.n_top : lead.p_top)));  // (the fit test of the update below wants it once per ENTRY of N)
-                }
-            }
+        if constexpr (L >= 16) {  // the wide types: streamed like the pricing pass in chunks of words (a thread per row with its integers in scratch: 1.2 ms a pivot at 128 limbs)
+            // (rounds 4-5 copied a priced column's products out of price_a; the pricing pass now forms estimates only.  price_a holds the
+            //  chunks: (L / 16) 19 m words -- one chunk at 16 limbs, which took a path of its own until round 6)
+            mark();
+            entering_column_chunks<L>(lp, q);
+            grid.sync();
+            lap(10);
+            entering_column_rows<L>(lp, q, s_dinv, LIMIT_BITS, &s_overflow, y_rides, word + 8);  // ... added up, and the rows' factors -alpha~_i u
+            lap(11);
         } else {
             for (int i = gtid; i < m; i += GT) {
                 Big<L> a = big_from<L>(0);
@@ -3149,14 +3062,6 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                 big_store(lp.alpha + (size_t)i * L, a);
                 lp.x_bits[i] = big_bits(a);  // (the fit test of the update below wants it once per ENTRY of N)
                 if constexpr (L < 16) big_store_s(lp.x_part + i, (size_t)m, big_negate(big_mul_lo(a, Dinv)));  // -alpha~_i / D_odd: the row's factor of the update below
-            }
-        }
-        if constexpr (L >= 16) {  // ... by a wave per row for the wide types (wave_mul_lo_store; from 32 limbs on entering_column_rows has formed them)
-            if (L < 2 * ENTER_CHUNK) {
-                grid.sync();
-                lap(18);  // (the barrier after the entering column)
-                for (int row = gtid / WAVE; row < m; row += GT / WAVE) wave_mul_lo_store<L>(lp.alpha + (size_t)row * L, s_dinv, lp.x_part + row, (size_t)m, tid & (WAVE - 1));
-                lap(19);
             }
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
@@ -3297,7 +3202,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         // new entry is that value shifted right by s -- known modulo 2^(64 L - s), sign-extended from there, and it must fit there.
         // TWO truncated products per entry (the numerator first and then its product with u were three); alpha~_p u once per
         // workgroup, alpha~_i u once per row (the alpha step).
-        if constexpr (L >= 2 * ENTER_CHUNK) {
+        if constexpr (L >= ENTER_CHUNK) {
             // (alpha~_p u is the negative of row p's factor, which entering_column_rows has just stored: a thread per word takes the two's
             //  complement -- zero up to the lowest non-zero word, that word's complement plus one, the complements above -- instead of
             //  one more truncated product by every workgroup, 8 us of every pivot at 128 limbs)
@@ -3388,7 +3293,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         const int n_heavy = word[7], n_rows_alpha = word[6];
-        if constexpr (L >= 32) if (on_matrix_cores) {
+        if constexpr (L >= 16) if (on_matrix_cores) {
             const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha, y_rides ? 1 : 0, cq_bits};
             update_on_matrix_cores<L>(lp, scalars, s_c1, s_words[0], products_needed, products_issued, barrier_epoch, barrier_place);
             dinv_ready = G > 1;  // (the last workgroup left 1 / D'_odd in lp.next_dinv)
@@ -3766,7 +3671,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
         // the update of N on the matrix cores (mfma_update_tile): from 32 limbs on (update_mode 1: never).  (At 16 limbs -- two
         // 64-byte blocks per integer -- the path was tried and hung on ISRAEL, unexplained; it is not compiled for that width.)
-        const bool mfma_update = limbs >= 32 && (update_mode & 1) == 0;
+        const bool mfma_update = limbs >= 16 && (update_mode & 1) == 0;
         u64* d_T = mfma_update ? dalloc<u64>((size_t)m * m * big, fresh) : nullptr;
         int* d_T_carry = mfma_update ? dalloc<int>((size_t)m * m * (big / 2), fresh) : nullptr;
         int* d_T_words = mfma_update ? dalloc<int>((size_t)m * m, fresh) : nullptr;
@@ -3859,6 +3764,24 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         int out[16];
         RELP_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream));
         RELP_HIP(hipStreamSynchronize(stream));
+        {   // the barrier's watchdog (grid_barrier.hpp): a launch whose workgroups made different numbers of barriers ends itself
+            std::vector<unsigned> tail(EX_BARRIER_WORDS - EX_BARRIER_ABORT);
+            RELP_HIP(hipMemcpy(tail.data(), d_barrier + EX_BARRIER_ABORT, tail.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+            if (tail[0] != 0) {
+                unsigned lowest = ~0u, highest = 0;
+                int waiting = 0;
+                for (int g = 0; g < grid; ++g) {
+                    const unsigned at = tail[EX_BARRIER_STUCK - EX_BARRIER_ABORT + g];
+                    if (at == 0) continue;
+                    ++waiting;
+                    lowest = std::min(lowest, at);
+                    highest = std::max(highest, at);
+                }
+                throw std::runtime_error("exact simplex at " + std::to_string(limbs) + " limbs: the grid barrier's watchdog ended the launch (barrier " + std::to_string(tail[0]) + ", " +
+                                         std::to_string(waiting) + " of " + std::to_string(grid) + " workgroups found waiting, at barriers " + std::to_string(lowest) + " to " +
+                                         std::to_string(highest) + "): the workgroups' barrier counts differ");
+            }
+        }
         {
             unsigned long long prof[EX_PROF_WORDS];
             RELP_HIP(hipMemcpy(prof, d_prof, sizeof(prof), hipMemcpyDeviceToHost));

@@ -1531,8 +1531,15 @@ void Solver::certify(relp_result* result) {
 
 // ---- LU carry ---------------------------------------------------------------------------------------
 // `BasisInverse::identity` (lower_upper/mod.rs:67-76) for the start of phase one.
-void Solver::lu_identity() {
+// A factorisation on its way on the second stream is given up (its basis is superseded): the handle's stream waits for it before the
+// snapshot buffers and the other set of factor arrays are written again -- the next start_async_refactor would otherwise copy a new
+// basis into d_basis_snapshot_ while the abandoned kernels still read the old one (advisor, round 5).
+void Solver::abandon_async_flight() {
+    if (async_in_flight_) RELP_HIP(hipStreamWaitEvent(stream_, ev_refactored_, 0));
     async_in_flight_ = false;
+}
+void Solver::lu_identity() {
+    abandon_async_flight();
     const int m = d_.m;
     HostLU f;
     f.m = m;
@@ -1550,7 +1557,7 @@ void Solver::lu_identity() {
 // carry/mod.rs:584-591): Markowitz factorisation of the current basis on the host, one upload, and -- `refresh_vectors` -- x_B,
 // -pi and the objective recomputed from the fresh factors (what the explicit carry's polish does too).
 void Solver::refactor_lu(bool refresh_vectors, bool settle) {
-    async_in_flight_ = false;  // (factors on their way on the other stream belong to a basis this call supersedes: never swapped in)
+    abandon_async_flight();  // (factors on their way on the other stream belong to a basis this call supersedes: never swapped in)
     if (!device_refactor_) {
         refactor_lu_host(refresh_vectors);
         return;
@@ -1668,7 +1675,7 @@ bool Solver::finish_async_refactor(long long iters_now) {
     return true;
 }
 void Solver::refactor_lu_host(bool refresh_vectors) {
-    async_in_flight_ = false;
+    abandon_async_flight();
     const double t0 = now_seconds();
     const int m = d_.m;
     std::vector<int> basis(m);

@@ -216,15 +216,25 @@ inline Tuning tuning_of(const relp_options& o) {
     t.luf_arena_cap = o.luf_arena_cap;
     return t;
 }
-// The caller's options into the library's struct: as many bytes as the caller's header had (relp_options.struct_size), the
-// defaults for the rest.  RELP_ERR_ARGUMENT when the struct was not initialised by relp_options_default or comes from a newer header.
-inline int32_t adopt_options(const relp_options* options, relp_options* out) {
-    relp_options_default(out);
-    if (!options) return RELP_OK;
+// The sizes relp_options has had: round 4 (through lu_refactor), round 5 / 6 (through carry_weights_min).  A struct of any other size
+// was not written by a header of this library.
+inline bool known_options_size(int32_t size) {
     const int32_t round4_size = (int32_t)(offsetof(relp_options, lu_refactor) + sizeof(int32_t));
-    if (options->struct_size < round4_size || options->struct_size > (int32_t)sizeof(relp_options)) return RELP_ERR_ARGUMENT;
+    const int32_t round5_size = (int32_t)(offsetof(relp_options, carry_weights_min) + sizeof(double));
+    static_assert(offsetof(relp_options, carry_weights_min) + sizeof(double) == sizeof(relp_options), "a field was appended: give its round a size here");
+    return size == round4_size || size == round5_size;
+}
+// The caller's options into the library's struct: as many bytes as the caller's header had (relp_options.struct_size, one of the known
+// sizes), the defaults for the rest.  RELP_ERR_ARGUMENT when the struct was not initialised by relp_options_default(_sized) or comes
+// from a newer header.  The tuning fields are clamped to what their comments promise.
+inline int32_t adopt_options(const relp_options* options, relp_options* out) {
+    relp_options_default_sized(out, (int32_t)sizeof(relp_options));
+    if (!options) return RELP_OK;
+    if (!known_options_size(options->struct_size)) return RELP_ERR_ARGUMENT;
     std::memcpy(out, options, (size_t)options->struct_size);
     out->struct_size = (int32_t)sizeof(relp_options);
+    out->ftran_slices = std::max(0, std::min(64, out->ftran_slices));
+    out->price_lds_max = std::max(0, std::min(160 * 1024, out->price_lds_max));  // (a CU of gfx950 has 160 KB of LDS)
     return RELP_OK;
 }
 struct TuningScope {  // the thread's tuning for the lifetime of the object
@@ -345,6 +355,7 @@ private:
     unsigned char* d_flipped_snapshot_ = nullptr;
     long long async_refactors_ = 0, async_abandoned_ = 0;
     void start_async_refactor(long long iters_now);
+    void abandon_async_flight();
     bool finish_async_refactor(long long iters_now);  // true: the handle now runs on the new factors
     bool lu_mode_ = false;
     bool lu_inverse_ = false;  // ... in its inverse-factor form (lu.hpp: L^-1, U^-1 and product-form updates)

@@ -125,3 +125,32 @@ def test_options_struct_size_is_checked_and_an_explicit_option_beats_the_environ
     sources = os.path.join(ROOT, "relp_amd", "csrc")
     calls = sum(open(os.path.join(sources, name)).read().count("getenv(") for name in os.listdir(sources) if name.endswith((".hip", ".cpp", ".hpp")))
     assert calls <= 2, calls  # model.hpp's `diagnostic` (stderr timelines only)
+
+
+def test_a_caller_built_against_an_older_header_gets_no_byte_past_its_struct():
+    """Advisor, round 5 (medium): relp_options_default used to memset the LIBRARY's sizeof(relp_options) into the caller's struct and to
+    store the library's size.  Now the caller states its size (the header's macro does it for C callers): only that many bytes are
+    written, struct_size is the caller's, relp_create reads that many, and a size no header ever had is refused."""
+    from relp_amd import api
+    lib = api.lib()
+    full = C.sizeof(api.Options)
+    round4 = api.Options.lu_refactor.offset + 4            # the struct as round 4's header had it
+    buffer = (C.c_ubyte * (full + 64))(*([0xAB] * (full + 64)))
+    options = C.cast(buffer, C.POINTER(api.Options))
+    assert lib.relp_options_default_sized(options, round4) == api.OK
+    assert options.contents.struct_size == round4 and options.contents.polish_period == 256 and options.contents.tol_dual == 1e-9
+    assert all(b == 0xAB for b in bytes(buffer)[round4:]), "bytes past the caller's struct were written"
+    # ... the full struct
+    for k in range(len(buffer)):
+        buffer[k] = 0xCD
+    assert lib.relp_options_default_sized(options, full) == api.OK
+    assert options.contents.struct_size == full and all(b == 0xCD for b in bytes(buffer)[full:])
+    # sizes no header ever had: between the rounds (a field would be copied in half), zero, larger than the library's
+    for size in (round4 + 4, round4 - 4, full - 4, 0, -8, full + 8):
+        assert lib.relp_options_default_sized(options, size) == api.ERR_ARGUMENT, size
+        stale = api.default_options()
+        stale.struct_size = size
+        handle = C.c_void_p()
+        assert lib.relp_create(C.byref(stale), C.byref(handle)) == api.ERR_ARGUMENT, size
+    assert lib.relp_options_default_sized(None, full) == api.ERR_ARGUMENT
+    # the tuning fields are clamped to what the header promises (64 slices, a CU's 160 KB of LDS): checked where a handle can be made
