@@ -67,8 +67,14 @@ typedef enum relp_carry {
 typedef enum relp_ratio_rule {
     RELP_RATIO_HARRIS = 0,     /* two-pass Harris test with slack `harris_delta`, largest pivot among the near-ties (what f64
                                   needs on real data), ties to the lowest leaving column */
-    RELP_RATIO_TEXTBOOK = 1    /* the reference's rule: the exact minimum ratio, ties to the lowest leaving column (Bland).  For
-                                  data on which f64 is exact (small integers); rows <= 8192 */
+    RELP_RATIO_TEXTBOOK = 1,   /* the reference's rule: the exact minimum ratio, ties to the lowest leaving column (Bland).  For
+                                  data on which f64 is exact (small integers); rows <= 8192 (RELP_ERR_ARGUMENT at load beyond:
+                                  the multi-workgroup ratio test implements the two-pass rule only) */
+    RELP_RATIO_AUTO = 2        /* the default since round 6 ("defaults reproduce the reference"): the
+                                  reference's rule where the data are small integers -- every matrix entry an integer of at most
+                                  64 in magnitude, every cost and right-hand side an integer below 2^20 -- and the LP has at most
+                                  8192 rows; the two-pass Harris test otherwise (decimal data: Netlib).  The per-LP record
+                                  (relp_get_record_json) says which one ran */
 } relp_ratio_rule;
 
 /* Storage type of a dense column block (`relp_options.dense_storage`). */

@@ -18,7 +18,7 @@ FINITE_OPTIMUM, INFEASIBLE, UNBOUNDED, ITERATION_LIMIT = 1, 2, 3, 4
 STEEPEST_EDGE, DANTZIG, FIRST_PROFITABLE, FIRST_PROFITABLE_MEMORY = 0, 1, 2, 3
 STOP_NO_ENTERING, STOP_UNBOUNDED, STOP_BUDGET = 1, 2, 3
 CARRY_EXPLICIT, CARRY_LU, CARRY_LU_INVERSE = 0, 1, 2
-RATIO_HARRIS, RATIO_TEXTBOOK = 0, 1
+RATIO_HARRIS, RATIO_TEXTBOOK, RATIO_AUTO = 0, 1, 2
 
 
 class RelpError(RuntimeError):

@@ -78,7 +78,7 @@ static void library_defaults(relp_options* o) {
     o->carry = RELP_CARRY_EXPLICIT;
     o->refactor_period = 0;
     o->lu_pivot_threshold = 0.0;
-    o->ratio_rule = RELP_RATIO_HARRIS;
+    o->ratio_rule = RELP_RATIO_AUTO;   // (round 6: the reference's ratio test where the data are small integers, else Harris)
     o->crash = 0;
     o->dense_storage = RELP_DENSE_NARROWEST;
     o->pivot_kernels = 0;
@@ -786,7 +786,7 @@ int32_t relp_get_record_json(const relp_handle* h, char* buffer, int32_t capacit
         << ", \"device_rows\": " << d.m << ", \"artificials\": " << d.n_art << ", \"result\": \"" << kinds[r.kind >= 0 && r.kind <= 4 ? r.kind : 0]
         << "\", \"carry\": \"" << (h->options.carry == RELP_CARRY_LU ? "lu" : h->options.carry == RELP_CARRY_LU_INVERSE ? "lu_inverse" : "explicit") << "\", \"pivots_phase_one\": " << r.pivots_phase_one
         << ", \"pivots_phase_two\": " << r.pivots_phase_two << ", \"polishes\": " << r.polishes << ", \"refactors\": " << r.refactors
-        << ", \"refactor_seconds\": " << r.refactor_seconds << ", \"lu_refactor\": \"" << (sv.refactors_asynchronously() ? "device, beside the pivots" : sv.refactors_on_device() ? "device" : "host")
+        << ", \"refactor_seconds\": " << r.refactor_seconds << ", \"ratio_rule\": \"" << (sv.ratio_textbook() ? "textbook" : "harris") << "\"" << ", \"lu_refactor\": \"" << (sv.refactors_asynchronously() ? "device, beside the pivots" : sv.refactors_on_device() ? "device" : "host")
         << "\", \"device_refactor_fallbacks\": " << sv.device_refactor_fallbacks()
         << ", \"async_refactors\": " << sv.async_refactors() << ", \"async_refactors_abandoned\": " << sv.async_refactors_abandoned() << ", \"async_worst_residual\": " << sv.async_worst_residual()
         << ", \"solve_seconds\": " << r.solve_seconds << ", \"certify_seconds\": " << r.certify_seconds

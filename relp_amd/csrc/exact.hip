@@ -3629,6 +3629,13 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     int* d_row_list = dalloc<int>((size_t)2 * m, owned);
     int* d_col_heavy = dalloc<int>((size_t)m + 1, owned);
     int* d_col_light = dalloc<int>((size_t)m + 1, owned);
+#ifdef RELP_REPRO_R5_LIST_RACE
+    // (diagnostic build, tools/repro_16_limb_hang.sh: the column classes of the update in the tournaments' arrays again, as they were when the
+    //  16-limb matrix-core run hung on ISRAEL in round 5 -- the splitter workgroup overwrites bracket[0] / cand[..] while a workgroup late
+    //  out of the ratio test's last barrier still reads the winner through them)
+    d_col_heavy = d_bracket;
+    d_col_light = d_cand;
+#endif
     RELP_HIP(hipMemcpyAsync(d_col_start, col_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_row_index, row_index.data(), row_index.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));

@@ -508,6 +508,20 @@ void Solver::upload() {
         d_.k2_partd = dmalloc<double>((size_t)8 * ((m + 1023) / 1024));
         d_.k2_parti = dmalloc<int>((size_t)4 * ((m + 1023) / 1024));
     }
+    // `Tableau::select_primal_pivot_row` (tableau/mod.rs:287-313): which ratio test runs.  The reference's rule is implemented by the
+    // register-resident ratio test (m <= 8192), the fused pivot kernel and the LU pivot kernel; the multi-workgroup test beyond 8192 rows
+    // and the one-workgroup fallback implement the two-pass rule only.  AUTO (the default): the reference's rule where the data are
+    // small integers, Harris on decimal data.
+    {
+        const bool kernels_have_it = lu_mode_ || fast_k2_available(d_, price_blocks_ + dense_blocks_);
+        bool small_integers = true;
+        for (size_t e = 0; e < nnz && small_integers; ++e) small_integers = value[e] == std::nearbyint(value[e]) && std::fabs(value[e]) <= 64.0;
+        for (int j = 0; j < n && small_integers; ++j) small_integers = cost2[j] == std::nearbyint(cost2[j]) && std::fabs(cost2[j]) < 1048576.0;
+        for (int i = 0; i < m && small_integers; ++i) small_integers = rhs[i] == std::nearbyint(rhs[i]) && std::fabs(rhs[i]) < 1048576.0;
+        if (opt_.ratio_rule == RELP_RATIO_TEXTBOOK && !kernels_have_it)
+            throw std::invalid_argument("RELP_RATIO_TEXTBOOK: the reference's ratio test is implemented up to 8192 rows (the multi-workgroup ratio test has the two-pass rule only)");
+        ratio_textbook_ = opt_.ratio_rule == RELP_RATIO_TEXTBOOK || (opt_.ratio_rule == RELP_RATIO_AUTO && small_integers && kernels_have_it);
+    }
     // small LPs: ratio test and inverse update in one launch (pivot_fused_kernel; RELP_NO_FUSED=1 keeps the three-kernel pivot)
     fused_ = !lu_mode_ && !bounded_ && !eta_mode_ && n_dense == 0 && ftran_slices_ == 0 && !d_.track_touched && d_.ell_w == ELL_W &&
              fused_pivot_available(d_, price_blocks_) && opt_.pivot_kernels != 1;

@@ -261,6 +261,7 @@ public:
 
     void load(StandardForm&& form);
     bool loaded() const { return loaded_; }
+    bool ratio_textbook() const { return ratio_textbook_; }
 
     void solve(relp_result* result);
     void begin_phase_one();
@@ -362,7 +363,8 @@ private:
     bool lu_is_identity_ = true;
     int refactor_period_ = 64;
     // (a negative slack selects the reference's ratio test in the kernels that implement it: the fused kernel for m <= 8192 and the LU kernel)
-    double ratio_delta() const { return opt_.ratio_rule == RELP_RATIO_TEXTBOOK ? -1.0 : opt_.harris_delta; }
+    double ratio_delta() const { return ratio_textbook_ ? -1.0 : opt_.harris_delta; }
+    bool ratio_textbook_ = false;  // the reference's ratio test runs (relp_options.ratio_rule resolved against the data and the kernels at upload)
     int unbounded_column_ = -1;  // provider column of the ray when the result is UNBOUNDED
     long long refactors_ = 0;
     double refactor_seconds_ = 0.0;

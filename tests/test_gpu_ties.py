@@ -182,3 +182,77 @@ def test_every_row_of_the_resident_inverse(name, checkpoints, carry):
                 scale = max(1.0, np.abs(want).max())
                 assert np.allclose(got, want, rtol=1e-9, atol=1e-10 * scale), (step, r)
     solver.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 6 (review item 10): the DEFAULT options reproduce the reference where f64 is exact, and how far the f64 loop follows the
+# reference's exact pivot sequence elsewhere is measured, not guessed
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_default_options_take_the_reference_ratio_test_on_small_integer_data(seed):
+    """`relp_options_default` leaves ratio_rule = RELP_RATIO_AUTO: on small-integer data (here the tied transportation LPs above) the
+    reference's rule (tableau/mod.rs:287-313) runs -- the per-LP record says so -- and the phase-one sequence is the oracle's."""
+    rng = random.Random(77 + seed)
+    sources, sinks = rng.randint(3, 6), rng.randint(3, 7)
+    columns, b, cost = transportation(rng, sources, sinks, False)
+    m = sources + sinks
+    data = MatrixData(columns, b, [], m, 0, 0, 0, [Variable(c) for c in cost])
+    column_start, rows, nums = [0], [], []
+    for column in columns:
+        for i, v in column:
+            rows.append(i)
+            nums.append(v)
+        column_start.append(len(rows))
+    solver = relp_amd.Solver(use_graph=0)  # (no ratio_rule given)
+    solver.load_matrix_data(column_start, rows, nums, [1] * len(nums), b=b, cost=cost, counts=(m, 0, 0, 0))
+    trace = Trace()
+    assert isinstance(solve_relaxation(data, BasisInverseRows, SteepestDescentAlongObjective, trace=trace), FiniteOptimum)
+    pivots, status = device_trace(solver)
+    assert status == "optimal" and solver.record()["ratio_rule"] == "textbook"
+    phase_one = [t for t in trace.pivots if t[0] == 1]
+    assert pivots[:len(phase_one)] == phase_one
+    solver.close()
+
+
+def test_how_far_the_f64_loop_follows_the_reference_sequence(capsys):
+    """Per LP and ratio rule: the length of the common prefix of the device's f64 pivot sequence and the golden trace of the exact reference
+    algorithm (first 64 pivots).  Decimal data resolve AUTO to Harris (the record says so); the explicit textbook rule follows the
+    reference at least as far on LPs without near-ties.  The optimum does not depend on any of this (exact certificate); `value` of the
+    bench line counts THESE pivots, which is why the exact path's pivots/s is reported beside it.  (-s prints the table.)"""
+    import glob
+    import json
+    golden = {os.path.basename(p)[:-5]: json.load(open(p)) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.json"))}
+    rows = []
+    for name in ["AFIRO", "SC50A", "SC50B", "SC105", "ADLITTLE", "SHARE2B", "KB2", "BLEND", "ISRAEL", "STOCFOR1", "E226", "25FV47"]:
+        g = golden[name]
+        head = [tuple(t) for t in g.get("trace", g["trace_head"])][:64]
+        prefix = {}
+        for label, rule in (("auto", relp_amd.api.RATIO_AUTO), ("textbook", relp_amd.api.RATIO_TEXTBOOK), ("harris", relp_amd.api.RATIO_HARRIS)):
+            solver = relp_amd.Solver(ratio_rule=rule, use_graph=0).load_mps(os.path.join(ROOT, g["file"]))
+            n_art = solver.n_art
+            expected = [(ph, q + (n_art if ph == 2 else 0), p, lv + (n_art if ph == 2 else 0)) for ph, q, p, lv in head]
+            solver.begin_phase_one()
+            pivots, phase = [], 1
+            while len(pivots) < len(expected):
+                done, reason = solver.iterate(1)
+                if done == 0:
+                    if phase == 2 or abs(solver.objective_function_value()) > 1e-7:
+                        break
+                    solver.begin_phase_two()
+                    phase = 2
+                    continue
+                _, q, p, leaving = solver.last_pivot()
+                pivots.append((phase, q, p, leaving))
+            common = next((k for k, (a, b) in enumerate(zip(pivots, expected)) if a != b), min(len(pivots), len(expected)))
+            prefix[label] = common
+            if label == "auto":
+                resolved = solver.record()["ratio_rule"]
+            solver.close()
+        rows.append((name, len(head), resolved, prefix))
+        assert resolved == "harris"  # (Netlib data are decimals)
+        assert prefix["auto"] == prefix["harris"]
+        assert prefix["textbook"] >= 1 and prefix["harris"] >= 1
+    with capsys.disabled():
+        print("\nf64 pivots that coincide with the reference's exact sequence (common prefix of the first 64):")
+        for name, total, resolved, prefix in rows:
+            print("  %-9s of %2d: auto (= %s) %2d, textbook %2d, harris %2d" % (name, total, resolved, prefix["auto"], prefix["textbook"], prefix["harris"]))
