@@ -179,7 +179,9 @@ typedef struct relp_options {
     int32_t certify_threads;   /* host threads of the exact certificate (by the core count, at most 32) */
     int32_t exact_grid;        /* relp_solve_exact: workgroups of the cooperative launch (by the work of a pivot) */
     int32_t exact_update;      /* relp_solve_exact, bits: 1 = the update of N = D B^-1 on the vector unit only (default: on the matrix
-                                  cores from 16 limbs on); 2 = the pricing pass forms the products N a_j of every column that can enter
+                                  cores from 16 limbs on); 4 = the update on the matrix cores in the two passes of round 5 (numerators,
+                                  then carries / shift / sign by a thread per entry; default since round 6: the tiles finish their
+                                  entries themselves into a second buffer of N); 2 = the pricing pass forms the products N a_j of every column that can enter
                                   exactly (default: weight estimates from the leading words, exact only where their error bound asks) */
     int32_t luf_dense_tail;    /* device refactorisation: rows of the dense tail (8); -1 = none */
     int32_t luf_slack;         /* ... Markowitz score slack of a round (16) */

@@ -855,6 +855,15 @@ struct ExactLP {
     u64* next_dinv;       // [limbs] 1 / D'_odd for the NEXT pivot, formed by the last workgroup while the others update N (update_on_matrix_cores)
     int* xt_bits;         // [m] bit length of |x~_i|, kept by whoever writes an entry
     int mfma_update;      // 1: the update runs on the matrix cores
+    // round 6: the second pass of the update inside the tiles.  N is double-buffered: a pivot's tiles read `N` and write the finished
+    // entries -- carries run through, shifted, sign-extended, bit lengths -- into `N_alt`; the kernel then swaps the two (and the bit lengths)
+    u64* N_alt;           // [limbs][m columns][m rows] the other buffer (zero at the launch)
+    int* N_bits_alt;      // [m columns][m rows] bit lengths of what N_alt holds
+    int fused_update;     // 1: the tiles finish their entries themselves (a pivot on a negative element -- zero-level pivots only -- takes the two passes)
+    u64* xt_alt;          // [m] Big, xt_bits_alt [m]: the other buffer of x~_B, likewise (a thread walking the 128 words of ONE entry of x~_B behind the
+    int* xt_bits_alt;     //   barrier was 0.2 ms of every pivot -- as long as the whole second pass over N, whose latency it had hidden in)
+    u64* y_alt;           // [m][limbs], y_bits_alt [m]: and of y = c_B' N
+    int* y_bits_alt;
     int price_exactly;    // 1: every column that can enter has its products formed exactly (test hook: the path of a column whose estimate is not good enough)
     unsigned* barrier;    // [EX_BARRIER_WORDS] the grid barrier's counters (grid_barrier), zero at the launch
 };
@@ -1654,10 +1663,12 @@ struct UpdateTileEntry {
 };
 // (the fields of UpdateTileEntry one by one: as a struct the argument travelled through the stack, and every tile began by waiting for
 //  four scratch loads before its first request could go out -- a third of the time of the "requests" section, tools: -DRELP_TILE_STAMPS)
-template <int L>
+// FUSED (round 6): the tile finishes its entries itself -- `numerator_of` is then word 0 of the entry in the OTHER buffer of N (stride
+// `numerator_stride`), `words_of` its bit length there, `shift` = ctz(D) -- see the epilogue below.
+template <int L, bool FUSED>
 __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_of_lp, global_cu64* entry_of, size_t entry_stride, global_cu64* second_of, size_t second_stride,
                                                     global_u64* numerator_of, global_i32* carry_of, global_i32* words_of, size_t numerator_stride, const lds_u32* toeplitz_lds,
-                                                    const lds_i32* prefix_lds, int row, bool store, int terms, int nb64, int lane) {
+                                                    const lds_i32* prefix_lds, int row, bool store, int terms, int nb64, int lane, int shift) {
     struct {
         unsigned long long* stamps;
     } lp{stamps_of_lp};
@@ -1686,6 +1697,29 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
     const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
     int issued = 0;
     constexpr int PB = UPDATE_PASS_BLOCKS;  // blocks of 64 digits per pass: 4 PB accumulator tiles
+    // ---- FUSED: what the epilogue carries from pass to pass (see below) ----
+    int k_below = 0;           // (lanes g == 0) what the pair below this pass's first carries on, as the tiles formed it
+    unsigned carry_below = 0;  // ... and the bit that the additions below it hand on
+    u64 pending = 0;           // (lanes g == 3) the pass's top word, not yet shifted: its upper neighbour belongs to the next pass
+    int top_nonzero = -1, top_not_ones = -1, lowest_nonzero = 4 * L;  // of the result's words this lane has formed
+    u64 word_nonzero = 0, word_not_ones = 0;
+    // (what the other buffer holds at this entry's place, asked for now: at the end of the tile the two loads were a round trip nothing hid)
+    int stale_bits = 0;
+    u64 stale_top = 0;
+    if constexpr (FUSED) {
+        if (store) {
+            stale_bits = *at_entry.words;
+            stale_top = at_entry.numerator[(size_t)(L - 1) * at_entry.numerator_stride];
+        }
+    }
+    const int bs = shift & 63, ws = shift >> 6;  // (D = 2^s D_odd: decimal data scaled to integers leave hundreds of factors 2 in it)
+    auto shifted = [&](u64 w, u64 above) { return bs ? (w >> bs) | (above << (64 - bs)) : w; };
+    auto emit = [&](int j, u64 v) {  // word j + ws of the numerator, shifted = word j of the new entry: tracked for the bit length, stored
+        if (j < 0) return;  // (the numerator's low words: zero, the division is exact)
+        if (v != 0) { top_nonzero = j; word_nonzero = v; lowest_nonzero = min(lowest_nonzero, j); }
+        if (v != ~0ull) { top_not_ones = j; word_not_ones = v; }
+        if (store) at_entry.numerator[(size_t)j * at_entry.numerator_stride] = v;
+    };
     for (int bp = 0; bp < nb64; bp += PB) {
         v4i acc[PB][4];
 #pragma unroll
@@ -1761,6 +1795,95 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
             }
         }
         TILE_STAMP(27);  // the steps of the pass
+        if constexpr (FUSED) {
+            // Round 6: the second pass in the tile's own registers.  Lane (entry e = lane & 15, group g = lane >> 4) holds, for block b of the
+            // pass, the 128-bit pair P = 4 b + g of its entry (digits 64 b + 16 g ..) and what it carries on, k_P < 2^22.  The finished pair is
+            // V_P + k_(P-1) + c_P where c_P is the carry bit of the additions below -- pair P - 1 sits in the lane 16 below (g > 0) or, for
+            // g = 0, in lane e + 48 of the block below (the previous pass's last block: k_below, carry_below).  The bits c_P are a
+            // carry-lookahead over (generate, propagate) flags gathered with ballots: no chain through the pairs, no numerator in memory.
+            // Then the arithmetic shift by s = ctz(D) bits (whole words by the index, the rest with a word's upper neighbour from the lane 16 above; a pass's top word waits
+            // for the next pass), the words straight into the OTHER buffer of N, the sign's fill above them at the end.
+            const int blocks_here = min(PB, nb64 - bp);  // (the same for every lane)
+            u64 lo[PB], hi[PB];
+            int kout[PB];
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) {
+                i64 quad[4];
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    const lds_i32* pa = prefix_lds + 64 * min(bp + bl, L / 8 - 1) + 16 * g + 4 * tq;
+                    v4i digit = acc[bl][tq] + v4i{pa[0], pa[1], pa[2], pa[3]};
+                    if (terms == 2) digit += v4i{pa[WB], pa[WB + 1], pa[WB + 2], pa[WB + 3]};
+                    quad[tq] = (i64)digit[0] + ((i64)digit[1] << 8) + ((i64)digit[2] << 16) + ((i64)digit[3] << 24);
+                }
+                const __int128 v0 = (__int128)quad[0] + ((__int128)quad[1] << 32);
+                const __int128 v1 = (__int128)quad[2] + ((__int128)quad[3] << 32) + (v0 >> 64);
+                const bool valid = bl < blocks_here;
+                lo[bl] = valid ? (u64)v0 : 0ull;
+                hi[bl] = valid ? (u64)v1 : 0ull;
+                kout[bl] = valid ? (int)(v1 >> 64) : 0;
+            }
+            // what pair P - 1 carries on, as formed
+            int from_below[PB];
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) from_below[bl] = __shfl(kout[bl], (lane + 48) & (WAVE - 1));  // lane - 16; for g = 0: lane e + 48, same block
+            unsigned long long generate_mask[PB], propagate_mask[PB];
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) {
+                const int kin = g > 0 ? from_below[bl] : (bl > 0 ? from_below[bl > 0 ? bl - 1 : 0] : k_below);
+                const u64 l = lo[bl] + (u64)(unsigned)kin;
+                const u64 c = l < lo[bl] ? 1ull : 0ull;
+                const u64 h = hi[bl] + c;
+                const bool valid = bl < blocks_here;
+                generate_mask[bl] = __ballot(valid && c != 0 && h == 0);
+                propagate_mask[bl] = __ballot(valid && l == ~0ull && h == ~0ull);
+                lo[bl] = l;
+                hi[bl] = h;
+            }
+            {   // (lanes g = 0 of the next pass: lane e + 48's last block of this one)
+                int k_next = from_below[0];
+#pragma unroll
+                for (int bl = 1; bl < PB; ++bl) k_next = bl < blocks_here ? from_below[bl] : k_next;
+                k_below = k_next;
+            }
+            // the flags of this lane's entry, pair 4 bl + g' at bit 4 bl + g' (bits e, e + 16, e + 32, e + 48 of a ballot)
+            unsigned generate = 0, propagate = 0;
+            const int e16 = lane & 15;
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) {
+                const u64 gm = (generate_mask[bl] >> e16) & 0x0001000100010001ull, pm = (propagate_mask[bl] >> e16) & 0x0001000100010001ull;
+                generate |= (unsigned)((gm * 0x0001000200040008ull) >> 48 & 15u) << (4 * bl);   // bit 16 g' -> bit 48 + g'
+                propagate |= (unsigned)((pm * 0x0001000200040008ull) >> 48 & 15u) << (4 * bl);
+            }
+            // carry-lookahead by one addition: position i generates (1 + 1), propagates (1 + 0) or stops a carry (0 + 0)
+            const unsigned a = generate | propagate, b2 = generate;
+            const unsigned sum = a + b2 + carry_below;
+            const unsigned carry_in = sum ^ a ^ b2;  // bit i: the carry into pair i of the pass (bit 16: out of the last)
+            carry_below = (carry_in >> (4 * blocks_here)) & 1u;
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) {
+                const u64 cbit = (carry_in >> (4 * bl + g)) & 1u;
+                const u64 l = lo[bl] + cbit;
+                hi[bl] += l < cbit ? 1ull : 0ull;
+                lo[bl] = l;
+            }
+            // shift and store: word 2 P of the entry is lo, 2 P + 1 is hi; the word above hi is the lo of pair P + 1
+            u64 above[PB];
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) above[bl] = __shfl(lo[bl], (lane + 16) & (WAVE - 1));  // for g = 3: lane e, same block
+            if (g == 3 && bp > 0) emit(8 * bp - 1 - ws, shifted(pending, above[0]));  // (the previous pass's top word: its neighbour is this pass's first)
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl) {
+                if (bl < blocks_here) {
+                    const int j = 8 * (bp + bl) + 2 * g - ws;
+                    emit(j, shifted(lo[bl], hi[bl]));
+                    const bool top_of_pass = g == 3 && bl == blocks_here - 1;
+                    const u64 next = g < 3 ? above[bl] : above[bl + 1 < PB ? bl + 1 : bl];
+                    if (top_of_pass) pending = hi[bl];
+                    else emit(j + 1, shifted(hi[bl], next));
+                }
+            }
+        } else {
         // this lane holds digits 64 b + 16 g + (4 tq + r) of entry (lane & 15): two words and a carry per block
 #pragma unroll
         for (int bl = 0; bl < PB; ++bl) {
@@ -1784,16 +1907,51 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
                 }
             }
         }
+        }
     }
     TILE_STAMP(28);  // words and carries out
-    if (store && g == 0) *at_entry.words = 8 * nb64;
+    if constexpr (FUSED) {
+        // the top word (lanes g = 3 hold it unshifted), the sign's fill above the words formed, the bit length of the new entry
+        const int formed = 8 * nb64 - ws;  // words of the numerator, less those the shift drops (formed > 0: the numerator's bound counts the shift)
+        const int e16 = lane & 15;
+        const u64 fill = __shfl((i64)pending < 0 ? ~0ull : 0ull, e16 + 48);
+        // (what the other buffer holds at this place: an entry of bit length `stale_bits`, sign-extended through all L words -- where the
+        //  sign stays, the fill above its words and the new value's is already there, as in the second pass of round 5)
+        const int stale_words = min(L, (stale_bits + 1 + 63) >> 6);
+        const bool same_sign = ((i64)stale_top < 0) == (fill != 0);
+        const int fill_end = same_sign ? max(formed, stale_words) : L;
+        if (g == 3) emit(formed - 1, shifted(pending, fill));
+        if (store)
+            for (int j = formed + g; j < fill_end; j += 4) at_entry.numerator[(size_t)j * at_entry.numerator_stride] = fill;
+        // the bit length of the magnitude (finish_update_entry's rules), over the four lanes of the entry
+        int top = fill ? top_not_ones : top_nonzero;
+        u64 at_top = fill ? ~word_not_ones : word_nonzero;
+        int lowest = lowest_nonzero;
+#pragma unroll
+        for (int d = 16; d < WAVE; d *= 2) {
+            const int other_top = __shfl_xor(top, d);
+            const u64 other_word = __shfl_xor(at_top, d);
+            lowest = min(lowest, __shfl_xor(lowest, d));
+            if (other_top > top) { top = other_top; at_top = other_word; }
+        }
+        int bits;
+        if (fill == 0) bits = top < 0 ? 0 : 64 * top + (64 - __clzll((long long)at_top));
+        else if (top < 0) bits = 1;  // -1
+        else {
+            bits = 64 * top + (64 - __clzll((long long)at_top));
+            if (lowest >= top && (at_top & (at_top + 1)) == 0) bits += 1;  // -(2^k): ~v + 1 carries into a new bit
+        }
+        if (store && g == 0) *at_entry.words = bits;
+    } else {
+        if (store && g == 0) *at_entry.words = 8 * nb64;
+    }
     return issued;
 }
-template <int L>
+template <int L, bool FUSED = false>
 __device__ __forceinline__ int mfma_update_tile(const UpdateTileArgs lp, const UpdateTileEntry at_entry, const lds_u32* toeplitz_lds, const lds_i32* prefix_lds, int row, bool store,
-                                                int terms, int nb64, int lane) {
-    return mfma_update_tile_fields<L>(lp.stamps, at_entry.entry, at_entry.entry_stride, at_entry.second, at_entry.second_stride, at_entry.numerator, at_entry.carry, at_entry.words,
-                                      at_entry.numerator_stride, toeplitz_lds, prefix_lds, row, store, terms, nb64, lane);
+                                                int terms, int nb64, int lane, int shift = 0) {
+    return mfma_update_tile_fields<L, FUSED>(lp.stamps, at_entry.entry, at_entry.entry_stride, at_entry.second, at_entry.second_stride, at_entry.numerator, at_entry.carry,
+                                             at_entry.words, at_entry.numerator_stride, toeplitz_lds, prefix_lds, row, store, terms, nb64, lane, shift);
 }
 
 // The numerator of one entry as the tiles left it (word w at numerator[w * numerator_stride], the carry of pair P at carries[P *
@@ -2348,6 +2506,7 @@ __device__ __noinline__ void price_estimates(const ExactLP& lp, double mD, int e
 struct UpdateScalars {
     int p, shift, flip, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha;
     int with_y, cq_bits;  // y = c_B' N rides along as one more row of N (its factor c~_q u in lp.y_part), |c~_q| has that many bits
+    int fused;            // the tiles finish the entries of N themselves, into lp.N_alt (x~_B and y keep the two passes)
 };
 template <int L>
 __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const UpdateScalars sc, const u64* s_c1, const u64* s_ap, unsigned long long& products_needed,
@@ -2367,6 +2526,7 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
     auto N_at = [&](int i, int c) { return lp.N + (size_t)c * m + i; };
     const int p = sc.p, shift = sc.shift, ap_bits = sc.ap_bits, D_bits = sc.D_bits, xp_bits = sc.xp_bits, n_heavy = sc.n_heavy, n_rows_alpha = sc.n_rows_alpha;
     const bool flip = sc.flip != 0;
+    const bool fused = sc.fused != 0;
         // ---- the update on the matrix cores (see mfma_update_tile): tiles of 16 entries of a column, a wave each ----
         __shared__ UpdateLds<L> s_update;
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, waves = T / WAVE;
@@ -2459,12 +2619,16 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
                             const int blocks = min(L / 4, max(1, (needed + 255) / 256));
                             products_needed += 16ull * blocks * (blocks + 1);
                         }
-                        if (kind == 0) at_entry = UpdateTileEntry{lp.N + idx, MM, lp.x_part + row, (size_t)m, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                        if (kind == 0 && fused) at_entry = UpdateTileEntry{lp.N + idx, MM, lp.x_part + row, (size_t)m, lp.N_alt + idx, nullptr, lp.N_bits_alt + idx, MM};
+                        else if (kind == 0) at_entry = UpdateTileEntry{lp.N + idx, MM, lp.x_part + row, (size_t)m, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                        else if (kind == 1 && fused) at_entry = UpdateTileEntry{lp.xt + idx * L, 1, lp.x_part + row, (size_t)m, lp.xt_alt + idx * L, nullptr, lp.xt_bits_alt + idx, 1};
                         else if (kind == 1) at_entry = UpdateTileEntry{lp.xt + idx * L, 1, lp.x_part + row, (size_t)m, lp.Tx + idx, lp.Tx_carry + idx, lp.Tx_words + idx, M2};
+                        else if (fused) at_entry = UpdateTileEntry{lp.y + idx * L, 1, N_at(p, row), MM, lp.y_alt + idx * L, nullptr, lp.y_bits_alt + idx, 1};
                         else at_entry = UpdateTileEntry{lp.y + idx * L, 1, N_at(p, row), MM, lp.Tx + m + idx, lp.Tx_carry + m + idx, lp.Tx_words + m + idx, M2};
                     }
                     nb = wave_max(nb);
-                    issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 2, nb, lane);
+                    if (fused) issued += mfma_update_tile<L, true>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 2, nb, lane, shift);
+                    else issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 2, nb, lane);
                 }
                 u = column_end;
             }
@@ -2499,13 +2663,35 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
                     }
                 }
                 nb = wave_max(nb);
-                if (nb == 0) continue;  // sixteen zeros
                 const size_t idx = (size_t)k * m + (row >= 0 ? row : 0);
-                const UpdateTileEntry at_entry{lp.N + idx, MM, lp.x_part, (size_t)m, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
-                issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 1, nb, lane);
+                if (fused && lane < 16 && row >= 0 && row != p && entry_bits == 0 && lp.N_bits_alt[idx] != 0) {
+                    // (a zero stays a zero -- but the other buffer holds the entry of two pivots ago at this place)
+                    for (int w = 0; w < L; ++w) lp.N_alt[(size_t)w * MM + idx] = 0ull;
+                    lp.N_bits_alt[idx] = 0;
+                }
+                if (nb == 0) continue;  // sixteen zeros
+                if (fused) {
+                    const UpdateTileEntry at_entry{lp.N + idx, MM, lp.x_part, (size_t)m, lp.N_alt + idx, nullptr, lp.N_bits_alt + idx, MM};
+                    issued += mfma_update_tile<L, true>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 1, nb, lane, shift);
+                } else {
+                    const UpdateTileEntry at_entry{lp.N + idx, MM, lp.x_part, (size_t)m, lp.T + idx, lp.T_carry + idx, lp.T_words + idx, MM};
+                    issued += mfma_update_tile<L>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, store, 1, nb, lane);
+                }
             }
         }
         if (lane == 0) products_issued += 256ull * issued;  // an MFMA is 16 x 16 x 64 byte products = 256 word products
+        if (fused) {  // row p stays as it is (D' = alpha~_p): into the other buffers with it
+            for (long long t = gtid; t < (long long)m * L; t += GT) {
+                const int w = (int)(t / m), k = (int)(t - (long long)w * m);
+                const size_t idx = (size_t)k * m + p;
+                lp.N_alt[(size_t)w * MM + idx] = lp.N[(size_t)w * MM + idx];
+                if (w == 0) lp.N_bits_alt[idx] = lp.N_bits[idx];
+            }
+            if (gtid < L) lp.xt_alt[(size_t)p * L + gtid] = lp.xt[(size_t)p * L + gtid];
+            if (gtid == 0) lp.xt_bits_alt[p] = lp.xt_bits[p];
+            substamp(21);
+            return;  // (nothing is left for a second pass, and nobody reads the new values before the barrier that ends the pivot)
+        }
         substamp(21);
         grid.sync();  // every numerator is in lp.T
         substamp(22);
@@ -2590,6 +2776,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     };
     unsigned long long products_needed = 0, products_issued = 0;  // this thread's word products in the update of N, whole run
+    int n_swaps = 0;  // pivots whose fused update left N in the other buffer (lp.N and lp.N_alt swapped)
+    u64* const xt_of_host = lp.xt;  // (x~_B swaps as well; the final x~_B goes where the host reads it)
     bool on_matrix_cores = false;  // the update of N by mfma_update_tile
     if constexpr (L >= 16) on_matrix_cores = lp.mfma_update != 0;
     int parity = 0;  // the partial arrays of the grid reductions alternate, so that a fast workgroup never overwrites what a slow one still reads
@@ -3294,9 +3482,36 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         const int n_heavy = word[7], n_rows_alpha = word[6];
         if constexpr (L >= 16) if (on_matrix_cores) {
-            const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha, y_rides ? 1 : 0, cq_bits};
+            // (the fused epilogue does not negate: a negative pivot element -- zero-level pivots only -- takes the two passes of round 5, in place)
+            const bool fused = lp.fused_update != 0 && !flip;
+            const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha, y_rides ? 1 : 0, cq_bits, fused ? 1 : 0};
             update_on_matrix_cores<L>(lp, scalars, s_c1, s_words[0], products_needed, products_issued, barrier_epoch, barrier_place);
             dinv_ready = G > 1;  // (the last workgroup left 1 / D'_odd in lp.next_dinv)
+            if (fused) {  // the other buffer holds N now (every workgroup alike; nobody reads N again before the barrier that ends the pivot)
+                u64* const was = lp.N;
+                lp.N = lp.N_alt;
+                lp.N_alt = was;
+                int* const was_bits = lp.N_bits;
+                lp.N_bits = lp.N_bits_alt;
+                lp.N_bits_alt = was_bits;
+                ++n_swaps;
+                {   // x~_B likewise
+                    u64* const x_was = lp.xt;
+                    lp.xt = lp.xt_alt;
+                    lp.xt_alt = x_was;
+                    int* const x_was_bits = lp.xt_bits;
+                    lp.xt_bits = lp.xt_bits_alt;
+                    lp.xt_bits_alt = x_was_bits;
+                }
+                if (y_rides) {  // ... and y where it rode along
+                    u64* const y_was = lp.y;
+                    lp.y = lp.y_alt;
+                    lp.y_alt = y_was;
+                    int* const y_was_bits = lp.y_bits;
+                    lp.y_bits = lp.y_bits_alt;
+                    lp.y_bits_alt = y_was_bits;
+                }
+            }
         }
         if (!on_matrix_cores)
         for (long long unit = gtid; unit < (long long)n_heavy * n_rows_alpha; unit += GT) {  // N(p, k) != 0 and alpha~_i != 0: two products
@@ -3426,7 +3641,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
             const i64 b = lp.rhs[k];
             if (b != 0) acc = big_add(acc, big_mul_small(big_load_s<L>(N_at(i, k), MM), b));
         }
-        big_store(lp.xt + (size_t)i * L, acc);
+        big_store(xt_of_host + (size_t)i * L, acc);
     }
     {   // the word products of the run: one sum per workgroup, one atomic per workgroup
         __shared__ unsigned long long s_products[2];
@@ -3457,6 +3672,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         lp.out[7] = trace_count;
         lp.out[8] = at_drive_row;
         lp.out[9] = at_removed;
+        lp.out[10] = n_swaps & 1;  // which buffer holds N now (the fused update swaps N and N_alt pivot by pivot)
+        lp.prof[32] = (unsigned long long)n_swaps;  // (diagnostic: pivots whose tiles finished their entries themselves)
     }
 }
 
@@ -3676,9 +3893,25 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         u64* d_gamma_terms = dalloc<u64>((size_t)EX_GAMMA_BATCH * (m + 1) * (2 * big + 2), fresh);
         u64* d_x_part = dalloc<u64>((size_t)m * ((m + 31) / 32) * big, fresh);
         int* d_x_bits = dalloc<int>((size_t)m * ((m + 31) / 32), fresh);
-        // the update of N on the matrix cores (mfma_update_tile): from 32 limbs on (update_mode 1: never).  (At 16 limbs -- two
-        // 64-byte blocks per integer -- the path was tried and hung on ISRAEL, unexplained; it is not compiled for that width.)
+        // the update of N on the matrix cores (mfma_update_tile): from 16 limbs on (update_mode bit 0: never).  Round 6: the tiles finish
+        // their entries themselves into a second buffer of N (update_mode bit 2: the two passes of round 5 -- numerators to T, a thread per
+        // entry behind a barrier -- which remain for the pivots the fused epilogue does not take: a negative pivot element, zero-level pivots only).
         const bool mfma_update = limbs >= 16 && (update_mode & 1) == 0;
+        const bool fused_update = mfma_update && (update_mode & 4) == 0;
+        u64* d_N_alt = fused_update ? dalloc<u64>((size_t)m * m * big, fresh) : nullptr;
+        int* d_N_bits_alt = fused_update ? dalloc<int>((size_t)m * m, fresh) : nullptr;
+        u64* d_xt_alt = fused_update ? dalloc<u64>((size_t)m * big, fresh) : nullptr;
+        int* d_xt_bits_alt = fused_update ? dalloc<int>((size_t)m, fresh) : nullptr;
+        u64* d_y_alt = fused_update ? dalloc<u64>((size_t)m * big, fresh) : nullptr;
+        int* d_y_bits_alt = fused_update ? dalloc<int>((size_t)m, fresh) : nullptr;
+        if (fused_update) {  // (every entry of a buffer is a whole sign-extended integer whose bit length its array holds: zeros to begin with)
+            RELP_HIP(hipMemsetAsync(d_N_alt, 0, (size_t)m * m * big * sizeof(u64), stream));
+            RELP_HIP(hipMemsetAsync(d_N_bits_alt, 0, (size_t)m * m * sizeof(int), stream));
+            RELP_HIP(hipMemsetAsync(d_xt_alt, 0, (size_t)m * big * sizeof(u64), stream));
+            RELP_HIP(hipMemsetAsync(d_xt_bits_alt, 0, (size_t)m * sizeof(int), stream));
+            RELP_HIP(hipMemsetAsync(d_y_alt, 0, (size_t)m * big * sizeof(u64), stream));
+            RELP_HIP(hipMemsetAsync(d_y_bits_alt, 0, (size_t)m * sizeof(int), stream));
+        }
         u64* d_T = mfma_update ? dalloc<u64>((size_t)m * m * big, fresh) : nullptr;
         int* d_T_carry = mfma_update ? dalloc<int>((size_t)m * m * (big / 2), fresh) : nullptr;
         int* d_T_words = mfma_update ? dalloc<int>((size_t)m * m, fresh) : nullptr;
@@ -3736,7 +3969,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         const auto width_start = std::chrono::steady_clock::now();
         ExactLP lp{m, n, n_art, limbs, d_col_start, d_row_index, d_value, d_cost2, d_cost1, d_weight, d_rhs, d_basis, d_pos, d_N, d_D, d_xt, d_alpha,
                    d_ctil, d_key, d_trace, trace_capacity, max_pivots, d_out, d_resume, d_removed, d_words, d_part_key, d_part_rank, d_prof, d_price_a, d_price_err, d_price_term, d_bracket, d_cand, d_gamma, d_gamma_terms, d_x_part, d_x_bits, d_cb_row, d_row_list, d_col_heavy, d_col_light, d_N_bits,
-                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_next_dinv, d_xt_bits, mfma_update ? 1 : 0, (update_mode & 2) ? 1 : 0, d_barrier};
+                   d_T, d_T_carry, d_T_words, d_y, d_y_bits, d_cd, d_neg_list, d_Tx, d_Tx_carry, d_Tx_words, d_y_part, d_next_dinv, d_xt_bits, mfma_update ? 1 : 0, d_N_alt, d_N_bits_alt, fused_update ? 1 : 0, d_xt_alt, d_xt_bits_alt, d_y_alt, d_y_bits_alt, (update_mode & 2) ? 1 : 0, d_barrier};
         // The grid by the work of a pivot (m^2 entries of `limbs`^2 word products each, and as much again for pricing): one workgroup
         // for the smallest LPs -- a grid barrier costs 2 us at 8 workgroups, 25 at 256 -- up to one per CU.  relp_options.exact_grid: A/B hook.
         int grid = (int)std::min<long long>(256, std::max<long long>(1, (long long)m * m * limbs / 4096));
@@ -3807,7 +4040,8 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
 #endif
                 fprintf(stderr, " | 1 / D_odd %.1f ms | entering column: chunks + barrier %.1f, adding up %.1f, barrier %.1f, row factors %.1f", prof[14] / 1e5, prof[10] / 1e5, prof[11] / 1e5,
                         prof[18] / 1e5, prof[19] / 1e5);
-                fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f\n", prof[20] / 1e5, prof[21] / 1e5, prof[22] / 1e5, prof[23] / 1e5);
+                fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f (%llu pivots finished inside their tiles)\n", prof[20] / 1e5, prof[21] / 1e5,
+                        prof[22] / 1e5, prof[23] / 1e5, prof[32]);
             }
             if (counters) {
                 ExactWidthRecord record;
@@ -3827,7 +4061,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         *pivots_phase_two = out[2];
         if (pivots_survived) pivots_survived->push_back({limbs, (long long)out[1] + out[2]});
         if (out[0] == EX_OVERFLOW) {
-            previous_N = d_N;
+            previous_N = out[10] ? d_N_alt : d_N;  // (the buffer that held N when the kernel stopped: the fused update swaps them pivot by pivot)
             previous_D = d_D;
             previous_limbs = limbs;
             resume_state[1] = out[6];

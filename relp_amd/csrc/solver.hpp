@@ -244,7 +244,7 @@ struct TuningScope {  // the thread's tuning for the lifetime of the object
 };
 
 // One run of the exact fixed-width simplex kernel (exact.hip) at one width: what `relp_get_exact_counters` reports.
-constexpr int EX_PROF_WORDS = 32;
+constexpr int EX_PROF_WORDS = 40;
 struct ExactWidthRecord {
     int limbs = 0, grid = 0;
     long long pivots_total_at_end = 0;            // pivots of the solve so far when this width stopped (overflow) or finished

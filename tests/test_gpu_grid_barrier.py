@@ -84,9 +84,9 @@ AT_16_LIMBS = ["ISRAEL", "BLEND", "STOCFOR1", "LOTFI", "BEACONFD", "BOEING1", "S
 
 
 @pytest.mark.parametrize("name", AT_16_LIMBS)
-@pytest.mark.parametrize("update", [0, 1])
+@pytest.mark.parametrize("update", [0, 4, 1])
 def test_the_update_on_the_matrix_cores_at_16_limbs(name, update):
-    """Started AT 16 limbs so that every pivot the LP makes at that width runs there; exact_update 0 = matrix cores, 1 = vector unit."""
+    """Started AT 16 limbs so that every pivot the LP makes at that width runs there; exact_update 0 = matrix cores (fused epilogue), 4 = matrix cores in two passes, 1 = vector unit."""
     golden = GOLDEN[name]
     if golden.get("status") != "optimal":
         pytest.skip("no optimum in the fixture")
