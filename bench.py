@@ -736,8 +736,10 @@ def single_lp(args, ctx):
                    "refactor_seconds_per_solve": float(last.refactor_seconds),
                    "polishes": int(last.polishes), "max_residual_before_polish": last.max_residual,
                    # the reference is exact and has neither tolerances nor a Harris test: what f64 adds, and what it changes
-                   "ratio_rule": "harris two-pass (default; the reference's textbook rule with Bland ties is relp_options.ratio_rule = 1)"
-                                 if options.ratio_rule == 0 else "textbook minimum ratio, Bland ties (the reference's)",
+                   # (relp_options.ratio_rule = AUTO resolves against the data at load: the per-LP record says which test ran)
+                   "ratio_rule": "harris two-pass (what AUTO -- the default -- resolves to on decimal data; the reference's textbook rule with Bland ties "
+                                 "runs on small-integer data and under relp_options.ratio_rule = 1)"
+                                 if solver.record().get("ratio_rule") == "harris" else "textbook minimum ratio, Bland ties (the reference's)",
                    "tolerances": {"tol_dual": options.tol_dual, "tol_pivot": options.tol_pivot, "harris_delta": options.harris_delta,
                                   "tol_feasible": options.tol_feasible},
                    "pivot_sequence": "f64 + Harris: 2383 pivots on 25FV47 where the exact reference rule makes 2392 (tests/golden/25FV47.json); "

@@ -586,6 +586,50 @@ int32_t relp_lu_factor_device(int32_t device, int32_t m, const int64_t* column_s
                               double* lower_value, int64_t* upper_start, int32_t* upper_column, double* upper_value,
                               double* upper_diagonal, int32_t* info);
 
+/* ---- `BasisInverse` over EXACT rationals (round 6) -----------------------------------------------------------------------
+ * The reference's `BasisInverse` is generic over the field: `Carry<RationalBig, BI>` is what its tests run (tests/netlib/mod.rs:62).
+ * relp_bi_* above is the f64 instantiation; these are the nine trait methods (carry/mod.rs:69-169) for exact rationals, one operation
+ * at a time, so that the reference's known-answer tests (lower_upper/mod.rs:536-939, decomposition/mod.rs:319-438) hold with `==`
+ * and a Rust shim can offer `Carry<RationalBig, GpuExact>`.  The object holds N = D B^-1 on the device --
+ * integer entries over ONE positive denominator, fixed-width two's complement words, the representation of relp_solve_exact -- and
+ * `change_basis` is Edmonds' integer-preserving pivot (exact division by a truncated multiplication with 1 / D_odd).  A bound that
+ * reaches the width doubles the words (up to 128) before anything is written; beyond that RELP_ERR_OVERFLOW.
+ * Sparse vectors come in as (index, numerator, denominator > 0) -- the reference's `Rational64` input type (io/mps/number/parse.rs:46-65);
+ * a result is m integer numerators of *words 64-bit words each (two's complement, least significant word first, entry e at
+ * numerators[e * *words]) and one positive denominator of *words words, NOT reduced (the caller's rational type reduces).
+ * `capacity_words` is the room per integer the caller's arrays have; relp_bix_result_words says what is needed now
+ * (RELP_ERR_ARGUMENT with *words set when it is not enough).  `should_refactor` is always 0: nothing accumulates. */
+typedef struct relp_basis_inverse_exact relp_basis_inverse_exact;
+/* `BasisInverse::identity(m)` (carry/mod.rs:83). */
+int32_t relp_bix_identity(int32_t device, int32_t m, relp_basis_inverse_exact** out);
+/* `BasisInverse::invert(columns)` (carry/mod.rs:89-92; lower_upper/mod.rs:78-92): m columns in basis order, CSC over the LP's rows.
+ * RELP_ERR_NUMERICAL when the columns are singular. */
+int32_t relp_bix_invert(int32_t device, int32_t m, const int64_t* column_start, const int32_t* row_index, const int64_t* value_num,
+                        const int64_t* value_den, relp_basis_inverse_exact** out);
+int32_t relp_bix_free(relp_basis_inverse_exact* bi);
+const char* relp_bix_last_error(const relp_basis_inverse_exact* bi);  /* bi == NULL: the last constructor error of this thread */
+/* `BasisInverse::m()` (carry/mod.rs:168). */
+int32_t relp_bix_m(const relp_basis_inverse_exact* bi, int32_t* m);
+int32_t relp_bix_result_words(const relp_basis_inverse_exact* bi, int32_t* words);
+/* `left_multiply_by_basis_inverse(column)` (carry/mod.rs:123-129): B^-1 c.  The object keeps the column for change_basis. */
+int32_t relp_bix_left_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* row_index, const int64_t* value_num, const int64_t* value_den,
+                               int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words);
+/* `right_multiply_by_basis_inverse(row)` (carry/mod.rs:135-141): r B^-1. */
+int32_t relp_bix_right_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* index, const int64_t* value_num, const int64_t* value_den,
+                                int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words);
+/* `basis_inverse_row(row)` (carry/mod.rs:165). */
+int32_t relp_bix_basis_inverse_row(relp_basis_inverse_exact* bi, int32_t row, int32_t capacity_words, uint64_t* numerators, uint64_t* denominator,
+                                   int32_t* words);
+/* `generate_element(i, original_column)` (carry/mod.rs:150-157): ONE numerator and the denominator; *is_some = 0 when it is zero. */
+int32_t relp_bix_generate_element(relp_basis_inverse_exact* bi, int32_t i, int32_t nnz, const int32_t* row_index, const int64_t* value_num,
+                                  const int64_t* value_den, int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words,
+                                  int32_t* is_some);
+/* `change_basis(pivot_row_index, column)` (carry/mod.rs:104-108): the column of the last relp_bix_left_multiply replaces the basis column
+ * of that row.  RELP_ERR_STATE without a preceding left_multiply; RELP_ERR_NUMERICAL when the pivot element is zero. */
+int32_t relp_bix_change_basis(relp_basis_inverse_exact* bi, int32_t pivot_row_index);
+/* `should_refactor()` (carry/mod.rs:163). */
+int32_t relp_bix_should_refactor(relp_basis_inverse_exact* bi, int32_t* should);
+
 
 /* ---- batches of independent LPs (BASELINE config 4) -------------------------------------------
  * The reference solves one LP per call on one thread (tests/netlib/mod.rs:47-71); independent LPs are the unit that shards.

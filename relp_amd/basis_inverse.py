@@ -225,3 +225,127 @@ def lu_factor_host(columns, pivot_threshold=0.1, reference_ties=False, inverted=
         "diag": [float(v) for v in ud[:m]], "depth_lower": dl.value, "depth_upper": du.value,
         "nnz_lower": int(ls[m]), "nnz_upper": int(us[m]), "info": [int(v) for v in info],
     }
+
+
+# ---- `BasisInverse` over exact rationals (relp_bix_*; relp_amd/csrc/exact_bi.hip) -----------------------------------------------
+def _exact_sparse(pairs):
+    from fractions import Fraction
+    pairs = [(int(i), Fraction(v)) for i, v in pairs]
+    index = np.array([i for i, _ in pairs] or [0], dtype=np.int32)
+    num = np.array([v.numerator for _, v in pairs] or [0], dtype=np.int64)
+    den = np.array([v.denominator for _, v in pairs] or [1], dtype=np.int64)
+    return len(pairs), index, num, den
+
+
+def _integer(words):
+    """Little-endian two's complement 64-bit words -> int."""
+    return int.from_bytes(np.ascontiguousarray(words, dtype=np.uint64).tobytes(), "little", signed=True)
+
+
+class ExactBasisInverse:
+    """The reference's ``BasisInverse`` (carry/mod.rs:69-169) for ``F = RationalBig`` on the device: N = D B^-1 in fixed-width integers,
+    ``change_basis`` by Edmonds' integer-preserving pivot.  Vectors in: sparse ``(index, Fraction-like)`` pairs; vectors out: lists of
+    ``Fraction`` (numerators and the one denominator cross the C ABI as 64-bit words; the reduction is Python's)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lib().relp_bix_last_error.restype = C.c_char_p
+        lib().relp_bix_last_error.argtypes = [C.c_void_p]
+
+    @classmethod
+    def identity(cls, m, device=0):
+        handle = C.c_void_p()
+        status = lib().relp_bix_identity(int(device), int(m), C.byref(handle))
+        if status != OK:
+            lib().relp_bix_last_error.restype = C.c_char_p
+            raise RelpError(status, (lib().relp_bix_last_error(None) or b"").decode())
+        return cls(handle)
+
+    @classmethod
+    def invert(cls, columns, device=0):
+        from fractions import Fraction
+        columns = [[(int(i), Fraction(v)) for i, v in column] for column in columns]
+        start = np.zeros(len(columns) + 1, dtype=np.int64)
+        rows, nums, dens = [], [], []
+        for j, column in enumerate(columns):
+            for i, v in column:
+                rows.append(i)
+                nums.append(v.numerator)
+                dens.append(v.denominator)
+            start[j + 1] = len(rows)
+        handle = C.c_void_p()
+        status = lib().relp_bix_invert(int(device), len(columns), _ptr(start, C.c_int64), _ptr(np.array(rows or [0], dtype=np.int32), C.c_int32),
+                                       _ptr(np.array(nums or [0], dtype=np.int64), C.c_int64), _ptr(np.array(dens or [1], dtype=np.int64), C.c_int64),
+                                       C.byref(handle))
+        if status != OK:
+            lib().relp_bix_last_error.restype = C.c_char_p
+            raise RelpError(status, (lib().relp_bix_last_error(None) or b"").decode())
+        return cls(handle)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().relp_bix_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, status):
+        if status != OK:
+            raise RelpError(status, (lib().relp_bix_last_error(self._h) or b"").decode())
+
+    def m(self):
+        out = C.c_int32()
+        self._check(lib().relp_bix_m(self._h, C.byref(out)))
+        return out.value
+
+    def result_words(self):
+        out = C.c_int32()
+        self._check(lib().relp_bix_result_words(self._h, C.byref(out)))
+        return out.value
+
+    def _vector(self, call, count):
+        """Run `call(capacity, numerators, denominator, words)`; retry once when the object widened meanwhile."""
+        from fractions import Fraction
+        for _ in range(3):
+            capacity = self.result_words() + 2
+            numerators = np.zeros(count * capacity, dtype=np.uint64)
+            denominator = np.zeros(capacity, dtype=np.uint64)
+            words = C.c_int32()
+            status = call(capacity, _ptr(numerators, C.c_uint64), _ptr(denominator, C.c_uint64), C.byref(words))
+            if status == OK:
+                w = words.value
+                d = _integer(denominator[:w])
+                assert d > 0
+                return [Fraction(_integer(numerators[e * w:(e + 1) * w]), d) for e in range(count)]
+            if words.value <= capacity:
+                self._check(status)
+        self._check(status)
+
+    def left_multiply_by_basis_inverse(self, column):
+        nnz, index, num, den = _exact_sparse(column)
+        return self._vector(lambda cap, n, d, w: lib().relp_bix_left_multiply(self._h, nnz, _ptr(index, C.c_int32), _ptr(num, C.c_int64),
+                                                                              _ptr(den, C.c_int64), cap, n, d, w), self.m())
+
+    def right_multiply_by_basis_inverse(self, row):
+        nnz, index, num, den = _exact_sparse(row)
+        return self._vector(lambda cap, n, d, w: lib().relp_bix_right_multiply(self._h, nnz, _ptr(index, C.c_int32), _ptr(num, C.c_int64),
+                                                                               _ptr(den, C.c_int64), cap, n, d, w), self.m())
+
+    def basis_inverse_row(self, row):
+        return self._vector(lambda cap, n, d, w: lib().relp_bix_basis_inverse_row(self._h, int(row), cap, n, d, w), self.m())
+
+    def generate_element(self, i, column):
+        """``None`` when the element is zero (the reference returns ``Option``)."""
+        nnz, index, num, den = _exact_sparse(column)
+        some = C.c_int32()
+        value = self._vector(lambda cap, n, d, w: lib().relp_bix_generate_element(self._h, int(i), nnz, _ptr(index, C.c_int32), _ptr(num, C.c_int64),
+                                                                                  _ptr(den, C.c_int64), cap, n, d, w, C.byref(some)), 1)[0]
+        return value if some.value else None
+
+    def change_basis(self, pivot_row_index):
+        self._check(lib().relp_bix_change_basis(self._h, int(pivot_row_index)))
+
+    def should_refactor(self):
+        out = C.c_int32()
+        self._check(lib().relp_bix_should_refactor(self._h, C.byref(out)))
+        return bool(out.value)

@@ -802,7 +802,8 @@ struct ExactLP {
     const i64* value;
     const i64* cost2;     // phase-two costs (scaled to integers)
     const i64* cost1;     // phase-one costs: lcm(r over the artificial rows) / r_i on the artificial of row i, 0 elsewhere
-    const i64* weight;    // w_j = W sigma_j^2 (see the header): W for a structural column, (lcm(r) / r_i)^2 for a unit column of row i
+    const u64* weight;    // w_j = W sigma_j^2 (see the header): W for a structural column, (lcm(r) / r_i)^2 for a unit column of row i -- two words each,
+                          //   low first (round 6: rows that need ten and more decimal digits -- CAPRI, ETAMACRO, FINNIS, STAIR -- make W = lcm(r)^2 67 to 80 bits)
     const i64* rhs;       // scaled right-hand side
     int* basis;           // [m]
     int* pos;             // [n]
@@ -869,8 +870,11 @@ struct ExactLP {
 };
 
 // out = w * v^2, unsigned, 2 L + 2 limbs: one term of the exact weight gamma~_j = w_j D^2 + sum_i w_i (N a_j)_i^2 of a tied candidate
+__device__ __forceinline__ double weight_as_double(const ExactLP& lp, int j) {
+    return (double)lp.weight[2 * j + 1] * 18446744073709551616.0 + (double)lp.weight[2 * j];
+}
 template <int L>
-__device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
+__device__ void weighted_square(const Big<L>& v, u64 w, u64 w_high, u64* out) {
     const Big<L> mag = big_neg(v) ? big_negate(v) : v;
     u64 sq[2 * L];
     for (int k = 0; k < 2 * L; ++k) sq[k] = 0;
@@ -883,14 +887,14 @@ __device__ void weighted_square(const Big<L>& v, u64 w, u64* out) {
         }
         sq[i + L] += carry;
     }
-    u64 carry = 0;
+    u128 carry = 0;  // (a two-word weight: the product has 2 L + 2 words)
     for (int k = 0; k < 2 * L; ++k) {
-        const u128 s = (u128)sq[k] * w + carry;
-        out[k] = (u64)s;
-        carry = (u64)(s >> 64);
+        const u128 low = (u128)sq[k] * w + (u64)carry;
+        out[k] = (u64)low;
+        carry = (u128)sq[k] * w_high + (carry >> 64) + (low >> 64);
     }
-    out[2 * L] = carry;
-    out[2 * L + 1] = 0;
+    out[2 * L] = (u64)carry;
+    out[2 * L + 1] = (u64)(carry >> 64);
 }
 // |v| of an L-word two's complement integer (word k at v[k * stride]) into out[0 .. L) (LDS), a lane per word: the two's complement of a
 // negative value is zero up to its lowest non-zero word, that word's complement plus one, the complements above.  Returns v != 0.
@@ -1023,20 +1027,21 @@ __device__ __noinline__ void exact_weight_terms(const ExactLP& lp, int c0, int b
         const int local = (int)(item / (m + 1)), i = (int)(item - (long long)local * (m + 1));
         const int j = lp.cand[c0 + local];
         u64* out = lp.gamma_terms + ((size_t)local * (m + 1) + i) * GW;
-        const u64 weight = i == m ? (u64)lp.weight[j] : (u64)lp.weight[lp.basis[i]];
+        const int weighted = i == m ? j : lp.basis[i];
+        const u64 weight = lp.weight[2 * weighted], weight_high = lp.weight[2 * weighted + 1];
         if (i == m) wave_magnitude<L>(lp.D, 1, magnitude, lane);
         else wave_magnitude<L>(lp.price_a + (size_t)local * m + i, (size_t)EX_PRODUCT_SLOTS * m, magnitude, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        u64 carry = 0;
+        u128 carry = 0;
         wave_square<L>(magnitude, lane, [&](int w, u64 word) {
-            const u128 scaled = (u128)word * weight + carry;
-            if (lane == 0) out[w] = (u64)scaled;
-            carry = (u64)(scaled >> 64);
+            const u128 low = (u128)word * weight + (u64)carry;
+            if (lane == 0) out[w] = (u64)low;
+            carry = (u128)word * weight_high + (carry >> 64) + (low >> 64);
         });
         if (lane == 0) {
-            out[2 * L] = carry;
-            out[2 * L + 1] = 0;
+            out[2 * L] = (u64)carry;
+            out[2 * L + 1] = (u64)(carry >> 64);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2362,7 +2367,7 @@ __device__ __noinline__ void price_products(const ExactLP& lp, const int* list, 
             int ea = 0;
             const double ma = lead.mantissa(&ea);
             const double ad = ldexp(ma / mD, ea - eD);
-            lp.price_term[pair] = ad * ad * (double)lp.weight[lp.basis[i]];
+            lp.price_term[pair] = ad * ad * weight_as_double(lp, lp.basis[i]);
             lp.price_err[pair] = 0.0;
         }
     }
@@ -2493,7 +2498,7 @@ __device__ __noinline__ void price_estimates(const ExactLP& lp, double mD, int e
             const double ma = lead.mantissa(&ea);
             const double ad = ldexp(ma / mD, ea + 64 * k0 - eD);
             const double eps = k0 > 0 ? ldexp(v_sum / mD, 64 * k0 - eD) : 0.0;  // what the cut-off words could add to |a_i / D|
-            const double w = (double)lp.weight[lp.basis[i]];
+            const double w = weight_as_double(lp, lp.basis[i]);
             lp.price_term[pair] = ad * ad * w;
             lp.price_err[pair] = (2.0 * fabs(ad) * eps + eps * eps) * w;
         }
@@ -3036,7 +3041,7 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                         terms += __shfl_xor(terms, d);
                         errors += __shfl_xor(errors, d);
                     }
-                    const double sumsq = (double)lp.weight[j] + terms;
+                    const double sumsq = weight_as_double(lp, j) + terms;
                     const double cd = lp.cd[j];
                     if (lane == 0) {
                         lp.key[j] = cd * cd / sumsq;
@@ -3099,8 +3104,8 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
                         const int c = c0 + (int)(pair / (m + 1)), i = (int)(pair - (long long)(c - c0) * (m + 1));
                         const int j = lp.cand[c];
                         u64* out = lp.gamma_terms + ((size_t)(c - c0) * (m + 1) + i) * GW;
-                        if (i == m) weighted_square<L>(big_load<L>(gD), (u64)lp.weight[j], out);
-                        else weighted_square<L>(big_load_s<L>(lp.price_a + (size_t)(c - c0) * m + i, (size_t)EX_PRODUCT_SLOTS * m), (u64)lp.weight[lp.basis[i]], out);
+                        if (i == m) weighted_square<L>(big_load<L>(gD), lp.weight[2 * j], lp.weight[2 * j + 1], out);
+                        else weighted_square<L>(big_load_s<L>(lp.price_a + (size_t)(c - c0) * m + i, (size_t)EX_PRODUCT_SLOTS * m), lp.weight[2 * lp.basis[i]], lp.weight[2 * lp.basis[i] + 1], out);
                     }
                     grid.sync();
                     // (a wave per candidate, a lane per word of the sum: the terms are read a whole row of words at a time, the carries
@@ -3481,12 +3486,14 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         if (sync_overflow()) { status = EX_OVERFLOW; break; }
         const int n_heavy = word[7], n_rows_alpha = word[6];
+        bool finished_in_tiles = false;
         if constexpr (L >= 16) if (on_matrix_cores) {
             // (the fused epilogue does not negate: a negative pivot element -- zero-level pivots only -- takes the two passes of round 5, in place)
             const bool fused = lp.fused_update != 0 && !flip;
             const UpdateScalars scalars{p, shift, flip ? 1 : 0, ap_bits, D_bits, xp_bits, n_heavy, n_rows_alpha, y_rides ? 1 : 0, cq_bits, fused ? 1 : 0};
             update_on_matrix_cores<L>(lp, scalars, s_c1, s_words[0], products_needed, products_issued, barrier_epoch, barrier_place);
             dinv_ready = G > 1;  // (the last workgroup left 1 / D'_odd in lp.next_dinv)
+            finished_in_tiles = fused;
             if (fused) {  // the other buffer holds N now (every workgroup alike; nobody reads N again before the barrier that ends the pivot)
                 u64* const was = lp.N;
                 lp.N = lp.N_alt;
@@ -3630,8 +3637,11 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if (!y_rides) y_phase = 0;  // y belongs to the basis that was
         ++trace_count;
         pivots[phase - 1]++;
+        // (step timers: a fused update has no barrier of its own -- the leader's wait for the last tiles of the grid is this barrier's, and
+        //  is counted as the update's, where it was before round 6)
+        if (finished_in_tiles) stamp(8);
         grid.sync();  // the new basis, D and (flip) row p for everybody
-        stamp(8);
+        stamp(finished_in_tiles ? 7 : 8);
     }
     grid.sync();
     // the final x~_B belongs to the final basis: recompute it (the loop computes it at the top of an iteration)
@@ -3763,14 +3773,21 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     for (int i = 0; i < m; ++i) lcm_all = lcm(lcm_all, row_mult[i]);
     for (int i : artificial_rows) lcm_art = lcm(lcm_art, row_mult[i]);
     std::vector<int> col_start(n + 1, 0), row_index;
-    std::vector<i64> value, cost2(n, 0), cost1(n, 0), weight(n, 0), rhs_scaled(m);
+    std::vector<i64> value, cost2(n, 0), cost1(n, 0), rhs_scaled(m);
+    std::vector<u64> weight(2 * (size_t)n, 0);  // two words per column, low first
+    auto set_weight = [&](int j, i128 ratio) {  // w_j = ratio^2: below 2^124 (the sums of m + 1 weighted squares keep their 2 L + 2 words)
+        if (ratio < 0 || ratio >= ((i128)1 << 54)) throw RatOverflow();  // (w < 2^108: with values below 2^(64 L - 3) and m + 1 < 2^17 terms the sums stay below 2^(128 L + 128))
+        const u128 w = (u128)ratio * (u128)ratio;
+        weight[2 * (size_t)j] = (u64)w;
+        weight[2 * (size_t)j + 1] = (u64)(w >> 64);
+    };
     for (int k = 0; k < n_art; ++k) {  // artificial of row i: the unit column, scaled by sigma = 1 / r_i => entry 1
         const int i = artificial_rows[k];
         row_index.push_back(i);
         value.push_back(1);
         col_start[k + 1] = (int)row_index.size();
         cost1[k] = small(lcm_art / row_mult[i]);
-        weight[k] = small(mul_checked(lcm_all / row_mult[i], lcm_all / row_mult[i]));
+        set_weight(k, lcm_all / row_mult[i]);
     }
     for (int j = 0; j < n_p; ++j) {
         const Rat c = md.cost_value(j);
@@ -3784,7 +3801,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
         col_start[n_art + j + 1] = (int)row_index.size();
         cost2[n_art + j] = small(mul_checked(c.n, cost_mult / c.d));
         const i128 ratio = unit ? lcm_all / row_mult[columns[j].index[0]] : lcm_all;
-        weight[n_art + j] = small(mul_checked(ratio, ratio));
+        set_weight(n_art + j, ratio);
     }
     for (int i = 0; i < m; ++i) rhs_scaled[i] = small(mul_checked(rhs[i].n, row_mult[i] / rhs[i].d));
     std::vector<int> basis0(m), pos0(n, -1);
@@ -3816,7 +3833,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     i64* d_value = dalloc<i64>(value.size(), owned);
     i64* d_cost2 = dalloc<i64>(n, owned);
     i64* d_cost1 = dalloc<i64>(n, owned);
-    i64* d_weight = dalloc<i64>(n, owned);
+    u64* d_weight = dalloc<u64>(2 * (size_t)n, owned);
     i64* d_rhs = dalloc<i64>(m, owned);
     int* d_basis = dalloc<int>(m, owned);
     int* d_pos = dalloc<int>(n, owned);
@@ -3858,7 +3875,7 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
     RELP_HIP(hipMemcpyAsync(d_value, value.data(), value.size() * sizeof(i64), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_cost2, cost2.data(), n * sizeof(i64), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_cost1, cost1.data(), n * sizeof(i64), hipMemcpyHostToDevice, stream));
-    RELP_HIP(hipMemcpyAsync(d_weight, weight.data(), n * sizeof(i64), hipMemcpyHostToDevice, stream));
+    RELP_HIP(hipMemcpyAsync(d_weight, weight.data(), weight.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
     RELP_HIP(hipMemcpyAsync(d_rhs, rhs_scaled.data(), m * sizeof(i64), hipMemcpyHostToDevice, stream));
 
     *status = EX_OVERFLOW;

@@ -1,0 +1,658 @@
+// relp_bix_*: the reference's trait `BasisInverse` (tableau/inverse_maintenance/carry/mod.rs:69-169) for `F = RationalBig`, as an object of
+// its own on the device -- what `Carry<RationalBig, BI>` calls one operation at a time (round-5 review: the exact path was reachable only as
+// the whole solve `relp_solve_exact`).
+//
+// Representation: the one of the exact simplex (exact.hip).  Every rational of B^-1 over ONE common denominator (Edmonds' integer-preserving
+// pivoting): N = D B^-1 with D > 0 and all entries integers of W x 64-bit two's complement words; `change_basis` on row p with
+// alpha~ = N c is  D' = alpha~_p,  N'_i = (alpha~_p N_i - alpha~_i N_p) / D  (exact), row p stays.  No gcd and no long division on the
+// device: the exact quotient is one truncated multiplication with u = 1 / D_odd modulo 2^(64 W) and a shift (D = 2^s D_odd).  Rational
+// columns come in as (numerator, denominator) pairs of int64 -- the reference's `Rational64` input type -- and are scaled to integers by
+// the lcm of their denominators; what leaves is a vector of integer numerators and ONE positive denominator (the caller reduces: the
+// Python binding returns `Fraction`s).  A bit bound that reaches the width doubles W (sign extension, up to 128 words) BEFORE anything is
+// written, so every answer is exact or the call fails with RELP_ERR_OVERFLOW.
+//
+// Kernels: a thread per row (FTRAN), per column (BTRAN), per entry (the pivot: two truncated Comba products straight into the other
+// buffer of N, then the shift in place).  W is a run-time value here -- these objects are the fine-grained boundary (the reference's
+// known-answer tests are 2 x 2 to 5 x 5); the solve that has to be fast is exact.hip's, with its widths compiled in and the update on
+// the matrix cores.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/relp_amd.h"
+#include "solver.hpp"
+
+namespace relp {
+namespace {
+
+using u64 = unsigned long long;
+using i64 = long long;
+using u128 = unsigned __int128;
+constexpr int BIX_MAX_WORDS = 128;
+
+// acc (n words, two's complement) += x (nx words, two's complement, sign-extended to n) * v
+__device__ void add_multiple(u64* acc, int n, const u64* x, int nx, i64 v) {
+    if (v == 0) return;
+    const bool negative = v < 0;
+    const u64 mag = negative ? (u64)(-(v + 1)) + 1 : (u64)v;
+    const u64 fill = (i64)x[nx - 1] < 0 ? ~0ull : 0ull;
+    u64 mul_carry = 0, borrow = 0, carry = 0;
+    for (int w = 0; w < n; ++w) {
+        const u128 prod = (u128)(w < nx ? x[w] : fill) * mag + mul_carry;
+        const u64 term = (u64)prod;
+        mul_carry = (u64)(prod >> 64);
+        if (negative) {
+            const u64 t = acc[w] - term;
+            const u64 r = t - borrow;
+            borrow = (acc[w] < term || t < borrow) ? 1 : 0;
+            acc[w] = r;
+        } else {
+            const u64 t = acc[w] + term;
+            const u64 r = t + carry;
+            carry = (t < term || r < t) ? 1 : 0;
+            acc[w] = r;
+        }
+    }
+}
+__device__ int bit_length(const u64* x, int n) {  // of |x|
+    const bool negative = (i64)x[n - 1] < 0;
+    if (!negative) {
+        for (int w = n - 1; w >= 0; --w)
+            if (x[w] != 0) return 64 * w + (64 - __clzll((long long)x[w]));
+        return 0;
+    }
+    int top = -1;
+    for (int w = n - 1; w >= 0; --w)
+        if (x[w] != ~0ull) { top = w; break; }
+    if (top < 0) return 1;  // -1
+    const u64 inverted = ~x[top];
+    int bits = 64 * top + (64 - __clzll((long long)inverted));
+    bool zeros_below = true;
+    for (int w = 0; w < top; ++w) zeros_below = zeros_below && x[w] == 0;
+    if (zeros_below && (inverted & (inverted + 1)) == 0) bits += 1;  // -(2^k)
+    return bits;
+}
+// out = a * b modulo 2^(64 n) (Comba, column sums in three words); out distinct from a and b
+__device__ void mul_low(const u64* a, int na, const u64* b, int nb, u64* out, int n) {
+    u64 c0 = 0, c1 = 0, c2 = 0;
+    for (int t = 0; t < n; ++t) {
+        for (int i = max(0, t - nb + 1); i <= min(t, na - 1); ++i) {
+            const u128 prod = (u128)a[i] * b[t - i];
+            const u64 lo = (u64)prod, hi = (u64)(prod >> 64);
+            const u64 s0 = c0 + lo;
+            const u64 k0 = s0 < lo ? 1 : 0;
+            const u64 s1 = c1 + hi;
+            const u64 k1 = s1 < hi ? 1 : 0;
+            const u64 s1b = s1 + k0;
+            const u64 k1b = s1b < k0 ? 1 : 0;
+            c0 = s0;
+            c1 = s1b;
+            c2 += k1 + k1b;
+        }
+        out[t] = c0;
+        c0 = c1;
+        c1 = c2;
+        c2 = 0;
+    }
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------------------------
+// FTRAN numerators: out_i = sum_e v_e N(i, r_e), W + 2 words each (a thread per row)
+__global__ void bix_left_kernel(const u64* N, int m, int W, int nnz, const int* rows, const i64* values, u64* out, int first_row, int n_rows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows) return;
+    const int i = first_row + t;
+    u64* acc = out + (size_t)t * (W + 2);
+    for (int w = 0; w < W + 2; ++w) acc[w] = 0;
+    for (int e = 0; e < nnz; ++e) add_multiple(acc, W + 2, N + ((size_t)i * m + rows[e]) * W, W, values[e]);
+}
+// BTRAN numerators: out_k = sum_e v_e N(r_e, k) (a thread per column of N)
+__global__ void bix_right_kernel(const u64* N, int m, int W, int nnz, const int* rows, const i64* values, u64* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    u64* acc = out + (size_t)k * (W + 2);
+    for (int w = 0; w < W + 2; ++w) acc[w] = 0;
+    for (int e = 0; e < nnz; ++e) add_multiple(acc, W + 2, N + ((size_t)rows[e] * m + k) * W, W, values[e]);
+}
+__global__ void bix_bits_kernel(const u64* x, long long count, int words, int* bits) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) bits[t] = bit_length(x + (size_t)t * words, words);
+}
+// the fit test of a pivot, from bit lengths alone: the largest bound over the entries (atomicMax into *worst).  What is formed modulo
+// 2^(64 W) is 2^s N' = (alpha~_p N_ik - alpha~_i N_pk) / D_odd, never longer than the numerator itself: its bound is the test's.
+__global__ void bix_fit_kernel(const int* N_bits, const int* alpha_bits, int m, int p, int scale_bits, int* worst) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)m * m) return;
+    const int i = (int)(t / m), k = (int)(t - (long long)i * m);
+    int bound;
+    if (i == p) bound = N_bits[t] + scale_bits;  // row p stays, times the entering column's scale
+    else bound = max(alpha_bits[p] + N_bits[t], alpha_bits[i] + N_bits[(size_t)p * m + k]) + 1;
+    atomicMax(worst, bound);
+}
+// one thread: D = 2^s D_odd, u = 1 / D_odd modulo 2^(64 W) by Newton's doubling (scratch: 3 W words), c1 = alpha~_p u; *shift_out = s
+__global__ void bix_scalars_kernel(const u64* D, int W, const u64* alpha_p /* W words */, u64* u, u64* c1, u64* scratch, int* shift_out) {
+    u64* d_odd = scratch;
+    u64* t = scratch + W;
+    u64* x2 = scratch + 2 * W;
+    int low = 0;
+    while (low < W - 1 && D[low] == 0) ++low;
+    const int bs = __ffsll((long long)D[low]) - 1, shift = 64 * low + bs;
+    for (int w = 0; w < W; ++w) {
+        const u64 lo = w + low < W ? D[w + low] : 0ull, hi = w + low + 1 < W ? D[w + low + 1] : 0ull;
+        d_odd[w] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+    }
+    u64 inv = d_odd[0];  // d * d = 1 (mod 8): three correct bits, doubled five times
+    for (int k = 0; k < 5; ++k) inv *= 2 - d_odd[0] * inv;
+    u[0] = inv;
+    for (int have = 1; have < W; have *= 2) {
+        const int want = min(2 * have, W);
+        mul_low(d_odd, want, u, have, t, want);
+        u64 carry = 3;  // t <- 2 - t = ~t + 3
+        for (int w = 0; w < want; ++w) {
+            const u128 sum = (u128)(~t[w]) + carry;
+            t[w] = (u64)sum;
+            carry = (u64)(sum >> 64);
+        }
+        mul_low(t, want, u, have, x2, want);
+        for (int w = 0; w < want; ++w) u[w] = x2[w];
+    }
+    mul_low(alpha_p, W, u, W, c1, W);
+    *shift_out = shift;
+}
+// the rows' factors r_i = -(alpha~_i u) modulo 2^(64 W) (a thread per row; alpha holds W + 2 words per row of which W are significant)
+__global__ void bix_factors_kernel(const u64* alpha, const u64* u, int m, int W, u64* factors) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    u64* r = factors + (size_t)i * W;
+    mul_low(alpha + (size_t)i * (W + 2), W, u, W, r, W);
+    bool carry = true;  // two's complement
+    for (int w = 0; w < W; ++w) {
+        const u64 v = ~r[w] + (carry ? 1ull : 0ull);
+        carry = carry && r[w] == 0;
+        r[w] = v;
+    }
+}
+// the pivot, a thread per entry: N'(i, k) = (c1 N(i, k) + r_i N(p, k)) modulo 2^(64 W), shifted right by s, negated on a flip; row p copied
+// and multiplied by the entering column's scale (`scale`: the true column is c / scale, see the header)
+__global__ void bix_pivot_kernel(const u64* N, u64* out, int m, int W, int p, const u64* c1, const u64* factors, const int* shift_in, int flip, i64 scale) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)m * m) return;
+    const int i = (int)(t / m), k = (int)(t - (long long)i * m);
+    const u64* x = N + (size_t)t * W;
+    u64* o = out + (size_t)t * W;
+    if (i == p) {
+        for (int w = 0; w < W; ++w) o[w] = 0;
+        add_multiple(o, W, x, W, flip ? -scale : scale);
+        return;
+    }
+    const u64* y = N + ((size_t)p * m + k) * W;
+    const u64* r = factors + (size_t)i * W;
+    u64 a0 = 0, a1 = 0, a2 = 0;
+    auto accumulate = [&](u64 f, u64 g) {
+        const u128 prod = (u128)f * g;
+        const u64 lo = (u64)prod, hi = (u64)(prod >> 64);
+        const u64 s0 = a0 + lo;
+        const u64 k0 = s0 < lo ? 1 : 0;
+        const u64 s1 = a1 + hi;
+        const u64 k1 = s1 < hi ? 1 : 0;
+        const u64 s1b = s1 + k0;
+        const u64 k1b = s1b < k0 ? 1 : 0;
+        a0 = s0;
+        a1 = s1b;
+        a2 += k1 + k1b;
+    };
+    for (int word = 0; word < W; ++word) {
+        for (int a = 0; a <= word; ++a) {
+            accumulate(c1[a], x[word - a]);
+            accumulate(r[a], y[word - a]);
+        }
+        o[word] = a0;
+        a0 = a1;
+        a1 = a2;
+        a2 = 0;
+    }
+    // 2^s N' modulo 2^(64 W): shift right by s, sign-extended from bit 64 W - 1
+    const int shift = *shift_in, ws = shift >> 6, bs = shift & 63;
+    const u64 fill = (i64)o[W - 1] < 0 ? ~0ull : 0ull;
+    for (int w = 0; w < W; ++w) {
+        const u64 lo = w + ws < W ? o[w + ws] : fill, hi = w + ws + 1 < W ? o[w + ws + 1] : fill;
+        o[w] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+    }
+    if (flip) {
+        bool carry = true;
+        for (int w = 0; w < W; ++w) {
+            const u64 v = ~o[w] + (carry ? 1ull : 0ull);
+            carry = carry && o[w] == 0;
+            o[w] = v;
+        }
+    }
+}
+// D' = |alpha~_p| (one thread)
+__global__ void bix_new_denominator_kernel(const u64* alpha_p, int W, int flip, u64* D) {
+    bool carry = true;
+    for (int w = 0; w < W; ++w) {
+        u64 v = alpha_p[w];
+        if (flip) {
+            v = ~alpha_p[w] + (carry ? 1ull : 0ull);
+            carry = carry && alpha_p[w] == 0;
+        }
+        D[w] = v;
+    }
+}
+// sign extension of `count` integers from `from` to `to` words
+__global__ void bix_widen_kernel(const u64* src, u64* dst, long long count, int from, int to) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const u64* s = src + (size_t)t * from;
+    u64* d = dst + (size_t)t * to;
+    const u64 fill = (i64)s[from - 1] < 0 ? ~0ull : 0ull;
+    for (int w = 0; w < to; ++w) d[w] = w < from ? s[w] : fill;
+}
+// rows of N permuted: out(row j) = N(row source[j])
+__global__ void bix_permute_rows_kernel(const u64* N, u64* out, int m, int W, const int* source) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)m * m) return;
+    const int j = (int)(t / m), k = (int)(t - (long long)j * m);
+    const u64* s = N + ((size_t)source[j] * m + k) * W;
+    u64* d = out + (size_t)t * W;
+    for (int w = 0; w < W; ++w) d[w] = s[w];
+}
+// out (n_out words) = x (W words, positive) * v (v > 0): the denominators D * scale
+__global__ void bix_scaled_copy_kernel(const u64* x, int W, i64 v, u64* out, int n_out) {
+    for (int w = 0; w < n_out; ++w) out[w] = 0;
+    add_multiple(out, n_out, x, W, v);
+}
+
+i64 lcm_checked(i64 a, i64 b) {
+    auto gcd = [](i64 x, i64 y) {
+        while (y) { const i64 t = x % y; x = y; y = t; }
+        return x < 0 ? -x : x;
+    };
+    const i64 g = gcd(a, b);
+    const __int128 l = (__int128)(a / g) * b;
+    if (l >= ((__int128)1 << 62)) throw RatOverflow();
+    return (i64)l;
+}
+int launch_blocks(long long threads) { return (int)std::max<long long>(1, (threads + 127) / 128); }
+
+}  // namespace
+
+class ExactBasisInverse {
+public:
+    ExactBasisInverse(int device, int m) : device_(device), m_(m) {
+        if (m < 1) throw std::invalid_argument("BasisInverse::identity: m >= 1");
+        RELP_HIP(hipSetDevice(device_));
+        allocate(1);
+        std::vector<u64> identity((size_t)m * m, 0ull);
+        for (int i = 0; i < m; ++i) identity[(size_t)i * m + i] = 1;
+        RELP_HIP(hipMemcpy(N_, identity.data(), identity.size() * sizeof(u64), hipMemcpyHostToDevice));
+        const u64 one = 1;
+        RELP_HIP(hipMemcpy(D_, &one, sizeof(u64), hipMemcpyHostToDevice));
+    }
+    ~ExactBasisInverse() { release(); }
+    ExactBasisInverse(const ExactBasisInverse&) = delete;
+    ExactBasisInverse& operator=(const ExactBasisInverse&) = delete;
+
+    int m() const { return m_; }
+    int words() const { return W_; }
+    int result_words() const { return W_ + 2; }
+
+    // `BasisInverse::invert` (carry/mod.rs:89-92): the columns in basis order.  Column j is brought into the identity basis by an
+    // integer-preserving pivot on the lowest free row with a non-zero element; the rows are put in basis order at the end.
+    void invert(const long long* column_start, const int* row_index, const long long* num, const long long* den) {
+        std::vector<int> row_of_column(m_, -1);
+        std::vector<char> taken(m_, 0);
+        std::vector<u64> numerators;
+        for (int j = 0; j < m_; ++j) {
+            const int nnz = (int)(column_start[j + 1] - column_start[j]);
+            left_multiply(nnz, row_index + column_start[j], num + column_start[j], den + column_start[j], nullptr, nullptr);
+            download_alpha(numerators);
+            int row = -1;
+            for (int i = 0; i < m_ && row < 0; ++i) {
+                if (taken[i]) continue;
+                bool nonzero = false;
+                for (int w = 0; w < W_ + 2; ++w) nonzero = nonzero || numerators[(size_t)i * (W_ + 2) + w] != 0;
+                if (nonzero) row = i;
+            }
+            if (row < 0) throw std::runtime_error("BasisInverse::invert: the columns are singular");
+            change_basis(row);
+            taken[row] = 1;
+            row_of_column[j] = row;
+        }
+        // row j of B^-1 belongs to the basis column at position j
+        int* d_source = nullptr;
+        RELP_HIP(hipMalloc((void**)&d_source, m_ * sizeof(int)));
+        RELP_HIP(hipMemcpy(d_source, row_of_column.data(), m_ * sizeof(int), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bix_permute_rows_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, N2_, m_, W_, d_source);
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipDeviceSynchronize());
+        (void)hipFree(d_source);
+        std::swap(N_, N2_);
+        have_column_ = false;
+    }
+
+    // `left_multiply_by_basis_inverse` (carry/mod.rs:123-129): B^-1 c = numerators / denominator.  Keeps alpha~ for change_basis.
+    void left_multiply(int nnz, const int* rows, const long long* num, const long long* den, u64* numerators_out, u64* denominator_out) {
+        std::vector<i64> scaled;
+        const i64 scale = scale_column(nnz, rows, num, den, scaled);
+        for (;;) {
+            upload_column(nnz, rows, scaled);
+            hipLaunchKernelGGL(bix_left_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, N_, m_, W_, nnz, d_rows_, d_values_, alpha_, 0, m_);
+            RELP_HIP(hipGetLastError());
+            // alpha~ must fit the width it is multiplied at
+            hipLaunchKernelGGL(bix_bits_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, alpha_, (long long)m_, W_ + 2, alpha_bits_);
+            std::vector<int> bits(m_);
+            RELP_HIP(hipMemcpy(bits.data(), alpha_bits_, m_ * sizeof(int), hipMemcpyDeviceToHost));
+            if (*std::max_element(bits.begin(), bits.end()) < 64 * W_ - 3) break;
+            widen();
+        }
+        alpha_scale_ = scale;
+        have_column_ = true;
+        if (numerators_out) RELP_HIP(hipMemcpy(numerators_out, alpha_, (size_t)m_ * (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
+        if (denominator_out) denominator(scale, denominator_out);
+    }
+    // `right_multiply_by_basis_inverse` (carry/mod.rs:135-141): r B^-1
+    void right_multiply(int nnz, const int* index, const long long* num, const long long* den, u64* numerators_out, u64* denominator_out) {
+        std::vector<i64> scaled;
+        const i64 scale = scale_column(nnz, index, num, den, scaled);
+        upload_column(nnz, index, scaled);
+        hipLaunchKernelGGL(bix_right_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, N_, m_, W_, nnz, d_rows_, d_values_, row_out_);
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipMemcpy(numerators_out, row_out_, (size_t)m_ * (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
+        denominator(scale, denominator_out);
+    }
+    // `basis_inverse_row` (carry/mod.rs:165)
+    void basis_inverse_row(int row, u64* numerators_out, u64* denominator_out) {
+        if (row < 0 || row >= m_) throw std::invalid_argument("basis_inverse_row: row out of range");
+        const int one_row = row;
+        const long long one = 1;
+        right_multiply(1, &one_row, &one, &one, numerators_out, denominator_out);
+    }
+    // `generate_element` (carry/mod.rs:150-157): element i of B^-1 c
+    bool generate_element(int i, int nnz, const int* rows, const long long* num, const long long* den, u64* numerator_out, u64* denominator_out) {
+        if (i < 0 || i >= m_) throw std::invalid_argument("generate_element: row out of range");
+        std::vector<i64> scaled;
+        const i64 scale = scale_column(nnz, rows, num, den, scaled);
+        upload_column(nnz, rows, scaled);
+        hipLaunchKernelGGL(bix_left_kernel, dim3(1), dim3(64), 0, 0, N_, m_, W_, nnz, d_rows_, d_values_, row_out_, i, 1);
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipMemcpy(numerator_out, row_out_, (size_t)(W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
+        denominator(scale, denominator_out);
+        bool nonzero = false;
+        for (int w = 0; w < W_ + 2; ++w) nonzero = nonzero || numerator_out[w] != 0;
+        return nonzero;
+    }
+    // `change_basis` (carry/mod.rs:104-108): the column of the last left_multiply replaces the basis column of row p
+    void change_basis(int p) {
+        if (!have_column_) throw std::logic_error("change_basis without a preceding left_multiply_by_basis_inverse");
+        if (p < 0 || p >= m_) throw std::invalid_argument("change_basis: row out of range");
+        int scale_bits = 0;
+        for (i64 s = alpha_scale_; s > 0; s >>= 1) ++scale_bits;
+        for (;;) {  // (a bound that reaches the width: widen and form alpha~ again)
+            std::vector<u64> alpha_p(W_ + 2);
+            RELP_HIP(hipMemcpy(alpha_p.data(), alpha_ + (size_t)p * (W_ + 2), (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
+            bool zero = true;
+            for (u64 w : alpha_p) zero = zero && w == 0;
+            if (zero) throw std::runtime_error("change_basis: the pivot element is zero (the new basis is singular)");
+            const int flip = (i64)alpha_p[W_ + 1] < 0 ? 1 : 0;
+            hipLaunchKernelGGL(bix_bits_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, (long long)m_ * m_, W_, N_bits_);
+            RELP_HIP(hipMemset(scalar_bits_, 0, sizeof(int)));
+            hipLaunchKernelGGL(bix_fit_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_bits_, alpha_bits_, m_, p, scale_bits, scalar_bits_);
+            int worst = 0;
+            RELP_HIP(hipMemcpy(&worst, scalar_bits_, sizeof(int), hipMemcpyDeviceToHost));
+            if (worst >= 64 * W_ - 3) {
+                widen();
+                relaunch_alpha();
+                continue;
+            }
+            hipLaunchKernelGGL(bix_scalars_kernel, dim3(1), dim3(1), 0, 0, D_, W_, alpha_ + (size_t)p * (W_ + 2), u_, c1_, scratch_, shift_);
+            hipLaunchKernelGGL(bix_factors_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, alpha_, u_, m_, W_, factors_);
+            hipLaunchKernelGGL(bix_pivot_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, N2_, m_, W_, p, c1_, factors_, shift_, flip, (i64)alpha_scale_);
+            hipLaunchKernelGGL(bix_new_denominator_kernel, dim3(1), dim3(1), 0, 0, alpha_ + (size_t)p * (W_ + 2), W_, flip, D_);
+            RELP_HIP(hipGetLastError());
+            RELP_HIP(hipDeviceSynchronize());
+            std::swap(N_, N2_);
+            have_column_ = false;
+            return;
+        }
+    }
+
+private:
+    int device_, m_, W_ = 0;
+    u64 *N_ = nullptr, *N2_ = nullptr, *D_ = nullptr, *alpha_ = nullptr, *row_out_ = nullptr, *u_ = nullptr, *c1_ = nullptr, *factors_ = nullptr, *scratch_ = nullptr;
+    int *N_bits_ = nullptr, *alpha_bits_ = nullptr, *scalar_bits_ = nullptr, *shift_ = nullptr, *d_rows_ = nullptr;
+    i64* d_values_ = nullptr;
+    int column_capacity_ = 0;
+    bool have_column_ = false;
+    i64 alpha_scale_ = 1;
+    std::vector<int> last_rows_;
+    std::vector<i64> last_values_;
+
+    template <class T>
+    static T* dmalloc(size_t count) {
+        void* p = nullptr;
+        RELP_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+        RELP_HIP(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+        return reinterpret_cast<T*>(p);
+    }
+    void allocate(int W) {
+        W_ = W;
+        const size_t mm = (size_t)m_ * m_;
+        N_ = dmalloc<u64>(mm * W);
+        N2_ = dmalloc<u64>(mm * W);
+        D_ = dmalloc<u64>(W);
+        alpha_ = dmalloc<u64>((size_t)m_ * (W + 2));
+        row_out_ = dmalloc<u64>((size_t)m_ * (W + 2));
+        u_ = dmalloc<u64>(W);
+        c1_ = dmalloc<u64>(W);
+        factors_ = dmalloc<u64>((size_t)m_ * W);
+        scratch_ = dmalloc<u64>(3 * (size_t)W);
+        if (!N_bits_) {
+            N_bits_ = dmalloc<int>(mm);
+            alpha_bits_ = dmalloc<int>(m_);
+            scalar_bits_ = dmalloc<int>(4);
+            shift_ = dmalloc<int>(4);
+        }
+    }
+    void release_width() {
+        for (u64** p : {&N_, &N2_, &D_, &alpha_, &row_out_, &u_, &c1_, &factors_, &scratch_}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+    }
+    void release() {
+        (void)hipSetDevice(device_);
+        release_width();
+        for (int** p : {&N_bits_, &alpha_bits_, &scalar_bits_, &shift_, &d_rows_}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        if (d_values_) (void)hipFree(d_values_);
+        d_values_ = nullptr;
+    }
+    // twice the words: N and D sign-extended; alpha~ is formed again by the caller
+    void widen() {
+        if (2 * W_ > BIX_MAX_WORDS) throw RatOverflow();
+        u64 *old_N = N_, *old_N2 = N2_, *old_D = D_, *old_alpha = alpha_, *old_row = row_out_, *old_u = u_, *old_c1 = c1_, *old_f = factors_, *old_s = scratch_;
+        const int from = W_;
+        N_ = N2_ = D_ = alpha_ = row_out_ = u_ = c1_ = factors_ = scratch_ = nullptr;
+        allocate(2 * from);
+        hipLaunchKernelGGL(bix_widen_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, old_N, N_, (long long)m_ * m_, from, W_);
+        hipLaunchKernelGGL(bix_widen_kernel, dim3(1), dim3(1), 0, 0, old_D, D_, 1LL, from, W_);
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipDeviceSynchronize());
+        for (u64* p : {old_N, old_N2, old_D, old_alpha, old_row, old_u, old_c1, old_f, old_s}) (void)hipFree(p);
+    }
+    i64 scale_column(int nnz, const int* rows, const long long* num, const long long* den, std::vector<i64>& scaled) {
+        if (nnz < 0 || (nnz > 0 && (!rows || !num || !den))) throw std::invalid_argument("sparse vector: bad pointers");
+        i64 scale = 1;
+        for (int e = 0; e < nnz; ++e) {
+            if (rows[e] < 0 || rows[e] >= m_) throw std::invalid_argument("sparse vector: index out of range");
+            if (den[e] <= 0) throw std::invalid_argument("sparse vector: denominators must be positive");
+            scale = lcm_checked(scale, den[e]);
+        }
+        scaled.resize(nnz);
+        for (int e = 0; e < nnz; ++e) {
+            const __int128 v = (__int128)num[e] * (scale / den[e]);
+            if (v >= ((__int128)1 << 62) || v <= -((__int128)1 << 62)) throw RatOverflow();
+            scaled[e] = (i64)v;
+        }
+        return scale;
+    }
+    void upload_column(int nnz, const int* rows, const std::vector<i64>& values) {
+        if (nnz > column_capacity_) {
+            if (d_rows_) (void)hipFree(d_rows_);
+            if (d_values_) (void)hipFree(d_values_);
+            column_capacity_ = std::max(nnz, 2 * column_capacity_ + 8);
+            d_rows_ = dmalloc<int>(column_capacity_);
+            d_values_ = dmalloc<i64>(column_capacity_);
+        }
+        if (nnz > 0) {
+            RELP_HIP(hipMemcpy(d_rows_, rows, nnz * sizeof(int), hipMemcpyHostToDevice));
+            RELP_HIP(hipMemcpy(d_values_, values.data(), nnz * sizeof(i64), hipMemcpyHostToDevice));
+        }
+        last_rows_.assign(rows, rows + nnz);
+        last_values_ = values;
+    }
+    void relaunch_alpha() {  // alpha~ again at the new width (the column of the last left_multiply)
+        const int nnz = (int)last_rows_.size();
+        hipLaunchKernelGGL(bix_left_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, N_, m_, W_, nnz, d_rows_, d_values_, alpha_, 0, m_);
+        hipLaunchKernelGGL(bix_bits_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, alpha_, (long long)m_, W_ + 2, alpha_bits_);
+        RELP_HIP(hipGetLastError());
+    }
+    void download_alpha(std::vector<u64>& out) {
+        out.resize((size_t)m_ * (W_ + 2));
+        RELP_HIP(hipMemcpy(out.data(), alpha_, out.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    }
+    void denominator(i64 scale, u64* out) {  // D * scale, W + 2 words
+        hipLaunchKernelGGL(bix_scaled_copy_kernel, dim3(1), dim3(1), 0, 0, D_, W_, scale, scratch_denominator(), W_ + 2);
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipMemcpy(out, scratch_denominator(), (size_t)(W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
+    }
+    u64* scratch_denominator() { return row_out_; }  // (read back before the next use; row results are copied out first)
+};
+
+}  // namespace relp
+
+// ---- extern "C" (include/relp_amd.h, section "BasisInverse over exact rationals") ------------------------------------------------
+using namespace relp;
+
+struct relp_basis_inverse_exact {
+    std::unique_ptr<ExactBasisInverse> object;
+    std::string error;
+};
+
+namespace {
+thread_local std::string g_bix_error;
+template <class F>
+int32_t guarded_bix(relp_basis_inverse_exact* h, F&& f) {
+    auto note = [&](const char* what) {
+        g_bix_error = what;
+        if (h) h->error = what;
+    };
+    try {
+        f();
+        return RELP_OK;
+    } catch (const DeviceError& e) {
+        note(e.what());
+        return RELP_ERR_DEVICE;
+    } catch (const RatOverflow& e) {
+        note(e.what());
+        return RELP_ERR_OVERFLOW;
+    } catch (const std::invalid_argument& e) {
+        note(e.what());
+        return RELP_ERR_ARGUMENT;
+    } catch (const std::logic_error& e) {
+        note(e.what());
+        return RELP_ERR_STATE;
+    } catch (const std::exception& e) {
+        note(e.what());
+        return RELP_ERR_NUMERICAL;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int32_t relp_bix_identity(int32_t device, int32_t m, relp_basis_inverse_exact** out) {
+    if (!out) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    auto handle = std::make_unique<relp_basis_inverse_exact>();
+    const int32_t status = guarded_bix(nullptr, [&] { handle->object = std::make_unique<ExactBasisInverse>(device, m); });
+    if (status == RELP_OK) *out = handle.release();
+    return status;
+}
+int32_t relp_bix_invert(int32_t device, int32_t m, const int64_t* column_start, const int32_t* row_index, const int64_t* value_num, const int64_t* value_den,
+                        relp_basis_inverse_exact** out) {
+    if (!out || !column_start || (column_start[m > 0 ? m : 0] > 0 && (!row_index || !value_num || !value_den))) return RELP_ERR_ARGUMENT;
+    *out = nullptr;
+    auto handle = std::make_unique<relp_basis_inverse_exact>();
+    const int32_t status = guarded_bix(nullptr, [&] {
+        handle->object = std::make_unique<ExactBasisInverse>(device, m);
+        handle->object->invert((const long long*)column_start, row_index, (const long long*)value_num, (const long long*)value_den);
+    });
+    if (status == RELP_OK) *out = handle.release();
+    return status;
+}
+int32_t relp_bix_free(relp_basis_inverse_exact* bi) {
+    delete bi;
+    return RELP_OK;
+}
+const char* relp_bix_last_error(const relp_basis_inverse_exact* bi) { return bi ? bi->error.c_str() : g_bix_error.c_str(); }
+int32_t relp_bix_m(const relp_basis_inverse_exact* bi, int32_t* m) {
+    if (!bi || !m) return RELP_ERR_ARGUMENT;
+    *m = bi->object->m();
+    return RELP_OK;
+}
+int32_t relp_bix_result_words(const relp_basis_inverse_exact* bi, int32_t* words) {
+    if (!bi || !words) return RELP_ERR_ARGUMENT;
+    *words = bi->object->result_words();
+    return RELP_OK;
+}
+#define BIX_RESULT(bi, capacity_words)                                                   \
+    if (!bi || !numerators || !denominator || !words) return RELP_ERR_ARGUMENT;          \
+    *words = bi->object->result_words();                                                 \
+    if (capacity_words < *words) return RELP_ERR_ARGUMENT;
+int32_t relp_bix_left_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* row_index, const int64_t* value_num, const int64_t* value_den,
+                               int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
+    BIX_RESULT(bi, capacity_words);
+    // (a width that alpha~ does not fit doubles the words: the result then needs more room than *words said -- form it, then check)
+    const int32_t status = guarded_bix(bi, [&] { bi->object->left_multiply(nnz, row_index, (const long long*)value_num, (const long long*)value_den, nullptr, nullptr); });
+    if (status != RELP_OK) return status;
+    *words = bi->object->result_words();
+    if (capacity_words < *words) return RELP_ERR_ARGUMENT;
+    return guarded_bix(bi, [&] { bi->object->left_multiply(nnz, row_index, (const long long*)value_num, (const long long*)value_den, (unsigned long long*)numerators, (unsigned long long*)denominator); });
+}
+int32_t relp_bix_right_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* index, const int64_t* value_num, const int64_t* value_den,
+                                int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
+    BIX_RESULT(bi, capacity_words);
+    return guarded_bix(bi, [&] { bi->object->right_multiply(nnz, index, (const long long*)value_num, (const long long*)value_den, (unsigned long long*)numerators, (unsigned long long*)denominator); });
+}
+int32_t relp_bix_basis_inverse_row(relp_basis_inverse_exact* bi, int32_t row, int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
+    BIX_RESULT(bi, capacity_words);
+    return guarded_bix(bi, [&] { bi->object->basis_inverse_row(row, (unsigned long long*)numerators, (unsigned long long*)denominator); });
+}
+int32_t relp_bix_generate_element(relp_basis_inverse_exact* bi, int32_t i, int32_t nnz, const int32_t* row_index, const int64_t* value_num, const int64_t* value_den,
+                                  int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words, int32_t* is_some) {
+    BIX_RESULT(bi, capacity_words);
+    if (!is_some) return RELP_ERR_ARGUMENT;
+    return guarded_bix(bi, [&] {
+        *is_some = bi->object->generate_element(i, nnz, row_index, (const long long*)value_num, (const long long*)value_den, (unsigned long long*)numerators, (unsigned long long*)denominator) ? 1 : 0;
+    });
+}
+int32_t relp_bix_change_basis(relp_basis_inverse_exact* bi, int32_t pivot_row_index) {
+    if (!bi) return RELP_ERR_ARGUMENT;
+    return guarded_bix(bi, [&] { bi->object->change_basis(pivot_row_index); });
+}
+int32_t relp_bix_should_refactor(relp_basis_inverse_exact* bi, int32_t* should) {
+    if (!bi || !should) return RELP_ERR_ARGUMENT;
+    *should = 0;  // (nothing accumulates: every change of basis leaves the whole inverse, exactly)
+    return RELP_OK;
+}
+
+}  // extern "C"

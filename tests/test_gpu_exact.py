@@ -95,7 +95,11 @@ def test_whole_pivot_sequence_is_the_reference_algorithms(name):
 # Limbs each one needs: 2 STANDATA | 4 SC205 RECIPELP VTP-BASE CZPROB | 8 SCTAP1 BOEING2 | 16 LOTFI BEACONFD BOEING1 STANDMPS |
 # 32 AGG AGG2 AGG3 SCFXM1 | 64 BANDM SCSD1 SCRS8 GFRD-PNC.
 WIDER = ["LOTFI", "SC205", "RECIPELP", "SCTAP1", "BEACONFD", "AGG", "AGG2", "AGG3", "BANDM", "BOEING2", "BOEING1", "SCSD1", "STANDATA",
-         "STANDMPS", "VTP-BASE", "SCFXM1", "SCRS8", "GFRD-PNC", "CZPROB"]
+         "STANDMPS", "VTP-BASE", "SCFXM1", "SCRS8", "GFRD-PNC", "CZPROB",
+         # round 6: two-word steepest-edge weights W sigma_j^2 -- rows that need ten and more decimal digits make W = lcm(r)^2 67 (CAPRI,
+         # ETAMACRO) to 80 (FINNIS) bits, which `relp_solve_exact` refused (RELP_ERR_OVERFLOW) while the reference runs them
+         # (tests/netlib/test.rs:126,155,162)
+         "CAPRI", "ETAMACRO", "FINNIS"]
 
 
 @pytest.mark.parametrize("name", WIDER)
