@@ -617,6 +617,12 @@ int32_t relp_bix_left_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const 
 /* `right_multiply_by_basis_inverse(row)` (carry/mod.rs:135-141): r B^-1. */
 int32_t relp_bix_right_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* index, const int64_t* value_num, const int64_t* value_den,
                                 int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words);
+/* The same for a row vector whose entries are themselves results of earlier solves -- `Carry::change_basis` multiplies B^-1 a_q from the
+ * left (carry/mod.rs:561-604: the work vector of the steepest-edge update), RationalBig values no int64 holds: entry e = integer of
+ * `value_words` two's complement words at values[e * value_words], all over ONE positive denominator of `value_words` words (the
+ * format results come in).  *words = value_words + the object's words + 2. */
+int32_t relp_bix_right_multiply_words(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* index, int32_t value_words, const uint64_t* values,
+                                      const uint64_t* value_denominator, int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words);
 /* `basis_inverse_row(row)` (carry/mod.rs:165). */
 int32_t relp_bix_basis_inverse_row(relp_basis_inverse_exact* bi, int32_t row, int32_t capacity_words, uint64_t* numerators, uint64_t* denominator,
                                    int32_t* words);

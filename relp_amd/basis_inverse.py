@@ -327,9 +327,41 @@ class ExactBasisInverse:
                                                                               _ptr(den, C.c_int64), cap, n, d, w), self.m())
 
     def right_multiply_by_basis_inverse(self, row):
-        nnz, index, num, den = _exact_sparse(row)
-        return self._vector(lambda cap, n, d, w: lib().relp_bix_right_multiply(self._h, nnz, _ptr(index, C.c_int32), _ptr(num, C.c_int64),
-                                                                               _ptr(den, C.c_int64), cap, n, d, w), self.m())
+        """int64 (numerator, denominator) pairs where the vector fits them -- the reference's `Rational64` inputs -- else multi-word integers
+        over one denominator (``relp_bix_right_multiply_words``: the row vectors `Carry::change_basis` forms are `RationalBig`)."""
+        import math
+        from fractions import Fraction
+        pairs = [(int(i), Fraction(v)) for i, v in row]
+        common = 1
+        for _, v in pairs:
+            common = common * v.denominator // math.gcd(common, v.denominator)
+        scaled = [v.numerator * (common // v.denominator) for _, v in pairs]
+        if common < (1 << 61) and all(abs(n) < (1 << 61) for n in scaled):
+            nnz, index, num, den = _exact_sparse(pairs)
+            return self._vector(lambda cap, n, d, w: lib().relp_bix_right_multiply(self._h, nnz, _ptr(index, C.c_int32), _ptr(num, C.c_int64),
+                                                                                   _ptr(den, C.c_int64), cap, n, d, w), self.m())
+        bits = max([common.bit_length()] + [abs(n).bit_length() for n in scaled]) + 2
+        vw = (bits + 63) // 64
+        mask = (1 << (64 * vw)) - 1
+
+        def words_of(value):
+            value &= mask
+            return [(value >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(vw)]
+        values = np.array([w for n in scaled for w in words_of(n)] or [0], dtype=np.uint64)
+        denominator_in = np.array(words_of(common), dtype=np.uint64)
+        index = np.array([i for i, _ in pairs] or [0], dtype=np.int32)
+        m = self.m()
+        capacity = self.result_words() + vw + 2
+        numerators = np.zeros(m * capacity, dtype=np.uint64)
+        denominator = np.zeros(capacity, dtype=np.uint64)
+        words = C.c_int32()
+        self._check(lib().relp_bix_right_multiply_words(self._h, len(pairs), _ptr(index, C.c_int32), vw, _ptr(values, C.c_uint64),
+                                                        _ptr(denominator_in, C.c_uint64), capacity, _ptr(numerators, C.c_uint64),
+                                                        _ptr(denominator, C.c_uint64), C.byref(words)))
+        w = words.value
+        d = _integer(denominator[:w])
+        assert d > 0
+        return [Fraction(_integer(numerators[e * w:(e + 1) * w]), d) for e in range(m)]
 
     def basis_inverse_row(self, row):
         return self._vector(lambda cap, n, d, w: lib().relp_bix_basis_inverse_row(self._h, int(row), cap, n, d, w), self.m())

@@ -244,6 +244,44 @@ __global__ void bix_new_denominator_kernel(const u64* alpha_p, int W, int flip, 
         D[w] = v;
     }
 }
+// BTRAN with multi-word multipliers (the row vectors `Carry::change_basis` forms are results of earlier solves: RationalBig):
+// out_k = sum_e V_e N(r_e, k) modulo 2^(64 n_out), V_e of `vw` two's complement words -- a thread per column of N, Comba over the columns of
+// all the products at once (operands sign-extended on the fly; the ring Z / 2^(64 n_out) takes two's complement as it is)
+__global__ void bix_right_words_kernel(const u64* N, int m, int W, int nnz, const int* rows, const u64* values, int vw, u64* out, int n_out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    u64* acc = out + (size_t)k * n_out;
+    u64 a0 = 0, a1 = 0, a2 = 0;
+    for (int t = 0; t < n_out; ++t) {
+        for (int e = 0; e < nnz; ++e) {
+            const u64* x = N + ((size_t)rows[e] * m + k) * W;
+            const u64* v = values + (size_t)e * vw;
+            const u64 fill_x = (i64)x[W - 1] < 0 ? ~0ull : 0ull, fill_v = (i64)v[vw - 1] < 0 ? ~0ull : 0ull;
+            if (fill_x == 0 && x[0] == 0 && bit_length(x, W) == 0) continue;  // (a zero entry: most of a sparse inverse)
+            for (int a = 0; a <= t; ++a) {
+                const u64 f = a < W ? x[a] : fill_x, g = t - a < vw ? v[t - a] : fill_v;
+                if (f == 0 || g == 0) continue;
+                const u128 prod = (u128)f * g;
+                const u64 lo = (u64)prod, hi = (u64)(prod >> 64);
+                const u64 s0 = a0 + lo;
+                const u64 k0 = s0 < lo ? 1 : 0;
+                const u64 s1 = a1 + hi;
+                const u64 k1 = s1 < hi ? 1 : 0;
+                const u64 s1b = s1 + k0;
+                const u64 k1b = s1b < k0 ? 1 : 0;
+                a0 = s0;
+                a1 = s1b;
+                a2 += k1 + k1b;
+            }
+        }
+        acc[t] = a0;
+        a0 = a1;
+        a1 = a2;
+        a2 = 0;
+    }
+}
+// out (n_out words) = a (na words) * b (nb words), both positive (one thread): the denominator D * d of such a result
+__global__ void bix_product_kernel(const u64* a, int na, const u64* b, int nb, u64* out, int n_out) { mul_low(a, na, b, nb, out, n_out); }
 // sign extension of `count` integers from `from` to `to` words
 __global__ void bix_widen_kernel(const u64* src, u64* dst, long long count, int from, int to) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,6 +391,8 @@ public:
         }
         alpha_scale_ = scale;
         have_column_ = true;
+        column_rows_.assign(rows, rows + nnz);
+        column_values_ = scaled;
         if (numerators_out) RELP_HIP(hipMemcpy(numerators_out, alpha_, (size_t)m_ * (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
         if (denominator_out) denominator(scale, denominator_out);
     }
@@ -365,6 +405,32 @@ public:
         RELP_HIP(hipGetLastError());
         RELP_HIP(hipMemcpy(numerators_out, row_out_, (size_t)m_ * (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
         denominator(scale, denominator_out);
+    }
+    // ... with multi-word multipliers over one denominator (see bix_right_words_kernel): numerators of vw + W + 2 words
+    int right_multiply_words(int nnz, const int* index, int vw, const u64* values, const u64* denominator_in, int capacity_words, u64* numerators_out,
+                             u64* denominator_out) {
+        if (nnz < 0 || vw < 1 || vw > 4 * BIX_MAX_WORDS || (nnz > 0 && (!index || !values)) || !denominator_in) throw std::invalid_argument("sparse vector: bad arguments");
+        for (int e = 0; e < nnz; ++e)
+            if (index[e] < 0 || index[e] >= m_) throw std::invalid_argument("sparse vector: index out of range");
+        const int n_out = W_ + vw + 2;
+        if (capacity_words < n_out) return n_out;
+        u64 *d_values = dmalloc<u64>((size_t)std::max(1, nnz) * vw), *d_den = dmalloc<u64>(vw), *d_out = dmalloc<u64>((size_t)(m_ + 1) * n_out);
+        int* d_index = dmalloc<int>(std::max(1, nnz));
+        struct Free {
+            std::vector<void*> p;
+            ~Free() { for (void* q : p) (void)hipFree(q); }
+        } owned{{d_values, d_den, d_out, d_index}};
+        if (nnz > 0) {
+            RELP_HIP(hipMemcpy(d_values, values, (size_t)nnz * vw * sizeof(u64), hipMemcpyHostToDevice));
+            RELP_HIP(hipMemcpy(d_index, index, nnz * sizeof(int), hipMemcpyHostToDevice));
+        }
+        RELP_HIP(hipMemcpy(d_den, denominator_in, vw * sizeof(u64), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bix_right_words_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, N_, m_, W_, nnz, d_index, d_values, vw, d_out, n_out);
+        hipLaunchKernelGGL(bix_product_kernel, dim3(1), dim3(1), 0, 0, D_, W_, d_den, vw, d_out + (size_t)m_ * n_out, n_out);
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipMemcpy(numerators_out, d_out, (size_t)m_ * n_out * sizeof(u64), hipMemcpyDeviceToHost));
+        RELP_HIP(hipMemcpy(denominator_out, d_out + (size_t)m_ * n_out, (size_t)n_out * sizeof(u64), hipMemcpyDeviceToHost));
+        return n_out;
     }
     // `basis_inverse_row` (carry/mod.rs:165)
     void basis_inverse_row(int row, u64* numerators_out, u64* denominator_out) {
@@ -430,8 +496,8 @@ private:
     int column_capacity_ = 0;
     bool have_column_ = false;
     i64 alpha_scale_ = 1;
-    std::vector<int> last_rows_;
-    std::vector<i64> last_values_;
+    std::vector<int> column_rows_;   // the (scaled) column of the last left_multiply: what change_basis brings into the basis
+    std::vector<i64> column_values_;
 
     template <class T>
     static T* dmalloc(size_t count) {
@@ -516,11 +582,10 @@ private:
             RELP_HIP(hipMemcpy(d_rows_, rows, nnz * sizeof(int), hipMemcpyHostToDevice));
             RELP_HIP(hipMemcpy(d_values_, values.data(), nnz * sizeof(i64), hipMemcpyHostToDevice));
         }
-        last_rows_.assign(rows, rows + nnz);
-        last_values_ = values;
     }
-    void relaunch_alpha() {  // alpha~ again at the new width (the column of the last left_multiply)
-        const int nnz = (int)last_rows_.size();
+    void relaunch_alpha() {  // alpha~ again at the new width (the column of the last left_multiply -- other vectors went through the buffers since)
+        const int nnz = (int)column_rows_.size();
+        upload_column(nnz, column_rows_.data(), column_values_);
         hipLaunchKernelGGL(bix_left_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, N_, m_, W_, nnz, d_rows_, d_values_, alpha_, 0, m_);
         hipLaunchKernelGGL(bix_bits_kernel, dim3(launch_blocks(m_)), dim3(128), 0, 0, alpha_, (long long)m_, W_ + 2, alpha_bits_);
         RELP_HIP(hipGetLastError());
@@ -632,6 +697,18 @@ int32_t relp_bix_right_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const
                                 int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
     BIX_RESULT(bi, capacity_words);
     return guarded_bix(bi, [&] { bi->object->right_multiply(nnz, index, (const long long*)value_num, (const long long*)value_den, (unsigned long long*)numerators, (unsigned long long*)denominator); });
+}
+int32_t relp_bix_right_multiply_words(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* index, int32_t value_words, const uint64_t* values,
+                                      const uint64_t* value_denominator, int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
+    if (!bi || !numerators || !denominator || !words) return RELP_ERR_ARGUMENT;
+    int32_t needed = 0;
+    const int32_t status = guarded_bix(bi, [&] {
+        needed = bi->object->right_multiply_words(nnz, index, value_words, (const unsigned long long*)values, (const unsigned long long*)value_denominator, capacity_words,
+                                                  (unsigned long long*)numerators, (unsigned long long*)denominator);
+    });
+    *words = needed;
+    if (status == RELP_OK && needed > capacity_words) return RELP_ERR_ARGUMENT;
+    return status;
 }
 int32_t relp_bix_basis_inverse_row(relp_basis_inverse_exact* bi, int32_t row, int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
     BIX_RESULT(bi, capacity_words);

@@ -217,6 +217,9 @@ def test_random_rational_updates_against_an_exact_inverse(m, steps, seed):
         assert bi.right_multiply_by_basis_inverse(r) == [sum(dense_r[i] * inverse[i][k] for i in range(m)) for k in range(m)]
         row = rng.randrange(m)
         assert bi.basis_inverse_row(row) == inverse[row]
+        # a row vector that is itself a result (what `Carry::change_basis` multiplies from the left): multi-word numerators over one denominator
+        big = [(i, alpha[i] * F(10 ** 25 + 7, 3)) for i in range(m) if alpha[i] != 0]
+        assert bi.right_multiply_by_basis_inverse(big) == [sum(v * inverse[i][k] for i, v in big) for k in range(m)]
         element = bi.generate_element(row, c)
         assert (element or 0) == alpha[row] and (element is None) == (alpha[row] == 0)
         candidates = [i for i in range(m) if alpha[i] != 0]
