@@ -635,6 +635,10 @@ int32_t relp_bix_generate_element(relp_basis_inverse_exact* bi, int32_t i, int32
 int32_t relp_bix_change_basis(relp_basis_inverse_exact* bi, int32_t pivot_row_index);
 /* `should_refactor()` (carry/mod.rs:163). */
 int32_t relp_bix_should_refactor(relp_basis_inverse_exact* bi, int32_t* should);
+/* `RemoveBasisPart::remove_basis_part(indices)` (carry/mod.rs:176-180; basis_inverse_rows.rs:212-229): rows `indices` and the basis
+ * columns of those rows -- artificial unit columns basic on redundant rows -- leave; what is left is the inverse of the smaller basis
+ * over the same denominator. */
+int32_t relp_bix_remove_basis_part(relp_basis_inverse_exact* bi, int32_t count, const int32_t* indices);
 
 
 /* ---- batches of independent LPs (BASELINE config 4) -------------------------------------------

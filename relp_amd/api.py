@@ -150,7 +150,7 @@ SYMBOLS = [
     "relp_bi_get_factors", "relp_lu_factor_host", "relp_lu_invert_host", "relp_lu_factor_device",
     # BasisInverse over exact rationals (relp_amd/basis_inverse.py: ExactBasisInverse)
     "relp_bix_identity", "relp_bix_invert", "relp_bix_free", "relp_bix_last_error", "relp_bix_m", "relp_bix_result_words", "relp_bix_left_multiply",
-    "relp_bix_right_multiply", "relp_bix_right_multiply_words", "relp_bix_basis_inverse_row", "relp_bix_generate_element", "relp_bix_change_basis", "relp_bix_should_refactor",
+    "relp_bix_right_multiply", "relp_bix_right_multiply_words", "relp_bix_basis_inverse_row", "relp_bix_generate_element", "relp_bix_change_basis", "relp_bix_should_refactor", "relp_bix_remove_basis_part",
     # exact solution vector, variable names, batches of independent LPs
     "relp_get_solution_exact", "relp_get_variable_name",
     "relp_batch_create", "relp_batch_destroy", "relp_batch_workers", "relp_batch_run", "relp_batch_get_objective_exact", "relp_batch_handle",

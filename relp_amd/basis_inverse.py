@@ -381,3 +381,7 @@ class ExactBasisInverse:
         out = C.c_int32()
         self._check(lib().relp_bix_should_refactor(self._h, C.byref(out)))
         return bool(out.value)
+
+    def remove_basis_part(self, indices):
+        idx = np.ascontiguousarray(list(indices), dtype=np.int32)
+        self._check(lib().relp_bix_remove_basis_part(self._h, len(idx), _ptr(idx, C.c_int32)))

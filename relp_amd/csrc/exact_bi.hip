@@ -300,6 +300,15 @@ __global__ void bix_permute_rows_kernel(const u64* N, u64* out, int m, int W, co
     u64* d = out + (size_t)t * W;
     for (int w = 0; w < W; ++w) d[w] = s[w];
 }
+// rows and columns `keep` of N (RemoveBasisPart): out(i', k') = N(keep[i'], keep[k'])
+__global__ void bix_compact_kernel(const u64* N, int m_old, u64* out, int m_new, int W, const int* keep) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)m_new * m_new) return;
+    const int i = (int)(t / m_new), k = (int)(t - (long long)i * m_new);
+    const u64* s = N + ((size_t)keep[i] * m_old + keep[k]) * W;
+    u64* d = out + (size_t)t * W;
+    for (int w = 0; w < W; ++w) d[w] = s[w];
+}
 // out (n_out words) = x (W words, positive) * v (v > 0): the denominators D * scale
 __global__ void bix_scaled_copy_kernel(const u64* x, int W, i64 v, u64* out, int n_out) {
     for (int w = 0; w < n_out; ++w) out[w] = 0;
@@ -486,6 +495,36 @@ public:
             have_column_ = false;
             return;
         }
+    }
+
+    // `RemoveBasisPart::remove_basis_part` (carry/mod.rs:176-180; basis_inverse_rows.rs:212-229): the rows `indices` and the basis columns of
+    // those rows leave.  What leaves are artificial unit columns basic on redundant rows (phase_one.rs:232-278): B = [[B', 0], [C, I]] up to a
+    // permutation, so B'^-1 is B^-1 without those rows and columns, over the same denominator (det B = det B').
+    void remove_basis_part(int count, const int* indices) {
+        if (count < 0 || (count > 0 && !indices)) throw std::invalid_argument("remove_basis_part: bad arguments");
+        std::vector<char> leaves(m_, 0);
+        for (int c = 0; c < count; ++c) {
+            if (indices[c] < 0 || indices[c] >= m_ || leaves[indices[c]]) throw std::invalid_argument("remove_basis_part: index out of range or twice");
+            leaves[indices[c]] = 1;
+        }
+        std::vector<int> keep;
+        for (int i = 0; i < m_; ++i)
+            if (!leaves[i]) keep.push_back(i);
+        if (keep.empty()) throw std::invalid_argument("remove_basis_part: nothing would be left");
+        const int m_old = m_, m_new = (int)keep.size();
+        u64 *old_N = N_, *old_N2 = N2_, *old_D = D_, *old_alpha = alpha_, *old_row = row_out_, *old_u = u_, *old_c1 = c1_, *old_f = factors_, *old_s = scratch_;
+        N_ = N2_ = D_ = alpha_ = row_out_ = u_ = c1_ = factors_ = scratch_ = nullptr;
+        m_ = m_new;
+        allocate(W_);
+        int* d_keep = dmalloc<int>(m_new);
+        RELP_HIP(hipMemcpy(d_keep, keep.data(), m_new * sizeof(int), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bix_compact_kernel, dim3(launch_blocks((long long)m_new * m_new)), dim3(128), 0, 0, old_N, m_old, N_, m_new, W_, d_keep);
+        RELP_HIP(hipMemcpy(D_, old_D, W_ * sizeof(u64), hipMemcpyDeviceToDevice));
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipDeviceSynchronize());
+        (void)hipFree(d_keep);
+        for (u64* p : {old_N, old_N2, old_D, old_alpha, old_row, old_u, old_c1, old_f, old_s}) (void)hipFree(p);
+        have_column_ = false;
     }
 
 private:
@@ -725,6 +764,10 @@ int32_t relp_bix_generate_element(relp_basis_inverse_exact* bi, int32_t i, int32
 int32_t relp_bix_change_basis(relp_basis_inverse_exact* bi, int32_t pivot_row_index) {
     if (!bi) return RELP_ERR_ARGUMENT;
     return guarded_bix(bi, [&] { bi->object->change_basis(pivot_row_index); });
+}
+int32_t relp_bix_remove_basis_part(relp_basis_inverse_exact* bi, int32_t count, const int32_t* indices) {
+    if (!bi) return RELP_ERR_ARGUMENT;
+    return guarded_bix(bi, [&] { bi->object->remove_basis_part(count, indices); });
 }
 int32_t relp_bix_should_refactor(relp_basis_inverse_exact* bi, int32_t* should) {
     if (!bi || !should) return RELP_ERR_ARGUMENT;

@@ -238,6 +238,34 @@ def test_random_rational_updates_against_an_exact_inverse(m, steps, seed):
     assert words[-1] >= words[0]
 
 
+def test_remove_basis_part():  # carry/mod.rs:176-180; basis_inverse_rows.rs:212-229
+    rng = random.Random(5)
+    m, drop = 12, [2, 7]
+    keep = [i for i in range(m) if i not in drop]
+    while True:
+        small = [[F(rng.randint(-5, 5), rng.randint(1, 3)) if rng.random() < 0.4 else F(0) for _ in keep] for _ in keep]
+        for d in range(len(keep)):
+            small[d][d] += F(7)
+        try:
+            inverse = exact_inverse(small)
+            break
+        except StopIteration:
+            continue
+    B = [[F(0)] * m for _ in range(m)]
+    for a, i in enumerate(keep):
+        for b, j in enumerate(keep):
+            B[i][j] = small[a][b]
+    for i in drop:  # what leaves: the unit column of an artificial variable that stayed basic on a redundant row ...
+        B[i][i] = F(1)
+        B[i][keep[0]] = F(3, 2)  # (... whose row may hold entries of the columns that stay)
+    bi = ExactBasisInverse.invert([[(i, B[i][j]) for i in range(m) if B[i][j]] for j in range(m)])
+    bi.remove_basis_part(drop)
+    assert bi.m() == m - len(drop)
+    for r in range(len(keep)):
+        assert bi.basis_inverse_row(r) == inverse[r]
+    assert bi.left_multiply_by_basis_inverse([(0, 1)]) == [inverse[r][0] for r in range(len(keep))]
+
+
 # ---- the oracle's own Carry, every BasisInverse call mirrored on the device with == ------------------------------------------------
 def make_mirrored(log):
     from relp_oracle import BasisInverseRows
@@ -315,6 +343,11 @@ def make_mirrored(log):
             assert self.device.basis_inverse_row(row) == dense_of(exact, self.exact.m()), "row"
             log["row"] += 1
             return exact
+
+        def remove_basis_part(self, indices):
+            log["remove"] += 1
+            self.exact.remove_basis_part(indices)
+            self.device.remove_basis_part(list(indices))
 
     return Mirrored
 
