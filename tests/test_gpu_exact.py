@@ -99,7 +99,10 @@ WIDER = ["LOTFI", "SC205", "RECIPELP", "SCTAP1", "BEACONFD", "AGG", "AGG2", "AGG
          # round 6: two-word steepest-edge weights W sigma_j^2 -- rows that need ten and more decimal digits make W = lcm(r)^2 67 (CAPRI,
          # ETAMACRO) to 80 (FINNIS) bits, which `relp_solve_exact` refused (RELP_ERR_OVERFLOW) while the reference runs them
          # (tests/netlib/test.rs:126,155,162)
-         "CAPRI", "ETAMACRO", "FINNIS"]
+         "CAPRI", "ETAMACRO", "FINNIS",
+         # ... and STAIR, which the reference's own test ignores ("could be cycling", tests/netlib/test.rs:300): it does not cycle -- the compiled
+         # oracle reaches the optimum the test expects in 498 + 204 pivots (oracle/gen_golden_cpp.py wrote the fixture)
+         "STAIR"]
 
 
 @pytest.mark.parametrize("name", WIDER)

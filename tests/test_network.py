@@ -478,6 +478,24 @@ def test_bench_two_ranks_without_a_launcher(workload):
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_on_one_device_print_the_eight_gpu_line():
+    """Round-5 review, item 9: when the driver does get an 8-GPU node, `bench.py --gpus 8` must need no code change.  Here the eight ranks of
+    the driver's invocation share the one device of the box (RELP_BENCH_SHARED_DEVICE=1, gloo for the reductions): BASELINE config 4 -- the
+    Netlib list served from ONE ticket queue in the store -- and the line says n_gpus 8 with the records of all eight ranks."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if torch.cuda.device_count() < 8:
+        env["RELP_BENCH_SHARED_DEVICE"] = "1"
+    from bench_support import run_bench
+    short, line, _ = run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0", "--workload", "netlib", "--no-cpu-baseline", "--no-concurrency-probe"], env=env)
+    assert short["n_gpus"] == 8 and line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["makespan_s"] > 0
+    tickets = line["config"]["tickets_per_rank"]
+    assert len(tickets) == 8 and sum(tickets) == 45 and len(line["config"]["pivots_per_rank"]) == 8
+    assert line["config"]["objectives_outside_reference_tolerance"] == []
+
+
+@pytest.mark.gpu
 def test_bench_more_ranks_than_devices_fails_loudly():
     """`--gpus N` on a box with fewer devices: non-zero exit, no line that claims N GPUs."""
     import subprocess
