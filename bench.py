@@ -694,7 +694,11 @@ def single_lp(args, ctx):
     tag = args.workload + (("_lu" if args.carry == 1 else "_lui") if lu_carry else "")
     if lu_carry and args.lu_refactor == 1:
         tag += "_device_refactor"
-    for candidate in ("r4_%s_pmc_traffic.json" % tag, "r3_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % args.workload,
+    # (round 6: one file per configuration as measured -- the dense block's storage, the max-flow start -- at this round's kernels; the older
+    #  files remain for the configurations not profiled again)
+    this_round = "r6_%s_%s_pmc_traffic.json" % (args.workload, args.dense_storage) if dense else \
+        "r6_maxflow_%s_pmc_traffic.json" % ("crash" if args.crash else "reference_start") if graph and args.workload == "maxflow" else "r6_%s_pmc_traffic.json" % tag
+    for candidate in (this_round, "r4_%s_pmc_traffic.json" % tag, "r3_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % tag, "r2_%s_pmc_traffic.json" % args.workload,
                       "r1_%s_pmc_traffic.json" % args.workload):
         pmc = os.path.join(ROOT, "profiles", candidate)
         if traffic is None and os.path.exists(pmc):
