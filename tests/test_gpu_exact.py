@@ -171,11 +171,14 @@ def test_infeasible_and_unbounded_exactly():
     solver.close()
 
 
+@pytest.mark.parametrize("first_limbs", [1, 16], ids=["from-1-limb", "from-16-limbs"])
 @pytest.mark.parametrize("seed", range(80))
-def test_random_lps_pivot_for_pivot(seed):
+def test_random_lps_pivot_for_pivot(seed, first_limbs):
     """Random LPs with every row kind and rational data: verdict, pivot counts, the WHOLE (phase, q, p, leaving) sequence and the
     exact optimum of the device equal the oracle's -- also on rank-deficient instances, where the reference removes the
-    redundant rows after phase one and counts the remaining ones in phase two (`RemoveRows`)."""
+    redundant rows after phase one and counts the remaining ones in phase two (`RemoveRows`).  Round 6: also started at 16 limbs, where
+    the update runs on the matrix cores with its second pass inside the tiles (short values in wide integers: the sign-fill and
+    bit-length logic of the epilogue; zero-level pivots on negative elements take the two passes in between)."""
     import random
     from fractions import Fraction
     from relp_oracle import FiniteOptimum, Infeasible, MatrixData, Unbounded, Variable
@@ -209,7 +212,7 @@ def test_random_lps_pivot_for_pivot(seed):
     solver = relp_amd.Solver()
     solver.load_matrix_data(column_start, rows, nums, dnms, b=[(v.numerator, v.denominator) for v in b],
                             cost=[(v.numerator, v.denominator) for v in cost], counts=tuple(counts))
-    got = solver.solve_exact(first_limbs=1, max_limbs=32)
+    got = solver.solve_exact(first_limbs=first_limbs, max_limbs=32)
     assert got["status"] != 6          # rank-deficient LPs are carried through (the redundant rows keep their artificial)
     n_art = solver.n_art
     if isinstance(exact, FiniteOptimum):
