@@ -789,6 +789,16 @@ __device__ __forceinline__ int wave_sign_of_difference(const u64* a, int la, con
 
 // The grid barrier of the cooperative launch: grid_barrier.hpp (per-die counting, one release fence per XCD, a watchdog that ends the
 // launch instead of hanging the device when the workgroups' barrier counts ever differ).
+// One LDS arena for the steps of a pivot that follow each other behind barriers -- the tournament's keys (41 KB at 128 limbs), the exact
+// weights' magnitudes, the entering column's rows, the update's operand images (44 KB since round 6's sixteen copies): as objects of
+// their own they added up to 99 KB a workgroup, ONE workgroup per CU instead of two, and the tiles ran at half the waves.
+template <int L>
+constexpr size_t exact_arena_bytes() { return (size_t)328 * L + 2064 + 64; }  // sizeof(UpdateLds<L>) (asserted where it is used) >= the others
+template <int L>
+__device__ __forceinline__ unsigned char* exact_arena() {
+    __shared__ __attribute__((aligned(16))) unsigned char s_arena[exact_arena_bytes<L>()];
+    return s_arena;
+}
 constexpr int EX_GAMMA_BATCH = 64;  // tied candidates whose exact weights are formed at a time (gamma_terms)
 constexpr int EX_PRODUCT_SLOTS = EX_GAMMA_BATCH;  // columns whose exact products N a_j price_a holds at a time
 
@@ -1019,7 +1029,8 @@ __device__ __forceinline__ int wave_compare_keys(const u64* ca, const u64* gamma
 template <int L>
 __device__ __noinline__ void exact_weight_terms(const ExactLP& lp, int c0, int batch) {
     constexpr int GW = 2 * L + 2;
-    __shared__ u64 s_magnitude[EX_THREADS / WAVE][L];
+    static_assert(sizeof(u64) * (EX_THREADS / WAVE) * L <= exact_arena_bytes<L>(), "arena");
+    u64 (*s_magnitude)[L] = reinterpret_cast<u64 (*)[L]>(exact_arena<L>());
     const int m = lp.m, lane = threadIdx.x & (WAVE - 1);
     const long long wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
     u64* magnitude = s_magnitude[threadIdx.x / WAVE];
@@ -1051,7 +1062,8 @@ __device__ __noinline__ void exact_weight_terms(const ExactLP& lp, int c0, int b
 // its registers' sake (the sums of a 4 L-word product a lane per word)
 template <int L>
 __device__ __noinline__ void tournament_round(const ExactLP& lp, int n_cand, int stride) {
-    __shared__ u64 s_keys[EX_THREADS / WAVE][10 * L + 4];
+    static_assert(sizeof(u64) * (EX_THREADS / WAVE) * (10 * L + 4) <= exact_arena_bytes<L>(), "arena");
+    u64 (*s_keys)[10 * L + 4] = reinterpret_cast<u64 (*)[10 * L + 4]>(exact_arena<L>());
     const int lane = threadIdx.x & (WAVE - 1);
     const long long wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
     for (long long c = wave_of_grid * 2 * stride; c + stride < n_cand; c += waves_of_grid * 2 * stride) {
@@ -1582,7 +1594,11 @@ struct alignas(16) UpdateLds {
     static constexpr int WB = 8 * L;        // bytes of an integer
     static constexpr int STRIDE = WB + 64;  // of one copy: index y <-> byte WB - 1 - y of the integer, zeros above
     int prefix[2][WB];                      // [operand] 128 * sum_{x <= d} byte x      (operand 0: alpha~_p u, 1: N(p, k))
-    unsigned toeplitz[2][4][STRIDE / 4];    // [operand][shift s][..]: byte y of copy s = (byte WB - 1 - (y + s) of the integer) ^ 0x80
+    // Round 6: SIXTEEN copies, one per byte shift, so that every fragment is one 16-BYTE-ALIGNED ds_read_b128.  Rounds 5 kept four copies
+    // (shifts 0..3) and read at 4-byte-aligned addresses: the LDS pipe takes such a read apart -- 6.7-7.4 ns per fragment per CU against 2.2
+    // aligned with the tile's own lane pattern (tools/micro/lds_fragment_bench.hip, profiles/r6_micro_lds_fragment.txt), 260 us of LDS time
+    // in every pivot of 25FV47 at 128 limbs, half of the tile phase.  35 KB at 128 limbs (two workgroups per CU: 160 KB of LDS).
+    unsigned toeplitz[2][16][STRIDE / 4];   // [operand][shift s][..]: byte y of copy s = (byte WB - 1 - (y + s) of the integer) ^ 0x80
     u64 words[L];                           // N(p, k) on its way in
     int scan[EX_THREADS / WAVE];
 };
@@ -1593,7 +1609,7 @@ __device__ __forceinline__ void build_toeplitz(UpdateLds<L>& lds, int op, const 
     constexpr int WB = UpdateLds<L>::WB, STRIDE = UpdateLds<L>::STRIDE;
     const int tid = threadIdx.x, T = blockDim.x;
     const unsigned char* xb = (const unsigned char*)xw;
-    for (int q = tid; q < STRIDE; q += T) {  // (4 copies of STRIDE / 4 dwords)
+    for (int q = tid; q < 4 * STRIDE; q += T) {  // (16 copies of STRIDE / 4 dwords)
         const int shift = q / (STRIDE / 4), y = 4 * (q - shift * (STRIDE / 4));
         unsigned v = 0;
 #pragma unroll
@@ -1637,6 +1653,7 @@ __device__ __forceinline__ void build_toeplitz(UpdateLds<L>& lds, int op, const 
 //  otherwise spills around every MFMA; the LDS operands arrive as address-space pointers so that their loads stay ds_read.)
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) v4i lds_v4i;
 struct UpdateTileArgs {
     const u64* x_part;  // the rows' factors -alpha~_i u, word-major with stride m
     int m;
@@ -1754,7 +1771,7 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
                 const int step = step0 + j;
                 if (step < steps) {
                     const int term = step >= kb_end ? 1 : 0, kb = step - term * kb_end;
-                    const lds_u32* image = toeplitz_lds + (term * 4 + (3 - rq)) * (STRIDE / 4);  // copy 3 - rq of this term's operand
+                    const lds_u32* image = toeplitz_lds + (term * 16 + (3 - rq)) * (STRIDE / 4);  // copies 4 (3 - tq) + 3 - rq of this term's operand
                     if (kb == 0) ones_acc = v4i{0, 0, 0, 0};
                     v4i entries;  // bytes 64 kb + 16 g .. + 15 of this lane's entry, each minus 128
                     entries[0] = (int)((unsigned)ring[j][0] ^ 0x80808080u);
@@ -1765,7 +1782,7 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
                     ones_acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, entries, ones_acc, 0, 0, 0);
                     ++issued;
                     // row 4 gq + rq of tile tq of block b is digit d = 64 b + 16 gq + 4 tq + rq; its k-th byte is byte d - (64 kb + 16 g + j)
-                    // of the integer = index WB - 1 - d + 64 kb + 16 g + j of the reversed string: a 4-aligned offset in copy 3 - rq.
+                    // of the integer = index WB - 1 - d + 64 kb + 16 g + j of the reversed string: a 16-aligned offset in copy 4 (3 - tq) + 3 - rq.
                     // The four fragments of block b + 1 are requested before the MFMAs of block b are issued (two sets of registers,
                     // by the parity of the block): with a block's loads and its MFMAs back to back every block waited out the LDS
                     // latency, 13 of the 27 us of a tile.
@@ -1773,9 +1790,9 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
                     auto request = [&](int bl, v4i* into) {
                         const int base = WB - 16 - 64 * (bp + bl - kb) - 16 * (gq - g);
 #pragma unroll
-                        for (int tq = 0; tq < 4; ++tq) {
-                            const lds_u32* at = image + (base + 4 * (3 - tq)) / 4;
-                            into[tq] = v4i{(int)at[0], (int)at[1], (int)at[2], (int)at[3]};
+                        for (int tq = 0; tq < 4; ++tq) {  // (the byte offset 4 (3 - tq) + 3 - rq is the copy's shift: the address is 16-byte aligned)
+                            const lds_v4i* at = (const lds_v4i*)(image + 4 * (3 - tq) * (STRIDE / 4) + base / 4);
+                            into[tq] = *at;
                         }
                     };
                     auto wanted = [&](int bl) { return bp + bl >= kb && bp + bl < nb64; };
@@ -2187,7 +2204,7 @@ __device__ __forceinline__ void wave_mul_lo_negated(const u64* a, const u64* b, 
 template <int L>
 __device__ __noinline__ void entering_column_rows(const ExactLP& lp, int q, const u64* dinv, int limit_bits, int* overflow, bool with_y, int* cq_bits_out) {
     constexpr int SLOTS = (L + WAVE - 1) / WAVE;
-    __shared__ u64 s_row[EX_THREADS / WAVE][L];
+    u64 (*s_row)[L] = reinterpret_cast<u64 (*)[L]>(exact_arena<L>());
     const int m = lp.m, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const int wave_of_grid = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves_of_grid = gridDim.x * blockDim.x / WAVE;
     const int e0 = __builtin_amdgcn_readfirstlane(lp.col_start[q]), e1 = __builtin_amdgcn_readfirstlane(lp.col_start[q + 1]);
@@ -2533,7 +2550,8 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
     const bool flip = sc.flip != 0;
     const bool fused = sc.fused != 0;
         // ---- the update on the matrix cores (see mfma_update_tile): tiles of 16 entries of a column, a wave each ----
-        __shared__ UpdateLds<L> s_update;
+        static_assert(sizeof(UpdateLds<L>) <= exact_arena_bytes<L>(), "arena");
+        UpdateLds<L>& s_update = *reinterpret_cast<UpdateLds<L>*>(exact_arena<L>());
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, waves = T / WAVE;
         const int e16 = lane & 15;
         int issued = 0;
