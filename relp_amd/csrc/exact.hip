@@ -1721,7 +1721,7 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
     constexpr int PB = UPDATE_PASS_BLOCKS;  // blocks of 64 digits per pass: 4 PB accumulator tiles
     // ---- FUSED: what the epilogue carries from pass to pass (see below) ----
     int k_below = 0;           // (lanes g == 0) what the pair below this pass's first carries on, as the tiles formed it
-    unsigned carry_below = 0;  // ... and the bit that the additions below it hand on
+    unsigned long long carry_below_mask = 0;  // ... and the bits that the additions below hand on (bits 0..15: entry e; the same in every lane)
     u64 pending = 0;           // (lanes g == 3) the pass's top word, not yet shifted: its upper neighbour belongs to the next pass
     int top_nonzero = -1, top_not_ones = -1, lowest_nonzero = 4 * L;  // of the result's words this lane has formed
     u64 word_nonzero = 0, word_not_ones = 0;
@@ -1747,7 +1747,18 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
 #pragma unroll
         for (int bl = 0; bl < PB; ++bl)
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) acc[bl][tq] = v4i{0, 0, 0, 0};
+            for (int tq = 0; tq < 4; ++tq) {
+                if constexpr (FUSED) {
+                    // (the accumulators START from the offset-binary corrections 128 * sum of the operands' bytes -- read here, behind the
+                    //  pass's first requests, instead of in the epilogue; sums stay below 2^29)
+                    const lds_v4i* pa = (const lds_v4i*)(prefix_lds + 64 * min(bp + bl, L / 8 - 1) + 16 * g + 4 * tq);
+                    v4i start = pa[0];
+                    if (terms == 2) start += pa[WB / 4];
+                    acc[bl][tq] = start;
+                } else {
+                    acc[bl][tq] = v4i{0, 0, 0, 0};
+                }
+            }
         const int kb_end = min(nb64, bp + PB);
         // The steps of the pass are (term, block of 64 bytes of the entries' operand) in order; eight steps' words are in flight at any
         // time (a ring of registers): with one block requested per step the tile waited for memory at every step.
@@ -1821,7 +1832,7 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
             // Round 6: the second pass in the tile's own registers.  Lane (entry e = lane & 15, group g = lane >> 4) holds, for block b of the
             // pass, the 128-bit pair P = 4 b + g of its entry (digits 64 b + 16 g ..) and what it carries on, k_P < 2^22.  The finished pair is
             // V_P + k_(P-1) + c_P where c_P is the carry bit of the additions below -- pair P - 1 sits in the lane 16 below (g > 0) or, for
-            // g = 0, in lane e + 48 of the block below (the previous pass's last block: k_below, carry_below).  The bits c_P are a
+            // g = 0, in lane e + 48 of the block below (the previous pass's last block: k_below, carry_below_mask).  The bits c_P are a
             // carry-lookahead over (generate, propagate) flags gathered with ballots: no chain through the pairs, no numerator in memory.
             // Then the arithmetic shift by s = ctz(D) bits (whole words by the index, the rest with a word's upper neighbour from the lane 16 above; a pass's top word waits
             // for the next pass), the words straight into the OTHER buffer of N, the sign's fill above them at the end.
@@ -1830,20 +1841,26 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
             int kout[PB];
 #pragma unroll
             for (int bl = 0; bl < PB; ++bl) {
-                i64 quad[4];
+                // sixteen digits d_0 .. d_15 (each below 2^29, non-negative) -> sum d_i 2^(8 i): four quads by multiply-adds (v_mad_u64_u32 is
+                // full rate), two words and what they carry on
+                u64 quad[4];
 #pragma unroll
                 for (int tq = 0; tq < 4; ++tq) {
-                    const lds_i32* pa = prefix_lds + 64 * min(bp + bl, L / 8 - 1) + 16 * g + 4 * tq;
-                    v4i digit = acc[bl][tq] + v4i{pa[0], pa[1], pa[2], pa[3]};
-                    if (terms == 2) digit += v4i{pa[WB], pa[WB + 1], pa[WB + 2], pa[WB + 3]};
-                    quad[tq] = (i64)digit[0] + ((i64)digit[1] << 8) + ((i64)digit[2] << 16) + ((i64)digit[3] << 24);
+                    const v4i digit = acc[bl][tq];
+                    u64 q = (u64)(unsigned)digit[3] * 256u + (unsigned)digit[2];
+                    q = q * 256u + (unsigned)digit[1];   // (q < 2^45: the products stay in 64 bits)
+                    q = q * 256u + (unsigned)digit[0];
+                    quad[tq] = q;                        // < 2^53
                 }
-                const __int128 v0 = (__int128)quad[0] + ((__int128)quad[1] << 32);
-                const __int128 v1 = (__int128)quad[2] + ((__int128)quad[3] << 32) + (v0 >> 64);
+                const u64 low0 = quad[0] + (quad[1] << 32);
+                const u64 high0 = (quad[1] >> 32) + (low0 < quad[0] ? 1ull : 0ull);
+                const u64 mid = quad[2] + high0;         // (no carry: both below 2^54)
+                const u64 low1 = mid + (quad[3] << 32);
+                const u64 high1 = (quad[3] >> 32) + (low1 < mid ? 1ull : 0ull);
                 const bool valid = bl < blocks_here;
-                lo[bl] = valid ? (u64)v0 : 0ull;
-                hi[bl] = valid ? (u64)v1 : 0ull;
-                kout[bl] = valid ? (int)(v1 >> 64) : 0;
+                lo[bl] = valid ? low0 : 0ull;
+                hi[bl] = valid ? low1 : 0ull;
+                kout[bl] = valid ? (int)high1 : 0;
             }
             // what pair P - 1 carries on, as formed
             int from_below[PB];
@@ -1868,23 +1885,31 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
                 for (int bl = 1; bl < PB; ++bl) k_next = bl < blocks_here ? from_below[bl] : k_next;
                 k_below = k_next;
             }
-            // the flags of this lane's entry, pair 4 bl + g' at bit 4 bl + g' (bits e, e + 16, e + 32, e + 48 of a ballot)
-            unsigned generate = 0, propagate = 0;
-            const int e16 = lane & 15;
+            // The carry-lookahead on the SCALAR unit: a ballot has lane e + 16 g at bit e + 16 g, so the chain g = 0 .. 3 of all sixteen
+            // entries at once is three steps "carry << 16" on the 64-bit masks, and a block hands on to the next from its bits 48..63 to the
+            // next one's bits 0..15 -- once per wave, not once per lane (the flags gathered per lane and one addition: ~90 vector instructions a pass).
+            unsigned long long carry_into[PB];  // bit e + 16 g: the carry into pair 4 bl + g of entry e
+            {
+                unsigned long long incoming = carry_below_mask;  // bits 0..15: into the pass's first pairs (g = 0 of block 0)
 #pragma unroll
-            for (int bl = 0; bl < PB; ++bl) {
-                const u64 gm = (generate_mask[bl] >> e16) & 0x0001000100010001ull, pm = (propagate_mask[bl] >> e16) & 0x0001000100010001ull;
-                generate |= (unsigned)((gm * 0x0001000200040008ull) >> 48 & 15u) << (4 * bl);   // bit 16 g' -> bit 48 + g'
-                propagate |= (unsigned)((pm * 0x0001000200040008ull) >> 48 & 15u) << (4 * bl);
+                for (int bl = 0; bl < PB; ++bl) {
+                    const unsigned long long gm = generate_mask[bl], pm = propagate_mask[bl];
+                    unsigned long long c = incoming & 0xffffull;  // into g = 0
+                    unsigned long long all = c;
+#pragma unroll
+                    for (int step = 0; step < 3; ++step) {  // into g = 1, 2, 3: out of the group below, whose flags sit in its sixteen bits
+                        c = ((gm | (pm & c)) & (0xffffull << (16 * step))) << 16;
+                        all |= c;
+                    }
+                    carry_into[bl] = all;
+                    const unsigned long long out_of_top = (gm | (pm & all)) >> 48;  // out of g = 3: into the next block's g = 0
+                    incoming = bl < blocks_here ? out_of_top : incoming;
+                }
+                carry_below_mask = incoming;
             }
-            // carry-lookahead by one addition: position i generates (1 + 1), propagates (1 + 0) or stops a carry (0 + 0)
-            const unsigned a = generate | propagate, b2 = generate;
-            const unsigned sum = a + b2 + carry_below;
-            const unsigned carry_in = sum ^ a ^ b2;  // bit i: the carry into pair i of the pass (bit 16: out of the last)
-            carry_below = (carry_in >> (4 * blocks_here)) & 1u;
 #pragma unroll
             for (int bl = 0; bl < PB; ++bl) {
-                const u64 cbit = (carry_in >> (4 * bl + g)) & 1u;
+                const u64 cbit = (carry_into[bl] >> lane) & 1ull;
                 const u64 l = lo[bl] + cbit;
                 hi[bl] += l < cbit ? 1ull : 0ull;
                 lo[bl] = l;
