@@ -493,6 +493,10 @@ int32_t relp_debug_exact_words(int32_t device, int32_t limbs, int32_t mode, int3
  * [3] ticks of 10 ns for workgroup 0's loop, [4] rounds, [5] workgroups that ran to the end, [6] the abort word (0: nobody gave up; else the
  * barrier's number), [7] workgroups found waiting then.  No reference counterpart (relp is single-threaded). */
 int32_t relp_debug_grid_barrier(int32_t device, int32_t grid, int32_t rounds, int32_t reads, int32_t mode, int64_t limit_ticks, int64_t* out8);
+/* Measurement hook of the exact update's MFMA tile by itself (exact.hip, mfma_update_tile with the fused epilogue): 512 workgroups x 4 waves
+ * each run `tiles` tiles of `blocks` 64-byte blocks (<= limbs / 8) and `terms` terms (1: rescaled, 2: both products) on synthetic operands,
+ * results shifted by `shift` bits; *seconds of the launch (tools/tile_bench.py).  limbs in {16, 32, 64, 128}.  No reference counterpart. */
+int32_t relp_debug_exact_tile_bench(int32_t device, int32_t limbs, int32_t tiles, int32_t blocks, int32_t terms, int32_t shift, double* seconds);
 
 /* ---- `BasisInverse` as an object of its own (no LP handle needed) ------------------------------------------------------
  * The reference's trait `BasisInverse` (tableau/inverse_maintenance/carry/mod.rs:69-169) and its main implementor

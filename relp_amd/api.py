@@ -142,7 +142,7 @@ SYMBOLS = [
     "relp_get_solution", "relp_get_objective_exact", "relp_get_record_json", "relp_solve_exact", "relp_get_exact_counters", "relp_get_basis", "relp_set_basis", "relp_begin_phase_one",
     "relp_begin_phase_two", "relp_bi_ftran", "relp_bi_btran", "relp_bi_row", "relp_price", "relp_relative_costs",
     "relp_get_gamma", "relp_ratio", "relp_bring_into_basis", "relp_get_last_pivot", "relp_se_after_basis_update", "relp_refactor", "relp_iterate", "relp_get_b", "relp_get_objective", "relp_get_stats",
-    "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps", "relp_debug_set_tuning", "relp_debug_exact_finish", "relp_debug_exact_words", "relp_debug_grid_barrier",
+    "relp_reset_stats", "relp_profile_kernel", "relp_debug_stamps", "relp_debug_set_tuning", "relp_debug_exact_finish", "relp_debug_exact_words", "relp_debug_grid_barrier", "relp_debug_exact_tile_bench",
     # BasisInverse as an object of its own (relp_amd/basis_inverse.py)
     "relp_bi_options_default", "relp_bi_identity", "relp_bi_invert", "relp_bi_free", "relp_bi_last_error", "relp_bi_m",
     "relp_bi_left_multiply", "relp_bi_right_multiply", "relp_bi_basis_inverse_row", "relp_bi_generate_element",

@@ -15,6 +15,7 @@ void exact_finish_entries(int device, int limbs, int count, const unsigned long 
                           unsigned long long* N_out, int* bits_out);
 void exact_words_test(int device, int limbs, int mode, int count, const unsigned long long* a, const unsigned long long* b, unsigned long long* out);
 void grid_barrier_test(int device, int grid, int rounds, int reads, int mode, long long limit_ticks, long long* out8);
+double exact_tile_bench(int device, int limbs, int tiles, int nb64, int terms, int shift);
 }
 using namespace relp;
 
@@ -1013,6 +1014,18 @@ int32_t relp_debug_grid_barrier(int32_t device, int32_t grid, int32_t rounds, in
     if (!out8 || grid < 1 || rounds < 1 || reads < 0 || mode < 0 || mode > 1 || limit_ticks < 0) return RELP_ERR_ARGUMENT;
     try {
         relp::grid_barrier_test(device, grid, rounds, reads, mode, (long long)limit_ticks, (long long*)out8);
+        return RELP_OK;
+    } catch (const std::invalid_argument&) {
+        return RELP_ERR_ARGUMENT;
+    } catch (const std::exception&) {
+        return RELP_ERR_DEVICE;
+    }
+}
+
+int32_t relp_debug_exact_tile_bench(int32_t device, int32_t limbs, int32_t tiles, int32_t blocks, int32_t terms, int32_t shift, double* seconds) {
+    if (!seconds || tiles < 1 || blocks < 1 || blocks > limbs / 8 || terms < 1 || terms > 2 || shift < 0) return RELP_ERR_ARGUMENT;
+    try {
+        *seconds = relp::exact_tile_bench(device, limbs, tiles, blocks, terms, shift);
         return RELP_OK;
     } catch (const std::invalid_argument&) {
         return RELP_ERR_ARGUMENT;

@@ -1584,6 +1584,11 @@ __device__ __forceinline__ double reduced_cost_wave(const ExactLP& lp, const u64
 // the vector unit (v_mad_u64_u32, full rate) gives 2.1 T/s to the compiled block products above and the update ran at 0.34
 // (tools/micro/intmul_rates.hip, profiles/r5_micro_intmul_rates.txt).
 typedef int v4i __attribute__((ext_vector_type(4)));
+// -DRELP_TILE_VARIANT=n (tools/tile_bench.py: the tile by itself with one of its resources taken out -- results are WRONG, only the time
+// means something): 1 no stores, 2 no Toeplitz fragments from LDS, 3 no entries from memory, 4 no MFMAs, 5 no epilogue
+#ifndef RELP_TILE_VARIANT
+#define RELP_TILE_VARIANT 0
+#endif
 #ifndef RELP_UPDATE_PASS_BLOCKS
 #define RELP_UPDATE_PASS_BLOCKS 4
 #endif
@@ -1740,7 +1745,7 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
         if (j < 0) return;  // (the numerator's low words: zero, the division is exact)
         if (v != 0) { top_nonzero = j; word_nonzero = v; lowest_nonzero = min(lowest_nonzero, j); }
         if (v != ~0ull) { top_not_ones = j; word_not_ones = v; }
-        if (store) at_entry.numerator[(size_t)j * at_entry.numerator_stride] = v;
+        if (store && RELP_TILE_VARIANT != 1) at_entry.numerator[(size_t)j * at_entry.numerator_stride] = v;
     };
     for (int bp = 0; bp < nb64; bp += PB) {
         v4i acc[PB][4];
@@ -1767,9 +1772,9 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
             const int term = step >= kb_end ? 1 : 0, kb = step - term * kb_end;
             global_cu64* src = term == 0 ? at_entry.entry : at_entry.second;
             const size_t stride = term == 0 ? at_entry.entry_stride : at_entry.second_stride;
-            const bool wanted = have && step < steps;
-            w0 = wanted ? src[(size_t)(8 * kb + 2 * g) * stride] : 0ull;
-            w1 = wanted ? src[(size_t)(8 * kb + 2 * g + 1) * stride] : 0ull;
+            const bool wanted = have && step < steps && RELP_TILE_VARIANT != 3;
+            w0 = wanted ? src[(size_t)(8 * kb + 2 * g) * stride] : (u64)step;
+            w1 = wanted ? src[(size_t)(8 * kb + 2 * g + 1) * stride] : (u64)lane;
         };
         u64 ring[8][2];
 #pragma unroll
@@ -1803,7 +1808,8 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
 #pragma unroll
                         for (int tq = 0; tq < 4; ++tq) {  // (the byte offset 4 (3 - tq) + 3 - rq is the copy's shift: the address is 16-byte aligned)
                             const lds_v4i* at = (const lds_v4i*)(image + 4 * (3 - tq) * (STRIDE / 4) + base / 4);
-                            into[tq] = *at;
+                            if (RELP_TILE_VARIANT == 2) into[tq] = v4i{base, tq, bl, lane};
+                            else into[tq] = *at;
                         }
                     };
                     auto wanted = [&](int bl) { return bp + bl >= kb && bp + bl < nb64; };
@@ -1813,8 +1819,10 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
                         if (bl + 1 < PB && wanted(bl + 1)) request(bl + 1, toeplitz[(bl + 1) & 1]);
                         if (wanted(bl)) {
 #pragma unroll
-                            for (int tq = 0; tq < 4; ++tq)
-                                acc[bl][tq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(toeplitz[bl & 1][tq], entries, acc[bl][tq], 0, 0, 0);
+                            for (int tq = 0; tq < 4; ++tq) {
+                                if (RELP_TILE_VARIANT == 4) acc[bl][tq] += toeplitz[bl & 1][tq] ^ entries;
+                                else acc[bl][tq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(toeplitz[bl & 1][tq], entries, acc[bl][tq], 0, 0, 0);
+                            }
                             issued += 4;
                             if (bp + bl == kb) {  // the block is complete for this term: 128 * (sum of the entry's bytes - 128 each, so far)
 #pragma unroll
@@ -1828,7 +1836,14 @@ __device__ __noinline__ int mfma_update_tile_fields(unsigned long long* stamps_o
             }
         }
         TILE_STAMP(27);  // the steps of the pass
-        if constexpr (FUSED) {
+        if (RELP_TILE_VARIANT == 5) {  // (diagnostic: the accumulators are used, nothing else happens)
+            int any = 0;
+#pragma unroll
+            for (int bl = 0; bl < PB; ++bl)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) any |= acc[bl][tq][0] ^ acc[bl][tq][1] ^ acc[bl][tq][2] ^ acc[bl][tq][3];
+            if (any == 0x7fffffff && store) at_entry.numerator[0] = 1;
+        } else if constexpr (FUSED) {
             // Round 6: the second pass in the tile's own registers.  Lane (entry e = lane & 15, group g = lane >> 4) holds, for block b of the
             // pass, the 128-bit pair P = 4 b + g of its entry (digits 64 b + 16 g ..) and what it carries on, k_P < 2^22.  The finished pair is
             // V_P + k_(P-1) + c_P where c_P is the carry bit of the additions below -- pair P - 1 sits in the lane 16 below (g > 0) or, for
@@ -4214,6 +4229,81 @@ void exact_words_test(int device, int limbs, int mode, int count, const unsigned
     RELP_HIP(hipGetLastError());
     RELP_HIP(hipDeviceSynchronize());
     RELP_HIP(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+}
+// The update tile by itself (tools/tile_bench.py): every wave of a full grid runs `tiles` fused tiles of `nb64` blocks and `terms` terms on
+// synthetic operands; returns the seconds of the launch.  With -DRELP_TILE_VARIANT the same with one resource taken out.
+template <int L>
+__global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) exact_tile_bench_kernel(const u64* N, u64* N_alt, int* bits_alt, const u64* x_part, int m,
+                                                                                                               int tiles, int nb64, int terms, int shift, const u64* operand) {
+    UpdateLds<L>& s_update = *reinterpret_cast<UpdateLds<L>*>(exact_arena<L>());
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const size_t MM = (size_t)m * m;
+    for (int w = tid; w < L; w += blockDim.x) s_update.words[w] = operand[w];
+    __syncthreads();
+    build_toeplitz<L>(s_update, 0, s_update.words);
+    __syncthreads();
+    build_toeplitz<L>(s_update, 1, s_update.words);
+    __syncthreads();
+    const lds_u32* toeplitz_lds = (const lds_u32*)&s_update.toeplitz[0][0][0];
+    const lds_i32* prefix_lds = (const lds_i32*)&s_update.prefix[0][0];
+    const UpdateTileArgs tile_args{x_part, m, nullptr};
+    int issued = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const size_t idx = (((size_t)blockIdx.x * (EX_THREADS / WAVE) + wave) * tiles + t) * 16 + (lane & 15);
+        const int row = (int)(idx % m);
+        const UpdateTileEntry at_entry{N + idx, MM, x_part + row, (size_t)m, N_alt + idx, nullptr, bits_alt + idx, MM};
+        issued += mfma_update_tile<L, true>(tile_args, at_entry, toeplitz_lds, prefix_lds, row, idx < MM, terms, nb64, lane, shift);
+    }
+    if (issued == -1) bits_alt[0] = 0;
+}
+double exact_tile_bench(int device, int limbs, int tiles, int nb64, int terms, int shift) {
+    RELP_HIP(hipSetDevice(device));
+    if (limbs != 128 && limbs != 64 && limbs != 32 && limbs != 16) throw std::invalid_argument("limbs must be 16, 32, 64 or 128");
+    const int grid = 512, waves = EX_THREADS / WAVE;
+    int m = 64;
+    while ((size_t)m * m < (size_t)grid * waves * tiles * 16) m += 64;
+    const size_t MM = (size_t)m * m;
+    std::vector<void*> owned;
+    struct Free {
+        std::vector<void*>& p;
+        ~Free() { for (void* q : p) (void)hipFree(q); }
+    } free_all{owned};
+    auto bytes = [&](size_t n) {
+        void* p = nullptr;
+        RELP_HIP(hipMalloc(&p, n));
+        owned.push_back(p);
+        return p;
+    };
+    u64* d_N = (u64*)bytes(MM * limbs * sizeof(u64));
+    u64* d_alt = (u64*)bytes(MM * limbs * sizeof(u64));
+    int* d_bits = (int*)bytes(MM * sizeof(int));
+    u64* d_x = (u64*)bytes((size_t)m * limbs * sizeof(u64));
+    u64* d_op = (u64*)bytes(limbs * sizeof(u64));
+    RELP_HIP(hipMemset(d_N, 0x5a, MM * limbs * sizeof(u64)));
+    RELP_HIP(hipMemset(d_alt, 0, MM * limbs * sizeof(u64)));
+    RELP_HIP(hipMemset(d_bits, 0, MM * sizeof(int)));
+    RELP_HIP(hipMemset(d_x, 0x3c, (size_t)m * limbs * sizeof(u64)));
+    RELP_HIP(hipMemset(d_op, 0x71, limbs * sizeof(u64)));
+    hipEvent_t start, stop;
+    RELP_HIP(hipEventCreate(&start));
+    RELP_HIP(hipEventCreate(&stop));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {  // (the second launch is the one timed)
+        RELP_HIP(hipEventRecord(start, 0));
+        switch (limbs) {
+            case 16: hipLaunchKernelGGL(exact_tile_bench_kernel<16>, dim3(grid), dim3(EX_THREADS), 0, 0, d_N, d_alt, d_bits, d_x, m, tiles, nb64, terms, shift, d_op); break;
+            case 32: hipLaunchKernelGGL(exact_tile_bench_kernel<32>, dim3(grid), dim3(EX_THREADS), 0, 0, d_N, d_alt, d_bits, d_x, m, tiles, nb64, terms, shift, d_op); break;
+            case 64: hipLaunchKernelGGL(exact_tile_bench_kernel<64>, dim3(grid), dim3(EX_THREADS), 0, 0, d_N, d_alt, d_bits, d_x, m, tiles, nb64, terms, shift, d_op); break;
+            default: hipLaunchKernelGGL(exact_tile_bench_kernel<128>, dim3(grid), dim3(EX_THREADS), 0, 0, d_N, d_alt, d_bits, d_x, m, tiles, nb64, terms, shift, d_op); break;
+        }
+        RELP_HIP(hipEventRecord(stop, 0));
+        RELP_HIP(hipEventSynchronize(stop));
+        RELP_HIP(hipGetLastError());
+        RELP_HIP(hipEventElapsedTime(&ms, start, stop));
+    }
+    (void)hipEventDestroy(start);
+    (void)hipEventDestroy(stop);
+    return ms * 1e-3;
 }
 void exact_finish_entries(int device, int limbs, int count, const unsigned long long* T, const int* carry, const int* words, int shift, int flip,
                           unsigned long long* N_out, int* bits_out) {
