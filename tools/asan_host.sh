@@ -9,11 +9,12 @@ mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer"
 cd $ROOT/relp_amd/csrc
 rm -f $OUT/*.o
-for f in kernels.hip solver.hip certify.hip lu.hip exact.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o $OUT/${f%.hip}.o & done; wait
-for f in capi.cpp capi_bi.cpp batch.cpp mps.cpp; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o $OUT/${f%.cpp}.o & done; wait
+# (the sources of the Makefile: every .hip and .cpp of the library)
+SRC=$(sed -n 's/^SRC := //p' Makefile)
+for f in $SRC; do case $f in *.hip) /opt/rocm/bin/hipcc $FLAGS -c $f -o $OUT/${f%.hip}.o & ;; *.cpp) /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o $OUT/${f%.cpp}.o & ;; esac; done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -o $OUT/librelp_amd.so $OUT/*.o
 cd $ROOT
 ASAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 RELP_AMD_LIB=$OUT/librelp_amd.so \
   python -m pytest tests/test_host_model.py tests/test_host_general_form.py tests/test_host_presolve.py tests/test_abi.py \
-  tests/test_network.py tests/test_bigint.py -q -m "not gpu" 2>&1 | grep -E "runtime error|AddressSanitizer|passed|failed|SUMMARY"
+  tests/test_network.py tests/test_bigint.py tests/test_struct_layouts.py -q -m "not gpu" 2>&1 | grep -E "runtime error|AddressSanitizer|passed|failed|SUMMARY"
