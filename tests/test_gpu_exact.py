@@ -123,10 +123,10 @@ def test_more_netlib_lps_follow_the_reference_pivot_for_pivot(name):
     solver.close()
 
 
-@pytest.mark.parametrize("name", ["GROW7", "BNL1"])
+@pytest.mark.parametrize("name", ["GROW7", "BNL1", "BNL2"])  # (BNL2, 2324 rows: 2827 + 857 pivots, 8 s -- round 6; CYCLE, 80BAU3B, GREENBEA / B outgrow 128 limbs: profiles/r6_exact_big_netlib.txt)
 def test_exact_simplex_and_exact_certificate_meet_where_no_golden_file_exists(name):
     """Shipped Netlib LPs the Fraction oracle is too slow for: the reference's rule in fixed-width integers (relp_solve_exact: 171 and
-    1036 pivots at 64 limbs) and the f64 loop with its exact certificate are two independent exact computations; they end on the
+    1036 pivots at 64 limbs, BNL2's 3684 at 128) and the f64 loop with its exact certificate are two independent exact computations; they end on the
     same rational optimum, digit for digit."""
     solver = relp_amd.Solver(certify=1).load_mps(os.path.join(ROOT, "data", "netlib", name + ".SIF"))
     relaxed = solver.solve_relaxation()
