@@ -372,13 +372,15 @@ public:
             row_of_column[j] = row;
         }
         // row j of B^-1 belongs to the basis column at position j
-        int* d_source = nullptr;
-        RELP_HIP(hipMalloc((void**)&d_source, m_ * sizeof(int)));
-        RELP_HIP(hipMemcpy(d_source, row_of_column.data(), m_ * sizeof(int), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(bix_permute_rows_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, N2_, m_, W_, d_source);
+        struct Owned {
+            int* p = nullptr;
+            ~Owned() { if (p) (void)hipFree(p); }
+        } source;
+        RELP_HIP(hipMalloc((void**)&source.p, m_ * sizeof(int)));
+        RELP_HIP(hipMemcpy(source.p, row_of_column.data(), m_ * sizeof(int), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bix_permute_rows_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, N2_, m_, W_, source.p);
         RELP_HIP(hipGetLastError());
         RELP_HIP(hipDeviceSynchronize());
-        (void)hipFree(d_source);
         std::swap(N_, N2_);
         have_column_ = false;
     }
@@ -404,6 +406,12 @@ public:
         column_values_ = scaled;
         if (numerators_out) RELP_HIP(hipMemcpy(numerators_out, alpha_, (size_t)m_ * (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
         if (denominator_out) denominator(scale, denominator_out);
+    }
+    // the result of the last left_multiply again (it stays on the device for change_basis)
+    void last_left_multiply(u64* numerators_out, u64* denominator_out) {
+        if (!have_column_) throw std::logic_error("no left_multiply_by_basis_inverse to read back");
+        RELP_HIP(hipMemcpy(numerators_out, alpha_, (size_t)m_ * (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
+        denominator(alpha_scale_, denominator_out);
     }
     // `right_multiply_by_basis_inverse` (carry/mod.rs:135-141): r B^-1
     void right_multiply(int nnz, const int* index, const long long* num, const long long* den, u64* numerators_out, u64* denominator_out) {
@@ -725,12 +733,12 @@ int32_t relp_bix_result_words(const relp_basis_inverse_exact* bi, int32_t* words
 int32_t relp_bix_left_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* row_index, const int64_t* value_num, const int64_t* value_den,
                                int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
     BIX_RESULT(bi, capacity_words);
-    // (a width that alpha~ does not fit doubles the words: the result then needs more room than *words said -- form it, then check)
+    // (a width that alpha~ does not fit doubles the words: the result then needs more room than *words said -- form it, then check, then copy)
     const int32_t status = guarded_bix(bi, [&] { bi->object->left_multiply(nnz, row_index, (const long long*)value_num, (const long long*)value_den, nullptr, nullptr); });
     if (status != RELP_OK) return status;
     *words = bi->object->result_words();
     if (capacity_words < *words) return RELP_ERR_ARGUMENT;
-    return guarded_bix(bi, [&] { bi->object->left_multiply(nnz, row_index, (const long long*)value_num, (const long long*)value_den, (unsigned long long*)numerators, (unsigned long long*)denominator); });
+    return guarded_bix(bi, [&] { bi->object->last_left_multiply((unsigned long long*)numerators, (unsigned long long*)denominator); });
 }
 int32_t relp_bix_right_multiply(relp_basis_inverse_exact* bi, int32_t nnz, const int32_t* index, const int64_t* value_num, const int64_t* value_den,
                                 int32_t capacity_words, uint64_t* numerators, uint64_t* denominator, int32_t* words) {
