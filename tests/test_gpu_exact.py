@@ -39,6 +39,9 @@ def device_indices(pivots, n_art):
 
 # the four LPs the round-1 verdict names, plus more small ones; (name, largest limb count allowed)
 WHOLE_TRACE = ["AFIRO", "SC50A", "SC50B", "SC105", "SCAGR7", "ADLITTLE", "SHARE2B", "KB2", "burkardt_afiro", "burkardt_testprob",
+               # round 6: the rest of the reference's small suites (tests/burkardt, tests/unicamp, tests/cook): every fixture the repo holds runs here
+               "burkardt_adlittle", "burkardt_maros", "cook_small_example", "unicamp_model_data_1", "unicamp_model_data_3_1", "unicamp_model_data_3_2",
+               "unicamp_model_data_3_3", "unicamp_model_data_3_4", "unicamp_model_data_4",
                # round 3 (the loop on the whole grid): the 16- and 32-limb LPs finish in seconds, so they are part of every run
                "BLEND", "ISRAEL", "STOCFOR1", "SHARE1B", "E226"]
 
