@@ -1,6 +1,6 @@
 """HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, csv output).
 
-    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json>
+    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [least number of launches of a kernel: 20]
 
 Per kernel: median counter value over its launches; HBM bytes = 2 x FETCH_SIZE(KB) x 1024 + WRITE_SIZE(KB) x 1024 -- the
 gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies the 128-B requests of wide streaming reads at 64 B).
@@ -28,11 +28,12 @@ def medians(directory, counter):
             {k: statistics.median(v) for k, v in durations.items() if v})
 
 
+MIN_LAUNCHES = int(sys.argv[4]) if len(sys.argv) > 4 else 20  # (the exact simplex is ONE launch per width: pass 1)
 fetch, launches, nanos = medians(sys.argv[1], "FETCH_SIZE")
 write, _, _ = medians(sys.argv[2], "WRITE_SIZE")
 out = {}
 for name in sorted(fetch, key=lambda k: -fetch[k] * launches[k]):
-    if launches[name] < 20:
+    if launches[name] < MIN_LAUNCHES:
         continue
     out[name] = {"FETCH_SIZE_KB_median": fetch[name], "WRITE_SIZE_KB_median": write.get(name, 0.0),
                  "hbm_bytes_corrected": 2 * 1024 * fetch[name] + 1024 * write.get(name, 0.0),

@@ -29,6 +29,7 @@ stats 25fv47 python3 $R/bench.py --steps 3 --warmup 1 $COMMON
 stats exact_25fv47 python3 $R/tools/exact_roofline.py 25FV47
 stats dense4096_f64 python3 $R/bench.py --steps 3 --warmup 1 $COMMON --workload dense4096 --dense-storage f64
 pmc dense4096_f64 python3 $R/bench.py --steps 1 --warmup 0 $COMMON --workload dense4096 --dense-storage f64
+# (no PMC pass for the exact solve: rocprofv3 --pmc segfaults behind its cooperative launches on this image; its roofline's `traffic` stays null)
 MF="--steps 1 --warmup 0 $COMMON --workload maxflow"
 stats maxflow_reference_start python3 $R/bench.py $MF --crash 0
 pmc maxflow_reference_start python3 $R/bench.py $MF --crash 0
