@@ -352,7 +352,7 @@ def make_mirrored(log):
     return Mirrored
 
 
-@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE"])
+@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "ADLITTLE", "SC50B", "KB2", "SC105", "SHARE2B", "BLEND", "STOCFOR1", "ISRAEL"])
 def test_the_oracles_carry_with_the_device_object_behind_every_call(name):
     import json
     from collections import Counter
