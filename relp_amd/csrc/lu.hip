@@ -83,7 +83,7 @@ struct LuLayout {
     } co[4];
     size_t compact_begin, compact_end, upload_bytes;
     size_t app, o_applen, o_appslot, o_appval, o_scs, o_scl, o_scrow, o_scval, o_T, o_trail, o_slotof, o_eta_start, o_eta_pivot, o_eta_idx, o_eta_val;
-    size_t o_eta_mf, o_eta_of, o_eta_first, o_eta_prev, o_eapp_len, o_eapp_eta, o_eapp_val, o_spike, pf_ld, o_pf_m, o_pf_slot, o_pf_col_of, o_state, o_log_factor, o_log_p;
+    size_t o_eta_mf, o_eta_of, o_eta_first, o_eta_prev, o_eapp_len, o_eapp_eta, o_eapp_val, o_spike, pf_ld, o_pf_m, o_pf_slot, o_pf_col_of, o_state, o_log_factor, o_log_p, o_log_w, o_log_plan;
     size_t device_bytes;
 };
 
@@ -126,44 +126,133 @@ __global__ void lu_start_log_kernel(DeviceLU lu) {
 }
 // The etas logged on `old` folded into the product form of `fresh` (factors of the basis at the start of the log; its M is the
 // identity): for every logged pivot (row factors f, slot p)  M[s][c] -= f_s M[p][c]  over the kept columns, and a new column
-// e_p - f for p when it has none -- the same arithmetic, in the same order, as the pivot kernel's fold.  One workgroup.
-__global__ void __launch_bounds__(1024) lu_replay_kernel(DeviceLU fresh, DeviceLU old) {
-    __shared__ double s_row_p[LU_MAX_SLOTS + 1];
-    __shared__ int s_k;
-    const int tid = threadIdx.x, T = blockDim.x, m = fresh.m;
-    const int count = min(old.state[LU_LOG_COUNT], LU_LOG_CAPACITY);
-    if (tid == 0) s_k = fresh.state[LU_PF_COUNT];
+// e_p - f for p when it has none -- the same arithmetic, in the same order, as the pivot kernel's fold.
+// Round 5 did this as the pivot kernel does, one workgroup walking eta after eta over the kept columns in global memory: 16 us per eta,
+// 0.5 ms for 32 of them -- what the refactorisation beside the pivots was meant to hide.  Round 6: row s of M needs of the other rows
+// only  w_e = row p_e of M as it stands BEFORE eta e  (M[s][:] = M0[s][:] - f_1[s] w_1 - f_2[s] w_2 - ...), and the w_e need only the
+// rows p_1, p_2, ... themselves.  So: (plan) one workgroup walks the at most LU_LOG_CAPACITY rows p_e through the etas in LDS (a thread
+// per entry, one barrier per eta), leaves the w_e and the new columns' slots behind; (rows) then every row of M is independent of the
+// others -- a thread per row, the w_e in LDS, the row's factors in flight eight at a time.  (A kept column that eta e finds not yet
+// made has w_e = 0 in it: its subtraction changes nothing, so all the columns are treated as there from the start.)
+constexpr int LU_REPLAY_THREADS = 1024;
+constexpr int LU_REPLAY_PER_THREAD = (LU_LOG_CAPACITY * LU_MAX_SLOTS + LU_REPLAY_THREADS - 1) / LU_REPLAY_THREADS;
+__global__ void __launch_bounds__(LU_REPLAY_THREADS) lu_replay_plan_kernel(DeviceLU fresh, DeviceLU old) {
+    __shared__ double s_w[2][LU_MAX_SLOTS];
+    __shared__ double s_f[LU_LOG_CAPACITY][LU_LOG_CAPACITY];  // s_f[e][u] = f_e at the u-th distinct logged slot
+    __shared__ int s_p[LU_LOG_CAPACITY], s_have[LU_LOG_CAPACITY], s_row_of[LU_LOG_CAPACITY], s_row_slot[LU_LOG_CAPACITY], s_slot_of_col[LU_MAX_SLOTS];
+    __shared__ int s_k0, s_k, s_rows, s_count;
+    const int tid = threadIdx.x;
+    const int logged = min(old.state[LU_LOG_COUNT], LU_LOG_CAPACITY);
+    if (tid < logged) {
+        s_p[tid] = old.log_p[tid];
+        s_have[tid] = fresh.pf_col_of[s_p[tid]];
+    }
+    if (tid < LU_MAX_SLOTS) s_slot_of_col[tid] = tid < fresh.state[LU_PF_COUNT] ? fresh.pf_slot[tid] : -1;
     __syncthreads();
+    if (tid == 0) {  // the kept columns the etas make, and the distinct slots among the p_e
+        const int k0 = fresh.state[LU_PF_COUNT];
+        int k = k0, rows = 0, count = 0;
+        for (int e = 0; e < logged; ++e) {
+            const int p = s_p[e];
+            int u = -1;
+            for (int b = 0; b < rows; ++b)
+                if (s_row_slot[b] == p) u = b;
+            if (u < 0) {
+                if (s_have[e] < 0) {
+                    if (k >= min(fresh.max_updates, LU_MAX_SLOTS)) break;  // (no room: the etas from here on are left out, and the caller's guard sees it)
+                    s_slot_of_col[k++] = p;
+                }
+                u = rows++;
+                s_row_slot[u] = p;
+            }
+            s_row_of[e] = u;
+            count = e + 1;
+        }
+        s_k0 = k0;
+        s_k = k;
+        s_rows = rows;
+        s_count = count;
+    }
+    __syncthreads();
+    const int k0 = s_k0, k = s_k, rows = s_rows, count = s_count;
+    for (int i = tid; i < count * rows; i += LU_REPLAY_THREADS) {
+        const int e = i / rows, u = i % rows;
+        s_f[e][u] = old.log_factor[(size_t)e * old.pf_ld + s_row_slot[u]];
+    }
+    // entry (u, c) of the walked rows: thread tid holds the entries tid, tid + LU_REPLAY_THREADS, ...
+    double held[LU_REPLAY_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < LU_REPLAY_PER_THREAD; ++j) {
+        const int i = tid + j * LU_REPLAY_THREADS, u = i / LU_MAX_SLOTS, c = i % LU_MAX_SLOTS;
+        held[j] = 0.0;
+        if (u < rows && c < k) held[j] = c < k0 ? fresh.pf_M[(size_t)c * fresh.pf_ld + s_row_slot[u]] : (s_slot_of_col[c] == s_row_slot[u] ? 1.0 : 0.0);
+    }
     for (int e = 0; e < count; ++e) {
-        const int p = old.log_p[e];
-        const double* f = old.log_factor + (size_t)e * old.pf_ld;
-        const int k = s_k;
-        const int have = fresh.pf_col_of[p];
-        const int k_new = have < 0 ? k + 1 : k;
-        if (tid < k) s_row_p[tid] = fresh.pf_M[(size_t)tid * fresh.pf_ld + p];
-        if (tid == k) s_row_p[k] = 1.0;  // (the new column starts as e_p)
-        __syncthreads();
-        for (int c = 0; c < k_new; ++c) {
-            double* column = fresh.pf_M + (size_t)c * fresh.pf_ld;
-            const double mp_c = s_row_p[c];
-            for (int s = tid; s < m; s += T) {
-                const double before = c < k ? column[s] : (s == p ? 1.0 : 0.0);
-                column[s] = before - f[s] * mp_c;
+        const int at = s_row_of[e];
+#pragma unroll
+        for (int j = 0; j < LU_REPLAY_PER_THREAD; ++j) {
+            const int i = tid + j * LU_REPLAY_THREADS, u = i / LU_MAX_SLOTS, c = i % LU_MAX_SLOTS;
+            if (u == at) {
+                s_w[e & 1][c] = held[j];
+                fresh.log_w[(size_t)e * LU_MAX_SLOTS + c] = held[j];
             }
         }
-        __syncthreads();
-        if (tid == 0) {
-            if (have < 0) {
-                fresh.pf_slot[k] = p;
-                fresh.pf_col_of[p] = k;
-            }
-            s_k = k_new;
+        __syncthreads();  // (the other half of s_w is written by the next eta: one barrier per eta)
+#pragma unroll
+        for (int j = 0; j < LU_REPLAY_PER_THREAD; ++j) {
+            const int i = tid + j * LU_REPLAY_THREADS, u = i / LU_MAX_SLOTS, c = i % LU_MAX_SLOTS;
+            if (u < rows) held[j] = held[j] - s_f[e][u] * s_w[e & 1][c];
         }
-        __syncthreads();
+    }
+    if (tid >= k0 && tid < k) {
+        fresh.pf_slot[tid] = s_slot_of_col[tid];
+        fresh.pf_col_of[s_slot_of_col[tid]] = tid;
     }
     if (tid == 0) {
-        fresh.state[LU_PF_COUNT] = s_k;
+        fresh.log_plan[0] = k0;
+        fresh.log_plan[1] = k;
+        fresh.log_plan[2] = count;
+        fresh.state[LU_PF_COUNT] = k;
         fresh.state[LU_N_UPDATES] = count;
+    }
+}
+constexpr int LU_REPLAY_ROW_THREADS = 256;
+__global__ void __launch_bounds__(LU_REPLAY_ROW_THREADS) lu_replay_rows_kernel(DeviceLU fresh, DeviceLU old) {
+    __shared__ double s_w[LU_LOG_CAPACITY][LU_MAX_SLOTS];
+    __shared__ int s_slot_of_col[LU_MAX_SLOTS];
+    const int tid = threadIdx.x, m = fresh.m;
+    const int k0 = fresh.log_plan[0], k = fresh.log_plan[1], count = fresh.log_plan[2];
+    for (int i = tid; i < LU_LOG_CAPACITY * LU_MAX_SLOTS; i += LU_REPLAY_ROW_THREADS) {
+        const int e = i / LU_MAX_SLOTS, c = i % LU_MAX_SLOTS;
+        s_w[e][c] = (e < count && c < k) ? fresh.log_w[i] : 0.0;
+    }
+    if (tid < LU_MAX_SLOTS) s_slot_of_col[tid] = tid < k ? fresh.pf_slot[tid] : -1;
+    __syncthreads();
+    const int s = blockIdx.x * LU_REPLAY_ROW_THREADS + tid;
+    if (s >= m) return;
+    const double* f = old.log_factor + s;
+    const size_t ld = old.pf_ld;
+    for (int c0 = 0; c0 < k; c0 += 8) {
+        double acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            acc[u] = c < k0 ? fresh.pf_M[(size_t)c * fresh.pf_ld + s] : (c < k && s_slot_of_col[c] == s ? 1.0 : 0.0);
+        }
+        for (int e0 = 0; e0 < count; e0 += 8) {
+            double fe[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) fe[v] = e0 + v < count ? f[(size_t)(e0 + v) * ld] : 0.0;
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                if (e0 + v < count) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[u] = acc[u] - fe[v] * s_w[e0 + v][(c0 + u) & (LU_MAX_SLOTS - 1)];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u < k) fresh.pf_M[(size_t)(c0 + u) * fresh.pf_ld + s] = acc[u];
     }
 }
 
@@ -417,6 +506,8 @@ LuLayout compute_layout(int m, int max_updates, bool inverse_factors, size_t cl,
     L.o_state = c.take<int>(LU_STATE_WORDS);
     L.o_log_factor = c.take<double>(inverse_factors ? L.pf_ld * LU_LOG_CAPACITY : 0);
     L.o_log_p = c.take<int>(LU_LOG_CAPACITY);
+    L.o_log_w = c.take<double>(inverse_factors ? (size_t)LU_LOG_CAPACITY * LU_MAX_SLOTS : 0);
+    L.o_log_plan = c.take<int>(4);
     L.device_bytes = c.offset;
     return L;
 }
@@ -456,6 +547,8 @@ DeviceLU bind_layout(const LuLayout& L, char* dev_, int m, int max_updates, int 
     d.pf_col_of = I(L.o_pf_col_of);
     d.log_factor = inverse_factors ? D(L.o_log_factor) : nullptr;
     d.log_p = I(L.o_log_p);
+    d.log_w = inverse_factors ? D(L.o_log_w) : nullptr;
+    d.log_plan = I(L.o_log_plan);
     for (int k = 0; k < 4; ++k) {
         LuTasks& t = d.tasks[k];
         auto GI = [&](size_t o) { return (lu_gptr_i32) reinterpret_cast<const int*>(dev_ + o); };
@@ -799,7 +892,8 @@ void launch_lu_basis_residual(const int* col_start, const int* row_index, const 
 
 void LuFactors::start_log(hipStream_t stream) { hipLaunchKernelGGL(lu_start_log_kernel, dim3(1), dim3(1), 0, stream, d_); }
 void LuFactors::replay_log_of(const LuFactors& old, hipStream_t stream) {
-    hipLaunchKernelGGL(lu_replay_kernel, dim3(1), dim3(1024), 0, stream, d_, old.d_);
+    hipLaunchKernelGGL(lu_replay_plan_kernel, dim3(1), dim3(LU_REPLAY_THREADS), 0, stream, d_, old.d_);
+    hipLaunchKernelGGL(lu_replay_rows_kernel, dim3((d_.m + LU_REPLAY_ROW_THREADS - 1) / LU_REPLAY_ROW_THREADS), dim3(LU_REPLAY_ROW_THREADS), 0, stream, d_, old.d_);
 }
 
 // LDS of the solve kernels: the two vectors (16 bytes per row), the mask of the replaced positions, one count per 64 rows for

@@ -132,6 +132,8 @@ struct DeviceLU {
     // B_now^-1 = E_k ... E_1 B_snapshot^-1 whatever factors the alphas were computed with.
     double* log_factor = nullptr;  // [LU_LOG_CAPACITY][pf_ld]
     int* log_p = nullptr;          // [LU_LOG_CAPACITY]
+    double* log_w = nullptr;       // [LU_LOG_CAPACITY][LU_MAX_SLOTS] scratch of the replay: row p_e of M as eta e finds it (lu_replay_plan_kernel)
+    int* log_plan = nullptr;       // [4] kept columns before / after the replay, etas folded
     double* pf_M = nullptr;     // [max_updates][pf_ld]
     int pf_ld = 0;
     int* pf_slot = nullptr;     // [max_updates] basis slot of kept column c
