@@ -352,6 +352,7 @@ public:
     // `BasisInverse::invert` (carry/mod.rs:89-92): the columns in basis order.  Column j is brought into the identity basis by an
     // integer-preserving pivot on the lowest free row with a non-zero element; the rows are put in basis order at the end.
     void invert(const long long* column_start, const int* row_index, const long long* num, const long long* den) {
+        here();
         std::vector<int> row_of_column(m_, -1);
         std::vector<char> taken(m_, 0);
         std::vector<u64> numerators;
@@ -387,6 +388,7 @@ public:
 
     // `left_multiply_by_basis_inverse` (carry/mod.rs:123-129): B^-1 c = numerators / denominator.  Keeps alpha~ for change_basis.
     void left_multiply(int nnz, const int* rows, const long long* num, const long long* den, u64* numerators_out, u64* denominator_out) {
+        here();
         std::vector<i64> scaled;
         const i64 scale = scale_column(nnz, rows, num, den, scaled);
         for (;;) {
@@ -409,12 +411,14 @@ public:
     }
     // the result of the last left_multiply again (it stays on the device for change_basis)
     void last_left_multiply(u64* numerators_out, u64* denominator_out) {
+        here();
         if (!have_column_) throw std::logic_error("no left_multiply_by_basis_inverse to read back");
         RELP_HIP(hipMemcpy(numerators_out, alpha_, (size_t)m_ * (W_ + 2) * sizeof(u64), hipMemcpyDeviceToHost));
         denominator(alpha_scale_, denominator_out);
     }
     // `right_multiply_by_basis_inverse` (carry/mod.rs:135-141): r B^-1
     void right_multiply(int nnz, const int* index, const long long* num, const long long* den, u64* numerators_out, u64* denominator_out) {
+        here();
         std::vector<i64> scaled;
         const i64 scale = scale_column(nnz, index, num, den, scaled);
         upload_column(nnz, index, scaled);
@@ -426,6 +430,7 @@ public:
     // ... with multi-word multipliers over one denominator (see bix_right_words_kernel): numerators of vw + W + 2 words
     int right_multiply_words(int nnz, const int* index, int vw, const u64* values, const u64* denominator_in, int capacity_words, u64* numerators_out,
                              u64* denominator_out) {
+        here();
         if (nnz < 0 || vw < 1 || vw > 4 * BIX_MAX_WORDS || (nnz > 0 && (!index || !values)) || !denominator_in) throw std::invalid_argument("sparse vector: bad arguments");
         for (int e = 0; e < nnz; ++e)
             if (index[e] < 0 || index[e] >= m_) throw std::invalid_argument("sparse vector: index out of range");
@@ -458,6 +463,7 @@ public:
     }
     // `generate_element` (carry/mod.rs:150-157): element i of B^-1 c
     bool generate_element(int i, int nnz, const int* rows, const long long* num, const long long* den, u64* numerator_out, u64* denominator_out) {
+        here();
         if (i < 0 || i >= m_) throw std::invalid_argument("generate_element: row out of range");
         std::vector<i64> scaled;
         const i64 scale = scale_column(nnz, rows, num, den, scaled);
@@ -472,6 +478,7 @@ public:
     }
     // `change_basis` (carry/mod.rs:104-108): the column of the last left_multiply replaces the basis column of row p
     void change_basis(int p) {
+        here();
         if (!have_column_) throw std::logic_error("change_basis without a preceding left_multiply_by_basis_inverse");
         if (p < 0 || p >= m_) throw std::invalid_argument("change_basis: row out of range");
         int scale_bits = 0;
@@ -509,6 +516,7 @@ public:
     // those rows leave.  What leaves are artificial unit columns basic on redundant rows (phase_one.rs:232-278): B = [[B', 0], [C, I]] up to a
     // permutation, so B'^-1 is B^-1 without those rows and columns, over the same denominator (det B = det B').
     void remove_basis_part(int count, const int* indices) {
+        here();
         if (count < 0 || (count > 0 && !indices)) throw std::invalid_argument("remove_basis_part: bad arguments");
         std::vector<char> leaves(m_, 0);
         for (int c = 0; c < count; ++c) {
@@ -537,6 +545,7 @@ public:
 
 private:
     int device_, m_, W_ = 0;
+    void here() const { RELP_HIP(hipSetDevice(device_)); }  // (the caller's thread may have another device current: every entry point selects its own)
     u64 *N_ = nullptr, *N2_ = nullptr, *D_ = nullptr, *alpha_ = nullptr, *row_out_ = nullptr, *u_ = nullptr, *c1_ = nullptr, *factors_ = nullptr, *scratch_ = nullptr;
     int *N_bits_ = nullptr, *alpha_bits_ = nullptr, *scalar_bits_ = nullptr, *shift_ = nullptr, *d_rows_ = nullptr;
     i64* d_values_ = nullptr;
