@@ -2625,6 +2625,10 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
         }
         __syncthreads();
         unsigned long long t_sub = wall_clock64();
+#ifdef RELP_STAMPS  // (diagnostic build, `make stamps`: how evenly the tiles are spread -- every workgroup's time in (a) + (b): sum in prof[33], the pivot's
+                    //  longest in prof[35] -> [34]; (a) alone in prof[36], [38] -> [37]; [39] pivots whose longest workgroup was one of the last eight)
+        const unsigned long long t_tiles0 = t_sub;
+#endif
         auto substamp = [&](int slot) {  // (diagnostic: the leader's time inside the update: [20] both-term tiles, [21] rescaled tiles, [22] barrier, [23] second pass)
             if (leader) {
                 const unsigned long long t = wall_clock64();
@@ -2697,6 +2701,14 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             }
         }
         substamp(20);
+#ifdef RELP_STAMPS
+        __syncthreads();  // (the workgroup's slowest wave counts; the diagnostic build pays for it)
+        if (tid == 0 && !inverse_duty) {
+            const unsigned long long dt = wall_clock64() - t_tiles0;
+            atomicAdd(&lp.prof[36], dt);
+            atomicMax(&lp.prof[38], dt);
+        }
+#endif
         // (b) the entries that are only rescaled: the rows with alpha~_i = 0 of those columns, then every row of the other columns
         {
             const int rest_rows = m - n_rows_alpha;
@@ -2743,6 +2755,14 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             }
         }
         if (lane == 0) products_issued += 256ull * issued;  // an MFMA is 16 x 16 x 64 byte products = 256 word products
+#ifdef RELP_STAMPS
+        __syncthreads();
+        if (tid == 0 && !inverse_duty) {
+            const unsigned long long dt = wall_clock64() - t_tiles0;
+            atomicAdd(&lp.prof[33], dt);
+            atomicMax(&lp.prof[35], dt * 1024ull + (unsigned long long)block);  // (... and which workgroup it was)
+        }
+#endif
         if (fused) {  // row p stays as it is (D' = alpha~_p): into the other buffers with it
             for (long long t = gtid; t < (long long)m * L; t += GT) {
                 const int w = (int)(t / m), k = (int)(t - (long long)w * m);
@@ -3700,6 +3720,15 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
         if (finished_in_tiles) stamp(8);
         grid.sync();  // the new basis, D and (flip) row p for everybody
         stamp(finished_in_tiles ? 7 : 8);
+#ifdef RELP_STAMPS
+        if (leader) {  // (the pivot's longest workgroup: see update_on_matrix_cores)
+            lp.prof[34] += lp.prof[35] / 1024ull;
+            if ((int)(lp.prof[35] % 1024ull) >= (int)gridDim.x - 9) lp.prof[39] += 1;
+            lp.prof[35] = 0;
+            lp.prof[37] += lp.prof[38];
+            lp.prof[38] = 0;
+        }
+#endif
     }
     grid.sync();
     // the final x~_B belongs to the final basis: recompute it (the loop computes it at the top of an iteration)
@@ -4117,6 +4146,11 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                         prof[18] / 1e5, prof[19] / 1e5);
                 fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f (%llu pivots finished inside their tiles)\n", prof[20] / 1e5, prof[21] / 1e5,
                         prof[22] / 1e5, prof[23] / 1e5, prof[32]);
+#ifdef RELP_STAMPS
+                fprintf(stderr, "[exact] tiles of the update by workgroup: mean %.1f ms, the pivots' longest %.1f ms (sums over the pivots)\n", prof[33] / 1e5 / std::max(1, grid - 1), prof[34] / 1e5);
+                fprintf(stderr, "[exact] ... the both-term tiles alone: mean %.1f ms, the pivots' longest %.1f ms; the longest workgroup was one of the last eight in %llu pivots\n",
+                        prof[36] / 1e5 / std::max(1, grid - 1), prof[37] / 1e5, prof[39]);
+#endif
             }
             if (counters) {
                 ExactWidthRecord record;
