@@ -2652,9 +2652,15 @@ __device__ __noinline__ void update_on_matrix_cores(const ExactLP& lp, const Upd
             //  longer reads the whole of N once per pivot to form it: 0.8 of 25FV47's 5.4 s.)
             const int tiles_per_column = (n_rows_alpha + 15) / 16, tiles_of_x = (m + 15) / 16, tiles_of_y = sc.with_y ? (m + 15) / 16 : 0;
             const long long total_N = (long long)n_heavy * tiles_per_column, total = total_N + tiles_of_x + tiles_of_y;
-            const long long per_block = (total + tile_blocks - 1) / tile_blocks;
-            long long u = inverse_duty ? total : min(total, (long long)block * per_block);
-            const long long u_end = min(total, u + per_block);
+            // (a tile of x~_B or y counts for three when the runs are measured out: their entries lie limb after limb -- sixteen cache lines
+            //  per load of a tile where sixteen entries of a column of N share one -- and with tiles counted alike the last workgroups, whose
+            //  runs they are, were the pivot's longest eight times as often as their number says)
+            constexpr int VECTOR_TILE_WEIGHT = 3;
+            const long long weighted = total_N + (long long)VECTOR_TILE_WEIGHT * (tiles_of_x + tiles_of_y);
+            const long long per_block = (weighted + tile_blocks - 1) / tile_blocks;
+            auto tile_at = [&](long long v) { return v <= total_N ? v : min(total, total_N + (v - total_N + VECTOR_TILE_WEIGHT - 1) / VECTOR_TILE_WEIGHT); };
+            long long u = inverse_duty ? total : tile_at(min(weighted, (long long)block * per_block));
+            const long long u_end = inverse_duty ? total : tile_at(min(weighted, (long long)(block + 1) * per_block));
             const size_t M2 = 2 * (size_t)m;  // stride of the numerators of x~_B and y
             while (u < u_end) {
                 const int kind = u < total_N ? 0 : u < total_N + tiles_of_x ? 1 : 2;  // a column of N, x~_B, y
