@@ -8,7 +8,8 @@ against the reference's own known answers -- with ``==`` on ``Fraction``s, not `
 * the Forrest-Tomlin known-answer tests (lower_upper/mod.rs:688-940: every column and row of the updated inverse of the 4 x 4 and the
   Elble-Sahinidis 5 x 5 example) -- the update itself is an integer-preserving pivot here, the INVERSE it leaves is what the trait promises;
 * random rational bases with random column replacements against an exact Fraction inverse, through widenings of the integers;
-* the ORACLE'S OWN ``Carry`` solving AFIRO / SC50A / ADLITTLE with this object mirrored behind every ``BasisInverse`` call, every answer equal.
+* the ORACLE'S OWN ``Carry`` solving AFIRO / SC50A / ADLITTLE with this object mirrored behind every ``BasisInverse`` call, every answer equal;
+* at the size of whole LPs: ``invert`` of the reference's optimal bases (223 to 874 rows), B^-1 B = I, x_B >= 0, c_B' x_B = the exact optimum.
 """
 import os
 import random
@@ -370,3 +371,34 @@ def test_the_oracles_carry_with_the_device_object_behind_every_call(name):
     assert result.basis == golden["basis"]  # the reference's pivot path, undisturbed by the mirror
     pivots = golden["pivots_phase1"] + golden["pivots_phase2"]
     assert log["change_basis"] + log["invert"] >= pivots and log["btran"] >= pivots and log["row"] >= pivots and log["ftran"] >= pivots
+
+
+# (up to 874 rows: larger than the metric's LP, whose own fixture holds the basis over the 820 rows its phase one keeps.  CZPROB's 1158
+#  columns taken in basis order outgrow 8192 bits on the way -- RELP_ERR_OVERFLOW, as the header says of widths beyond 128 words)
+@pytest.mark.parametrize("name", ["E226", "SCFXM1", "BANDM", "STAIR", "ETAMACRO", "GFRD-PNC"])
+def test_invert_the_optimal_basis_of_a_netlib_lp(name):
+    """At the size of a whole LP, through properties that need no second implementation: `invert` of the reference's OPTIMAL basis (the
+    golden fixture's) -- 223 to 874 columns of decimal data -- then B^-1 B = I column by column,
+    x_B = B^-1 b >= 0, and c_B' x_B equal to the reference's exact optimum, digit for digit."""
+    import json
+
+    from relp_oracle.mps import load_problem
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json")))
+    general, provider = load_problem(os.path.join(ROOT, golden["file"]))
+    m = provider.nr_rows()
+    basis = golden["basis"]
+    assert len(basis) == m
+    columns = [[(i, F(v)) for i, v in provider.column(j)] for j in basis]
+    bi = ExactBasisInverse.invert(columns)
+    for slot in list(range(0, m, 7)) + [m - 1]:  # (every seventh column: a left multiply is a launch and m Fractions back)
+        assert bi.left_multiply_by_basis_inverse(columns[slot]) == dense_of([(slot, 1)], m), slot
+    b = [(i, F(v)) for i, v in enumerate(provider.right_hand_side()) if v != 0]
+    x_basic = bi.left_multiply_by_basis_inverse(b)
+    assert all(v >= 0 for v in x_basic)
+    solution = sorted((j, x_basic[slot]) for slot, j in enumerate(basis) if x_basic[slot] != 0)  # (sparse, by column: what the oracle's solve returns)
+    objective = general.objective_of(provider.reconstruct_solution(solution))
+    assert "%d/%d" % (objective.numerator, objective.denominator) == golden["objective"]
+    # ... and a row of the inverse times the basis is a unit vector too (BTRAN side): row r of B^-1 against column `slot` of B
+    row = bi.basis_inverse_row(m // 2)
+    for slot in range(0, m, 11):
+        assert sum(row[i] * v for i, v in columns[slot]) == (1 if slot == m // 2 else 0)
