@@ -124,14 +124,17 @@ __global__ void bix_bits_kernel(const u64* x, long long count, int words, int* b
     if (t < count) bits[t] = bit_length(x + (size_t)t * words, words);
 }
 // the fit test of a pivot, from bit lengths alone: the largest bound over the entries (atomicMax into *worst).  What is formed modulo
-// 2^(64 W) is 2^s N' = (alpha~_p N_ik - alpha~_i N_pk) / D_odd, never longer than the numerator itself: its bound is the test's.
-__global__ void bix_fit_kernel(const int* N_bits, const int* alpha_bits, int m, int p, int scale_bits, int* worst) {
+// 2^(64 W) is 2^s N' = (alpha~_p N_ik - alpha~_i N_pk) / D_odd: the numerator has at most max(..) + 1 bits, D_odd at least D_bits - s of
+// them, so the quotient fits max(..) + 1 - (D_bits - 1) + s + 2 with its sign -- `reduction` = (D_bits - 1) - s - 2, the bound of the exact
+// simplex's update (exact.hip).  (Until the end of round 6 the test asked for room for the NUMERATOR: twice the width the inverse needs, and
+// the optimal basis of 25FV47 -- whose inverse fits 8192 bits -- was refused.)
+__global__ void bix_fit_kernel(const int* N_bits, const int* alpha_bits, int m, int p, int scale_bits, int reduction, int* worst) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)m * m) return;
     const int i = (int)(t / m), k = (int)(t - (long long)i * m);
     int bound;
     if (i == p) bound = N_bits[t] + scale_bits;  // row p stays, times the entering column's scale
-    else bound = max(alpha_bits[p] + N_bits[t], alpha_bits[i] + N_bits[(size_t)p * m + k]) + 1;
+    else bound = max(alpha_bits[p] + N_bits[t], alpha_bits[i] + N_bits[(size_t)p * m + k]) + 1 - reduction;
     atomicMax(worst, bound);
 }
 // one thread: D = 2^s D_odd, u = 1 / D_odd modulo 2^(64 W) by Newton's doubling (scratch: 3 W words), c1 = alpha~_p u; *shift_out = s
@@ -309,12 +312,46 @@ __global__ void bix_compact_kernel(const u64* N, int m_old, u64* out, int m_new,
     u64* d = out + (size_t)t * W;
     for (int w = 0; w < W; ++w) d[w] = s[w];
 }
+// N(i, k) *= scale[k] (scale > 0), in place: the rows' scales of `invert` folded back into the columns of the inverse
+__global__ void bix_scale_columns_kernel(u64* N, int m, int W, const i64* scale) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)m * m) return;
+    const i64 v = scale[(int)(t % m)];
+    if (v == 1) return;
+    u64* x = N + (size_t)t * W;
+    const bool negative = (i64)x[W - 1] < 0;
+    if (negative) {  // magnitude, multiply, back (two's complement)
+        bool carry = true;
+        for (int w = 0; w < W; ++w) {
+            const u64 inv = ~x[w] + (carry ? 1ull : 0ull);
+            carry = carry && x[w] == 0;
+            x[w] = inv;
+        }
+    }
+    u64 high = 0;
+    for (int w = 0; w < W; ++w) {
+        const unsigned __int128 prod = (unsigned __int128)x[w] * (u64)v + high;
+        x[w] = (u64)prod;
+        high = (u64)(prod >> 64);
+    }
+    if (negative) {
+        bool carry = true;
+        for (int w = 0; w < W; ++w) {
+            const u64 inv = ~x[w] + (carry ? 1ull : 0ull);
+            carry = carry && x[w] == 0;
+            x[w] = inv;
+        }
+    }
+}
 // out (n_out words) = x (W words, positive) * v (v > 0): the denominators D * scale
 __global__ void bix_scaled_copy_kernel(const u64* x, int W, i64 v, u64* out, int n_out) {
     for (int w = 0; w < n_out; ++w) out[w] = 0;
     add_multiple(out, n_out, x, W, v);
 }
 
+struct WidthOverflow : RatOverflow {  // (RELP_ERR_OVERFLOW, as a scale beyond 62 bits; the text says which)
+    const char* what() const noexcept override { return "the integers of the inverse outgrow 128 words (8192 bits)"; }
+};
 i64 lcm_checked(i64 a, i64 b) {
     auto gcd = [](i64 x, i64 y) {
         while (y) { const i64 t = x % y; x = y; y = t; }
@@ -356,16 +393,59 @@ public:
         std::vector<int> row_of_column(m_, -1);
         std::vector<char> taken(m_, 0);
         std::vector<u64> numerators;
-        for (int j = 0; j < m_; ++j) {
+        // The ROWS are brought to integers, not the columns: R B with R = diag(lcm of a row's denominators).  A column's own lcm turns its
+        // unit entries into the lcm -- (1, 1, 191/100000) into (100000, 100000, 191) -- and every pivot on such an entry multiplies the
+        // common denominator by it: CZPROB's 1158 columns outgrew 8192 bits that way, while its rows' scales leave the ones alone.
+        // (R B)^-1 = B^-1 R^-1: the columns of the inverse are multiplied by their rows' scales at the end.  (Scales or scaled values
+        // that do not fit 62 bits: the columns' own scales as before.)
+        const long long entries = column_start[m_];
+        std::vector<i64> row_scale(m_, 1), scaled_num, ones;
+        bool by_rows = true;
+        try {
+            for (long long e = 0; e < entries; ++e) {
+                if (row_index[e] < 0 || row_index[e] >= m_) throw std::invalid_argument("sparse vector: index out of range");
+                if (den[e] <= 0) throw std::invalid_argument("sparse vector: denominators must be positive");
+                row_scale[row_index[e]] = lcm_checked(row_scale[row_index[e]], den[e]);
+            }
+            scaled_num.resize(entries);
+            for (long long e = 0; e < entries; ++e) {
+                const __int128 v = (__int128)num[e] * (row_scale[row_index[e]] / den[e]);
+                if (v >= ((__int128)1 << 62) || v <= -((__int128)1 << 62)) throw RatOverflow();
+                scaled_num[e] = (i64)v;
+            }
+            ones.assign(entries, 1);
+        } catch (const RatOverflow&) {
+            by_rows = false;
+        }
+        if (by_rows) {
+            num = (const long long*)scaled_num.data();
+            den = (const long long*)ones.data();
+        }
+        // The order is free (the rows are put in basis order at the end) and decides how large the integers get on the way -- after k
+        // pivots the common denominator is a k x k minor of the basis: the shortest columns first (slacks and singletons cost nothing),
+        // and of the free rows with a non-zero element the one whose element is SMALLEST (the lowest such row took 25FV47's optimal
+        // basis past 8192 bits although its inverse fits).
+        std::vector<int> order(m_);
+        for (int j = 0; j < m_; ++j) order[j] = j;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return column_start[a + 1] - column_start[a] < column_start[b + 1] - column_start[b]; });
+        for (int j : order) {
             const int nnz = (int)(column_start[j + 1] - column_start[j]);
             left_multiply(nnz, row_index + column_start[j], num + column_start[j], den + column_start[j], nullptr, nullptr);
             download_alpha(numerators);
-            int row = -1;
-            for (int i = 0; i < m_ && row < 0; ++i) {
+            const int words = W_ + 2;
+            int row = -1, row_bits = 0;
+            for (int i = 0; i < m_; ++i) {
                 if (taken[i]) continue;
-                bool nonzero = false;
-                for (int w = 0; w < W_ + 2; ++w) nonzero = nonzero || numerators[(size_t)i * (W_ + 2) + w] != 0;
-                if (nonzero) row = i;
+                const u64* x = numerators.data() + (size_t)i * words;
+                const u64 fill = (i64)x[words - 1] < 0 ? ~0ull : 0ull;  // (bit length of the two's complement value, up to one: the order needs no more)
+                int top = words - 1;
+                while (top >= 0 && x[top] == fill) --top;
+                if (top < 0 && fill == 0) continue;  // zero
+                const int bits = top < 0 ? 1 : 64 * top + (64 - __builtin_clzll(fill ? ~x[top] | 1ull : x[top]));
+                if (row < 0 || bits < row_bits) {
+                    row = i;
+                    row_bits = bits;
+                }
             }
             if (row < 0) throw std::runtime_error("BasisInverse::invert: the columns are singular");
             change_basis(row);
@@ -384,6 +464,26 @@ public:
         RELP_HIP(hipDeviceSynchronize());
         std::swap(N_, N2_);
         have_column_ = false;
+        if (by_rows && std::any_of(row_scale.begin(), row_scale.end(), [](i64 v) { return v != 1; })) {  // B^-1 = (R B)^-1 R
+            int scale_bits = 0;
+            for (i64 v = *std::max_element(row_scale.begin(), row_scale.end()); v > 0; v >>= 1) ++scale_bits;
+            for (;;) {  // (the products must fit the width)
+                hipLaunchKernelGGL(bix_bits_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, (long long)m_ * m_, W_, N_bits_);
+                std::vector<int> bits((size_t)m_ * m_);
+                RELP_HIP(hipMemcpy(bits.data(), N_bits_, bits.size() * sizeof(int), hipMemcpyDeviceToHost));
+                if (*std::max_element(bits.begin(), bits.end()) + scale_bits < 64 * W_ - 3) break;
+                widen();
+            }
+            struct OwnedScales {
+                i64* p = nullptr;
+                ~OwnedScales() { if (p) (void)hipFree(p); }
+            } scales;
+            RELP_HIP(hipMalloc((void**)&scales.p, m_ * sizeof(i64)));
+            RELP_HIP(hipMemcpy(scales.p, row_scale.data(), m_ * sizeof(i64), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(bix_scale_columns_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, m_, W_, scales.p);
+            RELP_HIP(hipGetLastError());
+            RELP_HIP(hipDeviceSynchronize());
+        }
     }
 
     // `left_multiply_by_basis_inverse` (carry/mod.rs:123-129): B^-1 c = numerators / denominator.  Keeps alpha~ for change_basis.
@@ -492,7 +592,17 @@ public:
             const int flip = (i64)alpha_p[W_ + 1] < 0 ? 1 : 0;
             hipLaunchKernelGGL(bix_bits_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_, (long long)m_ * m_, W_, N_bits_);
             RELP_HIP(hipMemset(scalar_bits_, 0, sizeof(int)));
-            hipLaunchKernelGGL(bix_fit_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_bits_, alpha_bits_, m_, p, scale_bits, scalar_bits_);
+            std::vector<u64> D(W_);
+            RELP_HIP(hipMemcpy(D.data(), D_, W_ * sizeof(u64), hipMemcpyDeviceToHost));
+            int D_bits = 0, shift = 0;  // D > 0
+            for (int w = W_ - 1; w >= 0 && D_bits == 0; --w)
+                if (D[w]) D_bits = 64 * w + 64 - __builtin_clzll(D[w]);
+            for (int w = 0; w < W_; ++w) {
+                if (D[w]) { shift += __builtin_ctzll(D[w]); break; }
+                shift += 64;
+            }
+            const int reduction = (D_bits - 1) - shift - 2;
+            hipLaunchKernelGGL(bix_fit_kernel, dim3(launch_blocks((long long)m_ * m_)), dim3(128), 0, 0, N_bits_, alpha_bits_, m_, p, scale_bits, reduction, scalar_bits_);
             int worst = 0;
             RELP_HIP(hipMemcpy(&worst, scalar_bits_, sizeof(int), hipMemcpyDeviceToHost));
             if (worst >= 64 * W_ - 3) {
@@ -599,7 +709,7 @@ private:
     }
     // twice the words: N and D sign-extended; alpha~ is formed again by the caller
     void widen() {
-        if (2 * W_ > BIX_MAX_WORDS) throw RatOverflow();
+        if (2 * W_ > BIX_MAX_WORDS) throw WidthOverflow();
         u64 *old_N = N_, *old_N2 = N2_, *old_D = D_, *old_alpha = alpha_, *old_row = row_out_, *old_u = u_, *old_c1 = c1_, *old_f = factors_, *old_s = scratch_;
         const int from = W_;
         N_ = N2_ = D_ = alpha_ = row_out_ = u_ = c1_ = factors_ = scratch_ = nullptr;

@@ -9,7 +9,7 @@ against the reference's own known answers -- with ``==`` on ``Fraction``s, not `
   Elble-Sahinidis 5 x 5 example) -- the update itself is an integer-preserving pivot here, the INVERSE it leaves is what the trait promises;
 * random rational bases with random column replacements against an exact Fraction inverse, through widenings of the integers;
 * the ORACLE'S OWN ``Carry`` solving AFIRO / SC50A / ADLITTLE with this object mirrored behind every ``BasisInverse`` call, every answer equal;
-* at the size of whole LPs: ``invert`` of the reference's optimal bases (223 to 874 rows), B^-1 B = I, x_B >= 0, c_B' x_B = the exact optimum.
+* at the size of whole LPs: ``invert`` of the reference's optimal bases (223 to 1158 rows), B^-1 B = I, x_B >= 0, c_B' x_B = the exact optimum.
 """
 import os
 import random
@@ -373,12 +373,12 @@ def test_the_oracles_carry_with_the_device_object_behind_every_call(name):
     assert log["change_basis"] + log["invert"] >= pivots and log["btran"] >= pivots and log["row"] >= pivots and log["ftran"] >= pivots
 
 
-# (up to 874 rows: larger than the metric's LP, whose own fixture holds the basis over the 820 rows its phase one keeps.  CZPROB's 1158
-#  columns taken in basis order outgrow 8192 bits on the way -- RELP_ERR_OVERFLOW, as the header says of widths beyond 128 words)
-@pytest.mark.parametrize("name", ["E226", "SCFXM1", "BANDM", "STAIR", "ETAMACRO", "GFRD-PNC"])
+# (up to 1158 rows: larger than the metric's LP, whose own fixture holds the basis over the 820 rows its phase one keeps.  CZPROB is what
+#  made `invert` scale the ROWS to integers: with every column scaled by its own lcm its 1158 columns outgrew 8192 bits on the way)
+@pytest.mark.parametrize("name", ["E226", "SCFXM1", "BANDM", "STAIR", "ETAMACRO", "25FV47", "GFRD-PNC", "CZPROB"])
 def test_invert_the_optimal_basis_of_a_netlib_lp(name):
     """At the size of a whole LP, through properties that need no second implementation: `invert` of the reference's OPTIMAL basis (the
-    golden fixture's) -- 223 to 874 columns of decimal data -- then B^-1 B = I column by column,
+    golden fixture's) -- 223 to 1158 columns of decimal data -- then B^-1 B = I column by column,
     x_B = B^-1 b >= 0, and c_B' x_B equal to the reference's exact optimum, digit for digit."""
     import json
 
@@ -387,12 +387,27 @@ def test_invert_the_optimal_basis_of_a_netlib_lp(name):
     general, provider = load_problem(os.path.join(ROOT, golden["file"]))
     m = provider.nr_rows()
     basis = golden["basis"]
-    assert len(basis) == m
     columns = [[(i, F(v)) for i, v in provider.column(j)] for j in basis]
+    right_hand_side = list(provider.right_hand_side())
+    if len(basis) == m - 1:
+        # 25FV47, BASELINE configs[1]: one row is redundant, the reference's phase one removes it (`RemoveRows`) and its basis spans the 820
+        # others.  The rows that may go are those with a non-zero entry in the left null vector of the 821 x 820 basis; a consistent
+        # system gives the same x_B whichever of them goes.
+        import numpy as np
+        dense = np.zeros((m, m - 1))
+        for slot, column in enumerate(columns):
+            for i, v in column:
+                dense[i, slot] = float(v)
+        null_vector = np.linalg.svd(dense.T)[2][-1]  # (B' y = 0)
+        gone = int(np.argmax(np.abs(null_vector)))
+        columns = [[(i - (i > gone), v) for i, v in column if i != gone] for column in columns]
+        del right_hand_side[gone]
+        m -= 1
+    assert len(basis) == m
     bi = ExactBasisInverse.invert(columns)
     for slot in list(range(0, m, 7)) + [m - 1]:  # (every seventh column: a left multiply is a launch and m Fractions back)
         assert bi.left_multiply_by_basis_inverse(columns[slot]) == dense_of([(slot, 1)], m), slot
-    b = [(i, F(v)) for i, v in enumerate(provider.right_hand_side()) if v != 0]
+    b = [(i, F(v)) for i, v in enumerate(right_hand_side) if v != 0]
     x_basic = bi.left_multiply_by_basis_inverse(b)
     assert all(v >= 0 for v in x_basic)
     solution = sorted((j, x_basic[slot]) for slot, j in enumerate(basis) if x_basic[slot] != 0)  # (sparse, by column: what the oracle's solve returns)
