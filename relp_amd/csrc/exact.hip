@@ -3091,9 +3091,9 @@ __global__ void __launch_bounds__(EX_THREADS) __attribute__((amdgpu_waves_per_eu
 #endif
             price_reduced_costs<L>(lp, phase, mD, eD, D_bits, LIMIT_BITS, &s_overflow);
 #ifdef RELP_PRICE_BLOCK_TIMES
-            if (L == 128 && (tid & 63) == 0) {  // (diagnostic build: histogram of the waves' times in the pass, in prof[3, 4, 10, 11, 18] of the 128-limb run)
+            if (L == 128 && (tid & 63) == 0) {  // (diagnostic build: histogram of the waves' times in the pass, in prof[33 .. 37] of the 128-limb run)
                 const unsigned long long dt = wall_clock64() - t_block0;  // ticks of 10 ns
-                const int slots[5] = {3, 4, 10, 11, 18};
+                const int slots[5] = {33, 34, 35, 36, 37};  // (free outside the `make stamps` build, whose tile timers they are)
                 const int bin = dt < 1500 ? 0 : dt < 3000 ? 1 : dt < 6000 ? 2 : dt < 12000 ? 3 : 4;
                 atomicAdd(&lp.prof[slots[bin]], 1ull);
             }
@@ -4152,6 +4152,9 @@ void exact_simplex(const StandardForm& form, int device, hipStream_t stream, int
                         prof[18] / 1e5, prof[19] / 1e5);
                 fprintf(stderr, " | inside the update: both-term tiles %.1f ms, rescaled tiles %.1f, barrier %.1f, second pass %.1f (%llu pivots finished inside their tiles)\n", prof[20] / 1e5, prof[21] / 1e5,
                         prof[22] / 1e5, prof[23] / 1e5, prof[32]);
+#ifdef RELP_PRICE_BLOCK_TIMES
+                fprintf(stderr, "[exact] waves of the c~ pass by their time in it: < 15 us %llu, < 30 us %llu, < 60 us %llu, < 120 us %llu, longer %llu\n", prof[33], prof[34], prof[35], prof[36], prof[37]);
+#endif
 #ifdef RELP_STAMPS
                 fprintf(stderr, "[exact] tiles of the update by workgroup: mean %.1f ms, the pivots' longest %.1f ms (sums over the pivots)\n", prof[33] / 1e5 / std::max(1, grid - 1), prof[34] / 1e5);
                 fprintf(stderr, "[exact] ... the both-term tiles alone: mean %.1f ms, the pivots' longest %.1f ms; the longest workgroup was one of the last eight in %llu pivots\n",
